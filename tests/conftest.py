@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available():
+    try:
+        from dask_geomodeling_amd.hip import runtime
+
+        return runtime.device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are selected with -m gpu; when selected on a box without a GPU they
+    # must fail loudly (never silently pass), so no skip is added here.
+    pass
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    from dask_geomodeling_amd.hip import runtime
+
+    n = runtime.device_count()
+    assert n > 0, "no HIP device visible: GPU tests must run on the MI355X box"
+    runtime.set_device(0)
+    return runtime

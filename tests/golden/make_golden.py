@@ -1,0 +1,736 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own ``process()`` code.
+
+Run in the build container only (``/root/reference`` is mounted there):
+
+    python tests/golden/make_golden.py
+
+It imports nens/dask-geomodeling from ``/root/reference`` (third-party GIS
+dependencies stubbed, see ``_refimport.py``), feeds seeded inputs through the
+reference's hot-path functions and stores *inputs + outputs* under
+``tests/golden/*.json|*.npz``.  Only those vectors are committed; no reference
+source is copied.  NumPy used for generation: see ``manifest.json``.
+
+Families:
+  math        A1-A4  wrap_math_process_func x {add,subtract,multiply,divide,power}
+  n1          same wrapper for comparisons/logic/exp/log + Invert/IsData/IsNoData/
+              FillNoData/MaskBelow/Step
+  clip        A6     Clip.process
+  mask        A7     Mask.process
+  classify    A8     Classify.process
+  reclassify  A9     Reclassify.process
+  tiler       P1     RasterTiler.get_sources_and_requests / process
+  views       full get_data() of small views built from reference Blocks on a
+              probe source (graph core + dtype/fill algebra + chain semantics)
+  smoothzoom  R1     ndimage.affine_transform(order=0) call of Smooth's zoom branch
+"""
+import json
+import os
+import sys
+from datetime import datetime
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import _refimport  # noqa: E402
+from codec import Writer  # noqa: E402
+
+dg = _refimport.import_reference()
+from dask_geomodeling.raster import elemwise as R_el  # noqa: E402
+from dask_geomodeling.raster import misc as R_misc  # noqa: E402
+from dask_geomodeling.raster import parallelize as R_par  # noqa: E402
+from dask_geomodeling.raster.base import RasterBlock  # noqa: E402
+from dask_geomodeling import utils as R_utils  # noqa: E402
+
+F32MAX = float(np.finfo("f4").max)
+F64MAX = float(np.finfo("f8").max)
+
+
+class Probe(RasterBlock):
+    """Probe-only leaf: hands a fixed array to the reference graph machinery."""
+
+    def __init__(self, name, dtype_str, ndv):
+        super().__init__(name, dtype_str, ndv)
+
+    # populated outside of args so that tokenising stays cheap
+    ARRAYS = {}
+
+    @property
+    def dtype(self):
+        return np.dtype(self.args[1])
+
+    @property
+    def fillvalue(self):
+        return self.args[2]
+
+    period = (datetime(1970, 1, 1), datetime(1970, 1, 1))
+    timedelta = None
+    temporal = False
+    extent = None
+    geometry = None
+    projection = "EPSG:28992"
+    geo_transform = None
+
+    def get_sources_and_requests(self, **request):
+        return [(self.args[0], None), (request.get("mode", "vals"), None)]
+
+    @staticmethod
+    def process(name, mode):
+        if mode == "time":
+            return {"time": [datetime(1970, 1, 1)]}
+        if mode == "meta":
+            return {"meta": [None]}
+        values, ndv = Probe.ARRAYS[name]
+        if values is None:
+            return None
+        out = {"values": values}
+        if values.dtype != bool:
+            out["no_data_value"] = ndv
+        else:
+            out["no_data_value"] = None
+        return out
+
+
+def dtype_max(dt):
+    dt = np.dtype(dt)
+    return float(np.finfo(dt).max) if dt.kind == "f" else int(np.iinfo(dt).max)
+
+
+def make_tile(rng, dtype, shape, ndv, specials=True):
+    """Seeded tile with injected no-data, non-finite and edge values."""
+    dt = np.dtype(dtype)
+    if dt == bool:
+        return rng.random(shape) < 0.5
+    if dt.kind == "f":
+        v = (rng.random(shape) * 200 - 100).astype(dt)
+        flat = v.reshape(-1)
+        if specials:
+            n = flat.size
+            pos = rng.choice(n, size=min(n, 24), replace=False)
+            inject = [np.nan, np.inf, -np.inf, 0.0, -0.0, np.finfo(dt).max / 2,
+                      -np.finfo(dt).max / 2, np.finfo(dt).tiny / 4, np.finfo(dt).max,
+                      1.0, -1.0, 2.0, 0.5, 1e-30 if dt == np.float32 else 1e-300,
+                      np.nextafter(dt.type(ndv), dt.type(0)) if ndv is not None else 3.0,
+                      7.0, 100.0, -100.0, 1e30 if dt == np.float32 else 1e300]
+            for p, x in zip(pos, inject):
+                flat[p] = x
+    else:
+        info = np.iinfo(dt)
+        lo, hi = max(info.min, -50), min(info.max, 200)
+        v = rng.integers(lo, hi, size=shape, endpoint=True).astype(dt)
+        flat = v.reshape(-1)
+        if specials:
+            n = flat.size
+            pos = rng.choice(n, size=min(n, 10), replace=False)
+            inject = [0, 1, info.max, info.min, info.max - 1, 2, 3, 7, info.max // 2 + 1, 10]
+            for p, x in zip(pos, inject):
+                flat[p] = x
+    if ndv is not None:
+        mask = rng.random(shape) < 0.1
+        v[mask] = ndv
+    return v
+
+
+SHAPES = [(1, 24, 40), (3, 9, 21)]
+
+
+# --------------------------------------------------------------------------
+# family: math  (reference: raster/elemwise.py:235-406)
+# --------------------------------------------------------------------------
+def gen_math(w):
+    ops = {
+        "add": R_el.Add, "subtract": R_el.Subtract, "multiply": R_el.Multiply,
+        "divide": R_el.Divide, "power": R_el.Power,
+    }
+    # (kind_a, kind_b): kind = ("r", dtype, ndv_kind) raster | ("s", python scalar) | ("n", ndarray)
+    f32n = np.float32(F32MAX)
+    combos = [
+        (("r", "f4", f32n), ("r", "f4", F32MAX)),
+        (("r", "f4", f32n), ("s", 2.5)),
+        (("s", 2.5), ("r", "f4", F32MAX)),
+        (("r", "f4", F32MAX), ("s", 3)),
+        (("r", "f4", F32MAX), ("s", 0)),
+        (("r", "f8", F64MAX), ("r", "f8", np.float64(F64MAX))),
+        (("r", "f8", F64MAX), ("r", "f4", f32n)),
+        (("r", "i4", 2147483647), ("r", "i4", np.int32(2147483647))),
+        (("r", "i4", 2147483647), ("s", 3)),
+        (("r", "i4", 2147483647), ("s", 2.5)),
+        (("r", "i4", 2147483647), ("r", "f4", f32n)),
+        (("r", "u1", np.uint8(255)), ("r", "u1", np.uint8(255))),
+        (("r", "u1", np.uint8(255)), ("s", 5)),
+        (("r", "u1", np.uint8(255)), ("s", 0.5)),
+        (("r", "u1", np.uint8(255)), ("r", "f4", f32n)),
+        (("r", "i2", np.int16(-32768)), ("r", "u1", np.uint8(255))),
+        (("r", "i8", 9223372036854775807), ("r", "i4", 2147483647)),
+        (("r", "i8", 9223372036854775807), ("s", 2)),
+        (("r", "?", None), ("s", 2)),
+        (("r", "?", None), ("r", "u1", np.uint8(255))),
+        (("r", "f4", f32n), ("n", np.array([1.5], dtype="f4"))),
+        (("r", "u2", np.uint16(65535)), ("r", "i2", np.int16(32767))),
+        (("r", "f4", np.float32(-9999.0)), ("r", "f4", np.float32(-9999.0))),
+    ]
+    cid = 0
+    for opname, cls in ops.items():
+        for ci, (ka, kb) in enumerate(combos):
+            for si, shape in enumerate(SHAPES):
+                rng = np.random.default_rng(1000 * ci + 10 * si + 1)
+                args, blocks = [], []
+                for slot, k in enumerate((ka, kb)):
+                    if k[0] == "r":
+                        arr = make_tile(rng, k[1], shape, k[2])
+                        if opname == "power" and np.dtype(k[1]).kind in "iu" and slot == 1:
+                            # integer ** negative integer raises in NumPy: keep exponents >= 0
+                            arr = np.abs(arr.astype("i8")).astype(k[1]) % 5
+                        d = {"values": arr, "no_data_value": k[2]}
+                        args.append(d)
+                        blocks.append(Probe("p%d" % slot, np.dtype(k[1]).str, k[2]))
+                    elif k[0] == "s":
+                        args.append(k[1])
+                        blocks.append(k[1])
+                    else:
+                        args.append(k[1])
+                        blocks.append(k[1])
+                try:
+                    block = cls(*blocks)
+                    pk = {"dtype": block.dtype.name, "fillvalue": block.fillvalue}
+                except Exception as e:  # e.g. unsupported type
+                    print("skip", opname, ci, e)
+                    continue
+                try:
+                    out = cls.process(pk, *args)
+                except Exception as e:
+                    w.add(id="math%04d" % cid, op=opname, kwargs=pk, args=args,
+                          raises=type(e).__name__)
+                    cid += 1
+                    continue
+                w.add(id="math%04d" % cid, op=opname, kwargs=pk, args=args, expect=out)
+                cid += 1
+    # None / time / meta passthrough (elemwise.py:254-262)
+    pk = {"dtype": "float32", "fillvalue": F32MAX}
+    tile = {"values": np.ones((1, 2, 2), "f4"), "no_data_value": F32MAX}
+    for args in ([tile, None], [None, tile], [{"time": [datetime(2000, 1, 1).isoformat()]}, tile],
+                 [tile, {"meta": ["x"]}], []):
+        w.add(id="math%04d" % cid, op="add", kwargs=pk, args=args,
+              expect=R_el.Add.process(pk, *args))
+        cid += 1
+
+
+# --------------------------------------------------------------------------
+# family: n1  (same wrapper + the stand-alone element-wise blocks)
+# --------------------------------------------------------------------------
+def gen_n1(w):
+    cid = 0
+    f32n = np.float32(F32MAX)
+    cmp_ops = {"equal": R_el.Equal, "not_equal": R_el.NotEqual, "greater": R_el.Greater,
+               "greater_equal": R_el.GreaterEqual, "less": R_el.Less,
+               "less_equal": R_el.LessEqual}
+    combos = [
+        (("r", "f4", f32n), ("r", "f4", F32MAX)),
+        (("r", "f4", f32n), ("s", 7.0)),
+        (("s", 7), ("r", "u1", np.uint8(255))),
+        (("r", "i4", 2147483647), ("r", "u1", np.uint8(255))),
+        (("r", "u1", np.uint8(255)), ("s", 7)),
+    ]
+    for opname, cls in cmp_ops.items():
+        for ci, (ka, kb) in enumerate(combos):
+            rng = np.random.default_rng(77 + ci)
+            args = []
+            for k in (ka, kb):
+                if k[0] == "r":
+                    arr = make_tile(rng, k[1], SHAPES[1], k[2])
+                    if np.dtype(k[1]).kind in "iu":
+                        arr[arr != k[2]] = arr[arr != k[2]] % 12
+                    else:
+                        sel = rng.random(arr.shape) < 0.3
+                        arr[sel & (arr != k[2])] = 7.0
+                    args.append({"values": arr, "no_data_value": k[2]})
+                else:
+                    args.append(k[1])
+            pk = {"dtype": "bool", "fillvalue": None}
+            w.add(id="n1%04d" % cid, op=opname, kwargs=pk, args=args,
+                  expect=cls.process(pk, *args))
+            cid += 1
+    logic = {"logical_and": R_el.And, "logical_or": R_el.Or, "logical_xor": R_el.Xor}
+    for opname, cls in logic.items():
+        rng = np.random.default_rng(5)
+        a = {"values": make_tile(rng, "?", SHAPES[1], None), "no_data_value": None}
+        b = {"values": make_tile(rng, "?", SHAPES[1], None), "no_data_value": None}
+        pk = {"dtype": "bool", "fillvalue": None}
+        for args in ([a, b], [a, True], [False, b]):
+            w.add(id="n1%04d" % cid, op=opname, kwargs=pk, args=args,
+                  expect=cls.process(pk, *args))
+            cid += 1
+    unary = {"exp": R_el.Exp, "log": R_el.Log, "log10": R_el.Log10}
+    for opname, cls in unary.items():
+        for dt, ndv in (("f4", f32n), ("f8", F64MAX), ("u1", np.uint8(255)), ("i4", 2147483647)):
+            rng = np.random.default_rng(9)
+            arr = make_tile(rng, dt, SHAPES[0], ndv)
+            a = {"values": arr, "no_data_value": ndv}
+            blk = cls(Probe("p", np.dtype(dt).str, ndv))
+            pk = {"dtype": blk.dtype.name, "fillvalue": blk.fillvalue}
+            w.add(id="n1%04d" % cid, op=opname, kwargs=pk, args=[a],
+                  expect=cls.process(pk, a))
+            cid += 1
+    # stand-alone blocks
+    rng = np.random.default_rng(11)
+    b = {"values": make_tile(rng, "?", SHAPES[1], None), "no_data_value": None}
+    w.add(id="n1%04d" % cid, op="invert", args=[b], expect=R_el.Invert.process(b)); cid += 1
+    for dt, ndv in (("f4", f32n), ("u1", np.uint8(255)), ("i4", 2147483647)):
+        a = {"values": make_tile(rng, dt, SHAPES[1], ndv), "no_data_value": ndv}
+        w.add(id="n1%04d" % cid, op="isdata", args=[a], expect=R_el.IsData.process(a)); cid += 1
+        w.add(id="n1%04d" % cid, op="isnodata", args=[a], expect=R_el.IsNoData.process(a)); cid += 1
+        for value in (0, 7, 2.5):
+            if isinstance(value, float) and np.dtype(dt).kind != "f":
+                continue
+            w.add(id="n1%04d" % cid, op="maskbelow", args=[a, value],
+                  expect=R_misc.MaskBelow.process(a, value)); cid += 1
+        for (left, right, loc, at) in ((0, 1, 0, 0.5), (2, 5, 7, 3), (-1.5, 1.5, 2.0, 0.0)):
+            if np.dtype(dt).kind != "f" and any(isinstance(x, float) and x != int(x) for x in (left, right, at)):
+                # NumPy raises / truncates on float into int arrays; keep integer cases integral
+                continue
+            try:
+                out = R_misc.Step.process(a, left, right, loc, at)
+            except Exception as e:
+                print("skip step", dt, e)
+                continue
+            w.add(id="n1%04d" % cid, op="step", args=[a, left, right, loc, at], expect=out); cid += 1
+    # FillNoData (elemwise.py:724-757)
+    for dts in (("f4", "f4"), ("u1", "u1", "u1"), ("u1", "f4"), ("i4", "i4")):
+        tiles, blocks = [], []
+        for i, dt in enumerate(dts):
+            ndv = {"f4": f32n, "u1": np.uint8(255), "i4": 2147483647}[dt]
+            arr = make_tile(rng, dt, SHAPES[1], ndv)
+            arr[rng.random(arr.shape) < 0.4] = ndv
+            tiles.append({"values": arr, "no_data_value": ndv})
+            blocks.append(Probe("p%d" % i, np.dtype(dt).str, ndv))
+        blk = R_el.FillNoData(*blocks)
+        pk = {"dtype": blk.dtype.name, "fillvalue": blk.fillvalue}
+        w.add(id="n1%04d" % cid, op="fillnodata", kwargs=pk, args=tiles,
+              expect=R_el.FillNoData.process(pk, *tiles)); cid += 1
+        w.add(id="n1%04d" % cid, op="fillnodata", kwargs=pk, args=[None] + tiles[1:],
+              expect=R_el.FillNoData.process(pk, None, *tiles[1:])); cid += 1
+
+
+# --------------------------------------------------------------------------
+# family: clip  (reference: raster/misc.py:98-123)
+# --------------------------------------------------------------------------
+def gen_clip(w):
+    cid = 0
+    f32n = np.float32(F32MAX)
+    rng = np.random.default_rng(21)
+    for sdt, sndv in (("f4", f32n), ("f4", F32MAX), ("u1", np.uint8(255)), ("i4", 2147483647),
+                      ("f8", F64MAX), ("i8", 9223372036854775807)):
+        for mdt, mndv in (("?", None), ("f4", f32n), ("u1", np.uint8(255)), ("i4", -1)):
+            for shape in SHAPES:
+                store = {"values": make_tile(rng, sdt, shape, sndv), "no_data_value": sndv}
+                src = {"values": make_tile(rng, mdt, shape, mndv), "no_data_value": mndv}
+                w.add(id="clip%04d" % cid, op="clip", args=[store, src],
+                      expect=R_misc.Clip.process(store, src)); cid += 1
+    # early outs
+    tile = {"values": make_tile(rng, "f4", SHAPES[0], f32n), "no_data_value": f32n}
+    empty = {"values": np.full(SHAPES[0], F32MAX, "f4"), "no_data_value": F32MAX}
+    msk = {"values": make_tile(rng, "?", SHAPES[0], None), "no_data_value": None}
+    for args in ([None, msk], [tile, None], [empty, None], [empty, msk],
+                 [{"time": ["t"]}, msk], [{"meta": ["m"]}, None]):
+        w.add(id="clip%04d" % cid, op="clip", args=args,
+              expect=R_misc.Clip.process(*args)); cid += 1
+
+
+# --------------------------------------------------------------------------
+# family: mask  (reference: raster/misc.py:208-222, utils.py:61-64)
+# --------------------------------------------------------------------------
+def gen_mask(w):
+    cid = 0
+    rng = np.random.default_rng(31)
+    f32n = np.float32(F32MAX)
+    stores = [("u1", np.uint8(255)), ("i4", 2147483647), ("i8", 9223372036854775807),
+              ("f4", f32n), ("f4", F32MAX), ("f8", F64MAX), ("f4", np.float32(-9999.0)),
+              ("f4", -9999.0), ("f8", np.float64(1e-9)), ("i2", np.int16(-1))]
+    for sdt, sndv in stores:
+        arr = make_tile(rng, sdt, SHAPES[0], sndv)
+        if np.dtype(sdt).kind == "f":
+            # values just inside / outside the isclose() band around the ndv
+            flat = arr.reshape(-1)
+            nd = np.dtype(sdt).type(sndv)
+            band = [nd * (1 - 0.5e-5), nd * (1 - 2e-5), nd * (1 + 0.5e-5), nd * (1 + 2e-5),
+                    nd * (1 - 1.0e-5), nd - np.dtype(sdt).type(5e-9), nd + np.dtype(sdt).type(2e-8)]
+            with np.errstate(all="ignore"):
+                for i, x in enumerate(band):
+                    flat[40 + i] = x
+        data = {"values": arr, "no_data_value": sndv}
+        for value in (0, 1, 8, 255, 256, 1000, -1000, 3.14159, 0.0, -40000, 70000, 65536, -129):
+            try:
+                out = R_misc.Mask.process(data, value)
+            except Exception as e:  # value == 256: uint8 chosen, NumPy 2 refuses the store
+                w.add(id="mask%04d" % cid, op="mask", args=[data, value],
+                      raises=type(e).__name__); cid += 1
+                continue
+            w.add(id="mask%04d" % cid, op="mask", args=[data, value], expect=out); cid += 1
+    for args in ([None, 1], [{"time": ["t"]}, 1]):
+        w.add(id="mask%04d" % cid, op="mask", args=args, expect=R_misc.Mask.process(*args)); cid += 1
+
+
+# --------------------------------------------------------------------------
+# family: classify  (reference: raster/misc.py:387-399)
+# --------------------------------------------------------------------------
+def gen_classify(w):
+    cid = 0
+    rng = np.random.default_rng(41)
+    f32n = np.float32(F32MAX)
+    bins_sets = [
+        [3, 8], [0.5], [-10.5, 0.0, 7.0, 7.5, 100.0], [1, 2, 3, 4, 5, 6, 7],
+        list(np.linspace(-100, 100, 253)), list(np.linspace(-100, 100, 254)),
+        list(np.linspace(-100, 100, 255)), list(range(-50, 200, 2)),
+        [0.1, 0.2, 0.30000000000000004], [-1e30, 1e30],
+    ]
+    stores = [("f4", f32n), ("f8", F64MAX), ("u1", np.uint8(255)), ("i4", 2147483647),
+              ("i8", 9223372036854775807), ("i2", np.int16(-32768))]
+    for sdt, sndv in stores:
+        for bi, bins in enumerate(bins_sets):
+            for right in (False, True):
+                arr = make_tile(rng, sdt, SHAPES[bi % 2], sndv)
+                flat = arr.reshape(-1)
+                # hit bin edges exactly
+                edges = np.asarray(bins)
+                with np.errstate(all="ignore"):
+                    cast = edges.astype(arr.dtype)
+                k = min(len(cast), 20)
+                flat[100:100 + k] = cast[:k]
+                data = {"values": arr, "no_data_value": sndv}
+                bins_l = np.asarray(bins).tolist()
+                w.add(id="cls%04d" % cid, op="classify", args=[data, bins_l, right],
+                      expect=R_misc.Classify.process(data, bins_l, right)); cid += 1
+    # the reference's own KAT: tests/test_raster.py:1447-1467
+    arr = np.array([[[1, 5], [7, 10], [255, 255]]], dtype="u1")
+    data = {"values": arr, "no_data_value": 255}
+    for right in (False, True):
+        w.add(id="cls%04d" % cid, op="classify", args=[data, [3, 8], right],
+              expect=R_misc.Classify.process(data, [3, 8], right)); cid += 1
+    w.add(id="cls%04d" % cid, op="classify", args=[None, [3, 8], False],
+          expect=R_misc.Classify.process(None, [3, 8], False)); cid += 1
+
+
+# --------------------------------------------------------------------------
+# family: reclassify  (reference: raster/misc.py:421-515)
+# --------------------------------------------------------------------------
+def gen_reclassify(w):
+    cid = 0
+    rng = np.random.default_rng(51)
+    tables = []
+    tables.append([[7, 1000]])
+    tables.append([[7, 8.2]])
+    tables.append([[1, 10], [7, 70]])
+    tables.append([[k, (7 * k) % 1000] for k in range(0, 126, 2)])           # 63
+    tables.append([[k, (7 * k) % 1000] for k in range(0, 128, 2)])           # 64
+    tables.append([[k, (7 * k) % 1000] for k in range(0, 130, 2)])           # 65
+    tables.append([[int(k), int(v)] for k, v in zip(rng.permutation(1000) - 300,
+                                                     rng.integers(-5000, 5000, 1000))])  # unsorted, negative
+    tables.append([[k, k * 0.25 - 3.0] for k in range(-20, 180, 3)])          # float targets
+    tables.append([[255, 5], [3, 9]])                                         # ndv (u1) is a key
+    tables.append([[2147483647, 11], [-2147483648, -11], [0, 1]])             # i32 extremes
+    tables.append([[k, (7 * k) % 1000] for k in range(0, 256, 2)])           # cfg-3 table (128)
+    tables.append([[-1000000, 1], [5, 2], [1000000, 3], [99, 4]])            # sparse keys
+    stores = [("u1", np.uint8(255)), ("i4", 2147483647), ("i4", np.int32(-1)),
+              ("i8", 9223372036854775807), ("i2", np.int16(-32768)), ("?", None),
+              ("u2", np.uint16(65535))]
+    for ti, table in enumerate(tables):
+        for sdt, sndv in stores:
+            for select in (False, True):
+                arr = make_tile(rng, sdt, SHAPES[ti % 2], sndv)
+                data = {"values": arr, "no_data_value": sndv}
+                blk = R_misc.Reclassify(Probe("p", np.dtype(sdt).str, sndv), table, select)
+                pk = {"dtype": blk.dtype.str, "fillvalue": blk.fillvalue,
+                      "data": blk.data, "select": blk.select}
+                try:
+                    out = R_misc.Reclassify.process(data, pk)
+                except Exception as e:
+                    w.add(id="rcl%04d" % cid, op="reclassify", args=[data, pk],
+                          raises=type(e).__name__); cid += 1
+                    continue
+                w.add(id="rcl%04d" % cid, op="reclassify", args=[data, pk], expect=out); cid += 1
+    # bool keys on a bool store (tests/test_raster_misc.py:212-218)
+    arr = make_tile(rng, "?", SHAPES[1], None)
+    data = {"values": arr, "no_data_value": None}
+    blk = R_misc.Reclassify(Probe("p", "|b1", None), [[True, 1000]])
+    pk = {"dtype": blk.dtype.str, "fillvalue": blk.fillvalue, "data": blk.data, "select": False}
+    w.add(id="rcl%04d" % cid, op="reclassify", args=[data, pk],
+          expect=R_misc.Reclassify.process(data, pk)); cid += 1
+    w.add(id="rcl%04d" % cid, op="reclassify", args=[None, pk],
+          expect=R_misc.Reclassify.process(None, pk)); cid += 1
+    # construction-time errors (tests/test_raster_misc.py:232-248)
+    errs = []
+    for args in ((Probe("p", "<f4", 1.0), [[7.0, 1000]], False),
+                 (Probe("p", "|u1", 255), [[7.4, 1000]], False),
+                 (Probe("p", "|u1", 255), [[[7, 1000]], [1, 100]], False),
+                 (Probe("p", "|u1", 255), [[7, 1], [7, 2]], False),
+                 (Probe("p", "|u1", 255), [[7, 1]], 1)):
+        try:
+            R_misc.Reclassify(*args)
+            errs.append(None)
+        except Exception as e:
+            errs.append(type(e).__name__)
+    w.add(id="rcl_init_errors", op="reclassify_init_errors", expect=errs)
+
+
+# --------------------------------------------------------------------------
+# family: tiler  (reference: raster/parallelize.py:43-125)
+# --------------------------------------------------------------------------
+def gen_tiler(w):
+    cid = 0
+    src = Probe("p", "<f4", F32MAX)
+    for bbox, width, height, tile in (
+        ((0.0, 0.0, 14.0, 7.0), 14, 7, 7),
+        ((10.0, -10.0, 20.0, 2.0), 10, 12, 7),
+        ((3.0, 3.0, 15.0, 15.0), 6, 4, 24),
+        ((0.0, 0.0, 64.0, 48.0), 128, 96, [32, 16]),
+        ((5.0, 5.0, 5.0, 5.0), 1, 1, 4),
+    ):
+        blk = R_par.RasterTiler(src, tile)
+        req = dict(mode="vals", bbox=bbox, width=width, height=height, projection="EPSG:28992")
+        sr = blk.get_sources_and_requests(**req)
+        out = []
+        for s, r in sr:
+            if isinstance(s, dict):
+                s = dict(s)
+                s["dtype"] = np.dtype(s["dtype"]).str
+                out.append(["kwargs", s])
+            elif s is None:
+                out.append(["none", None])
+            else:
+                r = dict(r)
+                r["bbox"] = tuple(float(x) for x in r["bbox"])
+                out.append(["store", r])
+        w.add(id="tiler%04d" % cid, op="tiler_requests", tile_size=tile, request=req, expect=out)
+        cid += 1
+    # process: assemble tiles incl. leftovers and None tiles (parallelize.py:93-125)
+    rng = np.random.default_rng(61)
+    for (H, W, ty, tx) in ((12, 10, 7, 7), (96, 128, 16, 32), (5, 9, 2, 4)):
+        count_x, count_y = -(-W // tx), -(-H // ty)
+        kw = {"dtype": np.dtype("f4"), "fillvalue": F32MAX, "shape_yx": (H, W),
+              "count_xy": (count_x, count_y), "tilesize_xy": [tx, ty]}
+        tiles = []
+        for i in range(count_x):
+            for j in range(count_y):
+                w_ = min(tx, W - i * tx)
+                h_ = min(ty, H - j * ty)
+                if (i + j) % 5 == 4:
+                    tiles.append(None)
+                else:
+                    tiles.append({"values": rng.random((2, h_, w_)).astype("f4"),
+                                  "no_data_value": F32MAX})
+        out = R_par.RasterTiler.process(kw, *tiles)
+        kw_enc = dict(kw)
+        kw_enc["dtype"] = kw["dtype"].str
+        w.add(id="tiler%04d" % cid, op="tiler_process", kwargs=kw_enc, tiles=tiles, expect=out)
+        cid += 1
+
+
+# --------------------------------------------------------------------------
+# family: views  (graph core + attribute algebra + chains through get_data)
+# --------------------------------------------------------------------------
+def build(expr, leaves):
+    """expr: nested list ["Op", arg, ...]; str args name leaves; numbers are literals."""
+    if isinstance(expr, str):
+        return leaves[expr]
+    if isinstance(expr, (int, float, bool)) or expr is None:
+        return expr
+    if isinstance(expr, dict):  # literal payloads (lists as args)
+        return expr["lit"]
+    head, rest = expr[0], [build(x, leaves) for x in expr[1:]]
+    cls = getattr(R_el, head, None) or getattr(R_misc, head)
+    return cls(*rest)
+
+
+def gen_views(w):
+    cid = 0
+    f32n = np.float32(F32MAX)
+    shape = (1, 32, 48)
+
+    def leafset(rng, spec):
+        arrays, blocks = {}, {}
+        for name, (dt, ndv) in spec.items():
+            arr = make_tile(rng, dt, shape, ndv)
+            Probe.ARRAYS[name] = (arr, ndv)
+            arrays[name] = {"values": arr, "no_data_value": ndv}
+            blocks[name] = Probe(name, np.dtype(dt).str, ndv)
+        return arrays, blocks
+
+    views = [
+        # canonical 5-op chain
+        (["Clip", ["Add", ["Subtract", ["Multiply", ["Add", "A", "B"], 2.5], "B"], 1.5], "A"],
+         {"A": ("f4", f32n), "B": ("f4", f32n)}),
+        # BASELINE.md variant
+        (["Clip", ["Add", ["Subtract", ["Multiply", ["Add", "A", "B"], 2.0], "B"], 1.5], "B"],
+         {"A": ("f4", f32n), "B": ("f4", f32n)}),
+        # F/2 + F/2 trap: finite result equal to fill becomes no-data downstream
+        (["Multiply", ["Add", "A", "A"], 0.0], {"A": ("f4", f32n)}),
+        (["Divide", ["Subtract", ["Multiply", ["Add", "A", "B"], 0.5], "C"], 4.0],
+         {"A": ("f4", f32n), "B": ("f4", f32n), "C": ("f4", f32n)}),
+        (["Multiply", ["Add", "A", "B"], ["Subtract", "A", "B"]],
+         {"A": ("f4", f32n), "B": ("f4", f32n)}),
+        (["Add", ["Multiply", "U", 3], "V"], {"U": ("u1", np.uint8(255)), "V": ("u1", np.uint8(255))}),
+        (["Divide", "U", 10], {"U": ("u1", np.uint8(255))}),
+        (["Multiply", ["Add", "I", 1000], 2.5], {"I": ("i4", 2147483647)}),
+        (["Add", ["Multiply", "I", 65536], ["Multiply", "I", 65536]], {"I": ("i4", 2147483647)}),
+        (["Power", ["Add", "A", 1.0], 2], {"A": ("f4", f32n)}),
+        (["Power", "A", 0.5], {"A": ("f4", f32n)}),
+        (["Power", "A", -1], {"A": ("f4", f32n)}),
+        (["Power", "U", 2], {"U": ("u1", np.uint8(255))}),
+        (["Clip", "A", ["Greater", "A", 0.0]], {"A": ("f4", f32n)}),
+        (["Clip", ["Multiply", "U", 2], ["Equal", "U", 7]], {"U": ("u1", np.uint8(255))}),
+        (["Mask", ["Add", "A", "B"], 1], {"A": ("f4", f32n), "B": ("f4", f32n)}),
+        (["Mask", ["Reclassify", "I", {"lit": [[k, (7 * k) % 1000] for k in range(0, 256, 2)]}], 1],
+         {"I": ("i4", 2147483647)}),
+        (["Reclassify", ["Classify", ["Clip", ["Divide", ["Subtract", ["Multiply", ["Add", "A", "B"], 0.5], "C"], 2.0], "M"],
+                         {"lit": [-50.0, -10.0, 0.0, 10.0, 50.0]}],
+          {"lit": [[0, 10], [1, 11], [3, 13], [5, 15]]}],
+         {"A": ("f4", f32n), "B": ("f4", f32n), "C": ("f4", f32n), "M": ("?", None)}),
+        (["Mask", ["Reclassify", ["Classify", ["Clip", ["Divide", ["Subtract", ["Multiply", ["Add", "A", "B"], 0.5], "C"], 2.0], "M"],
+                                  {"lit": [-50.0, -10.0, 0.0, 10.0, 50.0]}],
+                   {"lit": [[0, 10], [1, 11], [3, 13], [5, 15]]}, True], 1],
+         {"A": ("f4", f32n), "B": ("f4", f32n), "C": ("f4", f32n), "M": ("?", None)}),
+        (["Add", ["Multiply", "D", 2.0], "A"], {"D": ("f8", F64MAX), "A": ("f4", f32n)}),
+        (["Subtract", "L", ["Multiply", "I", 3]], {"L": ("i8", 9223372036854775807), "I": ("i4", 2147483647)}),
+        (["And", ["Greater", "A", 0.0], ["Less", "B", 50.0]], {"A": ("f4", f32n), "B": ("f4", f32n)}),
+        (["Invert", ["Or", ["IsNoData", "A"], ["LessEqual", "A", "B"]]], {"A": ("f4", f32n), "B": ("f4", f32n)}),
+        (["FillNoData", "A", ["Multiply", "B", 2.0]], {"A": ("f4", f32n), "B": ("f4", f32n)}),
+        (["Log", ["Exp", "A"]], {"A": ("f4", f32n)}),
+        (["Step", ["MaskBelow", "A", 0.0], 0, 1, 50.0], {"A": ("f4", f32n)}),
+    ]
+    for vi, (expr, spec) in enumerate(views):
+        rng = np.random.default_rng(500 + vi)
+        arrays, blocks = leafset(rng, spec)
+        view = build(expr, blocks)
+        req = dict(mode="vals", bbox=(0.0, 0.0, 48.0, 32.0), width=48, height=32,
+                   projection="EPSG:28992")
+        out = view.get_data(**req)
+        graph, name = view.get_compute_graph(**req)
+        w.add(id="view%04d" % cid, op="view", expr=expr, leaves=arrays, request=req,
+              expect=out, dtype=np.dtype(view.dtype).str, fillvalue=view.fillvalue,
+              n_keys=len(graph), key_prefix=name.rsplit("_", 1)[0])
+        cid += 1
+    # None leaf propagation through a chain
+    rng = np.random.default_rng(600)
+    arrays, blocks = leafset(rng, {"A": ("f4", f32n), "B": ("f4", f32n)})
+    Probe.ARRAYS["B"] = (None, None)
+    for expr in (["Add", ["Multiply", "A", 2.0], "B"], ["Clip", "A", "B"], ["Clip", "B", "A"],
+                 ["Mask", "B", 1]):
+        view = build(expr, blocks)
+        req = dict(mode="vals", bbox=(0.0, 0.0, 48.0, 32.0), width=48, height=32,
+                   projection="EPSG:28992")
+        out = view.get_data(**req)
+        lv = dict(arrays)
+        lv["B"] = None
+        w.add(id="view%04d" % cid, op="view", expr=expr, leaves=lv, request=req, expect=out,
+              dtype=np.dtype(view.dtype).str, fillvalue=view.fillvalue)
+        cid += 1
+
+
+# --------------------------------------------------------------------------
+# family: dtype rules  (reference: elemwise.py:134-152, 377-380; misc.py:195-206, 380-385, 464-471)
+# --------------------------------------------------------------------------
+def gen_dtypes(w):
+    rows = []
+    dts = ["?", "u1", "i1", "u2", "i2", "u4", "i4", "u8", "i8", "f2", "f4", "f8"]
+    others = [("s", 5), ("s", 300), ("s", -3), ("s", 2.5), ("s", 70000), ("s", 2**40)] + [("r", d) for d in dts]
+    for cls_name in ("Add", "Subtract", "Multiply", "Divide", "Power"):
+        cls = getattr(R_el, cls_name)
+        for da in dts:
+            for kind, ob in others:
+                a = Probe("a", np.dtype(da).str, 0)
+                b = Probe("b", np.dtype(ob).str, 0) if kind == "r" else ob
+                for order in (0, 1):
+                    try:
+                        blk = cls(a, b) if order == 0 else cls(b, a)
+                        rows.append([cls_name, da, [kind, ob], order, blk.dtype.str, blk.fillvalue])
+                    except Exception as e:
+                        rows.append([cls_name, da, [kind, ob], order, "ERR:" + type(e).__name__, None])
+    w.add(id="dtype_math", op="dtype_math", expect=rows)
+    rows = []
+    for value in (0, 1, 8, 255, 256, 257, 1000, 65535, 65536, 65537, -1, -128, -129, -1000, -32768,
+                  -32769, 3.14159, 0.0, 2**32, 2**32 + 1, -2**31, -2**31 - 1):
+        blk = R_misc.Mask(Probe("a", "<f4", 0.0), value)
+        rows.append([value, blk.dtype.str, blk.fillvalue])
+    w.add(id="dtype_mask", op="dtype_mask", expect=rows)
+    rows = []
+    for n in (1, 2, 253, 254, 255, 256, 65533, 65534, 65535):
+        bins = list(range(n))
+        try:
+            blk = R_misc.Classify(Probe("a", "<f4", 0.0), bins)
+            rows.append([n, blk.dtype.str, blk.fillvalue])
+        except Exception as e:  # single-edge bins are rejected by the reference (empty diff)
+            rows.append([n, "ERR:" + type(e).__name__, None])
+    w.add(id="dtype_classify", op="dtype_classify", expect=rows)
+    rows = []
+    for n in (-2**63, -2**31 - 1, -2**31, -32769, -32768, -129, -128, -1, 0, 1, 127, 128, 129, 255, 256,
+              257, 32767, 32768, 65535, 65536, 65537, 2**31, 2**32, 2**32 + 1, 2**63):
+        row = [n]
+        for f in (R_utils.get_int_dtype, R_utils.get_uint_dtype):
+            try:
+                row.append(f(n).str)
+            except Exception as e:
+                row.append("ERR:" + type(e).__name__)
+        rows.append(row)
+    w.add(id="dtype_intuint", op="dtype_intuint", expect=rows)
+    rows = []
+    for dt in ("u1", "i1", "u2", "i2", "u4", "i4", "u8", "i8", "f2", "f4", "f8"):
+        rows.append([dt, R_utils.get_dtype_max(dt), R_utils.get_dtype_min(dt)])
+    w.add(id="dtype_maxmin", op="dtype_maxmin", expect=rows)
+
+
+# --------------------------------------------------------------------------
+# family: smoothzoom  (reference: raster/spatial.py:296-305 -- SciPy nearest)
+# --------------------------------------------------------------------------
+def gen_smoothzoom(w):
+    from scipy import ndimage
+    rng = np.random.default_rng(71)
+    cid = 0
+    for shape, size_px in (((1, 16, 24), (2.0, 3.0)), ((2, 9, 7), (1.5, 1.0)),
+                           ((1, 40, 40), (10.0, 10.0)), ((1, 12, 5), (0.25, 2.4)),
+                           ((1, 64, 64), (16.0, 8.0))):
+        values = rng.random(shape).astype("f4")
+        _, ny, nx = values.shape
+        zy, zx = [1 - 2 * size_px[0] / ny, 1 - 2 * size_px[1] / nx]
+        # literal call pattern of the reference's zoom-back step (spatial.py:300-305)
+        out = ndimage.affine_transform(values, order=0, matrix=np.diag([1, zy, zx]),
+                                       offset=[0, size_px[0], size_px[1]])
+        w.add(id="zoom%04d" % cid, op="affine_nearest",
+              args=[values, [zy, zx], [float(size_px[0]), float(size_px[1])]], expect=out)
+        cid += 1
+
+
+def main():
+    fams = {
+        "math": gen_math, "n1": gen_n1, "clip": gen_clip, "mask": gen_mask,
+        "classify": gen_classify, "reclassify": gen_reclassify, "tiler": gen_tiler,
+        "views": gen_views, "dtypes": gen_dtypes, "smoothzoom": gen_smoothzoom,
+    }
+    only = sys.argv[1:]
+    counts = {}
+    for name, fn in fams.items():
+        if only and name not in only:
+            continue
+        w = Writer()
+        with np.errstate(all="ignore"):
+            fn(w)
+        w.save(os.path.join(HERE, name))
+        counts[name] = len(w.cases)
+        print(name, len(w.cases), "cases")
+    import scipy
+    manifest_path = os.path.join(HERE, "manifest.json")
+    manifest = {}
+    if os.path.exists(manifest_path):
+        manifest = json.load(open(manifest_path))
+    manifest.update({
+        "generator": "tests/golden/make_golden.py",
+        "reference": "nens/dask-geomodeling @ /root/reference (v2.8.3.dev0)",
+        "python": sys.version.split()[0], "numpy": np.__version__, "scipy": scipy.__version__,
+    })
+    manifest.setdefault("cases", {}).update(counts)
+    json.dump(manifest, open(manifest_path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+"""Pin the CPU oracle (oracle/ref_numpy.py) to golden vectors produced by the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from helpers import assert_result_equal, assert_values_equal, load_family
+from oracle import ref_numpy as O
+
+# transcendental ufuncs may dispatch to different SIMD kernels on another host CPU
+ULP_OPS = {"power": 1, "exp": 1, "log": 1, "log10": 1}
+
+
+def _run_or_raises(case, fn):
+    if "raises" in case:
+        with pytest.raises(Exception) as ei:
+            with np.errstate(all="ignore"):
+                fn()
+        assert type(ei.value).__name__ == case["raises"]
+        return None
+    with np.errstate(all="ignore"):
+        return fn()
+
+
+@pytest.mark.parametrize("case", load_family("math"), ids=lambda c: c["id"] + "-" + c["op"])
+def test_math(case):
+    out = _run_or_raises(case, lambda: O.math_process(case["op"], case["kwargs"], *case["args"]))
+    if "raises" not in case:
+        assert_result_equal(out, case["expect"], ULP_OPS.get(case["op"], 0), case["id"])
+
+
+@pytest.mark.parametrize("case", load_family("n1"), ids=lambda c: c["id"] + "-" + c["op"])
+def test_n1(case):
+    op, args = case["op"], case["args"]
+    if op in O.UFUNCS:
+        out = O.math_process(op, case["kwargs"], *args)
+    elif op == "fillnodata":
+        out = O.fillnodata_process(case["kwargs"], *args)
+    else:
+        out = getattr(O, op + "_process")(*args)
+    assert_result_equal(out, case["expect"], ULP_OPS.get(op, 0), case["id"])
+
+
+@pytest.mark.parametrize("case", load_family("clip"), ids=lambda c: c["id"])
+def test_clip(case):
+    out = O.clip_process(*case["args"])
+    assert_result_equal(out, case["expect"], 0, case["id"])
+    # all-no-data early-out hands back the very same object (misc.py:108-109)
+    data = case["args"][0]
+    if data is not None and "values" in data and np.all(data["values"] == data["no_data_value"]):
+        assert out is data
+
+
+@pytest.mark.parametrize("case", load_family("mask"), ids=lambda c: c["id"])
+def test_mask(case):
+    out = _run_or_raises(case, lambda: O.mask_process(*case["args"]))
+    if "raises" not in case:
+        assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.mark.parametrize("case", load_family("classify"), ids=lambda c: c["id"])
+def test_classify(case):
+    assert_result_equal(O.classify_process(*case["args"]), case["expect"], 0, case["id"])
+
+
+@pytest.mark.parametrize("case", [c for c in load_family("reclassify") if c["op"] == "reclassify"],
+                         ids=lambda c: c["id"])
+def test_reclassify(case):
+    out = _run_or_raises(case, lambda: O.reclassify_process(*case["args"]))
+    if "raises" not in case:
+        assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.mark.parametrize("case", load_family("tiler"), ids=lambda c: c["id"])
+def test_tiler(case):
+    if case["op"] == "tiler_process":
+        kw = dict(case["kwargs"])
+        kw["dtype"] = np.dtype(kw["dtype"])
+        assert_result_equal(O.tiler_process(kw, *case["tiles"]), case["expect"], 0, case["id"])
+        return
+    tile = case["tile_size"]
+    tile = [int(x) for x in tile] if hasattr(tile, "__iter__") else [int(tile)] * 2
+    kw, reqs = O.tiler_requests(tile, case["request"])
+    expect = case["expect"]
+    if expect[0][0] == "none":
+        assert kw is None and len(reqs) == 1
+        assert reqs[0] == expect[1][1]
+        return
+    ekw = expect[0][1]
+    for k in ("shape_yx", "count_xy", "tilesize_xy"):
+        assert tuple(kw[k]) == tuple(ekw[k])
+    assert len(reqs) == len(expect) - 1
+    for got, (_, want) in zip(reqs, expect[1:]):
+        assert tuple(float(x) for x in got["bbox"]) == tuple(want["bbox"])
+        assert got["width"] == want["width"] and got["height"] == want["height"]
+
+
+def test_dtype_helpers():
+    cases = {c["id"]: c["expect"] for c in load_family("dtypes")}
+    for n, want_int, want_uint in cases["dtype_intuint"]:
+        for fn, want in ((O.get_int_dtype, want_int), (O.get_uint_dtype, want_uint)):
+            try:
+                got = fn(n).str
+            except Exception as e:
+                got = "ERR:" + type(e).__name__
+            assert got == want, (n, fn.__name__)
+    for dt, mx, mn in cases["dtype_maxmin"]:
+        assert O.get_dtype_max(dt) == mx and type(O.get_dtype_max(dt)) is type(mx)
+        assert O.get_dtype_min(dt) == mn
+    for value, dt, fill in cases["dtype_mask"]:
+        assert O.mask_dtype(value).str == dt
+        assert (1 if value == 0 else 0) == fill
+    for cls_name, da, (kind, ob), order, want, fill in cases["dtype_math"]:
+        a = np.dtype(da)
+        b = np.dtype(ob) if kind == "r" else ob
+        args = [a, b] if order == 0 else [b, a]
+        if cls_name == "Power" and isinstance(args[1], int) and args[1] < 0:
+            args[1] = float(args[1])  # Power.__init__, elemwise.py:401-406
+        try:
+            got = O.elemwise_dtype(args, divide=(cls_name == "Divide"))
+        except Exception as e:
+            assert want.startswith("ERR"), (cls_name, da, ob, e)
+            continue
+        if want.startswith("ERR"):
+            continue  # construction-time type errors are host-logic, tested there
+        assert got.str == want, (cls_name, da, kind, ob, order)
+        assert O.get_dtype_max(got) == fill
+
+
+@pytest.mark.parametrize("case", load_family("smoothzoom"), ids=lambda c: c["id"])
+def test_affine_nearest(case):
+    values, zoom, offset = case["args"]
+    assert_values_equal(O.affine_nearest(values, zoom, offset), case["expect"], 0, case["id"])
+
+
+# ---- the reference's own known-answer tests for the GDAL nearest warp ----------
+# expected arrays restated from tests/test_raster_sources.py:68-161 (source: one
+# 1x1 pixel of value 5 covering [136700,136705) x (455795,455800], ndv 255)
+GT = (136700.0, 5.0, 0, 455800.0, 0, -5.0)
+PIX = np.full((1, 1, 1), 5, dtype="u1")
+
+
+@pytest.mark.parametrize("bbox,h,w,expect", [
+    ((136700, 455795, 136705, 455800), 1, 1, [[[5]]]),
+    ((136700, 455790, 136705, 455795), 1, 1, [[[255]]]),
+    ((136695, 455795, 136700, 455800), 1, 1, [[[255]]]),
+    ((136700, 455800, 136705, 455805), 1, 1, [[[255]]]),
+    ((136705, 455795, 136710, 455800), 1, 1, [[[255]]]),
+    ((136700, 455795, 136710, 455800), 1, 2, [[[5, 255]]]),
+    ((136700, 455790, 136705, 455800), 2, 1, [[[5], [255]]]),
+    ((136700, 455795, 136710, 455800), 2, 4, [[[5, 5, 255, 255], [5, 5, 255, 255]]]),
+    ((136700, 455795, 136705, 455800), 5, 5, np.full((1, 5, 5), 5).tolist()),
+])
+def test_nearest_warp_reference_kats(bbox, h, w, expect):
+    out = O.nearest_warp(PIX, GT, bbox, h, w, 255)
+    assert out.tolist() == expect
+
+
+@pytest.mark.parametrize("dx,dy,hit", [
+    (0, 0, True), (0, -4.99, True), (4.99, 0, True), (4.99, -4.99, True),
+    (0, -5.0, False), (5.0, 0, False), (-5.0, 5.0, False), (-0.01, 0, False), (0, 0.01, False),
+])
+def test_point_read_reference_kats(dx, dy, hit):
+    out = O.point_read(PIX, GT, 136700 + dx, 455800 + dy, 255)
+    assert out.item() == (5 if hit else 255)
+
+
+def test_bilinear_vs_scipy():
+    """Own spec (parity unpinned): agree with SciPy's order-1 spline within 1 ulp (f32)."""
+    from scipy import ndimage
+    from helpers import ulp_distance
+
+    rng = np.random.default_rng(3)
+    for (hs, ws, hd, wd) in ((16, 20, 32, 40), (9, 7, 27, 21), (10, 10, 15, 15), (8, 8, 8, 8), (12, 6, 5, 4)):
+        src = (rng.random((2, hs, ws)) * 100).astype("f4")
+        got = O.bilinear_resample(src, hd, wd, np.float32(3.4028235e38))
+        v = (np.arange(hd) + 0.5) * (hs / hd) - 0.5
+        u = (np.arange(wd) + 0.5) * (ws / wd) - 0.5
+        vv, uu = np.meshgrid(v, u, indexing="ij")
+        for b in range(2):
+            want = ndimage.map_coordinates(src[b].astype("f8"), [vv, uu], order=1, mode="nearest")
+            assert ulp_distance(got[b], want.astype("f4")).max() <= 1
