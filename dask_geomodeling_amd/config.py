@@ -1,0 +1,90 @@
+"""Configuration (counterpart of the reference's config.py:4-12).
+
+Uses ``dask.config`` when dask is importable, otherwise a dict-backed shim with the
+same ``get / set / update_defaults`` surface.  Keys live under ``geomodeling.*``;
+besides the reference's own keys this path adds:
+
+  geomodeling.fuse         collapse element-wise sub-graphs into one launch (default True)
+  geomodeling.materialize  get_data() returns ndarrays (True) or DeviceArrays (False)
+  geomodeling.device       HIP device index used by this process/thread (default: current)
+"""
+import os
+import threading
+
+try:  # pragma: no cover - depends on the environment
+    import dask.config as _dask_config
+except ImportError:  # the GPU image ships no dask
+    _dask_config = None
+
+defaults = {
+    "root": os.getcwd(),
+    "strict-file-paths": False,
+    "raster-limit": 12 * (1024 ** 2),
+    "raster-limit-timesteps": 65536,
+    "geometry-limit": 10000,
+    "fuse": True,
+    "materialize": True,
+    "device": None,
+}
+
+
+class _Shim:
+    def __init__(self):
+        self._data = {}
+        self._lock = threading.Lock()
+
+    def update_defaults(self, new):
+        with self._lock:
+            for k, v in new.items():
+                if isinstance(v, dict):
+                    cur = self._data.setdefault(k, {})
+                    for kk, vv in v.items():
+                        cur.setdefault(kk, vv)
+                else:
+                    self._data.setdefault(k, v)
+
+    def get(self, key, default=KeyError):
+        cur = self._data
+        for part in key.split("."):
+            if not isinstance(cur, dict) or part not in cur:
+                if default is KeyError:
+                    raise KeyError(key)
+                return default
+            cur = cur[part]
+        return cur
+
+    class set:  # noqa: N801 - mirrors dask.config.set (usable as context manager)
+        def __init__(self, arg=None, **kwargs):
+            self._old = {}
+            items = dict(arg or {})
+            items.update({k.replace("__", "."): v for k, v in kwargs.items()})
+            for key, value in items.items():
+                self._old[key] = config.get(key, None)
+                self._assign(key, value)
+
+        @staticmethod
+        def _assign(key, value):
+            cur = config._data
+            parts = key.split(".")
+            for part in parts[:-1]:
+                cur = cur.setdefault(part, {})
+            cur[parts[-1]] = value
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            for key, value in self._old.items():
+                self._assign(key, value)
+            return False
+
+
+config = _dask_config if _dask_config is not None else _Shim()
+config.update_defaults({"geomodeling": defaults})
+
+
+def get(key, default=None):
+    try:
+        return config.get(key)
+    except KeyError:
+        return default

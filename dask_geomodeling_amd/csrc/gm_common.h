@@ -1,0 +1,40 @@
+// Shared internals of libgmhip (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "gmhip.h"
+
+namespace gm {
+
+// thread-local error text behind gm_last_error()
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+// current device's compute stream (creates device state on first use)
+hipStream_t current_stream();
+int current_cu_count();
+
+#define GM_HIP(call)                                  \
+  do {                                                \
+    hipError_t e_ = (call);                           \
+    if (e_ != hipSuccess) return gm::hip_fail(e_, #call); \
+  } while (0)
+
+inline int dtype_size(int dt) {
+  switch (dt) {
+    case GM_BOOL: case GM_U8: case GM_I8: return 1;
+    case GM_U16: case GM_I16: return 2;
+    case GM_U32: case GM_I32: case GM_F32: return 4;
+    case GM_U64: case GM_I64: case GM_F64: return 8;
+    default: return 0;
+  }
+}
+inline bool dtype_is_float(int dt) { return dt == GM_F32 || dt == GM_F64; }
+
+}  // namespace gm

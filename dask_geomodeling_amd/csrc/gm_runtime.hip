@@ -1,0 +1,317 @@
+// libgmhip runtime: devices, one compute stream per device, caching allocator,
+// copies, events, error reporting.  Plain HIP for gfx950; no torch, no shims.
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "gm_common.h"
+
+namespace gm {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  set_error("%s failed: %s (%d)", what, hipGetErrorString(e), (int)e);
+  (void)hipGetLastError();  // clear sticky error
+  return (int)e;
+}
+
+struct DeviceState {
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  int cu_count = 0;
+  // free blocks by rounded size; live blocks by pointer
+  std::multimap<size_t, void*> cached;
+  std::unordered_map<void*, size_t> live;
+  size_t in_use = 0, cached_bytes = 0;
+  bool ready = false;
+};
+
+static constexpr int kMaxDevices = 64;
+static DeviceState g_dev[kMaxDevices];
+static std::mutex g_init_mu;
+static int g_ndev = -1;
+
+static int probe_devices() {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (g_ndev >= 0) return g_ndev;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  if (n > kMaxDevices) n = kMaxDevices;
+  g_ndev = n;
+  return n;
+}
+
+static int ensure_device(int dev, DeviceState** out) {
+  if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  if (dev < 0 || dev >= g_ndev) return fail(GM_ERR_INVALID, "device %d out of range (0..%d)", dev, g_ndev - 1);
+  DeviceState& d = g_dev[dev];
+  std::lock_guard<std::mutex> lk(d.mu);
+  if (!d.ready) {
+    GM_HIP(hipSetDevice(dev));
+    GM_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    GM_HIP(hipGetDeviceProperties(&prop, dev));
+    d.cu_count = prop.multiProcessorCount;
+    d.ready = true;
+  }
+  *out = &d;
+  return GM_OK;
+}
+
+static int current(DeviceState** out) {
+  if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  int dev = 0;
+  GM_HIP(hipGetDevice(&dev));
+  return ensure_device(dev, out);
+}
+
+hipStream_t current_stream() {
+  DeviceState* d = nullptr;
+  if (current(&d) != GM_OK) return nullptr;
+  return d->stream;
+}
+
+int current_cu_count() {
+  DeviceState* d = nullptr;
+  if (current(&d) != GM_OK) return 0;
+  return d->cu_count;
+}
+
+static size_t round_size(size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  if (bytes <= (1u << 20)) {  // next power of two, >= 512 B
+    size_t r = 512;
+    while (r < bytes) r <<= 1;
+    return r;
+  }
+  const size_t g = 2u << 20;  // 2 MiB granules for large tiles
+  return (bytes + g - 1) / g * g;
+}
+
+}  // namespace gm
+
+using namespace gm;
+
+extern "C" {
+
+int gm_init(void) {
+  if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  DeviceState* d = nullptr;
+  return current(&d);
+}
+
+int gm_device_count(void) { return probe_devices(); }
+
+int gm_set_device(int device) {
+  if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= g_ndev) return fail(GM_ERR_INVALID, "device %d out of range", device);
+  GM_HIP(hipSetDevice(device));
+  DeviceState* d = nullptr;
+  return ensure_device(device, &d);
+}
+
+int gm_get_device(int* device) {
+  if (!device) return fail(GM_ERR_INVALID, "null pointer");
+  if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  GM_HIP(hipGetDevice(device));
+  return GM_OK;
+}
+
+int gm_device_name(char* buf, size_t len) {
+  if (!buf || len == 0) return fail(GM_ERR_INVALID, "null buffer");
+  DeviceState* d = nullptr;
+  int rc = current(&d);
+  if (rc) return rc;
+  int dev = 0;
+  GM_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  GM_HIP(hipGetDeviceProperties(&prop, dev));
+  snprintf(buf, len, "%s %s (%d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return GM_OK;
+}
+
+int gm_malloc(void** ptr, size_t bytes) {
+  if (!ptr) return fail(GM_ERR_INVALID, "null pointer");
+  DeviceState* d = nullptr;
+  int rc = current(&d);
+  if (rc) return rc;
+  size_t sz = round_size(bytes);
+  std::lock_guard<std::mutex> lk(d->mu);
+  auto it = d->cached.find(sz);
+  if (it != d->cached.end()) {
+    *ptr = it->second;
+    d->cached.erase(it);
+    d->cached_bytes -= sz;
+  } else {
+    hipError_t e = hipMalloc(ptr, sz);
+    if (e != hipSuccess) {
+      // out of memory: drop the cache and retry once
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(d->stream);
+      for (auto& kv : d->cached) (void)hipFree(kv.second);
+      d->cached.clear();
+      d->cached_bytes = 0;
+      e = hipMalloc(ptr, sz);
+      if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    }
+  }
+  d->live[*ptr] = sz;
+  d->in_use += sz;
+  return GM_OK;
+}
+
+int gm_free(void* ptr) {
+  if (!ptr) return GM_OK;
+  // the block may belong to any device: search the owner (few devices, cheap)
+  for (int i = 0; i < (g_ndev > 0 ? g_ndev : 0); ++i) {
+    DeviceState& d = g_dev[i];
+    std::lock_guard<std::mutex> lk(d.mu);
+    auto it = d.live.find(ptr);
+    if (it == d.live.end()) continue;
+    size_t sz = it->second;
+    d.live.erase(it);
+    d.in_use -= sz;
+    d.cached.emplace(sz, ptr);
+    d.cached_bytes += sz;
+    return GM_OK;
+  }
+  return fail(GM_ERR_INVALID, "gm_free: pointer %p not allocated by gm_malloc", ptr);
+}
+
+int gm_pool_trim(void) {
+  DeviceState* d = nullptr;
+  int rc = current(&d);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(d->mu);
+  GM_HIP(hipStreamSynchronize(d->stream));
+  for (auto& kv : d->cached) (void)hipFree(kv.second);
+  d->cached.clear();
+  d->cached_bytes = 0;
+  return GM_OK;
+}
+
+int gm_mem_info(size_t* free_bytes, size_t* total_bytes) {
+  DeviceState* d = nullptr;
+  int rc = current(&d);
+  if (rc) return rc;
+  size_t f = 0, t = 0;
+  GM_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return GM_OK;
+}
+
+int gm_pool_stats(size_t* in_use_bytes, size_t* cached_bytes) {
+  DeviceState* d = nullptr;
+  int rc = current(&d);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(d->mu);
+  if (in_use_bytes) *in_use_bytes = d->in_use;
+  if (cached_bytes) *cached_bytes = d->cached_bytes;
+  return GM_OK;
+}
+
+int gm_h2d(void* dst_dev, const void* src_host, size_t bytes) {
+  if (bytes == 0) return GM_OK;
+  hipStream_t s = current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  GM_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
+  GM_HIP(hipStreamSynchronize(s));
+  return GM_OK;
+}
+
+int gm_d2h(void* dst_host, const void* src_dev, size_t bytes) {
+  if (bytes == 0) return GM_OK;
+  hipStream_t s = current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  GM_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
+  GM_HIP(hipStreamSynchronize(s));
+  return GM_OK;
+}
+
+int gm_d2d(void* dst_dev, const void* src_dev, size_t bytes) {
+  if (bytes == 0) return GM_OK;
+  hipStream_t s = current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  GM_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, s));
+  return GM_OK;
+}
+
+int gm_memset(void* dst_dev, int byte_value, size_t bytes) {
+  if (bytes == 0) return GM_OK;
+  hipStream_t s = current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  GM_HIP(hipMemsetAsync(dst_dev, byte_value, bytes, s));
+  return GM_OK;
+}
+
+int gm_sync(void) {
+  hipStream_t s = current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  GM_HIP(hipStreamSynchronize(s));
+  return GM_OK;
+}
+
+int gm_event_create(void** event) {
+  if (!event) return fail(GM_ERR_INVALID, "null pointer");
+  if (!current_stream()) return GM_ERR_NO_DEVICE;
+  hipEvent_t ev;
+  GM_HIP(hipEventCreate(&ev));
+  *event = (void*)ev;
+  return GM_OK;
+}
+
+int gm_event_destroy(void* event) {
+  if (!event) return GM_OK;
+  GM_HIP(hipEventDestroy((hipEvent_t)event));
+  return GM_OK;
+}
+
+int gm_event_record(void* event) {
+  hipStream_t s = current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  GM_HIP(hipEventRecord((hipEvent_t)event, s));
+  return GM_OK;
+}
+
+int gm_event_sync(void* event) {
+  GM_HIP(hipEventSynchronize((hipEvent_t)event));
+  return GM_OK;
+}
+
+int gm_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!ms) return fail(GM_ERR_INVALID, "null pointer");
+  GM_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return GM_OK;
+}
+
+const char* gm_last_error(void) { return g_err.c_str(); }
+const char* gm_version(void) { return GM_VERSION; }
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+// K8: helper kernels -- constant fill, synthetic tile generator, all-equal reduction
+// (Clip's early-out, raster/misc.py:108), checksum (null sink), mosaic paste
+// (device side of RasterTiler.process, raster/parallelize.py:118-124).
+#include "gm_common.h"
+
+namespace {
+
+__device__ __host__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fill_kernel(T* out, T value, unsigned long long n) {
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = value;
+}
+
+template <typename T>
+__device__ __forceinline__ T cast_uniform(double x) { return (T)x; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void generate_kernel(T* out, unsigned long long seed, unsigned long long offset,
+                                                       double lo, double hi, unsigned long long n, unsigned width,
+                                                       unsigned ly, unsigned lx, T ndv) {
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned long long key = splitmix64(seed);
+  const double span = hi - lo;
+  for (; i < n; i += stride) {
+    const unsigned long long bits = splitmix64(key ^ (offset + i));
+    const double u = (double)(bits >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
+    T v = cast_uniform<T>(lo + u * span);
+    if (lx != 0 && width != 0) {
+      const unsigned long long row = i / width;
+      const unsigned col = (unsigned)(i % width);
+      if ((row % ly) == 0 && (col % lx) == 0) v = ndv;
+    }
+    out[i] = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void all_equal_kernel(const T* in, T value, unsigned long long n, int* flag) {
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  bool ok = true;
+  for (; i < n; i += stride) ok = ok && (in[i] == value);
+  // one store per wave that saw a mismatch (flag only ever goes 0 -> 1)
+  if (__ballot(!ok) != 0ull && (threadIdx.x & 63) == 0) *flag = 1;
+}
+
+__global__ __launch_bounds__(256) void checksum_kernel(const unsigned int* words, unsigned long long n_words,
+                                                       const unsigned char* tail, unsigned n_tail,
+                                                       unsigned long long* result) {
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned long long acc = 0;
+  for (; i < n_words; i += stride) acc += splitmix64(((i + 1) << 32) ^ (unsigned long long)words[i]);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_tail) {
+    unsigned int w = 0;
+    for (unsigned k = 0; k < n_tail; ++k) w |= (unsigned int)tail[k] << (8 * k);
+    acc += splitmix64(((n_words + 1) << 32) ^ (unsigned long long)w);
+  }
+  // wave reduction, then one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(result, acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void paste_kernel(T* mosaic, int H, int W, const T* tile, int bands, int th, int tw,
+                                                    int row0, int col0, int row_base) {
+  // grid.y walks (band, tile row); x walks columns (coalesced)
+  const int br = row_base + (int)blockIdx.y;
+  const int band = br / th, r = br % th;
+  const T* src = tile + ((size_t)band * th + r) * tw;
+  T* dst = mosaic + ((size_t)band * H + (row0 + r)) * W + col0;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < tw; c += gridDim.x * blockDim.x) dst[c] = src[c];
+}
+
+unsigned grid_for(size_t n, int cus) {
+  size_t blocks = (n + 255) / 256;
+  size_t cap = (size_t)(cus > 0 ? cus : 256) * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks == 0) blocks = 1;
+  return (unsigned)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gm_fill(void* out, int dtype, gm_scalar value, size_t n) {
+  if (!out) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (n == 0) return GM_OK;
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  dim3 grid(grid_for(n, gm::current_cu_count()));
+  switch (dtype) {
+    case GM_BOOL: case GM_U8: case GM_I8:
+      hipLaunchKernelGGL(fill_kernel<unsigned char>, grid, dim3(256), 0, s, (unsigned char*)out, (unsigned char)value.i64, n);
+      break;
+    case GM_U16: case GM_I16:
+      hipLaunchKernelGGL(fill_kernel<unsigned short>, grid, dim3(256), 0, s, (unsigned short*)out, (unsigned short)value.i64, n);
+      break;
+    case GM_U32: case GM_I32:
+      hipLaunchKernelGGL(fill_kernel<unsigned int>, grid, dim3(256), 0, s, (unsigned int*)out, (unsigned int)value.i64, n);
+      break;
+    case GM_U64: case GM_I64:
+      hipLaunchKernelGGL(fill_kernel<unsigned long long>, grid, dim3(256), 0, s, (unsigned long long*)out, (unsigned long long)value.u64, n);
+      break;
+    case GM_F32:
+      hipLaunchKernelGGL(fill_kernel<float>, grid, dim3(256), 0, s, (float*)out, (float)value.f64, n);
+      break;
+    case GM_F64:
+      hipLaunchKernelGGL(fill_kernel<double>, grid, dim3(256), 0, s, (double*)out, value.f64, n);
+      break;
+    default:
+      return gm::fail(GM_ERR_INVALID, "gm_fill: dtype %d", dtype);
+  }
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_generate(void* out, int dtype, uint64_t seed, uint64_t offset, double lo, double hi, size_t n,
+                uint32_t width, uint32_t lattice_y, uint32_t lattice_x, gm_scalar ndv) {
+  if (!out) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (n == 0) return GM_OK;
+  if (lattice_x != 0 && lattice_y == 0) lattice_y = 1;
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  dim3 grid(grid_for(n, gm::current_cu_count()));
+#define GM_GEN(T, NDV)                                                                                   \
+  hipLaunchKernelGGL(generate_kernel<T>, grid, dim3(256), 0, s, (T*)out, (unsigned long long)seed,       \
+                     (unsigned long long)offset, lo, hi, (unsigned long long)n, width, lattice_y, lattice_x, (T)(NDV))
+  switch (dtype) {
+    case GM_U8: GM_GEN(unsigned char, ndv.i64); break;
+    case GM_I8: GM_GEN(signed char, ndv.i64); break;
+    case GM_U16: GM_GEN(unsigned short, ndv.i64); break;
+    case GM_I16: GM_GEN(short, ndv.i64); break;
+    case GM_U32: GM_GEN(unsigned int, ndv.i64); break;
+    case GM_I32: GM_GEN(int, ndv.i64); break;
+    case GM_I64: GM_GEN(long long, ndv.i64); break;
+    case GM_F32: GM_GEN(float, ndv.f64); break;
+    case GM_F64: GM_GEN(double, ndv.f64); break;
+    default: return gm::fail(GM_ERR_INVALID, "gm_generate: dtype %d", dtype);
+  }
+#undef GM_GEN
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_all_equal(const void* in, int dtype, gm_scalar value, size_t n, int* result) {
+  if (!result) return gm::fail(GM_ERR_INVALID, "null pointer");
+  *result = 1;
+  if (n == 0) return GM_OK;
+  if (!in) return gm::fail(GM_ERR_INVALID, "null pointer");
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  int* flag = nullptr;
+  int rc = gm_malloc((void**)&flag, sizeof(int));
+  if (rc) return rc;
+  GM_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+  dim3 grid(grid_for(n, gm::current_cu_count()));
+#define GM_AE(T, V) hipLaunchKernelGGL(all_equal_kernel<T>, grid, dim3(256), 0, s, (const T*)in, (T)(V), (unsigned long long)n, flag)
+  switch (dtype) {
+    case GM_BOOL: case GM_U8: GM_AE(unsigned char, value.i64); break;
+    case GM_I8: GM_AE(signed char, value.i64); break;
+    case GM_U16: GM_AE(unsigned short, value.i64); break;
+    case GM_I16: GM_AE(short, value.i64); break;
+    case GM_U32: GM_AE(unsigned int, value.i64); break;
+    case GM_I32: GM_AE(int, value.i64); break;
+    case GM_U64: GM_AE(unsigned long long, value.u64); break;
+    case GM_I64: GM_AE(long long, value.i64); break;
+    case GM_F32: GM_AE(float, value.f64); break;
+    case GM_F64: GM_AE(double, value.f64); break;
+    default: gm_free(flag); return gm::fail(GM_ERR_INVALID, "gm_all_equal: dtype %d", dtype);
+  }
+#undef GM_AE
+  int mismatch = 0;
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&mismatch, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  gm_free(flag);
+  if (e != hipSuccess) return gm::hip_fail(e, "gm_all_equal");
+  *result = mismatch ? 0 : 1;
+  return GM_OK;
+}
+
+int gm_checksum(const void* in, size_t bytes, uint64_t* result) {
+  if (!result) return gm::fail(GM_ERR_INVALID, "null pointer");
+  *result = 0;
+  if (bytes == 0) return GM_OK;
+  if (!in) return gm::fail(GM_ERR_INVALID, "null pointer");
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  unsigned long long* acc = nullptr;
+  int rc = gm_malloc((void**)&acc, sizeof(unsigned long long));
+  if (rc) return rc;
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(unsigned long long), s);
+  const unsigned long long n_words = bytes / 4;
+  const unsigned n_tail = (unsigned)(bytes % 4);
+  dim3 grid(grid_for(n_words ? n_words : 1, gm::current_cu_count()));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(checksum_kernel, grid, dim3(256), 0, s, (const unsigned int*)in, n_words,
+                       (const unsigned char*)in + n_words * 4, n_tail, acc);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(result, acc, sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  gm_free(acc);
+  if (e != hipSuccess) return gm::hip_fail(e, "gm_checksum");
+  return GM_OK;
+}
+
+int gm_paste_tile(void* mosaic, int H, int W, const void* tile, int bands, int th, int tw, int row0, int col0,
+                  int itemsize) {
+  if (!mosaic || !tile) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (bands <= 0 || th <= 0 || tw <= 0) return GM_OK;
+  if (row0 < 0 || col0 < 0 || row0 + th > H || col0 + tw > W)
+    return gm::fail(GM_ERR_INVALID, "gm_paste_tile: tile (%d,%d)+(%d,%d) outside mosaic (%d,%d)", row0, col0, th, tw, H, W);
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  unsigned gx = (unsigned)((tw + 255) / 256);
+  if (gx > 64) gx = 64;
+  // grid.y is limited to 65535: walk the (band, row) space in chunks
+  const long long rows_total = (long long)bands * th;
+  if (rows_total > 2147483647ll) return gm::fail(GM_ERR_UNSUPPORTED, "gm_paste_tile: too many rows");
+  for (long long base = 0; base < rows_total; base += 65535) {
+    long long nrows = rows_total - base;
+    if (nrows > 65535) nrows = 65535;
+    dim3 grid(gx, (unsigned)nrows);
+#define GM_PASTE(T)                                                                                   \
+  hipLaunchKernelGGL(paste_kernel<T>, grid, dim3(256), 0, s, (T*)mosaic, H, W, (const T*)tile, bands, \
+                     th, tw, row0, col0, (int)base)
+    switch (itemsize) {
+      case 1: GM_PASTE(unsigned char); break;
+      case 2: GM_PASTE(unsigned short); break;
+      case 4: GM_PASTE(unsigned int); break;
+      case 8: GM_PASTE(unsigned long long); break;
+      default: return gm::fail(GM_ERR_INVALID, "gm_paste_tile: itemsize %d", itemsize);
+    }
+#undef GM_PASTE
+    GM_HIP(hipGetLastError());
+  }
+  return GM_OK;
+}
+
+}  // extern "C"

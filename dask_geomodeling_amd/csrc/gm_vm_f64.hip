@@ -1,0 +1,6 @@
+// VM kernels of register class f64 (see gm_vm.h)
+#include "gm_vm.h"
+
+namespace gmvm {
+GM_VM_DEFINE_LAUNCHER(double)
+}  // namespace gmvm

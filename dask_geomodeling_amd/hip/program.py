@@ -1,0 +1,582 @@
+"""Host side of K1: expression trees -> gm_program (include/gmhip.h) -> one launch.
+
+An expression tree mirrors a sub-graph of element-wise Blocks.  ``compile_expr``
+picks the register class, linearises the tree into the accumulator program the
+kernel interprets and converts every literal / no-data value into the class'
+representation *using NumPy's own scalar rules* (so that e.g. ``f32_tile == ndv``
+and ``np.add(tile, 2.5, dtype="float32")`` mean exactly what they mean in the
+reference, raster/elemwise.py:263-296).
+"""
+import ctypes
+
+import numpy as np
+
+from . import runtime
+from .array import DeviceArray, as_device
+from .dtypes import code_of
+from .runtime import gm_scalar
+
+GM_MAX_INPUTS, GM_MAX_STEPS, GM_MAX_TEMPS = 8, 32, 4
+CLASS_F32, CLASS_F64, CLASS_I32, CLASS_I64 = 0, 1, 2, 3
+CLASS_DTYPE = {CLASS_F32: np.dtype("f4"), CLASS_F64: np.dtype("f8"),
+               CLASS_I32: np.dtype("i4"), CLASS_I64: np.dtype("i8")}
+CLASS_COST = {CLASS_F32: 0, CLASS_I32: 1, CLASS_F64: 2, CLASS_I64: 3}
+OPD_NONE, OPD_ACC, OPD_INPUT, OPD_SCALAR, OPD_TEMP = 0, 1, 2, 3, 4
+
+OPCODES = {
+    "add": 1, "subtract": 2, "multiply": 3, "divide": 4, "power": 5,
+    "equal": 6, "not_equal": 7, "greater": 8, "greater_equal": 9, "less": 10, "less_equal": 11,
+    "logical_and": 12, "logical_or": 13, "logical_xor": 14,
+    "exp": 15, "log": 16, "log10": 17,
+    "invert": 18, "isdata": 19, "isnodata": 20, "clip": 21, "mask": 22,
+    "copy": 26,
+}
+MATH_OPS = ("add", "subtract", "multiply", "divide", "power", "exp", "log", "log10")
+COMPARE_OPS = ("equal", "not_equal", "greater", "greater_equal", "less", "less_equal")
+LOGIC_OPS = ("logical_and", "logical_or", "logical_xor")
+HEAVY_OPS = ("power", "exp", "log", "log10")
+
+
+class gm_operand(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint8), ("index", ctypes.c_uint8), ("has_ndv", ctypes.c_uint8),
+                ("is_bool", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 4), ("value", gm_scalar)]
+
+
+class gm_step(ctypes.Structure):
+    _fields_ = [("opcode", ctypes.c_uint8), ("round_f32", ctypes.c_uint8), ("wrap_i32", ctypes.c_uint8),
+                ("save_temp", ctypes.c_uint8), ("check_finite", ctypes.c_uint8), ("flags", ctypes.c_uint8),
+                ("pad_", ctypes.c_uint8 * 2), ("a", gm_operand), ("b", gm_operand), ("fill", gm_scalar),
+                ("aux0", gm_scalar), ("aux1", gm_scalar), ("aux2", gm_scalar), ("aux3", gm_scalar)]
+
+
+class gm_input_desc(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_uint8), ("broadcast", ctypes.c_uint8), ("has_ndv", ctypes.c_uint8),
+                ("pad_", ctypes.c_uint8 * 5), ("ndv", gm_scalar)]
+
+
+class gm_program(ctypes.Structure):
+    _fields_ = [("n_steps", ctypes.c_uint32), ("n_inputs", ctypes.c_uint32), ("reg_class", ctypes.c_uint8),
+                ("out_dtype", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 6),
+                ("inputs", gm_input_desc * GM_MAX_INPUTS), ("steps", gm_step * GM_MAX_STEPS)]
+
+
+class gm_vm_tuning(ctypes.Structure):
+    _fields_ = [("vec", ctypes.c_int32), ("blocks_per_cu", ctypes.c_int32),
+                ("xcd_chunking", ctypes.c_int32), ("nontemporal", ctypes.c_int32)]
+
+
+class FusionLimit(Exception):
+    """The expression does not fit one program (class conflict, too many inputs/steps/temps)."""
+
+
+# ----------------------------------------------------------------------------
+# NumPy-exact scalar handling
+# ----------------------------------------------------------------------------
+
+def effective_ndv(dtype, ndv):
+    """The value v (of ``dtype``) with ``tile == ndv``  <=>  ``tile == v``, or None if no
+    element of a ``dtype`` tile can ever compare equal to ``ndv``.  NumPy itself decides
+    (weak python scalars, promotion of NumPy scalars) on a 1-element array."""
+    if ndv is None:
+        return None
+    dtype = np.dtype(dtype)
+    with np.errstate(all="ignore"):
+        try:
+            cand = np.array(ndv).astype(dtype)
+        except (OverflowError, ValueError, TypeError):
+            return None
+        try:
+            hit = bool((np.array([cand], dtype=dtype) == ndv)[0])
+        except (OverflowError, TypeError):
+            hit = False
+    return cand[()] if hit else None
+
+
+def cast_scalar(value, dtype):
+    """A python/NumPy scalar operand as NumPy casts it for ``ufunc(..., dtype=dtype)``."""
+    with np.errstate(all="ignore"):
+        return np.array(value).astype(np.dtype(dtype))[()]
+
+
+def _set_scalar(slot, cls, value):
+    """Write ``value`` (already of a dtype exactly representable in the class) into a gm_scalar."""
+    if cls == CLASS_F32:
+        slot.f32 = float(np.float32(value))
+    elif cls == CLASS_F64:
+        slot.f64 = float(value)
+    elif cls == CLASS_I32:
+        slot.i32 = int(np.array(int(value)).astype("i8").astype("i4"))
+    else:
+        v = int(value)
+        if v >= 2 ** 63:  # uint64 bit pattern
+            v -= 2 ** 64
+        slot.i64 = v
+
+
+def exact_in_class(dtype, cls):
+    """Every value of ``dtype`` is exactly representable in the register class."""
+    dt = np.dtype(dtype)
+    if dt == bool:
+        return True
+    size = dt.itemsize
+    if cls == CLASS_F32:
+        return (dt.kind == "f" and size <= 4) or (dt.kind in "iu" and size <= 2)
+    if cls == CLASS_F64:
+        return dt.kind == "f" or (dt.kind in "iu" and size <= 4)
+    if cls == CLASS_I32:
+        return (dt.kind == "i" and size <= 4) or (dt.kind == "u" and size <= 2)
+    if cls == CLASS_I64:
+        return dt.kind in "iu"  # uint64 travels as its bit pattern (move-only)
+    return False
+
+
+ALL_CLASSES = frozenset((CLASS_F32, CLASS_F64, CLASS_I32, CLASS_I64))
+
+
+def classes_exact(dtype):
+    return frozenset(c for c in ALL_CLASSES if exact_in_class(dtype, c))
+
+
+def classes_for_compute(dtype):
+    """Classes able to *compute* in ``dtype`` bit-exactly (narrower step types are emulated:
+    f32 inside F64 by rounding after each op, i32 inside I64 by wrapping)."""
+    dt = np.dtype(dtype)
+    if dt == np.dtype("f4"):
+        return frozenset((CLASS_F32, CLASS_F64))
+    if dt == np.dtype("f8"):
+        return frozenset((CLASS_F64,))
+    if dt == np.dtype("i4"):
+        return frozenset((CLASS_I32, CLASS_I64))
+    if dt == np.dtype("i8"):
+        return frozenset((CLASS_I64,))
+    raise FusionLimit("no register class computes in %s" % dt)
+
+
+# ----------------------------------------------------------------------------
+# expression nodes
+# ----------------------------------------------------------------------------
+
+class Node:
+    dtype = None   # result dtype (np.dtype)
+    ndv = None     # result no_data_value as the reference would put in the dict
+
+    @property
+    def is_bool(self):
+        return self.dtype == np.dtype("bool")
+
+
+class Leaf(Node):
+    """A tile that arrives from outside the program (input slot)."""
+
+    def __init__(self, slot, dtype, ndv, broadcast=False):
+        self.slot, self.dtype, self.ndv, self.broadcast = slot, np.dtype(dtype), ndv, broadcast
+
+    def key(self):
+        return ("leaf", self.slot, self.dtype.str, _scalar_key(self.ndv), self.broadcast)
+
+
+class Lit(Node):
+    """A python / NumPy scalar operand."""
+
+    def __init__(self, value):
+        self.value = value
+        self.dtype = np.result_type(value) if isinstance(value, np.generic) else None
+
+    def key(self):
+        return ("lit", _scalar_key(self.value))
+
+
+class Op(Node):
+    def __init__(self, op, args, dtype, ndv, fill=None, extra=None):
+        self.op, self.args, self.dtype, self.ndv = op, list(args), np.dtype(dtype), ndv
+        self.fill, self.extra = fill, extra
+
+    def key(self):
+        return ("op", self.op, self.dtype.str, _scalar_key(self.ndv), _scalar_key(self.fill),
+                _scalar_key(self.extra), tuple(a.key() for a in self.args))
+
+
+def _scalar_key(v):
+    if v is None:
+        return None
+    if isinstance(v, (list, tuple)):
+        return tuple(_scalar_key(x) for x in v)
+    if isinstance(v, dict):
+        return tuple(sorted((k, _scalar_key(x)) for k, x in v.items()))
+    if isinstance(v, np.generic):
+        return (v.dtype.str, v.tobytes())
+    if isinstance(v, float):
+        return ("f", v.hex())
+    return (type(v).__name__, v)
+
+
+def compute_dtype(node):
+    """The dtype an Op's arithmetic / comparison is carried out in."""
+    if node.op in MATH_OPS:
+        return node.dtype
+    if node.op in COMPARE_OPS:
+        parts = []
+        for a in node.args:
+            parts.append(a.value if isinstance(a, Lit) and not isinstance(a.value, np.generic) else a.dtype)
+        try:
+            dt = np.result_type(*parts)
+        except OverflowError:  # python int outside the raster dtype: NumPy compares exactly
+            dt = np.dtype("i8")
+        if dt == bool:
+            return np.dtype("i4")
+        if dt.kind in "iu":
+            return np.dtype("i4") if exact_in_class(dt, CLASS_I32) else np.dtype("i8")
+        if dt.kind == "f" and dt.itemsize < 4:
+            return np.dtype("f4")
+        return dt
+    return None
+
+
+def node_classes(node):
+    """Admissible register classes of one node (not counting its children)."""
+    if isinstance(node, Lit):
+        return ALL_CLASSES
+    if isinstance(node, Leaf):
+        return ALL_CLASSES  # constrained by its consumers below
+    op = node.op
+    allowed = ALL_CLASSES
+    if op in MATH_OPS or op in COMPARE_OPS:
+        cd = compute_dtype(node)
+        if cd.kind == "u" and cd.itemsize == 8:
+            raise FusionLimit("uint64 arithmetic is not supported")
+        allowed = classes_for_compute(cd)
+        if op in COMPARE_OPS and cd.kind in "iu":
+            # small integers compare exactly in the float classes too
+            allowed = allowed | frozenset(c for c in (CLASS_F64, CLASS_F32, CLASS_I64)
+                                          if all(_operand_exact(a, c) for a in node.args))
+        for a in node.args:
+            if isinstance(a, Leaf):
+                # NumPy casts the operand to the compute dtype; the load does the same cast
+                # iff the class *is* the compute dtype or holds the leaf exactly
+                allowed = frozenset(c for c in allowed
+                                    if exact_in_class(a.dtype, c) or CLASS_DTYPE[c] == cd)
+    elif op in ("clip", "copy"):
+        allowed = classes_exact(node.args[0].dtype)
+    elif op == "mask":
+        store = node.args[0]
+        if store.dtype.kind == "f":
+            allowed = classes_exact(store.dtype)
+        value = node.extra["value"]
+        vdt = node.dtype
+        allowed = frozenset(c for c in allowed if _value_exact(value, vdt, c))
+    return allowed
+
+
+def _operand_exact(a, cls):
+    if isinstance(a, Lit):
+        try:
+            v = a.value
+            return bool(np.array(v).astype(CLASS_DTYPE[cls]) == v)
+        except (OverflowError, TypeError):
+            return False
+    return exact_in_class(a.dtype, cls)
+
+
+def _value_exact(value, dtype, cls):
+    v = cast_scalar(value, dtype)
+    with np.errstate(all="ignore"):
+        try:
+            return bool(np.array(v).astype(CLASS_DTYPE[cls]) == v)
+        except (OverflowError, TypeError):
+            return False
+
+
+def _leaf_use_exact(consumer, index):
+    """Does this use of a Leaf need its exact value (as opposed to a cast or its no-data bits)?"""
+    op = consumer.op
+    if op in ("clip", "copy"):
+        return index == 0
+    if op == "mask":
+        return consumer.args[0].dtype.kind == "f"
+    if op in ("isdata", "isnodata"):
+        return False
+    return False  # math / compare casts are handled in node_classes
+
+
+def tree_classes(root):
+    """Intersection of admissible classes over the whole tree (empty -> cannot fuse)."""
+    allowed = ALL_CLASSES
+    seen = set()
+    stack = [root]
+    while stack:
+        n = stack.pop()
+        if id(n) in seen:
+            continue
+        seen.add(id(n))
+        allowed = allowed & node_classes(n)
+        if isinstance(n, Op):
+            stack.extend(n.args)
+    return allowed
+
+
+# ----------------------------------------------------------------------------
+# compiler
+# ----------------------------------------------------------------------------
+
+class Compiled:
+    __slots__ = ("program", "out_dtype", "out_ndv", "n_inputs", "reg_class", "heavy", "n_steps")
+
+
+def compile_expr(root, n_inputs):
+    """Linearise ``root`` into a gm_program.  Raises FusionLimit if it does not fit."""
+    if isinstance(root, (Leaf, Lit)):
+        if isinstance(root, Lit):
+            raise FusionLimit("literal root")
+        root = Op("copy", [root], root.dtype, root.ndv)
+    allowed = tree_classes(root)
+    if not allowed:
+        raise FusionLimit("no common register class")
+    cls = min(allowed, key=lambda c: CLASS_COST[c])
+    if n_inputs > GM_MAX_INPUTS:
+        raise FusionLimit("too many inputs")
+
+    prog = gm_program()
+    prog.reg_class = cls
+    prog.n_inputs = n_inputs
+    steps = []
+    # consumers per shared Op node
+    refs = {}
+    order = []
+
+    def count(n):
+        if isinstance(n, Op):
+            refs[id(n)] = refs.get(id(n), 0) + 1
+            if refs[id(n)] == 1:
+                for a in n.args:
+                    count(a)
+                order.append(n)
+
+    count(root)
+    temp_of = {}           # id(node) -> temp index while it is live
+    remaining = dict(refs)  # uses still to come
+    free_temps = list(range(GM_MAX_TEMPS))
+    leaves = {}
+
+    def alloc_temp():
+        if not free_temps:
+            raise FusionLimit("out of temps")
+        return free_temps.pop(0)
+
+    def release(node):
+        if id(node) in temp_of:
+            remaining[id(node)] -= 1
+            if remaining[id(node)] == 0:
+                free_temps.insert(0, temp_of.pop(id(node)))
+
+    def is_simple(n):
+        return isinstance(n, (Leaf, Lit)) or id(n) in temp_of
+
+    def reg_operand(kind, index, node):
+        o = gm_operand()
+        o.kind, o.index = kind, index
+        o.is_bool = 1 if node.is_bool else 0
+        eff = None if node.is_bool else effective_ndv(node.dtype, node.ndv)
+        if eff is not None:
+            o.has_ndv = 1
+            _set_scalar(o.value, cls, eff)
+        return o
+
+    def operand(n, consumer, cd):
+        if isinstance(n, Leaf):
+            leaves[n.slot] = n
+            o = gm_operand()
+            o.kind, o.index = OPD_INPUT, n.slot
+            o.is_bool = 1 if n.is_bool else 0
+            return o
+        if isinstance(n, Lit):
+            o = gm_operand()
+            o.kind = OPD_SCALAR
+            target = cd if cd is not None else CLASS_DTYPE[cls]
+            _set_scalar(o.value, cls, cast_scalar(n.value, target))
+            return o
+        return reg_operand(OPD_TEMP, temp_of[id(n)], n)
+
+    def emit(node, a_opd, b_opd):
+        if len(steps) >= GM_MAX_STEPS:
+            raise FusionLimit("too many steps")
+        s = gm_step()
+        s.opcode = OPCODES[node.op]
+        s.a = a_opd
+        if b_opd is not None:
+            s.b = b_opd
+        cd = compute_dtype(node)
+        if node.op in MATH_OPS:
+            s.check_finite = 1 if cls in (CLASS_F32, CLASS_F64) else 0
+            s.round_f32 = 1 if (cls == CLASS_F64 and cd == np.dtype("f4")) else 0
+            s.wrap_i32 = 1 if (cls == CLASS_I64 and cd == np.dtype("i4")) else 0
+            _set_scalar(s.fill, cls, cast_scalar(node.fill, cd))
+            if node.op == "power" and cls in (CLASS_I32, CLASS_I64):
+                b = node.args[1]
+                if not (isinstance(b, Lit) and isinstance(b.value, (int, np.integer)) and b.value >= 0):
+                    raise NotImplementedError("integer Power needs a non-negative integer scalar exponent")
+        elif node.op in COMPARE_OPS or node.op in LOGIC_OPS:
+            _set_scalar(s.fill, cls, 1 if node.op == "not_equal" else 0)
+        elif node.op == "clip":
+            store = node.args[0]
+            eff = effective_ndv(store.dtype, store.ndv)
+            if eff is None:
+                # nothing can be marked: the reference writes the ndv as is
+                eff = cast_scalar(store.ndv, store.dtype)
+            _set_scalar(s.fill, cls, eff)
+        elif node.op == "mask":
+            ex = node.extra
+            _set_scalar(s.fill, cls, ex["fill"])
+            _set_scalar(s.aux0, cls, cast_scalar(ex["value"], node.dtype))
+            s.flags = ex["flags"]
+            s.aux1.f64 = ex["tol"]
+            s.aux2.f64 = ex["y"]
+        steps.append(s)
+        return s
+
+    def eval_to_acc(node):
+        """Emit the steps that leave ``node`` in the accumulator (and in a temp if shared)."""
+        if not isinstance(node, Op):
+            cp = Op("copy", [node], node.dtype, node.ndv)
+            emit(cp, operand(node, cp, None), None)
+            return
+        cd = compute_dtype(node)
+        args = node.args
+        pending = [a for a in args if not is_simple(a)]
+        if len(pending) == 2 and pending[0] is not pending[1]:
+            x, y = pending
+            eval_to_acc(x)
+            if not is_simple(x):  # spill the left value around the right sub-tree
+                t = alloc_temp()
+                steps[-1].save_temp = t + 1
+                temp_of[id(x)] = t
+                remaining[id(x)] = 1
+            eval_to_acc(y)
+        elif pending:
+            eval_to_acc(pending[0])
+        opds = []
+        for a in args:
+            if is_simple(a):
+                opds.append(operand(a, node, cd))
+            else:
+                opds.append(reg_operand(OPD_ACC, 0, a))
+        s = emit(node, opds[0], opds[1] if len(opds) > 1 else None)
+        for a in args:
+            release(a)
+        if refs.get(id(node), 1) > 1 and id(node) not in temp_of:
+            t = alloc_temp()
+            s.save_temp = t + 1
+            temp_of[id(node)] = t
+            remaining[id(node)] = refs[id(node)]
+
+    eval_to_acc(root)
+    prog.n_steps = len(steps)
+    for i, s in enumerate(steps):
+        prog.steps[i] = s
+    for slot, leaf in leaves.items():
+        d = prog.inputs[slot]
+        d.dtype = code_of(leaf.dtype)
+        d.broadcast = 1 if leaf.broadcast else 0
+        eff = None if leaf.is_bool else effective_ndv(leaf.dtype, leaf.ndv)
+        if eff is not None:
+            d.has_ndv = 1
+            if leaf.dtype.kind == "f":
+                d.ndv.f64 = float(eff)
+            elif leaf.dtype == np.dtype("u8"):
+                d.ndv.u64 = int(eff)
+            else:
+                d.ndv.i64 = int(eff)
+    for slot in range(n_inputs):
+        if slot not in leaves:  # unused input: still needs a valid dtype code
+            prog.inputs[slot].dtype = code_of(np.dtype("u1"))
+    prog.out_dtype = code_of(root.dtype)
+    out = Compiled()
+    out.program, out.out_dtype, out.out_ndv = prog, root.dtype, root.ndv
+    out.n_inputs, out.reg_class, out.n_steps = n_inputs, cls, len(steps)
+    out.heavy = any(OPCODES[k] == s.opcode for s in steps for k in HEAVY_OPS)
+    return out
+
+
+_CACHE = {}
+
+
+def compile_cached(root, n_inputs):
+    key = (root.key(), n_inputs)
+    hit = _CACHE.get(key)
+    if hit is None:
+        hit = compile_expr(root, n_inputs)
+        if len(_CACHE) > 512:
+            _CACHE.clear()
+        _CACHE[key] = hit
+    return hit
+
+
+# ----------------------------------------------------------------------------
+# launch
+# ----------------------------------------------------------------------------
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    L = runtime.lib()
+    if not _declared:
+        L.gm_elemwise_run.argtypes = [ctypes.POINTER(gm_program), ctypes.POINTER(ctypes.c_void_p),
+                                      ctypes.c_void_p, ctypes.c_size_t]
+        L.gm_elemwise_run.restype = ctypes.c_int
+        L.gm_vm_set_tuning.argtypes = [ctypes.POINTER(gm_vm_tuning)]
+        L.gm_vm_get_tuning.argtypes = [ctypes.POINTER(gm_vm_tuning)]
+        L.gm_sizeof.argtypes = [ctypes.c_int]
+        L.gm_sizeof.restype = ctypes.c_size_t
+        for which, struct in enumerate((gm_program, gm_step, gm_operand, gm_input_desc)):
+            if L.gm_sizeof(which) != ctypes.sizeof(struct):
+                raise runtime.GmHipError("ABI mismatch: sizeof(%s) is %d in Python, %d in libgmhip" % (
+                    struct.__name__, ctypes.sizeof(struct), L.gm_sizeof(which)))
+        _declared = True
+    return L
+
+
+def set_tuning(vec=8, blocks_per_cu=8, xcd_chunking=0, nontemporal=0):
+    t = gm_vm_tuning(vec, blocks_per_cu, xcd_chunking, nontemporal)
+    runtime.check(_lib().gm_vm_set_tuning(ctypes.byref(t)), "gm_vm_set_tuning")
+
+
+def get_tuning():
+    t = gm_vm_tuning()
+    runtime.check(_lib().gm_vm_get_tuning(ctypes.byref(t)), "gm_vm_get_tuning")
+    return {"vec": t.vec, "blocks_per_cu": t.blocks_per_cu, "xcd_chunking": t.xcd_chunking,
+            "nontemporal": t.nontemporal}
+
+
+def launch(compiled, inputs, shape, out=None):
+    """Run a compiled program over device tiles ``inputs`` -> DeviceArray of ``shape``."""
+    L = _lib()
+    n = int(np.prod(shape, dtype=np.int64))
+    if out is None:
+        out = DeviceArray.empty(shape, compiled.out_dtype)
+    ptrs = (ctypes.c_void_p * max(len(inputs), 1))(*[x.ptr for x in inputs])
+    runtime.check(L.gm_elemwise_run(ctypes.byref(compiled.program), ptrs, ctypes.c_void_p(out.ptr), n),
+                  "gm_elemwise_run")
+    return out
+
+
+def run_expr(build, tiles):
+    """Evaluate an expression over raster tiles.
+
+    ``tiles``: list of (values, ndv) with values ndarray | DeviceArray; ``build(leaves)``
+    receives one Leaf per tile and returns the root node.  Returns (DeviceArray, ndv).
+    """
+    runtime.require_device()
+    dev = [as_device(values) for values, _ in tiles]
+    big = max(dev, key=lambda a: a.size)
+    shape, n = big.shape, big.size
+    leaves = []
+    for slot, (arr, (_, ndv)) in enumerate(zip(dev, tiles)):
+        if arr.size != n and arr.size != 1:
+            raise NotImplementedError("operand shapes %s and %s differ (only equal shapes or "
+                                      "single-element operands are supported on the device)" % (shape, arr.shape))
+        leaves.append(Leaf(slot, arr.dtype, ndv, broadcast=(arr.size == 1 and n != 1)))
+    root = build(leaves)
+    compiled = compile_cached(root, len(leaves))
+    out = launch(compiled, dev, shape)
+    return out, compiled.out_ndv

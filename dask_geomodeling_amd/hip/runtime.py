@@ -1,0 +1,163 @@
+"""Loader and thin wrappers for the runtime part of the C-ABI (include/gmhip.h).
+
+The product path is HIP-only: there is no NumPy fallback.  If the shared library is
+missing, or no MI355X is visible when a kernel is requested, a ``GmHipError`` is
+raised -- loudly, never a silent CPU path.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgmhip.so")
+
+
+class GmHipError(RuntimeError):
+    """A C-ABI call returned non-zero (message from gm_last_error())."""
+
+
+class gm_scalar(ctypes.Union):
+    _fields_ = [("f64", ctypes.c_double), ("f32", ctypes.c_float), ("i64", ctypes.c_int64),
+                ("u64", ctypes.c_uint64), ("i32", ctypes.c_int32)]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """The loaded CDLL (loads on first use; raises if the extension was not built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise GmHipError(
+                "HIP extension not built: %s is missing. Build it with "
+                "`make -C dask_geomodeling_amd/csrc` (or __graft_entry__.build()). "
+                "There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        _declare(L)
+        _lib = L
+    return _lib
+
+
+def _declare(L):
+    c = ctypes
+    vp, sz, i32, u64 = c.c_void_p, c.c_size_t, c.c_int, c.c_uint64
+    L.gm_last_error.restype = c.c_char_p
+    L.gm_version.restype = c.c_char_p
+    sigs = {
+        "gm_init": [], "gm_device_count": [], "gm_set_device": [i32],
+        "gm_get_device": [c.POINTER(i32)], "gm_device_name": [c.c_char_p, sz],
+        "gm_malloc": [c.POINTER(vp), sz], "gm_free": [vp], "gm_pool_trim": [],
+        "gm_mem_info": [c.POINTER(sz), c.POINTER(sz)],
+        "gm_pool_stats": [c.POINTER(sz), c.POINTER(sz)],
+        "gm_h2d": [vp, vp, sz], "gm_d2h": [vp, vp, sz], "gm_d2d": [vp, vp, sz],
+        "gm_memset": [vp, i32, sz], "gm_sync": [],
+        "gm_event_create": [c.POINTER(vp)], "gm_event_destroy": [vp], "gm_event_record": [vp],
+        "gm_event_sync": [vp], "gm_event_elapsed_ms": [vp, vp, c.POINTER(c.c_float)],
+        "gm_all_equal": [vp, i32, gm_scalar, sz, c.POINTER(i32)],
+        "gm_fill": [vp, i32, gm_scalar, sz],
+        "gm_generate": [vp, i32, u64, u64, c.c_double, c.c_double, sz, c.c_uint32, c.c_uint32,
+                        c.c_uint32, gm_scalar],
+        "gm_checksum": [vp, sz, c.POINTER(u64)],
+        "gm_paste_tile": [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32],
+    }
+    for name, args in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = c.c_int
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().gm_last_error().decode("utf-8", "replace")
+        raise GmHipError("%s failed (code %d): %s" % (what or "libgmhip call", rc, msg))
+
+
+def device_count():
+    return int(lib().gm_device_count())
+
+
+def require_device():
+    if device_count() <= 0:
+        raise GmHipError("no HIP device visible: the raster compute path needs an MI355X "
+                         "(there is no CPU fallback)")
+
+
+def set_device(index):
+    check(lib().gm_set_device(int(index)), "gm_set_device")
+
+
+def get_device():
+    out = ctypes.c_int(0)
+    check(lib().gm_get_device(ctypes.byref(out)), "gm_get_device")
+    return out.value
+
+
+def device_name():
+    buf = ctypes.create_string_buffer(256)
+    check(lib().gm_device_name(buf, 256), "gm_device_name")
+    return buf.value.decode()
+
+
+def sync():
+    check(lib().gm_sync(), "gm_sync")
+
+
+def malloc(nbytes):
+    ptr = ctypes.c_void_p()
+    check(lib().gm_malloc(ctypes.byref(ptr), int(nbytes)), "gm_malloc(%d)" % nbytes)
+    return ptr.value
+
+
+def free(ptr):
+    if ptr:
+        lib().gm_free(ctypes.c_void_p(ptr))
+
+
+def pool_trim():
+    check(lib().gm_pool_trim(), "gm_pool_trim")
+
+
+def mem_info():
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib().gm_mem_info(ctypes.byref(f), ctypes.byref(t)), "gm_mem_info")
+    return f.value, t.value
+
+
+def pool_stats():
+    a, b = ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib().gm_pool_stats(ctypes.byref(a), ctypes.byref(b)), "gm_pool_stats")
+    return a.value, b.value
+
+
+class Event:
+    """HIP event on the current device's compute stream."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        check(lib().gm_event_create(ctypes.byref(h)), "gm_event_create")
+        self._h = h
+
+    def record(self):
+        check(lib().gm_event_record(self._h), "gm_event_record")
+        return self
+
+    def synchronize(self):
+        check(lib().gm_event_sync(self._h), "gm_event_sync")
+
+    def elapsed_ms(self, later):
+        ms = ctypes.c_float()
+        check(lib().gm_event_elapsed_ms(self._h, later._h, ctypes.byref(ms)), "gm_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().gm_event_destroy(self._h)
+        except Exception:
+            pass

@@ -1,0 +1,197 @@
+"""Device implementations of the hot ``process`` bodies.
+
+Each ``*_process`` function has the positional signature of the reference's
+``process`` staticmethod it stands in for and keeps its control flow for ``None`` /
+``time`` / ``meta`` responses; the numerics are handed to the HIP library as an
+expression (one launch).  The ``*_node`` builders are shared with the fusion pass
+(dask_geomodeling_amd/fuse.py), so a fused chain and the op-by-op path run the very
+same per-op program steps.
+
+There is no NumPy compute path here: without libgmhip / an MI355X these functions
+raise ``GmHipError``.
+"""
+import ctypes
+
+import numpy as np
+
+from ..hip import program as P
+from ..hip import runtime
+from ..hip.array import DeviceArray, as_device
+from ..hip.dtypes import code_of
+from ..hip.runtime import gm_scalar
+from .. import utils
+
+BOOL = np.dtype("bool")
+
+
+# ---------------------------------------------------------------------------
+# expression builders (shared with fuse.py)
+# ---------------------------------------------------------------------------
+
+def math_node(op, process_kwargs, nodes):
+    """Node of the no-data aware ufunc wrapper (raster/elemwise.py:243-297)."""
+    dtype = np.dtype(process_kwargs["dtype"])
+    fill = process_kwargs["fillvalue"]
+    if dtype == BOOL:  # elemwise.py:278-284
+        return P.Op(op, nodes, BOOL, None, fill=(op == "not_equal"))
+    return P.Op(op, nodes, dtype, fill, fill=fill)
+
+
+def clip_node(store, source):
+    """Clip.process numerics (raster/misc.py:115-123)."""
+    return P.Op("clip", [store, source], store.dtype, store.ndv)
+
+
+def mask_dtype(value):
+    """Output dtype of Mask (raster/misc.py:195-206)."""
+    if isinstance(value, float):
+        return np.dtype("float32")
+    if value >= 0:
+        return utils.get_uint_dtype(value)
+    return utils.get_int_dtype(value)
+
+
+def isclose_params(tile_dtype, ndv):
+    """Parameters of ``~np.isclose(tile, ndv)`` as utils.get_index evaluates it for a float
+    tile (utils.py:61-64) under NumPy's own scalar-promotion rules:
+    (evaluate_in_f64, ndv as compared, tolerance, ndv_is_finite)."""
+    x = np.zeros(1, dtype=tile_dtype)
+    with np.errstate(all="ignore"):
+        y = ndv if isinstance(ndv, (int, float, complex)) else np.asanyarray(ndv)
+        if getattr(y, "dtype", None) is not None and y.dtype.kind != "m":
+            y = np.asanyarray(y, dtype=np.result_type(y, 1.0))
+        elif isinstance(y, int):
+            y = float(y)
+        diff = np.abs(x - y)
+        tol = 1e-8 + 1e-5 * np.abs(y)
+        in_f64 = diff.dtype == np.dtype("f8")
+        ycmp = np.array(y).astype(diff.dtype)[()]
+        tolcmp = np.array(tol).astype(diff.dtype)[()]
+        finite = bool(np.isfinite(y))
+    return in_f64, float(ycmp), float(tolcmp), finite
+
+
+def mask_node(store, value):
+    """Mask.process numerics (raster/misc.py:213-221)."""
+    dtype = mask_dtype(value)
+    fill = 1 if value == 0 else 0
+    # NumPy refuses out-of-range python ints on assignment (e.g. value 256 -> uint8): same error
+    np.zeros(1, dtype=dtype)[0:1] = value
+    if store.dtype.kind == "f":
+        in_f64, y, tol, finite = isclose_params(store.dtype, store.ndv)
+        flags = (1 if in_f64 else 0) | (2 if finite else 0)
+    else:
+        flags, y, tol = 4, 0.0, 0.0
+    extra = {"value": value, "fill": fill, "flags": flags, "tol": tol, "y": y}
+    return P.Op("mask", [store], dtype, fill, extra=extra)
+
+
+def invert_node(x):
+    return P.Op("invert", [x], BOOL, None)
+
+
+def isdata_node(x):
+    return P.Op("isdata", [x], BOOL, None)
+
+
+def isnodata_node(x):
+    return P.Op("isnodata", [x], BOOL, None)
+
+
+# ---------------------------------------------------------------------------
+# process bodies
+# ---------------------------------------------------------------------------
+
+def is_tile(data):
+    return isinstance(data, dict) and "values" in data
+
+
+def math_process(op, process_kwargs, *args):
+    """Drop-in for ``wrap_math_process_func(np.<op>)`` (raster/elemwise.py:243-297)."""
+    if not args:
+        return None
+    tiles, slots = [], []
+    for data in args:  # same early-outs, same order as the reference
+        if data is None:
+            return None
+        if not isinstance(data, dict):
+            if isinstance(data, np.ndarray):
+                slots.append(("tile", len(tiles)))
+                tiles.append((data, None))
+            else:
+                slots.append(("lit", data))
+        elif "time" in data or "meta" in data:
+            return data
+        elif "values" in data:
+            slots.append(("tile", len(tiles)))
+            tiles.append((data["values"], data.get("no_data_value")))
+        else:
+            raise TypeError("Cannot apply math function to value {}".format(data))
+
+    def build(leaves):
+        nodes = [leaves[ref] if kind == "tile" else P.Lit(ref) for kind, ref in slots]
+        return math_node(op, process_kwargs, nodes)
+
+    if not tiles:
+        raise TypeError("at least one raster operand is required")
+    values, ndv = P.run_expr(build, tiles)
+    return {"no_data_value": ndv, "values": values}
+
+
+def make_math_process(op):
+    def process(process_kwargs, *args):
+        return math_process(op, process_kwargs, *args)
+
+    process.__name__ = op
+    process.gm_op = op  # recognised by the fusion pass
+    return process
+
+
+def all_equal(values, ndv):
+    """``np.all(values == ndv)`` on the device (Clip early-out, misc.py:108)."""
+    arr = as_device(values)
+    eff = P.effective_ndv(arr.dtype, ndv)
+    if eff is None:
+        return arr.size == 0
+    s = gm_scalar()
+    if arr.dtype.kind == "f":
+        s.f64 = float(eff)
+    elif arr.dtype == np.dtype("u8"):
+        s.u64 = int(eff)
+    else:
+        s.i64 = int(eff)
+    out = ctypes.c_int(0)
+    runtime.check(runtime.lib().gm_all_equal(ctypes.c_void_p(arr.ptr), code_of(arr.dtype), s, arr.size,
+                                             ctypes.byref(out)), "gm_all_equal")
+    return bool(out.value)
+
+
+def clip_process(data, source_data):
+    """Drop-in for Clip.process (raster/misc.py:98-123)."""
+    if data is None:
+        return None
+    if "values" not in data:
+        return data
+    if source_data is None:
+        # misc.py:108-113: an all-no-data store is handed back untouched, else None
+        return data if all_equal(data["values"], data["no_data_value"]) else None
+    tiles = [(data["values"], data["no_data_value"]),
+             (source_data["values"], source_data.get("no_data_value"))]
+    values, ndv = P.run_expr(lambda leaves: clip_node(leaves[0], leaves[1]), tiles)
+    return {"values": values, "no_data_value": data["no_data_value"]}
+
+
+def mask_process(data, value):
+    """Drop-in for Mask.process (raster/misc.py:208-222)."""
+    if data is None or "values" not in data:
+        return data
+    tiles = [(data["values"], data["no_data_value"])]
+    values, ndv = P.run_expr(lambda leaves: mask_node(leaves[0], value), tiles)
+    return {"values": values, "no_data_value": ndv}
+
+
+def unary_bool_process(kind, data):
+    tiles = [(data["values"], data.get("no_data_value"))]
+    builder = {"invert": invert_node, "isdata": isdata_node, "isnodata": isnodata_node}[kind]
+    values, _ = P.run_expr(lambda leaves: builder(leaves[0]), tiles)
+    return {"values": values, "no_data_value": None}

@@ -1,0 +1,279 @@
+/*
+ * gmhip.h -- C-ABI of libgmhip.so: the MI355X (gfx950) per-tile raster compute path
+ * behind dask-geomodeling's Block.process() bodies.
+ *
+ * The reference (nens/dask-geomodeling) is pure Python: there is no FFI to replace.
+ * The drop-in boundary is the `process` staticmethod of each hot Block; every entry
+ * point below is what the Python `process` body binds through ctypes *instead of*
+ * its NumPy sweeps.  Reference paths are relative to /root/reference/dask_geomodeling.
+ *
+ * Conventions
+ *   - plain C types only (pointers, sizes, PODs); no exceptions cross the ABI
+ *   - every function returns 0 on success, non-zero (a hipError_t value or a
+ *     GM_ERR_* code) on failure; gm_last_error() gives the message of the last
+ *     failure on the calling thread
+ *   - device pointers come from gm_malloc(); all work is enqueued on the calling
+ *     thread's current device's compute stream and is asynchronous with respect
+ *     to the host unless stated otherwise (gm_sync / gm_d2h are the sync points)
+ *   - tiles are C-contiguous (bands, H, W); element-wise kernels see n = bands*H*W
+ */
+#ifndef GMHIP_H
+#define GMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_VERSION "0.1.0"
+
+/* ---- error codes (besides hipError_t values, which are < 2000) ---------------- */
+#define GM_OK 0
+#define GM_ERR_INVALID 9001     /* bad argument / malformed program */
+#define GM_ERR_UNSUPPORTED 9002 /* valid request the kernels do not cover */
+#define GM_ERR_NO_DEVICE 9003
+
+/* ---- element types of tiles in HBM ------------------------------------------- */
+enum gm_dtype {
+  GM_BOOL = 0, /* 1 byte, 0/1 */
+  GM_U8 = 1,
+  GM_I8 = 2,
+  GM_U16 = 3,
+  GM_I16 = 4,
+  GM_U32 = 5,
+  GM_I32 = 6,
+  GM_U64 = 7,
+  GM_I64 = 8,
+  GM_F32 = 9,
+  GM_F64 = 10,
+  GM_DTYPE_COUNT = 11
+};
+
+/* 8-byte scalar slot; which member is meaningful is stated per use */
+typedef union gm_scalar {
+  double f64;
+  float f32;
+  int64_t i64;
+  uint64_t u64;
+  int32_t i32;
+} gm_scalar;
+
+/* =============================================================================
+ * Runtime: devices, memory, streams, events
+ * ========================================================================== */
+
+/* Initialise HIP; GM_ERR_NO_DEVICE when no GPU is visible (the library still loads). */
+int gm_init(void);
+/* Number of visible devices, or 0 when HIP cannot initialise. Never fails. */
+int gm_device_count(void);
+/* Select the calling thread's current device (also creates its stream/pool). */
+int gm_set_device(int device);
+int gm_get_device(int* device);
+/* Device name / arch string ("gfx950...") of the current device into buf. */
+int gm_device_name(char* buf, size_t len);
+
+/* Caching device allocator (per device, mutex-guarded; blocks are recycled without
+ * hipFree, safe because all work of a device is ordered on one stream). */
+int gm_malloc(void** ptr, size_t bytes);
+int gm_free(void* ptr);
+int gm_pool_trim(void);                      /* hipFree all cached blocks */
+int gm_mem_info(size_t* free_bytes, size_t* total_bytes);
+int gm_pool_stats(size_t* in_use_bytes, size_t* cached_bytes);
+
+int gm_h2d(void* dst_dev, const void* src_host, size_t bytes); /* returns after the copy */
+int gm_d2h(void* dst_host, const void* src_dev, size_t bytes); /* returns after the copy */
+int gm_d2d(void* dst_dev, const void* src_dev, size_t bytes);  /* async */
+int gm_memset(void* dst_dev, int byte_value, size_t bytes);    /* async */
+int gm_sync(void);                                             /* drain the current device's stream */
+
+/* Timing on the compute stream (HIP events). */
+int gm_event_create(void** event);
+int gm_event_destroy(void* event);
+int gm_event_record(void* event);
+int gm_event_sync(void* event);
+int gm_event_elapsed_ms(void* start, void* stop, float* ms);
+
+const char* gm_last_error(void);
+const char* gm_version(void);
+
+/* =============================================================================
+ * K1: fused element-wise program ("VM") -- one launch per tile
+ *
+ * Replaces the body of wrap_math_process_func (raster/elemwise.py:235-299) for
+ * Add/Subtract/Multiply/Divide/Power (:302-406), the comparison/logic/exp/log
+ * members of the same wrapper (:409-548, 641-697, 784-832), Invert/IsData/IsNoData
+ * (:551-638), FillNoData (:700-757), and Clip.process / Mask.process / MaskBelow /
+ * Step (raster/misc.py:98-123, 208-222, 245-251, 308-328) -- and chains of them.
+ *
+ * A program is a straight-line accumulator program: every step computes
+ *     acc = op(a, b)
+ * where each operand is the accumulator, an input tile, a literal or a saved temp.
+ * Every step re-applies the reference's per-op rule literally:
+ *     nodata = OR over raster operands (operand == operand_ndv)   [exact ==]
+ *     r = op(a, b) computed in the step's dtype
+ *     r = fill where !isfinite(r) or nodata
+ * so a fused chain is bit-identical to the unfused one.
+ * ========================================================================== */
+
+#define GM_MAX_INPUTS 8
+#define GM_MAX_STEPS 32
+#define GM_MAX_TEMPS 4
+
+/* register class: the type all VM registers are held in */
+enum gm_reg_class { GM_CLASS_F32 = 0, GM_CLASS_F64 = 1, GM_CLASS_I32 = 2, GM_CLASS_I64 = 3 };
+
+enum gm_operand_kind { GM_OPD_NONE = 0, GM_OPD_ACC = 1, GM_OPD_INPUT = 2, GM_OPD_SCALAR = 3, GM_OPD_TEMP = 4 };
+
+enum gm_opcode {
+  GM_OP_NOP = 0,
+  /* wrap_math_process_func family: r = ufunc(a, b) */
+  GM_OP_ADD = 1, GM_OP_SUB = 2, GM_OP_MUL = 3, GM_OP_DIV = 4, GM_OP_POW = 5,
+  GM_OP_EQ = 6, GM_OP_NE = 7, GM_OP_GT = 8, GM_OP_GE = 9, GM_OP_LT = 10, GM_OP_LE = 11,
+  GM_OP_AND = 12, GM_OP_OR = 13, GM_OP_XOR = 14,
+  GM_OP_EXP = 15, GM_OP_LOG = 16, GM_OP_LOG10 = 17,
+  /* stand-alone element-wise blocks */
+  GM_OP_INVERT = 18,   /* ~a (bool) */
+  GM_OP_ISDATA = 19,   /* a != ndv_a */
+  GM_OP_ISNODATA = 20, /* a == ndv_a */
+  GM_OP_CLIP = 21,     /* a where b has data (b bool: where b), else ndv_a */
+  GM_OP_MASK = 22,     /* aux where a is data (isclose rule for float tiles) else fill */
+  GM_OP_MASKBELOW = 23,/* ndv_a where a < aux else a */
+  GM_OP_STEP = 24,     /* left/at/right by comparing a with aux; no-data kept */
+  GM_OP_FILLNODATA = 25,/* b where b is data (isclose rule) else a */
+  GM_OP_COPY = 26,     /* acc = a (cast only) */
+  GM_OP_COUNT
+};
+
+typedef struct gm_operand {
+  uint8_t kind;     /* gm_operand_kind */
+  uint8_t index;    /* input / temp index */
+  uint8_t has_ndv;  /* ACC/TEMP: test the register against `value` (INPUT operands use
+                       their gm_input_desc instead) */
+  uint8_t is_bool;  /* operand is a boolean raster (never carries no-data) */
+  uint8_t pad_[4];
+  gm_scalar value;  /* SCALAR: the literal; ACC/TEMP: the ndv -- in register-class representation */
+} gm_operand;
+
+typedef struct gm_step {
+  uint8_t opcode;     /* gm_opcode */
+  uint8_t round_f32;  /* F64 class: step dtype is float32 -> round result to f32 */
+  uint8_t wrap_i32;   /* I64 class: step dtype is int32 -> wrap result to 32 bits */
+  uint8_t save_temp;  /* 0 = no, else 1 + temp index: also keep the result in a temp */
+  uint8_t check_finite; /* apply r[~isfinite(r)] = fill (float classes) */
+  uint8_t flags;      /* MASK/FILLNODATA: 1 = isclose evaluated in f64 (else f32), 2 = ndv finite,
+                         4 = integer tile (exact != instead of isclose) */
+  uint8_t pad_[2];
+  gm_operand a, b;
+  gm_scalar fill;     /* value written where no-data / non-finite (register-class repr) */
+  gm_scalar aux0;     /* MASK: value (register-class repr); MASKBELOW/STEP: threshold */
+  gm_scalar aux1;     /* MASK/FILLNODATA: .f64 isclose tolerance atol + rtol*|ndv|; STEP: left */
+  gm_scalar aux2;     /* MASK/FILLNODATA: .f64 the ndv isclose compares with; STEP: at */
+  gm_scalar aux3;     /* STEP: right */
+} gm_step;
+
+typedef struct gm_input_desc {
+  uint8_t dtype;      /* gm_dtype of the tile in HBM */
+  uint8_t broadcast;  /* 1: single element, broadcast to every pixel */
+  uint8_t has_ndv;    /* test elements against ndv (exact ==, in the tile's own dtype) */
+  uint8_t pad_[5];
+  gm_scalar ndv;      /* float tiles: .f64 (exactly representable in the tile dtype);
+                         integer/bool tiles: .i64 (.u64 for GM_U64) */
+} gm_input_desc;
+
+typedef struct gm_program {
+  uint32_t n_steps;
+  uint32_t n_inputs;
+  uint8_t reg_class;  /* gm_reg_class */
+  uint8_t out_dtype;  /* gm_dtype the final accumulator is stored as */
+  uint8_t pad_[6];
+  gm_input_desc inputs[GM_MAX_INPUTS];
+  gm_step steps[GM_MAX_STEPS];
+} gm_program;
+
+/* Run `prog` over n elements.  inputs[k] are device pointers (n elements each, or 1
+ * when broadcast); out is a device pointer to n elements of prog->out_dtype. */
+int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out, size_t n);
+
+/* Tuning knobs of the VM launch (0 = default): elements per lane per iteration
+ * (4 or 8), workgroups per CU, XCD-contiguous chunking, non-temporal access. */
+typedef struct gm_vm_tuning {
+  int32_t vec;            /* 4 | 8 */
+  int32_t blocks_per_cu;  /* grid = blocks_per_cu * CUs, capped by the work */
+  int32_t xcd_chunking;   /* 1: each XCD streams its own contiguous eighth */
+  int32_t nontemporal;    /* bit0: loads, bit1: stores */
+} gm_vm_tuning;
+int gm_vm_set_tuning(const gm_vm_tuning* t);
+int gm_vm_get_tuning(gm_vm_tuning* t);
+/* sizeof of the ABI structs (0 gm_program, 1 gm_step, 2 gm_operand, 3 gm_input_desc): lets a
+ * binding verify its struct layout at load time. */
+size_t gm_sizeof(int which);
+
+/* =============================================================================
+ * K4: Classify -- np.digitize + no-data.  raster/misc.py:387-399
+ *   out[i] = (in[i] == ndv && has_ndv) ? fill : digitize(in[i], bins, right)
+ * Comparisons are made in float64 (NumPy promotes value and edges); NaN -> nbins.
+ * out_dtype is GM_U8/GM_U16/GM_U32; bins is a HOST pointer (staged into LDS).
+ * ========================================================================== */
+int gm_classify(const void* in, int in_dtype, int has_ndv, gm_scalar ndv /* as in_dtype's class: f64 for floats, i64 for ints */,
+                const double* bins_host, int nbins, int right,
+                void* out, int out_dtype, uint64_t fill, size_t n);
+
+/* =============================================================================
+ * K5: Reclassify -- np.isin + np.searchsorted lookup.  raster/misc.py:482-515
+ *   keys_host: ntab sorted unique int64 keys (the no-data key already merged in by
+ *   the caller, misc.py:495-502); targets_host: ntab values of out_dtype's class
+ *   (int64 or float64 bit patterns).  select: unmapped -> fill, else value cast.
+ *   in_dtype: bool or any integer; out_dtype: GM_I64 or GM_F64.
+ * ========================================================================== */
+int gm_reclassify(const void* in, int in_dtype,
+                  const int64_t* keys_host, const gm_scalar* targets_host, int ntab,
+                  int select, gm_scalar fill, void* out, int out_dtype, size_t n);
+
+/* =============================================================================
+ * K6/K7: resampling of (bands, Hs, Ws) -> (bands, Hd, Wd)
+ * ========================================================================== */
+
+/* Nearest neighbour with a separable affine index map (float64):
+ *   src_col = floor(col_off + (c + 0.5) * col_scale + eps),  rows likewise;
+ *   outside the source -> fill.  Covers the GDAL nearest warp of an axis-aligned
+ *   same-CRS request (raster/sources.py:119-149; eps = 1e-10) and SciPy's
+ *   affine_transform(order=0) of Smooth's zoom branch (raster/spatial.py:296-305;
+ *   center = 0.0 variant, see gm_resample_nearest's `center` argument).
+ * finite_to_fill: also map non-finite source values to fill (sources.py:148). */
+int gm_resample_nearest(const void* src, int dtype, int bands, int hs, int ws,
+                        void* dst, int hd, int wd,
+                        double row_off, double row_scale, double col_off, double col_scale,
+                        double center, double eps, gm_scalar fill, int finite_to_fill);
+
+/* Bilinear (our spec; no reference implementation exists): pixel-centre
+ * aligned, edge-clamped, evaluated in float64, rounded once; any tap == ndv or
+ * non-finite -> ndv.  dtype: GM_F32 or GM_F64.  Source tile + 1 px apron staged in LDS. */
+int gm_resample_bilinear(const void* src, int dtype, int bands, int hs, int ws,
+                         void* dst, int hd, int wd, int has_ndv, gm_scalar ndv);
+
+/* =============================================================================
+ * K8: helpers
+ * ========================================================================== */
+
+/* *result = 1 iff every element equals `value` (Clip early-out, misc.py:108). Synchronous. */
+int gm_all_equal(const void* in, int dtype, gm_scalar value, size_t n, int* result);
+/* out[i] = value */
+int gm_fill(void* out, int dtype, gm_scalar value, size_t n);
+/* Synthetic tile: counter-based uniform values in [lo, hi) keyed by (seed, global index),
+ * with `ndv` written on the lattice (i / width) % ny == 0 && (i % width) % nx == 0
+ * (nx == 0 disables).  Element i of the tile has global index offset + i. */
+int gm_generate(void* out, int dtype, uint64_t seed, uint64_t offset, double lo, double hi,
+                size_t n, uint32_t width, uint32_t lattice_y, uint32_t lattice_x, gm_scalar ndv);
+/* 64-bit order-independent checksum (sum of mixed 32-bit words) of a device buffer. Synchronous. */
+int gm_checksum(const void* in, size_t bytes, uint64_t* result);
+/* Paste a (bands, th, tw) tile into a (bands, H, W) mosaic at (row0, col0): the device side
+ * of RasterTiler.process (raster/parallelize.py:118-124). itemsize in bytes. */
+int gm_paste_tile(void* mosaic, int H, int W, const void* tile, int bands, int th, int tw,
+                  int row0, int col0, int itemsize);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMHIP_H */

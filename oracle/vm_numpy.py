@@ -1,0 +1,159 @@
+"""CPU ORACLE (test infrastructure) -- NumPy interpreter of a ``gm_program``.
+
+It restates, step by step, what the HIP kernel ``vm_kernel`` (dask_geomodeling_amd/
+csrc/gm_vm.h) does with a program, so that CPU-only tests can check the *host*
+compiler (expression -> program, register class choice, scalar conversion) against
+the reference-generated golden vectors without a GPU, and so that GPU tests can
+tell compiler bugs from kernel bugs.  Only tests may import it; it is also what the
+``cpu_vm`` test fixture plugs in place of ``program.launch``.
+
+Every step re-applies raster/elemwise.py:263-296 literally (no-data by exact ==,
+compute in the step dtype, non-finite -> fill, no-data -> fill).
+"""
+import numpy as np
+
+CLASS_DTYPE = {0: np.dtype("f4"), 1: np.dtype("f8"), 2: np.dtype("i4"), 3: np.dtype("i8")}
+CODE_DTYPE = {0: "bool", 1: "u1", 2: "i1", 3: "u2", 4: "i2", 5: "u4", 6: "i4", 7: "u8", 8: "i8",
+              9: "f4", 10: "f8"}
+OPD_NONE, OPD_ACC, OPD_INPUT, OPD_SCALAR, OPD_TEMP = range(5)
+
+
+def _scalar(slot, cls):
+    return {0: slot.f32, 1: slot.f64, 2: slot.i32, 3: slot.i64}[cls]
+
+
+def run_program(prog, inputs, n):
+    """Interpret ``prog`` over flat ndarrays ``inputs`` (n elements each, or 1 if broadcast)."""
+    cls = prog.reg_class
+    rc = CLASS_DTYPE[cls]
+    regs_in, nd_in = [], []
+    for k in range(prog.n_inputs):
+        d = prog.inputs[k]
+        if k >= len(inputs) or inputs[k] is None:
+            regs_in.append(None)
+            nd_in.append(None)
+            continue
+        x = np.asarray(inputs[k]).reshape(-1)
+        assert x.dtype == np.dtype(CODE_DTYPE[d.dtype]), (x.dtype, d.dtype)
+        if d.broadcast:
+            x = np.broadcast_to(x[:1], (n,))
+        nd = np.zeros(n, dtype=bool)
+        if d.has_ndv:
+            if x.dtype.kind == "f":
+                nd = x == x.dtype.type(d.ndv.f64)
+            elif x.dtype == np.dtype("u8"):
+                nd = x == np.uint64(d.ndv.u64)
+            else:
+                nd = x.astype("i8") == np.int64(d.ndv.i64)
+        with np.errstate(all="ignore"):
+            regs_in.append(x.astype(rc))
+        nd_in.append(nd)
+    acc = np.zeros(n, dtype=rc)
+    temps = [None] * 4
+
+    def fetch(o):
+        if o.kind == OPD_INPUT:
+            return regs_in[o.index], nd_in[o.index]
+        if o.kind == OPD_SCALAR:
+            return np.full(n, _scalar(o.value, cls), dtype=rc), np.zeros(n, dtype=bool)
+        if o.kind in (OPD_ACC, OPD_TEMP):
+            v = acc if o.kind == OPD_ACC else temps[o.index]
+            nd = (v == rc.type(_scalar(o.value, cls))) if o.has_ndv else np.zeros(n, dtype=bool)
+            return v, nd
+        return np.zeros(n, dtype=rc), np.zeros(n, dtype=bool)
+
+    for s in range(prog.n_steps):
+        S = prog.steps[s]
+        a, nda = fetch(S.a)
+        b, ndb = fetch(S.b)
+        nd = nda | ndb
+        fill = rc.type(_scalar(S.fill, cls))
+        op = S.opcode
+        with np.errstate(all="ignore"):
+            if op == 1:
+                r = a + b
+            elif op == 2:
+                r = a - b
+            elif op == 3:
+                r = a * b
+            elif op == 4:
+                r = a / b
+            elif op == 5:
+                if rc.kind == "f":
+                    r = np.power(a.astype("f8"), b.astype("f8")).astype(rc)
+                else:
+                    r = np.power(a, b)
+            elif op == 6:
+                r = (a == b).astype(rc)
+            elif op == 7:
+                r = (a != b).astype(rc)
+            elif op == 8:
+                r = (a > b).astype(rc)
+            elif op == 9:
+                r = (a >= b).astype(rc)
+            elif op == 10:
+                r = (a < b).astype(rc)
+            elif op == 11:
+                r = (a <= b).astype(rc)
+            elif op == 12:
+                r = ((a != 0) & (b != 0)).astype(rc)
+            elif op == 13:
+                r = ((a != 0) | (b != 0)).astype(rc)
+            elif op == 14:
+                r = ((a != 0) ^ (b != 0)).astype(rc)
+            elif op in (15, 16, 17):
+                f = {15: np.exp, 16: np.log, 17: np.log10}[op]
+                r = f(a.astype("f8")).astype(rc)
+            elif op == 18:
+                r = (a == 0).astype(rc)
+                nd = np.zeros(n, dtype=bool)
+            elif op == 19:
+                r = (~nda).astype(rc)
+                nd = np.zeros(n, dtype=bool)
+            elif op == 20:
+                r = nda.astype(rc)
+                nd = np.zeros(n, dtype=bool)
+            elif op == 21:  # clip
+                drop = ndb.copy()
+                if S.b.is_bool:
+                    drop |= b == 0
+                r = a.copy()
+                nd = drop
+            elif op == 22:  # mask
+                value = rc.type(_scalar(S.aux0, cls))
+                if S.flags & 4:
+                    nodata = nda
+                else:
+                    y, tol = S.aux2.f64, S.aux1.f64
+                    y_finite = bool(S.flags & 2)
+                    if S.flags & 1:
+                        x64 = a.astype("f8")
+                        nodata = ((np.abs(x64 - y) <= tol) & y_finite) | (x64 == y)
+                    else:
+                        x32 = a.astype("f4")
+                        nodata = ((np.abs(x32 - np.float32(y)) <= np.float32(tol)) & y_finite) | (x32 == np.float32(y))
+                r = np.full(n, value, dtype=rc)
+                nd = nodata
+            else:  # copy
+                r = a.copy()
+            if cls == 1 and S.round_f32:
+                r = r.astype("f4").astype("f8")
+            if cls == 3 and S.wrap_i32:
+                r = r.astype("i4").astype("i8")
+            if rc.kind == "f" and S.check_finite:
+                nd = nd | ~np.isfinite(r)
+        acc = np.where(nd, fill, r).astype(rc)
+        if S.save_temp:
+            temps[S.save_temp - 1] = acc.copy()
+    out_dt = np.dtype(CODE_DTYPE[prog.out_dtype])
+    with np.errstate(all="ignore"):
+        if out_dt == np.dtype("u8") and rc == np.dtype("i8"):
+            return acc.view("u8")
+        return acc.astype(out_dt)
+
+
+def launch(compiled, inputs, shape, out=None):
+    """Drop-in for ``dask_geomodeling_amd.hip.program.launch`` on host arrays."""
+    n = int(np.prod(shape, dtype=np.int64))
+    flat = run_program(compiled.program, [np.asarray(x) for x in inputs], n)
+    return flat.reshape(shape)

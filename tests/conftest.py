@@ -36,3 +36,21 @@ def gpu():
     assert n > 0, "no HIP device visible: GPU tests must run on the MI355X box"
     runtime.set_device(0)
     return runtime
+
+
+@pytest.fixture
+def cpu_vm(monkeypatch):
+    """Run the product's host logic (Blocks, fusion, program compiler) on the CPU by
+    plugging the oracle's NumPy interpreter of gm_program in place of the HIP launch.
+    Test double only -- the product itself has no CPU path."""
+    import numpy as np
+
+    from dask_geomodeling_amd.hip import program, runtime
+    from oracle import vm_numpy
+
+    monkeypatch.setattr(runtime, "require_device", lambda: None)
+    monkeypatch.setattr(program, "as_device", lambda v: np.asarray(v))
+    monkeypatch.setattr(program, "launch", vm_numpy.launch)
+    program._CACHE.clear()
+    yield
+    program._CACHE.clear()
