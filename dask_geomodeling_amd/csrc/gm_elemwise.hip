@@ -6,7 +6,7 @@ using namespace gmvm;
 
 namespace {
 
-gm_vm_tuning g_tuning = {8, 8, 0, 0};
+gm_vm_tuning g_tuning = {8, 0, 0, 0};
 
 int validate_operand(const gm_operand& o, unsigned n_inputs, const char* which, unsigned step) {
   switch (o.kind) {
@@ -29,8 +29,8 @@ extern "C" {
 int gm_vm_set_tuning(const gm_vm_tuning* t) {
   if (!t) return gm::fail(GM_ERR_INVALID, "null tuning");
   gm_vm_tuning v = *t;
-  if (v.vec != 4 && v.vec != 8) v.vec = 8;
-  if (v.blocks_per_cu <= 0 || v.blocks_per_cu > 64) v.blocks_per_cu = 8;
+  if (v.vec != 4 && v.vec != 8 && v.vec != 16) v.vec = 8;
+  if (v.blocks_per_cu < 0 || v.blocks_per_cu > 4096) v.blocks_per_cu = 0;
   g_tuning = v;
   return GM_OK;
 }
@@ -77,34 +77,41 @@ int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out
   args.out = out;
   args.n = n;
   bool heavy = false;
+  unsigned max_in = prog->n_inputs, max_tmp = 0;
   for (unsigned s = 0; s < prog->n_steps; ++s) {
-    const unsigned op = prog->steps[s].opcode;
+    const gm_step& S = prog->steps[s];
+    const unsigned op = S.opcode;
     if (op == GM_OP_POW || op == GM_OP_EXP || op == GM_OP_LOG || op == GM_OP_LOG10) heavy = true;
+    if (S.save_temp > max_tmp) max_tmp = S.save_temp;
   }
-  const int U = (g_tuning.vec == 4 || heavy) ? 1 : 2;
+  const int size = (max_in <= 2 && max_tmp <= 1) ? 0 : ((max_in <= 4 && max_tmp <= 2) ? 1 : 2);
+  int G = g_tuning.vec >= 16 ? 4 : (g_tuning.vec >= 8 ? 2 : 1);
+  if (heavy || size == 2) G = 1;
+  else if (size == 1 && G > 2) G = 2;
   args.n_groups = aligned ? n / 4 : 0;
   args.tail_start = args.n_groups * 4;
-  const unsigned long long per_iter = 256ull * U;
+  const unsigned long long per_iter = 256ull * G;
   args.n_iters = (args.n_groups + per_iter - 1) / per_iter;
   args.xcd_chunking = g_tuning.xcd_chunking;
   args.nontemporal = g_tuning.nontemporal;
 
   const int cus = gm::current_cu_count();
-  unsigned long long want = args.n_iters;
-  if (want == 0) want = (n - args.tail_start + 255) / 256;
-  unsigned long long cap = (unsigned long long)cus * g_tuning.blocks_per_cu;
-  if (cap == 0) cap = 2048;
-  unsigned long long blocks = want < cap ? want : cap;
-  if (blocks == 0) blocks = 1;
+  unsigned long long cap = (unsigned long long)(cus > 0 ? cus : 256) * (unsigned long long)g_tuning.blocks_per_cu;
+  unsigned long long blocks = args.n_iters;
+  if (cap && blocks > cap) blocks = cap;
+  if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
   if (args.xcd_chunking && blocks >= 8) blocks -= blocks % 8;
-  dim3 grid((unsigned)blocks);
+  const unsigned long long tail = n - args.tail_start;
+  unsigned long long tail_blocks = (tail + 255) / 256;
+  const unsigned long long tail_cap = (unsigned long long)(cus > 0 ? cus : 256) * 8;
+  if (tail_blocks > tail_cap) tail_blocks = tail_cap;
+  dim3 grid((unsigned)blocks), tail_grid((unsigned)tail_blocks);
 
-  const int n_in = (int)prog->n_inputs;
   switch (prog->reg_class) {
-    case GM_CLASS_F32: return launch_class<float>(args, n_in, U, heavy, grid, stream);
-    case GM_CLASS_F64: return launch_class<double>(args, n_in, U, heavy, grid, stream);
-    case GM_CLASS_I32: return launch_class<int>(args, n_in, U, heavy, grid, stream);
-    default: return launch_class<long long>(args, n_in, U, heavy, grid, stream);
+    case GM_CLASS_F32: return launch_class<float>(args, size, G, heavy, grid, tail_grid, stream);
+    case GM_CLASS_F64: return launch_class<double>(args, size, G, heavy, grid, tail_grid, stream);
+    case GM_CLASS_I32: return launch_class<int>(args, size, G, heavy, grid, tail_grid, stream);
+    default: return launch_class<long long>(args, size, G, heavy, grid, tail_grid, stream);
   }
 }
 

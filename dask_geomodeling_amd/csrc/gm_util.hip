@@ -93,7 +93,9 @@ unsigned grid_for(size_t n, int cus) {
 
 extern "C" {
 
-int gm_fill(void* out, int dtype, gm_scalar value, size_t n) {
+int gm_fill(void* out, int dtype, uint64_t value_bits, size_t n) {
+  gm_scalar value;
+  value.u64 = value_bits;
   if (!out) return gm::fail(GM_ERR_INVALID, "null pointer");
   if (n == 0) return GM_OK;
   hipStream_t s = gm::current_stream();
@@ -126,7 +128,9 @@ int gm_fill(void* out, int dtype, gm_scalar value, size_t n) {
 }
 
 int gm_generate(void* out, int dtype, uint64_t seed, uint64_t offset, double lo, double hi, size_t n,
-                uint32_t width, uint32_t lattice_y, uint32_t lattice_x, gm_scalar ndv) {
+                uint32_t width, uint32_t lattice_y, uint32_t lattice_x, uint64_t ndv_bits) {
+  gm_scalar ndv;
+  ndv.u64 = ndv_bits;
   if (!out) return gm::fail(GM_ERR_INVALID, "null pointer");
   if (n == 0) return GM_OK;
   if (lattice_x != 0 && lattice_y == 0) lattice_y = 1;
@@ -153,7 +157,9 @@ int gm_generate(void* out, int dtype, uint64_t seed, uint64_t offset, double lo,
   return GM_OK;
 }
 
-int gm_all_equal(const void* in, int dtype, gm_scalar value, size_t n, int* result) {
+int gm_all_equal(const void* in, int dtype, uint64_t value_bits, size_t n, int* result) {
+  gm_scalar value;
+  value.u64 = value_bits;
   if (!result) return gm::fail(GM_ERR_INVALID, "null pointer");
   *result = 1;
   if (n == 0) return GM_OK;

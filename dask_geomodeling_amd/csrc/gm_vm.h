@@ -4,19 +4,20 @@
 // over one tile.  HBM traffic = one read of every distinct leaf tile + one write of
 // the result; everything in between lives in VGPRs.
 //
-// Execution shape (wave64, 256-thread workgroups, grid-stride):
-//   * a lane owns U sub-vectors of 4 consecutive elements per block-iteration; for
-//     every load instruction lane l reads 16 B (4-byte types) at base + l*16, i.e.
-//     each wave-instruction covers one contiguous 1 KiB span (coalescing rule of
-//     cdna_hip_programming.md section 2);
-//   * all leaf tiles of the program are loaded first (NIN*U independent loads in
-//     flight per lane), converted to the register class and tagged with their
-//     native-dtype no-data bits; then the program is interpreted from SGPR-resident
-//     step descriptors (kernarg -> s_load), every dispatch branch is wave-uniform
-//     (scalar branches, no divergence, no dynamic VGPR indexing);
+// Execution shape (wave64, 256-thread workgroups):
+//   * a lane owns G sub-vectors of 4 consecutive elements (N = 4*G elements) per
+//     block-iteration; for every load instruction lane l reads 16 B (4-byte types) at
+//     base + l*16, i.e. each wave-instruction covers one contiguous 1 KiB span (the
+//     coalescing rule of cdna_hip_programming.md section 2);
+//   * all leaf tiles of the program are loaded first (NIN*G independent 16-byte loads
+//     in flight per lane) and converted to the register class; then the program is
+//     interpreted from SGPR-resident step descriptors (kernarg -> s_load).  Every
+//     dispatch branch is wave-uniform (scalar branches, no divergence, no dynamic VGPR
+//     indexing) and its cost is amortised over the N*64 elements a wave owns;
 //   * every step re-applies the reference rule of raster/elemwise.py:263-296:
 //     no-data = OR(operand == its ndv), compute in the step dtype, non-finite -> fill,
-//     no-data -> fill.
+//     no-data -> fill.  The no-data test is a v_cmp into a lane mask that lives only
+//     until the v_cndmask that consumes it.
 //
 // No MFMA: the path is element-wise and HBM-bound (12 B/px for the canonical chain).
 #pragma once
@@ -39,10 +40,10 @@ struct VmArgs {
   gm_program prog;
   const void* in[GM_MAX_INPUTS];
   void* out;
-  unsigned long long n;         // total elements
-  unsigned long long n_groups;  // 4-element groups handled by the vector path
-  unsigned long long n_iters;   // block-iterations of the vector path
-  unsigned long long tail_start;  // first element of the scalar tail path
+  unsigned long long n;           // total elements
+  unsigned long long n_groups;    // 4-element groups handled by the vector kernel
+  unsigned long long n_iters;     // block-iterations of the vector kernel
+  unsigned long long tail_start;  // first element of the scalar tail kernel
   unsigned int xcd_chunking;
   unsigned int nontemporal;  // bit0 loads, bit1 stores
 };
@@ -71,61 +72,57 @@ template <> __device__ __forceinline__ int scalar_of<int>(const gm_scalar& s) { 
 template <> __device__ __forceinline__ long long scalar_of<long long>(const gm_scalar& s) { return (long long)s.i64; }
 
 // ---- typed loads of N (1 or 4) consecutive elements starting at element e ----
-// returns the native-dtype no-data bits (bit k: element k == ndv)
+// `native` (64-bit integer tiles in the F64 class only): cells equal to nv -- compared as
+// integers -- are replaced by the sentinel 0.5 (gmhip.h: gm_input_desc.native_ndv)
 template <typename RC, int N>
-__device__ __forceinline__ unsigned load_elems(const void* base, int dtype, unsigned long long e, bool nt,
-                                               bool has_ndv, const gm_scalar& ndv, RC (&v)[N]) {
-  unsigned nd = 0;
-#define GM_LOAD_CASE(DT, T, VT4, NATIVE_T, NDVEXPR)                                  \
+__device__ __forceinline__ void load_elems(const void* base, int dtype, unsigned long long e, bool nt, RC (&v)[N],
+                                           bool native = false, long long nv = 0) {
+#define GM_LOAD_CASE(DT, T, VT4)                                                     \
   case DT: {                                                                         \
-    NATIVE_T nv = (NATIVE_T)(NDVEXPR);                                               \
     if constexpr (N == 4) {                                                          \
       VT4 x = ld((const VT4*)((const T*)base + e), nt);                              \
-      _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                \
-        T t = x[k];                                                                  \
-        v[k] = (RC)t;                                                                \
-        if (has_ndv && (NATIVE_T)t == nv) nd |= 1u << k;                             \
-      }                                                                              \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) v[k] = (RC)(T)x[k];              \
     } else {                                                                         \
-      T t = ld((const T*)base + e, nt);                                              \
-      v[0] = (RC)t;                                                                  \
-      if (has_ndv && (NATIVE_T)t == nv) nd |= 1u;                                    \
+      v[0] = (RC)ld((const T*)base + e, nt);                                         \
     }                                                                                \
   } break;
-#define GM_LOAD_CASE8(DT, T, VT2, NATIVE_T, NDVEXPR)                                 \
+#define GM_LOAD_CASE8(DT, T, VT2)                                                    \
   case DT: {                                                                         \
-    NATIVE_T nv = (NATIVE_T)(NDVEXPR);                                               \
     if constexpr (N == 4) {                                                          \
       VT2 x0 = ld((const VT2*)((const T*)base + e), nt);                             \
       VT2 x1 = ld((const VT2*)((const T*)base + e + 2), nt);                         \
-      T t[4] = {(T)x0[0], (T)x0[1], (T)x1[0], (T)x1[1]};                             \
-      _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                \
-        v[k] = (RC)t[k];                                                             \
-        if (has_ndv && (NATIVE_T)t[k] == nv) nd |= 1u << k;                          \
+      const T t[4] = {(T)x0[0], (T)x0[1], (T)x1[0], (T)x1[1]};                       \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) v[k] = (RC)t[k];                 \
+      if constexpr (std::is_same<RC, double>::value && std::is_integral<T>::value) { \
+        if (native) {                                                                \
+          _Pragma("unroll") for (int k = 0; k < 4; ++k)                              \
+            if ((long long)t[k] == nv) v[k] = (RC)0.5;                               \
+        }                                                                            \
       }                                                                              \
     } else {                                                                         \
-      T t = ld((const T*)base + e, nt);                                              \
+      const T t = ld((const T*)base + e, nt);                                        \
       v[0] = (RC)t;                                                                  \
-      if (has_ndv && (NATIVE_T)t == nv) nd |= 1u;                                    \
+      if constexpr (std::is_same<RC, double>::value && std::is_integral<T>::value) { \
+        if (native && (long long)t == nv) v[0] = (RC)0.5;                            \
+      }                                                                              \
     }                                                                                \
   } break;
   switch (dtype) {
-    GM_LOAD_CASE(GM_F32, float, f32x4, float, ndv.f64)
-    GM_LOAD_CASE8(GM_F64, double, f64x2, double, ndv.f64)
-    GM_LOAD_CASE(GM_I32, int, i32x4, long long, ndv.i64)
-    GM_LOAD_CASE(GM_U32, unsigned int, u32x4, long long, ndv.i64)
-    GM_LOAD_CASE8(GM_I64, long long, i64x2, long long, ndv.i64)
-    GM_LOAD_CASE8(GM_U64, unsigned long long, i64x2, unsigned long long, ndv.u64)
-    GM_LOAD_CASE(GM_U16, unsigned short, u16x4, long long, ndv.i64)
-    GM_LOAD_CASE(GM_I16, short, u16x4, long long, ndv.i64)
-    GM_LOAD_CASE(GM_U8, unsigned char, u8x4, long long, ndv.i64)
-    GM_LOAD_CASE(GM_I8, signed char, u8x4, long long, ndv.i64)
-    GM_LOAD_CASE(GM_BOOL, unsigned char, u8x4, long long, ndv.i64)
+    GM_LOAD_CASE(GM_F32, float, f32x4)
+    GM_LOAD_CASE8(GM_F64, double, f64x2)
+    GM_LOAD_CASE(GM_I32, int, i32x4)
+    GM_LOAD_CASE(GM_U32, unsigned int, u32x4)
+    GM_LOAD_CASE8(GM_I64, long long, i64x2)
+    GM_LOAD_CASE8(GM_U64, unsigned long long, i64x2)
+    GM_LOAD_CASE(GM_U16, unsigned short, u16x4)
+    GM_LOAD_CASE(GM_I16, short, u16x4)
+    GM_LOAD_CASE(GM_U8, unsigned char, u8x4)
+    GM_LOAD_CASE(GM_I8, signed char, u8x4)
+    GM_LOAD_CASE(GM_BOOL, unsigned char, u8x4)
     default: break;
   }
 #undef GM_LOAD_CASE
 #undef GM_LOAD_CASE8
-  return nd;
 }
 
 template <typename RC, int N>
@@ -170,23 +167,22 @@ __device__ __forceinline__ void store_elems(void* base, int dtype, unsigned long
 }
 
 // ---- arithmetic in the register class ------------------------------------------
-template <typename RC> __device__ __forceinline__ RC op_add(RC a, RC b) { return a + b; }
-template <typename RC> __device__ __forceinline__ RC op_sub(RC a, RC b) { return a - b; }
-template <typename RC> __device__ __forceinline__ RC op_mul(RC a, RC b) { return a * b; }
 // integers wrap silently like NumPy under errstate(all="ignore")
-template <> __device__ __forceinline__ int op_add<int>(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
-template <> __device__ __forceinline__ int op_sub<int>(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
-template <> __device__ __forceinline__ int op_mul<int>(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
-template <> __device__ __forceinline__ long long op_add<long long>(long long a, long long b) {
-  return (long long)((unsigned long long)a + (unsigned long long)b);
+template <typename RC> __device__ __forceinline__ RC op_add(RC a, RC b) {
+  if constexpr (std::is_same<RC, int>::value) return (int)((unsigned)a + (unsigned)b);
+  else if constexpr (std::is_same<RC, long long>::value) return (long long)((unsigned long long)a + (unsigned long long)b);
+  else return a + b;
 }
-template <> __device__ __forceinline__ long long op_sub<long long>(long long a, long long b) {
-  return (long long)((unsigned long long)a - (unsigned long long)b);
+template <typename RC> __device__ __forceinline__ RC op_sub(RC a, RC b) {
+  if constexpr (std::is_same<RC, int>::value) return (int)((unsigned)a - (unsigned)b);
+  else if constexpr (std::is_same<RC, long long>::value) return (long long)((unsigned long long)a - (unsigned long long)b);
+  else return a - b;
 }
-template <> __device__ __forceinline__ long long op_mul<long long>(long long a, long long b) {
-  return (long long)((unsigned long long)a * (unsigned long long)b);
+template <typename RC> __device__ __forceinline__ RC op_mul(RC a, RC b) {
+  if constexpr (std::is_same<RC, int>::value) return (int)((unsigned)a * (unsigned)b);
+  else if constexpr (std::is_same<RC, long long>::value) return (long long)((unsigned long long)a * (unsigned long long)b);
+  else return a * b;
 }
-
 template <typename RC> __device__ __forceinline__ RC op_div(RC a, RC b) {
   if constexpr (is_float_class<RC>::value) return a / b;
   else return 0;  // Divide is always a float step (elemwise.py:377-380)
@@ -210,16 +206,6 @@ template <typename RC> __device__ __forceinline__ RC op_pow(RC a, RC b) {
   }
 }
 
-template <typename RC> __device__ __forceinline__ RC op_unary(int opcode, RC a) {
-  if constexpr (is_float_class<RC>::value) {
-    double x = (double)a;
-    double r = opcode == GM_OP_EXP ? exp(x) : (opcode == GM_OP_LOG ? log(x) : log10(x));
-    return (RC)r;
-  } else {
-    return a;
-  }
-}
-
 template <typename RC> __device__ __forceinline__ bool finite_rc(RC v) {
   if constexpr (is_float_class<RC>::value) return isfinite(v);
   else return true;
@@ -239,16 +225,16 @@ __device__ __forceinline__ bool is_close(RC x, double y, double tol, bool in_f64
 }
 
 // ---- the interpreter -------------------------------------------------------------
-template <typename RC, int N, int NIN, bool HEAVY>
+// N elements per lane, NIN input slots, NT temps.  HEAVY instantiations carry
+// pow/exp/log (their register appetite would otherwise cap every program's occupancy).
+template <typename RC, int N, int NIN, int NT, bool HEAVY>
 struct Machine {
   RC in[NIN][N];
-  unsigned in_nd[NIN];
-  RC tmp[GM_MAX_TEMPS][N];
+  RC tmp[NT][N];
   RC acc[N];
 
-  // operand fetch: value + no-data bits; every branch below is wave-uniform
-  __device__ __forceinline__ unsigned fetch(const gm_operand& o, RC (&v)[N]) const {
-    unsigned nd = 0;
+  // operand fetch; every branch below is wave-uniform
+  __device__ __forceinline__ void fetch(const gm_operand& o, RC (&v)[N]) const {
     switch (o.kind) {
       case GM_OPD_INPUT: {
         switch (o.index) {
@@ -256,7 +242,6 @@ struct Machine {
   case K:                                                                \
     if constexpr (K < NIN) {                                             \
       _Pragma("unroll") for (int k = 0; k < N; ++k) v[k] = in[K][k];     \
-      nd = in_nd[K];                                                     \
     }                                                                    \
     break;
           GM_IN_CASE(0) GM_IN_CASE(1) GM_IN_CASE(2) GM_IN_CASE(3)
@@ -266,7 +251,7 @@ struct Machine {
         }
       } break;
       case GM_OPD_SCALAR: {
-        RC s = scalar_of<RC>(o.value);
+        const RC s = scalar_of<RC>(o.value);
 #pragma unroll
         for (int k = 0; k < N; ++k) v[k] = s;
       } break;
@@ -274,194 +259,142 @@ struct Machine {
         switch (o.index) {
 #define GM_TMP_CASE(K)                                                   \
   case K:                                                                \
-    _Pragma("unroll") for (int k = 0; k < N; ++k) v[k] = tmp[K][k];      \
+    if constexpr (K < NT) {                                              \
+      _Pragma("unroll") for (int k = 0; k < N; ++k) v[k] = tmp[K][k];    \
+    }                                                                    \
     break;
           GM_TMP_CASE(0) GM_TMP_CASE(1) GM_TMP_CASE(2) GM_TMP_CASE(3)
 #undef GM_TMP_CASE
           default: break;
         }
-        if (o.has_ndv) {
-          RC ndv = scalar_of<RC>(o.value);
-#pragma unroll
-          for (int k = 0; k < N; ++k)
-            if (v[k] == ndv) nd |= 1u << k;
-        }
       } break;
       case GM_OPD_ACC: {
 #pragma unroll
         for (int k = 0; k < N; ++k) v[k] = acc[k];
-        if (o.has_ndv) {
-          RC ndv = scalar_of<RC>(o.value);
-#pragma unroll
-          for (int k = 0; k < N; ++k)
-            if (v[k] == ndv) nd |= 1u << k;
-        }
       } break;
       default: {
 #pragma unroll
         for (int k = 0; k < N; ++k) v[k] = (RC)0;
       } break;
     }
-    return nd;
   }
 
-  __device__ __forceinline__ void run(const gm_program& P) {
-    const unsigned n_steps = P.n_steps;
-    for (unsigned s = 0; s < n_steps; ++s) {
-      const gm_step& S = P.steps[s];
-      RC a[N], b[N], r[N];
-      unsigned nda = fetch(S.a, a);
-      unsigned ndb = fetch(S.b, b);
-      unsigned nd = nda | ndb;
-      const RC fill = scalar_of<RC>(S.fill);
-      const int opcode = S.opcode;
-      switch (opcode) {
-        case GM_OP_ADD:
+  // acc[k] = bad ? fill : f(a[k], b[k])   with bad = a is no-data | b is no-data | !finite
+  template <typename F>
+  __device__ __forceinline__ void apply(const gm_step& S, const RC (&a)[N], const RC (&b)[N], F f) {
+    // scalar operands never carry no-data (has_ndv = 0 from the host)
+    const bool a_has = S.a.has_ndv != 0, b_has = S.b.has_ndv != 0, chk = S.check_finite != 0;
+    const RC a_ndv = scalar_of<RC>(S.a.value), b_ndv = scalar_of<RC>(S.b.value);
+    const RC fill = scalar_of<RC>(S.fill);
 #pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = op_add<RC>(a[k], b[k]);
-          break;
-        case GM_OP_SUB:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = op_sub<RC>(a[k], b[k]);
-          break;
-        case GM_OP_MUL:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = op_mul<RC>(a[k], b[k]);
-          break;
-        case GM_OP_DIV:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = op_div<RC>(a[k], b[k]);
-          break;
-        case GM_OP_POW:
-          if constexpr (HEAVY) {
-#pragma unroll
-            for (int k = 0; k < N; ++k) r[k] = op_pow<RC>(a[k], b[k]);
-          }
-          break;
-        case GM_OP_EQ:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (RC)(a[k] == b[k]);
-          break;
-        case GM_OP_NE:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (RC)(a[k] != b[k]);
-          break;
-        case GM_OP_GT:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (RC)(a[k] > b[k]);
-          break;
-        case GM_OP_GE:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (RC)(a[k] >= b[k]);
-          break;
-        case GM_OP_LT:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (RC)(a[k] < b[k]);
-          break;
-        case GM_OP_LE:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (RC)(a[k] <= b[k]);
-          break;
-        case GM_OP_AND:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (RC)((a[k] != (RC)0) && (b[k] != (RC)0));
-          break;
-        case GM_OP_OR:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (RC)((a[k] != (RC)0) || (b[k] != (RC)0));
-          break;
-        case GM_OP_XOR:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (RC)((a[k] != (RC)0) != (b[k] != (RC)0));
-          break;
-        case GM_OP_EXP:
-        case GM_OP_LOG:
-        case GM_OP_LOG10:
-          if constexpr (HEAVY) {
-#pragma unroll
-            for (int k = 0; k < N; ++k) r[k] = op_unary<RC>(opcode, a[k]);
-          }
-          break;
-        case GM_OP_INVERT:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (RC)(a[k] == (RC)0);
-          nd = 0;
-          break;
-        case GM_OP_ISDATA:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (RC)(((nda >> k) & 1u) == 0u);
-          nd = 0;
-          break;
-        case GM_OP_ISNODATA:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (RC)((nda >> k) & 1u);
-          nd = 0;
-          break;
-        case GM_OP_CLIP: {
-          // misc.py:115-123: drop where the mask source is False (bool) / no-data
-          unsigned drop = ndb;
-          if (S.b.is_bool) {
-#pragma unroll
-            for (int k = 0; k < N; ++k)
-              if (b[k] == (RC)0) drop |= 1u << k;
-          }
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = a[k];
-          nd = drop;  // fill == the store's own no-data value
-        } break;
-        case GM_OP_MASK: {
-          // misc.py:213-221: value where get_index() says data, else fill
-          const RC value = scalar_of<RC>(S.aux0);
-          unsigned nodata_bits;
-          if (S.flags & 4u) {
-            nodata_bits = nda;  // integer tiles: exact !=
-          } else {
-            nodata_bits = 0;
-            const double y = S.aux2.f64;
-            const double tol = S.aux1.f64;
-            const bool in_f64 = (S.flags & 1u) != 0, y_finite = (S.flags & 2u) != 0;
-#pragma unroll
-            for (int k = 0; k < N; ++k)
-              if (is_close<RC>(a[k], y, tol, in_f64, y_finite)) nodata_bits |= 1u << k;
-          }
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = value;
-          nd = nodata_bits;
-        } break;
-        case GM_OP_COPY:
-        default:
-#pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = a[k];
-          break;
+    for (int k = 0; k < N; ++k) {
+      bool bad = (a_has && a[k] == a_ndv) || (b_has && b[k] == b_ndv);
+      RC r = f(a[k], b[k]);
+      if constexpr (is_float_class<RC>::value) bad = bad || (chk && !finite_rc<RC>(r));
+      acc[k] = bad ? fill : r;
+    }
+  }
+
+  // the same with the step-dtype narrowing of the wide classes applied to f's result
+  template <typename F>
+  __device__ __forceinline__ void math(const gm_step& S, const RC (&a)[N], const RC (&b)[N], F f) {
+    if constexpr (std::is_same<RC, double>::value) {
+      if (S.round_f32) {  // float32 step inside the F64 class: round after the op
+        apply(S, a, b, [f](RC x, RC y) { return (RC)(float)f(x, y); });
+        return;
       }
-      // step dtype narrower than the register class
-      if constexpr (std::is_same<RC, double>::value) {
-        if (S.round_f32) {
+    }
+    if constexpr (std::is_same<RC, long long>::value) {
+      if (S.wrap_i32) {  // int32 step inside the I64 class: wrap to 32 bits
+        apply(S, a, b, [f](RC x, RC y) { return (RC)(int)f(x, y); });
+        return;
+      }
+    }
+    apply(S, a, b, f);
+  }
+
+  __device__ __forceinline__ void step(const gm_step& S) {
+    RC a[N], b[N];
+    fetch(S.a, a);
+    fetch(S.b, b);
+    const int opcode = S.opcode;
+    switch (opcode) {
+      case GM_OP_ADD: math(S, a, b, [](RC x, RC y) { return op_add<RC>(x, y); }); break;
+      case GM_OP_SUB: math(S, a, b, [](RC x, RC y) { return op_sub<RC>(x, y); }); break;
+      case GM_OP_MUL: math(S, a, b, [](RC x, RC y) { return op_mul<RC>(x, y); }); break;
+      case GM_OP_DIV: math(S, a, b, [](RC x, RC y) { return op_div<RC>(x, y); }); break;
+      case GM_OP_POW:
+        if constexpr (HEAVY) math(S, a, b, [](RC x, RC y) { return op_pow<RC>(x, y); });
+        break;
+      case GM_OP_EXP:
+        if constexpr (HEAVY && is_float_class<RC>::value) math(S, a, b, [](RC x, RC) { return (RC)exp((double)x); });
+        break;
+      case GM_OP_LOG:
+        if constexpr (HEAVY && is_float_class<RC>::value) math(S, a, b, [](RC x, RC) { return (RC)log((double)x); });
+        break;
+      case GM_OP_LOG10:
+        if constexpr (HEAVY && is_float_class<RC>::value) math(S, a, b, [](RC x, RC) { return (RC)log10((double)x); });
+        break;
+      case GM_OP_EQ: apply(S, a, b, [](RC x, RC y) { return (RC)(x == y); }); break;
+      case GM_OP_NE: apply(S, a, b, [](RC x, RC y) { return (RC)(x != y); }); break;
+      case GM_OP_GT: apply(S, a, b, [](RC x, RC y) { return (RC)(x > y); }); break;
+      case GM_OP_GE: apply(S, a, b, [](RC x, RC y) { return (RC)(x >= y); }); break;
+      case GM_OP_LT: apply(S, a, b, [](RC x, RC y) { return (RC)(x < y); }); break;
+      case GM_OP_LE: apply(S, a, b, [](RC x, RC y) { return (RC)(x <= y); }); break;
+      case GM_OP_AND: apply(S, a, b, [](RC x, RC y) { return (RC)((x != (RC)0) && (y != (RC)0)); }); break;
+      case GM_OP_OR: apply(S, a, b, [](RC x, RC y) { return (RC)((x != (RC)0) || (y != (RC)0)); }); break;
+      case GM_OP_XOR: apply(S, a, b, [](RC x, RC y) { return (RC)((x != (RC)0) != (y != (RC)0)); }); break;
+      case GM_OP_INVERT:
 #pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (double)(float)r[k];
+        for (int k = 0; k < N; ++k) acc[k] = (RC)(a[k] == (RC)0);
+        break;
+      case GM_OP_ISDATA:
+      case GM_OP_ISNODATA: {
+        const bool a_has = S.a.has_ndv != 0, want = opcode == GM_OP_ISNODATA;
+        const RC a_ndv = scalar_of<RC>(S.a.value);
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = (RC)(((a_has && a[k] == a_ndv)) == want);
+      } break;
+      case GM_OP_CLIP: {
+        // misc.py:115-123: drop where the mask source is no-data / False (bool source);
+        // fill == the store's own no-data value
+        const bool b_has = S.b.has_ndv != 0, b_bool = S.b.is_bool != 0;
+        const RC b_ndv = scalar_of<RC>(S.b.value), fill = scalar_of<RC>(S.fill);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const bool drop = (b_has && b[k] == b_ndv) || (b_bool && b[k] == (RC)0);
+          acc[k] = drop ? fill : a[k];
         }
-      }
-      if constexpr (std::is_same<RC, long long>::value) {
-        if (S.wrap_i32) {
+      } break;
+      case GM_OP_MASK: {
+        // misc.py:213-221: value where get_index() says data, else fill
+        const RC value = scalar_of<RC>(S.aux0), fill = scalar_of<RC>(S.fill);
+        if (S.flags & 4u) {  // integer tiles: exact !=
+          const bool a_has = S.a.has_ndv != 0;
+          const RC a_ndv = scalar_of<RC>(S.a.value);
 #pragma unroll
-          for (int k = 0; k < N; ++k) r[k] = (long long)(int)r[k];
+          for (int k = 0; k < N; ++k) acc[k] = (a_has && a[k] == a_ndv) ? fill : value;
+        } else {
+          const double y = S.aux2.f64, tol = S.aux1.f64;
+          const bool in_f64 = (S.flags & 1u) != 0, y_finite = (S.flags & 2u) != 0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) acc[k] = is_close<RC>(a[k], y, tol, in_f64, y_finite) ? fill : value;
         }
-      }
-      // elemwise.py:292-296: non-finite -> fill, then input no-data -> fill
-      if constexpr (is_float_class<RC>::value) {
-        if (S.check_finite) {
+      } break;
+      case GM_OP_COPY:
+      default:
 #pragma unroll
-          for (int k = 0; k < N; ++k)
-            if (!finite_rc<RC>(r[k])) nd |= 1u << k;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < N; ++k) acc[k] = ((nd >> k) & 1u) ? fill : r[k];
+        for (int k = 0; k < N; ++k) acc[k] = a[k];
+        break;
+    }
+    if constexpr (NT > 0) {
       if (S.save_temp) {
         switch (S.save_temp - 1) {
-#define GM_SAVE_CASE(K)                                                  \
-  case K:                                                                \
-    _Pragma("unroll") for (int k = 0; k < N; ++k) tmp[K][k] = acc[k];    \
+#define GM_SAVE_CASE(K)                                                    \
+  case K:                                                                  \
+    if constexpr (K < NT) {                                                \
+      _Pragma("unroll") for (int k = 0; k < N; ++k) tmp[K][k] = acc[k];    \
+    }                                                                      \
     break;
           GM_SAVE_CASE(0) GM_SAVE_CASE(1) GM_SAVE_CASE(2) GM_SAVE_CASE(3)
 #undef GM_SAVE_CASE
@@ -469,6 +402,11 @@ struct Machine {
         }
       }
     }
+  }
+
+  __device__ __forceinline__ void run(const gm_program& P) {
+    const unsigned n_steps = P.n_steps;
+    for (unsigned s = 0; s < n_steps; ++s) step(P.steps[s]);
   }
 };
 
@@ -493,52 +431,47 @@ __device__ __forceinline__ unsigned long long first_iter(unsigned long long n_it
   return blockIdx.x;
 }
 
-// The kernel.  HEAVY instantiations carry pow/exp/log (their register appetite would
-// otherwise cap the occupancy of every program); light programs use HEAVY = false.
-template <typename RC, int NIN, int U, bool HEAVY>
+// vector kernel: every lane owns G groups of 4 consecutive elements per block-iteration
+template <typename RC, int G, int NIN, int NT, bool HEAVY>
 __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
   const gm_program& P = A.prog;
   const bool nt_ld = (A.nontemporal & 1u) != 0, nt_st = (A.nontemporal & 2u) != 0;
   const unsigned n_in = P.n_inputs;
   const int out_dtype = P.out_dtype;
-  constexpr int N = 4 * U;
+  constexpr int N = 4 * G;
 
   unsigned long long stride, end;
   unsigned long long it = first_iter(A.n_iters, A.xcd_chunking, &stride, &end);
   for (; it < end; it += stride) {
-    Machine<RC, N, NIN, HEAVY> M;
-    const unsigned long long g0 = it * (256ull * U) + threadIdx.x;  // sub-vector u is group g0 + 256*u
-    // phase 1: all leaf loads in flight (NIN*U independent 16-byte loads per lane)
+    Machine<RC, N, NIN, NT, HEAVY> M;
+    const unsigned long long g0 = it * (256ull * G) + threadIdx.x;  // sub-vector u is group g0 + 256*u
+    // phase 1: all leaf loads in flight (NIN*G independent 16-byte loads per lane)
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       if (k < (int)n_in) {
         const gm_input_desc& D = P.inputs[k];
         if (D.broadcast) {
           RC one[1];
-          unsigned nd1 = load_elems<RC, 1>(A.in[k], D.dtype, 0, false, D.has_ndv, D.ndv, one);
+          load_elems<RC, 1>(A.in[k], D.dtype, 0, false, one, D.native_ndv != 0, (long long)D.ndv.i64);
 #pragma unroll
           for (int q = 0; q < N; ++q) M.in[k][q] = one[0];
-          M.in_nd[k] = nd1 ? ((1u << N) - 1u) : 0u;
         } else {
-          unsigned nd = 0;
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
+          for (int u = 0; u < G; ++u) {
             RC v4[4] = {(RC)0, (RC)0, (RC)0, (RC)0};
-            unsigned nd4 = 0;
             const unsigned long long g = g0 + 256ull * u;
-            if (g < A.n_groups) nd4 = load_elems<RC, 4>(A.in[k], D.dtype, g * 4ull, nt_ld, D.has_ndv, D.ndv, v4);
+            if (g < A.n_groups)
+              load_elems<RC, 4>(A.in[k], D.dtype, g * 4ull, nt_ld, v4, D.native_ndv != 0, (long long)D.ndv.i64);
 #pragma unroll
             for (int q = 0; q < 4; ++q) M.in[k][4 * u + q] = v4[q];
-            nd |= nd4 << (4 * u);
           }
-          M.in_nd[k] = nd;
         }
       }
     }
     // phase 2: interpret; phase 3: store
     M.run(P);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < G; ++u) {
       const unsigned long long g = g0 + 256ull * u;
       if (g < A.n_groups) {
         RC v4[4];
@@ -548,42 +481,60 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
       }
     }
   }
+}
 
-  // scalar tail: elements the 16-byte vector path cannot take (n % 4, misaligned views)
+// scalar tail kernel: the elements the 16-byte vector path cannot take (n % 4, or
+// everything when a pointer is not 16-byte aligned); one element per lane, grid-stride
+template <typename RC, int NIN, int NT, bool HEAVY>
+__global__ __launch_bounds__(256) void vm_tail_kernel(const VmArgs A) {
+  const gm_program& P = A.prog;
+  const unsigned n_in = P.n_inputs;
   const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long e = A.tail_start + tid; e < A.n; e += nthreads) {
-    Machine<RC, 1, NIN, HEAVY> M1;
+    Machine<RC, 1, NIN, NT, HEAVY> M1;
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       if (k < (int)n_in) {
         const gm_input_desc& D = P.inputs[k];
-        M1.in_nd[k] = load_elems<RC, 1>(A.in[k], D.dtype, D.broadcast ? 0ull : e, false, D.has_ndv, D.ndv, M1.in[k]);
+        load_elems<RC, 1>(A.in[k], D.dtype, D.broadcast ? 0ull : e, false, M1.in[k], D.native_ndv != 0,
+                          (long long)D.ndv.i64);
       }
     }
     M1.run(P);
-    store_elems<RC, 1>(A.out, out_dtype, e, false, M1.acc);
+    store_elems<RC, 1>(A.out, P.out_dtype, e, false, M1.acc);
   }
 }
 
-// host-side launcher of one register class (defined once per class in gm_vm_<class>.hip)
+// host-side launcher of one register class (defined once per class in gm_vm_<class>.hip).
+// size: 0 = S (<= 2 inputs, <= 1 temp), 1 = M (<= 4 inputs, <= 2 temps), 2 = L (8 inputs, 4 temps)
 template <typename RC>
-int launch_class(const VmArgs& args, int n_inputs, int U, bool heavy, dim3 grid, hipStream_t stream);
+int launch_class(const VmArgs& args, int size, int G, bool heavy, dim3 grid, dim3 tail_grid, hipStream_t stream);
+
+#define GM_VM_LAUNCH(RC, G_, NIN_, NT_, HEAVY_)                                                          \
+  do {                                                                                                   \
+    if (grid.x) hipLaunchKernelGGL((vm_kernel<RC, G_, NIN_, NT_, HEAVY_>), grid, dim3(256), 0, stream, args); \
+    if (tail_grid.x)                                                                                     \
+      hipLaunchKernelGGL((vm_tail_kernel<RC, NIN_, NT_, HEAVY_>), tail_grid, dim3(256), 0, stream, args); \
+  } while (0)
 
 #define GM_VM_DEFINE_LAUNCHER(RC)                                                                  \
   template <>                                                                                      \
-  int launch_class<RC>(const VmArgs& args, int n_inputs, int U, bool heavy, dim3 grid,             \
+  int launch_class<RC>(const VmArgs& args, int size, int G, bool heavy, dim3 grid, dim3 tail_grid, \
                        hipStream_t stream) {                                                       \
-    const bool small = n_inputs <= 4;                                                              \
     if (heavy) {                                                                                   \
-      if (small) hipLaunchKernelGGL((vm_kernel<RC, 4, 1, true>), grid, dim3(256), 0, stream, args); \
-      else hipLaunchKernelGGL((vm_kernel<RC, 8, 1, true>), grid, dim3(256), 0, stream, args);      \
-    } else if (U == 2) {                                                                           \
-      if (small) hipLaunchKernelGGL((vm_kernel<RC, 4, 2, false>), grid, dim3(256), 0, stream, args); \
-      else hipLaunchKernelGGL((vm_kernel<RC, 8, 2, false>), grid, dim3(256), 0, stream, args);     \
+      if (size == 0) GM_VM_LAUNCH(RC, 1, 2, 1, true);                                              \
+      else if (size == 1) GM_VM_LAUNCH(RC, 1, 4, 2, true);                                         \
+      else GM_VM_LAUNCH(RC, 1, 8, 4, true);                                                        \
+    } else if (size == 0) {                                                                        \
+      if (G == 4) GM_VM_LAUNCH(RC, 4, 2, 1, false);                                                \
+      else if (G == 2) GM_VM_LAUNCH(RC, 2, 2, 1, false);                                           \
+      else GM_VM_LAUNCH(RC, 1, 2, 1, false);                                                       \
+    } else if (size == 1) {                                                                        \
+      if (G >= 2) GM_VM_LAUNCH(RC, 2, 4, 2, false);                                                \
+      else GM_VM_LAUNCH(RC, 1, 4, 2, false);                                                       \
     } else {                                                                                       \
-      if (small) hipLaunchKernelGGL((vm_kernel<RC, 4, 1, false>), grid, dim3(256), 0, stream, args); \
-      else hipLaunchKernelGGL((vm_kernel<RC, 8, 1, false>), grid, dim3(256), 0, stream, args);     \
+      GM_VM_LAUNCH(RC, 1, 8, 4, false);                                                            \
     }                                                                                              \
     hipError_t e = hipGetLastError();                                                              \
     if (e != hipSuccess) return gm::hip_fail(e, "vm_kernel launch");                               \

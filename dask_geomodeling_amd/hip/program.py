@@ -50,7 +50,7 @@ class gm_step(ctypes.Structure):
 
 
 class gm_input_desc(ctypes.Structure):
-    _fields_ = [("dtype", ctypes.c_uint8), ("broadcast", ctypes.c_uint8), ("has_ndv", ctypes.c_uint8),
+    _fields_ = [("dtype", ctypes.c_uint8), ("broadcast", ctypes.c_uint8), ("native_ndv", ctypes.c_uint8),
                 ("pad_", ctypes.c_uint8 * 5), ("ndv", gm_scalar)]
 
 
@@ -149,7 +149,7 @@ def classes_for_compute(dtype):
         return frozenset((CLASS_I32, CLASS_I64))
     if dt == np.dtype("i8"):
         return frozenset((CLASS_I64,))
-    raise FusionLimit("no register class computes in %s" % dt)
+    raise NotImplementedError("no register class computes in %s" % dt)
 
 
 # ----------------------------------------------------------------------------
@@ -249,12 +249,6 @@ def node_classes(node):
             # small integers compare exactly in the float classes too
             allowed = allowed | frozenset(c for c in (CLASS_F64, CLASS_F32, CLASS_I64)
                                           if all(_operand_exact(a, c) for a in node.args))
-        for a in node.args:
-            if isinstance(a, Leaf):
-                # NumPy casts the operand to the compute dtype; the load does the same cast
-                # iff the class *is* the compute dtype or holds the leaf exactly
-                allowed = frozenset(c for c in allowed
-                                    if exact_in_class(a.dtype, c) or CLASS_DTYPE[c] == cd)
     elif op in ("clip", "copy"):
         allowed = classes_exact(node.args[0].dtype)
     elif op == "mask":
@@ -264,7 +258,21 @@ def node_classes(node):
         value = node.extra["value"]
         vdt = node.dtype
         allowed = frozenset(c for c in allowed if _value_exact(value, vdt, c))
+    # Tiles are converted to the class type on load and tested for no-data on the converted
+    # value, so the class must hold every leaf exactly -- except 64-bit integer tiles feeding
+    # a float64 op: NumPy casts them (rounding) too, and their no-data cells are tagged at
+    # load time (gm_input_desc.native_ndv)
+    cd = compute_dtype(node)
+    for a in node.args:
+        if isinstance(a, Leaf):
+            allowed = frozenset(c for c in allowed if exact_in_class(a.dtype, c)
+                                or (c == CLASS_F64 and cd == np.dtype("f8") and _wide_int(a.dtype)))
     return allowed
+
+
+def _wide_int(dtype):
+    dt = np.dtype(dtype)
+    return dt.kind in "iu" and dt.itemsize == 8
 
 
 def _operand_exact(a, cls):
@@ -330,6 +338,11 @@ def compile_expr(root, n_inputs):
         root = Op("copy", [root], root.dtype, root.ndv)
     allowed = tree_classes(root)
     if not allowed:
+        if isinstance(root, Op) and all(isinstance(a, (Leaf, Lit)) for a in root.args):
+            # a single op that no class can run (e.g. int64 raster combined with a float raster:
+            # the int64 tile is not exact in float64 and float64 does not compute in int64)
+            raise NotImplementedError("operand dtypes %s of '%s' have no exact register class on the device"
+                                      % ([str(a.dtype) for a in root.args], root.op))
         raise FusionLimit("no common register class")
     cls = min(allowed, key=lambda c: CLASS_COST[c])
     if n_inputs > GM_MAX_INPUTS:
@@ -384,9 +397,15 @@ def compile_expr(root, n_inputs):
     def operand(n, consumer, cd):
         if isinstance(n, Leaf):
             leaves[n.slot] = n
-            o = gm_operand()
+            if exact_in_class(n.dtype, cls):
+                return reg_operand(OPD_INPUT, n.slot, n)
+            if not (cls == CLASS_F64 and _wide_int(n.dtype)):
+                raise FusionLimit("input dtype %s is not exact in register class %d" % (n.dtype, cls))
+            o = gm_operand()  # no-data cells arrive as the sentinel 0.5
             o.kind, o.index = OPD_INPUT, n.slot
-            o.is_bool = 1 if n.is_bool else 0
+            if effective_ndv(n.dtype, n.ndv) is not None:
+                o.has_ndv = 1
+                o.value.f64 = 0.5
             return o
         if isinstance(n, Lit):
             o = gm_operand()
@@ -476,15 +495,12 @@ def compile_expr(root, n_inputs):
         d = prog.inputs[slot]
         d.dtype = code_of(leaf.dtype)
         d.broadcast = 1 if leaf.broadcast else 0
-        eff = None if leaf.is_bool else effective_ndv(leaf.dtype, leaf.ndv)
-        if eff is not None:
-            d.has_ndv = 1
-            if leaf.dtype.kind == "f":
-                d.ndv.f64 = float(eff)
-            elif leaf.dtype == np.dtype("u8"):
-                d.ndv.u64 = int(eff)
-            else:
-                d.ndv.i64 = int(eff)
+        if not exact_in_class(leaf.dtype, cls):
+            eff = effective_ndv(leaf.dtype, leaf.ndv)
+            if eff is not None:
+                d.native_ndv = 1
+                v = int(eff)
+                d.ndv.i64 = v - 2 ** 64 if v >= 2 ** 63 else v
     for slot in range(n_inputs):
         if slot not in leaves:  # unused input: still needs a valid dtype code
             prog.inputs[slot].dtype = code_of(np.dtype("u1"))
@@ -536,7 +552,7 @@ def _lib():
     return L
 
 
-def set_tuning(vec=8, blocks_per_cu=8, xcd_chunking=0, nontemporal=0):
+def set_tuning(vec=8, blocks_per_cu=0, xcd_chunking=0, nontemporal=0):
     t = gm_vm_tuning(vec, blocks_per_cu, xcd_chunking, nontemporal)
     runtime.check(_lib().gm_vm_set_tuning(ctypes.byref(t)), "gm_vm_set_tuning")
 

@@ -21,6 +21,18 @@ class gm_scalar(ctypes.Union):
                 ("u64", ctypes.c_uint64), ("i32", ctypes.c_int32)]
 
 
+def scalar_bits(value, dtype):
+    """8-byte gm_scalar payload of ``value`` for a tile of ``dtype``: float tiles carry
+    the value as float64 bits, integer/bool tiles as (two's complement) int64 bits."""
+    import struct
+
+    import numpy as np
+    dt = np.dtype(dtype)
+    if dt.kind == "f":
+        return struct.unpack("<Q", struct.pack("<d", float(value)))[0]
+    return int(value) & 0xFFFFFFFFFFFFFFFF
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -59,10 +71,10 @@ def _declare(L):
         "gm_memset": [vp, i32, sz], "gm_sync": [],
         "gm_event_create": [c.POINTER(vp)], "gm_event_destroy": [vp], "gm_event_record": [vp],
         "gm_event_sync": [vp], "gm_event_elapsed_ms": [vp, vp, c.POINTER(c.c_float)],
-        "gm_all_equal": [vp, i32, gm_scalar, sz, c.POINTER(i32)],
-        "gm_fill": [vp, i32, gm_scalar, sz],
+        "gm_all_equal": [vp, i32, u64, sz, c.POINTER(i32)],
+        "gm_fill": [vp, i32, u64, sz],
         "gm_generate": [vp, i32, u64, u64, c.c_double, c.c_double, sz, c.c_uint32, c.c_uint32,
-                        c.c_uint32, gm_scalar],
+                        c.c_uint32, u64],
         "gm_checksum": [vp, sz, c.POINTER(u64)],
         "gm_paste_tile": [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32],
     }

@@ -18,7 +18,6 @@ from ..hip import program as P
 from ..hip import runtime
 from ..hip.array import DeviceArray, as_device
 from ..hip.dtypes import code_of
-from ..hip.runtime import gm_scalar
 from .. import utils
 
 BOOL = np.dtype("bool")
@@ -153,15 +152,9 @@ def all_equal(values, ndv):
     eff = P.effective_ndv(arr.dtype, ndv)
     if eff is None:
         return arr.size == 0
-    s = gm_scalar()
-    if arr.dtype.kind == "f":
-        s.f64 = float(eff)
-    elif arr.dtype == np.dtype("u8"):
-        s.u64 = int(eff)
-    else:
-        s.i64 = int(eff)
     out = ctypes.c_int(0)
-    runtime.check(runtime.lib().gm_all_equal(ctypes.c_void_p(arr.ptr), code_of(arr.dtype), s, arr.size,
+    runtime.check(runtime.lib().gm_all_equal(ctypes.c_void_p(arr.ptr), code_of(arr.dtype),
+                                             runtime.scalar_bits(eff, arr.dtype), arr.size,
                                              ctypes.byref(out)), "gm_all_equal")
     return bool(out.value)
 
@@ -177,7 +170,16 @@ def clip_process(data, source_data):
         return data if all_equal(data["values"], data["no_data_value"]) else None
     tiles = [(data["values"], data["no_data_value"]),
              (source_data["values"], source_data.get("no_data_value"))]
-    values, ndv = P.run_expr(lambda leaves: clip_node(leaves[0], leaves[1]), tiles)
+    try:
+        values, ndv = P.run_expr(lambda leaves: clip_node(leaves[0], leaves[1]), tiles)
+    except (NotImplementedError, P.FusionLimit):
+        # no register class holds both tiles exactly (e.g. int64 store, float mask source):
+        # reduce the source to its boolean "has data" tile first; Clip only needs that
+        if np.dtype(tiles[1][0].dtype) == BOOL:
+            raise
+        has_data, _ = P.run_expr(lambda leaves: isdata_node(leaves[0]), tiles[1:])
+        values, ndv = P.run_expr(lambda leaves: clip_node(leaves[0], leaves[1]),
+                                 [tiles[0], (has_data, None)])
     return {"values": values, "no_data_value": data["no_data_value"]}
 
 

@@ -51,7 +51,9 @@ enum gm_dtype {
   GM_DTYPE_COUNT = 11
 };
 
-/* 8-byte scalar slot; which member is meaningful is stated per use */
+/* 8-byte scalar slot; which member is meaningful is stated per use.  Functions take it as a
+ * raw `uint64_t *_bits` payload (the 8 bytes of this union; float tiles: .f64, integer and
+ * bool tiles: .i64/.u64) because unions cannot be passed by value through libffi/ctypes. */
 typedef union gm_scalar {
   double f64;
   float f32;
@@ -149,11 +151,11 @@ enum gm_opcode {
 typedef struct gm_operand {
   uint8_t kind;     /* gm_operand_kind */
   uint8_t index;    /* input / temp index */
-  uint8_t has_ndv;  /* ACC/TEMP: test the register against `value` (INPUT operands use
-                       their gm_input_desc instead) */
+  uint8_t has_ndv;  /* INPUT/ACC/TEMP: the operand is a raster whose cells equal to `value`
+                       are no-data (exact ==) */
   uint8_t is_bool;  /* operand is a boolean raster (never carries no-data) */
   uint8_t pad_[4];
-  gm_scalar value;  /* SCALAR: the literal; ACC/TEMP: the ndv -- in register-class representation */
+  gm_scalar value;  /* SCALAR: the literal; otherwise the ndv -- in register-class representation */
 } gm_operand;
 
 typedef struct gm_step {
@@ -176,10 +178,12 @@ typedef struct gm_step {
 typedef struct gm_input_desc {
   uint8_t dtype;      /* gm_dtype of the tile in HBM */
   uint8_t broadcast;  /* 1: single element, broadcast to every pixel */
-  uint8_t has_ndv;    /* test elements against ndv (exact ==, in the tile's own dtype) */
+  uint8_t native_ndv; /* 64-bit integer tile read into the F64 class (NumPy casts it to float64
+                         for the op, e.g. Divide(int64 raster, x)): cells equal to `ndv` -- compared
+                         as integers -- are loaded as the sentinel 0.5, a value no converted
+                         integer can take; operands of this input then test against 0.5 */
   uint8_t pad_[5];
-  gm_scalar ndv;      /* float tiles: .f64 (exactly representable in the tile dtype);
-                         integer/bool tiles: .i64 (.u64 for GM_U64) */
+  gm_scalar ndv;      /* .i64 / .u64, used when native_ndv is set */
 } gm_input_desc;
 
 typedef struct gm_program {
@@ -199,8 +203,9 @@ int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out
 /* Tuning knobs of the VM launch (0 = default): elements per lane per iteration
  * (4 or 8), workgroups per CU, XCD-contiguous chunking, non-temporal access. */
 typedef struct gm_vm_tuning {
-  int32_t vec;            /* 4 | 8 */
-  int32_t blocks_per_cu;  /* grid = blocks_per_cu * CUs, capped by the work */
+  int32_t vec;            /* 4 | 8 | 16 (programs with many inputs/temps use at most 8) */
+  int32_t blocks_per_cu;  /* grid = blocks_per_cu * CUs, capped by the work; 0 = one
+                             block-iteration per workgroup */
   int32_t xcd_chunking;   /* 1: each XCD streams its own contiguous eighth */
   int32_t nontemporal;    /* bit0: loads, bit1: stores */
 } gm_vm_tuning;
@@ -216,7 +221,7 @@ size_t gm_sizeof(int which);
  * Comparisons are made in float64 (NumPy promotes value and edges); NaN -> nbins.
  * out_dtype is GM_U8/GM_U16/GM_U32; bins is a HOST pointer (staged into LDS).
  * ========================================================================== */
-int gm_classify(const void* in, int in_dtype, int has_ndv, gm_scalar ndv /* as in_dtype's class: f64 for floats, i64 for ints */,
+int gm_classify(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits /* gm_scalar payload: .f64 for float tiles, .i64 for ints */,
                 const double* bins_host, int nbins, int right,
                 void* out, int out_dtype, uint64_t fill, size_t n);
 
@@ -229,7 +234,7 @@ int gm_classify(const void* in, int in_dtype, int has_ndv, gm_scalar ndv /* as i
  * ========================================================================== */
 int gm_reclassify(const void* in, int in_dtype,
                   const int64_t* keys_host, const gm_scalar* targets_host, int ntab,
-                  int select, gm_scalar fill, void* out, int out_dtype, size_t n);
+                  int select, uint64_t fill_bits, void* out, int out_dtype, size_t n);
 
 /* =============================================================================
  * K6/K7: resampling of (bands, Hs, Ws) -> (bands, Hd, Wd)
@@ -245,27 +250,27 @@ int gm_reclassify(const void* in, int in_dtype,
 int gm_resample_nearest(const void* src, int dtype, int bands, int hs, int ws,
                         void* dst, int hd, int wd,
                         double row_off, double row_scale, double col_off, double col_scale,
-                        double center, double eps, gm_scalar fill, int finite_to_fill);
+                        double center, double eps, uint64_t fill_bits, int finite_to_fill);
 
 /* Bilinear (our spec; no reference implementation exists): pixel-centre
  * aligned, edge-clamped, evaluated in float64, rounded once; any tap == ndv or
  * non-finite -> ndv.  dtype: GM_F32 or GM_F64.  Source tile + 1 px apron staged in LDS. */
 int gm_resample_bilinear(const void* src, int dtype, int bands, int hs, int ws,
-                         void* dst, int hd, int wd, int has_ndv, gm_scalar ndv);
+                         void* dst, int hd, int wd, int has_ndv, uint64_t ndv_bits);
 
 /* =============================================================================
  * K8: helpers
  * ========================================================================== */
 
 /* *result = 1 iff every element equals `value` (Clip early-out, misc.py:108). Synchronous. */
-int gm_all_equal(const void* in, int dtype, gm_scalar value, size_t n, int* result);
+int gm_all_equal(const void* in, int dtype, uint64_t value_bits, size_t n, int* result);
 /* out[i] = value */
-int gm_fill(void* out, int dtype, gm_scalar value, size_t n);
+int gm_fill(void* out, int dtype, uint64_t value_bits, size_t n);
 /* Synthetic tile: counter-based uniform values in [lo, hi) keyed by (seed, global index),
  * with `ndv` written on the lattice (i / width) % ny == 0 && (i % width) % nx == 0
  * (nx == 0 disables).  Element i of the tile has global index offset + i. */
 int gm_generate(void* out, int dtype, uint64_t seed, uint64_t offset, double lo, double hi,
-                size_t n, uint32_t width, uint32_t lattice_y, uint32_t lattice_x, gm_scalar ndv);
+                size_t n, uint32_t width, uint32_t lattice_y, uint32_t lattice_x, uint64_t ndv_bits);
 /* 64-bit order-independent checksum (sum of mixed 32-bit words) of a device buffer. Synchronous. */
 int gm_checksum(const void* in, size_t bytes, uint64_t* result);
 /* Paste a (bands, th, tw) tile into a (bands, H, W) mosaic at (row0, col0): the device side

@@ -26,38 +26,32 @@ def run_program(prog, inputs, n):
     """Interpret ``prog`` over flat ndarrays ``inputs`` (n elements each, or 1 if broadcast)."""
     cls = prog.reg_class
     rc = CLASS_DTYPE[cls]
-    regs_in, nd_in = [], []
+    regs_in = []
     for k in range(prog.n_inputs):
         d = prog.inputs[k]
         if k >= len(inputs) or inputs[k] is None:
             regs_in.append(None)
-            nd_in.append(None)
             continue
         x = np.asarray(inputs[k]).reshape(-1)
         assert x.dtype == np.dtype(CODE_DTYPE[d.dtype]), (x.dtype, d.dtype)
         if d.broadcast:
             x = np.broadcast_to(x[:1], (n,))
-        nd = np.zeros(n, dtype=bool)
-        if d.has_ndv:
-            if x.dtype.kind == "f":
-                nd = x == x.dtype.type(d.ndv.f64)
-            elif x.dtype == np.dtype("u8"):
-                nd = x == np.uint64(d.ndv.u64)
-            else:
-                nd = x.astype("i8") == np.int64(d.ndv.i64)
         with np.errstate(all="ignore"):
-            regs_in.append(x.astype(rc))
-        nd_in.append(nd)
+            if x.dtype == np.dtype("u8") and rc == np.dtype("i8"):
+                regs_in.append(x.view("i8") if x.flags.c_contiguous else x.astype("i8"))
+            else:
+                r = x.astype(rc)
+                if d.native_ndv:  # 64-bit integer tile in the F64 class: tag no-data cells
+                    r = np.where(x.astype("u8").view("i8") == np.int64(d.ndv.i64), rc.type(0.5), r)
+                regs_in.append(r)
     acc = np.zeros(n, dtype=rc)
     temps = [None] * 4
 
     def fetch(o):
-        if o.kind == OPD_INPUT:
-            return regs_in[o.index], nd_in[o.index]
         if o.kind == OPD_SCALAR:
             return np.full(n, _scalar(o.value, cls), dtype=rc), np.zeros(n, dtype=bool)
-        if o.kind in (OPD_ACC, OPD_TEMP):
-            v = acc if o.kind == OPD_ACC else temps[o.index]
+        if o.kind in (OPD_ACC, OPD_TEMP, OPD_INPUT):
+            v = acc if o.kind == OPD_ACC else (temps[o.index] if o.kind == OPD_TEMP else regs_in[o.index])
             nd = (v == rc.type(_scalar(o.value, cls))) if o.has_ndv else np.zeros(n, dtype=bool)
             return v, nd
         return np.zeros(n, dtype=rc), np.zeros(n, dtype=bool)
