@@ -9,16 +9,17 @@ namespace {
 gm_vm_tuning g_tuning = {8, 0, 0, 0};
 
 int validate_operand(const gm_operand& o, unsigned n_inputs, const char* which, unsigned step) {
-  switch (o.kind) {
+  const unsigned kind = o.bits & 0xffu, index = (o.bits >> 8) & 0xffu;
+  switch (kind) {
     case GM_OPD_NONE: case GM_OPD_ACC: case GM_OPD_SCALAR: return GM_OK;
     case GM_OPD_INPUT:
-      if (o.index >= n_inputs) return gm::fail(GM_ERR_INVALID, "step %u operand %s: input %u of %u", step, which, o.index, n_inputs);
+      if (index >= n_inputs) return gm::fail(GM_ERR_INVALID, "step %u operand %s: input %u of %u", step, which, index, n_inputs);
       return GM_OK;
     case GM_OPD_TEMP:
-      if (o.index >= GM_MAX_TEMPS) return gm::fail(GM_ERR_INVALID, "step %u operand %s: temp %u", step, which, o.index);
+      if (index >= GM_MAX_TEMPS) return gm::fail(GM_ERR_INVALID, "step %u operand %s: temp %u", step, which, index);
       return GM_OK;
     default:
-      return gm::fail(GM_ERR_INVALID, "step %u operand %s: kind %u", step, which, o.kind);
+      return gm::fail(GM_ERR_INVALID, "step %u operand %s: kind %u", step, which, kind);
   }
 }
 
@@ -48,18 +49,19 @@ int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out
   if (prog->reg_class > GM_CLASS_I64) return gm::fail(GM_ERR_INVALID, "reg_class %u", prog->reg_class);
   if (gm::dtype_size(prog->out_dtype) == 0) return gm::fail(GM_ERR_INVALID, "out_dtype %u", prog->out_dtype);
   for (unsigned k = 0; k < prog->n_inputs; ++k) {
-    if (gm::dtype_size(prog->inputs[k].dtype) == 0) return gm::fail(GM_ERR_INVALID, "input %u dtype %u", k, prog->inputs[k].dtype);
+    if (gm::dtype_size(prog->inputs[k].bits & 0xffu) == 0) return gm::fail(GM_ERR_INVALID, "input %u dtype %u", k, prog->inputs[k].bits & 0xffu);
     if (!inputs[k]) return gm::fail(GM_ERR_INVALID, "input %u is null", k);
   }
   for (unsigned s = 0; s < prog->n_steps; ++s) {
     const gm_step& S = prog->steps[s];
-    if (S.opcode == GM_OP_NOP || S.opcode >= GM_OP_COUNT) return gm::fail(GM_ERR_INVALID, "step %u opcode %u", s, S.opcode);
-    if (S.save_temp > GM_MAX_TEMPS) return gm::fail(GM_ERR_INVALID, "step %u save_temp %u", s, S.save_temp);
+    const unsigned opcode = S.bits & 0xffu, save_temp = (S.bits >> 8) & 0xffu;
+    if (opcode == GM_OP_NOP || opcode >= GM_OP_COUNT) return gm::fail(GM_ERR_INVALID, "step %u opcode %u", s, opcode);
+    if (save_temp > GM_MAX_TEMPS) return gm::fail(GM_ERR_INVALID, "step %u save_temp %u", s, save_temp);
     int rc = validate_operand(S.a, prog->n_inputs, "a", s);
     if (rc) return rc;
     rc = validate_operand(S.b, prog->n_inputs, "b", s);
     if (rc) return rc;
-    if (S.opcode == GM_OP_DIV && prog->reg_class >= GM_CLASS_I32)
+    if (opcode == GM_OP_DIV && prog->reg_class >= GM_CLASS_I32)
       return gm::fail(GM_ERR_INVALID, "step %u: DIV in an integer class", s);
   }
   if (n == 0) return GM_OK;
@@ -72,7 +74,7 @@ int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out
   bool aligned = ((uintptr_t)out % 16) == 0;
   for (unsigned k = 0; k < prog->n_inputs; ++k) {
     args.in[k] = inputs[k];
-    if (!prog->inputs[k].broadcast && ((uintptr_t)inputs[k] % 16) != 0) aligned = false;
+    if (!((prog->inputs[k].bits >> 8) & 1u) && ((uintptr_t)inputs[k] % 16) != 0) aligned = false;
   }
   args.out = out;
   args.n = n;
@@ -80,9 +82,9 @@ int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out
   unsigned max_in = prog->n_inputs, max_tmp = 0;
   for (unsigned s = 0; s < prog->n_steps; ++s) {
     const gm_step& S = prog->steps[s];
-    const unsigned op = S.opcode;
+    const unsigned op = S.bits & 0xffu, save_temp = (S.bits >> 8) & 0xffu;
     if (op == GM_OP_POW || op == GM_OP_EXP || op == GM_OP_LOG || op == GM_OP_LOG10) heavy = true;
-    if (S.save_temp > max_tmp) max_tmp = S.save_temp;
+    if (save_temp > max_tmp) max_tmp = save_temp;
   }
   const int size = (max_in <= 2 && max_tmp <= 1) ? 0 : ((max_in <= 4 && max_tmp <= 2) ? 1 : 2);
   int G = g_tuning.vec >= 16 ? 4 : (g_tuning.vec >= 8 ? 2 : 1);

@@ -34,7 +34,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef long long i64x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
+typedef signed char i8x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
 struct VmArgs {
   gm_program prog;
@@ -113,11 +116,11 @@ __device__ __forceinline__ void load_elems(const void* base, int dtype, unsigned
     GM_LOAD_CASE(GM_I32, int, i32x4)
     GM_LOAD_CASE(GM_U32, unsigned int, u32x4)
     GM_LOAD_CASE8(GM_I64, long long, i64x2)
-    GM_LOAD_CASE8(GM_U64, unsigned long long, i64x2)
+    GM_LOAD_CASE8(GM_U64, unsigned long long, u64x2)
     GM_LOAD_CASE(GM_U16, unsigned short, u16x4)
-    GM_LOAD_CASE(GM_I16, short, u16x4)
+    GM_LOAD_CASE(GM_I16, short, i16x4)
     GM_LOAD_CASE(GM_U8, unsigned char, u8x4)
-    GM_LOAD_CASE(GM_I8, signed char, u8x4)
+    GM_LOAD_CASE(GM_I8, signed char, i8x4)
     GM_LOAD_CASE(GM_BOOL, unsigned char, u8x4)
     default: break;
   }
@@ -154,11 +157,11 @@ __device__ __forceinline__ void store_elems(void* base, int dtype, unsigned long
     GM_STORE_CASE(GM_I32, int, i32x4)
     GM_STORE_CASE(GM_U32, unsigned int, u32x4)
     GM_STORE_CASE8(GM_I64, long long, i64x2)
-    GM_STORE_CASE8(GM_U64, long long, i64x2)
+    GM_STORE_CASE8(GM_U64, long long, i64x2)  /* uint64 travels as its bit pattern (I64 class) */
     GM_STORE_CASE(GM_U16, unsigned short, u16x4)
-    GM_STORE_CASE(GM_I16, unsigned short, u16x4)
+    GM_STORE_CASE(GM_I16, short, i16x4)
     GM_STORE_CASE(GM_U8, unsigned char, u8x4)
-    GM_STORE_CASE(GM_I8, unsigned char, u8x4)
+    GM_STORE_CASE(GM_I8, signed char, i8x4)
     GM_STORE_CASE(GM_BOOL, unsigned char, u8x4)
     default: break;
   }
@@ -217,12 +220,27 @@ template <typename RC>
 __device__ __forceinline__ bool is_close(RC x, double y, double tol, bool in_f64, bool y_finite) {
   if (in_f64) {
     double xd = (double)x;
-    return ((fabs(xd - y) <= tol) && y_finite) || (xd == y);
+    return ((fabs(xd - y) <= tol) & y_finite) | (xd == y);
   } else {
     float xf = (float)x, yf = (float)y;
-    return ((fabsf(xf - yf) <= (float)tol) && y_finite) || (xf == yf);
+    return ((fabsf(xf - yf) <= (float)tol) & y_finite) | (xf == yf);
   }
 }
+
+// ---- descriptor decoding (all wave-uniform: SALU on s_load'ed words) ----------------
+__device__ __forceinline__ unsigned opd_kind(const gm_operand& o) { return o.bits & 0xffu; }
+__device__ __forceinline__ unsigned opd_index(const gm_operand& o) { return (o.bits >> 8) & 0xffu; }
+__device__ __forceinline__ bool opd_has_ndv(const gm_operand& o) { return ((o.bits >> 16) & 1u) != 0; }
+__device__ __forceinline__ bool opd_is_bool(const gm_operand& o) { return ((o.bits >> 17) & 1u) != 0; }
+__device__ __forceinline__ unsigned step_opcode(const gm_step& S) { return S.bits & 0xffu; }
+__device__ __forceinline__ unsigned step_save_temp(const gm_step& S) { return (S.bits >> 8) & 0xffu; }
+__device__ __forceinline__ unsigned step_flags(const gm_step& S) { return (S.bits >> 16) & 0xffu; }
+__device__ __forceinline__ bool step_round_f32(const gm_step& S) { return ((S.bits >> 24) & 1u) != 0; }
+__device__ __forceinline__ bool step_wrap_i32(const gm_step& S) { return ((S.bits >> 25) & 1u) != 0; }
+__device__ __forceinline__ bool step_check_finite(const gm_step& S) { return ((S.bits >> 26) & 1u) != 0; }
+__device__ __forceinline__ int in_dtype(const gm_input_desc& D) { return (int)(D.bits & 0xffu); }
+__device__ __forceinline__ bool in_broadcast(const gm_input_desc& D) { return ((D.bits >> 8) & 1u) != 0; }
+__device__ __forceinline__ bool in_native(const gm_input_desc& D) { return ((D.bits >> 9) & 1u) != 0; }
 
 // ---- the interpreter -------------------------------------------------------------
 // N elements per lane, NIN input slots, NT temps.  HEAVY instantiations carry
@@ -235,9 +253,9 @@ struct Machine {
 
   // operand fetch; every branch below is wave-uniform
   __device__ __forceinline__ void fetch(const gm_operand& o, RC (&v)[N]) const {
-    switch (o.kind) {
+    switch (opd_kind(o)) {
       case GM_OPD_INPUT: {
-        switch (o.index) {
+        switch (opd_index(o)) {
 #define GM_IN_CASE(K)                                                    \
   case K:                                                                \
     if constexpr (K < NIN) {                                             \
@@ -256,7 +274,7 @@ struct Machine {
         for (int k = 0; k < N; ++k) v[k] = s;
       } break;
       case GM_OPD_TEMP: {
-        switch (o.index) {
+        switch (opd_index(o)) {
 #define GM_TMP_CASE(K)                                                   \
   case K:                                                                \
     if constexpr (K < NT) {                                              \
@@ -279,117 +297,144 @@ struct Machine {
     }
   }
 
-  // acc[k] = bad ? fill : f(a[k], b[k])   with bad = a is no-data | b is no-data | !finite
-  template <typename F>
-  __device__ __forceinline__ void apply(const gm_step& S, const RC (&a)[N], const RC (&b)[N], F f) {
-    // scalar operands never carry no-data (has_ndv = 0 from the host)
-    const bool a_has = S.a.has_ndv != 0, b_has = S.b.has_ndv != 0, chk = S.check_finite != 0;
-    const RC a_ndv = scalar_of<RC>(S.a.value), b_ndv = scalar_of<RC>(S.b.value);
+  // In-place step body: acc[k] = bad ? fill : f(acc[k], b[k])
+  //   bad = acc[k] is no-data | b[k] is no-data | !finite(result)
+  // The left operand is always the accumulator (step() loads it there first).  B_SCALAR:
+  // the right operand is a literal held in an SGPR -- no copy, no no-data test.
+  // Float classes: an operand without ndv is compared against NaN (== is never true), so the
+  // lane masks need no extra s_and; integer classes gate the compare with the has_ndv bit.
+  template <bool B_SCALAR, typename F>
+  __device__ __forceinline__ void apply(const gm_step& S, const RC (&b)[N], F f) {
+    const bool a_has = opd_has_ndv(S.a), b_has = opd_has_ndv(S.b);
+    RC a_ndv = scalar_of<RC>(S.a.value), b_ndv = scalar_of<RC>(S.b.value);
+    const RC b_val = b_ndv;  // B_SCALAR: the literal itself
+    if constexpr (is_float_class<RC>::value) {
+      // once per step, on the scalar unit: an operand without ndv compares against NaN
+      a_ndv = a_has ? a_ndv : (RC)__builtin_nanf("");
+      b_ndv = b_has ? b_ndv : (RC)__builtin_nanf("");
+    }
     const RC fill = scalar_of<RC>(S.fill);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      bool bad = (a_has && a[k] == a_ndv) || (b_has && b[k] == b_ndv);
-      RC r = f(a[k], b[k]);
-      if constexpr (is_float_class<RC>::value) bad = bad || (chk && !finite_rc<RC>(r));
+      const RC x = acc[k];
+      const RC y = B_SCALAR ? b_val : b[k];
+      bool bad;  // bitwise (not short-circuit) logic: v_cmp into lane masks, no branches
+      if constexpr (is_float_class<RC>::value) {
+        bad = (x == a_ndv);
+        if constexpr (!B_SCALAR) bad = bad | (y == b_ndv);
+      } else {
+        bad = a_has & (x == a_ndv);
+        if constexpr (!B_SCALAR) bad = bad | (b_has & (y == b_ndv));
+      }
+      const RC r = f(x, y);
+      if constexpr (is_float_class<RC>::value) bad = bad | !finite_rc<RC>(r);
       acc[k] = bad ? fill : r;
     }
   }
 
+  template <typename F>
+  __device__ __forceinline__ void apply2(const gm_step& S, bool b_scalar, const RC (&b)[N], F f) {
+    if (b_scalar) apply<true>(S, b, f);
+    else apply<false>(S, b, f);
+  }
+
   // the same with the step-dtype narrowing of the wide classes applied to f's result
   template <typename F>
-  __device__ __forceinline__ void math(const gm_step& S, const RC (&a)[N], const RC (&b)[N], F f) {
+  __device__ __forceinline__ void math(const gm_step& S, bool b_scalar, const RC (&b)[N], F f) {
     if constexpr (std::is_same<RC, double>::value) {
-      if (S.round_f32) {  // float32 step inside the F64 class: round after the op
-        apply(S, a, b, [f](RC x, RC y) { return (RC)(float)f(x, y); });
+      if (step_round_f32(S)) {  // float32 step inside the F64 class: round after the op
+        apply2(S, b_scalar, b, [f](RC x, RC y) { return (RC)(float)f(x, y); });
         return;
       }
     }
     if constexpr (std::is_same<RC, long long>::value) {
-      if (S.wrap_i32) {  // int32 step inside the I64 class: wrap to 32 bits
-        apply(S, a, b, [f](RC x, RC y) { return (RC)(int)f(x, y); });
+      if (step_wrap_i32(S)) {  // int32 step inside the I64 class: wrap to 32 bits
+        apply2(S, b_scalar, b, [f](RC x, RC y) { return (RC)(int)f(x, y); });
         return;
       }
     }
-    apply(S, a, b, f);
+    apply2(S, b_scalar, b, f);
   }
 
   __device__ __forceinline__ void step(const gm_step& S) {
-    RC a[N], b[N];
-    fetch(S.a, a);
-    fetch(S.b, b);
-    const int opcode = S.opcode;
+    RC b[N];
+    const unsigned b_kind = opd_kind(S.b);
+    const bool b_scalar = (b_kind == GM_OPD_SCALAR) | (b_kind == GM_OPD_NONE);
+    if (!b_scalar) fetch(S.b, b);                       // (also covers b == ACC: copied before acc changes)
+    if (opd_kind(S.a) != GM_OPD_ACC) fetch(S.a, acc);   // left operand -> accumulator
+    const int opcode = (int)step_opcode(S);
     switch (opcode) {
-      case GM_OP_ADD: math(S, a, b, [](RC x, RC y) { return op_add<RC>(x, y); }); break;
-      case GM_OP_SUB: math(S, a, b, [](RC x, RC y) { return op_sub<RC>(x, y); }); break;
-      case GM_OP_MUL: math(S, a, b, [](RC x, RC y) { return op_mul<RC>(x, y); }); break;
-      case GM_OP_DIV: math(S, a, b, [](RC x, RC y) { return op_div<RC>(x, y); }); break;
+      case GM_OP_ADD: math(S, b_scalar, b, [](RC x, RC y) { return op_add<RC>(x, y); }); break;
+      case GM_OP_SUB: math(S, b_scalar, b, [](RC x, RC y) { return op_sub<RC>(x, y); }); break;
+      case GM_OP_MUL: math(S, b_scalar, b, [](RC x, RC y) { return op_mul<RC>(x, y); }); break;
+      case GM_OP_DIV: math(S, b_scalar, b, [](RC x, RC y) { return op_div<RC>(x, y); }); break;
       case GM_OP_POW:
-        if constexpr (HEAVY) math(S, a, b, [](RC x, RC y) { return op_pow<RC>(x, y); });
+        if constexpr (HEAVY) math(S, b_scalar, b, [](RC x, RC y) { return op_pow<RC>(x, y); });
         break;
       case GM_OP_EXP:
-        if constexpr (HEAVY && is_float_class<RC>::value) math(S, a, b, [](RC x, RC) { return (RC)exp((double)x); });
+        if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { return (RC)exp((double)x); });
         break;
       case GM_OP_LOG:
-        if constexpr (HEAVY && is_float_class<RC>::value) math(S, a, b, [](RC x, RC) { return (RC)log((double)x); });
+        if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { return (RC)log((double)x); });
         break;
       case GM_OP_LOG10:
-        if constexpr (HEAVY && is_float_class<RC>::value) math(S, a, b, [](RC x, RC) { return (RC)log10((double)x); });
+        if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { return (RC)log10((double)x); });
         break;
-      case GM_OP_EQ: apply(S, a, b, [](RC x, RC y) { return (RC)(x == y); }); break;
-      case GM_OP_NE: apply(S, a, b, [](RC x, RC y) { return (RC)(x != y); }); break;
-      case GM_OP_GT: apply(S, a, b, [](RC x, RC y) { return (RC)(x > y); }); break;
-      case GM_OP_GE: apply(S, a, b, [](RC x, RC y) { return (RC)(x >= y); }); break;
-      case GM_OP_LT: apply(S, a, b, [](RC x, RC y) { return (RC)(x < y); }); break;
-      case GM_OP_LE: apply(S, a, b, [](RC x, RC y) { return (RC)(x <= y); }); break;
-      case GM_OP_AND: apply(S, a, b, [](RC x, RC y) { return (RC)((x != (RC)0) && (y != (RC)0)); }); break;
-      case GM_OP_OR: apply(S, a, b, [](RC x, RC y) { return (RC)((x != (RC)0) || (y != (RC)0)); }); break;
-      case GM_OP_XOR: apply(S, a, b, [](RC x, RC y) { return (RC)((x != (RC)0) != (y != (RC)0)); }); break;
+      case GM_OP_EQ: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)(x == y); }); break;
+      case GM_OP_NE: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)(x != y); }); break;
+      case GM_OP_GT: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)(x > y); }); break;
+      case GM_OP_GE: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)(x >= y); }); break;
+      case GM_OP_LT: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)(x < y); }); break;
+      case GM_OP_LE: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)(x <= y); }); break;
+      case GM_OP_AND: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)((x != (RC)0) & (y != (RC)0)); }); break;
+      case GM_OP_OR: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)((x != (RC)0) | (y != (RC)0)); }); break;
+      case GM_OP_XOR: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)((x != (RC)0) != (y != (RC)0)); }); break;
       case GM_OP_INVERT:
 #pragma unroll
-        for (int k = 0; k < N; ++k) acc[k] = (RC)(a[k] == (RC)0);
+        for (int k = 0; k < N; ++k) acc[k] = (RC)(acc[k] == (RC)0);
         break;
       case GM_OP_ISDATA:
       case GM_OP_ISNODATA: {
-        const bool a_has = S.a.has_ndv != 0, want = opcode == GM_OP_ISNODATA;
+        const bool a_has = opd_has_ndv(S.a), want = opcode == GM_OP_ISNODATA;
         const RC a_ndv = scalar_of<RC>(S.a.value);
 #pragma unroll
-        for (int k = 0; k < N; ++k) acc[k] = (RC)(((a_has && a[k] == a_ndv)) == want);
+        for (int k = 0; k < N; ++k) acc[k] = (RC)((a_has & (acc[k] == a_ndv)) == want);
       } break;
       case GM_OP_CLIP: {
         // misc.py:115-123: drop where the mask source is no-data / False (bool source);
         // fill == the store's own no-data value
-        const bool b_has = S.b.has_ndv != 0, b_bool = S.b.is_bool != 0;
+        const bool b_has = opd_has_ndv(S.b), b_bool = opd_is_bool(S.b);
         const RC b_ndv = scalar_of<RC>(S.b.value), fill = scalar_of<RC>(S.fill);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-          const bool drop = (b_has && b[k] == b_ndv) || (b_bool && b[k] == (RC)0);
-          acc[k] = drop ? fill : a[k];
+          const bool drop = (b_has & (b[k] == b_ndv)) | (b_bool & (b[k] == (RC)0));
+          acc[k] = drop ? fill : acc[k];
         }
       } break;
       case GM_OP_MASK: {
         // misc.py:213-221: value where get_index() says data, else fill
         const RC value = scalar_of<RC>(S.aux0), fill = scalar_of<RC>(S.fill);
-        if (S.flags & 4u) {  // integer tiles: exact !=
-          const bool a_has = S.a.has_ndv != 0;
+        const unsigned flags = step_flags(S);
+        if (flags & 4u) {  // integer tiles: exact !=
+          const bool a_has = opd_has_ndv(S.a);
           const RC a_ndv = scalar_of<RC>(S.a.value);
 #pragma unroll
-          for (int k = 0; k < N; ++k) acc[k] = (a_has && a[k] == a_ndv) ? fill : value;
+          for (int k = 0; k < N; ++k) acc[k] = (a_has & (acc[k] == a_ndv)) ? fill : value;
         } else {
           const double y = S.aux2.f64, tol = S.aux1.f64;
-          const bool in_f64 = (S.flags & 1u) != 0, y_finite = (S.flags & 2u) != 0;
+          const bool in_f64 = (flags & 1u) != 0, y_finite = (flags & 2u) != 0;
 #pragma unroll
-          for (int k = 0; k < N; ++k) acc[k] = is_close<RC>(a[k], y, tol, in_f64, y_finite) ? fill : value;
+          for (int k = 0; k < N; ++k) acc[k] = is_close<RC>(acc[k], y, tol, in_f64, y_finite) ? fill : value;
         }
       } break;
       case GM_OP_COPY:
       default:
-#pragma unroll
-        for (int k = 0; k < N; ++k) acc[k] = a[k];
-        break;
+        break;  // the accumulator already holds the operand
     }
     if constexpr (NT > 0) {
-      if (S.save_temp) {
-        switch (S.save_temp - 1) {
+      const unsigned save = step_save_temp(S);
+      if (save) {
+        switch (save - 1) {
 #define GM_SAVE_CASE(K)                                                    \
   case K:                                                                  \
     if constexpr (K < NT) {                                                \
@@ -437,7 +482,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
   const gm_program& P = A.prog;
   const bool nt_ld = (A.nontemporal & 1u) != 0, nt_st = (A.nontemporal & 2u) != 0;
   const unsigned n_in = P.n_inputs;
-  const int out_dtype = P.out_dtype;
+  const int out_dtype = (int)P.out_dtype;
   constexpr int N = 4 * G;
 
   unsigned long long stride, end;
@@ -450,9 +495,9 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
     for (int k = 0; k < NIN; ++k) {
       if (k < (int)n_in) {
         const gm_input_desc& D = P.inputs[k];
-        if (D.broadcast) {
+        if (in_broadcast(D)) {
           RC one[1];
-          load_elems<RC, 1>(A.in[k], D.dtype, 0, false, one, D.native_ndv != 0, (long long)D.ndv.i64);
+          load_elems<RC, 1>(A.in[k], in_dtype(D), 0, false, one, in_native(D), (long long)D.ndv.i64);
 #pragma unroll
           for (int q = 0; q < N; ++q) M.in[k][q] = one[0];
         } else {
@@ -461,7 +506,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
             RC v4[4] = {(RC)0, (RC)0, (RC)0, (RC)0};
             const unsigned long long g = g0 + 256ull * u;
             if (g < A.n_groups)
-              load_elems<RC, 4>(A.in[k], D.dtype, g * 4ull, nt_ld, v4, D.native_ndv != 0, (long long)D.ndv.i64);
+              load_elems<RC, 4>(A.in[k], in_dtype(D), g * 4ull, nt_ld, v4, in_native(D), (long long)D.ndv.i64);
 #pragma unroll
             for (int q = 0; q < 4; ++q) M.in[k][4 * u + q] = v4[q];
           }
@@ -497,12 +542,12 @@ __global__ __launch_bounds__(256) void vm_tail_kernel(const VmArgs A) {
     for (int k = 0; k < NIN; ++k) {
       if (k < (int)n_in) {
         const gm_input_desc& D = P.inputs[k];
-        load_elems<RC, 1>(A.in[k], D.dtype, D.broadcast ? 0ull : e, false, M1.in[k], D.native_ndv != 0,
+        load_elems<RC, 1>(A.in[k], in_dtype(D), in_broadcast(D) ? 0ull : e, false, M1.in[k], in_native(D),
                           (long long)D.ndv.i64);
       }
     }
     M1.run(P);
-    store_elems<RC, 1>(A.out, P.out_dtype, e, false, M1.acc);
+    store_elems<RC, 1>(A.out, (int)P.out_dtype, e, false, M1.acc);
   }
 }
 

@@ -38,25 +38,50 @@ HEAVY_OPS = ("power", "exp", "log", "log10")
 
 
 class gm_operand(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_uint8), ("index", ctypes.c_uint8), ("has_ndv", ctypes.c_uint8),
-                ("is_bool", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 4), ("value", gm_scalar)]
+    _fields_ = [("bits", ctypes.c_uint32), ("pad_", ctypes.c_uint32), ("value", gm_scalar)]
+
+    def set(self, kind, index=0, has_ndv=0, is_bool=0):
+        self.bits = kind | (index << 8) | (int(bool(has_ndv)) << 16) | (int(bool(is_bool)) << 17)
+
+    kind = property(lambda self: self.bits & 0xff)
+    index = property(lambda self: (self.bits >> 8) & 0xff)
+    has_ndv = property(lambda self: (self.bits >> 16) & 1)
+    is_bool = property(lambda self: (self.bits >> 17) & 1)
 
 
 class gm_step(ctypes.Structure):
-    _fields_ = [("opcode", ctypes.c_uint8), ("round_f32", ctypes.c_uint8), ("wrap_i32", ctypes.c_uint8),
-                ("save_temp", ctypes.c_uint8), ("check_finite", ctypes.c_uint8), ("flags", ctypes.c_uint8),
-                ("pad_", ctypes.c_uint8 * 2), ("a", gm_operand), ("b", gm_operand), ("fill", gm_scalar),
-                ("aux0", gm_scalar), ("aux1", gm_scalar), ("aux2", gm_scalar), ("aux3", gm_scalar)]
+    _fields_ = [("bits", ctypes.c_uint32), ("pad_", ctypes.c_uint32), ("a", gm_operand), ("b", gm_operand),
+                ("fill", gm_scalar), ("aux0", gm_scalar), ("aux1", gm_scalar), ("aux2", gm_scalar),
+                ("aux3", gm_scalar)]
+
+    def _get(self, shift, mask):
+        return (self.bits >> shift) & mask
+
+    def _put(self, shift, mask, value):
+        self.bits = (self.bits & ~(mask << shift)) | ((int(value) & mask) << shift)
+
+    opcode = property(lambda s: s._get(0, 0xff), lambda s, v: s._put(0, 0xff, v))
+    save_temp = property(lambda s: s._get(8, 0xff), lambda s, v: s._put(8, 0xff, v))
+    flags = property(lambda s: s._get(16, 0xff), lambda s, v: s._put(16, 0xff, v))
+    round_f32 = property(lambda s: s._get(24, 1), lambda s, v: s._put(24, 1, v))
+    wrap_i32 = property(lambda s: s._get(25, 1), lambda s, v: s._put(25, 1, v))
+    check_finite = property(lambda s: s._get(26, 1), lambda s, v: s._put(26, 1, v))
 
 
 class gm_input_desc(ctypes.Structure):
-    _fields_ = [("dtype", ctypes.c_uint8), ("broadcast", ctypes.c_uint8), ("native_ndv", ctypes.c_uint8),
-                ("pad_", ctypes.c_uint8 * 5), ("ndv", gm_scalar)]
+    _fields_ = [("bits", ctypes.c_uint32), ("pad_", ctypes.c_uint32), ("ndv", gm_scalar)]
+
+    def set(self, dtype_code, broadcast=0, native_ndv=0):
+        self.bits = dtype_code | (int(bool(broadcast)) << 8) | (int(bool(native_ndv)) << 9)
+
+    dtype = property(lambda self: self.bits & 0xff)
+    broadcast = property(lambda self: (self.bits >> 8) & 1)
+    native_ndv = property(lambda self: (self.bits >> 9) & 1)
 
 
 class gm_program(ctypes.Structure):
-    _fields_ = [("n_steps", ctypes.c_uint32), ("n_inputs", ctypes.c_uint32), ("reg_class", ctypes.c_uint8),
-                ("out_dtype", ctypes.c_uint8), ("pad_", ctypes.c_uint8 * 6),
+    _fields_ = [("n_steps", ctypes.c_uint32), ("n_inputs", ctypes.c_uint32), ("reg_class", ctypes.c_uint32),
+                ("out_dtype", ctypes.c_uint32),
                 ("inputs", gm_input_desc * GM_MAX_INPUTS), ("steps", gm_step * GM_MAX_STEPS)]
 
 
@@ -386,12 +411,12 @@ def compile_expr(root, n_inputs):
 
     def reg_operand(kind, index, node):
         o = gm_operand()
-        o.kind, o.index = kind, index
-        o.is_bool = 1 if node.is_bool else 0
         eff = None if node.is_bool else effective_ndv(node.dtype, node.ndv)
+        o.set(kind, index, has_ndv=eff is not None, is_bool=node.is_bool)
         if eff is not None:
-            o.has_ndv = 1
             _set_scalar(o.value, cls, eff)
+        elif cls in (CLASS_F32, CLASS_F64):
+            _set_scalar(o.value, cls, float("nan"))  # float classes: "no ndv" == compare with NaN
         return o
 
     def operand(n, consumer, cd):
@@ -402,14 +427,13 @@ def compile_expr(root, n_inputs):
             if not (cls == CLASS_F64 and _wide_int(n.dtype)):
                 raise FusionLimit("input dtype %s is not exact in register class %d" % (n.dtype, cls))
             o = gm_operand()  # no-data cells arrive as the sentinel 0.5
-            o.kind, o.index = OPD_INPUT, n.slot
-            if effective_ndv(n.dtype, n.ndv) is not None:
-                o.has_ndv = 1
-                o.value.f64 = 0.5
+            has = effective_ndv(n.dtype, n.ndv) is not None
+            o.set(OPD_INPUT, n.slot, has_ndv=has)
+            o.value.f64 = 0.5 if has else float("nan")
             return o
         if isinstance(n, Lit):
             o = gm_operand()
-            o.kind = OPD_SCALAR
+            o.set(OPD_SCALAR)
             target = cd if cd is not None else CLASS_DTYPE[cls]
             _set_scalar(o.value, cls, cast_scalar(n.value, target))
             return o
@@ -493,17 +517,17 @@ def compile_expr(root, n_inputs):
         prog.steps[i] = s
     for slot, leaf in leaves.items():
         d = prog.inputs[slot]
-        d.dtype = code_of(leaf.dtype)
-        d.broadcast = 1 if leaf.broadcast else 0
+        native = False
         if not exact_in_class(leaf.dtype, cls):
             eff = effective_ndv(leaf.dtype, leaf.ndv)
             if eff is not None:
-                d.native_ndv = 1
+                native = True
                 v = int(eff)
                 d.ndv.i64 = v - 2 ** 64 if v >= 2 ** 63 else v
+        d.set(code_of(leaf.dtype), leaf.broadcast, native)
     for slot in range(n_inputs):
         if slot not in leaves:  # unused input: still needs a valid dtype code
-            prog.inputs[slot].dtype = code_of(np.dtype("u1"))
+            prog.inputs[slot].set(code_of(np.dtype("u1")))
     prog.out_dtype = code_of(root.dtype)
     out = Compiled()
     out.program, out.out_dtype, out.out_ndv = prog, root.dtype, root.ndv

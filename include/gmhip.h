@@ -148,25 +148,30 @@ enum gm_opcode {
   GM_OP_COUNT
 };
 
+/* Descriptors are made of 32/64-bit words only so that a wave reads them with scalar loads
+ * (s_load_dword*) straight from the kernarg segment. */
 typedef struct gm_operand {
-  uint8_t kind;     /* gm_operand_kind */
-  uint8_t index;    /* input / temp index */
-  uint8_t has_ndv;  /* INPUT/ACC/TEMP: the operand is a raster whose cells equal to `value`
-                       are no-data (exact ==) */
-  uint8_t is_bool;  /* operand is a boolean raster (never carries no-data) */
-  uint8_t pad_[4];
+  uint32_t bits;    /* kind (gm_operand_kind) | index << 8 | has_ndv << 16 | is_bool << 17
+                       index:   input / temp index
+                       has_ndv: INPUT/ACC/TEMP: the operand is a raster whose cells equal to
+                                `value` are no-data (exact ==)
+                       is_bool: operand is a boolean raster (never carries no-data) */
+  uint32_t pad_;
   gm_scalar value;  /* SCALAR: the literal; otherwise the ndv -- in register-class representation */
 } gm_operand;
+#define GM_OPERAND_BITS(kind, index, has_ndv, is_bool) \
+  ((uint32_t)(kind) | ((uint32_t)(index) << 8) | ((uint32_t)(has_ndv) << 16) | ((uint32_t)(is_bool) << 17))
 
 typedef struct gm_step {
-  uint8_t opcode;     /* gm_opcode */
-  uint8_t round_f32;  /* F64 class: step dtype is float32 -> round result to f32 */
-  uint8_t wrap_i32;   /* I64 class: step dtype is int32 -> wrap result to 32 bits */
-  uint8_t save_temp;  /* 0 = no, else 1 + temp index: also keep the result in a temp */
-  uint8_t check_finite; /* apply r[~isfinite(r)] = fill (float classes) */
-  uint8_t flags;      /* MASK/FILLNODATA: 1 = isclose evaluated in f64 (else f32), 2 = ndv finite,
-                         4 = integer tile (exact != instead of isclose) */
-  uint8_t pad_[2];
+  uint32_t bits;      /* opcode (gm_opcode) | save_temp << 8 | flags << 16 | round_f32 << 24 |
+                         wrap_i32 << 25 | check_finite << 26
+                         save_temp:    0 = no, else 1 + temp index: also keep the result in a temp
+                         flags:        MASK/FILLNODATA: 1 = isclose evaluated in f64 (else f32),
+                                       2 = ndv finite, 4 = integer tile (exact != instead of isclose)
+                         round_f32:    F64 class: step dtype is float32 -> round result to f32
+                         wrap_i32:     I64 class: step dtype is int32 -> wrap result to 32 bits
+                         check_finite: apply r[~isfinite(r)] = fill (float classes) */
+  uint32_t pad_;
   gm_operand a, b;
   gm_scalar fill;     /* value written where no-data / non-finite (register-class repr) */
   gm_scalar aux0;     /* MASK: value (register-class repr); MASKBELOW/STEP: threshold */
@@ -174,24 +179,29 @@ typedef struct gm_step {
   gm_scalar aux2;     /* MASK/FILLNODATA: .f64 the ndv isclose compares with; STEP: at */
   gm_scalar aux3;     /* STEP: right */
 } gm_step;
+#define GM_STEP_BITS(opcode, save_temp, flags, round_f32, wrap_i32, check_finite)                     \
+  ((uint32_t)(opcode) | ((uint32_t)(save_temp) << 8) | ((uint32_t)(flags) << 16) |                    \
+   ((uint32_t)(round_f32) << 24) | ((uint32_t)(wrap_i32) << 25) | ((uint32_t)(check_finite) << 26))
 
 typedef struct gm_input_desc {
-  uint8_t dtype;      /* gm_dtype of the tile in HBM */
-  uint8_t broadcast;  /* 1: single element, broadcast to every pixel */
-  uint8_t native_ndv; /* 64-bit integer tile read into the F64 class (NumPy casts it to float64
-                         for the op, e.g. Divide(int64 raster, x)): cells equal to `ndv` -- compared
-                         as integers -- are loaded as the sentinel 0.5, a value no converted
-                         integer can take; operands of this input then test against 0.5 */
-  uint8_t pad_[5];
+  uint32_t bits;      /* dtype (gm_dtype of the tile in HBM) | broadcast << 8 | native_ndv << 9
+                         broadcast:  single element, broadcast to every pixel
+                         native_ndv: 64-bit integer tile read into the F64 class (NumPy casts it to
+                                     float64 for the op, e.g. Divide(int64 raster, x)): cells equal
+                                     to `ndv` -- compared as integers -- are loaded as the sentinel
+                                     0.5, a value no converted integer can take; operands of this
+                                     input then test against 0.5 */
+  uint32_t pad_;
   gm_scalar ndv;      /* .i64 / .u64, used when native_ndv is set */
 } gm_input_desc;
+#define GM_INPUT_BITS(dtype, broadcast, native_ndv) \
+  ((uint32_t)(dtype) | ((uint32_t)(broadcast) << 8) | ((uint32_t)(native_ndv) << 9))
 
 typedef struct gm_program {
   uint32_t n_steps;
   uint32_t n_inputs;
-  uint8_t reg_class;  /* gm_reg_class */
-  uint8_t out_dtype;  /* gm_dtype the final accumulator is stored as */
-  uint8_t pad_[6];
+  uint32_t reg_class;  /* gm_reg_class */
+  uint32_t out_dtype;  /* gm_dtype the final accumulator is stored as */
   gm_input_desc inputs[GM_MAX_INPUTS];
   gm_step steps[GM_MAX_STEPS];
 } gm_program;
