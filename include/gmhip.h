@@ -234,6 +234,10 @@ size_t gm_sizeof(int which);
 int gm_classify(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits /* gm_scalar payload: .f64 for float tiles, .i64 for ints */,
                 const double* bins_host, int nbins, int right,
                 void* out, int out_dtype, uint64_t fill, size_t n);
+/* Same with integer edges: when tile and edges are both integers NumPy compares in an integer
+ * type; bins_are_int = 1 makes bins_host an array of int64 and the comparison exact int64. */
+int gm_classify2(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, const void* bins_host, int nbins,
+                 int bins_are_int, int right, void* out, int out_dtype, uint64_t fill, size_t n);
 
 /* =============================================================================
  * K5: Reclassify -- np.isin + np.searchsorted lookup.  raster/misc.py:482-515

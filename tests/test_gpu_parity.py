@@ -97,3 +97,20 @@ def test_device_array_roundtrip_and_checksum(gpu):
             y = x.copy().reshape(-1)
             y[5] = y[5] + 1 if dt != "bool" else ~y[5]
             assert DeviceArray.from_numpy(y.reshape(x.shape)).checksum() != d.checksum()
+
+
+@pytest.mark.parametrize("case", load_family("classify"), ids=lambda c: c["id"])
+def test_classify_golden(gpu, case):
+    from dask_geomodeling_amd.raster import tables
+    out = tables.classify_process(*case["args"])
+    assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.mark.parametrize("case", [c for c in load_family("reclassify") if c["op"] == "reclassify"],
+                         ids=lambda c: c["id"])
+def test_reclassify_golden(gpu, case):
+    from dask_geomodeling_amd.raster import tables
+    if "raises" in case:
+        pytest.skip("reference raises %s" % case["raises"])
+    out = tables.reclassify_process(*case["args"])
+    assert_result_equal(out, case["expect"], 0, case["id"])
