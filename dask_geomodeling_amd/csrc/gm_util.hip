@@ -22,22 +22,26 @@ __global__ __launch_bounds__(256) void fill_kernel(T* out, T value, unsigned lon
 template <typename T>
 __device__ __forceinline__ T cast_uniform(double x) { return (T)x; }
 
+// window [row0, row0+h) x [col0, col0+w) of a procedural H x W mosaic: the value of a pixel is
+// a function of (seed, global row * W + global col) only, so tiles of any size agree
 template <typename T>
-__global__ __launch_bounds__(256) void generate_kernel(T* out, unsigned long long seed, unsigned long long offset,
-                                                       double lo, double hi, unsigned long long n, unsigned width,
+__global__ __launch_bounds__(256) void generate_kernel(T* out, unsigned long long seed, long long row0, long long col0,
+                                                       int h, int w, long long H, long long W, double lo, double hi,
                                                        unsigned ly, unsigned lx, T ndv) {
+  const unsigned long long n = (unsigned long long)h * (unsigned long long)w;
   unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   const unsigned long long key = splitmix64(seed);
   const double span = hi - lo;
   for (; i < n; i += stride) {
-    const unsigned long long bits = splitmix64(key ^ (offset + i));
-    const double u = (double)(bits >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
-    T v = cast_uniform<T>(lo + u * span);
-    if (lx != 0 && width != 0) {
-      const unsigned long long row = i / width;
-      const unsigned col = (unsigned)(i % width);
-      if ((row % ly) == 0 && (col % lx) == 0) v = ndv;
+    const long long gr = row0 + (long long)(i / (unsigned long long)w);
+    const long long gc = col0 + (long long)(i % (unsigned long long)w);
+    T v = ndv;
+    if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
+      const unsigned long long bits = splitmix64(key ^ ((unsigned long long)gr * (unsigned long long)W + (unsigned long long)gc));
+      const double u = (double)(bits >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
+      v = cast_uniform<T>(lo + u * span);
+      if (lx != 0 && (gr % ly) == 0 && (gc % lx) == 0) v = ndv;
     }
     out[i] = v;
   }
@@ -127,19 +131,22 @@ int gm_fill(void* out, int dtype, uint64_t value_bits, size_t n) {
   return GM_OK;
 }
 
-int gm_generate(void* out, int dtype, uint64_t seed, uint64_t offset, double lo, double hi, size_t n,
-                uint32_t width, uint32_t lattice_y, uint32_t lattice_x, uint64_t ndv_bits) {
+int gm_generate(void* out, int dtype, uint64_t seed, int64_t row0, int64_t col0, int h, int w, int64_t H, int64_t W,
+                double lo, double hi, uint32_t lattice_y, uint32_t lattice_x, uint64_t ndv_bits) {
   gm_scalar ndv;
   ndv.u64 = ndv_bits;
   if (!out) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (h < 0 || w < 0 || H < 0 || W < 0) return gm::fail(GM_ERR_INVALID, "negative extent");
+  const size_t n = (size_t)h * (size_t)w;
   if (n == 0) return GM_OK;
   if (lattice_x != 0 && lattice_y == 0) lattice_y = 1;
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
   dim3 grid(grid_for(n, gm::current_cu_count()));
-#define GM_GEN(T, NDV)                                                                                   \
-  hipLaunchKernelGGL(generate_kernel<T>, grid, dim3(256), 0, s, (T*)out, (unsigned long long)seed,       \
-                     (unsigned long long)offset, lo, hi, (unsigned long long)n, width, lattice_y, lattice_x, (T)(NDV))
+#define GM_GEN(T, NDV)                                                                                    \
+  hipLaunchKernelGGL(generate_kernel<T>, grid, dim3(256), 0, s, (T*)out, (unsigned long long)seed,        \
+                     (long long)row0, (long long)col0, h, w, (long long)H, (long long)W, lo, hi, lattice_y, \
+                     lattice_x, (T)(NDV))
   switch (dtype) {
     case GM_U8: GM_GEN(unsigned char, ndv.i64); break;
     case GM_I8: GM_GEN(signed char, ndv.i64); break;

@@ -191,10 +191,12 @@ class Node:
 
 
 class Leaf(Node):
-    """A tile that arrives from outside the program (input slot)."""
+    """A tile that arrives from outside the program (an input slot).  ``values`` is the
+    device tile (bound at evaluation time); ``slot``/``broadcast`` are assigned by ``evaluate``."""
 
-    def __init__(self, slot, dtype, ndv, broadcast=False):
+    def __init__(self, slot, dtype, ndv, broadcast=False, values=None):
         self.slot, self.dtype, self.ndv, self.broadcast = slot, np.dtype(dtype), ndv, broadcast
+        self.values = values
 
     def key(self):
         return ("leaf", self.slot, self.dtype.str, _scalar_key(self.ndv), self.broadcast)
@@ -600,23 +602,61 @@ def launch(compiled, inputs, shape, out=None):
     return out
 
 
-def run_expr(build, tiles):
-    """Evaluate an expression over raster tiles.
+def _collect_leaves(root):
+    """Distinct Leaf objects of the tree in first-use (DFS) order."""
+    seen, out, stack = set(), [], [root]
+    while stack:
+        n = stack.pop()
+        if id(n) in seen:
+            continue
+        seen.add(id(n))
+        if isinstance(n, Leaf):
+            out.append(n)
+        elif isinstance(n, Op):
+            stack.extend(reversed(n.args))
+    return out
 
-    ``tiles``: list of (values, ndv) with values ndarray | DeviceArray; ``build(leaves)``
-    receives one Leaf per tile and returns the root node.  Returns (DeviceArray, ndv).
-    """
+
+def evaluate(root):
+    """Evaluate an expression whose Leafs carry their tiles -> (DeviceArray, ndv).
+
+    One launch when the tree fits one program; otherwise (no common register class, too
+    many inputs / steps / temps) sub-trees are evaluated first and fed back as tiles."""
     runtime.require_device()
-    dev = [as_device(values) for values, _ in tiles]
-    big = max(dev, key=lambda a: a.size)
-    shape, n = big.shape, big.size
-    leaves = []
-    for slot, (arr, (_, ndv)) in enumerate(zip(dev, tiles)):
-        if arr.size != n and arr.size != 1:
-            raise NotImplementedError("operand shapes %s and %s differ (only equal shapes or "
-                                      "single-element operands are supported on the device)" % (shape, arr.shape))
-        leaves.append(Leaf(slot, arr.dtype, ndv, broadcast=(arr.size == 1 and n != 1)))
-    root = build(leaves)
-    compiled = compile_cached(root, len(leaves))
-    out = launch(compiled, dev, shape)
+    leaves = _collect_leaves(root)
+    if not leaves:
+        raise TypeError("at least one raster operand is required")
+    for leaf in leaves:
+        leaf.values = as_device(leaf.values)
+    big = max(leaves, key=lambda l: l.values.size)
+    shape, n = big.values.shape, big.values.size
+    for slot, leaf in enumerate(leaves):
+        size = leaf.values.size
+        if size != n and size != 1:
+            raise NotImplementedError("operand shapes %s and %s differ (only equal shapes or single-element "
+                                      "operands are supported on the device)" % (shape, leaf.values.shape))
+        leaf.slot, leaf.broadcast = slot, (size == 1 and n != 1)
+    try:
+        compiled = compile_cached(root, len(leaves))
+    except FusionLimit:
+        if not isinstance(root, Op) or all(isinstance(a, (Leaf, Lit)) for a in root.args):
+            raise NotImplementedError("expression '%s' does not fit the device program format"
+                                      % getattr(root, "op", root))
+        # evaluate the operand sub-trees on their own, then this node on their results
+        new_args = []
+        for a in root.args:
+            if isinstance(a, Op):
+                values, ndv = evaluate(a)
+                new_args.append(Leaf(None, values.dtype, ndv, values=values))
+            else:
+                new_args.append(a)
+        return evaluate(Op(root.op, new_args, root.dtype, root.ndv, fill=root.fill, extra=root.extra))
+    out = launch(compiled, [leaf.values for leaf in leaves], shape)
     return out, compiled.out_ndv
+
+
+def run_expr(build, tiles):
+    """Evaluate ``build(leaves)`` over raster tiles given as (values, ndv) pairs."""
+    leaves = [Leaf(None, np.asarray(v).dtype if not hasattr(v, "dtype") else v.dtype, ndv, values=v)
+              for v, ndv in tiles]
+    return evaluate(build(leaves))

@@ -1,0 +1,354 @@
+"""Raster sources (API of the reference's raster/sources.py:157-393, GDAL-free).
+
+``MemorySource`` keeps the constructor, attributes and request planning of the
+reference; its ``process`` -- a GDAL nearest-neighbour warp in the reference
+(sources.py:119-149) -- is the HIP gather kernel K6 on a device-resident copy of the
+array (uploaded once per device).  Only same-CRS requests are served: re-projection
+needs PROJ/GDAL, which this path does not carry (out of scope).
+
+``SyntheticSource`` is a procedural, device-side source for benchmarks and the
+65536x65536 virtual mosaic: pixels are a counter-based function of their global
+index, so any window of any size is generated in place without host data.
+"""
+import ctypes
+import weakref
+from datetime import datetime, timedelta, timezone
+
+import numpy as np
+
+from .. import utils
+from ..hip import runtime
+from ..hip.array import DeviceArray
+from ..hip.dtypes import code_of
+from . import resample
+from .base import RasterBlock
+
+__all__ = ["MemorySource", "SyntheticSource"]
+
+
+def utc_from_ms_timestamp(timestamp):
+    """Naive UTC datetime from a POSIX timestamp in milliseconds."""
+    return datetime.fromtimestamp(timestamp / 1000, tz=timezone.utc).replace(tzinfo=None)
+
+
+class RasterData(object):
+    """What a source hands to ``process``: the whole array + its geo-referencing
+    (sources.py:18-35).  Holds the host array and uploads it once per device."""
+
+    _device_copies = {}  # (id(array), device) -> DeviceArray, dropped with the array
+
+    def __init__(self, array, projection, geo_transform, no_data_value, metadata):
+        self.array, self.projection, self.geo_transform = array, projection, geo_transform
+        self.no_data_value, self.metadata = no_data_value, metadata
+
+    def on_device(self):
+        if isinstance(self.array, DeviceArray):
+            return self.array
+        key = (id(self.array), runtime.get_device())
+        hit = RasterData._device_copies.get(key)
+        if hit is None:
+            hit = DeviceArray.from_numpy(self.array)
+            RasterData._device_copies[key] = hit
+            try:
+                weakref.finalize(self.array, RasterData._device_copies.pop, key, None)
+            except TypeError:
+                pass
+        return hit
+
+    def __gm_tokenize__(self):
+        return ("RasterData", id(self.array), self.projection, tuple(self.geo_transform))
+
+
+class RasterSourceBase(RasterBlock):
+    @staticmethod
+    def process(process_kwargs):
+        """Counterpart of RasterSourceBase.process (sources.py:38-149) without GDAL."""
+        mode = process_kwargs["mode"]
+        if mode == "empty_vals":
+            return None
+        if mode == "empty_time":
+            return {"time": []}
+        if mode == "empty_meta":
+            return {"meta": []}
+        bands = process_kwargs["bands"]
+        length = bands[1] - bands[0]
+        if mode == "time":
+            start, delta = process_kwargs["start"], process_kwargs["delta"]
+            return {"time": [start + i * delta for i in range(length)]}
+        raster_data = process_kwargs["raster_data"]
+        if mode == "meta":
+            return {"meta": [raster_data.metadata[i] for i in range(bands[0], bands[1])]}
+
+        dtype = np.dtype(process_kwargs["dtype"])
+        bbox = process_kwargs["bbox"]
+        width, height = process_kwargs["width"], process_kwargs["height"]
+        fill = process_kwargs["fillvalue"]
+        fill = fill.item() if hasattr(fill, "item") else fill
+        if not utils.same_projection(process_kwargs["projection"], raster_data.projection):
+            raise NotImplementedError(
+                "request projection {} differs from the source's {}: re-projection is outside the "
+                "MI355X raster path".format(process_kwargs["projection"], raster_data.projection))
+        if width == 0 or height == 0:  # sources.py:91-92
+            return np.empty((length, height, width), dtype=dtype)
+        gt = utils.GeoTransform(raster_data.geo_transform)
+        if bbox[0] == bbox[2] or bbox[1] == bbox[3]:
+            # point request: one pixel by floor() of the source pixel coordinate (:94-117)
+            rows, cols = gt.get_indices(((bbox[0], bbox[1]),))
+            i, j = int(rows[0]), int(cols[0])
+            source = raster_data.array
+            count, ny, nx = source.shape
+            result = np.full((count, 1, 1), fill, dtype=dtype)
+            if 0 <= i < ny and 0 <= j < nx:
+                if isinstance(source, DeviceArray):
+                    plane = np.asarray(source)  # tiny sources only; point reads are host logic
+                    result[:, 0, 0] = plane[:, i, j]
+                else:
+                    result[:, 0, 0] = source[:, i, j]
+            return {"values": result[bands[0]:bands[1]], "no_data_value": fill}
+        runtime.require_device()
+        source = raster_data.on_device().band_slice(bands[0], bands[1])
+        values = resample.nearest_warp(source, gt, bbox, height, width, fill)
+        return {"values": values, "no_data_value": fill}
+
+
+class MemorySource(RasterSourceBase):
+    """A raster source that interfaces data from memory (sources.py:157-393).
+
+    The pixel with its top-left corner at [x, y] covers [x, x + dx) and (y - dy, y].
+
+    :param data: the pixel values: (y, x) or (t, y, x) ndarray (or a DeviceArray that
+        already lives in HBM)
+    :param no_data_value: the pixel value that designates 'no data'
+    :param projection: the projection of the pixels ('EPSG:<code>' or WKT text)
+    :param pixel_size: the size of one pixel; (x, y) if they differ
+    :param pixel_origin: the location (x, y) of the pixel with index (0, 0)
+    :param time_first: timestamp of the first frame (ms since 1-1-1970 or datetime)
+    :param time_delta: difference between two frames (ms or timedelta)
+    :param metadata: a list of metadata corresponding to the frames
+    """
+
+    def __init__(self, data, no_data_value, projection, pixel_size, pixel_origin, time_first=0,
+                 time_delta=None, metadata=None):
+        if not isinstance(data, DeviceArray):
+            data = np.asarray(data)
+            if data.dtype == "i8":
+                data = data.astype("i4")  # sources.py:201-203 (a GDAL limitation kept for parity)
+            if data.ndim == 2:
+                data = data[np.newaxis]
+        elif data.ndim == 2:
+            data = data.reshape((1,) + data.shape)
+        if data.ndim != 3:
+            raise ValueError("data should be two- or three-dimensional.")
+        no_data_value = data.dtype.type(no_data_value)
+        projection = utils.get_epsg_or_wkt(projection)
+        if not hasattr(pixel_size, "__iter__"):
+            pixel_size = [pixel_size] * 2
+        else:
+            pixel_size = list(pixel_size)
+            if len(pixel_size) != 2:
+                raise ValueError("pixel_size should have length 2")
+        pixel_size = [float(x) for x in pixel_size]
+        pixel_origin = [float(x) for x in pixel_origin]
+        if len(pixel_origin) != 2:
+            raise ValueError("pixel_origin should have length 2")
+        if isinstance(time_first, datetime):
+            time_first = utils.dt_to_ms(time_first)
+        else:
+            time_first = int(time_first)
+        if isinstance(time_delta, timedelta):
+            time_delta = int(time_delta.total_seconds() * 1000)
+        elif time_delta is None:
+            if data.shape[0] > 1:
+                raise ValueError("time_delta is required for temporal data")
+        else:
+            time_delta = int(time_delta)
+        if metadata is not None:
+            metadata = list(metadata)
+            if len(metadata) != data.shape[0]:
+                raise ValueError("Metadata length should match data length")
+        super().__init__(data, no_data_value, projection, pixel_size, pixel_origin, time_first,
+                         time_delta, metadata)
+
+    @property
+    def token(self):
+        # a device-resident array is identified by its checksum rather than by its bytes
+        try:
+            return self._cached_token
+        except AttributeError:
+            pass
+        if isinstance(self.args[0], DeviceArray):
+            from ..core.graphs import tokenize
+            d = self.args[0]
+            self._cached_token = tokenize(self.get_import_path(), ("device", d.shape, d.dtype.str, d.checksum()),
+                                          *self.args[1:])
+            return self._cached_token
+        return super().token
+
+    data = property(lambda self: self.args[0])
+    no_data_value = property(lambda self: self.args[1])
+    projection = property(lambda self: self.args[2])
+    pixel_size = property(lambda self: self.args[3])
+    pixel_origin = property(lambda self: self.args[4])
+    time_first = property(lambda self: self.args[5])
+    time_delta = property(lambda self: self.args[6])
+    metadata = property(lambda self: self.args[7])
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def fillvalue(self):
+        return self.no_data_value
+
+    @property
+    def geo_transform(self):
+        p, q = self.pixel_origin
+        a, d = self.pixel_size
+        return utils.GeoTransform((p, a, 0, q, 0, -d))
+
+    def _get_extent(self):
+        if not self.data.size:
+            return None
+        bbox = self.geo_transform.get_bbox((0, 0), self.data.shape[1:])
+        return utils.Extent(bbox, self.projection)
+
+    @property
+    def extent(self):
+        extent = self._get_extent()
+        if extent is None:
+            return None
+        return extent.transformed("EPSG:4326").bbox  # needs PROJ unless already WGS84
+
+    @property
+    def geometry(self):
+        extent = self._get_extent()
+        return None if extent is None else extent.as_geometry()
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    @property
+    def period(self):
+        n = len(self)
+        if n == 0:
+            return None
+        first = utc_from_ms_timestamp(self.time_first)
+        if n == 1:
+            return first, first
+        return first, first + (n - 1) * self.timedelta
+
+    @property
+    def timedelta(self):
+        return None if self.time_delta is None else timedelta(milliseconds=self.time_delta)
+
+    @property
+    def temporal(self):
+        return self.time_delta is not None
+
+    def get_sources_and_requests(self, **request):
+        mode = request["mode"]
+        if mode == "meta" and self.metadata is None:
+            return [({"mode": "empty_meta"}, None)]
+        start, stop, band1, band2 = utils.snap_start_stop(
+            request.get("start"), request.get("stop"), utc_from_ms_timestamp(self.time_first),
+            self.timedelta, len(self))
+        if start is None:
+            return [({"mode": "empty_" + mode}, None)]
+        bands = band1, band2 + 1
+        raster_data = RasterData(array=self.data, metadata=self.metadata, geo_transform=self.geo_transform,
+                                 no_data_value=self.no_data_value, projection=self.projection)
+        if mode == "vals":
+            kwargs = {"mode": "vals", "raster_data": raster_data, "bbox": request["bbox"],
+                      "width": request["width"], "height": request["height"],
+                      "projection": request["projection"], "bands": bands, "dtype": self.dtype,
+                      "fillvalue": self.fillvalue}
+        elif mode == "meta":
+            kwargs = {"mode": "meta", "raster_data": raster_data, "bands": bands}
+        elif mode == "time":
+            kwargs = {"mode": "time", "start": start, "delta": self.timedelta or timedelta(0), "bands": bands}
+        else:
+            raise RuntimeError("Unknown mode '{}'".format(mode))
+        return [(kwargs, None)]
+
+
+class SyntheticSource(RasterBlock):
+    """Procedural single-band raster living on the device: pixel (row, col) of the
+    ``shape`` = (H, W) mosaic is ``lo + u * (hi - lo)`` with u = splitmix64-uniform of
+    (seed, row * W + col); every ``lattice`` = (ny, nx)-th pixel is no-data.  Requests must be
+    aligned with the pixel grid (bbox on pixel edges, one cell per pixel)."""
+
+    def __init__(self, shape, dtype, seed, lo, hi, no_data_value, lattice=(0, 0), projection="EPSG:28992",
+                 pixel_size=1.0, pixel_origin=(0.0, 0.0)):
+        shape = tuple(int(s) for s in shape)
+        if len(shape) != 2:
+            raise ValueError("shape should be (height, width)")
+        dtype = np.dtype(dtype).str
+        code_of(dtype)
+        super().__init__(shape, dtype, int(seed), float(lo), float(hi),
+                         np.dtype(dtype).type(no_data_value).item(),
+                         tuple(int(x) for x in lattice), utils.get_epsg_or_wkt(projection),
+                         float(pixel_size), tuple(float(x) for x in pixel_origin))
+
+    shape = property(lambda self: self.args[0])
+    dtype = property(lambda self: np.dtype(self.args[1]))
+    fillvalue = property(lambda self: np.dtype(self.args[1]).type(self.args[5]))
+    projection = property(lambda self: self.args[7])
+    temporal = False
+    timedelta = None
+    period = (RasterBlock.DEFAULT_ORIGIN, RasterBlock.DEFAULT_ORIGIN)
+
+    @property
+    def geo_transform(self):
+        size, (p, q) = self.args[8], self.args[9]
+        return utils.GeoTransform((p, size, 0, q, 0, -size))
+
+    @property
+    def geometry(self):
+        return utils.Extent(self.geo_transform.get_bbox((0, 0), self.shape), self.projection).as_geometry()
+
+    @property
+    def extent(self):
+        return utils.Extent(self.geo_transform.get_bbox((0, 0), self.shape),
+                            self.projection).transformed("EPSG:4326").bbox
+
+    def get_sources_and_requests(self, **request):
+        mode = request["mode"]
+        if mode == "time":
+            return [({"mode": "time"}, None)]
+        if mode == "meta":
+            return [({"mode": "meta"}, None)]
+        size, (p, q) = self.args[8], self.args[9]
+        x1, y1, x2, y2 = request["bbox"]
+        col0, row0 = (x1 - p) / size, (q - y2) / size
+        w, h = request["width"], request["height"]
+        aligned = (col0 == int(col0) and row0 == int(row0) and (x2 - x1) == w * size and (y2 - y1) == h * size)
+        if not aligned or not utils.same_projection(request["projection"], self.projection):
+            raise NotImplementedError("SyntheticSource only serves pixel-aligned same-CRS requests")
+        kwargs = {"mode": "vals", "spec": self.args, "row0": int(row0), "col0": int(col0), "height": h, "width": w}
+        return [(kwargs, None)]
+
+    @staticmethod
+    def process(process_kwargs):
+        mode = process_kwargs["mode"]
+        if mode == "time":
+            return {"time": [RasterBlock.DEFAULT_ORIGIN]}
+        if mode == "meta":
+            return {"meta": [None]}
+        shape, dtype, seed, lo, hi, ndv, lattice = process_kwargs["spec"][:7]
+        dtype = np.dtype(dtype)
+        values = generate_window(shape, dtype, seed, lo, hi, ndv, lattice, process_kwargs["row0"],
+                                 process_kwargs["col0"], process_kwargs["height"], process_kwargs["width"])
+        return {"values": values, "no_data_value": dtype.type(ndv)}
+
+
+def generate_window(shape, dtype, seed, lo, hi, ndv, lattice, row0, col0, height, width):
+    """Window [row0:row0+height, col0:col0+width] of the procedural (H, W) mosaic -> (1, h, w)
+    DeviceArray; pixels outside the mosaic are no-data."""
+    runtime.require_device()
+    dtype = np.dtype(dtype)
+    out = DeviceArray.empty((1, height, width), dtype)
+    runtime.check(runtime.lib().gm_generate(ctypes.c_void_p(out.ptr), code_of(dtype), int(seed), int(row0), int(col0),
+                                int(height), int(width), int(shape[0]), int(shape[1]), float(lo), float(hi),
+                                int(lattice[0]), int(lattice[1]), runtime.scalar_bits(ndv, dtype)), "gm_generate")
+    return out

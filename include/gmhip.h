@@ -254,17 +254,21 @@ int gm_reclassify(const void* in, int in_dtype,
  * K6/K7: resampling of (bands, Hs, Ws) -> (bands, Hd, Wd)
  * ========================================================================== */
 
-/* Nearest neighbour with a separable affine index map (float64):
- *   src_col = floor(col_off + (c + 0.5) * col_scale + eps),  rows likewise;
- *   outside the source -> fill.  Covers the GDAL nearest warp of an axis-aligned
- *   same-CRS request (raster/sources.py:119-149; eps = 1e-10) and SciPy's
- *   affine_transform(order=0) of Smooth's zoom branch (raster/spatial.py:296-305;
- *   center = 0.0 variant, see gm_resample_nearest's `center` argument).
- * finite_to_fill: also map non-finite source values to fill (sources.py:148). */
+/* Nearest neighbour with separable destination->source index maps evaluated in float64.
+ * Per axis (rows: row_params, columns: col_params), for destination index k:
+ *   mode 0 (warp):   src = floor(((p[0] + (k + 0.5) * p[1]) - p[2]) / p[3] + eps)
+ *                    p = {dst origin, dst step, src origin, src step} in world units -- the
+ *                    GDAL nearest warp of an axis-aligned same-CRS request
+ *                    (raster/sources.py:119-149; GDAL's kernel uses eps = 1e-10)
+ *   mode 1 (affine): src = floor(k * p[0] + p[1] + 0.5)
+ *                    SciPy affine_transform(order=0, matrix=diag(z), offset=o) as called by
+ *                    Smooth's zoom branch (raster/spatial.py:296-305); p = {z, o, -, -}
+ * src outside [0, n_src) -> fill.  finite_to_fill: non-finite source values -> fill
+ * (sources.py:148).  row_params / col_params are HOST pointers to 4 doubles. */
 int gm_resample_nearest(const void* src, int dtype, int bands, int hs, int ws,
-                        void* dst, int hd, int wd,
-                        double row_off, double row_scale, double col_off, double col_scale,
-                        double center, double eps, uint64_t fill_bits, int finite_to_fill);
+                        void* dst, int hd, int wd, int mode,
+                        const double* row_params, const double* col_params, double eps,
+                        uint64_t fill_bits, int finite_to_fill);
 
 /* Bilinear (our spec; no reference implementation exists): pixel-centre
  * aligned, edge-clamped, evaluated in float64, rounded once; any tap == ndv or
@@ -280,11 +284,13 @@ int gm_resample_bilinear(const void* src, int dtype, int bands, int hs, int ws,
 int gm_all_equal(const void* in, int dtype, uint64_t value_bits, size_t n, int* result);
 /* out[i] = value */
 int gm_fill(void* out, int dtype, uint64_t value_bits, size_t n);
-/* Synthetic tile: counter-based uniform values in [lo, hi) keyed by (seed, global index),
- * with `ndv` written on the lattice (i / width) % ny == 0 && (i % width) % nx == 0
- * (nx == 0 disables).  Element i of the tile has global index offset + i. */
-int gm_generate(void* out, int dtype, uint64_t seed, uint64_t offset, double lo, double hi,
-                size_t n, uint32_t width, uint32_t lattice_y, uint32_t lattice_x, uint64_t ndv_bits);
+/* Synthetic tile: the window [row0, row0+h) x [col0, col0+w) of a procedural H x W mosaic.
+ * Pixel (r, c) of the mosaic = lo + u * (hi - lo) cast to dtype, u = splitmix64-uniform in [0, 1)
+ * keyed by (seed, r * W + c); `ndv` where r % lattice_y == 0 && c % lattice_x == 0
+ * (lattice_x == 0 disables) and outside the mosaic.  Tiles of any size therefore agree. */
+int gm_generate(void* out, int dtype, uint64_t seed, int64_t row0, int64_t col0, int h, int w,
+                int64_t H, int64_t W, double lo, double hi, uint32_t lattice_y, uint32_t lattice_x,
+                uint64_t ndv_bits);
 /* 64-bit order-independent checksum (sum of mixed 32-bit words) of a device buffer. Synchronous. */
 int gm_checksum(const void* in, size_t bytes, uint64_t* result);
 /* Paste a (bands, th, tw) tile into a (bands, H, W) mosaic at (row0, col0): the device side

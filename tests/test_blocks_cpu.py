@@ -1,0 +1,352 @@
+"""Host logic of the Block layer on the CPU: graph core, attribute/dtype algebra, request
+planning, the fusion pass and full views (numerics through the ``cpu_vm`` test double)."""
+import pickle
+from datetime import datetime, timedelta
+
+import numpy as np
+import pytest
+
+from blocks_util import ArrayLeaf, build_view, leaves_for
+from helpers import assert_result_equal, load_family
+from dask_geomodeling_amd import raster
+from dask_geomodeling_amd import config as gmconfig
+from dask_geomodeling_amd.core import Block, construct, graphs
+from dask_geomodeling_amd.fuse import FusedTask, fuse_graph
+
+ULP = {"Power": 1, "Exp": 3, "Log": 3, "Log10": 3}
+NEEDS_DEVICE = ("Classify", "Reclassify", "FillNoData", "Step", "MaskBelow")
+
+
+def _uses(expr, names):
+    if isinstance(expr, list):
+        return expr[0] in names or any(_uses(x, names) for x in expr[1:])
+    return False
+
+
+def _max_ulp(expr):
+    hits = [v for k, v in ULP.items() if _uses(expr, (k,))]
+    if len(hits) > 1:
+        return 16  # chained transcendental ops (Log(Exp(x))): the per-op ulp bounds compound
+    return max(hits or [0])
+
+
+VIEWS = load_family("views")
+
+
+# ---------------------------------------------------------------------------------
+# graph core (behaviour pinned by the reference's tests/test_core.py)
+# ---------------------------------------------------------------------------------
+class MockBlock(Block):
+    def __init__(self, a, b=None):
+        super().__init__(a, b)
+
+    @staticmethod
+    def process(a, b):
+        return (a, b)
+
+
+class AddOne(Block):
+    calls = 0
+
+    def __init__(self, store):
+        super().__init__(store)
+
+    def get_sources_and_requests(self, **request):
+        AddOne.calls += 1
+        return [(self.args[0], request)]
+
+    @staticmethod
+    def process(x):
+        return x + 1
+
+
+class Const(Block):
+    def __init__(self, value):
+        super().__init__(value)
+
+    def get_sources_and_requests(self, **request):
+        return [(self.args[0], None)]
+
+    @staticmethod
+    def process(v):
+        return v
+
+
+def test_token_deterministic_and_unique():
+    a, b = MockBlock(1, "x"), MockBlock(1, "x")
+    assert a.token == b.token and len(a.token) == 32 and int(a.token, 16) >= 0
+    assert MockBlock(2, "x").token != a.token
+    assert MockBlock(a).token == MockBlock(b).token
+    assert MockBlock(a).token != a.token
+    arr = np.arange(12.0)
+    assert MockBlock(arr).token == MockBlock(arr.copy()).token
+    assert MockBlock(arr).token != MockBlock(arr + 1).token
+    assert a.name == "MockBlock_" + a.token
+
+
+def test_dummy_block():
+    from dask_geomodeling_amd.core import DummyBlock
+    d = DummyBlock("Something_" + "ab" * 16)
+    assert d.token == "ab" * 16 and d.name == "Something_" + "ab" * 16
+
+
+def test_compute_graph_keys_dedup_and_cache():
+    c = Const(5)
+    shared = AddOne(c)
+    view = MockBlock(shared, shared)
+    AddOne.calls = 0
+    graph, name = view.get_compute_graph(mode="x")
+    assert name.startswith("mockblock_") and len(name) == len("mockblock_") + 32
+    assert len(graph) == 3  # shared sub-tree appears once
+    assert AddOne.calls == 1  # second reference hits the cached key
+    assert graphs.compute(graph, name) == (6, 6)
+    assert view.get_data(mode="x") == (6, 6)
+
+
+def test_get_graph_serialize_roundtrip():
+    view = MockBlock(AddOne(Const(3)), "lit")
+    graph, name = view.get_graph(serialize=True)
+    assert graph[name][0].endswith("test_blocks_cpu.MockBlock")
+    clone = Block.from_json(view.to_json())
+    assert clone.token == view.token and clone.get_data(mode="x") == (4, "lit")
+    clone = pickle.loads(pickle.dumps(view))
+    assert clone.token == view.token and clone.get_data() == (4, "lit")
+
+
+def test_construct_validation_and_error_prefix():
+    graph = {"a": (Const, 1), "b": (AddOne, "a"), "bad": (raster.Add, "a", 2)}
+    assert construct(graph, "b").get_data() == 2
+    with pytest.raises(TypeError, match="^bad: "):
+        construct(graph, "bad")
+    with pytest.raises(TypeError):
+        construct({"x": (int, 1)}, "x")
+    # without validation the token comes from the key
+    key = "Const_" + "0f" * 16
+    blk = construct({key: (Const, 1)}, key, validate=False)
+    assert blk.token == "0f" * 16
+
+
+def test_get_sync_deep_chain_and_lists():
+    graph = {"k0": 0}
+    for i in range(1, 3000):
+        graph["k%d" % i] = ((lambda x: x + 1), "k%d" % (i - 1))
+    assert graphs.get_sync(graph, ["k2999"]) == [2999]
+    graph = {"a": 1, "b": 2, "s": (sum, ["a", "b", 10])}
+    assert graphs.get_sync(graph, "s") == 13
+
+
+# ---------------------------------------------------------------------------------
+# dtype / fillvalue algebra against the reference (golden 'dtypes')
+# ---------------------------------------------------------------------------------
+def test_dtype_rules_match_reference():
+    cases = {c["id"]: c["expect"] for c in load_family("dtypes")}
+    for cls_name, da, (kind, ob), order, want, fill in cases["dtype_math"]:
+        a = ArrayLeaf("a", np.dtype(da).str, 0)
+        b = ArrayLeaf("b", np.dtype(ob).str, 0) if kind == "r" else ob
+        cls = getattr(raster, cls_name)
+        try:
+            blk = cls(a, b) if order == 0 else cls(b, a)
+            got, got_fill = blk.dtype.str, blk.fillvalue
+        except Exception as e:
+            got, got_fill = "ERR:" + type(e).__name__, None
+        assert got == want, (cls_name, da, kind, ob, order)
+        assert got_fill == fill and type(got_fill) is type(fill)
+    for value, dt, fill in cases["dtype_mask"]:
+        blk = raster.Mask(ArrayLeaf("a", "<f4", 0.0), value)
+        assert blk.dtype.str == dt and blk.fillvalue == fill
+    for n, dt, fill in cases["dtype_classify"]:
+        try:
+            blk = raster.Classify(ArrayLeaf("a", "<f4", 0.0), list(range(n)))
+            got = [blk.dtype.str, blk.fillvalue]
+        except Exception as e:
+            got = ["ERR:" + type(e).__name__, None]
+        assert got == [dt, fill], n
+
+
+def test_reclassify_init_errors_match_reference():
+    want = [c for c in load_family("reclassify") if c["id"] == "rcl_init_errors"][0]["expect"]
+    got = []
+    for args in ((ArrayLeaf("p", "<f4", 1.0), [[7.0, 1000]], False),
+                 (ArrayLeaf("p", "|u1", 255), [[7.4, 1000]], False),
+                 (ArrayLeaf("p", "|u1", 255), [[[7, 1000]], [1, 100]], False),
+                 (ArrayLeaf("p", "|u1", 255), [[7, 1], [7, 2]], False),
+                 (ArrayLeaf("p", "|u1", 255), [[7, 1]], 1)):
+        try:
+            raster.Reclassify(*args)
+            got.append(None)
+        except Exception as e:
+            got.append(type(e).__name__)
+    assert got == want
+
+
+def test_constructor_type_errors():
+    a = ArrayLeaf("a", "<f4", 0.0)
+    b = ArrayLeaf("b", "|b1", None)
+    with pytest.raises(TypeError):
+        raster.Add(a, "x")
+    with pytest.raises(TypeError):
+        raster.And(a, b)
+    with pytest.raises(TypeError):
+        raster.Invert(a)
+    with pytest.raises(TypeError):
+        raster.IsData(b)
+    with pytest.raises(TypeError):
+        raster.Mask(a, "1")
+    with pytest.raises(TypeError):
+        raster.Classify(a, 5)
+    with pytest.raises(TypeError):
+        raster.Classify(a, [3, 1, 2])
+    assert raster.Power(a, -2).args[1] == -2.0 and isinstance(raster.Power(a, -2).args[1], float)
+
+
+# ---------------------------------------------------------------------------------
+# operator DSL
+# ---------------------------------------------------------------------------------
+def test_operator_dsl():
+    a = ArrayLeaf("a", "<f4", 0.0)
+    b = ArrayLeaf("b", "|b1", None)
+    pairs = [(a + 1, raster.Add), (a - 1, raster.Subtract), (a * 2, raster.Multiply), (a / 2, raster.Divide),
+             (a ** 2, raster.Power), (-a, raster.Multiply), (a == 1, raster.Equal), (a != 1, raster.NotEqual),
+             (a > 1, raster.Greater), (a >= 1, raster.GreaterEqual), (a < 1, raster.Less),
+             (a <= 1, raster.LessEqual), (~b, raster.Invert), (b & b, raster.And), (b | b, raster.Or),
+             (b ^ b, raster.Xor)]
+    for blk, cls in pairs:
+        assert type(blk) is cls
+    assert (-a).args[1] == -1
+
+
+# ---------------------------------------------------------------------------------
+# fusion pass structure
+# ---------------------------------------------------------------------------------
+REQ = dict(mode="vals", bbox=(0.0, 0.0, 48.0, 32.0), width=48, height=32, projection="EPSG:28992")
+
+
+def test_fusion_collapses_canonical_chain():
+    case = VIEWS[0]
+    view = build_view(case["expr"], leaves_for(case))
+    graph, name = view.get_compute_graph(**REQ)
+    assert len(graph) == case["n_keys"] and name.startswith(case["key_prefix"])
+    fused = fuse_graph(graph, name)
+    tasks = [v[0] for v in fused.values() if isinstance(v[0], FusedTask)]
+    assert len(tasks) == 1 and len(fused) == 3  # two leaves + one fused launch
+    assert [tasks[0].members[k][0].gm_op for k in tasks[0].order] == ["add", "multiply", "subtract", "add", "clip"]
+    assert len(fused[name]) == 3  # (FusedTask, leaf A, leaf B): every leaf is read once
+
+
+def test_fusion_respects_non_fusable_consumers():
+    a = ArrayLeaf("va", "<i4", 2147483647)
+    mid = raster.Add(a, 1)
+    view = raster.Mask(raster.Reclassify(mid * 2, [[1, 2]]), 1)
+    graph, name = view.get_compute_graph(**REQ)
+    fused = fuse_graph(graph, name)
+    groups = [v[0] for v in fused.values() if isinstance(v[0], FusedTask)]
+    assert len(groups) == 1  # (a + 1) * 2 ; Reclassify and the lone Mask stay as they are
+    assert sum(1 for v in fused.values() if getattr(v[0], "__name__", "") == "process") >= 1
+
+
+# ---------------------------------------------------------------------------------
+# whole views, fused and op-by-op, against the reference's results
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("fuse", [True, False], ids=["fused", "unfused"])
+@pytest.mark.parametrize("case", [c for c in VIEWS if not _uses(c["expr"], NEEDS_DEVICE)],
+                         ids=lambda c: c["id"])
+def test_views_against_reference(cpu_vm, monkeypatch, case, fuse):
+    from dask_geomodeling_amd.raster import devops
+    monkeypatch.setattr(devops, "all_equal", lambda values, ndv: bool(np.all(np.asarray(values) == ndv)))
+    view = build_view(case["expr"], leaves_for(case))
+    assert view.dtype.str == case["dtype"]
+    assert view.fillvalue == case["fillvalue"]
+    with gmconfig.config.set({"geomodeling.fuse": fuse}):
+        out = view.get_data(**case["request"])
+    assert_result_equal(out, case["expect"], _max_ulp(case["expr"]), case["id"])
+
+
+def test_time_and_meta_requests_bypass_numerics(cpu_vm):
+    case = VIEWS[0]
+    view = build_view(case["expr"], leaves_for(case))
+    assert view.get_data(mode="time") == {"time": [datetime(1970, 1, 1)]}
+    assert view.get_data(mode="meta") == {"meta": [None]}
+
+
+# ---------------------------------------------------------------------------------
+# MemorySource host logic (attributes, request planning, time/meta/point requests)
+# ---------------------------------------------------------------------------------
+@pytest.fixture
+def source():
+    return raster.MemorySource(
+        data=[np.full((10, 10), 1, "u1"), np.full((10, 10), 7, "u1"), np.full((10, 10), 255, "u1")],
+        no_data_value=255, projection="EPSG:28992", pixel_size=0.5, pixel_origin=(135000, 456000),
+        time_first=datetime(2000, 1, 1), time_delta=timedelta(hours=1),
+        metadata=["Testmeta for band {}".format(i) for i in range(3)])
+
+
+def test_memorysource_attributes(source):
+    assert source.dtype == np.uint8 and source.fillvalue == np.uint8(255) and len(source) == 3
+    assert source.period == (datetime(2000, 1, 1), datetime(2000, 1, 1, 2))
+    assert source.timedelta == timedelta(hours=1) and source.temporal
+    assert tuple(source.geo_transform) == (135000.0, 0.5, 0, 456000.0, 0, -0.5)
+    assert source.geometry.GetEnvelope() == (135000.0, 135005.0, 455995.0, 456000.0)
+    assert source.projection == "EPSG:28992"
+    i8 = raster.MemorySource(np.ones((2, 2), "i8"), 5, "EPSG:28992", 1, (0, 0))
+    assert i8.dtype == np.int32  # int64 is narrowed like the reference does (sources.py:201-203)
+    with pytest.raises(ValueError):
+        raster.MemorySource(np.ones((2, 2, 2)), 0, "EPSG:28992", 1, (0, 0))  # temporal without delta
+
+
+def test_memorysource_time_meta_point(source):
+    t0 = datetime(2000, 1, 1)
+    assert source.get_data(mode="time")["time"] == [t0 + timedelta(hours=2)]
+    assert source.get_data(mode="time", start=t0, stop=t0 + timedelta(hours=5))["time"] == \
+        [t0 + timedelta(hours=i) for i in range(3)]
+    assert source.get_data(mode="time", start=t0 + timedelta(minutes=10),
+                           stop=t0 + timedelta(minutes=50))["time"] == []
+    assert source.get_data(mode="meta", start=t0, stop=t0 + timedelta(hours=5))["meta"] == \
+        ["Testmeta for band {}".format(i) for i in range(3)]
+    point = dict(mode="vals", start=t0, stop=t0 + timedelta(hours=3), width=1, height=1,
+                 bbox=(135001, 455999, 135001, 455999), projection="EPSG:28992")
+    assert source.get_data(**point)["values"].tolist() == [[[1]], [[7]], [[255]]]
+    point["bbox"] = (134999, 455999, 134999, 455999)
+    assert source.get_data(**point)["values"].tolist() == [[[255]], [[255]], [[255]]]
+    empty = raster.MemorySource(np.empty((0, 0, 0), "u1"), 255, "EPSG:28992", 0.5, (0, 0))
+    assert empty.period is None and empty.get_data(mode="vals", bbox=(0, 0, 1, 1), width=1, height=1,
+                                                    projection="EPSG:28992") is None
+
+
+def test_reprojection_is_refused(source):
+    with pytest.raises(NotImplementedError):
+        source.get_data(mode="vals", bbox=(0, 0, 1, 1), width=2, height=2, projection="EPSG:3857",
+                        start=datetime(2000, 1, 1))
+
+
+# ---------------------------------------------------------------------------------
+# RasterTiler request planning against the reference (golden 'tiler')
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [c for c in load_family("tiler") if c["op"] == "tiler_requests"],
+                         ids=lambda c: c["id"])
+def test_tiler_requests(case):
+    store = ArrayLeaf("p", "<f4", 3.4028234663852886e+38)
+    blk = raster.RasterTiler(store, case["tile_size"])
+    got = blk.get_sources_and_requests(**case["request"])
+    want = case["expect"]
+    assert len(got) == len(want)
+    for (src, req), (kind, payload) in zip(got, want):
+        if kind == "kwargs":
+            assert np.dtype(src["dtype"]).str == payload["dtype"] and src["fillvalue"] == payload["fillvalue"]
+            for k in ("shape_yx", "count_xy", "tilesize_xy"):
+                assert tuple(src[k]) == tuple(payload[k])
+        elif kind == "none":
+            assert src is None and req is None
+        else:
+            assert src is store
+            assert tuple(float(x) for x in req["bbox"]) == tuple(payload["bbox"])
+            assert (req["width"], req["height"]) == (payload["width"], payload["height"])
+
+
+def test_tiler_validation():
+    store = ArrayLeaf("p", "<f4", 0.0)
+    assert raster.RasterTiler(store, 10).tile_size == [10, 10]
+    for bad in ("a", 0, [1], [2, 3, 3]):
+        with pytest.raises((ValueError, TypeError)):
+            raster.RasterTiler(store, bad)
+    with pytest.raises(TypeError):
+        raster.RasterTiler("a", 10)

@@ -114,3 +114,182 @@ def test_reclassify_golden(gpu, case):
         pytest.skip("reference raises %s" % case["raises"])
     out = tables.reclassify_process(*case["args"])
     assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+# ---- resampling -------------------------------------------------------------------
+GT = (136700.0, 5.0, 0, 455800.0, 0, -5.0)
+
+
+@pytest.mark.parametrize("bbox,h,w", [
+    ((136700, 455795, 136705, 455800), 1, 1), ((136700, 455790, 136705, 455795), 1, 1),
+    ((136695, 455795, 136700, 455800), 1, 1), ((136700, 455795, 136710, 455800), 1, 2),
+    ((136700, 455790, 136705, 455800), 2, 1), ((136700, 455795, 136710, 455800), 2, 4),
+    ((136700, 455795, 136705, 455800), 5, 5),
+])
+def test_nearest_reference_kats(gpu, bbox, h, w):
+    """The reference's own expectations for the GDAL nearest warp (tests/test_raster_sources.py:
+    96-161): one 5 m pixel of value 5, no-data 255."""
+    from dask_geomodeling_amd.raster import resample
+    pix = np.full((1, 1, 1), 5, dtype="u1")
+    got = np.asarray(resample.nearest_warp(pix, GT, bbox, h, w, 255))
+    assert_values_equal(got, O.nearest_warp(pix, GT, bbox, h, w, 255))
+
+
+@pytest.mark.parametrize("dt", ["u1", "i2", "i4", "i8", "f4", "f8"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_nearest_vs_oracle(gpu, dt, seed):
+    from dask_geomodeling_amd.raster import resample
+    rng = np.random.default_rng(seed)
+    bands, hs, ws = int(rng.integers(1, 4)), int(rng.integers(5, 90)), int(rng.integers(5, 90))
+    src = (rng.random((bands, hs, ws)) * 200).astype(dt)
+    if np.dtype(dt).kind == "f":
+        src[0, 1, 1] = np.nan
+    px = float(rng.choice([0.5, 1.0, 2.5]))
+    gt = (1000.0, px, 0, 5000.0, 0, -px)
+    for _ in range(6):
+        x1 = 1000.0 + float(rng.integers(-20, ws)) * px * float(rng.choice([1.0, 0.5, 0.37]))
+        y2 = 5000.0 - float(rng.integers(-20, hs)) * px * float(rng.choice([1.0, 0.5, 0.37]))
+        w, h = int(rng.integers(1, 130)), int(rng.integers(1, 70))
+        cell = px * float(rng.choice([1.0, 0.5, 2.0, 0.3, 1.7]))
+        bbox = (x1, y2 - h * cell, x1 + w * cell, y2)
+        fill = 255 if np.dtype(dt).kind != "f" else float(np.finfo(dt).max)
+        got = np.asarray(resample.nearest_warp(src, gt, bbox, h, w, fill))
+        assert_values_equal(got, O.nearest_warp(src, gt, bbox, h, w, fill), 0, "%s %s" % (dt, bbox))
+
+
+@pytest.mark.parametrize("case", load_family("smoothzoom"), ids=lambda c: c["id"])
+def test_affine_nearest_golden(gpu, case):
+    from dask_geomodeling_amd.raster import resample
+    values, zoom, offset = case["args"]
+    got = np.asarray(resample.affine_nearest(values, zoom, offset))
+    assert_values_equal(got, case["expect"], 0, case["id"])
+
+
+@pytest.mark.parametrize("dt", ["f4", "f8"])
+@pytest.mark.parametrize("shape", [(16, 20, 32, 40), (9, 7, 27, 21), (10, 10, 15, 15), (8, 8, 8, 8),
+                                   (12, 6, 5, 4), (64, 300, 128, 600), (500, 40, 37, 91), (1, 1, 4, 4)])
+def test_bilinear_vs_oracle(gpu, dt, shape):
+    """Own spec (reference has no bilinear: parity unpinned).  Tolerance: 1 ulp (north_star)."""
+    from dask_geomodeling_amd.raster import resample
+    hs, ws, hd, wd = shape
+    rng = np.random.default_rng(hs * 1000 + ws)
+    src = (rng.random((2, hs, ws)) * 100).astype(dt)
+    ndv = np.dtype(dt).type(np.finfo(dt).max)
+    if hs > 4 and ws > 4:
+        src[0, 2, 3] = ndv
+        src[1, hs - 1, ws - 1] = np.nan
+    got = np.asarray(resample.bilinear(src, hd, wd, ndv))
+    assert_values_equal(got, O.bilinear_resample(src, hd, wd, ndv), 1, "bilinear %s %s" % (dt, shape))
+
+
+# ---- whole views through Blocks, fusion pass and MemorySource ------------------------
+from blocks_util import build_view, leaves_for  # noqa: E402
+from dask_geomodeling_amd import config as gmconfig  # noqa: E402
+from dask_geomodeling_amd import raster  # noqa: E402
+
+VIEW_ULP = {"Power": 1, "Exp": 3, "Log": 3, "Log10": 3}
+NOT_YET = ("FillNoData", "Step", "MaskBelow")
+
+
+def _uses(expr, names):
+    if isinstance(expr, list):
+        return expr[0] in names or any(_uses(x, names) for x in expr[1:])
+    return False
+
+
+def _view_ulp(expr):
+    hits = [v for k, v in VIEW_ULP.items() if _uses(expr, (k,))]
+    return 16 if len(hits) > 1 else max(hits or [0])
+
+
+@pytest.mark.parametrize("fuse", [True, False], ids=["fused", "unfused"])
+@pytest.mark.parametrize("case", [c for c in load_family("views") if not _uses(c["expr"], NOT_YET)],
+                         ids=lambda c: c["id"])
+def test_views_golden(gpu, case, fuse):
+    view = build_view(case["expr"], leaves_for(case, kind="memory"))
+    assert view.dtype.str == case["dtype"] and view.fillvalue == case["fillvalue"]
+    with gmconfig.config.set({"geomodeling.fuse": fuse}):
+        out = view.get_data(**case["request"])
+    if out is not None and "values" in out:
+        assert isinstance(out["values"], np.ndarray)  # get_data hands back host arrays
+    assert_result_equal(out, case["expect"], _view_ulp(case["expr"]), case["id"])
+
+
+@pytest.mark.parametrize("case", [c for c in load_family("tiler") if c["op"] == "tiler_process"],
+                         ids=lambda c: c["id"])
+def test_tiler_process_golden(gpu, case):
+    kw = dict(case["kwargs"])
+    kw["dtype"] = np.dtype(kw["dtype"])
+    out = raster.RasterTiler.process(kw, *case["tiles"])
+    out = dict(out, values=np.asarray(out["values"]))
+    assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.fixture
+def kat_source():
+    from datetime import datetime, timedelta
+    return raster.MemorySource(
+        data=[np.full((10, 10), 1, "u1"), np.full((10, 10), 7, "u1"), np.full((10, 10), 255, "u1")],
+        no_data_value=255, projection="EPSG:28992", pixel_size=0.5, pixel_origin=(135000, 456000),
+        time_first=datetime(2000, 1, 1), time_delta=timedelta(hours=1))
+
+
+@pytest.mark.parametrize("off", [(0, -5, 5, 0), (0, -5, 6, 0), (0, -6, 5, 0), (-1, -5, 5, 0), (0, -5, 5, 1)])
+def test_tiled_equals_untiled(gpu, kat_source, off):
+    """tests/test_raster_parallelize.py:87-116 of the reference."""
+    src = kat_source
+    block = raster.RasterTiler(src, 2)
+    ox, oy = src.pixel_origin
+    request = dict(mode="vals", bbox=(ox + off[0], oy + off[1], ox + off[2], oy + off[3]),
+                   width=(off[2] - off[0]) * 2, height=(off[3] - off[1]) * 2, projection="EPSG:28992",
+                   start=src.period[0])
+    actual, expected = block.get_data(**request), src.get_data(**request)
+    assert_values_equal(actual["values"], expected["values"])
+    assert actual["no_data_value"] == expected["no_data_value"]
+    want = O.nearest_warp(src.data[:1], src.geo_transform, request["bbox"], request["height"],
+                          request["width"], 255)
+    assert_values_equal(expected["values"], want)
+
+
+def test_reference_kats_through_blocks(gpu, kat_source):
+    """Known answers of the reference's own tests, through get_data on the device:
+    tests/test_raster.py:369-400, 552-564, 1356-1395, 1447-1467; tests/test_raster_misc.py:134-254."""
+    from datetime import datetime, timedelta
+    src = kat_source
+    req = dict(mode="vals", start=datetime(2000, 1, 1), stop=datetime(2000, 1, 1, 3), width=4, height=6,
+               bbox=(135000, 456000 - 3, 135000 + 2, 456000), projection="EPSG:28992")
+
+    def first(view):
+        return view.get_data(**req)["values"][:, 0, 0].tolist()
+
+    n32 = 2147483647
+    assert first(src + 5) == [6, 12, n32]
+    assert first(src - 1) == [0, 6, n32]
+    assert first(src * 10) == [10, 70, n32]
+    assert first(-src) == [-1, -7, n32]
+    out = (src / 10).get_data(**req)
+    assert out["values"].dtype == np.float32 and out["values"][0, 0, 0] == np.float32(0.1)
+    assert first(src ** 2)[:2] == [1, 49]
+    assert (src ** 0.5).get_data(**req)["values"][1, 0, 0] == np.float32(7 ** 0.5)
+    assert first(raster.Clip(src, src == 7)) == [255, 7, 255]
+    assert first(raster.Clip(src, src)) == [1, 7, 255]
+    assert first(raster.Mask(src, 8)) == [8, 8, 0]
+    assert first(raster.Mask(src, 0)) == [0, 0, 1]
+    assert raster.Mask(src, 1000).get_data(**req)["values"].dtype == np.uint16
+    assert first(raster.Classify(src, [3, 8])) == [0, 1, 255]
+    assert first(raster.Reclassify(src, [[7, 1000]])) == [1, 1000, np.iinfo("i8").max]
+    assert first(raster.Reclassify(src, [[7, 1000]], select=True)) == [np.iinfo("i8").max, 1000, np.iinfo("i8").max]
+    assert first(raster.Reclassify(src, [[7, 8.2]])) == [1.0, 8.2, np.finfo("f8").max]
+    assert first(raster.Reclassify(src == 7, [[True, 1000]])) == [0, 1000, 0]
+    assert first(raster.Reclassify(src * 1, [[7, 1000]])) == [1, 1000, np.iinfo("i8").max]
+    assert first(src == 7) == [False, True, False]
+    assert first(src != 7) == [True, False, True]
+    assert first((src > 1) & (src < 9)) == [False, True, False]
+    # no-data on either side of a Divide -> everything no-data (tests/test_raster.py:552-564)
+    nodata = raster.MemorySource(np.full((3, 10, 10), 255, "u1"), 255, "EPSG:28992", 0.5, (135000, 456000),
+                                 time_first=datetime(2000, 1, 1), time_delta=timedelta(hours=1))
+    fmax = float(np.finfo("f4").max)
+    assert first(src / nodata) == [fmax] * 3 and first(nodata / src) == [fmax] * 3
+    # zoom-in of the source (nearest), tests/test_raster_sources.py:140-161 pattern
+    zoom = dict(req, width=8, height=12)
+    assert (src.get_data(**zoom)["values"][0] == 1).all()

@@ -33,10 +33,8 @@ def single_add(leaves):
 
 
 def gen(shape, seed):
-    arr = DeviceArray.empty(shape, "f4")
-    runtime.check(runtime.lib().gm_generate(ctypes.c_void_p(arr.ptr), 9, seed, 0, 0.0, 100.0, arr.size,
-                                            shape[2], 97, 89, runtime.scalar_bits(F32MAX, "f4")), "gm_generate")
-    return arr
+    from dask_geomodeling_amd.raster.sources import generate_window
+    return generate_window(shape[1:], "f4", seed, 0.0, 100.0, F32MAX, (97, 89), 0, 0, shape[1], shape[2])
 
 
 def main():
