@@ -206,7 +206,9 @@ def _view_ulp(expr):
 @pytest.mark.parametrize("case", [c for c in load_family("views") if not _uses(c["expr"], NOT_YET)],
                          ids=lambda c: c["id"])
 def test_views_golden(gpu, case, fuse):
-    view = build_view(case["expr"], leaves_for(case, kind="memory"))
+    # leaves hand the golden arrays over unchanged (a MemorySource would first map NaN/inf to
+    # no-data like the reference's source does, sources.py:148 -- covered by the tests below)
+    view = build_view(case["expr"], leaves_for(case, kind="array"))
     assert view.dtype.str == case["dtype"] and view.fillvalue == case["fillvalue"]
     with gmconfig.config.set({"geomodeling.fuse": fuse}):
         out = view.get_data(**case["request"])
@@ -270,7 +272,11 @@ def test_reference_kats_through_blocks(gpu, kat_source):
     out = (src / 10).get_data(**req)
     assert out["values"].dtype == np.float32 and out["values"][0, 0, 0] == np.float32(0.1)
     assert first(src ** 2)[:2] == [1, 49]
-    assert (src ** 0.5).get_data(**req)["values"][1, 0, 0] == np.float32(7 ** 0.5)
+    root = (src ** 0.5).get_data(**req)["values"]  # u8 ** python float -> float64, like the reference
+    assert root.dtype == np.float64 and abs(root[1, 0, 0] - np.sqrt(7)) <= np.spacing(np.sqrt(7))
+    inv = (src ** -1).get_data(**req)["values"]
+    assert inv.dtype == np.float64 and abs(inv[1, 0, 0] - 1 / 7) <= np.spacing(1 / 7)
+    assert first(src ** 0)[:2] == [1, 1]
     assert first(raster.Clip(src, src == 7)) == [255, 7, 255]
     assert first(raster.Clip(src, src)) == [1, 7, 255]
     assert first(raster.Mask(src, 8)) == [8, 8, 0]
@@ -293,3 +299,32 @@ def test_reference_kats_through_blocks(gpu, kat_source):
     # zoom-in of the source (nearest), tests/test_raster_sources.py:140-161 pattern
     zoom = dict(req, width=8, height=12)
     assert (src.get_data(**zoom)["values"][0] == 1).all()
+
+
+def test_canonical_chain_on_memorysources(gpu):
+    """cfg 1/2 shape: MemorySource leaves (NaN/inf become no-data at the source, sources.py:148),
+    fused 5-op chain, bit-exact against the oracle applied to the same source tiles."""
+    rng = np.random.default_rng(0)
+    fmax = np.float32(np.finfo("f4").max)
+    a = (rng.random((256, 256)) * 100).astype("f4")
+    b = (rng.random((256, 256)) * 100).astype("f4")
+    a[::97, ::89] = fmax
+    a[3, 3], b[7, 7], b[9, 9] = np.nan, np.inf, fmax / 2
+    a[9, 9] = fmax / 2
+    A = raster.MemorySource(a, fmax, "EPSG:28992", 1.0, (0, 256))
+    B = raster.MemorySource(b, fmax, "EPSG:28992", 1.0, (0, 256))
+    view = raster.Clip(raster.Add(raster.Subtract(raster.Multiply(raster.Add(A, B), 2.5), B), 1.5), A)
+    req = dict(mode="vals", bbox=(0, 0, 256, 256), width=256, height=256, projection="EPSG:28992")
+    got = view.get_data(**req)
+    ta = {"values": O.nearest_warp(a[None], A.geo_transform, req["bbox"], 256, 256, fmax), "no_data_value": fmax}
+    tb = {"values": O.nearest_warp(b[None], B.geo_transform, req["bbox"], 256, 256, fmax), "no_data_value": fmax}
+    kw = {"dtype": "float32", "fillvalue": float(fmax)}
+    x = O.math_process("add", kw, ta, tb)
+    x = O.math_process("multiply", kw, x, 2.5)
+    x = O.math_process("subtract", kw, x, tb)
+    x = O.math_process("add", kw, x, 1.5)
+    want = O.clip_process(x, ta)
+    assert_result_equal(got, want, 0, "canonical chain")
+    # cfg 1: Add(src, src) and Add(src, 2.5) on one 256x256 tile
+    for view, args in ((raster.Add(A, A), (ta, ta)), (raster.Add(A, 2.5), (ta, 2.5))):
+        assert_result_equal(view.get_data(**req), O.math_process("add", kw, *args), 0, "cfg1")
