@@ -57,6 +57,15 @@ __global__ __launch_bounds__(256) void all_equal_kernel(const T* in, T value, un
   if (__ballot(!ok) != 0ull && (threadIdx.x & 63) == 0) *flag = 1;
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void all_finite_kernel(const T* in, unsigned long long n, int* flag) {
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  bool ok = true;
+  for (; i < n; i += stride) ok = ok & isfinite(in[i]);
+  if (__ballot(!ok) != 0ull && (threadIdx.x & 63) == 0) *flag = 1;
+}
+
 __global__ __launch_bounds__(256) void checksum_kernel(const unsigned int* words, unsigned long long n_words,
                                                        const unsigned char* tail, unsigned n_tail,
                                                        unsigned long long* result) {
@@ -200,6 +209,34 @@ int gm_all_equal(const void* in, int dtype, uint64_t value_bits, size_t n, int* 
   gm_free(flag);
   if (e != hipSuccess) return gm::hip_fail(e, "gm_all_equal");
   *result = mismatch ? 0 : 1;
+  return GM_OK;
+}
+
+int gm_all_finite(const void* in, int dtype, size_t n, int* result) {
+  if (!result) return gm::fail(GM_ERR_INVALID, "null pointer");
+  *result = 1;
+  if (n == 0 || (dtype != GM_F32 && dtype != GM_F64)) return GM_OK;  // integers are always finite
+  if (!in) return gm::fail(GM_ERR_INVALID, "null pointer");
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  int* flag = nullptr;
+  int rc = gm_malloc((void**)&flag, sizeof(int));
+  if (rc) return rc;
+  hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+  dim3 grid(grid_for(n, gm::current_cu_count()));
+  if (e == hipSuccess) {
+    if (dtype == GM_F32)
+      hipLaunchKernelGGL(all_finite_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (unsigned long long)n, flag);
+    else
+      hipLaunchKernelGGL(all_finite_kernel<double>, grid, dim3(256), 0, s, (const double*)in, (unsigned long long)n, flag);
+    e = hipGetLastError();
+  }
+  int bad = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  gm_free(flag);
+  if (e != hipSuccess) return gm::hip_fail(e, "gm_all_finite");
+  *result = bad ? 0 : 1;
   return GM_OK;
 }
 

@@ -48,6 +48,8 @@ class FusedTask(object):
         self.order = order          # member keys, producers first
         self.root = root
         self.leaf_keys = leaf_keys  # keys (outside the group) the call arguments correspond to
+        self._plans = {}            # tile signature -> (compiled program, slot binding, shape)
+        self._leaf_set = set(leaf_keys)
         self.__name__ = "fused_%d_ops" % len(order)
 
     def __repr__(self):
@@ -69,20 +71,47 @@ class FusedTask(object):
             return False
 
     def __call__(self, *leaf_values):
+        # fast path: the same kinds of tiles as last time -> the cached program, one launch
+        try:
+            sig = tuple((v["values"].dtype.num, v["values"].shape, type(v.get("no_data_value")),
+                         v.get("no_data_value")) for v in leaf_values)
+            hit = self._plans.get(sig)
+        except (TypeError, KeyError, AttributeError):
+            sig = hit = None
+        if hit is not None:
+            compiled, binding, shape = hit
+            tiles = [leaf_values[ref]["values"] if kind == 0 else ref for kind, ref in binding]
+            values = P.launch(compiled, [P.as_device(t) for t in tiles], shape)
+            return {"values": values, "no_data_value": compiled.out_ndv}
+
         self._leaf_set = set(self.leaf_keys)
         env = dict(zip(self.leaf_keys, leaf_values))
         if not all(isinstance(v, dict) and "values" in v for v in leaf_values):
             return self._run_unfused(env)
-        nodes = {}
-        for key, data in env.items():
-            nodes[key] = P.Leaf(None, data["values"].dtype, data.get("no_data_value"), values=data["values"])
+        nodes, arg_of = {}, {}
+        for i, (key, data) in enumerate(env.items()):
+            leaf = P.Leaf(None, data["values"].dtype, data.get("no_data_value"), values=data["values"])
+            nodes[key] = leaf
+            arg_of[id(leaf)] = i
         try:
             for key in self.order:
                 nodes[key] = self._node(key, nodes)
         except _NotFusable:
             return self._run_unfused(env)
-        values, ndv = P.evaluate(nodes[self.root])
-        return {"values": values, "no_data_value": ndv}
+        root = nodes[self.root]
+        try:
+            compiled, leaves, shape = P.plan(root)
+        except P.FusionLimit:
+            values, ndv = P.evaluate(root)  # several launches: sub-trees first
+            return {"values": values, "no_data_value": ndv}
+        if sig is not None:
+            # which call argument (or constant ndarray operand, uploaded once) feeds each slot
+            binding = [(0, arg_of[id(l)]) if id(l) in arg_of else (1, l.values) for l in leaves]
+            if len(self._plans) > 64:
+                self._plans.clear()
+            self._plans[sig] = (compiled, binding, shape)
+        values = P.launch(compiled, [leaf.values for leaf in leaves], shape)
+        return {"values": values, "no_data_value": compiled.out_ndv}
 
     def _node(self, key, nodes):
         task = self.members[key]

@@ -617,12 +617,9 @@ def _collect_leaves(root):
     return out
 
 
-def evaluate(root):
-    """Evaluate an expression whose Leafs carry their tiles -> (DeviceArray, ndv).
-
-    One launch when the tree fits one program; otherwise (no common register class, too
-    many inputs / steps / temps) sub-trees are evaluated first and fed back as tiles."""
-    runtime.require_device()
+def plan(root):
+    """Bind slots/broadcast flags of the tree's leaves and compile it -> (compiled, leaves, shape).
+    Raises FusionLimit when the tree does not fit one program."""
     leaves = _collect_leaves(root)
     if not leaves:
         raise TypeError("at least one raster operand is required")
@@ -636,8 +633,17 @@ def evaluate(root):
             raise NotImplementedError("operand shapes %s and %s differ (only equal shapes or single-element "
                                       "operands are supported on the device)" % (shape, leaf.values.shape))
         leaf.slot, leaf.broadcast = slot, (size == 1 and n != 1)
+    return compile_cached(root, len(leaves)), leaves, shape
+
+
+def evaluate(root):
+    """Evaluate an expression whose Leafs carry their tiles -> (DeviceArray, ndv).
+
+    One launch when the tree fits one program; otherwise (no common register class, too
+    many inputs / steps / temps) sub-trees are evaluated first and fed back as tiles."""
+    runtime.require_device()
     try:
-        compiled = compile_cached(root, len(leaves))
+        compiled, leaves, shape = plan(root)
     except FusionLimit:
         if not isinstance(root, Op) or all(isinstance(a, (Leaf, Lit)) for a in root.args):
             raise NotImplementedError("expression '%s' does not fit the device program format"

@@ -73,6 +73,7 @@ def _declare(L):
         "gm_event_sync": [vp], "gm_event_elapsed_ms": [vp, vp, c.POINTER(c.c_float)],
         "gm_all_equal": [vp, i32, u64, sz, c.POINTER(i32)],
         "gm_fill": [vp, i32, u64, sz],
+        "gm_all_finite": [vp, i32, sz, c.POINTER(i32)],
         "gm_generate": [vp, i32, u64, c.c_int64, c.c_int64, i32, i32, c.c_int64, c.c_int64, c.c_double,
                         c.c_double, c.c_uint32, c.c_uint32, u64],
         "gm_checksum": [vp, sz, c.POINTER(u64)],

@@ -55,6 +55,28 @@ class RasterData(object):
                 pass
         return hit
 
+    _finite = {}  # (id(array), device) -> bool
+
+    def all_finite(self):
+        """True when the array holds no NaN/inf (computed once per device, on the device): the
+        source's non-finite -> no-data rewrite (sources.py:148) is then a no-op."""
+        if np.dtype(self.array.dtype).kind != "f":
+            return True
+        dev = self.on_device()
+        key = (id(self.array), dev.device)
+        hit = RasterData._finite.get(key)
+        if hit is None:
+            out = ctypes.c_int(0)
+            runtime.check(runtime.lib().gm_all_finite(ctypes.c_void_p(dev.ptr), code_of(dev.dtype), dev.size,
+                                                      ctypes.byref(out)), "gm_all_finite")
+            hit = bool(out.value)
+            RasterData._finite[key] = hit
+            try:
+                weakref.finalize(self.array, RasterData._finite.pop, key, None)
+            except TypeError:
+                pass
+        return hit
+
     def __gm_tokenize__(self):
         return ("RasterData", id(self.array), self.projection, tuple(self.geo_transform))
 
@@ -107,6 +129,10 @@ class RasterSourceBase(RasterBlock):
             return {"values": result[bands[0]:bands[1]], "no_data_value": fill}
         runtime.require_device()
         source = raster_data.on_device().band_slice(bands[0], bands[1])
+        if process_kwargs.get("whole") and raster_data.all_finite():
+            # the request grid IS the source grid: the warp would be an identity copy, so the
+            # resident tile itself is handed on (responses are immutable by contract)
+            return {"values": source, "no_data_value": fill}
         values = resample.nearest_warp(source, gt, bbox, height, width, fill)
         return {"values": values, "no_data_value": fill}
 
@@ -246,6 +272,17 @@ class MemorySource(RasterSourceBase):
     def temporal(self):
         return self.time_delta is not None
 
+    def _is_whole_grid(self, request):
+        """Does the request ask for exactly the source's own pixel grid (same bbox, one request
+        cell per source pixel, same CRS)?"""
+        if not self.data.size or not utils.same_projection(request["projection"], self.projection):
+            return False
+        _, ny, nx = self.data.shape
+        west, south, east, north = self.geo_transform.get_bbox((0, 0), (ny, nx))
+        x1, y1, x2, y2 = request["bbox"]
+        return (request["width"] == nx and request["height"] == ny and
+                x1 == west and y1 == south and x2 == east and y2 == north)
+
     def get_sources_and_requests(self, **request):
         mode = request["mode"]
         if mode == "meta" and self.metadata is None:
@@ -262,7 +299,7 @@ class MemorySource(RasterSourceBase):
             kwargs = {"mode": "vals", "raster_data": raster_data, "bbox": request["bbox"],
                       "width": request["width"], "height": request["height"],
                       "projection": request["projection"], "bands": bands, "dtype": self.dtype,
-                      "fillvalue": self.fillvalue}
+                      "fillvalue": self.fillvalue, "whole": self._is_whole_grid(request)}
         elif mode == "meta":
             kwargs = {"mode": "meta", "raster_data": raster_data, "bands": bands}
         elif mode == "time":

@@ -282,6 +282,9 @@ int gm_resample_bilinear(const void* src, int dtype, int bands, int hs, int ws,
 
 /* *result = 1 iff every element equals `value` (Clip early-out, misc.py:108). Synchronous. */
 int gm_all_equal(const void* in, int dtype, uint64_t value_bits, size_t n, int* result);
+/* *result = 1 iff every element is finite (always 1 for integer tiles). Synchronous.  Lets a
+ * source skip the non-finite -> no-data rewrite of raster/sources.py:148 when nothing needs it. */
+int gm_all_finite(const void* in, int dtype, size_t n, int* result);
 /* out[i] = value */
 int gm_fill(void* out, int dtype, uint64_t value_bits, size_t n);
 /* Synthetic tile: the window [row0, row0+h) x [col0, col0+w) of a procedural H x W mosaic.
