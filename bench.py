@@ -46,6 +46,9 @@ def parse_args():
     p.add_argument("--tiles", type=int, default=16, help="tile pairs per GPU per step")
     p.add_argument("--cpu-tiles", type=int, default=-1, help="tiles of the CPU baseline sample (0 = skip)")
     p.add_argument("--no-check", action="store_true", help="skip the oracle check of one tile")
+    p.add_argument("--dry-run", action="store_true",
+                   help="exercise the multi-rank timing harness without a GPU (every tile is a 0.2 ms sleep); "
+                        "used by the CPU gloo test, never a measurement")
     return p.parse_args()
 
 
@@ -117,19 +120,45 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from dask_geomodeling_amd import raster
-    from dask_geomodeling_amd.core.graphs import get_sync
-    from dask_geomodeling_amd.hip import runtime
-
-    runtime.require_device()
-    runtime.set_device(local_rank % runtime.device_count())
     side, tiles = args.side, args.tiles
-    jobs, seeds, _ = build_batch(raster, side, tiles, rank)
-    runtime.sync()
+    if args.dry_run:
+        class _NoDevice:  # harness test only: no device, no kernels, no numbers worth reading
+            class Event:
+                def __init__(self):
+                    self.t = 0.0
 
-    def step():
-        for graph, name in jobs:
-            get_sync(graph, [name])  # result DeviceArray is dropped -> buffer returns to the pool
+                def record(self):
+                    self.t = time.perf_counter()
+
+                def synchronize(self):
+                    pass
+
+                def elapsed_ms(self, later):
+                    return (later.t - self.t) * 1e3
+
+            @staticmethod
+            def sync():
+                pass
+
+        runtime, jobs, seeds = _NoDevice, [None] * tiles, []
+        args.no_check = True
+
+        def step():
+            for _ in jobs:
+                time.sleep(0.0002)
+    else:
+        from dask_geomodeling_amd import raster
+        from dask_geomodeling_amd.core.graphs import get_sync
+        from dask_geomodeling_amd.hip import runtime
+
+        runtime.require_device()
+        runtime.set_device(local_rank % runtime.device_count())
+        jobs, seeds, _ = build_batch(raster, side, tiles, rank)
+        runtime.sync()
+
+        def step():
+            for graph, name in jobs:
+                get_sync(graph, [name])  # result DeviceArray is dropped -> buffer returns to the pool
 
     if not args.no_check and rank == 0:
         graph, name = jobs[0]
@@ -174,7 +203,7 @@ def main():
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not args.dry_run else "DRY RUN (no GPU work, harness test only)",
             "config": {"workload": "fused chain Clip(Add(Subtract(Multiply(Add(A,B),2.5),B),1.5),A) on %dx%d f32 "
                                    "MemorySource tiles, %d tile pairs per GPU per step, one fused launch per tile"
                                    % (side, side, tiles),
@@ -188,7 +217,7 @@ def main():
         cpu_tiles = args.cpu_tiles
         if cpu_tiles < 0:
             cpu_tiles = min(max(os.cpu_count() or 1, 4), 32) if world == 1 else 0
-        if cpu_tiles > 0 and world == 1:
+        if cpu_tiles > 0 and world == 1 and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(side, cpu_tiles)
         print(json.dumps(out), flush=True)
 

@@ -1,0 +1,66 @@
+"""N > 1 path on the CPU: tile sharding logic and the bench timing harness under
+torch.distributed (gloo, world_size 2)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from dask_geomodeling_amd import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tile_ownership_is_a_partition():
+    for n_tiles in (0, 1, 7, 256):
+        for world in (1, 2, 4, 8):
+            seen = []
+            for rank in range(world):
+                mine = shard.owned_tiles(n_tiles, rank, world)
+                assert all(shard.tile_owner(t, world) == rank for t in mine)
+                seen += mine
+            assert sorted(seen) == list(range(n_tiles))
+            sizes = [len(shard.owned_tiles(n_tiles, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1  # balanced
+    with pytest.raises(ValueError):
+        shard.owned_tiles(4, 2, 2)
+
+
+def test_run_owned_tiles_evaluates_only_own_subgraphs():
+    calls = []
+
+    def tile(i):
+        calls.append(i)
+        return {"values": i}
+
+    graph = {"t%d" % i: (tile, i) for i in range(6)}
+    graph["tiler"] = ((lambda kw, *tiles: tiles), {"count_xy": (3, 2)}) + tuple("t%d" % i for i in range(6))
+    got = shard.run_owned_tiles(graph, "tiler", rank=1, world=2, sink=lambda t, r: r["values"] * 10)
+    assert got == {1: 10, 3: 30, 5: 50} and calls == [1, 3, 5]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(300)
+def test_bench_harness_world_size_2_gloo():
+    """bench.py under torch.distributed.run with 2 ranks (gloo, no GPU: --dry-run): one JSON line
+    from rank 0, n_gpus = 2, whole-job value = units of both ranks / max time."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--tiles", "4", "--side", "64", "--dry-run"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["unit"] == "Mpix/s" and out["vs_baseline"] is None and "cpu_baseline" not in out
+    # 2 ranks x 4 tiles x 64^2 px per step
+    assert abs(out["value"] - 2 * 4 * 64 * 64 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) / out["value"] < 0.01
