@@ -23,6 +23,88 @@ int validate_operand(const gm_operand& o, unsigned n_inputs, const char* which, 
   }
 }
 
+// Lower the program into micro-ops (gm_vm.h).  A step whose accumulator-side operand is the
+// running value and whose opcode is +, -, *, / or Clip becomes a fast route; a leading non-ACC
+// left operand becomes an explicit LD; save_temp becomes ST.  Anything else stays GENERIC.
+int lower(const gm_program* prog, VmArgs* args) {
+  unsigned n = 0;
+  auto push = [&](unsigned kind, unsigned src, unsigned arg, gm_scalar acc_ndv, gm_scalar b_val, gm_scalar fill) -> bool {
+    if (n >= (unsigned)GM_MAX_UOPS) return false;
+    gm_uop& u = args->uops[n++];
+    u.route = kind | (src << 8);
+    u.arg = arg;
+    u.acc_ndv = acc_ndv;
+    u.b_val = b_val;
+    u.fill = fill;
+    return true;
+  };
+  const bool float_class = prog->reg_class <= GM_CLASS_F64;
+  gm_scalar zero;
+  zero.u64 = 0;
+  for (unsigned s = 0; s < prog->n_steps; ++s) {
+    const gm_step& S = prog->steps[s];
+    const unsigned opcode = S.bits & 0xffu, save = (S.bits >> 8) & 0xffu;
+    const unsigned round_f32 = (S.bits >> 24) & 1u, wrap_i32 = (S.bits >> 25) & 1u, chk = (S.bits >> 26) & 1u;
+    auto kind_of = [](const gm_operand& o) { return o.bits & 0xffu; };
+    auto src_of = [&](const gm_operand& o) -> int {  // -1: not addressable as a fast-route source
+      const unsigned k = kind_of(o), i = (o.bits >> 8) & 0xffu;
+      if (k == GM_OPD_SCALAR) return (int)UOP_SRC_SCALAR;
+      if (k == GM_OPD_INPUT) return (int)(UOP_SRC_INPUT + i);
+      if (k == GM_OPD_TEMP) return (int)(UOP_SRC_TEMP + i);
+      return -1;
+    };
+    auto has_ndv = [](const gm_operand& o) { return (o.bits >> 16) & 1u; };
+    auto is_bool = [](const gm_operand& o) { return (o.bits >> 17) & 1u; };
+    bool fast = false;
+    const bool arith = opcode == GM_OP_ADD || opcode == GM_OP_SUB || opcode == GM_OP_MUL ||
+                       (opcode == GM_OP_DIV && float_class);
+    // the finite check is part of every float fast body: only lower float math steps that ask for it
+    if (arith && (!float_class || chk)) {
+      const gm_operand *x = &S.a, *y = &S.b;  // x: accumulator side, y: other side
+      bool reversed = false, need_ld = false;
+      if (kind_of(S.a) == GM_OPD_ACC && kind_of(S.b) != GM_OPD_ACC) {
+      } else if (kind_of(S.b) == GM_OPD_ACC && kind_of(S.a) != GM_OPD_ACC) {
+        x = &S.b; y = &S.a; reversed = true;
+      } else if (kind_of(S.a) != GM_OPD_ACC && kind_of(S.b) != GM_OPD_ACC && kind_of(S.a) != GM_OPD_NONE) {
+        need_ld = true;
+      } else {
+        x = nullptr;
+      }
+      if (x && src_of(*y) >= 0 && (!need_ld || src_of(*x) >= 0)) {
+        unsigned kind = UOP_ADD;
+        if (opcode == GM_OP_SUB) kind = reversed ? UOP_RSUB : UOP_SUB;
+        else if (opcode == GM_OP_MUL) kind = UOP_MUL;
+        else if (opcode == GM_OP_DIV) kind = reversed ? UOP_RDIV : UOP_DIV;
+        if (need_ld && !push(UOP_LD, (unsigned)src_of(*x), 0, zero, x->value, zero)) return -1;
+        const unsigned x_has = kind_of(*x) == GM_OPD_SCALAR ? 0u : has_ndv(*x);
+        const unsigned y_has = kind_of(*y) == GM_OPD_SCALAR ? 0u : has_ndv(*y);
+        const unsigned arg = x_has | (y_has << 1) | (round_f32 << 3) | (wrap_i32 << 4);
+        if (!push(kind, (unsigned)src_of(*y), arg, x->value, y->value, S.fill)) return -1;
+        fast = true;
+      }
+    } else if (opcode == GM_OP_CLIP && src_of(S.b) > 0 && kind_of(S.a) != GM_OPD_NONE) {
+      bool ok = true;
+      if (kind_of(S.a) != GM_OPD_ACC) {
+        if (src_of(S.a) >= 0) ok = push(UOP_LD, (unsigned)src_of(S.a), 0, zero, S.a.value, zero);
+        else ok = false;
+        if (!ok && n >= (unsigned)GM_MAX_UOPS) return -1;
+      }
+      if (ok) {
+        const unsigned arg = (has_ndv(S.b) << 1) | (is_bool(S.b) << 2);
+        if (!push(UOP_CLIP, (unsigned)src_of(S.b), arg, zero, S.b.value, S.fill)) return -1;
+        fast = true;
+      }
+    }
+    if (fast) {
+      if (save && !push(UOP_ST, save - 1, 0, zero, zero, zero)) return -1;
+    } else {
+      if (!push(UOP_GENERIC, 0, s, zero, zero, zero)) return -1;  // its save_temp is handled by step()
+    }
+  }
+  args->n_uops = n;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -78,6 +160,14 @@ int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out
   }
   args.out = out;
   args.n = n;
+  if (lower(prog, &args) != 0) return gm::fail(GM_ERR_INVALID, "program does not fit %d micro-ops", GM_MAX_UOPS);
+  {
+    const int native_code = prog->reg_class == GM_CLASS_F32 ? GM_F32 : (prog->reg_class == GM_CLASS_I32 ? GM_I32 : -1);
+    bool native = native_code >= 0 && (int)prog->out_dtype == native_code;
+    for (unsigned k = 0; k < prog->n_inputs && native; ++k)
+      native = ((int)(prog->inputs[k].bits & 0xffu) == native_code) && !((prog->inputs[k].bits >> 8) & 3u);
+    args.native = native ? 1u : 0u;
+  }
   bool heavy = false;
   unsigned max_in = prog->n_inputs, max_tmp = 0;
   for (unsigned s = 0; s < prog->n_steps; ++s) {

@@ -39,8 +39,30 @@ typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
 typedef signed char i8x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
+// Micro-ops: gm_elemwise_run lowers every gm_step into 1-3 of these.  The four arithmetic
+// ops and Clip -- the bulk of real views -- get "fast routes": one flat wave-uniform switch per
+// micro-op selects a fully static body (operand arrays named at compile time: no operand copies,
+// no per-operand dispatch).  Everything else runs the generic step interpreter (UOP_GENERIC).
+enum { UOP_GENERIC = 0, UOP_LD = 1, UOP_ST = 2, UOP_ADD = 3, UOP_SUB = 4, UOP_RSUB = 5, UOP_MUL = 6,
+       UOP_DIV = 7, UOP_RDIV = 8, UOP_CLIP = 9 };
+// operand source of a micro-op: 0 = literal, 1 + k = input k, 1 + 8 + k = temp k
+constexpr unsigned UOP_SRC_SCALAR = 0, UOP_SRC_INPUT = 1, UOP_SRC_TEMP = 9;
+constexpr int GM_MAX_UOPS = 40;
+
+struct gm_uop {
+  unsigned int route;  // kind | src << 8
+  unsigned int arg;    // GENERIC: step index; fast routes: bit0 acc has ndv, bit1 b has ndv, bit2 b is
+                       // bool, bit3 round_f32, bit4 wrap_i32
+  gm_scalar acc_ndv;   // ndv of the value in the accumulator (register-class repr)
+  gm_scalar b_val;     // literal, or ndv of the b operand
+  gm_scalar fill;
+};
+
 struct VmArgs {
   gm_program prog;
+  gm_uop uops[GM_MAX_UOPS];
+  unsigned int n_uops;
+  unsigned int native;  // every input and the output are non-broadcast tiles of the class' own dtype
   const void* in[GM_MAX_INPUTS];
   void* out;
   unsigned long long n;           // total elements
@@ -449,9 +471,144 @@ struct Machine {
     }
   }
 
-  __device__ __forceinline__ void run(const gm_program& P) {
-    const unsigned n_steps = P.n_steps;
-    for (unsigned s = 0; s < n_steps; ++s) step(P.steps[s]);
+  // ---- fast routes ---------------------------------------------------------------------
+  // acc[k] = bad ? fill : f(acc[k], y) with y = literal (B_SCALAR) or b[k]; all-VALU select
+  // chain (v_cmp straight into v_cndmask, no lane-mask arithmetic on the shared scalar unit)
+  template <bool B_SCALAR, typename F>
+  __device__ __forceinline__ void fast_body(const gm_uop& U, const RC* b, F f) {
+    const unsigned arg = U.arg;
+    const bool a_has = (arg & 1u) != 0, b_has = (arg & 2u) != 0;
+    RC a_ndv = scalar_of<RC>(U.acc_ndv), b_ndv = scalar_of<RC>(U.b_val);
+    const RC b_lit = b_ndv, fill = scalar_of<RC>(U.fill);
+    if constexpr (is_float_class<RC>::value) {
+      a_ndv = a_has ? a_ndv : (RC)__builtin_nanf("");
+      b_ndv = b_has ? b_ndv : (RC)__builtin_nanf("");
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const RC x = acc[k];
+        const RC y = B_SCALAR ? b_lit : b[k];
+        RC r = f(x, y);
+        r = (x == a_ndv) ? fill : r;
+        if constexpr (!B_SCALAR) r = (y == b_ndv) ? fill : r;
+        acc[k] = finite_rc<RC>(r) ? r : fill;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const RC x = acc[k];
+        const RC y = B_SCALAR ? b_lit : b[k];
+        bool bad = a_has & (x == a_ndv);
+        if constexpr (!B_SCALAR) bad = bad | (b_has & (y == b_ndv));
+        acc[k] = bad ? fill : f(x, y);
+      }
+    }
+  }
+
+  template <bool B_SCALAR, typename F>
+  __device__ __forceinline__ void fast_math(const gm_uop& U, const RC* b, F f) {
+    if constexpr (std::is_same<RC, double>::value) {
+      if (U.arg & 8u) {
+        fast_body<B_SCALAR>(U, b, [f](RC x, RC y) { return (RC)(float)f(x, y); });
+        return;
+      }
+    }
+    if constexpr (std::is_same<RC, long long>::value) {
+      if (U.arg & 16u) {
+        fast_body<B_SCALAR>(U, b, [f](RC x, RC y) { return (RC)(int)f(x, y); });
+        return;
+      }
+    }
+    fast_body<B_SCALAR>(U, b, f);
+  }
+
+  template <bool B_SCALAR>
+  __device__ __forceinline__ void fast_op(const gm_uop& U, unsigned kind, const RC* b) {
+    switch (kind) {
+      case UOP_ADD: fast_math<B_SCALAR>(U, b, [](RC x, RC y) { return op_add<RC>(x, y); }); break;
+      case UOP_SUB: fast_math<B_SCALAR>(U, b, [](RC x, RC y) { return op_sub<RC>(x, y); }); break;
+      case UOP_RSUB: fast_math<B_SCALAR>(U, b, [](RC x, RC y) { return op_sub<RC>(y, x); }); break;
+      case UOP_MUL: fast_math<B_SCALAR>(U, b, [](RC x, RC y) { return op_mul<RC>(x, y); }); break;
+      case UOP_DIV: fast_math<B_SCALAR>(U, b, [](RC x, RC y) { return op_div<RC>(x, y); }); break;
+      case UOP_RDIV: fast_math<B_SCALAR>(U, b, [](RC x, RC y) { return op_div<RC>(y, x); }); break;
+      case UOP_CLIP:
+        if constexpr (!B_SCALAR) {
+          // misc.py:115-123: acc (the store) -> its own ndv where the mask source has no data
+          const bool b_has = (U.arg & 2u) != 0, b_bool = (U.arg & 4u) != 0;
+          const RC b_ndv = scalar_of<RC>(U.b_val), fill = scalar_of<RC>(U.fill);
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const bool drop = (b_has & (b[k] == b_ndv)) | (b_bool & (b[k] == (RC)0));
+            acc[k] = drop ? fill : acc[k];
+          }
+        }
+        break;
+      default: break;
+    }
+  }
+
+  __device__ __forceinline__ void load_acc(const RC* src) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = src[k];
+  }
+
+  // one micro-op; `src` selects the operand array with a single wave-uniform switch
+  __device__ __forceinline__ void exec(const gm_program& P, const gm_uop& U) {
+    const unsigned kind = U.route & 0xffu, src = (U.route >> 8) & 0xffu;
+    if (kind == UOP_GENERIC) {
+      step(P.steps[U.arg]);
+      return;
+    }
+    if (kind == UOP_ST) {
+      if constexpr (NT > 0) {
+        switch (src) {
+#define GM_ST_CASE(K)                                                         \
+  case K:                                                                     \
+    if constexpr (K < NT) {                                                   \
+      _Pragma("unroll") for (int k = 0; k < N; ++k) tmp[K][k] = acc[k];       \
+    }                                                                         \
+    break;
+          GM_ST_CASE(0) GM_ST_CASE(1) GM_ST_CASE(2) GM_ST_CASE(3)
+#undef GM_ST_CASE
+          default: break;
+        }
+      }
+      return;
+    }
+    if (kind == UOP_LD) {
+      if (src == UOP_SRC_SCALAR) {
+        const RC v = scalar_of<RC>(U.b_val);
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = v;
+        return;
+      }
+      switch (src) {
+#define GM_LD_IN(K) case UOP_SRC_INPUT + K: if constexpr (K < NIN) load_acc(in[K]); break;
+#define GM_LD_TMP(K) case UOP_SRC_TEMP + K: if constexpr (K < NT) load_acc(tmp[K]); break;
+        GM_LD_IN(0) GM_LD_IN(1) GM_LD_IN(2) GM_LD_IN(3) GM_LD_IN(4) GM_LD_IN(5) GM_LD_IN(6) GM_LD_IN(7)
+        GM_LD_TMP(0) GM_LD_TMP(1) GM_LD_TMP(2) GM_LD_TMP(3)
+#undef GM_LD_IN
+#undef GM_LD_TMP
+        default: break;
+      }
+      return;
+    }
+    if (src == UOP_SRC_SCALAR) {
+      fast_op<true>(U, kind, acc);
+      return;
+    }
+    switch (src) {
+#define GM_OP_IN(K) case UOP_SRC_INPUT + K: if constexpr (K < NIN) fast_op<false>(U, kind, in[K]); break;
+#define GM_OP_TMP(K) case UOP_SRC_TEMP + K: if constexpr (K < NT) fast_op<false>(U, kind, tmp[K]); break;
+      GM_OP_IN(0) GM_OP_IN(1) GM_OP_IN(2) GM_OP_IN(3) GM_OP_IN(4) GM_OP_IN(5) GM_OP_IN(6) GM_OP_IN(7)
+      GM_OP_TMP(0) GM_OP_TMP(1) GM_OP_TMP(2) GM_OP_TMP(3)
+#undef GM_OP_IN
+#undef GM_OP_TMP
+      default: break;
+    }
+  }
+
+  __device__ __forceinline__ void run(const gm_program& P, const gm_uop* uops, unsigned n_uops) {
+    for (unsigned i = 0; i < n_uops; ++i) exec(P, uops[i]);
   }
 };
 
@@ -477,6 +634,10 @@ __device__ __forceinline__ unsigned long long first_iter(unsigned long long n_it
 }
 
 // vector kernel: every lane owns G groups of 4 consecutive elements per block-iteration
+template <typename RC> struct native_vec;
+template <> struct native_vec<float> { typedef f32x4 type; };
+template <> struct native_vec<int> { typedef i32x4 type; };
+
 template <typename RC, int G, int NIN, int NT, bool HEAVY>
 __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
   const gm_program& P = A.prog;
@@ -491,6 +652,27 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
     Machine<RC, N, NIN, NT, HEAVY> M;
     const unsigned long long g0 = it * (256ull * G) + threadIdx.x;  // sub-vector u is group g0 + 256*u
     // phase 1: all leaf loads in flight (NIN*G independent 16-byte loads per lane)
+    bool native = false;
+    if constexpr (sizeof(RC) == 4) native = A.native != 0;
+    if (native) {
+      // every tile already has the class' dtype: straight 16-byte loads, no dtype dispatch
+      if constexpr (sizeof(RC) == 4) {
+        typedef typename native_vec<RC>::type V4;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+          if (k < (int)n_in) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+              const unsigned long long g = g0 + 256ull * u;
+              V4 x = {0, 0, 0, 0};
+              if (g < A.n_groups) x = ld((const V4*)A.in[k] + g, nt_ld);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) M.in[k][4 * u + q] = x[q];
+            }
+          }
+        }
+      }
+    } else
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       if (k < (int)n_in) {
@@ -514,15 +696,25 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
       }
     }
     // phase 2: interpret; phase 3: store
-    M.run(P);
+    M.run(P, A.uops, A.n_uops);
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const unsigned long long g = g0 + 256ull * u;
       if (g < A.n_groups) {
-        RC v4[4];
+        if (native) {
+          if constexpr (sizeof(RC) == 4) {
+            typedef typename native_vec<RC>::type V4;
+            V4 x;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v4[q] = M.acc[4 * u + q];
-        store_elems<RC, 4>(A.out, out_dtype, g * 4ull, nt_st, v4);
+            for (int q = 0; q < 4; ++q) x[q] = M.acc[4 * u + q];
+            st((V4*)A.out + g, x, nt_st);
+          }
+        } else {
+          RC v4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v4[q] = M.acc[4 * u + q];
+          store_elems<RC, 4>(A.out, out_dtype, g * 4ull, nt_st, v4);
+        }
       }
     }
   }
@@ -546,7 +738,7 @@ __global__ __launch_bounds__(256) void vm_tail_kernel(const VmArgs A) {
                           (long long)D.ndv.i64);
       }
     }
-    M1.run(P);
+    M1.run(P, A.uops, A.n_uops);
     store_elems<RC, 1>(A.out, (int)P.out_dtype, e, false, M1.acc);
   }
 }

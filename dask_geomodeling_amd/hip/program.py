@@ -16,7 +16,7 @@ from .array import DeviceArray, as_device
 from .dtypes import code_of
 from .runtime import gm_scalar
 
-GM_MAX_INPUTS, GM_MAX_STEPS, GM_MAX_TEMPS = 8, 32, 4
+GM_MAX_INPUTS, GM_MAX_STEPS, GM_MAX_TEMPS = 8, 24, 4
 CLASS_F32, CLASS_F64, CLASS_I32, CLASS_I64 = 0, 1, 2, 3
 CLASS_DTYPE = {CLASS_F32: np.dtype("f4"), CLASS_F64: np.dtype("f8"),
                CLASS_I32: np.dtype("i4"), CLASS_I64: np.dtype("i8")}

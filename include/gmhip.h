@@ -120,7 +120,7 @@ const char* gm_version(void);
  * ========================================================================== */
 
 #define GM_MAX_INPUTS 8
-#define GM_MAX_STEPS 32
+#define GM_MAX_STEPS 24
 #define GM_MAX_TEMPS 4
 
 /* register class: the type all VM registers are held in */
