@@ -522,8 +522,8 @@ struct Machine {
   }
 
   template <bool B_SCALAR>
-  __device__ __forceinline__ void fast_op(const gm_uop& U, unsigned kind, const RC* b) {
-    switch (kind) {
+  __device__ __forceinline__ void fast_op(const gm_uop& U, const unsigned kind, const RC* b) {
+    switch (kind) {  // `kind` is a literal at every call site: the switch folds away
       case UOP_ADD: fast_math<B_SCALAR>(U, b, [](RC x, RC y) { return op_add<RC>(x, y); }); break;
       case UOP_SUB: fast_math<B_SCALAR>(U, b, [](RC x, RC y) { return op_sub<RC>(x, y); }); break;
       case UOP_RSUB: fast_math<B_SCALAR>(U, b, [](RC x, RC y) { return op_sub<RC>(y, x); }); break;
@@ -551,60 +551,52 @@ struct Machine {
     for (int k = 0; k < N; ++k) acc[k] = src[k];
   }
 
-  // one micro-op; `src` selects the operand array with a single wave-uniform switch
+  // One micro-op.  The dispatch is ONE flat chain of wave-uniform compares on the route word
+  // (kind | src << 8), most frequent routes first; every body updates the accumulator in place
+  // and leaves through the single exit of the chain, so the register allocator keeps the state
+  // arrays in place (nested switches cost a copy of the whole accumulator per tree level).
   __device__ __forceinline__ void exec(const gm_program& P, const gm_uop& U) {
-    const unsigned kind = U.route & 0xffu, src = (U.route >> 8) & 0xffu;
-    if (kind == UOP_GENERIC) {
-      step(P.steps[U.arg]);
-      return;
-    }
-    if (kind == UOP_ST) {
-      if constexpr (NT > 0) {
-        switch (src) {
-#define GM_ST_CASE(K)                                                         \
-  case K:                                                                     \
-    if constexpr (K < NT) {                                                   \
-      _Pragma("unroll") for (int k = 0; k < N; ++k) tmp[K][k] = acc[k];       \
-    }                                                                         \
-    break;
-          GM_ST_CASE(0) GM_ST_CASE(1) GM_ST_CASE(2) GM_ST_CASE(3)
-#undef GM_ST_CASE
-          default: break;
-        }
-      }
-      return;
-    }
-    if (kind == UOP_LD) {
-      if (src == UOP_SRC_SCALAR) {
-        const RC v = scalar_of<RC>(U.b_val);
+    const unsigned route = U.route & 0xffffu;
+#define GM_ROUTE(KIND, SRC) ((unsigned)(KIND) | ((unsigned)(SRC) << 8))
+#define GM_FAST_SCALAR(KIND) \
+  if (route == GM_ROUTE(KIND, UOP_SRC_SCALAR)) { fast_op<true>(U, KIND, acc); return; }
+#define GM_FAST_IN(KIND, K) \
+  if constexpr (K < NIN) { if (route == GM_ROUTE(KIND, UOP_SRC_INPUT + K)) { fast_op<false>(U, KIND, in[K]); return; } }
+#define GM_FAST_TMP(KIND, K) \
+  if constexpr (K < NT) { if (route == GM_ROUTE(KIND, UOP_SRC_TEMP + K)) { fast_op<false>(U, KIND, tmp[K]); return; } }
+#define GM_LD_IN(K) \
+  if constexpr (K < NIN) { if (route == GM_ROUTE(UOP_LD, UOP_SRC_INPUT + K)) { load_acc(in[K]); return; } }
+#define GM_LD_TMP(K) \
+  if constexpr (K < NT) { if (route == GM_ROUTE(UOP_LD, UOP_SRC_TEMP + K)) { load_acc(tmp[K]); return; } }
+#define GM_ST_TMP(K) \
+  if constexpr (K < NT) { if (route == GM_ROUTE(UOP_ST, K)) { _Pragma("unroll") for (int k = 0; k < N; ++k) tmp[K][k] = acc[k]; return; } }
+#define GM_FAST_ALL_SRC(KIND)                                                                         \
+  GM_FAST_IN(KIND, 0) GM_FAST_IN(KIND, 1) GM_FAST_IN(KIND, 2) GM_FAST_IN(KIND, 3) GM_FAST_IN(KIND, 4) \
+  GM_FAST_IN(KIND, 5) GM_FAST_IN(KIND, 6) GM_FAST_IN(KIND, 7) GM_FAST_TMP(KIND, 0) GM_FAST_TMP(KIND, 1) \
+  GM_FAST_TMP(KIND, 2) GM_FAST_TMP(KIND, 3)
+    GM_LD_IN(0) GM_LD_IN(1)
+    GM_FAST_SCALAR(UOP_ADD) GM_FAST_SCALAR(UOP_MUL) GM_FAST_SCALAR(UOP_SUB) GM_FAST_SCALAR(UOP_DIV)
+    GM_FAST_ALL_SRC(UOP_ADD) GM_FAST_ALL_SRC(UOP_SUB) GM_FAST_ALL_SRC(UOP_MUL) GM_FAST_ALL_SRC(UOP_CLIP)
+    GM_FAST_ALL_SRC(UOP_DIV) GM_FAST_ALL_SRC(UOP_RSUB) GM_FAST_ALL_SRC(UOP_RDIV)
+    GM_FAST_SCALAR(UOP_RSUB) GM_FAST_SCALAR(UOP_RDIV)
+    GM_LD_IN(2) GM_LD_IN(3) GM_LD_IN(4) GM_LD_IN(5) GM_LD_IN(6) GM_LD_IN(7)
+    GM_LD_TMP(0) GM_LD_TMP(1) GM_LD_TMP(2) GM_LD_TMP(3)
+    GM_ST_TMP(0) GM_ST_TMP(1) GM_ST_TMP(2) GM_ST_TMP(3)
+    if (route == GM_ROUTE(UOP_LD, UOP_SRC_SCALAR)) {
+      const RC v = scalar_of<RC>(U.b_val);
 #pragma unroll
-        for (int k = 0; k < N; ++k) acc[k] = v;
-        return;
-      }
-      switch (src) {
-#define GM_LD_IN(K) case UOP_SRC_INPUT + K: if constexpr (K < NIN) load_acc(in[K]); break;
-#define GM_LD_TMP(K) case UOP_SRC_TEMP + K: if constexpr (K < NT) load_acc(tmp[K]); break;
-        GM_LD_IN(0) GM_LD_IN(1) GM_LD_IN(2) GM_LD_IN(3) GM_LD_IN(4) GM_LD_IN(5) GM_LD_IN(6) GM_LD_IN(7)
-        GM_LD_TMP(0) GM_LD_TMP(1) GM_LD_TMP(2) GM_LD_TMP(3)
+      for (int k = 0; k < N; ++k) acc[k] = v;
+      return;
+    }
+    if ((route & 0xffu) == UOP_GENERIC) step(P.steps[U.arg]);
+#undef GM_ROUTE
+#undef GM_FAST_SCALAR
+#undef GM_FAST_IN
+#undef GM_FAST_TMP
 #undef GM_LD_IN
 #undef GM_LD_TMP
-        default: break;
-      }
-      return;
-    }
-    if (src == UOP_SRC_SCALAR) {
-      fast_op<true>(U, kind, acc);
-      return;
-    }
-    switch (src) {
-#define GM_OP_IN(K) case UOP_SRC_INPUT + K: if constexpr (K < NIN) fast_op<false>(U, kind, in[K]); break;
-#define GM_OP_TMP(K) case UOP_SRC_TEMP + K: if constexpr (K < NT) fast_op<false>(U, kind, tmp[K]); break;
-      GM_OP_IN(0) GM_OP_IN(1) GM_OP_IN(2) GM_OP_IN(3) GM_OP_IN(4) GM_OP_IN(5) GM_OP_IN(6) GM_OP_IN(7)
-      GM_OP_TMP(0) GM_OP_TMP(1) GM_OP_TMP(2) GM_OP_TMP(3)
-#undef GM_OP_IN
-#undef GM_OP_TMP
-      default: break;
-    }
+#undef GM_ST_TMP
+#undef GM_FAST_ALL_SRC
   }
 
   __device__ __forceinline__ void run(const gm_program& P, const gm_uop* uops, unsigned n_uops) {
