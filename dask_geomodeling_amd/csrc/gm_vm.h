@@ -449,6 +449,43 @@ struct Machine {
           for (int k = 0; k < N; ++k) acc[k] = is_close<RC>(acc[k], y, tol, in_f64, y_finite) ? fill : value;
         }
       } break;
+      case GM_OP_FILLNODATA: {
+        // elemwise.py:749-755: take b where b is data (utils.get_index: isclose for float tiles)
+        const unsigned flags = step_flags(S);
+        if (flags & 4u) {
+          const bool b_has = opd_has_ndv(S.b);
+          const RC b_ndv = scalar_of<RC>(S.b.value);
+#pragma unroll
+          for (int k = 0; k < N; ++k) acc[k] = (b_has & (b[k] == b_ndv)) ? acc[k] : b[k];
+        } else {
+          const double y = S.aux2.f64, tol = S.aux1.f64;
+          const bool in_f64 = (flags & 1u) != 0, y_finite = (flags & 2u) != 0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) acc[k] = is_close<RC>(b[k], y, tol, in_f64, y_finite) ? acc[k] : b[k];
+        }
+      } break;
+      case GM_OP_MASKBELOW: {
+        // misc.py:249-250: values[values < value] = no_data_value
+        const RC thr = scalar_of<RC>(S.aux0), fill = scalar_of<RC>(S.fill);
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = (acc[k] < thr) ? fill : acc[k];
+      } break;
+      case GM_OP_STEP: {
+        // misc.py:314-326: left / at / right around `location`, no-data cells kept
+        const RC loc = scalar_of<RC>(S.aux0), left = scalar_of<RC>(S.aux1), at = scalar_of<RC>(S.aux2),
+                 right = scalar_of<RC>(S.aux3), fill = scalar_of<RC>(S.fill);
+        const bool a_has = opd_has_ndv(S.a);
+        const RC a_ndv = scalar_of<RC>(S.a.value);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const RC x = acc[k];
+          RC r = x;  // NaN compares false three times and stays
+          r = (x > loc) ? right : r;
+          r = (x == loc) ? at : r;
+          r = (x < loc) ? left : r;
+          acc[k] = (a_has & (x == a_ndv)) ? fill : r;
+        }
+      } break;
       case GM_OP_COPY:
       default:
         break;  // the accumulator already holds the operand

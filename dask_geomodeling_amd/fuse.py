@@ -134,6 +134,10 @@ class FusedTask(object):
             return devops.clip_node(operand(args[0]), operand(args[1]))
         if op == "mask":
             return devops.mask_node(operand(args[0]), args[1])
+        if op == "maskbelow":
+            return devops.maskbelow_node(operand(args[0]), args[1])
+        if op == "step":
+            return devops.step_node(operand(args[0]), *args[1:5])
         if op == "invert":
             return devops.invert_node(operand(args[0]))
         if op == "isdata":

@@ -29,7 +29,7 @@ OPCODES = {
     "logical_and": 12, "logical_or": 13, "logical_xor": 14,
     "exp": 15, "log": 16, "log10": 17,
     "invert": 18, "isdata": 19, "isnodata": 20, "clip": 21, "mask": 22,
-    "copy": 26,
+    "maskbelow": 23, "step": 24, "fillnodata": 25, "copy": 26,
 }
 MATH_OPS = ("add", "subtract", "multiply", "divide", "power", "exp", "log", "log10")
 COMPARE_OPS = ("equal", "not_equal", "greater", "greater_equal", "less", "less_equal")
@@ -162,6 +162,14 @@ def classes_exact(dtype):
     return frozenset(c for c in ALL_CLASSES if exact_in_class(dtype, c))
 
 
+def classes_for_compare(dtype):
+    """Classes in which a comparison carried out in ``dtype`` is exact."""
+    dt = np.dtype(dtype)
+    if dt.kind == "f":
+        return frozenset((CLASS_F64,)) if dt.itemsize == 8 else frozenset((CLASS_F32, CLASS_F64))
+    return frozenset(c for c in ALL_CLASSES if exact_in_class(dt, c))
+
+
 def classes_for_compute(dtype):
     """Classes able to *compute* in ``dtype`` bit-exactly (narrower step types are emulated:
     f32 inside F64 by rounding after each op, i32 inside I64 by wrapping)."""
@@ -239,7 +247,7 @@ def _scalar_key(v):
 
 def compute_dtype(node):
     """The dtype an Op's arithmetic / comparison is carried out in."""
-    if node.op in MATH_OPS:
+    if node.op in MATH_OPS or node.op == "fillnodata":
         return node.dtype
     if node.op in COMPARE_OPS:
         parts = []
@@ -276,6 +284,16 @@ def node_classes(node):
             # small integers compare exactly in the float classes too
             allowed = allowed | frozenset(c for c in (CLASS_F64, CLASS_F32, CLASS_I64)
                                           if all(_operand_exact(a, c) for a in node.args))
+    elif op in ("maskbelow", "step"):
+        # the tile travels through unchanged and is compared with a literal in NumPy's promoted dtype
+        allowed = classes_exact(node.args[0].dtype) & classes_for_compare(node.extra["compare_dtype"])
+        for v in node.extra.get("values", ()):
+            allowed = frozenset(c for c in allowed if _value_exact(v, node.dtype, c))
+    elif op == "fillnodata":
+        allowed = classes_for_compute(node.dtype) if node.dtype.kind == "f" or node.dtype.itemsize >= 4 else ALL_CLASSES
+        for a in node.args:
+            if not isinstance(a, Lit):
+                allowed = allowed & classes_exact(a.dtype)
     elif op in ("clip", "copy"):
         allowed = classes_exact(node.args[0].dtype)
     elif op == "mask":
@@ -468,6 +486,27 @@ def compile_expr(root, n_inputs):
                 # nothing can be marked: the reference writes the ndv as is
                 eff = cast_scalar(store.ndv, store.dtype)
             _set_scalar(s.fill, cls, eff)
+        elif node.op == "fillnodata":
+            ex = node.extra
+            s.flags = ex["flags"]
+            s.aux1.f64 = ex["tol"]
+            s.aux2.f64 = ex["y"]
+        elif node.op == "maskbelow":
+            ex = node.extra
+            store = node.args[0]
+            eff = effective_ndv(store.dtype, store.ndv)
+            _set_scalar(s.fill, cls, eff if eff is not None else cast_scalar(store.ndv, store.dtype))
+            _set_scalar(s.aux0, cls, cast_scalar(ex["value"], ex["compare_dtype"]))
+        elif node.op == "step":
+            ex = node.extra
+            store = node.args[0]
+            eff = effective_ndv(store.dtype, store.ndv)
+            _set_scalar(s.fill, cls, eff if eff is not None else cast_scalar(store.ndv, store.dtype))
+            _set_scalar(s.aux0, cls, cast_scalar(ex["value"], ex["compare_dtype"]))
+            left, at, right = ex["values"]
+            _set_scalar(s.aux1, cls, cast_scalar(left, node.dtype))
+            _set_scalar(s.aux2, cls, cast_scalar(at, node.dtype))
+            _set_scalar(s.aux3, cls, cast_scalar(right, node.dtype))
         elif node.op == "mask":
             ex = node.extra
             _set_scalar(s.fill, cls, ex["fill"])

@@ -85,6 +85,41 @@ def mask_node(store, value):
     return P.Op("mask", [store], dtype, fill, extra=extra)
 
 
+def compare_dtype(tile_dtype, value):
+    """dtype in which NumPy carries out ``tile < value`` for a python scalar ``value``."""
+    try:
+        dt = np.result_type(tile_dtype, value)
+    except OverflowError:  # python int outside the tile dtype: the comparison is still exact
+        dt = np.dtype("i8")
+    if dt.kind == "f" and dt.itemsize < 4:
+        dt = np.dtype("f4")
+    return dt
+
+
+def maskbelow_node(store, value):
+    """MaskBelow.process numerics (raster/misc.py:249-250)."""
+    extra = {"value": value, "compare_dtype": compare_dtype(store.dtype, value)}
+    return P.Op("maskbelow", [store], store.dtype, store.ndv, extra=extra)
+
+
+def step_node(store, left, right, location, at):
+    """Step.process numerics (raster/misc.py:314-326)."""
+    extra = {"value": location, "compare_dtype": compare_dtype(store.dtype, location),
+             "values": (left, at, right)}
+    return P.Op("step", [store], store.dtype, store.ndv, extra=extra)
+
+
+def fillnodata_node(prev, tile, dtype, fill):
+    """One round of FillNoData's loop (raster/elemwise.py:749-755): ``tile`` where it has data
+    (utils.get_index: isclose for float tiles), else ``prev``."""
+    if tile.dtype.kind == "f":
+        in_f64, y, tol, finite = isclose_params(tile.dtype, tile.ndv)
+        flags = (1 if in_f64 else 0) | (2 if finite else 0)
+    else:
+        flags, y, tol = 4, 0.0, 0.0
+    return P.Op("fillnodata", [prev, tile], dtype, fill, fill=fill, extra={"flags": flags, "tol": tol, "y": y})
+
+
 def invert_node(x):
     return P.Op("invert", [x], BOOL, None)
 
@@ -197,3 +232,46 @@ def unary_bool_process(kind, data):
     builder = {"invert": invert_node, "isdata": isdata_node, "isnodata": isnodata_node}[kind]
     values, _ = P.run_expr(lambda leaves: builder(leaves[0]), tiles)
     return {"values": values, "no_data_value": None}
+
+
+def maskbelow_process(data, value):
+    """Drop-in for MaskBelow.process (raster/misc.py:245-251)."""
+    if data is None or "values" not in data:
+        return data
+    tiles = [(data["values"], data["no_data_value"])]
+    values, _ = P.run_expr(lambda leaves: maskbelow_node(leaves[0], value), tiles)
+    return {"values": values, "no_data_value": data["no_data_value"]}
+
+
+def step_process(data, left, right, location, at):
+    """Drop-in for Step.process (raster/misc.py:308-328)."""
+    if data is None or "values" not in data:
+        return data
+    tiles = [(data["values"], data["no_data_value"])]
+    values, _ = P.run_expr(lambda leaves: step_node(leaves[0], left, right, location, at), tiles)
+    return {"values": values, "no_data_value": data["no_data_value"]}
+
+
+def fillnodata_process(process_kwargs, *args):
+    """Drop-in for FillNoData.process (raster/elemwise.py:726-757)."""
+    tiles = []
+    for data in args:
+        if data is None:
+            continue
+        if "time" in data or "meta" in data:
+            return data
+        if "values" in data and "no_data_value" in data:
+            tiles.append((data["values"], data["no_data_value"]))
+    dtype = np.dtype(process_kwargs["dtype"])
+    fill = utils.get_dtype_max(dtype)
+    if not tiles:
+        return None
+
+    def build(leaves):
+        node = P.Lit(fill)
+        for leaf in leaves:
+            node = fillnodata_node(node, leaf, dtype, fill)
+        return node
+
+    values, _ = P.run_expr(build, tiles)
+    return {"values": values, "no_data_value": fill}

@@ -129,6 +129,8 @@ class MaskBelow(BaseSingle):
     def process(data, value):
         return devops.maskbelow_process(data, value)
 
+    process.__func__.gm_op = "maskbelow"
+
 
 class Step(BaseSingle):
     """Three-valued step function around ``value`` (misc.py:254-328)."""
@@ -148,6 +150,8 @@ class Step(BaseSingle):
     @staticmethod
     def process(data, left, right, location, at):
         return devops.step_process(data, left, right, location, at)
+
+    process.__func__.gm_op = "step"
 
 
 class Classify(BaseSingle):

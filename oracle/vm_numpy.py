@@ -128,6 +128,30 @@ def run_program(prog, inputs, n):
                         nodata = ((np.abs(x32 - np.float32(y)) <= np.float32(tol)) & y_finite) | (x32 == np.float32(y))
                 r = np.full(n, value, dtype=rc)
                 nd = nodata
+            elif op == 25:  # fillnodata: b where b is data, else a
+                if S.flags & 4:
+                    nodata = ndb
+                else:
+                    y, tol = S.aux2.f64, S.aux1.f64
+                    y_finite = bool(S.flags & 2)
+                    if S.flags & 1:
+                        x64 = b.astype("f8")
+                        nodata = ((np.abs(x64 - y) <= tol) & y_finite) | (x64 == y)
+                    else:
+                        x32 = b.astype("f4")
+                        nodata = ((np.abs(x32 - np.float32(y)) <= np.float32(tol)) & y_finite) | (x32 == np.float32(y))
+                r = np.where(nodata, a, b)
+                nd = np.zeros(n, dtype=bool)
+            elif op == 23:  # maskbelow
+                r = a.copy()
+                nd = a < rc.type(_scalar(S.aux0, cls))
+            elif op == 24:  # step
+                loc = rc.type(_scalar(S.aux0, cls))
+                r = a.copy()
+                r = np.where(a > loc, rc.type(_scalar(S.aux3, cls)), r)
+                r = np.where(a == loc, rc.type(_scalar(S.aux2, cls)), r)
+                r = np.where(a < loc, rc.type(_scalar(S.aux1, cls)), r)
+                nd = nda
             else:  # copy
                 r = a.copy()
             if cls == 1 and S.round_f32:

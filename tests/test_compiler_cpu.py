@@ -39,6 +39,12 @@ def test_n1_wrapper_ops(cpu_vm, case):
     op = case["op"]
     if op in ("invert", "isdata", "isnodata"):
         out = devops.unary_bool_process(op, case["args"][0])
+    elif op == "maskbelow":
+        out = devops.maskbelow_process(*case["args"])
+    elif op == "step":
+        out = devops.step_process(*case["args"])
+    elif op == "fillnodata":
+        out = devops.fillnodata_process(case["kwargs"], *case["args"])
     else:
         out = devops.math_process(op, case["kwargs"], *case["args"])
     assert_result_equal(out, case["expect"], ULP_OPS.get(op, 0), case["id"])

@@ -39,6 +39,12 @@ def test_n1_wrapper_golden(gpu, case):
     op = case["op"]
     if op in ("invert", "isdata", "isnodata"):
         out = devops.unary_bool_process(op, case["args"][0])
+    elif op == "maskbelow":
+        out = devops.maskbelow_process(*case["args"])
+    elif op == "step":
+        out = devops.step_process(*case["args"])
+    elif op == "fillnodata":
+        out = devops.fillnodata_process(case["kwargs"], *case["args"])
     else:
         out = devops.math_process(op, case["kwargs"], *case["args"])
     assert_result_equal(out, case["expect"], ULP_OPS.get(op, 0), case["id"])
@@ -188,7 +194,7 @@ from dask_geomodeling_amd import config as gmconfig  # noqa: E402
 from dask_geomodeling_amd import raster  # noqa: E402
 
 VIEW_ULP = {"Power": 1, "Exp": 3, "Log": 3, "Log10": 3}
-NOT_YET = ("FillNoData", "Step", "MaskBelow")
+NOT_YET = ()
 
 
 def _uses(expr, names):
