@@ -42,8 +42,12 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--side", type=int, default=4096, help="tile side in pixels")
-    p.add_argument("--tiles", type=int, default=16, help="tile pairs per GPU per step")
+    p.add_argument("--workload", default="chain5", choices=["chain5", "reclass", "bilinear", "mosaic"],
+                   help="chain5 = the headline (BASELINE.json configs[1]); reclass = configs[2] "
+                        "(Reclassify + Mask on int32 tiles); bilinear = configs[3] (2x upsample); "
+                        "mosaic = configs[4] (10-Block view over a 65536^2 procedural mosaic, tiles sharded)")
+    p.add_argument("--side", type=int, default=0, help="tile side in pixels (0 = the workload's own size)")
+    p.add_argument("--tiles", type=int, default=0, help="tiles per GPU per step (0 = the workload's default)")
     p.add_argument("--cpu-tiles", type=int, default=-1, help="tiles of the CPU baseline sample (0 = skip)")
     p.add_argument("--no-check", action="store_true", help="skip the oracle check of one tile")
     p.add_argument("--dry-run", action="store_true",
@@ -72,6 +76,72 @@ def build_batch(raster, side, tiles, rank):
         jobs.append((fuse_graph(graph, name), name))
         seeds.append((sa, sb))
     return jobs, seeds, request
+
+
+def build_reclass(raster, side, tiles, rank):
+    """configs[2]: Mask(Reclassify(int32 tile, 128-entry table), 1); Reclassify int32 -> int64 is
+    12 B/px, Mask int64 -> uint8 9 B/px (two launches per tile: 21 B/px)."""
+    from dask_geomodeling_amd.fuse import fuse_graph
+    from dask_geomodeling_amd.raster.sources import generate_window
+
+    table = [[k, (7 * k) % 1000] for k in range(0, 256, 2)]
+    request = dict(mode="vals", bbox=(0.0, 0.0, float(side), float(side)), width=side, height=side,
+                   projection="EPSG:28992")
+    jobs = []
+    for i in range(tiles):
+        d = generate_window((side, side), "i4", 2000 + 100 * rank + i, 0.0, 256.0, 2147483647, (50, 50), 0, 0, side, side)
+        src = raster.MemorySource(d, 2147483647, "EPSG:28992", 1.0, (0.0, float(side)))
+        view = raster.Mask(raster.Reclassify(src, table), 1)
+        graph, name = view.get_compute_graph(**request)
+        jobs.append((fuse_graph(graph, name), name))
+    return jobs
+
+
+def build_bilinear(raster, side, tiles, rank):
+    """configs[3]: bilinear 2x upsample of a float32 side^2 tile -> (2 side)^2: 5 B per output px."""
+    from dask_geomodeling_amd.raster.sources import generate_window
+
+    request = dict(mode="vals", bbox=(0.0, 0.0, float(side), float(side)), width=2 * side, height=2 * side,
+                   projection="EPSG:28992")
+    jobs = []
+    for i in range(tiles):
+        d = generate_window((side, side), "f4", 3000 + 100 * rank + i, 0.0, 100.0, F32MAX, LATTICE, 0, 0, side, side)
+        src = raster.MemorySource(d, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(side)))
+        view = raster.SpatialResample(src, 2, "bilinear")
+        jobs.append(view.get_compute_graph(**request))
+    return jobs
+
+
+MOSAIC_SIDE = 65536
+
+
+def mosaic_view(raster):
+    """configs[4]: 10 Blocks (Add, Multiply, Subtract, Divide, Greater, Clip, Classify, Reclassify, Mask
+    under a RasterTiler) over four procedural leaves of a 65536^2 mosaic."""
+    def leaf(seed):
+        return raster.SyntheticSource((MOSAIC_SIDE, MOSAIC_SIDE), "f4", seed, 0.0, 100.0, F32MAX, LATTICE,
+                                      "EPSG:28992", 1.0, (0.0, float(MOSAIC_SIDE)))
+    A, B, C, D = leaf(11), leaf(12), leaf(13), leaf(14)
+    x = raster.Divide(raster.Subtract(raster.Multiply(raster.Add(A, B), 0.5), C), 2.0)
+    x = raster.Clip(x, raster.Greater(D, 20.0))
+    x = raster.Classify(x, [-50.0, -10.0, 0.0, 10.0, 50.0])
+    x = raster.Reclassify(x, [[0, 10], [1, 11], [3, 13], [5, 15]])
+    return raster.Mask(x, 1)
+
+
+def build_mosaic(raster, tile, rank, world):
+    """The tile sub-graphs of RasterTiler(view, tile) over the whole mosaic that this rank owns."""
+    from dask_geomodeling_amd import shard
+    from dask_geomodeling_amd.fuse import fuse_graph
+
+    tiler = raster.RasterTiler(mosaic_view(raster), tile)
+    request = dict(mode="vals", bbox=(0.0, 0.0, float(MOSAIC_SIDE), float(MOSAIC_SIDE)), width=MOSAIC_SIDE,
+                   height=MOSAIC_SIDE, projection="EPSG:28992")
+    graph, name = tiler.get_compute_graph(**request)
+    _, tile_keys = shard.split_tiler_graph(graph, name)
+    mine = shard.owned_tiles(len(tile_keys), rank, world)
+    fused = fuse_graph(graph, name)
+    return [(fused, tile_keys[t]) for t in mine], len(tile_keys)
 
 
 def oracle_chain(a, b):
@@ -120,7 +190,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    side, tiles = args.side, args.tiles
+    defaults = {"chain5": (4096, 16), "reclass": (8192, 4), "bilinear": (16384, 1), "mosaic": (4096, 0)}
+    side = args.side or defaults[args.workload][0]
+    tiles = args.tiles or defaults[args.workload][1]
+    if args.workload != "chain5":
+        args.no_check = True
     if args.dry_run:
         class _NoDevice:  # harness test only: no device, no kernels, no numbers worth reading
             class Event:
@@ -153,7 +227,16 @@ def main():
 
         runtime.require_device()
         runtime.set_device(local_rank % runtime.device_count())
-        jobs, seeds, _ = build_batch(raster, side, tiles, rank)
+        seeds = []
+        if args.workload == "chain5":
+            jobs, seeds, _ = build_batch(raster, side, tiles, rank)
+        elif args.workload == "reclass":
+            jobs = build_reclass(raster, side, tiles, rank)
+        elif args.workload == "bilinear":
+            jobs = build_bilinear(raster, side, tiles, rank)
+        else:
+            jobs, n_mosaic_tiles = build_mosaic(raster, side, rank, world)
+            tiles = len(jobs)
         runtime.sync()
 
         def step():
@@ -194,7 +277,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if rank == 0:
+    if rank == 0 and args.workload != "chain5":
+        # secondary workloads (BASELINE.json configs[2..4]): same line format, their own byte model
+        out_side = 2 * side if args.workload == "bilinear" else side
+        if args.workload == "mosaic":
+            px_per_step = MOSAIC_SIDE * MOSAIC_SIDE  # all ranks together cover the mosaic once per step
+            scaling = "strong"
+        else:
+            px_per_step = world * tiles * out_side * out_side
+            scaling = "weak"
+        bytes_px = {"reclass": 21, "bilinear": 5, "mosaic": None}[args.workload]
+        value = px_per_step * args.steps / elapsed / 1e6
+        out = {"metric": "Mpix/s, workload %s" % args.workload, "value": round(value, 1), "unit": "Mpix/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
+               "vs_baseline": None, "dtype": {"reclass": "int64", "bilinear": "f64", "mosaic": "f32"}[args.workload],
+               "data": "synthetic",
+               "config": {"workload": args.workload, "tile": [side, side], "tiles_per_gpu": tiles,
+                          "algorithmic_bytes_per_px": bytes_px}}
+        if bytes_px:
+            gbs = value * 1e6 * bytes_px / world / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                               "note": "whole-step rate x algorithmic bytes (several kernels per tile)"}
+        print(json.dumps(out), flush=True)
+    elif rank == 0:
         px_per_step = world * tiles * side * side
         value = px_per_step * args.steps / elapsed / 1e6
         achieved = BYTES_PER_PX * side * side / (kernel_ms * 1e-3) / 1e9
