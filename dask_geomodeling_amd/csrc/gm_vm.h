@@ -22,6 +22,7 @@
 // No MFMA: the path is element-wise and HBM-bound (12 B/px for the canonical chain).
 #pragma once
 #include <cmath>
+#include <cstddef>
 #include <type_traits>
 
 #include "gm_common.h"
@@ -72,6 +73,19 @@ struct VmArgs {
   unsigned int xcd_chunking;
   unsigned int nontemporal;  // bit0 loads, bit1 stores
 };
+
+// The launch arguments (3.4 KB) are read straight from the kernarg segment (constant address
+// space) with explicit typed loads -> s_load_dword*; the by-value parameter itself is never
+// touched, so the compiler cannot decide to spill a private copy of it to scratch.
+typedef const __attribute__((address_space(4))) char* kargs_t;
+template <typename T>
+__device__ __forceinline__ T kload(kargs_t base, size_t offset) {
+  T v;
+  __builtin_memcpy(&v, base + offset, sizeof(T));
+  return v;
+}
+#define GM_KARG(base, member) kload<decltype(VmArgs::member)>(base, offsetof(VmArgs, member))
+#define GM_KPROG(base, member) kload<decltype(gm_program::member)>(base, offsetof(VmArgs, prog) + offsetof(gm_program, member))
 
 template <typename T>
 __device__ __forceinline__ T ld(const T* p, bool nt) {
@@ -270,8 +284,11 @@ __device__ __forceinline__ bool in_native(const gm_input_desc& D) { return ((D.b
 template <typename RC, int N, int NIN, int NT, bool HEAVY>
 struct Machine {
   RC in[NIN][N];
-  RC tmp[NT][N];
+  RC tmp0[N], tmp1[N], tmp2[N], tmp3[N];  // separate members (an array of arrays kept the temps in scratch)
   RC acc[N];
+
+  __device__ __forceinline__ RC* tmp_ptr(int k) { return k == 0 ? tmp0 : (k == 1 ? tmp1 : (k == 2 ? tmp2 : tmp3)); }
+  __device__ __forceinline__ const RC* tmp_ptr(int k) const { return k == 0 ? tmp0 : (k == 1 ? tmp1 : (k == 2 ? tmp2 : tmp3)); }
 
   // operand fetch; every branch below is wave-uniform
   __device__ __forceinline__ void fetch(const gm_operand& o, RC (&v)[N]) const {
@@ -300,7 +317,7 @@ struct Machine {
 #define GM_TMP_CASE(K)                                                   \
   case K:                                                                \
     if constexpr (K < NT) {                                              \
-      _Pragma("unroll") for (int k = 0; k < N; ++k) v[k] = tmp[K][k];    \
+      _Pragma("unroll") for (int k = 0; k < N; ++k) v[k] = tmp_ptr(K)[k];    \
     }                                                                    \
     break;
           GM_TMP_CASE(0) GM_TMP_CASE(1) GM_TMP_CASE(2) GM_TMP_CASE(3)
@@ -497,7 +514,7 @@ struct Machine {
 #define GM_SAVE_CASE(K)                                                    \
   case K:                                                                  \
     if constexpr (K < NT) {                                                \
-      _Pragma("unroll") for (int k = 0; k < N; ++k) tmp[K][k] = acc[k];    \
+      _Pragma("unroll") for (int k = 0; k < N; ++k) tmp_ptr(K)[k] = acc[k];    \
     }                                                                      \
     break;
           GM_SAVE_CASE(0) GM_SAVE_CASE(1) GM_SAVE_CASE(2) GM_SAVE_CASE(3)
@@ -592,7 +609,7 @@ struct Machine {
   // (kind | src << 8), most frequent routes first; every body updates the accumulator in place
   // and leaves through the single exit of the chain, so the register allocator keeps the state
   // arrays in place (nested switches cost a copy of the whole accumulator per tree level).
-  __device__ __forceinline__ void exec(const gm_program& P, const gm_uop& U) {
+  __device__ __forceinline__ void exec(kargs_t K, const gm_uop& U) {
     const unsigned route = U.route & 0xffffu;
 #define GM_ROUTE(KIND, SRC) ((unsigned)(KIND) | ((unsigned)(SRC) << 8))
 #define GM_FAST_SCALAR(KIND) \
@@ -600,13 +617,13 @@ struct Machine {
 #define GM_FAST_IN(KIND, K) \
   if constexpr (K < NIN) { if (route == GM_ROUTE(KIND, UOP_SRC_INPUT + K)) { fast_op<false>(U, KIND, in[K]); return; } }
 #define GM_FAST_TMP(KIND, K) \
-  if constexpr (K < NT) { if (route == GM_ROUTE(KIND, UOP_SRC_TEMP + K)) { fast_op<false>(U, KIND, tmp[K]); return; } }
+  if constexpr (K < NT) { if (route == GM_ROUTE(KIND, UOP_SRC_TEMP + K)) { fast_op<false>(U, KIND, tmp_ptr(K)); return; } }
 #define GM_LD_IN(K) \
   if constexpr (K < NIN) { if (route == GM_ROUTE(UOP_LD, UOP_SRC_INPUT + K)) { load_acc(in[K]); return; } }
 #define GM_LD_TMP(K) \
-  if constexpr (K < NT) { if (route == GM_ROUTE(UOP_LD, UOP_SRC_TEMP + K)) { load_acc(tmp[K]); return; } }
+  if constexpr (K < NT) { if (route == GM_ROUTE(UOP_LD, UOP_SRC_TEMP + K)) { load_acc(tmp_ptr(K)); return; } }
 #define GM_ST_TMP(K) \
-  if constexpr (K < NT) { if (route == GM_ROUTE(UOP_ST, K)) { _Pragma("unroll") for (int k = 0; k < N; ++k) tmp[K][k] = acc[k]; return; } }
+  if constexpr (K < NT) { if (route == GM_ROUTE(UOP_ST, K)) { _Pragma("unroll") for (int k = 0; k < N; ++k) tmp_ptr(K)[k] = acc[k]; return; } }
 #define GM_FAST_ALL_SRC(KIND)                                                                         \
   GM_FAST_IN(KIND, 0) GM_FAST_IN(KIND, 1) GM_FAST_IN(KIND, 2) GM_FAST_IN(KIND, 3) GM_FAST_IN(KIND, 4) \
   GM_FAST_IN(KIND, 5) GM_FAST_IN(KIND, 6) GM_FAST_IN(KIND, 7) GM_FAST_TMP(KIND, 0) GM_FAST_TMP(KIND, 1) \
@@ -625,7 +642,10 @@ struct Machine {
       for (int k = 0; k < N; ++k) acc[k] = v;
       return;
     }
-    if ((route & 0xffu) == UOP_GENERIC) step(P.steps[U.arg]);
+    if ((route & 0xffu) == UOP_GENERIC) {
+      const gm_step S = kload<gm_step>(K, offsetof(VmArgs, prog) + offsetof(gm_program, steps) + sizeof(gm_step) * U.arg);
+      step(S);
+    }
 #undef GM_ROUTE
 #undef GM_FAST_SCALAR
 #undef GM_FAST_IN
@@ -636,8 +656,12 @@ struct Machine {
 #undef GM_FAST_ALL_SRC
   }
 
-  __device__ __forceinline__ void run(const gm_program& P, const gm_uop* uops, unsigned n_uops) {
-    for (unsigned i = 0; i < n_uops; ++i) exec(P, uops[i]);
+  __device__ __forceinline__ void run(kargs_t K) {
+    const unsigned n_uops = GM_KARG(K, n_uops);
+    for (unsigned i = 0; i < n_uops; ++i) {
+      const gm_uop U = kload<gm_uop>(K, offsetof(VmArgs, uops) + sizeof(gm_uop) * i);
+      exec(K, U);
+    }
   }
 };
 
@@ -668,21 +692,24 @@ template <> struct native_vec<float> { typedef f32x4 type; };
 template <> struct native_vec<int> { typedef i32x4 type; };
 
 template <typename RC, int G, int NIN, int NT, bool HEAVY>
-__global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
-  const gm_program& P = A.prog;
-  const bool nt_ld = (A.nontemporal & 1u) != 0, nt_st = (A.nontemporal & 2u) != 0;
-  const unsigned n_in = P.n_inputs;
-  const int out_dtype = (int)P.out_dtype;
+__global__ __launch_bounds__(256) void vm_kernel(const VmArgs) {
+  const kargs_t K = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const unsigned nontemporal = GM_KARG(K, nontemporal);
+  const bool nt_ld = (nontemporal & 1u) != 0, nt_st = (nontemporal & 2u) != 0;
+  const unsigned long long n_groups = GM_KARG(K, n_groups);
+  void* const out = GM_KARG(K, out);
+  const unsigned n_in = GM_KPROG(K, n_inputs);
+  const int out_dtype = (int)GM_KPROG(K, out_dtype);
   constexpr int N = 4 * G;
 
   unsigned long long stride, end;
-  unsigned long long it = first_iter(A.n_iters, A.xcd_chunking, &stride, &end);
+  unsigned long long it = first_iter(GM_KARG(K, n_iters), GM_KARG(K, xcd_chunking), &stride, &end);
   for (; it < end; it += stride) {
     Machine<RC, N, NIN, NT, HEAVY> M;
     const unsigned long long g0 = it * (256ull * G) + threadIdx.x;  // sub-vector u is group g0 + 256*u
     // phase 1: all leaf loads in flight (NIN*G independent 16-byte loads per lane)
     bool native = false;
-    if constexpr (sizeof(RC) == 4) native = A.native != 0;
+    if constexpr (sizeof(RC) == 4) native = GM_KARG(K, native) != 0;
     if (native) {
       // every tile already has the class' dtype: straight 16-byte loads, no dtype dispatch
       if constexpr (sizeof(RC) == 4) {
@@ -694,7 +721,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
             for (int u = 0; u < G; ++u) {
               const unsigned long long g = g0 + 256ull * u;
               V4 x = {0, 0, 0, 0};
-              if (g < A.n_groups) x = ld((const V4*)A.in[k] + g, nt_ld);
+              if (g < n_groups) x = ld((const V4*)kload<const void*>(K, offsetof(VmArgs, in) + 8 * k) + g, nt_ld);
 #pragma unroll
               for (int q = 0; q < 4; ++q) M.in[k][4 * u + q] = x[q];
             }
@@ -705,10 +732,11 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       if (k < (int)n_in) {
-        const gm_input_desc& D = P.inputs[k];
+        const gm_input_desc D = kload<gm_input_desc>(K, offsetof(VmArgs, prog) + offsetof(gm_program, inputs) + sizeof(gm_input_desc) * k);
+        const void* const in_k = kload<const void*>(K, offsetof(VmArgs, in) + 8 * k);
         if (in_broadcast(D)) {
           RC one[1];
-          load_elems<RC, 1>(A.in[k], in_dtype(D), 0, false, one, in_native(D), (long long)D.ndv.i64);
+          load_elems<RC, 1>(in_k, in_dtype(D), 0, false, one, in_native(D), (long long)D.ndv.i64);
 #pragma unroll
           for (int q = 0; q < N; ++q) M.in[k][q] = one[0];
         } else {
@@ -716,8 +744,8 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
           for (int u = 0; u < G; ++u) {
             RC v4[4] = {(RC)0, (RC)0, (RC)0, (RC)0};
             const unsigned long long g = g0 + 256ull * u;
-            if (g < A.n_groups)
-              load_elems<RC, 4>(A.in[k], in_dtype(D), g * 4ull, nt_ld, v4, in_native(D), (long long)D.ndv.i64);
+            if (g < n_groups)
+              load_elems<RC, 4>(in_k, in_dtype(D), g * 4ull, nt_ld, v4, in_native(D), (long long)D.ndv.i64);
 #pragma unroll
             for (int q = 0; q < 4; ++q) M.in[k][4 * u + q] = v4[q];
           }
@@ -725,24 +753,24 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
       }
     }
     // phase 2: interpret; phase 3: store
-    M.run(P, A.uops, A.n_uops);
+    M.run(K);
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const unsigned long long g = g0 + 256ull * u;
-      if (g < A.n_groups) {
+      if (g < n_groups) {
         if (native) {
           if constexpr (sizeof(RC) == 4) {
             typedef typename native_vec<RC>::type V4;
             V4 x;
 #pragma unroll
             for (int q = 0; q < 4; ++q) x[q] = M.acc[4 * u + q];
-            st((V4*)A.out + g, x, nt_st);
+            st((V4*)out + g, x, nt_st);
           }
         } else {
           RC v4[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) v4[q] = M.acc[4 * u + q];
-          store_elems<RC, 4>(A.out, out_dtype, g * 4ull, nt_st, v4);
+          store_elems<RC, 4>(out, out_dtype, g * 4ull, nt_st, v4);
         }
       }
     }
@@ -752,23 +780,27 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs A) {
 // scalar tail kernel: the elements the 16-byte vector path cannot take (n % 4, or
 // everything when a pointer is not 16-byte aligned); one element per lane, grid-stride
 template <typename RC, int NIN, int NT, bool HEAVY>
-__global__ __launch_bounds__(256) void vm_tail_kernel(const VmArgs A) {
-  const gm_program& P = A.prog;
-  const unsigned n_in = P.n_inputs;
+__global__ __launch_bounds__(256) void vm_tail_kernel(const VmArgs) {
+  const kargs_t K = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+  const unsigned n_in = GM_KPROG(K, n_inputs);
+  const int out_dtype = (int)GM_KPROG(K, out_dtype);
+  const unsigned long long n_total = GM_KARG(K, n);
+  void* const out = GM_KARG(K, out);
   const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long e = A.tail_start + tid; e < A.n; e += nthreads) {
+  for (unsigned long long e = GM_KARG(K, tail_start) + tid; e < n_total; e += nthreads) {
     Machine<RC, 1, NIN, NT, HEAVY> M1;
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       if (k < (int)n_in) {
-        const gm_input_desc& D = P.inputs[k];
-        load_elems<RC, 1>(A.in[k], in_dtype(D), in_broadcast(D) ? 0ull : e, false, M1.in[k], in_native(D),
+        const gm_input_desc D = kload<gm_input_desc>(K, offsetof(VmArgs, prog) + offsetof(gm_program, inputs) + sizeof(gm_input_desc) * k);
+        const void* const in_k = kload<const void*>(K, offsetof(VmArgs, in) + 8 * k);
+        load_elems<RC, 1>(in_k, in_dtype(D), in_broadcast(D) ? 0ull : e, false, M1.in[k], in_native(D),
                           (long long)D.ndv.i64);
       }
     }
-    M1.run(P, A.uops, A.n_uops);
-    store_elems<RC, 1>(A.out, (int)P.out_dtype, e, false, M1.acc);
+    M1.run(K);
+    store_elems<RC, 1>(out, out_dtype, e, false, M1.acc);
   }
 }
 
