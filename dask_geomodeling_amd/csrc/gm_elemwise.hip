@@ -1,12 +1,17 @@
 // K1 host side: validates a gm_program and launches the VM kernel of its register
 // class (kernels: gm_vm.h, instantiated per class in gm_vm_<class>.hip).
+#include <memory>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
 #include "gm_vm.h"
 
 using namespace gmvm;
 
 namespace {
 
-gm_vm_tuning g_tuning = {8, 0, 0, 0};
+gm_vm_tuning g_tuning = {0, 0, {0, 0}};
 
 int validate_operand(const gm_operand& o, unsigned n_inputs, const char* which, unsigned step) {
   const unsigned kind = o.bits & 0xffu, index = (o.bits >> 8) & 0xffu;
@@ -26,11 +31,11 @@ int validate_operand(const gm_operand& o, unsigned n_inputs, const char* which, 
 // Lower the program into micro-ops (gm_vm.h).  A step whose accumulator-side operand is the
 // running value and whose opcode is +, -, *, / or Clip becomes a fast route; a leading non-ACC
 // left operand becomes an explicit LD; save_temp becomes ST.  Anything else stays GENERIC.
-int lower(const gm_program* prog, VmArgs* args) {
+int lower(const gm_program* prog, VmCode* code, unsigned* n_uops) {
   unsigned n = 0;
   auto push = [&](unsigned kind, unsigned src, unsigned arg, gm_scalar acc_ndv, gm_scalar b_val, gm_scalar fill) -> bool {
     if (n >= (unsigned)GM_MAX_UOPS) return false;
-    gm_uop& u = args->uops[n++];
+    gm_uop& u = code->uops[n++];
     u.route = kind | (src << 8);
     u.arg = arg;
     u.acc_ndv = acc_ndv;
@@ -101,39 +106,38 @@ int lower(const gm_program* prog, VmArgs* args) {
       if (!push(UOP_GENERIC, 0, s, zero, zero, zero)) return -1;  // its save_temp is handled by step()
     }
   }
-  args->n_uops = n;
+  *n_uops = n;
   return 0;
 }
 
-}  // namespace
+// ---- lowered programs, device resident, cached by content per device ------------------------
+struct CodeEntry {
+  gm_program prog;     // the key (compared in full)
+  VmCode host;         // staging copy: stays alive for the asynchronous upload
+  VmCode* dev = nullptr;
+  unsigned n_uops = 0;
+  bool heavy = false;
+  int size = 0;        // kernel size class S/M/L
+  bool native = false;
+};
 
-extern "C" {
+std::mutex g_code_mu;
+std::unordered_map<unsigned long long, std::vector<std::unique_ptr<CodeEntry>>> g_code;  // (device, hash) buckets
 
-int gm_vm_set_tuning(const gm_vm_tuning* t) {
-  if (!t) return gm::fail(GM_ERR_INVALID, "null tuning");
-  gm_vm_tuning v = *t;
-  if (v.vec != 4 && v.vec != 8 && v.vec != 16) v.vec = 8;
-  if (v.blocks_per_cu < 0 || v.blocks_per_cu > 4096) v.blocks_per_cu = 0;
-  g_tuning = v;
-  return GM_OK;
+unsigned long long hash_program(const gm_program& p, int device) {
+  const unsigned char* b = (const unsigned char*)&p;
+  unsigned long long h = 1469598103934665603ull ^ (unsigned long long)device;
+  for (size_t i = 0; i < sizeof(gm_program); ++i) h = (h ^ b[i]) * 1099511628211ull;
+  return h;
 }
 
-int gm_vm_get_tuning(gm_vm_tuning* t) {
-  if (!t) return gm::fail(GM_ERR_INVALID, "null tuning");
-  *t = g_tuning;
-  return GM_OK;
-}
-
-int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out, size_t n) {
-  if (!prog || !out || (!inputs && prog->n_inputs)) return gm::fail(GM_ERR_INVALID, "null argument");
+int validate(const gm_program* prog) {
   if (prog->n_steps == 0 || prog->n_steps > GM_MAX_STEPS) return gm::fail(GM_ERR_INVALID, "n_steps %u", prog->n_steps);
   if (prog->n_inputs > GM_MAX_INPUTS) return gm::fail(GM_ERR_INVALID, "n_inputs %u", prog->n_inputs);
   if (prog->reg_class > GM_CLASS_I64) return gm::fail(GM_ERR_INVALID, "reg_class %u", prog->reg_class);
   if (gm::dtype_size(prog->out_dtype) == 0) return gm::fail(GM_ERR_INVALID, "out_dtype %u", prog->out_dtype);
-  for (unsigned k = 0; k < prog->n_inputs; ++k) {
+  for (unsigned k = 0; k < prog->n_inputs; ++k)
     if (gm::dtype_size(prog->inputs[k].bits & 0xffu) == 0) return gm::fail(GM_ERR_INVALID, "input %u dtype %u", k, prog->inputs[k].bits & 0xffu);
-    if (!inputs[k]) return gm::fail(GM_ERR_INVALID, "input %u is null", k);
-  }
   for (unsigned s = 0; s < prog->n_steps; ++s) {
     const gm_step& S = prog->steps[s];
     const unsigned opcode = S.bits & 0xffu, save_temp = (S.bits >> 8) & 0xffu;
@@ -146,65 +150,150 @@ int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out
     if (opcode == GM_OP_DIV && prog->reg_class >= GM_CLASS_I32)
       return gm::fail(GM_ERR_INVALID, "step %u: DIV in an integer class", s);
   }
-  if (n == 0) return GM_OK;
+  return GM_OK;
+}
+
+// validate + lower + upload once per (device, program); later launches only fill the kernarg
+int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) {
+  int device = 0;
+  GM_HIP(hipGetDevice(&device));
+  // only the used part of the program is meaningful: canonicalise the rest so that equal
+  // programs hash equal whatever the caller left in the unused slots
+  gm_program key;
+  memset(&key, 0, sizeof(key));
+  key.n_steps = prog->n_steps;
+  key.n_inputs = prog->n_inputs;
+  key.reg_class = prog->reg_class;
+  key.out_dtype = prog->out_dtype;
+  if (prog->n_steps > GM_MAX_STEPS || prog->n_inputs > GM_MAX_INPUTS) return validate(prog);
+  memcpy(key.inputs, prog->inputs, sizeof(gm_input_desc) * prog->n_inputs);
+  memcpy(key.steps, prog->steps, sizeof(gm_step) * prog->n_steps);
+  const unsigned long long h = hash_program(key, device);
+  std::lock_guard<std::mutex> lk(g_code_mu);
+  auto& bucket = g_code[h];
+  for (auto& e : bucket)
+    if (memcmp(&e->prog, &key, sizeof(key)) == 0) {
+      *out = e.get();
+      return GM_OK;
+    }
+  int rc = validate(&key);
+  if (rc) return rc;
+  std::unique_ptr<CodeEntry> e(new CodeEntry);
+  e->prog = key;
+  memset(&e->host, 0, sizeof(VmCode));
+  memcpy(e->host.inputs, key.inputs, sizeof(key.inputs));
+  memcpy(e->host.steps, key.steps, sizeof(key.steps));
+  if (lower(&key, &e->host, &e->n_uops) != 0) return gm::fail(GM_ERR_INVALID, "program does not fit %d micro-ops", GM_MAX_UOPS);
+  const int native_code = key.reg_class == GM_CLASS_F32 ? GM_F32 : (key.reg_class == GM_CLASS_I32 ? GM_I32 : -1);
+  bool native = native_code >= 0 && (int)key.out_dtype == native_code;
+  for (unsigned k = 0; k < key.n_inputs && native; ++k)
+    native = ((int)(key.inputs[k].bits & 0xffu) == native_code) && !((key.inputs[k].bits >> 8) & 3u);
+  e->native = native;
+  unsigned max_tmp = 0;
+  for (unsigned s = 0; s < key.n_steps; ++s) {
+    const gm_step& S = key.steps[s];
+    const unsigned op = S.bits & 0xffu, save_temp = (S.bits >> 8) & 0xffu;
+    if (op == GM_OP_POW || op == GM_OP_EXP || op == GM_OP_LOG || op == GM_OP_LOG10) e->heavy = true;
+    if (save_temp > max_tmp) max_tmp = save_temp;
+    for (const gm_operand* o : {&S.a, &S.b})
+      if ((o->bits & 0xffu) == GM_OPD_TEMP && ((o->bits >> 8) & 0xffu) + 1 > max_tmp) max_tmp = ((o->bits >> 8) & 0xffu) + 1;
+  }
+  e->size = (key.n_inputs <= 2 && max_tmp <= 1) ? 0 : ((key.n_inputs <= 4 && max_tmp <= 2) ? 1 : 2);
+  void* dev = nullptr;
+  rc = gm_malloc(&dev, sizeof(VmCode));
+  if (rc) return rc;
+  e->dev = (VmCode*)dev;
+  GM_HIP(hipMemcpyAsync(dev, &e->host, sizeof(VmCode), hipMemcpyHostToDevice, stream));
+  *out = e.get();
+  bucket.push_back(std::move(e));
+  return GM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gm_vm_set_tuning(const gm_vm_tuning* t) {
+  if (!t) return gm::fail(GM_ERR_INVALID, "null tuning");
+  gm_vm_tuning v = *t;
+  if (v.vec != 0 && v.vec != 4 && v.vec != 8) v.vec = 0;
+  if (v.max_batch < 0 || v.max_batch > GM_MAX_BATCH) v.max_batch = 0;
+  g_tuning = v;
+  return GM_OK;
+}
+
+int gm_vm_get_tuning(gm_vm_tuning* t) {
+  if (!t) return gm::fail(GM_ERR_INVALID, "null tuning");
+  *t = g_tuning;
+  return GM_OK;
+}
+
+int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const* inputs, void* const* outs, size_t n) {
+  if (!prog || !outs || (!inputs && prog->n_inputs)) return gm::fail(GM_ERR_INVALID, "null argument");
+  if (n_tiles < 0) return gm::fail(GM_ERR_INVALID, "n_tiles %d", n_tiles);
   hipStream_t stream = gm::current_stream();
   if (!stream) return GM_ERR_NO_DEVICE;
+  const CodeEntry* code = nullptr;
+  int rc = get_code(prog, stream, &code);
+  if (rc) return rc;
+  const unsigned n_in = code->prog.n_inputs;
+  for (int t = 0; t < n_tiles; ++t) {
+    if (!outs[t]) return gm::fail(GM_ERR_INVALID, "output of tile %d is null", t);
+    for (unsigned k = 0; k < n_in; ++k)
+      if (!inputs[(size_t)t * n_in + k]) return gm::fail(GM_ERR_INVALID, "input %u of tile %d is null", k, t);
+  }
+  if (n == 0 || n_tiles == 0) return GM_OK;
 
-  VmArgs args;
-  memset(&args, 0, sizeof(args));
-  args.prog = *prog;
-  bool aligned = ((uintptr_t)out % 16) == 0;
-  for (unsigned k = 0; k < prog->n_inputs; ++k) {
-    args.in[k] = inputs[k];
-    if (!((prog->inputs[k].bits >> 8) & 1u) && ((uintptr_t)inputs[k] % 16) != 0) aligned = false;
-  }
-  args.out = out;
-  args.n = n;
-  if (lower(prog, &args) != 0) return gm::fail(GM_ERR_INVALID, "program does not fit %d micro-ops", GM_MAX_UOPS);
-  {
-    const int native_code = prog->reg_class == GM_CLASS_F32 ? GM_F32 : (prog->reg_class == GM_CLASS_I32 ? GM_I32 : -1);
-    bool native = native_code >= 0 && (int)prog->out_dtype == native_code;
-    for (unsigned k = 0; k < prog->n_inputs && native; ++k)
-      native = ((int)(prog->inputs[k].bits & 0xffu) == native_code) && !((prog->inputs[k].bits >> 8) & 3u);
-    args.native = native ? 1u : 0u;
-  }
-  bool heavy = false;
-  unsigned max_in = prog->n_inputs, max_tmp = 0;
-  for (unsigned s = 0; s < prog->n_steps; ++s) {
-    const gm_step& S = prog->steps[s];
-    const unsigned op = S.bits & 0xffu, save_temp = (S.bits >> 8) & 0xffu;
-    if (op == GM_OP_POW || op == GM_OP_EXP || op == GM_OP_LOG || op == GM_OP_LOG10) heavy = true;
-    if (save_temp > max_tmp) max_tmp = save_temp;
-  }
-  const int size = (max_in <= 2 && max_tmp <= 1) ? 0 : ((max_in <= 4 && max_tmp <= 2) ? 1 : 2);
-  int G = g_tuning.vec >= 16 ? 4 : (g_tuning.vec >= 8 ? 2 : 1);
-  if (heavy || size == 2) G = 1;
-  else if (size == 1 && G > 2) G = 2;
-  args.n_groups = aligned ? n / 4 : 0;
-  args.tail_start = args.n_groups * 4;
-  const unsigned long long per_iter = 256ull * G;
-  args.n_iters = (args.n_groups + per_iter - 1) / per_iter;
-  args.xcd_chunking = g_tuning.xcd_chunking;
-  args.nontemporal = g_tuning.nontemporal;
-
+  int G = g_tuning.vec == 8 ? 2 : (g_tuning.vec == 4 ? 1 : (code->n_uops > 3 ? 2 : 1));
+  if (code->heavy || code->size == 2) G = 1;
+  const int max_batch = g_tuning.max_batch > 0 ? g_tuning.max_batch : GM_MAX_BATCH;
   const int cus = gm::current_cu_count();
-  unsigned long long cap = (unsigned long long)(cus > 0 ? cus : 256) * (unsigned long long)g_tuning.blocks_per_cu;
-  unsigned long long blocks = args.n_iters;
-  if (cap && blocks > cap) blocks = cap;
-  if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
-  if (args.xcd_chunking && blocks >= 8) blocks -= blocks % 8;
-  const unsigned long long tail = n - args.tail_start;
-  unsigned long long tail_blocks = (tail + 255) / 256;
-  const unsigned long long tail_cap = (unsigned long long)(cus > 0 ? cus : 256) * 8;
-  if (tail_blocks > tail_cap) tail_blocks = tail_cap;
-  dim3 grid((unsigned)blocks), tail_grid((unsigned)tail_blocks);
 
-  switch (prog->reg_class) {
-    case GM_CLASS_F32: return launch_class<float>(args, size, G, heavy, grid, tail_grid, stream);
-    case GM_CLASS_F64: return launch_class<double>(args, size, G, heavy, grid, tail_grid, stream);
-    case GM_CLASS_I32: return launch_class<int>(args, size, G, heavy, grid, tail_grid, stream);
-    default: return launch_class<long long>(args, size, G, heavy, grid, tail_grid, stream);
+  for (int t0 = 0; t0 < n_tiles; t0 += max_batch) {
+    const int nb = n_tiles - t0 < max_batch ? n_tiles - t0 : max_batch;
+    VmLaunch args;
+    memset(&args, 0, sizeof(args));
+    args.code = (unsigned long long)(uintptr_t)code->dev;
+    args.n = n;
+    args.n_uops = code->n_uops;
+    args.n_inputs = n_in;
+    args.out_dtype = code->prog.out_dtype;
+    bool aligned = true;
+    for (int t = 0; t < nb; ++t) {
+      args.out[t] = outs[t0 + t];
+      if (((uintptr_t)args.out[t] % 16) != 0) aligned = false;
+      for (unsigned k = 0; k < n_in; ++k) {
+        const void* p = inputs[(size_t)(t0 + t) * n_in + k];
+        args.in[t][k] = p;
+        if (!((code->prog.inputs[k].bits >> 8) & 1u) && ((uintptr_t)p % 16) != 0) aligned = false;
+      }
+    }
+    args.flags = code->native ? VM_FLAG_NATIVE : 0u;
+    args.n_groups = aligned ? n / 4 : 0;
+    args.tail_start = args.n_groups * 4;
+    const unsigned long long per_block = 256ull * G;
+    unsigned long long blocks = (args.n_groups + per_block - 1) / per_block;
+    if (blocks > 0x7fffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "tile of %zu elements is too large for one launch", n);
+    const unsigned long long tail = n - args.tail_start;
+    unsigned long long tail_blocks = (tail + 255) / 256;
+    const unsigned long long tail_cap = (unsigned long long)(cus > 0 ? cus : 256) * 8;
+    if (tail_blocks > tail_cap) tail_blocks = tail_cap;
+    dim3 grid((unsigned)blocks, (unsigned)nb), tail_grid((unsigned)tail_blocks, (unsigned)nb);
+    switch (code->prog.reg_class) {
+      case GM_CLASS_F32: rc = launch_class<float>(args, code->size, G, code->heavy, grid, tail_grid, stream); break;
+      case GM_CLASS_F64: rc = launch_class<double>(args, code->size, G, code->heavy, grid, tail_grid, stream); break;
+      case GM_CLASS_I32: rc = launch_class<int>(args, code->size, G, code->heavy, grid, tail_grid, stream); break;
+      default: rc = launch_class<long long>(args, code->size, G, code->heavy, grid, tail_grid, stream); break;
+    }
+    if (rc) return rc;
   }
+  return GM_OK;
+}
+
+int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out, size_t n) {
+  if (!out) return gm::fail(GM_ERR_INVALID, "null argument");
+  void* outs[1] = {out};
+  return gm_elemwise_run_batch(prog, 1, inputs, outs, n);
 }
 
 }  // extern "C"

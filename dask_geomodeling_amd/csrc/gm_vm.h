@@ -1,23 +1,25 @@
 // K1: the fused element-wise program kernel ("VM") for gfx950.
 //
-// One launch evaluates a straight-line accumulator program (gmhip.h: gm_program)
-// over one tile.  HBM traffic = one read of every distinct leaf tile + one write of
-// the result; everything in between lives in VGPRs.
+// One launch evaluates a straight-line accumulator program (gmhip.h: gm_program) over a batch of
+// up to GM_MAX_BATCH tiles (blockIdx.y = tile).  HBM traffic = one read of every distinct leaf
+// tile + one write of the result; everything in between lives in VGPRs.
 //
-// Execution shape (wave64, 256-thread workgroups):
-//   * a lane owns G sub-vectors of 4 consecutive elements (N = 4*G elements) per
-//     block-iteration; for every load instruction lane l reads 16 B (4-byte types) at
-//     base + l*16, i.e. each wave-instruction covers one contiguous 1 KiB span (the
-//     coalescing rule of cdna_hip_programming.md section 2);
-//   * all leaf tiles of the program are loaded first (NIN*G independent 16-byte loads
-//     in flight per lane) and converted to the register class; then the program is
-//     interpreted from SGPR-resident step descriptors (kernarg -> s_load).  Every
-//     dispatch branch is wave-uniform (scalar branches, no divergence, no dynamic VGPR
-//     indexing) and its cost is amortised over the N*64 elements a wave owns;
+// Execution shape (wave64, 256-thread workgroups), chosen from measurements on MI355X
+// (tools/ceiling*.hip):
+//   * FULL GRID, no grid-stride loop: a workgroup owns 256*G groups of 4 consecutive elements and
+//     ends.  A 2-read/1-write float4 stream runs 8-10 % faster this way than with persistent
+//     workgroups (fresh waves issue their loads at once; the dispatcher balances the CUs);
+//   * for every load instruction lane l reads 16 B at base + 16*l: one contiguous 1 KiB span per
+//     wave-instruction; loads and stores carry the non-temporal hint (the tiles are streamed once;
+//     +10 % on the same measurement);
+//   * all leaf loads are issued first, then the program is interpreted.  The lowered program
+//     (VmCode) lives in device memory, uploaded once per distinct program, and is read with scalar
+//     loads (s_load_dwordx8 per micro-op); every dispatch branch is wave-uniform.  Decode is a
+//     two-level compare tree (operand source, then operation), about 10 SALU instructions per
+//     micro-op, amortised over the 4*G*64 elements a wave owns;
 //   * every step re-applies the reference rule of raster/elemwise.py:263-296:
 //     no-data = OR(operand == its ndv), compute in the step dtype, non-finite -> fill,
-//     no-data -> fill.  The no-data test is a v_cmp into a lane mask that lives only
-//     until the v_cndmask that consumes it.
+//     no-data -> fill.
 //
 // No MFMA: the path is element-wise and HBM-bound (12 B/px for the canonical chain).
 #pragma once
@@ -59,34 +61,60 @@ struct gm_uop {
   gm_scalar fill;
 };
 
-struct VmArgs {
-  gm_program prog;
+constexpr int GM_MAX_BATCH = 16;
+
+// The lowered program: device resident, one per distinct gm_program (cached by content on the host).
+struct VmCode {
+  gm_input_desc inputs[GM_MAX_INPUTS];
   gm_uop uops[GM_MAX_UOPS];
-  unsigned int n_uops;
-  unsigned int native;  // every input and the output are non-broadcast tiles of the class' own dtype
-  const void* in[GM_MAX_INPUTS];
-  void* out;
-  unsigned long long n;           // total elements
-  unsigned long long n_groups;    // 4-element groups handled by the vector kernel
-  unsigned long long n_iters;     // block-iterations of the vector kernel
-  unsigned long long tail_start;  // first element of the scalar tail kernel
-  unsigned int xcd_chunking;
-  unsigned int nontemporal;  // bit0 loads, bit1 stores
+  gm_step steps[GM_MAX_STEPS];  // bodies of the UOP_GENERIC micro-ops
 };
 
-// The launch arguments (3.4 KB) are read straight from the kernarg segment (constant address
-// space) with explicit typed loads -> s_load_dword*; the by-value parameter itself is never
-// touched, so the compiler cannot decide to spill a private copy of it to scratch.
+// Launch arguments (kernarg segment, 1.3 KB).
+struct VmLaunch {
+  unsigned long long code;        // device address of the VmCode (an integer: the kernel turns it straight
+                                  // into a constant-address-space pointer, so the program is read with s_load)
+  unsigned long long n;           // elements per tile
+  unsigned long long n_groups;    // 4-element groups per tile handled by the vector kernel
+  unsigned long long tail_start;  // first element of the scalar tail kernel
+  unsigned int n_uops;
+  unsigned int n_inputs;
+  unsigned int out_dtype;
+  unsigned int flags;             // bit2 native: every input and the output are non-broadcast tiles of the
+                                  // class' own dtype
+  const void* in[GM_MAX_BATCH][GM_MAX_INPUTS];
+  void* out[GM_MAX_BATCH];
+};
+constexpr unsigned VM_FLAG_NATIVE = 4u;
+
+// Launch arguments and code are read through the constant address space with explicit typed
+// loads -> s_load_dword*; the by-value kernel parameter itself is never touched, so the compiler
+// cannot decide to keep a private copy of it in scratch.
 typedef const __attribute__((address_space(4))) char* kargs_t;
 template <typename T>
 __device__ __forceinline__ T kload(kargs_t base, size_t offset) {
-  T v;
-  __builtin_memcpy(&v, base + offset, sizeof(T));
-  return v;
+  // word-typed loads: the natural alignment of the words is what lets the compiler pick SMEM
+  // (a byte-typed memcpy from a pointer of unknown alignment becomes vector loads + readfirstlane)
+  if constexpr (sizeof(T) % 8 == 0) {
+    typedef const __attribute__((address_space(4))) unsigned long long* w64_t;
+    union { T v; unsigned long long w[sizeof(T) / 8]; } u;
+#pragma unroll
+    for (size_t j = 0; j < sizeof(T) / 8; ++j) u.w[j] = ((w64_t)(base + offset))[j];
+    return u.v;
+  } else {
+    static_assert(sizeof(T) % 4 == 0, "kload: 4-byte granularity");
+    typedef const __attribute__((address_space(4))) unsigned int* w32_t;
+    union { T v; unsigned int w[sizeof(T) / 4]; } u;
+#pragma unroll
+    for (size_t j = 0; j < sizeof(T) / 4; ++j) u.w[j] = ((w32_t)(base + offset))[j];
+    return u.v;
+  }
 }
-#define GM_KARG(base, member) kload<decltype(VmArgs::member)>(base, offsetof(VmArgs, member))
-#define GM_KPROG(base, member) kload<decltype(gm_program::member)>(base, offsetof(VmArgs, prog) + offsetof(gm_program, member))
+#define GM_KARG(base, member) kload<decltype(VmLaunch::member)>(base, offsetof(VmLaunch, member))
 
+// Tiles are streamed exactly once: every tile load and store carries the non-temporal hint
+// (+10 % on a 2-read/1-write float4 stream, tools/ceiling2.hip).  `nt` is a compile-time
+// constant at every call site (a run-time flag gets if-converted and the hint is lost).
 template <typename T>
 __device__ __forceinline__ T ld(const T* p, bool nt) {
   return nt ? __builtin_nontemporal_load(p) : *p;
@@ -284,11 +312,21 @@ __device__ __forceinline__ bool in_native(const gm_input_desc& D) { return ((D.b
 template <typename RC, int N, int NIN, int NT, bool HEAVY>
 struct Machine {
   RC in[NIN][N];
-  RC tmp0[N], tmp1[N], tmp2[N], tmp3[N];  // separate members (an array of arrays kept the temps in scratch)
-  RC acc[N];
+  RC tmp0[N], tmp1[N], tmp2[N], tmp3[N];  // separate members, selected at compile time only: an
+  RC acc[N];                               // array of arrays ends up in scratch for NT >= 2
 
-  __device__ __forceinline__ RC* tmp_ptr(int k) { return k == 0 ? tmp0 : (k == 1 ? tmp1 : (k == 2 ? tmp2 : tmp3)); }
-  __device__ __forceinline__ const RC* tmp_ptr(int k) const { return k == 0 ? tmp0 : (k == 1 ? tmp1 : (k == 2 ? tmp2 : tmp3)); }
+  template <int K> __device__ __forceinline__ RC (&T())[N] {
+    if constexpr (K == 0) return tmp0;
+    else if constexpr (K == 1) return tmp1;
+    else if constexpr (K == 2) return tmp2;
+    else return tmp3;
+  }
+  template <int K> __device__ __forceinline__ const RC (&T() const)[N] {
+    if constexpr (K == 0) return tmp0;
+    else if constexpr (K == 1) return tmp1;
+    else if constexpr (K == 2) return tmp2;
+    else return tmp3;
+  }
 
   // operand fetch; every branch below is wave-uniform
   __device__ __forceinline__ void fetch(const gm_operand& o, RC (&v)[N]) const {
@@ -317,7 +355,7 @@ struct Machine {
 #define GM_TMP_CASE(K)                                                   \
   case K:                                                                \
     if constexpr (K < NT) {                                              \
-      _Pragma("unroll") for (int k = 0; k < N; ++k) v[k] = tmp_ptr(K)[k];    \
+      _Pragma("unroll") for (int k = 0; k < N; ++k) v[k] = T<K>()[k];    \
     }                                                                    \
     break;
           GM_TMP_CASE(0) GM_TMP_CASE(1) GM_TMP_CASE(2) GM_TMP_CASE(3)
@@ -514,7 +552,7 @@ struct Machine {
 #define GM_SAVE_CASE(K)                                                    \
   case K:                                                                  \
     if constexpr (K < NT) {                                                \
-      _Pragma("unroll") for (int k = 0; k < N; ++k) tmp_ptr(K)[k] = acc[k];    \
+      _Pragma("unroll") for (int k = 0; k < N; ++k) T<K>()[k] = acc[k];    \
     }                                                                      \
     break;
           GM_SAVE_CASE(0) GM_SAVE_CASE(1) GM_SAVE_CASE(2) GM_SAVE_CASE(3)
@@ -600,140 +638,131 @@ struct Machine {
     }
   }
 
-  __device__ __forceinline__ void load_acc(const RC* src) {
+  // operand select of a micro-op: y = input k / temp k (wave-uniform compare tree, static indices)
+  __device__ __forceinline__ void select(const unsigned src, RC (&y)[N]) const {
+    switch (src) {
+#define GM_SEL_IN(K)                                                    \
+  case UOP_SRC_INPUT + K:                                               \
+    if constexpr (K < NIN) {                                            \
+      _Pragma("unroll") for (int k = 0; k < N; ++k) y[k] = in[K][k];    \
+    }                                                                   \
+    break;
+#define GM_SEL_TMP(K)                                                   \
+  case UOP_SRC_TEMP + K:                                                \
+    if constexpr (K < NT) {                                             \
+      _Pragma("unroll") for (int k = 0; k < N; ++k) y[k] = T<K>()[k];   \
+    }                                                                   \
+    break;
+      GM_SEL_IN(0) GM_SEL_IN(1) GM_SEL_IN(2) GM_SEL_IN(3) GM_SEL_IN(4) GM_SEL_IN(5) GM_SEL_IN(6) GM_SEL_IN(7)
+      GM_SEL_TMP(0) GM_SEL_TMP(1) GM_SEL_TMP(2) GM_SEL_TMP(3)
+#undef GM_SEL_IN
+#undef GM_SEL_TMP
+      default:
 #pragma unroll
-    for (int k = 0; k < N; ++k) acc[k] = src[k];
+        for (int k = 0; k < N; ++k) y[k] = (RC)0;
+        break;
+    }
   }
 
-  // One micro-op.  The dispatch is ONE flat chain of wave-uniform compares on the route word
-  // (kind | src << 8), most frequent routes first; every body updates the accumulator in place
-  // and leaves through the single exit of the chain, so the register allocator keeps the state
-  // arrays in place (nested switches cost a copy of the whole accumulator per tree level).
-  __device__ __forceinline__ void exec(kargs_t K, const gm_uop& U) {
-    const unsigned route = U.route & 0xffffu;
-#define GM_ROUTE(KIND, SRC) ((unsigned)(KIND) | ((unsigned)(SRC) << 8))
-#define GM_FAST_SCALAR(KIND) \
-  if (route == GM_ROUTE(KIND, UOP_SRC_SCALAR)) { fast_op<true>(U, KIND, acc); return; }
-#define GM_FAST_IN(KIND, K) \
-  if constexpr (K < NIN) { if (route == GM_ROUTE(KIND, UOP_SRC_INPUT + K)) { fast_op<false>(U, KIND, in[K]); return; } }
-#define GM_FAST_TMP(KIND, K) \
-  if constexpr (K < NT) { if (route == GM_ROUTE(KIND, UOP_SRC_TEMP + K)) { fast_op<false>(U, KIND, tmp_ptr(K)); return; } }
-#define GM_LD_IN(K) \
-  if constexpr (K < NIN) { if (route == GM_ROUTE(UOP_LD, UOP_SRC_INPUT + K)) { load_acc(in[K]); return; } }
-#define GM_LD_TMP(K) \
-  if constexpr (K < NT) { if (route == GM_ROUTE(UOP_LD, UOP_SRC_TEMP + K)) { load_acc(tmp_ptr(K)); return; } }
-#define GM_ST_TMP(K) \
-  if constexpr (K < NT) { if (route == GM_ROUTE(UOP_ST, K)) { _Pragma("unroll") for (int k = 0; k < N; ++k) tmp_ptr(K)[k] = acc[k]; return; } }
-#define GM_FAST_ALL_SRC(KIND)                                                                         \
-  GM_FAST_IN(KIND, 0) GM_FAST_IN(KIND, 1) GM_FAST_IN(KIND, 2) GM_FAST_IN(KIND, 3) GM_FAST_IN(KIND, 4) \
-  GM_FAST_IN(KIND, 5) GM_FAST_IN(KIND, 6) GM_FAST_IN(KIND, 7) GM_FAST_TMP(KIND, 0) GM_FAST_TMP(KIND, 1) \
-  GM_FAST_TMP(KIND, 2) GM_FAST_TMP(KIND, 3)
-    GM_LD_IN(0) GM_LD_IN(1)
-    GM_FAST_SCALAR(UOP_ADD) GM_FAST_SCALAR(UOP_MUL) GM_FAST_SCALAR(UOP_SUB) GM_FAST_SCALAR(UOP_DIV)
-    GM_FAST_ALL_SRC(UOP_ADD) GM_FAST_ALL_SRC(UOP_SUB) GM_FAST_ALL_SRC(UOP_MUL) GM_FAST_ALL_SRC(UOP_CLIP)
-    GM_FAST_ALL_SRC(UOP_DIV) GM_FAST_ALL_SRC(UOP_RSUB) GM_FAST_ALL_SRC(UOP_RDIV)
-    GM_FAST_SCALAR(UOP_RSUB) GM_FAST_SCALAR(UOP_RDIV)
-    GM_LD_IN(2) GM_LD_IN(3) GM_LD_IN(4) GM_LD_IN(5) GM_LD_IN(6) GM_LD_IN(7)
-    GM_LD_TMP(0) GM_LD_TMP(1) GM_LD_TMP(2) GM_LD_TMP(3)
-    GM_ST_TMP(0) GM_ST_TMP(1) GM_ST_TMP(2) GM_ST_TMP(3)
-    if (route == GM_ROUTE(UOP_LD, UOP_SRC_SCALAR)) {
-      const RC v = scalar_of<RC>(U.b_val);
+  // One micro-op: two-level wave-uniform decode (operand source, then operation).  The operand
+  // copy costs N v_mov; what it buys is a decode of ~10 scalar instructions instead of a linear
+  // chain over every (operation, source) pair -- with 4-8 elements per lane the decode, not the
+  // VALU work, is what a micro-op costs.
+  __device__ __forceinline__ void exec(kargs_t C, const gm_uop& U) {
+    const unsigned kind = U.route & 0xffu, src = (U.route >> 8) & 0xffu;
+    if (kind >= UOP_ADD) {
+      if (src == UOP_SRC_SCALAR) {
+        fast_op<true>(U, kind, acc);
+      } else {
+        RC y[N];
+        select(src, y);
+        fast_op<false>(U, kind, y);
+      }
+    } else if (kind == UOP_LD) {
+      if (src == UOP_SRC_SCALAR) {
+        const RC v = scalar_of<RC>(U.b_val);
 #pragma unroll
-      for (int k = 0; k < N; ++k) acc[k] = v;
-      return;
-    }
-    if ((route & 0xffu) == UOP_GENERIC) {
-      const gm_step S = kload<gm_step>(K, offsetof(VmArgs, prog) + offsetof(gm_program, steps) + sizeof(gm_step) * U.arg);
+        for (int k = 0; k < N; ++k) acc[k] = v;
+      } else {
+        select(src, acc);
+      }
+    } else if (kind == UOP_ST) {
+      switch (src) {
+#define GM_ST_TMP(K)                                                     \
+  case K:                                                                \
+    if constexpr (K < NT) {                                              \
+      _Pragma("unroll") for (int k = 0; k < N; ++k) T<K>()[k] = acc[k];  \
+    }                                                                    \
+    break;
+        GM_ST_TMP(0) GM_ST_TMP(1) GM_ST_TMP(2) GM_ST_TMP(3)
+#undef GM_ST_TMP
+        default: break;
+      }
+    } else {  // UOP_GENERIC
+      const gm_step S = kload<gm_step>(C, offsetof(VmCode, steps) + sizeof(gm_step) * U.arg);
       step(S);
     }
-#undef GM_ROUTE
-#undef GM_FAST_SCALAR
-#undef GM_FAST_IN
-#undef GM_FAST_TMP
-#undef GM_LD_IN
-#undef GM_LD_TMP
-#undef GM_ST_TMP
-#undef GM_FAST_ALL_SRC
   }
 
-  __device__ __forceinline__ void run(kargs_t K) {
-    const unsigned n_uops = GM_KARG(K, n_uops);
+  __device__ __forceinline__ void run(kargs_t C, const unsigned n_uops) {
     for (unsigned i = 0; i < n_uops; ++i) {
-      const gm_uop U = kload<gm_uop>(K, offsetof(VmArgs, uops) + sizeof(gm_uop) * i);
-      exec(K, U);
+      const gm_uop U = kload<gm_uop>(C, offsetof(VmCode, uops) + sizeof(gm_uop) * i);
+      exec(C, U);
     }
   }
 };
 
-// XCD-aware iteration order: workgroups are dealt round-robin over the 8 XCDs
-// (MI355X_MICROARCH.md "Workgroup dispatch"); with chunking on, the blocks that share
-// an XCD walk one contiguous eighth of the tile so each XCD's L2/fabric port streams
-// its own address range.  Placement affects speed only, never correctness.
-__device__ __forceinline__ unsigned long long first_iter(unsigned long long n_iters, unsigned xcd_chunking,
-                                                        unsigned long long* stride, unsigned long long* end) {
-  if (xcd_chunking && gridDim.x >= 8 && (gridDim.x % 8) == 0) {
-    const unsigned xcd = blockIdx.x & 7u;
-    const unsigned long long per = (n_iters + 7) / 8;
-    const unsigned long long lo = per * xcd;
-    unsigned long long hi = lo + per;
-    if (hi > n_iters) hi = n_iters;
-    *stride = gridDim.x / 8;
-    *end = hi;
-    return lo + (blockIdx.x >> 3);
-  }
-  *stride = gridDim.x;
-  *end = n_iters;
-  return blockIdx.x;
-}
-
-// vector kernel: every lane owns G groups of 4 consecutive elements per block-iteration
 template <typename RC> struct native_vec;
 template <> struct native_vec<float> { typedef f32x4 type; };
 template <> struct native_vec<int> { typedef i32x4 type; };
 
+// vector kernel: blockIdx.y = tile of the batch, blockIdx.x = span of 256*G groups of 4 elements
 template <typename RC, int G, int NIN, int NT, bool HEAVY>
-__global__ __launch_bounds__(256) void vm_kernel(const VmArgs) {
+__global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
   const kargs_t K = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
-  const unsigned nontemporal = GM_KARG(K, nontemporal);
-  const bool nt_ld = (nontemporal & 1u) != 0, nt_st = (nontemporal & 2u) != 0;
-  const unsigned long long n_groups = GM_KARG(K, n_groups);
-  void* const out = GM_KARG(K, out);
-  const unsigned n_in = GM_KPROG(K, n_inputs);
-  const int out_dtype = (int)GM_KPROG(K, out_dtype);
   constexpr int N = 4 * G;
+  const unsigned tile = blockIdx.y;
+  const unsigned flags = GM_KARG(K, flags);
+  const unsigned long long n_groups = GM_KARG(K, n_groups);
+  const unsigned n_in = GM_KARG(K, n_inputs);
+  const kargs_t C = (kargs_t)(uintptr_t)GM_KARG(K, code);
+  const size_t in_base = offsetof(VmLaunch, in) + sizeof(void*) * GM_MAX_INPUTS * tile;
+  const unsigned long long g0 = (unsigned long long)blockIdx.x * (256ull * G) + threadIdx.x;  // sub-vector u: group g0 + 256*u
+  constexpr bool nt_ld = true, nt_st = true;
+  // the whole pointer row of this tile in one scalar load (slots past n_inputs are null, never used)
+  const void* in_ptr[NIN];
+#pragma unroll
+  for (int k = 0; k < NIN; ++k) in_ptr[k] = kload<const void*>(K, in_base + sizeof(void*) * k);
+  bool native = false;
+  if constexpr (sizeof(RC) == 4) native = (flags & VM_FLAG_NATIVE) != 0;
 
-  unsigned long long stride, end;
-  unsigned long long it = first_iter(GM_KARG(K, n_iters), GM_KARG(K, xcd_chunking), &stride, &end);
-  for (; it < end; it += stride) {
-    Machine<RC, N, NIN, NT, HEAVY> M;
-    const unsigned long long g0 = it * (256ull * G) + threadIdx.x;  // sub-vector u is group g0 + 256*u
-    // phase 1: all leaf loads in flight (NIN*G independent 16-byte loads per lane)
-    bool native = false;
-    if constexpr (sizeof(RC) == 4) native = GM_KARG(K, native) != 0;
-    if (native) {
-      // every tile already has the class' dtype: straight 16-byte loads, no dtype dispatch
-      if constexpr (sizeof(RC) == 4) {
-        typedef typename native_vec<RC>::type V4;
+  Machine<RC, N, NIN, NT, HEAVY> M;
+  // phase 1: all leaf loads in flight (NIN*G independent 16-byte loads per lane)
+  if (native) {
+    // every tile already has the class' dtype: straight 16-byte loads, no dtype dispatch
+    if constexpr (sizeof(RC) == 4) {
+      typedef typename native_vec<RC>::type V4;
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) {
-          if (k < (int)n_in) {
+      for (int k = 0; k < NIN; ++k) {
+        if (k < (int)n_in) {
+          const V4* const p = (const V4*)in_ptr[k];
 #pragma unroll
-            for (int u = 0; u < G; ++u) {
-              const unsigned long long g = g0 + 256ull * u;
-              V4 x = {0, 0, 0, 0};
-              if (g < n_groups) x = ld((const V4*)kload<const void*>(K, offsetof(VmArgs, in) + 8 * k) + g, nt_ld);
+          for (int u = 0; u < G; ++u) {
+            const unsigned long long g = g0 + 256ull * u;
+            V4 x = {0, 0, 0, 0};
+            if (g < n_groups) x = ld(p + g, nt_ld);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) M.in[k][4 * u + q] = x[q];
-            }
+            for (int q = 0; q < 4; ++q) M.in[k][4 * u + q] = x[q];
           }
         }
       }
-    } else
+    }
+  } else {
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       if (k < (int)n_in) {
-        const gm_input_desc D = kload<gm_input_desc>(K, offsetof(VmArgs, prog) + offsetof(gm_program, inputs) + sizeof(gm_input_desc) * k);
-        const void* const in_k = kload<const void*>(K, offsetof(VmArgs, in) + 8 * k);
+        const gm_input_desc D = kload<gm_input_desc>(C, offsetof(VmCode, inputs) + sizeof(gm_input_desc) * k);
+        const void* const in_k = in_ptr[k];
         if (in_broadcast(D)) {
           RC one[1];
           load_elems<RC, 1>(in_k, in_dtype(D), 0, false, one, in_native(D), (long long)D.ndv.i64);
@@ -752,26 +781,28 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs) {
         }
       }
     }
-    // phase 2: interpret; phase 3: store
-    M.run(K);
+  }
+  // phase 2: interpret
+  M.run(C, GM_KARG(K, n_uops));
+  // phase 3: store
+  void* const out = kload<void*>(K, offsetof(VmLaunch, out) + sizeof(void*) * tile);
 #pragma unroll
-    for (int u = 0; u < G; ++u) {
-      const unsigned long long g = g0 + 256ull * u;
-      if (g < n_groups) {
-        if (native) {
-          if constexpr (sizeof(RC) == 4) {
-            typedef typename native_vec<RC>::type V4;
-            V4 x;
+  for (int u = 0; u < G; ++u) {
+    const unsigned long long g = g0 + 256ull * u;
+    if (g < n_groups) {
+      if (native) {
+        if constexpr (sizeof(RC) == 4) {
+          typedef typename native_vec<RC>::type V4;
+          V4 x;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = M.acc[4 * u + q];
-            st((V4*)out + g, x, nt_st);
-          }
-        } else {
-          RC v4[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v4[q] = M.acc[4 * u + q];
-          store_elems<RC, 4>(out, out_dtype, g * 4ull, nt_st, v4);
+          for (int q = 0; q < 4; ++q) x[q] = M.acc[4 * u + q];
+          st((V4*)out + g, x, nt_st);
         }
+      } else {
+        RC v4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v4[q] = M.acc[4 * u + q];
+        store_elems<RC, 4>(out, (int)GM_KARG(K, out_dtype), g * 4ull, nt_st, v4);
       }
     }
   }
@@ -780,12 +811,16 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmArgs) {
 // scalar tail kernel: the elements the 16-byte vector path cannot take (n % 4, or
 // everything when a pointer is not 16-byte aligned); one element per lane, grid-stride
 template <typename RC, int NIN, int NT, bool HEAVY>
-__global__ __launch_bounds__(256) void vm_tail_kernel(const VmArgs) {
+__global__ __launch_bounds__(256) void vm_tail_kernel(const VmLaunch) {
   const kargs_t K = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
-  const unsigned n_in = GM_KPROG(K, n_inputs);
-  const int out_dtype = (int)GM_KPROG(K, out_dtype);
+  const kargs_t C = (kargs_t)(uintptr_t)GM_KARG(K, code);
+  const unsigned tile = blockIdx.y;
+  const unsigned n_in = GM_KARG(K, n_inputs);
+  const unsigned n_uops = GM_KARG(K, n_uops);
+  const int out_dtype = (int)GM_KARG(K, out_dtype);
   const unsigned long long n_total = GM_KARG(K, n);
-  void* const out = GM_KARG(K, out);
+  const size_t in_base = offsetof(VmLaunch, in) + sizeof(void*) * GM_MAX_INPUTS * tile;
+  void* const out = kload<void*>(K, offsetof(VmLaunch, out) + sizeof(void*) * tile);
   const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long e = GM_KARG(K, tail_start) + tid; e < n_total; e += nthreads) {
@@ -793,21 +828,22 @@ __global__ __launch_bounds__(256) void vm_tail_kernel(const VmArgs) {
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       if (k < (int)n_in) {
-        const gm_input_desc D = kload<gm_input_desc>(K, offsetof(VmArgs, prog) + offsetof(gm_program, inputs) + sizeof(gm_input_desc) * k);
-        const void* const in_k = kload<const void*>(K, offsetof(VmArgs, in) + 8 * k);
+        const gm_input_desc D = kload<gm_input_desc>(C, offsetof(VmCode, inputs) + sizeof(gm_input_desc) * k);
+        const void* const in_k = kload<const void*>(K, in_base + sizeof(void*) * k);
         load_elems<RC, 1>(in_k, in_dtype(D), in_broadcast(D) ? 0ull : e, false, M1.in[k], in_native(D),
                           (long long)D.ndv.i64);
       }
     }
-    M1.run(K);
+    M1.run(C, n_uops);
     store_elems<RC, 1>(out, out_dtype, e, false, M1.acc);
   }
 }
 
 // host-side launcher of one register class (defined once per class in gm_vm_<class>.hip).
 // size: 0 = S (<= 2 inputs, <= 1 temp), 1 = M (<= 4 inputs, <= 2 temps), 2 = L (8 inputs, 4 temps)
+// grid.y = tail_grid.y = tiles of the batch
 template <typename RC>
-int launch_class(const VmArgs& args, int size, int G, bool heavy, dim3 grid, dim3 tail_grid, hipStream_t stream);
+int launch_class(const VmLaunch& args, int size, int G, bool heavy, dim3 grid, dim3 tail_grid, hipStream_t stream);
 
 #define GM_VM_LAUNCH(RC, G_, NIN_, NT_, HEAVY_)                                                          \
   do {                                                                                                   \
@@ -818,15 +854,14 @@ int launch_class(const VmArgs& args, int size, int G, bool heavy, dim3 grid, dim
 
 #define GM_VM_DEFINE_LAUNCHER(RC)                                                                  \
   template <>                                                                                      \
-  int launch_class<RC>(const VmArgs& args, int size, int G, bool heavy, dim3 grid, dim3 tail_grid, \
+  int launch_class<RC>(const VmLaunch& args, int size, int G, bool heavy, dim3 grid, dim3 tail_grid, \
                        hipStream_t stream) {                                                       \
     if (heavy) {                                                                                   \
       if (size == 0) GM_VM_LAUNCH(RC, 1, 2, 1, true);                                              \
       else if (size == 1) GM_VM_LAUNCH(RC, 1, 4, 2, true);                                         \
       else GM_VM_LAUNCH(RC, 1, 8, 4, true);                                                        \
     } else if (size == 0) {                                                                        \
-      if (G == 4) GM_VM_LAUNCH(RC, 4, 2, 1, false);                                                \
-      else if (G == 2) GM_VM_LAUNCH(RC, 2, 2, 1, false);                                           \
+      if (G >= 2) GM_VM_LAUNCH(RC, 2, 2, 1, false);                                                \
       else GM_VM_LAUNCH(RC, 1, 2, 1, false);                                                       \
     } else if (size == 1) {                                                                        \
       if (G >= 2) GM_VM_LAUNCH(RC, 2, 4, 2, false);                                                \

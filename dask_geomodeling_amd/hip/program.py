@@ -86,8 +86,7 @@ class gm_program(ctypes.Structure):
 
 
 class gm_vm_tuning(ctypes.Structure):
-    _fields_ = [("vec", ctypes.c_int32), ("blocks_per_cu", ctypes.c_int32),
-                ("xcd_chunking", ctypes.c_int32), ("nontemporal", ctypes.c_int32)]
+    _fields_ = [("vec", ctypes.c_int32), ("max_batch", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
 
 
 class FusionLimit(Exception):
@@ -605,6 +604,9 @@ def _lib():
         L.gm_elemwise_run.argtypes = [ctypes.POINTER(gm_program), ctypes.POINTER(ctypes.c_void_p),
                                       ctypes.c_void_p, ctypes.c_size_t]
         L.gm_elemwise_run.restype = ctypes.c_int
+        L.gm_elemwise_run_batch.argtypes = [ctypes.POINTER(gm_program), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                            ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        L.gm_elemwise_run_batch.restype = ctypes.c_int
         L.gm_vm_set_tuning.argtypes = [ctypes.POINTER(gm_vm_tuning)]
         L.gm_vm_get_tuning.argtypes = [ctypes.POINTER(gm_vm_tuning)]
         L.gm_sizeof.argtypes = [ctypes.c_int]
@@ -617,16 +619,16 @@ def _lib():
     return L
 
 
-def set_tuning(vec=8, blocks_per_cu=0, xcd_chunking=0, nontemporal=0):
-    t = gm_vm_tuning(vec, blocks_per_cu, xcd_chunking, nontemporal)
+def set_tuning(vec=0, max_batch=0):
+    """Measurement knobs of the VM launch (defaults = the measured optimum, see gmhip.h)."""
+    t = gm_vm_tuning(vec, max_batch)
     runtime.check(_lib().gm_vm_set_tuning(ctypes.byref(t)), "gm_vm_set_tuning")
 
 
 def get_tuning():
     t = gm_vm_tuning()
     runtime.check(_lib().gm_vm_get_tuning(ctypes.byref(t)), "gm_vm_get_tuning")
-    return {"vec": t.vec, "blocks_per_cu": t.blocks_per_cu, "xcd_chunking": t.xcd_chunking,
-            "nontemporal": t.nontemporal}
+    return {"vec": t.vec, "max_batch": t.max_batch}
 
 
 def launch(compiled, inputs, shape, out=None):
@@ -639,6 +641,24 @@ def launch(compiled, inputs, shape, out=None):
     runtime.check(L.gm_elemwise_run(ctypes.byref(compiled.program), ptrs, ctypes.c_void_p(out.ptr), n),
                   "gm_elemwise_run")
     return out
+
+
+def launch_batch(compiled, tiles, shape, outs=None):
+    """Run one compiled program over several tiles at once: ``tiles`` is a list of per-tile input
+    lists (all tiles of ``shape``) -> list of DeviceArrays.  One launch per 16 tiles."""
+    L = _lib()
+    n = int(np.prod(shape, dtype=np.int64))
+    n_in = len(tiles[0]) if tiles else 0
+    if outs is None:
+        outs = [DeviceArray.empty(shape, compiled.out_dtype) for _ in tiles]
+    flat = [x.ptr for inputs in tiles for x in inputs]
+    ptrs = (ctypes.c_void_p * max(len(flat), 1))(*flat)
+    out_ptrs = (ctypes.c_void_p * max(len(outs), 1))(*[o.ptr for o in outs])
+    if any(len(inputs) != n_in for inputs in tiles):
+        raise ValueError("every tile of a batch must bring the same number of inputs")
+    runtime.check(L.gm_elemwise_run_batch(ctypes.byref(compiled.program), len(tiles), ptrs, out_ptrs, n),
+                  "gm_elemwise_run_batch")
+    return outs
 
 
 def _collect_leaves(root):

@@ -207,17 +207,22 @@ typedef struct gm_program {
 } gm_program;
 
 /* Run `prog` over n elements.  inputs[k] are device pointers (n elements each, or 1
- * when broadcast); out is a device pointer to n elements of prog->out_dtype. */
+ * when broadcast); out is a device pointer to n elements of prog->out_dtype.
+ * The program is validated, lowered and uploaded on first use and cached by content. */
 int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out, size_t n);
 
-/* Tuning knobs of the VM launch (0 = default): elements per lane per iteration
- * (4 or 8), workgroups per CU, XCD-contiguous chunking, non-temporal access. */
+/* The same program over n_tiles independent tiles of n elements each in as few launches as
+ * possible (16 tiles per launch): inputs[t * prog->n_inputs + k] is input k of tile t, outs[t]
+ * its result.  This is how the tiles a RasterTiler fans out (raster/parallelize.py:82-89) -- one
+ * identical sub-graph per tile -- reach the GPU: kernel boundaries between tiles disappear. */
+int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const* inputs, void* const* outs, size_t n);
+
+/* Tuning knobs of the VM launch (for measurements; the defaults are the measured optimum). */
 typedef struct gm_vm_tuning {
-  int32_t vec;            /* 4 | 8 | 16 (programs with many inputs/temps use at most 8) */
-  int32_t blocks_per_cu;  /* grid = blocks_per_cu * CUs, capped by the work; 0 = one
-                             block-iteration per workgroup */
-  int32_t xcd_chunking;   /* 1: each XCD streams its own contiguous eighth */
-  int32_t nontemporal;    /* bit0: loads, bit1: stores */
+  int32_t vec;          /* elements per lane: 0 = auto (4; 8 for programs of more than 3 micro-ops), 4, 8 */
+  int32_t max_batch;    /* tiles per launch of gm_elemwise_run_batch: 0 = 16 */
+  int32_t reserved[2];  /* (tile loads/stores always carry the non-temporal hint: it is worth +10 % and
+                           has to be a compile-time property of the kernel) */
 } gm_vm_tuning;
 int gm_vm_set_tuning(const gm_vm_tuning* t);
 int gm_vm_get_tuning(gm_vm_tuning* t);

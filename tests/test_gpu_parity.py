@@ -80,15 +80,47 @@ def test_ragged_sizes_and_tuning(gpu, n, vec):
     kw = {"dtype": "float32", "fillvalue": float(fill)}
     want = O.math_process("multiply", kw, {"values": a, "no_data_value": fill},
                           {"values": b, "no_data_value": fill})
-    for xcd in (0, 1):
-        for nt in (0, 3):
-            program.set_tuning(vec=vec, blocks_per_cu=8, xcd_chunking=xcd, nontemporal=nt)
-            try:
-                got = devops.math_process("multiply", kw, {"values": a, "no_data_value": fill},
-                                          {"values": b, "no_data_value": fill})
-            finally:
-                program.set_tuning()
-            assert_result_equal(got, want, 0, "n=%d vec=%d xcd=%d nt=%d" % (n, vec, xcd, nt))
+    program.set_tuning(vec=vec)
+    try:
+        got = devops.math_process("multiply", kw, {"values": a, "no_data_value": fill},
+                                  {"values": b, "no_data_value": fill})
+    finally:
+        program.set_tuning()
+    assert_result_equal(got, want, 0, "n=%d vec=%d" % (n, vec))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_tiles", [1, 2, 16, 17, 33])
+@pytest.mark.parametrize("n", [5, 1024, 4099, 65536 + 3])
+def test_batched_launch_matches_per_tile(gpu, n_tiles, n):
+    """gm_elemwise_run_batch: many tiles per launch (blockIdx.y = tile), ragged sizes, more tiles
+    than one launch takes; every tile must equal the oracle's result for that tile."""
+    from dask_geomodeling_amd.hip import DeviceArray, program as P
+    fill = np.float32(np.finfo("f4").max)
+    kw = {"dtype": "float32", "fillvalue": float(fill)}
+    leaves = [P.Leaf(0, "f4", fill), P.Leaf(1, "f4", fill)]
+    x = devops.math_node("add", kw, leaves)
+    x = devops.math_node("multiply", kw, [x, P.Lit(2.5)])
+    x = devops.math_node("subtract", kw, [x, leaves[1]])
+    x = devops.clip_node(x, leaves[0])
+    comp = P.compile_expr(x, 2)
+    tiles, want = [], []
+    for t in range(n_tiles):
+        rng = np.random.default_rng(1000 * n_tiles + t)
+        a = (rng.random((1, 1, n)) * 100).astype("f4")
+        b = (rng.random((1, 1, n)) * 100).astype("f4")
+        a[..., t % 5::11] = fill
+        b[..., ::13] = fill
+        A = {"values": a, "no_data_value": fill}
+        B = {"values": b, "no_data_value": fill}
+        w = O.math_process("add", kw, A, B)
+        w = O.math_process("multiply", kw, w, 2.5)
+        w = O.math_process("subtract", kw, w, B)
+        want.append(O.clip_process(w, A))
+        tiles.append([DeviceArray.from_numpy(a), DeviceArray.from_numpy(b)])
+    outs = P.launch_batch(comp, tiles, (1, 1, n))
+    for t in range(n_tiles):
+        assert_values_equal(outs[t].to_numpy(), want[t]["values"], 0, "tile %d of %d, n=%d" % (t, n_tiles, n))
 
 
 def test_device_array_roundtrip_and_checksum(gpu):

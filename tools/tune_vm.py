@@ -52,8 +52,8 @@ def main():
     progs = {"chain5": P.compile_expr(chain(leaves), 2), "add": P.compile_expr(single_add(leaves), 2)}
     results = []
     for name, comp in progs.items():
-        for vec, bpc, xcd, nt in itertools.product((4, 8, 16), (0, 8, 16, 32), (0, 1), (0, 3)):
-            P.set_tuning(vec=vec, blocks_per_cu=bpc, xcd_chunking=xcd, nontemporal=nt)
+        for vec, nt in itertools.product((4, 8), (3,)):
+            P.set_tuning(vec=vec)
             for i in range(ntiles):  # warm-up
                 P.launch(comp, [A[i], B[i]], shape, out=OUT[i])
             runtime.sync()
@@ -67,12 +67,12 @@ def main():
             e1.synchronize()
             ms = e0.elapsed_ms(e1) / (reps * ntiles)
             gbs = 12.0 * n / (ms * 1e-3) / 1e9
-            results.append((name, vec, bpc, xcd, nt, ms * 1e3, gbs))
-            print("%-7s vec=%d bpc=%2d xcd=%d nt=%d  %8.1f us/tile  %7.1f GB/s" % results[-1], flush=True)
+            results.append((name, vec, nt, ms * 1e3, gbs))
+            print("%-7s vec=%d nt=%d  %8.1f us/tile  %7.1f GB/s" % results[-1], flush=True)
     P.set_tuning()
     best = {}
     for r in results:
-        if r[0] not in best or r[6] > best[r[0]][6]:
+        if r[0] not in best or r[4] > best[r[0]][4]:
             best[r[0]] = r
     print("BEST", json.dumps(best))
 
