@@ -6,16 +6,21 @@
 Workload (BASELINE.json configs[1]): per GPU a batch of B device-resident tile
 pairs (A_i, B_i), float32 4096x4096, no-data = float32 max on a [::97, ::89] lattice; one
 "step" evaluates   V_i = Clip(Add(Subtract(Multiply(Add(A_i, B_i), 2.5), B_i), 1.5), A_i)
-for every tile of the batch through the Block API: MemorySource leaves -> get_compute_graph
--> fusion pass -> the scheduler runs one fused HIP launch per tile.  The batch (B x 192 MiB)
-is far larger than the 256 MiB Infinity Cache, so every launch streams from HBM.
+for every tile of the batch through the Block API: MemorySource leaves -> get_compute_graph of
+every view, merged into one graph (the dask idiom for independent tiles) -> fusion pass: the five
+Blocks of a tile become one program, the B identical tile programs one batched launch
+(gm_elemwise_run_batch, 16 tiles per launch) -> the scheduler runs it.  The batch (B x 192 MiB) is
+far larger than the 256 MiB Infinity Cache, so every launch streams from HBM.
 
 Tiles are independent: with N GPUs every rank owns its own batch (weak scaling), there is no
 collective on the data path; torch.distributed (gloo) is used for the timing barrier and the
 max-over-ranks reduction only.
 
 Rank 0 prints ONE JSON line.  roofline.achieved = algorithmic bytes per launch (12 B/px x
-16.78 Mpix = 201.3 MB) / average launch duration from HIP events over the timed region.
+16.78 Mpix x tiles per launch) / average launch duration from HIP events (recorded on the
+library's compute stream) over the timed region.  roofline.traffic = HBM bytes per launch from
+the rocprofv3 PMC passes of the same command (profiles/<round>_pmc.json, FETCH_SIZE doubled as
+MI355X_MICROARCH.md prescribes for gfx950), when that file is present.
 cpu_baseline = the NumPy oracle (a restatement of the reference's process() bodies) on the
 host cores of the same box, same chain, same synthetic tiles (bounded sample).
 """
@@ -40,8 +45,8 @@ LATTICE = (97, 89)
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--workload", default="chain5", choices=["chain5", "reclass", "bilinear", "mosaic"],
                    help="chain5 = the headline (BASELINE.json configs[1]); reclass = configs[2] "
                         "(Reclassify + Mask on int32 tiles); bilinear = configs[3] (2x upsample); "
@@ -57,14 +62,14 @@ def parse_args():
 
 
 def build_batch(raster, side, tiles, rank):
-    """B independent views on device-resident MemorySources + their prebuilt fused graphs."""
+    """B independent views on device-resident MemorySources, merged into one prebuilt fused graph."""
     from dask_geomodeling_amd.fuse import fuse_graph
     from dask_geomodeling_amd.raster.sources import generate_window
 
     request = dict(mode="vals", bbox=(0.0, 0.0, float(side), float(side)), width=side, height=side,
                    projection="EPSG:28992")
     ndv = np.float32(F32MAX)
-    jobs, seeds = [], []
+    graph, names, seeds = {}, [], []
     for i in range(tiles):
         sa, sb = 1000 * rank + 2 * i, 1000 * rank + 2 * i + 1
         da = generate_window((side, side), "f4", sa, 0.0, 100.0, F32MAX, LATTICE, 0, 0, side, side)
@@ -72,10 +77,10 @@ def build_batch(raster, side, tiles, rank):
         A = raster.MemorySource(da, ndv, "EPSG:28992", 1.0, (0.0, float(side)))
         B = raster.MemorySource(db, ndv, "EPSG:28992", 1.0, (0.0, float(side)))
         view = raster.Clip(raster.Add(raster.Subtract(raster.Multiply(raster.Add(A, B), 2.5), B), 1.5), A)
-        graph, name = view.get_compute_graph(**request)
-        jobs.append((fuse_graph(graph, name), name))
+        graph, name = view.get_compute_graph(cached_compute_graph=graph, **request)
+        names.append(name)
         seeds.append((sa, sb))
-    return jobs, seeds, request
+    return [(fuse_graph(graph, names), names)], seeds, request
 
 
 def build_reclass(raster, side, tiles, rank):
@@ -93,7 +98,7 @@ def build_reclass(raster, side, tiles, rank):
         src = raster.MemorySource(d, 2147483647, "EPSG:28992", 1.0, (0.0, float(side)))
         view = raster.Mask(raster.Reclassify(src, table), 1)
         graph, name = view.get_compute_graph(**request)
-        jobs.append((fuse_graph(graph, name), name))
+        jobs.append((fuse_graph(graph, name), [name]))
     return jobs
 
 
@@ -108,7 +113,8 @@ def build_bilinear(raster, side, tiles, rank):
         d = generate_window((side, side), "f4", 3000 + 100 * rank + i, 0.0, 100.0, F32MAX, LATTICE, 0, 0, side, side)
         src = raster.MemorySource(d, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(side)))
         view = raster.SpatialResample(src, 2, "bilinear")
-        jobs.append(view.get_compute_graph(**request))
+        graph, name = view.get_compute_graph(**request)
+        jobs.append((graph, [name]))
     return jobs
 
 
@@ -140,8 +146,8 @@ def build_mosaic(raster, tile, rank, world):
     graph, name = tiler.get_compute_graph(**request)
     _, tile_keys = shard.split_tiler_graph(graph, name)
     mine = shard.owned_tiles(len(tile_keys), rank, world)
-    fused = fuse_graph(graph, name)
-    return [(fused, tile_keys[t]) for t in mine], len(tile_keys)
+    keys = [tile_keys[t] for t in mine]
+    return [(fuse_graph(graph, keys), keys)], len(tile_keys)
 
 
 def oracle_chain(a, b):
@@ -161,21 +167,46 @@ def host_tile(seed, side):
     return synth.generate_window((side, side), "f4", seed, 0.0, 100.0, np.float32(F32MAX), LATTICE, 0, 0, side, side)
 
 
-def cpu_baseline(side, n_tiles):
-    """The oracle chain on host cores: n_tiles tiles over a thread pool (NumPy releases the GIL)."""
+def cpu_baseline(side, n_tiles, budget_s=12.0):
+    """The oracle chain on host cores: passes of n_tiles tiles over a thread pool (NumPy releases
+    the GIL), repeated until about budget_s seconds of wall-clock are spent."""
     from concurrent.futures import ThreadPoolExecutor
     cores = os.cpu_count() or 1
     workers = min(cores, n_tiles)
     distinct = [(host_tile(2 * i, side), host_tile(2 * i + 1, side)) for i in range(min(n_tiles, 2))]
     tiles = [distinct[i % len(distinct)] for i in range(n_tiles)]  # timing does not depend on the values
     oracle_chain(*[t[:, :256, :256] for t in tiles[0]])  # warm
-    t0 = time.perf_counter()
+    passes, t0 = 0, time.perf_counter()
     with ThreadPoolExecutor(workers) as pool:
-        list(pool.map(lambda ab: oracle_chain(*ab)["values"][0, 0, 0], tiles))
-    dt = time.perf_counter() - t0
-    return {"value": round(n_tiles * side * side / dt / 1e6, 2), "unit": "Mpix/s", "cores": workers, "kind": "port",
-            "sample": "%d tiles of %dx%d f32, oracle/ref_numpy.py chain (NumPy %s) on a %d-thread pool, %.1f s"
-                      % (n_tiles, side, side, np.__version__, workers, dt)}
+        while True:
+            list(pool.map(lambda ab: oracle_chain(*ab)["values"][0, 0, 0], tiles))
+            passes += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget_s or passes >= 64:
+                break
+    return {"value": round(passes * n_tiles * side * side / dt / 1e6, 2), "unit": "Mpix/s", "cores": workers,
+            "kind": "port",
+            "sample": "%d passes over %d tiles of %dx%d f32, oracle/ref_numpy.py chain (NumPy %s) on a %d-thread "
+                      "pool, %.1f s" % (passes, n_tiles, side, side, np.__version__, workers, dt)}
+
+
+def pmc_traffic(side, tiles_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    command (tools/pmc_summary.py writes the file), or (None, None)."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        if name.endswith("_pmc.json"):
+            best = os.path.join(ROOT, "profiles", name)
+    if best is None:
+        return None, None
+    try:
+        with open(best) as f:
+            rec = json.load(f)
+        if rec.get("side") != side or rec.get("tiles_per_launch") != tiles_per_launch:
+            return None, None
+        return rec["hbm_bytes_per_launch"], "profiles/" + os.path.basename(best)
+    except (OSError, ValueError, KeyError):
+        return None, None
 
 
 def main():
@@ -236,22 +267,21 @@ def main():
             jobs = build_bilinear(raster, side, tiles, rank)
         else:
             jobs, n_mosaic_tiles = build_mosaic(raster, side, rank, world)
-            tiles = len(jobs)
+            tiles = len(jobs[0][1])
         runtime.sync()
 
         def step():
-            for graph, name in jobs:
-                get_sync(graph, [name])  # result DeviceArray is dropped -> buffer returns to the pool
+            for graph, names in jobs:
+                get_sync(graph, names)  # result DeviceArrays are dropped -> buffers return to the pool
 
-    if not args.no_check and rank == 0:
-        graph, name = jobs[0]
-        got = np.asarray(get_sync(graph, [name])[0]["values"])
-        want = oracle_chain(host_tile(seeds[0][0], side), host_tile(seeds[0][1], side))["values"]
-        if not np.array_equal(got.view("u4"), want.view("u4")):
-            raise SystemExit("bench: fused chain differs from the oracle on tile 0")
-
-    for _ in range(args.warmup):
+    # W untimed warm-up steps -- and, when those are shorter than that, keep stepping until the GPU
+    # has been busy for 50 ms, so that the clocks have left their idle state before the timed region
+    t_warm, done = time.perf_counter(), 0
+    while done < args.warmup or (not args.dry_run and time.perf_counter() - t_warm < 0.05):
         step()
+        done += 1
+        if done % 8 == 0:
+            runtime.sync()
 
     def barrier():
         runtime.sync()
@@ -269,7 +299,20 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     e1.synchronize()
-    kernel_ms = e0.elapsed_ms(e1) / (args.steps * tiles)  # average launch duration (HIP events)
+    tiles_per_launch = min(tiles, 16) if args.workload == "chain5" else 1
+    launches = args.steps * ((tiles + tiles_per_launch - 1) // tiles_per_launch)
+    kernel_ms = e0.elapsed_ms(e1) / launches  # average launch duration (HIP events on the compute stream)
+
+    if not args.no_check and rank == 0:
+        # parity of what was just timed: first and last tile of the batch against the oracle
+        graph, names = jobs[0]
+        results = get_sync(graph, names)
+        for t in sorted({0, len(names) - 1}):
+            got = np.asarray(results[t]["values"])
+            want = oracle_chain(host_tile(seeds[t][0], side), host_tile(seeds[t][1], side))["values"]
+            if not np.array_equal(got.view("u4"), want.view("u4")):
+                raise SystemExit("bench: fused chain differs from the oracle on tile %d" % t)
+        del results
 
     if dist is not None:
         import torch
@@ -304,7 +347,9 @@ def main():
     elif rank == 0:
         px_per_step = world * tiles * side * side
         value = px_per_step * args.steps / elapsed / 1e6
-        achieved = BYTES_PER_PX * side * side / (kernel_ms * 1e-3) / 1e9
+        launch_bytes = BYTES_PER_PX * side * side * tiles_per_launch
+        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(side, tiles_per_launch)
         out = {
             "metric": "Mpix/s on 4096x4096 f32 tiles, 5-op elemwise chain; % of HBM roofline",
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -312,13 +357,15 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not args.dry_run else "DRY RUN (no GPU work, harness test only)",
             "config": {"workload": "fused chain Clip(Add(Subtract(Multiply(Add(A,B),2.5),B),1.5),A) on %dx%d f32 "
-                                   "MemorySource tiles, %d tile pairs per GPU per step, one fused launch per tile"
-                                   % (side, side, tiles),
-                       "tile": [side, side], "tiles_per_gpu": tiles, "bytes_per_px": BYTES_PER_PX,
+                                   "MemorySource tiles, %d tile pairs per GPU per step, %d tiles per fused launch"
+                                   % (side, side, tiles, tiles_per_launch),
+                       "tile": [side, side], "tiles_per_gpu": tiles, "tiles_per_launch": tiles_per_launch,
+                       "bytes_per_px": BYTES_PER_PX,
                        "parallelism": "tiles sharded 1 rank per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "gmvm::vm_kernel<float,...>", "avg_launch_us": round(kernel_ms * 1e3, 2)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src, "kernel": "gmvm::vm_kernel<float, 2, 2, 1, false>",
+                         "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": round(kernel_ms * 1e3, 2)},
             "pct_of_hbm_roofline": round(100.0 * value * 1e6 * BYTES_PER_PX / world / (HBM_PEAK_GBS * 1e9), 2),
         }
         cpu_tiles = args.cpu_tiles

@@ -28,7 +28,7 @@ except ImportError:
 logger = logging.getLogger(__name__)
 
 __all__ = ["construct", "construct_multiple", "compute", "Block", "DummyBlock", "tokenize",
-           "get_sync"]
+           "get_sync", "get_data_many"]
 
 
 # ---------------------------------------------------------------------------
@@ -123,8 +123,34 @@ def _execute(obj, dsk, cache):
 
 def get_sync(dsk, keys, pack_exception=None, **kwargs):
     """Built-in synchronous scheduler with ``dask.local.get_sync``'s calling convention
-    (used when dask is not installed).  Iterative, so deep chains are fine."""
+    (used when dask is not installed).  Iterative, so deep chains are fine.  Like dask's
+    schedulers it drops an intermediate result as soon as its last consumer has run, which is
+    what hands device tiles back to the pool while a large tiled graph is still running."""
     cache = {}
+    wanted = list(keys) if isinstance(keys, list) else [keys]
+    deps_of, pending = {}, {}
+
+    def deps(key):
+        d = deps_of.get(key)
+        if d is None:
+            d = []
+            _dependencies(dsk[key], dsk, d)
+            deps_of[key] = d
+        return d
+
+    # reference counts over the part of the graph the wanted keys reach (every use counts)
+    seen, stack = set(), list(wanted)
+    while stack:
+        key = stack.pop()
+        if key in seen:
+            continue
+        seen.add(key)
+        for d in deps(key):
+            pending[d] = pending.get(d, 0) + 1
+            if d not in seen:
+                stack.append(d)
+    for key in wanted:
+        pending[key] = pending.get(key, 0) + 1  # never released
 
     def evaluate(target):
         stack = [target]
@@ -133,9 +159,7 @@ def get_sync(dsk, keys, pack_exception=None, **kwargs):
             if key in cache:
                 stack.pop()
                 continue
-            deps = []
-            _dependencies(dsk[key], dsk, deps)
-            missing = [d for d in deps if d not in cache]
+            missing = [d for d in deps(key) if d not in cache]
             if missing:
                 stack.extend(missing)
                 continue
@@ -145,6 +169,10 @@ def get_sync(dsk, keys, pack_exception=None, **kwargs):
                 if pack_exception is not None:
                     pack_exception(e, None)  # reads ``key`` from this frame, then re-raises
                 raise
+            for d in deps(key):
+                pending[d] -= 1
+                if pending[d] == 0:
+                    del cache[d]
             stack.pop()
         return cache[target]
 
@@ -159,6 +187,31 @@ def compute(graph, name, *args, **kwargs):
     if get is None:
         get = _config.get("scheduler_get") or get_sync
     return get(graph, [name])[0]
+
+
+def get_data_many(blocks, requests):
+    """Evaluate several (block, request) pairs as ONE graph -> list of results.
+
+    The dask idiom ``dask.compute(*delayed)``: the compute graphs are merged (shared keys are
+    computed once), fused as a whole -- so identical element-wise sub-graphs of different views
+    or tiles run as one batched launch -- and evaluated with the configured scheduler."""
+    if isinstance(requests, dict):
+        requests = [requests] * len(blocks)
+    graph, names = {}, []
+    for block, request in zip(blocks, requests):
+        graph, name = block.get_compute_graph(cached_compute_graph=graph, **request)
+        names.append(name)
+    if _config.get("geomodeling.fuse", True):
+        from ..fuse import fuse_graph
+        graph = fuse_graph(graph, names)
+    get = _dask_get_scheduler() if _dask_get_scheduler is not None else None
+    if get is None:
+        get = _config.get("scheduler_get") or get_sync
+    results = list(get(graph, names))
+    if _config.get("geomodeling.materialize", True):
+        from ..fuse import materialize
+        results = [materialize(r) for r in results]
+    return results
 
 
 def _construct_exc_callback(e, dumps):

@@ -10,6 +10,13 @@ FusedTask turns the member tasks into one expression and evaluates it as one pro
 (hip/program.py); each step keeps the reference's per-op no-data / non-finite rule, so the
 result is bit-identical to the op-by-op path.
 
+**Horizontal batching.**  A ``RasterTiler`` (raster/parallelize.py:82-89) fans a view out into
+one identical sub-graph per tile.  After the vertical fusion above, fused tasks that have the
+same structure (same ops, same constants, different leaves) and do not depend on one another
+are merged into one ``BatchedTask``: all its tiles run the same compiled program in one launch
+per 16 tiles (``gm_elemwise_run_batch``), which removes the kernel boundaries between tiles.
+The per-tile keys stay in the graph as ``(getitem, batch_key, i)``.
+
 ``None`` / ``time`` / ``meta`` responses are not numerics: when any leaf of a fused group is
 not a tile of values the member tasks are simply run one by one with their own ``process``
 bodies, which carry the reference's control flow for those cases.
@@ -20,7 +27,9 @@ from .hip import program as P
 from .hip.array import DeviceArray
 from .raster import devops
 
-__all__ = ["fuse_graph", "materialize", "FusedTask"]
+__all__ = ["fuse_graph", "materialize", "FusedTask", "BatchedTask"]
+
+MAX_BATCH_TILES = 64  # tiles per BatchedTask: bounds how many tile results are alive at once
 
 
 def _is_task(x):
@@ -70,14 +79,45 @@ class FusedTask(object):
         except TypeError:
             return False
 
-    def __call__(self, *leaf_values):
-        # fast path: the same kinds of tiles as last time -> the cached program, one launch
+    def _signature(self, leaf_values):
         try:
-            sig = tuple((v["values"].dtype.num, v["values"].shape, type(v.get("no_data_value")),
-                         v.get("no_data_value")) for v in leaf_values)
-            hit = self._plans.get(sig)
+            return tuple((v["values"].dtype.num, v["values"].shape, type(v.get("no_data_value")),
+                          v.get("no_data_value")) for v in leaf_values)
         except (TypeError, KeyError, AttributeError):
-            sig = hit = None
+            return None
+
+    def plan_for(self, leaf_values):
+        """-> (compiled program, slot binding, shape) when this kind of tiles runs as ONE launch of
+        one program, else None (control-flow responses, several launches, not fusable)."""
+        sig = self._signature(leaf_values)
+        if sig is None:
+            return None
+        hit = self._plans.get(sig)
+        if hit is not None:
+            return hit
+        if not all(isinstance(v, dict) and "values" in v for v in leaf_values):
+            return None
+        nodes, arg_of = {}, {}
+        for i, (key, data) in enumerate(zip(self.leaf_keys, leaf_values)):
+            leaf = P.Leaf(None, data["values"].dtype, data.get("no_data_value"), values=data["values"])
+            nodes[key] = leaf
+            arg_of[id(leaf)] = i
+        try:
+            for key in self.order:
+                nodes[key] = self._node(key, nodes)
+            compiled, leaves, shape = P.plan(nodes[self.root])
+        except (_NotFusable, P.FusionLimit, NotImplementedError, TypeError):
+            return None
+        # which call argument (or constant ndarray operand, uploaded once) feeds each slot
+        binding = [(0, arg_of[id(l)]) if id(l) in arg_of else (1, l.values) for l in leaves]
+        if len(self._plans) > 64:
+            self._plans.clear()
+        self._plans[sig] = (compiled, binding, shape)
+        return self._plans[sig]
+
+    def __call__(self, *leaf_values):
+        # fast path: one compiled program (cached per kind of tiles), one launch
+        hit = self.plan_for(leaf_values)
         if hit is not None:
             compiled, binding, shape = hit
             tiles = [leaf_values[ref]["values"] if kind == 0 else ref for kind, ref in binding]
@@ -88,30 +128,45 @@ class FusedTask(object):
         env = dict(zip(self.leaf_keys, leaf_values))
         if not all(isinstance(v, dict) and "values" in v for v in leaf_values):
             return self._run_unfused(env)
-        nodes, arg_of = {}, {}
-        for i, (key, data) in enumerate(env.items()):
-            leaf = P.Leaf(None, data["values"].dtype, data.get("no_data_value"), values=data["values"])
-            nodes[key] = leaf
-            arg_of[id(leaf)] = i
+        nodes = {}
+        for key, data in env.items():
+            nodes[key] = P.Leaf(None, data["values"].dtype, data.get("no_data_value"), values=data["values"])
         try:
             for key in self.order:
                 nodes[key] = self._node(key, nodes)
         except _NotFusable:
             return self._run_unfused(env)
-        root = nodes[self.root]
-        try:
-            compiled, leaves, shape = P.plan(root)
-        except P.FusionLimit:
-            values, ndv = P.evaluate(root)  # several launches: sub-trees first
-            return {"values": values, "no_data_value": ndv}
-        if sig is not None:
-            # which call argument (or constant ndarray operand, uploaded once) feeds each slot
-            binding = [(0, arg_of[id(l)]) if id(l) in arg_of else (1, l.values) for l in leaves]
-            if len(self._plans) > 64:
-                self._plans.clear()
-            self._plans[sig] = (compiled, binding, shape)
-        values = P.launch(compiled, [leaf.values for leaf in leaves], shape)
-        return {"values": values, "no_data_value": compiled.out_ndv}
+        values, ndv = P.evaluate(nodes[self.root])  # several launches: sub-trees first
+        return {"values": values, "no_data_value": ndv}
+
+    def structure(self):
+        """Hashable description of the group up to the identity of its leaves: two groups with
+        equal structure evaluate the same expression on different tiles."""
+        pos = {k: ("m", i) for i, k in enumerate(self.order)}
+        pos.update({k: ("l", i) for i, k in enumerate(self.leaf_keys)})
+
+        def const(a):
+            if isinstance(a, dict):
+                return ("d", tuple(sorted((str(k), const(v)) for k, v in a.items())))
+            if isinstance(a, (list, tuple)):
+                return ("t", tuple(const(x) for x in a))
+            if isinstance(a, np.ndarray):
+                return ("a", id(a))  # the same constant array object
+            if isinstance(a, np.generic):
+                return ("g", a.dtype.str, a.tobytes())
+            if isinstance(a, float) and a != a:
+                return ("nan",)
+            try:
+                hash(a)
+                return ("c", type(a).__name__, a)
+            except TypeError:
+                return ("o", id(a))
+
+        out = []
+        for key in self.order:
+            task = self.members[key]
+            out.append((task[0].gm_op, tuple(pos[a] if self._ref(a) else const(a) for a in task[1:])))
+        return (pos[self.root], tuple(out))
 
     def _node(self, key, nodes):
         task = self.members[key]
@@ -151,11 +206,54 @@ class _NotFusable(Exception):
     pass
 
 
+class BatchedTask(object):
+    """Several structurally identical fused groups (the tiles of one view) as one graph node:
+    called with the leaf values of all its tiles, returns the list of per-tile results."""
+
+    def __init__(self, tasks):
+        self.tasks = tasks                      # FusedTasks, one per tile
+        self.n_leaves = len(tasks[0].leaf_keys)
+        self.__name__ = "batch_%d_x_%s" % (len(tasks), tasks[0].__name__)
+
+    def __repr__(self):
+        return "<BatchedTask %d tiles of %r>" % (len(self.tasks), self.tasks[0])
+
+    def __call__(self, *all_leaf_values):
+        k = self.n_leaves
+        per_tile = [all_leaf_values[i * k:(i + 1) * k] for i in range(len(self.tasks))]
+        # every tile is planned by the first group (same structure => same plan for the same kind of
+        # tiles); tiles of a different kind (edge tiles of another shape, None responses) run alone
+        rep = self.tasks[0]
+        results = [None] * len(per_tile)
+        groups = {}
+        for i, values in enumerate(per_tile):
+            hit = rep.plan_for(values)
+            if hit is None:
+                results[i] = self.tasks[i](*values)
+            else:
+                groups.setdefault(id(hit), (hit, []))[1].append(i)
+        for hit, members in groups.values():
+            compiled, binding, shape = hit
+            tiles = [[P.as_device(per_tile[i][ref]["values"] if kind == 0 else ref) for kind, ref in binding]
+                     for i in members]
+            outs = P.launch_batch(compiled, tiles, shape)
+            for i, out in zip(members, outs):
+                results[i] = {"values": out, "no_data_value": compiled.out_ndv}
+        return results
+
+
+def _getitem(seq, index):
+    return seq[index]
+
+
 def fuse_graph(graph, name):
-    """Return a graph in which fusable element-wise sub-graphs are single FusedTasks."""
-    # consumers of every key, and a consumers-before-producers order starting at `name`
+    """Return a graph in which fusable element-wise sub-graphs are single FusedTasks and
+    structurally identical, independent FusedTasks are BatchedTasks.  ``name`` is the key (or
+    the list of keys) that will be asked of the graph."""
+    names = set(name) if isinstance(name, (list, tuple, set)) else {name}
+    # consumers of every key, and a consumers-before-producers order starting at the outputs
     consumers = {}
-    order, seen, stack = [], set(), [(name, False)]
+    order, seen, stack = [], set(), [(k, False) for k in names]
     while stack:
         key, expanded = stack.pop()
         if expanded:
@@ -177,7 +275,7 @@ def fuse_graph(graph, name):
             continue
         cons = consumers.get(key, ())
         groups = {group_of.get(c) for c in cons}
-        if key != name and cons and None not in groups and len(groups) == 1:
+        if key not in names and cons and None not in groups and len(groups) == 1:
             group_of[key] = groups.pop()  # every consumer sits in one fused group: join it
         else:
             group_of[key] = key           # output of its group (feeds non-fusable / several groups)
@@ -189,18 +287,50 @@ def fuse_graph(graph, name):
             groups.setdefault(root, []).append(key)
 
     new_graph = {k: v for k, v in graph.items() if k not in group_of}
+    fused = {}
     for root, members in groups.items():
-        if len(members) == 1:
-            new_graph[root] = graph[root]  # nothing to fuse
-            continue
         member_set = set(members)
         leaf_keys = []
         for key in members:
             for dep in _deps(graph[key], graph):
                 if dep not in member_set and dep not in leaf_keys:
                     leaf_keys.append(dep)
-        task = FusedTask({k: graph[k] for k in members}, members, root, leaf_keys)
-        new_graph[root] = (task,) + tuple(leaf_keys)
+        fused[root] = FusedTask({k: graph[k] for k in members}, members, root, leaf_keys)
+
+    # horizontal batching: same structure, same depth in the graph (=> mutually independent)
+    batches = {}
+    if len(fused) > 1:
+        depth = {}
+        for key in reversed(order):  # producers first
+            depth[key] = 1 + max([depth[d] for d in _deps(graph[key], graph)] or [0])
+        for root, task in fused.items():
+            if not task.leaf_keys:
+                continue
+            try:
+                sig = (task.structure(), depth[root], len(task.leaf_keys))
+                hash(sig)
+            except TypeError:
+                continue
+            batches.setdefault(sig, []).append(root)
+    batched = set()
+    for sig, roots in batches.items():
+        for start in range(0, len(roots), MAX_BATCH_TILES):
+            chunk = roots[start:start + MAX_BATCH_TILES]
+            if len(chunk) < 2:
+                continue
+            tasks = [fused[r] for r in chunk]
+            batch_key = "batch_%s" % chunk[0]
+            new_graph[batch_key] = (BatchedTask(tasks),) + tuple(k for t in tasks for k in t.leaf_keys)
+            for i, r in enumerate(chunk):
+                new_graph[r] = (_getitem, batch_key, i)
+                batched.add(r)
+    for root, task in fused.items():
+        if root in batched:
+            continue
+        if len(task.order) == 1:
+            new_graph[root] = graph[root]  # nothing to fuse
+        else:
+            new_graph[root] = (task,) + tuple(task.leaf_keys)
     return new_graph
 
 

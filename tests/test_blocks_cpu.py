@@ -244,6 +244,63 @@ def test_fusion_respects_non_fusable_consumers():
     assert sum(1 for v in fused.values() if getattr(v[0], "__name__", "") == "process") >= 1
 
 
+def test_identical_subgraphs_of_independent_tiles_are_batched(cpu_vm):
+    """Horizontal batching: the same element-wise chain over different leaves (what a RasterTiler
+    fans out) becomes one BatchedTask; results equal the per-view results."""
+    from dask_geomodeling_amd.core.graphs import get_data_many
+    from dask_geomodeling_amd.fuse import BatchedTask
+    rng = np.random.default_rng(5)
+    fill = np.float32(np.finfo("f4").max)
+    views, singles = [], []
+    for t in range(5):
+        arrays = {}
+        for name in "ab":
+            v = (rng.random((1, 32, 48)) * 100).astype("f4")
+            v[0, t::7, ::5] = fill
+            key = "batch%d/%s" % (t, name)
+            ArrayLeaf.ARRAYS[key] = {"values": v, "no_data_value": fill}
+            arrays[name] = ArrayLeaf(key, "<f4", fill)
+        a, b = arrays["a"], arrays["b"]
+        views.append(raster.Clip((a + b) * 2.5 - b + 1.5, a))
+    other = views[0] * 3  # a different structure on top of a batched tile: must stay outside the batch
+    graph, names = {}, []
+    for v in views + [other]:
+        graph, name = v.get_compute_graph(cached_compute_graph=graph, **REQ)
+        names.append(name)
+    fused = fuse_graph(graph, names)
+    batches = [v[0] for v in fused.values() if isinstance(v[0], BatchedTask)]
+    assert len(batches) == 1 and len(batches[0].tasks) == 5
+    singles = [v.get_data(**REQ) for v in views + [other]]
+    many = get_data_many(views + [other], REQ)
+    for got, want in zip(many, singles):
+        assert_result_equal(got, want, 0, "batched vs single")
+    with gmconfig.config.set({"geomodeling.fuse": False}):
+        unfused = get_data_many(views, REQ)
+    for got, want in zip(many, unfused):
+        assert_result_equal(got, want, 0, "batched vs unfused")
+
+
+def test_batching_keeps_dependent_and_odd_tiles_apart(cpu_vm):
+    """Tasks that feed one another never share a batch; a tile whose leaves are of another kind
+    (None response) falls back to its own evaluation inside the batch."""
+    from dask_geomodeling_amd.core.graphs import get_data_many
+    fill = np.float32(np.finfo("f4").max)
+    ArrayLeaf.ARRAYS["odd/a"] = {"values": np.full((1, 32, 48), 2, "f4"), "no_data_value": fill}
+    ArrayLeaf.ARRAYS["odd/none"] = None
+    a = ArrayLeaf("odd/a", "<f4", fill)
+    none = ArrayLeaf("odd/none", "<f4", fill)
+    v1 = (a + 1) * 2
+    v2 = (none + 1) * 2
+    r1, r2 = get_data_many([v1, v2], REQ)
+    assert r2 is None
+    assert np.all(r1["values"] == 6)
+    # a chain whose second link has the same structure as the first: different depth => no batch
+    w1 = (a + 1) * 2
+    w2 = raster.Reclassify(raster.Classify(w1, [1, 2, 3]), [[1, 2]])
+    graph, n2 = w2.get_compute_graph(**REQ)
+    assert not [v for v in fuse_graph(graph, n2).values() if type(v[0]).__name__ == "BatchedTask"]
+
+
 # ---------------------------------------------------------------------------------
 # whole views, fused and op-by-op, against the reference's results
 # ---------------------------------------------------------------------------------
