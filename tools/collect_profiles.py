@@ -19,7 +19,9 @@ KERNEL = "vm_kernel"
 
 def counter_mean(counter):
     vals = collections.defaultdict(list)
-    for path in glob.glob(os.path.join(OUT, "pmc_" + counter, "**", "*counter_collection.csv"), recursive=True):
+    paths = glob.glob(os.path.join(OUT, "pmc_" + counter, "**", "*counter_collection.csv"), recursive=True)
+    # gpurun merges new files into gpurun_out/ without deleting older runs: only the newest counts
+    for path in sorted(paths, key=os.path.getmtime)[-1:]:
         with open(path) as f:
             for r in csv.DictReader(f):
                 if KERNEL in r["Kernel_Name"] and "tail" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
@@ -52,7 +54,8 @@ def main():
                "hbm_bytes_per_launch": fetch_b + write_b,
                "algorithmic_bytes_per_launch": (line or {}).get("roofline", {}).get("algorithmic_bytes_per_launch"),
                "correction": "FETCH_SIZE x2 (gfx950 counts 128-B read requests as 64 B), WRITE_SIZE x1, KiB -> bytes"}
-    stats = glob.glob(os.path.join(OUT, "prof_" + tag, "**", "*kernel_stats.csv"), recursive=True)
+    stats = sorted(glob.glob(os.path.join(OUT, "prof_" + tag, "**", "*kernel_stats.csv"), recursive=True),
+                   key=os.path.getmtime)[-1:]
     print("bench line:", json.dumps(line)[:300] if line else None)
     print("pmc:", json.dumps(pmc))
     if stats:
