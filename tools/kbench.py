@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline check of the table / resample kernels (GPU box only).
+usage: kbench.py [reclass] [classify] [mask] [bilinear] [nearest] [side=8192]
+Prints average launch duration (HIP events) and algorithmic GB/s per kernel."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dask_geomodeling_amd.hip import runtime  # noqa: E402
+from dask_geomodeling_amd.raster import devops, resample, tables  # noqa: E402
+from dask_geomodeling_amd.raster.sources import generate_window  # noqa: E402
+
+F32MAX = float(np.finfo("f4").max)
+I32MAX = 2147483647
+
+
+def timeit(label, bytes_per_call, calls, reps=3):
+    for f in calls:
+        f()
+    runtime.sync()
+    e0, e1 = runtime.Event(), runtime.Event()
+    e0.record()
+    for _ in range(reps):
+        for f in calls:
+            f()
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_ms(e1) / (reps * len(calls)) * 1e3
+    print("%-44s %9.1f us  %7.1f GB/s  (%4.1f%% of 8 TB/s)" % (label, us, bytes_per_call / us / 1e3, bytes_per_call / us / 1e3 / 80), flush=True)
+
+
+def main():
+    which = [a for a in sys.argv[1:] if "=" not in a] or ["reclass", "classify", "mask", "bilinear", "nearest"]
+    opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+    side = int(opts.get("side", 8192))
+    runtime.set_device(0)
+    n = side * side
+    T = 4
+    if "reclass" in which:
+        table = [[k, (7 * k) % 1000] for k in range(0, 256, 2)]
+        kw = {"dtype": "int64", "fillvalue": 9223372036854775807, "data": table, "select": False}
+        tiles = [generate_window((side, side), "i4", 20 + i, 0.0, 256.0, I32MAX, (50, 50), 0, 0, side, side) for i in range(T)]
+        timeit("reclassify i32->i64 dense LUT (12 B/px)", 12.0 * n,
+               [lambda t=t: tables.reclassify_process({"values": t, "no_data_value": I32MAX}, kw) for t in tiles])
+        kw2 = dict(kw, data=[[k * 1000, k] for k in range(100)])
+        timeit("reclassify i32->i64 sparse keys (12 B/px)", 12.0 * n,
+               [lambda t=t: tables.reclassify_process({"values": t, "no_data_value": I32MAX}, kw2) for t in tiles])
+        u8 = [generate_window((side, side), "u1", 30 + i, 0.0, 6.0, 255, (50, 50), 0, 0, side, side) for i in range(T)]
+        kw3 = dict(kw, data=[[0, 10], [1, 11], [3, 13], [5, 15]])
+        timeit("reclassify u8->i64 dense LUT (9 B/px)", 9.0 * n,
+               [lambda t=t: tables.reclassify_process({"values": t, "no_data_value": 255}, kw3) for t in u8])
+        del tiles, u8
+    if "classify" in which:
+        tiles = [generate_window((side, side), "f4", 40 + i, -100.0, 100.0, F32MAX, (97, 89), 0, 0, side, side) for i in range(T)]
+        bins5 = [-50.0, -10.0, 0.0, 10.0, 50.0]
+        timeit("classify f32->u8, 5 edges (5 B/px)", 5.0 * n,
+               [lambda t=t: tables.classify_process({"values": t, "no_data_value": np.float32(F32MAX)}, bins5, False) for t in tiles])
+        bins200 = list(np.linspace(-100, 100, 200))
+        timeit("classify f32->u8, 200 edges (5 B/px)", 5.0 * n,
+               [lambda t=t: tables.classify_process({"values": t, "no_data_value": np.float32(F32MAX)}, bins200, True) for t in tiles])
+        del tiles
+    if "mask" in which:
+        i8 = [generate_window((side, side), "i8", 50 + i, 0.0, 1000.0, 9223372036854775807, (50, 50), 0, 0, side, side) for i in range(T)]
+        timeit("mask i64->u8 (VM, 9 B/px)", 9.0 * n,
+               [lambda t=t: devops.mask_process({"values": t, "no_data_value": 9223372036854775807}, 1) for t in i8])
+        del i8
+        i4 = [generate_window((side, side), "i4", 60 + i, 0.0, 1000.0, I32MAX, (50, 50), 0, 0, side, side) for i in range(T)]
+        timeit("mask i32->u8 (VM, 5 B/px)", 5.0 * n,
+               [lambda t=t: devops.mask_process({"values": t, "no_data_value": I32MAX}, 1) for t in i4])
+        del i4
+    if "bilinear" in which:
+        src = [generate_window((side, side), "f4", 70 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side, side) for i in range(2)]
+        timeit("bilinear f32 2x upsample (5 B/out px)", 5.0 * 4 * n,
+               [lambda t=t: resample.bilinear(t, 2 * side, 2 * side, np.float32(F32MAX)) for t in src])
+        timeit("bilinear f32 1.5x upsample (5.78 B/out px)", (4 + 4 / 2.25) * 2.25 * n,
+               [lambda t=t: resample.bilinear(t, side * 3 // 2, side * 3 // 2, np.float32(F32MAX)) for t in src])
+        del src
+    if "nearest" in which:
+        src = [generate_window((side, side), "f4", 80 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side, side) for i in range(T)]
+        gt = (0.0, 1.0, 0.0, float(side), 0.0, -1.0)
+        timeit("nearest warp f32 identity grid (8 B/px)", 8.0 * n,
+               [lambda t=t: resample.nearest_warp(t, gt, (0.0, 0.0, float(side), float(side)), side, side, F32MAX) for t in src])
+        timeit("nearest warp f32 2x upsample (5 B/out px)", 5.0 * 4 * n,
+               [lambda t=t: resample.nearest_warp(t, gt, (0.0, 0.0, float(side), float(side)), 2 * side, 2 * side, F32MAX) for t in src[:2]])
+        half = side // 2
+        timeit("nearest warp f32 window, quarter (8 B/out px)", 8.0 * n / 4,
+               [lambda t=t: resample.nearest_warp(t, gt, (100.0, 100.0, 100.0 + half, 100.0 + half), half, half, F32MAX) for t in src])
+
+
+if __name__ == "__main__":
+    main()
