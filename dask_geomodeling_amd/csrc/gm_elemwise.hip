@@ -1,5 +1,6 @@
 // K1 host side: validates a gm_program and launches the VM kernel of its register
 // class (kernels: gm_vm.h, instantiated per class in gm_vm_<class>.hip).
+#include <cmath>
 #include <memory>
 #include <mutex>
 #include <unordered_map>
@@ -112,11 +113,13 @@ int lower(const gm_program* prog, VmCode* code, unsigned* n_uops) {
 
 // ---- lowered programs, device resident, cached by content per device ------------------------
 struct CodeEntry {
-  gm_program prog;     // the key (compared in full)
+  gm_program prog;     // the key (compared in full; table pointers zeroed, contents in `tables`)
+  std::vector<unsigned long long> tables;  // words of all tables, in order (part of the key)
+  std::vector<unsigned long long> staged;  // device image of the tables: stays alive for the upload
   VmCode host;         // staging copy: stays alive for the asynchronous upload
   VmCode* dev = nullptr;
   unsigned n_uops = 0;
-  bool heavy = false;
+  int flavor = VM_LIGHT;
   int size = 0;        // kernel size class S/M/L
   bool native = false;
 };
@@ -124,10 +127,11 @@ struct CodeEntry {
 std::mutex g_code_mu;
 std::unordered_map<unsigned long long, std::vector<std::unique_ptr<CodeEntry>>> g_code;  // (device, hash) buckets
 
-unsigned long long hash_program(const gm_program& p, int device) {
+unsigned long long hash_program(const gm_program& p, const std::vector<unsigned long long>& tables, int device) {
   const unsigned char* b = (const unsigned char*)&p;
   unsigned long long h = 1469598103934665603ull ^ (unsigned long long)device;
   for (size_t i = 0; i < sizeof(gm_program); ++i) h = (h ^ b[i]) * 1099511628211ull;
+  for (unsigned long long w : tables) h = (h ^ w) * 1099511628211ull;
   return h;
 }
 
@@ -149,6 +153,19 @@ int validate(const gm_program* prog) {
     if (rc) return rc;
     if (opcode == GM_OP_DIV && prog->reg_class >= GM_CLASS_I32)
       return gm::fail(GM_ERR_INVALID, "step %u: DIV in an integer class", s);
+    if (opcode == GM_OP_DIGITIZE || opcode == GM_OP_LOOKUP) {
+      const unsigned long long t = S.aux0.u64;
+      if (t >= prog->n_tables) return gm::fail(GM_ERR_INVALID, "step %u: table %llu of %u", s, t, prog->n_tables);
+      const unsigned long long words = prog->tables[t].n_words;
+      if (opcode == GM_OP_DIGITIZE) {
+        if (S.aux1.u64 > GM_MAX_LINEAR_EDGES) return gm::fail(GM_ERR_UNSUPPORTED, "step %u: %llu edges (max %d inside a program)", s, (unsigned long long)S.aux1.u64, GM_MAX_LINEAR_EDGES);
+        if (words < S.aux1.u64) return gm::fail(GM_ERR_INVALID, "step %u: table shorter than its edges", s);
+        if (prog->reg_class <= GM_CLASS_F64 && (((S.bits >> 16) & 2u) != 0)) return gm::fail(GM_ERR_INVALID, "step %u: int64 edges in a float class", s);
+      } else {
+        if (prog->reg_class != GM_CLASS_I64 && prog->reg_class != GM_CLASS_F64) return gm::fail(GM_ERR_INVALID, "step %u: LOOKUP needs class I64 or F64", s);
+        if (S.aux2.u64 == 0 || words < S.aux2.u64 + 2 * S.aux3.u64) return gm::fail(GM_ERR_INVALID, "step %u: table shorter than its window + exceptions", s);
+      }
+    }
   }
   return GM_OK;
 }
@@ -166,13 +183,23 @@ int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) 
   key.reg_class = prog->reg_class;
   key.out_dtype = prog->out_dtype;
   if (prog->n_steps > GM_MAX_STEPS || prog->n_inputs > GM_MAX_INPUTS) return validate(prog);
+  if (prog->n_tables > GM_MAX_TABLES) return gm::fail(GM_ERR_INVALID, "n_tables %u", prog->n_tables);
   memcpy(key.inputs, prog->inputs, sizeof(gm_input_desc) * prog->n_inputs);
   memcpy(key.steps, prog->steps, sizeof(gm_step) * prog->n_steps);
-  const unsigned long long h = hash_program(key, device);
+  key.n_tables = prog->n_tables;
+  std::vector<unsigned long long> words;
+  for (unsigned t = 0; t < prog->n_tables; ++t) {
+    if (!prog->tables[t].data && prog->tables[t].n_words) return gm::fail(GM_ERR_INVALID, "table %u is null", t);
+    if (prog->tables[t].n_words > (1ull << 24)) return gm::fail(GM_ERR_UNSUPPORTED, "table %u too large", t);
+    key.tables[t].n_words = prog->tables[t].n_words;  // pointers stay null in the key
+    const unsigned long long* w = (const unsigned long long*)prog->tables[t].data;
+    words.insert(words.end(), w, w + prog->tables[t].n_words);
+  }
+  const unsigned long long h = hash_program(key, words, device);
   std::lock_guard<std::mutex> lk(g_code_mu);
   auto& bucket = g_code[h];
   for (auto& e : bucket)
-    if (memcmp(&e->prog, &key, sizeof(key)) == 0) {
+    if (memcmp(&e->prog, &key, sizeof(key)) == 0 && e->tables == words) {
       *out = e.get();
       return GM_OK;
     }
@@ -180,6 +207,7 @@ int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) 
   if (rc) return rc;
   std::unique_ptr<CodeEntry> e(new CodeEntry);
   e->prog = key;
+  e->tables = words;
   memset(&e->host, 0, sizeof(VmCode));
   memcpy(e->host.inputs, key.inputs, sizeof(key.inputs));
   memcpy(e->host.steps, key.steps, sizeof(key.steps));
@@ -190,20 +218,53 @@ int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) 
     native = ((int)(key.inputs[k].bits & 0xffu) == native_code) && !((key.inputs[k].bits >> 8) & 3u);
   e->native = native;
   unsigned max_tmp = 0;
+  bool has_math = false, has_tables = false;
   for (unsigned s = 0; s < key.n_steps; ++s) {
     const gm_step& S = key.steps[s];
     const unsigned op = S.bits & 0xffu, save_temp = (S.bits >> 8) & 0xffu;
-    if (op == GM_OP_POW || op == GM_OP_EXP || op == GM_OP_LOG || op == GM_OP_LOG10) e->heavy = true;
+    if (op == GM_OP_POW || op == GM_OP_EXP || op == GM_OP_LOG || op == GM_OP_LOG10) has_math = true;
+    if (op == GM_OP_DIGITIZE || op == GM_OP_LOOKUP) has_tables = true;
     if (save_temp > max_tmp) max_tmp = save_temp;
     for (const gm_operand* o : {&S.a, &S.b})
       if ((o->bits & 0xffu) == GM_OPD_TEMP && ((o->bits >> 8) & 0xffu) + 1 > max_tmp) max_tmp = ((o->bits >> 8) & 0xffu) + 1;
   }
   e->size = (key.n_inputs <= 2 && max_tmp <= 1) ? 0 : ((key.n_inputs <= 4 && max_tmp <= 2) ? 1 : 2);
+  if (has_math && has_tables)
+    return gm::fail(GM_ERR_UNSUPPORTED, "pow/exp/log and table lookups in one program (split it)");
+  e->flavor = has_math ? VM_MATH : (has_tables ? VM_TABLES : VM_LIGHT);
+  // device image of the tables: the words as given, except the edges of a DIGITIZE in the F32 class,
+  // which become float32 thresholds making the same decisions as NumPy's float64 compares:
+  //   edge <= x  <=>  ceil32(edge) <= x   (smallest float32 >= edge)
+  //   edge <  x  <=>  floor32(edge) < x   (largest float32 <= edge)
+  e->staged = words;
+  std::vector<size_t> offset(key.n_tables + 1, 0);
+  for (unsigned t = 0; t < key.n_tables; ++t) offset[t + 1] = offset[t] + key.tables[t].n_words;
+  if (key.reg_class == GM_CLASS_F32) {
+    for (unsigned s = 0; s < key.n_steps; ++s) {
+      const gm_step& S = key.steps[s];
+      if ((S.bits & 0xffu) != GM_OP_DIGITIZE) continue;
+      const bool right = ((S.bits >> 16) & 1u) != 0;
+      const size_t at = offset[S.aux0.u64];
+      float* thr = (float*)&e->staged[at];
+      for (unsigned long long i = 0; i < S.aux1.u64; ++i) {
+        double edge;
+        memcpy(&edge, &words[at + i], 8);
+        float f = (float)edge;
+        if (!right && (double)f < edge) f = nextafterf(f, INFINITY);
+        if (right && (double)f > edge) f = nextafterf(f, -INFINITY);
+        thr[i] = f;  // packs downwards: thr[i] never overtakes the words still to be read
+      }
+    }
+  }
   void* dev = nullptr;
-  rc = gm_malloc(&dev, sizeof(VmCode));
+  rc = gm_malloc(&dev, sizeof(VmCode) + e->staged.size() * 8 + 16);
   if (rc) return rc;
   e->dev = (VmCode*)dev;
+  const unsigned long long tables_dev = (unsigned long long)(uintptr_t)dev + ((sizeof(VmCode) + 15) / 16) * 16;
+  for (unsigned t = 0; t < key.n_tables; ++t) e->host.tables[t] = tables_dev + 8ull * offset[t];
   GM_HIP(hipMemcpyAsync(dev, &e->host, sizeof(VmCode), hipMemcpyHostToDevice, stream));
+  if (!e->staged.empty())
+    GM_HIP(hipMemcpyAsync((void*)(uintptr_t)tables_dev, e->staged.data(), e->staged.size() * 8, hipMemcpyHostToDevice, stream));
   *out = e.get();
   bucket.push_back(std::move(e));
   return GM_OK;
@@ -244,8 +305,14 @@ int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const
   }
   if (n == 0 || n_tiles == 0) return GM_OK;
 
-  int G = g_tuning.vec == 8 ? 2 : (g_tuning.vec == 4 ? 1 : (code->n_uops > 3 ? 2 : 1));
-  if (code->heavy || code->size == 2) G = 1;
+  // elements per lane: 4 (G = 1) streams best when a lane moves >= 8 bytes per element; programs of
+  // more than 3 micro-ops amortise their decode over 8 elements, and so do narrow streams (e.g.
+  // int32 -> uint8 Mask, 5 B/px: 48 % of peak with 4 elements per lane, 66 % with 8)
+  unsigned bytes_per_elem = (unsigned)gm::dtype_size(code->prog.out_dtype);
+  for (unsigned k = 0; k < n_in; ++k)
+    if (!((code->prog.inputs[k].bits >> 8) & 1u)) bytes_per_elem += (unsigned)gm::dtype_size(code->prog.inputs[k].bits & 0xffu);
+  int G = g_tuning.vec == 8 ? 2 : (g_tuning.vec == 4 ? 1 : ((code->n_uops > 3 || bytes_per_elem < 8) ? 2 : 1));
+  if (code->flavor == VM_MATH || code->size == 2) G = 1;
   const int max_batch = g_tuning.max_batch > 0 ? g_tuning.max_batch : GM_MAX_BATCH;
   const int cus = gm::current_cu_count();
 
@@ -280,10 +347,10 @@ int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const
     if (tail_blocks > tail_cap) tail_blocks = tail_cap;
     dim3 grid((unsigned)blocks, (unsigned)nb), tail_grid((unsigned)tail_blocks, (unsigned)nb);
     switch (code->prog.reg_class) {
-      case GM_CLASS_F32: rc = launch_class<float>(args, code->size, G, code->heavy, grid, tail_grid, stream); break;
-      case GM_CLASS_F64: rc = launch_class<double>(args, code->size, G, code->heavy, grid, tail_grid, stream); break;
-      case GM_CLASS_I32: rc = launch_class<int>(args, code->size, G, code->heavy, grid, tail_grid, stream); break;
-      default: rc = launch_class<long long>(args, code->size, G, code->heavy, grid, tail_grid, stream); break;
+      case GM_CLASS_F32: rc = launch_class<float>(args, code->size, G, code->flavor, grid, tail_grid, stream); break;
+      case GM_CLASS_F64: rc = launch_class<double>(args, code->size, G, code->flavor, grid, tail_grid, stream); break;
+      case GM_CLASS_I32: rc = launch_class<int>(args, code->size, G, code->flavor, grid, tail_grid, stream); break;
+      default: rc = launch_class<long long>(args, code->size, G, code->flavor, grid, tail_grid, stream); break;
     }
     if (rc) return rc;
   }

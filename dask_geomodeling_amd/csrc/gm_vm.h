@@ -65,6 +65,7 @@ constexpr int GM_MAX_BATCH = 16;
 
 // The lowered program: device resident, one per distinct gm_program (cached by content on the host).
 struct VmCode {
+  unsigned long long tables[GM_MAX_TABLES];  // device addresses of the program's lookup tables
   gm_input_desc inputs[GM_MAX_INPUTS];
   gm_uop uops[GM_MAX_UOPS];
   gm_step steps[GM_MAX_STEPS];  // bodies of the UOP_GENERIC micro-ops
@@ -307,10 +308,17 @@ __device__ __forceinline__ bool in_broadcast(const gm_input_desc& D) { return ((
 __device__ __forceinline__ bool in_native(const gm_input_desc& D) { return ((D.bits >> 9) & 1u) != 0; }
 
 // ---- the interpreter -------------------------------------------------------------
+// FLAVOR of an instantiation: rarely used, register-hungry opcodes live in their own kernels so that
+// they do not cap the occupancy of ordinary programs
+constexpr int VM_LIGHT = 0;   // everything else
+constexpr int VM_MATH = 1;    // + pow / exp / log / log10
+constexpr int VM_TABLES = 2;  // + DIGITIZE / LOOKUP
 // N elements per lane, NIN input slots, NT temps.  HEAVY instantiations carry
 // pow/exp/log (their register appetite would otherwise cap every program's occupancy).
-template <typename RC, int N, int NIN, int NT, bool HEAVY>
+template <typename RC, int N, int NIN, int NT, int FLAVOR>
 struct Machine {
+  static constexpr bool HEAVY = FLAVOR == VM_MATH;
+  static constexpr bool TABLES = FLAVOR == VM_TABLES;
   RC in[NIN][N];
   RC tmp0[N], tmp1[N], tmp2[N], tmp3[N];  // separate members, selected at compile time only: an
   RC acc[N];                               // array of arrays ends up in scratch for NT >= 2
@@ -433,7 +441,7 @@ struct Machine {
     apply2(S, b_scalar, b, f);
   }
 
-  __device__ __forceinline__ void step(const gm_step& S) {
+  __device__ __forceinline__ void step(kargs_t C, const gm_step& S) {
     RC b[N];
     const unsigned b_kind = opd_kind(S.b);
     const bool b_scalar = (b_kind == GM_OPD_SCALAR) | (b_kind == GM_OPD_NONE);
@@ -541,6 +549,84 @@ struct Machine {
           acc[k] = (a_has & (x == a_ndv)) ? fill : r;
         }
       } break;
+      case GM_OP_DIGITIZE:
+        if constexpr (TABLES) {
+          // misc.py:387-399.  Edge-major linear count: every edge is one scalar load (wave-uniform),
+          // v_cmp + v_addc per element; <= GM_MAX_LINEAR_EDGES edges.  Comparisons in the type NumPy's
+          // promoted searchsorted uses: F32 class -> float32 thresholds prepared by the host with
+          // directed rounding (same decisions as float64 compares), F64 -> float64 edges, integer
+          // classes -> int64 edges, or float64 edges against (double)value.
+          const unsigned nb = (unsigned)S.aux1.u64, flags = step_flags(S);
+          const bool right = (flags & 1u) != 0, int_edges = (flags & 2u) != 0;
+          const kargs_t tbl = (kargs_t)(uintptr_t)kload<unsigned long long>(C, offsetof(VmCode, tables) + 8 * (unsigned)S.aux0.u64);
+          const bool a_has = opd_has_ndv(S.a);
+          const RC a_ndv = scalar_of<RC>(S.a.value), fill = scalar_of<RC>(S.fill);
+          int cnt[N];
+#pragma unroll
+          for (int k = 0; k < N; ++k) cnt[k] = 0;
+          for (unsigned b = 0; b < nb; ++b) {
+            if constexpr (std::is_same<RC, float>::value) {
+              const float e = kload<float>(tbl, 4 * b);
+#pragma unroll
+              for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < acc[k]) : (e <= acc[k])) ? 1 : 0;
+            } else if constexpr (std::is_same<RC, double>::value) {
+              const double e = kload<double>(tbl, 8 * b);
+#pragma unroll
+              for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < acc[k]) : (e <= acc[k])) ? 1 : 0;
+            } else {
+              if (int_edges) {
+                const long long e = kload<long long>(tbl, 8 * b);
+#pragma unroll
+                for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < (long long)acc[k]) : (e <= (long long)acc[k])) ? 1 : 0;
+              } else {
+                const double e = kload<double>(tbl, 8 * b);
+#pragma unroll
+                for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < (double)acc[k]) : (e <= (double)acc[k])) ? 1 : 0;
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            int c = cnt[k];
+            if constexpr (is_float_class<RC>::value) c = (acc[k] != acc[k]) ? (int)nb : c;  // NaN sorts to the end
+            acc[k] = (a_has & (acc[k] == a_ndv)) ? fill : (RC)c;
+          }
+        }
+        break;
+      case GM_OP_LOOKUP:
+        if constexpr (TABLES && sizeof(RC) == 8) {
+          // misc.py:505-514.  Dense window of pre-resolved targets gathered from device memory (the
+          // table is a few KiB and stays in the vector L1); keys outside the window -- typically only
+          // the merged-in no-data key -- are matched against scalar registers.
+          const long long kmin = (long long)S.aux1.i64;
+          const unsigned long long range = S.aux2.u64;
+          const unsigned n_exc = (unsigned)S.aux3.u64;
+          const bool select = (step_flags(S) & 1u) != 0;
+          const unsigned long long addr = kload<unsigned long long>(C, offsetof(VmCode, tables) + 8 * (unsigned)S.aux0.u64);
+          const RC* const lut = (const RC*)(uintptr_t)addr;
+          const kargs_t exc = (kargs_t)(uintptr_t)(addr + 8ull * range);
+          const RC fill = scalar_of<RC>(S.fill);
+          long long key[N];
+          RC hit[N];
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            key[k] = (long long)acc[k];
+            const unsigned long long idx = (unsigned long long)(key[k] - kmin);
+            hit[k] = lut[idx < range ? idx : 0ull];
+          }
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const unsigned long long idx = (unsigned long long)(key[k] - kmin);
+            RC miss = select ? fill : acc[k];
+            for (unsigned x = 0; x < n_exc; ++x) {
+              const long long ek = kload<long long>(exc, 16 * x);
+              const RC ev = kload<RC>(exc, 16 * x + 8);
+              miss = (key[k] == ek) ? ev : miss;
+            }
+            acc[k] = idx < range ? hit[k] : miss;
+          }
+        }
+        break;
       case GM_OP_COPY:
       default:
         break;  // the accumulator already holds the operand
@@ -700,7 +786,7 @@ struct Machine {
       }
     } else {  // UOP_GENERIC
       const gm_step S = kload<gm_step>(C, offsetof(VmCode, steps) + sizeof(gm_step) * U.arg);
-      step(S);
+      step(C, S);
     }
   }
 
@@ -717,7 +803,7 @@ template <> struct native_vec<float> { typedef f32x4 type; };
 template <> struct native_vec<int> { typedef i32x4 type; };
 
 // vector kernel: blockIdx.y = tile of the batch, blockIdx.x = span of 256*G groups of 4 elements
-template <typename RC, int G, int NIN, int NT, bool HEAVY>
+template <typename RC, int G, int NIN, int NT, int FLAVOR>
 __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
   const kargs_t K = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int N = 4 * G;
@@ -736,7 +822,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
   bool native = false;
   if constexpr (sizeof(RC) == 4) native = (flags & VM_FLAG_NATIVE) != 0;
 
-  Machine<RC, N, NIN, NT, HEAVY> M;
+  Machine<RC, N, NIN, NT, FLAVOR> M;
   // phase 1: all leaf loads in flight (NIN*G independent 16-byte loads per lane)
   if (native) {
     // every tile already has the class' dtype: straight 16-byte loads, no dtype dispatch
@@ -810,7 +896,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
 
 // scalar tail kernel: the elements the 16-byte vector path cannot take (n % 4, or
 // everything when a pointer is not 16-byte aligned); one element per lane, grid-stride
-template <typename RC, int NIN, int NT, bool HEAVY>
+template <typename RC, int NIN, int NT, int FLAVOR>
 __global__ __launch_bounds__(256) void vm_tail_kernel(const VmLaunch) {
   const kargs_t K = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
   const kargs_t C = (kargs_t)(uintptr_t)GM_KARG(K, code);
@@ -824,7 +910,7 @@ __global__ __launch_bounds__(256) void vm_tail_kernel(const VmLaunch) {
   const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long e = GM_KARG(K, tail_start) + tid; e < n_total; e += nthreads) {
-    Machine<RC, 1, NIN, NT, HEAVY> M1;
+    Machine<RC, 1, NIN, NT, FLAVOR> M1;
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       if (k < (int)n_in) {
@@ -841,34 +927,37 @@ __global__ __launch_bounds__(256) void vm_tail_kernel(const VmLaunch) {
 
 // host-side launcher of one register class (defined once per class in gm_vm_<class>.hip).
 // size: 0 = S (<= 2 inputs, <= 1 temp), 1 = M (<= 4 inputs, <= 2 temps), 2 = L (8 inputs, 4 temps)
-// grid.y = tail_grid.y = tiles of the batch
+// flavor: VM_LIGHT / VM_MATH / VM_TABLES; grid.y = tail_grid.y = tiles of the batch
 template <typename RC>
-int launch_class(const VmLaunch& args, int size, int G, bool heavy, dim3 grid, dim3 tail_grid, hipStream_t stream);
+int launch_class(const VmLaunch& args, int size, int G, int flavor, dim3 grid, dim3 tail_grid, hipStream_t stream);
 
-#define GM_VM_LAUNCH(RC, G_, NIN_, NT_, HEAVY_)                                                          \
+#define GM_VM_LAUNCH(RC, G_, NIN_, NT_, FLAVOR_)                                                          \
   do {                                                                                                   \
-    if (grid.x) hipLaunchKernelGGL((vm_kernel<RC, G_, NIN_, NT_, HEAVY_>), grid, dim3(256), 0, stream, args); \
+    if (grid.x) hipLaunchKernelGGL((vm_kernel<RC, G_, NIN_, NT_, FLAVOR_>), grid, dim3(256), 0, stream, args); \
     if (tail_grid.x)                                                                                     \
-      hipLaunchKernelGGL((vm_tail_kernel<RC, NIN_, NT_, HEAVY_>), tail_grid, dim3(256), 0, stream, args); \
+      hipLaunchKernelGGL((vm_tail_kernel<RC, NIN_, NT_, FLAVOR_>), tail_grid, dim3(256), 0, stream, args); \
+  } while (0)
+
+#define GM_VM_LAUNCH_SIZES(RC, FLAVOR_, G_S, G_M)                     \
+  do {                                                               \
+    if (size == 0) {                                                 \
+      if (G >= 2 && G_S >= 2) GM_VM_LAUNCH(RC, G_S, 2, 1, FLAVOR_);  \
+      else GM_VM_LAUNCH(RC, 1, 2, 1, FLAVOR_);                       \
+    } else if (size == 1) {                                          \
+      if (G >= 2 && G_M >= 2) GM_VM_LAUNCH(RC, G_M, 4, 2, FLAVOR_);  \
+      else GM_VM_LAUNCH(RC, 1, 4, 2, FLAVOR_);                       \
+    } else {                                                         \
+      GM_VM_LAUNCH(RC, 1, 8, 4, FLAVOR_);                            \
+    }                                                                \
   } while (0)
 
 #define GM_VM_DEFINE_LAUNCHER(RC)                                                                  \
   template <>                                                                                      \
-  int launch_class<RC>(const VmLaunch& args, int size, int G, bool heavy, dim3 grid, dim3 tail_grid, \
+  int launch_class<RC>(const VmLaunch& args, int size, int G, int flavor, dim3 grid, dim3 tail_grid, \
                        hipStream_t stream) {                                                       \
-    if (heavy) {                                                                                   \
-      if (size == 0) GM_VM_LAUNCH(RC, 1, 2, 1, true);                                              \
-      else if (size == 1) GM_VM_LAUNCH(RC, 1, 4, 2, true);                                         \
-      else GM_VM_LAUNCH(RC, 1, 8, 4, true);                                                        \
-    } else if (size == 0) {                                                                        \
-      if (G >= 2) GM_VM_LAUNCH(RC, 2, 2, 1, false);                                                \
-      else GM_VM_LAUNCH(RC, 1, 2, 1, false);                                                       \
-    } else if (size == 1) {                                                                        \
-      if (G >= 2) GM_VM_LAUNCH(RC, 2, 4, 2, false);                                                \
-      else GM_VM_LAUNCH(RC, 1, 4, 2, false);                                                       \
-    } else {                                                                                       \
-      GM_VM_LAUNCH(RC, 1, 8, 4, false);                                                            \
-    }                                                                                              \
+    if (flavor == VM_MATH) GM_VM_LAUNCH_SIZES(RC, VM_MATH, 1, 1);                                  \
+    else if (flavor == VM_TABLES) GM_VM_LAUNCH_SIZES(RC, VM_TABLES, 2, 2);                         \
+    else GM_VM_LAUNCH_SIZES(RC, VM_LIGHT, 2, 2);                                                   \
     hipError_t e = hipGetLastError();                                                              \
     if (e != hipSuccess) return gm::hip_fail(e, "vm_kernel launch");                               \
     return GM_OK;                                                                                  \

@@ -25,7 +25,7 @@ import numpy as np
 
 from .hip import program as P
 from .hip.array import DeviceArray
-from .raster import devops
+from .raster import devops, tables
 
 __all__ = ["fuse_graph", "materialize", "FusedTask", "BatchedTask"]
 
@@ -46,7 +46,28 @@ def _is_key(x, graph):
 
 
 def _fusable(task):
-    return _is_task(task) and getattr(task[0], "gm_op", None) is not None
+    if not _is_task(task):
+        return False
+    op = getattr(task[0], "gm_op", None)
+    if op is None:
+        return False
+    # table lookups join a program only when they are small enough to run inside one; otherwise
+    # they keep their own kernel (and must not drag the rest of a group to the op-by-op path)
+    if op == "classify":
+        bins = task[2] if len(task) > 2 else None
+        return hasattr(bins, "__len__") and len(bins) <= P.GM_MAX_LINEAR_EDGES
+    if op == "reclassify":
+        kwargs = task[2] if len(task) > 2 else None
+        if not isinstance(kwargs, dict) or not kwargs.get("data"):
+            return False
+        keys = sorted(int(pair[0]) for pair in kwargs["data"])
+        best, lo = 0, 0
+        for hi in range(len(keys)):
+            while keys[hi] - keys[lo] >= P.LOOKUP_MAX_WINDOW:
+                lo += 1
+            best = max(best, hi - lo + 1)
+        return len(keys) - best <= P.LOOKUP_MAX_EXCEPTIONS - 1  # one slot stays free for the no-data key
+    return True
 
 
 class FusedTask(object):
@@ -87,8 +108,10 @@ class FusedTask(object):
             return None
 
     def plan_for(self, leaf_values):
-        """-> (compiled program, slot binding, shape) when this kind of tiles runs as ONE launch of
-        one program, else None (control-flow responses, several launches, not fusable)."""
+        """-> (stages, shape) when this kind of tiles runs as a fixed sequence of programs -- one
+        program in the common case, a few when no register class serves the whole group -- else
+        None (control-flow responses, not fusable).  A stage is (compiled, binding); a binding entry
+        is (0, call argument index), (1, constant array) or (2, index of an earlier stage)."""
         sig = self._signature(leaf_values)
         if sig is None:
             return None
@@ -105,39 +128,38 @@ class FusedTask(object):
         try:
             for key in self.order:
                 nodes[key] = self._node(key, nodes)
-            compiled, leaves, shape = P.plan(nodes[self.root])
+            staged, shape = P.plan_staged(nodes[self.root])
         except (_NotFusable, P.FusionLimit, NotImplementedError, TypeError):
             return None
-        # which call argument (or constant ndarray operand, uploaded once) feeds each slot
-        binding = [(0, arg_of[id(l)]) if id(l) in arg_of else (1, l.values) for l in leaves]
+        stages = []
+        for compiled, leaves in staged:
+            binding = []
+            for l in leaves:
+                if isinstance(l, P.StageRef):
+                    binding.append((2, l.stage))
+                elif id(l) in arg_of:
+                    binding.append((0, arg_of[id(l)]))
+                else:
+                    binding.append((1, l.values))  # constant ndarray operand, uploaded once
+            stages.append((compiled, binding))
         if len(self._plans) > 64:
             self._plans.clear()
-        self._plans[sig] = (compiled, binding, shape)
+        self._plans[sig] = (stages, shape)
         return self._plans[sig]
 
     def __call__(self, *leaf_values):
-        # fast path: one compiled program (cached per kind of tiles), one launch
+        # fast path: a fixed sequence of compiled programs (cached per kind of tiles)
         hit = self.plan_for(leaf_values)
         if hit is not None:
-            compiled, binding, shape = hit
-            tiles = [leaf_values[ref]["values"] if kind == 0 else ref for kind, ref in binding]
-            values = P.launch(compiled, [P.as_device(t) for t in tiles], shape)
-            return {"values": values, "no_data_value": compiled.out_ndv}
-
+            stages, shape = hit
+            outs = []
+            for compiled, binding in stages:
+                tiles = [P.as_device(leaf_values[ref]["values"]) if kind == 0 else
+                         (outs[ref] if kind == 2 else P.as_device(ref)) for kind, ref in binding]
+                outs.append(P.launch(compiled, tiles, shape))
+            return {"values": outs[-1], "no_data_value": stages[-1][0].out_ndv}
         self._leaf_set = set(self.leaf_keys)
-        env = dict(zip(self.leaf_keys, leaf_values))
-        if not all(isinstance(v, dict) and "values" in v for v in leaf_values):
-            return self._run_unfused(env)
-        nodes = {}
-        for key, data in env.items():
-            nodes[key] = P.Leaf(None, data["values"].dtype, data.get("no_data_value"), values=data["values"])
-        try:
-            for key in self.order:
-                nodes[key] = self._node(key, nodes)
-        except _NotFusable:
-            return self._run_unfused(env)
-        values, ndv = P.evaluate(nodes[self.root])  # several launches: sub-trees first
-        return {"values": values, "no_data_value": ndv}
+        return self._run_unfused(dict(zip(self.leaf_keys, leaf_values)))
 
     def structure(self):
         """Hashable description of the group up to the identity of its leaves: two groups with
@@ -199,6 +221,13 @@ class FusedTask(object):
             return devops.isdata_node(operand(args[0]))
         if op == "isnodata":
             return devops.isnodata_node(operand(args[0]))
+        try:
+            if op == "classify":
+                return tables.classify_node(operand(args[0]), args[1], args[2])
+            if op == "reclassify":
+                return tables.reclassify_node(operand(args[0]), args[1])
+        except P.FusionLimit:
+            raise _NotFusable()
         raise _NotFusable()
 
 
@@ -233,12 +262,16 @@ class BatchedTask(object):
             else:
                 groups.setdefault(id(hit), (hit, []))[1].append(i)
         for hit, members in groups.values():
-            compiled, binding, shape = hit
-            tiles = [[P.as_device(per_tile[i][ref]["values"] if kind == 0 else ref) for kind, ref in binding]
-                     for i in members]
-            outs = P.launch_batch(compiled, tiles, shape)
-            for i, out in zip(members, outs):
-                results[i] = {"values": out, "no_data_value": compiled.out_ndv}
+            stages, shape = hit
+            outs = []  # per stage: one result per member tile
+            for compiled, binding in stages:
+                tiles = [[P.as_device(per_tile[i][ref]["values"]) if kind == 0 else
+                          (outs[ref][m] if kind == 2 else P.as_device(ref)) for kind, ref in binding]
+                         for m, i in enumerate(members)]
+                outs.append(P.launch_batch(compiled, tiles, shape))
+            ndv = stages[-1][0].out_ndv
+            for i, out in zip(members, outs[-1]):
+                results[i] = {"values": out, "no_data_value": ndv}
         return results
 
 

@@ -17,6 +17,8 @@ from .dtypes import code_of
 from .runtime import gm_scalar
 
 GM_MAX_INPUTS, GM_MAX_STEPS, GM_MAX_TEMPS = 8, 24, 4
+GM_MAX_TABLES, GM_MAX_LINEAR_EDGES = 4, 32
+LOOKUP_MAX_WINDOW, LOOKUP_MAX_EXCEPTIONS = 65536, 8
 CLASS_F32, CLASS_F64, CLASS_I32, CLASS_I64 = 0, 1, 2, 3
 CLASS_DTYPE = {CLASS_F32: np.dtype("f4"), CLASS_F64: np.dtype("f8"),
                CLASS_I32: np.dtype("i4"), CLASS_I64: np.dtype("i8")}
@@ -29,7 +31,7 @@ OPCODES = {
     "logical_and": 12, "logical_or": 13, "logical_xor": 14,
     "exp": 15, "log": 16, "log10": 17,
     "invert": 18, "isdata": 19, "isnodata": 20, "clip": 21, "mask": 22,
-    "maskbelow": 23, "step": 24, "fillnodata": 25, "copy": 26,
+    "maskbelow": 23, "step": 24, "fillnodata": 25, "copy": 26, "digitize": 27, "lookup": 28,
 }
 MATH_OPS = ("add", "subtract", "multiply", "divide", "power", "exp", "log", "log10")
 COMPARE_OPS = ("equal", "not_equal", "greater", "greater_equal", "less", "less_equal")
@@ -79,10 +81,15 @@ class gm_input_desc(ctypes.Structure):
     native_ndv = property(lambda self: (self.bits >> 9) & 1)
 
 
+class gm_table(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("n_words", ctypes.c_uint64)]
+
+
 class gm_program(ctypes.Structure):
     _fields_ = [("n_steps", ctypes.c_uint32), ("n_inputs", ctypes.c_uint32), ("reg_class", ctypes.c_uint32),
                 ("out_dtype", ctypes.c_uint32),
-                ("inputs", gm_input_desc * GM_MAX_INPUTS), ("steps", gm_step * GM_MAX_STEPS)]
+                ("inputs", gm_input_desc * GM_MAX_INPUTS), ("steps", gm_step * GM_MAX_STEPS),
+                ("n_tables", ctypes.c_uint32), ("pad_", ctypes.c_uint32), ("tables", gm_table * GM_MAX_TABLES)]
 
 
 class gm_vm_tuning(ctypes.Structure):
@@ -237,6 +244,8 @@ def _scalar_key(v):
         return tuple(_scalar_key(x) for x in v)
     if isinstance(v, dict):
         return tuple(sorted((k, _scalar_key(x)) for k, x in v.items()))
+    if isinstance(v, np.ndarray):
+        return ("nd", v.dtype.str, v.shape, v.tobytes())
     if isinstance(v, np.generic):
         return (v.dtype.str, v.tobytes())
     if isinstance(v, float):
@@ -293,6 +302,18 @@ def node_classes(node):
         for a in node.args:
             if not isinstance(a, Lit):
                 allowed = allowed & classes_exact(a.dtype)
+    elif op == "digitize":
+        # Classify: the value is compared with the edges in NumPy's promoted dtype -- float tiles in a
+        # float class (float64 edges; the F32 class uses directed-rounded float32 thresholds),
+        # integer tiles in an integer class (int64 edges, or float64 edges against (double)value)
+        src = node.args[0].dtype
+        if src == np.dtype("bool") or (src.kind == "u" and src.itemsize == 8):
+            raise FusionLimit("Classify of %s tiles runs as its own kernel" % src)
+        float_side = frozenset((CLASS_F32, CLASS_F64)) if src.kind == "f" else frozenset((CLASS_I32, CLASS_I64))
+        allowed = classes_exact(src) & float_side
+    elif op == "lookup":
+        allowed = frozenset((CLASS_I64,)) if node.dtype == np.dtype("i8") else frozenset((CLASS_F64,))
+        allowed = allowed & classes_exact(node.args[0].dtype)
     elif op in ("clip", "copy"):
         allowed = classes_exact(node.args[0].dtype)
     elif op == "mask":
@@ -371,7 +392,7 @@ def tree_classes(root):
 # ----------------------------------------------------------------------------
 
 class Compiled:
-    __slots__ = ("program", "out_dtype", "out_ndv", "n_inputs", "reg_class", "heavy", "n_steps")
+    __slots__ = ("program", "out_dtype", "out_ndv", "n_inputs", "reg_class", "heavy", "n_steps", "tables")
 
 
 def compile_expr(root, n_inputs):
@@ -396,6 +417,14 @@ def compile_expr(root, n_inputs):
     prog.reg_class = cls
     prog.n_inputs = n_inputs
     steps = []
+    tables = []  # uint64 word arrays, kept alive by the Compiled object
+
+    def add_table(words):
+        if len(tables) >= GM_MAX_TABLES:
+            raise FusionLimit("too many tables")
+        tables.append(np.ascontiguousarray(words, dtype=np.uint64))
+        return len(tables) - 1
+
     # consumers per shared Op node
     refs = {}
     order = []
@@ -506,6 +535,28 @@ def compile_expr(root, n_inputs):
             _set_scalar(s.aux1, cls, cast_scalar(left, node.dtype))
             _set_scalar(s.aux2, cls, cast_scalar(at, node.dtype))
             _set_scalar(s.aux3, cls, cast_scalar(right, node.dtype))
+        elif node.op == "digitize":
+            ex = node.extra
+            edges = ex["edges"]
+            if cls in (CLASS_F32, CLASS_F64) and edges.dtype != np.dtype("f8"):
+                raise FusionLimit("integer edges in a float class")
+            _set_scalar(s.fill, cls, node.ndv)
+            s.aux0.u64 = add_table(edges.view(np.uint64))
+            s.aux1.u64 = int(edges.size)
+            s.flags = (1 if ex["right"] else 0) | (2 if edges.dtype == np.dtype("i8") else 0)
+        elif node.op == "lookup":
+            ex = node.extra
+            rc = CLASS_DTYPE[cls]
+            lut = np.ascontiguousarray(ex["lut"].astype(rc))
+            exc = np.zeros(2 * len(ex["exc_keys"]), dtype=np.uint64)
+            exc[0::2] = np.asarray(ex["exc_keys"], dtype=np.int64).view(np.uint64)
+            exc[1::2] = np.asarray(ex["exc_vals"]).astype(rc).view(np.uint64)
+            _set_scalar(s.fill, cls, node.ndv)
+            s.aux0.u64 = add_table(np.concatenate([lut.view(np.uint64), exc]))
+            s.aux1.i64 = int(ex["kmin"])
+            s.aux2.u64 = int(lut.size)
+            s.aux3.u64 = len(ex["exc_keys"])
+            s.flags = 1 if ex["select"] else 0
         elif node.op == "mask":
             ex = node.extra
             _set_scalar(s.fill, cls, ex["fill"])
@@ -569,7 +620,12 @@ def compile_expr(root, n_inputs):
         if slot not in leaves:  # unused input: still needs a valid dtype code
             prog.inputs[slot].set(code_of(np.dtype("u1")))
     prog.out_dtype = code_of(root.dtype)
+    prog.n_tables = len(tables)
+    for t, words in enumerate(tables):
+        prog.tables[t].data = words.ctypes.data
+        prog.tables[t].n_words = words.size
     out = Compiled()
+    out.tables = tables
     out.program, out.out_dtype, out.out_ndv = prog, root.dtype, root.ndv
     out.n_inputs, out.reg_class, out.n_steps = n_inputs, cls, len(steps)
     out.heavy = any(OPCODES[k] == s.opcode for s in steps for k in HEAVY_OPS)
@@ -676,6 +732,18 @@ def _collect_leaves(root):
     return out
 
 
+class StageRef(Leaf):
+    """Leaf standing for the result of an earlier stage of a staged plan (a full-size tile)."""
+
+    def __init__(self, stage, dtype, ndv, shape):
+        super().__init__(None, dtype, ndv)
+        self.stage, self.shape = stage, tuple(shape)
+
+
+def _leaf_shape(leaf):
+    return leaf.shape if isinstance(leaf, StageRef) else tuple(leaf.values.shape)
+
+
 def plan(root):
     """Bind slots/broadcast flags of the tree's leaves and compile it -> (compiled, leaves, shape).
     Raises FusionLimit when the tree does not fit one program."""
@@ -683,41 +751,114 @@ def plan(root):
     if not leaves:
         raise TypeError("at least one raster operand is required")
     for leaf in leaves:
-        leaf.values = as_device(leaf.values)
-    big = max(leaves, key=lambda l: l.values.size)
-    shape, n = big.values.shape, big.values.size
-    for slot, leaf in enumerate(leaves):
-        size = leaf.values.size
+        if not isinstance(leaf, StageRef):
+            leaf.values = as_device(leaf.values)
+    shapes = [_leaf_shape(leaf) for leaf in leaves]
+    sizes = [int(np.prod(sh, dtype=np.int64)) for sh in shapes]
+    shape, n = max(zip(shapes, sizes), key=lambda t: t[1])
+    for slot, (leaf, size, sh) in enumerate(zip(leaves, sizes, shapes)):
         if size != n and size != 1:
             raise NotImplementedError("operand shapes %s and %s differ (only equal shapes or single-element "
-                                      "operands are supported on the device)" % (shape, leaf.values.shape))
+                                      "operands are supported on the device)" % (shape, sh))
         leaf.slot, leaf.broadcast = slot, (size == 1 and n != 1)
     return compile_cached(root, len(leaves)), leaves, shape
+
+
+def _subtree_classes(root, memo):
+    """Admissible classes of the whole sub-tree under ``root`` (memoised by node identity)."""
+    hit = memo.get(id(root))
+    if hit is None:
+        hit = tree_classes(root) if isinstance(root, Op) else ALL_CLASSES
+        memo[id(root)] = hit
+    return hit
+
+
+def _weight(node):
+    return 1 + sum(_weight(a) for a in node.args) if isinstance(node, Op) else 0
+
+
+def plan_staged(root):
+    """Partition an expression into as few programs as possible -> (stages, shape).
+
+    ``stages`` is a list of (compiled, leaves) in execution order; a leaf is either a Leaf of the
+    expression (its tile bound in ``.values``) or a StageRef to an earlier stage's result; the last
+    stage computes ``root``.  Cuts are placed bottom-up where no register class serves both sides
+    (e.g. float32 arithmetic + Classify | Reclassify + Mask in the int64 class), keeping the largest
+    compatible part fused; programs that exceed the input / step / temp limits are split on top."""
+    stages = []
+    memo = {}
+    shape_of = {}
+
+    def any_shape(node):
+        for leaf in _collect_leaves(node):
+            sh = _leaf_shape(leaf)
+            if int(np.prod(sh, dtype=np.int64)) != 1:
+                return sh
+        return _leaf_shape(_collect_leaves(node)[0])
+
+    def cut(node):
+        """Return ``node`` with the sub-trees that cannot share its program replaced by StageRefs."""
+        if not isinstance(node, Op):
+            return node
+        args = [cut(a) for a in node.args]
+        node = Op(node.op, args, node.dtype, node.ndv, fill=node.fill, extra=node.extra) \
+            if any(x is not y for x, y in zip(args, node.args)) else node
+        if _subtree_classes(node, memo):
+            return node
+        own = node_classes(Op(node.op, [a if not isinstance(a, Op) else Leaf(None, a.dtype, a.ndv) for a in node.args],
+                              node.dtype, node.ndv, fill=node.fill, extra=node.extra))
+        if not own:
+            return node  # not even alone: compile_expr reports it
+        children = [a for a in node.args if isinstance(a, Op)]
+        best = max(own, key=lambda c: (sum(_weight(a) for a in children if c in _subtree_classes(a, memo)),
+                                       -CLASS_COST[c]))
+        new_args = []
+        for a in node.args:
+            if isinstance(a, Op) and best not in _subtree_classes(a, memo):
+                new_args.append(materialise(a))
+            else:
+                new_args.append(a)
+        return Op(node.op, new_args, node.dtype, node.ndv, fill=node.fill, extra=node.extra)
+
+    def materialise(node):
+        node = cut(node)
+        try:
+            compiled, leaves, shape = plan(node)
+        except FusionLimit:
+            if not isinstance(node, Op) or all(isinstance(a, (Leaf, Lit)) for a in node.args):
+                raise NotImplementedError("expression '%s' does not fit the device program format"
+                                          % getattr(node, "op", node))
+            # too many inputs / steps / temps: the operand sub-trees become stages of their own
+            new_args = [materialise(a) if isinstance(a, Op) else a for a in node.args]
+            node = Op(node.op, new_args, node.dtype, node.ndv, fill=node.fill, extra=node.extra)
+            compiled, leaves, shape = plan(node)
+        stages.append((compiled, leaves))
+        return StageRef(len(stages) - 1, node.dtype, compiled.out_ndv, shape)
+
+    if isinstance(root, (Leaf, Lit)):
+        compiled, leaves, shape = plan(root)
+        return [(compiled, leaves)], shape
+    last = materialise(root)
+    return stages, last.shape
+
+
+def run_staged(stages, shape):
+    """Execute a staged plan whose expression leaves carry their tiles -> DeviceArray of the last stage."""
+    outs = []
+    for compiled, leaves in stages:
+        inputs = [outs[leaf.stage] if isinstance(leaf, StageRef) else leaf.values for leaf in leaves]
+        outs.append(launch(compiled, inputs, shape))
+    return outs[-1]
 
 
 def evaluate(root):
     """Evaluate an expression whose Leafs carry their tiles -> (DeviceArray, ndv).
 
     One launch when the tree fits one program; otherwise (no common register class, too
-    many inputs / steps / temps) sub-trees are evaluated first and fed back as tiles."""
+    many inputs / steps / temps) it runs as the stages ``plan_staged`` cuts it into."""
     runtime.require_device()
-    try:
-        compiled, leaves, shape = plan(root)
-    except FusionLimit:
-        if not isinstance(root, Op) or all(isinstance(a, (Leaf, Lit)) for a in root.args):
-            raise NotImplementedError("expression '%s' does not fit the device program format"
-                                      % getattr(root, "op", root))
-        # evaluate the operand sub-trees on their own, then this node on their results
-        new_args = []
-        for a in root.args:
-            if isinstance(a, Op):
-                values, ndv = evaluate(a)
-                new_args.append(Leaf(None, values.dtype, ndv, values=values))
-            else:
-                new_args.append(a)
-        return evaluate(Op(root.op, new_args, root.dtype, root.ndv, fill=root.fill, extra=root.extra))
-    out = launch(compiled, [leaf.values for leaf in leaves], shape)
-    return out, compiled.out_ndv
+    stages, shape = plan_staged(root)
+    return run_staged(stages, shape), stages[-1][0].out_ndv
 
 
 def run_expr(build, tiles):

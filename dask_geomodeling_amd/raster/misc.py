@@ -195,6 +195,8 @@ class Classify(BaseSingle):
     def process(data, bins, right):
         return tables.classify_process(data, bins, right)
 
+    process.__func__.gm_op = "classify"
+
 
 class Reclassify(BaseSingle):
     """Map integer cell values through a list of [from, to] pairs (misc.py:402-515)."""
@@ -249,3 +251,5 @@ class Reclassify(BaseSingle):
     @staticmethod
     def process(store_data, process_kwargs):
         return tables.reclassify_process(store_data, process_kwargs)
+
+    process.__func__.gm_op = "reclassify"

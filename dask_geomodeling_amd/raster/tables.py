@@ -32,11 +32,83 @@ def _lib():
     return L
 
 
+def classify_node(store, bins, right):
+    """Classify.process numerics (raster/misc.py:391-398) as a program node (GM_OP_DIGITIZE).
+    Raises FusionLimit when the lookup has to run as its own kernel (many edges, bool / uint64
+    tiles, more classes than uint16 holds)."""
+    out_dtype = utils.get_uint_dtype(len(bins) + 2)
+    if out_dtype.itemsize > 2 or len(bins) > P.GM_MAX_LINEAR_EDGES:
+        raise P.FusionLimit("Classify with %d edges runs as its own kernel" % len(bins))
+    edges = np.asarray(bins)
+    # np.digitize -> searchsorted compares in result_type(tile, edges): integers stay integers
+    tile_is_int = store.dtype.kind in "iu"
+    if tile_is_int and edges.dtype.kind in "iub":
+        payload = np.ascontiguousarray(edges, dtype=np.int64)
+    else:
+        payload = np.ascontiguousarray(edges, dtype=np.float64)
+    fill = utils.get_dtype_max(out_dtype)
+    return P.Op("digitize", [store], out_dtype, fill, extra={"edges": payload, "right": bool(right)})
+
+
+def reclassify_node(store, process_kwargs):
+    """Reclassify.process numerics (raster/misc.py:489-514) as a program node (GM_OP_LOOKUP): a dense
+    window of pre-resolved targets + at most 8 keys outside it (typically the merged-in no-data key).
+    Raises FusionLimit when the table is too sparse for that (it then runs as its own kernel)."""
+    dtype = np.dtype(process_kwargs["dtype"])
+    if dtype not in (np.dtype("i8"), np.dtype("f8")):
+        raise P.FusionLimit("Reclassify target dtype %s" % dtype)
+    if store.dtype.kind not in "iub" or store.dtype == np.dtype("u8"):
+        raise P.FusionLimit("Reclassify of %s tiles" % store.dtype)
+    fill = process_kwargs["fillvalue"]
+    select = bool(process_kwargs["select"])
+    keys, targets = reclassify_table(process_kwargs, store.ndv)
+    keys = keys.astype(np.int64)
+    targets = targets.astype(dtype)
+    n = len(keys)
+    # densest run of keys spanning < LOOKUP_MAX_WINDOW slots
+    best_lo, best_cnt, lo = 0, 0, 0
+    for hi in range(n):
+        while int(keys[hi]) - int(keys[lo]) >= P.LOOKUP_MAX_WINDOW:
+            lo += 1
+        if hi - lo + 1 > best_cnt:
+            best_lo, best_cnt = lo, hi - lo + 1
+    if n == 0 or n - best_cnt > P.LOOKUP_MAX_EXCEPTIONS:
+        raise P.FusionLimit("Reclassify table too sparse for an in-program lookup")
+    w_lo, w_hi = best_lo, best_lo + best_cnt - 1
+    kmin = int(keys[w_lo])
+    slots = int(keys[w_hi]) - kmin + 1
+    if select:
+        lut = np.full(slots, fill, dtype=dtype)
+    else:  # unmapped values pass through, cast to the output dtype (misc.py:508)
+        lut = (np.arange(slots, dtype=np.int64) + kmin).astype(dtype)
+    lut[keys[w_lo:w_hi + 1] - kmin] = targets[w_lo:w_hi + 1]
+    outside = [i for i in range(n) if i < w_lo or i > w_hi]
+    extra = {"kmin": kmin, "lut": lut, "exc_keys": keys[outside], "exc_vals": targets[outside], "select": select}
+    return P.Op("lookup", [store], dtype, fill, extra=extra)
+
+
+def _try_program(node):
+    """Evaluate a single table node as a program; None when it has to run as its own kernel."""
+    try:
+        values, ndv = P.evaluate(node)
+    except (P.FusionLimit, NotImplementedError):
+        return None
+    return {"values": values, "no_data_value": ndv}
+
+
 def classify_process(data, bins, right):
     """Drop-in for Classify.process (raster/misc.py:387-399)."""
     if data is None or "values" not in data:
         return data
     runtime.require_device()
+    if data["values"].dtype != np.dtype("bool"):
+        try:  # few edges: one program step (the same one a fused chain uses)
+            leaf = P.Leaf(None, data["values"].dtype, data["no_data_value"], values=data["values"])
+            hit = _try_program(classify_node(leaf, bins, right))
+        except P.FusionLimit:
+            hit = None
+        if hit is not None:
+            return hit
     values = as_device(data["values"])
     out_dtype = utils.get_uint_dtype(len(bins) + 2)
     fill = utils.get_dtype_max(out_dtype)
@@ -76,11 +148,19 @@ def reclassify_process(store_data, process_kwargs):
     if store_data is None or "values" not in store_data:
         return store_data
     runtime.require_device()
-    values = as_device(store_data["values"])
-    if values.dtype.kind not in "iub" or values.dtype == np.dtype("u8"):
-        raise NotImplementedError("Reclassify on %s tiles is not supported on the device" % values.dtype)
+    in_dtype = store_data["values"].dtype
+    if in_dtype.kind not in "iub" or in_dtype == np.dtype("u8"):
+        raise NotImplementedError("Reclassify on %s tiles is not supported on the device" % in_dtype)
     dtype = np.dtype(process_kwargs["dtype"])
     fill = process_kwargs["fillvalue"]
+    try:  # dense table: one program step (the same one a fused chain uses)
+        leaf = P.Leaf(None, in_dtype, store_data["no_data_value"], values=store_data["values"])
+        hit = _try_program(reclassify_node(leaf, process_kwargs))
+    except P.FusionLimit:
+        hit = None
+    if hit is not None:
+        return hit
+    values = as_device(store_data["values"])
     keys, targets = reclassify_table(process_kwargs, store_data["no_data_value"])
     if dtype not in (np.dtype("i8"), np.dtype("f8")):
         raise NotImplementedError("Reclassify target dtype %s" % dtype)

@@ -122,6 +122,8 @@ const char* gm_version(void);
 #define GM_MAX_INPUTS 8
 #define GM_MAX_STEPS 24
 #define GM_MAX_TEMPS 4
+#define GM_MAX_TABLES 4
+#define GM_MAX_LINEAR_EDGES 32
 
 /* register class: the type all VM registers are held in */
 enum gm_reg_class { GM_CLASS_F32 = 0, GM_CLASS_F64 = 1, GM_CLASS_I32 = 2, GM_CLASS_I64 = 3 };
@@ -145,6 +147,11 @@ enum gm_opcode {
   GM_OP_STEP = 24,     /* left/at/right by comparing a with aux; no-data kept */
   GM_OP_FILLNODATA = 25,/* b where b is data (isclose rule) else a */
   GM_OP_COPY = 26,     /* acc = a (cast only) */
+  /* table lookups inside a program (tables travel with the program: gm_program.tables) */
+  GM_OP_DIGITIZE = 27, /* Classify.process (raster/misc.py:387-399): acc = number of edges e with e <= a
+                          (right: e < a); NaN -> nbins; a == ndv_a -> fill.  <= GM_MAX_LINEAR_EDGES edges */
+  GM_OP_LOOKUP = 28,   /* Reclassify.process (raster/misc.py:482-515): acc = LUT[a - kmin] inside the dense
+                          window, else the matching exception key's target, else select ? fill : a */
   GM_OP_COUNT
 };
 
@@ -178,6 +185,12 @@ typedef struct gm_step {
   gm_scalar aux1;     /* MASK/FILLNODATA: .f64 isclose tolerance atol + rtol*|ndv|; STEP: left */
   gm_scalar aux2;     /* MASK/FILLNODATA: .f64 the ndv isclose compares with; STEP: at */
   gm_scalar aux3;     /* STEP: right */
+  /* DIGITIZE: aux0.u64 = table index, aux1.u64 = number of edges; flags: 1 = right, 2 = the table
+               holds int64 edges (integer tile, integer edges) instead of float64 edges
+     LOOKUP:   aux0.u64 = table index, aux1.i64 = kmin, aux2.u64 = slots of the dense window,
+               aux3.u64 = number of exception keys; flags: 1 = select.  Table words: `slots` targets
+               (register-class bit patterns, unmapped slots already resolved), then one
+               (int64 key, target) pair per exception.  Classes I64 / F64 only. */
 } gm_step;
 #define GM_STEP_BITS(opcode, save_temp, flags, round_f32, wrap_i32, check_finite)                     \
   ((uint32_t)(opcode) | ((uint32_t)(save_temp) << 8) | ((uint32_t)(flags) << 16) |                    \
@@ -197,6 +210,13 @@ typedef struct gm_input_desc {
 #define GM_INPUT_BITS(dtype, broadcast, native_ndv) \
   ((uint32_t)(dtype) | ((uint32_t)(broadcast) << 8) | ((uint32_t)(native_ndv) << 9))
 
+/* A lookup table of a program: n_words 8-byte words in HOST memory (copied, uploaded and cached
+ * together with the program on its first use). */
+typedef struct gm_table {
+  const void* data;
+  uint64_t n_words;
+} gm_table;
+
 typedef struct gm_program {
   uint32_t n_steps;
   uint32_t n_inputs;
@@ -204,6 +224,9 @@ typedef struct gm_program {
   uint32_t out_dtype;  /* gm_dtype the final accumulator is stored as */
   gm_input_desc inputs[GM_MAX_INPUTS];
   gm_step steps[GM_MAX_STEPS];
+  uint32_t n_tables;
+  uint32_t pad_;
+  gm_table tables[GM_MAX_TABLES];
 } gm_program;
 
 /* Run `prog` over n elements.  inputs[k] are device pointers (n elements each, or 1

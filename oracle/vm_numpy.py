@@ -10,6 +10,8 @@ tell compiler bugs from kernel bugs.  Only tests may import it; it is also what 
 Every step re-applies raster/elemwise.py:263-296 literally (no-data by exact ==,
 compute in the step dtype, non-finite -> fill, no-data -> fill).
 """
+import ctypes
+
 import numpy as np
 
 CLASS_DTYPE = {0: np.dtype("f4"), 1: np.dtype("f8"), 2: np.dtype("i4"), 3: np.dtype("i8")}
@@ -20,6 +22,14 @@ OPD_NONE, OPD_ACC, OPD_INPUT, OPD_SCALAR, OPD_TEMP = range(5)
 
 def _scalar(slot, cls):
     return {0: slot.f32, 1: slot.f64, 2: slot.i32, 3: slot.i64}[cls]
+
+
+def _table(prog, index):
+    """The 8-byte words of table ``index`` of the program (host memory owned by the Compiled object)."""
+    t = prog.tables[index]
+    if t.n_words == 0:
+        return np.zeros(0, dtype=np.uint64)
+    return np.ctypeslib.as_array((ctypes.c_uint64 * t.n_words).from_address(t.data)).copy()
 
 
 def run_program(prog, inputs, n):
@@ -152,6 +162,32 @@ def run_program(prog, inputs, n):
                 r = np.where(a == loc, rc.type(_scalar(S.aux2, cls)), r)
                 r = np.where(a < loc, rc.type(_scalar(S.aux1, cls)), r)
                 nd = nda
+            elif op == 27:  # digitize (Classify.process, raster/misc.py:391-398)
+                nb = int(S.aux1.u64)
+                words = _table(prog, int(S.aux0.u64))[:nb]
+                right = bool(S.flags & 1)
+                if S.flags & 2:  # integer tile, integer edges: exact int64 compares
+                    edges, x = words.view("i8"), a.astype("i8")
+                else:            # float64 compares of the (exactly converted) value
+                    edges, x = words.view("f8"), a.astype("f8")
+                r = np.searchsorted(edges, x, side="left" if right else "right").astype(rc)
+                if rc.kind == "f":
+                    r = np.where(np.isnan(a), rc.type(nb), r)
+                nd = nda
+            elif op == 28:  # lookup (Reclassify.process, raster/misc.py:505-514)
+                kmin, slots, n_exc = int(S.aux1.i64), int(S.aux2.u64), int(S.aux3.u64)
+                words = _table(prog, int(S.aux0.u64))
+                lut = words[:slots].view(rc)
+                key = a.astype("i8")
+                idx = key - np.int64(kmin)
+                inside = (idx >= 0) & (idx < slots)
+                miss = np.full(n, fill, dtype=rc) if (S.flags & 1) else a.copy()
+                for x in range(n_exc):
+                    ek = words[slots + 2 * x:slots + 2 * x + 1].view("i8")[0]
+                    ev = words[slots + 2 * x + 1:slots + 2 * x + 2].view(rc)[0]
+                    miss = np.where(key == ek, ev, miss)
+                r = np.where(inside, lut[np.where(inside, idx, 0)], miss)
+                nd = np.zeros(n, dtype=bool)
             else:  # copy
                 r = a.copy()
             if cls == 1 and S.round_f32:

@@ -14,7 +14,7 @@ from dask_geomodeling_amd.core import Block, construct, graphs
 from dask_geomodeling_amd.fuse import FusedTask, fuse_graph
 
 ULP = {"Power": 1, "Exp": 3, "Log": 3, "Log10": 3}
-NEEDS_DEVICE = ("Classify", "Reclassify")
+NEEDS_DEVICE = ()  # Classify / Reclassify run as program ops on the interpreter too
 
 
 def _uses(expr, names):

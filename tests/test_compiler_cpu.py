@@ -67,3 +67,77 @@ def test_mask(cpu_vm, case):
         return
     out = devops.mask_process(*case["args"])
     assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+# ---------------------------------------------------------------------------------
+# Classify / Reclassify as program ops (GM_OP_DIGITIZE / GM_OP_LOOKUP): every golden case that
+# fits a program must come out of the compiler + interpreter exactly as the reference computed it
+# ---------------------------------------------------------------------------------
+def _program_result(node):
+    from dask_geomodeling_amd.hip import program as P
+    values, ndv = P.evaluate(node)
+    return {"values": values, "no_data_value": ndv}
+
+
+@pytest.mark.parametrize("case", load_family("classify"), ids=lambda c: c["id"])
+def test_classify_as_program_op(cpu_vm, case):
+    from dask_geomodeling_amd.hip import program as P
+    from dask_geomodeling_amd.raster import tables
+    data, bins, right = case["args"]
+    if data is None or "values" not in data:
+        pytest.skip("control-flow case")
+    leaf = P.Leaf(None, data["values"].dtype, data["no_data_value"], values=data["values"])
+    try:
+        node = tables.classify_node(leaf, bins, right)
+        out = _program_result(node)
+    except (P.FusionLimit, NotImplementedError):
+        pytest.skip("runs as its own kernel")
+    assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.mark.parametrize("case", [c for c in load_family("reclassify") if c["op"] == "reclassify"],
+                         ids=lambda c: c["id"])
+def test_reclassify_as_program_op(cpu_vm, case):
+    from dask_geomodeling_amd.hip import program as P
+    from dask_geomodeling_amd.raster import tables
+    data, kwargs = case["args"]
+    if data is None or "values" not in data:
+        pytest.skip("control-flow case")
+    leaf = P.Leaf(None, data["values"].dtype, data["no_data_value"], values=data["values"])
+    try:
+        node = tables.reclassify_node(leaf, kwargs)
+        out = _program_result(node)
+    except (P.FusionLimit, NotImplementedError):
+        pytest.skip("runs as its own kernel")
+    assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+def test_table_ops_fuse_into_two_programs(cpu_vm):
+    """float32 arithmetic + Classify | Reclassify + Mask: no single register class serves the chain;
+    the planner cuts it once (F32 program -> uint8 tile -> I64 program) instead of op by op."""
+    from dask_geomodeling_amd.hip import program as P
+    from dask_geomodeling_amd.raster import tables
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(3)
+    fill = np.float32(np.finfo("f4").max)
+    a = (rng.random((1, 40, 50)) * 200 - 100).astype("f4")
+    b = (rng.random((1, 40, 50)) * 50).astype("f4")
+    a[0, ::7, ::3] = fill
+    a[0, 3, 3] = np.nan
+    bins = [-50.0, -10.0, 0.0, 10.0, 50.0]
+    table = {"dtype": "<i8", "fillvalue": int(np.iinfo("i8").max), "select": False,
+             "data": [[0, 10], [1, 11], [3, 13], [5, 15]]}
+    kw = {"dtype": "float32", "fillvalue": float(fill)}
+    A, B = {"values": a, "no_data_value": fill}, {"values": b, "no_data_value": fill}
+    want = O.mask_process(O.reclassify_process(O.classify_process(O.math_process("add", kw, A, B), bins, False), table), 1)
+    la, lb = P.Leaf(None, "f4", fill, values=a), P.Leaf(None, "f4", fill, values=b)
+    x = devops.math_node("add", kw, [la, lb])
+    x = tables.classify_node(x, bins, False)
+    x = tables.reclassify_node(x, table)
+    x = devops.mask_node(x, 1)
+    stages, shape = P.plan_staged(x)
+    assert len(stages) == 2
+    assert [c.reg_class for c, _ in stages] == [P.CLASS_F32, P.CLASS_I64]
+    assert stages[0][0].out_dtype == np.dtype("u1") and stages[1][0].out_dtype == np.dtype("u1")
+    out = P.run_staged(stages, shape)
+    assert_result_equal({"values": out, "no_data_value": stages[-1][0].out_ndv}, want, 0, "two-stage chain")

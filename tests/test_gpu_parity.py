@@ -137,21 +137,63 @@ def test_device_array_roundtrip_and_checksum(gpu):
             assert DeviceArray.from_numpy(y.reshape(x.shape)).checksum() != d.checksum()
 
 
+# Both routes of the table lookups are pinned to the golden vectors: "program" = the in-program
+# op (GM_OP_DIGITIZE / GM_OP_LOOKUP, taken whenever the table is small / dense enough), "kernel" =
+# the stand-alone LDS kernels (gm_classify2 / gm_reclassify), forced here for every case.
+@pytest.mark.parametrize("route", ["program", "kernel"])
 @pytest.mark.parametrize("case", load_family("classify"), ids=lambda c: c["id"])
-def test_classify_golden(gpu, case):
+def test_classify_golden(gpu, case, route, monkeypatch):
     from dask_geomodeling_amd.raster import tables
+    if route == "kernel":
+        monkeypatch.setattr(tables, "_try_program", lambda node: None)
     out = tables.classify_process(*case["args"])
     assert_result_equal(out, case["expect"], 0, case["id"])
 
 
+@pytest.mark.parametrize("route", ["program", "kernel"])
 @pytest.mark.parametrize("case", [c for c in load_family("reclassify") if c["op"] == "reclassify"],
                          ids=lambda c: c["id"])
-def test_reclassify_golden(gpu, case):
+def test_reclassify_golden(gpu, case, route, monkeypatch):
     from dask_geomodeling_amd.raster import tables
     if "raises" in case:
         pytest.skip("reference raises %s" % case["raises"])
+    if route == "kernel":
+        monkeypatch.setattr(tables, "_try_program", lambda node: None)
     out = tables.reclassify_process(*case["args"])
     assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [7, 4096, 70001])
+@pytest.mark.parametrize("in_dtype", ["u1", "i2", "i4", "i8"])
+def test_table_ops_big_tiles_vs_oracle(gpu, n, in_dtype):
+    """Random tiles through Classify (few and many edges, both sides) and Reclassify (dense window +
+    far no-data key, sparse keys, select on/off, float targets) on both routes, against the oracle."""
+    from dask_geomodeling_amd.raster import tables
+    rng = np.random.default_rng(n)
+    ndv = int(np.iinfo(in_dtype).max)
+    v = rng.integers(0, 120, size=(1, 1, n)).astype(in_dtype)
+    v[..., ::11] = ndv
+    data = {"values": v, "no_data_value": ndv}
+    tabs = [[[k, (7 * k) % 50] for k in range(0, 120, 2)], [[k * 1000 % 127, k] for k in range(1, 40)],
+            [[k, k * 0.5] for k in range(0, 100, 3)]]
+    for table in tabs:
+        dt = np.asarray([t for _, t in table]).dtype
+        for select in (False, True):
+            kw = {"dtype": dt.str, "fillvalue": O.get_dtype_max(dt) if hasattr(O, "get_dtype_max") else
+                  (np.iinfo(dt).max.item() if dt.kind == "i" else np.finfo(dt).max.item()), "data": table, "select": select}
+            want = O.reclassify_process(data, kw)
+            assert_result_equal(tables.reclassify_process(data, kw), want, 0, "reclassify %s select=%s" % (in_dtype, select))
+    f = (rng.random((1, 1, n)) * 200 - 100).astype("f4")
+    fndv = np.float32(np.finfo("f4").max)
+    f[..., ::13] = fndv
+    f[..., 5:6] = np.nan
+    for bins in ([-50.0, -10.5, 0.0, 10.1, 50.0], list(np.linspace(-99.3, 99.1, 77)), [0, 10, 20]):
+        for right in (False, True):
+            for values, nd in ((f, fndv), (v, ndv)):
+                d = {"values": values, "no_data_value": nd}
+                want = O.classify_process(d, bins, right)
+                assert_result_equal(tables.classify_process(d, bins, right), want, 0, "classify %d edges right=%s" % (len(bins), right))
 
 
 # ---- resampling -------------------------------------------------------------------
