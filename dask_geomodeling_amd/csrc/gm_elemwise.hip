@@ -120,6 +120,7 @@ struct CodeEntry {
   VmCode* dev = nullptr;
   unsigned n_uops = 0;
   int flavor = VM_LIGHT;
+  unsigned lds_table = 0, lds_words = 0;  // 1 + index / window words of the LOOKUP table staged in LDS
   int size = 0;        // kernel size class S/M/L
   bool native = false;
 };
@@ -232,6 +233,13 @@ int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) 
   if (has_math && has_tables)
     return gm::fail(GM_ERR_UNSUPPORTED, "pow/exp/log and table lookups in one program (split it)");
   e->flavor = has_math ? VM_MATH : (has_tables ? VM_TABLES : VM_LIGHT);
+  for (unsigned s = 0; s < key.n_steps && !e->lds_table; ++s) {
+    const gm_step& S = key.steps[s];
+    if ((S.bits & 0xffu) == GM_OP_LOOKUP && S.aux2.u64 <= 8192) {  // window fits 64 KiB of LDS
+      e->lds_table = (unsigned)S.aux0.u64 + 1;
+      e->lds_words = (unsigned)S.aux2.u64;
+    }
+  }
   // device image of the tables: the words as given, except the edges of a DIGITIZE in the F32 class,
   // which become float32 thresholds making the same decisions as NumPy's float64 compares:
   //   edge <= x  <=>  ceil32(edge) <= x   (smallest float32 >= edge)
@@ -311,7 +319,9 @@ int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const
   unsigned bytes_per_elem = (unsigned)gm::dtype_size(code->prog.out_dtype);
   for (unsigned k = 0; k < n_in; ++k)
     if (!((code->prog.inputs[k].bits >> 8) & 1u)) bytes_per_elem += (unsigned)gm::dtype_size(code->prog.inputs[k].bits & 0xffu);
-  int G = g_tuning.vec == 8 ? 2 : (g_tuning.vec == 4 ? 1 : ((code->n_uops > 3 || bytes_per_elem < 8) ? 2 : 1));
+  const bool wide_class = code->prog.reg_class == GM_CLASS_F64 || code->prog.reg_class == GM_CLASS_I64;
+  // (the 64-bit classes pay 8 elements per lane with their occupancy: 132 VGPRs instead of 70)
+  int G = g_tuning.vec == 8 ? 2 : (g_tuning.vec == 4 ? 1 : ((code->n_uops > 3 || (bytes_per_elem < 8 && !wide_class)) ? 2 : 1));
   if (code->flavor == VM_MATH || code->size == 2) G = 1;
   const int max_batch = g_tuning.max_batch > 0 ? g_tuning.max_batch : GM_MAX_BATCH;
   const int cus = gm::current_cu_count();
@@ -340,6 +350,18 @@ int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const
     args.tail_start = args.n_groups * 4;
     const unsigned long long per_block = 256ull * G;
     unsigned long long blocks = (args.n_groups + per_block - 1) / per_block;
+    args.spans = 1;
+    if (code->flavor == VM_TABLES && code->lds_table) {
+      // a workgroup that stages W bytes of table streams >= 10 W bytes of tiles
+      args.lds_table = code->lds_table;
+      args.lds_words = code->lds_words;
+      const unsigned long long span_bytes = per_block * 4ull * (bytes_per_elem ? bytes_per_elem : 1);
+      unsigned long long spans = ((unsigned long long)code->lds_words * 8ull * 10ull + span_bytes - 1) / span_bytes;
+      if (spans < 1) spans = 1;
+      if (spans > 64) spans = 64;
+      args.spans = (unsigned)spans;
+      blocks = (blocks + spans - 1) / spans;
+    }
     if (blocks > 0x7fffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "tile of %zu elements is too large for one launch", n);
     const unsigned long long tail = n - args.tail_start;
     unsigned long long tail_blocks = (tail + 255) / 256;

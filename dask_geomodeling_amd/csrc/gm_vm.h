@@ -83,6 +83,10 @@ struct VmLaunch {
   unsigned int out_dtype;
   unsigned int flags;             // bit2 native: every input and the output are non-broadcast tiles of the
                                   // class' own dtype
+  unsigned int lds_table;         // TABLES kernels: 1 + index of the LOOKUP table staged in LDS (0 = none)
+  unsigned int lds_words;         //   its dense window, in 8-byte words
+  unsigned int spans;             //   spans of 256*G groups a workgroup walks (amortises the staging)
+  unsigned int pad_;
   const void* in[GM_MAX_BATCH][GM_MAX_INPUTS];
   void* out[GM_MAX_BATCH];
 };
@@ -320,6 +324,7 @@ struct Machine {
   static constexpr bool HEAVY = FLAVOR == VM_MATH;
   static constexpr bool TABLES = FLAVOR == VM_TABLES;
   RC in[NIN][N];
+  int lds_table = -1;  // TABLES: index of the table whose dense window sits in LDS
   RC tmp0[N], tmp1[N], tmp2[N], tmp3[N];  // separate members, selected at compile time only: an
   RC acc[N];                               // array of arrays ends up in scratch for NT >= 2
 
@@ -608,11 +613,26 @@ struct Machine {
           const RC fill = scalar_of<RC>(S.fill);
           long long key[N];
           RC hit[N];
+          if ((int)S.aux0.u64 == lds_table) {
+            // the window was staged in LDS behind the tile loads: ds_read_b64 per element (a gather
+            // from the vector L1 costs the whole CU ~64 cycles per wave-instruction instead)
+            extern __shared__ __align__(16) unsigned long long vm_lds[];
 #pragma unroll
-          for (int k = 0; k < N; ++k) {
-            key[k] = (long long)acc[k];
-            const unsigned long long idx = (unsigned long long)(key[k] - kmin);
-            hit[k] = lut[idx < range ? idx : 0ull];
+            for (int k = 0; k < N; ++k) {
+              key[k] = (long long)acc[k];
+              const unsigned long long idx = (unsigned long long)(key[k] - kmin);
+              const unsigned long long w = vm_lds[idx < range ? idx : 0ull];
+              RC h;
+              __builtin_memcpy(&h, &w, 8);
+              hit[k] = h;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              key[k] = (long long)acc[k];
+              const unsigned long long idx = (unsigned long long)(key[k] - kmin);
+              hit[k] = lut[idx < range ? idx : 0ull];
+            }
           }
 #pragma unroll
           for (int k = 0; k < N; ++k) {
@@ -813,7 +833,6 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
   const unsigned n_in = GM_KARG(K, n_inputs);
   const kargs_t C = (kargs_t)(uintptr_t)GM_KARG(K, code);
   const size_t in_base = offsetof(VmLaunch, in) + sizeof(void*) * GM_MAX_INPUTS * tile;
-  const unsigned long long g0 = (unsigned long long)blockIdx.x * (256ull * G) + threadIdx.x;  // sub-vector u: group g0 + 256*u
   constexpr bool nt_ld = true, nt_st = true;
   // the whole pointer row of this tile in one scalar load (slots past n_inputs are null, never used)
   const void* in_ptr[NIN];
@@ -821,6 +840,14 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
   for (int k = 0; k < NIN; ++k) in_ptr[k] = kload<const void*>(K, in_base + sizeof(void*) * k);
   bool native = false;
   if constexpr (sizeof(RC) == 4) native = (flags & VM_FLAG_NATIVE) != 0;
+  void* const out = kload<void*>(K, offsetof(VmLaunch, out) + sizeof(void*) * tile);
+
+  // TABLES kernels walk `spans` consecutive spans so that the LDS staging of a LOOKUP window is
+  // amortised; every other kernel does exactly one span (full grid)
+  unsigned spans = 1;
+  if constexpr (FLAVOR == VM_TABLES) spans = GM_KARG(K, spans);
+  for (unsigned span = 0; span < spans; ++span) {
+  const unsigned long long g0 = ((unsigned long long)blockIdx.x * spans + span) * (256ull * G) + threadIdx.x;  // sub-vector u: group g0 + 256*u
 
   Machine<RC, N, NIN, NT, FLAVOR> M;
   // phase 1: all leaf loads in flight (NIN*G independent 16-byte loads per lane)
@@ -868,10 +895,23 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
       }
     }
   }
+  if constexpr (FLAVOR == VM_TABLES) {
+    const unsigned lds_table = GM_KARG(K, lds_table);
+    if (lds_table) {
+      M.lds_table = (int)lds_table - 1;
+      if (span == 0) {  // stage the LOOKUP window while the tile loads are in flight
+        extern __shared__ __align__(16) unsigned long long vm_lds[];
+        const unsigned words = GM_KARG(K, lds_words);
+        const unsigned long long* const src =
+            (const unsigned long long*)(uintptr_t)kload<unsigned long long>(C, offsetof(VmCode, tables) + 8 * (lds_table - 1));
+        for (unsigned i = threadIdx.x; i < words; i += 256) vm_lds[i] = src[i];
+        __syncthreads();
+      }
+    }
+  }
   // phase 2: interpret
   M.run(C, GM_KARG(K, n_uops));
   // phase 3: store
-  void* const out = kload<void*>(K, offsetof(VmLaunch, out) + sizeof(void*) * tile);
 #pragma unroll
   for (int u = 0; u < G; ++u) {
     const unsigned long long g = g0 + 256ull * u;
@@ -892,6 +932,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
       }
     }
   }
+  }  // spans
 }
 
 // scalar tail kernel: the elements the 16-byte vector path cannot take (n % 4, or
@@ -933,7 +974,9 @@ int launch_class(const VmLaunch& args, int size, int G, int flavor, dim3 grid, d
 
 #define GM_VM_LAUNCH(RC, G_, NIN_, NT_, FLAVOR_)                                                          \
   do {                                                                                                   \
-    if (grid.x) hipLaunchKernelGGL((vm_kernel<RC, G_, NIN_, NT_, FLAVOR_>), grid, dim3(256), 0, stream, args); \
+    if (grid.x)                                                                                          \
+      hipLaunchKernelGGL((vm_kernel<RC, G_, NIN_, NT_, FLAVOR_>), grid, dim3(256),                       \
+                         (FLAVOR_ == VM_TABLES && args.lds_table) ? (size_t)args.lds_words * 8 : 0, stream, args); \
     if (tail_grid.x)                                                                                     \
       hipLaunchKernelGGL((vm_tail_kernel<RC, NIN_, NT_, FLAVOR_>), tail_grid, dim3(256), 0, stream, args); \
   } while (0)
