@@ -297,8 +297,18 @@ int gm_vm_get_tuning(gm_vm_tuning* t) {
   return GM_OK;
 }
 
+int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* const* inputs, const uint32_t* pitches,
+                             void* const* outs, size_t rows, size_t cols);
+
 int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const* inputs, void* const* outs, size_t n) {
+  return gm_elemwise_run_batch_2d(prog, n_tiles, inputs, nullptr, outs, 1, n);
+}
+
+int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* const* inputs, const uint32_t* pitches,
+                             void* const* outs, size_t rows, size_t cols) {
+  const size_t n = rows * cols;
   if (!prog || !outs || (!inputs && prog->n_inputs)) return gm::fail(GM_ERR_INVALID, "null argument");
+  if (pitches && cols > 0xffffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "strided tiles wider than 2^32 elements");
   if (n_tiles < 0) return gm::fail(GM_ERR_INVALID, "n_tiles %d", n_tiles);
   hipStream_t stream = gm::current_stream();
   if (!stream) return GM_ERR_NO_DEVICE;
@@ -335,17 +345,32 @@ int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const
     args.n_uops = code->n_uops;
     args.n_inputs = n_in;
     args.out_dtype = code->prog.out_dtype;
-    bool aligned = true;
+    bool aligned = true, strided = false;
     for (int t = 0; t < nb; ++t) {
       args.out[t] = outs[t0 + t];
       if (((uintptr_t)args.out[t] % 16) != 0) aligned = false;
       for (unsigned k = 0; k < n_in; ++k) {
         const void* p = inputs[(size_t)(t0 + t) * n_in + k];
         args.in[t][k] = p;
-        if (!((code->prog.inputs[k].bits >> 8) & 1u) && ((uintptr_t)p % 16) != 0) aligned = false;
+        const bool broadcast = ((code->prog.inputs[k].bits >> 8) & 1u) != 0;
+        if (!broadcast && ((uintptr_t)p % 16) != 0) aligned = false;
+        const uint32_t pitch = pitches ? pitches[(size_t)(t0 + t) * n_in + k] : 0u;
+        if (pitch && pitch != cols && !broadcast) {
+          if (pitch < cols) return gm::fail(GM_ERR_INVALID, "pitch %u of input %u is smaller than the tile width %zu", pitch, k, cols);
+          args.pitch[t][k] = pitch;
+          strided = true;
+          // 16-byte vector loads need every row of the window to start 16-byte aligned
+          const size_t item = (size_t)gm::dtype_size(code->prog.inputs[k].bits & 0xffu);
+          if (((size_t)pitch * item) % 16 != 0) aligned = false;
+        }
       }
     }
     args.flags = code->native ? VM_FLAG_NATIVE : 0u;
+    if (strided) {
+      args.flags |= VM_FLAG_STRIDED;
+      args.cols = (unsigned)cols;
+      if (cols % 4 != 0 || n / 4 > 0xffffffffull) aligned = false;  // groups must not straddle rows
+    }
     args.n_groups = aligned ? n / 4 : 0;
     args.tail_start = args.n_groups * 4;
     const unsigned long long per_block = 256ull * G;
@@ -386,6 +411,17 @@ int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out
 }
 
 }  // extern "C"
+
+// Device-to-device copy of a 2-D window (compaction of a strided view), asynchronous on the compute stream.
+extern "C" int gm_copy_2d(void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes,
+                          size_t width_bytes, size_t rows) {
+  if (!dst || !src) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (width_bytes == 0 || rows == 0) return GM_OK;
+  hipStream_t stream = gm::current_stream();
+  if (!stream) return GM_ERR_NO_DEVICE;
+  GM_HIP(hipMemcpy2DAsync(dst, dst_pitch_bytes, src, src_pitch_bytes, width_bytes, rows, hipMemcpyDeviceToDevice, stream));
+  return GM_OK;
+}
 
 // ABI self-check used by the Python binding: sizes of the program structs.
 extern "C" size_t gm_sizeof(int which) {

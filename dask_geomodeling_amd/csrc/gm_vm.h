@@ -86,11 +86,12 @@ struct VmLaunch {
   unsigned int lds_table;         // TABLES kernels: 1 + index of the LOOKUP table staged in LDS (0 = none)
   unsigned int lds_words;         //   its dense window, in 8-byte words
   unsigned int spans;             //   spans of 256*G groups a workgroup walks (amortises the staging)
-  unsigned int pad_;
+  unsigned int cols;              // strided inputs (windows of a larger resident raster): tile width in elements
+  unsigned int pitch[GM_MAX_BATCH][GM_MAX_INPUTS];  // row pitch in elements, 0 = contiguous
   const void* in[GM_MAX_BATCH][GM_MAX_INPUTS];
   void* out[GM_MAX_BATCH];
 };
-constexpr unsigned VM_FLAG_NATIVE = 4u;
+constexpr unsigned VM_FLAG_NATIVE = 4u, VM_FLAG_STRIDED = 8u;
 
 // Launch arguments and code are read through the constant address space with explicit typed
 // loads -> s_load_dword*; the by-value kernel parameter itself is never touched, so the compiler
@@ -849,6 +850,30 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
   for (unsigned span = 0; span < spans; ++span) {
   const unsigned long long g0 = ((unsigned long long)blockIdx.x * spans + span) * (256ull * G) + threadIdx.x;  // sub-vector u: group g0 + 256*u
 
+  // Strided inputs -- zero-copy windows of a larger raster resident in HBM (a tile request into a
+  // MemorySource): group g of the tile sits at row g / (cols/4), column 4 * (g % (cols/4)); the
+  // element offset of input k is row * pitch_k + column (4 g for contiguous inputs).  One 32-bit
+  // division per group, shared by all inputs.
+  const bool strided = (flags & VM_FLAG_STRIDED) != 0;
+  unsigned row_of[G], col_of[G];
+  if (strided) {
+    const unsigned cols4 = GM_KARG(K, cols) >> 2;
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const unsigned g32 = (unsigned)(g0 + 256ull * u);
+      row_of[u] = g32 / cols4;
+      col_of[u] = (g32 - row_of[u] * cols4) << 2;
+    }
+  }
+  const size_t pitch_base = offsetof(VmLaunch, pitch) + sizeof(unsigned) * GM_MAX_INPUTS * tile;
+  auto elem_offset = [&](int k, int u, unsigned long long g) -> unsigned long long {
+    if (strided) {
+      const unsigned pitch = kload<unsigned>(K, pitch_base + sizeof(unsigned) * k);
+      if (pitch) return (unsigned long long)row_of[u] * pitch + col_of[u];
+    }
+    return g * 4ull;
+  };
+
   Machine<RC, N, NIN, NT, FLAVOR> M;
   // phase 1: all leaf loads in flight (NIN*G independent 16-byte loads per lane)
   if (native) {
@@ -863,7 +888,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
           for (int u = 0; u < G; ++u) {
             const unsigned long long g = g0 + 256ull * u;
             V4 x = {0, 0, 0, 0};
-            if (g < n_groups) x = ld(p + g, nt_ld);
+            if (g < n_groups) x = ld((const V4*)((const RC*)p + elem_offset(k, u, g)), nt_ld);
 #pragma unroll
             for (int q = 0; q < 4; ++q) M.in[k][4 * u + q] = x[q];
           }
@@ -887,7 +912,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
             RC v4[4] = {(RC)0, (RC)0, (RC)0, (RC)0};
             const unsigned long long g = g0 + 256ull * u;
             if (g < n_groups)
-              load_elems<RC, 4>(in_k, in_dtype(D), g * 4ull, nt_ld, v4, in_native(D), (long long)D.ndv.i64);
+              load_elems<RC, 4>(in_k, in_dtype(D), elem_offset(k, u, g), nt_ld, v4, in_native(D), (long long)D.ndv.i64);
 #pragma unroll
             for (int q = 0; q < 4; ++q) M.in[k][4 * u + q] = v4[q];
           }
@@ -950,14 +975,27 @@ __global__ __launch_bounds__(256) void vm_tail_kernel(const VmLaunch) {
   void* const out = kload<void*>(K, offsetof(VmLaunch, out) + sizeof(void*) * tile);
   const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
+  const bool strided = (GM_KARG(K, flags) & VM_FLAG_STRIDED) != 0;
+  const unsigned long long cols = GM_KARG(K, cols);
+  const size_t pitch_base = offsetof(VmLaunch, pitch) + sizeof(unsigned) * GM_MAX_INPUTS * tile;
   for (unsigned long long e = GM_KARG(K, tail_start) + tid; e < n_total; e += nthreads) {
     Machine<RC, 1, NIN, NT, FLAVOR> M1;
+    unsigned long long row = 0, col = 0;
+    if (strided) {
+      row = e / cols;
+      col = e - row * cols;
+    }
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       if (k < (int)n_in) {
         const gm_input_desc D = kload<gm_input_desc>(C, offsetof(VmCode, inputs) + sizeof(gm_input_desc) * k);
         const void* const in_k = kload<const void*>(K, in_base + sizeof(void*) * k);
-        load_elems<RC, 1>(in_k, in_dtype(D), in_broadcast(D) ? 0ull : e, false, M1.in[k], in_native(D),
+        unsigned long long at = e;
+        if (strided) {
+          const unsigned pitch = kload<unsigned>(K, pitch_base + sizeof(unsigned) * k);
+          if (pitch) at = row * pitch + col;
+        }
+        load_elems<RC, 1>(in_k, in_dtype(D), in_broadcast(D) ? 0ull : at, false, M1.in[k], in_native(D),
                           (long long)D.ndv.i64);
       }
     }

@@ -154,7 +154,7 @@ class FusedTask(object):
             stages, shape = hit
             outs = []
             for compiled, binding in stages:
-                tiles = [P.as_device(leaf_values[ref]["values"]) if kind == 0 else
+                tiles = [P.as_device_view(leaf_values[ref]["values"]) if kind == 0 else
                          (outs[ref] if kind == 2 else P.as_device(ref)) for kind, ref in binding]
                 outs.append(P.launch(compiled, tiles, shape))
             return {"values": outs[-1], "no_data_value": stages[-1][0].out_ndv}
@@ -265,7 +265,7 @@ class BatchedTask(object):
             stages, shape = hit
             outs = []  # per stage: one result per member tile
             for compiled, binding in stages:
-                tiles = [[P.as_device(per_tile[i][ref]["values"]) if kind == 0 else
+                tiles = [[P.as_device_view(per_tile[i][ref]["values"]) if kind == 0 else
                           (outs[ref][m] if kind == 2 else P.as_device(ref)) for kind, ref in binding]
                          for m, i in enumerate(members)]
                 outs.append(P.launch_batch(compiled, tiles, shape))

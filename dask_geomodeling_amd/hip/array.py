@@ -1,4 +1,5 @@
-"""DeviceArray: a C-contiguous tile living in MI355X HBM.
+"""DeviceArray: a tile living in MI355X HBM -- C-contiguous, or a zero-copy 2-D window
+(``pitch``) of a larger resident raster.
 
 It quacks enough like an ndarray (``shape``, ``dtype``, ``ndim``, ``size``,
 ``__array__``) for dict-of-arrays raster responses to flow between ``process``
@@ -15,14 +16,16 @@ from .dtypes import code_of
 
 
 class DeviceArray:
-    __slots__ = ("ptr", "shape", "dtype", "device", "_owner", "__weakref__")
+    __slots__ = ("ptr", "shape", "dtype", "device", "_owner", "pitch", "__weakref__")
 
-    def __init__(self, ptr, shape, dtype, device, owner=None):
+    def __init__(self, ptr, shape, dtype, device, owner=None, pitch=None):
         self.ptr = ptr
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
         self.device = device
         self._owner = owner  # keeps a parent allocation alive for views
+        # row pitch in elements of a (1, h, w) window into a wider raster; None = C-contiguous
+        self.pitch = None if pitch is None or int(pitch) == self.shape[-1] else int(pitch)
 
     # -- construction ---------------------------------------------------------
     @classmethod
@@ -58,7 +61,40 @@ class DeviceArray:
     def nbytes(self):
         return self.size * self.dtype.itemsize
 
+    @property
+    def is_contiguous(self):
+        return self.pitch is None
+
+    def window(self, row0, col0, height, width):
+        """Zero-copy view of rows [row0, row0+height) x columns [col0, col0+width) of a single-band
+        (1, H, W) tile: same allocation, row pitch = the parent's."""
+        if len(self.shape) != 3 or self.shape[0] != 1:
+            raise ValueError("window() needs a (1, H, W) tile, got %s" % (self.shape,))
+        _, H, W = self.shape
+        row0, col0, height, width = int(row0), int(col0), int(height), int(width)
+        if not (0 <= row0 and 0 <= col0 and row0 + height <= H and col0 + width <= W):
+            raise ValueError("window outside the tile")
+        pitch = self.pitch or W
+        ptr = self.ptr + (row0 * pitch + col0) * self.dtype.itemsize
+        return DeviceArray(ptr, (1, height, width), self.dtype, self.device, owner=self, pitch=pitch)
+
+    def contiguous(self):
+        """This tile if it is C-contiguous, else a compacted copy (one 2-D device copy)."""
+        if self.pitch is None:
+            return self
+        out = DeviceArray.empty(self.shape, self.dtype)
+        item = self.dtype.itemsize
+        _, h, w = self.shape
+        L = runtime.lib()
+        L.gm_copy_2d.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                 ctypes.c_size_t, ctypes.c_size_t]
+        runtime.check(L.gm_copy_2d(ctypes.c_void_p(out.ptr), w * item, ctypes.c_void_p(self.ptr), self.pitch * item,
+                                   w * item, h), "gm_copy_2d")
+        return out
+
     def to_numpy(self):
+        if self.pitch is not None:
+            return self.contiguous().to_numpy()
         out = np.empty(self.shape, dtype=self.dtype)
         if out.nbytes:
             runtime.check(runtime.lib().gm_d2h(out.ctypes.data_as(ctypes.c_void_p),
@@ -72,6 +108,8 @@ class DeviceArray:
     def band_slice(self, start, stop):
         """View of bands [start, stop) of a (bands, H, W) tile (no copy)."""
         start, stop = int(start), int(stop)
+        if self.pitch is not None:
+            raise ValueError("band_slice() of a strided window")
         plane = int(np.prod(self.shape[1:], dtype=np.int64)) * self.dtype.itemsize
         return DeviceArray(self.ptr + start * plane, (stop - start,) + self.shape[1:], self.dtype,
                            self.device, owner=self)
@@ -81,9 +119,13 @@ class DeviceArray:
             shape = tuple(shape[0])
         if int(np.prod(shape, dtype=np.int64)) != self.size:
             raise ValueError("cannot reshape %s into %s" % (self.shape, shape))
+        if self.pitch is not None:
+            return self.contiguous().reshape(shape)
         return DeviceArray(self.ptr, shape, self.dtype, self.device, owner=self)
 
     def checksum(self):
+        if self.pitch is not None:
+            return self.contiguous().checksum()
         out = ctypes.c_uint64()
         runtime.check(runtime.lib().gm_checksum(ctypes.c_void_p(self.ptr), self.nbytes,
                                                 ctypes.byref(out)), "gm_checksum")
@@ -101,7 +143,15 @@ class DeviceArray:
 
 
 def as_device(values):
-    """ndarray -> DeviceArray upload; DeviceArray passes through."""
+    """ndarray -> DeviceArray upload; a DeviceArray passes through, compacted if it is a strided
+    window (what every kernel except the element-wise program kernel needs)."""
+    if isinstance(values, DeviceArray):
+        return values.contiguous()
+    return DeviceArray.from_numpy(np.asarray(values))
+
+
+def as_device_view(values):
+    """Like as_device, but strided windows stay zero-copy (for pitch-aware consumers)."""
     if isinstance(values, DeviceArray):
         return values
     return DeviceArray.from_numpy(np.asarray(values))

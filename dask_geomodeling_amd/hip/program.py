@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 
 from . import runtime
-from .array import DeviceArray, as_device
+from .array import DeviceArray, as_device, as_device_view
 from .dtypes import code_of
 from .runtime import gm_scalar
 
@@ -663,6 +663,10 @@ def _lib():
         L.gm_elemwise_run_batch.argtypes = [ctypes.POINTER(gm_program), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                             ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
         L.gm_elemwise_run_batch.restype = ctypes.c_int
+        L.gm_elemwise_run_batch_2d.argtypes = [ctypes.POINTER(gm_program), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                               ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_void_p),
+                                               ctypes.c_size_t, ctypes.c_size_t]
+        L.gm_elemwise_run_batch_2d.restype = ctypes.c_int
         L.gm_vm_set_tuning.argtypes = [ctypes.POINTER(gm_vm_tuning)]
         L.gm_vm_get_tuning.argtypes = [ctypes.POINTER(gm_vm_tuning)]
         L.gm_sizeof.argtypes = [ctypes.c_int]
@@ -689,31 +693,31 @@ def get_tuning():
 
 def launch(compiled, inputs, shape, out=None):
     """Run a compiled program over device tiles ``inputs`` -> DeviceArray of ``shape``."""
-    L = _lib()
-    n = int(np.prod(shape, dtype=np.int64))
-    if out is None:
-        out = DeviceArray.empty(shape, compiled.out_dtype)
-    ptrs = (ctypes.c_void_p * max(len(inputs), 1))(*[x.ptr for x in inputs])
-    runtime.check(L.gm_elemwise_run(ctypes.byref(compiled.program), ptrs, ctypes.c_void_p(out.ptr), n),
-                  "gm_elemwise_run")
-    return out
+    return launch_batch(compiled, [inputs], shape, outs=None if out is None else [out])[0]
 
 
 def launch_batch(compiled, tiles, shape, outs=None):
     """Run one compiled program over several tiles at once: ``tiles`` is a list of per-tile input
-    lists (all tiles of ``shape``) -> list of DeviceArrays.  One launch per 16 tiles."""
+    lists (all tiles of ``shape``) -> list of DeviceArrays.  One launch per 16 tiles.  Inputs may be
+    zero-copy windows (DeviceArray.pitch) of larger resident rasters."""
     L = _lib()
     n = int(np.prod(shape, dtype=np.int64))
     n_in = len(tiles[0]) if tiles else 0
-    if outs is None:
-        outs = [DeviceArray.empty(shape, compiled.out_dtype) for _ in tiles]
-    flat = [x.ptr for inputs in tiles for x in inputs]
-    ptrs = (ctypes.c_void_p * max(len(flat), 1))(*flat)
-    out_ptrs = (ctypes.c_void_p * max(len(outs), 1))(*[o.ptr for o in outs])
     if any(len(inputs) != n_in for inputs in tiles):
         raise ValueError("every tile of a batch must bring the same number of inputs")
-    runtime.check(L.gm_elemwise_run_batch(ctypes.byref(compiled.program), len(tiles), ptrs, out_ptrs, n),
-                  "gm_elemwise_run_batch")
+    if outs is None:
+        outs = [DeviceArray.empty(shape, compiled.out_dtype) for _ in tiles]
+    flat = [x for inputs in tiles for x in inputs]
+    ptrs = (ctypes.c_void_p * max(len(flat), 1))(*[x.ptr for x in flat])
+    out_ptrs = (ctypes.c_void_p * max(len(outs), 1))(*[o.ptr for o in outs])
+    if any(x.pitch is not None for x in flat):
+        rows, cols = int(np.prod(shape[:-1], dtype=np.int64)), int(shape[-1])
+        pitches = (ctypes.c_uint32 * len(flat))(*[x.pitch or 0 for x in flat])
+        runtime.check(L.gm_elemwise_run_batch_2d(ctypes.byref(compiled.program), len(tiles), ptrs, pitches, out_ptrs,
+                                                 rows, cols), "gm_elemwise_run_batch_2d")
+    else:
+        runtime.check(L.gm_elemwise_run_batch(ctypes.byref(compiled.program), len(tiles), ptrs, out_ptrs, n),
+                      "gm_elemwise_run_batch")
     return outs
 
 
@@ -752,7 +756,7 @@ def plan(root):
         raise TypeError("at least one raster operand is required")
     for leaf in leaves:
         if not isinstance(leaf, StageRef):
-            leaf.values = as_device(leaf.values)
+            leaf.values = as_device_view(leaf.values)
     shapes = [_leaf_shape(leaf) for leaf in leaves]
     sizes = [int(np.prod(sh, dtype=np.int64)) for sh in shapes]
     shape, n = max(zip(shapes, sizes), key=lambda t: t[1])

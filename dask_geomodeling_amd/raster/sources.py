@@ -133,6 +133,11 @@ class RasterSourceBase(RasterBlock):
             # the request grid IS the source grid: the warp would be an identity copy, so the
             # resident tile itself is handed on (responses are immutable by contract)
             return {"values": source, "no_data_value": fill}
+        window = process_kwargs.get("window")
+        if window is not None and length == 1 and raster_data.all_finite():
+            # pixel-aligned window inside the source: a zero-copy view (row pitch = source width) that
+            # the element-wise program kernel reads in place; other consumers compact it on demand
+            return {"values": source.window(window[0], window[1], height, width), "no_data_value": fill}
         values = resample.nearest_warp(source, gt, bbox, height, width, fill)
         return {"values": values, "no_data_value": fill}
 
@@ -283,6 +288,29 @@ class MemorySource(RasterSourceBase):
         return (request["width"] == nx and request["height"] == ny and
                 x1 == west and y1 == south and x2 == east and y2 == north)
 
+    def _aligned_window(self, request):
+        """(row0, col0) when the request grid coincides with source pixels -- same CRS, one request
+        cell per source pixel, bbox on pixel edges, entirely inside the source -- else None.  Such
+        a request (every tile a RasterTiler cuts from a pixel-aligned view) needs no resampling:
+        the nearest-neighbour warp of sources.py:133-144 would copy the window unchanged."""
+        if not self.data.size or not utils.same_projection(request["projection"], self.projection):
+            return None
+        _, ny, nx = self.data.shape
+        p, a, _, q, _, d = self.geo_transform
+        x1, y1, x2, y2 = request["bbox"]
+        w, h = request["width"], request["height"]
+        if w <= 0 or h <= 0 or a <= 0 or d >= 0:
+            return None
+        if (x2 - x1) != w * a or (y2 - y1) != h * -d:
+            return None
+        col0, row0 = (x1 - p) / a, (y2 - q) / d
+        if col0 != int(col0) or row0 != int(row0):
+            return None
+        col0, row0 = int(col0), int(row0)
+        if col0 < 0 or row0 < 0 or col0 + w > nx or row0 + h > ny:
+            return None
+        return row0, col0
+
     def get_sources_and_requests(self, **request):
         mode = request["mode"]
         if mode == "meta" and self.metadata is None:
@@ -299,7 +327,8 @@ class MemorySource(RasterSourceBase):
             kwargs = {"mode": "vals", "raster_data": raster_data, "bbox": request["bbox"],
                       "width": request["width"], "height": request["height"],
                       "projection": request["projection"], "bands": bands, "dtype": self.dtype,
-                      "fillvalue": self.fillvalue, "whole": self._is_whole_grid(request)}
+                      "fillvalue": self.fillvalue, "whole": self._is_whole_grid(request),
+                      "window": self._aligned_window(request)}
         elif mode == "meta":
             kwargs = {"mode": "meta", "raster_data": raster_data, "bands": bands}
         elif mode == "time":

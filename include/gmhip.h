@@ -240,6 +240,16 @@ int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out
  * identical sub-graph per tile -- reach the GPU: kernel boundaries between tiles disappear. */
 int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const* inputs, void* const* outs, size_t n);
 
+/* The same with inputs that are zero-copy WINDOWS of larger rasters resident in HBM -- what a tile
+ * request into a MemorySource hands on (raster/sources.py:119-149 does a warp + copy there): every
+ * tile is rows x cols elements; pitches[t * prog->n_inputs + k] is the row pitch, in elements, of
+ * input k of tile t (0 or cols: contiguous).  Outputs are contiguous.  16-byte vector loads need
+ * cols % 4 == 0 and 16-byte aligned rows; other windows take the scalar path (correct, slower). */
+int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* const* inputs, const uint32_t* pitches,
+                             void* const* outs, size_t rows, size_t cols);
+/* Device-to-device copy of a 2-D window into another pitch (compaction of a window), asynchronous. */
+int gm_copy_2d(void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes, size_t width_bytes, size_t rows);
+
 /* Tuning knobs of the VM launch (for measurements; the defaults are the measured optimum). */
 typedef struct gm_vm_tuning {
   int32_t vec;          /* elements per lane: 0 = auto (4; 8 for programs of more than 3 micro-ops), 4, 8 */

@@ -50,6 +50,7 @@ def cpu_vm(monkeypatch):
 
     monkeypatch.setattr(runtime, "require_device", lambda: None)
     monkeypatch.setattr(program, "as_device", lambda v: np.asarray(v))
+    monkeypatch.setattr(program, "as_device_view", lambda v: np.asarray(v))
     monkeypatch.setattr(program, "launch", vm_numpy.launch)
     monkeypatch.setattr(program, "launch_batch",
                         lambda compiled, tiles, shape, outs=None: [vm_numpy.launch(compiled, t, shape) for t in tiles])
