@@ -298,17 +298,17 @@ int gm_vm_get_tuning(gm_vm_tuning* t) {
 }
 
 int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* const* inputs, const uint32_t* pitches,
-                             void* const* outs, size_t rows, size_t cols);
+                             void* const* outs, const uint32_t* out_pitches, size_t rows, size_t cols);
 
 int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const* inputs, void* const* outs, size_t n) {
-  return gm_elemwise_run_batch_2d(prog, n_tiles, inputs, nullptr, outs, 1, n);
+  return gm_elemwise_run_batch_2d(prog, n_tiles, inputs, nullptr, outs, nullptr, 1, n);
 }
 
 int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* const* inputs, const uint32_t* pitches,
-                             void* const* outs, size_t rows, size_t cols) {
+                             void* const* outs, const uint32_t* out_pitches, size_t rows, size_t cols) {
   const size_t n = rows * cols;
   if (!prog || !outs || (!inputs && prog->n_inputs)) return gm::fail(GM_ERR_INVALID, "null argument");
-  if (pitches && cols > 0xffffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "strided tiles wider than 2^32 elements");
+  if ((pitches || out_pitches) && cols > 0xffffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "strided tiles wider than 2^32 elements");
   if (n_tiles < 0) return gm::fail(GM_ERR_INVALID, "n_tiles %d", n_tiles);
   hipStream_t stream = gm::current_stream();
   if (!stream) return GM_ERR_NO_DEVICE;
@@ -349,6 +349,13 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
     for (int t = 0; t < nb; ++t) {
       args.out[t] = outs[t0 + t];
       if (((uintptr_t)args.out[t] % 16) != 0) aligned = false;
+      const uint32_t opitch = out_pitches ? out_pitches[t0 + t] : 0u;
+      if (opitch && opitch != cols) {
+        if (opitch < cols) return gm::fail(GM_ERR_INVALID, "output pitch %u is smaller than the tile width %zu", opitch, cols);
+        args.out_pitch[t] = opitch;
+        strided = true;
+        if (((size_t)opitch * (size_t)gm::dtype_size(code->prog.out_dtype)) % 16 != 0) aligned = false;
+      }
       for (unsigned k = 0; k < n_in; ++k) {
         const void* p = inputs[(size_t)(t0 + t) * n_in + k];
         args.in[t][k] = p;

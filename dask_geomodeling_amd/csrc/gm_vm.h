@@ -88,6 +88,7 @@ struct VmLaunch {
   unsigned int spans;             //   spans of 256*G groups a workgroup walks (amortises the staging)
   unsigned int cols;              // strided inputs (windows of a larger resident raster): tile width in elements
   unsigned int pitch[GM_MAX_BATCH][GM_MAX_INPUTS];  // row pitch in elements, 0 = contiguous
+  unsigned int out_pitch[GM_MAX_BATCH];             // the same for the result (a window of a mosaic)
   const void* in[GM_MAX_BATCH][GM_MAX_INPUTS];
   void* out[GM_MAX_BATCH];
 };
@@ -936,24 +937,27 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
   }
   // phase 2: interpret
   M.run(C, GM_KARG(K, n_uops));
-  // phase 3: store
+  // phase 3: store (the result may itself be a window: a tile written straight into its mosaic)
+  unsigned out_pitch = 0;
+  if (strided) out_pitch = kload<unsigned>(K, offsetof(VmLaunch, out_pitch) + sizeof(unsigned) * tile);
 #pragma unroll
   for (int u = 0; u < G; ++u) {
     const unsigned long long g = g0 + 256ull * u;
     if (g < n_groups) {
+      const unsigned long long at = out_pitch ? (unsigned long long)row_of[u] * out_pitch + col_of[u] : g * 4ull;
       if (native) {
         if constexpr (sizeof(RC) == 4) {
           typedef typename native_vec<RC>::type V4;
           V4 x;
 #pragma unroll
           for (int q = 0; q < 4; ++q) x[q] = M.acc[4 * u + q];
-          st((V4*)out + g, x, nt_st);
+          st((V4*)((RC*)out + at), x, nt_st);
         }
       } else {
         RC v4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v4[q] = M.acc[4 * u + q];
-        store_elems<RC, 4>(out, (int)GM_KARG(K, out_dtype), g * 4ull, nt_st, v4);
+        store_elems<RC, 4>(out, (int)GM_KARG(K, out_dtype), at, nt_st, v4);
       }
     }
   }
@@ -1000,7 +1004,12 @@ __global__ __launch_bounds__(256) void vm_tail_kernel(const VmLaunch) {
       }
     }
     M1.run(C, n_uops);
-    store_elems<RC, 1>(out, out_dtype, e, false, M1.acc);
+    unsigned long long out_at = e;
+    if (strided) {
+      const unsigned out_pitch = kload<unsigned>(K, offsetof(VmLaunch, out_pitch) + sizeof(unsigned) * tile);
+      if (out_pitch) out_at = row * out_pitch + col;
+    }
+    store_elems<RC, 1>(out, out_dtype, out_at, false, M1.acc);
   }
 }
 

@@ -27,7 +27,7 @@ from .hip import program as P
 from .hip.array import DeviceArray
 from .raster import devops, tables
 
-__all__ = ["fuse_graph", "materialize", "FusedTask", "BatchedTask"]
+__all__ = ["fuse_graph", "materialize", "FusedTask", "BatchedTask", "TiledAssembly"]
 
 MAX_BATCH_TILES = 64  # tiles per BatchedTask: bounds how many tile results are alive at once
 
@@ -248,6 +248,11 @@ class BatchedTask(object):
         return "<BatchedTask %d tiles of %r>" % (len(self.tasks), self.tasks[0])
 
     def __call__(self, *all_leaf_values):
+        return self.run(all_leaf_values)
+
+    def run(self, all_leaf_values, dest=None):
+        """``dest(i, shape, dtype)`` may hand out the DeviceArray (e.g. a window of a mosaic) that the
+        result of tile i is to be written into; None -> a fresh tile."""
         k = self.n_leaves
         per_tile = [all_leaf_values[i * k:(i + 1) * k] for i in range(len(self.tasks))]
         # every tile is planned by the first group (same structure => same plan for the same kind of
@@ -264,11 +269,15 @@ class BatchedTask(object):
         for hit, members in groups.values():
             stages, shape = hit
             outs = []  # per stage: one result per member tile
-            for compiled, binding in stages:
+            for stage_no, (compiled, binding) in enumerate(stages):
                 tiles = [[P.as_device_view(per_tile[i][ref]["values"]) if kind == 0 else
                           (outs[ref][m] if kind == 2 else P.as_device(ref)) for kind, ref in binding]
                          for m, i in enumerate(members)]
-                outs.append(P.launch_batch(compiled, tiles, shape))
+                targets = None
+                if dest is not None and stage_no == len(stages) - 1:
+                    targets = [dest(i, shape, compiled.out_dtype) for i in members]
+                    targets = [t if t is not None else DeviceArray.empty(shape, compiled.out_dtype) for t in targets]
+                outs.append(P.launch_batch(compiled, tiles, shape, outs=targets))
             ndv = stages[-1][0].out_ndv
             for i, out in zip(members, outs[-1]):
                 results[i] = {"values": out, "no_data_value": ndv}
@@ -277,6 +286,57 @@ class BatchedTask(object):
 
 def _getitem(seq, index):
     return seq[index]
+
+
+class TiledAssembly(object):
+    """RasterTiler.process (raster/parallelize.py:93-125) fused with the batches that compute its
+    tiles: the mosaic is allocated first and every batched tile program writes its result straight
+    into its window of the mosaic (row pitch = mosaic width, y axis flipped as the reference
+    pastes), so the fill + paste passes over the result disappear.  Tiles that cannot be written in
+    place (several bands, another dtype, ``None`` responses) fall back to the reference's paste."""
+
+    def __init__(self, tiler_process, layout, batches):
+        self.tiler_process = tiler_process
+        self.layout = layout      # per tile position: (batch index, member index)
+        self.batches = batches    # BatchedTasks in call-argument order
+        self.__name__ = "tiled_%d" % len(layout)
+
+    def __call__(self, process_kwargs, *all_leaf_values):
+        height, width = process_kwargs["shape_yx"]
+        count_x, count_y = process_kwargs["count_xy"]
+        tile_x, tile_y = process_kwargs["tilesize_xy"]
+        dtype, fill = np.dtype(process_kwargs["dtype"]), process_kwargs["fillvalue"]
+        position = {bm: t for t, bm in enumerate(self.layout)}
+        state = {"mosaic": None}
+
+        def dest_for(b):
+            def dest(member, shape, out_dtype):
+                if len(shape) != 3 or shape[0] != 1 or np.dtype(out_dtype) != dtype:
+                    return None
+                if state["mosaic"] is None:
+                    state["mosaic"] = DeviceArray.empty((1, height, width), dtype)
+                ix, iy = divmod(position[(b, member)], count_y)
+                th, tw = shape[1], shape[2]
+                row0, col0 = height - (iy * tile_y + th), ix * tile_x  # low y -> high rows (parallelize.py:114-124)
+                if row0 < 0 or col0 + tw > width:
+                    return None
+                return state["mosaic"].window(row0, col0, th, tw)
+            return dest
+
+        results, offset = {}, 0
+        for b, batch in enumerate(self.batches):
+            n = batch.n_leaves * len(batch.tasks)
+            for member, res in enumerate(batch.run(all_leaf_values[offset:offset + n], dest_for(b))):
+                results[(b, member)] = res
+            offset += n
+        tiles = [results[bm] for bm in self.layout]
+        mosaic = state["mosaic"]
+        in_place = mosaic is not None and all(
+            isinstance(t, dict) and isinstance(t.get("values"), DeviceArray) and t["values"]._owner is mosaic
+            for t in tiles)
+        if in_place and len(tiles) == count_x * count_y:
+            return {"values": mosaic, "no_data_value": fill}
+        return self.tiler_process(process_kwargs, *tiles)  # the reference's fill + paste
 
 
 def fuse_graph(graph, name):
@@ -364,6 +424,29 @@ def fuse_graph(graph, name):
             new_graph[root] = graph[root]  # nothing to fuse
         else:
             new_graph[root] = (task,) + tuple(task.leaf_keys)
+
+    # a RasterTiler whose tiles all come out of batches (and feed nothing else) assembles in place
+    for key, task in list(new_graph.items()):
+        if not (_is_task(task) and getattr(task[0], "gm_tiler", False) and len(task) > 2 and isinstance(task[1], dict)):
+            continue
+        tile_keys = task[2:]
+        try:
+            ok = all(k in batched and consumers.get(k) == {key} for k in tile_keys)
+        except TypeError:
+            ok = False
+        if not ok or len(set(tile_keys)) != len(tile_keys):
+            continue
+        batch_keys, layout = [], []
+        for k in tile_keys:
+            _, bkey, member = new_graph[k]
+            if bkey not in batch_keys:
+                batch_keys.append(bkey)
+            layout.append((batch_keys.index(bkey), member))
+        batches = [new_graph[b][0] for b in batch_keys]
+        if sum(len(b.tasks) for b in batches) != len(layout):
+            continue  # a batch also serves tiles of another consumer
+        leaf_args = tuple(a for b in batch_keys for a in new_graph[b][1:])
+        new_graph[key] = (TiledAssembly(task[0], layout, batches), task[1]) + leaf_args
     return new_graph
 
 

@@ -665,7 +665,7 @@ def _lib():
         L.gm_elemwise_run_batch.restype = ctypes.c_int
         L.gm_elemwise_run_batch_2d.argtypes = [ctypes.POINTER(gm_program), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                                ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_void_p),
-                                               ctypes.c_size_t, ctypes.c_size_t]
+                                               ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t, ctypes.c_size_t]
         L.gm_elemwise_run_batch_2d.restype = ctypes.c_int
         L.gm_vm_set_tuning.argtypes = [ctypes.POINTER(gm_vm_tuning)]
         L.gm_vm_get_tuning.argtypes = [ctypes.POINTER(gm_vm_tuning)]
@@ -699,7 +699,8 @@ def launch(compiled, inputs, shape, out=None):
 def launch_batch(compiled, tiles, shape, outs=None):
     """Run one compiled program over several tiles at once: ``tiles`` is a list of per-tile input
     lists (all tiles of ``shape``) -> list of DeviceArrays.  One launch per 16 tiles.  Inputs may be
-    zero-copy windows (DeviceArray.pitch) of larger resident rasters."""
+    zero-copy windows (DeviceArray.pitch) of larger resident rasters, and so may the ``outs``
+    (tiles written straight into their mosaic)."""
     L = _lib()
     n = int(np.prod(shape, dtype=np.int64))
     n_in = len(tiles[0]) if tiles else 0
@@ -710,11 +711,12 @@ def launch_batch(compiled, tiles, shape, outs=None):
     flat = [x for inputs in tiles for x in inputs]
     ptrs = (ctypes.c_void_p * max(len(flat), 1))(*[x.ptr for x in flat])
     out_ptrs = (ctypes.c_void_p * max(len(outs), 1))(*[o.ptr for o in outs])
-    if any(x.pitch is not None for x in flat):
+    if any(x.pitch is not None for x in flat) or any(o.pitch is not None for o in outs):
         rows, cols = int(np.prod(shape[:-1], dtype=np.int64)), int(shape[-1])
-        pitches = (ctypes.c_uint32 * len(flat))(*[x.pitch or 0 for x in flat])
+        pitches = (ctypes.c_uint32 * max(len(flat), 1))(*[x.pitch or 0 for x in flat])
+        out_pitches = (ctypes.c_uint32 * max(len(outs), 1))(*[o.pitch or 0 for o in outs])
         runtime.check(L.gm_elemwise_run_batch_2d(ctypes.byref(compiled.program), len(tiles), ptrs, pitches, out_ptrs,
-                                                 rows, cols), "gm_elemwise_run_batch_2d")
+                                                 out_pitches, rows, cols), "gm_elemwise_run_batch_2d")
     else:
         runtime.check(L.gm_elemwise_run_batch(ctypes.byref(compiled.program), len(tiles), ptrs, out_ptrs, n),
                       "gm_elemwise_run_batch")

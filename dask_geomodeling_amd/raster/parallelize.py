@@ -95,3 +95,5 @@ class RasterTiler(BaseSingle):
             runtime.check(L.gm_paste_tile(ctypes.c_void_p(mosaic.ptr), height, width, ctypes.c_void_p(tile.ptr),
                                           bands, th, tw, row0, col0, dtype.itemsize), "gm_paste_tile")
         return {"values": mosaic, "no_data_value": fill}
+
+    process.__func__.gm_tiler = True  # lets the fusion pass write batched tiles straight into the mosaic

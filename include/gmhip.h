@@ -243,10 +243,12 @@ int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const
 /* The same with inputs that are zero-copy WINDOWS of larger rasters resident in HBM -- what a tile
  * request into a MemorySource hands on (raster/sources.py:119-149 does a warp + copy there): every
  * tile is rows x cols elements; pitches[t * prog->n_inputs + k] is the row pitch, in elements, of
- * input k of tile t (0 or cols: contiguous).  Outputs are contiguous.  16-byte vector loads need
- * cols % 4 == 0 and 16-byte aligned rows; other windows take the scalar path (correct, slower). */
+ * input k of tile t (0 or cols: contiguous); out_pitches[t] likewise for the result of tile t, so that
+ * a tile can be written straight into its place in a mosaic (raster/parallelize.py:118-124 pastes
+ * there).  Either array may be NULL.  16-byte vector access needs cols % 4 == 0 and 16-byte aligned
+ * rows; other windows take the scalar path (correct, slower). */
 int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* const* inputs, const uint32_t* pitches,
-                             void* const* outs, size_t rows, size_t cols);
+                             void* const* outs, const uint32_t* out_pitches, size_t rows, size_t cols);
 /* Device-to-device copy of a 2-D window into another pitch (compaction of a window), asynchronous. */
 int gm_copy_2d(void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes, size_t width_bytes, size_t rows);
 

@@ -465,6 +465,14 @@ def test_tiler_over_memory_source_is_zero_copy_and_exact(gpu):
     for tile in (32, [64, 48], 40):  # 40: leftover edge tiles of another shape
         tiled = raster.RasterTiler(view, tile).get_data(**req)
         assert_result_equal(tiled, whole, 0, "tile size %s" % (tile,))
+    from dask_geomodeling_amd.fuse import fuse_graph, TiledAssembly
+    graph, name = raster.RasterTiler(view, 32).get_compute_graph(**req)
+    fused = fuse_graph(graph, name)
+    assert isinstance(fused[name][0], TiledAssembly)  # tiles are written straight into the mosaic
+    # a second consumer of one tile keeps the reference's paste path (and the same numbers)
+    tiler = raster.RasterTiler(view, 32)
+    both = raster.Add(tiler, tiler)
+    assert_result_equal(both.get_data(**req), (view + view).get_data(**req), 0, "tiler consumed twice")
     sub = dict(req, bbox=(32.0, 16.0, 96.0, 80.0), width=64, height=64)
     got = A.get_data(**sub)
     assert_values_equal(got["values"], a[:, 16:80, 32:96], 0, "aligned sub-window of a MemorySource")

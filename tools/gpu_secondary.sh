@@ -5,7 +5,7 @@ REPO=$PWD
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
-for w in reclass bilinear mosaic; do
+for w in reclass bilinear mosaic tiler; do
   rm -rf "$OUT/prof_$w"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$w" -- python3 "$REPO/bench.py" --workload $w --steps 3 --warmup 1 > "$OUT/bench_$w.log" 2> "$OUT/bench_$w.err"
   grep '^{' "$OUT/bench_$w.log" | cut -c1-330
@@ -14,7 +14,7 @@ done
 cd "$REPO"
 python - <<'PY'
 import csv, glob, os
-for w in ["reclass", "bilinear", "mosaic"]:
+for w in ["reclass", "bilinear", "mosaic", "tiler"]:
     fs = sorted(glob.glob("gpurun_out/prof_%s/**/*kernel_stats.csv" % w, recursive=True), key=os.path.getmtime)
     if not fs:
         continue
