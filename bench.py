@@ -55,6 +55,8 @@ def parse_args():
     p.add_argument("--tiles", type=int, default=0, help="tiles per GPU per step (0 = the workload's default)")
     p.add_argument("--cpu-tiles", type=int, default=-1, help="tiles of the CPU baseline sample (0 = skip)")
     p.add_argument("--no-check", action="store_true", help="skip the oracle check of one tile")
+    p.add_argument("--procedural", action="store_true",
+                   help="mosaic: generate every leaf window on the fly instead of keeping the 4 x 16 GiB leaves resident")
     p.add_argument("--dry-run", action="store_true",
                    help="exercise the multi-rank timing harness without a GPU (every tile is a 0.2 ms sleep); "
                         "used by the CPU gloo test, never a measurement")
@@ -141,10 +143,18 @@ def build_tiler(raster, side, tile, rank):
 MOSAIC_SIDE = 65536
 
 
-def mosaic_view(raster):
+def mosaic_view(raster, resident=True):
     """configs[4]: 10 Blocks (Add, Multiply, Subtract, Divide, Greater, Clip, Classify, Reclassify, Mask
-    under a RasterTiler) over four procedural leaves of a 65536^2 mosaic."""
+    under a RasterTiler) over four float32 leaves of a 65536^2 mosaic.  resident: the leaves are
+    MemorySources holding the whole mosaic in HBM (4 x 16 GiB per GPU; tile requests are zero-copy
+    windows); otherwise SyntheticSources that generate every requested window on the fly."""
+    from dask_geomodeling_amd.raster.sources import generate_window
+
     def leaf(seed):
+        if resident:
+            data = generate_window((MOSAIC_SIDE, MOSAIC_SIDE), "f4", seed, 0.0, 100.0, F32MAX, LATTICE, 0, 0,
+                                   MOSAIC_SIDE, MOSAIC_SIDE)
+            return raster.MemorySource(data, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(MOSAIC_SIDE)))
         return raster.SyntheticSource((MOSAIC_SIDE, MOSAIC_SIDE), "f4", seed, 0.0, 100.0, F32MAX, LATTICE,
                                       "EPSG:28992", 1.0, (0.0, float(MOSAIC_SIDE)))
     A, B, C, D = leaf(11), leaf(12), leaf(13), leaf(14)
@@ -155,12 +165,12 @@ def mosaic_view(raster):
     return raster.Mask(x, 1)
 
 
-def build_mosaic(raster, tile, rank, world):
+def build_mosaic(raster, tile, rank, world, resident=True):
     """The tile sub-graphs of RasterTiler(view, tile) over the whole mosaic that this rank owns."""
     from dask_geomodeling_amd import shard
     from dask_geomodeling_amd.fuse import fuse_graph
 
-    tiler = raster.RasterTiler(mosaic_view(raster), tile)
+    tiler = raster.RasterTiler(mosaic_view(raster, resident), tile)
     request = dict(mode="vals", bbox=(0.0, 0.0, float(MOSAIC_SIDE), float(MOSAIC_SIDE)), width=MOSAIC_SIDE,
                    height=MOSAIC_SIDE, projection="EPSG:28992")
     graph, name = tiler.get_compute_graph(**request)
@@ -289,7 +299,7 @@ def main():
         elif args.workload == "tiler":
             jobs = build_tiler(raster, side, 4096, rank)
         else:
-            jobs, n_mosaic_tiles = build_mosaic(raster, side, rank, world)
+            jobs, n_mosaic_tiles = build_mosaic(raster, side, rank, world, resident=not args.procedural)
             tiles = len(jobs[0][1])
         runtime.sync()
 
