@@ -397,7 +397,7 @@ def main():
                        "parallelism": "tiles sharded 1 rank per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src, "kernel": "gmvm::vm_kernel<float, 2, 2, 1, false>",
+                         "traffic_source": traffic_src, "kernel": "gmvm::vm_kernel<float, 2, 2, 1, 0>",
                          "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": round(kernel_ms * 1e3, 2)},
             "pct_of_hbm_roofline": round(100.0 * value * 1e6 * BYTES_PER_PX / world / (HBM_PEAK_GBS * 1e9), 2),
         }
