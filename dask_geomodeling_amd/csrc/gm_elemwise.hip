@@ -143,6 +143,7 @@ int validate(const gm_program* prog) {
   if (gm::dtype_size(prog->out_dtype) == 0) return gm::fail(GM_ERR_INVALID, "out_dtype %u", prog->out_dtype);
   for (unsigned k = 0; k < prog->n_inputs; ++k)
     if (gm::dtype_size(prog->inputs[k].bits & 0xffu) == 0) return gm::fail(GM_ERR_INVALID, "input %u dtype %u", k, prog->inputs[k].bits & 0xffu);
+  long long lookup_table = -1;
   for (unsigned s = 0; s < prog->n_steps; ++s) {
     const gm_step& S = prog->steps[s];
     const unsigned opcode = S.bits & 0xffu, save_temp = (S.bits >> 8) & 0xffu;
@@ -163,8 +164,13 @@ int validate(const gm_program* prog) {
         if (words < S.aux1.u64) return gm::fail(GM_ERR_INVALID, "step %u: table shorter than its edges", s);
         if (prog->reg_class <= GM_CLASS_F64 && (((S.bits >> 16) & 2u) != 0)) return gm::fail(GM_ERR_INVALID, "step %u: int64 edges in a float class", s);
       } else {
-        if (prog->reg_class != GM_CLASS_I64 && prog->reg_class != GM_CLASS_F64) return gm::fail(GM_ERR_INVALID, "step %u: LOOKUP needs class I64 or F64", s);
-        if (S.aux2.u64 == 0 || words < S.aux2.u64 + 2 * S.aux3.u64) return gm::fail(GM_ERR_INVALID, "step %u: table shorter than its window + exceptions", s);
+        const unsigned long long esize = (prog->reg_class == GM_CLASS_I64 || prog->reg_class == GM_CLASS_F64) ? 8 : 4;
+        if (S.aux2.u64 == 0 || words < (S.aux2.u64 * esize + 7) / 8 + 2 * S.aux3.u64)
+          return gm::fail(GM_ERR_INVALID, "step %u: table shorter than its window + exceptions", s);
+        if (S.aux2.u64 * esize > 65536) return gm::fail(GM_ERR_UNSUPPORTED, "step %u: LOOKUP window larger than 64 KiB of LDS", s);
+        if (lookup_table >= 0 && lookup_table != (long long)t)
+          return gm::fail(GM_ERR_UNSUPPORTED, "step %u: a program stages one LOOKUP table in LDS (split it)", s);
+        lookup_table = (long long)t;
       }
     }
   }
@@ -235,9 +241,10 @@ int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) 
   e->flavor = has_math ? VM_MATH : (has_tables ? VM_TABLES : VM_LIGHT);
   for (unsigned s = 0; s < key.n_steps && !e->lds_table; ++s) {
     const gm_step& S = key.steps[s];
-    if ((S.bits & 0xffu) == GM_OP_LOOKUP && S.aux2.u64 <= 8192) {  // window fits 64 KiB of LDS
+    const unsigned long long esize = (key.reg_class == GM_CLASS_I64 || key.reg_class == GM_CLASS_F64) ? 8 : 4;
+    if ((S.bits & 0xffu) == GM_OP_LOOKUP) {  // (validate() checked that it fits 64 KiB of LDS)
       e->lds_table = (unsigned)S.aux0.u64 + 1;
-      e->lds_words = (unsigned)S.aux2.u64;
+      e->lds_words = (unsigned)((S.aux2.u64 * esize + 7) / 8);
     }
   }
   // device image of the tables: the words as given, except the edges of a DIGITIZE in the F32 class,
@@ -333,6 +340,9 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
   // (the 64-bit classes pay 8 elements per lane with their occupancy: 132 VGPRs instead of 70)
   int G = g_tuning.vec == 8 ? 2 : (g_tuning.vec == 4 ? 1 : ((code->n_uops > 3 || (bytes_per_elem < 8 && !wide_class)) ? 2 : 1));
   if (code->flavor == VM_MATH || code->size == 2) G = 1;
+  // table ops cost the integer and 64-bit classes too many registers at 8 elements per lane
+  // (102-136 VGPRs); the float32 class stays at 84
+  if (code->flavor == VM_TABLES && code->prog.reg_class != GM_CLASS_F32 && g_tuning.vec == 0) G = 1;
   const int max_batch = g_tuning.max_batch > 0 ? g_tuning.max_batch : GM_MAX_BATCH;
   const int cus = gm::current_cu_count();
 

@@ -557,6 +557,7 @@ struct Machine {
         }
       } break;
       case GM_OP_DIGITIZE:
+#ifndef GM_EXP_NO_DIGITIZE
         if constexpr (TABLES) {
           // misc.py:387-399.  Edge-major linear count: every edge is one scalar load (wave-uniform),
           // v_cmp + v_addc per element; <= GM_MAX_LINEAR_EDGES edges.  Comparisons in the type NumPy's
@@ -599,55 +600,60 @@ struct Machine {
             acc[k] = (a_has & (acc[k] == a_ndv)) ? fill : (RC)c;
           }
         }
+#endif
         break;
       case GM_OP_LOOKUP:
-        if constexpr (TABLES && sizeof(RC) == 8) {
-          // misc.py:505-514.  Dense window of pre-resolved targets gathered from device memory (the
-          // table is a few KiB and stays in the vector L1); keys outside the window -- typically only
-          // the merged-in no-data key -- are matched against scalar registers.
-          const long long kmin = (long long)S.aux1.i64;
-          const unsigned long long range = S.aux2.u64;
+#ifndef GM_EXP_NO_LOOKUP
+        if constexpr (TABLES) {
+          // misc.py:505-514.  Dense window of pre-resolved targets (entries in the register class'
+          // own width) + keys outside the window -- typically only the merged-in no-data key --
+          // matched against scalar registers.  The accumulator holds an exact integer in every class.
+          // Key arithmetic in the class' own width: in the 4-byte classes every key the accumulator
+          // can hold fits int32 (the host drops table keys outside that range: they cannot match).
+          typedef typename std::conditional<sizeof(RC) == 8, unsigned long long, unsigned int>::type W;
+          typedef typename std::conditional<sizeof(RC) == 8, long long, int>::type KT;
+          const KT kmin = (KT)(long long)S.aux1.i64;
+          const W range = (W)S.aux2.u64;
           const unsigned n_exc = (unsigned)S.aux3.u64;
           const bool select = (step_flags(S) & 1u) != 0;
           const unsigned long long addr = kload<unsigned long long>(C, offsetof(VmCode, tables) + 8 * (unsigned)S.aux0.u64);
-          const RC* const lut = (const RC*)(uintptr_t)addr;
-          const kargs_t exc = (kargs_t)(uintptr_t)(addr + 8ull * range);
+          const kargs_t exc = (kargs_t)(uintptr_t)(addr + (((unsigned long long)range * sizeof(RC) + 7ull) & ~7ull));
           const RC fill = scalar_of<RC>(S.fill);
-          long long key[N];
+          // (window index, looked-up target) are the only per-element state besides the accumulator;
+          // an exception key k matches where the index equals k - kmin (wrapping arithmetic)
+          W idx[N];
           RC hit[N];
-          if ((int)S.aux0.u64 == lds_table) {
-            // the window was staged in LDS behind the tile loads: ds_read_b64 per element (a gather
-            // from the vector L1 costs the whole CU ~64 cycles per wave-instruction instead)
+#pragma unroll
+          for (int k = 0; k < N; ++k) idx[k] = (W)(KT)acc[k] - (W)kmin;
+          {
+            // the window was staged in LDS behind the tile loads (the host stages the table of the
+            // program's LOOKUP; one per program): one ds_read per element.  A gather from device
+            // memory instead costs the whole CU ~64 cycles per wave-instruction and 2 VGPRs of
+            // address per element.
             extern __shared__ __align__(16) unsigned long long vm_lds[];
+            const W* const lds = (const W*)vm_lds;
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-              key[k] = (long long)acc[k];
-              const unsigned long long idx = (unsigned long long)(key[k] - kmin);
-              const unsigned long long w = vm_lds[idx < range ? idx : 0ull];
+              const W w = lds[idx[k] < range ? idx[k] : (W)0];
               RC h;
-              __builtin_memcpy(&h, &w, 8);
+              __builtin_memcpy(&h, &w, sizeof(RC));
               hit[k] = h;
             }
-          } else {
+          }
+          if (select) {
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-              key[k] = (long long)acc[k];
-              const unsigned long long idx = (unsigned long long)(key[k] - kmin);
-              hit[k] = lut[idx < range ? idx : 0ull];
-            }
+            for (int k = 0; k < N; ++k) acc[k] = fill;  // a miss: fill; else the value passes through
+          }
+          for (unsigned x = 0; x < n_exc; ++x) {  // exception-major: each pair is fetched once
+            const W ei = (W)(KT)kload<long long>(exc, 16 * x) - (W)kmin;
+            const RC ev = kload<RC>(exc, 16 * x + 8);
+#pragma unroll
+            for (int k = 0; k < N; ++k) acc[k] = (idx[k] == ei) ? ev : acc[k];
           }
 #pragma unroll
-          for (int k = 0; k < N; ++k) {
-            const unsigned long long idx = (unsigned long long)(key[k] - kmin);
-            RC miss = select ? fill : acc[k];
-            for (unsigned x = 0; x < n_exc; ++x) {
-              const long long ek = kload<long long>(exc, 16 * x);
-              const RC ev = kload<RC>(exc, 16 * x + 8);
-              miss = (key[k] == ek) ? ev : miss;
-            }
-            acc[k] = idx < range ? hit[k] : miss;
-          }
+          for (int k = 0; k < N; ++k) acc[k] = idx[k] < range ? hit[k] : acc[k];
         }
+#endif
         break;
       case GM_OP_COPY:
       default:
@@ -979,6 +985,17 @@ __global__ __launch_bounds__(256) void vm_tail_kernel(const VmLaunch) {
   void* const out = kload<void*>(K, offsetof(VmLaunch, out) + sizeof(void*) * tile);
   const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
+  if constexpr (FLAVOR == VM_TABLES) {
+    const unsigned lds_table = GM_KARG(K, lds_table);
+    if (lds_table) {  // the LOOKUP window lives in LDS here as well
+      extern __shared__ __align__(16) unsigned long long vm_lds[];
+      const unsigned words = GM_KARG(K, lds_words);
+      const unsigned long long* const src =
+          (const unsigned long long*)(uintptr_t)kload<unsigned long long>(C, offsetof(VmCode, tables) + 8 * (lds_table - 1));
+      for (unsigned i = threadIdx.x; i < words; i += 256) vm_lds[i] = src[i];
+      __syncthreads();
+    }
+  }
   const bool strided = (GM_KARG(K, flags) & VM_FLAG_STRIDED) != 0;
   const unsigned long long cols = GM_KARG(K, cols);
   const size_t pitch_base = offsetof(VmLaunch, pitch) + sizeof(unsigned) * GM_MAX_INPUTS * tile;
@@ -1025,7 +1042,8 @@ int launch_class(const VmLaunch& args, int size, int G, int flavor, dim3 grid, d
       hipLaunchKernelGGL((vm_kernel<RC, G_, NIN_, NT_, FLAVOR_>), grid, dim3(256),                       \
                          (FLAVOR_ == VM_TABLES && args.lds_table) ? (size_t)args.lds_words * 8 : 0, stream, args); \
     if (tail_grid.x)                                                                                     \
-      hipLaunchKernelGGL((vm_tail_kernel<RC, NIN_, NT_, FLAVOR_>), tail_grid, dim3(256), 0, stream, args); \
+      hipLaunchKernelGGL((vm_tail_kernel<RC, NIN_, NT_, FLAVOR_>), tail_grid, dim3(256),                 \
+                         (FLAVOR_ == VM_TABLES && args.lds_table) ? (size_t)args.lds_words * 8 : 0, stream, args); \
   } while (0)
 
 #define GM_VM_LAUNCH_SIZES(RC, FLAVOR_, G_S, G_M)                     \

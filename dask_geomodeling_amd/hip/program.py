@@ -18,7 +18,7 @@ from .runtime import gm_scalar
 
 GM_MAX_INPUTS, GM_MAX_STEPS, GM_MAX_TEMPS = 8, 24, 4
 GM_MAX_TABLES, GM_MAX_LINEAR_EDGES = 4, 32
-LOOKUP_MAX_WINDOW, LOOKUP_MAX_EXCEPTIONS = 65536, 8
+LOOKUP_MAX_WINDOW, LOOKUP_MAX_EXCEPTIONS = 8192, 8  # the window lives in LDS: 8192 x 8 B = 64 KiB
 CLASS_F32, CLASS_F64, CLASS_I32, CLASS_I64 = 0, 1, 2, 3
 CLASS_DTYPE = {CLASS_F32: np.dtype("f4"), CLASS_F64: np.dtype("f8"),
                CLASS_I32: np.dtype("i4"), CLASS_I64: np.dtype("i8")}
@@ -312,8 +312,27 @@ def node_classes(node):
         float_side = frozenset((CLASS_F32, CLASS_F64)) if src.kind == "f" else frozenset((CLASS_I32, CLASS_I64))
         allowed = classes_exact(src) & float_side
     elif op == "lookup":
-        allowed = frozenset((CLASS_I64,)) if node.dtype == np.dtype("i8") else frozenset((CLASS_F64,))
-        allowed = allowed & classes_exact(node.args[0].dtype)
+        # every target (and the value of a miss) must be exact in the class: plain Reclassify tables hold
+        # int64 / float64 targets incl. the dtype's max (I64 / F64); a table folded with a following
+        # Mask holds a few small integers and fits any class -- also the float32 class of the
+        # arithmetic that feeds a Classify in front of it
+        ex = node.extra
+        entries = np.concatenate([np.ravel(ex["lut"]), np.ravel(np.asarray(ex["exc_vals"], dtype=ex["lut"].dtype)),
+                                  np.asarray([ex.get("miss", node.ndv)], dtype=ex["lut"].dtype)])
+        ok = []
+        for c in ALL_CLASSES:
+            with np.errstate(all="ignore"):
+                back = entries.astype(CLASS_DTYPE[c])
+                same = (back.astype(np.float64) == entries.astype(np.float64)) & (back.astype(entries.dtype) == entries)
+            if not (bool(np.all(same)) and (entries.dtype.kind != "f" or c in (CLASS_F32, CLASS_F64))):
+                continue
+            if c in (CLASS_F32, CLASS_I32):
+                # key arithmetic happens in int32 there: the window must lie inside the keys the class can hold
+                limit = 2 ** 24 if c == CLASS_F32 else 2 ** 31 - 1
+                if not (-limit <= ex["kmin"] and ex["kmin"] + len(ex["lut"]) - 1 <= limit):
+                    continue
+            ok.append(c)
+        allowed = frozenset(ok) & classes_exact(node.args[0].dtype)
     elif op in ("clip", "copy"):
         allowed = classes_exact(node.args[0].dtype)
     elif op == "mask":
@@ -545,17 +564,28 @@ def compile_expr(root, n_inputs):
             s.aux1.u64 = int(edges.size)
             s.flags = (1 if ex["right"] else 0) | (2 if edges.dtype == np.dtype("i8") else 0)
         elif node.op == "lookup":
+            if any(OPCODES["lookup"] == t.opcode for t in steps):
+                raise FusionLimit("one lookup per program (its window is staged in LDS)")
             ex = node.extra
             rc = CLASS_DTYPE[cls]
             lut = np.ascontiguousarray(ex["lut"].astype(rc))
-            exc = np.zeros(2 * len(ex["exc_keys"]), dtype=np.uint64)
-            exc[0::2] = np.asarray(ex["exc_keys"], dtype=np.int64).view(np.uint64)
-            exc[1::2] = np.asarray(ex["exc_vals"]).astype(rc).view(np.uint64)
-            _set_scalar(s.fill, cls, node.ndv)
-            s.aux0.u64 = add_table(np.concatenate([lut.view(np.uint64), exc]))
+            window = np.zeros((lut.nbytes + 7) // 8, dtype=np.uint64)
+            window.view(np.uint8)[:lut.nbytes] = lut.view(np.uint8)
+            exc_keys = np.asarray(ex["exc_keys"], dtype=np.int64)
+            exc_vals = np.asarray(ex["exc_vals"]).astype(rc)
+            if rc.itemsize == 4:  # keys the accumulator cannot hold can never match: drop them
+                keep = (exc_keys >= -2 ** 31) & (exc_keys <= 2 ** 31 - 1)
+                exc_keys, exc_vals = exc_keys[keep], exc_vals[keep]
+            exc = np.zeros(2 * len(exc_keys), dtype=np.uint64)
+            exc[0::2] = exc_keys.view(np.uint64)
+            vals = np.zeros(len(exc_keys), dtype=np.uint64)
+            vals.view(rc)[::8 // rc.itemsize] = exc_vals
+            exc[1::2] = vals
+            _set_scalar(s.fill, cls, ex.get("miss", node.ndv))
+            s.aux0.u64 = add_table(np.concatenate([window, exc]))
             s.aux1.i64 = int(ex["kmin"])
             s.aux2.u64 = int(lut.size)
-            s.aux3.u64 = len(ex["exc_keys"])
+            s.aux3.u64 = len(exc_keys)
             s.flags = 1 if ex["select"] else 0
         elif node.op == "mask":
             ex = node.extra

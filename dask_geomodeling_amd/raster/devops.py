@@ -70,12 +70,35 @@ def isclose_params(tile_dtype, ndv):
     return in_f64, float(ycmp), float(tolcmp), finite
 
 
+def _is_data(values, ndv):
+    """utils.get_index (utils.py:61-64) on a small host array (table entries)."""
+    values = np.asarray(values)
+    if values.dtype.kind == "f":
+        with np.errstate(all="ignore"):
+            return ~np.isclose(values, ndv)
+    return values != ndv
+
+
 def mask_node(store, value):
     """Mask.process numerics (raster/misc.py:213-221)."""
     dtype = mask_dtype(value)
     fill = 1 if value == 0 else 0
     # NumPy refuses out-of-range python ints on assignment (e.g. value 256 -> uint8): same error
     np.zeros(1, dtype=dtype)[0:1] = value
+    if isinstance(store, P.Op) and store.op == "lookup" and "miss" not in store.extra:
+        # Mask(Reclassify(x)): "is the looked-up target data?" is a property of the table entry, so
+        # the Mask is folded into the table on the host: the lookup then yields `value` / `fill`
+        # directly -- entries small enough for every register class, and one step less per pixel.
+        # Unmapped values: select -> the lookup's fill -> no data; otherwise the value itself, cast to
+        # the table's dtype, which can never be that dtype's maximum (the key would be in the table).
+        ex = store.extra
+        data = _is_data(ex["lut"], store.ndv)
+        lut = np.where(data, value, fill).astype(dtype)
+        exc_vals = np.where(_is_data(np.asarray(ex["exc_vals"], dtype=ex["lut"].dtype), store.ndv), value, fill).astype(dtype)
+        miss = fill if ex["select"] else value
+        extra = {"kmin": ex["kmin"], "lut": lut, "exc_keys": ex["exc_keys"], "exc_vals": exc_vals,
+                 "select": True, "miss": dtype.type(miss)}
+        return P.Op("lookup", [store.args[0]], dtype, fill, extra=extra)
     if store.dtype.kind == "f":
         in_f64, y, tol, finite = isclose_params(store.dtype, store.ndv)
         flags = (1 if in_f64 else 0) | (2 if finite else 0)

@@ -188,9 +188,12 @@ typedef struct gm_step {
   /* DIGITIZE: aux0.u64 = table index, aux1.u64 = number of edges; flags: 1 = right, 2 = the table
                holds int64 edges (integer tile, integer edges) instead of float64 edges
      LOOKUP:   aux0.u64 = table index, aux1.i64 = kmin, aux2.u64 = slots of the dense window,
-               aux3.u64 = number of exception keys; flags: 1 = select.  Table words: `slots` targets
-               (register-class bit patterns, unmapped slots already resolved), then one
-               (int64 key, target) pair per exception.  Classes I64 / F64 only. */
+               aux3.u64 = number of exception keys; flags: 1 = select.  Table: `slots` targets in the
+               register class' own representation and width (unmapped slots already resolved),
+               padded to 8 bytes, then one 16-byte (int64 key, target) pair per exception.  The
+               class must hold every target exactly (plain Reclassify: I64 / F64; a table folded
+               with a following Mask holds small integers and runs in any class).  The window is
+               staged in LDS: at most 64 KiB, one LOOKUP table per program. */
 } gm_step;
 #define GM_STEP_BITS(opcode, save_temp, flags, round_f32, wrap_i32, check_finite)                     \
   ((uint32_t)(opcode) | ((uint32_t)(save_temp) << 8) | ((uint32_t)(flags) << 16) |                    \

@@ -177,14 +177,15 @@ def run_program(prog, inputs, n):
             elif op == 28:  # lookup (Reclassify.process, raster/misc.py:505-514)
                 kmin, slots, n_exc = int(S.aux1.i64), int(S.aux2.u64), int(S.aux3.u64)
                 words = _table(prog, int(S.aux0.u64))
-                lut = words[:slots].view(rc)
+                lut_words = (slots * rc.itemsize + 7) // 8
+                lut = words[:lut_words].view(rc)[:slots]
                 key = a.astype("i8")
                 idx = key - np.int64(kmin)
                 inside = (idx >= 0) & (idx < slots)
                 miss = np.full(n, fill, dtype=rc) if (S.flags & 1) else a.copy()
                 for x in range(n_exc):
-                    ek = words[slots + 2 * x:slots + 2 * x + 1].view("i8")[0]
-                    ev = words[slots + 2 * x + 1:slots + 2 * x + 2].view(rc)[0]
+                    ek = words[lut_words + 2 * x:lut_words + 2 * x + 1].view("i8")[0]
+                    ev = words[lut_words + 2 * x + 1:lut_words + 2 * x + 2].view(rc)[0]
                     miss = np.where(key == ek, ev, miss)
                 r = np.where(inside, lut[np.where(inside, idx, 0)], miss)
                 nd = np.zeros(n, dtype=bool)

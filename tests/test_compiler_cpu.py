@@ -112,12 +112,7 @@ def test_reclassify_as_program_op(cpu_vm, case):
     assert_result_equal(out, case["expect"], 0, case["id"])
 
 
-def test_table_ops_fuse_into_two_programs(cpu_vm):
-    """float32 arithmetic + Classify | Reclassify + Mask: no single register class serves the chain;
-    the planner cuts it once (F32 program -> uint8 tile -> I64 program) instead of op by op."""
-    from dask_geomodeling_amd.hip import program as P
-    from dask_geomodeling_amd.raster import tables
-    from oracle import ref_numpy as O
+def _table_chain_inputs():
     rng = np.random.default_rng(3)
     fill = np.float32(np.finfo("f4").max)
     a = (rng.random((1, 40, 50)) * 200 - 100).astype("f4")
@@ -128,6 +123,19 @@ def test_table_ops_fuse_into_two_programs(cpu_vm):
     table = {"dtype": "<i8", "fillvalue": int(np.iinfo("i8").max), "select": False,
              "data": [[0, 10], [1, 11], [3, 13], [5, 15]]}
     kw = {"dtype": "float32", "fillvalue": float(fill)}
+    return a, b, fill, bins, table, kw
+
+
+@pytest.mark.parametrize("select", [False, True])
+def test_mask_folds_into_the_lookup_and_the_chain_is_one_program(cpu_vm, select):
+    """float32 arithmetic -> Classify -> Reclassify -> Mask: the Mask is folded into the table on the
+    host, the folded table holds small integers, so the whole chain is ONE program of the F32 class
+    (4 f32 leaves in, uint8 out) and still equals the reference op by op."""
+    from dask_geomodeling_amd.hip import program as P
+    from dask_geomodeling_amd.raster import tables
+    from oracle import ref_numpy as O
+    a, b, fill, bins, table, kw = _table_chain_inputs()
+    table = dict(table, select=select)
     A, B = {"values": a, "no_data_value": fill}, {"values": b, "no_data_value": fill}
     want = O.mask_process(O.reclassify_process(O.classify_process(O.math_process("add", kw, A, B), bins, False), table), 1)
     la, lb = P.Leaf(None, "f4", fill, values=a), P.Leaf(None, "f4", fill, values=b)
@@ -136,8 +144,31 @@ def test_table_ops_fuse_into_two_programs(cpu_vm):
     x = tables.reclassify_node(x, table)
     x = devops.mask_node(x, 1)
     stages, shape = P.plan_staged(x)
+    assert len(stages) == 1 and stages[0][0].reg_class == P.CLASS_F32
+    assert stages[0][0].out_dtype == np.dtype("u1")
+    out = P.run_staged(stages, shape)
+    assert_result_equal({"values": out, "no_data_value": stages[-1][0].out_ndv}, want, 0, "folded chain")
+
+
+def test_table_ops_cut_at_the_register_class_boundary(cpu_vm):
+    """float32 arithmetic + Classify | Reclassify + integer arithmetic: no single register class
+    serves the chain (int64 targets); the planner cuts it once (F32 program -> uint8 tile -> I64
+    program) instead of op by op."""
+    from dask_geomodeling_amd.hip import program as P
+    from dask_geomodeling_amd.raster import tables
+    from oracle import ref_numpy as O
+    a, b, fill, bins, table, kw = _table_chain_inputs()
+    A, B = {"values": a, "no_data_value": fill}, {"values": b, "no_data_value": fill}
+    kwi = {"dtype": "int64", "fillvalue": int(np.iinfo("i8").max)}
+    want = O.math_process("add", kwi, O.reclassify_process(O.classify_process(O.math_process("add", kw, A, B), bins, False), table), 7)
+    la, lb = P.Leaf(None, "f4", fill, values=a), P.Leaf(None, "f4", fill, values=b)
+    x = devops.math_node("add", kw, [la, lb])
+    x = tables.classify_node(x, bins, False)
+    x = tables.reclassify_node(x, table)
+    x = devops.math_node("add", kwi, [x, P.Lit(7)])
+    stages, shape = P.plan_staged(x)
     assert len(stages) == 2
     assert [c.reg_class for c, _ in stages] == [P.CLASS_F32, P.CLASS_I64]
-    assert stages[0][0].out_dtype == np.dtype("u1") and stages[1][0].out_dtype == np.dtype("u1")
+    assert stages[0][0].out_dtype == np.dtype("u1") and stages[1][0].out_dtype == np.dtype("i8")
     out = P.run_staged(stages, shape)
     assert_result_equal({"values": out, "no_data_value": stages[-1][0].out_ndv}, want, 0, "two-stage chain")
