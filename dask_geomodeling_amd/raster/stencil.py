@@ -1,0 +1,86 @@
+"""Host wrappers of the stencil kernels (csrc/gm_stencil.hip): the device bodies of
+Dilate.process, MovingMax.process and HillShade.process (raster/spatial.py)."""
+import ctypes
+
+import numpy as np
+
+from ..hip import runtime
+from ..hip.array import DeviceArray, as_device
+from ..hip.dtypes import code_of
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    L = runtime.lib()
+    if not _declared:
+        c = ctypes
+        L.gm_dilate.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_uint64), c.c_int, c.c_void_p]
+        L.gm_dilate.restype = c.c_int
+        L.gm_moving_max.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_uint64, c.c_void_p]
+        L.gm_moving_max.restype = c.c_int
+        L.gm_hillshade.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_uint64, c.c_uint64,
+                                   c.c_double, c.c_double, c.c_double, c.c_double, c.c_void_p]
+        L.gm_hillshade.restype = c.c_int
+        _declared = True
+    return L
+
+
+MAX_DILATE_VALUES = 16
+
+
+def _ndv_bits(dtype, ndv):
+    """(has_ndv, payload): can a cell of a ``dtype`` tile ever equal ``ndv`` (NumPy's ==)?"""
+    from ..hip.program import effective_ndv
+    eff = effective_ndv(dtype, ndv)
+    if eff is None:
+        return 0, 0
+    return 1, runtime.scalar_bits(eff, dtype)
+
+
+def dilate(values, dilate_values):
+    """(bands, h, w) tile with a 1-pixel margin -> dilated (bands, h-2, w-2) tile."""
+    src = as_device(values)
+    bands, h, w = src.shape
+    vals = np.asarray(dilate_values, dtype=src.dtype)  # the reference's cast (spatial.py:151)
+    if h < 3 or w < 3:
+        return DeviceArray.empty((bands, max(h - 2, 0), max(w - 2, 0)), src.dtype)
+    out = DeviceArray.empty((bands, h - 2, w - 2), src.dtype)
+    todo, current = list(vals), src
+    # more values than one launch takes: later launches must still test the ORIGINAL tile, so the
+    # list is only split when it has to be (the kernel applies its values in order)
+    if len(todo) > MAX_DILATE_VALUES:
+        raise NotImplementedError("Dilate with more than %d values" % MAX_DILATE_VALUES)
+    bits = (ctypes.c_uint64 * max(len(todo), 1))(*[runtime.scalar_bits(v, src.dtype) for v in todo])
+    runtime.check(_lib().gm_dilate(ctypes.c_void_p(current.ptr), code_of(src.dtype), bands, h, w, bits, len(todo),
+                                   ctypes.c_void_p(out.ptr)), "gm_dilate")
+    return out
+
+
+def moving_max(values, no_data_value, size):
+    src = as_device(values)
+    bands, h, w = src.shape
+    radius = int(size // 2)
+    if src.dtype == np.dtype("bool"):
+        raise NotImplementedError("MovingMax on boolean tiles")
+    out = DeviceArray.empty((bands, h - 2 * radius, w - 2 * radius), src.dtype)
+    has, bits = _ndv_bits(src.dtype, no_data_value)
+    runtime.check(_lib().gm_moving_max(ctypes.c_void_p(src.ptr), code_of(src.dtype), bands, h, w, int(size), has, bits,
+                                       ctypes.c_void_p(out.ptr)), "gm_moving_max")
+    return out
+
+
+def hillshade(values, no_data_value, fill, resolution, altitude, azimuth):
+    src = as_device(values)
+    bands, h, w = src.shape
+    if src.dtype == np.dtype("bool") or src.dtype == np.dtype("u8"):
+        raise NotImplementedError("HillShade on %s tiles" % src.dtype)
+    out = DeviceArray.empty((bands, h - 2, w - 2), "u1")
+    has, bits = _ndv_bits(src.dtype, no_data_value)
+    with np.errstate(all="ignore"):
+        fill_cast = np.array(fill).astype(src.dtype)[()]  # array[mask] = fill casts like this (spatial.py:364)
+    runtime.check(_lib().gm_hillshade(ctypes.c_void_p(src.ptr), code_of(src.dtype), bands, h, w, has, bits,
+                                      runtime.scalar_bits(fill_cast, src.dtype), float(resolution[0]), float(resolution[1]),
+                                      float(altitude), float(azimuth), ctypes.c_void_p(out.ptr)), "gm_hillshade")
+    return out

@@ -320,6 +320,27 @@ int gm_resample_bilinear(const void* src, int dtype, int bands, int hs, int ws,
                          void* dst, int hd, int wd, int has_ndv, uint64_t ndv_bits);
 
 /* =============================================================================
+ * N3: small-radius stencils (raster/spatial.py).  `in` is the (bands, h, w) tile INCLUDING the
+ * margin the Block requested (expand_request_pixels, spatial.py:27-47); `out` is cropped.
+ * ========================================================================== */
+
+/* Dilate.process (spatial.py:143-154): out = (bands, h-2, w-2).  For every value, in order, a cell
+ * takes it when the value occurs in its 6-neighbourhood over (band, y, x) of the ORIGINAL tile
+ * (scipy.ndimage.binary_dilation's default structure).  values_bits: <= 16 gm_scalar payloads. */
+int gm_dilate(const void* in, int dtype, int bands, int h, int w, const uint64_t* values_bits, int n_values, void* out);
+/* MovingMax.process (spatial.py:190-213): maximum over the circular footprint of diameter `size`
+ * (odd, 3..63; utils.py:536-547) with no-data lowered to the dtype's minimum; a result that is
+ * still the minimum on a no-data centre stays no-data.  out = (bands, h-2r, w-2r), r = size/2.
+ * The (32 + 2r) x (64 + 2r) window of a workgroup is staged in LDS. */
+int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, int has_ndv, uint64_t ndv_bits, void* out);
+/* HillShade.process (spatial.py:354-417): out = uint8 (bands, h-2, w-2).  no-data -> fill (already
+ * cast to the tile's dtype), gradients in the tile's dtype (integers wrap like NumPy), then
+ * float32 exactly as NumPy orders it; arctan2 / sin are the float32 roundings of the float64
+ * functions, so a cell may differ by 1 from NumPy's float32 libm at a truncation boundary. */
+int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv, uint64_t ndv_bits, uint64_t fill_bits,
+                 double xres, double yres, double altitude_deg, double azimuth_deg, void* out);
+
+/* =============================================================================
  * K8: helpers
  * ========================================================================== */
 

@@ -475,3 +475,141 @@ def bilinear_resample(array, out_h, out_w, ndv):
         bad |= (t == nd64) | ~np.isfinite(t)
     out[bad] = ndv
     return out
+
+
+# --------------------------------------------------------------------------
+# N3: small-radius stencils (raster/spatial.py).  Inputs arrive with the margin the
+# Block requested (expand_request_pixels, spatial.py:27-47); results are cropped.
+# Pure NumPy shifts (no SciPy): pinned to the reference (which calls scipy.ndimage)
+# through the "spatial" golden family.
+# --------------------------------------------------------------------------
+def get_footprint(size):
+    """Circular footprint of diameter ``size`` (utils.py:536-547)."""
+    s = size // 2 * 2 + 1
+    o = (s - 1) // 2
+    r = s / 2
+    x, y = np.indices((s, s)) - o
+    return (x ** 2 + y ** 2) < (r ** 2)
+
+
+def dilate_process(data, values=None):
+    """Dilate.process (raster/spatial.py:143-154): for every value, in order, the cells whose
+    3-D 6-neighbourhood (scipy's default cross over (band, y, x); outside = False) holds the value
+    in the ORIGINAL tile take it; one pixel is cropped from the y and x borders."""
+    if data is None or values is None or "values" not in data:
+        return data
+    original = data["values"]
+    dilated = original.copy()
+    nb, ny, nx = original.shape
+    for value in np.asarray(values, dtype=original.dtype):
+        hit = original == value
+        grown = hit.copy()
+        grown[:, 1:, :] |= hit[:, :-1, :]
+        grown[:, :-1, :] |= hit[:, 1:, :]
+        grown[:, :, 1:] |= hit[:, :, :-1]
+        grown[:, :, :-1] |= hit[:, :, 1:]
+        grown[1:] |= hit[:-1]
+        grown[:-1] |= hit[1:]
+        dilated[grown] = value
+    return {"values": dilated[:, 1:-1, 1:-1], "no_data_value": data["no_data_value"]}
+
+
+def movingmax_process(data, size=None):
+    """MovingMax.process (raster/spatial.py:190-213): maximum over a circular footprint with
+    no-data cells lowered to the dtype's minimum first; a result that is still the minimum on a
+    no-data centre becomes no-data again; ``size // 2`` pixels are cropped."""
+    if data is None or size is None or "values" not in data:
+        return data
+    radius = int(size // 2)
+    footprint = get_footprint(size)
+    array = data["values"].copy()
+    minimum = get_dtype_min(array.dtype)
+    no_data_mask = array == data["no_data_value"]
+    array[no_data_mask] = minimum
+    nb, ny, nx = array.shape
+    oy, ox = ny - 2 * radius, nx - 2 * radius
+    filtered = np.full((nb, oy, ox), minimum, dtype=array.dtype)
+    for dy in range(footprint.shape[0]):
+        for dx in range(footprint.shape[1]):
+            if footprint[dy, dx]:
+                filtered = np.maximum(filtered, array[:, dy:dy + oy, dx:dx + ox])
+    centre = no_data_mask[:, radius:ny - radius, radius:nx - radius]
+    filtered[(filtered == minimum) & centre] = data["no_data_value"]
+    return {"values": filtered, "no_data_value": data["no_data_value"]}
+
+
+def hillshade_process(data, process_kwargs=None):
+    """HillShade.process (raster/spatial.py:354-417), operation by operation in the dtypes NumPy
+    uses there: no-data -> fill in the tile's dtype, Sobel-like sums in the tile's dtype, the
+    division and everything after it in float32 (python-float constants are weak scalars)."""
+    import math
+    if process_kwargs is None:
+        return data
+    array = data["values"].copy()
+    array[array == data["no_data_value"]] = process_kwargs["fill"]
+    xres, yres = process_kwargs["resolution"]
+    alt = math.radians(process_kwargs["altitude"])
+    az = math.radians(process_kwargs["azimuth"])
+    zsf = 1 / 8
+    square_zsf = zsf * zsf
+    a = array
+    n = (slice(None), slice(None, -2))
+    c = (slice(None), slice(1, -1))
+    s = (slice(None), slice(2, None))
+    w, m, e = slice(None, -2), slice(1, -1), slice(2, None)
+    with np.errstate(all="ignore"):
+        y = ((a[n + (w,)] + 2 * a[n + (m,)] + a[n + (e,)] - a[s + (w,)] - 2 * a[s + (m,)] - a[s + (e,)]) / yres).astype("f4")
+        x = ((a[n + (w,)] + 2 * a[c + (w,)] + a[s + (w,)] - a[n + (e,)] - 2 * a[c + (e,)] - a[s + (e,)]) / xres).astype("f4")
+        xx_plus_yy = x * x + y * y
+        aspect = np.arctan2(y, x)
+        cang = (math.sin(alt) - math.cos(alt) * zsf * np.sqrt(xx_plus_yy) * np.sin(aspect - az)) / np.sqrt(
+            1 + square_zsf * xx_plus_yy)
+        result = np.where(cang <= 0, 0, 255 * cang).astype("u1")
+    return {"values": result, "no_data_value": 256}
+
+
+def expand_request_pixels(request, radius=1):
+    """spatial.py:27-47, including its mixed use of amount_x / amount_y."""
+    if request["mode"] != "vals":
+        return None
+    width, height = request["width"], request["height"]
+    x1, y1, x2, y2 = request["bbox"]
+    pwidth, pheight = x2 - x1, y2 - y1
+    if pwidth == 0 or pheight == 0:
+        return None
+    amount_x = pwidth / width * radius
+    amount_y = pheight / height * radius
+    new_request = dict(request)
+    new_request["bbox"] = (x1 - amount_x, y1 - amount_x, x2 + amount_y, y2 + amount_y)
+    new_request["width"] += 2 * radius
+    new_request["height"] += 2 * radius
+    return new_request
+
+
+# --------------------------------------------------------------------------
+# N4: Max = reduce_rasters(stack, "max") (raster/reduction.py:38-119, 201-226)
+# --------------------------------------------------------------------------
+def reduce_max_process(process_kwargs, *args):
+    """wrap_reduction_function("max") (reduction.py:189-212) + reduce_rasters (:38-119): cells that
+    are data (utils.get_index) and not NaN take part; where nothing does the result is the fill."""
+    stack = []
+    for arg in args:
+        if "time" in arg or "meta" in arg:  # (a None argument raises TypeError here, as in the reference)
+            return arg
+        if arg is None:
+            continue
+        stack.append(arg)
+    if len(stack) == 0:
+        return None
+    dtype = np.dtype(process_kwargs["dtype"])
+    fill = process_kwargs["fillvalue"]
+    shape = stack[0]["values"].shape
+    out = np.full(shape, fill, dtype)
+    work = np.full((len(stack),) + shape, np.nan, np.result_type(dtype, np.float16))
+    for i, data in enumerate(stack):
+        index = get_index(data["values"], data["no_data_value"])
+        work[i, index] = data["values"][index]
+    with np.errstate(all="ignore"):
+        not_all_nan = ~np.all(np.isnan(work), axis=0)
+        out[not_all_nan] = np.nanmax(work[:, not_all_nan], axis=0)
+    return {"values": out, "no_data_value": fill}

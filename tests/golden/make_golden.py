@@ -23,6 +23,8 @@ Families:
   views       full get_data() of small views built from reference Blocks on a
               probe source (graph core + dtype/fill algebra + chain semantics)
   smoothzoom  R1     ndimage.affine_transform(order=0) call of Smooth's zoom branch
+  spatial     N3     Dilate / MovingMax / HillShade process() + expand_request_pixels
+  reduce      N4     Max.process = reduce_rasters(stack, "max")
 """
 import json
 import os
@@ -701,11 +703,99 @@ def gen_smoothzoom(w):
         cid += 1
 
 
+# --------------------------------------------------------------------------
+# family: spatial  (reference: raster/spatial.py:27-47, 111-213, 320-440)
+# --------------------------------------------------------------------------
+def gen_spatial(w):
+    from dask_geomodeling.raster import spatial as R_sp
+    rng = np.random.default_rng(81)
+    cid = 0
+    # Dilate: integer and float tiles, several bands (scipy's default structure also spans the band axis)
+    for dt, ndv in (("u1", np.uint8(255)), ("i4", -9999), ("f4", np.float32(F32MAX)), ("i8", 9223372036854775807)):
+        for shape in ((1, 14, 19), (3, 9, 12), (2, 3, 3)):
+            v = rng.integers(0, 6, size=shape).astype(dt)
+            v[rng.random(shape) < 0.1] = ndv
+            for values in ([1], [2, 3], [5, 1, 2], [dt == "f4" and 2.0 or 2, 4, 0]):
+                data = {"values": v, "no_data_value": ndv}
+                w.add(id="sp%04d" % cid, op="dilate", args=[data, values],
+                      expect=R_sp.Dilate.process(data, values)); cid += 1
+    for args in ([None, [1]], [{"time": ["t"]}, [1]], [{"values": np.zeros((1, 4, 4), "u1"), "no_data_value": 255}, None]):
+        w.add(id="sp%04d" % cid, op="dilate", args=args, expect=R_sp.Dilate.process(*args)); cid += 1
+    # MovingMax: finite values only (SciPy's NaN behaviour depends on the filter path it picks)
+    for dt, ndv in (("f4", np.float32(F32MAX)), ("f4", np.float32(-1.0)), ("u1", np.uint8(255)), ("i4", -9999),
+                    ("i2", np.int16(-32768)), ("f8", F64MAX)):
+        for size in (3, 5, 7, 11):
+            r = size // 2
+            for shape in ((1, 12 + 2 * r, 17 + 2 * r), (2, 5 + 2 * r, 6 + 2 * r)):
+                if np.dtype(dt).kind == "f":
+                    v = (rng.random(shape) * 100 - 50).astype(dt)
+                else:
+                    info = np.iinfo(dt)
+                    v = rng.integers(max(info.min, -100), min(info.max, 100), size=shape, endpoint=True).astype(dt)
+                v[rng.random(shape) < 0.3] = ndv
+                v[:, :r + 1, :r + 1] = ndv  # a region whose whole footprint is no-data
+                data = {"values": v, "no_data_value": ndv}
+                w.add(id="sp%04d" % cid, op="movingmax", args=[data, size],
+                      expect=R_sp.MovingMax.process(data, size)); cid += 1
+    for args in ([None, 3], [{"meta": ["m"]}, 3], [{"values": np.zeros((1, 4, 4), "u1"), "no_data_value": 255}, None]):
+        w.add(id="sp%04d" % cid, op="movingmax", args=args, expect=R_sp.MovingMax.process(*args)); cid += 1
+    # HillShade: float and integer elevation tiles
+    for dt, ndv in (("f4", np.float32(F32MAX)), ("f8", F64MAX), ("i4", -9999), ("u1", np.uint8(255)), ("i2", np.int16(-1))):
+        for shape in ((1, 16, 21), (2, 7, 9)):
+            for res, alt, az, fill in (((0.5, 0.5), 45.0, 315.0, 0), ((5.0, 2.0), 30.0, 90.0, 10), ((1.0, 1.0), 80.0, 200.5, 3)):
+                if np.dtype(dt).kind == "f":
+                    v = (np.cumsum(rng.random(shape), axis=2) * 3 + rng.random(shape)).astype(dt)
+                else:
+                    info = np.iinfo(dt)
+                    v = rng.integers(max(info.min, 0), min(info.max, 120), size=shape, endpoint=True).astype(dt)
+                v[rng.random(shape) < 0.05] = ndv
+                data = {"values": v, "no_data_value": ndv}
+                kw = dict(resolution=res, altitude=alt, azimuth=az, fill=fill)
+                w.add(id="sp%04d" % cid, op="hillshade", args=[data, kw],
+                      expect=R_sp.HillShade.process(data, kw)); cid += 1
+    w.add(id="sp%04d" % cid, op="hillshade", args=[{"time": ["t"]}, None],
+          expect=R_sp.HillShade.process({"time": ["t"]}, None)); cid += 1
+    # request expansion
+    for request in (dict(mode="vals", bbox=(0.0, 0.0, 10.0, 20.0), width=20, height=10, projection="EPSG:28992"),
+                    dict(mode="vals", bbox=(5.0, -3.0, 6.5, 0.0), width=3, height=12, projection="EPSG:28992"),
+                    dict(mode="time", bbox=(0.0, 0.0, 1.0, 1.0), width=1, height=1),
+                    dict(mode="vals", bbox=(1.0, 1.0, 1.0, 1.0), width=1, height=1, projection="EPSG:28992")):
+        for radius in (1, 2, 5):
+            w.add(id="sp%04d" % cid, op="expand", args=[request, radius],
+                  expect=R_sp.expand_request_pixels(dict(request), radius)); cid += 1
+
+
+# --------------------------------------------------------------------------
+# family: reduce  (reference: raster/reduction.py:38-119, 189-226)
+# --------------------------------------------------------------------------
+def gen_reduce(w):
+    from dask_geomodeling.raster import reduction as R_red
+    rng = np.random.default_rng(91)
+    cid = 0
+    f32n = np.float32(F32MAX)
+    for dts in (("f4", "f4"), ("f4", "f4", "f4"), ("u1", "u1"), ("i4", "u1"), ("i4", "i4", "i4", "i4"),
+                ("f8", "f4"), ("i2", "f4"), ("i8", "i8")):
+        for shape in SHAPES:
+            stack = []
+            for dt in dts:
+                ndv = {"f4": f32n, "f8": F64MAX, "u1": np.uint8(255), "i4": -9999, "i2": np.int16(-1),
+                       "i8": 9223372036854775807}[dt]
+                stack.append({"values": make_tile(rng, dt, shape, ndv, specials=(dt in ("f4", "f8"))), "no_data_value": ndv})
+            out_dt = np.result_type(*[np.dtype(d) for d in dts])
+            kw = {"dtype": out_dt.name, "fillvalue": dtype_max(out_dt)}
+            w.add(id="red%04d" % cid, op="max", args=[kw] + stack, expect=R_red.Max.process(kw, *stack)); cid += 1
+    tile = {"values": make_tile(rng, "f4", SHAPES[0], f32n), "no_data_value": f32n}
+    kw = {"dtype": "float32", "fillvalue": F32MAX}
+    for args in ([kw, {"time": ["t"]}, tile], [kw, tile, {"meta": ["m"]}], [kw]):
+        w.add(id="red%04d" % cid, op="max", args=args, expect=R_red.Max.process(*args)); cid += 1
+
+
 def main():
     fams = {
         "math": gen_math, "n1": gen_n1, "clip": gen_clip, "mask": gen_mask,
         "classify": gen_classify, "reclassify": gen_reclassify, "tiler": gen_tiler,
         "views": gen_views, "dtypes": gen_dtypes, "smoothzoom": gen_smoothzoom,
+        "spatial": gen_spatial, "reduce": gen_reduce,
     }
     only = sys.argv[1:]
     counts = {}

@@ -407,3 +407,34 @@ def test_tiler_validation():
             raster.RasterTiler(store, bad)
     with pytest.raises(TypeError):
         raster.RasterTiler("a", 10)
+
+
+# ---------------------------------------------------------------------------------
+# N3 stencil Blocks: host logic (constructors, request enlargement) against the reference's values
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [c for c in load_family("spatial") if c["op"] == "expand"], ids=lambda c: c["id"])
+def test_expand_request_pixels(case):
+    from dask_geomodeling_amd.raster.spatial import expand_request_pixels
+    assert expand_request_pixels(dict(case["args"][0]), case["args"][1]) == case["expect"]
+
+
+def test_stencil_block_constructors_and_requests():
+    a = ArrayLeaf("st", "<f4", np.float32(3.4028235e38))
+    assert raster.MovingMax(a, 4).size == 5 and raster.MovingMax(a, 3.2).size == 3
+    with pytest.raises(ValueError):
+        raster.MovingMax(a, 1)
+    with pytest.raises(TypeError):
+        raster.HillShade(a, altitude="45")
+    hs = raster.HillShade(a)
+    assert hs.dtype == np.dtype("u1") and hs.fillvalue == 256 and (hs.altitude, hs.azimuth, hs.fill) == (45.0, 315.0, 0)
+    assert raster.Dilate(ArrayLeaf("sti", "<i4", -1), [1, 2.0]).values == [1, 2]
+    (src, req), (kw, _) = hs.get_sources_and_requests(**REQ)
+    assert req["width"] == REQ["width"] + 2 and req["height"] == REQ["height"] + 2
+    assert kw["resolution"] == ((REQ["bbox"][2] - REQ["bbox"][0]) / REQ["width"], (REQ["bbox"][3] - REQ["bbox"][1]) / REQ["height"])
+    (src, req), (size, _) = raster.MovingMax(a, 7).get_sources_and_requests(**REQ)
+    assert size == 7 and req["width"] == REQ["width"] + 6
+    assert raster.MovingMax(a, 7).get_sources_and_requests(mode="time") == [(a, {"mode": "time"})]
+    # control flow of the process bodies needs no device
+    assert raster.Dilate.process(None, [1]) is None
+    assert raster.MovingMax.process({"time": ["t"]}, 3) == {"time": ["t"]}
+    assert raster.HillShade.process({"meta": ["m"]}, None) == {"meta": ["m"]}

@@ -480,3 +480,75 @@ def test_tiler_over_memory_source_is_zero_copy_and_exact(gpu):
     assert kwargs["window"] == (16, 32)
     raw = raster.MemorySource.process(kwargs)["values"]
     assert isinstance(raw, DeviceArray) and raw.pitch == 128
+
+
+# ---- N3: stencils (Dilate / MovingMax / HillShade) ------------------------------------------------
+def _hillshade_close(actual, expected, what):
+    actual, expected = np.asarray(actual), np.asarray(expected)
+    assert actual.dtype == expected.dtype == np.dtype("u1") and actual.shape == expected.shape, what
+    diff = np.abs(actual.astype("i2") - expected.astype("i2"))
+    assert diff.max(initial=0) <= 1, "%s: max |diff| %d" % (what, diff.max())
+    assert (diff != 0).mean() <= 0.01 if diff.size else True, "%s: %.2f %% differ" % (what, 100 * (diff != 0).mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in load_family("spatial") if c["op"] != "expand"],
+                         ids=lambda c: c["id"] + "-" + c["op"])
+def test_stencils_golden(gpu, case):
+    """Device Dilate / MovingMax / HillShade against vectors produced by the reference itself:
+    bit-exact, except HillShade (float32 trigonometry before a truncating uint8 cast: +-1 on <= 1 %)."""
+    from dask_geomodeling_amd import raster
+    fn = {"dilate": raster.Dilate.process, "movingmax": raster.MovingMax.process, "hillshade": raster.HillShade.process}[case["op"]]
+    out = fn(*case["args"])
+    if case["op"] == "hillshade" and isinstance(out, dict) and "values" in out:
+        assert out["no_data_value"] == 256
+        _hillshade_close(out["values"], case["expect"]["values"], case["id"])
+    else:
+        assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.mark.gpu
+def test_stencils_large_tiles_vs_oracle(gpu):
+    """Tiles larger than one workgroup window (several LDS tiles, ragged edges) against the oracle."""
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(4)
+    for dt, ndv in (("f4", np.float32(np.finfo("f4").max)), ("i4", -9999), ("u1", np.uint8(255))):
+        shape = (2, 157, 203)
+        if np.dtype(dt).kind == "f":
+            v = (rng.random(shape) * 100 - 50).astype(dt)
+        else:
+            v = rng.integers(0, 100, size=shape).astype(dt)
+        v[rng.random(shape) < 0.2] = ndv
+        v[:, 30:60, 40:90] = ndv
+        data = {"values": v, "no_data_value": ndv}
+        for size in (3, 9, 15):
+            assert_result_equal(raster.MovingMax.process(data, size), O.movingmax_process(data, size), 0, "movingmax %s %d" % (dt, size))
+        vals = [v.flat[7], v.flat[11], 3]
+        assert_result_equal(raster.Dilate.process(data, vals), O.dilate_process(data, vals), 0, "dilate %s" % dt)
+        kw = dict(resolution=(0.5, 2.0), altitude=45.0, azimuth=315.0, fill=1)
+        got, want = raster.HillShade.process(data, kw), O.hillshade_process(data, kw)
+        _hillshade_close(got["values"], want["values"], "hillshade %s" % dt)
+
+
+@pytest.mark.gpu
+def test_stencil_blocks_end_to_end(gpu):
+    """The Blocks through get_data on a MemorySource: request enlargement + kernel + crop equal the
+    oracle applied to the enlarged window (edge cells see the source's no-data outside its extent)."""
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(12)
+    fill = np.float32(np.finfo("f4").max)
+    a = (rng.random((1, 40, 56)) * 100).astype("f4")
+    a[0, 5:9, 7:15] = fill
+    src = raster.MemorySource(a, fill, "EPSG:28992", 1.0, (0.0, 40.0))
+    req = dict(mode="vals", bbox=(8.0, 8.0, 40.0, 32.0), width=32, height=24, projection="EPSG:28992")
+    for block, radius, fn in ((raster.MovingMax(src, 5), 2, lambda d: O.movingmax_process(d, 5)),
+                              (raster.HillShade(src), 1, lambda d: O.hillshade_process(d, dict(resolution=(1.0, 1.0), altitude=45.0, azimuth=315.0, fill=0)))):
+        big = src.get_data(**O.expand_request_pixels(req, radius))
+        want = fn(big)
+        got = block.get_data(**req)
+        if isinstance(block, raster.HillShade):
+            _hillshade_close(got["values"], want["values"], "HillShade block")
+        else:
+            assert_result_equal(got, want, 0, type(block).__name__)
+    for mode in ("time", "meta"):
+        assert raster.MovingMax(src, 3).get_data(mode=mode) == src.get_data(mode=mode)

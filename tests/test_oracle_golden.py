@@ -179,3 +179,37 @@ def test_bilinear_vs_scipy():
         for b in range(2):
             want = ndimage.map_coordinates(src[b].astype("f8"), [vv, uu], order=1, mode="nearest")
             assert ulp_distance(got[b], want.astype("f4")).max() <= 1
+
+
+# ---------------------------------------------------------------------------------
+# N3 / N4: stencils and the Max reduction
+# ---------------------------------------------------------------------------------
+def hillshade_close(actual, expected, what=""):
+    """HillShade ends in float32 sin / arctan2 followed by a truncating cast to uint8: another libm
+    (or the GPU) may land on the other side of an integer boundary.  Tolerance: |diff| <= 1 on at
+    most 1 % of the cells, everything else identical."""
+    actual, expected = np.asarray(actual), np.asarray(expected)
+    assert actual.dtype == expected.dtype == np.dtype("u1") and actual.shape == expected.shape, what
+    diff = np.abs(actual.astype("i2") - expected.astype("i2"))
+    assert diff.max(initial=0) <= 1, "%s: max |diff| %d" % (what, diff.max())
+    assert (diff != 0).mean() <= 0.01 if diff.size else True, "%s: %.2f %% of the cells differ" % (what, 100 * (diff != 0).mean())
+
+
+@pytest.mark.parametrize("case", load_family("spatial"), ids=lambda c: c["id"] + "-" + c["op"])
+def test_spatial(case):
+    op, args = case["op"], case["args"]
+    if op == "expand":
+        assert O.expand_request_pixels(*args) == case["expect"]
+        return
+    out = getattr(O, op + "_process")(*args)
+    if op == "hillshade" and isinstance(out, dict) and "values" in out:
+        assert out["no_data_value"] == case["expect"]["no_data_value"] == 256
+        hillshade_close(out["values"], case["expect"]["values"], case["id"])
+    else:
+        assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.mark.parametrize("case", load_family("reduce"), ids=lambda c: c["id"])
+def test_reduce_max(case):
+    out = O.reduce_max_process(*case["args"])
+    assert_result_equal(out, case["expect"], 0, case["id"])
