@@ -153,8 +153,9 @@ int validate(const gm_program* prog) {
     if (rc) return rc;
     rc = validate_operand(S.b, prog->n_inputs, "b", s);
     if (rc) return rc;
-    if (opcode == GM_OP_DIV && prog->reg_class >= GM_CLASS_I32)
-      return gm::fail(GM_ERR_INVALID, "step %u: DIV in an integer class", s);
+    if ((opcode == GM_OP_DIV || opcode == GM_OP_NANIFNODATA || opcode == GM_OP_FMAX || opcode == GM_OP_NANTOFILL) &&
+        prog->reg_class >= GM_CLASS_I32)
+      return gm::fail(GM_ERR_INVALID, "step %u: opcode %u needs a float class", s, opcode);
     if (opcode == GM_OP_DIGITIZE || opcode == GM_OP_LOOKUP) {
       const unsigned long long t = S.aux0.u64;
       if (t >= prog->n_tables) return gm::fail(GM_ERR_INVALID, "step %u: table %llu of %u", s, t, prog->n_tables);

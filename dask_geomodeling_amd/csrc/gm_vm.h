@@ -655,6 +655,37 @@ struct Machine {
         }
 #endif
         break;
+      case GM_OP_NANIFNODATA:
+        if constexpr (is_float_class<RC>::value) {
+          // reduction.py:102-107: stack_array[i, index] = values[index], NaN elsewhere
+          const unsigned flags = step_flags(S);
+          const RC nan = (RC)__builtin_nanf("");
+          if (flags & 4u) {  // integer tile (held exactly in the float class): exact !=
+            const bool a_has = opd_has_ndv(S.a);
+            const RC a_ndv = scalar_of<RC>(S.a.value);
+#pragma unroll
+            for (int k = 0; k < N; ++k) acc[k] = (a_has & (acc[k] == a_ndv)) ? nan : acc[k];
+          } else {
+            const double y = S.aux2.f64, tol = S.aux1.f64;
+            const bool in_f64 = (flags & 1u) != 0, y_finite = (flags & 2u) != 0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) acc[k] = is_close<RC>(acc[k], y, tol, in_f64, y_finite) ? nan : acc[k];
+          }
+        }
+        break;
+      case GM_OP_FMAX:
+        if constexpr (is_float_class<RC>::value) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) acc[k] = ((acc[k] >= b[k]) | (b[k] != b[k])) ? acc[k] : b[k];
+        }
+        break;
+      case GM_OP_NANTOFILL:
+        if constexpr (is_float_class<RC>::value) {
+          const RC fill = scalar_of<RC>(S.fill);
+#pragma unroll
+          for (int k = 0; k < N; ++k) acc[k] = (acc[k] != acc[k]) ? fill : acc[k];
+        }
+        break;
       case GM_OP_COPY:
       default:
         break;  // the accumulator already holds the operand

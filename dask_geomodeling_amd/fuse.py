@@ -207,6 +207,10 @@ class FusedTask(object):
             if not isinstance(args[0], dict):
                 raise _NotFusable()
             return devops.math_node(op, args[0], [operand(a) for a in args[1:]])
+        if op == "reduce_max":
+            if not isinstance(args[0], dict):
+                raise _NotFusable()
+            return devops.reduce_max_node(args[0], [operand(a) for a in args[1:]])
         if op == "clip":
             return devops.clip_node(operand(args[0]), operand(args[1]))
         if op == "mask":

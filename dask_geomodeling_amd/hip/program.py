@@ -32,6 +32,7 @@ OPCODES = {
     "exp": 15, "log": 16, "log10": 17,
     "invert": 18, "isdata": 19, "isnodata": 20, "clip": 21, "mask": 22,
     "maskbelow": 23, "step": 24, "fillnodata": 25, "copy": 26, "digitize": 27, "lookup": 28,
+    "nanifnodata": 29, "fmax": 30, "nantofill": 31,
 }
 MATH_OPS = ("add", "subtract", "multiply", "divide", "power", "exp", "log", "log10")
 COMPARE_OPS = ("equal", "not_equal", "greater", "greater_equal", "less", "less_equal")
@@ -302,6 +303,11 @@ def node_classes(node):
         for a in node.args:
             if not isinstance(a, Lit):
                 allowed = allowed & classes_exact(a.dtype)
+    elif op in ("nanifnodata", "fmax", "nantofill"):
+        # reduce_rasters works in result_type(dtype, float16) (reduction.py:99-101): values are exact
+        # there and so they are in the float class that holds the work dtype
+        work = node.extra["work"]
+        allowed = frozenset((CLASS_F32, CLASS_F64)) if work.itemsize <= 4 else frozenset((CLASS_F64,))
     elif op == "digitize":
         # Classify: the value is compared with the edges in NumPy's promoted dtype -- float tiles in a
         # float class (float64 edges; the F32 class uses directed-rounded float32 thresholds),
@@ -347,10 +353,12 @@ def node_classes(node):
     # a float64 op: NumPy casts them (rounding) too, and their no-data cells are tagged at
     # load time (gm_input_desc.native_ndv)
     cd = compute_dtype(node)
+    casts_to_f64 = (cd is not None and cd == np.dtype("f8")) or \
+        op in ("mask", "isdata", "isnodata")  # these only ask "is the cell no data?": the tag suffices
     for a in node.args:
         if isinstance(a, Leaf):
             allowed = frozenset(c for c in allowed if exact_in_class(a.dtype, c)
-                                or (c == CLASS_F64 and cd == np.dtype("f8") and _wide_int(a.dtype)))
+                                or (c == CLASS_F64 and casts_to_f64 and _wide_int(a.dtype)))
     return allowed
 
 
@@ -554,6 +562,13 @@ def compile_expr(root, n_inputs):
             _set_scalar(s.aux1, cls, cast_scalar(left, node.dtype))
             _set_scalar(s.aux2, cls, cast_scalar(at, node.dtype))
             _set_scalar(s.aux3, cls, cast_scalar(right, node.dtype))
+        elif node.op == "nanifnodata":
+            ex = node.extra
+            s.flags = ex["flags"]
+            s.aux1.f64 = ex["tol"]
+            s.aux2.f64 = ex["y"]
+        elif node.op == "nantofill":
+            _set_scalar(s.fill, cls, cast_scalar(node.ndv, node.dtype))
         elif node.op == "digitize":
             ex = node.extra
             edges = ex["edges"]

@@ -4,3 +4,4 @@ from .misc import *  # noqa: F401,F403
 from .sources import *  # noqa: F401,F403
 from .parallelize import *  # noqa: F401,F403
 from .spatial import *  # noqa: F401,F403
+from .reduction import *  # noqa: F401,F403

@@ -108,6 +108,49 @@ def mask_node(store, value):
     return P.Op("mask", [store], dtype, fill, extra=extra)
 
 
+def reduce_max_node(process_kwargs, nodes):
+    """reduce_rasters(stack, "max", fillvalue, dtype) (raster/reduction.py:38-119): every raster
+    with its no-data (utils.get_index) turned into NaN, np.fmax from left to right (what np.nanmax
+    reduces with), NaN -> fill, cast to the output dtype."""
+    dtype = np.dtype(process_kwargs["dtype"])
+    fill = process_kwargs["fillvalue"]
+    work = np.result_type(dtype, np.float16)
+    work = np.dtype("f4") if work.itemsize < 4 else work
+    acc = None
+    for node in nodes:
+        if node.dtype.kind in "iu" and node.dtype.itemsize == 8:
+            # the reference squeezes 64-bit integers through float64 (reduction.py:99-107) and casts
+            # back; what comes out near the ends of the range is a property of the host's cast
+            raise NotImplementedError("Max of 64-bit integer rasters is not supported on the device")
+        if node.dtype.kind == "f":
+            in_f64, y, tol, finite = isclose_params(node.dtype, node.ndv)
+            extra = {"flags": (1 if in_f64 else 0) | (2 if finite else 0), "tol": tol, "y": y, "work": work}
+        else:
+            extra = {"flags": 4, "tol": 0.0, "y": 0.0, "work": work}
+        coded = P.Op("nanifnodata", [node], work, None, extra=extra)
+        acc = coded if acc is None else P.Op("fmax", [acc, coded], work, None, extra={"work": work})
+    return P.Op("nantofill", [acc], dtype, fill, extra={"work": work})
+
+
+def reduce_max_process(process_kwargs, *args):
+    """Drop-in for Max.process = wrap_reduction_function("max") (raster/reduction.py:189-212)."""
+    stack = []
+    for arg in args:
+        if "time" in arg or "meta" in arg:  # (a None argument raises TypeError here, as in the reference)
+            return arg
+        if arg is None:
+            continue
+        stack.append(arg)
+    if len(stack) == 0:
+        return None
+    tiles = [(a["values"], a["no_data_value"]) for a in stack]
+    values, ndv = P.run_expr(lambda leaves: reduce_max_node(process_kwargs, leaves), tiles)
+    return {"values": values, "no_data_value": ndv}
+
+
+reduce_max_process.gm_op = "reduce_max"
+
+
 def compare_dtype(tile_dtype, value):
     """dtype in which NumPy carries out ``tile < value`` for a python scalar ``value``."""
     try:

@@ -152,6 +152,12 @@ enum gm_opcode {
                           (right: e < a); NaN -> nbins; a == ndv_a -> fill.  <= GM_MAX_LINEAR_EDGES edges */
   GM_OP_LOOKUP = 28,   /* Reclassify.process (raster/misc.py:482-515): acc = LUT[a - kmin] inside the dense
                           window, else the matching exception key's target, else select ? fill : a */
+  /* Max = reduce_rasters(stack, "max") (raster/reduction.py:38-119): like NumPy, carried out in a float
+     class with "no data" coded as NaN */
+  GM_OP_NANIFNODATA = 29, /* a where a is data (utils.get_index: isclose rule for float tiles, flags / aux1 /
+                             aux2 as MASK) else NaN */
+  GM_OP_FMAX = 30,        /* np.fmax(a, b) = (a >= b || isnan(b)) ? a : b  -- what np.nanmax reduces with */
+  GM_OP_NANTOFILL = 31,   /* fill where a is NaN else a */
   GM_OP_COUNT
 };
 

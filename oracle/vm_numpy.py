@@ -189,6 +189,26 @@ def run_program(prog, inputs, n):
                     miss = np.where(key == ek, ev, miss)
                 r = np.where(inside, lut[np.where(inside, idx, 0)], miss)
                 nd = np.zeros(n, dtype=bool)
+            elif op == 29:  # nanifnodata
+                if S.flags & 4:
+                    nodata = nda
+                else:
+                    y, tol = S.aux2.f64, S.aux1.f64
+                    y_finite = bool(S.flags & 2)
+                    if S.flags & 1:
+                        x64 = a.astype("f8")
+                        nodata = ((np.abs(x64 - y) <= tol) & y_finite) | (x64 == y)
+                    else:
+                        x32 = a.astype("f4")
+                        nodata = ((np.abs(x32 - np.float32(y)) <= np.float32(tol)) & y_finite) | (x32 == np.float32(y))
+                r = np.where(nodata, rc.type(np.nan), a)
+                nd = np.zeros(n, dtype=bool)
+            elif op == 30:  # fmax
+                r = np.where((a >= b) | np.isnan(b), a, b)
+                nd = np.zeros(n, dtype=bool)
+            elif op == 31:  # nantofill
+                r = a.copy()
+                nd = np.isnan(a)
             else:  # copy
                 r = a.copy()
             if cls == 1 and S.round_f32:

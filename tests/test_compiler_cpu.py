@@ -172,3 +172,42 @@ def test_table_ops_cut_at_the_register_class_boundary(cpu_vm):
     assert stages[0][0].out_dtype == np.dtype("u1") and stages[1][0].out_dtype == np.dtype("i8")
     out = P.run_staged(stages, shape)
     assert_result_equal({"values": out, "no_data_value": stages[-1][0].out_ndv}, want, 0, "two-stage chain")
+
+
+@pytest.mark.parametrize("case", load_family("reduce"), ids=lambda c: c["id"])
+def test_reduce_max(cpu_vm, case):
+    """Max.process = reduce_rasters(stack, "max") as one program (NaN-coded no data + np.fmax)."""
+    args = case["args"]
+    tiles = [a for a in args[1:] if isinstance(a, dict) and "values" in a]
+    if any(t["values"].dtype.itemsize == 8 and t["values"].dtype.kind in "iu" for t in tiles) and \
+            not any("time" in a or "meta" in a for a in args[1:]):
+        with pytest.raises(NotImplementedError):
+            devops.reduce_max_process(*args)
+        return
+    out = devops.reduce_max_process(*args)
+    assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+def test_max_block_fuses_with_its_neighbours(cpu_vm):
+    from dask_geomodeling_amd import raster
+    from dask_geomodeling_amd.fuse import fuse_graph, FusedTask
+    from blocks_util import ArrayLeaf
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(8)
+    fill = np.float32(np.finfo("f4").max)
+    leaves, tiles = [], []
+    for k in range(3):
+        v = (rng.random((1, 32, 48)) * 100).astype("f4")
+        v[0, k::5, ::3] = fill
+        ArrayLeaf.ARRAYS["mx/%d" % k] = {"values": v, "no_data_value": fill}
+        leaves.append(ArrayLeaf("mx/%d" % k, "<f4", fill))
+        tiles.append({"values": v, "no_data_value": fill})
+    view = raster.Max(leaves[0] + 1.5, leaves[1], leaves[2]) * 2.0
+    assert view.dtype == np.dtype("f4")
+    req = dict(mode="vals", bbox=(0.0, 0.0, 48.0, 32.0), width=48, height=32, projection="EPSG:28992")
+    graph, name = view.get_compute_graph(**req)
+    fused = fuse_graph(graph, name)
+    assert sum(isinstance(v[0], FusedTask) for v in fused.values()) == 1 and len(fused) == 4  # 3 leaves + 1 program
+    kw = {"dtype": "float32", "fillvalue": float(fill)}
+    want = O.math_process("multiply", kw, O.reduce_max_process(kw, O.math_process("add", kw, tiles[0], 1.5), tiles[1], tiles[2]), 2.0)
+    assert_result_equal(view.get_data(**req), want, 0, "Max inside a fused chain")

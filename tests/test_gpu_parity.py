@@ -552,3 +552,43 @@ def test_stencil_blocks_end_to_end(gpu):
             assert_result_equal(got, want, 0, type(block).__name__)
     for mode in ("time", "meta"):
         assert raster.MovingMax(src, 3).get_data(mode=mode) == src.get_data(mode=mode)
+
+
+# ---- N4: Max = reduce_rasters(stack, "max") ---------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", load_family("reduce"), ids=lambda c: c["id"])
+def test_reduce_max_golden(gpu, case):
+    args = case["args"]
+    tiles = [a for a in args[1:] if isinstance(a, dict) and "values" in a]
+    if any(t["values"].dtype.itemsize == 8 and t["values"].dtype.kind in "iu" for t in tiles) and \
+            not any("time" in a or "meta" in a for a in args[1:]):
+        with pytest.raises(NotImplementedError):
+            devops.reduce_max_process(*args)
+        return
+    assert_result_equal(devops.reduce_max_process(*args), case["expect"], 0, case["id"])
+
+
+@pytest.mark.gpu
+def test_max_block_on_device(gpu):
+    """(A tie between +0.0 and -0.0 is left out: NumPy's own answer depends on which SIMD maximum its
+    fmax loop was built with.)"""
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(21)
+    fill = np.float32(np.finfo("f4").max)
+    srcs, tiles = [], []
+    for k in range(4):
+        v = (rng.random((1, 64, 96)) * 100 - 50).astype("f4")
+        v[0, k::4, ::3] = fill
+        v[0, 5, 5 + k] = np.nan
+        srcs.append(raster.MemorySource(v, fill, "EPSG:28992", 1.0, (0.0, 64.0)))
+        tiles.append({"values": v, "no_data_value": fill})
+    tiles[0]["values"][0, :3, :3] = fill  # one corner where every raster is no data
+    for t in tiles[1:]:
+        t["values"][0, :3, :3] = fill
+    srcs = [raster.MemorySource(t["values"], fill, "EPSG:28992", 1.0, (0.0, 64.0)) for t in tiles]
+    req = dict(mode="vals", bbox=(0.0, 0.0, 96.0, 64.0), width=96, height=64, projection="EPSG:28992")
+    kw = {"dtype": "float32", "fillvalue": float(fill)}
+    got = raster.Max(*srcs).get_data(**req)
+    # MemorySource turns non-finite source cells into no data (sources.py:148) before Max sees them
+    clean = [{"values": np.where(np.isfinite(t["values"]), t["values"], fill), "no_data_value": fill} for t in tiles]
+    assert_result_equal(got, O.reduce_max_process(kw, *clean), 0, "Max of 4 sources")
