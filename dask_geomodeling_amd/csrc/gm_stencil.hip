@@ -28,25 +28,65 @@ struct DilateArgs {
 
 // grid: x over 256 output columns, y over output rows, z over bands; T compared by bit pattern for
 // integers, by == for floats (NaN never matches, as np.ndarray.__eq__)
+// Column walker: a workgroup owns 256 output columns and walks ST_ROWS rows downwards; a lane keeps
+// the 3 x 3 window of its column in registers and fetches one new row (3 values) per step.  The three
+// loads of a step are contiguous across the lanes (offsets 0, 1, 2 elements), so every
+// wave-instruction touches one 256-byte span (a lane that gathered a whole window itself would
+// spread each instruction over a 1 KiB span at 25 % use and make address processing the limit).
+constexpr int ST_ROWS = 32, ST_BATCH = 4;
+
 template <typename T>
 __global__ __launch_bounds__(256) void dilate_kernel(const T* __restrict__ in, T* __restrict__ out, int bands, int h,
                                                      int w, DilateArgs<T> A) {
-  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y, b = blockIdx.z;
+  const int c = blockIdx.x * 256 + threadIdx.x, r0 = blockIdx.y * ST_ROWS, b = blockIdx.z;
   const int ow = w - 2, oh = h - 2;
   if (c >= ow) return;
   const size_t plane = (size_t)h * w;
-  const T* p = in + (size_t)b * plane + (size_t)(r + 1) * w + (c + 1);  // the centre in the padded tile
-  const T centre = p[0], north = p[-w], south = p[w], west = p[-1], east = p[1];
+  const T* base = in + (size_t)b * plane + c;  // column c of the padded tile = west neighbour of output column c
   const bool has_up = b > 0, has_down = b + 1 < bands;
-  const T up = has_up ? p[-(ptrdiff_t)plane] : centre, down = has_down ? p[plane] : centre;
-  T result = centre;
-  for (int i = 0; i < A.n_values; ++i) {  // in order: later values overwrite earlier ones
-    const T v = A.values[i];
-    const bool hit = (centre == v) | (north == v) | (south == v) | (west == v) | (east == v) |
-                     (has_up & (up == v)) | (has_down & (down == v));
-    result = hit ? v : result;
+  // ST_BATCH new rows are fetched together (3 * ST_BATCH loads in flight) before their cells are
+  // computed: a row-by-row walk would pay one memory round trip per row
+  T rows[ST_BATCH + 2][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    rows[0][j] = base[(size_t)r0 * w + j];
+    rows[1][j] = base[(size_t)(r0 + 1) * w + j];
   }
-  __builtin_nontemporal_store(result, out + ((size_t)b * oh + r) * ow + c);
+  const int r1 = min(r0 + ST_ROWS, oh);
+  for (int rb = r0; rb < r1; rb += ST_BATCH) {
+    T up[ST_BATCH], down[ST_BATCH];
+#pragma unroll
+    for (int i = 0; i < ST_BATCH; ++i) {
+      const bool live = rb + i < r1;
+      const T* row = base + (size_t)(rb + i + 2) * w;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rows[i + 2][j] = live ? row[j] : (T)0;
+      const T* centre = base + (size_t)(rb + i + 1) * w + 1;
+      up[i] = (live && has_up) ? centre[-(ptrdiff_t)plane] : (T)0;
+      down[i] = (live && has_down) ? centre[plane] : (T)0;
+    }
+#pragma unroll
+    for (int i = 0; i < ST_BATCH; ++i) {
+      if (rb + i < r1) {
+        const T* top = rows[i];
+        const T* mid = rows[i + 1];
+        const T* bot = rows[i + 2];
+        T result = mid[1];
+        for (int k = 0; k < A.n_values; ++k) {  // in order: later values overwrite earlier ones
+          const T v = A.values[k];
+          const bool hit = (mid[1] == v) | (top[1] == v) | (bot[1] == v) | (mid[0] == v) | (mid[2] == v) |
+                           (has_up & (up[i] == v)) | (has_down & (down[i] == v));
+          result = hit ? v : result;
+        }
+        __builtin_nontemporal_store(result, out + ((size_t)b * oh + rb + i) * ow + c);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      rows[0][j] = rows[ST_BATCH][j];
+      rows[1][j] = rows[ST_BATCH + 1][j];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -54,7 +94,9 @@ __global__ __launch_bounds__(256) void dilate_kernel(const T* __restrict__ in, T
 // ---------------------------------------------------------------------------------
 constexpr int MM_TILE_H = 32, MM_TILE_W = 64;
 
-template <typename T>
+// RMAX: largest radius of the instantiation (bounds the staging loops at compile time so that all of
+// a wave's window loads are in flight together instead of one load-wait-store round trip per row)
+template <typename T, int RMAX>
 __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
                                                          int size, int has_ndv, T ndv, T minimum) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -67,11 +109,25 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
   const int pitch = MM_TILE_W + 2 * radius;
   // stage the window, no-data lowered to the dtype's minimum (spatial.py:199-203)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int y = wave; y < win_h; y += 4) {
-    const T* row = sband + (size_t)(r0 + y) * w + c0;
-    for (int x = lane; x < win_w; x += 64) {
-      const T v = row[x];
-      tile[y * pitch + x] = (has_ndv && v == ndv) ? minimum : v;
+  constexpr int ROWS_PER_WAVE = (MM_TILE_H + 2 * RMAX + 3) / 4, CHUNKS = (MM_TILE_W + 2 * RMAX + 63) / 64;
+  T staged[ROWS_PER_WAVE][CHUNKS];
+#pragma unroll
+  for (int i = 0; i < ROWS_PER_WAVE; ++i) {
+    const int y = wave + 4 * i;
+#pragma unroll
+    for (int j = 0; j < CHUNKS; ++j) {
+      const int x = lane + 64 * j;
+      staged[i][j] = (y < win_h && x < win_w) ? sband[(size_t)(r0 + y) * w + c0 + x] : minimum;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ROWS_PER_WAVE; ++i) {
+    const int y = wave + 4 * i;
+#pragma unroll
+    for (int j = 0; j < CHUNKS; ++j) {
+      const int x = lane + 64 * j;
+      const T v = staged[i][j];
+      if (y < win_h && x < win_w) tile[y * pitch + x] = (has_ndv && v == ndv) ? minimum : v;
     }
   }
   __syncthreads();
@@ -89,9 +145,12 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
         }
       }
     }
-    // still the minimum on a no-data centre: no-data again (spatial.py:208-209)
-    const T centre = sband[(size_t)(r0 + rr + radius) * w + (c0 + c + radius)];
-    if (has_ndv && best == minimum && centre == ndv) best = ndv;
+    // still the minimum on a no-data centre: no-data again (spatial.py:208-209).  Rare: only then is the
+    // original centre fetched (the LDS copy cannot tell "was no data" from "is the minimum")
+    if (has_ndv && best == minimum) {
+      const T centre = sband[(size_t)(r0 + rr + radius) * w + (c0 + c + radius)];
+      if (centre == ndv) best = ndv;
+    }
     __builtin_nontemporal_store(best, out + ((size_t)b * oh + (r0 + rr)) * ow + (c0 + c));
   }
 }
@@ -102,7 +161,7 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
 struct HillArgs {
   double xres, yres;       // division of integer / float64 tiles happens in float64
   float xres32, yres32;    // float32 tiles divide by the float32-rounded resolution (NumPy weak scalar)
-  float sin_alt, cos_alt_zsf, square_zsf, az32;
+  float sin_alt, cos_alt_zsf, square_zsf, cos_az, sin_az;
 };
 
 // T arithmetic exactly as NumPy carries it out on a T array: integers wrap modulo 2^bits,
@@ -122,32 +181,54 @@ __device__ __forceinline__ float gradient(T a, T b2, T c, T d, T e2, T f, double
   }
 }
 
+// Column walker like dilate_kernel: 3 x 3 window of the lane's column in registers, one new row of
+// three contiguous-across-lanes loads per step.
+// sin(arctan2(y, x) - az) * sqrt(x^2 + y^2) = y cos(az) - x sin(az): the trigonometry of
+// spatial.py:407-412 collapses into two multiplications (a few float32 ulp away from NumPy's
+// arctan2 -> sin -> sqrt chain, i.e. far inside the +-1 tolerance of the truncating uint8 cast).
 template <typename T>
 __global__ __launch_bounds__(256) void hillshade_kernel(const T* __restrict__ in, unsigned char* __restrict__ out, int h,
                                                         int w, int has_ndv, T ndv, T fill, HillArgs A) {
-  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y, b = blockIdx.z;
+  const int c = blockIdx.x * 256 + threadIdx.x, r0 = blockIdx.y * ST_ROWS, b = blockIdx.z;
   const int ow = w - 2, oh = h - 2;
   if (c >= ow) return;
-  const T* p = in + (size_t)b * h * w + (size_t)r * w + c;  // top-left of the 3x3 window
-  T v[3][3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
+  const T* base = in + (size_t)b * h * w + c;
+  auto fetch = [&](int row, T (&v)[3]) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const T x = p[(size_t)i * w + j];
-      v[i][j] = (has_ndv && x == ndv) ? fill : x;  // spatial.py:363-364
+      const T x = base[(size_t)row * w + j];
+      v[j] = (has_ndv && x == ndv) ? fill : x;  // spatial.py:363-364
     }
-  // spatial.py:384-404 (s0..s8 = rows top/middle/bottom x columns left/middle/right)
-  const float y = gradient<T>(v[0][0], v[0][1], v[0][2], v[2][0], v[2][1], v[2][2], A.yres, A.yres32);
-  const float x = gradient<T>(v[0][0], v[1][0], v[2][0], v[0][2], v[1][2], v[2][2], A.xres, A.xres32);
-  const float xx_plus_yy = x * x + y * y;
-  // float32 arctan2 / sin of NumPy are reproduced as the float32 rounding of the float64 functions
-  const float aspect = (float)atan2((double)y, (double)x);
-  const float shade = (float)sin((double)(aspect - A.az32));
-  const float cang = (A.sin_alt - ((A.cos_alt_zsf * sqrtf(xx_plus_yy)) * shade)) / sqrtf(1.0f + A.square_zsf * xx_plus_yy);
-  const float scaled = 255.0f * cang;
-  const unsigned char result = (cang <= 0.0f) ? (unsigned char)0 : (unsigned char)(int)scaled;
-  out[((size_t)b * oh + r) * ow + c] = result;
+  };
+  T rows[ST_BATCH + 2][3];
+  fetch(r0, rows[0]);
+  fetch(r0 + 1, rows[1]);
+  const int r1 = min(r0 + ST_ROWS, oh);
+  for (int rb = r0; rb < r1; rb += ST_BATCH) {
+#pragma unroll
+    for (int i = 0; i < ST_BATCH; ++i) {  // ST_BATCH rows of loads in flight together
+      if (rb + i < r1) fetch(rb + i + 2, rows[i + 2]);
+    }
+#pragma unroll
+    for (int i = 0; i < ST_BATCH; ++i) {
+      if (rb + i < r1) {
+        const T* top = rows[i];
+        const T* mid = rows[i + 1];
+        const T* bot = rows[i + 2];
+        // spatial.py:384-404 (s0..s8 = rows top/middle/bottom x columns left/middle/right)
+        const float y = gradient<T>(top[0], top[1], top[2], bot[0], bot[1], bot[2], A.yres, A.yres32);
+        const float x = gradient<T>(top[0], mid[0], bot[0], top[2], mid[2], bot[2], A.xres, A.xres32);
+        const float xx_plus_yy = x * x + y * y;
+        const float cang = (A.sin_alt - A.cos_alt_zsf * (y * A.cos_az - x * A.sin_az)) / sqrtf(1.0f + A.square_zsf * xx_plus_yy);
+        out[((size_t)b * oh + rb + i) * ow + c] = (cang <= 0.0f) ? (unsigned char)0 : (unsigned char)(int)(255.0f * cang);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      rows[0][j] = rows[ST_BATCH][j];
+      rows[1][j] = rows[ST_BATCH + 1][j];
+    }
+  }
 }
 
 template <typename T>
@@ -173,10 +254,10 @@ int gm_dilate(const void* in, int dtype, int bands, int h, int w, const uint64_t
   if (!in || !out || (!values_bits && n_values)) return gm::fail(GM_ERR_INVALID, "null pointer");
   if (bands <= 0 || h < 3 || w < 3) return gm::fail(GM_ERR_INVALID, "gm_dilate: tile %dx%dx%d has no interior", bands, h, w);
   if (n_values < 0 || n_values > DIL_MAX_VALUES) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: %d values (max %d)", n_values, DIL_MAX_VALUES);
-  if (bands > 65535 || h - 2 > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: tile too tall / too many bands");
+  if (bands > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: too many bands");
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
-  dim3 grid((unsigned)((w - 2 + 255) / 256), (unsigned)(h - 2), (unsigned)bands);
+  dim3 grid((unsigned)((w - 2 + 255) / 256), (unsigned)((h - 2 + ST_ROWS - 1) / ST_ROWS), (unsigned)bands);
 #define GM_DIL(T)                                                                                    \
   do {                                                                                               \
     DilateArgs<T> A;                                                                                 \
@@ -213,10 +294,17 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
   if (!s) return GM_ERR_NO_DEVICE;
   dim3 grid((unsigned)((ow + MM_TILE_W - 1) / MM_TILE_W), (unsigned)((oh + MM_TILE_H - 1) / MM_TILE_H), (unsigned)bands);
   if (grid.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: tile too tall");
-#define GM_MM(T)                                                                                              \
-  hipLaunchKernelGGL(moving_max_kernel<T>, grid, dim3(256),                                                   \
+#define GM_MM_R(T, RMAX_)                                                                                      \
+  hipLaunchKernelGGL((moving_max_kernel<T, RMAX_>), grid, dim3(256),                                           \
                      (size_t)(MM_TILE_H + 2 * radius) * (MM_TILE_W + 2 * radius) * sizeof(T), s, (const T*)in, \
                      (T*)out, h, w, size, has_ndv, from_bits<T>(ndv_bits), lowest<T>())
+#define GM_MM(T)                           \
+  do {                                     \
+    if (radius <= 3) GM_MM_R(T, 3);        \
+    else if (radius <= 7) GM_MM_R(T, 7);   \
+    else if (radius <= 15) GM_MM_R(T, 15); \
+    else GM_MM_R(T, 31);                   \
+  } while (0)
   switch (dtype) {
     case GM_U8: GM_MM(unsigned char); break;
     case GM_I8: GM_MM(signed char); break;
@@ -231,6 +319,7 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
     default: return gm::fail(GM_ERR_INVALID, "gm_moving_max: dtype %d", dtype);
   }
 #undef GM_MM
+#undef GM_MM_R
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
@@ -239,7 +328,7 @@ int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv
                  double xres, double yres, double altitude_deg, double azimuth_deg, void* out) {
   if (!in || !out) return gm::fail(GM_ERR_INVALID, "null pointer");
   if (bands <= 0 || h < 3 || w < 3) return gm::fail(GM_ERR_INVALID, "gm_hillshade: tile %dx%dx%d has no interior", bands, h, w);
-  if (bands > 65535 || h - 2 > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_hillshade: tile too tall / too many bands");
+  if (bands > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_hillshade: too many bands");
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
   const double pi = 3.141592653589793;
@@ -253,8 +342,9 @@ int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv
   A.sin_alt = (float)sin(alt);              // python floats meet float32 arrays as weak scalars:
   A.cos_alt_zsf = (float)(cos(alt) * zsf);  // the product of python floats is rounded to float32 once
   A.square_zsf = (float)(zsf * zsf);
-  A.az32 = (float)az;
-  dim3 grid((unsigned)((w - 2 + 255) / 256), (unsigned)(h - 2), (unsigned)bands);
+  A.cos_az = (float)cos(az);
+  A.sin_az = (float)sin(az);
+  dim3 grid((unsigned)((w - 2 + 255) / 256), (unsigned)((h - 2 + ST_ROWS - 1) / ST_ROWS), (unsigned)bands);
 #define GM_HS(T)                                                                                          \
   hipLaunchKernelGGL(hillshade_kernel<T>, grid, dim3(256), 0, s, (const T*)in, (unsigned char*)out, h, w, \
                      has_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A)

@@ -48,7 +48,9 @@ def cpu_vm(monkeypatch):
     from dask_geomodeling_amd.hip import program, runtime
     from oracle import vm_numpy
 
+    from dask_geomodeling_amd.raster import tables
     monkeypatch.setattr(runtime, "require_device", lambda: None)
+    monkeypatch.setattr(tables, "_PREFER_PROGRAM", True)  # lone table ops too run as program steps here
     monkeypatch.setattr(program, "as_device", lambda v: np.asarray(v))
     monkeypatch.setattr(program, "as_device_view", lambda v: np.asarray(v))
     monkeypatch.setattr(program, "launch", vm_numpy.launch)

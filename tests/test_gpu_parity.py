@@ -144,8 +144,7 @@ def test_device_array_roundtrip_and_checksum(gpu):
 @pytest.mark.parametrize("case", load_family("classify"), ids=lambda c: c["id"])
 def test_classify_golden(gpu, case, route, monkeypatch):
     from dask_geomodeling_amd.raster import tables
-    if route == "kernel":
-        monkeypatch.setattr(tables, "_try_program", lambda node: None)
+    monkeypatch.setattr(tables, "_PREFER_PROGRAM", route == "program")
     out = tables.classify_process(*case["args"])
     assert_result_equal(out, case["expect"], 0, case["id"])
 
@@ -157,19 +156,20 @@ def test_reclassify_golden(gpu, case, route, monkeypatch):
     from dask_geomodeling_amd.raster import tables
     if "raises" in case:
         pytest.skip("reference raises %s" % case["raises"])
-    if route == "kernel":
-        monkeypatch.setattr(tables, "_try_program", lambda node: None)
+    monkeypatch.setattr(tables, "_PREFER_PROGRAM", route == "program")
     out = tables.reclassify_process(*case["args"])
     assert_result_equal(out, case["expect"], 0, case["id"])
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("route", ["program", "kernel"])
 @pytest.mark.parametrize("n", [7, 4096, 70001])
 @pytest.mark.parametrize("in_dtype", ["u1", "i2", "i4", "i8"])
-def test_table_ops_big_tiles_vs_oracle(gpu, n, in_dtype):
+def test_table_ops_big_tiles_vs_oracle(gpu, n, in_dtype, route, monkeypatch):
     """Random tiles through Classify (few and many edges, both sides) and Reclassify (dense window +
     far no-data key, sparse keys, select on/off, float targets) on both routes, against the oracle."""
     from dask_geomodeling_amd.raster import tables
+    monkeypatch.setattr(tables, "_PREFER_PROGRAM", route == "program")
     rng = np.random.default_rng(n)
     ndv = int(np.iinfo(in_dtype).max)
     v = rng.integers(0, 120, size=(1, 1, n)).astype(in_dtype)

@@ -9,7 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dask_geomodeling_amd.hip import runtime  # noqa: E402
-from dask_geomodeling_amd.raster import devops, resample, tables  # noqa: E402
+from dask_geomodeling_amd.raster import devops, resample, stencil, tables  # noqa: E402
 from dask_geomodeling_amd.raster.sources import generate_window  # noqa: E402
 
 F32MAX = float(np.finfo("f4").max)
@@ -32,7 +32,7 @@ def timeit(label, bytes_per_call, calls, reps=3):
 
 
 def main():
-    which = [a for a in sys.argv[1:] if "=" not in a] or ["reclass", "classify", "mask", "bilinear", "nearest"]
+    which = [a for a in sys.argv[1:] if "=" not in a] or ["reclass", "classify", "mask", "bilinear", "nearest", "stencil"]
     opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
     side = int(opts.get("side", 8192))
     runtime.set_device(0)
@@ -77,6 +77,18 @@ def main():
         timeit("bilinear f32 1.5x upsample (5.78 B/out px)", (4 + 4 / 2.25) * 2.25 * n,
                [lambda t=t: resample.bilinear(t, side * 3 // 2, side * 3 // 2, np.float32(F32MAX)) for t in src])
         del src
+    if "stencil" in which:
+        src = [generate_window((side, side), "f4", 90 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side, side) for i in range(T)]
+        m = (side - 2) * (side - 2)
+        timeit("hillshade f32 -> u8 (5 B/px)", 5.0 * m,
+               [lambda t=t: stencil.hillshade(t, np.float32(F32MAX), 0, (0.5, 0.5), 45.0, 315.0) for t in src])
+        for size in (3, 7, 15):
+            timeit("moving max f32, size %d (8 B/px)" % size, 8.0 * (side - size + 1) ** 2,
+                   [lambda t=t: stencil.moving_max(t, np.float32(F32MAX), size) for t in src])
+        u8 = [generate_window((side, side), "u1", 95 + i, 0.0, 6.0, 255, (50, 50), 0, 0, side, side) for i in range(T)]
+        timeit("dilate u8, 2 values (2 B/px)", 2.0 * m, [lambda t=t: stencil.dilate(t, [1, 3]) for t in u8])
+        timeit("dilate f32, 2 values (8 B/px)", 8.0 * m, [lambda t=t: stencil.dilate(t, [1.0, 3.0]) for t in src])
+        del src, u8
     if "nearest" in which:
         src = [generate_window((side, side), "f4", 80 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side, side) for i in range(T)]
         gt = (0.0, 1.0, 0.0, float(side), 0.0, -1.0)
