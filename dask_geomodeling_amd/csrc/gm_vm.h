@@ -326,7 +326,6 @@ struct Machine {
   static constexpr bool HEAVY = FLAVOR == VM_MATH;
   static constexpr bool TABLES = FLAVOR == VM_TABLES;
   RC in[NIN][N];
-  int lds_table = -1;  // TABLES: index of the table whose dense window sits in LDS
   RC tmp0[N], tmp1[N], tmp2[N], tmp3[N];  // separate members, selected at compile time only: an
   RC acc[N];                               // array of arrays ends up in scratch for NT >= 2
 
@@ -557,7 +556,6 @@ struct Machine {
         }
       } break;
       case GM_OP_DIGITIZE:
-#ifndef GM_EXP_NO_DIGITIZE
         if constexpr (TABLES) {
           // misc.py:387-399.  Edge-major linear count: every edge is one scalar load (wave-uniform),
           // v_cmp + v_addc per element; <= GM_MAX_LINEAR_EDGES edges.  Comparisons in the type NumPy's
@@ -600,10 +598,8 @@ struct Machine {
             acc[k] = (a_has & (acc[k] == a_ndv)) ? fill : (RC)c;
           }
         }
-#endif
         break;
       case GM_OP_LOOKUP:
-#ifndef GM_EXP_NO_LOOKUP
         if constexpr (TABLES) {
           // misc.py:505-514.  Dense window of pre-resolved targets (entries in the register class'
           // own width) + keys outside the window -- typically only the merged-in no-data key --
@@ -653,7 +649,6 @@ struct Machine {
 #pragma unroll
           for (int k = 0; k < N; ++k) acc[k] = idx[k] < range ? hit[k] : acc[k];
         }
-#endif
         break;
       case GM_OP_NANIFNODATA:
         if constexpr (is_float_class<RC>::value) {
@@ -961,7 +956,6 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
   if constexpr (FLAVOR == VM_TABLES) {
     const unsigned lds_table = GM_KARG(K, lds_table);
     if (lds_table) {
-      M.lds_table = (int)lds_table - 1;
       if (span == 0) {  // stage the LOOKUP window while the tile loads are in flight
         extern __shared__ __align__(16) unsigned long long vm_lds[];
         const unsigned words = GM_KARG(K, lds_words);

@@ -592,3 +592,39 @@ def test_max_block_on_device(gpu):
     # MemorySource turns non-finite source cells into no data (sources.py:148) before Max sees them
     clean = [{"values": np.where(np.isfinite(t["values"]), t["values"], fill), "no_data_value": fill} for t in tiles]
     assert_result_equal(got, O.reduce_max_process(kw, *clean), 0, "Max of 4 sources")
+
+
+# ---- threaded scheduler: process bodies are re-entrant --------------------------------------------
+@pytest.mark.gpu
+def test_process_bodies_from_concurrent_threads(gpu):
+    """dask's threaded scheduler calls ``process`` from a pool (ctypes releases the GIL during the
+    calls): 8 threads hammer element-wise programs, table kernels and the allocator at once; every
+    result must equal the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    from dask_geomodeling_amd.raster import tables
+    fill = np.float32(np.finfo("f4").max)
+
+    def job(seed):
+        rng = np.random.default_rng(seed)
+        shape = (1, 64 + seed, 96)
+        a = (rng.random(shape) * 100).astype("f4")
+        b = (rng.random(shape) * 100).astype("f4")
+        a[0, ::7, seed % 5::9] = fill
+        A, B = {"values": a, "no_data_value": fill}, {"values": b, "no_data_value": fill}
+        kw = {"dtype": "float32", "fillvalue": float(fill)}
+        ok = True
+        for _ in range(20):
+            got = devops.clip_process(devops.math_process("multiply", kw, devops.math_process("add", kw, A, B), 1.0 + seed), A)
+            want = O.clip_process(O.math_process("multiply", kw, O.math_process("add", kw, A, B), 1.0 + seed), A)
+            ok &= np.array_equal(np.asarray(got["values"]).view("u4"), want["values"].view("u4"))
+            bins = [10.0 * k + seed for k in range(1, 6 + seed)]
+            c_got, c_want = tables.classify_process(A, bins, bool(seed % 2)), O.classify_process(A, bins, bool(seed % 2))
+            ok &= np.array_equal(np.asarray(c_got["values"]), c_want["values"])
+            table = {"dtype": "<i8", "fillvalue": int(np.iinfo("i8").max), "select": bool(seed % 2),
+                     "data": [[k, k * (seed + 2)] for k in range(0, 8)]}
+            r_got, r_want = tables.reclassify_process(c_got, table), O.reclassify_process(c_want, table)
+            ok &= np.array_equal(np.asarray(r_got["values"]), r_want["values"])
+        return ok
+
+    with ThreadPoolExecutor(8) as pool:
+        assert all(pool.map(job, range(8)))
