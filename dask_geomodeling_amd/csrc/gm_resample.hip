@@ -45,12 +45,18 @@ __device__ __forceinline__ bool is_finite_t(T v) {
   else return true;
 }
 
-// grid: x = groups of 4 destination columns (256 lanes -> 1024 columns), y = row strips, z = band
+// grid: x = groups of 4 destination columns (256 lanes -> 1024 columns), y = row strips, z = band.
+// Two things keep the gather close to a copy: (1) when the 4 source columns of a lane are consecutive
+// (no resampling along x: windows, identity grids) they are fetched as ONE 16-byte load; (2) when the
+// next destination row maps to the source row just read (up-sampling along y) the registers are
+// reused instead of gathering again.
 template <typename T, int ROWS>
 __global__ __launch_bounds__(256) void nearest_gather_kernel(const T* __restrict__ src, T* __restrict__ dst, int hs,
                                                              int ws, int hd, int wd, const int* __restrict__ row_idx,
                                                              const int* __restrict__ col_idx, T fill,
                                                              int finite_to_fill) {
+  typedef T VT __attribute__((ext_vector_type(4)));
+  typedef T VTU __attribute__((ext_vector_type(4), aligned(sizeof(T))));  // element-aligned 4-vector
   const int band = blockIdx.z;
   const int c0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (c0 >= wd) return;
@@ -59,30 +65,49 @@ __global__ __launch_bounds__(256) void nearest_gather_kernel(const T* __restrict
   int ci[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) ci[k] = (c0 + k < wd) ? col_idx[c0 + k] : -1;
+  const bool run = (ci[0] >= 0) & (ci[1] == ci[0] + 1) & (ci[2] == ci[0] + 2) & (ci[3] == ci[0] + 3);
   const int r_begin = blockIdx.y * ROWS;
   const bool vec_ok = (c0 + 3 < wd) && ((wd & 3) == 0) && ((((uintptr_t)dband) % (4 * sizeof(T))) == 0);
-  for (int r = r_begin; r < r_begin + ROWS && r < hd; ++r) {
-    const int ri = row_idx[r];  // wave-uniform
-    T v[4];
+  // all ROWS source rows of the strip are requested before the first store (ROWS independent
+  // gathers in flight per lane instead of one load-store round trip per row)
+  T v[ROWS][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      T x = fill;
-      if (ri >= 0 && ci[k] >= 0) {
-        x = sband[(size_t)ri * ws + ci[k]];
-        if (finite_to_fill && !is_finite_t<T>(x)) x = fill;
-      }
-      v[k] = x;
+  for (int i = 0; i < ROWS; ++i) {
+    const int r = r_begin + i;
+    const int ri = r < hd ? row_idx[r] : -1;                       // wave-uniform
+    const int prev = (i > 0 && r - 1 < hd) ? row_idx[r - 1] : -2;  // (scalar loads, cached)
+    if (i > 0 && ri == prev) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[i][k] = v[i - 1][k];
+    } else if (ri < 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[i][k] = fill;
+    } else if (run) {
+      const VTU x = *(const VTU*)(sband + (size_t)ri * ws + ci[0]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[i][k] = x[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[i][k] = (ci[k] >= 0) ? sband[(size_t)ri * ws + ci[k]] : fill;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const int r = r_begin + i;
+    if (r >= hd) break;
+    if (finite_to_fill) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[i][k] = is_finite_t<T>(v[i][k]) ? v[i][k] : fill;
     }
     T* out = dband + (size_t)r * wd + c0;
     if (vec_ok) {
-      typedef T VT __attribute__((ext_vector_type(4)));
       VT pack;
-      pack[0] = v[0]; pack[1] = v[1]; pack[2] = v[2]; pack[3] = v[3];
-      *(VT*)out = pack;
+      pack[0] = v[i][0]; pack[1] = v[i][1]; pack[2] = v[i][2]; pack[3] = v[i][3];
+      __builtin_nontemporal_store(pack, (VT*)out);
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (c0 + k < wd) out[k] = v[k];
+        if (c0 + k < wd) out[k] = v[i][k];
     }
   }
 }
@@ -238,15 +263,23 @@ int gm_resample_nearest(const void* src, int dtype, int bands, int hs, int ws, v
                      row_params[0], row_params[1], row_params[2], row_params[3], eps);
   hipLaunchKernelGGL(nearest_index_kernel, dim3((wd + 255) / 256), dim3(256), 0, s, col_idx, wd, ws, mode,
                      col_params[0], col_params[1], col_params[2], col_params[3], eps);
-  constexpr int ROWS = 8;
+  // rows per workgroup: 4 streams best (identity grid: 72 % of peak, 8 rows: 66 %); when the
+  // request up-samples along y, 8 rows share more source rows (2x: 61 % against 57 %)
+  const int ROWS = hd > hs ? 8 : 4;
   dim3 grid((unsigned)((wd + 1023) / 1024), (unsigned)((hd + ROWS - 1) / ROWS), (unsigned)bands);
   if (grid.y > 65535) {
     gm_free(tables);
     return gm::fail(GM_ERR_UNSUPPORTED, "destination taller than %d rows", 65535 * ROWS);
   }
-#define GM_NEAREST(T, FILL)                                                                                    \
-  hipLaunchKernelGGL((nearest_gather_kernel<T, ROWS>), grid, dim3(256), 0, s, (const T*)src, (T*)dst, hs, ws, \
-                     hd, wd, row_idx, col_idx, (T)(FILL), finite_to_fill)
+#define GM_NEAREST(T, FILL)                                                                                       \
+  do {                                                                                                            \
+    if (ROWS == 8)                                                                                                \
+      hipLaunchKernelGGL((nearest_gather_kernel<T, 8>), grid, dim3(256), 0, s, (const T*)src, (T*)dst, hs, ws,    \
+                         hd, wd, row_idx, col_idx, (T)(FILL), finite_to_fill);                                    \
+    else                                                                                                          \
+      hipLaunchKernelGGL((nearest_gather_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)src, (T*)dst, hs, ws,    \
+                         hd, wd, row_idx, col_idx, (T)(FILL), finite_to_fill);                                    \
+  } while (0)
   switch (dtype) {
     case GM_BOOL: case GM_U8: case GM_I8: GM_NEAREST(unsigned char, fill.i64); break;
     case GM_U16: case GM_I16: GM_NEAREST(unsigned short, fill.i64); break;
