@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void dilate_kernel(const T* __restrict__ in, T
 // ---------------------------------------------------------------------------------
 // MovingMax
 // ---------------------------------------------------------------------------------
-constexpr int MM_TILE_H = 32, MM_TILE_W = 64;
+constexpr int MM_TILE_H = 16, MM_TILE_W = 64;
 
 // RMAX: largest radius of the instantiation (bounds the staging loops at compile time so that all of
 // a wave's window loads are in flight together instead of one load-wait-store round trip per row)
@@ -131,20 +131,42 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
     }
   }
   __syncthreads();
-  const int c = threadIdx.x & 63;
+  // A lane owns 4 CONSECUTIVE output rows of one column.  The circle is scanned column by column
+  // (wave-uniform dx): the vertical runs of the 4 outputs overlap in all but 3 rows at either end,
+  // so the shared core is read and reduced once -- (2 hh + 4) LDS reads per column for 4 outputs
+  // instead of 4 (2 hh + 1); consecutive lanes read consecutive addresses (no bank conflicts).
+  const int c = threadIdx.x & 63, o0 = (threadIdx.x >> 6) * 4;
   if (c0 + c >= ow) return;
   const int s2 = size * size;
-  for (int rr = threadIdx.x >> 6; rr < MM_TILE_H && r0 + rr < oh; rr += 4) {
-    T best = minimum;
-    for (int dy = 0; dy < size; ++dy) {
-      for (int dx = 0; dx < size; ++dx) {  // wave-uniform footprint test: (x^2 + y^2) < (size/2)^2 (utils.py:536-547)
-        const int yy = dy - radius, xx = dx - radius;
-        if (4 * (xx * xx + yy * yy) < s2) {
-          const T v = tile[(rr + dy) * pitch + (c + dx)];
-          best = v > best ? v : best;
-        }
-      }
+  T m[4] = {minimum, minimum, minimum, minimum};
+  auto up = [](T a, T b) -> T { return b > a ? b : a; };
+  for (int dx = 0; dx < size; ++dx) {
+    const int xx = dx - radius;
+    int hh = -1;  // half-height of the footprint's column: (x^2 + y^2) < (size/2)^2 (utils.py:536-547)
+    while (4 * (xx * xx + (hh + 1) * (hh + 1)) < s2) ++hh;
+    if (hh < 0) continue;
+    const T* col = tile + (c + dx);
+    const int first = o0 + radius - hh;  // window row of the topmost cell of output 0's run
+    if (hh == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = up(m[k], col[(first + k) * pitch]);
+      continue;
     }
+    const T l0 = col[first * pitch], l1 = col[(first + 1) * pitch], l2 = col[(first + 2) * pitch];
+    const int after = first + 2 * hh + 1;
+    const T r0v = col[after * pitch], r1v = col[(after + 1) * pitch], r2v = col[(after + 2) * pitch];
+    T core = minimum;
+    for (int y = first + 3; y < after; ++y) core = up(core, col[y * pitch]);
+    m[0] = up(m[0], up(core, up(l0, up(l1, l2))));
+    m[1] = up(m[1], up(core, up(l1, up(l2, r0v))));
+    m[2] = up(m[2], up(core, up(l2, up(r0v, r1v))));
+    m[3] = up(m[3], up(core, up(r0v, up(r1v, r2v))));
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int rr = o0 + k;
+    if (r0 + rr >= oh) break;
+    T best = m[k];
     // still the minimum on a no-data centre: no-data again (spatial.py:208-209).  Rare: only then is the
     // original centre fetched (the LDS copy cannot tell "was no data" from "is the minimum")
     if (has_ndv && best == minimum) {
@@ -290,13 +312,15 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
   const int oh = h - 2 * radius, ow = w - 2 * radius;
   if (bands <= 0 || oh <= 0 || ow <= 0) return gm::fail(GM_ERR_INVALID, "gm_moving_max: tile smaller than the footprint");
   if (bands > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: too many bands");
+  if ((size_t)(MM_TILE_H + 2 * radius) * (MM_TILE_W + 2 * radius) * (size_t)gm::dtype_size(dtype) > 65536)
+    return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: the window of a size-%d footprint does not fit 64 KiB of LDS for this dtype", size);
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
   dim3 grid((unsigned)((ow + MM_TILE_W - 1) / MM_TILE_W), (unsigned)((oh + MM_TILE_H - 1) / MM_TILE_H), (unsigned)bands);
   if (grid.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: tile too tall");
 #define GM_MM_R(T, RMAX_)                                                                                      \
   hipLaunchKernelGGL((moving_max_kernel<T, RMAX_>), grid, dim3(256),                                           \
-                     (size_t)(MM_TILE_H + 2 * radius) * (MM_TILE_W + 2 * radius) * sizeof(T), s, (const T*)in, \
+                     (size_t)(MM_TILE_H + 2 * radius) * (MM_TILE_W + 2 * radius) * sizeof(T), s, (const T*)in,   \
                      (T*)out, h, w, size, has_ndv, from_bits<T>(ndv_bits), lowest<T>())
 #define GM_MM(T)                           \
   do {                                     \
