@@ -5,3 +5,4 @@ from .sources import *  # noqa: F401,F403
 from .parallelize import *  # noqa: F401,F403
 from .spatial import *  # noqa: F401,F403
 from .reduction import *  # noqa: F401,F403
+from .combine import *  # noqa: F401,F403

@@ -111,6 +111,10 @@ class Extent(object):
             return result
         return None
 
+    def union(self, other):
+        a, b = self.bbox, other.transformed(self.srs).bbox
+        return Extent((min(a[0], b[0]), min(a[1], b[1]), max(a[2], b[2]), max(a[3], b[3])), self.srs)
+
     def as_geometry(self):
         return BoxGeometry(self.bbox, self.srs)
 

@@ -67,3 +67,63 @@ def leaves_for(case, kind="array"):
             blocks[name] = raster.MemorySource(vals, data["no_data_value"], "EPSG:28992", 1.0,
                                                (0.0, float(vals.shape[1])))
     return blocks
+
+
+class TemporalLeaf(RasterBlock):
+    """Test-only temporal leaf: ``times`` frames (ISO strings), ``delta_s`` seconds apart or free
+    (None); answers vals / time / meta requests the way the golden generator's probe does."""
+
+    ARRAYS = {}
+
+    def __init__(self, name, dtype_str, ndv, times_iso, delta_s):
+        super().__init__(name, dtype_str, ndv, times_iso, delta_s)
+
+    dtype = property(lambda self: np.dtype(self.args[1]))
+    fillvalue = property(lambda self: self.args[2])
+    extent = None
+    geometry = None
+    projection = "EPSG:28992"
+    geo_transform = None
+
+    @property
+    def times(self):
+        return [datetime.fromisoformat(t) for t in self.args[3]]
+
+    @property
+    def period(self):
+        t = self.times
+        return (t[0], t[-1]) if t else None
+
+    @property
+    def timedelta(self):
+        from datetime import timedelta
+        return None if self.args[4] is None else timedelta(seconds=self.args[4])
+
+    @property
+    def temporal(self):
+        return self.args[4] is not None or len(self.args[3]) > 1
+
+    def get_sources_and_requests(self, **request):
+        return [({"name": self.args[0], "times": self.args[3], "mode": request["mode"],
+                  "start": request.get("start"), "stop": request.get("stop")}, None)]
+
+    @staticmethod
+    def process(kw):
+        times = [datetime.fromisoformat(t) for t in kw["times"]]
+        start, stop = kw["start"], kw["stop"]
+        if not times:
+            return None
+        if start is None:
+            sel = [len(times) - 1]
+        elif stop is None:
+            sel = [min(range(len(times)), key=lambda i: abs(times[i] - start))]
+        else:
+            sel = [i for i, t in enumerate(times) if start <= t <= stop]
+        if kw["mode"] == "time":
+            return {"time": [times[i] for i in sel]}
+        if kw["mode"] == "meta":
+            return {"meta": ["%s/%d" % (kw["name"], i) for i in sel]}
+        if not sel:
+            return None
+        data = TemporalLeaf.ARRAYS[kw["name"]]
+        return {"values": data["values"][sel], "no_data_value": data["no_data_value"]}

@@ -51,6 +51,9 @@ def cpu_vm(monkeypatch):
     from dask_geomodeling_amd.raster import tables
     monkeypatch.setattr(runtime, "require_device", lambda: None)
     monkeypatch.setattr(tables, "_PREFER_PROGRAM", True)  # lone table ops too run as program steps here
+    from dask_geomodeling_amd.raster import combine
+    monkeypatch.setattr(combine, "_stack_bands", lambda bands, dtype, fill, shape_yx: np.concatenate(
+        [np.full((1,) + tuple(shape_yx), fill, dtype) if b is None else np.asarray(b) for b in bands], axis=0))
     monkeypatch.setattr(program, "as_device", lambda v: np.asarray(v))
     monkeypatch.setattr(program, "as_device_view", lambda v: np.asarray(v))
     monkeypatch.setattr(program, "launch", vm_numpy.launch)

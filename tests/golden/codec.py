@@ -5,6 +5,7 @@ matters for NumPy's promotion rules, e.g. in ``np.isclose``).
 Test infrastructure only.
 """
 import json
+from datetime import datetime
 
 import numpy as np
 
@@ -33,6 +34,8 @@ class Writer:
             return {"__float__": obj.hex()}
         if isinstance(obj, np.dtype):
             return {"__dtype__": obj.str}
+        if isinstance(obj, datetime):
+            return {"__datetime__": obj.isoformat()}
         if isinstance(obj, (list, tuple)):
             return {"__seq__": type(obj).__name__, "v": [self._enc(x) for x in obj]}
         if isinstance(obj, dict):
@@ -65,6 +68,8 @@ def _dec(obj, arrays):
             return float.fromhex(obj["__float__"])
         if "__dtype__" in obj:
             return np.dtype(obj["__dtype__"])
+        if "__datetime__" in obj:
+            return datetime.fromisoformat(obj["__datetime__"])
         if "__seq__" in obj:
             seq = [_dec(x, arrays) for x in obj["v"]]
             return tuple(seq) if obj["__seq__"] == "tuple" else seq

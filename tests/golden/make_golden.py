@@ -25,6 +25,7 @@ Families:
   smoothzoom  R1     ndimage.affine_transform(order=0) call of Smooth's zoom branch
   spatial     N3     Dilate / MovingMax / HillShade process() + expand_request_pixels
   reduce      N4     Max.process = reduce_rasters(stack, "max")
+  group       N4     Group: whole get_data() on temporal probe sources (by time / by bands)
 """
 import json
 import os
@@ -790,12 +791,116 @@ def gen_reduce(w):
         w.add(id="red%04d" % cid, op="max", args=args, expect=R_red.Max.process(*args)); cid += 1
 
 
+# --------------------------------------------------------------------------
+# family: group  (reference: raster/combine.py:143-466) -- whole get_data() of Group views on
+# temporal probe sources (period / timedelta / frames of their own)
+# --------------------------------------------------------------------------
+class TemporalProbe(RasterBlock):
+    """Probe source with ``n`` frames ``delta`` apart from ``first`` (delta None: free time stamps)."""
+
+    ARRAYS = {}
+
+    def __init__(self, name, dtype_str, ndv, times_iso, delta_s):
+        super().__init__(name, dtype_str, ndv, times_iso, delta_s)
+
+    dtype = property(lambda self: np.dtype(self.args[1]))
+    fillvalue = property(lambda self: self.args[2])
+    extent = None
+    geometry = None
+    projection = "EPSG:28992"
+    geo_transform = None
+
+    @property
+    def times(self):
+        return [datetime.fromisoformat(t) for t in self.args[3]]
+
+    @property
+    def period(self):
+        t = self.times
+        return (t[0], t[-1]) if t else None
+
+    @property
+    def timedelta(self):
+        from datetime import timedelta
+        return None if self.args[4] is None else timedelta(seconds=self.args[4])
+
+    @property
+    def temporal(self):
+        return self.args[4] is not None or len(self.args[3]) > 1
+
+    def get_sources_and_requests(self, **request):
+        return [({"name": self.args[0], "times": self.args[3], "mode": request["mode"],
+                  "start": request.get("start"), "stop": request.get("stop")}, None)]
+
+    @staticmethod
+    def process(kw):
+        times = [datetime.fromisoformat(t) for t in kw["times"]]
+        start, stop = kw["start"], kw["stop"]
+        if not times:
+            return None
+        if start is None:
+            sel = [len(times) - 1]
+        elif stop is None:
+            sel = [min(range(len(times)), key=lambda i: abs(times[i] - start))]
+        else:
+            sel = [i for i, t in enumerate(times) if start <= t <= stop]
+        if kw["mode"] == "time":
+            return {"time": [times[i] for i in sel]}
+        if kw["mode"] == "meta":
+            return {"meta": ["%s/%d" % (kw["name"], i) for i in sel]}
+        if not sel:
+            return None
+        data = TemporalProbe.ARRAYS[kw["name"]]
+        return {"values": data["values"][sel], "no_data_value": data["no_data_value"]}
+
+
+def gen_group(w):
+    from dask_geomodeling.raster import combine as R_comb
+    rng = np.random.default_rng(101)
+    cid = 0
+    f32n = np.float32(F32MAX)
+    day = 86400
+
+    def src(name, dt, ndv, times, delta):
+        shape = (len(times), 12, 16)
+        TemporalProbe.ARRAYS[name] = {"values": make_tile(rng, dt, shape, ndv, specials=False), "no_data_value": ndv}
+        return TemporalProbe(name, np.dtype(dt).str, ndv, times, delta)
+
+    t = ["2020-01-%02dT00:00:00" % d for d in range(1, 11)]
+    setups = {
+        "static3": [("a", "f4", f32n, t[:1], None), ("b", "f4", f32n, t[:1], None), ("c", "f4", f32n, t[:1], None)],
+        "mixeddtype": [("a", "u1", np.uint8(255), t[:1], None), ("b", "i4", -9999, t[:1], None)],
+        "aligned": [("a", "f4", f32n, t[0:4], day), ("b", "f4", f32n, t[2:8], day), ("c", "f4", f32n, t[6:10], day)],
+        "freetimes": [("a", "f4", f32n, [t[0], t[3], t[4]], None), ("b", "f4", f32n, [t[3], t[7]], None)],
+        "misaligned": [("a", "i4", -9999, t[0:3], day), ("b", "i4", -9999, ["2020-01-02T12:00:00", "2020-01-03T12:00:00"], day)],
+    }
+    reqs = [dict(), dict(start=datetime(2020, 1, 3)), dict(start=datetime(2020, 1, 2), stop=datetime(2020, 1, 8)),
+            dict(start=datetime(2019, 1, 1)), dict(start=datetime(2020, 1, 4, 7)), dict(start=datetime(2021, 1, 1), stop=datetime(2021, 2, 1)),
+            dict(start=datetime(2020, 1, 7), stop=datetime(2020, 3, 1))]
+    for sname, specs in setups.items():
+        leaves, spec_out = [], []
+        for (name, dt, ndv, times, delta) in specs:
+            key = "%s/%s" % (sname, name)
+            leaves.append(src(key, dt, ndv, times, delta))
+            spec_out.append({"name": key, "dtype": np.dtype(dt).str, "ndv": ndv, "times": times, "delta": delta,
+                             "data": TemporalProbe.ARRAYS[key]["values"]})
+        view = R_comb.Group(*leaves)
+        attrs = {"dtype": view.dtype.str, "fillvalue": view.fillvalue, "period": list(view.period) if view.period else None,
+                 "timedelta": None if view.timedelta is None else view.timedelta.total_seconds(), "temporal": view.temporal}
+        for extra in reqs:
+            for mode in ("vals", "time", "meta"):
+                request = dict(mode=mode, bbox=(0.0, 0.0, 16.0, 12.0), width=16, height=12, projection="EPSG:28992", **extra)
+                out = view.get_data(**request)
+                w.add(id="grp%04d" % cid, setup=sname, sources=spec_out, attrs=attrs, request=request, expect=out)
+                cid += 1
+
+
 def main():
     fams = {
         "math": gen_math, "n1": gen_n1, "clip": gen_clip, "mask": gen_mask,
         "classify": gen_classify, "reclassify": gen_reclassify, "tiler": gen_tiler,
         "views": gen_views, "dtypes": gen_dtypes, "smoothzoom": gen_smoothzoom,
-        "spatial": gen_spatial, "reduce": gen_reduce,
+        "spatial": gen_spatial, "reduce": gen_reduce, "group": gen_group,
     }
     only = sys.argv[1:]
     counts = {}

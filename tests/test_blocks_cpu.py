@@ -438,3 +438,30 @@ def test_stencil_block_constructors_and_requests():
     assert raster.Dilate.process(None, [1]) is None
     assert raster.MovingMax.process({"time": ["t"]}, 3) == {"time": ["t"]}
     assert raster.HillShade.process({"meta": ["m"]}, None) == {"meta": ["m"]}
+
+
+# ---------------------------------------------------------------------------------
+# N4: Group -- whole get_data() on temporal sources against the reference's results
+# ---------------------------------------------------------------------------------
+def _group_view(case):
+    from blocks_util import TemporalLeaf
+    leaves = []
+    for spec in case["sources"]:
+        TemporalLeaf.ARRAYS[spec["name"]] = {"values": spec["data"], "no_data_value": spec["ndv"]}
+        leaves.append(TemporalLeaf(spec["name"], spec["dtype"], spec["ndv"], spec["times"], spec["delta"]))
+    return raster.Group(*leaves)
+
+
+@pytest.mark.parametrize("case", load_family("group"), ids=lambda c: c["id"] + "-" + c["setup"] + "-" + c["request"]["mode"])
+def test_group_against_reference(cpu_vm, case):
+    view = _group_view(case)
+    a = case["attrs"]
+    assert view.dtype.str == a["dtype"] and view.fillvalue == a["fillvalue"] and view.temporal == a["temporal"]
+    assert (list(view.period) if view.period else None) == a["period"]
+    assert (None if view.timedelta is None else view.timedelta.total_seconds()) == a["timedelta"]
+    out = view.get_data(**case["request"])
+    want = case["expect"]
+    if want is None or "values" not in want:
+        assert out == want, case["id"]
+    else:
+        assert_result_equal(out, want, 0, case["id"])

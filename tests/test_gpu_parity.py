@@ -628,3 +628,23 @@ def test_process_bodies_from_concurrent_threads(gpu):
 
     with ThreadPoolExecutor(8) as pool:
         assert all(pool.map(job, range(8)))
+
+
+# ---- N4: Group -------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in load_family("group") if c["request"]["mode"] == "vals"],
+                         ids=lambda c: c["id"] + "-" + c["setup"])
+def test_group_golden(gpu, case):
+    """Group.get_data on temporal sources: merge programs + band assembly on the device against the
+    reference's own results."""
+    from blocks_util import TemporalLeaf
+    from dask_geomodeling_amd import raster
+    leaves = []
+    for spec in case["sources"]:
+        TemporalLeaf.ARRAYS[spec["name"]] = {"values": spec["data"], "no_data_value": spec["ndv"]}
+        leaves.append(TemporalLeaf(spec["name"], spec["dtype"], spec["ndv"], spec["times"], spec["delta"]))
+    out = raster.Group(*leaves).get_data(**case["request"])
+    if case["expect"] is None:
+        assert out is None
+    else:
+        assert_result_equal(out, case["expect"], 0, case["id"])
