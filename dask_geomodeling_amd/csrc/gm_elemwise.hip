@@ -64,6 +64,22 @@ int lower(const gm_program* prog, VmCode* code, unsigned* n_uops) {
     bool fast = false;
     const bool arith = opcode == GM_OP_ADD || opcode == GM_OP_SUB || opcode == GM_OP_MUL ||
                        (opcode == GM_OP_DIV && float_class);
+    const bool compare = opcode >= GM_OP_EQ && opcode <= GM_OP_LE;
+    if (compare && kind_of(S.a) == GM_OPD_ACC && kind_of(S.b) != GM_OPD_ACC && src_of(S.b) >= 0) {
+      // acc OP b with b a literal / input / temp (the finite check of the float fast body is a no-op on 0 / 1)
+      const unsigned kind = UOP_EQ + (opcode - GM_OP_EQ);
+      const unsigned x_has = has_ndv(S.a), y_has = kind_of(S.b) == GM_OPD_SCALAR ? 0u : has_ndv(S.b);
+      if (!push(kind, (unsigned)src_of(S.b), x_has | (y_has << 1), S.a.value, S.b.value, S.fill)) return -1;
+      fast = true;
+    } else if (compare && kind_of(S.a) != GM_OPD_ACC && kind_of(S.a) != GM_OPD_NONE && src_of(S.a) >= 0 &&
+               kind_of(S.b) != GM_OPD_ACC && src_of(S.b) >= 0 && kind_of(S.a) != GM_OPD_SCALAR) {
+      // a OP b with neither in the accumulator: load a first
+      const unsigned kind = UOP_EQ + (opcode - GM_OP_EQ);
+      if (!push(UOP_LD, (unsigned)src_of(S.a), 0, zero, S.a.value, zero)) return -1;
+      const unsigned x_has = has_ndv(S.a), y_has = kind_of(S.b) == GM_OPD_SCALAR ? 0u : has_ndv(S.b);
+      if (!push(kind, (unsigned)src_of(S.b), x_has | (y_has << 1), S.a.value, S.b.value, S.fill)) return -1;
+      fast = true;
+    } else
     // the finite check is part of every float fast body: only lower float math steps that ask for it
     if (arith && (!float_class || chk)) {
       const gm_operand *x = &S.a, *y = &S.b;  // x: accumulator side, y: other side

@@ -47,7 +47,9 @@ typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 // micro-op selects a fully static body (operand arrays named at compile time: no operand copies,
 // no per-operand dispatch).  Everything else runs the generic step interpreter (UOP_GENERIC).
 enum { UOP_GENERIC = 0, UOP_LD = 1, UOP_ST = 2, UOP_ADD = 3, UOP_SUB = 4, UOP_RSUB = 5, UOP_MUL = 6,
-       UOP_DIV = 7, UOP_RDIV = 8, UOP_CLIP = 9 };
+       UOP_DIV = 7, UOP_RDIV = 8, UOP_CLIP = 9,
+       // comparisons acc OP b (a comparison feeding Clip is the idiomatic masking pattern)
+       UOP_EQ = 10, UOP_NE = 11, UOP_GT = 12, UOP_GE = 13, UOP_LT = 14, UOP_LE = 15 };
 // operand source of a micro-op: 0 = literal, 1 + k = input k, 1 + 8 + k = temp k
 constexpr unsigned UOP_SRC_SCALAR = 0, UOP_SRC_INPUT = 1, UOP_SRC_TEMP = 9;
 constexpr int GM_MAX_UOPS = 40;
@@ -762,6 +764,12 @@ struct Machine {
       case UOP_MUL: fast_math<B_SCALAR>(U, b, [](RC x, RC y) { return op_mul<RC>(x, y); }); break;
       case UOP_DIV: fast_math<B_SCALAR>(U, b, [](RC x, RC y) { return op_div<RC>(x, y); }); break;
       case UOP_RDIV: fast_math<B_SCALAR>(U, b, [](RC x, RC y) { return op_div<RC>(y, x); }); break;
+      case UOP_EQ: fast_body<B_SCALAR>(U, b, [](RC x, RC y) { return (RC)(x == y); }); break;
+      case UOP_NE: fast_body<B_SCALAR>(U, b, [](RC x, RC y) { return (RC)(x != y); }); break;
+      case UOP_GT: fast_body<B_SCALAR>(U, b, [](RC x, RC y) { return (RC)(x > y); }); break;
+      case UOP_GE: fast_body<B_SCALAR>(U, b, [](RC x, RC y) { return (RC)(x >= y); }); break;
+      case UOP_LT: fast_body<B_SCALAR>(U, b, [](RC x, RC y) { return (RC)(x < y); }); break;
+      case UOP_LE: fast_body<B_SCALAR>(U, b, [](RC x, RC y) { return (RC)(x <= y); }); break;
       case UOP_CLIP:
         if constexpr (!B_SCALAR) {
           // misc.py:115-123: acc (the store) -> its own ndv where the mask source has no data

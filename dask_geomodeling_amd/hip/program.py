@@ -622,14 +622,17 @@ def compile_expr(root, n_inputs):
         args = node.args
         pending = [a for a in args if not is_simple(a)]
         if len(pending) == 2 and pending[0] is not pending[1]:
+            # both operands are sub-trees: the RIGHT one is evaluated first and parked in a temp, so that
+            # the left one ends up in the accumulator -- op(acc, temp) is a fast route of the kernel for
+            # every arithmetic op and for Clip (whose mask typically is such a sub-tree: Greater(D, 20))
             x, y = pending
-            eval_to_acc(x)
-            if not is_simple(x):  # spill the left value around the right sub-tree
+            eval_to_acc(y)
+            if not is_simple(y):  # park the right value around the left sub-tree
                 t = alloc_temp()
                 steps[-1].save_temp = t + 1
-                temp_of[id(x)] = t
-                remaining[id(x)] = 1
-            eval_to_acc(y)
+                temp_of[id(y)] = t
+                remaining[id(y)] = 1
+            eval_to_acc(x)
         elif pending:
             eval_to_acc(pending[0])
         opds = []
