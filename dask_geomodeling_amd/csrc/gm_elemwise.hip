@@ -79,6 +79,24 @@ int lower(const gm_program* prog, VmCode* code, unsigned* n_uops) {
       const unsigned x_has = has_ndv(S.a), y_has = kind_of(S.b) == GM_OPD_SCALAR ? 0u : has_ndv(S.b);
       if (!push(kind, (unsigned)src_of(S.b), x_has | (y_has << 1), S.a.value, S.b.value, S.fill)) return -1;
       fast = true;
+    } else if ((opcode == GM_OP_DIGITIZE || opcode == GM_OP_LOOKUP || (opcode == GM_OP_MASK && (((S.bits >> 16) & 4u) != 0))) &&
+               (kind_of(S.a) == GM_OPD_ACC || (src_of(S.a) > 0))) {
+      // unary ops whose parameters fit one micro-op; an operand that is not the accumulator is loaded first
+      if (kind_of(S.a) != GM_OPD_ACC && !push(UOP_LD, (unsigned)src_of(S.a), 0, zero, S.a.value, zero)) return -1;
+      const unsigned flags = (S.bits >> 16) & 0xffu;
+      bool ok;
+      if (opcode == GM_OP_DIGITIZE) {
+        const unsigned arg = has_ndv(S.a) | ((flags & 1u) << 1) | (((flags >> 1) & 1u) << 2) |
+                             (((unsigned)S.aux1.u64 & 0xffu) << 8) | (((unsigned)S.aux0.u64 & 3u) << 16);
+        ok = push(UOP_DIGITIZE, 0, arg, S.a.value, zero, S.fill);
+      } else if (opcode == GM_OP_LOOKUP) {
+        const unsigned arg = (flags & 1u) | (((unsigned)S.aux3.u64 & 0xfu) << 8) | (((unsigned)S.aux0.u64 & 3u) << 16);
+        ok = push(UOP_LOOKUP, 0, arg, S.aux2, S.aux1, S.fill);
+      } else {
+        ok = push(UOP_MASKI, 0, has_ndv(S.a), S.a.value, S.aux0, S.fill);
+      }
+      if (!ok) return -1;
+      fast = true;
     } else
     // the finite check is part of every float fast body: only lower float math steps that ask for it
     if (arith && (!float_class || chk)) {

@@ -49,7 +49,15 @@ typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 enum { UOP_GENERIC = 0, UOP_LD = 1, UOP_ST = 2, UOP_ADD = 3, UOP_SUB = 4, UOP_RSUB = 5, UOP_MUL = 6,
        UOP_DIV = 7, UOP_RDIV = 8, UOP_CLIP = 9,
        // comparisons acc OP b (a comparison feeding Clip is the idiomatic masking pattern)
-       UOP_EQ = 10, UOP_NE = 11, UOP_GT = 12, UOP_GE = 13, UOP_LT = 14, UOP_LE = 15 };
+       UOP_EQ = 10, UOP_NE = 11, UOP_GT = 12, UOP_GE = 13, UOP_LT = 14, UOP_LE = 15,
+       // unary ops on the accumulator whose parameters fit the 32-byte micro-op (no second fetch of
+       // the 80-byte step, no walk through the generic opcode switch):
+       //   DIGITIZE arg: bit0 acc has ndv, bit1 right, bit2 int64 edges, bits 8-15 edges, 16-17 table;
+       //            acc_ndv = ndv of the accumulator, fill = fill
+       //   LOOKUP   arg: bit0 select, bits 8-11 exception keys, 16-17 table; acc_ndv.u64 = window
+       //            slots, b_val.i64 = kmin, fill = value of a miss under select
+       //   MASKI    (integer tiles) arg: bit0 acc has ndv; acc_ndv = ndv, b_val = value, fill = fill
+       UOP_DIGITIZE = 16, UOP_LOOKUP = 17, UOP_MASKI = 18 };
 // operand source of a micro-op: 0 = literal, 1 + k = input k, 1 + 8 + k = temp k
 constexpr unsigned UOP_SRC_SCALAR = 0, UOP_SRC_INPUT = 1, UOP_SRC_TEMP = 9;
 constexpr int GM_MAX_UOPS = 40;
@@ -449,6 +457,94 @@ struct Machine {
     apply2(S, b_scalar, b, f);
   }
 
+  // ---- table ops (TABLES kernels): shared by the generic step and the packed micro-ops -----------
+  // misc.py:387-399.  Edge-major linear count: every edge is one scalar load (wave-uniform),
+  // v_cmp + v_addc per element; <= GM_MAX_LINEAR_EDGES edges.  Comparisons in the type NumPy's
+  // promoted searchsorted uses: F32 class -> float32 thresholds prepared by the host with
+  // directed rounding (same decisions as float64 compares), F64 -> float64 edges, integer
+  // classes -> int64 edges, or float64 edges against (double)value.
+  __device__ __forceinline__ void op_digitize(kargs_t C, const unsigned table, const unsigned nb, const bool right,
+                                              const bool int_edges, const bool a_has, const RC a_ndv, const RC fill) {
+    const kargs_t tbl = (kargs_t)(uintptr_t)kload<unsigned long long>(C, offsetof(VmCode, tables) + 8 * table);
+    int cnt[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) cnt[k] = 0;
+    for (unsigned b = 0; b < nb; ++b) {
+      if constexpr (std::is_same<RC, float>::value) {
+        const float e = kload<float>(tbl, 4 * b);
+#pragma unroll
+        for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < acc[k]) : (e <= acc[k])) ? 1 : 0;
+      } else if constexpr (std::is_same<RC, double>::value) {
+        const double e = kload<double>(tbl, 8 * b);
+#pragma unroll
+        for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < acc[k]) : (e <= acc[k])) ? 1 : 0;
+      } else {
+        if (int_edges) {
+          const long long e = kload<long long>(tbl, 8 * b);
+#pragma unroll
+          for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < (long long)acc[k]) : (e <= (long long)acc[k])) ? 1 : 0;
+        } else {
+          const double e = kload<double>(tbl, 8 * b);
+#pragma unroll
+          for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < (double)acc[k]) : (e <= (double)acc[k])) ? 1 : 0;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      int c = cnt[k];
+      if constexpr (is_float_class<RC>::value) c = (acc[k] != acc[k]) ? (int)nb : c;  // NaN sorts to the end
+      acc[k] = (a_has & (acc[k] == a_ndv)) ? fill : (RC)c;
+    }
+  }
+
+  // misc.py:505-514.  Dense window of pre-resolved targets (entries in the register class' own
+  // width) + keys outside the window -- typically only the merged-in no-data key -- matched against
+  // scalar registers.  The accumulator holds an exact integer in every class.
+  __device__ __forceinline__ void op_lookup(kargs_t C, const unsigned table, const long long kmin64,
+                                            const unsigned long long range64, const unsigned n_exc, const bool select,
+                                            const RC fill) {
+    typedef typename std::conditional<sizeof(RC) == 8, unsigned long long, unsigned int>::type W;
+    typedef typename std::conditional<sizeof(RC) == 8, long long, int>::type KT;
+    const KT kmin = (KT)kmin64;
+    const W range = (W)range64;
+    const unsigned long long addr = kload<unsigned long long>(C, offsetof(VmCode, tables) + 8 * table);
+    const kargs_t exc = (kargs_t)(uintptr_t)(addr + (((unsigned long long)range * sizeof(RC) + 7ull) & ~7ull));
+    // (window index, looked-up target) are the only per-element state besides the accumulator;
+    // an exception key k matches where the index equals k - kmin (wrapping arithmetic)
+    W idx[N];
+    RC hit[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) idx[k] = (W)(KT)acc[k] - (W)kmin;
+    {
+      // the window was staged in LDS behind the tile loads (the host stages the table of the
+      // program's LOOKUP; one per program): one ds_read per element.  A gather from device
+      // memory instead costs the whole CU ~64 cycles per wave-instruction and 2 VGPRs of
+      // address per element.
+      extern __shared__ __align__(16) unsigned long long vm_lds[];
+      const W* const lds = (const W*)vm_lds;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const W w = lds[idx[k] < range ? idx[k] : (W)0];
+        RC h;
+        __builtin_memcpy(&h, &w, sizeof(RC));
+        hit[k] = h;
+      }
+    }
+    if (select) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] = fill;  // a miss: fill; else the value passes through
+    }
+    for (unsigned x = 0; x < n_exc; ++x) {  // exception-major: each pair is fetched once
+      const W ei = (W)(KT)kload<long long>(exc, 16 * x) - (W)kmin;
+      const RC ev = kload<RC>(exc, 16 * x + 8);
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] = (idx[k] == ei) ? ev : acc[k];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = idx[k] < range ? hit[k] : acc[k];
+  }
+
   __device__ __forceinline__ void step(kargs_t C, const gm_step& S) {
     RC b[N];
     const unsigned b_kind = opd_kind(S.b);
@@ -559,97 +655,15 @@ struct Machine {
       } break;
       case GM_OP_DIGITIZE:
         if constexpr (TABLES) {
-          // misc.py:387-399.  Edge-major linear count: every edge is one scalar load (wave-uniform),
-          // v_cmp + v_addc per element; <= GM_MAX_LINEAR_EDGES edges.  Comparisons in the type NumPy's
-          // promoted searchsorted uses: F32 class -> float32 thresholds prepared by the host with
-          // directed rounding (same decisions as float64 compares), F64 -> float64 edges, integer
-          // classes -> int64 edges, or float64 edges against (double)value.
-          const unsigned nb = (unsigned)S.aux1.u64, flags = step_flags(S);
-          const bool right = (flags & 1u) != 0, int_edges = (flags & 2u) != 0;
-          const kargs_t tbl = (kargs_t)(uintptr_t)kload<unsigned long long>(C, offsetof(VmCode, tables) + 8 * (unsigned)S.aux0.u64);
-          const bool a_has = opd_has_ndv(S.a);
-          const RC a_ndv = scalar_of<RC>(S.a.value), fill = scalar_of<RC>(S.fill);
-          int cnt[N];
-#pragma unroll
-          for (int k = 0; k < N; ++k) cnt[k] = 0;
-          for (unsigned b = 0; b < nb; ++b) {
-            if constexpr (std::is_same<RC, float>::value) {
-              const float e = kload<float>(tbl, 4 * b);
-#pragma unroll
-              for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < acc[k]) : (e <= acc[k])) ? 1 : 0;
-            } else if constexpr (std::is_same<RC, double>::value) {
-              const double e = kload<double>(tbl, 8 * b);
-#pragma unroll
-              for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < acc[k]) : (e <= acc[k])) ? 1 : 0;
-            } else {
-              if (int_edges) {
-                const long long e = kload<long long>(tbl, 8 * b);
-#pragma unroll
-                for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < (long long)acc[k]) : (e <= (long long)acc[k])) ? 1 : 0;
-              } else {
-                const double e = kload<double>(tbl, 8 * b);
-#pragma unroll
-                for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < (double)acc[k]) : (e <= (double)acc[k])) ? 1 : 0;
-              }
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < N; ++k) {
-            int c = cnt[k];
-            if constexpr (is_float_class<RC>::value) c = (acc[k] != acc[k]) ? (int)nb : c;  // NaN sorts to the end
-            acc[k] = (a_has & (acc[k] == a_ndv)) ? fill : (RC)c;
-          }
+          const unsigned flags = step_flags(S);
+          op_digitize(C, (unsigned)S.aux0.u64, (unsigned)S.aux1.u64, (flags & 1u) != 0, (flags & 2u) != 0,
+                      opd_has_ndv(S.a), scalar_of<RC>(S.a.value), scalar_of<RC>(S.fill));
         }
         break;
       case GM_OP_LOOKUP:
         if constexpr (TABLES) {
-          // misc.py:505-514.  Dense window of pre-resolved targets (entries in the register class'
-          // own width) + keys outside the window -- typically only the merged-in no-data key --
-          // matched against scalar registers.  The accumulator holds an exact integer in every class.
-          // Key arithmetic in the class' own width: in the 4-byte classes every key the accumulator
-          // can hold fits int32 (the host drops table keys outside that range: they cannot match).
-          typedef typename std::conditional<sizeof(RC) == 8, unsigned long long, unsigned int>::type W;
-          typedef typename std::conditional<sizeof(RC) == 8, long long, int>::type KT;
-          const KT kmin = (KT)(long long)S.aux1.i64;
-          const W range = (W)S.aux2.u64;
-          const unsigned n_exc = (unsigned)S.aux3.u64;
-          const bool select = (step_flags(S) & 1u) != 0;
-          const unsigned long long addr = kload<unsigned long long>(C, offsetof(VmCode, tables) + 8 * (unsigned)S.aux0.u64);
-          const kargs_t exc = (kargs_t)(uintptr_t)(addr + (((unsigned long long)range * sizeof(RC) + 7ull) & ~7ull));
-          const RC fill = scalar_of<RC>(S.fill);
-          // (window index, looked-up target) are the only per-element state besides the accumulator;
-          // an exception key k matches where the index equals k - kmin (wrapping arithmetic)
-          W idx[N];
-          RC hit[N];
-#pragma unroll
-          for (int k = 0; k < N; ++k) idx[k] = (W)(KT)acc[k] - (W)kmin;
-          {
-            // the window was staged in LDS behind the tile loads (the host stages the table of the
-            // program's LOOKUP; one per program): one ds_read per element.  A gather from device
-            // memory instead costs the whole CU ~64 cycles per wave-instruction and 2 VGPRs of
-            // address per element.
-            extern __shared__ __align__(16) unsigned long long vm_lds[];
-            const W* const lds = (const W*)vm_lds;
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-              const W w = lds[idx[k] < range ? idx[k] : (W)0];
-              RC h;
-              __builtin_memcpy(&h, &w, sizeof(RC));
-              hit[k] = h;
-            }
-          }
-          if (select) {
-#pragma unroll
-            for (int k = 0; k < N; ++k) acc[k] = fill;  // a miss: fill; else the value passes through
-          }
-          for (unsigned x = 0; x < n_exc; ++x) {  // exception-major: each pair is fetched once
-            const W ei = (W)(KT)kload<long long>(exc, 16 * x) - (W)kmin;
-            const RC ev = kload<RC>(exc, 16 * x + 8);
-#pragma unroll
-            for (int k = 0; k < N; ++k) acc[k] = (idx[k] == ei) ? ev : acc[k];
-          }
-#pragma unroll
-          for (int k = 0; k < N; ++k) acc[k] = idx[k] < range ? hit[k] : acc[k];
+          op_lookup(C, (unsigned)S.aux0.u64, (long long)S.aux1.i64, S.aux2.u64, (unsigned)S.aux3.u64,
+                    (step_flags(S) & 1u) != 0, scalar_of<RC>(S.fill));
         }
         break;
       case GM_OP_NANIFNODATA:
@@ -818,7 +832,22 @@ struct Machine {
   // VALU work, is what a micro-op costs.
   __device__ __forceinline__ void exec(kargs_t C, const gm_uop& U) {
     const unsigned kind = U.route & 0xffu, src = (U.route >> 8) & 0xffu;
-    if (kind >= UOP_ADD) {
+    if (kind >= UOP_DIGITIZE) {
+      const unsigned arg = U.arg;
+      if (kind == UOP_MASKI) {
+        const bool a_has = (arg & 1u) != 0;
+        const RC a_ndv = scalar_of<RC>(U.acc_ndv), value = scalar_of<RC>(U.b_val), fill = scalar_of<RC>(U.fill);
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = (a_has & (acc[k] == a_ndv)) ? fill : value;
+      } else if constexpr (TABLES) {
+        if (kind == UOP_DIGITIZE)
+          op_digitize(C, (arg >> 16) & 3u, (arg >> 8) & 0xffu, (arg & 2u) != 0, (arg & 4u) != 0, (arg & 1u) != 0,
+                      scalar_of<RC>(U.acc_ndv), scalar_of<RC>(U.fill));
+        else
+          op_lookup(C, (arg >> 16) & 3u, (long long)U.b_val.i64, U.acc_ndv.u64, (arg >> 8) & 0xfu, (arg & 1u) != 0,
+                    scalar_of<RC>(U.fill));
+      }
+    } else if (kind >= UOP_ADD) {
       if (src == UOP_SRC_SCALAR) {
         fast_op<true>(U, kind, acc);
       } else {
