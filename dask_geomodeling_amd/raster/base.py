@@ -28,73 +28,42 @@ class RasterBlock(Block):
             return len(self.get_data(mode="time", start=start, stop=stop)["time"])
         return int((stop - start).total_seconds() / delta.total_seconds()) + 1
 
-    # operator DSL (base.py:96-174) ------------------------------------------------
-    def __add__(self, other):
-        from . import Add
-        return Add(self, other)
-
-    def __mul__(self, other):
-        from . import Multiply
-        return Multiply(self, other)
-
-    def __neg__(self):
-        from . import Multiply
-        return Multiply(self, -1)
-
-    def __sub__(self, other):
-        from . import Subtract
-        return Subtract(self, other)
-
-    def __truediv__(self, other):
-        from . import Divide
-        return Divide(self, other)
-
-    def __pow__(self, other):
-        from . import Power
-        return Power(self, other)
-
-    def __eq__(self, other):
-        from . import Equal
-        return Equal(self, other)
-
-    def __ne__(self, other):
-        from . import NotEqual
-        return NotEqual(self, other)
-
-    def __gt__(self, other):
-        from . import Greater
-        return Greater(self, other)
-
-    def __ge__(self, other):
-        from . import GreaterEqual
-        return GreaterEqual(self, other)
-
-    def __lt__(self, other):
-        from . import Less
-        return Less(self, other)
-
-    def __le__(self, other):
-        from . import LessEqual
-        return LessEqual(self, other)
-
-    def __invert__(self):
-        from . import Invert
-        return Invert(self)
-
-    def __and__(self, other):
-        from . import And
-        return And(self, other)
-
-    def __or__(self, other):
-        from . import Or
-        return Or(self, other)
-
-    def __xor__(self, other):
-        from . import Xor
-        return Xor(self, other)
+    # The operator DSL (base.py:96-174) is attached below from a table: ``a + b`` -> Add(a, b) ...
 
     # __eq__ is overloaded: keep Blocks hashable (dict keys in graph tooling)
     __hash__ = object.__hash__
+
+
+def _attach_operators():
+    """``raster + other`` builds the element-wise Block of the same meaning (base.py:96-174).  The
+    Block classes live in sibling modules that import this one, hence the lookup at call time."""
+    binary = {"__add__": "Add", "__sub__": "Subtract", "__mul__": "Multiply", "__truediv__": "Divide",
+              "__pow__": "Power", "__eq__": "Equal", "__ne__": "NotEqual", "__gt__": "Greater",
+              "__ge__": "GreaterEqual", "__lt__": "Less", "__le__": "LessEqual", "__and__": "And",
+              "__or__": "Or", "__xor__": "Xor"}
+
+    def make_binary(block_name):
+        def operator(self, other):
+            from . import elemwise
+            return getattr(elemwise, block_name)(self, other)
+        return operator
+
+    for dunder, block_name in binary.items():
+        setattr(RasterBlock, dunder, make_binary(block_name))
+
+    def negate(self):
+        from . import elemwise
+        return elemwise.Multiply(self, -1)
+
+    def invert(self):
+        from . import elemwise
+        return elemwise.Invert(self)
+
+    RasterBlock.__neg__ = negate
+    RasterBlock.__invert__ = invert
+
+
+_attach_operators()
 
 
 class BaseSingle(RasterBlock):

@@ -21,106 +21,83 @@ def filter_none(lst):
     return [x for x in lst if x is not None]
 
 
+def _union_box(boxes):
+    """Smallest (x1, y1, x2, y2) around all boxes."""
+    x1, y1, x2, y2 = zip(*boxes)
+    return min(x1), min(y1), max(x2), max(y2)
+
+
 class BaseCombine(RasterBlock):
-    """combine.py:16-141: attributes are greedy -- period and extent are unions of the arguments',
-    the timedelta survives only when the arguments are equidistant and aligned."""
+    """Greedy attributes (combine.py:16-141): period, extent and geometry are unions over the
+    arguments that have any; the timedelta survives only when the arguments are equidistant and
+    their frames fall on one common grid."""
 
     def __init__(self, *args):
-        for arg in args:
-            if not isinstance(arg, RasterBlock):
-                raise TypeError("'{}' object is not allowed".format(type(arg)))
+        bad = [arg for arg in args if not isinstance(arg, RasterBlock)]
+        if bad:
+            raise TypeError("'{}' object is not allowed".format(type(bad[0])))
         super(BaseCombine, self).__init__(*args)
 
     @staticmethod
     def get_aligned_timedelta(sources):
-        timedeltas, periods = [], []
-        for arg in sources:
-            timedelta, period = arg.timedelta, arg.period
-            if period is not None and timedelta is not None:
-                timedeltas.append(timedelta)
-                periods.append(period)
-        if len(timedeltas) == 0:
+        grid = [(src.timedelta, src.period[0]) for src in sources
+                if src.period is not None and src.timedelta is not None]
+        if not grid:
             return None
-        if len(timedeltas) == 1:
-            return timedeltas[0]
-        if not timedeltas[1:] == timedeltas[:-1]:
-            return None
-        # the periods must be spaced an integer number of timedeltas apart
-        seconds = timedeltas[0].total_seconds()
-        first, _ = periods[0]
-        for a, _ in periods[1:]:
-            if (first - a).total_seconds() % seconds != 0:
+        step, origin = grid[0]
+        for other_step, other_origin in grid[1:]:
+            if other_step != step:
                 return None
-        return timedeltas[0]
+            # frames of every source must sit a whole number of steps from the first one's
+            if (origin - other_origin).total_seconds() % step.total_seconds() != 0:
+                return None
+        return step
 
-    @property
-    def timedelta(self):
-        return self.get_aligned_timedelta(self.args)
-
-    @property
-    def temporal(self):
-        return any(x.temporal for x in self.args)
+    timedelta = property(lambda self: self.get_aligned_timedelta(self.args))
+    temporal = property(lambda self: any(arg.temporal for arg in self.args))
+    dtype = property(lambda self: np.result_type(*self.args))
+    fillvalue = property(lambda self: get_dtype_max(self.dtype))
 
     @property
     def period(self):
-        periods = filter_none([x.period for x in self.args])
-        if len(periods) == 0:
+        known = filter_none([arg.period for arg in self.args])
+        if not known:
             return None
-        if len(periods) == 1:
-            return periods[0]
-        return min(p[0] for p in periods), max(p[1] for p in periods)
+        return min(p[0] for p in known), max(p[1] for p in known)
 
     @property
     def extent(self):
-        extents = filter_none([x.extent for x in self.args])
-        if len(extents) == 0:
-            return None
-        if len(extents) == 1:
-            return extents[0]
-        return (min(e[0] for e in extents), min(e[1] for e in extents),
-                max(e[2] for e in extents), max(e[3] for e in extents))
-
-    @property
-    def dtype(self):
-        return np.result_type(*self.args)
-
-    @property
-    def fillvalue(self):
-        return get_dtype_max(self.dtype)
+        known = filter_none([arg.extent for arg in self.args])
+        return _union_box(known) if known else None
 
     @property
     def geometry(self):
-        geometries = filter_none([x.geometry for x in self.args])
-        if len(geometries) == 0:
+        known = filter_none([arg.geometry for arg in self.args])
+        if not known:
             return None
-        if len(geometries) == 1:
-            return geometries[0]
-        extent = Extent.from_geometry(geometries[0])
-        for geometry in geometries[1:]:
-            extent = extent.union(Extent.from_geometry(geometry))
-        return extent.as_geometry()
+        joined = Extent.from_geometry(known[0])
+        for geometry in known[1:]:
+            joined = joined.union(Extent.from_geometry(geometry))
+        return joined.as_geometry() if len(known) > 1 else known[0]
 
     @property
     def projection(self):
-        projection = self.args[0].projection
-        if projection is None:
+        first = self.args[0].projection
+        if first is None or any(arg.projection != first for arg in self.args[1:]):
             return None
-        for arg in self.args[1:]:
-            if projection != arg.projection:
-                return None
-        return projection
+        return first
 
     @property
     def geo_transform(self):
-        geo_transform = self.args[0].geo_transform
-        if geo_transform is None:
+        first = self.args[0].geo_transform
+        if first is None:
             return None
-        geo_transform = GeoTransform(geo_transform)
+        first = GeoTransform(first)
         for arg in self.args[1:]:
             other = arg.geo_transform
-            if other is None or not geo_transform.aligns_with(other):
+            if other is None or not first.aligns_with(other):
                 return None
-        return geo_transform
+        return first
 
 
 def _band(values, index):
@@ -173,173 +150,166 @@ class Group(BaseCombine):
     Values at equal timesteps are considered starting with the leftmost raster: rasters more 'to
     the right' are shown in the result, 'no data' is transparent."""
 
+    NOTHING = [(dict(combine_mode="simple"), None)]
+
+    # -- request planning -----------------------------------------------------------------
     def get_relevant_sources(self, start, stop):
-        stores = [s for s in self.args if s.period is not None]
-        if not stores:
+        """The arguments that can contribute to the window [start, stop] (combine.py:164-196)."""
+        dated = [(src.period[0], src.period[1], src) for src in self.args if src.period is not None]
+        if not dated:
             return []
-        starts, stops = zip(*(s.period for s in stores))
-        if start is None:  # pick the latest store(s) in time
-            last = max(stops)
-            return [s for b, s in zip(stops, stores) if b == last]
-        if stop is None:  # any stores that contain start, else the closest ones
-            result = [s for a, b, s in zip(starts, stops, stores) if a <= start <= b]
-            if result:
-                return result
-            closest = min(starts + stops, key=lambda d: abs(d - start))
-            return [s for d, s in zip(stops + starts, stores + stores) if d == closest]
-        return [s for a, b, s in zip(starts, stops, stores) if not (stop < a or start > b)]
+        if start is None:  # latest frame wanted: whoever reaches furthest in time
+            horizon = max(last for _, last, _ in dated)
+            return [src for _, last, src in dated if last == horizon]
+        if stop is None:  # one moment: those that span it, else those whose edge lies nearest to it
+            spanning = [src for first, last, src in dated if first <= start <= last]
+            if spanning:
+                return spanning
+            firsts, lasts = [d[0] for d in dated], [d[1] for d in dated]
+            nearest = min(firsts + lasts, key=lambda moment: abs(moment - start))
+            order = [d[2] for d in dated]
+            return [src for edge, src in zip(lasts + firsts, order + order) if edge == nearest]
+        return [src for first, last, src in dated if not (stop < first or start > last)]
+
+    def _plan_by_time(self, request, mode, start, stop):
+        """No common time grid: frames are lined up by their time stamps, so besides the data every
+        source is also asked for its times (combine.py:214-235)."""
+        sources = self.get_relevant_sources(start, stop)
+        if not sources:
+            return self.NOTHING
+        asks = [(src, request) for src in sources]
+        if mode != "time":
+            asks += [(src, dict(mode="time", start=start, stop=stop)) for src in sources]
+        kwargs = dict(combine_mode="by_time", mode=mode, start=start, stop=stop)
+        if mode == "vals":
+            kwargs["dtype"] = self.dtype
+        return [(kwargs, None)] + asks
+
+    def _plan_by_bands(self, request, mode, start, stop, step):
+        """Common time grid: the window is snapped to the grid and every source fills a range of
+        result bands (combine.py:236-297)."""
+        step_s = step.total_seconds()
+        first, last = self.period
+        if start is None:
+            start = last
+        elif start < first:
+            start = first
+        else:  # up to the next grid point
+            start += Timedelta(seconds=(first - start).total_seconds() % step_s)
+        if stop is None:
+            stop = start
+        elif stop > last:
+            stop = last
+        else:  # down to the previous grid point
+            stop -= Timedelta(seconds=(stop - first).total_seconds() % step_s)
+        if mode == "time":
+            return [(dict(combine_mode="by_bands", mode=mode, start=start, stop=stop, timedelta=step), None)]
+
+        def band_of(moment):
+            return int((moment - start).total_seconds() // step_s)
+
+        asks, ranges = [], []
+        for src in self.get_relevant_sources(start, stop):
+            lo, hi = max(start, src.period[0]), min(stop, src.period[1])
+            ranges.append((band_of(lo), band_of(hi) + 1))
+            asks.append((src, dict(request, start=lo, stop=hi)))
+        kwargs = dict(combine_mode="by_bands", mode=mode, bands=ranges)
+        n_bands = band_of(stop) + 1
+        if mode == "meta":
+            kwargs["nbands"] = n_bands
+        if mode == "vals":
+            kwargs["shape"] = n_bands, request["height"], request["width"]
+            kwargs["dtype"] = self.dtype
+        return [(kwargs, None)] + asks
 
     def get_sources_and_requests(self, **request):
-        start, stop = request.get("start", None), request.get("stop", None)
-        mode = request["mode"]
-        if self.period is None:
-            return [(dict(combine_mode="simple"), None)]
-        if start is not None and stop is not None and (start > self.period[1] or stop < self.period[0]):
-            return [(dict(combine_mode="simple"), None)]
-        timedelta = self.timedelta
-        if timedelta is None:  # merge by time
-            sources = self.get_relevant_sources(start, stop)
-            if not sources:
-                return [(dict(combine_mode="simple"), None)]
-            requests, time_requests = [], []
-            for source in sources:
-                requests.append((source, request))
-                if mode != "time":  # the time stamps of the frames are needed to line them up
-                    time_requests.append((source, dict(mode="time", start=start, stop=stop)))
-            process_kwargs = dict(combine_mode="by_time", mode=mode, start=start, stop=stop)
-            requests = requests + time_requests
-        else:  # merge by bands
-            td_sec = timedelta.total_seconds()
-            period = self.period
-            origin = period[0]
-            if start is None:
-                start = period[1]
-            elif start < period[0]:
-                start = period[0]
-            else:  # ceil start to the closest integer timedelta
-                start += Timedelta(seconds=(origin - start).total_seconds() % td_sec)
-            if stop is None:
-                stop = start
-            elif stop > period[1]:
-                stop = period[1]
-            else:  # floor stop to the closest integer timedelta
-                stop -= Timedelta(seconds=(stop - origin).total_seconds() % td_sec)
-            if mode == "time":
-                return [(dict(combine_mode="by_bands", mode=mode, start=start, stop=stop, timedelta=timedelta), None)]
-            sources = self.get_relevant_sources(start, stop)
-            requests, bands = [], []
-            for source in sources:
-                this_start = max(start, source.period[0])
-                this_stop = min(stop, source.period[1])
-                first_i = int((this_start - start).total_seconds() // td_sec)
-                last_i = int((this_stop - start).total_seconds() // td_sec)
-                bands.append((first_i, last_i + 1))
-                this_request = request.copy()
-                this_request.update(start=this_start, stop=this_stop)
-                requests.append((source, this_request))
-            process_kwargs = dict(combine_mode="by_bands", mode=mode, bands=bands)
-            nbands = int((stop - start).total_seconds() // td_sec) + 1
-            if mode == "meta":
-                process_kwargs["nbands"] = nbands
-            if mode == "vals":
-                process_kwargs["shape"] = nbands, request["height"], request["width"]
-        if mode == "vals":
-            process_kwargs["dtype"] = self.dtype
-        return [(process_kwargs, None)] + requests
+        start, stop, mode = request.get("start", None), request.get("stop", None), request["mode"]
+        period = self.period
+        if period is None:
+            return self.NOTHING
+        if start is not None and stop is not None and (start > period[1] or stop < period[0]):
+            return self.NOTHING
+        step = self.timedelta
+        if step is None:
+            return self._plan_by_time(request, mode, start, stop)
+        return self._plan_by_bands(request, mode, start, stop, step)
+
+    # -- merging ----------------------------------------------------------------------------
+    @staticmethod
+    def _unique_times(responses):
+        stamps = filter_none([r.get("time", None) for r in responses])
+        return sorted(set(itertools.chain(*stamps)))
 
     @staticmethod
-    def _unique_times(multi):
-        times = filter_none([data.get("time", None) for data in multi])
-        return sorted(set(itertools.chain(*times)))
-
-    @staticmethod
-    def _nearest_index(time, start):
+    def _single_frame(times, start, stop):
+        """Index of the one frame a moment-request (stop None) is answered with, else None."""
+        if stop is not None or len(times) <= 1:
+            return None
         if start is None:
-            return len(time) - 1
-        return min(enumerate(time), key=lambda d: abs(d[1] - start))[0]
+            return len(times) - 1
+        return min(range(len(times)), key=lambda i: abs(times[i] - start))
 
     @staticmethod
-    def _merge_vals_by_time(multi, times, kwargs):
-        sorted_times = Group._unique_times(times)
-        bands = dict((y, x) for x, y in enumerate(sorted_times))
-        per_band = [[] for _ in sorted_times]
-        for data, time in zip(multi, times):
-            for source_index, datetime in enumerate(time["time"]):
-                per_band[bands[datetime]].append((_band(data["values"], source_index), data["no_data_value"]))
-        start, stop = kwargs["start"], kwargs["stop"]
-        if stop is None and len(sorted_times) > 1:  # single band result required
-            index = Group._nearest_index(sorted_times, start)
-            per_band = per_band[index:index + 1]
-        shape_yx = multi[0]["values"].shape[1:]
-        values = _merge_bands(kwargs["dtype"], per_band, shape_yx)
+    def _by_time(mode, responses, stamps, kwargs):
+        times = Group._unique_times(stamps)
+        slot = {moment: i for i, moment in enumerate(times)}
+        if mode == "vals":
+            frames = [[] for _ in times]
+            for data, stamp in zip(responses, stamps):
+                for k, moment in enumerate(stamp["time"]):
+                    frames[slot[moment]].append((_band(data["values"], k), data["no_data_value"]))
+        else:
+            frames = [None] * len(times)
+            for data, stamp in zip(responses, stamps):
+                for k, moment in enumerate(stamp["time"]):
+                    frames[slot[moment]] = data["meta"][k]
+        only = Group._single_frame(times, kwargs["start"], kwargs["stop"])
+        if only is not None:
+            frames = frames[only:only + 1]
+        if mode == "meta":
+            return {"meta": frames}
+        values = _merge_bands(kwargs["dtype"], frames, responses[0]["values"].shape[1:])
         return {"values": values, "no_data_value": get_dtype_max(kwargs["dtype"])}
 
     @staticmethod
-    def _merge_meta_by_time(multi, times, kwargs):
-        sorted_times = Group._unique_times(times)
-        bands = dict((y, x) for x, y in enumerate(sorted_times))
-        meta_result = [None] * len(sorted_times)
-        for data, time in zip(multi, times):
-            for source_index, datetime in enumerate(time["time"]):
-                meta_result[bands[datetime]] = data["meta"][source_index]
-        start, stop = kwargs["start"], kwargs["stop"]
-        if stop is None and len(sorted_times) > 1:
-            index = Group._nearest_index(sorted_times, start)
-            meta_result = meta_result[index:index + 1]
-        return {"meta": meta_result}
-
-    @staticmethod
-    def _merge_vals_by_bands(multi, bands, dtype, shape):
-        per_band = [[] for _ in range(shape[0])]
-        for data, (a, b) in zip(multi, bands):
-            for i in range(a, b):
-                per_band[i].append((_band(data["values"], i - a), data["no_data_value"]))
-        values = _merge_bands(dtype, per_band, shape[1:])
-        return {"values": values, "no_data_value": get_dtype_max(dtype)}
-
-    @staticmethod
-    def _merge_meta_by_bands(multi, bands, nbands):
-        meta_result = [""] * nbands
-        for data, (a, b) in zip(multi, bands):
-            for i, meta in zip(range(a, b), data["meta"]):
-                if meta:
-                    meta_result[i] = meta
-        return {"meta": meta_result}
+    def _by_bands(mode, responses, ranges, kwargs):
+        if mode == "meta":
+            merged = [""] * kwargs["nbands"]
+            for data, (lo, hi) in zip(responses, ranges):
+                for i, meta in zip(range(lo, hi), data["meta"]):
+                    if meta:
+                        merged[i] = meta
+            return {"meta": merged}
+        shape = kwargs["shape"]
+        frames = [[] for _ in range(shape[0])]
+        for data, (lo, hi) in zip(responses, ranges):
+            for i in range(lo, hi):
+                frames[i].append((_band(data["values"], i - lo), data["no_data_value"]))
+        values = _merge_bands(kwargs["dtype"], frames, shape[1:])
+        return {"values": values, "no_data_value": get_dtype_max(kwargs["dtype"])}
 
     @staticmethod
     def process(process_kwargs, *args):
-        combine_mode = process_kwargs["combine_mode"]
-        mode = process_kwargs.get("mode", None)
-        if combine_mode == "simple":
+        plan, mode = process_kwargs["combine_mode"], process_kwargs.get("mode", None)
+        if plan == "simple":
             return None
-        if combine_mode == "by_time" and mode == "time":
-            sorted_times = Group._unique_times(args)
-            start, stop = process_kwargs["start"], process_kwargs["stop"]
-            if stop is None and len(sorted_times) > 1:
-                index = Group._nearest_index(sorted_times, start)
-                sorted_times = sorted_times[index:index + 1]
-            return {"time": sorted_times}
-        if combine_mode == "by_time" and mode in ["meta", "vals"]:
-            n = int(len(args) // 2)
-            multi, times = filter_none(args[:n]), filter_none(args[n:])  # None sits at the same positions
-            if len(multi) == 0:
-                return None
-            if mode == "vals":
-                return Group._merge_vals_by_time(multi, times, process_kwargs)
-            return Group._merge_meta_by_time(multi, times, process_kwargs)
-        if combine_mode == "by_bands" and mode == "time":
-            start, stop, delta = process_kwargs["start"], process_kwargs["stop"], process_kwargs["timedelta"]
-            length = int((stop - start).total_seconds() // delta.total_seconds()) + 1  # includes the last frame
-            return {"time": [start + i * delta for i in range(length)]}
-        if combine_mode == "by_bands" and mode in ["meta", "vals"]:
-            multi, bands = [], []
-            for data, _bands in zip(args, process_kwargs["bands"]):
-                if data is None:
-                    continue
-                multi.append(data)
-                bands.append(_bands)
-            if mode == "vals":
-                return Group._merge_vals_by_bands(multi=multi, bands=bands, dtype=process_kwargs["dtype"],
-                                                  shape=process_kwargs["shape"])
-            return Group._merge_meta_by_bands(multi=multi, bands=bands, nbands=process_kwargs["nbands"])
+        if plan == "by_time":
+            if mode == "time":
+                times = Group._unique_times(args)
+                only = Group._single_frame(times, process_kwargs["start"], process_kwargs["stop"])
+                return {"time": times if only is None else times[only:only + 1]}
+            if mode in ("meta", "vals"):
+                half = len(args) // 2  # data responses, then the time responses in the same order
+                responses, stamps = filter_none(args[:half]), filter_none(args[half:])
+                if not responses:
+                    return None
+                return Group._by_time(mode, responses, stamps, process_kwargs)
+        elif plan == "by_bands":
+            if mode == "time":
+                first, step = process_kwargs["start"], process_kwargs["timedelta"]
+                count = int((process_kwargs["stop"] - first).total_seconds() // step.total_seconds()) + 1
+                return {"time": [first + i * step for i in range(count)]}
+            if mode in ("meta", "vals"):
+                present = [(data, rng) for data, rng in zip(args, process_kwargs["bands"]) if data is not None]
+                return Group._by_bands(mode, [d for d, _ in present], [r for _, r in present], process_kwargs)
         raise ValueError("Unknown combine_mode / mode combination")
