@@ -1,0 +1,43 @@
+"""Differential fuzzing on the device: random views (fused, cut at register-class boundaries,
+stand-alone table kernels where a table does not fit a program) against the op-by-op oracle,
+evaluated one by one and all together (batched where structures coincide)."""
+import numpy as np
+import pytest
+
+from fuzz_util import REQ, describe, oracle_eval, random_view, unsigned_zero
+from helpers import assert_result_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(300))
+def test_random_views_on_device(gpu, seed):
+    from dask_geomodeling_amd import config as gmconfig
+    rng = np.random.default_rng(10_000 + seed)
+    view = random_view(rng, "g%d" % seed)
+    with np.errstate(all="ignore"):
+        want = unsigned_zero(oracle_eval(view))
+    try:
+        got = view.get_data(**REQ)
+    except NotImplementedError as e:
+        pytest.skip("not on the device path: %s" % e)
+    assert_result_equal(unsigned_zero(got), want, 0, describe(view))
+    with gmconfig.config.set({"geomodeling.fuse": False}):
+        assert_result_equal(unsigned_zero(view.get_data(**REQ)), want, 0, "unfused " + describe(view))
+
+
+def test_random_views_evaluated_together(gpu):
+    from dask_geomodeling_amd.core.graphs import get_data_many
+    views, wants = [], []
+    for seed in range(40):
+        rng = np.random.default_rng(20_000 + seed)
+        view = random_view(rng, "m%d" % seed, depth=3)
+        try:
+            view.get_data(**REQ)
+        except NotImplementedError:
+            continue
+        with np.errstate(all="ignore"):
+            wants.append(unsigned_zero(oracle_eval(view)))
+        views.append(view)
+    for got, want, view in zip(get_data_many(views, REQ), wants, views):
+        assert_result_equal(unsigned_zero(got), want, 0, describe(view))
