@@ -17,7 +17,8 @@ SHAPE = (1, 24, 40)
 REQ = dict(mode="vals", bbox=(0.0, 0.0, 40.0, 24.0), width=40, height=24, projection="EPSG:28992")
 
 
-def make_leaf(rng, tag, k):
+def make_leaf(rng, tag, k, memory=False):
+    """memory=True: a MemorySource (the real source Block; answers any window) instead of an ArrayLeaf."""
     dt, ndv = LEAF_KINDS[int(rng.integers(len(LEAF_KINDS)))]
     if np.dtype(dt).kind == "f":
         v = (rng.random(SHAPE) * 40 - 10).astype(dt)
@@ -25,6 +26,10 @@ def make_leaf(rng, tag, k):
     else:
         v = rng.integers(0, 12, size=SHAPE).astype(dt)
     v[rng.random(SHAPE) < 0.15] = ndv
+    if memory:
+        if np.dtype(dt).kind == "f":
+            v[~np.isfinite(v)] = ndv  # (a source turns non-finite cells into no data itself, sources.py:148)
+        return raster.MemorySource(v, ndv, "EPSG:28992", 1.0, (0.0, float(SHAPE[1])))
     key = "fuzz/%s/%d" % (tag, k)
     ArrayLeaf.ARRAYS[key] = {"values": v, "no_data_value": ndv}
     return ArrayLeaf(key, np.dtype(dt).str, ndv)
@@ -38,9 +43,9 @@ def is_int(b):
     return b.dtype.kind in "iu"
 
 
-def random_view(rng, tag, depth=4):
+def random_view(rng, tag, depth=4, memory=False):
     """A random Block tree (and the leaves it uses)."""
-    leaves = [make_leaf(rng, tag, k) for k in range(int(rng.integers(1, 4)))]
+    leaves = [make_leaf(rng, tag, k, memory) for k in range(int(rng.integers(1, 4)))]
 
     def numeric(d):
         if d == 0 or rng.random() < 0.2:

@@ -41,3 +41,19 @@ def test_random_views_evaluated_together(gpu):
         views.append(view)
     for got, want, view in zip(get_data_many(views, REQ), wants, views):
         assert_result_equal(unsigned_zero(got), want, 0, describe(view))
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_views_tiled_equals_untiled(gpu, seed):
+    """RasterTiler around a random view on MemorySources (zero-copy windows, batched tile programs,
+    in-place mosaic, ragged edge tiles) gives exactly the untiled result."""
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(30_000 + seed)
+    view = random_view(rng, "t%d" % seed, depth=3, memory=True)
+    try:
+        whole = view.get_data(**REQ)
+    except NotImplementedError as e:
+        pytest.skip("not on the device path: %s" % e)
+    for tile in ([8, 8], [16, 12], 17):
+        tiled = raster.RasterTiler(view, tile).get_data(**REQ)
+        assert_result_equal(unsigned_zero(tiled), unsigned_zero(whole), 0, "tile %s of %s" % (tile, describe(view)))
