@@ -64,3 +64,23 @@ def test_bench_harness_world_size_2_gloo():
     assert out["unit"] == "Mpix/s" and out["vs_baseline"] is None and "cpu_baseline" not in out
     # 2 ranks x 4 tiles x 64^2 px per step
     assert abs(out["value"] - 2 * 4 * 64 * 64 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) / out["value"] < 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_world_size_2_on_the_gpu_box(gpu):
+    """The N > 1 path on real hardware: two ranks under torch.distributed.run (gloo barrier +
+    max-reduce), each with its own batch of tiles, here sharing the box's single MI355X; one JSON
+    line from rank 0 whose value counts the pixels of both ranks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "10", "--warmup", "3", "--tiles", "4", "--side", "1024"]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=560, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 10 and out["data"] == "synthetic"
+    assert abs(out["value"] - 2 * 4 * 1024 * 1024 * 10 / (out["ms_per_step"] * 10e-3) / 1e6) / out["value"] < 0.01
+    assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out
