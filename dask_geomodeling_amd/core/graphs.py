@@ -76,6 +76,21 @@ def tokenize(*args):
     return h.hexdigest()
 
 
+_PLAIN = (str, int, float, bool, type(None), datetime, timedelta)
+
+
+def _request_token(block_token, request):
+    """Token of (block, request) for the graph key.  A tiled view asks for it once per Block per
+    tile, so requests made of plain scalars and tuples of them -- all raster requests -- take a
+    repr + one md5 instead of the general recursive tokeniser (6x cheaper)."""
+    for value in request.values():
+        if not isinstance(value, _PLAIN):
+            if not (isinstance(value, (tuple, list)) and all(isinstance(v, _PLAIN) for v in value)):
+                return tokenize([block_token, request])
+    text = repr(sorted(request.items()))
+    return hashlib.md5((block_token + text).encode()).hexdigest()
+
+
 if _dask_normalize_token is not None:  # pragma: no cover
     @_dask_normalize_token.register((datetime, timedelta))
     def _normalize_datetime(value):
@@ -307,7 +322,7 @@ class Block(object):
         return result
 
     def get_compute_graph(self, cached_compute_graph=None, **request):
-        token = tokenize([self.token, request])
+        token = _request_token(self.token, request)
         name = "{}_{}".format(self.__class__.__name__.lower(), token)
         graph = cached_compute_graph or dict()
         if name in graph:

@@ -348,6 +348,14 @@ def fuse_graph(graph, name):
     structurally identical, independent FusedTasks are BatchedTasks.  ``name`` is the key (or
     the list of keys) that will be asked of the graph."""
     names = set(name) if isinstance(name, (list, tuple, set)) else {name}
+    deps_memo = {}
+
+    def deps_of(key):  # (a tiled view has thousands of keys: every key's dependencies are parsed once)
+        hit = deps_memo.get(key)
+        if hit is None:
+            hit = deps_memo[key] = _deps(graph[key], graph)
+        return hit
+
     # consumers of every key, and a consumers-before-producers order starting at the outputs
     consumers = {}
     order, seen, stack = [], set(), [(k, False) for k in names]
@@ -360,7 +368,7 @@ def fuse_graph(graph, name):
             continue
         seen.add(key)
         stack.append((key, True))
-        for dep in _deps(graph[key], graph):
+        for dep in deps_of(key):
             consumers.setdefault(dep, set()).add(key)
             if dep not in seen:
                 stack.append((dep, False))
@@ -389,7 +397,7 @@ def fuse_graph(graph, name):
         member_set = set(members)
         leaf_keys = []
         for key in members:
-            for dep in _deps(graph[key], graph):
+            for dep in deps_of(key):
                 if dep not in member_set and dep not in leaf_keys:
                     leaf_keys.append(dep)
         fused[root] = FusedTask({k: graph[k] for k in members}, members, root, leaf_keys)
@@ -399,7 +407,7 @@ def fuse_graph(graph, name):
     if len(fused) > 1:
         depth = {}
         for key in reversed(order):  # producers first
-            depth[key] = 1 + max([depth[d] for d in _deps(graph[key], graph)] or [0])
+            depth[key] = 1 + max([depth[d] for d in deps_of(key)] or [0])
         for root, task in fused.items():
             if not task.leaf_keys:
                 continue

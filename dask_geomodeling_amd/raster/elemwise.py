@@ -96,12 +96,17 @@ class BaseElementwise(RasterBlock):
 
     @property
     def dtype(self):
-        # result_type over all arguments (python scalars are weak), lifted to >= int32 / float32
+        # result_type over all arguments (python scalars are weak), lifted to >= int32 / float32.
+        # Blocks are immutable: computed once (request planning asks for it per tile).
+        cached = self.__dict__.get("_dtype_cache")
+        if cached is not None:
+            return cached
         dtype = np.result_type(*[a.dtype if isinstance(a, RasterBlock) else a for a in self.args])
         if np.issubdtype(dtype, np.integer) or dtype == BOOL:
-            return np.result_type(dtype, np.int32)
-        if np.issubdtype(dtype, np.floating):
-            return np.result_type(dtype, np.float32)
+            dtype = np.result_type(dtype, np.int32)
+        elif np.issubdtype(dtype, np.floating):
+            dtype = np.result_type(dtype, np.float32)
+        self.__dict__["_dtype_cache"] = dtype
         return dtype
 
     @property

@@ -277,13 +277,29 @@ class MemorySource(RasterSourceBase):
     def temporal(self):
         return self.time_delta is not None
 
+    def _grid(self):
+        """(geo_transform, (west, south, east, north)) of the source, computed once (a tiled view asks
+        per tile)."""
+        hit = self.__dict__.get("_grid_cache")
+        if hit is None:
+            gt = self.geo_transform
+            hit = self.__dict__["_grid_cache"] = (gt, gt.get_bbox((0, 0), self.data.shape[1:]))
+        return hit
+
+    def _same_crs(self, projection):
+        memo = self.__dict__.setdefault("_crs_memo", {})
+        hit = memo.get(projection)
+        if hit is None:
+            hit = memo[projection] = utils.same_projection(projection, self.projection)
+        return hit
+
     def _is_whole_grid(self, request):
         """Does the request ask for exactly the source's own pixel grid (same bbox, one request
         cell per source pixel, same CRS)?"""
-        if not self.data.size or not utils.same_projection(request["projection"], self.projection):
+        if not self.data.size or not self._same_crs(request["projection"]):
             return False
         _, ny, nx = self.data.shape
-        west, south, east, north = self.geo_transform.get_bbox((0, 0), (ny, nx))
+        west, south, east, north = self._grid()[1]
         x1, y1, x2, y2 = request["bbox"]
         return (request["width"] == nx and request["height"] == ny and
                 x1 == west and y1 == south and x2 == east and y2 == north)
@@ -293,10 +309,10 @@ class MemorySource(RasterSourceBase):
         cell per source pixel, bbox on pixel edges, entirely inside the source -- else None.  Such
         a request (every tile a RasterTiler cuts from a pixel-aligned view) needs no resampling:
         the nearest-neighbour warp of sources.py:133-144 would copy the window unchanged."""
-        if not self.data.size or not utils.same_projection(request["projection"], self.projection):
+        if not self.data.size or not self._same_crs(request["projection"]):
             return None
         _, ny, nx = self.data.shape
-        p, a, _, q, _, d = self.geo_transform
+        p, a, _, q, _, d = self._grid()[0]
         x1, y1, x2, y2 = request["bbox"]
         w, h = request["width"], request["height"]
         if w <= 0 or h <= 0 or a <= 0 or d >= 0:
@@ -321,8 +337,11 @@ class MemorySource(RasterSourceBase):
         if start is None:
             return [({"mode": "empty_" + mode}, None)]
         bands = band1, band2 + 1
-        raster_data = RasterData(array=self.data, metadata=self.metadata, geo_transform=self.geo_transform,
-                                 no_data_value=self.no_data_value, projection=self.projection)
+        raster_data = self.__dict__.get("_raster_data")
+        if raster_data is None:  # one RasterData per source: it also carries the per-device upload
+            raster_data = self.__dict__["_raster_data"] = RasterData(
+                array=self.data, metadata=self.metadata, geo_transform=self.geo_transform,
+                no_data_value=self.no_data_value, projection=self.projection)
         if mode == "vals":
             kwargs = {"mode": "vals", "raster_data": raster_data, "bbox": request["bbox"],
                       "width": request["width"], "height": request["height"],
