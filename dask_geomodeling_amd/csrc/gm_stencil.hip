@@ -253,6 +253,40 @@ __global__ __launch_bounds__(256) void hillshade_kernel(const T* __restrict__ in
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Gaussian smoothing, one axis (Smooth.process, spatial.py:276-290 = scipy.ndimage.gaussian_filter)
+// ---------------------------------------------------------------------------------
+// SciPy's correlate1d for a symmetric kernel, literally: the line extended with the constant, in
+// float64, out = x[0] w[0] + sum over j = r..1 of (x[-j] + x[+j]) w[j] (farthest pair first), cast to
+// the tile's dtype.  The first axis also performs values[values == ndv] = fill (spatial.py:284-285).
+constexpr int GAUSS_MAX_RADIUS = 64;
+struct GaussArgs {
+  double w[GAUSS_MAX_RADIUS + 1];  // w[j]: weight at distance j
+  int radius;
+  double cval;
+};
+
+// grid: x over 256 output columns, y over output rows, z over bands; the output is the window
+// [y0, y0+oh) x [x0, x0+ow) of the filtered tile (the last axis of an "exact" Smooth crops its margins)
+template <typename T, bool ALONG_X>
+__global__ __launch_bounds__(256) void gauss_axis_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
+                                                         int y0, int x0, int oh, int ow, int replace_ndv, T ndv, T fill,
+                                                         GaussArgs A) {
+  const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y, b = blockIdx.z;
+  if (ox >= ow) return;
+  const int y = y0 + oy, x = x0 + ox;
+  const T* plane = in + (size_t)b * h * w;
+  const int n = ALONG_X ? w : h, at = ALONG_X ? x : y;
+  auto sample = [&](int i) -> double {  // element i of the line through (y, x)
+    if (i < 0 || i >= n) return A.cval;
+    const T v = ALONG_X ? plane[(size_t)y * w + i] : plane[(size_t)i * w + x];
+    return (double)((replace_ndv && v == ndv) ? fill : v);
+  };
+  double acc = sample(at) * A.w[0];
+  for (int j = A.radius; j >= 1; --j) acc += (sample(at - j) + sample(at + j)) * A.w[j];
+  out[((size_t)b * oh + oy) * ow + ox] = (T)acc;
+}
+
 template <typename T>
 T from_bits(uint64_t bits) {
   gm_scalar s;
@@ -344,6 +378,40 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
   }
 #undef GM_MM
 #undef GM_MM_R
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, const double* weights_host, int radius,
+                  double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh, int ow,
+                  void* out) {
+  if (!in || !out || !weights_host) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (dtype != GM_F32 && dtype != GM_F64) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: float tiles only");
+  if (axis != 1 && axis != 2) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: axis %d (1 = y, 2 = x)", axis);
+  if (radius < 0 || radius > GAUSS_MAX_RADIUS) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: radius %d (max %d)", radius, GAUSS_MAX_RADIUS);
+  if (bands <= 0 || oh <= 0 || ow <= 0) return GM_OK;
+  if (y0 < 0 || x0 < 0 || y0 + oh > h || x0 + ow > w) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: output window outside the tile");
+  if (bands > 65535 || oh > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: tile too tall / too many bands");
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  GaussArgs A;
+  memset(&A, 0, sizeof(A));
+  for (int j = 0; j <= radius; ++j) A.w[j] = weights_host[j];
+  A.radius = radius;
+  A.cval = cval;
+  dim3 grid((unsigned)((ow + 255) / 256), (unsigned)oh, (unsigned)bands);
+#define GM_GAUSS(T)                                                                                            \
+  do {                                                                                                         \
+    if (axis == 2)                                                                                             \
+      hipLaunchKernelGGL((gauss_axis_kernel<T, true>), grid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, y0, \
+                         x0, oh, ow, replace_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);         \
+    else                                                                                                       \
+      hipLaunchKernelGGL((gauss_axis_kernel<T, false>), grid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, y0, \
+                         x0, oh, ow, replace_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);         \
+  } while (0)
+  if (dtype == GM_F32) GM_GAUSS(float);
+  else GM_GAUSS(double);
+#undef GM_GAUSS
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

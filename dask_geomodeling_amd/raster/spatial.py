@@ -17,7 +17,7 @@ import numpy as np
 from . import resample, stencil
 from .base import BaseSingle
 
-__all__ = ["SpatialResample", "Dilate", "MovingMax", "HillShade"]
+__all__ = ["SpatialResample", "Dilate", "MovingMax", "HillShade", "Smooth"]
 
 
 def expand_request_pixels(request, radius=1):
@@ -190,3 +190,82 @@ class SpatialResample(BaseSingle):
             out = resample.nearest_warp(values, gt, (0.0, 0.0, float(ws), float(hs)), h, w, ndv,
                                         finite_to_fill=False)
         return {"values": out, "no_data_value": ndv}
+
+
+def _metres_per_unit(projection):
+    """Length of one projection unit in metres for the projected CRSs this path knows (the
+    reference asks GDAL: spatial.py:61-72).  Geographic CRSs would need a re-projection of the
+    bounding box (PROJ), which this path does not carry."""
+    from ..utils import parse_epsg
+    code = parse_epsg(projection)
+    metric = code is not None and (code in (28992, 3857, 3035, 31370, 2154, 25831, 25832, 25833, 27700) or
+                                   32601 <= code <= 32660 or 32701 <= code <= 32760)
+    if not metric:
+        raise NotImplementedError("Smooth needs a projected CRS in metres that this path knows; got {}".format(projection))
+    return 1.0
+
+
+class Smooth(BaseSingle):
+    """Gaussian smoothing over ``size`` metres, sigma = size / 3 (spatial.py:216-318).  'no data' is
+    replaced by ``fill`` before smoothing.  Requests whose margin would exceed 6 pixels are answered
+    at the coarser ('zoom') resolution and zoomed back with nearest neighbour, like the reference."""
+
+    MARGIN_THRESHOLD = 6
+
+    def __init__(self, store, size, fill=0):
+        for x in (size, fill):
+            if not isinstance(x, (int, float)):
+                raise TypeError("'{}' object is not allowed".format(type(x)))
+        super(Smooth, self).__init__(store, size, fill)
+
+    size = property(lambda self: self.args[1])
+    fill = property(lambda self: self.args[2])
+
+    def _margins(self, request):
+        """(enlarged request, radius in pixels (y, x)) -- expand_request_meters, spatial.py:50-108."""
+        radius = self.size / _metres_per_unit(request["projection"])
+        x1, y1, x2, y2 = request["bbox"]
+        span_y, span_x = y2 - y1, x2 - x1
+        grown = request.copy()
+        if span_y > 0 and span_x > 0:
+            per_metre = request["height"] / span_y, request["width"] / span_x   # pixels per metre
+            radius_px = [radius * r for r in per_metre]
+            whole_px = [int(round(r)) for r in radius_px]                          # margin in whole pixels
+            margin = [px / r for px, r in zip(whole_px, per_metre)]               # ... and back in metres
+        else:  # point request: no resolution to speak of
+            radius_px = whole_px = [self.MARGIN_THRESHOLD] * 2
+            margin = [radius] * 2
+        grown["bbox"] = (x1 - margin[1], y1 - margin[0], x2 + margin[1], y2 + margin[0])
+        grown["height"] += 2 * whole_px[0]
+        grown["width"] += 2 * whole_px[1]
+        return grown, radius_px
+
+    def get_sources_and_requests(self, **request):
+        if request["mode"] != "vals":
+            return [(self.store, request)]
+        grown, size = self._margins(request)
+        if any(s > self.MARGIN_THRESHOLD for s in size):
+            mode = "zoom"  # smooth on the original pixel count over the enlarged box, zoom back afterwards
+            zoom = [grown[k] / request[k] for k in ("height", "width")]
+            size = [s / z for s, z in zip(size, zoom)]
+            grown["height"], grown["width"] = request["height"], request["width"]
+        else:
+            mode = "exact"
+        return [(self.store, grown), (dict(smooth_mode=mode, fill=self.fill, size=size), None)]
+
+    @staticmethod
+    def process(data, process_kwargs=None):
+        if data is None or process_kwargs is None:
+            return data
+        size_px, fill = process_kwargs["size"], process_kwargs["fill"]
+        sigma = size_px[0] / 3, size_px[1] / 3
+        ndv = data["no_data_value"]
+        if process_kwargs["smooth_mode"] == "exact":
+            crop = [int(round(s)) for s in size_px]
+            values = stencil.gaussian_smooth(data["values"], ndv, fill, sigma, crop)
+        else:
+            values = stencil.gaussian_smooth(data["values"], ndv, fill, sigma)
+            _, ny, nx = values.shape
+            zoom = 1 - 2 * size_px[0] / ny, 1 - 2 * size_px[1] / nx
+            values = resample.affine_nearest(values, zoom, (size_px[0], size_px[1]))
+        return {"values": values, "no_data_value": ndv}

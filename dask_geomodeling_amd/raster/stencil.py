@@ -23,6 +23,10 @@ def _lib():
         L.gm_hillshade.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_uint64, c.c_uint64,
                                    c.c_double, c.c_double, c.c_double, c.c_double, c.c_void_p]
         L.gm_hillshade.restype = c.c_int
+        L.gm_gauss_axis.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_double),
+                                    c.c_int, c.c_double, c.c_int, c.c_uint64, c.c_uint64, c.c_int, c.c_int, c.c_int,
+                                    c.c_int, c.c_void_p]
+        L.gm_gauss_axis.restype = c.c_int
         _declared = True
     return L
 
@@ -84,3 +88,44 @@ def hillshade(values, no_data_value, fill, resolution, altitude, azimuth):
                                       runtime.scalar_bits(fill_cast, src.dtype), float(resolution[0]), float(resolution[1]),
                                       float(altitude), float(azimuth), ctypes.c_void_p(out.ptr)), "gm_hillshade")
     return out
+
+
+def gaussian_weights(sigma, truncate=4.0):
+    """SciPy's Gaussian kernel (scipy.ndimage._filters._gaussian_kernel1d, order 0): weights by
+    distance 0..radius, radius = int(truncate * sigma + 0.5); normalised over the full kernel."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    phi = phi / phi.sum()
+    return np.ascontiguousarray(phi[radius:], dtype=np.float64), radius
+
+
+def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0)):
+    """values[values == ndv] = fill, then ndimage.gaussian_filter(values, (0, sy, sx), mode="constant",
+    cval=fill) axis by axis (the second axis reads the first one's result in the tile's dtype), the
+    result cropped by ``crop_yx`` pixels on every side."""
+    src = as_device(values)
+    if src.dtype.kind != "f":
+        raise NotImplementedError("Smooth on %s tiles (float rasters only)" % src.dtype)
+    bands, h, w = src.shape
+    has, ndv_bits = _ndv_bits(src.dtype, no_data_value)
+    with np.errstate(all="ignore"):
+        fill_cast = np.array(fill).astype(src.dtype)[()]
+    fill_bits = runtime.scalar_bits(fill_cast, src.dtype)
+    axes = [(axis, sigma) for axis, sigma in ((1, sigma_yx[0]), (2, sigma_yx[1])) if sigma > 1e-15]
+    if not axes:  # nothing to smooth: one pass with the identity kernel does the no-data replacement and the crop
+        axes = [(2, None)]
+    my, mx = crop_yx
+    current, replace = src, has
+    L = _lib()
+    for k, (axis, sigma) in enumerate(axes):
+        weights, radius = gaussian_weights(sigma) if sigma is not None else (np.ones(1, dtype=np.float64), 0)
+        last = k == len(axes) - 1
+        y0, x0, oh, ow = (my, mx, h - 2 * my, w - 2 * mx) if last else (0, 0, h, w)
+        out = DeviceArray.empty((bands, oh, ow), src.dtype)
+        runtime.check(L.gm_gauss_axis(ctypes.c_void_p(current.ptr), code_of(src.dtype), bands, h, w, axis,
+                                      weights.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), radius, float(fill),
+                                      1 if replace else 0, ndv_bits, fill_bits, y0, x0, oh, ow,
+                                      ctypes.c_void_p(out.ptr)), "gm_gauss_axis")
+        current, replace = out, 0
+    return current

@@ -346,6 +346,15 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
 int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv, uint64_t ndv_bits, uint64_t fill_bits,
                  double xres, double yres, double altitude_deg, double azimuth_deg, void* out);
 
+/* One axis (1 = y, 2 = x) of scipy.ndimage.gaussian_filter as Smooth.process calls it
+ * (spatial.py:276-290; mode="constant"): weights_host[j] = weight at distance j (radius + 1 float64
+ * values), accumulation in float64 in SciPy's order, result cast to the tile's dtype (float32 /
+ * float64).  replace_ndv: cells equal to ndv are read as fill (the first axis of Smooth does
+ * values[values == ndv] = fill).  out = the window [y0, y0+oh) x [x0, x0+ow) of the filtered tile. */
+int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, const double* weights_host, int radius,
+                  double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh, int ow,
+                  void* out);
+
 /* =============================================================================
  * K8: helpers
  * ========================================================================== */

@@ -613,3 +613,52 @@ def reduce_max_process(process_kwargs, *args):
         not_all_nan = ~np.all(np.isnan(work), axis=0)
         out[not_all_nan] = np.nanmax(work[:, not_all_nan], axis=0)
     return {"values": out, "no_data_value": fill}
+
+
+# --------------------------------------------------------------------------
+# Smooth.process (raster/spatial.py:276-308): scipy.ndimage.gaussian_filter restated.
+# SciPy's correlate1d (ni_filters.c) extends each line with the constant, converts it to
+# float64 and, for a symmetric kernel, evaluates
+#     out[l] = x[l]*w[0] + sum_{j = r .. 1} (x[l-j] + x[l+j]) * w[j]      (farthest pair first)
+# in float64; the result is cast to the array's dtype after every axis (output=values: the
+# second axis reads what the first one wrote).
+# --------------------------------------------------------------------------
+def gaussian_weights(sigma, truncate=4.0):
+    """scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, radius), radius = int(truncate*sigma + 0.5)."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return phi / phi.sum(), radius
+
+
+def gaussian_axis(values, sigma, axis, cval):
+    weights, radius = gaussian_weights(sigma)
+    x = np.moveaxis(values, axis, -1).astype(np.float64)
+    n = x.shape[-1]
+    pad = np.full(x.shape[:-1] + (radius,), float(cval), dtype=np.float64)
+    line = np.concatenate([pad, x, pad], axis=-1)
+    centre = weights[radius]
+    out = line[..., radius:radius + n] * centre
+    for j in range(radius, 0, -1):
+        out = out + (line[..., radius - j:radius - j + n] + line[..., radius + j:radius + j + n]) * weights[radius - j]
+    return np.moveaxis(out.astype(values.dtype), -1, axis)
+
+
+def smooth_process(data, process_kwargs=None):
+    if data is None or process_kwargs is None:
+        return data
+    smooth_mode, size_px, fill = process_kwargs["smooth_mode"], process_kwargs["size"], process_kwargs["fill"]
+    values = data["values"].copy()
+    no_data_value = data["no_data_value"]
+    values[values == no_data_value] = fill
+    for axis, sigma in ((1, size_px[0] / 3), (2, size_px[1] / 3)):
+        if sigma > 1e-15:
+            values = gaussian_axis(values, sigma, axis, fill)
+    if smooth_mode == "exact":
+        my, mx = [int(round(s)) for s in size_px]
+        values = values[:, my:values.shape[1] - my, mx:values.shape[2] - mx]
+    else:
+        _, ny, nx = values.shape
+        zy, zx = 1 - 2 * size_px[0] / ny, 1 - 2 * size_px[1] / nx
+        values = affine_nearest(values, (zy, zx), (size_px[0], size_px[1]))
+    return {"values": values, "no_data_value": no_data_value}

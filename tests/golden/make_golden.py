@@ -895,12 +895,33 @@ def gen_group(w):
                 cid += 1
 
 
+# --------------------------------------------------------------------------
+# family: smooth  (reference: raster/spatial.py:276-308; SciPy gaussian_filter + zoom)
+# --------------------------------------------------------------------------
+def gen_smooth(w):
+    from dask_geomodeling.raster import spatial as R_sp
+    rng = np.random.default_rng(111)
+    cid = 0
+    for dt, ndv in (("f4", np.float32(F32MAX)), ("f8", F64MAX), ("f4", np.float32(-9999.0))):
+        for shape, size, mode in (((1, 30, 41), (2.0, 3.0), "exact"), ((2, 17, 19), (1.0, 1.0), "exact"),
+                                  ((1, 24, 24), (4.6, 0.5), "exact"), ((1, 40, 48), (3.75, 6.0), "zoom"),
+                                  ((1, 33, 20), (5.2, 2.9), "zoom"), ((1, 12, 12), (0.2, 0.2), "exact")):
+            for fill in (0, 2.5):
+                v = (rng.random(shape) * 50).astype(dt)
+                v[rng.random(shape) < 0.1] = ndv
+                data = {"values": v, "no_data_value": ndv}
+                kw = dict(smooth_mode=mode, fill=fill, size=list(size))
+                w.add(id="sm%04d" % cid, op="smooth", args=[data, kw], expect=R_sp.Smooth.process(data, kw)); cid += 1
+    for args in ([None, dict(smooth_mode="exact", fill=0, size=[1.0, 1.0])], [{"time": ["t"]}, None]):
+        w.add(id="sm%04d" % cid, op="smooth", args=args, expect=R_sp.Smooth.process(*args)); cid += 1
+
+
 def main():
     fams = {
         "math": gen_math, "n1": gen_n1, "clip": gen_clip, "mask": gen_mask,
         "classify": gen_classify, "reclassify": gen_reclassify, "tiler": gen_tiler,
         "views": gen_views, "dtypes": gen_dtypes, "smoothzoom": gen_smoothzoom,
-        "spatial": gen_spatial, "reduce": gen_reduce, "group": gen_group,
+        "spatial": gen_spatial, "reduce": gen_reduce, "group": gen_group, "smooth": gen_smooth,
     }
     only = sys.argv[1:]
     counts = {}

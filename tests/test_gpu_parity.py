@@ -648,3 +648,33 @@ def test_group_golden(gpu, case):
         assert out is None
     else:
         assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+# ---- Smooth ---------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", load_family("smooth"), ids=lambda c: c["id"])
+def test_smooth_golden(gpu, case):
+    """Gaussian smoothing (SciPy's correlate1d order in float64, axis by axis) + crop / zoom against
+    the reference's own results: bit-exact."""
+    from dask_geomodeling_amd import raster
+    out = raster.Smooth.process(*case["args"])
+    assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.mark.gpu
+def test_smooth_block_requests_and_large_tile(gpu):
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(31)
+    fill = np.float32(np.finfo("f4").max)
+    a = (rng.random((1, 300, 420)) * 100).astype("f4")
+    a[0, 50:60, 70:90] = fill
+    src = raster.MemorySource(a, fill, "EPSG:28992", 0.5, (0.0, 150.0))
+    req = dict(mode="vals", bbox=(20.0, 20.0, 120.0, 100.0), width=200, height=160, projection="EPSG:28992")
+    for size in (1.4, 12.0):  # exact (margin 3 px) and zoom mode (margin 24 px)
+        block = raster.Smooth(src, size, fill=1.5)
+        (store, grown), (kw, _) = block.get_sources_and_requests(**req)
+        assert kw["smooth_mode"] == ("exact" if size < 3.5 else "zoom")
+        want = O.smooth_process(src.get_data(**grown), kw)
+        assert_result_equal(block.get_data(**req), want, 0, "Smooth size %s" % size)
+    with pytest.raises(NotImplementedError):
+        raster.Smooth(src, 2).get_sources_and_requests(**dict(req, projection="EPSG:4326"))

@@ -213,3 +213,9 @@ def test_spatial(case):
 def test_reduce_max(case):
     out = O.reduce_max_process(*case["args"])
     assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.mark.parametrize("case", load_family("smooth"), ids=lambda c: c["id"])
+def test_smooth(case):
+    out = O.smooth_process(*case["args"])
+    assert_result_equal(out, case["expect"], 0, case["id"])
