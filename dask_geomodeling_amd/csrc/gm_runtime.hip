@@ -204,6 +204,59 @@ int gm_free(void* ptr) {
   return fail(GM_ERR_INVALID, "gm_free: pointer %p not allocated by gm_malloc", ptr);
 }
 
+// ---- pinned host buffers for results handed back to the host -----------------------------------
+// A device-to-host copy into pageable memory runs at ~3 GB/s here (page faults of a fresh
+// destination + the runtime's staging); into pinned memory at PCIe speed.  Pinning is expensive,
+// so buffers are recycled by size (bounded cache).
+namespace {
+std::mutex g_host_mu;
+std::multimap<size_t, void*> g_host_cached;
+std::unordered_map<void*, size_t> g_host_live;
+size_t g_host_cached_bytes = 0;
+constexpr size_t kHostCacheLimit = 8ull << 30;
+}  // namespace
+
+int gm_host_malloc(void** ptr, size_t bytes) {
+  if (!ptr) return fail(GM_ERR_INVALID, "null pointer");
+  if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  const size_t sz = round_size(bytes);
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  auto it = g_host_cached.find(sz);
+  if (it != g_host_cached.end()) {
+    *ptr = it->second;
+    g_host_cached.erase(it);
+    g_host_cached_bytes -= sz;
+  } else {
+    hipError_t e = hipHostMalloc(ptr, sz, hipHostMallocNonCoherent);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      for (auto& kv : g_host_cached) (void)hipHostFree(kv.second);
+      g_host_cached.clear();
+      g_host_cached_bytes = 0;
+      e = hipHostMalloc(ptr, sz, hipHostMallocNonCoherent);
+      if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+    }
+  }
+  g_host_live[*ptr] = sz;
+  return GM_OK;
+}
+
+int gm_host_free(void* ptr) {
+  if (!ptr) return GM_OK;
+  std::lock_guard<std::mutex> lk(g_host_mu);
+  auto it = g_host_live.find(ptr);
+  if (it == g_host_live.end()) return fail(GM_ERR_INVALID, "gm_host_free: pointer %p not allocated by gm_host_malloc", ptr);
+  const size_t sz = it->second;
+  g_host_live.erase(it);
+  if (g_host_cached_bytes + sz > kHostCacheLimit) {
+    (void)hipHostFree(ptr);
+  } else {
+    g_host_cached.emplace(sz, ptr);
+    g_host_cached_bytes += sz;
+  }
+  return GM_OK;
+}
+
 int gm_pool_trim(void) {
   DeviceState* d = nullptr;
   int rc = current(&d);

@@ -68,6 +68,7 @@ def _declare(L):
         "gm_mem_info": [c.POINTER(sz), c.POINTER(sz)],
         "gm_pool_stats": [c.POINTER(sz), c.POINTER(sz)],
         "gm_h2d": [vp, vp, sz], "gm_d2h": [vp, vp, sz], "gm_d2d": [vp, vp, sz],
+        "gm_host_malloc": [c.POINTER(vp), sz], "gm_host_free": [vp],
         "gm_memset": [vp, i32, sz], "gm_sync": [],
         "gm_event_create": [c.POINTER(vp)], "gm_event_destroy": [vp], "gm_event_record": [vp],
         "gm_event_sync": [vp], "gm_event_elapsed_ms": [vp, vp, c.POINTER(c.c_float)],
@@ -130,6 +131,35 @@ def malloc(nbytes):
 def free(ptr):
     if ptr:
         lib().gm_free(ctypes.c_void_p(ptr))
+
+
+class _Pinned(object):
+    """Owner of one pinned host buffer; goes back to the library's cache when the last ndarray
+    viewing it dies."""
+
+    def __init__(self, nbytes):
+        p = ctypes.c_void_p()
+        check(lib().gm_host_malloc(ctypes.byref(p), nbytes), "gm_host_malloc(%d)" % nbytes)
+        self.ptr = p.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().gm_host_free(ctypes.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """ndarray of ``shape`` / ``dtype`` in pinned host memory (a device-to-host copy into it runs at
+    PCIe speed); the buffer is recycled when the array and all views of it are gone."""
+    import numpy as np
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    owner = _Pinned(max(nbytes, 1))
+    raw = (ctypes.c_ubyte * max(nbytes, 1)).from_address(owner.ptr)
+    raw._owner = owner  # the ndarray keeps `raw` alive, `raw` keeps the pinned buffer alive
+    return np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
 
 
 def pool_trim():

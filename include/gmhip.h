@@ -84,6 +84,10 @@ int gm_pool_trim(void);                      /* hipFree all cached blocks */
 int gm_mem_info(size_t* free_bytes, size_t* total_bytes);
 int gm_pool_stats(size_t* in_use_bytes, size_t* cached_bytes);
 
+/* Pinned host buffers (recycled by size) for results handed back to the host: gm_d2h into one runs
+ * at PCIe speed, into pageable memory at a small fraction of it. */
+int gm_host_malloc(void** ptr, size_t bytes);
+int gm_host_free(void* ptr);
 int gm_h2d(void* dst_dev, const void* src_host, size_t bytes); /* returns after the copy */
 int gm_d2h(void* dst_host, const void* src_dev, size_t bytes); /* returns after the copy */
 int gm_d2d(void* dst_dev, const void* src_dev, size_t bytes);  /* async */
