@@ -78,7 +78,9 @@ class RasterTiler(BaseSingle):
         fill = process_kwargs["fillvalue"]
         mosaic = DeviceArray.empty((bands, height, width), dtype)
         L = runtime.lib()
-        runtime.check(L.gm_fill(ctypes.c_void_p(mosaic.ptr), code_of(dtype), runtime.scalar_bits(fill, dtype),
+        # (a boolean view has no fill value: np.full(shape, None, dtype=bool) of the reference is all False)
+        runtime.check(L.gm_fill(ctypes.c_void_p(mosaic.ptr), code_of(dtype),
+                                runtime.scalar_bits(False if fill is None else fill, dtype),
                                 mosaic.size), "gm_fill")
         count_x, count_y = process_kwargs["count_xy"]
         tile_x, tile_y = process_kwargs["tilesize_xy"]

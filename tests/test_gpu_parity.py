@@ -678,3 +678,20 @@ def test_smooth_block_requests_and_large_tile(gpu):
         assert_result_equal(block.get_data(**req), want, 0, "Smooth size %s" % size)
     with pytest.raises(NotImplementedError):
         raster.Smooth(src, 2).get_sources_and_requests(**dict(req, projection="EPSG:4326"))
+
+
+@pytest.mark.gpu
+def test_tiler_over_boolean_view(gpu):
+    """A boolean view has no fill value (np.full(shape, None, dtype=bool) is all False in the
+    reference's assembly): found by the fuzzer."""
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(5)
+    v = rng.integers(0, 10, size=(1, 24, 40)).astype("i4")
+    v[0, ::3, ::4] = -1
+    src = raster.MemorySource(v, -1, "EPSG:28992", 1.0, (0.0, 24.0))
+    view = raster.GreaterEqual(raster.Clip(raster.Reclassify(src, [[1, 5], [2, 7]]), src), 5)
+    req = dict(mode="vals", bbox=(0.0, 0.0, 40.0, 24.0), width=40, height=24, projection="EPSG:28992")
+    whole = view.get_data(**req)
+    assert whole["values"].dtype == np.dtype("bool") and whole["no_data_value"] is None
+    for tile in ([7, 5], 16):
+        assert_result_equal(raster.RasterTiler(view, tile).get_data(**req), whole, 0, "bool view, tile %s" % (tile,))

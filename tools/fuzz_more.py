@@ -1,0 +1,34 @@
+"""One-off: many more fuzz seeds than the test suite runs (GPU box)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from fuzz_util import REQ, describe, oracle_eval, random_view, unsigned_zero
+from helpers import assert_result_equal
+from dask_geomodeling_amd import raster
+from dask_geomodeling_amd.hip import runtime
+runtime.set_device(0)
+bad = skipped = 0
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+for seed in range(N):
+    rng = np.random.default_rng(50_000 + seed)
+    memory = seed % 3 == 0
+    view = random_view(rng, "x%d" % seed, depth=int(rng.integers(2, 6)), memory=memory)
+    try:
+        if memory:
+            whole = view.get_data(**REQ)
+            tiled = raster.RasterTiler(view, [int(rng.integers(5, 30)), int(rng.integers(5, 20))]).get_data(**REQ)
+            assert_result_equal(unsigned_zero(tiled), unsigned_zero(whole), 0, "tiled")
+        else:
+            with np.errstate(all="ignore"):
+                want = unsigned_zero(oracle_eval(view))
+            assert_result_equal(unsigned_zero(view.get_data(**REQ)), want, 0, "fused")
+    except NotImplementedError:
+        skipped += 1
+    except Exception as e:  # noqa
+        bad += 1
+        print("SEED", seed, type(e).__name__, str(e)[:300])
+        print("   ", describe(view)[:400])
+        if bad > 8:
+            break
+print("done: %d views, %d skipped, %d failures" % (N, skipped, bad))
