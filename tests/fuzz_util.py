@@ -52,6 +52,18 @@ def random_view(rng, tag, depth=4, memory=False):
             return leaves[int(rng.integers(len(leaves)))]
         choice = rng.random()
         a = numeric(d - 1)
+        if memory and rng.random() < 0.12:
+            # stencils answer through request enlargement: only meaningful on real sources
+            # (Smooth is left out of the tiled == whole comparison: the reference's own margin, round(size),
+            #  is smaller than scipy's kernel radius, int(4 * size / 3 + 0.5), so its result depends on the
+            #  request box by construction -- spatial.py:255-295.  The golden 'smooth' family covers it.)
+            kind = int(rng.integers(4))
+            if kind == 0 and a.dtype != np.dtype("bool"):
+                return raster.MovingMax(a, [3, 5, 7][int(rng.integers(3))])
+            if kind == 1 and a.dtype != np.dtype("bool"):
+                return raster.Dilate(a, [int(x) for x in rng.integers(0, 12, size=int(rng.integers(1, 4)))])
+            if kind == 3 and a.dtype != np.dtype("bool") and not (a.dtype.kind == "u" and a.dtype.itemsize == 8):
+                return raster.HillShade(a, 45, 315, int(rng.integers(0, 3)))
         if choice < 0.45:
             op = ["Add", "Subtract", "Multiply", "Divide"][int(rng.integers(4))]
             b = numeric(d - 1) if rng.random() < 0.5 else [2.5, 3, -1.5, 0.5, 7][int(rng.integers(5))]
@@ -137,6 +149,8 @@ def oracle_eval(block):
 
 
 def describe(block, depth=0):
+    if isinstance(block, np.ndarray):
+        return "array<%s%s>" % (block.dtype, list(block.shape))
     if not isinstance(block, raster.RasterBlock):
         return repr(block)
     if isinstance(block, ArrayLeaf):

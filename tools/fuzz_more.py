@@ -27,8 +27,8 @@ for seed in range(N):
         skipped += 1
     except Exception as e:  # noqa
         bad += 1
-        print("SEED", seed, type(e).__name__, str(e)[:300])
+        print("SEED", seed, type(e).__name__, str(e)[:160])
         print("   ", describe(view)[:400])
-        if bad > 8:
+        if bad > 40:
             break
 print("done: %d views, %d skipped, %d failures" % (N, skipped, bad))
