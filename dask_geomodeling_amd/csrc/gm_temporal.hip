@@ -1,0 +1,440 @@
+// N4: statistics over the band (time) axis -- TemporalAggregate.process (raster/temporal.py:676-768)
+// and Cumulative.process (raster/temporal.py:912-1003).
+//
+// The host maps every output label to a run of consecutive source frames (pandas resampler bins of
+// an ascending time axis).  A lane owns V consecutive pixels and walks the frames of its bin in
+// order, so every wave-instruction reads one contiguous span of a frame; a workgroup row (blockIdx.y)
+// is one bin.  Every frame is read once (twice for var / std: mean first, deviations second), the
+// result is written once: an HBM stream of frames * itemsize + labels * out_itemsize bytes per pixel.
+//
+// Arithmetic follows NumPy's reductions over axis 0 of a C-contiguous stack, which accumulate frame
+// by frame in the working dtype C = result_type(float32, out dtype): no data (and NaN) is skipped
+// (nansum adds +0, nanmin / nanmax are fmin / fmax), the mean is float64(sum) / float64(count)
+// rounded to C (np.true_divide of a float32 array by an intp count runs the float64 loop), the
+// variance is the mean of squared float-C deviations from that mean.  No FMA contraction
+// (-ffp-contract=off) so every step rounds as NumPy's does.
+#include <cmath>
+#include <limits>
+#include <type_traits>
+
+#include "gm_common.h"
+
+namespace {
+
+constexpr int TB_MAX_BINS = 96;  // bins per launch (kernarg resident)
+struct Bins {
+  int first[TB_MAX_BINS];  // first source frame of the bin
+  int count[TB_MAX_BINS];  // frames in the bin (0: the label has no frame)
+  int out[TB_MAX_BINS];    // aggregate: output frame of the bin
+};
+
+// gm_scalar payload -> T (float tiles carry float64 bits, integer tiles int64 bits)
+template <typename T>
+T from_bits(uint64_t bits) {
+  gm_scalar s;
+  s.u64 = bits;
+  if constexpr (std::is_floating_point<T>::value) return (T)s.f64;
+  else return (T)s.i64;
+}
+
+// working dtype: result_type(float32, out dtype)
+template <typename Tout>
+struct Work {
+  using type = typename std::conditional<(sizeof(Tout) <= 2) || std::is_same<Tout, float>::value, float, double>::type;
+};
+// output dtype of a statistic (utils.py:826-845)
+template <typename Tin, int STAT>
+struct OutOf {
+  using sum_t = typename std::conditional<
+      std::is_floating_point<Tin>::value, Tin,
+      typename std::conditional<(sizeof(Tin) < 4), int,
+                                typename std::conditional<std::is_same<Tin, unsigned int>::value, long long, Tin>::type>::type>::type;
+  using mean_t = typename std::conditional<(sizeof(Tin) <= 2) || std::is_same<Tin, float>::value, float, double>::type;
+  using type = typename std::conditional<
+      STAT == GM_STAT_MIN || STAT == GM_STAT_MAX, Tin,
+      typename std::conditional<STAT == GM_STAT_SUM, sum_t,
+                                typename std::conditional<STAT == GM_STAT_COUNT, int, mean_t>::type>::type>::type;
+};
+
+template <typename T, int V>
+struct Pack {
+  T v[V];
+};
+
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> load_pack(const T* p) {
+  Pack<T, V> r;
+  if constexpr (V == 1) {
+    r.v[0] = __builtin_nontemporal_load(p);
+  } else if constexpr (sizeof(T) * V == 4) {
+    const unsigned w = __builtin_nontemporal_load((const unsigned*)p);
+    memcpy(&r, &w, 4);
+  } else if constexpr (sizeof(T) * V == 8) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 w = __builtin_nontemporal_load((const u2*)p);
+    memcpy(&r, &w, 8);
+  } else {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    constexpr int N = (int)(sizeof(T) * V / 16);
+    u4 w[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = __builtin_nontemporal_load((const u4*)p + i);
+    memcpy(&r, w, sizeof(r));
+  }
+  return r;
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void store_pack(T* p, const Pack<T, V>& r) {
+  if constexpr (V == 1) {
+    __builtin_nontemporal_store(r.v[0], p);
+  } else if constexpr (sizeof(T) * V == 4) {
+    unsigned w;
+    memcpy(&w, &r, 4);
+    __builtin_nontemporal_store(w, (unsigned*)p);
+  } else if constexpr (sizeof(T) * V == 8) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 w;
+    memcpy(&w, &r, 8);
+    __builtin_nontemporal_store(w, (u2*)p);
+  } else {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    constexpr int N = (int)(sizeof(T) * V / 16);
+    u4 w[N];
+    memcpy(w, &r, sizeof(r));
+#pragma unroll
+    for (int i = 0; i < N; ++i) __builtin_nontemporal_store(w[i], (u4*)p + i);
+  }
+}
+
+template <typename C>
+__device__ __forceinline__ bool finite_(C x) {
+  return fabs(x) <= std::numeric_limits<C>::max();  // false for NaN and +-inf
+}
+
+// One frame value -> (working value, skipped?).  values == no_data_value on the source dtype, NaN
+// sources are NaN in the working dtype already (temporal.py:738-741).
+template <typename Tin, typename C>
+__device__ __forceinline__ bool skipped(Tin v, Tin ndv, bool has_ndv, C& x) {
+  x = (C)v;
+  bool nd = has_ndv & (v == ndv);
+  if constexpr (std::is_floating_point<Tin>::value) nd |= (v != v);
+  return nd;
+}
+
+constexpr int TB_UNROLL = 4;  // frames in flight per lane
+
+// grid: x over groups of 256 * V pixels, y over bins
+template <typename Tin, int STAT, int V>
+__global__ __launch_bounds__(256) void aggregate_kernel(const Tin* __restrict__ frames, Tin ndv, bool has_ndv,
+                                                        long long pixels, Bins B,
+                                                        typename OutOf<Tin, STAT>::type* __restrict__ out,
+                                                        typename OutOf<Tin, STAT>::type fill) {
+  using Tout = typename OutOf<Tin, STAT>::type;
+  using C = typename Work<Tout>::type;
+  const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
+  if (p >= pixels) return;
+  const int first = B.first[blockIdx.y], count = B.count[blockIdx.y];
+  const Tin* src = frames + (long long)first * pixels + p;
+  C acc[V];    // sum / min / max
+  int cnt[V];  // frames that are data
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    acc[e] = (STAT == GM_STAT_MIN || STAT == GM_STAT_MAX) ? std::numeric_limits<C>::quiet_NaN() : (C)0;
+    cnt[e] = 0;
+  }
+  auto take = [&](const Pack<Tin, V>& f, bool is_first) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      C x;
+      const bool nd = skipped<Tin, C>(f.v[e], ndv, has_ndv, x);
+      cnt[e] += nd ? 0 : 1;
+      if constexpr (STAT == GM_STAT_MIN) {
+        // np.fmin.reduce: (acc <= x || isnan(x)) ? acc : x, the accumulator being the first operand
+        const C y = nd ? std::numeric_limits<C>::quiet_NaN() : x;
+        acc[e] = (acc[e] <= y || y != y) ? acc[e] : y;
+      } else if constexpr (STAT == GM_STAT_MAX) {
+        const C y = nd ? std::numeric_limits<C>::quiet_NaN() : x;
+        acc[e] = (acc[e] >= y || y != y) ? acc[e] : y;
+      } else if constexpr (STAT != GM_STAT_COUNT) {
+        const C y = nd ? (C)0 : x;
+        acc[e] = is_first ? y : acc[e] + y;  // np.add.reduce starts from the first frame (keeps a -0.0)
+      }
+    }
+  };
+  int j = 0;
+  if (count > 0) {
+    take(load_pack<Tin, V>(src), true);
+    j = 1;
+  }
+  for (; j + TB_UNROLL <= count; j += TB_UNROLL) {
+    Pack<Tin, V> f[TB_UNROLL];
+#pragma unroll
+    for (int u = 0; u < TB_UNROLL; ++u) f[u] = load_pack<Tin, V>(src + (long long)(j + u) * pixels);
+#pragma unroll
+    for (int u = 0; u < TB_UNROLL; ++u) take(f[u], false);
+  }
+  for (; j < count; ++j) take(load_pack<Tin, V>(src + (long long)j * pixels), false);
+
+  Pack<Tout, V> res;
+  if constexpr (STAT == GM_STAT_COUNT) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) res.v[e] = cnt[e];
+  } else {
+    C r[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) r[e] = acc[e];
+    if constexpr (STAT == GM_STAT_MEAN || STAT == GM_STAT_VAR || STAT == GM_STAT_STD) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) r[e] = (C)((double)acc[e] / (double)cnt[e]);  // 0 / 0 = NaN: no data
+    }
+    if constexpr (STAT == GM_STAT_VAR || STAT == GM_STAT_STD) {
+      // second pass: squared deviations from the (rounded) mean, summed frame by frame
+      C sq[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) sq[e] = (C)0;
+      auto dev = [&](const Pack<Tin, V>& f, bool is_first) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          C x;
+          const bool nd = skipped<Tin, C>(f.v[e], ndv, has_ndv, x);
+          const C d = nd ? (C)0 : x - r[e];
+          const C y = d * d;
+          sq[e] = is_first ? y : sq[e] + y;
+        }
+      };
+      int k = 0;
+      if (count > 0) {
+        dev(load_pack<Tin, V>(src), true);
+        k = 1;
+      }
+      for (; k + TB_UNROLL <= count; k += TB_UNROLL) {
+        Pack<Tin, V> f[TB_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TB_UNROLL; ++u) f[u] = load_pack<Tin, V>(src + (long long)(k + u) * pixels);
+#pragma unroll
+        for (int u = 0; u < TB_UNROLL; ++u) dev(f[u], false);
+      }
+      for (; k < count; ++k) dev(load_pack<Tin, V>(src + (long long)k * pixels), false);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        C var = cnt[e] > 0 ? (C)((double)sq[e] / (double)cnt[e]) : std::numeric_limits<C>::quiet_NaN();
+        if constexpr (STAT == GM_STAT_STD) var = sqrt(var);
+        r[e] = var;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) res.v[e] = (count > 0 && finite_<C>(r[e])) ? (Tout)r[e] : fill;
+  }
+  if constexpr (STAT == GM_STAT_COUNT) {
+    if (count == 0) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) res.v[e] = fill;
+    }
+  }
+  store_pack<Tout, V>(out + (long long)B.out[blockIdx.y] * pixels + p, res);
+}
+
+// Cumulative: running nancumsum / count of data within every bin; frame j is written to output frame
+// j - emit_first when emit_first <= j < emit_stop (the requested window, temporal.py:979-1001).
+template <typename Tin, int STAT, int V>
+__global__ __launch_bounds__(256) void cumulative_kernel(const Tin* __restrict__ frames, Tin ndv, bool has_ndv,
+                                                         long long pixels, Bins B, int emit_first, int emit_stop,
+                                                         typename OutOf<Tin, STAT>::type* __restrict__ out,
+                                                         typename OutOf<Tin, STAT>::type fill) {
+  using Tout = typename OutOf<Tin, STAT>::type;
+  using C = typename Work<Tout>::type;
+  const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
+  if (p >= pixels) return;
+  const int first = B.first[blockIdx.y], count = B.count[blockIdx.y];
+  const Tin* src = frames + (long long)first * pixels + p;
+  C acc[V];
+  int cnt[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    acc[e] = (C)0;
+    cnt[e] = 0;
+  }
+  auto step = [&](const Pack<Tin, V>& f, int j) {
+    Pack<Tout, V> res;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      C x;
+      const bool nd = skipped<Tin, C>(f.v[e], ndv, has_ndv, x);
+      cnt[e] += nd ? 0 : 1;
+      const C y = nd ? (C)0 : x;
+      acc[e] = j == 0 ? y : acc[e] + y;
+      if constexpr (STAT == GM_STAT_COUNT) res.v[e] = cnt[e];
+      else res.v[e] = finite_<C>(acc[e]) ? (Tout)acc[e] : fill;
+    }
+    const int frame = first + j;
+    if (frame >= emit_first && frame < emit_stop) store_pack<Tout, V>(out + (long long)(frame - emit_first) * pixels + p, res);
+  };
+  int j = 0;
+  for (; j + TB_UNROLL <= count; j += TB_UNROLL) {
+    Pack<Tin, V> f[TB_UNROLL];
+#pragma unroll
+    for (int u = 0; u < TB_UNROLL; ++u) f[u] = load_pack<Tin, V>(src + (long long)(j + u) * pixels);
+#pragma unroll
+    for (int u = 0; u < TB_UNROLL; ++u) step(f[u], j + u);
+  }
+  for (; j < count; ++j) step(load_pack<Tin, V>(src + (long long)j * pixels), j);
+}
+
+bool ascending_bins(const gm_frame_bin* bins, int n_bins, long long n_frames, int n_out) {
+  for (int i = 0; i < n_bins; ++i) {
+    if (bins[i].first < 0 || bins[i].count < 0 || (long long)bins[i].first + bins[i].count > n_frames) return false;
+    if (n_out >= 0 && (bins[i].out < 0 || bins[i].out >= n_out)) return false;
+  }
+  return true;
+}
+
+template <typename Tin, int STAT>
+int launch_aggregate(const void* frames, uint64_t ndv_bits, int has_ndv, long long pixels, const gm_frame_bin* bins,
+                     int n_bins, void* out, uint64_t fill_bits, hipStream_t s) {
+  using Tout = typename OutOf<Tin, STAT>::type;
+  const bool vec = (pixels % 4) == 0 && ((uintptr_t)frames % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  const int V = vec ? 4 : 1;
+  const unsigned gx = (unsigned)((pixels + 256LL * V - 1) / (256LL * V));
+  for (int b0 = 0; b0 < n_bins; b0 += TB_MAX_BINS) {
+    Bins B;
+    const int nb = n_bins - b0 < TB_MAX_BINS ? n_bins - b0 : TB_MAX_BINS;
+    for (int i = 0; i < nb; ++i) {
+      B.first[i] = bins[b0 + i].first;
+      B.count[i] = bins[b0 + i].count;
+      B.out[i] = bins[b0 + i].out;
+    }
+    if (vec)
+      hipLaunchKernelGGL((aggregate_kernel<Tin, STAT, 4>), dim3(gx, nb), dim3(256), 0, s, (const Tin*)frames,
+                         from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, (Tout*)out, from_bits<Tout>(fill_bits));
+    else
+      hipLaunchKernelGGL((aggregate_kernel<Tin, STAT, 1>), dim3(gx, nb), dim3(256), 0, s, (const Tin*)frames,
+                         from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, (Tout*)out, from_bits<Tout>(fill_bits));
+  }
+  return GM_OK;
+}
+
+template <typename Tin, int STAT>
+int launch_cumulative(const void* frames, uint64_t ndv_bits, int has_ndv, long long pixels, const gm_frame_bin* bins,
+                      int n_bins, int emit_first, int emit_stop, void* out, uint64_t fill_bits, hipStream_t s) {
+  using Tout = typename OutOf<Tin, STAT>::type;
+  const bool vec = (pixels % 4) == 0 && ((uintptr_t)frames % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  const int V = vec ? 4 : 1;
+  const unsigned gx = (unsigned)((pixels + 256LL * V - 1) / (256LL * V));
+  for (int b0 = 0; b0 < n_bins; b0 += TB_MAX_BINS) {
+    Bins B;
+    const int nb = n_bins - b0 < TB_MAX_BINS ? n_bins - b0 : TB_MAX_BINS;
+    for (int i = 0; i < nb; ++i) {
+      B.first[i] = bins[b0 + i].first;
+      B.count[i] = bins[b0 + i].count;
+      B.out[i] = 0;
+    }
+    if (vec)
+      hipLaunchKernelGGL((cumulative_kernel<Tin, STAT, 4>), dim3(gx, nb), dim3(256), 0, s, (const Tin*)frames,
+                         from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, emit_first, emit_stop, (Tout*)out,
+                         from_bits<Tout>(fill_bits));
+    else
+      hipLaunchKernelGGL((cumulative_kernel<Tin, STAT, 1>), dim3(gx, nb), dim3(256), 0, s, (const Tin*)frames,
+                         from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, emit_first, emit_stop, (Tout*)out,
+                         from_bits<Tout>(fill_bits));
+  }
+  return GM_OK;
+}
+
+template <typename Tin>
+int aggregate_of(int statistic, const void* frames, uint64_t ndv_bits, int has_ndv, long long pixels,
+                 const gm_frame_bin* bins, int n_bins, void* out, uint64_t fill_bits, hipStream_t s) {
+  switch (statistic) {
+    case GM_STAT_SUM: return launch_aggregate<Tin, GM_STAT_SUM>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, out, fill_bits, s);
+    case GM_STAT_COUNT: return launch_aggregate<Tin, GM_STAT_COUNT>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, out, fill_bits, s);
+    case GM_STAT_MIN: return launch_aggregate<Tin, GM_STAT_MIN>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, out, fill_bits, s);
+    case GM_STAT_MAX: return launch_aggregate<Tin, GM_STAT_MAX>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, out, fill_bits, s);
+    case GM_STAT_MEAN: return launch_aggregate<Tin, GM_STAT_MEAN>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, out, fill_bits, s);
+    case GM_STAT_VAR: return launch_aggregate<Tin, GM_STAT_VAR>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, out, fill_bits, s);
+    case GM_STAT_STD: return launch_aggregate<Tin, GM_STAT_STD>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, out, fill_bits, s);
+    default: return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_aggregate: statistic %d", statistic);
+  }
+}
+
+template <typename Tin>
+int cumulative_of(int statistic, const void* frames, uint64_t ndv_bits, int has_ndv, long long pixels,
+                  const gm_frame_bin* bins, int n_bins, int emit_first, int emit_stop, void* out, uint64_t fill_bits,
+                  hipStream_t s) {
+  switch (statistic) {
+    case GM_STAT_SUM:
+      return launch_cumulative<Tin, GM_STAT_SUM>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, emit_first, emit_stop, out, fill_bits, s);
+    case GM_STAT_COUNT:
+      return launch_cumulative<Tin, GM_STAT_COUNT>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, emit_first, emit_stop, out, fill_bits, s);
+    default: return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_cumulative: statistic %d", statistic);
+  }
+}
+
+}  // namespace
+
+#define GM_TEMPORAL_DISPATCH(CALL)                                   \
+  switch (dtype) {                                                   \
+    case GM_BOOL: case GM_U8: rc = CALL(unsigned char); break;       \
+    case GM_I8: rc = CALL(signed char); break;                       \
+    case GM_U16: rc = CALL(unsigned short); break;                   \
+    case GM_I16: rc = CALL(short); break;                            \
+    case GM_U32: rc = CALL(unsigned int); break;                     \
+    case GM_I32: rc = CALL(int); break;                              \
+    case GM_I64: rc = CALL(long long); break;                        \
+    case GM_F32: rc = CALL(float); break;                            \
+    case GM_F64: rc = CALL(double); break;                           \
+    default: return gm::fail(GM_ERR_UNSUPPORTED, "temporal statistics: dtype %d", dtype); \
+  }
+
+extern "C" {
+
+int gm_temporal_out_dtype(int dtype, int statistic) {
+  const bool is_float = gm::dtype_is_float(dtype);
+  switch (statistic) {
+    case GM_STAT_MIN: case GM_STAT_MAX: return dtype == GM_BOOL ? GM_U8 : dtype;
+    case GM_STAT_COUNT: return GM_I32;
+    case GM_STAT_SUM:
+      if (is_float) return dtype;
+      if (gm::dtype_size(dtype) < 4) return GM_I32;
+      return dtype == GM_U32 ? GM_I64 : dtype;
+    case GM_STAT_MEAN: case GM_STAT_VAR: case GM_STAT_STD:
+      return (gm::dtype_size(dtype) <= 2 || dtype == GM_F32) ? GM_F32 : GM_F64;
+    default: return -1;
+  }
+}
+
+int gm_temporal_aggregate(const void* frames, int dtype, int has_ndv, uint64_t ndv_bits, int64_t n_frames, int64_t pixels,
+                          const gm_frame_bin* bins, int n_bins, int n_out, int statistic, void* out, uint64_t fill_bits) {
+  if (!frames || !out || (!bins && n_bins)) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (n_frames < 0 || pixels <= 0 || n_bins < 0 || n_out < 0) return gm::fail(GM_ERR_INVALID, "gm_temporal_aggregate: bad shape");
+  if (!ascending_bins(bins, n_bins, n_frames, n_out)) return gm::fail(GM_ERR_INVALID, "gm_temporal_aggregate: bin outside the stack");
+  if (pixels > (1LL << 40)) return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_aggregate: too many pixels");
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  int rc = GM_OK;
+#define GM_AGG(T) aggregate_of<T>(statistic, frames, ndv_bits, has_ndv, (long long)pixels, bins, n_bins, out, fill_bits, s)
+  GM_TEMPORAL_DISPATCH(GM_AGG)
+#undef GM_AGG
+  if (rc != GM_OK) return rc;
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_temporal_cumulative(const void* frames, int dtype, int has_ndv, uint64_t ndv_bits, int64_t n_frames, int64_t pixels,
+                           const gm_frame_bin* bins, int n_bins, int emit_first, int emit_stop, int statistic, void* out,
+                           uint64_t fill_bits) {
+  if (!frames || !out || (!bins && n_bins)) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (n_frames < 0 || pixels <= 0 || n_bins < 0) return gm::fail(GM_ERR_INVALID, "gm_temporal_cumulative: bad shape");
+  if (emit_first < 0 || emit_stop < emit_first || emit_stop > n_frames) return gm::fail(GM_ERR_INVALID, "gm_temporal_cumulative: bad window");
+  if (!ascending_bins(bins, n_bins, n_frames, -1)) return gm::fail(GM_ERR_INVALID, "gm_temporal_cumulative: bin outside the stack");
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  int rc = GM_OK;
+#define GM_CUM(T) cumulative_of<T>(statistic, frames, ndv_bits, has_ndv, (long long)pixels, bins, n_bins, emit_first, emit_stop, out, fill_bits, s)
+  GM_TEMPORAL_DISPATCH(GM_CUM)
+#undef GM_CUM
+  if (rc != GM_OK) return rc;
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+}  // extern "C"

@@ -6,3 +6,4 @@ from .parallelize import *  # noqa: F401,F403
 from .spatial import *  # noqa: F401,F403
 from .reduction import *  # noqa: F401,F403
 from .combine import *  # noqa: F401,F403
+from .temporal import *  # noqa: F401,F403

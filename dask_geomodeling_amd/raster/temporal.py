@@ -1,0 +1,501 @@
+"""Statistics over the time axis (counterpart of raster/temporal.py:476-1003): ``TemporalAggregate``
+resamples a raster in time (hourly mean of 5-minute frames, ...), ``Cumulative`` accumulates frames
+inside every period.
+
+Which frames belong to which label is calendar work and stays on the host, done with pandas exactly
+as the reference does (``Series.resample(...).indices``); a source's frames ascend in time, so every
+label owns one run of consecutive frames.  The per-pixel reduction over those runs is the device
+kernel (csrc/gm_temporal.hip): every frame is read once, every label written once."""
+import ctypes
+import warnings
+from datetime import timedelta as Timedelta
+
+import numpy as np
+import pandas as pd
+import pytz
+from pandas.tseries.frequencies import to_offset
+
+from ..utils import get_dtype_max
+from .base import BaseSingle, RasterBlock
+
+__all__ = ["TemporalAggregate", "Cumulative"]
+
+# frequencies whose bins pandas closes and labels on the right by default (TimeGrouper.__init__)
+_END_ANCHORED = {"M", "A", "Q", "BM", "BA", "BQ", "W", "ME", "YE", "QE", "BME", "BYE", "BQE"}
+_TICK = Timedelta(microseconds=1)
+STATISTIC_CODES = {"sum": 0, "count": 1, "min": 2, "max": 3, "mean": 4, "var": 5, "std": 6}
+_EXTENSIVE = {"sum", "count"}  # additive statistics: nothing to add up = 0, not 'no data'
+
+
+def normalize_offset(freq):
+    """A pandas offset string in the spelling of the running pandas (utils.py:979-1013)."""
+    if freq is None:
+        return None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", FutureWarning)
+        return to_offset(freq).freqstr
+
+
+def offset_to_timedelta(freq):
+    """The fixed length of a frequency, None for calendar-dependent ones (utils.py:960-976)."""
+    try:
+        return pd.Timedelta(to_offset(freq).nanos, unit="ns").to_pytimedelta()
+    except (ValueError, AttributeError):
+        return None
+
+
+def parse_statistic(statistic):
+    """'p<number>' -> ("percentile", number), anything else -> (statistic, None) (utils.py:813-823)."""
+    import re
+    found = re.findall(r"^p(\d+(?:\.\d+)?)$", statistic)
+    if found:
+        q = float(found[0])
+        if not 0 <= q <= 100:
+            raise ValueError("Percentiles must be in the range [0, 100]")
+        return "percentile", q
+    return statistic, None
+
+
+def dtype_for_statistic(dtype, statistic):
+    """Result dtype of a statistic (utils.py:826-845): min / max keep the dtype, sum follows Add,
+    count is int32, the rest follows Divide."""
+    dtype = np.dtype(dtype)
+    if statistic in ("min", "max"):
+        return dtype
+    if statistic == "sum":
+        if dtype.kind in "iub":
+            return np.result_type(dtype, np.int32)
+        if dtype.kind == "f":
+            return np.result_type(dtype, np.float32)
+        return dtype
+    if statistic == "count":
+        return np.dtype(np.int32)
+    return np.result_type(np.float32, dtype)
+
+
+class _Calendar:
+    """The bins of one resampling rule: naive-UTC datetimes in and out, pandas in between."""
+
+    def __init__(self, frequency, closed, label, timezone):
+        self.frequency, self.timezone = frequency, timezone
+        if frequency is None:
+            self.closed = self.label = "right"
+        else:
+            rule = to_offset(frequency).rule_code
+            anchored = rule in _END_ANCHORED or rule.split("-")[0] in _END_ANCHORED
+            self.closed = closed or ("right" if anchored else "left")
+            self.label = label or ("right" if anchored else "left")
+
+    def kwargs(self):
+        return {"frequency": self.frequency, "closed": self.closed, "label": self.label, "timezone": self.timezone}
+
+    # -- conversions ---------------------------------------------------------------------
+    def stamp(self, dt):
+        """naive UTC datetime -> Timestamp in the rule's time zone (temporal.py:257-259)."""
+        return pd.Timestamp(dt, tz="UTC").tz_convert(self.timezone)
+
+    def moment(self, ts):
+        """Timestamp -> naive UTC datetime (temporal.py:262-268)."""
+        if ts.tzinfo is None:
+            ts = ts.tz_localize(self.timezone)
+        return ts.tz_convert("UTC").tz_localize(None).to_pydatetime(warn=False)
+
+    # -- single moments ------------------------------------------------------------------
+    def label_of(self, dt, closed=None, label=None):
+        """Label of the bin ``dt`` falls in (a one-sample resample; temporal.py:271-284)."""
+        probe = pd.Series([0], index=[self.stamp(dt)])
+        found = None
+        for found, members in probe.resample(self.frequency, closed=closed or self.closed, label=label or self.label):
+            if len(members):
+                break
+        return self.moment(found)
+
+    def bin_start_of(self, dt):
+        """Left edge (Timestamp) of the bin ``dt`` falls in (temporal.py:287-296)."""
+        probe = pd.Series([0], index=[self.stamp(dt)])
+        return probe.resample(self.frequency, closed=self.closed, label="left").first().index[0]
+
+    def nearest_label(self, dt, side):
+        """The label closest to ``dt``; side 'left' / 'right' only looks that way (temporal.py:321-347)."""
+        ts = self.stamp(dt)
+        step = to_offset(self.frequency)
+        centre = self.stamp(self.label_of(dt, "left", "left"))
+        around = pd.date_range(centre - step, centre + step, freq=step)
+        gaps = (around - ts).to_series()
+        gaps.index = around
+        if side == "right":
+            gaps = gaps[gaps >= pd.Timedelta(0)]
+        elif side == "left":
+            gaps = gaps[gaps <= pd.Timedelta(0)]
+        return self.moment(gaps.abs().idxmin())
+
+    def first_moment(self, label):
+        """First moment inside the bin labelled ``label`` (temporal.py:373-380)."""
+        ts = self.stamp(label)
+        if self.label == "right":
+            ts -= to_offset(self.frequency)
+        if self.closed == "right":
+            ts += _TICK
+        return self.moment(ts)
+
+    def last_moment(self, label):
+        """Last moment inside the bin labelled ``label`` (temporal.py:383-390)."""
+        ts = self.stamp(label)
+        if self.label == "left":
+            ts += to_offset(self.frequency)
+        if self.closed == "left":
+            ts -= _TICK
+        return self.moment(ts)
+
+    # -- periods and windows -------------------------------------------------------------
+    def resampled_period(self, period):
+        """(first label, last label) of the resampled raster (temporal.py:393-402)."""
+        if period is None:
+            return None
+        if self.frequency is None:
+            return period[-1], period[-1]
+        return tuple(self.label_of(moment) for moment in period)
+
+    def snap_window(self, period, start, stop):
+        """Requested (start, stop) -> (first label, last label) inside ``period``; (label, None) for a
+        one-moment request, (None, None) when no label is in range (temporal.py:405-455)."""
+        if period is None:
+            return None, None
+        first, last = period
+        if start is None:
+            start = last
+        if stop is None:
+            if start <= first:
+                return first, None
+            if start >= last:
+                return last, None
+            return self.nearest_label(start, "both"), None
+        if start > last or stop < first:
+            return None, None
+        start = first if start <= first else self.nearest_label(start, "right")
+        stop = last if stop >= last else self.nearest_label(stop, "left")
+        if start > stop:
+            return None, None
+        return start, stop
+
+    def frames_of(self, times, labels):
+        """[(first frame, count)] per label: the run of ``times`` (naive UTC, ascending) that falls in the
+        bin of every label (pandas' Resampler.indices, temporal.py:706-722)."""
+        if self.frequency is None:
+            return [(0, len(times))]
+        series = pd.Series(index=times, dtype=float).tz_localize("UTC").tz_convert(self.timezone)
+        members = series.resample(self.frequency, closed=self.closed, label=self.label).indices
+        runs = []
+        for stamp in labels:
+            frames = np.asarray(members.get(stamp, ()), dtype=np.int64)
+            if len(frames) and not np.array_equal(frames, np.arange(frames[0], frames[0] + len(frames))):
+                raise NotImplementedError("time stamps of the source are not ascending")
+            runs.append((int(frames[0]), len(frames)) if len(frames) else (0, 0))
+        return runs
+
+
+class GmFrameBin(ctypes.Structure):
+    """gm_frame_bin of include/gmhip.h."""
+    _fields_ = [("first", ctypes.c_int32), ("count", ctypes.c_int32), ("out", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+def _frame_bins(runs, outs=None):
+    bins = (GmFrameBin * max(len(runs), 1))()
+    for i, (first, count) in enumerate(runs):
+        bins[i].first, bins[i].count, bins[i].out = first, count, i if outs is None else outs[i]
+    return bins
+
+
+def _reduce_args(values, no_data_value):
+    from ..hip import runtime
+    from ..hip.array import as_device
+    from ..hip.dtypes import code_of
+    from ..hip.program import effective_ndv
+    src = as_device(values)
+    ndv = effective_ndv(src.dtype, no_data_value)
+    has, bits = (0, 0) if ndv is None else (1, runtime.scalar_bits(ndv, src.dtype))
+    frames, height, width = src.shape
+    return src, code_of(src.dtype), has, bits, frames, height, width
+
+
+def _fill_bits(statistic, dtype):
+    from ..hip import runtime
+    return runtime.scalar_bits(0 if statistic in _EXTENSIVE else get_dtype_max(dtype), dtype)
+
+
+def aggregate_frames(values, no_data_value, runs, statistic, dtype):
+    """(frames, h, w) tile + [(first, count)] per label -> (labels, h, w) device tile of ``dtype``
+    (the loop of temporal.py:743-766 as one launch)."""
+    from ..hip import runtime
+    from ..hip.array import DeviceArray
+    if statistic not in STATISTIC_CODES:
+        raise NotImplementedError("TemporalAggregate statistic %r (median and percentiles need a per-pixel sort)" % statistic)
+    src, code, has, bits, frames, height, width = _reduce_args(values, no_data_value)
+    L = runtime.lib()
+    if L.gm_temporal_out_dtype(code, STATISTIC_CODES[statistic]) != _code(dtype):
+        raise NotImplementedError("%s of a %s raster as %s" % (statistic, src.dtype, np.dtype(dtype)))
+    out = DeviceArray.empty((len(runs), height, width), np.dtype(dtype))
+    L.gm_temporal_aggregate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_uint64]
+    runtime.check(L.gm_temporal_aggregate(src.ptr, code, has, bits, frames, height * width, _frame_bins(runs), len(runs),
+                                          len(runs), STATISTIC_CODES[statistic], out.ptr, _fill_bits(statistic, dtype)),
+                  "gm_temporal_aggregate")
+    return out
+
+
+def accumulate_frames(values, no_data_value, runs, emit, statistic, dtype):
+    """Running sum / count inside every run; frames emit[0] .. emit[1]-1 are the result
+    (temporal.py:979-1001)."""
+    from ..hip import runtime
+    from ..hip.array import DeviceArray
+    if statistic not in ("sum", "count"):
+        raise NotImplementedError("Cumulative statistic %r" % statistic)
+    src, code, has, bits, frames, height, width = _reduce_args(values, no_data_value)
+    L = runtime.lib()
+    if L.gm_temporal_out_dtype(code, STATISTIC_CODES[statistic]) != _code(dtype):
+        raise NotImplementedError("cumulative %s of a %s raster as %s" % (statistic, src.dtype, np.dtype(dtype)))
+    out = DeviceArray.empty((emit[1] - emit[0], height, width), np.dtype(dtype))
+    L.gm_temporal_cumulative.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64]
+    runtime.check(L.gm_temporal_cumulative(src.ptr, code, has, bits, frames, height * width, _frame_bins(runs), len(runs),
+                                           int(emit[0]), int(emit[1]), STATISTIC_CODES[statistic], out.ptr,
+                                           _fill_bits(statistic, dtype)), "gm_temporal_cumulative")
+    return out
+
+
+def _code(dtype):
+    from ..hip.dtypes import code_of
+    return code_of(np.dtype(dtype))
+
+
+def _check_statistic(statistic, known):
+    if not isinstance(statistic, str):
+        raise TypeError("'{}' object is not allowed.".format(type(statistic)))
+    statistic, percentile = parse_statistic(statistic.lower())
+    if percentile:
+        return "p{0}".format(percentile)
+    if statistic not in known:
+        raise ValueError("Unknown statistic '{}'".format(statistic))
+    return statistic
+
+
+class TemporalAggregate(BaseSingle):
+    """Aggregate a raster in time (temporal.py:476-768).
+
+    Args: source, frequency (pandas offset string, or None for one statistic over the whole period,
+    labelled with the end of the period), statistic (sum, count, min, max, mean, median, std, var,
+    p<percentile>), closed / label ('left', 'right' or None for the frequency's default), timezone.
+    """
+
+    STATISTICS = ("sum", "count", "min", "max", "mean", "median", "std", "var")
+
+    def __init__(self, source, frequency, statistic="sum", closed=None, label=None, timezone="UTC"):
+        if not isinstance(source, RasterBlock):
+            raise TypeError("'{}' object is not allowed.".format(type(source)))
+        if frequency is None:
+            closed = label = timezone = None
+        else:
+            if not isinstance(frequency, str):
+                raise TypeError("'{}' object is not allowed.".format(type(frequency)))
+            frequency = normalize_offset(frequency)
+            if closed not in {None, "left", "right"}:
+                raise ValueError("closed must be None, 'left', or 'right'.")
+            if label not in {None, "left", "right"}:
+                raise ValueError("label must be None, 'left', or 'right'.")
+            if not isinstance(timezone, str):
+                raise TypeError("'{}' object is not allowed.".format(type(timezone)))
+            timezone = pytz.timezone(timezone).zone
+        statistic = _check_statistic(statistic, self.STATISTICS)
+        super().__init__(source, frequency, statistic, closed, label, timezone)
+
+    source = property(lambda self: self.args[0])
+    frequency = property(lambda self: normalize_offset(self.args[1]))
+    statistic = property(lambda self: self.args[2])
+    closed = property(lambda self: self.args[3])
+    label = property(lambda self: self.args[4])
+    timezone = property(lambda self: self.args[5])
+
+    @property
+    def _calendar(self):
+        return _Calendar(self.frequency, self.closed, self.label, self.timezone)
+
+    @property
+    def period(self):
+        return self._calendar.resampled_period(self.source.period)
+
+    @property
+    def timedelta(self):
+        return None if self.frequency is None else offset_to_timedelta(self.frequency)
+
+    @property
+    def temporal(self):
+        return self.frequency is not None
+
+    @property
+    def dtype(self):
+        return dtype_for_statistic(self.source.dtype, self.statistic)
+
+    @property
+    def fillvalue(self):
+        return get_dtype_max(self.dtype)
+
+    def get_sources_and_requests(self, **request):
+        calendar = self._calendar
+        mode = request["mode"]
+        first, last = calendar.snap_window(self.period, request.get("start"), request.get("stop"))
+        if first is None:
+            return [({"empty": True, "mode": mode}, None)]
+        kwargs = dict(calendar.kwargs(), mode=mode, start=first, stop=last)
+        if mode == "time":  # the labels alone answer a time request
+            return [(kwargs, None)]
+        if self.frequency is None:
+            request["start"], request["stop"] = self.source.period
+        else:
+            request["start"], request["stop"] = calendar.first_moment(first), calendar.last_moment(last or first)
+        if mode == "vals":
+            kwargs["dtype"] = np.dtype(self.dtype).str
+            kwargs["statistic"] = self.statistic
+        frames_request = {"mode": "time", "start": request["start"], "stop": request["stop"]}
+        if "time_resolution" in request:
+            frames_request["time_resolution"] = request["time_resolution"]
+        return [(kwargs, None), (self.source, frames_request), (self.source, request)]
+
+    @staticmethod
+    def process(process_kwargs, time_data=None, data=None):
+        mode = process_kwargs["mode"]
+        nothing = None if mode == "vals" else {mode: []}
+        if process_kwargs.get("empty"):
+            return nothing
+        calendar = _Calendar(process_kwargs["frequency"], process_kwargs["closed"], process_kwargs["label"],
+                             process_kwargs["timezone"])
+        start, stop = process_kwargs["start"], process_kwargs["stop"]
+        if calendar.frequency is None:
+            labels = pd.DatetimeIndex([start])
+        else:
+            labels = pd.date_range(start, stop or start, freq=calendar.frequency)
+        if mode == "time":
+            return {"time": labels.to_pydatetime().tolist()}
+        if time_data is None or not time_data.get("time"):
+            return nothing
+        times = time_data["time"]
+        runs = calendar.frames_of(times, labels.tz_localize("UTC").tz_convert(calendar.timezone))
+        if mode == "meta":
+            if data is None or "meta" not in data:
+                return {"meta": []}
+            return {"meta": [[data["meta"][i] for i in range(first, first + count)] for first, count in runs]}
+        if data is None or "values" not in data:
+            return None
+        if data["values"].shape[0] != len(times):
+            raise RuntimeError("Shape of raster does not match number of timestamps")
+        dtype = np.dtype(process_kwargs["dtype"])
+        statistic, percentile = parse_statistic(process_kwargs["statistic"])
+        if percentile is not None:
+            statistic = "p%s" % percentile
+        values = aggregate_frames(data["values"], data["no_data_value"], runs, statistic, dtype)
+        return {"values": values, "no_data_value": get_dtype_max(dtype)}
+
+
+class Cumulative(BaseSingle):
+    """Accumulate a raster over time (temporal.py:776-1003): the time structure of the source is
+    kept, every frame holds the sum (or count of data frames) since the start of its period.
+
+    Args: source, statistic ('sum' or 'count'), frequency (period after which the accumulation starts
+    again; None = never), timezone."""
+
+    STATISTICS = ("sum", "count")
+
+    def __init__(self, source, statistic="sum", frequency=None, timezone="UTC"):
+        if not isinstance(source, RasterBlock):
+            raise TypeError("'{}' object is not allowed.".format(type(source)))
+        statistic = _check_statistic(statistic, self.STATISTICS)
+        if frequency is None:
+            timezone = None
+        else:
+            if not isinstance(frequency, str):
+                raise TypeError("'{}' object is not allowed.".format(type(frequency)))
+            frequency = normalize_offset(frequency)
+            if not isinstance(timezone, str):
+                raise TypeError("'{}' object is not allowed.".format(type(timezone)))
+            timezone = pytz.timezone(timezone).zone
+        super().__init__(source, statistic, frequency, timezone)
+
+    source = property(lambda self: self.args[0])
+    statistic = property(lambda self: self.args[1])
+    frequency = property(lambda self: normalize_offset(self.args[2]))
+    timezone = property(lambda self: self.args[3])
+
+    @property
+    def dtype(self):
+        return dtype_for_statistic(self.source.dtype, self.statistic)
+
+    @property
+    def fillvalue(self):
+        return get_dtype_max(self.dtype)
+
+    def get_sources_and_requests(self, **request):
+        if request["mode"] == "time":  # the frames of the source are the frames of the result
+            return [({"mode": "time"}, None), (self.source, request)]
+        mode = request["mode"]
+        # which frames are asked for decides how far back the accumulation has to start
+        wanted = self.source.get_data(mode="time", start=request.get("start"), stop=request.get("stop"))
+        if wanted is None or not wanted.get("time"):
+            return [({"empty": True, "mode": mode}, None)]
+        first, last = wanted["time"][0], wanted["time"][-1]
+        calendar = _Calendar(self.frequency, "right", "right", self.timezone)
+        if self.frequency is None:
+            request["start"], request["stop"] = self.period[0], last
+        else:
+            request["start"] = calendar.moment(calendar.bin_start_of(first))
+            request["stop"] = last + _TICK
+        kwargs = dict(calendar.kwargs(), mode=mode, start=first, stop=last)
+        if mode == "vals":
+            kwargs["dtype"] = np.dtype(self.dtype).str
+            kwargs["statistic"] = self.statistic
+        frames_request = {"mode": "time", "start": request["start"], "stop": request["stop"]}
+        return [(kwargs, None), (self.source, frames_request), (self.source, request)]
+
+    @staticmethod
+    def process(process_kwargs, time_data=None, data=None):
+        mode = process_kwargs["mode"]
+        nothing = None if mode == "vals" else {mode: []}
+        if process_kwargs.get("empty"):
+            return nothing
+        if mode == "time":
+            return time_data
+        if time_data is None or not time_data.get("time"):
+            return nothing
+        calendar = _Calendar(process_kwargs["frequency"], process_kwargs["closed"], process_kwargs["label"],
+                             process_kwargs["timezone"])
+        times = time_data["time"]
+        stamps = pd.Series(index=times, dtype=float).tz_localize("UTC").tz_convert(calendar.timezone)
+        if calendar.frequency is None:
+            members = [np.arange(len(times))]
+        else:
+            resampled = stamps.resample(calendar.frequency, closed=calendar.closed, label=calendar.label)
+            members = [np.asarray(frames, dtype=np.int64) for frames in resampled.indices.values()]
+        first_stamp, last_stamp = calendar.stamp(process_kwargs["start"]), calendar.stamp(process_kwargs["stop"])
+        wanted = np.asarray((stamps.index >= first_stamp) & (stamps.index <= last_stamp))
+
+        if mode == "meta":
+            if data is None or "meta" not in data:
+                return {"meta": []}
+            meta = data["meta"]
+            return {"meta": [[meta[i] for i in frames[:n]] for frames in members for n in range(1, len(frames) + 1)
+                             if wanted[frames[n - 1]]]}
+        if data is None or "values" not in data:
+            return None
+        if data["values"].shape[0] != len(times):
+            raise RuntimeError("Shape of raster does not match number of timestamps")
+        runs = []
+        for frames in members:
+            if len(frames) and not np.array_equal(frames, np.arange(frames[0], frames[0] + len(frames))):
+                raise NotImplementedError("time stamps of the source are not ascending")
+            if len(frames):
+                runs.append((int(frames[0]), len(frames)))
+        emit_first = int(np.flatnonzero(wanted)[0])
+        emit = (emit_first, emit_first + int(wanted.sum()))
+        dtype = np.dtype(process_kwargs["dtype"])
+        values = accumulate_frames(data["values"], data["no_data_value"], runs, emit, process_kwargs["statistic"], dtype)
+        return {"values": values, "no_data_value": get_dtype_max(dtype)}

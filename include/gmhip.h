@@ -360,6 +360,48 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
                   void* out);
 
 /* =============================================================================
+ * N4: statistics over the band (time) axis (raster/temporal.py).  `frames` is a C-contiguous
+ * (n_frames, pixels) stack; a bin is a run of consecutive frames (the resampler bins of an
+ * ascending time axis, temporal.py:717-722).
+ * ========================================================================== */
+
+enum gm_statistic {
+  GM_STAT_SUM = 0,   /* np.nansum   */
+  GM_STAT_COUNT = 1, /* frames that are data */
+  GM_STAT_MIN = 2,   /* np.nanmin   */
+  GM_STAT_MAX = 3,   /* np.nanmax   */
+  GM_STAT_MEAN = 4,  /* np.nanmean  */
+  GM_STAT_VAR = 5,   /* np.nanvar   */
+  GM_STAT_STD = 6    /* np.nanstd   */
+};
+
+typedef struct gm_frame_bin {
+  int32_t first; /* first source frame */
+  int32_t count; /* frames in the bin; 0 = the label has no frame (result: fill) */
+  int32_t out;   /* gm_temporal_aggregate: output frame written by this bin */
+  int32_t reserved;
+} gm_frame_bin;
+
+/* dtype_for_statistic (utils.py:826-845) as a gm_dtype code; -1 for an unknown statistic. */
+int gm_temporal_out_dtype(int dtype, int statistic);
+
+/* TemporalAggregate.process, vals branch (temporal.py:724-768): out = (n_out, pixels) of
+ * gm_temporal_out_dtype(dtype, statistic).  Cells equal to ndv (and NaN) are skipped; a result that
+ * is not finite, or a bin without frames, becomes fill_bits (0 for sum / count, else the out
+ * dtype's maximum).  Output frames no bin writes to are left untouched (gm_fill them first).
+ * Accumulation runs frame by frame in result_type(float32, out dtype), like NumPy's axis-0
+ * reductions; the mean divides in float64 and rounds once. */
+int gm_temporal_aggregate(const void* frames, int dtype, int has_ndv, uint64_t ndv_bits, int64_t n_frames, int64_t pixels,
+                          const gm_frame_bin* bins, int n_bins, int n_out, int statistic, void* out, uint64_t fill_bits);
+
+/* Cumulative.process, vals branch (temporal.py:957-1003): running sum / count inside every bin;
+ * source frame j goes to output frame j - emit_first for emit_first <= j < emit_stop.
+ * statistic: GM_STAT_SUM or GM_STAT_COUNT. */
+int gm_temporal_cumulative(const void* frames, int dtype, int has_ndv, uint64_t ndv_bits, int64_t n_frames, int64_t pixels,
+                           const gm_frame_bin* bins, int n_bins, int emit_first, int emit_stop, int statistic, void* out,
+                           uint64_t fill_bits);
+
+/* =============================================================================
  * K8: helpers
  * ========================================================================== */
 

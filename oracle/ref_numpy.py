@@ -662,3 +662,154 @@ def smooth_process(data, process_kwargs=None):
         zy, zx = 1 - 2 * size_px[0] / ny, 1 - 2 * size_px[1] / nx
         values = affine_nearest(values, (zy, zx), (size_px[0], size_px[1]))
     return {"values": values, "no_data_value": no_data_value}
+
+
+# --------------------------------------------------------------------------
+# TemporalAggregate.process / Cumulative.process (raster/temporal.py:676-768, 912-1003).
+# The calendar part (which frames fall under which label) is pandas' resampler in the reference
+# and here alike; the numeric part is NumPy's nan-aware reductions over the frame axis of a copy
+# in result_type(float32, dtype) that has NaN where the source has no data.
+# --------------------------------------------------------------------------
+def _count_data(x, axis=0):
+    return np.sum(~np.isnan(x), axis=axis)  # temporal.py:472-473
+
+
+def _running_count(x, axis=0):
+    return np.cumsum(~np.isnan(x), axis=axis)  # temporal.py:771-772
+
+
+AGGREGATES = {"sum": (np.nansum, True), "count": (_count_data, True), "min": (np.nanmin, False),
+              "max": (np.nanmax, False), "mean": (np.nanmean, False), "median": (np.nanmedian, False),
+              "std": (np.nanstd, False), "var": (np.nanvar, False)}  # (function, extensive) temporal.py:515-525
+ACCUMULATORS = {"sum": (np.nancumsum, True), "count": (_running_count, True)}  # temporal.py:803-806
+
+
+def _statistic_function(statistic, table):
+    if statistic.startswith("p") and statistic[1:2].isdigit():  # p<percentile>: utils.py:813-823
+        q = float(statistic[1:])
+        return (lambda x, axis=0: np.nanpercentile(x, q=q, axis=axis)), False
+    return table[statistic]
+
+
+def _frames_with_nan(values, no_data_value, dtype):
+    work = values.astype(np.result_type(np.float32, dtype))  # temporal.py:738-741
+    work[values == no_data_value] = np.nan
+    return work
+
+
+def _cast_finite(result, dtype, fill):
+    bad = ~np.isfinite(result)  # temporal.py:757-763
+    if dtype != result.dtype:
+        result = result.astype(dtype)
+    result[bad] = fill
+    return result
+
+
+def temporal_aggregate_values(values, no_data_value, runs, statistic, dtype):
+    """The loop of temporal.py:743-766: ``runs`` = [(first frame, count)] per label."""
+    import warnings
+    dtype = np.dtype(dtype)
+    func, extensive = _statistic_function(statistic, AGGREGATES)
+    fill = 0 if extensive else get_dtype_max(dtype)
+    work = _frames_with_nan(values, no_data_value, dtype)
+    out = np.full((len(runs),) + values.shape[1:], fill, dtype)
+    for i, (first, count) in enumerate(runs):
+        if count == 0:
+            continue
+        with warnings.catch_warnings(), np.errstate(all="ignore"):
+            warnings.simplefilter("ignore", category=RuntimeWarning)
+            out[i] = _cast_finite(func(work[first:first + count], axis=0), dtype, fill)
+    return out
+
+
+def temporal_cumulative_values(values, no_data_value, runs, emit, statistic, dtype):
+    """The loop of temporal.py:979-1001: running statistic inside every run, frames
+    emit[0] <= j < emit[1] make up the result."""
+    dtype = np.dtype(dtype)
+    func, extensive = _statistic_function(statistic, ACCUMULATORS)
+    fill = 0 if extensive else get_dtype_max(dtype)
+    work = _frames_with_nan(values, no_data_value, dtype)
+    out = np.full((emit[1] - emit[0],) + values.shape[1:], fill, dtype)
+    for first, count in runs:
+        running = _cast_finite(func(work[first:first + count], axis=0), dtype, fill)
+        for j in range(count):
+            if emit[0] <= first + j < emit[1]:
+                out[first + j - emit[0]] = running[j]
+    return out
+
+
+def _resample_members(times, frequency, closed, label, timezone):
+    """{label: frame indices} -- pandas' own binning, as the reference uses it (temporal.py:706-722)."""
+    import pandas as pd
+    series = pd.Series(index=times, dtype=float).tz_localize("UTC").tz_convert(timezone)
+    return series, (None if frequency is None else series.resample(frequency, closed=closed, label=label).indices)
+
+
+def temporal_aggregate_process(process_kwargs, time_data=None, data=None):
+    """TemporalAggregate.process (temporal.py:676-768)."""
+    import pandas as pd
+    mode = process_kwargs["mode"]
+    if process_kwargs.get("empty"):
+        return None if mode == "vals" else {mode: []}
+    start, stop, frequency = process_kwargs["start"], process_kwargs["stop"], process_kwargs["frequency"]
+    labels = pd.DatetimeIndex([start]) if frequency is None else pd.date_range(start, stop or start, freq=frequency)
+    if mode == "time":
+        return {"time": labels.to_pydatetime().tolist()}
+    if time_data is None or not time_data.get("time"):
+        return None if mode == "vals" else {mode: []}
+    times = time_data["time"]
+    timezone = process_kwargs["timezone"]
+    _, members = _resample_members(times, frequency, process_kwargs["closed"], process_kwargs["label"], timezone)
+    labels = labels.tz_localize("UTC").tz_convert(timezone)
+    if members is None:
+        members = {labels[0]: range(len(times))}
+    if mode == "meta":
+        if data is None or "meta" not in data:
+            return {"meta": []}
+        return {"meta": [[data["meta"][i] for i in members[ts]] for ts in labels]}
+    if data is None or "values" not in data:
+        return None
+    if data["values"].shape[0] != len(times):
+        raise RuntimeError("Shape of raster does not match number of timestamps")
+    runs = []
+    for ts in labels:
+        frames = list(members[ts])
+        assert frames == list(range(frames[0], frames[0] + len(frames))) if frames else True
+        runs.append((frames[0], len(frames)) if frames else (0, 0))
+    dtype = np.dtype(process_kwargs["dtype"])
+    values = temporal_aggregate_values(data["values"], data["no_data_value"], runs, process_kwargs["statistic"], dtype)
+    return {"values": values, "no_data_value": get_dtype_max(dtype)}
+
+
+def cumulative_process(process_kwargs, time_data=None, data=None):
+    """Cumulative.process (temporal.py:912-1003)."""
+    import pandas as pd
+    mode = process_kwargs["mode"]
+    if process_kwargs.get("empty"):
+        return None if mode == "vals" else {mode: []}
+    if mode == "time":
+        return time_data
+    if time_data is None or not time_data.get("time"):
+        return None if mode == "vals" else {mode: []}
+    timezone = process_kwargs["timezone"]
+    series, members = _resample_members(time_data["time"], process_kwargs["frequency"], process_kwargs["closed"],
+                                        process_kwargs["label"], timezone)
+    members = [list(range(len(series)))] if members is None else [list(v) for v in members.values()]
+    first = pd.Timestamp(process_kwargs["start"], tz="UTC").tz_convert(timezone)
+    last = pd.Timestamp(process_kwargs["stop"], tz="UTC").tz_convert(timezone)
+    wanted = np.asarray((series.index >= first) & (series.index <= last))
+    if mode == "meta":
+        if data is None or "meta" not in data:
+            return {"meta": []}
+        return {"meta": [[data["meta"][i] for i in frames[:n]] for frames in members
+                         for n in range(1, len(frames) + 1) if wanted[frames[n - 1]]]}
+    if data is None or "values" not in data:
+        return None
+    if data["values"].shape[0] != len(series):
+        raise RuntimeError("Shape of raster does not match number of timestamps")
+    runs = [(frames[0], len(frames)) for frames in members if frames]
+    lo = int(np.flatnonzero(wanted)[0])
+    dtype = np.dtype(process_kwargs["dtype"])
+    values = temporal_cumulative_values(data["values"], data["no_data_value"], runs, (lo, lo + int(wanted.sum())),
+                                        process_kwargs["statistic"], dtype)
+    return {"values": values, "no_data_value": get_dtype_max(dtype)}

@@ -54,6 +54,10 @@ def cpu_vm(monkeypatch):
     from dask_geomodeling_amd.raster import combine
     monkeypatch.setattr(combine, "_stack_bands", lambda bands, dtype, fill, shape_yx: np.concatenate(
         [np.full((1,) + tuple(shape_yx), fill, dtype) if b is None else np.asarray(b) for b in bands], axis=0))
+    from dask_geomodeling_amd.raster import temporal
+    from oracle import ref_numpy
+    monkeypatch.setattr(temporal, "aggregate_frames", ref_numpy.temporal_aggregate_values)
+    monkeypatch.setattr(temporal, "accumulate_frames", ref_numpy.temporal_cumulative_values)
     monkeypatch.setattr(program, "as_device", lambda v: np.asarray(v))
     monkeypatch.setattr(program, "as_device_view", lambda v: np.asarray(v))
     monkeypatch.setattr(program, "launch", vm_numpy.launch)

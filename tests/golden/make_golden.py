@@ -26,6 +26,7 @@ Families:
   spatial     N3     Dilate / MovingMax / HillShade process() + expand_request_pixels
   reduce      N4     Max.process = reduce_rasters(stack, "max")
   group       N4     Group: whole get_data() on temporal probe sources (by time / by bands)
+  temporal    N4     TemporalAggregate / Cumulative: whole get_data() + the process() arguments
 """
 import json
 import os
@@ -916,12 +917,120 @@ def gen_smooth(w):
         w.add(id="sm%04d" % cid, op="smooth", args=args, expect=R_sp.Smooth.process(*args)); cid += 1
 
 
+# --------------------------------------------------------------------------
+# family: temporal  (reference: raster/temporal.py:476-1003) -- TemporalAggregate / Cumulative: whole
+# get_data() on temporal probe sources plus the process() arguments the reference built on the way
+# --------------------------------------------------------------------------
+def gen_temporal(w):
+    from datetime import timedelta
+    from dask_geomodeling.raster import temporal as R_tmp
+    rng = np.random.default_rng(131)
+    cid = 0
+    f32n = np.float32(F32MAX)
+
+    def stamps(first, n, seconds):
+        t0 = datetime.fromisoformat(first)
+        return [(t0 + timedelta(seconds=seconds * i)).isoformat() for i in range(n)]
+
+    def src(name, dt, ndv, times, delta, shape_yx):
+        shape = (len(times),) + shape_yx
+        v = make_tile(rng, dt, shape, ndv, specials=np.dtype(dt).kind == "f")
+        if ndv is not None:
+            v[:, 0, 1] = ndv          # a cell that never has data
+            v[: len(times) // 2, 1, 0] = ndv
+        TemporalProbe.ARRAYS[name] = {"values": v, "no_data_value": ndv}
+        return TemporalProbe(name, np.dtype(dt).str, ndv, times, delta)
+
+    free = ["2020-03-01T06:00:00", "2020-03-01T07:30:00", "2020-03-01T23:59:59", "2020-03-02T00:00:00",
+            "2020-03-04T12:00:00", "2020-03-04T12:00:01", "2020-03-07T01:00:00"]
+    sources = {
+        "tenmin_f4": ("f4", f32n, stamps("2020-01-01T00:00:00", 30, 600), 600, (6, 8)),
+        "daily_u1": ("u1", np.uint8(255), stamps("2020-01-25T00:00:00", 16, 86400), 86400, (5, 7)),
+        "free_i4": ("i4", -9999, free, None, (6, 8)),
+        "hourly_f8": ("f8", F64MAX, stamps("2019-12-31T20:00:00", 10, 3600), 3600, (5, 7)),
+        "hourly_i2": ("i2", np.int16(-1), stamps("2020-06-01T00:00:00", 12, 3600), 3600, (6, 8)),
+        "daily_bool": ("?", None, stamps("2020-01-01T00:00:00", 6, 86400), 86400, (6, 8)),
+        "tenmin_f4neg": ("f4", np.float32(-9999.0), stamps("2020-01-01T00:00:00", 13, 600), 600, (5, 7)),
+    }
+    probes, specs = {}, {}
+    for name, (dt, ndv, times, delta, shape_yx) in sources.items():
+        probes[name] = src(name, dt, ndv, times, delta, shape_yx)
+        specs[name] = {"name": name, "dtype": np.dtype(dt).str, "ndv": ndv, "times": times, "delta": delta,
+                       "data": TemporalProbe.ARRAYS[name]["values"]}
+
+    def window(name):
+        h, wd = specs[name]["data"].shape[1:]
+        return dict(bbox=(0.0, 0.0, float(wd), float(h)), width=wd, height=h, projection="EPSG:28992")
+
+    all_stats = ["sum", "count", "min", "max", "mean", "std", "var", "median", "p50", "p95"]
+    aggregates = [
+        ("tenmin_f4", dict(frequency="h"), all_stats),
+        ("tenmin_f4", dict(frequency="30min", closed="right", label="right"), ["sum", "mean"]),
+        ("tenmin_f4", dict(frequency=None), ["sum", "max", "std"]),
+        ("tenmin_f4", dict(frequency="D"), ["mean", "count"]),
+        ("daily_u1", dict(frequency="W"), ["sum", "min", "max", "mean", "var", "count"]),
+        ("daily_u1", dict(frequency="ME"), ["sum", "mean", "max"]),
+        ("daily_u1", dict(frequency="2D", closed="left", label="right"), ["sum", "std"]),
+        ("free_i4", dict(frequency="D"), ["sum", "count", "min", "max", "mean", "std", "var"]),
+        ("free_i4", dict(frequency="D", timezone="Europe/Amsterdam"), ["sum", "mean"]),
+        ("free_i4", dict(frequency=None), ["mean", "min"]),
+        ("hourly_f8", dict(frequency="D", timezone="Europe/Amsterdam"), ["sum", "mean", "std", "min"]),
+        ("hourly_f8", dict(frequency="3h"), ["sum", "count", "min", "max", "mean", "std", "var"]),
+        ("hourly_i2", dict(frequency="4h"), ["sum", "count", "min", "max", "mean", "std", "var", "median"]),
+        ("daily_bool", dict(frequency="2D"), ["sum", "count", "mean"]),
+        ("tenmin_f4neg", dict(frequency="h", closed="right"), ["sum", "min", "max", "mean", "var"]),
+    ]
+    day = timedelta(days=1)
+
+    def requests_for(name):
+        times = [datetime.fromisoformat(t) for t in specs[name]["times"]]
+        first, last = times[0], times[-1]
+        mid = first + (last - first) / 2
+        return [dict(), dict(start=mid), dict(start=first - day, stop=last + day), dict(start=mid, stop=last),
+                dict(start=first + (last - first) / 4, stop=mid), dict(start=last + 40 * day, stop=last + 50 * day),
+                dict(start=first - 3 * day)]
+
+    def record(kind, view, source, request, extra):
+        nonlocal cid
+        plan = view.get_sources_and_requests(**request)
+        args = [plan[0][0]] + [src_.get_data(**req) for src_, req in plan[1:]]
+        w.add(id="tmp%04d" % cid, kind=kind, source=specs[source], request=request, process_args=args,
+              attrs={"dtype": np.dtype(view.dtype).str, "fillvalue": view.fillvalue,
+                     "period": list(view.period) if view.period else None,
+                     "timedelta": None if view.timedelta is None else view.timedelta.total_seconds(),
+                     "temporal": view.temporal},
+              expect=view.get_data(**request), **extra)
+        cid += 1
+
+    for name, kw, stats in aggregates:
+        for k, stat in enumerate(stats):
+            view = R_tmp.TemporalAggregate(probes[name], kw.get("frequency"), stat, kw.get("closed"), kw.get("label"),
+                                           kw.get("timezone", "UTC"))
+            for extra in requests_for(name):
+                for mode in (("vals", "time", "meta") if k == 0 else ("vals",)):
+                    record("aggregate", view, name, dict(mode=mode, **window(name), **extra),
+                           dict(block_args=[kw.get("frequency"), stat, kw.get("closed"), kw.get("label"), kw.get("timezone", "UTC")]))
+
+    cumulatives = [
+        ("tenmin_f4", None, "UTC"), ("tenmin_f4", "h", "UTC"), ("daily_u1", "W", "UTC"), ("free_i4", "D", "Europe/Amsterdam"),
+        ("hourly_f8", "3h", "UTC"), ("hourly_i2", None, "UTC"), ("daily_bool", "2D", "UTC"), ("tenmin_f4neg", "30min", "UTC"),
+    ]
+    for name, freq, tz in cumulatives:
+        for k, stat in enumerate(("sum", "count")):
+            view = R_tmp.Cumulative(probes[name], stat, freq, tz)
+            for extra in requests_for(name):
+                for mode in (("vals", "time", "meta") if k == 0 else ("vals",)):
+                    record("cumulative", view, name, dict(mode=mode, **window(name), **extra),
+                           dict(block_args=[stat, freq, tz]))
+
+
 def main():
     fams = {
         "math": gen_math, "n1": gen_n1, "clip": gen_clip, "mask": gen_mask,
         "classify": gen_classify, "reclassify": gen_reclassify, "tiler": gen_tiler,
         "views": gen_views, "dtypes": gen_dtypes, "smoothzoom": gen_smoothzoom,
         "spatial": gen_spatial, "reduce": gen_reduce, "group": gen_group, "smooth": gen_smooth,
+        "temporal": gen_temporal,
     }
     only = sys.argv[1:]
     counts = {}

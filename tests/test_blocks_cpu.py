@@ -465,3 +465,66 @@ def test_group_against_reference(cpu_vm, case):
         assert out == want, case["id"]
     else:
         assert_result_equal(out, want, 0, case["id"])
+
+
+# ---------------------------------------------------------------------------------
+# N4: TemporalAggregate / Cumulative -- calendar logic (host) against the reference's results; the
+# per-pixel reduction itself is the oracle's here (cpu_vm), the device kernel's in test_gpu_parity
+# ---------------------------------------------------------------------------------
+def temporal_view(case):
+    from blocks_util import TemporalLeaf
+    spec = case["source"]
+    TemporalLeaf.ARRAYS[spec["name"]] = {"values": spec["data"], "no_data_value": spec["ndv"]}
+    leaf = TemporalLeaf(spec["name"], spec["dtype"], spec["ndv"], spec["times"], spec["delta"])
+    cls = raster.TemporalAggregate if case["kind"] == "aggregate" else raster.Cumulative
+    return cls(leaf, *case["block_args"])
+
+
+def temporal_on_device(case):
+    """Statistics the device kernel implements (median / percentiles need a per-pixel sort)."""
+    stat = case["block_args"][1] if case["kind"] == "aggregate" else case["block_args"][0]
+    return stat in ("sum", "count", "min", "max", "mean", "std", "var")
+
+
+@pytest.mark.parametrize("case", load_family("temporal"), ids=lambda c: c["id"] + "-" + c["kind"] + "-" + c["request"]["mode"])
+def test_temporal_against_reference(cpu_vm, case):
+    view = temporal_view(case)
+    a = case["attrs"]
+    assert np.dtype(view.dtype).str == a["dtype"] and view.fillvalue == a["fillvalue"] and view.temporal == a["temporal"]
+    assert (list(view.period) if view.period else None) == a["period"]
+    assert (None if view.timedelta is None else view.timedelta.total_seconds()) == a["timedelta"]
+    # the plan: same process arguments as the reference hands to its process()
+    plan = view.get_sources_and_requests(**case["request"])
+    assert plan[0][0] == case["process_args"][0], case["id"]
+    out = view.get_data(**case["request"])
+    want = case["expect"]
+    if want is None or "values" not in want:
+        assert out == want, case["id"]
+    else:
+        assert_result_equal(out, want, 0, case["id"])
+
+
+def test_temporal_construction_errors():
+    from blocks_util import TemporalLeaf
+    leaf = TemporalLeaf("tmp/err", "<f4", 1.0, ["2020-01-01T00:00:00"], None)
+    for bad in (dict(frequency=3), dict(frequency="h", closed="both"), dict(frequency="h", label="up"),
+                dict(frequency="h", timezone=1), dict(frequency="h", statistic=1)):
+        kw = dict(frequency="h", statistic="sum", closed=None, label=None, timezone="UTC")
+        kw.update(bad)
+        with pytest.raises((TypeError, ValueError)):
+            raster.TemporalAggregate(leaf, **kw)
+    with pytest.raises(ValueError):
+        raster.TemporalAggregate(leaf, "h", "mode")
+    with pytest.raises(ValueError):
+        raster.TemporalAggregate(leaf, "h", "p101")
+    with pytest.raises(TypeError):
+        raster.TemporalAggregate("leaf", "h")
+    with pytest.raises(ValueError):
+        raster.Cumulative(leaf, "mean")
+    with pytest.raises(TypeError):
+        raster.Cumulative(leaf, "sum", 5)
+    assert raster.TemporalAggregate(leaf, "H", "P95.0").args[1:3] == ("h", "p95.0")
+    assert raster.TemporalAggregate(leaf, None, "SUM", "left", "left", "Europe/Amsterdam").args[3:] == (None, None, None)
+    import pytz
+    with pytest.raises(pytz.UnknownTimeZoneError):
+        raster.TemporalAggregate(leaf, "h", "sum", None, None, "Mars/Olympus")

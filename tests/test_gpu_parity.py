@@ -695,3 +695,67 @@ def test_tiler_over_boolean_view(gpu):
     assert whole["values"].dtype == np.dtype("bool") and whole["no_data_value"] is None
     for tile in ([7, 5], 16):
         assert_result_equal(raster.RasterTiler(view, tile).get_data(**req), whole, 0, "bool view, tile %s" % (tile,))
+
+
+# ---- N4: TemporalAggregate / Cumulative -----------------------------------------------------------------
+def _temporal_cases():
+    from test_blocks_cpu import temporal_on_device
+    return [c for c in load_family("temporal") if c["request"]["mode"] == "vals" and temporal_on_device(c)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _temporal_cases(), ids=lambda c: c["id"] + "-" + c["kind"])
+def test_temporal_golden(gpu, case):
+    """Whole get_data() of TemporalAggregate / Cumulative views: pandas bins on the host, the
+    frame-axis reduction on the device (csrc/gm_temporal.hip), bit-exact against the reference."""
+    from test_blocks_cpu import temporal_view
+    out = temporal_view(case).get_data(**case["request"])
+    if case["expect"] is None:
+        assert out is None
+    else:
+        assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.mark.gpu
+def test_temporal_median_is_refused(gpu):
+    from test_blocks_cpu import temporal_view
+    case = next(c for c in load_family("temporal") if c["kind"] == "aggregate" and c["block_args"][1] == "median"
+                and c["request"]["mode"] == "vals" and c["expect"] is not None)
+    with pytest.raises(NotImplementedError):
+        temporal_view(case).get_data(**case["request"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,ndv", [("f4", np.float32(np.finfo("f4").max)), ("f8", -9999.0), ("u1", np.uint8(255)),
+                                       ("i2", np.int16(-1)), ("i4", 2147483647), ("u2", np.uint16(65535)),
+                                       ("i8", -1), ("u4", np.uint32(7))])
+@pytest.mark.parametrize("shape_yx", [(64, 96), (37, 53)])
+def test_temporal_kernels_against_oracle(gpu, dtype, ndv, shape_yx):
+    """Every statistic x dtype on stacks larger than a workgroup (vector and scalar pixel paths, bins
+    longer than the unroll, empty bins, more bins than one launch holds) against the oracle."""
+    from dask_geomodeling_amd.raster import temporal as T
+    rng = np.random.default_rng(hash((dtype,) + shape_yx) % 2**32)
+    frames = 23
+    if np.dtype(dtype).kind == "f":
+        v = (rng.random((frames,) + shape_yx) * 200 - 100).astype(dtype)
+        v[3, 2, 3] = np.inf
+        v[4, 5, 6] = np.nan
+    else:
+        v = rng.integers(0, 100, size=(frames,) + shape_yx).astype(dtype)
+    v[rng.random(v.shape) < 0.2] = ndv
+    v[:, 1, 1] = ndv
+    runs = [(0, 1), (1, 2), (3, 0), (3, 9), (12, 11), (0, 23), (22, 1)] + [(k % 20, 3) for k in range(100)]
+    for stat in ("sum", "count", "min", "max", "mean", "var", "std"):
+        out_dtype = T.dtype_for_statistic(dtype, stat)
+        got = T.aggregate_frames(v, ndv, runs, stat, out_dtype).to_numpy()
+        want = O.temporal_aggregate_values(v, ndv, runs, stat, out_dtype)
+        if stat in ("min", "max") and np.dtype(dtype).kind == "f":
+            got, want = got + 0.0, want + 0.0
+        assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (stat, dtype)
+    cruns = [(0, 5), (5, 1), (6, 10), (16, 7)]
+    for stat in ("sum", "count"):
+        out_dtype = T.dtype_for_statistic(dtype, stat)
+        for emit in ((0, 23), (4, 18), (22, 23)):
+            got = T.accumulate_frames(v, ndv, cruns, emit, stat, out_dtype).to_numpy()
+            want = O.temporal_cumulative_values(v, ndv, cruns, emit, stat, out_dtype)
+            assert got.dtype == want.dtype and np.array_equal(got, want), (stat, dtype, emit)

@@ -219,3 +219,15 @@ def test_reduce_max(case):
 def test_smooth(case):
     out = O.smooth_process(*case["args"])
     assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.mark.parametrize("case", load_family("temporal"), ids=lambda c: c["id"] + "-" + c["kind"])
+def test_temporal(case):
+    """TemporalAggregate.process / Cumulative.process on the arguments the reference built."""
+    func = O.temporal_aggregate_process if case["kind"] == "aggregate" else O.cumulative_process
+    out = func(*case["process_args"])
+    want = case["expect"]
+    if want is None or "values" not in want:
+        assert out == want, case["id"]
+    else:
+        assert_result_equal(out, want, 0, case["id"])
