@@ -281,6 +281,77 @@ __global__ __launch_bounds__(256) void cumulative_kernel(const Tin* __restrict__
   for (; j < count; ++j) step(load_pack<Tin, V>(src + (long long)j * pixels), j);
 }
 
+// Median: the data frames of a cell are insertion-sorted into the lane's column of an LDS array
+// (slot-major: lanes hit distinct banks), then (low + high) / 2 like np.ma.median, which is what
+// np.nanmedian runs for fewer than 600 frames.  Bins hold at most GM_MAX_MEDIAN_FRAMES frames.
+template <typename Tin>
+__global__ __launch_bounds__(256) void median_kernel(const Tin* __restrict__ frames, Tin ndv, bool has_ndv,
+                                                     long long pixels, Bins B,
+                                                     typename OutOf<Tin, GM_STAT_MEDIAN>::type* __restrict__ out,
+                                                     typename OutOf<Tin, GM_STAT_MEDIAN>::type fill) {
+  using C = typename OutOf<Tin, GM_STAT_MEDIAN>::type;  // = result_type(float32, dtype), the working dtype too
+  extern __shared__ unsigned char lds_raw[];
+  C* sorted = reinterpret_cast<C*>(lds_raw);  // [slot][lane]
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= pixels) return;
+  const int first = B.first[blockIdx.y], count = B.count[blockIdx.y];
+  const Tin* src = frames + (long long)first * pixels + p;
+  C* column = sorted + threadIdx.x;
+  int n = 0;
+  auto insert = [&](Tin v) {
+    C x;
+    if (skipped<Tin, C>(v, ndv, has_ndv, x)) return;
+    int i = n;
+    while (i > 0 && column[(i - 1) * 256] > x) {
+      column[i * 256] = column[(i - 1) * 256];
+      --i;
+    }
+    column[i * 256] = x;
+    ++n;
+  };
+  int j = 0;
+  for (; j + TB_UNROLL <= count; j += TB_UNROLL) {
+    Tin f[TB_UNROLL];
+#pragma unroll
+    for (int u = 0; u < TB_UNROLL; ++u) f[u] = __builtin_nontemporal_load(src + (long long)(j + u) * pixels);
+#pragma unroll
+    for (int u = 0; u < TB_UNROLL; ++u) insert(f[u]);
+  }
+  for (; j < count; ++j) insert(__builtin_nontemporal_load(src + (long long)j * pixels));
+  C r = std::numeric_limits<C>::quiet_NaN();
+  if (n > 0) {
+    const int h = n / 2;
+    const C high = column[h * 256];
+    const C low = (n & 1) ? high : column[(h - 1) * 256];
+    r = (low + high) / (C)2;
+  }
+  __builtin_nontemporal_store(finite_<C>(r) ? r : fill, out + (long long)B.out[blockIdx.y] * pixels + p);
+}
+
+template <typename Tin>
+int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long pixels, const gm_frame_bin* bins,
+                  int n_bins, void* out, uint64_t fill_bits, hipStream_t s) {
+  using C = typename OutOf<Tin, GM_STAT_MEDIAN>::type;
+  const unsigned gx = (unsigned)((pixels + 255) / 256);
+  for (int b0 = 0; b0 < n_bins; b0 += TB_MAX_BINS) {
+    Bins B;
+    const int nb = n_bins - b0 < TB_MAX_BINS ? n_bins - b0 : TB_MAX_BINS;
+    int longest = 1;
+    for (int i = 0; i < nb; ++i) {
+      B.first[i] = bins[b0 + i].first;
+      B.count[i] = bins[b0 + i].count;
+      B.out[i] = bins[b0 + i].out;
+      if (bins[b0 + i].count > longest) longest = bins[b0 + i].count;
+    }
+    if (longest > GM_MAX_MEDIAN_FRAMES || (size_t)longest * 256 * sizeof(C) > 64 * 1024)
+      return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_aggregate: median over %d frames (LDS holds %d)", longest,
+                      (int)(64 * 1024 / (256 * sizeof(C))));
+    hipLaunchKernelGGL((median_kernel<Tin>), dim3(gx, nb), dim3(256), (size_t)longest * 256 * sizeof(C), s,
+                       (const Tin*)frames, from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, (C*)out, from_bits<C>(fill_bits));
+  }
+  return GM_OK;
+}
+
 bool ascending_bins(const gm_frame_bin* bins, int n_bins, long long n_frames, int n_out) {
   for (int i = 0; i < n_bins; ++i) {
     if (bins[i].first < 0 || bins[i].count < 0 || (long long)bins[i].first + bins[i].count > n_frames) return false;
@@ -352,6 +423,7 @@ int aggregate_of(int statistic, const void* frames, uint64_t ndv_bits, int has_n
     case GM_STAT_MEAN: return launch_aggregate<Tin, GM_STAT_MEAN>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, out, fill_bits, s);
     case GM_STAT_VAR: return launch_aggregate<Tin, GM_STAT_VAR>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, out, fill_bits, s);
     case GM_STAT_STD: return launch_aggregate<Tin, GM_STAT_STD>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, out, fill_bits, s);
+    case GM_STAT_MEDIAN: return launch_median<Tin>(frames, ndv_bits, has_ndv, pixels, bins, n_bins, out, fill_bits, s);
     default: return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_aggregate: statistic %d", statistic);
   }
 }
@@ -396,7 +468,7 @@ int gm_temporal_out_dtype(int dtype, int statistic) {
       if (is_float) return dtype;
       if (gm::dtype_size(dtype) < 4) return GM_I32;
       return dtype == GM_U32 ? GM_I64 : dtype;
-    case GM_STAT_MEAN: case GM_STAT_VAR: case GM_STAT_STD:
+    case GM_STAT_MEAN: case GM_STAT_VAR: case GM_STAT_STD: case GM_STAT_MEDIAN:
       return (gm::dtype_size(dtype) <= 2 || dtype == GM_F32) ? GM_F32 : GM_F64;
     default: return -1;
   }

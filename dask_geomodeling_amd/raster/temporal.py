@@ -23,7 +23,8 @@ __all__ = ["TemporalAggregate", "Cumulative"]
 # frequencies whose bins pandas closes and labels on the right by default (TimeGrouper.__init__)
 _END_ANCHORED = {"M", "A", "Q", "BM", "BA", "BQ", "W", "ME", "YE", "QE", "BME", "BYE", "BQE"}
 _TICK = Timedelta(microseconds=1)
-STATISTIC_CODES = {"sum": 0, "count": 1, "min": 2, "max": 3, "mean": 4, "var": 5, "std": 6}
+STATISTIC_CODES = {"sum": 0, "count": 1, "min": 2, "max": 3, "mean": 4, "var": 5, "std": 6, "median": 7}
+MAX_MEDIAN_FRAMES = 64  # GM_MAX_MEDIAN_FRAMES: a cell's frames are sorted in LDS
 _EXTENSIVE = {"sum", "count"}  # additive statistics: nothing to add up = 0, not 'no data'
 
 
@@ -229,8 +230,12 @@ def aggregate_frames(values, no_data_value, runs, statistic, dtype):
     from ..hip import runtime
     from ..hip.array import DeviceArray
     if statistic not in STATISTIC_CODES:
-        raise NotImplementedError("TemporalAggregate statistic %r (median and percentiles need a per-pixel sort)" % statistic)
+        raise NotImplementedError("TemporalAggregate statistic %r (percentiles are not built)" % statistic)
     src, code, has, bits, frames, height, width = _reduce_args(values, no_data_value)
+    if statistic == "median":
+        longest = max([count for _, count in runs] + [0])
+        if longest > MAX_MEDIAN_FRAMES // (np.result_type(np.float32, dtype).itemsize // 4):
+            raise NotImplementedError("median over %d frames per label" % longest)
     L = runtime.lib()
     if L.gm_temporal_out_dtype(code, STATISTIC_CODES[statistic]) != _code(dtype):
         raise NotImplementedError("%s of a %s raster as %s" % (statistic, src.dtype, np.dtype(dtype)))

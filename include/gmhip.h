@@ -372,8 +372,10 @@ enum gm_statistic {
   GM_STAT_MAX = 3,   /* np.nanmax   */
   GM_STAT_MEAN = 4,  /* np.nanmean  */
   GM_STAT_VAR = 5,   /* np.nanvar   */
-  GM_STAT_STD = 6    /* np.nanstd   */
+  GM_STAT_STD = 6,   /* np.nanstd   */
+  GM_STAT_MEDIAN = 7 /* np.nanmedian (gm_temporal_aggregate only; bins of at most GM_MAX_MEDIAN_FRAMES frames) */
 };
+#define GM_MAX_MEDIAN_FRAMES 64
 
 typedef struct gm_frame_bin {
   int32_t first; /* first source frame */
@@ -390,7 +392,8 @@ int gm_temporal_out_dtype(int dtype, int statistic);
  * is not finite, or a bin without frames, becomes fill_bits (0 for sum / count, else the out
  * dtype's maximum).  Output frames no bin writes to are left untouched (gm_fill them first).
  * Accumulation runs frame by frame in result_type(float32, out dtype), like NumPy's axis-0
- * reductions; the mean divides in float64 and rounds once. */
+ * reductions; the mean divides in float64 and rounds once.  The median sorts the data frames of a
+ * cell in LDS (one column per lane) and returns (low + high) / 2 as np.ma.median does. */
 int gm_temporal_aggregate(const void* frames, int dtype, int has_ndv, uint64_t ndv_bits, int64_t n_frames, int64_t pixels,
                           const gm_frame_bin* bins, int n_bins, int n_out, int statistic, void* out, uint64_t fill_bits);
 

@@ -717,9 +717,9 @@ def test_temporal_golden(gpu, case):
 
 
 @pytest.mark.gpu
-def test_temporal_median_is_refused(gpu):
+def test_temporal_percentile_is_refused(gpu):
     from test_blocks_cpu import temporal_view
-    case = next(c for c in load_family("temporal") if c["kind"] == "aggregate" and c["block_args"][1] == "median"
+    case = next(c for c in load_family("temporal") if c["kind"] == "aggregate" and c["block_args"][1] == "p95"
                 and c["request"]["mode"] == "vals" and c["expect"] is not None)
     with pytest.raises(NotImplementedError):
         temporal_view(case).get_data(**case["request"])
@@ -745,7 +745,7 @@ def test_temporal_kernels_against_oracle(gpu, dtype, ndv, shape_yx):
     v[rng.random(v.shape) < 0.2] = ndv
     v[:, 1, 1] = ndv
     runs = [(0, 1), (1, 2), (3, 0), (3, 9), (12, 11), (0, 23), (22, 1)] + [(k % 20, 3) for k in range(100)]
-    for stat in ("sum", "count", "min", "max", "mean", "var", "std"):
+    for stat in ("sum", "count", "min", "max", "mean", "var", "std", "median"):
         out_dtype = T.dtype_for_statistic(dtype, stat)
         got = T.aggregate_frames(v, ndv, runs, stat, out_dtype).to_numpy()
         want = O.temporal_aggregate_values(v, ndv, runs, stat, out_dtype)

@@ -32,7 +32,7 @@ def timeit(label, bytes_per_call, calls, reps=3):
 
 
 def main():
-    which = [a for a in sys.argv[1:] if "=" not in a] or ["reclass", "classify", "mask", "bilinear", "nearest", "stencil"]
+    which = [a for a in sys.argv[1:] if "=" not in a] or ["reclass", "classify", "mask", "bilinear", "nearest", "stencil", "temporal"]
     opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
     side = int(opts.get("side", 8192))
     runtime.set_device(0)
@@ -89,6 +89,26 @@ def main():
         timeit("dilate u8, 2 values (2 B/px)", 2.0 * m, [lambda t=t: stencil.dilate(t, [1, 3]) for t in u8])
         timeit("dilate f32, 2 values (8 B/px)", 8.0 * m, [lambda t=t: stencil.dilate(t, [1.0, 3.0]) for t in src])
         del src, u8
+    if "temporal" in which:
+        from dask_geomodeling_amd.hip.array import DeviceArray
+        from dask_geomodeling_amd.raster import temporal
+        tside, frames = 4096, 24
+        stack = DeviceArray.empty((frames, tside, tside), np.dtype("f4"))
+        for k in range(frames):
+            tile = generate_window((tside, tside), "f4", 60 + k, 0.0, 100.0, F32MAX, (97, 89), 0, 0, tside, tside)
+            runtime.check(runtime.lib().gm_d2d(stack.band_slice(k, k + 1).ptr, tile.ptr, tside * tside * 4), "gm_d2d")
+        px = tside * tside
+        hourly = [(6 * i, 6) for i in range(4)]
+        for stat in ("sum", "mean", "max", "count", "std", "median"):
+            out_dt = temporal.dtype_for_statistic("f4", stat)
+            reads = 2 if stat == "std" else 1
+            timeit("temporal %s f32, 24 frames -> 4 labels (%d B/px)" % (stat, reads * 96 + 16), (reads * 96.0 + 16.0) * px,
+                   [lambda: temporal.aggregate_frames(stack, np.float32(F32MAX), hourly, stat, out_dt)])
+        timeit("temporal sum f32, 24 frames -> 1 label (100 B/px)", 100.0 * px,
+               [lambda: temporal.aggregate_frames(stack, np.float32(F32MAX), [(0, 24)], "sum", np.dtype("f4"))])
+        timeit("cumulative sum f32, 24 frames (192 B/px)", 192.0 * px,
+               [lambda: temporal.accumulate_frames(stack, np.float32(F32MAX), hourly, (0, 24), "sum", np.dtype("f4"))])
+        del stack
     if "nearest" in which:
         src = [generate_window((side, side), "f4", 80 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side, side) for i in range(T)]
         gt = (0.0, 1.0, 0.0, float(side), 0.0, -1.0)
