@@ -127,10 +127,10 @@ __device__ __forceinline__ double src_coord(int k, double scale) { return ((doub
 
 // T: float or double.  STAGED: the source window of a block fits LDS; otherwise (strong
 // down-sampling) taps are read from global memory directly.
-template <typename T, bool STAGED, int BL_TILE_H>
+template <typename T, bool STAGED, int BL_TILE_H, int SU>
 __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src, T* __restrict__ dst, int hs, int ws,
                                                        int hd, int wd, double sy, double sx, int has_ndv, T ndv,
-                                                       int pitch) {
+                                                       int pitch, int vec_src) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* const tile = (T*)smem;
   const int band = blockIdx.z;
@@ -145,18 +145,85 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src
   wy0 = max(wy0, 0); wx0 = max(wx0, 0);
   wy1 = min(wy1, hs - 1); wx1 = min(wx1, ws - 1);
   const int win_h = wy1 - wy0 + 1, win_w = wx1 - wx0 + 1;
+  // per destination row of the block: upper / lower source row and the lower row's weight, computed
+  // once by one lane each and broadcast from LDS (the rows a lane walks are wave-uniform)
+  __shared__ double row_fv[BL_TILE_H];
+  __shared__ int row_ia[BL_TILE_H], row_ib[BL_TILE_H];
+  if (threadIdx.x < BL_TILE_H) {
+    const double v = src_coord(r0 + (int)threadIdx.x, sy);
+    const double i0f = floor(v);
+    const int i0 = (int)i0f;
+    row_fv[threadIdx.x] = v - i0f;
+    row_ia[threadIdx.x] = min(max(i0, 0), hs - 1);
+    row_ib[threadIdx.x] = min(max(i0 + 1, 0), hs - 1);
+  }
+  if constexpr (!STAGED) __syncthreads();
+  // A tap that is no data or not finite voids every pixel it touches (any weight): it
+  // is turned into NaN once, where it enters the block, and the arithmetic carries it to the result.
+  // (without a no-data value nothing is marked: the limit becomes +inf, which only NaN itself fails)
+  const T mark_limit = has_ndv ? std::numeric_limits<T>::max() : std::numeric_limits<T>::infinity();
+  const T mark_ndv = has_ndv ? ndv : std::numeric_limits<T>::quiet_NaN();
+  const T void_out = has_ndv ? ndv : std::numeric_limits<T>::quiet_NaN();
+  auto mark = [&](T v) -> T {
+    const bool good = (fabs(v) <= mark_limit) & (v != mark_ndv);
+    return good ? v : std::numeric_limits<T>::quiet_NaN();
+  };
+  // vec_src: every source row starts 16-byte aligned and holds whole 16-byte groups
+  const int stage_x0 = vec_src ? (wx0 & ~(16 / (int)sizeof(T) - 1)) : -1;
   if constexpr (STAGED) {
-    // coalesced staging: a wave reads one source row segment (consecutive lanes, consecutive columns)
+    // Coalesced staging, a wave per source row segment.  All loads of a lane are issued before the
+    // first LDS write (a load -> wait -> write loop would pay one HBM round trip per row), and rows
+    // are fetched as aligned 16-byte groups when the source allows it.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int y = wave; y < win_h; y += 4) {
-      const T* row = sband + (size_t)(wy0 + y) * ws + wx0;
-      for (int x = lane; x < win_w; x += 64) tile[y * pitch + x] = __builtin_nontemporal_load(row + x);
+    // SU = rows in flight per lane: the launcher picks ceil(window rows / 4) so that one batch covers the window
+    constexpr int PER = 16 / (int)sizeof(T);
+    typedef T VT __attribute__((ext_vector_type(PER)));
+    if (stage_x0 >= 0) {
+      // columns [stage_x0, ...) with stage_x0 = wx0 rounded down to a 16-byte group: tile column of
+      // source column x is x - stage_x0
+      const int groups = (wx1 - stage_x0) / PER + 1;
+      for (int g = lane; g < groups; g += 64) {
+        for (int yb = wave; yb < win_h; yb += 4 * SU) {
+          VT v[SU];
+#pragma unroll
+          for (int u = 0; u < SU; ++u) {
+            const int y = min(yb + 4 * u, win_h - 1);  // (unconditional: rows past the window re-read its last row)
+            v[u] = __builtin_nontemporal_load((const VT*)(sband + (size_t)(wy0 + y) * ws + stage_x0) + g);
+          }
+#pragma unroll
+          for (int u = 0; u < SU; ++u) {
+            const int y = yb + 4 * u;
+            if (y < win_h) {
+#pragma unroll
+              for (int e = 0; e < PER; ++e) v[u][e] = mark(v[u][e]);
+              *(VT*)(tile + y * pitch + g * PER) = v[u];
+            }
+          }
+        }
+      }
+    } else {
+      for (int x = lane; x < win_w; x += 64) {
+        for (int yb = wave; yb < win_h; yb += 4 * SU) {
+          T v[SU];
+#pragma unroll
+          for (int u = 0; u < SU; ++u) {
+            const int y = min(yb + 4 * u, win_h - 1);
+            v[u] = __builtin_nontemporal_load(sband + (size_t)(wy0 + y) * ws + wx0 + x);
+          }
+#pragma unroll
+          for (int u = 0; u < SU; ++u) {
+            const int y = yb + 4 * u;
+            if (y < win_h) tile[y * pitch + x] = mark(v[u]);
+          }
+        }
+      }
     }
     __syncthreads();
   }
+  const int tile_x0 = (STAGED && stage_x0 >= 0) ? stage_x0 : wx0;
   auto tap = [&](int y, int x) -> T {
-    if constexpr (STAGED) return tile[(y - wy0) * pitch + (x - wx0)];
-    else return sband[(size_t)y * ws + x];
+    if constexpr (STAGED) return tile[(y - wy0) * pitch + (x - tile_x0)];
+    else return mark(sband[(size_t)y * ws + x]);
   };
 
   const int tx = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -182,40 +249,34 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src
   // LDS reads, the float64 conversions and two thirds of the float64 arithmetic are shared.
   constexpr int RPW = BL_TILE_H / 4;
   double hrow[2][4];   // [0] = source row `cur[0]`, [1] = source row `cur[1]`, per owned column
-  bool hbad[2][4];
   int cur[2] = {-1, -1};
-  auto horizontal = [&](int y, double (&h)[4], bool (&bad)[4]) {
+  auto horizontal = [&](int y, double (&h)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const T A = tap(y, ja[k]), B = tap(y, jb[k]);
       h[k] = gu[k] * (double)A + fu[k] * (double)B;
-      bool b = !(isfinite(A) & isfinite(B));
-      if (has_ndv) b = b | (A == ndv) | (B == ndv);
-      bad[k] = b;
     }
   };
+#pragma unroll 1
   for (int r = r0 + wave * RPW; r < min(r0 + (wave + 1) * RPW, r1); ++r) {
-    const double v = src_coord(r, sy);  // wave-uniform
-    const double i0f = floor(v);
-    const double fv = v - i0f, gv = 1.0 - fv;
-    const int i0 = (int)i0f;
-    const int ia = min(max(i0, 0), hs - 1), ib = min(max(i0 + 1, 0), hs - 1);
+    const double fv = row_fv[r - r0], gv = 1.0 - fv;  // wave-uniform
+    const int ia = row_ia[r - r0], ib = row_ib[r - r0];
     // wave-uniform reuse decisions
     if (ia != cur[0]) {
       if (ia == cur[1]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { hrow[0][k] = hrow[1][k]; hbad[0][k] = hbad[1][k]; }
+        for (int k = 0; k < 4; ++k) hrow[0][k] = hrow[1][k];
       } else {
-        horizontal(ia, hrow[0], hbad[0]);
+        horizontal(ia, hrow[0]);
       }
       cur[0] = ia;
     }
     if (ib != cur[1]) {
       if (ib == cur[0]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { hrow[1][k] = hrow[0][k]; hbad[1][k] = hbad[0][k]; }
+        for (int k = 0; k < 4; ++k) hrow[1][k] = hrow[0][k];
       } else {
-        horizontal(ib, hrow[1], hbad[1]);
+        horizontal(ib, hrow[1]);
       }
       cur[1] = ib;
     }
@@ -223,7 +284,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const T out = (T)(gv * hrow[0][k] + fv * hrow[1][k]);
-      res[k] = ((hbad[0][k] | hbad[1][k]) && has_ndv) ? ndv : out;
+      res[k] = (out != out) ? void_out : out;
     }
     T* out = dband + (size_t)r * wd + cb;
     if (vec_ok) {
@@ -311,17 +372,31 @@ int gm_resample_bilinear(const void* src, int dtype, int bands, int hs, int ws, 
   // largest source window a block can need, + apron; odd pitch (in 4-byte words) spreads the rows
   // of the window over the LDS banks
   const int itemsize = dtype == GM_F32 ? 4 : 8;
-  constexpr int BL_TILE_H = 32;  // destination rows per workgroup (measured: 4: 25 %, 8: 29 %, 16: 37 %, 32: 46 % of peak)
+  constexpr int BL_TILE_H = 32;  // destination rows per workgroup (measured: 16: 52 %, 32: 64 %, 64: 64 % of peak at 2x)
   long long win_h = (long long)ceil(BL_TILE_H * sy) + 3, win_w = (long long)ceil(BL_TILE_W * sx) + 3;
-  win_w |= 1;
-  const bool staged = win_h * win_w * itemsize <= BL_LDS_BYTES;
+  // 16-byte staging: the window may start up to a group earlier and is padded to whole groups
+  const int per = 16 / itemsize;
+  const bool vec_src = (ws % per) == 0 && ((uintptr_t)src % 16) == 0;
+  win_w = vec_src ? ((win_w + per - 1 + per - 1) / per) * per : (win_w | 1);
+  const bool staged = win_h * win_w * itemsize <= BL_LDS_BYTES - 2048;
   const size_t lds = staged ? (size_t)(win_h * win_w * itemsize) : 0;
   dim3 grid((unsigned)((wd + BL_TILE_W - 1) / BL_TILE_W), (unsigned)((hd + BL_TILE_H - 1) / BL_TILE_H), (unsigned)bands);
   if (grid.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "destination taller than %d rows", 65535 * BL_TILE_H);
-#define GM_BILINEAR_H(T, STAGED, NDV, H_)                                                                            \
-  hipLaunchKernelGGL((bilinear_kernel<T, STAGED, H_>), grid, dim3(256), lds, s, (const T*)src, (T*)dst, hs, ws, hd, \
-                     wd, sy, sx, has_ndv, (T)(NDV), (int)win_w)
-#define GM_BILINEAR(T, STAGED, NDV) GM_BILINEAR_H(T, STAGED, NDV, BL_TILE_H)
+#define GM_BILINEAR_SU(T, STAGED, NDV, H_, SU_)                                                                           \
+  hipLaunchKernelGGL((bilinear_kernel<T, STAGED, H_, SU_>), grid, dim3(256), lds, s, (const T*)src, (T*)dst, hs, ws, hd, \
+                     wd, sy, sx, has_ndv, (T)(NDV), (int)win_w, vec_src ? 1 : 0)
+#define GM_BILINEAR_H(T, STAGED, NDV, H_)                                   \
+  do {                                                                      \
+    const int rows_per_wave = (int)((win_h + 3) / 4);                       \
+    if (!STAGED || rows_per_wave > 6) GM_BILINEAR_SU(T, STAGED, NDV, H_, 8); \
+    else if (rows_per_wave > 5) GM_BILINEAR_SU(T, STAGED, NDV, H_, 6);      \
+    else if (rows_per_wave > 4) GM_BILINEAR_SU(T, STAGED, NDV, H_, 5);      \
+    else GM_BILINEAR_SU(T, STAGED, NDV, H_, 4);                             \
+  } while (0)
+#define GM_BILINEAR(T, STAGED, NDV)                                   \
+  do {                                                                \
+    GM_BILINEAR_H(T, STAGED, NDV, 32);                                \
+  } while (0)
   if (dtype == GM_F32) {
     if (staged) GM_BILINEAR(float, true, ndv.f64);
     else GM_BILINEAR(float, false, ndv.f64);
@@ -331,6 +406,7 @@ int gm_resample_bilinear(const void* src, int dtype, int bands, int hs, int ws, 
   }
 #undef GM_BILINEAR
 #undef GM_BILINEAR_H
+#undef GM_BILINEAR_SU
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
