@@ -894,6 +894,25 @@ template <> struct native_vec<float> { typedef f32x4 type; };
 template <> struct native_vec<int> { typedef i32x4 type; };
 
 // vector kernel: blockIdx.y = tile of the batch, blockIdx.x = span of 256*G groups of 4 elements
+// LOOKUP window -> LDS: 4 loads of a lane are in flight before the first LDS write (a load -> wait ->
+// write loop would pay one L2 round trip per 2 KiB of window)
+__device__ __forceinline__ void stage_window(unsigned long long* lds, const unsigned long long* __restrict__ src,
+                                             unsigned words) {
+  for (unsigned i = threadIdx.x; i < words; i += 1024) {
+    unsigned long long v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned k = i + 256u * u;
+      v[u] = src[k < words ? k : words - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned k = i + 256u * u;
+      if (k < words) lds[k] = v[u];
+    }
+  }
+}
+
 template <typename RC, int G, int NIN, int NT, int FLAVOR>
 __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
   const kargs_t K = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -998,7 +1017,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
         const unsigned words = GM_KARG(K, lds_words);
         const unsigned long long* const src =
             (const unsigned long long*)(uintptr_t)kload<unsigned long long>(C, offsetof(VmCode, tables) + 8 * (lds_table - 1));
-        for (unsigned i = threadIdx.x; i < words; i += 256) vm_lds[i] = src[i];
+        stage_window(vm_lds, src, words);
         __syncthreads();
       }
     }
@@ -1054,7 +1073,7 @@ __global__ __launch_bounds__(256) void vm_tail_kernel(const VmLaunch) {
       const unsigned words = GM_KARG(K, lds_words);
       const unsigned long long* const src =
           (const unsigned long long*)(uintptr_t)kload<unsigned long long>(C, offsetof(VmCode, tables) + 8 * (lds_table - 1));
-      for (unsigned i = threadIdx.x; i < words; i += 256) vm_lds[i] = src[i];
+      stage_window(vm_lds, src, words);
       __syncthreads();
     }
   }
