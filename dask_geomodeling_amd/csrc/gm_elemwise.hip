@@ -307,7 +307,7 @@ int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) 
     }
   }
   void* dev = nullptr;
-  rc = gm_malloc(&dev, sizeof(VmCode) + e->staged.size() * 8 + 16);
+  rc = gm_malloc(&dev, sizeof(VmCode) + e->staged.size() * 8 + 64);  // (+: DIGITIZE reads its edges four at a time)
   if (rc) return rc;
   e->dev = (VmCode*)dev;
   const unsigned long long tables_dev = (unsigned long long)(uintptr_t)dev + ((sizeof(VmCode) + 15) / 16) * 16;

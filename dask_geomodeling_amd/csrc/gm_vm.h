@@ -132,16 +132,23 @@ __device__ __forceinline__ T kload(kargs_t base, size_t offset) {
 // Tiles are streamed exactly once: every tile load and store carries the non-temporal hint
 // (+10 % on a 2-read/1-write float4 stream, tools/ceiling2.hip).  `nt` is a compile-time
 // constant at every call site (a run-time flag gets if-converted and the hint is lost).
+// Tile pointers come out of the kernarg tables as integers, i.e. as generic pointers: without the
+// address-space cast they are flat_load / flat_store, which also count against lgkmcnt (every
+// scalar load of a micro-op then waits for the tile loads in flight).
 template <typename T>
 __device__ __forceinline__ T ld(const T* p, bool nt) {
-  return nt ? __builtin_nontemporal_load(p) : *p;
+  typedef const __attribute__((address_space(1))) T* global_t;
+  const global_t g = (global_t)(uintptr_t)p;
+  return nt ? __builtin_nontemporal_load(g) : *g;
 }
 template <typename T>
 __device__ __forceinline__ void st(T* p, T v, bool nt) {
+  typedef __attribute__((address_space(1))) T* global_t;
+  const global_t g = (global_t)(uintptr_t)p;
   if (nt)
-    __builtin_nontemporal_store(v, p);
+    __builtin_nontemporal_store(v, g);
   else
-    *p = v;
+    *g = v;
 }
 
 // ---- register-class traits ---------------------------------------------------
@@ -469,16 +476,30 @@ struct Machine {
     int cnt[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) cnt[k] = 0;
-    for (unsigned b = 0; b < nb; ++b) {
-      if constexpr (std::is_same<RC, float>::value) {
-        const float e = kload<float>(tbl, 4 * b);
+    // count the edges below (or at) the value: one compare + one add-with-carry per edge and element.
+    // `right` is decided once, outside the loops (inside it would cost a select per compare), and the
+    // edges arrive four per scalar load.
+    auto count = [&](auto below) {
+      typedef typename std::conditional<std::is_same<RC, float>::value, float, double>::type E;
+      if constexpr (std::is_same<RC, float>::value || std::is_same<RC, double>::value) {
+        for (unsigned b0 = 0; b0 < nb; b0 += 4) {
+          struct Quad { E e[4]; };
+          const Quad q = kload<Quad>(tbl, (unsigned)sizeof(E) * b0);  // (tables are padded to 4 edges by the host)
 #pragma unroll
-        for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < acc[k]) : (e <= acc[k])) ? 1 : 0;
-      } else if constexpr (std::is_same<RC, double>::value) {
-        const double e = kload<double>(tbl, 8 * b);
+          for (int j = 0; j < 4; ++j) {
+            if (b0 + j < nb) {
 #pragma unroll
-        for (int k = 0; k < N; ++k) cnt[k] += (right ? (e < acc[k]) : (e <= acc[k])) ? 1 : 0;
-      } else {
+              for (int k = 0; k < N; ++k) cnt[k] += below(q.e[j], acc[k]) ? 1 : 0;
+            }
+          }
+        }
+      }
+    };
+    if constexpr (std::is_same<RC, float>::value || std::is_same<RC, double>::value) {
+      if (right) count([](RC e, RC x) { return e < x; });
+      else count([](RC e, RC x) { return e <= x; });
+    } else {
+      for (unsigned b = 0; b < nb; ++b) {
         if (int_edges) {
           const long long e = kload<long long>(tbl, 8 * b);
 #pragma unroll
@@ -803,15 +824,19 @@ struct Machine {
   // operand select of a micro-op: y = input k / temp k (wave-uniform compare tree, static indices)
   __device__ __forceinline__ void select(const unsigned src, RC (&y)[N]) const {
     switch (src) {
+    // (the empty asm keeps the compiler from running one case's copy speculatively and overriding it
+    //  with another's: exactly one copy of N registers is executed)
 #define GM_SEL_IN(K)                                                    \
   case UOP_SRC_INPUT + K:                                               \
     if constexpr (K < NIN) {                                            \
+      asm volatile("");                                                 \
       _Pragma("unroll") for (int k = 0; k < N; ++k) y[k] = in[K][k];    \
     }                                                                   \
     break;
 #define GM_SEL_TMP(K)                                                   \
   case UOP_SRC_TEMP + K:                                                \
     if constexpr (K < NT) {                                             \
+      asm volatile("");                                                 \
       _Pragma("unroll") for (int k = 0; k < N; ++k) y[k] = T<K>()[k];   \
     }                                                                   \
     break;
