@@ -434,7 +434,13 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
       args.lds_words = code->lds_words;
       const unsigned long long span_bytes = per_block * 4ull * (bytes_per_elem ? bytes_per_elem : 1);
       unsigned long long spans = ((unsigned long long)code->lds_words * 8ull * 10ull + span_bytes - 1) / span_bytes;
-      if (spans < 1) spans = 1;
+      // ... and at least 8 spans while that leaves >= 4 workgroups per CU: a wave that handles a
+      // single span lives mostly in its prologue (a chain of dependent scalar loads: kernarg -> code
+      // -> micro-op -> table), measured +8 % on configs[2] (8192^2 int32 lookup), +5 % on configs[4]
+      const unsigned long long fill_blocks = 4ull * (unsigned long long)(cus > 0 ? cus : 256);
+      unsigned long long amortise = blocks / fill_blocks;
+      if (amortise > 8) amortise = 8;
+      if (spans < amortise) spans = amortise;
       if (spans > 64) spans = 64;
       args.spans = (unsigned)spans;
       blocks = (blocks + spans - 1) / spans;

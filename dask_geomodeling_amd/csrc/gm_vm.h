@@ -959,6 +959,8 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
 
   // TABLES kernels walk `spans` consecutive spans so that the LDS staging of a LOOKUP window is
   // amortised; every other kernel does exactly one span (full grid)
+  // (a span loop in the other flavours was measured: it never helps them -- 5 % slower at 2 spans, 11 % at
+  //  4 on the canonical chain -- and its mere presence costs the 4-input LIGHT kernel 10 %)
   unsigned spans = 1;
   if constexpr (FLAVOR == VM_TABLES) spans = GM_KARG(K, spans);
   for (unsigned span = 0; span < spans; ++span) {
