@@ -284,9 +284,14 @@ __global__ __launch_bounds__(256) void cumulative_kernel(const Tin* __restrict__
 // Median: the data frames of a cell are insertion-sorted into the lane's column of an LDS array
 // (slot-major: lanes hit distinct banks), then (low + high) / 2 like np.ma.median, which is what
 // np.nanmedian runs for fewer than 600 frames.  Bins hold at most GM_MAX_MEDIAN_FRAMES frames.
-template <typename Tin>
+struct Plan {  // gm_percentile_step per number of data frames (1 .. GM_MAX_MEDIAN_FRAMES)
+  short lower[GM_MAX_MEDIAN_FRAMES], upper[GM_MAX_MEDIAN_FRAMES];
+  double gamma[GM_MAX_MEDIAN_FRAMES], one_minus_gamma[GM_MAX_MEDIAN_FRAMES];
+};
+
+template <typename Tin, bool PERCENTILE>
 __global__ __launch_bounds__(256) void median_kernel(const Tin* __restrict__ frames, Tin ndv, bool has_ndv,
-                                                     long long pixels, Bins B,
+                                                     long long pixels, Bins B, Plan P,
                                                      typename OutOf<Tin, GM_STAT_MEDIAN>::type* __restrict__ out,
                                                      typename OutOf<Tin, GM_STAT_MEDIAN>::type fill) {
   using C = typename OutOf<Tin, GM_STAT_MEDIAN>::type;  // = result_type(float32, dtype), the working dtype too
@@ -320,17 +325,37 @@ __global__ __launch_bounds__(256) void median_kernel(const Tin* __restrict__ fra
   for (; j < count; ++j) insert(__builtin_nontemporal_load(src + (long long)j * pixels));
   C r = std::numeric_limits<C>::quiet_NaN();
   if (n > 0) {
-    const int h = n / 2;
-    const C high = column[h * 256];
-    const C low = (n & 1) ? high : column[(h - 1) * 256];
-    r = (low + high) / (C)2;
+    if constexpr (PERCENTILE) {
+      // numpy's _lerp between the two neighbours of the virtual index (n varies per lane: the plan is
+      // read with a lane-dependent index)
+      const C a = column[P.lower[n - 1] * 256], b = column[P.upper[n - 1] * 256];
+      const C t = (C)P.gamma[n - 1], u = (C)P.one_minus_gamma[n - 1];
+      const C d = b - a;
+      r = (t >= (C)0.5) ? b - d * u : a + d * t;
+    } else {
+      const int h = n / 2;
+      const C high = column[h * 256];
+      const C low = (n & 1) ? high : column[(h - 1) * 256];
+      r = (low + high) / (C)2;
+    }
   }
   __builtin_nontemporal_store(finite_<C>(r) ? r : fill, out + (long long)B.out[blockIdx.y] * pixels + p);
 }
 
 template <typename Tin>
 int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long pixels, const gm_frame_bin* bins,
-                  int n_bins, void* out, uint64_t fill_bits, hipStream_t s) {
+                  int n_bins, void* out, uint64_t fill_bits, hipStream_t s, const gm_percentile_step* plan = nullptr,
+                  int n_plan = 0) {
+  Plan P;
+  memset(&P, 0, sizeof(P));
+  for (int i = 0; i < n_plan && i < GM_MAX_MEDIAN_FRAMES; ++i) {
+    if (plan[i].lower < 0 || plan[i].lower > i || plan[i].upper < 0 || plan[i].upper > i)
+      return gm::fail(GM_ERR_INVALID, "gm_temporal_percentile: plan[%d] points outside %d values", i, i + 1);
+    P.lower[i] = (short)plan[i].lower;
+    P.upper[i] = (short)plan[i].upper;
+    P.gamma[i] = plan[i].gamma;
+    P.one_minus_gamma[i] = plan[i].one_minus_gamma;
+  }
   using C = typename OutOf<Tin, GM_STAT_MEDIAN>::type;
   const unsigned gx = (unsigned)((pixels + 255) / 256);
   for (int b0 = 0; b0 < n_bins; b0 += TB_MAX_BINS) {
@@ -346,8 +371,13 @@ int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long 
     if (longest > GM_MAX_MEDIAN_FRAMES || (size_t)longest * 256 * sizeof(C) > 64 * 1024)
       return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_aggregate: median over %d frames (LDS holds %d)", longest,
                       (int)(64 * 1024 / (256 * sizeof(C))));
-    hipLaunchKernelGGL((median_kernel<Tin>), dim3(gx, nb), dim3(256), (size_t)longest * 256 * sizeof(C), s,
-                       (const Tin*)frames, from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, (C*)out, from_bits<C>(fill_bits));
+    if (plan && longest > n_plan) return gm::fail(GM_ERR_INVALID, "gm_temporal_percentile: plan covers %d frames, a bin has %d", n_plan, longest);
+    if (plan)
+      hipLaunchKernelGGL((median_kernel<Tin, true>), dim3(gx, nb), dim3(256), (size_t)longest * 256 * sizeof(C), s,
+                         (const Tin*)frames, from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, P, (C*)out, from_bits<C>(fill_bits));
+    else
+      hipLaunchKernelGGL((median_kernel<Tin, false>), dim3(gx, nb), dim3(256), (size_t)longest * 256 * sizeof(C), s,
+                         (const Tin*)frames, from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, P, (C*)out, from_bits<C>(fill_bits));
   }
   return GM_OK;
 }
@@ -486,6 +516,24 @@ int gm_temporal_aggregate(const void* frames, int dtype, int has_ndv, uint64_t n
 #define GM_AGG(T) aggregate_of<T>(statistic, frames, ndv_bits, has_ndv, (long long)pixels, bins, n_bins, out, fill_bits, s)
   GM_TEMPORAL_DISPATCH(GM_AGG)
 #undef GM_AGG
+  if (rc != GM_OK) return rc;
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_temporal_percentile(const void* frames, int dtype, int has_ndv, uint64_t ndv_bits, int64_t n_frames, int64_t pixels,
+                           const gm_frame_bin* bins, int n_bins, int n_out, const gm_percentile_step* plan, int n_plan,
+                           void* out, uint64_t fill_bits) {
+  if (!frames || !out || !plan || (!bins && n_bins)) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (n_frames < 0 || pixels <= 0 || n_bins < 0 || n_out < 0) return gm::fail(GM_ERR_INVALID, "gm_temporal_percentile: bad shape");
+  if (n_plan < 1 || n_plan > GM_MAX_MEDIAN_FRAMES) return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_percentile: plan of %d steps", n_plan);
+  if (!ascending_bins(bins, n_bins, n_frames, n_out)) return gm::fail(GM_ERR_INVALID, "gm_temporal_percentile: bin outside the stack");
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  int rc = GM_OK;
+#define GM_PCT(T) launch_median<T>(frames, ndv_bits, has_ndv, (long long)pixels, bins, n_bins, out, fill_bits, s, plan, n_plan)
+  GM_TEMPORAL_DISPATCH(GM_PCT)
+#undef GM_PCT
   if (rc != GM_OK) return rc;
   GM_HIP(hipGetLastError());
   return GM_OK;

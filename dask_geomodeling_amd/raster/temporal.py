@@ -219,6 +219,33 @@ def _reduce_args(values, no_data_value):
     return src, code_of(src.dtype), has, bits, frames, height, width
 
 
+class GmPercentileStep(ctypes.Structure):
+    """gm_percentile_step of include/gmhip.h."""
+    _fields_ = [("lower", ctypes.c_int32), ("upper", ctypes.c_int32), ("gamma", ctypes.c_double),
+                ("one_minus_gamma", ctypes.c_double)]
+
+
+def percentile_plan(q, longest, work_dtype):
+    """What np.nanpercentile(..., q) (method 'linear') takes from n = 1 .. ``longest`` sorted values:
+    the two neighbours of the virtual index (n - 1) * (q / 100) and the interpolation weight, all
+    rounded the way NumPy's own scalar arithmetic in ``work_dtype`` rounds them
+    (numpy/lib/_function_base_impl.py: _quantile, _get_indexes, _get_gamma, _lerp)."""
+    number = np.dtype(work_dtype).type
+    quantile = np.true_divide(float(q), number(100))  # nanpercentile: q / a.dtype.type(100)
+    plan = (GmPercentileStep * longest)()
+    for n in range(1, longest + 1):
+        virtual = (n - 1) * quantile
+        lower = int(np.floor(virtual))
+        upper = lower + 1
+        if virtual >= n - 1:  # at or past the last value: both neighbours are the last one (index -1)
+            lower = upper = -1
+        gamma = number(np.float64(virtual) - lower)  # (the difference is taken in float64, then cast back)
+        step = plan[n - 1]
+        step.lower, step.upper = lower % n, upper % n
+        step.gamma, step.one_minus_gamma = float(gamma), float(1 - gamma)
+    return plan
+
+
 def _fill_bits(statistic, dtype):
     from ..hip import runtime
     return runtime.scalar_bits(0 if statistic in _EXTENSIVE else get_dtype_max(dtype), dtype)
@@ -229,17 +256,28 @@ def aggregate_frames(values, no_data_value, runs, statistic, dtype):
     (the loop of temporal.py:743-766 as one launch)."""
     from ..hip import runtime
     from ..hip.array import DeviceArray
-    if statistic not in STATISTIC_CODES:
-        raise NotImplementedError("TemporalAggregate statistic %r (percentiles are not built)" % statistic)
+    name, percentile = parse_statistic(statistic)
+    if name not in STATISTIC_CODES and percentile is None:
+        raise NotImplementedError("TemporalAggregate statistic %r" % statistic)
     src, code, has, bits, frames, height, width = _reduce_args(values, no_data_value)
-    if statistic == "median":
-        longest = max([count for _, count in runs] + [0])
+    longest = max([count for _, count in runs] + [1])
+    if name in ("median", "percentile"):
+        # a cell's data frames are sorted in LDS: 64 float32 / 32 float64 values per lane
         if longest > MAX_MEDIAN_FRAMES // (np.result_type(np.float32, dtype).itemsize // 4):
-            raise NotImplementedError("median over %d frames per label" % longest)
+            raise NotImplementedError("%s over %d frames per label" % (statistic, longest))
     L = runtime.lib()
-    if L.gm_temporal_out_dtype(code, STATISTIC_CODES[statistic]) != _code(dtype):
+    if L.gm_temporal_out_dtype(code, STATISTIC_CODES["median" if percentile is not None else name]) != _code(dtype):
         raise NotImplementedError("%s of a %s raster as %s" % (statistic, src.dtype, np.dtype(dtype)))
     out = DeviceArray.empty((len(runs), height, width), np.dtype(dtype))
+    if percentile is not None:
+        plan = percentile_plan(percentile, longest, dtype)
+        L.gm_temporal_percentile.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64]
+        runtime.check(L.gm_temporal_percentile(src.ptr, code, has, bits, frames, height * width, _frame_bins(runs), len(runs),
+                                               len(runs), plan, longest, out.ptr, _fill_bits(statistic, dtype)),
+                      "gm_temporal_percentile")
+        return out
     L.gm_temporal_aggregate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_void_p, ctypes.c_uint64]

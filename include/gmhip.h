@@ -397,6 +397,20 @@ int gm_temporal_out_dtype(int dtype, int statistic);
 int gm_temporal_aggregate(const void* frames, int dtype, int has_ndv, uint64_t ndv_bits, int64_t n_frames, int64_t pixels,
                           const gm_frame_bin* bins, int n_bins, int n_out, int statistic, void* out, uint64_t fill_bits);
 
+/* np.nanpercentile (method "linear") of the data frames of a cell, for TemporalAggregate's
+ * "p<number>" statistics.  plan[n - 1] tells what a cell with n data frames returns from its sorted
+ * values v: a = v[lower], b = v[upper], d = b - a, result = gamma >= 0.5 ? b - d * one_minus_gamma
+ * : a + d * gamma (numpy.lib._function_base_impl._lerp), all in result_type(float32, dtype).  The
+ * host derives the plan with NumPy's own scalar arithmetic ((n - 1) * (q / 100) in that dtype), so
+ * the rounding of the virtual index is NumPy's.  n_plan >= the longest bin, <= GM_MAX_MEDIAN_FRAMES. */
+typedef struct gm_percentile_step {
+  int32_t lower, upper;
+  double gamma, one_minus_gamma;
+} gm_percentile_step;
+int gm_temporal_percentile(const void* frames, int dtype, int has_ndv, uint64_t ndv_bits, int64_t n_frames, int64_t pixels,
+                           const gm_frame_bin* bins, int n_bins, int n_out, const gm_percentile_step* plan, int n_plan,
+                           void* out, uint64_t fill_bits);
+
 /* Cumulative.process, vals branch (temporal.py:957-1003): running sum / count inside every bin;
  * source frame j goes to output frame j - emit_first for emit_first <= j < emit_stop.
  * statistic: GM_STAT_SUM or GM_STAT_COUNT. */

@@ -968,17 +968,18 @@ def gen_temporal(w):
         ("tenmin_f4", dict(frequency="30min", closed="right", label="right"), ["sum", "mean"]),
         ("tenmin_f4", dict(frequency=None), ["sum", "max", "std"]),
         ("tenmin_f4", dict(frequency="D"), ["mean", "count"]),
-        ("daily_u1", dict(frequency="W"), ["sum", "min", "max", "mean", "var", "count"]),
+        ("daily_u1", dict(frequency="W"), ["sum", "min", "max", "mean", "var", "count", "median", "p25", "p90"]),
         ("daily_u1", dict(frequency="ME"), ["sum", "mean", "max"]),
         ("daily_u1", dict(frequency="2D", closed="left", label="right"), ["sum", "std"]),
-        ("free_i4", dict(frequency="D"), ["sum", "count", "min", "max", "mean", "std", "var"]),
+        ("free_i4", dict(frequency="D"), ["sum", "count", "min", "max", "mean", "std", "var", "median", "p10", "p66.6"]),
         ("free_i4", dict(frequency="D", timezone="Europe/Amsterdam"), ["sum", "mean"]),
         ("free_i4", dict(frequency=None), ["mean", "min"]),
         ("hourly_f8", dict(frequency="D", timezone="Europe/Amsterdam"), ["sum", "mean", "std", "min"]),
-        ("hourly_f8", dict(frequency="3h"), ["sum", "count", "min", "max", "mean", "std", "var"]),
+        ("hourly_f8", dict(frequency="3h"), ["sum", "count", "min", "max", "mean", "std", "var", "median", "p100", "p33"]),
         ("hourly_i2", dict(frequency="4h"), ["sum", "count", "min", "max", "mean", "std", "var", "median"]),
         ("daily_bool", dict(frequency="2D"), ["sum", "count", "mean"]),
-        ("tenmin_f4neg", dict(frequency="h", closed="right"), ["sum", "min", "max", "mean", "var"]),
+        ("tenmin_f4neg", dict(frequency="h", closed="right"), ["sum", "min", "max", "mean", "var", "p75", "p99.9"]),
+        ("tenmin_f4", dict(frequency=None), ["median", "p5", "p50", "p87.5"]),
     ]
     day = timedelta(days=1)
 
