@@ -89,6 +89,115 @@ __global__ __launch_bounds__(256) void dilate_kernel(const T* __restrict__ in, T
   }
 }
 
+// Dilate for 1-byte tiles (class rasters are uint8): a lane owns FOUR consecutive output columns and
+// works on them as one 32-bit word (SWAR).  Per input row it loads 8 bytes (the 6 columns its
+// outputs see), takes the three byte-shifted words (west / centre / east), and per value turns
+// "byte == v" into a 0xFF / 0x00 byte mask with five integer operations -- so a row costs one load
+// instead of twelve byte loads, and ~7 VALU operations per pixel and value instead of ~14.
+constexpr int DIL8_MAX_VALUES = 4;
+// rows a lane walks / rows fetched together; measured on 8192^2, 2 values: 32/4 92 us, 32/8 109, 16/4 79, 8/4 76,
+// 8/2 73, 4/4 72 (short walks = more waves in flight; the two priming rows are re-read from L2)
+constexpr int D8_ROWS = 8, D8_BATCH = 2;
+struct Dilate8Args {
+  unsigned splat[DIL8_MAX_VALUES];  // the value in every byte
+  int n_values;
+};
+
+__device__ __forceinline__ unsigned bytes_equal(unsigned x, unsigned splat) {
+  const unsigned t = x ^ splat;                                       // zero byte <=> equal
+  const unsigned nz = ((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t;          // bit 7 of a byte set <=> byte != 0
+  const unsigned m = ~nz & 0x80808080u;                               // 0x80 in equal bytes
+  return m | (m - (m >> 7));                                          // 0xFF in equal bytes
+}
+
+// 8 bytes at p (any alignment); columns at or past `limit` read as `pad`
+__device__ __forceinline__ unsigned long long load_window8(const unsigned char* p, int col, int limit, unsigned char pad) {
+  unsigned long long x;
+  if (col + 8 <= limit) {
+    __builtin_memcpy(&x, p, 8);
+  } else {
+    x = 0;
+    for (int j = 0; j < 8; ++j) x |= (unsigned long long)(col + j < limit ? p[j] : pad) << (8 * j);
+  }
+  return x;
+}
+
+__global__ __launch_bounds__(256) void dilate8_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                                      int bands, int h, int w, Dilate8Args A) {
+  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4, r0 = blockIdx.y * D8_ROWS, b = blockIdx.z;
+  const int ow = w - 2, oh = h - 2;
+  if (c4 >= ow) return;
+  const size_t plane = (size_t)h * w;
+  const unsigned char* base = in + (size_t)b * plane + c4;  // input column c4 = west neighbour of output column c4
+  const bool has_up = b > 0, has_down = b + 1 < bands;
+  const int r1 = min(r0 + D8_ROWS, oh);
+  // per value: horizontal hits of the previous input row (as a centre row), and the centre-column
+  // equality of the previous two input rows (the vertical neighbours of the rows around them)
+  unsigned horiz_prev[DIL8_MAX_VALUES], eq_prev[DIL8_MAX_VALUES], eq_prev2[DIL8_MAX_VALUES], band_prev[DIL8_MAX_VALUES];
+  unsigned centre_prev = 0;
+  auto absorb = [&](unsigned long long win, unsigned long long up, unsigned long long down, bool emit, int out_row) {
+    const unsigned west = (unsigned)win, centre = (unsigned)(win >> 8), east = (unsigned)(win >> 16);
+    const unsigned upc = (unsigned)(up >> 8), downc = (unsigned)(down >> 8);
+    unsigned result = centre_prev;
+#pragma unroll
+    for (int k = 0; k < DIL8_MAX_VALUES; ++k) {
+      if (k < A.n_values) {
+        const unsigned v = A.splat[k];
+        const unsigned eq = bytes_equal(centre, v);
+        const unsigned horiz = eq | bytes_equal(west, v) | bytes_equal(east, v);
+        unsigned band = 0;
+        if (has_up) band |= bytes_equal(upc, v);
+        if (has_down) band |= bytes_equal(downc, v);
+        // the previous input row is the centre row of `out_row`: its own horizontal hits, the rows above
+        // (eq_prev2) and below (eq: this row), and its band neighbours
+        const unsigned hit = horiz_prev[k] | eq_prev2[k] | eq | band_prev[k];
+        result = (result & ~hit) | (v & hit);  // in order: later values overwrite earlier ones
+        eq_prev2[k] = eq_prev[k];
+        eq_prev[k] = eq;
+        horiz_prev[k] = horiz;
+        band_prev[k] = band;
+      }
+    }
+    centre_prev = centre;
+    if (emit) {
+      unsigned char* o = out + ((size_t)b * oh + out_row) * ow + c4;
+      if (c4 + 4 <= ow) {
+        __builtin_memcpy(o, &result, 4);
+      } else {
+        for (int j = 0; c4 + j < ow; ++j) o[j] = (unsigned char)(result >> (8 * j));
+      }
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < DIL8_MAX_VALUES; ++k) horiz_prev[k] = eq_prev[k] = eq_prev2[k] = band_prev[k] = 0;
+  auto fetch = [&](int y, unsigned long long& win, unsigned long long& up, unsigned long long& down) {
+    const unsigned char* row = base + (size_t)y * w;
+    win = load_window8(row, c4, w, 0);
+    up = has_up ? load_window8(row - plane, c4, w, 0) : 0ull;
+    down = has_down ? load_window8(row + plane, c4, w, 0) : 0ull;
+  };
+  // input rows r0, r0 + 1 prime the state (no output), then input row y + 1 completes output row y - 1 ... :
+  // output row r has centre input row r + 1 and is complete once input row r + 2 was absorbed
+  {
+    unsigned long long w0, u0, d0, w1, u1, d1;
+    fetch(r0, w0, u0, d0);
+    fetch(r0 + 1, w1, u1, d1);
+    absorb(w0, u0, d0, false, 0);
+    absorb(w1, u1, d1, false, 0);
+  }
+  for (int rb = r0; rb < r1; rb += D8_BATCH) {
+    unsigned long long win[D8_BATCH], up[D8_BATCH], down[D8_BATCH];
+#pragma unroll
+    for (int i = 0; i < D8_BATCH; ++i) {
+      win[i] = up[i] = down[i] = 0;
+      if (rb + i < r1) fetch(rb + i + 2, win[i], up[i], down[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < D8_BATCH; ++i)
+      if (rb + i < r1) absorb(win[i], up[i], down[i], true, rb + i);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // MovingMax
 // ---------------------------------------------------------------------------------
@@ -313,6 +422,16 @@ int gm_dilate(const void* in, int dtype, int bands, int h, int w, const uint64_t
   if (bands > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: too many bands");
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
+  if (gm::dtype_size(dtype) == 1 && n_values >= 1 && n_values <= DIL8_MAX_VALUES) {
+    Dilate8Args A8;
+    A8.n_values = n_values;
+    for (int i = 0; i < DIL8_MAX_VALUES; ++i) A8.splat[i] = i < n_values ? 0x01010101u * (unsigned)(values_bits[i] & 0xffu) : 0u;
+    dim3 grid8((unsigned)((w - 2 + 1023) / 1024), (unsigned)((h - 2 + D8_ROWS - 1) / D8_ROWS), (unsigned)bands);
+    if (grid8.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: tile taller than %d rows", 65535 * D8_ROWS);
+    hipLaunchKernelGGL(dilate8_kernel, grid8, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, bands, h, w, A8);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+  }
   dim3 grid((unsigned)((w - 2 + 255) / 256), (unsigned)((h - 2 + ST_ROWS - 1) / ST_ROWS), (unsigned)bands);
 #define GM_DIL(T)                                                                                    \
   do {                                                                                               \

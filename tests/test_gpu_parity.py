@@ -772,3 +772,23 @@ def test_temporal_kernels_against_oracle(gpu, dtype, ndv, shape_yx):
             got = T.accumulate_frames(v, ndv, cruns, emit, stat, out_dtype).to_numpy()
             want = O.temporal_cumulative_values(v, ndv, cruns, emit, stat, out_dtype)
             assert got.dtype == want.dtype and np.array_equal(got, want), (stat, dtype, emit)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["u1", "i1", "?"])
+@pytest.mark.parametrize("shape", [(1, 40, 70), (3, 19, 23), (2, 130, 1031), (1, 11, 6)])
+def test_dilate_one_byte_tiles(gpu, dtype, shape):
+    """The 4-pixels-per-lane word kernel of 1-byte tiles (ragged widths, several bands, 1..4 values in
+    order, rows that end inside a lane's 8-byte window) against the oracle."""
+    from dask_geomodeling_amd.raster import stencil
+    rng = np.random.default_rng(hash((dtype,) + shape) % 2**32)
+    if dtype == "?":
+        v = rng.random(shape) < 0.2
+        value_sets = [[True], [False, True]]
+    else:
+        v = rng.integers(-3 if dtype == "i1" else 0, 6, size=shape).astype(dtype)
+        value_sets = [[1], [3, 1], [1, 3, 5], [5, 0, 2, 4], [2, 2]]
+    for values in value_sets:
+        want = O.dilate_process({"values": v, "no_data_value": None}, values)["values"]
+        got = stencil.dilate(v, values).to_numpy()
+        assert got.dtype == want.dtype and np.array_equal(got, want), (dtype, shape, values)
