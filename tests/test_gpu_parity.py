@@ -792,3 +792,36 @@ def test_dilate_one_byte_tiles(gpu, dtype, shape):
         want = O.dilate_process({"values": v, "no_data_value": None}, values)["values"]
         got = stencil.dilate(v, values).to_numpy()
         assert got.dtype == want.dtype and np.array_equal(got, want), (dtype, shape, values)
+
+
+@pytest.mark.gpu
+def test_temporal_views_end_to_end(gpu):
+    """TemporalAggregate / Cumulative inside larger views: element-wise programs in front (device tiles
+    handed over without a host round trip) and behind, a RasterTiler on top, on a temporal MemorySource."""
+    from datetime import datetime
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(5)
+    frames, h, w = 12, 40, 56
+    data = (rng.random((frames, h, w)) * 50).astype("f4")
+    data[rng.random(data.shape) < 0.1] = -9999.0
+    hour = 3600 * 1000
+    src = raster.MemorySource(data, -9999.0, "EPSG:28992", 1.0, (0.0, float(h)), time_first=0, time_delta=hour)
+    req = dict(mode="vals", bbox=(0.0, 0.0, float(w), float(h)), width=w, height=h, projection="EPSG:28992",
+               start=datetime(1970, 1, 1, 0), stop=datetime(1970, 1, 1, 11))
+    kw32 = {"dtype": "float32", "fillvalue": float(np.finfo("f4").max)}
+    # oracle, Block by Block: (src * 2 + 1) -> 4-hourly mean -> minus 3
+    x = O.math_process("multiply", kw32, {"values": data, "no_data_value": np.float32(-9999.0)}, 2)
+    x = O.math_process("add", kw32, x, 1)
+    runs = [(0, 4), (4, 4), (8, 4)]
+    agg = O.temporal_aggregate_values(x["values"], x["no_data_value"], runs, "mean", np.dtype("f4"))
+    want = O.math_process("subtract", kw32, {"values": agg, "no_data_value": kw32["fillvalue"]}, 3)
+    view = raster.TemporalAggregate(src * 2 + 1, "4h", "mean") - 3
+    got = view.get_data(**req)
+    assert_result_equal(got, want, 0, "aggregate view")
+    tiled = raster.RasterTiler(view, [16, 24]).get_data(**req)
+    assert_result_equal(tiled, want, 0, "tiled aggregate view")
+    # running sum per 6-hour period of the same source
+    cum = raster.Cumulative(src, "sum", "6h").get_data(**req)
+    want_cum = O.temporal_cumulative_values(data, np.float32(-9999.0), [(1, 6), (7, 5)], (1, 12), "sum", np.dtype("f4"))
+    first = O.temporal_cumulative_values(data, np.float32(-9999.0), [(0, 1)], (0, 1), "sum", np.dtype("f4"))
+    assert np.array_equal(np.asarray(cum["values"]), np.concatenate([first, want_cum]))
