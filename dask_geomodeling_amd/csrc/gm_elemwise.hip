@@ -47,7 +47,39 @@ int lower(const gm_program* prog, VmCode* code, unsigned* n_uops) {
   const bool float_class = prog->reg_class <= GM_CLASS_F64;
   gm_scalar zero;
   zero.u64 = 0;
+  // A comparison "tile CMP literal" whose only use is the boolean mask of one later Clip (the idiomatic
+  // masking pattern, Clip(x, Greater(D, 20))) is folded into that Clip: fold_into[q] = s, folded[s] = true.
+  int fold_into[GM_MAX_STEPS];
+  bool folded[GM_MAX_STEPS];
+  for (unsigned s = 0; s < prog->n_steps; ++s) { fold_into[s] = -1; folded[s] = false; }
+  for (unsigned s = 0; s + 1 < prog->n_steps; ++s) {
+    const gm_step& S = prog->steps[s];
+    const unsigned opcode = S.bits & 0xffu, save = (S.bits >> 8) & 0xffu;
+    auto kind = [](const gm_operand& o) { return o.bits & 0xffu; };
+    auto index = [](const gm_operand& o) { return (o.bits >> 8) & 0xffu; };
+    if (opcode < GM_OP_EQ || opcode > GM_OP_LE || !save) continue;
+    if (kind(S.a) != GM_OPD_INPUT || kind(S.b) != GM_OPD_SCALAR) continue;
+    const gm_step& N1 = prog->steps[s + 1];  // the comparison's value must not be consumed from the accumulator
+    if (kind(N1.a) == GM_OPD_ACC || kind(N1.b) == GM_OPD_ACC || kind(N1.a) == GM_OPD_NONE) continue;
+    int user = -1, uses = 0;
+    bool resaved = false;
+    for (unsigned q = s + 1; q < prog->n_steps; ++q) {
+      const gm_step& Q = prog->steps[q];
+      for (const gm_operand* o : {&Q.a, &Q.b})
+        if (kind(*o) == GM_OPD_TEMP && index(*o) == save - 1 && !resaved) { ++uses; user = (int)q; }
+      if (((Q.bits >> 8) & 0xffu) == save) resaved = true;  // the slot is reused from here on
+    }
+    if (uses != 1) continue;
+    const gm_step& Q = prog->steps[user];
+    const bool is_clip_mask = (Q.bits & 0xffu) == GM_OP_CLIP && kind(Q.b) == GM_OPD_TEMP && index(Q.b) == save - 1 &&
+                              ((Q.b.bits >> 17) & 1u);
+    if (!is_clip_mask || (kind(Q.a) == GM_OPD_TEMP && index(Q.a) == save - 1)) continue;
+    // the tile must still be addressable at the Clip: inputs always are
+    fold_into[user] = (int)s;
+    folded[s] = true;
+  }
   for (unsigned s = 0; s < prog->n_steps; ++s) {
+    if (folded[s]) continue;
     const gm_step& S = prog->steps[s];
     const unsigned opcode = S.bits & 0xffu, save = (S.bits >> 8) & 0xffu;
     const unsigned round_f32 = (S.bits >> 24) & 1u, wrap_i32 = (S.bits >> 25) & 1u, chk = (S.bits >> 26) & 1u;
@@ -144,6 +176,18 @@ int lower(const gm_program* prog, VmCode* code, unsigned* n_uops) {
         if (!push(kind, (unsigned)src_of(*y), arg, x->value, y_value, S.fill)) return -1;
         fast = true;
       }
+    } else if (opcode == GM_OP_CLIP && fold_into[s] >= 0 && kind_of(S.a) != GM_OPD_NONE &&
+               (kind_of(S.a) == GM_OPD_ACC || src_of(S.a) >= 0)) {
+      const gm_step& M = prog->steps[fold_into[s]];  // the comparison: tile CMP literal
+      if (kind_of(S.a) != GM_OPD_ACC && !push(UOP_LD, (unsigned)src_of(S.a), 0, zero, S.a.value, zero)) return -1;
+      const unsigned cmp = (M.bits & 0xffu) - GM_OP_EQ;
+      // a no-data cell of the tile takes the comparison's fill (False unless stated otherwise): dropped iff 0
+      const bool fill_is_false = prog->reg_class <= GM_CLASS_F64
+                                     ? (prog->reg_class == GM_CLASS_F32 ? M.fill.f32 == 0.0f : M.fill.f64 == 0.0)
+                                     : (prog->reg_class == GM_CLASS_I32 ? M.fill.i32 == 0 : M.fill.i64 == 0);
+      const unsigned arg = has_ndv(M.a) | ((fill_is_false ? 1u : 0u) << 1) | (cmp << 8);
+      if (!push(UOP_CLIPCMP, (unsigned)src_of(M.a), arg, M.a.value, M.b.value, S.fill)) return -1;
+      fast = true;
     } else if (opcode == GM_OP_CLIP && src_of(S.b) > 0 && kind_of(S.a) != GM_OPD_NONE) {
       bool ok = true;
       if (kind_of(S.a) != GM_OPD_ACC) {

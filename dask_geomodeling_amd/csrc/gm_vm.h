@@ -57,7 +57,13 @@ enum { UOP_GENERIC = 0, UOP_LD = 1, UOP_ST = 2, UOP_ADD = 3, UOP_SUB = 4, UOP_RS
        //   LOOKUP   arg: bit0 select, bits 8-11 exception keys, 16-17 table; acc_ndv.u64 = window
        //            slots, b_val.i64 = kmin, fill = value of a miss under select
        //   MASKI    (integer tiles) arg: bit0 acc has ndv; acc_ndv = ndv, b_val = value, fill = fill
-       UOP_DIGITIZE = 16, UOP_LOOKUP = 17, UOP_MASKI = 18 };
+       UOP_DIGITIZE = 16, UOP_LOOKUP = 17, UOP_MASKI = 18,
+       // Clip(acc, y CMP literal) in one micro-op -- the comparison whose only use is the mask of a
+       // Clip never materialises (saves LD y, CMP, ST temp and the operand fetch of the CLIP):
+       //   arg: bit0 y has ndv, bit1 a no-data y drops the cell (the comparison's fill is False),
+       //        bits 8-10 comparison (0..5 = EQ NE GT GE LT LE); acc_ndv = ndv of y, b_val = literal,
+       //        fill = the store's no-data value
+       UOP_CLIPCMP = 19 };
 // operand source of a micro-op: 0 = literal, 1 + k = input k, 1 + 8 + k = temp k
 constexpr unsigned UOP_SRC_SCALAR = 0, UOP_SRC_INPUT = 1, UOP_SRC_TEMP = 9;
 constexpr int GM_MAX_UOPS = 40;
@@ -859,7 +865,28 @@ struct Machine {
     const unsigned kind = U.route & 0xffu, src = (U.route >> 8) & 0xffu;
     if (kind >= UOP_DIGITIZE) {
       const unsigned arg = U.arg;
-      if (kind == UOP_MASKI) {
+      if (kind == UOP_CLIPCMP) {
+        RC y[N];
+        select(src, y);
+        const bool y_has = (arg & 1u) != 0, ndv_drops = (arg & 2u) != 0;
+        const RC y_ndv = scalar_of<RC>(U.acc_ndv), lit = scalar_of<RC>(U.b_val), fill = scalar_of<RC>(U.fill);
+        auto clip_if = [&](auto keep) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const bool nodata = y_has & (y[k] == y_ndv);
+            const bool drop = nodata ? ndv_drops : !keep(y[k], lit);
+            acc[k] = drop ? fill : acc[k];
+          }
+        };
+        switch ((arg >> 8) & 7u) {
+          case 0: clip_if([](RC a, RC b) { return a == b; }); break;
+          case 1: clip_if([](RC a, RC b) { return a != b; }); break;
+          case 2: clip_if([](RC a, RC b) { return a > b; }); break;
+          case 3: clip_if([](RC a, RC b) { return a >= b; }); break;
+          case 4: clip_if([](RC a, RC b) { return a < b; }); break;
+          default: clip_if([](RC a, RC b) { return a <= b; }); break;
+        }
+      } else if (kind == UOP_MASKI) {
         const bool a_has = (arg & 1u) != 0;
         const RC a_ndv = scalar_of<RC>(U.acc_ndv), value = scalar_of<RC>(U.b_val), fill = scalar_of<RC>(U.fill);
 #pragma unroll

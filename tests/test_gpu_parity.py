@@ -854,3 +854,43 @@ def test_divide_by_power_of_two_literal(gpu, dt):
         assert_result_equal(got, want, 0, "x / %r" % c)
         got2 = (raster.Divide(leaf, c) + 1.5).get_data(**req)
         assert_result_equal(got2, want2, 0, "x / %r + 1.5" % c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,ndv", [("f4", np.float32(np.finfo("f4").max)), ("f8", -9999.0), ("i4", -1), ("u1", np.uint8(255))])
+def test_clip_by_folded_comparison(gpu, dt, ndv):
+    """Clip(x, D CMP literal): the comparison is folded into the Clip micro-op (UOP_CLIPCMP) -- all six
+    comparisons, mask tiles with no data / NaN / inf / cells equal to the literal, against the oracle's
+    two separate process() bodies."""
+    from blocks_util import ArrayLeaf
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(11)
+    shape = (1, 33, 47)
+    if np.dtype(dt).kind == "f":
+        d = (rng.random(shape) * 40).astype(dt)
+        d[0, 0, :6] = [np.nan, np.inf, -np.inf, 20.0, 20.000001, 19.999999]
+    else:
+        d = rng.integers(0, 40, size=shape).astype(dt)
+        d[0, 0, :3] = [20, 21, 19]
+    d[rng.random(shape) < 0.15] = ndv
+    a = (rng.random(shape) * 100).astype("f4")
+    a[rng.random(shape) < 0.1] = -9999.0
+    ArrayLeaf.ARRAYS["cc/d/" + dt] = {"values": d, "no_data_value": ndv}
+    ArrayLeaf.ARRAYS["cc/a"] = {"values": a, "no_data_value": np.float32(-9999.0)}
+    D, A = ArrayLeaf("cc/d/" + dt, np.dtype(dt).str, ndv), ArrayLeaf("cc/a", "<f4", np.float32(-9999.0))
+    req = dict(mode="vals", bbox=(0.0, 0.0, 47.0, 33.0), width=47, height=33, projection="EPSG:28992")
+    kw = {"dtype": "float32", "fillvalue": float(np.finfo("f4").max)}
+    kwd = {"dtype": np.result_type(np.float32, dt).name, "fillvalue": float(np.finfo(np.result_type(np.float32, dt)).max)}
+    for name, op in (("Equal", "equal"), ("NotEqual", "not_equal"), ("Greater", "greater"), ("GreaterEqual", "greater_equal"),
+                     ("Less", "less"), ("LessEqual", "less_equal")):
+        mask = O.math_process(op, {"dtype": "bool", "fillvalue": None}, {"values": d, "no_data_value": ndv}, 20)
+        with np.errstate(all="ignore"):
+            store = O.math_process("add", kw, {"values": a, "no_data_value": np.float32(-9999.0)}, 1.5)
+            want = O.clip_process(store, mask)
+            want_after = O.math_process("multiply", kw, want, 2)
+        view = raster.Clip(A + 1.5, getattr(raster, name)(D, 20))
+        assert_result_equal(view.get_data(**req), want, 0, name)
+        assert_result_equal((view * 2).get_data(**req), want_after, 0, name + " * 2")
+        # the same mask used twice is not folded (two users of the temp): still right
+        both = raster.Clip(raster.Clip(A + 1.5, getattr(raster, name)(D, 20)) * 2, getattr(raster, name)(D, 20))
+        assert_result_equal(both.get_data(**req), O.clip_process(want_after, mask), 0, name + " twice")
