@@ -487,6 +487,14 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
     if (strided) {
       args.flags |= VM_FLAG_STRIDED;
       args.cols = (unsigned)cols;
+      {
+        const unsigned long long d = cols / 4 ? cols / 4 : 1;
+        unsigned l = 0;
+        while ((1ull << l) < d) ++l;  // ceil(log2 d)
+        args.div_magic = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1ull);
+        args.div_sh1 = l < 1 ? l : 1;
+        args.div_sh2 = l > 1 ? l - 1 : 0;
+      }
       if (cols % 4 != 0 || n / 4 > 0xffffffffull) aligned = false;  // groups must not straddle rows
     }
     args.n_groups = aligned ? n / 4 : 0;
