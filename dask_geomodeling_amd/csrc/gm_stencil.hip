@@ -292,23 +292,28 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
 struct HillArgs {
   double xres, yres;       // division of integer / float64 tiles happens in float64
   float xres32, yres32;    // float32 tiles divide by the float32-rounded resolution (NumPy weak scalar)
+  // a resolution that is a power of two (1 m, 0.5 m, ...) divides exactly as a multiplication by its
+  // reciprocal: 0 = divide, else multiply by the exact 1 / res
+  double xinv, yinv;
+  float xinv32, yinv32;
   float sin_alt, cos_alt_zsf, square_zsf, cos_az, sin_az;
 };
 
 // T arithmetic exactly as NumPy carries it out on a T array: integers wrap modulo 2^bits,
 // float32 / float64 round after every operation (-ffp-contract=off)
 template <typename T>
-__device__ __forceinline__ float gradient(T a, T b2, T c, T d, T e2, T f, double res, float res32) {
+__device__ __forceinline__ float gradient(T a, T b2, T c, T d, T e2, T f, double res, float res32, double inv, float inv32) {
   if constexpr (std::is_integral<T>::value) {
     typedef unsigned long long U;  // modular arithmetic: the truncation to T equals NumPy's wrap-around
     const U wide = (U)(long long)a + 2ull * (U)(long long)b2 + (U)(long long)c - (U)(long long)d - 2ull * (U)(long long)e2 - (U)(long long)f;
-    return (float)((double)(T)wide / res);
+    const double s = (double)(T)wide;
+    return (float)(inv != 0.0 ? s * inv : s / res);
   } else if constexpr (std::is_same<T, float>::value) {
     const float s = ((((a + 2.0f * b2) + c) - d) - 2.0f * e2) - f;
-    return s / res32;
+    return inv32 != 0.0f ? s * inv32 : s / res32;
   } else {
     const double s = ((((a + 2.0 * b2) + c) - d) - 2.0 * e2) - f;
-    return (float)(s / res);
+    return (float)(inv != 0.0 ? s * inv : s / res);
   }
 }
 
@@ -347,10 +352,12 @@ __global__ __launch_bounds__(256) void hillshade_kernel(const T* __restrict__ in
         const T* mid = rows[i + 1];
         const T* bot = rows[i + 2];
         // spatial.py:384-404 (s0..s8 = rows top/middle/bottom x columns left/middle/right)
-        const float y = gradient<T>(top[0], top[1], top[2], bot[0], bot[1], bot[2], A.yres, A.yres32);
-        const float x = gradient<T>(top[0], mid[0], bot[0], top[2], mid[2], bot[2], A.xres, A.xres32);
+        const float y = gradient<T>(top[0], top[1], top[2], bot[0], bot[1], bot[2], A.yres, A.yres32, A.yinv, A.yinv32);
+        const float x = gradient<T>(top[0], mid[0], bot[0], top[2], mid[2], bot[2], A.xres, A.xres32, A.xinv, A.xinv32);
         const float xx_plus_yy = x * x + y * y;
-        const float cang = (A.sin_alt - A.cos_alt_zsf * (y * A.cos_az - x * A.sin_az)) / sqrtf(1.0f + A.square_zsf * xx_plus_yy);
+        // 1 / sqrt in one (1 ulp) instruction instead of a correctly rounded sqrt and division: the result
+        // is truncated to uint8, a float32 ulp of `cang` matters only on a truncation boundary
+        const float cang = (A.sin_alt - A.cos_alt_zsf * (y * A.cos_az - x * A.sin_az)) * __builtin_amdgcn_rsqf(1.0f + A.square_zsf * xx_plus_yy);
         out[((size_t)b * oh + rb + i) * ow + c] = (cang <= 0.0f) ? (unsigned char)0 : (unsigned char)(int)(255.0f * cang);
       }
     }
@@ -550,6 +557,17 @@ int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv
   A.yres = yres;
   A.xres32 = (float)xres;
   A.yres32 = (float)yres;
+  auto exact_inverse = [](double r) -> double {  // 1 / r when r is a power of two (normal, as its inverse), else 0
+    int e;
+    const double inv = 1.0 / r;
+    return (std::isnormal(r) && std::isnormal(inv) && frexp(fabs(r), &e) == 0.5) ? inv : 0.0;
+  };
+  A.xinv = exact_inverse(xres);
+  A.yinv = exact_inverse(yres);
+  A.xinv32 = (float)exact_inverse((double)A.xres32);  // (a power of two in float32 is one in float64 and vice versa
+  A.yinv32 = (float)exact_inverse((double)A.yres32);  //  within float32's exponent range; outside, the cast gives 0 / inf)
+  if (!std::isnormal(A.xinv32)) A.xinv32 = 0.0f;
+  if (!std::isnormal(A.yinv32)) A.yinv32 = 0.0f;
   A.sin_alt = (float)sin(alt);              // python floats meet float32 arrays as weak scalars:
   A.cos_alt_zsf = (float)(cos(alt) * zsf);  // the product of python floats is rounded to float32 once
   A.square_zsf = (float)(zsf * zsf);
