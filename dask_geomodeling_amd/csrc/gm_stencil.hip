@@ -384,23 +384,103 @@ struct GaussArgs {
 
 // grid: x over 256 output columns, y over output rows, z over bands; the output is the window
 // [y0, y0+oh) x [x0, x0+ow) of the filtered tile (the last axis of an "exact" Smooth crops its margins)
+// A lane owns GAUSS_ROWS consecutive output rows of one column: the weight of a tap pair is fetched once
+// (a scalar load) for all of them and 2 x GAUSS_ROWS tap loads are in flight per pair -- one output
+// per lane made a wave live through `radius` dependent scalar-load round trips for 64 pixels of work.
+constexpr int GAUSS_ROWS = 8;
 template <typename T, bool ALONG_X>
 __global__ __launch_bounds__(256) void gauss_axis_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
                                                          int y0, int x0, int oh, int ow, int replace_ndv, T ndv, T fill,
                                                          GaussArgs A) {
-  const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y, b = blockIdx.z;
+  const int ox = blockIdx.x * 256 + threadIdx.x, oy0 = blockIdx.y * GAUSS_ROWS, b = blockIdx.z;
   if (ox >= ow) return;
-  const int y = y0 + oy, x = x0 + ox;
+  const int x = x0 + ox;
   const T* plane = in + (size_t)b * h * w;
-  const int n = ALONG_X ? w : h, at = ALONG_X ? x : y;
-  auto sample = [&](int i) -> double {  // element i of the line through (y, x)
-    if (i < 0 || i >= n) return A.cval;
-    const T v = ALONG_X ? plane[(size_t)y * w + i] : plane[(size_t)i * w + x];
-    return (double)((replace_ndv && v == ndv) ? fill : v);
+  const int n = ALONG_X ? w : h;
+  // element i of the line through output row r of this lane (unconditional load from the clamped
+  // index, the constant selected afterwards: no branch around the load)
+  auto sample = [&](int r, int i) -> double {
+    const int y = min(y0 + oy0 + r, h - 1);  // (rows past the window are computed and not stored)
+    const int ic = min(max(i, 0), n - 1);
+    const T v = ALONG_X ? plane[(size_t)y * w + ic] : plane[(size_t)ic * w + x];
+    const double inside = (double)((replace_ndv && v == ndv) ? fill : v);
+    return (i < 0 || i >= n) ? A.cval : inside;
   };
-  double acc = sample(at) * A.w[0];
-  for (int j = A.radius; j >= 1; --j) acc += (sample(at - j) + sample(at + j)) * A.w[j];
-  out[((size_t)b * oh + oy) * ow + ox] = (T)acc;
+  auto centre = [&](int r) { return ALONG_X ? x : y0 + oy0 + r; };
+  double acc[GAUSS_ROWS];
+#pragma unroll
+  for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] = sample(r, centre(r)) * A.w[0];
+  for (int j = A.radius; j >= 1; --j) {  // farthest pair first, as SciPy adds them
+    const double wj = A.w[j];
+    double lo[GAUSS_ROWS], hi[GAUSS_ROWS];
+#pragma unroll
+    for (int r = 0; r < GAUSS_ROWS; ++r) {
+      lo[r] = sample(r, centre(r) - j);
+      hi[r] = sample(r, centre(r) + j);
+    }
+#pragma unroll
+    for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] += (lo[r] + hi[r]) * wj;
+  }
+#pragma unroll
+  for (int r = 0; r < GAUSS_ROWS; ++r)
+    if (oy0 + r < oh) out[((size_t)b * oh + oy0 + r) * ow + ox] = (T)acc[r];
+}
+
+// The same pass with the taps served from LDS: a workgroup stages the window its 8 x 256 outputs read --
+// (8 + 2 r) x 256 cells along y, 8 x (256 + 2 r) along x -- once, already as the float64 values SciPy's
+// line buffer holds (no data -> fill, cells outside the line -> cval), all loads of a lane in flight
+// before the first LDS write; every output then reads its 2 r + 1 taps from LDS instead of issuing as
+// many 4-byte global loads.  Used while the window fits 64 KiB (r <= 12 along y).
+template <typename T, bool ALONG_X>
+__global__ __launch_bounds__(256) void gauss_axis_lds_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
+                                                             int y0, int x0, int oh, int ow, int replace_ndv, T ndv,
+                                                             T fill, GaussArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* const tile = reinterpret_cast<double*>(smem);
+  const int radius = A.radius;
+  const int ox0 = blockIdx.x * 256, oy0 = blockIdx.y * GAUSS_ROWS, b = blockIdx.z;
+  const T* plane = in + (size_t)b * h * w;
+  const int n = ALONG_X ? w : h;
+  const int win_w = ALONG_X ? 256 + 2 * radius : 256, win_h = ALONG_X ? GAUSS_ROWS : GAUSS_ROWS + 2 * radius;
+  auto cell = [&](int wy, int wx) -> double {  // window cell -> the float64 value of SciPy's extended line
+    const int sy = y0 + oy0 + wy - (ALONG_X ? 0 : radius), sx = x0 + ox0 + wx - (ALONG_X ? radius : 0);
+    const int along = ALONG_X ? sx : sy;
+    const int cy = min(max(sy, 0), h - 1), cx = min(max(sx, 0), w - 1);
+    const T v = plane[(size_t)cy * w + cx];
+    const double inside = (double)((replace_ndv && v == ndv) ? fill : v);
+    return (along < 0 || along >= n) ? A.cval : inside;
+  };
+  constexpr int SB = 8;  // window rows fetched together per lane
+  for (int wx = threadIdx.x; wx < win_w; wx += 256) {
+    for (int wy0 = 0; wy0 < win_h; wy0 += SB) {
+      double v[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) v[u] = cell(min(wy0 + u, win_h - 1), wx);
+#pragma unroll
+      for (int u = 0; u < SB; ++u)
+        if (wy0 + u < win_h) tile[(wy0 + u) * win_w + wx] = v[u];
+    }
+  }
+  __syncthreads();
+  const int ox = ox0 + threadIdx.x;
+  if (ox >= ow) return;
+  // this lane's taps: along x the cells (r, threadIdx.x + radius +- j), along y the cells (r + radius +- j, threadIdx.x)
+  const int step = ALONG_X ? 1 : win_w;
+  double acc[GAUSS_ROWS];
+  const double* centre[GAUSS_ROWS];
+#pragma unroll
+  for (int r = 0; r < GAUSS_ROWS; ++r) {
+    centre[r] = tile + (ALONG_X ? r * win_w + threadIdx.x + radius : (r + radius) * win_w + threadIdx.x);
+    acc[r] = centre[r][0] * A.w[0];
+  }
+  for (int j = radius; j >= 1; --j) {  // farthest pair first, as SciPy adds them
+    const double wj = A.w[j];
+#pragma unroll
+    for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] += (centre[r][-j * step] + centre[r][j * step]) * wj;
+  }
+#pragma unroll
+  for (int r = 0; r < GAUSS_ROWS; ++r)
+    if (oy0 + r < oh) out[((size_t)b * oh + oy0 + r) * ow + ox] = (T)acc[r];
 }
 
 template <typename T>
@@ -517,7 +597,7 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
   if (radius < 0 || radius > GAUSS_MAX_RADIUS) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: radius %d (max %d)", radius, GAUSS_MAX_RADIUS);
   if (bands <= 0 || oh <= 0 || ow <= 0) return GM_OK;
   if (y0 < 0 || x0 < 0 || y0 + oh > h || x0 + ow > w) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: output window outside the tile");
-  if (bands > 65535 || oh > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: tile too tall / too many bands");
+  if (bands > 65535 || oh > 65535 * GAUSS_ROWS) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: tile too tall / too many bands");
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
   GaussArgs A;
@@ -525,10 +605,18 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
   for (int j = 0; j <= radius; ++j) A.w[j] = weights_host[j];
   A.radius = radius;
   A.cval = cval;
-  dim3 grid((unsigned)((ow + 255) / 256), (unsigned)oh, (unsigned)bands);
+  dim3 grid((unsigned)((ow + 255) / 256), (unsigned)((oh + GAUSS_ROWS - 1) / GAUSS_ROWS), (unsigned)bands);
+  const size_t lds_x = (size_t)GAUSS_ROWS * (256 + 2 * radius) * 8, lds_y = (size_t)(GAUSS_ROWS + 2 * radius) * 256 * 8;
+  const bool staged = (axis == 2 ? lds_x : lds_y) <= 64 * 1024;
 #define GM_GAUSS(T)                                                                                            \
   do {                                                                                                         \
-    if (axis == 2)                                                                                             \
+    if (staged && axis == 2)                                                                                   \
+      hipLaunchKernelGGL((gauss_axis_lds_kernel<T, true>), grid, dim3(256), lds_x, s, (const T*)in, (T*)out, h, w, y0, \
+                         x0, oh, ow, replace_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);         \
+    else if (staged)                                                                                           \
+      hipLaunchKernelGGL((gauss_axis_lds_kernel<T, false>), grid, dim3(256), lds_y, s, (const T*)in, (T*)out, h, w, y0, \
+                         x0, oh, ow, replace_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);         \
+    else if (axis == 2)                                                                                        \
       hipLaunchKernelGGL((gauss_axis_kernel<T, true>), grid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, y0, \
                          x0, oh, ow, replace_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);         \
     else                                                                                                       \

@@ -894,3 +894,28 @@ def test_clip_by_folded_comparison(gpu, dt, ndv):
         # the same mask used twice is not folded (two users of the temp): still right
         both = raster.Clip(raster.Clip(A + 1.5, getattr(raster, name)(D, 20)) * 2, getattr(raster, name)(D, 20))
         assert_result_equal(both.get_data(**req), O.clip_process(want_after, mask), 0, name + " twice")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f4", "f8"])
+@pytest.mark.parametrize("sigma", [(0.5, 0.5), (2.0, 1.0), (3.0, 3.0), (5.5, 0.0), (1.0, 7.0)])
+def test_gauss_axis_kernels_against_oracle(gpu, dt, sigma):
+    """Both Gaussian kernels -- taps from LDS (radius <= 12 along y) and taps from memory (larger radii) --
+    on ragged tiles larger than a workgroup window, several bands, no data and a non-zero fill, against
+    the oracle's restatement of SciPy's correlate1d (bit-exact)."""
+    from dask_geomodeling_amd.raster import stencil
+    rng = np.random.default_rng(int(sigma[0] * 10 + sigma[1] * 100))
+    ndv = np.dtype(dt).type(-9999.0)
+    v = (rng.random((2, 75, 531)) * 50).astype(dt)
+    v[rng.random(v.shape) < 0.05] = ndv
+    for fill, crop in ((0, (0, 0)), (2.5, (3, 5)), (0.1, (0, 2))):
+        got = stencil.gaussian_smooth(v, ndv, fill, sigma, crop).to_numpy()
+        # (Smooth.process ties the crop to the sigma; here they vary independently, so the oracle's steps
+        #  are spelled out: no data -> fill, one correlate1d per axis, crop)
+        work = v.copy()
+        work[work == ndv] = fill
+        for axis, s in ((1, sigma[0]), (2, sigma[1])):
+            if s > 1e-15:
+                work = O.gaussian_axis(work, s, axis, fill)
+        want = work[:, crop[0]:work.shape[1] - crop[0], crop[1]:work.shape[2] - crop[1]]
+        assert got.dtype == want.dtype and np.array_equal(got, want), (dt, sigma, fill, crop)

@@ -88,6 +88,9 @@ def main():
         u8 = [generate_window((side, side), "u1", 95 + i, 0.0, 6.0, 255, (50, 50), 0, 0, side, side) for i in range(T)]
         timeit("dilate u8, 2 values (2 B/px)", 2.0 * m, [lambda t=t: stencil.dilate(t, [1, 3]) for t in u8])
         timeit("dilate f32, 2 values (8 B/px)", 8.0 * m, [lambda t=t: stencil.dilate(t, [1.0, 3.0]) for t in src])
+        for size_px in (3.0, 6.0):
+            timeit("smooth f32, sigma %.0f px, radius %d (2 passes, 16 B/px)" % (size_px / 3, int(4 * size_px / 3 + 0.5)), 16.0 * n,
+                   [lambda t=t: stencil.gaussian_smooth(t, np.float32(F32MAX), 0, (size_px / 3, size_px / 3)) for t in src[:2]])
         del src, u8
     if "temporal" in which:
         from dask_geomodeling_amd.hip.array import DeviceArray
