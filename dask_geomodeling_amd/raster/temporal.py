@@ -207,6 +207,29 @@ def _frame_bins(runs, outs=None):
     return bins
 
 
+_declared = False
+
+
+def _lib():
+    """The loaded library with the temporal entry points declared (once)."""
+    global _declared
+    from ..hip import runtime
+    L = runtime.lib()
+    if not _declared:
+        c = ctypes
+        common = [c.c_void_p, c.c_int, c.c_int, c.c_uint64, c.c_int64, c.c_int64, c.c_void_p, c.c_int]
+        L.gm_temporal_out_dtype.argtypes = [c.c_int, c.c_int]
+        L.gm_temporal_out_dtype.restype = c.c_int
+        L.gm_temporal_aggregate.argtypes = common + [c.c_int, c.c_int, c.c_void_p, c.c_uint64]
+        L.gm_temporal_aggregate.restype = c.c_int
+        L.gm_temporal_percentile.argtypes = common + [c.c_int, c.c_void_p, c.c_int, c.c_void_p, c.c_uint64]
+        L.gm_temporal_percentile.restype = c.c_int
+        L.gm_temporal_cumulative.argtypes = common + [c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_uint64]
+        L.gm_temporal_cumulative.restype = c.c_int
+        _declared = True
+    return L
+
+
 def _reduce_args(values, no_data_value):
     from ..hip import runtime
     from ..hip.array import as_device
@@ -265,22 +288,16 @@ def aggregate_frames(values, no_data_value, runs, statistic, dtype):
         # a cell's data frames are sorted in LDS: 64 float32 / 32 float64 values per lane
         if longest > MAX_MEDIAN_FRAMES // (np.result_type(np.float32, dtype).itemsize // 4):
             raise NotImplementedError("%s over %d frames per label" % (statistic, longest))
-    L = runtime.lib()
+    L = _lib()
     if L.gm_temporal_out_dtype(code, STATISTIC_CODES["median" if percentile is not None else name]) != _code(dtype):
         raise NotImplementedError("%s of a %s raster as %s" % (statistic, src.dtype, np.dtype(dtype)))
     out = DeviceArray.empty((len(runs), height, width), np.dtype(dtype))
     if percentile is not None:
         plan = percentile_plan(percentile, longest, dtype)
-        L.gm_temporal_percentile.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
-                                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64]
         runtime.check(L.gm_temporal_percentile(src.ptr, code, has, bits, frames, height * width, _frame_bins(runs), len(runs),
                                                len(runs), plan, longest, out.ptr, _fill_bits(statistic, dtype)),
                       "gm_temporal_percentile")
         return out
-    L.gm_temporal_aggregate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
-                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                        ctypes.c_void_p, ctypes.c_uint64]
     runtime.check(L.gm_temporal_aggregate(src.ptr, code, has, bits, frames, height * width, _frame_bins(runs), len(runs),
                                           len(runs), STATISTIC_CODES[statistic], out.ptr, _fill_bits(statistic, dtype)),
                   "gm_temporal_aggregate")
@@ -295,13 +312,10 @@ def accumulate_frames(values, no_data_value, runs, emit, statistic, dtype):
     if statistic not in ("sum", "count"):
         raise NotImplementedError("Cumulative statistic %r" % statistic)
     src, code, has, bits, frames, height, width = _reduce_args(values, no_data_value)
-    L = runtime.lib()
+    L = _lib()
     if L.gm_temporal_out_dtype(code, STATISTIC_CODES[statistic]) != _code(dtype):
         raise NotImplementedError("cumulative %s of a %s raster as %s" % (statistic, src.dtype, np.dtype(dtype)))
     out = DeviceArray.empty((emit[1] - emit[0], height, width), np.dtype(dtype))
-    L.gm_temporal_cumulative.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64,
-                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64]
     runtime.check(L.gm_temporal_cumulative(src.ptr, code, has, bits, frames, height * width, _frame_bins(runs), len(runs),
                                            int(emit[0]), int(emit[1]), STATISTIC_CODES[statistic], out.ptr,
                                            _fill_bits(statistic, dtype)), "gm_temporal_cumulative")
