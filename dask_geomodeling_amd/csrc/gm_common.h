@@ -26,6 +26,13 @@ int current_cu_count();
     if (e_ != hipSuccess) return gm::hip_fail(e_, #call); \
   } while (0)
 
+// out[i] = table[in[i]] over 1-byte tiles (gm_tables.hip): n_tiles <= 16 tiles of rows x cols elements,
+// pitches in elements (0 = contiguous); table: 256 entries of out_size bytes on the device.
+// Requirements (checked by the caller): 16-byte aligned tile pointers; strided tiles have cols and
+// pitches divisible by 16.
+int lut8_launch(int n_tiles, const void* const* in, const uint32_t* in_pitch, void* const* out, const uint32_t* out_pitch,
+                size_t rows, size_t cols, const void* table, int out_size, hipStream_t stream);
+
 inline int dtype_size(int dt) {
   switch (dt) {
     case GM_BOOL: case GM_U8: case GM_I8: return 1;

@@ -223,6 +223,11 @@ struct CodeEntry {
   unsigned lds_table = 0, lds_words = 0;  // 1 + index / window words of the LOOKUP table staged in LDS
   int size = 0;        // kernel size class S/M/L
   bool native = false;
+  // programs of ONE 1-byte input tile: the 256-entry table of the program's results (device), built on
+  // first use by running the program itself on the tile 0..255
+  mutable void* lut = nullptr;
+  mutable std::once_flag lut_once;
+  mutable int lut_rc = GM_OK;
 };
 
 std::mutex g_code_mu;
@@ -279,6 +284,29 @@ int validate(const gm_program* prog) {
 }
 
 // validate + lower + upload once per (device, program); later launches only fill the kernarg
+constexpr size_t LUT8_MIN_ELEMS = 512;  // (the table itself is built with a 256-element run of the VM, which stays below this)
+
+// the tile 0, 1, ..., 255 on the current device (uploaded once per device)
+int byte_ramp(hipStream_t stream, void** out) {
+  static std::mutex mu;
+  static std::unordered_map<int, void*> ramps;
+  static unsigned char host[256];
+  int device = 0;
+  GM_HIP(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = ramps.find(device);
+  if (it == ramps.end()) {
+    for (int i = 0; i < 256; ++i) host[i] = (unsigned char)i;
+    void* dev = nullptr;
+    const int rc = gm_malloc(&dev, 256);
+    if (rc) return rc;
+    GM_HIP(hipMemcpyAsync(dev, host, 256, hipMemcpyHostToDevice, stream));
+    it = ramps.emplace(device, dev).first;
+  }
+  *out = it->second;
+  return GM_OK;
+}
+
 int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) {
   int device = 0;
   GM_HIP(hipGetDevice(&device));
@@ -430,6 +458,48 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
       if (!inputs[(size_t)t * n_in + k]) return gm::fail(GM_ERR_INVALID, "input %u of tile %d is null", k, t);
   }
   if (n == 0 || n_tiles == 0) return GM_OK;
+
+  // A program whose only input is a 1-byte tile (class rasters: Reclassify / Mask / Classify / arithmetic
+  // on uint8) is a function of 256 values: tabulate it once with the VM itself, then apply the table
+  // with the byte-LUT kernel (gm_tables.hip; 16 pixels per lane, table in LDS).  Bit-exact by
+  // construction.  Small launches and tiles the LUT kernel's 16-byte accesses cannot address keep the VM.
+  if (n_in == 1 && n >= LUT8_MIN_ELEMS && gm::dtype_size(code->prog.inputs[0].bits & 0xffu) == 1 &&
+      !((code->prog.inputs[0].bits >> 8) & 1u) && n_tiles <= GM_MAX_BATCH * 64) {
+    bool addressable = true;
+    for (int t = 0; t < n_tiles && addressable; ++t) {
+      const uint32_t ip = pitches ? pitches[t] : 0u, op = out_pitches ? out_pitches[t] : 0u;
+      const bool strided = (ip && ip != cols) || (op && op != cols);
+      if (((uintptr_t)inputs[t] % 16) || ((uintptr_t)outs[t] % 16)) addressable = false;
+      if (strided && ((cols % 16) || (ip % 16) || (op % 16))) addressable = false;
+    }
+    if (addressable) {
+      const int out_size = gm::dtype_size(code->prog.out_dtype);
+      std::call_once(code->lut_once, [&]() {
+        void* ramp = nullptr;
+        code->lut_rc = byte_ramp(stream, &ramp);
+        if (code->lut_rc) return;
+        void* table = nullptr;
+        code->lut_rc = gm_malloc(&table, 256 * (size_t)out_size);
+        if (code->lut_rc) return;
+        const void* in0 = ramp;
+        // (256 elements: below LUT8_MIN_ELEMS, i.e. this runs on the VM)
+        code->lut_rc = gm_elemwise_run_batch_2d(prog, 1, &in0, nullptr, &table, nullptr, 1, 256);
+        if (!code->lut_rc) code->lut = table;
+      });
+      if (code->lut_rc) return code->lut_rc;
+      for (int t0 = 0; t0 < n_tiles; t0 += 16) {
+        const int nb = n_tiles - t0 < 16 ? n_tiles - t0 : 16;
+        uint32_t ip[16], op[16];
+        for (int t = 0; t < nb; ++t) {
+          ip[t] = pitches && pitches[t0 + t] != cols ? pitches[t0 + t] : 0u;
+          op[t] = out_pitches && out_pitches[t0 + t] != cols ? out_pitches[t0 + t] : 0u;
+        }
+        rc = gm::lut8_launch(nb, inputs + t0, ip, outs + t0, op, rows, cols, code->lut, out_size, stream);
+        if (rc) return rc;
+      }
+      return GM_OK;
+    }
+  }
 
   // elements per lane: 4 (G = 1) streams best when a lane moves >= 8 bytes per element; programs of
   // more than 3 micro-ops amortise their decode over 8 elements, and so do narrow streams (e.g.

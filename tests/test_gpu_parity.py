@@ -919,3 +919,58 @@ def test_gauss_axis_kernels_against_oracle(gpu, dt, sigma):
                 work = O.gaussian_axis(work, s, axis, fill)
         want = work[:, crop[0]:work.shape[1] - crop[0], crop[1]:work.shape[2] - crop[1]]
         assert got.dtype == want.dtype and np.array_equal(got, want), (dt, sigma, fill, crop)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,ndv", [("u1", np.uint8(255)), ("u1", np.uint8(0)), ("i1", np.int8(-1)), ("?", None)])
+def test_single_byte_input_programs_by_table(gpu, dt, ndv):
+    """Programs whose only input is a 1-byte tile run as a 256-entry table (built by the VM itself) + the
+    byte-LUT kernel from 4096 elements on: every output width, ragged sizes (scalar tail), batches, and
+    zero-copy windows of a resident raster (strided tiles; widths the LUT kernel cannot address fall
+    back to the VM) -- against the oracle, Block by Block."""
+    from blocks_util import ArrayLeaf
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(17)
+    shape = (1, 70, 97)  # 6790 elements: not a multiple of 16
+    if dt == "?":
+        v = rng.random(shape) < 0.4
+    else:
+        v = rng.integers(-5 if dt == "i1" else 0, 12, size=shape).astype(dt)
+        v[rng.random(shape) < 0.1] = ndv
+    key = "lut/%s/%s" % (dt, ndv)
+    ArrayLeaf.ARRAYS[key] = {"values": v, "no_data_value": ndv}
+    leaf = ArrayLeaf(key, np.dtype(dt).str, ndv)
+    req = dict(mode="vals", bbox=(0.0, 0.0, 97.0, 70.0), width=97, height=70, projection="EPSG:28992")
+    data = {"values": v, "no_data_value": ndv}
+    arith = leaf * 2.5 + 1
+    flt = {"dtype": arith.dtype.name, "fillvalue": arith.fillvalue}  # (the Block's own dtype rule: float64 for u8 * python float)
+    with np.errstate(all="ignore"):
+        cases = [("mask -> u8", raster.Mask(leaf, 7), O.mask_process(data, 7)),
+                 ("x * 2.5 + 1 -> float", arith, O.math_process("add", flt, O.math_process("multiply", flt, data, 2.5), 1)),
+                 ("x > 3 -> bool", leaf > 3, O.math_process("greater", {"dtype": "bool", "fillvalue": None}, data, 3)),
+                 ("classify -> u8", raster.Classify(leaf, [1.5, 3.0, 8.0]), O.classify_process(data, [1.5, 3.0, 8.0], False))]
+        if dt != "?":
+            table = [[1, 10], [2, 20], [3, 7], [11, 5]]
+            cases.append(("reclassify -> i64", raster.Reclassify(leaf, table),
+                          O.reclassify_process(data, {"dtype": "<i8", "fillvalue": int(np.iinfo("i8").max), "data": table, "select": False})))
+            tf = [[1, 0.5], [4, 2.25]]
+            cases.append(("reclassify -> f64, select", raster.Reclassify(leaf, tf, True),
+                          O.reclassify_process(data, {"dtype": "<f8", "fillvalue": float(np.finfo("f8").max), "data": tf, "select": True})))
+            plus = leaf + 100
+            cases.append(("x + 100 -> int", plus, O.math_process("add", {"dtype": plus.dtype.name, "fillvalue": plus.fillvalue}, data, 100)))
+    for name, view, want in cases:
+        assert_result_equal(view.get_data(**req), want, 0, name)
+    if dt == "u1":
+        # strided: tiles of a resident raster are windows (pitch 256); 64-wide tiles take the table path,
+        # 40-wide ones the VM -- both must equal the untiled result
+        big = rng.integers(0, 12, size=(1, 192, 256)).astype("u1")
+        big[rng.random(big.shape) < 0.1] = ndv
+        src = raster.MemorySource(big, ndv, "EPSG:28992", 1.0, (0.0, 192.0))
+        view = raster.Reclassify(src, [[1, 10], [2, 20], [3, 7]]) 
+        whole_req = dict(mode="vals", bbox=(0.0, 0.0, 256.0, 192.0), width=256, height=192, projection="EPSG:28992")
+        whole = view.get_data(**whole_req)
+        want = O.reclassify_process({"values": big, "no_data_value": ndv},
+                                    {"dtype": "<i8", "fillvalue": int(np.iinfo("i8").max), "data": [[1, 10], [2, 20], [3, 7]], "select": False})
+        assert_result_equal(whole, want, 0, "whole")
+        for tile in ([64, 64], [40, 96], [64, 48]):
+            assert_result_equal(raster.RasterTiler(view, tile).get_data(**whole_req), want, 0, "tiles %s" % tile)
