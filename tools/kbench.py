@@ -70,6 +70,16 @@ def main():
         timeit("mask i32->u8 (VM, 5 B/px)", 5.0 * n,
                [lambda t=t: devops.mask_process({"values": t, "no_data_value": I32MAX}, 1) for t in i4])
         del i4
+        from dask_geomodeling_amd.hip import program as P
+        u8 = [generate_window((side, side), "u1", 30 + i, 0.0, 12.0, 255, (50, 50), 0, 0, side, side) for i in range(T)]
+        table = {"dtype": "<i8", "fillvalue": int(np.iinfo("i8").max), "select": False, "data": [[0, 10], [1, 11], [3, 13], [5, 15]]}
+        leaf = P.Leaf(0, "u1", 255)
+        for label, root, bpp in (("u8 program: mask -> u8 (table path, 2 B/px)", devops.mask_node(leaf, 1), 2.0),
+                                 ("u8 program: reclassify + mask -> u8 (table path, 2 B/px)", devops.mask_node(tables.reclassify_node(leaf, table), 1), 2.0),
+                                 ("u8 program: reclassify -> i64 (table path, 9 B/px)", tables.reclassify_node(leaf, table), 9.0)):
+            comp = P.compile_expr(root, 1)
+            timeit(label, bpp * n, [lambda t=t: P.launch(comp, [t], (1, side, side)) for t in u8])
+        del u8
     if "bilinear" in which:
         src = [generate_window((side, side), "f4", 70 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side, side) for i in range(2)]
         timeit("bilinear f32 2x upsample (5 B/out px)", 5.0 * 4 * n,
