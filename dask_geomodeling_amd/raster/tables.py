@@ -90,7 +90,13 @@ def reclassify_node(store, process_kwargs):
 # A lone Classify / Reclassify (nothing to fuse with) runs fastest in its dedicated LDS kernel
 # (measured 8192^2: Classify 60 vs 111 us, Reclassify u8 -> i64 92 vs 220 us); the program ops exist
 # for fusion.  Tests flip this switch to pin the program route to the golden vectors as well.
+# 1-byte tiles always take the program route: a program over one 1-byte tile runs as a 256-entry table
+# (DESIGN K1b; Classify uint8 -> uint8 24 us, Reclassify uint8 -> int64 86 us on 8192^2).
 _PREFER_PROGRAM = False
+
+
+def _by_table(dtype):
+    return np.dtype(dtype).itemsize == 1
 
 
 def _try_program(node):
@@ -107,7 +113,7 @@ def classify_process(data, bins, right):
     if data is None or "values" not in data:
         return data
     runtime.require_device()
-    if _PREFER_PROGRAM and data["values"].dtype != np.dtype("bool"):
+    if (_PREFER_PROGRAM or _by_table(data["values"].dtype)) and data["values"].dtype != np.dtype("bool"):
         try:  # few edges: one program step (the same one a fused chain uses)
             leaf = P.Leaf(None, data["values"].dtype, data["no_data_value"], values=data["values"])
             hit = _try_program(classify_node(leaf, bins, right))
@@ -160,7 +166,7 @@ def reclassify_process(store_data, process_kwargs):
     dtype = np.dtype(process_kwargs["dtype"])
     fill = process_kwargs["fillvalue"]
     hit = None
-    if _PREFER_PROGRAM:
+    if _PREFER_PROGRAM or _by_table(in_dtype):
         try:  # dense table: one program step (the same one a fused chain uses)
             leaf = P.Leaf(None, in_dtype, store_data["no_data_value"], values=store_data["values"])
             hit = _try_program(reclassify_node(leaf, process_kwargs))
