@@ -33,6 +33,21 @@ int current_cu_count();
 int lut8_launch(int n_tiles, const void* const* in, const uint32_t* in_pitch, void* const* out, const uint32_t* out_pitch,
                 size_t rows, size_t cols, const void* table, int out_size, hipStream_t stream);
 
+// A program that is nothing but LOOKUP(int32 tile) (gm_tables.hip): out = (E)(window hit | exception |
+// fill / pass-through), exactly Machine::op_lookup of the int32 class.  window: `range` int32 entries on
+// the device; exceptions: <= 8 (key, value) pairs.  Contiguous, 16-byte aligned tiles only.
+struct Lookup32 {
+  const int* window;
+  unsigned range;
+  int kmin;
+  int n_exc;
+  int exc_key[8], exc_val[8];
+  int select;
+  int fill;
+};
+int lookup32_launch(int n_tiles, const void* const* in, void* const* out, size_t n, const Lookup32& table, int out_size,
+                    hipStream_t stream);
+
 inline int dtype_size(int dt) {
   switch (dt) {
     case GM_BOOL: case GM_U8: case GM_I8: return 1;

@@ -228,6 +228,10 @@ struct CodeEntry {
   mutable void* lut = nullptr;
   mutable std::once_flag lut_once;
   mutable int lut_rc = GM_OK;
+  // programs that are nothing but LOOKUP(int32 tile) -> narrow integer tile (configs[2]): the dedicated
+  // kernel of gm_tables.hip
+  bool lookup_only = false;
+  gm::Lookup32 lookup;
 };
 
 std::mutex g_code_mu;
@@ -406,6 +410,35 @@ int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) 
   e->dev = (VmCode*)dev;
   const unsigned long long tables_dev = (unsigned long long)(uintptr_t)dev + ((sizeof(VmCode) + 15) / 16) * 16;
   for (unsigned t = 0; t < key.n_tables; ++t) e->host.tables[t] = tables_dev + 8ull * offset[t];
+  {
+    const unsigned in_bits = key.inputs[0].bits;
+    const unsigned od = key.out_dtype;
+    const bool narrow_int_out = od == GM_U8 || od == GM_I8;  // (the kernel packs 1-byte results)
+    if (key.reg_class == GM_CLASS_I32 && key.n_inputs == 1 && (in_bits & 0xffu) == GM_I32 && !((in_bits >> 8) & 1u) &&
+        narrow_int_out && e->n_uops == 2 && (e->host.uops[0].route & 0xffu) == UOP_LD &&
+        ((e->host.uops[0].route >> 8) & 0xffu) == UOP_SRC_INPUT && (e->host.uops[1].route & 0xffu) == UOP_LOOKUP) {
+      const gm_uop& U = e->host.uops[1];
+      const unsigned t = (U.arg >> 16) & 3u, n_exc = (U.arg >> 8) & 0xfu;
+      const unsigned long long range = U.acc_ndv.u64;
+      if (t < key.n_tables && n_exc <= 8 && range >= 1 && range * 4ull <= 61440ull) {
+        gm::Lookup32& K = e->lookup;
+        memset(&K, 0, sizeof(K));
+        K.window = (const int*)(uintptr_t)e->host.tables[t];
+        K.range = (unsigned)range;
+        K.kmin = (int)U.b_val.i64;
+        K.n_exc = (int)n_exc;
+        K.select = (int)(U.arg & 1u);
+        K.fill = U.fill.i32;
+        const size_t exc_at = offset[t] + (size_t)((range * 4ull + 7ull) / 8ull);
+        bool ok = exc_at + 2ull * n_exc <= e->staged.size();
+        for (unsigned x = 0; x < n_exc && ok; ++x) {
+          K.exc_key[x] = (int)(long long)e->staged[exc_at + 2 * x];
+          K.exc_val[x] = (int)(unsigned)e->staged[exc_at + 2 * x + 1];
+        }
+        e->lookup_only = ok;
+      }
+    }
+  }
   GM_HIP(hipMemcpyAsync(dev, &e->host, sizeof(VmCode), hipMemcpyHostToDevice, stream));
   if (!e->staged.empty())
     GM_HIP(hipMemcpyAsync((void*)(uintptr_t)tables_dev, e->staged.data(), e->staged.size() * 8, hipMemcpyHostToDevice, stream));
@@ -495,6 +528,24 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
           op[t] = out_pitches && out_pitches[t0 + t] != cols ? out_pitches[t0 + t] : 0u;
         }
         rc = gm::lut8_launch(nb, inputs + t0, ip, outs + t0, op, rows, cols, code->lut, out_size, stream);
+        if (rc) return rc;
+      }
+      return GM_OK;
+    }
+  }
+
+  // The whole program is LOOKUP(int32 tile) -> narrow integer tile: dedicated kernel (contiguous tiles)
+  if (code->lookup_only && n >= LUT8_MIN_ELEMS) {
+    bool addressable = true;
+    for (int t = 0; t < n_tiles && addressable; ++t) {
+      const uint32_t ip = pitches ? pitches[t] : 0u, op = out_pitches ? out_pitches[t] : 0u;
+      if ((ip && ip != cols) || (op && op != cols)) addressable = false;
+      if (((uintptr_t)inputs[t] % 16) || ((uintptr_t)outs[t] % 16)) addressable = false;
+    }
+    if (addressable) {
+      for (int t0 = 0; t0 < n_tiles; t0 += 16) {
+        const int nb = n_tiles - t0 < 16 ? n_tiles - t0 : 16;
+        rc = gm::lookup32_launch(nb, inputs + t0, outs + t0, n, code->lookup, gm::dtype_size(code->prog.out_dtype), stream);
         if (rc) return rc;
       }
       return GM_OK;

@@ -463,6 +463,113 @@ int gm::lut8_launch(int n_tiles, const void* const* in, const uint32_t* in_pitch
 }
 
 namespace {
+// ---------------------------------------------------------------------------------
+// int32 tile -> LOOKUP -> narrow integer tile: the whole program of configs[2] (Reclassify with the Mask
+// folded into its table).  Same arithmetic as Machine::op_lookup (gm_vm.h) of the int32 class, with the
+// access pattern of the byte-LUT kernel: 16 / sizeof(E) pixels per lane, ONE 16-byte store per lane,
+// the window staged in LDS once per workgroup for `chunks` consecutive spans.
+// ---------------------------------------------------------------------------------
+struct Lookup32Launch {
+  const int* in[16];
+  unsigned char* out[16];
+  unsigned long long n;
+  int chunks;
+  gm::Lookup32 T;
+};
+
+// uint8 / int8 results.  Loads want consecutive lanes on consecutive 16 bytes (4 pixels), 16-byte stores
+// want consecutive lanes on consecutive 16 pixels: a lane looks up the 4 pixels of each of its 4
+// coalesced loads, packs them into a word, and the wave transposes through its own 1 KiB of LDS
+// (4 ds_write_b32 + 1 ds_read_b128 per lane, no barrier: one wave, in-order LDS) so that lane l stores
+// the 16 consecutive pixels 16 l .. 16 l + 15 of the wave's 1024.  (16 consecutive pixels per lane
+// straight from memory -- four 16-byte loads at a 64-byte lane stride -- ran at 43 % of peak.)
+__global__ __launch_bounds__(256) void lookup32_kernel(Lookup32Launch L) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  unsigned* const swap = (unsigned*)smem + (threadIdx.x >> 6) * 256;  // this wave's transpose buffer
+  int* const window = (int*)(smem + 4096);
+  const unsigned tile = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int* in = L.in[tile];
+  unsigned char* out = L.out[tile];
+  const unsigned range = L.T.range, kmin = (unsigned)L.T.kmin;
+  auto lookup = [&](int value) -> unsigned {
+    const unsigned idx = (unsigned)value - kmin;  // wrapping, as op_lookup
+    const int hit = window[idx < range ? idx : 0u];
+    int miss = L.T.select ? L.T.fill : value;
+    for (int x = 0; x < L.T.n_exc; ++x) miss = (idx == (unsigned)L.T.exc_key[x] - kmin) ? L.T.exc_val[x] : miss;
+    return (unsigned)(idx < range ? hit : miss) & 0xffu;
+  };
+  for (int c = 0; c < L.chunks; ++c) {
+    // the workgroup's span: 4096 pixels; wave w owns pixels [1024 w, 1024 w + 1024) of it as 4 groups
+    // of 256: group q of lane l = pixels 256 q + 4 l .. + 3
+    const unsigned long long span0 = ((unsigned long long)blockIdx.x * L.chunks + c) * 4096ull + 1024ull * wave;
+    i32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned long long e = span0 + 256ull * q + 4ull * lane;
+      v[q] = i32x4{0, 0, 0, 0};
+      if (e + 4 <= L.n) v[q] = __builtin_nontemporal_load((const i32x4*)(in + e));
+    }
+    if (c == 0) {  // stage the window behind the first tile loads, 4 loads of a lane in flight
+      for (unsigned i = threadIdx.x; i < range; i += 1024) {
+        int w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = L.T.window[min(i + 256u * u, range - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i + 256u * u < range) window[i + 256u * u] = w[u];
+      }
+      __syncthreads();
+    }
+    if (span0 + 1024 <= L.n) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        swap[64 * q + lane] = lookup(v[q][0]) | (lookup(v[q][1]) << 8) | (lookup(v[q][2]) << 16) | (lookup(v[q][3]) << 24);
+      const u32x4 words = *(const u32x4*)(swap + 4 * lane);  // pixels 16 lane .. 16 lane + 15 of the wave's 1024
+      __builtin_nontemporal_store(words, (u32x4*)(out + span0 + 16ull * lane));
+    } else {  // ragged end of the tile: pixel by pixel
+      for (unsigned long long e = span0 + lane; e < L.n && e < span0 + 1024; e += 64) out[e] = (unsigned char)lookup(in[e]);
+    }
+  }
+}
+
+}  // namespace
+
+int gm::lookup32_launch(int n_tiles, const void* const* in, void* const* out, size_t n, const gm::Lookup32& table,
+                        int out_size, hipStream_t stream) {
+  Lookup32Launch L;
+  memset(&L, 0, sizeof(L));
+  L.n = n;
+  L.T = table;
+  for (int t = 0; t < n_tiles; ++t) {
+    L.in[t] = (const int*)in[t];
+    L.out[t] = (unsigned char*)out[t];
+  }
+  if (out_size != 1) return gm::fail(GM_ERR_INVALID, "lookup32: element size %d", out_size);
+  const unsigned long long per_block = 4096ull;
+  unsigned long long blocks = (n + per_block - 1) / per_block;
+  // a workgroup that stages W bytes of window streams >= 10 W bytes of tiles, and at least 4 spans
+  // while the grid still fills the GPU (as the VM's tables flavour)
+  const unsigned long long span_bytes = per_block * 5ull;
+  unsigned long long chunks = ((unsigned long long)table.range * 4ull * 10ull + span_bytes - 1) / span_bytes;
+  const unsigned long long fill_blocks = 4ull * (unsigned long long)(gm::current_cu_count() > 0 ? gm::current_cu_count() : 256);
+  unsigned long long amortise = blocks / fill_blocks;
+  if (amortise > 4) amortise = 4;
+  if (chunks < amortise) chunks = amortise;
+  if (chunks < 1) chunks = 1;
+  if (chunks > 64) chunks = 64;
+  L.chunks = (int)chunks;
+  blocks = (blocks + chunks - 1) / chunks;
+  if (blocks > 0x7fffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "lookup32: tile too large for one launch");
+  const size_t lds = 4096 + (size_t)table.range * 4;
+  dim3 grid((unsigned)blocks, (unsigned)n_tiles);
+  hipLaunchKernelGGL(lookup32_kernel, grid, dim3(256), lds, stream, L);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+namespace {
 }  // namespace
 
 extern "C" {
