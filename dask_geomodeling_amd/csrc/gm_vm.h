@@ -1087,6 +1087,35 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
   // phase 3: store (the result may itself be a window: a tile written straight into its mosaic)
   unsigned out_pitch = 0;
   if (strided) out_pitch = kload<unsigned>(K, offsetof(VmLaunch, out_pitch) + sizeof(unsigned) * tile);
+  if constexpr (G == 2 && sizeof(RC) == 4) {
+    // 1-byte results, both groups of every lane of this wave inside the tile: the 4 bytes of a group are
+    // a 4-byte store per lane as they stand.  The wave transposes its 2 x 64 words through 512 bytes of
+    // its own LDS instead (2 ds_write_b32 + 1 ds_read_b64 per lane, no barrier: one wave, in-order LDS)
+    // and lane l stores the 8 consecutive pixels 8 l .. 8 l + 7 of the 256-pixel run it belongs to.
+    const int od = (int)GM_KARG(K, out_dtype);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned long long wave_g0 = g0 - lane;
+    if ((od == GM_U8 || od == GM_I8 || od == GM_BOOL) && !out_pitch && wave_g0 + 256ull + 63ull < n_groups) {
+      __shared__ unsigned vm_swap[4][128];
+      unsigned* const mine = vm_swap[threadIdx.x >> 6];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        unsigned word = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const RC r = M.acc[4 * u + q];
+          const unsigned byte = od == GM_I8 ? (unsigned)(unsigned char)(signed char)r : (unsigned)(unsigned char)r;
+          word |= byte << (8 * q);
+        }
+        mine[64 * u + lane] = word;
+      }
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 pair = *(const u32x2*)(mine + 2 * lane);
+      const unsigned long long px = (wave_g0 + 256ull * (lane >> 5)) * 4ull + 8ull * (lane & 31u);
+      st((u32x2*)((unsigned char*)out + px), pair, nt_st);
+      continue;  // next span
+    }
+  }
 #pragma unroll
   for (int u = 0; u < G; ++u) {
     const unsigned long long g = g0 + 256ull * u;
