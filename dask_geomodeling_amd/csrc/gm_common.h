@@ -35,7 +35,7 @@ int lut8_launch(int n_tiles, const void* const* in, const uint32_t* in_pitch, vo
 
 // A program that is nothing but LOOKUP(int32 tile) (gm_tables.hip): out = (E)(window hit | exception |
 // fill / pass-through), exactly Machine::op_lookup of the int32 class.  window: `range` int32 entries on
-// the device; exceptions: <= 8 (key, value) pairs.  Contiguous, 16-byte aligned tiles only.
+// the device; exceptions: <= 8 (key, value) pairs.  16-byte aligned tile pointers.
 struct Lookup32 {
   const int* window;
   unsigned range;
@@ -45,7 +45,10 @@ struct Lookup32 {
   int select;
   int fill;
 };
-int lookup32_launch(int n_tiles, const void* const* in, void* const* out, size_t n, const Lookup32& table, int out_size,
+// in_pitch / out_pitch: elements per row of strided tiles (zero-copy windows), nullptr / 0 = contiguous; strided
+// tiles need cols % 16 == 0, in_pitch % 4 == 0, out_pitch % 16 == 0 and fewer than 2^32 elements.
+int lookup32_launch(int n_tiles, const void* const* in, const uint32_t* in_pitch, void* const* out,
+                    const uint32_t* out_pitch, size_t rows, size_t cols, const Lookup32& table, int out_size,
                     hipStream_t stream);
 
 inline int dtype_size(int dt) {

@@ -534,18 +534,25 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
     }
   }
 
-  // The whole program is LOOKUP(int32 tile) -> narrow integer tile: dedicated kernel (contiguous tiles)
+  // The whole program is LOOKUP(int32 tile) -> 1-byte tile: dedicated kernel (gm_tables.hip)
   if (code->lookup_only && n >= LUT8_MIN_ELEMS) {
     bool addressable = true;
     for (int t = 0; t < n_tiles && addressable; ++t) {
       const uint32_t ip = pitches ? pitches[t] : 0u, op = out_pitches ? out_pitches[t] : 0u;
-      if ((ip && ip != cols) || (op && op != cols)) addressable = false;
+      const bool strided = (ip && ip != cols) || (op && op != cols);
       if (((uintptr_t)inputs[t] % 16) || ((uintptr_t)outs[t] % 16)) addressable = false;
+      if (strided && ((cols % 16) || (ip % 4) || (op % 16) || n > 0xffffffffull)) addressable = false;
     }
     if (addressable) {
       for (int t0 = 0; t0 < n_tiles; t0 += 16) {
         const int nb = n_tiles - t0 < 16 ? n_tiles - t0 : 16;
-        rc = gm::lookup32_launch(nb, inputs + t0, outs + t0, n, code->lookup, gm::dtype_size(code->prog.out_dtype), stream);
+        uint32_t ip[16], op[16];
+        for (int t = 0; t < nb; ++t) {
+          ip[t] = pitches && pitches[t0 + t] != cols ? pitches[t0 + t] : 0u;
+          op[t] = out_pitches && out_pitches[t0 + t] != cols ? out_pitches[t0 + t] : 0u;
+        }
+        rc = gm::lookup32_launch(nb, inputs + t0, ip, outs + t0, op, rows, cols, code->lookup,
+                                 gm::dtype_size(code->prog.out_dtype), stream);
         if (rc) return rc;
       }
       return GM_OK;

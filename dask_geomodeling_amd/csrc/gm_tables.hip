@@ -472,8 +472,10 @@ namespace {
 struct Lookup32Launch {
   const int* in[16];
   unsigned char* out[16];
+  unsigned in_pitch[16], out_pitch[16];  // elements per row; 0 = contiguous
   unsigned long long n;
   int chunks;
+  unsigned cols, div_magic, div_sh1, div_sh2;  // element -> row of a strided tile (division by an invariant)
   gm::Lookup32 T;
 };
 
@@ -493,6 +495,14 @@ __global__ __launch_bounds__(256) void lookup32_kernel(Lookup32Launch L) {
   const int* in = L.in[tile];
   unsigned char* out = L.out[tile];
   const unsigned range = L.T.range, kmin = (unsigned)L.T.kmin;
+  const unsigned ip = L.in_pitch[tile], op = L.out_pitch[tile];
+  // element index -> offset in a strided tile (groups of 16 never straddle rows: cols % 16 == 0)
+  auto offset = [&](unsigned long long e, unsigned pitch) -> unsigned long long {
+    if (!pitch) return e;
+    const unsigned e32 = (unsigned)e, t = __umulhi(e32, L.div_magic);
+    const unsigned row = (t + ((e32 - t) >> L.div_sh1)) >> L.div_sh2;
+    return (unsigned long long)row * pitch + (e32 - row * L.cols);
+  };
   auto lookup = [&](int value) -> unsigned {
     const unsigned idx = (unsigned)value - kmin;  // wrapping, as op_lookup
     const int hit = window[idx < range ? idx : 0u];
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(256) void lookup32_kernel(Lookup32Launch L) {
     for (int q = 0; q < 4; ++q) {
       const unsigned long long e = span0 + 256ull * q + 4ull * lane;
       v[q] = i32x4{0, 0, 0, 0};
-      if (e + 4 <= L.n) v[q] = __builtin_nontemporal_load((const i32x4*)(in + e));
+      if (e + 4 <= L.n) v[q] = __builtin_nontemporal_load((const i32x4*)(in + offset(e, ip)));
     }
     if (c == 0) {  // stage the window behind the first tile loads, 4 loads of a lane in flight
       for (unsigned i = threadIdx.x; i < range; i += 1024) {
@@ -527,24 +537,38 @@ __global__ __launch_bounds__(256) void lookup32_kernel(Lookup32Launch L) {
       for (int q = 0; q < 4; ++q)
         swap[64 * q + lane] = lookup(v[q][0]) | (lookup(v[q][1]) << 8) | (lookup(v[q][2]) << 16) | (lookup(v[q][3]) << 24);
       const u32x4 words = *(const u32x4*)(swap + 4 * lane);  // pixels 16 lane .. 16 lane + 15 of the wave's 1024
-      __builtin_nontemporal_store(words, (u32x4*)(out + span0 + 16ull * lane));
+      __builtin_nontemporal_store(words, (u32x4*)(out + offset(span0 + 16ull * lane, op)));
     } else {  // ragged end of the tile: pixel by pixel
-      for (unsigned long long e = span0 + lane; e < L.n && e < span0 + 1024; e += 64) out[e] = (unsigned char)lookup(in[e]);
+      for (unsigned long long e = span0 + lane; e < L.n && e < span0 + 1024; e += 64)
+        out[offset(e, op)] = (unsigned char)lookup(in[offset(e, ip)]);
     }
   }
 }
 
 }  // namespace
 
-int gm::lookup32_launch(int n_tiles, const void* const* in, void* const* out, size_t n, const gm::Lookup32& table,
-                        int out_size, hipStream_t stream) {
+int gm::lookup32_launch(int n_tiles, const void* const* in, const uint32_t* in_pitch, void* const* out,
+                        const uint32_t* out_pitch, size_t rows, size_t cols, const gm::Lookup32& table, int out_size,
+                        hipStream_t stream) {
+  const size_t n = rows * cols;
   Lookup32Launch L;
   memset(&L, 0, sizeof(L));
   L.n = n;
   L.T = table;
+  L.cols = (unsigned)cols;
+  {
+    const unsigned long long d = cols ? cols : 1;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    L.div_magic = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1ull);
+    L.div_sh1 = l < 1 ? l : 1;
+    L.div_sh2 = l > 1 ? l - 1 : 0;
+  }
   for (int t = 0; t < n_tiles; ++t) {
     L.in[t] = (const int*)in[t];
     L.out[t] = (unsigned char*)out[t];
+    L.in_pitch[t] = in_pitch ? in_pitch[t] : 0u;
+    L.out_pitch[t] = out_pitch ? out_pitch[t] : 0u;
   }
   if (out_size != 1) return gm::fail(GM_ERR_INVALID, "lookup32: element size %d", out_size);
   const unsigned long long per_block = 4096ull;

@@ -1010,3 +1010,26 @@ def test_int32_reclassify_mask_dedicated_kernel(gpu, shape):
                                              {"dtype": "<i8", "fillvalue": int(np.iinfo("i8").max), "data": table, "select": select})
                     want = O.mask_process(r, value)
                     assert_result_equal(view.get_data(**req), want, 0, "%s ndv %d select %s value %d" % (tname, ndv, select, value))
+
+
+@pytest.mark.gpu
+def test_int32_reclassify_mask_on_windows(gpu):
+    """The dedicated LOOKUP kernel on zero-copy windows of a resident int32 raster (strided tiles written
+    straight into the mosaic): tile widths it can address (multiples of 16) and widths that fall back to
+    the VM must both equal the untiled result and the oracle."""
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(23)
+    ndv = 2147483647
+    big = rng.integers(-3, 40, size=(1, 192, 320)).astype("i4")
+    big[rng.random(big.shape) < 0.1] = ndv
+    table = [[k, (7 * k) % 251] for k in range(0, 40, 3)]
+    src = raster.MemorySource(big, ndv, "EPSG:28992", 1.0, (0.0, 192.0))
+    req = dict(mode="vals", bbox=(0.0, 0.0, 320.0, 192.0), width=320, height=192, projection="EPSG:28992")
+    for select in (False, True):
+        view = raster.Mask(raster.Reclassify(src, table, select), 3)
+        r = O.reclassify_process({"values": big, "no_data_value": ndv},
+                                 {"dtype": "<i8", "fillvalue": int(np.iinfo("i8").max), "data": table, "select": select})
+        want = O.mask_process(r, 3)
+        assert_result_equal(view.get_data(**req), want, 0, "whole")
+        for tile in ([64, 64], [48, 80], [96, 160], [40, 72], [64, 100]):
+            assert_result_equal(raster.RasterTiler(view, tile).get_data(**req), want, 0, "tiles %s select %s" % (tile, select))
