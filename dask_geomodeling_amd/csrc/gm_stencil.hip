@@ -287,6 +287,57 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
   }
 }
 
+// The 3 x 3 footprint (size 3: every cell of the square satisfies x^2 + y^2 < 2.25) is separable: the
+// maximum of each window row, then the maximum of three row maxima.  Same LDS tile as HillShade: a
+// workgroup stages the 18 x 258 window of its 16 x 256 outputs (no data lowered to the dtype's minimum,
+// all loads of a lane in flight), a lane walks its column keeping the row maxima of the last two rows.
+constexpr int M3_H = 16, M3_W = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
+                                                          int has_ndv, T ndv, T minimum) {
+  __shared__ T tile[(M3_H + 2) * (M3_W + 2)];
+  const int c0 = blockIdx.x * M3_W, r0 = blockIdx.y * M3_H, b = blockIdx.z;
+  const int ow = w - 2, oh = h - 2;
+  const T* plane = in + (size_t)b * h * w;
+  constexpr int PITCH = M3_W + 2, CELLS = (M3_H + 2) * PITCH, PER_LANE = (CELLS + 255) / 256;
+  T staged[PER_LANE];
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) {
+    const int cell = threadIdx.x + 256 * i;
+    const int wy = min(cell / PITCH, M3_H + 1), wx = cell - (cell / PITCH) * PITCH;
+    const int sy = min(r0 + wy, h - 1), sx = min(c0 + wx, w - 1);
+    staged[i] = plane[(size_t)sy * w + sx];
+  }
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) {
+    const int cell = threadIdx.x + 256 * i;
+    if (cell < CELLS) tile[cell] = (has_ndv && staged[i] == ndv) ? minimum : staged[i];  // spatial.py:199-203
+  }
+  __syncthreads();
+  const int c = c0 + threadIdx.x;
+  if (c >= ow) return;
+  auto up = [](T a, T b) -> T { return b > a ? b : a; };
+  const T* col = tile + threadIdx.x;
+  auto row_max = [&](int wy) -> T { return up(up(col[wy * PITCH], col[wy * PITCH + 1]), col[wy * PITCH + 2]); };
+  T above = row_max(0), centre = row_max(1);
+#pragma unroll
+  for (int r = 0; r < M3_H; ++r) {
+    const T below = row_max(r + 2);
+    T best = up(up(above, centre), below);
+    above = centre;
+    centre = below;
+    if (r0 + r < oh) {
+      // still the minimum on a no-data centre: no-data again (spatial.py:208-209); only then is the
+      // original centre fetched (the LDS copy cannot tell "was no data" from "is the minimum")
+      if (has_ndv && best == minimum) {
+        const T original = plane[(size_t)(r0 + r + 1) * w + (c + 1)];
+        if (original == ndv) best = ndv;
+      }
+      __builtin_nontemporal_store(best, out + ((size_t)b * oh + (r0 + r)) * ow + c);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // HillShade
 // ---------------------------------------------------------------------------------
@@ -630,6 +681,23 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
     return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: the window of a size-%d footprint does not fit 64 KiB of LDS for this dtype", size);
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
+  if (size == 3 && gm::dtype_size(dtype) <= 4 && (oh + M3_H - 1) / M3_H <= 65535) {
+    dim3 grid3((unsigned)((ow + M3_W - 1) / M3_W), (unsigned)((oh + M3_H - 1) / M3_H), (unsigned)bands);
+#define GM_M3(T) hipLaunchKernelGGL(moving_max3_kernel<T>, grid3, dim3(256), 0, s, (const T*)in, (T*)out, h, w, has_ndv, from_bits<T>(ndv_bits), lowest<T>())
+    switch (dtype) {
+      case GM_U8: GM_M3(unsigned char); break;
+      case GM_I8: GM_M3(signed char); break;
+      case GM_U16: GM_M3(unsigned short); break;
+      case GM_I16: GM_M3(short); break;
+      case GM_U32: GM_M3(unsigned int); break;
+      case GM_I32: GM_M3(int); break;
+      case GM_F32: GM_M3(float); break;
+      default: return gm::fail(GM_ERR_INVALID, "gm_moving_max: dtype %d", dtype);
+    }
+#undef GM_M3
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+  }
   dim3 grid((unsigned)((ow + MM_TILE_W - 1) / MM_TILE_W), (unsigned)((oh + MM_TILE_H - 1) / MM_TILE_H), (unsigned)bands);
   if (grid.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: tile too tall");
 #define GM_MM_R(T, RMAX_)                                                                                      \
