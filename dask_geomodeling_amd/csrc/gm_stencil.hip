@@ -338,6 +338,81 @@ __global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ 
   }
 }
 
+// Fixed small footprints (sizes 5 and 7).  The disk is a stack of horizontal runs: out(r) = max over dy of
+// HM_{a(dy)}(row r + dy), HM_a(row) = maximum of the 2 a + 1 cells around the lane's column, a(dy) = the
+// half-width of the footprint at that row offset.  HM_0 .. HM_R of a window row are nested (two more
+// cells per step), so a lane that walks its column keeps them for the last 2 R + 1 window rows in
+// registers and spends 2 R + 1 LDS reads and 4 R maxima per output -- all indices compile-time constants
+// (fully unrolled walk), i.e. straight-line code without the data-dependent loops of the general kernel.
+template <int R>
+__host__ __device__ constexpr int disk_half_width(int dy) {
+  int a = -1;
+  const int s2 = (2 * R + 1) * (2 * R + 1);
+  for (int dx = 0; dx <= R; ++dx)
+    if (4 * (dx * dx + dy * dy) < s2) a = dx;
+  return a;  // -1: the row offset is outside the footprint (cannot happen for |dy| <= R)
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
+                                                              int has_ndv, T ndv, T minimum) {
+  constexpr int TH = 16, TW = 256, PITCH = TW + 2 * R, ROWS = TH + 2 * R, CELLS = ROWS * PITCH;
+  constexpr int PER_LANE = (CELLS + 255) / 256;
+  __shared__ T tile[CELLS];
+  const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH, b = blockIdx.z;
+  const int ow = w - 2 * R, oh = h - 2 * R;
+  const T* plane = in + (size_t)b * h * w;
+  T staged[PER_LANE];
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) {
+    const int cell = threadIdx.x + 256 * i;
+    const int wy = min(cell / PITCH, ROWS - 1), wx = cell - (cell / PITCH) * PITCH;
+    const int sy = min(r0 + wy, h - 1), sx = min(c0 + wx, w - 1);
+    staged[i] = plane[(size_t)sy * w + sx];
+  }
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) {
+    const int cell = threadIdx.x + 256 * i;
+    if (cell < CELLS) tile[cell] = (has_ndv && staged[i] == ndv) ? minimum : staged[i];  // spatial.py:199-203
+  }
+  __syncthreads();
+  const int c = c0 + threadIdx.x;
+  if (c >= ow) return;
+  auto up = [](T a, T b) -> T { return b > a ? b : a; };
+  const T* col = tile + threadIdx.x;  // window columns threadIdx.x .. threadIdx.x + 2 R = dx -R .. R
+  T hm[2 * R + 1][R + 1];             // hm[k][a]: HM_a of window row y - 2 R + k after window row y was taken
+#pragma unroll
+  for (int k = 0; k <= 2 * R; ++k)
+#pragma unroll
+    for (int a = 0; a <= R; ++a) hm[k][a] = minimum;
+#pragma unroll
+  for (int y = 0; y < ROWS; ++y) {
+#pragma unroll
+    for (int k = 0; k < 2 * R; ++k)
+#pragma unroll
+      for (int a = 0; a <= R; ++a) hm[k][a] = hm[k + 1][a];
+    T v[2 * R + 1];
+#pragma unroll
+    for (int j = 0; j <= 2 * R; ++j) v[j] = col[y * PITCH + j];
+    hm[2 * R][0] = v[R];
+#pragma unroll
+    for (int a = 1; a <= R; ++a) hm[2 * R][a] = up(up(hm[2 * R][a - 1], v[R - a]), v[R + a]);
+    if (y >= 2 * R) {
+      const int r = y - 2 * R;
+      T best = hm[0][disk_half_width<R>(R)];
+#pragma unroll
+      for (int k = 1; k <= 2 * R; ++k) best = up(best, hm[k][disk_half_width<R>(k > R ? k - R : R - k)]);
+      if (r0 + r < oh) {
+        if (has_ndv && best == minimum) {  // no data again where the centre was no data (spatial.py:208-209)
+          const T original = plane[(size_t)(r0 + r + R) * w + (c + R)];
+          if (original == ndv) best = ndv;
+        }
+        __builtin_nontemporal_store(best, out + ((size_t)b * oh + (r0 + r)) * ow + c);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // HillShade
 // ---------------------------------------------------------------------------------
@@ -695,6 +770,31 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
       default: return gm::fail(GM_ERR_INVALID, "gm_moving_max: dtype %d", dtype);
     }
 #undef GM_M3
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+  }
+  if ((size == 5 || size == 7) && gm::dtype_size(dtype) <= 4 && (oh + 15) / 16 <= 65535) {
+    dim3 gridd((unsigned)((ow + 255) / 256), (unsigned)((oh + 15) / 16), (unsigned)bands);
+#define GM_MD(T)                                                                                                  \
+  do {                                                                                                            \
+    if (size == 5)                                                                                                \
+      hipLaunchKernelGGL((moving_max_disk_kernel<T, 2>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
+                         has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+    else                                                                                                          \
+      hipLaunchKernelGGL((moving_max_disk_kernel<T, 3>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
+                         has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+  } while (0)
+    switch (dtype) {
+      case GM_U8: GM_MD(unsigned char); break;
+      case GM_I8: GM_MD(signed char); break;
+      case GM_U16: GM_MD(unsigned short); break;
+      case GM_I16: GM_MD(short); break;
+      case GM_U32: GM_MD(unsigned int); break;
+      case GM_I32: GM_MD(int); break;
+      case GM_F32: GM_MD(float); break;
+      default: return gm::fail(GM_ERR_INVALID, "gm_moving_max: dtype %d", dtype);
+    }
+#undef GM_MD
     GM_HIP(hipGetLastError());
     return GM_OK;
   }

@@ -1033,3 +1033,25 @@ def test_int32_reclassify_mask_on_windows(gpu):
         assert_result_equal(view.get_data(**req), want, 0, "whole")
         for tile in ([64, 64], [48, 80], [96, 160], [40, 72], [64, 100]):
             assert_result_equal(raster.RasterTiler(view, tile).get_data(**req), want, 0, "tiles %s select %s" % (tile, select))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [3, 5, 7, 9])
+@pytest.mark.parametrize("dt,ndv", [("f4", np.float32(-9999.0)), ("u1", np.uint8(255)), ("i2", np.int16(-1)), ("i4", 2147483647), ("f8", 1e300)])
+def test_moving_max_kernels_against_oracle(gpu, size, dt, ndv):
+    """The separable 3 x 3 kernel, the fixed-footprint kernels (5, 7) and the general kernel (9; 8-byte
+    tiles at every size) on ragged multi-band tiles larger than a workgroup tile, with no-data regions
+    wide enough to leave all-no-data windows, against the oracle (bit-exact)."""
+    from dask_geomodeling_amd.raster import stencil
+    rng = np.random.default_rng(size * 100 + len(dt))
+    shape = (2, 45 + size, 533 + size)
+    if np.dtype(dt).kind == "f":
+        v = (rng.random(shape) * 200 - 100).astype(dt)
+    else:
+        v = rng.integers(0, 100, size=shape).astype(dt)
+    v[rng.random(shape) < 0.15] = ndv
+    v[:, 10:10 + 2 * size, 40:40 + 2 * size] = ndv  # a hole larger than the footprint
+    v[0, 0, 0] = np.finfo(dt).min if np.dtype(dt).kind == "f" else np.iinfo(dt).min  # the dtype's minimum as data
+    want = O.movingmax_process({"values": v, "no_data_value": ndv}, size)["values"]
+    got = stencil.moving_max(v, ndv, size).to_numpy()
+    assert got.dtype == want.dtype and np.array_equal(got, want), (size, dt)
