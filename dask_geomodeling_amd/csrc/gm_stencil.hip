@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ 
   }
 }
 
-// Fixed small footprints (sizes 5 and 7).  The disk is a stack of horizontal runs: out(r) = max over dy of
+// Fixed small footprints (sizes 5 to 15).  The disk is a stack of horizontal runs: out(r) = max over dy of
 // HM_{a(dy)}(row r + dy), HM_a(row) = maximum of the 2 a + 1 cells around the lane's column, a(dy) = the
 // half-width of the footprint at that row offset.  HM_0 .. HM_R of a window row are nested (two more
 // cells per step), so a lane that walks its column keeps them for the last 2 R + 1 window rows in
@@ -773,15 +773,27 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
     GM_HIP(hipGetLastError());
     return GM_OK;
   }
-  if ((size == 5 || size == 7) && gm::dtype_size(dtype) <= 4 && (oh + 15) / 16 <= 65535) {
+  if (size >= 5 && size <= 15 && gm::dtype_size(dtype) <= 4 && (oh + 15) / 16 <= 65535) {
     dim3 gridd((unsigned)((ow + 255) / 256), (unsigned)((oh + 15) / 16), (unsigned)bands);
 #define GM_MD(T)                                                                                                  \
   do {                                                                                                            \
     if (size == 5)                                                                                                \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 2>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
                          has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
-    else                                                                                                          \
+    else if (size == 7)                                                                                           \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 3>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
+                         has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+    else if (size == 9)                                                                                           \
+      hipLaunchKernelGGL((moving_max_disk_kernel<T, 4>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
+                         has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+    else if (size == 11)                                                                                          \
+      hipLaunchKernelGGL((moving_max_disk_kernel<T, 5>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
+                         has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+    else if (size == 13)                                                                                          \
+      hipLaunchKernelGGL((moving_max_disk_kernel<T, 6>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
+                         has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+    else                                                                                                          \
+      hipLaunchKernelGGL((moving_max_disk_kernel<T, 7>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
                          has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
   } while (0)
     switch (dtype) {

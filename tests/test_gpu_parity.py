@@ -1036,10 +1036,10 @@ def test_int32_reclassify_mask_on_windows(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [3, 5, 7, 9])
+@pytest.mark.parametrize("size", [3, 5, 7, 9, 11, 13, 15, 17])
 @pytest.mark.parametrize("dt,ndv", [("f4", np.float32(-9999.0)), ("u1", np.uint8(255)), ("i2", np.int16(-1)), ("i4", 2147483647), ("f8", 1e300)])
 def test_moving_max_kernels_against_oracle(gpu, size, dt, ndv):
-    """The separable 3 x 3 kernel, the fixed-footprint kernels (5, 7) and the general kernel (9; 8-byte
+    """The separable 3 x 3 kernel, the fixed-footprint kernels (5 .. 15) and the general kernel (17; 8-byte
     tiles at every size) on ragged multi-band tiles larger than a workgroup tile, with no-data regions
     wide enough to leave all-no-data windows, against the oracle (bit-exact)."""
     from dask_geomodeling_amd.raster import stencil

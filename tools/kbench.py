@@ -92,7 +92,7 @@ def main():
         m = (side - 2) * (side - 2)
         timeit("hillshade f32 -> u8 (5 B/px)", 5.0 * m,
                [lambda t=t: stencil.hillshade(t, np.float32(F32MAX), 0, (0.5, 0.5), 45.0, 315.0) for t in src])
-        for size in (3, 7, 15):
+        for size in (3, 5, 7, 11, 15):
             timeit("moving max f32, size %d (8 B/px)" % size, 8.0 * (side - size + 1) ** 2,
                    [lambda t=t: stencil.moving_max(t, np.float32(F32MAX), size) for t in src])
         u8 = [generate_window((side, side), "u1", 95 + i, 0.0, 6.0, 255, (50, 50), 0, 0, side, side) for i in range(T)]
