@@ -90,6 +90,52 @@ __global__ __launch_bounds__(256) void dilate_kernel(const T* __restrict__ in, T
   }
 }
 
+// Single-band tiles of 2- and 4-byte cells through the LDS tile of HillShade / MovingMax (the window
+// of 16 x 256 outputs staged once, all loads of a lane in flight; lanes walk their column out of LDS):
+// the column walker above waits one memory round trip per 4 rows, eight times per wave.
+constexpr int DT_H = 16, DT_W = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void dilate_tile_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
+                                                          DilateArgs<T> A) {
+  __shared__ T tile[(DT_H + 2) * (DT_W + 2)];
+  const int c0 = blockIdx.x * DT_W, r0 = blockIdx.y * DT_H;
+  const int ow = w - 2, oh = h - 2;
+  constexpr int PITCH = DT_W + 2, CELLS = (DT_H + 2) * PITCH, PER_LANE = (CELLS + 255) / 256;
+  T staged[PER_LANE];
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) {
+    const int cell = threadIdx.x + 256 * i;
+    const int wy = min(cell / PITCH, DT_H + 1), wx = cell - (cell / PITCH) * PITCH;
+    const int sy = min(r0 + wy, h - 1), sx = min(c0 + wx, w - 1);
+    staged[i] = in[(size_t)sy * w + sx];
+  }
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) {
+    const int cell = threadIdx.x + 256 * i;
+    if (cell < CELLS) tile[cell] = staged[i];
+  }
+  __syncthreads();
+  const int c = c0 + threadIdx.x;
+  if (c >= ow) return;
+  const T* col = tile + threadIdx.x;  // window columns threadIdx.x .. + 2 = west, centre, east
+  T north = col[1], west = col[PITCH], centre = col[PITCH + 1], east = col[PITCH + 2];
+#pragma unroll
+  for (int r = 0; r < DT_H; ++r) {
+    const T sw = col[(r + 2) * PITCH], south = col[(r + 2) * PITCH + 1], se = col[(r + 2) * PITCH + 2];
+    T result = centre;
+    for (int k = 0; k < A.n_values; ++k) {  // in order: later values overwrite earlier ones
+      const T v = A.values[k];
+      const bool hit = (centre == v) | (north == v) | (south == v) | (west == v) | (east == v);
+      result = hit ? v : result;
+    }
+    if (r0 + r < oh) __builtin_nontemporal_store(result, out + (size_t)(r0 + r) * ow + c);
+    north = centre;
+    west = sw;
+    centre = south;
+    east = se;
+  }
+}
+
 // Dilate for 1-byte tiles (class rasters are uint8): a lane owns FOUR consecutive output columns and
 // works on them as one 32-bit word (SWAR).  Per input row it loads 8 bytes (the 6 columns its
 // outputs see), takes the three byte-shifted words (west / centre / east), and per value turns
@@ -720,6 +766,28 @@ int gm_dilate(const void* in, int dtype, int bands, int h, int w, const uint64_t
     return GM_OK;
   }
   dim3 grid((unsigned)((w - 2 + 255) / 256), (unsigned)((h - 2 + ST_ROWS - 1) / ST_ROWS), (unsigned)bands);
+  const int cell = gm::dtype_size(dtype);
+  if (bands == 1 && (cell == 2 || cell == 4) && (h - 2 + DT_H - 1) / DT_H <= 65535) {
+    dim3 tgrid((unsigned)((w - 2 + DT_W - 1) / DT_W), (unsigned)((h - 2 + DT_H - 1) / DT_H));
+#define GM_DILT(T)                                                                                  \
+  do {                                                                                              \
+    DilateArgs<T> A;                                                                                \
+    A.n_values = n_values;                                                                          \
+    for (int i = 0; i < n_values; ++i) A.values[i] = from_bits<T>(values_bits[i]);                  \
+    hipLaunchKernelGGL(dilate_tile_kernel<T>, tgrid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, A); \
+  } while (0)
+    switch (dtype) {
+      case GM_U16: GM_DILT(unsigned short); break;
+      case GM_I16: GM_DILT(short); break;
+      case GM_U32: GM_DILT(unsigned int); break;
+      case GM_I32: GM_DILT(int); break;
+      case GM_F32: GM_DILT(float); break;
+      default: return gm::fail(GM_ERR_INVALID, "gm_dilate: dtype %d", dtype);
+    }
+#undef GM_DILT
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+  }
 #define GM_DIL(T)                                                                                    \
   do {                                                                                               \
     DilateArgs<T> A;                                                                                 \

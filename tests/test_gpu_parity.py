@@ -1055,3 +1055,18 @@ def test_moving_max_kernels_against_oracle(gpu, size, dt, ndv):
     want = O.movingmax_process({"values": v, "no_data_value": ndv}, size)["values"]
     got = stencil.moving_max(v, ndv, size).to_numpy()
     assert got.dtype == want.dtype and np.array_equal(got, want), (size, dt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["i2", "u2", "i4", "f4", "f8"])
+@pytest.mark.parametrize("shape", [(1, 45, 533), (1, 18, 258), (3, 20, 70)])
+def test_dilate_kernels_against_oracle(gpu, dt, shape):
+    """Dilate on 2- / 4-byte single-band tiles (LDS-tile kernel), on multi-band and 8-byte tiles (column
+    walker): ragged shapes around the workgroup tile, 1..3 values in order, against the oracle."""
+    from dask_geomodeling_amd.raster import stencil
+    rng = np.random.default_rng(len(dt) * 7 + shape[2])
+    v = rng.integers(0, 7, size=shape).astype(dt)
+    for values in ([1], [3, 1], [5, 0, 2]):
+        want = O.dilate_process({"values": v, "no_data_value": None}, values)["values"]
+        got = stencil.dilate(v, values).to_numpy()
+        assert got.dtype == want.dtype and np.array_equal(got, want), (dt, shape, values)
