@@ -245,6 +245,75 @@ __global__ __launch_bounds__(256) void dilate8_kernel(const unsigned char* __res
   }
 }
 
+// The same word-parallel scheme for single-band tiles, fed from an LDS tile: a workgroup stages the
+// 18 rows x 1032 bytes its 16 x 1024 outputs see (as unaligned 4-byte loads, all of a lane in flight),
+// a lane then walks 16 rows of its 4 columns reading two aligned words per row from LDS.
+constexpr int D8T_H = 16, D8T_WORDS = 258;  // window: (D8T_H + 2) rows of 258 words (1032 bytes)
+__global__ __launch_bounds__(256) void dilate8_tile_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                                           int h, int w, Dilate8Args A) {
+  __shared__ unsigned tile[(D8T_H + 2) * D8T_WORDS];
+  const int c0 = blockIdx.x * 1024, r0 = blockIdx.y * D8T_H;
+  const int ow = w - 2, oh = h - 2;
+  constexpr int CELLS = (D8T_H + 2) * D8T_WORDS, PER_LANE = (CELLS + 255) / 256;
+  unsigned staged[PER_LANE];
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) {
+    const int cell = threadIdx.x + 256 * i;
+    const int wy = min(cell / D8T_WORDS, D8T_H + 1), wd = cell - (cell / D8T_WORDS) * D8T_WORDS;
+    const int sy = min(r0 + wy, h - 1), sx = c0 + 4 * wd;
+    const unsigned char* p = in + (size_t)sy * w + sx;
+    unsigned word = 0;
+    if (sx + 4 <= w) {
+      __builtin_memcpy(&word, p, 4);
+    } else {
+      for (int j = 0; j < 4; ++j)
+        if (sx + j < w) word |= (unsigned)p[j] << (8 * j);
+    }
+    staged[i] = word;
+  }
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) {
+    const int cell = threadIdx.x + 256 * i;
+    if (cell < CELLS) tile[cell] = staged[i];
+  }
+  __syncthreads();
+  const int c4 = c0 + 4 * threadIdx.x;
+  if (c4 >= ow) return;
+  unsigned horiz_prev[DIL8_MAX_VALUES], eq_prev[DIL8_MAX_VALUES], eq_prev2[DIL8_MAX_VALUES];
+#pragma unroll
+  for (int k = 0; k < DIL8_MAX_VALUES; ++k) horiz_prev[k] = eq_prev[k] = eq_prev2[k] = 0;
+  unsigned centre_prev = 0;
+#pragma unroll
+  for (int y = 0; y < D8T_H + 2; ++y) {
+    const unsigned lo = tile[y * D8T_WORDS + threadIdx.x], hi = tile[y * D8T_WORDS + threadIdx.x + 1];
+    const unsigned west = lo, centre = __builtin_amdgcn_alignbyte(hi, lo, 1), east = __builtin_amdgcn_alignbyte(hi, lo, 2);
+    unsigned result = centre_prev;
+#pragma unroll
+    for (int k = 0; k < DIL8_MAX_VALUES; ++k) {
+      if (k < A.n_values) {
+        const unsigned v = A.splat[k];
+        const unsigned eq = bytes_equal(centre, v);
+        const unsigned horiz = eq | bytes_equal(west, v) | bytes_equal(east, v);
+        const unsigned hit = horiz_prev[k] | eq_prev2[k] | eq;  // centre row y - 1: its own row, the rows above and below
+        result = (result & ~hit) | (v & hit);
+        eq_prev2[k] = eq_prev[k];
+        eq_prev[k] = eq;
+        horiz_prev[k] = horiz;
+      }
+    }
+    centre_prev = centre;
+    const int orow = r0 + y - 2;
+    if (y >= 2 && orow < oh) {
+      unsigned char* o = out + (size_t)orow * ow + c4;
+      if (c4 + 4 <= ow) {
+        __builtin_memcpy(o, &result, 4);
+      } else {
+        for (int j = 0; c4 + j < ow; ++j) o[j] = (unsigned char)(result >> (8 * j));
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // MovingMax
 // ---------------------------------------------------------------------------------
@@ -759,6 +828,12 @@ int gm_dilate(const void* in, int dtype, int bands, int h, int w, const uint64_t
     Dilate8Args A8;
     A8.n_values = n_values;
     for (int i = 0; i < DIL8_MAX_VALUES; ++i) A8.splat[i] = i < n_values ? 0x01010101u * (unsigned)(values_bits[i] & 0xffu) : 0u;
+    if (bands == 1 && (h - 2 + D8T_H - 1) / D8T_H <= 65535) {
+      dim3 tgrid8((unsigned)((w - 2 + 1023) / 1024), (unsigned)((h - 2 + D8T_H - 1) / D8T_H));
+      hipLaunchKernelGGL(dilate8_tile_kernel, tgrid8, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, h, w, A8);
+      GM_HIP(hipGetLastError());
+      return GM_OK;
+    }
     dim3 grid8((unsigned)((w - 2 + 1023) / 1024), (unsigned)((h - 2 + D8_ROWS - 1) / D8_ROWS), (unsigned)bands);
     if (grid8.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: tile taller than %d rows", 65535 * D8_ROWS);
     hipLaunchKernelGGL(dilate8_kernel, grid8, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, bands, h, w, A8);
