@@ -7,7 +7,9 @@ mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
 for w in reclass bilinear mosaic tiler; do
   rm -rf "$OUT/prof_$w"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$w" -- python3 "$REPO/bench.py" --workload $w --steps 3 --warmup 1 > "$OUT/bench_$w.log" 2> "$OUT/bench_$w.err"
+  # (the cheap workloads need more steps than the 20 ms mosaic for a timed region of some milliseconds)
+  STEPS=30; [ $w = mosaic ] && STEPS=5
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$w" -- python3 "$REPO/bench.py" --workload $w --steps $STEPS --warmup 3 > "$OUT/bench_$w.log" 2> "$OUT/bench_$w.err"
   grep '^{' "$OUT/bench_$w.log" | cut -c1-330
   tail -2 "$OUT/bench_$w.err"
 done
