@@ -362,7 +362,8 @@ def main():
         else:
             px_per_step = world * tiles * out_side * out_side
             scaling = "weak"
-        bytes_px = {"reclass": 5, "bilinear": 5, "mosaic": None, "tiler": 12}[args.workload]
+        # mosaic: one fused program per tile reads its four float32 leaves and writes uint8 (4 x 4 + 1)
+        bytes_px = {"reclass": 5, "bilinear": 5, "mosaic": 17, "tiler": 12}[args.workload]
         value = px_per_step * args.steps / elapsed / 1e6
         out = {"metric": "Mpix/s, workload %s" % args.workload, "value": round(value, 1), "unit": "Mpix/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
