@@ -1,0 +1,38 @@
+"""One-off: random shapes / dtypes through the stencil kernels against the oracle (GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from dask_geomodeling_amd.hip import runtime
+from dask_geomodeling_amd.raster import stencil
+from oracle import ref_numpy as O
+runtime.set_device(0)
+rng = np.random.default_rng(2026)
+bad = 0
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+for it in range(N):
+    dt = ["u1", "i1", "i2", "u2", "i4", "f4", "f8"][int(rng.integers(7))]
+    bands = int(rng.integers(1, 4))
+    size = [3, 3, 5, 7, 9, 11, 13, 15, 17][int(rng.integers(9))]
+    h, w = int(rng.integers(size + 1, 80)), int(rng.integers(size + 1, 700))
+    if np.dtype(dt).kind == "f":
+        v = (rng.random((bands, h, w)) * 20 - 5).astype(dt); ndv = np.dtype(dt).type(-9999.0)
+    else:
+        v = rng.integers(0, 9, size=(bands, h, w)).astype(dt); ndv = np.dtype(dt).type(7)
+    v[rng.random(v.shape) < 0.2] = ndv
+    try:
+        want = O.movingmax_process({"values": v, "no_data_value": ndv}, size)["values"]
+        got = stencil.moving_max(v, ndv, size).to_numpy()
+        assert np.array_equal(got, want), "movingmax"
+        vals = [int(x) for x in rng.integers(0, 9, size=int(rng.integers(1, 5)))]
+        want = O.dilate_process({"values": v, "no_data_value": ndv}, vals)["values"]
+        got = stencil.dilate(v, vals).to_numpy()
+        assert np.array_equal(got, want), "dilate"
+        kw = dict(resolution=(float(rng.choice([0.5, 1.0, 2.0, 3.0])), float(rng.choice([0.5, 1.0, 0.7]))), altitude=45.0, azimuth=315.0, fill=int(rng.integers(0, 3)))
+        want = O.hillshade_process({"values": v, "no_data_value": ndv}, kw)["values"]
+        got = stencil.hillshade(v, ndv, kw["fill"], kw["resolution"], kw["altitude"], kw["azimuth"]).to_numpy()
+        d = np.abs(got.astype("i2") - want.astype("i2"))
+        assert d.max(initial=0) <= 1 and (d != 0).mean() <= 0.02, "hillshade max %d frac %.3f" % (d.max(), (d != 0).mean())
+    except AssertionError as e:
+        bad += 1
+        print("FAIL", it, dt, (bands, h, w), size, e)
+print("done", N, "failures", bad)
