@@ -1,4 +1,5 @@
-"""One-off: many more fuzz seeds than the test suite runs (GPU box)."""
+"""Many more fuzz seeds than the test suite runs (GPU box): python tests/fuzz_more.py [n].  Lives under tests/
+because it checks against the oracle."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

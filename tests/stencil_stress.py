@@ -1,4 +1,5 @@
-"""One-off: random shapes / dtypes through the stencil kernels against the oracle (GPU box)."""
+"""Random shapes / dtypes through the stencil kernels against the oracle (GPU box): python tests/stencil_stress.py [n].
+Lives under tests/ because it checks against the oracle."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
