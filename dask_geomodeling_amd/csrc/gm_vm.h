@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
     const unsigned magic = GM_KARG(K, div_magic), sh1 = GM_KARG(K, div_sh1), sh2 = GM_KARG(K, div_sh2);
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-      const unsigned g32 = (unsigned)(g0 + 256ull * u);
+      const unsigned g32 = (unsigned)min(g0 + 256ull * u, n_groups - 1);  // (clamped like the loads below)
       const unsigned t = __umulhi(g32, magic);
       row_of[u] = (t + ((g32 - t) >> sh1)) >> sh2;
       col_of[u] = (g32 - row_of[u] * cols4) << 2;
@@ -1035,9 +1035,10 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
           const V4* const p = (const V4*)in_ptr[k];
 #pragma unroll
           for (int u = 0; u < G; ++u) {
-            const unsigned long long g = g0 + 256ull * u;
-            V4 x = {0, 0, 0, 0};
-            if (g < n_groups) x = ld((const V4*)((const RC*)p + elem_offset(k, u, g)), nt_ld);
+            // (groups past the tile re-read its last group: an unconditional load -- no zero fill, no
+            //  branch around it -- whose result is computed on and never stored)
+            const unsigned long long g = min(g0 + 256ull * u, n_groups - 1);
+            const V4 x = ld((const V4*)((const RC*)p + elem_offset(k, u, g)), nt_ld);
 #pragma unroll
             for (int q = 0; q < 4; ++q) M.in[k][4 * u + q] = x[q];
           }
