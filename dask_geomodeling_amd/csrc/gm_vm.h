@@ -352,6 +352,7 @@ template <typename RC, int N, int NIN, int NT, int FLAVOR>
 struct Machine {
   static constexpr bool HEAVY = FLAVOR == VM_MATH;
   static constexpr bool TABLES = FLAVOR == VM_TABLES;
+  static constexpr bool FOLD_LD = FLAVOR == VM_LIGHT && NIN <= 2;  // kernels that accept "LD folded into the op"
   RC in[NIN][N];
   RC tmp0[N], tmp1[N], tmp2[N], tmp3[N];  // separate members, selected at compile time only: an
   RC acc[N];                               // array of arrays ends up in scratch for NT >= 2
@@ -904,6 +905,14 @@ struct Machine {
                     scalar_of<RC>(U.fill));
       }
     } else if (kind >= UOP_ADD) {
+      // bits 16-23 of the route: a tile / temp to load into the accumulator first (a leading LD folded
+      // into the operation by lower(): one micro-op fetch and decode less)
+      // (only the small LIGHT kernels: in the others the extra operand select costs registers -- the
+      //  4-input LIGHT kernel went from 95 to 97 VGPRs, i.e. from 5 to 4 waves per SIMD)
+      if constexpr (FOLD_LD) {
+        const unsigned first = (U.route >> 16) & 0xffu;
+        if (first) select(first, acc);
+      }
       if (src == UOP_SRC_SCALAR) {
         fast_op<true>(U, kind, acc);
       } else {
