@@ -249,7 +249,18 @@ def main():
     if world > 1:
         import torch.distributed as dist  # timing barrier / max-reduce only (no data-path collective)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its peers on stdout ("[Gloo] Rank 0 is connected to ..."): stdout belongs to the one
+        # JSON line, so file descriptor 1 points at stderr while the process group is set up
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     defaults = {"chain5": (4096, 16), "reclass": (8192, 4), "bilinear": (16384, 1), "mosaic": (4096, 0),
                 "tiler": (16384, 1)}
