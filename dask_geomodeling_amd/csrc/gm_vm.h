@@ -763,15 +763,19 @@ struct Machine {
     if constexpr (is_float_class<RC>::value) {
       a_ndv = a_has ? a_ndv : (RC)__builtin_nanf("");
       b_ndv = b_has ? b_ndv : (RC)__builtin_nanf("");
+      // no-data tests first (lane masks), then the operation IN PLACE: the old accumulator value is dead
+      // when its result is born, so the result can keep its register (with the test after the operation
+      // both are live at once, the result lands elsewhere, and every micro-op ends in N register moves)
+      bool nodata[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) {
-        const RC x = acc[k];
-        const RC y = B_SCALAR ? b_lit : b[k];
-        RC r = f(x, y);
-        r = (x == a_ndv) ? fill : r;
-        if constexpr (!B_SCALAR) r = (y == b_ndv) ? fill : r;
-        acc[k] = finite_rc<RC>(r) ? r : fill;
+        nodata[k] = acc[k] == a_ndv;
+        if constexpr (!B_SCALAR) nodata[k] = nodata[k] | (b[k] == b_ndv);
       }
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] = f(acc[k], B_SCALAR ? b_lit : b[k]);
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] = (nodata[k] | !finite_rc<RC>(acc[k])) ? fill : acc[k];
     } else {
 #pragma unroll
       for (int k = 0; k < N; ++k) {

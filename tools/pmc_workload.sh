@@ -4,7 +4,7 @@ R=$PWD
 W=${1:-reclass}
 cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_wl
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --kernel-trace --output-format csv -d $R/gpurun_out/pmc_wl -- python3 $R/bench.py --workload $W --steps 3 --warmup 1 --no-check > $R/gpurun_out/pmc_wl.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --kernel-trace --output-format csv -d $R/gpurun_out/pmc_wl -- python3 $R/bench.py --workload $W --steps 10 --warmup 3 --no-check --cpu-tiles 0 > $R/gpurun_out/pmc_wl.log 2>&1
 cd $R
 python - "$2" <<'PY'
 import csv, glob, collections, sys
