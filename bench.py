@@ -55,8 +55,12 @@ def parse_args():
     p.add_argument("--tiles", type=int, default=0, help="tiles per GPU per step (0 = the workload's default)")
     p.add_argument("--cpu-tiles", type=int, default=-1, help="tiles of the CPU baseline sample (0 = skip)")
     p.add_argument("--no-check", action="store_true", help="skip the oracle check of one tile")
-    p.add_argument("--procedural", action="store_true",
-                   help="mosaic: generate every leaf window on the fly instead of keeping the 4 x 16 GiB leaves resident")
+    p.add_argument("--leaves", default="owned", choices=["owned", "whole", "procedural"],
+                   help="mosaic leaves: owned = every rank keeps the leaf windows of the tiles it owns resident "
+                        "(4 x 16 GiB / N per GPU, generated on the owning GPU during warm-up); whole = every rank "
+                        "holds the four whole 16 GiB leaves as MemorySources (tiles = zero-copy windows); "
+                        "procedural = every window is regenerated on the fly inside the timed region")
+    p.add_argument("--procedural", action="store_true", help="same as --leaves procedural")
     p.add_argument("--dry-run", action="store_true",
                    help="exercise the multi-rank timing harness without a GPU (every tile is a 0.2 ms sleep); "
                         "used by the CPU gloo test, never a measurement")
@@ -143,20 +147,21 @@ def build_tiler(raster, side, tile, rank):
 MOSAIC_SIDE = 65536
 
 
-def mosaic_view(raster, resident=True):
+def mosaic_view(raster, leaves="owned"):
     """configs[4]: 10 Blocks (Add, Multiply, Subtract, Divide, Greater, Clip, Classify, Reclassify, Mask
-    under a RasterTiler) over four float32 leaves of a 65536^2 mosaic.  resident: the leaves are
-    MemorySources holding the whole mosaic in HBM (4 x 16 GiB per GPU; tile requests are zero-copy
-    windows); otherwise SyntheticSources that generate every requested window on the fly."""
+    under a RasterTiler) over four float32 leaves of a 65536^2 mosaic.  leaves: "owned" = procedural
+    sources that keep every window they served resident, so a rank holds the leaf windows of ITS tiles
+    only (64 GiB / N per GPU); "whole" = MemorySources holding the whole mosaic in HBM (4 x 16 GiB on
+    every GPU; tile requests are zero-copy windows); "procedural" = every window regenerated per request."""
     from dask_geomodeling_amd.raster.sources import generate_window
 
     def leaf(seed):
-        if resident:
+        if leaves == "whole":
             data = generate_window((MOSAIC_SIDE, MOSAIC_SIDE), "f4", seed, 0.0, 100.0, F32MAX, LATTICE, 0, 0,
                                    MOSAIC_SIDE, MOSAIC_SIDE)
             return raster.MemorySource(data, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(MOSAIC_SIDE)))
         return raster.SyntheticSource((MOSAIC_SIDE, MOSAIC_SIDE), "f4", seed, 0.0, 100.0, F32MAX, LATTICE,
-                                      "EPSG:28992", 1.0, (0.0, float(MOSAIC_SIDE)))
+                                      "EPSG:28992", 1.0, (0.0, float(MOSAIC_SIDE)), resident=(leaves == "owned"))
     A, B, C, D = leaf(11), leaf(12), leaf(13), leaf(14)
     x = raster.Divide(raster.Subtract(raster.Multiply(raster.Add(A, B), 0.5), C), 2.0)
     x = raster.Clip(x, raster.Greater(D, 20.0))
@@ -165,12 +170,12 @@ def mosaic_view(raster, resident=True):
     return raster.Mask(x, 1)
 
 
-def build_mosaic(raster, tile, rank, world, resident=True):
+def build_mosaic(raster, tile, rank, world, leaves="owned"):
     """The tile sub-graphs of RasterTiler(view, tile) over the whole mosaic that this rank owns."""
     from dask_geomodeling_amd import shard
     from dask_geomodeling_amd.fuse import fuse_graph
 
-    tiler = raster.RasterTiler(mosaic_view(raster, resident), tile)
+    tiler = raster.RasterTiler(mosaic_view(raster, leaves), tile)
     request = dict(mode="vals", bbox=(0.0, 0.0, float(MOSAIC_SIDE), float(MOSAIC_SIDE)), width=MOSAIC_SIDE,
                    height=MOSAIC_SIDE, projection="EPSG:28992")
     graph, name = tiler.get_compute_graph(**request)
@@ -239,11 +244,53 @@ def pmc_traffic(side, tiles_per_launch):
         return None, None
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes of this very
+    command (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, one per GPU), relay rank 0's
+    JSON line and return non-zero if any rank failed.  The parent never touches the GPU (no HIP call, no
+    library load) and never exec()s: the ranks are ordinary children."""
+    import subprocess
+    port = str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, cwd=os.getcwd()))
+    line, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=120))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(p.wait())
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench: rank(s) failed: %s\n" % bad)
+        return 1
+    return 0
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world))
 
     dist = None
     if world > 1:
@@ -310,7 +357,7 @@ def main():
         elif args.workload == "tiler":
             jobs = build_tiler(raster, side, 4096, rank)
         else:
-            jobs, n_mosaic_tiles = build_mosaic(raster, side, rank, world, resident=not args.procedural)
+            jobs, n_mosaic_tiles = build_mosaic(raster, side, rank, world, leaves="procedural" if args.procedural else args.leaves)
             tiles = len(jobs[0][1])
         runtime.sync()
 

@@ -1,5 +1,6 @@
 // libgmhip runtime: devices, one compute stream per device, caching allocator,
 // copies, events, error reporting.  Plain HIP for gfx950; no torch, no shims.
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -84,8 +85,20 @@ static int ensure_device(int dev, DeviceState** out) {
   return GM_OK;
 }
 
+// The device chosen with gm_set_device is the PROCESS's device (one worker process per GPU): HIP's own
+// current device is per thread and starts at 0, so the pool threads of a threaded dask scheduler would
+// otherwise allocate and launch on device 0 while the tiles live on device k.  Every entry point goes
+// through current(), which points a thread that has not been pointed yet at the process's device.
+static std::atomic<int> g_process_dev{-1};
+static thread_local int t_bound_dev = -1;
+
 static int current(DeviceState** out) {
   if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  int want = g_process_dev.load(std::memory_order_acquire);
+  if (want >= 0 && t_bound_dev != want) {
+    GM_HIP(hipSetDevice(want));
+    t_bound_dev = want;
+  }
   int dev = 0;
   GM_HIP(hipGetDevice(&dev));
   return ensure_device(dev, out);
@@ -132,6 +145,8 @@ int gm_set_device(int device) {
   if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
   if (device < 0 || device >= g_ndev) return fail(GM_ERR_INVALID, "device %d out of range", device);
   GM_HIP(hipSetDevice(device));
+  g_process_dev.store(device, std::memory_order_release);
+  t_bound_dev = device;
   DeviceState* d = nullptr;
   return ensure_device(device, &d);
 }
@@ -139,6 +154,9 @@ int gm_set_device(int device) {
 int gm_get_device(int* device) {
   if (!device) return fail(GM_ERR_INVALID, "null pointer");
   if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  DeviceState* d = nullptr;
+  int rc = current(&d);
+  if (rc) return rc;
   GM_HIP(hipGetDevice(device));
   return GM_OK;
 }

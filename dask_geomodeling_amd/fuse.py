@@ -100,12 +100,21 @@ class FusedTask(object):
         except TypeError:
             return False
 
+    @staticmethod
+    def _ndv_key(ndv):
+        # a NaN no-data value must hit the cache too (NaN != NaN would miss for ever)
+        if isinstance(ndv, (float, np.floating)) and ndv != ndv:
+            return "nan"
+        return ndv
+
     def _signature(self, leaf_values):
         try:
             return tuple((v["values"].dtype.num, v["values"].shape, type(v.get("no_data_value")),
-                          v.get("no_data_value")) for v in leaf_values)
+                          self._ndv_key(v.get("no_data_value"))) for v in leaf_values)
         except (TypeError, KeyError, AttributeError):
             return None
+
+    _UNFUSABLE = ("unfusable",)  # cached verdict: this kind of tiles runs op by op
 
     def plan_for(self, leaf_values):
         """-> (stages, shape) when this kind of tiles runs as a fixed sequence of programs -- one
@@ -117,9 +126,11 @@ class FusedTask(object):
             return None
         hit = self._plans.get(sig)
         if hit is not None:
-            return hit
+            return None if hit is self._UNFUSABLE else hit
         if not all(isinstance(v, dict) and "values" in v for v in leaf_values):
             return None
+        if len(self._plans) > 64:
+            self._plans.clear()
         nodes, arg_of = {}, {}
         for i, (key, data) in enumerate(zip(self.leaf_keys, leaf_values)):
             leaf = P.Leaf(None, data["values"].dtype, data.get("no_data_value"), values=data["values"])
@@ -130,6 +141,7 @@ class FusedTask(object):
                 nodes[key] = self._node(key, nodes)
             staged, shape = P.plan_staged(nodes[self.root])
         except (_NotFusable, P.FusionLimit, NotImplementedError, TypeError):
+            self._plans[sig] = self._UNFUSABLE  # do not rebuild the node tree for every tile
             return None
         stages = []
         for compiled, leaves in staged:
@@ -142,8 +154,6 @@ class FusedTask(object):
                 else:
                     binding.append((1, l.values))  # constant ndarray operand, uploaded once
             stages.append((compiled, binding))
-        if len(self._plans) > 64:
-            self._plans.clear()
         self._plans[sig] = (stages, shape)
         return self._plans[sig]
 
@@ -311,7 +321,7 @@ class TiledAssembly(object):
         tile_x, tile_y = process_kwargs["tilesize_xy"]
         dtype, fill = np.dtype(process_kwargs["dtype"]), process_kwargs["fillvalue"]
         position = {bm: t for t, bm in enumerate(self.layout)}
-        state = {"mosaic": None}
+        state = {"mosaic": None, "covered": 0}
 
         def dest_for(b):
             def dest(member, shape, out_dtype):
@@ -324,6 +334,7 @@ class TiledAssembly(object):
                 row0, col0 = height - (iy * tile_y + th), ix * tile_x  # low y -> high rows (parallelize.py:114-124)
                 if row0 < 0 or col0 + tw > width:
                     return None
+                state["covered"] += th * tw  # the slots of distinct tiles are disjoint
                 return state["mosaic"].window(row0, col0, th, tw)
             return dest
 
@@ -338,7 +349,11 @@ class TiledAssembly(object):
         in_place = mosaic is not None and all(
             isinstance(t, dict) and isinstance(t.get("values"), DeviceArray) and t["values"]._owner is mosaic
             for t in tiles)
-        if in_place and len(tiles) == count_x * count_y:
+        # the mosaic was never filled: it only IS the result when the tiles written into it cover every
+        # pixel.  The reference's int() truncation of the tile sizes (parallelize.py:85-86) can leave a
+        # tile one pixel short of its slot for cell sizes that are not exact in binary; those pixels
+        # keep the fill value of np.full there, so such requests take the fill + paste below.
+        if in_place and len(tiles) == count_x * count_y and state["covered"] == height * width:
             return {"values": mosaic, "no_data_value": fill}
         return self.tiler_process(process_kwargs, *tiles)  # the reference's fill + paste
 

@@ -361,10 +361,17 @@ class SyntheticSource(RasterBlock):
     """Procedural single-band raster living on the device: pixel (row, col) of the
     ``shape`` = (H, W) mosaic is ``lo + u * (hi - lo)`` with u = splitmix64-uniform of
     (seed, row * W + col); every ``lattice`` = (ny, nx)-th pixel is no-data.  Requests must be
-    aligned with the pixel grid (bbox on pixel edges, one cell per pixel)."""
+    aligned with the pixel grid (bbox on pixel edges, one cell per pixel).
+
+    ``resident=True`` keeps every window it has generated in HBM (a per-device tile cache keyed by the
+    window): a worker that owns some tiles of a mosaic then holds exactly the leaf windows of those
+    tiles -- 1/N of the mosaic per GPU when the tiles are dealt over N workers -- and later requests
+    for the same tile are served without regenerating it (the responses are immutable by contract)."""
+
+    _windows = {}  # (spec, device, row0, col0, h, w) -> DeviceArray
 
     def __init__(self, shape, dtype, seed, lo, hi, no_data_value, lattice=(0, 0), projection="EPSG:28992",
-                 pixel_size=1.0, pixel_origin=(0.0, 0.0)):
+                 pixel_size=1.0, pixel_origin=(0.0, 0.0), resident=False):
         shape = tuple(int(s) for s in shape)
         if len(shape) != 2:
             raise ValueError("shape should be (height, width)")
@@ -373,7 +380,7 @@ class SyntheticSource(RasterBlock):
         super().__init__(shape, dtype, int(seed), float(lo), float(hi),
                          np.dtype(dtype).type(no_data_value).item(),
                          tuple(int(x) for x in lattice), utils.get_epsg_or_wkt(projection),
-                         float(pixel_size), tuple(float(x) for x in pixel_origin))
+                         float(pixel_size), tuple(float(x) for x in pixel_origin), bool(resident))
 
     shape = property(lambda self: self.args[0])
     dtype = property(lambda self: np.dtype(self.args[1]))
@@ -420,11 +427,26 @@ class SyntheticSource(RasterBlock):
             return {"time": [RasterBlock.DEFAULT_ORIGIN]}
         if mode == "meta":
             return {"meta": [None]}
-        shape, dtype, seed, lo, hi, ndv, lattice = process_kwargs["spec"][:7]
+        spec = process_kwargs["spec"]
+        shape, dtype, seed, lo, hi, ndv, lattice = spec[:7]
         dtype = np.dtype(dtype)
-        values = generate_window(shape, dtype, seed, lo, hi, ndv, lattice, process_kwargs["row0"],
-                                 process_kwargs["col0"], process_kwargs["height"], process_kwargs["width"])
+        window = (process_kwargs["row0"], process_kwargs["col0"], process_kwargs["height"], process_kwargs["width"])
+        resident = len(spec) > 10 and spec[10]
+        values = None
+        if resident:
+            runtime.require_device()
+            key = (tuple(spec[:7]), runtime.get_device()) + window
+            values = SyntheticSource._windows.get(key)
+        if values is None:
+            values = generate_window(shape, dtype, seed, lo, hi, ndv, lattice, *window)
+            if resident:
+                SyntheticSource._windows[key] = values
         return {"values": values, "no_data_value": dtype.type(ndv)}
+
+    @classmethod
+    def drop_resident_windows(cls):
+        """Give the cached windows of all resident SyntheticSources back to the allocator."""
+        cls._windows.clear()
 
 
 def generate_window(shape, dtype, seed, lo, hi, ndv, lattice, row0, col0, height, width):

@@ -70,7 +70,9 @@ typedef union gm_scalar {
 int gm_init(void);
 /* Number of visible devices, or 0 when HIP cannot initialise. Never fails. */
 int gm_device_count(void);
-/* Select the calling thread's current device (also creates its stream/pool). */
+/* Select the PROCESS's device (one worker process per GPU; also creates its stream/pool): every
+ * thread that enters the library afterwards -- e.g. the pool threads of dask's threaded scheduler
+ * (core/graphs.py:42-49) -- is pointed at this device, not at HIP's per-thread default 0. */
 int gm_set_device(int device);
 int gm_get_device(int* device);
 /* Device name / arch string ("gfx950...") of the current device into buf. */

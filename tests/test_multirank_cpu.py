@@ -66,6 +66,50 @@ def test_bench_harness_world_size_2_gloo():
     assert abs(out["value"] - 2 * 4 * 64 * 64 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) / out["value"] < 0.01
 
 
+@pytest.mark.timeout(300)
+def test_bench_gpus_flag_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the documented CLI): the parent starts
+    two fresh rank processes itself and relays rank 0's single JSON line."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--tiles", "4", "--side", "64", "--dry-run"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert abs(out["value"] - 2 * 4 * 64 * 64 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) / out["value"] < 0.01
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert res.returncode != 0 and "WORLD_SIZE" in res.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_gpus_flag_two_ranks_on_the_gpu_box(gpu):
+    """`python bench.py --gpus 2` on real hardware, no launcher: two self-spawned ranks (sharing the box's
+    single MI355X), for the headline chain and for the sharded mosaic view (strong scaling, every rank
+    holding only the leaf windows of the tiles it owns)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"]
+    res = subprocess.run(base + ["--steps", "10", "--warmup", "3", "--tiles", "4", "--side", "1024"],
+                         capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["roofline"]["achieved"] > 0
+    res = subprocess.run(base + ["--workload", "mosaic", "--side", "8192", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["tiles_per_gpu"] == 32
+    assert abs(out["value"] - 65536.0 ** 2 * 2 / (out["ms_per_step"] * 2e-3) / 1e6) / out["value"] < 0.01
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
 def test_bench_world_size_2_on_the_gpu_box(gpu):
