@@ -1,18 +1,30 @@
 // K1 host side: validates a gm_program and launches the VM kernel of its register
 // class (kernels: gm_vm.h, instantiated per class in gm_vm_<class>.hip).
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
 
+#include "gm_spec.h"
 #include "gm_vm.h"
 
 using namespace gmvm;
 
 namespace {
 
-gm_vm_tuning g_tuning = {0, 0, {0, 0}};
+// (measurement knob: GM_VM_VEC=4|8 presets the elements per lane, like gm_vm_set_tuning)
+gm_vm_tuning initial_tuning() {
+  gm_vm_tuning t = {0, 0, {0, 0}};
+  if (const char* e = getenv("GM_VM_VEC")) {
+    const int v = atoi(e);
+    if (v == 4 || v == 8) t.vec = v;
+  }
+  return t;
+}
+gm_vm_tuning g_tuning = initial_tuning();
 
 int validate_operand(const gm_operand& o, unsigned n_inputs, const char* which, unsigned step) {
   const unsigned kind = o.bits & 0xffu, index = (o.bits >> 8) & 0xffu;
@@ -256,6 +268,13 @@ struct CodeEntry {
   // kernel of gm_tables.hip
   bool lookup_only = false;
   gm::Lookup32 lookup;
+  // specialised kernels of this program (gm_spec.hip), resolved on first hot use: [strided][G - 1]
+  int n_temps = 0;
+  std::vector<size_t> table_offset;     // word offset of table t in `staged`
+  mutable std::atomic<unsigned long long> elements_seen{0};
+  mutable std::mutex spec_mu;
+  mutable gmspec::Kernel spec[2][2];
+  mutable bool spec_tried[2][2] = {{false, false}, {false, false}};
 };
 
 std::mutex g_code_mu;
@@ -335,12 +354,10 @@ int byte_ramp(hipStream_t stream, void** out) {
   return GM_OK;
 }
 
-int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) {
-  int device = 0;
-  GM_HIP(hipGetDevice(&device));
-  // only the used part of the program is meaningful: canonicalise the rest so that equal
-  // programs hash equal whatever the caller left in the unused slots
-  gm_program key;
+// canonical key of a program (only the used part is meaningful: equal programs hash equal whatever the
+// caller left in the unused slots) + the words of its tables
+int canonical_key(const gm_program* prog, gm_program* key_out, std::vector<unsigned long long>* words) {
+  gm_program& key = *key_out;
   memset(&key, 0, sizeof(key));
   key.n_steps = prog->n_steps;
   key.n_inputs = prog->n_inputs;
@@ -351,25 +368,20 @@ int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) 
   memcpy(key.inputs, prog->inputs, sizeof(gm_input_desc) * prog->n_inputs);
   memcpy(key.steps, prog->steps, sizeof(gm_step) * prog->n_steps);
   key.n_tables = prog->n_tables;
-  std::vector<unsigned long long> words;
   for (unsigned t = 0; t < prog->n_tables; ++t) {
     if (!prog->tables[t].data && prog->tables[t].n_words) return gm::fail(GM_ERR_INVALID, "table %u is null", t);
     if (prog->tables[t].n_words > (1ull << 24)) return gm::fail(GM_ERR_UNSUPPORTED, "table %u too large", t);
     key.tables[t].n_words = prog->tables[t].n_words;  // pointers stay null in the key
     const unsigned long long* w = (const unsigned long long*)prog->tables[t].data;
-    words.insert(words.end(), w, w + prog->tables[t].n_words);
+    words->insert(words->end(), w, w + prog->tables[t].n_words);
   }
-  const unsigned long long h = hash_program(key, words, device);
-  std::lock_guard<std::mutex> lk(g_code_mu);
-  auto& bucket = g_code[h];
-  for (auto& e : bucket)
-    if (memcmp(&e->prog, &key, sizeof(key)) == 0 && e->tables == words) {
-      *out = e.get();
-      return GM_OK;
-    }
+  return GM_OK;
+}
+
+// host half of a CodeEntry: validate, lower, classify, stage the tables (no device needed)
+int build_entry(const gm_program& key, const std::vector<unsigned long long>& words, CodeEntry* e) {
   int rc = validate(&key);
   if (rc) return rc;
-  std::unique_ptr<CodeEntry> e(new CodeEntry);
   e->prog = key;
   e->tables = words;
   memset(&e->host, 0, sizeof(VmCode));
@@ -392,6 +404,7 @@ int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) 
     for (const gm_operand* o : {&S.a, &S.b})
       if ((o->bits & 0xffu) == GM_OPD_TEMP && ((o->bits >> 8) & 0xffu) + 1 > max_tmp) max_tmp = ((o->bits >> 8) & 0xffu) + 1;
   }
+  e->n_temps = (int)max_tmp;
   e->size = (key.n_inputs <= 2 && max_tmp <= 1) ? 0 : ((key.n_inputs <= 4 && max_tmp <= 2) ? 1 : 2);
   if (has_math && has_tables)
     return gm::fail(GM_ERR_UNSUPPORTED, "pow/exp/log and table lookups in one program (split it)");
@@ -411,7 +424,8 @@ int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) 
   //   edge <= x  <=>  ceil32(edge) <= x   (smallest float32 >= edge)
   //   edge <  x  <=>  floor32(edge) < x   (largest float32 <= edge)
   e->staged = words;
-  std::vector<size_t> offset(key.n_tables + 1, 0);
+  std::vector<size_t>& offset = e->table_offset;
+  offset.assign(key.n_tables + 1, 0);
   for (unsigned t = 0; t < key.n_tables; ++t) offset[t + 1] = offset[t] + key.tables[t].n_words;
   if (key.reg_class == GM_CLASS_F32) {
     for (unsigned s = 0; s < key.n_steps; ++s) {
@@ -430,6 +444,45 @@ int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) 
       }
     }
   }
+  return GM_OK;
+}
+
+gmspec::Request spec_request(const CodeEntry& e, bool strided, int G) {
+  gmspec::Request r;
+  r.host = &e.host;
+  r.n_uops = e.n_uops;
+  r.n_inputs = e.prog.n_inputs;
+  r.reg_class = e.prog.reg_class;
+  r.out_dtype = e.prog.out_dtype;
+  r.flavor = e.flavor;
+  r.n_temps = e.n_temps;
+  r.native = e.native;
+  r.strided = strided;
+  r.G = G;
+  r.tables = &e.staged;
+  r.table_offset = e.table_offset;
+  return r;
+}
+
+int get_code(const gm_program* prog, hipStream_t stream, const CodeEntry** out) {
+  int device = 0;
+  GM_HIP(hipGetDevice(&device));
+  gm_program key;
+  std::vector<unsigned long long> words;
+  int rc = canonical_key(prog, &key, &words);
+  if (rc) return rc;
+  const unsigned long long h = hash_program(key, words, device);
+  std::lock_guard<std::mutex> lk(g_code_mu);
+  auto& bucket = g_code[h];
+  for (auto& e : bucket)
+    if (memcmp(&e->prog, &key, sizeof(key)) == 0 && e->tables == words) {
+      *out = e.get();
+      return GM_OK;
+    }
+  std::unique_ptr<CodeEntry> e(new CodeEntry);
+  rc = build_entry(key, words, e.get());
+  if (rc) return rc;
+  const std::vector<size_t>& offset = e->table_offset;
   void* dev = nullptr;
   rc = gm_malloc(&dev, sizeof(VmCode) + e->staged.size() * 8 + 64);  // (+: DIGITIZE reads its edges four at a time)
   if (rc) return rc;
@@ -600,6 +653,17 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
   if (code->flavor == VM_TABLES && code->prog.reg_class != GM_CLASS_F32 && g_tuning.vec == 0) G = 1;
   const int max_batch = g_tuning.max_batch > 0 ? g_tuning.max_batch : GM_MAX_BATCH;
   const int cus = gm::current_cu_count();
+  // hot programs run as kernels of their own (gm_spec.hip); everything else -- and the scalar tails --
+  // on the interpreter kernels
+  const int spec_mode = gmspec::mode();
+  bool want_spec = false;
+  if (spec_mode == 2) {
+    want_spec = true;
+  } else if (spec_mode == 1) {
+    const unsigned long long seen = code->elements_seen.fetch_add((unsigned long long)n * (unsigned long long)n_tiles) +
+                                    (unsigned long long)n * (unsigned long long)n_tiles;
+    want_spec = seen >= gmspec::hot_elements();
+  }
 
   for (int t0 = 0; t0 < n_tiles; t0 += max_batch) {
     const int nb = n_tiles - t0 < max_batch ? n_tiles - t0 : max_batch;
@@ -653,10 +717,22 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
     }
     args.n_groups = aligned ? n / 4 : 0;
     args.tail_start = args.n_groups * 4;
+    gmspec::Kernel spec;
+    if (want_spec && args.n_groups) {
+      std::lock_guard<std::mutex> lock(code->spec_mu);
+      const int si = strided ? 1 : 0, gi = G - 1;
+      if (!code->spec_tried[si][gi]) {
+        code->spec_tried[si][gi] = true;
+        rc = gmspec::get_kernel(spec_request(*code, strided, G), &code->spec[si][gi]);
+        if (rc) return rc;
+      }
+      spec = code->spec[si][gi];
+    }
+    const bool stage_lds = code->flavor == VM_TABLES && code->lds_table && (!spec.function || spec.stages_lds);
     const unsigned long long per_block = 256ull * G;
     unsigned long long blocks = (args.n_groups + per_block - 1) / per_block;
     args.spans = 1;
-    if (code->flavor == VM_TABLES && code->lds_table) {
+    if (stage_lds) {
       // a workgroup that stages W bytes of table streams >= 10 W bytes of tiles
       args.lds_table = code->lds_table;
       args.lds_words = code->lds_words;
@@ -679,6 +755,16 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
     const unsigned long long tail_cap = (unsigned long long)(cus > 0 ? cus : 256) * 8;
     if (tail_blocks > tail_cap) tail_blocks = tail_cap;
     dim3 grid((unsigned)blocks, (unsigned)nb), tail_grid((unsigned)tail_blocks, (unsigned)nb);
+    if (spec.function && grid.x) {
+      rc = gmspec::launch(spec, args, grid.x, grid.y, stage_lds ? (size_t)args.lds_words * 8 : 0, stream);
+      if (rc) return rc;
+      grid.x = 0;  // the interpreter only runs the scalar tail (if any)
+      if (!tail_grid.x) continue;
+      if (!stage_lds && code->lds_table) {  // the tail kernel stages its LOOKUP window itself
+        args.lds_table = code->lds_table;
+        args.lds_words = code->lds_words;
+      }
+    }
     switch (code->prog.reg_class) {
       case GM_CLASS_F32: rc = launch_class<float>(args, code->size, G, code->flavor, grid, tail_grid, stream); break;
       case GM_CLASS_F64: rc = launch_class<double>(args, code->size, G, code->flavor, grid, tail_grid, stream); break;
@@ -687,6 +773,47 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
     }
     if (rc) return rc;
   }
+  return GM_OK;
+}
+
+/* The HIP source the specialiser generates for `prog` (no device needed): copies at most len - 1 bytes into
+ * buf, *needed = strlen + 1.  group = 1 or 2 (4 or 8 elements per lane). */
+int gm_spec_source(const gm_program* prog, int strided, int group, char* buf, size_t len, size_t* needed) {
+  if (!prog) return gm::fail(GM_ERR_INVALID, "null program");
+  gm_program key;
+  std::vector<unsigned long long> words;
+  int rc = canonical_key(prog, &key, &words);
+  if (rc) return rc;
+  CodeEntry e;
+  rc = build_entry(key, words, &e);
+  if (rc) return rc;
+  const std::string src = gmspec::generate(spec_request(e, strided != 0, group == 2 ? 2 : 1), nullptr);
+  if (needed) *needed = src.size() + 1;
+  if (buf && len) {
+    const size_t m = src.size() < len - 1 ? src.size() : len - 1;
+    memcpy(buf, src.data(), m);
+    buf[m] = 0;
+  }
+  return GM_OK;
+}
+
+/* Generate and compile (hiprtc, gfx950) the specialised kernel of `prog` without loading it: a build
+ * check that needs no device.  *code_bytes = size of the code object. */
+int gm_spec_compile_check(const gm_program* prog, int strided, int group, size_t* code_bytes) {
+  if (!prog) return gm::fail(GM_ERR_INVALID, "null program");
+  gm_program key;
+  std::vector<unsigned long long> words;
+  int rc = canonical_key(prog, &key, &words);
+  if (rc) return rc;
+  CodeEntry e;
+  rc = build_entry(key, words, &e);
+  if (rc) return rc;
+  const std::string src = gmspec::generate(spec_request(e, strided != 0, group == 2 ? 2 : 1), nullptr);
+  std::vector<char> code;
+  std::string log;
+  rc = gmspec::compile(src, &code, &log);
+  if (rc) return rc;
+  if (code_bytes) *code_bytes = code.size();
   return GM_OK;
 }
 

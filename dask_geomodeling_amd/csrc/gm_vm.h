@@ -23,11 +23,43 @@
 //
 // No MFMA: the path is element-wise and HBM-bound (12 B/px for the canonical chain).
 #pragma once
+#ifdef __HIPCC_RTC__
+// Compiled at run time by hiprtc (gm_spec.hip: kernels specialised per program): no host headers there.
+// hiprtc predeclares the device runtime (math functions, __umulhi, threadIdx ...); what this file uses
+// of the standard library is declared here.
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef short int16_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long uintptr_t;
+#define offsetof(t, m) __builtin_offsetof(t, m)
+namespace std {
+template <typename A, typename B> struct is_same { static constexpr bool value = false; };
+template <typename A> struct is_same<A, A> { static constexpr bool value = true; };
+template <bool C, typename A, typename B> struct conditional { typedef A type; };
+template <typename A, typename B> struct conditional<false, A, B> { typedef B type; };
+template <typename T> struct is_integral { static constexpr bool value = false; };
+template <> struct is_integral<signed char> { static constexpr bool value = true; };
+template <> struct is_integral<unsigned char> { static constexpr bool value = true; };
+template <> struct is_integral<short> { static constexpr bool value = true; };
+template <> struct is_integral<unsigned short> { static constexpr bool value = true; };
+template <> struct is_integral<int> { static constexpr bool value = true; };
+template <> struct is_integral<unsigned int> { static constexpr bool value = true; };
+template <> struct is_integral<long long> { static constexpr bool value = true; };
+template <> struct is_integral<unsigned long long> { static constexpr bool value = true; };
+}  // namespace std
+#include "gmhip.h"
+#else
 #include <cmath>
 #include <cstddef>
 #include <type_traits>
 
 #include "gm_common.h"
+#endif
 
 namespace gmvm {
 
@@ -171,6 +203,20 @@ template <> __device__ __forceinline__ float scalar_of<float>(const gm_scalar& s
 template <> __device__ __forceinline__ double scalar_of<double>(const gm_scalar& s) { return s.f64; }
 template <> __device__ __forceinline__ int scalar_of<int>(const gm_scalar& s) { return s.i32; }
 template <> __device__ __forceinline__ long long scalar_of<long long>(const gm_scalar& s) { return (long long)s.i64; }
+
+// a literal of a generated kernel: the 8 bytes of a gm_scalar -> the register class' value
+template <typename RC> __device__ __forceinline__ RC lit(unsigned long long bits) {
+  gm_scalar s;
+  s.u64 = bits;
+  return scalar_of<RC>(s);
+}
+// packs of such literals (gm_spec.hip hands tables over as template arguments), and a DIGITIZE edge
+template <unsigned long long... V> struct Bits {};
+template <typename E> __device__ __forceinline__ E edge_of(unsigned long long bits) {
+  if constexpr (std::is_same<E, float>::value) return __builtin_bit_cast(float, (unsigned)bits);
+  else if constexpr (std::is_same<E, double>::value) return __builtin_bit_cast(double, bits);
+  else return (E)(long long)bits;
+}
 
 // ---- typed loads of N (1 or 4) consecutive elements starting at element e ----
 // `native` (64-bit integer tiles in the F64 class only): cells equal to nv -- compared as
@@ -575,6 +621,62 @@ struct Machine {
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) acc[k] = idx[k] < range ? hit[k] : acc[k];
+  }
+
+  // ---- the table ops with their tables as LITERALS (kernels specialised per program, gm_spec.hip):
+  // the same decisions as op_digitize / op_lookup above, without table loads, LDS staging or barrier.
+  // The literals travel as packs of bit patterns (Bits<...>), expanded with fold expressions: a local
+  // array of them would be an alloca, which the backend may "promote" to LDS and index dynamically.
+  template <typename E, unsigned long long... EB>
+  __device__ __forceinline__ void op_digitize_lit(Bits<EB...>, const bool right, const bool a_has, const RC a_ndv,
+                                                  const RC fill) {
+    constexpr int NB = (int)sizeof...(EB);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const E x = (E)acc[k];
+      int c = 0;
+      ((c += (right ? (edge_of<E>(EB) < x) : (edge_of<E>(EB) <= x)) ? 1 : 0), ...);
+      if constexpr (is_float_class<RC>::value) c = (acc[k] != acc[k]) ? NB : c;  // NaN sorts to the end
+      acc[k] = (a_has & (acc[k] == a_ndv)) ? fill : (RC)c;
+    }
+  }
+
+  // DIGITIZE followed by LOOKUP (Reclassify(Classify(x)), the class raster idiom): the lookup's result is a
+  // function of the edge count, tabulated by the specialiser -- M0 for no edge below the value, the k-th MB
+  // once the k-th edge is below it (edges ascend, so the edges below a value are a prefix and the last
+  // satisfied compare selects the count; the specialiser drops edges that do not change the result),
+  // map_nan for NaN, map_fill for a no-data cell.  One compare + one select per remaining edge.
+  template <typename E, unsigned long long M0, unsigned long long... EB, unsigned long long... MB>
+  __device__ __forceinline__ void op_digimap_lit(Bits<EB...>, Bits<M0, MB...>, const bool right, const bool a_has,
+                                                 const RC a_ndv, const RC map_nan, const RC map_fill) {
+    static_assert(sizeof...(EB) == sizeof...(MB), "one result per edge");
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const E x = (E)acc[k];
+      RC r = lit<RC>(M0);
+      ((r = (right ? (edge_of<E>(EB) < x) : (edge_of<E>(EB) <= x)) ? lit<RC>(MB) : r), ...);
+      if constexpr (is_float_class<RC>::value) r = (acc[k] != acc[k]) ? map_nan : r;  // NaN sorts to the end
+      acc[k] = (a_has & (acc[k] == a_ndv)) ? map_fill : r;
+    }
+  }
+
+  // small dense windows (<= 16 slots): a select chain over the slots instead of a read from LDS
+  template <unsigned long long... WB, unsigned long long... EK, unsigned long long... EV>
+  __device__ __forceinline__ void op_lookup_lit(Bits<WB...>, Bits<EK...>, Bits<EV...>, const long long kmin64,
+                                                const bool select, const RC fill) {
+    static_assert(sizeof...(EK) == sizeof...(EV), "one target per exception key");
+    typedef typename std::conditional<sizeof(RC) == 8, unsigned long long, unsigned int>::type W;
+    typedef typename std::conditional<sizeof(RC) == 8, long long, int>::type KT;
+    const KT kmin = (KT)kmin64;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const W idx = (W)(KT)acc[k] - (W)kmin;
+      RC r = select ? fill : acc[k];
+      ((r = (idx == (W)(KT)(long long)EK - (W)kmin) ? lit<RC>(EV) : r), ...);
+      W j = 0;
+      ((r = (idx == j++) ? lit<RC>(WB) : r), ...);
+      acc[k] = r;
+    }
   }
 
   __device__ __forceinline__ void step(kargs_t C, const gm_step& S) {
@@ -982,14 +1084,31 @@ __device__ __forceinline__ void stage_window(unsigned long long* lds, const unsi
   }
 }
 
-template <typename RC, int G, int NIN, int NT, int FLAVOR>
-__global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
+// Where the program comes from.  PROG = InterpProg: read from device memory at run time (one kernel per
+// register class / size / flavour serves every program).  gm_spec.hip generates, per hot program, a PROG
+// whose members are literals: the same body and the same Machine then compile into a kernel with the
+// decode, the operand copies and the dtype dispatch folded away (the arithmetic is this file's, so the
+// results are the interpreter's bit for bit).
+struct InterpProg {
+  static __device__ __forceinline__ unsigned flags(kargs_t K) { return GM_KARG(K, flags); }
+  static __device__ __forceinline__ unsigned n_inputs(kargs_t K) { return GM_KARG(K, n_inputs); }
+  static __device__ __forceinline__ int out_dtype(kargs_t K) { return (int)GM_KARG(K, out_dtype); }
+  static __device__ __forceinline__ unsigned lds_table(kargs_t K) { return GM_KARG(K, lds_table); }
+  static __device__ __forceinline__ gm_input_desc input(kargs_t C, int k) {
+    return kload<gm_input_desc>(C, offsetof(VmCode, inputs) + sizeof(gm_input_desc) * k);
+  }
+  template <typename M>
+  static __device__ __forceinline__ void run(M& m, kargs_t K, kargs_t C) { m.run(C, GM_KARG(K, n_uops)); }
+};
+
+template <typename RC, int G, int NIN, int NT, int FLAVOR, typename PROG>
+__device__ __forceinline__ void vm_body() {
   const kargs_t K = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int N = 4 * G;
   const unsigned tile = blockIdx.y;
-  const unsigned flags = GM_KARG(K, flags);
+  const unsigned flags = PROG::flags(K);
   const unsigned long long n_groups = GM_KARG(K, n_groups);
-  const unsigned n_in = GM_KARG(K, n_inputs);
+  const unsigned n_in = PROG::n_inputs(K);
   const kargs_t C = (kargs_t)(uintptr_t)GM_KARG(K, code);
   const size_t in_base = offsetof(VmLaunch, in) + sizeof(void*) * GM_MAX_INPUTS * tile;
   constexpr bool nt_ld = true, nt_st = true;
@@ -1062,7 +1181,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       if (k < (int)n_in) {
-        const gm_input_desc D = kload<gm_input_desc>(C, offsetof(VmCode, inputs) + sizeof(gm_input_desc) * k);
+        const gm_input_desc D = PROG::input(C, k);
         const void* const in_k = in_ptr[k];
         if (in_broadcast(D)) {
           RC one[1];
@@ -1084,7 +1203,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
     }
   }
   if constexpr (FLAVOR == VM_TABLES) {
-    const unsigned lds_table = GM_KARG(K, lds_table);
+    const unsigned lds_table = PROG::lds_table(K);
     if (lds_table) {
       if (span == 0) {  // stage the LOOKUP window while the tile loads are in flight
         extern __shared__ __align__(16) unsigned long long vm_lds[];
@@ -1097,7 +1216,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
     }
   }
   // phase 2: interpret
-  M.run(C, GM_KARG(K, n_uops));
+  PROG::run(M, K, C);
   // phase 3: store (the result may itself be a window: a tile written straight into its mosaic)
   unsigned out_pitch = 0;
   if (strided) out_pitch = kload<unsigned>(K, offsetof(VmLaunch, out_pitch) + sizeof(unsigned) * tile);
@@ -1106,7 +1225,7 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
     // a 4-byte store per lane as they stand.  The wave transposes its 2 x 64 words through 512 bytes of
     // its own LDS instead (2 ds_write_b32 + 1 ds_read_b64 per lane, no barrier: one wave, in-order LDS)
     // and lane l stores the 8 consecutive pixels 8 l .. 8 l + 7 of the 256-pixel run it belongs to.
-    const int od = (int)GM_KARG(K, out_dtype);
+    const int od = PROG::out_dtype(K);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned long long wave_g0 = g0 - lane;
     if ((od == GM_U8 || od == GM_I8 || od == GM_BOOL) && !out_pitch && wave_g0 + 256ull + 63ull < n_groups) {
@@ -1147,11 +1266,16 @@ __global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
         RC v4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v4[q] = M.acc[4 * u + q];
-        store_elems<RC, 4>(out, (int)GM_KARG(K, out_dtype), at, nt_st, v4);
+        store_elems<RC, 4>(out, PROG::out_dtype(K), at, nt_st, v4);
       }
     }
   }
   }  // spans
+}
+
+template <typename RC, int G, int NIN, int NT, int FLAVOR>
+__global__ __launch_bounds__(256) void vm_kernel(const VmLaunch) {
+  vm_body<RC, G, NIN, NT, FLAVOR, InterpProg>();
 }
 
 // scalar tail kernel: the elements the 16-byte vector path cannot take (n % 4, or
@@ -1214,6 +1338,7 @@ __global__ __launch_bounds__(256) void vm_tail_kernel(const VmLaunch) {
   }
 }
 
+#ifndef __HIPCC_RTC__
 // host-side launcher of one register class (defined once per class in gm_vm_<class>.hip).
 // size: 0 = S (<= 2 inputs, <= 1 temp), 1 = M (<= 4 inputs, <= 2 temps), 2 = L (8 inputs, 4 temps)
 // flavor: VM_LIGHT / VM_MATH / VM_TABLES; grid.y = tail_grid.y = tiles of the batch
@@ -1254,5 +1379,7 @@ int launch_class(const VmLaunch& args, int size, int G, int flavor, dim3 grid, d
     if (e != hipSuccess) return gm::hip_fail(e, "vm_kernel launch");                               \
     return GM_OK;                                                                                  \
   }
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace gmvm

@@ -719,6 +719,13 @@ def _lib():
         L.gm_vm_get_tuning.argtypes = [ctypes.POINTER(gm_vm_tuning)]
         L.gm_sizeof.argtypes = [ctypes.c_int]
         L.gm_sizeof.restype = ctypes.c_size_t
+        L.gm_spec_set_mode.argtypes = [ctypes.c_int, ctypes.c_uint64]
+        L.gm_spec_get_mode.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]
+        L.gm_spec_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)] * 4
+        L.gm_spec_source.argtypes = [ctypes.POINTER(gm_program), ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
+                                     ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.gm_spec_compile_check.argtypes = [ctypes.POINTER(gm_program), ctypes.c_int, ctypes.c_int,
+                                            ctypes.POINTER(ctypes.c_size_t)]
         for which, struct in enumerate((gm_program, gm_step, gm_operand, gm_input_desc)):
             if L.gm_sizeof(which) != ctypes.sizeof(struct):
                 raise runtime.GmHipError("ABI mismatch: sizeof(%s) is %d in Python, %d in libgmhip" % (
@@ -737,6 +744,50 @@ def get_tuning():
     t = gm_vm_tuning()
     runtime.check(_lib().gm_vm_get_tuning(ctypes.byref(t)), "gm_vm_get_tuning")
     return {"vec": t.vec, "max_batch": t.max_batch}
+
+
+def set_spec_mode(mode, hot_elements=0):
+    """The program specialiser (csrc/gm_spec.hip): 0 = off (interpreter kernels only), 1 = programs that
+    have been asked for ``hot_elements`` pixels get a kernel of their own (default), 2 = every program at its
+    first launch (tests)."""
+    runtime.check(_lib().gm_spec_set_mode(int(mode), int(hot_elements)), "gm_spec_set_mode")
+
+
+def get_spec_mode():
+    mode, hot = ctypes.c_int(0), ctypes.c_uint64(0)
+    runtime.check(_lib().gm_spec_get_mode(ctypes.byref(mode), ctypes.byref(hot)), "gm_spec_get_mode")
+    return mode.value, hot.value
+
+
+def spec_stats():
+    v = [ctypes.c_uint64(0) for _ in range(4)]
+    runtime.check(_lib().gm_spec_stats(*[ctypes.byref(x) for x in v]), "gm_spec_stats")
+    return dict(zip(("compiled", "disk_hits", "launches", "failed"), (x.value for x in v)))
+
+
+def spec_available():
+    return bool(_lib().gm_spec_available())
+
+
+def spec_source(compiled, strided=False, group=2):
+    """The HIP source of the kernel the specialiser generates for a compiled program (no device needed)."""
+    L = _lib()
+    needed = ctypes.c_size_t(0)
+    runtime.check(L.gm_spec_source(ctypes.byref(compiled.program), int(strided), int(group), None, 0,
+                                   ctypes.byref(needed)), "gm_spec_source")
+    buf = ctypes.create_string_buffer(needed.value)
+    runtime.check(L.gm_spec_source(ctypes.byref(compiled.program), int(strided), int(group), buf, needed.value,
+                                   ctypes.byref(needed)), "gm_spec_source")
+    return buf.value.decode()
+
+
+def spec_compile_check(compiled, strided=False, group=2):
+    """Generate + compile (hiprtc, gfx950) the specialised kernel of a program without a device ->
+    size of the code object in bytes."""
+    size = ctypes.c_size_t(0)
+    runtime.check(_lib().gm_spec_compile_check(ctypes.byref(compiled.program), int(strided), int(group),
+                                               ctypes.byref(size)), "gm_spec_compile_check")
+    return size.value
 
 
 def launch(compiled, inputs, shape, out=None):

@@ -20,8 +20,10 @@
 #ifndef GMHIP_H
 #define GMHIP_H
 
+#ifndef __HIPCC_RTC__ /* (hiprtc has no host headers: gm_vm.h declares the fixed-width types there) */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -276,6 +278,22 @@ typedef struct gm_vm_tuning {
 } gm_vm_tuning;
 int gm_vm_set_tuning(const gm_vm_tuning* t);
 int gm_vm_get_tuning(gm_vm_tuning* t);
+/* Program specialiser (csrc/gm_spec.hip).  The kernels behind gm_elemwise_run* interpret a program; a
+ * program that turns out to be hot is compiled once, at run time (hiprtc, gfx950), into a kernel of its
+ * own -- the same templates with the program as literals, hence the same results bit for bit -- and
+ * cached per device and on disk ($GM_SPEC_CACHE, default ~/.cache/gmhip).  mode: 0 = off, 1 = programs
+ * asked for at least hot_elements pixels (default; 0 keeps the current threshold, initially 2^25),
+ * 2 = every program at its first launch (tests; a failing compilation is then an error).  Environment:
+ * GM_SPEC, GM_SPEC_HOT, GM_SPEC_CACHE, GM_SPEC_VERBOSE.  Without hiprtc everything keeps the interpreter. */
+int gm_spec_set_mode(int mode, uint64_t hot_elements);
+int gm_spec_get_mode(int* mode, uint64_t* hot_elements);
+int gm_spec_stats(uint64_t* compiled, uint64_t* disk_hits, uint64_t* launches, uint64_t* failed);
+int gm_spec_available(void);
+/* The generated HIP source of a program's kernel / a compile check of it; neither needs a device.
+ * group: 1 or 2 (4 or 8 elements per lane); strided: tiles are zero-copy windows. */
+int gm_spec_source(const gm_program* prog, int strided, int group, char* buf, size_t len, size_t* needed);
+int gm_spec_compile_check(const gm_program* prog, int strided, int group, size_t* code_bytes);
+
 /* sizeof of the ABI structs (0 gm_program, 1 gm_step, 2 gm_operand, 3 gm_input_desc): lets a
  * binding verify its struct layout at load time. */
 size_t gm_sizeof(int which);

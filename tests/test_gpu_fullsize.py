@@ -110,15 +110,17 @@ def test_config4_bilinear_16384_to_32768(gpu):
     assert_values_equal(np.asarray(out.window(0, 0, 64, 64)), want, 1, "top-left corner")
 
 
-def test_config5_mosaic_tiles_65536(gpu):
-    """The 10-Block view over the resident 65536^2 mosaic (4 x 16 GiB leaves): four of the 256 tiles
-    are evaluated through the tiler's sub-graphs (one fused float32 program each) and spot-checked."""
+@pytest.mark.parametrize("leaves", ["whole", "owned"])
+def test_config5_mosaic_tiles_65536(gpu, leaves):
+    """The 10-Block view over the 65536^2 mosaic -- leaves "whole" (4 x 16 GiB MemorySources, tiles are
+    zero-copy windows) and "owned" (only the windows of the evaluated tiles are resident): four of the
+    256 tiles are evaluated through the tiler's sub-graphs (one fused float32 program each) and spot-checked."""
     import bench
     from dask_geomodeling_amd import raster, shard
     from dask_geomodeling_amd.core.graphs import get_sync
     from dask_geomodeling_amd.fuse import fuse_graph
     side = bench.MOSAIC_SIDE
-    tiler = raster.RasterTiler(bench.mosaic_view(raster, resident=True), 4096)
+    tiler = raster.RasterTiler(bench.mosaic_view(raster, leaves), 4096)
     req = dict(mode="vals", bbox=(0.0, 0.0, float(side), float(side)), width=side, height=side, projection="EPSG:28992")
     graph, name = tiler.get_compute_graph(**req)
     _, tile_keys = shard.split_tiler_graph(graph, name)
@@ -149,3 +151,5 @@ def test_config5_mosaic_tiles_65536(gpu):
                                          "data": [[0, 10], [1, 11], [3, 13], [5, 15]]})
             want = O.mask_process(x, 1)["values"]
             assert_values_equal(got[:, r0:r0 + 96, c0:c0 + 96], want, 0, "tile %d window (%d, %d)" % (t, r0, c0))
+    del results, tiler, graph
+    raster.SyntheticSource.drop_resident_windows()
