@@ -664,6 +664,9 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
                                     (unsigned long long)n * (unsigned long long)n_tiles;
     want_spec = seen >= gmspec::hot_elements();
   }
+  // a kernel of its own has no decode to amortise and few registers: the 4-byte classes always take 8
+  // elements per lane there (at 4 waves per SIMD, gm_spec.hip), the 8-byte classes keep 4
+  if (want_spec && g_tuning.vec == 0 && code->flavor != VM_MATH) G = wide_class ? 1 : 2;
 
   for (int t0 = 0; t0 < n_tiles; t0 += max_batch) {
     const int nb = n_tiles - t0 < max_batch ? n_tiles - t0 : max_batch;

@@ -40,7 +40,7 @@ unsigned long long hot_elements();      // mode 1: elements a program must have 
 
 // The HIP source of the kernel for `r` (no device needed).  `literal_lookup` reports whether every LOOKUP
 // window became literals (no LDS staging).
-std::string generate(const Request& r, bool* literal_lookup);
+std::string generate(const Request& r, bool* literal_lookup, std::string* kernel_name = nullptr);
 
 // Compile `source` for gfx950 with hiprtc (no device needed); the code object lands in `code`.
 int compile(const std::string& source, std::vector<char>* code, std::string* log);

@@ -539,7 +539,46 @@ struct HillArgs {
   double xinv, yinv;
   float xinv32, yinv32;
   float sin_alt, cos_alt_zsf, square_zsf, cos_az, sin_az;
+  float az32;              // float32(az): what `aspect - az` subtracts (python float meets a float32 array)
 };
+
+// spatial.py:405-416 on one cell: x, y are the float32 gradients.
+//
+// Reference sequence (NumPy, float32 arrays, python floats as weak scalars), every step rounded to
+// float32: xx = x*x + y*y; aspect = arctan2(y, x); t = aspect - az; s = sin(t); root = sqrt(xx);
+// num = sin_alt - (k * root) * s; den = sqrt(1 + zsf^2 * xx); cang = num / den; result = trunc(255 * cang).
+//
+// Two tiers.  FAST: sin(arctan2(y, x) - az) * sqrt(xx) = y cos(az) - x sin(az), one v_rsq for the
+// normalisation; its 255 * cang lies within 1.4e-4 of the reference sequence's (measured over 3e8 random
+// gradients at scales 1e-2 .. 1e5 and four sun positions; the bound does not depend on the scale since
+// every term is <= 1 in magnitude).  The truncation can only differ when that value is within the error of
+// an integer, so only cells within HS_MARGIN = 1e-3 of one (0.2 % of cells) take the EXACT tier: the
+// reference sequence step by step, arctan2 and sin as the float32 roundings of the float64 functions,
+// sqrt and division correctly rounded.  What then remains against NumPy is its own float32 arctan2 (SVML
+// on AVX512 hosts, glibc elsewhere: the reference's output itself differs between such hosts) and sin,
+// which are off the correctly rounded value by 1 ulp on 38 % / 24 % of arguments: 1-5 cells per million
+// differ by 1 (tests/test_gpu_parity.py records the count).
+constexpr float HS_MARGIN = 1e-3f;
+__device__ __forceinline__ unsigned char shade_exact(float x, float y, float xx_plus_yy, const HillArgs& A) {
+  const float aspect = (float)atan2((double)y, (double)x);
+  const float t = aspect - A.az32;
+  const float s = (float)sin((double)t);
+  const float root = __fsqrt_rn(xx_plus_yy);
+  const float num = A.sin_alt - (A.cos_alt_zsf * root) * s;
+  const float den = __fsqrt_rn(1.0f + A.square_zsf * xx_plus_yy);
+  const float cang = __fdiv_rn(num, den);
+  return (cang <= 0.0f) ? (unsigned char)0 : (unsigned char)(int)(255.0f * cang);
+}
+__device__ __forceinline__ unsigned char shade_cell(float x, float y, const HillArgs& A) {
+  const float xx_plus_yy = x * x + y * y;
+  const float fast = (A.sin_alt - A.cos_alt_zsf * (y * A.cos_az - x * A.sin_az)) * __builtin_amdgcn_rsqf(1.0f + A.square_zsf * xx_plus_yy);
+  const float v = 255.0f * fast;
+  const float nearest = rintf(v);
+  // (NaN / inf gradients compare false here and take the exact tier, which treats them like NumPy does)
+  const bool decided = fabsf(v - nearest) > HS_MARGIN || nearest < 0.5f;
+  if (decided) return (fast <= 0.0f) ? (unsigned char)0 : (unsigned char)(int)v;
+  return shade_exact(x, y, xx_plus_yy, A);
+}
 
 // T arithmetic exactly as NumPy carries it out on a T array: integers wrap modulo 2^bits,
 // float32 / float64 round after every operation (-ffp-contract=off)
@@ -561,9 +600,7 @@ __device__ __forceinline__ float gradient(T a, T b2, T c, T d, T e2, T f, double
 
 // Column walker like dilate_kernel: 3 x 3 window of the lane's column in registers, one new row of
 // three contiguous-across-lanes loads per step.
-// sin(arctan2(y, x) - az) * sqrt(x^2 + y^2) = y cos(az) - x sin(az): the trigonometry of
-// spatial.py:407-412 collapses into two multiplications (a few float32 ulp away from NumPy's
-// arctan2 -> sin -> sqrt chain, i.e. far inside the +-1 tolerance of the truncating uint8 cast).
+// The shading of a cell is shade_cell() above.
 template <typename T>
 __global__ __launch_bounds__(256) void hillshade_kernel(const T* __restrict__ in, unsigned char* __restrict__ out, int h,
                                                         int w, int has_ndv, T ndv, T fill, HillArgs A) {
@@ -596,11 +633,7 @@ __global__ __launch_bounds__(256) void hillshade_kernel(const T* __restrict__ in
         // spatial.py:384-404 (s0..s8 = rows top/middle/bottom x columns left/middle/right)
         const float y = gradient<T>(top[0], top[1], top[2], bot[0], bot[1], bot[2], A.yres, A.yres32, A.yinv, A.yinv32);
         const float x = gradient<T>(top[0], mid[0], bot[0], top[2], mid[2], bot[2], A.xres, A.xres32, A.xinv, A.xinv32);
-        const float xx_plus_yy = x * x + y * y;
-        // 1 / sqrt in one (1 ulp) instruction instead of a correctly rounded sqrt and division: the result
-        // is truncated to uint8, a float32 ulp of `cang` matters only on a truncation boundary
-        const float cang = (A.sin_alt - A.cos_alt_zsf * (y * A.cos_az - x * A.sin_az)) * __builtin_amdgcn_rsqf(1.0f + A.square_zsf * xx_plus_yy);
-        out[((size_t)b * oh + rb + i) * ow + c] = (cang <= 0.0f) ? (unsigned char)0 : (unsigned char)(int)(255.0f * cang);
+        out[((size_t)b * oh + rb + i) * ow + c] = shade_cell(x, y, A);
       }
     }
 #pragma unroll
@@ -657,9 +690,7 @@ __global__ __launch_bounds__(256) void hillshade_tile_kernel(const T* __restrict
     // spatial.py:384-404 (s0..s8 = rows top/middle/bottom x columns left/middle/right)
     const float y = gradient<T>(top[0], top[1], top[2], bot[0], bot[1], bot[2], A.yres, A.yres32, A.yinv, A.yinv32);
     const float x = gradient<T>(top[0], mid[0], bot[0], top[2], mid[2], bot[2], A.xres, A.xres32, A.xinv, A.xinv32);
-    const float xx_plus_yy = x * x + y * y;
-    const float cang = (A.sin_alt - A.cos_alt_zsf * (y * A.cos_az - x * A.sin_az)) * __builtin_amdgcn_rsqf(1.0f + A.square_zsf * xx_plus_yy);
-    shade[wave][r * 64 + lane] = (cang <= 0.0f) ? (unsigned char)0 : (unsigned char)(int)(255.0f * cang);
+    shade[wave][r * 64 + lane] = shade_cell(x, y, A);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       top[j] = mid[j];
@@ -1058,6 +1089,7 @@ int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv
   A.square_zsf = (float)(zsf * zsf);
   A.cos_az = (float)cos(az);
   A.sin_az = (float)sin(az);
+  A.az32 = (float)az;
   dim3 grid((unsigned)((w - 2 + 255) / 256), (unsigned)((h - 2 + ST_ROWS - 1) / ST_ROWS), (unsigned)bands);
   dim3 tgrid((unsigned)((w - 2 + HT_W - 1) / HT_W), (unsigned)((h - 2 + HT_H - 1) / HT_H), (unsigned)bands);
   const bool tiled = gm::dtype_size(dtype) <= 4 && tgrid.y <= 65535;  // (8-byte tiles: the window would not fit LDS twice)

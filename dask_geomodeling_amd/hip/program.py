@@ -722,6 +722,7 @@ def _lib():
         L.gm_spec_set_mode.argtypes = [ctypes.c_int, ctypes.c_uint64]
         L.gm_spec_get_mode.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]
         L.gm_spec_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)] * 4
+        L.gm_spec_last_kernel.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         L.gm_spec_source.argtypes = [ctypes.POINTER(gm_program), ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
                                      ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         L.gm_spec_compile_check.argtypes = [ctypes.POINTER(gm_program), ctypes.c_int, ctypes.c_int,
@@ -763,6 +764,12 @@ def spec_stats():
     v = [ctypes.c_uint64(0) for _ in range(4)]
     runtime.check(_lib().gm_spec_stats(*[ctypes.byref(x) for x in v]), "gm_spec_stats")
     return dict(zip(("compiled", "disk_hits", "launches", "failed"), (x.value for x in v)))
+
+
+def spec_last_kernel():
+    buf = ctypes.create_string_buffer(64)
+    runtime.check(_lib().gm_spec_last_kernel(buf, 64), "gm_spec_last_kernel")
+    return buf.value.decode()
 
 
 def spec_available():

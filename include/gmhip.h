@@ -289,6 +289,8 @@ int gm_spec_set_mode(int mode, uint64_t hot_elements);
 int gm_spec_get_mode(int* mode, uint64_t* hot_elements);
 int gm_spec_stats(uint64_t* compiled, uint64_t* disk_hits, uint64_t* launches, uint64_t* failed);
 int gm_spec_available(void);
+/* Name of the specialised kernel resolved last ("gm_spec_<hash of its program>", as profilers show it). */
+int gm_spec_last_kernel(char* buf, size_t len);
 /* The generated HIP source of a program's kernel / a compile check of it; neither needs a device.
  * group: 1 or 2 (4 or 8 elements per lane); strided: tiles are zero-copy windows. */
 int gm_spec_source(const gm_program* prog, int strided, int group, char* buf, size_t len, size_t* needed);
@@ -366,7 +368,8 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
 /* HillShade.process (spatial.py:354-417): out = uint8 (bands, h-2, w-2).  no-data -> fill (already
  * cast to the tile's dtype), gradients in the tile's dtype (integers wrap like NumPy), then
  * float32 exactly as NumPy orders it; arctan2 / sin are the float32 roundings of the float64
- * functions, so a cell may differ by 1 from NumPy's float32 libm at a truncation boundary. */
+ * functions (NumPy's own float32 arctan2 / sin are not correctly rounded and differ between hosts), so
+ * about 1-5 cells per million differ by 1 from a given NumPy build, at truncation boundaries. */
 int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv, uint64_t ndv_bits, uint64_t fill_bits,
                  double xres, double yres, double altitude_deg, double azimuth_deg, void* out);
 

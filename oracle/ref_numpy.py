@@ -538,10 +538,17 @@ def movingmax_process(data, size=None):
     return {"values": filtered, "no_data_value": data["no_data_value"]}
 
 
-def hillshade_process(data, process_kwargs=None):
+def hillshade_process(data, process_kwargs=None, trig="numpy"):
     """HillShade.process (raster/spatial.py:354-417), operation by operation in the dtypes NumPy
     uses there: no-data -> fill in the tile's dtype, Sobel-like sums in the tile's dtype, the
-    division and everything after it in float32 (python-float constants are weak scalars)."""
+    division and everything after it in float32 (python-float constants are weak scalars).
+
+    trig="numpy": np.arctan2 / np.sin on the float32 arrays, like the reference -- pinned by the golden
+    vectors, but the last bit of those two functions depends on the NumPy build and the host (SVML on
+    AVX512 hosts, glibc elsewhere; neither is correctly rounded).  trig="rounded": the same sequence with
+    arctan2 and sin as the float32 roundings of the float64 functions -- host independent, and what the
+    device computes; tests/test_oracle_golden.py records how many cells of the reference's vectors the two
+    differ on (a few per million, by 1, on truncation boundaries of the uint8 cast)."""
     import math
     if process_kwargs is None:
         return data
@@ -561,8 +568,13 @@ def hillshade_process(data, process_kwargs=None):
         y = ((a[n + (w,)] + 2 * a[n + (m,)] + a[n + (e,)] - a[s + (w,)] - 2 * a[s + (m,)] - a[s + (e,)]) / yres).astype("f4")
         x = ((a[n + (w,)] + 2 * a[c + (w,)] + a[s + (w,)] - a[n + (e,)] - 2 * a[c + (e,)] - a[s + (e,)]) / xres).astype("f4")
         xx_plus_yy = x * x + y * y
-        aspect = np.arctan2(y, x)
-        cang = (math.sin(alt) - math.cos(alt) * zsf * np.sqrt(xx_plus_yy) * np.sin(aspect - az)) / np.sqrt(
+        if trig == "rounded":
+            aspect = np.arctan2(y.astype("f8"), x.astype("f8")).astype("f4")
+            sin_term = np.sin((aspect - az).astype("f8")).astype("f4")
+        else:
+            aspect = np.arctan2(y, x)
+            sin_term = np.sin(aspect - az)
+        cang = (math.sin(alt) - math.cos(alt) * zsf * np.sqrt(xx_plus_yy) * sin_term) / np.sqrt(
             1 + square_zsf * xx_plus_yy)
         result = np.where(cang <= 0, 0, 255 * cang).astype("u1")
     return {"values": result, "no_data_value": 256}

@@ -515,12 +515,19 @@ def test_tiler_with_tiles_one_pixel_short_of_their_slot(gpu, cell):
 
 
 # ---- N3: stencils (Dilate / MovingMax / HillShade) ------------------------------------------------
-def _hillshade_close(actual, expected, what):
-    actual, expected = np.asarray(actual), np.asarray(expected)
-    assert actual.dtype == expected.dtype == np.dtype("u1") and actual.shape == expected.shape, what
-    diff = np.abs(actual.astype("i2") - expected.astype("i2"))
-    assert diff.max(initial=0) <= 1, "%s: max |diff| %d" % (what, diff.max())
-    assert (diff != 0).mean() <= 0.01 if diff.size else True, "%s: %.2f %% differ" % (what, 100 * (diff != 0).mean())
+def _hillshade_exact(got, data, kw, what):
+    """HillShade is bit-exact against the host-independent oracle (float32 arctan2 / sin = roundings of the
+    float64 functions, oracle/ref_numpy.py); against THIS host's NumPy trig a cell per ~1e5 may differ by 1 on
+    a truncation boundary -- counted and bounded, not tolerated wholesale."""
+    want = O.hillshade_process(data, kw, trig="rounded")
+    assert got["no_data_value"] == 256
+    assert_values_equal(got["values"], want["values"], 0, what)
+    host = O.hillshade_process(data, kw)["values"].astype("i2")
+    diff = np.abs(np.asarray(got["values"]).astype("i2") - host)
+    # (integer terrain has few distinct gradient pairs: an affected pair shows up in several cells at once)
+    assert diff.max(initial=0) <= 1 and (diff != 0).sum() <= max(8, 20e-6 * diff.size), \
+        "%s: %d of %d cells differ from this host's NumPy" % (what, (diff != 0).sum(), diff.size)
+    return int((diff != 0).sum())
 
 
 @pytest.mark.gpu
@@ -532,11 +539,7 @@ def test_stencils_golden(gpu, case):
     from dask_geomodeling_amd import raster
     fn = {"dilate": raster.Dilate.process, "movingmax": raster.MovingMax.process, "hillshade": raster.HillShade.process}[case["op"]]
     out = fn(*case["args"])
-    if case["op"] == "hillshade" and isinstance(out, dict) and "values" in out:
-        assert out["no_data_value"] == 256
-        _hillshade_close(out["values"], case["expect"]["values"], case["id"])
-    else:
-        assert_result_equal(out, case["expect"], 0, case["id"])
+    assert_result_equal(out, case["expect"], 0, case["id"])  # HillShade included: bit-exact
 
 
 @pytest.mark.gpu
@@ -558,8 +561,27 @@ def test_stencils_large_tiles_vs_oracle(gpu):
         vals = [v.flat[7], v.flat[11], 3]
         assert_result_equal(raster.Dilate.process(data, vals), O.dilate_process(data, vals), 0, "dilate %s" % dt)
         kw = dict(resolution=(0.5, 2.0), altitude=45.0, azimuth=315.0, fill=1)
-        got, want = raster.HillShade.process(data, kw), O.hillshade_process(data, kw)
-        _hillshade_close(got["values"], want["values"], "hillshade %s" % dt)
+        _hillshade_exact(raster.HillShade.process(data, kw), data, kw, "hillshade %s" % dt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,scale", [("f4", 1.0), ("f4", 40.0), ("i2", 200.0), ("f8", 3.0), ("u1", 60.0)])
+def test_hillshade_bit_exact_on_terrain(gpu, dt, scale):
+    """4 M cells of random terrain per dtype, two sun positions: every cell equals the host-independent oracle
+    (both tiers of the kernel: the algebraic fast tier decides 99.8 % of the cells, the step-by-step tier the
+    cells within 1e-3 of a truncation boundary); the cells that differ from this host's NumPy are counted."""
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(77)
+    v = rng.standard_normal((1, 2050, 2050)) * scale
+    v = np.cumsum(v, axis=2).astype(dt) if dt in ("f4", "f8") else np.round(np.abs(v) if dt == "u1" else v).astype(dt)
+    ndv = np.dtype(dt).type(250 if dt == "u1" else -9999)
+    v[0, ::37, ::41] = ndv
+    data = {"values": v, "no_data_value": ndv}
+    total = 0
+    for alt, az, res in ((45.0, 315.0, (0.5, 2.0)), (30.0, 10.0, (1.0, 1.0))):
+        kw = dict(resolution=res, altitude=alt, azimuth=az, fill=1)
+        total += _hillshade_exact(raster.HillShade.process(data, kw), data, kw, "terrain %s %s" % (dt, alt))
+    print("hillshade %s: %d of %d cells differ from this host's NumPy float32 trig" % (dt, total, 2 * 2048 * 2048))
 
 
 @pytest.mark.gpu
@@ -574,14 +596,11 @@ def test_stencil_blocks_end_to_end(gpu):
     src = raster.MemorySource(a, fill, "EPSG:28992", 1.0, (0.0, 40.0))
     req = dict(mode="vals", bbox=(8.0, 8.0, 40.0, 32.0), width=32, height=24, projection="EPSG:28992")
     for block, radius, fn in ((raster.MovingMax(src, 5), 2, lambda d: O.movingmax_process(d, 5)),
-                              (raster.HillShade(src), 1, lambda d: O.hillshade_process(d, dict(resolution=(1.0, 1.0), altitude=45.0, azimuth=315.0, fill=0)))):
+                              (raster.HillShade(src), 1, lambda d: O.hillshade_process(d, dict(resolution=(1.0, 1.0), altitude=45.0, azimuth=315.0, fill=0), trig="rounded"))):
         big = src.get_data(**O.expand_request_pixels(req, radius))
         want = fn(big)
         got = block.get_data(**req)
-        if isinstance(block, raster.HillShade):
-            _hillshade_close(got["values"], want["values"], "HillShade block")
-        else:
-            assert_result_equal(got, want, 0, type(block).__name__)
+        assert_result_equal(got, want, 0, type(block).__name__)
     for mode in ("time", "meta"):
         assert raster.MovingMax(src, 3).get_data(mode=mode) == src.get_data(mode=mode)
 

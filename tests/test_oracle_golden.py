@@ -184,15 +184,33 @@ def test_bilinear_vs_scipy():
 # ---------------------------------------------------------------------------------
 # N3 / N4: stencils and the Max reduction
 # ---------------------------------------------------------------------------------
-def hillshade_close(actual, expected, what=""):
-    """HillShade ends in float32 sin / arctan2 followed by a truncating cast to uint8: another libm
-    (or the GPU) may land on the other side of an integer boundary.  Tolerance: |diff| <= 1 on at
-    most 1 % of the cells, everything else identical."""
-    actual, expected = np.asarray(actual), np.asarray(expected)
-    assert actual.dtype == expected.dtype == np.dtype("u1") and actual.shape == expected.shape, what
-    diff = np.abs(actual.astype("i2") - expected.astype("i2"))
-    assert diff.max(initial=0) <= 1, "%s: max |diff| %d" % (what, diff.max())
-    assert (diff != 0).mean() <= 0.01 if diff.size else True, "%s: %.2f %% of the cells differ" % (what, 100 * (diff != 0).mean())
+def hillshade_numpy_dependence(data, kwargs):
+    """(cells, cells where the oracle with NumPy's own float32 arctan2 / sin differs from the oracle with the
+    correctly rounded ones, max |difference|): the part of HillShade's output that depends on the NumPy
+    build and host."""
+    a = O.hillshade_process(data, kwargs)["values"].astype("i2")
+    b = O.hillshade_process(data, kwargs, trig="rounded")["values"].astype("i2")
+    return a.size, int((a != b).sum()), int(np.abs(a - b).max(initial=0))
+
+
+def test_hillshade_trig_rounding_only_moves_truncation_boundaries():
+    """HillShade ends in float32 arctan2 -> sin -> ... -> truncating uint8 cast.  NumPy's float32 arctan2 /
+    sin are not correctly rounded (SVML on AVX512 hosts, glibc elsewhere: 38 % / 24 % of arguments are 1 ulp
+    off on the host this was written on), so the reference's own output depends on the host in a few cells
+    per million.  The device evaluates the host-independent variant (trig="rounded"); this pins how far the
+    two are apart: never more than 1, and on fewer than 20 cells per million."""
+    rng = np.random.default_rng(42)
+    cells = differ = 0
+    for scale, dt in ((1.0, "f4"), (30.0, "f4"), (200.0, "i2"), (3.0, "f8")):
+        v = (rng.standard_normal((1, 1026, 1026)) * scale)
+        v = np.cumsum(v, axis=2).astype(dt) if dt != "i2" else np.round(v).astype(dt)
+        data = {"values": v, "no_data_value": np.dtype(dt).type(-9999)}
+        for alt, az in ((45.0, 315.0), (30.0, 10.0)):
+            n, d, worst = hillshade_numpy_dependence(data, dict(resolution=(0.5, 2.0), altitude=alt, azimuth=az, fill=1))
+            assert worst <= 1
+            cells, differ = cells + n, differ + d
+    print("hillshade: %d of %d cells depend on the host's float32 arctan2 / sin (%.2e)" % (differ, cells, differ / cells))
+    assert differ <= 20e-6 * cells
 
 
 @pytest.mark.parametrize("case", load_family("spatial"), ids=lambda c: c["id"] + "-" + c["op"])
@@ -203,8 +221,11 @@ def test_spatial(case):
         return
     out = getattr(O, op + "_process")(*args)
     if op == "hillshade" and isinstance(out, dict) and "values" in out:
-        assert out["no_data_value"] == case["expect"]["no_data_value"] == 256
-        hillshade_close(out["values"], case["expect"]["values"], case["id"])
+        # the host-independent variant reproduces every reference vector exactly; NumPy's own trig may move a
+        # cell by 1 on another host (see the test above)
+        assert_result_equal(O.hillshade_process(*args, trig="rounded"), case["expect"], 0, case["id"])
+        n, differ, worst = hillshade_numpy_dependence(*args)
+        assert worst <= 1 and differ <= max(1, n // 1000), case["id"]
     else:
         assert_result_equal(out, case["expect"], 0, case["id"])
 
