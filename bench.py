@@ -55,6 +55,7 @@ def parse_args():
     p.add_argument("--tiles", type=int, default=0, help="tiles per GPU per step (0 = the workload's default)")
     p.add_argument("--cpu-tiles", type=int, default=-1, help="tiles of the CPU baseline sample (0 = skip)")
     p.add_argument("--no-check", action="store_true", help="skip the oracle check of one tile")
+    p.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block (get_data rates seen by a caller)")
     p.add_argument("--leaves", default="owned", choices=["owned", "whole", "procedural"],
                    help="mosaic leaves: owned = every rank keeps the leaf windows of the tiles it owns resident "
                         "(4 x 16 GiB / N per GPU, generated on the owning GPU during warm-up); whole = every rank "
@@ -90,22 +91,23 @@ def build_batch(raster, side, tiles, rank):
 
 
 def build_reclass(raster, side, tiles, rank):
-    """configs[2]: Mask(Reclassify(int32 tile, 128-entry table), 1), fused into one program of the
-    int64 class (LOOKUP + MASK): int32 in, uint8 out = 5 B/px."""
+    """configs[2]: Mask(Reclassify(int32 tile, 128-entry table), 1): one int32 program (LOOKUP with the Mask
+    folded into its table), int32 in, uint8 out = 5 B/px; the tiles of a step form one merged graph, i.e.
+    one launch."""
     from dask_geomodeling_amd.fuse import fuse_graph
     from dask_geomodeling_amd.raster.sources import generate_window
 
     table = [[k, (7 * k) % 1000] for k in range(0, 256, 2)]
     request = dict(mode="vals", bbox=(0.0, 0.0, float(side), float(side)), width=side, height=side,
                    projection="EPSG:28992")
-    jobs = []
+    graph, names = {}, []
     for i in range(tiles):
         d = generate_window((side, side), "i4", 2000 + 100 * rank + i, 0.0, 256.0, 2147483647, (50, 50), 0, 0, side, side)
         src = raster.MemorySource(d, 2147483647, "EPSG:28992", 1.0, (0.0, float(side)))
         view = raster.Mask(raster.Reclassify(src, table), 1)
-        graph, name = view.get_compute_graph(**request)
-        jobs.append((fuse_graph(graph, name), [name]))
-    return jobs
+        graph, name = view.get_compute_graph(cached_compute_graph=graph, **request)
+        names.append(name)
+    return [(fuse_graph(graph, names), names)]
 
 
 def build_bilinear(raster, side, tiles, rank):
@@ -203,45 +205,126 @@ def host_tile(seed, side):
 
 
 def cpu_baseline(side, n_tiles, budget_s=12.0):
-    """The oracle chain on host cores: passes of n_tiles tiles over a thread pool (NumPy releases
-    the GIL), repeated until about budget_s seconds of wall-clock are spent."""
+    """The oracle chain on host cores (the restatement of the reference's process() bodies; the reference
+    itself cannot travel to the GPU box): (i) the synchronous leg -- tiles one after the other on one thread,
+    what dask's synchronous scheduler does -- and (ii) the threaded leg -- passes of n_tiles tiles over a
+    thread pool (NumPy releases the GIL; dask's threaded scheduler), until about budget_s seconds are spent.
+    `value` is the threaded rate (the faster one)."""
     from concurrent.futures import ThreadPoolExecutor
     cores = os.cpu_count() or 1
     workers = min(cores, n_tiles)
     distinct = [(host_tile(2 * i, side), host_tile(2 * i + 1, side)) for i in range(min(n_tiles, 2))]
     tiles = [distinct[i % len(distinct)] for i in range(n_tiles)]  # timing does not depend on the values
     oracle_chain(*[t[:, :256, :256] for t in tiles[0]])  # warm
+    t0, sync_tiles = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s / 4 and sync_tiles < 8:
+        oracle_chain(*tiles[sync_tiles % n_tiles])
+        sync_tiles += 1
+    sync_rate = sync_tiles * side * side / (time.perf_counter() - t0) / 1e6
     passes, t0 = 0, time.perf_counter()
     with ThreadPoolExecutor(workers) as pool:
         while True:
             list(pool.map(lambda ab: oracle_chain(*ab)["values"][0, 0, 0], tiles))
             passes += 1
             dt = time.perf_counter() - t0
-            if dt >= budget_s or passes >= 64:
+            if dt >= budget_s * 3 / 4 or passes >= 64:
                 break
     return {"value": round(passes * n_tiles * side * side / dt / 1e6, 2), "unit": "Mpix/s", "cores": workers,
-            "kind": "port",
-            "sample": "%d passes over %d tiles of %dx%d f32, oracle/ref_numpy.py chain (NumPy %s) on a %d-thread "
-                      "pool, %.1f s" % (passes, n_tiles, side, side, np.__version__, workers, dt)}
+            "kind": "port", "synchronous": {"value": round(sync_rate, 2), "unit": "Mpix/s", "cores": 1},
+            "sample": "oracle/ref_numpy.py chain (NumPy %s): threaded leg %d passes over %d tiles of %dx%d f32 on a "
+                      "%d-thread pool, %.1f s; synchronous leg %d tiles on 1 thread"
+                      % (np.__version__, passes, n_tiles, side, side, workers, dt, sync_tiles)}
 
 
-def pmc_traffic(side, tiles_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-    command (tools/pmc_summary.py writes the file), or (None, None)."""
-    best = None
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-        if name.endswith("_pmc.json"):
-            best = os.path.join(ROOT, "profiles", name)
-    if best is None:
+def kernel_source_hash():
+    """Identity of the device code a measurement was taken with (kernel sources + the program compiler)."""
+    import hashlib
+    h = hashlib.sha1()
+    base = os.path.join(ROOT, "dask_geomodeling_amd")
+    files = sorted(os.path.join(base, "csrc", f) for f in os.listdir(os.path.join(base, "csrc"))
+                   if f.endswith((".hip", ".h")))
+    for path in files + [os.path.join(base, "hip", "program.py"), os.path.join(base, "fuse.py")]:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload, tiles_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this very
+    command AND this very device code (profiles/*_pmc*.json, written by tools/collect_profiles.py with the
+    hash above): a stale file -- another kernel version, another workload -- yields (None, None)."""
+    folder = os.path.join(ROOT, "profiles")
+    if not os.path.isdir(folder):
         return None, None
-    try:
-        with open(best) as f:
-            rec = json.load(f)
-        if rec.get("side") != side or rec.get("tiles_per_launch") != tiles_per_launch:
-            return None, None
-        return rec["hbm_bytes_per_launch"], "profiles/" + os.path.basename(best)
-    except (OSError, ValueError, KeyError):
-        return None, None
+    want = kernel_source_hash()
+    for name in sorted(os.listdir(folder), reverse=True):
+        if "_pmc" not in name or not name.endswith(".json"):
+            continue
+        try:
+            with open(os.path.join(folder, name)) as f:
+                rec = json.load(f)
+            if (rec.get("workload") == workload and rec.get("tiles_per_launch") == tiles_per_launch and
+                    rec.get("kernel_source_hash") == want):
+                return rec["hbm_bytes_per_launch"], "profiles/" + name
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
+def end_to_end(raster, runtime, side, budget_s=6.0):
+    """What a caller of the Block API sees (rank 0, N = 1 only; bounded): Mpix/s and host microseconds per
+    request of ``view.get_data(**request)`` -- graph build / plan lookup + source windows + launch + (with
+    materialize) the device-to-host copy -- for single 4096^2 tile requests at ever-changing bounding boxes of a
+    resident 16384^2 source pair, and for ``RasterTiler(view, 4096).get_data`` over the whole 16384^2."""
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd.raster.sources import generate_window
+    big = 4 * side
+    ndv = np.float32(F32MAX)
+    da = generate_window((big, big), "f4", 7001, 0.0, 100.0, F32MAX, LATTICE, 0, 0, big, big)
+    db = generate_window((big, big), "f4", 7002, 0.0, 100.0, F32MAX, LATTICE, 0, 0, big, big)
+    A = raster.MemorySource(da, ndv, "EPSG:28992", 1.0, (0.0, float(big)))
+    B = raster.MemorySource(db, ndv, "EPSG:28992", 1.0, (0.0, float(big)))
+    view = raster.Clip(raster.Add(raster.Subtract(raster.Multiply(raster.Add(A, B), 2.5), B), 1.5), A)
+    boxes = [(float(i * side), float(j * side), float((i + 1) * side), float((j + 1) * side))
+             for i in range(4) for j in range(4)]
+    req = dict(mode="vals", width=side, height=side, projection="EPSG:28992")
+
+    def rate(fn, px, min_calls, share):
+        fn()
+        runtime.sync()
+        calls, t0 = 0, time.perf_counter()
+        while calls < min_calls or time.perf_counter() - t0 < budget_s * share:
+            fn()
+            calls += 1
+            if calls >= 2000:
+                break
+        runtime.sync()
+        dt = time.perf_counter() - t0
+        return round(px * calls / dt / 1e6, 1), round(dt / calls * 1e6, 1), calls
+
+    out = {"config": "view = the canonical chain over two resident %dx%d f32 MemorySources; requests = %dx%d tiles "
+                     "at 16 different bounding boxes in turn" % (big, big, side, side)}
+    state = {"k": 0}
+
+    def one_tile():
+        state["k"] += 1
+        return view.get_data(bbox=boxes[state["k"] % 16], **req)
+
+    for label, plans in (("plans", True), ("graph_per_request", False)):
+        with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": plans}):
+            v, us, n = rate(one_tile, side * side, 32, 0.2)
+        out["get_data_tile_device_" + label] = {"Mpix/s": v, "us_per_request": us, "requests": n}
+    with gmconfig.config.set({"geomodeling.materialize": True}):
+        v, us, n = rate(one_tile, side * side, 4, 0.15)
+    out["get_data_tile_to_host"] = {"Mpix/s": v, "us_per_request": us, "requests": n,
+                                    "note": "includes the 64 MiB device-to-host copy of every result (PCIe)"}
+    tiler = raster.RasterTiler(view, side)
+    whole = dict(req, bbox=(0.0, 0.0, float(big), float(big)), width=big, height=big)
+    for label, plans in (("plans", True), ("graph_per_request", False)):
+        with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": plans}):
+            v, us, n = rate(lambda: tiler.get_data(**whole), big * big, 4, 0.15)
+        out["tiler_get_data_device_" + label] = {"Mpix/s": v, "us_per_request": us, "requests": n, "tiles": 16}
+    return out
 
 
 def _free_port():
@@ -315,6 +398,7 @@ def main():
     tiles = args.tiles or defaults[args.workload][1]
     if args.workload != "chain5":
         args.no_check = True
+    P = None
     if args.dry_run:
         class _NoDevice:  # harness test only: no device, no kernels, no numbers worth reading
             class Event:
@@ -343,6 +427,7 @@ def main():
     else:
         from dask_geomodeling_amd import raster
         from dask_geomodeling_amd.core.graphs import get_sync
+        from dask_geomodeling_amd.hip import program as P
         from dask_geomodeling_amd.hip import runtime
 
         runtime.require_device()
@@ -367,6 +452,7 @@ def main():
 
     # W untimed warm-up steps -- and, when those are shorter than that, keep stepping until the GPU
     # has been busy for 50 ms, so that the clocks have left their idle state before the timed region
+    # (hot programs also get their specialised kernels here: csrc/gm_spec.hip)
     t_warm, done = time.perf_counter(), 0
     while done < args.warmup or (not args.dry_run and time.perf_counter() - t_warm < 0.05):
         step()
@@ -381,6 +467,7 @@ def main():
         runtime.sync()
 
     barrier()
+    spec_before = P.spec_stats()["launches"] if P is not None else 0
     e0, e1 = runtime.Event(), runtime.Event()
     t0 = time.perf_counter()
     e0.record()
@@ -390,9 +477,26 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     e1.synchronize()
-    tiles_per_launch = min(tiles, 16) if args.workload == "chain5" else 1
-    launches = args.steps * ((tiles + tiles_per_launch - 1) // tiles_per_launch)
-    kernel_ms = e0.elapsed_ms(e1) / launches  # average launch duration (HIP events on the compute stream)
+    spec_launches = (P.spec_stats()["launches"] - spec_before) if P is not None else 0
+
+    # the dominant kernel of every workload: tiles per launch, output pixels per tile, algorithmic bytes per
+    # OUTPUT pixel (SURVEY 8d / DESIGN section 4) and its name when the program is interpreted
+    out_side = 2 * side if args.workload == "bilinear" else side
+    if args.workload == "tiler":
+        tile_px, n_tiles_step = 4096 * 4096, (side // 4096) ** 2
+    else:
+        tile_px, n_tiles_step = out_side * out_side, tiles
+    model = {"chain5": (16, 12, "f32", "gmvm::vm_kernel<float, 2, 2, 1, 0>"),
+             "reclass": (16, 5, "i32", "gm::lookup32_kernel<unsigned char>"),
+             "bilinear": (1, 5, "f64", "gm::bilinear_kernel<float, true, 32, 5>"),
+             "mosaic": (16, 17, "f32", "gmvm::vm_kernel<float, 2, 4, 2, 2>"),
+             "tiler": (16, 12, "f32", "gmvm::vm_kernel<float, 2, 2, 1, 0>")}[args.workload]
+    tiles_per_launch = min(n_tiles_step, model[0])
+    launches_per_step = (n_tiles_step + tiles_per_launch - 1) // tiles_per_launch
+    bytes_px, dtype, kernel = model[1], model[2], model[3]
+    if spec_launches >= args.steps * launches_per_step and P is not None:
+        kernel = P.spec_last_kernel() + " (specialised per program by csrc/gm_spec.hip)"
+    kernel_ms = e0.elapsed_ms(e1) / (args.steps * launches_per_step)  # average launch duration (HIP events, compute stream)
 
     if not args.no_check and rank == 0:
         # parity of what was just timed: first and last tile of the batch against the oracle
@@ -411,60 +515,52 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if rank == 0 and args.workload != "chain5":
-        # secondary workloads (BASELINE.json configs[2..4]): same line format, their own byte model
-        out_side = 2 * side if args.workload == "bilinear" else side
+    if rank == 0:
         if args.workload == "mosaic":
-            px_per_step = MOSAIC_SIDE * MOSAIC_SIDE  # all ranks together cover the mosaic once per step
-            scaling = "strong"
+            px_per_step, scaling = MOSAIC_SIDE * MOSAIC_SIDE, "strong"  # all ranks together cover the mosaic once per step
         else:
-            px_per_step = world * tiles * out_side * out_side
-            scaling = "weak"
-        # mosaic: one fused program per tile reads its four float32 leaves and writes uint8 (4 x 4 + 1)
-        bytes_px = {"reclass": 5, "bilinear": 5, "mosaic": 17, "tiler": 12}[args.workload]
+            px_per_step, scaling = world * n_tiles_step * tile_px, "weak"
         value = px_per_step * args.steps / elapsed / 1e6
-        out = {"metric": "Mpix/s, workload %s" % args.workload, "value": round(value, 1), "unit": "Mpix/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
-               "vs_baseline": None, "dtype": {"reclass": "int64", "bilinear": "f64", "mosaic": "f32", "tiler": "f32"}[args.workload],
-               "data": "synthetic",
-               "config": {"workload": args.workload, "tile": [side, side], "tiles_per_gpu": tiles,
-                          "algorithmic_bytes_per_px": bytes_px}}
-        if bytes_px:
-            gbs = value * 1e6 * bytes_px / world / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                               "note": "whole-step rate x algorithmic bytes (several kernels per tile)"}
-        print(json.dumps(out), flush=True)
-    elif rank == 0:
-        px_per_step = world * tiles * side * side
-        value = px_per_step * args.steps / elapsed / 1e6
-        launch_bytes = BYTES_PER_PX * side * side * tiles_per_launch
+        launch_bytes = bytes_px * tile_px * tiles_per_launch
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(side, tiles_per_launch)
+        traffic, traffic_src = pmc_traffic(args.workload, tiles_per_launch)
+        workloads = {
+            "chain5": "fused chain Clip(Add(Subtract(Multiply(Add(A,B),2.5),B),1.5),A) on %dx%d f32 MemorySource tiles, "
+                      "%d tile pairs per GPU per step, %d tiles per fused launch" % (side, side, tiles, tiles_per_launch),
+            "reclass": "Mask(Reclassify(int32 tile, 128 pairs), 1) on %dx%d tiles (BASELINE configs[2]), %d tiles per "
+                       "GPU per step in one launch" % (side, side, tiles),
+            "bilinear": "bilinear 2x upsample %dx%d -> %dx%d f32 (BASELINE configs[3])" % (side, side, out_side, out_side),
+            "mosaic": "10-Block view over the 65536^2 mosaic (BASELINE configs[4]): %d tiles of %dx%d per GPU per step, "
+                      "leaves '%s', one float32 program per tile (4 leaves in, uint8 out)"
+                      % (tiles, side, side, "procedural" if args.procedural else args.leaves),
+            "tiler": "canonical chain under RasterTiler(4096) over two resident %dx%d sources: zero-copy windows in, "
+                     "mosaic written in place" % (side, side)}
         out = {
-            "metric": "Mpix/s on 4096x4096 f32 tiles, 5-op elemwise chain; % of HBM roofline",
+            "metric": "Mpix/s on 4096x4096 f32 tiles, 5-op elemwise chain; % of HBM roofline" if args.workload == "chain5"
+                      else "Mpix/s, workload %s" % args.workload,
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": dtype,
             "data": "synthetic" if not args.dry_run else "DRY RUN (no GPU work, harness test only)",
-            "config": {"workload": "fused chain Clip(Add(Subtract(Multiply(Add(A,B),2.5),B),1.5),A) on %dx%d f32 "
-                                   "MemorySource tiles, %d tile pairs per GPU per step, %d tiles per fused launch"
-                                   % (side, side, tiles, tiles_per_launch),
-                       "tile": [side, side], "tiles_per_gpu": tiles, "tiles_per_launch": tiles_per_launch,
-                       "bytes_per_px": BYTES_PER_PX,
+            "config": {"workload": workloads[args.workload], "name": args.workload, "tile": [side, side],
+                       "tiles_per_gpu": tiles, "tiles_per_launch": tiles_per_launch, "bytes_per_px": bytes_px,
                        "parallelism": "tiles sharded 1 rank per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src, "kernel": "gmvm::vm_kernel<float, 2, 2, 1, 0>",
-                         "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": round(kernel_ms * 1e3, 2)},
-            "pct_of_hbm_roofline": round(100.0 * value * 1e6 * BYTES_PER_PX / world / (HBM_PEAK_GBS * 1e9), 2),
+                         "traffic_source": traffic_src, "kernel": kernel,
+                         "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": round(kernel_ms * 1e3, 2),
+                         "launches_per_step": launches_per_step, "kernel_source_hash": kernel_source_hash()},
+            "pct_of_hbm_roofline": round(100.0 * value * 1e6 * bytes_px / world / (HBM_PEAK_GBS * 1e9), 2),
         }
         cpu_tiles = args.cpu_tiles
         if cpu_tiles < 0:
             cpu_tiles = min(max(os.cpu_count() or 1, 4), 32) if world == 1 else 0
-        if cpu_tiles > 0 and world == 1 and not args.dry_run:
-            out["cpu_baseline"] = cpu_baseline(side, cpu_tiles)
+        if args.workload == "chain5" and world == 1 and not args.dry_run:
+            if cpu_tiles > 0:
+                out["cpu_baseline"] = cpu_baseline(side, cpu_tiles)
+            if not args.no_e2e:
+                del jobs
+                out["end_to_end"] = end_to_end(raster, runtime, side)
         print(json.dumps(out), flush=True)
 
     if dist is not None:

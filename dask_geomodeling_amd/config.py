@@ -5,6 +5,8 @@ same ``get / set / update_defaults`` surface.  Keys live under ``geomodeling.*``
 besides the reference's own keys this path adds:
 
   geomodeling.fuse         collapse element-wise sub-graphs into one launch (default True)
+  geomodeling.plans        get_data() reuses the fused plan of a view for requests that differ in their
+                           bbox only instead of rebuilding the graph (default True; plan.py)
   geomodeling.materialize  get_data() returns ndarrays (True) or DeviceArrays (False)
   geomodeling.device       HIP device index used by this process/thread (default: current)
 """
@@ -23,6 +25,7 @@ defaults = {
     "raster-limit-timesteps": 65536,
     "geometry-limit": 10000,
     "fuse": True,
+    "plans": True,
     "materialize": True,
     "device": None,
 }

@@ -311,11 +311,14 @@ class Block(object):
     def get_data(self, **request):
         """Evaluate the request.  Element-wise sub-graphs are fused into single HIP
         launches first; the result is handed back as host ndarrays."""
-        graph, name = self.get_compute_graph(**request)
-        if _config.get("geomodeling.fuse", True):
-            from ..fuse import fuse_graph
-            graph = fuse_graph(graph, name)
-        result = compute(graph, name)
+        from ..plan import evaluate
+        planned, result = evaluate(self, request)  # a cached plan of this view, if it has one (plan.py)
+        if not planned:
+            graph, name = self.get_compute_graph(**request)
+            if _config.get("geomodeling.fuse", True):
+                from ..fuse import fuse_graph
+                graph = fuse_graph(graph, name)
+            result = compute(graph, name)
         if _config.get("geomodeling.materialize", True):
             from ..fuse import materialize
             result = materialize(result)

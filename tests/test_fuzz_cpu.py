@@ -26,3 +26,24 @@ def test_random_views_fused_vs_oracle(cpu_vm, monkeypatch, seed):
             raise
         pytest.skip("this view needs a stand-alone kernel (covered by the GPU fuzz test)")
     assert_result_equal(unsigned_zero(got), unsigned_zero(want), 0, describe(view))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_plans_equal_the_graph_path(cpu_vm, seed):
+    """get_data through a cached ViewPlan (plan.py) gives what the graph path gives, on first use and on reuse."""
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd import plan
+    rng = np.random.default_rng(50_000 + seed)
+    view = random_view(rng, "p%d" % seed)
+    with np.errstate(all="ignore"):
+        try:
+            with gmconfig.config.set({"geomodeling.plans": False}):
+                want = view.get_data(**REQ)
+        except NotImplementedError:
+            pytest.skip("not on the device path")
+        first = view.get_data(**REQ)
+        again = view.get_data(**REQ)
+    assert_result_equal(first, want, 0, "first use " + describe(view))
+    assert_result_equal(again, want, 0, "reuse " + describe(view))
+    plans = view.__dict__.get("_gm_plans", {})
+    assert len(plans) <= 1

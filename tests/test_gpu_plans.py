@@ -1,0 +1,82 @@
+"""Evaluation plans (dask_geomodeling_amd/plan.py) on the device: a view's cached plan answers requests that
+differ in their bounding box only -- aligned windows, unaligned boxes (nearest warp), boxes partly outside the
+sources -- exactly like the graph path, for single views and under a RasterTiler."""
+import numpy as np
+import pytest
+
+from fuzz_util import describe, random_view, unsigned_zero
+from helpers import assert_result_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph_path(view, req):
+    from dask_geomodeling_amd import config as gmconfig
+    with gmconfig.config.set({"geomodeling.plans": False}):
+        return view.get_data(**req)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_plan_reused_across_bounding_boxes(gpu, seed):
+    rng = np.random.default_rng(40_000 + seed)
+    view = random_view(rng, "q%d" % seed, depth=3, memory=True)  # sources: 24 x 40 MemorySources at (0, 0)-(40, 24)
+    boxes = [(0.0, 0.0, 16.0, 12.0), (8.0, 4.0, 24.0, 16.0), (24.0, 12.0, 40.0, 24.0),   # aligned windows
+             (3.5, 2.25, 19.5, 14.25), (-6.0, -5.0, 10.0, 7.0), (30.0, 18.0, 46.0, 30.0)]  # unaligned / partly outside
+    for k, bbox in enumerate(boxes):
+        req = dict(mode="vals", bbox=bbox, width=16, height=12, projection="EPSG:28992")
+        try:
+            want = _graph_path(view, req)
+        except NotImplementedError as e:
+            pytest.skip("not on the device path: %s" % e)
+        got = view.get_data(**req)
+        assert_result_equal(unsigned_zero(got), unsigned_zero(want), 0, "bbox %d of %s" % (k, describe(view)))
+    assert len(view.__dict__.get("_gm_plans", {})) <= 1  # one request shape -> at most one plan
+
+
+def test_plan_exists_for_the_canonical_chain_and_is_reused(gpu):
+    from dask_geomodeling_amd import plan, raster
+    from dask_geomodeling_amd.hip import DeviceArray
+    from dask_geomodeling_amd import config as gmconfig
+    rng = np.random.default_rng(1)
+    fill = np.float32(np.finfo("f4").max)
+    a = (rng.random((1, 256, 256)) * 100).astype("f4")
+    b = (rng.random((1, 256, 256)) * 100).astype("f4")
+    a[0, ::9, ::4] = fill
+    A = raster.MemorySource(a, fill, "EPSG:28992", 1.0, (0.0, 256.0))
+    B = raster.MemorySource(b, fill, "EPSG:28992", 1.0, (0.0, 256.0))
+    view = raster.Clip((A + B) * 2.5 - B + 1.5, A)
+    req = dict(mode="vals", bbox=(0.0, 0.0, 64.0, 64.0), width=64, height=64, projection="EPSG:28992")
+    p = plan.view_plan(view, req)
+    assert p is not None and len(p.leaves) == 2
+    for x0, y0 in ((0.0, 0.0), (64.0, 128.0), (192.0, 192.0)):
+        r = dict(req, bbox=(x0, y0, x0 + 64.0, y0 + 64.0))
+        assert plan.view_plan(view, r) is p
+        assert_result_equal(view.get_data(**r), _graph_path(view, r), 0, "window at %s" % ((x0, y0),))
+        with gmconfig.config.set({"geomodeling.materialize": False}):
+            raw = view.get_data(**r)["values"]
+        assert isinstance(raw, DeviceArray)
+    # another request shape: another plan; a stencil view: no plan, graph path
+    assert plan.view_plan(view, dict(req, width=32, height=32, bbox=(0.0, 0.0, 32.0, 32.0))) is not p
+    assert plan.view_plan(raster.MovingMax(view, 3), req) is None
+    # RasterTiler through the store's plans == untiled
+    big = dict(mode="vals", bbox=(0.0, 0.0, 256.0, 256.0), width=256, height=256, projection="EPSG:28992")
+    whole = _graph_path(view, big)
+    for tile in (64, [128, 64], 100):
+        tiler = raster.RasterTiler(view, tile)
+        assert_result_equal(tiler.get_data(**big), whole, 0, "tiler %s through plans" % (tile,))
+        assert_result_equal(_graph_path(tiler, big), whole, 0, "tiler %s through the graph" % (tile,))
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_tiler_through_plans_equals_untiled(gpu, seed):
+    from dask_geomodeling_amd import raster
+    from fuzz_util import REQ
+    rng = np.random.default_rng(30_000 + seed)
+    view = random_view(rng, "u%d" % seed, depth=3, memory=True)
+    try:
+        whole = _graph_path(view, REQ)
+    except NotImplementedError as e:
+        pytest.skip("not on the device path: %s" % e)
+    for tile in ([8, 8], [16, 12], 17):
+        tiled = raster.RasterTiler(view, tile).get_data(**REQ)
+        assert_result_equal(unsigned_zero(tiled), unsigned_zero(whole), 0, "tile %s of %s" % (tile, describe(view)))

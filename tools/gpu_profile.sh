@@ -1,0 +1,19 @@
+#!/bin/bash
+# Measurement of one bench workload on the GPU box (run from the repo root through gpurun):
+#   tools/gpu_profile.sh <tag> <workload> [bench args...]
+# the bench line, the rocprofv3 kernel stats of the same command and the two PMC passes (FETCH_SIZE /
+# WRITE_SIZE need separate passes on gfx950; never combined with trace domains other than --kernel-trace).
+# Everything lands under gpurun_out/prof_<tag>_<workload>/; tools/collect_profiles.py copies the summaries
+# into profiles/.
+TAG=$1; WL=$2; shift 2
+REPO=$PWD
+BASE=$REPO/gpurun_out/prof_${TAG}_${WL}
+rm -rf "$BASE"; mkdir -p "$BASE"
+python bench.py --workload $WL "$@" > "$BASE/bench.log" 2> "$BASE/bench.err"; cut -c1-300 "$BASE/bench.log"; tail -2 "$BASE/bench.err"
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$BASE/stats" -- python3 "$REPO/bench.py" --workload $WL "$@" --cpu-tiles 0 --no-e2e > "$BASE/stats.log" 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$BASE/pmc_$c" -- python3 "$REPO/bench.py" --workload $WL "$@" --steps 3 --warmup 2 --cpu-tiles 0 --no-check --no-e2e > "$BASE/pmc_$c.log" 2>&1
+done
+cd "$REPO"
+python tools/collect_profiles.py "$TAG" "$WL" --dry
