@@ -551,33 +551,41 @@ struct HillArgs {
 // Two tiers.  FAST: sin(arctan2(y, x) - az) * sqrt(xx) = y cos(az) - x sin(az), one v_rsq for the
 // normalisation; its 255 * cang lies within 1.4e-4 of the reference sequence's (measured over 3e8 random
 // gradients at scales 1e-2 .. 1e5 and four sun positions; the bound does not depend on the scale since
-// every term is <= 1 in magnitude).  The truncation can only differ when that value is within the error of
-// an integer, so only cells within HS_MARGIN = 1e-3 of one (0.2 % of cells) take the EXACT tier: the
+// every term is <= 1 in magnitude; worst case by error analysis 3.8e-4, reached only for a sun on the
+// horizon).  The truncation can only differ when that value is within the error of
+// an integer, so only cells within HS_MARGIN = 6e-4 of one (0.12 % of cells) take the EXACT tier: the
 // reference sequence step by step, arctan2 and sin as the float32 roundings of the float64 functions,
 // sqrt and division correctly rounded.  What then remains against NumPy is its own float32 arctan2 (SVML
 // on AVX512 hosts, glibc elsewhere: the reference's output itself differs between such hosts) and sin,
 // which are off the correctly rounded value by 1 ulp on 38 % / 24 % of arguments: 1-5 cells per million
 // differ by 1 (tests/test_gpu_parity.py records the count).
-constexpr float HS_MARGIN = 1e-3f;
-__device__ __forceinline__ unsigned char shade_exact(float x, float y, float xx_plus_yy, const HillArgs& A) {
+constexpr float HS_MARGIN = 6e-4f;
+__device__ __forceinline__ unsigned char shade_exact(float x, float y, const HillArgs& A) {
+  const float xx_plus_yy = x * x + y * y;
   const float aspect = (float)atan2((double)y, (double)x);
   const float t = aspect - A.az32;
   const float s = (float)sin((double)t);
-  const float root = __fsqrt_rn(xx_plus_yy);
+  // (sqrtf and / are the correctly rounded ones under hipcc's default
+  //  -fhip-fp32-correctly-rounded-divide-sqrt; __fsqrt_rn is the 1-ulp native instruction in this toolchain)
+  const float root = sqrtf(xx_plus_yy);
   const float num = A.sin_alt - (A.cos_alt_zsf * root) * s;
-  const float den = __fsqrt_rn(1.0f + A.square_zsf * xx_plus_yy);
-  const float cang = __fdiv_rn(num, den);
+  const float den = sqrtf(1.0f + A.square_zsf * xx_plus_yy);
+  const float cang = num / den;
   return (cang <= 0.0f) ? (unsigned char)0 : (unsigned char)(int)(255.0f * cang);
 }
-__device__ __forceinline__ unsigned char shade_cell(float x, float y, const HillArgs& A) {
+// the fast tier: true when it decided the cell (-> *out), false when the cell is for the exact tier
+__device__ __forceinline__ bool shade_fast(float x, float y, const HillArgs& A, unsigned char* out) {
   const float xx_plus_yy = x * x + y * y;
   const float fast = (A.sin_alt - A.cos_alt_zsf * (y * A.cos_az - x * A.sin_az)) * __builtin_amdgcn_rsqf(1.0f + A.square_zsf * xx_plus_yy);
   const float v = 255.0f * fast;
   const float nearest = rintf(v);
   // (NaN / inf gradients compare false here and take the exact tier, which treats them like NumPy does)
-  const bool decided = fabsf(v - nearest) > HS_MARGIN || nearest < 0.5f;
-  if (decided) return (fast <= 0.0f) ? (unsigned char)0 : (unsigned char)(int)v;
-  return shade_exact(x, y, xx_plus_yy, A);
+  *out = (fast <= 0.0f) ? (unsigned char)0 : (unsigned char)(int)v;
+  return fabsf(v - nearest) > HS_MARGIN || nearest < 0.5f;
+}
+__device__ __forceinline__ unsigned char shade_cell(float x, float y, const HillArgs& A) {
+  unsigned char r;
+  return shade_fast(x, y, A, &r) ? r : shade_exact(x, y, A);
 }
 
 // T arithmetic exactly as NumPy carries it out on a T array: integers wrap modulo 2^bits,
@@ -657,6 +665,11 @@ __global__ __launch_bounds__(256) void hillshade_tile_kernel(const T* __restrict
                                                              int h, int w, int has_ndv, T ndv, T fill, HillArgs A) {
   __shared__ T tile[(HT_H + 2) * (HT_W + 2)];
   __shared__ unsigned char shade[4][HT_H * 64];  // per wave: HT_H rows x 64 columns
+  constexpr unsigned HT_PENDING = 256;
+  __shared__ float pending_x[HT_PENDING], pending_y[HT_PENDING];
+  __shared__ unsigned short pending_at[HT_PENDING];
+  __shared__ unsigned pending_count;
+  if (threadIdx.x == 0) pending_count = 0;
   const int c0 = blockIdx.x * HT_W, r0 = blockIdx.y * HT_H, b = blockIdx.z;
   const int ow = w - 2, oh = h - 2;
   const T* plane = in + (size_t)b * h * w;
@@ -690,14 +703,36 @@ __global__ __launch_bounds__(256) void hillshade_tile_kernel(const T* __restrict
     // spatial.py:384-404 (s0..s8 = rows top/middle/bottom x columns left/middle/right)
     const float y = gradient<T>(top[0], top[1], top[2], bot[0], bot[1], bot[2], A.yres, A.yres32, A.yinv, A.yinv32);
     const float x = gradient<T>(top[0], mid[0], bot[0], top[2], mid[2], bot[2], A.xres, A.xres32, A.xinv, A.xinv32);
-    shade[wave][r * 64 + lane] = shade_cell(x, y, A);
+    // cells the fast tier cannot decide are queued for the whole workgroup and shaded together after the
+    // walk: a wave that met one would otherwise run the (float64 arctan2 + sin) exact tier for a single lane
+    unsigned char fast_result;
+    if (!shade_fast(x, y, A, &fast_result)) {
+      const unsigned slot = atomicAdd(&pending_count, 1u);
+      if (slot < HT_PENDING) {
+        pending_x[slot] = x;
+        pending_y[slot] = y;
+        pending_at[slot] = (unsigned short)((wave << 10) | (r * 64 + lane));
+      } else {
+        fast_result = shade_exact(x, y, A);  // (queue full -- e.g. a plateau whose shade sits on an integer)
+      }
+    }
+    shade[wave][r * 64 + lane] = fast_result;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       top[j] = mid[j];
       mid[j] = bot[j];
     }
   }
-  // (one wave wrote, the same wave reads: in-order LDS, no barrier)  lane l: row l / 4, columns 16 (l % 4) ..
+  __syncthreads();
+  {
+    const unsigned n_pending = min(pending_count, HT_PENDING);
+    for (unsigned i = threadIdx.x; i < n_pending; i += 256) {
+      const unsigned at = pending_at[i];
+      shade[at >> 10][at & 1023u] = shade_exact(pending_x[i], pending_y[i], A);
+    }
+  }
+  __syncthreads();
+  // lane l: row l / 4, columns 16 (l % 4) ..
   const int part = lane & 3;
 #pragma unroll
   for (int row = lane >> 2; row < HT_H; row += 16) {
