@@ -1,0 +1,288 @@
+// N4: reduce_rasters (raster/reduction.py:38-119) -- a statistic over a stack of rasters, skipping no data.
+//
+// The host has cast every raster of the stack to the reference's work dtype
+// W = result_type(dtype, float16) with NaN for no data (program op NANIFNODATA, one launch per raster),
+// exactly as reduction.py:99-107 fills `stack_array`; this file is NumPy's nan-function along axis 0 of
+// that (n, pixels) stack:
+//   * a lane owns V consecutive pixels and walks the frames in order -- NumPy's axis-0 reduction of a
+//     C-contiguous stack accumulates frame by frame in W (the pairwise summation only applies along the
+//     contiguous axis), so sum / product / mean / var round exactly where NumPy rounds;
+//   * nansum adds +0 for NaN, nanprod multiplies by 1, nanmin / nanmax are fmin / fmax with the
+//     accumulator first, nanargmin / nanargmax replace NaN by +-inf and take the first extremum;
+//   * nanmean = float64(sum) / float64(count) rounded once to W (np.true_divide of a W array by an intp
+//     count runs the float64 loop); nanvar = mean of squared W-deviations from that rounded mean,
+//     nanstd its square root in W;
+//   * nanmedian (< 600 frames: np.ma.median) sorts the data frames of a cell and returns (low + high) / 2;
+//     nanpercentile interpolates between the two neighbours of the virtual index with NumPy's _lerp, the
+//     host having derived index and weight per number of data frames with NumPy's own arithmetic.
+// W = float16 (1-byte rasters) is float32 storage here; NumPy's float16 loops compute in float32 and round
+// the result to float16 after every operation, and so does HALF = true (division by the count: float64
+// quotient rounded straight to float16).  Cells that are NaN in every raster get `fill`; every other
+// result is left as it is (incl. NaN / inf of overflowing data): the cast into the output dtype is the
+// caller's, like the reference's `out[not_all_nan] = func(...)`.
+// HBM traffic: n * itemsize + itemsize bytes per pixel (twice the reads for var / std).
+#include <cmath>
+#include <limits>
+
+#include "gm_common.h"
+
+namespace {
+
+template <typename C, int V>
+struct Pack {
+  C v[V];
+};
+template <typename C, int V>
+__device__ __forceinline__ Pack<C, V> load_pack(const C* p) {
+  Pack<C, V> r;
+  if constexpr (V == 1) {
+    r.v[0] = __builtin_nontemporal_load(p);
+  } else {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 w = __builtin_nontemporal_load((const u4*)p);
+    memcpy(&r, &w, 16);
+  }
+  return r;
+}
+template <typename C, int V>
+__device__ __forceinline__ void store_pack(C* p, const Pack<C, V>& r) {
+  if constexpr (V == 1) {
+    __builtin_nontemporal_store(r.v[0], p);
+  } else {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 w;
+    memcpy(&w, &r, 16);
+    __builtin_nontemporal_store(w, (u4*)p);
+  }
+}
+
+// rounding of a float32 result to float16 (NumPy's HALF loops: float32 operation, then npy_float_to_half)
+template <bool HALF, typename C>
+__device__ __forceinline__ C rnd(C x) {
+  if constexpr (HALF) return (C)(float)(_Float16)(float)x;
+  else return x;
+}
+// float64 -> W: for float16 one rounding straight from the float64 value (npy_double_to_half): float64 ->
+// float32 rounded to odd keeps the sticky information the final float32 -> float16 rounding needs
+template <bool HALF, typename C>
+__device__ __forceinline__ C from_f64(double d) {
+  if constexpr (!HALF) {
+    return (C)d;
+  } else {
+    float f = __double2float_rz(d);
+    if ((double)f != d && d == d && fabs(d) <= 3.0e38) f = __uint_as_float(__float_as_uint(f) | 1u);
+    return (C)(float)(_Float16)f;
+  }
+}
+
+constexpr int RD_UNROLL = 4;
+constexpr int RD_MAX_SORT = 64;
+
+// sum / product / min / max / mean / var / std / argmin / argmax
+template <typename C, bool HALF, int STAT, int V>
+__global__ __launch_bounds__(256) void reduce_kernel(const C* __restrict__ stack, int n, long long pixels,
+                                                     C* __restrict__ out, C fill) {
+  const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
+  if (p >= pixels) return;
+  const C* src = stack + p;
+  const C nan = std::numeric_limits<C>::quiet_NaN(), inf = std::numeric_limits<C>::infinity();
+  C acc[V];
+  int cnt[V], arg[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    acc[e] = (STAT == GM_RED_MIN || STAT == GM_RED_MAX) ? nan : (C)0;
+    cnt[e] = 0;
+    arg[e] = 0;
+  }
+  auto take = [&](const Pack<C, V>& f, int j) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const C x = f.v[e];
+      const bool nd = x != x;
+      cnt[e] += nd ? 0 : 1;
+      if constexpr (STAT == GM_RED_MIN) {
+        acc[e] = (acc[e] <= x || nd) ? acc[e] : x;  // np.fmin.reduce, the accumulator first
+      } else if constexpr (STAT == GM_RED_MAX) {
+        acc[e] = (acc[e] >= x || nd) ? acc[e] : x;
+      } else if constexpr (STAT == GM_RED_PRODUCT) {
+        const C y = nd ? (C)1 : x;
+        acc[e] = j == 0 ? y : rnd<HALF, C>(acc[e] * y);
+      } else if constexpr (STAT == GM_RED_ARGMIN) {
+        const C y = nd ? inf : x;  // _replace_nan(a, +inf), np.argmin: the first minimum
+        if (j == 0 || y < acc[e]) { acc[e] = y; arg[e] = j; }
+      } else if constexpr (STAT == GM_RED_ARGMAX) {
+        const C y = nd ? -inf : x;
+        if (j == 0 || y > acc[e]) { acc[e] = y; arg[e] = j; }
+      } else {
+        const C y = nd ? (C)0 : x;
+        acc[e] = j == 0 ? y : rnd<HALF, C>(acc[e] + y);  // np.add.reduce starts from the first frame
+      }
+    }
+  };
+  int j = 0;
+  for (; j + RD_UNROLL <= n; j += RD_UNROLL) {
+    Pack<C, V> f[RD_UNROLL];
+#pragma unroll
+    for (int u = 0; u < RD_UNROLL; ++u) f[u] = load_pack<C, V>(src + (long long)(j + u) * pixels);
+#pragma unroll
+    for (int u = 0; u < RD_UNROLL; ++u) take(f[u], j + u);
+  }
+  for (; j < n; ++j) take(load_pack<C, V>(src + (long long)j * pixels), j);
+
+  C r[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) r[e] = (STAT == GM_RED_ARGMIN || STAT == GM_RED_ARGMAX) ? (C)arg[e] : acc[e];
+  if constexpr (STAT == GM_RED_MEAN || STAT == GM_RED_VAR || STAT == GM_RED_STD) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) r[e] = from_f64<HALF, C>((double)acc[e] / (double)cnt[e]);
+  }
+  if constexpr (STAT == GM_RED_VAR || STAT == GM_RED_STD) {
+    C sq[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) sq[e] = (C)0;
+    auto dev = [&](const Pack<C, V>& f, int k) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const C x = f.v[e];
+        const C d = (x != x) ? (C)0 : rnd<HALF, C>(x - r[e]);
+        const C y = rnd<HALF, C>(d * d);
+        sq[e] = k == 0 ? y : rnd<HALF, C>(sq[e] + y);
+      }
+    };
+    int k = 0;
+    for (; k + RD_UNROLL <= n; k += RD_UNROLL) {
+      Pack<C, V> f[RD_UNROLL];
+#pragma unroll
+      for (int u = 0; u < RD_UNROLL; ++u) f[u] = load_pack<C, V>(src + (long long)(k + u) * pixels);
+#pragma unroll
+      for (int u = 0; u < RD_UNROLL; ++u) dev(f[u], k + u);
+    }
+    for (; k < n; ++k) dev(load_pack<C, V>(src + (long long)k * pixels), k);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      C var = from_f64<HALF, C>((double)sq[e] / (double)cnt[e]);
+      if constexpr (STAT == GM_RED_STD) var = rnd<HALF, C>(sqrt(var));
+      r[e] = var;
+    }
+  }
+  Pack<C, V> res;
+#pragma unroll
+  for (int e = 0; e < V; ++e) res.v[e] = cnt[e] > 0 ? r[e] : fill;
+  store_pack<C, V>(out + p, res);
+}
+
+struct SortPlan {  // gm_percentile_step per number of data frames (1 .. RD_MAX_SORT)
+  short lower[RD_MAX_SORT], upper[RD_MAX_SORT];
+  double gamma[RD_MAX_SORT], one_minus_gamma[RD_MAX_SORT];
+};
+
+// median / percentile: the data frames of a cell insertion-sorted into the lane's column of an LDS array
+template <typename C, bool HALF, bool PERCENTILE>
+__global__ __launch_bounds__(256) void reduce_sorted_kernel(const C* __restrict__ stack, int n, long long pixels,
+                                                            SortPlan P, C* __restrict__ out, C fill) {
+  extern __shared__ unsigned char lds_raw[];
+  C* column = reinterpret_cast<C*>(lds_raw) + threadIdx.x;  // [slot][lane]
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= pixels) return;
+  const C* src = stack + p;
+  int m = 0;
+  for (int j = 0; j < n; ++j) {
+    const C x = __builtin_nontemporal_load(src + (long long)j * pixels);
+    if (x != x) continue;
+    int i = m;
+    while (i > 0 && column[(i - 1) * 256] > x) {
+      column[i * 256] = column[(i - 1) * 256];
+      --i;
+    }
+    column[i * 256] = x;
+    ++m;
+  }
+  C r = fill;
+  if (m > 0) {
+    if constexpr (PERCENTILE) {
+      const C a = column[P.lower[m - 1] * 256], b = column[P.upper[m - 1] * 256];
+      const C t = (C)P.gamma[m - 1], u = (C)P.one_minus_gamma[m - 1];
+      const C d = rnd<HALF, C>(b - a);
+      r = (t >= (C)0.5) ? rnd<HALF, C>(b - rnd<HALF, C>(d * u)) : rnd<HALF, C>(a + rnd<HALF, C>(d * t));
+    } else {
+      const int h = m / 2;
+      const C high = column[h * 256];
+      const C low = (m & 1) ? high : column[(h - 1) * 256];
+      r = rnd<HALF, C>(rnd<HALF, C>(low + high) / (C)2);  // np.ma.median: sum of the two, then / 2.
+    }
+  }
+  __builtin_nontemporal_store(r, out + p);
+}
+
+template <typename C>
+C fill_of(uint64_t bits) {
+  gm_scalar s;
+  s.u64 = bits;
+  return (C)s.f64;
+}
+
+template <typename C, bool HALF>
+int launch_reduce(const void* stack, int n, long long pixels, int statistic, const gm_percentile_step* plan,
+                  void* out, uint64_t fill_bits, hipStream_t s) {
+  const C fill = fill_of<C>(fill_bits);
+  if (statistic == GM_RED_MEDIAN || statistic == GM_RED_PERCENTILE) {
+    if (n > RD_MAX_SORT || (size_t)n * 256 * sizeof(C) > 64 * 1024)
+      return gm::fail(GM_ERR_UNSUPPORTED, "gm_reduce_stack: median / percentile over %d rasters (LDS holds %d)", n,
+                      (int)(64 * 1024 / (256 * sizeof(C))));
+    SortPlan P;
+    memset(&P, 0, sizeof(P));
+    if (statistic == GM_RED_PERCENTILE) {
+      if (!plan) return gm::fail(GM_ERR_INVALID, "gm_reduce_stack: percentile without a plan");
+      for (int i = 0; i < n; ++i) {
+        if (plan[i].lower < 0 || plan[i].lower > i || plan[i].upper < 0 || plan[i].upper > i)
+          return gm::fail(GM_ERR_INVALID, "gm_reduce_stack: plan[%d] points outside %d values", i, i + 1);
+        P.lower[i] = (short)plan[i].lower;
+        P.upper[i] = (short)plan[i].upper;
+        P.gamma[i] = plan[i].gamma;
+        P.one_minus_gamma[i] = plan[i].one_minus_gamma;
+      }
+    }
+    const unsigned gx = (unsigned)((pixels + 255) / 256);
+    const size_t lds = (size_t)n * 256 * sizeof(C);
+    if (statistic == GM_RED_PERCENTILE)
+      hipLaunchKernelGGL((reduce_sorted_kernel<C, HALF, true>), dim3(gx), dim3(256), lds, s, (const C*)stack, n, pixels, P, (C*)out, fill);
+    else
+      hipLaunchKernelGGL((reduce_sorted_kernel<C, HALF, false>), dim3(gx), dim3(256), lds, s, (const C*)stack, n, pixels, P, (C*)out, fill);
+    return GM_OK;
+  }
+  constexpr int VV = 16 / (int)sizeof(C);
+  const bool vec = (pixels % VV) == 0 && ((uintptr_t)stack % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  const int V = vec ? VV : 1;
+  const unsigned gx = (unsigned)((pixels + 256LL * V - 1) / (256LL * V));
+#define GM_RD(STAT)                                                                                                    \
+  case STAT:                                                                                                           \
+    if (vec) hipLaunchKernelGGL((reduce_kernel<C, HALF, STAT, VV>), dim3(gx), dim3(256), 0, s, (const C*)stack, n, pixels, (C*)out, fill); \
+    else hipLaunchKernelGGL((reduce_kernel<C, HALF, STAT, 1>), dim3(gx), dim3(256), 0, s, (const C*)stack, n, pixels, (C*)out, fill);      \
+    break;
+  switch (statistic) {
+    GM_RD(GM_RED_SUM) GM_RD(GM_RED_MIN) GM_RD(GM_RED_MAX) GM_RD(GM_RED_MEAN) GM_RD(GM_RED_VAR) GM_RD(GM_RED_STD)
+    GM_RD(GM_RED_PRODUCT) GM_RD(GM_RED_ARGMIN) GM_RD(GM_RED_ARGMAX)
+    default: return gm::fail(GM_ERR_INVALID, "gm_reduce_stack: statistic %d", statistic);
+  }
+#undef GM_RD
+  return GM_OK;
+}
+
+}  // namespace
+
+extern "C" int gm_reduce_stack(const void* stack, int work_dtype, int half, int64_t n, int64_t pixels, int statistic,
+                               const gm_percentile_step* plan, void* out, uint64_t fill_bits) {
+  if (!stack || !out) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (n <= 0 || n > 0x7fffffff || pixels < 0) return gm::fail(GM_ERR_INVALID, "gm_reduce_stack: %lld rasters of %lld pixels", (long long)n, (long long)pixels);
+  if (pixels == 0) return GM_OK;
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  int rc;
+  if (work_dtype == GM_F32) rc = half ? launch_reduce<float, true>(stack, (int)n, pixels, statistic, plan, out, fill_bits, s)
+                                      : launch_reduce<float, false>(stack, (int)n, pixels, statistic, plan, out, fill_bits, s);
+  else if (work_dtype == GM_F64 && !half) rc = launch_reduce<double, false>(stack, (int)n, pixels, statistic, plan, out, fill_bits, s);
+  else return gm::fail(GM_ERR_INVALID, "gm_reduce_stack: work dtype %d (half %d)", work_dtype, half);
+  if (rc) return rc;
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}

@@ -272,27 +272,45 @@ __device__ __forceinline__ void load_elems(const void* base, int dtype, unsigned
 #undef GM_LOAD_CASE8
 }
 
+// float64 -> int64 of a result: the one value that matters beyond 2^63 - 1024 is the int64 fill value
+// (the dtype's maximum, which float64 holds as 2^63): it must come out as INT64_MAX, like the reference's
+// np.full(shape, fillvalue, int64) -- a plain cast of 2^63 is undefined
+template <typename T, typename RC>
+__device__ __forceinline__ T to_stored(RC v) {
+  if constexpr (std::is_same<RC, double>::value && std::is_same<T, long long>::value) {
+    return v >= 9223372036854775807.0 ? 9223372036854775807ll : (long long)v;
+  } else if constexpr (is_float_class<RC>::value && std::is_integral<T>::value && sizeof(T) < 4) {
+    // float -> 1- / 2-byte integer: through int32 and a truncation, like NumPy's cast on x86 (700.0 -> 188).
+    // A direct float -> uint8 conversion is undefined for values outside the type, and the compiler then
+    // packs the four bytes of a group without masking: an out-of-range value would spill into its neighbours
+    return (T)(int)v;
+  } else {
+    return (T)v;
+  }
+}
+
 template <typename RC, int N>
 __device__ __forceinline__ void store_elems(void* base, int dtype, unsigned long long e, bool nt, const RC (&v)[N]) {
 #define GM_STORE_CASE(DT, T, VT4)                                                    \
   case DT: {                                                                         \
     if constexpr (N == 4) {                                                          \
       VT4 x;                                                                         \
-      _Pragma("unroll") for (int k = 0; k < 4; ++k) x[k] = (T)v[k];                  \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) x[k] = to_stored<T, RC>(v[k]);   \
       st((VT4*)((T*)base + e), x, nt);                                               \
     } else {                                                                         \
-      st((T*)base + e, (T)v[0], nt);                                                 \
+      st((T*)base + e, to_stored<T, RC>(v[0]), nt);                                  \
     }                                                                                \
   } break;
 #define GM_STORE_CASE8(DT, T, VT2)                                                   \
   case DT: {                                                                         \
     if constexpr (N == 4) {                                                          \
       VT2 x0, x1;                                                                    \
-      x0[0] = (T)v[0]; x0[1] = (T)v[1]; x1[0] = (T)v[2]; x1[1] = (T)v[3];            \
+      x0[0] = to_stored<T, RC>(v[0]); x0[1] = to_stored<T, RC>(v[1]);                \
+      x1[0] = to_stored<T, RC>(v[2]); x1[1] = to_stored<T, RC>(v[3]);                \
       st((VT2*)((T*)base + e), x0, nt);                                              \
       st((VT2*)((T*)base + e + 2), x1, nt);                                          \
     } else {                                                                         \
-      st((T*)base + e, (T)v[0], nt);                                                 \
+      st((T*)base + e, to_stored<T, RC>(v[0]), nt);                                  \
     }                                                                                \
   } break;
   switch (dtype) {
@@ -1237,7 +1255,7 @@ __device__ __forceinline__ void vm_body() {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const RC r = M.acc[4 * u + q];
-          const unsigned byte = od == GM_I8 ? (unsigned)(unsigned char)(signed char)r : (unsigned)(unsigned char)r;
+          const unsigned byte = (unsigned)(unsigned char)(int)r;  // (through int32: see to_stored)
           word |= byte << (8 * q);
         }
         mine[64 * u + lane] = word;

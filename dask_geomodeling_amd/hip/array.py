@@ -10,6 +10,7 @@ object dies (all work of a device is ordered on one stream, so reuse is safe).
 import ctypes
 
 import numpy as np
+from math import prod as _prod
 
 from . import runtime
 from .dtypes import code_of
@@ -34,7 +35,7 @@ class DeviceArray:
         dtype = np.dtype(dtype)
         code_of(dtype)
         shape = tuple(int(s) for s in shape)
-        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        nbytes = _prod(shape) * dtype.itemsize
         ptr = runtime.malloc(max(nbytes, 1))
         return cls(ptr, shape, dtype, runtime.get_device())
 
@@ -55,7 +56,7 @@ class DeviceArray:
 
     @property
     def size(self):
-        return int(np.prod(self.shape, dtype=np.int64))
+        return _prod(self.shape)
 
     @property
     def nbytes(self):
@@ -112,14 +113,14 @@ class DeviceArray:
         start, stop = int(start), int(stop)
         if self.pitch is not None:
             raise ValueError("band_slice() of a strided window")
-        plane = int(np.prod(self.shape[1:], dtype=np.int64)) * self.dtype.itemsize
+        plane = _prod(self.shape[1:]) * self.dtype.itemsize
         return DeviceArray(self.ptr + start * plane, (stop - start,) + self.shape[1:], self.dtype,
                            self.device, owner=self)
 
     def reshape(self, *shape):
         if len(shape) == 1 and hasattr(shape[0], "__iter__"):
             shape = tuple(shape[0])
-        if int(np.prod(shape, dtype=np.int64)) != self.size:
+        if _prod(shape) != self.size:
             raise ValueError("cannot reshape %s into %s" % (self.shape, shape))
         if self.pitch is not None:
             return self.contiguous().reshape(shape)

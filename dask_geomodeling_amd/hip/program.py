@@ -10,6 +10,7 @@ reference, raster/elemwise.py:263-296).
 import ctypes
 
 import numpy as np
+from math import prod as _prod
 
 from . import runtime
 from .array import DeviceArray, as_device, as_device_view
@@ -300,6 +301,11 @@ def node_classes(node):
             allowed = frozenset(c for c in allowed if _value_exact(v, node.dtype, c))
     elif op == "fillnodata":
         allowed = classes_for_compute(node.dtype) if node.dtype.kind == "f" or node.dtype.itemsize >= 4 else ALL_CLASSES
+        if node.dtype.kind != "f" and any(not isinstance(a, Lit) and a.dtype.kind == "f" for a in node.args):
+            # float tiles pasted into an integer result (reduce_rasters 'first' / 'last' with an integer output
+            # dtype: out[index] = values[index] casts on assignment): nothing is computed on the way, so the values
+            # travel as float64 and the truncating cast happens once, at the store
+            allowed = frozenset((CLASS_F64,))
         for a in node.args:
             if not isinstance(a, Lit):
                 allowed = allowed & classes_exact(a.dtype)
@@ -354,7 +360,10 @@ def node_classes(node):
     # load time (gm_input_desc.native_ndv)
     cd = compute_dtype(node)
     casts_to_f64 = (cd is not None and cd == np.dtype("f8")) or \
-        op in ("mask", "isdata", "isnodata")  # these only ask "is the cell no data?": the tag suffices
+        op in ("mask", "isdata", "isnodata") or \
+        (op == "nanifnodata" and np.dtype(node.extra["work"]) == np.dtype("f8"))
+    # (mask / isdata / isnodata only ask "is the cell no data?": the tag suffices; nanifnodata into a float64
+    #  work dtype is the reference's own values.astype(float64), reduction.py:99-107)
     for a in node.args:
         if isinstance(a, Leaf):
             allowed = frozenset(c for c in allowed if exact_in_class(a.dtype, c)
@@ -808,7 +817,7 @@ def launch_batch(compiled, tiles, shape, outs=None):
     zero-copy windows (DeviceArray.pitch) of larger resident rasters, and so may the ``outs``
     (tiles written straight into their mosaic)."""
     L = _lib()
-    n = int(np.prod(shape, dtype=np.int64))
+    n = _prod(shape)
     n_in = len(tiles[0]) if tiles else 0
     if any(len(inputs) != n_in for inputs in tiles):
         raise ValueError("every tile of a batch must bring the same number of inputs")
@@ -818,7 +827,7 @@ def launch_batch(compiled, tiles, shape, outs=None):
     ptrs = (ctypes.c_void_p * max(len(flat), 1))(*[x.ptr for x in flat])
     out_ptrs = (ctypes.c_void_p * max(len(outs), 1))(*[o.ptr for o in outs])
     if any(x.pitch is not None for x in flat) or any(o.pitch is not None for o in outs):
-        rows, cols = int(np.prod(shape[:-1], dtype=np.int64)), int(shape[-1])
+        rows, cols = _prod(shape[:-1]), int(shape[-1])
         pitches = (ctypes.c_uint32 * max(len(flat), 1))(*[x.pitch or 0 for x in flat])
         out_pitches = (ctypes.c_uint32 * max(len(outs), 1))(*[o.pitch or 0 for o in outs])
         runtime.check(L.gm_elemwise_run_batch_2d(ctypes.byref(compiled.program), len(tiles), ptrs, pitches, out_ptrs,
@@ -866,7 +875,7 @@ def plan(root):
         if not isinstance(leaf, StageRef):
             leaf.values = as_device_view(leaf.values)
     shapes = [_leaf_shape(leaf) for leaf in leaves]
-    sizes = [int(np.prod(sh, dtype=np.int64)) for sh in shapes]
+    sizes = [_prod(sh) for sh in shapes]
     shape, n = max(zip(shapes, sizes), key=lambda t: t[1])
     for slot, (leaf, size, sh) in enumerate(zip(leaves, sizes, shapes)):
         if size != n and size != 1:
@@ -904,7 +913,7 @@ def plan_staged(root):
     def any_shape(node):
         for leaf in _collect_leaves(node):
             sh = _leaf_shape(leaf)
-            if int(np.prod(sh, dtype=np.int64)) != 1:
+            if _prod(sh) != 1:
                 return sh
         return _leaf_shape(_collect_leaves(node)[0])
 

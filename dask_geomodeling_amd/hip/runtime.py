@@ -5,6 +5,7 @@ missing, or no MI355X is visible when a kernel is requested, a ``GmHipError`` is
 raised -- loudly, never a silent CPU path.
 """
 import ctypes
+from math import prod as _prod
 import os
 import threading
 
@@ -155,11 +156,11 @@ def pinned_empty(shape, dtype):
     PCIe speed); the buffer is recycled when the array and all views of it are gone."""
     import numpy as np
     dtype = np.dtype(dtype)
-    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    nbytes = _prod(shape) * dtype.itemsize
     owner = _Pinned(max(nbytes, 1))
     raw = (ctypes.c_ubyte * max(nbytes, 1)).from_address(owner.ptr)
     raw._owner = owner  # the ndarray keeps `raw` alive, `raw` keeps the pinned buffer alive
-    return np.frombuffer(raw, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+    return np.frombuffer(raw, dtype=dtype, count=_prod(shape)).reshape(shape)
 
 
 def pool_trim():

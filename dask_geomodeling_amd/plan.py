@@ -20,6 +20,11 @@ dask schedulers -- takes the ordinary graph path, as does a request whose plan c
 from . import config as _config
 from .core.graphs import Block, _request_token
 
+try:  # resolved once: a failing import would search sys.path on every request
+    from dask.base import get_scheduler as _dask_get_scheduler
+except ImportError:
+    _dask_get_scheduler = None
+
 __all__ = ["evaluate", "ViewPlan", "clear"]
 
 MAX_PLANS_PER_VIEW = 32
@@ -61,8 +66,13 @@ class ViewPlan(object):
     def leaf_values(self, bbox):
         values = []
         for block, request in self.leaves:
-            pairs = block.get_sources_and_requests(**dict(request, bbox=bbox))
-            values.append(block.process(*[s for s, _ in pairs]))
+            request = dict(request, bbox=bbox)
+            short_cut = getattr(block, "gm_plan_response", None)
+            response = short_cut(request) if short_cut is not None else None
+            if response is None:
+                pairs = block.get_sources_and_requests(**request)
+                response = block.process(*[s for s, _ in pairs])
+            values.append(response)
         return values
 
     def run(self, bbox):
@@ -149,12 +159,8 @@ def enabled():
         return False
     if _config.get("scheduler_get") is not None:
         return False
-    try:  # a scheduler configured in dask owns the evaluation
-        from dask.base import get_scheduler
-        if get_scheduler() is not None:
-            return False
-    except ImportError:
-        pass
+    if _dask_get_scheduler is not None and _dask_get_scheduler() is not None:
+        return False  # a scheduler configured in dask owns the evaluation
     return True
 
 

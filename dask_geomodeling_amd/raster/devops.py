@@ -118,10 +118,8 @@ def reduce_max_node(process_kwargs, nodes):
     work = np.dtype("f4") if work.itemsize < 4 else work
     acc = None
     for node in nodes:
-        if node.dtype.kind in "iu" and node.dtype.itemsize == 8:
-            # the reference squeezes 64-bit integers through float64 (reduction.py:99-107) and casts
-            # back; what comes out near the ends of the range is a property of the host's cast
-            raise NotImplementedError("Max of 64-bit integer rasters is not supported on the device")
+        # (64-bit integer rasters go through float64 like in the reference, reduction.py:99-107: values
+        #  beyond 2^53 round on the way, the int64 fill value comes back as INT64_MAX)
         if node.dtype.kind == "f":
             in_f64, y, tol, finite = isclose_params(node.dtype, node.ndv)
             extra = {"flags": (1 if in_f64 else 0) | (2 if finite else 0), "tol": tol, "y": y, "work": work}

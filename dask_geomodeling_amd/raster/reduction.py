@@ -1,7 +1,24 @@
-"""Reduction Blocks (counterpart of raster/reduction.py): ``Max`` takes the maximum of two or
-more rasters, ignoring no data.  The numerics run as one element-wise program
-(devops.reduce_max_node): every raster with its no-data coded as NaN, np.fmax left to right,
-NaN -> fill -- fusable with whatever feeds and follows it."""
+"""Reduction over a stack of rasters (counterpart of raster/reduction.py).
+
+``reduce_rasters(stack, statistic, no_data_value=None, dtype=None)`` applies one of the reference's
+statistics -- first, last, count, sum, mean, min, max, argmin, argmax, std, var, median, product,
+p<number> -- to a list of raster responses, skipping no data (reduction.py:38-119); ``Max`` is the Block
+built on it (reduction.py:215-230).  On this path the rasters stay on the device:
+
+* ``first`` / ``last`` / ``count`` work on the rasters themselves: a chain of "take the tile where it has
+  data" steps (the FillNoData program op, utils.get_index's isclose rule for float tiles), resp. a sum of
+  data masks, as ONE element-wise program over the stack;
+* ``max`` is a program too (NaN-coded no data, np.fmax left to right: devops.reduce_max_node) -- it fuses
+  with whatever feeds and follows a ``Max`` Block;
+* every other statistic follows the reference literally: each raster is cast to the work dtype
+  ``result_type(dtype, float16)`` with NaN for no data into one (n, bands, H, W) stack (program op
+  NANIFNODATA writing straight into its slice), ``gm_reduce_stack`` (csrc/gm_reduce.hip) is NumPy's
+  nan-function along axis 0 of that stack -- same accumulation order, same roundings, float16 work dtypes
+  rounded after every operation like NumPy's float16 loops --, cells that are no data everywhere get the
+  fill value and the result is cast into the output dtype.
+"""
+import ctypes
+
 import numpy as np
 
 from ..utils import Extent
@@ -9,61 +26,206 @@ from . import devops
 from .base import RasterBlock
 from .elemwise import BaseElementwise
 
-__all__ = ["Max"]
+__all__ = ["Max", "reduce_rasters", "check_statistic"]
+
+# statistic -> code of csrc/gm_reduce.hip (None: handled by an element-wise program)
+STATISTICS = {"first": None, "last": None, "count": None, "sum": 0, "mean": 4, "min": 2, "max": 3, "argmin": 9,
+              "argmax": 10, "std": 6, "var": 5, "median": 7, "product": 8}
+_PERCENTILE_CODE = 11
+MAX_SORTED_RASTERS = 64  # median / percentile sort a cell's values in LDS
 
 
-def filter_none(lst):
-    return [x for x in lst if x is not None]
+def parse_percentile_statistic(statistic):
+    """'p<number>' -> ('percentile', number); anything else -> (statistic, None)  (utils.py:805-823)."""
+    import re
+    match = re.match(r"^p(\d+(\.\d+)?)$", statistic)
+    if not match:
+        return statistic, None
+    percentile = float(match.group(1))
+    if not 0 <= percentile <= 100:
+        raise ValueError("Percentiles must be in the range [0, 100]")
+    return "percentile", percentile
+
+
+def check_statistic(statistic):
+    if statistic not in STATISTICS:
+        statistic, percentile = parse_percentile_statistic(statistic)
+        if percentile is None:
+            raise ValueError('Unknown statistic "{}"'.format(statistic))
+
+
+def _index_extra(dtype, ndv):
+    """flags / tolerance of utils.get_index for a tile: isclose for float tiles, exact != for the others."""
+    dtype = np.dtype(dtype)
+    if dtype.kind == "f":
+        in_f64, y, tol, finite = devops.isclose_params(dtype, ndv)
+        return {"flags": (1 if in_f64 else 0) | (2 if finite else 0), "tol": tol, "y": y}
+    return {"flags": 4, "tol": 0.0, "y": 0.0}
+
+
+def _stack_nodes(stack):
+    from ..hip import program as P
+    return [P.Leaf(None, data["values"].dtype, data["no_data_value"], values=data["values"]) for data in stack]
+
+
+def _through_program(root):
+    from ..hip import program as P
+    values, _ = P.evaluate(root)
+    return values
+
+
+def _pick(stack, order, fill_value, dtype):
+    """'last' / 'first': out[index] = values[index] raster after raster (reduction.py:78-87)."""
+    from ..hip import program as P
+    nodes = _stack_nodes(stack)
+    acc = P.Lit(dtype.type(fill_value))
+    for node in (nodes if order == "last" else nodes[::-1]):
+        acc = devops.fillnodata_node(acc, node, dtype, fill_value)
+    return _through_program(acc)
+
+
+def _count(stack, dtype):
+    """'count': out += get_index(values, ndv) raster after raster (reduction.py:88-91)."""
+    from ..hip import program as P
+    counter = np.dtype("f8") if dtype.kind == "f" else (np.dtype("i8") if dtype.itemsize == 8 else np.dtype("i4"))
+    acc = None
+    for node in _stack_nodes(stack):
+        extra = dict(_index_extra(node.dtype, node.ndv), value=1, fill=0)
+        is_data = P.Op("mask", [node], counter, None, extra=extra)
+        acc = is_data if acc is None else P.Op("add", [acc, is_data], counter, None, fill=0)
+    if counter != dtype:
+        acc = P.Op("copy", [acc], dtype, None)  # (integers wrap modulo the output width, like out += index)
+    return _through_program(acc)
+
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    from ..hip import runtime
+    L = runtime.lib()
+    if not _declared:
+        c = ctypes
+        L.gm_reduce_stack.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int64, c.c_int64, c.c_int, c.c_void_p,
+                                      c.c_void_p, c.c_uint64]
+        L.gm_reduce_stack.restype = c.c_int
+        _declared = True
+    return L
+
+
+def _nan_function(stack, statistic, percentile, fill_value, dtype):
+    """NumPy's nan-function of the statistic over the NaN-coded stack in the work dtype (reduction.py:92-117)."""
+    from ..hip import program as P
+    from ..hip import runtime
+    from ..hip.array import DeviceArray
+    from ..hip.dtypes import code_of
+    from .temporal import percentile_plan
+    work = np.result_type(dtype, np.float16)
+    half = work.itemsize < 4
+    storage = np.dtype("f4") if work.itemsize <= 4 else np.dtype("f8")
+    nodes = _stack_nodes(stack)
+    if half and any(node.dtype.itemsize != 1 for node in nodes):
+        raise NotImplementedError("reduce_rasters in float16 (output dtype %s) of rasters wider than one byte" % dtype)
+    n, shape = len(stack), tuple(stack[0]["values"].shape)
+    if statistic in ("median", "percentile") and n > MAX_SORTED_RASTERS:
+        raise NotImplementedError("%s over %d rasters (at most %d)" % (statistic, n, MAX_SORTED_RASTERS))
+    bands = shape[0]
+    stacked = DeviceArray.empty((n * bands,) + shape[1:], storage)
+    for i, node in enumerate(nodes):
+        coded = P.Op("nanifnodata", [node], storage, None, extra=dict(_index_extra(node.dtype, node.ndv), work=storage))
+        compiled, leaves, tile_shape = P.plan(coded)
+        if tuple(tile_shape) != shape:
+            raise ValueError("could not broadcast raster %d of shape %s into shape %s" % (i, tuple(tile_shape), shape))
+        P.launch(compiled, [leaf.values for leaf in leaves], shape, out=stacked.band_slice(i * bands, (i + 1) * bands))
+    result = DeviceArray.empty(shape, storage)
+    plan = percentile_plan(percentile, n, work) if statistic == "percentile" else None
+    code = _PERCENTILE_CODE if statistic == "percentile" else STATISTICS[statistic]
+    runtime.check(_lib().gm_reduce_stack(stacked.ptr, code_of(storage), int(half), n, result.size, code,
+                                         plan, result.ptr, runtime.scalar_bits(float(fill_value), storage)),
+                  "gm_reduce_stack")
+    if storage == dtype:
+        return result
+    return _through_program(P.Op("copy", [P.Leaf(None, storage, None, values=result)], dtype, None))
+
+
+def reduce_rasters(stack, statistic, no_data_value=None, dtype=None):
+    """Apply a statistic (e.g. "mean") to a stack of rasters, skipping 'no data' values
+    (reduction.py:38-119; same arguments, same errors).  ``stack`` is a list of raster responses
+    (``values`` ndarray or DeviceArray + ``no_data_value``); the result's ``values`` is a DeviceArray."""
+    if statistic not in STATISTICS:
+        statistic, percentile = parse_percentile_statistic(statistic)
+        if percentile is None:
+            raise KeyError('Unknown statistic "{}"'.format(statistic))
+    else:
+        percentile = None
+    if len(stack) == 0:
+        raise ValueError("Cannot reduce a zero-length stack")
+    dtype = np.dtype(stack[0]["values"].dtype if dtype is None else dtype)
+    if no_data_value is None:
+        no_data_value = stack[0]["no_data_value"]
+    # sum and count never hold no data: cells without a contribution are 0
+    fill_value = 0 if statistic in ("sum", "count") else no_data_value
+    if statistic in ("first", "last"):
+        values = _pick(stack, statistic, fill_value, dtype)
+    elif statistic == "count":
+        values = _count(stack, dtype)
+    elif statistic == "max":
+        from ..hip import program as P
+        kwargs = {"dtype": dtype, "fillvalue": fill_value}
+        values, _ = P.run_expr(lambda leaves: devops.reduce_max_node(kwargs, leaves),
+                               [(d["values"], d["no_data_value"]) for d in stack])
+    else:
+        values = _nan_function(stack, statistic, percentile, fill_value, dtype)
+    return {"values": values, "no_data_value": no_data_value}
 
 
 class BaseReduction(BaseElementwise):
-    """reduction.py:122-186: all arguments are rasters; the extent / geometry is the UNION of the
-    arguments' (a cell is data as soon as one raster has data there)."""
+    """A Block over several rasters whose result exists wherever ANY of them has data: extent and geometry
+    are unions, and -- unlike the element-wise Blocks -- there is nothing to compute at all when the
+    arguments share no period (reduction.py:122-186)."""
 
     def __init__(self, *args):
-        for arg in args:
-            if not isinstance(arg, RasterBlock):
-                raise TypeError("'{}' object is not allowed".format(type(arg)))
+        bad = next((arg for arg in args if not isinstance(arg, RasterBlock)), None)
+        if bad is not None:
+            raise TypeError("'{}' object is not allowed".format(type(bad)))
         super().__init__(*args)
 
     def get_sources_and_requests(self, **request):
-        # stricter than BaseElementwise: no data at all when the arguments share no period
-        period = self.period
         process_kwargs = {"dtype": self.dtype.name, "fillvalue": self.fillvalue}
-        if period is None:
+        common = self.period
+        if common is None:
             return [(process_kwargs, None)]
-        start, stop = request.get("start", None), request.get("stop", None)
-        if start is not None:
-            if stop is not None:
-                request["start"] = max(start, period[0])
-                request["stop"] = min(stop, period[1])
-            else:  # stop is None but start isn't
-                request["start"] = min(max(start, period[0]), period[1])
-        else:  # start and stop are both None
-            request["start"] = period[1]
-        return [(process_kwargs, None)] + [(source, request) for source in self.args]
+        # every argument must answer the same frames: move the requested window into the common period
+        first, last = common
+        start, stop = request.get("start"), request.get("stop")
+        if start is None:
+            request["start"] = last
+        elif stop is None:
+            request["start"] = min(max(start, first), last)
+        else:
+            request["start"], request["stop"] = max(start, first), min(stop, last)
+        return [(process_kwargs, None)] + [(raster, request) for raster in self.args]
 
     @property
     def extent(self):
-        extents = filter_none([x.extent for x in self.args])
-        if len(extents) == 0:
+        boxes = [box for box in (raster.extent for raster in self.args) if box is not None]
+        if not boxes:
             return None
-        if len(extents) == 1:
-            return extents[0]
-        return (min(e[0] for e in extents), min(e[1] for e in extents),
-                max(e[2] for e in extents), max(e[3] for e in extents))
+        west, south, east, north = zip(*boxes)
+        return min(west), min(south), max(east), max(north)
 
     @property
     def geometry(self):
-        geometries = filter_none([x.geometry for x in self.args])
-        if len(geometries) == 0:
+        shapes = [shape for shape in (raster.geometry for raster in self.args) if shape is not None]
+        if not shapes:
             return None
-        if len(geometries) == 1:
-            return geometries[0]
-        extent = Extent.from_geometry(geometries[0])
-        for geometry in geometries[1:]:
-            extent = extent.union(Extent.from_geometry(geometry))
-        return extent.as_geometry()
+        if len(shapes) == 1:
+            return shapes[0]
+        union = Extent.from_geometry(shapes[0])
+        for shape in shapes[1:]:
+            union = union.union(Extent.from_geometry(shape))
+        return union.as_geometry()
 
 
 class Max(BaseReduction):
@@ -73,5 +235,4 @@ class Max(BaseReduction):
 
     @property
     def dtype(self):
-        # skip the default behaviour where we use at least int32 / float32
-        return np.result_type(*self.args)
+        return np.result_type(*self.args)  # (not lifted to int32 / float32 like the arithmetic Blocks)

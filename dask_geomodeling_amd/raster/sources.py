@@ -327,6 +327,27 @@ class MemorySource(RasterSourceBase):
             return None
         return row0, col0
 
+    def gm_plan_response(self, request):
+        """Short cut for evaluation plans (plan.py): the response ``process`` gives for a 'vals' request that
+        is a pixel-aligned window of a single-frame source -- the zero-copy window itself -- without the
+        general request planning; None when the request is of any other kind (the caller then takes
+        ``get_sources_and_requests`` + ``process``)."""
+        if (request.get("start") is not None or request.get("stop") is not None or self.data.shape[0] != 1 or
+                request.get("mode") != "vals"):
+            return None
+        window = self._aligned_window(request)
+        if window is None:
+            return None
+        raster_data = self.__dict__.get("_raster_data")
+        if raster_data is None:
+            return None  # (the general path creates it on first use)
+        if not raster_data.all_finite():
+            return None
+        fill = self.fillvalue
+        fill = fill.item() if hasattr(fill, "item") else fill
+        return {"values": raster_data.on_device().window(window[0], window[1], request["height"], request["width"]),
+                "no_data_value": fill}
+
     def get_sources_and_requests(self, **request):
         mode = request["mode"]
         if mode == "meta" and self.metadata is None:

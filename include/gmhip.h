@@ -434,6 +434,20 @@ int gm_temporal_percentile(const void* frames, int dtype, int has_ndv, uint64_t 
                            const gm_frame_bin* bins, int n_bins, int n_out, const gm_percentile_step* plan, int n_plan,
                            void* out, uint64_t fill_bits);
 
+/* reduce_rasters (raster/reduction.py:38-119), the part behind NumPy's nan-functions: `stack` is the
+ * (n, pixels) C-contiguous stack the reference builds in its work dtype result_type(dtype, float16) with NaN
+ * for no data (reduction.py:99-107) -- float32 or float64 storage; half = 1: the work dtype is float16
+ * (1-byte rasters), stored as float32 and rounded to float16 after every operation like NumPy's float16
+ * loops.  out = (pixels) in the same storage type: NumPy's func(stack, axis=0) per cell, `fill` (.f64
+ * payload) where every raster is NaN.  MEDIAN / PERCENTILE: at most 64 rasters; PERCENTILE takes the plan of
+ * gm_temporal_percentile (one step per number of data rasters, n steps). */
+enum gm_reduce_statistic {
+  GM_RED_SUM = 0, GM_RED_MIN = 2, GM_RED_MAX = 3, GM_RED_MEAN = 4, GM_RED_VAR = 5, GM_RED_STD = 6, GM_RED_MEDIAN = 7,
+  GM_RED_PRODUCT = 8, GM_RED_ARGMIN = 9, GM_RED_ARGMAX = 10, GM_RED_PERCENTILE = 11
+};
+int gm_reduce_stack(const void* stack, int work_dtype, int half, int64_t n, int64_t pixels, int statistic,
+                    const gm_percentile_step* plan, void* out, uint64_t fill_bits);
+
 /* Cumulative.process, vals branch (temporal.py:957-1003): running sum / count inside every bin;
  * source frame j goes to output frame j - emit_first for emit_first <= j < emit_stop.
  * statistic: GM_STAT_SUM or GM_STAT_COUNT. */

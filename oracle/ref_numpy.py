@@ -627,6 +627,64 @@ def reduce_max_process(process_kwargs, *args):
     return {"values": out, "no_data_value": fill}
 
 
+def parse_percentile_statistic(statistic):
+    """utils.parse_percentile_statistic (utils.py:805-823): 'p<number>' -> ('percentile', number)."""
+    import re
+    match = re.match(r"^p(\d+(\.\d+)?)$", statistic)
+    if not match:
+        return statistic, None
+    percentile = float(match.group(1))
+    if not 0 <= percentile <= 100:
+        raise ValueError("Percentiles must be in the range [0, 100]")
+    return "percentile", percentile
+
+
+REDUCE_FUNCTIONS = {"sum": np.nansum, "mean": np.nanmean, "min": np.nanmin, "max": np.nanmax, "argmin": np.nanargmin,
+                    "argmax": np.nanargmax, "std": np.nanstd, "var": np.nanvar, "median": np.nanmedian,
+                    "product": np.nanprod}
+
+
+def reduce_rasters(stack, statistic, no_data_value=None, dtype=None):
+    """reduce_rasters (raster/reduction.py:38-119): a statistic over a stack of rasters, skipping no data.
+    'first' / 'last' / 'count' work on the rasters themselves; everything else on the stack cast to
+    result_type(dtype, float16) with NaN for no data, reduced by NumPy's nan-function along axis 0 over the
+    cells that are data somewhere, the result assigned (i.e. cast) into the output dtype."""
+    import functools
+    if statistic not in REDUCE_FUNCTIONS and statistic not in ("first", "last", "count"):
+        statistic, percentile = parse_percentile_statistic(statistic)
+        if percentile is None:
+            raise KeyError('Unknown statistic "{}"'.format(statistic))
+    if len(stack) == 0:
+        raise ValueError("Cannot reduce a zero-length stack")
+    if dtype is None:
+        dtype = stack[0]["values"].dtype
+    if no_data_value is None:
+        no_data_value = stack[0]["no_data_value"]
+    shape = stack[0]["values"].shape
+    fill_value = 0 if statistic in ("sum", "count", "nans") else no_data_value
+    out = np.full(shape, fill_value, dtype)
+    if statistic == "last":
+        for data in stack:
+            index = get_index(data["values"], data["no_data_value"])
+            out[index] = data["values"][index]
+    elif statistic == "first":
+        for data in stack[::-1]:
+            index = get_index(data["values"], data["no_data_value"])
+            out[index] = data["values"][index]
+    elif statistic == "count":
+        for data in stack:
+            out += get_index(data["values"], data["no_data_value"])
+    else:
+        func = functools.partial(np.nanpercentile, q=percentile) if statistic == "percentile" else REDUCE_FUNCTIONS[statistic]
+        work = np.full((len(stack),) + shape, np.nan, np.result_type(dtype, np.float16))
+        for i, data in enumerate(stack):
+            index = get_index(data["values"], data["no_data_value"])
+            work[i, index] = data["values"][index]
+        not_all_nan = ~np.all(np.isnan(work), axis=0)
+        out[not_all_nan] = func(work[:, not_all_nan], axis=0)
+    return {"values": out, "no_data_value": no_data_value}
+
+
 # --------------------------------------------------------------------------
 # Smooth.process (raster/spatial.py:276-308): scipy.ndimage.gaussian_filter restated.
 # SciPy's correlate1d (ni_filters.c) extends each line with the constant, converts it to

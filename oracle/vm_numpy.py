@@ -224,6 +224,10 @@ def run_program(prog, inputs, n):
     with np.errstate(all="ignore"):
         if out_dt == np.dtype("u8") and rc == np.dtype("i8"):
             return acc.view("u8")
+        if out_dt == np.dtype("i8") and rc == np.dtype("f8"):
+            # gm_vm.h to_stored(): 2^63 (the int64 fill value as float64) is stored as INT64_MAX
+            top = acc >= 9223372036854775807.0
+            return np.where(top, np.int64(9223372036854775807), np.where(top, 0.0, acc).astype("i8"))
         return acc.astype(out_dt)
 
 

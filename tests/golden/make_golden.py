@@ -25,6 +25,7 @@ Families:
   smoothzoom  R1     ndimage.affine_transform(order=0) call of Smooth's zoom branch
   spatial     N3     Dilate / MovingMax / HillShade process() + expand_request_pixels
   reduce      N4     Max.process = reduce_rasters(stack, "max")
+  reducestats N4     reduce_rasters(stack, statistic, no_data_value, dtype) for every statistic
   group       N4     Group: whole get_data() on temporal probe sources (by time / by bands)
   temporal    N4     TemporalAggregate / Cumulative: whole get_data() + the process() arguments
 """
@@ -793,6 +794,47 @@ def gen_reduce(w):
 
 
 # --------------------------------------------------------------------------
+# family: reducestats  (reference: raster/reduction.py:38-119) -- reduce_rasters with every statistic
+# --------------------------------------------------------------------------
+REDUCE_STATISTICS = ("first", "last", "count", "sum", "mean", "min", "max", "argmin", "argmax", "std", "var",
+                     "median", "product", "p25", "p50", "p99.5")
+
+
+def gen_reducestats(w):
+    from dask_geomodeling.raster import reduction as R_red
+    rng = np.random.default_rng(191)
+    cid = 0
+    ndvs = {"f4": np.float32(F32MAX), "f8": F64MAX, "u1": np.uint8(255), "i4": -9999, "i2": np.int16(-1), "i1": np.int8(-128)}
+    shape = (2, 11, 19)
+    # (stack dtypes, output dtype or None = the first element's, inject non-finite values)
+    plans = [(("f4", "f4", "f4", "f4", "f4"), None, False), (("f4", "f4", "f4"), None, True),
+             (("u1", "u1", "u1", "u1"), None, False), (("i1", "i1", "i1"), None, False),
+             (("i2", "i2", "i2", "i2", "i2", "i2"), None, False), (("i4", "i4", "i4"), None, False),
+             (("f8", "f8", "f8", "f8"), None, False), (("f4", "f8", "f4"), None, False),
+             (("i2", "u1", "i2"), None, False), (("i4", "i4", "i4"), "f4", False), (("f4", "f4", "f4"), "i4", False),
+             (("u1", "u1", "u1"), "f4", False), (("f4", "f4"), "f8", False), (("f4",), None, False)]
+    for dts, out_dt, specials in plans:
+        stack = []
+        for dt in dts:
+            ndv = ndvs[dt]
+            v = make_tile(rng, dt, shape, ndv, specials=specials)
+            if np.dtype(dt).kind != "f":  # small values: sums and products stay inside every dtype involved
+                v = np.where(v == ndv, v, (v.astype("i8") % 7 + 1).astype(dt))
+            v[0, 0, :4] = ndv   # a run of cells that are no data in every raster
+            stack.append({"values": v, "no_data_value": ndv})
+        for stat in REDUCE_STATISTICS:
+            kwargs = {}
+            if out_dt is not None:
+                kwargs = {"dtype": out_dt, "no_data_value": dtype_max(np.dtype(out_dt))}
+            try:
+                expect = R_red.reduce_rasters([dict(d) for d in stack], stat, **kwargs)
+            except Exception as e:  # noqa: BLE001 -- what the reference raises is part of its behaviour
+                w.add(id="rs%04d" % cid, op=stat, stack=stack, kwargs=kwargs, raises=type(e).__name__); cid += 1
+                continue
+            w.add(id="rs%04d" % cid, op=stat, stack=stack, kwargs=kwargs, expect=expect); cid += 1
+
+
+# --------------------------------------------------------------------------
 # family: group  (reference: raster/combine.py:143-466) -- whole get_data() of Group views on
 # temporal probe sources (period / timedelta / frames of their own)
 # --------------------------------------------------------------------------
@@ -1030,7 +1072,7 @@ def main():
         "math": gen_math, "n1": gen_n1, "clip": gen_clip, "mask": gen_mask,
         "classify": gen_classify, "reclassify": gen_reclassify, "tiler": gen_tiler,
         "views": gen_views, "dtypes": gen_dtypes, "smoothzoom": gen_smoothzoom,
-        "spatial": gen_spatial, "reduce": gen_reduce, "group": gen_group, "smooth": gen_smooth,
+        "spatial": gen_spatial, "reduce": gen_reduce, "reducestats": gen_reducestats, "group": gen_group, "smooth": gen_smooth,
         "temporal": gen_temporal,
     }
     only = sys.argv[1:]

@@ -177,13 +177,7 @@ def test_table_ops_cut_at_the_register_class_boundary(cpu_vm):
 @pytest.mark.parametrize("case", load_family("reduce"), ids=lambda c: c["id"])
 def test_reduce_max(cpu_vm, case):
     """Max.process = reduce_rasters(stack, "max") as one program (NaN-coded no data + np.fmax)."""
-    args = case["args"]
-    tiles = [a for a in args[1:] if isinstance(a, dict) and "values" in a]
-    if any(t["values"].dtype.itemsize == 8 and t["values"].dtype.kind in "iu" for t in tiles) and \
-            not any("time" in a or "meta" in a for a in args[1:]):
-        with pytest.raises(NotImplementedError):
-            devops.reduce_max_process(*args)
-        return
+    args = case["args"]  # (incl. 64-bit integer rasters: through float64 like the reference)
     out = devops.reduce_max_process(*args)
     assert_result_equal(out, case["expect"], 0, case["id"])
 
@@ -211,3 +205,25 @@ def test_max_block_fuses_with_its_neighbours(cpu_vm):
     kw = {"dtype": "float32", "fillvalue": float(fill)}
     want = O.math_process("multiply", kw, O.reduce_max_process(kw, O.math_process("add", kw, tiles[0], 1.5), tiles[1], tiles[2]), 2.0)
     assert_result_equal(view.get_data(**req), want, 0, "Max inside a fused chain")
+
+
+@pytest.mark.parametrize("case", [c for c in load_family("reducestats") if c["op"] in ("first", "last", "count", "max")],
+                         ids=lambda c: c["id"] + "-" + c["op"])
+def test_reduce_rasters_program_statistics(cpu_vm, case):
+    """reduce_rasters: the statistics that run as one element-wise program (first / last / count / max)
+    against the reference's vectors (the nan-function statistics need the device: tests/test_gpu_parity.py)."""
+    from dask_geomodeling_amd.raster.reduction import reduce_rasters
+    out = reduce_rasters([dict(d) for d in case["stack"]], case["op"], **case["kwargs"])
+    assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+def test_reduce_rasters_errors():
+    from dask_geomodeling_amd.raster.reduction import check_statistic, reduce_rasters
+    with pytest.raises(ValueError, match="zero-length"):
+        reduce_rasters([], "first")
+    with pytest.raises(KeyError):
+        reduce_rasters([{"values": np.zeros((1, 2, 2), "f4"), "no_data_value": 1.0}], "mode")
+    with pytest.raises(ValueError):
+        check_statistic("p101")
+    check_statistic("p99.5")
+    check_statistic("median")

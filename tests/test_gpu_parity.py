@@ -609,14 +609,24 @@ def test_stencil_blocks_end_to_end(gpu):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", load_family("reduce"), ids=lambda c: c["id"])
 def test_reduce_max_golden(gpu, case):
-    args = case["args"]
-    tiles = [a for a in args[1:] if isinstance(a, dict) and "values" in a]
-    if any(t["values"].dtype.itemsize == 8 and t["values"].dtype.kind in "iu" for t in tiles) and \
-            not any("time" in a or "meta" in a for a in args[1:]):
-        with pytest.raises(NotImplementedError):
-            devops.reduce_max_process(*args)
-        return
+    args = case["args"]  # (incl. 64-bit integer rasters: through float64 like the reference)
     assert_result_equal(devops.reduce_max_process(*args), case["expect"], 0, case["id"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", load_family("reducestats"), ids=lambda c: c["id"] + "-" + c["op"])
+def test_reduce_rasters_golden(gpu, case):
+    """reduce_rasters with every statistic of the reference (first, last, count, sum, mean, min, max, argmin,
+    argmax, std, var, median, product, p<number>) on stacks of every dtype, incl. float16 work dtypes (1-byte
+    rasters) and casts into another output dtype: bit-exact against the reference's own results."""
+    from dask_geomodeling_amd.raster.reduction import reduce_rasters
+    out = reduce_rasters([dict(d) for d in case["stack"]], case["op"], **case["kwargs"])
+    out, want = dict(out, values=np.asarray(out["values"])), case["expect"]
+    if case["op"] == "median" or case["op"].startswith("p"):
+        # which of -0.0 / +0.0 a sort puts first is a property of NumPy's SIMD sort on the generating host
+        from fuzz_util import unsigned_zero
+        out, want = unsigned_zero(out), unsigned_zero(want)
+    assert_result_equal(out, want, 0, "%s %s" % (case["id"], case["op"]))
 
 
 @pytest.mark.gpu

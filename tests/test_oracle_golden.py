@@ -236,6 +236,13 @@ def test_reduce_max(case):
     assert_result_equal(out, case["expect"], 0, case["id"])
 
 
+@pytest.mark.parametrize("case", load_family("reducestats"), ids=lambda c: c["id"] + "-" + c["op"])
+def test_reduce_rasters(case):
+    with np.errstate(all="ignore"):
+        out = O.reduce_rasters([dict(d) for d in case["stack"]], case["op"], **case["kwargs"])
+    assert_result_equal(out, case["expect"], 0, case["id"])
+
+
 @pytest.mark.parametrize("case", load_family("smooth"), ids=lambda c: c["id"])
 def test_smooth(case):
     out = O.smooth_process(*case["args"])

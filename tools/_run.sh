@@ -1,3 +1,2 @@
 #!/bin/bash
-python -m pytest tests/test_gpu_parity.py -x -q -s -k "hillshade or stencil" 2>&1 | grep -E "^E|passed|failed|hillshade" | head -20
-python tools/kbench.py stencil 2>&1 | head -1
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4
