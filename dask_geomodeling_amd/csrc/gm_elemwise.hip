@@ -334,9 +334,11 @@ int validate(const gm_program* prog) {
 constexpr size_t LUT8_MIN_ELEMS = 512;  // (the table itself is built with a 256-element run of the VM, which stays below this)
 
 // the tile 0, 1, ..., 255 on the current device (uploaded once per device)
+std::mutex g_ramp_mu;
+std::unordered_map<int, void*> g_ramps;
 int byte_ramp(hipStream_t stream, void** out) {
-  static std::mutex mu;
-  static std::unordered_map<int, void*> ramps;
+  std::mutex& mu = g_ramp_mu;
+  std::unordered_map<int, void*>& ramps = g_ramps;
   static unsigned char host[256];
   int device = 0;
   GM_HIP(hipGetDevice(&device));
@@ -536,6 +538,24 @@ int gm_vm_set_tuning(const gm_vm_tuning* t) {
   if (v.vec != 0 && v.vec != 4 && v.vec != 8) v.vec = 0;
   if (v.max_batch < 0 || v.max_batch > GM_MAX_BATCH) v.max_batch = 0;
   g_tuning = v;
+  return GM_OK;
+}
+
+int gm_program_cache_clear(void) {
+  // (no launch may be in flight on another thread: entries are handed out as raw pointers)
+  std::lock_guard<std::mutex> lk(g_code_mu);
+  size_t n = 0;
+  for (auto& bucket : g_code)
+    for (auto& e : bucket.second) {
+      if (e->dev) (void)gm_free(e->dev);
+      if (e->lut) (void)gm_free(e->lut);
+      ++n;
+    }
+  g_code.clear();
+  (void)n;
+  std::lock_guard<std::mutex> ramp_lock(g_ramp_mu);
+  for (auto& kv : g_ramps) (void)gm_free(kv.second);
+  g_ramps.clear();
   return GM_OK;
 }
 

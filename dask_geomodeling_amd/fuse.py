@@ -53,6 +53,10 @@ def _fusable(task):
         return False
     # table lookups join a program only when they are small enough to run inside one; otherwise
     # they keep their own kernel (and must not drag the rest of a group to the op-by-op path)
+    if op == "power" and len(task) > 3 and isinstance(task[1], dict):
+        # integer ** raster: NumPy raises when any exponent is negative, which only the op's own body checks
+        if np.dtype(task[1].get("dtype", "f4")).kind in "iu" and not isinstance(task[3], (int, float, np.number)):
+            return False
     if op == "classify":
         bins = task[2] if len(task) > 2 else None
         return hasattr(bins, "__len__") and len(bins) <= P.GM_MAX_LINEAR_EDGES
@@ -208,6 +212,7 @@ class FusedTask(object):
             if self._ref(a):
                 return nodes[a]
             if isinstance(a, np.ndarray):
+                a = devops.constant_operand(a)
                 return P.Leaf(None, a.dtype, None, values=a)
             if isinstance(a, (bool, int, float, np.generic)):
                 return P.Lit(a)

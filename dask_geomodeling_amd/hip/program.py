@@ -308,7 +308,10 @@ def node_classes(node):
             allowed = frozenset((CLASS_F64,))
         for a in node.args:
             if not isinstance(a, Lit):
-                allowed = allowed & classes_exact(a.dtype)
+                # (a 64-bit integer tile pasted into a float64 result is cast like NumPy casts it; its no-data
+                #  cells are tagged at load time: gm_input_desc.native_ndv)
+                wide_into_f64 = _wide_int(a.dtype) and node.dtype == np.dtype("f8")
+                allowed = allowed & (classes_exact(a.dtype) | (frozenset((CLASS_F64,)) if wide_into_f64 else frozenset()))
     elif op in ("nanifnodata", "fmax", "nantofill"):
         # reduce_rasters works in result_type(dtype, float16) (reduction.py:99-101): values are exact
         # there and so they are in the float class that holds the work dtype
@@ -538,9 +541,17 @@ def compile_expr(root, n_inputs):
             s.wrap_i32 = 1 if (cls == CLASS_I64 and cd == np.dtype("i4")) else 0
             _set_scalar(s.fill, cls, cast_scalar(node.fill, cd))
             if node.op == "power" and cls in (CLASS_I32, CLASS_I64):
+                # NumPy raises for a negative integer exponent anywhere in the array; the kernel squares and
+                # multiplies with an unsigned exponent.  A literal is checked here, a raster exponent by the caller
+                # before the launch (devops.math_process sets `exponent_checked`)
                 b = node.args[1]
-                if not (isinstance(b, Lit) and isinstance(b.value, (int, np.integer)) and b.value >= 0):
-                    raise NotImplementedError("integer Power needs a non-negative integer scalar exponent")
+                checked = bool(node.extra and node.extra.get("exponent_checked"))
+                if isinstance(b, Lit):
+                    if not (isinstance(b.value, (int, np.integer)) and b.value >= 0):
+                        raise NotImplementedError("integer Power needs a non-negative integer exponent")
+                elif not checked:
+                    raise NotImplementedError("integer Power with a raster exponent runs op by op "
+                                              "(its exponents are checked for negative values first)")
         elif node.op in COMPARE_OPS or node.op in LOGIC_OPS:
             _set_scalar(s.fill, cls, 1 if node.op == "not_equal" else 0)
         elif node.op == "clip":
@@ -871,18 +882,39 @@ def plan(root):
     leaves = _collect_leaves(root)
     if not leaves:
         raise TypeError("at least one raster operand is required")
-    for leaf in leaves:
-        if not isinstance(leaf, StageRef):
-            leaf.values = as_device_view(leaf.values)
     shapes = [_leaf_shape(leaf) for leaf in leaves]
-    sizes = [_prod(sh) for sh in shapes]
-    shape, n = max(zip(shapes, sizes), key=lambda t: t[1])
-    for slot, (leaf, size, sh) in enumerate(zip(leaves, sizes, shapes)):
+    try:
+        shape = tuple(np.broadcast_shapes(*shapes))  # NumPy's own rule (and its own error for a mismatch)
+    except ValueError:
+        raise ValueError("operands could not be broadcast together with shapes %s" % " ".join(str(s) for s in shapes))
+    n = _prod(shape)
+    for slot, (leaf, sh) in enumerate(zip(leaves, shapes)):
+        size = _prod(sh)
         if size != n and size != 1:
-            raise NotImplementedError("operand shapes %s and %s differ (only equal shapes or single-element "
-                                      "operands are supported on the device)" % (shape, sh))
+            # e.g. one constant per band, (bands, 1, 1), against a (bands, H, W) raster: the kernels index
+            # tiles linearly, so such an operand is expanded to the full shape first (rare, and small)
+            leaf.values = _broadcast_operand(leaf.values, shape)
+        elif not isinstance(leaf, StageRef):
+            leaf.values = as_device_view(leaf.values)
         leaf.slot, leaf.broadcast = slot, (size == 1 and n != 1)
     return compile_cached(root, len(leaves)), leaves, shape
+
+
+def _broadcast_operand(values, shape):
+    """An operand expanded to ``shape`` by NumPy's broadcasting rule -> contiguous DeviceArray."""
+    if isinstance(values, DeviceArray):
+        have = tuple(values.shape)
+        lead = len(shape) - len(have)
+        if values.pitch is None and lead >= 0 and _prod(shape[:lead + 1]) * _prod(have[1:] if have else ()) == _prod(shape) \
+                and tuple(shape[lead + 1:]) == have[1:] and (not have or have[0] == 1):
+            # only leading axes grow: the tile repeated back to back (device-to-device copies)
+            out = DeviceArray.empty(shape, values.dtype)
+            for k in range(_prod(shape) // max(values.size, 1)):
+                runtime.check(runtime.lib().gm_d2d(ctypes.c_void_p(out.ptr + k * values.nbytes), ctypes.c_void_p(values.ptr),
+                                                   values.nbytes), "gm_d2d")
+            return out
+        values = values.to_numpy()
+    return as_device_view(np.ascontiguousarray(np.broadcast_to(np.asarray(values), shape)))
 
 
 def _subtree_classes(root, memo):

@@ -27,13 +27,30 @@ BOOL = np.dtype("bool")
 # expression builders (shared with fuse.py)
 # ---------------------------------------------------------------------------
 
-def math_node(op, process_kwargs, nodes):
+def math_node(op, process_kwargs, nodes, extra=None):
     """Node of the no-data aware ufunc wrapper (raster/elemwise.py:243-297)."""
     dtype = np.dtype(process_kwargs["dtype"])
     fill = process_kwargs["fillvalue"]
     if dtype == BOOL:  # elemwise.py:278-284
         return P.Op(op, nodes, BOOL, None, fill=(op == "not_equal"))
-    return P.Op(op, nodes, dtype, fill, fill=fill)
+    return P.Op(op, nodes, dtype, fill, fill=fill, extra=extra)
+
+
+def any_negative(values):
+    """Does an integer tile hold a negative value anywhere (no-data cells included)?"""
+    arr = as_device(values)
+    if arr.dtype.kind != "i" or arr.size == 0:
+        return False
+    below = P.evaluate(P.Op("less", [P.Leaf(None, arr.dtype, None, values=arr), P.Lit(0)], BOOL, None, fill=False))[0]
+    return not _all_false(below)
+
+
+def _all_false(bool_tile):
+    out = ctypes.c_int(0)
+    runtime.check(runtime.lib().gm_all_equal(ctypes.c_void_p(bool_tile.ptr), code_of(bool_tile.dtype),
+                                             runtime.scalar_bits(0, bool_tile.dtype), bool_tile.size,
+                                             ctypes.byref(out)), "gm_all_equal")
+    return bool(out.value)
 
 
 def clip_node(store, source):
@@ -160,14 +177,36 @@ def compare_dtype(tile_dtype, value):
     return dt
 
 
+def _integer_threshold(store_dtype, value):
+    """A 64-bit integer tile against a python float: NumPy compares (double)x with the float, the tile itself
+    must stay exact (int64 class).  For integer x and any real v: x < v <=> x < ceil(v) and x > v <=> x >= ceil(v)
+    unless v is itself an integer -- so the comparison is carried out on integers.  -> (threshold, exact) with
+    `exact` telling whether x == v is possible at all; None when the rewrite does not apply."""
+    import math
+    dt = np.dtype(store_dtype)
+    if not (dt.kind in "iu" and dt.itemsize == 8 and isinstance(value, (float, np.floating))):
+        return None
+    if not math.isfinite(value) or abs(value) >= 2.0 ** 53:
+        return None
+    return (int(value), True) if float(value).is_integer() else (math.ceil(value), False)
+
+
 def maskbelow_node(store, value):
     """MaskBelow.process numerics (raster/misc.py:249-250)."""
+    rewritten = _integer_threshold(store.dtype, value)
+    if rewritten is not None:
+        value = rewritten[0]
     extra = {"value": value, "compare_dtype": compare_dtype(store.dtype, value)}
     return P.Op("maskbelow", [store], store.dtype, store.ndv, extra=extra)
 
 
 def step_node(store, left, right, location, at):
     """Step.process numerics (raster/misc.py:314-326)."""
+    rewritten = _integer_threshold(store.dtype, location)
+    if rewritten is not None:
+        location, exact = rewritten
+        if not exact:
+            at = right  # x == ceil(v) means x > v: the value "at" the location can never be taken
     extra = {"value": location, "compare_dtype": compare_dtype(store.dtype, location),
              "values": (left, at, right)}
     return P.Op("step", [store], store.dtype, store.ndv, extra=extra)
@@ -200,6 +239,13 @@ def isnodata_node(x):
 # process bodies
 # ---------------------------------------------------------------------------
 
+def constant_operand(array):
+    """An ndarray operand of an element-wise Block as the device takes it: float16 constants (tests/test_raster.py:
+    343-367 pins float16 operand -> float32 result) are widened to float32 -- exact, and what NumPy's own cast to
+    the float32 compute dtype does; HBM tiles have no 2-byte float type."""
+    return array.astype(np.float32) if array.dtype == np.float16 else array
+
+
 def is_tile(data):
     return isinstance(data, dict) and "values" in data
 
@@ -215,7 +261,7 @@ def math_process(op, process_kwargs, *args):
         if not isinstance(data, dict):
             if isinstance(data, np.ndarray):
                 slots.append(("tile", len(tiles)))
-                tiles.append((data, None))
+                tiles.append((constant_operand(data), None))
             else:
                 slots.append(("lit", data))
         elif "time" in data or "meta" in data:
@@ -226,9 +272,18 @@ def math_process(op, process_kwargs, *args):
         else:
             raise TypeError("Cannot apply math function to value {}".format(data))
 
+    extra = None
+    if (op == "power" and np.dtype(process_kwargs["dtype"]).kind in "iu" and len(slots) > 1 and
+            slots[1][0] == "tile"):
+        # np.power(integers, integer array): "Integers to negative integer powers are not allowed" as soon as ONE
+        # exponent is negative (elemwise.py:383-406 only guards scalar exponents) -- checked before the launch
+        if any_negative(tiles[slots[1][1]][0]):
+            raise ValueError("Integers to negative integer powers are not allowed.")
+        extra = {"exponent_checked": True}
+
     def build(leaves):
         nodes = [leaves[ref] if kind == "tile" else P.Lit(ref) for kind, ref in slots]
-        return math_node(op, process_kwargs, nodes)
+        return math_node(op, process_kwargs, nodes, extra)
 
     if not tiles:
         raise TypeError("at least one raster operand is required")

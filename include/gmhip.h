@@ -296,6 +296,11 @@ int gm_spec_last_kernel(char* buf, size_t len);
 int gm_spec_source(const gm_program* prog, int strided, int group, char* buf, size_t len, size_t* needed);
 int gm_spec_compile_check(const gm_program* prog, int strided, int group, size_t* code_bytes);
 
+/* Drop every cached program (lowered code, tables and byte-LUTs go back to the pool).  Programs are cached by
+ * content for the life of the process; a long-lived worker that has seen very many distinct programs -- or a
+ * leak checker -- calls this while no launch is in flight. */
+int gm_program_cache_clear(void);
+
 /* sizeof of the ABI structs (0 gm_program, 1 gm_step, 2 gm_operand, 3 gm_input_desc): lets a
  * binding verify its struct layout at load time. */
 size_t gm_sizeof(int which);

@@ -547,3 +547,23 @@ def test_percentile_plan_reproduces_numpy(work):
             got = b - d * u if t >= 0.5 else a + d * t
             want = np.percentile(v, q)
             assert got.dtype == want.dtype and got == want, (q, n, got, want)
+
+
+def test_float16_ndarray_operand_gives_float32(cpu_vm):
+    """tests/test_raster.py:343-367 of the reference: storage + np.ones(1, dtype=f2) is float32, values and all."""
+    from dask_geomodeling_amd import raster
+    from blocks_util import ArrayLeaf
+    from fuzz_util import REQ
+    rng = np.random.default_rng(2)
+    fill = np.float32(np.finfo("f4").max)
+    ArrayLeaf.ARRAYS["f2/a"] = {"values": (rng.random((1, 24, 40)) * 10).astype("f4"), "no_data_value": fill}
+    A = ArrayLeaf("f2/a", "<f4", fill)
+    for dtype, expected in (("bool", "f4"), ("u1", "f4"), ("f2", "f4"), ("f8", "f8")):
+        const = np.ones(1, dtype=dtype)
+        for view in (A + const, A / const):
+            assert view.dtype == np.dtype(expected)
+            got = view.get_data(**REQ)["values"]
+            assert got.dtype == np.dtype(expected)
+            want = ArrayLeaf.ARRAYS["f2/a"]["values"].astype(expected) + 1 if view.__class__.__name__ == "Add" else \
+                ArrayLeaf.ARRAYS["f2/a"]["values"].astype(expected) / 1
+            assert np.array_equal(got, want.astype(expected))

@@ -12,23 +12,10 @@ from dask_geomodeling_amd.raster import devops
 ULP_OPS = {"power": 1, "exp": 3, "log": 3, "log10": 3}
 
 
-def _supported_math(case):
-    """Integer Power with raster exponents is not on the device (NumPy raises for negative
-    integer exponents at run time; the device cannot)."""
-    if case["op"] == "power" and np.dtype(case["kwargs"]["dtype"]).kind in "iu":
-        b = case["args"][1] if len(case["args"]) > 1 else None
-        return not isinstance(b, dict)
-    return True
-
-
 @pytest.mark.parametrize("case", load_family("math"), ids=lambda c: c["id"] + "-" + c["op"])
 def test_math(cpu_vm, case):
     if "raises" in case:
         pytest.skip("reference raises %s" % case["raises"])
-    if not _supported_math(case):
-        with pytest.raises(NotImplementedError):
-            devops.math_process(case["op"], case["kwargs"], *case["args"])
-        return
     out = devops.math_process(case["op"], case["kwargs"], *case["args"])
     assert_result_equal(out, case["expect"], ULP_OPS.get(case["op"], 0), case["id"])
 
@@ -227,3 +214,39 @@ def test_reduce_rasters_errors():
         check_statistic("p101")
     check_statistic("p99.5")
     check_statistic("median")
+
+
+def test_integer_power_with_negative_raster_exponent_raises(cpu_vm):
+    """np.power(integer array, integer array) refuses negative exponents anywhere in the array -- no-data cells
+    included (the reference's Power only guards scalar exponents, elemwise.py:383-406): same error here."""
+    a = {"values": np.full((1, 4, 4), 3, "i4"), "no_data_value": -9999}
+    b = {"values": np.arange(16, dtype="i4").reshape(1, 4, 4) % 5, "no_data_value": -9999}
+    kw = {"dtype": "int32", "fillvalue": 2147483647}
+    out = devops.math_process("power", kw, a, b)
+    assert np.array_equal(np.asarray(out["values"]), np.power(a["values"], b["values"]))
+    b["values"][0, 2, 1] = -9999  # a no-data cell: NumPy still raises
+    with pytest.raises(ValueError, match="negative integer powers"):
+        devops.math_process("power", kw, a, b)
+    with pytest.raises(ValueError, match="negative integer powers"):
+        np.power(a["values"], b["values"])
+
+
+@pytest.mark.parametrize("const_shape", [(3, 1, 1), (1, 5, 7), (5, 7), (7,), (3, 5, 1), (1,), ()])
+def test_ndarray_operands_broadcast_like_numpy(cpu_vm, const_shape):
+    """An ndarray operand of wrap_math_process_func (elemwise.py:257-258) broadcasts against the raster by
+    NumPy's rule: one constant per band, per row, per cell ..."""
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(5)
+    fill = np.float32(np.finfo("f4").max)
+    tile = {"values": (rng.random((3, 5, 7)) * 10).astype("f4"), "no_data_value": fill}
+    tile["values"][1, 2, 3] = fill
+    const = (rng.random(const_shape) * 4 + 1).astype("f4")
+    kw = {"dtype": "float32", "fillvalue": float(fill)}
+    for op, args in (("multiply", (tile, const)), ("subtract", (const, tile))):
+        assert_result_equal(devops.math_process(op, kw, *args), O.math_process(op, kw, *args), 0, "%s %s" % (op, const_shape))
+
+
+def test_ndarray_operand_that_does_not_broadcast(cpu_vm):
+    tile = {"values": np.zeros((3, 5, 7), "f4"), "no_data_value": np.float32(1)}
+    with pytest.raises(ValueError, match="broadcast"):
+        devops.math_process("add", {"dtype": "float32", "fillvalue": 1.0}, tile, np.zeros((2, 5, 7), "f4"))

@@ -8,7 +8,7 @@ from fuzz_util import REQ, describe, oracle_eval, random_view, unsigned_zero
 from helpers import assert_result_equal
 
 
-@pytest.mark.parametrize("seed", range(120))
+@pytest.mark.parametrize("seed", range(400))
 def test_random_views_fused_vs_oracle(cpu_vm, monkeypatch, seed):
     from dask_geomodeling_amd.raster import devops
     monkeypatch.setattr(devops, "all_equal", lambda values, ndv: bool(np.all(np.asarray(values) == ndv)))
