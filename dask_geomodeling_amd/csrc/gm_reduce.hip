@@ -176,13 +176,16 @@ struct SortPlan {  // gm_percentile_step per number of data frames (1 .. RD_MAX_
   double gamma[RD_MAX_SORT], one_minus_gamma[RD_MAX_SORT];
 };
 
-// median / percentile: the data frames of a cell insertion-sorted into the lane's column of an LDS array
-template <typename C, bool HALF, bool PERCENTILE>
-__global__ __launch_bounds__(256) void reduce_sorted_kernel(const C* __restrict__ stack, int n, long long pixels,
-                                                            SortPlan P, C* __restrict__ out, C fill) {
+// median / percentile: the data frames of a cell insertion-sorted into the lane's column of an LDS array.
+// Up to RD_MAX_SORT rasters: 256-lane workgroups, the plan in the kernarg segment; more (LONG): 64-lane
+// workgroups -- four times the rasters in the same LDS, up to the CU's 160 KiB -- and the plan in memory.
+template <typename C, bool HALF, bool PERCENTILE, int WG, bool LONG>
+__global__ __launch_bounds__(WG) void reduce_sorted_kernel(const C* __restrict__ stack, int n, long long pixels,
+                                                           SortPlan P, const gm_percentile_step* __restrict__ long_plan,
+                                                           C* __restrict__ out, C fill) {
   extern __shared__ unsigned char lds_raw[];
   C* column = reinterpret_cast<C*>(lds_raw) + threadIdx.x;  // [slot][lane]
-  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long p = (long long)blockIdx.x * WG + threadIdx.x;
   if (p >= pixels) return;
   const C* src = stack + p;
   int m = 0;
@@ -190,24 +193,31 @@ __global__ __launch_bounds__(256) void reduce_sorted_kernel(const C* __restrict_
     const C x = __builtin_nontemporal_load(src + (long long)j * pixels);
     if (x != x) continue;
     int i = m;
-    while (i > 0 && column[(i - 1) * 256] > x) {
-      column[i * 256] = column[(i - 1) * 256];
+    while (i > 0 && column[(i - 1) * WG] > x) {
+      column[i * WG] = column[(i - 1) * WG];
       --i;
     }
-    column[i * 256] = x;
+    column[i * WG] = x;
     ++m;
   }
   C r = fill;
   if (m > 0) {
     if constexpr (PERCENTILE) {
-      const C a = column[P.lower[m - 1] * 256], b = column[P.upper[m - 1] * 256];
-      const C t = (C)P.gamma[m - 1], u = (C)P.one_minus_gamma[m - 1];
+      int lower, upper;
+      C t, u;
+      if constexpr (LONG) {
+        const gm_percentile_step step = long_plan[m - 1];
+        lower = step.lower; upper = step.upper; t = (C)step.gamma; u = (C)step.one_minus_gamma;
+      } else {
+        lower = P.lower[m - 1]; upper = P.upper[m - 1]; t = (C)P.gamma[m - 1]; u = (C)P.one_minus_gamma[m - 1];
+      }
+      const C a = column[lower * WG], b = column[upper * WG];
       const C d = rnd<HALF, C>(b - a);
       r = (t >= (C)0.5) ? rnd<HALF, C>(b - rnd<HALF, C>(d * u)) : rnd<HALF, C>(a + rnd<HALF, C>(d * t));
     } else {
       const int h = m / 2;
-      const C high = column[h * 256];
-      const C low = (m & 1) ? high : column[(h - 1) * 256];
+      const C high = column[h * WG];
+      const C low = (m & 1) ? high : column[(h - 1) * WG];
       r = rnd<HALF, C>(rnd<HALF, C>(low + high) / (C)2);  // np.ma.median: sum of the two, then / 2.
     }
   }
@@ -226,29 +236,56 @@ int launch_reduce(const void* stack, int n, long long pixels, int statistic, con
                   void* out, uint64_t fill_bits, hipStream_t s) {
   const C fill = fill_of<C>(fill_bits);
   if (statistic == GM_RED_MEDIAN || statistic == GM_RED_PERCENTILE) {
-    if (n > RD_MAX_SORT || (size_t)n * 256 * sizeof(C) > 64 * 1024)
-      return gm::fail(GM_ERR_UNSUPPORTED, "gm_reduce_stack: median / percentile over %d rasters (LDS holds %d)", n,
-                      (int)(64 * 1024 / (256 * sizeof(C))));
+    const bool percentile = statistic == GM_RED_PERCENTILE;
+    if (percentile && !plan) return gm::fail(GM_ERR_INVALID, "gm_reduce_stack: percentile without a plan");
+    for (int i = 0; percentile && i < n; ++i)
+      if (plan[i].lower < 0 || plan[i].lower > i || plan[i].upper < 0 || plan[i].upper > i)
+        return gm::fail(GM_ERR_INVALID, "gm_reduce_stack: plan[%d] points outside %d values", i, i + 1);
+    const bool long_stack = n > RD_MAX_SORT || (size_t)n * 256 * sizeof(C) > 64 * 1024;
+    if (long_stack && (n > GM_MAX_MEDIAN_FRAMES_LONG || (size_t)n * 64 * sizeof(C) > 160 * 1024))
+      return gm::fail(GM_ERR_UNSUPPORTED, "gm_reduce_stack: median / percentile over %d rasters", n);
     SortPlan P;
     memset(&P, 0, sizeof(P));
-    if (statistic == GM_RED_PERCENTILE) {
-      if (!plan) return gm::fail(GM_ERR_INVALID, "gm_reduce_stack: percentile without a plan");
+    gm_percentile_step* plan_dev = nullptr;
+    if (percentile && long_stack) {
+      int rc = gm_malloc((void**)&plan_dev, sizeof(gm_percentile_step) * (size_t)n);
+      if (rc) return rc;
+      GM_HIP(hipMemcpyAsync(plan_dev, plan, sizeof(gm_percentile_step) * (size_t)n, hipMemcpyHostToDevice, s));
+      GM_HIP(hipStreamSynchronize(s));
+    } else if (percentile) {
       for (int i = 0; i < n; ++i) {
-        if (plan[i].lower < 0 || plan[i].lower > i || plan[i].upper < 0 || plan[i].upper > i)
-          return gm::fail(GM_ERR_INVALID, "gm_reduce_stack: plan[%d] points outside %d values", i, i + 1);
         P.lower[i] = (short)plan[i].lower;
         P.upper[i] = (short)plan[i].upper;
         P.gamma[i] = plan[i].gamma;
         P.one_minus_gamma[i] = plan[i].one_minus_gamma;
       }
     }
-    const unsigned gx = (unsigned)((pixels + 255) / 256);
-    const size_t lds = (size_t)n * 256 * sizeof(C);
-    if (statistic == GM_RED_PERCENTILE)
-      hipLaunchKernelGGL((reduce_sorted_kernel<C, HALF, true>), dim3(gx), dim3(256), lds, s, (const C*)stack, n, pixels, P, (C*)out, fill);
-    else
-      hipLaunchKernelGGL((reduce_sorted_kernel<C, HALF, false>), dim3(gx), dim3(256), lds, s, (const C*)stack, n, pixels, P, (C*)out, fill);
-    return GM_OK;
+    const int WG = long_stack ? 64 : 256;
+    const unsigned gx = (unsigned)((pixels + WG - 1) / WG);
+    const size_t lds = (size_t)n * WG * sizeof(C);
+    int rc = GM_OK;
+#define GM_SORTED_LAUNCH(PCT, WG_, LONG_)                                                                              \
+  do {                                                                                                                 \
+    auto kernel = reduce_sorted_kernel<C, HALF, PCT, WG_, LONG_>;                                                      \
+    if (lds > 64 * 1024 &&                                                                                             \
+        hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+      (void)hipGetLastError();                                                                                         \
+      rc = gm::fail(GM_ERR_UNSUPPORTED, "gm_reduce_stack: %zu bytes of LDS per workgroup refused", lds);               \
+      break;                                                                                                           \
+    }                                                                                                                  \
+    hipLaunchKernelGGL(kernel, dim3(gx), dim3(WG_), lds, s, (const C*)stack, n, pixels, P,                            \
+                       (const gm_percentile_step*)plan_dev, (C*)out, fill);                                            \
+  } while (0)
+    if (long_stack) {
+      if (percentile) GM_SORTED_LAUNCH(true, 64, true);
+      else GM_SORTED_LAUNCH(false, 64, true);
+    } else {
+      if (percentile) GM_SORTED_LAUNCH(true, 256, false);
+      else GM_SORTED_LAUNCH(false, 256, false);
+    }
+#undef GM_SORTED_LAUNCH
+    if (plan_dev) (void)gm_free(plan_dev);
+    return rc;
   }
   constexpr int VV = 16 / (int)sizeof(C);
   const bool vec = (pixels % VV) == 0 && ((uintptr_t)stack % 16) == 0 && ((uintptr_t)out % 16) == 0;

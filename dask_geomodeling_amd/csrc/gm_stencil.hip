@@ -1055,7 +1055,8 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
                   double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh, int ow,
                   void* out) {
   if (!in || !out || !weights_host) return gm::fail(GM_ERR_INVALID, "null pointer");
-  if (dtype != GM_F32 && dtype != GM_F64) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: float tiles only");
+  if (dtype == GM_BOOL || dtype == GM_U64 || gm::dtype_size(dtype) == 0)
+    return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: dtype %d", dtype);
   if (axis != 1 && axis != 2) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: axis %d (1 = y, 2 = x)", axis);
   if (radius < 0 || radius > GAUSS_MAX_RADIUS) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: radius %d (max %d)", radius, GAUSS_MAX_RADIUS);
   if (bands <= 0 || oh <= 0 || ow <= 0) return GM_OK;
@@ -1086,8 +1087,19 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
       hipLaunchKernelGGL((gauss_axis_kernel<T, false>), grid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, y0, \
                          x0, oh, ow, replace_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);         \
   } while (0)
-  if (dtype == GM_F32) GM_GAUSS(float);
-  else GM_GAUSS(double);
+  // integer tiles: SciPy filters in float64 and stores with a C cast (truncation), measured against
+  // scipy.ndimage.gaussian_filter(output=<integer array>)
+  switch (dtype) {
+    case GM_F32: GM_GAUSS(float); break;
+    case GM_F64: GM_GAUSS(double); break;
+    case GM_U8: GM_GAUSS(unsigned char); break;
+    case GM_I8: GM_GAUSS(signed char); break;
+    case GM_U16: GM_GAUSS(unsigned short); break;
+    case GM_I16: GM_GAUSS(short); break;
+    case GM_U32: GM_GAUSS(unsigned int); break;
+    case GM_I32: GM_GAUSS(int); break;
+    default: GM_GAUSS(long long); break;
+  }
 #undef GM_GAUSS
   GM_HIP(hipGetLastError());
   return GM_OK;

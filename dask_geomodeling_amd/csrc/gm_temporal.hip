@@ -13,6 +13,7 @@
 // rounded to C (np.true_divide of a float32 array by an intp count runs the float64 loop), the
 // variance is the mean of squared float-C deviations from that mean.  No FMA contraction
 // (-ffp-contract=off) so every step rounds as NumPy's does.
+#include <algorithm>
 #include <cmath>
 #include <limits>
 #include <type_traits>
@@ -283,21 +284,25 @@ __global__ __launch_bounds__(256) void cumulative_kernel(const Tin* __restrict__
 
 // Median: the data frames of a cell are insertion-sorted into the lane's column of an LDS array
 // (slot-major: lanes hit distinct banks), then (low + high) / 2 like np.ma.median, which is what
-// np.nanmedian runs for fewer than 600 frames.  Bins hold at most GM_MAX_MEDIAN_FRAMES frames.
+// np.nanmedian runs for fewer than 600 frames.  Bins of up to GM_MAX_MEDIAN_FRAMES frames: 256-lane
+// workgroups, the percentile plan in the kernarg segment; longer bins (up to GM_MAX_MEDIAN_FRAMES_LONG): 64-lane
+// workgroups -- a quarter of the columns, four times the frames in the same LDS, up to the 160 KiB of a CU --
+// and the plan in device memory.
 struct Plan {  // gm_percentile_step per number of data frames (1 .. GM_MAX_MEDIAN_FRAMES)
   short lower[GM_MAX_MEDIAN_FRAMES], upper[GM_MAX_MEDIAN_FRAMES];
   double gamma[GM_MAX_MEDIAN_FRAMES], one_minus_gamma[GM_MAX_MEDIAN_FRAMES];
 };
 
-template <typename Tin, bool PERCENTILE>
-__global__ __launch_bounds__(256) void median_kernel(const Tin* __restrict__ frames, Tin ndv, bool has_ndv,
-                                                     long long pixels, Bins B, Plan P,
-                                                     typename OutOf<Tin, GM_STAT_MEDIAN>::type* __restrict__ out,
-                                                     typename OutOf<Tin, GM_STAT_MEDIAN>::type fill) {
+template <typename Tin, bool PERCENTILE, int WG, bool LONG>
+__global__ __launch_bounds__(WG) void median_kernel(const Tin* __restrict__ frames, Tin ndv, bool has_ndv,
+                                                    long long pixels, Bins B, Plan P,
+                                                    const gm_percentile_step* __restrict__ long_plan,
+                                                    typename OutOf<Tin, GM_STAT_MEDIAN>::type* __restrict__ out,
+                                                    typename OutOf<Tin, GM_STAT_MEDIAN>::type fill) {
   using C = typename OutOf<Tin, GM_STAT_MEDIAN>::type;  // = result_type(float32, dtype), the working dtype too
   extern __shared__ unsigned char lds_raw[];
   C* sorted = reinterpret_cast<C*>(lds_raw);  // [slot][lane]
-  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long p = (long long)blockIdx.x * WG + threadIdx.x;
   if (p >= pixels) return;
   const int first = B.first[blockIdx.y], count = B.count[blockIdx.y];
   const Tin* src = frames + (long long)first * pixels + p;
@@ -307,11 +312,11 @@ __global__ __launch_bounds__(256) void median_kernel(const Tin* __restrict__ fra
     C x;
     if (skipped<Tin, C>(v, ndv, has_ndv, x)) return;
     int i = n;
-    while (i > 0 && column[(i - 1) * 256] > x) {
-      column[i * 256] = column[(i - 1) * 256];
+    while (i > 0 && column[(i - 1) * WG] > x) {
+      column[i * WG] = column[(i - 1) * WG];
       --i;
     }
-    column[i * 256] = x;
+    column[i * WG] = x;
     ++n;
   };
   int j = 0;
@@ -328,14 +333,21 @@ __global__ __launch_bounds__(256) void median_kernel(const Tin* __restrict__ fra
     if constexpr (PERCENTILE) {
       // numpy's _lerp between the two neighbours of the virtual index (n varies per lane: the plan is
       // read with a lane-dependent index)
-      const C a = column[P.lower[n - 1] * 256], b = column[P.upper[n - 1] * 256];
-      const C t = (C)P.gamma[n - 1], u = (C)P.one_minus_gamma[n - 1];
+      int lower, upper;
+      C t, u;
+      if constexpr (LONG) {
+        const gm_percentile_step step = long_plan[n - 1];
+        lower = step.lower; upper = step.upper; t = (C)step.gamma; u = (C)step.one_minus_gamma;
+      } else {
+        lower = P.lower[n - 1]; upper = P.upper[n - 1]; t = (C)P.gamma[n - 1]; u = (C)P.one_minus_gamma[n - 1];
+      }
+      const C a = column[lower * WG], b = column[upper * WG];
       const C d = b - a;
       r = (t >= (C)0.5) ? b - d * u : a + d * t;
     } else {
       const int h = n / 2;
-      const C high = column[h * 256];
-      const C low = (n & 1) ? high : column[(h - 1) * 256];
+      const C high = column[h * WG];
+      const C low = (n & 1) ? high : column[(h - 1) * WG];
       r = (low + high) / (C)2;
     }
   }
@@ -346,19 +358,40 @@ template <typename Tin>
 int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long pixels, const gm_frame_bin* bins,
                   int n_bins, void* out, uint64_t fill_bits, hipStream_t s, const gm_percentile_step* plan = nullptr,
                   int n_plan = 0) {
-  Plan P;
-  memset(&P, 0, sizeof(P));
-  for (int i = 0; i < n_plan && i < GM_MAX_MEDIAN_FRAMES; ++i) {
+  using C = typename OutOf<Tin, GM_STAT_MEDIAN>::type;
+  int longest_all = 1;
+  for (int i = 0; i < n_bins; ++i)
+    if (bins[i].count > longest_all) longest_all = bins[i].count;
+  if (plan && longest_all > n_plan) return gm::fail(GM_ERR_INVALID, "gm_temporal_percentile: plan covers %d frames, a bin has %d", n_plan, longest_all);
+  for (int i = 0; plan && i < n_plan; ++i)
     if (plan[i].lower < 0 || plan[i].lower > i || plan[i].upper < 0 || plan[i].upper > i)
       return gm::fail(GM_ERR_INVALID, "gm_temporal_percentile: plan[%d] points outside %d values", i, i + 1);
-    P.lower[i] = (short)plan[i].lower;
-    P.upper[i] = (short)plan[i].upper;
-    P.gamma[i] = plan[i].gamma;
-    P.one_minus_gamma[i] = plan[i].one_minus_gamma;
+  const bool long_bins = longest_all > GM_MAX_MEDIAN_FRAMES || (size_t)longest_all * 256 * sizeof(C) > 64 * 1024;
+  Plan P;
+  memset(&P, 0, sizeof(P));
+  gm_percentile_step* plan_dev = nullptr;
+  if (long_bins) {
+    if (longest_all > GM_MAX_MEDIAN_FRAMES_LONG || (size_t)longest_all * 64 * sizeof(C) > 160 * 1024)
+      return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_aggregate: median / percentile over %d frames (at most %d)", longest_all,
+                      (int)std::min<size_t>(GM_MAX_MEDIAN_FRAMES_LONG, 160 * 1024 / (64 * sizeof(C))));
+    if (plan) {
+      int rc = gm_malloc((void**)&plan_dev, sizeof(gm_percentile_step) * (size_t)n_plan);
+      if (rc) return rc;
+      GM_HIP(hipMemcpyAsync(plan_dev, plan, sizeof(gm_percentile_step) * (size_t)n_plan, hipMemcpyHostToDevice, s));
+      GM_HIP(hipStreamSynchronize(s));  // (the caller's plan may go away after this call)
+    }
+  } else {
+    for (int i = 0; i < n_plan && i < GM_MAX_MEDIAN_FRAMES; ++i) {
+      P.lower[i] = (short)plan[i].lower;
+      P.upper[i] = (short)plan[i].upper;
+      P.gamma[i] = plan[i].gamma;
+      P.one_minus_gamma[i] = plan[i].one_minus_gamma;
+    }
   }
-  using C = typename OutOf<Tin, GM_STAT_MEDIAN>::type;
-  const unsigned gx = (unsigned)((pixels + 255) / 256);
-  for (int b0 = 0; b0 < n_bins; b0 += TB_MAX_BINS) {
+  const int WG = long_bins ? 64 : 256;
+  const unsigned gx = (unsigned)((pixels + WG - 1) / WG);
+  int rc = GM_OK;
+  for (int b0 = 0; b0 < n_bins && rc == GM_OK; b0 += TB_MAX_BINS) {
     Bins B;
     const int nb = n_bins - b0 < TB_MAX_BINS ? n_bins - b0 : TB_MAX_BINS;
     int longest = 1;
@@ -368,18 +401,30 @@ int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long 
       B.out[i] = bins[b0 + i].out;
       if (bins[b0 + i].count > longest) longest = bins[b0 + i].count;
     }
-    if (longest > GM_MAX_MEDIAN_FRAMES || (size_t)longest * 256 * sizeof(C) > 64 * 1024)
-      return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_aggregate: median over %d frames (LDS holds %d)", longest,
-                      (int)(64 * 1024 / (256 * sizeof(C))));
-    if (plan && longest > n_plan) return gm::fail(GM_ERR_INVALID, "gm_temporal_percentile: plan covers %d frames, a bin has %d", n_plan, longest);
-    if (plan)
-      hipLaunchKernelGGL((median_kernel<Tin, true>), dim3(gx, nb), dim3(256), (size_t)longest * 256 * sizeof(C), s,
-                         (const Tin*)frames, from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, P, (C*)out, from_bits<C>(fill_bits));
-    else
-      hipLaunchKernelGGL((median_kernel<Tin, false>), dim3(gx, nb), dim3(256), (size_t)longest * 256 * sizeof(C), s,
-                         (const Tin*)frames, from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, P, (C*)out, from_bits<C>(fill_bits));
+    const size_t lds = (size_t)longest * WG * sizeof(C);
+#define GM_MEDIAN_LAUNCH(PCT, WG_, LONG_)                                                                              \
+  do {                                                                                                                 \
+    auto kernel = median_kernel<Tin, PCT, WG_, LONG_>;                                                                 \
+    if (lds > 64 * 1024 &&                                                                                             \
+        hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+      (void)hipGetLastError();                                                                                         \
+      rc = gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_aggregate: %zu bytes of LDS per workgroup refused", lds);         \
+      break;                                                                                                           \
+    }                                                                                                                  \
+    hipLaunchKernelGGL(kernel, dim3(gx, nb), dim3(WG_), lds, s, (const Tin*)frames, from_bits<Tin>(ndv_bits), has_ndv != 0, \
+                       pixels, B, P, (const gm_percentile_step*)plan_dev, (C*)out, from_bits<C>(fill_bits));           \
+  } while (0)
+    if (long_bins) {
+      if (plan) GM_MEDIAN_LAUNCH(true, 64, true);
+      else GM_MEDIAN_LAUNCH(false, 64, true);
+    } else {
+      if (plan) GM_MEDIAN_LAUNCH(true, 256, false);
+      else GM_MEDIAN_LAUNCH(false, 256, false);
+    }
+#undef GM_MEDIAN_LAUNCH
   }
-  return GM_OK;
+  if (plan_dev) (void)gm_free(plan_dev);  // (stream-ordered pool: reuse happens behind the kernels above)
+  return rc;
 }
 
 bool ascending_bins(const gm_frame_bin* bins, int n_bins, long long n_frames, int n_out) {
@@ -526,7 +571,7 @@ int gm_temporal_percentile(const void* frames, int dtype, int has_ndv, uint64_t 
                            void* out, uint64_t fill_bits) {
   if (!frames || !out || !plan || (!bins && n_bins)) return gm::fail(GM_ERR_INVALID, "null pointer");
   if (n_frames < 0 || pixels <= 0 || n_bins < 0 || n_out < 0) return gm::fail(GM_ERR_INVALID, "gm_temporal_percentile: bad shape");
-  if (n_plan < 1 || n_plan > GM_MAX_MEDIAN_FRAMES) return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_percentile: plan of %d steps", n_plan);
+  if (n_plan < 1 || n_plan > GM_MAX_MEDIAN_FRAMES_LONG) return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_percentile: plan of %d steps", n_plan);
   if (!ascending_bins(bins, n_bins, n_frames, n_out)) return gm::fail(GM_ERR_INVALID, "gm_temporal_percentile: bin outside the stack");
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;

@@ -32,7 +32,7 @@ __all__ = ["Max", "reduce_rasters", "check_statistic"]
 STATISTICS = {"first": None, "last": None, "count": None, "sum": 0, "mean": 4, "min": 2, "max": 3, "argmin": 9,
               "argmax": 10, "std": 6, "var": 5, "median": 7, "product": 8}
 _PERCENTILE_CODE = 11
-MAX_SORTED_RASTERS = 64  # median / percentile sort a cell's values in LDS
+MAX_SORTED_RASTERS = 599  # median / percentile sort a cell's values in LDS (float64 work dtype: 320)
 
 
 def parse_percentile_statistic(statistic):
@@ -128,7 +128,7 @@ def _nan_function(stack, statistic, percentile, fill_value, dtype):
     if half and any(node.dtype.itemsize != 1 for node in nodes):
         raise NotImplementedError("reduce_rasters in float16 (output dtype %s) of rasters wider than one byte" % dtype)
     n, shape = len(stack), tuple(stack[0]["values"].shape)
-    if statistic in ("median", "percentile") and n > MAX_SORTED_RASTERS:
+    if statistic in ("median", "percentile") and n > (MAX_SORTED_RASTERS if storage.itemsize == 4 else 320):
         raise NotImplementedError("%s over %d rasters (at most %d)" % (statistic, n, MAX_SORTED_RASTERS))
     bands = shape[0]
     stacked = DeviceArray.empty((n * bands,) + shape[1:], storage)

@@ -24,7 +24,7 @@ __all__ = ["TemporalAggregate", "Cumulative"]
 _END_ANCHORED = {"M", "A", "Q", "BM", "BA", "BQ", "W", "ME", "YE", "QE", "BME", "BYE", "BQE"}
 _TICK = Timedelta(microseconds=1)
 STATISTIC_CODES = {"sum": 0, "count": 1, "min": 2, "max": 3, "mean": 4, "var": 5, "std": 6, "median": 7}
-MAX_MEDIAN_FRAMES = 64  # GM_MAX_MEDIAN_FRAMES: a cell's frames are sorted in LDS
+MAX_MEDIAN_FRAMES = 599  # GM_MAX_MEDIAN_FRAMES_LONG: a cell's frames are sorted in LDS (float64: 320)
 _EXTENSIVE = {"sum", "count"}  # additive statistics: nothing to add up = 0, not 'no data'
 
 
@@ -286,7 +286,7 @@ def aggregate_frames(values, no_data_value, runs, statistic, dtype):
     longest = max([count for _, count in runs] + [1])
     if name in ("median", "percentile"):
         # a cell's data frames are sorted in LDS: 64 float32 / 32 float64 values per lane
-        if longest > MAX_MEDIAN_FRAMES // (np.result_type(np.float32, dtype).itemsize // 4):
+        if longest > (MAX_MEDIAN_FRAMES if np.result_type(np.float32, dtype).itemsize == 4 else 320):
             raise NotImplementedError("%s over %d frames per label" % (statistic, longest))
     L = _lib()
     if L.gm_temporal_out_dtype(code, STATISTIC_CODES["median" if percentile is not None else name]) != _code(dtype):

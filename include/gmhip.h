@@ -381,7 +381,7 @@ int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv
 /* One axis (1 = y, 2 = x) of scipy.ndimage.gaussian_filter as Smooth.process calls it
  * (spatial.py:276-290; mode="constant"): weights_host[j] = weight at distance j (radius + 1 float64
  * values), accumulation in float64 in SciPy's order, result cast to the tile's dtype (float32 /
- * float64).  replace_ndv: cells equal to ndv are read as fill (the first axis of Smooth does
+ * float64; integer tiles are truncated like SciPy's C cast).  replace_ndv: cells equal to ndv are read as fill (the first axis of Smooth does
  * values[values == ndv] = fill).  out = the window [y0, y0+oh) x [x0, x0+ow) of the filtered tile. */
 int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, const double* weights_host, int radius,
                   double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh, int ow,
@@ -401,9 +401,12 @@ enum gm_statistic {
   GM_STAT_MEAN = 4,  /* np.nanmean  */
   GM_STAT_VAR = 5,   /* np.nanvar   */
   GM_STAT_STD = 6,   /* np.nanstd   */
-  GM_STAT_MEDIAN = 7 /* np.nanmedian (gm_temporal_aggregate only; bins of at most GM_MAX_MEDIAN_FRAMES frames) */
+  GM_STAT_MEDIAN = 7 /* np.nanmedian (gm_temporal_aggregate only; bins of at most GM_MAX_MEDIAN_FRAMES_LONG frames) */
 };
-#define GM_MAX_MEDIAN_FRAMES 64
+#define GM_MAX_MEDIAN_FRAMES 64       /* per bin, sorted by 256-lane workgroups */
+#define GM_MAX_MEDIAN_FRAMES_LONG 599 /* longer bins: 64-lane workgroups, as far as the 160 KiB of LDS reach
+                                         (640 float32 / 320 float64 values per lane); np.nanmedian itself takes
+                                         another route from 600 frames on */
 
 typedef struct gm_frame_bin {
   int32_t first; /* first source frame */
@@ -430,7 +433,7 @@ int gm_temporal_aggregate(const void* frames, int dtype, int has_ndv, uint64_t n
  * values v: a = v[lower], b = v[upper], d = b - a, result = gamma >= 0.5 ? b - d * one_minus_gamma
  * : a + d * gamma (numpy.lib._function_base_impl._lerp), all in result_type(float32, dtype).  The
  * host derives the plan with NumPy's own scalar arithmetic ((n - 1) * (q / 100) in that dtype), so
- * the rounding of the virtual index is NumPy's.  n_plan >= the longest bin, <= GM_MAX_MEDIAN_FRAMES. */
+ * the rounding of the virtual index is NumPy's.  n_plan >= the longest bin, <= GM_MAX_MEDIAN_FRAMES_LONG. */
 typedef struct gm_percentile_step {
   int32_t lower, upper;
   double gamma, one_minus_gamma;

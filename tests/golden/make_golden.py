@@ -957,6 +957,16 @@ def gen_smooth(w):
                 w.add(id="sm%04d" % cid, op="smooth", args=[data, kw], expect=R_sp.Smooth.process(data, kw)); cid += 1
     for args in ([None, dict(smooth_mode="exact", fill=0, size=[1.0, 1.0])], [{"time": ["t"]}, None]):
         w.add(id="sm%04d" % cid, op="smooth", args=args, expect=R_sp.Smooth.process(*args)); cid += 1
+    # integer rasters (elevation models in int16 ...): SciPy filters in float64 and stores with a C cast
+    for dt, ndv in (("i2", np.int16(-9999)), ("u1", np.uint8(255)), ("i4", -9999), ("i8", -9999), ("u2", np.uint16(65535))):
+        for shape, size, mode in (((1, 30, 41), (2.0, 3.0), "exact"), ((2, 17, 19), (1.0, 1.0), "exact"),
+                                  ((1, 40, 48), (3.75, 6.0), "zoom")):
+            for fill in (0, 2.5):
+                v = rng.integers(0, 200, size=shape).astype(dt)
+                v[rng.random(shape) < 0.1] = ndv
+                data = {"values": v, "no_data_value": ndv}
+                kw = dict(smooth_mode=mode, fill=fill, size=list(size))
+                w.add(id="sm%04d" % cid, op="smooth", args=[data, kw], expect=R_sp.Smooth.process(data, kw)); cid += 1
 
 
 # --------------------------------------------------------------------------

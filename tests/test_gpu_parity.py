@@ -798,14 +798,42 @@ def test_temporal_golden(gpu, case):
 
 
 @pytest.mark.gpu
-def test_temporal_long_bins_are_refused(gpu):
-    """Median / percentiles sort a cell's frames in LDS: more than 64 (float32) frames per label is refused loudly."""
+@pytest.mark.parametrize("dtype,frames", [("f4", 70), ("f4", 365), ("f4", 599), ("f8", 200), ("f8", 320), ("i2", 130)])
+def test_temporal_median_and_percentiles_over_long_bins(gpu, dtype, frames):
+    """Beyond 64 frames per label (a year of daily frames ...) the sort moves to 64-lane workgroups: up to 599
+    float32 / 320 float64 values per cell in the 160 KiB of LDS, the percentile plan in device memory."""
     from dask_geomodeling_amd.raster import temporal as T
-    v = np.zeros((70, 4, 8), "f4")
+    rng = np.random.default_rng(frames)
+    ndv = np.dtype(dtype).type(-999)
+    v = (rng.random((frames, 9, 37)) * 200 - 100).astype(dtype)
+    v[rng.random(v.shape) < 0.3] = ndv
+    v[:, 0, 0] = ndv
+    runs = [(0, frames), (3, frames - 5), (0, 10)]
+    for stat in ("median", "p10.0", "p50.0", "p97.5"):
+        out_dtype = T.dtype_for_statistic(dtype, stat)
+        got = T.aggregate_frames(v, ndv, runs, stat, out_dtype).to_numpy() + 0.0
+        want = O.temporal_aggregate_values(v, ndv, runs, stat, out_dtype) + 0.0
+        assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (stat, dtype, frames)
+    too_many = 600 if np.dtype(out_dtype).itemsize == 4 else 321
     with pytest.raises(NotImplementedError):
-        T.aggregate_frames(v, None, [(0, 70)], "median", np.dtype("f4"))
-    with pytest.raises(NotImplementedError):
-        T.aggregate_frames(v, None, [(0, 70)], "p95.0", np.dtype("f4"))
+        T.aggregate_frames(np.zeros((too_many, 2, 4), dtype), None, [(0, too_many)], "median", out_dtype)
+
+
+@pytest.mark.gpu
+def test_reduce_rasters_median_over_many_rasters(gpu):
+    from dask_geomodeling_amd.raster.reduction import reduce_rasters
+    rng = np.random.default_rng(8)
+    ndv = np.float32(-1)
+    stack = []
+    for _ in range(90):
+        v = (rng.random((1, 12, 20)) * 50).astype("f4")
+        v[rng.random(v.shape) < 0.2] = ndv
+        stack.append({"values": v, "no_data_value": ndv})
+    for stat in ("median", "p25"):
+        got = reduce_rasters([dict(d) for d in stack], stat)
+        with np.errstate(all="ignore"):
+            want = O.reduce_rasters([dict(d) for d in stack], stat)
+        assert_result_equal(dict(got, values=np.asarray(got["values"]) + 0.0), dict(want, values=want["values"] + 0.0), 0, stat)
 
 
 @pytest.mark.gpu
