@@ -149,6 +149,100 @@ __global__ __launch_bounds__(256) void classify_kernel(const TI* __restrict__ in
   }
 }
 
+// Many edges, float32 tiles: the branch-free binary search above costs ~8 VALU instructions per step and
+// value -- 64 per value at 200 edges, which is what bounds it (27 % of the HBM roofline), not its LDS reads.
+// Here a uniform grid over [first edge, last edge] narrows the search first: bucket b = (x - lo) * inv holds
+// base[b] = a lower bound of the count for every x the float arithmetic can put into b (the host allows one
+// bucket of slack on either side), and the host has checked that the count of such an x exceeds base[b] by at
+// most GRID_SCAN: those GRID_SCAN thresholds are compared independently (sorted: the satisfied ones are a
+// prefix).  ~25 VALU instructions and 1 + GRID_SCAN LDS reads per value whatever the number of edges.
+constexpr int GRID_SCAN = 4;
+struct ClassifyGrid {
+  float lo, inv;
+  int buckets;  // K
+};
+template <typename TO, bool RIGHT, int CLS_U>
+__global__ __launch_bounds__(256) void classify_grid_kernel(const float* __restrict__ in, TO* __restrict__ out,
+                                                            unsigned long long n_groups, const float* __restrict__ thr_g,
+                                                            const unsigned short* __restrict__ base_g, int nbins,
+                                                            ClassifyGrid G, int chunks, int has_ndv, float ndv, TO fill) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* const thr = (float*)smem;                                  // nbins + GRID_SCAN (NaN padded)
+  unsigned short* const base = (unsigned short*)(thr + nbins + GRID_SCAN);
+  const unsigned long long span = 256ull * CLS_U;
+  for (int c = 0; c < chunks; ++c) {
+    const unsigned long long g0 = ((unsigned long long)blockIdx.x * chunks + c) * span + threadIdx.x;
+    float v[CLS_U][4];
+#pragma unroll
+    for (int u = 0; u < CLS_U; ++u) {
+      const unsigned long long g = g0 + 256ull * u;
+      VecK<float, 4>::load(in + (g < n_groups ? g : n_groups - 1) * 4, v[u]);
+    }
+    if (c == 0) {  // staged behind the first tile loads
+      for (int i = threadIdx.x; i < nbins + GRID_SCAN; i += 256) thr[i] = i < nbins ? thr_g[i] : __builtin_nanf("");
+      for (int i = threadIdx.x; i < G.buckets; i += 256) base[i] = base_g[i];
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < CLS_U; ++u) {
+      TO r[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float x = v[u][k];
+        int b = (int)((x - G.lo) * G.inv);  // (NaN -> 0, +-inf saturate: clamped below)
+        b = min(max(b, 0), G.buckets - 1);
+        const int first = base[b];
+        int cnt = first;
+#pragma unroll
+        for (int j = 0; j < GRID_SCAN; ++j) cnt += (RIGHT ? (thr[first + j] < x) : (thr[first + j] <= x)) ? 1 : 0;
+        cnt = (x != x) ? nbins : cnt;  // NaN sorts to the end
+        r[k] = (has_ndv && x == ndv) ? fill : (TO)cnt;
+      }
+      const unsigned long long g = g0 + 256ull * u;
+      if (g < n_groups) VecK<TO, 4>::store(out + g * 4, r);
+    }
+  }
+}
+
+// base[] of the grid for float32 thresholds, or false when no grid of <= 8192 buckets keeps every bucket's
+// count within GRID_SCAN of its base (clustered edges: the binary search serves those)
+bool build_classify_grid(const float* thr, int nbins, bool right, ClassifyGrid* G, std::vector<unsigned short>* base) {
+  if (nbins < 2 || nbins > 60000) return false;
+  const float lo = thr[0], hi = thr[nbins - 1];
+  if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) return false;
+  auto count_at = [&](double x) {  // thresholds below x (right) / at or below x (left); thr is ascending
+    int a = 0, b = nbins;
+    while (a < b) {
+      const int m = (a + b) / 2;
+      if (right ? ((double)thr[m] < x) : ((double)thr[m] <= x)) a = m + 1;
+      else b = m;
+    }
+    return a;
+  };
+  for (int K = 1024; K <= 8192; K *= 2) {
+    const float inv = (float)((double)K / ((double)hi - (double)lo));
+    if (!std::isfinite(inv) || inv <= 0.0f) return false;
+    const double step = 1.0 / (double)inv;
+    base->assign((size_t)K, 0);
+    bool ok = true;
+    for (int b = 0; b < K && ok; ++b) {
+      // every x the device can put into bucket b lies in [lo + (b - 1) step, lo + (b + 2) step]: a whole bucket
+      // of slack on either side covers the rounding of (x - lo) * inv in float32 (a few 2^-23 * K << 1)
+      const int lower = b == 0 ? 0 : count_at((double)lo + (b - 1) * step);
+      const int upper = b == K - 1 ? nbins : count_at((double)lo + (b + 2) * step);
+      if (upper - lower > GRID_SCAN) ok = false;
+      (*base)[b] = (unsigned short)lower;
+    }
+    if (ok) {
+      G->lo = lo;
+      G->inv = inv;
+      G->buckets = K;
+      return true;
+    }
+  }
+  return false;
+}
+
 // =====================================================================================
 // Reclassify
 // =====================================================================================
@@ -197,12 +291,23 @@ __global__ __launch_bounds__(256) void reclassify_kernel(const TI* __restrict__ 
   };
 
   auto lookup = [&](long long v) -> unsigned long long {
-    if (T.dense) {
+    if (T.dense == 1) {
       const unsigned long long idx = (unsigned long long)(v - T.kmin);
       const unsigned long long hit = val_at(idx < (unsigned long long)T.range ? (int)idx : 0);
       unsigned long long miss = select ? fill : passthrough(v);
       for (int x = 0; x < T.n_exc; ++x) miss = (v == T.exc_keys[x]) ? T.exc_vals[x] : miss;
       return idx < (unsigned long long)T.range ? hit : miss;
+    }
+    if (T.dense == 2) {
+      // sparse keys as an open-addressing hash table (the host found a multiplier that puts every key into its
+      // home slot or the one after it; an empty slot holds a key whose own home is elsewhere): two slots
+      // probed, ~16 VALU instructions and 4 LDS reads per value against ~70 / 9 of the binary search below
+      const unsigned h0 = ((unsigned)v * (unsigned)T.kmin) >> T.range;
+      const unsigned h1 = (h0 + 1u) & (unsigned)(T.ntab - 1);
+      const long long k0 = key_at((int)h0), k1 = key_at((int)h1);
+      const unsigned long long v0 = val_at((int)h0), v1 = val_at((int)h1);
+      const unsigned long long miss = select ? fill : passthrough(v);
+      return k0 == v ? v0 : (k1 == v ? v1 : miss);
     }
     // lower bound of v in the sorted keys
     int lo = 0, len = T.ntab;
@@ -232,9 +337,9 @@ __global__ __launch_bounds__(256) void reclassify_kernel(const TI* __restrict__ 
     if (LDS && c == 0) {
       // stage the table while the tile loads are in flight
       unsigned long long* sv = (unsigned long long*)smem;
-      const int nv = T.dense ? T.range : T.ntab;
+      const int nv = T.dense == 1 ? T.range : T.ntab;
       for (int i = threadIdx.x; i < nv; i += blockDim.x) sv[i] = T.vals[i];
-      if (!T.dense) {
+      if (T.dense != 1) {
         long long* sk = (long long*)(sv + T.ntab);
         for (int i = threadIdx.x; i < T.ntab; i += blockDim.x) sk[i] = T.keys[i];
       }
@@ -641,6 +746,39 @@ int gm_classify2(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, c
     void* thr_dev = nullptr;
     int rc32 = cached_upload(packed, &thr_dev);
     if (rc32) return rc32;
+    if (nbins > CLS_LINEAR_MAX && (out_dtype == GM_U8 || out_dtype == GM_U16) && ((uintptr_t)in % 16) == 0 &&
+        ((uintptr_t)out % 8) == 0 && n / 4 >= 4096) {
+      ClassifyGrid G;
+      std::vector<unsigned short> base;
+      if (build_classify_grid(thr, nbins, right != 0, &G, &base)) {
+        std::vector<unsigned long long> packed_base((base.size() * 2 + 7) / 8 + 1, 0ull);
+        memcpy(packed_base.data(), base.data(), base.size() * 2);
+        packed_base.back() = 0x6B1Dull << 32 | (unsigned)G.buckets;
+        void* base_dev = nullptr;
+        int rcg = cached_upload(packed_base, &base_dev);
+        if (rcg) return rcg;
+        const unsigned long long n4 = n / 4;
+        constexpr int U = 2;
+        const size_t lds = (size_t)(nbins + GRID_SCAN) * 4 + (size_t)G.buckets * 2;
+        const int chunks = chunks_for(lds, (size_t)256 * 4 * U * 5);
+        const unsigned long long blocks = (n4 + 256ull * U * chunks - 1) / (256ull * U * chunks);
+        if (blocks > 0x7fffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "tile too large for one launch");
+        const float ndv32 = (float)ndv.f64;
+#define GM_GRID(TO_, RIGHT_)                                                                                          \
+  hipLaunchKernelGGL((classify_grid_kernel<TO_, RIGHT_, U>), dim3((unsigned)blocks), dim3(256), lds, s, (const float*)in, \
+                     (TO_*)out, n4, (const float*)thr_dev, (const unsigned short*)base_dev, nbins, G, chunks, has_ndv,  \
+                     ndv32, (TO_)fill)
+        if (out_dtype == GM_U8) { if (right) GM_GRID(unsigned char, true); else GM_GRID(unsigned char, false); }
+        else { if (right) GM_GRID(unsigned short, true); else GM_GRID(unsigned short, false); }
+#undef GM_GRID
+        GM_HIP(hipGetLastError());
+        if (n4 * 4 == n) return GM_OK;
+        // the last n % 4 values: the general kernel's scalar path
+        return classify_out<float, float>((const float*)in + n4 * 4,
+                                          (char*)out + n4 * 4 * (out_dtype == GM_U8 ? 1 : 2), out_dtype, n - n4 * 4, thr_dev,
+                                          nbins, right, has_ndv, ndv, fill, s);
+      }
+    }
     return classify_out<float, float>(in, out, out_dtype, n, thr_dev, nbins, right, has_ndv, ndv, fill, s);
   }
 #define GM_CLS(TI)                                                                                              \
@@ -660,6 +798,56 @@ int gm_classify2(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, c
     default: return gm::fail(GM_ERR_INVALID, "gm_classify: in_dtype %d", in_dtype);
   }
 #undef GM_CLS
+}
+
+// Sparse keys -> a two-probe hash table (mode 2 of ReclassTable): slots = a power of two >= 4 x keys (<= 2048,
+// 32 KiB of LDS), slot of key k = ((uint32)k * multiplier) >> shift; a multiplier is searched that leaves every
+// key in its home slot or the next one.  payload = [slot values][slot keys][trailer].
+static bool build_hash_table(const int64_t* keys, const gm_scalar* targets, int ntab, std::vector<unsigned long long>* payload,
+                             ReclassTable* T) {
+  if (ntab < 1 || ntab > 512) return false;
+  int bits = 4;
+  while ((1 << bits) < 4 * ntab) ++bits;
+  const int slots = 1 << bits, shift = 32 - bits;
+  unsigned mult = 0x9E3779B1u;
+  for (int attempt = 0; attempt < 64; ++attempt, mult = mult * 0x85EBCA6Bu + 0xC2B2AE35u) {
+    mult |= 1u;
+    std::vector<int> owner((size_t)slots, -1);
+    bool ok = true;
+    for (int i = 0; i < ntab && ok; ++i) {
+      const unsigned h0 = ((unsigned)keys[i] * mult) >> shift, h1 = (h0 + 1u) & (unsigned)(slots - 1);
+      if (owner[h0] < 0) owner[h0] = i;
+      else if (owner[h1] < 0) owner[h1] = i;
+      else ok = false;
+    }
+    if (!ok) continue;
+    payload->assign((size_t)2 * slots + 2, 0ull);
+    for (int sl = 0; sl < slots; ++sl) {
+      if (owner[sl] >= 0) {
+        (*payload)[sl] = targets[owner[sl]].u64;
+        (*payload)[slots + sl] = (unsigned long long)keys[owner[sl]];
+      } else {
+        // an empty slot: a key that is not in the table and whose own two probe slots are elsewhere, so that
+        // looking that very value up can never find it here
+        long long filler = 0;
+        for (;; ++filler) {
+          const unsigned f0 = ((unsigned)filler * mult) >> shift, f1 = (f0 + 1u) & (unsigned)(slots - 1);
+          bool is_key = false;
+          for (int i = 0; i < ntab && !is_key; ++i) is_key = keys[i] == filler;
+          if (!is_key && f0 != (unsigned)sl && f1 != (unsigned)sl) break;
+        }
+        (*payload)[slots + sl] = (unsigned long long)filler;
+      }
+    }
+    (*payload)[2 * (size_t)slots] = ((unsigned long long)mult << 32) | (unsigned)shift;
+    (*payload)[2 * (size_t)slots + 1] = 0x4A5Bull;
+    T->dense = 2;
+    T->kmin = (long long)mult;
+    T->range = shift;
+    T->ntab = slots;
+    return true;
+  }
+  return false;
 }
 
 int gm_reclassify(const void* in, int in_dtype, const int64_t* keys_host, const gm_scalar* targets_host, int ntab,
@@ -732,6 +920,13 @@ int gm_reclassify(const void* in, int in_dtype, const int64_t* keys_host, const 
     if (rc) return rc;
     T.vals = (const unsigned long long*)dev;
     T.use_lds = 1;
+  } else if (build_hash_table(keys_host, targets_host, ntab, &payload, &T)) {
+    void* dev = nullptr;
+    int rc = cached_upload(payload, &dev);
+    if (rc) return rc;
+    T.vals = (const unsigned long long*)dev;
+    T.keys = (const long long*)((const unsigned long long*)dev + T.ntab);
+    T.use_lds = 1;
   } else {
     payload.resize((size_t)2 * ntab + 1);
     for (int i = 0; i < ntab; ++i) payload[i] = targets_host[i].u64;
@@ -744,7 +939,7 @@ int gm_reclassify(const void* in, int in_dtype, const int64_t* keys_host, const 
     T.keys = (const long long*)((const unsigned long long*)dev + ntab);
     T.use_lds = ((size_t)ntab * 16 <= (size_t)kLdsBudget) ? 1 : 0;
   }
-  const size_t lds = T.use_lds ? (T.dense ? (size_t)T.range * 8 : (size_t)T.ntab * 16) : 0;
+  const size_t lds = T.use_lds ? (T.dense == 1 ? (size_t)T.range * 8 : (size_t)T.ntab * 16) : 0;
   constexpr int tune_u = 4;  // sub-iterations per workgroup: 4 measured best (2: 68 %/72 %, 4: 68 %/82 %, 8: 65 %/74 %)
 #define GM_RCL_LAUNCH(TI, K_, FIRST, END)                                                                        \
   GM_RCL_LAUNCH_U(TI, K_, FIRST, END, tune_u)

@@ -496,6 +496,66 @@ def test_tiler_over_memory_source_is_zero_copy_and_exact(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("select", [False, True])
+@pytest.mark.parametrize("dtype", ["i4", "i8", "i2", "u2"])
+def test_reclassify_sparse_keys_hash_table(gpu, dtype, select):
+    """Keys too scattered for a dense window run through the two-probe hash table (and, beyond 512 keys, the
+    binary search): hits, misses, negative keys, keys that collide in their low bits, the no-data key."""
+    from dask_geomodeling_amd.raster import tables
+    rng = np.random.default_rng(17)
+    info = np.iinfo(dtype)
+    span = min(int(info.max), 2_000_000_000)
+    for n_keys in (3, 100, 400, 700):
+        keys = np.unique(rng.integers(max(int(info.min), -span), span, size=n_keys).astype(dtype)).tolist()
+        if dtype == "i8":
+            keys += [2 ** 40 + 5, 2 ** 40 + 5 + 2 ** 32, -2 ** 45]  # equal low 32 bits: only the full key tells them apart
+        table = [[int(k), float(i) + 0.5 if i % 3 == 0 else int(i * 7)] for i, k in enumerate(sorted(set(keys)))]
+        ndv = np.dtype(dtype).type(info.max)
+        v = rng.choice(np.asarray([k for k, _ in table] + [0, 1, -1 if info.min < 0 else 2, int(info.max) - 1], dtype=dtype),
+                       size=(1, 300, 257))
+        v[rng.random(v.shape) < 0.3] = rng.integers(max(int(info.min), -span), span)
+        v[0, ::11, ::7] = ndv
+        data = {"values": v, "no_data_value": ndv}
+        target_dtype = np.asarray([t for _, t in table]).dtype
+        kw = {"dtype": target_dtype.str, "fillvalue": (float(np.finfo("f8").max) if target_dtype.kind == "f" else int(np.iinfo("i8").max)),
+              "data": table, "select": select}
+        got = tables.reclassify_process(data, kw)
+        want = O.reclassify_process(data, kw)
+        assert_result_equal(dict(got, values=np.asarray(got["values"])), want, 0, "%s %d keys select=%s" % (dtype, n_keys, select))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("right", [False, True])
+@pytest.mark.parametrize("kind", ["uniform200", "random37", "clustered", "u16_300"])
+def test_classify_many_edges_large_tile(gpu, kind, right):
+    """Stand-alone Classify with many edges on a tile large enough for the grid-accelerated kernel (uniform and
+    irregular edges; clustered edges fall back to the binary search): exact against np.digitize, values on the
+    edges, NaN, +-inf and no data included."""
+    from dask_geomodeling_amd.raster import tables
+    rng = np.random.default_rng(len(kind))
+    if kind == "uniform200":
+        bins = np.linspace(-100, 100, 200).tolist()
+    elif kind == "random37":
+        bins = sorted(set(np.round(rng.random(37) * 180 - 90, 3).tolist()))
+    elif kind == "u16_300":
+        bins = (np.arange(300) * 0.61 - 90).tolist()
+    else:
+        bins = sorted(set((np.concatenate([np.linspace(-100, 100, 20), 1.0 + np.arange(40) * 1e-4])).tolist()))
+    ndv = np.float32(np.finfo("f4").max)
+    v = (rng.random((1, 1024, 1031)) * 220 - 110).astype("f4")
+    flat = v.reshape(-1)
+    flat[:len(bins)] = np.asarray(bins, dtype="f4")             # values on (float32-rounded) edges
+    flat[len(bins):2 * len(bins)] = np.nextafter(np.asarray(bins, dtype="f4"), np.float32(1e9))
+    flat[2 * len(bins):3 * len(bins)] = np.nextafter(np.asarray(bins, dtype="f4"), np.float32(-1e9))
+    v[0, 5, :7] = [np.nan, np.inf, -np.inf, ndv, 0.0, -0.0, 1e30]
+    v[0, ::53, ::47] = ndv
+    data = {"values": v, "no_data_value": ndv}
+    got = tables.classify_process(data, bins, right)
+    want = O.classify_process(data, bins, right)
+    assert_result_equal(dict(got, values=np.asarray(got["values"])), want, 0, "%s right=%s" % (kind, right))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cell", [0.1, 0.3, 0.7])
 def test_tiler_with_tiles_one_pixel_short_of_their_slot(gpu, cell):
     """The reference truncates tile sizes with int() (parallelize.py:85-86): for cell sizes that are not
