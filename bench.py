@@ -561,6 +561,27 @@ def main():
             if not args.no_e2e:
                 del jobs
                 out["end_to_end"] = end_to_end(raster, runtime, side)
+        if args.workload == "mosaic" and world == 1 and not args.no_e2e:
+            # what a caller sees: RasterTiler(view, 4096).get_data over the whole 65536^2 request (256 tiles), result
+            # left on the device -- through the view's cached plan, and building + fusing the graph per request
+            from dask_geomodeling_amd import config as gmconfig
+            tiler = raster.RasterTiler(mosaic_view(raster, "procedural" if args.procedural else args.leaves), side)
+            whole = dict(mode="vals", bbox=(0.0, 0.0, float(MOSAIC_SIDE), float(MOSAIC_SIDE)), width=MOSAIC_SIDE,
+                         height=MOSAIC_SIDE, projection="EPSG:28992")
+            e2e = {}
+            for label, plans in (("plans", True), ("graph_per_request", False)):
+                with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": plans}):
+                    tiler.get_data(**whole)
+                    runtime.sync()
+                    t1, calls = time.perf_counter(), 0
+                    while calls < 3 or time.perf_counter() - t1 < 1.0:
+                        tiler.get_data(**whole)
+                        calls += 1
+                    runtime.sync()
+                    dt = (time.perf_counter() - t1) / calls
+                e2e["tiler_get_data_device_" + label] = {"Mpix/s": round(MOSAIC_SIDE ** 2 / dt / 1e6, 1),
+                                                         "ms_per_request": round(dt * 1e3, 2), "requests": calls, "tiles": tiles}
+            out["end_to_end"] = e2e
         print(json.dumps(out), flush=True)
 
     if dist is not None:
