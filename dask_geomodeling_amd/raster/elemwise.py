@@ -22,51 +22,49 @@ BOOL = np.dtype("bool")
 
 def _overlap(boxes):
     """Intersection of (x1, y1, x2, y2) boxes or None."""
-    x1 = max(b[0] for b in boxes)
-    y1 = max(b[1] for b in boxes)
-    x2 = min(b[2] for b in boxes)
-    y2 = min(b[3] for b in boxes)
-    if x2 <= x1 or y2 <= y1:
-        return None
-    return x1, y1, x2, y2
+    west, south = max(b[0] for b in boxes), max(b[1] for b in boxes)
+    east, north = min(b[2] for b in boxes), min(b[3] for b in boxes)
+    return (west, south, east, north) if east > west and north > south else None
 
 
 class BaseElementwise(RasterBlock):
-    """Base of element-wise operations; extent and period are the intersection of the
-    raster arguments' (elemwise.py:37-191)."""
+    """Base of element-wise operations.  The result exists where ALL raster arguments exist: period, extent
+    and geometry are intersections, projection and geo_transform survive only when the arguments agree
+    (elemwise.py:37-191)."""
 
     def __init__(self, *args):
-        super(BaseElementwise, self).__init__(*args)
+        super().__init__(*args)
         rasters = self._sources
-        if len(rasters) > 1:  # elemwise.py:46-57
-            temporal, delta = rasters[0].temporal, rasters[0].timedelta
-            if any(r.temporal != temporal for r in rasters[1:]):
+        lead = rasters[0] if rasters else None
+        for other in rasters[1:]:  # elemwise.py:46-57
+            if other.temporal != lead.temporal:
                 raise ValueError("Temporal properties of input rasters do not match.")
-            if temporal and delta is not None:
-                if not all(r.timedelta in (None, delta) for r in rasters[1:]):
+        if lead is not None and lead.temporal and lead.timedelta is not None:
+            for other in rasters[1:]:
+                if other.timedelta not in (None, lead.timedelta):
                     raise ValueError("Time resolutions of input rasters are not equal.")
 
     @property
     def _sources(self):
         return [arg for arg in self.args if isinstance(arg, RasterBlock)]
 
+    def _of_all(self, attribute):
+        """The attribute of every raster argument, or None as soon as one of them has none."""
+        values = [getattr(raster, attribute) for raster in self._sources]
+        return None if any(v is None for v in values) else values
+
     def get_sources_and_requests(self, **request):
-        start, stop = request.get("start"), request.get("stop")
-        if start is not None and stop is not None:
-            period = self.period  # clamp so that all arguments answer the same frames
-            if period is not None:
-                request["start"] = max(start, period[0])
-                request["stop"] = min(stop, period[1])
+        if request.get("start") is not None and request.get("stop") is not None:
+            common = self.period  # every argument must answer the same frames
+            if common is not None:
+                request["start"], request["stop"] = max(request["start"], common[0]), min(request["stop"], common[1])
         process_kwargs = {"dtype": self.dtype.name, "fillvalue": self.fillvalue}
         return [(process_kwargs, None)] + [(arg, request) for arg in self.args]
 
     @property
     def timedelta(self):
-        rasters = self._sources
-        if len(rasters) == 1:
-            return rasters[0].timedelta
-        deltas = [r.timedelta for r in rasters]
-        return None if any(d is None for d in deltas) else deltas[0]
+        deltas = self._of_all("timedelta")
+        return None if deltas is None else deltas[0]
 
     @property
     def temporal(self):
@@ -74,113 +72,90 @@ class BaseElementwise(RasterBlock):
 
     @property
     def period(self):
-        rasters = self._sources
-        if len(rasters) == 1:
-            return rasters[0].period
-        periods = [r.period for r in rasters]
-        if any(p is None for p in periods):
+        periods = self._of_all("period")
+        if periods is None:
             return None
-        start = max(p[0] for p in periods)
-        stop = min(p[1] for p in periods)
-        return None if stop < start else (start, stop)
+        begin, end = max(p[0] for p in periods), min(p[1] for p in periods)
+        return (begin, end) if begin <= end else None
 
     @property
     def extent(self):
-        rasters = self._sources
-        if len(rasters) == 1:
-            return rasters[0].extent
-        extents = [r.extent for r in rasters]
-        if any(e is None for e in extents):
+        boxes = self._of_all("extent")
+        if boxes is None:
             return None
-        return _overlap(extents)
+        return boxes[0] if len(boxes) == 1 else _overlap(boxes)
 
     @property
     def dtype(self):
-        # result_type over all arguments (python scalars are weak), lifted to >= int32 / float32.
+        # NumPy's result type over all arguments (python scalars are weak), lifted to >= int32 / float32.
         # Blocks are immutable: computed once (request planning asks for it per tile).
-        cached = self.__dict__.get("_dtype_cache")
-        if cached is not None:
-            return cached
-        dtype = np.result_type(*[a.dtype if isinstance(a, RasterBlock) else a for a in self.args])
-        if np.issubdtype(dtype, np.integer) or dtype == BOOL:
-            dtype = np.result_type(dtype, np.int32)
-        elif np.issubdtype(dtype, np.floating):
-            dtype = np.result_type(dtype, np.float32)
-        self.__dict__["_dtype_cache"] = dtype
-        return dtype
+        known = self.__dict__.get("_dtype_cache")
+        if known is None:
+            known = np.result_type(*[a.dtype if isinstance(a, RasterBlock) else a for a in self.args])
+            if known == BOOL or np.issubdtype(known, np.integer):
+                known = np.result_type(known, np.int32)
+            elif np.issubdtype(known, np.floating):
+                known = np.result_type(known, np.float32)
+            self.__dict__["_dtype_cache"] = known
+        return known
 
     @property
     def fillvalue(self):
-        dtype = self.dtype
-        return None if dtype == BOOL else get_dtype_max(dtype)
+        return None if self.dtype == BOOL else get_dtype_max(self.dtype)
 
     @property
     def geometry(self):
-        geometries = [r.geometry for r in self._sources]
-        if any(g is None for g in geometries):
+        shapes = self._of_all("geometry")
+        if shapes is None:
             return None
-        if len(geometries) == 1:
-            return geometries[0]
-        extent = Extent.from_geometry(geometries[0])
-        for geometry in geometries[1:]:
-            extent = extent.intersection(Extent.from_geometry(geometry))
-            if extent is None:
+        common = Extent.from_geometry(shapes[0])
+        for shape in shapes[1:]:
+            common = common.intersection(Extent.from_geometry(shape))
+            if common is None:
                 return None
-        return extent.as_geometry()
+        return shapes[0] if len(shapes) == 1 else common.as_geometry()
 
     @property
     def projection(self):
-        rasters = self._sources
-        projection = rasters[0].projection
-        if projection is None:
-            return None
-        return projection if all(r.projection == projection for r in rasters[1:]) else None
+        found = {raster.projection for raster in self._sources}
+        return found.pop() if len(found) == 1 else None  # (a lone None stays None)
 
     @property
     def geo_transform(self):
-        rasters = self._sources
-        first = rasters[0].geo_transform
-        if first is None:
+        grids = self._of_all("geo_transform")
+        if grids is None:
             return None
-        first = GeoTransform(first)
-        for r in rasters[1:]:
-            other = r.geo_transform
-            if other is None or not first.aligns_with(other):
-                return None
-        return first
+        lead = GeoTransform(grids[0])
+        return lead if all(lead.aligns_with(other) for other in grids[1:]) else None
+
+
+def _allowed(value, kinds):
+    if not isinstance(value, kinds):
+        raise TypeError("'{}' object is not allowed".format(type(value)))
 
 
 class BaseMath(BaseElementwise):
     def __init__(self, a, b):
-        for x in (a, b):
-            if not isinstance(x, (RasterBlock, np.ndarray, float, int)):
-                raise TypeError("'{}' object is not allowed".format(type(x)))
-        super(BaseMath, self).__init__(a, b)
+        for operand in (a, b):
+            _allowed(operand, (RasterBlock, np.ndarray, float, int))
+        super().__init__(a, b)
 
 
 class BaseComparison(BaseMath):
-    @property
-    def dtype(self):
-        return BOOL
+    dtype = property(lambda self: BOOL)
 
 
 class BaseLogic(BaseElementwise):
     def __init__(self, a, b):
-        for x in (a, b):
-            if isinstance(x, (RasterBlock, np.ndarray)):
-                if x.dtype != BOOL:
-                    raise TypeError("inputs must have boolean dtypes")
-            elif not isinstance(x, bool):
-                raise TypeError("'{}' object is not allowed".format(type(x)))
-        super(BaseLogic, self).__init__(a, b)
+        for operand in (a, b):
+            if not isinstance(operand, (RasterBlock, np.ndarray)):
+                _allowed(operand, bool)
+            elif operand.dtype != BOOL:
+                raise TypeError("inputs must have boolean dtypes")
+        super().__init__(a, b)
 
-    @property
-    def dtype(self):
-        return BOOL
-
-    @property
-    def fillvalue(self):
-        return None
+    dtype = property(lambda self: BOOL)
+    fillvalue = property(lambda self: None)
 
 
 class Add(BaseMath):

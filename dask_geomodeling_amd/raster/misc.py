@@ -8,7 +8,8 @@ import numpy as np
 
 from .. import utils
 from . import devops, tables
-from .base import BaseSingle, RasterBlock
+from ._checks import argument, need_iterable, need_number, need_raster, not_allowed
+from .base import BaseSingle
 
 __all__ = ["Clip", "Classify", "Reclassify", "Mask", "MaskBelow", "Step"]
 
@@ -20,38 +21,35 @@ class Clip(BaseSingle):
     (misc.py:30-166)."""
 
     def __init__(self, store, source):
-        if not isinstance(source, RasterBlock):
-            raise TypeError("'{}' object is not allowed".format(type(store)))
-        if store.temporal and not source.temporal:
-            raise ValueError("The values raster is temporal while the clipping mask is not. "
-                             "Consider using Snap.")
-        if not store.temporal and source.temporal:
-            raise ValueError("The clipping mask is temporal while the values raster is not. "
-                             "Consider using Snap.")
-        if store.temporal and store.timedelta != source.timedelta:
-            raise ValueError("Time resolution of the clipping mask does not match that of "
-                             "the values raster. Consider using Snap.")
-        super(Clip, self).__init__(store, source)
+        need_raster(source, blame=store)  # (the reference names the store's type here, misc.py:54)
+        mismatch = None
+        if store.temporal != source.temporal:
+            first, second = ("values raster", "clipping mask") if store.temporal else ("clipping mask", "values raster")
+            mismatch = "The {} is temporal while the {} is not.".format(first, second)
+        elif store.temporal and store.timedelta != source.timedelta:
+            mismatch = "Time resolution of the clipping mask does not match that of the values raster."
+        if mismatch is not None:
+            raise ValueError(mismatch + " Consider using Snap.")
+        super().__init__(store, source)
 
-    @property
-    def source(self):
-        return self.args[1]
+    source = argument(1)
 
     def get_sources_and_requests(self, **request):
-        """Clamp start/stop into the common period so both tiles are aligned (misc.py:75-96)."""
-        period = self.period
-        if period is None:
-            return [(None, None), (None, None)]
-        start = request.get("start")
-        if start is None:
-            start = period[1]
-        stop = request.get("stop")
+        """Both tiles must answer the same frames: the window is moved into the common period, and there is
+        nothing to ask for when it misses that period altogether (misc.py:75-96)."""
+        nothing = [(None, None), (None, None)]
+        common = self.period
+        if common is None:
+            return nothing
+        first, last = common
+        start, stop = request.get("start"), request.get("stop")
+        start = last if start is None else start
         if stop is not None:
-            if stop < period[0] or start > period[1]:
-                return [(None, None), (None, None)]
-            request["stop"] = min(max(stop, period[0]), period[1])
-        request["start"] = min(max(start, period[0]), period[1])
-        return [(arg, request) for arg in self.args]
+            if stop < first or start > last:
+                return nothing
+            request["stop"] = min(max(stop, first), last)
+        request["start"] = min(max(start, first), last)
+        return [(raster, request) for raster in self.args]
 
     @staticmethod
     def process(data, source_data):
@@ -59,55 +57,46 @@ class Clip(BaseSingle):
 
     process.__func__.gm_op = "clip"
 
+    def _both(self, attribute):
+        pair = [getattr(raster, attribute) for raster in self.args]
+        return None if None in pair else pair
+
     @property
     def extent(self):
-        store, mask = [x.extent for x in self.args]
-        if store is None or mask is None:
+        boxes = self._both("extent")
+        if boxes is None:
             return None
-        x1, y1 = max(store[0], mask[0]), max(store[1], mask[1])
-        x2, y2 = min(store[2], mask[2]), min(store[3], mask[3])
-        if x2 <= x1 or y2 <= y1:
-            return None
-        return x1, y1, x2, y2
+        (ax1, ay1, ax2, ay2), (bx1, by1, bx2, by2) = boxes
+        west, south, east, north = max(ax1, bx1), max(ay1, by1), min(ax2, bx2), min(ay2, by2)
+        return (west, south, east, north) if east > west and north > south else None
 
     @property
     def geometry(self):
-        store, mask = [x.geometry for x in self.args]
-        if store is None or mask is None:
+        shapes = self._both("geometry")
+        if shapes is None:
             return None
-        extent = utils.Extent.from_geometry(store).intersection(utils.Extent.from_geometry(mask))
-        return None if extent is None else extent.as_geometry()
+        common = utils.Extent.from_geometry(shapes[0]).intersection(utils.Extent.from_geometry(shapes[1]))
+        return None if common is None else common.as_geometry()
 
     @property
     def period(self):
-        periods = [x.period for x in self.args]
-        if any(p is None for p in periods):
+        periods = self._both("period")
+        if periods is None:
             return None
-        start = max(p[0] for p in periods)
-        stop = min(p[1] for p in periods)
-        return None if stop < start else (start, stop)
+        begin, end = max(p[0] for p in periods), min(p[1] for p in periods)
+        return (begin, end) if begin <= end else None
 
 
 class Mask(BaseSingle):
     """Replace every data cell by one constant; no-data stays no-data (misc.py:169-222)."""
 
     def __init__(self, store, value):
-        if not isinstance(value, (float, int)):
-            raise TypeError("'{}' object is not allowed".format(type(value)))
-        super(Mask, self).__init__(store, value)
+        need_number(value)
+        super().__init__(store, value)
 
-    @property
-    def value(self):
-        return self.args[1]
-
-    @property
-    def fillvalue(self):
-        return 1 if self.value == 0 else 0
-
-    @property
-    def dtype(self):
-        return devops.mask_dtype(self.value)
-
+    value = argument(1)
+    fillvalue = property(lambda self: 1 if self.value == 0 else 0)  # whatever differs from the constant
+    dtype = property(lambda self: devops.mask_dtype(self.value))
     _dtype_from_value = staticmethod(devops.mask_dtype)
 
     @staticmethod
@@ -121,9 +110,8 @@ class MaskBelow(BaseSingle):
     """Cells below ``value`` become no-data (misc.py:225-251)."""
 
     def __init__(self, store, value):
-        if not isinstance(value, (float, int)):
-            raise TypeError("'{}' object is not allowed".format(type(value)))
-        super(MaskBelow, self).__init__(store, value)
+        need_number(value)
+        super().__init__(store, value)
 
     @staticmethod
     def process(data, value):
@@ -136,16 +124,12 @@ class Step(BaseSingle):
     """Three-valued step function around ``value`` (misc.py:254-328)."""
 
     def __init__(self, store, left=0, right=1, value=0, at=None):
-        at = (left + right) / 2 if at is None else at
-        for x in left, right, value, at:
-            if not isinstance(x, (float, int)):
-                raise TypeError("'{}' object is not allowed".format(type(x)))
-        super(Step, self).__init__(store, left, right, value, at)
+        if at is None:
+            at = (left + right) / 2
+        need_number(left, right, value, at)
+        super().__init__(store, left, right, value, at)
 
-    left = property(lambda self: self.args[1])
-    right = property(lambda self: self.args[2])
-    value = property(lambda self: self.args[3])
-    at = property(lambda self: self.args[4])
+    left, right, value, at = argument(1), argument(2), argument(3), argument(4)
 
     @staticmethod
     def process(data, left, right, location, at):
@@ -158,38 +142,28 @@ class Classify(BaseSingle):
     """Bin index of every cell for increasing ``bins`` (misc.py:331-399)."""
 
     def __init__(self, store, bins, right=False):
-        if not isinstance(store, RasterBlock):
-            raise TypeError("'{}' object is not allowed".format(type(store)))
-        if not hasattr(bins, "__iter__"):
-            raise TypeError("'{}' object is not allowed".format(type(bins)))
+        need_raster(store)
+        need_iterable(bins)
         edges = np.asarray(bins)
+        complaint = None
         if edges.ndim != 1:
-            raise TypeError("'bins' should be one-dimensional")
-        if not np.issubdtype(edges.dtype, np.number):
-            raise TypeError("'bins' should be numeric")
-        steps = np.diff(bins)
-        # same acceptance test as the reference (misc.py:364-366), including its rejection
-        # of single-edge lists (all() of an empty difference is True)
-        if not np.all(steps > 0) or np.all(steps < 0):
-            raise TypeError("'bins' should be monotonic")
-        super(Classify, self).__init__(store, edges.tolist(), right)
+            complaint = "one-dimensional"
+        elif not np.issubdtype(edges.dtype, np.number):
+            complaint = "numeric"
+        else:
+            # the reference's own acceptance test (misc.py:364-366), quirks included: increasing edges pass;
+            # a single edge does not (all() of its empty difference is True on both sides)
+            steps = np.diff(bins)
+            if not np.all(steps > 0) or np.all(steps < 0):
+                complaint = "monotonic"
+        if complaint is not None:
+            raise TypeError("'bins' should be " + complaint)
+        super().__init__(store, edges.tolist(), right)
 
-    @property
-    def bins(self):
-        return self.args[1]
-
-    @property
-    def right(self):
-        return self.args[2]
-
-    @property
-    def dtype(self):
-        # n edges -> n + 1 classes, plus one code for no-data
-        return utils.get_uint_dtype(len(self.bins) + 2)
-
-    @property
-    def fillvalue(self):
-        return utils.get_dtype_max(self.dtype)
+    bins, right = argument(1), argument(2)
+    # n edges -> n + 1 classes, plus one code for no data
+    dtype = property(lambda self: utils.get_uint_dtype(len(self.bins) + 2))
+    fillvalue = property(lambda self: utils.get_dtype_max(self.dtype))
 
     @staticmethod
     def process(data, bins, right):
@@ -198,55 +172,44 @@ class Classify(BaseSingle):
     process.__func__.gm_op = "classify"
 
 
+def _whole_numbers(dtype):
+    return dtype == BOOL or np.issubdtype(dtype, np.integer)
+
+
 class Reclassify(BaseSingle):
     """Map integer cell values through a list of [from, to] pairs (misc.py:402-515)."""
 
     def __init__(self, store, data, select=False):
-        dtype = store.dtype
-        if dtype != BOOL and not np.issubdtype(dtype, np.integer):
+        if not _whole_numbers(store.dtype):
             raise TypeError("The store must be of boolean or integer datatype")
-        if not hasattr(data, "__iter__"):
-            raise TypeError("'{}' object is not allowed".format(type(data)))
+        need_iterable(data)
         try:
-            source, target = self._data_as_ndarray(data)
+            keys, targets = self._data_as_ndarray(data)
         except ValueError:
             raise ValueError("Please supply a list of [from, to] values")
-        if source.dtype != BOOL and not np.issubdtype(source.dtype, np.integer):
-            raise TypeError("Cannot reclassify from value with type '{}'".format(source.dtype))
-        if len(np.unique(source)) != len(source):
+        if not _whole_numbers(keys.dtype):
+            raise TypeError("Cannot reclassify from value with type '{}'".format(keys.dtype))
+        if np.unique(keys).size != keys.size:
             raise ValueError("There are duplicates in the reclassify values")
-        if not np.issubdtype(target.dtype, np.number):
-            raise TypeError("Cannot reclassify to value with type '{}'".format(target.dtype))
-        data = [list(pair) for pair in zip(source.tolist(), target.tolist())]
+        if not np.issubdtype(targets.dtype, np.number):
+            raise TypeError("Cannot reclassify to value with type '{}'".format(targets.dtype))
         if select is not True and select is not False:
-            raise TypeError("'{}' object is not allowed".format(type(select)))
-        super().__init__(store, data, select)
+            raise not_allowed(select)
+        # stored with consistent (python) value types: what dtype / JSON round trips see
+        super().__init__(store, [[k, t] for k, t in zip(keys.tolist(), targets.tolist())], select)
 
     @staticmethod
     def _data_as_ndarray(data):
-        source, target = zip(*data)
-        return np.asarray(source), np.asarray(target)
+        keys, targets = zip(*data)
+        return np.asarray(keys), np.asarray(targets)
 
-    @property
-    def data(self):
-        return self.args[1]
-
-    @property
-    def select(self):
-        return self.args[2]
-
-    @property
-    def dtype(self):
-        return self._data_as_ndarray(self.data)[1].dtype
-
-    @property
-    def fillvalue(self):
-        return utils.get_dtype_max(self.dtype)
+    data, select = argument(1), argument(2)
+    dtype = property(lambda self: self._data_as_ndarray(self.data)[1].dtype)  # int64 / float64
+    fillvalue = property(lambda self: utils.get_dtype_max(self.dtype))
 
     def get_sources_and_requests(self, **request):
-        process_kwargs = {"dtype": self.dtype.str, "fillvalue": self.fillvalue,
-                          "data": self.data, "select": self.select}
-        return [(self.store, request), (process_kwargs, None)]
+        table = {"dtype": self.dtype.str, "fillvalue": self.fillvalue, "data": self.data, "select": self.select}
+        return [(self.store, request), (table, None)]
 
     @staticmethod
     def process(store_data, process_kwargs):

@@ -122,8 +122,9 @@ class RasterSourceBase(RasterBlock):
             result = np.full((count, 1, 1), fill, dtype=dtype)
             if 0 <= i < ny and 0 <= j < nx:
                 if isinstance(source, DeviceArray):
-                    plane = np.asarray(source)  # tiny sources only; point reads are host logic
-                    result[:, 0, 0] = plane[:, i, j]
+                    # one cell per band comes back (a source may be a 16 GiB plane resident in HBM)
+                    for band in range(count):
+                        result[band, 0, 0] = np.asarray(source.band_slice(band, band + 1).window(i, j, 1, 1))[0, 0, 0]
                 else:
                     result[:, 0, 0] = source[:, i, j]
             return {"values": result[bands[0]:bands[1]], "no_data_value": fill}

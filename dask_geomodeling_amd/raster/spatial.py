@@ -15,49 +15,59 @@ grid with nearest-neighbour or bilinear interpolation (spec in DESIGN.md).
 import numpy as np
 
 from . import resample, stencil
+from ._checks import argument, need_number
 from .base import BaseSingle
 
 __all__ = ["SpatialResample", "Dilate", "MovingMax", "HillShade", "Smooth"]
 
 
 def expand_request_pixels(request, radius=1):
-    """Expand a request by ``radius`` pixels; None for non-vals and point requests
-    (spatial.py:27-47, including its mixed use of the x / y amounts)."""
+    """The request grown by ``radius`` cells on every side; None for requests without cells to grow
+    (other modes, point requests).  Faithful to spatial.py:27-47, including its swap: the west / south
+    edges move by the x amount, the east / north edges by the y amount."""
     if request["mode"] != "vals":
         return None
-    width, height = request["width"], request["height"]
-    x1, y1, x2, y2 = request["bbox"]
-    pwidth, pheight = x2 - x1, y2 - y1
-    if pwidth == 0 or pheight == 0:
+    west, south, east, north = request["bbox"]
+    span_x, span_y = east - west, north - south
+    if span_x == 0 or span_y == 0:
         return None
-    amount_x = pwidth / width * radius
-    amount_y = pheight / height * radius
-    new_request = request.copy()
-    new_request["bbox"] = (x1 - amount_x, y1 - amount_x, x2 + amount_y, y2 + amount_y)
-    new_request["width"] += 2 * radius
-    new_request["height"] += 2 * radius
-    return new_request
+    by_x, by_y = span_x / request["width"] * radius, span_y / request["height"] * radius
+    grown = request.copy()
+    grown["bbox"] = (west - by_x, south - by_x, east + by_y, north + by_y)
+    grown["width"], grown["height"] = request["width"] + 2 * radius, request["height"] + 2 * radius
+    return grown
 
 
-class Dilate(BaseSingle):
+class _Stencil(BaseSingle):
+    """A Block that needs ``radius`` cells around every requested cell: the store is asked for the grown
+    request and ``process`` crops; requests that cannot grow pass through untouched (spatial.py:130-141)."""
+
+    def _radius(self):
+        return 1
+
+    def _process_argument(self, request):
+        raise NotImplementedError
+
+    def get_sources_and_requests(self, **request):
+        grown = expand_request_pixels(request, radius=self._radius())
+        if grown is None:
+            return [(self.store, request)]
+        return [(self.store, grown), (self._process_argument(request), None)]
+
+
+class Dilate(_Stencil):
     """Spatially dilate the cells holding one of ``values`` by one cell (spatial.py:111-155).
 
     Dilation is performed in the order of the values parameter.
     """
 
     def __init__(self, store, values):
-        values = np.asarray(values, dtype=store.dtype)
-        super().__init__(store, values.tolist())
+        super().__init__(store, np.asarray(values, dtype=store.dtype).tolist())  # (the reference's cast)
 
-    @property
-    def values(self):
-        return self.args[1]
+    values = argument(1)
 
-    def get_sources_and_requests(self, **request):
-        new_request = expand_request_pixels(request, radius=1)
-        if new_request is None:  # not an expandable request: do nothing
-            return [(self.store, request)]
-        return [(self.store, new_request), (self.values, None)]
+    def _process_argument(self, request):
+        return self.values
 
     @staticmethod
     def process(data, values=None):
@@ -66,80 +76,54 @@ class Dilate(BaseSingle):
         return {"values": stencil.dilate(data["values"], values), "no_data_value": data["no_data_value"]}
 
 
-class MovingMax(BaseSingle):
+class MovingMax(_Stencil):
     """Spatial maximum filter with a circular footprint of diameter ``size`` (spatial.py:158-213)."""
 
     def __init__(self, store, size):
-        size = int(2 * round((size - 1) / 2) + 1)  # round to the nearest odd integer
-        if size < 3:
+        odd = int(2 * round((size - 1) / 2) + 1)  # the nearest odd integer
+        if odd < 3:
             raise ValueError("The size should be odd and larger than 1")
-        super(MovingMax, self).__init__(store, size)
+        super().__init__(store, odd)
 
-    @property
-    def size(self):
-        return self.args[1]
+    size = argument(1)
 
-    def get_sources_and_requests(self, **request):
-        size = self.size
-        new_request = expand_request_pixels(request, radius=int(size // 2))
-        if new_request is None:  # not an expandable request: do nothing
-            return [(self.store, request)]
-        return [(self.store, new_request), (size, None)]
+    def _radius(self):
+        return int(self.size // 2)
+
+    def _process_argument(self, request):
+        return self.size
 
     @staticmethod
     def process(data, size=None):
         if data is None or size is None or "values" not in data:
             return data
-        return {"values": stencil.moving_max(data["values"], data["no_data_value"], size),
-                "no_data_value": data["no_data_value"]}
+        ndv = data["no_data_value"]
+        return {"values": stencil.moving_max(data["values"], ndv, size), "no_data_value": ndv}
 
 
-class HillShade(BaseSingle):
+class HillShade(_Stencil):
     """Hillshade of an elevation raster (spatial.py:320-440): uint8, 'no data' value 256 on purpose."""
 
     def __init__(self, store, altitude=45, azimuth=315, fill=0):
-        for x in (altitude, azimuth, fill):
-            if not isinstance(x, (int, float)):
-                raise TypeError("'{}' object is not allowed".format(type(x)))
-        super(HillShade, self).__init__(store, float(altitude), float(azimuth), fill)
+        need_number(altitude, azimuth, fill)
+        super().__init__(store, float(altitude), float(azimuth), fill)
 
-    @property
-    def altitude(self):
-        return self.args[1]
+    altitude, azimuth, fill = argument(1), argument(2), argument(3)
+    dtype = property(lambda self: np.dtype("u1"))
+    fillvalue = property(lambda self: 256)  # deliberately outside uint8: a shade is never "no data"
 
-    @property
-    def azimuth(self):
-        return self.args[2]
-
-    @property
-    def fill(self):
-        return self.args[3]
-
-    @property
-    def dtype(self):
-        return np.dtype("u1")
-
-    @property
-    def fillvalue(self):
-        return 256  # on purpose, it does not exist in bytes
-
-    def get_sources_and_requests(self, **request):
-        new_request = expand_request_pixels(request, radius=1)
-        if new_request is None:  # not an expandable request: do nothing
-            return [(self.store, request)]
-        bbox = request["bbox"]
-        resolution = ((bbox[2] - bbox[0]) / request["width"], (bbox[3] - bbox[1]) / request["height"])
-        process_kwargs = dict(resolution=resolution, altitude=self.altitude, azimuth=self.azimuth, fill=self.fill)
-        return [(self.store, new_request), (process_kwargs, None)]
+    def _process_argument(self, request):
+        west, south, east, north = request["bbox"]
+        cell = ((east - west) / request["width"], (north - south) / request["height"])
+        return dict(resolution=cell, altitude=self.altitude, azimuth=self.azimuth, fill=self.fill)
 
     @staticmethod
     def process(data, process_kwargs=None):
         if process_kwargs is None:
             return data
-        values = stencil.hillshade(data["values"], data["no_data_value"], process_kwargs["fill"],
-                                   process_kwargs["resolution"], process_kwargs["altitude"],
-                                   process_kwargs["azimuth"])
-        return {"values": values, "no_data_value": 256}
+        shade = stencil.hillshade(data["values"], data["no_data_value"], process_kwargs["fill"],
+                                  process_kwargs["resolution"], process_kwargs["altitude"], process_kwargs["azimuth"])
+        return {"values": shade, "no_data_value": 256}
 
 
 class SpatialResample(BaseSingle):
@@ -213,13 +197,10 @@ class Smooth(BaseSingle):
     MARGIN_THRESHOLD = 6
 
     def __init__(self, store, size, fill=0):
-        for x in (size, fill):
-            if not isinstance(x, (int, float)):
-                raise TypeError("'{}' object is not allowed".format(type(x)))
-        super(Smooth, self).__init__(store, size, fill)
+        need_number(size, fill)
+        super().__init__(store, size, fill)
 
-    size = property(lambda self: self.args[1])
-    fill = property(lambda self: self.args[2])
+    size, fill = argument(1), argument(2)
 
     def _margins(self, request):
         """(enlarged request, radius in pixels (y, x)) -- expand_request_meters, spatial.py:50-108."""

@@ -12,39 +12,38 @@ __all__ = ["get_dtype_max", "get_dtype_min", "get_int_dtype", "get_uint_dtype", 
            "Extent", "snap_start_stop", "dt_to_ms", "get_epsg_or_wkt", "parse_epsg"]
 
 
+def _limits(dtype):
+    dtype = np.dtype(dtype)
+    return np.finfo(dtype) if dtype.kind == "f" else np.iinfo(dtype)
+
+
 def get_dtype_max(dtype):
-    """Largest value of a dtype as a python scalar (utils.py:67-76)."""
-    d = np.dtype(dtype)
-    if d.kind == "f":
-        return np.finfo(d).max.item()
-    return np.iinfo(d).max
+    """Largest value of a dtype as a python scalar (utils.py:67-76): float for float dtypes, int otherwise."""
+    top = _limits(dtype).max
+    return top.item() if hasattr(top, "item") else top
 
 
 def get_dtype_min(dtype):
     """Smallest value of a dtype as a python scalar (utils.py:79-88)."""
-    d = np.dtype(dtype)
-    if d.kind == "f":
-        return np.finfo(d).min.item()
-    return np.iinfo(d).min
+    bottom = _limits(dtype).min
+    return bottom.item() if hasattr(bottom, "item") else bottom
+
+
+def _narrowest(codes, fits, kind, n):
+    for code in codes:
+        if fits(np.iinfo(code)):
+            return np.dtype(code)
+    raise ValueError("Value does not fit in {} dtype ({})".format(kind, n))
 
 
 def get_int_dtype(n):
-    """Smallest signed dtype holding ``n`` plus a spare no-data code (utils.py:91-97)."""
-    for code in ("i1", "i2", "i4", "i8"):
-        info = np.iinfo(code)
-        if n - 1 <= info.max and n >= info.min:
-            return np.dtype(code)
-    raise ValueError("Value does not fit in int dtype ({})".format(n))
+    """Smallest signed dtype holding ``n`` with its maximum left over as a no-data code (utils.py:91-97)."""
+    return _narrowest(("i1", "i2", "i4", "i8"), lambda info: info.min <= n and n - 1 <= info.max, "int", n)
 
 
 def get_uint_dtype(n):
-    """Smallest unsigned dtype holding ``n`` plus a spare no-data code (utils.py:100-108)."""
-    if n < 0:
-        raise ValueError("Value does not fit in uint dtype ({})".format(n))
-    for code in ("u1", "u2", "u4", "u8"):
-        if n - 1 <= np.iinfo(code).max:
-            return np.dtype(code)
-    raise ValueError("Value does not fit in uint dtype ({})".format(n))
+    """Smallest unsigned dtype holding ``n`` with its maximum left over as a no-data code (utils.py:100-108)."""
+    return _narrowest(("u1", "u2", "u4", "u8") if n >= 0 else (), lambda info: n - 1 <= info.max, "uint", n)
 
 
 def get_rounded_repr(obj, significant=4, fmt="{} (rounded)"):
@@ -150,7 +149,8 @@ class BoxGeometry(object):
 
 
 class GeoTransform(tuple):
-    """GDAL-style affine (p, a, b, q, c, d):  x = p + a*j + b*i ;  y = q + c*j + d*i."""
+    """GDAL-style affine (p, a, b, q, c, d):  x = p + a*j + b*i ;  y = q + c*j + d*i  for the cell in row i,
+    column j.  North-up grids only: b = c = 0 (utils.py:208-393)."""
 
     def __new__(cls, tpl):
         return super().__new__(cls, tuple(tpl))
@@ -158,70 +158,64 @@ class GeoTransform(tuple):
     def __init__(self, tpl):
         if len(self) != 6:
             raise ValueError("GeoTransform expected an iterable of length 6")
-        if not all(math.isclose(self[i], 0.0, abs_tol=1e-7) for i in (2, 4)):
+        near_zero = [math.isclose(term, 0.0, abs_tol=1e-7) for term in self]
+        if not (near_zero[2] and near_zero[4]):
             raise ValueError("Tilted geo_transforms are not supported")
-        if any(math.isclose(self[i], 0.0, abs_tol=1e-7) for i in (1, 5)):
+        if near_zero[1] or near_zero[5]:
             raise ValueError("Pixel size should not be zero")
 
     @classmethod
     def from_bbox(cls, bbox, height, width):
-        x1, y1, x2, y2 = bbox
-        return cls((x1, (x2 - x1) / width, 0, y2, 0, (y1 - y2) / height))
+        west, south, east, north = bbox
+        return cls((west, (east - west) / width, 0, north, 0, (south - north) / height))
 
     def __repr__(self):
         return get_rounded_repr(tuple(self))
 
+    def _terms(self):
+        return tuple.__iter__(self)
+
     @property
     def cell_area(self):
-        _, a, b, _, c, d = self
+        _, a, b, _, c, d = self._terms()
         return abs(a * d - b * c)
 
-    @property
-    def origin(self):
-        return self[0], self[3]
-
-    @property
-    def origin_normalized(self):
-        return self[0] % self[1], self[3] % self[5]
+    origin = property(lambda self: (self[0], self[3]))
+    origin_normalized = property(lambda self: (self[0] % self[1], self[3] % self[5]))
 
     def get_inverse(self):
-        _, a, b, _, c, d = self
-        D = 1 / (a * d - b * c)
-        return d * D, -b * D, -c * D, a * D
+        """The 2 x 2 part inverted: (e, f, g, h) with  j = e dx + f dy,  i = g dx + h dy."""
+        _, a, b, _, c, d = self._terms()
+        det = 1 / (a * d - b * c)
+        return d * det, -b * det, -c * det, a * det
 
     def scale(self, x, y):
-        p, a, b, q, c, d = self
-        return self.__class__([p, a * x, b * x, q, c * y, d * y])
+        p, a, b, q, c, d = self._terms()
+        return type(self)([p, a * x, b * x, q, c * y, d * y])
 
     def shift(self, origin):
-        p, a, b, q, c, d = self
-        i, j = origin
-        return self.__class__([p + a * j + b * i, a, b, q + c * j + d * i, c, d])
+        row, col = origin
+        p, a, b, q, c, d = self._terms()
+        return type(self)([p + a * col + b * row, a, b, q + c * col + d * row, c, d])
 
     def get_indices(self, points):
         """(row indices, column indices) of world points, by floor()."""
-        p, _, _, q, _, _ = self
         e, f, g, h = self.get_inverse()
-        x, y = np.asarray(points).transpose()
-        return (np.floor(g * (x - p) + h * (y - q)).astype(np.int64),
-                np.floor(e * (x - p) + f * (y - q)).astype(np.int64))
+        xs, ys = np.asarray(points).transpose()
+        dx, dy = xs - self[0], ys - self[3]
+        return np.floor(g * dx + h * dy).astype(np.int64), np.floor(e * dx + f * dy).astype(np.int64)
 
     def get_bbox(self, offset, shape):
-        p, a, b, q, c, d = self
-        i, j = offset
-        m, n = shape
-        west = p + a * j + b * i
-        north = q + c * j + d * i
-        east = west + a * n + b * m
-        south = north + c * n + d * m
-        return west, south, east, north
+        """(west, south, east, north) of the ``shape`` = (rows, columns) cells from row / column ``offset`` on."""
+        p, a, b, q, c, d = self._terms()
+        (row, col), (rows, cols) = offset, shape
+        west, north = p + a * col + b * row, q + c * col + d * row
+        return west, north + c * cols + d * rows, west + a * cols + b * rows, north
 
     def aligns_with(self, other):
-        if not isinstance(other, GeoTransform):
-            other = GeoTransform(other)
-        if abs(self[1]) != abs(other[1]) or abs(self[5]) != abs(other[5]):
-            return False
-        return self.origin_normalized == other.origin_normalized
+        other = other if isinstance(other, GeoTransform) else GeoTransform(other)
+        same_cells = abs(self[1]) == abs(other[1]) and abs(self[5]) == abs(other[5])
+        return same_cells and self.origin_normalized == other.origin_normalized
 
 
 def dt_to_ms(dt):

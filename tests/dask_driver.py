@@ -51,7 +51,7 @@ def main():
     for seed in range(60):
         view = random_view(np.random.default_rng(90_000 + seed), "d%d" % seed)
         with np.errstate(all="ignore"):
-            views.append((describe(view), view, REQ, unsigned_zero(oracle_eval(view))))
+            views.append((describe(view), view, REQ, unsigned_zero(oracle_eval(view), view)))
     def uses(expr, name):
         return isinstance(expr, list) and (expr[0] == name or any(uses(x, name) for x in expr[1:]))
 
@@ -76,7 +76,7 @@ def main():
                     skipped += 1  # stand-alone kernels need the device
                     continue
                 ulp = tolerance.get(what, 0)
-                assert_result_equal(unsigned_zero(got), unsigned_zero(want), ulp, "%s under %s" % (what, name))
+                assert_result_equal(unsigned_zero(got, view), unsigned_zero(want, view), ulp, "%s under %s" % (what, name))
                 checked += 1
             # structurally identical views evaluated together: one BatchedTask (what a RasterTiler's tiles
             # become) travels through dask as well

@@ -19,11 +19,11 @@ for seed in range(N):
         if memory:
             whole = view.get_data(**REQ)
             tiled = raster.RasterTiler(view, [int(rng.integers(5, 30)), int(rng.integers(5, 20))]).get_data(**REQ)
-            assert_result_equal(unsigned_zero(tiled), unsigned_zero(whole), 0, "tiled")
+            assert_result_equal(unsigned_zero(tiled, view), unsigned_zero(whole, view), 0, "tiled")
         else:
             with np.errstate(all="ignore"):
-                want = unsigned_zero(oracle_eval(view))
-            assert_result_equal(unsigned_zero(view.get_data(**REQ)), want, 0, "fused")
+                want = unsigned_zero(oracle_eval(view), view)
+            assert_result_equal(unsigned_zero(view.get_data(**REQ), view), want, 0, "fused")
     except NotImplementedError:
         skipped += 1
     except Exception as e:  # noqa

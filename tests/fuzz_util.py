@@ -158,8 +158,19 @@ def describe(block, depth=0):
     return "%s(%s)" % (type(block).__name__, ", ".join(describe(a, depth + 1) for a in block.args))
 
 
-def unsigned_zero(result):
-    """-0.0 -> +0.0: the sign of a zero that wins a Max tie is NumPy-build dependent (np.fmax)."""
+def contains(block, name):
+    """Does the Block tree contain a Block of class ``name``?"""
+    if not isinstance(block, raster.RasterBlock):
+        return False
+    return type(block).__name__ == name or any(contains(a, name) for a in block.args)
+
+
+def unsigned_zero(result, view=None):
+    """-0.0 -> +0.0: the sign of a zero that wins a Max tie is NumPy-build dependent (np.fmax).  With ``view``
+    given the normalisation is applied only when the view contains a ``Max``; every other view is compared
+    with its zeros signed."""
+    if view is not None and not contains(view, "Max"):
+        return result
     if isinstance(result, dict) and "values" in result and np.asarray(result["values"]).dtype.kind == "f":
         result = dict(result)
         result["values"] = np.asarray(result["values"]) + 0.0

@@ -25,7 +25,7 @@ def test_random_views_fused_vs_oracle(cpu_vm, monkeypatch, seed):
         if "no HIP device" not in str(e):
             raise
         pytest.skip("this view needs a stand-alone kernel (covered by the GPU fuzz test)")
-    assert_result_equal(unsigned_zero(got), unsigned_zero(want), 0, describe(view))
+    assert_result_equal(unsigned_zero(got, view), unsigned_zero(want, view), 0, describe(view))
 
 
 @pytest.mark.parametrize("seed", range(40))

@@ -16,14 +16,14 @@ def test_random_views_on_device(gpu, seed):
     rng = np.random.default_rng(10_000 + seed)
     view = random_view(rng, "g%d" % seed)
     with np.errstate(all="ignore"):
-        want = unsigned_zero(oracle_eval(view))
+        want = unsigned_zero(oracle_eval(view), view)
     try:
         got = view.get_data(**REQ)
     except NotImplementedError as e:
         pytest.skip("not on the device path: %s" % e)
-    assert_result_equal(unsigned_zero(got), want, 0, describe(view))
+    assert_result_equal(unsigned_zero(got, view), want, 0, describe(view))
     with gmconfig.config.set({"geomodeling.fuse": False}):
-        assert_result_equal(unsigned_zero(view.get_data(**REQ)), want, 0, "unfused " + describe(view))
+        assert_result_equal(unsigned_zero(view.get_data(**REQ), view), want, 0, "unfused " + describe(view))
 
 
 def test_random_views_evaluated_together(gpu):
@@ -37,10 +37,10 @@ def test_random_views_evaluated_together(gpu):
         except NotImplementedError:
             continue
         with np.errstate(all="ignore"):
-            wants.append(unsigned_zero(oracle_eval(view)))
+            wants.append(unsigned_zero(oracle_eval(view), view))
         views.append(view)
     for got, want, view in zip(get_data_many(views, REQ), wants, views):
-        assert_result_equal(unsigned_zero(got), want, 0, describe(view))
+        assert_result_equal(unsigned_zero(got, view), want, 0, describe(view))
 
 
 @pytest.mark.parametrize("seed", range(60))
@@ -56,4 +56,4 @@ def test_random_views_tiled_equals_untiled(gpu, seed):
         pytest.skip("not on the device path: %s" % e)
     for tile in ([8, 8], [16, 12], 17):
         tiled = raster.RasterTiler(view, tile).get_data(**REQ)
-        assert_result_equal(unsigned_zero(tiled), unsigned_zero(whole), 0, "tile %s of %s" % (tile, describe(view)))
+        assert_result_equal(unsigned_zero(tiled, view), unsigned_zero(whole, view), 0, "tile %s of %s" % (tile, describe(view)))

@@ -29,7 +29,7 @@ def test_plan_reused_across_bounding_boxes(gpu, seed):
         except NotImplementedError as e:
             pytest.skip("not on the device path: %s" % e)
         got = view.get_data(**req)
-        assert_result_equal(unsigned_zero(got), unsigned_zero(want), 0, "bbox %d of %s" % (k, describe(view)))
+        assert_result_equal(unsigned_zero(got, view), unsigned_zero(want, view), 0, "bbox %d of %s" % (k, describe(view)))
     assert len(view.__dict__.get("_gm_plans", {})) <= 1  # one request shape -> at most one plan
 
 
@@ -79,4 +79,4 @@ def test_tiler_through_plans_equals_untiled(gpu, seed):
         pytest.skip("not on the device path: %s" % e)
     for tile in ([8, 8], [16, 12], 17):
         tiled = raster.RasterTiler(view, tile).get_data(**REQ)
-        assert_result_equal(unsigned_zero(tiled), unsigned_zero(whole), 0, "tile %s of %s" % (tile, describe(view)))
+        assert_result_equal(unsigned_zero(tiled, view), unsigned_zero(whole, view), 0, "tile %s of %s" % (tile, describe(view)))
