@@ -451,10 +451,13 @@ def main():
                 get_sync(graph, names)  # result DeviceArrays are dropped -> buffers return to the pool
 
     # W untimed warm-up steps -- and, when those are shorter than that, keep stepping until the GPU
-    # has been busy for 50 ms, so that the clocks have left their idle state before the timed region
-    # (hot programs also get their specialised kernels here: csrc/gm_spec.hip)
-    t_warm, done = time.perf_counter(), 0
-    while done < args.warmup or (not args.dry_run and time.perf_counter() - t_warm < 0.05):
+    # has been busy for 200 ms, so that the clocks have left their idle state before the timed region
+    # (a 20-step timed region is only ~10 ms long; hot programs also get their specialised kernels here:
+    # csrc/gm_spec.hip, ~1 s of compilation on the first step that finds a program hot)
+    t_warm, done, t_busy = time.perf_counter(), 0, None
+    while done < args.warmup or (not args.dry_run and (t_busy is None or time.perf_counter() - t_busy < 0.2)):
+        if t_busy is None and done >= 1:
+            t_busy = time.perf_counter()  # the first step may have compiled: the busy period starts after it
         step()
         done += 1
         if done % 8 == 0:

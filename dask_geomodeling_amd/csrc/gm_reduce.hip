@@ -224,6 +224,70 @@ __global__ __launch_bounds__(WG) void reduce_sorted_kernel(const C* __restrict__
   __builtin_nontemporal_store(r, out + p);
 }
 
+// Up to 16 rasters -- the usual stack -- sort in registers (Batcher's odd-even merge network, NaN frames entering as
+// +inf behind the data) instead of LDS; the element of the rank a cell needs is picked with a select chain.
+template <typename C, int N>
+__device__ __forceinline__ void sort_network(C (&v)[N]) {
+#pragma unroll
+  for (int p = 1; p < N; p *= 2) {
+#pragma unroll
+    for (int k = p; k >= 1; k /= 2) {
+#pragma unroll
+      for (int j = k % p; j <= N - 1 - k; j += 2 * k) {
+#pragma unroll
+        for (int i = 0; i <= k - 1; ++i) {
+          if (i + j + k <= N - 1 && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+            const C lo = v[i + j] < v[i + j + k] ? v[i + j] : v[i + j + k];
+            const C hi = v[i + j] < v[i + j + k] ? v[i + j + k] : v[i + j];
+            v[i + j] = lo;
+            v[i + j + k] = hi;
+          }
+        }
+      }
+    }
+  }
+}
+template <typename C, int N>
+__device__ __forceinline__ C pick(const C (&v)[N], int index) {
+  C r = v[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) r = index == i ? v[i] : r;
+  return r;
+}
+
+template <typename C, bool HALF, bool PERCENTILE, int N>
+__global__ __launch_bounds__(256) void reduce_sorted_small_kernel(const C* __restrict__ stack, int n, long long pixels,
+                                                                  SortPlan P, C* __restrict__ out, C fill) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= pixels) return;
+  const C* src = stack + p;
+  C v[N];
+  int m = 0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const C x = __builtin_nontemporal_load(src + (long long)(j < n ? j : 0) * pixels);
+    const bool nd = j >= n || x != x;
+    v[j] = nd ? std::numeric_limits<C>::infinity() : x;
+    m += nd ? 0 : 1;
+  }
+  sort_network<C, N>(v);
+  C r = fill;
+  if (m > 0) {
+    if constexpr (PERCENTILE) {
+      const C a = pick<C, N>(v, P.lower[m - 1]), b = pick<C, N>(v, P.upper[m - 1]);
+      const C t = (C)P.gamma[m - 1], u = (C)P.one_minus_gamma[m - 1];
+      const C d = rnd<HALF, C>(b - a);
+      r = (t >= (C)0.5) ? rnd<HALF, C>(b - rnd<HALF, C>(d * u)) : rnd<HALF, C>(a + rnd<HALF, C>(d * t));
+    } else {
+      const int h = m / 2;
+      const C high = pick<C, N>(v, h);
+      const C low = (m & 1) ? high : pick<C, N>(v, h - 1);
+      r = rnd<HALF, C>(rnd<HALF, C>(low + high) / (C)2);
+    }
+  }
+  __builtin_nontemporal_store(r, out + p);
+}
+
 template <typename C>
 C fill_of(uint64_t bits) {
   gm_scalar s;
@@ -259,6 +323,17 @@ int launch_reduce(const void* stack, int n, long long pixels, int statistic, con
         P.gamma[i] = plan[i].gamma;
         P.one_minus_gamma[i] = plan[i].one_minus_gamma;
       }
+    }
+    if (n <= 16) {  // the usual stack: sorted in registers
+      const unsigned gxs = (unsigned)((pixels + 255) / 256);
+#define GM_SORTED_SMALL(PCT, N_)                                                                                   \
+  hipLaunchKernelGGL((reduce_sorted_small_kernel<C, HALF, PCT, N_>), dim3(gxs), dim3(256), 0, s, (const C*)stack, n, \
+                     pixels, P, (C*)out, fill)
+      if (n <= 4) { if (percentile) GM_SORTED_SMALL(true, 4); else GM_SORTED_SMALL(false, 4); }
+      else if (n <= 8) { if (percentile) GM_SORTED_SMALL(true, 8); else GM_SORTED_SMALL(false, 8); }
+      else { if (percentile) GM_SORTED_SMALL(true, 16); else GM_SORTED_SMALL(false, 16); }
+#undef GM_SORTED_SMALL
+      return GM_OK;
     }
     const int WG = long_stack ? 64 : 256;
     const unsigned gx = (unsigned)((pixels + WG - 1) / WG);

@@ -1,4 +1,3 @@
 #!/bin/bash
-mkdir -p gpurun_out/prof_r02_mosaic
-python bench.py --workload mosaic --steps 5 --warmup 2 2>gpurun_out/mosaic.err | tee gpurun_out/prof_r02_mosaic/bench.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['frac'], d['roofline']['traffic'], json.dumps(d.get('end_to_end')))"
-tail -2 gpurun_out/mosaic.err
+python -m pytest tests/test_gpu_parity.py -x -q -k "temporal or reduce or cumulative or group" 2>&1 | grep -E "^E  |passed|failed" | head
+python tools/kbench.py temporal 2>&1 | grep -E "median|mean"
