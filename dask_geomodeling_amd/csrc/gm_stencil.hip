@@ -245,70 +245,97 @@ __global__ __launch_bounds__(256) void dilate8_kernel(const unsigned char* __res
   }
 }
 
-// The same word-parallel scheme for single-band tiles, fed from an LDS tile: a workgroup stages the
-// 18 rows x 1032 bytes its 16 x 1024 outputs see (as unaligned 4-byte loads, all of a lane in flight),
-// a lane then walks 16 rows of its 4 columns reading two aligned words per row from LDS.
-constexpr int D8T_H = 16, D8T_WORDS = 258;  // window: (D8T_H + 2) rows of 258 words (1032 bytes)
-__global__ __launch_bounds__(256) void dilate8_tile_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+// Single-band tiles, eight pixels per lane from an LDS tile: a workgroup stages the 18 rows x 2064 bytes its
+// 16 x 2048 outputs see.  The byte compare is the expensive part of the word-parallel scheme (~8 integer
+// operations per word and value, three words per output word above).  Here a lane owns 8
+// consecutive output columns = input bytes [8 l, 8 l + 10) = three aligned LDS words; "byte == value" is
+// computed ONCE per input word as a flag (0x80 in equal bytes: 5 operations) and the west / centre / east
+// views of an output word are byte shifts of those flags (v_alignbyte); the flags are OR-ed as they are and
+// widened to byte masks once per output word.  ~4 integer operations per pixel and value instead of ~7,
+// 8-byte stores, 16-byte staging loads (unaligned when the row pitch is: a load that runs past the end of
+// its row reads the start of the next one, which feeds no output; only the end of the tile is guarded).
+__device__ __forceinline__ unsigned equal_flags(unsigned x, unsigned splat) {
+  const unsigned t = x ^ splat;                                // zero byte <=> equal
+  const unsigned nz = ((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t;   // bit 7 of a byte set <=> byte != 0
+  return ~nz & 0x80808080u;                                    // 0x80 in equal bytes
+}
+constexpr int D8W_H = 16, D8W_COLS = 2048, D8W_PITCH = 516;  // window: (D8W_H + 2) rows of 516 words (2064 bytes)
+__global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
                                                            int h, int w, Dilate8Args A) {
-  __shared__ unsigned tile[(D8T_H + 2) * D8T_WORDS];
-  const int c0 = blockIdx.x * 1024, r0 = blockIdx.y * D8T_H;
+  __shared__ __align__(16) unsigned tile[(D8W_H + 2) * D8W_PITCH];
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int c0 = blockIdx.x * D8W_COLS, r0 = blockIdx.y * D8W_H;
   const int ow = w - 2, oh = h - 2;
-  constexpr int CELLS = (D8T_H + 2) * D8T_WORDS, PER_LANE = (CELLS + 255) / 256;
-  unsigned staged[PER_LANE];
+  const size_t left = (size_t)h * w;
+  constexpr int QUADS = D8W_PITCH / 4, CELLS = (D8W_H + 2) * QUADS, PER_LANE = (CELLS + 255) / 256;
+  u32x4 staged[PER_LANE];
 #pragma unroll
   for (int i = 0; i < PER_LANE; ++i) {
     const int cell = threadIdx.x + 256 * i;
-    const int wy = min(cell / D8T_WORDS, D8T_H + 1), wd = cell - (cell / D8T_WORDS) * D8T_WORDS;
-    const int sy = min(r0 + wy, h - 1), sx = c0 + 4 * wd;
-    const unsigned char* p = in + (size_t)sy * w + sx;
-    unsigned word = 0;
-    if (sx + 4 <= w) {
-      __builtin_memcpy(&word, p, 4);
-    } else {
-      for (int j = 0; j < 4; ++j)
-        if (sx + j < w) word |= (unsigned)p[j] << (8 * j);
+    const int wy = min(cell / QUADS, D8W_H + 1), q = cell - (cell / QUADS) * QUADS;
+    const int sy = min(r0 + wy, h - 1), sx = c0 + 16 * q;
+    const size_t at = (size_t)sy * w + sx;
+    u32x4 x = {0u, 0u, 0u, 0u};
+    if (sx < w) {
+      if (at + 16 <= left) {
+        __builtin_memcpy(&x, in + at, 16);
+      } else {
+        unsigned char tail[16] = {0};
+        for (int j = 0; at + j < left; ++j) tail[j] = in[at + j];
+        __builtin_memcpy(&x, tail, 16);
+      }
     }
-    staged[i] = word;
+    staged[i] = x;
   }
 #pragma unroll
   for (int i = 0; i < PER_LANE; ++i) {
     const int cell = threadIdx.x + 256 * i;
-    if (cell < CELLS) tile[cell] = staged[i];
+    if (cell < CELLS) *(u32x4*)(tile + 4 * cell) = staged[i];
   }
   __syncthreads();
-  const int c4 = c0 + 4 * threadIdx.x;
-  if (c4 >= ow) return;
-  unsigned horiz_prev[DIL8_MAX_VALUES], eq_prev[DIL8_MAX_VALUES], eq_prev2[DIL8_MAX_VALUES];
+  const int c8 = c0 + 8 * threadIdx.x;
+  if (c8 >= ow) return;
+  unsigned horiz_prev[DIL8_MAX_VALUES][2], eq_prev[DIL8_MAX_VALUES][2], eq_prev2[DIL8_MAX_VALUES][2];
 #pragma unroll
-  for (int k = 0; k < DIL8_MAX_VALUES; ++k) horiz_prev[k] = eq_prev[k] = eq_prev2[k] = 0;
-  unsigned centre_prev = 0;
+  for (int k = 0; k < DIL8_MAX_VALUES; ++k)
 #pragma unroll
-  for (int y = 0; y < D8T_H + 2; ++y) {
-    const unsigned lo = tile[y * D8T_WORDS + threadIdx.x], hi = tile[y * D8T_WORDS + threadIdx.x + 1];
-    const unsigned west = lo, centre = __builtin_amdgcn_alignbyte(hi, lo, 1), east = __builtin_amdgcn_alignbyte(hi, lo, 2);
-    unsigned result = centre_prev;
+    for (int j = 0; j < 2; ++j) horiz_prev[k][j] = eq_prev[k][j] = eq_prev2[k][j] = 0;
+  unsigned centre_prev[2] = {0u, 0u};
+#pragma unroll
+  for (int y = 0; y < D8W_H + 2; ++y) {
+    const unsigned* row = tile + y * D8W_PITCH + 2 * threadIdx.x;
+    const unsigned w0 = row[0], w1 = row[1], w2 = row[2];
+    const unsigned centre[2] = {__builtin_amdgcn_alignbyte(w1, w0, 1), __builtin_amdgcn_alignbyte(w2, w1, 1)};
+    unsigned result[2] = {centre_prev[0], centre_prev[1]};
 #pragma unroll
     for (int k = 0; k < DIL8_MAX_VALUES; ++k) {
       if (k < A.n_values) {
         const unsigned v = A.splat[k];
-        const unsigned eq = bytes_equal(centre, v);
-        const unsigned horiz = eq | bytes_equal(west, v) | bytes_equal(east, v);
-        const unsigned hit = horiz_prev[k] | eq_prev2[k] | eq;  // centre row y - 1: its own row, the rows above and below
-        result = (result & ~hit) | (v & hit);
-        eq_prev2[k] = eq_prev[k];
-        eq_prev[k] = eq;
-        horiz_prev[k] = horiz;
+        const unsigned f0 = equal_flags(w0, v), f1 = equal_flags(w1, v), f2 = equal_flags(w2, v);
+        const unsigned eq[2] = {__builtin_amdgcn_alignbyte(f1, f0, 1), __builtin_amdgcn_alignbyte(f2, f1, 1)};
+        const unsigned east[2] = {__builtin_amdgcn_alignbyte(f1, f0, 2), __builtin_amdgcn_alignbyte(f2, f1, 2)};
+        const unsigned west[2] = {f0, f1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const unsigned horiz = eq[j] | west[j] | east[j];
+          const unsigned hit = horiz_prev[k][j] | eq_prev2[k][j] | eq[j];  // centre row y - 1: its row, the rows above / below
+          const unsigned mask = hit | (hit - (hit >> 7));                  // 0x80 flags -> 0xFF bytes
+          result[j] = (result[j] & ~mask) | (v & mask);                    // in order: later values overwrite earlier ones
+          eq_prev2[k][j] = eq_prev[k][j];
+          eq_prev[k][j] = eq[j];
+          horiz_prev[k][j] = horiz;
+        }
       }
     }
-    centre_prev = centre;
+    centre_prev[0] = centre[0];
+    centre_prev[1] = centre[1];
     const int orow = r0 + y - 2;
     if (y >= 2 && orow < oh) {
-      unsigned char* o = out + (size_t)orow * ow + c4;
-      if (c4 + 4 <= ow) {
-        __builtin_memcpy(o, &result, 4);
+      unsigned char* o = out + (size_t)orow * ow + c8;
+      if (c8 + 8 <= ow) {
+        __builtin_memcpy(o, result, 8);
       } else {
-        for (int j = 0; c4 + j < ow; ++j) o[j] = (unsigned char)(result >> (8 * j));
+        for (int j = 0; c8 + j < ow; ++j) o[j] = (unsigned char)(result[j >> 2] >> (8 * (j & 3)));
       }
     }
   }
@@ -894,9 +921,10 @@ int gm_dilate(const void* in, int dtype, int bands, int h, int w, const uint64_t
     Dilate8Args A8;
     A8.n_values = n_values;
     for (int i = 0; i < DIL8_MAX_VALUES; ++i) A8.splat[i] = i < n_values ? 0x01010101u * (unsigned)(values_bits[i] & 0xffu) : 0u;
-    if (bands == 1 && (h - 2 + D8T_H - 1) / D8T_H <= 65535) {
-      dim3 tgrid8((unsigned)((w - 2 + 1023) / 1024), (unsigned)((h - 2 + D8T_H - 1) / D8T_H));
-      hipLaunchKernelGGL(dilate8_tile_kernel, tgrid8, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, h, w, A8);
+    // (one band: with several, the cells of the neighbouring bands count too -- the row kernel below)
+    if (bands == 1 && w >= 64 && (h - 2 + D8W_H - 1) / D8W_H <= 65535) {
+      dim3 wgrid((unsigned)((w - 2 + D8W_COLS - 1) / D8W_COLS), (unsigned)((h - 2 + D8W_H - 1) / D8W_H));
+      hipLaunchKernelGGL(dilate8_wide_kernel, wgrid, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, h, w, A8);
       GM_HIP(hipGetLastError());
       return GM_OK;
     }

@@ -938,9 +938,10 @@ def test_temporal_kernels_against_oracle(gpu, dtype, ndv, shape_yx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["u1", "i1", "?"])
-@pytest.mark.parametrize("shape", [(1, 40, 70), (3, 19, 23), (2, 130, 1031), (1, 11, 6)])
+@pytest.mark.parametrize("shape", [(1, 40, 70), (3, 19, 23), (2, 130, 1031), (1, 11, 6), (1, 21, 64), (2, 35, 2064),
+                                   (1, 50, 4115), (3, 3, 66), (1, 18, 2050), (1, 19, 2051)])
 def test_dilate_one_byte_tiles(gpu, dtype, shape):
-    """The 4-pixels-per-lane word kernel of 1-byte tiles (ragged widths, several bands, 1..4 values in
+    """The word kernels of 1-byte tiles (8 pixels per lane from 64 columns on, 4 below) (ragged widths, several bands, 1..4 values in
     order, rows that end inside a lane's 8-byte window) against the oracle."""
     from dask_geomodeling_amd.raster import stencil
     rng = np.random.default_rng(hash((dtype,) + shape) % 2**32)

@@ -1,3 +1,4 @@
 #!/bin/bash
-python -m pytest tests/test_gpu_parity.py -x -q -k "temporal or reduce or cumulative or group" 2>&1 | grep -E "^E  |passed|failed" | head
-python tools/kbench.py temporal 2>&1 | grep -E "median|mean"
+python -m pytest tests/test_gpu_parity.py -x -q -k "dilate or stencil" 2>&1 | tail -3
+python tests/stencil_stress.py 2>&1 | tail -2
+python tools/kbench.py stencil 2>&1 | grep -i dilate

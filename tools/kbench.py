@@ -97,6 +97,9 @@ def main():
                    [lambda t=t: stencil.moving_max(t, np.float32(F32MAX), size) for t in src])
         u8 = [generate_window((side, side), "u1", 95 + i, 0.0, 6.0, 255, (50, 50), 0, 0, side, side) for i in range(T)]
         timeit("dilate u8, 2 values (2 B/px)", 2.0 * m, [lambda t=t: stencil.dilate(t, [1, 3]) for t in u8])
+        u8m = [generate_window((side + 2, side + 2), "u1", 95 + i, 0.0, 6.0, 255, (50, 50), 0, 0, side + 2, side + 2) for i in range(T)]
+        timeit("dilate u8 with margin (%d wide), 2 values (2 B/px)" % (side + 2), 2.0 * n, [lambda t=t: stencil.dilate(t, [1, 3]) for t in u8m])
+        del u8m
         timeit("dilate f32, 2 values (8 B/px)", 8.0 * m, [lambda t=t: stencil.dilate(t, [1.0, 3.0]) for t in src])
         for size_px in (3.0, 6.0):
             timeit("smooth f32, sigma %.0f px, radius %d (2 passes, 16 B/px)" % (size_px / 3, int(4 * size_px / 3 + 0.5)), 16.0 * n,
