@@ -891,6 +891,114 @@ __global__ __launch_bounds__(256) void gauss_axis_lds_kernel(const T* __restrict
     if (oy0 + r < oh) out[((size_t)b * oh + oy0 + r) * ow + ox] = (T)acc[r];
 }
 
+// Both axes of a float32 tile in ONE launch (round 2): the two passes above move 16 bytes per pixel
+// through HBM and serve every tap from LDS as an 8-byte read (LDS-bound from radius ~6 on).  Here a
+// workgroup makes G2_TH x TW outputs, TW = 256 - 2 RCAP:
+//   y axis: a lane owns one of the TW + 2 R columns the x axis will read and walks down the rows with a
+//     register window of 8 + 2 R float64 values (8 new rows loaded per step, every row read once per
+//     workgroup): 8 outputs per step, rounded to float32 -- what the first pass stores -- into LDS;
+//   x axis: a lane owns 8 consecutive outputs of a row: 8 + 2 R floats from LDS (16-byte reads) into a
+//     register window, the same arithmetic, two 16-byte stores.
+// The operations and their order are those of the one-axis kernels (SciPy's: centre tap, then the pairs
+// from the farthest in); columns outside the tile are the x line's constant extension, not filtered values.
+constexpr int G2_TH = 32, G2_MAX_RADIUS = 16;
+struct Gauss2Args {
+  double wy[G2_MAX_RADIUS + 1], wx[G2_MAX_RADIUS + 1];  // weight at distance j along y / x
+  double cval;
+};
+template <int R, int RCAP>
+__global__ __launch_bounds__(256) void gauss2d_kernel(const float* __restrict__ in, float* __restrict__ out, int h, int w,
+                                                      int y0, int x0, int oh, int ow, int replace_ndv, float ndv, float fill,
+                                                      Gauss2Args A) {
+  constexpr int TW = 256 - 2 * RCAP, WIN = 8 + 2 * R, WIN4 = (WIN + 3) / 4;
+  __shared__ __align__(16) float mid[G2_TH * 256 + 4];
+  const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * G2_TH, b = blockIdx.z;
+  const float* plane = in + (size_t)b * h * w;
+  const int rows = min(G2_TH, oh - oy0);  // output rows of this workgroup
+  {
+    const int e = threadIdx.x;            // column of the extended tile
+    const int sx = x0 + ox0 - R + e;
+    if (e < TW + 2 * R && sx >= 0 && sx < w) {
+      const float* column = plane + sx;
+      // loads first, conversions after: written as one expression per row the compiler waits for every
+      // load before it issues the next (rows are uniform, the address arithmetic is scalar code)
+      auto load = [&](int ty) -> float { return column[(size_t)min(max(ty, 0), h - 1) * w]; };
+      auto value = [&](float v, int ty) -> double {  // what SciPy's line buffer holds for tile row ty
+        const double inside = (double)((replace_ndv && v == ndv) ? fill : v);
+        return (ty < 0 || ty >= h) ? A.cval : inside;
+      };
+      const int top = y0 + oy0 - R;  // tile row of win[0]
+      double win[WIN];
+      {
+        float raw[2 * R];
+#pragma unroll
+        for (int i = 0; i < 2 * R; ++i) raw[i] = load(top + i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2 * R; ++i) win[i] = value(raw[i], top + i);
+      }
+      float ahead[8];  // the 8 rows the next step adds, in flight while this step computes
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ahead[i] = load(top + 2 * R + i);
+      __builtin_amdgcn_sched_barrier(0);
+      for (int slab = 0; slab * 8 < rows; ++slab) {
+        const int first = top + slab * 8 + 2 * R;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) win[2 * R + i] = value(ahead[i], first + i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ahead[i] = load(first + 8 + i);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          double acc = win[r + R] * A.wy[0];
+#pragma unroll
+          for (int j = R; j >= 1; --j) acc += (win[r + R - j] + win[r + R + j]) * A.wy[j];
+          mid[(slab * 8 + r) * 256 + e] = (float)acc;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * R; ++i) win[i] = win[i + 8];
+      }
+    }
+  }
+  __syncthreads();
+  const bool at_edge = x0 + ox0 - R < 0 || x0 + ox0 + TW + R > w;  // (uniform) some columns are the constant extension
+  constexpr int SEGS = TW / 8;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  for (int item = threadIdx.x; item < rows * SEGS; item += 256) {
+    const int r = item / SEGS, seg = item - r * SEGS;
+    const int ox = ox0 + seg * 8;
+    if (ox >= ow) continue;
+    f32x4 raw[WIN4];
+    const f32x4* src = reinterpret_cast<const f32x4*>(mid + r * 256 + seg * 8);
+#pragma unroll
+    for (int i = 0; i < WIN4; ++i) raw[i] = src[i];
+    double win[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) win[i] = (double)raw[i / 4][i % 4];
+    if (at_edge) {
+      const int sx = x0 + ox - R;  // tile column of win[0]
+#pragma unroll
+      for (int i = 0; i < WIN; ++i)
+        if (sx + i < 0 || sx + i >= w) win[i] = A.cval;
+    }
+    float res[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      double acc = win[k + R] * A.wx[0];
+#pragma unroll
+      for (int j = R; j >= 1; --j) acc += (win[k + R - j] + win[k + R + j]) * A.wx[j];
+      res[k] = (float)acc;
+    }
+    float* o = out + ((size_t)b * oh + oy0 + r) * ow + ox;
+    if (ox + 8 <= ow) {
+      __builtin_memcpy(o, res, 32);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)  // (static indices: a loop over `res` would move the array into LDS)
+        if (ox + k < ow) o[k] = res[k];
+    }
+  }
+}
+
 template <typename T>
 T from_bits(uint64_t bits) {
   gm_scalar s;
@@ -1129,6 +1237,41 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
     default: GM_GAUSS(long long); break;
   }
 #undef GM_GAUSS
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_gauss_2d(const void* in, int dtype, int bands, int h, int w, const double* weights_y, const double* weights_x,
+                int radius, double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh,
+                int ow, void* out) {
+  if (!in || !out || !weights_y || !weights_x) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (dtype != GM_F32) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_2d: dtype %d (float32 tiles)", dtype);
+  if (radius < 1 || radius > G2_MAX_RADIUS) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_2d: radius %d (1..%d)", radius, G2_MAX_RADIUS);
+  if (bands <= 0 || oh <= 0 || ow <= 0) return GM_OK;
+  if (y0 < 0 || x0 < 0 || y0 + oh > h || x0 + ow > w) return gm::fail(GM_ERR_INVALID, "gm_gauss_2d: output window outside the tile");
+  if (bands > 65535 || (oh + G2_TH - 1) / G2_TH > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_2d: tile too tall / too many bands");
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  Gauss2Args A;
+  memset(&A, 0, sizeof(A));
+  for (int j = 0; j <= radius; ++j) {
+    A.wy[j] = weights_y[j];
+    A.wx[j] = weights_x[j];
+  }
+  A.cval = cval;
+  const float ndv = from_bits<float>(ndv_bits), fill = from_bits<float>(fill_bits);
+  const int tw = 256 - 2 * (radius <= 8 ? 8 : 16);
+  dim3 grid((unsigned)((ow + tw - 1) / tw), (unsigned)((oh + G2_TH - 1) / G2_TH), (unsigned)bands);
+#define GM_G2(R, RCAP)                                                                                              \
+  case R:                                                                                                           \
+    hipLaunchKernelGGL((gauss2d_kernel<R, RCAP>), grid, dim3(256), 0, s, (const float*)in, (float*)out, h, w, y0, x0, oh, \
+                       ow, replace_ndv, ndv, fill, A);                                                              \
+    break
+  switch (radius) {
+    GM_G2(1, 8); GM_G2(2, 8); GM_G2(3, 8); GM_G2(4, 8); GM_G2(5, 8); GM_G2(6, 8); GM_G2(7, 8); GM_G2(8, 8);
+    GM_G2(9, 16); GM_G2(10, 16); GM_G2(11, 16); GM_G2(12, 16); GM_G2(13, 16); GM_G2(14, 16); GM_G2(15, 16); GM_G2(16, 16);
+  }
+#undef GM_G2
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

@@ -27,11 +27,16 @@ def _lib():
                                     c.c_int, c.c_double, c.c_int, c.c_uint64, c.c_uint64, c.c_int, c.c_int, c.c_int,
                                     c.c_int, c.c_void_p]
         L.gm_gauss_axis.restype = c.c_int
+        L.gm_gauss_2d.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_double), c.POINTER(c.c_double),
+                                  c.c_int, c.c_double, c.c_int, c.c_uint64, c.c_uint64, c.c_int, c.c_int, c.c_int, c.c_int,
+                                  c.c_void_p]
+        L.gm_gauss_2d.restype = c.c_int
         _declared = True
     return L
 
 
 MAX_DILATE_VALUES = 16
+MAX_FUSED_RADIUS = 16  # gm_gauss_2d (both axes of a float32 Smooth in one launch)
 
 
 def _ndv_bits(dtype, ndv):
@@ -101,7 +106,7 @@ def gaussian_weights(sigma, truncate=4.0):
     return np.ascontiguousarray(phi[radius:], dtype=np.float64), radius
 
 
-def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0)):
+def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0), fused=True):
     """values[values == ndv] = fill, then ndimage.gaussian_filter(values, (0, sy, sx), mode="constant",
     cval=fill) axis by axis (the second axis reads the first one's result in the tile's dtype), the
     result cropped by ``crop_yx`` pixels on every side."""
@@ -119,6 +124,16 @@ def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0)):
     my, mx = crop_yx
     current, replace = src, has
     L = _lib()
+    if fused and len(axes) == 2 and src.dtype == np.dtype("f4"):
+        (wy, ry), (wx, rx) = gaussian_weights(axes[0][1]), gaussian_weights(axes[1][1])
+        if ry == rx and 1 <= ry <= MAX_FUSED_RADIUS:  # both axes in one launch (csrc/gm_stencil.hip gauss2d_kernel)
+            out = DeviceArray.empty((bands, h - 2 * my, w - 2 * mx), src.dtype)
+            as_doubles = ctypes.POINTER(ctypes.c_double)
+            runtime.check(L.gm_gauss_2d(ctypes.c_void_p(src.ptr), code_of(src.dtype), bands, h, w,
+                                        wy.ctypes.data_as(as_doubles), wx.ctypes.data_as(as_doubles), ry, float(fill),
+                                        1 if has else 0, ndv_bits, fill_bits, my, mx, h - 2 * my, w - 2 * mx,
+                                        ctypes.c_void_p(out.ptr)), "gm_gauss_2d")
+            return out
     for k, (axis, sigma) in enumerate(axes):
         weights, radius = gaussian_weights(sigma) if sigma is not None else (np.ones(1, dtype=np.float64), 0)
         last = k == len(axes) - 1

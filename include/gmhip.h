@@ -387,6 +387,14 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
                   double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh, int ow,
                   void* out);
 
+/* Both axes of the same filter in one launch for float32 tiles whose two axes have the same radius
+ * (1..16): exactly gm_gauss_axis(axis 1) followed by gm_gauss_axis(axis 2) -- the first axis's result is
+ * rounded to float32 before the second reads it, as SciPy stores it -- without the round trip of the
+ * intermediate tile through HBM. */
+int gm_gauss_2d(const void* in, int dtype, int bands, int h, int w, const double* weights_y, const double* weights_x,
+                int radius, double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh,
+                int ow, void* out);
+
 /* =============================================================================
  * N4: statistics over the band (time) axis (raster/temporal.py).  `frames` is a C-contiguous
  * (n_frames, pixels) stack; a bin is a run of consecutive frames (the resampler bins of an

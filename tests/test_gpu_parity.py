@@ -1085,6 +1085,32 @@ def test_gauss_axis_kernels_against_oracle(gpu, dt, sigma):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sigma", [(0.3, 0.3), (0.5, 0.5), (1.0, 1.0), (1.3, 1.4), (2.0, 2.0), (2.2, 2.2), (3.0, 3.0),
+                                   (4.0, 4.0), (3.9, 4.1)])
+@pytest.mark.parametrize("shape", [(2, 75, 531), (1, 200, 700), (1, 9, 70)])
+def test_gauss_both_axes_in_one_launch(gpu, sigma, shape):
+    """float32 tiles whose axes share a radius (1..16) are filtered by ONE kernel (y axis into LDS rounded to
+    float32, x axis from there): bit-exact against the oracle's axis-by-axis restatement and against the
+    two one-axis launches, on tiles spanning several workgroup windows both ways, with no data, non-zero
+    fills that float32 cannot hold (the constant extension stays float64) and crops."""
+    from dask_geomodeling_amd.raster import stencil
+    rng = np.random.default_rng(int(sigma[0] * 10 + sigma[1] * 100) + shape[2])
+    ndv = np.float32(-9999.0)
+    v = (rng.random(shape) * 50).astype("f4")
+    v[rng.random(v.shape) < 0.05] = ndv
+    for fill, crop in ((0, (0, 0)), (2.5, (3, 5)), (0.1, (1, 0))):
+        got = stencil.gaussian_smooth(v, ndv, fill, sigma, crop).to_numpy()
+        two = stencil.gaussian_smooth(v, ndv, fill, sigma, crop, fused=False).to_numpy()
+        work = v.copy()
+        work[work == ndv] = fill
+        for axis, s in ((1, sigma[0]), (2, sigma[1])):
+            work = O.gaussian_axis(work, s, axis, fill)
+        want = work[:, crop[0]:work.shape[1] - crop[0], crop[1]:work.shape[2] - crop[1]]
+        assert got.dtype == want.dtype and np.array_equal(got, want), (sigma, fill, crop)
+        assert np.array_equal(two, want), (sigma, fill, crop, "two launches")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt,ndv", [("u1", np.uint8(255)), ("u1", np.uint8(0)), ("i1", np.int8(-1)), ("?", None)])
 def test_single_byte_input_programs_by_table(gpu, dt, ndv):
     """Programs whose only input is a 1-byte tile run as a 256-entry table (built by the VM itself) + the

@@ -102,8 +102,10 @@ def main():
         del u8m
         timeit("dilate f32, 2 values (8 B/px)", 8.0 * m, [lambda t=t: stencil.dilate(t, [1.0, 3.0]) for t in src])
         for size_px in (3.0, 6.0):
-            timeit("smooth f32, sigma %.0f px, radius %d (2 passes, 16 B/px)" % (size_px / 3, int(4 * size_px / 3 + 0.5)), 16.0 * n,
+            timeit("smooth f32, sigma %.0f px, radius %d (one launch, 8 B/px)" % (size_px / 3, int(4 * size_px / 3 + 0.5)), 8.0 * n,
                    [lambda t=t: stencil.gaussian_smooth(t, np.float32(F32MAX), 0, (size_px / 3, size_px / 3)) for t in src[:2]])
+            timeit("smooth f32, sigma %.0f px, radius %d (two launches, 16 B/px)" % (size_px / 3, int(4 * size_px / 3 + 0.5)), 16.0 * n,
+                   [lambda t=t: stencil.gaussian_smooth(t, np.float32(F32MAX), 0, (size_px / 3, size_px / 3), fused=False) for t in src[:2]])
         del src, u8
     if "temporal" in which:
         from dask_geomodeling_amd.hip.array import DeviceArray
