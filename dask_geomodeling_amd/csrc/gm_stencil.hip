@@ -602,6 +602,7 @@ __device__ __forceinline__ unsigned char shade_exact(float x, float y, const Hil
 }
 // the fast tier: true when it decided the cell (-> *out), false when the cell is for the exact tier
 __device__ __forceinline__ bool shade_fast(float x, float y, const HillArgs& A, unsigned char* out) {
+#pragma clang fp contract(fast)  // (this tier only has to land within HS_MARGIN: fused multiply-adds are welcome)
   const float xx_plus_yy = x * x + y * y;
   const float fast = (A.sin_alt - A.cos_alt_zsf * (y * A.cos_az - x * A.sin_az)) * __builtin_amdgcn_rsqf(1.0f + A.square_zsf * xx_plus_yy);
   const float v = 255.0f * fast;
@@ -700,19 +701,23 @@ __global__ __launch_bounds__(256) void hillshade_tile_kernel(const T* __restrict
   const int c0 = blockIdx.x * HT_W, r0 = blockIdx.y * HT_H, b = blockIdx.z;
   const int ow = w - 2, oh = h - 2;
   const T* plane = in + (size_t)b * h * w;
-  constexpr int PITCH = HT_W + 2, CELLS = (HT_H + 2) * PITCH, PER_LANE = (CELLS + 255) / 256;
-  T staged[PER_LANE];
+  constexpr int PITCH = HT_W + 2;
+  // staging: a lane loads its own column of the window (row offsets are scalar arithmetic), lanes 0..35 the
+  // two columns to the east of the workgroup's 256 as well -- cell / PITCH arithmetic per element cost as
+  // many instructions as the shading itself
+  auto clean = [&](T v) -> T { return (has_ndv && v == ndv) ? fill : v; };  // spatial.py:363-364
+  {
+    const T* column = plane + min(c0 + (int)threadIdx.x, w - 1);  // (clamped: cells past the tile feed no output)
+    T staged[HT_H + 2];
 #pragma unroll
-  for (int i = 0; i < PER_LANE; ++i) {
-    const int cell = threadIdx.x + 256 * i;
-    const int wy = min(cell / PITCH, HT_H + 1), wx = cell - (cell / PITCH) * PITCH;
-    const int sy = min(r0 + wy, h - 1), sx = min(c0 + wx, w - 1);  // (clamped: cells past the tile feed no output)
-    staged[i] = plane[(size_t)sy * w + sx];
-  }
+    for (int wy = 0; wy < HT_H + 2; ++wy) staged[wy] = column[(size_t)min(r0 + wy, h - 1) * w];
+    const bool east = threadIdx.x < 2 * (HT_H + 2);
+    const int ey = threadIdx.x >> 1, ex = HT_W + (threadIdx.x & 1);
+    T beyond = T(0);
+    if (east) beyond = plane[(size_t)min(r0 + ey, h - 1) * w + min(c0 + ex, w - 1)];
 #pragma unroll
-  for (int i = 0; i < PER_LANE; ++i) {
-    const int cell = threadIdx.x + 256 * i;
-    if (cell < CELLS) tile[cell] = (has_ndv && staged[i] == ndv) ? fill : staged[i];  // spatial.py:363-364
+    for (int wy = 0; wy < HT_H + 2; ++wy) tile[wy * PITCH + threadIdx.x] = clean(staged[wy]);
+    if (east) tile[ey * PITCH + ex] = clean(beyond);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -723,6 +728,7 @@ __global__ __launch_bounds__(256) void hillshade_tile_kernel(const T* __restrict
     top[j] = col[j];
     mid[j] = col[PITCH + j];
   }
+  bool overflowed = false;  // this lane met a full queue
 #pragma unroll
   for (int r = 0; r < HT_H; ++r) {
 #pragma unroll
@@ -740,7 +746,7 @@ __global__ __launch_bounds__(256) void hillshade_tile_kernel(const T* __restrict
         pending_y[slot] = y;
         pending_at[slot] = (unsigned short)((wave << 10) | (r * 64 + lane));
       } else {
-        fast_result = shade_exact(x, y, A);  // (queue full -- e.g. a plateau whose shade sits on an integer)
+        overflowed = true;  // (queue full -- e.g. a plateau whose shade sits on an integer)
       }
     }
     shade[wave][r * 64 + lane] = fast_result;
@@ -748,6 +754,18 @@ __global__ __launch_bounds__(256) void hillshade_tile_kernel(const T* __restrict
     for (int j = 0; j < 3; ++j) {
       top[j] = mid[j];
       mid[j] = bot[j];
+    }
+  }
+  if (overflowed) {
+    // the lane walks its column again and shades what the fast tier leaves open itself (one copy of the
+    // exact tier -- float64 arctan2 and sin, ~350 instructions -- instead of one per row of the unrolled walk)
+#pragma unroll 1
+    for (int r = 0; r < HT_H; ++r) {
+      const T* p = col + r * PITCH;
+      const float y = gradient<T>(p[0], p[1], p[2], p[2 * PITCH], p[2 * PITCH + 1], p[2 * PITCH + 2], A.yres, A.yres32, A.yinv, A.yinv32);
+      const float x = gradient<T>(p[0], p[PITCH], p[2 * PITCH], p[2], p[PITCH + 2], p[2 * PITCH + 2], A.xres, A.xres32, A.xinv, A.xinv32);
+      unsigned char unused;
+      if (!shade_fast(x, y, A, &unused)) shade[wave][r * 64 + lane] = shade_exact(x, y, A);
     }
   }
   __syncthreads();
@@ -769,6 +787,147 @@ __global__ __launch_bounds__(256) void hillshade_tile_kernel(const T* __restrict
       const unsigned char* srcb = shade[wave] + row * 64 + 16 * part;
       if (ocol + 16 <= ow && (((uintptr_t)dst) & 15) == 0) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(*(const u32x4*)srcb, (u32x4*)dst);
+      } else {
+        for (int k = 0; k < 16 && ocol + k < ow; ++k) dst[k] = srcb[k];
+      }
+    }
+  }
+}
+
+// float32 tiles, two pixels per lane in packed arithmetic (round 2).  The tile kernel above is bound by its
+// vector instructions (46 per pixel, 73 % of the issue slots): here a lane owns two adjacent columns and the
+// Sobel sums, the products with the reciprocal resolution and most of the fast tier run as v_pk_*_f32
+// instructions on (pixel 0, pixel 1) pairs -- the same IEEE operations in the same order per pixel, two per
+// issue slot.  Per row of the window a lane reads L = (v0, v1), M = (v1, v2), R = (v2, v3); 2 M is shared by
+// the pixel above and the one below.  Workgroup: HP_H rows x 512 columns.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int HP_H = 8, HP_W = 512;
+template <bool USE_INV>
+__global__ __launch_bounds__(256) void hillshade_pair_kernel(const float* __restrict__ in, unsigned char* __restrict__ out,
+                                                             int h, int w, int has_ndv, float ndv, float fill, HillArgs A) {
+  constexpr int PITCH = HP_W + 2;
+  __shared__ __align__(16) float tile[(HP_H + 2) * PITCH];
+  __shared__ __align__(16) unsigned char shade[HP_H * HP_W];
+  constexpr unsigned HP_PENDING = 256;
+  __shared__ float pending_x[HP_PENDING], pending_y[HP_PENDING];
+  __shared__ unsigned short pending_at[HP_PENDING];
+  __shared__ unsigned pending_count;
+  if (threadIdx.x == 0) pending_count = 0;
+  const int c0 = blockIdx.x * HP_W, r0 = blockIdx.y * HP_H, b = blockIdx.z;
+  const int ow = w - 2, oh = h - 2;
+  const float* plane = in + (size_t)b * h * w;
+  auto clean = [&](float v) -> float { return (has_ndv && v == ndv) ? fill : v; };  // spatial.py:363-364
+  {
+    // a lane stages columns t and t + 256 of the window, lanes 0..35 the two columns east of the 512
+    const float* west = plane + min(c0 + (int)threadIdx.x, w - 1);  // (clamped: cells past the tile feed no output)
+    const float* east = plane + min(c0 + 256 + (int)threadIdx.x, w - 1);
+    float sw[HP_H + 2], se[HP_H + 2];
+#pragma unroll
+    for (int wy = 0; wy < HP_H + 2; ++wy) {
+      const size_t row = (size_t)min(r0 + wy, h - 1) * w;
+      sw[wy] = west[row];
+      se[wy] = east[row];
+    }
+    const bool rim = threadIdx.x < 2 * (HP_H + 2);
+    const int ry = threadIdx.x >> 1, rx = HP_W + (threadIdx.x & 1);
+    float beyond = 0.0f;
+    if (rim) beyond = plane[(size_t)min(r0 + ry, h - 1) * w + min(c0 + rx, w - 1)];
+#pragma unroll
+    for (int wy = 0; wy < HP_H + 2; ++wy) {
+      tile[wy * PITCH + threadIdx.x] = clean(sw[wy]);
+      tile[wy * PITCH + 256 + threadIdx.x] = clean(se[wy]);
+    }
+    if (rim) tile[ry * PITCH + rx] = clean(beyond);
+  }
+  __syncthreads();
+  const float* col = tile + 2 * threadIdx.x;  // window column of the west neighbour of the lane's first pixel
+  struct Row { f32x2 L, R, M2; };
+  auto read_row = [&](int wy) -> Row {
+    const float* p = col + wy * PITCH;
+    Row row;
+    row.L = *reinterpret_cast<const f32x2*>(p);
+    row.R = *reinterpret_cast<const f32x2*>(p + 2);
+    const f32x2 M = {p[1], p[2]};
+    row.M2 = M + M;
+    return row;
+  };
+  const f32x2 inv_x = {A.xinv32, A.xinv32}, inv_y = {A.yinv32, A.yinv32};
+  bool overflowed = false;  // this lane met a full queue
+  Row top = read_row(0), mid = read_row(1);
+#pragma unroll
+  for (int r = 0; r < HP_H; ++r) {
+    const Row bot = read_row(r + 2);
+    // spatial.py:384-404, per pixel: ((((a + 2 b) + c) - d) - 2 e) - f
+    const f32x2 sy = ((((top.L + top.M2) + top.R) - bot.L) - bot.M2) - bot.R;
+    const f32x2 sx = ((((top.L + (mid.L + mid.L)) + bot.L) - top.R) - (mid.R + mid.R)) - bot.R;
+    f32x2 x, y;
+    if (USE_INV) {
+      x = sx * inv_x;
+      y = sy * inv_y;
+    } else {
+      x = f32x2{sx.x / A.xres32, sx.y / A.xres32};
+      y = f32x2{sy.x / A.yres32, sy.y / A.yres32};
+    }
+    unsigned packed = 0;
+    {
+#pragma clang fp contract(fast)  // (the fast tier only has to land within HS_MARGIN)
+      const f32x2 xx_plus_yy = x * x + y * y;
+      const f32x2 den = 1.0f + A.square_zsf * xx_plus_yy;
+      const f32x2 num = A.sin_alt - A.cos_alt_zsf * (y * A.cos_az - x * A.sin_az);
+      const f32x2 fast = num * f32x2{__builtin_amdgcn_rsqf(den.x), __builtin_amdgcn_rsqf(den.y)};
+      const f32x2 v = 255.0f * fast;
+      const f32x2 nearest = {rintf(v.x), rintf(v.y)};
+      const f32x2 off = v - nearest;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        // (NaN / inf gradients compare false here and take the exact tier, which treats them like NumPy does)
+        const bool decided = fabsf(off[k]) > HS_MARGIN || nearest[k] < 0.5f;
+        if (!decided) {
+          const unsigned slot = atomicAdd(&pending_count, 1u);
+          if (slot < HP_PENDING) {
+            pending_x[slot] = x[k];
+            pending_y[slot] = y[k];
+            pending_at[slot] = (unsigned short)(r * HP_W + 2 * threadIdx.x + k);
+          } else {
+            overflowed = true;  // (queue full -- e.g. a plateau whose shade sits on an integer)
+          }
+        }
+        packed |= (unsigned)(int)fmaxf(v[k], 0.0f) << (8 * k);  // (v < 256; NaN -> 0, redone by the exact tier)
+      }
+    }
+    *reinterpret_cast<unsigned short*>(shade + r * HP_W + 2 * threadIdx.x) = (unsigned short)packed;
+    top = mid;
+    mid = bot;
+  }
+  if (overflowed) {
+    // the lane walks its columns again and shades them itself (one copy of the exact tier -- float64
+    // arctan2 and sin, ~350 instructions -- instead of one per row of the unrolled walk)
+#pragma unroll 1
+    for (int i = 0; i < 2 * HP_H; ++i) {
+      const int r = i >> 1, k = i & 1;
+      const float* p = col + r * PITCH + k;
+      const float y = gradient<float>(p[0], p[1], p[2], p[2 * PITCH], p[2 * PITCH + 1], p[2 * PITCH + 2], A.yres, A.yres32, A.yinv, A.yinv32);
+      const float x = gradient<float>(p[0], p[PITCH], p[2 * PITCH], p[2], p[PITCH + 2], p[2 * PITCH + 2], A.xres, A.xres32, A.xinv, A.xinv32);
+      shade[r * HP_W + 2 * threadIdx.x + k] = shade_cell(x, y, A);
+    }
+  }
+  __syncthreads();
+  {
+    const unsigned n_pending = min(pending_count, HP_PENDING);
+    for (unsigned i = threadIdx.x; i < n_pending; i += 256) shade[pending_at[i]] = shade_exact(pending_x[i], pending_y[i], A);
+  }
+  __syncthreads();
+  // 16 consecutive pixels of a row per lane and step
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int chunk = threadIdx.x; chunk < HP_H * (HP_W / 16); chunk += 256) {
+    const int row = chunk / (HP_W / 16), part = chunk % (HP_W / 16);
+    const int orow = r0 + row, ocol = c0 + 16 * part;
+    if (orow < oh && ocol < ow) {
+      unsigned char* dst = out + ((size_t)b * oh + orow) * ow + ocol;
+      const unsigned char* srcb = shade + row * HP_W + 16 * part;
+      if (ocol + 16 <= ow && (((uintptr_t)dst) & 15) == 0) {
         __builtin_nontemporal_store(*(const u32x4*)srcb, (u32x4*)dst);
       } else {
         for (int k = 0; k < 16 && ocol + k < ow; ++k) dst[k] = srcb[k];
@@ -1311,6 +1470,16 @@ int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv
   dim3 grid((unsigned)((w - 2 + 255) / 256), (unsigned)((h - 2 + ST_ROWS - 1) / ST_ROWS), (unsigned)bands);
   dim3 tgrid((unsigned)((w - 2 + HT_W - 1) / HT_W), (unsigned)((h - 2 + HT_H - 1) / HT_H), (unsigned)bands);
   const bool tiled = gm::dtype_size(dtype) <= 4 && tgrid.y <= 65535;  // (8-byte tiles: the window would not fit LDS twice)
+  if (dtype == GM_F32 && !getenv("GM_HS_SINGLE") && (h - 2 + HP_H - 1) / HP_H <= 65535) {
+    dim3 pgrid((unsigned)((w - 2 + HP_W - 1) / HP_W), (unsigned)((h - 2 + HP_H - 1) / HP_H), (unsigned)bands);
+    const float ndv = from_bits<float>(ndv_bits), fill = from_bits<float>(fill_bits);
+    if (A.xinv32 != 0.0f && A.yinv32 != 0.0f)
+      hipLaunchKernelGGL(hillshade_pair_kernel<true>, pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, has_ndv, ndv, fill, A);
+    else
+      hipLaunchKernelGGL(hillshade_pair_kernel<false>, pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, has_ndv, ndv, fill, A);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+  }
 #define GM_HS(T)                                                                                                     \
   do {                                                                                                               \
     if constexpr (sizeof(T) <= 4) {                                                                                  \

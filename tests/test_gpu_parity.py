@@ -658,6 +658,28 @@ def test_hillshade_bit_exact_on_terrain(gpu, dt, scale):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f4", "i2"])
+def test_hillshade_full_exact_queue_and_true_division(gpu, dt):
+    """The corners of the two-tier kernels: a plateau under a sun in the zenith (255 * cang sits exactly on an
+    integer in every cell: the exact-tier queue of every workgroup overflows and lanes shade their own
+    columns), mixed with terrain, and resolutions that are not powers of two (true division instead of
+    the product with the reciprocal)."""
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(5)
+    v = np.zeros((1, 300, 1100), dtype="f8")
+    v[0, 100:200, 300:800] = np.cumsum(rng.standard_normal((100, 500)) * 3, axis=1)
+    v = np.round(v).astype(dt) if dt != "f4" else v.astype(dt)
+    ndv = np.dtype(dt).type(-9999)
+    v[0, ::53, ::29] = ndv
+    data = {"values": v, "no_data_value": ndv}
+    for alt, az, res in ((90.0, 315.0, (1.0, 1.0)), (90.0, 0.0, (0.3, 0.7)), (45.0, 315.0, (0.3, 0.7)), (60.0, 200.0, (3.0, 0.5))):
+        kw = dict(resolution=res, altitude=alt, azimuth=az, fill=0)
+        got = raster.HillShade.process(data, kw)
+        want = O.hillshade_process(data, kw, trig="rounded")  # (a plateau is one gradient pair: no count against NumPy here)
+        assert_values_equal(got["values"], want["values"], 0, "plateau %s %s %s" % (dt, alt, res))
+
+
+@pytest.mark.gpu
 def test_stencil_blocks_end_to_end(gpu):
     """The Blocks through get_data on a MemorySource: request enlargement + kernel + crop equal the
     oracle applied to the enlarged window (edge cells see the source's no-data outside its extent)."""

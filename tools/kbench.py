@@ -92,6 +92,10 @@ def main():
         m = (side - 2) * (side - 2)
         timeit("hillshade f32 -> u8 (5 B/px)", 5.0 * m,
                [lambda t=t: stencil.hillshade(t, np.float32(F32MAX), 0, (0.5, 0.5), 45.0, 315.0) for t in src])
+        srcm = [generate_window((side + 2, side + 2), "f4", 90 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side + 2, side + 2) for i in range(2)]
+        timeit("hillshade f32 -> u8 with margin (%d wide, 5 B/px)" % (side + 2), 5.0 * n,
+               [lambda t=t: stencil.hillshade(t, np.float32(F32MAX), 0, (0.5, 0.5), 45.0, 315.0) for t in srcm])
+        del srcm
         for size in (3, 5, 7, 11, 15):
             timeit("moving max f32, size %d (8 B/px)" % size, 8.0 * (side - size + 1) ** 2,
                    [lambda t=t: stencil.moving_max(t, np.float32(F32MAX), size) for t in src])
