@@ -90,6 +90,59 @@ __global__ __launch_bounds__(256) void dilate_kernel(const T* __restrict__ in, T
   }
 }
 
+// Staging of the LDS tiles of this file: the ROWS x (256 + HALO) window at (r0, c0) of a plane, pitch
+// 256 + HALO.  A lane loads its own column (the row offsets are scalar arithmetic: ~3 vector instructions per
+// cell; addressing cell by cell with `cell / PITCH` cost ~15, as much as the stencils themselves), the HALO
+// columns east of the workgroup's 256 are shared out cell by cell.  All loads of a lane are in flight before
+// the first LDS write; rows / columns past the plane are clamped (those cells feed no output).
+template <typename T, int ROWS, int HALO, typename F>
+__device__ __forceinline__ void stage_window(T* tile, const T* __restrict__ plane, int r0, int c0, int h, int w, F clean) {
+  constexpr int PITCH = 256 + HALO, EAST = ROWS * HALO, EAST_PER_LANE = (EAST + 255) / 256;
+  const T* column = plane + min(c0 + (int)threadIdx.x, w - 1);
+  T own[ROWS], east[EAST_PER_LANE];
+#pragma unroll
+  for (int wy = 0; wy < ROWS; ++wy) own[wy] = column[(size_t)min(r0 + wy, h - 1) * w];
+#pragma unroll
+  for (int i = 0; i < EAST_PER_LANE; ++i) {
+    const int cell = min((int)threadIdx.x + 256 * i, EAST - 1);
+    const int ey = cell / HALO, ex = 256 + cell - ey * HALO;
+    east[i] = plane[(size_t)min(r0 + ey, h - 1) * w + min(c0 + ex, w - 1)];
+  }
+#pragma unroll
+  for (int wy = 0; wy < ROWS; ++wy) tile[wy * PITCH + threadIdx.x] = clean(own[wy]);
+#pragma unroll
+  for (int i = 0; i < EAST_PER_LANE; ++i) {
+    const int cell = (int)threadIdx.x + 256 * i;
+    const int ey = cell / HALO, ex = 256 + cell - ey * HALO;
+    if (cell < EAST) tile[ey * PITCH + ex] = clean(east[i]);
+  }
+}
+
+// Maximum as the hardware has it: one instruction for two or three operands (the b > a ? b : a form costs a
+// compare and a select each).  NaN operands are ignored -- see the note on NaN at the MovingMax kernels.
+template <typename T>
+__device__ __forceinline__ T hw_max(T a, T b) {
+  if constexpr (std::is_same<T, float>::value) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+  } else if constexpr (std::is_same<T, double>::value) {
+    return __builtin_fmax(a, b);
+  } else {
+    return b > a ? b : a;
+  }
+}
+template <typename T>
+__device__ __forceinline__ T hw_max3(T a, T b, T c) {
+  if constexpr (std::is_same<T, float>::value) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+  } else {
+    return hw_max(hw_max(a, b), c);  // (integers: the compiler forms v_max3_i32 / _u32 itself)
+  }
+}
+
 // Single-band tiles of 2- and 4-byte cells through the LDS tile of HillShade / MovingMax (the window
 // of 16 x 256 outputs staged once, all loads of a lane in flight; lanes walk their column out of LDS):
 // the column walker above waits one memory round trip per 4 rows, eight times per wave.
@@ -100,20 +153,8 @@ __global__ __launch_bounds__(256) void dilate_tile_kernel(const T* __restrict__ 
   __shared__ T tile[(DT_H + 2) * (DT_W + 2)];
   const int c0 = blockIdx.x * DT_W, r0 = blockIdx.y * DT_H;
   const int ow = w - 2, oh = h - 2;
-  constexpr int PITCH = DT_W + 2, CELLS = (DT_H + 2) * PITCH, PER_LANE = (CELLS + 255) / 256;
-  T staged[PER_LANE];
-#pragma unroll
-  for (int i = 0; i < PER_LANE; ++i) {
-    const int cell = threadIdx.x + 256 * i;
-    const int wy = min(cell / PITCH, DT_H + 1), wx = cell - (cell / PITCH) * PITCH;
-    const int sy = min(r0 + wy, h - 1), sx = min(c0 + wx, w - 1);
-    staged[i] = in[(size_t)sy * w + sx];
-  }
-#pragma unroll
-  for (int i = 0; i < PER_LANE; ++i) {
-    const int cell = threadIdx.x + 256 * i;
-    if (cell < CELLS) tile[cell] = staged[i];
-  }
+  constexpr int PITCH = DT_W + 2;
+  stage_window<T, DT_H + 2, 2>(tile, in, r0, c0, h, w, [](T v) { return v; });
   __syncthreads();
   const int c = c0 + threadIdx.x;
   if (c >= ow) return;
@@ -345,6 +386,10 @@ __global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* 
 // MovingMax
 // ---------------------------------------------------------------------------------
 constexpr int MM_TILE_H = 16, MM_TILE_W = 64;
+// NaN.  scipy.ndimage.maximum_filter starts from the first cell of the footprint (top row, leftmost) and
+// takes every later cell that compares greater: a NaN in that first cell stays (nothing compares greater than
+// it), a NaN anywhere else is never taken.  The kernels below reduce with the hardware maximum, which ignores
+// NaN operands, and then apply exactly that rule: the result is NaN where the first cell of the footprint is.
 
 // RMAX: largest radius of the instantiation (bounds the staging loops at compile time so that all of
 // a wave's window loads are in flight together instead of one load-wait-store round trip per row)
@@ -391,7 +436,7 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
   if (c0 + c >= ow) return;
   const int s2 = size * size;
   T m[4] = {minimum, minimum, minimum, minimum};
-  auto up = [](T a, T b) -> T { return b > a ? b : a; };
+  auto up = [](T a, T b) -> T { return hw_max(a, b); };
   for (int dx = 0; dx < size; ++dx) {
     const int xx = dx - radius;
     int hh = -1;  // half-height of the footprint's column: (x^2 + y^2) < (size/2)^2 (utils.py:536-547)
@@ -419,6 +464,12 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
     const int rr = o0 + k;
     if (r0 + rr >= oh) break;
     T best = m[k];
+    if constexpr (std::is_floating_point<T>::value) {  // (NaN: see the note above the kernel)
+      int a = -1;
+      while (4 * ((a + 1) * (a + 1) + radius * radius) < s2) ++a;
+      const T first = tile[rr * pitch + c + radius - a];
+      if (first != first) best = first;
+    }
     // still the minimum on a no-data centre: no-data again (spatial.py:208-209).  Rare: only then is the
     // original centre fetched (the LDS copy cannot tell "was no data" from "is the minimum")
     if (has_ndv && best == minimum) {
@@ -441,33 +492,24 @@ __global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ 
   const int c0 = blockIdx.x * M3_W, r0 = blockIdx.y * M3_H, b = blockIdx.z;
   const int ow = w - 2, oh = h - 2;
   const T* plane = in + (size_t)b * h * w;
-  constexpr int PITCH = M3_W + 2, CELLS = (M3_H + 2) * PITCH, PER_LANE = (CELLS + 255) / 256;
-  T staged[PER_LANE];
-#pragma unroll
-  for (int i = 0; i < PER_LANE; ++i) {
-    const int cell = threadIdx.x + 256 * i;
-    const int wy = min(cell / PITCH, M3_H + 1), wx = cell - (cell / PITCH) * PITCH;
-    const int sy = min(r0 + wy, h - 1), sx = min(c0 + wx, w - 1);
-    staged[i] = plane[(size_t)sy * w + sx];
-  }
-#pragma unroll
-  for (int i = 0; i < PER_LANE; ++i) {
-    const int cell = threadIdx.x + 256 * i;
-    if (cell < CELLS) tile[cell] = (has_ndv && staged[i] == ndv) ? minimum : staged[i];  // spatial.py:199-203
-  }
+  constexpr int PITCH = M3_W + 2;
+  stage_window<T, M3_H + 2, 2>(tile, plane, r0, c0, h, w, [&](T v) { return (has_ndv && v == ndv) ? minimum : v; });  // spatial.py:199-203
   __syncthreads();
   const int c = c0 + threadIdx.x;
   if (c >= ow) return;
-  auto up = [](T a, T b) -> T { return b > a ? b : a; };
   const T* col = tile + threadIdx.x;
-  auto row_max = [&](int wy) -> T { return up(up(col[wy * PITCH], col[wy * PITCH + 1]), col[wy * PITCH + 2]); };
+  auto row_max = [&](int wy) -> T { return hw_max3(col[wy * PITCH], col[wy * PITCH + 1], col[wy * PITCH + 2]); };
   T above = row_max(0), centre = row_max(1);
 #pragma unroll
   for (int r = 0; r < M3_H; ++r) {
     const T below = row_max(r + 2);
-    T best = up(up(above, centre), below);
+    T best = hw_max3(above, centre, below);
     above = centre;
     centre = below;
+    if constexpr (std::is_floating_point<T>::value) {  // (NaN: see the note above moving_max_kernel)
+      const T first = col[r * PITCH];
+      if (first != first) best = first;
+    }
     if (r0 + r < oh) {
       // still the minimum on a no-data centre: no-data again (spatial.py:208-209); only then is the
       // original centre fetched (the LDS copy cannot tell "was no data" from "is the minimum")
@@ -484,7 +526,7 @@ __global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ 
 // HM_{a(dy)}(row r + dy), HM_a(row) = maximum of the 2 a + 1 cells around the lane's column, a(dy) = the
 // half-width of the footprint at that row offset.  HM_0 .. HM_R of a window row are nested (two more
 // cells per step), so a lane that walks its column keeps them for the last 2 R + 1 window rows in
-// registers and spends 2 R + 1 LDS reads and 4 R maxima per output -- all indices compile-time constants
+// registers and spends 2 R + 1 LDS reads and 2 R three-operand maxima per output -- all indices compile-time constants
 // (fully unrolled walk), i.e. straight-line code without the data-dependent loops of the general kernel.
 template <int R>
 __host__ __device__ constexpr int disk_half_width(int dy) {
@@ -495,32 +537,20 @@ __host__ __device__ constexpr int disk_half_width(int dy) {
   return a;  // -1: the row offset is outside the footprint (cannot happen for |dy| <= R)
 }
 
+// output rows per workgroup: the walk passes TH + 2 R window rows for TH outputs
+__host__ __device__ constexpr int disk_tile_rows(int R) { return R >= 7 ? 32 : 16; }
 template <typename T, int R>
 __global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
                                                               int has_ndv, T ndv, T minimum) {
-  constexpr int TH = 16, TW = 256, PITCH = TW + 2 * R, ROWS = TH + 2 * R, CELLS = ROWS * PITCH;
-  constexpr int PER_LANE = (CELLS + 255) / 256;
-  __shared__ T tile[CELLS];
+  constexpr int TH = disk_tile_rows(R), TW = 256, PITCH = TW + 2 * R, ROWS = TH + 2 * R;
+  __shared__ T tile[ROWS * PITCH];
   const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH, b = blockIdx.z;
   const int ow = w - 2 * R, oh = h - 2 * R;
   const T* plane = in + (size_t)b * h * w;
-  T staged[PER_LANE];
-#pragma unroll
-  for (int i = 0; i < PER_LANE; ++i) {
-    const int cell = threadIdx.x + 256 * i;
-    const int wy = min(cell / PITCH, ROWS - 1), wx = cell - (cell / PITCH) * PITCH;
-    const int sy = min(r0 + wy, h - 1), sx = min(c0 + wx, w - 1);
-    staged[i] = plane[(size_t)sy * w + sx];
-  }
-#pragma unroll
-  for (int i = 0; i < PER_LANE; ++i) {
-    const int cell = threadIdx.x + 256 * i;
-    if (cell < CELLS) tile[cell] = (has_ndv && staged[i] == ndv) ? minimum : staged[i];  // spatial.py:199-203
-  }
+  stage_window<T, ROWS, 2 * R>(tile, plane, r0, c0, h, w, [&](T v) { return (has_ndv && v == ndv) ? minimum : v; });  // spatial.py:199-203
   __syncthreads();
   const int c = c0 + threadIdx.x;
   if (c >= ow) return;
-  auto up = [](T a, T b) -> T { return b > a ? b : a; };
   const T* col = tile + threadIdx.x;  // window columns threadIdx.x .. threadIdx.x + 2 R = dx -R .. R
   T hm[2 * R + 1][R + 1];             // hm[k][a]: HM_a of window row y - 2 R + k after window row y was taken
 #pragma unroll
@@ -538,12 +568,18 @@ __global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restric
     for (int j = 0; j <= 2 * R; ++j) v[j] = col[y * PITCH + j];
     hm[2 * R][0] = v[R];
 #pragma unroll
-    for (int a = 1; a <= R; ++a) hm[2 * R][a] = up(up(hm[2 * R][a - 1], v[R - a]), v[R + a]);
+    for (int a = 1; a <= R; ++a) hm[2 * R][a] = hw_max3(hm[2 * R][a - 1], v[R - a], v[R + a]);
     if (y >= 2 * R) {
       const int r = y - 2 * R;
       T best = hm[0][disk_half_width<R>(R)];
 #pragma unroll
-      for (int k = 1; k <= 2 * R; ++k) best = up(best, hm[k][disk_half_width<R>(k > R ? k - R : R - k)]);
+      for (int k = 1; k <= 2 * R; k += 2)
+        best = hw_max3(best, hm[k][disk_half_width<R>(k > R ? k - R : R - k)],
+                       hm[k + 1][disk_half_width<R>(k + 1 > R ? k + 1 - R : R - k - 1)]);
+      if constexpr (std::is_floating_point<T>::value) {  // (NaN: see the note above moving_max_kernel)
+        const T first = col[r * PITCH + R - disk_half_width<R>(R)];
+        if (first != first) best = first;
+      }
       if (r0 + r < oh) {
         if (has_ndv && best == minimum) {  // no data again where the centre was no data (spatial.py:208-209)
           const T original = plane[(size_t)(r0 + r + R) * w + (c + R)];
@@ -702,23 +738,7 @@ __global__ __launch_bounds__(256) void hillshade_tile_kernel(const T* __restrict
   const int ow = w - 2, oh = h - 2;
   const T* plane = in + (size_t)b * h * w;
   constexpr int PITCH = HT_W + 2;
-  // staging: a lane loads its own column of the window (row offsets are scalar arithmetic), lanes 0..35 the
-  // two columns to the east of the workgroup's 256 as well -- cell / PITCH arithmetic per element cost as
-  // many instructions as the shading itself
-  auto clean = [&](T v) -> T { return (has_ndv && v == ndv) ? fill : v; };  // spatial.py:363-364
-  {
-    const T* column = plane + min(c0 + (int)threadIdx.x, w - 1);  // (clamped: cells past the tile feed no output)
-    T staged[HT_H + 2];
-#pragma unroll
-    for (int wy = 0; wy < HT_H + 2; ++wy) staged[wy] = column[(size_t)min(r0 + wy, h - 1) * w];
-    const bool east = threadIdx.x < 2 * (HT_H + 2);
-    const int ey = threadIdx.x >> 1, ex = HT_W + (threadIdx.x & 1);
-    T beyond = T(0);
-    if (east) beyond = plane[(size_t)min(r0 + ey, h - 1) * w + min(c0 + ex, w - 1)];
-#pragma unroll
-    for (int wy = 0; wy < HT_H + 2; ++wy) tile[wy * PITCH + threadIdx.x] = clean(staged[wy]);
-    if (east) tile[ey * PITCH + ex] = clean(beyond);
-  }
+  stage_window<T, HT_H + 2, 2>(tile, plane, r0, c0, h, w, [&](T v) { return (has_ndv && v == ndv) ? fill : v; });  // spatial.py:363-364
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* col = tile + threadIdx.x;  // window column of the west neighbour of output column c0 + threadIdx.x
@@ -1278,7 +1298,8 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
     return GM_OK;
   }
   if (size >= 5 && size <= 15 && gm::dtype_size(dtype) <= 4 && (oh + 15) / 16 <= 65535) {
-    dim3 gridd((unsigned)((ow + 255) / 256), (unsigned)((oh + 15) / 16), (unsigned)bands);
+    const int th = disk_tile_rows(radius);
+    dim3 gridd((unsigned)((ow + 255) / 256), (unsigned)((oh + th - 1) / th), (unsigned)bands);
 #define GM_MD(T)                                                                                                  \
   do {                                                                                                            \
     if (size == 5)                                                                                                \

@@ -528,11 +528,19 @@ def movingmax_process(data, size=None):
     array[no_data_mask] = minimum
     nb, ny, nx = array.shape
     oy, ox = ny - 2 * radius, nx - 2 * radius
-    filtered = np.full((nb, oy, ox), minimum, dtype=array.dtype)
+    # scipy.ndimage.maximum_filter (ni_filters.c, NI_MinOrMaxFilter): the result starts as the first cell of
+    # the footprint (raster order) and every later cell that compares GREATER replaces it -- so a NaN in the
+    # first cell stays and a NaN anywhere else is never taken
+    filtered = None
     for dy in range(footprint.shape[0]):
         for dx in range(footprint.shape[1]):
             if footprint[dy, dx]:
-                filtered = np.maximum(filtered, array[:, dy:dy + oy, dx:dx + ox])
+                cell = array[:, dy:dy + oy, dx:dx + ox]
+                if filtered is None:
+                    filtered = cell.copy()
+                else:
+                    with np.errstate(invalid="ignore"):
+                        np.copyto(filtered, cell, where=cell > filtered)
     centre = no_data_mask[:, radius:ny - radius, radius:nx - radius]
     filtered[(filtered == minimum) & centre] = data["no_data_value"]
     return {"values": filtered, "no_data_value": data["no_data_value"]}

@@ -680,6 +680,28 @@ def test_hillshade_full_exact_queue_and_true_division(gpu, dt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size", [3, 5, 7, 9, 11, 13, 15, 17, 21])
+@pytest.mark.parametrize("dt", ["f4", "f8"])
+def test_movingmax_nan_cells_like_scipy(gpu, size, dt):
+    """NaN cells: the kernels reduce with the hardware maximum (NaN operands ignored) and make the result NaN
+    where the first cell of the footprint is NaN -- SciPy's rule (the oracle is pinned against SciPy on
+    exactly this in tests/test_oracle_golden.py).  All three kernels (3 x 3, fixed disks, general), ragged
+    tiles, no data next to NaN."""
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(size)
+    v = (rng.standard_normal((2, 90, 300)) * 10).astype(dt)
+    ndv = np.dtype(dt).type(-9999)
+    v[rng.random(v.shape) < 0.2] = ndv
+    v[rng.random(v.shape) < 0.03] = np.nan
+    data = {"values": v, "no_data_value": ndv}
+    got = raster.MovingMax.process(data, size)
+    want = O.movingmax_process(data, size)
+    g, x = np.asarray(got["values"]), want["values"]
+    assert np.isnan(x).any() and not np.isnan(x).all()
+    assert g.dtype == x.dtype and np.array_equal(g, x, equal_nan=True)
+
+
+@pytest.mark.gpu
 def test_stencil_blocks_end_to_end(gpu):
     """The Blocks through get_data on a MemorySource: request enlargement + kernel + crop equal the
     oracle applied to the enlarged window (edge cells see the source's no-data outside its extent)."""

@@ -213,6 +213,43 @@ def test_hillshade_trig_rounding_only_moves_truncation_boundaries():
     assert differ <= 20e-6 * cells
 
 
+@pytest.mark.parametrize("size", [3, 4, 5, 7, 11, 15, 18])
+@pytest.mark.parametrize("dt", ["f4", "f8", "i2"])
+def test_movingmax_is_scipys_filter_including_nan(size, dt):
+    """MovingMax.process calls scipy.ndimage.maximum_filter (spatial.py:205), which is not in /root/reference:
+    the oracle restates its published algorithm (the first footprint cell, then every cell that compares
+    greater) and is pinned here against SciPy itself, NaN cells and signed zeros included (a NaN only
+    survives as the first cell of the footprint; bit patterns compared, not values)."""
+    from scipy import ndimage
+    rng = np.random.default_rng(int(size * 10))
+    v = np.round(rng.standard_normal((2, 60, 70)) * 3, 1)
+    v[rng.random(v.shape) < 0.1] = 0.0
+    v[rng.random(v.shape) < 0.1] = -0.0
+    v = v.astype(dt)
+    ndv = np.dtype(dt).type(-9999)
+    v[rng.random(v.shape) < 0.1] = ndv
+    full_square = bool(O.get_footprint(size).all())
+    if dt != "i2" and not full_square:
+        # (an all-true footprint -- size 3 -- makes SciPy filter axis by axis with a running-maximum queue whose
+        #  output after a NaN depends on the cells met before it along the whole line: no rule to restate)
+        v[rng.random(v.shape) < 0.03] = np.nan
+    data = {"values": v, "no_data_value": ndv}
+    radius = int(size // 2)
+    array = v.copy()
+    minimum = O.get_dtype_min(array.dtype)
+    mask = array == ndv
+    array[mask] = minimum
+    want = ndimage.maximum_filter(array, footprint=O.get_footprint(size)[np.newaxis])
+    want[(want == minimum) & mask] = ndv
+    want = want[:, radius:-radius, radius:-radius]
+    got = O.movingmax_process(data, size)["values"]
+    assert got.dtype == want.dtype
+    if full_square:
+        assert np.array_equal(got, want)  # (the queue keeps the LAST of equal cells: the sign of a zero may differ)
+    else:
+        assert got.tobytes() == want.tobytes()
+
+
 @pytest.mark.parametrize("case", load_family("spatial"), ids=lambda c: c["id"] + "-" + c["op"])
 def test_spatial(case):
     op, args = case["op"], case["args"]
