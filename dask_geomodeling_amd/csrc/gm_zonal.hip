@@ -1,0 +1,316 @@
+// N4: labelled (zonal) statistics -- the numeric core of geometry.AggregateRaster
+// (geometry/aggregate.py:160-203): for one frame of a raster and a label raster (cell -> index of the
+// geometry that covers it, as utils.rasterize_geoseries paints it), one statistic per label over the
+// label's ACTIVE cells (data, and not below the label's threshold when thresholds are given).
+//
+// The reference computes these with scipy.ndimage.{sum, mean, minimum, maximum, median} and its own
+// measurements.percentile, whose results depend on the ORDER of the cells:
+//   * sum / mean are np.bincount(labels, weights=values): float64 accumulation cell after cell in raster
+//     order -- float64 addition is not associative, so only the same order gives the same bits;
+//   * minimum / maximum / median / percentile pick from the cells sorted by (label, value), NaN last.
+// So the cells are sorted, not reduced in a tree: a STABLE radix sort by label (rocPRIM's device-wide sort;
+// keys of bit_width(n_labels) bits) leaves every label's active cells contiguous and in raster order; the
+// statistics that pick sort by value first.  Then
+//   * sum / mean: one wave per label loads 64 cells at a time and adds them one after the other in float64
+//     (the bincount order; the chain of dependent additions is the price of bit-exactness -- a label of
+//     10 M cells takes as long as it does on a CPU core, thousands of labels run side by side);
+//   * count: the length of the label's segment;
+//   * min / max / median / percentile: a lane per label picks from its sorted segment and combines exactly
+//     as SciPy / measurements.percentile do (median of integers in float64, of float32 in float32; the
+//     percentile's difference in the raster's own dtype, wrap-around included).
+// Results are float32 like the reference's `agg` array; labels without an active cell stay NaN.
+// HBM traffic: dominated by the sort passes (each moves keys + payload twice), ~40-100 bytes per cell.
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <type_traits>
+
+#include "gm_common.h"
+
+namespace {
+
+enum { Z_SUM = 0, Z_COUNT = 1, Z_MIN = 2, Z_MAX = 3, Z_MEAN = 4, Z_MEDIAN = 5, Z_PERCENTILE = 6 };
+
+// Order-preserving unsigned image of a value in NumPy's sort order: ascending, NaN after everything else.
+template <typename T>
+struct Ordered {
+  typedef typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned>::type Key;
+  static __device__ __forceinline__ Key encode(T v) {
+    if constexpr (std::is_same<T, float>::value) {
+      if (v != v) return 0xFFFFFFFFu;
+      const unsigned u = __float_as_uint(v);
+      return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    } else if constexpr (std::is_same<T, double>::value) {
+      if (v != v) return ~0ull;
+      const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+      return (u >> 63) ? ~u : (u | (1ull << 63));
+    } else if constexpr (std::is_signed<T>::value) {
+      typedef typename std::make_unsigned<T>::type U;
+      return (Key)(U)((U)v ^ (U)((U)1 << (8 * sizeof(T) - 1)));
+    } else {
+      return (Key)v;
+    }
+  }
+  static __device__ __forceinline__ T decode(Key k) {
+    if constexpr (std::is_same<T, float>::value) {
+      if (k == 0xFFFFFFFFu) return std::numeric_limits<float>::quiet_NaN();
+      return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+    } else if constexpr (std::is_same<T, double>::value) {
+      if (k == ~0ull) return std::numeric_limits<double>::quiet_NaN();
+      return __longlong_as_double((long long)((k >> 63) ? (k & ~(1ull << 63)) : ~k));
+    } else if constexpr (std::is_signed<T>::value) {
+      typedef typename std::make_unsigned<T>::type U;
+      return (T)(U)((U)k ^ (U)((U)1 << (8 * sizeof(T) - 1)));
+    } else {
+      return (T)k;
+    }
+  }
+};
+
+// aggregate.py:177-186: active = frame != no_data_value, and with thresholds only cells whose label has one
+// (not NaN) and whose value reaches it; the comparison promotes like NumPy (value vs float32 threshold:
+// float32 for float32 and narrow integers, float64 otherwise -- all exact images in float64).
+// key = label of an active cell, n_labels for every other cell (sorts behind all labels).
+template <typename T>
+__global__ __launch_bounds__(256) void zonal_keys_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
+                                                         int n_labels, int has_ndv, T ndv, const float* __restrict__ thresholds,
+                                                         unsigned* __restrict__ keys, typename Ordered<T>::Key* __restrict__ payload,
+                                                         unsigned char* __restrict__ present) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += stride) {
+    const T v = values[i];
+    const int label = labels[i];
+    const bool labelled = (unsigned)label < (unsigned)n_labels;
+    if (present && labelled) present[label] = 1;
+    bool active = labelled && !(has_ndv && v == ndv);
+    if (thresholds && active) {
+      const float t = thresholds[label];
+      active = !(t != t) && (double)v >= (double)t;
+    }
+    keys[i] = active ? (unsigned)label : (unsigned)n_labels;
+    payload[i] = Ordered<T>::encode(v);
+  }
+}
+
+// first[l] = index of the first sorted cell whose key is >= l, for l = 0 .. n_labels (first[n_labels] = the
+// number of active cells): label l owns the sorted cells [first[l], first[l + 1])
+__global__ __launch_bounds__(256) void zonal_bounds_kernel(const unsigned* __restrict__ keys, unsigned cells, int n_labels,
+                                                           unsigned* __restrict__ first) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l > n_labels) return;
+  unsigned lo = 0, hi = cells;
+  while (lo < hi) {
+    const unsigned mid = lo + (hi - lo) / 2;
+    if (keys[mid] < (unsigned)l) lo = mid + 1;
+    else hi = mid;
+  }
+  first[l] = lo;
+}
+
+__device__ __forceinline__ double read_lane(double x, int lane) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// np.bincount(labels, weights=values)[l]: sums[l] += (double)value, cell after cell in raster order.
+// One wave per label: 64 cells per load, 64 dependent additions.
+template <typename T>
+__global__ __launch_bounds__(256) void zonal_sum_kernel(const typename Ordered<T>::Key* __restrict__ payload,
+                                                        const unsigned* __restrict__ first, int n_labels, int statistic,
+                                                        float* __restrict__ out, long long* __restrict__ counts) {
+  const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (l >= n_labels) return;
+  const unsigned a = first[l], b = first[l + 1];
+  double acc = 0.0;
+  for (unsigned i = a; i < b; i += 64) {
+    const unsigned at = i + lane;
+    const double x = at < b ? (double)Ordered<T>::decode(payload[at]) : 0.0;
+    const unsigned m = min(64u, b - i);
+    if (m == 64u) {
+#pragma unroll
+      for (int k = 0; k < 64; ++k) acc += read_lane(x, k);
+    } else {
+      for (unsigned k = 0; k < m; ++k) acc += read_lane(x, (int)k);
+    }
+  }
+  if (lane == 0) {
+    const unsigned n = b - a;
+    counts[l] = n;
+    const float nan = std::numeric_limits<float>::quiet_NaN();
+    // ndimage.mean: sum / count in float64; the assignment into the float32 `agg` rounds once
+    out[l] = n == 0 ? nan : (statistic == Z_MEAN ? (float)(acc / (double)n) : (float)acc);
+  }
+}
+
+// count (ndimage.sum of ones) and the statistics that pick from the cells sorted by (label, value)
+template <typename T>
+__global__ __launch_bounds__(256) void zonal_pick_kernel(const typename Ordered<T>::Key* __restrict__ payload,
+                                                         const unsigned* __restrict__ first, int n_labels, int statistic,
+                                                         double qval, float* __restrict__ out, long long* __restrict__ counts) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= n_labels) return;
+  const unsigned a = first[l], b = first[l + 1], n = b - a;
+  counts[l] = n;
+  if (n == 0) {
+    out[l] = std::numeric_limits<float>::quiet_NaN();
+    return;
+  }
+  auto cell = [&](unsigned i) -> T { return Ordered<T>::decode(payload[i]); };
+  float result;
+  if (statistic == Z_COUNT) {
+    result = (float)(double)n;
+  } else if (statistic == Z_MIN) {
+    result = (float)cell(a);
+  } else if (statistic == Z_MAX) {
+    result = (float)cell(b - 1);  // (NaN sorts last: a label with a NaN cell has a NaN maximum, like SciPy's)
+  } else if (statistic == Z_MEDIAN) {
+    // scipy.ndimage._measurements._select: the two middle cells (the same cell for an odd count) averaged --
+    // integers and booleans in float64, floats in their own precision
+    const unsigned step = (n - 1) / 2, lo = a + step, hi = (b - 1) - step;
+    const T x = cell(lo), y = cell(hi);
+    if constexpr (std::is_same<T, float>::value) result = (x + y) / 2.0f;
+    else if constexpr (std::is_same<T, double>::value) result = (float)((x + y) / 2.0);
+    else result = (float)(((double)x + (double)y) / 2.0);
+  } else {
+    // measurements.percentile (measurements.py:126-134): np.percentile's linear interpolation between the
+    // floor and the ceiling of the fractional index; the difference is taken in the raster's dtype
+    const double frac = (double)(n - 1) * (qval / 100.0);
+    const double below = floor(frac), above = ceil(frac);
+    const T x = cell(a + (unsigned)below), y = cell(a + (unsigned)above);
+    const T diff = (T)(y - x);
+    result = (float)((double)x + (frac - below) * (double)diff);
+  }
+  out[l] = result;
+}
+
+template <typename T>
+T scalar_from_bits(uint64_t bits) {
+  gm_scalar s;
+  s.u64 = bits;
+  if constexpr (std::is_floating_point<T>::value) return (T)s.f64;
+  else if constexpr (std::is_same<T, unsigned long long>::value) return (T)s.u64;
+  else return (T)s.i64;
+}
+
+struct Scratch {  // device buffers of one call, returned to the pool on every exit path
+  void* p[8] = {nullptr};
+  int n = 0;
+  int take(void** out, size_t bytes) {
+    const int rc = gm_malloc(out, bytes ? bytes : 1);
+    if (rc == GM_OK) p[n++] = *out;
+    return rc;
+  }
+  ~Scratch() {
+    for (int i = 0; i < n; ++i) gm_free(p[i]);
+  }
+};
+
+template <typename T>
+int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, uint64_t ndv_bits, const int* labels,
+              int n_labels, const float* thresholds, int statistic, double qval, float* out, long long* counts,
+              unsigned char* present, hipStream_t s) {
+  typedef typename Ordered<T>::Key Key;
+  const T* values = (const T*)values_v;
+  const T ndv = scalar_from_bits<T>(ndv_bits);
+  Scratch scratch;
+  unsigned *keys_a, *keys_b, *first;
+  Key *pay_a, *pay_b;
+  int rc;
+  if ((rc = scratch.take((void**)&keys_a, sizeof(unsigned) * cells))) return rc;
+  if ((rc = scratch.take((void**)&keys_b, sizeof(unsigned) * cells))) return rc;
+  if ((rc = scratch.take((void**)&pay_a, sizeof(Key) * cells))) return rc;
+  if ((rc = scratch.take((void**)&pay_b, sizeof(Key) * cells))) return rc;
+  if ((rc = scratch.take((void**)&first, sizeof(unsigned) * ((size_t)n_labels + 2)))) return rc;
+  const bool by_value = statistic == Z_MIN || statistic == Z_MAX || statistic == Z_MEDIAN || statistic == Z_PERCENTILE;
+  unsigned label_bits = 1;
+  while ((1ull << label_bits) <= (unsigned long long)n_labels) ++label_bits;
+  size_t temp_value = 0, temp_label = 0;
+  if (by_value)
+    GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_value, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 0, 8 * sizeof(Key), s));
+  GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_label, keys_a, keys_b, pay_a, pay_b, (size_t)cells, 0, label_bits, s));
+  void* temp;
+  const size_t temp_bytes = temp_value > temp_label ? temp_value : temp_label;
+  if ((rc = scratch.take(&temp, temp_bytes))) return rc;
+  const unsigned blocks = (unsigned)std::min<int64_t>((cells + 255) / 256, (int64_t)gm::current_cu_count() * 32);
+  for (int64_t f = 0; f < frames; ++f) {
+    hipLaunchKernelGGL(zonal_keys_kernel<T>, dim3(blocks), dim3(256), 0, s, values + (size_t)f * cells, labels, (size_t)cells,
+                       n_labels, has_ndv, ndv, thresholds, keys_a, pay_a, f == 0 ? present : (unsigned char*)nullptr);
+    const unsigned* sorted_keys;
+    const Key* sorted_pay;
+    size_t bytes = temp_bytes;
+    if (by_value) {
+      // lexsort((values, labels)): by value, then stably by label
+      GM_HIP(rocprim::radix_sort_pairs(temp, bytes, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 0, 8 * sizeof(Key), s));
+      bytes = temp_bytes;
+      GM_HIP(rocprim::radix_sort_pairs(temp, bytes, keys_b, keys_a, pay_b, pay_a, (size_t)cells, 0, label_bits, s));
+      sorted_keys = keys_a;
+      sorted_pay = pay_a;
+    } else {
+      GM_HIP(rocprim::radix_sort_pairs(temp, bytes, keys_a, keys_b, pay_a, pay_b, (size_t)cells, 0, label_bits, s));
+      sorted_keys = keys_b;
+      sorted_pay = pay_b;
+    }
+    hipLaunchKernelGGL(zonal_bounds_kernel, dim3((n_labels + 1 + 255) / 256), dim3(256), 0, s, sorted_keys, (unsigned)cells, n_labels, first);
+    float* out_f = out + (size_t)f * n_labels;
+    long long* counts_f = counts + (size_t)f * n_labels;
+    if (statistic == Z_SUM || statistic == Z_MEAN)
+      hipLaunchKernelGGL(zonal_sum_kernel<T>, dim3((unsigned)(((size_t)n_labels * 64 + 255) / 256)), dim3(256), 0, s, sorted_pay, first,
+                         n_labels, statistic, out_f, counts_f);
+    else
+      hipLaunchKernelGGL(zonal_pick_kernel<T>, dim3((n_labels + 255) / 256), dim3(256), 0, s, sorted_pay, first, n_labels, statistic,
+                         qval, out_f, counts_f);
+    GM_HIP(hipGetLastError());
+  }
+  // the scratch buffers go back to the pool: the pool is stream-ordered like every other buffer of this library
+  return GM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gm_zonal_statistic(const void* values, int dtype, int64_t frames, int64_t cells, int has_ndv, uint64_t ndv_bits,
+                       const int32_t* labels, int32_t n_labels, const float* thresholds, int statistic, double percentile,
+                       float* out, int64_t* counts, uint8_t* present) {
+  if (!values || !labels || !out || !counts) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (frames < 0 || cells < 0 || n_labels < 0) return gm::fail(GM_ERR_INVALID, "negative extent");
+  if (statistic < Z_SUM || statistic > Z_PERCENTILE) return gm::fail(GM_ERR_INVALID, "gm_zonal_statistic: statistic %d", statistic);
+  if (statistic == Z_PERCENTILE && !(percentile >= 0.0 && percentile <= 100.0))
+    return gm::fail(GM_ERR_INVALID, "gm_zonal_statistic: percentile %g", percentile);
+  if (statistic == Z_PERCENTILE && dtype == GM_BOOL)
+    return gm::fail(GM_ERR_UNSUPPORTED, "gm_zonal_statistic: percentile of a boolean raster (NumPy has no boolean subtraction)");
+  if (cells >= (int64_t)1 << 31) return gm::fail(GM_ERR_UNSUPPORTED, "gm_zonal_statistic: %lld cells (fewer than 2^31)", (long long)cells);
+  if (n_labels == INT32_MAX) return gm::fail(GM_ERR_UNSUPPORTED, "gm_zonal_statistic: too many labels");
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  if (present && n_labels) GM_HIP(hipMemsetAsync(present, 0, (size_t)n_labels, s));
+  if (frames == 0 || n_labels == 0) return GM_OK;
+  if (cells == 0) {
+    // nothing is active: every label stays NaN with a count of zero
+    const size_t n = (size_t)frames * n_labels;
+    GM_HIP(hipMemsetAsync(out, 0xFF, n * sizeof(float), s));  // (all-ones is a quiet NaN)
+    GM_HIP(hipMemsetAsync(counts, 0, n * sizeof(int64_t), s));
+    return GM_OK;
+  }
+#define GM_Z(T) \
+  return zonal_run<T>(values, frames, cells, has_ndv, ndv_bits, labels, n_labels, thresholds, statistic, percentile, out, (long long*)counts, present, s)
+  switch (dtype) {
+    case GM_BOOL: case GM_U8: GM_Z(unsigned char);
+    case GM_I8: GM_Z(signed char);
+    case GM_U16: GM_Z(unsigned short);
+    case GM_I16: GM_Z(short);
+    case GM_U32: GM_Z(unsigned int);
+    case GM_I32: GM_Z(int);
+    case GM_U64: GM_Z(unsigned long long);
+    case GM_I64: GM_Z(long long);
+    case GM_F32: GM_Z(float);
+    case GM_F64: GM_Z(double);
+    default: return gm::fail(GM_ERR_INVALID, "gm_zonal_statistic: dtype %d", dtype);
+  }
+#undef GM_Z
+}
+
+}  // extern "C"

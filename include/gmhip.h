@@ -464,6 +464,35 @@ enum gm_reduce_statistic {
 int gm_reduce_stack(const void* stack, int work_dtype, int half, int64_t n, int64_t pixels, int statistic,
                     const gm_percentile_step* plan, void* out, uint64_t fill_bits);
 
+/* ==========================================================================
+ * N4: labelled (zonal) statistics -- the numeric core of geometry.AggregateRaster
+ * (geometry/aggregate.py:160-203, the loop over frames inside aggregate_polygons).
+ *
+ *   values  : frames x cells raster values (device), dtype any gm_dtype
+ *   labels  : cells int32 (device): the index of the geometry painted on each cell by
+ *             utils.rasterize_geoseries; cells outside [0, n_labels) are unlabelled (the
+ *             reference's rasterize no-data label is INT32_MAX)
+ *   thresholds : n_labels float32 (device) or NULL: a cell only counts when its label's threshold is
+ *             not NaN and value >= threshold (aggregate.py:181-184)
+ *   statistic : gm_zonal_statistic_code; percentile in [0, 100] for GM_ZONAL_PERCENTILE
+ *   out     : frames x n_labels float32 (device): what the reference assigns into `agg` -- scipy.ndimage
+ *             sum / sum of ones / minimum / maximum / mean / median resp. measurements.percentile
+ *             (measurements.py:24-134) of the label's active cells, cast to float32; NaN for a label
+ *             without an active cell
+ *   counts  : frames x n_labels int64 (device): active cells per label (the caller assigns only labels
+ *             with counts > 0, like `agg[frame_no][select_and_active] = ...`)
+ *   present : n_labels bytes (device) or NULL: 1 where the label occurs in `labels` at all
+ *             (set(select) - unique_labels are the reference's geometries_no_cells)
+ * sum and mean add the cells of a label in raster order in float64, as np.bincount does.
+ * ========================================================================== */
+enum gm_zonal_statistic_code {
+  GM_ZONAL_SUM = 0, GM_ZONAL_COUNT = 1, GM_ZONAL_MIN = 2, GM_ZONAL_MAX = 3, GM_ZONAL_MEAN = 4, GM_ZONAL_MEDIAN = 5,
+  GM_ZONAL_PERCENTILE = 6
+};
+int gm_zonal_statistic(const void* values, int dtype, int64_t frames, int64_t cells, int has_ndv, uint64_t ndv_bits,
+                       const int32_t* labels, int32_t n_labels, const float* thresholds, int statistic, double percentile,
+                       float* out, int64_t* counts, uint8_t* present);
+
 /* Cumulative.process, vals branch (temporal.py:957-1003): running sum / count inside every bin;
  * source frame j goes to output frame j - emit_first for emit_first <= j < emit_stop.
  * statistic: GM_STAT_SUM or GM_STAT_COUNT. */

@@ -891,3 +891,89 @@ def cumulative_process(process_kwargs, time_data=None, data=None):
     values = temporal_cumulative_values(data["values"], data["no_data_value"], runs, (lo, lo + int(wanted.sum())),
                                         process_kwargs["statistic"], dtype)
     return {"values": values, "no_data_value": get_dtype_max(dtype)}
+
+
+# ---------------------------------------------------------------------------------
+# N4: zonal statistics -- geometry/aggregate.py:113-203 from the label rasters on
+# ---------------------------------------------------------------------------------
+ZONAL_STATISTICS = ("sum", "count", "min", "max", "mean", "median", "percentile")
+
+
+def _labelled_sums(weights, labels, index):
+    """scipy.ndimage sum / mean over labels (``_stats``): np.bincount -- float64 accumulation cell after cell
+    in raster order.  Returns (counts, sums) for ``index``."""
+    labels = labels.ravel()
+    counts = np.bincount(labels)
+    sums = np.bincount(labels, weights=np.broadcast_to(weights, labels.shape) if np.ndim(weights) == 0 else weights.ravel())
+    return counts[index], sums[index]
+
+
+def _labelled_segments(values, labels, index):
+    """Cells sorted by (label, value) -- NumPy's order, NaN last -- and the [first, last] positions of the
+    labels of ``index`` in it (what SciPy's ``_select`` and measurements.percentile build with lexsort)."""
+    order = np.lexsort((values.ravel(), labels.ravel()))
+    values, labels = values.ravel()[order], labels.ravel()[order]
+    first = np.searchsorted(labels, index, side="left")
+    last = np.searchsorted(labels, index, side="right") - 1
+    return values, first, last
+
+
+def zonal_label_statistic(values, labels, index, statistic, percentile=None):
+    """The statistic of the 1-D ``values`` per label of ``index`` (every one of them occurs in ``labels``),
+    as the reference's STATISTICS table computes it (aggregate.py:311-319): scipy.ndimage.sum (of ones for
+    "count"), minimum, maximum, mean, median, or measurements.percentile (measurements.py:24-134)."""
+    index = np.asarray(index, dtype=np.int64)
+    if statistic in ("sum", "count", "mean"):
+        counts, sums = _labelled_sums(1 if statistic == "count" else values, labels, index)
+        return sums / counts.astype(np.float64) if statistic == "mean" else sums
+    values, first, last = _labelled_segments(values, labels, index)
+    if statistic == "min":
+        return values[first]
+    if statistic == "max":
+        return values[last]
+    if statistic == "median":
+        step = (last - first) // 2
+        low, high = values[first + step], values[last - step]
+        if values.dtype.kind in "iub":  # (integers and booleans are averaged in float64)
+            return (low.astype("d") + high.astype("d")) / 2.0
+        return (low + high) / 2.0
+    if statistic == "percentile":
+        size = last - first + 1
+        frac = (size - 1) * (percentile / 100)
+        high = first - np.int64(-frac // 1)
+        low = first + np.int64(frac // 1)
+        part = frac % 1
+        return values[low] + part * (values[high] - values[low])  # (the difference in the raster's dtype)
+    raise KeyError(statistic)
+
+
+def aggregate_labelled(label_rasters, n_geometries, values, no_data_value, threshold_values, statistic, percentile=None):
+    """aggregate_polygons (aggregate.py:113-203) with the rasterization taken out: ``label_rasters`` is the
+    sequence of (select, labels) the reference obtains per bucket from utils.rasterize_geoseries (int32
+    geometry indices, INT32_MAX where no geometry of the bucket covers the cell)."""
+    label_ndv = np.iinfo(np.int32).max
+    if threshold_values is not None:
+        threshold_values = np.concatenate([threshold_values, np.array([np.nan], dtype=threshold_values.dtype)])
+    agg = np.full((values.shape[0], n_geometries), np.nan, dtype="f4")
+    no_cells = set()
+    for select, labels in label_rasters:
+        covered = set(np.unique(labels[labels != label_ndv]).tolist())
+        no_cells |= set(select) - covered
+        if not covered:
+            continue
+        thresholds = None if threshold_values is None else np.take(threshold_values, labels, mode="clip")
+        for frame_no, frame in enumerate(values):
+            active = frame != no_data_value
+            if thresholds is not None:
+                valid = ~np.isnan(thresholds)
+                active[~valid] = False
+                active[valid] &= frame[valid] >= thresholds[valid]
+            if not active.any():
+                continue
+            active_labels = labels[active]
+            chosen = sorted(set(np.unique(active_labels).tolist()) & set(select))
+            if not chosen:
+                continue
+            with np.errstate(all="ignore"):
+                agg[frame_no][chosen] = zonal_label_statistic(frame[active], active_labels, chosen, statistic, percentile)
+    return agg, sorted(no_cells)

@@ -1077,13 +1077,115 @@ def gen_temporal(w):
                            dict(block_args=[stat, freq, tz]))
 
 
+# --------------------------------------------------------------------------
+# family: zonal  (reference: geometry/aggregate.py:113-203 aggregate_polygons) -- the real function with the
+# real scipy.ndimage / measurements.percentile; only the rasterization (GDAL, absent here) is replaced: the
+# "geometries" are masks, and utils.rasterize_geoseries paints the masks of the requested bucket in order
+# --------------------------------------------------------------------------
+class MaskGeometries:
+    """Stand-in for the GeoSeries aggregate_polygons receives: a list of boolean masks (the cells GDAL would
+    paint for each polygon).  Supports exactly what the function uses: len(), .bounds.values, .iloc[select]."""
+
+    def __init__(self, masks, picked=None):
+        self.masks, self.picked = masks, picked
+
+    def __len__(self):
+        return len(self.masks)
+
+    @property
+    def bounds(self):
+        boxes = []
+        for m in self.masks:
+            ys, xs = np.nonzero(m)
+            if len(ys) == 0:  # a polygon too small to cover a cell centre: a sliver of a bbox
+                boxes.append((0.25, 0.25, 0.3, 0.3))
+            else:
+                h = m.shape[0]
+                boxes.append((float(xs.min()), float(h - 1 - ys.max()), float(xs.max() + 1), float(h - ys.min())))
+        return type("Bounds", (), {"values": np.array(boxes, dtype="f8")})()
+
+    @property
+    def iloc(self):
+        outer = self
+        return type("ILoc", (), {"__getitem__": lambda _, select: MaskGeometries(outer.masks, list(select))})()
+
+
+def gen_zonal(w):
+    from dask_geomodeling.geometry import aggregate as R_agg
+    rng = np.random.default_rng(733)
+    label_ndv = np.iinfo(np.int32).max
+    painted = []
+
+    def rasterize(geoseries, bbox, projection, height, width, values=None):
+        labels = np.full((1, height, width), label_ndv, dtype=np.int32)
+        for index in geoseries.picked:
+            labels[0][geoseries.masks[index]] = index
+        painted.append(([int(i) for i in geoseries.picked], labels[0].copy()))
+        return {"values": labels, "no_data_value": label_ndv}
+
+    R_agg.utils.rasterize_geoseries = rasterize
+    ndvs = {"f4": np.float32(F32MAX), "f8": F64MAX, "u1": np.uint8(255), "i4": -9999, "i2": np.int16(-1), "i1": np.int8(-128),
+            "i8": np.int64(-1), "u2": np.uint16(65535), "?": None}
+    cid = 0
+    h, wd = 37, 53
+    for dt in ("f4", "f8", "u1", "i1", "i2", "u2", "i4", "i8", "?"):
+        for layout in ("tiles", "overlap"):
+            n = 9
+            masks = []
+            for g in range(n):
+                m = np.zeros((h, wd), dtype=bool)
+                if layout == "tiles":   # disjoint blobs in a 3 x 3 grid: one bucket
+                    y0, x0 = (g // 3) * 12, (g % 3) * 17
+                    m[y0 + 1:y0 + 11, x0 + 1:x0 + 15] = rng.random((10, 14)) < 0.8
+                else:                   # overlapping rectangles: several buckets
+                    y0, x0 = rng.integers(0, h - 8), rng.integers(0, wd - 8)
+                    m[y0:y0 + rng.integers(1, 20), x0:x0 + rng.integers(1, 25)] = True
+                masks.append(m)
+            masks[4][:] = False  # a geometry that covers no cell
+            ndv = ndvs[dt]
+            if dt == "?":
+                values = rng.random((2, h, wd)) < 0.6
+            elif np.dtype(dt).kind == "f":
+                values = (rng.standard_normal((2, h, wd)) * 50).astype(dt)
+                values[rng.random(values.shape) < 0.05] = 0.0
+            else:
+                info = np.iinfo(dt)
+                values = rng.integers(max(info.min, -120), min(info.max, 120), size=(2, h, wd)).astype(dt)
+            if ndv is not None:
+                values[rng.random(values.shape) < 0.15] = ndv
+                values[1][masks[2]] = ndv  # a geometry without an active cell in one frame
+            thresholds = (rng.standard_normal(n) * 20).astype("f4")
+            thresholds[1] = np.nan
+            runs, buckets = [], None
+            for stat, q in (("sum", None), ("count", None), ("min", None), ("max", None), ("mean", None), ("median", None),
+                            ("percentile", 0.0), ("percentile", 37.5), ("percentile", 95.0), ("percentile", 100.0)):
+                for thr in (None, thresholds):
+                    if thr is not None and stat in ("count", "max", "percentile") and q not in (None, 37.5):
+                        continue
+                    del painted[:]
+                    run = dict(statistic=stat, percentile=q, thresholds=thr is not None)
+                    try:
+                        with np.errstate(all="ignore"):
+                            agg, no_cells = R_agg.aggregate_polygons(MaskGeometries(masks), values.copy(), ndv, (0, 0, wd, h),
+                                                                     "EPSG:28992", None if thr is None else thr.copy(), stat, q)
+                        run.update(expect=agg, no_cells=sorted(int(i) for i in no_cells))
+                    except Exception as e:  # noqa: BLE001 -- what the reference raises is part of its behaviour
+                        run.update(raises=type(e).__name__)
+                    if "expect" in run:  # (the buckets do not depend on the statistic: kept once per case)
+                        assert buckets is None or [b[0] for b in buckets] == [b[0] for b in painted]
+                        buckets = list(painted)
+                    runs.append(run)
+            w.add(id="zn%04d" % cid, n=n, values=values, no_data_value=ndv, threshold_values=thresholds, buckets=buckets, runs=runs)
+            cid += 1
+
+
 def main():
     fams = {
         "math": gen_math, "n1": gen_n1, "clip": gen_clip, "mask": gen_mask,
         "classify": gen_classify, "reclassify": gen_reclassify, "tiler": gen_tiler,
         "views": gen_views, "dtypes": gen_dtypes, "smoothzoom": gen_smoothzoom,
         "spatial": gen_spatial, "reduce": gen_reduce, "reducestats": gen_reducestats, "group": gen_group, "smooth": gen_smooth,
-        "temporal": gen_temporal,
+        "temporal": gen_temporal, "zonal": gen_zonal,
     }
     only = sys.argv[1:]
     counts = {}

@@ -1303,3 +1303,65 @@ def test_dilate_kernels_against_oracle(gpu, dt, shape):
         want = O.dilate_process({"values": v, "no_data_value": None}, values)["values"]
         got = stencil.dilate(v, values).to_numpy()
         assert got.dtype == want.dtype and np.array_equal(got, want), (dt, shape, values)
+
+
+# ---- N4: zonal statistics (AggregateRaster's numeric core) -----------------------------------------------
+def _zonal_runs():
+    for case in load_family("zonal"):
+        for run in case["runs"]:
+            yield pytest.param(case, run, id="%s-%s%s%s" % (case["id"], run["statistic"], run["percentile"] or "",
+                                                           "-thr" if run["thresholds"] else ""))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,run", list(_zonal_runs()))
+def test_zonal_golden(gpu, case, run):
+    """gm_zonal_statistic through geometry.aggregate_labelled against the results of the reference's own
+    aggregate_polygons (306 runs: 9 dtypes, disjoint and overlapping geometries = several buckets, thresholds,
+    a geometry without cells, a geometry without active cells): bit-exact, sums included."""
+    from dask_geomodeling_amd import geometry
+    thresholds = case["threshold_values"] if run["thresholds"] else None
+    args = (case["buckets"], case["n"], case["values"], case["no_data_value"], thresholds, run["statistic"], run["percentile"])
+    if "raises" in run:
+        with pytest.raises(TypeError):
+            geometry.aggregate_labelled(*args)
+        return
+    agg, no_cells = geometry.aggregate_labelled(*args)
+    assert_values_equal(agg, run["expect"], 0, case["id"])
+    assert no_cells == run["no_cells"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f4", "f8", "i4", "u1", "i8"])
+def test_zonal_large_tiles_vs_oracle(gpu, dt):
+    """A 1500 x 2000 raster, 700 labels from one cell to 400 k cells (the sequential float64 sums run over many
+    64-cell steps), NaN cells and signed zeros in the float rasters, thresholds: every statistic against the
+    oracle -- sum and mean bit for bit."""
+    from dask_geomodeling_amd import geometry
+    rng = np.random.default_rng(17)
+    h, w, n = 1500, 2000, 700
+    labels = np.full((h, w), np.iinfo(np.int32).max, dtype=np.int32)
+    labels[:, :] = (np.arange(h)[:, None] // 60) * 26 + np.arange(w)[None, :] // 80   # 25 x 25 blocks -> labels 0..649
+    labels[900:1400, 100:900] = 660                                                  # one label of 400 k cells
+    labels[5, 7] = 699                                                                # one of a single cell
+    labels[rng.random((h, w)) < 0.02] = np.iinfo(np.int32).max
+    if np.dtype(dt).kind == "f":
+        values = (rng.standard_normal((2, h, w)) * rng.choice([1e-3, 1.0, 1e4], size=(2, h, w))).astype(dt)
+        values[rng.random(values.shape) < 0.001] = np.nan
+        values[rng.random(values.shape) < 0.01] = -0.0
+        ndv = np.dtype(dt).type(-9999.0)
+    else:
+        info = np.iinfo(dt)
+        values = rng.integers(max(info.min, -30000), min(info.max, 30000), size=(2, h, w)).astype(dt)
+        ndv = np.dtype(dt).type(info.max)
+    values[rng.random(values.shape) < 0.1] = ndv
+    thresholds = (rng.standard_normal(n) * 0.5).astype("f4")
+    thresholds[3] = np.nan
+    buckets = [(list(range(n)), labels)]
+    for stat, q in (("sum", None), ("mean", None), ("count", None), ("min", None), ("max", None), ("median", None),
+                    ("percentile", 12.5), ("percentile", 50.0)):
+        for thr in (None, thresholds):
+            want, want_no = O.aggregate_labelled(buckets, n, values, ndv, thr, stat, q)
+            got, got_no = geometry.aggregate_labelled(buckets, n, values, ndv, thr, stat, q)
+            assert_values_equal(got, want, 0, "%s %s %s" % (dt, stat, q))
+            assert got_no == want_no

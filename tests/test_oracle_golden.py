@@ -296,3 +296,53 @@ def test_temporal(case):
         assert out == want, case["id"]
     else:
         assert_result_equal(out, want, 0, case["id"])
+
+
+# ---------------------------------------------------------------------------------
+# N4: zonal statistics (AggregateRaster's numeric core)
+# ---------------------------------------------------------------------------------
+def zonal_runs():
+    for case in load_family("zonal"):
+        for k, run in enumerate(case["runs"]):
+            yield pytest.param(case, run, id="%s-%s%s%s" % (case["id"], run["statistic"], run["percentile"] or "",
+                                                           "-thr" if run["thresholds"] else ""))
+
+
+@pytest.mark.parametrize("case,run", list(zonal_runs()))
+def test_zonal(case, run):
+    """The oracle's aggregate_labelled against the reference's own aggregate_polygons (real scipy.ndimage and
+    measurements.percentile; only GDAL's rasterization replaced by painted masks, tests/golden/make_golden.py):
+    the float32 result array bit for bit, the geometries without cells, and the TypeError of a boolean percentile."""
+    thresholds = case["threshold_values"] if run["thresholds"] else None
+    args = (case["buckets"], case["n"], case["values"], case["no_data_value"], thresholds, run["statistic"], run["percentile"])
+    if "raises" in run:
+        with pytest.raises(TypeError):
+            O.aggregate_labelled(*args)
+        return
+    agg, no_cells = O.aggregate_labelled(*args)
+    assert_values_equal(agg, run["expect"], 0, case["id"])
+    assert no_cells == run["no_cells"]
+
+
+def test_zonal_label_statistic_is_scipys():
+    """scipy.ndimage itself (the reference's STATISTICS table) on a larger labelled raster: long labels,
+    NaN cells, signed zeros -- sum / mean bit for bit (same bincount order), the picked statistics by value."""
+    from scipy import ndimage
+    rng = np.random.default_rng(8)
+    labels = (rng.integers(0, 40, size=(1, 1))[0, 0] + np.add.outer(np.arange(300) // 23, 13 * (np.arange(400) // 31))).astype(np.int32)
+    for dt in ("f4", "f8", "i2", "u1"):
+        values = (rng.standard_normal(labels.shape) * 1000).astype(dt)
+        if dt in ("f4", "f8"):
+            values[rng.random(labels.shape) < 0.01] = np.nan
+            values[rng.random(labels.shape) < 0.05] = -0.0
+        index = np.unique(labels)
+        for name, fn in (("sum", ndimage.sum), ("mean", ndimage.mean), ("min", ndimage.minimum), ("max", ndimage.maximum),
+                         ("median", ndimage.median)):
+            want = np.asarray(fn(values, labels=labels, index=index))
+            got = np.asarray(O.zonal_label_statistic(values.ravel(), labels.ravel(), index, name))
+            if name in ("sum", "mean"):
+                assert got.dtype == want.dtype and got.tobytes() == want.tobytes(), (dt, name)
+            else:
+                assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (dt, name)
+        want = np.asarray(ndimage.sum(1, labels=labels, index=index))
+        assert np.array_equal(O.zonal_label_statistic(values.ravel(), labels.ravel(), index, "count"), want)

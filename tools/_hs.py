@@ -13,6 +13,9 @@ for rep in range(5):
             stencil.hillshade(t, np.float32(F32MAX), 0, (0.5, 0.5), 45.0, 315.0)
         elif which.startswith("mm"):
             stencil.moving_max(t, np.float32(F32MAX), int(which[2:]))
+        elif which == "bilinear":
+            from dask_geomodeling_amd.raster import resample
+            resample.bilinear(t, 2 * side, 2 * side, np.float32(F32MAX))
         elif which.startswith("smooth"):
             stencil.gaussian_smooth(t, np.float32(F32MAX), 0, (float(which[6:]), float(which[6:])))
 runtime.sync()
