@@ -109,32 +109,40 @@ __global__ __launch_bounds__(256) void zonal_bounds_kernel(const unsigned* __res
   first[l] = lo;
 }
 
-__device__ __forceinline__ double read_lane(double x, int lane) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
 // np.bincount(labels, weights=values)[l]: sums[l] += (double)value, cell after cell in raster order.
-// One wave per label: 64 cells per load, 64 dependent additions.
+// One wave per label.  64 cells per step: a coalesced load and the conversion to float64 by all lanes, the
+// values parked in LDS, then every lane runs the same chain of 64 dependent additions on broadcast reads (the
+// wave is one sequential adder; what bounds it is the latency of v_add_f64, ~8 cycles per cell).  Cells past
+// the end of the label add +0.0, which changes nothing (the sum starts from +0.0 like bincount's zeros).
 template <typename T>
 __global__ __launch_bounds__(256) void zonal_sum_kernel(const typename Ordered<T>::Key* __restrict__ payload,
                                                         const unsigned* __restrict__ first, int n_labels, int statistic,
                                                         float* __restrict__ out, long long* __restrict__ counts) {
-  const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  __shared__ __align__(16) double parked[4][64];
+  const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (l >= n_labels) return;
   const unsigned a = first[l], b = first[l + 1];
+  double* mine = parked[wave];
   double acc = 0.0;
+  unsigned at = a + lane;
+  double next = at < b ? (double)Ordered<T>::decode(payload[at]) : 0.0;
   for (unsigned i = a; i < b; i += 64) {
-    const unsigned at = i + lane;
-    const double x = at < b ? (double)Ordered<T>::decode(payload[at]) : 0.0;
-    const unsigned m = min(64u, b - i);
-    if (m == 64u) {
+    mine[lane] = next;  // (a wave's LDS accesses complete in order: no barrier between its own write and reads)
+    at += 64;
+    next = at < b ? (double)Ordered<T>::decode(payload[at]) : 0.0;  // the next step's cells, in flight during the chain
+    // all 32 LDS reads first (128 registers), then the chain: left to itself the compiler keeps three reads
+    // in flight and the chain waits for LDS every second addition
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 cell[32];
 #pragma unroll
-      for (int k = 0; k < 64; ++k) acc += read_lane(x, k);
-    } else {
-      for (unsigned k = 0; k < m; ++k) acc += read_lane(x, (int)k);
+    for (int k = 0; k < 32; ++k) cell[k] = *reinterpret_cast<const f64x2*>(mine + 2 * k);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      acc += cell[k].x;
+      acc += cell[k].y;
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (lane == 0) {
     const unsigned n = b - a;

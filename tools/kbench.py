@@ -32,7 +32,7 @@ def timeit(label, bytes_per_call, calls, reps=3):
 
 
 def main():
-    which = [a for a in sys.argv[1:] if "=" not in a] or ["reclass", "classify", "mask", "bilinear", "nearest", "stencil", "temporal"]
+    which = [a for a in sys.argv[1:] if "=" not in a] or ["reclass", "classify", "mask", "bilinear", "nearest", "stencil", "temporal", "zonal"]
     opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
     side = int(opts.get("side", 8192))
     runtime.set_device(0)
@@ -141,6 +141,38 @@ def main():
         half = side // 2
         timeit("nearest warp f32 window, quarter (8 B/out px)", 8.0 * n / 4,
                [lambda t=t: resample.nearest_warp(t, gt, (100.0, 100.0, 100.0 + half, 100.0 + half), half, half, F32MAX) for t in src])
+
+    if "zonal" in which:
+        # AggregateRaster's numeric core on the reference's default raster limit (12 * 1024^2 cells): 8 B/cell
+        # algorithmic (value + label); device-resident raster and labels, results copied back (as the caller needs them)
+        import time
+        from dask_geomodeling_amd import geometry
+        from dask_geomodeling_amd.hip.array import DeviceArray
+        h, w = 3072, 4096
+        rng = np.random.default_rng(5)
+        values = (rng.standard_normal((1, h, w)) * 100).astype("f4")
+        values[rng.random(values.shape) < 0.1] = -9999.0
+        blocks = ((np.arange(h)[:, None] // 96) * 32 + np.arange(w)[None, :] // 128).astype(np.int32)  # 1024 labels of 12 k cells
+        one = np.zeros((h, w), dtype=np.int32)                                                       # one label of 12.6 M cells
+        dev_values = DeviceArray.from_numpy(values)
+        for name, labels, n_labels in (("1024 labels", blocks, 1024), ("1 label", one, 1)):
+            dev_labels = DeviceArray.from_numpy(labels)
+            for stat, q in (("sum", None), ("mean", None), ("count", None), ("max", None), ("median", None), ("percentile", 95.0)):
+                geometry.label_statistics(dev_values, np.float32(-9999.0), dev_labels, n_labels, stat, q)
+                runtime.sync()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    geometry.label_statistics(dev_values, np.float32(-9999.0), dev_labels, n_labels, stat, q)
+                us = (time.perf_counter() - t0) / 3 * 1e6
+                print("zonal %-10s f32 %d x %d, %-12s %9.1f us  %7.1f GB/s" % (stat + ("" if q is None else str(q)), h, w, name, us, 8.0 * h * w / us / 1e3), flush=True)
+        if opts.get("cpu", "1") == "1":
+            from scipy import ndimage
+            frame = values[0]
+            active = frame != np.float32(-9999.0)
+            for stat, fn in (("sum", ndimage.sum), ("median", ndimage.median)):
+                t0 = time.perf_counter()
+                fn(frame[active], labels=blocks[active], index=np.arange(1024))
+                print("  scipy.ndimage.%s on the host, 1024 labels: %.1f ms" % (stat, (time.perf_counter() - t0) * 1e3), flush=True)
 
 
 if __name__ == "__main__":
