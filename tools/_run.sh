@@ -1,4 +1,2 @@
 #!/bin/bash
-python -m pytest tests/test_gpu_parity.py -x -q -k "hillshade or stencil" 2>&1 | tail -2
-python tests/stencil_stress.py 2>&1 | tail -1
-python tools/kbench.py stencil 2>&1 | grep -i "hillshade"
+tools/gpu_profile.sh r02 mosaic --steps 5 --warmup 2 2>&1 | tail -4
