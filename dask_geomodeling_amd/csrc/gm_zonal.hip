@@ -14,10 +14,10 @@
 //   * sum / mean: one wave per label loads 64 cells at a time and adds them one after the other in float64
 //     (the bincount order; the chain of dependent additions is the price of bit-exactness -- a label of
 //     10 M cells takes as long as it does on a CPU core, thousands of labels run side by side);
-//   * count: the length of the label's segment;
-//   * min / max / median / percentile: a lane per label picks from its sorted segment and combines exactly
-//     as SciPy / measurements.percentile do (median of integers in float64, of float32 in float32; the
-//     percentile's difference in the raster's own dtype, wrap-around included).
+//   * median / percentile: a lane per label picks from its sorted segment and combines exactly as SciPy /
+//     measurements.percentile do (median of integers in float64, of float32 in float32; the percentile's
+//     difference in the raster's own dtype, wrap-around included).
+// count, min and max do not depend on the order: they take one pass of atomics (zonal_direct_kernel) and no sort.
 // Results are float32 like the reference's `agg` array; labels without an active cell stay NaN.
 // HBM traffic: dominated by the sort passes (each moves keys + payload twice), ~40-100 bytes per cell.
 #include <rocprim/device/device_radix_sort.hpp>
@@ -194,6 +194,107 @@ __global__ __launch_bounds__(256) void zonal_pick_kernel(const typename Ordered<
   out[l] = result;
 }
 
+// count / min / max need no order at all: one pass of atomics on the per-label counters and on the ordered
+// keys (the smallest key is the minimum with NaN last -- NaN only if every cell is; the largest key is the
+// maximum -- NaN if any cell is: exactly the first / last cell of the sorted segment).  Label rasters are
+// made of runs: a wave walks a contiguous stretch of cells and, as long as the 64 cells of a step carry one label
+// (the usual case), only accumulates per lane; when the label changes it reduces across its lanes once and issues
+// one atomic per quantity.  Steps that straddle a label boundary fall back to one atomic per cell.
+template <typename T, int STAT>
+__global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
+                                                           size_t cells_per_wave, int n_labels, int has_ndv, T ndv,
+                                                           const float* __restrict__ thresholds,
+                                                           unsigned long long* __restrict__ counts,
+                                                           typename Ordered<T>::Key* __restrict__ extreme,
+                                                           unsigned char* __restrict__ present) {
+  typedef typename Ordered<T>::Key Key;
+  constexpr Key NEUTRAL = STAT == Z_MIN ? ~(Key)0 : (Key)0;
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const size_t begin = wave * cells_per_wave, end = min(begin + cells_per_wave, cells);  // (cells_per_wave: a multiple of 64)
+  // the run the wave is in: its label (wave-uniform), and per lane the cells counted / the extreme key so far
+  int run_label = -1;
+  unsigned run_count = 0;
+  Key run_key = NEUTRAL;
+  auto better = [](Key a, Key b) -> Key { return STAT == Z_MIN ? (b < a ? b : a) : (b > a ? b : a); };
+  auto flush = [&]() {  // (wave-uniform call)
+    if (run_label < 0) return;
+    unsigned long long n = run_count;
+    Key key = run_key;
+#pragma unroll
+    for (int offset = 32; offset >= 1; offset >>= 1) {
+      n += __shfl_xor((unsigned)n, offset);  // (fewer than 2^32 cells)
+      if constexpr (STAT != Z_COUNT) {
+        Key other;
+        if constexpr (sizeof(Key) == 8) {
+          const unsigned lo = __shfl_xor((unsigned)key, offset), hi = __shfl_xor((unsigned)(key >> 32), offset);
+          other = ((Key)hi << 32) | lo;
+        } else {
+          other = __shfl_xor(key, offset);
+        }
+        key = better(key, other);
+      }
+    }
+    if (lane == 0 && n != 0) {
+      atomicAdd(&counts[run_label], n);
+      if constexpr (STAT == Z_MIN) atomicMin(&extreme[run_label], key);
+      if constexpr (STAT == Z_MAX) atomicMax(&extreme[run_label], key);
+    }
+    run_label = -1;
+    run_count = 0;
+    run_key = NEUTRAL;
+  };
+  for (size_t i = begin + lane; i < end + lane; i += 64) {  // (whole waves enter every step)
+    if (i - lane >= end) break;
+    const bool inside = i < end;
+    const T v = inside ? values[i] : T(0);
+    const int label = inside ? labels[i] : -1;
+    const bool labelled = (unsigned)label < (unsigned)n_labels;
+    if (present && labelled) present[label] = 1;
+    bool active = labelled && !(has_ndv && v == ndv);
+    if (thresholds && active) {
+      const float t = thresholds[label];
+      active = !(t != t) && (double)v >= (double)t;
+    }
+    const unsigned long long mask = __ballot(active);
+    if (mask == 0) continue;  // (wave-uniform)
+    const int leader_label = __shfl(label, __ffsll((long long)mask) - 1);
+    const Key key = Ordered<T>::encode(v);
+    if (__all(!active || label == leader_label)) {
+      // one label among the active cells of this step: it joins the wave's run, no traffic between lanes
+      if (leader_label != run_label) {
+        flush();
+        run_label = leader_label;
+      }
+      if (active) {
+        run_count += 1;
+        run_key = better(run_key, key);
+      }
+    } else if (active) {  // (a step across a label boundary: every lane for itself)
+      atomicAdd(&counts[label], 1ull);
+      if constexpr (STAT == Z_MIN) atomicMin(&extreme[label], key);
+      if constexpr (STAT == Z_MAX) atomicMax(&extreme[label], key);
+    }
+  }
+  flush();
+}
+
+template <typename T, int STAT>
+__global__ __launch_bounds__(256) void zonal_direct_result_kernel(const unsigned long long* __restrict__ tally,
+                                                                  const typename Ordered<T>::Key* __restrict__ extreme, int n_labels,
+                                                                  float* __restrict__ out, long long* __restrict__ counts) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= n_labels) return;
+  const unsigned long long n = tally[l];
+  counts[l] = (long long)n;
+  float result = std::numeric_limits<float>::quiet_NaN();
+  if (n != 0) {
+    if constexpr (STAT == Z_COUNT) result = (float)(double)n;
+    else result = (float)Ordered<T>::decode(extreme[l]);
+  }
+  out[l] = result;
+}
+
 template <typename T>
 T scalar_from_bits(uint64_t bits) {
   gm_scalar s;
@@ -224,6 +325,37 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   const T* values = (const T*)values_v;
   const T ndv = scalar_from_bits<T>(ndv_bits);
   Scratch scratch;
+  if (statistic == Z_COUNT || statistic == Z_MIN || statistic == Z_MAX) {
+    unsigned long long* tally;
+    Key* extreme;
+    int rc;
+    if ((rc = scratch.take((void**)&tally, sizeof(unsigned long long) * n_labels))) return rc;
+    if ((rc = scratch.take((void**)&extreme, sizeof(Key) * n_labels))) return rc;
+    // every wave walks one contiguous stretch of cells (label runs continue from step to step)
+    const int64_t waves = std::max<int64_t>(1, std::min<int64_t>((cells + 4095) / 4096, (int64_t)gm::current_cu_count() * 32));
+    const size_t cells_per_wave = (size_t)(((cells + waves - 1) / waves + 63) / 64 * 64);
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    for (int64_t f = 0; f < frames; ++f) {
+      GM_HIP(hipMemsetAsync(tally, 0, sizeof(unsigned long long) * n_labels, s));
+      GM_HIP(hipMemsetAsync(extreme, statistic == Z_MIN ? 0xFF : 0, sizeof(Key) * n_labels, s));
+      unsigned char* seen = f == 0 ? present : (unsigned char*)nullptr;
+      float* out_f = out + (size_t)f * n_labels;
+      long long* counts_f = counts + (size_t)f * n_labels;
+#define GM_ZD(STAT)                                                                                                        \
+  do {                                                                                                                     \
+    hipLaunchKernelGGL((zonal_direct_kernel<T, STAT>), dim3(blocks), dim3(256), 0, s, values + (size_t)f * cells, labels,  \
+                       (size_t)cells, cells_per_wave, n_labels, has_ndv, ndv, thresholds, tally, extreme, seen);          \
+    hipLaunchKernelGGL((zonal_direct_result_kernel<T, STAT>), dim3((n_labels + 255) / 256), dim3(256), 0, s, tally, extreme, \
+                       n_labels, out_f, counts_f);                                                                        \
+  } while (0)
+      if (statistic == Z_COUNT) GM_ZD(Z_COUNT);
+      else if (statistic == Z_MIN) GM_ZD(Z_MIN);
+      else GM_ZD(Z_MAX);
+#undef GM_ZD
+      GM_HIP(hipGetLastError());
+    }
+    return GM_OK;
+  }
   unsigned *keys_a, *keys_b, *first;
   Key *pay_a, *pay_b;
   int rc;
@@ -232,7 +364,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   if ((rc = scratch.take((void**)&pay_a, sizeof(Key) * cells))) return rc;
   if ((rc = scratch.take((void**)&pay_b, sizeof(Key) * cells))) return rc;
   if ((rc = scratch.take((void**)&first, sizeof(unsigned) * ((size_t)n_labels + 2)))) return rc;
-  const bool by_value = statistic == Z_MIN || statistic == Z_MAX || statistic == Z_MEDIAN || statistic == Z_PERCENTILE;
+  const bool by_value = statistic == Z_MEDIAN || statistic == Z_PERCENTILE;
   unsigned label_bits = 1;
   while ((1ull << label_bits) <= (unsigned long long)n_labels) ++label_bits;
   size_t temp_value = 0, temp_label = 0;

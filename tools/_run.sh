@@ -1,2 +1,3 @@
 #!/bin/bash
-tools/gpu_profile.sh r02 mosaic --steps 5 --warmup 2 2>&1 | tail -4
+python -m pytest tests/test_gpu_parity.py -x -q -k "zonal" 2>&1 | tail -2
+python tools/kbench.py zonal cpu=0 2>&1 | grep -E "count|max"
