@@ -1,12 +1,12 @@
 #!/bin/bash
-# tools/_pmc.sh <which>  : kernel durations + SQ counters of tools/_hs.py <which>
+# tools/pmc_stencil.sh <which>  : kernel durations + SQ counters of tools/stencil_driver.py <which>
 W=$1
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/k_*
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/k_trace -o k -- python3 $R/tools/_hs.py $W > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $R/gpurun_out/k_pmc -o k -- python3 $R/tools/_hs.py $W > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INST_CYCLES_VMEM --output-format csv -d $R/gpurun_out/k_pmc2 -o k -- python3 $R/tools/_hs.py $W > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/k_trace -o k -- python3 $R/tools/stencil_driver.py $W > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $R/gpurun_out/k_pmc -o k -- python3 $R/tools/stencil_driver.py $W > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INST_CYCLES_VMEM --output-format csv -d $R/gpurun_out/k_pmc2 -o k -- python3 $R/tools/stencil_driver.py $W > /dev/null 2>&1
 cd $R
 python3 - <<'PY'
 import csv, glob, collections
