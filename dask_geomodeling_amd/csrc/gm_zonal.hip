@@ -23,7 +23,9 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <vector>
 #include <limits>
 #include <type_traits>
 
@@ -295,6 +297,175 @@ __global__ __launch_bounds__(256) void zonal_direct_result_kernel(const unsigned
   out[l] = result;
 }
 
+// sum / mean without the sort, when the order cannot matter.  Every partial sum of a label's cells -- in ANY
+// order -- is a multiple of 2^lo (lo = the lowest set bit among the cells) and smaller than count * 2^(hi + 1)
+// (hi = the highest exponent): if hi + 1 + ceil(log2(count)) - lo <= 53 all of them are exactly representable in
+// float64, bincount's sequential sum rounds nowhere, and a parallel sum gives the same bits.  Integer rasters and
+// data on a dyadic grid qualify (class maps, masks, counts, centimetres as integers); data that spans many octaves
+// does not and keeps the sorted, sequential path.  PHASE 0 gathers count / hi / lo per label, PHASE 1 adds.
+struct ExactRange {
+  unsigned long long count;
+  int hi, lo;       // top exponent / exponent of the lowest set bit over the non-zero cells
+  unsigned bad;     // a NaN or an infinity among the cells
+};
+__device__ __forceinline__ void exponent_span(double x, int* top, int* low) {  // x finite, not zero
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+  const int e = (int)((bits >> 52) & 0x7ff);
+  unsigned long long mant = bits & ((1ull << 52) - 1);
+  if (e != 0) mant |= 1ull << 52;
+  const int base = (e != 0 ? e : 1) - 1075;  // value = mant * 2^base
+  *top = base + 63 - __clzll((long long)mant);
+  *low = base + __ffsll((long long)mant) - 1;
+}
+__device__ __forceinline__ double shuffle_xor(double x, int offset) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = __shfl_xor((unsigned)u, offset), hi = __shfl_xor((unsigned)(u >> 32), offset);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <typename T, int PHASE>
+__global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
+                                                          size_t cells_per_wave, int n_labels, int has_ndv, T ndv,
+                                                          const float* __restrict__ thresholds, ExactRange* __restrict__ range,
+                                                          double* __restrict__ sums, unsigned char* __restrict__ present,
+                                                          unsigned* __restrict__ keys, typename Ordered<T>::Key* __restrict__ payload) {
+  // (PHASE 0 also writes the sort keys of zonal_keys_kernel: if the order turns out to matter the sort can start at once)
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const size_t begin = wave * cells_per_wave, end = min(begin + cells_per_wave, cells);
+  int run_label = -1;  // the run the wave is in (wave-uniform); per lane what it has gathered for it
+  unsigned run_count = 0, run_bad = 0;
+  int run_hi = INT_MIN, run_lo = INT_MAX;
+  double run_sum = 0.0;
+  auto flush = [&]() {  // (wave-uniform call)
+    if (run_label < 0) return;
+    if constexpr (PHASE == 0) {
+      unsigned n = run_count, bad = run_bad;
+      int hi = run_hi, lo = run_lo;
+#pragma unroll
+      for (int offset = 32; offset >= 1; offset >>= 1) {
+        n += __shfl_xor(n, offset);
+        bad |= __shfl_xor(bad, offset);
+        hi = max(hi, __shfl_xor(hi, offset));
+        lo = min(lo, __shfl_xor(lo, offset));
+      }
+      if (lane == 0 && n != 0) {
+        ExactRange* slot = range + run_label;
+        atomicAdd(&slot->count, (unsigned long long)n);
+        atomicMax(&slot->hi, hi);
+        atomicMin(&slot->lo, lo);
+        if (bad) atomicOr(&slot->bad, 1u);
+      }
+    } else {
+      double total = run_sum;
+#pragma unroll
+      for (int offset = 32; offset >= 1; offset >>= 1) total += shuffle_xor(total, offset);  // (exact: see above)
+      if (lane == 0) atomicAdd(&sums[run_label], total);
+    }
+    run_label = -1;
+    run_count = run_bad = 0;
+    run_hi = INT_MIN;
+    run_lo = INT_MAX;
+    run_sum = 0.0;
+  };
+  auto take = [&](int label, double x) {  // one active cell outside a run: straight to the label's slot
+    if constexpr (PHASE == 0) {
+      ExactRange* slot = range + label;
+      atomicAdd(&slot->count, 1ull);
+      if (!(fabs(x) <= 1.7976931348623157e308)) {
+        atomicOr(&slot->bad, 1u);
+      } else if (x != 0.0) {
+        int top, low;
+        exponent_span(x, &top, &low);
+        atomicMax(&slot->hi, top);
+        atomicMin(&slot->lo, low);
+      }
+    } else {
+      atomicAdd(&sums[label], x);
+    }
+  };
+  for (size_t i = begin + lane; i - lane < end; i += 64) {  // (whole waves enter every step)
+    const bool inside = i < end;
+    const T v = inside ? values[i] : T(0);
+    const int label = inside ? labels[i] : -1;
+    const bool labelled = (unsigned)label < (unsigned)n_labels;
+    if (PHASE == 0 && present && labelled) present[label] = 1;
+    bool active = labelled && !(has_ndv && v == ndv);
+    if (thresholds && active) {
+      const float t = thresholds[label];
+      active = !(t != t) && (double)v >= (double)t;
+    }
+    if constexpr (PHASE == 0) {
+      if (keys && inside) {
+        keys[i] = active ? (unsigned)label : (unsigned)n_labels;
+        payload[i] = Ordered<T>::encode(v);
+      }
+    }
+    const unsigned long long mask = __ballot(active);
+    if (mask == 0) continue;  // (wave-uniform)
+    const int leader_label = __shfl(label, __ffsll((long long)mask) - 1);
+    const double x = (double)v;  // what bincount adds
+    if (__all(!active || label == leader_label)) {
+      if (leader_label != run_label) {
+        flush();
+        run_label = leader_label;
+      }
+      if (active) {
+        if constexpr (PHASE == 0) {
+          run_count += 1;
+          if (!(fabs(x) <= 1.7976931348623157e308)) {
+            run_bad = 1;
+          } else if (x != 0.0) {
+            int top, low;
+            exponent_span(x, &top, &low);
+            run_hi = max(run_hi, top);
+            run_lo = min(run_lo, low);
+          }
+        } else {
+          run_sum += x;
+        }
+      }
+    } else if (active) {
+      take(label, x);
+    }
+  }
+  flush();
+}
+
+__global__ __launch_bounds__(256) void zonal_exact_init_kernel(ExactRange* __restrict__ range, double* __restrict__ sums, int n_labels,
+                                                               unsigned* __restrict__ inexact) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l == 0) *inexact = 0;
+  if (l >= n_labels) return;
+  range[l] = ExactRange{0ull, INT_MIN, INT_MAX, 0u};
+  sums[l] = 0.0;
+}
+
+// per label: can the order matter?  `inexact` counts the labels for which it can.
+__global__ __launch_bounds__(256) void zonal_exact_decide_kernel(const ExactRange* __restrict__ range, int n_labels,
+                                                                 unsigned* __restrict__ inexact) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= n_labels) return;
+  const ExactRange r = range[l];
+  bool exact = !r.bad;
+  if (exact && r.count != 0 && r.hi != INT_MIN) {
+    const int growth = r.count <= 1 ? 0 : 64 - __clzll((long long)(r.count - 1));  // ceil(log2(count))
+    const int top = r.hi + 1 + growth;
+    exact = top - r.lo <= 53 && top < 1023;
+  }
+  if (!exact) atomicAdd(inexact, 1u);
+}
+
+__global__ __launch_bounds__(256) void zonal_exact_result_kernel(const ExactRange* __restrict__ range, const double* __restrict__ sums,
+                                                                 int n_labels, int statistic, float* __restrict__ out,
+                                                                 long long* __restrict__ counts) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= n_labels) return;
+  const unsigned long long n = range[l].count;
+  counts[l] = (long long)n;
+  const double total = sums[l];
+  out[l] = n == 0 ? std::numeric_limits<float>::quiet_NaN() : (statistic == Z_MEAN ? (float)(total / (double)n) : (float)total);
+}
+
 template <typename T>
 T scalar_from_bits(uint64_t bits) {
   gm_scalar s;
@@ -305,9 +476,10 @@ T scalar_from_bits(uint64_t bits) {
 }
 
 struct Scratch {  // device buffers of one call, returned to the pool on every exit path
-  void* p[8] = {nullptr};
+  void* p[16] = {nullptr};
   int n = 0;
   int take(void** out, size_t bytes) {
+    if (n == 16) return gm::fail(GM_ERR_INVALID, "gm_zonal_statistic: scratch table full");
     const int rc = gm_malloc(out, bytes ? bytes : 1);
     if (rc == GM_OK) p[n++] = *out;
     return rc;
@@ -356,28 +528,71 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     }
     return GM_OK;
   }
-  unsigned *keys_a, *keys_b, *first;
-  Key *pay_a, *pay_b;
-  int rc;
-  if ((rc = scratch.take((void**)&keys_a, sizeof(unsigned) * cells))) return rc;
-  if ((rc = scratch.take((void**)&keys_b, sizeof(unsigned) * cells))) return rc;
-  if ((rc = scratch.take((void**)&pay_a, sizeof(Key) * cells))) return rc;
-  if ((rc = scratch.take((void**)&pay_b, sizeof(Key) * cells))) return rc;
-  if ((rc = scratch.take((void**)&first, sizeof(unsigned) * ((size_t)n_labels + 2)))) return rc;
   const bool by_value = statistic == Z_MEDIAN || statistic == Z_PERCENTILE;
+  // every wave of the direct kernels walks one contiguous stretch of cells
+  const int64_t waves = std::max<int64_t>(1, std::min<int64_t>((cells + 4095) / 4096, (int64_t)gm::current_cu_count() * 32));
+  const size_t cells_per_wave = (size_t)(((cells + waves - 1) / waves + 63) / 64 * 64);
+  const unsigned direct_blocks = (unsigned)((waves + 3) / 4);
+  int rc;
+  ExactRange* range = nullptr;
+  double* sums = nullptr;
+  unsigned* inexact = nullptr;
+  if (!by_value && !getenv("GM_ZONAL_SORTED")) {
+    if ((rc = scratch.take((void**)&range, sizeof(ExactRange) * n_labels))) return rc;
+    if ((rc = scratch.take((void**)&sums, sizeof(double) * n_labels))) return rc;
+    if ((rc = scratch.take((void**)&inexact, sizeof(unsigned)))) return rc;
+  }
+  unsigned *keys_a = nullptr, *keys_b = nullptr, *first = nullptr;
+  Key *pay_a = nullptr, *pay_b = nullptr;
+  void* temp = nullptr;
+  size_t temp_bytes = 0;
   unsigned label_bits = 1;
   while ((1ull << label_bits) <= (unsigned long long)n_labels) ++label_bits;
-  size_t temp_value = 0, temp_label = 0;
-  if (by_value)
-    GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_value, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 0, 8 * sizeof(Key), s));
-  GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_label, keys_a, keys_b, pay_a, pay_b, (size_t)cells, 0, label_bits, s));
-  void* temp;
-  const size_t temp_bytes = temp_value > temp_label ? temp_value : temp_label;
-  if ((rc = scratch.take(&temp, temp_bytes))) return rc;
   const unsigned blocks = (unsigned)std::min<int64_t>((cells + 255) / 256, (int64_t)gm::current_cu_count() * 32);
   for (int64_t f = 0; f < frames; ++f) {
-    hipLaunchKernelGGL(zonal_keys_kernel<T>, dim3(blocks), dim3(256), 0, s, values + (size_t)f * cells, labels, (size_t)cells,
-                       n_labels, has_ndv, ndv, thresholds, keys_a, pay_a, f == 0 ? present : (unsigned char*)nullptr);
+    const T* frame = values + (size_t)f * cells;
+    float* out_f = out + (size_t)f * n_labels;
+    long long* counts_f = counts + (size_t)f * n_labels;
+    unsigned char* seen = f == 0 ? present : (unsigned char*)nullptr;
+    auto sort_buffers = [&]() -> int {
+      if (keys_a) return GM_OK;
+      int rc2;
+      if ((rc2 = scratch.take((void**)&keys_a, sizeof(unsigned) * cells))) return rc2;
+      if ((rc2 = scratch.take((void**)&keys_b, sizeof(unsigned) * cells))) return rc2;
+      if ((rc2 = scratch.take((void**)&pay_a, sizeof(Key) * cells))) return rc2;
+      if ((rc2 = scratch.take((void**)&pay_b, sizeof(Key) * cells))) return rc2;
+      if ((rc2 = scratch.take((void**)&first, sizeof(unsigned) * ((size_t)n_labels + 2)))) return rc2;
+      size_t temp_value = 0, temp_label = 0;
+      if (by_value)
+        GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_value, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 0, 8 * sizeof(Key), s));
+      GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_label, keys_a, keys_b, pay_a, pay_b, (size_t)cells, 0, label_bits, s));
+      temp_bytes = temp_value > temp_label ? temp_value : temp_label;
+      return scratch.take(&temp, temp_bytes);
+    };
+    if ((rc = sort_buffers())) return rc;
+    bool keys_written = false;
+    if (range) {
+      hipLaunchKernelGGL(zonal_exact_init_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, inexact);
+      hipLaunchKernelGGL((zonal_exact_kernel<T, 0>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells, cells_per_wave,
+                         n_labels, has_ndv, ndv, thresholds, range, sums, seen, keys_a, pay_a);
+      hipLaunchKernelGGL(zonal_exact_decide_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, n_labels, inexact);
+      unsigned verdict = 1;
+      GM_HIP(hipMemcpyAsync(&verdict, inexact, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+      GM_HIP(hipStreamSynchronize(s));
+      if (verdict == 0) {
+        hipLaunchKernelGGL((zonal_exact_kernel<T, 1>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells,
+                           cells_per_wave, n_labels, has_ndv, ndv, thresholds, range, sums, (unsigned char*)nullptr,
+                           (unsigned*)nullptr, (Key*)nullptr);
+        hipLaunchKernelGGL(zonal_exact_result_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, statistic,
+                           out_f, counts_f);
+        GM_HIP(hipGetLastError());
+        continue;
+      }
+      keys_written = true;  // (and `present` is recorded)
+    }
+    if (!keys_written)
+      hipLaunchKernelGGL(zonal_keys_kernel<T>, dim3(blocks), dim3(256), 0, s, frame, labels, (size_t)cells, n_labels, has_ndv, ndv,
+                         thresholds, keys_a, pay_a, seen);
     const unsigned* sorted_keys;
     const Key* sorted_pay;
     size_t bytes = temp_bytes;
@@ -394,8 +609,6 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       sorted_pay = pay_b;
     }
     hipLaunchKernelGGL(zonal_bounds_kernel, dim3((n_labels + 1 + 255) / 256), dim3(256), 0, s, sorted_keys, (unsigned)cells, n_labels, first);
-    float* out_f = out + (size_t)f * n_labels;
-    long long* counts_f = counts + (size_t)f * n_labels;
     if (statistic == Z_SUM || statistic == Z_MEAN)
       hipLaunchKernelGGL(zonal_sum_kernel<T>, dim3((unsigned)(((size_t)n_labels * 64 + 255) / 256)), dim3(256), 0, s, sorted_pay, first,
                          n_labels, statistic, out_f, counts_f);

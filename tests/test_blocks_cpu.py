@@ -567,3 +567,25 @@ def test_float16_ndarray_operand_gives_float32(cpu_vm):
             want = ArrayLeaf.ARRAYS["f2/a"]["values"].astype(expected) + 1 if view.__class__.__name__ == "Add" else \
                 ArrayLeaf.ARRAYS["f2/a"]["values"].astype(expected) / 1
             assert np.array_equal(got, want.astype(expected))
+
+
+def test_zonal_statistic_names_and_errors():
+    """geometry.check_statistic = the validation of AggregateRaster.__init__ (aggregate.py:336-342): names are
+    lowered, 'p<number>' becomes a percentile, 'percentile' itself and unknown names are ValueErrors, non-strings
+    TypeErrors; the device entry refuses what the reference cannot compute either (no device needed for these)."""
+    from dask_geomodeling_amd import geometry
+    assert geometry.check_statistic("Mean") == ("mean", None)
+    assert geometry.check_statistic("p95") == ("percentile", 95.0)
+    assert geometry.check_statistic("P12.5") == ("percentile", 12.5)
+    for bad in ("percentile", "mode", "p"):
+        with pytest.raises(ValueError):
+            geometry.check_statistic(bad)
+    with pytest.raises(ValueError):
+        geometry.check_statistic("p101")
+    with pytest.raises(TypeError):
+        geometry.check_statistic(95)
+    assert set(geometry.STATISTICS) == {"sum", "count", "min", "max", "mean", "median", "percentile"}
+    with pytest.raises(ValueError):
+        geometry.label_statistics(np.zeros((1, 2, 2), "f4"), None, np.zeros((2, 2), "i4"), 1, "mode")
+    with pytest.raises(ValueError):
+        geometry.label_statistics(np.zeros((1, 2, 2), "f4"), None, np.zeros((2, 2), "i4"), 1, "percentile")

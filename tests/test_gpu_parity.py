@@ -1365,3 +1365,39 @@ def test_zonal_large_tiles_vs_oracle(gpu, dt):
             got, got_no = geometry.aggregate_labelled(buckets, n, values, ndv, thr, stat, q)
             assert_values_equal(got, want, 0, "%s %s %s" % (dt, stat, q))
             assert got_no == want_no
+
+
+@pytest.mark.gpu
+def test_zonal_sums_without_the_sort_when_order_cannot_matter(gpu, monkeypatch):
+    """sum / mean skip the sort when every partial sum of every label is exactly representable (integer rasters,
+    dyadic data): the parallel sum then has the bits of bincount's sequential one.  Both routes against the oracle
+    on the same data, and data that must NOT qualify (many octaves; one NaN; one huge outlier) still right."""
+    from dask_geomodeling_amd import geometry
+    rng = np.random.default_rng(23)
+    h, w, n = 700, 900, 40
+    labels = ((np.arange(h)[:, None] // 140) * 8 + np.arange(w)[None, :] // 120).astype(np.int32)
+    labels[rng.random((h, w)) < 0.05] = np.iinfo(np.int32).max
+    tiles = {
+        "i4": rng.integers(-50000, 50000, size=(2, h, w)).astype("i4"),
+        "u1": rng.integers(0, 255, size=(2, h, w)).astype("u1"),
+        "i8 large": rng.integers(-2**40, 2**40, size=(1, h, w)).astype("i8"),
+        "f4 quarters": (rng.integers(-4000, 4000, size=(2, h, w)) / 4).astype("f4"),
+        "f4 octaves": (rng.standard_normal((2, h, w)) * rng.choice([1e-6, 1.0, 1e6], size=(2, h, w))).astype("f4"),
+        "f8 outlier": rng.integers(0, 100, size=(1, h, w)).astype("f8"),
+        "f4 nan": rng.integers(0, 100, size=(1, h, w)).astype("f4"),
+    }
+    tiles["f8 outlier"][0, 3, 3] = 1e300
+    tiles["f8 outlier"][0, 3, 4] = 1e-300
+    tiles["f4 nan"][0, 650, 10] = np.nan
+    thresholds = (rng.standard_normal(n) * 10).astype("f4")
+    for name, values in tiles.items():
+        ndv = values.dtype.type(77)
+        for stat in ("sum", "mean"):
+            for thr in (None, thresholds):
+                want, _ = O.aggregate_labelled([(list(range(n)), labels)], n, values, ndv, thr, stat)
+                got, _ = geometry.aggregate_labelled([(list(range(n)), labels)], n, values, ndv, thr, stat)
+                assert_values_equal(got, want, 0, "%s %s" % (name, stat))
+                monkeypatch.setenv("GM_ZONAL_SORTED", "1")
+                forced, _ = geometry.aggregate_labelled([(list(range(n)), labels)], n, values, ndv, thr, stat)
+                monkeypatch.delenv("GM_ZONAL_SORTED")
+                assert_values_equal(forced, want, 0, "%s %s (sorted route)" % (name, stat))
