@@ -94,14 +94,18 @@ def label_statistics(values, no_data_value, labels, n_labels, statistic, percent
         ndv_bits = runtime.scalar_bits(np.asarray(no_data_value).astype(tile.dtype)[()] if has_ndv else 0, tile.dtype)
     if has_ndv and np.asarray(no_data_value).astype(tile.dtype)[()] != no_data_value:
         has_ndv = False  # a no-data value the raster's dtype cannot hold equals no cell (frame != value is all True)
-    out = DeviceArray.empty((frames, n_labels), "f4")
-    counts = DeviceArray.empty((frames, n_labels), "i8")
-    present = DeviceArray.empty((n_labels,), "u1")
+    # one device buffer for the three results (counts first: 8-byte aligned), one copy back
+    cells = frames * n_labels
+    packed = DeviceArray.empty((cells * 12 + n_labels,), "u1")
+    counts_ptr, out_ptr, present_ptr = packed.ptr, packed.ptr + 8 * cells, packed.ptr + 12 * cells
     runtime.check(_lib().gm_zonal_statistic(tile.ptr, code_of(tile.dtype), frames, height * width, int(has_ndv), ndv_bits,
                                             label_tile.ptr, n_labels, thresholds.ptr if thresholds is not None else None,
-                                            STATISTICS[statistic], float(percentile or 0.0), out.ptr, counts.ptr, present.ptr),
+                                            STATISTICS[statistic], float(percentile or 0.0), out_ptr, counts_ptr, present_ptr),
                   "gm_zonal_statistic")
-    return out.to_numpy(), counts.to_numpy(), present.to_numpy().astype(bool)
+    host = packed.to_numpy()
+    counts = host[:8 * cells].view("i8").reshape(frames, n_labels)
+    out = host[8 * cells:12 * cells].view("f4").reshape(frames, n_labels)
+    return out, counts, host[12 * cells:].astype(bool)
 
 
 def aggregate_labelled(label_rasters, n_geometries, values, no_data_value, threshold_values, statistic, percentile=None):

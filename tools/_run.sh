@@ -1,2 +1,3 @@
 #!/bin/bash
-python tools/kbench.py zonal cpu=0 2>&1 | grep -E "i32"
+python -m pytest tests/test_gpu_parity.py -x -q -k "zonal" 2>&1 | tail -2
+python tools/kbench.py zonal cpu=0 2>&1 | grep -E "1024"
