@@ -13,8 +13,10 @@ request is "leaf Blocks -> ONE fused program", the same program serves every oth
 in its ``bbox`` only, and all that has to be redone per request is the leaves' own planning (which window of
 which source).  A ``ViewPlan`` keeps the fused task and the leaf Blocks of one (view, request-without-bbox);
 a ``RasterTiler`` over such a view evaluates all its tiles through the store's plans and the in-place
-mosaic assembly of fuse.py.  Everything else -- other modes, stencil Blocks, temporal Blocks, configured
-dask schedulers -- takes the ordinary graph path, as does a request whose plan cannot be built.
+mosaic assembly of fuse.py.  Blocks with a kernel of their own over one store (Dilate, MovingMax, HillShade, Smooth,
+SpatialResample: ``gm_direct``) are leaves of the plans above them and evaluate their store through the store's plan
+(``_direct``).  Everything else -- other modes, temporal Blocks, configured dask schedulers -- takes the ordinary
+graph path, as does a request whose plan cannot be built.
 """
 
 from . import config as _config
@@ -43,15 +45,35 @@ def _request_key(request):
 
 def _leaf_blocks(block, request, out):
     """{graph key: (leaf Block, the request that reaches it)} of the view under ``block``, walking the
-    Blocks exactly like ``Block.get_compute_graph`` does."""
+    Blocks exactly like ``Block.get_compute_graph`` does.  A leaf is a Block the fusion pass cannot make part of
+    a program: a source, or a Block with a kernel of its own (stencils, temporal statistics ...) -- the view
+    below such a Block is its own business (``_direct``)."""
     pairs = list(block.get_sources_and_requests(**request))
     children = [(s, r) for s, r in pairs if isinstance(s, Block) and r is not None]
-    if not children:
+    if not children or getattr(type(block).process, "gm_op", None) is None:
         name = "{}_{}".format(block.__class__.__name__.lower(), _request_token(block.token, request))
         out[name] = (block, request)
         return
     for source, sub in children:
         _leaf_blocks(source, sub, out)
+
+
+class _PlainTask(object):
+    """``(process, literal or graph key, ...)`` of one element-wise Block as a callable of its leaves' responses."""
+
+    __slots__ = ("function", "template", "leaf_keys")
+
+    def __init__(self, task, graph):
+        self.function = task[0]
+        self.template, self.leaf_keys = [], []
+        for arg in task[1:]:
+            is_key = isinstance(arg, str) and arg in graph
+            self.template.append(len(self.leaf_keys) if is_key else (arg,))
+            if is_key:
+                self.leaf_keys.append(arg)
+
+    def __call__(self, *values):
+        return self.function(*[values[slot] if isinstance(slot, int) else slot[0] for slot in self.template])
 
 
 class ViewPlan(object):
@@ -70,8 +92,7 @@ class ViewPlan(object):
             short_cut = getattr(block, "gm_plan_response", None)
             response = short_cut(request) if short_cut is not None else None
             if response is None:
-                pairs = block.get_sources_and_requests(**request)
-                response = block.process(*[s for s, _ in pairs])
+                response = _direct(block, request)
             values.append(response)
         return values
 
@@ -84,11 +105,21 @@ def _build_view_plan(view, request):
     graph, name = view.get_compute_graph(**request)
     fused = fuse_graph(graph, name)
     task = fused.get(name)
-    if not (isinstance(task, tuple) and task and isinstance(task[0], FusedTask)):
+    if not (isinstance(task, tuple) and task and callable(task[0])):
         return None
-    leaf_keys = list(task[1:])
-    if leaf_keys != list(task[0].leaf_keys) or set(fused) != set(leaf_keys) | {name}:
-        return None  # something besides leaves and the one fused program is left in the graph
+    if isinstance(task[0], FusedTask):
+        leaf_keys = list(task[1:])
+        if leaf_keys != list(task[0].leaf_keys):
+            return None
+        run = task[0]
+    elif getattr(task[0], "gm_op", None) is not None:
+        # a single element-wise operation stays a plain task (nothing to fuse it with): same treatment
+        run = _PlainTask(task, fused)
+        leaf_keys = run.leaf_keys
+    else:
+        return None
+    # (every input of the one fused program must be a leaf Block of the walk below; what the graph holds
+    #  underneath a leaf with a kernel of its own is evaluated by that leaf)
     found = {}
     _leaf_blocks(view, dict(request), found)
     leaves = []
@@ -101,7 +132,7 @@ def _build_view_plan(view, request):
         if any(sub.get(k) != request.get(k) for k in ("bbox", "width", "height", "projection", "mode")):
             return None
         leaves.append((block, dict(sub)))
-    return ViewPlan(task[0], leaves)
+    return ViewPlan(run, leaves)
 
 
 def view_plan(view, request):
@@ -134,9 +165,10 @@ def _run_tiler(tiler, request):
     store = tiler.store
     batches, members, layout = [], [], []   # per distinct plan: BatchedTask material
     index_of = {}
+    from .fuse import FusedTask
     for _, tile_request in pairs[1:]:
         plan = view_plan(store, tile_request)
-        if plan is None:
+        if plan is None or not isinstance(plan.task, FusedTask):
             return False, None
         b = index_of.get(id(plan))
         if b is None:
@@ -152,6 +184,28 @@ def _run_tiler(tiler, request):
         tasks.append(BatchedTask([plan.task] * len(boxes)))
     assembly = TiledAssembly(type(tiler).process, layout, tasks)
     return True, assembly(kwargs, *leaf_values)
+
+
+def _direct(block, request):
+    """``block.process`` on its sources' responses without a graph: what ``get_compute_graph`` + ``compute`` do for
+    a Block whose sources are evaluated one by one (no key to share between them)."""
+    args = []
+    for source, sub in block.get_sources_and_requests(**request):
+        args.append(_child(source, sub) if isinstance(source, Block) and sub is not None else source)
+    return block.process(*args)
+
+
+def _child(block, request):
+    """The response of a source Block for one request, not materialised: through its plan when it has one."""
+    planned, response = evaluate(block, request)
+    if planned:
+        return response
+    from .core.graphs import compute
+    graph, name = block.get_compute_graph(**request)
+    if _config.get("geomodeling.fuse", True):
+        from .fuse import fuse_graph
+        graph = fuse_graph(graph, name)
+    return compute(graph, name)
 
 
 def enabled():
@@ -171,9 +225,13 @@ def evaluate(view, request):
     if getattr(type(view).process, "gm_tiler", False) and hasattr(view, "store"):
         return _run_tiler(view, request)
     plan = view_plan(view, request)
-    if plan is None:
-        return False, None
-    return True, plan.run(request["bbox"])
+    if plan is not None:
+        return True, plan.run(request["bbox"])
+    if getattr(view, "gm_direct", False):
+        # a Block with a kernel of its own over ONE store (stencils, Smooth, resample): its store is evaluated
+        # through the store's plan, the Block's own request planning is all that is redone per request
+        return True, _direct(view, request)
+    return False, None
 
 
 def clear(view):

@@ -42,6 +42,8 @@ class _Stencil(BaseSingle):
     """A Block that needs ``radius`` cells around every requested cell: the store is asked for the grown
     request and ``process`` crops; requests that cannot grow pass through untouched (spatial.py:130-141)."""
 
+    gm_direct = True  # plan.py: evaluated as process(store's response) without a graph per request
+
     def _radius(self):
         return 1
 
@@ -135,6 +137,8 @@ class SpatialResample(BaseSingle):
       method (str): "nearest" or "bilinear" (float rasters only)
     """
 
+    gm_direct = True
+
     def __init__(self, store, zoom, method="bilinear"):
         if not isinstance(zoom, (int, float)) or zoom <= 0:
             raise ValueError("'zoom' should be a positive number")
@@ -193,6 +197,8 @@ class Smooth(BaseSingle):
     """Gaussian smoothing over ``size`` metres, sigma = size / 3 (spatial.py:216-318).  'no data' is
     replaced by ``fill`` before smoothing.  Requests whose margin would exceed 6 pixels are answered
     at the coarser ('zoom') resolution and zoomed back with nearest neighbour, like the reference."""
+
+    gm_direct = True
 
     MARGIN_THRESHOLD = 6
 

@@ -55,7 +55,7 @@ def test_plan_exists_for_the_canonical_chain_and_is_reused(gpu):
         with gmconfig.config.set({"geomodeling.materialize": False}):
             raw = view.get_data(**r)["values"]
         assert isinstance(raw, DeviceArray)
-    # another request shape: another plan; a stencil view: no plan, graph path
+    # another request shape: another plan; a stencil view has no program of its own (it evaluates its store's plan)
     assert plan.view_plan(view, dict(req, width=32, height=32, bbox=(0.0, 0.0, 32.0, 32.0))) is not p
     assert plan.view_plan(raster.MovingMax(view, 3), req) is None
     # RasterTiler through the store's plans == untiled
@@ -80,3 +80,38 @@ def test_tiler_through_plans_equals_untiled(gpu, seed):
     for tile in ([8, 8], [16, 12], 17):
         tiled = raster.RasterTiler(view, tile).get_data(**REQ)
         assert_result_equal(unsigned_zero(tiled, view), unsigned_zero(whole, view), 0, "tile %s of %s" % (tile, describe(view)))
+
+
+def test_stencil_blocks_through_plans(gpu):
+    """Blocks with a kernel of their own (gm_direct) are answered without a graph per request: alone over a source,
+    over a planned element-wise view, as leaves of an element-wise view above them, nested, and under a RasterTiler --
+    every time exactly the graph path's result, and through plan.evaluate."""
+    from dask_geomodeling_amd import plan, raster
+    rng = np.random.default_rng(4)
+    fill = np.float32(np.finfo("f4").max)
+    a = np.cumsum(rng.standard_normal((1, 200, 240)), axis=2).astype("f4")
+    b = (rng.random((1, 200, 240)) * 10).astype("f4")
+    a[0, ::13, ::7] = fill
+    A = raster.MemorySource(a, fill, "EPSG:28992", 1.0, (0.0, 200.0))
+    B = raster.MemorySource(b, fill, "EPSG:28992", 1.0, (0.0, 200.0))
+    classes = raster.Classify(A + B, [-10, 0, 10, 20])
+    views = {
+        "hillshade(source)": raster.HillShade(A),
+        "hillshade(view)": raster.HillShade(A * 2 + B),
+        "view(hillshade)": raster.HillShade(A) * 0.5 + B,
+        "view(movingmax(view), smooth(view))": raster.MovingMax(A + B, 5) - raster.Smooth(A - B, 2.0),
+        "dilate(classify)": raster.Dilate(classes, [1, 3]),
+        "movingmax(smooth(view))": raster.MovingMax(raster.Smooth(A + 1, 3.0), 3),
+        "tiler(view(hillshade))": raster.RasterTiler(raster.HillShade(A) * 0.5 + B, 64),
+    }
+    boxes = [(0.0, 0.0, 128.0, 128.0), (40.0, 30.0, 168.0, 158.0), (100.0, 60.0, 228.0, 188.0), (-20.0, -10.0, 108.0, 118.0)]
+    for name, view in views.items():
+        for bbox in boxes:
+            req = dict(mode="vals", bbox=bbox, width=128, height=128, projection="EPSG:28992")
+            planned, raw = plan.evaluate(view, req)
+            assert planned, name
+            got = view.get_data(**req)
+            assert_result_equal(got, _graph_path(view, req), 0, "%s at %s" % (name, (bbox,)))
+    # other modes keep the graph path and agree with it
+    for mode in ("time", "meta"):
+        assert views["hillshade(view)"].get_data(mode=mode) == _graph_path(views["hillshade(view)"], dict(mode=mode))

@@ -1,3 +1,2 @@
 #!/bin/bash
-python -m pytest tests/test_gpu_parity.py -x -q -k "zonal" 2>&1 | tail -2
-python tools/kbench.py zonal cpu=0 2>&1 | grep -E "1024"
+python tools/_e2e_stencil.py 2>&1 | tail -10
