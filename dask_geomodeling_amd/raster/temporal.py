@@ -346,6 +346,8 @@ class TemporalAggregate(BaseSingle):
     p<percentile>), closed / label ('left', 'right' or None for the frequency's default), timezone.
     """
 
+    gm_direct = True  # plan.py: evaluated as process(store's responses) without a graph per request
+
     STATISTICS = ("sum", "count", "min", "max", "mean", "median", "std", "var")
 
     def __init__(self, source, frequency, statistic="sum", closed=None, label=None, timezone="UTC"):
@@ -460,6 +462,8 @@ class Cumulative(BaseSingle):
 
     Args: source, statistic ('sum' or 'count'), frequency (period after which the accumulation starts
     again; None = never), timezone."""
+
+    gm_direct = True  # plan.py: evaluated as process(store's responses) without a graph per request
 
     STATISTICS = ("sum", "count")
 

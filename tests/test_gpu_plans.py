@@ -115,3 +115,29 @@ def test_stencil_blocks_through_plans(gpu):
     # other modes keep the graph path and agree with it
     for mode in ("time", "meta"):
         assert views["hillshade(view)"].get_data(mode=mode) == _graph_path(views["hillshade(view)"], dict(mode=mode))
+
+
+def test_temporal_blocks_through_plans(gpu):
+    """TemporalAggregate / Cumulative (gm_direct) over planned element-wise views, and under one: plan path == graph path
+    for vals, time and meta requests."""
+    from datetime import datetime
+    from dask_geomodeling_amd import plan, raster
+    rng = np.random.default_rng(9)
+    frames, h, w = 24, 48, 64
+    data = (rng.random((frames, h, w)) * 50).astype("f4")
+    data[rng.random(data.shape) < 0.1] = -9999.0
+    src = raster.MemorySource(data, -9999.0, "EPSG:28992", 1.0, (0.0, float(h)), time_first=0, time_delta=3600 * 1000,
+                              metadata=["frame %d" % i for i in range(frames)])
+    views = {"aggregate(view) - 3": raster.TemporalAggregate(src * 2 + 1, "6h", "mean") - 3,
+             "aggregate(source, median)": raster.TemporalAggregate(src, "12h", "median"),
+             "cumulative(view)": raster.Cumulative(src + 1, "sum", "6h")}
+    for name, view in views.items():
+        for bbox in ((0.0, 0.0, 32.0, 24.0), (16.0, 8.0, 48.0, 32.0)):
+            req = dict(mode="vals", bbox=bbox, width=32, height=24, projection="EPSG:28992",
+                       start=datetime(1970, 1, 1, 0), stop=datetime(1970, 1, 1, 23))
+            planned, _ = plan.evaluate(view, req)
+            assert planned, name
+            assert_result_equal(view.get_data(**req), _graph_path(view, req), 0, name)
+            for mode in ("time", "meta"):
+                other = dict(req, mode=mode)
+                assert view.get_data(**other) == _graph_path(view, other)

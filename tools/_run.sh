@@ -1,2 +1,2 @@
 #!/bin/bash
-python tools/_e2e_stencil.py 2>&1 | tail -10
+python -m pytest tests/test_gpu_plans.py -x -q 2>&1 | tail -3
