@@ -94,19 +94,20 @@ __global__ __launch_bounds__(256) void dilate_kernel(const T* __restrict__ in, T
 // 256 + HALO.  A lane loads its own column (the row offsets are scalar arithmetic: ~3 vector instructions per
 // cell; addressing cell by cell with `cell / PITCH` cost ~15, as much as the stencils themselves), the HALO
 // columns east of the workgroup's 256 are shared out cell by cell.  All loads of a lane are in flight before
-// the first LDS write; rows / columns past the plane are clamped (those cells feed no output).
+// the first LDS write; rows / columns past the plane are clamped (those cells feed no output).  `pitch`: elements
+// between the rows of the plane (a zero-copy window of a wider resident raster has pitch > w).
 template <typename T, int ROWS, int HALO, typename F>
-__device__ __forceinline__ void stage_window(T* tile, const T* __restrict__ plane, int r0, int c0, int h, int w, F clean) {
+__device__ __forceinline__ void stage_window(T* tile, const T* __restrict__ plane, int r0, int c0, int h, int w, int pitch, F clean) {
   constexpr int PITCH = 256 + HALO, EAST = ROWS * HALO, EAST_PER_LANE = (EAST + 255) / 256;
   const T* column = plane + min(c0 + (int)threadIdx.x, w - 1);
   T own[ROWS], east[EAST_PER_LANE];
 #pragma unroll
-  for (int wy = 0; wy < ROWS; ++wy) own[wy] = column[(size_t)min(r0 + wy, h - 1) * w];
+  for (int wy = 0; wy < ROWS; ++wy) own[wy] = column[(size_t)min(r0 + wy, h - 1) * pitch];
 #pragma unroll
   for (int i = 0; i < EAST_PER_LANE; ++i) {
     const int cell = min((int)threadIdx.x + 256 * i, EAST - 1);
     const int ey = cell / HALO, ex = 256 + cell - ey * HALO;
-    east[i] = plane[(size_t)min(r0 + ey, h - 1) * w + min(c0 + ex, w - 1)];
+    east[i] = plane[(size_t)min(r0 + ey, h - 1) * pitch + min(c0 + ex, w - 1)];
   }
 #pragma unroll
   for (int wy = 0; wy < ROWS; ++wy) tile[wy * PITCH + threadIdx.x] = clean(own[wy]);
@@ -149,12 +150,12 @@ __device__ __forceinline__ T hw_max3(T a, T b, T c) {
 constexpr int DT_H = 16, DT_W = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void dilate_tile_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                          DilateArgs<T> A) {
+                                                          int pitch, DilateArgs<T> A) {
   __shared__ T tile[(DT_H + 2) * (DT_W + 2)];
   const int c0 = blockIdx.x * DT_W, r0 = blockIdx.y * DT_H;
   const int ow = w - 2, oh = h - 2;
   constexpr int PITCH = DT_W + 2;
-  stage_window<T, DT_H + 2, 2>(tile, in, r0, c0, h, w, [](T v) { return v; });
+  stage_window<T, DT_H + 2, 2>(tile, in, r0, c0, h, w, pitch, [](T v) { return v; });
   __syncthreads();
   const int c = c0 + threadIdx.x;
   if (c >= ow) return;
@@ -302,12 +303,12 @@ __device__ __forceinline__ unsigned equal_flags(unsigned x, unsigned splat) {
 }
 constexpr int D8W_H = 16, D8W_COLS = 2048, D8W_PITCH = 516;  // window: (D8W_H + 2) rows of 516 words (2064 bytes)
 __global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
-                                                           int h, int w, Dilate8Args A) {
+                                                           int h, int w, int pitch, Dilate8Args A) {
   __shared__ __align__(16) unsigned tile[(D8W_H + 2) * D8W_PITCH];
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const int c0 = blockIdx.x * D8W_COLS, r0 = blockIdx.y * D8W_H;
   const int ow = w - 2, oh = h - 2;
-  const size_t left = (size_t)h * w;
+  const size_t left = (size_t)(h - 1) * pitch + w;  // bytes from the first cell to the end of the last row
   constexpr int QUADS = D8W_PITCH / 4, CELLS = (D8W_H + 2) * QUADS, PER_LANE = (CELLS + 255) / 256;
   u32x4 staged[PER_LANE];
 #pragma unroll
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* 
     const int cell = threadIdx.x + 256 * i;
     const int wy = min(cell / QUADS, D8W_H + 1), q = cell - (cell / QUADS) * QUADS;
     const int sy = min(r0 + wy, h - 1), sx = c0 + 16 * q;
-    const size_t at = (size_t)sy * w + sx;
+    const size_t at = (size_t)sy * pitch + sx;
     u32x4 x = {0u, 0u, 0u, 0u};
     if (sx < w) {
       if (at + 16 <= left) {
@@ -487,13 +488,13 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
 constexpr int M3_H = 16, M3_W = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                          int has_ndv, T ndv, T minimum) {
+                                                          int pitch, int has_ndv, T ndv, T minimum) {
   __shared__ T tile[(M3_H + 2) * (M3_W + 2)];
   const int c0 = blockIdx.x * M3_W, r0 = blockIdx.y * M3_H, b = blockIdx.z;
   const int ow = w - 2, oh = h - 2;
   const T* plane = in + (size_t)b * h * w;
   constexpr int PITCH = M3_W + 2;
-  stage_window<T, M3_H + 2, 2>(tile, plane, r0, c0, h, w, [&](T v) { return (has_ndv && v == ndv) ? minimum : v; });  // spatial.py:199-203
+  stage_window<T, M3_H + 2, 2>(tile, plane, r0, c0, h, w, pitch, [&](T v) { return (has_ndv && v == ndv) ? minimum : v; });  // spatial.py:199-203
   __syncthreads();
   const int c = c0 + threadIdx.x;
   if (c >= ow) return;
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ 
       // still the minimum on a no-data centre: no-data again (spatial.py:208-209); only then is the
       // original centre fetched (the LDS copy cannot tell "was no data" from "is the minimum")
       if (has_ndv && best == minimum) {
-        const T original = plane[(size_t)(r0 + r + 1) * w + (c + 1)];
+        const T original = plane[(size_t)(r0 + r + 1) * pitch + (c + 1)];
         if (original == ndv) best = ndv;
       }
       __builtin_nontemporal_store(best, out + ((size_t)b * oh + (r0 + r)) * ow + c);
@@ -541,13 +542,13 @@ __host__ __device__ constexpr int disk_half_width(int dy) {
 __host__ __device__ constexpr int disk_tile_rows(int R) { return R >= 7 ? 32 : 16; }
 template <typename T, int R>
 __global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                              int has_ndv, T ndv, T minimum) {
+                                                              int pitch, int has_ndv, T ndv, T minimum) {
   constexpr int TH = disk_tile_rows(R), TW = 256, PITCH = TW + 2 * R, ROWS = TH + 2 * R;
   __shared__ T tile[ROWS * PITCH];
   const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH, b = blockIdx.z;
   const int ow = w - 2 * R, oh = h - 2 * R;
   const T* plane = in + (size_t)b * h * w;
-  stage_window<T, ROWS, 2 * R>(tile, plane, r0, c0, h, w, [&](T v) { return (has_ndv && v == ndv) ? minimum : v; });  // spatial.py:199-203
+  stage_window<T, ROWS, 2 * R>(tile, plane, r0, c0, h, w, pitch, [&](T v) { return (has_ndv && v == ndv) ? minimum : v; });  // spatial.py:199-203
   __syncthreads();
   const int c = c0 + threadIdx.x;
   if (c >= ow) return;
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restric
       }
       if (r0 + r < oh) {
         if (has_ndv && best == minimum) {  // no data again where the centre was no data (spatial.py:208-209)
-          const T original = plane[(size_t)(r0 + r + R) * w + (c + R)];
+          const T original = plane[(size_t)(r0 + r + R) * pitch + (c + R)];
           if (original == ndv) best = ndv;
         }
         __builtin_nontemporal_store(best, out + ((size_t)b * oh + (r0 + r)) * ow + c);
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(256) void hillshade_kernel(const T* __restrict__ in
 constexpr int HT_H = 16, HT_W = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void hillshade_tile_kernel(const T* __restrict__ in, unsigned char* __restrict__ out,
-                                                             int h, int w, int has_ndv, T ndv, T fill, HillArgs A) {
+                                                             int h, int w, int pitch, int has_ndv, T ndv, T fill, HillArgs A) {
   __shared__ T tile[(HT_H + 2) * (HT_W + 2)];
   __shared__ unsigned char shade[4][HT_H * 64];  // per wave: HT_H rows x 64 columns
   constexpr unsigned HT_PENDING = 256;
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(256) void hillshade_tile_kernel(const T* __restrict
   const int ow = w - 2, oh = h - 2;
   const T* plane = in + (size_t)b * h * w;
   constexpr int PITCH = HT_W + 2;
-  stage_window<T, HT_H + 2, 2>(tile, plane, r0, c0, h, w, [&](T v) { return (has_ndv && v == ndv) ? fill : v; });  // spatial.py:363-364
+  stage_window<T, HT_H + 2, 2>(tile, plane, r0, c0, h, w, pitch, [&](T v) { return (has_ndv && v == ndv) ? fill : v; });  // spatial.py:363-364
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* col = tile + threadIdx.x;  // window column of the west neighbour of output column c0 + threadIdx.x
@@ -825,7 +826,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int HP_H = 8, HP_W = 512;
 template <bool USE_INV>
 __global__ __launch_bounds__(256) void hillshade_pair_kernel(const float* __restrict__ in, unsigned char* __restrict__ out,
-                                                             int h, int w, int has_ndv, float ndv, float fill, HillArgs A) {
+                                                             int h, int w, int pitch, int has_ndv, float ndv, float fill, HillArgs A) {
   constexpr int PITCH = HP_W + 2;
   __shared__ __align__(16) float tile[(HP_H + 2) * PITCH];
   __shared__ __align__(16) unsigned char shade[HP_H * HP_W];
@@ -845,14 +846,14 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const float* __rest
     float sw[HP_H + 2], se[HP_H + 2];
 #pragma unroll
     for (int wy = 0; wy < HP_H + 2; ++wy) {
-      const size_t row = (size_t)min(r0 + wy, h - 1) * w;
+      const size_t row = (size_t)min(r0 + wy, h - 1) * pitch;
       sw[wy] = west[row];
       se[wy] = east[row];
     }
     const bool rim = threadIdx.x < 2 * (HP_H + 2);
     const int ry = threadIdx.x >> 1, rx = HP_W + (threadIdx.x & 1);
     float beyond = 0.0f;
-    if (rim) beyond = plane[(size_t)min(r0 + ry, h - 1) * w + min(c0 + rx, w - 1)];
+    if (rim) beyond = plane[(size_t)min(r0 + ry, h - 1) * pitch + min(c0 + rx, w - 1)];
 #pragma unroll
     for (int wy = 0; wy < HP_H + 2; ++wy) {
       tile[wy * PITCH + threadIdx.x] = clean(sw[wy]);
@@ -1087,8 +1088,8 @@ struct Gauss2Args {
 };
 template <int R, int RCAP>
 __global__ __launch_bounds__(256) void gauss2d_kernel(const float* __restrict__ in, float* __restrict__ out, int h, int w,
-                                                      int y0, int x0, int oh, int ow, int replace_ndv, float ndv, float fill,
-                                                      Gauss2Args A) {
+                                                      int pitch, int y0, int x0, int oh, int ow, int replace_ndv, float ndv,
+                                                      float fill, Gauss2Args A) {
   constexpr int TW = 256 - 2 * RCAP, WIN = 8 + 2 * R, WIN4 = (WIN + 3) / 4;
   __shared__ __align__(16) float mid[G2_TH * 256 + 4];
   const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * G2_TH, b = blockIdx.z;
@@ -1101,7 +1102,7 @@ __global__ __launch_bounds__(256) void gauss2d_kernel(const float* __restrict__ 
       const float* column = plane + sx;
       // loads first, conversions after: written as one expression per row the compiler waits for every
       // load before it issues the next (rows are uniform, the address arithmetic is scalar code)
-      auto load = [&](int ty) -> float { return column[(size_t)min(max(ty, 0), h - 1) * w]; };
+      auto load = [&](int ty) -> float { return column[(size_t)min(max(ty, 0), h - 1) * pitch]; };
       auto value = [&](float v, int ty) -> double {  // what SciPy's line buffer holds for tile row ty
         const double inside = (double)((replace_ndv && v == ndv) ? fill : v);
         return (ty < 0 || ty >= h) ? A.cval : inside;
@@ -1198,7 +1199,15 @@ T lowest() {
 extern "C" {
 
 int gm_dilate(const void* in, int dtype, int bands, int h, int w, const uint64_t* values_bits, int n_values, void* out) {
+  return gm_dilate_window(in, dtype, bands, h, w, w, values_bits, n_values, out);
+}
+
+int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, const uint64_t* values_bits, int n_values,
+                     void* out) {
   if (!in || !out || (!values_bits && n_values)) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (in_pitch < w) return gm::fail(GM_ERR_INVALID, "gm_dilate: pitch %d of a %d-wide tile", in_pitch, w);
+  const bool window = in_pitch != w;
+  if (window && bands != 1) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: a window of %d bands", bands);
   if (bands <= 0 || h < 3 || w < 3) return gm::fail(GM_ERR_INVALID, "gm_dilate: tile %dx%dx%d has no interior", bands, h, w);
   if (n_values < 0 || n_values > DIL_MAX_VALUES) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: %d values (max %d)", n_values, DIL_MAX_VALUES);
   if (bands > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: too many bands");
@@ -1211,10 +1220,11 @@ int gm_dilate(const void* in, int dtype, int bands, int h, int w, const uint64_t
     // (one band: with several, the cells of the neighbouring bands count too -- the row kernel below)
     if (bands == 1 && w >= 64 && (h - 2 + D8W_H - 1) / D8W_H <= 65535) {
       dim3 wgrid((unsigned)((w - 2 + D8W_COLS - 1) / D8W_COLS), (unsigned)((h - 2 + D8W_H - 1) / D8W_H));
-      hipLaunchKernelGGL(dilate8_wide_kernel, wgrid, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, h, w, A8);
+      hipLaunchKernelGGL(dilate8_wide_kernel, wgrid, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, h, w, in_pitch, A8);
       GM_HIP(hipGetLastError());
       return GM_OK;
     }
+    if (window) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: this tile shape wants a compact tile");
     dim3 grid8((unsigned)((w - 2 + 1023) / 1024), (unsigned)((h - 2 + D8_ROWS - 1) / D8_ROWS), (unsigned)bands);
     if (grid8.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: tile taller than %d rows", 65535 * D8_ROWS);
     hipLaunchKernelGGL(dilate8_kernel, grid8, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, bands, h, w, A8);
@@ -1230,7 +1240,7 @@ int gm_dilate(const void* in, int dtype, int bands, int h, int w, const uint64_t
     DilateArgs<T> A;                                                                                \
     A.n_values = n_values;                                                                          \
     for (int i = 0; i < n_values; ++i) A.values[i] = from_bits<T>(values_bits[i]);                  \
-    hipLaunchKernelGGL(dilate_tile_kernel<T>, tgrid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, A); \
+    hipLaunchKernelGGL(dilate_tile_kernel<T>, tgrid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, in_pitch, A); \
   } while (0)
     switch (dtype) {
       case GM_U16: GM_DILT(unsigned short); break;
@@ -1244,6 +1254,7 @@ int gm_dilate(const void* in, int dtype, int bands, int h, int w, const uint64_t
     GM_HIP(hipGetLastError());
     return GM_OK;
   }
+  if (window) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: this dtype / tile shape wants a compact tile");
 #define GM_DIL(T)                                                                                    \
   do {                                                                                               \
     DilateArgs<T> A;                                                                                 \
@@ -1270,7 +1281,15 @@ int gm_dilate(const void* in, int dtype, int bands, int h, int w, const uint64_t
 }
 
 int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, int has_ndv, uint64_t ndv_bits, void* out) {
+  return gm_moving_max_window(in, dtype, bands, h, w, w, size, has_ndv, ndv_bits, out);
+}
+
+int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, int size, int has_ndv,
+                         uint64_t ndv_bits, void* out) {
   if (!in || !out) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (in_pitch < w) return gm::fail(GM_ERR_INVALID, "gm_moving_max: pitch %d of a %d-wide tile", in_pitch, w);
+  const bool window = in_pitch != w;
+  if (window && bands != 1) return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: a window of %d bands", bands);
   if (size < 3 || (size & 1) == 0 || size > 63) return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: size %d (odd, 3..63)", size);
   const int radius = size / 2;
   const int oh = h - 2 * radius, ow = w - 2 * radius;
@@ -1282,7 +1301,7 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
   if (!s) return GM_ERR_NO_DEVICE;
   if (size == 3 && gm::dtype_size(dtype) <= 4 && (oh + M3_H - 1) / M3_H <= 65535) {
     dim3 grid3((unsigned)((ow + M3_W - 1) / M3_W), (unsigned)((oh + M3_H - 1) / M3_H), (unsigned)bands);
-#define GM_M3(T) hipLaunchKernelGGL(moving_max3_kernel<T>, grid3, dim3(256), 0, s, (const T*)in, (T*)out, h, w, has_ndv, from_bits<T>(ndv_bits), lowest<T>())
+#define GM_M3(T) hipLaunchKernelGGL(moving_max3_kernel<T>, grid3, dim3(256), 0, s, (const T*)in, (T*)out, h, w, in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>())
     switch (dtype) {
       case GM_U8: GM_M3(unsigned char); break;
       case GM_I8: GM_M3(signed char); break;
@@ -1304,22 +1323,22 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
   do {                                                                                                            \
     if (size == 5)                                                                                                \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 2>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+                         in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
     else if (size == 7)                                                                                           \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 3>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+                         in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
     else if (size == 9)                                                                                           \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 4>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+                         in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
     else if (size == 11)                                                                                          \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 5>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+                         in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
     else if (size == 13)                                                                                          \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 6>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+                         in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
     else                                                                                                          \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 7>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+                         in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
   } while (0)
     switch (dtype) {
       case GM_U8: GM_MD(unsigned char); break;
@@ -1335,6 +1354,7 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
     GM_HIP(hipGetLastError());
     return GM_OK;
   }
+  if (window) return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: this footprint / dtype wants a compact tile");
   dim3 grid((unsigned)((ow + MM_TILE_W - 1) / MM_TILE_W), (unsigned)((oh + MM_TILE_H - 1) / MM_TILE_H), (unsigned)bands);
   if (grid.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: tile too tall");
 #define GM_MM_R(T, RMAX_)                                                                                      \
@@ -1424,7 +1444,16 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
 int gm_gauss_2d(const void* in, int dtype, int bands, int h, int w, const double* weights_y, const double* weights_x,
                 int radius, double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh,
                 int ow, void* out) {
+  return gm_gauss_2d_window(in, dtype, bands, h, w, w, weights_y, weights_x, radius, cval, replace_ndv, ndv_bits, fill_bits, y0, x0,
+                            oh, ow, out);
+}
+
+int gm_gauss_2d_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, const double* weights_y,
+                       const double* weights_x, int radius, double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits,
+                       int y0, int x0, int oh, int ow, void* out) {
   if (!in || !out || !weights_y || !weights_x) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (in_pitch < w) return gm::fail(GM_ERR_INVALID, "gm_gauss_2d: pitch %d of a %d-wide tile", in_pitch, w);
+  if (in_pitch != w && bands != 1) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_2d: a window of %d bands", bands);
   if (dtype != GM_F32) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_2d: dtype %d (float32 tiles)", dtype);
   if (radius < 1 || radius > G2_MAX_RADIUS) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_2d: radius %d (1..%d)", radius, G2_MAX_RADIUS);
   if (bands <= 0 || oh <= 0 || ow <= 0) return GM_OK;
@@ -1444,8 +1473,8 @@ int gm_gauss_2d(const void* in, int dtype, int bands, int h, int w, const double
   dim3 grid((unsigned)((ow + tw - 1) / tw), (unsigned)((oh + G2_TH - 1) / G2_TH), (unsigned)bands);
 #define GM_G2(R, RCAP)                                                                                              \
   case R:                                                                                                           \
-    hipLaunchKernelGGL((gauss2d_kernel<R, RCAP>), grid, dim3(256), 0, s, (const float*)in, (float*)out, h, w, y0, x0, oh, \
-                       ow, replace_ndv, ndv, fill, A);                                                              \
+    hipLaunchKernelGGL((gauss2d_kernel<R, RCAP>), grid, dim3(256), 0, s, (const float*)in, (float*)out, h, w, in_pitch,   \
+                       y0, x0, oh, ow, replace_ndv, ndv, fill, A);                                                  \
     break
   switch (radius) {
     GM_G2(1, 8); GM_G2(2, 8); GM_G2(3, 8); GM_G2(4, 8); GM_G2(5, 8); GM_G2(6, 8); GM_G2(7, 8); GM_G2(8, 8);
@@ -1458,7 +1487,15 @@ int gm_gauss_2d(const void* in, int dtype, int bands, int h, int w, const double
 
 int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv, uint64_t ndv_bits, uint64_t fill_bits,
                  double xres, double yres, double altitude_deg, double azimuth_deg, void* out) {
+  return gm_hillshade_window(in, dtype, bands, h, w, w, has_ndv, ndv_bits, fill_bits, xres, yres, altitude_deg, azimuth_deg, out);
+}
+
+int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, int has_ndv, uint64_t ndv_bits,
+                        uint64_t fill_bits, double xres, double yres, double altitude_deg, double azimuth_deg, void* out) {
   if (!in || !out) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (in_pitch < w) return gm::fail(GM_ERR_INVALID, "gm_hillshade: pitch %d of a %d-wide tile", in_pitch, w);
+  const bool window = in_pitch != w;
+  if (window && bands != 1) return gm::fail(GM_ERR_UNSUPPORTED, "gm_hillshade: a window of %d bands", bands);
   if (bands <= 0 || h < 3 || w < 3) return gm::fail(GM_ERR_INVALID, "gm_hillshade: tile %dx%dx%d has no interior", bands, h, w);
   if (bands > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_hillshade: too many bands");
   hipStream_t s = gm::current_stream();
@@ -1495,9 +1532,9 @@ int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv
     dim3 pgrid((unsigned)((w - 2 + HP_W - 1) / HP_W), (unsigned)((h - 2 + HP_H - 1) / HP_H), (unsigned)bands);
     const float ndv = from_bits<float>(ndv_bits), fill = from_bits<float>(fill_bits);
     if (A.xinv32 != 0.0f && A.yinv32 != 0.0f)
-      hipLaunchKernelGGL(hillshade_pair_kernel<true>, pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, has_ndv, ndv, fill, A);
+      hipLaunchKernelGGL(hillshade_pair_kernel<true>, pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, in_pitch, has_ndv, ndv, fill, A);
     else
-      hipLaunchKernelGGL(hillshade_pair_kernel<false>, pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, has_ndv, ndv, fill, A);
+      hipLaunchKernelGGL(hillshade_pair_kernel<false>, pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, in_pitch, has_ndv, ndv, fill, A);
     GM_HIP(hipGetLastError());
     return GM_OK;
   }
@@ -1506,10 +1543,11 @@ int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv
     if constexpr (sizeof(T) <= 4) {                                                                                  \
       if (tiled) {                                                                                                   \
         hipLaunchKernelGGL(hillshade_tile_kernel<T>, tgrid, dim3(256), 0, s, (const T*)in, (unsigned char*)out, h, w, \
-                           has_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);                            \
+                           in_pitch, has_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);                  \
         break;                                                                                                       \
       }                                                                                                              \
     }                                                                                                                \
+    if (window) return gm::fail(GM_ERR_UNSUPPORTED, "gm_hillshade: this dtype / tile shape wants a compact tile");  \
     hipLaunchKernelGGL(hillshade_kernel<T>, grid, dim3(256), 0, s, (const T*)in, (unsigned char*)out, h, w,         \
                        has_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);                                \
   } while (0)

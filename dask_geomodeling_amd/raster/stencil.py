@@ -5,7 +5,7 @@ import ctypes
 import numpy as np
 
 from ..hip import runtime
-from ..hip.array import DeviceArray, as_device
+from ..hip.array import DeviceArray, as_device, as_device_view
 from ..hip.dtypes import code_of
 
 _declared = False
@@ -31,6 +31,17 @@ def _lib():
                                   c.c_int, c.c_double, c.c_int, c.c_uint64, c.c_uint64, c.c_int, c.c_int, c.c_int, c.c_int,
                                   c.c_void_p]
         L.gm_gauss_2d.restype = c.c_int
+        L.gm_dilate_window.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_uint64), c.c_int,
+                                       c.c_void_p]
+        L.gm_moving_max_window.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_uint64,
+                                           c.c_void_p]
+        L.gm_hillshade_window.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_uint64, c.c_uint64,
+                                          c.c_double, c.c_double, c.c_double, c.c_double, c.c_void_p]
+        L.gm_gauss_2d_window.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_double),
+                                         c.POINTER(c.c_double), c.c_int, c.c_double, c.c_int, c.c_uint64, c.c_uint64, c.c_int,
+                                         c.c_int, c.c_int, c.c_int, c.c_void_p]
+        for fn in (L.gm_dilate_window, L.gm_moving_max_window, L.gm_hillshade_window, L.gm_gauss_2d_window):
+            fn.restype = c.c_int
         _declared = True
     return L
 
@@ -48,9 +59,22 @@ def _ndv_bits(dtype, ndv):
     return 1, runtime.scalar_bits(eff, dtype)
 
 
+GM_ERR_UNSUPPORTED = 9002
+
+
+def _on_window(src, launch, what):
+    """``launch(tile, pitch)`` on a zero-copy window as it is; when the library wants a compact tile for this
+    dtype / shape (GM_ERR_UNSUPPORTED), on a compacted copy.  Compact tiles go straight through."""
+    rc = launch(src, src.pitch or src.shape[-1])
+    if rc == GM_ERR_UNSUPPORTED and src.pitch is not None:
+        src = src.contiguous()
+        rc = launch(src, src.shape[-1])
+    runtime.check(rc, what)
+
+
 def dilate(values, dilate_values):
     """(bands, h, w) tile with a 1-pixel margin -> dilated (bands, h-2, w-2) tile."""
-    src = as_device(values)
+    src = as_device_view(values)
     bands, h, w = src.shape
     vals = np.asarray(dilate_values, dtype=src.dtype)  # the reference's cast (spatial.py:151)
     if h < 3 or w < 3:
@@ -62,13 +86,14 @@ def dilate(values, dilate_values):
     if len(todo) > MAX_DILATE_VALUES:
         raise NotImplementedError("Dilate with more than %d values" % MAX_DILATE_VALUES)
     bits = (ctypes.c_uint64 * max(len(todo), 1))(*[runtime.scalar_bits(v, src.dtype) for v in todo])
-    runtime.check(_lib().gm_dilate(ctypes.c_void_p(current.ptr), code_of(src.dtype), bands, h, w, bits, len(todo),
-                                   ctypes.c_void_p(out.ptr)), "gm_dilate")
+    L = _lib()
+    _on_window(current, lambda tile, pitch: L.gm_dilate_window(ctypes.c_void_p(tile.ptr), code_of(src.dtype), bands, h, w, pitch,
+                                                              bits, len(todo), ctypes.c_void_p(out.ptr)), "gm_dilate")
     return out
 
 
 def moving_max(values, no_data_value, size):
-    src = as_device(values)
+    src = as_device_view(values)
     bands, h, w = src.shape
     radius = int(size // 2)
     if src.dtype == np.dtype("bool"):
@@ -76,13 +101,14 @@ def moving_max(values, no_data_value, size):
         raise ValueError("Invalid integer data type 'b'.")
     out = DeviceArray.empty((bands, h - 2 * radius, w - 2 * radius), src.dtype)
     has, bits = _ndv_bits(src.dtype, no_data_value)
-    runtime.check(_lib().gm_moving_max(ctypes.c_void_p(src.ptr), code_of(src.dtype), bands, h, w, int(size), has, bits,
-                                       ctypes.c_void_p(out.ptr)), "gm_moving_max")
+    L = _lib()
+    _on_window(src, lambda tile, pitch: L.gm_moving_max_window(ctypes.c_void_p(tile.ptr), code_of(src.dtype), bands, h, w, pitch,
+                                                              int(size), has, bits, ctypes.c_void_p(out.ptr)), "gm_moving_max")
     return out
 
 
 def hillshade(values, no_data_value, fill, resolution, altitude, azimuth):
-    src = as_device(values)
+    src = as_device_view(values)
     bands, h, w = src.shape
     if src.dtype == np.dtype("bool") or src.dtype == np.dtype("u8"):
         raise NotImplementedError("HillShade on %s tiles" % src.dtype)
@@ -90,9 +116,12 @@ def hillshade(values, no_data_value, fill, resolution, altitude, azimuth):
     has, bits = _ndv_bits(src.dtype, no_data_value)
     with np.errstate(all="ignore"):
         fill_cast = np.array(fill).astype(src.dtype)[()]  # array[mask] = fill casts like this (spatial.py:364)
-    runtime.check(_lib().gm_hillshade(ctypes.c_void_p(src.ptr), code_of(src.dtype), bands, h, w, has, bits,
-                                      runtime.scalar_bits(fill_cast, src.dtype), float(resolution[0]), float(resolution[1]),
-                                      float(altitude), float(azimuth), ctypes.c_void_p(out.ptr)), "gm_hillshade")
+    L = _lib()
+    fill_bits = runtime.scalar_bits(fill_cast, src.dtype)
+    _on_window(src, lambda tile, pitch: L.gm_hillshade_window(ctypes.c_void_p(tile.ptr), code_of(src.dtype), bands, h, w, pitch, has,
+                                                             bits, fill_bits, float(resolution[0]), float(resolution[1]),
+                                                             float(altitude), float(azimuth), ctypes.c_void_p(out.ptr)),
+               "gm_hillshade")
     return out
 
 
@@ -110,7 +139,7 @@ def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0), fused
     """values[values == ndv] = fill, then ndimage.gaussian_filter(values, (0, sy, sx), mode="constant",
     cval=fill) axis by axis (the second axis reads the first one's result in the tile's dtype), the
     result cropped by ``crop_yx`` pixels on every side."""
-    src = as_device(values)
+    src = as_device_view(values)
     if src.dtype == np.dtype("bool") or src.dtype == np.dtype("u8"):
         raise NotImplementedError("Smooth on %s tiles" % src.dtype)
     bands, h, w = src.shape
@@ -122,18 +151,18 @@ def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0), fused
     if not axes:  # nothing to smooth: one pass with the identity kernel does the no-data replacement and the crop
         axes = [(2, None)]
     my, mx = crop_yx
-    current, replace = src, has
     L = _lib()
     if fused and len(axes) == 2 and src.dtype == np.dtype("f4"):
         (wy, ry), (wx, rx) = gaussian_weights(axes[0][1]), gaussian_weights(axes[1][1])
         if ry == rx and 1 <= ry <= MAX_FUSED_RADIUS:  # both axes in one launch (csrc/gm_stencil.hip gauss2d_kernel)
             out = DeviceArray.empty((bands, h - 2 * my, w - 2 * mx), src.dtype)
             as_doubles = ctypes.POINTER(ctypes.c_double)
-            runtime.check(L.gm_gauss_2d(ctypes.c_void_p(src.ptr), code_of(src.dtype), bands, h, w,
-                                        wy.ctypes.data_as(as_doubles), wx.ctypes.data_as(as_doubles), ry, float(fill),
-                                        1 if has else 0, ndv_bits, fill_bits, my, mx, h - 2 * my, w - 2 * mx,
-                                        ctypes.c_void_p(out.ptr)), "gm_gauss_2d")
+            _on_window(src, lambda tile, pitch: L.gm_gauss_2d_window(
+                ctypes.c_void_p(tile.ptr), code_of(src.dtype), bands, h, w, pitch, wy.ctypes.data_as(as_doubles),
+                wx.ctypes.data_as(as_doubles), ry, float(fill), 1 if has else 0, ndv_bits, fill_bits, my, mx, h - 2 * my,
+                w - 2 * mx, ctypes.c_void_p(out.ptr)), "gm_gauss_2d")
             return out
+    current, replace = src.contiguous(), has  # (the one-axis kernels read compact tiles)
     for k, (axis, sigma) in enumerate(axes):
         weights, radius = gaussian_weights(sigma) if sigma is not None else (np.ones(1, dtype=np.float64), 0)
         last = k == len(axes) - 1

@@ -365,11 +365,18 @@ int gm_resample_bilinear(const void* src, int dtype, int bands, int hs, int ws,
  * takes it when the value occurs in its 6-neighbourhood over (band, y, x) of the ORIGINAL tile
  * (scipy.ndimage.binary_dilation's default structure).  values_bits: <= 16 gm_scalar payloads. */
 int gm_dilate(const void* in, int dtype, int bands, int h, int w, const uint64_t* values_bits, int n_values, void* out);
+/* The same on a zero-copy window of a wider resident raster: rows in_pitch elements apart (in_pitch >= w), one band.
+ * Served by the LDS-tile kernels; a tile shape / dtype that would need another kernel returns GM_ERR_UNSUPPORTED and
+ * the caller hands over a compact copy instead.  The plain entry point is this one with in_pitch = w. */
+int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, const uint64_t* values_bits, int n_values,
+                     void* out);
 /* MovingMax.process (spatial.py:190-213): maximum over the circular footprint of diameter `size`
  * (odd, 3..63; utils.py:536-547) with no-data lowered to the dtype's minimum; a result that is
  * still the minimum on a no-data centre stays no-data.  out = (bands, h-2r, w-2r), r = size/2.
  * The (32 + 2r) x (64 + 2r) window of a workgroup is staged in LDS. */
 int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, int has_ndv, uint64_t ndv_bits, void* out);
+int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, int size, int has_ndv,
+                         uint64_t ndv_bits, void* out); /* (window rules of gm_dilate_window) */
 /* HillShade.process (spatial.py:354-417): out = uint8 (bands, h-2, w-2).  no-data -> fill (already
  * cast to the tile's dtype), gradients in the tile's dtype (integers wrap like NumPy), then
  * float32 exactly as NumPy orders it; arctan2 / sin are the float32 roundings of the float64
@@ -377,6 +384,9 @@ int gm_moving_max(const void* in, int dtype, int bands, int h, int w, int size, 
  * about 1-5 cells per million differ by 1 from a given NumPy build, at truncation boundaries. */
 int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv, uint64_t ndv_bits, uint64_t fill_bits,
                  double xres, double yres, double altitude_deg, double azimuth_deg, void* out);
+int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, int has_ndv, uint64_t ndv_bits,
+                        uint64_t fill_bits, double xres, double yres, double altitude_deg, double azimuth_deg,
+                        void* out); /* (window rules of gm_dilate_window) */
 
 /* One axis (1 = y, 2 = x) of scipy.ndimage.gaussian_filter as Smooth.process calls it
  * (spatial.py:276-290; mode="constant"): weights_host[j] = weight at distance j (radius + 1 float64
@@ -394,6 +404,9 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
 int gm_gauss_2d(const void* in, int dtype, int bands, int h, int w, const double* weights_y, const double* weights_x,
                 int radius, double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh,
                 int ow, void* out);
+int gm_gauss_2d_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, const double* weights_y,
+                       const double* weights_x, int radius, double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits,
+                       int y0, int x0, int oh, int ow, void* out); /* (window rules of gm_dilate_window) */
 
 /* =============================================================================
  * N4: statistics over the band (time) axis (raster/temporal.py).  `frames` is a C-contiguous

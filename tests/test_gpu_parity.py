@@ -1401,3 +1401,42 @@ def test_zonal_sums_without_the_sort_when_order_cannot_matter(gpu, monkeypatch):
                 forced, _ = geometry.aggregate_labelled([(list(range(n)), labels)], n, values, ndv, thr, stat)
                 monkeypatch.delenv("GM_ZONAL_SORTED")
                 assert_values_equal(forced, want, 0, "%s %s (sorted route)" % (name, stat))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f4", "u1", "i2", "i4", "f8"])
+def test_stencils_on_zero_copy_windows(gpu, dt):
+    """Dilate / MovingMax / HillShade / Smooth on a strided window of a resident raster (rows `pitch` elements apart):
+    the LDS-tile kernels read the window in place (gm_*_window); dtypes / shapes they do not cover are compacted first
+    (GM_ERR_UNSUPPORTED -> copy -> plain call).  Either way the result is that of the compact tile and of the oracle;
+    windows at the raster's corners make the staging's clamped reads touch the first / last rows of the allocation."""
+    from dask_geomodeling_amd.hip.array import DeviceArray
+    from dask_geomodeling_amd.raster import stencil
+    rng = np.random.default_rng(31)
+    H, W = 420, 2300
+    if np.dtype(dt).kind == "f":
+        full = np.cumsum(rng.standard_normal((1, H, W)), axis=2).astype(dt)
+        ndv = np.dtype(dt).type(-9999.0)
+    else:
+        full = rng.integers(0, 9, size=(1, H, W)).astype(dt)
+        ndv = np.dtype(dt).type(7)
+    full[rng.random(full.shape) < 0.1] = ndv
+    resident = DeviceArray.from_numpy(full)
+    for row0, col0, h, w in ((0, 0, 150, 700), (37, 111, 300, 2100), (H - 90, W - 530, 90, 530), (5, 3, 40, 66)):
+        win = resident.window(row0, col0, h, w)
+        assert win.pitch == W
+        host = np.ascontiguousarray(full[:, row0:row0 + h, col0:col0 + w])
+        data = {"values": host, "no_data_value": ndv}
+        for size in (3, 7, 21):
+            got = stencil.moving_max(win, ndv, size).to_numpy()
+            assert np.array_equal(got, O.movingmax_process(data, size)["values"]), ("movingmax", size)
+        for values in ([1], [3, 1, 5]):
+            got = stencil.dilate(win, values).to_numpy()
+            assert np.array_equal(got, O.dilate_process(data, values)["values"]), ("dilate", values)
+        kw = dict(resolution=(0.5, 2.0), altitude=45.0, azimuth=315.0, fill=1)
+        got = stencil.hillshade(win, ndv, 1, kw["resolution"], 45.0, 315.0).to_numpy()
+        with np.errstate(all="ignore"):
+            assert np.array_equal(got, O.hillshade_process(data, kw, trig="rounded")["values"]), "hillshade"
+        for sigma in ((1.0, 1.0), (2.0, 0.7)):
+            got = stencil.gaussian_smooth(win, ndv, 0.5, sigma, (1, 2)).to_numpy()
+            assert np.array_equal(got, stencil.gaussian_smooth(host, ndv, 0.5, sigma, (1, 2)).to_numpy()), ("smooth", sigma)

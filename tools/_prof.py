@@ -1,0 +1,24 @@
+import sys, time, cProfile, pstats, numpy as np
+sys.path.insert(0, "/root/repo")
+from dask_geomodeling_amd import raster, config as gmconfig
+from dask_geomodeling_amd.hip import runtime
+from dask_geomodeling_amd.raster.sources import generate_window
+runtime.set_device(0)
+F32MAX = float(np.finfo("f4").max)
+side, big = 4096, 16384
+da = generate_window((big, big), "f4", 7001, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big)
+A = raster.MemorySource(da, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
+view = raster.HillShade(A)
+boxes = [(float(i * side + 64), float(j * side + 64), float((i + 1) * side + 64), float((j + 1) * side + 64)) for i in range(3) for j in range(3)]
+req = dict(mode="vals", width=side, height=side, projection="EPSG:28992")
+with gmconfig.config.set({"geomodeling.materialize": False}):
+    for k in range(20):
+        view.get_data(bbox=boxes[k % 9], **req)
+    runtime.sync()
+    pr = cProfile.Profile()
+    pr.enable()
+    for k in range(500):
+        view.get_data(bbox=boxes[k % 9], **req)
+    pr.disable()
+    runtime.sync()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(32)
