@@ -318,6 +318,19 @@ def end_to_end(raster, runtime, side, budget_s=6.0):
         v, us, n = rate(one_tile, side * side, 4, 0.15)
     out["get_data_tile_to_host"] = {"Mpix/s": v, "us_per_request": us, "requests": n,
                                     "note": "includes the 64 MiB device-to-host copy of every result (PCIe)"}
+    # a stencil Block over the resident source (row N3): the window is read in place, the margin planned per request
+    shade = raster.HillShade(A)
+    inner = [(b[0] + 64.0, b[1] + 64.0, b[2] - 64.0, b[3] - 64.0) for b in boxes]
+    shade_req = dict(req, width=side - 128, height=side - 128)
+
+    def one_shade():
+        state["k"] += 1
+        return shade.get_data(bbox=inner[state["k"] % 16], **shade_req)
+
+    for label, plans in (("plans", True), ("graph_per_request", False)):
+        with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": plans}):
+            v, us, n = rate(one_shade, (side - 128) ** 2, 32, 0.08)
+        out["hillshade_get_data_tile_device_" + label] = {"Mpix/s": v, "us_per_request": us, "requests": n}
     tiler = raster.RasterTiler(view, side)
     whole = dict(req, bbox=(0.0, 0.0, float(big), float(big)), width=big, height=big)
     for label, plans in (("plans", True), ("graph_per_request", False)):
