@@ -1,2 +1,7 @@
 #!/bin/bash
-python bench.py --steps 20 --warmup 3 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['frac'], d['roofline']['traffic']); print(json.dumps(d['end_to_end'], indent=1)[:1800])"
+tools/gpu_profile.sh r02 chain5 2>&1 | tail -2 | cut -c1-400
+tools/gpu_profile.sh r02 reclass --steps 20 --warmup 3 2>&1 | tail -1 | cut -c1-300
+tools/gpu_profile.sh r02 bilinear --steps 20 --warmup 3 2>&1 | tail -1 | cut -c1-300
+tools/gpu_profile.sh r02 tiler --steps 20 --warmup 3 2>&1 | tail -1 | cut -c1-300
+tools/gpu_profile.sh r02 mosaic --steps 5 --warmup 2 2>&1 | tail -1 | cut -c1-300
+python tools/kbench.py > gpurun_out/kbench_r02.log 2>&1; tail -3 gpurun_out/kbench_r02.log
