@@ -113,9 +113,18 @@ def _build_view_plan(view, request):
             return None
         run = task[0]
     elif getattr(task[0], "gm_op", None) is not None:
-        # a single element-wise operation stays a plain task (nothing to fuse it with): same treatment
-        run = _PlainTask(task, fused)
-        leaf_keys = run.leaf_keys
+        # a single element-wise operation stays a plain task in the graph (nothing to fuse it with); here it becomes a
+        # program of one step, so that its compiled form is kept like everyone else's
+        from .fuse import _deps, _fusable
+        if _fusable(task):
+            leaf_keys = []
+            for dep in _deps(task, fused):
+                if dep not in leaf_keys:
+                    leaf_keys.append(dep)
+            run = FusedTask({name: task}, [name], name, leaf_keys)
+        else:
+            run = _PlainTask(task, fused)
+            leaf_keys = run.leaf_keys
     else:
         return None
     # (every input of the one fused program must be a leaf Block of the walk below; what the graph holds

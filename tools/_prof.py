@@ -8,7 +8,9 @@ F32MAX = float(np.finfo("f4").max)
 side, big = 4096, 16384
 da = generate_window((big, big), "f4", 7001, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big)
 A = raster.MemorySource(da, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
-view = raster.HillShade(A)
+db = generate_window((big, big), "f4", 7002, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big)
+B = raster.MemorySource(db, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
+view = raster.HillShade(A + B) * 0.5
 boxes = [(float(i * side + 64), float(j * side + 64), float((i + 1) * side + 64), float((j + 1) * side + 64)) for i in range(3) for j in range(3)]
 req = dict(mode="vals", width=side, height=side, projection="EPSG:28992")
 with gmconfig.config.set({"geomodeling.materialize": False}):
@@ -21,4 +23,4 @@ with gmconfig.config.set({"geomodeling.materialize": False}):
         view.get_data(bbox=boxes[k % 9], **req)
     pr.disable()
     runtime.sync()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(32)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(45)

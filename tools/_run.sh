@@ -1,7 +1,3 @@
 #!/bin/bash
-tools/gpu_profile.sh r02 chain5 2>&1 | tail -2 | cut -c1-400
-tools/gpu_profile.sh r02 reclass --steps 20 --warmup 3 2>&1 | tail -1 | cut -c1-300
-tools/gpu_profile.sh r02 bilinear --steps 20 --warmup 3 2>&1 | tail -1 | cut -c1-300
-tools/gpu_profile.sh r02 tiler --steps 20 --warmup 3 2>&1 | tail -1 | cut -c1-300
-tools/gpu_profile.sh r02 mosaic --steps 5 --warmup 2 2>&1 | tail -1 | cut -c1-300
-python tools/kbench.py > gpurun_out/kbench_r02.log 2>&1; tail -3 gpurun_out/kbench_r02.log
+python -m pytest tests/test_gpu_plans.py -x -q 2>&1 | tail -2
+python tools/e2e_stencil.py 2>&1 | grep plans
