@@ -333,9 +333,18 @@ class MemorySource(RasterSourceBase):
         is a pixel-aligned window of a single-frame source -- the zero-copy window itself -- without the
         general request planning; None when the request is of any other kind (the caller then takes
         ``get_sources_and_requests`` + ``process``)."""
-        if (request.get("start") is not None or request.get("stop") is not None or self.data.shape[0] != 1 or
-                request.get("mode") != "vals"):
+        if self.data.shape[0] != 1 or request.get("mode") != "vals":
             return None
+        start, stop = request.get("start"), request.get("stop")
+        if start is not None and stop is not None:
+            # a time window (the element-wise Blocks clamp start / stop to the period, elemwise.py:64-78): the one frame
+            # answers it exactly when it lies inside (utils.snap_start_stop); anything else takes the general path
+            moment = self.period[0]
+            try:
+                if not (start <= moment <= stop):
+                    return None
+            except TypeError:
+                return None
         window = self._aligned_window(request)
         if window is None:
             return None

@@ -10,8 +10,8 @@ da = generate_window((big, big), "f4", 7001, 0.0, 100.0, F32MAX, (97, 89), 0, 0,
 A = raster.MemorySource(da, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
 db = generate_window((big, big), "f4", 7002, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big)
 B = raster.MemorySource(db, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
-view = raster.HillShade(A + B) * 0.5
-boxes = [(float(i * side + 64), float(j * side + 64), float((i + 1) * side + 64), float((j + 1) * side + 64)) for i in range(3) for j in range(3)]
+view = raster.Clip(raster.Add(raster.Subtract(raster.Multiply(raster.Add(A, B), 2.5), B), 1.5), A)
+boxes = [(float(i * side), float(j * side), float((i + 1) * side), float((j + 1) * side)) for i in range(3) for j in range(3)]
 req = dict(mode="vals", width=side, height=side, projection="EPSG:28992")
 with gmconfig.config.set({"geomodeling.materialize": False}):
     for k in range(20):
@@ -23,4 +23,4 @@ with gmconfig.config.set({"geomodeling.materialize": False}):
         view.get_data(bbox=boxes[k % 9], **req)
     pr.disable()
     runtime.sync()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
