@@ -658,6 +658,20 @@ def test_hillshade_bit_exact_on_terrain(gpu, dt, scale):
 
 
 @pytest.mark.gpu
+def test_hillshade_float32_kernels_agree(gpu, monkeypatch):
+    """float32 tiles have two kernels: two pixels per lane in packed arithmetic (the default) and the one-pixel LDS-tile
+    kernel every other dtype uses (GM_HS_SINGLE=1 selects it for float32 too): same bits, on a tile with ragged edges."""
+    from dask_geomodeling_amd.raster import stencil
+    rng = np.random.default_rng(6)
+    v = np.cumsum(rng.standard_normal((2, 333, 1111)) * 2, axis=2).astype("f4")
+    v[rng.random(v.shape) < 0.05] = -9999.0
+    pair = stencil.hillshade(v, np.float32(-9999.0), 1, (0.5, 1.0), 45.0, 315.0).to_numpy()
+    monkeypatch.setenv("GM_HS_SINGLE", "1")
+    single = stencil.hillshade(v, np.float32(-9999.0), 1, (0.5, 1.0), 45.0, 315.0).to_numpy()
+    assert np.array_equal(pair, single)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["f4", "i2"])
 def test_hillshade_full_exact_queue_and_true_division(gpu, dt):
     """The corners of the two-tier kernels: a plateau under a sun in the zenith (255 * cang sits exactly on an
