@@ -111,40 +111,218 @@ __global__ __launch_bounds__(256) void zonal_bounds_kernel(const unsigned* __res
   first[l] = lo;
 }
 
+__device__ __forceinline__ void exponent_span(double x, int* top, int* low) {  // x finite, not zero
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+  const int e = (int)((bits >> 52) & 0x7ff);
+  unsigned long long mant = bits & ((1ull << 52) - 1);
+  if (e != 0) mant |= 1ull << 52;
+  const int base = (e != 0 ? e : 1) - 1075;  // value = mant * 2^base
+  *top = base + 63 - __clzll((long long)mant);
+  *low = base + __ffsll((long long)mant) - 1;
+}
+__device__ __forceinline__ double shuffle_xor(double x, int offset) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = __shfl_xor((unsigned)u, offset), hi = __shfl_xor((unsigned)(u >> 32), offset);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// Wave-wide reductions through the data-parallel-primitive paths of the vector unit (a few cycles per step;
+// __shfl goes through the LDS crossbar at ~100): butterflies inside each row of 16 lanes, then the row totals are
+// passed on with row_bcast15 / row_bcast31; lane 63 ends up with the total, which is read back for everybody.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_move(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ int wave_max(int v) {
+  v = max(v, dpp_move<0xB1>(v, v));    // quad_perm [1,0,3,2]
+  v = max(v, dpp_move<0x4E>(v, v));    // quad_perm [2,3,0,1]
+  v = max(v, dpp_move<0x141>(v, v));   // row_half_mirror
+  v = max(v, dpp_move<0x140>(v, v));   // row_mirror
+  v = max(v, dpp_move<0x142, 0xA>(INT_MIN, v));  // row_bcast15 into rows 1 and 3
+  v = max(v, dpp_move<0x143, 0xC>(INT_MIN, v));  // row_bcast31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min(int v) { return -wave_max(v == INT_MIN ? INT_MAX : -v); }
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_move_f64(double identity, double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v), w = (unsigned long long)__double_as_longlong(identity);
+  const unsigned lo = (unsigned)dpp_move<CTRL, ROW_MASK>((int)(unsigned)w, (int)(unsigned)u);
+  const unsigned hi = (unsigned)dpp_move<CTRL, ROW_MASK>((int)(unsigned)(w >> 32), (int)(unsigned)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum_exact(double v) {  // (for sums known to be exact: the tree's shape is immaterial)
+  v += dpp_move_f64<0xB1>(v, v);
+  v += dpp_move_f64<0x4E>(v, v);
+  v += dpp_move_f64<0x141>(v, v);
+  v += dpp_move_f64<0x140>(v, v);
+  v += dpp_move_f64<0x142, 0xA>(0.0, v);
+  v += dpp_move_f64<0x143, 0xC>(0.0, v);
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, 63), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// top exponent / exponent of the lowest set bit of a cell as bincount sees it ((double)v), from the cell's own
+// representation where that is cheaper; zero, NaN and infinities are the caller's business (finite, not zero here)
+template <typename T>
+__device__ __forceinline__ void cell_span(T v, int* top, int* low) {
+  if constexpr (std::is_same<T, float>::value) {
+    const unsigned bits = __float_as_uint(v);
+    const int e = (int)((bits >> 23) & 0xff);
+    const unsigned mant = (bits & 0x7fffffu) | (e != 0 ? 0x800000u : 0u);
+    const int base = (e != 0 ? e : 1) - 150;  // value = mant * 2^base
+    *top = base + 31 - __clz((int)mant);
+    *low = base + __ffs((int)mant) - 1;
+  } else if constexpr (std::is_integral<T>::value && sizeof(T) <= 4) {
+    const long long wide = (long long)v;
+    const unsigned mag = (unsigned)(wide < 0 ? -wide : wide);
+    *top = 31 - __clz((int)mag);
+    *low = __ffs((int)mag) - 1;
+  } else {
+    exponent_span((double)v, top, low);
+  }
+}
+
 // np.bincount(labels, weights=values)[l]: sums[l] += (double)value, cell after cell in raster order.
-// One wave per label.  64 cells per step: a coalesced load and the conversion to float64 by all lanes, the
-// values parked in LDS, then every lane runs the same chain of 64 dependent additions on broadcast reads (the
-// wave is one sequential adder; what bounds it is the latency of v_add_f64, ~8 cycles per cell).  Cells past
-// the end of the label add +0.0, which changes nothing (the sum starts from +0.0 like bincount's zeros).
+// One wave per label, 256 cells per step (a lane loads 4 consecutive cells with one 16-byte load).
+//   * The step is EXACT when none of its additions can round: with lo = the lowest set bit among the 256 cells and the
+//     running sum, every intermediate value is a multiple of 2^lo, and it stays below 2^(lo + 53) when
+//     max(top of the sum, top of the cells + 8) + 2 - lo <= 53 -- then the order inside the step is immaterial: every
+//     lane adds its 4 cells, the wave adds the 64 partial sums as a tree and puts the total onto the running sum; the
+//     bits are those of bincount's 256 additions.  Sums of ordinary data over thousands of cells run on this path.
+//   * Otherwise the step is replayed literally: the values parked in LDS, every lane runs the same chain of dependent
+//     additions on broadcast reads (the wave as one sequential adder, ~20 cycles per cell).
+// Cells past the end of the label add +0.0, which changes nothing (the sum starts from +0.0 like bincount's zeros).
+constexpr int ZS_PER_LANE = 4, ZS_STEP = 64 * ZS_PER_LANE;
 template <typename T>
 __global__ __launch_bounds__(256) void zonal_sum_kernel(const typename Ordered<T>::Key* __restrict__ payload,
                                                         const unsigned* __restrict__ first, int n_labels, int statistic,
                                                         float* __restrict__ out, long long* __restrict__ counts) {
-  __shared__ __align__(16) double parked[4][64];
+  typedef typename Ordered<T>::Key Key;
+  __shared__ __align__(16) double parked[4][ZS_STEP];
   const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (l >= n_labels) return;
   const unsigned a = first[l], b = first[l + 1];
+  if (a == b) {  // no active cell
+    if (lane == 0) {
+      counts[l] = 0;
+      out[l] = std::numeric_limits<float>::quiet_NaN();
+    }
+    return;
+  }
   double* mine = parked[wave];
   double acc = 0.0;
-  unsigned at = a + lane;
-  double next = at < b ? (double)Ordered<T>::decode(payload[at]) : 0.0;
-  for (unsigned i = a; i < b; i += 64) {
-    mine[lane] = next;  // (a wave's LDS accesses complete in order: no barrier between its own write and reads)
-    at += 64;
-    next = at < b ? (double)Ordered<T>::decode(payload[at]) : 0.0;  // the next step's cells, in flight during the chain
-    // all 32 LDS reads first (128 registers), then the chain: left to itself the compiler keeps three reads
-    // in flight and the chain waits for LDS every second addition
-    typedef double f64x2 __attribute__((ext_vector_type(2)));
-    f64x2 cell[32];
+  struct Four { Key k[ZS_PER_LANE]; };
+  const Key nothing = Ordered<T>::encode(T(0));
+  // The lane's 4 consecutive cells of a step.  The loads of the full steps are unconditional (addresses clamped into
+  // the label, nothing selected): with a branch or a select around them the compiler drains all outstanding loads at
+  // every step, and a wave that is alone on its SIMD then pays the full memory latency 40 times per 10 k cells.  Only
+  // the last, partial step masks the cells past the label (they become zeros).
+  const unsigned last = b - 1;  // (b > a here)
+  auto fetch = [&](unsigned step) -> Four {
+    Four f;
+    const unsigned at = a + step * ZS_STEP + ZS_PER_LANE * lane;  // (fewer than 2^31 cells: no wrap for the steps asked)
 #pragma unroll
-    for (int k = 0; k < 32; ++k) cell[k] = *reinterpret_cast<const f64x2*>(mine + 2 * k);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int k = 0; k < ZS_PER_LANE; ++k) f.k[k] = payload[min(at + k, last)];
+    return f;
+  };
+  const unsigned full_steps = (b - a) / ZS_STEP, steps = (b - a + ZS_STEP - 1) / ZS_STEP;
+  // Steps are taken UNROLL at a time: what a step needs from its own cells -- their span, the tree sum -- does not depend
+  // on the running sum, so the instruction streams of UNROLL steps interleave (a wave that is alone on its SIMD has no
+  // other wave to fill the latency of its dependent instructions); only the verdict and the addition go step by step.
+  constexpr int UNROLL = 4, AHEAD = 2;  // AHEAD groups of UNROLL steps of cells in flight
+  struct Step {
+    T cell[ZS_PER_LANE];
+    int top, low;
+    bool finite;
+    double total;
+  };
+  auto analyse = [&](Four now, unsigned step) -> Step {
+    if (step >= full_steps) {  // (wave-uniform; the one partial step, or a step past the label: all zeros)
+      const unsigned at = a + step * ZS_STEP + ZS_PER_LANE * lane;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      acc += cell[k].x;
-      acc += cell[k].y;
+      for (int k = 0; k < ZS_PER_LANE; ++k)
+        if (at + k >= b || step >= steps) now.k[k] = nothing;
     }
-    __builtin_amdgcn_sched_barrier(0);
+    Step s;
+    s.top = INT_MIN;
+    s.low = INT_MAX;
+    bool finite = true;
+    double partial = 0.0;
+#pragma unroll
+    for (int k = 0; k < ZS_PER_LANE; ++k) {
+      s.cell[k] = Ordered<T>::decode(now.k[k]);
+      const double x = (double)s.cell[k];
+      if constexpr (std::is_floating_point<T>::value) finite = finite && fabs(x) <= 1.7976931348623157e308;
+      if (x != 0.0 && fabs(x) <= 1.7976931348623157e308) {
+        int t, w;
+        cell_span<T>(s.cell[k], &t, &w);
+        s.top = max(s.top, t);
+        s.low = min(s.low, w);
+      }
+      partial += x;
+    }
+    s.top = wave_max(s.top);
+    s.low = wave_min(s.low);
+    s.finite = __all(finite);
+    s.total = wave_sum_exact(partial);  // (only used when the step is exact)
+    return s;
+  };
+  auto apply = [&](const Step& s) {
+    int acc_top = INT_MIN, acc_low = INT_MAX;
+    const bool acc_finite = fabs(acc) <= 1.7976931348623157e308;
+    if (acc_finite && acc != 0.0) exponent_span(acc, &acc_top, &acc_low);
+    const int lo = min(s.low, acc_low);
+    const long long hi = max((long long)acc_top, (long long)s.top + 8) + 2;  // 256 cells: 8 more bits
+    const bool exact = s.finite && acc_finite && (s.top == INT_MIN || (hi - lo <= 53 && hi < 1023));
+    if (exact) {
+      acc += s.total;
+      return;
+    }
+    // replay: park the 256 values in order (a wave's LDS accesses complete in order: no barrier between its own write
+    // and reads), then 4 rounds of: all 32 LDS reads first (128 registers), then the chain of 64 additions
+#pragma unroll
+    for (int k = 0; k < ZS_PER_LANE; ++k) mine[ZS_PER_LANE * lane + k] = (double)s.cell[k];
+    // 16 values (8 sixteen-byte reads) per round, the next round's reads issued before this round's 16 additions: the
+    // chain never waits for LDS (8 reads outstanding fit the 4-bit counter the wait instruction can express)
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    constexpr int ROUND = 16, ROUNDS = ZS_STEP / ROUND;
+    f64x2 buffer[2][ROUND / 2];
+#pragma unroll
+    for (int k = 0; k < ROUND / 2; ++k) buffer[0][k] = *reinterpret_cast<const f64x2*>(mine + 2 * k);
+#pragma unroll
+    for (int round = 0; round < ROUNDS; ++round) {
+      if (round + 1 < ROUNDS) {
+#pragma unroll
+        for (int k = 0; k < ROUND / 2; ++k)
+          buffer[(round + 1) & 1][k] = *reinterpret_cast<const f64x2*>(mine + ROUND * (round + 1) + 2 * k);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < ROUND / 2; ++k) {
+        acc += buffer[round & 1][k].x;
+        acc += buffer[round & 1][k].y;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  Four ahead[AHEAD][UNROLL];
+#pragma unroll
+  for (int g = 0; g < AHEAD; ++g)
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) ahead[g][u] = fetch((unsigned)(g * UNROLL + u));
+  for (unsigned step = 0; step < steps; step += UNROLL) {
+    Step group[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) group[u] = analyse(ahead[0][u], step + u);
+#pragma unroll
+    for (int g = 0; g + 1 < AHEAD; ++g)
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) ahead[g][u] = ahead[g + 1][u];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) ahead[AHEAD - 1][u] = fetch(step + AHEAD * UNROLL + u);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      if (step + u < steps) apply(group[u]);  // (wave-uniform)
   }
   if (lane == 0) {
     const unsigned n = b - a;
@@ -194,6 +372,43 @@ __global__ __launch_bounds__(256) void zonal_pick_kernel(const typename Ordered<
     result = (float)((double)x + (frac - below) * (double)diff);
   }
   out[l] = result;
+}
+
+// The walk of a wave over its stretch of cells [begin, end), 64 at a time: `body(value, label, inside, index)`.  The
+// loads of the full steps are unconditional and DEPTH steps ahead (a select or a branch around a load makes the
+// compiler drain every outstanding load at each step); only the last, partial step tests `inside`.
+template <typename T, typename Body>
+__device__ __forceinline__ void walk_cells(const T* __restrict__ values, const int* __restrict__ labels, size_t begin, size_t end,
+                                           int lane, Body body) {
+  if (begin >= end) return;
+  constexpr int DEPTH = 4;
+  const size_t full = (end - begin) / 64, last = end - 1;
+  T ahead_v[DEPTH];
+  int ahead_l[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    const size_t at = min(begin + (size_t)d * 64 + lane, last);
+    ahead_v[d] = values[at];
+    ahead_l[d] = labels[at];
+  }
+  for (size_t step = 0; step < full; ++step) {
+    const T v = ahead_v[0];
+    const int label = ahead_l[0];
+#pragma unroll
+    for (int d = 0; d + 1 < DEPTH; ++d) {
+      ahead_v[d] = ahead_v[d + 1];
+      ahead_l[d] = ahead_l[d + 1];
+    }
+    const size_t at = min(begin + (step + DEPTH) * 64 + lane, last);
+    ahead_v[DEPTH - 1] = values[at];
+    ahead_l[DEPTH - 1] = labels[at];
+    body(v, label, true, begin + step * 64 + lane);
+  }
+  if (begin + full * 64 < end) {  // (whole waves enter the partial step too: cross-lane operations in the body)
+    const size_t i = begin + full * 64 + lane;
+    const bool inside = i < end;
+    body(inside ? values[i] : T(0), inside ? labels[i] : -1, inside, i);
+  }
 }
 
 // count / min / max need no order at all: one pass of atomics on the per-label counters and on the ordered
@@ -246,11 +461,9 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
     run_count = 0;
     run_key = NEUTRAL;
   };
-  for (size_t i = begin + lane; i < end + lane; i += 64) {  // (whole waves enter every step)
-    if (i - lane >= end) break;
-    const bool inside = i < end;
-    const T v = inside ? values[i] : T(0);
-    const int label = inside ? labels[i] : -1;
+  walk_cells<T>(values, labels, begin, end, lane, [&](T v, int label, bool inside, size_t i) {
+    (void)inside;
+    (void)i;
     const bool labelled = (unsigned)label < (unsigned)n_labels;
     if (present && labelled) present[label] = 1;
     bool active = labelled && !(has_ndv && v == ndv);
@@ -259,8 +472,8 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
       active = !(t != t) && (double)v >= (double)t;
     }
     const unsigned long long mask = __ballot(active);
-    if (mask == 0) continue;  // (wave-uniform)
-    const int leader_label = __shfl(label, __ffsll((long long)mask) - 1);
+    if (mask == 0) return;  // (wave-uniform)
+    const int leader_label = __builtin_amdgcn_readlane(label, __ffsll((long long)mask) - 1);  // (a uniform lane index)
     const Key key = Ordered<T>::encode(v);
     if (__all(!active || label == leader_label)) {
       // one label among the active cells of this step: it joins the wave's run, no traffic between lanes
@@ -277,7 +490,7 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
       if constexpr (STAT == Z_MIN) atomicMin(&extreme[label], key);
       if constexpr (STAT == Z_MAX) atomicMax(&extreme[label], key);
     }
-  }
+  });
   flush();
 }
 
@@ -308,20 +521,6 @@ struct ExactRange {
   int hi, lo;       // top exponent / exponent of the lowest set bit over the non-zero cells
   unsigned bad;     // a NaN or an infinity among the cells
 };
-__device__ __forceinline__ void exponent_span(double x, int* top, int* low) {  // x finite, not zero
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
-  const int e = (int)((bits >> 52) & 0x7ff);
-  unsigned long long mant = bits & ((1ull << 52) - 1);
-  if (e != 0) mant |= 1ull << 52;
-  const int base = (e != 0 ? e : 1) - 1075;  // value = mant * 2^base
-  *top = base + 63 - __clzll((long long)mant);
-  *low = base + __ffsll((long long)mant) - 1;
-}
-__device__ __forceinline__ double shuffle_xor(double x, int offset) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-  const unsigned lo = __shfl_xor((unsigned)u, offset), hi = __shfl_xor((unsigned)(u >> 32), offset);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
 template <typename T, int PHASE>
 __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
                                                           size_t cells_per_wave, int n_labels, int has_ndv, T ndv,
@@ -383,10 +582,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
       atomicAdd(&sums[label], x);
     }
   };
-  for (size_t i = begin + lane; i - lane < end; i += 64) {  // (whole waves enter every step)
-    const bool inside = i < end;
-    const T v = inside ? values[i] : T(0);
-    const int label = inside ? labels[i] : -1;
+  walk_cells<T>(values, labels, begin, end, lane, [&](T v, int label, bool inside, size_t i) {
     const bool labelled = (unsigned)label < (unsigned)n_labels;
     if (PHASE == 0 && present && labelled) present[label] = 1;
     bool active = labelled && !(has_ndv && v == ndv);
@@ -401,8 +597,8 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
       }
     }
     const unsigned long long mask = __ballot(active);
-    if (mask == 0) continue;  // (wave-uniform)
-    const int leader_label = __shfl(label, __ffsll((long long)mask) - 1);
+    if (mask == 0) return;  // (wave-uniform)
+    const int leader_label = __builtin_amdgcn_readlane(label, __ffsll((long long)mask) - 1);  // (a uniform lane index)
     const double x = (double)v;  // what bincount adds
     if (__all(!active || label == leader_label)) {
       if (leader_label != run_label) {
@@ -416,7 +612,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
             run_bad = 1;
           } else if (x != 0.0) {
             int top, low;
-            exponent_span(x, &top, &low);
+            cell_span<T>(v, &top, &low);
             run_hi = max(run_hi, top);
             run_lo = min(run_lo, low);
           }
@@ -427,7 +623,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
     } else if (active) {
       take(label, x);
     }
-  }
+  });
   flush();
 }
 

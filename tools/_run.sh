@@ -1,4 +1,12 @@
 #!/bin/bash
-python -m pytest tests/test_gpu_plans.py tests/test_gpu_fuzz.py -x -q 2>&1 | tail -2
-python tools/e2e_stencil.py 2>&1 | grep plans
-python bench.py --steps 20 --warmup 3 --cpu-tiles 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); e=d['end_to_end']; print({k:v for k,v in e.items() if k!='config'})"
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/k_trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/k_trace -o k -- python3 $R/tools/stencil_driver.py zonalsum > /dev/null 2>&1
+cd $R
+python3 - <<'PY'
+import csv, glob
+for f in glob.glob("gpurun_out/k_trace/**/*kernel_stats.csv", recursive=True):
+    for row in list(csv.DictReader(open(f)))[:12]:
+        print("%-90s %5s avg us %9.1f" % (row["Name"][:90], row["Calls"], float(row["AverageNs"]) / 1e3))
+PY
