@@ -1,4 +1,7 @@
 #!/bin/bash
-python tests/fuzz_more.py 4000 2>&1 | tail -4
-GM_SPEC=2 python tests/fuzz_more.py 500 2>&1 | tail -2
-python tests/stencil_stress.py 1200 2>&1 | tail -2
+tools/gpu_profile.sh r02 chain5 2>&1 | tail -1 | cut -c1-200
+tools/gpu_profile.sh r02 reclass --steps 20 --warmup 3 2>&1 | tail -1 | cut -c1-200
+tools/gpu_profile.sh r02 bilinear --steps 20 --warmup 3 2>&1 | tail -1 | cut -c1-200
+tools/gpu_profile.sh r02 tiler --steps 20 --warmup 3 2>&1 | tail -1 | cut -c1-200
+tools/gpu_profile.sh r02 mosaic --steps 5 --warmup 2 2>&1 | tail -1 | cut -c1-200
+python tools/kbench.py > gpurun_out/kbench_r02.log 2>&1; grep zonal gpurun_out/kbench_r02.log
