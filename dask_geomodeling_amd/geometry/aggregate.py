@@ -92,8 +92,9 @@ def label_statistics(values, no_data_value, labels, n_labels, statistic, percent
     has_ndv = no_data_value is not None
     with np.errstate(all="ignore"):
         ndv_bits = runtime.scalar_bits(np.asarray(no_data_value).astype(tile.dtype)[()] if has_ndv else 0, tile.dtype)
-    if has_ndv and np.asarray(no_data_value).astype(tile.dtype)[()] != no_data_value:
-        has_ndv = False  # a no-data value the raster's dtype cannot hold equals no cell (frame != value is all True)
+    with np.errstate(all="ignore"):
+        if has_ndv and np.asarray(no_data_value).astype(tile.dtype)[()] != no_data_value:
+            has_ndv = False  # a no-data value the raster's dtype cannot hold equals no cell (frame != value is all True)
     # one device buffer for the three results (counts first: 8-byte aligned), one copy back
     cells = frames * n_labels
     packed = DeviceArray.empty((cells * 12 + n_labels,), "u1")

@@ -902,10 +902,14 @@ ZONAL_STATISTICS = ("sum", "count", "min", "max", "mean", "median", "percentile"
 def _labelled_sums(weights, labels, index):
     """scipy.ndimage sum / mean over labels (``_stats``): np.bincount -- float64 accumulation cell after cell
     in raster order.  Returns (counts, sums) for ``index``."""
-    labels = labels.ravel()
-    counts = np.bincount(labels)
-    sums = np.bincount(labels, weights=np.broadcast_to(weights, labels.shape) if np.ndim(weights) == 0 else weights.ravel())
-    return counts[index], sums[index]
+    # (SciPy remaps the labels through np.unique when they are negative or larger than the number of cells, and calls
+    #  bincount directly otherwise: the accumulation order is the cells' order either way)
+    unique_labels, dense = np.unique(labels.ravel(), return_inverse=True)
+    dense = dense.reshape(-1)
+    counts = np.bincount(dense)
+    sums = np.bincount(dense, weights=np.broadcast_to(weights, dense.shape) if np.ndim(weights) == 0 else weights.ravel())
+    where = np.searchsorted(unique_labels, index)
+    return counts[where], sums[where]
 
 
 def _labelled_segments(values, labels, index):

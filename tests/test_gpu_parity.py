@@ -1454,3 +1454,39 @@ def test_stencils_on_zero_copy_windows(gpu, dt):
         for sigma in ((1.0, 1.0), (2.0, 0.7)):
             got = stencil.gaussian_smooth(win, ndv, 0.5, sigma, (1, 2)).to_numpy()
             assert np.array_equal(got, stencil.gaussian_smooth(host, ndv, 0.5, sigma, (1, 2)).to_numpy()), ("smooth", sigma)
+
+
+@pytest.mark.gpu
+def test_zonal_edge_cases(gpu):
+    """Corners of geometry.label_statistics: no labels at all, nothing labelled, a raster without cells, zero frames, a
+    million labels of which three occur, thresholds that are all NaN, a no-data value the dtype cannot hold, labels outside
+    [0, n), int8 percentiles whose difference wraps -- against the oracle's per-bucket restatement."""
+    from dask_geomodeling_amd import geometry
+    rng = np.random.default_rng(3)
+    values = (rng.standard_normal((2, 30, 40)) * 10).astype("f4")
+    labels = rng.integers(0, 5, size=(30, 40)).astype(np.int32)
+
+    def check(values, ndv, labels, n, stat, q=None, thr=None):
+        got, counts, present = geometry.label_statistics(values, ndv, labels, n, stat, q, thr)
+        want, _ = O.aggregate_labelled([(list(range(n)), labels)], n, values, ndv, thr, stat, q)
+        assert got.shape == (values.shape[0], n) and counts.shape == got.shape and present.shape == (n,)
+        merged = np.where(counts > 0, got, np.float32(np.nan)).astype("f4")
+        assert_values_equal(merged, want, 0, "%s n=%d" % (stat, n))
+        return got, counts, present
+
+    for stat, q in (("sum", None), ("count", None), ("max", None), ("median", None), ("percentile", 30.0)):
+        got, counts, present = check(values, np.float32(-1.0), labels, 0, stat, q)                       # no labels
+        check(values, np.float32(-1.0), np.full((30, 40), np.iinfo(np.int32).max, np.int32), 4, stat, q)  # nothing labelled
+        check(values[:, :0, :], np.float32(-1.0), labels[:0, :], 3, stat, q)                              # no cells
+        check(values[:0], np.float32(-1.0), labels, 5, stat, q)                                           # no frames
+        check(values, np.float32(-1.0), labels - 2, 3, stat, q)                                           # labels -2 .. 2: negative ones ignored
+        check(values, np.float32(-1.0), labels, 5, stat, q, np.full(5, np.nan, "f4"))                     # no geometry has a threshold
+        check(values, 1e300, labels, 5, stat, q)                                                          # a no-data value float32 cannot hold
+        sparse = np.where(labels < 3, labels * 499_999, np.iinfo(np.int32).max).astype(np.int32)
+        got, counts, present = check(values, np.float32(-1.0), sparse, 1_000_000, stat, q)                # a million labels, three occur
+        assert present.sum() == 3 and (counts[0] > 0).sum() == 3
+    small = rng.integers(-128, 128, size=(1, 30, 40)).astype("i1")
+    for q in (10.0, 50.0, 99.0):
+        check(small, np.int8(-128), labels, 5, "percentile", q)  # int8: data[hi] - data[lo] wraps modulo 256
+    with pytest.raises(TypeError):
+        geometry.label_statistics(values > 0, None, labels, 5, "percentile", 50.0)
