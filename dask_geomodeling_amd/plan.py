@@ -178,7 +178,15 @@ def _run_tiler(tiler, request):
     for _, tile_request in pairs[1:]:
         plan = view_plan(store, tile_request)
         if plan is None or not isinstance(plan.task, FusedTask):
-            return False, None
+            # no program to batch (a store with a kernel of its own, a single unfusable operation): tile by tile
+            # through whatever plan the store has, assembled by the Block's own process
+            responses = []
+            for _, request in pairs[1:]:
+                planned, response = evaluate(store, request)
+                if not planned:
+                    return False, None
+                responses.append(response)
+            return True, type(tiler).process(kwargs, *responses)
         b = index_of.get(id(plan))
         if b is None:
             b = index_of[id(plan)] = len(batches)

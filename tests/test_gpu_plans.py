@@ -103,6 +103,8 @@ def test_stencil_blocks_through_plans(gpu):
         "dilate(classify)": raster.Dilate(classes, [1, 3]),
         "movingmax(smooth(view))": raster.MovingMax(raster.Smooth(A + 1, 3.0), 3),
         "tiler(view(hillshade))": raster.RasterTiler(raster.HillShade(A) * 0.5 + B, 64),
+        "tiler(hillshade(view))": raster.RasterTiler(raster.HillShade(A * 2 + B), [48, 64]),
+        "tiler(smooth(source))": raster.RasterTiler(raster.Smooth(A, 2.0), 64),
     }
     boxes = [(0.0, 0.0, 128.0, 128.0), (40.0, 30.0, 168.0, 158.0), (100.0, 60.0, 228.0, 188.0), (-20.0, -10.0, 108.0, 118.0)]
     for name, view in views.items():

@@ -1,2 +1,2 @@
 #!/bin/bash
-python -m pytest tests/test_gpu_parity.py -x -q -k "zonal_edge" 2>&1 | tail -15
+python -m pytest tests/test_gpu_plans.py tests/test_gpu_fuzz.py -x -q 2>&1 | tail -3
