@@ -14,8 +14,8 @@ in its ``bbox`` only, and all that has to be redone per request is the leaves' o
 which source).  A ``ViewPlan`` keeps the fused task and the leaf Blocks of one (view, request-without-bbox);
 a ``RasterTiler`` over such a view evaluates all its tiles through the store's plans and the in-place
 mosaic assembly of fuse.py.  Blocks with a kernel of their own over one store (Dilate, MovingMax, HillShade, Smooth,
-SpatialResample, TemporalAggregate, Cumulative: ``gm_direct``) are leaves of the plans above them and evaluate their store
-through the store's plan (``_direct``).  Everything else -- other modes, Group, configured dask schedulers -- takes the
+SpatialResample, TemporalAggregate, Cumulative, Group: ``gm_direct``) are leaves of the plans above them and evaluate their store
+through the store's plan (``_direct``).  Everything else -- other modes, configured dask schedulers -- takes the
 ordinary graph path, as does a request whose plan cannot be built.
 """
 

@@ -151,6 +151,7 @@ class Group(BaseCombine):
     the right' are shown in the result, 'no data' is transparent."""
 
     NOTHING = [(dict(combine_mode="simple"), None)]
+    gm_direct = True  # plan.py: evaluated as process(sources' responses) without a graph per request
 
     # -- request planning -----------------------------------------------------------------
     def get_relevant_sources(self, start, stop):
