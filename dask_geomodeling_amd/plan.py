@@ -19,6 +19,8 @@ through the store's plan (``_direct``).  Everything else -- other modes, configu
 ordinary graph path, as does a request whose plan cannot be built.
 """
 
+import threading
+
 from . import config as _config
 from .core.graphs import Block, _request_token
 
@@ -212,22 +214,37 @@ def _direct(block, request):
     return block.process(*args)
 
 
+_running = threading.local()  # .memo: {(id(block), request): response} of the evaluation in progress on this thread
+
+
 def _child(block, request):
-    """The response of a source Block for one request, not materialised: through its plan when it has one."""
+    """The response of a source Block for one request, not materialised: through its plan when it has one.  Within
+    one evaluation the same (Block, request) is answered once -- what the shared keys of a graph achieve."""
     short_cut = getattr(block, "gm_plan_response", None)  # (a resident source answers an aligned window at once)
     if short_cut is not None and request.get("mode") == "vals":
         response = short_cut(request)
         if response is not None:
             return response
+    memo = getattr(_running, "memo", None)
+    key = None
+    if memo is not None:
+        try:
+            key = (id(block), tuple(sorted((k, tuple(v) if isinstance(v, list) else v) for k, v in request.items())))
+            if key in memo:
+                return memo[key]
+        except TypeError:
+            key = None
     planned, response = evaluate(block, request)
-    if planned:
-        return response
-    from .core.graphs import compute
-    graph, name = block.get_compute_graph(**request)
-    if _config.get("geomodeling.fuse", True):
-        from .fuse import fuse_graph
-        graph = fuse_graph(graph, name)
-    return compute(graph, name)
+    if not planned:
+        from .core.graphs import compute
+        graph, name = block.get_compute_graph(**request)
+        if _config.get("geomodeling.fuse", True):
+            from .fuse import fuse_graph
+            graph = fuse_graph(graph, name)
+        response = compute(graph, name)
+    if key is not None:
+        memo[key] = response
+    return response
 
 
 def enabled():
@@ -244,6 +261,16 @@ def evaluate(view, request):
     """(True, response) when the request was answered through a plan, else (False, None)."""
     if request.get("mode") != "vals" or "bbox" not in request or not enabled():
         return False, None
+    if getattr(_running, "memo", None) is None:  # the outermost evaluation on this thread owns the memo
+        _running.memo = {}
+        try:
+            return _evaluate(view, request)
+        finally:
+            _running.memo = None
+    return _evaluate(view, request)
+
+
+def _evaluate(view, request):
     if getattr(type(view).process, "gm_tiler", False) and hasattr(view, "store"):
         return _run_tiler(view, request)
     plan = view_plan(view, request)
