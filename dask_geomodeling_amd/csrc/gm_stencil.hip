@@ -657,7 +657,17 @@ __device__ __forceinline__ unsigned char shade_cell(float x, float y, const Hill
 // float32 / float64 round after every operation (-ffp-contract=off)
 template <typename T>
 __device__ __forceinline__ float gradient(T a, T b2, T c, T d, T e2, T f, double res, float res32, double inv, float inv32) {
-  if constexpr (std::is_integral<T>::value) {
+  if constexpr (std::is_integral<T>::value && sizeof(T) <= 4) {
+    // modular arithmetic in 32 bits: the truncation to T equals NumPy's wrap-around at every step
+    const unsigned wide = (unsigned)a + 2u * (unsigned)b2 + (unsigned)c - (unsigned)d - 2u * (unsigned)e2 - (unsigned)f;
+    const T s = (T)wide;
+    // a power-of-two resolution: float(float64(s) * inv) = float(s) * inv32 -- the product with a power of two is exact
+    // either way and the one rounding (of s, when it has more than 24 bits) is the same; far outside float32's
+    // comfortable exponent range the float64 route stays
+    if (inv32 != 0.0f && fabsf(inv32) < 0x1p64f && fabsf(inv32) > 0x1p-64f) return (float)s * inv32;
+    const double wide_s = (double)s;
+    return (float)(inv != 0.0 ? wide_s * inv : wide_s / res);
+  } else if constexpr (std::is_integral<T>::value) {
     typedef unsigned long long U;  // modular arithmetic: the truncation to T equals NumPy's wrap-around
     const U wide = (U)(long long)a + 2ull * (U)(long long)b2 + (U)(long long)c - (U)(long long)d - 2ull * (U)(long long)e2 - (U)(long long)f;
     const double s = (double)(T)wide;
@@ -824,11 +834,15 @@ __global__ __launch_bounds__(256) void hillshade_tile_kernel(const T* __restrict
 // the pixel above and the one below.  Workgroup: HP_H rows x 512 columns.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int HP_H = 8, HP_W = 512;
-template <bool USE_INV>
-__global__ __launch_bounds__(256) void hillshade_pair_kernel(const float* __restrict__ in, unsigned char* __restrict__ out,
-                                                             int h, int w, int pitch, int has_ndv, float ndv, float fill, HillArgs A) {
+// T: float, or an integer type of up to 4 bytes (USE_INV only): the Sobel sums of integers run in 32-bit modular
+// arithmetic per pixel (NumPy's wrap-around), and float(s) * inv is the float32 the reference's float64 route gives for
+// a power-of-two resolution (see gradient()); everything after the gradient is the same packed float32 arithmetic.
+template <typename T, bool USE_INV>
+__global__ __launch_bounds__(256) void hillshade_pair_kernel(const T* __restrict__ in, unsigned char* __restrict__ out,
+                                                             int h, int w, int pitch, int has_ndv, T ndv, T fill, HillArgs A) {
+  static_assert(std::is_same<T, float>::value || (std::is_integral<T>::value && sizeof(T) <= 4 && USE_INV), "see above");
   constexpr int PITCH = HP_W + 2;
-  __shared__ __align__(16) float tile[(HP_H + 2) * PITCH];
+  __shared__ __align__(16) T tile[(HP_H + 2) * PITCH];
   __shared__ __align__(16) unsigned char shade[HP_H * HP_W];
   constexpr unsigned HP_PENDING = 256;
   __shared__ float pending_x[HP_PENDING], pending_y[HP_PENDING];
@@ -837,13 +851,13 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const float* __rest
   if (threadIdx.x == 0) pending_count = 0;
   const int c0 = blockIdx.x * HP_W, r0 = blockIdx.y * HP_H, b = blockIdx.z;
   const int ow = w - 2, oh = h - 2;
-  const float* plane = in + (size_t)b * h * w;
-  auto clean = [&](float v) -> float { return (has_ndv && v == ndv) ? fill : v; };  // spatial.py:363-364
+  const T* plane = in + (size_t)b * h * w;
+  auto clean = [&](T v) -> T { return (has_ndv && v == ndv) ? fill : v; };  // spatial.py:363-364
   {
     // a lane stages columns t and t + 256 of the window, lanes 0..35 the two columns east of the 512
-    const float* west = plane + min(c0 + (int)threadIdx.x, w - 1);  // (clamped: cells past the tile feed no output)
-    const float* east = plane + min(c0 + 256 + (int)threadIdx.x, w - 1);
-    float sw[HP_H + 2], se[HP_H + 2];
+    const T* west = plane + min(c0 + (int)threadIdx.x, w - 1);  // (clamped: cells past the tile feed no output)
+    const T* east = plane + min(c0 + 256 + (int)threadIdx.x, w - 1);
+    T sw[HP_H + 2], se[HP_H + 2];
 #pragma unroll
     for (int wy = 0; wy < HP_H + 2; ++wy) {
       const size_t row = (size_t)min(r0 + wy, h - 1) * pitch;
@@ -852,7 +866,7 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const float* __rest
     }
     const bool rim = threadIdx.x < 2 * (HP_H + 2);
     const int ry = threadIdx.x >> 1, rx = HP_W + (threadIdx.x & 1);
-    float beyond = 0.0f;
+    T beyond = T(0);
     if (rim) beyond = plane[(size_t)min(r0 + ry, h - 1) * pitch + min(c0 + rx, w - 1)];
 #pragma unroll
     for (int wy = 0; wy < HP_H + 2; ++wy) {
@@ -862,15 +876,20 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const float* __rest
     if (rim) tile[ry * PITCH + rx] = clean(beyond);
   }
   __syncthreads();
-  const float* col = tile + 2 * threadIdx.x;  // window column of the west neighbour of the lane's first pixel
-  struct Row { f32x2 L, R, M2; };
+  const T* col = tile + 2 * threadIdx.x;  // window column of the west neighbour of the lane's first pixel
+  // a window row as the lane needs it: floats as the pairs L = (v0, v1), R = (v2, v3) and 2 M = 2 (v1, v2); integers as
+  // the four cells in 32 bits
+  typedef typename std::conditional<std::is_same<T, float>::value, float, unsigned>::type Cell;
+  struct Row { Cell v[4]; f32x2 M2; };
   auto read_row = [&](int wy) -> Row {
-    const float* p = col + wy * PITCH;
+    const T* p = col + wy * PITCH;
     Row row;
-    row.L = *reinterpret_cast<const f32x2*>(p);
-    row.R = *reinterpret_cast<const f32x2*>(p + 2);
-    const f32x2 M = {p[1], p[2]};
-    row.M2 = M + M;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) row.v[k] = (Cell)p[k];  // (signed integers: sign-extended, then modulo 2^32)
+    if constexpr (std::is_same<T, float>::value) {
+      const f32x2 M = {p[1], p[2]};
+      row.M2 = M + M;
+    }
     return row;
   };
   const f32x2 inv_x = {A.xinv32, A.xinv32}, inv_y = {A.yinv32, A.yinv32};
@@ -880,15 +899,30 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const float* __rest
   for (int r = 0; r < HP_H; ++r) {
     const Row bot = read_row(r + 2);
     // spatial.py:384-404, per pixel: ((((a + 2 b) + c) - d) - 2 e) - f
-    const f32x2 sy = ((((top.L + top.M2) + top.R) - bot.L) - bot.M2) - bot.R;
-    const f32x2 sx = ((((top.L + (mid.L + mid.L)) + bot.L) - top.R) - (mid.R + mid.R)) - bot.R;
     f32x2 x, y;
-    if (USE_INV) {
+    if constexpr (std::is_same<T, float>::value) {
+      const f32x2 tL = {top.v[0], top.v[1]}, tR = {top.v[2], top.v[3]}, mL = {mid.v[0], mid.v[1]}, mR = {mid.v[2], mid.v[3]};
+      const f32x2 bL = {bot.v[0], bot.v[1]}, bR = {bot.v[2], bot.v[3]};
+      const f32x2 sy = ((((tL + top.M2) + tR) - bL) - bot.M2) - bR;
+      const f32x2 sx = ((((tL + (mL + mL)) + bL) - tR) - (mR + mR)) - bR;
+      if (USE_INV) {
+        x = sx * inv_x;
+        y = sy * inv_y;
+      } else {
+        x = f32x2{sx.x / A.xres32, sx.y / A.xres32};
+        y = f32x2{sy.x / A.yres32, sy.y / A.yres32};
+      }
+    } else {
+      f32x2 sx, sy;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const unsigned wy_ = top.v[k] + 2u * top.v[k + 1] + top.v[k + 2] - bot.v[k] - 2u * bot.v[k + 1] - bot.v[k + 2];
+        const unsigned wx_ = top.v[k] + 2u * mid.v[k] + bot.v[k] - top.v[k + 2] - 2u * mid.v[k + 2] - bot.v[k + 2];
+        sy[k] = (float)(T)wy_;  // the truncation to T is NumPy's wrap-around
+        sx[k] = (float)(T)wx_;
+      }
       x = sx * inv_x;
       y = sy * inv_y;
-    } else {
-      x = f32x2{sx.x / A.xres32, sx.y / A.xres32};
-      y = f32x2{sy.x / A.yres32, sy.y / A.yres32};
     }
     unsigned packed = 0;
     {
@@ -927,9 +961,9 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const float* __rest
 #pragma unroll 1
     for (int i = 0; i < 2 * HP_H; ++i) {
       const int r = i >> 1, k = i & 1;
-      const float* p = col + r * PITCH + k;
-      const float y = gradient<float>(p[0], p[1], p[2], p[2 * PITCH], p[2 * PITCH + 1], p[2 * PITCH + 2], A.yres, A.yres32, A.yinv, A.yinv32);
-      const float x = gradient<float>(p[0], p[PITCH], p[2 * PITCH], p[2], p[PITCH + 2], p[2 * PITCH + 2], A.xres, A.xres32, A.xinv, A.xinv32);
+      const T* p = col + r * PITCH + k;
+      const float y = gradient<T>(p[0], p[1], p[2], p[2 * PITCH], p[2 * PITCH + 1], p[2 * PITCH + 2], A.yres, A.yres32, A.yinv, A.yinv32);
+      const float x = gradient<T>(p[0], p[PITCH], p[2 * PITCH], p[2], p[PITCH + 2], p[2 * PITCH + 2], A.xres, A.xres32, A.xinv, A.xinv32);
       shade[r * HP_W + 2 * threadIdx.x + k] = shade_cell(x, y, A);
     }
   }
@@ -1528,13 +1562,33 @@ int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int 
   dim3 grid((unsigned)((w - 2 + 255) / 256), (unsigned)((h - 2 + ST_ROWS - 1) / ST_ROWS), (unsigned)bands);
   dim3 tgrid((unsigned)((w - 2 + HT_W - 1) / HT_W), (unsigned)((h - 2 + HT_H - 1) / HT_H), (unsigned)bands);
   const bool tiled = gm::dtype_size(dtype) <= 4 && tgrid.y <= 65535;  // (8-byte tiles: the window would not fit LDS twice)
-  if (dtype == GM_F32 && !getenv("GM_HS_SINGLE") && (h - 2 + HP_H - 1) / HP_H <= 65535) {
-    dim3 pgrid((unsigned)((w - 2 + HP_W - 1) / HP_W), (unsigned)((h - 2 + HP_H - 1) / HP_H), (unsigned)bands);
+  const bool pairs_fit = !getenv("GM_HS_SINGLE") && (h - 2 + HP_H - 1) / HP_H <= 65535;
+  dim3 pgrid((unsigned)((w - 2 + HP_W - 1) / HP_W), (unsigned)((h - 2 + HP_H - 1) / HP_H), (unsigned)bands);
+  if (dtype == GM_F32 && pairs_fit) {
     const float ndv = from_bits<float>(ndv_bits), fill = from_bits<float>(fill_bits);
     if (A.xinv32 != 0.0f && A.yinv32 != 0.0f)
-      hipLaunchKernelGGL(hillshade_pair_kernel<true>, pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, in_pitch, has_ndv, ndv, fill, A);
+      hipLaunchKernelGGL((hillshade_pair_kernel<float, true>), pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, in_pitch, has_ndv, ndv, fill, A);
     else
-      hipLaunchKernelGGL(hillshade_pair_kernel<false>, pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, in_pitch, has_ndv, ndv, fill, A);
+      hipLaunchKernelGGL((hillshade_pair_kernel<float, false>), pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, in_pitch, has_ndv, ndv, fill, A);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+  }
+  // integer tiles of up to 4 bytes at power-of-two resolutions (well inside float32's exponent range): the same kernel
+  const bool int_pairs = pairs_fit && A.xinv32 != 0.0f && A.yinv32 != 0.0f && fabsf(A.xinv32) < 0x1p64f &&
+                         fabsf(A.xinv32) > 0x1p-64f && fabsf(A.yinv32) < 0x1p64f && fabsf(A.yinv32) > 0x1p-64f;
+  if (int_pairs && gm::dtype_size(dtype) <= 4 && !gm::dtype_is_float(dtype) && dtype != GM_BOOL) {
+#define GM_HP(T)                                                                                                          \
+  hipLaunchKernelGGL((hillshade_pair_kernel<T, true>), pgrid, dim3(256), 0, s, (const T*)in, (unsigned char*)out, h, w, in_pitch, \
+                     has_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A)
+    switch (dtype) {
+      case GM_U8: GM_HP(unsigned char); break;
+      case GM_I8: GM_HP(signed char); break;
+      case GM_U16: GM_HP(unsigned short); break;
+      case GM_I16: GM_HP(short); break;
+      case GM_U32: GM_HP(unsigned int); break;
+      default: GM_HP(int); break;
+    }
+#undef GM_HP
     GM_HIP(hipGetLastError());
     return GM_OK;
   }

@@ -1,19 +1,16 @@
 #!/bin/bash
 python - <<'PY'
-import sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
-from dask_geomodeling_amd import raster, config as gmconfig
-rng = np.random.default_rng(1)
-a = (rng.random((1, 64, 64)) * 10).astype("f4")
-A = raster.MemorySource(a, np.float32(-1), "EPSG:28992", 1.0, (0.0, 64.0))
-x = raster.HillShade(A + 1)
-for level in range(10):
-    x = raster.Group(x, x)
-req = dict(mode="vals", bbox=(0.0, 0.0, 32.0, 32.0), width=32, height=32, projection="EPSG:28992")
-x.get_data(**req)
-t0 = time.perf_counter(); got = x.get_data(**req); t1 = time.perf_counter()
-with gmconfig.config.set({"geomodeling.plans": False}):
-    want = x.get_data(**req)
-    t2 = time.perf_counter(); want = x.get_data(**req); t3 = time.perf_counter()
-print("10 nested groups: plans %.1f ms, graph %.1f ms, equal: %s" % ((t1 - t0) * 1e3, (t3 - t2) * 1e3, np.array_equal(got["values"], want["values"])))
+import sys, numpy as np
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+from dask_geomodeling_amd.hip import runtime
+from dask_geomodeling_amd.raster import stencil
+from dask_geomodeling_amd.raster.sources import generate_window
+import kbench
+runtime.set_device(0)
+side = 8192
+for dt, ndv in (("i2", 32767), ("u1", 255), ("f4", float(np.finfo("f4").max)), ("i4", 2**31 - 1)):
+    src = [generate_window((side, side), dt, 90 + i, 0.0, 100.0, ndv, (97, 89), 0, 0, side, side) for i in range(2)]
+    item = np.dtype(dt).itemsize
+    kbench.timeit("hillshade %s -> u8 (%d B/px)" % (dt, item + 1), (item + 1.0) * (side - 2) ** 2,
+                  [lambda t=t: stencil.hillshade(t, np.dtype(dt).type(ndv), 0, (0.5, 0.5), 45.0, 315.0) for t in src])
 PY
