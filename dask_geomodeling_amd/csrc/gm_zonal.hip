@@ -411,6 +411,48 @@ __device__ __forceinline__ void walk_cells(const T* __restrict__ values, const i
   }
 }
 
+// A step whose 64 cells carry several labels: the lanes of every run of equal labels combine first (a segmented
+// inclusive scan over the lanes, log2(64) exchange steps per quantity) and only the last lane of a run touches the
+// label's counters -- a raster of small polygons is all such steps, and one atomic per cell is an order of magnitude
+// slower than one per run, more when neighbouring rows hammer the same few counters.
+struct LabelRuns {
+  int distance;  // lanes between this lane and the first lane of its run
+  bool last;     // the last lane of its run
+};
+__device__ __forceinline__ LabelRuns label_runs(int label, int lane) {
+  const int before = __shfl_up(label, 1), after = __shfl_down(label, 1);
+  int start = (lane == 0 || label != before) ? lane : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int other = __shfl_up(start, d);
+    if (lane >= d) start = max(start, other);
+  }
+  return LabelRuns{lane - start, lane == 63 || label != after};
+}
+template <typename V>
+__device__ __forceinline__ V lane_up(V v, int d) {
+  if constexpr (sizeof(V) == 8) {
+    unsigned long long u;
+    __builtin_memcpy(&u, &v, 8);
+    const unsigned lo = __shfl_up((unsigned)u, d), hi = __shfl_up((unsigned)(u >> 32), d);
+    u = ((unsigned long long)hi << 32) | lo;
+    V r;
+    __builtin_memcpy(&r, &u, 8);
+    return r;
+  } else {
+    return __shfl_up(v, d);
+  }
+}
+template <typename V, typename Op>
+__device__ __forceinline__ V run_total(V v, const LabelRuns& runs, Op op) {  // at the last lane of a run: the run's total
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const V other = lane_up(v, d);
+    if (runs.distance >= d) v = op(v, other);
+  }
+  return v;
+}
+
 // count / min / max need no order at all: one pass of atomics on the per-label counters and on the ordered
 // keys (the smallest key is the minimum with NaN last -- NaN only if every cell is; the largest key is the
 // maximum -- NaN if any cell is: exactly the first / last cell of the sorted segment).  Label rasters are
@@ -485,10 +527,16 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
         run_count += 1;
         run_key = better(run_key, key);
       }
-    } else if (active) {  // (a step across a label boundary: every lane for itself)
-      atomicAdd(&counts[label], 1ull);
-      if constexpr (STAT == Z_MIN) atomicMin(&extreme[label], key);
-      if constexpr (STAT == Z_MAX) atomicMax(&extreme[label], key);
+    } else {  // (a step across label boundaries: run by run)
+      const LabelRuns runs = label_runs(labelled ? label : -1, lane);
+      const unsigned n = run_total(active ? 1u : 0u, runs, [](unsigned a, unsigned b) { return a + b; });
+      Key best = NEUTRAL;
+      if constexpr (STAT != Z_COUNT) best = run_total(active ? key : NEUTRAL, runs, better);
+      if (runs.last && labelled && n != 0) {
+        atomicAdd(&counts[label], (unsigned long long)n);
+        if constexpr (STAT == Z_MIN) atomicMin(&extreme[label], best);
+        if constexpr (STAT == Z_MAX) atomicMax(&extreme[label], best);
+      }
     }
   });
   flush();
@@ -566,22 +614,6 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
     run_lo = INT_MAX;
     run_sum = 0.0;
   };
-  auto take = [&](int label, double x) {  // one active cell outside a run: straight to the label's slot
-    if constexpr (PHASE == 0) {
-      ExactRange* slot = range + label;
-      atomicAdd(&slot->count, 1ull);
-      if (!(fabs(x) <= 1.7976931348623157e308)) {
-        atomicOr(&slot->bad, 1u);
-      } else if (x != 0.0) {
-        int top, low;
-        exponent_span(x, &top, &low);
-        atomicMax(&slot->hi, top);
-        atomicMin(&slot->lo, low);
-      }
-    } else {
-      atomicAdd(&sums[label], x);
-    }
-  };
   walk_cells<T>(values, labels, begin, end, lane, [&](T v, int label, bool inside, size_t i) {
     const bool labelled = (unsigned)label < (unsigned)n_labels;
     if (PHASE == 0 && present && labelled) present[label] = 1;
@@ -620,8 +652,32 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
           run_sum += x;
         }
       }
-    } else if (active) {
-      take(label, x);
+    } else {  // (a step across label boundaries: run by run)
+      const LabelRuns runs = label_runs(labelled ? label : -1, lane);
+      if constexpr (PHASE == 0) {
+        int top = INT_MIN, low = INT_MAX;
+        unsigned bad = 0;
+        if (active) {
+          if (!(fabs(x) <= 1.7976931348623157e308)) bad = 1;
+          else if (x != 0.0) cell_span<T>(v, &top, &low);
+        }
+        const unsigned n = run_total(active ? 1u : 0u, runs, [](unsigned a, unsigned b) { return a + b; });
+        top = run_total(top, runs, [](int a, int b) { return max(a, b); });
+        low = run_total(low, runs, [](int a, int b) { return min(a, b); });
+        bad = run_total(bad, runs, [](unsigned a, unsigned b) { return a | b; });
+        if (runs.last && labelled && n != 0) {
+          ExactRange* slot = range + label;
+          atomicAdd(&slot->count, (unsigned long long)n);
+          if (top != INT_MIN) {
+            atomicMax(&slot->hi, top);
+            atomicMin(&slot->lo, low);
+          }
+          if (bad) atomicOr(&slot->bad, 1u);
+        }
+      } else {
+        const double total = run_total(active ? x : 0.0, runs, [](double a, double b) { return a + b; });  // (exact: see above)
+        if (runs.last && labelled && total != 0.0) atomicAdd(&sums[label], total);
+      }
     }
   });
   flush();

@@ -1,0 +1,26 @@
+import sys, time, numpy as np
+sys.path.insert(0, "/root/repo")
+from dask_geomodeling_amd import geometry
+from dask_geomodeling_amd.hip import runtime
+from dask_geomodeling_amd.hip.array import DeviceArray
+runtime.set_device(0)
+h, w = 3072, 4096
+rng = np.random.default_rng(5)
+values = (rng.standard_normal((1, h, w)) * 100).astype("f4")
+values[rng.random(values.shape) < 0.1] = -9999.0
+ints = DeviceArray.from_numpy(np.round(values).astype("i4"))
+dv = DeviceArray.from_numpy(values)
+for side in (128, 48, 20, 7):
+    per_row = (w + side - 1) // side
+    labels = ((np.arange(h)[:, None] // side) * per_row + np.arange(w)[None, :] // side).astype(np.int32)
+    n = int(labels.max()) + 1
+    dl = DeviceArray.from_numpy(labels)
+    for what, tile, ndv, stat in (("count f32", dv, np.float32(-9999.0), "count"), ("max f32", dv, np.float32(-9999.0), "max"),
+                                  ("sum i32", ints, -9999, "sum"), ("sum f32", dv, np.float32(-9999.0), "sum")):
+        geometry.label_statistics(tile, ndv, dl, n, stat)
+        runtime.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            geometry.label_statistics(tile, ndv, dl, n, stat)
+        us = (time.perf_counter() - t0) / 3 * 1e6
+        print("labels of %3d x %3d cells (%6d labels): %-10s %9.1f us" % (side, side, n, what, us), flush=True)
