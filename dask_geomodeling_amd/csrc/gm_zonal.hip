@@ -193,6 +193,7 @@ __device__ __forceinline__ void cell_span(T v, int* top, int* low) {
 //     additions on broadcast reads (the wave as one sequential adder, ~20 cycles per cell).
 // Cells past the end of the label add +0.0, which changes nothing (the sum starts from +0.0 like bincount's zeros).
 constexpr int ZS_PER_LANE = 4, ZS_STEP = 64 * ZS_PER_LANE;
+constexpr unsigned ZS_SHORT = 192;  // labels of up to this many active cells: a lane each (zonal_short_sum_kernel)
 template <typename T>
 __global__ __launch_bounds__(256) void zonal_sum_kernel(const typename Ordered<T>::Key* __restrict__ payload,
                                                         const unsigned* __restrict__ first, int n_labels, int statistic,
@@ -202,13 +203,7 @@ __global__ __launch_bounds__(256) void zonal_sum_kernel(const typename Ordered<T
   const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (l >= n_labels) return;
   const unsigned a = first[l], b = first[l + 1];
-  if (a == b) {  // no active cell
-    if (lane == 0) {
-      counts[l] = 0;
-      out[l] = std::numeric_limits<float>::quiet_NaN();
-    }
-    return;
-  }
+  if (b - a <= ZS_SHORT) return;  // (zonal_short_sum_kernel's)
   double* mine = parked[wave];
   double acc = 0.0;
   struct Four { Key k[ZS_PER_LANE]; };
@@ -331,6 +326,22 @@ __global__ __launch_bounds__(256) void zonal_sum_kernel(const typename Ordered<T
     // ndimage.mean: sum / count in float64; the assignment into the float32 `agg` rounds once
     out[l] = n == 0 ? nan : (statistic == Z_MEAN ? (float)(acc / (double)n) : (float)acc);
   }
+}
+
+// Labels of a few cells (a raster of small polygons has hundreds of thousands): a lane per label adds its cells one after
+// the other straight from memory -- a wave per label would spend its life waiting for 40 cells.
+template <typename T>
+__global__ __launch_bounds__(256) void zonal_short_sum_kernel(const typename Ordered<T>::Key* __restrict__ payload,
+                                                              const unsigned* __restrict__ first, int n_labels, int statistic,
+                                                              float* __restrict__ out, long long* __restrict__ counts) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= n_labels) return;
+  const unsigned a = first[l], b = first[l + 1], n = b - a;
+  if (n > ZS_SHORT) return;  // (zonal_sum_kernel's)
+  double acc = 0.0;
+  for (unsigned i = a; i < b; ++i) acc += (double)Ordered<T>::decode(payload[i]);
+  counts[l] = n;
+  out[l] = n == 0 ? std::numeric_limits<float>::quiet_NaN() : (statistic == Z_MEAN ? (float)(acc / (double)n) : (float)acc);
 }
 
 // count (ndimage.sum of ones) and the statistics that pick from the cells sorted by (label, value)
@@ -861,9 +872,12 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       sorted_pay = pay_b;
     }
     hipLaunchKernelGGL(zonal_bounds_kernel, dim3((n_labels + 1 + 255) / 256), dim3(256), 0, s, sorted_keys, (unsigned)cells, n_labels, first);
-    if (statistic == Z_SUM || statistic == Z_MEAN)
+    if (statistic == Z_SUM || statistic == Z_MEAN) {
+      hipLaunchKernelGGL(zonal_short_sum_kernel<T>, dim3((n_labels + 255) / 256), dim3(256), 0, s, sorted_pay, first, n_labels,
+                         statistic, out_f, counts_f);
       hipLaunchKernelGGL(zonal_sum_kernel<T>, dim3((unsigned)(((size_t)n_labels * 64 + 255) / 256)), dim3(256), 0, s, sorted_pay, first,
                          n_labels, statistic, out_f, counts_f);
+    }
     else
       hipLaunchKernelGGL(zonal_pick_kernel<T>, dim3((n_labels + 255) / 256), dim3(256), 0, s, sorted_pay, first, n_labels, statistic,
                          qval, out_f, counts_f);

@@ -1,2 +1,2 @@
 #!/bin/bash
-python tools/_zn48.py 2>&1 | tail -30
+python tools/_t48.py
