@@ -197,11 +197,12 @@ constexpr unsigned ZS_SHORT = 192;  // labels of up to this many active cells: a
 template <typename T>
 __global__ __launch_bounds__(256) void zonal_sum_kernel(const typename Ordered<T>::Key* __restrict__ payload,
                                                         const unsigned* __restrict__ first, int n_labels, int statistic,
-                                                        float* __restrict__ out, long long* __restrict__ counts) {
+                                                        const unsigned char* __restrict__ only, float* __restrict__ out,
+                                                        long long* __restrict__ counts) {
   typedef typename Ordered<T>::Key Key;
   __shared__ __align__(16) double parked[4][ZS_STEP];
   const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (l >= n_labels) return;
+  if (l >= n_labels || (only && !only[l])) return;  // (only: the labels this launch is about)
   const unsigned a = first[l], b = first[l + 1];
   if (b - a <= ZS_SHORT) return;  // (zonal_short_sum_kernel's)
   double* mine = parked[wave];
@@ -333,9 +334,10 @@ __global__ __launch_bounds__(256) void zonal_sum_kernel(const typename Ordered<T
 template <typename T>
 __global__ __launch_bounds__(256) void zonal_short_sum_kernel(const typename Ordered<T>::Key* __restrict__ payload,
                                                               const unsigned* __restrict__ first, int n_labels, int statistic,
-                                                              float* __restrict__ out, long long* __restrict__ counts) {
+                                                              const unsigned char* __restrict__ only, float* __restrict__ out,
+                                                              long long* __restrict__ counts) {
   const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= n_labels) return;
+  if (l >= n_labels || (only && !only[l])) return;
   const unsigned a = first[l], b = first[l + 1], n = b - a;
   if (n > ZS_SHORT) return;  // (zonal_sum_kernel's)
   double acc = 0.0;
@@ -580,6 +582,10 @@ struct ExactRange {
   int hi, lo;       // top exponent / exponent of the lowest set bit over the non-zero cells
   unsigned bad;     // a NaN or an infinity among the cells
 };
+struct ExactVerdict {  // over all labels: how many are not exact, and how many active cells they hold
+  unsigned labels, pad;
+  unsigned long long cells;
+};
 template <typename T, int PHASE>
 __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
                                                           size_t cells_per_wave, int n_labels, int has_ndv, T ndv,
@@ -695,17 +701,20 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void zonal_exact_init_kernel(ExactRange* __restrict__ range, double* __restrict__ sums, int n_labels,
-                                                               unsigned* __restrict__ inexact) {
+                                                               ExactVerdict* __restrict__ verdict, unsigned* __restrict__ cursor) {
   const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l == 0) *inexact = 0;
+  if (l == 0) {
+    *verdict = ExactVerdict{0u, 0u, 0ull};
+    *cursor = 0;
+  }
   if (l >= n_labels) return;
   range[l] = ExactRange{0ull, INT_MIN, INT_MAX, 0u};
   sums[l] = 0.0;
 }
 
-// per label: can the order matter?  `inexact` counts the labels for which it can.
+// per label: can the order matter?  The verdict counts the labels for which it can and the cells they hold, and flags them.
 __global__ __launch_bounds__(256) void zonal_exact_decide_kernel(const ExactRange* __restrict__ range, int n_labels,
-                                                                 unsigned* __restrict__ inexact) {
+                                                                 unsigned char* __restrict__ inexact, ExactVerdict* __restrict__ verdict) {
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= n_labels) return;
   const ExactRange r = range[l];
@@ -715,7 +724,50 @@ __global__ __launch_bounds__(256) void zonal_exact_decide_kernel(const ExactRang
     const int top = r.hi + 1 + growth;
     exact = top - r.lo <= 53 && top < 1023;
   }
-  if (!exact) atomicAdd(inexact, 1u);
+  inexact[l] = exact ? 0 : 1;
+  if (!exact) {
+    atomicAdd(&verdict->labels, 1u);
+    atomicAdd(&verdict->cells, r.count);
+  }
+}
+
+// When only a few labels need their cells in order, only their cells are sorted: the active cells of the flagged labels are
+// appended to a list as (label << 32 | cell index, value) -- in any order: the sort by that key restores the raster order
+// inside every label --, and the sequential sums run on the list.
+template <typename K>
+__global__ __launch_bounds__(256) void zonal_gather_kernel(const unsigned* __restrict__ keys, const K* __restrict__ payload, size_t cells,
+                                                           int n_labels, const unsigned char* __restrict__ inexact,
+                                                           unsigned long long* __restrict__ list_keys, K* __restrict__ list_payload,
+                                                           unsigned* __restrict__ cursor) {
+  const int lane = threadIdx.x & 63;
+  const size_t stride = (size_t)gridDim.x * 256, rounded = (cells + 63) & ~(size_t)63;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < rounded; i += stride) {  // (whole waves enter every step)
+    const unsigned label = i < cells ? keys[i] : (unsigned)n_labels;
+    const bool take = label < (unsigned)n_labels && inexact[label];
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0) continue;
+    unsigned base = 0;
+    if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(cursor, (unsigned)__popcll(mask));
+    base = __builtin_amdgcn_readlane(base, __ffsll((long long)mask) - 1);
+    if (take) {
+      const unsigned at = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+      list_keys[at] = ((unsigned long long)label << 32) | (unsigned long long)i;
+      list_payload[at] = payload[i];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void zonal_list_bounds_kernel(const unsigned long long* __restrict__ keys, unsigned count, int n_labels,
+                                                                unsigned* __restrict__ first) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l > n_labels) return;
+  const unsigned long long bound = (unsigned long long)l << 32;
+  unsigned lo = 0, hi = count;
+  while (lo < hi) {
+    const unsigned mid = lo + (hi - lo) / 2;
+    if (keys[mid] < bound) lo = mid + 1;
+    else hi = mid;
+  }
+  first[l] = lo;
 }
 
 __global__ __launch_bounds__(256) void zonal_exact_result_kernel(const ExactRange* __restrict__ range, const double* __restrict__ sums,
@@ -799,11 +851,15 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   int rc;
   ExactRange* range = nullptr;
   double* sums = nullptr;
-  unsigned* inexact = nullptr;
+  unsigned char* inexact = nullptr;  // per label: its sum needs the cells in order
+  ExactVerdict* verdict_dev = nullptr;
+  unsigned* cursor = nullptr;
   if (!by_value && !getenv("GM_ZONAL_SORTED")) {
     if ((rc = scratch.take((void**)&range, sizeof(ExactRange) * n_labels))) return rc;
     if ((rc = scratch.take((void**)&sums, sizeof(double) * n_labels))) return rc;
-    if ((rc = scratch.take((void**)&inexact, sizeof(unsigned)))) return rc;
+    if ((rc = scratch.take((void**)&inexact, (size_t)n_labels))) return rc;
+    if ((rc = scratch.take((void**)&verdict_dev, sizeof(ExactVerdict)))) return rc;
+    if ((rc = scratch.take((void**)&cursor, sizeof(unsigned)))) return rc;
   }
   unsigned *keys_a = nullptr, *keys_b = nullptr, *first = nullptr;
   Key *pay_a = nullptr, *pay_b = nullptr;
@@ -835,19 +891,44 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     if ((rc = sort_buffers())) return rc;
     bool keys_written = false;
     if (range) {
-      hipLaunchKernelGGL(zonal_exact_init_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, inexact);
+      hipLaunchKernelGGL(zonal_exact_init_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, verdict_dev, cursor);
       hipLaunchKernelGGL((zonal_exact_kernel<T, 0>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells, cells_per_wave,
                          n_labels, has_ndv, ndv, thresholds, range, sums, seen, keys_a, pay_a);
-      hipLaunchKernelGGL(zonal_exact_decide_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, n_labels, inexact);
-      unsigned verdict = 1;
-      GM_HIP(hipMemcpyAsync(&verdict, inexact, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+      hipLaunchKernelGGL(zonal_exact_decide_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, n_labels, inexact, verdict_dev);
+      ExactVerdict verdict{1u, 0u, (unsigned long long)cells};
+      GM_HIP(hipMemcpyAsync(&verdict, verdict_dev, sizeof(verdict), hipMemcpyDeviceToHost, s));
       GM_HIP(hipStreamSynchronize(s));
-      if (verdict == 0) {
+      // every label exact: the parallel sums are the answer.  A few labels not (they hold at most 1/8 of the cells): the
+      // parallel sums answer all the others, and only the cells of those few are sorted and added in order.
+      const bool partial = verdict.labels != 0 && verdict.cells != 0 && verdict.cells <= (unsigned long long)cells / 8;
+      if (verdict.labels == 0 || partial) {
         hipLaunchKernelGGL((zonal_exact_kernel<T, 1>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells,
                            cells_per_wave, n_labels, has_ndv, ndv, thresholds, range, sums, (unsigned char*)nullptr,
                            (unsigned*)nullptr, (Key*)nullptr);
         hipLaunchKernelGGL(zonal_exact_result_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, statistic,
                            out_f, counts_f);
+        if (partial) {
+          const size_t m = (size_t)verdict.cells;
+          Scratch local;  // the list's buffers: sized by this frame's verdict
+          unsigned long long *list_a, *list_b;
+          Key *value_a, *value_b;
+          void* list_temp;
+          if ((rc = local.take((void**)&list_a, sizeof(unsigned long long) * m))) return rc;
+          if ((rc = local.take((void**)&list_b, sizeof(unsigned long long) * m))) return rc;
+          if ((rc = local.take((void**)&value_a, sizeof(Key) * m))) return rc;
+          if ((rc = local.take((void**)&value_b, sizeof(Key) * m))) return rc;
+          size_t list_bytes = 0;
+          GM_HIP(rocprim::radix_sort_pairs(nullptr, list_bytes, list_a, list_b, value_a, value_b, m, 0, 32 + label_bits, s));
+          if ((rc = local.take(&list_temp, list_bytes))) return rc;
+          hipLaunchKernelGGL(zonal_gather_kernel<Key>, dim3(blocks), dim3(256), 0, s, keys_a, pay_a, (size_t)cells, n_labels, inexact,
+                             list_a, value_a, cursor);
+          GM_HIP(rocprim::radix_sort_pairs(list_temp, list_bytes, list_a, list_b, value_a, value_b, m, 0, 32 + label_bits, s));
+          hipLaunchKernelGGL(zonal_list_bounds_kernel, dim3((n_labels + 1 + 255) / 256), dim3(256), 0, s, list_b, (unsigned)m, n_labels, first);
+          hipLaunchKernelGGL(zonal_short_sum_kernel<T>, dim3((n_labels + 255) / 256), dim3(256), 0, s, value_b, first, n_labels, statistic,
+                             inexact, out_f, counts_f);
+          hipLaunchKernelGGL(zonal_sum_kernel<T>, dim3((unsigned)(((size_t)n_labels * 64 + 255) / 256)), dim3(256), 0, s, value_b, first,
+                             n_labels, statistic, inexact, out_f, counts_f);
+        }
         GM_HIP(hipGetLastError());
         continue;
       }
@@ -874,9 +955,9 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     hipLaunchKernelGGL(zonal_bounds_kernel, dim3((n_labels + 1 + 255) / 256), dim3(256), 0, s, sorted_keys, (unsigned)cells, n_labels, first);
     if (statistic == Z_SUM || statistic == Z_MEAN) {
       hipLaunchKernelGGL(zonal_short_sum_kernel<T>, dim3((n_labels + 255) / 256), dim3(256), 0, s, sorted_pay, first, n_labels,
-                         statistic, out_f, counts_f);
+                         statistic, (const unsigned char*)nullptr, out_f, counts_f);
       hipLaunchKernelGGL(zonal_sum_kernel<T>, dim3((unsigned)(((size_t)n_labels * 64 + 255) / 256)), dim3(256), 0, s, sorted_pay, first,
-                         n_labels, statistic, out_f, counts_f);
+                         n_labels, statistic, (const unsigned char*)nullptr, out_f, counts_f);
     }
     else
       hipLaunchKernelGGL(zonal_pick_kernel<T>, dim3((n_labels + 255) / 256), dim3(256), 0, s, sorted_pay, first, n_labels, statistic,

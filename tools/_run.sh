@@ -1,2 +1,4 @@
 #!/bin/bash
-python tools/zonal_shapes.py > gpurun_out/zonal_shapes_r02.log 2>&1; cat gpurun_out/zonal_shapes_r02.log | grep "sum f32"
+python -m pytest tests/test_gpu_parity.py -x -q -k "zonal" 2>&1 | tail -2
+python tools/zonal_shapes.py | grep "sum"
+python tools/kbench.py zonal cpu=0 2>&1 | grep -E "sum|mean"
