@@ -129,8 +129,9 @@ __device__ __forceinline__ double src_coord(int k, double scale) { return ((doub
 // down-sampling) taps are read from global memory directly.
 template <typename T, bool STAGED, int BL_TILE_H, int SU>
 __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src, T* __restrict__ dst, int hs, int ws,
-                                                       int hd, int wd, double sy, double sx, int has_ndv, T ndv,
+                                                       int spitch, int hd, int wd, double sy, double sx, int has_ndv, T ndv,
                                                        int pitch, int vec_src) {
+  // spitch: elements between the rows of the source (a zero-copy window of a wider resident raster: spitch > ws, one band)
   extern __shared__ __align__(16) unsigned char smem[];
   T* const tile = (T*)smem;
   const int band = blockIdx.z;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
             const int y = min(yb + 4 * u, win_h - 1);  // (unconditional: rows past the window re-read its last row)
-            v[u] = __builtin_nontemporal_load((const VT*)(sband + (size_t)(wy0 + y) * ws + stage_x0) + g);
+            v[u] = __builtin_nontemporal_load((const VT*)(sband + (size_t)(wy0 + y) * spitch + stage_x0) + g);
           }
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
             const int y = min(yb + 4 * u, win_h - 1);
-            v[u] = __builtin_nontemporal_load(sband + (size_t)(wy0 + y) * ws + wx0 + x);
+            v[u] = __builtin_nontemporal_load(sband + (size_t)(wy0 + y) * spitch + wx0 + x);
           }
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src
   const int tile_x0 = (STAGED && stage_x0 >= 0) ? stage_x0 : wx0;
   auto tap = [&](int y, int x) -> T {
     if constexpr (STAGED) return tile[(y - wy0) * pitch + (x - tile_x0)];
-    else return mark(sband[(size_t)y * ws + x]);
+    else return mark(sband[(size_t)y * spitch + x]);
   };
 
   const int tx = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -359,7 +360,14 @@ int gm_resample_nearest(const void* src, int dtype, int bands, int hs, int ws, v
 
 int gm_resample_bilinear(const void* src, int dtype, int bands, int hs, int ws, void* dst, int hd, int wd,
                          int has_ndv, uint64_t ndv_bits) {
+  return gm_resample_bilinear_window(src, dtype, bands, hs, ws, ws, dst, hd, wd, has_ndv, ndv_bits);
+}
+
+int gm_resample_bilinear_window(const void* src, int dtype, int bands, int hs, int ws, int src_pitch, void* dst, int hd, int wd,
+                                int has_ndv, uint64_t ndv_bits) {
   if (!src || !dst) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (src_pitch < ws) return gm::fail(GM_ERR_INVALID, "gm_resample_bilinear: pitch %d of a %d-wide source", src_pitch, ws);
+  if (src_pitch != ws && bands != 1) return gm::fail(GM_ERR_UNSUPPORTED, "gm_resample_bilinear: a window of %d bands", bands);
   if (dtype != GM_F32 && dtype != GM_F64) return gm::fail(GM_ERR_UNSUPPORTED, "bilinear needs a float tile");
   if (bands <= 0 || hd <= 0 || wd <= 0) return GM_OK;
   if (hs <= 0 || ws <= 0) return gm::fail(GM_ERR_INVALID, "empty source");
@@ -376,15 +384,15 @@ int gm_resample_bilinear(const void* src, int dtype, int bands, int hs, int ws, 
   long long win_h = (long long)ceil(BL_TILE_H * sy) + 3, win_w = (long long)ceil(BL_TILE_W * sx) + 3;
   // 16-byte staging: the window may start up to a group earlier and is padded to whole groups
   const int per = 16 / itemsize;
-  const bool vec_src = (ws % per) == 0 && ((uintptr_t)src % 16) == 0;
+  const bool vec_src = (ws % per) == 0 && (src_pitch % per) == 0 && ((uintptr_t)src % 16) == 0;
   win_w = vec_src ? ((win_w + per - 1 + per - 1) / per) * per : (win_w | 1);
   const bool staged = win_h * win_w * itemsize <= BL_LDS_BYTES - 2048;
   const size_t lds = staged ? (size_t)(win_h * win_w * itemsize) : 0;
   dim3 grid((unsigned)((wd + BL_TILE_W - 1) / BL_TILE_W), (unsigned)((hd + BL_TILE_H - 1) / BL_TILE_H), (unsigned)bands);
   if (grid.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "destination taller than %d rows", 65535 * BL_TILE_H);
 #define GM_BILINEAR_SU(T, STAGED, NDV, H_, SU_)                                                                           \
-  hipLaunchKernelGGL((bilinear_kernel<T, STAGED, H_, SU_>), grid, dim3(256), lds, s, (const T*)src, (T*)dst, hs, ws, hd, \
-                     wd, sy, sx, has_ndv, (T)(NDV), (int)win_w, vec_src ? 1 : 0)
+  hipLaunchKernelGGL((bilinear_kernel<T, STAGED, H_, SU_>), grid, dim3(256), lds, s, (const T*)src, (T*)dst, hs, ws,     \
+                     src_pitch, hd, wd, sy, sx, has_ndv, (T)(NDV), (int)win_w, vec_src ? 1 : 0)
 #define GM_BILINEAR_H(T, STAGED, NDV, H_)                                   \
   do {                                                                      \
     const int rows_per_wave = (int)((win_h + 3) / 4);                       \

@@ -4,7 +4,7 @@ import ctypes
 import numpy as np
 
 from ..hip import runtime
-from ..hip.array import DeviceArray, as_device
+from ..hip.array import DeviceArray, as_device, as_device_view
 from ..hip.dtypes import code_of
 
 _declared = False
@@ -22,6 +22,9 @@ def _lib():
         L.gm_resample_bilinear.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_int,
                                            c.c_int, c.c_int, c.c_uint64]
         L.gm_resample_bilinear.restype = c.c_int
+        L.gm_resample_bilinear_window.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_int,
+                                                  c.c_int, c.c_int, c.c_uint64]
+        L.gm_resample_bilinear_window.restype = c.c_int
         _declared = True
     return L
 
@@ -64,15 +67,15 @@ def affine_nearest(source, zoom_yx, offset_yx, cval=0.0):
 
 def bilinear(source, out_height, out_width, no_data_value):
     """Bilinear resize of a float (bands, H, W) tile (our spec)."""
-    src = as_device(source)
+    src = as_device_view(source)  # (a window of a resident raster is read where it lies)
     if src.dtype.kind != "f":
         raise TypeError("bilinear resampling needs a float32/float64 tile, got %s" % src.dtype)
     bands, hs, ws = src.shape
     out = DeviceArray.empty((bands, int(out_height), int(out_width)), src.dtype)
     has = no_data_value is not None
     ndv = src.dtype.type(no_data_value) if has else 0.0
-    runtime.check(_lib().gm_resample_bilinear(
-        ctypes.c_void_p(src.ptr), code_of(src.dtype), bands, hs, ws, ctypes.c_void_p(out.ptr),
+    runtime.check(_lib().gm_resample_bilinear_window(
+        ctypes.c_void_p(src.ptr), code_of(src.dtype), bands, hs, ws, src.pitch or ws, ctypes.c_void_p(out.ptr),
         int(out_height), int(out_width), 1 if has else 0, runtime.scalar_bits(ndv, src.dtype)),
         "gm_resample_bilinear")
     return out

@@ -355,6 +355,9 @@ int gm_resample_nearest(const void* src, int dtype, int bands, int hs, int ws,
  * non-finite -> ndv.  dtype: GM_F32 or GM_F64.  Source tile + 1 px apron staged in LDS. */
 int gm_resample_bilinear(const void* src, int dtype, int bands, int hs, int ws,
                          void* dst, int hd, int wd, int has_ndv, uint64_t ndv_bits);
+/* The same on a zero-copy window of a wider resident raster: source rows src_pitch elements apart (>= ws), one band. */
+int gm_resample_bilinear_window(const void* src, int dtype, int bands, int hs, int ws, int src_pitch, void* dst, int hd, int wd,
+                                int has_ndv, uint64_t ndv_bits);
 
 /* =============================================================================
  * N3: small-radius stencils (raster/spatial.py).  `in` is the (bands, h, w) tile INCLUDING the
