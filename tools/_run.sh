@@ -1,4 +1,10 @@
 #!/bin/bash
-python -m pytest tests/test_gpu_parity.py -x -q -k "bilinear or resample or canonical or nearest" 2>&1 | tail -2
-python -m pytest tests/test_gpu_fullsize.py -x -q 2>&1 | tail -2
-python bench.py --workload bilinear --steps 20 --warmup 3 --cpu-tiles 0 --no-e2e 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['frac'])"
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+tools/gpu_profile.sh r02 chain5 2>&1 | tail -1 | cut -c1-160
+tools/gpu_profile.sh r02 reclass --steps 20 --warmup 3 2>&1 | tail -1 | cut -c1-120
+tools/gpu_profile.sh r02 bilinear --steps 20 --warmup 3 2>&1 | tail -1 | cut -c1-120
+tools/gpu_profile.sh r02 tiler --steps 20 --warmup 3 2>&1 | tail -1 | cut -c1-120
+tools/gpu_profile.sh r02 mosaic --steps 5 --warmup 2 2>&1 | tail -1 | cut -c1-120
+python tools/kbench.py > gpurun_out/kbench_r02.log 2>&1; grep -c us gpurun_out/kbench_r02.log
+python tools/zonal_shapes.py > gpurun_out/zonal_shapes_r02.log 2>&1; tail -2 gpurun_out/zonal_shapes_r02.log
