@@ -589,3 +589,64 @@ def test_zonal_statistic_names_and_errors():
         geometry.label_statistics(np.zeros((1, 2, 2), "f4"), None, np.zeros((2, 2), "i4"), 1, "mode")
     with pytest.raises(ValueError):
         geometry.label_statistics(np.zeros((1, 2, 2), "f4"), None, np.zeros((2, 2), "i4"), 1, "percentile")
+
+
+FLIP_CALLS = []
+
+
+from dask_geomodeling_amd.raster.base import BaseSingle as _BaseSingle  # noqa: E402
+
+
+class FlipBlock(_BaseSingle):
+    """Test-only Block "with a kernel of its own" (pure Python): mirrors the tile, keeps the request as it is."""
+
+    gm_direct = True
+
+    @staticmethod
+    def process(data):
+        FLIP_CALLS.append(1)
+        if data is None or "values" not in data:
+            return data
+        return {"values": np.ascontiguousarray(np.asarray(data["values"])[:, :, ::-1]), "no_data_value": data["no_data_value"]}
+
+
+def test_plans_through_blocks_with_their_own_kernels(cpu_vm):
+    """plan.py on the host side: a Block flagged gm_direct is a leaf of the plan above it and evaluates its store through
+    the store's plan; one evaluation answers the same (Block, request) once; a RasterTiler over such a store assembles the
+    tiles it gets from the store's plans.  Plan path == graph path (a pure-Python stand-in for a stencil Block: the real
+    ones need the device)."""
+    from blocks_util import ArrayLeaf
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd import plan, raster
+    calls = FLIP_CALLS
+    Flip = FlipBlock
+
+    rng = np.random.default_rng(11)
+    a = (rng.random((1, 12, 16)) * 10).astype("f4")
+    a[0, 2, 3] = -1.0
+    ArrayLeaf.ARRAYS["pa"] = {"values": a, "no_data_value": np.float32(-1.0)}
+    A = ArrayLeaf("pa", "f4", np.float32(-1.0))
+    req = dict(mode="vals", bbox=(0.0, 0.0, 16.0, 12.0), width=16, height=12, projection="EPSG:28992")
+
+    def both(view):
+        got = view.get_data(**req)
+        with gmconfig.config.set({"geomodeling.plans": False}):
+            want = view.get_data(**req)
+        assert np.array_equal(np.asarray(got["values"]), np.asarray(want["values"]))
+        return got
+
+    inner = A * 2 + 1
+    flipped = Flip(inner)
+    assert plan.view_plan(flipped, req) is None and plan.evaluate(flipped, req)[0]      # no program of its own, yet planned
+    both(flipped)
+    outer = flipped * 0.5 - flipped                                                      # the Flip block twice in one view
+    top = plan.view_plan(outer, req)
+    assert top is not None and {type(block).__name__ for block, _ in top.leaves} == {"FlipBlock"}
+    del calls[:]
+    got = both(outer)
+    assert len(calls) == 2  # once on the plan path (the second use is the memo / the same leaf), once on the graph path
+    want = np.asarray(both(inner)["values"])[:, :, ::-1] * np.float32(0.5) - np.asarray(both(inner)["values"])[:, :, ::-1]
+    ok = np.asarray(got["values"]) != got["no_data_value"]
+    assert np.allclose(np.asarray(got["values"])[ok], want[ok])
+    for mode in ("time", "meta"):
+        assert outer.get_data(**dict(req, mode=mode)) == inner.get_data(**dict(req, mode=mode))
