@@ -183,11 +183,16 @@ def _run_tiler(tiler, request):
             # no program to batch (a store with a kernel of its own, a single unfusable operation): tile by tile
             # through whatever plan the store has, assembled by the Block's own process
             responses = []
-            for _, request in pairs[1:]:
-                planned, response = evaluate(store, request)
-                if not planned:
-                    return False, None
-                responses.append(response)
+            outer = getattr(_running, "memo", None)
+            try:
+                for _, request in pairs[1:]:
+                    _running.memo = {}  # a memo per tile: the tiles share nothing, and theirs must not pile up
+                    planned, response = _evaluate(store, request)
+                    if not planned:
+                        return False, None
+                    responses.append(response)
+            finally:
+                _running.memo = outer
             return True, type(tiler).process(kwargs, *responses)
         b = index_of.get(id(plan))
         if b is None:
