@@ -202,10 +202,15 @@ def _run_tiler(tiler, request):
         layout.append((b, len(members[b])))
         members[b].append(tile_request["bbox"])
     leaf_values, tasks = [], []
-    for plan, boxes in zip(batches, members):
-        for bbox in boxes:
-            leaf_values.extend(plan.leaf_values(bbox))
-        tasks.append(BatchedTask([plan.task] * len(boxes)))
+    outer = getattr(_running, "memo", None)
+    try:
+        for plan, boxes in zip(batches, members):
+            for bbox in boxes:
+                _running.memo = {}  # (a memo per tile: what the leaves of one tile evaluate underneath must not pile up)
+                leaf_values.extend(plan.leaf_values(bbox))
+            tasks.append(BatchedTask([plan.task] * len(boxes)))
+    finally:
+        _running.memo = outer
     assembly = TiledAssembly(type(tiler).process, layout, tasks)
     return True, assembly(kwargs, *leaf_values)
 
