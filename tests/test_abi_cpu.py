@@ -43,6 +43,12 @@ def test_struct_layout_and_no_device_behaviour():
         tile = {"values": np.ones((1, 2, 2), "f4"), "no_data_value": np.float32(9)}
         with pytest.raises(runtime.GmHipError):
             devops.math_process("add", {"dtype": "float32", "fillvalue": 1.0}, tile, tile)
+        from dask_geomodeling_amd import geometry
+        from dask_geomodeling_amd.raster import stencil
+        with pytest.raises(runtime.GmHipError):
+            geometry.label_statistics(tile["values"], tile["no_data_value"], np.zeros((2, 2), "i4"), 1, "sum")
+        with pytest.raises(runtime.GmHipError):
+            stencil.hillshade(np.ones((1, 5, 5), "f4"), np.float32(9), 0, (1.0, 1.0), 45.0, 315.0)
         assert L.gm_init() != 0 and b"no HIP device" in L.gm_last_error()
 
 
