@@ -1,3 +1,6 @@
 #!/bin/bash
-python bench.py --steps 20 --warmup 3 --cpu-tiles 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); e=d['end_to_end']; print(d['value'], d['roofline']['traffic'] is not None); print({k:(v['Mpix/s'], v.get('us_per_request')) for k,v in e.items() if isinstance(v,dict)})"
-python bench.py --workload mosaic --steps 3 --warmup 1 --cpu-tiles 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d.get('end_to_end'))"
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/kb_trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kb_trace -o kb -- python3 $R/tools/kbench.py cpu=0 > $R/gpurun_out/kb_trace.log 2>&1
+cd $R; ls gpurun_out/kb_trace; head -5 gpurun_out/kb_trace/kb_kernel_stats.csv | cut -c1-200
