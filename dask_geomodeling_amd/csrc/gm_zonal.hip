@@ -8,24 +8,25 @@
 //   * sum / mean are np.bincount(labels, weights=values): float64 accumulation cell after cell in raster
 //     order -- float64 addition is not associative, so only the same order gives the same bits;
 //   * minimum / maximum / median / percentile pick from the cells sorted by (label, value), NaN last.
-// So the cells are sorted, not reduced in a tree: a STABLE radix sort by label (rocPRIM's device-wide sort;
-// keys of bit_width(n_labels) bits) leaves every label's active cells contiguous and in raster order; the
-// statistics that pick sort by value first.  Then
-//   * sum / mean: one wave per label loads 64 cells at a time and adds them one after the other in float64
-//     (the bincount order; the chain of dependent additions is the price of bit-exactness -- a label of
-//     10 M cells takes as long as it does on a CPU core, thousands of labels run side by side);
-//   * median / percentile: a lane per label picks from its sorted segment and combines exactly as SciPy /
-//     measurements.percentile do (median of integers in float64, of float32 in float32; the percentile's
+// Where the order matters the cells are sorted, not reduced in a tree: a STABLE radix sort by label (rocPRIM's
+// device-wide sort; keys of bit_width(n_labels) bits) leaves every label's active cells contiguous and in raster
+// order; the statistics that pick sort by value first.  Then
+//   * sum / mean (zonal_sum_kernel, zonal_short_sum_kernel): a wave (a lane for labels of a few cells) adds the label's
+//     cells in that order in float64 -- as a tree for the steps that are certified exact, as a chain of dependent
+//     additions for the others: bincount's bits either way;
+//   * median / percentile (zonal_pick_kernel): a lane per label picks from its sorted segment and combines exactly as
+//     SciPy / measurements.percentile do (median of integers in float64, of float32 in float32; the percentile's
 //     difference in the raster's own dtype, wrap-around included).
-// count, min and max do not depend on the order: they take one pass of atomics (zonal_direct_kernel) and no sort.
+// Where it does not, nothing is sorted: count, min and max take one pass of atomics (zonal_direct_kernel); sum / mean of
+// labels whose every partial sum is exactly representable -- integer rasters, dyadic data, small polygons -- take two
+// (zonal_exact_kernel), and when only a few labels fail that test only their cells are gathered and sorted.
 // Results are float32 like the reference's `agg` array; labels without an active cell stay NaN.
-// HBM traffic: dominated by the sort passes (each moves keys + payload twice), ~40-100 bytes per cell.
+// HBM traffic: 8 algorithmic bytes per cell (value + label); the full sort moves ~40-100.
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <climits>
 #include <cmath>
-#include <vector>
 #include <limits>
 #include <type_traits>
 
