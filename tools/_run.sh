@@ -1,2 +1,2 @@
 #!/bin/bash
-python tools/_tiler_stencil.py 2>&1 | tail -7
+python tests/zonal_stress.py 4000 2>&1 | tail -8
