@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void checksum_kernel(const unsigned int* words
   if ((threadIdx.x & 63) == 0) atomicAdd(result, acc);
 }
 
+typedef unsigned Word16 __attribute__((ext_vector_type(4)));  // 16 bytes moved as one word
 template <typename T>
 __global__ __launch_bounds__(256) void paste_kernel(T* mosaic, int H, int W, const T* tile, int bands, int th, int tw,
                                                     int row0, int col0, int row_base) {
@@ -274,6 +275,13 @@ int gm_paste_tile(void* mosaic, int H, int W, const void* tile, int bands, int t
     return gm::fail(GM_ERR_INVALID, "gm_paste_tile: tile (%d,%d)+(%d,%d) outside mosaic (%d,%d)", row0, col0, th, tw, H, W);
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
+  // rows that are whole 16-byte groups on both sides (4064-wide uint8 tiles of a 16256-wide mosaic ...) move as 16-byte words
+  // through the widest instantiation: one byte per lane made the paste of a HillShade tile slower than its shading
+  const long long row_bytes = (long long)tw * itemsize, mosaic_row_bytes = (long long)W * itemsize;
+  if (itemsize < 16 && row_bytes % 16 == 0 && mosaic_row_bytes % 16 == 0 && ((long long)col0 * itemsize) % 16 == 0 &&
+      ((uintptr_t)mosaic % 16) == 0 && ((uintptr_t)tile % 16) == 0)
+    return gm_paste_tile(mosaic, H, (int)(mosaic_row_bytes / 16), tile, bands, th, (int)(row_bytes / 16), row0,
+                         (int)((long long)col0 * itemsize / 16), 16);
   unsigned gx = (unsigned)((tw + 255) / 256);
   if (gx > 64) gx = 64;
   // grid.y is limited to 65535: walk the (band, row) space in chunks
@@ -291,6 +299,7 @@ int gm_paste_tile(void* mosaic, int H, int W, const void* tile, int bands, int t
       case 2: GM_PASTE(unsigned short); break;
       case 4: GM_PASTE(unsigned int); break;
       case 8: GM_PASTE(unsigned long long); break;
+      case 16: GM_PASTE(Word16); break;
       default: return gm::fail(GM_ERR_INVALID, "gm_paste_tile: itemsize %d", itemsize);
     }
 #undef GM_PASTE
