@@ -1,2 +1,2 @@
 #!/bin/bash
-for i in 1 2 3; do python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -1; done
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4
