@@ -503,8 +503,8 @@ def main():
     else:
         tile_px, n_tiles_step = out_side * out_side, tiles
     model = {"chain5": (16, 12, "f32", "gmvm::vm_kernel<float, 2, 2, 1, 0>"),
-             "reclass": (16, 5, "i32", "gm::lookup32_kernel<unsigned char>"),
-             "bilinear": (1, 5, "f64", "gm::bilinear_kernel<float, true, 32, 5>"),
+             "reclass": (16, 5, "i32", "lookup32_kernel_w4<1>"),
+             "bilinear": (1, 5, "f64", "bilinear2x_kernel<16, 512, 256, false, true, false>"),
              "mosaic": (16, 17, "f32", "gmvm::vm_kernel<float, 2, 4, 2, 2>"),
              "tiler": (16, 12, "f32", "gmvm::vm_kernel<float, 2, 2, 1, 0>")}[args.workload]
     tiles_per_launch = min(n_tiles_step, model[0])

@@ -301,6 +301,186 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src
   }
 }
 
+// ---------------------------------------------------------------------------------
+// bilinear, exact 2x up-sampling of a float32 tile (BASELINE configs[3])
+// ---------------------------------------------------------------------------------
+// The general kernel above spends its time on things a 2x zoom does not need: per-pixel float64 index
+// arithmetic, LDS gathers through computed columns, and -- what the PMC passes showed -- a source window
+// whose two apron columns each pull in a whole 128-byte line per staged row (FETCH 1.54 x the source).
+// With wd = 2 ws the spec of DESIGN section 5 collapses: destination columns 4t .. 4t+3 read the source
+// columns 2t-1 .. 2t+2 with the weights (1/4, 3/4), (3/4, 1/4), (1/4, 3/4), (3/4, 1/4) -- the very
+// values fu = u - floor(u) and 1 - fu take there, so the float64 products and sums below are the
+// general kernel's, bit for bit -- and rows pair up the same way.
+//   * a workgroup owns TH x TW destination pixels = SH x SW source pixels + a one-pixel apron.  The
+//     SW interior columns start on a 16-byte boundary and are staged as whole 1 KiB rows (one wave
+//     instruction per row); the two apron columns are single 4-byte loads of 2 (SH + 2) lanes;
+//   * tiles are dealt to the XCDs in contiguous row-major runs (blocks b, b + 8, ... share an XCD):
+//     horizontally adjacent tiles run side by side on ONE L2, so the line an apron column drags in
+//     is the neighbour's interior line and is fetched from HBM once;
+//   * a wave walks RPW consecutive destination rows and keeps the horizontally interpolated values
+//     of the last three source rows in registers: every source row is read from LDS once per lane
+//     (one ds_read_b64 + two ds_read_b32) and feeds two destination rows.
+template <int TH, int TW, int THREADS, bool NT, bool NTS, bool LATE>
+__global__ __launch_bounds__(THREADS) void bilinear2x_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             int hs, int ws, int spitch, int has_ndv, float ndv,
+                                                             unsigned tiles_x, unsigned tiles, int swizzle) {
+  constexpr int SH = TH / 2, SW = TW / 2;
+  constexpr int P = SW + 8;           // LDS row pitch in floats: source column x of the tile sits at 4 + (x - sx0)
+  constexpr int G = SW / 4;           // 16-byte groups per staged row
+  constexpr int ROWS = SH + 2;
+  constexpr int NW = THREADS / 64, WPR = TW / 256, RG = NW / WPR, RPW = TH / RG;
+  static_assert(TW % 256 == 0 && NW % WPR == 0 && TH % RG == 0 && RPW % 2 == 0, "tile shape");
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* const tile = (float*)smem;
+
+  // blocks b, b + 8, ... share an XCD (and its L2).  swizzle 1: every XCD takes a contiguous run of the row-major tile
+  // order (eight write fronts); swizzle 2: the tile order stays row-major in TIME -- the whole chip sweeps the
+  // destination top to bottom, which is what the memory side wants from a write-heavy kernel -- and only inside a
+  // row of tiles every XCD takes a contiguous run, so that horizontal neighbours share an L2
+  unsigned pid = blockIdx.x;
+  if (swizzle == 1) {
+    const unsigned per = (tiles + 7u) / 8u;
+    pid = (pid & 7u) * per + (pid >> 3);
+    if (pid >= tiles) return;
+  } else if (swizzle == 2 && (tiles_x & 7u) == 0) {
+    const unsigned row = pid / tiles_x, j = pid - row * tiles_x;
+    pid = row * tiles_x + (j & 7u) * (tiles_x >> 3) + (j >> 3);
+  }
+  const int band = blockIdx.y;
+  const int hd = 2 * hs, wd = 2 * ws;
+  const float* sband = src + (size_t)band * hs * ws;  // (a window -- spitch != ws -- has one band)
+  float* dband = dst + (size_t)band * hd * wd;
+  const int ty = pid / tiles_x, tx = pid - ty * tiles_x;
+  const int r0 = ty * TH, c0 = tx * TW;
+  const int sy0 = r0 / 2, sx0 = c0 / 2;
+
+  const float mark_limit = has_ndv ? std::numeric_limits<float>::max() : std::numeric_limits<float>::infinity();
+  const float mark_ndv = has_ndv ? ndv : std::numeric_limits<float>::quiet_NaN();
+  const float void_out = has_ndv ? ndv : std::numeric_limits<float>::quiet_NaN();
+  auto mark = [&](float v) -> float {
+    const bool good = (fabsf(v) <= mark_limit) & (v != mark_ndv);
+    return good ? v : std::numeric_limits<float>::quiet_NaN();
+  };
+  auto load4 = [&](const float* p) -> f4 {
+    if constexpr (NT) return __builtin_nontemporal_load((const f4*)p);
+    else return *(const f4*)p;
+  };
+
+  // staging: every load of a lane is issued before its first LDS write.  LATE: the apron (first and last row of the
+  // window, the columns left and right of it) is requested only once the interior has arrived: those lines are interior
+  // lines of the neighbouring tiles, which -- dispatched alongside on the same XCD -- have requested them by then, so the
+  // apron is served by the L2 instead of a second trip to HBM.
+  constexpr int AROWS = LATE ? SH : ROWS, AOFF = LATE ? 1 : 0;
+  constexpr int LPL = (AROWS * G + THREADS - 1) / THREADS;  // staging loads per lane
+  f4 v[LPL];
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) {
+    const int idx = min((int)threadIdx.x + k * THREADS, AROWS * G - 1);
+    const int row = idx / G + AOFF, g = idx % G;
+    const int y = min(max(sy0 - 1 + row, 0), hs - 1);
+    const int x = min(sx0 + 4 * g, ws - 4);  // (groups past a ragged right edge re-read the last one; never stored)
+    v[k] = load4(sband + (size_t)y * spitch + x);
+  }
+  auto apron_column = [&](int i) {  // i = 2 * row + side
+    const int row = i >> 1, right = i & 1;
+    const int y = min(max(sy0 - 1 + row, 0), hs - 1);
+    const int x = right ? min(sx0 + SW, ws - 1) : max(sx0 - 1, 0);  // edge-clamped taps
+    return sband[(size_t)y * spitch + x];
+  };
+  auto apron_slot = [&](int i) { return (i >> 1) * P + ((i & 1) ? 4 + min(SW, ws - sx0) : 3); };
+  float apron = 0.f;
+  const bool early_apron = !LATE && threadIdx.x < 2 * ROWS;
+  if (early_apron) apron = apron_column(threadIdx.x);
+#pragma unroll
+  for (int k = 0; k < LPL; ++k) {
+    const int idx = (int)threadIdx.x + k * THREADS;
+    const int row = idx / G + AOFF, g = idx % G;
+    if (idx < AROWS * G && sx0 + 4 * g < ws) {
+      f4 m;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = mark(v[k][e]);
+      *(f4*)(tile + row * P + 4 + 4 * g) = m;
+    }
+  }
+  if (early_apron) tile[apron_slot(threadIdx.x)] = mark(apron);
+  if constexpr (LATE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (keeps the compiler from hoisting the apron loads)
+#pragma unroll
+    for (int i = threadIdx.x; i < 2 * G + 2 * ROWS; i += THREADS) {
+      if (i < 2 * G) {
+        const int row = (i / G) ? ROWS - 1 : 0, g = i % G;
+        const int y = min(max(sy0 - 1 + row, 0), hs - 1);
+        const f4 w = load4(sband + (size_t)y * spitch + min(sx0 + 4 * g, ws - 4));
+        if (sx0 + 4 * g < ws) {
+          f4 m;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[e] = mark(w[e]);
+          *(f4*)(tile + row * P + 4 + 4 * g) = m;
+        }
+      } else {
+        tile[apron_slot(i - 2 * G)] = mark(apron_column(i - 2 * G));
+      }
+    }
+  }
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = (wave % WPR) * 64 + lane;  // destination columns c0 + 4t .. + 3  <-  source columns sx0 + 2t - 1 .. + 2
+  const int cb = c0 + 4 * t;
+  if (cb >= wd) return;
+  const int rg = wave / WPR;
+  const int r_begin = r0 + rg * RPW;
+  const float* const col = tile + (rg * (RPW / 2)) * P + 3 + 2 * t;
+  auto horizontal = [&](int i, double (&h)[4]) {
+    const float* p = col + i * P;
+    const double a = (double)p[0];
+    const f2 bc = *(const f2*)(p + 1);
+    const double b = (double)bc[0], c = (double)bc[1], d = (double)p[3];
+    h[0] = 0.25 * a + 0.75 * b;
+    h[1] = 0.75 * b + 0.25 * c;
+    h[2] = 0.25 * b + 0.75 * c;
+    h[3] = 0.75 * c + 0.25 * d;
+  };
+  auto store_row = [&](int r, const double (&up)[4], double wu, const double (&lo)[4], double wl) {
+    f4 pack;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float out = (float)(wu * up[k] + wl * lo[k]);
+      pack[k] = (out != out) ? void_out : out;
+    }
+    if constexpr (NTS) __builtin_nontemporal_store(pack, (f4*)(dband + (size_t)r * wd + cb));
+    else *(f4*)(dband + (size_t)r * wd + cb) = pack;
+  };
+  double hm[4], h0[4], hp[4];
+  horizontal(0, hm);
+  horizontal(1, h0);
+#pragma unroll
+  for (int p = 0; p < RPW / 2; ++p) {
+    const int r = r_begin + 2 * p;
+    if (r >= hd) break;  // (wave-uniform; hd is even)
+    horizontal(2 + p, hp);
+    store_row(r, hm, 0.25, h0, 0.75);
+    store_row(r + 1, h0, 0.75, hp, 0.25);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hm[k] = h0[k]; h0[k] = hp[k]; }
+  }
+}
+
+struct Bl2xShape { int th, tw, threads; };
+
+// GM_BL2X="<shape>,<swizzle>,<nt>" overrides the launch shape (tuning runs); read once.
+static void bl2x_config(int* shape, int* swizzle, int* nt) {
+  static int cfg[3] = {-1, 0, 0};
+  if (cfg[0] < 0) {
+    int s = 16, z = 0, n = 0;
+    if (const char* e = getenv("GM_BL2X")) sscanf(e, "%d,%d,%d", &s, &z, &n);
+    cfg[1] = z; cfg[2] = n; cfg[0] = s;
+  }
+  *shape = cfg[0]; *swizzle = cfg[1]; *nt = cfg[2];
+}
+
 }  // namespace
 
 extern "C" {
@@ -376,11 +556,58 @@ int gm_resample_bilinear_window(const void* src, int dtype, int bands, int hs, i
   if (!s) return GM_ERR_NO_DEVICE;
   gm_scalar ndv;
   ndv.u64 = ndv_bits;
+  if (dtype == GM_F32 && hd == 2 * hs && wd == 2 * ws && ws >= 4 && (ws % 4) == 0 && (src_pitch % 4) == 0 &&
+      ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
+    int shape, swizzle, nt;
+    bl2x_config(&shape, &swizzle, &nt);
+    if (shape > 0) {
+#define GM_BL2X_K(TH_, TW_, N_, NT_, NTS_, LATE_)                                                                     \
+  do {                                                                                                               \
+    if (lds2 > 65536) GM_HIP(hipFuncSetAttribute((const void*)bilinear2x_kernel<TH_, TW_, N_, NT_, NTS_, LATE_>,    \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));            \
+    hipLaunchKernelGGL((bilinear2x_kernel<TH_, TW_, N_, NT_, NTS_, LATE_>), dim3(blocks, (unsigned)bands), dim3(N_), \
+                       lds2, s, (const float*)src, (float*)dst, hs, ws, src_pitch, has_ndv, (float)ndv.f64, tiles_x, \
+                       (unsigned)tiles, swizzle);                                                                    \
+  } while (0)
+#define GM_BL2X_GO(TH_, TW_, N_)                                                                                     \
+  do {                                                                                                               \
+    const unsigned tiles_x = (unsigned)((wd + TW_ - 1) / TW_), tiles_y = (unsigned)((hd + TH_ - 1) / TH_);           \
+    const unsigned long long tiles = (unsigned long long)tiles_x * tiles_y;                                          \
+    if (tiles > 0x7ffffff0ull) return gm::fail(GM_ERR_UNSUPPORTED, "gm_resample_bilinear: tile too large for one launch"); \
+    const unsigned blocks = swizzle == 1 ? (unsigned)((tiles + 7) / 8 * 8) : (unsigned)tiles;                       \
+    const size_t lds2 = (size_t)(TH_ / 2 + 2) * (TW_ / 2 + 8) * sizeof(float);                                       \
+    switch (nt & 7) {                                                                                                \
+      case 0: GM_BL2X_K(TH_, TW_, N_, false, true, false); break;                                                    \
+      case 1: GM_BL2X_K(TH_, TW_, N_, true, true, false); break;                                                     \
+      case 2: GM_BL2X_K(TH_, TW_, N_, false, false, false); break;                                                   \
+      case 4: GM_BL2X_K(TH_, TW_, N_, false, true, true); break;                                                     \
+      default: return gm::fail(GM_ERR_INVALID, "GM_BL2X: flags %d", nt);                                             \
+    }                                                                                                                \
+  } while (0)
+      switch (shape) {
+        case 4: GM_BL2X_GO(32, 512, 256); break;
+        case 13: GM_BL2X_GO(8, 1024, 256); break;
+        case 29: GM_BL2X_GO(32, 512, 512); break;
+        default: GM_BL2X_GO(16, 512, 256); break;
+      }
+#undef GM_BL2X_K
+#undef GM_BL2X_GO
+      GM_HIP(hipGetLastError());
+      return GM_OK;
+    }
+  }
   const double sy = (double)hs / (double)hd, sx = (double)ws / (double)wd;
   // largest source window a block can need, + apron; odd pitch (in 4-byte words) spreads the rows
   // of the window over the LDS banks
   const int itemsize = dtype == GM_F32 ? 4 : 8;
-  constexpr int BL_TILE_H = 32;  // destination rows per workgroup (measured: 16: 52 %, 32: 64 %, 64: 64 % of peak at 2x)
+  // destination rows per workgroup (GM_BL_H: tuning runs)
+  static int tile_h_cfg = 0;
+  if (!tile_h_cfg) {
+    const char* e = getenv("GM_BL_H");
+    tile_h_cfg = e ? atoi(e) : 32;
+    if (tile_h_cfg != 8 && tile_h_cfg != 16) tile_h_cfg = 32;
+  }
+  const int BL_TILE_H = tile_h_cfg;
   long long win_h = (long long)ceil(BL_TILE_H * sy) + 3, win_w = (long long)ceil(BL_TILE_W * sx) + 3;
   // 16-byte staging: the window may start up to a group earlier and is padded to whole groups
   const int per = 16 / itemsize;
@@ -403,7 +630,9 @@ int gm_resample_bilinear_window(const void* src, int dtype, int bands, int hs, i
   } while (0)
 #define GM_BILINEAR(T, STAGED, NDV)                                   \
   do {                                                                \
-    GM_BILINEAR_H(T, STAGED, NDV, 32);                                \
+    if (BL_TILE_H == 8) GM_BILINEAR_H(T, STAGED, NDV, 8);             \
+    else if (BL_TILE_H == 16) GM_BILINEAR_H(T, STAGED, NDV, 16);      \
+    else GM_BILINEAR_H(T, STAGED, NDV, 32);                           \
   } while (0)
   if (dtype == GM_F32) {
     if (staged) GM_BILINEAR(float, true, ndv.f64);

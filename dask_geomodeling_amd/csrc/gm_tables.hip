@@ -590,7 +590,11 @@ struct Lookup32Launch {
 // (4 ds_write_b32 + 1 ds_read_b128 per lane, no barrier: one wave, in-order LDS) so that lane l stores
 // the 16 consecutive pixels 16 l .. 16 l + 15 of the wave's 1024.  (16 consecutive pixels per lane
 // straight from memory -- four 16-byte loads at a 64-byte lane stride -- ran at 43 % of peak.)
-__global__ __launch_bounds__(256) void lookup32_kernel(Lookup32Launch L) {
+// EXC: number of exception keys as a compile-time constant (0 .. 2; -1 = L.T.n_exc, a run-time loop).
+// Measured and dropped (round 3): issuing the loads of the next span before the lookups of the current one (229-243 us
+// against 217-223 us on configs[2]).
+template <int EXC>
+__device__ __forceinline__ void lookup32_body(const Lookup32Launch& L) {
   extern __shared__ __align__(16) unsigned char smem[];
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -612,20 +616,32 @@ __global__ __launch_bounds__(256) void lookup32_kernel(Lookup32Launch L) {
     const unsigned idx = (unsigned)value - kmin;  // wrapping, as op_lookup
     const int hit = window[idx < range ? idx : 0u];
     int miss = L.T.select ? L.T.fill : value;
-    for (int x = 0; x < L.T.n_exc; ++x) miss = (idx == (unsigned)L.T.exc_key[x] - kmin) ? L.T.exc_val[x] : miss;
+    if constexpr (EXC < 0) {
+      for (int x = 0; x < L.T.n_exc; ++x) miss = (idx == (unsigned)L.T.exc_key[x] - kmin) ? L.T.exc_val[x] : miss;
+    } else {
+#pragma unroll
+      for (int x = 0; x < EXC; ++x) miss = (idx == (unsigned)L.T.exc_key[x] - kmin) ? L.T.exc_val[x] : miss;
+    }
     return (unsigned)(idx < range ? hit : miss) & 0xffu;
   };
-  for (int c = 0; c < L.chunks; ++c) {
-    // the workgroup's span: 4096 pixels; wave w owns pixels [1024 w, 1024 w + 1024) of it as 4 groups
-    // of 256: group q of lane l = pixels 256 q + 4 l .. + 3
-    const unsigned long long span0 = ((unsigned long long)blockIdx.x * L.chunks + c) * 4096ull + 1024ull * wave;
-    i32x4 v[4];
+  // the workgroup's span c: 4096 pixels; wave w owns pixels [1024 w, 1024 w + 1024) of it as 4 groups
+  // of 256: group q of lane l = pixels 256 q + 4 l .. + 3
+  auto span_of = [&](int c) -> unsigned long long {
+    return ((unsigned long long)blockIdx.x * L.chunks + c) * 4096ull + 1024ull * wave;
+  };
+  auto fetch = [&](int c, i32x4 (&v)[4]) {
+    const unsigned long long span0 = span_of(c);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const unsigned long long e = span0 + 256ull * q + 4ull * lane;
       v[q] = i32x4{0, 0, 0, 0};
       if (e + 4 <= L.n) v[q] = __builtin_nontemporal_load((const i32x4*)(in + offset(e, ip)));
     }
+  };
+  i32x4 v[4];
+  for (int c = 0; c < L.chunks; ++c) {
+    const unsigned long long span0 = span_of(c);
+    fetch(c, v);
     if (c == 0) {  // stage the window behind the first tile loads, 4 loads of a lane in flight
       for (unsigned i = threadIdx.x; i < range; i += 1024) {
         int w[4];
@@ -648,6 +664,26 @@ __global__ __launch_bounds__(256) void lookup32_kernel(Lookup32Launch L) {
         out[offset(e, op)] = (unsigned char)lookup(in[offset(e, ip)]);
     }
   }
+}
+
+template <int EXC>
+__global__ __launch_bounds__(256) void lookup32_kernel(Lookup32Launch L) { lookup32_body<EXC>(L); }
+// compiled for 4 waves per SIMD: the scheduler then keeps all 4 tile loads of a lane (and the window reads behind
+// them) in flight instead of trading them for occupancy -- 245 -> 221 us on configs[2]
+template <int EXC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void lookup32_kernel_w4(Lookup32Launch L) {
+  lookup32_body<EXC>(L);
+}
+
+// GM_LOOKUP32="<spans per workgroup>,<unused>,<waves per SIMD: 4 | 0>" overrides the launch shape (tuning runs); read once.
+static const int* lookup32_config() {
+  static int cfg[4] = {-1, 0, 0, 0};
+  if (cfg[0] < 0) {
+    int c = 0, p = 0, w = 4;  // 4 waves per SIMD: 245 -> 221 us on configs[2] (more loads in flight per wave)
+    if (const char* e = getenv("GM_LOOKUP32")) sscanf(e, "%d,%d,%d", &c, &p, &w);
+    cfg[1] = c; cfg[2] = p; cfg[3] = w; cfg[0] = 1;
+  }
+  return cfg;
 }
 
 }  // namespace
@@ -684,16 +720,29 @@ int gm::lookup32_launch(int n_tiles, const void* const* in, const uint32_t* in_p
   unsigned long long chunks = ((unsigned long long)table.range * 4ull * 10ull + span_bytes - 1) / span_bytes;
   const unsigned long long fill_blocks = 4ull * (unsigned long long)(gm::current_cu_count() > 0 ? gm::current_cu_count() : 256);
   unsigned long long amortise = blocks / fill_blocks;
-  if (amortise > 4) amortise = 4;
+  if (amortise > 2) amortise = 2;  // (measured on 4 x 8192^2: 1 span 233 us, 2: 217, 3: 219, 4: 222, 8: 236)
   if (chunks < amortise) chunks = amortise;
   if (chunks < 1) chunks = 1;
   if (chunks > 64) chunks = 64;
+  const int* cfg = lookup32_config();
+  if (cfg[1] > 0) chunks = (unsigned long long)cfg[1];
   L.chunks = (int)chunks;
   blocks = (blocks + chunks - 1) / chunks;
   if (blocks > 0x7fffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "lookup32: tile too large for one launch");
   const size_t lds = 4096 + (size_t)table.range * 4;
   dim3 grid((unsigned)blocks, (unsigned)n_tiles);
-  hipLaunchKernelGGL(lookup32_kernel, grid, dim3(256), lds, stream, L);
+#define GM_L32(EXC_)                                                                                  \
+  do {                                                                                                \
+    if (cfg[3] == 4) hipLaunchKernelGGL((lookup32_kernel_w4<EXC_>), grid, dim3(256), lds, stream, L); \
+    else hipLaunchKernelGGL((lookup32_kernel<EXC_>), grid, dim3(256), lds, stream, L);                \
+  } while (0)
+  switch (table.n_exc) {
+    case 0: GM_L32(0); break;
+    case 1: GM_L32(1); break;
+    case 2: GM_L32(2); break;
+    default: GM_L32(-1); break;
+  }
+#undef GM_L32
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
