@@ -351,8 +351,11 @@ def spawn_ranks(n):
     """``python bench.py --gpus N`` without a launcher: start N fresh rank processes of this very
     command (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, one per GPU), relay rank 0's
     JSON line and return non-zero if any rank failed.  The parent never touches the GPU (no HIP call, no
-    library load) and never exec()s: the ranks are ordinary children."""
+    library load) and never exec()s: the ranks are ordinary children.  All children are watched: as soon
+    as one of them exits non-zero the others are terminated (they would otherwise sit in a barrier until
+    the process group's timeout) and the command fails within seconds, saying which rank died."""
     import subprocess
+    import threading
     port = str(_free_port())
     procs = []
     for r in range(n):
@@ -361,19 +364,32 @@ def spawn_ranks(n):
         env.setdefault("OMP_NUM_THREADS", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, cwd=os.getcwd()))
-    line, _ = procs[0].communicate()
-    codes = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            codes.append(p.wait(timeout=120))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            codes.append(p.wait())
-    sys.stdout.write(line.decode())
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()  # (rank 0's pipe is drained while the children are polled)
+    bad = []
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad or all(c is not None for c in codes):
+            break
+        time.sleep(0.05)
     if bad:
-        sys.stderr.write("bench: rank(s) failed: %s\n" % bad)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=5.0)
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
+    if bad:
+        sys.stderr.write("bench: rank(s) failed (rank, exit code): %s -- the other ranks were stopped\n" % bad)
         return 1
     return 0
 
@@ -398,12 +414,17 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            from datetime import timedelta
+            # (a rank that dies leaves the others in a collective: two minutes, not gloo's default thirty)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=120))
             dist.barrier()
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
+
+    if os.environ.get("GM_BENCH_FAIL_RANK") == str(rank):  # harness test: this rank dies before its first barrier
+        raise SystemExit("bench: rank %d fails on purpose (GM_BENCH_FAIL_RANK)" % rank)
 
     defaults = {"chain5": (4096, 16), "reclass": (8192, 4), "bilinear": (16384, 1), "mosaic": (4096, 0),
                 "tiler": (16384, 1)}
@@ -482,6 +503,12 @@ def main():
             dist.barrier()
         runtime.sync()
 
+    if P is not None and P.spec_pending():
+        # hot programs are compiled on the library's worker thread while the interpreter keeps serving them: the
+        # timed region is to run the kernels it is meant to time, so wait for them and step until they have taken over
+        P.spec_wait()
+        for _ in range(3):
+            step()
     barrier()
     spec_before = P.spec_stats()["launches"] if P is not None else 0
     e0, e1 = runtime.Event(), runtime.Event()
@@ -513,6 +540,18 @@ def main():
     if spec_launches >= args.steps * launches_per_step and P is not None:
         kernel = P.spec_last_kernel() + " (specialised per program by csrc/gm_spec.hip)"
     kernel_ms = e0.elapsed_ms(e1) / (args.steps * launches_per_step)  # average launch duration (HIP events, compute stream)
+    # kernel-only duration, outside the timed region: the same steps once more with every specialised launch bracketed
+    # by events that the kernel itself stamps at its begin and end (no submission gaps in the figure)
+    kernel_only_us = None
+    if P is not None and spec_launches >= args.steps * launches_per_step:
+        P.spec_timing(True)
+        for _ in range(min(args.steps, 10)):
+            step()
+        runtime.sync()
+        P.spec_timing(False)
+        total_us, timed = P.spec_timing_read()
+        if timed:
+            kernel_only_us = total_us / timed
 
     if not args.no_check and rank == 0:
         # parity of what was just timed: first and last tile of the batch against the oracle
@@ -525,11 +564,17 @@ def main():
                 raise SystemExit("bench: fused chain differs from the oracle on tile %d" % t)
         del results
 
+    own_elapsed, per_rank = elapsed, None
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own time, so that a straggler shows in the line instead of hiding in the maximum
+        mine = torch.tensor([float(rank), own_elapsed], dtype=torch.float64)
+        gathered = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = sorted((int(g[0].item()), float(g[1].item())) for g in gathered)
 
     if rank == 0:
         if args.workload == "mosaic":
@@ -565,9 +610,17 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src, "kernel": kernel,
                          "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_us": round(kernel_ms * 1e3, 2),
+                         "kernel_only_us": None if kernel_only_us is None else round(kernel_only_us, 2),
+                         "wall_us_per_launch": round(elapsed / (args.steps * launches_per_step) * 1e6, 2),
                          "launches_per_step": launches_per_step, "kernel_source_hash": kernel_source_hash()},
             "pct_of_hbm_roofline": round(100.0 * value * 1e6 * bytes_px / world / (HBM_PEAK_GBS * 1e9), 2),
         }
+        if per_rank is not None:
+            rank_px = px_per_step / world if args.workload != "mosaic" else None
+            out["ranks_reported"] = len(per_rank)
+            out["per_rank"] = [{"rank": r, "ms_per_step": round(t / args.steps * 1e3, 4),
+                                "Mpix/s": None if rank_px is None else round(rank_px * args.steps / t / 1e6, 1)}
+                               for r, t in per_rank]
         cpu_tiles = args.cpu_tiles
         if cpu_tiles < 0:
             cpu_tiles = min(max(os.cpu_count() or 1, 4), 32) if world == 1 else 0

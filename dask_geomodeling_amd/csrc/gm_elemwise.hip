@@ -274,7 +274,8 @@ struct CodeEntry {
   mutable std::atomic<unsigned long long> elements_seen{0};
   mutable std::mutex spec_mu;
   mutable gmspec::Kernel spec[2][2];
-  mutable bool spec_tried[2][2] = {{false, false}, {false, false}};
+  mutable gmspec::Ticket spec_ticket[2][2];
+  mutable int spec_state[2][2] = {{0, 0}, {0, 0}};  // 0 = not asked for yet, 1 = being compiled (worker thread), 2 = settled
 };
 
 std::mutex g_code_mu;
@@ -685,8 +686,15 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
     want_spec = seen >= gmspec::hot_elements();
   }
   // a kernel of its own has no decode to amortise and few registers: the 4-byte classes always take 8
-  // elements per lane there (at 4 waves per SIMD, gm_spec.hip), the 8-byte classes keep 4
-  if (want_spec && g_tuning.vec == 0 && code->flavor != VM_MATH) G = wide_class ? 1 : 2;
+  // elements per lane there (at 4 waves per SIMD, gm_spec.hip), the 8-byte classes keep 4.  The interpreter
+  // keeps the launch shape it was tuned for: G changes only for launches that do run a specialised kernel.
+  const int G_interp = G;
+  int G_spec = G;
+  if (want_spec && g_tuning.vec == 0 && code->flavor != VM_MATH) G_spec = wide_class ? 1 : 2;
+  // hot programs (mode 1) are compiled on the library's worker thread while the interpreter keeps serving them;
+  // mode 2 (tests) and GM_SPEC_SYNC=1 compile on the calling thread
+  static const bool spec_sync = getenv("GM_SPEC_SYNC") && atoi(getenv("GM_SPEC_SYNC")) != 0;
+  const bool spec_async = spec_mode == 1 && !spec_sync;
 
   for (int t0 = 0; t0 < n_tiles; t0 += max_batch) {
     const int nb = n_tiles - t0 < max_batch ? n_tiles - t0 : max_batch;
@@ -741,15 +749,24 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
     args.n_groups = aligned ? n / 4 : 0;
     args.tail_start = args.n_groups * 4;
     gmspec::Kernel spec;
+    G = G_interp;
     if (want_spec && args.n_groups) {
       std::lock_guard<std::mutex> lock(code->spec_mu);
-      const int si = strided ? 1 : 0, gi = G - 1;
-      if (!code->spec_tried[si][gi]) {
-        code->spec_tried[si][gi] = true;
-        rc = gmspec::get_kernel(spec_request(*code, strided, G), &code->spec[si][gi]);
+      const int si = strided ? 1 : 0, gi = G_spec - 1;
+      int& state = code->spec_state[si][gi];
+      bool pending = false;
+      if (state == 0) {
+        rc = gmspec::get_kernel(spec_request(*code, strided, G_spec), &code->spec[si][gi], spec_async,
+                                &code->spec_ticket[si][gi], &pending);
         if (rc) return rc;
+        state = pending ? 1 : 2;
+      } else if (state == 1) {
+        rc = gmspec::poll_kernel(code->spec_ticket[si][gi], &code->spec[si][gi], &pending);
+        if (rc) return rc;
+        if (!pending) state = 2;
       }
       spec = code->spec[si][gi];
+      if (spec.function) G = G_spec;
     }
     const bool stage_lds = code->flavor == VM_TABLES && code->lds_table && (!spec.function || spec.stages_lds);
     const unsigned long long per_block = 256ull * G;

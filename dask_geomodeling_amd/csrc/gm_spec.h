@@ -45,9 +45,21 @@ std::string generate(const Request& r, bool* literal_lookup, std::string* kernel
 // Compile `source` for gfx950 with hiprtc (no device needed); the code object lands in `code`.
 int compile(const std::string& source, std::vector<char>* code, std::string* log);
 
+// What identifies a requested kernel once its source has been generated (cheap to poll with).
+struct Ticket {
+  bool valid = false;
+  int device = 0;
+  unsigned long long hash = 0;
+  char kernel_name[40] = {0};
+};
+
 // Kernel for `r` on the current device: memory cache -> disk cache -> compile.  Returns GM_OK and a null
 // function when specialisation is unavailable (no hiprtc) -- the caller keeps the interpreter.
-int get_kernel(const Request& r, Kernel* out);
+// async: the disk read / compilation / module load happens on the library's worker thread; the call returns at
+// once with a null function and *pending = true, and the caller keeps launching the interpreter until
+// poll_kernel(ticket) hands the kernel over.  The global lock is never held across a compilation.
+int get_kernel(const Request& r, Kernel* out, bool async = false, Ticket* ticket = nullptr, bool* pending = nullptr);
+int poll_kernel(const Ticket& t, Kernel* out, bool* pending);
 
 int launch(const Kernel& k, const gmvm::VmLaunch& args, unsigned grid_x, unsigned grid_y, size_t shmem, hipStream_t stream);
 

@@ -743,6 +743,9 @@ def _lib():
         L.gm_spec_get_mode.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]
         L.gm_spec_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)] * 4
         L.gm_spec_last_kernel.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+        L.gm_spec_pending.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+        L.gm_spec_timing.argtypes = [ctypes.c_int]
+        L.gm_spec_timing_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         L.gm_spec_source.argtypes = [ctypes.POINTER(gm_program), ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
                                      ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
         L.gm_spec_compile_check.argtypes = [ctypes.POINTER(gm_program), ctypes.c_int, ctypes.c_int,
@@ -794,6 +797,30 @@ def spec_last_kernel():
 
 def spec_available():
     return bool(_lib().gm_spec_available())
+
+
+def spec_pending():
+    """Number of kernels the library's worker thread is still compiling / loading."""
+    n = ctypes.c_uint64(0)
+    runtime.check(_lib().gm_spec_pending(ctypes.byref(n)), "gm_spec_pending")
+    return n.value
+
+
+def spec_wait():
+    """Block until no kernel is being compiled in the background any more."""
+    runtime.check(_lib().gm_spec_wait(), "gm_spec_wait")
+
+
+def spec_timing(enable):
+    """Bracket every specialised launch with events stamped by the kernel itself (kernel-only durations)."""
+    runtime.check(_lib().gm_spec_timing(1 if enable else 0), "gm_spec_timing")
+
+
+def spec_timing_read():
+    """-> (sum of the kernel durations in microseconds, number of launches) since the last call."""
+    total, n = ctypes.c_double(0.0), ctypes.c_uint64(0)
+    runtime.check(_lib().gm_spec_timing_read(ctypes.byref(total), ctypes.byref(n)), "gm_spec_timing_read")
+    return total.value, n.value
 
 
 def spec_source(compiled, strided=False, group=2):

@@ -284,11 +284,24 @@ int gm_vm_get_tuning(gm_vm_tuning* t);
  * cached per device and on disk ($GM_SPEC_CACHE, default ~/.cache/gmhip).  mode: 0 = off, 1 = programs
  * asked for at least hot_elements pixels (default; 0 keeps the current threshold, initially 2^25),
  * 2 = every program at its first launch (tests; a failing compilation is then an error).  Environment:
- * GM_SPEC, GM_SPEC_HOT, GM_SPEC_CACHE, GM_SPEC_VERBOSE.  Without hiprtc everything keeps the interpreter. */
+ * GM_SPEC, GM_SPEC_HOT, GM_SPEC_CACHE, GM_SPEC_VERBOSE, GM_SPEC_SYNC.  Without hiprtc everything keeps the interpreter.
+ * In mode 1 the compilation (about a second) runs on a worker thread of the library: the launch that finds a
+ * program hot -- and every launch until the kernel is loaded -- stays on the interpreter, no caller waits for the
+ * compiler (GM_SPEC_SYNC=1: compile on the calling thread instead).  The disk cache is used only when its
+ * directory is a private directory of this user (no link, mode 0700); its key covers the hiprtc / HIP versions. */
 int gm_spec_set_mode(int mode, uint64_t hot_elements);
 int gm_spec_get_mode(int* mode, uint64_t* hot_elements);
 int gm_spec_stats(uint64_t* compiled, uint64_t* disk_hits, uint64_t* launches, uint64_t* failed);
 int gm_spec_available(void);
+/* Kernels being compiled in the background: their number / wait until there are none (a benchmark calls this after
+ * its warm-up so that the timed region runs the kernels it is meant to time). */
+int gm_spec_pending(uint64_t* pending);
+int gm_spec_wait(void);
+/* Kernel-only timing of specialised launches: while enabled every such launch is bracketed by events stamped with
+ * the kernel's own begin and end; gm_spec_timing_read waits for them, returns the sum of their durations in
+ * microseconds and their number, and forgets them. */
+int gm_spec_timing(int enable);
+int gm_spec_timing_read(double* total_us, uint64_t* launches);
 /* Name of the specialised kernel resolved last ("gm_spec_<hash of its program>", as profilers show it). */
 int gm_spec_last_kernel(char* buf, size_t len);
 /* The generated HIP source of a program's kernel / a compile check of it; neither needs a device.

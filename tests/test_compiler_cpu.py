@@ -7,9 +7,10 @@ import pytest
 from helpers import assert_result_equal, load_family
 from dask_geomodeling_amd.raster import devops
 
-# NumPy's float32 exp/log SIMD loops are themselves up to ~2.5 ulp off; the device result is the
-# correctly rounded float64 value, hence up to 3 ulp from NumPy's (Power stays within 1 ulp)
-ULP_OPS = {"power": 1, "exp": 3, "log": 3, "log10": 3}
+# NumPy's float32 exp/log SIMD loops are themselves 2 ulp off the correctly rounded value on these vectors
+# (measured: tests/test_gpu_parity.py); the program interpreter evaluates in float64 and rounds once like the
+# device does, hence 2 ulp from NumPy's (Power stays within 1 ulp)
+ULP_OPS = {"power": 1, "exp": 2, "log": 2, "log10": 2}
 
 
 @pytest.mark.parametrize("case", load_family("math"), ids=lambda c: c["id"] + "-" + c["op"])

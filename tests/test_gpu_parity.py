@@ -3,15 +3,28 @@ vectors and against the CPU oracle on seeded inputs.  Run with ``-m gpu`` on an 
 import numpy as np
 import pytest
 
-from helpers import assert_result_equal, assert_values_equal, load_family
+from helpers import ulp_distance, assert_result_equal, assert_values_equal, load_family
 from dask_geomodeling_amd.raster import devops
 from oracle import ref_numpy as O
 
 pytestmark = pytest.mark.gpu
 
-# Power: float64 pow rounded once vs NumPy's faithful powf -> <= 1 ulp (north_star tolerance).
-# Exp/Log (outside the north-star op list): NumPy's own SIMD loops are ~2.5 ulp off -> 3 ulp.
-ULP_OPS = {"power": 1, "exp": 3, "log": 3, "log10": 3}
+# Budgets against the reference-generated vectors, MEASURED on the MI355X (tools/ulp_measure.py,
+# profiles/r03_ulp.log), not allowances:
+#  * Power: float64 pow rounded once vs NumPy's faithful powf / pow: 1 ulp (north_star tolerance);
+#  * Exp / Log / Log10 on float32: the device result IS the correctly rounded value (0 ulp from the function
+#    evaluated in extended precision and rounded once: test_exp_log_are_correctly_rounded below); NumPy's own
+#    float32 SIMD loops -- the reference -- are 2 ulp off it on these vectors (n10039, n10047, n10049), so 2 is the
+#    distance between the reference and the truth, not a device error;
+#  * on float64 the device (ocml) and NumPy (libm) are each within 1 ulp of the truth and within 1 ulp of each other.
+ULP_OPS = {"power": 1, "exp": 2, "log": 2, "log10": 2}
+ULP_F64 = {"power": 1, "exp": 1, "log": 1, "log10": 1}
+
+
+def _ulp(op, expect):
+    values = expect.get("values") if isinstance(expect, dict) else None
+    table = ULP_F64 if getattr(values, "dtype", None) == np.dtype("f8") else ULP_OPS
+    return table.get(op, 0)
 
 
 @pytest.mark.parametrize("case", load_family("math"), ids=lambda c: c["id"] + "-" + c["op"])
@@ -19,7 +32,7 @@ def test_math_golden(gpu, case):
     if "raises" in case:
         pytest.skip("reference raises %s" % case["raises"])
     out = devops.math_process(case["op"], case["kwargs"], *case["args"])
-    assert_result_equal(out, case["expect"], ULP_OPS.get(case["op"], 0), case["id"])
+    assert_result_equal(out, case["expect"], _ulp(case["op"], case["expect"]), case["id"])
 
 
 def test_integer_power_with_raster_exponent(gpu):
@@ -60,7 +73,29 @@ def test_n1_wrapper_golden(gpu, case):
         out = devops.fillnodata_process(case["kwargs"], *case["args"])
     else:
         out = devops.math_process(op, case["kwargs"], *case["args"])
-    assert_result_equal(out, case["expect"], ULP_OPS.get(op, 0), case["id"])
+    assert_result_equal(out, case["expect"], _ulp(op, case["expect"]), case["id"])
+
+
+@pytest.mark.parametrize("dt", ["f4", "f8"])
+@pytest.mark.parametrize("op", ["exp", "log", "log10"])
+def test_exp_log_are_correctly_rounded(gpu, op, dt):
+    """The device against the truth instead of against NumPy: the function in x87 extended precision (64-bit
+    significand) rounded once.  float32: bit-exact (the kernel evaluates in float64 and rounds once); float64:
+    within 1 ulp (measured maximum, tools/ulp_measure.py).  450 000 arguments over 60 decades, both signs."""
+    assert np.finfo(np.longdouble).nmant >= 63, "needs x87 long double"
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(-80, 80, 200000), rng.uniform(0, 1e-3, 50000),
+                        10.0 ** rng.uniform(-30, 30, 200000)]).astype(dt).reshape(1, 450, 1000)
+    fill = float(np.finfo(dt).max)
+    f = {"exp": np.exp, "log": np.log, "log10": np.log10}[op]
+    with np.errstate(all="ignore"):
+        true = f(x.astype(np.longdouble)).astype(dt)
+    got = np.asarray(devops.math_process(op, {"dtype": np.dtype(dt).name, "fillvalue": fill},
+                                         {"values": x, "no_data_value": fill})["values"])
+    data = np.isfinite(true)
+    assert (got[~data] == np.dtype(dt).type(fill)).all()  # log of a negative number / overflow -> no data
+    d = ulp_distance(got[data], true[data])
+    assert d.max() <= (0 if dt == "f4" else 1), "%s %s: %d ulp from the correctly rounded value" % (op, dt, d.max())
 
 
 @pytest.mark.parametrize("case", load_family("clip"), ids=lambda c: c["id"])
@@ -280,7 +315,7 @@ from blocks_util import build_view, leaves_for  # noqa: E402
 from dask_geomodeling_amd import config as gmconfig  # noqa: E402
 from dask_geomodeling_amd import raster  # noqa: E402
 
-VIEW_ULP = {"Power": 1, "Exp": 3, "Log": 3, "Log10": 3}
+VIEW_ULP = {"Power": 1, "Exp": 2, "Log": 2, "Log10": 2}  # (see ULP_OPS)
 NOT_YET = ()
 
 
@@ -608,7 +643,8 @@ def _hillshade_exact(got, data, kw, what):
                          ids=lambda c: c["id"] + "-" + c["op"])
 def test_stencils_golden(gpu, case):
     """Device Dilate / MovingMax / HillShade against vectors produced by the reference itself:
-    bit-exact, except HillShade (float32 trigonometry before a truncating uint8 cast: +-1 on <= 1 %)."""
+    bit-exact, HillShade included (the exact tier of the kernel reproduces the reference's float32 sequence; what
+    depends on the host's NumPy trigonometry is measured in _hillshade_exact, not allowed for here)."""
     from dask_geomodeling_amd import raster
     fn = {"dilate": raster.Dilate.process, "movingmax": raster.MovingMax.process, "hillshade": raster.HillShade.process}[case["op"]]
     out = fn(*case["args"])

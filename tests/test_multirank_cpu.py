@@ -80,6 +80,26 @@ def test_bench_gpus_flag_spawns_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
     assert abs(out["value"] - 2 * 4 * 64 * 64 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) / out["value"] < 0.01
+    assert out["ranks_reported"] == 2 and [r["rank"] for r in out["per_rank"]] == [0, 1]
+    assert all(r["Mpix/s"] > 0 and r["ms_per_step"] <= out["ms_per_step"] * 1.001 for r in out["per_rank"])
+
+
+@pytest.mark.timeout(120)
+def test_bench_fails_within_seconds_when_a_rank_dies():
+    """A rank that dies (GM_BENCH_FAIL_RANK) must not leave the others waiting in a barrier until the process
+    group's timeout -- the parent watches all its children, stops the survivors and reports which rank failed."""
+    import time
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--tiles", "4", "--side", "64", "--dry-run"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["GM_BENCH_FAIL_RANK"] = "1"
+    t0 = time.time()
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=100, env=env, cwd=ROOT)
+    took = time.time() - t0
+    assert res.returncode != 0
+    assert "rank(s) failed" in res.stderr and "(1, " in res.stderr, res.stderr[-1000:]
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")], "no result line from a failed run"
+    assert took < 30, "took %.0f s" % took  # (seconds: interpreter + torch start-up, not a barrier timeout)
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
