@@ -310,9 +310,14 @@ def end_to_end(raster, runtime, side, budget_s=6.0):
         state["k"] += 1
         return view.get_data(bbox=boxes[state["k"] % 16], **req)
 
-    for label, plans in (("plans", True), ("graph_per_request", False)):
-        with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": plans}):
-            v, us, n = rate(one_tile, side * side, 32, 0.2)
+    # plans: no graph at all (plan.py; steps aside when a scheduler is configured in dask); graph_per_request: a real
+    # graph for the configured scheduler, made from the view's template (template.py); graph_from_scratch: the
+    # reference's way, get_compute_graph + the fusion pass for every request
+    modes = (("plans", True, True, 0.2), ("graph_per_request", False, True, 0.2), ("graph_from_scratch", False, False, 0.1))
+    for label, plans, templates, share in modes:
+        with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": plans,
+                                  "geomodeling.templates": templates}):
+            v, us, n = rate(one_tile, side * side, 32, share)
         out["get_data_tile_device_" + label] = {"Mpix/s": v, "us_per_request": us, "requests": n}
     with gmconfig.config.set({"geomodeling.materialize": True}):
         v, us, n = rate(one_tile, side * side, 4, 0.15)
@@ -333,9 +338,10 @@ def end_to_end(raster, runtime, side, budget_s=6.0):
         out["hillshade_get_data_tile_device_" + label] = {"Mpix/s": v, "us_per_request": us, "requests": n}
     tiler = raster.RasterTiler(view, side)
     whole = dict(req, bbox=(0.0, 0.0, float(big), float(big)), width=big, height=big)
-    for label, plans in (("plans", True), ("graph_per_request", False)):
-        with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": plans}):
-            v, us, n = rate(lambda: tiler.get_data(**whole), big * big, 4, 0.15)
+    for label, plans, templates, share in modes:
+        with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": plans,
+                                  "geomodeling.templates": templates}):
+            v, us, n = rate(lambda: tiler.get_data(**whole), big * big, 4, share * 0.75)
         out["tiler_get_data_device_" + label] = {"Mpix/s": v, "us_per_request": us, "requests": n, "tiles": 16}
     return out
 

@@ -7,6 +7,8 @@ besides the reference's own keys this path adds:
   geomodeling.fuse         collapse element-wise sub-graphs into one launch (default True)
   geomodeling.plans        get_data() reuses the fused plan of a view for requests that differ in their
                            bbox only instead of rebuilding the graph (default True; plan.py)
+  geomodeling.templates    the fused graph of a request is made from the view's template instead of built and fused
+                           from scratch (default True; template.py)
   geomodeling.materialize  get_data() returns ndarrays (True) or DeviceArrays (False)
   geomodeling.device       HIP device index used by this process/thread (default: current)
 """
@@ -26,6 +28,7 @@ defaults = {
     "geometry-limit": 10000,
     "fuse": True,
     "plans": True,
+    "templates": True,
     "materialize": True,
     "device": None,
 }
@@ -34,6 +37,7 @@ defaults = {
 class _Shim:
     def __init__(self):
         self._data = {}
+        self._flat = {}  # "a.b.c" -> value of the lookups made so far (get_data reads half a dozen keys per request)
         self._lock = threading.Lock()
 
     def update_defaults(self, new):
@@ -45,8 +49,19 @@ class _Shim:
                         cur.setdefault(kk, vv)
                 else:
                     self._data.setdefault(k, v)
+            self._flat.clear()
 
     def get(self, key, default=KeyError):
+        try:
+            return self._flat[key]
+        except KeyError:
+            pass
+        value = self._lookup(key, default)
+        if value is not default:
+            self._flat[key] = value
+        return value
+
+    def _lookup(self, key, default):
         cur = self._data
         for part in key.split("."):
             if not isinstance(cur, dict) or part not in cur:
@@ -72,6 +87,7 @@ class _Shim:
             for part in parts[:-1]:
                 cur = cur.setdefault(part, {})
             cur[parts[-1]] = value
+            config._flat.clear()
 
         def __enter__(self):
             return self

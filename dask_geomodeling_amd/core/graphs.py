@@ -314,10 +314,10 @@ class Block(object):
         from ..plan import evaluate
         planned, result = evaluate(self, request)  # a cached plan of this view, if it has one (plan.py)
         if not planned:
-            graph, name = self.get_compute_graph(**request)
-            if _config.get("geomodeling.fuse", True):
-                from ..fuse import fuse_graph
-                graph = fuse_graph(graph, name)
+            # a real graph for whatever scheduler is configured (core/graphs.py:42-49), already fused, made from the
+            # view's template when it has one (template.py) instead of from scratch
+            from ..template import fused_compute_graph
+            graph, name = fused_compute_graph(self, request)
             result = compute(graph, name)
         if _config.get("geomodeling.materialize", True):
             from ..fuse import materialize

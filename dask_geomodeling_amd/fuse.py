@@ -89,6 +89,13 @@ class FusedTask(object):
     def __repr__(self):
         return "<FusedTask %s: %s>" % (self.root, " -> ".join(self.members[k][0].gm_op for k in self.order))
 
+    def __getstate__(self):
+        # a FusedTask kept by a graph template travels to worker processes (dask's multiprocessing scheduler)
+        # without its compiled programs: those hold device handles of this process; the worker compiles its own
+        state = dict(self.__dict__)
+        state["_plans"] = {}
+        return state
+
     # -- slow path: exact reference control flow, one launch per op ---------------------
     def _run_unfused(self, env):
         for key in self.order:

@@ -247,10 +247,8 @@ def _child(block, request):
     planned, response = evaluate(block, request)
     if not planned:
         from .core.graphs import compute
-        graph, name = block.get_compute_graph(**request)
-        if _config.get("geomodeling.fuse", True):
-            from .fuse import fuse_graph
-            graph = fuse_graph(graph, name)
+        from .template import fused_compute_graph
+        graph, name = fused_compute_graph(block, request)
         response = compute(graph, name)
     if key is not None:
         memo[key] = response

@@ -294,17 +294,6 @@ class MemorySource(RasterSourceBase):
             hit = memo[projection] = utils.same_projection(projection, self.projection)
         return hit
 
-    def _is_whole_grid(self, request):
-        """Does the request ask for exactly the source's own pixel grid (same bbox, one request
-        cell per source pixel, same CRS)?"""
-        if not self.data.size or not self._same_crs(request["projection"]):
-            return False
-        _, ny, nx = self.data.shape
-        west, south, east, north = self._grid()[1]
-        x1, y1, x2, y2 = request["bbox"]
-        return (request["width"] == nx and request["height"] == ny and
-                x1 == west and y1 == south and x2 == east and y2 == north)
-
     def _aligned_window(self, request):
         """(row0, col0) when the request grid coincides with source pixels -- same CRS, one request
         cell per source pixel, bbox on pixel edges, entirely inside the source -- else None.  Such
@@ -362,9 +351,13 @@ class MemorySource(RasterSourceBase):
         mode = request["mode"]
         if mode == "meta" and self.metadata is None:
             return [({"mode": "empty_meta"}, None)]
-        start, stop, band1, band2 = utils.snap_start_stop(
-            request.get("start"), request.get("stop"), utc_from_ms_timestamp(self.time_first),
-            self.timedelta, len(self))
+        # (the time planning does not depend on the bounding box: a tiled view asks once per tile)
+        when = (request.get("start"), request.get("stop"))
+        memo = self.__dict__.get("_snap_memo")
+        if memo is None or memo[0] != when:
+            memo = self.__dict__["_snap_memo"] = (when, utils.snap_start_stop(
+                when[0], when[1], utc_from_ms_timestamp(self.time_first), self.timedelta, len(self)))
+        start, stop, band1, band2 = memo[1]
         if start is None:
             return [({"mode": "empty_" + mode}, None)]
         bands = band1, band2 + 1
@@ -374,11 +367,13 @@ class MemorySource(RasterSourceBase):
                 array=self.data, metadata=self.metadata, geo_transform=self.geo_transform,
                 no_data_value=self.no_data_value, projection=self.projection)
         if mode == "vals":
+            window = self._aligned_window(request)
+            # (the source's own grid = the aligned window at (0, 0) that covers it)
+            whole = window == (0, 0) and (request["height"], request["width"]) == tuple(self.data.shape[1:])
             kwargs = {"mode": "vals", "raster_data": raster_data, "bbox": request["bbox"],
                       "width": request["width"], "height": request["height"],
                       "projection": request["projection"], "bands": bands, "dtype": self.dtype,
-                      "fillvalue": self.fillvalue, "whole": self._is_whole_grid(request),
-                      "window": self._aligned_window(request)}
+                      "fillvalue": self.fillvalue, "whole": whole, "window": window}
         elif mode == "meta":
             kwargs = {"mode": "meta", "raster_data": raster_data, "bands": bands}
         elif mode == "time":

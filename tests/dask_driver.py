@@ -67,6 +67,8 @@ def main():
     for name, settings in (("synchronous", {"scheduler": "synchronous"}), ("threads", {"scheduler": "threads"}),
                            ("processes", {"scheduler": "processes", "pool": pool})):
         checked = skipped = 0
+        from dask_geomodeling_amd import template
+        stats_before = dict(template.stats)
         with dask.config.set(**settings):
             for what, view, request, want in views:
                 try:
@@ -106,7 +108,12 @@ def main():
                     batched_tasks += isinstance(task[0], BatchedTask)
             from dask_geomodeling_amd.core.graphs import compute
             report.setdefault("task_ran_in_another_process", {})[name] = compute({"pid": (os.getpid,)}, "pid") != os.getpid()
-        report["schedulers"][name] = {"views_checked": checked, "views_skipped": skipped}
+        # the graph every get_data above handed to dask came from the views' templates (template.py): built under
+        # the first scheduler, reused -- same FusedTask, same compiled programs -- under the following ones
+        report["schedulers"][name] = {"views_checked": checked, "views_skipped": skipped,
+                                      "templates_built": template.stats["built"] - stats_before["built"],
+                                      "template_hits": template.stats["hits"] - stats_before["hits"],
+                                      "full_graph_builds": template.stats["full"] - stats_before["full"]}
     pool.shutdown()
     report["fused_tasks_seen"], report["batched_tasks_seen"] = fused_tasks, batched_tasks
     print("DASK_REPORT " + json.dumps(report))

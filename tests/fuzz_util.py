@@ -116,6 +116,10 @@ def oracle_eval(block):
     """Evaluate the Block tree op by op with the reference restatement."""
     if isinstance(block, ArrayLeaf):
         return dict(ArrayLeaf.ARRAYS[block.args[0]])
+    if isinstance(block, raster.MemorySource):
+        # (the whole source on its own grid: what a request for its full extent is answered with)
+        ndv = block.no_data_value
+        return {"values": np.asarray(block.data), "no_data_value": ndv.item() if hasattr(ndv, "item") else ndv}
     if not isinstance(block, raster.RasterBlock):
         return block
     name = type(block).__name__

@@ -11,9 +11,29 @@ pytestmark = pytest.mark.gpu
 
 
 def _graph_path(view, req):
+    """The reference's way: the graph of the request built and fused from scratch (core/graphs.py:157-190)."""
     from dask_geomodeling_amd import config as gmconfig
-    with gmconfig.config.set({"geomodeling.plans": False}):
+    with gmconfig.config.set({"geomodeling.plans": False, "geomodeling.templates": False}):
         return view.get_data(**req)
+
+
+def _template_path(view, req):
+    """A real graph for the scheduler, made from the view's template (template.py): what get_data does as soon as
+    a scheduler is configured in dask."""
+    from dask_geomodeling_amd import config as gmconfig
+    with gmconfig.config.set({"geomodeling.plans": False, "geomodeling.templates": True}):
+        return view.get_data(**req)
+
+
+def _oracle_window(view, bbox):
+    """The oracle's result for an aligned window: element-wise Blocks are local, so it is the crop of the oracle's
+    whole-extent result (fuzz_util.oracle_eval walks the tree op by op with oracle/ref_numpy.py)."""
+    from fuzz_util import SHAPE, oracle_eval
+    with np.errstate(all="ignore"):
+        whole = oracle_eval(view)  # NotImplementedError for views with stencils
+    x1, y1, x2, y2 = (int(v) for v in bbox)
+    rows = slice(SHAPE[1] - y2, SHAPE[1] - y1)
+    return {"values": whole["values"][:, rows, x1:x2], "no_data_value": whole["no_data_value"]}
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -30,7 +50,17 @@ def test_plan_reused_across_bounding_boxes(gpu, seed):
             pytest.skip("not on the device path: %s" % e)
         got = view.get_data(**req)
         assert_result_equal(unsigned_zero(got, view), unsigned_zero(want, view), 0, "bbox %d of %s" % (k, describe(view)))
+        tpl = _template_path(view, req)
+        assert_result_equal(unsigned_zero(tpl, view), unsigned_zero(want, view), 0, "template, bbox %d of %s" % (k, describe(view)))
+        if k < 3:  # aligned windows inside the sources: the oracle itself, not only the other path
+            try:
+                oracle = _oracle_window(view, bbox)
+            except NotImplementedError:
+                continue
+            assert_result_equal(unsigned_zero(got, view), unsigned_zero(oracle, view), 0, "plan vs oracle, bbox %d of %s" % (k, describe(view)))
+            assert_result_equal(unsigned_zero(tpl, view), unsigned_zero(oracle, view), 0, "template vs oracle, bbox %d of %s" % (k, describe(view)))
     assert len(view.__dict__.get("_gm_plans", {})) <= 1  # one request shape -> at most one plan
+    assert len(view.__dict__.get("_gm_templates", {})) <= 1  # ... and at most one template
 
 
 def test_plan_exists_for_the_canonical_chain_and_is_reused(gpu):
@@ -77,9 +107,19 @@ def test_tiler_through_plans_equals_untiled(gpu, seed):
         whole = _graph_path(view, REQ)
     except NotImplementedError as e:
         pytest.skip("not on the device path: %s" % e)
+    try:
+        from fuzz_util import oracle_eval
+        with np.errstate(all="ignore"):
+            assert_result_equal(unsigned_zero(whole, view), unsigned_zero(oracle_eval(view), view), 0, "whole vs oracle: " + describe(view))
+    except NotImplementedError:
+        pass  # (stencil Blocks: compared with the oracle in test_gpu_parity.py)
     for tile in ([8, 8], [16, 12], 17):
-        tiled = raster.RasterTiler(view, tile).get_data(**REQ)
+        tiler = raster.RasterTiler(view, tile)
+        tiled = tiler.get_data(**REQ)
         assert_result_equal(unsigned_zero(tiled, view), unsigned_zero(whole, view), 0, "tile %s of %s" % (tile, describe(view)))
+        for _ in range(2):  # (the second request finds the tiler's assembly and the store's templates)
+            tiled = _template_path(tiler, REQ)
+            assert_result_equal(unsigned_zero(tiled, view), unsigned_zero(whole, view), 0, "template, tile %s of %s" % (tile, describe(view)))
 
 
 def test_stencil_blocks_through_plans(gpu):
@@ -113,7 +153,9 @@ def test_stencil_blocks_through_plans(gpu):
             planned, raw = plan.evaluate(view, req)
             assert planned, name
             got = view.get_data(**req)
-            assert_result_equal(got, _graph_path(view, req), 0, "%s at %s" % (name, (bbox,)))
+            want = _graph_path(view, req)
+            assert_result_equal(got, want, 0, "%s at %s" % (name, (bbox,)))
+            assert_result_equal(_template_path(view, req), want, 0, "template: %s at %s" % (name, (bbox,)))
     # other modes keep the graph path and agree with it
     for mode in ("time", "meta"):
         assert views["hillshade(view)"].get_data(mode=mode) == _graph_path(views["hillshade(view)"], dict(mode=mode))
@@ -143,3 +185,49 @@ def test_temporal_blocks_through_plans(gpu):
             for mode in ("time", "meta"):
                 other = dict(req, mode=mode)
                 assert view.get_data(**other) == _graph_path(view, other)
+
+
+def test_templates_make_real_graphs_and_are_reused(gpu):
+    """template.fused_compute_graph: a dask-style graph any scheduler can run -- leaf tasks + ONE FusedTask (the same
+    object, with its compiled programs, for every bounding box) -- equal to the from-scratch graph's result, for a
+    single view and for a RasterTiler (one TiledAssembly kept per tile layout)."""
+    from dask_geomodeling_amd import raster, template
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd.core.graphs import get_sync
+    from dask_geomodeling_amd.fuse import FusedTask, TiledAssembly
+    rng = np.random.default_rng(2)
+    fill = np.float32(np.finfo("f4").max)
+    a = (rng.random((1, 256, 256)) * 100).astype("f4")
+    b = (rng.random((1, 256, 256)) * 100).astype("f4")
+    a[0, ::9, ::4] = fill
+    A = raster.MemorySource(a, fill, "EPSG:28992", 1.0, (0.0, 256.0))
+    B = raster.MemorySource(b, fill, "EPSG:28992", 1.0, (0.0, 256.0))
+    view = raster.Clip((A + B) * 2.5 - B + 1.5, A)
+    req = dict(mode="vals", width=64, height=64, projection="EPSG:28992")
+    runs = []
+    before = dict(template.stats)
+    for x0, y0 in ((0.0, 0.0), (64.0, 128.0), (192.0, 192.0), (10.5, 3.25)):
+        r = dict(req, bbox=(x0, y0, x0 + 64.0, y0 + 64.0))
+        graph, name = template.fused_compute_graph(view, r)
+        assert name == view.get_compute_graph(**r)[1] and set(graph) >= {name}
+        assert len(graph) == 3 and isinstance(graph[name][0], FusedTask)  # two source tasks + the fused view
+        runs.append(graph[name][0])
+        got = get_sync(graph, [name])[0]
+        assert_result_equal({"values": np.asarray(got["values"]), "no_data_value": got["no_data_value"]},
+                            _graph_path(view, r), 0, "window at %s" % ((x0, y0),))
+    assert all(run is runs[0] for run in runs), "the FusedTask (and its compiled programs) is reused"
+    assert template.stats["built"] == before["built"] + 1 and template.stats["hits"] == before["hits"] + 4
+    tiler = raster.RasterTiler(view, 64)
+    big = dict(mode="vals", bbox=(0.0, 0.0, 256.0, 256.0), width=256, height=256, projection="EPSG:28992")
+    assemblies = []
+    for _ in range(2):
+        graph, name = template.fused_compute_graph(tiler, big)
+        assert isinstance(graph[name][0], TiledAssembly) and len(graph) == 1 + 2 * 16
+        assemblies.append(graph[name][0])
+        got = get_sync(graph, [name])[0]
+        assert_result_equal({"values": np.asarray(got["values"]), "no_data_value": got["no_data_value"]},
+                            _graph_path(view, big), 0, "tiler through templates")
+    assert assemblies[0] is assemblies[1]
+    with gmconfig.config.set({"geomodeling.templates": False}):
+        graph, name = template.fused_compute_graph(view, dict(req, bbox=(0.0, 0.0, 64.0, 64.0)))
+        assert graph[name][0] is not runs[0]  # switched off: built and fused from scratch

@@ -38,5 +38,12 @@ def test_views_under_dask_schedulers():
     for name, counts in report["schedulers"].items():
         assert counts["views_checked"] >= 60, (name, counts)
     assert report["batched_tasks_seen"] >= 3
+    # graph templates: built once (under the first scheduler), hit under threads and processes -- no view pays the
+    # full get_compute_graph + fuse_graph again
+    first, threads, processes = (report["schedulers"][k] for k in ("synchronous", "threads", "processes"))
+    assert first["templates_built"] >= 50
+    for later in (threads, processes):
+        assert later["templates_built"] == 0 and later["template_hits"] >= first["templates_built"], report["schedulers"]
+        assert later["full_graph_builds"] <= first["full_graph_builds"]
     assert report["task_ran_in_another_process"] == {"synchronous": False, "threads": False, "processes": True}
     print(report)

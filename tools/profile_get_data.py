@@ -13,7 +13,8 @@ B = raster.MemorySource(db, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(b
 view = raster.Clip(raster.Add(raster.Subtract(raster.Multiply(raster.Add(A, B), 2.5), B), 1.5), A)
 boxes = [(float(i * side), float(j * side), float((i + 1) * side), float((j + 1) * side)) for i in range(3) for j in range(3)]
 req = dict(mode="vals", width=side, height=side, projection="EPSG:28992")
-with gmconfig.config.set({"geomodeling.materialize": False}):
+import os
+with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": os.environ.get("PLANS", "1") == "1"}):
     for k in range(20):
         view.get_data(bbox=boxes[k % 9], **req)
     runtime.sync()
