@@ -301,7 +301,8 @@ __device__ __forceinline__ unsigned equal_flags(unsigned x, unsigned splat) {
   const unsigned nz = ((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t;   // bit 7 of a byte set <=> byte != 0
   return ~nz & 0x80808080u;                                    // 0x80 in equal bytes
 }
-constexpr int D8W_H = 16, D8W_COLS = 2048, D8W_PITCH = 516;  // window: (D8W_H + 2) rows of 516 words (2064 bytes)
+constexpr int D8W_COLS = 2048, D8W_PITCH = 516;  // window: (D8W_H + 2) rows of 516 words (2064 bytes)
+template <int D8W_H>
 __global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
                                                            int h, int w, int pitch, Dilate8Args A) {
   __shared__ __align__(16) unsigned tile[(D8W_H + 2) * D8W_PITCH];
@@ -375,6 +376,12 @@ __global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* 
     if (y >= 2 && orow < oh) {
       unsigned char* o = out + (size_t)orow * ow + c8;
       if (c8 + 8 <= ow) {
+        // (rows of w - 2 bytes: unless that is a multiple of 8 these stores are not 8-byte aligned, which is what
+        //  separates the 8192-column tile -- 8190-byte rows, 42-46 % of peak -- from the 8194-column one a Dilate
+        //  Block actually requests -- 8192-byte rows, 54-57 %.  Measured and dropped: storing in naturally aligned
+        //  pieces by the row's phase (2 + 4 + 2 bytes ...: no faster than the hardware's own split) and rotating
+        //  the column segment with the tile row so that an XCD does not stay on one segment (no effect: it is not
+        //  the channel aliasing of 8 KiB pitches suspected in round 2).)
         __builtin_memcpy(o, result, 8);
       } else {
         for (int j = 0; c8 + j < ow; ++j) o[j] = (unsigned char)(result[j >> 2] >> (8 * (j & 3)));
@@ -1252,9 +1259,20 @@ int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_
     A8.n_values = n_values;
     for (int i = 0; i < DIL8_MAX_VALUES; ++i) A8.splat[i] = i < n_values ? 0x01010101u * (unsigned)(values_bits[i] & 0xffu) : 0u;
     // (one band: with several, the cells of the neighbouring bands count too -- the row kernel below)
-    if (bands == 1 && w >= 64 && (h - 2 + D8W_H - 1) / D8W_H <= 65535) {
-      dim3 wgrid((unsigned)((w - 2 + D8W_COLS - 1) / D8W_COLS), (unsigned)((h - 2 + D8W_H - 1) / D8W_H));
-      hipLaunchKernelGGL(dilate8_wide_kernel, wgrid, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, h, w, in_pitch, A8);
+    static int d8h = 0;  // output rows per workgroup (GM_D8W_H: tuning runs)
+    if (!d8h) {
+      const char* e = getenv("GM_D8W_H");
+      d8h = e ? atoi(e) : 8;  // (8192^2, 2 values: 16 rows 41 us, 8: 38, 4: 36; with a margin 31.6 / 29.4 / 29.9)
+      if (d8h != 4 && d8h != 8 && d8h != 32) d8h = 16;
+    }
+    if (bands == 1 && w >= 64 && (h - 2 + d8h - 1) / d8h <= 65535) {
+      dim3 wgrid((unsigned)((w - 2 + D8W_COLS - 1) / D8W_COLS), (unsigned)((h - 2 + d8h - 1) / d8h));
+#define GM_D8W(H_) hipLaunchKernelGGL(dilate8_wide_kernel<H_>, wgrid, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, h, w, in_pitch, A8)
+      if (d8h == 4) GM_D8W(4);
+      else if (d8h == 8) GM_D8W(8);
+      else if (d8h == 32) GM_D8W(32);
+      else GM_D8W(16);
+#undef GM_D8W
       GM_HIP(hipGetLastError());
       return GM_OK;
     }

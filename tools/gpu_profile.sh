@@ -5,8 +5,11 @@
 # WRITE_SIZE need separate passes on gfx950; never combined with trace domains other than --kernel-trace).
 # Everything lands under gpurun_out/prof_<tag>_<workload>/; tools/collect_profiles.py copies the summaries
 # into profiles/.
-TAG=$1; WL=$2; shift 2
+set -u
+TAG=${1:?usage: gpu_profile.sh <tag> <workload> [bench args]}; WL=${2:?usage: gpu_profile.sh <tag> <workload> [bench args]}; shift 2
+case "$TAG$WL" in *[!A-Za-z0-9_,.-]*) echo "gpu_profile.sh: tag / workload may only hold [A-Za-z0-9_,.-]" >&2; exit 2;; esac
 REPO=$PWD
+[ -f "$REPO/bench.py" ] || { echo "gpu_profile.sh: run from the repo root" >&2; exit 2; }
 BASE=$REPO/gpurun_out/prof_${TAG}_${WL}
 rm -rf "$BASE"; mkdir -p "$BASE"
 python bench.py --workload $WL "$@" > "$BASE/bench.log" 2> "$BASE/bench.err"; cut -c1-300 "$BASE/bench.log"; tail -2 "$BASE/bench.err"

@@ -20,8 +20,11 @@ if which.startswith("zonal"):
         geometry.label_statistics(dv, np.float32(-9999.0), dl, 1024, which[5:] or "sum")
     runtime.sync()
     sys.exit(0)
+u8 = [generate_window((side, side), "u1", 95 + i, 0.0, 6.0, 255, (50, 50), 0, 0, side, side) for i in range(2)] if which == "dilate8" else []
 for rep in range(5):
-    for t in src:
+    for t in u8:
+        stencil.dilate(t, [1, 3])
+    for t in (src if not u8 else []):
         if which == "hillshade":
             stencil.hillshade(t, np.float32(F32MAX), 0, (0.5, 0.5), 45.0, 315.0)
         elif which.startswith("mm"):
