@@ -8,6 +8,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <chrono>
+
 #include "gm_spec.h"
 #include "gm_vm.h"
 
@@ -573,8 +575,37 @@ int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const
   return gm_elemwise_run_batch_2d(prog, n_tiles, inputs, nullptr, outs, nullptr, 1, n);
 }
 
+// the longest time any caller has spent inside gm_elemwise_run* (what a thread that had to wait for a compilation,
+// a lock or an upload would show): read and reset by gm_elemwise_call_stats
+static std::atomic<unsigned long long> g_calls{0}, g_longest_ns{0};
+static int run_batch_2d(const gm_program* prog, int n_tiles, const void* const* inputs, const uint32_t* pitches,
+                        void* const* outs, const uint32_t* out_pitches, size_t rows, size_t cols);
+
 int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* const* inputs, const uint32_t* pitches,
                              void* const* outs, const uint32_t* out_pitches, size_t rows, size_t cols) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = run_batch_2d(prog, n_tiles, inputs, pitches, outs, out_pitches, rows, cols);
+  const unsigned long long ns =
+      (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  g_calls++;
+  unsigned long long seen = g_longest_ns.load();
+  while (ns > seen && !g_longest_ns.compare_exchange_weak(seen, ns)) {
+  }
+  return rc;
+}
+
+int gm_elemwise_call_stats(uint64_t* calls, double* longest_ms, int reset) {
+  if (calls) *calls = g_calls.load();
+  if (longest_ms) *longest_ms = (double)g_longest_ns.load() * 1e-6;
+  if (reset) {
+    g_calls.store(0);
+    g_longest_ns.store(0);
+  }
+  return GM_OK;
+}
+
+static int run_batch_2d(const gm_program* prog, int n_tiles, const void* const* inputs, const uint32_t* pitches,
+                        void* const* outs, const uint32_t* out_pitches, size_t rows, size_t cols) {
   const size_t n = rows * cols;
   if (!prog || !outs || (!inputs && prog->n_inputs)) return gm::fail(GM_ERR_INVALID, "null argument");
   if ((pitches || out_pitches) && cols > 0xffffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "strided tiles wider than 2^32 elements");

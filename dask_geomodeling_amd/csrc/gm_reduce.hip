@@ -4,9 +4,17 @@
 // W = result_type(dtype, float16) with NaN for no data (program op NANIFNODATA, one launch per raster),
 // exactly as reduction.py:99-107 fills `stack_array`; this file is NumPy's nan-function along axis 0 of
 // that (n, pixels) stack:
-//   * a lane owns V consecutive pixels and walks the frames in order -- NumPy's axis-0 reduction of a
-//     C-contiguous stack accumulates frame by frame in W (the pairwise summation only applies along the
-//     contiguous axis), so sum / product / mean / var round exactly where NumPy rounds;
+//   * a lane owns V consecutive pixels and walks the frames in order.  The array the reference reduces is
+//     `stack_array[:, not_all_nan]` (reduction.py:113-115): boolean-mask indexing hands NumPy an (n, K) array
+//     whose FAST axis is n (strides (itemsize, n * itemsize)), so `func(..., axis=0)` reduces along the
+//     contiguous axis: sums are NumPy's PAIRWISE summation over the n frames (loops_utils.h: fewer than 8
+//     terms one after the other from -0.0; up to 128 in eight interleaved accumulators combined as
+//     ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) plus the remainder; beyond that halves, the first a
+//     multiple of 8), products run frame by frame; a float16 work dtype accumulates both in float32 and
+//     rounds ONCE at the end (HALF_add / HALF_multiply with a reduced inner axis), while the element-wise
+//     steps of var / std (deviation, square) round per element.  Round 3: until then the frames were added
+//     one after the other, which is the same thing below 8 rasters in float32 / float64 -- all the vectors
+//     of round 2 -- and is not from 8 rasters on, nor for float16 sums that actually round;
 //   * nansum adds +0 for NaN, nanprod multiplies by 1, nanmin / nanmax are fmin / fmax with the
 //     accumulator first, nanargmin / nanargmax replace NaN by +-inf and take the first extremum;
 //   * nanmean = float64(sum) / float64(count) rounded once to W (np.true_divide of a W array by an intp
@@ -15,9 +23,9 @@
 //   * nanmedian (< 600 frames: np.ma.median) sorts the data frames of a cell and returns (low + high) / 2;
 //     nanpercentile interpolates between the two neighbours of the virtual index with NumPy's _lerp, the
 //     host having derived index and weight per number of data frames with NumPy's own arithmetic.
-// W = float16 (1-byte rasters) is float32 storage here; NumPy's float16 loops compute in float32 and round
-// the result to float16 after every operation, and so does HALF = true (division by the count: float64
-// quotient rounded straight to float16).  Cells that are NaN in every raster get `fill`; every other
+// W = float16 (1-byte output dtypes) is float32 storage here; NumPy's element-wise float16 loops compute in
+// float32 and round the result to float16 after every operation, and so does HALF = true (division by the
+// count: float64 quotient rounded straight to float16).  Cells that are NaN in every raster get `fill`; every other
 // result is left as it is (incl. NaN / inf of overflowing data): the cast into the output dtype is the
 // caller's, like the reference's `out[not_all_nan] = func(...)`.
 // HBM traffic: n * itemsize + itemsize bytes per pixel (twice the reads for var / std).
@@ -77,6 +85,89 @@ __device__ __forceinline__ C from_f64(double d) {
 
 constexpr int RD_UNROLL = 4;
 constexpr int RD_MAX_SORT = 64;
+constexpr int RD_PW_BLOCK = 128, RD_PW_DEPTH = 5;  // NumPy's PW_BLOCKSIZE; halvings this file unrolls: n <= 128 * 2^5
+
+// What a frame contributes to a sum.  MODE 0: the value, NaN (no data) as +0 (np.nansum's _replace_nan), counting the
+// data frames; MODE 1: the squared deviation from `mean` (np.nanvar: arr - avg where data, 0 elsewhere, then
+// np.multiply(arr, arr): two element-wise operations, each rounded to W).
+template <typename C, typename A, bool HALF, int V, int MODE>
+__device__ __forceinline__ void pw_term(const Pack<C, V>& f, const C (&mean)[V], A (&term)[V], int (&cnt)[V]) {
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const C x = f.v[e];
+    const bool nd = x != x;
+    if constexpr (MODE == 0) {
+      cnt[e] += nd ? 0 : 1;
+      term[e] = nd ? (A)0 : (A)x;
+    } else {
+      const C d = nd ? (C)0 : rnd<HALF, C>(x - mean[e]);
+      term[e] = (A)rnd<HALF, C>(d * d);
+    }
+  }
+}
+
+// NumPy's pairwise_sum over frames [start, start + len), len <= 128 (loops_utils.h, @TYPE@_pairwise_sum)
+template <typename C, typename A, bool HALF, int V, int MODE>
+__device__ __forceinline__ void pw_leaf(const C* src, long long pixels, int start, int len, const C (&mean)[V], A (&res)[V],
+                                        int (&cnt)[V]) {
+  A term[V];
+  if (len < 8) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) res[e] = (A)-0.0;  // (-0.0: a sum of nothing but -0.0 stays -0.0)
+    for (int i = 0; i < len; ++i) {
+      pw_term<C, A, HALF, V, MODE>(load_pack<C, V>(src + (long long)(start + i) * pixels), mean, term, cnt);
+#pragma unroll
+      for (int e = 0; e < V; ++e) res[e] += term[e];
+    }
+    return;
+  }
+  A r[8][V];
+  {
+    Pack<C, V> f[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) f[u] = load_pack<C, V>(src + (long long)(start + u) * pixels);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pw_term<C, A, HALF, V, MODE>(f[u], mean, r[u], cnt);
+  }
+  int i = 8;
+  for (; i < len - (len % 8); i += 8) {
+    Pack<C, V> f[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) f[u] = load_pack<C, V>(src + (long long)(start + i + u) * pixels);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      pw_term<C, A, HALF, V, MODE>(f[u], mean, term, cnt);
+#pragma unroll
+      for (int e = 0; e < V; ++e) r[u][e] += term[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) res[e] = ((r[0][e] + r[1][e]) + (r[2][e] + r[3][e])) + ((r[4][e] + r[5][e]) + (r[6][e] + r[7][e]));
+  for (; i < len; ++i) {
+    pw_term<C, A, HALF, V, MODE>(load_pack<C, V>(src + (long long)(start + i) * pixels), mean, term, cnt);
+#pragma unroll
+    for (int e = 0; e < V; ++e) res[e] += term[e];
+  }
+}
+
+template <typename C, typename A, bool HALF, int V, int MODE, int DEPTH>
+__device__ void pw_sum(const C* src, long long pixels, int start, int n, const C (&mean)[V], A (&res)[V], int (&cnt)[V]) {
+  if constexpr (DEPTH == 0) {
+    pw_leaf<C, A, HALF, V, MODE>(src, pixels, start, n, mean, res, cnt);  // (the host refuses n > 128 * 2^RD_PW_DEPTH)
+  } else {
+    if (n <= RD_PW_BLOCK) {
+      pw_leaf<C, A, HALF, V, MODE>(src, pixels, start, n, mean, res, cnt);
+      return;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    A right[V];
+    pw_sum<C, A, HALF, V, MODE, DEPTH - 1>(src, pixels, start, n2, mean, res, cnt);
+    pw_sum<C, A, HALF, V, MODE, DEPTH - 1>(src, pixels, start + n2, n - n2, mean, right, cnt);
+#pragma unroll
+    for (int e = 0; e < V; ++e) res[e] += right[e];
+  }
+}
 
 // sum / product / min / max / mean / var / std / argmin / argmax
 template <typename C, bool HALF, int STAT, int V>
@@ -106,64 +197,55 @@ __global__ __launch_bounds__(256) void reduce_kernel(const C* __restrict__ stack
         acc[e] = (acc[e] >= x || nd) ? acc[e] : x;
       } else if constexpr (STAT == GM_RED_PRODUCT) {
         const C y = nd ? (C)1 : x;
-        acc[e] = j == 0 ? y : rnd<HALF, C>(acc[e] * y);
+        acc[e] = j == 0 ? y : acc[e] * y;  // (float16: the product runs in float32 and is rounded once, below)
       } else if constexpr (STAT == GM_RED_ARGMIN) {
         const C y = nd ? inf : x;  // _replace_nan(a, +inf), np.argmin: the first minimum
         if (j == 0 || y < acc[e]) { acc[e] = y; arg[e] = j; }
       } else if constexpr (STAT == GM_RED_ARGMAX) {
         const C y = nd ? -inf : x;
         if (j == 0 || y > acc[e]) { acc[e] = y; arg[e] = j; }
-      } else {
-        const C y = nd ? (C)0 : x;
-        acc[e] = j == 0 ? y : rnd<HALF, C>(acc[e] + y);  // np.add.reduce starts from the first frame
       }
     }
   };
-  int j = 0;
-  for (; j + RD_UNROLL <= n; j += RD_UNROLL) {
-    Pack<C, V> f[RD_UNROLL];
-#pragma unroll
-    for (int u = 0; u < RD_UNROLL; ++u) f[u] = load_pack<C, V>(src + (long long)(j + u) * pixels);
-#pragma unroll
-    for (int u = 0; u < RD_UNROLL; ++u) take(f[u], j + u);
-  }
-  for (; j < n; ++j) take(load_pack<C, V>(src + (long long)j * pixels), j);
-
+  constexpr bool ADDITIVE = STAT == GM_RED_SUM || STAT == GM_RED_MEAN || STAT == GM_RED_VAR || STAT == GM_RED_STD;
+  typedef typename std::conditional<std::is_same<C, double>::value, double, float>::type A;  // what the sums run in
   C r[V];
+  if constexpr (ADDITIVE) {
+    A total[V];
+    C none[V];
 #pragma unroll
-  for (int e = 0; e < V; ++e) r[e] = (STAT == GM_RED_ARGMIN || STAT == GM_RED_ARGMAX) ? (C)arg[e] : acc[e];
-  if constexpr (STAT == GM_RED_MEAN || STAT == GM_RED_VAR || STAT == GM_RED_STD) {
+    for (int e = 0; e < V; ++e) none[e] = (C)0;
+    pw_sum<C, A, HALF, V, 0, RD_PW_DEPTH>(src, pixels, 0, n, none, total, cnt);
 #pragma unroll
-    for (int e = 0; e < V; ++e) r[e] = from_f64<HALF, C>((double)acc[e] / (double)cnt[e]);
-  }
-  if constexpr (STAT == GM_RED_VAR || STAT == GM_RED_STD) {
-    C sq[V];
+    for (int e = 0; e < V; ++e) r[e] = rnd<HALF, C>((C)total[e]);
+    if constexpr (STAT != GM_RED_SUM) {
 #pragma unroll
-    for (int e = 0; e < V; ++e) sq[e] = (C)0;
-    auto dev = [&](const Pack<C, V>& f, int k) {
+      for (int e = 0; e < V; ++e) r[e] = from_f64<HALF, C>((double)r[e] / (double)cnt[e]);
+    }
+    if constexpr (STAT == GM_RED_VAR || STAT == GM_RED_STD) {
+      A squares[V];
+      int ignored[V];
+      pw_sum<C, A, HALF, V, 1, RD_PW_DEPTH>(src, pixels, 0, n, r, squares, ignored);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        const C x = f.v[e];
-        const C d = (x != x) ? (C)0 : rnd<HALF, C>(x - r[e]);
-        const C y = rnd<HALF, C>(d * d);
-        sq[e] = k == 0 ? y : rnd<HALF, C>(sq[e] + y);
+        C var = from_f64<HALF, C>((double)rnd<HALF, C>((C)squares[e]) / (double)cnt[e]);
+        if constexpr (STAT == GM_RED_STD) var = rnd<HALF, C>(sqrt(var));
+        r[e] = var;
       }
-    };
-    int k = 0;
-    for (; k + RD_UNROLL <= n; k += RD_UNROLL) {
+    }
+  } else {
+    int j = 0;
+    for (; j + RD_UNROLL <= n; j += RD_UNROLL) {
       Pack<C, V> f[RD_UNROLL];
 #pragma unroll
-      for (int u = 0; u < RD_UNROLL; ++u) f[u] = load_pack<C, V>(src + (long long)(k + u) * pixels);
+      for (int u = 0; u < RD_UNROLL; ++u) f[u] = load_pack<C, V>(src + (long long)(j + u) * pixels);
 #pragma unroll
-      for (int u = 0; u < RD_UNROLL; ++u) dev(f[u], k + u);
+      for (int u = 0; u < RD_UNROLL; ++u) take(f[u], j + u);
     }
-    for (; k < n; ++k) dev(load_pack<C, V>(src + (long long)k * pixels), k);
+    for (; j < n; ++j) take(load_pack<C, V>(src + (long long)j * pixels), j);
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      C var = from_f64<HALF, C>((double)sq[e] / (double)cnt[e]);
-      if constexpr (STAT == GM_RED_STD) var = rnd<HALF, C>(sqrt(var));
-      r[e] = var;
-    }
+    for (int e = 0; e < V; ++e)
+      r[e] = (STAT == GM_RED_ARGMIN || STAT == GM_RED_ARGMAX) ? (C)arg[e] : (STAT == GM_RED_PRODUCT ? rnd<HALF, C>(acc[e]) : acc[e]);
   }
   Pack<C, V> res;
 #pragma unroll
@@ -386,6 +468,9 @@ extern "C" int gm_reduce_stack(const void* stack, int work_dtype, int half, int6
                                const gm_percentile_step* plan, void* out, uint64_t fill_bits) {
   if (!stack || !out) return gm::fail(GM_ERR_INVALID, "null pointer");
   if (n <= 0 || n > 0x7fffffff || pixels < 0) return gm::fail(GM_ERR_INVALID, "gm_reduce_stack: %lld rasters of %lld pixels", (long long)n, (long long)pixels);
+  if ((statistic == GM_RED_SUM || statistic == GM_RED_MEAN || statistic == GM_RED_VAR || statistic == GM_RED_STD) &&
+      n > (int64_t)RD_PW_BLOCK << RD_PW_DEPTH)
+    return gm::fail(GM_ERR_UNSUPPORTED, "gm_reduce_stack: sums over more than %d rasters", RD_PW_BLOCK << RD_PW_DEPTH);
   if (pixels == 0) return GM_OK;
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;

@@ -36,8 +36,10 @@ struct DilateArgs {
 // (16 / 8 rows and batches of 2 were measured for the float32 walkers: no gain over 32 / 4)
 constexpr int ST_ROWS = 32, ST_BATCH = 4;
 
-template <typename T>
-__global__ __launch_bounds__(256) void dilate_kernel(const T* __restrict__ in, T* __restrict__ out, int bands, int h,
+// CHAIN: the values of this launch are applied on top of what earlier launches over the same tile left in `out`
+// (more values than one launch carries: every group still tests the ORIGINAL tile, spatial.py:147-154).
+template <typename T, bool CHAIN = false>
+__global__ __launch_bounds__(256) void dilate_kernel(const T* __restrict__ in, T* out, int bands, int h,
                                                      int w, DilateArgs<T> A) {
   const int c = blockIdx.x * 256 + threadIdx.x, r0 = blockIdx.y * ST_ROWS, b = blockIdx.z;
   const int ow = w - 2, oh = h - 2;
@@ -72,14 +74,15 @@ __global__ __launch_bounds__(256) void dilate_kernel(const T* __restrict__ in, T
         const T* top = rows[i];
         const T* mid = rows[i + 1];
         const T* bot = rows[i + 2];
-        T result = mid[1];
+        T* const cell = out + ((size_t)b * oh + rb + i) * ow + c;
+        T result = CHAIN ? *cell : mid[1];
         for (int k = 0; k < A.n_values; ++k) {  // in order: later values overwrite earlier ones
           const T v = A.values[k];
           const bool hit = (mid[1] == v) | (top[1] == v) | (bot[1] == v) | (mid[0] == v) | (mid[2] == v) |
                            (has_up & (up[i] == v)) | (has_down & (down[i] == v));
           result = hit ? v : result;
         }
-        __builtin_nontemporal_store(result, out + ((size_t)b * oh + rb + i) * ow + c);
+        __builtin_nontemporal_store(result, cell);
       }
     }
 #pragma unroll
@@ -1250,7 +1253,7 @@ int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_
   const bool window = in_pitch != w;
   if (window && bands != 1) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: a window of %d bands", bands);
   if (bands <= 0 || h < 3 || w < 3) return gm::fail(GM_ERR_INVALID, "gm_dilate: tile %dx%dx%d has no interior", bands, h, w);
-  if (n_values < 0 || n_values > DIL_MAX_VALUES) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: %d values (max %d)", n_values, DIL_MAX_VALUES);
+  if (n_values < 0) return gm::fail(GM_ERR_INVALID, "gm_dilate: %d values", n_values);
   if (bands > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: too many bands");
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
@@ -1285,6 +1288,31 @@ int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_
   }
   dim3 grid((unsigned)((w - 2 + 255) / 256), (unsigned)((h - 2 + ST_ROWS - 1) / ST_ROWS), (unsigned)bands);
   const int cell = gm::dtype_size(dtype);
+  if (n_values > DIL_MAX_VALUES) {
+    // the reference takes any number of values (spatial.py:147-154): groups of DIL_MAX_VALUES, every group testing
+    // the original tile and writing on top of what the groups before it left in `out`
+    if (window) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: %d values want a compact tile", n_values);
+#define GM_DILC(T)                                                                                                     \
+  do {                                                                                                                 \
+    for (int v0 = 0; v0 < n_values; v0 += DIL_MAX_VALUES) {                                                            \
+      DilateArgs<T> A;                                                                                                 \
+      A.n_values = n_values - v0 < DIL_MAX_VALUES ? n_values - v0 : DIL_MAX_VALUES;                                    \
+      for (int i = 0; i < A.n_values; ++i) A.values[i] = from_bits<T>(values_bits[v0 + i]);                            \
+      if (v0 == 0) hipLaunchKernelGGL((dilate_kernel<T, false>), grid, dim3(256), 0, s, (const T*)in, (T*)out, bands, h, w, A); \
+      else hipLaunchKernelGGL((dilate_kernel<T, true>), grid, dim3(256), 0, s, (const T*)in, (T*)out, bands, h, w, A); \
+    }                                                                                                                  \
+  } while (0)
+    switch (cell) {  // (values are compared by bit pattern for integers, by == for floats)
+      case 1: GM_DILC(unsigned char); break;
+      case 2: GM_DILC(unsigned short); break;
+      case 4: if (dtype == GM_F32) GM_DILC(float); else GM_DILC(unsigned int); break;
+      case 8: if (dtype == GM_F64) GM_DILC(double); else GM_DILC(unsigned long long); break;
+      default: return gm::fail(GM_ERR_INVALID, "gm_dilate: dtype %d", dtype);
+    }
+#undef GM_DILC
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+  }
   if (bands == 1 && (cell == 2 || cell == 4) && (h - 2 + DT_H - 1) / DT_H <= 65535) {
     dim3 tgrid((unsigned)((w - 2 + DT_W - 1) / DT_W), (unsigned)((h - 2 + DT_H - 1) / DT_H));
 #define GM_DILT(T)                                                                                  \
@@ -1443,8 +1471,7 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
                   double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh, int ow,
                   void* out) {
   if (!in || !out || !weights_host) return gm::fail(GM_ERR_INVALID, "null pointer");
-  if (dtype == GM_BOOL || dtype == GM_U64 || gm::dtype_size(dtype) == 0)
-    return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: dtype %d", dtype);
+  if (gm::dtype_size(dtype) == 0) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: dtype %d", dtype);
   if (axis != 1 && axis != 2) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: axis %d (1 = y, 2 = x)", axis);
   if (radius < 0 || radius > GAUSS_MAX_RADIUS) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: radius %d (max %d)", radius, GAUSS_MAX_RADIUS);
   if (bands <= 0 || oh <= 0 || ow <= 0) return GM_OK;
@@ -1480,13 +1507,16 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
   switch (dtype) {
     case GM_F32: GM_GAUSS(float); break;
     case GM_F64: GM_GAUSS(double); break;
+    case GM_BOOL:  // (SciPy stores into a bool array with the C cast to npy_bool = unsigned char: truncation)
     case GM_U8: GM_GAUSS(unsigned char); break;
     case GM_I8: GM_GAUSS(signed char); break;
     case GM_U16: GM_GAUSS(unsigned short); break;
     case GM_I16: GM_GAUSS(short); break;
     case GM_U32: GM_GAUSS(unsigned int); break;
     case GM_I32: GM_GAUSS(int); break;
-    default: GM_GAUSS(long long); break;
+    case GM_U64: GM_GAUSS(unsigned long long); break;
+    case GM_I64: GM_GAUSS(long long); break;
+    default: return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: dtype %d", dtype);
   }
 #undef GM_GAUSS
   GM_HIP(hipGetLastError());
@@ -1631,6 +1661,7 @@ int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int 
     case GM_U32: GM_HS(unsigned int); break;
     case GM_I32: GM_HS(int); break;
     case GM_I64: GM_HS(long long); break;
+    case GM_U64: GM_HS(unsigned long long); break;  // (sums wrap modulo 2^64 like NumPy's; the quotient is float64)
     case GM_F32: GM_HS(float); break;
     case GM_F64: GM_HS(double); break;
     default: return gm::fail(GM_ERR_INVALID, "gm_hillshade: dtype %d", dtype);

@@ -834,6 +834,24 @@ struct Machine {
 #pragma unroll
             for (int k = 0; k < N; ++k) acc[k] = is_close<RC>(acc[k], y, tol, in_f64, y_finite) ? nan : acc[k];
           }
+          if (flags & 8u) {
+            // the work dtype is float16 and the raster is wider than it (a 1-byte output dtype over int32 / float
+            // rasters): the assignment into the float16 stack rounds the value -- once, to nearest even, from
+            // the class's own precision (float64 -> float16 directly, like NumPy's cast) -- and overflows to inf
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              if constexpr (std::is_same<RC, double>::value) {
+                // one rounding, straight from the float64 value (npy_double_to_half): float64 -> float32 rounded to
+                // odd keeps the sticky information the float32 -> float16 rounding needs
+                const double d = acc[k];
+                float f = __double2float_rz(d);
+                if ((double)f != d && d == d && fabs(d) <= 3.0e38) f = __uint_as_float(__float_as_uint(f) | 1u);
+                acc[k] = (RC)(float)(_Float16)f;
+              } else {
+                acc[k] = (RC)(_Float16)acc[k];
+              }
+            }
+          }
         }
         break;
       case GM_OP_FMAX:
@@ -850,6 +868,18 @@ struct Machine {
         }
         break;
       case GM_OP_COPY:
+        if constexpr (is_float_class<RC>::value) {
+          if (step_flags(S) & 1u) {
+            // the copy feeds a float -> integer store that has to come out like NumPy's cast on x86 (cvttss2si /
+            // cvttsd2si): whatever lies outside the 32-bit range -- inf and NaN included -- converts to the
+            // "integer indefinite" value, INT32_MIN (its low byte / half: 0).  reduce_rasters assigns float16 /
+            // float32 statistics into integer rasters without a finite check (reduction.py:115): a sum that
+            // overflowed float16 reads 0 in a uint8 result, not the 255 a saturating conversion gives
+#pragma unroll
+            for (int k = 0; k < N; ++k) acc[k] = (acc[k] >= (RC)-2147483648.0 && acc[k] < (RC)2147483648.0) ? acc[k] : (RC)-2147483648.0;
+          }
+        }
+        break;
       default:
         break;  // the accumulator already holds the operand
     }

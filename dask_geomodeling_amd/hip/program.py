@@ -566,6 +566,8 @@ def compile_expr(root, n_inputs):
             s.flags = ex["flags"]
             s.aux1.f64 = ex["tol"]
             s.aux2.f64 = ex["y"]
+        elif node.op == "copy" and node.extra and node.extra.get("indefinite"):
+            s.flags = 1  # float -> integer store with x86's out-of-range result (gm_vm.h GM_OP_COPY)
         elif node.op == "maskbelow":
             ex = node.extra
             store = node.args[0]
@@ -588,7 +590,10 @@ def compile_expr(root, n_inputs):
             s.aux1.f64 = ex["tol"]
             s.aux2.f64 = ex["y"]
         elif node.op == "nantofill":
-            _set_scalar(s.fill, cls, cast_scalar(node.ndv, node.dtype))
+            # (extra["fill"]: the value NaN becomes when the node itself declares no no-data value -- an intermediate
+            #  that a cast follows)
+            value = node.extra["fill"] if node.extra and "fill" in node.extra else node.ndv
+            _set_scalar(s.fill, cls, cast_scalar(value, node.dtype))
         elif node.op == "digitize":
             ex = node.extra
             edges = ex["edges"]
@@ -744,6 +749,7 @@ def _lib():
         L.gm_spec_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)] * 4
         L.gm_spec_last_kernel.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         L.gm_spec_pending.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+        L.gm_elemwise_call_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double), ctypes.c_int]
         L.gm_spec_timing.argtypes = [ctypes.c_int]
         L.gm_spec_timing_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
         L.gm_spec_source.argtypes = [ctypes.POINTER(gm_program), ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
@@ -804,6 +810,14 @@ def spec_pending():
     n = ctypes.c_uint64(0)
     runtime.check(_lib().gm_spec_pending(ctypes.byref(n)), "gm_spec_pending")
     return n.value
+
+
+def call_stats(reset=False):
+    """-> (program launches so far, the longest time one of them kept its caller inside the library, in ms)."""
+    calls, longest = ctypes.c_uint64(0), ctypes.c_double(0.0)
+    runtime.check(_lib().gm_elemwise_call_stats(ctypes.byref(calls), ctypes.byref(longest), 1 if reset else 0),
+                  "gm_elemwise_call_stats")
+    return calls.value, longest.value
 
 
 def spec_wait():

@@ -134,6 +134,7 @@ def reduce_max_node(process_kwargs, nodes):
     work = np.result_type(dtype, np.float16)
     work = np.dtype("f4") if work.itemsize < 4 else work
     acc = None
+    half = np.result_type(dtype, np.float16).itemsize < 4
     for node in nodes:
         # (64-bit integer rasters go through float64 like in the reference, reduction.py:99-107: values
         #  beyond 2^53 round on the way, the int64 fill value comes back as INT64_MAX)
@@ -142,9 +143,25 @@ def reduce_max_node(process_kwargs, nodes):
             extra = {"flags": (1 if in_f64 else 0) | (2 if finite else 0), "tol": tol, "y": y, "work": work}
         else:
             extra = {"flags": 4, "tol": 0.0, "y": 0.0, "work": work}
+        if half and node.dtype.itemsize != 1:
+            extra.update(half_round_extra(node.dtype, extra["flags"]))
         coded = P.Op("nanifnodata", [node], work, None, extra=extra)
         acc = coded if acc is None else P.Op("fmax", [acc, coded], work, None, extra={"work": work})
+    if half and any(node.dtype.itemsize != 1 for node in nodes):
+        # a float16 maximum -- possibly inf: a value beyond 65504 -- assigned into the 1-byte raster
+        # (reduction.py:115) converts like NumPy on x86
+        filled = P.Op("nantofill", [acc], work, None, extra={"work": work, "fill": fill})
+        return P.Op("copy", [filled], dtype, fill, extra={"indefinite": True})
     return P.Op("nantofill", [acc], dtype, fill, extra={"work": work})
+
+
+def half_round_extra(dtype, flags):
+    """NANIFNODATA extras of a raster wider than a byte that enters a float16 stack (a 1-byte output dtype works in
+    float16, reduction.py:99-101): the value is rounded to float16 as the reference's assignment rounds it -- once,
+    from a register class that holds the raster exactly -- and values beyond 65504 become inf."""
+    dtype = np.dtype(dtype)
+    wide = dtype.itemsize > 4 or (dtype.kind in "iu" and dtype.itemsize == 4)
+    return {"flags": flags | 8, "work": np.dtype("f8") if wide else np.dtype("f4")}
 
 
 def reduce_max_process(process_kwargs, *args):

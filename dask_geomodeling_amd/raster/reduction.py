@@ -125,15 +125,16 @@ def _nan_function(stack, statistic, percentile, fill_value, dtype):
     half = work.itemsize < 4
     storage = np.dtype("f4") if work.itemsize <= 4 else np.dtype("f8")
     nodes = _stack_nodes(stack)
-    if half and any(node.dtype.itemsize != 1 for node in nodes):
-        raise NotImplementedError("reduce_rasters in float16 (output dtype %s) of rasters wider than one byte" % dtype)
     n, shape = len(stack), tuple(stack[0]["values"].shape)
     if statistic in ("median", "percentile") and n > (MAX_SORTED_RASTERS if storage.itemsize == 4 else 320):
         raise NotImplementedError("%s over %d rasters (at most %d)" % (statistic, n, MAX_SORTED_RASTERS))
     bands = shape[0]
     stacked = DeviceArray.empty((n * bands,) + shape[1:], storage)
     for i, node in enumerate(nodes):
-        coded = P.Op("nanifnodata", [node], storage, None, extra=dict(_index_extra(node.dtype, node.ndv), work=storage))
+        extra = dict(_index_extra(node.dtype, node.ndv), work=storage)
+        if half and node.dtype.itemsize != 1:
+            extra.update(devops.half_round_extra(node.dtype, extra["flags"]))
+        coded = P.Op("nanifnodata", [node], storage, None, extra=extra)
         compiled, leaves, tile_shape = P.plan(coded)
         if tuple(tile_shape) != shape:
             raise ValueError("could not broadcast raster %d of shape %s into shape %s" % (i, tuple(tile_shape), shape))
@@ -146,7 +147,11 @@ def _nan_function(stack, statistic, percentile, fill_value, dtype):
                   "gm_reduce_stack")
     if storage == dtype:
         return result
-    return _through_program(P.Op("copy", [P.Leaf(None, storage, None, values=result)], dtype, None))
+    # (`out[...] = func(...)` assigns the float statistic into the output raster without a finite check,
+    #  reduction.py:115: an integer raster of up to 32 bits gets NumPy's x86 conversion of whatever it is)
+    like_x86 = dtype.kind in "iub" and dtype.itemsize <= 4 and dtype != np.dtype("u4")
+    return _through_program(P.Op("copy", [P.Leaf(None, storage, None, values=result)], dtype, None,
+                                 extra={"indefinite": True} if like_x86 else None))
 
 
 def reduce_rasters(stack, statistic, no_data_value=None, dtype=None):

@@ -72,6 +72,13 @@ def _on_window(src, launch, what):
     runtime.check(rc, what)
 
 
+def _cast_tile(src, dtype):
+    """The tile in another dtype (a COPY program: NumPy's astype)."""
+    from ..hip import program as P
+    values, _ = P.evaluate(P.Op("copy", [P.Leaf(None, src.dtype, None, values=src)], np.dtype(dtype), None))
+    return values
+
+
 def dilate(values, dilate_values):
     """(bands, h, w) tile with a 1-pixel margin -> dilated (bands, h-2, w-2) tile."""
     src = as_device_view(values)
@@ -81,10 +88,8 @@ def dilate(values, dilate_values):
         return DeviceArray.empty((bands, max(h - 2, 0), max(w - 2, 0)), src.dtype)
     out = DeviceArray.empty((bands, h - 2, w - 2), src.dtype)
     todo, current = list(vals), src
-    # more values than one launch takes: later launches must still test the ORIGINAL tile, so the
-    # list is only split when it has to be (the kernel applies its values in order)
-    if len(todo) > MAX_DILATE_VALUES:
-        raise NotImplementedError("Dilate with more than %d values" % MAX_DILATE_VALUES)
+    # (any number of values, spatial.py:147-154: beyond what one launch carries the library applies them group by
+    #  group, every group testing the original tile)
     bits = (ctypes.c_uint64 * max(len(todo), 1))(*[runtime.scalar_bits(v, src.dtype) for v in todo])
     L = _lib()
     _on_window(current, lambda tile, pitch: L.gm_dilate_window(ctypes.c_void_p(tile.ptr), code_of(src.dtype), bands, h, w, pitch,
@@ -110,12 +115,17 @@ def moving_max(values, no_data_value, size):
 def hillshade(values, no_data_value, fill, resolution, altitude, azimuth):
     src = as_device_view(values)
     bands, h, w = src.shape
-    if src.dtype == np.dtype("bool") or src.dtype == np.dtype("u8"):
-        raise NotImplementedError("HillShade on %s tiles" % src.dtype)
-    out = DeviceArray.empty((bands, h - 2, w - 2), "u1")
-    has, bits = _ndv_bits(src.dtype, no_data_value)
     with np.errstate(all="ignore"):
         fill_cast = np.array(fill).astype(src.dtype)[()]  # array[mask] = fill casts like this (spatial.py:364)
+    if src.dtype == np.dtype("bool"):
+        # `2 * array` of a bool array is int64, and so are the Sobel sums (spatial.py:384-404): with cells of 0 / 1
+        # they lie in [-4, 4], so the int16 kernel computes the very same integers (no wrap-around to reproduce)
+        src = _cast_tile(src, "i2")
+        fill_cast = np.int16(bool(fill_cast))
+        if no_data_value is not None:
+            no_data_value = np.int16(bool(no_data_value))
+    out = DeviceArray.empty((bands, h - 2, w - 2), "u1")
+    has, bits = _ndv_bits(src.dtype, no_data_value)
     L = _lib()
     fill_bits = runtime.scalar_bits(fill_cast, src.dtype)
     _on_window(src, lambda tile, pitch: L.gm_hillshade_window(ctypes.c_void_p(tile.ptr), code_of(src.dtype), bands, h, w, pitch, has,
@@ -140,8 +150,6 @@ def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0), fused
     cval=fill) axis by axis (the second axis reads the first one's result in the tile's dtype), the
     result cropped by ``crop_yx`` pixels on every side."""
     src = as_device_view(values)
-    if src.dtype == np.dtype("bool") or src.dtype == np.dtype("u8"):
-        raise NotImplementedError("Smooth on %s tiles" % src.dtype)
     bands, h, w = src.shape
     has, ndv_bits = _ndv_bits(src.dtype, no_data_value)
     with np.errstate(all="ignore"):

@@ -163,7 +163,8 @@ enum gm_opcode {
   /* Max = reduce_rasters(stack, "max") (raster/reduction.py:38-119): like NumPy, carried out in a float
      class with "no data" coded as NaN */
   GM_OP_NANIFNODATA = 29, /* a where a is data (utils.get_index: isclose rule for float tiles, flags / aux1 /
-                             aux2 as MASK) else NaN */
+                             aux2 as MASK) else NaN; flags & 8: the data value rounded to float16 (the work dtype
+                             of a 1-byte output, reduction.py:99-107, over wider rasters) */
   GM_OP_FMAX = 30,        /* np.fmax(a, b) = (a >= b || isnan(b)) ? a : b  -- what np.nanmax reduces with */
   GM_OP_NANTOFILL = 31,   /* fill where a is NaN else a */
   GM_OP_COUNT
@@ -297,6 +298,9 @@ int gm_spec_available(void);
  * its warm-up so that the timed region runs the kernels it is meant to time). */
 int gm_spec_pending(uint64_t* pending);
 int gm_spec_wait(void);
+/* Calls of gm_elemwise_run* so far and the longest time any of them kept its caller (milliseconds) -- what a caller
+ * that had to wait for a compilation would show; reset != 0 clears both. */
+int gm_elemwise_call_stats(uint64_t* calls, double* longest_ms, int reset);
 /* Kernel-only timing of specialised launches: while enabled every such launch is bracketed by events stamped with
  * the kernel's own begin and end; gm_spec_timing_read waits for them, returns the sum of their durations in
  * microseconds and their number, and forgets them. */

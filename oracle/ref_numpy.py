@@ -719,6 +719,9 @@ def gaussian_axis(values, sigma, axis, cval):
     out = line[..., radius:radius + n] * centre
     for j in range(radius, 0, -1):
         out = out + (line[..., radius - j:radius - j + n] + line[..., radius + j:radius + j + n]) * weights[radius - j]
+    if values.dtype == np.dtype("bool"):
+        # SciPy stores with a C cast to npy_bool = unsigned char (ni_filters.c, CASE_FILTER_OUT): truncation, not "!= 0"
+        return np.moveaxis(out.astype(np.uint8).astype(bool), -1, axis)
     return np.moveaxis(out.astype(values.dtype), -1, axis)
 
 

@@ -202,6 +202,9 @@ def run_program(prog, inputs, n):
                         x32 = a.astype("f4")
                         nodata = ((np.abs(x32 - np.float32(y)) <= np.float32(tol)) & y_finite) | (x32 == np.float32(y))
                 r = np.where(nodata, rc.type(np.nan), a)
+                if S.flags & 8:  # float16 work dtype over a wider raster: the assignment rounds (reduction.py:99-107)
+                    with np.errstate(over="ignore"):
+                        r = r.astype(np.float16).astype(rc)
                 nd = np.zeros(n, dtype=bool)
             elif op == 30:  # fmax
                 r = np.where((a >= b) | np.isnan(b), a, b)
@@ -211,6 +214,9 @@ def run_program(prog, inputs, n):
                 nd = np.isnan(a)
             else:  # copy
                 r = a.copy()
+                if rc.kind == "f" and (S.flags & 1):  # float -> integer store like x86's cvttss2si (gm_vm.h GM_OP_COPY)
+                    inside = (a >= rc.type(-2147483648.0)) & (a < rc.type(2147483648.0))
+                    r = np.where(inside, a, rc.type(-2147483648.0))
             if cls == 1 and S.round_f32:
                 r = r.astype("f4").astype("f8")
             if cls == 3 and S.wrap_i32:

@@ -1179,13 +1179,117 @@ def gen_zonal(w):
             cid += 1
 
 
+# --------------------------------------------------------------------------
+# family: round3  (what the device refused until round 3, each produced by the reference itself)
+#   dilate with more than 16 values (spatial.py:147-154), HillShade / Smooth on bool and uint64 rasters
+#   (spatial.py:276-308, 354-417), reduce_rasters into a 1-byte dtype from wider rasters (reduction.py:99-107:
+#   the work dtype is float16 and the assignment into the stack rounds)
+# --------------------------------------------------------------------------
+def gen_round3(w):
+    from dask_geomodeling.raster import reduction as R_red
+    from dask_geomodeling.raster import spatial as R_sp
+    rng = np.random.default_rng(303)
+    cid = 0
+    # Dilate, 17 .. 40 values, in an order that makes later values overwrite earlier ones
+    for dt, ndv in (("u1", np.uint8(255)), ("i4", -9999), ("f4", np.float32(F32MAX)), ("i8", 9223372036854775807), ("u2", np.uint16(65535))):
+        for shape in ((1, 20, 31), (2, 9, 12)):
+            v = rng.integers(0, 48, size=shape).astype(dt)
+            v[rng.random(shape) < 0.1] = ndv
+            for count in (17, 33, 40):
+                values = [int(x) for x in rng.permutation(48)[:count]]
+                if dt == "f4":
+                    values = [float(x) for x in values]
+                data = {"values": v, "no_data_value": ndv}
+                w.add(id="r3%04d" % cid, op="dilate", args=[data, values], expect=R_sp.Dilate.process(data, values)); cid += 1
+    # HillShade on bool and uint64 elevation tiles
+    u64max = np.uint64(18446744073709551615)
+    for dt, ndv in (("bool", None), ("u8", u64max), ("u8", np.uint64(7))):
+        for shape in ((1, 16, 21), (2, 7, 9)):
+            for res, alt, az, fill in (((0.5, 0.5), 45.0, 315.0, 0), ((5.0, 2.0), 30.0, 90.0, 1), ((1.0, 1.0), 80.0, 200.5, 3)):
+                if dt == "bool":
+                    v = rng.random(shape) < 0.4
+                else:
+                    v = rng.integers(0, 120, size=shape).astype(dt)
+                    v[rng.random(shape) < 0.05] = ndv
+                    v.reshape(-1)[:3] = [u64max - np.uint64(1), np.uint64(2 ** 63), np.uint64(2 ** 53 + 1)]  # sums wrap modulo 2^64
+                data = {"values": v, "no_data_value": ndv}
+                kw = dict(resolution=res, altitude=alt, azimuth=az, fill=fill)
+                w.add(id="r3%04d" % cid, op="hillshade", args=[data, kw], expect=R_sp.HillShade.process(data, kw)); cid += 1
+    # Smooth on bool and uint64 tiles (SciPy filters in float64 and stores with a C cast)
+    for dt, ndv in (("bool", None), ("u8", u64max)):
+        for shape, size, mode in (((1, 30, 41), (2.0, 3.0), "exact"), ((2, 17, 19), (1.0, 1.0), "exact"), ((1, 40, 48), (3.75, 6.0), "zoom")):
+            for fill in (0, 1):
+                if dt == "bool":
+                    v = rng.random(shape) < 0.6
+                    v[:, 10:16, 8:16] = True  # (a region whose filtered value reaches 1.0 and survives the cast)
+                else:
+                    v = rng.integers(0, 200, size=shape).astype(dt)
+                    v[rng.random(shape) < 0.1] = ndv
+                    v.reshape(-1)[5] = np.uint64(2 ** 62)
+                data = {"values": v, "no_data_value": ndv}
+                kw = dict(smooth_mode=mode, fill=fill, size=list(size))
+                w.add(id="r3%04d" % cid, op="smooth", args=[data, kw], expect=R_sp.Smooth.process(data, kw)); cid += 1
+    # reduce_rasters into a 1-byte output dtype from wider rasters: work dtype float16
+    ndvs = {"f4": np.float32(F32MAX), "f8": F64MAX, "u1": np.uint8(255), "i4": -9999, "i2": np.int16(-1), "i8": -9999}
+    shape = (2, 11, 19)
+    plans = [(("i4", "i4", "i4"), "u1"), (("f4", "f4"), "u1"), (("f8", "f4", "i2"), "i1"), (("f8", "f8", "f8"), "u1"),
+             (("i2", "u1", "i4"), "u1"), (("i8", "i8"), "i1")]
+    for dts, out_dt in plans:
+        stack = []
+        for dt in dts:
+            ndv = ndvs[dt]
+            if np.dtype(dt).kind == "f":
+                v = (rng.random(shape) * 12).astype(dt)
+                flat = v.reshape(-1)
+                # float16 traps: a tie that only the float64 value breaks (rounding through float32 would lose it),
+                # values that need rounding, one beyond float16's range (-> inf) and one just inside
+                trap = 1.0 + 2.0 ** -11 + 2.0 ** -30
+                v[1, 3, :8] = [trap, 1.0 + 2.0 ** -11, 2049.0, 0.1, 65519.9, 70000.0, 3.0001, 1e-8]
+            else:
+                v = rng.integers(0, 9, size=shape).astype(dt)
+                if np.dtype(dt).itemsize >= 4:
+                    v[1, 3, :4] = [2049, 4099, 65519, 70000]  # not float16 numbers; the last one overflows
+            drop = rng.random(shape) < 0.1
+            drop[1, 3, :8] = False  # (the traps stay data in every raster)
+            v[drop] = ndv
+            v[0, 0, :4] = ndv
+            stack.append({"values": v, "no_data_value": ndv})
+        for stat in REDUCE_STATISTICS:
+            kwargs = {"dtype": out_dt, "no_data_value": dtype_max(np.dtype(out_dt))}
+            try:
+                expect = R_red.reduce_rasters([dict(d) for d in stack], stat, **kwargs)
+            except Exception as e:  # noqa: BLE001
+                w.add(id="r3%04d" % cid, op="reduce:" + stat, stack=stack, kwargs=kwargs, raises=type(e).__name__); cid += 1
+                continue
+            w.add(id="r3%04d" % cid, op="reduce:" + stat, stack=stack, kwargs=kwargs, expect=expect); cid += 1
+    # long stacks: the array the reference reduces, stack_array[:, not_all_nan], has the rasters along its FAST axis, so
+    # NumPy sums them pairwise (8 interleaved accumulators from 8 rasters on, halves beyond 128) -- not one after the other
+    small = (1, 6, 9)
+    for n, dt, out_dt in ((8, "f4", None), (9, "f4", None), (17, "f4", None), (40, "f8", None), (130, "f4", None),
+                          (300, "f4", None), (23, "i4", "f4"), (9, "f4", "u1"), (40, "u1", None)):
+        ndv = ndvs[dt]
+        stack = []
+        for _ in range(n):
+            if np.dtype(dt).kind == "f":
+                v = (rng.random(small) * 100 - 20).astype(dt)
+            else:
+                v = rng.integers(0, 7, size=small).astype(dt)
+            v[rng.random(small) < 0.15] = ndv
+            v[0, 0, 0] = ndv
+            stack.append({"values": v, "no_data_value": ndv})
+        for stat in ("sum", "mean", "var", "std", "product", "median", "max", "count"):
+            kwargs = {} if out_dt is None else {"dtype": out_dt, "no_data_value": dtype_max(np.dtype(out_dt))}
+            expect = R_red.reduce_rasters([dict(d) for d in stack], stat, **kwargs)
+            w.add(id="r3%04d" % cid, op="reduce:" + stat, stack=stack, kwargs=kwargs, expect=expect); cid += 1
+
+
 def main():
     fams = {
         "math": gen_math, "n1": gen_n1, "clip": gen_clip, "mask": gen_mask,
         "classify": gen_classify, "reclassify": gen_reclassify, "tiler": gen_tiler,
         "views": gen_views, "dtypes": gen_dtypes, "smoothzoom": gen_smoothzoom,
         "spatial": gen_spatial, "reduce": gen_reduce, "reducestats": gen_reducestats, "group": gen_group, "smooth": gen_smooth,
-        "temporal": gen_temporal, "zonal": gen_zonal,
+        "temporal": gen_temporal, "zonal": gen_zonal, "round3": gen_round3,
     }
     only = sys.argv[1:]
     counts = {}

@@ -1550,3 +1550,27 @@ def test_bilinear_on_zero_copy_windows(gpu, dt):
             want = resample.bilinear(host, hd, wd, ndv).to_numpy()
             assert np.array_equal(got, want, equal_nan=True), (dt, (row0, col0, h, w), (hd, wd))
             assert_values_equal(got, O.bilinear_resample(host, hd, wd, ndv), 1, "bilinear window %s" % dt)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 3: the last refusals, closed -- each against vectors produced by the reference itself
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", load_family("round3"), ids=lambda c: c["id"] + "-" + c["op"])
+def test_round3_golden(gpu, case):
+    """Dilate with more than 16 values (value groups chained over the original tile, spatial.py:147-154), HillShade and
+    Smooth on bool / uint64 rasters (spatial.py:276-308, 354-417), reduce_rasters into a 1-byte dtype from wider
+    rasters (float16 work dtype: the stack assignment rounds, reduction.py:99-107): bit-exact."""
+    from dask_geomodeling_amd import raster
+    from dask_geomodeling_amd.raster.reduction import reduce_rasters
+    op = case["op"]
+    if op.startswith("reduce:"):
+        out = reduce_rasters([dict(d) for d in case["stack"]], op.split(":")[1], **case["kwargs"])
+        out, want = dict(out, values=np.asarray(out["values"])), case["expect"]
+        if op.endswith("median") or op.split(":")[1].startswith("p"):
+            from fuzz_util import unsigned_zero
+            out, want = unsigned_zero(out), unsigned_zero(want)
+        assert_result_equal(out, want, 0, "%s %s" % (case["id"], op))
+        return
+    fn = {"dilate": raster.Dilate.process, "hillshade": raster.HillShade.process, "smooth": raster.Smooth.process}[op]
+    assert_result_equal(fn(*case["args"]), case["expect"], 0, case["id"])

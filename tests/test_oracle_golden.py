@@ -346,3 +346,23 @@ def test_zonal_label_statistic_is_scipys():
                 assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (dt, name)
         want = np.asarray(ndimage.sum(1, labels=labels, index=index))
         assert np.array_equal(O.zonal_label_statistic(values.ravel(), labels.ravel(), index, "count"), want)
+
+
+# ---------------------------------------------------------------------------------
+# round 3: what the device refused until then (Dilate with many values, HillShade / Smooth on bool and uint64
+# rasters, reduce_rasters into a 1-byte dtype from wider rasters), produced by the reference itself
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", load_family("round3"), ids=lambda c: c["id"] + "-" + c["op"])
+def test_round3(case):
+    op = case["op"]
+    if op.startswith("reduce:"):
+        out = O.reduce_rasters([dict(d) for d in case["stack"]], op.split(":")[1], **case["kwargs"])
+        want = case["expect"]
+        if op.endswith("median") or op.split(":")[1].startswith("p"):
+            from fuzz_util import unsigned_zero
+            out, want = unsigned_zero(out), unsigned_zero(want)
+        assert_result_equal(out, want, 0, case["id"])
+    elif op == "hillshade":
+        assert_result_equal(O.hillshade_process(*case["args"], trig="rounded"), case["expect"], 0, case["id"])
+    else:
+        assert_result_equal(getattr(O, op + "_process")(*case["args"]), case["expect"], 0, case["id"])
