@@ -11,6 +11,7 @@ besides the reference's own keys this path adds:
                            from scratch (default True; template.py)
   geomodeling.materialize  get_data() returns ndarrays (True) or DeviceArrays (False)
   geomodeling.device       HIP device index used by this process/thread (default: current)
+  geomodeling.resident-window-bytes  bound of the per-device window cache of resident SyntheticSources (LRU)
 """
 import os
 import threading
@@ -31,6 +32,7 @@ defaults = {
     "templates": True,
     "materialize": True,
     "device": None,
+    "resident-window-bytes": 192 << 30,
 }
 
 

@@ -396,8 +396,12 @@ int launch_reduce(const void* stack, int n, long long pixels, int statistic, con
     if (percentile && long_stack) {
       int rc = gm_malloc((void**)&plan_dev, sizeof(gm_percentile_step) * (size_t)n);
       if (rc) return rc;
-      GM_HIP(hipMemcpyAsync(plan_dev, plan, sizeof(gm_percentile_step) * (size_t)n, hipMemcpyHostToDevice, s));
-      GM_HIP(hipStreamSynchronize(s));
+      hipError_t e = hipMemcpyAsync(plan_dev, plan, sizeof(gm_percentile_step) * (size_t)n, hipMemcpyHostToDevice, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess) {
+        (void)gm_free(plan_dev);  // (not leaked on the error path)
+        return gm::hip_fail(e, "gm_reduce_stack: percentile plan upload");
+      }
     } else if (percentile) {
       for (int i = 0; i < n; ++i) {
         P.lower[i] = (short)plan[i].lower;

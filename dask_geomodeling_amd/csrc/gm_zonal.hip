@@ -874,14 +874,21 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     float* out_f = out + (size_t)f * n_labels;
     long long* counts_f = counts + (size_t)f * n_labels;
     unsigned char* seen = f == 0 ? present : (unsigned char*)nullptr;
-    auto sort_buffers = [&]() -> int {
+    // the keys / payloads the first pass writes are taken up front; the sort's double buffers and its temporary
+    // storage -- 8 to 12 more bytes per cell plus rocPRIM's scratch, gigabytes for a 16384^2 frame -- only once a
+    // verdict asks for the full sort: sums that the two-pass parallel path answers never allocate them
+    auto key_buffers = [&]() -> int {
       if (keys_a) return GM_OK;
       int rc2;
       if ((rc2 = scratch.take((void**)&keys_a, sizeof(unsigned) * cells))) return rc2;
-      if ((rc2 = scratch.take((void**)&keys_b, sizeof(unsigned) * cells))) return rc2;
       if ((rc2 = scratch.take((void**)&pay_a, sizeof(Key) * cells))) return rc2;
+      return scratch.take((void**)&first, sizeof(unsigned) * ((size_t)n_labels + 2));
+    };
+    auto sort_buffers = [&]() -> int {
+      if (keys_b) return GM_OK;
+      int rc2;
+      if ((rc2 = scratch.take((void**)&keys_b, sizeof(unsigned) * cells))) return rc2;
       if ((rc2 = scratch.take((void**)&pay_b, sizeof(Key) * cells))) return rc2;
-      if ((rc2 = scratch.take((void**)&first, sizeof(unsigned) * ((size_t)n_labels + 2)))) return rc2;
       size_t temp_value = 0, temp_label = 0;
       if (by_value)
         GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_value, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 0, 8 * sizeof(Key), s));
@@ -889,7 +896,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       temp_bytes = temp_value > temp_label ? temp_value : temp_label;
       return scratch.take(&temp, temp_bytes);
     };
-    if ((rc = sort_buffers())) return rc;
+    if ((rc = key_buffers())) return rc;
     bool keys_written = false;
     if (range) {
       hipLaunchKernelGGL(zonal_exact_init_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, verdict_dev, cursor);
@@ -935,6 +942,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       }
       keys_written = true;  // (and `present` is recorded)
     }
+    if ((rc = sort_buffers())) return rc;
     if (!keys_written)
       hipLaunchKernelGGL(zonal_keys_kernel<T>, dim3(blocks), dim3(256), 0, s, frame, labels, (size_t)cells, n_labels, has_ndv, ndv,
                          thresholds, keys_a, pay_a, seen);

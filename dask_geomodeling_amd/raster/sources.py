@@ -10,7 +10,9 @@ needs PROJ/GDAL, which this path does not carry (out of scope)
 65536x65536 virtual mosaic: pixels are a counter-based function of their global
 index, so any window of any size is generated in place without host data.
 """
+import collections
 import ctypes
+import threading
 import weakref
 from datetime import datetime, timedelta, timezone
 
@@ -143,6 +145,41 @@ class RasterSourceBase(RasterBlock):
         return {"values": values, "no_data_value": fill}
 
 
+def _as_frames(data):
+    """The pixel values as a (t, y, x) stack: host arrays through NumPy (int64 narrowed to int32: sources.py:201-203,
+    a GDAL limitation kept for parity), device-resident arrays as they are; 2-D data is one frame."""
+    if not isinstance(data, DeviceArray):
+        data = np.asarray(data)
+        if data.dtype == np.dtype("i8"):
+            data = data.astype("i4")
+        if data.ndim == 2:
+            data = data[np.newaxis]
+    elif data.ndim == 2:
+        data = data.reshape((1,) + data.shape)
+    if data.ndim != 3:
+        raise ValueError("data should be two- or three-dimensional.")
+    return data
+
+
+def _pair(value, name, scalar_ok=False):
+    """[float, float] from a sequence of two (or, for the pixel size, one number for both axes)."""
+    if scalar_ok and not hasattr(value, "__iter__"):
+        value = (value, value)
+    pair = [float(x) for x in value]
+    if len(pair) != 2:
+        raise ValueError("{} should have length 2".format(name))
+    return pair
+
+
+def _milliseconds(delta):
+    """A time step as integer milliseconds (None stays None)."""
+    if delta is None:
+        return None
+    if isinstance(delta, timedelta):
+        return int(delta.total_seconds() * 1000)
+    return int(delta)
+
+
 class MemorySource(RasterSourceBase):
     """A raster source that interfaces data from memory (sources.py:157-393).
 
@@ -161,45 +198,18 @@ class MemorySource(RasterSourceBase):
 
     def __init__(self, data, no_data_value, projection, pixel_size, pixel_origin, time_first=0,
                  time_delta=None, metadata=None):
-        if not isinstance(data, DeviceArray):
-            data = np.asarray(data)
-            if data.dtype == "i8":
-                data = data.astype("i4")  # sources.py:201-203 (a GDAL limitation kept for parity)
-            if data.ndim == 2:
-                data = data[np.newaxis]
-        elif data.ndim == 2:
-            data = data.reshape((1,) + data.shape)
-        if data.ndim != 3:
-            raise ValueError("data should be two- or three-dimensional.")
-        no_data_value = data.dtype.type(no_data_value)
-        projection = utils.get_epsg_or_wkt(projection)
-        if not hasattr(pixel_size, "__iter__"):
-            pixel_size = [pixel_size] * 2
-        else:
-            pixel_size = list(pixel_size)
-            if len(pixel_size) != 2:
-                raise ValueError("pixel_size should have length 2")
-        pixel_size = [float(x) for x in pixel_size]
-        pixel_origin = [float(x) for x in pixel_origin]
-        if len(pixel_origin) != 2:
-            raise ValueError("pixel_origin should have length 2")
-        if isinstance(time_first, datetime):
-            time_first = utils.dt_to_ms(time_first)
-        else:
-            time_first = int(time_first)
-        if isinstance(time_delta, timedelta):
-            time_delta = int(time_delta.total_seconds() * 1000)
-        elif time_delta is None:
-            if data.shape[0] > 1:
-                raise ValueError("time_delta is required for temporal data")
-        else:
-            time_delta = int(time_delta)
+        frames = _as_frames(data)
+        stamp = utils.dt_to_ms(time_first) if isinstance(time_first, datetime) else int(time_first)
+        step = _milliseconds(time_delta)
+        if step is None and frames.shape[0] > 1:
+            raise ValueError("time_delta is required for temporal data")
         if metadata is not None:
             metadata = list(metadata)
-            if len(metadata) != data.shape[0]:
+            if len(metadata) != frames.shape[0]:
                 raise ValueError("Metadata length should match data length")
-        super().__init__(data, no_data_value, projection, pixel_size, pixel_origin, time_first,
-                         time_delta, metadata)
+        super().__init__(frames, frames.dtype.type(no_data_value), utils.get_epsg_or_wkt(projection),
+                         _pair(pixel_size, "pixel_size", scalar_ok=True), _pair(pixel_origin, "pixel_origin"),
+                         stamp, step, metadata)
 
     @property
     def token(self):
@@ -394,7 +404,13 @@ class SyntheticSource(RasterBlock):
     tiles -- 1/N of the mosaic per GPU when the tiles are dealt over N workers -- and later requests
     for the same tile are served without regenerating it (the responses are immutable by contract)."""
 
-    _windows = {}  # (spec, device, row0, col0, h, w) -> DeviceArray
+    # per-device tile cache of the resident sources: (spec, device, row0, col0, h, w) -> DeviceArray, least recently
+    # used first.  Bounded by bytes (geomodeling.resident-window-bytes, default 192 GiB of the MI355X's 288 GB): a
+    # source asked for ever new windows (sliding boxes, stencil-grown requests) evicts its oldest instead of pinning
+    # HBM until drop_resident_windows() is called by hand; guarded by a lock (get_data runs on scheduler threads).
+    _windows = collections.OrderedDict()
+    _window_bytes = 0
+    _window_lock = threading.Lock()
 
     def __init__(self, shape, dtype, seed, lo, hi, no_data_value, lattice=(0, 0), projection="EPSG:28992",
                  pixel_size=1.0, pixel_origin=(0.0, 0.0), resident=False):
@@ -459,20 +475,35 @@ class SyntheticSource(RasterBlock):
         window = (process_kwargs["row0"], process_kwargs["col0"], process_kwargs["height"], process_kwargs["width"])
         resident = len(spec) > 10 and spec[10]
         values = None
+        cls = SyntheticSource
         if resident:
             runtime.require_device()
             key = (tuple(spec[:7]), runtime.get_device()) + window
-            values = SyntheticSource._windows.get(key)
+            with cls._window_lock:
+                values = cls._windows.get(key)
+                if values is not None:
+                    cls._windows.move_to_end(key)
         if values is None:
             values = generate_window(shape, dtype, seed, lo, hi, ndv, lattice, *window)
             if resident:
-                SyntheticSource._windows[key] = values
+                from .. import config as _config
+                limit = int(_config.get("geomodeling.resident-window-bytes", 192 << 30))
+                size = int(values.size) * dtype.itemsize
+                with cls._window_lock:
+                    if key not in cls._windows:  # (another thread may have generated the same window meanwhile)
+                        cls._windows[key] = values
+                        cls._window_bytes += size
+                    while cls._window_bytes > limit and len(cls._windows) > 1:
+                        _, old = cls._windows.popitem(last=False)
+                        cls._window_bytes -= int(old.size) * old.dtype.itemsize
         return {"values": values, "no_data_value": dtype.type(ndv)}
 
     @classmethod
     def drop_resident_windows(cls):
         """Give the cached windows of all resident SyntheticSources back to the allocator."""
-        cls._windows.clear()
+        with cls._window_lock:
+            cls._windows.clear()
+            cls._window_bytes = 0
 
 
 def generate_window(shape, dtype, seed, lo, hi, ndv, lattice, row0, col0, height, width):
