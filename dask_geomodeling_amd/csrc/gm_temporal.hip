@@ -428,6 +428,112 @@ __global__ __launch_bounds__(256) void median_small_kernel(const Tin* __restrict
   __builtin_nontemporal_store(finite_<C>(r) ? r : fill, out + (long long)B.out[blockIdx.y] * pixels + p);
 }
 
+// Bins too long for the LDS sort (a year of hourly frames ...): the order statistics are SELECTED instead of sorted.
+// A lane counts the data frames of its cell, takes the two ranks it needs (the middle pair, or the percentile plan's
+// neighbours), and finds the value of the lower rank by a radix select over the order-preserving integer image of the
+// working dtype -- bit by bit from the top, each bit one pass over the bin counting the frames below the candidate --
+// and the upper rank's value with one more pass (the same value when it occurs again, else the smallest larger one).
+// 34 (float32) / 66 (float64) passes over the bin, every pass a coalesced stream (lane = pixel) that mostly stays
+// in the Infinity Cache; no limit on the length of a bin.  np.nanmedian's >= 600-frame route (np.median of the data
+// frames: the mean of the middle pair) and np.nanpercentile give the very same two values and combine them as below.
+template <typename C>
+struct SelectKey;
+template <>
+struct SelectKey<float> {
+  typedef unsigned K;
+  static constexpr int BITS = 32;
+  static __device__ __forceinline__ K encode(float v) {
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  }
+  static __device__ __forceinline__ float decode(K k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+};
+template <>
+struct SelectKey<double> {
+  typedef unsigned long long K;
+  static constexpr int BITS = 64;
+  static __device__ __forceinline__ K encode(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+  }
+  static __device__ __forceinline__ double decode(K k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+  }
+};
+
+template <typename Tin, bool PERCENTILE>
+__global__ __launch_bounds__(256) void median_select_kernel(const Tin* __restrict__ frames, Tin ndv, bool has_ndv,
+                                                            long long pixels, Bins B,
+                                                            const gm_percentile_step* __restrict__ long_plan,
+                                                            typename OutOf<Tin, GM_STAT_MEDIAN>::type* __restrict__ out,
+                                                            typename OutOf<Tin, GM_STAT_MEDIAN>::type fill) {
+  using C = typename OutOf<Tin, GM_STAT_MEDIAN>::type;
+  using SK = SelectKey<C>;
+  using K = typename SK::K;
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= pixels) return;
+  const int first = B.first[blockIdx.y], count = B.count[blockIdx.y];
+  const Tin* src = frames + (long long)first * pixels + p;
+  // one pass over the bin: visit(key) for every data frame (TB_UNROLL loads in flight)
+  auto sweep = [&](auto visit) {
+    int j = 0;
+    for (; j + TB_UNROLL <= count; j += TB_UNROLL) {
+      Tin f[TB_UNROLL];
+#pragma unroll
+      for (int u = 0; u < TB_UNROLL; ++u) f[u] = src[(long long)(j + u) * pixels];
+#pragma unroll
+      for (int u = 0; u < TB_UNROLL; ++u) {
+        C x;
+        if (!skipped<Tin, C>(f[u], ndv, has_ndv, x)) visit(SK::encode(x));
+      }
+    }
+    for (; j < count; ++j) {
+      C x;
+      if (!skipped<Tin, C>(src[(long long)j * pixels], ndv, has_ndv, x)) visit(SK::encode(x));
+    }
+  };
+  int n = 0;
+  sweep([&](K) { ++n; });
+  C r = std::numeric_limits<C>::quiet_NaN();
+  if (n > 0) {
+    int lower, upper;
+    C t = (C)0, u = (C)0;
+    if constexpr (PERCENTILE) {
+      const gm_percentile_step step = long_plan[n - 1];
+      lower = step.lower; upper = step.upper; t = (C)step.gamma; u = (C)step.one_minus_gamma;
+    } else {
+      upper = n / 2;
+      lower = (n & 1) ? upper : upper - 1;
+    }
+    // the largest candidate with at most `lower` frames below it is the frame of that rank
+    K prefix = 0;
+    for (int bit = SK::BITS - 1; bit >= 0; --bit) {
+      const K candidate = prefix | ((K)1 << bit);
+      int below = 0;
+      sweep([&](K key) { below += key < candidate ? 1 : 0; });
+      if (below <= lower) prefix = candidate;
+    }
+    const C a = SK::decode(prefix);
+    C b = a;
+    if (upper != lower) {  // (the next rank: the same value when it occurs again, else the smallest larger one)
+      int not_above = 0;
+      K next = ~(K)0;
+      sweep([&](K key) {
+        not_above += key <= prefix ? 1 : 0;
+        next = (key > prefix && key < next) ? key : next;
+      });
+      if (not_above <= lower + 1) b = SK::decode(next);
+    }
+    if constexpr (PERCENTILE) {
+      const C d = b - a;
+      r = (t >= (C)0.5) ? b - d * u : a + d * t;
+    } else {
+      r = (a + b) / (C)2;
+    }
+  }
+  __builtin_nontemporal_store(finite_<C>(r) ? r : fill, out + (long long)B.out[blockIdx.y] * pixels + p);
+}
+
 template <typename Tin>
 int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long pixels, const gm_frame_bin* bins,
                   int n_bins, void* out, uint64_t fill_bits, hipStream_t s, const gm_percentile_step* plan = nullptr,
@@ -444,15 +550,18 @@ int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long 
   Plan P;
   memset(&P, 0, sizeof(P));
   gm_percentile_step* plan_dev = nullptr;
+  // bins beyond what the 160 KiB of a CU sort: selection in global memory (median_select_kernel)
+  const bool select = long_bins && (longest_all > GM_MAX_MEDIAN_FRAMES_LONG || (size_t)longest_all * 64 * sizeof(C) > 160 * 1024);
   if (long_bins) {
-    if (longest_all > GM_MAX_MEDIAN_FRAMES_LONG || (size_t)longest_all * 64 * sizeof(C) > 160 * 1024)
-      return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_aggregate: median / percentile over %d frames (at most %d)", longest_all,
-                      (int)std::min<size_t>(GM_MAX_MEDIAN_FRAMES_LONG, 160 * 1024 / (64 * sizeof(C))));
     if (plan) {
       int rc = gm_malloc((void**)&plan_dev, sizeof(gm_percentile_step) * (size_t)n_plan);
       if (rc) return rc;
-      GM_HIP(hipMemcpyAsync(plan_dev, plan, sizeof(gm_percentile_step) * (size_t)n_plan, hipMemcpyHostToDevice, s));
-      GM_HIP(hipStreamSynchronize(s));  // (the caller's plan may go away after this call)
+      hipError_t e = hipMemcpyAsync(plan_dev, plan, sizeof(gm_percentile_step) * (size_t)n_plan, hipMemcpyHostToDevice, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);  // (the caller's plan may go away after this call)
+      if (e != hipSuccess) {
+        (void)gm_free(plan_dev);
+        return gm::hip_fail(e, "gm_temporal_percentile: plan upload");
+      }
     }
   } else {
     for (int i = 0; i < n_plan && i < GM_MAX_MEDIAN_FRAMES; ++i) {
@@ -481,6 +590,27 @@ int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long 
 #undef GM_MEDIAN_SMALL
     }
     return GM_OK;
+  }
+  if (select) {
+    const unsigned gxs = (unsigned)((pixels + 255) / 256);
+    for (int b0 = 0; b0 < n_bins; b0 += TB_MAX_BINS) {
+      Bins B;
+      const int nb = n_bins - b0 < TB_MAX_BINS ? n_bins - b0 : TB_MAX_BINS;
+      for (int i = 0; i < nb; ++i) {
+        B.first[i] = bins[b0 + i].first;
+        B.count[i] = bins[b0 + i].count;
+        B.out[i] = bins[b0 + i].out;
+      }
+      if (plan)
+        hipLaunchKernelGGL((median_select_kernel<Tin, true>), dim3(gxs, nb), dim3(256), 0, s, (const Tin*)frames, from_bits<Tin>(ndv_bits),
+                           has_ndv != 0, pixels, B, (const gm_percentile_step*)plan_dev, (C*)out, from_bits<C>(fill_bits));
+      else
+        hipLaunchKernelGGL((median_select_kernel<Tin, false>), dim3(gxs, nb), dim3(256), 0, s, (const Tin*)frames, from_bits<Tin>(ndv_bits),
+                           has_ndv != 0, pixels, B, (const gm_percentile_step*)nullptr, (C*)out, from_bits<C>(fill_bits));
+    }
+    hipError_t e = hipGetLastError();
+    if (plan_dev) (void)gm_free(plan_dev);
+    return e == hipSuccess ? GM_OK : gm::hip_fail(e, "gm_temporal_aggregate: median selection");
   }
   const int WG = long_bins ? 64 : 256;
   const unsigned gx = (unsigned)((pixels + WG - 1) / WG);
@@ -665,7 +795,7 @@ int gm_temporal_percentile(const void* frames, int dtype, int has_ndv, uint64_t 
                            void* out, uint64_t fill_bits) {
   if (!frames || !out || !plan || (!bins && n_bins)) return gm::fail(GM_ERR_INVALID, "null pointer");
   if (n_frames < 0 || pixels <= 0 || n_bins < 0 || n_out < 0) return gm::fail(GM_ERR_INVALID, "gm_temporal_percentile: bad shape");
-  if (n_plan < 1 || n_plan > GM_MAX_MEDIAN_FRAMES_LONG) return gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_percentile: plan of %d steps", n_plan);
+  if (n_plan < 1) return gm::fail(GM_ERR_INVALID, "gm_temporal_percentile: plan of %d steps", n_plan);
   if (!ascending_bins(bins, n_bins, n_frames, n_out)) return gm::fail(GM_ERR_INVALID, "gm_temporal_percentile: bin outside the stack");
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;

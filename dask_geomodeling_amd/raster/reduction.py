@@ -126,8 +126,9 @@ def _nan_function(stack, statistic, percentile, fill_value, dtype):
     storage = np.dtype("f4") if work.itemsize <= 4 else np.dtype("f8")
     nodes = _stack_nodes(stack)
     n, shape = len(stack), tuple(stack[0]["values"].shape)
-    if statistic in ("median", "percentile") and n > (MAX_SORTED_RASTERS if storage.itemsize == 4 else 320):
-        raise NotImplementedError("%s over %d rasters (at most %d)" % (statistic, n, MAX_SORTED_RASTERS))
+    long_sort = statistic in ("median", "percentile") and n > (MAX_SORTED_RASTERS if storage.itemsize == 4 else 320)
+    if long_sort and half:
+        raise NotImplementedError("%s over %d rasters in float16 (a 1-byte output dtype)" % (statistic, n))
     bands = shape[0]
     stacked = DeviceArray.empty((n * bands,) + shape[1:], storage)
     for i, node in enumerate(nodes):
@@ -139,6 +140,19 @@ def _nan_function(stack, statistic, percentile, fill_value, dtype):
         if tuple(tile_shape) != shape:
             raise ValueError("could not broadcast raster %d of shape %s into shape %s" % (i, tuple(tile_shape), shape))
         P.launch(compiled, [leaf.values for leaf in leaves], shape, out=stacked.band_slice(i * bands, (i + 1) * bands))
+    if long_sort:
+        # more rasters than a cell's values fit the LDS sort: the stack is n frames of bands * H * W cells, NaN for no
+        # data -- what the temporal kernels select the middle pair / the percentile's neighbours from in global memory
+        from .temporal import aggregate_frames
+        name = "median" if statistic == "median" else "p%r" % float(percentile)
+        frames = stacked.reshape((n, bands * shape[1], shape[2]))
+        # (a cell without data in any raster gets the fill value, like with every other statistic)
+        result = aggregate_frames(frames, None, [(0, n)], name, storage, fill=storage.type(fill_value)).reshape(shape)
+        if storage == dtype:
+            return result
+        like_x86 = dtype.kind in "iub" and dtype.itemsize <= 4 and dtype != np.dtype("u4")
+        return _through_program(P.Op("copy", [P.Leaf(None, storage, None, values=result)], dtype, None,
+                                     extra={"indefinite": True} if like_x86 else None))
     result = DeviceArray.empty(shape, storage)
     plan = percentile_plan(percentile, n, work) if statistic == "percentile" else None
     code = _PERCENTILE_CODE if statistic == "percentile" else STATISTICS[statistic]

@@ -274,9 +274,10 @@ def _fill_bits(statistic, dtype):
     return runtime.scalar_bits(0 if statistic in _EXTENSIVE else get_dtype_max(dtype), dtype)
 
 
-def aggregate_frames(values, no_data_value, runs, statistic, dtype):
+def aggregate_frames(values, no_data_value, runs, statistic, dtype, fill=None):
     """(frames, h, w) tile + [(first, count)] per label -> (labels, h, w) device tile of ``dtype``
-    (the loop of temporal.py:743-766 as one launch)."""
+    (the loop of temporal.py:743-766 as one launch).  ``fill``: what a label without a finite result gets
+    (default: the reference's, 0 for the additive statistics, else the dtype's maximum)."""
     from ..hip import runtime
     from ..hip.array import DeviceArray
     name, percentile = parse_statistic(statistic)
@@ -284,22 +285,21 @@ def aggregate_frames(values, no_data_value, runs, statistic, dtype):
         raise NotImplementedError("TemporalAggregate statistic %r" % statistic)
     src, code, has, bits, frames, height, width = _reduce_args(values, no_data_value)
     longest = max([count for _, count in runs] + [1])
-    if name in ("median", "percentile"):
-        # a cell's data frames are sorted in LDS: 64 float32 / 32 float64 values per lane
-        if longest > (MAX_MEDIAN_FRAMES if np.result_type(np.float32, dtype).itemsize == 4 else 320):
-            raise NotImplementedError("%s over %d frames per label" % (statistic, longest))
+    # (median / percentiles: a cell's data frames are sorted in LDS up to MAX_MEDIAN_FRAMES float32 / 320 float64
+    #  frames per label; longer bins -- a year of hourly frames -- are selected in global memory: no limit)
     L = _lib()
     if L.gm_temporal_out_dtype(code, STATISTIC_CODES["median" if percentile is not None else name]) != _code(dtype):
         raise NotImplementedError("%s of a %s raster as %s" % (statistic, src.dtype, np.dtype(dtype)))
     out = DeviceArray.empty((len(runs), height, width), np.dtype(dtype))
+    fill_bits = _fill_bits(statistic, dtype) if fill is None else runtime.scalar_bits(fill, np.dtype(dtype))
     if percentile is not None:
         plan = percentile_plan(percentile, longest, dtype)
         runtime.check(L.gm_temporal_percentile(src.ptr, code, has, bits, frames, height * width, _frame_bins(runs), len(runs),
-                                               len(runs), plan, longest, out.ptr, _fill_bits(statistic, dtype)),
+                                               len(runs), plan, longest, out.ptr, fill_bits),
                       "gm_temporal_percentile")
         return out
     runtime.check(L.gm_temporal_aggregate(src.ptr, code, has, bits, frames, height * width, _frame_bins(runs), len(runs),
-                                          len(runs), STATISTIC_CODES[statistic], out.ptr, _fill_bits(statistic, dtype)),
+                                          len(runs), STATISTIC_CODES[statistic], out.ptr, fill_bits),
                   "gm_temporal_aggregate")
     return out
 

@@ -442,7 +442,8 @@ enum gm_statistic {
   GM_STAT_MEAN = 4,  /* np.nanmean  */
   GM_STAT_VAR = 5,   /* np.nanvar   */
   GM_STAT_STD = 6,   /* np.nanstd   */
-  GM_STAT_MEDIAN = 7 /* np.nanmedian (gm_temporal_aggregate only; bins of at most GM_MAX_MEDIAN_FRAMES_LONG frames) */
+  GM_STAT_MEDIAN = 7 /* np.nanmedian (gm_temporal_aggregate only; bins of any length: sorted in LDS up to
+                        GM_MAX_MEDIAN_FRAMES_LONG frames, selected in global memory beyond) */
 };
 #define GM_MAX_MEDIAN_FRAMES 64       /* per bin, sorted by 256-lane workgroups */
 #define GM_MAX_MEDIAN_FRAMES_LONG 599 /* longer bins: 64-lane workgroups, as far as the 160 KiB of LDS reach
@@ -474,7 +475,7 @@ int gm_temporal_aggregate(const void* frames, int dtype, int has_ndv, uint64_t n
  * values v: a = v[lower], b = v[upper], d = b - a, result = gamma >= 0.5 ? b - d * one_minus_gamma
  * : a + d * gamma (numpy.lib._function_base_impl._lerp), all in result_type(float32, dtype).  The
  * host derives the plan with NumPy's own scalar arithmetic ((n - 1) * (q / 100) in that dtype), so
- * the rounding of the virtual index is NumPy's.  n_plan >= the longest bin, <= GM_MAX_MEDIAN_FRAMES_LONG. */
+ * the rounding of the virtual index is NumPy's.  n_plan >= the longest bin. */
 typedef struct gm_percentile_step {
   int32_t lower, upper;
   double gamma, one_minus_gamma;

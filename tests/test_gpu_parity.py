@@ -968,9 +968,11 @@ def test_temporal_median_and_percentiles_over_long_bins(gpu, dtype, frames):
         got = T.aggregate_frames(v, ndv, runs, stat, out_dtype).to_numpy() + 0.0
         want = O.temporal_aggregate_values(v, ndv, runs, stat, out_dtype) + 0.0
         assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (stat, dtype, frames)
-    too_many = 600 if np.dtype(out_dtype).itemsize == 4 else 321
-    with pytest.raises(NotImplementedError):
-        T.aggregate_frames(np.zeros((too_many, 2, 4), dtype), None, [(0, too_many)], "median", out_dtype)
+    # (one frame more than the LDS sort takes: selected in global memory since round 3 -- no limit any more;
+    #  test_median_and_percentiles_over_bins_longer_than_the_lds_sort compares those with the oracle)
+    one_more = 600 if np.dtype(out_dtype).itemsize == 4 else 321
+    zeros = T.aggregate_frames(np.zeros((one_more, 2, 4), dtype), None, [(0, one_more)], "median", out_dtype).to_numpy()
+    assert zeros.shape == (1, 2, 4) and not zeros.any()
 
 
 @pytest.mark.gpu
@@ -1574,3 +1576,53 @@ def test_round3_golden(gpu, case):
         return
     fn = {"dilate": raster.Dilate.process, "hillshade": raster.HillShade.process, "smooth": raster.Smooth.process}[op]
     assert_result_equal(fn(*case["args"]), case["expect"], 0, case["id"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f4", "f8", "i2", "u1"])
+def test_median_and_percentiles_over_bins_longer_than_the_lds_sort(gpu, dt):
+    """Medians / percentiles over bins of 599, 600, 601 and 1500 frames (temporal.py:724-768): up to 599 float32
+    frames a cell's values are sorted in LDS, beyond that they are selected in global memory (radix select of the middle
+    pair / the percentile's neighbours) -- 600 is also where np.nanmedian itself changes its route.  Against the oracle
+    (NumPy's own nan-functions), bit for bit up to the sign of a zero median."""
+    from dask_geomodeling_amd.raster import temporal
+    from fuzz_util import unsigned_zero
+    rng = np.random.default_rng(77)
+    frames, h, w = 3800, 6, 40
+    ndv = {"f4": np.float32(-9999.0), "f8": -9999.0, "i2": np.int16(-1), "u1": np.uint8(255)}[dt]
+    if np.dtype(dt).kind == "f":
+        v = (rng.standard_normal((frames, h, w)) * 50).astype(dt)
+        v[rng.random(v.shape) < 0.02] = np.nan
+        v[5:900, 0, 0] = 7.25   # long runs of equal values: the upper rank is the same value again
+        v[:, 0, 1] = ndv        # a cell without data
+    else:
+        v = rng.integers(0, 100, size=(frames, h, w)).astype(dt)
+    v[rng.random(v.shape) < 0.1] = ndv
+    runs = [(0, 599), (599, 600), (1199, 601), (1800, 1500), (3300, 1), (3301, 499)]
+    for stat in ("median", "p25", "p50", "p99.5", "p0", "p100"):
+        out_dt = temporal.dtype_for_statistic(dt, stat)
+        got = np.asarray(temporal.aggregate_frames(v, ndv, runs, stat, out_dt))
+        with np.errstate(all="ignore"):
+            want = O.temporal_aggregate_values(v, ndv, runs, stat, out_dt)
+        assert_values_equal(unsigned_zero({"values": got})["values"], unsigned_zero({"values": want})["values"], 0,
+                            "%s of %s frames" % (stat, dt))
+
+
+@pytest.mark.gpu
+def test_reduce_rasters_median_over_650_rasters(gpu):
+    """reduce_rasters median / percentile over more rasters than the LDS sort takes (reduction.py:92-117)."""
+    from dask_geomodeling_amd.raster.reduction import reduce_rasters
+    from fuzz_util import unsigned_zero
+    rng = np.random.default_rng(78)
+    ndv = np.float32(-1.0)
+    stack = []
+    for _ in range(650):
+        v = (rng.random((2, 5, 12)) * 80).astype("f4")
+        v[rng.random(v.shape) < 0.2] = ndv
+        v[0, 0, 0] = ndv
+        stack.append({"values": v, "no_data_value": ndv})
+    for stat, kwargs in (("median", {}), ("p90", {}), ("median", {"dtype": "i4", "no_data_value": 2147483647})):
+        out = reduce_rasters([dict(d) for d in stack], stat, **kwargs)
+        with np.errstate(all="ignore"):
+            want = O.reduce_rasters([dict(d) for d in stack], stat, **kwargs)
+        assert_result_equal(unsigned_zero(dict(out, values=np.asarray(out["values"]))), unsigned_zero(want), 0, stat)
