@@ -199,13 +199,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void zonal_sum_kernel(const typename Ordered<T>::Key* __restrict__ payload,
                                                         const unsigned* __restrict__ first, int n_labels, int statistic,
                                                         const unsigned char* __restrict__ only, float* __restrict__ out,
-                                                        long long* __restrict__ counts) {
+                                                        long long* __restrict__ counts, unsigned long_from = 0) {
   typedef typename Ordered<T>::Key Key;
   __shared__ __align__(16) double parked[4][ZS_STEP];
   const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (l >= n_labels || (only && !only[l])) return;  // (only: the labels this launch is about)
   const unsigned a = first[l], b = first[l + 1];
   if (b - a <= ZS_SHORT) return;  // (zonal_short_sum_kernel's)
+  if (long_from && b - a >= long_from) return;  // (the block pipeline's: zonal_compose_kernel)
   double* mine = parked[wave];
   double acc = 0.0;
   struct Four { Key k[ZS_PER_LANE]; };
@@ -327,6 +328,398 @@ __global__ __launch_bounds__(256) void zonal_sum_kernel(const typename Ordered<T
     const float nan = std::numeric_limits<float>::quiet_NaN();
     // ndimage.mean: sum / count in float64; the assignment into the float32 `agg` rounds once
     out[l] = n == 0 ? nan : (statistic == Z_MEAN ? (float)(acc / (double)n) : (float)acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Long labels (round 3): bincount's sequential float64 sum, block-parallel.
+//
+// One wave adding one label's cells in order -- the kernel above -- is bound by the chain of dependent additions
+// whenever a step cannot be certified exact (12.6 M cells of wide-range float32 data under ONE label: 41.6 ms).  What
+// makes the sum parallel after all: while the running sum stays inside one binade [2^E, 2^(E+1)) its unit in the last
+// place u = 2^(E-52) does not move, and adding a cell x is adding round(x / u) units -- the direction of the rounding
+// depends on the cell alone, EXCEPT for an exact tie (x mod u == u / 2), which rounds to even, i.e. depends on the
+// parity of the sum before it ... and leaves an even sum behind, whatever came before.  So a block of cells acts on
+// the sum s (in units of u) as s -> s + D[s mod 2] with two precomputable integers D[0], D[1], valid while every
+// prefix stays inside the binade, which two more numbers per parity (the lowest and the highest prefix) decide.
+//   1. zonal_block_sum_kernel: a plain tree sum per block of 256 sorted cells (blocks aligned to the sorted array);
+//   2. zonal_block_prefix_kernel: per long label the running total BEFORE each of its blocks -- approximate (tree
+//      order), only used to PREDICT the binade the exact sum will be in there;
+//   3. zonal_block_info_kernel: per block, for the predicted binade, D / lowest / highest prefix for both parities (the
+//      256 cells in order: a lane composes its 4 cells, the wave scans the 64 parity -> (sum, parity) functions);
+//   4. zonal_compose_kernel: a wave per label walks its blocks: when the exact running sum is in the predicted binade and
+//      the block's prefixes stay inside it, the block is ONE integer addition; otherwise -- the sum crosses a power of
+//      two inside the block, the sum is still small against the cells, a cell is not finite, the prediction was off
+//      -- the block's 256 cells are added literally, like above.  Correctness never rests on the prediction.
+// The restatement was checked against literal float64 accumulation on 7 000 random and edge-case blocks before it
+// was written down here (sums next to powers of two, exact half-unit cells, both signs).
+constexpr unsigned ZB = 256;            // cells per block
+// labels of at least this many cells take the pipeline (1024 labels of 11 k cells of zero-mean data: 0.52 ms on the
+// wave-per-label kernel, 0.61 through the pipeline -- their sums stay small against the cells, most blocks are replayed);
+// GM_ZONAL_LONG overrides it (the tests run small labels through the pipeline too)
+constexpr unsigned ZL_LONG = 65536;
+struct BlockInfo {
+  long long D[2], lo[2], hi[2];  // per parity of the incoming sum: total, lowest and highest prefix, in units of u
+  int E;                         // the binade the block was analysed for; INT_MIN: not analysed (replay it)
+  int negative;                  // the sum it was analysed for is negative (the block is mirrored)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void zonal_block_sum_kernel(const typename Ordered<T>::Key* __restrict__ payload,
+                                                              const unsigned* __restrict__ keys, unsigned cells, int n_labels,
+                                                              double* __restrict__ blk_sum, int* __restrict__ blk_label) {
+  const unsigned j = (unsigned)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if ((size_t)j * ZB >= cells) return;
+  const unsigned base = j * ZB, last = cells - 1;
+  double partial = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned at = base + 4 * lane + k;
+    partial += at <= last ? (double)Ordered<T>::decode(payload[at]) : 0.0;
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) partial += shuffle_xor(partial, off);
+  if (lane == 0) {
+    blk_sum[j] = partial;
+    const unsigned ka = keys[base], kb = keys[min(base + ZB - 1, last)];
+    blk_label[j] = (base + ZB <= cells && ka == kb && ka < (unsigned)n_labels) ? (int)ka : -1;
+  }
+}
+
+// wave-wide exclusive prefix sum of one double per lane (Hillis-Steele over shuffles); total in *total
+__device__ __forceinline__ double shuffle_up_f64(double x, int delta) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = __shfl_up((unsigned)u, delta), hi = __shfl_up((unsigned)(u >> 32), delta);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__device__ __forceinline__ double broadcast_f64(double x, int lane) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = __shfl((unsigned)u, lane), hi = __shfl((unsigned)(u >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void zonal_block_prefix_kernel(const typename Ordered<T>::Key* __restrict__ payload,
+                                                                 const unsigned* __restrict__ first, int n_labels,
+                                                                 const double* __restrict__ blk_sum, double* __restrict__ blk_pred,
+                                                                 unsigned long_from) {
+  const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (l >= n_labels) return;
+  const unsigned a = first[l], b = first[l + 1];
+  if (b - a < long_from) return;
+  const unsigned j0 = (a + ZB - 1) / ZB, j1 = b / ZB;  // the label's whole blocks [j0, j1)
+  double running = 0.0;
+  {  // the cells before the first whole block
+    double partial = 0.0;
+    for (unsigned at = a + lane; at < j0 * ZB; at += 64) partial += (double)Ordered<T>::decode(payload[at]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) partial += shuffle_xor(partial, off);
+    running = partial;
+  }
+  for (unsigned j = j0; j < j1; j += 64) {
+    const double mine = j + lane < j1 ? blk_sum[j + lane] : 0.0;
+    double scan = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double up = shuffle_up_f64(scan, off);
+      if ((int)lane >= off) scan += up;
+    }
+    if (j + lane < j1) blk_pred[j + lane] = running + (scan - mine);
+    running += broadcast_f64(scan, 63);
+  }
+}
+
+// what a run of cells does to (sum in units of u, parity): for either parity coming in
+struct ParityFn {
+  double S[2];
+  int q[2];
+};
+__device__ __forceinline__ ParityFn compose(const ParityFn& first_fn, const ParityFn& then) {
+  ParityFn r;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int mid = first_fn.q[p];
+    r.S[p] = first_fn.S[p] + (mid ? then.S[1] : then.S[0]);
+    r.q[p] = mid ? then.q[1] : then.q[0];
+  }
+  return r;
+}
+__device__ __forceinline__ ParityFn shuffle_up_fn(const ParityFn& f, int delta) {
+  ParityFn r;
+  r.S[0] = shuffle_up_f64(f.S[0], delta);
+  r.S[1] = shuffle_up_f64(f.S[1], delta);
+  const int packed = __shfl_up(f.q[0] | (f.q[1] << 1), delta);
+  r.q[0] = packed & 1;
+  r.q[1] = (packed >> 1) & 1;
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void zonal_block_info_kernel(const typename Ordered<T>::Key* __restrict__ payload,
+                                                               const unsigned* __restrict__ first, unsigned cells,
+                                                               const int* __restrict__ blk_label, const double* __restrict__ blk_pred,
+                                                               BlockInfo* __restrict__ info, unsigned long_from) {
+  const unsigned j = (unsigned)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if ((size_t)j * ZB >= cells) return;
+  const int l = blk_label[j];
+  if (l < 0) return;
+  if (first[l + 1] - first[l] < long_from) return;
+  const double pred = blk_pred[j];
+  int E = INT_MIN;
+  if (pred != 0.0 && fabs(pred) <= 1.7976931348623157e308) {
+    const int e = ilogb(fabs(pred));
+    if (e > -900 && e < 900) E = e;
+  }
+  const bool negative = pred < 0.0;
+  const double scale = E == INT_MIN ? 1.0 : ldexp(negative ? -1.0 : 1.0, 52 - E);  // cell -> signed units of u
+  // the lane's 4 cells, in order, for either parity coming in
+  ParityFn mine;
+  double lo[2], hi[2];
+  bool finite = true;
+  {
+    double k[4], frac[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double x = (double)Ordered<T>::decode(payload[j * ZB + 4 * lane + c]);
+      finite = finite && fabs(x) <= 1.7976931348623157e308;
+      const double t = x * scale;  // exact: a power of two (|E| < 900 keeps it far from overflow and underflow)
+      k[c] = floor(t);
+      frac[c] = t - k[c];          // exact, in [0, 1)
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      int parity = p;
+      double sum = 0.0, low = 1.0e300, high = -1.0e300;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k_odd = (int)(k[c] - 2.0 * floor(k[c] * 0.5));
+        // the rounding: up for more than half a unit, to even on exactly half (which leaves an even sum)
+        const int up = frac[c] == 0.5 ? (parity ^ k_odd) : (frac[c] > 0.5 ? 1 : 0);
+        sum += k[c] + (double)up;
+        parity ^= k_odd ^ up;
+        low = fmin(low, sum);
+        high = fmax(high, sum);
+      }
+      mine.S[p] = sum;
+      mine.q[p] = parity;
+      lo[p] = low;
+      hi[p] = high;
+    }
+  }
+  // inclusive scan of the lanes' functions, in lane order
+  ParityFn scan = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const ParityFn before = shuffle_up_fn(scan, off);
+    if ((int)lane >= off) scan = compose(before, scan);
+  }
+  ParityFn excl = shuffle_up_fn(scan, 1);
+  if (lane == 0) {
+    excl.S[0] = excl.S[1] = 0.0;
+    excl.q[0] = 0;
+    excl.q[1] = 1;
+  }
+  double lowest[2], highest[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    lowest[p] = excl.S[p] + (excl.q[p] ? lo[1] : lo[0]);
+    highest[p] = excl.S[p] + (excl.q[p] ? hi[1] : hi[0]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      lowest[p] = fmin(lowest[p], shuffle_xor(lowest[p], off));
+      highest[p] = fmax(highest[p], shuffle_xor(highest[p], off));
+    }
+  }
+  const bool all_finite = __all(finite);
+  if (lane == 63) {
+    BlockInfo out;
+    // (offsets that could take a sum out of its binade anyway -- beyond 2^60 units -- are not worth an integer)
+    bool small = true;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) small = small && fabs(scan.S[p]) < 0x1p60 && fabs(lowest[p]) < 0x1p60 && fabs(highest[p]) < 0x1p60;
+    out.E = (all_finite && small) ? E : INT_MIN;
+    out.negative = negative ? 1 : 0;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      out.D[p] = small ? (long long)scan.S[p] : 0;
+      out.lo[p] = small ? (long long)lowest[p] : 0;
+      out.hi[p] = small ? (long long)highest[p] : 0;
+    }
+    info[j] = out;
+  }
+}
+
+// the same composition over whole blocks, in integer units
+struct UnitsFn {
+  long long S[2];
+  int q[2];
+};
+__device__ __forceinline__ UnitsFn compose_units(const UnitsFn& first_fn, const UnitsFn& then) {
+  UnitsFn r;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int mid = first_fn.q[p];
+    r.S[p] = first_fn.S[p] + (mid ? then.S[1] : then.S[0]);
+    r.q[p] = mid ? then.q[1] : then.q[0];
+  }
+  return r;
+}
+__device__ __forceinline__ long long shuffle_up_i64(long long x, int delta) {
+  const unsigned lo = __shfl_up((unsigned)x, delta), hi = __shfl_up((unsigned)((unsigned long long)x >> 32), delta);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ UnitsFn shuffle_up_units(const UnitsFn& f, int delta) {
+  UnitsFn r;
+  r.S[0] = shuffle_up_i64(f.S[0], delta);
+  r.S[1] = shuffle_up_i64(f.S[1], delta);
+  const int packed = __shfl_up(f.q[0] | (f.q[1] << 1), delta);
+  r.q[0] = packed & 1;
+  r.q[1] = (packed >> 1) & 1;
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Ordered<T>::Key* __restrict__ payload,
+                                                            const unsigned* __restrict__ first, int n_labels, int statistic,
+                                                            const int* __restrict__ blk_label, const BlockInfo* __restrict__ info,
+                                                            float* __restrict__ out, long long* __restrict__ counts,
+                                                            unsigned* __restrict__ replayed, unsigned long_from) {
+  __shared__ __align__(16) double parked[4][ZB];
+  const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (l >= n_labels) return;
+  const unsigned a = first[l], b = first[l + 1];
+  if (b - a < long_from) return;
+  double* mine = parked[wave];
+  double acc = 0.0;
+  // cells [from, to), at most ZB of them, added one after the other (the chain of zonal_sum_kernel's replay)
+  auto literally = [&](unsigned from, unsigned to) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned at = from + 4 * lane + k;
+      mine[4 * lane + k] = at < to ? (double)Ordered<T>::decode(payload[at]) : 0.0;  // (+0.0 changes nothing)
+    }
+    // 16 values (8 sixteen-byte reads) per round, the next round's reads issued before this round's 16 additions: the
+    // chain never waits for LDS (rounds past the stretch add the +0.0 padding)
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    constexpr int ROUND = 16;
+    const int rounds = (int)((to - from + ROUND - 1) / ROUND);
+    f64x2 buffer[2][ROUND / 2];
+#pragma unroll
+    for (int k = 0; k < ROUND / 2; ++k) buffer[0][k] = *reinterpret_cast<const f64x2*>(mine + 2 * k);
+    for (int round = 0; round < rounds; round += 2) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int next = min(round + half + 1, (int)(ZB / ROUND) - 1);
+#pragma unroll
+        for (int k = 0; k < ROUND / 2; ++k) buffer[(half + 1) & 1][k] = *reinterpret_cast<const f64x2*>(mine + ROUND * next + 2 * k);
+        __builtin_amdgcn_sched_barrier(0);
+        if (round + half < rounds) {
+#pragma unroll
+          for (int k = 0; k < ROUND / 2; ++k) {
+            acc += buffer[half & 1][k].x;
+            acc += buffer[half & 1][k].y;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  const unsigned j0 = (a + ZB - 1) / ZB, j1 = b / ZB;
+  unsigned n_replayed = 0;
+  if (j0 * ZB > a) literally(a, min(j0 * ZB, b));
+  // Between literal stretches the sum lives as (binade E, sign, integer s = |sum| / u in [2^52, 2^53)): a block that is
+  // valid for it is a handful of scalar integer operations.  The blocks' descriptions are fetched 64 at a time (a lane
+  // each) and handed round with readlane: a load per block would cost the wave one memory round trip per block
+  // (measured: 500 ns of the 520 per block).
+  bool as_integer = false;
+  long long units = 0;
+  int E = 0, negative = 0;
+  auto to_integer = [&]() {
+    as_integer = false;
+    if (acc != 0.0 && fabs(acc) <= 1.7976931348623157e308) {
+      const int e = ilogb(fabs(acc));
+      if (e > -900 && e < 900) {
+        E = __builtin_amdgcn_readfirstlane(e);
+        negative = __builtin_amdgcn_readfirstlane(acc < 0.0 ? 1 : 0);
+        const long long v = (long long)ldexp(fabs(acc), 52 - e);  // exact: an integer in [2^52, 2^53)
+        units = ((long long)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+        as_integer = true;
+      }
+    }
+  };
+  auto to_double = [&]() {
+    if (as_integer) {
+      const double magnitude = ldexp((double)units, E - 52);  // exact
+      acc = negative ? -magnitude : magnitude;
+    }
+  };
+  auto pass = [&](long long mine64, int i) -> long long {  // lane i's value for everybody
+    return ((long long)__builtin_amdgcn_readlane((int)(mine64 >> 32), i) << 32) | (unsigned)__builtin_amdgcn_readlane((int)mine64, i);
+  };
+  to_integer();
+  for (unsigned g = j0; g < j1; g += 64) {
+    const unsigned here = min(64u, j1 - g);
+    BlockInfo B;
+    {
+      const unsigned jj = min(g + (unsigned)lane, j1 - 1);
+      B = info[jj];
+      if (blk_label[jj] != l) B.E = INT_MIN;
+    }
+    // The 64 blocks of a group are taken together: every block is a function parity -> (units added, parity left), the
+    // wave composes them in lane order (six shuffle steps), every lane then knows the sum ENTERING its block and tests its
+    // block's validity for it; up to the first block that fails all are one addition, that block is added literally, and
+    // the rest of the group is composed again from the sum it leaves.
+    unsigned start = 0;
+    while (start < here) {
+      const bool mine_in = (unsigned)lane >= start && (unsigned)lane < here;
+      UnitsFn scan;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        scan.S[p] = mine_in ? B.D[p] : 0;
+        scan.q[p] = mine_in ? (int)((p + B.D[p]) & 1) : p;
+      }
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const UnitsFn before = shuffle_up_units(scan, off);
+        if (lane >= off) scan = compose_units(before, scan);
+      }
+      UnitsFn excl = shuffle_up_units(scan, 1);
+      if (lane == 0) {
+        excl.S[0] = excl.S[1] = 0;
+        excl.q[0] = 0;
+        excl.q[1] = 1;
+      }
+      const int p0 = (int)(units & 1);
+      const long long entering = units + (p0 ? excl.S[1] : excl.S[0]);
+      const int parity = p0 ? excl.q[1] : excl.q[0];
+      const long long lowest = entering + (parity ? B.lo[1] : B.lo[0]), highest = entering + (parity ? B.hi[1] : B.hi[0]);
+      // every prefix strictly inside the binade (one unit of margin below: the exact value before a rounding may lie
+      // half a unit under the rounded one)
+      const bool valid = as_integer && B.E == E && B.negative == negative && lowest >= 4503599627370497ll && highest <= 9007199254740991ll;
+      const unsigned long long bad = __ballot(mine_in && !valid);
+      if (bad == 0) {
+        const long long total = p0 ? scan.S[1] : scan.S[0];
+        units += pass(total, 63);
+        start = here;
+      } else {
+        const int k = __ffsll((long long)bad) - 1;
+        units = pass(entering, k);
+        to_double();
+        literally((g + (unsigned)k) * ZB, (g + (unsigned)k) * ZB + ZB);
+        to_integer();
+        ++n_replayed;
+        start = (unsigned)k + 1;
+      }
+    }
+  }
+  to_double();
+  if (j1 >= j0 && j1 * ZB < b) literally(max(j1 * ZB, a), b);
+  if (lane == 0) {
+    const unsigned n = b - a;
+    counts[l] = n;
+    out[l] = statistic == Z_MEAN ? (float)(acc / (double)n) : (float)acc;
+    if (replayed) atomicAdd(replayed, n_replayed);
   }
 }
 
@@ -863,6 +1256,9 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     if ((rc = scratch.take((void**)&cursor, sizeof(unsigned)))) return rc;
   }
   unsigned *keys_a = nullptr, *keys_b = nullptr, *first = nullptr;
+  double *blk_sum = nullptr, *blk_pred = nullptr;  // (the block pipeline of the long labels)
+  int* blk_label = nullptr;
+  BlockInfo* blk_info = nullptr;
   Key *pay_a = nullptr, *pay_b = nullptr;
   void* temp = nullptr;
   size_t temp_bytes = 0;
@@ -963,10 +1359,46 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     }
     hipLaunchKernelGGL(zonal_bounds_kernel, dim3((n_labels + 1 + 255) / 256), dim3(256), 0, s, sorted_keys, (unsigned)cells, n_labels, first);
     if (statistic == Z_SUM || statistic == Z_MEAN) {
+      // labels of ZL_LONG cells and more: block-parallel (zonal_compose_kernel and its three helpers); GM_ZONAL_BLOCKS=0
+      // keeps every label on the wave-per-label kernel (A/B runs, and the tests compare the two)
+      static const bool block_pipeline = !(getenv("GM_ZONAL_BLOCKS") && atoi(getenv("GM_ZONAL_BLOCKS")) == 0);
+      static const unsigned long_from = getenv("GM_ZONAL_LONG") ? (unsigned)std::max(2 * (int)ZB, atoi(getenv("GM_ZONAL_LONG"))) : ZL_LONG;
+      const bool long_labels = block_pipeline && (uint64_t)cells >= long_from;
+      if (long_labels) {
+        const size_t n_blocks = ((size_t)cells + ZB - 1) / ZB;
+        if (!blk_sum) {
+          if ((rc = scratch.take((void**)&blk_sum, sizeof(double) * n_blocks))) return rc;
+          if ((rc = scratch.take((void**)&blk_pred, sizeof(double) * n_blocks))) return rc;
+          if ((rc = scratch.take((void**)&blk_label, sizeof(int) * n_blocks))) return rc;
+          if ((rc = scratch.take((void**)&blk_info, sizeof(BlockInfo) * n_blocks))) return rc;
+        }
+        const unsigned block_grid = (unsigned)((n_blocks * 64 + 255) / 256), label_grid = (unsigned)(((size_t)n_labels * 64 + 255) / 256);
+        hipLaunchKernelGGL(zonal_block_sum_kernel<T>, dim3(block_grid), dim3(256), 0, s, sorted_pay, sorted_keys, (unsigned)cells, n_labels,
+                           blk_sum, blk_label);
+        hipLaunchKernelGGL(zonal_block_prefix_kernel<T>, dim3(label_grid), dim3(256), 0, s, sorted_pay, first, n_labels, blk_sum, blk_pred,
+                           long_from);
+        hipLaunchKernelGGL(zonal_block_info_kernel<T>, dim3(block_grid), dim3(256), 0, s, sorted_pay, first, (unsigned)cells, blk_label,
+                           blk_pred, blk_info, long_from);
+        static const bool verbose = getenv("GM_ZONAL_VERBOSE") != nullptr;
+        unsigned* replayed = nullptr;
+        if (verbose) {
+          if ((rc = gm_malloc((void**)&replayed, 8 * sizeof(unsigned)))) return rc;
+          GM_HIP(hipMemsetAsync(replayed, 0, 8 * sizeof(unsigned), s));
+        }
+        hipLaunchKernelGGL(zonal_compose_kernel<T>, dim3(label_grid), dim3(256), 0, s, sorted_pay, first, n_labels, statistic, blk_label,
+                           blk_info, out_f, counts_f, replayed, long_from);
+        if (verbose) {
+          unsigned host[8] = {0};
+          GM_HIP(hipMemcpyAsync(host, replayed, sizeof(host), hipMemcpyDeviceToHost, s));
+          GM_HIP(hipStreamSynchronize(s));
+          fprintf(stderr, "[gmhip] zonal block pipeline: %zu blocks, %u of them added literally\n", n_blocks, host[0]);
+          (void)gm_free(replayed);
+        }
+      }
       hipLaunchKernelGGL(zonal_short_sum_kernel<T>, dim3((n_labels + 255) / 256), dim3(256), 0, s, sorted_pay, first, n_labels,
                          statistic, (const unsigned char*)nullptr, out_f, counts_f);
       hipLaunchKernelGGL(zonal_sum_kernel<T>, dim3((unsigned)(((size_t)n_labels * 64 + 255) / 256)), dim3(256), 0, s, sorted_pay, first,
-                         n_labels, statistic, (const unsigned char*)nullptr, out_f, counts_f);
+                         n_labels, statistic, (const unsigned char*)nullptr, out_f, counts_f, long_labels ? long_from : 0u);
     }
     else
       hipLaunchKernelGGL(zonal_pick_kernel<T>, dim3((n_labels + 255) / 256), dim3(256), 0, s, sorted_pay, first, n_labels, statistic,

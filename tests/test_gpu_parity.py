@@ -1626,3 +1626,20 @@ def test_reduce_rasters_median_over_650_rasters(gpu):
         with np.errstate(all="ignore"):
             want = O.reduce_rasters([dict(d) for d in stack], stat, **kwargs)
         assert_result_equal(unsigned_zero(dict(out, values=np.asarray(out["values"]))), unsigned_zero(want), 0, stat)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks", ["1", "0"], ids=["block-pipeline", "wave-per-label"])
+def test_zonal_block_pipeline(gpu, blocks):
+    """Sums of long labels, block-parallel (csrc/gm_zonal.hip: every 256-cell block as "sum += D[sum mod 2]" while the
+    running sum stays inside its binade, literal addition otherwise) against the oracle's np.bincount order: 240 label
+    sums on adversarial rasters (tests/zonal_blocks_driver.py) with the threshold lowered so that labels of 512 cells
+    already take the pipeline -- and the same cases with the pipeline switched off."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GM_ZONAL_LONG="512", GM_ZONAL_BLOCKS=blocks, GM_ZONAL_SORTED="1")
+    driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_blocks_driver.py")
+    res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
+    assert "BLOCKS ok 240" in res.stdout
