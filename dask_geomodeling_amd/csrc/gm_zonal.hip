@@ -976,8 +976,8 @@ struct ExactRange {
   int hi, lo;       // top exponent / exponent of the lowest set bit over the non-zero cells
   unsigned bad;     // a NaN or an infinity among the cells
 };
-struct ExactVerdict {  // over all labels: how many are not exact, and how many active cells they hold
-  unsigned labels, pad;
+struct ExactVerdict {  // over all labels: how many are not exact, how many active cells they hold; the longest label's cells
+  unsigned labels, longest;
   unsigned long long cells;
 };
 template <typename T, int PHASE>
@@ -985,8 +985,15 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
                                                           size_t cells_per_wave, int n_labels, int has_ndv, T ndv,
                                                           const float* __restrict__ thresholds, ExactRange* __restrict__ range,
                                                           double* __restrict__ sums, unsigned char* __restrict__ present,
-                                                          unsigned* __restrict__ keys, typename Ordered<T>::Key* __restrict__ payload) {
-  // (PHASE 0 also writes the sort keys of zonal_keys_kernel: if the order turns out to matter the sort can start at once)
+                                                          unsigned* __restrict__ keys, typename Ordered<T>::Key* __restrict__ payload,
+                                                          unsigned* __restrict__ tile_counts) {
+  // (PHASE 0 also writes the sort keys of zonal_keys_kernel: if the order turns out to matter the sort can start at once --
+  // and, with tile_counts, what the label partition's counting pass would find: the cells of every key per tile of TILE
+  // cells, one atomic per run and tile)
+  constexpr size_t TILE = 16384;  // (= ZP_TILE, declared further down)
+  const int bins = n_labels + 1;
+  size_t run_tile = 0;
+  unsigned idle = 0;  // cells of the tile that carry the key n_labels (wave-uniform)
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const size_t begin = wave * cells_per_wave, end = min(begin + cells_per_wave, cells);
@@ -1012,6 +1019,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
         atomicMax(&slot->hi, hi);
         atomicMin(&slot->lo, lo);
         if (bad) atomicOr(&slot->bad, 1u);
+        if (tile_counts) atomicAdd(&tile_counts[run_tile * bins + run_label], n);
       }
     } else {
       double total = run_sum;
@@ -1040,6 +1048,18 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
       }
     }
     const unsigned long long mask = __ballot(active);
+    if constexpr (PHASE == 0) {
+      if (tile_counts) {
+        const size_t tile = (i - lane) / TILE;  // (a step never straddles two tiles: stretches start on multiples of 64)
+        if (tile != run_tile) {
+          flush();
+          if (lane == 0 && idle) atomicAdd(&tile_counts[run_tile * bins + n_labels], idle);
+          idle = 0;
+          run_tile = tile;
+        }
+        idle += (unsigned)__popcll(__ballot(inside && !active));
+      }
+    }
     if (mask == 0) return;  // (wave-uniform)
     const int leader_label = __builtin_amdgcn_readlane(label, __ffsll((long long)mask) - 1);  // (a uniform lane index)
     const double x = (double)v;  // what bincount adds
@@ -1084,6 +1104,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
             atomicMin(&slot->lo, low);
           }
           if (bad) atomicOr(&slot->bad, 1u);
+          if (tile_counts) atomicAdd(&tile_counts[run_tile * bins + label], n);
         }
       } else {
         const double total = run_total(active ? x : 0.0, runs, [](double a, double b) { return a + b; });  // (exact: see above)
@@ -1092,6 +1113,9 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
     }
   });
   flush();
+  if constexpr (PHASE == 0) {
+    if (tile_counts && lane == 0 && idle) atomicAdd(&tile_counts[run_tile * bins + n_labels], idle);
+  }
 }
 
 __global__ __launch_bounds__(256) void zonal_exact_init_kernel(ExactRange* __restrict__ range, double* __restrict__ sums, int n_labels,
@@ -1119,6 +1143,7 @@ __global__ __launch_bounds__(256) void zonal_exact_decide_kernel(const ExactRang
     exact = top - r.lo <= 53 && top < 1023;
   }
   inexact[l] = exact ? 0 : 1;
+  if (r.count) atomicMax(&verdict->longest, (unsigned)min(r.count, 0xffffffffull));
   if (!exact) {
     atomicAdd(&verdict->labels, 1u);
     atomicAdd(&verdict->cells, r.count);
@@ -1164,6 +1189,186 @@ __global__ __launch_bounds__(256) void zonal_list_bounds_kernel(const unsigned l
   first[l] = lo;
 }
 
+// ---------------------------------------------------------------------------------
+// the label sort as a stable partition (up to ZP_BINS - 1 labels)
+// ---------------------------------------------------------------------------------
+// np.lexsort / bincount's order needs the cells of every label in raster order: a STABLE sort by label.  rocPRIM's radix
+// sort takes two 8-bit passes for the 11 bits of 1024 labels, each moving key and payload (2 x 103 us on the 12.6 M
+// cells of the default raster limit, + 30 us of histograms).  With a few thousand labels at most the sort is one
+// counting pass instead:
+//   count    a workgroup per tile of ZP_TILE consecutive cells: the tile's histogram (LDS) -> counts[tile][bin] (where the
+//            keys come from zonal_exact_kernel, that kernel has gathered the counts on its way: one atomic per run);
+//   scan     a wave per bin: the exclusive prefix over the tiles -> offsets[tile][bin], totals[bin];
+//   first    one workgroup: the exclusive prefix of the totals = first[] (what zonal_bounds_kernel searches for);
+//   scatter  a workgroup per tile: every wave owns ZP_WAVE consecutive cells of it, histograms them into its own LDS row,
+//            the rows become the waves' write cursors (first[bin] + offsets[tile][bin] + the rows of the waves before),
+//            and the wave walks its cells again in order, 64 at a time: rank among the lanes holding the same label
+//            (match_label: one ballot per label bit; label rasters are runs, and a step whose 64 cells share one label
+//            takes a short cut), cursor read, cells stored at cursor + rank, cursor advanced by the last such lane.
+// Every cell is read twice (the second time from the L2) and written once.
+constexpr int ZP_TILE = 16384, ZP_BINS = 2048, ZP_GROUP = 8;  // (a wave of an NW-wave workgroup owns ZP_TILE / NW cells)
+
+// among the lanes with valid set: how many hold this lane's label, and how many of those sit below it
+__device__ __forceinline__ void match_label(unsigned label, bool valid, int bits, unsigned* rank, unsigned* count) {
+  unsigned long long mask = __ballot(valid);
+  for (int b = 0; b < bits; ++b) {
+    const bool one = (label >> b) & 1u;
+    const unsigned long long ones = __ballot(one);
+    mask &= one ? ones : ~ones;
+  }
+  *rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+  *count = (unsigned)__popcll(mask);
+}
+
+// histogram of the WAVE_CELLS cells from `begin` on into `hist` (LDS): a step whose 64 cells share one label is one
+// addition, any other step 64 LDS atomics (the order of the additions is immaterial here)
+template <int WAVE_CELLS>
+__device__ __forceinline__ void partition_histogram(const unsigned* __restrict__ keys, unsigned begin, unsigned cells, unsigned* hist,
+                                                    int lane) {
+  constexpr int STEPS = WAVE_CELLS / 64, GROUP = STEPS < 8 ? STEPS : 8;
+  for (int step0 = 0; step0 < STEPS; step0 += GROUP) {
+    unsigned label[GROUP];
+#pragma unroll
+    for (int k = 0; k < GROUP; ++k) {
+      const unsigned i = begin + (unsigned)(step0 + k) * 64u + (unsigned)lane;
+      label[k] = keys[min(i, cells - 1)];  // (unconditional: a branch around a load makes the compiler wait for it)
+      if (i >= cells) label[k] = ~0u;
+    }
+#pragma unroll
+    for (int k = 0; k < GROUP; ++k) {
+      const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)label[k]);
+      if (__all(label[k] == f)) {  // one label (or nothing: past the end) in all 64 cells
+        if (lane == 0 && f != ~0u) atomicAdd(&hist[f], 64u);
+      } else if (label[k] != ~0u) {
+        atomicAdd(&hist[label[k]], 1u);
+      }
+    }
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void zonal_part_count_kernel(const unsigned* __restrict__ keys, unsigned cells, int bins,
+                                                                   unsigned* __restrict__ counts) {
+  __shared__ unsigned hist[ZP_BINS];
+  for (int b = threadIdx.x; b < bins; b += 64 * NW) hist[b] = 0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  partition_histogram<ZP_TILE / NW>(keys, blockIdx.x * (unsigned)ZP_TILE + (unsigned)wave * (ZP_TILE / NW), cells, hist, lane);
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += 64 * NW) counts[(size_t)blockIdx.x * bins + b] = hist[b];
+}
+
+__global__ __launch_bounds__(256) void zonal_part_scan_kernel(const unsigned* __restrict__ counts, unsigned tiles, int bins,
+                                                              unsigned* __restrict__ offsets, unsigned* __restrict__ totals) {
+  const int bin = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (bin >= bins) return;
+  unsigned carry = 0;
+  for (unsigned t0 = 0; t0 < tiles; t0 += 64) {
+    const unsigned t = t0 + (unsigned)lane;
+    const unsigned c = t < tiles ? counts[(size_t)t * bins + bin] : 0u;
+    unsigned inclusive = c;
+#pragma unroll
+    for (int offset = 1; offset < 64; offset <<= 1) {
+      const unsigned below = __shfl_up(inclusive, offset);
+      if (lane >= offset) inclusive += below;
+    }
+    if (t < tiles) offsets[(size_t)t * bins + bin] = carry + inclusive - c;
+    carry += __shfl(inclusive, 63);
+  }
+  if (lane == 0) totals[bin] = carry;
+}
+
+__global__ __launch_bounds__(256) void zonal_part_first_kernel(const unsigned* __restrict__ totals, int bins, unsigned* __restrict__ first) {
+  __shared__ unsigned partial[256];
+  const int per = (bins + 255) / 256;
+  unsigned local = 0;
+  for (int k = 0; k < per; ++k) {
+    const int b = threadIdx.x * per + k;
+    if (b < bins) local += totals[b];
+  }
+  partial[threadIdx.x] = local;
+  __syncthreads();
+  for (int offset = 1; offset < 256; offset <<= 1) {
+    const unsigned below = (int)threadIdx.x >= offset ? partial[threadIdx.x - offset] : 0u;
+    __syncthreads();
+    partial[threadIdx.x] += below;
+    __syncthreads();
+  }
+  unsigned run = partial[threadIdx.x] - local;
+  for (int k = 0; k < per; ++k) {
+    const int b = threadIdx.x * per + k;
+    if (b < bins) {
+      first[b] = run;
+      run += totals[b];
+    }
+  }
+}
+
+template <typename K, int NW>
+__global__ __launch_bounds__(64 * NW) void zonal_part_scatter_kernel(const unsigned* __restrict__ keys, const K* __restrict__ payload,
+                                                                     unsigned cells, int bins, int bits,
+                                                                     const unsigned* __restrict__ offsets,
+                                                                     const unsigned* __restrict__ first, unsigned* __restrict__ out_keys,
+                                                                     K* __restrict__ out_payload) {
+  constexpr int WAVE_CELLS = ZP_TILE / NW, STEPS = WAVE_CELLS / 64, GROUP = STEPS < ZP_GROUP ? STEPS : ZP_GROUP;
+  extern __shared__ unsigned cursor[];  // [NW][bins]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < NW * bins; i += 64 * NW) cursor[i] = 0;
+  __syncthreads();
+  unsigned* const mine = cursor + wave * bins;  // (a wave's LDS operations complete in order: no barrier around its own row)
+  const unsigned begin = blockIdx.x * (unsigned)ZP_TILE + (unsigned)wave * WAVE_CELLS;
+  partition_histogram<WAVE_CELLS>(keys, begin, cells, mine, lane);
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += 64 * NW) {
+    unsigned at = first[b] + offsets[(size_t)blockIdx.x * bins + b];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const unsigned c = cursor[w * bins + b];
+      cursor[w * bins + b] = at;
+      at += c;
+    }
+  }
+  __syncthreads();
+  for (int step0 = 0; step0 < STEPS; step0 += GROUP) {
+    unsigned label[GROUP];
+    K cell[GROUP];
+#pragma unroll
+    for (int k = 0; k < GROUP; ++k) {
+      const unsigned i = begin + (unsigned)(step0 + k) * 64u + (unsigned)lane;
+      const unsigned at = min(i, cells - 1);
+      label[k] = keys[at];
+      cell[k] = payload[at];
+      if (i >= cells) label[k] = ~0u;
+    }
+#pragma unroll
+    for (int k = 0; k < GROUP; ++k) {
+      const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)label[k]);
+      if (__all(label[k] == f)) {
+        if (f == ~0u) continue;
+        const unsigned base = mine[f];
+        if (lane == 0) mine[f] = base + 64u;
+        out_keys[base + lane] = f;
+        out_payload[base + lane] = cell[k];
+        continue;
+      }
+      const bool valid = label[k] != ~0u;
+      unsigned rank, count;
+      match_label(label[k], valid, bits, &rank, &count);
+      if (valid) {
+        const unsigned base = mine[label[k]];
+        if (rank + 1 == count) mine[label[k]] = base + count;
+        out_keys[base + rank] = label[k];
+        out_payload[base + rank] = cell[k];
+      }
+    }
+  }
+}
+
+struct PartitionBuffers {
+  unsigned *counts = nullptr, *offsets = nullptr, *totals = nullptr;
+  bool counted = false;  // counts[] already holds this frame's tile histograms (zonal_exact_kernel gathered them)
+};
+
 __global__ __launch_bounds__(256) void zonal_exact_result_kernel(const ExactRange* __restrict__ range, const double* __restrict__ sums,
                                                                  int n_labels, int statistic, float* __restrict__ out,
                                                                  long long* __restrict__ counts) {
@@ -1184,11 +1389,17 @@ T scalar_from_bits(uint64_t bits) {
   else return (T)s.i64;
 }
 
+// The contiguous stretch of cells a wave of the direct kernels walks: at least 2048 cells, at most 16 waves per CU (more,
+// shorter stretches keep more loads in flight -- 1024-label sums 428 -> 377 us, integer sums 201 -> 150 us -- but every
+// wave ends with atomics on its last label's counters, which one label covering the raster serialises: 265 -> 302 us).
+static int64_t stretch() { static const int64_t v = getenv("GM_ZONAL_STRETCH") ? atoll(getenv("GM_ZONAL_STRETCH")) : 2048; return v; }
+static int64_t wave_cap() { static const int64_t v = getenv("GM_ZONAL_WAVECAP") ? atoll(getenv("GM_ZONAL_WAVECAP")) : 16; return v; }
+
 struct Scratch {  // device buffers of one call, returned to the pool on every exit path
-  void* p[16] = {nullptr};
+  void* p[24] = {nullptr};
   int n = 0;
   int take(void** out, size_t bytes) {
-    if (n == 16) return gm::fail(GM_ERR_INVALID, "gm_zonal_statistic: scratch table full");
+    if (n == 24) return gm::fail(GM_ERR_INVALID, "gm_zonal_statistic: scratch table full");
     const int rc = gm_malloc(out, bytes ? bytes : 1);
     if (rc == GM_OK) p[n++] = *out;
     return rc;
@@ -1213,7 +1424,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     if ((rc = scratch.take((void**)&tally, sizeof(unsigned long long) * n_labels))) return rc;
     if ((rc = scratch.take((void**)&extreme, sizeof(Key) * n_labels))) return rc;
     // every wave walks one contiguous stretch of cells (label runs continue from step to step)
-    const int64_t waves = std::max<int64_t>(1, std::min<int64_t>((cells + 4095) / 4096, (int64_t)gm::current_cu_count() * 32));
+    const int64_t waves = std::max<int64_t>(1, std::min<int64_t>((cells + stretch() - 1) / stretch(), (int64_t)gm::current_cu_count() * wave_cap()));
     const size_t cells_per_wave = (size_t)(((cells + waves - 1) / waves + 63) / 64 * 64);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     for (int64_t f = 0; f < frames; ++f) {
@@ -1239,7 +1450,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   }
   const bool by_value = statistic == Z_MEDIAN || statistic == Z_PERCENTILE;
   // every wave of the direct kernels walks one contiguous stretch of cells
-  const int64_t waves = std::max<int64_t>(1, std::min<int64_t>((cells + 4095) / 4096, (int64_t)gm::current_cu_count() * 32));
+  const int64_t waves = std::max<int64_t>(1, std::min<int64_t>((cells + stretch() - 1) / stretch(), (int64_t)gm::current_cu_count() * wave_cap()));
   const size_t cells_per_wave = (size_t)(((cells + waves - 1) / waves + 63) / 64 * 64);
   const unsigned direct_blocks = (unsigned)((waves + 3) / 4);
   int rc;
@@ -1264,6 +1475,13 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   size_t temp_bytes = 0;
   unsigned label_bits = 1;
   while ((1ull << label_bits) <= (unsigned long long)n_labels) ++label_bits;
+  // (GM_ZONAL_PART=0: rocPRIM's radix sort for every label count -- A/B runs, and the tests compare the two)
+  static const bool partition_allowed = !(getenv("GM_ZONAL_PART") && atoi(getenv("GM_ZONAL_PART")) == 0);
+  // (sorts that start from cells in value order -- medians, percentiles -- see the labels as noise, where the partition's
+  // per-lane scatter loses to the radix sort's exchange through LDS: 985 against 748 us; GM_ZONAL_PART=1 forces it, for the tests)
+  const bool partition = partition_allowed && n_labels + 1 <= ZP_BINS && (!by_value || getenv("GM_ZONAL_PART"));
+  const size_t part_bins = (size_t)n_labels + 1, part_tiles = ((size_t)cells + ZP_TILE - 1) / ZP_TILE;
+  PartitionBuffers part;
   const unsigned blocks = (unsigned)std::min<int64_t>((cells + 255) / 256, (int64_t)gm::current_cu_count() * 32);
   for (int64_t f = 0; f < frames; ++f) {
     const T* frame = values + (size_t)f * cells;
@@ -1280,24 +1498,74 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       if ((rc2 = scratch.take((void**)&pay_a, sizeof(Key) * cells))) return rc2;
       return scratch.take((void**)&first, sizeof(unsigned) * ((size_t)n_labels + 2));
     };
-    auto sort_buffers = [&]() -> int {
-      if (keys_b) return GM_OK;
+    auto sort_buffers = [&]() -> int {  // (what this frame's sort needs and earlier frames have not taken yet)
       int rc2;
-      if ((rc2 = scratch.take((void**)&keys_b, sizeof(unsigned) * cells))) return rc2;
-      if ((rc2 = scratch.take((void**)&pay_b, sizeof(Key) * cells))) return rc2;
+      if (!keys_b) {
+        if ((rc2 = scratch.take((void**)&keys_b, sizeof(unsigned) * cells))) return rc2;
+        if ((rc2 = scratch.take((void**)&pay_b, sizeof(Key) * cells))) return rc2;
+      }
       size_t temp_value = 0, temp_label = 0;
       if (by_value)
         GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_value, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 0, 8 * sizeof(Key), s));
-      GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_label, keys_a, keys_b, pay_a, pay_b, (size_t)cells, 0, label_bits, s));
-      temp_bytes = temp_value > temp_label ? temp_value : temp_label;
-      return scratch.take(&temp, temp_bytes);
+      if (!partition) {
+        GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_label, keys_a, keys_b, pay_a, pay_b, (size_t)cells, 0, label_bits, s));
+      } else if (!part.offsets) {
+        if (!part.counts && (rc2 = scratch.take((void**)&part.counts, sizeof(unsigned) * part_tiles * part_bins))) return rc2;
+        if ((rc2 = scratch.take((void**)&part.offsets, sizeof(unsigned) * part_tiles * part_bins))) return rc2;
+        if ((rc2 = scratch.take((void**)&part.totals, sizeof(unsigned) * part_bins))) return rc2;
+      }
+      const size_t need = temp_value > temp_label ? temp_value : temp_label;
+      if (need > temp_bytes) {  // (at most twice per call: the earlier, smaller one goes back with the rest of the scratch)
+        if ((rc2 = scratch.take(&temp, need))) return rc2;
+        temp_bytes = need;
+      }
+      return GM_OK;
+    };
+    // the stable sort by label of (keys, payload): one counting pass for up to ZP_BINS - 1 labels (which also yields
+    // first[]), rocPRIM's radix sort + the search for the bounds otherwise
+    auto sort_by_label = [&](const unsigned* keys_in, const Key* pay_in, unsigned* keys_out, Key* pay_out) -> int {
+      if (partition) {
+        static const int nw = getenv("GM_ZONAL_PART_WAVES") ? atoi(getenv("GM_ZONAL_PART_WAVES")) : 8;
+        const size_t lds = sizeof(unsigned) * part_bins;
+#define GM_ZP(NW)                                                                                                              \
+  do {                                                                                                                         \
+    if (NW * lds > 65536)                                                                                                      \
+      GM_HIP(hipFuncSetAttribute((const void*)zonal_part_scatter_kernel<Key, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                 (int)(NW * lds)));                                                                            \
+    if (!part.counted)                                                                                                         \
+      hipLaunchKernelGGL(zonal_part_count_kernel<NW>, dim3((unsigned)part_tiles), dim3(64 * NW), 0, s, keys_in, (unsigned)cells, \
+                         (int)part_bins, part.counts);                                                                         \
+    hipLaunchKernelGGL(zonal_part_scan_kernel, dim3((unsigned)((part_bins * 64 + 255) / 256)), dim3(256), 0, s, part.counts,   \
+                       (unsigned)part_tiles, (int)part_bins, part.offsets, part.totals);                                       \
+    hipLaunchKernelGGL(zonal_part_first_kernel, dim3(1), dim3(256), 0, s, part.totals, (int)part_bins, first);                 \
+    hipLaunchKernelGGL((zonal_part_scatter_kernel<Key, NW>), dim3((unsigned)part_tiles), dim3(64 * NW), NW * lds, s, keys_in,   \
+                       pay_in, (unsigned)cells, (int)part_bins, (int)label_bits, part.offsets, first, keys_out, pay_out);      \
+  } while (0)
+        if (nw == 4) GM_ZP(4);
+        else if (nw == 16) GM_ZP(16);
+        else GM_ZP(8);
+#undef GM_ZP
+      } else {
+        size_t bytes = temp_bytes;
+        GM_HIP(rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, pay_in, pay_out, (size_t)cells, 0, label_bits, s));
+        hipLaunchKernelGGL(zonal_bounds_kernel, dim3((n_labels + 1 + 255) / 256), dim3(256), 0, s, keys_out, (unsigned)cells, n_labels, first);
+      }
+      GM_HIP(hipGetLastError());
+      return GM_OK;
     };
     if ((rc = key_buffers())) return rc;
     bool keys_written = false;
+    unsigned longest = ~0u;  // (cells of the longest label, where a verdict has counted them)
+    part.counted = false;
     if (range) {
+      if (partition) {  // (3 MB for the default raster limit and 1024 labels)
+        if (!part.counts && (rc = scratch.take((void**)&part.counts, sizeof(unsigned) * part_tiles * part_bins))) return rc;
+        GM_HIP(hipMemsetAsync(part.counts, 0, sizeof(unsigned) * part_tiles * part_bins, s));
+        part.counted = true;
+      }
       hipLaunchKernelGGL(zonal_exact_init_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, verdict_dev, cursor);
       hipLaunchKernelGGL((zonal_exact_kernel<T, 0>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells, cells_per_wave,
-                         n_labels, has_ndv, ndv, thresholds, range, sums, seen, keys_a, pay_a);
+                         n_labels, has_ndv, ndv, thresholds, range, sums, seen, keys_a, pay_a, part.counted ? part.counts : (unsigned*)nullptr);
       hipLaunchKernelGGL(zonal_exact_decide_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, n_labels, inexact, verdict_dev);
       ExactVerdict verdict{1u, 0u, (unsigned long long)cells};
       GM_HIP(hipMemcpyAsync(&verdict, verdict_dev, sizeof(verdict), hipMemcpyDeviceToHost, s));
@@ -1308,7 +1576,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       if (verdict.labels == 0 || partial) {
         hipLaunchKernelGGL((zonal_exact_kernel<T, 1>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells,
                            cells_per_wave, n_labels, has_ndv, ndv, thresholds, range, sums, (unsigned char*)nullptr,
-                           (unsigned*)nullptr, (Key*)nullptr);
+                           (unsigned*)nullptr, (Key*)nullptr, (unsigned*)nullptr);
         hipLaunchKernelGGL(zonal_exact_result_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, statistic,
                            out_f, counts_f);
         if (partial) {
@@ -1337,6 +1605,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         continue;
       }
       keys_written = true;  // (and `present` is recorded)
+      longest = verdict.longest;
     }
     if ((rc = sort_buffers())) return rc;
     if (!keys_written)
@@ -1348,22 +1617,20 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     if (by_value) {
       // lexsort((values, labels)): by value, then stably by label
       GM_HIP(rocprim::radix_sort_pairs(temp, bytes, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 0, 8 * sizeof(Key), s));
-      bytes = temp_bytes;
-      GM_HIP(rocprim::radix_sort_pairs(temp, bytes, keys_b, keys_a, pay_b, pay_a, (size_t)cells, 0, label_bits, s));
+      if ((rc = sort_by_label(keys_b, pay_b, keys_a, pay_a))) return rc;
       sorted_keys = keys_a;
       sorted_pay = pay_a;
     } else {
-      GM_HIP(rocprim::radix_sort_pairs(temp, bytes, keys_a, keys_b, pay_a, pay_b, (size_t)cells, 0, label_bits, s));
+      if ((rc = sort_by_label(keys_a, pay_a, keys_b, pay_b))) return rc;
       sorted_keys = keys_b;
       sorted_pay = pay_b;
     }
-    hipLaunchKernelGGL(zonal_bounds_kernel, dim3((n_labels + 1 + 255) / 256), dim3(256), 0, s, sorted_keys, (unsigned)cells, n_labels, first);
     if (statistic == Z_SUM || statistic == Z_MEAN) {
       // labels of ZL_LONG cells and more: block-parallel (zonal_compose_kernel and its three helpers); GM_ZONAL_BLOCKS=0
       // keeps every label on the wave-per-label kernel (A/B runs, and the tests compare the two)
       static const bool block_pipeline = !(getenv("GM_ZONAL_BLOCKS") && atoi(getenv("GM_ZONAL_BLOCKS")) == 0);
       static const unsigned long_from = getenv("GM_ZONAL_LONG") ? (unsigned)std::max(2 * (int)ZB, atoi(getenv("GM_ZONAL_LONG"))) : ZL_LONG;
-      const bool long_labels = block_pipeline && (uint64_t)cells >= long_from;
+      const bool long_labels = block_pipeline && (uint64_t)cells >= long_from && longest >= long_from;
       if (long_labels) {
         const size_t n_blocks = ((size_t)cells + ZB - 1) / ZB;
         if (!blk_sum) {

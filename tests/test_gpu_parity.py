@@ -1643,3 +1643,19 @@ def test_zonal_block_pipeline(gpu, blocks):
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
     assert "BLOCKS ok 240" in res.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("part", ["1", "0"], ids=["partition", "radix-sort"])
+def test_zonal_label_partition(gpu, part):
+    """The stable sort by label as one counting pass (csrc/gm_zonal.hip: zonal_part_*_kernel, up to 2047 labels) and as
+    rocPRIM's radix sort, against the oracle: 240 statistics over label rasters of every texture
+    (tests/zonal_partition_driver.py), sums forced through the sort."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GM_ZONAL_PART=part, GM_ZONAL_SORTED="1")
+    driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_partition_driver.py")
+    res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
+    assert "PARTITION ok 240" in res.stdout

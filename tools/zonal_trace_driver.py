@@ -1,0 +1,28 @@
+"""One zonal statistic on the 3072 x 4096 float32 raster of tools/kbench.py, for ``rocprofv3 --kernel-trace --stats``:
+python3 tools/zonal_trace_driver.py [n_labels] [statistic] [repeats]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from dask_geomodeling_amd import geometry  # noqa: E402
+from dask_geomodeling_amd.hip import runtime  # noqa: E402
+from dask_geomodeling_amd.hip.array import DeviceArray  # noqa: E402
+
+n_labels = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+stat = sys.argv[2] if len(sys.argv) > 2 else "sum"
+repeats = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+h, w = 3072, 4096
+rng = np.random.default_rng(5)
+values = (rng.standard_normal((1, h, w)) * 100).astype("f4")
+values[rng.random(values.shape) < 0.1] = -9999.0
+if n_labels == 1:
+    labels = np.zeros((h, w), dtype=np.int32)
+else:
+    labels = ((np.arange(h)[:, None] // 96) * 32 + np.arange(w)[None, :] // 128).astype(np.int32)
+    n_labels = 1024
+dev_values, dev_labels = DeviceArray.from_numpy(values), DeviceArray.from_numpy(labels)
+for _ in range(repeats):
+    geometry.label_statistics(dev_values, np.float32(-9999.0), dev_labels, n_labels, stat, None)
+runtime.sync()
