@@ -193,6 +193,10 @@ __device__ __forceinline__ void cell_span(T v, int* top, int* low) {
 //   * Otherwise the step is replayed literally: the values parked in LDS, every lane runs the same chain of dependent
 //     additions on broadcast reads (the wave as one sequential adder, ~20 cycles per cell).
 // Cells past the end of the label add +0.0, which changes nothing (the sum starts from +0.0 like bincount's zeros).
+#ifndef GM_ZP_TILE
+#define GM_ZP_TILE 16384
+#endif
+constexpr int ZP_TILE = GM_ZP_TILE;  // cells per tile of the label partition (further down)
 constexpr int ZS_PER_LANE = 4, ZS_STEP = 64 * ZS_PER_LANE;
 constexpr unsigned ZS_SHORT = 192;  // labels of up to this many active cells: a lane each (zonal_short_sum_kernel)
 template <typename T>
@@ -417,15 +421,39 @@ __global__ __launch_bounds__(256) void zonal_block_prefix_kernel(const typename 
     for (int off = 1; off < 64; off <<= 1) partial += shuffle_xor(partial, off);
     running = partial;
   }
-  for (unsigned j = j0; j < j1; j += 64) {
-    const double mine = j + lane < j1 ? blk_sum[j + lane] : 0.0;
-    double scan = mine;
+  // 64 x PER blocks per round: a lane takes PER consecutive block sums (any order will do: the result only predicts), the
+  // wave scans the 64 lane totals; the next round's loads are issued before this round's scan (one label covering the
+  // default raster limit, 49 152 blocks: 362 us at one block per lane and round, the loads not ahead)
+  constexpr int PER = 16;
+  auto fetch = [&](unsigned j, double* v) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const unsigned at = j + PER * lane + k;
+      v[k] = blk_sum[min(at, j1 - 1)];
+    }
+  };
+  double ahead[PER];
+  if (j0 < j1) fetch(j0, ahead);
+  for (unsigned j = j0; j < j1; j += 64 * PER) {
+    double mine[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) mine[k] = j + PER * lane + k < j1 ? ahead[k] : 0.0;
+    if (j + 64 * PER < j1) fetch(j + 64 * PER, ahead);
+    double total = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) total += mine[k];
+    double scan = total;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const double up = shuffle_up_f64(scan, off);
       if ((int)lane >= off) scan += up;
     }
-    if (j + lane < j1) blk_pred[j + lane] = running + (scan - mine);
+    double before = running + (scan - total);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (j + PER * lane + k < j1) blk_pred[j + PER * lane + k] = before;
+      before += mine[k];
+    }
     running += broadcast_f64(scan, 63);
   }
 }
@@ -658,26 +686,48 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
     return ((long long)__builtin_amdgcn_readlane((int)(mine64 >> 32), i) << 32) | (unsigned)__builtin_amdgcn_readlane((int)mine64, i);
   };
   to_integer();
-  for (unsigned g = j0; g < j1; g += 64) {
-    const unsigned here = min(64u, j1 - g);
-    BlockInfo B;
-    {
-      const unsigned jj = min(g + (unsigned)lane, j1 - 1);
-      B = info[jj];
-      if (blk_label[jj] != l) B.E = INT_MIN;
+  // Groups of 64 x PER blocks, a lane holding PER consecutive ones (the next group's descriptions are requested before this
+  // group is worked on).  Every block is a function parity -> (units added, parity left): a lane composes its own blocks,
+  // the wave composes the lanes' functions in lane order (six shuffle steps), every lane then knows the sum ENTERING its
+  // first block and walks its blocks, testing each one's validity for the sum entering it; up to the first block that
+  // fails all are one addition, that block is added literally, and the rest of the group is composed again from the sum
+  // it leaves.  (One label over the default raster limit, 49 152 blocks, 16 of them literal: 743 us at one block per lane
+  // and nothing requested ahead.)
+  constexpr int PER = 4;
+  auto fetch = [&](unsigned g, BlockInfo* B) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const unsigned jj = min(g + (unsigned)(PER * lane + k), j1 - 1);
+      B[k] = info[jj];
+      if (blk_label[jj] != l) B[k].E = INT_MIN;
     }
-    // The 64 blocks of a group are taken together: every block is a function parity -> (units added, parity left), the
-    // wave composes them in lane order (six shuffle steps), every lane then knows the sum ENTERING its block and tests its
-    // block's validity for it; up to the first block that fails all are one addition, that block is added literally, and
-    // the rest of the group is composed again from the sum it leaves.
+  };
+  BlockInfo ahead[PER];
+  if (j0 < j1) fetch(j0, ahead);
+  for (unsigned g = j0; g < j1; g += 64 * PER) {
+    const unsigned here = min((unsigned)(64 * PER), j1 - g);
+    BlockInfo B[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) B[k] = ahead[k];
+    if (g + 64 * PER < j1) fetch(g + 64 * PER, ahead);
     unsigned start = 0;
     while (start < here) {
-      const bool mine_in = (unsigned)lane >= start && (unsigned)lane < here;
       UnitsFn scan;
+      scan.S[0] = scan.S[1] = 0;
+      scan.q[0] = 0;
+      scan.q[1] = 1;
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        scan.S[p] = mine_in ? B.D[p] : 0;
-        scan.q[p] = mine_in ? (int)((p + B.D[p]) & 1) : p;
+      for (int k = 0; k < PER; ++k) {
+        const unsigned idx = (unsigned)(PER * lane + k);
+        if (idx >= start && idx < here) {
+          UnitsFn f;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            f.S[p] = B[k].D[p];
+            f.q[p] = (int)((p + B[k].D[p]) & 1);
+          }
+          scan = compose_units(scan, f);
+        }
       }
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
@@ -691,25 +741,43 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
         excl.q[1] = 1;
       }
       const int p0 = (int)(units & 1);
-      const long long entering = units + (p0 ? excl.S[1] : excl.S[0]);
-      const int parity = p0 ? excl.q[1] : excl.q[0];
-      const long long lowest = entering + (parity ? B.lo[1] : B.lo[0]), highest = entering + (parity ? B.hi[1] : B.hi[0]);
-      // every prefix strictly inside the binade (one unit of margin below: the exact value before a rounding may lie
-      // half a unit under the rounded one)
-      const bool valid = as_integer && B.E == E && B.negative == negative && lowest >= 4503599627370497ll && highest <= 9007199254740991ll;
-      const unsigned long long bad = __ballot(mine_in && !valid);
+      long long entering = units + (p0 ? excl.S[1] : excl.S[0]);
+      int parity = p0 ? excl.q[1] : excl.q[0];
+      int failed = -1;           // the lane's first block that is not valid for the sum entering it
+      long long failed_entering = 0;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const unsigned idx = (unsigned)(PER * lane + k);
+        if (idx >= start && idx < here && failed < 0) {
+          const long long lowest = entering + (parity ? B[k].lo[1] : B[k].lo[0]), highest = entering + (parity ? B[k].hi[1] : B[k].hi[0]);
+          // every prefix strictly inside the binade (one unit of margin below: the exact value before a rounding may lie
+          // half a unit under the rounded one)
+          const bool valid = as_integer && B[k].E == E && B[k].negative == negative && lowest >= 4503599627370497ll &&
+                             highest <= 9007199254740991ll;
+          if (!valid) {
+            failed = (int)idx;
+            failed_entering = entering;
+          } else {
+            const long long d = parity ? B[k].D[1] : B[k].D[0];
+            entering += d;
+            parity = (int)((parity + d) & 1);
+          }
+        }
+      }
+      const unsigned long long bad = __ballot(failed >= 0);
       if (bad == 0) {
         const long long total = p0 ? scan.S[1] : scan.S[0];
         units += pass(total, 63);
         start = here;
       } else {
-        const int k = __ffsll((long long)bad) - 1;
-        units = pass(entering, k);
+        const int from = __ffsll((long long)bad) - 1;  // (lanes hold ascending blocks: the lowest lane has the first failure)
+        const unsigned k = (unsigned)__builtin_amdgcn_readlane(failed, from);
+        units = pass(failed_entering, from);
         to_double();
-        literally((g + (unsigned)k) * ZB, (g + (unsigned)k) * ZB + ZB);
+        literally((g + k) * ZB, (g + k) * ZB + ZB);
         to_integer();
         ++n_replayed;
-        start = (unsigned)k + 1;
+        start = k + 1;
       }
     }
   }
@@ -990,10 +1058,11 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
   // (PHASE 0 also writes the sort keys of zonal_keys_kernel: if the order turns out to matter the sort can start at once --
   // and, with tile_counts, what the label partition's counting pass would find: the cells of every key per tile of TILE
   // cells, one atomic per run and tile)
-  constexpr size_t TILE = 16384;  // (= ZP_TILE, declared further down)
+  constexpr size_t TILE = ZP_TILE;
   const int bins = n_labels + 1;
   size_t run_tile = 0;
-  unsigned idle = 0;  // cells of the tile that carry the key n_labels (wave-uniform)
+  unsigned idle = 0;    // cells of the tile that carry the key n_labels (wave-uniform)
+  unsigned tile_n = 0;  // per lane: cells of the run inside the tile
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const size_t begin = wave * cells_per_wave, end = min(begin + cells_per_wave, cells);
@@ -1001,9 +1070,18 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
   unsigned run_count = 0, run_bad = 0;
   int run_hi = INT_MIN, run_lo = INT_MAX;
   double run_sum = 0.0;
+  auto tile_flush = [&]() {  // (wave-uniform call; a run that crosses a tile border keeps gathering for its label's range)
+    if (run_label < 0) return;
+    unsigned n = tile_n;
+#pragma unroll
+    for (int offset = 32; offset >= 1; offset >>= 1) n += __shfl_xor(n, offset);
+    if (lane == 0 && n != 0) atomicAdd(&tile_counts[run_tile * bins + run_label], n);
+    tile_n = 0;
+  };
   auto flush = [&]() {  // (wave-uniform call)
     if (run_label < 0) return;
     if constexpr (PHASE == 0) {
+      if (tile_counts) tile_flush();
       unsigned n = run_count, bad = run_bad;
       int hi = run_hi, lo = run_lo;
 #pragma unroll
@@ -1019,7 +1097,6 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
         atomicMax(&slot->hi, hi);
         atomicMin(&slot->lo, lo);
         if (bad) atomicOr(&slot->bad, 1u);
-        if (tile_counts) atomicAdd(&tile_counts[run_tile * bins + run_label], n);
       }
     } else {
       double total = run_sum;
@@ -1052,7 +1129,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
       if (tile_counts) {
         const size_t tile = (i - lane) / TILE;  // (a step never straddles two tiles: stretches start on multiples of 64)
         if (tile != run_tile) {
-          flush();
+          tile_flush();
           if (lane == 0 && idle) atomicAdd(&tile_counts[run_tile * bins + n_labels], idle);
           idle = 0;
           run_tile = tile;
@@ -1071,6 +1148,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
       if (active) {
         if constexpr (PHASE == 0) {
           run_count += 1;
+          tile_n += 1;
           if (!(fabs(x) <= 1.7976931348623157e308)) {
             run_bad = 1;
           } else if (x != 0.0) {
@@ -1206,7 +1284,7 @@ __global__ __launch_bounds__(256) void zonal_list_bounds_kernel(const unsigned l
 //            (match_label: one ballot per label bit; label rasters are runs, and a step whose 64 cells share one label
 //            takes a short cut), cursor read, cells stored at cursor + rank, cursor advanced by the last such lane.
 // Every cell is read twice (the second time from the L2) and written once.
-constexpr int ZP_TILE = 16384, ZP_BINS = 2048, ZP_GROUP = 8;  // (a wave of an NW-wave workgroup owns ZP_TILE / NW cells)
+constexpr int ZP_BINS = 2048, ZP_GROUP = 8;  // (a wave of an NW-wave workgroup owns ZP_TILE / NW cells)
 
 // among the lanes with valid set: how many hold this lane's label, and how many of those sit below it
 __device__ __forceinline__ void match_label(unsigned label, bool valid, int bits, unsigned* rank, unsigned* count) {

@@ -1,5 +1,5 @@
 """One zonal statistic on the 3072 x 4096 float32 raster of tools/kbench.py, for ``rocprofv3 --kernel-trace --stats``:
-python3 tools/zonal_trace_driver.py [n_labels] [statistic] [repeats]"""
+python3 tools/zonal_trace_driver.py [n_labels] [statistic] [repeats] [positive]"""
 import os
 import sys
 
@@ -13,9 +13,12 @@ from dask_geomodeling_amd.hip.array import DeviceArray  # noqa: E402
 n_labels = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 stat = sys.argv[2] if len(sys.argv) > 2 else "sum"
 repeats = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+positive = len(sys.argv) > 4 and sys.argv[4] == "positive"  # elevation-like cells: the sums only grow
 h, w = 3072, 4096
 rng = np.random.default_rng(5)
 values = (rng.standard_normal((1, h, w)) * 100).astype("f4")
+if positive:
+    values = np.abs(values) + np.float32(3.0)
 values[rng.random(values.shape) < 0.1] = -9999.0
 if n_labels == 1:
     labels = np.zeros((h, w), dtype=np.int32)
