@@ -22,21 +22,23 @@ namespace {
 // ---------------------------------------------------------------------------------
 // mode 0 (warp):   idx = floor(((o_dst + (k + 0.5) * s_dst) - o_src) / s_src + eps)
 // mode 1 (affine): idx = floor(k * z + off + 0.5)            params = {z, off, -, -}
-__global__ __launch_bounds__(256) void nearest_index_kernel(int* __restrict__ idx, int n_dst, int n_src, int mode,
-                                                            double p0, double p1, double p2, double p3, double eps) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_dst) return;
+// Evaluated inside the gather kernel (round 3; two small table kernels and a dependent memory round trip before): a lane
+// needs its 4 columns and one of the strip's rows -- five float64 divisions per 32 pixels.
+struct AxisMap {
+  double p0, p1, p2, p3;
+};
+__device__ __forceinline__ int nearest_index(int k, int n_src, int mode, const AxisMap& m, double eps) {
   double pix;
   if (mode == 0) {
-    const double world = p0 + ((double)k + 0.5) * p1;
-    pix = (world - p2) / p3 + eps;
+    const double world = m.p0 + ((double)k + 0.5) * m.p1;
+    pix = (world - m.p2) / m.p3 + eps;
   } else {
-    pix = ((double)k * p0 + p1) + 0.5;
+    pix = ((double)k * m.p0 + m.p1) + 0.5;
   }
   const double f = floor(pix);
   int i = -1;
   if (f >= 0.0 && f < (double)n_src) i = (int)f;
-  idx[k] = i;
+  return i;
 }
 
 template <typename T>
@@ -52,44 +54,84 @@ __device__ __forceinline__ bool is_finite_t(T v) {
 // reused instead of gathering again.
 template <typename T, int ROWS>
 __global__ __launch_bounds__(256) void nearest_gather_kernel(const T* __restrict__ src, T* __restrict__ dst, int hs,
-                                                             int ws, int hd, int wd, const int* __restrict__ row_idx,
-                                                             const int* __restrict__ col_idx, T fill,
-                                                             int finite_to_fill) {
+                                                             int ws, int hd, int wd, int mode, AxisMap row_map,
+                                                             AxisMap col_map, double eps, T fill, int finite_to_fill) {
   typedef T VT __attribute__((ext_vector_type(4)));
   typedef T VTU __attribute__((ext_vector_type(4), aligned(sizeof(T))));  // element-aligned 4-vector
   const int band = blockIdx.z;
-  const int c0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (c0 >= wd) return;
+  const int c0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;  // (lanes past the last column stay: they hold row indices)
   const T* sband = src + (size_t)band * hs * ws;
   T* dband = dst + (size_t)band * hd * wd;
   int ci[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) ci[k] = (c0 + k < wd) ? col_idx[c0 + k] : -1;
+  for (int k = 0; k < 4; ++k) ci[k] = (c0 + k < wd) ? nearest_index(c0 + k, ws, mode, col_map, eps) : -1;
   const bool run = (ci[0] >= 0) & (ci[1] == ci[0] + 1) & (ci[2] == ci[0] + 2) & (ci[3] == ci[0] + 3);
   const int r_begin = blockIdx.y * ROWS;
   const bool vec_ok = (c0 + 3 < wd) && ((wd & 3) == 0) && ((((uintptr_t)dband) % (4 * sizeof(T))) == 0);
-  // all ROWS source rows of the strip are requested before the first store (ROWS independent
-  // gathers in flight per lane instead of one load-store round trip per row)
+  // all ROWS source rows of the strip are requested before the first store (ROWS independent gathers in flight per lane
+  // instead of one load-store round trip per row).  Every load is UNCONDITIONAL -- its address clamped into the raster, what
+  // it must not deliver selected away afterwards -- and the one choice left, 16-byte loads or four gathers, is made for the
+  // whole wave: with per-lane branches around the loads the compiler waited for every row's loads before it issued the next
+  // row's (round 3: eight memory round trips per workgroup, 2x up-sampling 278 us; see DESIGN K6).
+  // the strip's source rows (wave-uniform): lane l works out row l mod ROWS, everybody reads them off the first lanes
+  static_assert((ROWS & (ROWS - 1)) == 0 && ROWS <= 64, "ROWS");
+  const int my_row = nearest_index(min(r_begin + (int)(threadIdx.x & (ROWS - 1)), hd - 1), hs, mode, row_map, eps);
+  int rows[ROWS];
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) rows[i] = __builtin_amdgcn_readlane(my_row, i);
+  const bool idle = c0 >= wd;  // (takes part in the wave's choices and loads -- from a clamped address -- and stores nothing)
+  const bool all_run = __all(run || idle) && ws >= 4;
+  const int first_col = min(max(ci[0], 0), max(ws - 4, 0));
+  int off[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) off[k] = ci[k] - ci[0];
+  const bool span = (ci[0] >= 0) & (ci[0] + 3 < ws) & (off[1] >= 0) & (off[2] >= off[1]) & (off[3] >= off[2]) & (off[3] <= 3);
+  int cc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cc[k] = min(max(ci[k], 0), ws - 1);
   T v[ROWS][4];
+  // (a row that repeats the one before it -- up-sampling along y, wave-uniform -- is not loaded again; its registers are
+  // filled from the row before once ALL loads are on their way: a copy in between would wait for the load it copies)
+  if (__builtin_amdgcn_readfirstlane(all_run ? 1 : 0)) {
 #pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    const int r = r_begin + i;
-    const int ri = r < hd ? row_idx[r] : -1;                       // wave-uniform
-    const int prev = (i > 0 && r - 1 < hd) ? row_idx[r - 1] : -2;  // (scalar loads, cached)
-    if (i > 0 && ri == prev) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[i][k] = v[i - 1][k];
-    } else if (ri < 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[i][k] = fill;
-    } else if (run) {
-      const VTU x = *(const VTU*)(sband + (size_t)ri * ws + ci[0]);
+    for (int i = 0; i < ROWS; ++i) {
+      if (i > 0 && rows[i] == rows[i - 1]) continue;
+      const VTU x = *(const VTU*)(sband + (size_t)max(rows[i], 0) * ws + first_col);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[i][k] = x[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[i][k] = (ci[k] >= 0) ? sband[(size_t)ri * ws + ci[k]] : fill;
     }
+  } else if (__builtin_amdgcn_readfirstlane((__all(span || idle) && ws >= 4) ? 1 : 0)) {
+    // up-sampling along x: the lane's 4 source columns lie within 4 consecutive ones (2x: j j j+1 j+1): one 16-byte load
+    // and a pick per column instead of four 4-byte gathers
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      if (i > 0 && rows[i] == rows[i - 1]) continue;
+      const VTU x = *(const VTU*)(sband + (size_t)max(rows[i], 0) * ws + first_col);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[i][k] = off[k] == 0 ? x[0] : (off[k] == 1 ? x[1] : (off[k] == 2 ? x[2] : x[3]));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      if (i > 0 && rows[i] == rows[i - 1]) continue;
+      const T* srow = sband + (size_t)max(rows[i], 0) * ws;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[i][k] = srow[cc[k]];
+    }
+  }
+#pragma unroll
+  for (int i = 1; i < ROWS; ++i) {
+    if (rows[i] == rows[i - 1]) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[i][k] = v[i - 1][k];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const bool void_row = rows[i] < 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (void_row || ci[k] < 0) v[i][k] = fill;
   }
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
@@ -496,31 +538,21 @@ int gm_resample_nearest(const void* src, int dtype, int bands, int hs, int ws, v
   if (!s) return GM_ERR_NO_DEVICE;
   gm_scalar fill;
   fill.u64 = fill_bits;
-  int* tables = nullptr;
-  int rc = gm_malloc((void**)&tables, sizeof(int) * ((size_t)hd + (size_t)wd));
-  if (rc) return rc;
-  int* row_idx = tables;
-  int* col_idx = tables + hd;
-  hipLaunchKernelGGL(nearest_index_kernel, dim3((hd + 255) / 256), dim3(256), 0, s, row_idx, hd, hs, mode,
-                     row_params[0], row_params[1], row_params[2], row_params[3], eps);
-  hipLaunchKernelGGL(nearest_index_kernel, dim3((wd + 255) / 256), dim3(256), 0, s, col_idx, wd, ws, mode,
-                     col_params[0], col_params[1], col_params[2], col_params[3], eps);
+  const AxisMap row_map{row_params[0], row_params[1], row_params[2], row_params[3]};
+  const AxisMap col_map{col_params[0], col_params[1], col_params[2], col_params[3]};
   // rows per workgroup: 4 streams best (identity grid: 72 % of peak, 8 rows: 66 %); when the
   // request up-samples along y, 8 rows share more source rows (2x: 61 % against 57 %)
   const int ROWS = hd > hs ? 8 : 4;
   dim3 grid((unsigned)((wd + 1023) / 1024), (unsigned)((hd + ROWS - 1) / ROWS), (unsigned)bands);
-  if (grid.y > 65535) {
-    gm_free(tables);
-    return gm::fail(GM_ERR_UNSUPPORTED, "destination taller than %d rows", 65535 * ROWS);
-  }
+  if (grid.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "destination taller than %d rows", 65535 * ROWS);
 #define GM_NEAREST(T, FILL)                                                                                       \
   do {                                                                                                            \
     if (ROWS == 8)                                                                                                \
       hipLaunchKernelGGL((nearest_gather_kernel<T, 8>), grid, dim3(256), 0, s, (const T*)src, (T*)dst, hs, ws,    \
-                         hd, wd, row_idx, col_idx, (T)(FILL), finite_to_fill);                                    \
+                         hd, wd, mode, row_map, col_map, eps, (T)(FILL), finite_to_fill);                                    \
     else                                                                                                          \
       hipLaunchKernelGGL((nearest_gather_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)src, (T*)dst, hs, ws,    \
-                         hd, wd, row_idx, col_idx, (T)(FILL), finite_to_fill);                                    \
+                         hd, wd, mode, row_map, col_map, eps, (T)(FILL), finite_to_fill);                                    \
   } while (0)
   switch (dtype) {
     case GM_BOOL: case GM_U8: case GM_I8: GM_NEAREST(unsigned char, fill.i64); break;
@@ -529,11 +561,10 @@ int gm_resample_nearest(const void* src, int dtype, int bands, int hs, int ws, v
     case GM_U64: case GM_I64: GM_NEAREST(unsigned long long, fill.u64); break;
     case GM_F32: GM_NEAREST(float, fill.f64); break;
     case GM_F64: GM_NEAREST(double, fill.f64); break;
-    default: gm_free(tables); return gm::fail(GM_ERR_INVALID, "gm_resample_nearest: dtype %d", dtype);
+    default: return gm::fail(GM_ERR_INVALID, "gm_resample_nearest: dtype %d", dtype);
   }
 #undef GM_NEAREST
   hipError_t e = hipGetLastError();
-  gm_free(tables);  // stream-ordered reuse: later work on this stream runs after the gather
   if (e != hipSuccess) return gm::hip_fail(e, "gm_resample_nearest");
   return GM_OK;
 }
