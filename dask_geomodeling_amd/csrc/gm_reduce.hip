@@ -345,9 +345,14 @@ __global__ __launch_bounds__(256) void reduce_sorted_small_kernel(const C* __res
   const C* src = stack + p;
   C v[N];
   int m = 0;
+  // (all N loads first: with each value examined right behind its load the compiler waited for every load before it
+  // issued the next -- N memory round trips per pixel)
+  C raw[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) raw[j] = __builtin_nontemporal_load(src + (long long)(j < n ? j : 0) * pixels);
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    const C x = __builtin_nontemporal_load(src + (long long)(j < n ? j : 0) * pixels);
+    const C x = raw[j];
     const bool nd = j >= n || x != x;
     v[j] = nd ? std::numeric_limits<C>::infinity() : x;
     m += nd ? 0 : 1;

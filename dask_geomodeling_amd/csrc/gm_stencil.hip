@@ -314,7 +314,11 @@ __global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* 
   const int ow = w - 2, oh = h - 2;
   const size_t left = (size_t)(h - 1) * pitch + w;  // bytes from the first cell to the end of the last row
   constexpr int QUADS = D8W_PITCH / 4, CELLS = (D8W_H + 2) * QUADS, PER_LANE = (CELLS + 255) / 256;
+  // Staging: every 16-byte load is UNCONDITIONAL, from an address clamped into the raster -- what a cell past the row end must
+  // hold (zeros) or the last 15 bytes of the raster need (byte loads) is put right afterwards.  With the tests around the
+  // loads the compiler waited for each load before it issued the next (round 3: PER_LANE memory round trips per lane).
   u32x4 staged[PER_LANE];
+  const bool roomy = left >= 16;  // (a raster of fewer than 16 bytes: everything goes byte by byte)
 #pragma unroll
   for (int i = 0; i < PER_LANE; ++i) {
     const int cell = threadIdx.x + 256 * i;
@@ -322,21 +326,24 @@ __global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* 
     const int sy = min(r0 + wy, h - 1), sx = c0 + 16 * q;
     const size_t at = (size_t)sy * pitch + sx;
     u32x4 x = {0u, 0u, 0u, 0u};
-    if (sx < w) {
-      if (at + 16 <= left) {
-        __builtin_memcpy(&x, in + at, 16);
-      } else {
-        unsigned char tail[16] = {0};
-        for (int j = 0; at + j < left; ++j) tail[j] = in[at + j];
-        __builtin_memcpy(&x, tail, 16);
-      }
-    }
+    if (roomy) __builtin_memcpy(&x, in + min(at, left - 16), 16);  // (wave-uniform test)
     staged[i] = x;
   }
 #pragma unroll
   for (int i = 0; i < PER_LANE; ++i) {
     const int cell = threadIdx.x + 256 * i;
-    if (cell < CELLS) *(u32x4*)(tile + 4 * cell) = staged[i];
+    const int wy = min(cell / QUADS, D8W_H + 1), q = cell - (cell / QUADS) * QUADS;
+    const int sy = min(r0 + wy, h - 1), sx = c0 + 16 * q;
+    const size_t at = (size_t)sy * pitch + sx;
+    u32x4 x = staged[i];
+    if (sx >= w) {
+      x = u32x4{0u, 0u, 0u, 0u};
+    } else if (!roomy || at + 16 > left) {
+      unsigned char tail[16] = {0};
+      for (int j = 0; at + j < left; ++j) tail[j] = in[at + j];
+      __builtin_memcpy(&x, tail, 16);
+    }
+    if (cell < CELLS) *(u32x4*)(tile + 4 * cell) = x;
   }
   __syncthreads();
   const int c8 = c0 + 8 * threadIdx.x;
@@ -1029,29 +1036,38 @@ __global__ __launch_bounds__(256) void gauss_axis_kernel(const T* __restrict__ i
   const int x = x0 + ox;
   const T* plane = in + (size_t)b * h * w;
   const int n = ALONG_X ? w : h;
-  // element i of the line through output row r of this lane (unconditional load from the clamped
-  // index, the constant selected afterwards: no branch around the load)
-  auto sample = [&](int r, int i) -> double {
+  // element i of the line through output row r of this lane: an unconditional load from the clamped index (`fetch`), the
+  // constants selected afterwards (`value`).  All loads of a step are written -- and so issued -- before the first of them
+  // is looked at: with every value examined right behind its load the compiler waited for each load before it issued
+  // the next (round 3: 16 memory round trips per tap pair).
+  auto fetch = [&](int r, int i) -> T {
     const int y = min(y0 + oy0 + r, h - 1);  // (rows past the window are computed and not stored)
     const int ic = min(max(i, 0), n - 1);
-    const T v = ALONG_X ? plane[(size_t)y * w + ic] : plane[(size_t)ic * w + x];
+    return ALONG_X ? plane[(size_t)y * w + ic] : plane[(size_t)ic * w + x];
+  };
+  auto value = [&](T v, int i) -> double {
     const double inside = (double)((replace_ndv && v == ndv) ? fill : v);
     return (i < 0 || i >= n) ? A.cval : inside;
   };
   auto centre = [&](int r) { return ALONG_X ? x : y0 + oy0 + r; };
   double acc[GAUSS_ROWS];
+  {
+    T raw[GAUSS_ROWS];
 #pragma unroll
-  for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] = sample(r, centre(r)) * A.w[0];
+    for (int r = 0; r < GAUSS_ROWS; ++r) raw[r] = fetch(r, centre(r));
+#pragma unroll
+    for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] = value(raw[r], centre(r)) * A.w[0];
+  }
   for (int j = A.radius; j >= 1; --j) {  // farthest pair first, as SciPy adds them
     const double wj = A.w[j];
-    double lo[GAUSS_ROWS], hi[GAUSS_ROWS];
+    T raw_lo[GAUSS_ROWS], raw_hi[GAUSS_ROWS];
 #pragma unroll
     for (int r = 0; r < GAUSS_ROWS; ++r) {
-      lo[r] = sample(r, centre(r) - j);
-      hi[r] = sample(r, centre(r) + j);
+      raw_lo[r] = fetch(r, centre(r) - j);
+      raw_hi[r] = fetch(r, centre(r) + j);
     }
 #pragma unroll
-    for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] += (lo[r] + hi[r]) * wj;
+    for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] += (value(raw_lo[r], centre(r) - j) + value(raw_hi[r], centre(r) + j)) * wj;
   }
 #pragma unroll
   for (int r = 0; r < GAUSS_ROWS; ++r)

@@ -103,12 +103,19 @@ __global__ __launch_bounds__(256) void classify_kernel(const TI* __restrict__ in
   for (int c = 0; c < chunks; ++c) {
     const unsigned long long base = first + ((unsigned long long)blockIdx.x * chunks + c) * span + (unsigned long long)threadIdx.x * K;
     TI v[CLS_U][K];
+    // a chunk that lies wholly inside the range (workgroup-uniform; every chunk but the last) loads without a test: with a
+    // per-lane test around them the compiler waited for each of the CLS_U loads before it issued the next
+    if (first + ((unsigned long long)blockIdx.x * chunks + c + 1) * span <= n_end) {
 #pragma unroll
-    for (int u = 0; u < CLS_U; ++u) {
-      const unsigned long long e = base + (unsigned long long)u * 256 * K;
+      for (int u = 0; u < CLS_U; ++u) VecK<TI, K>::load(in + base + (unsigned long long)u * 256 * K, v[u]);
+    } else {
 #pragma unroll
-      for (int k = 0; k < K; ++k) v[u][k] = 0;
-      if (e + K <= n_end) VecK<TI, K>::load(in + e, v[u]);
+      for (int u = 0; u < CLS_U; ++u) {
+        const unsigned long long e = base + (unsigned long long)u * 256 * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[u][k] = 0;
+        if (e + K <= n_end) VecK<TI, K>::load(in + e, v[u]);
+      }
     }
     if (LDS && c == 0 && !linear) {
       CT* sb = (CT*)smem;
@@ -327,12 +334,19 @@ __global__ __launch_bounds__(256) void reclassify_kernel(const TI* __restrict__ 
   for (int c = 0; c < chunks; ++c) {
     const unsigned long long base = first + ((unsigned long long)blockIdx.x * chunks + c) * span + (unsigned long long)threadIdx.x * K;
     TI v[RCL_U][K];
+    // a chunk that lies wholly inside the range (workgroup-uniform; every chunk but the last) loads without a test: with a
+    // per-lane test around them the compiler waited for each of the RCL_U loads before it issued the next
+    if (first + ((unsigned long long)blockIdx.x * chunks + c + 1) * span <= n_end) {
 #pragma unroll
-    for (int u = 0; u < RCL_U; ++u) {
-      const unsigned long long e = base + (unsigned long long)u * 256 * K;
+      for (int u = 0; u < RCL_U; ++u) VecK<TI, K>::load(in + base + (unsigned long long)u * 256 * K, v[u]);
+    } else {
 #pragma unroll
-      for (int k = 0; k < K; ++k) v[u][k] = 0;
-      if (e + K <= n_end) VecK<TI, K>::load(in + e, v[u]);
+      for (int u = 0; u < RCL_U; ++u) {
+        const unsigned long long e = base + (unsigned long long)u * 256 * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[u][k] = 0;
+        if (e + K <= n_end) VecK<TI, K>::load(in + e, v[u]);
+      }
     }
     if (LDS && c == 0) {
       // stage the table while the tile loads are in flight

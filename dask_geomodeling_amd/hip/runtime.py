@@ -7,6 +7,7 @@ raised -- loudly, never a silent CPU path.
 import ctypes
 from math import prod as _prod
 import os
+import atexit
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -54,7 +55,18 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         _declare(L)
         _lib = L
+        # kernels still being compiled in the background when the interpreter exits: wait for them here, while every
+        # library is still whole (the compiler stack's own exit handlers would otherwise run under the worker thread)
+        atexit.register(_quiesce)
     return _lib
+
+
+def _quiesce():
+    try:
+        if _lib is not None and not os.environ.get("GM_EXIT_NOWAIT"):  # (tools/exit_stress.py exercises the library's own exit path)
+            _lib.gm_spec_wait()
+    except Exception:  # (exit path: nothing to report to)
+        pass
 
 
 def _declare(L):

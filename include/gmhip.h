@@ -295,7 +295,11 @@ int gm_spec_get_mode(int* mode, uint64_t* hot_elements);
 int gm_spec_stats(uint64_t* compiled, uint64_t* disk_hits, uint64_t* launches, uint64_t* failed);
 int gm_spec_available(void);
 /* Kernels being compiled in the background: their number / wait until there are none (a benchmark calls this after
- * its warm-up so that the timed region runs the kernels it is meant to time). */
+ * its warm-up so that the timed region runs the kernels it is meant to time).  A host that may exit while a program has
+ * just become hot calls gm_spec_wait() before it does: the compiler stack registers exit handlers of its own while it
+ * works, and a process that runs them under the worker thread can crash or hang.  The library stops its worker from an
+ * exit handler (no new compilation starts, no module is loaded once the exit has begun), which covers everything but an
+ * exit in the middle of a compilation; the Python package calls gm_spec_wait() from the interpreter's exit hook. */
 int gm_spec_pending(uint64_t* pending);
 int gm_spec_wait(void);
 /* Calls of gm_elemwise_run* so far and the longest time any of them kept its caller (milliseconds) -- what a caller
