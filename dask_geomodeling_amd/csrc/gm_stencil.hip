@@ -262,11 +262,22 @@ __global__ __launch_bounds__(256) void dilate8_kernel(const unsigned char* __res
   };
 #pragma unroll
   for (int k = 0; k < DIL8_MAX_VALUES; ++k) horiz_prev[k] = eq_prev[k] = eq_prev2[k] = band_prev[k] = 0;
+  // (a wave whose lanes all have their 8 bytes inside the row -- every wave but the last of a row -- loads without the
+  // per-lane test of load_window8: with that test around them the loads went out one memory round trip at a time)
+  const bool all_inside = __all(c4 + 8 <= w);
+  auto window = [&](const unsigned char* p) -> unsigned long long {
+    if (all_inside) {
+      unsigned long long x;
+      __builtin_memcpy(&x, p, 8);
+      return x;
+    }
+    return load_window8(p, c4, w, 0);
+  };
   auto fetch = [&](int y, unsigned long long& win, unsigned long long& up, unsigned long long& down) {
     const unsigned char* row = base + (size_t)y * w;
-    win = load_window8(row, c4, w, 0);
-    up = has_up ? load_window8(row - plane, c4, w, 0) : 0ull;
-    down = has_down ? load_window8(row + plane, c4, w, 0) : 0ull;
+    win = window(row);
+    up = has_up ? window(row - plane) : 0ull;
+    down = has_down ? window(row + plane) : 0ull;
   };
   // input rows r0, r0 + 1 prime the state (no output), then input row y + 1 completes output row y - 1 ... :
   // output row r has centre input row r + 1 and is complete once input row r + 2 was absorbed
