@@ -123,7 +123,8 @@ __device__ __forceinline__ bool skipped(Tin v, Tin ndv, bool has_ndv, C& x) {
   return nd;
 }
 
-constexpr int TB_UNROLL = 4;  // frames in flight per lane
+
+constexpr int TB_UNROLL = 4;  // frames in flight per lane (the median kernels' passes)
 
 // grid: x over groups of 256 * V pixels, y over bins
 template <typename Tin, int STAT, int V>
@@ -163,19 +164,23 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const Tin* __restrict__ 
       }
     }
   };
+  // Rounds of 8, 4, 2, 1 frames (`count` is the same for the whole workgroup), every round's loads requested before the
+  // first of them is looked at: a bin of any length takes its frames in at most count / 8 + 3 dependent memory round
+  // trips and reads nothing twice (round 3: the first frame used to go alone and the last count mod 4 one by one).
   int j = 0;
-  if (count > 0) {
-    take(load_pack<Tin, V>(src), true);
-    j = 1;
-  }
-  for (; j + TB_UNROLL <= count; j += TB_UNROLL) {
-    Pack<Tin, V> f[TB_UNROLL];
+  auto round = [&](auto n_) {
+    constexpr int N = decltype(n_)::value;
+    Pack<Tin, V> f[N];
 #pragma unroll
-    for (int u = 0; u < TB_UNROLL; ++u) f[u] = load_pack<Tin, V>(src + (long long)(j + u) * pixels);
+    for (int u = 0; u < N; ++u) f[u] = load_pack<Tin, V>(src + (long long)(j + u) * pixels);
 #pragma unroll
-    for (int u = 0; u < TB_UNROLL; ++u) take(f[u], false);
-  }
-  for (; j < count; ++j) take(load_pack<Tin, V>(src + (long long)j * pixels), false);
+    for (int u = 0; u < N; ++u) take(f[u], j + u == 0);
+    j += N;
+  };
+  while (count - j >= 8) round(std::integral_constant<int, 8>());
+  if (count - j >= 4) round(std::integral_constant<int, 4>());
+  if (count - j >= 2) round(std::integral_constant<int, 2>());
+  if (count - j >= 1) round(std::integral_constant<int, 1>());
 
   Pack<Tout, V> res;
   if constexpr (STAT == GM_STAT_COUNT) {
@@ -205,18 +210,19 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const Tin* __restrict__ 
         }
       };
       int k = 0;
-      if (count > 0) {
-        dev(load_pack<Tin, V>(src), true);
-        k = 1;
-      }
-      for (; k + TB_UNROLL <= count; k += TB_UNROLL) {
-        Pack<Tin, V> f[TB_UNROLL];
+      auto round2 = [&](auto n_) {
+        constexpr int N = decltype(n_)::value;
+        Pack<Tin, V> f[N];
 #pragma unroll
-        for (int u = 0; u < TB_UNROLL; ++u) f[u] = load_pack<Tin, V>(src + (long long)(k + u) * pixels);
+        for (int u = 0; u < N; ++u) f[u] = load_pack<Tin, V>(src + (long long)(k + u) * pixels);
 #pragma unroll
-        for (int u = 0; u < TB_UNROLL; ++u) dev(f[u], false);
-      }
-      for (; k < count; ++k) dev(load_pack<Tin, V>(src + (long long)k * pixels), false);
+        for (int u = 0; u < N; ++u) dev(f[u], k + u == 0);
+        k += N;
+      };
+      while (count - k >= 8) round2(std::integral_constant<int, 8>());
+      if (count - k >= 4) round2(std::integral_constant<int, 4>());
+      if (count - k >= 2) round2(std::integral_constant<int, 2>());
+      if (count - k >= 1) round2(std::integral_constant<int, 1>());
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         C var = cnt[e] > 0 ? (C)((double)sq[e] / (double)cnt[e]) : std::numeric_limits<C>::quiet_NaN();
@@ -271,15 +277,20 @@ __global__ __launch_bounds__(256) void cumulative_kernel(const Tin* __restrict__
     const int frame = first + j;
     if (frame >= emit_first && frame < emit_stop) store_pack<Tout, V>(out + (long long)(frame - emit_first) * pixels + p, res);
   };
-  int j = 0;
-  for (; j + TB_UNROLL <= count; j += TB_UNROLL) {
-    Pack<Tin, V> f[TB_UNROLL];
+  int j = 0;  // (rounds of 8, 4, 2, 1 frames as in aggregate_kernel)
+  auto round = [&](auto n_) {
+    constexpr int N = decltype(n_)::value;
+    Pack<Tin, V> f[N];
 #pragma unroll
-    for (int u = 0; u < TB_UNROLL; ++u) f[u] = load_pack<Tin, V>(src + (long long)(j + u) * pixels);
+    for (int u = 0; u < N; ++u) f[u] = load_pack<Tin, V>(src + (long long)(j + u) * pixels);
 #pragma unroll
-    for (int u = 0; u < TB_UNROLL; ++u) step(f[u], j + u);
-  }
-  for (; j < count; ++j) step(load_pack<Tin, V>(src + (long long)j * pixels), j);
+    for (int u = 0; u < N; ++u) step(f[u], j + u);
+    j += N;
+  };
+  while (count - j >= 8) round(std::integral_constant<int, 8>());
+  if (count - j >= 4) round(std::integral_constant<int, 4>());
+  if (count - j >= 2) round(std::integral_constant<int, 2>());
+  if (count - j >= 1) round(std::integral_constant<int, 1>());
 }
 
 // Median: the data frames of a cell are insertion-sorted into the lane's column of an LDS array
