@@ -362,10 +362,17 @@ constexpr unsigned ZB = 256;            // cells per block
 // wave-per-label kernel, 0.61 through the pipeline -- their sums stay small against the cells, most blocks are replayed);
 // GM_ZONAL_LONG overrides it (the tests run small labels through the pipeline too)
 constexpr unsigned ZL_LONG = 65536;
-struct BlockInfo {
-  long long D[2], lo[2], hi[2];  // per parity of the incoming sum: total, lowest and highest prefix, in units of u
-  int E;                         // the binade the block was analysed for; INT_MIN: not analysed (replay it)
-  int negative;                  // the sum it was analysed for is negative (the block is mirrored)
+struct BlockInfo {  // 32 bytes
+  // Units added for an even incoming sum; for an odd one D0 + delta (the two trajectories take the same steps until the first
+  // exact tie, differ by one unit in that step, and are both even -- hence identical -- from there on: delta is -1, 0 or 1).
+  long long D0;
+  // lowest / highest prefix relative to the incoming sum, over BOTH parities (they differ by at most that one unit, so the
+  // test is conservative by at most one unit -- a block it turns away needlessly is added literally, which is always right)
+  long long lo, hi;
+  int E;      // the binade the block was analysed for; INT_MIN: not analysed (add it literally)
+  int flags;  // bit 0: the sum it was analysed for is negative (the block is mirrored); bit 1: expected to be added literally;
+              // bits 2-3: delta + 1
+  __device__ __forceinline__ long long D(int parity) const { return D0 + (parity ? ((flags >> 2) & 3) - 1 : 0); }
 };
 
 template <typename T>
@@ -483,6 +490,108 @@ __device__ __forceinline__ ParityFn shuffle_up_fn(const ParityFn& f, int delta) 
   return r;
 }
 
+// what a lane's 4 cells do to (sum in units of u, parity) for the binade E and sign of the sum, and the lowest / highest prefix
+// inside them, for either parity coming in
+struct LaneFn {
+  ParityFn f;
+  double lo[2], hi[2];
+};
+__device__ __forceinline__ LaneFn lane_function(const double* x, int E, bool negative) {
+  const double scale = E == INT_MIN ? 1.0 : ldexp(negative ? -1.0 : 1.0, 52 - E);  // cell -> signed units of u
+  double k[4], frac[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const double t = x[c] * scale;  // exact: a power of two (|E| < 900 keeps it far from overflow and underflow)
+    k[c] = floor(t);
+    frac[c] = t - k[c];             // exact, in [0, 1)
+  }
+  LaneFn r;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    int parity = p;
+    double sum = 0.0, low = 1.0e300, high = -1.0e300;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k_odd = (int)(k[c] - 2.0 * floor(k[c] * 0.5));
+      // the rounding: up for more than half a unit, to even on exactly half (which leaves an even sum)
+      const int up = frac[c] == 0.5 ? (parity ^ k_odd) : (frac[c] > 0.5 ? 1 : 0);
+      sum += k[c] + (double)up;
+      parity ^= k_odd ^ up;
+      low = fmin(low, sum);
+      high = fmax(high, sum);
+    }
+    r.f.S[p] = sum;
+    r.f.q[p] = parity;
+    r.lo[p] = low;
+    r.hi[p] = high;
+  }
+  return r;
+}
+// the functions of WIDTH consecutive lanes composed in lane order (the group's last lane ends up with the total) and the
+// lowest / highest prefix anywhere in the group (every lane of the group ends up with them)
+template <int WIDTH>
+__device__ __forceinline__ void group_function(const LaneFn& m, int lane, ParityFn* total, double* lowest, double* highest) {
+  const int at = lane & (WIDTH - 1);
+  ParityFn scan = m.f;
+#pragma unroll
+  for (int off = 1; off < WIDTH; off <<= 1) {
+    const ParityFn before = shuffle_up_fn(scan, off);
+    if (at >= off) scan = compose(before, scan);
+  }
+  ParityFn excl = shuffle_up_fn(scan, 1);
+  if (at == 0) {
+    excl.S[0] = excl.S[1] = 0.0;
+    excl.q[0] = 0;
+    excl.q[1] = 1;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    lowest[p] = excl.S[p] + (excl.q[p] ? m.lo[1] : m.lo[0]);
+    highest[p] = excl.S[p] + (excl.q[p] ? m.hi[1] : m.hi[0]);
+#pragma unroll
+    for (int off = 1; off < WIDTH; off <<= 1) {
+      lowest[p] = fmin(lowest[p], shuffle_xor(lowest[p], off));
+      highest[p] = fmax(highest[p], shuffle_xor(highest[p], off));
+    }
+  }
+  *total = scan;
+}
+// the description of a group of cells from its composed function (call on the group's last lane); *risky: the sum predicted
+// to enter it would take a prefix out of the binade (or the group is not analysable at all)
+__device__ __forceinline__ BlockInfo describe(const ParityFn& total, const double* lowest, const double* highest, int E, bool negative,
+                                              double pred, bool all_finite) {
+  BlockInfo out;
+  // (offsets that could take a sum out of its binade anyway -- beyond 2^60 units -- are not worth an integer)
+  bool small = true;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) small = small && fabs(total.S[p]) < 0x1p60 && fabs(lowest[p]) < 0x1p60 && fabs(highest[p]) < 0x1p60;
+  const long long d0 = small ? (long long)total.S[0] : 0, d1 = small ? (long long)total.S[1] : 0;
+  const long long delta = d1 - d0;  // (-1, 0 or 1: see BlockInfo; anything else would be a flaw in the analysis)
+  out.E = (E != INT_MIN && all_finite && small && delta >= -1 && delta <= 1) ? E : INT_MIN;
+  out.D0 = d0;
+  out.lo = small ? (long long)fmin(lowest[0], lowest[1]) : 0;
+  out.hi = small ? (long long)fmax(highest[0], highest[1]) : 0;
+  // Will the group be added literally?  Known ahead with near certainty: the predicted sum entering it is off the exact one
+  // by parts in 10^9 of its binade, its prefixes range over parts in 10^3 and more.
+  bool risky = out.E == INT_MIN;
+  if (!risky) {
+    const double entering = fabs(pred) * ldexp(1.0, 52 - E), slack = 0x1p30;  // units of u, in [2^52, 2^53)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) risky = risky || entering + lowest[p] < 0x1p52 + slack || entering + highest[p] > 0x1p53 - slack;
+  }
+  out.flags = (negative ? 1 : 0) | (risky ? 2 : 0) | ((int)((delta >= -1 && delta <= 1 ? delta : 0) + 1) << 2);
+  return out;
+}
+__device__ __forceinline__ int binade_of(double pred) {
+  if (pred != 0.0 && fabs(pred) <= 1.7976931348623157e308) {
+    const int e = ilogb(fabs(pred));
+    if (e > -900 && e < 900) return e;
+  }
+  return INT_MIN;
+}
+
+// Per block: its description for the binade the predicted sum is in (flags bit 1: the block will be added literally -- the
+// composing wave requests the cells of those blocks ahead).
 template <typename T>
 __global__ __launch_bounds__(256) void zonal_block_info_kernel(const typename Ordered<T>::Key* __restrict__ payload,
                                                                const unsigned* __restrict__ first, unsigned cells,
@@ -494,88 +603,21 @@ __global__ __launch_bounds__(256) void zonal_block_info_kernel(const typename Or
   if (l < 0) return;
   if (first[l + 1] - first[l] < long_from) return;
   const double pred = blk_pred[j];
-  int E = INT_MIN;
-  if (pred != 0.0 && fabs(pred) <= 1.7976931348623157e308) {
-    const int e = ilogb(fabs(pred));
-    if (e > -900 && e < 900) E = e;
-  }
+  const int E = binade_of(pred);
   const bool negative = pred < 0.0;
-  const double scale = E == INT_MIN ? 1.0 : ldexp(negative ? -1.0 : 1.0, 52 - E);  // cell -> signed units of u
-  // the lane's 4 cells, in order, for either parity coming in
-  ParityFn mine;
-  double lo[2], hi[2];
+  double x[4];
   bool finite = true;
-  {
-    double k[4], frac[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const double x = (double)Ordered<T>::decode(payload[j * ZB + 4 * lane + c]);
-      finite = finite && fabs(x) <= 1.7976931348623157e308;
-      const double t = x * scale;  // exact: a power of two (|E| < 900 keeps it far from overflow and underflow)
-      k[c] = floor(t);
-      frac[c] = t - k[c];          // exact, in [0, 1)
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      int parity = p;
-      double sum = 0.0, low = 1.0e300, high = -1.0e300;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int k_odd = (int)(k[c] - 2.0 * floor(k[c] * 0.5));
-        // the rounding: up for more than half a unit, to even on exactly half (which leaves an even sum)
-        const int up = frac[c] == 0.5 ? (parity ^ k_odd) : (frac[c] > 0.5 ? 1 : 0);
-        sum += k[c] + (double)up;
-        parity ^= k_odd ^ up;
-        low = fmin(low, sum);
-        high = fmax(high, sum);
-      }
-      mine.S[p] = sum;
-      mine.q[p] = parity;
-      lo[p] = low;
-      hi[p] = high;
-    }
+  for (int c = 0; c < 4; ++c) {
+    x[c] = (double)Ordered<T>::decode(payload[j * ZB + 4 * lane + c]);
+    finite = finite && fabs(x[c]) <= 1.7976931348623157e308;
   }
-  // inclusive scan of the lanes' functions, in lane order
-  ParityFn scan = mine;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const ParityFn before = shuffle_up_fn(scan, off);
-    if ((int)lane >= off) scan = compose(before, scan);
-  }
-  ParityFn excl = shuffle_up_fn(scan, 1);
-  if (lane == 0) {
-    excl.S[0] = excl.S[1] = 0.0;
-    excl.q[0] = 0;
-    excl.q[1] = 1;
-  }
+  const unsigned long long finite_lanes = __ballot(finite);
+  const LaneFn mine = lane_function(x, E, negative);
+  ParityFn total;
   double lowest[2], highest[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    lowest[p] = excl.S[p] + (excl.q[p] ? lo[1] : lo[0]);
-    highest[p] = excl.S[p] + (excl.q[p] ? hi[1] : hi[0]);
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      lowest[p] = fmin(lowest[p], shuffle_xor(lowest[p], off));
-      highest[p] = fmax(highest[p], shuffle_xor(highest[p], off));
-    }
-  }
-  const bool all_finite = __all(finite);
-  if (lane == 63) {
-    BlockInfo out;
-    // (offsets that could take a sum out of its binade anyway -- beyond 2^60 units -- are not worth an integer)
-    bool small = true;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) small = small && fabs(scan.S[p]) < 0x1p60 && fabs(lowest[p]) < 0x1p60 && fabs(highest[p]) < 0x1p60;
-    out.E = (all_finite && small) ? E : INT_MIN;
-    out.negative = negative ? 1 : 0;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      out.D[p] = small ? (long long)scan.S[p] : 0;
-      out.lo[p] = small ? (long long)lowest[p] : 0;
-      out.hi[p] = small ? (long long)highest[p] : 0;
-    }
-    info[j] = out;
-  }
+  group_function<64>(mine, (int)lane, &total, lowest, highest);
+  if (lane == 63) info[j] = describe(total, lowest, highest, E, negative, pred, finite_lanes == ~0ull);
 }
 
 // the same composition over whole blocks, in integer units
@@ -621,20 +663,17 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
   double* mine = parked[wave];
   double acc = 0.0;
   // cells [from, to), at most ZB of them, added one after the other (the chain of zonal_sum_kernel's replay)
-  auto literally = [&](unsigned from, unsigned to) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const unsigned at = from + 4 * lane + k;
-      mine[4 * lane + k] = at < to ? (double)Ordered<T>::decode(payload[at]) : 0.0;  // (+0.0 changes nothing)
-    }
-    // 16 values (8 sixteen-byte reads) per round, the next round's reads issued before this round's 16 additions: the
-    // chain never waits for LDS (rounds past the stretch add the +0.0 padding)
+  typedef typename Ordered<T>::Key Key;
+  // the n parked values (n <= ZB; the rest of the last round is +0.0 padding) added one after the other: 16 values (8
+  // sixteen-byte reads) per round, the next round's reads issued before this round's 16 additions -- the chain never waits for LDS
+  auto chain = [&](unsigned n) {
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     constexpr int ROUND = 16;
-    const int rounds = (int)((to - from + ROUND - 1) / ROUND);
+    const int rounds = (int)((n + ROUND - 1) / ROUND);
     f64x2 buffer[2][ROUND / 2];
 #pragma unroll
     for (int k = 0; k < ROUND / 2; ++k) buffer[0][k] = *reinterpret_cast<const f64x2*>(mine + 2 * k);
+#pragma unroll 1  // (a real loop also where n is a constant: unrolled, the optimiser hoists every LDS read to the front -- 512 registers)
     for (int round = 0; round < rounds; round += 2) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -653,8 +692,25 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
       }
     }
   };
+  auto literally = [&](unsigned from, unsigned to) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned at = from + 4 * lane + k;
+      mine[4 * lane + k] = at < to ? (double)Ordered<T>::decode(payload[at]) : 0.0;  // (+0.0 changes nothing)
+    }
+    chain(to - from);
+  };
+  struct Cells {
+    Key k[4];  // the lane's four cells of the block
+  };
+  auto request = [&](unsigned block) -> Cells {  // (used later: the loads are only issued here)
+    Cells c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c.k[k] = payload[block * ZB + 4 * lane + k];
+    return c;
+  };
   const unsigned j0 = (a + ZB - 1) / ZB, j1 = b / ZB;
-  unsigned n_replayed = 0;
+  unsigned n_replayed = 0, n_ahead = 0;  // literal blocks; those among them whose cells had been requested ahead
   if (j0 * ZB > a) literally(a, min(j0 * ZB, b));
   // Between literal stretches the sum lives as (binade E, sign, integer s = |sum| / u in [2^52, 2^53)): a block that is
   // valid for it is a handful of scalar integer operations.  The blocks' descriptions are fetched 64 at a time (a lane
@@ -710,7 +766,21 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
 #pragma unroll
     for (int k = 0; k < PER; ++k) B[k] = ahead[k];
     if (g + 64 * PER < j1) fetch(g + 64 * PER, ahead);
+    // the first block from `from_idx` on that the info kernel expects to be added literally (64 * PER: none in this group)
+    auto next_risky = [&](unsigned from_idx) -> unsigned {
+      unsigned first_risky = 64u * PER;
+#pragma unroll
+      for (int k = PER - 1; k >= 0; --k) {
+        const unsigned idx = (unsigned)(PER * lane + k);
+        if (idx >= from_idx && idx < here && (B[k].flags & 2)) first_risky = idx;
+      }
+      const unsigned long long any = __ballot(first_risky < 64u * PER);
+      if (any == 0) return 64u * PER;
+      return (unsigned)__builtin_amdgcn_readlane((int)first_risky, __ffsll((long long)any) - 1);
+    };
     unsigned start = 0;
+    unsigned wanted = next_risky(0);  // its cells are requested now and used when the composition stops there
+    Cells ahead_cells = request(g + min(wanted, here - 1));
     while (start < here) {
       UnitsFn scan;
       scan.S[0] = scan.S[1] = 0;
@@ -723,8 +793,8 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
           UnitsFn f;
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
-            f.S[p] = B[k].D[p];
-            f.q[p] = (int)((p + B[k].D[p]) & 1);
+            f.S[p] = B[k].D(p);
+            f.q[p] = (int)((p + B[k].D(p)) & 1);
           }
           scan = compose_units(scan, f);
         }
@@ -749,16 +819,16 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
       for (int k = 0; k < PER; ++k) {
         const unsigned idx = (unsigned)(PER * lane + k);
         if (idx >= start && idx < here && failed < 0) {
-          const long long lowest = entering + (parity ? B[k].lo[1] : B[k].lo[0]), highest = entering + (parity ? B[k].hi[1] : B[k].hi[0]);
+          const long long lowest = entering + B[k].lo, highest = entering + B[k].hi;
           // every prefix strictly inside the binade (one unit of margin below: the exact value before a rounding may lie
           // half a unit under the rounded one)
-          const bool valid = as_integer && B[k].E == E && B[k].negative == negative && lowest >= 4503599627370497ll &&
+          const bool valid = as_integer && B[k].E == E && (B[k].flags & 1) == negative && lowest >= 4503599627370497ll &&
                              highest <= 9007199254740991ll;
           if (!valid) {
             failed = (int)idx;
             failed_entering = entering;
           } else {
-            const long long d = parity ? B[k].D[1] : B[k].D[0];
+            const long long d = B[k].D(parity);
             entering += d;
             parity = (int)((parity + d) & 1);
           }
@@ -774,7 +844,25 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
         const unsigned k = (unsigned)__builtin_amdgcn_readlane(failed, from);
         units = pass(failed_entering, from);
         to_double();
-        literally((g + k) * ZB, (g + k) * ZB + ZB);
+        if (k == wanted) {
+          // the cells asked for earlier; the next expected block's are requested before this block's chain starts.
+          // (Tried and dropped: descriptions per quarter of such a block, so that only the quarter in which the sum crosses
+          // the power of two is added literally -- around a power of two the sum of zero-mean data wanders back and forth,
+          // 2.04 of the 4 quarters stay literal, and the extra conversions cost more than the shorter chains save: 3.9 -> 4.6 ms.)
+          const Cells now = ahead_cells;
+          wanted = next_risky(k + 1);
+          ahead_cells = request(g + min(wanted, here - 1));
+#pragma unroll
+          for (int c = 0; c < 4; ++c) mine[4 * lane + c] = (double)Ordered<T>::decode(now.k[c]);
+          chain(ZB);
+          ++n_ahead;
+        } else {
+          literally((g + k) * ZB, (g + k) * ZB + ZB);
+          if (wanted < k + 1) {  // (the expected block was passed without stopping: look further)
+            wanted = next_risky(k + 1);
+            ahead_cells = request(g + min(wanted, here - 1));
+          }
+        }
         to_integer();
         ++n_replayed;
         start = k + 1;
@@ -787,7 +875,10 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
     const unsigned n = b - a;
     counts[l] = n;
     out[l] = statistic == Z_MEAN ? (float)(acc / (double)n) : (float)acc;
-    if (replayed) atomicAdd(replayed, n_replayed);
+    if (replayed) {
+      atomicAdd(replayed, n_replayed);
+      atomicAdd(replayed + 1, n_ahead);
+    }
   }
 }
 
@@ -1736,7 +1827,8 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
           unsigned host[8] = {0};
           GM_HIP(hipMemcpyAsync(host, replayed, sizeof(host), hipMemcpyDeviceToHost, s));
           GM_HIP(hipStreamSynchronize(s));
-          fprintf(stderr, "[gmhip] zonal block pipeline: %zu blocks, %u of them added literally\n", n_blocks, host[0]);
+          fprintf(stderr, "[gmhip] zonal block pipeline: %zu blocks, %u of them added literally (%u with their cells requested ahead)\n",
+                  n_blocks, host[0], host[1]);
           (void)gm_free(replayed);
         }
       }
