@@ -3,10 +3,10 @@
 // K6 nearest: the warp every source read performs (raster/sources.py:119-149 hands it
 //   to GDAL's GRA_NearestNeighbour) for axis-aligned same-CRS requests, and SciPy's
 //   affine_transform(order=0) of Smooth's zoom branch (raster/spatial.py:296-305).
-//   The separable destination->source index maps are computed once per launch in
-//   float64 (same operation order as the oracle, FMA contraction off) into small
-//   int32 tables; the gather kernel is output-stationary: a lane owns 4 consecutive
-//   destination columns (one 16-byte store) and walks a strip of rows.
+//   The separable destination->source index maps are evaluated inside the gather kernel in
+//   float64 (same operation order as the oracle, FMA contraction off; until round 3 two
+//   small kernels wrote them into int32 tables first); the gather kernel is output-stationary:
+//   a lane owns 4 consecutive destination columns (one 16-byte store) and walks a strip of rows.
 //
 // K7 bilinear (our spec -- the reference has none): pixel-centre aligned,
 //   edge-clamped, evaluated in float64 and rounded once.  A workgroup owns a
@@ -18,7 +18,7 @@
 namespace {
 
 // ---------------------------------------------------------------------------------
-// index tables
+// index maps
 // ---------------------------------------------------------------------------------
 // mode 0 (warp):   idx = floor(((o_dst + (k + 0.5) * s_dst) - o_src) / s_src + eps)
 // mode 1 (affine): idx = floor(k * z + off + 0.5)            params = {z, off, -, -}

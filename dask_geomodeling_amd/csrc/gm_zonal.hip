@@ -1105,7 +1105,55 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
       }
     }
   });
-  flush();
+  // The run a wave ENDS in meets the other three waves' in LDS, and waves that end in the same label issue their atomics
+  // together: under a label that covers the raster every wave ends on the same counters, and atomics on one address
+  // serialise (round 3: 4 x fewer of them; count under one label 111 -> see DESIGN K14).
+  __shared__ int end_label[4];
+  __shared__ unsigned long long end_count[4];
+  __shared__ Key end_key[4];
+  {
+    unsigned long long n = run_count;
+    Key key = run_key;
+#pragma unroll
+    for (int offset = 32; offset >= 1; offset >>= 1) {
+      n += __shfl_xor((unsigned)n, offset);
+      if constexpr (STAT != Z_COUNT) {
+        Key other;
+        if constexpr (sizeof(Key) == 8) {
+          const unsigned lo = __shfl_xor((unsigned)key, offset), hi = __shfl_xor((unsigned)(key >> 32), offset);
+          other = ((Key)hi << 32) | lo;
+        } else {
+          other = __shfl_xor(key, offset);
+        }
+        key = better(key, other);
+      }
+    }
+    if (lane == 0) {
+      const int w = threadIdx.x >> 6;
+      end_label[w] = (run_label >= 0 && n != 0) ? run_label : -1;
+      end_count[w] = n;
+      end_key[w] = key;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 0; w < 4; ++w) {
+      const int label = end_label[w];
+      if (label < 0) continue;
+      unsigned long long n = end_count[w];
+      Key key = end_key[w];
+      for (int v = w + 1; v < 4; ++v) {
+        if (end_label[v] == label) {
+          n += end_count[v];
+          key = better(key, end_key[v]);
+          end_label[v] = -1;
+        }
+      }
+      atomicAdd(&counts[label], n);
+      if constexpr (STAT == Z_MIN) atomicMin(&extreme[label], key);
+      if constexpr (STAT == Z_MAX) atomicMax(&extreme[label], key);
+    }
+  }
 }
 
 template <typename T, int STAT>
@@ -1281,7 +1329,77 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
       }
     }
   });
-  flush();
+  // the run a wave ENDS in: combined across the workgroup before it goes to the label's counters (see zonal_direct_kernel)
+  __shared__ int end_label[4];
+  __shared__ unsigned long long end_count[4];
+  __shared__ int end_hi[4], end_lo[4];
+  __shared__ unsigned end_bad[4];
+  __shared__ double end_sum[4];
+  {
+    const int w = threadIdx.x >> 6;
+    if constexpr (PHASE == 0) {
+      if (tile_counts && run_label >= 0) tile_flush();
+      unsigned n = run_count, bad = run_bad;
+      int hi = run_hi, lo = run_lo;
+#pragma unroll
+      for (int offset = 32; offset >= 1; offset >>= 1) {
+        n += __shfl_xor(n, offset);
+        bad |= __shfl_xor(bad, offset);
+        hi = max(hi, __shfl_xor(hi, offset));
+        lo = min(lo, __shfl_xor(lo, offset));
+      }
+      if (lane == 0) {
+        end_label[w] = (run_label >= 0 && n != 0) ? run_label : -1;
+        end_count[w] = n;
+        end_hi[w] = hi;
+        end_lo[w] = lo;
+        end_bad[w] = bad;
+      }
+    } else {
+      double total = run_sum;
+#pragma unroll
+      for (int offset = 32; offset >= 1; offset >>= 1) total += shuffle_xor(total, offset);  // (exact: see above)
+      if (lane == 0) {
+        end_label[w] = run_label;
+        end_sum[w] = total;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 0; w < 4; ++w) {
+      const int label = end_label[w];
+      if (label < 0) continue;
+      if constexpr (PHASE == 0) {
+        unsigned long long n = end_count[w];
+        int hi = end_hi[w], lo = end_lo[w];
+        unsigned bad = end_bad[w];
+        for (int v = w + 1; v < 4; ++v) {
+          if (end_label[v] == label) {
+            n += end_count[v];
+            hi = max(hi, end_hi[v]);
+            lo = min(lo, end_lo[v]);
+            bad |= end_bad[v];
+            end_label[v] = -1;
+          }
+        }
+        ExactRange* slot = range + label;
+        atomicAdd(&slot->count, n);
+        atomicMax(&slot->hi, hi);
+        atomicMin(&slot->lo, lo);
+        if (bad) atomicOr(&slot->bad, 1u);
+      } else {
+        double total = end_sum[w];
+        for (int v = w + 1; v < 4; ++v) {
+          if (end_label[v] == label) {
+            total += end_sum[v];  // (exact like every addition of this pass)
+            end_label[v] = -1;
+          }
+        }
+        atomicAdd(&sums[label], total);
+      }
+    }
+  }
   if constexpr (PHASE == 0) {
     if (tile_counts && lane == 0 && idle) atomicAdd(&tile_counts[run_tile * bins + n_labels], idle);
   }
