@@ -1533,6 +1533,58 @@ __device__ __forceinline__ void partition_histogram(const unsigned* __restrict__
   }
 }
 
+// zonal_keys_kernel and the counting pass in one (where the keys do not come from zonal_exact_kernel): a workgroup per tile
+// turns its cells into (key, payload) and histograms the keys on the way
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void zonal_keys_count_kernel(const T* __restrict__ values, const int* __restrict__ labels,
+                                                                   unsigned cells, int n_labels, int has_ndv, T ndv,
+                                                                   const float* __restrict__ thresholds, unsigned* __restrict__ keys,
+                                                                   typename Ordered<T>::Key* __restrict__ payload,
+                                                                   unsigned char* __restrict__ present, unsigned* __restrict__ counts) {
+  __shared__ unsigned hist[ZP_BINS];
+  const int bins = n_labels + 1;
+  for (int b = threadIdx.x; b < bins; b += 64 * NW) hist[b] = 0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int WAVE_CELLS = ZP_TILE / NW, STEPS = WAVE_CELLS / 64, GROUP = STEPS < 8 ? STEPS : 8;
+  const unsigned begin = blockIdx.x * (unsigned)ZP_TILE + (unsigned)wave * WAVE_CELLS;
+  for (int step0 = 0; step0 < STEPS; step0 += GROUP) {
+    T v[GROUP];
+    int label[GROUP];
+#pragma unroll
+    for (int k = 0; k < GROUP; ++k) {
+      const unsigned i = min(begin + (unsigned)(step0 + k) * 64u + (unsigned)lane, cells - 1);
+      v[k] = values[i];
+      label[k] = labels[i];
+    }
+#pragma unroll
+    for (int k = 0; k < GROUP; ++k) {
+      const unsigned i = begin + (unsigned)(step0 + k) * 64u + (unsigned)lane;
+      const bool inside = i < cells;
+      const bool labelled = (unsigned)label[k] < (unsigned)n_labels;
+      if (present && inside && labelled) present[label[k]] = 1;
+      bool active = labelled && !(has_ndv && v[k] == ndv);
+      if (thresholds && active) {
+        const float t = thresholds[label[k]];
+        active = !(t != t) && (double)v[k] >= (double)t;
+      }
+      const unsigned key = inside ? (active ? (unsigned)label[k] : (unsigned)n_labels) : ~0u;
+      if (inside) {
+        keys[i] = key;
+        payload[i] = Ordered<T>::encode(v[k]);
+      }
+      const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)key);
+      if (__all(key == f)) {
+        if (lane == 0 && f != ~0u) atomicAdd(&hist[f], 64u);
+      } else if (key != ~0u) {
+        atomicAdd(&hist[key], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += 64 * NW) counts[(size_t)blockIdx.x * bins + b] = hist[b];
+}
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void zonal_part_count_kernel(const unsigned* __restrict__ keys, unsigned cells, int bins,
                                                                    unsigned* __restrict__ counts) {
@@ -1634,7 +1686,7 @@ __global__ __launch_bounds__(64 * NW) void zonal_part_scatter_kernel(const unsig
         if (f == ~0u) continue;
         const unsigned base = mine[f];
         if (lane == 0) mine[f] = base + 64u;
-        out_keys[base + lane] = f;
+        if (out_keys) out_keys[base + lane] = f;  // (the select path only wants the payloads)
         out_payload[base + lane] = cell[k];
         continue;
       }
@@ -1644,11 +1696,203 @@ __global__ __launch_bounds__(64 * NW) void zonal_part_scatter_kernel(const unsig
       if (valid) {
         const unsigned base = mine[label[k]];
         if (rank + 1 == count) mine[label[k]] = base + count;
-        out_keys[base + rank] = label[k];
+        if (out_keys) out_keys[base + rank] = label[k];
         out_payload[base + rank] = cell[k];
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------
+// medians and percentiles by radix SELECT (round 3; up to ZP_BINS - 1 labels)
+// ---------------------------------------------------------------------------------
+// lexsort((values, labels)) costs two full radix sorts (0.44 + 0.24 ms for 12.6 M float32 cells) to read two cells per
+// label.  Instead: the cells are partitioned by label (the counting pass above; their order inside a label is immaterial
+// here), and every label finds the key of its wanted rank digit by digit from the top: per 8-bit digit one pass over the
+// partitioned keys builds, per label, the histogram of that digit among the cells that match the digits chosen so far
+// (a wave keeps the histogram of the label it is in in LDS and sends it to the label's 256 global counters when the label
+// changes -- the array is sorted by label, so that is once per label and wave), and a lane per label picks the digit that
+// holds the rank.  sizeof(T) passes (the order-preserving keys of narrow types have zero upper bytes); then, for a label
+// that also needs the element one rank up (an even count, a fractional percentile index) and has no second cell equal to
+// the selected key, one more pass finds the smallest key above it.
+struct SelectState {
+  unsigned long long prefix;  // the digits chosen so far, in place
+  unsigned rank;              // rank of the wanted cell among the cells that match the prefix
+  unsigned n_eq;              // (after the last pass) cells equal to the selected key
+  unsigned want_next;         // the cell one rank up is wanted as well
+  unsigned count;             // active cells of the label
+};
+constexpr int SEL_WAVE = 4096;  // cells a wave walks per pass
+
+__global__ __launch_bounds__(256) void zonal_select_init_kernel(const unsigned* __restrict__ first, int n_labels, int statistic,
+                                                                double qval, SelectState* __restrict__ state,
+                                                                unsigned long long* __restrict__ next) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= n_labels) return;
+  const unsigned n = first[l + 1] - first[l];
+  SelectState st{0ull, 0u, 0u, 0u, n};
+  if (n != 0) {
+    if (statistic == Z_MEDIAN) {  // scipy.ndimage._measurements._select: the two middle cells
+      const unsigned step = (n - 1) / 2;
+      st.rank = step;
+      st.want_next = (n - 1 - step) != step ? 1u : 0u;
+    } else {  // measurements.percentile: floor and ceiling of the fractional index
+      const double frac = (double)(n - 1) * (qval / 100.0);
+      st.rank = (unsigned)floor(frac);
+      st.want_next = ceil(frac) != floor(frac) ? 1u : 0u;
+    }
+  }
+  state[l] = st;
+  next[l] = ~0ull;
+}
+
+// NEXT = false: the histogram pass for the digit at `shift`; NEXT = true: the smallest key above the selected one.
+// A wave walks SEL_WAVE consecutive cells of the partitioned array, label segment by label segment (first[] says where the
+// labels change: the label array itself is not read).
+template <typename K, bool NEXT>
+__global__ __launch_bounds__(256) void zonal_select_pass_kernel(const unsigned* __restrict__ first, const K* __restrict__ keys,
+                                                                int n_labels, int shift, const SelectState* __restrict__ state,
+                                                                unsigned* __restrict__ hist, unsigned long long* __restrict__ next) {
+  __shared__ unsigned local[4][256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned* const mine = local[wave];  // (a wave's LDS operations complete in order: no barrier around its own row)
+  const unsigned active = first[n_labels];
+  const unsigned begin = (unsigned)(((size_t)blockIdx.x * 4 + wave) * SEL_WAVE);
+  if (begin >= active) return;
+  const unsigned end = min(begin + (unsigned)SEL_WAVE, active);
+  // the label that holds cell `begin`: the last one that starts at or before it
+  int cur = 0;
+  {
+    int lo = 0, hi = n_labels;  // first[lo] <= begin < first[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) / 2;
+      if (first[mid] <= begin) lo = mid;
+      else hi = mid;
+    }
+    cur = lo;
+  }
+  if constexpr (!NEXT) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mine[lane + 64 * k] = 0;
+  }
+  unsigned pos = begin;
+  while (pos < end) {
+    while (first[cur + 1] <= pos) ++cur;  // (labels without cells; wave-uniform)
+    const SelectState st = state[cur];
+    const unsigned long long prefix = st.prefix;
+    const unsigned stop = min(end, first[cur + 1]);
+    if constexpr (!NEXT) {
+      const bool top = shift + 8 >= 64;
+      for (unsigned i0 = pos; i0 < stop; i0 += 256) {  // (four steps' loads together)
+        unsigned long long key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = (unsigned long long)keys[min(i0 + 64u * u + (unsigned)lane, stop - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool inside = i0 + 64u * u + (unsigned)lane < stop;
+          const bool match = top || (key[u] >> ((shift + 8) & 63)) == (prefix >> ((shift + 8) & 63));
+          if (inside && match) atomicAdd(&mine[(unsigned)(key[u] >> shift) & 255u], 1u);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned c = mine[lane + 64 * k];
+        if (c) atomicAdd(&hist[(size_t)cur * 256 + lane + 64 * k], c);
+        mine[lane + 64 * k] = 0;
+      }
+    } else {
+      if (st.want_next && !(st.rank + 1 < st.n_eq)) {  // (wave-uniform)
+        unsigned long long best = ~0ull;
+        for (unsigned i0 = pos; i0 < stop; i0 += 256) {
+          unsigned long long key[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) key[u] = (unsigned long long)keys[min(i0 + 64u * u + (unsigned)lane, stop - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)  // (a clamped re-read is a cell of the segment: harmless for a minimum)
+            if (key[u] > prefix && key[u] < best) best = key[u];
+        }
+#pragma unroll
+        for (int offset = 32; offset >= 1; offset >>= 1) {
+          const unsigned lo = __shfl_xor((unsigned)best, offset), hi = __shfl_xor((unsigned)(best >> 32), offset);
+          const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+          best = other < best ? other : best;
+        }
+        if (lane == 0 && best != ~0ull) atomicMin(&next[cur], best);
+      }
+    }
+    pos = stop;
+  }
+}
+
+// a wave per label: lane l holds the bins 4 l .. 4 l + 3, the wave scans the 64 lane totals and the lane whose bins hold the
+// rank picks the digit
+__global__ __launch_bounds__(256) void zonal_select_step_kernel(int n_labels, int shift, SelectState* __restrict__ state,
+                                                                unsigned* __restrict__ hist) {
+  const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (l >= n_labels) return;
+  SelectState st = state[l];
+  if (st.count == 0) return;  // (wave-uniform)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4* const h = reinterpret_cast<u32x4*>(hist + (size_t)l * 256) + lane;
+  const u32x4 c = *h;
+  *h = u32x4{0u, 0u, 0u, 0u};
+  const unsigned mine = c[0] + c[1] + c[2] + c[3];
+  unsigned inclusive = mine;
+#pragma unroll
+  for (int offset = 1; offset < 64; offset <<= 1) {
+    const unsigned below = __shfl_up(inclusive, offset);
+    if (lane >= offset) inclusive += below;
+  }
+  unsigned before = inclusive - mine;
+  const bool holds = st.rank >= before && st.rank < inclusive;  // (exactly one lane: the counts add up to more than the rank)
+  if (holds) {
+    int digit = 4 * lane;
+    unsigned inside = c[0];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (st.rank >= before + inside) {
+        before += inside;
+        digit += 1;
+        inside = c[k + 1];
+      }
+    }
+    st.prefix |= (unsigned long long)digit << shift;
+    st.rank -= before;
+    st.n_eq = inside;
+    state[l] = st;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void zonal_select_result_kernel(const SelectState* __restrict__ state,
+                                                                  const unsigned long long* __restrict__ next, int n_labels,
+                                                                  int statistic, double qval, float* __restrict__ out,
+                                                                  long long* __restrict__ counts) {
+  typedef typename Ordered<T>::Key Key;
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= n_labels) return;
+  const SelectState st = state[l];
+  const unsigned n = st.count;
+  counts[l] = n;
+  if (n == 0) {
+    out[l] = std::numeric_limits<float>::quiet_NaN();
+    return;
+  }
+  const Key k1 = (Key)st.prefix;
+  const Key k2 = st.want_next ? ((st.rank + 1 < st.n_eq) ? k1 : (Key)next[l]) : k1;
+  const T x = Ordered<T>::decode(k1), y = Ordered<T>::decode(k2);
+  float result;
+  if (statistic == Z_MEDIAN) {  // (as zonal_pick_kernel)
+    if constexpr (std::is_same<T, float>::value) result = (x + y) / 2.0f;
+    else if constexpr (std::is_same<T, double>::value) result = (float)((x + y) / 2.0);
+    else result = (float)(((double)x + (double)y) / 2.0);
+  } else {
+    const double frac = (double)(n - 1) * (qval / 100.0);
+    const double below = floor(frac);
+    const T diff = (T)(y - x);
+    result = (float)((double)x + (frac - below) * (double)diff);
+  }
+  out[l] = result;
 }
 
 struct PartitionBuffers {
@@ -1766,7 +2010,13 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   static const bool partition_allowed = !(getenv("GM_ZONAL_PART") && atoi(getenv("GM_ZONAL_PART")) == 0);
   // (sorts that start from cells in value order -- medians, percentiles -- see the labels as noise, where the partition's
   // per-lane scatter loses to the radix sort's exchange through LDS: 985 against 748 us; GM_ZONAL_PART=1 forces it, for the tests)
-  const bool partition = partition_allowed && n_labels + 1 <= ZP_BINS && (!by_value || getenv("GM_ZONAL_PART"));
+  // medians / percentiles: partition by label, then a radix select per label (GM_ZONAL_SELECT=0: the two sorts of lexsort)
+  static const bool select_allowed = !(getenv("GM_ZONAL_SELECT") && atoi(getenv("GM_ZONAL_SELECT")) == 0);
+  const bool select_path = by_value && select_allowed && partition_allowed && n_labels + 1 <= ZP_BINS;
+  const bool partition = partition_allowed && n_labels + 1 <= ZP_BINS && (!by_value || select_path || getenv("GM_ZONAL_PART"));
+  SelectState* sel_state = nullptr;
+  unsigned* sel_hist = nullptr;
+  unsigned long long* sel_next = nullptr;
   const size_t part_bins = (size_t)n_labels + 1, part_tiles = ((size_t)cells + ZP_TILE - 1) / ZP_TILE;
   PartitionBuffers part;
   const unsigned blocks = (unsigned)std::min<int64_t>((cells + 255) / 256, (int64_t)gm::current_cu_count() * 32);
@@ -1792,8 +2042,13 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         if ((rc2 = scratch.take((void**)&pay_b, sizeof(Key) * cells))) return rc2;
       }
       size_t temp_value = 0, temp_label = 0;
-      if (by_value)
+      if (by_value && !select_path)
         GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_value, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 0, 8 * sizeof(Key), s));
+      if (select_path && !sel_state) {
+        if ((rc2 = scratch.take((void**)&sel_state, sizeof(SelectState) * n_labels))) return rc2;
+        if ((rc2 = scratch.take((void**)&sel_hist, sizeof(unsigned) * 256 * (size_t)n_labels))) return rc2;
+        if ((rc2 = scratch.take((void**)&sel_next, sizeof(unsigned long long) * n_labels))) return rc2;
+      }
       if (!partition) {
         GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_label, keys_a, keys_b, pay_a, pay_b, (size_t)cells, 0, label_bits, s));
       } else if (!part.offsets) {
@@ -1895,12 +2150,39 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       longest = verdict.longest;
     }
     if ((rc = sort_buffers())) return rc;
-    if (!keys_written)
-      hipLaunchKernelGGL(zonal_keys_kernel<T>, dim3(blocks), dim3(256), 0, s, frame, labels, (size_t)cells, n_labels, has_ndv, ndv,
-                         thresholds, keys_a, pay_a, seen);
+    if (!keys_written) {
+      if (partition && (!by_value || select_path)) {  // (keys and the tile histograms of the partition that follows, in one pass)
+        hipLaunchKernelGGL((zonal_keys_count_kernel<T, 8>), dim3((unsigned)part_tiles), dim3(512), 0, s, frame, labels, (unsigned)cells, n_labels,
+                           has_ndv, ndv, thresholds, keys_a, pay_a, seen, part.counts);
+        part.counted = true;
+      } else {
+        hipLaunchKernelGGL(zonal_keys_kernel<T>, dim3(blocks), dim3(256), 0, s, frame, labels, (size_t)cells, n_labels, has_ndv, ndv,
+                           thresholds, keys_a, pay_a, seen);
+      }
+    }
     const unsigned* sorted_keys;
     const Key* sorted_pay;
     size_t bytes = temp_bytes;
+    if (select_path) {
+      // the cells of every label together (in any order), then the wanted ranks by radix select: no sort by value
+      if ((rc = sort_by_label(keys_a, pay_a, (unsigned*)nullptr, pay_b))) return rc;
+      const unsigned label_grid = (unsigned)((n_labels + 255) / 256);
+      const unsigned pass_grid = (unsigned)(((size_t)cells + 4 * SEL_WAVE - 1) / (4 * SEL_WAVE));
+      GM_HIP(hipMemsetAsync(sel_hist, 0, sizeof(unsigned) * 256 * (size_t)n_labels, s));
+      hipLaunchKernelGGL(zonal_select_init_kernel, dim3(label_grid), dim3(256), 0, s, first, n_labels, statistic, qval, sel_state, sel_next);
+      for (int shift = 8 * ((int)sizeof(T) - 1); shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL((zonal_select_pass_kernel<Key, false>), dim3(pass_grid), dim3(256), 0, s, first, pay_b, n_labels, shift, sel_state,
+                           sel_hist, sel_next);
+        hipLaunchKernelGGL(zonal_select_step_kernel, dim3((unsigned)(((size_t)n_labels * 64 + 255) / 256)), dim3(256), 0, s, n_labels, shift,
+                           sel_state, sel_hist);
+      }
+      hipLaunchKernelGGL((zonal_select_pass_kernel<Key, true>), dim3(pass_grid), dim3(256), 0, s, first, pay_b, n_labels, 0, sel_state,
+                         sel_hist, sel_next);
+      hipLaunchKernelGGL(zonal_select_result_kernel<T>, dim3(label_grid), dim3(256), 0, s, sel_state, sel_next, n_labels, statistic, qval,
+                         out_f, counts_f);
+      GM_HIP(hipGetLastError());
+      continue;
+    }
     if (by_value) {
       // lexsort((values, labels)): by value, then stably by label
       GM_HIP(rocprim::radix_sort_pairs(temp, bytes, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 0, 8 * sizeof(Key), s));

@@ -1646,15 +1646,16 @@ def test_zonal_block_pipeline(gpu, blocks):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("part", ["1", "0"], ids=["partition", "radix-sort"])
-def test_zonal_label_partition(gpu, part):
+@pytest.mark.parametrize("part,select", [("1", "1"), ("0", "1"), ("1", "0")], ids=["partition+select", "radix-sort", "partition+lexsort"])
+def test_zonal_label_partition(gpu, part, select):
     """The stable sort by label as one counting pass (csrc/gm_zonal.hip: zonal_part_*_kernel, up to 2047 labels) and as
-    rocPRIM's radix sort, against the oracle: 240 statistics over label rasters of every texture
+    rocPRIM's radix sort; medians / percentiles by radix select per label on the partitioned cells (zonal_select_*_kernel) and
+    by the two sorts of lexsort -- against the oracle: 240 statistics over label rasters of every texture
     (tests/zonal_partition_driver.py), sums forced through the sort."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, GM_ZONAL_PART=part, GM_ZONAL_SORTED="1")
+    env = dict(os.environ, GM_ZONAL_PART=part, GM_ZONAL_SELECT=select, GM_ZONAL_SORTED="1")
     driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_partition_driver.py")
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
