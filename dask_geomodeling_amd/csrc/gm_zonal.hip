@@ -72,6 +72,18 @@ struct Ordered {
   }
 };
 
+// `present[label] = 1` for every labelled cell, without one store instruction per step: a step whose 64 cells carry the label
+// of the step before it (the rule inside a polygon) has nothing new to say.  `*last` is the wave's label of the step before
+// (INT_MIN: none / mixed); wave-uniform control flow.
+__device__ __forceinline__ void mark_present(unsigned char* __restrict__ present, int label, bool labelled, int* last) {
+  if (!present) return;
+  const int lead = __builtin_amdgcn_readfirstlane(label);
+  const bool uniform = __all(label == lead);
+  if (uniform && lead == *last) return;
+  if (labelled) present[label] = 1;
+  *last = uniform ? lead : INT_MIN;
+}
+
 // aggregate.py:177-186: active = frame != no_data_value, and with thresholds only cells whose label has one
 // (not NaN) and whose value reaches it; the comparison promotes like NumPy (value vs float32 threshold:
 // float32 for float32 and narrow integers, float64 otherwise -- all exact images in float64).
@@ -1039,6 +1051,7 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
   const size_t begin = wave * cells_per_wave, end = min(begin + cells_per_wave, cells);  // (cells_per_wave: a multiple of 64)
   // the run the wave is in: its label (wave-uniform), and per lane the cells counted / the extreme key so far
   int run_label = -1;
+  int marked = INT_MIN;  // (mark_present)
   unsigned run_count = 0;
   Key run_key = NEUTRAL;
   auto better = [](Key a, Key b) -> Key { return STAT == Z_MIN ? (b < a ? b : a) : (b > a ? b : a); };
@@ -1073,7 +1086,7 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
     (void)inside;
     (void)i;
     const bool labelled = (unsigned)label < (unsigned)n_labels;
-    if (present && labelled) present[label] = 1;
+    mark_present(present, label, labelled, &marked);
     bool active = labelled && !(has_ndv && v == ndv);
     if (thresholds && active) {
       const float t = thresholds[label];
@@ -1202,6 +1215,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
   size_t run_tile = 0;
   unsigned idle = 0;    // cells of the tile that carry the key n_labels (wave-uniform)
   unsigned tile_n = 0;  // per lane: cells of the run inside the tile
+  int marked = INT_MIN;  // (mark_present)
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const size_t begin = wave * cells_per_wave, end = min(begin + cells_per_wave, cells);
@@ -1251,7 +1265,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
   };
   walk_cells<T>(values, labels, begin, end, lane, [&](T v, int label, bool inside, size_t i) {
     const bool labelled = (unsigned)label < (unsigned)n_labels;
-    if (PHASE == 0 && present && labelled) present[label] = 1;
+    if constexpr (PHASE == 0) mark_present(present, label, labelled, &marked);
     bool active = labelled && !(has_ndv && v == ndv);
     if (thresholds && active) {
       const float t = thresholds[label];
@@ -1548,6 +1562,7 @@ __global__ __launch_bounds__(64 * NW) void zonal_keys_count_kernel(const T* __re
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   constexpr int WAVE_CELLS = ZP_TILE / NW, STEPS = WAVE_CELLS / 64, GROUP = STEPS < 8 ? STEPS : 8;
   const unsigned begin = blockIdx.x * (unsigned)ZP_TILE + (unsigned)wave * WAVE_CELLS;
+  int marked = INT_MIN;  // (mark_present)
   for (int step0 = 0; step0 < STEPS; step0 += GROUP) {
     T v[GROUP];
     int label[GROUP];
@@ -1562,7 +1577,7 @@ __global__ __launch_bounds__(64 * NW) void zonal_keys_count_kernel(const T* __re
       const unsigned i = begin + (unsigned)(step0 + k) * 64u + (unsigned)lane;
       const bool inside = i < cells;
       const bool labelled = (unsigned)label[k] < (unsigned)n_labels;
-      if (present && inside && labelled) present[label[k]] = 1;
+      mark_present(present, inside ? label[k] : -1, inside && labelled, &marked);
       bool active = labelled && !(has_ndv && v[k] == ndv);
       if (thresholds && active) {
         const float t = thresholds[label[k]];
