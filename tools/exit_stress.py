@@ -11,14 +11,11 @@ CHILD = r'''
 import os, sys, time
 import numpy as np
 sys.path.insert(0, %r)
-from dask_geomodeling_amd.hip import program as P, runtime
-from dask_geomodeling_amd.hip.array import DeviceArray
-from dask_geomodeling_amd.raster import devops
+from dask_geomodeling_amd.hip import program as P
 rng = np.random.default_rng(int(sys.argv[1]))
 a = rng.random((1, 512, 512)).astype("f4")
 b = rng.random((1, 512, 512)).astype("f4")
 k = float(rng.random())  # a different program (and kernel) per child
-import dask_geomodeling_amd as gm
 from dask_geomodeling_amd import raster
 from datetime import datetime
 src = [raster.MemorySource(np.asarray(x), -9999.0, "EPSG:28992", 1.0, (0.0, 512.0), datetime(2000, 1, 1)) for x in (a, b)]
