@@ -422,42 +422,89 @@ __device__ __forceinline__ double broadcast_f64(double x, int lane) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// A workgroup of four waves per long label.  A round is 64 x PER consecutive block sums (a lane takes PER of them; any order
+// of addition will do: the result only predicts); wave w takes the rounds w, w + 4, ...: first their totals (into LDS), then
+// -- once one wave has turned the totals into the sums before every round -- the prefixes inside them.  (One label covering
+// the default raster limit, 49 152 blocks: 362 us with one wave, one block per lane and round and the loads not ahead; 59 us
+// with 16 blocks per lane and the loads ahead; the four waves' rounds now overlap.)
 template <typename T>
 __global__ __launch_bounds__(256) void zonal_block_prefix_kernel(const typename Ordered<T>::Key* __restrict__ payload,
                                                                  const unsigned* __restrict__ first, int n_labels,
                                                                  const double* __restrict__ blk_sum, double* __restrict__ blk_pred,
                                                                  unsigned long_from) {
-  const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  constexpr int PER = 16, ROUND = 64 * PER, RMAX = 2048;  // (RMAX rounds = 2 M blocks = 537 M cells; more: one wave, in order)
+  __shared__ double before_round[RMAX];
+  const int l = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (l >= n_labels) return;
   const unsigned a = first[l], b = first[l + 1];
-  if (b - a < long_from) return;
+  if (b - a < long_from) return;  // (workgroup-uniform)
   const unsigned j0 = (a + ZB - 1) / ZB, j1 = b / ZB;  // the label's whole blocks [j0, j1)
-  double running = 0.0;
-  {  // the cells before the first whole block
+  if (j0 >= j1) return;
+  const unsigned rounds = (j1 - j0 + ROUND - 1) / ROUND;
+  const bool team = rounds <= (unsigned)RMAX;
+  if (!team && wave != 0) return;
+  double head = 0.0;  // the cells before the first whole block
+  {
     double partial = 0.0;
     for (unsigned at = a + lane; at < j0 * ZB; at += 64) partial += (double)Ordered<T>::decode(payload[at]);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) partial += shuffle_xor(partial, off);
-    running = partial;
+    head = partial;
   }
-  // 64 x PER blocks per round: a lane takes PER consecutive block sums (any order will do: the result only predicts), the
-  // wave scans the 64 lane totals; the next round's loads are issued before this round's scan (one label covering the
-  // default raster limit, 49 152 blocks: 362 us at one block per lane and round, the loads not ahead)
-  constexpr int PER = 16;
   auto fetch = [&](unsigned j, double* v) {
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const unsigned at = j + PER * lane + k;
-      v[k] = blk_sum[min(at, j1 - 1)];
-    }
+    for (int k = 0; k < PER; ++k) v[k] = blk_sum[min(j + PER * lane + k, j1 - 1)];
   };
+  const unsigned stride = team ? 4u : 1u, mine_first = team ? (unsigned)wave : 0u;
+  if (team) {
+    // pass A: the totals of this wave's rounds
+    for (unsigned r = mine_first; r < rounds; r += stride) {
+      const unsigned j = j0 + r * ROUND;
+      double v[PER];
+      fetch(j, v);
+      double total = 0.0;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) total += j + PER * lane + k < j1 ? v[k] : 0.0;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) total += shuffle_xor(total, off);
+      if (lane == 0) before_round[r] = total;
+    }
+    __syncthreads();
+    if (wave == 0) {  // the sums before every round: a lane takes RMAX / 64 consecutive rounds, the wave scans the lane totals
+      constexpr int CHUNK = RMAX / 64;
+      double mine[CHUNK], total = 0.0;
+#pragma unroll
+      for (int k = 0; k < CHUNK; ++k) {
+        const unsigned r = (unsigned)(CHUNK * lane + k);
+        mine[k] = r < rounds ? before_round[r] : 0.0;
+        total += mine[k];
+      }
+      double scan = total;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double up = shuffle_up_f64(scan, off);
+        if (lane >= off) scan += up;
+      }
+      double before = head + (scan - total);
+#pragma unroll
+      for (int k = 0; k < CHUNK; ++k) {
+        const unsigned r = (unsigned)(CHUNK * lane + k);
+        if (r < rounds) before_round[r] = before;
+        before += mine[k];
+      }
+    }
+    __syncthreads();
+  }
+  // pass B: the prefixes inside the rounds (team: each round starts from its sum before; one wave: a running sum)
+  double running = head;
   double ahead[PER];
-  if (j0 < j1) fetch(j0, ahead);
-  for (unsigned j = j0; j < j1; j += 64 * PER) {
+  fetch(j0 + mine_first * ROUND, ahead);
+  for (unsigned r = mine_first; r < rounds; r += stride) {
+    const unsigned j = j0 + r * ROUND;
     double mine[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) mine[k] = j + PER * lane + k < j1 ? ahead[k] : 0.0;
-    if (j + 64 * PER < j1) fetch(j + 64 * PER, ahead);
+    if (r + stride < rounds) fetch(j0 + (r + stride) * ROUND, ahead);
     double total = 0.0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) total += mine[k];
@@ -467,13 +514,14 @@ __global__ __launch_bounds__(256) void zonal_block_prefix_kernel(const typename 
       const double up = shuffle_up_f64(scan, off);
       if ((int)lane >= off) scan += up;
     }
+    if (team) running = before_round[r];
     double before = running + (scan - total);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       if (j + PER * lane + k < j1) blk_pred[j + PER * lane + k] = before;
       before += mine[k];
     }
-    running += broadcast_f64(scan, 63);
+    if (!team) running += broadcast_f64(scan, 63);
   }
 }
 
@@ -661,11 +709,108 @@ __device__ __forceinline__ UnitsFn shuffle_up_units(const UnitsFn& f, int delta)
   return r;
 }
 
+// The same once more over groups of 256 blocks (aligned to the block index): what the group adds for either parity of the sum
+// entering it and the extreme prefixes anywhere inside it -- usable when its 256 blocks are whole blocks of ONE long label,
+// analysed for one binade and sign, none of them expected to be added literally.  The composing wave then takes such a
+// group in one step (and still checks it against the exact sum entering it); groups that hold a flagged block -- or any
+// other irregularity -- are walked block by block as before.
+struct GroupInfo {
+  long long D[2], lo[2], hi[2];
+  int E;      // INT_MIN: not usable
+  int flags;  // bit 0: negative
+};
+__device__ __forceinline__ long long shuffle_xor_i64(long long x, int offset) {
+  const unsigned lo = __shfl_xor((unsigned)x, offset), hi = __shfl_xor((unsigned)((unsigned long long)x >> 32), offset);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+constexpr int ZG = 256;  // blocks per group
+
+__global__ __launch_bounds__(256) void zonal_group_info_kernel(const int* __restrict__ blk_label, const BlockInfo* __restrict__ info,
+                                                               const unsigned* __restrict__ first, unsigned whole_blocks,
+                                                               unsigned long_from, GroupInfo* __restrict__ ginfo, unsigned n_groups) {
+  const unsigned G = (unsigned)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if (G >= n_groups) return;
+  GroupInfo out;
+  out.D[0] = out.D[1] = out.lo[0] = out.lo[1] = out.hi[0] = out.hi[1] = 0;
+  out.E = INT_MIN;
+  out.flags = 0;
+  const unsigned base = G * ZG;
+  if (base + ZG > whole_blocks) {  // (wave-uniform)
+    if (lane == 0) ginfo[G] = out;
+    return;
+  }
+  BlockInfo B[4];
+  bool regular = true;
+  const int l = __builtin_amdgcn_readfirstlane(blk_label[base]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    B[k] = info[base + 4 * lane + k];
+    regular = regular && blk_label[base + 4 * lane + k] == l;
+  }
+  const int E0 = __builtin_amdgcn_readfirstlane(B[0].E), neg0 = __builtin_amdgcn_readfirstlane(B[0].flags & 1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) regular = regular && B[k].E == E0 && (B[k].flags & 3) == neg0;  // (same sign, not flagged)
+  const bool long_label = l >= 0 && first[max(l, 0) + 1] - first[max(l, 0)] >= long_from;
+  if (!(__all(regular) && long_label && E0 != INT_MIN)) {
+    if (lane == 0) ginfo[G] = out;
+    return;
+  }
+  // the lane's four blocks in order, for either parity coming in
+  UnitsFn mine;
+  long long llo[2], lhi[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    long long run = 0, low = LLONG_MAX, high = LLONG_MIN;
+    int parity = p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      low = min(low, run + B[k].lo);
+      high = max(high, run + B[k].hi);
+      const long long d = B[k].D(parity);
+      run += d;
+      parity = (int)((parity + d) & 1);
+    }
+    mine.S[p] = run;
+    mine.q[p] = parity;
+    llo[p] = low;
+    lhi[p] = high;
+  }
+  UnitsFn scan = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const UnitsFn before = shuffle_up_units(scan, off);
+    if (lane >= off) scan = compose_units(before, scan);
+  }
+  UnitsFn excl = shuffle_up_units(scan, 1);
+  if (lane == 0) {
+    excl.S[0] = excl.S[1] = 0;
+    excl.q[0] = 0;
+    excl.q[1] = 1;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    long long lowest = excl.S[p] + (excl.q[p] ? llo[1] : llo[0]), highest = excl.S[p] + (excl.q[p] ? lhi[1] : lhi[0]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      lowest = min(lowest, shuffle_xor_i64(lowest, off));
+      highest = max(highest, shuffle_xor_i64(highest, off));
+    }
+    out.lo[p] = lowest;
+    out.hi[p] = highest;
+    out.D[p] = scan.S[p];  // (lane 63's is the group's)
+  }
+  out.E = E0;
+  out.flags = neg0;
+  if (lane == 63) ginfo[G] = out;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Ordered<T>::Key* __restrict__ payload,
                                                             const unsigned* __restrict__ first, int n_labels, int statistic,
                                                             const int* __restrict__ blk_label, const BlockInfo* __restrict__ info,
-                                                            float* __restrict__ out, long long* __restrict__ counts,
+                                                            const GroupInfo* __restrict__ ginfo, float* __restrict__ out,
+                                                            long long* __restrict__ counts,
                                                             unsigned* __restrict__ replayed, unsigned long_from) {
   __shared__ __align__(16) double parked[4][ZB];
   const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -770,14 +915,62 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
       if (blk_label[jj] != l) B[k].E = INT_MIN;
     }
   };
+  static_assert(64 * PER == ZG, "groups");
+  // (the first group ends at the next multiple of ZG, so that the later ones coincide with the groups of ginfo[])
+  // The groups' descriptions are held 64 at a time, a lane each (one memory round trip per 64 groups = 16 384 blocks), and read
+  // off the lanes where they are needed; a group's 256 BLOCK descriptions are requested one group ahead -- but only when the
+  // group's description says it will have to be walked: a usable group is expected to go in one step, and asking for its
+  // blocks anyway would put a memory round trip into every iteration.
+  const unsigned last_group = (j1 - 1) / ZG;  // (j1 > j0 wherever this is used)
+  unsigned held_from = ~0u;  // group index of lane 0's description
+  GroupInfo held;
+  held.E = INT_MIN;
+  auto hold = [&](unsigned gi) {  // make sure group gi's description is in a lane; returns the lane
+    if (held_from == ~0u || gi < held_from || gi >= held_from + 64u) {
+      held_from = gi;
+      held = ginfo[min(gi + (unsigned)lane, last_group)];
+    }
+    return (int)(gi - held_from);
+  };
+  // does the group that starts at block g go in one step, as far as its description can tell?
+  auto usable = [&](unsigned g) -> bool {
+    if (!(g < j1 && g % ZG == 0 && j1 - g >= (unsigned)ZG)) return false;
+    const int at = hold(g / ZG);
+    return __builtin_amdgcn_readlane(held.E, at) != INT_MIN;
+  };
   BlockInfo ahead[PER];
-  if (j0 < j1) fetch(j0, ahead);
-  for (unsigned g = j0; g < j1; g += 64 * PER) {
-    const unsigned here = min((unsigned)(64 * PER), j1 - g);
+  bool have_ahead = false;
+  if (j0 < j1 && !usable(j0)) {
+    fetch(j0, ahead);
+    have_ahead = true;
+  }
+  unsigned here = 0;
+  for (unsigned g = j0; g < j1; g += here) {
+    here = min((unsigned)ZG - g % ZG, j1 - g);
     BlockInfo B[PER];
+    const bool have = have_ahead;
 #pragma unroll
     for (int k = 0; k < PER; ++k) B[k] = ahead[k];
-    if (g + 64 * PER < j1) fetch(g + 64 * PER, ahead);
+    const bool whole = usable(g);
+    int at = 0;
+    if (whole) at = hold(g / ZG);
+    // the next group's blocks, if it will be walked
+    const unsigned g1 = g + here;
+    have_ahead = false;
+    if (g1 < j1 && !usable(g1)) {
+      fetch(g1, ahead);
+      have_ahead = true;
+      if (whole) at = hold(g / ZG);  // (usable(g1) may have moved the window of held descriptions)
+    }
+    if (whole && as_integer && __builtin_amdgcn_readlane(held.E, at) == E && (__builtin_amdgcn_readlane(held.flags, at) & 1) == negative) {
+      const int p0 = (int)(units & 1);
+      const long long lo = pass(p0 ? held.lo[1] : held.lo[0], at), hi = pass(p0 ? held.hi[1] : held.hi[0], at);
+      if (units + lo >= 4503599627370497ll && units + hi <= 9007199254740991ll) {
+        units += pass(p0 ? held.D[1] : held.D[0], at);  // (256 blocks, 65 536 cells: one addition)
+        continue;
+      }
+    }
+    if (!have) fetch(g, B);  // (a group that was expected to go in one step and did not)
     // the first block from `from_idx` on that the info kernel expects to be added literally (64 * PER: none in this group)
     auto next_risky = [&](unsigned from_idx) -> unsigned {
       unsigned first_risky = 64u * PER;
@@ -2016,6 +2209,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   double *blk_sum = nullptr, *blk_pred = nullptr;  // (the block pipeline of the long labels)
   int* blk_label = nullptr;
   BlockInfo* blk_info = nullptr;
+  GroupInfo* grp_info = nullptr;
   Key *pay_a = nullptr, *pay_b = nullptr;
   void* temp = nullptr;
   size_t temp_bytes = 0;
@@ -2222,14 +2416,20 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
           if ((rc = scratch.take((void**)&blk_pred, sizeof(double) * n_blocks))) return rc;
           if ((rc = scratch.take((void**)&blk_label, sizeof(int) * n_blocks))) return rc;
           if ((rc = scratch.take((void**)&blk_info, sizeof(BlockInfo) * n_blocks))) return rc;
+          if ((rc = scratch.take((void**)&grp_info, sizeof(GroupInfo) * ((n_blocks + ZG - 1) / ZG)))) return rc;
         }
         const unsigned block_grid = (unsigned)((n_blocks * 64 + 255) / 256), label_grid = (unsigned)(((size_t)n_labels * 64 + 255) / 256);
         hipLaunchKernelGGL(zonal_block_sum_kernel<T>, dim3(block_grid), dim3(256), 0, s, sorted_pay, sorted_keys, (unsigned)cells, n_labels,
                            blk_sum, blk_label);
-        hipLaunchKernelGGL(zonal_block_prefix_kernel<T>, dim3(label_grid), dim3(256), 0, s, sorted_pay, first, n_labels, blk_sum, blk_pred,
-                           long_from);
+        hipLaunchKernelGGL(zonal_block_prefix_kernel<T>, dim3((unsigned)n_labels), dim3(256), 0, s, sorted_pay, first, n_labels, blk_sum,
+                           blk_pred, long_from);
         hipLaunchKernelGGL(zonal_block_info_kernel<T>, dim3(block_grid), dim3(256), 0, s, sorted_pay, first, (unsigned)cells, blk_label,
                            blk_pred, blk_info, long_from);
+        {
+          const unsigned n_groups = (unsigned)((n_blocks + ZG - 1) / ZG);
+          hipLaunchKernelGGL(zonal_group_info_kernel, dim3((unsigned)(((size_t)n_groups * 64 + 255) / 256)), dim3(256), 0, s, blk_label, blk_info,
+                             first, (unsigned)((size_t)cells / ZB), long_from, grp_info, n_groups);
+        }
         static const bool verbose = getenv("GM_ZONAL_VERBOSE") != nullptr;
         unsigned* replayed = nullptr;
         if (verbose) {
@@ -2237,7 +2437,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
           GM_HIP(hipMemsetAsync(replayed, 0, 8 * sizeof(unsigned), s));
         }
         hipLaunchKernelGGL(zonal_compose_kernel<T>, dim3(label_grid), dim3(256), 0, s, sorted_pay, first, n_labels, statistic, blk_label,
-                           blk_info, out_f, counts_f, replayed, long_from);
+                           blk_info, grp_info, out_f, counts_f, replayed, long_from);
         if (verbose) {
           unsigned host[8] = {0};
           GM_HIP(hipMemcpyAsync(host, replayed, sizeof(host), hipMemcpyDeviceToHost, s));
