@@ -40,6 +40,7 @@ class _Shim:
     def __init__(self):
         self._data = {}
         self._flat = {}  # "a.b.c" -> value of the lookups made so far (get_data reads half a dozen keys per request)
+        self._generation = 0  # bumped by every write: a lookup that raced a write is not remembered
         self._lock = threading.Lock()
 
     def update_defaults(self, new):
@@ -51,6 +52,7 @@ class _Shim:
                         cur.setdefault(kk, vv)
                 else:
                     self._data.setdefault(k, v)
+            self._generation += 1
             self._flat.clear()
 
     def get(self, key, default=KeyError):
@@ -58,9 +60,12 @@ class _Shim:
             return self._flat[key]
         except KeyError:
             pass
+        generation = self._generation
         value = self._lookup(key, default)
         if value is not default:
-            self._flat[key] = value
+            with self._lock:
+                if generation == self._generation:  # no set() since the lookup began: the value is current
+                    self._flat[key] = value
         return value
 
     def _lookup(self, key, default):
@@ -84,12 +89,14 @@ class _Shim:
 
         @staticmethod
         def _assign(key, value):
-            cur = config._data
             parts = key.split(".")
-            for part in parts[:-1]:
-                cur = cur.setdefault(part, {})
-            cur[parts[-1]] = value
-            config._flat.clear()
+            with config._lock:
+                cur = config._data
+                for part in parts[:-1]:
+                    cur = cur.setdefault(part, {})
+                cur[parts[-1]] = value
+                config._generation += 1
+                config._flat.clear()
 
         def __enter__(self):
             return self

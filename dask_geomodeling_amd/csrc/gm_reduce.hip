@@ -150,10 +150,54 @@ __device__ __forceinline__ void pw_leaf(const C* src, long long pixels, int star
   }
 }
 
+// DEPTH >= 0: the recursion unrolled (everything stays in registers; n <= 128 * 2^DEPTH).  DEPTH < 0: stacks of any
+// length -- the recursion walked with an explicit stack of the left halves' sums (a lane-private array indexed at run
+// time lives in scratch memory, which is why the short stacks do not take this route), piece by piece.
 template <typename C, typename A, bool HALF, int V, int MODE, int DEPTH>
 __device__ void pw_sum(const C* src, long long pixels, int start, int n, const C (&mean)[V], A (&res)[V], int (&cnt)[V]) {
-  if constexpr (DEPTH == 0) {
-    pw_leaf<C, A, HALF, V, MODE>(src, pixels, start, n, mean, res, cnt);  // (the host refuses n > 128 * 2^RD_PW_DEPTH)
+  if constexpr (DEPTH < 0) {
+    // NumPy hands the reduction loop at most `bufsize` = 8192 elements at a time (the ufunc's buffered iterator),
+    // so a longer stack is the chain  -0.0 + pairwise(first 8192) + pairwise(next 8192) + ...  (measured against
+    // np.nansum on the (n, cells) array the reference reduces; 8192 = 128 * 2^6: six halvings inside a piece)
+    constexpr int PIECE = 8192, LEVELS = 8;
+    int at[LEVELS], len[LEVELS], phase[LEVELS];
+    A left[LEVELS][V], part[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) res[e] = (A)-0.0;
+    for (int piece = 0; piece < n; piece += PIECE) {
+      int sp = 0;
+      at[0] = start + piece; len[0] = n - piece < PIECE ? n - piece : PIECE; phase[0] = 0;
+      while (sp >= 0) {
+        if (phase[sp] == 0) {
+          if (len[sp] <= RD_PW_BLOCK || sp == LEVELS - 1) {
+            pw_leaf<C, A, HALF, V, MODE>(src, pixels, at[sp], len[sp], mean, part, cnt);
+            --sp;
+            continue;
+          }
+          int n2 = len[sp] / 2;
+          n2 -= n2 % 8;
+          phase[sp] = 1;
+          at[sp + 1] = at[sp]; len[sp + 1] = n2; phase[sp + 1] = 0;
+          ++sp;
+        } else if (phase[sp] == 1) {  // the left half is in `part`: keep it, walk the right half
+          int n2 = len[sp] / 2;
+          n2 -= n2 % 8;
+#pragma unroll
+          for (int e = 0; e < V; ++e) left[sp][e] = part[e];
+          phase[sp] = 2;
+          at[sp + 1] = at[sp] + n2; len[sp + 1] = len[sp] - n2; phase[sp + 1] = 0;
+          ++sp;
+        } else {
+#pragma unroll
+          for (int e = 0; e < V; ++e) part[e] = left[sp][e] + part[e];
+          --sp;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < V; ++e) res[e] += part[e];
+    }
+  } else if constexpr (DEPTH == 0) {
+    pw_leaf<C, A, HALF, V, MODE>(src, pixels, start, n, mean, res, cnt);  // (longer stacks take the DEPTH < 0 form)
   } else {
     if (n <= RD_PW_BLOCK) {
       pw_leaf<C, A, HALF, V, MODE>(src, pixels, start, n, mean, res, cnt);
@@ -170,7 +214,7 @@ __device__ void pw_sum(const C* src, long long pixels, int start, int n, const C
 }
 
 // sum / product / min / max / mean / var / std / argmin / argmax
-template <typename C, bool HALF, int STAT, int V>
+template <typename C, bool HALF, int STAT, int V, int PW_DEPTH = RD_PW_DEPTH>
 __global__ __launch_bounds__(256) void reduce_kernel(const C* __restrict__ stack, int n, long long pixels,
                                                      C* __restrict__ out, C fill) {
   const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
@@ -215,7 +259,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const C* __restrict__ stack
     C none[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) none[e] = (C)0;
-    pw_sum<C, A, HALF, V, 0, RD_PW_DEPTH>(src, pixels, 0, n, none, total, cnt);
+    pw_sum<C, A, HALF, V, 0, PW_DEPTH>(src, pixels, 0, n, none, total, cnt);
 #pragma unroll
     for (int e = 0; e < V; ++e) r[e] = rnd<HALF, C>((C)total[e]);
     if constexpr (STAT != GM_RED_SUM) {
@@ -225,7 +269,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const C* __restrict__ stack
     if constexpr (STAT == GM_RED_VAR || STAT == GM_RED_STD) {
       A squares[V];
       int ignored[V];
-      pw_sum<C, A, HALF, V, 1, RD_PW_DEPTH>(src, pixels, 0, n, r, squares, ignored);
+      pw_sum<C, A, HALF, V, 1, PW_DEPTH>(src, pixels, 0, n, r, squares, ignored);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         C var = from_f64<HALF, C>((double)rnd<HALF, C>((C)squares[e]) / (double)cnt[e]);
@@ -453,6 +497,20 @@ int launch_reduce(const void* stack, int n, long long pixels, int statistic, con
     if (plan_dev) (void)gm_free(plan_dev);
     return rc;
   }
+  if (n > (RD_PW_BLOCK << RD_PW_DEPTH) &&
+      (statistic == GM_RED_SUM || statistic == GM_RED_MEAN || statistic == GM_RED_VAR || statistic == GM_RED_STD)) {
+    // sums over more rasters than the unrolled recursion covers: the explicit-stack form, one cell per lane
+    const unsigned g1 = (unsigned)((pixels + 255) / 256);
+#define GM_RD_DEEP(STAT)                                                                                               \
+  case STAT:                                                                                                           \
+    hipLaunchKernelGGL((reduce_kernel<C, HALF, STAT, 1, -1>), dim3(g1), dim3(256), 0, s, (const C*)stack, n, pixels, (C*)out, fill); \
+    break;
+    switch (statistic) {
+      GM_RD_DEEP(GM_RED_SUM) GM_RD_DEEP(GM_RED_MEAN) GM_RD_DEEP(GM_RED_VAR) GM_RD_DEEP(GM_RED_STD)
+    }
+#undef GM_RD_DEEP
+    return GM_OK;
+  }
   constexpr int VV = 16 / (int)sizeof(C);
   const bool vec = (pixels % VV) == 0 && ((uintptr_t)stack % 16) == 0 && ((uintptr_t)out % 16) == 0;
   const int V = vec ? VV : 1;
@@ -477,9 +535,6 @@ extern "C" int gm_reduce_stack(const void* stack, int work_dtype, int half, int6
                                const gm_percentile_step* plan, void* out, uint64_t fill_bits) {
   if (!stack || !out) return gm::fail(GM_ERR_INVALID, "null pointer");
   if (n <= 0 || n > 0x7fffffff || pixels < 0) return gm::fail(GM_ERR_INVALID, "gm_reduce_stack: %lld rasters of %lld pixels", (long long)n, (long long)pixels);
-  if ((statistic == GM_RED_SUM || statistic == GM_RED_MEAN || statistic == GM_RED_VAR || statistic == GM_RED_STD) &&
-      n > (int64_t)RD_PW_BLOCK << RD_PW_DEPTH)
-    return gm::fail(GM_ERR_UNSUPPORTED, "gm_reduce_stack: sums over more than %d rasters", RD_PW_BLOCK << RD_PW_DEPTH);
   if (pixels == 0) return GM_OK;
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;

@@ -67,6 +67,9 @@ __device__ __forceinline__ Pack<T, V> load_pack(const T* p) {
   Pack<T, V> r;
   if constexpr (V == 1) {
     r.v[0] = __builtin_nontemporal_load(p);
+  } else if constexpr (sizeof(T) * V == 2) {
+    const unsigned short w = __builtin_nontemporal_load((const unsigned short*)p);
+    memcpy(&r, &w, 2);
   } else if constexpr (sizeof(T) * V == 4) {
     const unsigned w = __builtin_nontemporal_load((const unsigned*)p);
     memcpy(&r, &w, 4);
@@ -305,12 +308,13 @@ struct Plan {  // gm_percentile_step per number of data frames (1 .. GM_MAX_MEDI
 };
 
 template <typename Tin, bool PERCENTILE, int WG, bool LONG>
-__global__ __launch_bounds__(WG) void median_kernel(const Tin* __restrict__ frames, Tin ndv, bool has_ndv,
+__global__ __launch_bounds__(WG) void median_kernel(const Tin* __restrict__ frames, Tin ndv, int flags,
                                                     long long pixels, Bins B, Plan P,
                                                     const gm_percentile_step* __restrict__ long_plan,
                                                     typename OutOf<Tin, GM_STAT_MEDIAN>::type* __restrict__ out,
                                                     typename OutOf<Tin, GM_STAT_MEDIAN>::type fill) {
   using C = typename OutOf<Tin, GM_STAT_MEDIAN>::type;  // = result_type(float32, dtype), the working dtype too
+  const bool has_ndv = (flags & 1) != 0, keep = (flags & GM_TEMPORAL_KEEP_NONFINITE) != 0;
   extern __shared__ unsigned char lds_raw[];
   C* sorted = reinterpret_cast<C*>(lds_raw);  // [slot][lane]
   const long long p = (long long)blockIdx.x * WG + threadIdx.x;
@@ -362,7 +366,9 @@ __global__ __launch_bounds__(WG) void median_kernel(const Tin* __restrict__ fram
       r = (low + high) / (C)2;
     }
   }
-  __builtin_nontemporal_store(finite_<C>(r) ? r : fill, out + (long long)B.out[blockIdx.y] * pixels + p);
+  // (TemporalAggregate fills every non-finite result, temporal.py:760-766; reduce_rasters only the cells without
+  //  a data raster, reduction.py:113-115: GM_TEMPORAL_KEEP_NONFINITE)
+  __builtin_nontemporal_store((keep ? n > 0 : finite_<C>(r)) ? r : fill, out + (long long)B.out[blockIdx.y] * pixels + p);
 }
 
 // Bins of up to 16 frames (hourly -> daily of 6-hourly data, 5-minute -> hourly ...): the data frames of a cell are
@@ -400,11 +406,12 @@ __device__ __forceinline__ C pick(const C (&v)[N], int index) {
 }
 
 template <typename Tin, bool PERCENTILE, int N>
-__global__ __launch_bounds__(256) void median_small_kernel(const Tin* __restrict__ frames, Tin ndv, bool has_ndv,
+__global__ __launch_bounds__(256) void median_small_kernel(const Tin* __restrict__ frames, Tin ndv, int flags,
                                                            long long pixels, Bins B, Plan P,
                                                            typename OutOf<Tin, GM_STAT_MEDIAN>::type* __restrict__ out,
                                                            typename OutOf<Tin, GM_STAT_MEDIAN>::type fill) {
   using C = typename OutOf<Tin, GM_STAT_MEDIAN>::type;
+  const bool has_ndv = (flags & 1) != 0, keep = (flags & GM_TEMPORAL_KEEP_NONFINITE) != 0;
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= pixels) return;
   const int first = B.first[blockIdx.y], count = B.count[blockIdx.y];
@@ -436,7 +443,9 @@ __global__ __launch_bounds__(256) void median_small_kernel(const Tin* __restrict
       r = (low + high) / (C)2;
     }
   }
-  __builtin_nontemporal_store(finite_<C>(r) ? r : fill, out + (long long)B.out[blockIdx.y] * pixels + p);
+  // (TemporalAggregate fills every non-finite result, temporal.py:760-766; reduce_rasters only the cells without
+  //  a data raster, reduction.py:113-115: GM_TEMPORAL_KEEP_NONFINITE)
+  __builtin_nontemporal_store((keep ? n > 0 : finite_<C>(r)) ? r : fill, out + (long long)B.out[blockIdx.y] * pixels + p);
 }
 
 // Bins too long for the LDS sort (a year of hourly frames ...): the order statistics are SELECTED instead of sorted.
@@ -473,12 +482,13 @@ struct SelectKey<double> {
 };
 
 template <typename Tin, bool PERCENTILE>
-__global__ __launch_bounds__(256) void median_select_kernel(const Tin* __restrict__ frames, Tin ndv, bool has_ndv,
+__global__ __launch_bounds__(256) void median_select_kernel(const Tin* __restrict__ frames, Tin ndv, int flags,
                                                             long long pixels, Bins B,
                                                             const gm_percentile_step* __restrict__ long_plan,
                                                             typename OutOf<Tin, GM_STAT_MEDIAN>::type* __restrict__ out,
                                                             typename OutOf<Tin, GM_STAT_MEDIAN>::type fill) {
   using C = typename OutOf<Tin, GM_STAT_MEDIAN>::type;
+  const bool has_ndv = (flags & 1) != 0, keep = (flags & GM_TEMPORAL_KEEP_NONFINITE) != 0;
   using SK = SelectKey<C>;
   using K = typename SK::K;
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -542,7 +552,9 @@ __global__ __launch_bounds__(256) void median_select_kernel(const Tin* __restric
       r = (a + b) / (C)2;
     }
   }
-  __builtin_nontemporal_store(finite_<C>(r) ? r : fill, out + (long long)B.out[blockIdx.y] * pixels + p);
+  // (TemporalAggregate fills every non-finite result, temporal.py:760-766; reduce_rasters only the cells without
+  //  a data raster, reduction.py:113-115: GM_TEMPORAL_KEEP_NONFINITE)
+  __builtin_nontemporal_store((keep ? n > 0 : finite_<C>(r)) ? r : fill, out + (long long)B.out[blockIdx.y] * pixels + p);
 }
 
 template <typename Tin>
@@ -594,7 +606,7 @@ int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long 
       }
 #define GM_MEDIAN_SMALL(PCT, N_)                                                                                     \
   hipLaunchKernelGGL((median_small_kernel<Tin, PCT, N_>), dim3(gxs, nb), dim3(256), 0, s, (const Tin*)frames,        \
-                     from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, P, (C*)out, from_bits<C>(fill_bits))
+                     from_bits<Tin>(ndv_bits), has_ndv, pixels, B, P, (C*)out, from_bits<C>(fill_bits))
       if (longest_all <= 4) { if (plan) GM_MEDIAN_SMALL(true, 4); else GM_MEDIAN_SMALL(false, 4); }
       else if (longest_all <= 8) { if (plan) GM_MEDIAN_SMALL(true, 8); else GM_MEDIAN_SMALL(false, 8); }
       else { if (plan) GM_MEDIAN_SMALL(true, 16); else GM_MEDIAN_SMALL(false, 16); }
@@ -614,10 +626,10 @@ int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long 
       }
       if (plan)
         hipLaunchKernelGGL((median_select_kernel<Tin, true>), dim3(gxs, nb), dim3(256), 0, s, (const Tin*)frames, from_bits<Tin>(ndv_bits),
-                           has_ndv != 0, pixels, B, (const gm_percentile_step*)plan_dev, (C*)out, from_bits<C>(fill_bits));
+                           has_ndv, pixels, B, (const gm_percentile_step*)plan_dev, (C*)out, from_bits<C>(fill_bits));
       else
         hipLaunchKernelGGL((median_select_kernel<Tin, false>), dim3(gxs, nb), dim3(256), 0, s, (const Tin*)frames, from_bits<Tin>(ndv_bits),
-                           has_ndv != 0, pixels, B, (const gm_percentile_step*)nullptr, (C*)out, from_bits<C>(fill_bits));
+                           has_ndv, pixels, B, (const gm_percentile_step*)nullptr, (C*)out, from_bits<C>(fill_bits));
     }
     hipError_t e = hipGetLastError();
     if (plan_dev) (void)gm_free(plan_dev);
@@ -646,7 +658,7 @@ int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long 
       rc = gm::fail(GM_ERR_UNSUPPORTED, "gm_temporal_aggregate: %zu bytes of LDS per workgroup refused", lds);         \
       break;                                                                                                           \
     }                                                                                                                  \
-    hipLaunchKernelGGL(kernel, dim3(gx, nb), dim3(WG_), lds, s, (const Tin*)frames, from_bits<Tin>(ndv_bits), has_ndv != 0, \
+    hipLaunchKernelGGL(kernel, dim3(gx, nb), dim3(WG_), lds, s, (const Tin*)frames, from_bits<Tin>(ndv_bits), has_ndv, \
                        pixels, B, P, (const gm_percentile_step*)plan_dev, (C*)out, from_bits<C>(fill_bits));           \
   } while (0)
     if (long_bins) {
@@ -687,10 +699,10 @@ int launch_aggregate(const void* frames, uint64_t ndv_bits, int has_ndv, long lo
     }
     if (vec)
       hipLaunchKernelGGL((aggregate_kernel<Tin, STAT, 4>), dim3(gx, nb), dim3(256), 0, s, (const Tin*)frames,
-                         from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, (Tout*)out, from_bits<Tout>(fill_bits));
+                         from_bits<Tin>(ndv_bits), (has_ndv & 1) != 0, pixels, B, (Tout*)out, from_bits<Tout>(fill_bits));
     else
       hipLaunchKernelGGL((aggregate_kernel<Tin, STAT, 1>), dim3(gx, nb), dim3(256), 0, s, (const Tin*)frames,
-                         from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, (Tout*)out, from_bits<Tout>(fill_bits));
+                         from_bits<Tin>(ndv_bits), (has_ndv & 1) != 0, pixels, B, (Tout*)out, from_bits<Tout>(fill_bits));
   }
   return GM_OK;
 }
@@ -712,11 +724,11 @@ int launch_cumulative(const void* frames, uint64_t ndv_bits, int has_ndv, long l
     }
     if (vec)
       hipLaunchKernelGGL((cumulative_kernel<Tin, STAT, 4>), dim3(gx, nb), dim3(256), 0, s, (const Tin*)frames,
-                         from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, emit_first, emit_stop, (Tout*)out,
+                         from_bits<Tin>(ndv_bits), (has_ndv & 1) != 0, pixels, B, emit_first, emit_stop, (Tout*)out,
                          from_bits<Tout>(fill_bits));
     else
       hipLaunchKernelGGL((cumulative_kernel<Tin, STAT, 1>), dim3(gx, nb), dim3(256), 0, s, (const Tin*)frames,
-                         from_bits<Tin>(ndv_bits), has_ndv != 0, pixels, B, emit_first, emit_stop, (Tout*)out,
+                         from_bits<Tin>(ndv_bits), (has_ndv & 1) != 0, pixels, B, emit_first, emit_stop, (Tout*)out,
                          from_bits<Tout>(fill_bits));
   }
   return GM_OK;
@@ -752,6 +764,121 @@ int cumulative_of(int statistic, const void* frames, uint64_t ndv_bits, int has_
 }
 
 }  // namespace
+
+// ---- Snap / Resample (raster/temporal.py:165-182, 1196-1214): values[nearest] --------------------------------
+// out frame j = source frame index[j]: a gather of whole frames, 16 bytes per lane and load, four loads in flight.
+// grid: x over pieces of a frame, y over output frames.
+template <typename W>
+__global__ __launch_bounds__(256) void frames_take_kernel(const W* __restrict__ frames, long long frame_words,
+                                                          const int* __restrict__ index, W* __restrict__ out) {
+  const W* src = frames + (long long)index[blockIdx.y] * frame_words;
+  W* dst = out + (long long)blockIdx.y * frame_words;
+  const long long base = (long long)blockIdx.x * 1024 + threadIdx.x;
+  W w[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long i = base + u * 256;
+    w[u] = __builtin_nontemporal_load(src + (i < frame_words ? i : frame_words - 1));
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long i = base + u * 256;
+    if (i < frame_words) __builtin_nontemporal_store(w[u], dst + i);
+  }
+}
+
+// ---- TemporalSum.process (raster/temporal.py:239-257): values.sum(axis=0) ------------------------------------
+// A plain NumPy sum over the frame axis: no-data values are added like any other.  np.sum accumulates integers
+// narrower than the platform integer in int64 (signed, bool) / uint64 (unsigned) and floats in their own type;
+// over axis 0 of a C-contiguous (frames, h, w) stack it adds frame by frame (the reduction runs over the outer
+// axis).  A raster of ONE cell is a contiguous 1-D reduction instead: pairwise (frames_sum_cell_kernel).
+template <typename Tin>
+struct SumOf {
+  using type = typename std::conditional<
+      std::is_floating_point<Tin>::value, Tin,
+      typename std::conditional<std::is_signed<Tin>::value, long long, unsigned long long>::type>::type;
+};
+template <typename Tin, bool IS_BOOL, int V>
+__global__ __launch_bounds__(256) void frames_sum_kernel(const Tin* __restrict__ frames, int n, long long pixels,
+                                                         typename std::conditional<IS_BOOL, long long, typename SumOf<Tin>::type>::type* __restrict__ out) {
+  using A = typename std::conditional<IS_BOOL, long long, typename SumOf<Tin>::type>::type;
+  const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
+  if (p >= pixels) return;
+  const Tin* src = frames + p;
+  A acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = (A)0;
+  int j = 0;
+  for (; j + 8 <= n; j += 8) {
+    Pack<Tin, V> f[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) f[u] = load_pack<Tin, V>(src + (long long)(j + u) * pixels);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = j + u == 0 ? (A)f[u].v[e] : acc[e] + (A)f[u].v[e];
+  }
+  for (; j < n; ++j) {
+    const Pack<Tin, V> f = load_pack<Tin, V>(src + (long long)j * pixels);
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = j == 0 ? (A)f.v[e] : acc[e] + (A)f.v[e];
+  }
+  Pack<A, V> res;
+#pragma unroll
+  for (int e = 0; e < V; ++e) res.v[e] = acc[e];
+  store_pack<A, V>(out + p, res);
+}
+
+// One cell, float: NumPy's pairwise sum (loops_utils.h) over pieces of at most 8192 elements -- what the ufunc's
+// buffered iterator hands the loop at a time -- chained from -0.0.  One lane does it (a raster of one cell).
+template <typename T>
+__device__ T cell_pairwise(const T* a, int n) {
+  if (n < 8) {
+    T r = (T)-0.0;
+    for (int i = 0; i < n; ++i) r += a[i];
+    return r;
+  }
+  if (n <= 128) {
+    T r[8];
+    for (int u = 0; u < 8; ++u) r[u] = a[u];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int u = 0; u < 8; ++u) r[u] += a[i + u];
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return cell_pairwise(a, n2) + cell_pairwise(a + n2, n - n2);  // (six levels deep at most: a piece is 8192 long)
+}
+template <typename T>
+__global__ void frames_sum_cell_kernel(const T* __restrict__ frames, int n, T* __restrict__ out) {
+  T total = (T)-0.0;
+  for (int piece = 0; piece < n; piece += 8192) total += cell_pairwise(frames + piece, n - piece < 8192 ? n - piece : 8192);
+  *out = total;
+}
+
+template <typename Tin, bool IS_BOOL>
+int launch_frames_sum(const void* frames, int n, long long pixels, void* out, hipStream_t s) {
+  using A = typename std::conditional<IS_BOOL, long long, typename SumOf<Tin>::type>::type;
+  if constexpr (std::is_floating_point<Tin>::value) {
+    if (pixels == 1) {
+      hipLaunchKernelGGL((frames_sum_cell_kernel<Tin>), dim3(1), dim3(1), 0, s, (const Tin*)frames, n, (Tin*)out);
+      return GM_OK;
+    }
+  }
+  constexpr int VV = 16 / (int)sizeof(A);  // the wider side (the accumulator) sets the vector width
+  const bool vec = VV > 1 && (pixels % VV) == 0 && ((uintptr_t)frames % (VV * sizeof(Tin))) == 0 && ((uintptr_t)out % 16) == 0;
+  if (vec) {
+    const unsigned gx = (unsigned)((pixels / VV + 255) / 256);
+    hipLaunchKernelGGL((frames_sum_kernel<Tin, IS_BOOL, VV>), dim3(gx), dim3(256), 0, s, (const Tin*)frames, n, pixels, (A*)out);
+  } else {
+    const unsigned gx = (unsigned)((pixels + 255) / 256);
+    hipLaunchKernelGGL((frames_sum_kernel<Tin, IS_BOOL, 1>), dim3(gx), dim3(256), 0, s, (const Tin*)frames, n, pixels, (A*)out);
+  }
+  return GM_OK;
+}
 
 #define GM_TEMPORAL_DISPATCH(CALL)                                   \
   switch (dtype) {                                                   \
@@ -832,6 +959,78 @@ int gm_temporal_cumulative(const void* frames, int dtype, int has_ndv, uint64_t 
 #define GM_CUM(T) cumulative_of<T>(statistic, frames, ndv_bits, has_ndv, (long long)pixels, bins, n_bins, emit_first, emit_stop, out, fill_bits, s)
   GM_TEMPORAL_DISPATCH(GM_CUM)
 #undef GM_CUM
+  if (rc != GM_OK) return rc;
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_frames_take(const void* frames, size_t frame_bytes, int64_t n_frames, const int32_t* index, int n_out, void* out) {
+  if (!frames || !out || (!index && n_out)) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (n_frames < 0 || n_out < 0 || n_out > 65535) return gm::fail(GM_ERR_INVALID, "gm_frames_take: %d frames out of %lld", n_out, (long long)n_frames);
+  for (int j = 0; j < n_out; ++j)
+    if (index[j] < 0 || index[j] >= n_frames) return gm::fail(GM_ERR_INVALID, "gm_frames_take: frame %d of %lld", index[j], (long long)n_frames);
+  if (n_out == 0 || frame_bytes == 0) return GM_OK;
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  int* index_dev = nullptr;
+  int rc = gm_malloc((void**)&index_dev, sizeof(int) * (size_t)n_out);
+  if (rc) return rc;
+  hipError_t e = hipMemcpyAsync(index_dev, index, sizeof(int) * (size_t)n_out, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // (the caller's index may go away after this call)
+  if (e != hipSuccess) {
+    (void)gm_free(index_dev);
+    return gm::hip_fail(e, "gm_frames_take: index upload");
+  }
+  // the widest word that divides the frame size and both base addresses
+  const uintptr_t both = (uintptr_t)frames | (uintptr_t)out | (uintptr_t)frame_bytes;
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+#define GM_TAKE(W)                                                                                                     \
+  do {                                                                                                                 \
+    const long long words = (long long)(frame_bytes / sizeof(W));                                                      \
+    hipLaunchKernelGGL((frames_take_kernel<W>), dim3((unsigned)((words + 1023) / 1024), (unsigned)n_out), dim3(256), 0, s, \
+                       (const W*)frames, words, (const int*)index_dev, (W*)out);                                      \
+  } while (0)
+  if (both % 16 == 0) GM_TAKE(u4);
+  else if (both % 4 == 0) GM_TAKE(unsigned);
+  else GM_TAKE(unsigned char);
+#undef GM_TAKE
+  e = hipGetLastError();
+  (void)gm_free(index_dev);  // (stream-ordered pool: reuse happens behind the kernel)
+  return e == hipSuccess ? GM_OK : gm::hip_fail(e, "gm_frames_take");
+}
+
+int gm_frames_sum_dtype(int dtype) {
+  switch (dtype) {
+    case GM_BOOL: case GM_I8: case GM_I16: case GM_I32: case GM_I64: return GM_I64;
+    case GM_U8: case GM_U16: case GM_U32: case GM_U64: return GM_U64;
+    case GM_F32: return GM_F32;
+    case GM_F64: return GM_F64;
+    default: return -1;
+  }
+}
+
+int gm_frames_sum(const void* frames, int dtype, int64_t n_frames, int64_t pixels, void* out) {
+  if (!frames || !out) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (n_frames <= 0 || n_frames > 0x7fffffff || pixels < 0) return gm::fail(GM_ERR_INVALID, "gm_frames_sum: %lld frames of %lld cells", (long long)n_frames, (long long)pixels);
+  if (pixels == 0) return GM_OK;
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  int rc = GM_OK;
+  const int n = (int)n_frames;
+  switch (dtype) {
+    case GM_BOOL: rc = launch_frames_sum<unsigned char, true>(frames, n, pixels, out, s); break;
+    case GM_U8: rc = launch_frames_sum<unsigned char, false>(frames, n, pixels, out, s); break;
+    case GM_I8: rc = launch_frames_sum<signed char, false>(frames, n, pixels, out, s); break;
+    case GM_U16: rc = launch_frames_sum<unsigned short, false>(frames, n, pixels, out, s); break;
+    case GM_I16: rc = launch_frames_sum<short, false>(frames, n, pixels, out, s); break;
+    case GM_U32: rc = launch_frames_sum<unsigned int, false>(frames, n, pixels, out, s); break;
+    case GM_I32: rc = launch_frames_sum<int, false>(frames, n, pixels, out, s); break;
+    case GM_U64: rc = launch_frames_sum<unsigned long long, false>(frames, n, pixels, out, s); break;
+    case GM_I64: rc = launch_frames_sum<long long, false>(frames, n, pixels, out, s); break;
+    case GM_F32: rc = launch_frames_sum<float, false>(frames, n, pixels, out, s); break;
+    case GM_F64: rc = launch_frames_sum<double, false>(frames, n, pixels, out, s); break;
+    default: return gm::fail(GM_ERR_UNSUPPORTED, "gm_frames_sum: dtype %d", dtype);
+  }
   if (rc != GM_OK) return rc;
   GM_HIP(hipGetLastError());
   return GM_OK;

@@ -33,6 +33,7 @@ __all__ = ["evaluate", "ViewPlan", "clear"]
 
 MAX_PLANS_PER_VIEW = 32
 _NO_PLAN = object()
+_lock = threading.RLock()
 
 
 def _request_key(request):
@@ -152,17 +153,19 @@ def view_plan(view, request):
     if key is None:
         return None
     plans = view.__dict__.get("_gm_plans")
-    if plans is None:
-        plans = view.__dict__["_gm_plans"] = {}
-    hit = plans.get(key)
+    hit = plans.get(key) if plans is not None else None
     if hit is None:
-        try:
-            hit = _build_view_plan(view, request) or _NO_PLAN
-        except NotImplementedError:
-            hit = _NO_PLAN
-        if len(plans) >= MAX_PLANS_PER_VIEW:
-            plans.clear()
-        plans[key] = hit
+        with _lock:  # get_data may run on several threads: one of them builds the plan
+            plans = view.__dict__.setdefault("_gm_plans", {})
+            hit = plans.get(key)
+            if hit is None:
+                try:
+                    hit = _build_view_plan(view, request) or _NO_PLAN
+                except NotImplementedError:
+                    hit = _NO_PLAN
+                if len(plans) >= MAX_PLANS_PER_VIEW:
+                    plans.clear()
+                plans[key] = hit
     return None if hit is _NO_PLAN else hit
 
 

@@ -146,8 +146,10 @@ def _nan_function(stack, statistic, percentile, fill_value, dtype):
         from .temporal import aggregate_frames
         name = "median" if statistic == "median" else "p%r" % float(percentile)
         frames = stacked.reshape((n, bands * shape[1], shape[2]))
-        # (a cell without data in any raster gets the fill value, like with every other statistic)
-        result = aggregate_frames(frames, None, [(0, n)], name, storage, fill=storage.type(fill_value)).reshape(shape)
+        # (a cell without data in any raster gets the fill value, like with every other statistic; a median that is
+        #  infinite or NaN -- inf - inf between the middle pair -- stays what it is, reduction.py:113-115)
+        result = aggregate_frames(frames, None, [(0, n)], name, storage, fill=storage.type(fill_value),
+                                  keep_nonfinite=True).reshape(shape)
         if storage == dtype:
             return result
         like_x86 = dtype.kind in "iub" and dtype.itemsize <= 4 and dtype != np.dtype("u4")

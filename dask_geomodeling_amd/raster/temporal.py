@@ -274,16 +274,22 @@ def _fill_bits(statistic, dtype):
     return runtime.scalar_bits(0 if statistic in _EXTENSIVE else get_dtype_max(dtype), dtype)
 
 
-def aggregate_frames(values, no_data_value, runs, statistic, dtype, fill=None):
+def aggregate_frames(values, no_data_value, runs, statistic, dtype, fill=None, keep_nonfinite=False):
     """(frames, h, w) tile + [(first, count)] per label -> (labels, h, w) device tile of ``dtype``
     (the loop of temporal.py:743-766 as one launch).  ``fill``: what a label without a finite result gets
-    (default: the reference's, 0 for the additive statistics, else the dtype's maximum)."""
+    (default: the reference's, 0 for the additive statistics, else the dtype's maximum).  ``keep_nonfinite``
+    (median / percentiles): only the cells without a data frame get ``fill``, an infinite or NaN result stays
+    (what reduce_rasters does, reduction.py:113-115)."""
     from ..hip import runtime
     from ..hip.array import DeviceArray
     name, percentile = parse_statistic(statistic)
     if name not in STATISTIC_CODES and percentile is None:
         raise NotImplementedError("TemporalAggregate statistic %r" % statistic)
     src, code, has, bits, frames, height, width = _reduce_args(values, no_data_value)
+    if keep_nonfinite:
+        if name != "median" and percentile is None:
+            raise NotImplementedError("keep_nonfinite with statistic %r" % statistic)
+        has |= 2  # GM_TEMPORAL_KEEP_NONFINITE
     longest = max([count for _, count in runs] + [1])
     # (median / percentiles: a cell's data frames are sorted in LDS up to MAX_MEDIAN_FRAMES float32 / 320 float64
     #  frames per label; longer bins -- a year of hourly frames -- are selected in global memory: no limit)

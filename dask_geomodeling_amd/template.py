@@ -25,6 +25,8 @@ Keys keep the reference's form ``<classname lowercase>_<32 hex>`` (core/graphs.p
 A request whose template cannot be built (fused graph of another shape, other modes) takes the full
 ``get_compute_graph`` + ``fuse_graph`` path; ``geomodeling.templates = False`` switches the templates off.
 """
+import threading
+
 from . import config as _config
 from .core.graphs import Block, _request_token
 
@@ -36,6 +38,14 @@ _NONE = object()
 # what the real-dask driver and the tests read: templates built, requests served from one, requests that took
 # the full path
 stats = {"built": 0, "hits": 0, "full": 0}
+# get_data runs on the threads of the configured scheduler: templates are built and put into their view's cache, and
+# the counters are updated, under this lock (the look-up of an existing template takes no lock)
+_lock = threading.RLock()
+
+
+def _count(name, n=1):
+    with _lock:
+        stats[name] += n
 
 _SAME = ("bbox", "width", "height", "projection", "mode")
 
@@ -86,9 +96,12 @@ class _KeyMaker(object):
 
 
 def _request_key(request):
-    """Hashable identity of a request up to its bounding box, or None."""
+    """Hashable identity of a request up to its bounding box, or None.  The type of every value is part of it:
+    256, 256.0 and True are equal and hash alike but print differently, and the template's _KeyMakers hold the
+    printed request."""
     try:
-        key = tuple(sorted((k, tuple(v) if isinstance(v, list) else v) for k, v in request.items() if k != "bbox"))
+        key = tuple(sorted((k, type(v), tuple(v) if isinstance(v, list) else v)
+                           for k, v in request.items() if k != "bbox"))
         hash(key)
         return key
     except TypeError:
@@ -172,19 +185,21 @@ def _view_template(view, request):
     if key is None:
         return None
     cache = view.__dict__.get("_gm_templates")
-    if cache is None:
-        cache = view.__dict__["_gm_templates"] = {}
-    hit = cache.get(key)
+    hit = cache.get(key) if cache is not None else None
     if hit is None:
-        try:
-            hit = _build_view_template(view, request) or _NONE
-        except NotImplementedError:
-            hit = _NONE
-        if len(cache) >= MAX_TEMPLATES_PER_VIEW:
-            cache.clear()
-        cache[key] = hit
-        if hit is not _NONE:
-            stats["built"] += 1
+        with _lock:
+            cache = view.__dict__.setdefault("_gm_templates", {})
+            hit = cache.get(key)  # another thread may have built it meanwhile
+            if hit is None:
+                try:
+                    hit = _build_view_template(view, request) or _NONE
+                except NotImplementedError:
+                    hit = _NONE
+                if len(cache) >= MAX_TEMPLATES_PER_VIEW:
+                    cache.clear()
+                cache[key] = hit
+                if hit is not _NONE:
+                    stats["built"] += 1
     return None if hit is _NONE else hit
 
 
@@ -225,7 +240,7 @@ def _tiler(tiler, request, graph):
         names = [_graph_of(store, tile_request, graph) for _, tile_request in pairs[1:]]
         graph[name] = (type(tiler).process, kwargs) + tuple(names)
         return name
-    stats["hits"] += len(templates)
+    _count("hits", len(templates))
     index_of, order, members, layout = {}, [], [], []
     for tpl, (_, tile_request) in zip(templates, pairs[1:]):
         b = index_of.get(id(tpl))
@@ -237,15 +252,17 @@ def _tiler(tiler, request, graph):
         members[b].append(tile_request["bbox"])
     signature = (tuple(id(t) for t in order), tuple(layout))
     cache = tiler.__dict__.get("_gm_assemblies")
-    if cache is None:
-        cache = tiler.__dict__["_gm_assemblies"] = {}
-    assembly = cache.get(signature)
+    assembly = cache.get(signature) if cache is not None else None
     if assembly is None:
-        if len(cache) >= MAX_TEMPLATES_PER_VIEW:
-            cache.clear()
-        tasks = [BatchedTask([tpl.run] * len(boxes)) for tpl, boxes in zip(order, members)]
-        # (the FusedTasks -- hence the templates' programs -- are kept alive by the assembly)
-        assembly = cache[signature] = TiledAssembly(type(tiler).process, layout, tasks)
+        with _lock:
+            cache = tiler.__dict__.setdefault("_gm_assemblies", {})
+            assembly = cache.get(signature)
+            if assembly is None:
+                if len(cache) >= MAX_TEMPLATES_PER_VIEW:
+                    cache.clear()
+                tasks = [BatchedTask([tpl.run] * len(boxes)) for tpl, boxes in zip(order, members)]
+                # (the FusedTasks -- hence the templates' programs -- are kept alive by the assembly)
+                assembly = cache[signature] = TiledAssembly(type(tiler).process, layout, tasks)
     leaf_names = []
     for tpl, boxes in zip(order, members):
         for bbox in boxes:
@@ -268,11 +285,11 @@ def _graph_of(block, request, graph, key=None):
             return _one_level(block, request, graph, key)
         tpl = _view_template(block, request)
         if tpl is not None:
-            stats["hits"] += 1
+            _count("hits")
             return tpl.instantiate(block, request, graph)
     # everything else: the whole graph, fused as a whole
     from .fuse import fuse_graph
-    stats["full"] += 1
+    _count("full")
     full, name = block.get_compute_graph(**request)
     graph.update(fuse_graph(full, name))
     return name

@@ -470,7 +470,12 @@ int gm_temporal_out_dtype(int dtype, int statistic);
  * dtype's maximum).  Output frames no bin writes to are left untouched (gm_fill them first).
  * Accumulation runs frame by frame in result_type(float32, out dtype), like NumPy's axis-0
  * reductions; the mean divides in float64 and rounds once.  The median sorts the data frames of a
- * cell in LDS (one column per lane) and returns (low + high) / 2 as np.ma.median does. */
+ * cell in LDS (one column per lane) and returns (low + high) / 2 as np.ma.median does.
+ * has_ndv: bit 0 = cells equal to ndv are no data; for GM_STAT_MEDIAN and gm_temporal_percentile bit 1
+ * (GM_TEMPORAL_KEEP_NONFINITE) leaves a result that is not finite as it is and fills only the cells without a
+ * data frame -- what reduce_rasters does with its nan-functions (reduction.py:113-115), where TemporalAggregate
+ * fills both (temporal.py:760-766). */
+#define GM_TEMPORAL_KEEP_NONFINITE 2
 int gm_temporal_aggregate(const void* frames, int dtype, int has_ndv, uint64_t ndv_bits, int64_t n_frames, int64_t pixels,
                           const gm_frame_bin* bins, int n_bins, int n_out, int statistic, void* out, uint64_t fill_bits);
 
@@ -487,6 +492,19 @@ typedef struct gm_percentile_step {
 int gm_temporal_percentile(const void* frames, int dtype, int has_ndv, uint64_t ndv_bits, int64_t n_frames, int64_t pixels,
                            const gm_frame_bin* bins, int n_bins, int n_out, const gm_percentile_step* plan, int n_plan,
                            void* out, uint64_t fill_bits);
+
+/* Snap.process / Resample.process (raster/temporal.py:165-182, 1196-1214): `data["values"][nearest]` -- output frame
+ * j is source frame index[j] (0 <= index[j] < n_frames; index on the host, n_out <= 65535).  frames: (n_frames,
+ * frame_bytes) C-contiguous on the device, out: (n_out, frame_bytes). */
+int gm_frames_take(const void* frames, size_t frame_bytes, int64_t n_frames, const int32_t* index, int n_out, void* out);
+
+/* TemporalSum.process (raster/temporal.py:239-257): `data["values"].sum(axis=0)` -- np.sum over the frame axis of a
+ * (n_frames, pixels) stack, no-data values added like any other value, in np.sum's accumulator type
+ * (gm_frames_sum_dtype: int64 for bool and signed integers, uint64 for unsigned ones, the type itself for floats),
+ * which is the type of `out` (pixels).  Floats add frame by frame like NumPy's reduction over the outer axis; a
+ * raster of one cell is NumPy's pairwise sum in pieces of 8192 frames. */
+int gm_frames_sum_dtype(int dtype);
+int gm_frames_sum(const void* frames, int dtype, int64_t n_frames, int64_t pixels, void* out);
 
 /* reduce_rasters (raster/reduction.py:38-119), the part behind NumPy's nan-functions: `stack` is the
  * (n, pixels) C-contiguous stack the reference builds in its work dtype result_type(dtype, float16) with NaN

@@ -1629,6 +1629,58 @@ def test_reduce_rasters_median_over_650_rasters(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [9, 40, 90, 650])
+def test_reduce_rasters_median_keeps_non_finite_results(gpu, n):
+    """reduction.py:113-115 protects only the cells without a data raster: a median that is +-inf, the mean of a middle
+    pair that overflows and the NaN of inf - inf stay what they are -- on every route (register network, LDS sort,
+    selection in global memory beyond 64 rasters)."""
+    from dask_geomodeling_amd.raster.reduction import reduce_rasters
+    rng = np.random.default_rng(100 + n)
+    ndv = np.float32(-1.0)
+    big = np.float32(3.0e38)
+    stack = []
+    for i in range(n):
+        v = (rng.random((1, 6, 16)) * 80).astype("f4")
+        v[rng.random(v.shape) < 0.1] = ndv
+        v[0, 0, 0] = ndv                                   # no data anywhere: the fill value
+        v[0, 0, 1] = np.inf                                # median +inf
+        v[0, 0, 2] = -np.inf                               # median -inf
+        v[0, 0, 3] = np.inf if i % 2 else -np.inf          # even n: (-inf + inf) / 2 = NaN
+        v[0, 0, 4] = big                                   # (big + big) overflows before the halving
+        v[0, 0, 5] = np.inf if i < n // 2 else np.float32(i)  # percentile interpolation with an infinite neighbour
+        stack.append({"values": v, "no_data_value": ndv})
+    for stat in ("median", "p50", "p30", "p99"):
+        out = reduce_rasters([dict(d) for d in stack], stat)
+        with np.errstate(all="ignore"):
+            want = O.reduce_rasters([dict(d) for d in stack], stat)
+        got = np.asarray(out["values"])
+        assert got[0, 0, 0] == ndv and want["values"][0, 0, 0] == ndv
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want["values"]), err_msg=stat)
+        assert_values_equal(np.nan_to_num(got, nan=0.0) + 0.0, np.nan_to_num(want["values"], nan=0.0) + 0.0, 0, "%s of %d" % (stat, n))
+    assert not np.isfinite(np.asarray(reduce_rasters([dict(d) for d in stack], "median")["values"])[0, 0, 1:3]).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4096, 4097, 8193, 9001, 17000])
+@pytest.mark.parametrize("dtype", ["f4", "f8"])
+def test_reduce_rasters_sums_over_deep_stacks(gpu, n, dtype):
+    """sum / mean / var / std over more rasters than the unrolled pairwise recursion covers (128 * 2^5): NumPy's
+    pairwise order walked with an explicit stack (csrc/gm_reduce.hip pw_sum, DEPTH < 0), bit for bit."""
+    from dask_geomodeling_amd.raster.reduction import reduce_rasters
+    rng = np.random.default_rng(n)
+    ndv = np.dtype(dtype).type(-5.0)
+    base = (rng.random((n, 1, 3, 7)) * 1000 - 300).astype(dtype)
+    base[rng.random(base.shape) < 0.05] = ndv
+    base[:, 0, 0, 0] = ndv
+    stack = [{"values": base[i], "no_data_value": ndv} for i in range(n)]
+    for stat in ("sum", "mean", "var", "std"):
+        out = reduce_rasters([dict(d) for d in stack], stat)
+        with np.errstate(all="ignore"):
+            want = O.reduce_rasters([dict(d) for d in stack], stat)
+        assert_values_equal(np.asarray(out["values"]), want["values"], 0, "%s over %d %s rasters" % (stat, n, dtype))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("blocks", ["1", "0"], ids=["block-pipeline", "wave-per-label"])
 def test_zonal_block_pipeline(gpu, blocks):
     """Sums of long labels, block-parallel (csrc/gm_zonal.hip: every 256-cell block as "sum += D[sum mod 2]" while the
