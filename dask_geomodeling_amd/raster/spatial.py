@@ -1,5 +1,5 @@
 """Spatial Blocks: the 3x3 / small-radius stencils of the reference (Dilate, MovingMax, HillShade,
-raster/spatial.py:111-213, 320-440) and SpatialResample.
+raster/spatial.py:111-213, 320-440), Place (spatial.py:441-731) and SpatialResample.
 
 The stencil Blocks enlarge the request by their radius (``expand_request_pixels``,
 spatial.py:27-47) -- the halo is recomputed per tile, never exchanged, so tiles stay independent --
@@ -12,13 +12,17 @@ step.  ``SpatialResample`` is the Block form of kernels K6/K7: it asks its store
 ``zoom`` times coarser grid over the same bbox and resamples the answer to the requested
 grid with nearest-neighbour or bilinear interpolation (spec in DESIGN.md).
 """
+import ctypes
+import math
+
 import numpy as np
 
+from .. import utils
 from . import resample, stencil
 from ._checks import argument, need_number
-from .base import BaseSingle
+from .base import BaseSingle, RasterBlock
 
-__all__ = ["SpatialResample", "Dilate", "MovingMax", "HillShade", "Smooth"]
+__all__ = ["SpatialResample", "Dilate", "MovingMax", "HillShade", "Smooth", "Place"]
 
 
 def expand_request_pixels(request, radius=1):
@@ -256,3 +260,213 @@ class Smooth(BaseSingle):
             zoom = 1 - 2 * size_px[0] / ny, 1 - 2 * size_px[1] / nx
             values = resample.affine_nearest(values, zoom, (size_px[0], size_px[1]))
         return {"values": values, "no_data_value": ndv}
+
+
+def _same_crs_point(point, source_projection, target_projection):
+    """A point of one projection in another: the identity between equal projections; anything else needs PROJ."""
+    if utils.same_projection(source_projection, target_projection):
+        return float(point[0]), float(point[1])
+    raise NotImplementedError("re-projection ({} -> {}) is outside the MI355X raster path (no PROJ/GDAL)".format(
+        source_projection, target_projection))
+
+
+def _filled(shape, value, dtype):
+    """np.full(shape, value, dtype) on the device."""
+    from ..hip import runtime
+    from ..hip.array import DeviceArray
+    from ..hip.dtypes import code_of
+    out = DeviceArray.empty(shape, dtype)
+    if out.size:
+        runtime.check(runtime.lib().gm_fill(ctypes.c_void_p(out.ptr), code_of(out.dtype),
+                                            runtime.scalar_bits(value, out.dtype), out.size), "gm_fill")
+    return out
+
+
+def _shifted_copy(source, fill, out_shape, di, dj):
+    """full(out_shape, fill) with ``source`` pasted so that source cell (j, i) lands on (j + dj, i + di); cells that
+    fall outside are dropped (the two 'place' branches of spatial.py:700-718 before their data test)."""
+    from ..hip import runtime
+    out = _filled(out_shape, fill, source.dtype)
+    bands, src_h, src_w = source.shape
+    _, dst_h, dst_w = out_shape
+    i0, i1 = max(0, -di), min(src_w, dst_w - di)  # source columns that land inside
+    j0, j1 = max(0, -dj), min(src_h, dst_h - dj)
+    if i1 <= i0 or j1 <= j0:
+        return out
+    item = source.dtype.itemsize
+    L = runtime.lib()
+    L.gm_copy_2d.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                             ctypes.c_size_t]
+    for band in range(bands):
+        src_ptr = source.ptr + ((band * src_h + j0) * src_w + i0) * item
+        dst_ptr = out.ptr + ((band * dst_h + j0 + dj) * dst_w + i0 + di) * item
+        runtime.check(L.gm_copy_2d(ctypes.c_void_p(dst_ptr), dst_w * item, ctypes.c_void_p(src_ptr), src_w * item,
+                                   (i1 - i0) * item, j1 - j0), "gm_copy_2d")
+    return out
+
+
+def _has_data(values, no_data_value):
+    """get_index(values, no_data_value).any() (utils.py:61-64) without leaving the device."""
+    from . import devops
+    mask = devops.unary_bool_process("isdata", {"values": values, "no_data_value": no_data_value})["values"]
+    return not devops._all_false(mask)
+
+
+class Place(BaseSingle):
+    """Place an input raster at given coordinates (spatial.py:441-731): the ``anchor`` of the store is put on each of
+    ``coordinates``; where the placed copies overlap, ``statistic`` merges them (reduce_rasters).
+
+    Args: store, place_projection (projection of anchor and coordinates), anchor (x, y), coordinates ([(x, y) ...]),
+    statistic (last, first, count, sum, mean, min, max, argmin, argmax, product, std, var, p<number>).
+
+    This path carries no PROJ: the place projection, the store's projection and the requested one have to be the
+    same (anything else raises NotImplementedError)."""
+
+    def __init__(self, store, place_projection, anchor, coordinates, statistic="last"):
+        from .reduction import check_statistic
+        if not isinstance(store, RasterBlock):
+            raise TypeError("'{}' object is not allowed".format(type(store)))
+        if not isinstance(place_projection, str) or not place_projection.strip():
+            raise ValueError("'{}' is not a valid projection string".format(place_projection))
+        anchor = list(anchor)
+        if len(anchor) != 2:
+            raise ValueError("Expected 2 numbers in the 'anchor' parameter")
+        for x in anchor:
+            if not isinstance(x, (int, float)):
+                raise TypeError("'{}' object is not allowed".format(type(x)))
+        if coordinates is None or len(coordinates) == 0:
+            coordinates = []
+        else:
+            coordinates = np.asarray(coordinates, dtype=float)
+            if coordinates.ndim != 2 or coordinates.shape[1] != 2:
+                raise ValueError("Expected a list of lists of 2 numbers in the 'coordinates' parameter")
+            coordinates = coordinates.tolist()
+        check_statistic(statistic)
+        super().__init__(store, place_projection, anchor, coordinates, statistic)
+
+    place_projection = property(lambda self: self.args[1])
+    anchor = property(lambda self: self.args[2])
+    coordinates = property(lambda self: self.args[3])
+    statistic = property(lambda self: self.args[4])
+
+    @property
+    def projection(self):
+        """The store's projection when the place projection equals it, else None (spatial.py:509-519)."""
+        store_projection = self.store.projection
+        if store_projection is not None and utils.same_projection(self.place_projection, store_projection):
+            return store_projection
+
+    @property
+    def geo_transform(self):
+        if self.projection is not None:
+            return self.store.geo_transform
+
+    @property
+    def extent(self):
+        geometry = self.geometry
+        if geometry is None:
+            return
+        return utils.Extent.from_geometry(geometry).transformed("EPSG:4326").bbox
+
+    @property
+    def geometry(self):
+        """The store's box moved onto every coordinate, combined, in the place projection (spatial.py:536-549)."""
+        store_geometry = self.store.geometry
+        if store_geometry is None:
+            return
+        extent = utils.Extent.from_geometry(store_geometry).transformed(self.place_projection)
+        left, bottom, right, top = extent.bbox
+        p, q = self.anchor
+        xs, ys = zip(*self.coordinates)
+        box = (left + min(xs) - p, bottom + min(ys) - q, right + max(xs) - p, top + max(ys) - q)
+        return utils.Extent(box, extent.srs).as_geometry()
+
+    def get_sources_and_requests(self, **request):
+        if request["mode"] != "vals":
+            return ({"mode": request["mode"]}, None), (self.store, request)
+        anchor = _same_crs_point(self.anchor, self.place_projection, request["projection"])
+        coordinates = [_same_crs_point(c, self.place_projection, request["projection"]) for c in self.coordinates]
+        store_geometry = self.store.geometry
+        if store_geometry is None:  # no geometry: no data
+            return (({"mode": "null"}, None),)
+        xmin, ymin, xmax, ymax = utils.Extent.from_geometry(store_geometry).transformed(request["projection"]).bbox
+        x1, y1, x2, y2 = request["bbox"]
+        size_x = (x2 - x1) / request["width"]
+        size_y = (y2 - y1) / request["height"]
+        if size_x > 0 and size_y > 0:  # (point requests never ask for the whole source)
+            full_height = math.ceil((ymax - ymin) / size_y)
+            full_width = math.ceil((xmax - xmin) / size_x)
+            if full_height * full_width <= request["width"] * request["height"]:
+                # the whole source at the requested cell size is no larger than the request: fetch it once and paste
+                whole = request.copy()
+                whole["width"], whole["height"] = full_width, full_height
+                whole["bbox"] = (xmin, ymin, xmin + full_width * size_x, ymin + full_height * size_y)
+                process_kwargs = {"mode": "warp", "anchor": anchor, "coordinates": coordinates,
+                                  "src_bbox": whole["bbox"], "dst_bbox": request["bbox"],
+                                  "cellsize": (size_x, size_y), "statistic": self.statistic}
+                return [(process_kwargs, None), (self.store, whole)]
+        # else one request per coordinate, shifted backwards; cells are [xmin, xmax) x (ymin, ymax]
+        pairs = []
+        for x, y in coordinates:
+            box = [x1 + anchor[0] - x, y1 + anchor[1] - y, x2 + anchor[0] - x, y2 + anchor[1] - y]
+            if box[0] >= xmax or box[1] > ymax or box[2] < xmin or box[3] <= ymin:
+                continue
+            shifted = request.copy()
+            shifted["bbox"] = box
+            pairs.append((self.store, shifted))
+        if not pairs:
+            # nothing lands inside: a time request tells how many bands the empty answer has
+            probe = request.copy()
+            probe["mode"] = "time"
+            process_kwargs = {"mode": "empty", "dtype": self.dtype, "fillvalue": self.fillvalue,
+                              "width": request["width"], "height": request["height"], "statistic": self.statistic}
+            return [(process_kwargs, None), (self.store, probe)]
+        return [({"mode": "group", "statistic": self.statistic}, None)] + pairs
+
+    @staticmethod
+    def process(process_kwargs, *multi):
+        from ..hip.array import as_device
+        from .reduction import reduce_rasters
+        mode = process_kwargs["mode"]
+        if mode in {"meta", "time"}:
+            return multi[0]
+        if mode == "null":
+            return
+        if mode == "empty":
+            data = multi[0]
+            if data is None:
+                return
+            out_shape = (len(data["time"]), process_kwargs["height"], process_kwargs["width"])
+            out_no_data_value, out_dtype = process_kwargs["fillvalue"], np.dtype(process_kwargs["dtype"])
+            stack = []
+        elif mode == "group":
+            stack = [data for data in multi if data is not None]
+            if len(stack) == 0:
+                return
+        elif mode == "warp":
+            data = multi[0]
+            if data is None:
+                return
+            out_no_data_value = data["no_data_value"]
+            source = as_device(data["values"])
+            out_dtype = source.dtype
+            anchor, src_bbox = process_kwargs["anchor"], process_kwargs["src_bbox"]
+            size_x, size_y = process_kwargs["cellsize"]
+            anchor_px = ((anchor[0] - src_bbox[0]) / size_x, (anchor[1] - src_bbox[1]) / size_y)
+            x1, y1, x2, y2 = process_kwargs["dst_bbox"]
+            dst_h, dst_w = round((y2 - y1) / size_y), round((x2 - x1) / size_x)
+            src_d, src_h, src_w = source.shape
+            out_shape = (src_d, dst_h, dst_w)
+            stack = []
+            for x, y in process_kwargs["coordinates"]:
+                di = round((x - x1) / size_x - anchor_px[0])
+                dj = dst_h - src_h - round((y - y1) / size_y - anchor_px[1])  # (the array's y axis points down)
+                if di <= -src_w or di >= dst_w or dj <= -src_h or dj >= dst_h:
+                    continue  # shifted completely outside
+                placed = _shifted_copy(source, out_no_data_value, out_shape, di, dj)
+                # (a copy none of whose data cells lands inside is left out -- it would count in argmin / argmax)
+                if _has_data(placed, out_no_data_value):
+                    stack.append({"values": placed, "no_data_value": out_no_data_value})
+        if len(stack) == 0:
+            return {"values": _filled(out_shape, out_no_data_value, out_dtype), "no_data_value": out_no_data_value}
+        return reduce_rasters(stack, process_kwargs["statistic"])

@@ -1,6 +1,7 @@
-"""Statistics over the time axis (counterpart of raster/temporal.py:476-1003): ``TemporalAggregate``
-resamples a raster in time (hourly mean of 5-minute frames, ...), ``Cumulative`` accumulates frames
-inside every period.
+"""Blocks over the time axis (counterpart of raster/temporal.py): ``TemporalAggregate`` resamples a raster in
+time with a statistic (hourly mean of 5-minute frames, ...), ``Cumulative`` accumulates frames inside every period;
+``Snap`` / ``Resample`` re-arrange frames (every result frame is the nearest / next / previous source frame),
+``Shift`` moves the time axis, ``TemporalSum`` adds all frames up.
 
 Which frames belong to which label is calendar work and stays on the host, done with pandas exactly
 as the reference does (``Series.resample(...).indices``); a source's frames ascend in time, so every
@@ -18,7 +19,7 @@ from pandas.tseries.frequencies import to_offset
 from ..utils import get_dtype_max
 from .base import BaseSingle, RasterBlock
 
-__all__ = ["TemporalAggregate", "Cumulative"]
+__all__ = ["Snap", "Shift", "TemporalSum", "TemporalAggregate", "Cumulative", "Resample"]
 
 # frequencies whose bins pandas closes and labels on the right by default (TimeGrouper.__init__)
 _END_ANCHORED = {"M", "A", "Q", "BM", "BA", "BQ", "W", "ME", "YE", "QE", "BME", "BYE", "BQE"}
@@ -147,6 +148,28 @@ class _Calendar:
         if self.closed == "left":
             ts -= _TICK
         return self.moment(ts)
+
+    def shifted(self, dt, n):
+        """``dt`` moved by n periods of the rule, n possibly fractional: a fraction of a calendar period (a month)
+        is that fraction of the period it falls in (temporal.py:298-319)."""
+        if n == 0:
+            return dt
+        ts = self.stamp(dt)
+        step = to_offset(self.frequency)
+        if isinstance(n, float):
+            whole = int(n // 1.0)
+            part = n % 1.0 if n > 0 else -(n % 1.0)
+            ts = ts + ((ts + step * (whole + 1)) - (ts + step * whole)) * part
+        else:
+            ts = ts + n * step
+        return self.moment(ts)
+
+    def label_range(self, first, last):
+        """All labels from ``first`` to ``last`` inclusive; [first] when last is None (temporal.py:463-473)."""
+        if last is None:
+            return [first]
+        stamps = pd.date_range(start=self.stamp(first), end=self.stamp(last), freq=to_offset(self.frequency))
+        return [self.moment(ts) for ts in stamps]
 
     # -- periods and windows -------------------------------------------------------------
     def resampled_period(self, period):
@@ -342,6 +365,278 @@ def _check_statistic(statistic, known):
     if statistic not in known:
         raise ValueError("Unknown statistic '{}'".format(statistic))
     return statistic
+
+
+
+def find_neighbours(array, value, direction="nearest"):
+    """Index into the ascending ``array`` of the neighbour of every ``value``: the nearest one (ties go to the
+    earlier element), the first one not before it ('forward') or the last one not after it ('backward'); never out
+    of bounds (utils.py:929-958, ``find_neigbours``)."""
+    array, value = np.asarray(array), np.asarray(value)
+    if array.size == 1:
+        return np.zeros(value.shape, dtype=int)
+    if direction == "nearest":
+        halfway = array[:-1] + (array[1:] - array[:-1]) / 2
+        found = np.searchsorted(halfway, value)
+    elif direction == "forward":
+        found = np.searchsorted(array, value, side="left")
+    elif direction == "backward":
+        found = np.searchsorted(array, value, side="right") - 1
+    else:
+        raise ValueError("Unknown direction: {}".format(direction))
+    return np.clip(found, 0, array.size - 1)
+
+
+def take_frames(values, nearest):
+    """``values[nearest]`` on the device: result frame j is source frame nearest[j] (csrc/gm_temporal.hip
+    gm_frames_take)."""
+    from ..hip import runtime
+    from ..hip.array import DeviceArray, as_device
+    src = as_device(values)
+    nearest = np.ascontiguousarray(nearest, dtype=np.int32).ravel()
+    out = DeviceArray.empty((len(nearest),) + src.shape[1:], src.dtype)
+    frame_bytes = int(np.prod(src.shape[1:], dtype=np.int64)) * src.dtype.itemsize
+    L = runtime.lib()
+    L.gm_frames_take.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                 ctypes.c_void_p]
+    L.gm_frames_take.restype = ctypes.c_int
+    runtime.check(L.gm_frames_take(src.ptr, frame_bytes, src.shape[0], nearest.ctypes.data_as(ctypes.c_void_p),
+                                   len(nearest), out.ptr), "gm_frames_take")
+    return out
+
+
+def sum_frames(values):
+    """``values.sum(axis=0)[np.newaxis]`` on the device, in np.sum's accumulator dtype (gm_frames_sum)."""
+    from ..hip import runtime
+    from ..hip.array import DeviceArray, as_device
+    from ..hip.dtypes import code_of, dtype_of
+    src = as_device(values)
+    L = runtime.lib()
+    L.gm_frames_sum.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    L.gm_frames_sum.restype = ctypes.c_int
+    code = code_of(src.dtype)
+    out = DeviceArray.empty((1,) + src.shape[1:], dtype_of(L.gm_frames_sum_dtype(code)))
+    if src.shape[0] == 0:  # (a sum of nothing)
+        runtime.check(L.gm_fill(ctypes.c_void_p(out.ptr), code_of(out.dtype), runtime.scalar_bits(0, out.dtype), out.size),
+                      "gm_fill")
+        return out
+    runtime.check(L.gm_frames_sum(src.ptr, code, src.shape[0], int(np.prod(src.shape[1:], dtype=np.int64)), out.ptr),
+                  "gm_frames_sum")
+    return out
+
+
+def _time_set(block, start=None, stop=None):
+    answer = block.get_data(mode="time", start=start, stop=stop)
+    return set() if answer is None else set(answer["time"])
+
+
+def _frames_near(block, start, stop):
+    """The frames of ``block`` near ``start``, between the two and near ``stop``: a result frame may be nearest to
+    a source frame outside the requested interval (temporal.py:144-157, 1166-1176)."""
+    return sorted(_time_set(block, start=start) | _time_set(block, start=start, stop=stop) | _time_set(block, start=stop))
+
+
+def _rearranged(process_kwargs, data):
+    """data with its frames (values or meta) picked by process_kwargs["nearest"] (temporal.py:172-182)."""
+    nearest = process_kwargs["nearest"]
+    if "values" in data:
+        return dict(data, values=take_frames(data["values"], nearest))
+    if "meta" in data:
+        return dict(data, meta=[data["meta"][i] for i in nearest])
+
+
+class Snap(RasterBlock):
+    """Snap the time structure of a raster to that of another raster (temporal.py:42-182): the cell values of
+    ``store`` at the time stamps of ``index`` -- for every index frame the store frame closest in time.
+
+    Args: store (cell values), index (time stamps)."""
+
+    def __init__(self, store, index):
+        for x in (store, index):
+            if not isinstance(x, RasterBlock):
+                raise TypeError("'{}' object is not allowed".format(type(x)))
+        super(Snap, self).__init__(store, index)
+
+    store = property(lambda self: self.args[0])
+    index = property(lambda self: self.args[1])
+
+    def __len__(self):
+        return len(self.index)
+
+    dtype = property(lambda self: self.store.dtype)
+    fillvalue = property(lambda self: self.store.fillvalue)
+    period = property(lambda self: self.index.period if self.store else None)
+    timedelta = property(lambda self: self.index.timedelta)
+    temporal = property(lambda self: self.index.temporal)
+    extent = property(lambda self: self.store.extent)
+    geometry = property(lambda self: self.store.geometry)
+    projection = property(lambda self: self.store.projection)
+    geo_transform = property(lambda self: self.store.geo_transform)
+
+    def get_sources_and_requests(self, **request):
+        store_period, index_period = self.store.period, self.index.period
+        if store_period is None or index_period is None:  # an empty raster on either side: empty
+            return [(None, None)]
+        if request["mode"] == "time":  # the index answers time requests
+            return [(None, None), (self.index, request)]
+        start, stop = request.get("start"), request.get("stop")
+        index_answer = self.index.get_data(mode="time", start=start, stop=stop)
+        if index_answer is None:
+            return [(None, None)]
+        index_time = index_answer["time"]
+        if stop is None:  # one frame: the store is asked at the index's time stamp
+            request["start"] = index_time[0]
+            return [(None, None), (self.store, request)]
+        if store_period[0] == store_period[1]:
+            store_time = [store_period[0]]
+        else:
+            store_time = _frames_near(self.store, start, stop)
+        request["start"], request["stop"] = store_time[0], store_time[-1]
+        return [({"nearest": find_neighbours(store_time, index_time)}, None), (self.store, request)]
+
+    @staticmethod
+    def process(process_kwargs, data=None):
+        if process_kwargs is None:
+            return data
+        return _rearranged(process_kwargs, data)
+
+
+class Shift(BaseSingle):
+    """Shift a temporal raster by a timedelta (temporal.py:185-236): positive into the future.
+
+    Args: store, time (milliseconds, or a datetime.timedelta)."""
+
+    def __init__(self, store, time):
+        if isinstance(time, Timedelta):
+            time = int(time.total_seconds() * 1000)
+        if not isinstance(time, int):
+            raise TypeError("'{}' object is not allowed".format(type(time)))
+        super(Shift, self).__init__(store, time)
+
+    @property
+    def time(self):
+        return Timedelta(milliseconds=self.args[1])
+
+    @property
+    def period(self):
+        start, stop = self.store.period
+        return start + self.time, stop + self.time
+
+    def get_sources_and_requests(self, **request):
+        for key in ("start", "stop"):
+            if request.get(key) is not None:
+                request[key] = request[key] - self.time
+        return [(self.store, request), (self.time, None)]
+
+    @staticmethod
+    def process(data, time):
+        if data is None:
+            return None
+        if "time" in data:
+            return dict(data, time=[t + time for t in data["time"]])
+        return data
+
+
+class TemporalSum(BaseSingle):
+    """All frames of the store added up into one (temporal.py:239-255): a plain sum -- 'no data' values are added
+    like any other value -- in np.sum's accumulator dtype; time and meta answer with their last entry."""
+
+    @staticmethod
+    def process(data):
+        if data is None:
+            return data
+        if "time" in data:
+            return {"time": data["time"][-1:]}
+        if "meta" in data:
+            return {"meta": data["meta"][-1:]}
+        if "values" in data:
+            return {"values": sum_frames(data["values"]), "no_data_value": data["no_data_value"]}
+
+
+class Resample(BaseSingle):
+    """Resample a raster in time (temporal.py:1008-1214): the frames of the result lie at the labels of
+    ``frequency`` and each takes the nearest source frame, or the first one after / before it.
+
+    Args: source, frequency (pandas offset string), direction ('nearest', 'backward' or 'forward'), timezone."""
+
+    def __init__(self, source, frequency, direction="nearest", timezone="UTC"):
+        if not isinstance(source, RasterBlock):
+            raise TypeError("'{}' object is not allowed.".format(type(source)))
+        if not isinstance(frequency, str):
+            raise TypeError("'{}' object is not allowed.".format(type(frequency)))
+        frequency = normalize_offset(frequency)
+        if not isinstance(timezone, str):
+            raise TypeError("'{}' object is not allowed.".format(type(timezone)))
+        timezone = pytz.timezone(timezone).zone
+        if not isinstance(direction, str):
+            raise TypeError("'{}' object is not allowed.".format(type(direction)))
+        if direction not in {"nearest", "backward", "forward"}:
+            raise ValueError("direction must be one of 'nearest', 'backward', or 'forward'.")
+        super(Resample, self).__init__(source, frequency, direction, timezone)
+
+    source = property(lambda self: self.args[0])
+    frequency = property(lambda self: normalize_offset(self.args[1]))
+    direction = property(lambda self: self.args[2])
+    timezone = property(lambda self: self.args[3])
+
+    @property
+    def _calendar(self):
+        return _Calendar(self.frequency, None, None, self.timezone)
+
+    @property
+    def period(self):
+        """First and last label that can snap to a source frame (temporal.py:1080-1125): a label t reaches the
+        source frames in [t, t + p) forwards, (t - p, t] backwards, [t - p/2, t + p/2) for the nearest one."""
+        source_period = self.source.period
+        if source_period is None:
+            return None
+        calendar = self._calendar
+        first, last = source_period
+        if self.direction in ("forward", "backward"):
+            side = "left" if self.direction == "forward" else "right"
+            return calendar.nearest_label(first, side), calendar.nearest_label(last, side)
+        start = calendar.nearest_label(first, "left")
+        if first >= calendar.shifted(start, 0.5):  # too far to the left of the first frame to be nearest to it
+            start = calendar.nearest_label(first, "right")
+        end = calendar.nearest_label(last, "right")
+        if last < calendar.shifted(end, -0.5):
+            end = calendar.nearest_label(last, "left")
+        return start, end
+
+    @property
+    def timedelta(self):
+        return offset_to_timedelta(self.frequency)
+
+    def get_sources_and_requests(self, **request):
+        calendar = self._calendar
+        mode = request["mode"]
+        kwargs = {"mode": mode, "direction": self.direction, "frequency": self.frequency, "timezone": self.timezone}
+        kwargs["start"], kwargs["stop"] = calendar.snap_window(self.period, request.get("start"), request.get("stop"))
+        if kwargs["start"] is None:
+            return [({"empty": True, "mode": mode}, None)]
+        if mode == "time":  # the labels alone answer a time request
+            return [(kwargs, None)]
+        index_time = calendar.label_range(kwargs["start"], kwargs["stop"])
+        shift = {"forward": 0, "backward": -1}.get(self.direction, -0.5)
+        near_start = calendar.shifted(kwargs["start"], shift)
+        near_stop = calendar.shifted(kwargs["stop"] or kwargs["start"], shift + 1)
+        store_time = _frames_near(self.store, near_start, near_stop)
+        if not store_time:
+            return [({"empty": True, "mode": mode}, None)]
+        nearest = find_neighbours(store_time, index_time, self.direction)
+        request["start"], request["stop"] = store_time[nearest.min()], store_time[nearest.max()]
+        kwargs["nearest"] = nearest - nearest.min()
+        return [(kwargs, None), (self.store, request)]
+
+    @staticmethod
+    def process(process_kwargs, data=None):
+        mode = process_kwargs["mode"]
+        if process_kwargs.get("empty"):
+            return None if mode == "vals" else {mode: []}
+        if mode == "time":
+            calendar = _Calendar(process_kwargs["frequency"], None, None, process_kwargs["timezone"])
+            return {"time": calendar.label_range(process_kwargs["start"], process_kwargs["stop"])}
+        return _rearranged(process_kwargs, data)
 
 
 class TemporalAggregate(BaseSingle):

@@ -897,6 +897,133 @@ def cumulative_process(process_kwargs, time_data=None, data=None):
 
 
 # ---------------------------------------------------------------------------------
+# Snap / Shift / TemporalSum / Resample (raster/temporal.py:42-255, 1008-1214): the process() bodies.  The frame
+# re-arrangement is `values[nearest]`, TemporalSum is a plain `values.sum(axis=0)` (no-data values included).
+# ---------------------------------------------------------------------------------
+def take_frames(values, nearest):
+    """data["values"][nearest] (temporal.py:176, 1208)."""
+    return np.asarray(values)[np.asarray(nearest)]
+
+
+def frames_sum(values):
+    """data["values"].sum(axis=0)[np.newaxis, ...] (temporal.py:252)."""
+    return np.asarray(values).sum(axis=0)[np.newaxis, ...]
+
+
+def snap_process(process_kwargs, data=None):
+    """Snap.process (temporal.py:165-182)."""
+    if process_kwargs is None:
+        return data
+    nearest = process_kwargs["nearest"]
+    if "values" in data:
+        return dict(data, values=take_frames(data["values"], nearest))
+    if "meta" in data:
+        return dict(data, meta=[data["meta"][i] for i in nearest])
+
+
+def shift_process(data, time):
+    """Shift.process (temporal.py:227-235)."""
+    if data is None:
+        return None
+    if "time" in data:
+        return dict(data, time=[t + time for t in data["time"]])
+    return data
+
+
+def temporal_sum_process(data):
+    """TemporalSum.process (temporal.py:240-255)."""
+    if data is None:
+        return data
+    if "time" in data:
+        return {"time": data["time"][-1:]}
+    if "meta" in data:
+        return {"meta": data["meta"][-1:]}
+    if "values" in data:
+        return {"values": frames_sum(data["values"]), "no_data_value": data["no_data_value"]}
+
+
+def resample_process(process_kwargs, data=None):
+    """Resample.process (temporal.py:1189-1214)."""
+    import pandas as pd
+    from pandas.tseries.frequencies import to_offset
+    mode = process_kwargs["mode"]
+    if process_kwargs.get("empty"):
+        return None if mode == "vals" else {mode: []}
+    if mode == "time":
+        start, stop, tz = process_kwargs["start"], process_kwargs["stop"], process_kwargs["timezone"]
+        if stop is None:
+            return {"time": [start]}
+        stamps = pd.date_range(start=pd.Timestamp(start, tz="UTC").tz_convert(tz), end=pd.Timestamp(stop, tz="UTC").tz_convert(tz),
+                               freq=to_offset(process_kwargs["frequency"]))
+        return {"time": [ts.tz_convert("UTC").tz_localize(None).to_pydatetime(warn=False) for ts in stamps]}
+    nearest = process_kwargs["nearest"]
+    if "values" in data:
+        return dict(data, values=take_frames(data["values"], nearest))
+    if "meta" in data:
+        return dict(data, meta=[data["meta"][i] for i in nearest])
+
+
+# ---------------------------------------------------------------------------------
+# Place.process (raster/spatial.py:620-731): one source raster pasted at several positions ("warp": shifted copies
+# of its data cells), or already shifted rasters ("group"), merged by reduce_rasters.
+# ---------------------------------------------------------------------------------
+def place_process(process_kwargs, *multi):
+    mode = process_kwargs["mode"]
+    if mode in {"meta", "time"}:
+        return multi[0]
+    if mode == "null":
+        return
+    if mode == "empty":
+        data = multi[0]
+        if data is None:
+            return
+        out_shape = (len(data["time"]), process_kwargs["height"], process_kwargs["width"])
+        out_no_data_value = process_kwargs["fillvalue"]
+        out_dtype = process_kwargs["dtype"]
+        stack = []
+    elif mode == "group":
+        stack = [data for data in multi if data is not None]
+        if len(stack) == 0:
+            return
+    elif mode == "warp":
+        data = multi[0]
+        if data is None:
+            return
+        out_no_data_value = data["no_data_value"]
+        source = data["values"]
+        out_dtype = source.dtype
+        anchor = process_kwargs["anchor"]
+        src_bbox = process_kwargs["src_bbox"]
+        size_x, size_y = process_kwargs["cellsize"]
+        anchor_px = ((anchor[0] - src_bbox[0]) / size_x, (anchor[1] - src_bbox[1]) / size_y)
+        x1, y1, x2, y2 = process_kwargs["dst_bbox"]
+        dst_h = round((y2 - y1) / size_y)
+        dst_w = round((x2 - x1) / size_x)
+        src_d, src_h, src_w = source.shape
+        out_shape = (src_d, dst_h, dst_w)
+        k, j, i = np.where(get_index(source, out_no_data_value))
+        stack = []
+        for x, y in process_kwargs["coordinates"]:
+            if i.size == 0:
+                break
+            di = round((x - x1) / size_x - anchor_px[0])
+            dj = round((y - y1) / size_y - anchor_px[1])
+            dj = dst_h - src_h - dj  # (the y axis of the array runs the other way)
+            if di <= -src_w or di >= dst_w or dj <= -src_h or dj >= dst_h:
+                continue
+            i_s, j_s = i + di, j + dj
+            m = (i_s >= 0) & (j_s >= 0) & (i_s < dst_w) & (j_s < dst_h)
+            if not m.any():
+                continue
+            values = np.full(out_shape, out_no_data_value, out_dtype)
+            values[k[m], j_s[m], i_s[m]] = source[k[m], j[m], i[m]]
+            stack.append({"values": values, "no_data_value": out_no_data_value})
+    if len(stack) == 0:
+        return {"values": np.full(out_shape, out_no_data_value, out_dtype), "no_data_value": out_no_data_value}
+    return reduce_rasters(stack, process_kwargs["statistic"])
+
+
+# ---------------------------------------------------------------------------------
 # N4: zonal statistics -- geometry/aggregate.py:113-203 from the label rasters on
 # ---------------------------------------------------------------------------------
 ZONAL_STATISTICS = ("sum", "count", "min", "max", "mean", "median", "percentile")

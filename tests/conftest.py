@@ -58,6 +58,8 @@ def cpu_vm(monkeypatch):
     from oracle import ref_numpy
     monkeypatch.setattr(temporal, "aggregate_frames", ref_numpy.temporal_aggregate_values)
     monkeypatch.setattr(temporal, "accumulate_frames", ref_numpy.temporal_cumulative_values)
+    monkeypatch.setattr(temporal, "take_frames", ref_numpy.take_frames)
+    monkeypatch.setattr(temporal, "sum_frames", ref_numpy.frames_sum)
     from dask_geomodeling_amd.raster import devops
     monkeypatch.setattr(devops, "_all_false", lambda tile: not np.any(np.asarray(tile)))
     monkeypatch.setattr(devops, "as_device", lambda v: np.asarray(v))

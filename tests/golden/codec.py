@@ -5,7 +5,7 @@ matters for NumPy's promotion rules, e.g. in ``np.isclose``).
 Test infrastructure only.
 """
 import json
-from datetime import datetime
+from datetime import datetime, timedelta
 
 import numpy as np
 
@@ -14,13 +14,17 @@ class Writer:
     def __init__(self):
         self.arrays = {}
         self.cases = []
+        self._seen = {}  # id(array) -> key: an array that many cases share (a probe source) is stored once
 
     def _enc(self, obj):
         if obj is None or isinstance(obj, (bool, str)):
             return obj
         if isinstance(obj, np.ndarray):
-            key = "a%d" % len(self.arrays)
-            self.arrays[key] = obj
+            key = self._seen.get(id(obj))
+            if key is None or self.arrays[key] is not obj:
+                key = "a%d" % len(self.arrays)
+                self.arrays[key] = obj
+                self._seen[id(obj)] = key
             return {"__nd__": key}
         if isinstance(obj, np.generic):
             if obj.dtype.kind == "f":
@@ -36,6 +40,8 @@ class Writer:
             return {"__dtype__": obj.str}
         if isinstance(obj, datetime):
             return {"__datetime__": obj.isoformat()}
+        if isinstance(obj, timedelta):
+            return {"__timedelta__": [obj.days, obj.seconds, obj.microseconds]}
         if isinstance(obj, (list, tuple)):
             return {"__seq__": type(obj).__name__, "v": [self._enc(x) for x in obj]}
         if isinstance(obj, dict):
@@ -70,6 +76,9 @@ def _dec(obj, arrays):
             return np.dtype(obj["__dtype__"])
         if "__datetime__" in obj:
             return datetime.fromisoformat(obj["__datetime__"])
+        if "__timedelta__" in obj:
+            days, seconds, microseconds = obj["__timedelta__"]
+            return timedelta(days=days, seconds=seconds, microseconds=microseconds)
         if "__seq__" in obj:
             seq = [_dec(x, arrays) for x in obj["v"]]
             return tuple(seq) if obj["__seq__"] == "tuple" else seq

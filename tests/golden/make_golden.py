@@ -28,6 +28,7 @@ Families:
   reducestats N4     reduce_rasters(stack, statistic, no_data_value, dtype) for every statistic
   group       N4     Group: whole get_data() on temporal probe sources (by time / by bands)
   temporal    N4     TemporalAggregate / Cumulative: whole get_data() + the process() arguments
+  round4      Snap / Shift / TemporalSum / Resample: whole get_data() + the process() arguments; Place.process
 """
 import json
 import os
@@ -1283,13 +1284,193 @@ def gen_round3(w):
             w.add(id="r3%04d" % cid, op="reduce:" + stat, stack=stack, kwargs=kwargs, expect=expect); cid += 1
 
 
+# --------------------------------------------------------------------------
+# family: round4  (reference: raster/temporal.py Snap 42-182, Shift 185-236, TemporalSum 239-255, Resample 1008-1214:
+# whole get_data() on temporal probe sources + the arguments their process() got; raster/spatial.py Place.process
+# 620-731 called directly -- Place's request planning needs GDAL / PROJ (Extent, get_sr), absent here)
+# --------------------------------------------------------------------------
+def gen_round4(w):
+    from datetime import timedelta
+    from dask_geomodeling.raster import spatial as R_sp
+    from dask_geomodeling.raster import temporal as R_tmp
+    rng = np.random.default_rng(404)
+    cid = 0
+    f32n = np.float32(F32MAX)
+
+    def stamps(first, n, seconds):
+        t0 = datetime.fromisoformat(first)
+        return [(t0 + timedelta(seconds=seconds * i)).isoformat() for i in range(n)]
+
+    free = ["2020-01-01T00:20:00", "2020-01-01T00:55:00", "2020-01-01T01:00:00", "2020-01-01T03:10:00",
+            "2020-01-01T03:15:00", "2020-01-02T12:00:00", "2020-01-05T00:00:00"]
+    sources = {
+        "r4_tenmin_f4": ("f4", f32n, stamps("2020-01-01T00:00:00", 30, 600), 600, (6, 8)),
+        "r4_hourly_f8": ("f8", F64MAX, stamps("2019-12-31T20:00:00", 10, 3600), 3600, (6, 8)),
+        "r4_free_i4": ("i4", -9999, free, None, (6, 8)),
+        "r4_daily_u1": ("u1", np.uint8(255), stamps("2019-12-30T00:00:00", 9, 86400), 86400, (6, 8)),
+        "r4_single_i2": ("i2", np.int16(-1), ["2020-01-01T02:00:00"], None, (6, 8)),
+        "r4_hourly_bool": ("?", None, stamps("2020-01-01T00:00:00", 7, 3600), 3600, (6, 8)),
+        "r4_halfhour_u4": ("u4", np.uint32(4294967295), stamps("2020-01-01T00:15:00", 9, 1800), 1800, (6, 8)),
+        "r4_onecell_f4": ("f4", f32n, stamps("2020-01-01T00:00:00", 40, 600), 600, (1, 1)),
+        "r4_empty_f4": ("f4", f32n, [], None, (6, 8)),
+    }
+    probes, specs = {}, {}
+    for name, (dt, ndv, times, delta, shape_yx) in sources.items():
+        shape = (len(times),) + shape_yx
+        v = make_tile(rng, dt, shape, ndv, specials=False) if len(times) else np.zeros(shape, dt)
+        if np.dtype(dt).kind == "f" and len(times):
+            v = (rng.random(shape) * 2000 - 500).astype(dt)  # sums whose order of addition shows
+        if ndv is not None and len(times) and shape_yx != (1, 1):
+            v[:, 0, 1] = ndv
+            v[: len(times) // 2, 1, 0] = ndv
+        TemporalProbe.ARRAYS[name] = {"values": v, "no_data_value": ndv}
+        probes[name] = TemporalProbe(name, np.dtype(dt).str, ndv, times, delta)
+        specs[name] = {"name": name, "dtype": np.dtype(dt).str, "ndv": ndv, "times": times, "delta": delta, "data": v}
+
+    def window(name):
+        h, wd = specs[name]["data"].shape[1:]
+        return dict(bbox=(0.0, 0.0, float(wd), float(h)), width=wd, height=h, projection="EPSG:28992")
+
+    day, hour = timedelta(days=1), timedelta(hours=1)
+
+    def requests_around(times_iso):
+        times = [datetime.fromisoformat(t) for t in times_iso] or [datetime(2020, 1, 1)]
+        first, last = times[0], times[-1]
+        mid = first + (last - first) / 2
+        return [dict(), dict(start=mid), dict(start=first - day, stop=last + day), dict(start=mid, stop=last),
+                dict(start=first + (last - first) / 4, stop=mid), dict(start=last + 40 * day, stop=last + 50 * day),
+                dict(start=first - 3 * day), dict(start=mid, stop=mid)]
+
+    def record(kind, view, names, block_args, request):
+        nonlocal cid
+        try:
+            plan = view.get_sources_and_requests(**request)
+            args = [src_.get_data(**req) if isinstance(src_, RasterBlock) and req is not None else src_ for src_, req in plan]
+            period = view.period
+            expect = view.get_data(**request)
+        except Exception as e:  # noqa: BLE001 -- (what the reference itself does with this request)
+            w.add(id="r4%04d" % cid, kind=kind, sources=[specs[n] for n in names], block_args=block_args, request=request,
+                  raises=type(e).__name__)
+            cid += 1
+            return
+        w.add(id="r4%04d" % cid, kind=kind, sources=[specs[n] for n in names], block_args=block_args, request=request,
+              process_args=args,
+              attrs={"dtype": np.dtype(view.dtype).str, "fillvalue": view.fillvalue,
+                     "period": list(period) if period else None,
+                     "timedelta": None if view.timedelta is None else view.timedelta.total_seconds(),
+                     "temporal": view.temporal, "len": len(view)},
+              expect=expect)
+        cid += 1
+
+    # Snap(store, index)
+    for store, index in (("r4_hourly_f8", "r4_tenmin_f4"), ("r4_tenmin_f4", "r4_hourly_f8"), ("r4_free_i4", "r4_tenmin_f4"),
+                         ("r4_single_i2", "r4_tenmin_f4"), ("r4_tenmin_f4", "r4_free_i4"), ("r4_daily_u1", "r4_free_i4"),
+                         ("r4_hourly_bool", "r4_halfhour_u4"), ("r4_tenmin_f4", "r4_single_i2"),
+                         ("r4_empty_f4", "r4_tenmin_f4"), ("r4_tenmin_f4", "r4_empty_f4")):
+        view = R_tmp.Snap(probes[store], probes[index])
+        for extra in requests_around(specs[index]["times"]):
+            for mode in ("vals", "time", "meta"):
+                record("snap", view, [store, index], [], dict(mode=mode, **window(store), **extra))
+    # Shift(store, milliseconds)
+    for store, ms in (("r4_tenmin_f4", 3600 * 1000), ("r4_tenmin_f4", -90 * 1000), ("r4_free_i4", 86400 * 1000),
+                      ("r4_daily_u1", -12 * 3600 * 1000), ("r4_single_i2", 1)):
+        view = R_tmp.Shift(probes[store], ms)
+        shifted = [(datetime.fromisoformat(t) + timedelta(milliseconds=ms)).isoformat() for t in specs[store]["times"]]
+        for extra in requests_around(shifted):
+            for mode in ("vals", "time", "meta"):
+                record("shift", view, [store], [ms], dict(mode=mode, **window(store), **extra))
+    # TemporalSum(store)
+    for store in ("r4_tenmin_f4", "r4_hourly_f8", "r4_free_i4", "r4_daily_u1", "r4_single_i2", "r4_hourly_bool",
+                  "r4_halfhour_u4", "r4_onecell_f4"):
+        view = R_tmp.TemporalSum(probes[store])
+        for extra in requests_around(specs[store]["times"]):
+            for mode in ("vals", "time", "meta"):
+                record("temporalsum", view, [store], [], dict(mode=mode, **window(store), **extra))
+    # Resample(source, frequency, direction, timezone)
+    resamples = [("r4_tenmin_f4", "h", "nearest", "UTC"), ("r4_tenmin_f4", "h", "forward", "UTC"), ("r4_tenmin_f4", "h", "backward", "UTC"),
+                 ("r4_tenmin_f4", "5min", "nearest", "UTC"), ("r4_tenmin_f4", "25min", "backward", "UTC"),
+                 ("r4_hourly_f8", "D", "nearest", "Europe/Amsterdam"), ("r4_hourly_f8", "20min", "forward", "UTC"),
+                 ("r4_free_i4", "h", "nearest", "UTC"), ("r4_free_i4", "D", "backward", "Europe/Amsterdam"),
+                 ("r4_free_i4", "30min", "forward", "UTC"), ("r4_daily_u1", "ME", "nearest", "UTC"), ("r4_daily_u1", "W", "forward", "UTC"),
+                 ("r4_daily_u1", "12h", "backward", "UTC"), ("r4_single_i2", "h", "nearest", "UTC"), ("r4_hourly_bool", "90min", "nearest", "UTC"),
+                 ("r4_halfhour_u4", "h", "nearest", "UTC"), ("r4_empty_f4", "h", "nearest", "UTC")]
+    for store, freq, direction, tz in resamples:
+        view = R_tmp.Resample(probes[store], freq, direction, tz)
+        for extra in requests_around(specs[store]["times"]):
+            for mode in ("vals", "time", "meta"):
+                record("resample", view, [store], [freq, direction, tz], dict(mode=mode, **window(store), **extra))
+
+    # Place.process, called directly
+    def place(kw, *multi):
+        nonlocal cid
+        try:
+            expect = R_sp.Place.process(dict(kw), *[None if d is None else dict(d) for d in multi])
+        except Exception as e:  # noqa: BLE001
+            w.add(id="r4%04d" % cid, kind="place", process_args=[kw] + list(multi), raises=type(e).__name__)
+            cid += 1
+            return
+        w.add(id="r4%04d" % cid, kind="place", process_args=[kw] + list(multi), expect=expect)
+        cid += 1
+
+    statistics = ["last", "first", "count", "sum", "mean", "min", "max", "argmin", "argmax", "product", "std", "var", "median", "p30"]
+    tiles = [("u1", np.uint8(255), (1, 6, 8)), ("f4", f32n, (2, 5, 7)), ("i4", -9999, (1, 7, 5)), ("f8", -1.5, (1, 4, 6)),
+             ("i2", np.int16(-32768), (3, 4, 4))]
+    for dt, ndv, shape in tiles:
+        v = make_tile(rng, dt, shape, ndv, specials=False)
+        v[rng.random(shape) < 0.2] = ndv
+        v[:, 0, :] = ndv                          # a whole row without data: copies that only show this row are left out
+        if np.dtype(dt).kind == "f":
+            v[0, 1, 1] = ndv * (1 + 1e-7) if dt == "f8" else np.nextafter(ndv, np.float32(0))  # close to no data
+        data = {"values": v, "no_data_value": ndv}
+        _, src_h, src_w = shape
+        for cell, dst_hw in (((1.0, 1.0), (9, 11)), ((0.5, 0.5), (6, 6)), ((2.0, 1.0), (5, 9)), ((1.0, 1.0), (3, 3))):
+            size_x, size_y = cell
+            dst_h, dst_w = dst_hw
+            src_bbox = (100.0, 200.0, 100.0 + src_w * size_x, 200.0 + src_h * size_y)
+            dst_bbox = (40.0, 60.0, 40.0 + dst_w * size_x, 60.0 + dst_h * size_y)
+            anchor = (100.0 + 0.5 * src_w * size_x, 200.0 + 0.5 * src_h * size_y)
+            cx, cy = dst_bbox[0] + 0.5 * dst_w * size_x, dst_bbox[1] + 0.5 * dst_h * size_y
+            layouts = [
+                [(cx, cy)],
+                [(cx - 2 * size_x, cy + size_y), (cx + 2 * size_x, cy - 2 * size_y), (cx, cy)],
+                [(dst_bbox[0], dst_bbox[1]), (dst_bbox[2], dst_bbox[3]), (cx + 0.4 * size_x, cy - 0.6 * size_y)],
+                [(dst_bbox[0] - src_w * size_x, cy), (cx, dst_bbox[3] + src_h * size_y), (cx, dst_bbox[1] - 0.5 * (src_h - 1) * size_y)],
+                [(cx - 1e4, cy), (cx, cy + 1e4)],
+                [],
+            ]
+            for k, coordinates in enumerate(layouts):
+                for stat in (statistics if k in (1, 3) and cell == (1.0, 1.0) else ["last", "sum", "argmax"]):
+                    place({"mode": "warp", "anchor": anchor, "coordinates": coordinates, "src_bbox": src_bbox, "dst_bbox": dst_bbox,
+                           "cellsize": cell, "statistic": stat}, data)
+        place({"mode": "warp", "anchor": (0.0, 0.0), "coordinates": [(1.0, 1.0)], "src_bbox": (0.0, 0.0, 8.0, 6.0),
+               "dst_bbox": (0.0, 0.0, 8.0, 6.0), "cellsize": (1.0, 1.0), "statistic": "last"}, None)
+        nothing = {"values": np.full(shape, ndv, dt), "no_data_value": ndv}
+        place({"mode": "warp", "anchor": (104.0, 203.0), "coordinates": [(44.0, 63.0)], "src_bbox": (100.0, 200.0, 100.0 + shape[2], 200.0 + shape[1]),
+               "dst_bbox": (40.0, 60.0, 50.0, 70.0), "cellsize": (1.0, 1.0), "statistic": "sum"}, nothing)
+        # already shifted rasters (one request per coordinate)
+        others = []
+        for _ in range(3):
+            o = make_tile(rng, dt, shape, ndv, specials=False)
+            o[rng.random(shape) < 0.4] = ndv
+            others.append({"values": o, "no_data_value": ndv})
+        for stat in statistics:
+            place({"mode": "group", "statistic": stat}, others[0], None, others[1], others[2])
+        place({"mode": "group", "statistic": "last"}, None, None)
+        place({"mode": "empty", "dtype": np.dtype(dt), "fillvalue": dtype_max(np.dtype(dt)), "width": 5, "height": 4, "statistic": "last"},
+              {"time": [datetime(2020, 1, 1), datetime(2020, 1, 2)]})
+        place({"mode": "empty", "dtype": np.dtype(dt), "fillvalue": dtype_max(np.dtype(dt)), "width": 5, "height": 4, "statistic": "sum"}, None)
+    place({"mode": "time"}, {"time": [datetime(2020, 1, 1)]})
+    place({"mode": "meta"}, {"meta": ["a"]})
+    place({"mode": "null"})
+
+
 def main():
     fams = {
         "math": gen_math, "n1": gen_n1, "clip": gen_clip, "mask": gen_mask,
         "classify": gen_classify, "reclassify": gen_reclassify, "tiler": gen_tiler,
         "views": gen_views, "dtypes": gen_dtypes, "smoothzoom": gen_smoothzoom,
         "spatial": gen_spatial, "reduce": gen_reduce, "reducestats": gen_reducestats, "group": gen_group, "smooth": gen_smooth,
-        "temporal": gen_temporal, "zonal": gen_zonal, "round3": gen_round3,
+        "temporal": gen_temporal, "zonal": gen_zonal, "round3": gen_round3, "round4": gen_round4,
     }
     only = sys.argv[1:]
     counts = {}

@@ -503,6 +503,178 @@ def test_temporal_against_reference(cpu_vm, case):
         assert_result_equal(out, want, 0, case["id"])
 
 
+# ---------------------------------------------------------------------------------
+# Snap / Shift / TemporalSum / Resample -- request planning and time arithmetic (host) against the reference's
+# results; the frame gather / frame sum are the oracle's here (cpu_vm), the device's in test_gpu_parity
+# ---------------------------------------------------------------------------------
+def round4_view(case):
+    from blocks_util import TemporalLeaf
+    leaves = []
+    for spec in case["sources"]:
+        TemporalLeaf.ARRAYS[spec["name"]] = {"values": spec["data"], "no_data_value": spec["ndv"]}
+        leaves.append(TemporalLeaf(spec["name"], spec["dtype"], spec["ndv"], spec["times"], spec["delta"]))
+    cls = {"snap": raster.Snap, "shift": raster.Shift, "temporalsum": raster.TemporalSum, "resample": raster.Resample}[case["kind"]]
+    return cls(*leaves, *case["block_args"])
+
+
+def same_plan_argument(ours, theirs):
+    """process_kwargs of ours == the reference's (dicts that may hold the ndarray of frame indices)."""
+    if not isinstance(theirs, dict) or not isinstance(ours, dict):
+        return ours == theirs
+    if set(ours) != set(theirs):
+        return False
+    return all(np.array_equal(ours[k], theirs[k]) if isinstance(theirs[k], np.ndarray) else ours[k] == theirs[k]
+               for k in theirs)
+
+
+def round4_temporal_cases():
+    return [c for c in load_family("round4") if c["kind"] != "place"]
+
+
+@pytest.mark.parametrize("case", round4_temporal_cases(), ids=lambda c: c["id"] + "-" + c["kind"] + "-" + c["request"]["mode"])
+def test_round4_temporal_against_reference(cpu_vm, case):
+    view = round4_view(case)
+    a = case["attrs"]
+    assert np.dtype(view.dtype).str == a["dtype"] and view.fillvalue == a["fillvalue"] and view.temporal == a["temporal"]
+    assert (list(view.period) if view.period else None) == a["period"]
+    assert (None if view.timedelta is None else view.timedelta.total_seconds()) == a["timedelta"]
+    assert len(view) == a["len"]
+    plan = list(view.get_sources_and_requests(**case["request"]))
+    assert len(plan) == len(case["process_args"])
+    if not isinstance(plan[0][0], raster.RasterBlock):
+        assert same_plan_argument(plan[0][0], case["process_args"][0]), case["id"]
+    out = view.get_data(**case["request"])
+    want = case["expect"]
+    if want is None or "values" not in want:
+        assert out == want, case["id"]
+    else:
+        assert_result_equal(out, want, 0, case["id"])
+
+
+@pytest.fixture
+def cpu_place(cpu_vm, monkeypatch):
+    """Place.process with its four device helpers replaced by NumPy doubles: what is tested here is the host side --
+    the shifts, which copies are left out, the modes."""
+    from dask_geomodeling_amd.hip import array as hip_array
+    from dask_geomodeling_amd.raster import reduction, spatial
+    from oracle import ref_numpy as O
+
+    def shifted_copy(source, fill, out_shape, di, dj):
+        out = np.full(out_shape, fill, source.dtype)
+        _, src_h, src_w = source.shape
+        _, dst_h, dst_w = out_shape
+        for j in range(src_h):
+            for i in range(src_w):
+                if 0 <= j + dj < dst_h and 0 <= i + di < dst_w:
+                    out[:, j + dj, i + di] = source[:, j, i]
+        return out
+
+    monkeypatch.setattr(hip_array, "as_device", lambda v: np.asarray(v))
+    monkeypatch.setattr(spatial, "_filled", lambda shape, value, dtype: np.full(shape, value, dtype))
+    monkeypatch.setattr(spatial, "_shifted_copy", shifted_copy)
+    monkeypatch.setattr(spatial, "_has_data", lambda values, ndv: bool(O.get_index(values, ndv).any()))
+    monkeypatch.setattr(reduction, "reduce_rasters", O.reduce_rasters)
+    yield
+
+
+@pytest.mark.parametrize("case", [c for c in load_family("round4") if c["kind"] == "place"],
+                         ids=lambda c: c["id"] + "-" + c["process_args"][0]["mode"] + "-" + str(c["process_args"][0].get("statistic")))
+def test_place_process_against_reference(cpu_place, case):
+    with np.errstate(all="ignore"):
+        out = raster.Place.process(*case["process_args"])
+    want = case["expect"]
+    if want is None or "values" not in want:
+        assert out == want, case["id"]
+    else:
+        assert_result_equal(out, want, 0, case["id"])
+
+
+def _place_source():
+    from blocks_util import ArrayLeaf  # noqa: F401
+    return raster.MemorySource(np.full((1, 10, 10), 7, dtype=np.uint8), 255, "EPSG:28992", 10, (135000, 456000))
+
+
+def test_place_attributes_and_planning():
+    """Attributes and request planning of Place on the reference's own test raster (10 x 10 cells of 10 m with their
+    centre as anchor; tests/test_raster_spatial.py:60-131, 203-218 of the reference)."""
+    source = _place_source()
+    center = (135050, 455950)
+    place = raster.Place(source, "EPSG:28992", center, [(50, 50)])
+    assert place.period == source.period and place.timedelta == source.timedelta
+    assert place.dtype == source.dtype and place.fillvalue == source.fillvalue
+    assert place.projection == source.projection and place.geo_transform == source.geo_transform
+    x1, x2, y1, y2 = place.geometry.GetEnvelope()
+    assert (x1, y1, x2, y2) == (0, 0, 100, 100)
+    two = raster.Place(source, "EPSG:28992", center, [(50, 50), (250, -150)])
+    x1, x2, y1, y2 = two.geometry.GetEnvelope()
+    assert (x1, y1, x2, y2) == (0, -200, 300, 100)
+    other = raster.Place(source, "EPSG:3857", (0.0, 0.0), [(5.0, 5.0)])
+    assert other.projection is None and other.geo_transform is None
+    with pytest.raises(ValueError):
+        raster.Place(source, "EPSG:28992", center, [(50, 50)], statistic="nonexisting")
+    with pytest.raises(ValueError):
+        raster.Place(source, "EPSG:28992", (1, 2, 3), [(50, 50)])
+    with pytest.raises(ValueError):
+        raster.Place(source, "EPSG:28992", center, [(50, 50, 1)])
+    with pytest.raises(TypeError):
+        raster.Place(source, "EPSG:28992", ("a", 1), [(50, 50)])
+    with pytest.raises(TypeError):
+        raster.Place("source", "EPSG:28992", center, [(50, 50)])
+    assert raster.Place(source, "EPSG:28992", center, None).coordinates == []
+
+    for box in ((0, 0, 100, 80), (0, 0, 50, 40), (0, 0, 200, 160)):
+        request = dict(mode="vals", bbox=box, projection="EPSG:28992", width=int(box[2] / 10), height=int(box[3] / 10))
+        plan = place.get_sources_and_requests(**request)
+        kwargs, asked = plan[0][0], plan[1][1]
+        if kwargs["mode"] == "warp":  # the whole source at the requested cell size: never more cells than it has
+            assert asked["width"] * asked["height"] <= 100
+            assert asked["bbox"] == (135000.0, 455900.0, 135100.0, 456000.0)
+            assert kwargs["cellsize"] == (10.0, 10.0) and kwargs["dst_bbox"] == box
+        else:
+            assert kwargs["mode"] == "group" and asked["bbox"] == [135000, 455900, 135000 + box[2], 455900 + box[3]]
+        # all coordinates outside: an empty answer of the store's depth
+        x1, y1, x2, y2 = box
+        away = raster.Place(source, "EPSG:28992", center, [(x1 - 5000, y1), (x1, y1 - 5000), (x2 + 5000, y2), (x2, y2 + 5000)])
+        plan = away.get_sources_and_requests(**request)
+        if box[2] * box[3] < 100 * 100:  # (a request as large as the source is pasted from one fetch of it instead)
+            assert plan[0][0]["mode"] == "empty" and plan[1][1]["mode"] == "time"
+            assert plan[0][0]["width"] == request["width"] and plan[0][0]["dtype"] == np.uint8
+        else:
+            assert plan[0][0]["mode"] == "warp"
+    # other modes pass through, another projection is refused
+    plan = place.get_sources_and_requests(mode="time")
+    assert plan[0][0] == {"mode": "time"} and plan[1][0] is source
+    with pytest.raises(NotImplementedError):
+        other.get_sources_and_requests(mode="vals", bbox=(0, 0, 10, 10), projection="EPSG:28992", width=1, height=1)
+    # point requests never fetch the whole source
+    plan = place.get_sources_and_requests(mode="vals", bbox=(5, 15, 5, 15), projection="EPSG:28992", width=1, height=1)
+    assert plan[0][0]["mode"] == "group" and plan[1][1]["bbox"] == [135005, 455915, 135005, 455915]
+
+
+def test_round4_construction_errors():
+    from datetime import timedelta
+    from blocks_util import TemporalLeaf
+    leaf = TemporalLeaf("tmp/r4err", "<f4", 1.0, ["2020-01-01T00:00:00", "2020-01-01T01:00:00"], 3600)
+    with pytest.raises(TypeError):
+        raster.Snap(leaf, "index")
+    with pytest.raises(TypeError):
+        raster.Snap(3, leaf)
+    with pytest.raises(TypeError):
+        raster.Shift(leaf, 1.5)
+    assert raster.Shift(leaf, timedelta(hours=2)).args[1] == 7200000
+    assert raster.Shift(leaf, 1000).period == (leaf.period[0] + timedelta(seconds=1), leaf.period[1] + timedelta(seconds=1))
+    for bad in (dict(frequency=1), dict(timezone=2), dict(direction=3)):
+        with pytest.raises(TypeError):
+            raster.Resample(leaf, **dict(dict(frequency="h", direction="nearest", timezone="UTC"), **bad))
+    with pytest.raises(ValueError):
+        raster.Resample(leaf, "h", "sideways")
+    with pytest.raises(TypeError):
+        raster.Resample("leaf", "h")
+    assert raster.Resample(leaf, "H", "forward", "Europe/Amsterdam").args[1:] == ("h", "forward", "Europe/Amsterdam")
+    with pytest.raises(TypeError):
+        raster.TemporalSum("leaf")
+
+
 def test_temporal_construction_errors():
     from blocks_util import TemporalLeaf
     leaf = TemporalLeaf("tmp/err", "<f4", 1.0, ["2020-01-01T00:00:00"], None)

@@ -1680,6 +1680,117 @@ def test_reduce_rasters_sums_over_deep_stacks(gpu, n, dtype):
         assert_values_equal(np.asarray(out["values"]), want["values"], 0, "%s over %d %s rasters" % (stat, n, dtype))
 
 
+# ---------------------------------------------------------------------------------
+# round 4: Snap / Shift / TemporalSum / Resample (frame gather + frame sum on the device), Place
+# ---------------------------------------------------------------------------------
+def _round4_vals_cases():
+    return [c for c in load_family("round4") if c["kind"] != "place" and c["request"]["mode"] == "vals"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _round4_vals_cases(), ids=lambda c: c["id"] + "-" + c["kind"])
+def test_round4_temporal_golden(gpu, case):
+    """Whole get_data() of Snap / Shift / TemporalSum / Resample views (temporal.py:42-255, 1008-1214) with the frames
+    re-arranged (gm_frames_take) and added up (gm_frames_sum) on the device, bit for bit what the reference returns."""
+    from test_blocks_cpu import round4_view
+    out = round4_view(case).get_data(**case["request"])
+    assert_result_equal(out, case["expect"], 0, case["id"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in load_family("round4") if c["kind"] == "place"],
+                         ids=lambda c: c["id"] + "-" + c["process_args"][0]["mode"] + "-" + str(c["process_args"][0].get("statistic")))
+def test_place_process_golden(gpu, case):
+    """Place.process (spatial.py:620-731) on the device -- shifted copies, the data test that decides which copies
+    take part, reduce_rasters -- against what the reference's own process() returned for the same arguments."""
+    from dask_geomodeling_amd import raster
+    out = raster.Place.process(*case["process_args"])
+    want = case["expect"]
+    if want is None or "values" not in want:
+        assert out == want, case["id"]
+    else:
+        assert_result_equal(dict(out, values=np.asarray(out["values"])), want, 0, case["id"])
+
+
+@pytest.mark.gpu
+def test_place_known_answers(gpu):
+    """Place through get_data on the raster of the reference's own tests (10 x 10 cells of 10 m, value 7, anchored
+    at its centre; tests/test_raster_spatial.py:119-257 of the reference): exact / shifted placement at three zoom
+    levels, overlapping copies under every statistic, everything outside, point requests on the cell edges."""
+    from dask_geomodeling_amd import raster
+    source = raster.MemorySource(np.full((1, 10, 10), 7, dtype=np.uint8), 255, "EPSG:28992", 10, (135000, 456000))
+    center = (135050, 455950)
+    requests = []
+    for box in ((0, 0, 100, 80), (0, 0, 50, 40), (0, 0, 200, 160)):
+        requests.append(dict(mode="vals", bbox=box, projection="EPSG:28992", width=int(box[2] / 10), height=int(box[3] / 10)))
+
+    def values(place, request):
+        return np.asarray(place.get_data(**request)["values"])[:, ::-1, :]  # (south up: readable indices)
+
+    for request in requests:
+        v = values(raster.Place(source, "EPSG:28992", center, []), request)
+        assert (v[:, :10, :10] == 255).all()
+        v = values(raster.Place(source, "EPSG:28992", center, [(50, 50)]), request)
+        assert (v[:, :10, :10] == 7).all() and v.shape == (1, request["height"], request["width"])
+        v = values(raster.Place(source, "EPSG:28992", center, [(60, 50)]), request)  # one cell to the right
+        assert (v[:, :10, 1:11] == 7).all() and (v[:, :, 0] == 255).all()
+        v = values(raster.Place(source, "EPSG:28992", center, [(50, 60)]), request)  # one cell up
+        assert (v[:, 1:11, :10] == 7).all() and (v[:, 0, :] == 255).all()
+        # two copies of which only the left and the bottom ridge show: (nothing, first, second, both)
+        table = {"first": (255, 7, 7, 7), "last": (255, 7, 7, 7), "count": (0, 1, 1, 2), "sum": (0, 7, 7, 14),
+                 "mean": (255, 7, 7, 7), "min": (255, 7, 7, 7), "max": (255, 7, 7, 7), "argmin": (255, 0, 1, 0),
+                 "argmax": (255, 0, 1, 0), "std": (255, 0, 0, 0), "var": (255, 0, 0, 0), "median": (255, 7, 7, 7),
+                 "p99": (255, 7, 7, 7)}
+        for statistic, (none, first, second, both) in table.items():
+            v = values(raster.Place(source, "EPSG:28992", center, [(-40, 50), (50, -40)], statistic), request)
+            assert (v[:, 1:, 1:] == none).all(), statistic
+            assert (v[:, 1:10, 0] == first).all() and (v[:, 0, 1:10] == second).all(), statistic
+            assert (v[:, 0, 0] == both).all(), statistic
+        x1, y1, x2, y2 = request["bbox"]
+        away = raster.Place(source, "EPSG:28992", center, [(x1 - 50, y1), (x1, y1 - 50), (x2 + 50, y2), (x2, y2 + 50)])
+        assert (values(away, request) == 255).all()
+    place = raster.Place(source, "EPSG:28992", center, [(150, 50)])
+    assert place.get_data(mode="time") == source.get_data(mode="time")
+    assert place.get_data(mode="meta") == source.get_data(mode="meta")
+    # point requests: a cell owns its top-left corner and its top and left edges
+    two = raster.Place(source, "EPSG:28992", anchor=center, coordinates=[(60, -40), (-40, 60)])
+    for point, expected in (((5, 15), 7), ((15, 15), 255), ((5, 5), 255), ((15, 5), 7), ((10, 15), 255), ((5, 10), 255),
+                            ((15, 10), 7), ((10, 5), 7), ((10, 10), 7), ((1000, 1000), 255)):
+        got = np.asarray(two.get_data(mode="vals", bbox=point * 2, projection="EPSG:28992", width=1, height=1)["values"])
+        assert got.shape == (1, 1, 1) and got.item() == expected, point
+    empty = raster.MemorySource(np.full((0, 0, 0), 7, dtype=np.uint8), 255, "EPSG:28992", 20, (0, 0))
+    nothing = raster.Place(empty, "EPSG:28992", center, [(50, 50)])
+    assert nothing.geometry is None and nothing.extent is None and nothing.get_data(**requests[0]) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["?", "u1", "i1", "u2", "i2", "u4", "i4", "u8", "i8", "f4", "f8"])
+def test_frame_kernels_against_numpy(gpu, dtype):
+    """gm_frames_sum against np.sum(axis=0) (accumulator dtype, wrap-around of 64-bit sums, frame-by-frame float order;
+    a raster of ONE cell is summed pairwise, in pieces of 8192) and gm_frames_take against fancy indexing: vector and
+    scalar cell counts, more frames than the unroll."""
+    from dask_geomodeling_amd.raster import temporal as T
+    rng = np.random.default_rng(abs(hash(dtype)) % 2**32)
+    for shape in ((1, 3, 5), (7, 16, 64), (19, 37, 53), (130, 1, 1), (20000, 1, 1), (9, 1, 4096), (3, 128, 256)):
+        dt = np.dtype(dtype)
+        if dt.kind == "f":
+            v = (rng.random(shape) * 2000 - 700).astype(dt)
+        elif dt.kind == "b":
+            v = rng.random(shape) < 0.5
+        else:
+            info = np.iinfo(dt)
+            v = rng.integers(info.min, info.max, size=shape, dtype=dt, endpoint=True)
+        with np.errstate(all="ignore"):
+            want = O.frames_sum(v)
+        got = np.asarray(T.sum_frames(v))
+        assert_values_equal(got, want, 0, "sum of %s %s" % (shape, dt))
+        index = rng.integers(0, shape[0], size=min(2 * shape[0] + 1, 300))
+        assert_values_equal(np.asarray(T.take_frames(v, index)), O.take_frames(v, index), 0, "take of %s %s" % (shape, dt))
+    assert np.asarray(T.take_frames(np.zeros((3, 2, 2), dtype), [])).shape == (0, 2, 2)
+    zeros = np.asarray(T.sum_frames(np.zeros((0, 2, 3), dtype)))
+    assert zeros.shape == (1, 2, 3) and not zeros.any() and zeros.dtype == np.zeros((0, 2, 3), dtype).sum(axis=0).dtype
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("blocks", ["1", "0"], ids=["block-pipeline", "wave-per-label"])
 def test_zonal_block_pipeline(gpu, blocks):

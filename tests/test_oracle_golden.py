@@ -298,6 +298,23 @@ def test_temporal(case):
         assert_result_equal(out, want, 0, case["id"])
 
 
+ROUND4_PROCESS = {"snap": "snap_process", "shift": "shift_process", "temporalsum": "temporal_sum_process",
+                  "resample": "resample_process", "place": "place_process"}
+
+
+@pytest.mark.parametrize("case", load_family("round4"), ids=lambda c: c["id"] + "-" + c["kind"])
+def test_round4(case):
+    """Snap / Shift / TemporalSum / Resample / Place: the oracle's process() on the arguments the reference built."""
+    func = getattr(O, ROUND4_PROCESS[case["kind"]])
+    with np.errstate(all="ignore"):
+        out = func(*case["process_args"])
+    want = case["expect"]
+    if want is None or "values" not in want:
+        assert out == want, case["id"]
+    else:
+        assert_result_equal(out, want, 0, case["id"])
+
+
 # ---------------------------------------------------------------------------------
 # N4: zonal statistics (AggregateRaster's numeric core)
 # ---------------------------------------------------------------------------------
