@@ -114,26 +114,68 @@ def _is_key(x, dsk):
         return False
 
 
-def _dependencies(obj, dsk, out):
-    """Collect the graph keys referenced by a task / list / alias."""
-    if _is_task(obj):
-        for a in obj[1:]:
-            _dependencies(a, dsk, out)
-    elif isinstance(obj, list):
-        for a in obj:
-            _dependencies(a, dsk, out)
-    elif _is_key(obj, dsk):
-        out.append(obj)
+# One look at every graph value instead of two (dependencies, then execution): a value is turned into a small plan
+# -- (_KEY, key), (_FLAT, func, args, positions of the args that are keys), (_TASK, func, [plans]), (_LIST, [plans])
+# or (_CONST, object) -- together with the keys it needs.  Nearly every task is flat: a function over keys and plain
+# arguments (a fused launch over its leaf tiles, a source over its request).
+_KEY, _FLAT, _TASK, _LIST, _CONST = range(5)
 
 
-def _execute(obj, dsk, cache):
-    if _is_task(obj):
-        return obj[0](*[_execute(a, dsk, cache) for a in obj[1:]])
-    if isinstance(obj, list):
-        return [_execute(a, dsk, cache) for a in obj]
+def _plan_of(obj, dsk, needs):
+    kind = type(obj)
+    if kind is str:  # (most arguments: graph keys are strings)
+        if obj in dsk:
+            needs.append(obj)
+            return (_KEY, obj)
+        return (_CONST, obj)
+    if kind is tuple and len(obj) > 0 and callable(obj[0]):
+        args = obj[1:]
+        at, flat = [], True
+        for i, a in enumerate(args):
+            ka = type(a)
+            if ka is str:
+                if a in dsk:
+                    needs.append(a)
+                    at.append(i)
+            elif ka is list or (ka is tuple and len(a) > 0 and callable(a[0])):
+                flat = False
+                break
+            elif ka is not dict and ka is not np.ndarray and a is not None:
+                try:
+                    if a in dsk:
+                        needs.append(a)
+                        at.append(i)
+                except TypeError:
+                    pass
+        if flat:
+            return (_FLAT, obj[0], args, tuple(at))
+        del needs[len(needs) - len(at):]  # nested arguments: the general form collects the keys itself
+        return (_TASK, obj[0], [_plan_of(a, dsk, needs) for a in args])
+    if kind is list:
+        return (_LIST, [_plan_of(a, dsk, needs) for a in obj])
     if _is_key(obj, dsk):
-        return cache[obj]
-    return obj
+        needs.append(obj)
+        return (_KEY, obj)
+    return (_CONST, obj)
+
+
+def _run(plan, cache):
+    kind = plan[0]
+    if kind == _FLAT:
+        at = plan[3]
+        if not at:
+            return plan[1](*plan[2])
+        args = list(plan[2])
+        for i in at:
+            args[i] = cache[args[i]]
+        return plan[1](*args)
+    if kind == _KEY:
+        return cache[plan[1]]
+    if kind == _CONST:
+        return plan[1]
+    if kind == _TASK:
+        return plan[1](*[_run(a, cache) for a in plan[2]])
+    return [_run(a, cache) for a in plan[1]]
 
 
 def get_sync(dsk, keys, pack_exception=None, **kwargs):
@@ -143,26 +185,19 @@ def get_sync(dsk, keys, pack_exception=None, **kwargs):
     what hands device tiles back to the pool while a large tiled graph is still running."""
     cache = {}
     wanted = list(keys) if isinstance(keys, list) else [keys]
-    deps_of, pending = {}, {}
+    plans, pending = {}, {}
 
-    def deps(key):
-        d = deps_of.get(key)
-        if d is None:
-            d = []
-            _dependencies(dsk[key], dsk, d)
-            deps_of[key] = d
-        return d
-
-    # reference counts over the part of the graph the wanted keys reach (every use counts)
-    seen, stack = set(), list(wanted)
+    # plans and reference counts over the part of the graph the wanted keys reach (every use counts)
+    stack = list(wanted)
     while stack:
         key = stack.pop()
-        if key in seen:
+        if key in plans:
             continue
-        seen.add(key)
-        for d in deps(key):
+        needs = []
+        plans[key] = (_plan_of(dsk[key], dsk, needs), needs)
+        for d in needs:
             pending[d] = pending.get(d, 0) + 1
-            if d not in seen:
+            if d not in plans:
                 stack.append(d)
     for key in wanted:
         pending[key] = pending.get(key, 0) + 1  # never released
@@ -174,17 +209,18 @@ def get_sync(dsk, keys, pack_exception=None, **kwargs):
             if key in cache:
                 stack.pop()
                 continue
-            missing = [d for d in deps(key) if d not in cache]
+            plan, needs = plans[key]
+            missing = [d for d in needs if d not in cache]
             if missing:
                 stack.extend(missing)
                 continue
             try:
-                cache[key] = _execute(dsk[key], dsk, cache)
+                cache[key] = _run(plan, cache)
             except Exception as e:
                 if pack_exception is not None:
                     pack_exception(e, None)  # reads ``key`` from this frame, then re-raises
                 raise
-            for d in deps(key):
+            for d in needs:
                 pending[d] -= 1
                 if pending[d] == 0:
                     del cache[d]

@@ -962,22 +962,30 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const T* __restrict
       const f32x2 v = 255.0f * fast;
       const f32x2 nearest = {rintf(v.x), rintf(v.y)};
       const f32x2 off = v - nearest;
+      // (NaN / inf gradients compare false here and take the exact tier, which treats them like NumPy does)
+      const bool open0 = !(fabsf(off.x) > HS_MARGIN || nearest.x < 0.5f);
+      const bool open1 = !(fabsf(off.y) > HS_MARGIN || nearest.y < 0.5f);
+      if (open0 | open1) {  // one test for the pair: 0.12 % of the cells are within the margin of an integer
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        // (NaN / inf gradients compare false here and take the exact tier, which treats them like NumPy does)
-        const bool decided = fabsf(off[k]) > HS_MARGIN || nearest[k] < 0.5f;
-        if (!decided) {
-          const unsigned slot = atomicAdd(&pending_count, 1u);
-          if (slot < HP_PENDING) {
-            pending_x[slot] = x[k];
-            pending_y[slot] = y[k];
-            pending_at[slot] = (unsigned short)(r * HP_W + 2 * threadIdx.x + k);
-          } else {
-            overflowed = true;  // (queue full -- e.g. a plateau whose shade sits on an integer)
+        for (int k = 0; k < 2; ++k) {
+          if (k ? open1 : open0) {
+            const unsigned slot = atomicAdd(&pending_count, 1u);
+            if (slot < HP_PENDING) {
+              pending_x[slot] = x[k];
+              pending_y[slot] = y[k];
+              pending_at[slot] = (unsigned short)(r * HP_W + 2 * threadIdx.x + k);
+            } else {
+              overflowed = true;  // (queue full -- e.g. a plateau whose shade sits on an integer)
+            }
           }
         }
-        packed |= (unsigned)(int)fmaxf(v[k], 0.0f) << (8 * k);  // (v < 256; NaN -> 0, redone by the exact tier)
       }
+      // trunc(max(v, 0)) as ONE instruction: v_cvt_u32_f32 truncates and clamps negative values and NaN to 0 (v < 256;
+      // the C cast of a negative float to unsigned is undefined, hence the instruction by name)
+      unsigned lo, hi;
+      asm("v_cvt_u32_f32 %0, %1" : "=v"(lo) : "v"(v.x));
+      asm("v_cvt_u32_f32 %0, %1" : "=v"(hi) : "v"(v.y));
+      packed = lo | (hi << 8);
     }
     *reinterpret_cast<unsigned short*>(shade + r * HP_W + 2 * threadIdx.x) = (unsigned short)packed;
     top = mid;
