@@ -308,8 +308,9 @@ def _shifted_copy(source, fill, out_shape, di, dj):
 def _has_data(values, no_data_value):
     """get_index(values, no_data_value).any() (utils.py:61-64) without leaving the device."""
     from . import devops
-    mask = devops.unary_bool_process("isdata", {"values": values, "no_data_value": no_data_value})["values"]
-    return not devops._all_false(mask)
+    # (Mask is the Block whose cell test is get_index -- isclose for float tiles; IsData compares exactly)
+    marked = devops.mask_process({"values": values, "no_data_value": no_data_value}, 1)["values"]  # 1 = data, 0 = not
+    return not devops._all_false(marked)
 
 
 class Place(BaseSingle):

@@ -1713,6 +1713,35 @@ def test_place_process_golden(gpu, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f4", "f8"])
+def test_place_leaves_out_copies_whose_cells_are_only_close_to_no_data(gpu, dtype):
+    """The data test of Place.process is utils.get_index -- np.isclose for float rasters -- so a copy whose only cells
+    inside the window are merely CLOSE to the no-data value does not take part: the sum over nothing is the no-data
+    raster (not zeros), and argmax counts the copies that remain."""
+    from dask_geomodeling_amd import raster
+    dt = np.dtype(dtype)
+    ndv = dt.type(-9999.0)
+    near = np.nextafter(ndv, dt.type(0))  # isclose(near, ndv), near != ndv
+    assert near != ndv and np.isclose(near, ndv)
+    source = np.full((1, 4, 4), ndv, dt)
+    source[0, 1, 2] = near
+    source[0, 3, 3] = 5.0
+    kwargs = {"mode": "warp", "anchor": (2.0, 2.0), "src_bbox": (0.0, 0.0, 4.0, 4.0), "dst_bbox": (10.0, 10.0, 13.0, 13.0),
+              "cellsize": (1.0, 1.0)}
+    # first copy: only the close-to-no-data cell lands inside (the 5.0 falls outside); second copy: the 5.0 lands inside
+    for coordinates, statistic in (([(12.0, 11.0)], "sum"), ([(12.0, 11.0), (11.0, 12.0)], "argmax"), ([(12.0, 11.0), (11.0, 12.0)], "count")):
+        kw = dict(kwargs, coordinates=coordinates, statistic=statistic)
+        data = {"values": source, "no_data_value": ndv}
+        want = O.place_process(kw, dict(data))
+        got = raster.Place.process(kw, dict(data))
+        assert_result_equal(dict(got, values=np.asarray(got["values"])), want, 0, statistic)
+    only_close = O.place_process(dict(kwargs, coordinates=[(12.0, 11.0)], statistic="sum"), {"values": source, "no_data_value": ndv})
+    assert (only_close["values"] == ndv).all()
+    two = O.place_process(dict(kwargs, coordinates=[(12.0, 11.0), (11.0, 12.0)], statistic="argmax"), {"values": source, "no_data_value": ndv})
+    assert two["values"][0, 2, 2] == 0  # (the copy that remains is the first of the stack)
+
+
+@pytest.mark.gpu
 def test_place_known_answers(gpu):
     """Place through get_data on the raster of the reference's own tests (10 x 10 cells of 10 m, value 7, anchored
     at its centre; tests/test_raster_spatial.py:119-257 of the reference): exact / shifted placement at three zoom
