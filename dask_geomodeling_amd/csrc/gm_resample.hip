@@ -636,7 +636,7 @@ int gm_resample_bilinear_window(const void* src, int dtype, int bands, int hs, i
   if (!tile_h_cfg) {
     const char* e = getenv("GM_BL_H");
     tile_h_cfg = e ? atoi(e) : 32;
-    if (tile_h_cfg != 8 && tile_h_cfg != 16) tile_h_cfg = 32;
+    if (tile_h_cfg != 8 && tile_h_cfg != 16 && tile_h_cfg != 64) tile_h_cfg = 32;
   }
   const int BL_TILE_H = tile_h_cfg;
   long long win_h = (long long)ceil(BL_TILE_H * sy) + 3, win_w = (long long)ceil(BL_TILE_W * sx) + 3;
@@ -663,6 +663,7 @@ int gm_resample_bilinear_window(const void* src, int dtype, int bands, int hs, i
   do {                                                                \
     if (BL_TILE_H == 8) GM_BILINEAR_H(T, STAGED, NDV, 8);             \
     else if (BL_TILE_H == 16) GM_BILINEAR_H(T, STAGED, NDV, 16);      \
+    else if (BL_TILE_H == 64) GM_BILINEAR_H(T, STAGED, NDV, 64);      \
     else GM_BILINEAR_H(T, STAGED, NDV, 32);                           \
   } while (0)
   if (dtype == GM_F32) {

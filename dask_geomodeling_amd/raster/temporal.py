@@ -400,8 +400,11 @@ def take_frames(values, nearest):
     L.gm_frames_take.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                  ctypes.c_void_p]
     L.gm_frames_take.restype = ctypes.c_int
-    runtime.check(L.gm_frames_take(src.ptr, frame_bytes, src.shape[0], nearest.ctypes.data_as(ctypes.c_void_p),
-                                   len(nearest), out.ptr), "gm_frames_take")
+    step = 65535  # (frames per launch: the grid's second dimension)
+    for first in range(0, len(nearest), step):
+        part = np.ascontiguousarray(nearest[first:first + step])
+        runtime.check(L.gm_frames_take(src.ptr, frame_bytes, src.shape[0], part.ctypes.data_as(ctypes.c_void_p),
+                                       len(part), out.ptr + first * frame_bytes), "gm_frames_take")
     return out
 
 

@@ -86,6 +86,11 @@ def main():
                [lambda t=t: resample.bilinear(t, 2 * side, 2 * side, np.float32(F32MAX)) for t in src])
         timeit("bilinear f32 1.5x upsample (5.78 B/out px)", (4 + 4 / 2.25) * 2.25 * n,
                [lambda t=t: resample.bilinear(t, side * 3 // 2, side * 3 // 2, np.float32(F32MAX)) for t in src])
+        half = [generate_window((side // 2, side // 2), "f4", 72 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side // 2, side // 2) for i in range(2)]
+        timeit("bilinear f32 3x upsample (4.44 B/out px)", (4 + 4 / 9.0) * 2.25 * n,
+               [lambda t=t: resample.bilinear(t, side * 3 // 2, side * 3 // 2, np.float32(F32MAX)) for t in half])
+        timeit("bilinear f32 1.25x upsample (6.56 B/out px)", (4 + 4 / 1.5625) * 1.5625 * n,
+               [lambda t=t: resample.bilinear(t, side * 5 // 4, side * 5 // 4, np.float32(F32MAX)) for t in src])
         del src
     if "stencil" in which:
         src = [generate_window((side, side), "f4", 90 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side, side) for i in range(T)]
