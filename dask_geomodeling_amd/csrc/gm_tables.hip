@@ -161,14 +161,17 @@ __global__ __launch_bounds__(256) void classify_kernel(const TI* __restrict__ in
 // Here a uniform grid over [first edge, last edge] narrows the search first: bucket b = (x - lo) * inv holds
 // base[b] = a lower bound of the count for every x the float arithmetic can put into b (the host allows one
 // bucket of slack on either side), and the host has checked that the count of such an x exceeds base[b] by at
-// most GRID_SCAN: those GRID_SCAN thresholds are compared independently (sorted: the satisfied ones are a
-// prefix).  ~25 VALU instructions and 1 + GRID_SCAN LDS reads per value whatever the number of edges.
-constexpr int GRID_SCAN = 4;
+// most SCAN: those SCAN thresholds are compared independently (sorted: the satisfied ones are a
+// prefix).  ~25 VALU instructions and 1 + SCAN LDS reads per value at SCAN = 4, whatever the number of edges; round 4:
+// the host takes the smallest SCAN (1, 2 or 4) for which a grid of at most 8192 buckets exists -- evenly spaced class
+// boundaries, the usual case, need one comparison per value instead of four.
+constexpr int GRID_SCAN = 4;  // the widest scan (what the threshold table in LDS is padded for)
 struct ClassifyGrid {
   float lo, inv;
   int buckets;  // K
+  int scan;     // thresholds compared per value: 1, 2 or 4
 };
-template <typename TO, bool RIGHT, int CLS_U>
+template <typename TO, bool RIGHT, int CLS_U, int SCAN>
 __global__ __launch_bounds__(256) void classify_grid_kernel(const float* __restrict__ in, TO* __restrict__ out,
                                                             unsigned long long n_groups, const float* __restrict__ thr_g,
                                                             const unsigned short* __restrict__ base_g, int nbins,
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void classify_grid_kernel(const float* __restr
         const int first = base[b];
         int cnt = first;
 #pragma unroll
-        for (int j = 0; j < GRID_SCAN; ++j) cnt += (RIGHT ? (thr[first + j] < x) : (thr[first + j] <= x)) ? 1 : 0;
+        for (int j = 0; j < SCAN; ++j) cnt += (RIGHT ? (thr[first + j] < x) : (thr[first + j] <= x)) ? 1 : 0;
         cnt = (x != x) ? nbins : cnt;  // NaN sorts to the end
         r[k] = (has_ndv && x == ndv) ? fill : (TO)cnt;
       }
@@ -226,25 +229,28 @@ bool build_classify_grid(const float* thr, int nbins, bool right, ClassifyGrid* 
     }
     return a;
   };
-  for (int K = 1024; K <= 8192; K *= 2) {
-    const float inv = (float)((double)K / ((double)hi - (double)lo));
-    if (!std::isfinite(inv) || inv <= 0.0f) return false;
-    const double step = 1.0 / (double)inv;
-    base->assign((size_t)K, 0);
-    bool ok = true;
-    for (int b = 0; b < K && ok; ++b) {
-      // every x the device can put into bucket b lies in [lo + (b - 1) step, lo + (b + 2) step]: a whole bucket
-      // of slack on either side covers the rounding of (x - lo) * inv in float32 (a few 2^-23 * K << 1)
-      const int lower = b == 0 ? 0 : count_at((double)lo + (b - 1) * step);
-      const int upper = b == K - 1 ? nbins : count_at((double)lo + (b + 2) * step);
-      if (upper - lower > GRID_SCAN) ok = false;
-      (*base)[b] = (unsigned short)lower;
-    }
-    if (ok) {
-      G->lo = lo;
-      G->inv = inv;
-      G->buckets = K;
-      return true;
+  for (int scan = 1; scan <= GRID_SCAN; scan *= 2) {
+    for (int K = 1024; K <= 8192; K *= 2) {
+      const float inv = (float)((double)K / ((double)hi - (double)lo));
+      if (!std::isfinite(inv) || inv <= 0.0f) return false;
+      const double step = 1.0 / (double)inv;
+      base->assign((size_t)K, 0);
+      bool ok = true;
+      for (int b = 0; b < K && ok; ++b) {
+        // every x the device can put into bucket b lies in [lo + (b - 1) step, lo + (b + 2) step]: a whole bucket
+        // of slack on either side covers the rounding of (x - lo) * inv in float32 (a few 2^-23 * K << 1)
+        const int lower = b == 0 ? 0 : count_at((double)lo + (b - 1) * step);
+        const int upper = b == K - 1 ? nbins : count_at((double)lo + (b + 2) * step);
+        if (upper - lower > scan) ok = false;
+        (*base)[b] = (unsigned short)lower;
+      }
+      if (ok) {
+        G->lo = lo;
+        G->inv = inv;
+        G->buckets = K;
+        G->scan = scan;
+        return true;
+      }
     }
   }
   return false;
@@ -816,7 +822,7 @@ int gm_classify2(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, c
       if (build_classify_grid(thr, nbins, right != 0, &G, &base)) {
         std::vector<unsigned long long> packed_base((base.size() * 2 + 7) / 8 + 1, 0ull);
         memcpy(packed_base.data(), base.data(), base.size() * 2);
-        packed_base.back() = 0x6B1Dull << 32 | (unsigned)G.buckets;
+        packed_base.back() = 0x6B1Dull << 32 | (unsigned)G.buckets << 4 | (unsigned)G.scan;
         void* base_dev = nullptr;
         int rcg = cached_upload(packed_base, &base_dev);
         if (rcg) return rcg;
@@ -827,13 +833,20 @@ int gm_classify2(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, c
         const unsigned long long blocks = (n4 + 256ull * U * chunks - 1) / (256ull * U * chunks);
         if (blocks > 0x7fffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "tile too large for one launch");
         const float ndv32 = (float)ndv.f64;
-#define GM_GRID(TO_, RIGHT_)                                                                                          \
-  hipLaunchKernelGGL((classify_grid_kernel<TO_, RIGHT_, U>), dim3((unsigned)blocks), dim3(256), lds, s, (const float*)in, \
+#define GM_GRID_SCAN(TO_, RIGHT_, SCAN_)                                                                              \
+  hipLaunchKernelGGL((classify_grid_kernel<TO_, RIGHT_, U, SCAN_>), dim3((unsigned)blocks), dim3(256), lds, s, (const float*)in, \
                      (TO_*)out, n4, (const float*)thr_dev, (const unsigned short*)base_dev, nbins, G, chunks, has_ndv,  \
                      ndv32, (TO_)fill)
+#define GM_GRID(TO_, RIGHT_)                                \
+  do {                                                      \
+    if (G.scan == 1) GM_GRID_SCAN(TO_, RIGHT_, 1);          \
+    else if (G.scan == 2) GM_GRID_SCAN(TO_, RIGHT_, 2);     \
+    else GM_GRID_SCAN(TO_, RIGHT_, 4);                      \
+  } while (0)
         if (out_dtype == GM_U8) { if (right) GM_GRID(unsigned char, true); else GM_GRID(unsigned char, false); }
         else { if (right) GM_GRID(unsigned short, true); else GM_GRID(unsigned short, false); }
 #undef GM_GRID
+#undef GM_GRID_SCAN
         GM_HIP(hipGetLastError());
         if (n4 * 4 == n) return GM_OK;
         // the last n % 4 values: the general kernel's scalar path

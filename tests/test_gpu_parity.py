@@ -561,7 +561,7 @@ def test_reclassify_sparse_keys_hash_table(gpu, dtype, select):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("right", [False, True])
-@pytest.mark.parametrize("kind", ["uniform200", "random37", "clustered", "u16_300"])
+@pytest.mark.parametrize("kind", ["uniform200", "random37", "clustered", "u16_300", "pairs", "triples"])
 def test_classify_many_edges_large_tile(gpu, kind, right):
     """Stand-alone Classify with many edges on a tile large enough for the grid-accelerated kernel (uniform and
     irregular edges; clustered edges fall back to the binary search): exact against np.digitize, values on the
@@ -574,6 +574,11 @@ def test_classify_many_edges_large_tile(gpu, kind, right):
         bins = sorted(set(np.round(rng.random(37) * 180 - 90, 3).tolist()))
     elif kind == "u16_300":
         bins = (np.arange(300) * 0.61 - 90).tolist()
+    elif kind == "pairs":    # two edges closer than a grid bucket, pair after pair: two comparisons per value
+        bins = np.sort(np.concatenate([np.linspace(-100, 100, 60), np.linspace(-100, 100, 60)[:-1] + 0.01])).tolist()
+    elif kind == "triples":  # three: the four-wide scan
+        base = np.linspace(-100, 100, 50)
+        bins = np.sort(np.concatenate([base, base[:-1] + 0.004, base[:-1] + 0.008])).tolist()
     else:
         bins = sorted(set((np.concatenate([np.linspace(-100, 100, 20), 1.0 + np.arange(40) * 1e-4])).tolist()))
     ndv = np.float32(np.finfo("f4").max)
