@@ -737,6 +737,7 @@ static int run_batch_2d(const gm_program* prog, int n_tiles, const void* const* 
     args.n_inputs = n_in;
     args.out_dtype = code->prog.out_dtype;
     bool aligned = true, strided = false;
+    static const bool unaligned_loads = !(getenv("GM_VM_UNALIGNED") && atoi(getenv("GM_VM_UNALIGNED")) == 0);
     for (int t = 0; t < nb; ++t) {
       args.out[t] = outs[t0 + t];
       if (((uintptr_t)args.out[t] % 16) != 0) aligned = false;
@@ -751,15 +752,20 @@ static int run_batch_2d(const gm_program* prog, int n_tiles, const void* const* 
         const void* p = inputs[(size_t)(t0 + t) * n_in + k];
         args.in[t][k] = p;
         const bool broadcast = ((code->prog.inputs[k].bits >> 8) & 1u) != 0;
-        if (!broadcast && ((uintptr_t)p % 16) != 0) aligned = false;
+        // Tile LOADS need not be 16-byte aligned: a group of 4 elements is one global_load of 4 x itemsize bytes, which
+        // the memory pipeline takes at any element-aligned address (a window that starts at an odd column of a resident
+        // raster -- every request a stencil Block grows by its radius -- used to send the whole tile down the
+        // one-element-per-lane path: 2.7x the time of the vector kernel; round 4).  Stores stay aligned: the caller
+        // allocates the result.  GM_VM_UNALIGNED=0 restores the old rule.
+        const size_t item = (size_t)gm::dtype_size(code->prog.inputs[k].bits & 0xffu);
+        const size_t need = unaligned_loads ? item : 16;
+        if (!broadcast && ((uintptr_t)p % need) != 0) aligned = false;
         const uint32_t pitch = pitches ? pitches[(size_t)(t0 + t) * n_in + k] : 0u;
         if (pitch && pitch != cols && !broadcast) {
           if (pitch < cols) return gm::fail(GM_ERR_INVALID, "pitch %u of input %u is smaller than the tile width %zu", pitch, k, cols);
           args.pitch[t][k] = pitch;
           strided = true;
-          // 16-byte vector loads need every row of the window to start 16-byte aligned
-          const size_t item = (size_t)gm::dtype_size(code->prog.inputs[k].bits & 0xffu);
-          if (((size_t)pitch * item) % 16 != 0) aligned = false;
+          if (!unaligned_loads && ((size_t)pitch * item) % 16 != 0) aligned = false;
         }
       }
     }

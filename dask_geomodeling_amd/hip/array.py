@@ -79,6 +79,19 @@ class DeviceArray:
         ptr = self.ptr + (row0 * pitch + col0) * self.dtype.itemsize
         return DeviceArray(ptr, (1, height, width), self.dtype, self.device, owner=self, pitch=pitch)
 
+    def room_right(self):
+        """Columns of the parent raster to the right of this zero-copy window, in the window's rows (0 for a tile that
+        is not a window): how far a kernel may read past the window's last column."""
+        if self.pitch is None:
+            return 0
+        root = self
+        while root._owner is not None and isinstance(root._owner, DeviceArray):
+            root = root._owner
+        if root.pitch is not None or len(root.shape) != 3 or root.shape[-1] != self.pitch:
+            return 0
+        first = (self.ptr - root.ptr) // self.dtype.itemsize
+        return root.shape[-1] - (first % root.shape[-1]) - self.shape[-1]
+
     def contiguous(self):
         """This tile if it is C-contiguous, else a compacted copy (one 2-D device copy)."""
         if self.pitch is None:

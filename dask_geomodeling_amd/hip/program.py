@@ -873,9 +873,12 @@ def launch_batch(compiled, tiles, shape, outs=None):
     n_in = len(tiles[0]) if tiles else 0
     if any(len(inputs) != n_in for inputs in tiles):
         raise ValueError("every tile of a batch must bring the same number of inputs")
-    if outs is None:
-        outs = [DeviceArray.empty(shape, compiled.out_dtype) for _ in tiles]
     flat = [x for inputs in tiles for x in inputs]
+    if outs is None:
+        padded = _padded_launch(L, compiled, tiles, flat, shape, n)
+        if padded is not None:
+            return padded
+        outs = [DeviceArray.empty(shape, compiled.out_dtype) for _ in tiles]
     ptrs = (ctypes.c_void_p * max(len(flat), 1))(*[x.ptr for x in flat])
     out_ptrs = (ctypes.c_void_p * max(len(outs), 1))(*[o.ptr for o in outs])
     if any(x.pitch is not None for x in flat) or any(o.pitch is not None for o in outs):
@@ -888,6 +891,36 @@ def launch_batch(compiled, tiles, shape, outs=None):
         runtime.check(L.gm_elemwise_run_batch(ctypes.byref(compiled.program), len(tiles), ptrs, out_ptrs, n),
                       "gm_elemwise_run_batch")
     return outs
+
+
+def _padded_launch(L, compiled, tiles, flat, shape, n):
+    """Windows whose width is no multiple of 4 -- the request a stencil Block grows by its radius, 4096 + 2 columns --
+    cannot run on the 16-byte vector kernels, whose groups of 4 cells must not straddle rows.  When every raster input
+    is a zero-copy window with enough of its parent raster to its right, the program runs over the next multiple of 4
+    columns instead (up to 3 columns of neighbouring cells are computed for nothing) into a result tile of that
+    width, and the result is handed on as the window of the requested width inside it (row pitch = the padded
+    width: what the stencil kernels and this launch path read in place).  None when that is not possible."""
+    if len(shape) != 3 or shape[0] != 1 or shape[-1] % 4 == 0 or shape[-1] < 4:
+        return None
+    rows, cols = int(shape[1]), int(shape[2])
+    pad = (-cols) % 4
+    pitches = []
+    for x in flat:
+        if x.size == 1 and n != 1:  # broadcast operand: no rows
+            pitches.append(0)
+        elif x.pitch is not None and tuple(x.shape) == tuple(shape) and x.room_right() >= pad:
+            pitches.append(x.pitch)
+        else:
+            return None
+    wide = (1, rows, cols + pad)
+    outs = [DeviceArray.empty(wide, compiled.out_dtype) for _ in tiles]
+    ptrs = (ctypes.c_void_p * max(len(flat), 1))(*[x.ptr for x in flat])
+    out_ptrs = (ctypes.c_void_p * len(outs))(*[o.ptr for o in outs])
+    pitch_arr = (ctypes.c_uint32 * max(len(flat), 1))(*pitches)
+    out_pitches = (ctypes.c_uint32 * len(outs))(*[0] * len(outs))
+    runtime.check(L.gm_elemwise_run_batch_2d(ctypes.byref(compiled.program), len(tiles), ptrs, pitch_arr, out_ptrs,
+                                             out_pitches, rows, cols + pad), "gm_elemwise_run_batch_2d")
+    return [DeviceArray(o.ptr, shape, o.dtype, o.device, owner=o, pitch=cols + pad) for o in outs]
 
 
 def _collect_leaves(root):

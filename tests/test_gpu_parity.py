@@ -1685,6 +1685,52 @@ def test_reduce_rasters_sums_over_deep_stacks(gpu, n, dtype):
         assert_values_equal(np.asarray(out["values"]), want["values"], 0, "%s over %d %s rasters" % (stat, n, dtype))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f4", "u1", "i2", "i4", "f8", "i8"])
+def test_programs_over_windows_at_any_column(gpu, dtype):
+    """Element-wise programs over zero-copy windows of resident rasters that start at ANY column and have ANY width --
+    what a stencil Block asks of its store (4096 + 2 columns from an odd column on): 16-byte groups loaded from
+    element-aligned addresses, widths that are no multiple of 4 run over the next multiple (the result comes back as
+    a window of a padded tile), windows at the right edge of their raster, where there is nothing to pad with, take
+    the one-element path.  All against the oracle on the same slices."""
+    from dask_geomodeling_amd.hip import program as P
+    from dask_geomodeling_amd.hip.array import DeviceArray
+    rng = np.random.default_rng(abs(hash(dtype)) % 2**31)
+    dt = np.dtype(dtype)
+    H, W = 70, 520
+    if dt.kind == "f":
+        a = (rng.random((1, H, W)) * 200 - 100).astype(dt)
+        b = (rng.random((1, H, W)) * 200 - 100).astype(dt)
+        ndv = dt.type(np.finfo(dt).max)
+    else:
+        a = rng.integers(0, 100, size=(1, H, W)).astype(dt)
+        b = rng.integers(0, 100, size=(1, H, W)).astype(dt)
+        ndv = dt.type(np.iinfo(dt).max)
+    a[rng.random(a.shape) < 0.05] = ndv
+    da, db = DeviceArray.from_numpy(a), DeviceArray.from_numpy(b)
+    out_dt = np.result_type(dt, np.int32) if dt.kind in "iu" else np.result_type(dt, np.float32)
+    kw = {"dtype": out_dt.name, "fillvalue": O.get_dtype_max(out_dt)}
+    cases = [(0, 0, 16, 64), (3, 1, 16, 64), (5, 2, 33, 66), (7, 3, 20, 67), (1, 5, 64, 129), (2, 7, 9, 509),
+             (0, 517, 70, 3), (4, 453, 30, 67), (6, 9, 1, 5), (0, 1, 70, 518), (9, 258, 17, 262)]
+    for row0, col0, h, w in cases:
+        wa, wb = da.window(row0, col0, h, w), db.window(row0, col0, h, w)
+        sa, sb = a[:, row0:row0 + h, col0:col0 + w], b[:, row0:row0 + h, col0:col0 + w]
+        A = {"values": wa, "no_data_value": ndv}
+        B = {"values": wb, "no_data_value": ndv}
+        got = devops.math_process("add", kw, A, B)
+        want = O.math_process("add", kw, {"values": sa, "no_data_value": ndv}, {"values": sb, "no_data_value": ndv})
+        what = "%s window (%d, %d, %d, %d)" % (dtype, row0, col0, h, w)
+        assert tuple(got["values"].shape) == (1, h, w)
+        assert_result_equal(dict(got, values=np.asarray(got["values"])), want, 0, what)
+        # the (possibly pitched) result feeds the next program as it is
+        again = devops.math_process("multiply", kw, got, 3)
+        want2 = O.math_process("multiply", kw, want, 3)
+        assert_result_equal(dict(again, values=np.asarray(again["values"])), want2, 0, what + " * 3")
+        masked = devops.mask_process(A, 7)
+        assert_result_equal(dict(masked, values=np.asarray(masked["values"])),
+                            O.mask_process({"values": sa, "no_data_value": ndv}, 7), 0, what + " mask")
+
+
 # ---------------------------------------------------------------------------------
 # round 4: Snap / Shift / TemporalSum / Resample (frame gather + frame sum on the device), Place
 # ---------------------------------------------------------------------------------
