@@ -23,6 +23,7 @@ bodies, which carry the reference's control flow for those cases.
 """
 import numpy as np
 
+from . import utils
 from .hip import program as P
 from .hip.array import DeviceArray
 from .raster import devops, tables
@@ -233,6 +234,18 @@ class FusedTask(object):
             if not isinstance(args[0], dict):
                 raise _NotFusable()
             return devops.reduce_max_node(args[0], [operand(a) for a in args[1:]])
+        if op == "fillnodata":
+            # FillNoData's loop (elemwise.py:749-755): every raster in turn pasted where it has data
+            if not isinstance(args[0], dict) or len(args) < 2:
+                raise _NotFusable()
+            dtype = np.dtype(args[0]["dtype"])
+            fill = utils.get_dtype_max(dtype)
+            node = P.Lit(fill)
+            for a in args[1:]:
+                if not self._ref(a):
+                    raise _NotFusable()
+                node = devops.fillnodata_node(node, operand(a), dtype, fill)
+            return node
         if op == "clip":
             return devops.clip_node(operand(args[0]), operand(args[1]))
         if op == "mask":

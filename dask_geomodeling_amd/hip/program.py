@@ -1088,8 +1088,70 @@ def evaluate(root):
     return run_staged(stages, shape), stages[-1][0].out_ndv
 
 
-def run_expr(build, tiles):
-    """Evaluate ``build(leaves)`` over raster tiles given as (values, ndv) pairs."""
+_EXPR_PLANS = {}  # (what the expression is, what kind of tiles it is applied to) -> (stages, shape)
+_EXPR_PLANS_MAX = 512
+
+
+def _tiles_key(tiles):
+    """dtype, shape and no-data value of every tile, or None when the tiles are not all of one shape (operands that
+    are expanded per call) or a value does not hash."""
+    try:
+        key, shape = [], None
+        for v, ndv in tiles:
+            sh = tuple(v.shape)
+            if _prod(sh) != 1:
+                if shape is not None and sh != shape:
+                    return None
+                shape = sh
+            key.append((np.dtype(v.dtype).num, sh, None if ndv is None else _scalar_key(ndv)))
+        key = tuple(key)
+        hash(key)
+        return key
+    except TypeError:
+        return None
+
+
+def run_expr(build, tiles, key=None):
+    """Evaluate ``build(leaves)`` over raster tiles given as (values, ndv) pairs.
+
+    ``key``: a hashable description of everything ``build`` puts into the expression besides the tiles (operation,
+    dtype, literals ...).  With it the staged plan -- the expression tree, its register class, the compiled programs
+    -- is made once per kind of tiles and later calls only bind their tiles and launch: what a Block that runs on its
+    own (not inside a fused group) pays per request drops from ~100 microseconds of Python to ~10."""
+    cache_key = None
+    if key is not None:
+        tk = _tiles_key(tiles)
+        if tk is not None:
+            cache_key = (key, tk)
+            hit = _EXPR_PLANS.get(cache_key)
+            if hit is not None:
+                runtime.require_device()
+                stages, shape = hit
+                outs = []
+                for compiled, binding in stages:
+                    inputs = [as_device_view(tiles[ref][0]) if kind == 0 else (outs[ref] if kind == 2 else ref)
+                              for kind, ref in binding]
+                    outs.append(launch(compiled, inputs, shape))
+                return outs[-1], stages[-1][0].out_ndv
     leaves = [Leaf(None, np.asarray(v).dtype if not hasattr(v, "dtype") else v.dtype, ndv, values=v)
               for v, ndv in tiles]
-    return evaluate(build(leaves))
+    if cache_key is None:
+        return evaluate(build(leaves))
+    runtime.require_device()
+    arg_of = {id(leaf): i for i, leaf in enumerate(leaves)}
+    staged, shape = plan_staged(build(leaves))
+    stages = []
+    for compiled, stage_leaves in staged:
+        binding = []
+        for leaf in stage_leaves:
+            if isinstance(leaf, StageRef):
+                binding.append((2, leaf.stage))
+            elif id(leaf) in arg_of:
+                binding.append((0, arg_of[id(leaf)]))
+            else:
+                binding.append((1, leaf.values))  # a constant of the expression, on the device already
+        stages.append((compiled, binding))
+    if len(_EXPR_PLANS) >= _EXPR_PLANS_MAX:
+        _EXPR_PLANS.clear()
+    _EXPR_PLANS[cache_key] = (stages, shape)
+    return run_staged(staged, shape), staged[-1][0].out_ndv

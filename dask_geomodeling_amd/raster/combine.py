@@ -103,6 +103,8 @@ class BaseCombine(RasterBlock):
 def _band(values, index):
     """Band ``index`` of a (bands, H, W) tile as a (1, H, W) tile, without a copy."""
     if isinstance(values, DeviceArray):
+        if values.shape[0] == 1 and index == 0:
+            return values  # (a zero-copy window of a resident raster stays one: the merge program reads it in place)
         return values.contiguous().band_slice(index, index + 1)
     return np.asarray(values)[index:index + 1]
 

@@ -176,7 +176,12 @@ def reduce_max_process(process_kwargs, *args):
     if len(stack) == 0:
         return None
     tiles = [(a["values"], a["no_data_value"]) for a in stack]
-    values, ndv = P.run_expr(lambda leaves: reduce_max_node(process_kwargs, leaves), tiles)
+    try:
+        key = ("reduce_max", str(process_kwargs["dtype"]), P._scalar_key(process_kwargs["fillvalue"]), len(tiles))
+        hash(key)
+    except (TypeError, KeyError):
+        key = None
+    values, ndv = P.run_expr(lambda leaves: reduce_max_node(process_kwargs, leaves), tiles, key)
     return {"values": values, "no_data_value": ndv}
 
 
@@ -304,7 +309,13 @@ def math_process(op, process_kwargs, *args):
 
     if not tiles:
         raise TypeError("at least one raster operand is required")
-    values, ndv = P.run_expr(build, tiles)
+    try:
+        key = ("math", op, str(process_kwargs["dtype"]), P._scalar_key(process_kwargs["fillvalue"]), extra is not None,
+               tuple(ref if kind == "tile" else P._scalar_key(ref) for kind, ref in slots))
+        hash(key)
+    except (TypeError, KeyError):
+        key = None
+    values, ndv = P.run_expr(build, tiles, key)
     return {"no_data_value": ndv, "values": values}
 
 
@@ -342,7 +353,7 @@ def clip_process(data, source_data):
     tiles = [(data["values"], data["no_data_value"]),
              (source_data["values"], source_data.get("no_data_value"))]
     try:
-        values, ndv = P.run_expr(lambda leaves: clip_node(leaves[0], leaves[1]), tiles)
+        values, ndv = P.run_expr(lambda leaves: clip_node(leaves[0], leaves[1]), tiles, ("clip",))
     except (NotImplementedError, P.FusionLimit):
         # no register class holds both tiles exactly (e.g. int64 store, float mask source):
         # reduce the source to its boolean "has data" tile first; Clip only needs that
@@ -359,14 +370,14 @@ def mask_process(data, value):
     if data is None or "values" not in data:
         return data
     tiles = [(data["values"], data["no_data_value"])]
-    values, ndv = P.run_expr(lambda leaves: mask_node(leaves[0], value), tiles)
+    values, ndv = P.run_expr(lambda leaves: mask_node(leaves[0], value), tiles, ("mask", P._scalar_key(value)))
     return {"values": values, "no_data_value": ndv}
 
 
 def unary_bool_process(kind, data):
     tiles = [(data["values"], data.get("no_data_value"))]
     builder = {"invert": invert_node, "isdata": isdata_node, "isnodata": isnodata_node}[kind]
-    values, _ = P.run_expr(lambda leaves: builder(leaves[0]), tiles)
+    values, _ = P.run_expr(lambda leaves: builder(leaves[0]), tiles, (kind,))
     return {"values": values, "no_data_value": None}
 
 
@@ -409,5 +420,5 @@ def fillnodata_process(process_kwargs, *args):
             node = fillnodata_node(node, leaf, dtype, fill)
         return node
 
-    values, _ = P.run_expr(build, tiles)
+    values, _ = P.run_expr(build, tiles, ("fillnodata", dtype.str, len(tiles)))
     return {"values": values, "no_data_value": fill}

@@ -305,6 +305,8 @@ class FillNoData(BaseElementwise):
     def process(process_kwargs, *args):
         return devops.fillnodata_process(process_kwargs, *args)
 
+    process.__func__.gm_op = "fillnodata"  # recognised by the fusion pass (fuse.py)
+
 
 class BaseLogExp(BaseSingle):
     def __init__(self, x):

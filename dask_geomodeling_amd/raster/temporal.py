@@ -75,6 +75,33 @@ def dtype_for_statistic(dtype, statistic):
     return np.result_type(np.float32, dtype)
 
 
+def _remembered(method):
+    """Calendar answers depend on the rule and the moments asked about, nothing else -- and pandas takes 100 to 400
+    microseconds for each (a one-sample Series, a resampler, its bins).  Every tile of a temporal view asks the same
+    questions, so the answers are kept (bounded); a key that does not hash is answered afresh."""
+    answers = {}
+
+    def hashable(a):
+        if isinstance(a, (list, pd.DatetimeIndex)):
+            return tuple(a)
+        return a
+
+    def wrapper(self, *args):
+        try:
+            key = (self.frequency, self.closed, self.label, self.timezone) + tuple(hashable(a) for a in args)
+            hit = answers.get(key, answers)
+        except TypeError:
+            return method(self, *args)
+        if hit is answers:
+            if len(answers) >= 4096:
+                answers.clear()
+            hit = answers[key] = method(self, *args)
+        return list(hit) if isinstance(hit, list) else hit  # (a list is handed out as a copy)
+
+    wrapper.__name__, wrapper.__doc__ = method.__name__, method.__doc__
+    return wrapper
+
+
 class _Calendar:
     """The bins of one resampling rule: naive-UTC datetimes in and out, pandas in between."""
 
@@ -103,6 +130,7 @@ class _Calendar:
         return ts.tz_convert("UTC").tz_localize(None).to_pydatetime(warn=False)
 
     # -- single moments ------------------------------------------------------------------
+    @_remembered
     def label_of(self, dt, closed=None, label=None):
         """Label of the bin ``dt`` falls in (a one-sample resample; temporal.py:271-284)."""
         probe = pd.Series([0], index=[self.stamp(dt)])
@@ -112,11 +140,13 @@ class _Calendar:
                 break
         return self.moment(found)
 
+    @_remembered
     def bin_start_of(self, dt):
         """Left edge (Timestamp) of the bin ``dt`` falls in (temporal.py:287-296)."""
         probe = pd.Series([0], index=[self.stamp(dt)])
         return probe.resample(self.frequency, closed=self.closed, label="left").first().index[0]
 
+    @_remembered
     def nearest_label(self, dt, side):
         """The label closest to ``dt``; side 'left' / 'right' only looks that way (temporal.py:321-347)."""
         ts = self.stamp(dt)
@@ -131,6 +161,7 @@ class _Calendar:
             gaps = gaps[gaps <= pd.Timedelta(0)]
         return self.moment(gaps.abs().idxmin())
 
+    @_remembered
     def first_moment(self, label):
         """First moment inside the bin labelled ``label`` (temporal.py:373-380)."""
         ts = self.stamp(label)
@@ -140,6 +171,7 @@ class _Calendar:
             ts += _TICK
         return self.moment(ts)
 
+    @_remembered
     def last_moment(self, label):
         """Last moment inside the bin labelled ``label`` (temporal.py:383-390)."""
         ts = self.stamp(label)
@@ -149,6 +181,7 @@ class _Calendar:
             ts -= _TICK
         return self.moment(ts)
 
+    @_remembered
     def shifted(self, dt, n):
         """``dt`` moved by n periods of the rule, n possibly fractional: a fraction of a calendar period (a month)
         is that fraction of the period it falls in (temporal.py:298-319)."""
@@ -164,6 +197,7 @@ class _Calendar:
             ts = ts + n * step
         return self.moment(ts)
 
+    @_remembered
     def label_range(self, first, last):
         """All labels from ``first`` to ``last`` inclusive; [first] when last is None (temporal.py:463-473)."""
         if last is None:
@@ -172,6 +206,7 @@ class _Calendar:
         return [self.moment(ts) for ts in stamps]
 
     # -- periods and windows -------------------------------------------------------------
+    @_remembered
     def resampled_period(self, period):
         """(first label, last label) of the resampled raster (temporal.py:393-402)."""
         if period is None:
@@ -180,6 +215,7 @@ class _Calendar:
             return period[-1], period[-1]
         return tuple(self.label_of(moment) for moment in period)
 
+    @_remembered
     def snap_window(self, period, start, stop):
         """Requested (start, stop) -> (first label, last label) inside ``period``; (label, None) for a
         one-moment request, (None, None) when no label is in range (temporal.py:405-455)."""
@@ -202,6 +238,30 @@ class _Calendar:
             return None, None
         return start, stop
 
+    @_remembered
+    def labels_between(self, start, stop):
+        """The labels from ``start`` to ``stop`` (start alone when stop is None, or without a frequency): as naive
+        UTC stamps and in the rule's time zone (temporal.py:696-704)."""
+        if self.frequency is None:
+            labels = pd.DatetimeIndex([start])
+            return labels, labels.tz_localize("UTC")
+        labels = pd.date_range(start, stop or start, freq=self.frequency)
+        return labels, labels.tz_localize("UTC").tz_convert(self.timezone)
+
+    @_remembered
+    def periods_of(self, times, start, stop):
+        """The frames of every accumulation period of ``times`` (index arrays, in order) and which frames lie between
+        ``start`` and ``stop`` (boolean per frame): Cumulative's bookkeeping (temporal.py:940-975)."""
+        stamps = pd.Series(index=times, dtype=float).tz_localize("UTC").tz_convert(self.timezone)
+        if self.frequency is None:
+            members = (np.arange(len(times)),)
+        else:
+            resampled = stamps.resample(self.frequency, closed=self.closed, label=self.label)
+            members = tuple(np.asarray(frames, dtype=np.int64) for frames in resampled.indices.values())
+        wanted = np.asarray((stamps.index >= self.stamp(start)) & (stamps.index <= self.stamp(stop)))
+        return members, wanted
+
+    @_remembered
     def frames_of(self, times, labels):
         """[(first frame, count)] per label: the run of ``times`` (naive UTC, ascending) that falls in the
         bin of every label (pandas' Resampler.indices, temporal.py:706-722)."""
@@ -733,17 +793,13 @@ class TemporalAggregate(BaseSingle):
             return nothing
         calendar = _Calendar(process_kwargs["frequency"], process_kwargs["closed"], process_kwargs["label"],
                              process_kwargs["timezone"])
-        start, stop = process_kwargs["start"], process_kwargs["stop"]
-        if calendar.frequency is None:
-            labels = pd.DatetimeIndex([start])
-        else:
-            labels = pd.date_range(start, stop or start, freq=calendar.frequency)
+        labels, local_labels = calendar.labels_between(process_kwargs["start"], process_kwargs["stop"])
         if mode == "time":
             return {"time": labels.to_pydatetime().tolist()}
         if time_data is None or not time_data.get("time"):
             return nothing
         times = time_data["time"]
-        runs = calendar.frames_of(times, labels.tz_localize("UTC").tz_convert(calendar.timezone))
+        runs = calendar.frames_of(times, local_labels)
         if mode == "meta":
             if data is None or "meta" not in data:
                 return {"meta": []}
@@ -834,14 +890,7 @@ class Cumulative(BaseSingle):
         calendar = _Calendar(process_kwargs["frequency"], process_kwargs["closed"], process_kwargs["label"],
                              process_kwargs["timezone"])
         times = time_data["time"]
-        stamps = pd.Series(index=times, dtype=float).tz_localize("UTC").tz_convert(calendar.timezone)
-        if calendar.frequency is None:
-            members = [np.arange(len(times))]
-        else:
-            resampled = stamps.resample(calendar.frequency, closed=calendar.closed, label=calendar.label)
-            members = [np.asarray(frames, dtype=np.int64) for frames in resampled.indices.values()]
-        first_stamp, last_stamp = calendar.stamp(process_kwargs["start"]), calendar.stamp(process_kwargs["stop"])
-        wanted = np.asarray((stamps.index >= first_stamp) & (stamps.index <= last_stamp))
+        members, wanted = calendar.periods_of(times, process_kwargs["start"], process_kwargs["stop"])
 
         if mode == "meta":
             if data is None or "meta" not in data:

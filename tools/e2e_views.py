@@ -1,0 +1,68 @@
+"""get_data of mixed views (GPU box): microseconds per 4096^2 tile request on the plan path, next to the time the
+kernels of the view would take at their stand-alone rates (bytes moved / 6 TB/s) -- a view that takes much longer
+than that has a slow seam somewhere (a compaction copy, a one-element-per-lane launch, host time)."""
+import sys, time, numpy as np
+from datetime import datetime, timedelta
+sys.path.insert(0, "/root/repo")
+from dask_geomodeling_amd import raster, config as gmconfig
+from dask_geomodeling_amd.hip import runtime
+from dask_geomodeling_amd.raster.sources import generate_window
+runtime.set_device(0)
+F32MAX = float(np.finfo("f4").max)
+side, big = 4096, 16384
+da = generate_window((big, big), "f4", 7001, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big)
+db = generate_window((big, big), "f4", 7002, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big)
+dc = generate_window((big, big), "u1", 7003, 0.0, 12.0, 255, (97, 89), 0, 0, big, big)
+A = raster.MemorySource(da, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
+B = raster.MemorySource(db, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
+C = raster.MemorySource(dc, np.uint8(255), "EPSG:28992", 1.0, (0.0, float(big)))
+frames = 8
+dt = generate_window((frames * 4096, 4096), "f4", 7004, 0.0, 100.0, F32MAX, (97, 89), 0, 0, frames * 4096, 4096).reshape((frames, 4096, 4096))
+T = raster.MemorySource(dt, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, 4096.0), time_first=datetime(2020, 1, 1), time_delta=timedelta(hours=6))
+px = side * side
+views = [
+    ("A + B", A + B, 12 * px),
+    ("Clip(A * 2, B > 50)", raster.Clip(A * 2, B > 50), 12 * px),
+    ("Classify(HillShade(A), 8 bins)", raster.Classify(raster.HillShade(A), [20, 50, 80, 110, 140, 170, 200, 230]), (5 + 2) * px),
+    ("Dilate(Reclassify(C), [3])", raster.Dilate(raster.Reclassify(C, [[1, 3], [2, 3], [5, 9]]), [3]), (1 + 8 + 8 + 8) * px),
+    ("Mask(Dilate(C, [3, 5]), 1)", raster.Mask(raster.Dilate(C, [3, 5]), 1), (2 + 2) * px),
+    ("Smooth(A, 2) (exact)", raster.Smooth(A, 2.0), 8 * px),
+    ("Clip(Smooth(A, 2), B > 50)", raster.Clip(raster.Smooth(A, 2.0), B > 50), (8 + 12) * px),
+    ("MovingMax(A + B, 7)", raster.MovingMax(A + B, 7), (12 + 8) * px),
+    ("Max(A, B, A * 2)", raster.Max(A, B, A * 2), 12 * px),
+    ("Group(A, B)", raster.Group(A, B), 12 * px),
+    ("FillNoData(A, B)", raster.FillNoData(A, B), 12 * px),
+    ("Place(A, 2 coordinates)", raster.Place(A, "EPSG:28992", (8192.0, 8192.0), [(8192.0, 8192.0), (8292.0, 8092.0)]), None),
+]
+boxes = [(float(i * side + 64), float(j * side + 64), float((i + 1) * side + 64), float((j + 1) * side + 64)) for i in range(3) for j in range(3)]
+req = dict(mode="vals", width=side, height=side, projection="EPSG:28992")
+
+
+def run(name, view, nbytes, requests, n=90):
+    with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": True}):
+        try:
+            for k in range(9):
+                view.get_data(**requests[k % len(requests)])
+            runtime.sync()
+            t0 = time.perf_counter()
+            for k in range(n):
+                view.get_data(**requests[k % len(requests)])
+            runtime.sync()
+        except Exception as e:  # noqa: BLE001
+            print("%-34s %s: %s" % (name, type(e).__name__, str(e)[:90]), flush=True)
+            return
+        us = (time.perf_counter() - t0) / n * 1e6
+    floor = "" if nbytes is None else "  kernels at 6 TB/s: %6.1f us  (x %.2f)" % (nbytes / 6e6, us / (nbytes / 6e6))
+    print("%-34s %8.1f us per request%s" % (name, us, floor), flush=True)
+
+
+for name, view, nbytes in views:
+    run(name, view, nbytes, [dict(req, bbox=b) for b in boxes])
+tbox = dict(mode="vals", bbox=(0.0, 0.0, 4096.0, 4096.0), width=4096, height=4096, projection="EPSG:28992",
+            start=datetime(2020, 1, 1), stop=datetime(2020, 1, 3))
+run("TemporalAggregate(T, D, mean)", raster.TemporalAggregate(T, "D", "mean"), (frames * 4 + 2 * 4) * px, [tbox], n=30)
+run("TemporalAggregate(T * 2, D, mean)", raster.TemporalAggregate(T * 2, "D", "mean"), (frames * 8 + frames * 4 + 2 * 4) * px, [tbox], n=30)
+run("Cumulative(T)", raster.Cumulative(T), (frames * 8) * px, [tbox], n=30)
+run("TemporalSum(T)", raster.TemporalSum(T), (frames * 4 + 4) * px, [tbox], n=30)
+run("Shift(T, 1h)", raster.Shift(T, 3600 * 1000), 0.001, [tbox], n=30)
+run("Resample(T, 3h, nearest)", raster.Resample(T, "3h", "nearest"), 2 * 15 * 4 * px, [tbox], n=30)
