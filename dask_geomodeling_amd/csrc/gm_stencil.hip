@@ -40,10 +40,13 @@ constexpr int ST_ROWS = 32, ST_BATCH = 4;
 // (more values than one launch carries: every group still tests the ORIGINAL tile, spatial.py:147-154).
 template <typename T, bool CHAIN = false>
 __global__ __launch_bounds__(256) void dilate_kernel(const T* __restrict__ in, T* out, int bands, int h,
-                                                     int w, DilateArgs<T> A) {
+                                                     int w_cols, int pitch, DilateArgs<T> A) {
+  // pitch: elements between the rows of the input (a zero-copy window, or a tile inside a padded one: pitch > w_cols,
+  // one band); the walk below addresses rows by `w`
   const int c = blockIdx.x * 256 + threadIdx.x, r0 = blockIdx.y * ST_ROWS, b = blockIdx.z;
-  const int ow = w - 2, oh = h - 2;
+  const int ow = w_cols - 2, oh = h - 2;
   if (c >= ow) return;
+  const int w = pitch;
   const size_t plane = (size_t)h * w;
   const T* base = in + (size_t)b * plane + c;  // column c of the padded tile = west neighbour of output column c
   const bool has_up = b > 0, has_down = b + 1 < bands;
@@ -1326,15 +1329,14 @@ int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_
   if (n_values > DIL_MAX_VALUES) {
     // the reference takes any number of values (spatial.py:147-154): groups of DIL_MAX_VALUES, every group testing
     // the original tile and writing on top of what the groups before it left in `out`
-    if (window) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: %d values want a compact tile", n_values);
 #define GM_DILC(T)                                                                                                     \
   do {                                                                                                                 \
     for (int v0 = 0; v0 < n_values; v0 += DIL_MAX_VALUES) {                                                            \
       DilateArgs<T> A;                                                                                                 \
       A.n_values = n_values - v0 < DIL_MAX_VALUES ? n_values - v0 : DIL_MAX_VALUES;                                    \
       for (int i = 0; i < A.n_values; ++i) A.values[i] = from_bits<T>(values_bits[v0 + i]);                            \
-      if (v0 == 0) hipLaunchKernelGGL((dilate_kernel<T, false>), grid, dim3(256), 0, s, (const T*)in, (T*)out, bands, h, w, A); \
-      else hipLaunchKernelGGL((dilate_kernel<T, true>), grid, dim3(256), 0, s, (const T*)in, (T*)out, bands, h, w, A); \
+      if (v0 == 0) hipLaunchKernelGGL((dilate_kernel<T, false>), grid, dim3(256), 0, s, (const T*)in, (T*)out, bands, h, w, in_pitch, A); \
+      else hipLaunchKernelGGL((dilate_kernel<T, true>), grid, dim3(256), 0, s, (const T*)in, (T*)out, bands, h, w, in_pitch, A); \
     }                                                                                                                  \
   } while (0)
     switch (cell) {  // (values are compared by bit pattern for integers, by == for floats)
@@ -1369,13 +1371,12 @@ int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_
     GM_HIP(hipGetLastError());
     return GM_OK;
   }
-  if (window) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: this dtype / tile shape wants a compact tile");
 #define GM_DIL(T)                                                                                    \
   do {                                                                                               \
     DilateArgs<T> A;                                                                                 \
     A.n_values = n_values;                                                                           \
     for (int i = 0; i < n_values; ++i) A.values[i] = from_bits<T>(values_bits[i]);                   \
-    hipLaunchKernelGGL(dilate_kernel<T>, grid, dim3(256), 0, s, (const T*)in, (T*)out, bands, h, w, A); \
+    hipLaunchKernelGGL(dilate_kernel<T>, grid, dim3(256), 0, s, (const T*)in, (T*)out, bands, h, w, in_pitch, A); \
   } while (0)
   switch (dtype) {
     case GM_BOOL: case GM_U8: GM_DIL(unsigned char); break;

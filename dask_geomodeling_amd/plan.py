@@ -247,12 +247,17 @@ def _child(block, request):
                 return memo[key]
         except TypeError:
             key = None
-    planned, response = evaluate(block, request)
-    if not planned:
-        from .core.graphs import compute
-        from .template import fused_compute_graph
-        graph, name = fused_compute_graph(block, request)
-        response = compute(graph, name)
+    if request.get("mode") in ("time", "meta"):
+        # time stamps and metadata: no tiles, nothing to fuse -- the Blocks' own process() over their sources' answers,
+        # without a graph, a token and a scheduler pass per question (a Group asks every source for its time stamps)
+        response = _direct(block, request)
+    else:
+        planned, response = evaluate(block, request)
+        if not planned:
+            from .core.graphs import compute
+            from .template import fused_compute_graph
+            graph, name = fused_compute_graph(block, request)
+            response = compute(graph, name)
     if key is not None:
         memo[key] = response
     return response

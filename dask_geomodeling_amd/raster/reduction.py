@@ -77,25 +77,36 @@ def _through_program(root):
 def _pick(stack, order, fill_value, dtype):
     """'last' / 'first': out[index] = values[index] raster after raster (reduction.py:78-87)."""
     from ..hip import program as P
-    nodes = _stack_nodes(stack)
-    acc = P.Lit(dtype.type(fill_value))
-    for node in (nodes if order == "last" else nodes[::-1]):
-        acc = devops.fillnodata_node(acc, node, dtype, fill_value)
-    return _through_program(acc)
+
+    def build(nodes):
+        acc = P.Lit(dtype.type(fill_value))
+        for node in (nodes if order == "last" else nodes[::-1]):
+            acc = devops.fillnodata_node(acc, node, dtype, fill_value)
+        return acc
+
+    tiles = [(data["values"], data["no_data_value"]) for data in stack]
+    values, _ = P.run_expr(build, tiles, ("pick", order, dtype.str, P._scalar_key(fill_value), len(stack)))
+    return values
 
 
 def _count(stack, dtype):
     """'count': out += get_index(values, ndv) raster after raster (reduction.py:88-91)."""
     from ..hip import program as P
     counter = np.dtype("f8") if dtype.kind == "f" else (np.dtype("i8") if dtype.itemsize == 8 else np.dtype("i4"))
-    acc = None
-    for node in _stack_nodes(stack):
-        extra = dict(_index_extra(node.dtype, node.ndv), value=1, fill=0)
-        is_data = P.Op("mask", [node], counter, None, extra=extra)
-        acc = is_data if acc is None else P.Op("add", [acc, is_data], counter, None, fill=0)
-    if counter != dtype:
-        acc = P.Op("copy", [acc], dtype, None)  # (integers wrap modulo the output width, like out += index)
-    return _through_program(acc)
+
+    def build(nodes):
+        acc = None
+        for node in nodes:
+            extra = dict(_index_extra(node.dtype, node.ndv), value=1, fill=0)
+            is_data = P.Op("mask", [node], counter, None, extra=extra)
+            acc = is_data if acc is None else P.Op("add", [acc, is_data], counter, None, fill=0)
+        if counter != dtype:
+            acc = P.Op("copy", [acc], dtype, None)  # (integers wrap modulo the output width, like out += index)
+        return acc
+
+    tiles = [(data["values"], data["no_data_value"]) for data in stack]
+    values, _ = P.run_expr(build, tiles, ("count", dtype.str, len(stack)))
+    return values
 
 
 _declared = False
