@@ -72,3 +72,21 @@ run("Cumulative(T)", raster.Cumulative(T), (frames * 8) * px, [tbox], n=30)
 run("TemporalSum(T)", raster.TemporalSum(T), (frames * 4 + 4) * px, [tbox], n=30)
 run("Shift(T, 1h)", raster.Shift(T, 3600 * 1000), 0.001, [tbox], n=30)
 run("Resample(T, 3h, nearest)", raster.Resample(T, "3h", "nearest"), 2 * 15 * 4 * px, [tbox], n=30)
+run("T * 2 (8 frames)", T * 2, frames * 8 * px, [tbox], n=30)
+run("Clip(T, T > 50) (8 frames)", raster.Clip(T, T > 50), frames * 8 * px, [tbox], n=30)
+run("Snap(A', T) (8 frames of one)", raster.Snap(raster.MemorySource(dt.band_slice(0, 1), np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, 4096.0)), T),
+    frames * 8 * px, [tbox], n=30)
+# requests off the source's grid: the nearest resample at the source, then the program
+zoom_in = [dict(req, bbox=(b[0], b[1], b[0] + side / 2, b[1] + side / 2)) for b in boxes]    # 2x up-sampling
+zoom_out = [dict(req, bbox=(b[0] / 2, b[1] / 2, b[0] / 2 + 2 * side, b[1] / 2 + 2 * side)) for b in boxes]  # 2x down
+shifted = [dict(req, bbox=(b[0] + 0.5, b[1] + 0.5, b[2] + 0.5, b[3] + 0.5)) for b in boxes]   # half a cell off
+run("A + B, 2x zoomed in", A + B, (2 * 5 + 12) * px, zoom_in)
+run("A + B, 2x zoomed out", A + B, (2 * 8 + 12) * px, zoom_out)
+run("A + B, half a cell off", A + B, (2 * 8 + 12) * px, shifted)
+run("HillShade(A), 2x zoomed in", raster.HillShade(A), (5 + 5) * px, zoom_in)
+small = [dict(mode="vals", bbox=(float(i * 256), float(j * 256), float(i * 256 + 256), float(j * 256 + 256)), width=256, height=256,
+              projection="EPSG:28992") for i in range(3) for j in range(3)]
+run("A + B, 256^2 tiles", A + B, 12 * 256 * 256, small, n=900)
+run("Clip(A * 2, B > 50), 256^2", raster.Clip(A * 2, B > 50), 12 * 256 * 256, small, n=900)
+run("HillShade(A), 256^2", raster.HillShade(A), 5 * 256 * 256, small, n=900)
+run("Smooth(A, 2), 256^2", raster.Smooth(A, 2.0), 8 * 256 * 256, small, n=900)

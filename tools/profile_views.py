@@ -39,6 +39,10 @@ views = {"group": (raster.Group(A, B), spatial),
          "resample": (raster.Resample(T, "3h", "nearest"), [tbox]),
          "cumulative": (raster.Cumulative(T), [tbox]),
          "place": (raster.Place(A, "EPSG:28992", (8192.0, 8192.0), [(8192.0, 8192.0), (8292.0, 8092.0)]), spatial)}
+small = [dict(mode="vals", bbox=(float(i * 256), float(j * 256), float(i * 256 + 256), float(j * 256 + 256)), width=256, height=256,
+              projection="EPSG:28992") for i in range(3) for j in range(3)]
+views.update({"hillshade256": (raster.HillShade(A), small), "smooth256": (raster.Smooth(A, 2.0), small),
+              "add256": (A + B, small)})
 for name in sys.argv[1:] or views:
     view, requests = views[name]
     with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": True}):
@@ -47,11 +51,11 @@ for name in sys.argv[1:] or views:
         runtime.sync()
         pr = cProfile.Profile()
         pr.enable()
-        for k in range(40):
+        for k in range(400):
             view.get_data(**requests[k % len(requests)])
         pr.disable()
         runtime.sync()
     out = io.StringIO()
     pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(30)
-    print("=====", name, "(40 requests)")
+    print("=====", name, "(400 requests)")
     print("\n".join(line for line in out.getvalue().splitlines() if line.strip())[:7000])
