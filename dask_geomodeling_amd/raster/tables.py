@@ -99,10 +99,15 @@ def _by_table(dtype):
     return np.dtype(dtype).itemsize == 1
 
 
-def _try_program(node):
-    """Evaluate a single table node as a program; None when it has to run as its own kernel."""
+def _try_program(build, data, key):
+    """Evaluate the single table node ``build(leaf)`` over the tile as a program (the staged plan kept per ``key`` and
+    kind of tile: program.run_expr); None when it has to run as its own kernel."""
     try:
-        values, ndv = P.evaluate(node)
+        hash(key)
+    except TypeError:
+        key = None
+    try:
+        values, ndv = P.run_expr(lambda leaves: build(leaves[0]), [(data["values"], data["no_data_value"])], key)
     except (P.FusionLimit, NotImplementedError):
         return None
     return {"values": values, "no_data_value": ndv}
@@ -115,8 +120,8 @@ def classify_process(data, bins, right):
     runtime.require_device()
     if (_PREFER_PROGRAM or _by_table(data["values"].dtype)) and data["values"].dtype != np.dtype("bool"):
         try:  # few edges: one program step (the same one a fused chain uses)
-            leaf = P.Leaf(None, data["values"].dtype, data["no_data_value"], values=data["values"])
-            hit = _try_program(classify_node(leaf, bins, right))
+            key = ("classify", tuple(P._scalar_key(b) for b in bins), bool(right))
+            hit = _try_program(lambda leaf: classify_node(leaf, bins, right), data, key)
         except P.FusionLimit:
             hit = None
         if hit is not None:
@@ -168,8 +173,9 @@ def reclassify_process(store_data, process_kwargs):
     hit = None
     if _PREFER_PROGRAM or _by_table(in_dtype):
         try:  # dense table: one program step (the same one a fused chain uses)
-            leaf = P.Leaf(None, in_dtype, store_data["no_data_value"], values=store_data["values"])
-            hit = _try_program(reclassify_node(leaf, process_kwargs))
+            key = ("reclassify", str(process_kwargs["dtype"]), P._scalar_key(process_kwargs["fillvalue"]),
+                   bool(process_kwargs["select"]), P._scalar_key(process_kwargs["data"]))
+            hit = _try_program(lambda leaf: reclassify_node(leaf, process_kwargs), store_data, key)
         except P.FusionLimit:
             hit = None
     if hit is not None:

@@ -278,6 +278,10 @@ def _graph_of(block, request, graph, key=None):
     """Add the fused graph of (block, request) to ``graph``; -> its key.  ``key``: a _KeyMaker of (block, request up
     to its bbox) when the caller keeps one."""
     process = type(block).process
+    if request.get("mode") in ("time", "meta"):
+        # time stamps and metadata: no tiles, nothing to fuse -- one task per Block over its sources' graphs, which is
+        # what get_compute_graph builds (a Group asks every source for its time stamps with every request)
+        return _one_level(block, request, graph, key)
     if request.get("mode") == "vals" and "bbox" in request:
         if getattr(process, "gm_tiler", False) and hasattr(block, "store"):
             return _tiler(block, request, graph)

@@ -1,7 +1,8 @@
-"""get_data of mixed views (GPU box): microseconds per 4096^2 tile request on the plan path, next to the time the
+"""get_data of mixed views (GPU box): microseconds per 4096^2 tile request on the plan path (PLANS=0: as a fused graph
+per request through the built-in scheduler -- what a configured dask scheduler gets), next to the time the
 kernels of the view would take at their stand-alone rates (bytes moved / 6 TB/s) -- a view that takes much longer
 than that has a slow seam somewhere (a compaction copy, a one-element-per-lane launch, host time)."""
-import sys, time, numpy as np
+import os, sys, time, numpy as np
 from datetime import datetime, timedelta
 sys.path.insert(0, "/root/repo")
 from dask_geomodeling_amd import raster, config as gmconfig
@@ -40,7 +41,7 @@ req = dict(mode="vals", width=side, height=side, projection="EPSG:28992")
 
 
 def run(name, view, nbytes, requests, n=90):
-    with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": True}):
+    with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": os.environ.get("PLANS", "1") == "1"}):
         try:
             for k in range(9):
                 view.get_data(**requests[k % len(requests)])

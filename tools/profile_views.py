@@ -1,7 +1,8 @@
-"""cProfile of get_data on the plan path for the views tools/e2e_views.py found slow (GPU box):
+"""cProfile of get_data on the plan path (PLANS=0: the graph path) for the views tools/e2e_views.py found slow (GPU box):
     python tools/profile_views.py [group fill max tagg resample cumulative place dilate]"""
 import cProfile
 import io
+import os
 import pstats
 import sys
 from datetime import datetime, timedelta
@@ -41,11 +42,13 @@ views = {"group": (raster.Group(A, B), spatial),
          "place": (raster.Place(A, "EPSG:28992", (8192.0, 8192.0), [(8192.0, 8192.0), (8292.0, 8092.0)]), spatial)}
 small = [dict(mode="vals", bbox=(float(i * 256), float(j * 256), float(i * 256 + 256), float(j * 256 + 256)), width=256, height=256,
               projection="EPSG:28992") for i in range(3) for j in range(3)]
+views.update({"classify_hs": (raster.Classify(raster.HillShade(A), [20, 50, 80, 110, 140, 170, 200, 230]), spatial),
+              "mask_dilate": (raster.Mask(raster.Dilate(C, [3, 5]), 1), spatial)})
 views.update({"hillshade256": (raster.HillShade(A), small), "smooth256": (raster.Smooth(A, 2.0), small),
               "add256": (A + B, small)})
 for name in sys.argv[1:] or views:
     view, requests = views[name]
-    with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": True}):
+    with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": os.environ.get("PLANS", "1") == "1"}):
         for k in range(5):
             view.get_data(**requests[k % len(requests)])
         runtime.sync()
