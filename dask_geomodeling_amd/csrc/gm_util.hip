@@ -95,6 +95,25 @@ __global__ __launch_bounds__(256) void paste_kernel(T* mosaic, int H, int W, con
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < tw; c += gridDim.x * blockDim.x) dst[c] = src[c];
 }
 
+// All tiles of a mosaic in one launch (grid.z = tile): a RasterTiler over a store with a kernel of its own pastes
+// 16 ... 256 tiles per request, and a launch per tile was a quarter of the time of a 16-tile HillShade mosaic.
+constexpr int PASTE_BATCH = 64;
+struct PasteBatch {
+  const void* tile[PASTE_BATCH];
+  int th[PASTE_BATCH], tw[PASTE_BATCH], row0[PASTE_BATCH], col0[PASTE_BATCH];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void paste_batch_kernel(T* mosaic, int H, int W, PasteBatch B, int bands) {
+  const int t = blockIdx.z;
+  const int th = B.th[t], tw = B.tw[t];
+  const int br = (int)blockIdx.y;
+  if (br >= bands * th) return;
+  const int band = br / th, r = br % th;
+  const T* src = (const T*)B.tile[t] + ((size_t)band * th + r) * tw;
+  T* dst = mosaic + ((size_t)band * H + (B.row0[t] + r)) * W + B.col0[t];
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < tw; c += gridDim.x * blockDim.x) dst[c] = src[c];
+}
+
 unsigned grid_for(size_t n, int cus) {
   size_t blocks = (n + 255) / 256;
   size_t cap = (size_t)(cus > 0 ? cus : 256) * 8;
@@ -303,6 +322,59 @@ int gm_paste_tile(void* mosaic, int H, int W, const void* tile, int bands, int t
       default: return gm::fail(GM_ERR_INVALID, "gm_paste_tile: itemsize %d", itemsize);
     }
 #undef GM_PASTE
+    GM_HIP(hipGetLastError());
+  }
+  return GM_OK;
+}
+
+int gm_paste_tiles(void* mosaic, int H, int W, int n_tiles, const void* const* tiles, const int* th, const int* tw,
+                   const int* row0, const int* col0, int bands, int itemsize) {
+  if (!mosaic || (n_tiles && (!tiles || !th || !tw || !row0 || !col0))) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (n_tiles <= 0 || bands <= 0) return GM_OK;
+  if (itemsize != 1 && itemsize != 2 && itemsize != 4 && itemsize != 8) return gm::fail(GM_ERR_INVALID, "gm_paste_tiles: itemsize %d", itemsize);
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  // as in gm_paste_tile: rows that are whole 16-byte groups on both sides move as 16-byte words
+  bool words = ((uintptr_t)mosaic % 16) == 0 && ((long long)W * itemsize) % 16 == 0;
+  long long most_rows = 0;
+  for (int t = 0; t < n_tiles; ++t) {
+    if (!tiles[t]) return gm::fail(GM_ERR_INVALID, "gm_paste_tiles: tile %d is null", t);
+    if (th[t] <= 0 || tw[t] <= 0 || row0[t] < 0 || col0[t] < 0 || row0[t] + th[t] > H || col0[t] + tw[t] > W)
+      return gm::fail(GM_ERR_INVALID, "gm_paste_tiles: tile %d (%d,%d)+(%d,%d) outside mosaic (%d,%d)", t, row0[t], col0[t], th[t], tw[t], H, W);
+    words = words && ((uintptr_t)tiles[t] % 16) == 0 && ((long long)tw[t] * itemsize) % 16 == 0 && ((long long)col0[t] * itemsize) % 16 == 0;
+    if ((long long)bands * th[t] > most_rows) most_rows = (long long)bands * th[t];
+  }
+  if (most_rows > 65535) {  // (grid.y): tile by tile
+    for (int t = 0; t < n_tiles; ++t) {
+      int rc = gm_paste_tile(mosaic, H, W, tiles[t], bands, th[t], tw[t], row0[t], col0[t], itemsize);
+      if (rc) return rc;
+    }
+    return GM_OK;
+  }
+  const int scale = words ? 16 / itemsize : 1;  // elements per moved word
+  for (int t0 = 0; t0 < n_tiles; t0 += PASTE_BATCH) {
+    const int nb = n_tiles - t0 < PASTE_BATCH ? n_tiles - t0 : PASTE_BATCH;
+    PasteBatch B;
+    memset(&B, 0, sizeof(B));
+    int widest = 1;
+    for (int i = 0; i < nb; ++i) {
+      B.tile[i] = tiles[t0 + i];
+      B.th[i] = th[t0 + i];
+      B.tw[i] = tw[t0 + i] / scale;
+      B.row0[i] = row0[t0 + i];
+      B.col0[i] = col0[t0 + i] / scale;
+      if (B.tw[i] > widest) widest = B.tw[i];
+    }
+    unsigned gx = (unsigned)((widest + 255) / 256);
+    if (gx > 64) gx = 64;
+    dim3 grid(gx, (unsigned)most_rows, (unsigned)nb);
+#define GM_PASTEB(T) hipLaunchKernelGGL(paste_batch_kernel<T>, grid, dim3(256), 0, s, (T*)mosaic, H, W / scale, B, bands)
+    if (words) GM_PASTEB(Word16);
+    else if (itemsize == 1) GM_PASTEB(unsigned char);
+    else if (itemsize == 2) GM_PASTEB(unsigned short);
+    else if (itemsize == 4) GM_PASTEB(unsigned int);
+    else GM_PASTEB(unsigned long long);
+#undef GM_PASTEB
     GM_HIP(hipGetLastError());
   }
   return GM_OK;

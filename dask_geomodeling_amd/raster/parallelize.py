@@ -78,24 +78,47 @@ class RasterTiler(BaseSingle):
         fill = process_kwargs["fillvalue"]
         mosaic = DeviceArray.empty((bands, height, width), dtype)
         L = runtime.lib()
-        # (a boolean view has no fill value: np.full(shape, None, dtype=bool) of the reference is all False)
-        runtime.check(L.gm_fill(ctypes.c_void_p(mosaic.ptr), code_of(dtype),
-                                runtime.scalar_bits(False if fill is None else fill, dtype),
-                                mosaic.size), "gm_fill")
         count_x, count_y = process_kwargs["count_xy"]
         tile_x, tile_y = process_kwargs["tilesize_xy"]
+        # np.full(shape, fill) of the reference (parallelize.py:108-112) -- skipped when the tiles, which sit in disjoint
+        # slots, cover every cell of the mosaic between them (a pass over the whole result that nothing would read:
+        # 170 us for a 16384^2 float32 mosaic); a tile that is None or short of its slot leaves fill values behind
+        covered = 0
+        for (ix, iy), data in zip(product(range(count_x), range(count_y)), all_data):
+            if data is not None and len(data["values"].shape) == 3 and data["values"].shape[0] == bands:
+                _, th, tw = data["values"].shape
+                if height - (iy * tile_y + th) >= 0 and ix * tile_x + tw <= width and th <= tile_y and tw <= tile_x:
+                    covered += th * tw
+        if covered != height * width or len(all_data) != count_x * count_y:
+            # (a boolean view has no fill value: np.full(shape, None, dtype=bool) of the reference is all False)
+            runtime.check(L.gm_fill(ctypes.c_void_p(mosaic.ptr), code_of(dtype),
+                                    runtime.scalar_bits(False if fill is None else fill, dtype),
+                                    mosaic.size), "gm_fill")
+        tiles, th_, tw_, row_, col_ = [], [], [], [], []
         for (ix, iy), data in zip(product(range(count_x), range(count_y)), all_data):
             if data is None:
                 continue
             tile = as_device(data["values"])
             if tile.dtype != dtype:
                 raise TypeError("tile dtype %s does not match the tiler's %s" % (tile.dtype, dtype))
+            if tile.shape[0] != bands:
+                raise ValueError("tile of %d bands in a mosaic of %d" % (tile.shape[0], bands))
             _, th, tw = tile.shape
-            # low y maps to high row index (parallelize.py:114-124)
-            row0 = height - (iy * tile_y + th)
-            col0 = ix * tile_x
-            runtime.check(L.gm_paste_tile(ctypes.c_void_p(mosaic.ptr), height, width, ctypes.c_void_p(tile.ptr),
-                                          bands, th, tw, row0, col0, dtype.itemsize), "gm_paste_tile")
+            tiles.append(tile)
+            th_.append(th)
+            tw_.append(tw)
+            row_.append(height - (iy * tile_y + th))  # low y maps to high row index (parallelize.py:114-124)
+            col_.append(ix * tile_x)
+        if tiles:
+            n = len(tiles)
+            ints = ctypes.c_int * n
+            L.gm_paste_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_int]
+            L.gm_paste_tiles.restype = ctypes.c_int
+            runtime.check(L.gm_paste_tiles(ctypes.c_void_p(mosaic.ptr), height, width, n,
+                                           (ctypes.c_void_p * n)(*[t.ptr for t in tiles]), ints(*th_), ints(*tw_),
+                                           ints(*row_), ints(*col_), bands, dtype.itemsize), "gm_paste_tiles")
         return {"values": mosaic, "no_data_value": fill}
 
     process.__func__.gm_tiler = True  # lets the fusion pass write batched tiles straight into the mosaic

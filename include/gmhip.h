@@ -580,6 +580,10 @@ int gm_checksum(const void* in, size_t bytes, uint64_t* result);
  * of RasterTiler.process (raster/parallelize.py:118-124). itemsize in bytes. */
 int gm_paste_tile(void* mosaic, int H, int W, const void* tile, int bands, int th, int tw,
                   int row0, int col0, int itemsize);
+/* The same for all tiles of a mosaic in one launch (RasterTiler.process, parallelize.py:113-124): tile t of th[t] x tw[t]
+ * cells per band goes to rows row0[t] .., columns col0[t] .. of every band of the mosaic (host arrays of n_tiles). */
+int gm_paste_tiles(void* mosaic, int H, int W, int n_tiles, const void* const* tiles, const int* th, const int* tw,
+                   const int* row0, const int* col0, int bands, int itemsize);
 
 #ifdef __cplusplus
 }

@@ -41,7 +41,7 @@ views = {"group": (raster.Group(A, B), spatial),
          "cumulative": (raster.Cumulative(T), [tbox]),
          "place": (raster.Place(A, "EPSG:28992", (8192.0, 8192.0), [(8192.0, 8192.0), (8292.0, 8092.0)]), spatial)}
 small = [dict(mode="vals", bbox=(float(i * 256), float(j * 256), float(i * 256 + 256), float(j * 256 + 256)), width=256, height=256,
-              projection="EPSG:28992") for i in range(3) for j in range(3)]
+              projection="EPSG:28992") for i in range(1, 4) for j in range(1, 4)]
 views.update({"classify_hs": (raster.Classify(raster.HillShade(A), [20, 50, 80, 110, 140, 170, 200, 230]), spatial),
               "mask_dilate": (raster.Mask(raster.Dilate(C, [3, 5]), 1), spatial)})
 views.update({"hillshade256": (raster.HillShade(A), small), "smooth256": (raster.Smooth(A, 2.0), small),
