@@ -63,7 +63,7 @@ struct DeviceState {
 // 530.9 k: what it buys is mostly that the run-to-run spread of the address lottery goes away.  Steps of 256 B ..
 // 4 KiB were no better or worse (a tiled chain over 64 KiB row pitches lost 2-4 % at 512 B and 4 KiB).
 // GM_ALLOC_STAGGER = bytes per step (0 switches it off; a multiple of 256).
-constexpr size_t kStaggerFrom = 1u << 20;
+constexpr size_t kStaggerFrom = 16u << 20;  // (the runtime hands out 2 MiB granules: below 16 MiB the extra granule would cost > 12 %)
 constexpr unsigned kStaggerTurns = 16;
 static size_t stagger_step() {
   static const size_t step = []() -> size_t {

@@ -106,6 +106,9 @@ class FusionLimit(Exception):
 # NumPy-exact scalar handling
 # ----------------------------------------------------------------------------
 
+_EFFECTIVE_NDV = {}  # (dtype, what the no-data value is) -> effective_ndv: asked with every stencil / plan call
+
+
 def effective_ndv(dtype, ndv):
     """The value v (of ``dtype``) with ``tile == ndv``  <=>  ``tile == v``, or None if no
     element of a ``dtype`` tile can ever compare equal to ``ndv``.  NumPy itself decides
@@ -113,6 +116,22 @@ def effective_ndv(dtype, ndv):
     if ndv is None:
         return None
     dtype = np.dtype(dtype)
+    try:
+        key = (dtype.num, _scalar_key(ndv))
+        hit = _EFFECTIVE_NDV.get(key, _EFFECTIVE_NDV)
+    except TypeError:
+        key, hit = None, _EFFECTIVE_NDV
+    if hit is not _EFFECTIVE_NDV:
+        return hit
+    value = _effective_ndv(dtype, ndv)
+    if key is not None:
+        if len(_EFFECTIVE_NDV) > 1024:
+            _EFFECTIVE_NDV.clear()
+        _EFFECTIVE_NDV[key] = value
+    return value
+
+
+def _effective_ndv(dtype, ndv):
     with np.errstate(all="ignore"):
         try:
             cand = np.array(ndv).astype(dtype)

@@ -46,6 +46,9 @@ views.update({"classify_hs": (raster.Classify(raster.HillShade(A), [20, 50, 80, 
               "mask_dilate": (raster.Mask(raster.Dilate(C, [3, 5]), 1), spatial)})
 views.update({"hillshade256": (raster.HillShade(A), small), "smooth256": (raster.Smooth(A, 2.0), small),
               "add256": (A + B, small)})
+whole = [dict(mode="vals", bbox=(64.0, 64.0, 64.0 + 16256, 64.0 + 16256), width=16256, height=16256, projection="EPSG:28992")]
+views.update({"tiler_hs_mix": (raster.RasterTiler(raster.HillShade(A) * 0.5 + B, 4064), whole),
+              "tiler_hs": (raster.RasterTiler(raster.HillShade(A), 4064), whole)})
 for name in sys.argv[1:] or views:
     view, requests = views[name]
     with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": os.environ.get("PLANS", "1") == "1"}):
@@ -54,7 +57,7 @@ for name in sys.argv[1:] or views:
         runtime.sync()
         pr = cProfile.Profile()
         pr.enable()
-        for k in range(400):
+        for k in range(40 if len(requests) == 1 else 400):
             view.get_data(**requests[k % len(requests)])
         pr.disable()
         runtime.sync()
