@@ -651,6 +651,55 @@ def test_place_attributes_and_planning():
     assert plan[0][0]["mode"] == "group" and plan[1][1]["bbox"] == [135005, 455915, 135005, 455915]
 
 
+def test_calendar_answers_are_remembered_and_handed_out_as_copies():
+    from datetime import datetime
+    from dask_geomodeling_amd.raster import temporal
+    calendar = temporal._Calendar("h", None, None, "UTC")
+    first = calendar.label_range(datetime(2020, 1, 1), datetime(2020, 1, 1, 3))
+    assert first == [datetime(2020, 1, 1, k) for k in range(4)]
+    first.append("tampered")  # (a caller that changes its list must not change the next caller's)
+    again = temporal._Calendar("h", None, None, "UTC").label_range(datetime(2020, 1, 1), datetime(2020, 1, 1, 3))
+    assert again == [datetime(2020, 1, 1, k) for k in range(4)]
+    other = temporal._Calendar("h", None, None, "Europe/Amsterdam")
+    assert other.label_of(datetime(2020, 1, 1, 0, 30)) == calendar.label_of(datetime(2020, 1, 1, 0, 30))
+    daily = temporal._Calendar("D", None, None, "Europe/Amsterdam")
+    assert daily.label_of(datetime(2020, 1, 1, 0, 30)) != temporal._Calendar("D", None, None, "UTC").label_of(datetime(2020, 1, 1, 0, 30))
+    times = [datetime(2020, 1, 1, k) for k in range(6)]
+    labels, local = temporal._Calendar("3h", "left", "left", "UTC").labels_between(times[0], times[-1])
+    runs = temporal._Calendar("3h", "left", "left", "UTC").frames_of(times, local)
+    assert runs == [(0, 3), (3, 3)] and temporal._Calendar("3h", "left", "left", "UTC").frames_of(list(times), local) == runs
+
+
+def test_stand_alone_bodies_keep_their_plan_but_not_their_tiles(cpu_vm):
+    """program.run_expr(build, tiles, key): the staged plan is kept per kind of tiles -- the second call must compute on
+    ITS tiles, another literal / no-data value / dtype must not hit the first plan, and a NaN literal is a key too."""
+    from dask_geomodeling_amd.hip import program as P
+    from dask_geomodeling_amd.raster import devops
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(5)
+    kw = {"dtype": "float32", "fillvalue": float(np.finfo("f4").max)}
+    ndv = np.float32(-1.0)
+    before = len(P._EXPR_PLANS)
+    for round_ in range(3):
+        a = (rng.random((1, 6, 9)) * 10).astype("f4")
+        a[0, 0, round_] = ndv
+        for literal in (2.5, 3.5, float("nan")):
+            got = devops.math_process("add", kw, {"values": a, "no_data_value": ndv}, literal)
+            want = O.math_process("add", kw, {"values": a, "no_data_value": ndv}, literal)
+            assert_result_equal(got, want, 0, "add %r round %d" % (literal, round_))
+        other_ndv = {"values": a, "no_data_value": np.float32(7.0)}
+        assert_result_equal(devops.math_process("add", kw, other_ndv, 2.5), O.math_process("add", kw, other_ndv, 2.5), 0, "ndv")
+        b = (rng.random((1, 6, 9)) * 10).astype("f8")
+        kw8 = {"dtype": "float64", "fillvalue": float(np.finfo("f8").max)}
+        assert_result_equal(devops.math_process("add", kw8, {"values": b, "no_data_value": -1.0}, 2.5),
+                            O.math_process("add", kw8, {"values": b, "no_data_value": -1.0}, 2.5), 0, "f8")
+        filled = devops.fillnodata_process(kw, {"values": a, "no_data_value": ndv}, {"values": a[:, ::-1].copy(), "no_data_value": ndv})
+        assert_result_equal(filled, O.fillnodata_process(kw, {"values": a, "no_data_value": ndv},
+                                                         {"values": a[:, ::-1].copy(), "no_data_value": ndv}), 0, "fill")
+    made = len(P._EXPR_PLANS) - before
+    assert 1 <= made <= 6  # (3 literals + another ndv + float64 + fillnodata: one plan each, however often they ran)
+
+
 def test_round4_construction_errors():
     from datetime import timedelta
     from blocks_util import TemporalLeaf

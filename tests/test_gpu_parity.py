@@ -355,6 +355,49 @@ def test_tiler_process_golden(gpu, case):
     assert_result_equal(out, case["expect"], 0, case["id"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["u1", "i2", "f4", "f8"])
+def test_tiler_process_fill_and_batched_paste(gpu, dtype):
+    """RasterTiler.process (parallelize.py:93-125) with the tiles of a mosaic pasted in one launch and the fill skipped
+    exactly when the tiles cover the mosaic: full coverage, a tile that is None, tiles short of their slot (the fill
+    value has to show there), several bands, widths that are / are not whole 16-byte groups -- against the oracle."""
+    rng = np.random.default_rng(abs(hash(dtype)) % 2**31)
+    dt = np.dtype(dtype)
+    fill = O.get_dtype_max(dt)
+
+    def tile(bands, th, tw):
+        v = (rng.random((bands, th, tw)) * 100).astype(dt)
+        return {"values": v, "no_data_value": fill}
+
+    cases = []
+    for bands, (count_x, count_y), (tx, ty), (height, width), holes, short in (
+            (1, (2, 2), (32, 16), (32, 64), (), ()),               # full coverage: no fill
+            (1, (2, 2), (32, 16), (32, 64), ((1, 0),), ()),        # one tile missing
+            (2, (3, 2), (16, 8), (16, 48), (), ()),                # two bands, full
+            (1, (2, 2), (33, 17), (34, 66), (), ()),               # odd sizes (no 16-byte groups), full
+            (1, (2, 3), (20, 10), (28, 37), (), ()),               # ragged last column / top row of tiles
+            (1, (2, 2), (32, 16), (32, 64), (), ((0, 1),)),        # a tile one row and one column short of its slot
+            (3, (1, 1), (8, 8), (8, 8), (), ())):
+        kw = {"shape_yx": (height, width), "count_xy": (count_x, count_y), "tilesize_xy": (tx, ty), "dtype": dt, "fillvalue": fill}
+        tiles = []
+        for ix in range(count_x):
+            for iy in range(count_y):
+                if (ix, iy) in holes:
+                    tiles.append(None)
+                    continue
+                tw = min(tx, width - ix * tx)
+                th = min(ty, height - iy * ty)
+                if (ix, iy) in short:
+                    tw, th = tw - 1, th - 1
+                tiles.append(tile(bands, th, tw))
+        cases.append((kw, tiles))
+    for kw, tiles in cases:
+        want = O.tiler_process(dict(kw, dtype=dt.str), *tiles)
+        got = raster.RasterTiler.process(kw, *tiles)
+        assert_result_equal(dict(got, values=np.asarray(got["values"])), want, 0, "%s %s" % (dtype, kw["count_xy"]))
+    assert raster.RasterTiler.process(cases[0][0], None, None, None, None) is None
+
+
 @pytest.fixture
 def kat_source():
     from datetime import datetime, timedelta
