@@ -343,6 +343,37 @@ def end_to_end(raster, runtime, side, budget_s=6.0):
                                   "geomodeling.templates": templates}):
             v, us, n = rate(lambda: tiler.get_data(**whole), big * big, 4, share * 0.75)
         out["tiler_get_data_device_" + label] = {"Mpix/s": v, "us_per_request": us, "requests": n, "tiles": 16}
+    # mixed views (round 4; tools/e2e_views.py is the long form): microseconds per request of the inner boxes on the plan
+    # path next to the bytes the view's kernels move / 6 TB/s -- a view far above that has a slow seam
+    from datetime import datetime, timedelta
+    frames = 8
+    dt = generate_window((frames * side, side), "f4", 7003, 0.0, 100.0, F32MAX, LATTICE, 0, 0, frames * side, side)
+    T = raster.MemorySource(dt.reshape((frames, side, side)), ndv, "EPSG:28992", 1.0, (0.0, float(side)),
+                            time_first=datetime(2020, 1, 1), time_delta=timedelta(hours=6))
+    days = dict(req, bbox=(0.0, 0.0, float(side), float(side)), start=datetime(2020, 1, 1), stop=datetime(2020, 1, 3))
+    px = (side - 128) ** 2
+    mixed = [("HillShade(A + B) * 0.5", raster.HillShade(A + B) * 0.5, None, (12 + 5 + 5) * px),
+             ("FillNoData(A, B)", raster.FillNoData(A, B), None, 12 * px),
+             ("Group(A, B)", raster.Group(A, B), None, 12 * px),
+             ("Max(A, B, A * 2)", raster.Max(A, B, A * 2), None, 12 * px),
+             ("TemporalAggregate(T, 'D', 'mean'), 8 frames", raster.TemporalAggregate(T, "D", "mean"), days, (frames + 2) * 4 * side * side),
+             ("Resample(T, '3h', 'nearest'), 8 -> 17 frames", raster.Resample(T, "3h", "nearest"), days, 2 * 17 * 4 * side * side)]
+    views = {}
+    from dask_geomodeling_amd.hip import program as P
+    for label, mixed_view, fixed, nbytes in mixed:
+        def one_mixed():
+            state["k"] += 1
+            if fixed is not None:
+                return mixed_view.get_data(**fixed)
+            return mixed_view.get_data(bbox=inner[state["k"] % 16], **shade_req)
+        with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": True}):
+            for _ in range(4):
+                one_mixed()
+            if P.spec_pending():
+                P.spec_wait()
+            _, us, n = rate(one_mixed, px, 16, 0.04)
+        views[label] = {"us_per_request": us, "kernels_at_6TBps_us": round(nbytes / 6e6, 1), "requests": n}
+    out["views"] = views
     return out
 
 
