@@ -868,9 +868,20 @@ constexpr int HP_H = 8, HP_W = 512;
 // T: float, or an integer type of up to 4 bytes (USE_INV only): the Sobel sums of integers run in 32-bit modular
 // arithmetic per pixel (NumPy's wrap-around), and float(s) * inv is the float32 the reference's float64 route gives for
 // a power-of-two resolution (see gradient()); everything after the gradient is the same packed float32 arithmetic.
-template <typename T, bool USE_INV>
+// BATCH: the tiles of one mosaic in one launch (blockIdx.z = tile, one band each): per-tile input pointer / pitch and
+// output pointer / pitch -- the shades are written straight into their windows of the mosaic (round 4: a RasterTiler
+// over HillShade launched and pasted its tiles one by one, ~35 us of host time each against 23 us of kernel).
+constexpr int HS_BATCH = 64;
+struct HillBatch {
+  const void* in[HS_BATCH];
+  unsigned char* out[HS_BATCH];
+  int in_pitch[HS_BATCH], out_pitch[HS_BATCH];
+};
+struct NoBatch {};
+template <typename T, bool USE_INV, bool BATCH = false>
 __global__ __launch_bounds__(256) void hillshade_pair_kernel(const T* __restrict__ in, unsigned char* __restrict__ out,
-                                                             int h, int w, int pitch, int has_ndv, T ndv, T fill, HillArgs A) {
+                                                             int h, int w, int pitch, int has_ndv, T ndv, T fill, HillArgs A,
+                                                             typename std::conditional<BATCH, HillBatch, NoBatch>::type B = {}) {
   static_assert(std::is_same<T, float>::value || (std::is_integral<T>::value && sizeof(T) <= 4 && USE_INV), "see above");
   constexpr int PITCH = HP_W + 2;
   __shared__ __align__(16) T tile[(HP_H + 2) * PITCH];
@@ -883,6 +894,14 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const T* __restrict
   const int c0 = blockIdx.x * HP_W, r0 = blockIdx.y * HP_H, b = blockIdx.z;
   const int ow = w - 2, oh = h - 2;
   const T* plane = in + (size_t)b * h * w;
+  unsigned char* oplane = out + (size_t)b * oh * ow;
+  int opitch = ow;
+  if constexpr (BATCH) {
+    plane = (const T*)B.in[b];
+    pitch = B.in_pitch[b];
+    oplane = B.out[b];
+    opitch = B.out_pitch[b];
+  }
   auto clean = [&](T v) -> T { return (has_ndv && v == ndv) ? fill : v; };  // spatial.py:363-364
   {
     // a lane stages columns t and t + 256 of the window, lanes 0..35 the two columns east of the 512
@@ -1019,7 +1038,7 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const T* __restrict
     const int row = chunk / (HP_W / 16), part = chunk % (HP_W / 16);
     const int orow = r0 + row, ocol = c0 + 16 * part;
     if (orow < oh && ocol < ow) {
-      unsigned char* dst = out + ((size_t)b * oh + orow) * ow + ocol;
+      unsigned char* dst = oplane + (size_t)orow * opitch + ocol;
       const unsigned char* srcb = shade + row * HP_W + 16 * part;
       if (ocol + 16 <= ow && (((uintptr_t)dst) & 15) == 0) {
         __builtin_nontemporal_store(*(const u32x4*)srcb, (u32x4*)dst);
@@ -1603,21 +1622,8 @@ int gm_gauss_2d_window(const void* in, int dtype, int bands, int h, int w, int i
   return GM_OK;
 }
 
-int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv, uint64_t ndv_bits, uint64_t fill_bits,
-                 double xres, double yres, double altitude_deg, double azimuth_deg, void* out) {
-  return gm_hillshade_window(in, dtype, bands, h, w, w, has_ndv, ndv_bits, fill_bits, xres, yres, altitude_deg, azimuth_deg, out);
-}
-
-int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, int has_ndv, uint64_t ndv_bits,
-                        uint64_t fill_bits, double xres, double yres, double altitude_deg, double azimuth_deg, void* out) {
-  if (!in || !out) return gm::fail(GM_ERR_INVALID, "null pointer");
-  if (in_pitch < w) return gm::fail(GM_ERR_INVALID, "gm_hillshade: pitch %d of a %d-wide tile", in_pitch, w);
-  const bool window = in_pitch != w;
-  if (window && bands != 1) return gm::fail(GM_ERR_UNSUPPORTED, "gm_hillshade: a window of %d bands", bands);
-  if (bands <= 0 || h < 3 || w < 3) return gm::fail(GM_ERR_INVALID, "gm_hillshade: tile %dx%dx%d has no interior", bands, h, w);
-  if (bands > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_hillshade: too many bands");
-  hipStream_t s = gm::current_stream();
-  if (!s) return GM_ERR_NO_DEVICE;
+// the scalars of spatial.py:370-383 as the kernels take them
+static HillArgs hill_args(double xres, double yres, double altitude_deg, double azimuth_deg) {
   const double pi = 3.141592653589793;
   const double alt = altitude_deg * (pi / 180.0), az = azimuth_deg * (pi / 180.0);  // math.radians
   const double zsf = 1.0 / 8.0;
@@ -1643,6 +1649,25 @@ int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int 
   A.cos_az = (float)cos(az);
   A.sin_az = (float)sin(az);
   A.az32 = (float)az;
+  return A;
+}
+
+int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv, uint64_t ndv_bits, uint64_t fill_bits,
+                 double xres, double yres, double altitude_deg, double azimuth_deg, void* out) {
+  return gm_hillshade_window(in, dtype, bands, h, w, w, has_ndv, ndv_bits, fill_bits, xres, yres, altitude_deg, azimuth_deg, out);
+}
+
+int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, int has_ndv, uint64_t ndv_bits,
+                        uint64_t fill_bits, double xres, double yres, double altitude_deg, double azimuth_deg, void* out) {
+  if (!in || !out) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (in_pitch < w) return gm::fail(GM_ERR_INVALID, "gm_hillshade: pitch %d of a %d-wide tile", in_pitch, w);
+  const bool window = in_pitch != w;
+  if (window && bands != 1) return gm::fail(GM_ERR_UNSUPPORTED, "gm_hillshade: a window of %d bands", bands);
+  if (bands <= 0 || h < 3 || w < 3) return gm::fail(GM_ERR_INVALID, "gm_hillshade: tile %dx%dx%d has no interior", bands, h, w);
+  if (bands > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_hillshade: too many bands");
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  const HillArgs A = hill_args(xres, yres, altitude_deg, azimuth_deg);
   dim3 grid((unsigned)((w - 2 + 255) / 256), (unsigned)((h - 2 + ST_ROWS - 1) / ST_ROWS), (unsigned)bands);
   dim3 tgrid((unsigned)((w - 2 + HT_W - 1) / HT_W), (unsigned)((h - 2 + HT_H - 1) / HT_H), (unsigned)bands);
   const bool tiled = gm::dtype_size(dtype) <= 4 && tgrid.y <= 65535;  // (8-byte tiles: the window would not fit LDS twice)
@@ -1704,6 +1729,55 @@ int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int 
   }
 #undef GM_HS
   GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+int gm_hillshade_batch(int n_tiles, const void* const* in, int dtype, int h, int w, const int* in_pitch, int has_ndv,
+                       uint64_t ndv_bits, uint64_t fill_bits, double xres, double yres, double altitude_deg, double azimuth_deg,
+                       void* const* out, const int* out_pitch) {
+  if (n_tiles < 0 || (n_tiles && (!in || !in_pitch || !out || !out_pitch))) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (n_tiles == 0) return GM_OK;
+  if (h < 3 || w < 3) return gm::fail(GM_ERR_INVALID, "gm_hillshade_batch: tiles of %dx%d have no interior", h, w);
+  for (int t = 0; t < n_tiles; ++t) {
+    if (!in[t] || !out[t]) return gm::fail(GM_ERR_INVALID, "gm_hillshade_batch: tile %d is null", t);
+    if (in_pitch[t] < w || out_pitch[t] < w - 2) return gm::fail(GM_ERR_INVALID, "gm_hillshade_batch: pitch of tile %d", t);
+  }
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  const HillArgs A = hill_args(xres, yres, altitude_deg, azimuth_deg);
+  // the pair kernel's routes only (float32 tiles; integer tiles of up to 4 bytes at power-of-two resolutions): anything else
+  // is for the caller to run tile by tile
+  const bool pow2 = A.xinv32 != 0.0f && A.yinv32 != 0.0f;
+  const bool ints = pow2 && gm::dtype_size(dtype) <= 4 && !gm::dtype_is_float(dtype) && dtype != GM_BOOL &&
+                    fabsf(A.xinv32) < 0x1p64f && fabsf(A.xinv32) > 0x1p-64f && fabsf(A.yinv32) < 0x1p64f && fabsf(A.yinv32) > 0x1p-64f;
+  if ((dtype != GM_F32 && !ints) || getenv("GM_HS_SINGLE") || (h - 2 + HP_H - 1) / HP_H > 65535)
+    return gm::fail(GM_ERR_UNSUPPORTED, "gm_hillshade_batch: dtype %d at this resolution runs tile by tile", dtype);
+  for (int t0 = 0; t0 < n_tiles; t0 += HS_BATCH) {
+    const int nb = n_tiles - t0 < HS_BATCH ? n_tiles - t0 : HS_BATCH;
+    HillBatch B;
+    memset(&B, 0, sizeof(B));
+    for (int i = 0; i < nb; ++i) {
+      B.in[i] = in[t0 + i];
+      B.out[i] = (unsigned char*)out[t0 + i];
+      B.in_pitch[i] = in_pitch[t0 + i];
+      B.out_pitch[i] = out_pitch[t0 + i];
+    }
+    dim3 pgrid((unsigned)((w - 2 + HP_W - 1) / HP_W), (unsigned)((h - 2 + HP_H - 1) / HP_H), (unsigned)nb);
+#define GM_HPB(T, INV)                                                                                               \
+  hipLaunchKernelGGL((hillshade_pair_kernel<T, INV, true>), pgrid, dim3(256), 0, s, (const T*)nullptr,              \
+                     (unsigned char*)nullptr, h, w, w, has_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A, B)
+    switch (dtype) {
+      case GM_F32: if (pow2) GM_HPB(float, true); else GM_HPB(float, false); break;
+      case GM_U8: GM_HPB(unsigned char, true); break;
+      case GM_I8: GM_HPB(signed char, true); break;
+      case GM_U16: GM_HPB(unsigned short, true); break;
+      case GM_I16: GM_HPB(short, true); break;
+      case GM_U32: GM_HPB(unsigned int, true); break;
+      default: GM_HPB(int, true); break;
+    }
+#undef GM_HPB
+    GM_HIP(hipGetLastError());
+  }
   return GM_OK;
 }
 

@@ -21,6 +21,8 @@ ordinary graph path, as does a request whose plan cannot be built.
 
 import threading
 
+import numpy as np
+
 from . import config as _config
 from .core.graphs import Block, _request_token
 
@@ -184,7 +186,15 @@ def _run_tiler(tiler, request):
         plan = view_plan(store, tile_request)
         if plan is None or not isinstance(plan.task, FusedTask):
             # no program to batch (a store with a kernel of its own, a single unfusable operation): tile by tile
-            # through whatever plan the store has, assembled by the Block's own process
+            # through whatever plan the store has, assembled by the Block's own process -- unless the Block takes
+            # the tiles of a mosaic in one launch and writes them in place (gm_batch: HillShade)
+            # (only straight over a resident source, whose tiles are zero-copy windows: over a computed store the
+            #  one-by-one order is the better one -- every intermediate tile is read back while the Infinity Cache still
+            #  holds it, 1.04 ms against 1.64 for a 16-tile HillShade(A * 2 + B) mosaic)
+            if _batches_tiles(store):
+                done = _run_tiler_batch(tiler, store, kwargs, pairs[1:])
+                if done is not None:
+                    return True, done
             responses = []
             outer = getattr(_running, "memo", None)
             try:
@@ -208,14 +218,93 @@ def _run_tiler(tiler, request):
     outer = getattr(_running, "memo", None)
     try:
         for plan, boxes in zip(batches, members):
-            for bbox in boxes:
-                _running.memo = {}  # (a memo per tile: what the leaves of one tile evaluate underneath must not pile up)
-                leaf_values.extend(plan.leaf_values(bbox))
+            leaf_values.extend(_leaf_values_of_tiles(plan, boxes))
             tasks.append(BatchedTask([plan.task] * len(boxes)))
     finally:
         _running.memo = outer
     assembly = TiledAssembly(type(tiler).process, layout, tasks)
     return True, assembly(kwargs, *leaf_values)
+
+
+def _batches_tiles(block):
+    """A Block that takes the tiles of a mosaic in one launch (gm_batch), straight over a resident source."""
+    return (getattr(block, "gm_direct", False) and hasattr(type(block), "gm_batch") and
+            hasattr(getattr(block, "store", None), "gm_plan_response"))
+
+
+def _process_arguments(block, request):
+    """What ``_direct`` hands to ``block.process`` for one request."""
+    return tuple(_child(source, sub) if isinstance(source, Block) and sub is not None else source
+                 for source, sub in block.get_sources_and_requests(**request))
+
+
+def _leaf_values_of_tiles(plan, boxes):
+    """ViewPlan.leaf_values for all tiles of a mosaic -> [leaf values of tile 0 ..., of tile 1 ...]: leaves that take the
+    tiles of a mosaic in one launch (a HillShade under an element-wise view under a RasterTiler) are evaluated once for
+    all tiles, the others tile by tile."""
+    columns = []
+    for block, request in plan.leaves:
+        requests = [dict(request, bbox=bbox) for bbox in boxes]
+        column = None
+        if len(boxes) > 1 and _batches_tiles(block):
+            calls = []
+            for tile_request in requests:
+                _running.memo = {}  # (a memo per tile: what the leaves of one tile evaluate underneath must not pile up)
+                calls.append(_process_arguments(block, tile_request))
+            column = type(block).gm_batch(calls, None)
+        if column is None:
+            short_cut = getattr(block, "gm_plan_response", None)
+            column = []
+            for tile_request in requests:
+                _running.memo = {}
+                response = short_cut(tile_request) if short_cut is not None else None
+                column.append(response if response is not None else _direct(block, tile_request))
+        columns.append(column)
+    return [column[i] for i in range(len(boxes)) for column in columns]
+
+
+def _run_tiler_batch(tiler, store, kwargs, tile_pairs):
+    """The tiles of a RasterTiler over a Block with ``gm_batch``: the store's sources are evaluated tile by tile (their
+    plans, zero-copy windows), the Block's kernel runs ONCE over all tiles and writes into the mosaic.  The mosaic is the
+    result only when the tiles cover it (fuse.TiledAssembly's rule); otherwise, or when the Block declines, None / the
+    reference's fill + paste."""
+    from .hip.array import DeviceArray
+    calls = []
+    outer = getattr(_running, "memo", None)
+    try:
+        for _, tile_request in tile_pairs:
+            _running.memo = {}  # (a memo per tile)
+            calls.append(_process_arguments(store, tile_request))
+    finally:
+        _running.memo = outer
+    height, width = kwargs["shape_yx"]
+    count_x, count_y = kwargs["count_xy"]
+    tile_x, tile_y = kwargs["tilesize_xy"]
+    dtype = np.dtype(kwargs["dtype"])
+    state = {"mosaic": None, "covered": 0}
+
+    def dest(i, shape, out_dtype):
+        if len(shape) != 3 or shape[0] != 1 or np.dtype(out_dtype) != dtype:
+            return None
+        ix, iy = divmod(i, count_y)
+        th, tw = shape[1], shape[2]
+        row0, col0 = height - (iy * tile_y + th), ix * tile_x  # low y -> high rows (parallelize.py:114-124)
+        if row0 < 0 or col0 + tw > width or th > tile_y or tw > tile_x:
+            return None
+        if state["mosaic"] is None:
+            state["mosaic"] = DeviceArray.empty((1, height, width), dtype)
+        state["covered"] += th * tw
+        return state["mosaic"].window(row0, col0, th, tw)
+
+    responses = type(store).gm_batch(calls, dest)
+    if responses is None:
+        return None
+    mosaic = state["mosaic"]
+    in_place = mosaic is not None and len(responses) == count_x * count_y and all(
+        isinstance(r, dict) and isinstance(r.get("values"), DeviceArray) and r["values"]._owner is mosaic for r in responses)
+    if in_place and state["covered"] == height * width:
+        return {"values": mosaic, "no_data_value": kwargs["fillvalue"]}
+    return type(tiler).process(kwargs, *responses)
 
 
 def _direct(block, request):

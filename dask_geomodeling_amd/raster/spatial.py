@@ -131,6 +131,25 @@ class HillShade(_Stencil):
                                   process_kwargs["resolution"], process_kwargs["altitude"], process_kwargs["azimuth"])
         return {"values": shade, "no_data_value": 256}
 
+    @staticmethod
+    def gm_batch(calls, dest):
+        """``process`` for the tiles of one mosaic at once (plan.py: a RasterTiler over this Block): ``calls`` = the
+        argument tuples ``process`` would get, tile by tile; ``dest(i, shape, dtype)`` may give the window of the mosaic
+        the result of tile i goes to.  -> the list of responses, or None when the tiles have to go one by one."""
+        if not calls or any(len(args) != 2 or args[1] is None or args[0] is None or "values" not in args[0] for args in calls):
+            return None
+        data0, kw0 = calls[0]
+        ndv = data0["no_data_value"]
+        for data, kw in calls[1:]:
+            same_ndv = data["no_data_value"] == ndv or (data["no_data_value"] != data["no_data_value"] and ndv != ndv)
+            if kw != kw0 or not same_ndv or type(data["no_data_value"]) is not type(ndv):
+                return None
+        shades = stencil.hillshade_batch([data["values"] for data, _ in calls], ndv, kw0["fill"], kw0["resolution"],
+                                         kw0["altitude"], kw0["azimuth"], dest)
+        if shades is None:
+            return None
+        return [{"values": shade, "no_data_value": 256} for shade in shades]
+
 
 class SpatialResample(BaseSingle):
     """Upsample ``store`` by an integer or fractional ``zoom`` (> 0).

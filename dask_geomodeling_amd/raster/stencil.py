@@ -135,6 +135,48 @@ def hillshade(values, no_data_value, fill, resolution, altitude, azimuth):
     return out
 
 
+def hillshade_batch(tiles, no_data_value, fill, resolution, altitude, azimuth, dest=None):
+    """HillShade of the tiles of one mosaic in one launch per tile shape (gm_hillshade_batch; a ragged mosaic has up to
+    four shapes: interior, last column, top row, corner): ``tiles`` = single-band device tiles of one dtype (zero-copy
+    windows welcome); ``dest(i, shape, dtype)`` may hand out the DeviceArray window the shades of tile i are to be written
+    into.  -> list of DeviceArrays, or None when the library wants the tiles one by one (dtype / resolution route)."""
+    if not tiles:
+        return []
+    srcs = [as_device_view(t) for t in tiles]
+    first = srcs[0]
+    if first.dtype == np.dtype("bool") or any(x.dtype != first.dtype or x.shape[0] != 1 or x.shape[1] < 3 or x.shape[2] < 3
+                                                for x in srcs):
+        return None
+    with np.errstate(all="ignore"):
+        fill_cast = np.array(fill).astype(first.dtype)[()]
+    has, bits = _ndv_bits(first.dtype, no_data_value)
+    fill_bits = runtime.scalar_bits(fill_cast, first.dtype)
+    L = _lib()
+    c = ctypes
+    L.gm_hillshade_batch.argtypes = [c.c_int, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_int, c.c_uint64, c.c_uint64,
+                                     c.c_double, c.c_double, c.c_double, c.c_double, c.c_void_p, c.c_void_p]
+    L.gm_hillshade_batch.restype = c.c_int
+    groups = {}
+    for i, x in enumerate(srcs):
+        groups.setdefault(x.shape, []).append(i)
+    outs = [None] * len(srcs)
+    for (_, h, w), members in groups.items():
+        shape = (1, h - 2, w - 2)
+        for i in members:
+            out = dest(i, shape, np.dtype("u1")) if dest is not None else None
+            outs[i] = out if out is not None else DeviceArray.empty(shape, "u1")
+        n = len(members)
+        rc = L.gm_hillshade_batch(n, (c.c_void_p * n)(*[srcs[i].ptr for i in members]), code_of(first.dtype), h, w,
+                                  (c.c_int * n)(*[srcs[i].pitch or w for i in members]), has, bits, fill_bits,
+                                  float(resolution[0]), float(resolution[1]), float(altitude), float(azimuth),
+                                  (c.c_void_p * n)(*[outs[i].ptr for i in members]),
+                                  (c.c_int * n)(*[outs[i].pitch or (w - 2) for i in members]))
+        if rc == GM_ERR_UNSUPPORTED:
+            return None
+        runtime.check(rc, "gm_hillshade_batch")
+    return outs
+
+
 def gaussian_weights(sigma, truncate=4.0):
     """SciPy's Gaussian kernel (scipy.ndimage._filters._gaussian_kernel1d, order 0): weights by
     distance 0..radius, radius = int(truncate * sigma + 0.5); normalised over the full kernel."""

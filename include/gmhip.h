@@ -410,7 +410,15 @@ int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv
                  double xres, double yres, double altitude_deg, double azimuth_deg, void* out);
 int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, int has_ndv, uint64_t ndv_bits,
                         uint64_t fill_bits, double xres, double yres, double altitude_deg, double azimuth_deg,
-                        void* out); /* (window rules of gm_dilate_window) */
+                        void* out);
+/* HillShade over the tiles of one mosaic in ONE launch (RasterTiler over HillShade: parallelize.py:82-89 fans the tiles out,
+ * spatial.py:354-417 shades each): tile t is a single band of h x w cells at in[t] with row pitch in_pitch[t] (cells), its
+ * (h - 2) x (w - 2) shades go to out[t] with row pitch out_pitch[t] (bytes = cells) -- e.g. straight into its window of the
+ * mosaic.  float32 tiles, and integer tiles of up to 4 bytes at power-of-two resolutions; GM_ERR_UNSUPPORTED otherwise (run
+ * gm_hillshade_window tile by tile). */
+int gm_hillshade_batch(int n_tiles, const void* const* in, int dtype, int h, int w, const int* in_pitch, int has_ndv,
+                       uint64_t ndv_bits, uint64_t fill_bits, double xres, double yres, double altitude_deg, double azimuth_deg,
+                       void* const* out, const int* out_pitch); /* (window rules of gm_dilate_window) */
 
 /* One axis (1 = y, 2 = x) of scipy.ndimage.gaussian_filter as Smooth.process calls it
  * (spatial.py:276-290; mode="constant"): weights_host[j] = weight at distance j (radius + 1 float64

@@ -122,6 +122,35 @@ def test_tiler_through_plans_equals_untiled(gpu, seed):
             assert_result_equal(unsigned_zero(tiled, view), unsigned_zero(whole, view), 0, "template, tile %s of %s" % (tile, describe(view)))
 
 
+@pytest.mark.parametrize("dtype,cell", [("f4", 1.0), ("f4", 0.75), ("i2", 0.5), ("u1", 2.0), ("i4", 0.75), ("f8", 1.0)])
+def test_tiler_over_hillshade_in_one_launch(gpu, dtype, cell):
+    """A RasterTiler over HillShade on the plan path: the tiles of a mosaic shaded in ONE launch, written straight
+    into the mosaic (gm_hillshade_batch) -- even tilings, ragged ones (tiles of two shapes: tile by tile + paste), dtypes
+    and resolutions the batch kernel declines -- always the untiled HillShade, which test_gpu_parity pins to the
+    reference, and the graph path's mosaic."""
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(11)
+    dt = np.dtype(dtype)
+    ndv = dt.type(np.finfo(dt).max) if dt.kind == "f" else dt.type(np.iinfo(dt).max)
+    if dt.kind == "f":
+        a = np.cumsum(rng.standard_normal((1, 192, 256)), axis=2).astype(dt) * 3
+    else:
+        a = rng.integers(0, 100, size=(1, 192, 256)).astype(dt)
+    a[0, ::17, ::11] = ndv
+    A = raster.MemorySource(a, ndv, "EPSG:28992", cell, (0.0, 192.0 * cell))
+    shade = raster.HillShade(A, altitude=40, azimuth=300, fill=3)
+    for box in ((16.0, 16.0, 144.0, 144.0), (0.0, 0.0, 256.0, 192.0), (3.0, 5.0, 131.0, 101.0)):
+        x0, y0, x1, y1 = (v * cell for v in box)
+        width, height = int(round(box[2] - box[0])), int(round(box[3] - box[1]))
+        request = dict(mode="vals", bbox=(x0, y0, x1, y1), width=width, height=height, projection="EPSG:28992")
+        whole = shade.get_data(**request)
+        for tile in (64, [32, 64], 48):
+            tiler = raster.RasterTiler(shade, tile)
+            what = "%s cell %s box %s tile %s" % (dtype, cell, box, tile)
+            assert_result_equal(tiler.get_data(**request), whole, 0, what + " (plans)")
+            assert_result_equal(_graph_path(tiler, request), whole, 0, what + " (graph)")
+
+
 def test_stencil_blocks_through_plans(gpu):
     """Blocks with a kernel of their own (gm_direct) are answered without a graph per request: alone over a source,
     over a planned element-wise view, as leaves of an element-wise view above them, nested, and under a RasterTiler --
