@@ -156,7 +156,7 @@ __device__ __forceinline__ T hw_max3(T a, T b, T c) {
 constexpr int DT_H = 16, DT_W = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void dilate_tile_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                          int pitch, DilateArgs<T> A) {
+                                                          int pitch, int opitch, DilateArgs<T> A) {
   __shared__ T tile[(DT_H + 2) * (DT_W + 2)];
   const int c0 = blockIdx.x * DT_W, r0 = blockIdx.y * DT_H;
   const int ow = w - 2, oh = h - 2;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void dilate_tile_kernel(const T* __restrict__ 
       const bool hit = (centre == v) | (north == v) | (south == v) | (west == v) | (east == v);
       result = hit ? v : result;
     }
-    if (r0 + r < oh) __builtin_nontemporal_store(result, out + (size_t)(r0 + r) * ow + c);
+    if (r0 + r < oh) __builtin_nontemporal_store(result, out + (size_t)(r0 + r) * opitch + c);
     north = centre;
     west = sw;
     centre = south;
@@ -321,7 +321,7 @@ __device__ __forceinline__ unsigned equal_flags(unsigned x, unsigned splat) {
 constexpr int D8W_COLS = 2048, D8W_PITCH = 516;  // window: (D8W_H + 2) rows of 516 words (2064 bytes)
 template <int D8W_H>
 __global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
-                                                           int h, int w, int pitch, Dilate8Args A) {
+                                                           int h, int w, int pitch, int opitch, Dilate8Args A) {
   __shared__ __align__(16) unsigned tile[(D8W_H + 2) * D8W_PITCH];
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const int c0 = blockIdx.x * D8W_COLS, r0 = blockIdx.y * D8W_H;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* 
     centre_prev[1] = centre[1];
     const int orow = r0 + y - 2;
     if (y >= 2 && orow < oh) {
-      unsigned char* o = out + (size_t)orow * ow + c8;
+      unsigned char* o = out + (size_t)orow * opitch + c8;
       if (c8 + 8 <= ow) {
         // (rows of w - 2 bytes: unless that is a multiple of 8 these stores are not 8-byte aligned, which is what
         //  separates the 8192-column tile -- 8190-byte rows, 42-46 % of peak -- from the 8194-column one a Dilate
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
 constexpr int M3_H = 16, M3_W = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                          int pitch, int has_ndv, T ndv, T minimum) {
+                                                          int pitch, int opitch, int has_ndv, T ndv, T minimum) {
   __shared__ T tile[(M3_H + 2) * (M3_W + 2)];
   const int c0 = blockIdx.x * M3_W, r0 = blockIdx.y * M3_H, b = blockIdx.z;
   const int ow = w - 2, oh = h - 2;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ 
         const T original = plane[(size_t)(r0 + r + 1) * pitch + (c + 1)];
         if (original == ndv) best = ndv;
       }
-      __builtin_nontemporal_store(best, out + ((size_t)b * oh + (r0 + r)) * ow + c);
+      __builtin_nontemporal_store(best, out + (size_t)b * oh * ow + (size_t)(r0 + r) * opitch + c);
     }
   }
 }
@@ -573,7 +573,7 @@ __host__ __device__ constexpr int disk_half_width(int dy) {
 __host__ __device__ constexpr int disk_tile_rows(int R) { return R >= 7 ? 32 : 16; }
 template <typename T, int R>
 __global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                              int pitch, int has_ndv, T ndv, T minimum) {
+                                                              int pitch, int opitch, int has_ndv, T ndv, T minimum) {
   constexpr int TH = disk_tile_rows(R), TW = 256, PITCH = TW + 2 * R, ROWS = TH + 2 * R;
   __shared__ T tile[ROWS * PITCH];
   const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH, b = blockIdx.z;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restric
           const T original = plane[(size_t)(r0 + r + R) * pitch + (c + R)];
           if (original == ndv) best = ndv;
         }
-        __builtin_nontemporal_store(best, out + ((size_t)b * oh + (r0 + r)) * ow + c);
+        __builtin_nontemporal_store(best, out + (size_t)b * oh * ow + (size_t)(r0 + r) * opitch + c);
       }
     }
   }
@@ -1189,7 +1189,7 @@ struct Gauss2Args {
 };
 template <int R, int RCAP>
 __global__ __launch_bounds__(256) void gauss2d_kernel(const float* __restrict__ in, float* __restrict__ out, int h, int w,
-                                                      int pitch, int y0, int x0, int oh, int ow, int replace_ndv, float ndv,
+                                                      int pitch, int y0, int x0, int oh, int ow, int opitch, int replace_ndv, float ndv,
                                                       float fill, Gauss2Args A) {
   constexpr int TW = 256 - 2 * RCAP, WIN = 8 + 2 * R, WIN4 = (WIN + 3) / 4;
   __shared__ __align__(16) float mid[G2_TH * 256 + 4];
@@ -1269,7 +1269,7 @@ __global__ __launch_bounds__(256) void gauss2d_kernel(const float* __restrict__ 
       for (int j = R; j >= 1; --j) acc += (win[k + R - j] + win[k + R + j]) * A.wx[j];
       res[k] = (float)acc;
     }
-    float* o = out + ((size_t)b * oh + oy0 + r) * ow + ox;
+    float* o = out + (size_t)b * oh * ow + (size_t)(oy0 + r) * opitch + ox;
     if (ox + 8 <= ow) {
       __builtin_memcpy(o, res, 32);
     } else {
@@ -1296,6 +1296,15 @@ T lowest() {
 }
 
 }  // namespace
+
+// The *_into entry points: the result written with a row pitch of its own (a window of a mosaic).  They call the
+// *_window launchers with this thread's output pitch set; a route whose kernel writes compact rows only declines.
+static thread_local int t_out_pitch = 0;
+static inline int out_pitch_or(int ow) { return t_out_pitch ? t_out_pitch : ow; }
+#define GM_COMPACT_ONLY(what)                                                                                    \
+  do {                                                                                                           \
+    if (t_out_pitch) return gm::fail(GM_ERR_UNSUPPORTED, what ": this route writes compact tiles only");         \
+  } while (0)
 
 extern "C" {
 
@@ -1327,7 +1336,7 @@ int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_
     }
     if (bands == 1 && w >= 64 && (h - 2 + d8h - 1) / d8h <= 65535) {
       dim3 wgrid((unsigned)((w - 2 + D8W_COLS - 1) / D8W_COLS), (unsigned)((h - 2 + d8h - 1) / d8h));
-#define GM_D8W(H_) hipLaunchKernelGGL(dilate8_wide_kernel<H_>, wgrid, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, h, w, in_pitch, A8)
+#define GM_D8W(H_) hipLaunchKernelGGL(dilate8_wide_kernel<H_>, wgrid, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, h, w, in_pitch, out_pitch_or(w - 2), A8)
       if (d8h == 4) GM_D8W(4);
       else if (d8h == 8) GM_D8W(8);
       else if (d8h == 32) GM_D8W(32);
@@ -1337,6 +1346,7 @@ int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_
       return GM_OK;
     }
     if (window) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: this tile shape wants a compact tile");
+    GM_COMPACT_ONLY("gm_dilate");
     dim3 grid8((unsigned)((w - 2 + 1023) / 1024), (unsigned)((h - 2 + D8_ROWS - 1) / D8_ROWS), (unsigned)bands);
     if (grid8.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: tile taller than %d rows", 65535 * D8_ROWS);
     hipLaunchKernelGGL(dilate8_kernel, grid8, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, bands, h, w, A8);
@@ -1348,6 +1358,7 @@ int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_
   if (n_values > DIL_MAX_VALUES) {
     // the reference takes any number of values (spatial.py:147-154): groups of DIL_MAX_VALUES, every group testing
     // the original tile and writing on top of what the groups before it left in `out`
+    GM_COMPACT_ONLY("gm_dilate");
 #define GM_DILC(T)                                                                                                     \
   do {                                                                                                                 \
     for (int v0 = 0; v0 < n_values; v0 += DIL_MAX_VALUES) {                                                            \
@@ -1376,7 +1387,7 @@ int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_
     DilateArgs<T> A;                                                                                \
     A.n_values = n_values;                                                                          \
     for (int i = 0; i < n_values; ++i) A.values[i] = from_bits<T>(values_bits[i]);                  \
-    hipLaunchKernelGGL(dilate_tile_kernel<T>, tgrid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, in_pitch, A); \
+    hipLaunchKernelGGL(dilate_tile_kernel<T>, tgrid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, in_pitch, out_pitch_or(w - 2), A); \
   } while (0)
     switch (dtype) {
       case GM_U16: GM_DILT(unsigned short); break;
@@ -1390,6 +1401,7 @@ int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_
     GM_HIP(hipGetLastError());
     return GM_OK;
   }
+  GM_COMPACT_ONLY("gm_dilate");
 #define GM_DIL(T)                                                                                    \
   do {                                                                                               \
     DilateArgs<T> A;                                                                                 \
@@ -1436,7 +1448,7 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
   if (!s) return GM_ERR_NO_DEVICE;
   if (size == 3 && gm::dtype_size(dtype) <= 4 && (oh + M3_H - 1) / M3_H <= 65535) {
     dim3 grid3((unsigned)((ow + M3_W - 1) / M3_W), (unsigned)((oh + M3_H - 1) / M3_H), (unsigned)bands);
-#define GM_M3(T) hipLaunchKernelGGL(moving_max3_kernel<T>, grid3, dim3(256), 0, s, (const T*)in, (T*)out, h, w, in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>())
+#define GM_M3(T) hipLaunchKernelGGL(moving_max3_kernel<T>, grid3, dim3(256), 0, s, (const T*)in, (T*)out, h, w, in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>())
     switch (dtype) {
       case GM_U8: GM_M3(unsigned char); break;
       case GM_I8: GM_M3(signed char); break;
@@ -1458,22 +1470,22 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
   do {                                                                                                            \
     if (size == 5)                                                                                                \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 2>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
     else if (size == 7)                                                                                           \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 3>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
     else if (size == 9)                                                                                           \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 4>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
     else if (size == 11)                                                                                          \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 5>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
     else if (size == 13)                                                                                          \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 6>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
     else                                                                                                          \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 7>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, has_ndv, from_bits<T>(ndv_bits), lowest<T>());                                          \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
   } while (0)
     switch (dtype) {
       case GM_U8: GM_MD(unsigned char); break;
@@ -1490,6 +1502,7 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
     return GM_OK;
   }
   if (window) return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: this footprint / dtype wants a compact tile");
+  GM_COMPACT_ONLY("gm_moving_max");
   dim3 grid((unsigned)((ow + MM_TILE_W - 1) / MM_TILE_W), (unsigned)((oh + MM_TILE_H - 1) / MM_TILE_H), (unsigned)bands);
   if (grid.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: tile too tall");
 #define GM_MM_R(T, RMAX_)                                                                                      \
@@ -1611,7 +1624,7 @@ int gm_gauss_2d_window(const void* in, int dtype, int bands, int h, int w, int i
 #define GM_G2(R, RCAP)                                                                                              \
   case R:                                                                                                           \
     hipLaunchKernelGGL((gauss2d_kernel<R, RCAP>), grid, dim3(256), 0, s, (const float*)in, (float*)out, h, w, in_pitch,   \
-                       y0, x0, oh, ow, replace_ndv, ndv, fill, A);                                                  \
+                       y0, x0, oh, ow, out_pitch_or(ow), replace_ndv, ndv, fill, A);                                \
     break
   switch (radius) {
     GM_G2(1, 8); GM_G2(2, 8); GM_G2(3, 8); GM_G2(4, 8); GM_G2(5, 8); GM_G2(6, 8); GM_G2(7, 8); GM_G2(8, 8);
@@ -1731,6 +1744,39 @@ int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int 
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
+
+// ---- results written with a row pitch of their own (one band; the tile's window of a mosaic) ----
+#define GM_INTO(CALL)                                                                                         \
+  do {                                                                                                        \
+    if (!out) return gm::fail(GM_ERR_INVALID, "null pointer");                                                \
+    if (bands != 1) return gm::fail(GM_ERR_UNSUPPORTED, "an output pitch needs a single band");               \
+    if (out_pitch < min_pitch) return gm::fail(GM_ERR_INVALID, "output pitch %d of a %d-wide result", out_pitch, min_pitch); \
+    t_out_pitch = out_pitch;                                                                                  \
+    const int rc_ = (CALL);                                                                                   \
+    t_out_pitch = 0;                                                                                          \
+    return rc_;                                                                                               \
+  } while (0)
+
+int gm_dilate_into(const void* in, int dtype, int bands, int h, int w, int in_pitch, const uint64_t* values_bits, int n_values,
+                   void* out, int out_pitch) {
+  const int min_pitch = w - 2;
+  GM_INTO(gm_dilate_window(in, dtype, bands, h, w, in_pitch, values_bits, n_values, out));
+}
+
+int gm_moving_max_into(const void* in, int dtype, int bands, int h, int w, int in_pitch, int size, int has_ndv,
+                       uint64_t ndv_bits, void* out, int out_pitch) {
+  const int min_pitch = w - 2 * (size / 2);
+  GM_INTO(gm_moving_max_window(in, dtype, bands, h, w, in_pitch, size, has_ndv, ndv_bits, out));
+}
+
+int gm_gauss_2d_into(const void* in, int dtype, int bands, int h, int w, int in_pitch, const double* weights_y,
+                     const double* weights_x, int radius, double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits,
+                     int y0, int x0, int oh, int ow, void* out, int out_pitch) {
+  const int min_pitch = ow;
+  GM_INTO(gm_gauss_2d_window(in, dtype, bands, h, w, in_pitch, weights_y, weights_x, radius, cval, replace_ndv, ndv_bits,
+                             fill_bits, y0, x0, oh, ow, out));
+}
+#undef GM_INTO
 
 int gm_hillshade_batch(int n_tiles, const void* const* in, int dtype, int h, int w, const int* in_pitch, int has_ndv,
                        uint64_t ndv_bits, uint64_t fill_bits, double xres, double yres, double altitude_deg, double azimuth_deg,

@@ -61,6 +61,15 @@ class _Stencil(BaseSingle):
         return [(self.store, grown), (self._process_argument(request), None)]
 
 
+def _tile_by_tile(calls, dest, one):
+    """gm_batch of a Block whose kernel takes one tile per launch: ``one(data, argument, out)`` tile after tile, the
+    result of tile i written into ``dest(i, shape, dtype)`` where the kernel can (no paste into the mosaic afterwards)."""
+    if not calls or any(len(args) != 2 or args[0] is None or args[1] is None or "values" not in args[0] for args in calls):
+        return None
+    return [one(data, argument, lambda shape, dtype, i=i: dest(i, shape, dtype) if dest is not None else None)
+            for i, (data, argument) in enumerate(calls)]
+
+
 class Dilate(_Stencil):
     """Spatially dilate the cells holding one of ``values`` by one cell (spatial.py:111-155).
 
@@ -80,6 +89,14 @@ class Dilate(_Stencil):
         if data is None or values is None or "values" not in data:
             return data
         return {"values": stencil.dilate(data["values"], values), "no_data_value": data["no_data_value"]}
+
+    @staticmethod
+    def gm_batch(calls, dest):
+        def one(data, values, out_for):
+            tile = data["values"]
+            out = out_for((tile.shape[0], tile.shape[1] - 2, tile.shape[2] - 2), tile.dtype) if tile.shape[0] == 1 else None
+            return {"values": stencil.dilate(tile, values, out=out), "no_data_value": data["no_data_value"]}
+        return _tile_by_tile(calls, dest, one)
 
 
 class MovingMax(_Stencil):
@@ -105,6 +122,15 @@ class MovingMax(_Stencil):
             return data
         ndv = data["no_data_value"]
         return {"values": stencil.moving_max(data["values"], ndv, size), "no_data_value": ndv}
+
+    @staticmethod
+    def gm_batch(calls, dest):
+        def one(data, size, out_for):
+            tile, ndv, radius = data["values"], data["no_data_value"], int(size // 2)
+            out = (out_for((1, tile.shape[1] - 2 * radius, tile.shape[2] - 2 * radius), tile.dtype)
+                   if tile.shape[0] == 1 and tile.dtype != np.dtype("bool") else None)
+            return {"values": stencil.moving_max(tile, ndv, size, out=out), "no_data_value": ndv}
+        return _tile_by_tile(calls, dest, one)
 
 
 class HillShade(_Stencil):
@@ -272,13 +298,28 @@ class Smooth(BaseSingle):
         ndv = data["no_data_value"]
         if process_kwargs["smooth_mode"] == "exact":
             crop = [int(round(s)) for s in size_px]
-            values = stencil.gaussian_smooth(data["values"], ndv, fill, sigma, crop)
+            values = stencil.gaussian_smooth(data["values"], ndv, fill, sigma, crop, out=process_kwargs.get("gm_out"))
         else:
             values = stencil.gaussian_smooth(data["values"], ndv, fill, sigma)
             _, ny, nx = values.shape
             zoom = 1 - 2 * size_px[0] / ny, 1 - 2 * size_px[1] / nx
             values = resample.affine_nearest(values, zoom, (size_px[0], size_px[1]))
         return {"values": values, "no_data_value": ndv}
+
+
+def _smooth_batch(calls, dest):
+    """Smooth.gm_batch: tile by tile, the exact mode's result written into its window of the mosaic."""
+    def one(data, process_kwargs, out_for):
+        tile = data["values"]
+        if process_kwargs["smooth_mode"] == "exact" and tile.shape[0] == 1:
+            crop = [int(round(s)) for s in process_kwargs["size"]]
+            out = out_for((1, tile.shape[1] - 2 * crop[0], tile.shape[2] - 2 * crop[1]), tile.dtype)
+            process_kwargs = dict(process_kwargs, gm_out=out)
+        return Smooth.process(data, process_kwargs)
+    return _tile_by_tile(calls, dest, one)
+
+
+Smooth.gm_batch = staticmethod(_smooth_batch)
 
 
 def _same_crs_point(point, source_projection, target_projection):

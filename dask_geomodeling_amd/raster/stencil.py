@@ -40,7 +40,11 @@ def _lib():
         L.gm_gauss_2d_window.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_double),
                                          c.POINTER(c.c_double), c.c_int, c.c_double, c.c_int, c.c_uint64, c.c_uint64, c.c_int,
                                          c.c_int, c.c_int, c.c_int, c.c_void_p]
-        for fn in (L.gm_dilate_window, L.gm_moving_max_window, L.gm_hillshade_window, L.gm_gauss_2d_window):
+        L.gm_dilate_into.argtypes = L.gm_dilate_window.argtypes + [c.c_int]
+        L.gm_moving_max_into.argtypes = L.gm_moving_max_window.argtypes + [c.c_int]
+        L.gm_gauss_2d_into.argtypes = L.gm_gauss_2d_window.argtypes + [c.c_int]
+        for fn in (L.gm_dilate_window, L.gm_moving_max_window, L.gm_hillshade_window, L.gm_gauss_2d_window, L.gm_dilate_into,
+                   L.gm_moving_max_into, L.gm_gauss_2d_into):
             fn.restype = c.c_int
         _declared = True
     return L
@@ -62,6 +66,28 @@ def _ndv_bits(dtype, ndv):
 GM_ERR_UNSUPPORTED = 9002
 
 
+def _into(out, shape, dtype):
+    """``out`` when it can take the result as it is -- a single band of that shape and dtype, possibly a window of a
+    mosaic (row pitch) -- else None."""
+    if out is None or tuple(out.shape) != tuple(shape) or out.dtype != np.dtype(dtype) or shape[0] != 1:
+        return None
+    return out
+
+
+def _launch_into(src, out, plain, into, what):
+    """The kernel on ``src`` (a tile or zero-copy window) with the result in ``out``: ``into(tile, pitch, out_pitch)``
+    when ``out`` has a row pitch of its own and the library's route for this tile can write one, else
+    ``plain(tile, pitch)`` into a compact tile (-> that tile: the caller's ``out`` was not used)."""
+    if out.pitch is not None:
+        rc = into(src, src.pitch or src.shape[-1], out.pitch)
+        if rc != GM_ERR_UNSUPPORTED:
+            runtime.check(rc, what)
+            return out
+        out = DeviceArray.empty(out.shape, out.dtype)  # this route writes compact tiles only
+    _on_window(src, lambda tile, pitch: plain(tile, pitch, out), what)
+    return out
+
+
 def _on_window(src, launch, what):
     """``launch(tile, pitch)`` on a zero-copy window as it is; when the library wants a compact tile for this
     dtype / shape (GM_ERR_UNSUPPORTED), on a compacted copy.  Compact tiles go straight through."""
@@ -79,37 +105,48 @@ def _cast_tile(src, dtype):
     return values
 
 
-def dilate(values, dilate_values):
-    """(bands, h, w) tile with a 1-pixel margin -> dilated (bands, h-2, w-2) tile."""
+def dilate(values, dilate_values, out=None):
+    """(bands, h, w) tile with a 1-pixel margin -> dilated (bands, h-2, w-2) tile.  ``out``: where the result may be
+    written (e.g. the tile's window of a mosaic); what is returned is the tile that holds the result."""
     src = as_device_view(values)
     bands, h, w = src.shape
     vals = np.asarray(dilate_values, dtype=src.dtype)  # the reference's cast (spatial.py:151)
     if h < 3 or w < 3:
         return DeviceArray.empty((bands, max(h - 2, 0), max(w - 2, 0)), src.dtype)
-    out = DeviceArray.empty((bands, h - 2, w - 2), src.dtype)
-    todo, current = list(vals), src
+    shape = (bands, h - 2, w - 2)
+    out = _into(out, shape, src.dtype) or DeviceArray.empty(shape, src.dtype)
+    todo = list(vals)
     # (any number of values, spatial.py:147-154: beyond what one launch carries the library applies them group by
     #  group, every group testing the original tile)
     bits = (ctypes.c_uint64 * max(len(todo), 1))(*[runtime.scalar_bits(v, src.dtype) for v in todo])
     L = _lib()
-    _on_window(current, lambda tile, pitch: L.gm_dilate_window(ctypes.c_void_p(tile.ptr), code_of(src.dtype), bands, h, w, pitch,
-                                                              bits, len(todo), ctypes.c_void_p(out.ptr)), "gm_dilate")
-    return out
+    code = code_of(src.dtype)
+    return _launch_into(
+        src, out,
+        lambda tile, pitch, o: L.gm_dilate_window(ctypes.c_void_p(tile.ptr), code, bands, h, w, pitch, bits, len(todo),
+                                                  ctypes.c_void_p(o.ptr)),
+        lambda tile, pitch, opitch: L.gm_dilate_into(ctypes.c_void_p(tile.ptr), code, bands, h, w, pitch, bits, len(todo),
+                                                     ctypes.c_void_p(out.ptr), opitch), "gm_dilate")
 
 
-def moving_max(values, no_data_value, size):
+def moving_max(values, no_data_value, size, out=None):
     src = as_device_view(values)
     bands, h, w = src.shape
     radius = int(size // 2)
     if src.dtype == np.dtype("bool"):
         # the reference fails here too: utils.get_dtype_min has no minimum for bool (spatial.py:198)
         raise ValueError("Invalid integer data type 'b'.")
-    out = DeviceArray.empty((bands, h - 2 * radius, w - 2 * radius), src.dtype)
+    shape = (bands, h - 2 * radius, w - 2 * radius)
+    out = _into(out, shape, src.dtype) or DeviceArray.empty(shape, src.dtype)
     has, bits = _ndv_bits(src.dtype, no_data_value)
     L = _lib()
-    _on_window(src, lambda tile, pitch: L.gm_moving_max_window(ctypes.c_void_p(tile.ptr), code_of(src.dtype), bands, h, w, pitch,
-                                                              int(size), has, bits, ctypes.c_void_p(out.ptr)), "gm_moving_max")
-    return out
+    code = code_of(src.dtype)
+    return _launch_into(
+        src, out,
+        lambda tile, pitch, o: L.gm_moving_max_window(ctypes.c_void_p(tile.ptr), code, bands, h, w, pitch, int(size), has, bits,
+                                                      ctypes.c_void_p(o.ptr)),
+        lambda tile, pitch, opitch: L.gm_moving_max_into(ctypes.c_void_p(tile.ptr), code, bands, h, w, pitch, int(size), has,
+                                                         bits, ctypes.c_void_p(out.ptr), opitch), "gm_moving_max")
 
 
 def hillshade(values, no_data_value, fill, resolution, altitude, azimuth):
@@ -187,7 +224,7 @@ def gaussian_weights(sigma, truncate=4.0):
     return np.ascontiguousarray(phi[radius:], dtype=np.float64), radius
 
 
-def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0), fused=True):
+def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0), fused=True, out=None):
     """values[values == ndv] = fill, then ndimage.gaussian_filter(values, (0, sy, sx), mode="constant",
     cval=fill) axis by axis (the second axis reads the first one's result in the tile's dtype), the
     result cropped by ``crop_yx`` pixels on every side."""
@@ -205,13 +242,20 @@ def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0), fused
     if fused and len(axes) == 2 and src.dtype == np.dtype("f4"):
         (wy, ry), (wx, rx) = gaussian_weights(axes[0][1]), gaussian_weights(axes[1][1])
         if ry == rx and 1 <= ry <= MAX_FUSED_RADIUS:  # both axes in one launch (csrc/gm_stencil.hip gauss2d_kernel)
-            out = DeviceArray.empty((bands, h - 2 * my, w - 2 * mx), src.dtype)
+            shape = (bands, h - 2 * my, w - 2 * mx)
+            out = _into(out, shape, src.dtype) or DeviceArray.empty(shape, src.dtype)
             as_doubles = ctypes.POINTER(ctypes.c_double)
-            _on_window(src, lambda tile, pitch: L.gm_gauss_2d_window(
-                ctypes.c_void_p(tile.ptr), code_of(src.dtype), bands, h, w, pitch, wy.ctypes.data_as(as_doubles),
-                wx.ctypes.data_as(as_doubles), ry, float(fill), 1 if has else 0, ndv_bits, fill_bits, my, mx, h - 2 * my,
-                w - 2 * mx, ctypes.c_void_p(out.ptr)), "gm_gauss_2d")
-            return out
+            code = code_of(src.dtype)
+            return _launch_into(
+                src, out,
+                lambda tile, pitch, o: L.gm_gauss_2d_window(
+                    ctypes.c_void_p(tile.ptr), code, bands, h, w, pitch, wy.ctypes.data_as(as_doubles),
+                    wx.ctypes.data_as(as_doubles), ry, float(fill), 1 if has else 0, ndv_bits, fill_bits, my, mx, h - 2 * my,
+                    w - 2 * mx, ctypes.c_void_p(o.ptr)),
+                lambda tile, pitch, opitch: L.gm_gauss_2d_into(
+                    ctypes.c_void_p(tile.ptr), code, bands, h, w, pitch, wy.ctypes.data_as(as_doubles),
+                    wx.ctypes.data_as(as_doubles), ry, float(fill), 1 if has else 0, ndv_bits, fill_bits, my, mx, h - 2 * my,
+                    w - 2 * mx, ctypes.c_void_p(out.ptr), opitch), "gm_gauss_2d")
     current, replace = src.contiguous(), has  # (the one-axis kernels read compact tiles)
     for k, (axis, sigma) in enumerate(axes):
         weights, radius = gaussian_weights(sigma) if sigma is not None else (np.ones(1, dtype=np.float64), 0)

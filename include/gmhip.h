@@ -411,6 +411,18 @@ int gm_hillshade(const void* in, int dtype, int bands, int h, int w, int has_ndv
 int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, int has_ndv, uint64_t ndv_bits,
                         uint64_t fill_bits, double xres, double yres, double altitude_deg, double azimuth_deg,
                         void* out);
+/* gm_dilate_window / gm_moving_max_window / gm_gauss_2d_window with the result written at a row pitch of its own
+ * (out_pitch cells between the rows of `out`: the tile's window of a mosaic, RasterTiler.process parallelize.py:113-124
+ * without the paste).  One band; GM_ERR_UNSUPPORTED for the dtypes / footprints whose kernels write compact tiles only
+ * (then: the plain call + gm_paste_tile). */
+int gm_dilate_into(const void* in, int dtype, int bands, int h, int w, int in_pitch, const uint64_t* values_bits, int n_values,
+                   void* out, int out_pitch);
+int gm_moving_max_into(const void* in, int dtype, int bands, int h, int w, int in_pitch, int size, int has_ndv,
+                       uint64_t ndv_bits, void* out, int out_pitch);
+int gm_gauss_2d_into(const void* in, int dtype, int bands, int h, int w, int in_pitch, const double* weights_y,
+                     const double* weights_x, int radius, double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits,
+                     int y0, int x0, int oh, int ow, void* out, int out_pitch);
+
 /* HillShade over the tiles of one mosaic in ONE launch (RasterTiler over HillShade: parallelize.py:82-89 fans the tiles out,
  * spatial.py:354-417 shades each): tile t is a single band of h x w cells at in[t] with row pitch in_pitch[t] (cells), its
  * (h - 2) x (w - 2) shades go to out[t] with row pitch out_pitch[t] (bytes = cells) -- e.g. straight into its window of the

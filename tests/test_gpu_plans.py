@@ -151,6 +151,42 @@ def test_tiler_over_hillshade_in_one_launch(gpu, dtype, cell):
             assert_result_equal(_graph_path(tiler, request), whole, 0, what + " (graph)")
 
 
+@pytest.mark.parametrize("dtype", ["f4", "u1", "i2", "i8", "f8"])
+@pytest.mark.parametrize("kind", ["dilate", "movingmax3", "movingmax7", "movingmax21", "smooth"])
+def test_tiler_over_stencils_writes_in_place(gpu, kind, dtype):
+    """A RasterTiler over Dilate / MovingMax / Smooth of a resident source on the plan path: every tile's result is
+    written straight into its window of the mosaic where the kernel route can (gm_*_into), pasted otherwise (8-byte
+    cells, large footprints, ragged tilings) -- always the untiled Block's result and the graph path's mosaic."""
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(17)
+    dt = np.dtype(dtype)
+    if kind == "smooth" and dt.kind != "f":
+        pytest.skip("Smooth of integer rasters: compared in test_gpu_parity")
+    ndv = dt.type(np.finfo(dt).max) if dt.kind == "f" else dt.type(np.iinfo(dt).max)
+    a = rng.integers(0, 12, size=(1, 192, 256)).astype(dt)
+    if dt.kind == "f":
+        a = a + rng.random(a.shape).astype(dt)
+    a[0, ::17, ::11] = ndv
+    A = raster.MemorySource(a, ndv, "EPSG:28992", 1.0, (0.0, 192.0))
+    view = {"dilate": lambda: raster.Dilate(A, [3, 5, 7]), "movingmax3": lambda: raster.MovingMax(A, 3),
+            "movingmax7": lambda: raster.MovingMax(A, 7), "movingmax21": lambda: raster.MovingMax(A, 21),
+            "smooth": lambda: raster.Smooth(A, 4.0)}[kind]()
+    for box in ((32.0, 32.0, 160.0, 160.0), (0.0, 0.0, 256.0, 192.0), (35.0, 37.0, 163.0, 133.0)):
+        width, height = int(box[2] - box[0]), int(box[3] - box[1])
+        request = dict(mode="vals", bbox=box, width=width, height=height, projection="EPSG:28992")
+        whole = view.get_data(**request)
+        for tile in (64, [32, 64], 48):
+            tiler = raster.RasterTiler(view, tile)
+            what = "%s %s box %s tile %s" % (kind, dtype, box, tile)
+            if kind == "smooth":
+                # (a tile of a Smooth is not a window of the whole: the reference crops by `size` cells while the Gaussian
+                #  reaches 4/3 of that, spatial.py:262-290 -- the tiled results agree with each other)
+                assert_result_equal(tiler.get_data(**request), _graph_path(tiler, request), 0, what + " (plans vs graph)")
+                continue
+            assert_result_equal(tiler.get_data(**request), whole, 0, what + " (plans)")
+            assert_result_equal(_graph_path(tiler, request), whole, 0, what + " (graph)")
+
+
 def test_stencil_blocks_through_plans(gpu):
     """Blocks with a kernel of their own (gm_direct) are answered without a graph per request: alone over a source,
     over a planned element-wise view, as leaves of an element-wise view above them, nested, and under a RasterTiler --

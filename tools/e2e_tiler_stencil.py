@@ -10,7 +10,12 @@ da = generate_window((big, big), "f4", 7001, 0.0, 100.0, F32MAX, (97, 89), 0, 0,
 db = generate_window((big, big), "f4", 7002, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big)
 A = raster.MemorySource(da, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
 B = raster.MemorySource(db, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
+dc = generate_window((big, big), "u1", 7003, 0.0, 12.0, 255, (97, 89), 0, 0, big, big)
+C = raster.MemorySource(dc, np.uint8(255), "EPSG:28992", 1.0, (0.0, float(big)))
 views = {"tiler(HillShade(A))": raster.RasterTiler(raster.HillShade(A), side),
+         "tiler(Dilate(C, [3, 5]))": raster.RasterTiler(raster.Dilate(C, [3, 5]), side),
+         "tiler(MovingMax(A, 5))": raster.RasterTiler(raster.MovingMax(A, 5), side),
+         "tiler(Smooth(A, 2))": raster.RasterTiler(raster.Smooth(A, 2.0), side),
          "tiler(HillShade(A * 2 + B))": raster.RasterTiler(raster.HillShade(A * 2 + B), side),
          "tiler(HillShade(A) * 0.5 + B)": raster.RasterTiler(raster.HillShade(A) * 0.5 + B, side)}
 inner = 64.0
