@@ -383,6 +383,61 @@ class TiledAssembly(object):
         return self.tiler_process(process_kwargs, *tiles)  # the reference's fill + paste
 
 
+def tiles_in_place(tiler_process, block_type, process_kwargs, calls):
+    """The tiles of a RasterTiler over a Block with ``gm_batch`` (a stencil over a resident source): ``calls`` = what
+    the Block's ``process`` would get tile by tile; its kernel writes every tile into its window of the mosaic (one
+    launch for all tiles where the Block has one).  The mosaic is the result only when the tiles cover it (TiledAssembly's
+    rule); otherwise the reference's fill + paste.  None when the Block declines these tiles."""
+    height, width = process_kwargs["shape_yx"]
+    count_x, count_y = process_kwargs["count_xy"]
+    tile_x, tile_y = process_kwargs["tilesize_xy"]
+    dtype = np.dtype(process_kwargs["dtype"])
+    state = {"mosaic": None, "covered": 0}
+
+    def dest(i, shape, out_dtype):
+        if len(shape) != 3 or shape[0] != 1 or np.dtype(out_dtype) != dtype:
+            return None
+        ix, iy = divmod(i, count_y)
+        th, tw = shape[1], shape[2]
+        row0, col0 = height - (iy * tile_y + th), ix * tile_x  # low y -> high rows (parallelize.py:114-124)
+        if row0 < 0 or col0 + tw > width or th > tile_y or tw > tile_x:
+            return None
+        if state["mosaic"] is None:
+            state["mosaic"] = DeviceArray.empty((1, height, width), dtype)
+        state["covered"] += th * tw
+        return state["mosaic"].window(row0, col0, th, tw)
+
+    responses = block_type.gm_batch(calls, dest)
+    if responses is None:
+        return None
+    mosaic = state["mosaic"]
+    in_place = mosaic is not None and len(responses) == count_x * count_y and all(
+        isinstance(r, dict) and isinstance(r.get("values"), DeviceArray) and r["values"]._owner is mosaic for r in responses)
+    if in_place and state["covered"] == height * width:
+        return {"values": mosaic, "no_data_value": process_kwargs["fillvalue"]}
+    return tiler_process(process_kwargs, *responses)
+
+
+class MosaicOfTiles(object):
+    """Graph task of a RasterTiler over a Block with ``gm_batch``: called with the tiler's process kwargs, the number of
+    ``process`` arguments of every tile and those arguments back to back (the tiles' source responses computed by the
+    scheduler) -> the mosaic, written in place (tiles_in_place), or process + paste tile by tile."""
+
+    def __init__(self, tiler_process, block_type):
+        self.tiler_process, self.block_type = tiler_process, block_type
+        self.__name__ = "mosaic_of_%s" % block_type.__name__.lower()
+
+    def __call__(self, process_kwargs, counts, *flat):
+        calls, at = [], 0
+        for n in counts:
+            calls.append(tuple(flat[at:at + n]))
+            at += n
+        done = tiles_in_place(self.tiler_process, self.block_type, process_kwargs, calls)
+        if done is not None:
+            return done
+        return self.tiler_process(process_kwargs, *[self.block_type.process(*call) for call in calls])
+
+
 def fuse_graph(graph, name):
     """Return a graph in which fusable element-wise sub-graphs are single FusedTasks and
     structurally identical, independent FusedTasks are BatchedTasks.  ``name`` is the key (or

@@ -268,7 +268,6 @@ def _run_tiler_batch(tiler, store, kwargs, tile_pairs):
     plans, zero-copy windows), the Block's kernel runs ONCE over all tiles and writes into the mosaic.  The mosaic is the
     result only when the tiles cover it (fuse.TiledAssembly's rule); otherwise, or when the Block declines, None / the
     reference's fill + paste."""
-    from .hip.array import DeviceArray
     calls = []
     outer = getattr(_running, "memo", None)
     try:
@@ -277,34 +276,8 @@ def _run_tiler_batch(tiler, store, kwargs, tile_pairs):
             calls.append(_process_arguments(store, tile_request))
     finally:
         _running.memo = outer
-    height, width = kwargs["shape_yx"]
-    count_x, count_y = kwargs["count_xy"]
-    tile_x, tile_y = kwargs["tilesize_xy"]
-    dtype = np.dtype(kwargs["dtype"])
-    state = {"mosaic": None, "covered": 0}
-
-    def dest(i, shape, out_dtype):
-        if len(shape) != 3 or shape[0] != 1 or np.dtype(out_dtype) != dtype:
-            return None
-        ix, iy = divmod(i, count_y)
-        th, tw = shape[1], shape[2]
-        row0, col0 = height - (iy * tile_y + th), ix * tile_x  # low y -> high rows (parallelize.py:114-124)
-        if row0 < 0 or col0 + tw > width or th > tile_y or tw > tile_x:
-            return None
-        if state["mosaic"] is None:
-            state["mosaic"] = DeviceArray.empty((1, height, width), dtype)
-        state["covered"] += th * tw
-        return state["mosaic"].window(row0, col0, th, tw)
-
-    responses = type(store).gm_batch(calls, dest)
-    if responses is None:
-        return None
-    mosaic = state["mosaic"]
-    in_place = mosaic is not None and len(responses) == count_x * count_y and all(
-        isinstance(r, dict) and isinstance(r.get("values"), DeviceArray) and r["values"]._owner is mosaic for r in responses)
-    if in_place and state["covered"] == height * width:
-        return {"values": mosaic, "no_data_value": kwargs["fillvalue"]}
-    return type(tiler).process(kwargs, *responses)
+    from .fuse import tiles_in_place
+    return tiles_in_place(type(tiler).process, type(store), kwargs, calls)
 
 
 def _direct(block, request):

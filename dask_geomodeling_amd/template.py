@@ -236,6 +236,19 @@ def _tiler(tiler, request, graph):
             templates.append(tpl)
     name = _key_of(tiler, request)
     if not templates:
+        from .plan import _batches_tiles
+        if _batches_tiles(store):
+            # a stencil straight over a resident source: ONE task shades / filters all tiles into the mosaic (gm_batch);
+            # the scheduler computes the tiles' source windows
+            from .fuse import MosaicOfTiles
+            counts, args = [], []
+            for _, tile_request in pairs[1:]:
+                per_tile = list(store.get_sources_and_requests(**tile_request))
+                counts.append(len(per_tile))
+                for source, sub in per_tile:
+                    args.append(_graph_of(source, sub, graph) if isinstance(source, Block) and sub is not None else source)
+            graph[name] = (MosaicOfTiles(type(tiler).process, type(store)), kwargs, tuple(counts)) + tuple(args)
+            return name
         # a store with a kernel of its own, a single operation: tile by tile, pasted by the Block's own process
         names = [_graph_of(store, tile_request, graph) for _, tile_request in pairs[1:]]
         graph[name] = (type(tiler).process, kwargs) + tuple(names)

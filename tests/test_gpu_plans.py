@@ -148,7 +148,8 @@ def test_tiler_over_hillshade_in_one_launch(gpu, dtype, cell):
             tiler = raster.RasterTiler(shade, tile)
             what = "%s cell %s box %s tile %s" % (dtype, cell, box, tile)
             assert_result_equal(tiler.get_data(**request), whole, 0, what + " (plans)")
-            assert_result_equal(_graph_path(tiler, request), whole, 0, what + " (graph)")
+            assert_result_equal(_graph_path(tiler, request), whole, 0, what + " (graph from scratch)")
+            assert_result_equal(_template_path(tiler, request), whole, 0, what + " (graph from the template)")
 
 
 @pytest.mark.parametrize("dtype", ["f4", "u1", "i2", "i8", "f8"])
@@ -181,10 +182,10 @@ def test_tiler_over_stencils_writes_in_place(gpu, kind, dtype):
             if kind == "smooth":
                 # (a tile of a Smooth is not a window of the whole: the reference crops by `size` cells while the Gaussian
                 #  reaches 4/3 of that, spatial.py:262-290 -- the tiled results agree with each other)
-                assert_result_equal(tiler.get_data(**request), _graph_path(tiler, request), 0, what + " (plans vs graph)")
-                continue
+                whole = _graph_path(tiler, request)
             assert_result_equal(tiler.get_data(**request), whole, 0, what + " (plans)")
-            assert_result_equal(_graph_path(tiler, request), whole, 0, what + " (graph)")
+            assert_result_equal(_graph_path(tiler, request), whole, 0, what + " (graph from scratch)")
+            assert_result_equal(_template_path(tiler, request), whole, 0, what + " (graph from the template)")
 
 
 def test_stencil_blocks_through_plans(gpu):
