@@ -383,11 +383,13 @@ class TiledAssembly(object):
         return self.tiler_process(process_kwargs, *tiles)  # the reference's fill + paste
 
 
-def tiles_in_place(tiler_process, block_type, process_kwargs, calls):
-    """The tiles of a RasterTiler over a Block with ``gm_batch`` (a stencil over a resident source): ``calls`` = what
-    the Block's ``process`` would get tile by tile; its kernel writes every tile into its window of the mosaic (one
-    launch for all tiles where the Block has one).  The mosaic is the result only when the tiles cover it (TiledAssembly's
-    rule); otherwise the reference's fill + paste.  None when the Block declines these tiles."""
+def tiles_in_place(tiler_process, block_type, process_kwargs, calls, one_by_one=False):
+    """The tiles of a RasterTiler over a Block with ``gm_batch`` (a stencil): ``calls`` = what the Block's ``process``
+    would get tile by tile; its kernel writes every tile into its window of the mosaic (one launch for all tiles where
+    the Block has one).  The mosaic is the result only when the tiles cover it (TiledAssembly's rule); otherwise the
+    reference's fill + paste.  None when the Block declines these tiles.  ``one_by_one``: ``calls`` is consumed tile
+    after tile, each tile processed before the next one's arguments are asked for (a stencil over a COMPUTED store: the
+    intermediate tile is read back while the Infinity Cache still holds it)."""
     height, width = process_kwargs["shape_yx"]
     count_x, count_y = process_kwargs["count_xy"]
     tile_x, tile_y = process_kwargs["tilesize_xy"]
@@ -407,9 +409,15 @@ def tiles_in_place(tiler_process, block_type, process_kwargs, calls):
         state["covered"] += th * tw
         return state["mosaic"].window(row0, col0, th, tw)
 
-    responses = block_type.gm_batch(calls, dest)
-    if responses is None:
-        return None
+    if one_by_one:
+        responses = []
+        for i, call in enumerate(calls):
+            one = block_type.gm_batch([call], lambda _, shape, out_dtype, i=i: dest(i, shape, out_dtype))
+            responses.append(one[0] if one is not None else block_type.process(*call))
+    else:
+        responses = block_type.gm_batch(calls, dest)
+        if responses is None:
+            return None
     mosaic = state["mosaic"]
     in_place = mosaic is not None and len(responses) == count_x * count_y and all(
         isinstance(r, dict) and isinstance(r.get("values"), DeviceArray) and r["values"]._owner is mosaic for r in responses)

@@ -195,6 +195,20 @@ def _run_tiler(tiler, request):
                 done = _run_tiler_batch(tiler, store, kwargs, pairs[1:])
                 if done is not None:
                     return True, done
+            elif getattr(store, "gm_direct", False) and hasattr(type(store), "gm_batch"):
+                # over a computed store: tile after tile (the order that keeps the intermediates in the cache), each
+                # result still written straight into the mosaic
+                from .fuse import tiles_in_place
+                outer = getattr(_running, "memo", None)
+
+                def arguments():
+                    for _, tile_request in pairs[1:]:
+                        _running.memo = {}
+                        yield _process_arguments(store, tile_request)
+                try:
+                    return True, tiles_in_place(type(tiler).process, type(store), kwargs, arguments(), one_by_one=True)
+                finally:
+                    _running.memo = outer
             responses = []
             outer = getattr(_running, "memo", None)
             try:

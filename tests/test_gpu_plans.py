@@ -152,9 +152,10 @@ def test_tiler_over_hillshade_in_one_launch(gpu, dtype, cell):
             assert_result_equal(_template_path(tiler, request), whole, 0, what + " (graph from the template)")
 
 
+@pytest.mark.parametrize("over", ["source", "computed"])
 @pytest.mark.parametrize("dtype", ["f4", "u1", "i2", "i8", "f8"])
-@pytest.mark.parametrize("kind", ["dilate", "movingmax3", "movingmax7", "movingmax21", "smooth"])
-def test_tiler_over_stencils_writes_in_place(gpu, kind, dtype):
+@pytest.mark.parametrize("kind", ["dilate", "movingmax3", "movingmax7", "movingmax21", "smooth", "hillshade"])
+def test_tiler_over_stencils_writes_in_place(gpu, kind, dtype, over):
     """A RasterTiler over Dilate / MovingMax / Smooth of a resident source on the plan path: every tile's result is
     written straight into its window of the mosaic where the kernel route can (gm_*_into), pasted otherwise (8-byte
     cells, large footprints, ragged tilings) -- always the untiled Block's result and the graph path's mosaic."""
@@ -169,9 +170,16 @@ def test_tiler_over_stencils_writes_in_place(gpu, kind, dtype):
         a = a + rng.random(a.shape).astype(dt)
     a[0, ::17, ::11] = ndv
     A = raster.MemorySource(a, ndv, "EPSG:28992", 1.0, (0.0, 192.0))
+    if over == "computed":  # (a stencil over a computed store: tile after tile, still written in place)
+        if dt.kind == "f":
+            A = A * 2
+        elif kind == "dilate":
+            A = raster.Clip(A, A < 11)
+        else:
+            pytest.skip("integer stores: the element-wise result is at least int32 -- covered by the other dtypes")
     view = {"dilate": lambda: raster.Dilate(A, [3, 5, 7]), "movingmax3": lambda: raster.MovingMax(A, 3),
             "movingmax7": lambda: raster.MovingMax(A, 7), "movingmax21": lambda: raster.MovingMax(A, 21),
-            "smooth": lambda: raster.Smooth(A, 4.0)}[kind]()
+            "smooth": lambda: raster.Smooth(A, 4.0), "hillshade": lambda: raster.HillShade(A)}[kind]()
     for box in ((32.0, 32.0, 160.0, 160.0), (0.0, 0.0, 256.0, 192.0), (35.0, 37.0, 163.0, 133.0)):
         width, height = int(box[2] - box[0]), int(box[3] - box[1])
         request = dict(mode="vals", bbox=box, width=width, height=height, projection="EPSG:28992")

@@ -16,6 +16,8 @@ views = {"tiler(HillShade(A))": raster.RasterTiler(raster.HillShade(A), side),
          "tiler(Dilate(C, [3, 5]))": raster.RasterTiler(raster.Dilate(C, [3, 5]), side),
          "tiler(MovingMax(A, 5))": raster.RasterTiler(raster.MovingMax(A, 5), side),
          "tiler(Smooth(A, 2))": raster.RasterTiler(raster.Smooth(A, 2.0), side),
+         "tiler(MovingMax(A + B, 5))": raster.RasterTiler(raster.MovingMax(A + B, 5), side),
+         "tiler(Smooth(A * 2, 2))": raster.RasterTiler(raster.Smooth(A * 2, 2.0), side),
          "tiler(HillShade(A * 2 + B))": raster.RasterTiler(raster.HillShade(A * 2 + B), side),
          "tiler(HillShade(A) * 0.5 + B)": raster.RasterTiler(raster.HillShade(A) * 0.5 + B, side)}
 inner = 64.0
