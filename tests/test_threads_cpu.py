@@ -108,3 +108,25 @@ def test_spec_wait_returns_in_a_forked_child():
     os.kill(pid, 9)
     os.waitpid(pid, 0)
     raise AssertionError("gm_spec_wait() hung in the forked child")
+
+
+def test_tiler_over_a_stencil_on_a_source_is_one_graph_task():
+    """template.fused_compute_graph of a RasterTiler over a stencil Block on a resident source: ONE MosaicOfTiles task over
+    the tiles' source windows (the stencil writes every tile into the mosaic); over a computed store: a task per tile."""
+    from dask_geomodeling_amd.fuse import MosaicOfTiles
+    a = np.arange(64 * 64, dtype="f4").reshape(1, 64, 64)
+    source = raster.MemorySource(a, 255.0, "EPSG:28992", 1.0, (0.0, 64.0))
+    request = dict(mode="vals", bbox=(8.0, 8.0, 40.0, 40.0), width=32, height=32, projection="EPSG:28992")
+    for block in (raster.HillShade(source), raster.MovingMax(source, 3), raster.Dilate(source, [3.0]), raster.Smooth(source, 2.0)):
+        tiler = raster.RasterTiler(block, 16)
+        graph, name = template.fused_compute_graph(tiler, request)
+        task = graph[name]
+        assert isinstance(task[0], MosaicOfTiles), type(block).__name__
+        kwargs, counts, args = task[1], task[2], task[3:]
+        assert kwargs["count_xy"] == (2, 2) and counts == (2, 2, 2, 2) and len(args) == 8
+        assert all(isinstance(args[i], str) and args[i] in graph for i in range(0, 8, 2))  # the tiles' source windows
+        full, full_name = tiler.get_compute_graph(**request)
+        assert name == full_name
+    computed = raster.RasterTiler(raster.HillShade(source * 2), 16)
+    graph, name = template.fused_compute_graph(computed, request)
+    assert not isinstance(graph[name][0], MosaicOfTiles) and len(graph[name]) == 2 + 4
