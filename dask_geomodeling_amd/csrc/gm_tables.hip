@@ -817,9 +817,32 @@ int gm_classify2(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, c
     if (rc32) return rc32;
     if (nbins > CLS_LINEAR_MAX && (out_dtype == GM_U8 || out_dtype == GM_U16) && ((uintptr_t)in % 16) == 0 &&
         ((uintptr_t)out % 8) == 0 && n / 4 >= 4096) {
+      // (the grid of a threshold table is built once: 1024-8192 buckets x two binary searches each were ~25 us of
+      //  host time per call, more than the kernel takes for a 4096^2 tile)
       ClassifyGrid G;
       std::vector<unsigned short> base;
-      if (build_classify_grid(thr, nbins, right != 0, &G, &base)) {
+      bool have_grid;
+      {
+        static std::mutex grid_mu;
+        static std::map<std::pair<std::vector<float>, bool>, std::pair<ClassifyGrid, std::vector<unsigned short>>> grids;
+        std::lock_guard<std::mutex> lk(grid_mu);
+        const auto key = std::make_pair(std::vector<float>(thr, thr + nbins), right != 0);
+        auto it = grids.find(key);
+        if (it == grids.end()) {
+          ClassifyGrid made;
+          std::vector<unsigned short> made_base;
+          if (!build_classify_grid(thr, nbins, right != 0, &made, &made_base)) {
+            made.buckets = 0;
+            made_base.clear();
+          }
+          if (grids.size() > 64) grids.clear();
+          it = grids.emplace(key, std::make_pair(made, std::move(made_base))).first;
+        }
+        G = it->second.first;
+        base = it->second.second;
+        have_grid = G.buckets > 0;
+      }
+      if (have_grid) {
         std::vector<unsigned long long> packed_base((base.size() * 2 + 7) / 8 + 1, 0ull);
         memcpy(packed_base.data(), base.data(), base.size() * 2);
         packed_base.back() = 0x6B1Dull << 32 | (unsigned)G.buckets << 4 | (unsigned)G.scan;

@@ -85,6 +85,19 @@ run("A + B, 2x zoomed in", A + B, (2 * 5 + 12) * px, zoom_in)
 run("A + B, 2x zoomed out", A + B, (2 * 8 + 12) * px, zoom_out)
 run("A + B, half a cell off", A + B, (2 * 8 + 12) * px, shifted)
 run("HillShade(A), 2x zoomed in", raster.HillShade(A), (5 + 5) * px, zoom_in)
+# synthetic (procedural) sources and a Smooth that has to zoom (a margin beyond its threshold)
+S1 = raster.SyntheticSource((big, big), "f4", 9001, 0.0, 100.0, F32MAX, (97, 89), "EPSG:28992", 1.0, (0.0, float(big)), resident=False) \
+    if hasattr(raster, "SyntheticSource") else None
+if S1 is not None:
+    try:
+        run("Synthetic + B (generated per request)", S1 + B, (4 + 12) * px, [dict(req, bbox=b) for b in boxes])
+    except Exception as e:  # noqa: BLE001
+        print("SyntheticSource probe skipped:", type(e).__name__, str(e)[:80])
+run("Smooth(A, 40) (zoom mode)", raster.Smooth(A, 40.0), 8 * px, [dict(req, bbox=b) for b in boxes], n=30)
+run("Reclassify(C) + Mask (u8 table path)", raster.Mask(raster.Reclassify(C, [[1, 3], [2, 3], [5, 9]]), 1), 2 * px, [dict(req, bbox=b) for b in boxes])
+run("Classify(A, 200 edges)", raster.Classify(A, list(np.linspace(0, 100, 200))), 5 * px, [dict(req, bbox=b) for b in boxes])
+run("A ** 2.5 (Power)", A ** 2.5, 8 * px, [dict(req, bbox=b) for b in boxes])
+run("Exp(A / 50)", raster.Exp(A / 50), 8 * px, [dict(req, bbox=b) for b in boxes])
 small = [dict(mode="vals", bbox=(float(i * 256), float(j * 256), float(i * 256 + 256), float(j * 256 + 256)), width=256, height=256,
               projection="EPSG:28992") for i in range(1, 4) for j in range(1, 4)]
 run("A + B, 256^2 tiles", A + B, 12 * 256 * 256, small, n=900)
