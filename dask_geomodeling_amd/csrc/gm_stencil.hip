@@ -10,6 +10,11 @@
 // non-temporal stores; the moving maximum stages its (tile + 2 r) window in LDS because a pixel is
 // read by up to size^2 neighbours.
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
 #include <limits>
 
 #include "gm_common.h"
@@ -1055,40 +1060,147 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const T* __restrict
 // SciPy's correlate1d for a symmetric kernel, literally: the line extended with the constant, in
 // float64, out = x[0] w[0] + sum over j = r..1 of (x[-j] + x[+j]) w[j] (farthest pair first), cast to
 // the tile's dtype.  The first axis also performs values[values == ndv] = fill (spatial.py:284-285).
-constexpr int GAUSS_MAX_RADIUS = 64;
-struct GaussArgs {
-  double w[GAUSS_MAX_RADIUS + 1];  // w[j]: weight at distance j
-  int radius;
-  double cval;
-};
+// grid: the output is the window [y0, y0+oh) x [x0, x0+ow) of the filtered tile (the last axis of an "exact" Smooth
+// crops its margins); z over bands.
+constexpr int GAUSS_ROWS = 8;  // outputs per lane
 
-// grid: x over 256 output columns, y over output rows, z over bands; the output is the window
-// [y0, y0+oh) x [x0, x0+ow) of the filtered tile (the last axis of an "exact" Smooth crops its margins)
-// A lane owns GAUSS_ROWS consecutive output rows of one column: the weight of a tap pair is fetched once
-// (a scalar load) for all of them and 2 x GAUSS_ROWS tap loads are in flight per pair -- one output
-// per lane made a wave live through `radius` dependent scalar-load round trips for 64 pixels of work.
-constexpr int GAUSS_ROWS = 8;
+// The taps from LDS, through a sliding register window (round 4).  A lane owns 8 consecutive outputs ALONG the axis
+// (8 rows of a column for y, 8 columns of a row for x).  At distance j it needs lo[r] = x[c + r - j] and
+// hi[r] = x[c + r + j], r = 0..7; at distance j - 1 seven of each are the neighbours' values of the step before
+// (lo[r] <- lo[r + 1], hi[r] <- hi[r - 1]) -- so a step costs TWO LDS reads per lane, not sixteen, and the window can
+// hold the float64 values SciPy's line buffer holds (no data -> fill, outside the line -> cval, converted once when
+// staged) without the 8-byte reads becoming the bound.  The rotation is free: the loop over j is unrolled by 8 and
+// the registers are renamed (a ring of 8).  Round 3 served every tap as its own LDS read while the float64 window
+// fitted 64 KiB (radius 12 along y) and as its own global load after that: 895 us for the two axes of a 4096^2 tile at
+// radius 52, 2 x 104 loads per output.
+//   along y: a workgroup makes 8 G x COLS outputs (G = 256 / COLS row groups) from a (8 G + 2 r) x COLS window;
+//   along x: 4 rows x 512 columns (a wave per row) from 4 x (512 + 2 r) cells, column c of a row at
+//            (c & 7) S + (c >> 3): the lanes of a wave read cells 8 apart, which land on consecutive words.
+// Weights from device memory (scalar loads), so LDS alone bounds the radius.
+template <typename T, bool ALONG_X, int COLS>
+__global__ __launch_bounds__(256) void gauss_axis_slide_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
+                                                               int y0, int x0, int oh, int ow, int replace_ndv, T ndv,
+                                                               T fill, const double* __restrict__ wts, int radius,
+                                                               double cval) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* const tile = reinterpret_cast<double*>(smem);
+  const int tid = threadIdx.x, b = blockIdx.z;
+  const T* plane = in + (size_t)b * h * w;
+  auto line_value = [&](int sy, int sx) -> double {  // SciPy's extended line at (sy, sx); sy / sx may lie outside along the axis
+    const int cy = min(max(sy, 0), h - 1), cx = min(max(sx, 0), w - 1);
+    const T v = plane[(size_t)cy * w + cx];
+    const double inside = (double)((replace_ndv && v == ndv) ? fill : v);
+    const int along = ALONG_X ? sx : sy;
+    return (along < 0 || along >= (ALONG_X ? w : h)) ? cval : inside;
+  };
+  constexpr int G = 256 / COLS;  // row groups of a workgroup (along y)
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tx = tid % COLS, group = tid / COLS;
+  const int S = (((512 + 2 * radius + 7) >> 3) | 1);  // (odd: the 8 residues of a row land on different banks)
+  int ox0, oy0;
+  if (ALONG_X) {
+    ox0 = blockIdx.x * 512;
+    oy0 = blockIdx.y * 4;
+    const int win_cols = 512 + 2 * radius;
+    for (int c = tid; c < win_cols; c += 256) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = line_value(y0 + oy0 + u, x0 + ox0 + c - radius);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) tile[u * 8 * S + (c & 7) * S + (c >> 3)] = v[u];
+    }
+  } else {
+    ox0 = blockIdx.x * COLS;
+    oy0 = blockIdx.y * (GAUSS_ROWS * G);
+    const int win_h = GAUSS_ROWS * G + 2 * radius;
+    constexpr int SB = 8;  // window rows fetched together per lane
+    for (int wy0 = group; wy0 < win_h; wy0 += G * SB) {
+      double v[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) v[u] = line_value(y0 + oy0 + min(wy0 + G * u, win_h - 1) - radius, x0 + ox0 + tx);
+#pragma unroll
+      for (int u = 0; u < SB; ++u)
+        if (wy0 + G * u < win_h) tile[(wy0 + G * u) * COLS + tx] = v[u];
+    }
+  }
+  __syncthreads();
+  // W(k): cell k of this lane's line through the window; output r of the lane has its centre at W(c0 + r)
+  const double* const mine = ALONG_X ? tile + wave * 8 * S : tile + tx;
+  auto W = [&](int k) -> double { return ALONG_X ? mine[(k & 7) * S + (k >> 3)] : mine[k * COLS]; };
+  const int c0 = (ALONG_X ? 8 * lane : GAUSS_ROWS * group) + radius;
+  if (ALONG_X ? (ox0 + 8 * lane >= ow || oy0 + wave >= oh) : (ox0 + tx >= ow)) return;
+  double acc[GAUSS_ROWS], lo[GAUSS_ROWS], hi[GAUSS_ROWS];
+  {
+    const double w0 = wts[0];
+#pragma unroll
+    for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] = W(c0 + r) * w0;
+  }
+  int j = radius;
+  for (int odd = radius & 7; odd > 0; --odd, --j) {  // the steps that do not fill a round of 8: every tap its own read
+    const double wj = wts[j];
+#pragma unroll
+    for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] += (W(c0 + r - j) + W(c0 + r + j)) * wj;
+  }
+  if (j >= 8) {
+#pragma unroll
+    for (int r = 0; r < GAUSS_ROWS; ++r) {
+      lo[r] = W(c0 + r - j);
+      hi[r] = W(c0 + r + j);
+    }
+  }
+  for (; j >= 8; j -= 8) {  // farthest pair first, as SciPy adds them
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int jj = j - s;
+      const double wj = wts[jj];
+#pragma unroll
+      for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] += (lo[(r + s) & 7] + hi[(r - s) & 7]) * wj;
+      lo[s & 7] = W(c0 + 8 - jj);        // the new last `lo` of distance jj - 1 takes the place of the first of distance jj
+      hi[(7 - s) & 7] = W(c0 + jj - 1);  // the new first `hi` takes the place of the last
+    }
+  }
+  if (ALONG_X) {
+    T* const row = out + ((size_t)b * oh + oy0 + wave) * ow + ox0 + 8 * lane;
+    const int count = min(GAUSS_ROWS, ow - (ox0 + 8 * lane));
+    constexpr int PER16 = 16 / (int)sizeof(T);
+    if (count == GAUSS_ROWS && ((uintptr_t)row & 15) == 0 && PER16 <= GAUSS_ROWS) {
+      T packed[GAUSS_ROWS];
+#pragma unroll
+      for (int r = 0; r < GAUSS_ROWS; ++r) packed[r] = (T)acc[r];
+#pragma unroll
+      for (int q = 0; q < GAUSS_ROWS / PER16; ++q)
+        *reinterpret_cast<uint4*>(row + q * PER16) = *reinterpret_cast<const uint4*>(packed + q * PER16);
+    } else {
+#pragma unroll
+      for (int r = 0; r < GAUSS_ROWS; ++r)
+        if (r < count) row[r] = (T)acc[r];
+    }
+  } else {
+    const int row0 = oy0 + GAUSS_ROWS * group;
+#pragma unroll
+    for (int r = 0; r < GAUSS_ROWS; ++r)
+      if (row0 + r < oh) out[((size_t)b * oh + row0 + r) * ow + ox0 + tx] = (T)acc[r];
+  }
+}
+
+// From memory, any radius (a window that does not fit LDS): the kernel of round 3 with its weights in device memory.
 template <typename T, bool ALONG_X>
-__global__ __launch_bounds__(256) void gauss_axis_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                         int y0, int x0, int oh, int ow, int replace_ndv, T ndv, T fill,
-                                                         GaussArgs A) {
+__global__ __launch_bounds__(256) void gauss_axis_far_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
+                                                             int y0, int x0, int oh, int ow, int replace_ndv, T ndv, T fill,
+                                                             const double* __restrict__ wts, int radius, double cval) {
   const int ox = blockIdx.x * 256 + threadIdx.x, oy0 = blockIdx.y * GAUSS_ROWS, b = blockIdx.z;
   if (ox >= ow) return;
   const int x = x0 + ox;
   const T* plane = in + (size_t)b * h * w;
   const int n = ALONG_X ? w : h;
-  // element i of the line through output row r of this lane: an unconditional load from the clamped index (`fetch`), the
-  // constants selected afterwards (`value`).  All loads of a step are written -- and so issued -- before the first of them
-  // is looked at: with every value examined right behind its load the compiler waited for each load before it issued
-  // the next (round 3: 16 memory round trips per tap pair).
   auto fetch = [&](int r, int i) -> T {
-    const int y = min(y0 + oy0 + r, h - 1);  // (rows past the window are computed and not stored)
+    const int y = min(y0 + oy0 + r, h - 1);
     const int ic = min(max(i, 0), n - 1);
     return ALONG_X ? plane[(size_t)y * w + ic] : plane[(size_t)ic * w + x];
   };
   auto value = [&](T v, int i) -> double {
     const double inside = (double)((replace_ndv && v == ndv) ? fill : v);
-    return (i < 0 || i >= n) ? A.cval : inside;
+    return (i < 0 || i >= n) ? cval : inside;
   };
   auto centre = [&](int r) { return ALONG_X ? x : y0 + oy0 + r; };
   double acc[GAUSS_ROWS];
@@ -1096,11 +1208,12 @@ __global__ __launch_bounds__(256) void gauss_axis_kernel(const T* __restrict__ i
     T raw[GAUSS_ROWS];
 #pragma unroll
     for (int r = 0; r < GAUSS_ROWS; ++r) raw[r] = fetch(r, centre(r));
+    const double w0 = wts[0];
 #pragma unroll
-    for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] = value(raw[r], centre(r)) * A.w[0];
+    for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] = value(raw[r], centre(r)) * w0;
   }
-  for (int j = A.radius; j >= 1; --j) {  // farthest pair first, as SciPy adds them
-    const double wj = A.w[j];
+  for (int j = radius; j >= 1; --j) {
+    const double wj = wts[j];
     T raw_lo[GAUSS_ROWS], raw_hi[GAUSS_ROWS];
 #pragma unroll
     for (int r = 0; r < GAUSS_ROWS; ++r) {
@@ -1109,63 +1222,6 @@ __global__ __launch_bounds__(256) void gauss_axis_kernel(const T* __restrict__ i
     }
 #pragma unroll
     for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] += (value(raw_lo[r], centre(r) - j) + value(raw_hi[r], centre(r) + j)) * wj;
-  }
-#pragma unroll
-  for (int r = 0; r < GAUSS_ROWS; ++r)
-    if (oy0 + r < oh) out[((size_t)b * oh + oy0 + r) * ow + ox] = (T)acc[r];
-}
-
-// The same pass with the taps served from LDS: a workgroup stages the window its 8 x 256 outputs read --
-// (8 + 2 r) x 256 cells along y, 8 x (256 + 2 r) along x -- once, already as the float64 values SciPy's
-// line buffer holds (no data -> fill, cells outside the line -> cval), all loads of a lane in flight
-// before the first LDS write; every output then reads its 2 r + 1 taps from LDS instead of issuing as
-// many 4-byte global loads.  Used while the window fits 64 KiB (r <= 12 along y).
-template <typename T, bool ALONG_X>
-__global__ __launch_bounds__(256) void gauss_axis_lds_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                             int y0, int x0, int oh, int ow, int replace_ndv, T ndv,
-                                                             T fill, GaussArgs A) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  double* const tile = reinterpret_cast<double*>(smem);
-  const int radius = A.radius;
-  const int ox0 = blockIdx.x * 256, oy0 = blockIdx.y * GAUSS_ROWS, b = blockIdx.z;
-  const T* plane = in + (size_t)b * h * w;
-  const int n = ALONG_X ? w : h;
-  const int win_w = ALONG_X ? 256 + 2 * radius : 256, win_h = ALONG_X ? GAUSS_ROWS : GAUSS_ROWS + 2 * radius;
-  auto cell = [&](int wy, int wx) -> double {  // window cell -> the float64 value of SciPy's extended line
-    const int sy = y0 + oy0 + wy - (ALONG_X ? 0 : radius), sx = x0 + ox0 + wx - (ALONG_X ? radius : 0);
-    const int along = ALONG_X ? sx : sy;
-    const int cy = min(max(sy, 0), h - 1), cx = min(max(sx, 0), w - 1);
-    const T v = plane[(size_t)cy * w + cx];
-    const double inside = (double)((replace_ndv && v == ndv) ? fill : v);
-    return (along < 0 || along >= n) ? A.cval : inside;
-  };
-  constexpr int SB = 8;  // window rows fetched together per lane
-  for (int wx = threadIdx.x; wx < win_w; wx += 256) {
-    for (int wy0 = 0; wy0 < win_h; wy0 += SB) {
-      double v[SB];
-#pragma unroll
-      for (int u = 0; u < SB; ++u) v[u] = cell(min(wy0 + u, win_h - 1), wx);
-#pragma unroll
-      for (int u = 0; u < SB; ++u)
-        if (wy0 + u < win_h) tile[(wy0 + u) * win_w + wx] = v[u];
-    }
-  }
-  __syncthreads();
-  const int ox = ox0 + threadIdx.x;
-  if (ox >= ow) return;
-  // this lane's taps: along x the cells (r, threadIdx.x + radius +- j), along y the cells (r + radius +- j, threadIdx.x)
-  const int step = ALONG_X ? 1 : win_w;
-  double acc[GAUSS_ROWS];
-  const double* centre[GAUSS_ROWS];
-#pragma unroll
-  for (int r = 0; r < GAUSS_ROWS; ++r) {
-    centre[r] = tile + (ALONG_X ? r * win_w + threadIdx.x + radius : (r + radius) * win_w + threadIdx.x);
-    acc[r] = centre[r][0] * A.w[0];
-  }
-  for (int j = radius; j >= 1; --j) {  // farthest pair first, as SciPy adds them
-    const double wj = A.w[j];
-#pragma unroll
-    for (int r = 0; r < GAUSS_ROWS; ++r) acc[r] += (centre[r][-j * step] + centre[r][j * step]) * wj;
   }
 #pragma unroll
   for (int r = 0; r < GAUSS_ROWS; ++r)
@@ -1305,6 +1361,90 @@ static inline int out_pitch_or(int ow) { return t_out_pitch ? t_out_pitch : ow; 
   do {                                                                                                           \
     if (t_out_pitch) return gm::fail(GM_ERR_UNSUPPORTED, what ": this route writes compact tiles only");         \
   } while (0)
+
+namespace {
+// Gaussian weights in device memory, keyed by content (a Smooth block asks for the same one or two kernels all day)
+std::mutex g_weights_mu;
+std::map<std::pair<int, std::vector<double>>, void*> g_weights;
+
+int cached_weights(const double* host, int count, const double** dev_out) {
+  int dev = 0;
+  GM_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_weights_mu);
+  auto key = std::make_pair(dev, std::vector<double>(host, host + count));
+  auto it = g_weights.find(key);
+  if (it != g_weights.end()) {
+    *dev_out = (const double*)it->second;
+    return GM_OK;
+  }
+  if (g_weights.size() > 256) {  // bounded: drop everything once nothing in flight reads it
+    hipStream_t s = gm::current_stream();
+    if (s) (void)hipStreamSynchronize(s);
+    for (auto& kv : g_weights) gm_free(kv.second);
+    g_weights.clear();
+  }
+  void* buf = nullptr;
+  int rc = gm_malloc(&buf, sizeof(double) * (size_t)count);
+  if (rc) return rc;
+  rc = gm_h2d(buf, key.second.data(), sizeof(double) * (size_t)count);  // (the key's copy outlives the asynchronous upload)
+  if (rc) {
+    gm_free(buf);
+    return rc;
+  }
+  g_weights.emplace(std::move(key), buf);
+  *dev_out = (const double*)buf;
+  return GM_OK;
+}
+
+constexpr size_t kGaussLdsDefault = 64 * 1024, kGaussLdsMax = 160 * 1024;
+
+template <typename T, bool ALONG_X, int COLS>
+int launch_gauss_slide(size_t lds, const void* in, void* out, int bands, int h, int w, int y0, int x0, int oh, int ow,
+                       int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, const double* wts, int radius, double cval,
+                       hipStream_t s) {
+  auto kernel = gauss_axis_slide_kernel<T, ALONG_X, COLS>;
+  if (lds > kGaussLdsDefault)  // (a table lookup in the runtime after the first time)
+    GM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGaussLdsMax));
+  constexpr int rows_wg = ALONG_X ? 4 : GAUSS_ROWS * (256 / COLS), cols_wg = ALONG_X ? 512 : COLS;
+  dim3 grid((unsigned)((ow + cols_wg - 1) / cols_wg), (unsigned)((oh + rows_wg - 1) / rows_wg), (unsigned)bands);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, (const T*)in, (T*)out, h, w, y0, x0, oh, ow, replace_ndv,
+                     from_bits<T>(ndv_bits), from_bits<T>(fill_bits), wts, radius, cval);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+template <typename T, bool ALONG_X>
+int launch_gauss_axis(const void* in, void* out, int bands, int h, int w, int y0, int x0, int oh, int ow, int replace_ndv,
+                      uint64_t ndv_bits, uint64_t fill_bits, const double* wts, int radius, double cval, hipStream_t s) {
+  static const bool from_memory = getenv("GM_GAUSS_FAR") && atoi(getenv("GM_GAUSS_FAR"));
+  static const int force_cols = getenv("GM_GAUSS_COLS") ? atoi(getenv("GM_GAUSS_COLS")) : 0;
+#define GM_SLIDE(COLS) \
+  return launch_gauss_slide<T, ALONG_X, COLS>(lds, in, out, bands, h, w, y0, x0, oh, ow, replace_ndv, ndv_bits, fill_bits, wts, radius, cval, s)
+  if (!from_memory) {
+    if (ALONG_X) {
+      const size_t lds = (size_t)4 * 8 * ((((size_t)512 + 2 * (size_t)radius + 7) >> 3) | 1) * sizeof(double);
+      if (lds <= kGaussLdsMax) GM_SLIDE(64);
+    } else {
+      // 16 columns x 128 rows per workgroup from radius 8 on: the window is read (128 + 2 r) / 128 times over and
+      // several workgroups share a CU (y pass of a 4096^2 float32 tile at radius 52: 64 columns 217 us, 32: 158, 16: 135;
+      // radius 104: 562 / 305 / 244; below radius 8 the three are equal and 64 columns read whole 256-byte rows)
+      const int want = force_cols ? force_cols : (radius >= 8 ? 16 : 64);
+      const size_t lds = ((size_t)GAUSS_ROWS * (256 / want) + 2 * (size_t)radius) * want * sizeof(double);
+      if (lds <= kGaussLdsMax) {
+        if (want == 64) GM_SLIDE(64);
+        if (want == 32) GM_SLIDE(32);
+        GM_SLIDE(16);
+      }
+    }
+  }
+#undef GM_SLIDE
+  dim3 grid((unsigned)((ow + 255) / 256), (unsigned)((oh + GAUSS_ROWS - 1) / GAUSS_ROWS), (unsigned)bands);
+  hipLaunchKernelGGL((gauss_axis_far_kernel<T, ALONG_X>), grid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, y0, x0, oh,
+                     ow, replace_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), wts, radius, cval);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -1541,54 +1681,37 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
   if (!in || !out || !weights_host) return gm::fail(GM_ERR_INVALID, "null pointer");
   if (gm::dtype_size(dtype) == 0) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: dtype %d", dtype);
   if (axis != 1 && axis != 2) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: axis %d (1 = y, 2 = x)", axis);
-  if (radius < 0 || radius > GAUSS_MAX_RADIUS) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: radius %d (max %d)", radius, GAUSS_MAX_RADIUS);
+  if (radius < 0 || radius > (1 << 24)) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: radius %d", radius);
   if (bands <= 0 || oh <= 0 || ow <= 0) return GM_OK;
   if (y0 < 0 || x0 < 0 || y0 + oh > h || x0 + ow > w) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: output window outside the tile");
-  if (bands > 65535 || oh > 65535 * GAUSS_ROWS) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: tile too tall / too many bands");
+  if (bands > 65535 || oh > 65535 * 4) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: tile too tall / too many bands");
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
-  GaussArgs A;
-  memset(&A, 0, sizeof(A));
-  for (int j = 0; j <= radius; ++j) A.w[j] = weights_host[j];
-  A.radius = radius;
-  A.cval = cval;
-  dim3 grid((unsigned)((ow + 255) / 256), (unsigned)((oh + GAUSS_ROWS - 1) / GAUSS_ROWS), (unsigned)bands);
-  const size_t lds_x = (size_t)GAUSS_ROWS * (256 + 2 * radius) * 8, lds_y = (size_t)(GAUSS_ROWS + 2 * radius) * 256 * 8;
-  const bool staged = (axis == 2 ? lds_x : lds_y) <= 64 * 1024;
-#define GM_GAUSS(T)                                                                                            \
-  do {                                                                                                         \
-    if (staged && axis == 2)                                                                                   \
-      hipLaunchKernelGGL((gauss_axis_lds_kernel<T, true>), grid, dim3(256), lds_x, s, (const T*)in, (T*)out, h, w, y0, \
-                         x0, oh, ow, replace_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);         \
-    else if (staged)                                                                                           \
-      hipLaunchKernelGGL((gauss_axis_lds_kernel<T, false>), grid, dim3(256), lds_y, s, (const T*)in, (T*)out, h, w, y0, \
-                         x0, oh, ow, replace_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);         \
-    else if (axis == 2)                                                                                        \
-      hipLaunchKernelGGL((gauss_axis_kernel<T, true>), grid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, y0, \
-                         x0, oh, ow, replace_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);         \
-    else                                                                                                       \
-      hipLaunchKernelGGL((gauss_axis_kernel<T, false>), grid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, y0, \
-                         x0, oh, ow, replace_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A);         \
-  } while (0)
+  const double* wts = nullptr;
+  int rc = cached_weights(weights_host, radius + 1, &wts);
+  if (rc) return rc;
+#define GM_GAUSS(T)                                                                                                       \
+  return axis == 2 ? launch_gauss_axis<T, true>(in, out, bands, h, w, y0, x0, oh, ow, replace_ndv, ndv_bits, fill_bits, wts, \
+                                                radius, cval, s)                                                          \
+                   : launch_gauss_axis<T, false>(in, out, bands, h, w, y0, x0, oh, ow, replace_ndv, ndv_bits, fill_bits, wts, \
+                                                 radius, cval, s)
   // integer tiles: SciPy filters in float64 and stores with a C cast (truncation), measured against
   // scipy.ndimage.gaussian_filter(output=<integer array>)
   switch (dtype) {
-    case GM_F32: GM_GAUSS(float); break;
-    case GM_F64: GM_GAUSS(double); break;
+    case GM_F32: GM_GAUSS(float);
+    case GM_F64: GM_GAUSS(double);
     case GM_BOOL:  // (SciPy stores into a bool array with the C cast to npy_bool = unsigned char: truncation)
-    case GM_U8: GM_GAUSS(unsigned char); break;
-    case GM_I8: GM_GAUSS(signed char); break;
-    case GM_U16: GM_GAUSS(unsigned short); break;
-    case GM_I16: GM_GAUSS(short); break;
-    case GM_U32: GM_GAUSS(unsigned int); break;
-    case GM_I32: GM_GAUSS(int); break;
-    case GM_U64: GM_GAUSS(unsigned long long); break;
-    case GM_I64: GM_GAUSS(long long); break;
+    case GM_U8: GM_GAUSS(unsigned char);
+    case GM_I8: GM_GAUSS(signed char);
+    case GM_U16: GM_GAUSS(unsigned short);
+    case GM_I16: GM_GAUSS(short);
+    case GM_U32: GM_GAUSS(unsigned int);
+    case GM_I32: GM_GAUSS(int);
+    case GM_U64: GM_GAUSS(unsigned long long);
+    case GM_I64: GM_GAUSS(long long);
     default: return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: dtype %d", dtype);
   }
 #undef GM_GAUSS
-  GM_HIP(hipGetLastError());
-  return GM_OK;
 }
 
 int gm_gauss_2d(const void* in, int dtype, int bands, int h, int w, const double* weights_y, const double* weights_x,

@@ -436,7 +436,8 @@ int gm_hillshade_batch(int n_tiles, const void* const* in, int dtype, int h, int
  * (spatial.py:276-290; mode="constant"): weights_host[j] = weight at distance j (radius + 1 float64
  * values), accumulation in float64 in SciPy's order, result cast to the tile's dtype (float32 /
  * float64; integer tiles are truncated like SciPy's C cast).  replace_ndv: cells equal to ndv are read as fill (the first axis of Smooth does
- * values[values == ndv] = fill).  out = the window [y0, y0+oh) x [x0, x0+ow) of the filtered tile. */
+ * values[values == ndv] = fill).  out = the window [y0, y0+oh) x [x0, x0+ow) of the filtered tile.  Any radius (a zoomed
+ * Smooth request of N pixels can ask for up to 2 N / 3): the weights are kept in device memory, keyed by content. */
 int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, const double* weights_host, int radius,
                   double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh, int ow,
                   void* out);

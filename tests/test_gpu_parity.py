@@ -1207,9 +1207,9 @@ def test_clip_by_folded_comparison(gpu, dt, ndv):
 @pytest.mark.parametrize("dt", ["f4", "f8"])
 @pytest.mark.parametrize("sigma", [(0.5, 0.5), (2.0, 1.0), (3.0, 3.0), (5.5, 0.0), (1.0, 7.0)])
 def test_gauss_axis_kernels_against_oracle(gpu, dt, sigma):
-    """Both Gaussian kernels -- taps from LDS (radius <= 12 along y) and taps from memory (larger radii) --
-    on ragged tiles larger than a workgroup window, several bands, no data and a non-zero fill, against
-    the oracle's restatement of SciPy's correlate1d (bit-exact)."""
+    """The one-axis Gaussian kernel (taps through a sliding register window fed from LDS) on ragged tiles larger
+    than a workgroup window, several bands, no data and a non-zero fill, against the oracle's restatement of
+    SciPy's correlate1d (bit-exact); radii below 8 (every tap its own read), 8..16 and with a remainder."""
     from dask_geomodeling_amd.raster import stencil
     rng = np.random.default_rng(int(sigma[0] * 10 + sigma[1] * 100))
     ndv = np.dtype(dt).type(-9999.0)
@@ -1226,6 +1226,41 @@ def test_gauss_axis_kernels_against_oracle(gpu, dt, sigma):
                 work = O.gaussian_axis(work, s, axis, fill)
         want = work[:, crop[0]:work.shape[1] - crop[0], crop[1]:work.shape[2] - crop[1]]
         assert got.dtype == want.dtype and np.array_equal(got, want), (dt, sigma, fill, crop)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f4", "f8", "i2", "u1", "i8", "?"])
+@pytest.mark.parametrize("shape,sigma,crop", [
+    ((2, 300, 517), (13.07, 13.07), (40, 40)),   # the zoom mode of a 40-pixel Smooth: radius 52 both ways
+    ((1, 300, 517), (30.0, 2.0), (0, 0)),        # radius 120 along y: a window beyond 64 KiB of LDS
+    ((1, 97, 1030), (0.7, 50.3), (3, 7)),        # radius 201 along x, lines shorter than the radius along y
+    ((1, 700, 130), (80.0, 80.0), (0, 0)),       # radius 320 > the tile's width
+    ((1, 64, 64), (100.0, 100.0), (0, 0)),       # the kernel many times the tile
+    ((1, 1200, 70), (200.0, 3.0), (5, 5)),       # radius 800 along y: no window fits, taps from memory
+    ((1, 40, 5000), (2.0, 600.0), (0, 9)),       # radius 2400 along x: the same for the other axis
+])
+def test_gauss_any_radius(gpu, dt, shape, sigma, crop):
+    """Smooth has no largest radius (spatial.py:216-318: a zoomed request of N pixels can ask for up to 2 N / 3): the
+    sliding-window kernel while its window fits 160 KiB of LDS, taps from memory beyond, weights from device memory either
+    way -- bit-exact against the oracle's restatement of SciPy for every dtype family, no data, a fill the dtype cannot
+    hold, several bands, crops."""
+    from dask_geomodeling_amd.raster import stencil
+    rng = np.random.default_rng(shape[1] + shape[2])
+    if dt == "?":
+        v, ndv = rng.random(shape) < 0.5, None
+    else:
+        v = (rng.random(shape) * 200).astype(dt)
+        ndv = np.array(199 if dt == "u1" else 200).astype(dt)[()]
+        v[:, ::7, ::5] = ndv
+    for fill in (3, 0.25):
+        got = stencil.gaussian_smooth(v, ndv, fill, sigma, crop, fused=False).to_numpy()
+        work = v.copy()
+        if ndv is not None:
+            work[work == ndv] = fill
+        for axis, s in ((1, sigma[0]), (2, sigma[1])):
+            work = O.gaussian_axis(work, s, axis, fill)
+        want = work[:, crop[0]:work.shape[1] - crop[0], crop[1]:work.shape[2] - crop[1]]
+        assert got.dtype == want.dtype and np.array_equal(got, want), (dt, shape, sigma, fill)
 
 
 @pytest.mark.gpu
