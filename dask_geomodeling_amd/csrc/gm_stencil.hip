@@ -1078,17 +1078,17 @@ constexpr int GAUSS_ROWS = 8;  // outputs per lane
 //            (c & 7) S + (c >> 3): the lanes of a wave read cells 8 apart, which land on consecutive words.
 // Weights from device memory (scalar loads), so LDS alone bounds the radius.
 template <typename T, bool ALONG_X, int COLS>
-__global__ __launch_bounds__(256) void gauss_axis_slide_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
+__global__ __launch_bounds__(256) void gauss_axis_slide_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w, int pitch,
                                                                int y0, int x0, int oh, int ow, int replace_ndv, T ndv,
                                                                T fill, const double* __restrict__ wts, int radius,
                                                                double cval) {
   extern __shared__ __align__(16) unsigned char smem[];
   double* const tile = reinterpret_cast<double*>(smem);
   const int tid = threadIdx.x, b = blockIdx.z;
-  const T* plane = in + (size_t)b * h * w;
+  const T* plane = in + (size_t)b * h * pitch;
   auto line_value = [&](int sy, int sx) -> double {  // SciPy's extended line at (sy, sx); sy / sx may lie outside along the axis
     const int cy = min(max(sy, 0), h - 1), cx = min(max(sx, 0), w - 1);
-    const T v = plane[(size_t)cy * w + cx];
+    const T v = plane[(size_t)cy * pitch + cx];
     const double inside = (double)((replace_ndv && v == ndv) ? fill : v);
     const int along = ALONG_X ? sx : sy;
     return (along < 0 || along >= (ALONG_X ? w : h)) ? cval : inside;
@@ -1185,18 +1185,18 @@ __global__ __launch_bounds__(256) void gauss_axis_slide_kernel(const T* __restri
 
 // From memory, any radius (a window that does not fit LDS): the kernel of round 3 with its weights in device memory.
 template <typename T, bool ALONG_X>
-__global__ __launch_bounds__(256) void gauss_axis_far_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
+__global__ __launch_bounds__(256) void gauss_axis_far_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w, int pitch,
                                                              int y0, int x0, int oh, int ow, int replace_ndv, T ndv, T fill,
                                                              const double* __restrict__ wts, int radius, double cval) {
   const int ox = blockIdx.x * 256 + threadIdx.x, oy0 = blockIdx.y * GAUSS_ROWS, b = blockIdx.z;
   if (ox >= ow) return;
   const int x = x0 + ox;
-  const T* plane = in + (size_t)b * h * w;
+  const T* plane = in + (size_t)b * h * pitch;
   const int n = ALONG_X ? w : h;
   auto fetch = [&](int r, int i) -> T {
     const int y = min(y0 + oy0 + r, h - 1);
     const int ic = min(max(i, 0), n - 1);
-    return ALONG_X ? plane[(size_t)y * w + ic] : plane[(size_t)ic * w + x];
+    return ALONG_X ? plane[(size_t)y * pitch + ic] : plane[(size_t)ic * pitch + x];
   };
   auto value = [&](T v, int i) -> double {
     const double inside = (double)((replace_ndv && v == ndv) ? fill : v);
@@ -1399,7 +1399,7 @@ int cached_weights(const double* host, int count, const double** dev_out) {
 constexpr size_t kGaussLdsDefault = 64 * 1024, kGaussLdsMax = 160 * 1024;
 
 template <typename T, bool ALONG_X, int COLS>
-int launch_gauss_slide(size_t lds, const void* in, void* out, int bands, int h, int w, int y0, int x0, int oh, int ow,
+int launch_gauss_slide(size_t lds, const void* in, int pitch, void* out, int bands, int h, int w, int y0, int x0, int oh, int ow,
                        int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, const double* wts, int radius, double cval,
                        hipStream_t s) {
   auto kernel = gauss_axis_slide_kernel<T, ALONG_X, COLS>;
@@ -1407,19 +1407,19 @@ int launch_gauss_slide(size_t lds, const void* in, void* out, int bands, int h, 
     GM_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGaussLdsMax));
   constexpr int rows_wg = ALONG_X ? 4 : GAUSS_ROWS * (256 / COLS), cols_wg = ALONG_X ? 512 : COLS;
   dim3 grid((unsigned)((ow + cols_wg - 1) / cols_wg), (unsigned)((oh + rows_wg - 1) / rows_wg), (unsigned)bands);
-  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, (const T*)in, (T*)out, h, w, y0, x0, oh, ow, replace_ndv,
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, (const T*)in, (T*)out, h, w, pitch, y0, x0, oh, ow, replace_ndv,
                      from_bits<T>(ndv_bits), from_bits<T>(fill_bits), wts, radius, cval);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
 
 template <typename T, bool ALONG_X>
-int launch_gauss_axis(const void* in, void* out, int bands, int h, int w, int y0, int x0, int oh, int ow, int replace_ndv,
+int launch_gauss_axis(const void* in, int pitch, void* out, int bands, int h, int w, int y0, int x0, int oh, int ow, int replace_ndv,
                       uint64_t ndv_bits, uint64_t fill_bits, const double* wts, int radius, double cval, hipStream_t s) {
   static const bool from_memory = getenv("GM_GAUSS_FAR") && atoi(getenv("GM_GAUSS_FAR"));
   static const int force_cols = getenv("GM_GAUSS_COLS") ? atoi(getenv("GM_GAUSS_COLS")) : 0;
 #define GM_SLIDE(COLS) \
-  return launch_gauss_slide<T, ALONG_X, COLS>(lds, in, out, bands, h, w, y0, x0, oh, ow, replace_ndv, ndv_bits, fill_bits, wts, radius, cval, s)
+  return launch_gauss_slide<T, ALONG_X, COLS>(lds, in, pitch, out, bands, h, w, y0, x0, oh, ow, replace_ndv, ndv_bits, fill_bits, wts, radius, cval, s)
   if (!from_memory) {
     if (ALONG_X) {
       const size_t lds = (size_t)4 * 8 * ((((size_t)512 + 2 * (size_t)radius + 7) >> 3) | 1) * sizeof(double);
@@ -1439,7 +1439,7 @@ int launch_gauss_axis(const void* in, void* out, int bands, int h, int w, int y0
   }
 #undef GM_SLIDE
   dim3 grid((unsigned)((ow + 255) / 256), (unsigned)((oh + GAUSS_ROWS - 1) / GAUSS_ROWS), (unsigned)bands);
-  hipLaunchKernelGGL((gauss_axis_far_kernel<T, ALONG_X>), grid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, y0, x0, oh,
+  hipLaunchKernelGGL((gauss_axis_far_kernel<T, ALONG_X>), grid, dim3(256), 0, s, (const T*)in, (T*)out, h, w, pitch, y0, x0, oh,
                      ow, replace_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), wts, radius, cval);
   GM_HIP(hipGetLastError());
   return GM_OK;
@@ -1675,11 +1675,13 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
   return GM_OK;
 }
 
-int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, const double* weights_host, int radius,
+int gm_gauss_axis_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, int axis, const double* weights_host, int radius,
                   double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh, int ow,
                   void* out) {
   if (!in || !out || !weights_host) return gm::fail(GM_ERR_INVALID, "null pointer");
   if (gm::dtype_size(dtype) == 0) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: dtype %d", dtype);
+  if (in_pitch < w) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: pitch %d of a %d-wide tile", in_pitch, w);
+  if (in_pitch != w && bands != 1) return gm::fail(GM_ERR_UNSUPPORTED, "gm_gauss_axis: a window of %d bands", bands);
   if (axis != 1 && axis != 2) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: axis %d (1 = y, 2 = x)", axis);
   if (radius < 0 || radius > (1 << 24)) return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: radius %d", radius);
   if (bands <= 0 || oh <= 0 || ow <= 0) return GM_OK;
@@ -1691,9 +1693,9 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
   int rc = cached_weights(weights_host, radius + 1, &wts);
   if (rc) return rc;
 #define GM_GAUSS(T)                                                                                                       \
-  return axis == 2 ? launch_gauss_axis<T, true>(in, out, bands, h, w, y0, x0, oh, ow, replace_ndv, ndv_bits, fill_bits, wts, \
+  return axis == 2 ? launch_gauss_axis<T, true>(in, in_pitch, out, bands, h, w, y0, x0, oh, ow, replace_ndv, ndv_bits, fill_bits, wts, \
                                                 radius, cval, s)                                                          \
-                   : launch_gauss_axis<T, false>(in, out, bands, h, w, y0, x0, oh, ow, replace_ndv, ndv_bits, fill_bits, wts, \
+                   : launch_gauss_axis<T, false>(in, in_pitch, out, bands, h, w, y0, x0, oh, ow, replace_ndv, ndv_bits, fill_bits, wts, \
                                                  radius, cval, s)
   // integer tiles: SciPy filters in float64 and stores with a C cast (truncation), measured against
   // scipy.ndimage.gaussian_filter(output=<integer array>)
@@ -1712,6 +1714,13 @@ int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, 
     default: return gm::fail(GM_ERR_INVALID, "gm_gauss_axis: dtype %d", dtype);
   }
 #undef GM_GAUSS
+}
+
+int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, const double* weights_host, int radius,
+                  double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh, int ow,
+                  void* out) {
+  return gm_gauss_axis_window(in, dtype, bands, h, w, w, axis, weights_host, radius, cval, replace_ndv, ndv_bits, fill_bits, y0,
+                              x0, oh, ow, out);
 }
 
 int gm_gauss_2d(const void* in, int dtype, int bands, int h, int w, const double* weights_y, const double* weights_x,

@@ -1,6 +1,7 @@
 """Host wrappers of the stencil kernels (csrc/gm_stencil.hip): the device bodies of
 Dilate.process, MovingMax.process and HillShade.process (raster/spatial.py)."""
 import ctypes
+import functools
 
 import numpy as np
 
@@ -27,6 +28,10 @@ def _lib():
                                     c.c_int, c.c_double, c.c_int, c.c_uint64, c.c_uint64, c.c_int, c.c_int, c.c_int,
                                     c.c_int, c.c_void_p]
         L.gm_gauss_axis.restype = c.c_int
+        L.gm_gauss_axis_window.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_double),
+                                           c.c_int, c.c_double, c.c_int, c.c_uint64, c.c_uint64, c.c_int, c.c_int, c.c_int,
+                                           c.c_int, c.c_void_p]
+        L.gm_gauss_axis_window.restype = c.c_int
         L.gm_gauss_2d.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.POINTER(c.c_double), c.POINTER(c.c_double),
                                   c.c_int, c.c_double, c.c_int, c.c_uint64, c.c_uint64, c.c_int, c.c_int, c.c_int, c.c_int,
                                   c.c_void_p]
@@ -214,6 +219,10 @@ def hillshade_batch(tiles, no_data_value, fill, resolution, altitude, azimuth, d
     return outs
 
 
+_IDENTITY_WEIGHTS = (np.ones(1, dtype=np.float64), 0)
+
+
+@functools.lru_cache(maxsize=256)
 def gaussian_weights(sigma, truncate=4.0):
     """SciPy's Gaussian kernel (scipy.ndimage._filters._gaussian_kernel1d, order 0): weights by
     distance 0..radius, radius = int(truncate * sigma + 0.5); normalised over the full kernel."""
@@ -221,7 +230,9 @@ def gaussian_weights(sigma, truncate=4.0):
     x = np.arange(-radius, radius + 1)
     phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
     phi = phi / phi.sum()
-    return np.ascontiguousarray(phi[radius:], dtype=np.float64), radius
+    weights = np.ascontiguousarray(phi[radius:], dtype=np.float64)
+    weights.setflags(write=False)  # (remembered per sigma: a Smooth block asks for the same kernel all day)
+    return weights, radius
 
 
 def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0), fused=True, out=None):
@@ -256,15 +267,15 @@ def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0), fused
                     ctypes.c_void_p(tile.ptr), code, bands, h, w, pitch, wy.ctypes.data_as(as_doubles),
                     wx.ctypes.data_as(as_doubles), ry, float(fill), 1 if has else 0, ndv_bits, fill_bits, my, mx, h - 2 * my,
                     w - 2 * mx, ctypes.c_void_p(out.ptr), opitch), "gm_gauss_2d")
-    current, replace = src.contiguous(), has  # (the one-axis kernels read compact tiles)
+    current, replace = (src if bands == 1 else src.contiguous()), has  # (a single-band window is read where it lies)
     for k, (axis, sigma) in enumerate(axes):
-        weights, radius = gaussian_weights(sigma) if sigma is not None else (np.ones(1, dtype=np.float64), 0)
+        weights, radius = gaussian_weights(sigma) if sigma is not None else _IDENTITY_WEIGHTS
         last = k == len(axes) - 1
         y0, x0, oh, ow = (my, mx, h - 2 * my, w - 2 * mx) if last else (0, 0, h, w)
         out = DeviceArray.empty((bands, oh, ow), src.dtype)
-        runtime.check(L.gm_gauss_axis(ctypes.c_void_p(current.ptr), code_of(src.dtype), bands, h, w, axis,
-                                      weights.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), radius, float(fill),
-                                      1 if replace else 0, ndv_bits, fill_bits, y0, x0, oh, ow,
-                                      ctypes.c_void_p(out.ptr)), "gm_gauss_axis")
+        runtime.check(L.gm_gauss_axis_window(ctypes.c_void_p(current.ptr), code_of(src.dtype), bands, h, w, current.pitch or w,
+                                             axis, weights.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), radius, float(fill),
+                                             1 if replace else 0, ndv_bits, fill_bits, y0, x0, oh, ow,
+                                             ctypes.c_void_p(out.ptr)), "gm_gauss_axis")
         current, replace = out, 0
     return current

@@ -441,6 +441,11 @@ int gm_hillshade_batch(int n_tiles, const void* const* in, int dtype, int h, int
 int gm_gauss_axis(const void* in, int dtype, int bands, int h, int w, int axis, const double* weights_host, int radius,
                   double cval, int replace_ndv, uint64_t ndv_bits, uint64_t fill_bits, int y0, int x0, int oh, int ow,
                   void* out);
+/* ... of a single-band tile that is a window of a wider allocation: rows in_pitch cells apart (window rules of
+ * gm_dilate_window). */
+int gm_gauss_axis_window(const void* in, int dtype, int bands, int h, int w, int in_pitch, int axis,
+                         const double* weights_host, int radius, double cval, int replace_ndv, uint64_t ndv_bits,
+                         uint64_t fill_bits, int y0, int x0, int oh, int ow, void* out);
 
 /* Both axes of the same filter in one launch for float32 tiles whose two axes have the same radius
  * (1..16): exactly gm_gauss_axis(axis 1) followed by gm_gauss_axis(axis 2) -- the first axis's result is

@@ -1572,7 +1572,7 @@ def test_stencils_on_zero_copy_windows(gpu, dt):
         got = stencil.hillshade(win, ndv, 1, kw["resolution"], 45.0, 315.0).to_numpy()
         with np.errstate(all="ignore"):
             assert np.array_equal(got, O.hillshade_process(data, kw, trig="rounded")["values"]), "hillshade"
-        for sigma in ((1.0, 1.0), (2.0, 0.7)):
+        for sigma in ((1.0, 1.0), (2.0, 0.7), (6.0, 6.0), (0.0, 9.1)):  # (one launch; the one-axis kernel, small and large radii)
             got = stencil.gaussian_smooth(win, ndv, 0.5, sigma, (1, 2)).to_numpy()
             assert np.array_equal(got, stencil.gaussian_smooth(host, ndv, 0.5, sigma, (1, 2)).to_numpy()), ("smooth", sigma)
 
