@@ -353,10 +353,146 @@ template <typename RC> __device__ __forceinline__ RC op_div(RC a, RC b) {
   else return 0;  // Divide is always a float step (elemwise.py:377-380)
 }
 
-// np.power: float classes go through float64 pow and one rounding (<= 1 ulp of any
-// faithful powf); integer classes use exponentiation by squaring with wrap-around.
+// generated by tools/gen_pow_tables.py: {1 / c, log2(c)} for the 128 intervals of [0x3f338000, 2x) as float32 bits
+static __device__ const double POWF_LOG2_TAB[128][2] = {
+    {0x1.6c16c16c16c17p+0, -0x1.042bd4b9a7c99p-1}, {0x1.6a13cd1537290p+0, -0x1.0014332be0032p-1},
+    {0x1.6816816816817p+0, -0x1.f804ae8d0cd04p-2}, {0x1.661ec6a5122f9p+0, -0x1.efec61b011f85p-2},
+    {0x1.642c8590b2164p+0, -0x1.e7df5fe538ab3p-2}, {0x1.623fa77016240p+0, -0x1.dfdd89d586e2cp-2},
+    {0x1.6058160581606p+0, -0x1.d7e6c0abc357bp-2}, {0x1.5e75bb8d015e7p+0, -0x1.cffae611ad12ap-2},
+    {0x1.5c9882b931057p+0, -0x1.c819dc2d45fe4p-2}, {0x1.5ac056b015ac0p+0, -0x1.c043859e2fdb2p-2},
+    {0x1.58ed2308158edp+0, -0x1.b877c57b1b06fp-2}, {0x1.571ed3c506b3ap+0, -0x1.b0b67f4f46812p-2},
+    {0x1.5555555555555p+0, -0x1.a8ff971810a5dp-2}, {0x1.5390948f40febp+0, -0x1.a152f142981b5p-2},
+    {0x1.51d07eae2f815p+0, -0x1.99b072a96c6b2p-2}, {0x1.5015015015015p+0, -0x1.921800924dd3bp-2},
+    {0x1.4e5e0a72f0539p+0, -0x1.8a8980abfbd30p-2}, {0x1.4cab88725af6ep+0, -0x1.8304d90c11fd1p-2},
+    {0x1.4afd6a052bf5bp+0, -0x1.7b89f02cf2aafp-2}, {0x1.49539e3b2d067p+0, -0x1.7418acebbf18fp-2},
+    {0x1.47ae147ae147bp+0, -0x1.6cb0f6865c8ebp-2}, {0x1.460cbc7f5cf9ap+0, -0x1.6552b49986277p-2},
+    {0x1.446f86562d9fbp+0, -0x1.5dfdcf1eeae0fp-2}, {0x1.42d6625d51f87p+0, -0x1.56b22e6b578e5p-2},
+    {0x1.4141414141414p+0, -0x1.4f6fbb2cec598p-2}, {0x1.3fb013fb013fbp+0, -0x1.48365e695d797p-2},
+    {0x1.3e22cbce4a902p+0, -0x1.4106017c3eca0p-2}, {0x1.3c995a47babe7p+0, -0x1.39de8e1559f6ep-2},
+    {0x1.3b13b13b13b14p+0, -0x1.32bfee370ee6ap-2}, {0x1.3991c2c187f63p+0, -0x1.2baa0c34be1ebp-2},
+    {0x1.3813813813814p+0, -0x1.249cd2b13cd6fp-2}, {0x1.3698df3de0748p+0, -0x1.1d982c9d5270ap-2},
+    {0x1.3521cfb2b78c1p+0, -0x1.169c05363f157p-2}, {0x1.33ae45b57bcb2p+0, -0x1.0fa848044b352p-2},
+    {0x1.323e34a2b10bfp+0, -0x1.08bce0d95fa36p-2}, {0x1.30d190130d190p+0, -0x1.01d9bbcfa61d4p-2},
+    {0x1.2f684bda12f68p+0, -0x1.f5fd8a9063e32p-3}, {0x1.2e025c04b8097p+0, -0x1.e857d3d361368p-3},
+    {0x1.2c9fb4d812ca0p+0, -0x1.dac22d3e441d6p-3}, {0x1.2b404ad012b40p+0, -0x1.cd3c712d31106p-3},
+    {0x1.29e4129e4129ep+0, -0x1.bfc67a7fff4cap-3}, {0x1.288b01288b013p+0, -0x1.b2602497d534ap-3},
+    {0x1.27350b8812735p+0, -0x1.a5094b54d2828p-3}, {0x1.25e22708092f1p+0, -0x1.97c1cb13c7ec0p-3},
+    {0x1.2492492492492p+0, -0x1.8a8980abfbd30p-3}, {0x1.23456789abcdfp+0, -0x1.7d60496cfbb4cp-3},
+    {0x1.21fb78121fb78p+0, -0x1.7046031c79f84p-3}, {0x1.20b470c67c0d9p+0, -0x1.633a8bf437ce6p-3},
+    {0x1.1f7047dc11f70p+0, -0x1.563dc29ffacafp-3}, {0x1.1e2ef3b3fb874p+0, -0x1.494f863b8df32p-3},
+    {0x1.1cf06ada2811dp+0, -0x1.3c6fb650cde51p-3}, {0x1.1bb4a4046ed29p+0, -0x1.2f9e32d5bfdd1p-3},
+    {0x1.1a7b9611a7b96p+0, -0x1.22dadc2ab3496p-3}, {0x1.19453808ca29cp+0, -0x1.162593186da70p-3},
+    {0x1.1811811811812p+0, -0x1.097e38ce6064ep-3}, {0x1.16e0689427379p+0, -0x1.f9c95dc1d1167p-4},
+    {0x1.15b1e5f75270dp+0, -0x1.e0b1ae8f2fd56p-4}, {0x1.1485f0e0acd3bp+0, -0x1.c7b528b70f1bcp-4},
+    {0x1.135c81135c811p+0, -0x1.aed391ab6674ap-4}, {0x1.12358e75d3033p+0, -0x1.960caf9abb7c1p-4},
+    {0x1.1111111111111p+0, -0x1.7d60496cfbb4bp-4}, {0x1.0fef010fef011p+0, -0x1.64ce26c067157p-4},
+    {0x1.0ecf56be69c90p+0, -0x1.4c560fe68af8bp-4}, {0x1.0db20a88f4696p+0, -0x1.33f7cde14cf63p-4},
+    {0x1.0c9714fbcda3bp+0, -0x1.1bb32a60054a2p-4}, {0x1.0b7e6ec259dc8p+0, -0x1.0387efbca86a7p-4},
+    {0x1.0a6810a6810a7p+0, -0x1.d6ebd1f1fec14p-5}, {0x1.0953f39010954p+0, -0x1.a6f9c377dd31dp-5},
+    {0x1.0842108421084p+0, -0x1.77394c9d958d0p-5}, {0x1.073260a47f7c6p+0, -0x1.47aa07357703cp-5},
+    {0x1.0624dd2f1a9fcp+0, -0x1.184b8e4c56afcp-5}, {0x1.05197f7d73404p+0, -0x1.d23afc49139f1p-6},
+    {0x1.0410410410410p+0, -0x1.743ee861f353fp-6}, {0x1.03091b51f5e1ap+0, -0x1.16a21e20a0a29p-6},
+    {0x1.0204081020408p+0, -0x1.72c7ba20f731cp-7}, {0x1.0101010101010p+0, -0x1.720d9c06a8348p-8},
+    {0x1.0000000000000p+0, 0x0.0p+0}, {0x1.fc07f01fc07f0p-1, 0x1.6fe50b6ef085dp-7},
+    {0x1.f81f81f81f820p-1, 0x1.6e79685c2d212p-6}, {0x1.f44659e4a4271p-1, 0x1.11cd1d513341bp-5},
+    {0x1.f07c1f07c1f08p-1, 0x1.6bad3758efd81p-5}, {0x1.ecc07b301ecc0p-1, 0x1.c4dfab90aab6ap-5},
+    {0x1.e9131abf0b767p-1, 0x1.0eb389fa29f9dp-4}, {0x1.e573ac901e574p-1, 0x1.3aa2fdd27f1bfp-4},
+    {0x1.e1e1e1e1e1e1ep-1, 0x1.663f6fac91318p-4}, {0x1.de5d6e3f8868ap-1, 0x1.918a16e46335ep-4},
+    {0x1.dae6076b981dbp-1, 0x1.bc84240adabb9p-4}, {0x1.d77b654b82c34p-1, 0x1.e72ec117fa5adp-4},
+    {0x1.d41d41d41d41dp-1, 0x1.08c588cda79e5p-3}, {0x1.d0cb58f6ec074p-1, 0x1.1dcd197552b7dp-3},
+    {0x1.cd85689039b0bp-1, 0x1.32ae9e278ae19p-3}, {0x1.ca4b3055ee191p-1, 0x1.476a9f983f74dp-3},
+    {0x1.c71c71c71c71cp-1, 0x1.5c01a39fbd68bp-3}, {0x1.c3f8f01c3f8f0p-1, 0x1.70742d4ef0280p-3},
+    {0x1.c0e070381c0e0p-1, 0x1.84c2bd02f03b6p-3}, {0x1.bdd2b899406f7p-1, 0x1.98edd077e70e1p-3},
+    {0x1.bacf914c1bad0p-1, 0x1.acf5e2db4ec91p-3}, {0x1.b7d6c3dda338bp-1, 0x1.c0db6cdd94defp-3},
+    {0x1.b4e81b4e81b4fp-1, 0x1.d49ee4c32596cp-3}, {0x1.b2036406c80d9p-1, 0x1.e840be74e6a4dp-3},
+    {0x1.af286bca1af28p-1, 0x1.fbc16b902680dp-3}, {0x1.ac5701ac5701bp-1, 0x1.0790adbb03009p-2},
+    {0x1.a98ef606a63bep-1, 0x1.11307dad30b74p-2}, {0x1.a6d01a6d01a6dp-1, 0x1.1ac05b291f070p-2},
+    {0x1.a41a41a41a41ap-1, 0x1.24407ab0e073ap-2}, {0x1.a16d3f97a4b02p-1, 0x1.2db10fc4d9aaep-2},
+    {0x1.9ec8e951033d9p-1, 0x1.37124cea4cdedp-2}, {0x1.9c2d14ee4a102p-1, 0x1.406463b1b0448p-2},
+    {0x1.999999999999ap-1, 0x1.49a784bcd1b8ap-2}, {0x1.970e4f80cb872p-1, 0x1.52dbdfc4c96b5p-2},
+    {0x1.948b0fcd6e9e0p-1, 0x1.5c01a39fbd689p-2}, {0x1.920fb49d0e229p-1, 0x1.6518fe4677ba6p-2},
+    {0x1.8f9c18f9c18fap-1, 0x1.6e221cd9d0cddp-2}, {0x1.8d3018d3018d3p-1, 0x1.771d2ba7efb3cp-2},
+    {0x1.8acb90f6bf3aap-1, 0x1.800a563161c53p-2}, {0x1.886e5f0abb04ap-1, 0x1.88e9c72e0b224p-2},
+    {0x1.8618618618618p-1, 0x1.91bba891f170ap-2}, {0x1.83c977ab2beddp-1, 0x1.9a802391e2330p-2},
+    {0x1.8181818181818p-1, 0x1.a33760a7f6051p-2}, {0x1.7f405fd017f40p-1, 0x1.abe18797f1f4ap-2},
+    {0x1.7d05f417d05f4p-1, 0x1.b47ebf73882a1p-2}, {0x1.7ad2208e0ecc3p-1, 0x1.bd0f2e9e79032p-2},
+    {0x1.78a4c8178a4c8p-1, 0x1.c592fad295b57p-2}, {0x1.767dce434a9b1p-1, 0x1.ce0a4923a587dp-2},
+    {0x1.745d1745d1746p-1, 0x1.d6753e032ea0ep-2}, {0x1.724287f46debcp-1, 0x1.ded3fd442364cp-2},
+    {0x1.702e05c0b8170p-1, 0x1.e726aa1e754d3p-2}, {0x1.6e1f76b4337c7p-1, 0x1.ef6d67328e220p-2},
+};
+static __device__ const double POWF_EXP2_TAB[32] = {
+    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
+    0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
+    0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
+    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0, 0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0,
+    0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
+    0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0,
+};
+// log2(1 + r) = r (C1 + C2 r + ... + C5 r^4) + O(r^6),  2^r = 1 + r (L1 + ... + L5 r^4) + O(r^6): Taylor coefficients
+static __device__ const double POWF_LOG2_C[5] = {0x1.71547652b82fep+0, -0x1.71547652b82fep-1, 0x1.ec709dc3a03fdp-2, -0x1.71547652b82fep-2, 0x1.2776c50ef9bfep-2};
+static __device__ const double POWF_EXP2_L[5] = {0x1.62e42fefa39efp-1, 0x1.ebfbdff82c58fp-3, 0x1.c6b08d704a0c0p-5, 0x1.3b2ab6fba4e77p-7, 0x1.5d87fe78a6731p-10};
+
+// np.power on the float32 class (round 4).  float64 pow() rounded once cost ~130 float64 operations per value (a
+// 4096^2 tile: 109 us against 22 us of streaming); float32 needs far less than a float64 pow delivers.  Here, in
+// float64 arithmetic: log2|x| = e + log2(c) + log2(1 + r), r = z / c - 1 by a table of 128 mantissa intervals (the
+// one around 1.0 has c = 1: values near 1 keep their RELATIVE precision, which is what a large exponent magnifies)
+// and five Taylor terms (|r| <= 2^-8: error < 2^-50); 2^(y log2|x|) by 32 table steps and five Taylor terms.  The
+// exponent argument is good to ~2^-35 absolutely over the float32 range, so the float64 result rounds to the correctly
+// rounded float32 except within 2^-11 ulp of a tie -- there it is the other neighbour, i.e. <= 1 ulp from any faithful
+// powf (glibc's: 0.52 ulp), the budget of tests/test_gpu_parity.py.  Signs, zeros, infinities and NaN follow C99 F.9.4.4
+// = NumPy.  (tools/ulp_measure.py: measured against the extended-precision value.)
+__device__ __forceinline__ float powf_via_f64(float xf, float yf) {
+  const unsigned ix = __float_as_uint(xf), iy = __float_as_uint(yf);
+  const unsigned ax = ix & 0x7fffffffu, ay = iy & 0x7fffffffu;
+  // y: 0 = not an integer, 1 = an odd integer, 2 = an even one (everything from 2^24 on and +-inf included)
+  const int ey = (int)(ay >> 23);
+  const unsigned unit = 1u << ((150 - ey) & 31);  // the bit worth 1 when 127 <= ey <= 150
+  int yint = (ay & (unit - 1)) ? 0 : ((ay & unit) ? 1 : 2);
+  yint = ey > 150 ? 2 : yint;
+  yint = ey < 127 ? (ay == 0 ? 2 : 0) : yint;
+  // log2 |x|
+  const bool tiny = ax < 0x00800000u;  // subnormal: scaled by 2^23 first
+  const unsigned nx = tiny ? __float_as_uint(__uint_as_float(ax) * 0x1p23f) : ax;
+  const unsigned tmp = nx - 0x3f338000u;
+  const int i = (int)((tmp >> 16) & 127u);
+  const int e = ((int)tmp >> 23) - (tiny ? 23 : 0);
+  const double z = (double)__uint_as_float(nx - (tmp & 0xff800000u));  // in [0.7, 1.4)
+  const double r = fma(z, POWF_LOG2_TAB[i][0], -1.0);
+  double p = fma(r, POWF_LOG2_C[4], POWF_LOG2_C[3]);
+  p = fma(r, p, POWF_LOG2_C[2]);
+  p = fma(r, p, POWF_LOG2_C[1]);
+  p = fma(r, p, POWF_LOG2_C[0]);
+  double l2 = fma(r, p, (double)e + POWF_LOG2_TAB[i][1]);
+  l2 = ax == 0 ? -__builtin_huge_val() : l2;
+  l2 = ax == 0x7f800000u ? __builtin_huge_val() : l2;
+  double zz = (double)yf * l2;
+  zz = ax == 0x3f800000u ? 0.0 : zz;                 // |x| = 1: 1 whatever y (0 * inf otherwise)
+  zz = fmin(fmax(zz, -160.0), 130.0);                // (beyond: 0 / inf as float32 either way; keeps 2^k a normal double)
+  const double kd = rint(zz * 32.0);
+  const int ki = (int)kd;
+  const double rr = fma(kd, -0x1p-5, zz);
+  double q = fma(rr, POWF_EXP2_L[4], POWF_EXP2_L[3]);
+  q = fma(rr, q, POWF_EXP2_L[2]);
+  q = fma(rr, q, POWF_EXP2_L[1]);
+  q = fma(rr, q, POWF_EXP2_L[0]);
+  q = fma(rr, q, 1.0);
+  const long long scaled = __double_as_longlong(POWF_EXP2_TAB[ki & 31]) + ((long long)(ki >> 5) << 52);
+  float out = (float)(__longlong_as_double(scaled) * q);
+  const bool negative = (ix >> 31) != 0;
+  out = (negative && yint == 1) ? -out : out;
+  out = (negative && yint == 0 && ax != 0 && ax < 0x7f800000u) ? __builtin_nanf("") : out;  // finite x < 0, y not an integer
+  out = (ax > 0x7f800000u || ay > 0x7f800000u) ? __builtin_nanf("") : out;
+  return (ay == 0 || ix == 0x3f800000u) ? 1.0f : out;
+}
+
+// np.power: the float32 class by powf_via_f64 above, float64 through pow() (<= 1 ulp);
+// integer classes use exponentiation by squaring with wrap-around.
 template <typename RC> __device__ __forceinline__ RC op_pow(RC a, RC b) {
-  if constexpr (is_float_class<RC>::value) {
+  if constexpr (std::is_same<RC, float>::value) {
+    return powf_via_f64(a, b);
+  } else if constexpr (is_float_class<RC>::value) {
     return (RC)pow((double)a, (double)b);
   } else {
     typedef typename std::conditional<sizeof(RC) == 4, unsigned, unsigned long long>::type U;

@@ -35,6 +35,41 @@ def test_math_golden(gpu, case):
     assert_result_equal(out, case["expect"], _ulp(case["op"], case["expect"]), case["id"])
 
 
+def test_power_float32_values_and_special_cases(gpu):
+    """np.power on float32 rasters (powf_via_f64, csrc/gm_vm.h): every pair of 31 special bases / exponents (zeros of both
+    signs, +-1, +-inf, NaN, subnormals, odd / even / huge integers, values next to 1) agrees with the host's np.power through the
+    oracle's wrapper -- finite where it is finite, the same sign of zero, <= 1 ulp -- and sweeps over bases near 1 with huge
+    exponents, subnormal bases, negative bases with integer exponents and results in the subnormal range stay within 1 ulp of
+    the oracle and equal the extended-precision value rounded once (measured: every one of 8 M samples, tools/ulp_measure.py)."""
+    fill = float(np.finfo("f4").max)
+    kw = {"dtype": "float32", "fillvalue": fill}
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 2.0, -2.0, 3.0, -3.0, 2.5, -2.5, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.0e38,
+                        -3.0e38, 16777216.0, 16777217.0, -16777216.0, 33554432.0, 1e10, -1e10, 0.99999994, 1.0000001, 7.0, -7.0, 1e-20,
+                        1e20], dtype="f4")
+    xs, ys = [a.reshape(1, len(special), len(special)).copy() for a in np.meshgrid(special, special)]
+    rng = np.random.default_rng(8)
+    n = 1 << 16
+    sweeps = [(xs, ys),
+              (10.0 ** rng.uniform(-10, 10, n), rng.uniform(-8, 8, n)),
+              (rng.uniform(0.5, 2, n), rng.uniform(-120, 120, n)),
+              (np.float32(1) + rng.integers(-64, 65, n).astype("f4") * np.float32(2 ** -24), rng.uniform(-1e9, 1e9, n)),
+              (rng.uniform(1e-45, 1e-38, n), rng.uniform(-1, 1, n)),
+              (-(10.0 ** rng.uniform(-3, 3, n)), rng.integers(-20, 21, n).astype("f8")),
+              (rng.uniform(1e-3, 1e-1, n), rng.uniform(15, 45, n))]
+    for k, (x, y) in enumerate(sweeps):
+        x, y = np.asarray(x, dtype="f4").reshape(1, 1, -1), np.asarray(y, dtype="f4").reshape(1, 1, -1)
+        a, b = {"values": x, "no_data_value": fill}, {"values": y, "no_data_value": fill}
+        with np.errstate(all="ignore"):
+            want = O.math_process("power", kw, a, b)
+            true = np.power(x.astype(np.longdouble), y.astype(np.longdouble)).astype("f4")
+        got = devops.math_process("power", kw, a, b)
+        assert_result_equal(got, want, 1, "sweep %d" % k)
+        values = np.asarray(got["values"])
+        assert np.array_equal(np.signbit(values), np.signbit(want["values"])), "sign of zero, sweep %d" % k
+        finite = np.isfinite(true) & (values != np.float32(fill))
+        assert np.array_equal(values[finite], true[finite]), "sweep %d: not the correctly rounded value" % k
+
+
 def test_integer_power_with_raster_exponent(gpu):
     """Integer ** integer raster: computed (wrapping like NumPy) when every exponent is >= 0, ValueError like
     NumPy's as soon as one is negative -- no-data cells included; inside a view the op is kept out of fused
