@@ -53,17 +53,26 @@ class BaseCombine(RasterBlock):
                 return None
         return step
 
-    timedelta = property(lambda self: self.get_aligned_timedelta(self.args))
+    def _once(self, name, compute):
+        """A property of the (immutable) Block computed on first use: request planning reads period / timedelta / dtype
+        several times per request."""
+        slot = "_once_" + name
+        if slot not in self.__dict__:
+            self.__dict__[slot] = compute()
+        return self.__dict__[slot]
+
+    timedelta = property(lambda self: self._once("timedelta", lambda: self.get_aligned_timedelta(self.args)))
     temporal = property(lambda self: any(arg.temporal for arg in self.args))
-    dtype = property(lambda self: np.result_type(*self.args))
+    dtype = property(lambda self: self._once("dtype", lambda: np.result_type(*self.args)))
     fillvalue = property(lambda self: get_dtype_max(self.dtype))
 
-    @property
-    def period(self):
+    def _period(self):
         known = filter_none([arg.period for arg in self.args])
         if not known:
             return None
         return min(p[0] for p in known), max(p[1] for p in known)
+
+    period = property(lambda self: self._once("period", self._period))
 
     @property
     def extent(self):

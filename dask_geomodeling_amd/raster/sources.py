@@ -284,17 +284,23 @@ class MemorySource(RasterSourceBase):
 
     @property
     def period(self):
-        n = len(self)
-        if n == 0:
-            return None
-        first = utc_from_ms_timestamp(self.time_first)
-        if n == 1:
-            return first, first
-        return first, first + (n - 1) * self.timedelta
+        hit = self.__dict__.get("_period_cache")  # (a Block never changes: request planning asks per request and per parent)
+        if hit is None:
+            n = len(self)
+            if n == 0:
+                return None
+            first = utc_from_ms_timestamp(self.time_first)
+            hit = self.__dict__["_period_cache"] = (first, first) if n == 1 else (first, first + (n - 1) * self.timedelta)
+        return hit
 
     @property
     def timedelta(self):
-        return None if self.time_delta is None else timedelta(milliseconds=self.time_delta)
+        if self.time_delta is None:
+            return None
+        hit = self.__dict__.get("_timedelta_cache")
+        if hit is None:
+            hit = self.__dict__["_timedelta_cache"] = timedelta(milliseconds=self.time_delta)
+        return hit
 
     @property
     def temporal(self):
