@@ -153,3 +153,70 @@ def test_config5_mosaic_tiles_65536(gpu, leaves):
             assert_values_equal(got[:, r0:r0 + 96, c0:c0 + 96], want, 0, "tile %d window (%d, %d)" % (t, r0, c0))
     del results, tiler, graph
     raster.SyntheticSource.drop_resident_windows()
+
+
+def test_more_than_2_to_the_32_cells_in_one_tile(gpu):
+    """The maximum sizes: one tile of 2^32 + 9.9 M cells (65 600 x 65 622) evaluated in ONE request per view -- flat cell
+    indices and byte offsets beyond 32 bits in the interpreter (uint8 and float32 tiles: 4.3 GB and 17 GB per operand), the
+    1-byte table path, a stencil, Classify / Reclassify and the reductions -- spot-checked at the far end of the tile (cells
+    whose flat index no longer fits 32 bits) and at its start against the oracle on host copies of those windows."""
+    from dask_geomodeling_amd import raster
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd.hip import DeviceArray
+    from dask_geomodeling_amd.raster.sources import generate_window
+    h, w = 65600, 65622
+    assert h * w > 2 ** 32
+    size = 96
+    spots = [(0, 0), (h - size, w - size), (h - 2 * size, 4), (h // 2 + 1, w // 2 + 2), (h - size, 0)]
+    req = dict(mode="vals", bbox=(0.0, 0.0, float(w), float(h)), width=w, height=h, projection="EPSG:28992")
+
+    def host(seed, dtype, lo, hi, ndv, r0, c0):
+        return {"values": synth.generate_window((h, w), dtype, seed, lo, hi, ndv, LATTICE, r0, c0, size, size), "no_data_value": ndv}
+
+    def window(values, r0, c0, margin=0):
+        assert isinstance(values, DeviceArray)
+        return np.asarray(values.window(r0 - margin if margin else r0, c0 - margin if margin else c0, size, size))
+
+    with gmconfig.config.set({"geomodeling.materialize": False}):
+        # -- uint8 --
+        dc = generate_window((h, w), "u1", 4100, 0.0, 12.0, 255, LATTICE, 0, 0, h, w)
+        C = raster.MemorySource(dc, np.uint8(255), "EPSG:28992", 1.0, (0.0, float(h)))
+        table = [[k, (5 * k) % 11] for k in range(0, 12, 2)]
+        views = {
+            "C > 5": (raster.Greater(C, 5), lambda c: O.math_process("greater", {"dtype": "bool", "fillvalue": None}, c, 5)),
+            "Mask(Reclassify(C))": (raster.Mask(raster.Reclassify(C, table), 1),
+                                    lambda c: O.mask_process(O.reclassify_process(c, {"dtype": "<i8", "fillvalue": int(np.iinfo("i8").max),
+                                                                                      "data": table, "select": False}), 1)),
+            "Classify(C, 40 edges)": (raster.Classify(C, [0.25 * k for k in range(40)]),
+                                      lambda c: O.classify_process(c, [0.25 * k for k in range(40)], False)),
+        }
+        for name, (view, want_of) in views.items():
+            got = view.get_data(**req)["values"]
+            assert got.shape == (1, h, w), name
+            for r0, c0 in spots:
+                want = want_of(host(4100, "u1", 0.0, 12.0, np.uint8(255), r0, c0))["values"]
+                assert_values_equal(window(got, r0, c0), want, 0, "%s at (%d, %d)" % (name, r0, c0))
+            del got
+        # a stencil whose last rows lie beyond 2^32 cells (the request is the tile less a one-cell margin)
+        inner = dict(req, bbox=(1.0, 1.0, float(w - 1), float(h - 1)), width=w - 2, height=h - 2)
+        got = raster.Dilate(C, [3]).get_data(**inner)["values"]
+        for r0, c0 in ((0, 0), (h - 2 - size, w - 2 - size), (h - 2 - size, 0)):
+            around = {"values": synth.generate_window((h, w), "u1", 4100, 0.0, 12.0, 255, LATTICE, r0, c0, size + 2, size + 2),
+                      "no_data_value": np.uint8(255)}
+            assert_values_equal(window(got, r0, c0), O.dilate_process(around, [3])["values"], 0, "Dilate at (%d, %d)" % (r0, c0))
+        del got, C, dc
+        # -- float32: 17 GB per operand --
+        ndv = np.float32(F32MAX)
+        da = generate_window((h, w), "f4", 4101, 0.0, 100.0, F32MAX, LATTICE, 0, 0, h, w)
+        db = generate_window((h, w), "f4", 4102, 0.0, 100.0, F32MAX, LATTICE, 0, 0, h, w)
+        A = raster.MemorySource(da, ndv, "EPSG:28992", 1.0, (0.0, float(h)))
+        B = raster.MemorySource(db, ndv, "EPSG:28992", 1.0, (0.0, float(h)))
+        kw = {"dtype": "float32", "fillvalue": F32MAX}
+        got = raster.Clip(A * 2.5 + B, B > 50).get_data(**req)["values"]
+        most = raster.Max(A, B).get_data(**req)["values"]
+        for r0, c0 in spots:
+            a, b = host(4101, "f4", 0.0, 100.0, ndv, r0, c0), host(4102, "f4", 0.0, 100.0, ndv, r0, c0)
+            x = O.math_process("add", kw, O.math_process("multiply", kw, a, 2.5), b)
+            want = O.clip_process(x, O.math_process("greater", {"dtype": "bool", "fillvalue": None}, b, 50))["values"]
+            assert_values_equal(window(got, r0, c0), want, 0, "Clip(A * 2.5 + B, B > 50) at (%d, %d)" % (r0, c0))
+            assert_values_equal(window(most, r0, c0), O.reduce_max_process(kw, a, b)["values"], 0, "Max at (%d, %d)" % (r0, c0))
