@@ -38,7 +38,7 @@ for it in range(N):
         got = stencil.hillshade(v, ndv, kw["fill"], kw["resolution"], kw["altitude"], kw["azimuth"]).to_numpy()
         assert np.array_equal(got, want), "hillshade: %d cells differ" % (got != want).sum()
         if np.dtype(dt).kind == "f" or it % 3 == 0:
-            sigma = (float(rng.choice([0.4, 1.0, 1.7, 2.0, 3.3, 4.0])),) * 2 if it % 2 else (float(rng.random() * 3), float(rng.random() * 3))
+            sigma = (float(rng.choice([0.4, 1.0, 1.7, 2.0, 3.3, 4.0])),) * 2 if it % 2 else (float(rng.random() * 3), float(rng.random() * (30 if it % 4 == 0 else 3)))  # (now and then a radius of up to 120)
             crop = (int(rng.integers(0, 3)), int(rng.integers(0, 3)))
             fill = float(rng.choice([0, 0.1, 2.5]))
             clean = np.where(np.isnan(v), 0, v).astype(dt) if np.dtype(dt).kind == "f" else v
