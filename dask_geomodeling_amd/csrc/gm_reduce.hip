@@ -113,7 +113,7 @@ __device__ __forceinline__ void pw_leaf(const C* src, long long pixels, int star
   A term[V];
   if (len < 8) {
 #pragma unroll
-    for (int e = 0; e < V; ++e) res[e] = (A)-0.0;  // (-0.0: a sum of nothing but -0.0 stays -0.0)
+    for (int e = 0; e < V; ++e) res[e] = (A)-0.0;  // (the loop's own start; the reduction adds it to add's identity: reduce_kernel)
     for (int i = 0; i < len; ++i) {
       pw_term<C, A, HALF, V, MODE>(load_pack<C, V>(src + (long long)(start + i) * pixels), mean, term, cnt);
 #pragma unroll
@@ -157,13 +157,13 @@ template <typename C, typename A, bool HALF, int V, int MODE, int DEPTH>
 __device__ void pw_sum(const C* src, long long pixels, int start, int n, const C (&mean)[V], A (&res)[V], int (&cnt)[V]) {
   if constexpr (DEPTH < 0) {
     // NumPy hands the reduction loop at most `bufsize` = 8192 elements at a time (the ufunc's buffered iterator),
-    // so a longer stack is the chain  -0.0 + pairwise(first 8192) + pairwise(next 8192) + ...  (measured against
+    // so a longer stack is the chain  0.0 + pairwise(first 8192) + pairwise(next 8192) + ...  (measured against
     // np.nansum on the (n, cells) array the reference reduces; 8192 = 128 * 2^6: six halvings inside a piece)
     constexpr int PIECE = 8192, LEVELS = 8;
     int at[LEVELS], len[LEVELS], phase[LEVELS];
     A left[LEVELS][V], part[V];
 #pragma unroll
-    for (int e = 0; e < V; ++e) res[e] = (A)-0.0;
+    for (int e = 0; e < V; ++e) res[e] = (A)0.0;
     for (int piece = 0; piece < n; piece += PIECE) {
       int sp = 0;
       at[0] = start + piece; len[0] = n - piece < PIECE ? n - piece : PIECE; phase[0] = 0;
@@ -260,8 +260,10 @@ __global__ __launch_bounds__(256) void reduce_kernel(const C* __restrict__ stack
 #pragma unroll
     for (int e = 0; e < V; ++e) none[e] = (C)0;
     pw_sum<C, A, HALF, V, 0, PW_DEPTH>(src, pixels, 0, n, none, total, cnt);
+    // (np.sum puts the loop's result on top of add's identity: cells whose every raster is -0.0 sum to +0.0 -- measured,
+    //  NumPy 2.2, round-4 fuzzing; until then such a cell came out as -0.0)
 #pragma unroll
-    for (int e = 0; e < V; ++e) r[e] = rnd<HALF, C>((C)total[e]);
+    for (int e = 0; e < V; ++e) r[e] = rnd<HALF, C>((C)((A)0.0 + total[e]));
     if constexpr (STAT != GM_RED_SUM) {
 #pragma unroll
       for (int e = 0; e < V; ++e) r[e] = from_f64<HALF, C>((double)r[e] / (double)cnt[e]);
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(WG) void reduce_sorted_kernel(const C* __restrict__
       const int h = m / 2;
       const C high = column[h * WG];
       const C low = (m & 1) ? high : column[(h - 1) * WG];
-      r = rnd<HALF, C>(rnd<HALF, C>(low + high) / (C)2);  // np.ma.median: sum of the two, then / 2.
+      r = rnd<HALF, C>(rnd<HALF, C>((low + high) + (C)0) / (C)2);  // np.ma.median: sum of the two, then / 2.
     }
   }
   __builtin_nontemporal_store(r, out + p);
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(256) void reduce_sorted_small_kernel(const C* __res
       const int h = m / 2;
       const C high = pick<C, N>(v, h);
       const C low = (m & 1) ? high : pick<C, N>(v, h - 1);
-      r = rnd<HALF, C>(rnd<HALF, C>(low + high) / (C)2);
+      r = rnd<HALF, C>(rnd<HALF, C>((low + high) + (C)0) / (C)2);
     }
   }
   __builtin_nontemporal_store(r, out + p);

@@ -155,15 +155,19 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const Tin* __restrict__ 
       const bool nd = skipped<Tin, C>(f.v[e], ndv, has_ndv, x);
       cnt[e] += nd ? 0 : 1;
       if constexpr (STAT == GM_STAT_MIN) {
-        // np.fmin.reduce: (acc <= x || isnan(x)) ? acc : x, the accumulator being the first operand
+        // np.fmin.reduce over the frame axis, the accumulator being the first operand.  A tie goes to the NEW frame: only
+        // -0.0 against +0.0 can tell, and NumPy's SIMD loops (x86 min / max return their second operand on a tie) say so
+        // on the hosts the golden vectors and the fuzzing oracle ran on; the scalar loop would keep the accumulator.
         const C y = nd ? std::numeric_limits<C>::quiet_NaN() : x;
-        acc[e] = (acc[e] <= y || y != y) ? acc[e] : y;
+        acc[e] = (acc[e] < y || y != y) ? acc[e] : y;
       } else if constexpr (STAT == GM_STAT_MAX) {
         const C y = nd ? std::numeric_limits<C>::quiet_NaN() : x;
-        acc[e] = (acc[e] >= y || y != y) ? acc[e] : y;
+        acc[e] = (acc[e] > y || y != y) ? acc[e] : y;
       } else if constexpr (STAT != GM_STAT_COUNT) {
         const C y = nd ? (C)0 : x;
-        acc[e] = is_first ? y : acc[e] + y;  // np.add.reduce starts from the first frame (keeps a -0.0)
+        // np.nansum = np.sum of the frames with NaN -> 0, and np.sum over the frame axis starts from add's identity:
+        // 0.0 + f0 + f1 ... (a cell whose every frame is -0.0 sums to +0.0; measured, NumPy 2.2: round-4 fuzzing)
+        acc[e] = acc[e] + y;
       }
     }
   };
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(WG) void median_kernel(const Tin* __restrict__ fram
       const int h = n / 2;
       const C high = column[h * WG];
       const C low = (n & 1) ? high : column[(h - 1) * WG];
-      r = (low + high) / (C)2;
+      r = ((C)0 + low + high) / (C)2;  // (np.mean of the middle pair starts from add's identity: a -0.0 median is +0.0)
     }
   }
   // (TemporalAggregate fills every non-finite result, temporal.py:760-766; reduce_rasters only the cells without
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(256) void median_small_kernel(const Tin* __restrict
       const int h = n / 2;
       const C high = pick<C, N>(v, h);
       const C low = (n & 1) ? high : pick<C, N>(v, h - 1);
-      r = (low + high) / (C)2;
+      r = ((C)0 + low + high) / (C)2;  // (np.mean of the middle pair starts from add's identity: a -0.0 median is +0.0)
     }
   }
   // (TemporalAggregate fills every non-finite result, temporal.py:760-766; reduce_rasters only the cells without
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(256) void median_select_kernel(const Tin* __restric
       const C d = b - a;
       r = (t >= (C)0.5) ? b - d * u : a + d * t;
     } else {
-      r = (a + b) / (C)2;
+      r = ((C)0 + a + b) / (C)2;
     }
   }
   // (TemporalAggregate fills every non-finite result, temporal.py:760-766; reduce_rasters only the cells without
@@ -816,12 +820,12 @@ __global__ __launch_bounds__(256) void frames_sum_kernel(const Tin* __restrict__
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int e = 0; e < V; ++e) acc[e] = j + u == 0 ? (A)f[u].v[e] : acc[e] + (A)f[u].v[e];
+      for (int e = 0; e < V; ++e) acc[e] = acc[e] + (A)f[u].v[e];  // (from add's identity: -0.0 frames sum to +0.0)
   }
   for (; j < n; ++j) {
     const Pack<Tin, V> f = load_pack<Tin, V>(src + (long long)j * pixels);
 #pragma unroll
-    for (int e = 0; e < V; ++e) acc[e] = j == 0 ? (A)f.v[e] : acc[e] + (A)f.v[e];
+    for (int e = 0; e < V; ++e) acc[e] = acc[e] + (A)f.v[e];
   }
   Pack<A, V> res;
 #pragma unroll
@@ -830,7 +834,7 @@ __global__ __launch_bounds__(256) void frames_sum_kernel(const Tin* __restrict__
 }
 
 // One cell, float: NumPy's pairwise sum (loops_utils.h) over pieces of at most 8192 elements -- what the ufunc's
-// buffered iterator hands the loop at a time -- chained from -0.0.  One lane does it (a raster of one cell).
+// buffered iterator hands the loop at a time -- added to add's identity.  One lane does it (a raster of one cell).
 template <typename T>
 __device__ T cell_pairwise(const T* a, int n) {
   if (n < 8) {
@@ -854,7 +858,7 @@ __device__ T cell_pairwise(const T* a, int n) {
 }
 template <typename T>
 __global__ void frames_sum_cell_kernel(const T* __restrict__ frames, int n, T* __restrict__ out) {
-  T total = (T)-0.0;
+  T total = (T)0.0;  // (add's identity; the pieces themselves chain from -0.0, loops_utils.h)
   for (int piece = 0; piece < n; piece += 8192) total += cell_pairwise(frames + piece, n - piece < 8192 ? n - piece : 8192);
   *out = total;
 }
@@ -889,6 +893,7 @@ int launch_frames_sum(const void* frames, int n, long long pixels, void* out, hi
     case GM_U32: rc = CALL(unsigned int); break;                     \
     case GM_I32: rc = CALL(int); break;                              \
     case GM_I64: rc = CALL(long long); break;                        \
+    case GM_U64: rc = CALL(unsigned long long); break;               \
     case GM_F32: rc = CALL(float); break;                            \
     case GM_F64: rc = CALL(double); break;                           \
     default: return gm::fail(GM_ERR_UNSUPPORTED, "temporal statistics: dtype %d", dtype); \

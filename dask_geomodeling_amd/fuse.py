@@ -21,6 +21,8 @@ The per-tile keys stay in the graph as ``(getitem, batch_key, i)``.
 not a tile of values the member tasks are simply run one by one with their own ``process``
 bodies, which carry the reference's control flow for those cases.
 """
+import math
+
 import numpy as np
 
 from . import utils
@@ -152,7 +154,9 @@ class FusedTask(object):
             for key in self.order:
                 nodes[key] = self._node(key, nodes)
             staged, shape = P.plan_staged(nodes[self.root])
-        except (_NotFusable, P.FusionLimit, NotImplementedError, TypeError):
+        except (_NotFusable, P.FusionLimit, NotImplementedError, TypeError, IndexError):
+            # (IndexError: frames that NumPy's boolean indexing would refuse -- op by op the Block that refuses them raises,
+            #  or hands back what the reference hands back before it gets there: Clip of an all-no-data store)
             self._plans[sig] = self._UNFUSABLE  # do not rebuild the node tree for every tile
             return None
         stages = []
@@ -162,6 +166,13 @@ class FusedTask(object):
                 if isinstance(l, P.StageRef):
                     binding.append((2, l.stage))
                 elif id(l) in arg_of:
+                    arrived = tuple(leaf_values[arg_of[id(l)]]["values"].shape)
+                    if arrived != tuple(shape) and math.prod(arrived) != 1:
+                        # a raster of 1 frame against rasters of n (NumPy broadcasts them in a ufunc): P.plan expanded THIS
+                        # call's tile; a remembered binding would hand the next call's tile to the program as it arrives.
+                        # Rare (TemporalSum / a single-frame source next to a series): such tiles run op by op.
+                        self._plans[sig] = self._UNFUSABLE
+                        return None
                     binding.append((0, arg_of[id(l)]))
                 else:
                     binding.append((1, l.values))  # constant ndarray operand, uploaded once
@@ -231,7 +242,7 @@ class FusedTask(object):
                 raise _NotFusable()
             return devops.math_node(op, args[0], [operand(a) for a in args[1:]])
         if op == "reduce_max":
-            if not isinstance(args[0], dict):
+            if not isinstance(args[0], dict) or len(args) < 2:  # (no raster at all: the Block's own process answers)
                 raise _NotFusable()
             return devops.reduce_max_node(args[0], [operand(a) for a in args[1:]])
         if op == "fillnodata":

@@ -1023,6 +1023,45 @@ def _weight(node):
     return 1 + sum(_weight(a) for a in node.args) if isinstance(node, Op) else 0
 
 
+# Steps the reference computes by BOOLEAN INDEXING rather than by a ufunc -- values[mask] = ... in Clip.process
+# (misc.py:119-122), values[index] = data[index] in FillNoData.process (elemwise.py:749-755), stack_array[i, index] in
+# reduce_rasters (reduction.py:103-107): NumPy does not broadcast there, a raster of 1 frame against one of n is an
+# IndexError, not n copies.  The kernels would broadcast; the shapes are checked here so that the caller sees the
+# reference's error (args: which operands must agree).
+_INDEXED = {"clip": (0, 1), "fillnodata": (0, 1), "fmax": (0, 1)}
+
+
+def _check_indexed_shapes(root):
+    memo = {}
+
+    def shape_of(node):
+        hit = memo.get(id(node))
+        if hit is not None:
+            return hit
+        if isinstance(node, Leaf):
+            out = tuple(_leaf_shape(node))
+        elif isinstance(node, Op):
+            shapes = [shape_of(a) for a in node.args]
+            pair = _INDEXED.get(node.op)
+            if pair is not None:
+                a, b = shapes[pair[0]], shapes[pair[1]]
+                if a != () and b != () and a != b:
+                    axis = next((k for k, (x, y) in enumerate(zip(a, b)) if x != y), 0) if len(a) == len(b) else 0
+                    raise IndexError("boolean index did not match indexed array along axis %d; size of axis is %s but size of "
+                                     "corresponding boolean axis is %s" % (axis, a[axis] if axis < len(a) else "?",
+                                                                           b[axis] if axis < len(b) else "?"))
+            try:
+                out = tuple(np.broadcast_shapes(*shapes)) if shapes else ()
+            except ValueError:
+                out = ()  # (plan() reports it, with every operand's shape)
+        else:
+            out = ()
+        memo[id(node)] = out
+        return out
+
+    shape_of(root)
+
+
 def plan_staged(root):
     """Partition an expression into as few programs as possible -> (stages, shape).
 
@@ -1031,6 +1070,7 @@ def plan_staged(root):
     stage computes ``root``.  Cuts are placed bottom-up where no register class serves both sides
     (e.g. float32 arithmetic + Classify | Reclassify + Mask in the int64 class), keeping the largest
     compatible part fused; programs that exceed the input / step / temp limits are split on top."""
+    _check_indexed_shapes(root)
     stages = []
     memo = {}
     shape_of = {}

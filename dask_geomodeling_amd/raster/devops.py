@@ -175,7 +175,7 @@ def reduce_max_process(process_kwargs, *args):
         stack.append(arg)
     if len(stack) == 0:
         return None
-    tiles = [(a["values"], a["no_data_value"]) for a in stack]
+    tiles = _without_empty_indices([(a["values"], a["no_data_value"]) for a in stack])
     try:
         key = ("reduce_max", str(process_kwargs["dtype"]), P._scalar_key(process_kwargs["fillvalue"]), len(tiles))
         hash(key)
@@ -328,6 +328,19 @@ def make_math_process(op):
     return process
 
 
+def _size(values):
+    return int(np.prod(values.shape, dtype=np.int64))
+
+
+def _without_empty_indices(tiles):
+    """The rasters of a FillNoData / reduce_rasters loop less those that cannot change the result: ``out[index] = ...`` with
+    an EMPTY index (a raster without a frame in the window, next to a first raster that has some) is no error in NumPy
+    and assigns nothing.  (An empty FIRST raster, or frames that differ otherwise, are NumPy's IndexError: raised by
+    hip/program.py _check_indexed_shapes.)"""
+    first = tuple(tiles[0][0].shape)
+    return [tiles[0]] + [t for t in tiles[1:] if not (_size(t[0]) == 0 and tuple(t[0].shape) != first)]
+
+
 def all_equal(values, ndv):
     """``np.all(values == ndv)`` on the device (Clip early-out, misc.py:108)."""
     arr = as_device(values)
@@ -352,6 +365,13 @@ def clip_process(data, source_data):
         return data if all_equal(data["values"], data["no_data_value"]) else None
     tiles = [(data["values"], data["no_data_value"]),
              (source_data["values"], source_data.get("no_data_value"))]
+    if tuple(tiles[0][0].shape) != tuple(tiles[1][0].shape):
+        if all_equal(data["values"], data["no_data_value"]):
+            return data  # (misc.py:106-108 looks at the store first; the indexing that refuses the shapes comes after)
+        if _size(tiles[1][0]) == 0:
+            # values[mask] with an EMPTY mask (no frame of the source in the window) is no error in NumPy whatever the
+            # shapes: nothing is masked.  Any other mismatch is NumPy's IndexError (hip/program.py _check_indexed_shapes)
+            return {"values": data["values"], "no_data_value": data["no_data_value"]}
     try:
         values, ndv = P.run_expr(lambda leaves: clip_node(leaves[0], leaves[1]), tiles, ("clip",))
     except (NotImplementedError, P.FusionLimit):
@@ -413,6 +433,7 @@ def fillnodata_process(process_kwargs, *args):
     fill = utils.get_dtype_max(dtype)
     if not tiles:
         return None
+    tiles = _without_empty_indices(tiles)
 
     def build(leaves):
         node = P.Lit(fill)

@@ -301,6 +301,8 @@ class Smooth(BaseSingle):
             values = stencil.gaussian_smooth(data["values"], ndv, fill, sigma, crop, out=process_kwargs.get("gm_out"))
         else:
             values = stencil.gaussian_smooth(data["values"], ndv, fill, sigma)
+            if values.shape[0] == 0:
+                return {"values": values, "no_data_value": ndv}
             _, ny, nx = values.shape
             zoom = 1 - 2 * size_px[0] / ny, 1 - 2 * size_px[1] / nx
             values = resample.affine_nearest(values, zoom, (size_px[0], size_px[1]))

@@ -116,7 +116,7 @@ def dilate(values, dilate_values, out=None):
     src = as_device_view(values)
     bands, h, w = src.shape
     vals = np.asarray(dilate_values, dtype=src.dtype)  # the reference's cast (spatial.py:151)
-    if h < 3 or w < 3:
+    if h < 3 or w < 3 or bands == 0:  # (no frame in the requested window: an empty stack goes in and comes out)
         return DeviceArray.empty((bands, max(h - 2, 0), max(w - 2, 0)), src.dtype)
     shape = (bands, h - 2, w - 2)
     out = _into(out, shape, src.dtype) or DeviceArray.empty(shape, src.dtype)
@@ -142,6 +142,8 @@ def moving_max(values, no_data_value, size, out=None):
         # the reference fails here too: utils.get_dtype_min has no minimum for bool (spatial.py:198)
         raise ValueError("Invalid integer data type 'b'.")
     shape = (bands, h - 2 * radius, w - 2 * radius)
+    if bands == 0:
+        return DeviceArray.empty(shape, src.dtype)
     out = _into(out, shape, src.dtype) or DeviceArray.empty(shape, src.dtype)
     has, bits = _ndv_bits(src.dtype, no_data_value)
     L = _lib()
@@ -167,6 +169,8 @@ def hillshade(values, no_data_value, fill, resolution, altitude, azimuth):
         if no_data_value is not None:
             no_data_value = np.int16(bool(no_data_value))
     out = DeviceArray.empty((bands, h - 2, w - 2), "u1")
+    if bands == 0:
+        return out
     has, bits = _ndv_bits(src.dtype, no_data_value)
     L = _lib()
     fill_bits = runtime.scalar_bits(fill_cast, src.dtype)
@@ -249,6 +253,8 @@ def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0), fused
     if not axes:  # nothing to smooth: one pass with the identity kernel does the no-data replacement and the crop
         axes = [(2, None)]
     my, mx = crop_yx
+    if bands == 0:
+        return DeviceArray.empty((0, h - 2 * my, w - 2 * mx), src.dtype)
     L = _lib()
     if fused and len(axes) == 2 and src.dtype == np.dtype("f4"):
         (wy, ry), (wx, rx) = gaussian_weights(axes[0][1]), gaussian_weights(axes[1][1])

@@ -1,0 +1,50 @@
+"""Many more temporal fuzz seeds than the test suite runs (GPU box): python tests/fuzz_temporal.py [n].  Lives under
+tests/ because it checks against the oracle (tests/oracle_walk.py)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from fuzz_util import describe, unsigned_zero
+from helpers import assert_result_equal
+from oracle_walk import comparable, random_requests, random_temporal_view, walk
+from dask_geomodeling_amd import config as gmconfig
+from dask_geomodeling_amd.hip import runtime
+runtime.set_device(0)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+bad = raised = asked = refused = 0
+for seed in range(N):
+    rng = np.random.default_rng(90_000 + seed)
+    view = random_temporal_view(rng, depth=int(rng.integers(1, 5)))
+    with gmconfig.config.set({"geomodeling.plans": seed % 2 == 0}):
+        for request in random_requests(rng, view):
+            asked += 1
+            try:
+                want = walk(view, request)
+            except Exception:
+                raised += 1
+                try:
+                    view.get_data(**request)
+                except Exception:
+                    continue
+                bad += 1
+                print("SEED", seed, "the reference raises, the device path answers")
+                continue
+            try:
+                try:
+                    got = view.get_data(**request)
+                except NotImplementedError:  # (a refusal DESIGN.md section 9 lists: no answer is not a wrong answer)
+                    refused += 1
+                    continue
+                if isinstance(want, np.ndarray):
+                    assert isinstance(got, np.ndarray) and got.shape == want.shape
+                else:
+                    assert_result_equal(comparable(got, view), comparable(want, view), 0, "")
+            except Exception as e:  # noqa
+                bad += 1
+                print("SEED", seed, type(e).__name__, str(e)[:200])
+                print("   ", describe(view)[:500])
+                print("   ", {k: str(v) for k, v in request.items() if k in ("mode", "start", "stop")})
+    if bad > 25:
+        break
+print("done: %d views, %d requests (%d of them raise in the reference too, %d refused by the device), %d failures"
+      % (N, asked, raised, refused, bad))

@@ -92,3 +92,40 @@ def test_sign_of_zero_normalisation_is_measured(gpu):
           % (views, cells, signed, 100.0 * signed / max(cells, 1)))
     assert views >= 20
     assert signed <= cells // 100, "%d of %d cells differ in the sign of zero" % (signed, cells)
+
+
+def _same_response(got, want, what):
+    if isinstance(want, np.ndarray):  # (an empty window: sources.py:91-92 hands back the bare array)
+        assert isinstance(got, np.ndarray) and got.shape == want.shape and got.dtype == want.dtype, what
+        return
+    assert_result_equal(got, want, 0, what)
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_temporal_views_against_the_walking_oracle(gpu, seed):
+    """Random trees over multi-frame MemorySources -- element-wise steps, Snap / Shift / TemporalSum / TemporalAggregate /
+    Cumulative / Resample, Place, the stencils -- asked for values in six time windows (none, a moment, windows inside, across and
+    beyond the period), for their times and their metadata: the device answer equals, bit for bit, the view walked Block by
+    Block with the reference's planning and the oracle's process bodies (tests/oracle_walk.py); where the reference's own
+    evaluation raises (frames of two sources that do not line up, metadata a source does not have), so does the device path.
+    Every other seed runs with a graph per request instead of the plans."""
+    from dask_geomodeling_amd import config as gmconfig
+    from oracle_walk import comparable, random_requests, random_temporal_view, walk
+    rng = np.random.default_rng(70_000 + seed)
+    view = random_temporal_view(rng, depth=int(rng.integers(1, 4)))
+    with gmconfig.config.set({"geomodeling.plans": seed % 2 == 0}):
+        for request in random_requests(rng, view):
+            what = "%s <- %s" % (describe(view)[:600], {k: str(v) for k, v in request.items() if k in ("mode", "start", "stop")})
+            try:
+                want = walk(view, request)
+            except NotImplementedError:
+                raise
+            except Exception:  # noqa: BLE001 -- whatever NumPy / pandas raise inside the reference's bodies
+                with pytest.raises(Exception):
+                    view.get_data(**request)
+                continue
+            try:
+                got = view.get_data(**request)
+            except NotImplementedError as refusal:  # (DESIGN.md section 9: e.g. uint64 + float32 has no exact register class)
+                pytest.skip("not on the device path: %s" % refusal)
+            _same_response(comparable(got, view), comparable(want, view), what)

@@ -2016,3 +2016,98 @@ def test_zonal_label_partition(gpu, part, select):
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
     assert "PARTITION ok 240" in res.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f4", "f8"])
+def test_signed_zeros_through_the_temporal_statistics(gpu, dt):
+    """What the temporal fuzzing of round 4 found: NumPy's sums over the frame axis start from add's identity, so a cell whose
+    every frame is -0.0 sums (and averages, and -- through np.mean of the middle pair -- has a median of) +0.0; minima and
+    maxima hand a tie between -0.0 and +0.0 to the later frame.  Every pattern of zeros and no data over 1-3 frames, every
+    statistic, against the oracle (= the NumPy functions of the reference's table); TemporalSum and reduce_rasters likewise."""
+    from dask_geomodeling_amd.raster import temporal as T
+    from dask_geomodeling_amd.raster import reduction
+    nd = np.dtype(dt).type(np.finfo(dt).max)
+    patterns = [[-0.0], [-0.0, -0.0], [-0.0, 0.0], [0.0, -0.0], [-0.0, nd], [nd, -0.0], [-0.0] * 3, [nd, nd], [-0.0, 1.0, -1.0],
+                [-0.0] * 9, [0.0, -0.0, -0.0], [nd, -0.0, 0.0]]
+
+    def same(got, want, what):
+        got, want = np.asarray(got), np.asarray(want)
+        assert got.dtype == want.dtype and got.shape == want.shape, what
+        assert np.array_equal(got, want, equal_nan=True) and np.array_equal(np.signbit(got), np.signbit(want)), (what, got.ravel()[:3], want.ravel()[:3])
+
+    for p in patterns:
+        v = np.array(p, dtype=dt).reshape(len(p), 1, 1) * np.ones((1, 5, 7), dtype=dt)
+        runs = [(0, len(p))]
+        mixed = any(x == 0 and np.signbit(x) for x in p) and any(x == 0 and not np.signbit(x) for x in p)
+        for stat in ("sum", "mean", "min", "max", "median", "std", "count", "p90"):
+            if stat == "p90" and mixed:
+                continue  # (a percentile picks from the SORTED frames: where +0.0 lands among -0.0s is the sort's business)
+            dtype = np.dtype("i4") if stat == "count" else np.dtype(dt)
+            same(T.aggregate_frames(v, nd, runs, stat, dtype), O.temporal_aggregate_values(v, nd, runs, stat, dtype), (p, stat))
+        same(T.sum_frames(v), O.frames_sum(v), (p, "TemporalSum"))
+        one = v[:, :1, :1]
+        same(T.sum_frames(one), O.frames_sum(one), (p, "TemporalSum of one cell"))
+        stack = [{"values": v[k:k + 1], "no_data_value": nd} for k in range(len(p))]
+        for stat in ("sum", "mean", "median"):
+            got = reduction.reduce_rasters(stack, stat)
+            want = O.reduce_rasters(stack, stat)
+            same(got["values"], want["values"], (p, "reduce_rasters " + stat))
+
+
+@pytest.mark.gpu
+def test_frames_that_do_not_line_up(gpu):
+    """More of what the temporal fuzzing found.  (1) A raster of one frame next to a series in a ufunc step is NumPy
+    broadcasting -- also when the step is planned / fused (the remembered program used to be handed the one frame as if it were
+    n).  (2) Where the reference indexes with a boolean array (Clip, FillNoData, Max) frames that differ are NumPy's IndexError,
+    except for an EMPTY index, which selects nothing; an all-no-data store leaves Clip before it gets there.  (3) An empty stack
+    (no frame in the window) passes through the stencils.  (4) uint64 series (TemporalSum of a uint8 raster) are counted."""
+    from datetime import datetime, timedelta
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd import raster
+    from oracle_walk import walk
+    rng = np.random.default_rng(11)
+    day = timedelta(days=1)
+
+    def source(frames, dt="f4", ndv=-9999.0, first=datetime(2021, 3, 1)):
+        v = (rng.random((frames, 24, 40)) * 40).astype(dt)
+        v[rng.random(v.shape) < 0.1] = ndv
+        return raster.MemorySource(v, ndv, "EPSG:28992", 1.0, (0.0, 24.0), time_first=first, time_delta=day if frames > 1 else None)
+
+    box = dict(mode="vals", bbox=(0.0, 0.0, 40.0, 24.0), width=40, height=24, projection="EPSG:28992")
+    everything = dict(box, start=datetime(2021, 1, 1), stop=datetime(2021, 6, 1))
+    series, one = source(3), raster.TemporalSum(source(5))
+    for view in (series / one, one / series, series * 0.5 / one, raster.Snap(series, series) - one):
+        for plans in (True, False):
+            with gmconfig.config.set({"geomodeling.plans": plans}):
+                assert_result_equal(view.get_data(**everything), walk(view, everything), 0, "1 frame against 3, plans %s" % plans)
+    for view in (raster.Clip(series, one > 5), raster.FillNoData(series, one), raster.Max(series, one), raster.Clip(series * 2, one > 5)):
+        for plans in (True, False):
+            with gmconfig.config.set({"geomodeling.plans": plans}):
+                with pytest.raises(IndexError):
+                    walk(view, everything)
+                with pytest.raises(IndexError):
+                    view.get_data(**everything)
+    # an empty index: the second source has no frame between its days
+    gap = dict(box, start=datetime(2021, 3, 1, 3), stop=datetime(2021, 3, 1, 9))
+    late = source(3, first=datetime(2021, 3, 1, 6))
+    assert walk(late, gap)["values"].shape[0] == 1 and walk(series, gap)["values"].shape[0] == 0
+    for view in (raster.Clip(raster.TemporalSum(late), series > 5), raster.Mask(raster.Clip(raster.TemporalSum(late) * 2, series > 5), 1)):
+        for plans in (True, False):
+            with gmconfig.config.set({"geomodeling.plans": plans}):
+                want = walk(view, gap)
+                assert want["values"].shape[0] == 1
+                assert_result_equal(view.get_data(**gap), want, 0, "empty mask, plans %s" % plans)
+    # an empty stack through the stencils
+    between = dict(box, start=datetime(2021, 3, 1, 15), stop=datetime(2021, 3, 1, 22))
+    for view in (raster.Dilate(source(2, "i4", -9999), [0, 7]), raster.MovingMax(series, 3), raster.Smooth(series, 1.5), raster.HillShade(series),
+                 raster.Smooth(series, 30.0)):
+        want, got = walk(view, between), view.get_data(**between)
+        assert want["values"].shape[0] == 0 and np.asarray(got["values"]).shape == want["values"].shape, type(view).__name__
+    # uint64 series
+    counts = raster.TemporalSum(source(4, "u1", 255))
+    assert np.asarray(counts.get_data(**everything)["values"]).dtype == np.dtype("u8")  # (np.sum's accumulator)
+    # (the Block still declares uint8 -- the reference's TemporalSum inherits its store's dtype --, so statistics whose result
+    #  dtype follows the declared one are refused rather than cast; the counting ones do not depend on it)
+    for view in (raster.Cumulative(counts, "count"), raster.TemporalAggregate(counts, "D", "count"), raster.TemporalAggregate(counts, None, "count")):
+        assert_result_equal(view.get_data(**everything), walk(view, everything), 0, type(view).__name__ + " of uint64")
