@@ -126,6 +126,8 @@ class DeviceArray:
         start, stop = int(start), int(stop)
         if self.pitch is not None:
             raise ValueError("band_slice() of a strided window")
+        if not 0 <= start <= stop <= self.shape[0]:
+            raise IndexError("bands [%d, %d) of a tile of %d" % (start, stop, self.shape[0]))
         plane = _prod(self.shape[1:]) * self.dtype.itemsize
         return DeviceArray(self.ptr + start * plane, (stop - start,) + self.shape[1:], self.dtype,
                            self.device, owner=self)

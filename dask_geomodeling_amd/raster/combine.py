@@ -268,7 +268,10 @@ class Group(BaseCombine):
         if mode == "vals":
             frames = [[] for _ in times]
             for data, stamp in zip(responses, stamps):
+                held = data["values"].shape[0]
                 for k, moment in enumerate(stamp["time"]):
+                    if k >= held:  # data["values"][k] of combine.py:331 (a source whose times and frames disagree)
+                        raise IndexError("index %d is out of bounds for axis 0 with size %d" % (k, held))
                     frames[slot[moment]].append((_band(data["values"], k), data["no_data_value"]))
         else:
             frames = [None] * len(times)
@@ -295,7 +298,13 @@ class Group(BaseCombine):
         shape = kwargs["shape"]
         frames = [[] for _ in range(shape[0])]
         for data, (lo, hi) in zip(responses, ranges):
-            for i in range(lo, hi):
+            held, span = data["values"].shape[0], max(min(hi, shape[0]) - lo, 0)
+            if held == 0:
+                continue  # values[lo:hi][index] with an empty index assigns nothing (combine.py:388-391)
+            if held != span:  # ... and any other index of another length is NumPy's error
+                raise IndexError("boolean index did not match indexed array along axis 0; size of axis is %d but size of "
+                                 "corresponding boolean axis is %d" % (span, held))
+            for i in range(lo, lo + span):
                 frames[i].append((_band(data["values"], i - lo), data["no_data_value"]))
         values = _merge_bands(kwargs["dtype"], frames, shape[1:])
         return {"values": values, "no_data_value": get_dtype_max(kwargs["dtype"])}

@@ -100,7 +100,10 @@ class RasterTiler(BaseSingle):
                 continue
             tile = as_device(data["values"])
             if tile.dtype != dtype:
-                raise TypeError("tile dtype %s does not match the tiler's %s" % (tile.dtype, dtype))
+                # values[...] = tile of parallelize.py:118-124 casts on assignment (a TemporalSum below the tiler hands
+                # int64 sums to a mosaic of its store's declared dtype): NumPy's astype, as a COPY program
+                from .stencil import _cast_tile
+                tile = _cast_tile(tile, dtype)
             if tile.shape[0] != bands:
                 raise ValueError("tile of %d bands in a mosaic of %d" % (tile.shape[0], bands))
             _, th, tw = tile.shape

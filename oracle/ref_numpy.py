@@ -1029,6 +1029,81 @@ def place_process(process_kwargs, *multi):
 ZONAL_STATISTICS = ("sum", "count", "min", "max", "mean", "median", "percentile")
 
 
+def _group_moments(responses):
+    """Group._unique_times (combine.py:301-304): the time stamps of all responses, once each, in order."""
+    stamps = set()
+    for response in responses:
+        if response is not None and response.get("time") is not None:
+            stamps.update(response["time"])
+    return sorted(stamps)
+
+
+def _group_one_frame(items, moments, process_kwargs):
+    """combine.py:339-343 / 366-370 / 418-422: a request for a moment (stop is None) is answered with the frame
+    nearest to it -- the last one when no moment was asked for."""
+    if process_kwargs["stop"] is not None or len(moments) <= 1:
+        return items
+    start = process_kwargs["start"]
+    k = len(moments) - 1 if start is None else min(range(len(moments)), key=lambda i: abs(moments[i] - start))
+    return items[k:k + 1]
+
+
+def group_process(process_kwargs, *args):
+    """Group.process (combine.py:407-461) with its merge helpers (:314-404): later sources are pasted over earlier
+    ones wherever they have data (utils.get_index), frames lined up by time stamp ('by_time') or by position on the
+    common time grid ('by_bands')."""
+    plan, mode = process_kwargs["combine_mode"], process_kwargs.get("mode")
+    if plan == "simple":
+        return None
+    if plan == "by_time" and mode == "time":
+        moments = _group_moments(args)
+        return {"time": _group_one_frame(moments, moments, process_kwargs)}
+    if plan == "by_time" and mode in ("meta", "vals"):
+        half = len(args) // 2
+        responses = [a for a in args[:half] if a is not None]
+        stamps = [a for a in args[half:] if a is not None]
+        if not responses:
+            return None
+        moments = _group_moments(stamps)
+        slot = {moment: k for k, moment in enumerate(moments)}
+        if mode == "meta":
+            merged = [None] * len(moments)
+            for response, stamp in zip(responses, stamps):
+                for k, moment in enumerate(stamp["time"]):
+                    merged[slot[moment]] = response["meta"][k]
+            return {"meta": _group_one_frame(merged, moments, process_kwargs)}
+        dtype = process_kwargs["dtype"]
+        fill = get_dtype_max(dtype)
+        merged = np.full((len(moments),) + responses[0]["values"].shape[1:], fill, dtype=dtype)
+        for response, stamp in zip(responses, stamps):
+            for k, moment in enumerate(stamp["time"]):
+                frame = response["values"][k]
+                has_data = get_index(frame, response["no_data_value"])
+                merged[slot[moment]][has_data] = frame[has_data]
+        return {"values": _group_one_frame(merged, moments, process_kwargs), "no_data_value": fill}
+    if plan == "by_bands" and mode == "time":
+        first, last, step = process_kwargs["start"], process_kwargs["stop"], process_kwargs["timedelta"]
+        count = int((last - first).total_seconds() // step.total_seconds()) + 1
+        return {"time": [first + k * step for k in range(count)]}
+    if plan == "by_bands" and mode in ("meta", "vals"):
+        present = [(a, span) for a, span in zip(args, process_kwargs["bands"]) if a is not None]
+        if mode == "meta":
+            merged = [""] * process_kwargs["nbands"]
+            for response, (lo, hi) in present:
+                for k, item in zip(range(lo, hi), response["meta"]):
+                    if item:
+                        merged[k] = item
+            return {"meta": merged}
+        dtype = process_kwargs["dtype"]
+        fill = get_dtype_max(dtype)
+        merged = np.full(process_kwargs["shape"], fill, dtype=dtype)
+        for response, (lo, hi) in present:
+            has_data = get_index(response["values"], response["no_data_value"])
+            merged[lo:hi][has_data] = response["values"][has_data]
+        return {"values": merged, "no_data_value": fill}
+    raise ValueError("Unknown combine_mode / mode combination")
+
+
 def _labelled_sums(weights, labels, index):
     """scipy.ndimage sum / mean over labels (``_stats``): np.bincount -- float64 accumulation cell after cell
     in raster order.  Returns (counts, sums) for ``index``."""

@@ -20,14 +20,16 @@ for seed in range(N):
             asked += 1
             try:
                 want = walk(view, request)
-            except Exception:
+            except Exception as reference_error:
                 raised += 1
                 try:
                     view.get_data(**request)
                 except Exception:
                     continue
                 bad += 1
-                print("SEED", seed, "the reference raises, the device path answers")
+                print("SEED", seed, "the reference raises, the device path answers:", type(reference_error).__name__, str(reference_error)[:120])
+                print("   ", describe(view)[:500])
+                print("   ", {k: str(v) for k, v in request.items() if k in ("mode", "start", "stop", "bbox", "width", "height")})
                 continue
             try:
                 try:

@@ -56,11 +56,13 @@ def _process(block, args):
               "Dilate": O.dilate_process, "MovingMax": O.movingmax_process, "Smooth": O.smooth_process,
               "TemporalAggregate": O.temporal_aggregate_process, "Cumulative": O.cumulative_process, "Snap": O.snap_process,
               "Shift": O.shift_process, "TemporalSum": O.temporal_sum_process, "Resample": O.resample_process,
-              "Place": O.place_process, "RasterTiler": O.tiler_process}
+              "Place": O.place_process, "RasterTiler": O.tiler_process, "Group": O.group_process}
     if name in simple:
         return simple[name](*args)
     if name == "HillShade":
         return O.hillshade_process(*args, trig="rounded")  # (host-independent trigonometry: see test_stencils_golden)
+    if name in ("ArrayLeaf", "TemporalLeaf"):
+        return type(block).process(*args)  # (test-only leaves, tests/blocks_util.py: host code)
     raise NotImplementedError("no oracle process for " + name)
 
 
@@ -129,6 +131,8 @@ def random_temporal_view(rng, depth=3):
             return raster.Mask(a, [1, 7, 2.5][int(rng.integers(3))])
         if c < 0.52:
             return raster.Classify(a, [0.0, 5.0, 11.5, 20.0], bool(rng.random() < 0.5))
+        if c < 0.56:
+            return raster.Group(a, node(d - 1)) if rng.random() < 0.7 else raster.Group(a, node(d - 1), node(d - 1))
         if c < 0.60:
             return raster.Snap(a, node(d - 1))
         if c < 0.67:
@@ -159,6 +163,9 @@ def random_temporal_view(rng, depth=3):
     for _ in range(30):
         try:
             view = node(depth)
+            if rng.random() < 0.2:  # the tiles of a mosaic, each with the planning of the whole tree behind it
+                view = raster.RasterTiler(view, [int(rng.integers(4, 30)), int(rng.integers(4, 30))]
+                                          if rng.random() < 0.7 else int(rng.integers(5, 40)))
             view.dtype, view.fillvalue, view.period, view.timedelta  # attribute algebra must hold
             return view
         except (TypeError, ValueError):
@@ -182,8 +189,24 @@ def random_requests(rng, view):
         asks.append(dict(start=a, stop=b))
     asks.append(dict(start=lo - timedelta(days=30), stop=hi + timedelta(days=30)))
     out = []
+    c = rng.random()
+    if c < 0.55:
+        box = BOX
+    elif c < 0.70:   # a window of the sources' grid
+        x0, y0 = int(rng.integers(0, 20)), int(rng.integers(0, 12))
+        w, h = int(rng.integers(1, 20)), int(rng.integers(1, 12))
+        box = dict(BOX, bbox=(float(x0), float(y0), float(x0 + w), float(y0 + h)), width=w, height=h)
+    elif c < 0.80:   # coarser cells
+        box = dict(BOX, width=20, height=12)
+    elif c < 0.88:   # finer cells
+        box = dict(BOX, bbox=(10.0, 6.0, 30.0, 18.0), width=40, height=24)
+    elif c < 0.96:   # half a cell off the grid and partly outside the sources
+        box = dict(BOX, bbox=(-7.5, -3.5, 32.5, 20.5))
+    else:            # a point
+        x, y = float(rng.integers(0, 40)) + 0.5, float(rng.integers(0, 24)) + 0.5
+        box = dict(BOX, bbox=(x, y, x, y), width=1, height=1)
     for when in asks:
-        out.append(dict(BOX, mode="vals", **when))
+        out.append(dict(box, mode="vals", **when))
     out.append(dict(mode="time", **asks[int(rng.integers(len(asks)))]))
     out.append(dict(mode="meta", **asks[int(rng.integers(len(asks)))]))
     return out

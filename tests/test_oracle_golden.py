@@ -315,6 +315,24 @@ def test_round4(case):
         assert_result_equal(out, want, 0, case["id"])
 
 
+@pytest.mark.parametrize("case", load_family("group"), ids=lambda c: c["id"] + "-" + c["setup"] + "-" + c["request"]["mode"])
+def test_group_walked(case):
+    """Group over temporal sources, every request mode: the view walked with the reference's planning and the oracle's
+    group_process (tests/oracle_walk.py) against what the reference's own Group answered."""
+    from blocks_util import TemporalLeaf
+    from dask_geomodeling_amd import raster
+    from oracle_walk import walk
+    leaves = []
+    for spec in case["sources"]:
+        TemporalLeaf.ARRAYS[spec["name"]] = {"values": spec["data"], "no_data_value": spec["ndv"]}
+        leaves.append(TemporalLeaf(spec["name"], spec["dtype"], spec["ndv"], spec["times"], spec["delta"]))
+    out = walk(raster.Group(*leaves), case["request"])
+    if case["expect"] is None:
+        assert out is None
+    else:
+        assert_result_equal(out, case["expect"], 0, case["id"])
+
+
 # ---------------------------------------------------------------------------------
 # N4: zonal statistics (AggregateRaster's numeric core)
 # ---------------------------------------------------------------------------------
