@@ -43,8 +43,9 @@ def is_int(b):
     return b.dtype.kind in "iu"
 
 
-def random_view(rng, tag, depth=4, memory=False):
-    """A random Block tree (and the leaves it uses)."""
+def random_view(rng, tag, depth=4, memory=False, smooth=False):
+    """A random Block tree (and the leaves it uses).  ``smooth``: Smooth among the stencils (not for tiled == whole
+    comparisons, see below)."""
     leaves = [make_leaf(rng, tag, k, memory) for k in range(int(rng.integers(1, 4)))]
 
     def numeric(d):
@@ -64,6 +65,8 @@ def random_view(rng, tag, depth=4, memory=False):
                 return raster.Dilate(a, [int(x) for x in rng.integers(0, 12, size=int(rng.integers(1, 4)))])
             if kind == 3 and a.dtype != np.dtype("bool") and not (a.dtype.kind == "u" and a.dtype.itemsize == 8):
                 return raster.HillShade(a, 45, 315, int(rng.integers(0, 3)))
+            if kind == 2 and smooth and a.dtype != np.dtype("bool"):
+                return raster.Smooth(a, [1.0, 2.5, 9.0][int(rng.integers(3))], int(rng.integers(0, 3)))
         if choice < 0.45:
             op = ["Add", "Subtract", "Multiply", "Divide"][int(rng.integers(4))]
             b = numeric(d - 1) if rng.random() < 0.5 else [2.5, 3, -1.5, 0.5, 7][int(rng.integers(5))]

@@ -129,3 +129,35 @@ def test_random_temporal_views_against_the_walking_oracle(gpu, seed):
             except NotImplementedError as refusal:  # (e.g. uint64 + float32 has no exact register class)
                 pytest.skip("not on the device path: %s" % refusal)
             _same_response(comparable(got, view), comparable(want, view), what)
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_memory_views_against_the_walking_oracle(gpu, seed):
+    """The random views of this file over MemorySources -- stencils (request enlargement) and Smooth (exact and zoom mode)
+    included -- asked for the whole grid, a window, coarser and finer cells, a box half a cell off the grid and partly outside
+    the sources, and a point: against the view walked with the oracle's process bodies (tests/oracle_walk.py).  Every other seed
+    with a graph per request instead of the plans."""
+    from dask_geomodeling_amd import config as gmconfig
+    from oracle_walk import comparable, walk
+    rng = np.random.default_rng(40_000 + seed)
+    view = random_view(rng, "w%d" % seed, depth=int(rng.integers(1, 4)), memory=True, smooth=True)
+    boxes = [REQ,
+             dict(REQ, bbox=(7.0, 3.0, 27.0, 15.0), width=20, height=12),
+             dict(REQ, width=20, height=12),
+             dict(REQ, bbox=(10.0, 6.0, 30.0, 18.0)),
+             dict(REQ, bbox=(-7.5, -3.5, 32.5, 20.5)),
+             dict(REQ, bbox=(11.5, 7.5, 11.5, 7.5), width=1, height=1)]
+    with gmconfig.config.set({"geomodeling.plans": seed % 2 == 0}):
+        for request in boxes:
+            what = "%s <- %s" % (describe(view)[:600], {k: request[k] for k in ("bbox", "width", "height")})
+            try:
+                want = walk(view, request)
+            except Exception:  # noqa: BLE001 -- the reference's own bodies raise: so must the device path
+                with pytest.raises(Exception):
+                    view.get_data(**request)
+                continue
+            try:
+                got = view.get_data(**request)
+            except NotImplementedError as refusal:
+                pytest.skip("not on the device path: %s" % refusal)
+            _same_response(comparable(got, view), comparable(want, view), what)
