@@ -91,10 +91,10 @@ KINDS = [("f4", np.float32(np.finfo("f4").max)), ("f4", -9999.0), ("u1", np.uint
          ("f8", float(np.finfo("f8").max))]
 
 
-def temporal_leaf(rng, frames=None, step_hours=None):
+def temporal_leaf(rng, frames=None, step_hours=None, shape_yx=SHAPE_YX):
     dt, ndv = KINDS[int(rng.integers(len(KINDS)))]
     n = int(rng.integers(1, 9)) if frames is None else frames
-    shape = (n,) + SHAPE_YX
+    shape = (n,) + tuple(shape_yx)
     if np.dtype(dt).kind == "f":
         v = (rng.random(shape) * 40 - 10).astype(dt)
     else:
@@ -103,14 +103,15 @@ def temporal_leaf(rng, frames=None, step_hours=None):
     step = timedelta(hours=int(step_hours if step_hours is not None else [1, 6, 24][int(rng.integers(3))]))
     first = T0 + timedelta(hours=int(rng.integers(0, 3))) * (1 if rng.random() < 0.15 else 0)  # (now and then off the others' grid)
     metadata = ["frame %d of %s" % (i, dt) for i in range(n)] if rng.random() < 0.5 else None
-    return raster.MemorySource(v, ndv, "EPSG:28992", 1.0, (0.0, float(SHAPE_YX[0])), time_first=first,
+    return raster.MemorySource(v, ndv, "EPSG:28992", 1.0, (0.0, float(shape_yx[0])), time_first=first,
                                time_delta=step if n > 1 else None, metadata=metadata)
 
 
-def random_temporal_view(rng, depth=3):
+def random_temporal_view(rng, depth=3, shape_yx=SHAPE_YX):
     """A random tree over multi-frame MemorySources: element-wise steps, the temporal Blocks, Place and the stencils."""
     step_hours = [1, 6, 24][int(rng.integers(3))]
-    leaves = [temporal_leaf(rng, step_hours=step_hours) for _ in range(int(rng.integers(1, 4)))]
+    leaves = [temporal_leaf(rng, step_hours=step_hours, shape_yx=shape_yx) for _ in range(int(rng.integers(1, 4)))]
+    ny, nx = shape_yx
 
     def node(d):
         if d == 0 or rng.random() < 0.15:
@@ -122,15 +123,29 @@ def random_temporal_view(rng, depth=3):
             b = node(d - 1) if rng.random() < 0.5 else [2.5, 3, -1.5, 0.5][int(rng.integers(4))]
             return getattr(raster, op)(a, b)
         if c < 0.30:
-            return raster.Clip(a, raster.Greater(node(d - 1), [3, 5.5, 0][int(rng.integers(3))]))
+            b = node(d - 1)
+            kind = rng.random()
+            mask = (raster.Greater(b, [3, 5.5, 0][int(rng.integers(3))]) if kind < 0.5 else
+                    raster.IsData(b) if kind < 0.65 else raster.Invert(raster.IsNoData(b)) if kind < 0.8 else b)
+            return raster.Clip(a, mask)
         if c < 0.36:
             return raster.FillNoData(a, node(d - 1))
         if c < 0.42:
             return raster.Max(a, node(d - 1))
         if c < 0.47:
             return raster.Mask(a, [1, 7, 2.5][int(rng.integers(3))])
-        if c < 0.52:
+        if c < 0.49:
             return raster.Classify(a, [0.0, 5.0, 11.5, 20.0], bool(rng.random() < 0.5))
+        if c < 0.52:
+            kind = int(rng.integers(3))
+            if kind == 0:
+                return raster.MaskBelow(a, [0.0, 3, 5.5][int(rng.integers(3))])
+            if kind == 1:
+                return raster.Step(a, 1, 5, [2.0, 4][int(rng.integers(2))], 3)
+            if a.dtype.kind in "iu":
+                table = [[int(k), int(rng.integers(0, 50))] for k in rng.choice(14, size=int(rng.integers(1, 8)), replace=False)]
+                return raster.Reclassify(a, table, bool(rng.random() < 0.4))
+            return raster.MaskBelow(a, 2.5)
         if c < 0.56:
             return raster.Group(a, node(d - 1)) if rng.random() < 0.7 else raster.Group(a, node(d - 1), node(d - 1))
         if c < 0.60:
@@ -150,8 +165,8 @@ def random_temporal_view(rng, depth=3):
             direction = ["nearest", "backward", "forward"][int(rng.integers(3))]
             return raster.Resample(a, ["H", "2H", "6H", "D"][int(rng.integers(4))], direction)
         if c < 0.96:
-            anchor = (float(rng.integers(5, 35)), float(rng.integers(5, 20)))
-            spots = [(float(rng.integers(0, 40)), float(rng.integers(0, 24))) for _ in range(int(rng.integers(1, 4)))]
+            anchor = (float(rng.integers(5, nx - 5)), float(rng.integers(5, ny - 4)))
+            spots = [(float(rng.integers(0, nx)), float(rng.integers(0, ny))) for _ in range(int(rng.integers(1, 4)))]
             return raster.Place(a, "EPSG:28992", anchor, spots)
         kind = int(rng.integers(3))
         if kind == 0:
@@ -164,8 +179,8 @@ def random_temporal_view(rng, depth=3):
         try:
             view = node(depth)
             if rng.random() < 0.2:  # the tiles of a mosaic, each with the planning of the whole tree behind it
-                view = raster.RasterTiler(view, [int(rng.integers(4, 30)), int(rng.integers(4, 30))]
-                                          if rng.random() < 0.7 else int(rng.integers(5, 40)))
+                view = raster.RasterTiler(view, [int(rng.integers(4, max(nx - 10, 6))), int(rng.integers(4, max(ny + 6, 6)))]
+                                          if rng.random() < 0.7 else int(rng.integers(5, nx)))
             view.dtype, view.fillvalue, view.period, view.timedelta  # attribute algebra must hold
             return view
         except (TypeError, ValueError):
@@ -173,9 +188,11 @@ def random_temporal_view(rng, depth=3):
     return leaves[0] + 1
 
 
-def random_requests(rng, view):
+def random_requests(rng, view, shape_yx=SHAPE_YX):
     """Time windows around the view's period (none: the latest frame; a moment; a window; windows that miss it) for the
-    three request modes."""
+    three request modes, over one of six kinds of box."""
+    ny, nx = shape_yx
+    whole = dict(bbox=(0.0, 0.0, float(nx), float(ny)), width=nx, height=ny, projection="EPSG:28992")
     period = view.period
     lo, hi = period if period is not None else (T0, T0)
     span = max((hi - lo).total_seconds() / 3600.0, 1.0)
@@ -191,20 +208,20 @@ def random_requests(rng, view):
     out = []
     c = rng.random()
     if c < 0.55:
-        box = BOX
+        box = whole
     elif c < 0.70:   # a window of the sources' grid
-        x0, y0 = int(rng.integers(0, 20)), int(rng.integers(0, 12))
-        w, h = int(rng.integers(1, 20)), int(rng.integers(1, 12))
-        box = dict(BOX, bbox=(float(x0), float(y0), float(x0 + w), float(y0 + h)), width=w, height=h)
+        x0, y0 = int(rng.integers(0, nx // 2)), int(rng.integers(0, ny // 2))
+        w, h = int(rng.integers(1, nx // 2)), int(rng.integers(1, ny // 2))
+        box = dict(whole, bbox=(float(x0), float(y0), float(x0 + w), float(y0 + h)), width=w, height=h)
     elif c < 0.80:   # coarser cells
-        box = dict(BOX, width=20, height=12)
+        box = dict(whole, width=nx // 2, height=ny // 2)
     elif c < 0.88:   # finer cells
-        box = dict(BOX, bbox=(10.0, 6.0, 30.0, 18.0), width=40, height=24)
+        box = dict(whole, bbox=(nx / 4.0, ny / 4.0, 3 * nx / 4.0, 3 * ny / 4.0))
     elif c < 0.96:   # half a cell off the grid and partly outside the sources
-        box = dict(BOX, bbox=(-7.5, -3.5, 32.5, 20.5))
+        box = dict(whole, bbox=(-7.5, -3.5, nx - 7.5, ny - 3.5))
     else:            # a point
-        x, y = float(rng.integers(0, 40)) + 0.5, float(rng.integers(0, 24)) + 0.5
-        box = dict(BOX, bbox=(x, y, x, y), width=1, height=1)
+        x, y = float(rng.integers(0, nx)) + 0.5, float(rng.integers(0, ny)) + 0.5
+        box = dict(whole, bbox=(x, y, x, y), width=1, height=1)
     for when in asks:
         out.append(dict(box, mode="vals", **when))
     out.append(dict(mode="time", **asks[int(rng.integers(len(asks)))]))

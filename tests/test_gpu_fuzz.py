@@ -101,7 +101,7 @@ def _same_response(got, want, what):
     assert_result_equal(got, want, 0, what)
 
 
-@pytest.mark.parametrize("seed", range(150))
+@pytest.mark.parametrize("seed", list(range(150)) + list(range(1000, 1030)))
 def test_random_temporal_views_against_the_walking_oracle(gpu, seed):
     """Random trees over multi-frame MemorySources -- element-wise steps, Snap / Shift / TemporalSum / TemporalAggregate /
     Cumulative / Resample, Place, the stencils -- asked for values in six time windows (none, a moment, windows inside, across and
@@ -112,9 +112,10 @@ def test_random_temporal_views_against_the_walking_oracle(gpu, seed):
     from dask_geomodeling_amd import config as gmconfig
     from oracle_walk import comparable, random_requests, random_temporal_view, walk
     rng = np.random.default_rng(70_000 + seed)
-    view = random_temporal_view(rng, depth=int(rng.integers(1, 4)))
+    shape = (24, 40) if seed < 1000 else (150, 517)  # (the larger rasters: windows with a pitch, several workgroups per tile)
+    view = random_temporal_view(rng, depth=int(rng.integers(1, 4)), shape_yx=shape)
     with gmconfig.config.set({"geomodeling.plans": seed % 2 == 0}):
-        for request in random_requests(rng, view):
+        for request in random_requests(rng, view, shape):
             what = "%s <- %s" % (describe(view)[:600], {k: str(v) for k, v in request.items() if k in ("mode", "start", "stop")})
             try:
                 want = walk(view, request)
