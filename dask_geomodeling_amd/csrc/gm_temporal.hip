@@ -249,6 +249,73 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const Tin* __restrict__ 
   store_pack<Tout, V>(out + (long long)B.out[blockIdx.y] * pixels + p, res);
 }
 
+// A raster of ONE cell (a point request: the time series of a location) is another reduction in NumPy: with nothing left
+// beside the frame axis, np.sum(work, axis=0) runs its contiguous inner loop -- PAIRWISE summation over pieces of at most
+// 8192 frames (loops_utils.h; the same rule as TemporalSum's frames_sum_cell_kernel) -- instead of adding frame by frame.
+// A lane per bin walks its frames that way: the sum, the mean from it, and for var / std the squared deviations summed
+// the same way (np.nanvar, nanfunctions.py).  Found by the round-4 fuzzing (a float64 mean of 24 frames, last bit).
+template <typename C, typename F>
+__device__ C pairwise_terms(const F& term, int start, int n) {
+  if (n < 8) {
+    C r = (C)-0.0;
+    for (int i = 0; i < n; ++i) r += term(start + i);
+    return r;
+  }
+  if (n <= 128) {
+    C r[8];
+    for (int u = 0; u < 8; ++u) r[u] = term(start + u);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int u = 0; u < 8; ++u) r[u] += term(start + i + u);
+    C res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += term(start + i);
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return pairwise_terms<C, F>(term, start, n2) + pairwise_terms<C, F>(term, start + n2, n - n2);
+}
+template <typename C, typename F>
+__device__ C chunked_pairwise(const F& term, int n) {
+  C total = (C)0.0;  // add's identity
+  for (int piece = 0; piece < n; piece += 8192) total += pairwise_terms<C, F>(term, piece, n - piece < 8192 ? n - piece : 8192);
+  return total;
+}
+template <typename Tin, int STAT>
+__global__ void aggregate_cell_kernel(const Tin* __restrict__ frames, Tin ndv, bool has_ndv, Bins B, int n_bins,
+                                      typename OutOf<Tin, STAT>::type* __restrict__ out,
+                                      typename OutOf<Tin, STAT>::type fill) {
+  using Tout = typename OutOf<Tin, STAT>::type;
+  using C = typename Work<Tout>::type;
+  const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bin >= n_bins) return;
+  const int count = B.count[bin];
+  const Tin* src = frames + B.first[bin];
+  int cnt = 0;
+  for (int i = 0; i < count; ++i) {
+    C x;
+    cnt += skipped<Tin, C>(src[i], ndv, has_ndv, x) ? 0 : 1;
+  }
+  auto value = [&](int i) -> C {
+    C x;
+    return skipped<Tin, C>(src[i], ndv, has_ndv, x) ? (C)0 : x;
+  };
+  C r = chunked_pairwise<C>(value, count);
+  if constexpr (STAT == GM_STAT_MEAN || STAT == GM_STAT_VAR || STAT == GM_STAT_STD) r = (C)((double)r / (double)cnt);  // 0 / 0 = NaN
+  if constexpr (STAT == GM_STAT_VAR || STAT == GM_STAT_STD) {
+    const C mean = r;
+    auto squared = [&](int i) -> C {
+      C x;
+      const C d = skipped<Tin, C>(src[i], ndv, has_ndv, x) ? (C)0 : x - mean;
+      return d * d;
+    };
+    const C sq = chunked_pairwise<C>(squared, count);
+    r = cnt > 0 ? (C)((double)sq / (double)cnt) : std::numeric_limits<C>::quiet_NaN();
+    if constexpr (STAT == GM_STAT_STD) r = sqrt(r);
+  }
+  out[B.out[bin]] = (count > 0 && finite_<C>(r)) ? (Tout)r : fill;
+}
+
 // Cumulative: running nancumsum / count of data within every bin; frame j is written to output frame
 // j - emit_first when emit_first <= j < emit_stop (the requested window, temporal.py:979-1001).
 template <typename Tin, int STAT, int V>
@@ -700,6 +767,14 @@ int launch_aggregate(const void* frames, uint64_t ndv_bits, int has_ndv, long lo
       B.first[i] = bins[b0 + i].first;
       B.count[i] = bins[b0 + i].count;
       B.out[i] = bins[b0 + i].out;
+    }
+    constexpr bool additive = STAT == GM_STAT_SUM || STAT == GM_STAT_MEAN || STAT == GM_STAT_VAR || STAT == GM_STAT_STD;
+    if constexpr (additive) {  // (integer rasters too: their means and deviations are summed in the float work dtype)
+      if (pixels == 1) {  // the time series of one cell: NumPy sums it pairwise (aggregate_cell_kernel)
+        hipLaunchKernelGGL((aggregate_cell_kernel<Tin, STAT>), dim3(1), dim3(128), 0, s, (const Tin*)frames, from_bits<Tin>(ndv_bits),
+                           (has_ndv & 1) != 0, B, nb, (Tout*)out, from_bits<Tout>(fill_bits));
+        continue;
+      }
     }
     if (vec)
       hipLaunchKernelGGL((aggregate_kernel<Tin, STAT, 4>), dim3(gx, nb), dim3(256), 0, s, (const Tin*)frames,

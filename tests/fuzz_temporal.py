@@ -13,6 +13,7 @@ runtime.set_device(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 SHAPE = tuple(int(x) for x in sys.argv[2].split("x")) if len(sys.argv) > 2 else (24, 40)  # e.g. 150x517
 bad = raised = asked = refused = 0
+refusals = {}
 for seed in range(N):
     rng = np.random.default_rng(90_000 + seed)
     view = random_temporal_view(rng, depth=int(rng.integers(1, 5)), shape_yx=SHAPE)
@@ -35,8 +36,10 @@ for seed in range(N):
             try:
                 try:
                     got = view.get_data(**request)
-                except NotImplementedError:  # (a refusal DESIGN.md section 9 lists: no answer is not a wrong answer)
+                except NotImplementedError as refusal:  # (a refusal DESIGN.md section 9 lists: no answer is not a wrong answer)
                     refused += 1
+                    why = str(refusal)[:110]
+                    refusals[why] = refusals.get(why, 0) + 1
                     continue
                 if isinstance(want, np.ndarray):
                     assert isinstance(got, np.ndarray) and got.shape == want.shape
@@ -51,3 +54,5 @@ for seed in range(N):
         break
 print("done: %d views, %d requests (%d of them raise in the reference too, %d refused by the device), %d failures"
       % (N, asked, raised, refused, bad))
+for why, count in sorted(refusals.items(), key=lambda kv: -kv[1]):
+    print("  refused %4d x  %s" % (count, why))

@@ -88,7 +88,8 @@ T0 = datetime(2021, 3, 1)
 SHAPE_YX = (24, 40)
 BOX = dict(bbox=(0.0, 0.0, 40.0, 24.0), width=40, height=24, projection="EPSG:28992")
 KINDS = [("f4", np.float32(np.finfo("f4").max)), ("f4", -9999.0), ("u1", np.uint8(255)), ("i2", np.int16(-1)), ("i4", -9999),
-         ("f8", float(np.finfo("f8").max))]
+         ("f8", float(np.finfo("f8").max)), ("u2", np.uint16(65535)), ("i1", np.int8(-128)), ("u4", np.uint32(4294967295)),
+         ("i8", -9999), ("f4", np.float32(-3.5))]
 
 
 def temporal_leaf(rng, frames=None, step_hours=None, shape_yx=SHAPE_YX):

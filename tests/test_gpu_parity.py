@@ -2111,3 +2111,33 @@ def test_frames_that_do_not_line_up(gpu):
     #  dtype follows the declared one are refused rather than cast; the counting ones do not depend on it)
     for view in (raster.Cumulative(counts, "count"), raster.TemporalAggregate(counts, "D", "count"), raster.TemporalAggregate(counts, None, "count")):
         assert_result_equal(view.get_data(**everything), walk(view, everything), 0, type(view).__name__ + " of uint64")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f4", "f8", "i2", "u1", "i4"])
+def test_temporal_statistics_of_one_cell(gpu, dt):
+    """The time series of a point (a 1 x 1 request): with no axis beside the frames NumPy's sums run their contiguous loop --
+    pairwise over pieces of 8192 frames -- not frame by frame; sum / mean / std (and the rest, for completeness) of 1 to 9000
+    frames in bins of several lengths, with no data and NaN frames, bit for bit against the oracle."""
+    from dask_geomodeling_amd.raster import temporal as T
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 8, 24, 129, 1000, 9000):
+        if np.dtype(dt).kind == "f":
+            v = (rng.random((n, 1, 1)) * 1000 - 300).astype(dt)
+            nd = np.dtype(dt).type(np.finfo(dt).max)
+            if n > 8:
+                v[5] = np.nan
+        else:
+            v = rng.integers(0, 120, size=(n, 1, 1)).astype(dt)
+            nd = np.dtype(dt).type(7)
+        v[rng.random(n) < 0.1] = nd
+        runs = [(0, n)] if n < 24 else [(0, 9), (9, n // 2 - 9), (n // 2, 0), (n // 2, n - n // 2)]
+        for stat in ("sum", "mean", "std", "min", "max", "count", "median"):
+            source = np.dtype(dt)
+            narrow = source.itemsize <= 2 or source == np.dtype("f4")
+            dtype = {"count": np.dtype("i4"), "min": source, "max": source,
+                     "sum": source if source.kind == "f" else (np.dtype("i4") if source.itemsize < 4 else source)
+                     }.get(stat, np.dtype("f4") if narrow else np.dtype("f8"))  # (utils.py:826-845)
+            want = O.temporal_aggregate_values(v, nd, runs, stat, dtype)
+            got = np.asarray(T.aggregate_frames(v, nd, runs, stat, dtype))
+            assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (dt, n, stat, got.ravel(), want.ravel())
