@@ -105,7 +105,12 @@ class RasterTiler(BaseSingle):
                 from .stencil import _cast_tile
                 tile = _cast_tile(tile, dtype)
             if tile.shape[0] != bands:
-                raise ValueError("tile of %d bands in a mosaic of %d" % (tile.shape[0], bands))
+                if tile.shape[0] != 1:
+                    raise ValueError("could not broadcast input array from shape %s into shape %s"
+                                     % (tuple(tile.shape), (bands,) + tuple(tile.shape[1:])))
+                # values[:, rows, columns] = tile of one band: NumPy's assignment repeats it in every band of the mosaic
+                from ..hip.program import _broadcast_operand
+                tile = _broadcast_operand(tile, (bands,) + tuple(tile.shape[1:]))
             _, th, tw = tile.shape
             tiles.append(tile)
             th_.append(th)

@@ -218,8 +218,12 @@ def random_requests(rng, view, shape_yx=SHAPE_YX):
         box = dict(whole, width=nx // 2, height=ny // 2)
     elif c < 0.88:   # finer cells
         box = dict(whole, bbox=(nx / 4.0, ny / 4.0, 3 * nx / 4.0, 3 * ny / 4.0))
-    elif c < 0.96:   # half a cell off the grid and partly outside the sources
+    elif c < 0.93:   # half a cell off the grid and partly outside the sources
         box = dict(whole, bbox=(-7.5, -3.5, nx - 7.5, ny - 3.5))
+    elif c < 0.96:   # one row, one column or a handful of cells
+        x0, y0 = int(rng.integers(0, nx - 3)), int(rng.integers(0, ny - 3))
+        w, h = [(nx - x0, 1), (1, ny - y0), (2, 2), (1, 1)][int(rng.integers(4))]
+        box = dict(whole, bbox=(float(x0), float(y0), float(x0 + w), float(y0 + h)), width=w, height=h)
     else:            # a point
         x, y = float(rng.integers(0, nx)) + 0.5, float(rng.integers(0, ny)) + 0.5
         box = dict(whole, bbox=(x, y, x, y), width=1, height=1)
