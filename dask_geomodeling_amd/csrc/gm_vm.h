@@ -279,6 +279,10 @@ template <typename T, typename RC>
 __device__ __forceinline__ T to_stored(RC v) {
   if constexpr (std::is_same<RC, double>::value && std::is_same<T, long long>::value) {
     return v >= 9223372036854775807.0 ? 9223372036854775807ll : (long long)v;
+  } else if constexpr (std::is_same<RC, double>::value && std::is_same<T, unsigned long long>::value) {
+    // (likewise the uint64 fill value, 2^64 as a float64; values from 2^63 on -- reduce_rasters of uint64 rasters works in
+    //  float64 -- must not go through int64)
+    return v >= 18446744073709551615.0 ? 18446744073709551615ull : (unsigned long long)v;
   } else if constexpr (is_float_class<RC>::value && std::is_integral<T>::value && sizeof(T) < 4) {
     // float -> 1- / 2-byte integer: through int32 and a truncation, like NumPy's cast on x86 (700.0 -> 188).
     // A direct float -> uint8 conversion is undefined for values outside the type, and the compiler then
@@ -319,7 +323,7 @@ __device__ __forceinline__ void store_elems(void* base, int dtype, unsigned long
     GM_STORE_CASE(GM_I32, int, i32x4)
     GM_STORE_CASE(GM_U32, unsigned int, u32x4)
     GM_STORE_CASE8(GM_I64, long long, i64x2)
-    GM_STORE_CASE8(GM_U64, long long, i64x2)  /* uint64 travels as its bit pattern (I64 class) */
+    GM_STORE_CASE8(GM_U64, unsigned long long, u64x2)  /* (from the I64 class: the bit pattern it travelled as) */
     GM_STORE_CASE(GM_U16, unsigned short, u16x4)
     GM_STORE_CASE(GM_I16, short, i16x4)
     GM_STORE_CASE(GM_U8, unsigned char, u8x4)

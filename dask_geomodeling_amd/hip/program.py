@@ -319,7 +319,9 @@ def node_classes(node):
         for v in node.extra.get("values", ()):
             allowed = frozenset(c for c in allowed if _value_exact(v, node.dtype, c))
     elif op == "fillnodata":
-        allowed = classes_for_compute(node.dtype) if node.dtype.kind == "f" or node.dtype.itemsize >= 4 else ALL_CLASSES
+        # (integer results: nothing is computed -- a cell is taken from one raster or the other --, so any class that holds
+        #  the values will do: uint32 in I64 / F64, uint64 as its bit pattern in I64; round 4, found refused by the fuzzing)
+        allowed = classes_for_compute(node.dtype) if node.dtype.kind == "f" else classes_exact(node.dtype)
         if node.dtype.kind != "f" and any(not isinstance(a, Lit) and a.dtype.kind == "f" for a in node.args):
             # float tiles pasted into an integer result (reduce_rasters 'first' / 'last' with an integer output
             # dtype: out[index] = values[index] casts on assignment): nothing is computed on the way, so the values

@@ -2141,3 +2141,31 @@ def test_temporal_statistics_of_one_cell(gpu, dt):
             want = O.temporal_aggregate_values(v, nd, runs, stat, dtype)
             got = np.asarray(T.aggregate_frames(v, nd, runs, stat, dtype))
             assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), (dt, n, stat, got.ravel(), want.ravel())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,ndv", [("u4", np.uint32(4294967295)), ("u8", np.uint64(2 ** 64 - 1)), ("u2", np.uint16(65535)), ("i8", -9999),
+                                    ("u4", np.uint32(7))])
+def test_merges_of_wide_unsigned_rasters(gpu, dt, ndv):
+    """FillNoData / Group / Clip / Max of uint32 and uint64 rasters -- values beyond 2^31 and 2^63, the dtype's maximum as
+    no data: nothing is computed in a merge, so the values travel in the int64 class (uint64 as its bit pattern; the fuzzing
+    of round 4 found these refused), and a float64 result above 2^63 is stored as uint64, not through int64 (Max of uint64
+    rasters works in float64: reduction.py:99-107)."""
+    from datetime import datetime, timedelta
+    from dask_geomodeling_amd import raster
+    from oracle_walk import walk
+    rng = np.random.default_rng(2)
+    box = dict(mode="vals", bbox=(0.0, 0.0, 40.0, 24.0), width=40, height=24, projection="EPSG:28992",
+               start=datetime(2021, 1, 1), stop=datetime(2021, 6, 1))
+
+    def source(first_hour=0):
+        v = rng.integers(0, 2 ** 31, size=(3, 24, 40)).astype(dt) * (2 if dt in ("u4", "u8") else 1)
+        if dt == "u8":
+            v = v * np.uint64(2 ** 32 + 3)
+        v[rng.random(v.shape) < 0.3] = ndv
+        return raster.MemorySource(v, ndv, "EPSG:28992", 1.0, (0.0, 24.0), time_first=datetime(2021, 3, 1, first_hour),
+                                   time_delta=timedelta(days=1))
+
+    a, b = source(), source()
+    for view in (raster.FillNoData(a, b), raster.Group(a, b), raster.Group(a, source(6)), raster.Clip(a, b), raster.Max(a, b)):
+        assert_result_equal(view.get_data(**box), walk(view, box), 0, "%s of %s" % (type(view).__name__, dt))
