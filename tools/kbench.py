@@ -32,7 +32,7 @@ def timeit(label, bytes_per_call, calls, reps=3):
 
 
 def main():
-    which = [a for a in sys.argv[1:] if "=" not in a] or ["reclass", "classify", "mask", "bilinear", "nearest", "stencil", "temporal", "zonal"]
+    which = [a for a in sys.argv[1:] if "=" not in a] or ["reclass", "classify", "mask", "bilinear", "nearest", "stencil", "power", "temporal", "zonal"]
     opts = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
     side = int(opts.get("side", 8192))
     runtime.set_device(0)
@@ -115,7 +115,19 @@ def main():
                    [lambda t=t: stencil.gaussian_smooth(t, np.float32(F32MAX), 0, (size_px / 3, size_px / 3)) for t in src[:2]])
             timeit("smooth f32, sigma %.0f px, radius %d (two launches, 16 B/px)" % (size_px / 3, int(4 * size_px / 3 + 0.5)), 16.0 * n,
                    [lambda t=t: stencil.gaussian_smooth(t, np.float32(F32MAX), 0, (size_px / 3, size_px / 3), fused=False) for t in src[:2]])
+        for size_px in (18.0, 39.0):  # (radii 24 and 52: what a Smooth of 40 pixels in zoom mode asks for)
+            timeit("smooth f32, sigma %.0f px, radius %d (two launches: the sliding-window passes, 16 B/px)"
+                   % (size_px / 3, int(4 * size_px / 3 + 0.5)), 16.0 * n,
+                   [lambda t=t: stencil.gaussian_smooth(t, np.float32(F32MAX), 0, (size_px / 3, size_px / 3)) for t in src[:2]])
         del src, u8
+    if "power" in which:
+        from dask_geomodeling_amd.raster import devops
+        tiles = [generate_window((side, side), "f4", 50 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side, side) for i in range(T)]
+        kw = {"dtype": "float32", "fillvalue": F32MAX}
+        for op, args in (("power", (2.5,)), ("exp", ()), ("log", ())):
+            timeit("%s f32 (VM, 8 B/px)" % op, 8.0 * n,
+                   [lambda t=t: devops.math_process(op, kw, {"values": t, "no_data_value": np.float32(F32MAX)}, *args) for t in tiles])
+        del tiles
     if "temporal" in which:
         from dask_geomodeling_amd.hip.array import DeviceArray
         from dask_geomodeling_amd.raster import temporal
