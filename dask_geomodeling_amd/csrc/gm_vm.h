@@ -434,15 +434,66 @@ static __device__ const double POWF_EXP2_TAB[32] = {
     0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
     0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0,
 };
-// log2(1 + r) = r (C1 + C2 r + ... + C5 r^4) + O(r^6),  2^r = 1 + r (L1 + ... + L5 r^4) + O(r^6): Taylor coefficients
-static __device__ const double POWF_LOG2_C[5] = {0x1.71547652b82fep+0, -0x1.71547652b82fep-1, 0x1.ec709dc3a03fdp-2, -0x1.71547652b82fep-2, 0x1.2776c50ef9bfep-2};
+// log2(1 + r) = r (C1 + C2 r + ... + C7 r^6) + O(r^8),  2^r = 1 + r (L1 + ... + L5 r^4) + O(r^6): Taylor coefficients
+static __device__ const double POWF_LOG2_C[7] = {0x1.71547652b82fep+0, -0x1.71547652b82fep-1, 0x1.ec709dc3a03fdp-2, -0x1.71547652b82fep-2, 0x1.2776c50ef9bfep-2, -0x1.ec709dc3a03fdp-3, 0x1.a61762a7aded9p-3};
 static __device__ const double POWF_EXP2_L[5] = {0x1.62e42fefa39efp-1, 0x1.ebfbdff82c58fp-3, 0x1.c6b08d704a0c0p-5, 0x1.3b2ab6fba4e77p-7, 0x1.5d87fe78a6731p-10};
+// ln(2), log10(2)
+#define POWF_LN2 0x1.62e42fefa39efp-1
+#define POWF_LOG10_2 0x1.34413509f79ffp-2
+
+// The two halves of the float32 transcendentals, in float64 arithmetic (round 4):
+//   log2 of a positive finite float32 = e + log2(c) + log2(1 + r), r = z / c - 1, by a table of 128 mantissa intervals (the one
+//     around 1.0 has c = 1: values near 1 keep their RELATIVE precision) and five or seven Taylor terms (|r| <= 2^-8);
+//   2^(z + z_lo) -> float32 by 32 table steps and five Taylor terms (|r| <= 2^-6: error < 2^-48), z clamped to the range in which
+//     the float32 result is not 0 / inf anyway.
+template <int TERMS>  // 5: good to ~2^-42 of the value at the interval edges (power); 7: ~2^-56 (log / log10)
+__device__ __forceinline__ double log2_of_positive_f32(unsigned ax) {
+  const bool tiny = ax < 0x00800000u;  // subnormal: scaled by 2^23 first
+  const unsigned nx = tiny ? __float_as_uint(__uint_as_float(ax) * 0x1p23f) : ax;
+  const unsigned tmp = nx - 0x3f338000u;
+  const int i = (int)((tmp >> 16) & 127u);
+  const int e = ((int)tmp >> 23) - (tiny ? 23 : 0);
+  const double z = (double)__uint_as_float(nx - (tmp & 0xff800000u));  // in [0.7, 1.4)
+  const double r = fma(z, POWF_LOG2_TAB[i][0], -1.0);
+  double p = POWF_LOG2_C[TERMS - 1];
+#pragma unroll
+  for (int k = TERMS - 2; k >= 2; --k) p = fma(r, p, POWF_LOG2_C[k]);
+  p = fma(r, p, POWF_LOG2_C[1]);
+  p = fma(r, p, POWF_LOG2_C[0]);
+  return fma(r, p, (double)e + POWF_LOG2_TAB[i][1]);
+}
+__device__ __forceinline__ float exp2_to_f32(double z, double z_lo) {
+  z = fmin(fmax(z, -160.0), 130.0);  // (beyond: 0 / inf as float32 either way; keeps 2^k a normal double)
+  const double kd = rint(z * 32.0);
+  const int ki = (int)kd;
+  const double rr = fma(kd, -0x1p-5, z) + z_lo;
+  double q = fma(rr, POWF_EXP2_L[4], POWF_EXP2_L[3]);
+  q = fma(rr, q, POWF_EXP2_L[2]);
+  q = fma(rr, q, POWF_EXP2_L[1]);
+  q = fma(rr, q, POWF_EXP2_L[0]);
+  q = fma(rr, q, 1.0);
+  const long long scaled = __double_as_longlong(POWF_EXP2_TAB[ki & 31]) + ((long long)(ki >> 5) << 52);
+  return (float)(__longlong_as_double(scaled) * q);
+}
+
+// np.log / np.log10 on the float32 class: the float64 ocml calls rounded once cost 204 us per 8192^2 tile (84 us of streaming);
+// log2 through the half above times ln(2) / log10(2): 161 us, and still the correctly rounded float32 -- the float64 value is
+// good to ~2^-52, so a float32 rounding boundary lies inside the error only once in ~2^27 arguments
+// (tests/test_gpu_parity.py::test_exp_log_are_correctly_rounded, tools/ulp_measure.py).  np.exp stays on ocml's float64 exp:
+// the same construction (x log2(e) in two pieces, the 2^x half with six terms) was measured at 162 us against its 110.
+__device__ __forceinline__ float logf_via_f64(float xf, double scale) {  // scale: ln(2) or log10(2)
+  const unsigned ix = __float_as_uint(xf), ax = ix & 0x7fffffffu;
+  float out = (float)(log2_of_positive_f32<7>(ax) * scale);
+  out = ax == 0x7f800000u ? xf : out;                   // +inf (-inf: below)
+  out = (ix >> 31) != 0 ? __builtin_nanf("") : out;     // negative
+  out = ax == 0 ? -__builtin_inff() : out;              // +-0
+  return ax > 0x7f800000u ? xf : out;                   // NaN
+}
 
 // np.power on the float32 class (round 4).  float64 pow() rounded once cost ~130 float64 operations per value (a
 // 4096^2 tile: 109 us against 22 us of streaming); float32 needs far less than a float64 pow delivers.  Here, in
-// float64 arithmetic: log2|x| = e + log2(c) + log2(1 + r), r = z / c - 1 by a table of 128 mantissa intervals (the
-// one around 1.0 has c = 1: values near 1 keep their RELATIVE precision, which is what a large exponent magnifies)
-// and five Taylor terms (|r| <= 2^-8: error < 2^-50); 2^(y log2|x|) by 32 table steps and five Taylor terms.  The
+// float64 arithmetic: 2^(y log2|x|) by the two halves above (values near 1 keep their RELATIVE precision in the logarithm,
+// which is what a large exponent magnifies).  The
 // exponent argument is good to ~2^-35 absolutely over the float32 range, so the float64 result rounds to the correctly
 // rounded float32 except within 2^-11 ulp of a tie -- there it is the other neighbour, i.e. <= 1 ulp from any faithful
 // powf (glibc's: 0.52 ulp), the budget of tests/test_gpu_parity.py.  Signs, zeros, infinities and NaN follow C99 F.9.4.4
@@ -456,34 +507,12 @@ __device__ __forceinline__ float powf_via_f64(float xf, float yf) {
   int yint = (ay & (unit - 1)) ? 0 : ((ay & unit) ? 1 : 2);
   yint = ey > 150 ? 2 : yint;
   yint = ey < 127 ? (ay == 0 ? 2 : 0) : yint;
-  // log2 |x|
-  const bool tiny = ax < 0x00800000u;  // subnormal: scaled by 2^23 first
-  const unsigned nx = tiny ? __float_as_uint(__uint_as_float(ax) * 0x1p23f) : ax;
-  const unsigned tmp = nx - 0x3f338000u;
-  const int i = (int)((tmp >> 16) & 127u);
-  const int e = ((int)tmp >> 23) - (tiny ? 23 : 0);
-  const double z = (double)__uint_as_float(nx - (tmp & 0xff800000u));  // in [0.7, 1.4)
-  const double r = fma(z, POWF_LOG2_TAB[i][0], -1.0);
-  double p = fma(r, POWF_LOG2_C[4], POWF_LOG2_C[3]);
-  p = fma(r, p, POWF_LOG2_C[2]);
-  p = fma(r, p, POWF_LOG2_C[1]);
-  p = fma(r, p, POWF_LOG2_C[0]);
-  double l2 = fma(r, p, (double)e + POWF_LOG2_TAB[i][1]);
+  double l2 = log2_of_positive_f32<5>(ax);  // (ax == 0 / inf / NaN: garbage, replaced below)
   l2 = ax == 0 ? -__builtin_huge_val() : l2;
   l2 = ax == 0x7f800000u ? __builtin_huge_val() : l2;
   double zz = (double)yf * l2;
   zz = ax == 0x3f800000u ? 0.0 : zz;                 // |x| = 1: 1 whatever y (0 * inf otherwise)
-  zz = fmin(fmax(zz, -160.0), 130.0);                // (beyond: 0 / inf as float32 either way; keeps 2^k a normal double)
-  const double kd = rint(zz * 32.0);
-  const int ki = (int)kd;
-  const double rr = fma(kd, -0x1p-5, zz);
-  double q = fma(rr, POWF_EXP2_L[4], POWF_EXP2_L[3]);
-  q = fma(rr, q, POWF_EXP2_L[2]);
-  q = fma(rr, q, POWF_EXP2_L[1]);
-  q = fma(rr, q, POWF_EXP2_L[0]);
-  q = fma(rr, q, 1.0);
-  const long long scaled = __double_as_longlong(POWF_EXP2_TAB[ki & 31]) + ((long long)(ki >> 5) << 52);
-  float out = (float)(__longlong_as_double(scaled) * q);
+  float out = exp2_to_f32(zz, 0.0);
   const bool negative = (ix >> 31) != 0;
   out = (negative && yint == 1) ? -out : out;
   out = (negative && yint == 0 && ax != 0 && ax < 0x7f800000u) ? __builtin_nanf("") : out;  // finite x < 0, y not an integer
@@ -856,10 +885,10 @@ struct Machine {
         if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { return (RC)exp((double)x); });
         break;
       case GM_OP_LOG:
-        if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { return (RC)log((double)x); });
+        if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { if constexpr (std::is_same<RC, float>::value) return logf_via_f64(x, POWF_LN2); else return (RC)log((double)x); });
         break;
       case GM_OP_LOG10:
-        if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { return (RC)log10((double)x); });
+        if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { if constexpr (std::is_same<RC, float>::value) return logf_via_f64(x, POWF_LOG10_2); else return (RC)log10((double)x); });
         break;
       case GM_OP_EQ: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)(x == y); }); break;
       case GM_OP_NE: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)(x != y); }); break;

@@ -121,7 +121,6 @@ def main():
                    [lambda t=t: stencil.gaussian_smooth(t, np.float32(F32MAX), 0, (size_px / 3, size_px / 3)) for t in src[:2]])
         del src, u8
     if "power" in which:
-        from dask_geomodeling_amd.raster import devops
         tiles = [generate_window((side, side), "f4", 50 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side, side) for i in range(T)]
         kw = {"dtype": "float32", "fillvalue": F32MAX}
         for op, args in (("power", (2.5,)), ("exp", ()), ("log", ())):
