@@ -387,22 +387,49 @@ struct BlockInfo {  // 32 bytes
   __device__ __forceinline__ long long D(int parity) const { return D0 + (parity ? ((flags >> 2) & 3) - 1 : 0); }
 };
 
+// exponent of the lowest set bit of a finite non-zero double: x is an odd multiple of 2^lowbit_exp(x)
+__device__ __forceinline__ int lowbit_exp(double x) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(x) & 0x7fffffffffffffffull;
+  const int field = (int)(bits >> 52);
+  const unsigned long long mantissa = bits & 0xfffffffffffffull;
+  if (field == 0) return -1074 + __builtin_ctzll(mantissa);  // subnormal
+  return field - 1075 + __builtin_ctzll(mantissa | (1ull << 52));
+}
+
+// Besides the tree sum, what CERTIFIES it (round 4): the sum of the |cells| and the finest bit any cell carries.  A block
+// whose cells are all multiples of 2^g, entered by a running sum s that is one too, with |s| + sum|x| < 2^(53 + g), is
+// added without a single rounding -- every prefix is a multiple of 2^g below 2^(53 + g), i.e. a float64 -- so the order does
+// not matter, the tree sum is that exact sum, and s + tree sum is what bincount's chain leaves, whatever powers of two the
+// prefixes cross on the way.  The composing wave asks this of the blocks the binade analysis turns away (zero-mean data:
+// sums that are small against the cells, sums that wander around a power of two) before it adds them literally.
 template <typename T>
 __global__ __launch_bounds__(256) void zonal_block_sum_kernel(const typename Ordered<T>::Key* __restrict__ payload,
                                                               const unsigned* __restrict__ keys, unsigned cells, int n_labels,
-                                                              double* __restrict__ blk_sum, int* __restrict__ blk_label) {
+                                                              double* __restrict__ blk_sum, int* __restrict__ blk_label,
+                                                              double* __restrict__ blk_abs, int* __restrict__ blk_gexp) {
   const unsigned j = (unsigned)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
   if ((size_t)j * ZB >= cells) return;
   const unsigned base = j * ZB, last = cells - 1;
-  double partial = 0.0;
+  double partial = 0.0, magnitude = 0.0;
+  int finest = INT_MAX;  // INT_MAX: nothing but zeros; INT_MIN: a cell that is not finite
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const unsigned at = base + 4 * lane + k;
-    partial += at <= last ? (double)Ordered<T>::decode(payload[at]) : 0.0;
+    const double x = at <= last ? (double)Ordered<T>::decode(payload[at]) : 0.0;
+    partial += x;
+    magnitude += fabs(x);
+    if (!(fabs(x) <= 1.7976931348623157e308)) finest = INT_MIN;
+    else if (x != 0.0 && finest != INT_MIN) finest = min(finest, lowbit_exp(x));
   }
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) partial += shuffle_xor(partial, off);
+  for (int off = 1; off < 64; off <<= 1) {
+    partial += shuffle_xor(partial, off);
+    magnitude += shuffle_xor(magnitude, off);
+    finest = min(finest, __shfl_xor(finest, off));
+  }
   if (lane == 0) {
+    blk_abs[j] = magnitude;
+    blk_gexp[j] = finest;
     blk_sum[j] = partial;
     const unsigned ka = keys[base], kb = keys[min(base + ZB - 1, last)];
     blk_label[j] = (base + ZB <= cells && ka == kb && ka < (unsigned)n_labels) ? (int)ka : -1;
@@ -805,13 +832,89 @@ __global__ __launch_bounds__(256) void zonal_group_info_kernel(const int* __rest
   if (lane == 63) ginfo[G] = out;
 }
 
+// The exactness certificate of zonal_block_sum_kernel for a whole group of 256 blocks (round 4).  With t_j the blocks' tree
+// sums, o_j = t_0 + ... + t_(j-1) and a_j their sums of |cells|, every prefix inside the group lies, relative to the sum
+// entering the group, in [lo, hi] = [min_j (o_j - a_j), max_j (o_j + a_j)].  The composing wave certifies the group for the
+// exact sum s entering it when max(|s + lo|, |s + hi|) < 2^(53 + g), g = min(finest bit of the group's cells, lowest bit of s):
+// no addition of the group rounds, and s + total is what the chain leaves.  (hi - lo < 2^(52 + g) makes sure of the o_j
+// themselves: every range of blocks then sums without rounding.)  Usable under the conditions of GroupInfo: 256 whole blocks
+// of ONE long label, every cell finite.
+struct GroupExact {
+  double total, lo, hi;
+  int grain;  // INT_MIN: not usable; INT_MAX: nothing but zeros
+  int pad;
+};
+__global__ __launch_bounds__(256) void zonal_group_exact_kernel(const int* __restrict__ blk_label, const double* __restrict__ blk_sum,
+                                                                const double* __restrict__ blk_abs, const int* __restrict__ blk_gexp,
+                                                                const unsigned* __restrict__ first, unsigned whole_blocks,
+                                                                unsigned long_from, GroupExact* __restrict__ gexact, unsigned n_groups) {
+  const unsigned G = (unsigned)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  if (G >= n_groups) return;
+  GroupExact out;
+  out.total = out.lo = out.hi = 0.0;
+  out.grain = INT_MIN;
+  out.pad = 0;
+  const unsigned base = G * ZG;
+  if (base + ZG > whole_blocks) {  // (wave-uniform)
+    if (lane == 0) gexact[G] = out;
+    return;
+  }
+  const int l = __builtin_amdgcn_readfirstlane(blk_label[base]);
+  bool regular = true;
+  int finest = INT_MAX;
+  double t[4], a[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned j = base + 4 * lane + k;
+    regular = regular && blk_label[j] == l && blk_gexp[j] != INT_MIN;
+    finest = min(finest, blk_gexp[j]);
+    t[k] = blk_sum[j];
+    a[k] = blk_abs[j];
+  }
+  const bool long_label = l >= 0 && first[max(l, 0) + 1] - first[max(l, 0)] >= long_from;
+  if (!(__all(regular) && long_label)) {
+    if (lane == 0) gexact[G] = out;
+    return;
+  }
+  double run = 0.0, low = 1.0e300, high = -1.0e300;  // the lane's four blocks, relative to the sum entering the lane
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    low = fmin(low, run - a[k]);
+    high = fmax(high, run + a[k]);
+    run += t[k];
+  }
+  double scan = run;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double up = shuffle_up_f64(scan, off);
+    if (lane >= off) scan += up;
+  }
+  const double before = scan - run;  // (exact whenever the certificate will hold: see above)
+  low += before;
+  high += before;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    low = fmin(low, shuffle_xor(low, off));
+    high = fmax(high, shuffle_xor(high, off));
+    finest = min(finest, __shfl_xor(finest, off));
+  }
+  out.total = scan;  // (lane 63's is the group's)
+  out.lo = low;
+  out.hi = high;
+  out.grain = finest;
+  if (lane == 63) gexact[G] = out;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Ordered<T>::Key* __restrict__ payload,
                                                             const unsigned* __restrict__ first, int n_labels, int statistic,
                                                             const int* __restrict__ blk_label, const BlockInfo* __restrict__ info,
                                                             const GroupInfo* __restrict__ ginfo, float* __restrict__ out,
                                                             long long* __restrict__ counts,
-                                                            unsigned* __restrict__ replayed, unsigned long_from) {
+                                                            unsigned* __restrict__ replayed, unsigned long_from,
+                                                            const double* __restrict__ blk_sum, const double* __restrict__ blk_abs,
+                                                            const int* __restrict__ blk_gexp, const GroupExact* __restrict__ gexact) {
   __shared__ __align__(16) double parked[4][ZB];
   const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (l >= n_labels) return;
@@ -867,7 +970,7 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
     return c;
   };
   const unsigned j0 = (a + ZB - 1) / ZB, j1 = b / ZB;
-  unsigned n_replayed = 0, n_ahead = 0;  // literal blocks; those among them whose cells had been requested ahead
+  unsigned n_replayed = 0, n_ahead = 0, n_exact = 0, n_exact_groups = 0;  // literal blocks; ... requested ahead; certified blocks / groups
   if (j0 * ZB > a) literally(a, min(j0 * ZB, b));
   // Between literal stretches the sum lives as (binade E, sign, integer s = |sum| / u in [2^52, 2^53)): a block that is
   // valid for it is a handful of scalar integer operations.  The blocks' descriptions are fetched 64 at a time (a lane
@@ -932,11 +1035,29 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
     }
     return (int)(gi - held_from);
   };
-  // does the group that starts at block g go in one step, as far as its description can tell?
+  unsigned exact_from = ~0u;  // the same for the exactness certificates of the groups
+  GroupExact certified;
+  certified.grain = INT_MIN;
+  auto hold_exact = [&](unsigned gi) {
+    if (exact_from == ~0u || gi < exact_from || gi >= exact_from + 64u) {
+      exact_from = gi;
+      certified = gexact[min(gi + (unsigned)lane, last_group)];
+    }
+    return (int)(gi - exact_from);
+  };
+  auto pass_f64 = [&](double mine64, int i) -> double {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(mine64);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(u >> 32), i) << 32) |
+                                            (unsigned)__builtin_amdgcn_readlane((int)u, i)));
+  };
+  // does the group that starts at block g go in one step, as far as its descriptions can tell?
   auto usable = [&](unsigned g) -> bool {
     if (!(g < j1 && g % ZG == 0 && j1 - g >= (unsigned)ZG)) return false;
     const int at = hold(g / ZG);
-    return __builtin_amdgcn_readlane(held.E, at) != INT_MIN;
+    if (__builtin_amdgcn_readlane(held.E, at) != INT_MIN) return true;
+    if (!gexact) return false;
+    const int xat = hold_exact(g / ZG);
+    return __builtin_amdgcn_readlane(certified.grain, xat) != INT_MIN;
   };
   BlockInfo ahead[PER];
   bool have_ahead = false;
@@ -968,6 +1089,25 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
       if (units + lo >= 4503599627370497ll && units + hi <= 9007199254740991ll) {
         units += pass(p0 ? held.D[1] : held.D[0], at);  // (256 blocks, 65 536 cells: one addition)
         continue;
+      }
+    }
+    if (whole && gexact) {
+      const int xat = hold_exact(g / ZG);
+      const int finest = __builtin_amdgcn_readlane(certified.grain, xat);
+      if (finest != INT_MIN) {
+        to_double();
+        if (fabs(acc) <= 1.7976931348623157e308) {
+          const int held_bit = acc == 0.0 ? INT_MAX : lowbit_exp(acc);
+          const int grain = min(finest, held_bit);
+          const double lo = pass_f64(certified.lo, xat), hi = pass_f64(certified.hi, xat);
+          const double reach = fmax(fabs(acc + lo), fabs(acc + hi)) * 1.001;  // (the bounds are float64 sums themselves)
+          if (grain == INT_MAX || (grain > -1000 && grain < 900 && reach < ldexp(0.99, 53 + grain) && hi - lo < ldexp(0.99, 52 + grain))) {
+            acc += pass_f64(certified.total, xat);  // 256 blocks without a rounding: one addition
+            to_integer();
+            ++n_exact_groups;
+            continue;
+          }
+        }
       }
     }
     if (!have) fetch(g, B);  // (a group that was expected to go in one step and did not)
@@ -1049,7 +1189,25 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
         const unsigned k = (unsigned)__builtin_amdgcn_readlane(failed, from);
         units = pass(failed_entering, from);
         to_double();
-        if (k == wanted) {
+        // the exactness certificate of zonal_block_sum_kernel: no rounding anywhere in this block for the sum entering it?
+        bool exact = false;
+        if (blk_gexp) {
+          const int finest = blk_gexp[g + k];
+          if (finest != INT_MIN && fabs(acc) <= 1.7976931348623157e308) {
+            const int held_bit = acc == 0.0 ? INT_MAX : lowbit_exp(acc);
+            const int grain = min(finest, held_bit);
+            // (0.99: the two magnitudes are float64 sums themselves; the bound has to hold for the exact ones)
+            exact = grain == INT_MAX || (grain > -1000 && grain < 900 && fabs(acc) + blk_abs[g + k] < ldexp(0.99, 53 + grain));
+          }
+        }
+        if (exact) {
+          acc += blk_sum[g + k];  // exact: the block in one addition
+          ++n_exact;
+          if (wanted < k + 1 || k == wanted) {
+            wanted = next_risky(k + 1);
+            ahead_cells = request(g + min(wanted, here - 1));
+          }
+        } else if (k == wanted) {
           // the cells asked for earlier; the next expected block's are requested before this block's chain starts.
           // (Tried and dropped: descriptions per quarter of such a block, so that only the quarter in which the sum crosses
           // the power of two is added literally -- around a power of two the sum of zero-mean data wanders back and forth,
@@ -1069,7 +1227,7 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
           }
         }
         to_integer();
-        ++n_replayed;
+        n_replayed += exact ? 0u : 1u;
         start = k + 1;
       }
     }
@@ -1083,6 +1241,8 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
     if (replayed) {
       atomicAdd(replayed, n_replayed);
       atomicAdd(replayed + 1, n_ahead);
+      atomicAdd(replayed + 2, n_exact);
+      atomicAdd(replayed + 3, n_exact_groups);
     }
   }
 }
@@ -2206,7 +2366,9 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     if ((rc = scratch.take((void**)&cursor, sizeof(unsigned)))) return rc;
   }
   unsigned *keys_a = nullptr, *keys_b = nullptr, *first = nullptr;
-  double *blk_sum = nullptr, *blk_pred = nullptr;  // (the block pipeline of the long labels)
+  double *blk_sum = nullptr, *blk_pred = nullptr, *blk_abs = nullptr;  // (the block pipeline of the long labels)
+  int* blk_gexp = nullptr;
+  GroupExact* grp_exact = nullptr;
   int* blk_label = nullptr;
   BlockInfo* blk_info = nullptr;
   GroupInfo* grp_info = nullptr;
@@ -2414,13 +2576,16 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         if (!blk_sum) {
           if ((rc = scratch.take((void**)&blk_sum, sizeof(double) * n_blocks))) return rc;
           if ((rc = scratch.take((void**)&blk_pred, sizeof(double) * n_blocks))) return rc;
+          if ((rc = scratch.take((void**)&blk_abs, sizeof(double) * n_blocks))) return rc;
+          if ((rc = scratch.take((void**)&blk_gexp, sizeof(int) * n_blocks))) return rc;
+          if ((rc = scratch.take((void**)&grp_exact, sizeof(GroupExact) * ((n_blocks + ZG - 1) / ZG)))) return rc;
           if ((rc = scratch.take((void**)&blk_label, sizeof(int) * n_blocks))) return rc;
           if ((rc = scratch.take((void**)&blk_info, sizeof(BlockInfo) * n_blocks))) return rc;
           if ((rc = scratch.take((void**)&grp_info, sizeof(GroupInfo) * ((n_blocks + ZG - 1) / ZG)))) return rc;
         }
         const unsigned block_grid = (unsigned)((n_blocks * 64 + 255) / 256), label_grid = (unsigned)(((size_t)n_labels * 64 + 255) / 256);
         hipLaunchKernelGGL(zonal_block_sum_kernel<T>, dim3(block_grid), dim3(256), 0, s, sorted_pay, sorted_keys, (unsigned)cells, n_labels,
-                           blk_sum, blk_label);
+                           blk_sum, blk_label, blk_abs, blk_gexp);
         hipLaunchKernelGGL(zonal_block_prefix_kernel<T>, dim3((unsigned)n_labels), dim3(256), 0, s, sorted_pay, first, n_labels, blk_sum,
                            blk_pred, long_from);
         hipLaunchKernelGGL(zonal_block_info_kernel<T>, dim3(block_grid), dim3(256), 0, s, sorted_pay, first, (unsigned)cells, blk_label,
@@ -2429,21 +2594,26 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
           const unsigned n_groups = (unsigned)((n_blocks + ZG - 1) / ZG);
           hipLaunchKernelGGL(zonal_group_info_kernel, dim3((unsigned)(((size_t)n_groups * 64 + 255) / 256)), dim3(256), 0, s, blk_label, blk_info,
                              first, (unsigned)((size_t)cells / ZB), long_from, grp_info, n_groups);
+          hipLaunchKernelGGL(zonal_group_exact_kernel, dim3((unsigned)(((size_t)n_groups * 64 + 255) / 256)), dim3(256), 0, s, blk_label, blk_sum,
+                             blk_abs, blk_gexp, first, (unsigned)((size_t)cells / ZB), long_from, grp_exact, n_groups);
         }
         static const bool verbose = getenv("GM_ZONAL_VERBOSE") != nullptr;
+        static const bool certify = !(getenv("GM_ZONAL_CERTIFY") && atoi(getenv("GM_ZONAL_CERTIFY")) == 0);  // (0: A/B runs, tests)
         unsigned* replayed = nullptr;
         if (verbose) {
           if ((rc = gm_malloc((void**)&replayed, 8 * sizeof(unsigned)))) return rc;
           GM_HIP(hipMemsetAsync(replayed, 0, 8 * sizeof(unsigned), s));
         }
         hipLaunchKernelGGL(zonal_compose_kernel<T>, dim3(label_grid), dim3(256), 0, s, sorted_pay, first, n_labels, statistic, blk_label,
-                           blk_info, grp_info, out_f, counts_f, replayed, long_from);
+                           blk_info, grp_info, out_f, counts_f, replayed, long_from, blk_sum, blk_abs,
+                           certify ? blk_gexp : (const int*)nullptr, certify ? grp_exact : (const GroupExact*)nullptr);
         if (verbose) {
           unsigned host[8] = {0};
           GM_HIP(hipMemcpyAsync(host, replayed, sizeof(host), hipMemcpyDeviceToHost, s));
           GM_HIP(hipStreamSynchronize(s));
-          fprintf(stderr, "[gmhip] zonal block pipeline: %zu blocks, %u of them added literally (%u with their cells requested ahead)\n",
-                  n_blocks, host[0], host[1]);
+          fprintf(stderr, "[gmhip] zonal block pipeline: %zu blocks, %u of them added literally (%u with their cells requested ahead), "
+                          "%u turned away by the binade analysis but certified exact, %u groups of 256 certified exact\n", n_blocks, host[0],
+                  host[1], host[2], host[3]);
           (void)gm_free(replayed);
         }
       }

@@ -2019,6 +2019,25 @@ def test_zonal_label_partition(gpu, part, select):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("certify", ["1", "0"])
+def test_zonal_exactness_certificates(gpu, certify):
+    """Labels of 7 - 15 whole groups of 256 blocks whose tails cancel the sequential float64 sum before them, so that the
+    float32 result shows every bit of it (tests/zonal_certificate_driver.py): the block and group certificates of round 4
+    ("no addition of this block / group rounds for the sum entering it": one addition instead of a walk) against np.bincount's
+    order, on data made for them and data made to break them; and the same cases with the certificates switched off."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GM_ZONAL_CERTIFY=certify, GM_ZONAL_VERBOSE="1")
+    driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_certificate_driver.py")
+    res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
+    assert "CERTIFICATES ok 56" in res.stdout
+    groups = [int(line.split("certified exact, ")[1].split(" groups")[0]) for line in res.stderr.splitlines() if "groups of 256 certified" in line]
+    assert groups and (sum(groups) > 100 if certify == "1" else sum(groups) == 0), groups[:20]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["f4", "f8"])
 def test_signed_zeros_through_the_temporal_statistics(gpu, dt):
     """What the temporal fuzzing of round 4 found: NumPy's sums over the frame axis start from add's identity, so a cell whose
