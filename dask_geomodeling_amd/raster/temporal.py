@@ -8,6 +8,7 @@ as the reference does (``Series.resample(...).indices``); a source's frames asce
 label owns one run of consecutive frames.  The per-pixel reduction over those runs is the device
 kernel (csrc/gm_temporal.hip): every frame is read once, every label written once."""
 import ctypes
+import functools
 import warnings
 from datetime import timedelta as Timedelta
 
@@ -29,8 +30,10 @@ MAX_MEDIAN_FRAMES = 599  # GM_MAX_MEDIAN_FRAMES_LONG: a cell's frames are sorted
 _EXTENSIVE = {"sum", "count"}  # additive statistics: nothing to add up = 0, not 'no data'
 
 
+@functools.lru_cache(maxsize=256)
 def normalize_offset(freq):
-    """A pandas offset string in the spelling of the running pandas (utils.py:979-1013)."""
+    """A pandas offset string in the spelling of the running pandas (utils.py:979-1013).  (Remembered: the Blocks ask per
+    request and per tile, and pandas takes its time to parse a rule.)"""
     if freq is None:
         return None
     with warnings.catch_warnings():
@@ -38,6 +41,7 @@ def normalize_offset(freq):
         return to_offset(freq).freqstr
 
 
+@functools.lru_cache(maxsize=256)
 def offset_to_timedelta(freq):
     """The fixed length of a frequency, None for calendar-dependent ones (utils.py:960-976)."""
     try:
@@ -100,6 +104,12 @@ def _remembered(method):
 
     wrapper.__name__, wrapper.__doc__ = method.__name__, method.__doc__
     return wrapper
+
+
+@functools.lru_cache(maxsize=256)
+def _calendar_for(frequency, closed, label, timezone):
+    """The (stateless) calendar of a rule, made once: every request and every tile of a temporal view asks for it."""
+    return _Calendar(frequency, closed, label, timezone)
 
 
 class _Calendar:
@@ -644,7 +654,7 @@ class Resample(BaseSingle):
 
     @property
     def _calendar(self):
-        return _Calendar(self.frequency, None, None, self.timezone)
+        return _calendar_for(self.frequency, None, None, self.timezone)
 
     @property
     def period(self):
@@ -697,7 +707,7 @@ class Resample(BaseSingle):
         if process_kwargs.get("empty"):
             return None if mode == "vals" else {mode: []}
         if mode == "time":
-            calendar = _Calendar(process_kwargs["frequency"], None, None, process_kwargs["timezone"])
+            calendar = _calendar_for(process_kwargs["frequency"], None, None, process_kwargs["timezone"])
             return {"time": calendar.label_range(process_kwargs["start"], process_kwargs["stop"])}
         return _rearranged(process_kwargs, data)
 
@@ -742,7 +752,7 @@ class TemporalAggregate(BaseSingle):
 
     @property
     def _calendar(self):
-        return _Calendar(self.frequency, self.closed, self.label, self.timezone)
+        return _calendar_for(self.frequency, self.closed, self.label, self.timezone)
 
     @property
     def period(self):
@@ -791,7 +801,7 @@ class TemporalAggregate(BaseSingle):
         nothing = None if mode == "vals" else {mode: []}
         if process_kwargs.get("empty"):
             return nothing
-        calendar = _Calendar(process_kwargs["frequency"], process_kwargs["closed"], process_kwargs["label"],
+        calendar = _calendar_for(process_kwargs["frequency"], process_kwargs["closed"], process_kwargs["label"],
                              process_kwargs["timezone"])
         labels, local_labels = calendar.labels_between(process_kwargs["start"], process_kwargs["stop"])
         if mode == "time":
@@ -864,7 +874,7 @@ class Cumulative(BaseSingle):
         if wanted is None or not wanted.get("time"):
             return [({"empty": True, "mode": mode}, None)]
         first, last = wanted["time"][0], wanted["time"][-1]
-        calendar = _Calendar(self.frequency, "right", "right", self.timezone)
+        calendar = _calendar_for(self.frequency, "right", "right", self.timezone)
         if self.frequency is None:
             request["start"], request["stop"] = self.period[0], last
         else:
@@ -887,7 +897,7 @@ class Cumulative(BaseSingle):
             return time_data
         if time_data is None or not time_data.get("time"):
             return nothing
-        calendar = _Calendar(process_kwargs["frequency"], process_kwargs["closed"], process_kwargs["label"],
+        calendar = _calendar_for(process_kwargs["frequency"], process_kwargs["closed"], process_kwargs["label"],
                              process_kwargs["timezone"])
         times = time_data["time"]
         members, wanted = calendar.periods_of(times, process_kwargs["start"], process_kwargs["stop"])

@@ -104,6 +104,11 @@ def temporal_leaf(rng, frames=None, step_hours=None, shape_yx=SHAPE_YX):
     step = timedelta(hours=int(step_hours if step_hours is not None else [1, 6, 24][int(rng.integers(3))]))
     first = T0 + timedelta(hours=int(rng.integers(0, 3))) * (1 if rng.random() < 0.15 else 0)  # (now and then off the others' grid)
     metadata = ["frame %d of %s" % (i, dt) for i in range(n)] if rng.random() < 0.5 else None
+    if rng.random() < 0.3:  # resident in HBM from the start (zero-copy windows, strided point reads)
+        from dask_geomodeling_amd.hip.array import DeviceArray
+        if np.dtype(dt).kind == "f":
+            v[~np.isfinite(v)] = ndv
+        v = DeviceArray.from_numpy(v)
     return raster.MemorySource(v, ndv, "EPSG:28992", 1.0, (0.0, float(shape_yx[0])), time_first=first,
                                time_delta=step if n > 1 else None, metadata=metadata)
 

@@ -2188,3 +2188,30 @@ def test_merges_of_wide_unsigned_rasters(gpu, dt, ndv):
     a, b = source(), source()
     for view in (raster.FillNoData(a, b), raster.Group(a, b), raster.Group(a, source(6)), raster.Clip(a, b), raster.Max(a, b)):
         assert_result_equal(view.get_data(**box), walk(view, box), 0, "%s of %s" % (type(view).__name__, dt))
+
+
+@pytest.mark.gpu
+def test_point_requests_on_resident_series(gpu):
+    """The time series of a location from a source that lives in HBM: the cell of every requested frame comes back in one
+    strided copy (raster/sources.py) -- every time window, points on cell edges and outside the raster, against the same
+    source held on the host and against the walking oracle; and through a view."""
+    from datetime import datetime, timedelta
+    from dask_geomodeling_amd import raster
+    from dask_geomodeling_amd.hip.array import DeviceArray
+    from oracle_walk import walk
+    rng = np.random.default_rng(4)
+    v = (rng.random((9, 31, 45)) * 100).astype("f4")
+    v[rng.random(v.shape) < 0.2] = -9999.0
+    kw = dict(time_first=datetime(2021, 3, 1), time_delta=timedelta(hours=6))
+    host = raster.MemorySource(v, -9999.0, "EPSG:28992", 2.0, (10.0, 100.0), **kw)
+    resident = raster.MemorySource(DeviceArray.from_numpy(v), -9999.0, "EPSG:28992", 2.0, (10.0, 100.0), **kw)
+    windows = [dict(), dict(start=datetime(2021, 3, 2)), dict(start=datetime(2021, 3, 1, 5), stop=datetime(2021, 3, 2, 13)),
+               dict(start=datetime(2021, 1, 1), stop=datetime(2021, 6, 1)), dict(start=datetime(2021, 3, 1, 1), stop=datetime(2021, 3, 1, 2))]
+    for x, y in ((11.0, 99.0), (10.0, 100.0), (12.0, 98.0), (99.9, 38.1), (100.0, 38.0), (5.0, 50.0), (50.0, 120.0), (57.3, 61.9)):
+        for when in windows:
+            request = dict(mode="vals", bbox=(x, y, x, y), width=1, height=1, projection="EPSG:28992", **when)
+            want = walk(host, request)
+            for source in (host, resident):
+                assert_result_equal(source.get_data(**request), want, 0, "%s at (%s, %s) %s" % (type(source.data).__name__, x, y, when))
+            view = raster.TemporalAggregate(resident * 2, "D", "mean")
+            assert_result_equal(view.get_data(**request), walk(raster.TemporalAggregate(host * 2, "D", "mean"), request), 0, "view")

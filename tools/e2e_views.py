@@ -104,3 +104,13 @@ run("A + B, 256^2 tiles", A + B, 12 * 256 * 256, small, n=900)
 run("Clip(A * 2, B > 50), 256^2", raster.Clip(A * 2, B > 50), 12 * 256 * 256, small, n=900)
 run("HillShade(A), 256^2", raster.HillShade(A), 5 * 256 * 256, small, n=900)
 run("Smooth(A, 2), 256^2", raster.Smooth(A, 2.0), 8 * 256 * 256, small, n=900)
+# temporal views under a tiler and in combination (round 4, second half)
+run("tiler(TemporalAggregate(T, D, mean), 1024)", raster.RasterTiler(raster.TemporalAggregate(T, "D", "mean"), 1024), (frames * 4 + 2 * 4) * px, [tbox], n=20)
+run("tiler(T * 2, 1024) (8 frames)", raster.RasterTiler(T * 2, 1024), frames * 8 * px, [tbox], n=20)
+run("TemporalAggregate(Clip(T, T > 50), D, max)", raster.TemporalAggregate(raster.Clip(T, T > 50), "D", "max"), (frames * 8 + frames * 4 + 2 * 4) * px, [tbox], n=20)
+run("Cumulative(T * 2)", raster.Cumulative(T * 2), (frames * 8 + frames * 8) * px, [tbox], n=20)
+run("TemporalSum(T) / 8", raster.TemporalSum(T) / 8, (frames * 4 + 4 + 8) * px, [tbox], n=20)
+run("Group(T, T2) (8 + 8 frames, one grid)", raster.Group(T, T * 0.5), (frames * 8 + frames * 12) * px, [tbox], n=20)
+point = dict(tbox, bbox=(2000.5, 2000.5, 2000.5, 2000.5), width=1, height=1)
+run("TemporalAggregate(T, D, mean) at a point", raster.TemporalAggregate(T, "D", "mean"), 1.0, [point], n=200)
+run("T * 2 at a point (8 frames)", T * 2, 1.0, [point], n=200)
