@@ -327,6 +327,10 @@ def _child(block, request):
         # time stamps and metadata: no tiles, nothing to fuse -- the Blocks' own process() over their sources' answers,
         # without a graph, a token and a scheduler pass per question (a Group asks every source for its time stamps)
         response = _direct(block, request)
+    elif not any(isinstance(a, Block) for a in block.args):
+        # a source (nothing below it to plan or fuse): its own process(), without a graph per request -- the frames of a
+        # series under a tiled temporal view are asked for tile by tile
+        response = _direct(block, request)
     else:
         planned, response = evaluate(block, request)
         if not planned:
