@@ -913,6 +913,61 @@ extern "C" int gm_copy_2d(void* dst, size_t dst_pitch_bytes, const void* src, si
   return GM_OK;
 }
 
+// ... of a window of several planes (the frames of a series inside a tile of its raster): `planes` windows of `rows` rows,
+// the source's `src_plane_rows` rows of src_pitch_bytes apart, the destination's dst_plane_rows.  One copy.
+extern "C" int gm_copy_3d(void* dst, size_t dst_pitch_bytes, size_t dst_plane_rows, const void* src, size_t src_pitch_bytes,
+                          size_t src_plane_rows, size_t width_bytes, size_t rows, size_t planes) {
+  if (!dst || !src) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (width_bytes == 0 || rows == 0 || planes == 0) return GM_OK;
+  if (rows > dst_plane_rows || rows > src_plane_rows || width_bytes > dst_pitch_bytes || width_bytes > src_pitch_bytes)
+    return gm::fail(GM_ERR_INVALID, "gm_copy_3d: window larger than its plane");
+  hipStream_t stream = gm::current_stream();
+  if (!stream) return GM_ERR_NO_DEVICE;
+  hipMemcpy3DParms parms;
+  memset(&parms, 0, sizeof(parms));
+  parms.srcPtr = make_hipPitchedPtr(const_cast<void*>(src), src_pitch_bytes, width_bytes, src_plane_rows);
+  parms.dstPtr = make_hipPitchedPtr(dst, dst_pitch_bytes, width_bytes, dst_plane_rows);
+  parms.extent = make_hipExtent(width_bytes, rows, planes);
+  parms.kind = hipMemcpyDeviceToDevice;
+  GM_HIP(hipMemcpy3DAsync(&parms, stream));
+  return GM_OK;
+}
+
+// gm_elemwise_run_batch_2d over tiles of several bands whose bands are not back to back: input k of tile t is `bands` windows
+// of rows x cols, band_pitches[t * n_inputs + k] elements apart (0: the same operand for every band -- a broadcast scalar);
+// the result of tile t likewise with out_band_pitches[t].  An element-wise program treats every band alike, so the bands go
+// as tiles of their own: bands x n_tiles windows in the launches of one call.
+extern "C" int gm_elemwise_run_batch_bands(const gm_program* prog, int n_tiles, const void* const* inputs, const uint32_t* pitches,
+                                           const uint64_t* band_pitches, void* const* outs, const uint32_t* out_pitches,
+                                           const uint64_t* out_band_pitches, int bands, size_t rows, size_t cols) {
+  if (!prog || !outs || !band_pitches || !out_band_pitches || (!inputs && prog->n_inputs)) return gm::fail(GM_ERR_INVALID, "null argument");
+  if (n_tiles < 0 || bands < 0) return gm::fail(GM_ERR_INVALID, "gm_elemwise_run_batch_bands: %d tiles of %d bands", n_tiles, bands);
+  const size_t n_in = prog->n_inputs, total = (size_t)n_tiles * (size_t)bands;
+  if (total == 0) return GM_OK;
+  if (total > 0x7fffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "gm_elemwise_run_batch_bands: %zu windows", total);
+  std::vector<const void*> in(total * n_in);
+  std::vector<uint32_t> in_pitch(total * n_in);
+  std::vector<void*> out(total);
+  std::vector<uint32_t> out_pitch(total);
+  const size_t out_item = gm::dtype_size(prog->out_dtype);
+  for (int t = 0; t < n_tiles; ++t) {
+    for (int b = 0; b < bands; ++b) {
+      const size_t v = (size_t)t * bands + b;
+      for (size_t k = 0; k < n_in; ++k) {
+        const size_t at = (size_t)t * n_in + k;
+        if (!inputs[at]) return gm::fail(GM_ERR_INVALID, "input %zu of tile %d is null", k, t);
+        const size_t item = gm::dtype_size(prog->inputs[k].bits & 0xffu);
+        in[v * n_in + k] = (const char*)inputs[at] + (size_t)b * band_pitches[at] * item;
+        in_pitch[v * n_in + k] = pitches ? pitches[at] : 0u;
+      }
+      if (!outs[t]) return gm::fail(GM_ERR_INVALID, "output of tile %d is null", t);
+      out[v] = (char*)outs[t] + (size_t)b * out_band_pitches[t] * out_item;
+      out_pitch[v] = out_pitches ? out_pitches[t] : 0u;
+    }
+  }
+  return gm_elemwise_run_batch_2d(prog, (int)total, in.data(), in_pitch.data(), out.data(), out_pitch.data(), rows, cols);
+}
+
 // ABI self-check used by the Python binding: sizes of the program structs.
 extern "C" size_t gm_sizeof(int which) {
   switch (which) {

@@ -343,7 +343,7 @@ class TiledAssembly(object):
     tiles: the mosaic is allocated first and every batched tile program writes its result straight
     into its window of the mosaic (row pitch = mosaic width, y axis flipped as the reference
     pastes), so the fill + paste passes over the result disappear.  Tiles that cannot be written in
-    place (several bands, another dtype, ``None`` responses) fall back to the reference's paste."""
+    place (another dtype, another number of bands than the first tile's, ``None`` responses) fall back to the reference's paste."""
 
     def __init__(self, tiler_process, layout, batches):
         self.tiler_process = tiler_process
@@ -361,10 +361,12 @@ class TiledAssembly(object):
 
         def dest_for(b):
             def dest(member, shape, out_dtype):
-                if len(shape) != 3 or shape[0] != 1 or np.dtype(out_dtype) != dtype:
+                if len(shape) != 3 or shape[0] < 1 or np.dtype(out_dtype) != dtype:
                     return None
-                if state["mosaic"] is None:
-                    state["mosaic"] = DeviceArray.empty((1, height, width), dtype)
+                if state["mosaic"] is None:  # (several bands: the frames of a series, every tile a window of as many planes)
+                    state["mosaic"] = DeviceArray.empty((shape[0], height, width), dtype)
+                if state["mosaic"].shape[0] != shape[0]:
+                    return None
                 ix, iy = divmod(position[(b, member)], count_y)
                 th, tw = shape[1], shape[2]
                 row0, col0 = height - (iy * tile_y + th), ix * tile_x  # low y -> high rows (parallelize.py:114-124)

@@ -1,5 +1,6 @@
-"""DeviceArray: a tile living in MI355X HBM -- C-contiguous, or a zero-copy 2-D window
-(``pitch``) of a larger resident raster.
+"""DeviceArray: a tile living in MI355X HBM -- C-contiguous, or a zero-copy window of a larger resident raster:
+rows ``pitch`` cells apart, and for a window of several bands (round 4: the frames of a series) bands ``band_pitch``
+cells apart.
 
 It quacks enough like an ndarray (``shape``, ``dtype``, ``ndim``, ``size``,
 ``__array__``) for dict-of-arrays raster responses to flow between ``process``
@@ -17,16 +18,21 @@ from .dtypes import code_of
 
 
 class DeviceArray:
-    __slots__ = ("ptr", "shape", "dtype", "device", "_owner", "pitch", "__weakref__")
+    __slots__ = ("ptr", "shape", "dtype", "device", "_owner", "pitch", "band_pitch", "__weakref__")
 
-    def __init__(self, ptr, shape, dtype, device, owner=None, pitch=None):
+    def __init__(self, ptr, shape, dtype, device, owner=None, pitch=None, band_pitch=None):
         self.ptr = ptr
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
         self.device = device
         self._owner = owner  # keeps a parent allocation alive for views
-        # row pitch in elements of a (1, h, w) window into a wider raster; None = C-contiguous
+        # row pitch in elements of a window into a wider raster; None = C-contiguous
         self.pitch = None if pitch is None or int(pitch) == self.shape[-1] else int(pitch)
+        # cells between the bands of a window of several bands (the parent's plane); None: one band, or C-contiguous
+        self.band_pitch = int(band_pitch) if band_pitch is not None and self.shape[0] > 1 and (
+            self.pitch is not None or int(band_pitch) != _prod(self.shape[1:])) else None
+        if self.band_pitch is not None and self.pitch is None:
+            self.pitch = self.shape[-1]  # (whole rows, but planes apart: still a window)
 
     # -- construction ---------------------------------------------------------
     @classmethod
@@ -67,17 +73,20 @@ class DeviceArray:
         return self.pitch is None
 
     def window(self, row0, col0, height, width):
-        """Zero-copy view of rows [row0, row0+height) x columns [col0, col0+width) of a single-band
-        (1, H, W) tile: same allocation, row pitch = the parent's."""
-        if len(self.shape) != 3 or self.shape[0] != 1:
-            raise ValueError("window() needs a (1, H, W) tile, got %s" % (self.shape,))
-        _, H, W = self.shape
+        """Zero-copy view of rows [row0, row0+height) x columns [col0, col0+width) of a (bands, H, W) tile: same allocation,
+        row pitch = the parent's; several bands stay a plane of the parent apart (``band_pitch``)."""
+        if len(self.shape) != 3:
+            raise ValueError("window() needs a (bands, H, W) tile, got %s" % (self.shape,))
+        bands, H, W = self.shape
+        if bands != 1 and self.pitch is not None:
+            raise ValueError("window() of a window of several bands")
         row0, col0, height, width = int(row0), int(col0), int(height), int(width)
         if not (0 <= row0 and 0 <= col0 and row0 + height <= H and col0 + width <= W):
             raise ValueError("window outside the tile")
         pitch = self.pitch or W
         ptr = self.ptr + (row0 * pitch + col0) * self.dtype.itemsize
-        return DeviceArray(ptr, (1, height, width), self.dtype, self.device, owner=self, pitch=pitch)
+        return DeviceArray(ptr, (bands, height, width), self.dtype, self.device, owner=self, pitch=pitch,
+                           band_pitch=H * W if bands > 1 else None)
 
     def room_right(self):
         """Columns of the parent raster to the right of this zero-copy window, in the window's rows (0 for a tile that
@@ -98,12 +107,18 @@ class DeviceArray:
             return self
         out = DeviceArray.empty(self.shape, self.dtype)
         item = self.dtype.itemsize
-        _, h, w = self.shape
+        bands, h, w = self.shape
         L = runtime.lib()
         L.gm_copy_2d.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
                                  ctypes.c_size_t, ctypes.c_size_t]
-        runtime.check(L.gm_copy_2d(ctypes.c_void_p(out.ptr), w * item, ctypes.c_void_p(self.ptr), self.pitch * item,
-                                   w * item, h), "gm_copy_2d")
+        if self.band_pitch is None:
+            runtime.check(L.gm_copy_2d(ctypes.c_void_p(out.ptr), w * item, ctypes.c_void_p(self.ptr), self.pitch * item,
+                                       w * item, h), "gm_copy_2d")
+        else:  # (the frames of a series inside a tile of its raster: planes of band_pitch / pitch rows, one copy)
+            L.gm_copy_3d.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                     ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t]
+            runtime.check(L.gm_copy_3d(ctypes.c_void_p(out.ptr), w * item, h, ctypes.c_void_p(self.ptr), self.pitch * item,
+                                       self.band_pitch // self.pitch, w * item, h, bands), "gm_copy_3d")
         return out
 
     def to_numpy(self):
@@ -124,10 +139,17 @@ class DeviceArray:
     def band_slice(self, start, stop):
         """View of bands [start, stop) of a (bands, H, W) tile (no copy)."""
         start, stop = int(start), int(stop)
-        if self.pitch is not None:
-            raise ValueError("band_slice() of a strided window")
         if not 0 <= start <= stop <= self.shape[0]:
             raise IndexError("bands [%d, %d) of a tile of %d" % (start, stop, self.shape[0]))
+        if self.pitch is not None:
+            if self.shape[0] == 1:
+                if (start, stop) == (0, 1):
+                    return self
+                raise ValueError("band_slice() of a strided window")
+            # bands of a window of several: windows themselves
+            ptr = self.ptr + start * self.band_pitch * self.dtype.itemsize
+            return DeviceArray(ptr, (stop - start,) + self.shape[1:], self.dtype, self.device, owner=self, pitch=self.pitch,
+                               band_pitch=self.band_pitch)
         plane = _prod(self.shape[1:]) * self.dtype.itemsize
         return DeviceArray(self.ptr + start * plane, (stop - start,) + self.shape[1:], self.dtype,
                            self.device, owner=self)

@@ -761,6 +761,11 @@ def _lib():
                                                ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_void_p),
                                                ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t, ctypes.c_size_t]
         L.gm_elemwise_run_batch_2d.restype = ctypes.c_int
+        L.gm_elemwise_run_batch_bands.argtypes = [ctypes.POINTER(gm_program), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                                  ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64),
+                                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32),
+                                                  ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t]
+        L.gm_elemwise_run_batch_bands.restype = ctypes.c_int
         L.gm_vm_set_tuning.argtypes = [ctypes.POINTER(gm_vm_tuning)]
         L.gm_vm_get_tuning.argtypes = [ctypes.POINTER(gm_vm_tuning)]
         L.gm_sizeof.argtypes = [ctypes.c_int]
@@ -895,6 +900,39 @@ def launch_batch(compiled, tiles, shape, outs=None):
     if any(len(inputs) != n_in for inputs in tiles):
         raise ValueError("every tile of a batch must bring the same number of inputs")
     flat = [x for inputs in tiles for x in inputs]
+    if any(x.band_pitch is not None for x in flat):
+        # windows of several bands (the frames of a series inside a tile of its raster): an element-wise program treats
+        # every band alike, so each band goes as a single-band window of its own -- bands x tiles in one batch, nothing
+        # compacted first (round 4; a tiled `T * 2` over 8 frames copied every tile's window before: 2 x the traffic)
+        if len(shape) == 3 and shape[0] > 1 and (outs is None or all(tuple(o.shape) == tuple(shape) for o in outs)):
+            bands, rows, cols = (int(d) for d in shape)
+            results = [DeviceArray.empty(shape, compiled.out_dtype) for _ in tiles] if outs is None else outs
+            count = max(len(flat), 1)
+            ptrs = (ctypes.c_void_p * count)(*[x.ptr for x in flat])
+            pitches = (ctypes.c_uint32 * count)(*[x.pitch or 0 for x in flat])
+            # cells between the bands of an operand: a window's, a compact tile's plane, nothing for one value for all
+            apart = (ctypes.c_uint64 * count)(*[0 if x.size == 1 else (x.band_pitch or rows * cols) for x in flat])
+            out_ptrs = (ctypes.c_void_p * len(results))(*[r.ptr for r in results])
+            out_pitches = (ctypes.c_uint32 * len(results))(*[r.pitch or 0 for r in results])
+            out_apart = (ctypes.c_uint64 * len(results))(*[r.band_pitch or rows * cols for r in results])
+            runtime.check(L.gm_elemwise_run_batch_bands(ctypes.byref(compiled.program), len(tiles), ptrs, pitches, apart, out_ptrs,
+                                                        out_pitches, out_apart, bands, rows, cols), "gm_elemwise_run_batch_bands")
+            return results
+        tiles = [[x.contiguous() if x.band_pitch is not None else x for x in inputs] for inputs in tiles]
+        flat = [x for inputs in tiles for x in inputs]
+    if outs is not None and any(o.band_pitch is not None for o in outs):
+        # results that are windows of several bands (tiles of a mosaic of frames) while every operand is compact
+        bands, rows, cols = (int(d) for d in shape)
+        count = max(len(flat), 1)
+        ptrs = (ctypes.c_void_p * count)(*[x.ptr for x in flat])
+        pitches = (ctypes.c_uint32 * count)(*[x.pitch or 0 for x in flat])
+        apart = (ctypes.c_uint64 * count)(*[0 if x.size == 1 else rows * cols for x in flat])
+        out_ptrs = (ctypes.c_void_p * len(outs))(*[r.ptr for r in outs])
+        out_pitches = (ctypes.c_uint32 * len(outs))(*[r.pitch or 0 for r in outs])
+        out_apart = (ctypes.c_uint64 * len(outs))(*[r.band_pitch or rows * cols for r in outs])
+        runtime.check(L.gm_elemwise_run_batch_bands(ctypes.byref(compiled.program), len(tiles), ptrs, pitches, apart, out_ptrs,
+                                                    out_pitches, out_apart, bands, rows, cols), "gm_elemwise_run_batch_bands")
+        return outs
     if outs is None:
         padded = _padded_launch(L, compiled, tiles, flat, shape, n)
         if padded is not None:

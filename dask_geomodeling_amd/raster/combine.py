@@ -114,6 +114,8 @@ def _band(values, index):
     if isinstance(values, DeviceArray):
         if values.shape[0] == 1 and index == 0:
             return values  # (a zero-copy window of a resident raster stays one: the merge program reads it in place)
+        if values.band_pitch is not None:
+            return values.band_slice(index, index + 1)  # (... and so does one frame of a window over a series)
         return values.contiguous().band_slice(index, index + 1)
     return np.asarray(values)[index:index + 1]
 

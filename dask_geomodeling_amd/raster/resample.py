@@ -68,6 +68,8 @@ def affine_nearest(source, zoom_yx, offset_yx, cval=0.0):
 def bilinear(source, out_height, out_width, no_data_value):
     """Bilinear resize of a float (bands, H, W) tile (our spec)."""
     src = as_device_view(source)  # (a window of a resident raster is read where it lies)
+    if src.band_pitch is not None:
+        src = src.contiguous()
     if src.dtype.kind != "f":
         raise TypeError("bilinear resampling needs a float32/float64 tile, got %s" % src.dtype)
     bands, hs, ws = src.shape

@@ -109,14 +109,14 @@ class RasterSourceBase(RasterBlock):
         fill = process_kwargs["fillvalue"]
         fill = fill.item() if hasattr(fill, "item") else fill
         window = process_kwargs.get("window")
-        if window is not None and length == 1 and width and height and raster_data.all_finite():
+        if window is not None and length >= 1 and width and height and raster_data.all_finite():
             # pixel-aligned window inside the source (the planning has checked CRS, cell size and bounds: _aligned_window):
             # a zero-copy view (row pitch = source width) that the element-wise program kernel reads in place; other
             # consumers compact it on demand.  First, because it is what every tile of a tiled view asks for.
             runtime.require_device()
             source = raster_data.on_device()
-            if source.shape[0] != 1:
-                source = source.band_slice(bands[0], bands[1])
+            if source.shape[0] != length:
+                source = source.band_slice(bands[0], bands[1])  # (several frames: a window whose bands lie a plane apart)
             if process_kwargs.get("whole"):
                 return {"values": source, "no_data_value": fill}  # the request grid IS the source grid
             return {"values": source.window(window[0], window[1], height, width), "no_data_value": fill}

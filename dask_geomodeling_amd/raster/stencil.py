@@ -6,10 +6,17 @@ import functools
 import numpy as np
 
 from ..hip import runtime
-from ..hip.array import DeviceArray, as_device, as_device_view
+from ..hip.array import DeviceArray, as_device
+from ..hip.array import as_device_view as _any_view
 from ..hip.dtypes import code_of
 
 _declared = False
+
+
+def as_device_view(values):
+    """The tile as the kernels of this file read it: a single-band window where it lies, anything of several bands compact."""
+    view = _any_view(values)
+    return view.contiguous() if view.band_pitch is not None else view
 
 
 def _lib():

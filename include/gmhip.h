@@ -269,6 +269,18 @@ int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* co
                              void* const* outs, const uint32_t* out_pitches, size_t rows, size_t cols);
 /* Device-to-device copy of a 2-D window into another pitch (compaction of a window), asynchronous. */
 int gm_copy_2d(void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes, size_t width_bytes, size_t rows);
+/* ... of a window of several planes -- the frames of a series inside a tile of its raster (sources.py:119-149 warps every
+ * frame): `planes` windows of `rows` rows; a plane of the source is src_plane_rows rows of src_pitch_bytes, one of the
+ * destination dst_plane_rows rows of dst_pitch_bytes.  One copy. */
+int gm_copy_3d(void* dst, size_t dst_pitch_bytes, size_t dst_plane_rows, const void* src, size_t src_pitch_bytes,
+               size_t src_plane_rows, size_t width_bytes, size_t rows, size_t planes);
+/* gm_elemwise_run_batch_2d over tiles of several bands that do not lie back to back (elemwise.py:243-297 computes on
+ * (bands, y, x) arrays): input k of tile t is `bands` windows of rows x cols, band_pitches[t * prog->n_inputs + k] elements
+ * apart (0: one operand for every band), the result of tile t likewise with out_band_pitches[t].  The bands run as tiles of
+ * their own. */
+int gm_elemwise_run_batch_bands(const gm_program* prog, int n_tiles, const void* const* inputs, const uint32_t* pitches,
+                                const uint64_t* band_pitches, void* const* outs, const uint32_t* out_pitches,
+                                const uint64_t* out_band_pitches, int bands, size_t rows, size_t cols);
 
 /* Tuning knobs of the VM launch (for measurements; the defaults are the measured optimum). */
 typedef struct gm_vm_tuning {

@@ -305,3 +305,46 @@ def test_templates_make_real_graphs_and_are_reused(gpu):
     with gmconfig.config.set({"geomodeling.templates": False}):
         graph, name = template.fused_compute_graph(view, dict(req, bbox=(0.0, 0.0, 64.0, 64.0)))
         assert graph[name][0] is not runs[0]  # switched off: built and fused from scratch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("plans", [True, False])
+def test_tiled_series_windows_of_several_frames_in_place(gpu, plans):
+    """A RasterTiler over element-wise views of resident multi-frame sources: every tile's operands are zero-copy windows of
+    several bands (rows a source width apart, bands a source plane apart: DeviceArray.band_pitch), the program runs band by band
+    in one call (gm_elemwise_run_batch_bands) and writes into the tile's window of a mosaic of as many frames -- ragged edge
+    tiles, a time window that selects a sub-range of the frames, a single-frame operand next to the series, and a consumer
+    that needs compact tiles (TemporalAggregate), against the walking oracle and the untiled evaluation."""
+    from datetime import datetime, timedelta
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd import raster
+    from dask_geomodeling_amd.hip.array import DeviceArray
+    from helpers import assert_result_equal
+    from oracle_walk import walk
+    rng = np.random.default_rng(12)
+
+    def series(frames, dt="f4", ndv=-9999.0):
+        v = (rng.random((frames, 300, 517)) * 100).astype(dt)
+        v[rng.random(v.shape) < 0.1] = ndv
+        return raster.MemorySource(DeviceArray.from_numpy(v), ndv, "EPSG:28992", 1.0, (0.0, 300.0), time_first=datetime(2021, 3, 1),
+                                   time_delta=timedelta(hours=6) if frames > 1 else None)
+
+    a, b = series(5), series(5, "i2", -1)
+    box = dict(mode="vals", bbox=(0.0, 0.0, 517.0, 300.0), width=517, height=300, projection="EPSG:28992")
+    windows = [dict(start=datetime(2021, 1, 1), stop=datetime(2021, 6, 1)), dict(start=datetime(2021, 3, 1, 5), stop=datetime(2021, 3, 1, 19)),
+               dict(start=datetime(2021, 3, 2))]
+    views = [a * 2, raster.Clip(a * 2 + b, b > 40), raster.Classify(a - b, [0.0, 20.0, 50.0]), a + raster.TemporalSum(a),
+             raster.TemporalAggregate(a * 2, "D", "mean"), raster.Group(a, b)]
+    with gmconfig.config.set({"geomodeling.plans": plans}):
+        for view in views:
+            for when in windows:
+                request = dict(box, **when)
+                want = walk(view, request)
+                for tile in (128, [200, 77]):
+                    got = raster.RasterTiler(view, tile).get_data(**request)
+                    assert_result_equal(got, want, 0, "%s tiled by %s, %s" % (type(view).__name__, tile, when))
+                assert_result_equal(view.get_data(**request), want, 0, "%s untiled, %s" % (type(view).__name__, when))
+    # the mosaic of a multi-frame view is written in place (no paste): the tiles' results are windows of it
+    with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": True}):
+        out = raster.RasterTiler(a * 2, 128).get_data(**dict(box, **windows[0]))["values"]
+        assert isinstance(out, DeviceArray) and out.shape == (5, 300, 517)
