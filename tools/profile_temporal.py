@@ -1,3 +1,5 @@
+"""cProfile of get_data for tiled temporal views over a resident series of 8 frames of 4096^2 (GPU box): where the host time of
+`tiler(TemporalAggregate(T, "D", "mean"), 1024)` and `tiler(T * 2, 1024)` goes (windows of several bands)."""
 import cProfile, io, os, pstats, sys
 from datetime import datetime, timedelta
 import numpy as np
