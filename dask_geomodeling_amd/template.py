@@ -150,6 +150,17 @@ def _build_view_template(view, request):
     task = fused.get(name)
     if not (isinstance(task, tuple) and task and callable(task[0])):
         return None
+    if not isinstance(task[0], FusedTask) and getattr(task[0], "gm_op", None) is not None:
+        # a single element-wise operation stays a plain task in the graph (nothing to fuse it with); as a program of one step
+        # it can be batched over the tiles of a RasterTiler and written into the mosaic like any other (plan.py does the
+        # same): a tiled `T * 2` over 8 frames as a graph per request 670 -> ~250 us
+        from .fuse import _deps, _fusable
+        if _fusable(task):
+            inputs = []
+            for dep in _deps(task, fused):
+                if dep not in inputs:
+                    inputs.append(dep)
+            task = (FusedTask({name: task}, [name], name, inputs),) + tuple(inputs)
     leaf_keys, pattern = [], []
     if isinstance(task[0], FusedTask):
         if list(task[1:]) != list(task[0].leaf_keys):

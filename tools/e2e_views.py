@@ -114,3 +114,9 @@ run("Group(T, T2) (8 + 8 frames, one grid)", raster.Group(T, T * 0.5), (frames *
 point = dict(tbox, bbox=(2000.5, 2000.5, 2000.5, 2000.5), width=1, height=1)
 run("TemporalAggregate(T, D, mean) at a point", raster.TemporalAggregate(T, "D", "mean"), 1.0, [point], n=200)
 run("T * 2 at a point (8 frames)", T * 2, 1.0, [point], n=200)
+run("TemporalAggregate(Group(T, T2), D, mean)", raster.TemporalAggregate(raster.Group(T, T * 0.5), "D", "mean"), (frames * 8 + frames * 12 + frames * 4 + 8) * px, [tbox], n=20)
+run("Resample(T * 2, 3h, nearest)", raster.Resample(T * 2, "3h", "nearest"), (frames * 8 + 2 * 15 * 4) * px, [tbox], n=20)
+run("Snap(T * 2, T)", raster.Snap(T * 2, T), (frames * 8 + frames * 8) * px, [tbox], n=20)
+run("Place(T, 1 coordinate) (8 frames)", raster.Place(T, "EPSG:28992", (2048.0, 2048.0), [(2100.0, 2000.0)]), frames * 8 * px, [tbox], n=20)
+run("Clip(Cumulative(T), T > 50)", raster.Clip(raster.Cumulative(T), T > 50), (frames * 8 + frames * 12) * px, [tbox], n=20)
+run("FillNoData(T, T2) (8 frames)", raster.FillNoData(T, T * 0.5), (frames * 8 + frames * 12) * px, [tbox], n=20)
