@@ -357,7 +357,9 @@ def end_to_end(raster, runtime, side, budget_s=6.0):
              ("Group(A, B)", raster.Group(A, B), None, 12 * px),
              ("Max(A, B, A * 2)", raster.Max(A, B, A * 2), None, 12 * px),
              ("TemporalAggregate(T, 'D', 'mean'), 8 frames", raster.TemporalAggregate(T, "D", "mean"), days, (frames + 2) * 4 * side * side),
-             ("Resample(T, '3h', 'nearest'), 8 -> 17 frames", raster.Resample(T, "3h", "nearest"), days, 2 * 17 * 4 * side * side)]
+             ("Resample(T, '3h', 'nearest'), 8 -> 17 frames", raster.Resample(T, "3h", "nearest"), days, 2 * 17 * 4 * side * side),
+             ("RasterTiler(T * 2, 1024), 8 frames in 16 tiles", raster.RasterTiler(T * 2, 1024), days, frames * 8 * side * side),
+             ("T * 2 at a point, 8 frames", T * 2, dict(days, bbox=(2000.5, 2000.5, 2000.5, 2000.5), width=1, height=1), 64)]
     views = {}
     from dask_geomodeling_amd.hip import program as P
     for label, mixed_view, fixed, nbytes in mixed:
