@@ -357,13 +357,13 @@ def _shifted_copy(source, fill, out_shape, di, dj):
         return out
     item = source.dtype.itemsize
     L = runtime.lib()
-    L.gm_copy_2d.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
-                             ctypes.c_size_t]
-    for band in range(bands):
-        src_ptr = source.ptr + ((band * src_h + j0) * src_w + i0) * item
-        dst_ptr = out.ptr + ((band * dst_h + j0 + dj) * dst_w + i0 + di) * item
-        runtime.check(L.gm_copy_2d(ctypes.c_void_p(dst_ptr), dst_w * item, ctypes.c_void_p(src_ptr), src_w * item,
-                                   (i1 - i0) * item, j1 - j0), "gm_copy_2d")
+    L.gm_copy_3d.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                             ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t]
+    # the window of every band in one copy (planes of src_h / dst_h rows)
+    src_ptr = source.ptr + (j0 * src_w + i0) * item
+    dst_ptr = out.ptr + ((j0 + dj) * dst_w + i0 + di) * item
+    runtime.check(L.gm_copy_3d(ctypes.c_void_p(dst_ptr), dst_w * item, dst_h, ctypes.c_void_p(src_ptr), src_w * item, src_h,
+                               (i1 - i0) * item, j1 - j0, bands), "gm_copy_3d")
     return out
 
 
