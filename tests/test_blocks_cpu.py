@@ -871,3 +871,28 @@ def test_plans_through_blocks_with_their_own_kernels(cpu_vm):
     assert np.allclose(np.asarray(got["values"])[ok], want[ok])
     for mode in ("time", "meta"):
         assert outer.get_data(**dict(req, mode=mode)) == inner.get_data(**dict(req, mode=mode))
+
+
+def test_device_array_windows_of_several_bands_geometry():
+    """DeviceArray.window / band_slice arithmetic without a device (addresses only): a window of a (bands, H, W) tile keeps
+    the parent's row pitch and lies a parent plane apart per band (band_pitch); its bands are single-band windows; windows
+    that cover whole planes are plain contiguous tiles; out-of-range requests raise."""
+    from dask_geomodeling_amd.hip.array import DeviceArray
+    keep = object()
+    a = DeviceArray(4096, (5, 100, 200), "f4", 0, owner=keep)
+    w = a.window(10, 20, 30, 40)
+    assert (w.shape, w.pitch, w.band_pitch, w.ptr) == ((5, 30, 40), 200, 20000, 4096 + (10 * 200 + 20) * 4)
+    one = w.band_slice(2, 3)
+    assert (one.shape, one.pitch, one.band_pitch, one.ptr) == ((1, 30, 40), 200, None, w.ptr + 2 * 20000 * 4)
+    some = w.band_slice(1, 4)
+    assert (some.shape, some.pitch, some.band_pitch, some.ptr) == ((3, 30, 40), 200, 20000, w.ptr + 20000 * 4)
+    full = a.window(0, 0, 100, 200)
+    assert (full.pitch, full.band_pitch, full.is_contiguous) == (None, None, True)
+    rows = a.window(10, 0, 30, 200)  # whole rows, but the bands are not back to back
+    assert (rows.pitch, rows.band_pitch, rows.is_contiguous) == (200, 20000, False)
+    single = DeviceArray(4096, (1, 100, 200), "f4", 0, owner=keep).window(1, 2, 3, 4)
+    assert (single.shape, single.pitch, single.band_pitch) == ((1, 3, 4), 200, None)
+    assert single.band_slice(0, 1) is single
+    for bad in (lambda: a.window(90, 0, 20, 10), lambda: a.band_slice(3, 7), lambda: w.window(0, 0, 1, 1), lambda: single.band_slice(0, 2)):
+        with pytest.raises((ValueError, IndexError)):
+            bad()
