@@ -1,4 +1,4 @@
-"""Many more temporal fuzz seeds than the test suite runs (GPU box): python tests/fuzz_temporal.py [n] [HxW].  Lives under
+"""Many more temporal fuzz seeds than the test suite runs (GPU box): python tests/fuzz_temporal.py [n] [HxW] [first seed].  Lives under
 tests/ because it checks against the oracle (tests/oracle_walk.py)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,10 +12,11 @@ from dask_geomodeling_amd.hip import runtime
 runtime.set_device(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 SHAPE = tuple(int(x) for x in sys.argv[2].split("x")) if len(sys.argv) > 2 else (24, 40)  # e.g. 150x517
+BASE = int(sys.argv[3]) if len(sys.argv) > 3 else 90_000  # first seed
 bad = raised = asked = refused = 0
 refusals = {}
 for seed in range(N):
-    rng = np.random.default_rng(90_000 + seed)
+    rng = np.random.default_rng(BASE + seed)
     view = random_temporal_view(rng, depth=int(rng.integers(1, 5)), shape_yx=SHAPE)
     with gmconfig.config.set({"geomodeling.plans": seed % 2 == 0}):
         for request in random_requests(rng, view, SHAPE):

@@ -88,10 +88,13 @@ T0 = datetime(2021, 3, 1)
 SHAPE_YX = (24, 40)
 BOX = dict(bbox=(0.0, 0.0, 40.0, 24.0), width=40, height=24, projection="EPSG:28992")
 KINDS = [("f4", np.float32(np.finfo("f4").max)), ("f4", -9999.0), ("u1", np.uint8(255)), ("i2", np.int16(-1)), ("i4", -9999),
-         ("f8", float(np.finfo("f8").max)), ("u2", np.uint16(65535)), ("i1", np.int8(-128)), ("u4", np.uint32(4294967295)),
+         ("f8", float(np.finfo("f8").max)), ("u2", np.uint16(65535)), ("i1", np.int8(-128)), ("u4", np.uint32(77)),
          ("i8", -9999), ("f4", np.float32(-3.5))]
 
 
+# (uint32 with a small no-data value: TemporalSum adds no-data cells like any other, and seven times 4294967295 under a Max that
+#  still declares uint32 is a float64 -> uint32 cast out of range -- undefined in C, 0 in this NumPy build, and not emulated;
+#  the dtype's maximum as no data is covered by test_merges_of_wide_unsigned_rasters)
 def temporal_leaf(rng, frames=None, step_hours=None, shape_yx=SHAPE_YX):
     dt, ndv = KINDS[int(rng.integers(len(KINDS)))]
     n = int(rng.integers(1, 9)) if frames is None else frames
