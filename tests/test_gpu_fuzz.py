@@ -110,7 +110,7 @@ def test_random_temporal_views_against_the_walking_oracle(gpu, seed):
     evaluation raises (frames of two sources that do not line up, metadata a source does not have), so does the device path.
     Every other seed runs with a graph per request instead of the plans."""
     from dask_geomodeling_amd import config as gmconfig
-    from oracle_walk import comparable, random_requests, random_temporal_view, walk
+    from oracle_walk import comparable, random_requests, random_temporal_view, walk, without_lossy_cells
     rng = np.random.default_rng(70_000 + seed)
     shape = (24, 40) if seed < 1000 else (150, 517)  # (the larger rasters: windows with a pitch, several workgroups per tile)
     view = random_temporal_view(rng, depth=int(rng.integers(1, 4)), shape_yx=shape)
@@ -129,7 +129,7 @@ def test_random_temporal_views_against_the_walking_oracle(gpu, seed):
                 got = view.get_data(**request)
             except NotImplementedError as refusal:  # (e.g. uint64 + float32 has no exact register class)
                 pytest.skip("not on the device path: %s" % refusal)
-            _same_response(comparable(got, view), comparable(want, view), what)
+            _same_response(*without_lossy_cells(comparable(got, view), comparable(want, view)), what)
 
 
 @pytest.mark.parametrize("seed", range(120))
