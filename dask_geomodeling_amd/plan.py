@@ -210,7 +210,8 @@ def _run_tiler(tiler, request):
                 finally:
                     _running.memo = outer
             responses = []
-            outer = getattr(_running, "memo", None)
+            outer, outer_boxless = getattr(_running, "memo", None), getattr(_running, "boxless", None)
+            _running.boxless = {}
             try:
                 for _, request in pairs[1:]:
                     _running.memo = {}  # a memo per tile: the tiles share nothing, and theirs must not pile up
@@ -219,7 +220,7 @@ def _run_tiler(tiler, request):
                         return False, None
                     responses.append(response)
             finally:
-                _running.memo = outer
+                _running.memo, _running.boxless = outer, outer_boxless
             return True, type(tiler).process(kwargs, *responses)
         b = index_of.get(id(plan))
         if b is None:
@@ -315,6 +316,12 @@ def _child(block, request):
         if response is not None:
             return response
     memo = getattr(_running, "memo", None)
+    if memo is not None and "bbox" not in request:
+        # a question without a box (the time stamps / metadata of a window in time) has one answer for all tiles of a
+        # mosaic: kept for the whole tiler request, not per tile
+        shared = getattr(_running, "boxless", None)
+        if shared is not None:
+            memo = shared
     key = None
     if memo is not None:
         try:
