@@ -162,6 +162,7 @@ class Group(BaseCombine):
 
     Values at equal timesteps are considered starting with the leftmost raster: rasters more 'to
     the right' are shown in the result, 'no data' is transparent."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     NOTHING = [(dict(combine_mode="simple"), None)]
     gm_direct = True  # plan.py: evaluated as process(sources' responses) without a graph per request

@@ -31,6 +31,7 @@ class BaseElementwise(RasterBlock):
     """Base of element-wise operations.  The result exists where ALL raster arguments exist: period, extent
     and geometry are intersections, projection and geo_transform survive only when the arguments agree
     (elemwise.py:37-191)."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, *args):
         super().__init__(*args)
@@ -239,6 +240,7 @@ _invert_process.gm_op = "invert"
 
 class Invert(BaseSingle):
     """Logical not of a boolean raster (elemwise.py:551-579)."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, x):
         super(Invert, self).__init__(x)
@@ -270,6 +272,7 @@ _isnodata_process.gm_op = "isnodata"
 
 class IsData(BaseSingle):
     """True where the raster has data (elemwise.py:582-615)."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, store):
         if store.dtype == BOOL:
@@ -309,6 +312,7 @@ class FillNoData(BaseElementwise):
 
 
 class BaseLogExp(BaseSingle):
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
     def __init__(self, x):
         if x.dtype == BOOL:
             raise TypeError("input block must not have boolean dtype")

@@ -19,6 +19,7 @@ BOOL = np.dtype("bool")
 class Clip(BaseSingle):
     """Keep ``store`` where ``source`` has data (or is True), no-data elsewhere
     (misc.py:30-166)."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, store, source):
         need_raster(source, blame=store)  # (the reference names the store's type here, misc.py:54)
@@ -89,6 +90,7 @@ class Clip(BaseSingle):
 
 class Mask(BaseSingle):
     """Replace every data cell by one constant; no-data stays no-data (misc.py:169-222)."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, store, value):
         need_number(value)
@@ -108,6 +110,7 @@ class Mask(BaseSingle):
 
 class MaskBelow(BaseSingle):
     """Cells below ``value`` become no-data (misc.py:225-251)."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, store, value):
         need_number(value)
@@ -122,6 +125,7 @@ class MaskBelow(BaseSingle):
 
 class Step(BaseSingle):
     """Three-valued step function around ``value`` (misc.py:254-328)."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, store, left=0, right=1, value=0, at=None):
         if at is None:
@@ -140,6 +144,7 @@ class Step(BaseSingle):
 
 class Classify(BaseSingle):
     """Bin index of every cell for increasing ``bins`` (misc.py:331-399)."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, store, bins, right=False):
         need_raster(store)
@@ -178,6 +183,7 @@ def _whole_numbers(dtype):
 
 class Reclassify(BaseSingle):
     """Map integer cell values through a list of [from, to] pairs (misc.py:402-515)."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, store, data, select=False):
         if not _whole_numbers(store.dtype):

@@ -217,6 +217,7 @@ class MemorySource(RasterSourceBase):
     :param time_delta: difference between two frames (ms or timedelta)
     :param metadata: a list of metadata corresponding to the frames
     """
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, data, no_data_value, projection, pixel_size, pixel_origin, time_first=0,
                  time_delta=None, metadata=None):

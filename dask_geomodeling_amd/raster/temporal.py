@@ -523,6 +523,7 @@ class Snap(RasterBlock):
     ``store`` at the time stamps of ``index`` -- for every index frame the store frame closest in time.
 
     Args: store (cell values), index (time stamps)."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, store, index):
         for x in (store, index):
@@ -578,6 +579,7 @@ class Shift(BaseSingle):
     """Shift a temporal raster by a timedelta (temporal.py:185-236): positive into the future.
 
     Args: store, time (milliseconds, or a datetime.timedelta)."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, store, time):
         if isinstance(time, Timedelta):
@@ -613,6 +615,7 @@ class Shift(BaseSingle):
 class TemporalSum(BaseSingle):
     """All frames of the store added up into one (temporal.py:239-255): a plain sum -- 'no data' values are added
     like any other value -- in np.sum's accumulator dtype; time and meta answer with their last entry."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     @staticmethod
     def process(data):
@@ -631,6 +634,7 @@ class Resample(BaseSingle):
     ``frequency`` and each takes the nearest source frame, or the first one after / before it.
 
     Args: source, frequency (pandas offset string), direction ('nearest', 'backward' or 'forward'), timezone."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, source, frequency, direction="nearest", timezone="UTC"):
         if not isinstance(source, RasterBlock):
@@ -719,6 +723,7 @@ class TemporalAggregate(BaseSingle):
     labelled with the end of the period), statistic (sum, count, min, max, mean, median, std, var,
     p<percentile>), closed / label ('left', 'right' or None for the frequency's default), timezone.
     """
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     gm_direct = True  # plan.py: evaluated as process(store's responses) without a graph per request
 
@@ -832,6 +837,7 @@ class Cumulative(BaseSingle):
 
     Args: source, statistic ('sum' or 'count'), frequency (period after which the accumulation starts
     again; None = never), timezone."""
+    gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     gm_direct = True  # plan.py: evaluated as process(store's responses) without a graph per request
 

@@ -188,8 +188,13 @@ def random_temporal_view(rng, depth=3, shape_yx=SHAPE_YX):
         try:
             view = node(depth)
             if rng.random() < 0.2:  # the tiles of a mosaic, each with the planning of the whole tree behind it
-                view = raster.RasterTiler(view, [int(rng.integers(4, max(nx - 10, 6))), int(rng.integers(4, max(ny + 6, 6)))]
-                                          if rng.random() < 0.7 else int(rng.integers(5, nx)))
+                exact = [t for t in (2, 4, 5, 8, 10, 20) if nx % t == 0], [t for t in (2, 3, 4, 6, 8, 12) if ny % t == 0]
+                if rng.random() < 0.4 and exact[0] and exact[1]:  # tiles that cover the box exactly
+                    tile = [int(nx // exact[0][int(rng.integers(len(exact[0])))]), int(ny // exact[1][int(rng.integers(len(exact[1])))])]
+                else:
+                    tile = ([int(rng.integers(4, max(nx - 10, 6))), int(rng.integers(4, max(ny + 6, 6)))]
+                            if rng.random() < 0.7 else int(rng.integers(5, nx)))
+                view = raster.RasterTiler(view, tile)
             view.dtype, view.fillvalue, view.period, view.timedelta  # attribute algebra must hold
             return view
         except (TypeError, ValueError):

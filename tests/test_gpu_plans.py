@@ -348,3 +348,68 @@ def test_tiled_series_windows_of_several_frames_in_place(gpu, plans):
     with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": True}):
         out = raster.RasterTiler(a * 2, 128).get_data(**dict(box, **windows[0]))["values"]
         assert isinstance(out, DeviceArray) and out.shape == (5, 300, 517)
+
+
+@pytest.mark.gpu
+def test_tiler_over_pixel_local_temporal_views_is_one_request(gpu):
+    """A RasterTiler over a temporal Block (no program to batch over the tiles) whose view is pixel-local and whose tiles cover
+    the box exactly is answered by ONE request for the whole box (plan._whole_instead_of_tiles) -- the same cells as the tiles
+    pasted next to each other: against the walking oracle (which pastes tiles), for every temporal Block, Group, a declared
+    dtype that the values do not have (TemporalSum), time windows that miss the series; and NOT where it could differ: tiles
+    that leave cells uncovered, tiles of one cell, a stencil in the view."""
+    from datetime import datetime, timedelta
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd import plan, raster
+    from helpers import assert_result_equal
+    from oracle_walk import walk
+    rng = np.random.default_rng(21)
+
+    def series(frames, dt="f4", ndv=-9999.0, hours=6):
+        v = (rng.random((frames, 48, 64)) * 100).astype(dt)
+        v[rng.random(v.shape) < 0.1] = ndv
+        return raster.MemorySource(v, ndv, "EPSG:28992", 1.0, (0.0, 48.0), time_first=datetime(2021, 3, 1), time_delta=timedelta(hours=hours))
+
+    a, b = series(9), series(9, "i2", -1)
+    box = dict(mode="vals", bbox=(0.0, 0.0, 64.0, 48.0), width=64, height=48, projection="EPSG:28992")
+    windows = [dict(start=datetime(2021, 1, 1), stop=datetime(2021, 6, 1)), dict(start=datetime(2021, 3, 1, 5), stop=datetime(2021, 3, 2, 19)),
+               dict(start=datetime(2021, 3, 2)), dict(), dict(start=datetime(2022, 1, 1), stop=datetime(2022, 1, 2))]
+    stores = [raster.TemporalAggregate(a * 2, "D", "mean"), raster.TemporalAggregate(raster.Clip(a, b > 40), None, "max"),
+              raster.Cumulative(a - b, "sum", "D"), raster.TemporalSum(b), raster.Resample(a, "3h", "nearest"), raster.Snap(a, b),
+              raster.Shift(a * 2, 3600 * 1000), raster.Group(a, a * 0.5), raster.TemporalAggregate(raster.Group(a, a * 0.5), "D", "median")]
+    calls = []
+    original = plan._whole_instead_of_tiles
+
+    def spy(*args):
+        calls.append(original(*args))
+        return calls[-1]
+    plan._whole_instead_of_tiles = spy
+    try:
+        with gmconfig.config.set({"geomodeling.plans": True}):
+            for store in stores:
+                for when in windows:
+                    request = dict(box, **when)
+                    for tile, whole in ((16, True), ([32, 12], True), ([20, 16], True), ([64, 48], False)):  # (ragged edge tiles still cover; one tile: nothing to elide)
+                        del calls[:]
+                        view = raster.RasterTiler(store, tile)
+                        assert_result_equal(view.get_data(**request), walk(view, request), 0, "%s tiled by %s, %s" % (type(store).__name__, tile, when))
+                        taken = bool(calls and calls[-1])
+                        assert taken == whole, (type(store).__name__, tile, taken)
+            # a stencil in the view, and tiles of one cell: tile by tile
+            for view in (raster.RasterTiler(raster.TemporalAggregate(raster.MovingMax(a, 3), "D", "max"), 16), ):
+                del calls[:]
+                assert_result_equal(view.get_data(**dict(box, **windows[0])), walk(view, dict(box, **windows[0])), 0, "stencil below")
+                assert not any(calls)
+            # cells of 0.3 units: the sources do not lie on the request's grid (and the reference's int() truncation of the tile
+            # sizes leaves cells uncovered there)
+            coarse = dict(mode="vals", bbox=(0.0, 0.0, 19.2, 14.4), width=64, height=48, projection="EPSG:28992", **windows[0])
+            view = raster.RasterTiler(raster.TemporalAggregate(a, None, "mean"), 4.8)
+            del calls[:]
+            assert_result_equal(view.get_data(**coarse), walk(view, coarse), 0, "cells of 0.3")
+            assert not any(calls)
+            tiny = dict(mode="vals", bbox=(0.0, 0.0, 4.0, 1.0), width=4, height=1, projection="EPSG:28992", **windows[0])
+            view = raster.RasterTiler(raster.TemporalAggregate(a, None, "mean"), 1)
+            del calls[:]
+            assert_result_equal(view.get_data(**tiny), walk(view, tiny), 0, "tiles of one cell")
+            assert not any(calls)
+    finally:
+        plan._whole_instead_of_tiles = original
