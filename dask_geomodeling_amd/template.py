@@ -229,6 +229,15 @@ def _one_level(block, request, graph, key=None):
     return name
 
 
+def mosaic_of_whole(process_kwargs, response):
+    """Graph task: the store's answer for the whole box as RasterTiler.process hands its mosaic on (plan._as_mosaic)."""
+    from .plan import _as_mosaic
+    mosaic = _as_mosaic(response, process_kwargs)
+    if mosaic is False:
+        raise RuntimeError("the store answered the whole box with %r" % (getattr(response.get("values"), "shape", None),))
+    return mosaic
+
+
 def _tiler(tiler, request, graph):
     """RasterTiler: the tiles through the templates of its store, batched and assembled in place."""
     from .fuse import BatchedTask, FusedTask, TiledAssembly
@@ -237,6 +246,13 @@ def _tiler(tiler, request, graph):
     if kwargs is None or len(pairs) < 2:
         return _one_level(tiler, request, graph)  # non-tiled / point requests
     store = tiler.store
+    from .plan import _whole_instead_of_tiles
+    if _whole_instead_of_tiles(store, request, kwargs, pairs[1:]):
+        # a pixel-local view whose tiles cover the box exactly: the store's graph for the whole box, handed on as the mosaic
+        # (plan.py: the same cells as the tiles pasted next to each other)
+        name = _key_of(tiler, request)
+        graph[name] = (mosaic_of_whole, kwargs, _graph_of(store, dict(request), graph))
+        return name
     templates = []
     if getattr(type(store).process, "gm_op", None) is not None:
         for _, tile_request in pairs[1:]:
