@@ -22,7 +22,11 @@ def same(a, b):
     if "values" not in b:
         return a == b
     x, y = np.asarray(a["values"]), np.asarray(b["values"])
-    return x.shape == y.shape and x.dtype == y.dtype and np.array_equal(x, y, equal_nan=True) and a.get("no_data_value") == b.get("no_data_value")
+    if not (x.shape == y.shape and x.dtype == y.dtype and np.array_equal(x, y, equal_nan=True)):
+        return False
+    if x.dtype.kind == "f" and not np.array_equal(np.signbit(x), np.signbit(y)):
+        return False  # (the sign of a zero counts)
+    return a.get("no_data_value") == b.get("no_data_value")
 
 
 def answer(block, request, how):
