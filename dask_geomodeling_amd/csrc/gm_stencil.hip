@@ -422,6 +422,18 @@ __global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* 
 // ---------------------------------------------------------------------------------
 // MovingMax
 // ---------------------------------------------------------------------------------
+// The sign of a zero maximum.  The hardware maximum of +0.0 and -0.0 is +0.0; scipy.ndimage.maximum_filter keeps whichever
+// zero its scan order leaves standing (moving_max_zero_sign_kernel below restates the two orders).  A raster holding -0.0 at
+// all is rare, so the kernels only NOTE one while they stage their windows (a compare per staged cell): `*seen = ticket`,
+// a slot of a small per-device ring, and the fix-up pass that follows every float launch returns at once unless its
+// launch's ticket is there.
+template <typename T>
+__device__ __forceinline__ bool is_negative_zero(T v) {
+  if constexpr (std::is_same<T, float>::value) return __float_as_uint(v) == 0x80000000u;
+  else if constexpr (std::is_same<T, double>::value) return (unsigned long long)__double_as_longlong(v) == 0x8000000000000000ull;
+  else return false;
+}
+
 constexpr int MM_TILE_H = 16, MM_TILE_W = 64;
 // NaN.  scipy.ndimage.maximum_filter starts from the first cell of the footprint (top row, leftmost) and
 // takes every later cell that compares greater: a NaN in that first cell stays (nothing compares greater than
@@ -432,7 +444,7 @@ constexpr int MM_TILE_H = 16, MM_TILE_W = 64;
 // a wave's window loads are in flight together instead of one load-wait-store round trip per row)
 template <typename T, int RMAX>
 __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                         int size, int has_ndv, T ndv, T minimum) {
+                                                         int size, int has_ndv, T ndv, T minimum, unsigned* seen, unsigned ticket) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* const tile = (T*)smem;
   const int radius = size / 2;
@@ -445,6 +457,7 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int ROWS_PER_WAVE = (MM_TILE_H + 2 * RMAX + 3) / 4, CHUNKS = (MM_TILE_W + 2 * RMAX + 63) / 64;
   T staged[ROWS_PER_WAVE][CHUNKS];
+  bool negative_zero = false;
 #pragma unroll
   for (int i = 0; i < ROWS_PER_WAVE; ++i) {
     const int y = wave + 4 * i;
@@ -461,9 +474,11 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
     for (int j = 0; j < CHUNKS; ++j) {
       const int x = lane + 64 * j;
       const T v = staged[i][j];
+      negative_zero |= is_negative_zero(v);
       if (y < win_h && x < win_w) tile[y * pitch + x] = (has_ndv && v == ndv) ? minimum : v;
     }
   }
+  if (negative_zero) *seen = ticket;
   __syncthreads();
   // A lane owns 4 CONSECUTIVE output rows of one column.  The circle is scanned column by column
   // (wave-uniform dx): the vertical runs of the 4 outputs overlap in all but 3 rows at either end,
@@ -524,13 +539,18 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
 constexpr int M3_H = 16, M3_W = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                          int pitch, int opitch, int has_ndv, T ndv, T minimum) {
+                                                          int pitch, int opitch, int has_ndv, T ndv, T minimum, unsigned* seen, unsigned ticket) {
   __shared__ T tile[(M3_H + 2) * (M3_W + 2)];
   const int c0 = blockIdx.x * M3_W, r0 = blockIdx.y * M3_H, b = blockIdx.z;
   const int ow = w - 2, oh = h - 2;
   const T* plane = in + (size_t)b * h * w;
   constexpr int PITCH = M3_W + 2;
-  stage_window<T, M3_H + 2, 2>(tile, plane, r0, c0, h, w, pitch, [&](T v) { return (has_ndv && v == ndv) ? minimum : v; });  // spatial.py:199-203
+  bool negative_zero = false;
+  stage_window<T, M3_H + 2, 2>(tile, plane, r0, c0, h, w, pitch, [&](T v) {
+    negative_zero |= is_negative_zero(v);
+    return (has_ndv && v == ndv) ? minimum : v;  // spatial.py:199-203
+  });
+  if (negative_zero) *seen = ticket;
   __syncthreads();
   const int c = c0 + threadIdx.x;
   if (c >= ow) return;
@@ -578,13 +598,18 @@ __host__ __device__ constexpr int disk_half_width(int dy) {
 __host__ __device__ constexpr int disk_tile_rows(int R) { return R >= 7 ? 32 : 16; }
 template <typename T, int R>
 __global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                              int pitch, int opitch, int has_ndv, T ndv, T minimum) {
+                                                              int pitch, int opitch, int has_ndv, T ndv, T minimum, unsigned* seen, unsigned ticket) {
   constexpr int TH = disk_tile_rows(R), TW = 256, PITCH = TW + 2 * R, ROWS = TH + 2 * R;
   __shared__ T tile[ROWS * PITCH];
   const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH, b = blockIdx.z;
   const int ow = w - 2 * R, oh = h - 2 * R;
   const T* plane = in + (size_t)b * h * w;
-  stage_window<T, ROWS, 2 * R>(tile, plane, r0, c0, h, w, pitch, [&](T v) { return (has_ndv && v == ndv) ? minimum : v; });  // spatial.py:199-203
+  bool negative_zero = false;
+  stage_window<T, ROWS, 2 * R>(tile, plane, r0, c0, h, w, pitch, [&](T v) {
+    negative_zero |= is_negative_zero(v);
+    return (has_ndv && v == ndv) ? minimum : v;  // spatial.py:199-203
+  });
+  if (negative_zero) *seen = ticket;
   __syncthreads();
   const int c = c0 + threadIdx.x;
   if (c >= ow) return;
@@ -625,6 +650,58 @@ __global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restric
         __builtin_nontemporal_store(best, out + (size_t)b * oh * ow + (size_t)(r0 + r) * opitch + c);
       }
     }
+  }
+}
+
+// The zero-sign pass (float tiles only; returns at once unless the launch before it noted a -0.0 in its input).
+// For every output that is a zero: the zero SciPy's scan leaves standing, restated from measurements against
+// scipy.ndimage.maximum_filter 1.15 (tools/ulp_measure.py has no say here: the value is 0 either way, only its sign moves):
+//   * a footprint with holes (sizes 5 and up: the disk) is scanned in raster order, a later cell replaces the running
+//     maximum only when it compares GREATER -- the FIRST zero of the footprint stays;
+//   * the all-true 3 x 3 footprint takes SciPy's separable route, maximum_filter1d down the columns and then along the
+//     rows, whose running-maximum queue takes a later cell that compares greater OR EQUAL -- the bottom-most zero of the
+//     right-most column that has one.
+// No data is lowered to the dtype's minimum first, as in the kernels above; an output with no zero in its footprint
+// (a no-data centre restored to a no-data value of 0) keeps what it has.
+template <typename T>
+__global__ __launch_bounds__(256) void moving_max_zero_sign_kernel(const T* __restrict__ in, int h, int w, int pitch,
+                                                                   T* __restrict__ out, int opitch, int bands, int size,
+                                                                   int has_ndv, T ndv, const unsigned* __restrict__ seen,
+                                                                   unsigned ticket) {
+  if (*seen != ticket) return;
+  // (a few workgroups that walk the tiles: a grid of one workgroup per tile costs its dispatch -- 50 us for an 8192^2
+  //  raster -- on every launch, also on the ones that return here)
+  const int radius = size / 2, oh = h - 2 * radius, ow = w - 2 * radius, s2 = size * size;
+  const int tiles_x = (ow + 63) / 64, tiles_y = (oh + 3) / 4;
+  const long long tiles = (long long)tiles_x * tiles_y * bands;
+  for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int b = (int)(t / ((long long)tiles_x * tiles_y)), rest = (int)(t - (long long)b * tiles_x * tiles_y);
+    const int c = (rest % tiles_x) * 64 + (threadIdx.x & 63), r = (rest / tiles_x) * 4 + (threadIdx.x >> 6);
+    if (c >= ow || r >= oh) continue;
+    T* const cell = out + (size_t)b * oh * ow + (size_t)r * opitch + c;
+    if (!(*cell == (T)0)) continue;
+    const T* const window = in + (size_t)b * h * w + (size_t)r * pitch + c;  // its top-left cell
+    bool found = false;
+    if (size == 3) {
+      for (int dx = 2; dx >= 0 && !found; --dx)
+        for (int dy = 2; dy >= 0 && !found; --dy) {
+          const T v = window[(size_t)dy * pitch + dx];
+          if (v == (T)0 && !(has_ndv && v == ndv)) {
+            *cell = v;
+            found = true;
+          }
+        }
+      continue;
+    }
+    for (int dy = 0; dy < size && !found; ++dy)
+      for (int dx = 0; dx < size && !found; ++dx) {
+        if (4 * ((dx - radius) * (dx - radius) + (dy - radius) * (dy - radius)) >= s2) continue;
+        const T v = window[(size_t)dy * pitch + dx];
+        if (v == (T)0 && !(has_ndv && v == ndv)) {
+          *cell = v;
+          found = true;
+        }
+      }
   }
 }
 
@@ -1396,6 +1473,29 @@ int cached_weights(const double* host, int count, const double** dev_out) {
   return GM_OK;
 }
 
+// The ring of "a -0.0 was staged" slots of the MovingMax kernels: launch n of a device owns slot n % 64 and writes n
+// there, so a slot never needs clearing (its last owner left n - 64 at most); 64 launches of one stream cannot overlap.
+constexpr int kZeroSignSlots = 64;
+std::mutex g_zero_sign_mu;
+std::map<int, std::pair<unsigned*, unsigned>> g_zero_sign;  // device -> (ring, launches so far)
+int zero_sign_slot(hipStream_t s, unsigned** slot, unsigned* ticket) {
+  int dev = 0;
+  GM_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_zero_sign_mu);
+  auto& ring = g_zero_sign[dev];
+  if (!ring.first) {
+    void* buf = nullptr;
+    int rc = gm_malloc(&buf, sizeof(unsigned) * kZeroSignSlots);
+    if (rc) return rc;
+    GM_HIP(hipMemsetAsync(buf, 0, sizeof(unsigned) * kZeroSignSlots, s));
+    ring.first = (unsigned*)buf;
+  }
+  *ticket = ++ring.second;
+  if (*ticket == 0) *ticket = ++ring.second;  // (0 is what an untouched slot holds)
+  *slot = ring.first + *ticket % kZeroSignSlots;
+  return GM_OK;
+}
+
 constexpr size_t kGaussLdsDefault = 64 * 1024, kGaussLdsMax = 160 * 1024;
 
 template <typename T, bool ALONG_X, int COLS>
@@ -1586,9 +1686,27 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
     return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: the window of a size-%d footprint does not fit 64 KiB of LDS for this dtype", size);
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
+  unsigned* seen = nullptr;
+  unsigned ticket = 0;
+  const bool floats = dtype == GM_F32 || dtype == GM_F64;
+  if (floats) {
+    int rc = zero_sign_slot(s, &seen, &ticket);
+    if (rc) return rc;
+  }
+  // after a float launch: the sign of the zero maxima, should the launch have staged a -0.0 (see the kernel)
+  auto zero_signs = [&]() {
+    const long long tiles = (long long)((ow + 63) / 64) * ((oh + 3) / 4) * bands;
+    dim3 gridz((unsigned)std::min<long long>(tiles, 2048));
+    if (dtype == GM_F32)
+      hipLaunchKernelGGL(moving_max_zero_sign_kernel<float>, gridz, dim3(256), 0, s, (const float*)in, h, w, in_pitch, (float*)out,
+                         out_pitch_or(ow), bands, size, has_ndv, from_bits<float>(ndv_bits), seen, ticket);
+    else if (dtype == GM_F64)
+      hipLaunchKernelGGL(moving_max_zero_sign_kernel<double>, gridz, dim3(256), 0, s, (const double*)in, h, w, in_pitch,
+                         (double*)out, out_pitch_or(ow), bands, size, has_ndv, from_bits<double>(ndv_bits), seen, ticket);
+  };
   if (size == 3 && gm::dtype_size(dtype) <= 4 && (oh + M3_H - 1) / M3_H <= 65535) {
     dim3 grid3((unsigned)((ow + M3_W - 1) / M3_W), (unsigned)((oh + M3_H - 1) / M3_H), (unsigned)bands);
-#define GM_M3(T) hipLaunchKernelGGL(moving_max3_kernel<T>, grid3, dim3(256), 0, s, (const T*)in, (T*)out, h, w, in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>())
+#define GM_M3(T) hipLaunchKernelGGL(moving_max3_kernel<T>, grid3, dim3(256), 0, s, (const T*)in, (T*)out, h, w, in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket)
     switch (dtype) {
       case GM_U8: GM_M3(unsigned char); break;
       case GM_I8: GM_M3(signed char); break;
@@ -1600,6 +1718,7 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
       default: return gm::fail(GM_ERR_INVALID, "gm_moving_max: dtype %d", dtype);
     }
 #undef GM_M3
+    zero_signs();
     GM_HIP(hipGetLastError());
     return GM_OK;
   }
@@ -1610,22 +1729,22 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
   do {                                                                                                            \
     if (size == 5)                                                                                                \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 2>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket);                        \
     else if (size == 7)                                                                                           \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 3>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket);                        \
     else if (size == 9)                                                                                           \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 4>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket);                        \
     else if (size == 11)                                                                                          \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 5>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket);                        \
     else if (size == 13)                                                                                          \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 6>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket);                        \
     else                                                                                                          \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 7>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket);                        \
   } while (0)
     switch (dtype) {
       case GM_U8: GM_MD(unsigned char); break;
@@ -1638,6 +1757,7 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
       default: return gm::fail(GM_ERR_INVALID, "gm_moving_max: dtype %d", dtype);
     }
 #undef GM_MD
+    zero_signs();
     GM_HIP(hipGetLastError());
     return GM_OK;
   }
@@ -1648,7 +1768,7 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
 #define GM_MM_R(T, RMAX_)                                                                                      \
   hipLaunchKernelGGL((moving_max_kernel<T, RMAX_>), grid, dim3(256),                                           \
                      (size_t)(MM_TILE_H + 2 * radius) * (MM_TILE_W + 2 * radius) * sizeof(T), s, (const T*)in,   \
-                     (T*)out, h, w, size, has_ndv, from_bits<T>(ndv_bits), lowest<T>())
+                     (T*)out, h, w, size, has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket)
 #define GM_MM(T)                           \
   do {                                     \
     if (radius <= 3) GM_MM_R(T, 3);        \
@@ -1671,6 +1791,7 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
   }
 #undef GM_MM
 #undef GM_MM_R
+  zero_signs();
   GM_HIP(hipGetLastError());
   return GM_OK;
 }

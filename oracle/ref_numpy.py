@@ -541,6 +541,23 @@ def movingmax_process(data, size=None):
                 else:
                     with np.errstate(invalid="ignore"):
                         np.copyto(filtered, cell, where=cell > filtered)
+    if footprint.all() and array.dtype.kind == "f":
+        # An all-true footprint (size 3) sends SciPy down its separable route: maximum_filter1d (ni_filters.c,
+        # NI_MinOrMaxFilter1D) down the columns (axis 1) and then along the rows (axis 2), whose running-maximum queue takes a later
+        # cell that compares greater OR EQUAL.  Values are the same; the SIGN of a zero maximum is that of the last zero
+        # met: the bottom-most zero of the right-most column that has one.  (NaN cells, for which that queue follows no
+        # rule one could restate -- see tests/test_oracle_golden.py -- are left out of it.)
+        work = np.where(np.isnan(array), minimum, array)
+        columns = work[:, 0:oy, :].copy()
+        for dy in range(1, footprint.shape[0]):
+            cell = work[:, dy:dy + oy, :]
+            np.copyto(columns, cell, where=cell >= columns)
+        last = columns[:, :, 0:ox].copy()
+        for dx in range(1, footprint.shape[1]):
+            cell = columns[:, :, dx:dx + ox]
+            np.copyto(last, cell, where=cell >= last)
+        zero = (filtered == 0) & (last == 0)
+        filtered[zero] = last[zero]
     centre = no_data_mask[:, radius:ny - radius, radius:nx - radius]
     filtered[(filtered == minimum) & centre] = data["no_data_value"]
     return {"values": filtered, "no_data_value": data["no_data_value"]}

@@ -255,10 +255,6 @@ def zero_sign_is_the_hosts(block):
     name = type(block).__name__
     if name == "Max" or (name == "TemporalAggregate" and block.args[2] in ("min", "max")):
         return True
-    if name == "MovingMax":
-        # (not the host's but the hardware's: a window whose maximum is zero and which holds zeros of both signs comes out
-        #  as +0.0 from v_max_f32 / v_max_f64, SciPy keeps the first zero in footprint order -- DESIGN.md section 9)
-        return True
     return any(zero_sign_is_the_hosts(a) for a in block.args)
 
 

@@ -835,6 +835,42 @@ def test_movingmax_nan_cells_like_scipy(gpu, size, dt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size", [3, 5, 7, 9, 15, 17, 21])
+@pytest.mark.parametrize("dt", ["f4", "f8"])
+def test_movingmax_sign_of_a_zero_maximum_like_scipy(gpu, size, dt):
+    """Windows whose maximum is zero and which hold zeros of BOTH signs: SciPy keeps the zero its scan leaves standing (the
+    first of the footprint in raster order for the disks; for the all-true 3 x 3, which it filters separably, the bottom-most
+    zero of the right-most column with one).  The hardware maximum says +0.0; the zero-sign pass behind every float launch
+    restores SciPy's.  All three kernels, compact tiles and windows of a resident raster, with and without no data (also a
+    no-data value of 0: every zero is no data then), and tiles without any -0.0 (the pass returns at once)."""
+    from dask_geomodeling_amd import raster
+    from dask_geomodeling_amd.hip.array import DeviceArray
+    rng = np.random.default_rng(size)
+    kind = np.dtype(dt).type
+    for trial, ndv in enumerate((None, kind(-9999), kind(0), None)):
+        v = rng.choice(np.array([0.0, -0.0, -1.0, -2.5], dtype=dt), size=(2, 70, 300), p=[.15, .15, .4, .3])
+        if trial == 3:
+            v[v == 0] = 0.0  # zeros of one sign only
+            assert not np.signbit(v[v == 0]).any()
+        if ndv is not None and ndv != 0:
+            v[rng.random(v.shape) < 0.2] = ndv
+        data = {"values": v, "no_data_value": ndv}
+        want = O.movingmax_process(data, size)["values"]
+        got = np.asarray(raster.MovingMax.process(data, size)["values"])
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+        assert np.array_equal(np.signbit(got), np.signbit(want)), (size, dt, ndv)
+        if trial == 0:
+            zeros = want == 0
+            assert np.signbit(want[zeros]).any() and not np.signbit(want[zeros]).all()
+    # a window of a wider resident raster (rows a pitch apart), one band
+    wide = rng.choice(np.array([0.0, -0.0, -1.0], dtype=dt), size=(1, 90, 400), p=[.2, .2, .6])
+    resident = DeviceArray.from_numpy(wide)
+    got = np.asarray(raster.MovingMax.process({"values": resident.window(7, 13, 64, 290), "no_data_value": None}, size)["values"])
+    want = O.movingmax_process({"values": wide[:, 7:71, 13:303], "no_data_value": None}, size)["values"]
+    assert np.array_equal(got, want) and np.array_equal(np.signbit(got), np.signbit(want))
+
+
+@pytest.mark.gpu
 def test_stencil_blocks_end_to_end(gpu):
     """The Blocks through get_data on a MemorySource: request enlargement + kernel + crop equal the
     oracle applied to the enlarged window (edge cells see the source's no-data outside its extent)."""
