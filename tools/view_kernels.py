@@ -1,0 +1,64 @@
+"""Which kernels one request of a view launches, and for how long (GPU box).
+
+  rocprofv3 --kernel-trace -d gpurun_out/vk -o vk -- python3 tools/view_kernels.py place      # run the view 12 times
+  python3 tools/view_kernels.py --read gpurun_out/vk 12                                       # per-request kernel table
+
+Views: the series probes of tools/e2e_views.py that sit well above their kernels' time (series seams)."""
+import csv, glob, sys
+from collections import OrderedDict
+
+RUNS = 12
+
+
+def read(folder, runs):
+    for f in glob.glob(folder + "/**/*kernel_trace.csv", recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        per = OrderedDict()
+        for r in rows:
+            name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0][:90]
+            e = per.setdefault(name, [0, 0])
+            e[0] += 1
+            e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        total = 0
+        for name, (n, ns) in per.items():
+            print("%6.2f launches  %9.1f us per request  %s" % (n / runs, ns / 1e3 / runs, name))
+            total += ns
+        print("kernels per request (uploads of the setup included in the first lines): %.1f us" % (total / 1e3 / runs))
+
+
+def main():
+    if sys.argv[1] == "--read":
+        return read(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else RUNS)
+    sys.path.insert(0, "/root/repo")
+    from datetime import datetime, timedelta
+    import numpy as np
+    from dask_geomodeling_amd import raster
+    from dask_geomodeling_amd.hip import runtime
+    from dask_geomodeling_amd.raster.sources import generate_window
+    runtime.set_device(0)
+    F32MAX = float(np.finfo("f4").max)
+    frames, side = 8, 4096
+    dt = generate_window((frames * side, side), "f4", 7004, 0.0, 100.0, F32MAX, (97, 89), 0, 0, frames * side, side).reshape((frames, side, side))
+    T = raster.MemorySource(dt, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(side)), time_first=datetime(2020, 1, 1),
+                            time_delta=timedelta(hours=6))
+    tbox = dict(mode="vals", bbox=(0.0, 0.0, float(side), float(side)), width=side, height=side, projection="EPSG:28992",
+                start=datetime(2020, 1, 1), stop=datetime(2020, 1, 3))
+    views = {
+        "place": raster.Place(T, "EPSG:28992", (2048.0, 2048.0), [(2100.0, 2000.0)]),
+        "group": raster.TemporalAggregate(raster.Group(T, T * 0.5), "D", "mean"),
+        "fillnodata": raster.FillNoData(T, T * 0.5),
+        "clip": raster.Clip(raster.Cumulative(T), T > 50),
+    }
+    view = views[sys.argv[1]]
+    import time
+    for i in range(RUNS):
+        if i == RUNS - 5:
+            runtime.sync()
+            t0 = time.perf_counter()
+        view.get_data(**tbox)
+    runtime.sync()
+    print("%s: %.1f us per request (last 5 of %d)" % (sys.argv[1], (time.perf_counter() - t0) / 5 * 1e6, RUNS))
+
+
+if __name__ == "__main__":
+    main()
