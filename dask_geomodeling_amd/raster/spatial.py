@@ -348,31 +348,46 @@ def _shifted_copy(source, fill, out_shape, di, dj):
     """full(out_shape, fill) with ``source`` pasted so that source cell (j, i) lands on (j + dj, i + di); cells that
     fall outside are dropped (the two 'place' branches of spatial.py:700-718 before their data test)."""
     from ..hip import runtime
-    out = _filled(out_shape, fill, source.dtype)
+    from ..hip.array import DeviceArray
+    from ..hip.dtypes import code_of
+    from .resample import _lib, _params
     bands, src_h, src_w = source.shape
     _, dst_h, dst_w = out_shape
-    i0, i1 = max(0, -di), min(src_w, dst_w - di)  # source columns that land inside
-    j0, j1 = max(0, -dj), min(src_h, dst_h - dj)
-    if i1 <= i0 or j1 <= j0:
-        return out
-    item = source.dtype.itemsize
-    L = runtime.lib()
-    L.gm_copy_3d.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
-                             ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t]
-    # the window of every band in one copy (planes of src_h / dst_h rows)
-    src_ptr = source.ptr + (j0 * src_w + i0) * item
-    dst_ptr = out.ptr + ((j0 + dj) * dst_w + i0 + di) * item
-    runtime.check(L.gm_copy_3d(ctypes.c_void_p(dst_ptr), dst_w * item, dst_h, ctypes.c_void_p(src_ptr), src_w * item, src_h,
-                               (i1 - i0) * item, j1 - j0, bands), "gm_copy_3d")
+    if bands == 0 or dst_h == 0 or dst_w == 0 or di <= -src_w or di >= dst_w or dj <= -src_h or dj >= dst_h:
+        return _filled(out_shape, fill, source.dtype)
+    # ONE pass that writes every cell of the result once -- the source cell (row - dj, column - di) or the fill value: the
+    # nearest-neighbour kernel in its affine mode (index = floor(k * 1 - shift + 0.5), exact for whole shifts).  A fill
+    # of the result followed by a rectangular copy of the runtime wrote the landing zone twice and copied at 2.9 TB/s:
+    # 81 + 366 us for 8 frames of 4096^2 float32, against 180 us
+    out = DeviceArray.empty(out_shape, source.dtype)
+    runtime.check(_lib().gm_resample_nearest(
+        ctypes.c_void_p(source.ptr), code_of(source.dtype), bands, src_h, src_w, ctypes.c_void_p(out.ptr), dst_h, dst_w, 1,
+        _params((1.0, float(-dj), 0, 0)), _params((1.0, float(-di), 0, 0)), 0.0,
+        runtime.scalar_bits(fill, source.dtype), 0), "gm_resample_nearest")
     return out
 
 
-def _has_data(values, no_data_value):
-    """get_index(values, no_data_value).any() (utils.py:61-64) without leaving the device."""
+def _any_data(values, no_data_value):
     from . import devops
     # (Mask is the Block whose cell test is get_index -- isclose for float tiles; IsData compares exactly)
     marked = devops.mask_process({"values": values, "no_data_value": no_data_value}, 1)["values"]  # 1 = data, 0 = not
     return not devops._all_false(marked)
+
+
+def _has_data(values, no_data_value, landed=None):
+    """get_index(values, no_data_value).any() (utils.py:61-64) without leaving the device.  ``landed``: (row0, row1, column0,
+    column1) of the cells that can hold data at all (the landing zone of a placed copy)."""
+    bands, h, w = values.shape
+    if landed is not None and bands * h * w > (1 << 22):
+        # a few rows from the middle of the landing zone of the first band answer "is there any data" for nearly every
+        # raster (two small launches); the pass over all of it -- a mask and a reduction, 250 us for 8 frames of 4096^2 --
+        # is for the copies whose sample holds none
+        r0, r1, c0, c1 = landed
+        middle = (r0 + r1) // 2
+        rows = min(16, r1 - middle)
+        if rows > 0 and c1 > c0 and _any_data(values.band_slice(0, 1).window(middle, c0, rows, c1 - c0), no_data_value):
+            return True
+    return _any_data(values, no_data_value)
 
 
 class Place(BaseSingle):
@@ -527,8 +542,9 @@ class Place(BaseSingle):
                 if di <= -src_w or di >= dst_w or dj <= -src_h or dj >= dst_h:
                     continue  # shifted completely outside
                 placed = _shifted_copy(source, out_no_data_value, out_shape, di, dj)
+                landed = (max(0, dj), min(dst_h, src_h + dj), max(0, di), min(dst_w, src_w + di))
                 # (a copy none of whose data cells lands inside is left out -- it would count in argmin / argmax)
-                if _has_data(placed, out_no_data_value):
+                if _has_data(placed, out_no_data_value, landed):
                     stack.append({"values": placed, "no_data_value": out_no_data_value})
         if len(stack) == 0:
             return {"values": _filled(out_shape, out_no_data_value, out_dtype), "no_data_value": out_no_data_value}

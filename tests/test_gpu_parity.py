@@ -871,6 +871,43 @@ def test_movingmax_sign_of_a_zero_maximum_like_scipy(gpu, size, dt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["u1", "i2", "f4", "i8", "f8", "?"])
+def test_all_equal_heads_tails_and_where_the_odd_cell_sits(gpu, dt):
+    """gm_all_equal (np.all(tile == value): Clip's early-out misc.py:108, Place's data test) reads 16 bytes per lane: tiles
+    that start off a 16-byte boundary, lengths around the group size, the one differing cell in the head, the body, the tail;
+    a tile of several sweeps of the grid (the early exit)."""
+    from dask_geomodeling_amd.hip.array import DeviceArray
+    from dask_geomodeling_amd.raster import devops
+    dtype = np.dtype(dt)
+    same = True if dt == "?" else 7
+    base = np.full(5000, same, dtype=dtype)
+
+    def view(host, first, count):
+        dev = DeviceArray.from_numpy(host.reshape(1, 1, -1))
+        return DeviceArray(dev.ptr + first * dtype.itemsize, (1, 1, count), dtype, dev.device, owner=dev)
+
+    for first in (0, 1, 3, 5, 15, 16, 17):
+        for count in (0, 1, 2, 15, 16, 17, 31, 33, 100, 4097):
+            host = base.copy()
+            assert devops.all_equal(view(host, first, count), same) is True, (first, count)
+            for at in sorted({0, count // 2, count - 1} - {-1}) if count else ():
+                host = base.copy()
+                host[first + at] = 0
+                assert devops.all_equal(view(host, first, count), same) is False, (first, count, at)
+                host = base.copy()
+                host[first + count] = 0  # (the cell after the tile is none of its business)
+                if first:
+                    host[first - 1] = 0
+                assert devops.all_equal(view(host, first, count), same) is True, (first, count, "neighbours")
+    big = np.full((3, 1500, 2001), same, dtype=dtype)
+    assert devops.all_equal(big, same) is True
+    for where in ((0, 0, 0), (1, 700, 1000), (2, 1499, 2000)):
+        odd = big.copy()
+        odd[where] = 0
+        assert devops.all_equal(odd, same) is False, where
+
+
+@pytest.mark.gpu
 def test_stencil_blocks_end_to_end(gpu):
     """The Blocks through get_data on a MemorySource: request enlargement + kernel + crop equal the
     oracle applied to the enlarged window (edge cells see the source's no-data outside its extent)."""

@@ -1,6 +1,6 @@
 """Which kernels one request of a view launches, and for how long (GPU box).
 
-  rocprofv3 --kernel-trace -d gpurun_out/vk -o vk -- python3 tools/view_kernels.py place      # run the view 12 times
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/vk -- python3 tools/view_kernels.py place      # run the view 12 times
   python3 tools/view_kernels.py --read gpurun_out/vk 12                                       # per-request kernel table
 
 Views: the series probes of tools/e2e_views.py that sit well above their kernels' time (series seams)."""
@@ -32,7 +32,7 @@ def main():
     sys.path.insert(0, "/root/repo")
     from datetime import datetime, timedelta
     import numpy as np
-    from dask_geomodeling_amd import raster
+    from dask_geomodeling_amd import config as gmconfig, raster
     from dask_geomodeling_amd.hip import runtime
     from dask_geomodeling_amd.raster.sources import generate_window
     runtime.set_device(0)
@@ -50,6 +50,7 @@ def main():
         "clip": raster.Clip(raster.Cumulative(T), T > 50),
     }
     view = views[sys.argv[1]]
+    gmconfig.config.set({"geomodeling.materialize": False}).__enter__()  # (results stay on the device, like tools/e2e_views.py)
     import time
     for i in range(RUNS):
         if i == RUNS - 5:
