@@ -1,4 +1,4 @@
-"""Many more fuzz seeds than the test suite runs (GPU box): python tests/fuzz_more.py [n].  Lives under tests/
+"""Many more fuzz seeds than the test suite runs (GPU box): python tests/fuzz_more.py [n] [first seed].  Lives under tests/
 because it checks against the oracle."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,8 +11,9 @@ from dask_geomodeling_amd.hip import runtime
 runtime.set_device(0)
 bad = skipped = 0
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+BASE = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000  # first seed
 for seed in range(N):
-    rng = np.random.default_rng(50_000 + seed)
+    rng = np.random.default_rng(BASE + seed)
     memory = seed % 3 == 0
     view = random_view(rng, "x%d" % seed, depth=int(rng.integers(2, 6)), memory=memory)
     try:

@@ -7,9 +7,9 @@ from dask_geomodeling_amd.hip import runtime
 from dask_geomodeling_amd.raster import stencil
 from oracle import ref_numpy as O
 runtime.set_device(0)
-rng = np.random.default_rng(2026)
-bad = 0
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)  # [n] [seed]
+bad = 0
 for it in range(N):
     dt = ["u1", "i1", "i2", "u2", "i4", "f4", "f8"][int(rng.integers(7))]
     bands = int(rng.integers(1, 4))
@@ -21,6 +21,12 @@ for it in range(N):
         v = (rng.random((bands, h, w)) * 20 - 5).astype(dt); ndv = np.dtype(dt).type(-9999.0)
     else:
         v = rng.integers(0, 9, size=(bands, h, w)).astype(dt); ndv = np.dtype(dt).type(7)
+    if np.dtype(dt).kind == "f" and it % 4 == 1:
+        # zeros of both signs under a negative neighbourhood: the sign of a zero maximum is SciPy's scan's
+        v = -np.abs(v) - 1
+        pick = rng.random(v.shape)
+        v[pick < 0.1] = -0.0
+        v[pick > 0.9] = 0.0
     v[rng.random(v.shape) < 0.2] = ndv
     if np.dtype(dt).kind == "f" and it % 5 == 0:
         v[rng.random(v.shape) < 0.02] = np.nan
@@ -28,6 +34,7 @@ for it in range(N):
         want = O.movingmax_process({"values": v, "no_data_value": ndv}, size)["values"]
         got = stencil.moving_max(v, ndv, size).to_numpy()
         assert np.array_equal(got, want, equal_nan=True), "movingmax"
+        assert got.dtype.kind != "f" or np.array_equal(np.signbit(got), np.signbit(want)), "movingmax: the sign of a zero"
         vals = [int(x) for x in rng.integers(0, 9, size=int(rng.integers(1, 5)))]
         want = O.dilate_process({"values": v, "no_data_value": ndv}, vals)["values"]
         got = stencil.dilate(v, vals).to_numpy()

@@ -49,6 +49,16 @@ def main():
         "fillnodata": raster.FillNoData(T, T * 0.5),
         "clip": raster.Clip(raster.Cumulative(T), T > 50),
     }
+    if sys.argv[1] in ("smooth40", "classify200", "maskdilate", "hillclass"):
+        big = 16384
+        A = raster.MemorySource(generate_window((big, big), "f4", 7001, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big),
+                                np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
+        C = raster.MemorySource(generate_window((big, big), "u1", 7003, 0.0, 12.0, 255, (97, 89), 0, 0, big, big),
+                                np.uint8(255), "EPSG:28992", 1.0, (0.0, float(big)))
+        views = {"smooth40": raster.Smooth(A, 40.0), "classify200": raster.Classify(A, [float(x) / 2 for x in range(200)]),
+                 "maskdilate": raster.Mask(raster.Dilate(C, [3, 5]), 1),
+                 "hillclass": raster.Classify(raster.HillShade(A), [20, 50, 80, 110, 140, 170, 200, 230])}
+        tbox = dict(mode="vals", bbox=(4160.0, 4160.0, 8256.0, 8256.0), width=side, height=side, projection="EPSG:28992")
     view = views[sys.argv[1]]
     gmconfig.config.set({"geomodeling.materialize": False}).__enter__()  # (results stay on the device, like tools/e2e_views.py)
     import time
