@@ -25,6 +25,9 @@ def _lib():
         L.gm_classify2.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_uint64, c.c_void_p, c.c_int, c.c_int,
                                    c.c_int, c.c_void_p, c.c_int, c.c_uint64, c.c_size_t]
         L.gm_classify2.restype = c.c_int
+        L.gm_classify2_window.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_uint64, c.c_void_p, c.c_int, c.c_int,
+                                          c.c_int, c.c_void_p, c.c_int, c.c_uint64, c.c_int, c.c_int, c.c_int]
+        L.gm_classify2_window.restype = c.c_int
         L.gm_reclassify.argtypes = [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_uint64,
                                     c.c_void_p, c.c_int, c.c_size_t]
         L.gm_reclassify.restype = c.c_int
@@ -126,7 +129,12 @@ def classify_process(data, bins, right):
             hit = None
         if hit is not None:
             return hit
-    values = as_device(data["values"])
+    values = data["values"]
+    # (a window of a resident raster is read where it lies by the kernel of float32 tiles with many edges; one band)
+    windowed = (isinstance(values, DeviceArray) and values.pitch is not None and values.band_pitch is None
+                and values.dtype == np.dtype("f4") and len(values.shape) == 3 and values.shape[0] == 1)
+    if not windowed:
+        values = as_device(values)
     out_dtype = utils.get_uint_dtype(len(bins) + 2)
     fill = utils.get_dtype_max(out_dtype)
     edges = np.asarray(bins)
@@ -140,6 +148,17 @@ def classify_process(data, bins, right):
     if values.dtype == np.dtype("bool") and data["no_data_value"] is not None:
         eff = P.effective_ndv(values.dtype, data["no_data_value"])
     out = DeviceArray.empty(values.shape, out_dtype)
+    if windowed:
+        rc = _lib().gm_classify2_window(
+            ctypes.c_void_p(values.ptr), code_of(values.dtype), 1 if eff is not None else 0,
+            runtime.scalar_bits(eff if eff is not None else 0, values.dtype),
+            payload.ctypes.data_as(ctypes.c_void_p), int(payload.size), are_int, 1 if right else 0,
+            ctypes.c_void_p(out.ptr), code_of(out_dtype), int(fill), values.shape[1], values.shape[2], values.pitch)
+        if rc == 0:
+            return {"values": out, "no_data_value": fill}
+        if rc != 9002:  # GM_ERR_UNSUPPORTED: these edges / this shape want the compact tile
+            runtime.check(rc, "gm_classify")
+        values = values.contiguous()
     runtime.check(_lib().gm_classify2(
         ctypes.c_void_p(values.ptr), code_of(values.dtype), 1 if eff is not None else 0,
         runtime.scalar_bits(eff if eff is not None else 0, values.dtype),

@@ -351,6 +351,12 @@ int gm_classify(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits /* 
  * type; bins_are_int = 1 makes bins_host an array of int64 and the comparison exact int64. */
 int gm_classify2(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, const void* bins_host, int nbins,
                  int bins_are_int, int right, void* out, int out_dtype, uint64_t fill, size_t n);
+/* The tile as a window of a wider resident raster: rows x cols cells, rows `pitch` cells apart; out is compact.  Served for
+ * float32 tiles whose edges take the grid kernel (more than a handful of float edges, cols and pitch multiples of 4);
+ * GM_ERR_UNSUPPORTED = compact the window and call gm_classify2 (what the window path of the reference's Classify.process,
+ * raster/misc.py:387-399, amounts to: it sees the array the source cut out). */
+int gm_classify2_window(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, const void* bins_host, int nbins,
+                        int bins_are_int, int right, void* out, int out_dtype, uint64_t fill, int rows, int cols, int pitch);
 
 /* =============================================================================
  * K5: Reclassify -- np.isin + np.searchsorted lookup.  raster/misc.py:482-515

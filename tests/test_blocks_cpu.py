@@ -572,7 +572,7 @@ def cpu_place(cpu_vm, monkeypatch):
     monkeypatch.setattr(hip_array, "as_device", lambda v: np.asarray(v))
     monkeypatch.setattr(spatial, "_filled", lambda shape, value, dtype: np.full(shape, value, dtype))
     monkeypatch.setattr(spatial, "_shifted_copy", shifted_copy)
-    monkeypatch.setattr(spatial, "_has_data", lambda values, ndv: bool(O.get_index(values, ndv).any()))
+    monkeypatch.setattr(spatial, "_has_data", lambda values, ndv, landed=None: bool(O.get_index(values, ndv).any()))
     monkeypatch.setattr(reduction, "reduce_rasters", O.reduce_rasters)
     yield
 

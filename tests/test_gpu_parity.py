@@ -674,6 +674,46 @@ def test_classify_many_edges_large_tile(gpu, kind, right):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("right", [False, True])
+@pytest.mark.parametrize("kind", ["uniform200", "clustered", "few"])
+def test_classify_many_edges_on_windows_of_a_resident_raster(gpu, kind, right):
+    """Classify of a zero-copy window (rows a pitch apart): the grid kernel reads it where it lies when columns and pitch are
+    whole groups of four cells on a 16-byte boundary (gm_classify2_window); other windows, clustered edges (binary search)
+    and few edges (the program route) come to the same answer through a compact copy.  Also through the Block, as
+    `Classify(A, edges)` over a resident MemorySource meets it."""
+    from dask_geomodeling_amd import raster
+    from dask_geomodeling_amd.hip.array import DeviceArray
+    from dask_geomodeling_amd.raster import tables
+    rng = np.random.default_rng(11)
+    if kind == "uniform200":
+        bins = np.linspace(-100, 100, 200).tolist()
+    elif kind == "few":
+        bins = [-50.0, 0.0, 12.5, 70.0]
+    else:
+        bins = sorted(set((np.concatenate([np.linspace(-100, 100, 20), 1.0 + np.arange(40) * 1e-4])).tolist()))
+    ndv = np.float32(np.finfo("f4").max)
+    wide = (rng.random((1, 700, 1100)) * 220 - 110).astype("f4")
+    wide[0, ::37, ::41] = ndv
+    wide[0, 300, 400:406] = [np.nan, np.inf, -np.inf, ndv, 0.0, -0.0]
+    edges32 = np.asarray(bins, dtype="f4")
+    wide[0, 301, 400:400 + len(bins)] = edges32[:700]
+    resident = DeviceArray.from_numpy(wide)
+    for row0, col0, h, w in ((0, 0, 700, 1100), (16, 64, 512, 640), (3, 4, 300, 1000), (3, 5, 300, 1000), (9, 8, 600, 1001),
+                             (0, 0, 128, 1100), (100, 96, 17, 132)):
+        data = {"values": resident.window(row0, col0, h, w), "no_data_value": ndv}
+        want = O.classify_process({"values": wide[:, row0:row0 + h, col0:col0 + w], "no_data_value": ndv}, bins, right)
+        got = tables.classify_process(data, bins, right)
+        assert_result_equal(dict(got, values=np.asarray(got["values"])), want, 0, "%s right=%s %s" % (kind, right, (row0, col0, h, w)))
+    finite = np.where(np.isfinite(wide), wide, np.float32(1.0))  # (a source hands non-finite cells on as no data, sources.py:141-143)
+    source = raster.MemorySource(DeviceArray.from_numpy(finite), ndv, "EPSG:28992", 1.0, (0.0, 700.0))
+    view = raster.Classify(source, bins, right)
+    request = dict(mode="vals", bbox=(64.0, 100.0, 704.0, 612.0), width=640, height=512, projection="EPSG:28992")
+    got = view.get_data(**request)
+    want = O.classify_process({"values": finite[:, 88:600, 64:704], "no_data_value": ndv}, bins, right)
+    assert_result_equal(dict(got, values=np.asarray(got["values"])), want, 0, "Block %s right=%s" % (kind, right))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cell", [0.1, 0.3, 0.7])
 def test_tiler_with_tiles_one_pixel_short_of_their_slot(gpu, cell):
     """The reference truncates tile sizes with int() (parallelize.py:85-86): for cell sizes that are not
