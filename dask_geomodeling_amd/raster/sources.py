@@ -148,6 +148,10 @@ class RasterSourceBase(RasterBlock):
                     runtime.check(L.gm_copy_2d(ctypes.c_void_p(cells.ptr), item,
                                                ctypes.c_void_p(source.ptr + ((bands[0] * ny + i) * nx + j) * item), ny * nx * item,
                                                item, length), "gm_copy_2d")
+                    if cells.dtype == dtype:
+                        # (the series stays where it is: what reads it next -- an aggregation, an element-wise view -- runs
+                        #  on the device, and a transfer to the host and back cost 40 us of such a request's 124)
+                        return {"values": cells, "no_data_value": fill}
                     result[:, 0, 0] = cells.to_numpy()[:, 0, 0]
                 else:
                     result[:, 0, 0] = source[bands[0]:bands[1], i, j]

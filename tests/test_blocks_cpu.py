@@ -133,6 +133,11 @@ def test_get_sync_deep_chain_and_lists():
     assert graphs.get_sync(graph, ["k2999"]) == [2999]
     graph = {"a": 1, "b": 2, "s": (sum, ["a", "b", 10])}
     assert graphs.get_sync(graph, "s") == 13
+    # long lists of plain numbers are taken as one constant (the edges of a Classify) -- unless a number IS a key
+    edges, halves = [float(i) for i in range(40)], [i + 0.5 for i in range(40)]
+    graph = {"e": (sum, edges), 7: 100, "k": (sum, list(range(20))), "f": ((lambda a, b: a + sum(b)), "e", edges),
+             "h": (sum, halves), "g": ((lambda a, b: a + sum(b)), "h", halves)}
+    assert graphs.get_sync(graph, ["e", "k", "f", "h", "g"]) == [873.0, 283, 1746.0, 800.0, 1600.0]  # (7.0 == 7: a key)
 
 
 # ---------------------------------------------------------------------------------

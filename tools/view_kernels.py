@@ -2,6 +2,7 @@
 
   rocprofv3 --kernel-trace --output-format csv -d gpurun_out/vk -- python3 tools/view_kernels.py place      # run the view 12 times
   python3 tools/view_kernels.py --read gpurun_out/vk 12                                       # per-request kernel table
+  PLANS=0 CPROFILE=1 python3 tools/view_kernels.py classify200                                # cProfile of 50 requests (graph path)
 
 Views: the series probes of tools/e2e_views.py that sit well above their kernels' time (series seams)."""
 import csv, glob, sys
@@ -26,18 +27,27 @@ def read(folder, runs):
         print("kernels per request (uploads of the setup included in the first lines): %.1f us" % (total / 1e3 / runs))
 
 
-def main():
-    if sys.argv[1] == "--read":
-        return read(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else RUNS)
+def build(name):
+    """(view, request) of one of the probes."""
     sys.path.insert(0, "/root/repo")
     from datetime import datetime, timedelta
     import numpy as np
-    from dask_geomodeling_amd import config as gmconfig, raster
+    from dask_geomodeling_amd import raster
     from dask_geomodeling_amd.hip import runtime
     from dask_geomodeling_amd.raster.sources import generate_window
     runtime.set_device(0)
     F32MAX = float(np.finfo("f4").max)
     frames, side = 8, 4096
+    if name in ("smooth40", "classify200", "maskdilate", "hillclass"):
+        big = 16384
+        A = raster.MemorySource(generate_window((big, big), "f4", 7001, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big),
+                                np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
+        C = raster.MemorySource(generate_window((big, big), "u1", 7003, 0.0, 12.0, 255, (97, 89), 0, 0, big, big),
+                                np.uint8(255), "EPSG:28992", 1.0, (0.0, float(big)))
+        views = {"smooth40": raster.Smooth(A, 40.0), "classify200": raster.Classify(A, [float(x) / 2 for x in range(200)]),
+                 "maskdilate": raster.Mask(raster.Dilate(C, [3, 5]), 1),
+                 "hillclass": raster.Classify(raster.HillShade(A), [20, 50, 80, 110, 140, 170, 200, 230])}
+        return views[name], dict(mode="vals", bbox=(4160.0, 4160.0, 8256.0, 8256.0), width=side, height=side, projection="EPSG:28992")
     dt = generate_window((frames * side, side), "f4", 7004, 0.0, 100.0, F32MAX, (97, 89), 0, 0, frames * side, side).reshape((frames, side, side))
     T = raster.MemorySource(dt, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(side)), time_first=datetime(2020, 1, 1),
                             time_delta=timedelta(hours=6))
@@ -48,20 +58,37 @@ def main():
         "group": raster.TemporalAggregate(raster.Group(T, T * 0.5), "D", "mean"),
         "fillnodata": raster.FillNoData(T, T * 0.5),
         "clip": raster.Clip(raster.Cumulative(T), T > 50),
+        "pointmean": raster.TemporalAggregate(T, "D", "mean"),
     }
-    if sys.argv[1] in ("smooth40", "classify200", "maskdilate", "hillclass"):
-        big = 16384
-        A = raster.MemorySource(generate_window((big, big), "f4", 7001, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big),
-                                np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
-        C = raster.MemorySource(generate_window((big, big), "u1", 7003, 0.0, 12.0, 255, (97, 89), 0, 0, big, big),
-                                np.uint8(255), "EPSG:28992", 1.0, (0.0, float(big)))
-        views = {"smooth40": raster.Smooth(A, 40.0), "classify200": raster.Classify(A, [float(x) / 2 for x in range(200)]),
-                 "maskdilate": raster.Mask(raster.Dilate(C, [3, 5]), 1),
-                 "hillclass": raster.Classify(raster.HillShade(A), [20, 50, 80, 110, 140, 170, 200, 230])}
-        tbox = dict(mode="vals", bbox=(4160.0, 4160.0, 8256.0, 8256.0), width=side, height=side, projection="EPSG:28992")
-    view = views[sys.argv[1]]
-    gmconfig.config.set({"geomodeling.materialize": False}).__enter__()  # (results stay on the device, like tools/e2e_views.py)
-    import time
+    if name == "pointmean":
+        tbox = dict(tbox, bbox=(2000.5, 2000.5, 2000.5, 2000.5), width=1, height=1)
+    return views[name], tbox
+
+
+def main():
+    if sys.argv[1] == "--read":
+        return read(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else RUNS)
+    import os, time
+    view, tbox = build(sys.argv[1])
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd.hip import runtime
+    # (results stay on the device, like tools/e2e_views.py; PLANS=0: the fused graph per request through the scheduler)
+    gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": os.environ.get("PLANS", "1") == "1"}).__enter__()
+    if os.environ.get("CPROFILE"):  # where the host time of a request goes
+        import cProfile, io, pstats
+        for _ in range(8):
+            view.get_data(**tbox)
+        runtime.sync()
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(50):
+            view.get_data(**tbox)
+        runtime.sync()
+        pr.disable()
+        out = io.StringIO()
+        pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(45)
+        print("\n".join(line[:160] for line in out.getvalue().splitlines()[4:60]))
+        return
     for i in range(RUNS):
         if i == RUNS - 5:
             runtime.sync()
