@@ -171,15 +171,28 @@ def view_plan(view, request):
     return None if hit is _NO_PLAN else hit
 
 
-def _local_everywhere(block, request):
+def _local_everywhere(block, request, stencils=1):
     """Every Block of the view computes a cell from that cell of its sources alone (``gm_local``), and every source answers
-    ``request`` with a window of its own grid."""
-    if not getattr(type(block), "gm_local", False):
-        return False
-    aligned = getattr(block, "_aligned_window", None)
-    if aligned is not None and aligned(request) is None:
-        return False
-    return all(_local_everywhere(a, request) for a in block.args if isinstance(a, Block))
+    ``request`` with a window of its own grid.  ``stencils``: how many Blocks that look around a cell instead
+    (``gm_tiling_invariant``: Dilate, MovingMax, HillShade -- they ask their store for the box grown by their margin,
+    so a tile's cells see exactly what the whole box's cells see) a path to the leaves may still hold: one, because their
+    process arguments follow from the cell size of the request they are asked (the whole and its tiles agree on it,
+    _whole_instead_of_tiles looks), not from that of a request another stencil has grown."""
+    kind = type(block)
+    if getattr(kind, "gm_local", False):
+        aligned = getattr(block, "_aligned_window", None)
+        if aligned is not None and aligned(request) is None:
+            return False
+        return all(_local_everywhere(a, request, stencils) for a in block.args if isinstance(a, Block))
+    if getattr(kind, "gm_tiling_invariant", False) and stencils > 0 and request.get("mode") == "vals":
+        found = False
+        for source, asked in block.get_sources_and_requests(**request):
+            if isinstance(source, Block):
+                if asked is None or not _local_everywhere(source, asked, stencils - 1):
+                    return False
+                found = True
+        return found
+    return False
 
 
 def _whole_instead_of_tiles(store, request, kwargs, tile_requests):
@@ -196,10 +209,20 @@ def _whole_instead_of_tiles(store, request, kwargs, tile_requests):
     if height * width > (1 << 28) or len(tile_requests) < 2:
         return False
     covered = 0
+    x1, y1, x2, y2 = request["bbox"]
+    if x2 == x1 or y2 == y1:
+        return False
+    per_x, per_y, cell_x, cell_y = width / (x2 - x1), height / (y2 - y1), (x2 - x1) / width, (y2 - y1) / height
     for _, tile in tile_requests:
         if tile["width"] * tile["height"] < 2:
             return False
         covered += tile["width"] * tile["height"]
+        # the tiles' cells are the box's cells to the last bit (what a HillShade's resolution is
+        # computed from): cell sizes that are no binary fractions can differ in it from tile to tile
+        tx1, ty1, tx2, ty2 = tile["bbox"]
+        if tx2 == tx1 or ty2 == ty1 or tile["width"] / (tx2 - tx1) != per_x or tile["height"] / (ty2 - ty1) != per_y \
+                or (tx2 - tx1) / tile["width"] != cell_x or (ty2 - ty1) / tile["height"] != cell_y:
+            return False
     if covered != height * width:
         return False
     return _local_everywhere(store, request)

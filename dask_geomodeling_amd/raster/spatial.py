@@ -47,6 +47,9 @@ class _Stencil(BaseSingle):
     request and ``process`` crops; requests that cannot grow pass through untouched (spatial.py:130-141)."""
 
     gm_direct = True  # plan.py: evaluated as process(store's response) without a graph per request
+    # plan._whole_instead_of_tiles: a mosaic of this Block's tiles IS its answer for the whole box (every tile's cells see
+    # their neighbours through the margin the tile asks its store for; the kernels compute a cell from its window alone)
+    gm_tiling_invariant = True
 
     def _radius(self):
         return 1
@@ -248,6 +251,8 @@ class Smooth(BaseSingle):
     at the coarser ('zoom') resolution and zoomed back with nearest neighbour, like the reference."""
 
     gm_direct = True
+    # (NOT gm_tiling_invariant: the reference grows the request by `size` cells while the Gaussian reaches 4 / 3 of that,
+    #  spatial.py:262-290 -- the border cells of a tile see the edge of the tile's window, a mosaic of tiles is not the whole)
 
     MARGIN_THRESHOLD = 6
 

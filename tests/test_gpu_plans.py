@@ -413,3 +413,69 @@ def test_tiler_over_pixel_local_temporal_views_is_one_request(gpu):
             assert not any(calls)
     finally:
         plan._whole_instead_of_tiles = original
+
+
+def test_tiler_over_a_stencil_is_one_request_where_the_margins_lie_inside(gpu):
+    """Dilate, MovingMax and HillShade ask their store for the box grown by exactly the margin their kernels look at, so a mosaic
+    of their tiles IS their answer for the whole box: a RasterTiler over one of them (alone, or under / over pixel-local Blocks
+    with a kernel of their own) is ONE request where the grown box lies on the sources' grid (plan._whole_instead_of_tiles) --
+    256 tiles of a HillShade are 256 launches otherwise.  Against the walking oracle, which pastes tiles; on the plan path and
+    from the template.  NOT: Smooth (the reference grows by `size` cells, the Gaussian reaches 4 / 3 of that), two stencils on a
+    path (the inner one's arguments follow from a request the outer one has grown), a margin past the source's edge."""
+    from datetime import datetime, timedelta
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd import plan, raster
+    from helpers import assert_result_equal
+    from oracle_walk import walk
+    rng = np.random.default_rng(33)
+    v = (rng.random((1, 96, 128)) * 12).astype("f4")
+    v[rng.random(v.shape) < 0.1] = -9999.0
+    A = raster.MemorySource(v, -9999.0, "EPSG:28992", 1.0, (0.0, 96.0))
+    half = raster.MemorySource(v, -9999.0, "EPSG:28992", 0.5, (0.0, 48.0))
+    c = rng.integers(0, 9, size=(1, 96, 128)).astype("u1")
+    C = raster.MemorySource(c, 255, "EPSG:28992", 1.0, (0.0, 96.0))
+    s = (rng.random((6, 96, 128)) * 50).astype("f4")
+    s[rng.random(s.shape) < 0.1] = -9999.0
+    S = raster.MemorySource(s, -9999.0, "EPSG:28992", 1.0, (0.0, 96.0), time_first=datetime(2021, 3, 1), time_delta=timedelta(hours=6))
+    inner = dict(mode="vals", bbox=(16.0, 8.0, 112.0, 88.0), width=96, height=80, projection="EPSG:28992")
+    when = dict(start=datetime(2021, 1, 1), stop=datetime(2021, 6, 1))
+    calls = []
+    original = plan._whole_instead_of_tiles
+
+    def spy(*args):
+        calls.append(original(*args))
+        return calls[-1]
+    plan._whole_instead_of_tiles = spy
+    try:
+        cases = [
+            (raster.Dilate(C, [3, 5]), inner, True), (raster.MovingMax(A, 3), inner, True), (raster.MovingMax(A, 7), inner, True),
+            (raster.HillShade(A), inner, True),
+            (raster.HillShade(half), dict(inner, bbox=(8.0, 4.0, 56.0, 44.0)), True),                # cells of 0.5
+            (raster.TemporalAggregate(raster.MovingMax(S, 5), "D", "max"), dict(inner, **when), True),  # a pixel-local store over it
+            (raster.MovingMax(raster.Snap(S, S), 3), dict(inner, **when), True),                       # ... and under it
+            (raster.Smooth(A, 2.0), inner, False),
+            (raster.Dilate(raster.MovingMax(C, 3), [3]), inner, False),                                # two stencils on a path
+            (raster.MovingMax(A, 21), inner, False),                                                   # margin 10 > the 8 rows below the box
+            (raster.HillShade(A), dict(inner, bbox=(0.0, 0.0, 128.0, 96.0), width=128, height=96), False),
+        ]
+        for store, request, whole in cases:
+            for tile in (16, [32, 12], [20, 16]):
+                view = raster.RasterTiler(store, tile)
+                try:
+                    want = walk(view, request)
+                except OverflowError:
+                    # (np.full(shape, 256, uint8), parallelize.py:108-112 over a HillShade: NumPy 2 refuses the fill value the
+                    #  reference declares; the mosaic has no cell to fill here and is the untiled answer, tested against the oracle elsewhere)
+                    assert isinstance(store, raster.HillShade)
+                    want = _graph_path(store, request)
+                what = "%s(%s) tiled by %s" % (type(store).__name__, type(store.args[0]).__name__, tile)
+                del calls[:]
+                with gmconfig.config.set({"geomodeling.plans": True}):
+                    assert_result_equal(view.get_data(**request), want, 0, what + " (plans)")
+                assert bool(calls and calls[-1]) == whole, (what, calls)
+                del calls[:]
+                assert_result_equal(_template_path(view, request), want, 0, what + " (template)")
+                assert bool(calls and calls[-1]) == whole, (what, calls, "template")
+                assert_result_equal(_graph_path(view, request), want, 0, what + " (graph from scratch)")
+    finally:
+        plan._whole_instead_of_tiles = original

@@ -19,7 +19,11 @@ views = {"tiler(HillShade(A))": raster.RasterTiler(raster.HillShade(A), side),
          "tiler(MovingMax(A + B, 5))": raster.RasterTiler(raster.MovingMax(A + B, 5), side),
          "tiler(Smooth(A * 2, 2))": raster.RasterTiler(raster.Smooth(A * 2, 2.0), side),
          "tiler(HillShade(A * 2 + B))": raster.RasterTiler(raster.HillShade(A * 2 + B), side),
-         "tiler(HillShade(A) * 0.5 + B)": raster.RasterTiler(raster.HillShade(A) * 0.5 + B, side)}
+         "tiler(HillShade(A) * 0.5 + B)": raster.RasterTiler(raster.HillShade(A) * 0.5 + B, side),
+         # 254 tiles: one request where a mosaic of tiles is the whole (plan._whole_instead_of_tiles: the stencils but Smooth)
+         "tiler(HillShade(A), 1024)": raster.RasterTiler(raster.HillShade(A), 1024),
+         "tiler(Dilate(C, [3, 5]), 1024)": raster.RasterTiler(raster.Dilate(C, [3, 5]), 1024),
+         "tiler(Smooth(A, 2), 1024)": raster.RasterTiler(raster.Smooth(A, 2.0), 1024)}
 inner = 64.0
 req = dict(mode="vals", bbox=(inner, inner, big - inner, big - inner), width=big - 128, height=big - 128, projection="EPSG:28992")
 for name, view in views.items():
