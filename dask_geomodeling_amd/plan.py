@@ -19,6 +19,7 @@ through the store's plan (``_direct``).  Everything else -- other modes, configu
 ordinary graph path, as does a request whose plan cannot be built.
 """
 
+import os
 import threading
 
 import numpy as np
@@ -171,6 +172,9 @@ def view_plan(view, request):
     return None if hit is _NO_PLAN else hit
 
 
+_STENCILS_WHOLE = True  # (tests of the tile-by-tile route of stencil Blocks under a tiler switch it off)
+
+
 def _local_everywhere(block, request, stencils=1):
     """Every Block of the view computes a cell from that cell of its sources alone (``gm_local``), and every source answers
     ``request`` with a window of its own grid.  ``stencils``: how many Blocks that look around a cell instead
@@ -184,7 +188,7 @@ def _local_everywhere(block, request, stencils=1):
         if aligned is not None and aligned(request) is None:
             return False
         return all(_local_everywhere(a, request, stencils) for a in block.args if isinstance(a, Block))
-    if getattr(kind, "gm_tiling_invariant", False) and stencils > 0 and request.get("mode") == "vals":
+    if getattr(kind, "gm_tiling_invariant", False) and stencils > 0 and _STENCILS_WHOLE and request.get("mode") == "vals":
         found = False
         for source, asked in block.get_sources_and_requests(**request):
             if isinstance(source, Block):
@@ -195,6 +199,11 @@ def _local_everywhere(block, request, stencils=1):
     return False
 
 
+# tiles of 2048^2 cells and more: the batched launch over the tiles (the test suites, whose rasters are small, set 0: their
+# tiles go the way the bench's 4096^2 tiles go)
+_BATCHED_TILE_CELLS = int(os.environ.get("GM_TILER_BATCH_CELLS", 1 << 22))
+
+
 def _whole_instead_of_tiles(store, request, kwargs, tile_requests):
     """A mosaic of a pixel-local view over sources on the request's grid IS that view asked for the whole box: the reference
     computes it tile by tile to bound the memory of a task (parallelize.py:43-91) and pastes the tiles next to each other
@@ -203,10 +212,14 @@ def _whole_instead_of_tiles(store, request, kwargs, tile_requests):
     in 1024^2 tiles: 1.0 -> ~0.15 ms).  Only where nothing can differ: the tiles cover the box exactly (the reference's int()
     truncation of tile sizes can leave cells to the fill value), none of them is a single cell (NumPy sums the series of ONE
     cell pairwise), the box is of moderate size."""
-    if getattr(type(store).process, "gm_op", None) is not None:
-        return False  # (element-wise stores are batched over the tiles and written into the mosaic: TiledAssembly)
     height, width = kwargs["shape_yx"]
     if height * width > (1 << 28) or len(tile_requests) < 2:
+        return False
+    if getattr(type(store).process, "gm_op", None) is not None and \
+            max(tile["width"] * tile["height"] for _, tile in tile_requests) >= _BATCHED_TILE_CELLS:
+        # element-wise stores are batched over the tiles and written into the mosaic (TiledAssembly): one launch, at the kernel's
+        # rate for tiles of this size; it is the planning around SMALL tiles (8 frames of 4096^2 in 16 tiles: 337 us against 164
+        # for the whole) that one request saves
         return False
     covered = 0
     x1, y1, x2, y2 = request["bbox"]

@@ -38,6 +38,16 @@ def gpu():
     return runtime
 
 
+@pytest.fixture(autouse=True)
+def _tiles_take_the_batched_route(monkeypatch):
+    """A RasterTiler over an element-wise store in tiles of fewer than 2048^2 cells is answered as one request for the whole
+    box where that changes no cell (plan._whole_instead_of_tiles).  The suites' rasters are small: without this their tiles
+    would never take the batched launch into the mosaic (fuse.TiledAssembly) that the bench's 4096^2 tiles take.  The tests of
+    the shortcut itself set the product's threshold back."""
+    from dask_geomodeling_amd import plan
+    monkeypatch.setattr(plan, "_BATCHED_TILE_CELLS", 0)
+
+
 @pytest.fixture
 def cpu_vm(monkeypatch):
     """Run the product's host logic (Blocks, fusion, program compiler) on the CPU by

@@ -8,12 +8,17 @@ from fuzz_util import REQ, describe, oracle_eval, random_view, unsigned_zero
 from helpers import assert_result_equal
 from dask_geomodeling_amd import raster
 from dask_geomodeling_amd.hip import runtime
+from dask_geomodeling_amd import plan as _plan
 runtime.set_device(0)
 bad = skipped = 0
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 BASE = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000  # first seed
 for seed in range(N):
     rng = np.random.default_rng(BASE + seed)
+    # (tilers over element-wise stores: odd seeds tile by tile -- the batched launch into the mosaic --, even seeds the
+    #  product's own rule, one request for small tiles: plan._whole_instead_of_tiles)
+    _plan._BATCHED_TILE_CELLS = 0 if seed % 2 else 1 << 22
+    _plan._STENCILS_WHOLE = seed % 4 < 2  # (likewise the one-request rule for tilers over Dilate / MovingMax / HillShade)
     memory = seed % 3 == 0
     view = random_view(rng, "x%d" % seed, depth=int(rng.integers(2, 6)), memory=memory)
     try:

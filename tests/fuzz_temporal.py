@@ -9,6 +9,7 @@ from helpers import assert_result_equal
 from oracle_walk import comparable, random_requests, random_temporal_view, walk, without_lossy_cells
 from dask_geomodeling_amd import config as gmconfig
 from dask_geomodeling_amd.hip import runtime
+from dask_geomodeling_amd import plan as _plan
 runtime.set_device(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 SHAPE = tuple(int(x) for x in sys.argv[2].split("x")) if len(sys.argv) > 2 else (24, 40)  # e.g. 150x517
@@ -17,6 +18,10 @@ bad = raised = asked = refused = 0
 refusals = {}
 for seed in range(N):
     rng = np.random.default_rng(BASE + seed)
+    # (tilers over element-wise stores: odd seeds tile by tile -- the batched launch into the mosaic --, even seeds the
+    #  product's own rule, one request for small tiles: plan._whole_instead_of_tiles)
+    _plan._BATCHED_TILE_CELLS = 0 if seed % 2 else 1 << 22
+    _plan._STENCILS_WHOLE = seed % 4 < 2  # (likewise the one-request rule for tilers over Dilate / MovingMax / HillShade)
     view = random_temporal_view(rng, depth=int(rng.integers(1, 5)), shape_yx=SHAPE)
     with gmconfig.config.set({"geomodeling.plans": seed % 2 == 0}):
         for request in random_requests(rng, view, SHAPE):

@@ -155,11 +155,12 @@ def test_tiler_over_hillshade_in_one_launch(gpu, dtype, cell):
 @pytest.mark.parametrize("over", ["source", "computed"])
 @pytest.mark.parametrize("dtype", ["f4", "u1", "i2", "i8", "f8"])
 @pytest.mark.parametrize("kind", ["dilate", "movingmax3", "movingmax7", "movingmax21", "smooth", "hillshade"])
-def test_tiler_over_stencils_writes_in_place(gpu, kind, dtype, over):
+def test_tiler_over_stencils_writes_in_place(gpu, kind, dtype, over, monkeypatch):
     """A RasterTiler over Dilate / MovingMax / Smooth of a resident source on the plan path: every tile's result is
     written straight into its window of the mosaic where the kernel route can (gm_*_into), pasted otherwise (8-byte
     cells, large footprints, ragged tilings) -- always the untiled Block's result and the graph path's mosaic."""
-    from dask_geomodeling_amd import raster
+    from dask_geomodeling_amd import plan, raster
+    monkeypatch.setattr(plan, "_STENCILS_WHOLE", False)  # (tile by tile; the one-request rule has its own test below)
     rng = np.random.default_rng(17)
     dt = np.dtype(dtype)
     if kind == "smooth" and dt.kind != "f":
@@ -479,3 +480,54 @@ def test_tiler_over_a_stencil_is_one_request_where_the_margins_lie_inside(gpu):
                 assert_result_equal(_graph_path(view, request), want, 0, what + " (graph from scratch)")
     finally:
         plan._whole_instead_of_tiles = original
+
+
+def test_tiler_in_small_tiles_over_an_element_wise_store_is_one_request(gpu, monkeypatch):
+    """Element-wise stores under a RasterTiler are launched once over all tiles, written into the mosaic (fuse.TiledAssembly) --
+    at the kernel's rate for tiles of 2048^2 cells and more; around SMALL tiles it is the planning per tile that costs, and a
+    pixel-local view over sources on the request's grid is asked once for the whole box instead (the suites switch that off to
+    keep their small tiles on the batched route: conftest.py).  Both ways the walking oracle's mosaic, on the plan path, from
+    the template and as a graph from scratch; series of several frames, a declared dtype, tiles that leave cells uncovered."""
+    from datetime import datetime, timedelta
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd import plan, raster
+    from helpers import assert_result_equal
+    from oracle_walk import walk
+    rng = np.random.default_rng(44)
+    v = (rng.random((5, 48, 64)) * 100).astype("f4")
+    v[rng.random(v.shape) < 0.1] = -9999.0
+    T = raster.MemorySource(v, -9999.0, "EPSG:28992", 1.0, (0.0, 48.0), time_first=datetime(2021, 3, 1), time_delta=timedelta(hours=6))
+    w = rng.integers(0, 50, size=(5, 48, 64)).astype("i2")
+    W = raster.MemorySource(w, -1, "EPSG:28992", 1.0, (0.0, 48.0), time_first=datetime(2021, 3, 1), time_delta=timedelta(hours=6))
+    box = dict(mode="vals", bbox=(0.0, 0.0, 64.0, 48.0), width=64, height=48, projection="EPSG:28992",
+               start=datetime(2021, 1, 1), stop=datetime(2021, 6, 1))
+    stores = [T * 2, raster.Clip(T, T > 20), (T + W) / 3, raster.Classify(T, [10, 50, 90]), W * 2 > 30, raster.FillNoData(T, T * 0.5)]
+    calls = []
+    original = plan._whole_instead_of_tiles
+
+    def spy(*args):
+        calls.append(original(*args))
+        return calls[-1]
+    monkeypatch.setattr(plan, "_whole_instead_of_tiles", spy)
+    for cells, elided in ((1 << 22, True), (0, False), (16 * 16, False), (16 * 16 + 1, True)):
+        monkeypatch.setattr(plan, "_BATCHED_TILE_CELLS", cells)
+        for store in stores:
+            for tile, covers in ((16, True), ([32, 12], True), ([64, 48], False)):
+                if cells in (16 * 16, 16 * 16 + 1) and tile != 16:
+                    continue
+                view = raster.RasterTiler(store, tile)
+                want = walk(view, box)
+                what = "%s tiled by %s, batched from %d cells" % (type(store).__name__, tile, cells)
+                del calls[:]
+                with gmconfig.config.set({"geomodeling.plans": True}):
+                    assert_result_equal(view.get_data(**box), want, 0, what + " (plans)")
+                assert bool(calls and calls[-1]) == (elided and covers), (what, calls)
+                assert_result_equal(_template_path(view, box), want, 0, what + " (template)")
+                assert_result_equal(_graph_path(view, box), want, 0, what + " (graph from scratch)")
+    # cells of 0.3 units: the reference's int() truncation leaves cells uncovered -- tile by tile whatever the threshold
+    monkeypatch.setattr(plan, "_BATCHED_TILE_CELLS", 1 << 22)
+    coarse = dict(box, bbox=(0.0, 0.0, 19.2, 14.4))
+    view = raster.RasterTiler(T * 2, 4.8)
+    del calls[:]
+    assert_result_equal(view.get_data(**coarse), walk(view, coarse), 0, "cells of 0.3")
+    assert not any(calls)

@@ -110,13 +110,20 @@ def test_spec_wait_returns_in_a_forked_child():
     raise AssertionError("gm_spec_wait() hung in the forked child")
 
 
-def test_tiler_over_a_stencil_on_a_source_is_one_graph_task():
+def test_tiler_over_a_stencil_on_a_source_is_one_graph_task(monkeypatch):
     """template.fused_compute_graph of a RasterTiler over a stencil Block on a resident source: ONE MosaicOfTiles task over
-    the tiles' source windows (the stencil writes every tile into the mosaic); over a computed store: a task per tile."""
+    the tiles' source windows (the stencil writes every tile into the mosaic); over a computed store: a task per tile.
+    (Where a mosaic of tiles is the whole -- Dilate, MovingMax, HillShade with their margins inside the source -- the graph
+    holds the store's graph for the whole box and one mosaic_of_whole task instead: plan._whole_instead_of_tiles.)"""
+    from dask_geomodeling_amd import plan
     from dask_geomodeling_amd.fuse import MosaicOfTiles
     a = np.arange(64 * 64, dtype="f4").reshape(1, 64, 64)
     source = raster.MemorySource(a, 255.0, "EPSG:28992", 1.0, (0.0, 64.0))
     request = dict(mode="vals", bbox=(8.0, 8.0, 40.0, 40.0), width=32, height=32, projection="EPSG:28992")
+    for block in (raster.HillShade(source), raster.MovingMax(source, 3), raster.Dilate(source, [3.0]), raster.Smooth(source, 2.0)):
+        graph, name = template.fused_compute_graph(raster.RasterTiler(block, 16), request)
+        assert (graph[name][0] is template.mosaic_of_whole) == (not isinstance(block, raster.Smooth)), type(block).__name__
+    monkeypatch.setattr(plan, "_STENCILS_WHOLE", False)
     for block in (raster.HillShade(source), raster.MovingMax(source, 3), raster.Dilate(source, [3.0]), raster.Smooth(source, 2.0)):
         tiler = raster.RasterTiler(block, 16)
         graph, name = template.fused_compute_graph(tiler, request)
