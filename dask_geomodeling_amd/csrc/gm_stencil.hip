@@ -1487,7 +1487,10 @@ int zero_sign_slot(hipStream_t s, unsigned** slot, unsigned* ticket) {
     void* buf = nullptr;
     int rc = gm_malloc(&buf, sizeof(unsigned) * kZeroSignSlots);
     if (rc) return rc;
+    // (once per device, and finished before anybody's launch can write a ticket: another thread's stream must not see its
+    //  ticket wiped by a fill still queued on this one)
     GM_HIP(hipMemsetAsync(buf, 0, sizeof(unsigned) * kZeroSignSlots, s));
+    GM_HIP(hipStreamSynchronize(s));
     ring.first = (unsigned*)buf;
   }
   *ticket = ++ring.second;
