@@ -38,7 +38,7 @@ def build(name):
     runtime.set_device(0)
     F32MAX = float(np.finfo("f4").max)
     frames, side = 8, 4096
-    if name in ("smooth40", "classify200", "maskdilate", "hillclass"):
+    if name in ("smooth40", "classify200", "maskdilate", "hillclass", "groupab", "hillmix"):
         big = 16384
         A = raster.MemorySource(generate_window((big, big), "f4", 7001, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big),
                                 np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
@@ -47,6 +47,10 @@ def build(name):
         views = {"smooth40": raster.Smooth(A, 40.0), "classify200": raster.Classify(A, [float(x) / 2 for x in range(200)]),
                  "maskdilate": raster.Mask(raster.Dilate(C, [3, 5]), 1),
                  "hillclass": raster.Classify(raster.HillShade(A), [20, 50, 80, 110, 140, 170, 200, 230])}
+        if name in ("groupab", "hillmix"):
+            B = raster.MemorySource(generate_window((big, big), "f4", 7002, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big),
+                                    np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
+            views.update(groupab=raster.Group(A, B), hillmix=raster.HillShade(A + B) * 0.5)
         return views[name], dict(mode="vals", bbox=(4160.0, 4160.0, 8256.0, 8256.0), width=side, height=side, projection="EPSG:28992")
     dt = generate_window((frames * side, side), "f4", 7004, 0.0, 100.0, F32MAX, (97, 89), 0, 0, frames * side, side).reshape((frames, side, side))
     T = raster.MemorySource(dt, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(side)), time_first=datetime(2020, 1, 1),
