@@ -1210,7 +1210,59 @@ def _tiles_key(tiles):
         return None
 
 
+_NARROW_LIMIT = 1 << 24  # whole numbers up to here are exact in every register class, float32 included
+
+
+def _narrowed(values, ndv):
+    """A 64-bit integer tile all of whose values lie within +-2^24 as an int32 tile with the same values (and its no-data
+    value, if an int32 can be equal to it); None for every other tile.  Three passes and two round trips to the host: for
+    the views this serves there was no answer at all before (see run_expr)."""
+    if not isinstance(values, DeviceArray) or not _wide_int(values.dtype) or values.size == 0:
+        return None
+    eff = effective_ndv(values.dtype, ndv)
+    if ndv is not None and (eff is None or not -(1 << 31) <= int(eff) < (1 << 31)):
+        return None  # (a Clip writes its store's no-data value: it has to be one an int32 tile can hold -- a TemporalSum's is)
+    tile = values.contiguous()
+    bits = DeviceArray(tile.ptr, tile.shape, np.dtype("i8"), tile.device, owner=tile)  # (uint64: in range <=> 0 <= bits <= 2^24)
+    low = -_NARROW_LIMIT if values.dtype.kind == "i" else 0
+    for op, bound in (("less", low), ("greater", _NARROW_LIMIT)):
+        outside, _ = evaluate(Op(op, [Leaf(None, bits.dtype, None, values=bits), Lit(bound)], np.dtype("bool"), None, fill=False))
+        none = ctypes.c_int(0)
+        runtime.check(runtime.lib().gm_all_equal(ctypes.c_void_p(outside.ptr), code_of(outside.dtype), runtime.scalar_bits(0, outside.dtype),
+                                                 outside.size, ctypes.byref(none)), "gm_all_equal")
+        if not none.value:
+            return None
+    narrow, _ = evaluate(Op("copy", [Leaf(None, bits.dtype, None, values=bits)], np.dtype("i4"), None))
+    return narrow, (None if eff is None else np.int32(int(eff)))
+
+
 def run_expr(build, tiles, key=None):
+    """``_run_expr``; an expression that no register class can run because of a 64-bit integer tile -- a TemporalSum of an
+    integer series under a Block that still declares its store's dtype: `TemporalSum(rain) / 100` asks for
+    np.divide(int64 tile, 100, dtype=float32), whose cast of the tile to float32 comes first -- is tried again with the tile
+    as int32 when all its values lie within +-2^24: the same values, exact in every class, and NumPy's casts of them
+    (to float32, to int32) change nothing.  Tiles with larger values keep the refusal."""
+    try:
+        return _run_expr(build, tiles, key)
+    except NotImplementedError as refusal:
+        if "no exact register class" not in str(refusal):
+            raise
+        retry, changed = [], False
+        for values, ndv in tiles:
+            narrow = _narrowed(values, ndv) if hasattr(values, "dtype") and _wide_int(values.dtype) else None
+            retry.append((values, ndv) if narrow is None else narrow)
+            changed = changed or narrow is not None
+        if not changed:
+            raise
+        values, _ = _run_expr(build, retry, key)
+        # what the expression over the tiles as they came declares (a Clip hands its store's dtype and no-data value on)
+        root = build([Leaf(None, np.asarray(v).dtype if not hasattr(v, "dtype") else v.dtype, ndv, values=v) for v, ndv in tiles])
+        if values.dtype != root.dtype:
+            values, _ = evaluate(Op("copy", [Leaf(None, values.dtype, None, values=values)], root.dtype, None))
+        return values, root.ndv
+
+
+def _run_expr(build, tiles, key=None):
     """Evaluate ``build(leaves)`` over raster tiles given as (values, ndv) pairs.
 
     ``key``: a hashable description of everything ``build`` puts into the expression besides the tiles (operation,

@@ -308,6 +308,8 @@ class Group(BaseCombine):
                         merged[i] = meta
             return {"meta": merged}
         shape = kwargs["shape"]
+        if shape[0] < 0:  # (a request whose stop lies before its start: np.full(shape, ...) of combine.py:384 refuses it)
+            raise ValueError("negative dimensions are not allowed")
         if responses and all((lo, hi) == (0, shape[0]) and data["values"].shape[0] == shape[0] for data, (lo, hi) in zip(responses, ranges)):
             # every source fills every band (series on one grid over one window: the usual Group): the whole stacks are merged
             # by ONE program -- FillNoData's loop is the same paste, band by band or all at once -- instead of a program and a

@@ -362,6 +362,18 @@ def percentile_plan(q, longest, work_dtype):
     return plan
 
 
+def _sums_as_int32(src, no_data_value, kernel_statistic, dtype):
+    """The 64-bit integer frames a TemporalSum of an integer series hands on (under a dtype declared for its store:
+    temporal.py:548-602) as int32 frames -- _reduce_args of them -- when all values lie within +-2^24 and the kernels of
+    int32 frames give the declared ``dtype``: NumPy's statistics of the same numbers in either integer type are the same
+    numbers (sums in int64, means / deviations / medians in float64), and so is their cast to ``dtype``.  Else None."""
+    from ..hip import program as P
+    if not P._wide_int(src.dtype) or _lib().gm_temporal_out_dtype(_code("i4"), kernel_statistic) != _code(dtype):
+        return None
+    narrow = P._narrowed(src, no_data_value)
+    return None if narrow is None else _reduce_args(*narrow)
+
+
 def _fill_bits(statistic, dtype):
     from ..hip import runtime
     return runtime.scalar_bits(0 if statistic in _EXTENSIVE else get_dtype_max(dtype), dtype)
@@ -387,8 +399,12 @@ def aggregate_frames(values, no_data_value, runs, statistic, dtype, fill=None, k
     # (median / percentiles: a cell's data frames are sorted in LDS up to MAX_MEDIAN_FRAMES float32 / 320 float64
     #  frames per label; longer bins -- a year of hourly frames -- are selected in global memory: no limit)
     L = _lib()
-    if L.gm_temporal_out_dtype(code, STATISTIC_CODES["median" if percentile is not None else name]) != _code(dtype):
-        raise NotImplementedError("%s of a %s raster as %s" % (statistic, src.dtype, np.dtype(dtype)))
+    kernel_statistic = STATISTIC_CODES["median" if percentile is not None else name]
+    if L.gm_temporal_out_dtype(code, kernel_statistic) != _code(dtype):
+        narrow = _sums_as_int32(src, no_data_value, kernel_statistic, dtype)
+        if narrow is None:
+            raise NotImplementedError("%s of a %s raster as %s" % (statistic, src.dtype, np.dtype(dtype)))
+        src, code, has, bits, frames, height, width = narrow
     out = DeviceArray.empty((len(runs), height, width), np.dtype(dtype))
     fill_bits = _fill_bits(statistic, dtype) if fill is None else runtime.scalar_bits(fill, np.dtype(dtype))
     if percentile is not None:
@@ -413,7 +429,10 @@ def accumulate_frames(values, no_data_value, runs, emit, statistic, dtype):
     src, code, has, bits, frames, height, width = _reduce_args(values, no_data_value)
     L = _lib()
     if L.gm_temporal_out_dtype(code, STATISTIC_CODES[statistic]) != _code(dtype):
-        raise NotImplementedError("cumulative %s of a %s raster as %s" % (statistic, src.dtype, np.dtype(dtype)))
+        narrow = _sums_as_int32(src, no_data_value, STATISTIC_CODES[statistic], dtype)
+        if narrow is None:
+            raise NotImplementedError("cumulative %s of a %s raster as %s" % (statistic, src.dtype, np.dtype(dtype)))
+        src, code, has, bits, frames, height, width = narrow
     out = DeviceArray.empty((emit[1] - emit[0], height, width), np.dtype(dtype))
     runtime.check(L.gm_temporal_cumulative(src.ptr, code, has, bits, frames, height * width, _frame_bins(runs), len(runs),
                                            int(emit[0]), int(emit[1]), STATISTIC_CODES[statistic], out.ptr,
