@@ -38,7 +38,7 @@ def build(name):
     runtime.set_device(0)
     F32MAX = float(np.finfo("f4").max)
     frames, side = 8, 4096
-    if name in ("smooth40", "classify200", "maskdilate", "hillclass", "groupab", "hillmix"):
+    if name in ("smooth40", "classify200", "maskdilate", "hillclass", "groupab", "hillmix", "tilesmooth"):
         big = 16384
         A = raster.MemorySource(generate_window((big, big), "f4", 7001, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big),
                                 np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
@@ -47,6 +47,9 @@ def build(name):
         views = {"smooth40": raster.Smooth(A, 40.0), "classify200": raster.Classify(A, [float(x) / 2 for x in range(200)]),
                  "maskdilate": raster.Mask(raster.Dilate(C, [3, 5]), 1),
                  "hillclass": raster.Classify(raster.HillShade(A), [20, 50, 80, 110, 140, 170, 200, 230])}
+        if name == "tilesmooth":  # 254 tiles, tile by tile (a Smooth's tiles are not windows of the whole)
+            return raster.RasterTiler(raster.Smooth(A, 2.0), 1024), dict(mode="vals", bbox=(64.0, 64.0, big - 64.0, big - 64.0),
+                                                                         width=big - 128, height=big - 128, projection="EPSG:28992")
         if name in ("groupab", "hillmix"):
             B = raster.MemorySource(generate_window((big, big), "f4", 7002, 0.0, 100.0, F32MAX, (97, 89), 0, 0, big, big),
                                     np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
