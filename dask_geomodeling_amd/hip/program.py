@@ -1213,27 +1213,32 @@ def _tiles_key(tiles):
 _NARROW_LIMIT = 1 << 24  # whole numbers up to here are exact in every register class, float32 included
 
 
-def _narrowed(values, ndv):
-    """A 64-bit integer tile all of whose values lie within +-2^24 as an int32 tile with the same values (and its no-data
-    value, if an int32 can be equal to it); None for every other tile.  Three passes and two round trips to the host: for
-    the views this serves there was no answer at all before (see run_expr)."""
+def _narrowed(values, ndv, to="i4"):
+    """A 64-bit integer tile all of whose values lie within +-2^24 as an int32 (``to``: or float32) tile with the same values
+    and its no-data value, if an int32 can be equal to it; None for every other tile.  Three passes and two round trips to the
+    host: for the views this serves there was no answer at all before (see run_expr)."""
     if not isinstance(values, DeviceArray) or not _wide_int(values.dtype) or values.size == 0:
         return None
+    to = np.dtype(to)
+    low, high = (-_NARROW_LIMIT if values.dtype.kind == "i" else 0), _NARROW_LIMIT
+    fits = (-(1 << 31), (1 << 31) - 1)
+    if to.kind in "iu":  # (narrower targets: the minima of such sums under a declared int16 / uint16)
+        fits = (int(np.iinfo(to).min), int(np.iinfo(to).max))
+        low, high = max(low, fits[0]), min(high, fits[1])
     eff = effective_ndv(values.dtype, ndv)
-    if ndv is not None and (eff is None or not -(1 << 31) <= int(eff) < (1 << 31)):
-        return None  # (a Clip writes its store's no-data value: it has to be one an int32 tile can hold -- a TemporalSum's is)
+    if ndv is not None and (eff is None or not fits[0] <= int(eff) <= fits[1]):
+        return None  # (a Clip writes its store's no-data value: it has to be one the narrow tile can hold -- a TemporalSum's is)
     tile = values.contiguous()
     bits = DeviceArray(tile.ptr, tile.shape, np.dtype("i8"), tile.device, owner=tile)  # (uint64: in range <=> 0 <= bits <= 2^24)
-    low = -_NARROW_LIMIT if values.dtype.kind == "i" else 0
-    for op, bound in (("less", low), ("greater", _NARROW_LIMIT)):
+    for op, bound in (("less", low), ("greater", high)):
         outside, _ = evaluate(Op(op, [Leaf(None, bits.dtype, None, values=bits), Lit(bound)], np.dtype("bool"), None, fill=False))
         none = ctypes.c_int(0)
         runtime.check(runtime.lib().gm_all_equal(ctypes.c_void_p(outside.ptr), code_of(outside.dtype), runtime.scalar_bits(0, outside.dtype),
                                                  outside.size, ctypes.byref(none)), "gm_all_equal")
         if not none.value:
             return None
-    narrow, _ = evaluate(Op("copy", [Leaf(None, bits.dtype, None, values=bits)], np.dtype("i4"), None))
-    return narrow, (None if eff is None else np.int32(int(eff)))
+    narrow, _ = evaluate(Op("copy", [Leaf(None, bits.dtype, None, values=bits)], to, None))
+    return narrow, (None if eff is None else to.type(int(eff)))
 
 
 def run_expr(build, tiles, key=None):

@@ -364,14 +364,21 @@ def percentile_plan(q, longest, work_dtype):
 
 def _sums_as_int32(src, no_data_value, kernel_statistic, dtype):
     """The 64-bit integer frames a TemporalSum of an integer series hands on (under a dtype declared for its store:
-    temporal.py:548-602) as int32 frames -- _reduce_args of them -- when all values lie within +-2^24 and the kernels of
-    int32 frames give the declared ``dtype``: NumPy's statistics of the same numbers in either integer type are the same
-    numbers (sums in int64, means / deviations / medians in float64), and so is their cast to ``dtype``.  Else None."""
+    temporal.py:548-602) as int32 -- or float32 -- frames, _reduce_args of them, when all values lie within +-2^24 and the
+    kernels of such frames give the declared ``dtype``.  The reference works on values.astype(result_type(float32, dtype))
+    whatever the frames' own dtype (temporal.py:738-741), which is what the kernels derive from ``dtype`` too: the same
+    numbers in, the same statistic out.  Else None."""
     from ..hip import program as P
-    if not P._wide_int(src.dtype) or _lib().gm_temporal_out_dtype(_code("i4"), kernel_statistic) != _code(dtype):
+    if not P._wide_int(src.dtype):
         return None
-    narrow = P._narrowed(src, no_data_value)
-    return None if narrow is None else _reduce_args(*narrow)
+    for to in ("i4", "f4", "i2", "u2", "i1", "u1"):
+        if _lib().gm_temporal_out_dtype(_code(to), kernel_statistic) == _code(dtype):
+            if to == "f4" and abs(int(no_data_value if no_data_value is not None else 0)) > P._NARROW_LIMIT:
+                continue  # (a no-data value float32 would round)
+            narrow = P._narrowed(src, no_data_value, to)
+            if narrow is not None:
+                return _reduce_args(*narrow)
+    return None
 
 
 def _fill_bits(statistic, dtype):
