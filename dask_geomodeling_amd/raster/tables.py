@@ -185,6 +185,11 @@ def reclassify_process(store_data, process_kwargs):
         return store_data
     runtime.require_device()
     in_dtype = store_data["values"].dtype
+    if in_dtype == np.dtype("u8"):
+        # (the sums of an unsigned series, temporal.py:548-602: as int32 when they lie within 2^24 -- the same keys are hit)
+        narrow = P._narrowed(as_device(store_data["values"]), store_data["no_data_value"])
+        if narrow is not None:
+            return reclassify_process({"values": narrow[0], "no_data_value": narrow[1]}, process_kwargs)
     if in_dtype.kind not in "iub" or in_dtype == np.dtype("u8"):
         raise NotImplementedError("Reclassify on %s tiles is not supported on the device" % in_dtype)
     dtype = np.dtype(process_kwargs["dtype"])
