@@ -56,6 +56,9 @@ def parse_args():
     p.add_argument("--cpu-tiles", type=int, default=-1, help="tiles of the CPU baseline sample (0 = skip)")
     p.add_argument("--no-check", action="store_true", help="skip the oracle check of one tile")
     p.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block (get_data rates seen by a caller)")
+    p.add_argument("--no-secondary", action="store_true",
+                   help="skip the `secondary` block of the headline run (BASELINE configs[2], [3], [4] clocked in the same run)")
+    p.add_argument("--secondary-steps", type=int, default=20)
     p.add_argument("--leaves", default="owned", choices=["owned", "whole", "procedural"],
                    help="mosaic leaves: owned = every rank keeps the leaf windows of the tiles it owns resident "
                         "(4 x 16 GiB / N per GPU, generated on the owning GPU during warm-up); whole = every rank "
@@ -433,8 +436,187 @@ def spawn_ranks(n):
     return 0
 
 
+# the dominant kernel of every workload: tiles per launch, algorithmic bytes per OUTPUT pixel (SURVEY 8d / DESIGN
+# section 4), arithmetic type, and its name when the program is interpreted
+MODEL = {"chain5": (16, 12, "f32", "gmvm::vm_kernel<float, 2, 2, 1, 0>"),
+         "reclass": (16, 5, "i32", "lookup32_kernel_w4<1>"),
+         "bilinear": (1, 5, "f64", "bilinear2x_kernel<16, 512, 256, false, true, false>"),
+         "mosaic": (16, 17, "f32", "gmvm::vm_kernel<float, 2, 4, 2, 2>"),
+         "tiler": (16, 12, "f32", "gmvm::vm_kernel<float, 2, 2, 1, 0>")}
+DEFAULTS = {"chain5": (4096, 16), "reclass": (8192, 4), "bilinear": (16384, 1), "mosaic": (4096, 0), "tiler": (16384, 1)}
+
+
+def warm_up(step, warmup, runtime, P, min_busy_s=0.2):
+    """W untimed warm-up steps -- and, when those are shorter than that, keep stepping until the GPU has been busy for
+    200 ms, so that the clocks have left their idle state before the timed region (a 20-step timed region is only ~10 ms
+    long; hot programs also get their specialised kernels here: csrc/gm_spec.hip, ~1 s of compilation on the first step
+    that finds a program hot) -- then wait for kernels still being compiled and step until they have taken over."""
+    done, t_busy = 0, None
+    while done < warmup or (min_busy_s and (t_busy is None or time.perf_counter() - t_busy < min_busy_s)):
+        if t_busy is None and done >= 1:
+            t_busy = time.perf_counter()  # the first step may have compiled: the busy period starts after it
+        step()
+        done += 1
+        if done % 8 == 0:
+            runtime.sync()
+    if P is not None and P.spec_pending():
+        P.spec_wait()
+        for _ in range(3):
+            step()
+
+
+def secondary_line(name, raster, runtime, P, get_sync, steps, warmup):
+    """One of BASELINE.json's other GPU configs, clocked in the same process as the headline, the same way: `steps` steps
+    after a warm-up, HIP events on the compute stream around the timed region, no host sync in between."""
+    side, tiles = DEFAULTS[name]
+    jobs = build_reclass(raster, side, tiles, 0) if name == "reclass" else build_bilinear(raster, side, tiles, 0)
+    runtime.sync()
+
+    def step():
+        for graph, names in jobs:
+            get_sync(graph, names)
+
+    warm_up(step, warmup, runtime, P)
+    runtime.sync()
+    spec_before = P.spec_stats()["launches"]
+    e0, e1 = runtime.Event(), runtime.Event()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    runtime.sync()
+    elapsed = time.perf_counter() - t0
+    spec_launches = P.spec_stats()["launches"] - spec_before
+    out_side = 2 * side if name == "bilinear" else side
+    per_launch, bytes_px, dtype, kernel = MODEL[name]
+    tiles_per_launch = min(tiles, per_launch)
+    launches = (tiles + tiles_per_launch - 1) // tiles_per_launch
+    if spec_launches >= steps * launches:
+        kernel = P.spec_last_kernel() + " (specialised per program by csrc/gm_spec.hip)"
+    launch_us = e0.elapsed_ms(e1) / (steps * launches) * 1e3
+    launch_bytes = bytes_px * out_side * out_side * tiles_per_launch
+    traffic, traffic_src = pmc_traffic(name, tiles_per_launch)
+    del jobs
+    return {"workload": {"reclass": "BASELINE configs[2]: Mask(Reclassify(int32 tile, 128 pairs), 1) on %d tiles of %dx%d in one launch"
+                                     % (tiles, side, side),
+                         "bilinear": "BASELINE configs[3]: bilinear 2x upsample %dx%d -> %dx%d f32" % (side, side, out_side, out_side)}[name],
+            "value": round(tiles * out_side * out_side * steps / elapsed / 1e6, 1), "unit": "Mpix/s", "steps": steps,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "avg_launch_us": round(launch_us, 2),
+            "wall_us_per_launch": round(elapsed / (steps * launches) * 1e6, 2), "launches_per_step": launches,
+            "dtype": dtype, "bytes_per_px": bytes_px, "algorithmic_bytes_per_launch": launch_bytes,
+            "achieved_GBps": round(launch_bytes / launch_us / 1e3, 1), "frac": round(launch_bytes / launch_us / 1e3 / HBM_PEAK_GBS, 4),
+            "kernel": kernel, "traffic": traffic, "traffic_source": traffic_src}
+
+
+def mosaic_through_the_scheduler(devices, side, steps, warmup, leaves, e2e=True):
+    """BASELINE configs[4] through the PRODUCT's one-worker-per-GPU scheduler (dask_geomodeling_amd/shard.py): this process
+    only deals -- RasterTiler(view, side).get_data over the whole 65536^2 box with geomodeling.devices = `devices`, results left
+    on the GPUs that computed them --, every worker process fuses and runs the tiles t % G it owns and keeps the leaf windows
+    of those tiles resident.  A step = one such request; it returns when every worker's stream is empty.  -> result fields."""
+    from dask_geomodeling_amd import raster, shard
+    G = len(devices)
+    tiler = raster.RasterTiler(mosaic_view(raster, leaves), side)
+    whole = dict(mode="vals", bbox=(0.0, 0.0, float(MOSAIC_SIDE), float(MOSAIC_SIDE)), width=MOSAIC_SIDE,
+                 height=MOSAIC_SIDE, projection="EPSG:28992")
+    pool = shard.pool_for(devices)
+
+    def step():
+        shard.get_data(tiler, whole, devices, materialize=False)  # (the handle is dropped: the workers free the tiles)
+        return max(ms for ms in pool.last_device_ms.values() if ms is not None)
+
+    t_busy = None
+    done = 0
+    while done < warmup or t_busy is None or time.perf_counter() - t_busy < 0.3:
+        if t_busy is None and done >= 1:
+            t_busy = time.perf_counter()
+        step()
+        done += 1
+    spec = pool.request({w: ("spec_wait",) for w in range(G)}, what="waiting for specialised kernels")
+    for _ in range(3):
+        step()
+    before = pool.request({w: ("spec_wait",) for w in range(G)}, what="kernel statistics")
+    device_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        device_ms += step()
+    elapsed = time.perf_counter() - t0
+    spec = pool.request({w: ("spec_wait",) for w in range(G)}, what="kernel statistics")
+    n_tiles = (MOSAIC_SIDE // side) ** 2
+    per_worker = (n_tiles + G - 1) // G
+    per_launch, bytes_px, dtype, kernel = MODEL["mosaic"]
+    tiles_per_launch = min(per_worker, per_launch)
+    launches = (per_worker + tiles_per_launch - 1) // tiles_per_launch   # of the busiest worker, per step
+    if all(spec[w]["launches"] - before[w]["launches"] >= steps * launches for w in range(G)):
+        kernel = spec[0]["kernel"] + " (specialised per program by csrc/gm_spec.hip)"
+    launch_us = device_ms / (steps * launches) * 1e3
+    launch_bytes = bytes_px * side * side * tiles_per_launch
+    traffic, traffic_src = pmc_traffic("mosaic", tiles_per_launch)
+    out = {"workload": "BASELINE configs[4]: 10-Block view over the 65536^2 mosaic, %d tiles of %dx%d dealt t %% %d over %d worker "
+                       "process(es) by dask_geomodeling_amd.shard (leaves '%s'), results left on the devices"
+                       % (n_tiles, side, side, G, G, leaves),
+           "value": round(MOSAIC_SIDE * MOSAIC_SIDE * steps / elapsed / 1e6, 1), "unit": "Mpix/s", "steps": steps,
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "device_ms_per_step": round(device_ms / steps, 4),
+           "avg_launch_us": round(launch_us, 2), "launches_per_step_per_worker": launches, "tiles_per_worker": per_worker,
+           "dtype": dtype, "bytes_per_px": bytes_px, "algorithmic_bytes_per_launch": launch_bytes,
+           "achieved_GBps": round(launch_bytes / launch_us / 1e3, 1), "frac": round(launch_bytes / launch_us / 1e3 / HBM_PEAK_GBS, 4),
+           "kernel": kernel, "traffic": traffic, "traffic_source": traffic_src, "workers": G,
+           "worker_devices": pool.device_names}
+    if e2e:
+        # what an ndarray-returning caller gets: the 4 GiB uint8 mosaic assembled on the host, every worker copying its tiles
+        # device-to-host straight to their place of a shared-memory mosaic it has pinned (the first request pins)
+        timings = []
+        for _ in range(2):
+            t1 = time.perf_counter()
+            got = shard.get_data(tiler, whole, devices, materialize=True)
+            timings.append(round((time.perf_counter() - t1) * 1e3, 1))
+            shape = tuple(got["values"].shape)
+            del got
+        out["to_host_ms"] = {"first_request": timings[0], "second_request": timings[1], "shape": shape,
+                             "GBps_second": round(MOSAIC_SIDE ** 2 / timings[1] / 1e6, 1)}
+    return out
+
+
+def main_mosaic(args):
+    """`--workload mosaic`: the product's scheduler is what runs (and what is timed): this process is the parent of one worker
+    per GPU and never touches a GPU itself.  Under a launcher (WORLD_SIZE set: one rank per GPU already) rank 0 is that parent
+    and the other ranks have nothing to do."""
+    if int(os.environ.get("RANK", "0")) != 0:
+        return 0
+    if args.dry_run:
+        raise SystemExit("bench: --workload mosaic runs the real scheduler; its CPU coverage is tests/test_shard_cpu.py")
+    side = args.side or 4096
+    leaves = "procedural" if args.procedural else args.leaves
+    devices = tuple(range(max(args.gpus, 1)))
+    from dask_geomodeling_amd import shard
+    try:
+        line = mosaic_through_the_scheduler(devices, side, args.steps, args.warmup, leaves, e2e=not args.no_e2e)
+    finally:
+        shard.shutdown()
+    out = {"metric": "Mpix/s, workload mosaic", "value": line["value"], "unit": "Mpix/s", "n_gpus": len(devices),
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": line["ms_per_step"], "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": line["dtype"], "data": "synthetic",
+           "config": {"workload": line["workload"], "name": "mosaic", "tile": [side, side],
+                      "tiles_per_gpu": line["tiles_per_worker"], "tiles_per_launch": min(line["tiles_per_worker"], 16),
+                      "bytes_per_px": line["bytes_per_px"],
+                      "parallelism": "dask_geomodeling_amd.shard: tiles dealt t % G, one worker process per GPU, no collective"},
+           "roofline": {"bound": "hbm", "achieved": line["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": line["frac"], "traffic": line["traffic"], "traffic_source": line["traffic_source"],
+                        "kernel": line["kernel"], "algorithmic_bytes_per_launch": line["algorithmic_bytes_per_launch"],
+                        "avg_launch_us": line["avg_launch_us"], "launches_per_step": line["launches_per_step_per_worker"],
+                        "kernel_source_hash": kernel_source_hash()},
+           "pct_of_hbm_roofline": round(100.0 * line["value"] * 1e6 * line["bytes_per_px"] / len(devices) / (HBM_PEAK_GBS * 1e9), 2),
+           "device_ms_per_step": line["device_ms_per_step"], "worker_devices": line["worker_devices"]}
+    if "to_host_ms" in line:
+        out["end_to_end"] = {"sharded_get_data_to_host": line["to_host_ms"]}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     args = parse_args()
+    if args.workload == "mosaic":
+        raise SystemExit(main_mosaic(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -465,10 +647,8 @@ def main():
     if os.environ.get("GM_BENCH_FAIL_RANK") == str(rank):  # harness test: this rank dies before its first barrier
         raise SystemExit("bench: rank %d fails on purpose (GM_BENCH_FAIL_RANK)" % rank)
 
-    defaults = {"chain5": (4096, 16), "reclass": (8192, 4), "bilinear": (16384, 1), "mosaic": (4096, 0),
-                "tiler": (16384, 1)}
-    side = args.side or defaults[args.workload][0]
-    tiles = args.tiles or defaults[args.workload][1]
+    side = args.side or DEFAULTS[args.workload][0]
+    tiles = args.tiles or DEFAULTS[args.workload][1]
     if args.workload != "chain5":
         args.no_check = True
     P = None
@@ -512,29 +692,13 @@ def main():
             jobs = build_reclass(raster, side, tiles, rank)
         elif args.workload == "bilinear":
             jobs = build_bilinear(raster, side, tiles, rank)
-        elif args.workload == "tiler":
-            jobs = build_tiler(raster, side, 4096, rank)
         else:
-            jobs, n_mosaic_tiles = build_mosaic(raster, side, rank, world, leaves="procedural" if args.procedural else args.leaves)
-            tiles = len(jobs[0][1])
+            jobs = build_tiler(raster, side, 4096, rank)
         runtime.sync()
 
         def step():
             for graph, names in jobs:
                 get_sync(graph, names)  # result DeviceArrays are dropped -> buffers return to the pool
-
-    # W untimed warm-up steps -- and, when those are shorter than that, keep stepping until the GPU
-    # has been busy for 200 ms, so that the clocks have left their idle state before the timed region
-    # (a 20-step timed region is only ~10 ms long; hot programs also get their specialised kernels here:
-    # csrc/gm_spec.hip, ~1 s of compilation on the first step that finds a program hot)
-    t_warm, done, t_busy = time.perf_counter(), 0, None
-    while done < args.warmup or (not args.dry_run and (t_busy is None or time.perf_counter() - t_busy < 0.2)):
-        if t_busy is None and done >= 1:
-            t_busy = time.perf_counter()  # the first step may have compiled: the busy period starts after it
-        step()
-        done += 1
-        if done % 8 == 0:
-            runtime.sync()
 
     def barrier():
         runtime.sync()
@@ -542,12 +706,7 @@ def main():
             dist.barrier()
         runtime.sync()
 
-    if P is not None and P.spec_pending():
-        # hot programs are compiled on the library's worker thread while the interpreter keeps serving them: the
-        # timed region is to run the kernels it is meant to time, so wait for them and step until they have taken over
-        P.spec_wait()
-        for _ in range(3):
-            step()
+    warm_up(step, args.warmup, runtime, P, min_busy_s=0.0 if args.dry_run else 0.2)
     barrier()
     spec_before = P.spec_stats()["launches"] if P is not None else 0
     e0, e1 = runtime.Event(), runtime.Event()
@@ -561,18 +720,12 @@ def main():
     e1.synchronize()
     spec_launches = (P.spec_stats()["launches"] - spec_before) if P is not None else 0
 
-    # the dominant kernel of every workload: tiles per launch, output pixels per tile, algorithmic bytes per
-    # OUTPUT pixel (SURVEY 8d / DESIGN section 4) and its name when the program is interpreted
     out_side = 2 * side if args.workload == "bilinear" else side
     if args.workload == "tiler":
         tile_px, n_tiles_step = 4096 * 4096, (side // 4096) ** 2
     else:
         tile_px, n_tiles_step = out_side * out_side, tiles
-    model = {"chain5": (16, 12, "f32", "gmvm::vm_kernel<float, 2, 2, 1, 0>"),
-             "reclass": (16, 5, "i32", "lookup32_kernel_w4<1>"),
-             "bilinear": (1, 5, "f64", "bilinear2x_kernel<16, 512, 256, false, true, false>"),
-             "mosaic": (16, 17, "f32", "gmvm::vm_kernel<float, 2, 4, 2, 2>"),
-             "tiler": (16, 12, "f32", "gmvm::vm_kernel<float, 2, 2, 1, 0>")}[args.workload]
+    model = MODEL[args.workload]
     tiles_per_launch = min(n_tiles_step, model[0])
     launches_per_step = (n_tiles_step + tiles_per_launch - 1) // tiles_per_launch
     bytes_px, dtype, kernel = model[1], model[2], model[3]
@@ -616,10 +769,7 @@ def main():
         per_rank = sorted((int(g[0].item()), float(g[1].item())) for g in gathered)
 
     if rank == 0:
-        if args.workload == "mosaic":
-            px_per_step, scaling = MOSAIC_SIDE * MOSAIC_SIDE, "strong"  # all ranks together cover the mosaic once per step
-        else:
-            px_per_step, scaling = world * n_tiles_step * tile_px, "weak"
+        px_per_step, scaling = world * n_tiles_step * tile_px, "weak"
         value = px_per_step * args.steps / elapsed / 1e6
         launch_bytes = bytes_px * tile_px * tiles_per_launch
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
@@ -630,9 +780,6 @@ def main():
             "reclass": "Mask(Reclassify(int32 tile, 128 pairs), 1) on %dx%d tiles (BASELINE configs[2]), %d tiles per "
                        "GPU per step in one launch" % (side, side, tiles),
             "bilinear": "bilinear 2x upsample %dx%d -> %dx%d f32 (BASELINE configs[3])" % (side, side, out_side, out_side),
-            "mosaic": "10-Block view over the 65536^2 mosaic (BASELINE configs[4]): %d tiles of %dx%d per GPU per step, "
-                      "leaves '%s', one float32 program per tile (4 leaves in, uint8 out)"
-                      % (tiles, side, side, "procedural" if args.procedural else args.leaves),
             "tiler": "canonical chain under RasterTiler(4096) over two resident %dx%d sources: zero-copy windows in, "
                      "mosaic written in place" % (side, side)}
         out = {
@@ -655,7 +802,7 @@ def main():
             "pct_of_hbm_roofline": round(100.0 * value * 1e6 * bytes_px / world / (HBM_PEAK_GBS * 1e9), 2),
         }
         if per_rank is not None:
-            rank_px = px_per_step / world if args.workload != "mosaic" else None
+            rank_px = px_per_step / world
             out["ranks_reported"] = len(per_rank)
             out["per_rank"] = [{"rank": r, "ms_per_step": round(t / args.steps * 1e3, 4),
                                 "Mpix/s": None if rank_px is None else round(rank_px * args.steps / t / 1e6, 1)}
@@ -669,27 +816,26 @@ def main():
             if not args.no_e2e:
                 del jobs
                 out["end_to_end"] = end_to_end(raster, runtime, side)
-        if args.workload == "mosaic" and world == 1 and not args.no_e2e:
-            # what a caller sees: RasterTiler(view, 4096).get_data over the whole 65536^2 request (256 tiles), result
-            # left on the device -- through the view's cached plan, and building + fusing the graph per request
-            from dask_geomodeling_amd import config as gmconfig
-            tiler = raster.RasterTiler(mosaic_view(raster, "procedural" if args.procedural else args.leaves), side)
-            whole = dict(mode="vals", bbox=(0.0, 0.0, float(MOSAIC_SIDE), float(MOSAIC_SIDE)), width=MOSAIC_SIDE,
-                         height=MOSAIC_SIDE, projection="EPSG:28992")
-            e2e = {}
-            for label, plans in (("plans", True), ("graph_per_request", False)):
-                with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": plans}):
-                    tiler.get_data(**whole)
-                    runtime.sync()
-                    t1, calls = time.perf_counter(), 0
-                    while calls < 3 or time.perf_counter() - t1 < 1.0:
-                        tiler.get_data(**whole)
-                        calls += 1
-                    runtime.sync()
-                    dt = (time.perf_counter() - t1) / calls
-                e2e["tiler_get_data_device_" + label] = {"Mpix/s": round(MOSAIC_SIDE ** 2 / dt / 1e6, 1),
-                                                         "ms_per_request": round(dt * 1e3, 2), "requests": calls, "tiles": tiles}
-            out["end_to_end"] = e2e
+        if args.workload == "chain5" and world == 1 and not args.dry_run and not args.no_secondary:
+            # BASELINE.json's other GPU configs, clocked in this very run (20 steps each, the headline's way): configs[2]
+            # and [3] in this process, configs[4] through the product's one-worker-per-GPU scheduler (one worker: this GPU)
+            try:
+                del jobs
+            except NameError:
+                pass
+            runtime.sync()
+            runtime.pool_trim()
+            secondary = {}
+            for name in ("reclass", "bilinear"):
+                secondary[name] = secondary_line(name, raster, runtime, P, get_sync, args.secondary_steps, 3)
+                runtime.sync()
+                runtime.pool_trim()
+            from dask_geomodeling_amd import shard
+            try:
+                secondary["mosaic"] = mosaic_through_the_scheduler((0,), 4096, args.secondary_steps, 3, "owned", e2e=not args.no_e2e)
+            finally:
+                shard.shutdown()
+            out["secondary"] = secondary
         print(json.dumps(out), flush=True)
 
     if dist is not None:

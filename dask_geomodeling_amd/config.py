@@ -10,7 +10,11 @@ besides the reference's own keys this path adds:
   geomodeling.templates    the fused graph of a request is made from the view's template instead of built and fused
                            from scratch (default True; template.py)
   geomodeling.materialize  get_data() returns ndarrays (True) or DeviceArrays (False)
-  geomodeling.device       HIP device index used by this process/thread (default: current)
+  geomodeling.devices      None: evaluate in this process, on its current device.  A list of HIP device indices (or "all"):
+                           get_data() / compute() hand the work to one worker process per listed GPU (shard.py) -- the
+                           tiles of a RasterTiler are dealt t % G over them, the host mosaic is assembled from their tiles
+  geomodeling.worker-preload  "module:function" every such worker imports and calls before it binds its device (a
+                           deployment's own Blocks)
   geomodeling.resident-window-bytes  bound of the per-device window cache of resident SyntheticSources (LRU)
 """
 import os
@@ -31,7 +35,8 @@ defaults = {
     "plans": True,
     "templates": True,
     "materialize": True,
-    "device": None,
+    "devices": None,
+    "worker-preload": None,
     "resident-window-bytes": 192 << 30,
 }
 

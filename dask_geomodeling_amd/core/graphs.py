@@ -237,12 +237,20 @@ def get_sync(dsk, keys, pack_exception=None, **kwargs):
     return evaluate(keys)
 
 
-def compute(graph, name, *args, **kwargs):
-    """Evaluate ``graph[name]`` with the configured scheduler (graphs.py:42-49)."""
+def _configured_get():
+    """The scheduler ``compute`` hands a graph to (graphs.py:42-49): dask's configured one; else ``scheduler_get``; else --
+    when ``geomodeling.devices`` lists devices -- the one-worker-per-GPU scheduler (shard.get); else the built-in one."""
     get = _dask_get_scheduler() if _dask_get_scheduler is not None else None
     if get is None:
-        get = _config.get("scheduler_get") or get_sync
-    return get(graph, [name])[0]
+        get = _config.get("scheduler_get")
+    if get is None and _config.get("geomodeling.devices"):
+        from ..shard import get
+    return get or get_sync
+
+
+def compute(graph, name, *args, **kwargs):
+    """Evaluate ``graph[name]`` with the configured scheduler (graphs.py:42-49)."""
+    return _configured_get()(graph, [name])[0]
 
 
 def get_data_many(blocks, requests):
@@ -257,12 +265,11 @@ def get_data_many(blocks, requests):
     for block, request in zip(blocks, requests):
         graph, name = block.get_compute_graph(cached_compute_graph=graph, **request)
         names.append(name)
-    if _config.get("geomodeling.fuse", True):
+    get = _configured_get()
+    if _config.get("geomodeling.fuse", True) and getattr(get, "__module__", "") != "dask_geomodeling_amd.shard":
+        # (the sharded scheduler's workers fuse the part of the graph they are dealt)
         from ..fuse import fuse_graph
         graph = fuse_graph(graph, names)
-    get = _dask_get_scheduler() if _dask_get_scheduler is not None else None
-    if get is None:
-        get = _config.get("scheduler_get") or get_sync
     results = list(get(graph, names))
     if _config.get("geomodeling.materialize", True):
         from ..fuse import materialize
@@ -352,6 +359,11 @@ class Block(object):
     def get_data(self, **request):
         """Evaluate the request.  Element-wise sub-graphs are fused into single HIP
         launches first; the result is handed back as host ndarrays."""
+        if _config.get("geomodeling.devices"):
+            # one worker process per GPU (shard.py): a RasterTiler deals its tiles over them, the result is assembled here
+            from .. import shard
+            if shard.sharded_here():
+                return shard.get_data(self, request)
         from ..plan import evaluate
         planned, result = evaluate(self, request)  # a cached plan of this view, if it has one (plan.py)
         if not planned:

@@ -9,6 +9,9 @@
 
 #include <cstdlib>
 
+#include <pthread.h>
+#include <unistd.h>
+
 #include "gm_common.h"
 
 namespace gm {
@@ -89,6 +92,28 @@ static DeviceState g_dev[kMaxDevices];
 static std::mutex g_init_mu;
 static int g_ndev = -1;
 
+// fork(): the child inherits this library's tables (streams, pools, the device count) but no usable HIP runtime -- its
+// first kernel launch or copy would hang or crash somewhere inside the driver.  A child forked after the parent probed
+// for devices is therefore marked, and every runtime entry point answers GM_ERR_FORKED in it.  (dask's `processes`
+// scheduler forks its workers by default: core/graphs.py:42-49 hands the graph to whatever get_scheduler() returns.)
+static std::atomic<bool> g_forked{false};
+static int g_parent_pid = 0;
+static void mark_forked_child() {
+  if (g_ndev >= 0) {
+    g_parent_pid = (int)getppid();
+    g_forked.store(true, std::memory_order_release);
+  }
+}
+struct ForkMark {
+  ForkMark() { pthread_atfork(nullptr, nullptr, mark_forked_child); }
+} g_fork_mark;
+static inline bool forked() { return g_forked.load(std::memory_order_acquire); }
+static int forked_fail() {
+  return fail(GM_ERR_FORKED, "forked after gm_init: process %d is a fork() of %d, which had entered libgmhip; a HIP runtime does "
+              "not survive fork() -- start workers with spawn (dask_geomodeling_amd.shard starts one fresh process per GPU)",
+              (int)getpid(), g_parent_pid);
+}
+
 static int probe_devices() {
   std::lock_guard<std::mutex> lk(g_init_mu);
   if (g_ndev >= 0) return g_ndev;
@@ -103,8 +128,14 @@ static int probe_devices() {
   return n;
 }
 
-static int ensure_device(int dev, DeviceState** out) {
+static int usable() {
+  if (forked()) return forked_fail();
   if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  return GM_OK;
+}
+
+static int ensure_device(int dev, DeviceState** out) {
+  if (int rc = usable()) return rc;
   if (dev < 0 || dev >= g_ndev) return fail(GM_ERR_INVALID, "device %d out of range (0..%d)", dev, g_ndev - 1);
   DeviceState& d = g_dev[dev];
   std::lock_guard<std::mutex> lk(d.mu);
@@ -128,7 +159,7 @@ static std::atomic<int> g_process_dev{-1};
 static thread_local int t_bound_dev = -1;
 
 static int current(DeviceState** out) {
-  if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  if (int rc = usable()) return rc;
   int want = g_process_dev.load(std::memory_order_acquire);
   if (want >= 0 && t_bound_dev != want) {
     GM_HIP(hipSetDevice(want));
@@ -169,15 +200,21 @@ using namespace gm;
 extern "C" {
 
 int gm_init(void) {
-  if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  if (int rc = usable()) return rc;
   DeviceState* d = nullptr;
   return current(&d);
 }
 
-int gm_device_count(void) { return probe_devices(); }
+int gm_device_count(void) {
+  if (forked()) {
+    (void)forked_fail();  // (never fails: 0 devices, and gm_last_error() says why)
+    return 0;
+  }
+  return probe_devices();
+}
 
 int gm_set_device(int device) {
-  if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  if (int rc = usable()) return rc;
   if (device < 0 || device >= g_ndev) return fail(GM_ERR_INVALID, "device %d out of range", device);
   GM_HIP(hipSetDevice(device));
   g_process_dev.store(device, std::memory_order_release);
@@ -188,7 +225,7 @@ int gm_set_device(int device) {
 
 int gm_get_device(int* device) {
   if (!device) return fail(GM_ERR_INVALID, "null pointer");
-  if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  if (int rc = usable()) return rc;
   DeviceState* d = nullptr;
   int rc = current(&d);
   if (rc) return rc;
@@ -279,7 +316,7 @@ constexpr size_t kHostCacheLimit = 8ull << 30;
 
 int gm_host_malloc(void** ptr, size_t bytes) {
   if (!ptr) return fail(GM_ERR_INVALID, "null pointer");
-  if (probe_devices() <= 0) return fail(GM_ERR_NO_DEVICE, "no HIP device visible");
+  if (int rc = usable()) return rc;
   const size_t sz = round_size(bytes);
   std::lock_guard<std::mutex> lk(g_host_mu);
   auto it = g_host_cached.find(sz);
@@ -309,6 +346,7 @@ int gm_host_free(void* ptr) {
   if (it == g_host_live.end()) return fail(GM_ERR_INVALID, "gm_host_free: pointer %p not allocated by gm_host_malloc", ptr);
   const size_t sz = it->second;
   g_host_live.erase(it);
+  if (forked()) return GM_OK;  // (the parent's buffer: nothing of the runtime is touched in a forked child)
   if (g_host_cached_bytes + sz > kHostCacheLimit) {
     (void)hipHostFree(ptr);
   } else {
@@ -369,6 +407,38 @@ int gm_d2h(void* dst_host, const void* src_dev, size_t bytes) {
   return GM_OK;
 }
 
+int gm_d2h_2d(void* dst_host, size_t dst_pitch_bytes, const void* src_dev, size_t src_pitch_bytes, size_t width_bytes,
+              size_t rows) {
+  if (!dst_host || !src_dev) return fail(GM_ERR_INVALID, "null pointer");
+  if (width_bytes == 0 || rows == 0) return GM_OK;
+  if (width_bytes > dst_pitch_bytes || width_bytes > src_pitch_bytes)
+    return fail(GM_ERR_INVALID, "gm_d2h_2d: rows of %zu bytes in pitches of %zu / %zu", width_bytes, dst_pitch_bytes, src_pitch_bytes);
+  hipStream_t s = current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  if (width_bytes == dst_pitch_bytes && width_bytes == src_pitch_bytes)
+    GM_HIP(hipMemcpyAsync(dst_host, src_dev, width_bytes * rows, hipMemcpyDeviceToHost, s));
+  else
+    GM_HIP(hipMemcpy2DAsync(dst_host, dst_pitch_bytes, src_dev, src_pitch_bytes, width_bytes, rows, hipMemcpyDeviceToHost, s));
+  return GM_OK;
+}
+
+int gm_host_register(void* ptr, size_t bytes) {
+  if (!ptr || bytes == 0) return fail(GM_ERR_INVALID, "gm_host_register: empty range");
+  DeviceState* d = nullptr;
+  if (int rc = current(&d)) return rc;
+  GM_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return GM_OK;
+}
+
+int gm_host_unregister(void* ptr) {
+  if (!ptr || forked()) return GM_OK;
+  DeviceState* d = nullptr;
+  if (int rc = current(&d)) return rc;
+  GM_HIP(hipStreamSynchronize(d->stream));  // (copies into the range may still be in flight)
+  GM_HIP(hipHostUnregister(ptr));
+  return GM_OK;
+}
+
 int gm_d2d(void* dst_dev, const void* src_dev, size_t bytes) {
   if (bytes == 0) return GM_OK;
   hipStream_t s = current_stream();
@@ -402,7 +472,7 @@ int gm_event_create(void** event) {
 }
 
 int gm_event_destroy(void* event) {
-  if (!event) return GM_OK;
+  if (!event || forked()) return GM_OK;
   GM_HIP(hipEventDestroy((hipEvent_t)event));
   return GM_OK;
 }
@@ -415,12 +485,14 @@ int gm_event_record(void* event) {
 }
 
 int gm_event_sync(void* event) {
+  if (forked()) return forked_fail();
   GM_HIP(hipEventSynchronize((hipEvent_t)event));
   return GM_OK;
 }
 
 int gm_event_elapsed_ms(void* start, void* stop, float* ms) {
   if (!ms) return fail(GM_ERR_INVALID, "null pointer");
+  if (forked()) return forked_fail();
   GM_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
   return GM_OK;
 }

@@ -82,6 +82,7 @@ def _declare(L):
         "gm_pool_stats": [c.POINTER(sz), c.POINTER(sz)],
         "gm_h2d": [vp, vp, sz], "gm_d2h": [vp, vp, sz], "gm_d2d": [vp, vp, sz],
         "gm_host_malloc": [c.POINTER(vp), sz], "gm_host_free": [vp],
+        "gm_host_register": [vp, sz], "gm_host_unregister": [vp], "gm_d2h_2d": [vp, sz, vp, sz, sz, sz],
         "gm_memset": [vp, i32, sz], "gm_sync": [],
         "gm_event_create": [c.POINTER(vp)], "gm_event_destroy": [vp], "gm_event_record": [vp],
         "gm_event_sync": [vp], "gm_event_elapsed_ms": [vp, vp, c.POINTER(c.c_float)],
@@ -111,6 +112,9 @@ def device_count():
 
 def require_device():
     if device_count() <= 0:
+        why = lib().gm_last_error().decode("utf-8", "replace")
+        if why.startswith("forked after gm_init"):  # a fork() of a process that had entered the library (GM_ERR_FORKED)
+            raise GmHipError(why)
         raise GmHipError("no HIP device visible: the raster compute path needs an MI355X "
                          "(there is no CPU fallback)")
 

@@ -1,0 +1,313 @@
+"""The worker side of dask_geomodeling_amd.shard: one process, one GPU.
+
+    python -m dask_geomodeling_amd.shard_worker <fd of the socket to the parent>
+
+A fresh interpreter (the parent starts it with fork + exec before anything of HIP exists in it).  It binds itself to its
+device once (gm_set_device), then serves messages until the socket closes: build and fuse the sub-graphs of its units
+(fuse.fuse_graph -- what the reference's ``compute`` does for the whole graph, core/graphs.py:42-49), run them, keep the
+results on the device until they are fetched or released, copy fetched tiles device-to-host straight to their place of
+the parent's shared-memory mosaic (``values[:, rows, columns] = tile``, raster/parallelize.py:118-124).  Jobs stay --
+with their compiled programs, specialised kernels and resident leaf windows -- so that the same request costs one small
+message the second time.
+"""
+import ctypes
+import io
+import mmap
+import os
+import pickle
+import sys
+import traceback
+import zlib
+
+import numpy as np
+
+
+class _State(object):
+    def __init__(self):
+        self.index = self.device = None
+        self.on_device = False
+        self.arrays = {}     # shared-memory name -> (mmap, ndarray): the large arrays of views and graphs
+        self.ranges = {}     # shared-memory name -> (mmap, address, pinned?): result mosaics of the parent
+        self.jobs = {}       # job id -> prepared job
+        self.results = {}    # run id -> [response per unit]
+        self.device_ms = None  # HIP-event time of the last run on the compute stream
+
+
+STATE = _State()
+
+
+class _Unpickler(pickle.Unpickler):
+    def persistent_load(self, pid):
+        kind = pid[0]
+        if kind == "gm-array":
+            _, name, size, dtype, shape = pid
+            hit = STATE.arrays.get(name)
+            if hit is None:
+                fd = os.open(os.path.join("/dev/shm", name), os.O_RDONLY)
+                try:
+                    m = mmap.mmap(fd, max(size, 1), access=mmap.ACCESS_READ)
+                finally:
+                    os.close(fd)
+                count = int(np.prod(shape, dtype=np.int64))
+                hit = STATE.arrays[name] = (m, np.frombuffer(m, dtype=dtype, count=count).reshape(shape))
+            return hit[1]  # (the same object every time: what the per-device upload of a source is remembered by)
+        if kind == "gm-small-device-array":
+            return pid[1]
+        raise pickle.UnpicklingError("unknown persistent id %r" % (kind,))
+
+
+def _loads(data):
+    return _Unpickler(io.BytesIO(data)).load()
+
+
+def _init(settings):
+    for p in settings.get("path") or ():
+        if p not in sys.path:
+            sys.path.append(p)
+    STATE.index, STATE.device = settings["index"], settings["device"]
+    from . import config as _config
+    values = dict(settings.get("config") or {})
+    values.update({"geomodeling.devices": None, "geomodeling.materialize": False})
+    _config.config.set(values)
+    preload = settings.get("preload")
+    if preload:
+        # "module:function", called before the device is bound (dask's worker preload): what a deployment uses to import its
+        # own Blocks -- and the CPU test suite to plug its NumPy double of the device in
+        module, _, function = preload.partition(":")
+        hook = __import__(module, fromlist=["_"])
+        if function:
+            getattr(hook, function)()
+    from .hip import runtime
+    if runtime.device_count() > 0:
+        runtime.set_device(int(STATE.device))
+        STATE.on_device = True
+        return runtime.device_name()
+    if not preload:
+        raise runtime.GmHipError("no HIP device visible in the worker for device %s (there is no CPU fallback)" % (STATE.device,))
+    return None
+
+
+def _meta(response):
+    if response is None:
+        return None
+    if isinstance(response, dict) and "values" in response:
+        values = response["values"]
+        if hasattr(values, "shape") and hasattr(values, "dtype"):
+            ndv = response.get("no_data_value")
+            return ("raster", tuple(int(s) for s in values.shape), np.dtype(values.dtype).str, ndv)
+    return ("object", response)
+
+
+def _prepare(spec):
+    from . import config as _config
+    from .core.graphs import get_sync
+    from .fuse import fuse_graph
+    kind = spec[0]
+    fuse = bool(_config.get("geomodeling.fuse", True))
+    if kind == "graph":
+        _, graph, keys = spec
+        return ("graph", fuse_graph(graph, keys) if fuse else graph, keys, get_sync)
+    if kind == "tiles":
+        # the sub-graphs of OUR tiles only (parallelize.py:82-89 emits them x-major, low y first), as one graph: equal tile
+        # programs then run as batched launches, shared keys are computed once
+        _, view, request, indices = spec
+        pairs = list(view.get_sources_and_requests(**request))
+        graph, keys = {}, []
+        for t in indices:
+            store, tile_request = pairs[1 + t]
+            graph, key = store.get_compute_graph(cached_compute_graph=graph, **tile_request)
+            keys.append(key)
+        return ("graph", fuse_graph(graph, keys) if fuse else graph, keys, get_sync)
+    if kind == "view":
+        _, view, request = spec
+        return ("view", view, request)
+    raise ValueError("unknown job kind %r" % (kind,))
+
+
+def _run(job):
+    events = None
+    if STATE.on_device:
+        from .hip import runtime
+        events = (runtime.Event().record(), runtime.Event())  # (on the compute stream: what the launches of this run take)
+    results = _evaluate(job)
+    if events is not None:
+        events[1].record()
+        runtime.sync()  # "done" means done: the parent's clock stops when every worker's stream is empty
+        STATE.device_ms = events[0].elapsed_ms(events[1])
+    return results
+
+
+def _evaluate(job):
+    if job[0] == "graph":
+        _, graph, keys, get = job
+        results = list(get(graph, keys))
+    else:
+        _, view, request = job
+        results = [view.get_data(**request)]  # (this process's config: not materialised, no device list)
+    return results
+
+
+def _range(name, size):
+    hit = STATE.ranges.get(name)
+    if hit is None:
+        fd = os.open(os.path.join("/dev/shm", name), os.O_RDWR)
+        try:
+            m = mmap.mmap(fd, size)
+        finally:
+            os.close(fd)
+        address = ctypes.addressof((ctypes.c_char * size).from_buffer(m))
+        pinned = False
+        if STATE.on_device:
+            from .hip import runtime
+            runtime.check(runtime.lib().gm_host_register(ctypes.c_void_p(address), size), "gm_host_register(%d bytes)" % size)
+            pinned = True
+        hit = STATE.ranges[name] = (m, address, pinned, size)
+    return hit
+
+
+def _drop_names(names):
+    for name in names:
+        STATE.arrays.pop(name, None)
+        hit = STATE.ranges.pop(name, None)
+        if hit is not None and hit[2]:
+            from .hip import runtime
+            runtime.lib().gm_host_unregister(ctypes.c_void_p(hit[1]))
+
+
+def _fetch(run_id, name, size, parts):
+    m, address, _, _ = _range(name, size)
+    responses = STATE.results[run_id]
+    alive = []  # device tiles (compacted / cast copies) the asynchronous copies read: kept until the sync below
+    for unit, offset, pitch, plane, dtype, bands, rows, cols in parts:
+        values = responses[unit]["values"]
+        dtype = np.dtype(dtype)
+        if type(values).__name__ == "DeviceArray":
+            from .hip import runtime
+            tile = values.contiguous()
+            if tile.dtype != dtype:  # values[...] = tile casts on assignment (parallelize.py:118-124): NumPy's astype, on the device
+                from .raster.stencil import _cast_tile
+                tile = _cast_tile(tile, dtype)
+            lead = tile.size // max(rows * cols, 1)
+            if lead * rows * cols != tile.size or lead not in (bands, 1) or tuple(tile.shape[-2:]) != (rows, cols):
+                raise ValueError("a result of shape %s does not fit its place of %d x %d x %d" % (tile.shape, bands, rows, cols))
+            item = dtype.itemsize
+            L = runtime.lib()
+            for b in range(bands):
+                src = tile.ptr + (b if lead == bands else 0) * rows * cols * item  # (one band is repeated in every band)
+                runtime.check(L.gm_d2h_2d(ctypes.c_void_p(address + offset + b * plane), pitch, ctypes.c_void_p(src), cols * item,
+                                          cols * item, rows), "gm_d2h_2d")
+            alive.append(tile)
+        else:
+            dest = np.ndarray((bands, rows, cols), dtype=dtype, buffer=m, offset=offset, strides=(plane, pitch, dtype.itemsize))
+            dest[...] = np.asarray(values).reshape((-1, rows, cols))  # NumPy's assignment: casts, repeats one band
+    if alive:
+        from .hip import runtime
+        runtime.sync()
+    return True
+
+
+def _checksums(run_id, units):
+    out = []
+    for unit in units:
+        response = STATE.results[run_id][unit]
+        if response is None or not isinstance(response, dict) or "values" not in response:
+            out.append(None)
+            continue
+        values = response["values"]
+        if type(values).__name__ == "DeviceArray":
+            out.append(int(values.checksum()))  # on the device (gm_checksum)
+        else:
+            out.append(zlib.crc32(np.ascontiguousarray(values).tobytes()))  # host-resident values (no device involved)
+    return out
+
+
+def _handle(message):
+    kind = message[0]
+    if kind == "run":
+        _, job_id, run_id, spec, keep = message
+        job = _prepare(spec)
+        if keep:
+            STATE.jobs[job_id] = job
+        results = STATE.results[run_id] = _run(job)
+        return {"metas": [_meta(r) for r in results], "device_ms": STATE.device_ms}
+    if kind == "rerun":
+        _, job_id, run_id = message
+        job = STATE.jobs.get(job_id)
+        if job is None:
+            raise KeyError("job %r is not known to this worker" % (job_id,))
+        results = STATE.results[run_id] = _run(job)
+        return {"metas": [_meta(r) for r in results], "device_ms": STATE.device_ms}
+    if kind == "fetch":
+        return _fetch(*message[1:])
+    if kind == "checksums":
+        return _checksums(message[1], message[2])
+    if kind == "drop":
+        for job_id in message[1]:
+            STATE.jobs.pop(job_id, None)
+        return True
+    if kind == "spec_wait":
+        # kernels specialised per program are compiled in the background (csrc/gm_spec.hip): wait for them; what ran so far
+        from .hip import program as P
+        if P.spec_pending():
+            P.spec_wait()
+        return {"launches": P.spec_stats()["launches"], "kernel": P.spec_last_kernel()}
+    if kind == "ping":
+        return (os.getpid(), STATE.device, len(STATE.jobs), len(STATE.results))
+    raise ValueError("unknown message %r" % (kind,))
+
+
+def _reply(conn, kind, payload):
+    try:
+        data = pickle.dumps((kind, payload), protocol=pickle.HIGHEST_PROTOCOL)
+    except Exception as e:  # an unpicklable result: say so instead of dying with the socket half written
+        data = pickle.dumps(("error", ("reply could not be pickled: %r" % (e,), "", None)))
+    conn.send_bytes(data)
+
+
+def _error_payload(e):
+    try:
+        pickled = pickle.dumps(e)
+        pickle.loads(pickled)
+    except Exception:
+        pickled = None
+    return ("%s: %s" % (type(e).__name__, e), traceback.format_exc(), pickled)
+
+
+def main(fd):
+    from multiprocessing.connection import Connection
+    conn = Connection(fd)
+    try:
+        first = _loads(conn.recv_bytes())
+        assert first[0] == "init"
+        _reply(conn, "ok", _init(first[1]))
+    except BaseException as e:  # noqa: BLE001 -- the parent must hear about it
+        _reply(conn, "error", _error_payload(e))
+        return 1
+    while True:
+        try:
+            data = conn.recv_bytes()
+        except (EOFError, OSError):
+            return 0  # the parent has gone (or closed the pool)
+        try:
+            message = _loads(data)
+            if message[0] == "stop":
+                return 0
+            _, work, names, runs = message
+            for run_id in runs:
+                STATE.results.pop(run_id, None)
+            _drop_names(names)
+            if work is None:
+                continue
+            payload = _handle(work)
+        except Exception as e:  # noqa: BLE001 -- every failure of a request travels to the parent
+            _reply(conn, "error", _error_payload(e))
+            continue
+        _reply(conn, "ok", payload)
+
+
+if __name__ == "__main__":
+    code = main(int(sys.argv[1]))
+    sys.stdout.flush()
+    sys.stderr.flush()
+    # (leave through the interpreter's normal exit: the library's exit handlers wait for kernels still being compiled)
+    sys.exit(code)

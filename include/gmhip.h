@@ -36,6 +36,7 @@ extern "C" {
 #define GM_ERR_INVALID 9001     /* bad argument / malformed program */
 #define GM_ERR_UNSUPPORTED 9002 /* valid request the kernels do not cover */
 #define GM_ERR_NO_DEVICE 9003
+#define GM_ERR_FORKED 9004 /* this process is a fork() of one that had entered the library: see gm_init */
 
 /* ---- element types of tiles in HBM ------------------------------------------- */
 enum gm_dtype {
@@ -68,7 +69,11 @@ typedef union gm_scalar {
  * Runtime: devices, memory, streams, events
  * ========================================================================== */
 
-/* Initialise HIP; GM_ERR_NO_DEVICE when no GPU is visible (the library still loads). */
+/* Initialise HIP; GM_ERR_NO_DEVICE when no GPU is visible (the library still loads).
+ * fork(): a HIP runtime does not survive it.  A child forked after its parent probed for devices (any call
+ * below but gm_last_error / gm_version) gets GM_ERR_FORKED -- "forked after gm_init: start workers with spawn" --
+ * from every runtime call instead of a hang: dask's `processes` scheduler (core/graphs.py:42-49) must be given
+ * spawned workers, as dask_geomodeling_amd.shard starts them. */
 int gm_init(void);
 /* Number of visible devices, or 0 when HIP cannot initialise. Never fails. */
 int gm_device_count(void);
@@ -92,8 +97,18 @@ int gm_pool_stats(size_t* in_use_bytes, size_t* cached_bytes);
  * at PCIe speed, into pageable memory at a small fraction of it. */
 int gm_host_malloc(void** ptr, size_t bytes);
 int gm_host_free(void* ptr);
+/* Pin a host range somebody else owns -- the shared-memory mosaic the one-worker-per-GPU scheduler hands to every worker
+ * (raster/parallelize.py:108-124 assembles it on the host): device-to-host copies into it then run at PCIe speed and
+ * straight to their place.  The range stays the caller's; unregister before unmapping. */
+int gm_host_register(void* ptr, size_t bytes);
+int gm_host_unregister(void* ptr);
 int gm_h2d(void* dst_dev, const void* src_host, size_t bytes); /* returns after the copy */
 int gm_d2h(void* dst_host, const void* src_dev, size_t bytes); /* returns after the copy */
+/* `rows` rows of width_bytes from a device tile (rows src_pitch_bytes apart) to a host window (rows dst_pitch_bytes
+ * apart): a result tile pasted at its place of a host mosaic (`values[:, rows, columns] = tile`, parallelize.py:118-124).
+ * Asynchronous: gm_sync() is the sync point (the host range should be pinned: gm_host_malloc / gm_host_register). */
+int gm_d2h_2d(void* dst_host, size_t dst_pitch_bytes, const void* src_dev, size_t src_pitch_bytes, size_t width_bytes,
+              size_t rows);
 int gm_d2d(void* dst_dev, const void* src_dev, size_t bytes);  /* async */
 int gm_memset(void* dst_dev, int byte_value, size_t bytes);    /* async */
 int gm_sync(void);                                             /* drain the current device's stream */
