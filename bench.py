@@ -522,26 +522,31 @@ def mosaic_through_the_scheduler(devices, side, steps, warmup, leaves, e2e=True)
     pool = shard.pool_for(devices)
 
     def step():
-        shard.get_data(tiler, whole, devices, materialize=False)  # (the handle is dropped: the workers free the tiles)
-        return max(ms for ms in pool.last_device_ms.values() if ms is not None)
+        # (returns when every worker has queued its launches, like a get_data that leaves its result on the device in the
+        #  single-process path; the handle is dropped: the workers free the tiles)
+        shard.get_data(tiler, whole, devices, materialize=False)
 
-    t_busy = None
-    done = 0
+    everybody = list(range(G))
+    t_busy, done = None, 0
     while done < warmup or t_busy is None or time.perf_counter() - t_busy < 0.3:
         if t_busy is None and done >= 1:
+            pool.sync()
             t_busy = time.perf_counter()
         step()
         done += 1
-    spec = pool.request({w: ("spec_wait",) for w in range(G)}, what="waiting for specialised kernels")
+    pool.request({w: ("spec_wait",) for w in everybody}, what="waiting for specialised kernels")
     for _ in range(3):
         step()
-    before = pool.request({w: ("spec_wait",) for w in range(G)}, what="kernel statistics")
-    device_ms = 0.0
+    pool.sync()
+    before = pool.request({w: ("spec_wait",) for w in everybody}, what="kernel statistics")
+    pool.request({w: ("mark",) for w in everybody}, what="timing marks")   # a HIP event on every worker's compute stream
     t0 = time.perf_counter()
     for _ in range(steps):
-        device_ms += step()
+        step()
+    pool.sync()
     elapsed = time.perf_counter() - t0
-    spec = pool.request({w: ("spec_wait",) for w in range(G)}, what="kernel statistics")
+    device_ms = max(ms for ms in pool.request({w: ("elapsed",) for w in everybody}, what="timing marks").values())
+    spec = pool.request({w: ("spec_wait",) for w in everybody}, what="kernel statistics")
     n_tiles = (MOSAIC_SIDE // side) ** 2
     per_worker = (n_tiles + G - 1) // G
     per_launch, bytes_px, dtype, kernel = MODEL["mosaic"]
@@ -561,7 +566,7 @@ def mosaic_through_the_scheduler(devices, side, steps, warmup, leaves, e2e=True)
            "dtype": dtype, "bytes_per_px": bytes_px, "algorithmic_bytes_per_launch": launch_bytes,
            "achieved_GBps": round(launch_bytes / launch_us / 1e3, 1), "frac": round(launch_bytes / launch_us / 1e3 / HBM_PEAK_GBS, 4),
            "kernel": kernel, "traffic": traffic, "traffic_source": traffic_src, "workers": G,
-           "worker_devices": pool.device_names}
+           "worker_devices": ["%d:%s" % (d, n) for d, n in zip(devices, pool.device_names)]}
     if e2e:
         # what an ndarray-returning caller gets: the 4 GiB uint8 mosaic assembled on the host, every worker copying its tiles
         # device-to-host straight to their place of a shared-memory mosaic it has pinned (the first request pins)
@@ -587,8 +592,12 @@ def main_mosaic(args):
         raise SystemExit("bench: --workload mosaic runs the real scheduler; its CPU coverage is tests/test_shard_cpu.py")
     side = args.side or 4096
     leaves = "procedural" if args.procedural else args.leaves
-    devices = tuple(range(max(args.gpus, 1)))
     from dask_geomodeling_amd import shard
+    from dask_geomodeling_amd.hip import runtime
+    visible = runtime.device_count()  # (counts; this process never initialises a GPU)
+    if visible <= 0:
+        raise SystemExit("bench: no HIP device visible")
+    devices = tuple(g % visible for g in range(max(args.gpus, 1)))  # (more workers than GPUs share them: the 1-GPU test box)
     try:
         line = mosaic_through_the_scheduler(devices, side, args.steps, args.warmup, leaves, e2e=not args.no_e2e)
     finally:

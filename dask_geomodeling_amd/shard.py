@@ -18,7 +18,8 @@ collective on the data path.  What this module adds to the reference's ``compute
     builds and fuses the sub-graphs of ITS tiles only, keeps the fused job (compiled programs, specialised
     kernels, resident leaf windows) and re-runs it when the same request comes again.  With
     ``geomodeling.materialize`` off the tiles stay on their GPUs and the response holds a ``ShardedTiles`` handle
-    (``to_numpy()``, ``checksums()``).
+    (``to_numpy()``, ``checksums()``); such a request returns when every worker has queued its launches -- as a
+    get_data that leaves a DeviceArray behind does in one process -- and ``Pool.sync()`` waits for the streams.
 
 Workers are fresh interpreters (``python -m dask_geomodeling_amd.shard_worker``): started with fork + exec
 *before* they touch HIP, never by fork() alone -- a HIP runtime does not survive fork(), the library refuses it
@@ -328,7 +329,6 @@ class Pool(object):
         self.released = []       # run ids whose results the workers may drop (piggybacked on the next message)
         self.forgotten = []      # names of shared-memory ranges that are gone (likewise)
         self.closed = False
-        self.last_device_ms = {}  # worker index -> HIP-event milliseconds of its part of the last run (None without a device)
         settings = {"preload": preload if preload is not None else _config.get("geomodeling.worker-preload"),
                     "path": [p for p in sys.path if p], "config": _forwarded_config()}
         self.workers = []
@@ -431,16 +431,32 @@ class Pool(object):
 
     # -- jobs -----------------------------------------------------------------------------------------------
     def job_for(self, key):
-        """(job id, known to the workers already?) of a job key; the least recently used jobs are dropped."""
+        """(job record, known to the workers already?) of a job key; the least recently used jobs are dropped (-> their ids)."""
         job = self.jobs.pop(key, None)
         known = job is not None
         if job is None:
-            job = next(self.job_ids)
+            job = _Job(next(self.job_ids))
         self.jobs[key] = job
         dropped = []
         while len(self.jobs) > MAX_JOBS:
-            dropped.append(self.jobs.pop(next(iter(self.jobs))))
+            dropped.append(self.jobs.pop(next(iter(self.jobs))).id)
         return job, known, dropped
+
+    def sync(self):
+        """Wait until every worker's compute stream is empty (requests return when their launches are queued)."""
+        self.request({w.index: ("sync",) for w in self.workers}, what="sync")
+
+
+class _Job(object):
+    """What the parent remembers of a (view, request) the workers keep a fused job for."""
+
+    __slots__ = ("id", "kwargs", "n_tiles", "shares", "owners", "metas")
+
+    def __init__(self, job_id):
+        self.id = job_id
+        self.kwargs = self.shares = self.owners = None
+        self.n_tiles = 0
+        self.metas = {}   # worker index -> metas of its last answer
 
 
 def _worker_error(worker, payload, what):
@@ -723,8 +739,7 @@ def get(dsk, keys, devices=None, **kwargs):
         what = "get() of %d keys" % len(flat)
         try:
             replies = pool.request(messages, what=what) if messages else {}
-            pool.last_device_ms = {w: r["device_ms"] for w, r in replies.items()}
-            metas = [replies[w]["metas"][i] for w, i in owners]
+            metas = [replies[w][i] for w, i in owners]
             values = _assemble_results(pool, run_id, plans, metas, owners, what)
         finally:
             if not pool.closed:
@@ -788,33 +803,36 @@ def get_data(view, request, devices=None, materialize=None):
     if materialize is None:
         materialize = bool(_config.get("geomodeling.materialize", True))
     G = len(pool.devices)
-    kwargs, n_tiles = None, 0
-    if getattr(type(view).process, "gm_tiler", False) and request.get("mode") == "vals":
-        pairs = list(view.get_sources_and_requests(**request))
-        if pairs and pairs[0][0] is not None and len(pairs) > 1:
-            kwargs, n_tiles = pairs[0][0], len(pairs) - 1
     rkey = _request_key(request)
     with pool.lock:
         key = (view.token, rkey) if rkey is not None else None
         if key is not None:
             job, known, dropped = pool.job_for(key)
         else:
-            job, known, dropped = next(pool.job_ids), False, []
+            job, known, dropped = _Job(next(pool.job_ids)), False, []
+        if not known:
+            # the dealing: a RasterTiler's tiles t % G (parallelize.py:82 emits them x-major, low y first); any other view is
+            # one unit on one worker
+            if getattr(type(view).process, "gm_tiler", False) and request.get("mode") == "vals":
+                pairs = list(view.get_sources_and_requests(**request))
+                if pairs and pairs[0][0] is not None and len(pairs) > 1:
+                    job.kwargs, job.n_tiles = pairs[0][0], len(pairs) - 1
+            if job.n_tiles:
+                shares = {w: owned_tiles(job.n_tiles, w, G) for w in range(G)}
+                job.shares = {w: mine for w, mine in shares.items() if mine}
+                job.owners = [(tile_owner(t, G), t // G) for t in range(job.n_tiles)]
+            else:
+                w = int(view.token[:8], 16) % G if isinstance(view.token, str) else 0
+                job.shares, job.owners = {w: None}, [(w, 0)]
+        kwargs, n_tiles, owners = job.kwargs, job.n_tiles, job.owners
         run_id = next(pool.run_ids)
-        if n_tiles:
-            shares = {w: owned_tiles(n_tiles, w, G) for w in range(G)}
-            shares = {w: mine for w, mine in shares.items() if mine}
-            owners = [(tile_owner(t, G), t // G) for t in range(n_tiles)]
-        else:
-            w = int(view.token[:8], 16) % G if isinstance(view.token, str) else 0
-            shares, owners = {w: None}, [(w, 0)]
         messages = {}
-        for w, mine in shares.items():
+        for w, mine in job.shares.items():
             if known:
-                messages[w] = ("rerun", job, run_id)
+                messages[w] = ("rerun", job.id, run_id)
             else:
                 spec = ("tiles", view, request, mine) if n_tiles else ("view", view, request)
-                messages[w] = ("run", job, run_id, spec, True)
+                messages[w] = ("run", job.id, run_id, spec, True)
         what = "get_data of %s" % type(view).__name__
         if dropped:
             pool.request({w.index: ("drop", dropped) for w in pool.workers}, what="clean-up")
@@ -823,10 +841,12 @@ def get_data(view, request, devices=None, materialize=None):
         except BaseException:
             pool.jobs.pop(key, None)
             raise
-        pool.last_device_ms = {w: r["device_ms"] for w, r in replies.items()}
-        metas = [replies[w]["metas"][i] for w, i in owners]
+        for w, reply in replies.items():
+            if not isinstance(reply, str):  # ("same": what this worker answered last time)
+                job.metas[w] = reply
+        metas = [job.metas[w][i] for w, i in owners]
         if key is None:
-            pool.request({w: ("drop", [job]) for w in messages}, what="clean-up")
+            pool.request({w: ("drop", [job.id]) for w in messages}, what="clean-up")
 
         def assemble():
             plans = {"result": ("mosaic", None, kwargs, [("unit", t) for t in range(n_tiles)]) if n_tiles else ("unit", 0)}

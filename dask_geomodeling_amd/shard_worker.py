@@ -30,7 +30,8 @@ class _State(object):
         self.ranges = {}     # shared-memory name -> (mmap, address, pinned?): result mosaics of the parent
         self.jobs = {}       # job id -> prepared job
         self.results = {}    # run id -> [response per unit]
-        self.device_ms = None  # HIP-event time of the last run on the compute stream
+        self.mark = None     # HIP event recorded by the parent's ("mark",): start of a timed region
+        self.last_metas = {} # job id -> metas of its last run (a re-run that answers the same says so in one word)
 
 
 STATE = _State()
@@ -125,16 +126,11 @@ def _prepare(spec):
 
 
 def _run(job):
-    events = None
-    if STATE.on_device:
-        from .hip import runtime
-        events = (runtime.Event().record(), runtime.Event())  # (on the compute stream: what the launches of this run take)
-    results = _evaluate(job)
-    if events is not None:
-        events[1].record()
-        runtime.sync()  # "done" means done: the parent's clock stops when every worker's stream is empty
-        STATE.device_ms = events[0].elapsed_ms(events[1])
-    return results
+    """The job's units, enqueued on this worker's compute stream.  Like a get_data that leaves its result on the device in the
+    single-process path, this returns when the launches are queued, not when they have run: the next request's host work
+    (leaf windows, launch arguments) overlaps this one's kernels.  Whatever reads the results -- a fetch, a checksum, the
+    parent's sync() -- is ordered behind them on the same stream."""
+    return _evaluate(job)
 
 
 def _evaluate(job):
@@ -229,14 +225,42 @@ def _handle(message):
         if keep:
             STATE.jobs[job_id] = job
         results = STATE.results[run_id] = _run(job)
-        return {"metas": [_meta(r) for r in results], "device_ms": STATE.device_ms}
+        metas = [_meta(r) for r in results]
+        if keep:
+            STATE.last_metas[job_id] = metas
+        return metas
     if kind == "rerun":
         _, job_id, run_id = message
         job = STATE.jobs.get(job_id)
         if job is None:
             raise KeyError("job %r is not known to this worker" % (job_id,))
         results = STATE.results[run_id] = _run(job)
-        return {"metas": [_meta(r) for r in results], "device_ms": STATE.device_ms}
+        metas = [_meta(r) for r in results]
+        try:
+            if metas == STATE.last_metas.get(job_id):
+                return "same"
+        except Exception:  # (metas that do not compare: objects of a non-raster answer)
+            pass
+        STATE.last_metas[job_id] = metas
+        return metas
+    if kind == "sync":
+        if STATE.on_device:
+            from .hip import runtime
+            runtime.sync()
+        return True
+    if kind == "mark":
+        # start of a timed region on this worker's compute stream (bench.py): ("elapsed",) answers the HIP-event time since
+        if STATE.on_device:
+            from .hip import runtime
+            STATE.mark = runtime.Event().record()
+        return True
+    if kind == "elapsed":
+        if not STATE.on_device or STATE.mark is None:
+            return None
+        from .hip import runtime
+        stop = runtime.Event().record()
+        stop.synchronize()
+        return STATE.mark.elapsed_ms(stop)
     if kind == "fetch":
         return _fetch(*message[1:])
     if kind == "checksums":
@@ -244,6 +268,7 @@ def _handle(message):
     if kind == "drop":
         for job_id in message[1]:
             STATE.jobs.pop(job_id, None)
+            STATE.last_metas.pop(job_id, None)
         return True
     if kind == "spec_wait":
         # kernels specialised per program are compiled in the background (csrc/gm_spec.hip): wait for them; what ran so far

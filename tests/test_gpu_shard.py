@@ -63,7 +63,9 @@ def test_two_workers_return_the_single_process_mosaic(two_workers):
         assert np.array_equal(_bits(again["values"]), _bits(want["values"]))
     assert {w.pid for w in two_workers.workers}.isdisjoint({os.getpid()}) and len({w.pid for w in two_workers.workers}) == 2
     assert all("gfx950" in name for name in two_workers.device_names)
-    assert all(ms is not None and ms > 0 for ms in two_workers.last_device_ms.values())
+    two_workers.request({0: ("mark",), 1: ("mark",)})
+    tiler.get_data(**_request(side))
+    assert all(ms is not None and ms > 0 for ms in two_workers.request({0: ("elapsed",), 1: ("elapsed",)}).values())
 
 
 @pytest.mark.timeout(600)
