@@ -38,14 +38,25 @@ def gpu():
     return runtime
 
 
-@pytest.fixture(autouse=True)
-def _tiles_take_the_batched_route(monkeypatch):
-    """A RasterTiler over an element-wise store in tiles of fewer than 2048^2 cells is answered as one request for the whole
-    box where that changes no cell (plan._whole_instead_of_tiles).  The suites' rasters are small: without this their tiles
-    would never take the batched launch into the mosaic (fuse.TiledAssembly) that the bench's 4096^2 tiles take.  The tests of
-    the shortcut itself set the product's threshold back."""
+TILER_ROUTES = ("product-default", "batched-tiles")
+
+
+def pytest_generate_tests(metafunc):
+    # every test that evaluates a RasterTiler names the route its tiles take (the `tiler_route` fixture) and runs once per route
+    if "tiler_route" in metafunc.fixturenames:
+        metafunc.parametrize("tiler_route", TILER_ROUTES, indirect=True)
+
+
+@pytest.fixture
+def tiler_route(request, monkeypatch):
+    """The route of a RasterTiler over an element-wise store in tiles of fewer than 2048^2 cells: "product-default" answers it
+    as one request for the whole box where that changes no cell (plan._whole_instead_of_tiles) -- what a user of the product
+    gets for rasters as small as the suites' --, "batched-tiles" makes those tiles take the batched launch into the mosaic
+    (fuse.TiledAssembly) that the bench's 4096^2 tiles take."""
     from dask_geomodeling_amd import plan
-    monkeypatch.setattr(plan, "_BATCHED_TILE_CELLS", 0)
+    if request.param == "batched-tiles":
+        monkeypatch.setattr(plan, "_BATCHED_TILE_CELLS", 0)
+    return request.param
 
 
 @pytest.fixture

@@ -44,7 +44,7 @@ def test_random_views_evaluated_together(gpu):
 
 
 @pytest.mark.parametrize("seed", range(60))
-def test_random_views_tiled_equals_untiled(gpu, seed):
+def test_random_views_tiled_equals_untiled(gpu, seed, tiler_route):
     """RasterTiler around a random view on MemorySources (zero-copy windows, batched tile programs,
     in-place mosaic, ragged edge tiles) gives exactly the untiled result."""
     from dask_geomodeling_amd import raster
@@ -113,8 +113,7 @@ def test_random_temporal_views_against_the_walking_oracle(gpu, seed, monkeypatch
     from dask_geomodeling_amd import config as gmconfig
     from dask_geomodeling_amd import plan
     from oracle_walk import comparable, random_requests, random_temporal_view, walk, without_lossy_cells
-    if (seed // 2) % 2 == 0:
-        monkeypatch.setattr(plan, "_BATCHED_TILE_CELLS", 1 << 22)
+    monkeypatch.setattr(plan, "_BATCHED_TILE_CELLS", 1 << 22 if (seed // 2) % 2 == 0 else 0)
     rng = np.random.default_rng(70_000 + seed)
     shape = (24, 40) if seed < 1000 else (150, 517)  # (the larger rasters: windows with a pitch, several workgroups per tile)
     view = random_temporal_view(rng, depth=int(rng.integers(1, 4)), shape_yx=shape)
@@ -137,7 +136,7 @@ def test_random_temporal_views_against_the_walking_oracle(gpu, seed, monkeypatch
 
 
 @pytest.mark.parametrize("seed", range(120))
-def test_random_memory_views_against_the_walking_oracle(gpu, seed):
+def test_random_memory_views_against_the_walking_oracle(gpu, seed, tiler_route):
     """The random views of this file over MemorySources -- stencils (request enlargement) and Smooth (exact and zoom mode)
     included -- asked for the whole grid, a window, coarser and finer cells, a box half a cell off the grid and partly outside
     the sources, and a point: against the view walked with the oracle's process bodies (tests/oracle_walk.py).  Every other seed

@@ -443,7 +443,7 @@ def kat_source():
 
 
 @pytest.mark.parametrize("off", [(0, -5, 5, 0), (0, -5, 6, 0), (0, -6, 5, 0), (-1, -5, 5, 0), (0, -5, 5, 1)])
-def test_tiled_equals_untiled(gpu, kat_source, off):
+def test_tiled_equals_untiled(gpu, kat_source, off, tiler_route):
     """tests/test_raster_parallelize.py:87-116 of the reference."""
     src = kat_source
     block = raster.RasterTiler(src, 2)
@@ -573,7 +573,7 @@ def test_program_on_strided_windows(gpu, dtype, win):
 
 
 @pytest.mark.gpu
-def test_tiler_over_memory_source_is_zero_copy_and_exact(gpu):
+def test_tiler_over_memory_source_is_zero_copy_and_exact(gpu, tiler_route):
     """RasterTiler over a view on resident MemorySources: every aligned tile reaches the fused
     program as a strided window (no warp kernel), results equal the untiled evaluation."""
     from dask_geomodeling_amd import raster
@@ -715,7 +715,7 @@ def test_classify_many_edges_on_windows_of_a_resident_raster(gpu, kind, right):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cell", [0.1, 0.3, 0.7])
-def test_tiler_with_tiles_one_pixel_short_of_their_slot(gpu, cell):
+def test_tiler_with_tiles_one_pixel_short_of_their_slot(gpu, cell, tiler_route):
     """The reference truncates tile sizes with int() (parallelize.py:85-86): for cell sizes that are not
     exact in binary a tile can come out one pixel narrower than its slot, and np.full leaves the fill
     value in the uncovered column / row.  The in-place mosaic must not hand out unwritten memory there."""
@@ -1105,7 +1105,7 @@ def test_smooth_block_requests_and_large_tile(gpu):
 
 
 @pytest.mark.gpu
-def test_tiler_over_boolean_view(gpu):
+def test_tiler_over_boolean_view(gpu, tiler_route):
     """A boolean view has no fill value (np.full(shape, None, dtype=bool) is all False in the
     reference's assembly): found by the fuzzer."""
     from dask_geomodeling_amd import raster
@@ -1250,7 +1250,7 @@ def test_dilate_one_byte_tiles(gpu, dtype, shape):
 
 
 @pytest.mark.gpu
-def test_temporal_views_end_to_end(gpu):
+def test_temporal_views_end_to_end(gpu, tiler_route):
     """TemporalAggregate / Cumulative inside larger views: element-wise programs in front (device tiles
     handed over without a host round trip) and behind, a RasterTiler on top, on a temporal MemorySource."""
     from datetime import datetime
@@ -1439,7 +1439,7 @@ def test_gauss_both_axes_in_one_launch(gpu, sigma, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt,ndv", [("u1", np.uint8(255)), ("u1", np.uint8(0)), ("i1", np.int8(-1)), ("?", None)])
-def test_single_byte_input_programs_by_table(gpu, dt, ndv):
+def test_single_byte_input_programs_by_table(gpu, dt, ndv, tiler_route):
     """Programs whose only input is a 1-byte tile run as a 256-entry table (built by the VM itself) + the
     byte-LUT kernel from 4096 elements on: every output width, ragged sizes (scalar tail), batches, and
     zero-copy windows of a resident raster (strided tiles; widths the LUT kernel cannot address fall
@@ -1529,7 +1529,7 @@ def test_int32_reclassify_mask_dedicated_kernel(gpu, shape):
 
 
 @pytest.mark.gpu
-def test_int32_reclassify_mask_on_windows(gpu):
+def test_int32_reclassify_mask_on_windows(gpu, tiler_route):
     """The dedicated LOOKUP kernel on zero-copy windows of a resident int32 raster (strided tiles written
     straight into the mosaic): tile widths it can address (multiples of 16) and widths that fall back to
     the VM must both equal the untiled result and the oracle."""
@@ -2188,7 +2188,7 @@ def test_signed_zeros_through_the_temporal_statistics(gpu, dt):
 
 
 @pytest.mark.gpu
-def test_frames_that_do_not_line_up(gpu):
+def test_frames_that_do_not_line_up(gpu, tiler_route):
     """More of what the temporal fuzzing found.  (1) A raster of one frame next to a series in a ufunc step is NumPy
     broadcasting -- also when the step is planned / fused (the remembered program used to be handed the one frame as if it were
     n).  (2) Where the reference indexes with a boolean array (Clip, FillNoData, Max) frames that differ are NumPy's IndexError,
@@ -2278,7 +2278,7 @@ def test_temporal_statistics_of_one_cell(gpu, dt):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt,ndv", [("u4", np.uint32(4294967295)), ("u8", np.uint64(2 ** 64 - 1)), ("u2", np.uint16(65535)), ("i8", -9999),
                                     ("u4", np.uint32(7))])
-def test_merges_of_wide_unsigned_rasters(gpu, dt, ndv):
+def test_merges_of_wide_unsigned_rasters(gpu, dt, ndv, tiler_route):
     """FillNoData / Group / Clip / Max of uint32 and uint64 rasters -- values beyond 2^31 and 2^63, the dtype's maximum as
     no data: nothing is computed in a merge, so the values travel in the int64 class (uint64 as its bit pattern; the fuzzing
     of round 4 found these refused), and a float64 result above 2^63 is stored as uint64, not through int64 (Max of uint64
@@ -2304,7 +2304,7 @@ def test_merges_of_wide_unsigned_rasters(gpu, dt, ndv):
 
 
 @pytest.mark.gpu
-def test_point_requests_on_resident_series(gpu):
+def test_point_requests_on_resident_series(gpu, tiler_route):
     """The time series of a location from a source that lives in HBM: the cell of every requested frame comes back in one
     strided copy (raster/sources.py) -- every time window, points on cell edges and outside the raster, against the same
     source held on the host and against the walking oracle; and through a view."""
@@ -2332,7 +2332,7 @@ def test_point_requests_on_resident_series(gpu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("plans", [True, False])
-def test_sums_of_integer_series_under_blocks_that_cast_them(gpu, plans):
+def test_sums_of_integer_series_under_blocks_that_cast_them(gpu, plans, tiler_route):
     """TemporalSum of an integer series is an int64 / uint64 tile under a Block that declares its store's dtype
     (temporal.py:548-602); the Blocks above it ask NumPy for their declared float32 / int32 results, and NumPy casts the
     tile first (`np.divide(int64 tile, 100, dtype=float32)`).  No register class holds an int64 tile next to float32

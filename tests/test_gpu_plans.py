@@ -63,7 +63,7 @@ def test_plan_reused_across_bounding_boxes(gpu, seed):
     assert len(view.__dict__.get("_gm_templates", {})) <= 1  # ... and at most one template
 
 
-def test_plan_exists_for_the_canonical_chain_and_is_reused(gpu):
+def test_plan_exists_for_the_canonical_chain_and_is_reused(gpu, tiler_route):
     from dask_geomodeling_amd import plan, raster
     from dask_geomodeling_amd.hip import DeviceArray
     from dask_geomodeling_amd import config as gmconfig
@@ -98,7 +98,7 @@ def test_plan_exists_for_the_canonical_chain_and_is_reused(gpu):
 
 
 @pytest.mark.parametrize("seed", range(30))
-def test_tiler_through_plans_equals_untiled(gpu, seed):
+def test_tiler_through_plans_equals_untiled(gpu, seed, tiler_route):
     from dask_geomodeling_amd import raster
     from fuzz_util import REQ
     rng = np.random.default_rng(30_000 + seed)
@@ -123,7 +123,7 @@ def test_tiler_through_plans_equals_untiled(gpu, seed):
 
 
 @pytest.mark.parametrize("dtype,cell", [("f4", 1.0), ("f4", 0.75), ("i2", 0.5), ("u1", 2.0), ("i4", 0.75), ("f8", 1.0)])
-def test_tiler_over_hillshade_in_one_launch(gpu, dtype, cell):
+def test_tiler_over_hillshade_in_one_launch(gpu, dtype, cell, tiler_route):
     """A RasterTiler over HillShade on the plan path: the tiles of a mosaic shaded in ONE launch, written straight
     into the mosaic (gm_hillshade_batch) -- even tilings, ragged ones (tiles of two shapes: tile by tile + paste), dtypes
     and resolutions the batch kernel declines -- always the untiled HillShade, which test_gpu_parity pins to the
@@ -155,7 +155,7 @@ def test_tiler_over_hillshade_in_one_launch(gpu, dtype, cell):
 @pytest.mark.parametrize("over", ["source", "computed"])
 @pytest.mark.parametrize("dtype", ["f4", "u1", "i2", "i8", "f8"])
 @pytest.mark.parametrize("kind", ["dilate", "movingmax3", "movingmax7", "movingmax21", "smooth", "hillshade"])
-def test_tiler_over_stencils_writes_in_place(gpu, kind, dtype, over, monkeypatch):
+def test_tiler_over_stencils_writes_in_place(gpu, kind, dtype, over, monkeypatch, tiler_route):
     """A RasterTiler over Dilate / MovingMax / Smooth of a resident source on the plan path: every tile's result is
     written straight into its window of the mosaic where the kernel route can (gm_*_into), pasted otherwise (8-byte
     cells, large footprints, ragged tilings) -- always the untiled Block's result and the graph path's mosaic."""
@@ -197,7 +197,7 @@ def test_tiler_over_stencils_writes_in_place(gpu, kind, dtype, over, monkeypatch
             assert_result_equal(_template_path(tiler, request), whole, 0, what + " (graph from the template)")
 
 
-def test_stencil_blocks_through_plans(gpu):
+def test_stencil_blocks_through_plans(gpu, tiler_route):
     """Blocks with a kernel of their own (gm_direct) are answered without a graph per request: alone over a source,
     over a planned element-wise view, as leaves of an element-wise view above them, nested, and under a RasterTiler --
     every time exactly the graph path's result, and through plan.evaluate."""
@@ -262,7 +262,7 @@ def test_temporal_blocks_through_plans(gpu):
                 assert view.get_data(**other) == _graph_path(view, other)
 
 
-def test_templates_make_real_graphs_and_are_reused(gpu):
+def test_templates_make_real_graphs_and_are_reused(gpu, tiler_route):
     """template.fused_compute_graph: a dask-style graph any scheduler can run -- leaf tasks + ONE FusedTask (the same
     object, with its compiled programs, for every bounding box) -- equal to the from-scratch graph's result, for a
     single view and for a RasterTiler (one TiledAssembly kept per tile layout)."""
@@ -310,7 +310,7 @@ def test_templates_make_real_graphs_and_are_reused(gpu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("plans", [True, False])
-def test_tiled_series_windows_of_several_frames_in_place(gpu, plans):
+def test_tiled_series_windows_of_several_frames_in_place(gpu, plans, tiler_route):
     """A RasterTiler over element-wise views of resident multi-frame sources: every tile's operands are zero-copy windows of
     several bands (rows a source width apart, bands a source plane apart: DeviceArray.band_pitch), the program runs band by band
     in one call (gm_elemwise_run_batch_bands) and writes into the tile's window of a mosaic of as many frames -- ragged edge
@@ -352,7 +352,7 @@ def test_tiled_series_windows_of_several_frames_in_place(gpu, plans):
 
 
 @pytest.mark.gpu
-def test_tiler_over_pixel_local_temporal_views_is_one_request(gpu):
+def test_tiler_over_pixel_local_temporal_views_is_one_request(gpu, tiler_route):
     """A RasterTiler over a temporal Block (no program to batch over the tiles) whose view is pixel-local and whose tiles cover
     the box exactly is answered by ONE request for the whole box (plan._whole_instead_of_tiles) -- the same cells as the tiles
     pasted next to each other: against the walking oracle (which pastes tiles), for every temporal Block, Group, a declared
@@ -416,7 +416,7 @@ def test_tiler_over_pixel_local_temporal_views_is_one_request(gpu):
         plan._whole_instead_of_tiles = original
 
 
-def test_tiler_over_a_stencil_is_one_request_where_the_margins_lie_inside(gpu):
+def test_tiler_over_a_stencil_is_one_request_where_the_margins_lie_inside(gpu, tiler_route):
     """Dilate, MovingMax and HillShade ask their store for the box grown by exactly the margin their kernels look at, so a mosaic
     of their tiles IS their answer for the whole box: a RasterTiler over one of them (alone, or under / over pixel-local Blocks
     with a kernel of their own) is ONE request where the grown box lies on the sources' grid (plan._whole_instead_of_tiles) --
