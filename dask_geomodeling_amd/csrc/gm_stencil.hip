@@ -423,10 +423,18 @@ __global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* 
 // MovingMax
 // ---------------------------------------------------------------------------------
 // The sign of a zero maximum.  The hardware maximum of +0.0 and -0.0 is +0.0; scipy.ndimage.maximum_filter keeps whichever
-// zero its scan order leaves standing (moving_max_zero_sign_kernel below restates the two orders).  A raster holding -0.0 at
-// all is rare, so the kernels only NOTE one while they stage their windows (a compare per staged cell): `*seen = ticket`,
-// a slot of a small per-device ring, and the fix-up pass that follows every float launch returns at once unless its
-// launch's ticket is there.
+// zero its scan order leaves standing (restated from measurements against SciPy 1.15):
+//   * a footprint with holes (sizes 5 and up: the disk) is scanned in raster order, a later cell replaces the running
+//     maximum only when it compares GREATER -- the FIRST zero of the footprint stays;
+//   * the all-true 3 x 3 footprint takes SciPy's separable route, maximum_filter1d down the columns and then along the
+//     rows, whose running-maximum queue takes a later cell that compares greater OR EQUAL -- the bottom-most zero of the
+//     right-most column that has one.
+// Both rules pick the zero that comes first in an order of the CELLS that does not depend on the window (raster order; columns
+// from the right, rows from below): a maximum over (value, rank of the cell) pairs.  A zero has 31 idle bits, so the pair fits
+// the cell: the kernels note a -0.0 while they stage their window (a compare per staged cell, a rare thing in a raster),
+// and a workgroup that staged one re-writes its LDS window as sortable integer KEYS -- negative values below, zeros in the middle
+// carrying their rank and their sign, positive values above -- and walks it with the integer maximum instead: the same
+// walk, the same instruction count, no second pass over the raster.  Workgroups without a -0.0 never leave the float walk.
 template <typename T>
 __device__ __forceinline__ bool is_negative_zero(T v) {
   if constexpr (std::is_same<T, float>::value) return __float_as_uint(v) == 0x80000000u;
@@ -434,18 +442,137 @@ __device__ __forceinline__ bool is_negative_zero(T v) {
   else return false;
 }
 
+// K = T: the window holds values.  K = the signed integer of T's width: it holds keys (float tiles of a workgroup that staged a -0.0).
+template <typename T>
+struct ZeroKey {
+  typedef T K;
+};
+template <>
+struct ZeroKey<float> {
+  typedef int K;
+  typedef unsigned U;
+  static constexpr U SIGN = 0x80000000u, INF = 0x7F800000u;
+  static constexpr K NAN_KEY = (K)0x80000000u;  // below every value: a NaN loses every maximum, as with the hardware maximum
+};
+template <>
+struct ZeroKey<double> {
+  typedef long long K;
+  typedef unsigned long long U;
+  static constexpr U SIGN = 0x8000000000000000ull, INF = 0x7FF0000000000000ull;
+  static constexpr K NAN_KEY = (K)0x8000000000000000ull;
+};
+template <typename T>
+__device__ __forceinline__ typename ZeroKey<T>::U float_bits(T v) {
+  if constexpr (std::is_same<T, float>::value) return __float_as_uint(v);
+  else return (unsigned long long)__double_as_longlong(v);
+}
+// rank: which zero wins among zeros (larger wins), 0 <= rank < zoff / 2; keys of zeros are 0 .. zoff - 1
+template <typename T>
+__device__ __forceinline__ typename ZeroKey<T>::K zero_key(T v, int rank, int zoff) {
+  typedef ZeroKey<T> Z;
+  const typename Z::U b = float_bits(v), mag = b & ~Z::SIGN;
+  if (mag > Z::INF) return Z::NAN_KEY;
+  if (mag == 0) return (typename Z::K)(2 * rank + ((b & Z::SIGN) ? 0 : 1));
+  if (b & Z::SIGN) return (typename Z::K)(b ^ ~Z::SIGN);  // -tiny -> -2 ... -max -> far below: the order of the values
+  return (typename Z::K)(b + (typename Z::U)zoff);
+}
+template <typename T>
+__device__ __forceinline__ T zero_key_value(typename ZeroKey<T>::K k, int zoff) {
+  typedef ZeroKey<T> Z;
+  typename Z::U b;
+  if (k < 0) b = (typename Z::U)k ^ ~Z::SIGN;
+  else if (k < (typename Z::K)zoff) b = (k & 1) ? 0 : Z::SIGN;
+  else b = (typename Z::U)k - (typename Z::U)zoff;
+  if constexpr (std::is_same<T, float>::value) return __uint_as_float(b);
+  else return __longlong_as_double((long long)b);
+}
+// Has any lane of the workgroup `mine`?  (One ballot per wave into its own LDS word: nothing to clear, one barrier -- the one
+// the kernels need after staging anyway.)
+__device__ __forceinline__ bool workgroup_any_and_sync(bool mine, unsigned* flags) {
+  const unsigned long long votes = __ballot(mine);
+  if ((threadIdx.x & 63) == 0) flags[threadIdx.x >> 6] = votes != 0;
+  __syncthreads();
+  return (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+}
+
 constexpr int MM_TILE_H = 16, MM_TILE_W = 64;
 // NaN.  scipy.ndimage.maximum_filter starts from the first cell of the footprint (top row, leftmost) and
 // takes every later cell that compares greater: a NaN in that first cell stays (nothing compares greater than
 // it), a NaN anywhere else is never taken.  The kernels below reduce with the hardware maximum, which ignores
-// NaN operands, and then apply exactly that rule: the result is NaN where the first cell of the footprint is.
+// NaN operands, and then apply exactly that rule: the result is NaN where the first cell of the footprint is
+// (in a window of keys a NaN is the lowest key; the NaN itself is then fetched from the raster).
+
+// The walk of the general kernel over a window of values (K = T) or of keys.
+// A lane owns 4 CONSECUTIVE output rows of one column.  The circle is scanned column by column
+// (wave-uniform dx): the vertical runs of the 4 outputs overlap in all but 3 rows at either end,
+// so the shared core is read and reduced once -- (2 hh + 4) LDS reads per column for 4 outputs
+// instead of 4 (2 hh + 1); consecutive lanes read consecutive addresses (no bank conflicts).
+template <typename T, typename K>
+__device__ __forceinline__ void moving_max_walk(const K* tile, int pitch, const T* __restrict__ sband, T* __restrict__ out, int b,
+                                                int w, int size, int radius, int oh, int ow, int r0, int c0, int has_ndv, T ndv,
+                                                T minimum, K identity, int zoff) {
+  constexpr bool KEYS = !std::is_same<T, K>::value;
+  const int c = threadIdx.x & 63, o0 = (threadIdx.x >> 6) * 4;
+  if (c0 + c >= ow) return;
+  const int s2 = size * size;
+  K m[4] = {identity, identity, identity, identity};
+  auto up = [](K a, K b) -> K { return hw_max(a, b); };
+  for (int dx = 0; dx < size; ++dx) {
+    const int xx = dx - radius;
+    int hh = -1;  // half-height of the footprint's column: (x^2 + y^2) < (size/2)^2 (utils.py:536-547)
+    while (4 * (xx * xx + (hh + 1) * (hh + 1)) < s2) ++hh;
+    if (hh < 0) continue;
+    const K* col = tile + (c + dx);
+    const int first = o0 + radius - hh;  // window row of the topmost cell of output 0's run
+    if (hh == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = up(m[k], col[(first + k) * pitch]);
+      continue;
+    }
+    const K l0 = col[first * pitch], l1 = col[(first + 1) * pitch], l2 = col[(first + 2) * pitch];
+    const int after = first + 2 * hh + 1;
+    const K r0v = col[after * pitch], r1v = col[(after + 1) * pitch], r2v = col[(after + 2) * pitch];
+    K core = identity;
+    for (int y = first + 3; y < after; ++y) core = up(core, col[y * pitch]);
+    m[0] = up(m[0], up(core, up(l0, up(l1, l2))));
+    m[1] = up(m[1], up(core, up(l1, up(l2, r0v))));
+    m[2] = up(m[2], up(core, up(l2, up(r0v, r1v))));
+    m[3] = up(m[3], up(core, up(r0v, up(r1v, r2v))));
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int rr = o0 + k;
+    if (r0 + rr >= oh) break;
+    T best;
+    if constexpr (KEYS) best = zero_key_value<T>(m[k], zoff);
+    else best = m[k];
+    if constexpr (std::is_floating_point<T>::value) {  // (NaN: see the note above)
+      int a = -1;
+      while (4 * ((a + 1) * (a + 1) + radius * radius) < s2) ++a;
+      const K first = tile[rr * pitch + c + radius - a];
+      if constexpr (KEYS) {
+        if (first == ZeroKey<T>::NAN_KEY) best = sband[(size_t)(r0 + rr) * w + (c0 + c + radius - a)];
+      } else {
+        if (first != first) best = first;
+      }
+    }
+    // still the minimum on a no-data centre: no-data again (spatial.py:208-209).  Rare: only then is the
+    // original centre fetched (the LDS copy cannot tell "was no data" from "is the minimum")
+    if (has_ndv && best == minimum) {
+      const T centre = sband[(size_t)(r0 + rr + radius) * w + (c0 + c + radius)];
+      if (centre == ndv) best = ndv;
+    }
+    __builtin_nontemporal_store(best, out + ((size_t)b * oh + (r0 + rr)) * ow + (c0 + c));
+  }
+}
 
 // RMAX: largest radius of the instantiation (bounds the staging loops at compile time so that all of
 // a wave's window loads are in flight together instead of one load-wait-store round trip per row)
 template <typename T, int RMAX>
 __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                         int size, int has_ndv, T ndv, T minimum, unsigned* seen, unsigned ticket) {
+                                                         int size, int has_ndv, T ndv, T minimum) {
   extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ unsigned flags[4];
   T* const tile = (T*)smem;
   const int radius = size / 2;
   const int oh = h - 2 * radius, ow = w - 2 * radius;
@@ -478,58 +605,27 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
       if (y < win_h && x < win_w) tile[y * pitch + x] = (has_ndv && v == ndv) ? minimum : v;
     }
   }
-  if (negative_zero) *seen = ticket;
-  __syncthreads();
-  // A lane owns 4 CONSECUTIVE output rows of one column.  The circle is scanned column by column
-  // (wave-uniform dx): the vertical runs of the 4 outputs overlap in all but 3 rows at either end,
-  // so the shared core is read and reduced once -- (2 hh + 4) LDS reads per column for 4 outputs
-  // instead of 4 (2 hh + 1); consecutive lanes read consecutive addresses (no bank conflicts).
-  const int c = threadIdx.x & 63, o0 = (threadIdx.x >> 6) * 4;
-  if (c0 + c >= ow) return;
-  const int s2 = size * size;
-  T m[4] = {minimum, minimum, minimum, minimum};
-  auto up = [](T a, T b) -> T { return hw_max(a, b); };
-  for (int dx = 0; dx < size; ++dx) {
-    const int xx = dx - radius;
-    int hh = -1;  // half-height of the footprint's column: (x^2 + y^2) < (size/2)^2 (utils.py:536-547)
-    while (4 * (xx * xx + (hh + 1) * (hh + 1)) < s2) ++hh;
-    if (hh < 0) continue;
-    const T* col = tile + (c + dx);
-    const int first = o0 + radius - hh;  // window row of the topmost cell of output 0's run
-    if (hh == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] = up(m[k], col[(first + k) * pitch]);
-      continue;
+  if constexpr (std::is_floating_point<T>::value) {
+    if (workgroup_any_and_sync(negative_zero, flags)) {
+      // a -0.0 in this window: the walk over keys (see "The sign of a zero maximum"); zeros rank in raster order, first wins
+      // -- but by column, then by row, last wins, under the all-true 3 x 3 footprint (8-byte cells come here at every size)
+      typedef typename ZeroKey<T>::K K;
+      K* const keys = (K*)smem;
+      const int rows = MM_TILE_H + 2 * radius, cells = rows * pitch, zoff = 2 * cells;
+      for (int i = threadIdx.x; i < cells; i += 256) {
+        const int y = i / pitch, x = i - y * pitch;
+        const T v = (y < win_h && x < win_w) ? tile[i] : minimum;  // (cells nobody staged)
+        keys[i] = zero_key<T>(v, size == 3 ? x * rows + y : cells - 1 - i, zoff);
+      }
+      __syncthreads();
+      moving_max_walk<T, K>(keys, pitch, sband, out, b, w, size, radius, oh, ow, r0, c0, has_ndv, ndv, minimum,
+                            zero_key<T>(minimum, 0, zoff), zoff);
+      return;
     }
-    const T l0 = col[first * pitch], l1 = col[(first + 1) * pitch], l2 = col[(first + 2) * pitch];
-    const int after = first + 2 * hh + 1;
-    const T r0v = col[after * pitch], r1v = col[(after + 1) * pitch], r2v = col[(after + 2) * pitch];
-    T core = minimum;
-    for (int y = first + 3; y < after; ++y) core = up(core, col[y * pitch]);
-    m[0] = up(m[0], up(core, up(l0, up(l1, l2))));
-    m[1] = up(m[1], up(core, up(l1, up(l2, r0v))));
-    m[2] = up(m[2], up(core, up(l2, up(r0v, r1v))));
-    m[3] = up(m[3], up(core, up(r0v, up(r1v, r2v))));
+  } else {
+    __syncthreads();
   }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int rr = o0 + k;
-    if (r0 + rr >= oh) break;
-    T best = m[k];
-    if constexpr (std::is_floating_point<T>::value) {  // (NaN: see the note above the kernel)
-      int a = -1;
-      while (4 * ((a + 1) * (a + 1) + radius * radius) < s2) ++a;
-      const T first = tile[rr * pitch + c + radius - a];
-      if (first != first) best = first;
-    }
-    // still the minimum on a no-data centre: no-data again (spatial.py:208-209).  Rare: only then is the
-    // original centre fetched (the LDS copy cannot tell "was no data" from "is the minimum")
-    if (has_ndv && best == minimum) {
-      const T centre = sband[(size_t)(r0 + rr + radius) * w + (c0 + c + radius)];
-      if (centre == ndv) best = ndv;
-    }
-    __builtin_nontemporal_store(best, out + ((size_t)b * oh + (r0 + rr)) * ow + (c0 + c));
-  }
+  moving_max_walk<T, T>(tile, pitch, sband, out, b, w, size, radius, oh, ow, r0, c0, has_ndv, ndv, minimum, minimum, 0);
 }
 
 // The 3 x 3 footprint (size 3: every cell of the square satisfies x^2 + y^2 < 2.25) is separable: the
@@ -537,35 +633,32 @@ __global__ __launch_bounds__(256) void moving_max_kernel(const T* __restrict__ i
 // workgroup stages the 18 x 258 window of its 16 x 256 outputs (no data lowered to the dtype's minimum,
 // all loads of a lane in flight), a lane walks its column keeping the row maxima of the last two rows.
 constexpr int M3_H = 16, M3_W = 256;
-template <typename T>
-__global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                          int pitch, int opitch, int has_ndv, T ndv, T minimum, unsigned* seen, unsigned ticket) {
-  __shared__ T tile[(M3_H + 2) * (M3_W + 2)];
-  const int c0 = blockIdx.x * M3_W, r0 = blockIdx.y * M3_H, b = blockIdx.z;
-  const int ow = w - 2, oh = h - 2;
-  const T* plane = in + (size_t)b * h * w;
+template <typename T, typename K>
+__device__ __forceinline__ void moving_max3_walk(const K* tile, const T* __restrict__ plane, T* __restrict__ out, int b, int oh, int ow,
+                                                 int r0, int c0, int pitch, int opitch, int has_ndv, T ndv, T minimum, int zoff) {
+  constexpr bool KEYS = !std::is_same<T, K>::value;
   constexpr int PITCH = M3_W + 2;
-  bool negative_zero = false;
-  stage_window<T, M3_H + 2, 2>(tile, plane, r0, c0, h, w, pitch, [&](T v) {
-    negative_zero |= is_negative_zero(v);
-    return (has_ndv && v == ndv) ? minimum : v;  // spatial.py:199-203
-  });
-  if (negative_zero) *seen = ticket;
-  __syncthreads();
   const int c = c0 + threadIdx.x;
   if (c >= ow) return;
-  const T* col = tile + threadIdx.x;
-  auto row_max = [&](int wy) -> T { return hw_max3(col[wy * PITCH], col[wy * PITCH + 1], col[wy * PITCH + 2]); };
-  T above = row_max(0), centre = row_max(1);
+  const K* col = tile + threadIdx.x;
+  auto row_max = [&](int wy) -> K { return hw_max3(col[wy * PITCH], col[wy * PITCH + 1], col[wy * PITCH + 2]); };
+  K above = row_max(0), centre = row_max(1);
 #pragma unroll
   for (int r = 0; r < M3_H; ++r) {
-    const T below = row_max(r + 2);
-    T best = hw_max3(above, centre, below);
+    const K below = row_max(r + 2);
+    const K top = hw_max3(above, centre, below);
     above = centre;
     centre = below;
-    if constexpr (std::is_floating_point<T>::value) {  // (NaN: see the note above moving_max_kernel)
-      const T first = col[r * PITCH];
-      if (first != first) best = first;
+    T best;
+    if constexpr (KEYS) best = zero_key_value<T>(top, zoff);
+    else best = top;
+    if constexpr (std::is_floating_point<T>::value) {  // (NaN: see the note above moving_max_walk)
+      const K first = col[r * PITCH];
+      if constexpr (KEYS) {
+        if (first == ZeroKey<T>::NAN_KEY) best = plane[(size_t)(r0 + r) * pitch + c];
+      } else {
+        if (first != first) best = first;
+      }
     }
     if (r0 + r < oh) {
       // still the minimum on a no-data centre: no-data again (spatial.py:208-209); only then is the
@@ -577,6 +670,39 @@ __global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ 
       __builtin_nontemporal_store(best, out + (size_t)b * oh * ow + (size_t)(r0 + r) * opitch + c);
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void moving_max3_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
+                                                          int pitch, int opitch, int has_ndv, T ndv, T minimum) {
+  constexpr int ROWS = M3_H + 2, PITCH = M3_W + 2;
+  __shared__ T tile[ROWS * PITCH];
+  __shared__ unsigned flags[4];
+  const int c0 = blockIdx.x * M3_W, r0 = blockIdx.y * M3_H, b = blockIdx.z;
+  const int ow = w - 2, oh = h - 2;
+  const T* plane = in + (size_t)b * h * w;
+  bool negative_zero = false;
+  stage_window<T, ROWS, 2>(tile, plane, r0, c0, h, w, pitch, [&](T v) {
+    negative_zero |= is_negative_zero(v);
+    return (has_ndv && v == ndv) ? minimum : v;  // spatial.py:199-203
+  });
+  if constexpr (std::is_same<T, float>::value) {
+    if (workgroup_any_and_sync(negative_zero, flags)) {
+      // a -0.0 in this window: keys; zeros rank by column, then by row -- the bottom-most zero of the right-most column wins
+      int* const keys = (int*)tile;
+      constexpr int zoff = 2 * ROWS * PITCH;
+      for (int i = threadIdx.x; i < ROWS * PITCH; i += 256) {
+        const int y = i / PITCH, x = i - y * PITCH;
+        keys[i] = zero_key<float>(tile[i], x * ROWS + y, zoff);
+      }
+      __syncthreads();
+      moving_max3_walk<T, int>(keys, plane, out, b, oh, ow, r0, c0, pitch, opitch, has_ndv, ndv, minimum, zoff);
+      return;
+    }
+  } else {
+    __syncthreads();
+  }
+  moving_max3_walk<T, T>(tile, plane, out, b, oh, ow, r0, c0, pitch, opitch, has_ndv, ndv, minimum, 0);
 }
 
 // Fixed small footprints (sizes 5 to 15).  The disk is a stack of horizontal runs: out(r) = max over dy of
@@ -596,36 +722,27 @@ __host__ __device__ constexpr int disk_half_width(int dy) {
 
 // output rows per workgroup: the walk passes TH + 2 R window rows for TH outputs
 __host__ __device__ constexpr int disk_tile_rows(int R) { return R >= 7 ? 32 : 16; }
-template <typename T, int R>
-__global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
-                                                              int pitch, int opitch, int has_ndv, T ndv, T minimum, unsigned* seen, unsigned ticket) {
+template <typename T, typename K, int R>
+__device__ __forceinline__ void moving_max_disk_walk(const K* tile, const T* __restrict__ plane, T* __restrict__ out, int b, int oh,
+                                                     int ow, int r0, int c0, int pitch, int opitch, int has_ndv, T ndv, T minimum,
+                                                     K identity, int zoff) {
+  constexpr bool KEYS = !std::is_same<T, K>::value;
   constexpr int TH = disk_tile_rows(R), TW = 256, PITCH = TW + 2 * R, ROWS = TH + 2 * R;
-  __shared__ T tile[ROWS * PITCH];
-  const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH, b = blockIdx.z;
-  const int ow = w - 2 * R, oh = h - 2 * R;
-  const T* plane = in + (size_t)b * h * w;
-  bool negative_zero = false;
-  stage_window<T, ROWS, 2 * R>(tile, plane, r0, c0, h, w, pitch, [&](T v) {
-    negative_zero |= is_negative_zero(v);
-    return (has_ndv && v == ndv) ? minimum : v;  // spatial.py:199-203
-  });
-  if (negative_zero) *seen = ticket;
-  __syncthreads();
   const int c = c0 + threadIdx.x;
   if (c >= ow) return;
-  const T* col = tile + threadIdx.x;  // window columns threadIdx.x .. threadIdx.x + 2 R = dx -R .. R
-  T hm[2 * R + 1][R + 1];             // hm[k][a]: HM_a of window row y - 2 R + k after window row y was taken
+  const K* col = tile + threadIdx.x;  // window columns threadIdx.x .. threadIdx.x + 2 R = dx -R .. R
+  K hm[2 * R + 1][R + 1];             // hm[k][a]: HM_a of window row y - 2 R + k after window row y was taken
 #pragma unroll
   for (int k = 0; k <= 2 * R; ++k)
 #pragma unroll
-    for (int a = 0; a <= R; ++a) hm[k][a] = minimum;
+    for (int a = 0; a <= R; ++a) hm[k][a] = identity;
 #pragma unroll
   for (int y = 0; y < ROWS; ++y) {
 #pragma unroll
     for (int k = 0; k < 2 * R; ++k)
 #pragma unroll
       for (int a = 0; a <= R; ++a) hm[k][a] = hm[k + 1][a];
-    T v[2 * R + 1];
+    K v[2 * R + 1];
 #pragma unroll
     for (int j = 0; j <= 2 * R; ++j) v[j] = col[y * PITCH + j];
     hm[2 * R][0] = v[R];
@@ -633,14 +750,21 @@ __global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restric
     for (int a = 1; a <= R; ++a) hm[2 * R][a] = hw_max3(hm[2 * R][a - 1], v[R - a], v[R + a]);
     if (y >= 2 * R) {
       const int r = y - 2 * R;
-      T best = hm[0][disk_half_width<R>(R)];
+      K top = hm[0][disk_half_width<R>(R)];
 #pragma unroll
       for (int k = 1; k <= 2 * R; k += 2)
-        best = hw_max3(best, hm[k][disk_half_width<R>(k > R ? k - R : R - k)],
-                       hm[k + 1][disk_half_width<R>(k + 1 > R ? k + 1 - R : R - k - 1)]);
-      if constexpr (std::is_floating_point<T>::value) {  // (NaN: see the note above moving_max_kernel)
-        const T first = col[r * PITCH + R - disk_half_width<R>(R)];
-        if (first != first) best = first;
+        top = hw_max3(top, hm[k][disk_half_width<R>(k > R ? k - R : R - k)],
+                      hm[k + 1][disk_half_width<R>(k + 1 > R ? k + 1 - R : R - k - 1)]);
+      T best;
+      if constexpr (KEYS) best = zero_key_value<T>(top, zoff);
+      else best = top;
+      if constexpr (std::is_floating_point<T>::value) {  // (NaN: see the note above moving_max_walk)
+        const K first = col[r * PITCH + R - disk_half_width<R>(R)];
+        if constexpr (KEYS) {
+          if (first == ZeroKey<T>::NAN_KEY) best = plane[(size_t)(r0 + r) * pitch + (c + R - disk_half_width<R>(R))];
+        } else {
+          if (first != first) best = first;
+        }
       }
       if (r0 + r < oh) {
         if (has_ndv && best == minimum) {  // no data again where the centre was no data (spatial.py:208-209)
@@ -653,56 +777,35 @@ __global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restric
   }
 }
 
-// The zero-sign pass (float tiles only; returns at once unless the launch before it noted a -0.0 in its input).
-// For every output that is a zero: the zero SciPy's scan leaves standing, restated from measurements against
-// scipy.ndimage.maximum_filter 1.15 (tools/ulp_measure.py has no say here: the value is 0 either way, only its sign moves):
-//   * a footprint with holes (sizes 5 and up: the disk) is scanned in raster order, a later cell replaces the running
-//     maximum only when it compares GREATER -- the FIRST zero of the footprint stays;
-//   * the all-true 3 x 3 footprint takes SciPy's separable route, maximum_filter1d down the columns and then along the
-//     rows, whose running-maximum queue takes a later cell that compares greater OR EQUAL -- the bottom-most zero of the
-//     right-most column that has one.
-// No data is lowered to the dtype's minimum first, as in the kernels above; an output with no zero in its footprint
-// (a no-data centre restored to a no-data value of 0) keeps what it has.
-template <typename T>
-__global__ __launch_bounds__(256) void moving_max_zero_sign_kernel(const T* __restrict__ in, int h, int w, int pitch,
-                                                                   T* __restrict__ out, int opitch, int bands, int size,
-                                                                   int has_ndv, T ndv, const unsigned* __restrict__ seen,
-                                                                   unsigned ticket) {
-  if (*seen != ticket) return;
-  // (a few workgroups that walk the tiles: a grid of one workgroup per tile costs its dispatch -- 50 us for an 8192^2
-  //  raster -- on every launch, also on the ones that return here)
-  const int radius = size / 2, oh = h - 2 * radius, ow = w - 2 * radius, s2 = size * size;
-  const int tiles_x = (ow + 63) / 64, tiles_y = (oh + 3) / 4;
-  const long long tiles = (long long)tiles_x * tiles_y * bands;
-  for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
-    const int b = (int)(t / ((long long)tiles_x * tiles_y)), rest = (int)(t - (long long)b * tiles_x * tiles_y);
-    const int c = (rest % tiles_x) * 64 + (threadIdx.x & 63), r = (rest / tiles_x) * 4 + (threadIdx.x >> 6);
-    if (c >= ow || r >= oh) continue;
-    T* const cell = out + (size_t)b * oh * ow + (size_t)r * opitch + c;
-    if (!(*cell == (T)0)) continue;
-    const T* const window = in + (size_t)b * h * w + (size_t)r * pitch + c;  // its top-left cell
-    bool found = false;
-    if (size == 3) {
-      for (int dx = 2; dx >= 0 && !found; --dx)
-        for (int dy = 2; dy >= 0 && !found; --dy) {
-          const T v = window[(size_t)dy * pitch + dx];
-          if (v == (T)0 && !(has_ndv && v == ndv)) {
-            *cell = v;
-            found = true;
-          }
-        }
-      continue;
+template <typename T, int R>
+__global__ __launch_bounds__(256) void moving_max_disk_kernel(const T* __restrict__ in, T* __restrict__ out, int h, int w,
+                                                              int pitch, int opitch, int has_ndv, T ndv, T minimum) {
+  constexpr int TH = disk_tile_rows(R), TW = 256, PITCH = TW + 2 * R, ROWS = TH + 2 * R;
+  __shared__ T tile[ROWS * PITCH];
+  __shared__ unsigned flags[4];
+  const int c0 = blockIdx.x * TW, r0 = blockIdx.y * TH, b = blockIdx.z;
+  const int ow = w - 2 * R, oh = h - 2 * R;
+  const T* plane = in + (size_t)b * h * w;
+  bool negative_zero = false;
+  stage_window<T, ROWS, 2 * R>(tile, plane, r0, c0, h, w, pitch, [&](T v) {
+    negative_zero |= is_negative_zero(v);
+    return (has_ndv && v == ndv) ? minimum : v;  // spatial.py:199-203
+  });
+  if constexpr (std::is_same<T, float>::value) {
+    if (workgroup_any_and_sync(negative_zero, flags)) {
+      // a -0.0 in this window: keys; zeros rank in raster order, the first of the footprint wins
+      int* const keys = (int*)tile;
+      constexpr int cells = ROWS * PITCH, zoff = 2 * cells;
+      for (int i = threadIdx.x; i < cells; i += 256) keys[i] = zero_key<float>(tile[i], cells - 1 - i, zoff);
+      __syncthreads();
+      moving_max_disk_walk<T, int, R>(keys, plane, out, b, oh, ow, r0, c0, pitch, opitch, has_ndv, ndv, minimum,
+                                      zero_key<float>(minimum, 0, zoff), zoff);
+      return;
     }
-    for (int dy = 0; dy < size && !found; ++dy)
-      for (int dx = 0; dx < size && !found; ++dx) {
-        if (4 * ((dx - radius) * (dx - radius) + (dy - radius) * (dy - radius)) >= s2) continue;
-        const T v = window[(size_t)dy * pitch + dx];
-        if (v == (T)0 && !(has_ndv && v == ndv)) {
-          *cell = v;
-          found = true;
-        }
-      }
+  } else {
+    __syncthreads();
   }
+  moving_max_disk_walk<T, T, R>(tile, plane, out, b, oh, ow, r0, c0, pitch, opitch, has_ndv, ndv, minimum, minimum, 0);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1473,32 +1576,6 @@ int cached_weights(const double* host, int count, const double** dev_out) {
   return GM_OK;
 }
 
-// The ring of "a -0.0 was staged" slots of the MovingMax kernels: launch n of a device owns slot n % 64 and writes n
-// there, so a slot never needs clearing (its last owner left n - 64 at most); 64 launches of one stream cannot overlap.
-constexpr int kZeroSignSlots = 64;
-std::mutex g_zero_sign_mu;
-std::map<int, std::pair<unsigned*, unsigned>> g_zero_sign;  // device -> (ring, launches so far)
-int zero_sign_slot(hipStream_t s, unsigned** slot, unsigned* ticket) {
-  int dev = 0;
-  GM_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lk(g_zero_sign_mu);
-  auto& ring = g_zero_sign[dev];
-  if (!ring.first) {
-    void* buf = nullptr;
-    int rc = gm_malloc(&buf, sizeof(unsigned) * kZeroSignSlots);
-    if (rc) return rc;
-    // (once per device, and finished before anybody's launch can write a ticket: another thread's stream must not see its
-    //  ticket wiped by a fill still queued on this one)
-    GM_HIP(hipMemsetAsync(buf, 0, sizeof(unsigned) * kZeroSignSlots, s));
-    GM_HIP(hipStreamSynchronize(s));
-    ring.first = (unsigned*)buf;
-  }
-  *ticket = ++ring.second;
-  if (*ticket == 0) *ticket = ++ring.second;  // (0 is what an untouched slot holds)
-  *slot = ring.first + *ticket % kZeroSignSlots;
-  return GM_OK;
-}
-
 constexpr size_t kGaussLdsDefault = 64 * 1024, kGaussLdsMax = 160 * 1024;
 
 template <typename T, bool ALONG_X, int COLS>
@@ -1689,27 +1766,9 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
     return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: the window of a size-%d footprint does not fit 64 KiB of LDS for this dtype", size);
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
-  unsigned* seen = nullptr;
-  unsigned ticket = 0;
-  const bool floats = dtype == GM_F32 || dtype == GM_F64;
-  if (floats) {
-    int rc = zero_sign_slot(s, &seen, &ticket);
-    if (rc) return rc;
-  }
-  // after a float launch: the sign of the zero maxima, should the launch have staged a -0.0 (see the kernel)
-  auto zero_signs = [&]() {
-    const long long tiles = (long long)((ow + 63) / 64) * ((oh + 3) / 4) * bands;
-    dim3 gridz((unsigned)std::min<long long>(tiles, 2048));
-    if (dtype == GM_F32)
-      hipLaunchKernelGGL(moving_max_zero_sign_kernel<float>, gridz, dim3(256), 0, s, (const float*)in, h, w, in_pitch, (float*)out,
-                         out_pitch_or(ow), bands, size, has_ndv, from_bits<float>(ndv_bits), seen, ticket);
-    else if (dtype == GM_F64)
-      hipLaunchKernelGGL(moving_max_zero_sign_kernel<double>, gridz, dim3(256), 0, s, (const double*)in, h, w, in_pitch,
-                         (double*)out, out_pitch_or(ow), bands, size, has_ndv, from_bits<double>(ndv_bits), seen, ticket);
-  };
   if (size == 3 && gm::dtype_size(dtype) <= 4 && (oh + M3_H - 1) / M3_H <= 65535) {
     dim3 grid3((unsigned)((ow + M3_W - 1) / M3_W), (unsigned)((oh + M3_H - 1) / M3_H), (unsigned)bands);
-#define GM_M3(T) hipLaunchKernelGGL(moving_max3_kernel<T>, grid3, dim3(256), 0, s, (const T*)in, (T*)out, h, w, in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket)
+#define GM_M3(T) hipLaunchKernelGGL(moving_max3_kernel<T>, grid3, dim3(256), 0, s, (const T*)in, (T*)out, h, w, in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>())
     switch (dtype) {
       case GM_U8: GM_M3(unsigned char); break;
       case GM_I8: GM_M3(signed char); break;
@@ -1721,7 +1780,6 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
       default: return gm::fail(GM_ERR_INVALID, "gm_moving_max: dtype %d", dtype);
     }
 #undef GM_M3
-    zero_signs();
     GM_HIP(hipGetLastError());
     return GM_OK;
   }
@@ -1732,22 +1790,22 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
   do {                                                                                                            \
     if (size == 5)                                                                                                \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 2>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket);                        \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
     else if (size == 7)                                                                                           \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 3>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket);                        \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
     else if (size == 9)                                                                                           \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 4>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket);                        \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
     else if (size == 11)                                                                                          \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 5>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket);                        \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
     else if (size == 13)                                                                                          \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 6>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket);                        \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
     else                                                                                                          \
       hipLaunchKernelGGL((moving_max_disk_kernel<T, 7>), gridd, dim3(256), 0, s, (const T*)in, (T*)out, h, w,     \
-                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket);                        \
+                         in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>());                        \
   } while (0)
     switch (dtype) {
       case GM_U8: GM_MD(unsigned char); break;
@@ -1760,7 +1818,6 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
       default: return gm::fail(GM_ERR_INVALID, "gm_moving_max: dtype %d", dtype);
     }
 #undef GM_MD
-    zero_signs();
     GM_HIP(hipGetLastError());
     return GM_OK;
   }
@@ -1771,7 +1828,7 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
 #define GM_MM_R(T, RMAX_)                                                                                      \
   hipLaunchKernelGGL((moving_max_kernel<T, RMAX_>), grid, dim3(256),                                           \
                      (size_t)(MM_TILE_H + 2 * radius) * (MM_TILE_W + 2 * radius) * sizeof(T), s, (const T*)in,   \
-                     (T*)out, h, w, size, has_ndv, from_bits<T>(ndv_bits), lowest<T>(), seen, ticket)
+                     (T*)out, h, w, size, has_ndv, from_bits<T>(ndv_bits), lowest<T>())
 #define GM_MM(T)                           \
   do {                                     \
     if (radius <= 3) GM_MM_R(T, 3);        \
@@ -1794,7 +1851,6 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
   }
 #undef GM_MM
 #undef GM_MM_R
-  zero_signs();
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
