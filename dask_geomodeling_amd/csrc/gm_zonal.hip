@@ -8,9 +8,9 @@
 //   * sum / mean are np.bincount(labels, weights=values): float64 accumulation cell after cell in raster
 //     order -- float64 addition is not associative, so only the same order gives the same bits;
 //   * minimum / maximum / median / percentile pick from the cells sorted by (label, value), NaN last.
-// Where the order matters the cells are sorted, not reduced in a tree: a STABLE radix sort by label (rocPRIM's
-// device-wide sort; keys of bit_width(n_labels) bits) leaves every label's active cells contiguous and in raster
-// order; the statistics that pick sort by value first.  Then
+// Where the order matters the cells are sorted, not reduced in a tree: a STABLE sort by label -- one counting pass for up to
+// 2047 labels, this file's own least-significant-digit radix sort (passes of that same counting pass over 11-bit digits)
+// beyond -- leaves every label's active cells contiguous and in raster order; the statistics that pick sort by value first.  Then
 //   * sum / mean (zonal_sum_kernel, zonal_short_sum_kernel): a wave (a lane for labels of a few cells) adds the label's
 //     cells in that order in float64 -- as a tree for the steps that are certified exact, as a chain of dependent
 //     additions for the others: bincount's bits either way;
@@ -22,8 +22,6 @@
 // (zonal_exact_kernel), and when only a few labels fail that test only their cells are gathered and sorted.
 // Results are float32 like the reference's `agg` array; labels without an active cell stay NaN.
 // HBM traffic: 8 algorithmic bytes per cell (value + label); the full sort moves ~40-100.
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include <algorithm>
 #include <climits>
 #include <cmath>
@@ -1846,7 +1844,7 @@ __global__ __launch_bounds__(256) void zonal_list_bounds_kernel(const unsigned l
 // ---------------------------------------------------------------------------------
 // the label sort as a stable partition (up to ZP_BINS - 1 labels)
 // ---------------------------------------------------------------------------------
-// np.lexsort / bincount's order needs the cells of every label in raster order: a STABLE sort by label.  rocPRIM's radix
+// np.lexsort / bincount's order needs the cells of every label in raster order: a STABLE sort by label.  A general radix
 // sort takes two 8-bit passes for the 11 bits of 1024 labels, each moving key and payload (2 x 103 us on the 12.6 M
 // cells of the default raster limit, + 30 us of histograms).  With a few thousand labels at most the sort is one
 // counting pass instead:
@@ -2069,6 +2067,173 @@ __global__ __launch_bounds__(64 * NW) void zonal_part_scatter_kernel(const unsig
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------
+// stable radix sort of (key, value) pairs: passes of the counting pass above over digits of up to 11 bits
+// ---------------------------------------------------------------------------------
+// What the partition cannot take in one pass -- more than ZP_BINS - 1 labels, a sort by VALUE (32- or 64-bit keys), the
+// (label << 32 | cell) list of the labels that need their cells in order -- is sorted least significant digit first: every pass
+// is the partition's count -> scan -> first -> scatter with digit = (key >> shift) & mask as the bin, moving key and value;
+// each pass is stable, so the whole is.  (Rounds 1-4 called rocPRIM's device radix sort here.)
+constexpr int RS_NW = 8;
+template <typename KeyT>
+__device__ __forceinline__ unsigned radix_digit(KeyT key, int shift, unsigned mask) {
+  return (unsigned)(key >> shift) & mask;
+}
+template <typename KeyT, int NW>
+__global__ __launch_bounds__(64 * NW) void radix_count_kernel(const KeyT* __restrict__ keys, unsigned cells, int shift, unsigned mask,
+                                                              int bins, unsigned* __restrict__ counts) {
+  __shared__ unsigned hist[ZP_BINS];
+  for (int b = threadIdx.x; b < bins; b += 64 * NW) hist[b] = 0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int WAVE_CELLS = ZP_TILE / NW, STEPS = WAVE_CELLS / 64, GROUP = STEPS < 8 ? STEPS : 8;
+  const unsigned begin = blockIdx.x * (unsigned)ZP_TILE + (unsigned)wave * WAVE_CELLS;
+  for (int step0 = 0; step0 < STEPS; step0 += GROUP) {
+    unsigned digit[GROUP];
+#pragma unroll
+    for (int k = 0; k < GROUP; ++k) {
+      const unsigned i = begin + (unsigned)(step0 + k) * 64u + (unsigned)lane;
+      digit[k] = radix_digit(keys[min(i, cells - 1)], shift, mask);  // (unconditional load: see partition_histogram)
+      if (i >= cells) digit[k] = ~0u;
+    }
+#pragma unroll
+    for (int k = 0; k < GROUP; ++k) {
+      const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)digit[k]);
+      if (__all(digit[k] == f)) {
+        if (lane == 0 && f != ~0u) atomicAdd(&hist[f], 64u);
+      } else if (digit[k] != ~0u) {
+        atomicAdd(&hist[digit[k]], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += 64 * NW) counts[(size_t)blockIdx.x * bins + b] = hist[b];
+}
+
+template <typename KeyT, typename ValT, int NW>
+__global__ __launch_bounds__(64 * NW) void radix_scatter_kernel(const KeyT* __restrict__ keys, const ValT* __restrict__ values,
+                                                                unsigned cells, int shift, unsigned mask, int bins, int bits,
+                                                                const unsigned* __restrict__ offsets, const unsigned* __restrict__ first,
+                                                                KeyT* __restrict__ out_keys, ValT* __restrict__ out_values) {
+  constexpr int WAVE_CELLS = ZP_TILE / NW, STEPS = WAVE_CELLS / 64, GROUP = STEPS < ZP_GROUP ? STEPS : ZP_GROUP;
+  extern __shared__ unsigned cursor[];  // [NW][bins]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < NW * bins; i += 64 * NW) cursor[i] = 0;
+  __syncthreads();
+  unsigned* const mine = cursor + wave * bins;  // (a wave's LDS operations complete in order: no barrier around its own row)
+  const unsigned begin = blockIdx.x * (unsigned)ZP_TILE + (unsigned)wave * WAVE_CELLS;
+  for (int step0 = 0; step0 < STEPS; step0 += GROUP) {  // the wave's own histogram
+    unsigned digit[GROUP];
+#pragma unroll
+    for (int k = 0; k < GROUP; ++k) {
+      const unsigned i = begin + (unsigned)(step0 + k) * 64u + (unsigned)lane;
+      digit[k] = radix_digit(keys[min(i, cells - 1)], shift, mask);
+      if (i >= cells) digit[k] = ~0u;
+    }
+#pragma unroll
+    for (int k = 0; k < GROUP; ++k) {
+      const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)digit[k]);
+      if (__all(digit[k] == f)) {
+        if (lane == 0 && f != ~0u) atomicAdd(&mine[f], 64u);
+      } else if (digit[k] != ~0u) {
+        atomicAdd(&mine[digit[k]], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += 64 * NW) {  // the rows become the waves' write cursors
+    unsigned at = first[b] + offsets[(size_t)blockIdx.x * bins + b];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const unsigned c = cursor[w * bins + b];
+      cursor[w * bins + b] = at;
+      at += c;
+    }
+  }
+  __syncthreads();
+  for (int step0 = 0; step0 < STEPS; step0 += GROUP) {
+    unsigned digit[GROUP];
+    KeyT key[GROUP];
+    ValT cell[GROUP];
+#pragma unroll
+    for (int k = 0; k < GROUP; ++k) {
+      const unsigned i = begin + (unsigned)(step0 + k) * 64u + (unsigned)lane;
+      const unsigned at = min(i, cells - 1);
+      key[k] = keys[at];
+      cell[k] = values[at];
+      digit[k] = i < cells ? radix_digit(key[k], shift, mask) : ~0u;
+    }
+#pragma unroll
+    for (int k = 0; k < GROUP; ++k) {
+      const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)digit[k]);
+      if (__all(digit[k] == f)) {
+        if (f == ~0u) continue;
+        const unsigned base = mine[f];
+        if (lane == 0) mine[f] = base + 64u;
+        out_keys[base + lane] = key[k];
+        out_values[base + lane] = cell[k];
+        continue;
+      }
+      const bool valid = digit[k] != ~0u;
+      unsigned rank, count;
+      match_label(digit[k], valid, bits, &rank, &count);
+      if (valid) {
+        const unsigned base = mine[digit[k]];
+        if (rank + 1 == count) mine[digit[k]] = base + count;
+        out_keys[base + rank] = key[k];
+        out_values[base + rank] = cell[k];
+      }
+    }
+  }
+}
+
+struct RadixTemp {  // counts / offsets of a pass: tiles x bins each; totals, first: bins (+ 1)
+  unsigned *counts = nullptr, *offsets = nullptr, *totals = nullptr, *first = nullptr;
+  size_t tiles = 0;
+};
+static size_t radix_temp_bytes(size_t n) {
+  const size_t tiles = (n + ZP_TILE - 1) / ZP_TILE;
+  return sizeof(unsigned) * (2 * tiles * ZP_BINS + 2 * ZP_BINS + 2) + 64;
+}
+// Sorts the n pairs by bits [0, end_bit) of their keys; the sorted pairs end up in (keys_b, values_b), the contents of
+// (keys_a, values_a) are destroyed.  temp: radix_temp_bytes(n) bytes.
+template <typename KeyT, typename ValT>
+int radix_sort_pairs(void* temp, KeyT* keys_a, KeyT* keys_b, ValT* values_a, ValT* values_b, size_t n, int end_bit, hipStream_t s) {
+  if (n == 0) return GM_OK;
+  if (n >= (1ull << 32) - ZP_TILE) return gm::fail(GM_ERR_UNSUPPORTED, "gm_zonal_statistic: %zu cells in one sort", n);
+  const size_t tiles = (n + ZP_TILE - 1) / ZP_TILE;
+  unsigned* counts = (unsigned*)temp;
+  unsigned* offsets = counts + tiles * ZP_BINS;
+  unsigned* totals = offsets + tiles * ZP_BINS;
+  unsigned* first = totals + ZP_BINS;
+  if (end_bit < 1) end_bit = 1;
+  const int passes = (end_bit + 10) / 11, width = (end_bit + passes - 1) / passes;
+  KeyT *kin = keys_a, *kout = keys_b;
+  ValT *vin = values_a, *vout = values_b;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = pass * width, bits = std::min(width, end_bit - shift), bins = 1 << bits;
+    const unsigned mask = (unsigned)bins - 1u;
+    const size_t lds = sizeof(unsigned) * RS_NW * (size_t)bins;
+    if (lds > 65536)
+      GM_HIP(hipFuncSetAttribute((const void*)radix_scatter_kernel<KeyT, ValT, RS_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((radix_count_kernel<KeyT, RS_NW>), dim3((unsigned)tiles), dim3(64 * RS_NW), 0, s, kin, (unsigned)n, shift, mask, bins,
+                       counts);
+    hipLaunchKernelGGL(zonal_part_scan_kernel, dim3((unsigned)(((size_t)bins * 64 + 255) / 256)), dim3(256), 0, s, counts, (unsigned)tiles,
+                       bins, offsets, totals);
+    hipLaunchKernelGGL(zonal_part_first_kernel, dim3(1), dim3(256), 0, s, totals, bins, first);
+    hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, RS_NW>), dim3((unsigned)tiles), dim3(64 * RS_NW), lds, s, kin, vin, (unsigned)n,
+                       shift, mask, bins, bits, offsets, first, kout, vout);
+    std::swap(kin, kout);
+    std::swap(vin, vout);
+  }
+  GM_HIP(hipGetLastError());
+  if (kin != keys_b) {  // (an even number of passes ended in the a-buffers)
+    GM_HIP(hipMemcpyAsync(keys_b, kin, sizeof(KeyT) * n, hipMemcpyDeviceToDevice, s));
+    GM_HIP(hipMemcpyAsync(values_b, vin, sizeof(ValT) * n, hipMemcpyDeviceToDevice, s));
+  }
+  return GM_OK;
 }
 
 // ---------------------------------------------------------------------------------
@@ -2377,7 +2542,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   size_t temp_bytes = 0;
   unsigned label_bits = 1;
   while ((1ull << label_bits) <= (unsigned long long)n_labels) ++label_bits;
-  // (GM_ZONAL_PART=0: rocPRIM's radix sort for every label count -- A/B runs, and the tests compare the two)
+  // (GM_ZONAL_PART=0: the general radix sort for every label count -- A/B runs, and the tests compare the two)
   static const bool partition_allowed = !(getenv("GM_ZONAL_PART") && atoi(getenv("GM_ZONAL_PART")) == 0);
   // (sorts that start from cells in value order -- medians, percentiles -- see the labels as noise, where the partition's
   // per-lane scatter loses to the radix sort's exchange through LDS: 985 against 748 us; GM_ZONAL_PART=1 forces it, for the tests)
@@ -2397,7 +2562,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     long long* counts_f = counts + (size_t)f * n_labels;
     unsigned char* seen = f == 0 ? present : (unsigned char*)nullptr;
     // the keys / payloads the first pass writes are taken up front; the sort's double buffers and its temporary
-    // storage -- 8 to 12 more bytes per cell plus rocPRIM's scratch, gigabytes for a 16384^2 frame -- only once a
+    // storage -- 8 to 12 more bytes per cell plus the sort's scratch, gigabytes for a 16384^2 frame -- only once a
     // verdict asks for the full sort: sums that the two-pass parallel path answers never allocate them
     auto key_buffers = [&]() -> int {
       if (keys_a) return GM_OK;
@@ -2413,15 +2578,14 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         if ((rc2 = scratch.take((void**)&pay_b, sizeof(Key) * cells))) return rc2;
       }
       size_t temp_value = 0, temp_label = 0;
-      if (by_value && !select_path)
-        GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_value, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 0, 8 * sizeof(Key), s));
+      if (by_value && !select_path) temp_value = radix_temp_bytes((size_t)cells);
       if (select_path && !sel_state) {
         if ((rc2 = scratch.take((void**)&sel_state, sizeof(SelectState) * n_labels))) return rc2;
         if ((rc2 = scratch.take((void**)&sel_hist, sizeof(unsigned) * 256 * (size_t)n_labels))) return rc2;
         if ((rc2 = scratch.take((void**)&sel_next, sizeof(unsigned long long) * n_labels))) return rc2;
       }
       if (!partition) {
-        GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_label, keys_a, keys_b, pay_a, pay_b, (size_t)cells, 0, label_bits, s));
+        temp_label = radix_temp_bytes((size_t)cells);
       } else if (!part.offsets) {
         if (!part.counts && (rc2 = scratch.take((void**)&part.counts, sizeof(unsigned) * part_tiles * part_bins))) return rc2;
         if ((rc2 = scratch.take((void**)&part.offsets, sizeof(unsigned) * part_tiles * part_bins))) return rc2;
@@ -2435,7 +2599,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       return GM_OK;
     };
     // the stable sort by label of (keys, payload): one counting pass for up to ZP_BINS - 1 labels (which also yields
-    // first[]), rocPRIM's radix sort + the search for the bounds otherwise
+    // first[]), the general radix sort + the search for the bounds otherwise
     auto sort_by_label = [&](const unsigned* keys_in, const Key* pay_in, unsigned* keys_out, Key* pay_out) -> int {
       if (partition) {
         static const int nw = getenv("GM_ZONAL_PART_WAVES") ? atoi(getenv("GM_ZONAL_PART_WAVES")) : 8;
@@ -2459,8 +2623,10 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         else GM_ZP(8);
 #undef GM_ZP
       } else {
-        size_t bytes = temp_bytes;
-        GM_HIP(rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, pay_in, pay_out, (size_t)cells, 0, label_bits, s));
+        // (the sort is free to use its input as a buffer: nobody reads the unsorted pairs again)
+        if (int rc3 = radix_sort_pairs<unsigned, Key>(temp, const_cast<unsigned*>(keys_in), keys_out, const_cast<Key*>(pay_in), pay_out,
+                                                      (size_t)cells, (int)label_bits, s))
+          return rc3;
         hipLaunchKernelGGL(zonal_bounds_kernel, dim3((n_labels + 1 + 255) / 256), dim3(256), 0, s, keys_out, (unsigned)cells, n_labels, first);
       }
       GM_HIP(hipGetLastError());
@@ -2502,12 +2668,10 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
           if ((rc = local.take((void**)&list_b, sizeof(unsigned long long) * m))) return rc;
           if ((rc = local.take((void**)&value_a, sizeof(Key) * m))) return rc;
           if ((rc = local.take((void**)&value_b, sizeof(Key) * m))) return rc;
-          size_t list_bytes = 0;
-          GM_HIP(rocprim::radix_sort_pairs(nullptr, list_bytes, list_a, list_b, value_a, value_b, m, 0, 32 + label_bits, s));
-          if ((rc = local.take(&list_temp, list_bytes))) return rc;
+          if ((rc = local.take(&list_temp, radix_temp_bytes(m)))) return rc;
           hipLaunchKernelGGL(zonal_gather_kernel<Key>, dim3(blocks), dim3(256), 0, s, keys_a, pay_a, (size_t)cells, n_labels, inexact,
                              list_a, value_a, cursor);
-          GM_HIP(rocprim::radix_sort_pairs(list_temp, list_bytes, list_a, list_b, value_a, value_b, m, 0, 32 + label_bits, s));
+          if ((rc = radix_sort_pairs<unsigned long long, Key>(list_temp, list_a, list_b, value_a, value_b, m, 32 + (int)label_bits, s))) return rc;
           hipLaunchKernelGGL(zonal_list_bounds_kernel, dim3((n_labels + 1 + 255) / 256), dim3(256), 0, s, list_b, (unsigned)m, n_labels, first);
           hipLaunchKernelGGL(zonal_short_sum_kernel<T>, dim3((n_labels + 255) / 256), dim3(256), 0, s, value_b, first, n_labels, statistic,
                              inexact, out_f, counts_f);
@@ -2533,7 +2697,6 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     }
     const unsigned* sorted_keys;
     const Key* sorted_pay;
-    size_t bytes = temp_bytes;
     if (select_path) {
       // the cells of every label together (in any order), then the wanted ranks by radix select: no sort by value
       if ((rc = sort_by_label(keys_a, pay_a, (unsigned*)nullptr, pay_b))) return rc;
@@ -2556,7 +2719,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     }
     if (by_value) {
       // lexsort((values, labels)): by value, then stably by label
-      GM_HIP(rocprim::radix_sort_pairs(temp, bytes, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 0, 8 * sizeof(Key), s));
+      if ((rc = radix_sort_pairs<Key, unsigned>(temp, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 8 * (int)sizeof(Key), s))) return rc;
       if ((rc = sort_by_label(keys_b, pay_b, keys_a, pay_a))) return rc;
       sorted_keys = keys_a;
       sorted_pay = pay_a;
