@@ -2647,8 +2647,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
                          n_labels, has_ndv, ndv, thresholds, range, sums, seen, keys_a, pay_a, part.counted ? part.counts : (unsigned*)nullptr);
       hipLaunchKernelGGL(zonal_exact_decide_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, n_labels, inexact, verdict_dev);
       ExactVerdict verdict{1u, 0u, (unsigned long long)cells};
-      GM_HIP(hipMemcpyAsync(&verdict, verdict_dev, sizeof(verdict), hipMemcpyDeviceToHost, s));
-      GM_HIP(hipStreamSynchronize(s));
+      if ((rc = gm_d2h(&verdict, verdict_dev, sizeof(verdict)))) return rc;  // (the one host decision of a sum: through pinned memory)
       // every label exact: the parallel sums are the answer.  A few labels not (they hold at most 1/8 of the cells): the
       // parallel sums answer all the others, and only the cells of those few are sorted and added in order.
       const bool partial = verdict.labels != 0 && verdict.cells != 0 && verdict.cells <= (unsigned long long)cells / 8;
