@@ -236,9 +236,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(const C* __restrict__ stack
       const bool nd = x != x;
       cnt[e] += nd ? 0 : 1;
       if constexpr (STAT == GM_RED_MIN) {
-        acc[e] = (acc[e] <= x || nd) ? acc[e] : x;  // np.fmin.reduce, the accumulator first
+        // np.fmin.reduce over the rasters.  A tie -- +0.0 against -0.0 -- goes to the LATER raster, as in the temporal kernels
+        // (gm_temporal.hip aggregate_kernel): NumPy's loops on x86 hosts end in minps / maxps, which hand back their second
+        // operand when the two compare equal (np.nanmin([[0.], [-0.]], axis=0) is -0.0, the other order +0.0)
+        acc[e] = (acc[e] < x || nd) ? acc[e] : x;
       } else if constexpr (STAT == GM_RED_MAX) {
-        acc[e] = (acc[e] >= x || nd) ? acc[e] : x;
+        acc[e] = (acc[e] > x || nd) ? acc[e] : x;
       } else if constexpr (STAT == GM_RED_PRODUCT) {
         const C y = nd ? (C)1 : x;
         acc[e] = j == 0 ? y : acc[e] * y;  // (float16: the product runs in float32 and is rounded once, below)

@@ -215,6 +215,22 @@ def _whole_instead_of_tiles(store, request, kwargs, tile_requests):
     height, width = kwargs["shape_yx"]
     if height * width > (1 << 28) or len(tile_requests) < 2:
         return False
+    # the tiler exists to bound the memory of a task (parallelize.py:43-91): the whole box at once must stay moderate in BYTES --
+    # the frames a temporal store would hold in its window and the width of its cells count, not just the cells of one frame
+    # (a series of N frames answered whole allocates N times the intermediates the tiles would, one after the other)
+    try:
+        frames = 1
+        start, stop, delta = request.get("start"), request.get("stop"), getattr(store, "timedelta", None)
+        if delta and start is not None and stop is not None:
+            frames = max(1, int((stop - start) / delta) + 1)
+        if height * width * frames * max(np.dtype(kwargs["dtype"]).itemsize, 4) > (4 << 30):
+            return False
+    except (TypeError, ValueError, OverflowError):
+        return False
+    if getattr(store, "gm_direct", False) and hasattr(type(store), "gm_batch") and not _batches_tiles(store):
+        # a stencil that takes tiles in one launch, over a COMPUTED store: tile after tile is the faster order (every intermediate
+        # tile is read back while the Infinity Cache still holds it: 1.04 against 1.64 ms for a 16-tile HillShade(A * 2 + B))
+        return False
     if getattr(type(store).process, "gm_op", None) is not None and \
             max(tile["width"] * tile["height"] for _, tile in tile_requests) >= _BATCHED_TILE_CELLS:
         # element-wise stores are batched over the tiles and written into the mosaic (TiledAssembly): one launch, at the kernel's

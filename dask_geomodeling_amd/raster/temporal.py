@@ -88,6 +88,8 @@ def _remembered(method):
     def hashable(a):
         if isinstance(a, (list, pd.DatetimeIndex)):
             return tuple(a)
+        if isinstance(a, (int, float)) and not isinstance(a, bool):
+            return (type(a).__name__, a)  # (1 and 1.0 hash alike but mean different things to shifted(): periods vs a fraction)
         return a
 
     def wrapper(self, *args):
@@ -398,10 +400,8 @@ def aggregate_frames(values, no_data_value, runs, statistic, dtype, fill=None, k
     if name not in STATISTIC_CODES and percentile is None:
         raise NotImplementedError("TemporalAggregate statistic %r" % statistic)
     src, code, has, bits, frames, height, width = _reduce_args(values, no_data_value)
-    if keep_nonfinite:
-        if name != "median" and percentile is None:
-            raise NotImplementedError("keep_nonfinite with statistic %r" % statistic)
-        has |= 2  # GM_TEMPORAL_KEEP_NONFINITE
+    if keep_nonfinite and name != "median" and percentile is None:
+        raise NotImplementedError("keep_nonfinite with statistic %r" % statistic)
     longest = max([count for _, count in runs] + [1])
     # (median / percentiles: a cell's data frames are sorted in LDS up to MAX_MEDIAN_FRAMES float32 / 320 float64
     #  frames per label; longer bins -- a year of hourly frames -- are selected in global memory: no limit)
@@ -412,6 +412,8 @@ def aggregate_frames(values, no_data_value, runs, statistic, dtype, fill=None, k
         if narrow is None:
             raise NotImplementedError("%s of a %s raster as %s" % (statistic, src.dtype, np.dtype(dtype)))
         src, code, has, bits, frames, height, width = narrow
+    if keep_nonfinite:
+        has |= 2  # GM_TEMPORAL_KEEP_NONFINITE (after the narrowing, which hands back flags of its own)
     out = DeviceArray.empty((len(runs), height, width), np.dtype(dtype))
     fill_bits = _fill_bits(statistic, dtype) if fill is None else runtime.scalar_bits(fill, np.dtype(dtype))
     if percentile is not None:
