@@ -1026,7 +1026,9 @@ struct Machine {
       case GM_OP_FMAX:
         if constexpr (is_float_class<RC>::value) {
 #pragma unroll
-          for (int k = 0; k < N; ++k) acc[k] = ((acc[k] >= b[k]) | (b[k] != b[k])) ? acc[k] : b[k];
+          // (a tie -- the two zeros -- goes to the later operand, like the minima / maxima of gm_reduce.hip and gm_temporal.hip:
+          //  NumPy's loops on x86 hosts end in maxps, which hands back its second operand when the two compare equal)
+          for (int k = 0; k < N; ++k) acc[k] = ((acc[k] > b[k]) | (b[k] != b[k])) ? acc[k] : b[k];
         }
         break;
       case GM_OP_NANTOFILL:

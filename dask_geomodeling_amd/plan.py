@@ -227,9 +227,11 @@ def _whole_instead_of_tiles(store, request, kwargs, tile_requests):
             return False
     except (TypeError, ValueError, OverflowError):
         return False
-    if getattr(store, "gm_direct", False) and hasattr(type(store), "gm_batch") and not _batches_tiles(store):
-        # a stencil that takes tiles in one launch, over a COMPUTED store: tile after tile is the faster order (every intermediate
-        # tile is read back while the Infinity Cache still holds it: 1.04 against 1.64 ms for a 16-tile HillShade(A * 2 + B))
+    if getattr(store, "gm_direct", False) and hasattr(type(store), "gm_batch") and not _batches_tiles(store) and \
+            max(tile["width"] * tile["height"] for _, tile in tile_requests) >= _BATCHED_TILE_CELLS:
+        # a stencil that takes tiles in one launch, over a COMPUTED store, in LARGE tiles: tile after tile is the faster order
+        # (every intermediate tile is read back while the Infinity Cache still holds it: 1.04 against 1.64 ms for a 16-tile
+        # HillShade(A * 2 + B) in 4096^2 tiles); it is the planning around small tiles that one request for the whole saves
         return False
     if getattr(type(store).process, "gm_op", None) is not None and \
             max(tile["width"] * tile["height"] for _, tile in tile_requests) >= _BATCHED_TILE_CELLS:

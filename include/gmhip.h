@@ -180,7 +180,7 @@ enum gm_opcode {
   GM_OP_NANIFNODATA = 29, /* a where a is data (utils.get_index: isclose rule for float tiles, flags / aux1 /
                              aux2 as MASK) else NaN; flags & 8: the data value rounded to float16 (the work dtype
                              of a 1-byte output, reduction.py:99-107, over wider rasters) */
-  GM_OP_FMAX = 30,        /* np.fmax(a, b) = (a >= b || isnan(b)) ? a : b  -- what np.nanmax reduces with */
+  GM_OP_FMAX = 30,        /* np.fmax(a, b) = (a > b || isnan(b)) ? a : b  -- what np.nanmax reduces with (ties: b) */
   GM_OP_NANTOFILL = 31,   /* fill where a is NaN else a */
   GM_OP_COUNT
 };

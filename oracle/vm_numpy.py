@@ -207,7 +207,7 @@ def run_program(prog, inputs, n):
                         r = r.astype(np.float16).astype(rc)
                 nd = np.zeros(n, dtype=bool)
             elif op == 30:  # fmax
-                r = np.where((a >= b) | np.isnan(b), a, b)
+                r = np.where((a > b) | np.isnan(b), a, b)  # (ties: the later operand, as maxps does)
                 nd = np.zeros(n, dtype=bool)
             elif op == 31:  # nantofill
                 r = a.copy()
