@@ -419,7 +419,7 @@ def test_tiler_over_pixel_local_temporal_views_is_one_request(gpu, tiler_route):
         plan._whole_instead_of_tiles = original
 
 
-def test_tiler_over_a_stencil_is_one_request_where_the_margins_lie_inside(gpu, tiler_route):
+def test_tiler_over_a_stencil_is_one_request_where_the_margins_lie_inside(gpu):
     """Dilate, MovingMax and HillShade ask their store for the box grown by exactly the margin their kernels look at, so a mosaic
     of their tiles IS their answer for the whole box: a RasterTiler over one of them (alone, or under / over pixel-local Blocks
     with a kernel of their own) is ONE request where the grown box lies on the sources' grid (plan._whole_instead_of_tiles) --
