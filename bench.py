@@ -59,6 +59,9 @@ def parse_args():
     p.add_argument("--no-secondary", action="store_true",
                    help="skip the `secondary` block of the headline run (BASELINE configs[2], [3], [4] clocked in the same run)")
     p.add_argument("--secondary-steps", type=int, default=20)
+    p.add_argument("--in-process", action="store_true",
+                   help="mosaic only: run the tiles' fused programs in THIS process (what one worker of the scheduler does), "
+                        "so that rocprofv3 can attach to the kernels; never the product's route")
     p.add_argument("--leaves", default="owned", choices=["owned", "whole", "procedural"],
                    help="mosaic leaves: owned = every rank keeps the leaf windows of the tiles it owns resident "
                         "(4 x 16 GiB / N per GPU, generated on the owning GPU during warm-up); whole = every rank "
@@ -347,7 +350,7 @@ def end_to_end(raster, runtime, side, budget_s=6.0):
             v, us, n = rate(lambda: tiler.get_data(**whole), big * big, 4, share * 0.75)
         out["tiler_get_data_device_" + label] = {"Mpix/s": v, "us_per_request": us, "requests": n, "tiles": 16}
     # mixed views (round 4; tools/e2e_views.py is the long form): microseconds per request of the inner boxes on the plan
-    # path next to the bytes the view's kernels move / 6 TB/s -- a view far above that has a slow seam
+    # path next to the bytes the view's kernels move / 6 TB/s -- a view far above that has a slow seam (MEASUREMENTS 6.7)
     from datetime import datetime, timedelta
     frames = 8
     dt = generate_window((frames * side, side), "f4", 7003, 0.0, 100.0, F32MAX, LATTICE, 0, 0, frames * side, side)
@@ -624,8 +627,10 @@ def main_mosaic(args):
 
 def main():
     args = parse_args()
-    if args.workload == "mosaic":
+    if args.workload == "mosaic" and not args.in_process:
         raise SystemExit(main_mosaic(args))
+    if args.workload == "mosaic" and args.gpus > 1:
+        raise SystemExit("bench: --in-process is the one-GPU profiling variant of the mosaic workload")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -701,8 +706,11 @@ def main():
             jobs = build_reclass(raster, side, tiles, rank)
         elif args.workload == "bilinear":
             jobs = build_bilinear(raster, side, tiles, rank)
-        else:
+        elif args.workload == "tiler":
             jobs = build_tiler(raster, side, 4096, rank)
+        else:  # mosaic --in-process
+            jobs, _ = build_mosaic(raster, side, 0, 1, leaves="procedural" if args.procedural else args.leaves)
+            tiles = len(jobs[0][1])
         runtime.sync()
 
         def step():
@@ -790,7 +798,9 @@ def main():
                        "GPU per step in one launch" % (side, side, tiles),
             "bilinear": "bilinear 2x upsample %dx%d -> %dx%d f32 (BASELINE configs[3])" % (side, side, out_side, out_side),
             "tiler": "canonical chain under RasterTiler(4096) over two resident %dx%d sources: zero-copy windows in, "
-                     "mosaic written in place" % (side, side)}
+                     "mosaic written in place" % (side, side),
+            "mosaic": "10-Block view over the 65536^2 mosaic (BASELINE configs[4]), the %d tile programs of %dx%d run IN THIS PROCESS "
+                      "(profiling variant: what the one worker of the scheduler does)" % (tiles, side, side)}
         out = {
             "metric": "Mpix/s on 4096x4096 f32 tiles, 5-op elemwise chain; % of HBM roofline" if args.workload == "chain5"
                       else "Mpix/s, workload %s" % args.workload,

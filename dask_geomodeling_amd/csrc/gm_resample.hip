@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void nearest_gather_kernel(const T* __restrict
   // instead of one load-store round trip per row).  Every load is UNCONDITIONAL -- its address clamped into the raster, what
   // it must not deliver selected away afterwards -- and the one choice left, 16-byte loads or four gathers, is made for the
   // whole wave: with per-lane branches around the loads the compiler waited for every row's loads before it issued the next
-  // row's (round 3: eight memory round trips per workgroup, 2x up-sampling 278 us; see DESIGN K6).
+  // row's (round 3: eight memory round trips per workgroup, 2x up-sampling 278 us; see MEASUREMENTS K6).
   // the strip's source rows (wave-uniform): lane l works out row l mod ROWS, everybody reads them off the first lanes
   static_assert((ROWS & (ROWS - 1)) == 0 && ROWS <= 64, "ROWS");
   const int my_row = nearest_index(min(r_begin + (int)(threadIdx.x & (ROWS - 1)), hd - 1), hs, mode, row_map, eps);

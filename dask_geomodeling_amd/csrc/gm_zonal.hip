@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
   });
   // The run a wave ENDS in meets the other three waves' in LDS, and waves that end in the same label issue their atomics
   // together: under a label that covers the raster every wave ends on the same counters, and atomics on one address
-  // serialise (round 3: 4 x fewer of them; count under one label 111 -> see DESIGN K14).
+  // serialise (round 3: 4 x fewer of them; count under one label 111 -> see MEASUREMENTS K14).
   __shared__ int end_label[4];
   __shared__ unsigned long long end_count[4];
   __shared__ Key end_key[4];

@@ -94,7 +94,7 @@ def reclassify_node(store, process_kwargs):
 # (measured 8192^2: Classify 60 vs 111 us, Reclassify u8 -> i64 92 vs 220 us); the program ops exist
 # for fusion.  Tests flip this switch to pin the program route to the golden vectors as well.
 # 1-byte tiles always take the program route: a program over one 1-byte tile runs as a 256-entry table
-# (DESIGN K1b; Classify uint8 -> uint8 24 us, Reclassify uint8 -> int64 86 us on 8192^2).
+# (MEASUREMENTS K1b; Classify uint8 -> uint8 24 us, Reclassify uint8 -> int64 86 us on 8192^2).
 _PREFER_PROGRAM = False
 
 

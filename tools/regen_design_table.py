@@ -1,4 +1,4 @@
-"""Prints the measurement table of DESIGN.md section 8 for one round from profiles/<tag>_*_bench_line.json and
+"""Prints the measurement table of MEASUREMENTS.md section 8 for one round from profiles/<tag>_*_bench_line.json and
 profiles/<tag>_*_pmc.json (run after tools/collect_profiles.py):  python tools/regen_design_table.py r04"""
 import json
 import sys

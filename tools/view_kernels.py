@@ -4,7 +4,7 @@
   python3 tools/view_kernels.py --read gpurun_out/vk 12                                       # per-request kernel table
   PLANS=0 CPROFILE=1 python3 tools/view_kernels.py classify200                                # cProfile of 50 requests (graph path)
 
-Views: the series probes of tools/e2e_views.py that sit well above their kernels' time (series seams)."""
+Views: the series probes of tools/e2e_views.py that sit well above their kernels' time (MEASUREMENTS.md section 8, series seams)."""
 import csv, glob, sys
 from collections import OrderedDict
 
