@@ -111,6 +111,34 @@ def test_get_of_a_graph_with_memorysources(two_workers):
     assert len(shard._shared_arrays) == 1
 
 
+@pytest.mark.timeout(600)
+def test_series_tiles_and_tiles_that_are_cast(two_workers):
+    """A tiler over a view of a resident SERIES (tiles of several frames: every frame of a tile lands in its plane of the host
+    mosaic) and over a store whose tiles arrive in another dtype than the tiler declares (TemporalSum: int64 sums under a
+    declared int16 -- `values[...] = tile` casts on assignment, parallelize.py:118-124; here on the device, before the copy)."""
+    from datetime import datetime, timedelta
+    rng = np.random.default_rng(11)
+    s = (rng.random((5, 192, 256)) * 50).astype("f4")
+    s[rng.random(s.shape) < 0.1] = -9999.0
+    S = raster.MemorySource(s, -9999.0, "EPSG:28992", 1.0, (0.0, 192.0), time_first=datetime(2021, 3, 1),
+                            time_delta=timedelta(hours=6))
+    c = rng.integers(0, 40, size=(5, 192, 256)).astype("i2")
+    C = raster.MemorySource(c, -1, "EPSG:28992", 1.0, (0.0, 192.0), time_first=datetime(2021, 3, 1), time_delta=timedelta(hours=6))
+    box = dict(mode="vals", bbox=(0.0, 0.0, 256.0, 192.0), width=256, height=192, projection="EPSG:28992",
+               start=datetime(2021, 1, 1), stop=datetime(2021, 6, 1))
+    for view, tile in ((S * 2 + 1, [64, 48]), (raster.TemporalSum(C), [128, 64]), (raster.TemporalAggregate(S, "D", "max"), 96)):
+        tiler = raster.RasterTiler(view, tile)
+        with config.config.set({"geomodeling.devices": None}):
+            want = tiler.get_data(**box)
+        got = tiler.get_data(**box)
+        assert got["values"].shape == want["values"].shape and got["values"].dtype == want["values"].dtype, type(view).__name__
+        assert np.array_equal(_bits(got["values"]), _bits(want["values"])), type(view).__name__
+        with config.config.set({"geomodeling.devices": None}):
+            when = tiler.get_data(**dict(box, mode="time"))
+        assert tiler.get_data(**dict(box, mode="time")) == when  # (no tiles: one unit on one worker)
+    two_workers.sync()
+
+
 @pytest.mark.timeout(300)
 def test_a_forked_child_of_an_initialised_process_fails_loudly(gpu):
     """What dask's `processes` scheduler does by default (fork) after this process has used the GPU: the child's runtime calls
