@@ -172,6 +172,29 @@ __device__ __forceinline__ double wave_sum_exact(double v) {  // (for sums known
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// ... and for the counters of a run (zonal_direct_kernel / zonal_exact_kernel flush a run whenever the wave's label changes -- every
+// other step inside a 128-cell polygon row: the __shfl_xor butterflies there cost 6 LDS-crossbar round trips per quantity)
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+  v += (unsigned)dpp_move<0xB1>(0, (int)v);
+  v += (unsigned)dpp_move<0x4E>(0, (int)v);
+  v += (unsigned)dpp_move<0x141>(0, (int)v);
+  v += (unsigned)dpp_move<0x140>(0, (int)v);
+  v += (unsigned)dpp_move<0x142, 0xA>(0, (int)v);
+  v += (unsigned)dpp_move<0x143, 0xC>(0, (int)v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+  v |= (unsigned)dpp_move<0xB1>(0, (int)v);
+  v |= (unsigned)dpp_move<0x4E>(0, (int)v);
+  v |= (unsigned)dpp_move<0x141>(0, (int)v);
+  v |= (unsigned)dpp_move<0x140>(0, (int)v);
+  v |= (unsigned)dpp_move<0x142, 0xA>(0, (int)v);
+  v |= (unsigned)dpp_move<0x143, 0xC>(0, (int)v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) { return (unsigned)wave_max((int)(v ^ 0x80000000u)) ^ 0x80000000u; }
+__device__ __forceinline__ unsigned wave_umin(unsigned v) { return ~wave_umax(~v); }
+
 // top exponent / exponent of the lowest set bit of a cell as bincount sees it ((double)v), from the cell's own
 // representation where that is cheaper; zero, NaN and infinities are the caller's business (finite, not zero here)
 template <typename T>
@@ -1406,24 +1429,23 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
   unsigned run_count = 0;
   Key run_key = NEUTRAL;
   auto better = [](Key a, Key b) -> Key { return STAT == Z_MIN ? (b < a ? b : a) : (b > a ? b : a); };
+  auto wave_best = [&](Key key) -> Key {  // the wave's extreme key, in every lane
+    if constexpr (sizeof(Key) == 4) {
+      return STAT == Z_MIN ? wave_umin((unsigned)key) : wave_umax((unsigned)key);
+    } else {
+#pragma unroll
+      for (int offset = 32; offset >= 1; offset >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)key, offset), hi = __shfl_xor((unsigned)(key >> 32), offset);
+        key = better(key, ((Key)hi << 32) | lo);
+      }
+      return key;
+    }
+  };
   auto flush = [&]() {  // (wave-uniform call)
     if (run_label < 0) return;
-    unsigned long long n = run_count;
+    unsigned long long n = wave_sum_u32(run_count);  // (fewer than 2^32 cells)
     Key key = run_key;
-#pragma unroll
-    for (int offset = 32; offset >= 1; offset >>= 1) {
-      n += __shfl_xor((unsigned)n, offset);  // (fewer than 2^32 cells)
-      if constexpr (STAT != Z_COUNT) {
-        Key other;
-        if constexpr (sizeof(Key) == 8) {
-          const unsigned lo = __shfl_xor((unsigned)key, offset), hi = __shfl_xor((unsigned)(key >> 32), offset);
-          other = ((Key)hi << 32) | lo;
-        } else {
-          other = __shfl_xor(key, offset);
-        }
-        key = better(key, other);
-      }
-    }
+    if constexpr (STAT != Z_COUNT) key = wave_best(key);
     if (lane == 0 && n != 0) {
       atomicAdd(&counts[run_label], n);
       if constexpr (STAT == Z_MIN) atomicMin(&extreme[run_label], key);
@@ -1476,22 +1498,9 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
   __shared__ unsigned long long end_count[4];
   __shared__ Key end_key[4];
   {
-    unsigned long long n = run_count;
+    unsigned long long n = wave_sum_u32(run_count);  // (fewer than 2^32 cells)
     Key key = run_key;
-#pragma unroll
-    for (int offset = 32; offset >= 1; offset >>= 1) {
-      n += __shfl_xor((unsigned)n, offset);
-      if constexpr (STAT != Z_COUNT) {
-        Key other;
-        if constexpr (sizeof(Key) == 8) {
-          const unsigned lo = __shfl_xor((unsigned)key, offset), hi = __shfl_xor((unsigned)(key >> 32), offset);
-          other = ((Key)hi << 32) | lo;
-        } else {
-          other = __shfl_xor(key, offset);
-        }
-        key = better(key, other);
-      }
-    }
+    if constexpr (STAT != Z_COUNT) key = wave_best(key);
     if (lane == 0) {
       const int w = threadIdx.x >> 6;
       end_label[w] = (run_label >= 0 && n != 0) ? run_label : -1;
@@ -1576,9 +1585,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
   double run_sum = 0.0;
   auto tile_flush = [&]() {  // (wave-uniform call; a run that crosses a tile border keeps gathering for its label's range)
     if (run_label < 0) return;
-    unsigned n = tile_n;
-#pragma unroll
-    for (int offset = 32; offset >= 1; offset >>= 1) n += __shfl_xor(n, offset);
+    const unsigned n = wave_sum_u32(tile_n);
     if (lane == 0 && n != 0) atomicAdd(&tile_counts[run_tile * bins + run_label], n);
     tile_n = 0;
   };
@@ -1586,15 +1593,8 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
     if (run_label < 0) return;
     if constexpr (PHASE == 0) {
       if (tile_counts) tile_flush();
-      unsigned n = run_count, bad = run_bad;
-      int hi = run_hi, lo = run_lo;
-#pragma unroll
-      for (int offset = 32; offset >= 1; offset >>= 1) {
-        n += __shfl_xor(n, offset);
-        bad |= __shfl_xor(bad, offset);
-        hi = max(hi, __shfl_xor(hi, offset));
-        lo = min(lo, __shfl_xor(lo, offset));
-      }
+      const unsigned n = wave_sum_u32(run_count), bad = wave_or_u32(run_bad);
+      const int hi = wave_max(run_hi), lo = wave_min(run_lo);
       if (lane == 0 && n != 0) {
         ExactRange* slot = range + run_label;
         atomicAdd(&slot->count, (unsigned long long)n);
@@ -1603,9 +1603,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
         if (bad) atomicOr(&slot->bad, 1u);
       }
     } else {
-      double total = run_sum;
-#pragma unroll
-      for (int offset = 32; offset >= 1; offset >>= 1) total += shuffle_xor(total, offset);  // (exact: see above)
+      const double total = wave_sum_exact(run_sum);  // (exact: see above)
       if (lane == 0) atomicAdd(&sums[run_label], total);
     }
     run_label = -1;
@@ -1704,15 +1702,8 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
     const int w = threadIdx.x >> 6;
     if constexpr (PHASE == 0) {
       if (tile_counts && run_label >= 0) tile_flush();
-      unsigned n = run_count, bad = run_bad;
-      int hi = run_hi, lo = run_lo;
-#pragma unroll
-      for (int offset = 32; offset >= 1; offset >>= 1) {
-        n += __shfl_xor(n, offset);
-        bad |= __shfl_xor(bad, offset);
-        hi = max(hi, __shfl_xor(hi, offset));
-        lo = min(lo, __shfl_xor(lo, offset));
-      }
+      const unsigned n = wave_sum_u32(run_count), bad = wave_or_u32(run_bad);
+      const int hi = wave_max(run_hi), lo = wave_min(run_lo);
       if (lane == 0) {
         end_label[w] = (run_label >= 0 && n != 0) ? run_label : -1;
         end_count[w] = n;
@@ -1721,9 +1712,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
         end_bad[w] = bad;
       }
     } else {
-      double total = run_sum;
-#pragma unroll
-      for (int offset = 32; offset >= 1; offset >>= 1) total += shuffle_xor(total, offset);  // (exact: see above)
+      const double total = wave_sum_exact(run_sum);  // (exact: see above)
       if (lane == 0) {
         end_label[w] = run_label;
         end_sum[w] = total;
