@@ -49,7 +49,7 @@ __all__ = ["tile_owner", "owned_tiles", "split_tiler_graph", "run_owned_tiles", 
 
 SHARE_FROM = 1 << 20       # ndarrays of this many bytes and more travel through shared memory, once
 MAX_JOBS = 64              # fused jobs a pool keeps per (view, request)
-RESULT_CACHE_BYTES = 16 << 30
+RESULT_CACHE_BYTES = 8 << 30   # host mosaics kept (pinned by the workers) for the next request of their size
 
 
 class ShardError(RuntimeError):
@@ -139,6 +139,13 @@ class Segment(object):
             raise ShardError("no /dev/shm on this host: the sharded scheduler moves arrays through shared memory")
         self.name, self.size, self.owner = name, int(size), create
         path = os.path.join(_SHM_DIR, name)
+        if create:
+            # (a mapping of a shared-memory file that the file system cannot back dies with SIGBUS on first touch: ask first)
+            room = os.statvfs(_SHM_DIR)
+            if room.f_bavail * room.f_frsize < self.size + (16 << 20):
+                raise ShardError("%s has %.1f MiB free, the scheduler needs %.1f MiB of shared memory there (arrays of views and "
+                                 "host mosaics travel through it)" % (_SHM_DIR, room.f_bavail * room.f_frsize / 2.0 ** 20,
+                                                                      self.size / 2.0 ** 20))
         fd = os.open(path, (os.O_CREAT | os.O_EXCL | os.O_RDWR) if create else os.O_RDWR, 0o600)
         try:
             if create:
