@@ -454,10 +454,27 @@ def _code(dtype):
     return code_of(np.dtype(dtype))
 
 
+def _expect(value, kind):
+    """``value`` if it is a ``kind``; otherwise the reference's refusal of a constructor argument of the wrong type."""
+    if not isinstance(value, kind):
+        raise TypeError("'{}' object is not allowed.".format(type(value)))
+    return value
+
+
+def _rule_arguments(frequency, timezone, closed=None, label=None, sides=False):
+    """(frequency, timezone[, closed, label]) of a calendar rule as the Blocks keep them: the offset string normalised, the
+    time zone by its canonical name; ``closed`` / ``label`` one of None, 'left', 'right'."""
+    frequency = normalize_offset(_expect(frequency, str))
+    if sides:
+        for name, side in (("closed", closed), ("label", label)):
+            if side not in {None, "left", "right"}:
+                raise ValueError("{} must be None, 'left', or 'right'.".format(name))
+    timezone = pytz.timezone(_expect(timezone, str)).zone
+    return (frequency, timezone, closed, label) if sides else (frequency, timezone)
+
+
 def _check_statistic(statistic, known):
-    if not isinstance(statistic, str):
-        raise TypeError("'{}' object is not allowed.".format(type(statistic)))
-    statistic, percentile = parse_statistic(statistic.lower())
+    statistic, percentile = parse_statistic(_expect(statistic, str).lower())
     if percentile:
         return "p{0}".format(percentile)
     if statistic not in known:
@@ -665,17 +682,10 @@ class Resample(BaseSingle):
     gm_local = True  # every cell of the result depends on that cell of the sources alone (plan.py: tiles of a mosaic)
 
     def __init__(self, source, frequency, direction="nearest", timezone="UTC"):
-        if not isinstance(source, RasterBlock):
-            raise TypeError("'{}' object is not allowed.".format(type(source)))
-        if not isinstance(frequency, str):
-            raise TypeError("'{}' object is not allowed.".format(type(frequency)))
-        frequency = normalize_offset(frequency)
-        if not isinstance(timezone, str):
-            raise TypeError("'{}' object is not allowed.".format(type(timezone)))
-        timezone = pytz.timezone(timezone).zone
-        if not isinstance(direction, str):
-            raise TypeError("'{}' object is not allowed.".format(type(direction)))
-        if direction not in {"nearest", "backward", "forward"}:
+        _expect(source, RasterBlock)
+        # (the order of the checks is the reference's: the frequency, the time zone, then the direction)
+        frequency, timezone = _rule_arguments(frequency, timezone)
+        if _expect(direction, str) not in {"nearest", "backward", "forward"}:
             raise ValueError("direction must be one of 'nearest', 'backward', or 'forward'.")
         super(Resample, self).__init__(source, frequency, direction, timezone)
 
@@ -758,21 +768,10 @@ class TemporalAggregate(BaseSingle):
     STATISTICS = ("sum", "count", "min", "max", "mean", "median", "std", "var")
 
     def __init__(self, source, frequency, statistic="sum", closed=None, label=None, timezone="UTC"):
-        if not isinstance(source, RasterBlock):
-            raise TypeError("'{}' object is not allowed.".format(type(source)))
-        if frequency is None:
-            closed = label = timezone = None
-        else:
-            if not isinstance(frequency, str):
-                raise TypeError("'{}' object is not allowed.".format(type(frequency)))
-            frequency = normalize_offset(frequency)
-            if closed not in {None, "left", "right"}:
-                raise ValueError("closed must be None, 'left', or 'right'.")
-            if label not in {None, "left", "right"}:
-                raise ValueError("label must be None, 'left', or 'right'.")
-            if not isinstance(timezone, str):
-                raise TypeError("'{}' object is not allowed.".format(type(timezone)))
-            timezone = pytz.timezone(timezone).zone
+        _expect(source, RasterBlock)
+        # no frequency: one bin over everything, and the rule's other arguments mean nothing (kept as None)
+        rule = (None, None, None, None) if frequency is None else _rule_arguments(frequency, timezone, closed, label, sides=True)
+        frequency, timezone, closed, label = rule
         statistic = _check_statistic(statistic, self.STATISTICS)
         super().__init__(source, frequency, statistic, closed, label, timezone)
 
@@ -872,18 +871,9 @@ class Cumulative(BaseSingle):
     STATISTICS = ("sum", "count")
 
     def __init__(self, source, statistic="sum", frequency=None, timezone="UTC"):
-        if not isinstance(source, RasterBlock):
-            raise TypeError("'{}' object is not allowed.".format(type(source)))
+        _expect(source, RasterBlock)
         statistic = _check_statistic(statistic, self.STATISTICS)
-        if frequency is None:
-            timezone = None
-        else:
-            if not isinstance(frequency, str):
-                raise TypeError("'{}' object is not allowed.".format(type(frequency)))
-            frequency = normalize_offset(frequency)
-            if not isinstance(timezone, str):
-                raise TypeError("'{}' object is not allowed.".format(type(timezone)))
-            timezone = pytz.timezone(timezone).zone
+        frequency, timezone = (None, None) if frequency is None else _rule_arguments(frequency, timezone)
         super().__init__(source, statistic, frequency, timezone)
 
     source = property(lambda self: self.args[0])
