@@ -178,6 +178,36 @@ class Segment(object):
                 pass
 
 
+def sweep_stale_segments():
+    """Remove the shared-memory files of processes that no longer exist (a parent that was killed could not unlink its own:
+    the files are named after their creator's pid).  Called when a pool starts; returns the names removed."""
+    removed = []
+    if _SHM_DIR is None:
+        return removed
+    try:
+        names = [n for n in os.listdir(_SHM_DIR) if n.startswith("gm-shard-")]
+    except OSError:
+        return removed
+    for name in names:
+        try:
+            pid = int(name.split("-")[2])
+        except (IndexError, ValueError):
+            continue
+        if pid == os.getpid():
+            continue
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            try:
+                os.unlink(os.path.join(_SHM_DIR, name))
+                removed.append(name)
+            except OSError:
+                pass
+        except OSError:  # (exists, somebody else's: not ours to judge)
+            pass
+    return removed
+
+
 def _unlink_all():
     with _segments_lock:
         names = list(_live_segments)
@@ -210,6 +240,8 @@ def _share_array(obj, host):
             weakref.finalize(obj, gone)
         except TypeError:  # (not weak-referenceable: lives as long as the process)
             pass
+    # (shared by value at the time of the first message that mentions it: like a dask token, an array in a graph is taken to be
+    #  immutable -- a later in-place change does not reach the workers)
     return ("gm-array", hit[0].name, hit[0].size, hit[1], hit[2])
 
 
@@ -339,6 +371,7 @@ class Pool(object):
         settings = {"preload": preload if preload is not None else _config.get("geomodeling.worker-preload"),
                     "path": [p for p in sys.path if p], "config": _forwarded_config()}
         self.workers = []
+        sweep_stale_segments()
         try:
             for i, device in enumerate(self.devices):
                 self.workers.append(_Worker(i, device, settings))
@@ -413,7 +446,8 @@ class Pool(object):
             if self.closed:
                 return
             self.closed = True
-            _pools.pop(self.devices, None) if _pools.get(self.devices) is self else None
+            if _pools.get(self.devices) is self:
+                del _pools[self.devices]
             for w in self.workers:
                 try:
                     if not kill:

@@ -209,6 +209,27 @@ def test_shared_arrays_are_dropped_with_their_array(monkeypatch):
     assert not os.path.exists("/dev/shm/" + name)
 
 
+def test_stale_segments_of_dead_processes_are_swept():
+    """A parent that was killed leaves its /dev/shm files behind (they hold memory): the next pool removes the files of pids
+    that no longer exist, and only those."""
+    import subprocess
+    child = subprocess.run([sys.executable, "-c", "import os; print(os.getpid())"], capture_output=True, text=True)
+    dead = int(child.stdout)
+    stale = "/dev/shm/gm-shard-%d-0-deadbeef" % dead
+    mine = "/dev/shm/gm-shard-%d-999999-cafecafe" % os.getpid()
+    for path in (stale, mine):
+        with open(path, "wb") as f:
+            f.write(b"x")
+    try:
+        removed = shard.sweep_stale_segments()
+        assert os.path.basename(stale) in removed and not os.path.exists(stale)
+        assert os.path.exists(mine)
+    finally:
+        for path in (stale, mine):
+            if os.path.exists(path):
+                os.unlink(path)
+
+
 def test_a_forked_child_fails_loudly():
     """fork() after the library was entered: every runtime call of the child answers GM_ERR_FORKED -- what dask's `processes`
     scheduler would otherwise hang in on a GPU box (core/graphs.py:42-49 hands the graph to any configured scheduler)."""
