@@ -404,8 +404,11 @@ class Pool(object):
             return self._collect({i: None for i in messages}, timeout, what)
 
     def _collect(self, pending, timeout, what):
+        """The replies of the workers in ``pending``.  A worker that DIED fails the request at once and takes the pool with it;
+        a worker that RAISED is alive and in step: the other replies of this request are waited for (so that none of them is
+        mistaken for the answer to the next one), then the first error is raised and the pool lives on."""
         by_conn = {self.workers[i].conn: self.workers[i] for i in pending}
-        replies = {}
+        replies, errors = {}, []
         deadline = None if timeout is None else time.time() + timeout
         while by_conn:
             ready = _wait(list(by_conn), 0.25)
@@ -423,8 +426,9 @@ class Pool(object):
                     self._fail(WorkerDied("%s died (exit code %s) during %s -- the other workers were stopped"
                                           % (w.describe(), code, what)))
                 if kind == "error":
-                    self._fail(_worker_error(w, payload, what))
-                replies[w.index] = payload
+                    errors.append(_worker_error(w, payload, what))
+                else:
+                    replies[w.index] = payload
                 del by_conn[conn]
             if not ready:
                 for w in list(by_conn.values()):
@@ -435,6 +439,8 @@ class Pool(object):
                 if deadline is not None and time.time() > deadline:
                     self._fail(ShardError("no answer from %s within %.0f s during %s"
                                           % (", ".join(w.describe() for w in by_conn.values()), timeout, what)))
+        if errors:
+            raise errors[0]
         return replies
 
     def _fail(self, error):
@@ -881,6 +887,9 @@ def get_data(view, request, devices=None, materialize=None):
             replies = pool.request(messages, what=what)
         except BaseException:
             pool.jobs.pop(key, None)
+            if not pool.closed:  # (a worker raised: the pool lives on, the half-made job is forgotten everywhere)
+                pool.released.append(run_id)
+                pool.request({w: ("drop", [job.id]) for w in messages}, what="clean-up")
             raise
         for w, reply in replies.items():
             if not isinstance(reply, str):  # ("same": what this worker answered last time)

@@ -179,12 +179,42 @@ def test_a_dying_worker_fails_the_request_within_seconds_and_is_named(pool2):
 
 @pytest.mark.timeout(120)
 def test_an_exception_in_a_worker_travels_with_its_type_and_the_workers_name(pool2):
+    """A task that raises fails the request with the worker's exception type, name and traceback -- and nothing else: the
+    workers stay (their resident sources and kept jobs with them), the next request is answered by the same processes."""
     graph = {"ok": (shard_util.tile_of, 1.0), "bad": (shard_util.boom, "no such thing")}
+    pids = [w.pid for w in pool2.workers]
     with pytest.raises(ValueError) as info:
         shard.get(graph, ["ok", "bad"])
     text = str(info.value)
     assert "shard worker 1 (device 1" in text and "no such thing" in text and "worker traceback" in text
-    assert pool2.closed
+    assert not pool2.closed and [w.proc.poll() for w in pool2.workers] == [None, None]
+    got = shard.get(graph, ["ok", "ok"])
+    assert got[0]["values"].shape == (1, 3, 5) and [w.pid for w in shard.pool_for((0, 1)).workers] == pids
+    # the same through get_data: a view whose evaluation raises in the worker (a refusal, say) leaves no job behind
+    A, B = _leaves(7)
+    view = raster.RasterTiler(_chain(A, B), [32, 24])
+    with pytest.raises(AssertionError):   # (cells of 95 / 96 units: HostGrid serves aligned windows only, and says so in the worker)
+        view.get_data(**dict(_request(), bbox=(0.0, 0.0, 95.0, 80.0)))
+    assert not pool2.closed and pool2.request({0: ("ping",), 1: ("ping",)})[0][2] == 0   # no kept job
+    assert np.array_equal(_bits(view.get_data(**_request())["values"]),
+                          _bits(_chain(A, B).get_data(**_request())["values"]))
+
+
+@pytest.mark.timeout(120)
+def test_many_views_at_once_and_a_single_view_left_on_its_worker(pool2):
+    """get_data_many under geomodeling.devices hands the merged graph to shard.get (its units dealt over the workers); a view
+    that is no tiler, not materialised, is a one-unit ShardedTiles."""
+    from dask_geomodeling_amd.core.graphs import get_data_many
+    A, B = _leaves(8)
+    views = [_chain(A, B), raster.Add(A, B), raster.Multiply(B, 3.0)]
+    with config.config.set({"geomodeling.devices": None}):
+        wants = [v.get_data(**_request()) for v in views]
+    for got, want in zip(get_data_many(views, _request()), wants):
+        assert np.array_equal(_bits(got["values"]), _bits(want["values"]))
+    with config.config.set({"geomodeling.materialize": False}):
+        lazy = views[1].get_data(**_request())
+    assert isinstance(lazy["values"], shard.ShardedTiles) and len(lazy["values"].units) == 1
+    assert np.array_equal(_bits(np.asarray(lazy["values"])), _bits(wants[1]["values"]))
 
 
 @pytest.mark.timeout(120)
