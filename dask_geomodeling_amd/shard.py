@@ -24,8 +24,8 @@ collective on the data path.  What this module adds to the reference's ``compute
 Workers are fresh interpreters (``python -m dask_geomodeling_amd.shard_worker``): started with fork + exec
 *before* they touch HIP, never by fork() alone -- a HIP runtime does not survive fork(), the library refuses it
 (GM_ERR_FORKED) -- and never by exec() of an initialised process.  The parent never needs a GPU of its own.
-A worker that dies (or raises) fails the request within seconds, naming the worker; the pool is then torn down
-and the next request starts a fresh one.
+A worker that raises fails the request (its exception type, name and traceback) and stays; a worker that dies fails the
+request within seconds, naming the worker: the pool is then torn down and the next request starts a fresh one.
 """
 import atexit
 import itertools
