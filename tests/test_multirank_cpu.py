@@ -123,11 +123,11 @@ def test_bench_gpus_flag_two_ranks_on_the_gpu_box(gpu):
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["roofline"]["achieved"] > 0
     # (leaves regenerated per request: the two workers share this box's one GPU with whatever else the suite is running)
-    res = subprocess.run(base + ["--workload", "mosaic", "--side", "8192", "--steps", "2", "--warmup", "1", "--leaves", "procedural", "--no-e2e"],
+    res = subprocess.run(base + ["--workload", "mosaic", "--side", "4096", "--steps", "2", "--warmup", "1", "--leaves", "procedural", "--no-e2e"],
                          capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["tiles_per_gpu"] == 32
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["tiles_per_gpu"] == 128
     assert abs(out["value"] - 65536.0 ** 2 * 2 / (out["ms_per_step"] * 2e-3) / 1e6) / out["value"] < 0.01
 
 
