@@ -462,6 +462,21 @@ __device__ __forceinline__ double log2_of_positive_f32(unsigned ax) {
   p = fma(r, p, POWF_LOG2_C[0]);
   return fma(r, p, (double)e + POWF_LOG2_TAB[i][1]);
 }
+// ... of a NORMAL float32 (no scaling of subnormals): the common case of the routes below, which check for it
+template <int TERMS>
+__device__ __forceinline__ double log2_of_normal_f32(unsigned ax) {
+  const unsigned tmp = ax - 0x3f338000u;
+  const int i = (int)((tmp >> 16) & 127u);
+  const int e = (int)tmp >> 23;
+  const double z = (double)__uint_as_float(ax - (tmp & 0xff800000u));  // in [0.7, 1.4)
+  const double r = fma(z, POWF_LOG2_TAB[i][0], -1.0);
+  double p = POWF_LOG2_C[TERMS - 1];
+#pragma unroll
+  for (int k = TERMS - 2; k >= 2; --k) p = fma(r, p, POWF_LOG2_C[k]);
+  p = fma(r, p, POWF_LOG2_C[1]);
+  p = fma(r, p, POWF_LOG2_C[0]);
+  return fma(r, p, (double)e + POWF_LOG2_TAB[i][1]);
+}
 __device__ __forceinline__ float exp2_to_f32(double z, double z_lo) {
   z = fmin(fmax(z, -160.0), 130.0);  // (beyond: 0 / inf as float32 either way; keeps 2^k a normal double)
   const double kd = rint(z * 32.0);
@@ -481,6 +496,18 @@ __device__ __forceinline__ float exp2_to_f32(double z, double z_lo) {
 // good to ~2^-52, so a float32 rounding boundary lies inside the error only once in ~2^27 arguments
 // (tests/test_gpu_parity.py::test_exp_log_are_correctly_rounded, tools/ulp_measure.py).  np.exp stays on ocml's float64 exp:
 // the same construction (x log2(e) in two pieces, the 2^x half with six terms) was measured at 162 us against its 110.
+// The common case first (round 5): a positive normal argument needs none of the selects of logf_via_f64 below; zero, subnormal,
+// negative, infinite and NaN arguments are one unsigned compare away.  `special` = the value still needs the full routine (the
+// caller -- Machine::apply_logf -- runs the common case for ALL its values first, so that their table reads are in flight
+// together, and then asks once per wave whether any value was special).  +-0 is settled here (-inf: rasters are full of zeros).
+__device__ __forceinline__ float logf_common(float xf, double scale, bool& special) {
+  const unsigned ix = __float_as_uint(xf);
+  const bool ordinary = ix - 0x00800000u < 0x7f800000u - 0x00800000u;  // positive, normal, finite
+  const bool zero = (ix << 1) == 0u;
+  const float out = (float)(log2_of_normal_f32<7>(ordinary ? ix : 0x3f800000u) * scale);
+  special = !(ordinary | zero);
+  return zero ? -__builtin_inff() : out;
+}
 __device__ __forceinline__ float logf_via_f64(float xf, double scale) {  // scale: ln(2) or log10(2)
   const unsigned ix = __float_as_uint(xf), ax = ix & 0x7fffffffu;
   float out = (float)(log2_of_positive_f32<7>(ax) * scale);
@@ -498,6 +525,31 @@ __device__ __forceinline__ float logf_via_f64(float xf, double scale) {  // scal
 // rounded float32 except within 2^-11 ulp of a tie -- there it is the other neighbour, i.e. <= 1 ulp from any faithful
 // powf (glibc's: 0.52 ulp), the budget of tests/test_gpu_parity.py.  Signs, zeros, infinities and NaN follow C99 F.9.4.4
 // = NumPy.  (tools/ulp_measure.py: measured against the extended-precision value.)
+// The common case first (round 5): a positive normal base, a finite exponent and a result well inside float32's normal range
+// need none of the C99 special cases of powf_via_f64 below, no scaling of subnormals and no clamp -- the same operations on the
+// same values, hence the same bits (rint(32 z) by the 1.5 * 2^52 shift: the same integer).  (+0) ** (a positive finite y) = +0 is
+// settled here as well.  Anything else (a negative or subnormal base, -0, inf / NaN anywhere, |y log2 x| beyond 125) is
+// `special`: Machine::apply_powf runs the common case for ALL its values first and then asks once per wave.
+__device__ __forceinline__ float powf_common(float xf, float yf, bool& special) {
+  const unsigned ix = __float_as_uint(xf), ay = __float_as_uint(yf) & 0x7fffffffu;
+  const bool base_ok = ix - 0x00800000u < 0x7f800000u - 0x00800000u;  // positive, normal, finite
+  const double zz = (double)yf * log2_of_normal_f32<5>(base_ok ? ix : 0x3f800000u);
+  const bool ordinary = base_ok & (ay < 0x7f800000u) & (fabs(zz) <= 125.0);  // (NaN compares false)
+  const bool zero = (ix == 0u) & (yf > 0.0f) & (ay < 0x7f800000u);
+  // 2^zz as in exp2_to_f32 (a zz out of range gives garbage that `special` replaces; the table index is masked)
+  const double km = fma(zz, 32.0, 0x1.8p52);
+  const int ki = (int)(unsigned)__double_as_longlong(km);
+  const double rr = fma(km - 0x1.8p52, -0x1p-5, zz);
+  double q = fma(rr, POWF_EXP2_L[4], POWF_EXP2_L[3]);
+  q = fma(rr, q, POWF_EXP2_L[2]);
+  q = fma(rr, q, POWF_EXP2_L[1]);
+  q = fma(rr, q, POWF_EXP2_L[0]);
+  q = fma(rr, q, 1.0);
+  const long long scaled = __double_as_longlong(POWF_EXP2_TAB[ki & 31]) + ((long long)(ki >> 5) << 52);
+  const float out = (float)(__longlong_as_double(scaled) * q);
+  special = !(ordinary | zero);
+  return zero ? 0.0f : out;
+}
 __device__ __forceinline__ float powf_via_f64(float xf, float yf) {
   const unsigned ix = __float_as_uint(xf), iy = __float_as_uint(yf);
   const unsigned ax = ix & 0x7fffffffu, ay = iy & 0x7fffffffu;
@@ -681,6 +733,59 @@ struct Machine {
       const RC r = f(x, y);
       if constexpr (is_float_class<RC>::value) bad = bad | !finite_rc<RC>(r);
       acc[k] = bad ? fill : r;
+    }
+  }
+
+  // np.power / np.log / np.log10 on the float32 class (round 5): the common case of powf_common / logf_common for all N values
+  // first -- straight-line code, the N table reads of each half in flight together -- with no-data cells evaluated as 1.0 so that
+  // a raster's no-data value never sends a wave into the full routine; then one wave-level test for values that need it.
+  template <bool B_SCALAR>
+  __device__ __forceinline__ void apply_powf(const gm_step& S, const RC (&b)[N]) {
+    if constexpr (std::is_same<RC, float>::value) {
+      const float a_ndv = opd_has_ndv(S.a) ? scalar_of<RC>(S.a.value) : __builtin_nanf("");
+      const float b_lit = scalar_of<RC>(S.b.value);
+      const float b_ndv = opd_has_ndv(S.b) ? b_lit : __builtin_nanf("");
+      const float fill = scalar_of<RC>(S.fill);
+      float xs[N], ys[N], r[N];
+      bool bad[N], special[N], any = false;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        bad[k] = (acc[k] == a_ndv);
+        if constexpr (!B_SCALAR) bad[k] = bad[k] | (b[k] == b_ndv);
+        xs[k] = bad[k] ? 1.0f : acc[k];
+        ys[k] = B_SCALAR ? b_lit : (bad[k] ? 1.0f : b[k]);
+        r[k] = powf_common(xs[k], ys[k], special[k]);
+        any = any | special[k];
+      }
+      if (__builtin_amdgcn_ballot_w64(any)) {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          if (special[k]) r[k] = powf_via_f64(xs[k], ys[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] = (bad[k] | !finite_rc<RC>(r[k])) ? fill : r[k];
+    }
+  }
+  __device__ __forceinline__ void apply_logf(const gm_step& S, const double scale) {
+    if constexpr (std::is_same<RC, float>::value) {
+      const float a_ndv = opd_has_ndv(S.a) ? scalar_of<RC>(S.a.value) : __builtin_nanf("");
+      const float fill = scalar_of<RC>(S.fill);
+      float xs[N], r[N];
+      bool bad[N], special[N], any = false;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        bad[k] = (acc[k] == a_ndv);
+        xs[k] = bad[k] ? 1.0f : acc[k];
+        r[k] = logf_common(xs[k], scale, special[k]);
+        any = any | special[k];
+      }
+      if (__builtin_amdgcn_ballot_w64(any)) {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          if (special[k]) r[k] = logf_via_f64(xs[k], scale);
+      }
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] = (bad[k] | !finite_rc<RC>(r[k])) ? fill : r[k];
     }
   }
 
@@ -879,16 +984,25 @@ struct Machine {
       case GM_OP_MUL: math(S, b_scalar, b, [](RC x, RC y) { return op_mul<RC>(x, y); }); break;
       case GM_OP_DIV: math(S, b_scalar, b, [](RC x, RC y) { return op_div<RC>(x, y); }); break;
       case GM_OP_POW:
-        if constexpr (HEAVY) math(S, b_scalar, b, [](RC x, RC y) { return op_pow<RC>(x, y); });
+        if constexpr (HEAVY) {
+          if constexpr (std::is_same<RC, float>::value) {
+            if (b_scalar) apply_powf<true>(S, b);
+            else apply_powf<false>(S, b);
+          } else {
+            math(S, b_scalar, b, [](RC x, RC y) { return op_pow<RC>(x, y); });
+          }
+        }
         break;
       case GM_OP_EXP:
         if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { return (RC)exp((double)x); });
         break;
       case GM_OP_LOG:
-        if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { if constexpr (std::is_same<RC, float>::value) return logf_via_f64(x, POWF_LN2); else return (RC)log((double)x); });
+        if constexpr (HEAVY && std::is_same<RC, float>::value) apply_logf(S, POWF_LN2);
+        else if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { return (RC)log((double)x); });
         break;
       case GM_OP_LOG10:
-        if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { if constexpr (std::is_same<RC, float>::value) return logf_via_f64(x, POWF_LOG10_2); else return (RC)log10((double)x); });
+        if constexpr (HEAVY && std::is_same<RC, float>::value) apply_logf(S, POWF_LOG10_2);
+        else if constexpr (HEAVY && is_float_class<RC>::value) math(S, true, b, [](RC x, RC) { return (RC)log10((double)x); });
         break;
       case GM_OP_EQ: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)(x == y); }); break;
       case GM_OP_NE: apply2(S, b_scalar, b, [](RC x, RC y) { return (RC)(x != y); }); break;
