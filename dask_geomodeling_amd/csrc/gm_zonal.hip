@@ -2445,6 +2445,552 @@ __global__ __launch_bounds__(256) void zonal_exact_result_kernel(const ExactRang
   out[l] = n == 0 ? std::numeric_limits<float>::quiet_NaN() : (statistic == Z_MEAN ? (float)(total / (double)n) : (float)total);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// sum / mean without the sort (round 5): chunk records.
+//
+// bincount adds a label's cells in raster order.  Cut the raster into stretches of consecutive cells, one per wave: the cells
+// of label l inside stretch w -- its CHUNK (w, l) -- are consecutive in l's sequence, and the chunks of l in the order of w are
+// that sequence.  Pass 1 (zonal_chunk_kernel, the only pass over the raster: 8 bytes per cell, 4 cells per lane and step) leaves
+// per chunk what certifies it and what it adds up to when certified: the count, the highest exponent and the lowest set bit
+// among its cells, the sum of their magnitudes, a tree sum, the steps it lies in; and a note of the same kind per step of 256
+// cells.  Pass 2 (zonal_chunk_combine_kernel, a wave per label) walks the label's chunks in order: a chunk none of whose
+// additions can round, given the running sum that enters it -- every intermediate value a multiple of 2^lo below 2^(lo + 53)
+// -- is ONE addition of its tree sum; any other chunk is replayed: its cells read from the raster again and added one after
+// the other (chunks of one or two steps), or step by step from the notes (certified steps one addition each, the others cell
+// after cell).  Nothing is sorted, nothing is written per cell.  A wave finds its chunks through one byte per (label,
+// stretch): the slot of the chunk among the stretch's records.
+// Label rasters that are not made of runs (more than ZC_SLOTS labels inside a stretch, or more than ZC_LABELS_PER_STEP in one
+// step) raise `overflow` and the sums take the sorting route above.
+constexpr int ZC_LANE = 4, ZC_STEP = 64 * ZC_LANE;  // cells per lane and step / per step
+constexpr int ZC_SLOTS = 64;                        // chunk records per stretch (a lane each)
+constexpr int ZC_MAX_STEPS = 64;                    // steps per stretch
+constexpr int ZC_LABELS_PER_STEP = 8;
+constexpr int ZC_LIST = 4096;                       // chunks of a label listed at a time (one byte-row round of the table)
+struct ChunkRec {  // 32 bytes
+  double total;      // tree sum of the chunk's cells (meaningful when the chunk is certified)
+  double magnitude;  // sum of their absolute values (any order; an upper bound within 2^-40 relatively)
+  unsigned count;    // active cells
+  int label;
+  short hi, lo;      // top exponent / exponent of the lowest set bit over the non-zero cells (SHRT_MIN / SHRT_MAX: none)
+  unsigned char first, last;  // the steps of the stretch that hold the chunk's cells
+  unsigned char bad, pad;     // bad: a NaN or an infinity among the cells
+};
+struct StepRec {  // 24 bytes, per step of ZC_STEP cells
+  double total;
+  float magnitude;  // rounded up
+  int label;        // >= 0: the one label of the step's active cells; -1: no active cell; -2: add it literally (several labels, a non-finite cell)
+  short hi, lo;     // as in ChunkRec
+  int pad;
+};
+struct ChunkVerdict {
+  unsigned overflow;  // pass 1: the label raster is not made of runs
+  unsigned hard;      // pass 2: a label whose chunks had to be replayed too often (a long label, or a sum that keeps rounding)
+};
+// A label is given up (`hard`: the whole call takes the sorting route, whose block pipeline is built for such sums) after this
+// many replayed chunks -- replays read the raster again, a few microseconds each -- or, once ZL_LONG of its cells have gone
+// by, after a few chunks that had to be walked step by step.
+constexpr unsigned ZC_REPLAYS = 64, ZC_LONG_WALKS = 4;
+template <typename T>
+struct alignas(4 * sizeof(T) > 16 ? 16 : 4 * sizeof(T)) CellQuad {
+  T c[ZC_LANE];
+};
+struct alignas(16) LabelQuad {
+  int c[ZC_LANE];
+};
+
+template <typename T>
+__device__ __forceinline__ bool cell_active(T v, int label, int n_labels, int has_ndv, T ndv, const float* __restrict__ thresholds) {
+  bool active = (unsigned)label < (unsigned)n_labels && !(has_ndv && v == ndv);
+  if (thresholds && active) {
+    const float t = thresholds[label];
+    active = !(t != t) && (double)v >= (double)t;
+  }
+  return active;
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// No addition of `cells` cells -- multiples of 2^low, below 2^(top + 1) each, their magnitudes adding up to `magnitude` at most
+// -- onto acc can round: every intermediate value is a multiple of 2^lo, lo = min(low, lowest set bit of acc), and smaller than
+// |acc| + magnitude; below 2^(lo + 53) it is a float64.  Two bounds, either suffices: by the exponents (zonal_sum_kernel's), by
+// the magnitudes (tighter by the bits a sum of mixed signs does not grow).  Then the cells' own partial sums -- in any order --
+// are multiples of 2^lo below 2^(lo + 53) as well: the tree sum is their exact sum.
+__device__ __forceinline__ bool additions_exact(double acc, int top, int low, unsigned cells, double magnitude) {
+  if (top == INT_MIN) return true;  // nothing but zeros
+  if (!(fabs(acc) <= 1.7976931348623157e308)) return false;
+  int acc_top = INT_MIN, acc_low = INT_MAX;
+  if (acc != 0.0) exponent_span(acc, &acc_top, &acc_low);
+  const int lo = min(low, acc_low);
+  const int growth = cells <= 1 ? 0 : 32 - __clz((int)(cells - 1));  // ceil(log2(cells))
+  const long long hi = max((long long)acc_top, (long long)top + growth) + 2;
+  if (hi - lo <= 53 && hi < 1023) return true;
+  const double bound = (fabs(acc) + magnitude) * 1.000000000001;  // (the two sums may have rounded)
+  if (!(bound < 8.98846567431158e307)) return false;              // (2^1023; also NaN)
+  int bound_top, bound_low;
+  exponent_span(bound, &bound_top, &bound_low);  // bound < 2^(bound_top + 1)
+  return bound_top + 1 - lo <= 53;
+}
+// acc + the first n of the doubles parked in `mine`, in order, n <= ZC_STEP; the caller has zeroed up to the next multiple of
+// 16 (the wave as one sequential adder: zonal_sum_kernel's replay)
+__device__ __forceinline__ double chain_add_parked(const double* mine, double acc, unsigned n) {
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  constexpr int ROUND = 16;
+  f64x2 now[ROUND / 2], next[ROUND / 2];
+#pragma unroll
+  for (int k = 0; k < ROUND / 2; ++k) now[k] = *reinterpret_cast<const f64x2*>(mine + 2 * k);
+  for (unsigned base = 0; base < n; base += ROUND) {  // (wave-uniform)
+    // the next round's reads are issued before this round's 16 additions (past n: the zeros, or stale values never added)
+#pragma unroll
+    for (int k = 0; k < ROUND / 2; ++k) next[k] = *reinterpret_cast<const f64x2*>(mine + base + ROUND + 2 * k);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < ROUND / 2; ++k) {
+      acc += now[k].x;
+      acc += now[k].y;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < ROUND / 2; ++k) now[k] = next[k];
+  }
+  return acc;
+}
+
+// The verdict of pass 1 where the host can read it without a copy: a pinned word the kernel writes, and the event behind the
+// kernel -- the host waits for pass 1 only, pass 2 is already queued behind it.
+struct HostFlag {
+  unsigned* word = nullptr;
+  hipEvent_t event = nullptr;
+  int device = -1;
+};
+static HostFlag* host_flag() {
+  static thread_local HostFlag f;
+  int device = -1;
+  if (hipGetDevice(&device) != hipSuccess) return nullptr;
+  if (!f.word && hipHostMalloc((void**)&f.word, 64, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    f.word = nullptr;
+    return nullptr;
+  }
+  if (f.device != device) {
+    if (f.event) (void)hipEventDestroy(f.event);
+    f.event = nullptr;
+    if (hipEventCreateWithFlags(&f.event, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      f.event = nullptr;
+      f.device = -1;
+      return nullptr;
+    }
+    f.device = device;
+  }
+  return &f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void zonal_chunk_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
+                                                          size_t cells_per_wave, unsigned stretches, unsigned row_bytes, int n_labels,
+                                                          int has_ndv, T ndv, const float* __restrict__ thresholds,
+                                                          ChunkRec* __restrict__ records, unsigned char* __restrict__ slot_of,
+                                                          StepRec* __restrict__ step_records, ChunkVerdict* __restrict__ verdict,
+                                                          unsigned* __restrict__ verdict_host, unsigned char* __restrict__ present) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (wave >= stretches) return;
+  const size_t begin = wave * cells_per_wave, end = min(begin + cells_per_wave, cells);
+  if (begin >= end) return;
+  const unsigned steps_per_wave = (unsigned)(cells_per_wave / ZC_STEP);
+  const unsigned steps = (unsigned)((end - begin + ZC_STEP - 1) / ZC_STEP), full = (unsigned)((end - begin) / ZC_STEP);
+  // the stretch's chunk records, a lane each
+  int slot_label = -1, n_slots = 0;
+  double r_total = 0.0, r_magnitude = 0.0;
+  unsigned r_count = 0, r_bad = 0, r_first = 255u, r_last = 0u;
+  int r_hi = INT_MIN, r_lo = INT_MAX;
+  bool dead = false;     // this label raster is not for chunk records (wave-uniform)
+  int marked = INT_MIN;  // the label whose `present` flag the step before has set (INT_MIN: none / several)
+  // the cells of the full steps: unconditional 16-byte loads, one step ahead
+  auto fetch_v = [&](unsigned step) -> CellQuad<T> {
+    return *reinterpret_cast<const CellQuad<T>*>(values + begin + (size_t)step * ZC_STEP + ZC_LANE * (size_t)lane);
+  };
+  auto fetch_l = [&](unsigned step) -> LabelQuad {
+    return *reinterpret_cast<const LabelQuad*>(labels + begin + (size_t)step * ZC_STEP + ZC_LANE * (size_t)lane);
+  };
+  CellQuad<T> next_v{};
+  LabelQuad next_l{};
+  if (full) {
+    next_v = fetch_v(0);
+    next_l = fetch_l(0);
+  }
+  for (unsigned step = 0; step < steps; ++step) {
+    T v[ZC_LANE];
+    int label[ZC_LANE];
+    bool inside[ZC_LANE];
+    if (step < full) {  // (wave-uniform)
+#pragma unroll
+      for (int k = 0; k < ZC_LANE; ++k) {
+        v[k] = next_v.c[k];
+        label[k] = next_l.c[k];
+        inside[k] = true;
+      }
+      if (step + 1 < full) {
+        next_v = fetch_v(step + 1);
+        next_l = fetch_l(step + 1);
+      }
+    } else {  // the stretch's ragged last step (the raster's end): cell by cell
+#pragma unroll
+      for (int k = 0; k < ZC_LANE; ++k) {
+        const size_t i = begin + (size_t)step * ZC_STEP + ZC_LANE * (size_t)lane + k;
+        inside[k] = i < end;
+        v[k] = inside[k] ? values[i] : T(0);
+        label[k] = inside[k] ? labels[i] : -1;
+      }
+    }
+    // `present[label] = 1` for every labelled cell; a step of one label that the step before has marked says nothing new
+    if (present) {
+      const int lead = __builtin_amdgcn_readfirstlane(label[0]);
+      bool same = true;
+#pragma unroll
+      for (int k = 0; k < ZC_LANE; ++k) same = same && label[k] == lead;
+      const bool uniform = __all(same);
+      if (!(uniform && lead == marked)) {
+#pragma unroll
+        for (int k = 0; k < ZC_LANE; ++k)
+          if ((unsigned)label[k] < (unsigned)n_labels) present[label[k]] = 1;
+        marked = uniform ? lead : INT_MIN;
+      }
+    }
+    if (dead) continue;
+    bool remaining[ZC_LANE];
+#pragma unroll
+    for (int k = 0; k < ZC_LANE; ++k) remaining[k] = inside[k] && cell_active<T>(v[k], label[k], n_labels, has_ndv, ndv, thresholds);
+    StepRec note{0.0, 0.0f, -1, SHRT_MIN, SHRT_MAX, 0};
+    int found = 0;
+    while (true) {
+      const unsigned long long open = __ballot(remaining[0] | remaining[1] | remaining[2] | remaining[3]);
+      if (!open) break;
+      if (found == ZC_LABELS_PER_STEP) {
+        dead = true;
+        break;
+      }
+      const int mine = remaining[0] ? label[0] : remaining[1] ? label[1] : remaining[2] ? label[2] : label[3];
+      const int lead = __builtin_amdgcn_readlane(mine, __ffsll((long long)open) - 1);  // (a uniform lane index)
+      unsigned n = 0, bad = 0;
+      int hi = INT_MIN, lo = INT_MAX;
+      double sum = 0.0, magnitude = 0.0;
+#pragma unroll
+      for (int k = 0; k < ZC_LANE; ++k) {
+        const bool taken = remaining[k] && label[k] == lead;
+        n += (unsigned)__popcll(__ballot(taken));  // (wave-uniform: the cells of this label in the step)
+        if (taken) {
+          remaining[k] = false;
+          const double x = (double)v[k];  // what bincount adds
+          if (!(fabs(x) <= 1.7976931348623157e308)) {
+            bad = 1;
+          } else if (x != 0.0) {
+            int top, low;
+            cell_span<T>(v[k], &top, &low);
+            hi = max(hi, top);
+            lo = min(lo, low);
+          }
+          sum += x;
+          magnitude += fabs(x);
+        }
+      }
+      bad = wave_or_u32(bad);
+      hi = wave_max(hi);
+      lo = wave_min(lo);
+      sum = wave_sum_exact(sum);  // (only used when certified exact)
+      magnitude = wave_sum_exact(magnitude);
+      if (found == 0) {
+        note.total = sum;
+        note.magnitude = (float)(magnitude * 1.000001);  // (an upper bound after the rounding to float32; inf for huge values)
+        note.label = bad ? -2 : lead;
+        note.hi = (short)max(hi, (int)SHRT_MIN);  // (float64 exponents fit; INT_MIN -> SHRT_MIN)
+        note.lo = (short)min(lo, (int)SHRT_MAX);
+      } else {
+        note.label = -2;
+      }
+      ++found;
+      // into the stretch's record of this label
+      const unsigned long long hit = __ballot(slot_label == lead);
+      int slot;
+      if (hit) {
+        slot = __ffsll((long long)hit) - 1;
+      } else if (n_slots < ZC_SLOTS) {
+        slot = n_slots++;
+      } else {
+        dead = true;
+        break;
+      }
+      if (lane == slot) {
+        slot_label = lead;
+        r_total += sum;
+        r_magnitude += magnitude;
+        r_count += n;
+        r_bad |= bad;
+        r_hi = max(r_hi, hi);
+        r_lo = min(r_lo, lo);
+        r_first = min(r_first, step);
+        r_last = max(r_last, step);
+      }
+    }
+    if (dead) {
+      if (lane == 0) {
+        verdict->overflow = 1u;
+        if (verdict_host) *verdict_host = 1u;
+      }
+      continue;
+    }
+    if (lane == 0) step_records[wave * steps_per_wave + step] = note;
+  }
+  if (dead) return;
+  if (lane < n_slots) {
+    ChunkRec rec;
+    rec.total = r_total;
+    rec.magnitude = r_magnitude;
+    rec.count = r_count;
+    rec.label = slot_label;
+    rec.hi = (short)max(r_hi, (int)SHRT_MIN);
+    rec.lo = (short)min(r_lo, (int)SHRT_MAX);
+    rec.first = (unsigned char)r_first;
+    rec.last = (unsigned char)r_last;
+    rec.bad = (unsigned char)r_bad;
+    rec.pad = 0;
+    records[wave * ZC_SLOTS + lane] = rec;
+    slot_of[(size_t)slot_label * row_bytes + wave] = (unsigned char)(lane + 1);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void zonal_chunk_combine_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
+                                                                  size_t cells_per_wave, unsigned stretches, unsigned row_bytes, int n_labels,
+                                                                  int has_ndv, T ndv, const float* __restrict__ thresholds,
+                                                                  const ChunkRec* __restrict__ records,
+                                                                  const unsigned char* __restrict__ slot_of,
+                                                                  const StepRec* __restrict__ step_records,
+                                                                  ChunkVerdict* __restrict__ verdict, unsigned* __restrict__ verdict_host,
+                                                                  unsigned long_from, unsigned patience, int statistic,
+                                                                  float* __restrict__ out, long long* __restrict__ counts) {
+  __shared__ __align__(16) double parked[4][2][ZC_STEP + 32];
+  __shared__ unsigned listed[4][ZC_LIST];
+  const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (l >= n_labels) return;
+  if (*(const volatile unsigned*)&verdict->overflow || *(const volatile unsigned*)&verdict->hard) return;  // (the sorting route will answer)
+  double* const mine = parked[threadIdx.x >> 6][0];
+  double* const mine_b = parked[threadIdx.x >> 6][1];
+  unsigned* const list = listed[threadIdx.x >> 6];
+  const unsigned steps_per_wave = (unsigned)(cells_per_wave / ZC_STEP);
+  double acc = 0.0;
+  unsigned long long n_total = 0;
+  unsigned replays = 0, walks = 0;
+  auto give_up = [&]() {
+    if (lane == 0) {
+      verdict->hard = 1u;
+      if (verdict_host) verdict_host[1] = 1u;
+    }
+  };
+  // One step of a stretch, cell after cell: the cells of this label parked in order, then the chain of dependent additions.
+  struct StepCells {
+    T v[ZC_LANE];
+    int label[ZC_LANE];
+  };
+  auto load_step = [&](size_t begin, size_t end, unsigned step) -> StepCells {
+    StepCells c;
+#pragma unroll
+    for (int k = 0; k < ZC_LANE; ++k) {
+      const size_t i = begin + (size_t)step * ZC_STEP + ZC_LANE * (size_t)lane + k;
+      c.v[k] = values[min(i, cells - 1)];
+      c.label[k] = i < end ? labels[min(i, cells - 1)] : -1;
+    }
+    return c;
+  };
+  // the cells of this label among a step's, parked in raster order (then zeros up to a whole round of the chain): how many
+  auto park = [&](const StepCells& c, double* where) -> unsigned {
+    bool take[ZC_LANE];
+    unsigned below = 0, n = 0;
+#pragma unroll
+    for (int k = 0; k < ZC_LANE; ++k) {
+      take[k] = c.label[k] == l && cell_active<T>(c.v[k], c.label[k], n_labels, has_ndv, ndv, thresholds);
+      const unsigned long long m = __ballot(take[k]);
+      below += __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));  // taken in the lanes below
+      n += (unsigned)__popcll(m);
+    }
+    // rank of cell (lane, k) in raster order: the cells of the lanes below, then this lane's earlier ones
+    unsigned rank = below;
+#pragma unroll
+    for (int k = 0; k < ZC_LANE; ++k) {
+      if (take[k]) where[rank++] = (double)c.v[k];
+    }
+    if (lane < 16) where[n + lane] = 0.0;  // (+0.0 changes nothing: the sum starts from +0.0 and can never become -0.0)
+    return n;
+  };
+  auto literally = [&](const StepCells& c) {
+    const unsigned n = park(c, mine);
+    if (n) acc = chain_add_parked(mine, acc, n);  // (wave-uniform)
+  };
+  for (unsigned round0 = 0; round0 < row_bytes; round0 += ZC_LIST) {
+    // the label's chunks of this round in order: (stretch << 8 | slot); a lane reads 64 stretches' bytes
+    unsigned n_list = 0;
+    {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const unsigned at = round0 + 64u * (unsigned)lane;
+      u32x4 q[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = u32x4{0u, 0u, 0u, 0u};
+      if (at < row_bytes) {
+        const u32x4* const row = reinterpret_cast<const u32x4*>(slot_of + (size_t)l * row_bytes + at);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = row[i];
+      }
+      unsigned mine_n = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned word = q[i][c];
+          mine_n += (word & 0xffu ? 1u : 0u) + (word & 0xff00u ? 1u : 0u) + (word & 0xff0000u ? 1u : 0u) + (word & 0xff000000u ? 1u : 0u);
+        }
+      unsigned inclusive = mine_n;
+#pragma unroll
+      for (int offset = 1; offset < 64; offset <<= 1) {
+        const unsigned other = __shfl_up(inclusive, offset);
+        if (lane >= offset) inclusive += other;
+      }
+      n_list = (unsigned)__builtin_amdgcn_readlane((int)inclusive, 63);
+      if (n_list == 0) continue;  // (wave-uniform)
+      unsigned pos = inclusive - mine_n;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int byte = 0; byte < 4; ++byte) {
+            const unsigned slot = (q[i][c] >> (8 * byte)) & 0xffu;
+            if (slot) list[pos++] = ((at + 16u * i + 4u * c + byte) << 8) | slot;
+          }
+    }
+    // (a batch's records are requested while the batch before it is worked on: one memory round trip per label, not per batch)
+    auto fetch_batch = [&](unsigned b0, unsigned* entry_out) -> ChunkRec {
+      const unsigned entry = b0 + (unsigned)lane < n_list ? list[b0 + lane] : 0u;
+      ChunkRec rec{};
+      rec.hi = SHRT_MIN;
+      rec.lo = SHRT_MAX;
+      if (entry) rec = records[(size_t)(entry >> 8) * ZC_SLOTS + (entry & 0xffu) - 1];
+      *entry_out = entry;
+      return rec;
+    };
+    unsigned entry_next = 0u;
+    ChunkRec rec_next = fetch_batch(0u, &entry_next);
+    for (unsigned b0 = 0; b0 < n_list; b0 += 64) {
+      const unsigned entry = entry_next;
+      const ChunkRec rec = rec_next;
+      if (b0 + 64 < n_list) rec_next = fetch_batch(b0 + 64, &entry_next);  // (wave-uniform)
+      const unsigned in_batch = min(64u, n_list - b0);
+      {
+        // all the batch's chunks at once: their cells are multiples of 2^low, their magnitudes add up to `magnitude`
+        const int low = wave_min(rec.lo == SHRT_MAX ? INT_MAX : (int)rec.lo);
+        const double magnitude = wave_sum_exact(rec.magnitude);
+        bool exact = __ballot(rec.bad != 0) == 0 && fabs(acc) <= 1.7976931348623157e308;
+        if (exact && low != INT_MAX) {
+          int acc_top = INT_MIN, acc_low = INT_MAX;
+          if (acc != 0.0) exponent_span(acc, &acc_top, &acc_low);
+          const double bound = (fabs(acc) + magnitude) * 1.000000000001;
+          exact = bound < 8.98846567431158e307;
+          if (exact) {
+            int bound_top, bound_low;
+            exponent_span(bound, &bound_top, &bound_low);
+            exact = bound_top + 1 - min(low, acc_low) <= 53;
+          }
+        }
+        if (exact) {  // (wave-uniform)
+          acc += wave_sum_exact(rec.total);
+          n_total += wave_sum_u32(rec.count);
+          continue;
+        }
+      }
+      // (a chunk that has to be replayed is often followed by another -- a running sum that has taken up a very fine cell fails
+      //  the test until it has grown past it: the cells of the NEXT chunk are requested before this one's chain of additions)
+      bool have_ahead = false;
+      StepCells ahead_one{}, ahead_two{};
+      for (unsigned j = 0; j < in_batch; ++j) {
+        const double total = readlane_f64(rec.total, (int)j), magnitude = readlane_f64(rec.magnitude, (int)j);
+        const unsigned count = (unsigned)__builtin_amdgcn_readlane((int)rec.count, (int)j);
+        const unsigned packed = (unsigned)__builtin_amdgcn_readlane((int)((unsigned)(unsigned short)rec.hi | ((unsigned)(unsigned short)rec.lo << 16)), (int)j);
+        const unsigned range = (unsigned)__builtin_amdgcn_readlane((int)((unsigned)rec.first | ((unsigned)rec.last << 8) | ((unsigned)rec.bad << 16)), (int)j);
+        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)entry, (int)j) >> 8;
+        const int hi16 = (int)(short)(packed & 0xffffu), lo16 = (int)(short)(packed >> 16);
+        const int hi = hi16 == SHRT_MIN ? INT_MIN : hi16, lo = lo16 == SHRT_MAX ? INT_MAX : lo16;
+        const unsigned first = range & 0xffu, last = (range >> 8) & 0xffu, bad = range >> 16;
+        n_total += count;
+        if (!bad && additions_exact(acc, hi, lo, count, magnitude)) {
+          acc += total;
+          have_ahead = false;
+          continue;
+        }
+        if (++replays > patience || (n_total >= long_from && last - first >= 2 && ++walks > ZC_LONG_WALKS)) {  // (wave-uniform)
+          give_up();
+          return;
+        }
+        const size_t begin = (size_t)w * cells_per_wave, end = min(begin + cells_per_wave, cells);
+        if (last - first < 2) {  // a chunk of one or two steps: its cells, one after the other
+          StepCells one, two;
+          if (have_ahead) {
+            one = ahead_one;
+            two = ahead_two;
+          } else {
+            one = load_step(begin, end, first);
+            two = load_step(begin, end, last);
+          }
+          const unsigned n_one = park(one, mine), n_two = last != first ? park(two, mine_b) : 0u;
+          // (this chunk's cells are in LDS: the next chunk's are requested now and arrive during the chains below)
+          have_ahead = false;
+          if (j + 1 < in_batch) {
+            const unsigned next_range = (unsigned)__builtin_amdgcn_readlane((int)((unsigned)rec.first | ((unsigned)rec.last << 8)), (int)j + 1);
+            const unsigned next_first = next_range & 0xffu, next_last = next_range >> 8;
+            if (next_last - next_first < 2) {
+              const unsigned next_w = (unsigned)__builtin_amdgcn_readlane((int)entry, (int)j + 1) >> 8;
+              const size_t next_begin = (size_t)next_w * cells_per_wave, next_end = min(next_begin + cells_per_wave, cells);
+              ahead_one = load_step(next_begin, next_end, next_first);
+              ahead_two = load_step(next_begin, next_end, next_last);
+              have_ahead = true;
+            }
+          }
+          if (n_one) acc = chain_add_parked(mine, acc, n_one);
+          if (n_two) acc = chain_add_parked(mine_b, acc, n_two);
+          continue;
+        }
+        have_ahead = false;
+        // a longer chunk step by step, from the notes (a lane reads the note of a step)
+        StepRec note{0.0, 0.0f, -1, SHRT_MIN, SHRT_MAX, 0};
+        if (first + (unsigned)lane <= last) note = step_records[(size_t)w * steps_per_wave + first + lane];
+        unsigned long long wanted = __ballot(note.label == l || note.label == -2);
+        while (wanted) {
+          const int t = __ffsll((long long)wanted) - 1;
+          wanted &= wanted - 1;
+          const int label = __builtin_amdgcn_readlane(note.label, t);
+          if (label == l) {
+            const double step_total = readlane_f64(note.total, t);
+            const float step_magnitude = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(note.magnitude), t));
+            const unsigned span = (unsigned)__builtin_amdgcn_readlane((int)((unsigned)(unsigned short)note.hi | ((unsigned)(unsigned short)note.lo << 16)), t);
+            const int top16 = (int)(short)(span & 0xffffu), low16 = (int)(short)(span >> 16);
+            if (additions_exact(acc, top16 == SHRT_MIN ? INT_MIN : top16, low16 == SHRT_MAX ? INT_MAX : low16, (unsigned)ZC_STEP, (double)step_magnitude)) {
+              acc += step_total;
+              continue;
+            }
+          }
+          literally(load_step(begin, end, first + (unsigned)t));
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    counts[l] = (long long)n_total;
+    const float nan = std::numeric_limits<float>::quiet_NaN();
+    // ndimage.mean: sum / count in float64; the assignment into the float32 `agg` rounds once
+    out[l] = n_total == 0 ? nan : (statistic == Z_MEAN ? (float)(acc / (double)n_total) : (float)acc);
+  }
+}
+
 template <typename T>
 T scalar_from_bits(uint64_t bits) {
   gm_scalar s;
@@ -2461,10 +3007,10 @@ static int64_t stretch() { static const int64_t v = getenv("GM_ZONAL_STRETCH") ?
 static int64_t wave_cap() { static const int64_t v = getenv("GM_ZONAL_WAVECAP") ? atoll(getenv("GM_ZONAL_WAVECAP")) : 16; return v; }
 
 struct Scratch {  // device buffers of one call, returned to the pool on every exit path
-  void* p[24] = {nullptr};
+  void* p[32] = {nullptr};
   int n = 0;
   int take(void** out, size_t bytes) {
-    if (n == 24) return gm::fail(GM_ERR_INVALID, "gm_zonal_statistic: scratch table full");
+    if (n == 32) return gm::fail(GM_ERR_INVALID, "gm_zonal_statistic: scratch table full");
     const int rc = gm_malloc(out, bytes ? bytes : 1);
     if (rc == GM_OK) p[n++] = *out;
     return rc;
@@ -2556,6 +3102,12 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   unsigned long long* sel_next = nullptr;
   const size_t part_bins = (size_t)n_labels + 1, part_tiles = ((size_t)cells + ZP_TILE - 1) / ZP_TILE;
   PartitionBuffers part;
+  struct {
+    ChunkRec* records = nullptr;
+    unsigned char* slot_of = nullptr;
+    StepRec* steps = nullptr;
+    ChunkVerdict* verdict = nullptr;
+  } chunk;
   const unsigned blocks = (unsigned)std::min<int64_t>((cells + 255) / 256, (int64_t)gm::current_cu_count() * 32);
   for (int64_t f = 0; f < frames; ++f) {
     const T* frame = values + (size_t)f * cells;
@@ -2633,11 +3185,59 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       GM_HIP(hipGetLastError());
       return GM_OK;
     };
+    // sums first try the route that sorts nothing (chunk records: zonal_chunk_kernel); GM_ZONAL_CHUNKS=0 switches it off and
+    // GM_ZONAL_SORTED=1 skips it together with the other parallel sums (A/B runs, and the tests compare the routes)
+    // (GM_ZONAL_CHUNKS=2: also the labels of ZL_LONG cells and more stay on this route however often they are replayed -- the tests do)
+    static const int chunks_mode = getenv("GM_ZONAL_CHUNKS") ? atoi(getenv("GM_ZONAL_CHUNKS")) : 1;
+    const bool chunks_allowed = chunks_mode != 0;
+    bool chunk_gave_up_hard = false;  // (a sum that keeps rounding: the parallel sums below cannot answer it either)
+    if (range && chunks_allowed && n_labels + 1 <= ZP_BINS && cells >= ZC_LANE && (uintptr_t)frame % sizeof(CellQuad<T>) == 0 &&
+        (uintptr_t)labels % sizeof(LabelQuad) == 0) {
+      // stretches of at least `stretch()` cells, whole steps, at most 64 steps each (more, shorter stretches for large rasters)
+      int64_t n_stretch = std::max<int64_t>(1, std::min<int64_t>((cells + stretch() - 1) / stretch(), (int64_t)gm::current_cu_count() * wave_cap()));
+      size_t chunk_cells = (size_t)(((cells + n_stretch - 1) / n_stretch + ZC_STEP - 1) / ZC_STEP * ZC_STEP);
+      if (chunk_cells > ZC_MAX_STEPS * (size_t)ZC_STEP) chunk_cells = ZC_MAX_STEPS * (size_t)ZC_STEP;
+      n_stretch = (int64_t)(((size_t)cells + chunk_cells - 1) / chunk_cells);
+      const size_t row_bytes = ((size_t)n_stretch + 63) / 64 * 64;  // a label's row of the slot table: whole 64-byte groups
+      const size_t table_bytes = (size_t)n_labels * row_bytes;
+      if (table_bytes <= ((size_t)64 << 20)) {
+        if (!chunk.records) {
+          if ((rc = scratch.take((void**)&chunk.records, sizeof(ChunkRec) * ZC_SLOTS * (size_t)n_stretch))) return rc;
+          if ((rc = scratch.take((void**)&chunk.slot_of, table_bytes + 64))) return rc;  // (the verdict behind the table: one fill)
+          if ((rc = scratch.take((void**)&chunk.steps, sizeof(StepRec) * (chunk_cells / ZC_STEP) * (size_t)n_stretch))) return rc;
+          chunk.verdict = (ChunkVerdict*)(chunk.slot_of + table_bytes);
+        }
+        GM_HIP(hipMemsetAsync(chunk.slot_of, 0, table_bytes + 64, s));
+        HostFlag* const flag = host_flag();
+        if (flag) flag->word[0] = flag->word[1] = 0u;
+        static const unsigned chunk_long = getenv("GM_ZONAL_LONG") ? (unsigned)std::max(2 * (int)ZB, atoi(getenv("GM_ZONAL_LONG"))) : ZL_LONG;
+        hipLaunchKernelGGL(zonal_chunk_kernel<T>, dim3((unsigned)((n_stretch + 3) / 4)), dim3(256), 0, s, frame, labels, (size_t)cells, chunk_cells,
+                           (unsigned)n_stretch, (unsigned)row_bytes, n_labels, has_ndv, ndv, thresholds, chunk.records, chunk.slot_of,
+                           chunk.steps, chunk.verdict, flag ? flag->word : (unsigned*)nullptr, seen);
+        hipLaunchKernelGGL(zonal_chunk_combine_kernel<T>, dim3((unsigned)(((size_t)n_labels * 64 + 255) / 256)), dim3(256), 0, s, frame, labels,
+                           (size_t)cells, chunk_cells, (unsigned)n_stretch, (unsigned)row_bytes, n_labels, has_ndv, ndv, thresholds,
+                           chunk.records, chunk.slot_of, chunk.steps, chunk.verdict,
+                           flag ? flag->word : (unsigned*)nullptr, chunks_mode == 2 ? ~0u : chunk_long,
+                           chunks_mode == 2 ? ~0u : ZC_REPLAYS, statistic, out_f, counts_f);
+        GM_HIP(hipGetLastError());
+        ChunkVerdict chunk_verdict{1u, 0u};
+        if (flag) {  // (the one host decision of this route: two words in pinned memory, read once the kernels are through)
+          GM_HIP(hipEventRecord(flag->event, s));
+          GM_HIP(hipEventSynchronize(flag->event));
+          chunk_verdict.overflow = ((volatile unsigned*)flag->word)[0];
+          chunk_verdict.hard = ((volatile unsigned*)flag->word)[1];
+        } else if ((rc = gm_d2h(&chunk_verdict, chunk.verdict, sizeof(chunk_verdict)))) {
+          return rc;
+        }
+        if (!chunk_verdict.overflow && !chunk_verdict.hard) continue;
+        chunk_gave_up_hard = chunk_verdict.hard != 0;
+      }
+    }
     if ((rc = key_buffers())) return rc;
     bool keys_written = false;
     unsigned longest = ~0u;  // (cells of the longest label, where a verdict has counted them)
     part.counted = false;
-    if (range) {
+    if (range && !chunk_gave_up_hard) {
       if (partition) {  // (3 MB for the default raster limit and 1024 labels)
         if (!part.counts && (rc = scratch.take((void**)&part.counts, sizeof(unsigned) * part_tiles * part_bins))) return rc;
         GM_HIP(hipMemsetAsync(part.counts, 0, sizeof(unsigned) * part_tiles * part_bins, s));

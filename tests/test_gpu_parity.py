@@ -2132,6 +2132,38 @@ def test_zonal_label_partition(gpu, part, select):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunks", ["2", "1", "0"], ids=["chunks-always", "product", "chunks-off"])
+def test_zonal_chunk_records(gpu, chunks):
+    """Sums and means without a sort (csrc/gm_zonal.hip: zonal_chunk_kernel leaves a record per (stretch of the raster, label),
+    zonal_chunk_combine_kernel walks a label's records in order -- one addition per chunk that cannot round, the chunk's cells
+    again from the raster otherwise) against np.bincount's order: 80 statistics over label layouts of many chunks per label,
+    every label ending in cells that cancel the sequential sum before them (tests/zonal_chunks_driver.py).  With every label
+    kept on the route, with the product's choice (labels that are replayed too often take the sorting route), and without it."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GM_ZONAL_CHUNKS=chunks)
+    driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_chunks_driver.py")
+    res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
+    assert "CHUNKS ok 80" in res.stdout
+
+
+@pytest.mark.gpu
+def test_zonal_exactness_certificates_through_the_chunks(gpu):
+    """The adversarial rasters of the block pipeline's certificates (labels of 450 k - 1 M cells whose tails cancel the sum
+    before them) answered by the chunk records alone (GM_ZONAL_CHUNKS=2: no label is handed to the sorting route)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GM_ZONAL_CHUNKS="2")
+    driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_certificate_driver.py")
+    res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
+    assert "CERTIFICATES ok 56" in res.stdout
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("certify", ["1", "0"])
 def test_zonal_exactness_certificates(gpu, certify):
     """Labels of 7 - 15 whole groups of 256 blocks whose tails cancel the sequential float64 sum before them, so that the
@@ -2141,7 +2173,7 @@ def test_zonal_exactness_certificates(gpu, certify):
     import os
     import subprocess
     import sys
-    env = dict(os.environ, GM_ZONAL_CERTIFY=certify, GM_ZONAL_VERBOSE="1")
+    env = dict(os.environ, GM_ZONAL_CERTIFY=certify, GM_ZONAL_VERBOSE="1", GM_ZONAL_CHUNKS="0")
     driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_certificate_driver.py")
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])

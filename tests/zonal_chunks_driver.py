@@ -1,0 +1,96 @@
+"""Sums / means through the chunk records of csrc/gm_zonal.hip (zonal_chunk_kernel / zonal_chunk_combine_kernel) against the
+oracle's np.bincount order, on rasters large enough for labels of many chunks: blocks, stripes, one label with strays, rows
+that end inside a step, cells of much finer grain than the sums (chunks and steps that must be replayed), non-finite cells,
+thresholds, several frames.  Every label ends with cells that CANCEL the sequential float64 sum before them (as in
+tests/zonal_certificate_driver.py), so that the float32 result shows every bit of it.  Run by
+tests/test_gpu_parity.py::test_zonal_chunk_records with GM_ZONAL_CHUNKS=2 (every label stays on the route), =1 (the
+product's choice) and =0 (off).  Prints 'CHUNKS ok <cases>'."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dask_geomodeling_amd import geometry  # noqa: E402
+from dask_geomodeling_amd.hip import runtime  # noqa: E402
+from oracle import ref_numpy as O  # noqa: E402
+
+runtime.set_device(0)
+rng = np.random.default_rng(2026)
+cases = 0
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+for it in range(N):
+    kind = it % 8
+    h, w = int(rng.integers(300, 700)), int(rng.integers(500, 1500))
+    frames = 1 + (it % 5 == 0)
+    dt = ["f4", "f4", "f8", "f4", "i4", "f4", "f8", "f4"][kind]
+    layout = it % 4
+    if layout == 0:      # blocks
+        by, bx = int(rng.integers(20, 120)), int(rng.integers(30, 300))
+        labels = (np.arange(h)[:, None] // by) * ((w + bx - 1) // bx) + np.arange(w)[None, :] // bx
+    elif layout == 1:    # vertical stripes: every row of the raster holds every label
+        labels = np.broadcast_to(np.arange(w)[None, :] // int(rng.integers(40, 400)), (h, w)).copy()
+    elif layout == 2:    # one label and a few strays
+        labels = np.zeros((h, w), dtype=np.int64)
+        labels[rng.random((h, w)) < 0.002] = 1
+    else:                # horizontal bands of whole rows (chunks of many steps)
+        labels = np.broadcast_to((np.arange(h)[:, None] // int(rng.integers(5, 80))), (h, w)).copy()
+    labels = labels.astype(np.int32)
+    n = int(labels.max()) + 1
+    labels[rng.random((h, w)) < 0.02] = np.iinfo(np.int32).max
+    base = rng.standard_normal((frames, h, w))
+    shape = base.shape
+    if kind == 0:
+        values = base * 100
+    elif kind == 1:      # a few cells of much finer grain
+        values = base * 100
+        fine = rng.random(shape) < 3e-4
+        values[fine] = rng.standard_normal(int(fine.sum())) * 1e-7
+    elif kind == 2:
+        values = base * rng.choice([1e-3, 1.0, 1e3], size=shape)
+    elif kind == 3:      # positive, elevation-like
+        values = np.abs(base) * 50 + 3
+    elif kind == 4:
+        values = np.round(base * 1e5)
+    elif kind == 5:      # mostly zeros, signed
+        values = np.where(rng.random(shape) < 0.02, base * 1e4, np.where(rng.random(shape) < 0.5, 0.0, -0.0))
+    elif kind == 6:      # tiny and huge together
+        values = base * np.exp2(rng.integers(-40, 40, size=shape).astype(np.float64))
+    else:                # non-finite cells
+        values = base * 10
+        values[rng.random(shape) < 1e-4] = np.inf
+        values[rng.random(shape) < 1e-4] = np.nan
+    values = values.astype(dt)
+    ndv = np.dtype(dt).type(-9999 if np.dtype(dt).kind == "f" else np.iinfo(dt).max)
+    values[rng.random(shape) < 0.08] = ndv
+    if kind != 7 and np.dtype(dt).kind == "f":
+        # the cancelling tail of every label: its last three active cells become -(the sequential sum before them), in pieces
+        flat_l = labels.reshape(-1)
+        for f in range(frames):
+            flat_v = values[f].reshape(-1)
+            for l in range(min(n, 40)):
+                idx = np.flatnonzero((flat_l == l) & (flat_v != ndv))
+                if len(idx) < 8:
+                    continue
+                running = np.cumsum(flat_v[idx[:-3]].astype(np.float64))[-1]   # np.cumsum adds in order, like bincount
+                for k in range(3):
+                    piece = np.dtype(dt).type(-running)
+                    if not np.isfinite(piece):
+                        break
+                    flat_v[idx[-3 + k]] = piece
+                    running = running + float(piece)
+    thr = None
+    if it % 6 == 3:
+        thr = (rng.standard_normal(n) * 5).astype("f4")
+        thr[rng.random(n) < 0.2] = np.nan
+    for stat in ("sum", "mean"):
+        with np.errstate(all="ignore"):
+            want, want_no = O.aggregate_labelled([(list(range(n)), labels)], n, values, ndv, thr, stat)
+        got, got_no = geometry.aggregate_labelled([(list(range(n)), labels)], n, values, ndv, thr, stat)
+        same = (got.view("u4") == want.view("u4")) | (np.isnan(got) & np.isnan(want)) | (got == want)
+        assert same.all(), "case %d kind %d layout %d %s %s: %d of %d results differ (first at %s: %r against %r)" % (
+            it, kind, layout, dt, stat, (~same).sum(), same.size, np.argwhere(~same)[0], got[~same][0], want[~same][0])
+        assert got_no == want_no
+        cases += 1
+print("CHUNKS ok %d" % cases)
