@@ -2452,7 +2452,7 @@ __global__ __launch_bounds__(256) void zonal_exact_result_kernel(const ExactRang
 // of label l inside stretch w -- its CHUNK (w, l) -- are consecutive in l's sequence, and the chunks of l in the order of w are
 // that sequence.  Pass 1 (zonal_chunk_kernel, the only pass over the raster: 8 bytes per cell, 4 cells per lane and step) leaves
 // per chunk what certifies it and what it adds up to when certified: the count, the highest exponent and the lowest set bit
-// among its cells, the sum of their magnitudes, a tree sum, the steps it lies in; and a note of the same kind per step of 256
+// among its cells, the extreme partial sums on the way, a tree sum, the steps it lies in; and a note of the same kind per step of 256
 // cells.  Pass 2 (zonal_chunk_combine_kernel, a wave per label) walks the label's chunks in order: a chunk none of whose
 // additions can round, given the running sum that enters it -- every intermediate value a multiple of 2^lo below 2^(lo + 53)
 // -- is ONE addition of its tree sum; any other chunk is replayed: its cells read from the raster again and added one after
@@ -2467,20 +2467,20 @@ constexpr int ZC_MAX_STEPS = 64;                    // steps per stretch
 constexpr int ZC_LABELS_PER_STEP = 8;
 constexpr int ZC_LIST = 4096;                       // chunks of a label listed at a time (one byte-row round of the table)
 struct ChunkRec {  // 32 bytes
-  double total;      // tree sum of the chunk's cells (meaningful when the chunk is certified)
-  double magnitude;  // sum of their absolute values (any order; an upper bound within 2^-40 relatively)
-  unsigned count;    // active cells
+  double total;    // tree sum of the chunk's cells (meaningful when the chunk is certified)
+  float low, high;  // the lowest / highest partial sum while the chunk's cells are added in order, relative to the sum entering
+                    // the chunk and to within the four cells of a lane (rounded outwards; low <= 0 <= high)
+  unsigned count;  // active cells
   int label;
-  short hi, lo;      // top exponent / exponent of the lowest set bit over the non-zero cells (SHRT_MIN / SHRT_MAX: none)
+  short hi, lo;    // top exponent / exponent of the lowest set bit over the non-zero cells (SHRT_MIN / SHRT_MAX: none)
   unsigned char first, last;  // the steps of the stretch that hold the chunk's cells
   unsigned char bad, pad;     // bad: a NaN or an infinity among the cells
 };
 struct StepRec {  // 24 bytes, per step of ZC_STEP cells
   double total;
-  float magnitude;  // rounded up
+  float low, high;  // as in ChunkRec
   int label;        // >= 0: the one label of the step's active cells; -1: no active cell; -2: add it literally (several labels, a non-finite cell)
   short hi, lo;     // as in ChunkRec
-  int pad;
 };
 struct ChunkVerdict {
   unsigned overflow;  // pass 1: the label raster is not made of runs
@@ -2488,8 +2488,8 @@ struct ChunkVerdict {
 };
 // A label is given up (`hard`: the whole call takes the sorting route, whose block pipeline is built for such sums) after this
 // many replayed chunks -- replays read the raster again, a few microseconds each -- or, once ZL_LONG of its cells have gone
-// by, after a few chunks that had to be walked step by step.
-constexpr unsigned ZC_REPLAYS = 64, ZC_LONG_WALKS = 4;
+// by, at the first chunk that has to be walked step by step.
+constexpr unsigned ZC_REPLAYS = 64, ZC_LONG_WALKS = 0;
 template <typename T>
 struct alignas(4 * sizeof(T) > 16 ? 16 : 4 * sizeof(T)) CellQuad {
   T c[ZC_LANE];
@@ -2512,26 +2512,61 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {
   const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// No addition of `cells` cells -- multiples of 2^low, below 2^(top + 1) each, their magnitudes adding up to `magnitude` at most
-// -- onto acc can round: every intermediate value is a multiple of 2^lo, lo = min(low, lowest set bit of acc), and smaller than
-// |acc| + magnitude; below 2^(lo + 53) it is a float64.  Two bounds, either suffices: by the exponents (zonal_sum_kernel's), by
-// the magnitudes (tighter by the bits a sum of mixed signs does not grow).  Then the cells' own partial sums -- in any order --
-// are multiples of 2^lo below 2^(lo + 53) as well: the tree sum is their exact sum.
-__device__ __forceinline__ bool additions_exact(double acc, int top, int low, unsigned cells, double magnitude) {
+// No addition of `cells` cells -- multiples of 2^low, below 2^(top + 1) each, their partial sums in order inside [below, above]
+// -- onto acc can round: every intermediate value is a multiple of 2^g, g = min(low, lowest set bit of acc), and lies inside
+// acc + [below, above]; below 2^(g + 53) in magnitude it is a float64.  Two bounds, either suffices: by the exponents
+// (zonal_sum_kernel's), by the partial sums (zonal_group_exact_kernel's: tighter by what a sum of mixed signs does not grow;
+// above - below < 2^(52 + g) makes sure that every RANGE of the cells sums without rounding, so that the partial sums -- float64
+// sums themselves, hence the 0.99 -- and the tree sum are the exact ones).
+__device__ __forceinline__ bool additions_exact(double acc, int top, int low, unsigned cells, double below, double above) {
   if (top == INT_MIN) return true;  // nothing but zeros
   if (!(fabs(acc) <= 1.7976931348623157e308)) return false;
   int acc_top = INT_MIN, acc_low = INT_MAX;
   if (acc != 0.0) exponent_span(acc, &acc_top, &acc_low);
-  const int lo = min(low, acc_low);
+  const int g = min(low, acc_low);
   const int growth = cells <= 1 ? 0 : 32 - __clz((int)(cells - 1));  // ceil(log2(cells))
   const long long hi = max((long long)acc_top, (long long)top + growth) + 2;
-  if (hi - lo <= 53 && hi < 1023) return true;
-  const double bound = (fabs(acc) + magnitude) * 1.000000000001;  // (the two sums may have rounded)
-  if (!(bound < 8.98846567431158e307)) return false;              // (2^1023; also NaN)
-  int bound_top, bound_low;
-  exponent_span(bound, &bound_top, &bound_low);  // bound < 2^(bound_top + 1)
-  return bound_top + 1 - lo <= 53;
+  if (hi - g <= 53 && hi < 1023) return true;
+  if (!(g > -1000 && g < 900)) return false;
+  const double reach = fmax(fabs(acc + below), fabs(acc + above));
+  return reach < ldexp(0.99, 53 + g) && above - below < ldexp(0.99, 52 + g);  // (false for NaN / inf bounds)
 }
+// Inclusive sum over the lanes in lane order (data-parallel primitives: shifts inside the rows of 16 lanes -- a lane without a
+// source adds 0.0 --, then the row totals are passed on like in wave_sum_exact)
+__device__ __forceinline__ double wave_scan_f64(double v) {
+  v += dpp_move_f64<0x111>(0.0, v);        // row_shr:1
+  v += dpp_move_f64<0x112>(0.0, v);        // row_shr:2
+  v += dpp_move_f64<0x114>(0.0, v);        // row_shr:4
+  v += dpp_move_f64<0x118>(0.0, v);        // row_shr:8
+  v += dpp_move_f64<0x142, 0xA>(0.0, v);   // row_bcast15 into rows 1 and 3
+  v += dpp_move_f64<0x143, 0xC>(0.0, v);   // row_bcast31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+  const double inf = __builtin_huge_val();
+  v = fmin(v, dpp_move_f64<0xB1>(v, v));
+  v = fmin(v, dpp_move_f64<0x4E>(v, v));
+  v = fmin(v, dpp_move_f64<0x141>(v, v));
+  v = fmin(v, dpp_move_f64<0x140>(v, v));
+  v = fmin(v, dpp_move_f64<0x142, 0xA>(inf, v));
+  v = fmin(v, dpp_move_f64<0x143, 0xC>(inf, v));
+  return readlane_f64(v, 63);
+}
+__device__ __forceinline__ double wave_max_f64(double v) { return -wave_min_f64(-v); }
+__device__ __forceinline__ float wave_min_f32(float v) {
+  const int inf = 0x7f800000;
+  v = fminf(v, __int_as_float(dpp_move<0xB1>(__float_as_int(v), __float_as_int(v))));
+  v = fminf(v, __int_as_float(dpp_move<0x4E>(__float_as_int(v), __float_as_int(v))));
+  v = fminf(v, __int_as_float(dpp_move<0x141>(__float_as_int(v), __float_as_int(v))));
+  v = fminf(v, __int_as_float(dpp_move<0x140>(__float_as_int(v), __float_as_int(v))));
+  v = fminf(v, __int_as_float(dpp_move<0x142, 0xA>(inf, __float_as_int(v))));
+  v = fminf(v, __int_as_float(dpp_move<0x143, 0xC>(inf, __float_as_int(v))));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v); }
+// float32 bounds that contain the float64 ones (inf for what float32 cannot hold: such a chunk is never certified by them)
+__device__ __forceinline__ float outward_low(double x) { return (float)(fmin(x, 0.0) * 1.000001 - 1.0e-30); }
+__device__ __forceinline__ float outward_high(double x) { return (float)(fmax(x, 0.0) * 1.000001 + 1.0e-30); }
 // acc + the first n of the doubles parked in `mine`, in order, n <= ZC_STEP; the caller has zeroed up to the next multiple of
 // 16 (the wave as one sequential adder: zonal_sum_kernel's replay)
 __device__ __forceinline__ double chain_add_parked(const double* mine, double acc, unsigned n) {
@@ -2603,7 +2638,8 @@ __global__ __launch_bounds__(256) void zonal_chunk_kernel(const T* __restrict__ 
   const unsigned steps = (unsigned)((end - begin + ZC_STEP - 1) / ZC_STEP), full = (unsigned)((end - begin) / ZC_STEP);
   // the stretch's chunk records, a lane each
   int slot_label = -1, n_slots = 0;
-  double r_total = 0.0, r_magnitude = 0.0;
+  double r_total = 0.0;
+  float r_low = 0.0f, r_high = 0.0f;
   unsigned r_count = 0, r_bad = 0, r_first = 255u, r_last = 0u;
   int r_hi = INT_MIN, r_lo = INT_MAX;
   bool dead = false;     // this label raster is not for chunk records (wave-uniform)
@@ -2663,7 +2699,7 @@ __global__ __launch_bounds__(256) void zonal_chunk_kernel(const T* __restrict__ 
     bool remaining[ZC_LANE];
 #pragma unroll
     for (int k = 0; k < ZC_LANE; ++k) remaining[k] = inside[k] && cell_active<T>(v[k], label[k], n_labels, has_ndv, ndv, thresholds);
-    StepRec note{0.0, 0.0f, -1, SHRT_MIN, SHRT_MAX, 0};
+    StepRec note{0.0, 0.0f, 0.0f, -1, SHRT_MIN, SHRT_MAX};
     int found = 0;
     while (true) {
       const unsigned long long open = __ballot(remaining[0] | remaining[1] | remaining[2] | remaining[3]);
@@ -2674,44 +2710,57 @@ __global__ __launch_bounds__(256) void zonal_chunk_kernel(const T* __restrict__ 
       }
       const int mine = remaining[0] ? label[0] : remaining[1] ? label[1] : remaining[2] ? label[2] : label[3];
       const int lead = __builtin_amdgcn_readlane(mine, __ffsll((long long)open) - 1);  // (a uniform lane index)
-      unsigned n = 0, bad = 0;
-      int hi = INT_MIN, lo = INT_MAX;
+      unsigned n = 0;
+      int hi = INT_MIN, lo = INT_MAX;  // (hi == INT_MAX: a NaN or an infinity among the cells)
       double sum = 0.0, magnitude = 0.0;
+      if constexpr (std::is_same<T, float>::value) {
+        // float32 cells: the top exponent is that of the largest magnitude (one integer maximum per cell), the lowest set bit
+        // e - 150 + ctz(mantissa with its hidden bit) -- one less than the truth for subnormals, which only makes the test stricter
+        unsigned widest = 0u;
+        int finest = INT_MAX;
 #pragma unroll
-      for (int k = 0; k < ZC_LANE; ++k) {
-        const bool taken = remaining[k] && label[k] == lead;
-        n += (unsigned)__popcll(__ballot(taken));  // (wave-uniform: the cells of this label in the step)
-        if (taken) {
-          remaining[k] = false;
-          const double x = (double)v[k];  // what bincount adds
-          if (!(fabs(x) <= 1.7976931348623157e308)) {
-            bad = 1;
-          } else if (x != 0.0) {
-            int top, low;
-            cell_span<T>(v[k], &top, &low);
-            hi = max(hi, top);
-            lo = min(lo, low);
+        for (int k = 0; k < ZC_LANE; ++k) {
+          const bool taken = remaining[k] && label[k] == lead;
+          n += (unsigned)__popcll(__ballot(taken));  // (wave-uniform: the cells of this label in the step)
+          if (taken) {
+            remaining[k] = false;
+            const unsigned magnitude_bits = __float_as_uint(v[k]) & 0x7fffffffu;
+            widest = max(widest, magnitude_bits);
+            if (magnitude_bits != 0u) finest = min(finest, (int)(magnitude_bits >> 23) + (__ffs((int)(magnitude_bits | 0x800000u)) - 1));
+            const double x = (double)v[k];  // what bincount adds
+            sum += x;
+            magnitude += fabs(x);
           }
-          sum += x;
-          magnitude += fabs(x);
+        }
+        if (widest >= 0x7f800000u) hi = INT_MAX;
+        else if (widest != 0u) hi = max((int)(widest >> 23), 1) - 127;
+        if (finest != INT_MAX) lo = finest - 150;
+      } else {
+#pragma unroll
+        for (int k = 0; k < ZC_LANE; ++k) {
+          const bool taken = remaining[k] && label[k] == lead;
+          n += (unsigned)__popcll(__ballot(taken));
+          if (taken) {
+            remaining[k] = false;
+            const double x = (double)v[k];
+            if (!(fabs(x) <= 1.7976931348623157e308)) {
+              hi = INT_MAX;
+            } else if (x != 0.0) {
+              int top, low;
+              cell_span<T>(v[k], &top, &low);
+              hi = max(hi, top);
+              lo = min(lo, low);
+            }
+            sum += x;
+            magnitude += fabs(x);
+          }
         }
       }
-      bad = wave_or_u32(bad);
       hi = wave_max(hi);
       lo = wave_min(lo);
-      sum = wave_sum_exact(sum);  // (only used when certified exact)
-      magnitude = wave_sum_exact(magnitude);
-      if (found == 0) {
-        note.total = sum;
-        note.magnitude = (float)(magnitude * 1.000001);  // (an upper bound after the rounding to float32; inf for huge values)
-        note.label = bad ? -2 : lead;
-        note.hi = (short)max(hi, (int)SHRT_MIN);  // (float64 exponents fit; INT_MIN -> SHRT_MIN)
-        note.lo = (short)min(lo, (int)SHRT_MAX);
-      } else {
-        note.label = -2;
-      }
-      ++found;
-      // into the stretch's record of this label
+      const unsigned bad = hi == INT_MAX ? 1u : 0u;
+      if (bad) hi = INT_MIN;
+      // the stretch's record of this label (a lane's)
       const unsigned long long hit = __ballot(slot_label == lead);
       int slot;
       if (hit) {
@@ -2722,10 +2771,30 @@ __global__ __launch_bounds__(256) void zonal_chunk_kernel(const T* __restrict__ 
         dead = true;
         break;
       }
+      // The partial sums in raster order, to within a lane's four cells: the sum before the lane -/+ the lane's magnitudes,
+      // relative to the sum entering the CHUNK (the record's total so far); their extremes as float32 rounded outwards --
+      // minima and maxima of float32 values do not round.
+      const double inclusive = wave_scan_f64(sum);
+      const double chunk_so_far = hit ? readlane_f64(r_total, slot) : 0.0;
+      const double before = chunk_so_far + (inclusive - sum);
+      const float lowest = wave_min_f32(outward_low(before - magnitude)), highest = wave_max_f32(outward_high(before + magnitude));
+      sum = readlane_f64(inclusive, 63);  // the step's tree sum (only used when certified exact)
+      if (found == 0) {
+        note.total = sum;
+        note.low = outward_low((double)lowest - chunk_so_far);  // (relative to the sum entering the step)
+        note.high = outward_high((double)highest - chunk_so_far);
+        note.label = bad ? -2 : lead;
+        note.hi = (short)max(hi, (int)SHRT_MIN);  // (float64 exponents fit; INT_MIN -> SHRT_MIN)
+        note.lo = (short)min(lo, (int)SHRT_MAX);
+      } else {
+        note.label = -2;
+      }
+      ++found;
       if (lane == slot) {
         slot_label = lead;
+        r_low = fminf(r_low, lowest);
+        r_high = fmaxf(r_high, highest);
         r_total += sum;
-        r_magnitude += magnitude;
         r_count += n;
         r_bad |= bad;
         r_hi = max(r_hi, hi);
@@ -2747,7 +2816,8 @@ __global__ __launch_bounds__(256) void zonal_chunk_kernel(const T* __restrict__ 
   if (lane < n_slots) {
     ChunkRec rec;
     rec.total = r_total;
-    rec.magnitude = r_magnitude;
+    rec.low = r_low;
+    rec.high = r_high;
     rec.count = r_count;
     rec.label = slot_label;
     rec.hi = (short)max(r_hi, (int)SHRT_MIN);
@@ -2887,22 +2957,13 @@ __global__ __launch_bounds__(256) void zonal_chunk_combine_kernel(const T* __res
       if (b0 + 64 < n_list) rec_next = fetch_batch(b0 + 64, &entry_next);  // (wave-uniform)
       const unsigned in_batch = min(64u, n_list - b0);
       {
-        // all the batch's chunks at once: their cells are multiples of 2^low, their magnitudes add up to `magnitude`
+        // all the batch's chunks at once: their cells are multiples of 2^low, the partial sums stay inside [below, above]
         const int low = wave_min(rec.lo == SHRT_MAX ? INT_MAX : (int)rec.lo);
-        const double magnitude = wave_sum_exact(rec.magnitude);
-        bool exact = __ballot(rec.bad != 0) == 0 && fabs(acc) <= 1.7976931348623157e308;
-        if (exact && low != INT_MAX) {
-          int acc_top = INT_MIN, acc_low = INT_MAX;
-          if (acc != 0.0) exponent_span(acc, &acc_top, &acc_low);
-          const double bound = (fabs(acc) + magnitude) * 1.000000000001;
-          exact = bound < 8.98846567431158e307;
-          if (exact) {
-            int bound_top, bound_low;
-            exponent_span(bound, &bound_top, &bound_low);
-            exact = bound_top + 1 - min(low, acc_low) <= 53;
-          }
-        }
-        if (exact) {  // (wave-uniform)
+        const int top = wave_max(rec.hi == SHRT_MIN ? INT_MIN : (int)rec.hi);
+        const double before = wave_scan_f64(rec.total) - rec.total;
+        const double below = wave_min_f64(before + (double)rec.low), above = wave_max_f64(before + (double)rec.high);
+        // (the exponent rule would need the batch's cell count: pass a count that rules it out unless everything is tiny)
+        if (__ballot(rec.bad != 0) == 0 && additions_exact(acc, top, low, 0x7fffffffu, below, above)) {  // (wave-uniform)
           acc += wave_sum_exact(rec.total);
           n_total += wave_sum_u32(rec.count);
           continue;
@@ -2913,7 +2974,9 @@ __global__ __launch_bounds__(256) void zonal_chunk_combine_kernel(const T* __res
       bool have_ahead = false;
       StepCells ahead_one{}, ahead_two{};
       for (unsigned j = 0; j < in_batch; ++j) {
-        const double total = readlane_f64(rec.total, (int)j), magnitude = readlane_f64(rec.magnitude, (int)j);
+        const double total = readlane_f64(rec.total, (int)j);
+        const double below = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.low), (int)j));
+        const double above = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.high), (int)j));
         const unsigned count = (unsigned)__builtin_amdgcn_readlane((int)rec.count, (int)j);
         const unsigned packed = (unsigned)__builtin_amdgcn_readlane((int)((unsigned)(unsigned short)rec.hi | ((unsigned)(unsigned short)rec.lo << 16)), (int)j);
         const unsigned range = (unsigned)__builtin_amdgcn_readlane((int)((unsigned)rec.first | ((unsigned)rec.last << 8) | ((unsigned)rec.bad << 16)), (int)j);
@@ -2922,7 +2985,7 @@ __global__ __launch_bounds__(256) void zonal_chunk_combine_kernel(const T* __res
         const int hi = hi16 == SHRT_MIN ? INT_MIN : hi16, lo = lo16 == SHRT_MAX ? INT_MAX : lo16;
         const unsigned first = range & 0xffu, last = (range >> 8) & 0xffu, bad = range >> 16;
         n_total += count;
-        if (!bad && additions_exact(acc, hi, lo, count, magnitude)) {
+        if (!bad && additions_exact(acc, hi, lo, count, below, above)) {
           acc += total;
           have_ahead = false;
           continue;
@@ -2961,7 +3024,7 @@ __global__ __launch_bounds__(256) void zonal_chunk_combine_kernel(const T* __res
         }
         have_ahead = false;
         // a longer chunk step by step, from the notes (a lane reads the note of a step)
-        StepRec note{0.0, 0.0f, -1, SHRT_MIN, SHRT_MAX, 0};
+        StepRec note{0.0, 0.0f, 0.0f, -1, SHRT_MIN, SHRT_MAX};
         if (first + (unsigned)lane <= last) note = step_records[(size_t)w * steps_per_wave + first + lane];
         unsigned long long wanted = __ballot(note.label == l || note.label == -2);
         while (wanted) {
@@ -2970,10 +3033,11 @@ __global__ __launch_bounds__(256) void zonal_chunk_combine_kernel(const T* __res
           const int label = __builtin_amdgcn_readlane(note.label, t);
           if (label == l) {
             const double step_total = readlane_f64(note.total, t);
-            const float step_magnitude = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(note.magnitude), t));
+            const double step_below = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(note.low), t));
+            const double step_above = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(note.high), t));
             const unsigned span = (unsigned)__builtin_amdgcn_readlane((int)((unsigned)(unsigned short)note.hi | ((unsigned)(unsigned short)note.lo << 16)), t);
             const int top16 = (int)(short)(span & 0xffffu), low16 = (int)(short)(span >> 16);
-            if (additions_exact(acc, top16 == SHRT_MIN ? INT_MIN : top16, low16 == SHRT_MAX ? INT_MAX : low16, (unsigned)ZC_STEP, (double)step_magnitude)) {
+            if (additions_exact(acc, top16 == SHRT_MIN ? INT_MIN : top16, low16 == SHRT_MAX ? INT_MAX : low16, (unsigned)ZC_STEP, step_below, step_above)) {
               acc += step_total;
               continue;
             }
