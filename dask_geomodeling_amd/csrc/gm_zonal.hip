@@ -17,11 +17,16 @@
 //   * median / percentile (zonal_pick_kernel): a lane per label picks from its sorted segment and combines exactly as
 //     SciPy / measurements.percentile do (median of integers in float64, of float32 in float32; the percentile's
 //     difference in the raster's own dtype, wrap-around included).
-// Where it does not, nothing is sorted: count, min and max take one pass of atomics (zonal_direct_kernel); sum / mean of
-// labels whose every partial sum is exactly representable -- integer rasters, dyadic data, small polygons -- take two
-// (zonal_exact_kernel), and when only a few labels fail that test only their cells are gathered and sorted.
+// Where it does not, nothing is sorted: count, min and max take one pass of atomics (zonal_direct_kernel).  Sums and means
+// first take the chunk records (round 5: zonal_chunk_kernel / zonal_chunk_combine_kernel, further down): one pass over the
+// raster leaves, per stretch of cells and label, a tree sum and what certifies it; a wave per label adds the certified chunks
+// in order -- one addition each -- and reads the cells of the others again.  Label rasters that are not made of runs, and
+// labels that have to be replayed too often, fall back: sums whose every partial sum is exactly representable -- integer
+// rasters, dyadic data, small polygons -- take two passes of atomics (zonal_exact_kernel; when only a few labels fail that
+// test only their cells are gathered and sorted), everything else the sort.
 // Results are float32 like the reference's `agg` array; labels without an active cell stay NaN.
-// HBM traffic: 8 algorithmic bytes per cell (value + label); the full sort moves ~40-100.
+// HBM traffic: 8 algorithmic bytes per cell (value + label); the chunk records move 1.2 x that
+// (profiles/r05_zonal_pmc_1024.json), the full sort ~6-7 x.
 #include <algorithm>
 #include <climits>
 #include <cmath>

@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     per = collections.defaultdict(float)
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] == c:
-            per[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:60]] += float(r["Counter_Value"])
+            per[r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]] += float(r["Counter_Value"])
     for k, v in per.items():
         out["kernels"].setdefault(k, {})[c + "_KiB_per_call"] = v / 4
     total[c] = sum(per.values()) / 4 * 1024  # (the counters are in KiB)
