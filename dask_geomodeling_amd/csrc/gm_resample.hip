@@ -179,7 +179,13 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src
   const int band = blockIdx.z;
   const T* sband = src + (size_t)band * hs * ws;
   T* dband = dst + (size_t)band * hd * wd;
-  const int r0 = blockIdx.y * BL_TILE_H, c0 = blockIdx.x * BL_TILE_W;
+  // (tuning flags in vec_src: bit 1 -- staging loads through the caches instead of non-temporal; bit 2 -- inside a row of
+  //  tiles every XCD takes a contiguous run, so that horizontal neighbours share an L2)
+  const bool cached_staging = (vec_src & 2) != 0;
+  unsigned bx = blockIdx.x;
+  if ((vec_src & 4) && (gridDim.x & 7u) == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+  vec_src &= 1;
+  const int r0 = blockIdx.y * BL_TILE_H, c0 = (int)bx * BL_TILE_W;
   const int r1 = min(r0 + BL_TILE_H, hd), c1 = min(c0 + BL_TILE_W, wd);
 
   // source window of this block (clamped taps): rows [wy0, wy1], cols [wx0, wx1]
@@ -191,14 +197,12 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src
   // per destination row of the block: upper / lower source row and the lower row's weight, computed
   // once by one lane each and broadcast from LDS (the rows a lane walks are wave-uniform)
   __shared__ double row_fv[BL_TILE_H];
-  __shared__ int row_ia[BL_TILE_H], row_ib[BL_TILE_H];
+  __shared__ int row_i0[BL_TILE_H];  // the upper source row, not clamped: -1 .. hs - 1
   if (threadIdx.x < BL_TILE_H) {
     const double v = src_coord(r0 + (int)threadIdx.x, sy);
     const double i0f = floor(v);
-    const int i0 = (int)i0f;
     row_fv[threadIdx.x] = v - i0f;
-    row_ia[threadIdx.x] = min(max(i0, 0), hs - 1);
-    row_ib[threadIdx.x] = min(max(i0 + 1, 0), hs - 1);
+    row_i0[threadIdx.x] = (int)i0f;
   }
   if constexpr (!STAGED) __syncthreads();
   // A tap that is no data or not finite voids every pixel it touches (any weight): it
@@ -231,7 +235,8 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
             const int y = min(yb + 4 * u, win_h - 1);  // (unconditional: rows past the window re-read its last row)
-            v[u] = __builtin_nontemporal_load((const VT*)(sband + (size_t)(wy0 + y) * spitch + stage_x0) + g);
+            const VT* const at = (const VT*)(sband + (size_t)(wy0 + y) * spitch + stage_x0) + g;
+            v[u] = cached_staging ? *at : __builtin_nontemporal_load(at);
           }
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
@@ -251,7 +256,8 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
             const int y = min(yb + 4 * u, win_h - 1);
-            v[u] = __builtin_nontemporal_load(sband + (size_t)(wy0 + y) * spitch + wx0 + x);
+            const T* const at = sband + (size_t)(wy0 + y) * spitch + wx0 + x;
+            v[u] = cached_staging ? *at : __builtin_nontemporal_load(at);
           }
 #pragma unroll
           for (int u = 0; u < SU; ++u) {
@@ -285,61 +291,72 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ src
     ja[k] = min(max(j0, 0), ws - 1);
     jb[k] = min(max(j0 + 1, 0), ws - 1);
   }
-  const bool vec_ok = (cb + 3 < wd) && ((wd & 3) == 0) && ((((uintptr_t)dband) % (4 * sizeof(T))) == 0);
-  // A wave walks BL_TILE_H / 4 CONSECUTIVE rows.  The horizontally interpolated values of the two
-  // source rows a destination row needs are kept in registers: when up-sampling, the next
-  // destination row mostly needs the same pair (or the lower row becomes the upper one), so the
-  // LDS reads, the float64 conversions and two thirds of the float64 arithmetic are shared.
+  // one 16-byte store per row and lane wherever the four columns exist; rows that do not start on 16 bytes (a width that is not
+  // a multiple of 4, a band at an odd offset) take the same store unaligned -- element-aligned is all the hardware asks for
+  // (12285-wide tiles: 323 -> 216 us at 1.25 x, 310 -> 179 at 2 x against four 4-byte stores)
+  const bool vec_ok = cb + 3 < wd;
+  const bool vec_aligned = ((wd & 3) == 0) && ((((uintptr_t)dband) % (4 * sizeof(T))) == 0);
+  // A wave walks BL_TILE_H / 4 CONSECUTIVE destination rows, source row by source row: the horizontally interpolated values
+  // of the source rows y (`upper`) and y + 1 (`lower`) stay in registers while every destination row between them is written
+  // -- when up-sampling several, and the lower row then becomes the upper one: every source row is read from LDS, converted
+  // and interpolated across once per lane.  (Until round 5 the walk went destination row by destination row and decided per
+  // row which of its two source rows it already had: ~90 instructions per row plus ~50 per new source row, issue-bound at
+  // 3 x; now ~40 + ~60.)  The rows' source rows are wave-uniform: read from the table through readfirstlane, the loops'
+  // branches are scalar.
   constexpr int RPW = BL_TILE_H / 4;
-  double hrow[2][4];   // [0] = source row `cur[0]`, [1] = source row `cur[1]`, per owned column
-  int cur[2] = {-1, -1};
-  auto horizontal = [&](int y, double (&h)[4]) {
+  const int r_begin = r0 + wave * RPW, r_end = min(r0 + (wave + 1) * RPW, r1);
+  if (r_begin >= r_end) return;
+  auto horizontal = [&](int y_unclamped, double (&h)[4]) {
+    const int y = min(max(y_unclamped, 0), hs - 1);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const T A = tap(y, ja[k]), B = tap(y, jb[k]);
       h[k] = gu[k] * (double)A + fu[k] * (double)B;
     }
   };
+  auto upper_row_of = [&](int r) { return __builtin_amdgcn_readfirstlane(row_i0[r - r0]); };
+  const bool fast_store = __all(vec_ok) && vec_aligned;  // (wave-uniform)
+  double upper[4], lower[4];
+  int r = r_begin, y = upper_row_of(r_begin);
+  horizontal(y, upper);
+  T* out = dband + (size_t)r * wd + cb;
 #pragma unroll 1
-  for (int r = r0 + wave * RPW; r < min(r0 + (wave + 1) * RPW, r1); ++r) {
-    const double fv = row_fv[r - r0], gv = 1.0 - fv;  // wave-uniform
-    const int ia = row_ia[r - r0], ib = row_ib[r - r0];
-    // wave-uniform reuse decisions
-    if (ia != cur[0]) {
-      if (ia == cur[1]) {
+  while (true) {
+    horizontal(y + 1, lower);
+#pragma unroll 1
+    while (r < r_end && upper_row_of(r) == y) {
+      const double fv = row_fv[r - r0], gv = 1.0 - fv;  // (wave-uniform values)
+      T res[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) hrow[0][k] = hrow[1][k];
-      } else {
-        horizontal(ia, hrow[0]);
+      for (int k = 0; k < 4; ++k) {
+        const T v = (T)(gv * upper[k] + fv * lower[k]);
+        res[k] = (v != v) ? void_out : v;
       }
-      cur[0] = ia;
-    }
-    if (ib != cur[1]) {
-      if (ib == cur[0]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) hrow[1][k] = hrow[0][k];
-      } else {
-        horizontal(ib, hrow[1]);
-      }
-      cur[1] = ib;
-    }
-    T res[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const T out = (T)(gv * hrow[0][k] + fv * hrow[1][k]);
-      res[k] = (out != out) ? void_out : out;
-    }
-    T* out = dband + (size_t)r * wd + cb;
-    if (vec_ok) {
       typedef T VT __attribute__((ext_vector_type(4)));
       VT pack;
       pack[0] = res[0]; pack[1] = res[1]; pack[2] = res[2]; pack[3] = res[3];
-      __builtin_nontemporal_store(pack, (VT*)out);
-    } else {
+      if (fast_store) {
+        __builtin_nontemporal_store(pack, (VT*)out);
+      } else if (vec_ok) {
+        typedef T VU __attribute__((ext_vector_type(4), aligned(sizeof(T))));
+        __builtin_nontemporal_store(pack, (VU*)out);
+      } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (cb + k < wd) out[k] = res[k];
+        for (int k = 0; k < 4; ++k)
+          if (cb + k < wd) out[k] = res[k];
+      }
+      out += wd;
+      ++r;
     }
+    if (r >= r_end) break;
+    const int next = upper_row_of(r);
+    if (next == y + 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) upper[k] = lower[k];
+    } else {  // (down-sampling: source rows are skipped)
+      horizontal(next, upper);
+    }
+    y = next;
   }
 }
 
@@ -644,13 +661,23 @@ int gm_resample_bilinear_window(const void* src, int dtype, int bands, int hs, i
   const int per = 16 / itemsize;
   const bool vec_src = (ws % per) == 0 && (src_pitch % per) == 0 && ((uintptr_t)src % 16) == 0;
   win_w = vec_src ? ((win_w + per - 1 + per - 1) / per) * per : (win_w | 1);
-  const bool staged = win_h * win_w * itemsize <= BL_LDS_BYTES - 2048;
+  // From a zoom of 2.5 on the taps are read through the caches instead (a destination row of a lane touches two source cells
+  // or three, a wave ~100 consecutive ones, and every source row feeds several destination rows out of registers): no staging
+  // phase, no barrier, every wave on its own -- 12288^2 results (tools/bilinear_zoom_sweep.py): 3 x 142 -> 117 us, 4 x 153 -> 101,
+  // 6 x 136 -> 96; at 2.5 x the two routes meet (150 / 155), below that the staged window wins by as
+  // much (1.5 x: 161 against 304).  GM_BL_STAGED=0 / 1 forces a route (tuning runs).
+  static const int staged_cfg = getenv("GM_BL_STAGED") ? atoi(getenv("GM_BL_STAGED")) : -1;
+  const bool direct = staged_cfg < 0 ? (2.5 * sy <= 1.0 && 2.5 * sx <= 1.0) : staged_cfg == 0;
+  const bool staged = !direct && win_h * win_w * itemsize <= BL_LDS_BYTES - 2048;
   const size_t lds = staged ? (size_t)(win_h * win_w * itemsize) : 0;
+  // (GM_BL_SWZ=0: tiles dealt to the XCDs in launch order -- tuning runs; with the runs per XCD 1.5 x 157 -> 151 us, 3 x 135 -> 125,
+  //  12285-wide rows 192 -> 170 -- the staged route only: the direct one loses by it, 4 x 96 -> 122; GM_BL_CACHED=1: staging loads through the caches -- no effect measured)
+  static const int stage_flags = (getenv("GM_BL_CACHED") && atoi(getenv("GM_BL_CACHED")) ? 2 : 0) | (getenv("GM_BL_SWZ") && !atoi(getenv("GM_BL_SWZ")) ? 0 : 4);
   dim3 grid((unsigned)((wd + BL_TILE_W - 1) / BL_TILE_W), (unsigned)((hd + BL_TILE_H - 1) / BL_TILE_H), (unsigned)bands);
   if (grid.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "destination taller than %d rows", 65535 * BL_TILE_H);
 #define GM_BILINEAR_SU(T, STAGED, NDV, H_, SU_)                                                                           \
   hipLaunchKernelGGL((bilinear_kernel<T, STAGED, H_, SU_>), grid, dim3(256), lds, s, (const T*)src, (T*)dst, hs, ws,     \
-                     src_pitch, hd, wd, sy, sx, has_ndv, (T)(NDV), (int)win_w, vec_src ? 1 : 0)
+                     src_pitch, hd, wd, sy, sx, has_ndv, (T)(NDV), (int)win_w, (vec_src ? 1 : 0) | (STAGED ? stage_flags : 0))
 #define GM_BILINEAR_H(T, STAGED, NDV, H_)                                   \
   do {                                                                      \
     const int rows_per_wave = (int)((win_h + 3) / 4);                       \

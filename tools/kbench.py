@@ -91,7 +91,12 @@ def main():
                [lambda t=t: resample.bilinear(t, side * 3 // 2, side * 3 // 2, np.float32(F32MAX)) for t in half])
         timeit("bilinear f32 1.25x upsample (6.56 B/out px)", (4 + 4 / 1.5625) * 1.5625 * n,
                [lambda t=t: resample.bilinear(t, side * 5 // 4, side * 5 // 4, np.float32(F32MAX)) for t in src])
-        del src
+        timeit("bilinear f32 1.5x upsample onto %d columns (rows not 16-byte aligned)" % (side * 3 // 2 - 3), (4 + 4 / 2.25) * 2.25 * n,
+               [lambda t=t: resample.bilinear(t, side * 3 // 2 - 3, side * 3 // 2 - 3, np.float32(F32MAX)) for t in src])
+        quarter = [generate_window((side * 3 // 8, side * 3 // 8), "f4", 74 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side * 3 // 8, side * 3 // 8) for i in range(2)]
+        timeit("bilinear f32 4x upsample (4.25 B/out px)", (4 + 4 / 16.0) * 2.25 * n,
+               [lambda t=t: resample.bilinear(t, side * 3 // 2, side * 3 // 2, np.float32(F32MAX)) for t in quarter])
+        del src, half, quarter
     if "stencil" in which:
         src = [generate_window((side, side), "f4", 90 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side, side) for i in range(T)]
         m = (side - 2) * (side - 2)
