@@ -67,7 +67,10 @@ __global__ __launch_bounds__(256) void nearest_gather_kernel(const T* __restrict
   for (int k = 0; k < 4; ++k) ci[k] = (c0 + k < wd) ? nearest_index(c0 + k, ws, mode, col_map, eps) : -1;
   const bool run = (ci[0] >= 0) & (ci[1] == ci[0] + 1) & (ci[2] == ci[0] + 2) & (ci[3] == ci[0] + 3);
   const int r_begin = blockIdx.y * ROWS;
-  const bool vec_ok = (c0 + 3 < wd) && ((wd & 3) == 0) && ((((uintptr_t)dband) % (4 * sizeof(T))) == 0);
+  // (destination rows that do not start on 16 bytes -- a width that is not a multiple of 4 -- keep their 16-byte stores,
+  //  element-aligned: see bilinear_kernel)
+  const bool vec_ok = c0 + 3 < wd;
+  const bool vec_aligned = ((wd & 3) == 0) && ((((uintptr_t)dband) % (4 * sizeof(T))) == 0);
   // all ROWS source rows of the strip are requested before the first store (ROWS independent gathers in flight per lane
   // instead of one load-store round trip per row).  Every load is UNCONDITIONAL -- its address clamped into the raster, what
   // it must not deliver selected away afterwards -- and the one choice left, 16-byte loads or four gathers, is made for the
@@ -145,7 +148,8 @@ __global__ __launch_bounds__(256) void nearest_gather_kernel(const T* __restrict
     if (vec_ok) {
       VT pack;
       pack[0] = v[i][0]; pack[1] = v[i][1]; pack[2] = v[i][2]; pack[3] = v[i][3];
-      __builtin_nontemporal_store(pack, (VT*)out);
+      if (vec_aligned) __builtin_nontemporal_store(pack, (VT*)out);
+      else __builtin_nontemporal_store(pack, (VTU*)out);
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k)

@@ -192,6 +192,9 @@ def main():
                [lambda t=t: resample.nearest_warp(t, gt, (0.0, 0.0, float(side), float(side)), side, side, F32MAX) for t in src])
         timeit("nearest warp f32 2x upsample (5 B/out px)", 5.0 * 4 * n,
                [lambda t=t: resample.nearest_warp(t, gt, (0.0, 0.0, float(side), float(side)), 2 * side, 2 * side, F32MAX) for t in src[:2]])
+        odd = side * 3 // 2 - 3
+        timeit("nearest warp f32 1.5x upsample onto %d columns (rows not 16-byte aligned, 5.78 B/out px)" % odd, (4 + 4 / 2.25) * 2.25 * n,
+               [lambda t=t: resample.nearest_warp(t, gt, (0.0, 0.0, float(side), float(side)), odd, odd, F32MAX) for t in src[:2]])
         half = side // 2
         timeit("nearest warp f32 window, quarter (8 B/out px)", 8.0 * n / 4,
                [lambda t=t: resample.nearest_warp(t, gt, (100.0, 100.0, 100.0 + half, 100.0 + half), half, half, F32MAX) for t in src])
