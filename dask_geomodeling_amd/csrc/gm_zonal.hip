@@ -1878,8 +1878,22 @@ __device__ __forceinline__ void match_label(unsigned label, bool valid, int bits
   *count = (unsigned)__popcll(mask);
 }
 
-// histogram of the WAVE_CELLS cells from `begin` on into `hist` (LDS): a step whose 64 cells share one label is one
-// addition, any other step 64 LDS atomics (the order of the additions is immaterial here)
+// One step of 64 keys (~0u: past the end) into `hist` (LDS).  A step holds few distinct keys as a rule -- one label, or one label
+// and the idle key of its no-data cells: every distinct key is ONE addition of its lanes' count (a ballot per key); a step of
+// more than ZP_DISTINCT keys finishes with an LDS atomic per remaining lane (the order of the additions is immaterial here).
+constexpr int ZP_DISTINCT = 4;
+__device__ __forceinline__ void histogram_step(unsigned key, unsigned* hist, int lane) {
+  unsigned long long open = __ballot(key != ~0u);
+#pragma unroll 1
+  for (int round = 0; open && round < ZP_DISTINCT; ++round) {
+    const unsigned lead = (unsigned)__builtin_amdgcn_readlane((int)key, __ffsll((long long)open) - 1);
+    const unsigned long long same = __ballot(key == lead);
+    if (lane == 0) atomicAdd(&hist[lead], (unsigned)__popcll(same));
+    open &= ~same;
+  }
+  if (open && ((open >> lane) & 1ull)) atomicAdd(&hist[key], 1u);
+}
+// histogram of the WAVE_CELLS cells from `begin` on into `hist` (LDS)
 template <int WAVE_CELLS>
 __device__ __forceinline__ void partition_histogram(const unsigned* __restrict__ keys, unsigned begin, unsigned cells, unsigned* hist,
                                                     int lane) {
@@ -1893,14 +1907,7 @@ __device__ __forceinline__ void partition_histogram(const unsigned* __restrict__
       if (i >= cells) label[k] = ~0u;
     }
 #pragma unroll
-    for (int k = 0; k < GROUP; ++k) {
-      const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)label[k]);
-      if (__all(label[k] == f)) {  // one label (or nothing: past the end) in all 64 cells
-        if (lane == 0 && f != ~0u) atomicAdd(&hist[f], 64u);
-      } else if (label[k] != ~0u) {
-        atomicAdd(&hist[label[k]], 1u);
-      }
-    }
+    for (int k = 0; k < GROUP; ++k) histogram_step(label[k], hist, lane);
   }
 }
 
@@ -1945,12 +1952,7 @@ __global__ __launch_bounds__(64 * NW) void zonal_keys_count_kernel(const T* __re
         keys[i] = key;
         payload[i] = Ordered<T>::encode(v[k]);
       }
-      const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)key);
-      if (__all(key == f)) {
-        if (lane == 0 && f != ~0u) atomicAdd(&hist[f], 64u);
-      } else if (key != ~0u) {
-        atomicAdd(&hist[key], 1u);
-      }
+      histogram_step(key, hist, lane);
     }
   }
   __syncthreads();
@@ -2053,16 +2055,24 @@ __global__ __launch_bounds__(64 * NW) void zonal_part_scatter_kernel(const unsig
     }
 #pragma unroll
     for (int k = 0; k < GROUP; ++k) {
-      const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)label[k]);
-      if (__all(label[k] == f)) {
-        if (f == ~0u) continue;
-        const unsigned base = mine[f];
-        if (lane == 0) mine[f] = base + 64u;
-        if (out_keys) out_keys[base + lane] = f;  // (the select path only wants the payloads)
-        out_payload[base + lane] = cell[k];
-        continue;
+      // the step's distinct keys one after the other (one label, or one label and the idle key, as a rule): the lanes of a key
+      // rank themselves with one ballot; a step of more than ZP_DISTINCT keys finishes with match_label (a ballot per label bit)
+      unsigned long long open = __ballot(label[k] != ~0u);
+#pragma unroll 1
+      for (int round = 0; open && round < ZP_DISTINCT; ++round) {
+        const unsigned lead = (unsigned)__builtin_amdgcn_readlane((int)label[k], __ffsll((long long)open) - 1);
+        const unsigned long long same = __ballot(label[k] == lead);
+        const unsigned base = mine[lead];  // (one address for the wave)
+        if (lane == 0) mine[lead] = base + (unsigned)__popcll(same);
+        if (label[k] == lead) {
+          const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
+          if (out_keys) out_keys[base + rank] = lead;  // (the select path only wants the payloads)
+          out_payload[base + rank] = cell[k];
+        }
+        open &= ~same;
       }
-      const bool valid = label[k] != ~0u;
+      if (open == 0) continue;  // (wave-uniform)
+      const bool valid = ((open >> lane) & 1ull) != 0;
       unsigned rank, count;
       match_label(label[k], valid, bits, &rank, &count);
       if (valid) {
