@@ -762,6 +762,34 @@ __device__ __forceinline__ UnitsFn shuffle_up_units(const UnitsFn& f, int delta)
   return r;
 }
 
+// The inclusive composition over the lanes in lane order, through the data-parallel primitives (shifts inside the rows of 16
+// lanes, then the row totals passed on: see wave_scan_f64); a lane without a source composes with the identity.  Until round 5
+// the scan went through __shfl_up: five LDS-crossbar round trips per step and function, six steps -- most of what the composing
+// wave of a long label spent per group of blocks it had to walk.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ UnitsFn dpp_units(const UnitsFn& f) {
+  UnitsFn r;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const unsigned lo = (unsigned)dpp_move<CTRL, ROW_MASK>(0, (int)(unsigned)f.S[p]);
+    const unsigned hi = (unsigned)dpp_move<CTRL, ROW_MASK>(0, (int)(unsigned)((unsigned long long)f.S[p] >> 32));
+    r.S[p] = (long long)(((unsigned long long)hi << 32) | lo);
+  }
+  const int packed = dpp_move<CTRL, ROW_MASK>(2, f.q[0] | (f.q[1] << 1));  // (identity: parity p stays p)
+  r.q[0] = packed & 1;
+  r.q[1] = (packed >> 1) & 1;
+  return r;
+}
+__device__ __forceinline__ UnitsFn scan_units(UnitsFn scan) {
+  scan = compose_units(dpp_units<0x111>(scan), scan);       // row_shr:1
+  scan = compose_units(dpp_units<0x112>(scan), scan);       // row_shr:2
+  scan = compose_units(dpp_units<0x114>(scan), scan);       // row_shr:4
+  scan = compose_units(dpp_units<0x118>(scan), scan);       // row_shr:8
+  scan = compose_units(dpp_units<0x142, 0xA>(scan), scan);  // row_bcast15 into rows 1 and 3
+  scan = compose_units(dpp_units<0x143, 0xC>(scan), scan);  // row_bcast31 into rows 2 and 3
+  return scan;
+}
+
 // The same once more over groups of 256 blocks (aligned to the block index): what the group adds for either parity of the sum
 // entering it and the extreme prefixes anywhere inside it -- usable when its 256 blocks are whole blocks of ONE long label,
 // analysed for one binade and sign, none of them expected to be added literally.  The composing wave then takes such a
@@ -829,12 +857,7 @@ __global__ __launch_bounds__(256) void zonal_group_info_kernel(const int* __rest
     llo[p] = low;
     lhi[p] = high;
   }
-  UnitsFn scan = mine;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const UnitsFn before = shuffle_up_units(scan, off);
-    if (lane >= off) scan = compose_units(before, scan);
-  }
+  const UnitsFn scan = scan_units(mine);
   UnitsFn excl = shuffle_up_units(scan, 1);
   if (lane == 0) {
     excl.S[0] = excl.S[1] = 0;
@@ -1036,12 +1059,22 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
   // it leaves.  (One label over the default raster limit, 49 152 blocks, 16 of them literal: 743 us at one block per lane
   // and nothing requested ahead.)
   constexpr int PER = 4;
-  auto fetch = [&](unsigned g, BlockInfo* B) {
+  // (with a block's description come the three numbers of its exactness certificate: asked for only when a block is turned
+  //  away they were two dependent memory round trips per such block -- ~2.5 us, 164 times for one label of noise over the
+  //  default raster limit: most of this kernel's 500 us)
+  struct Certificate {
+    double sum, magnitude;
+    int finest;
+  };
+  auto fetch = [&](unsigned g, BlockInfo* B, Certificate* C) {
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const unsigned jj = min(g + (unsigned)(PER * lane + k), j1 - 1);
       B[k] = info[jj];
       if (blk_label[jj] != l) B[k].E = INT_MIN;
+      C[k].finest = blk_gexp ? blk_gexp[jj] : INT_MIN;
+      C[k].sum = blk_sum[jj];
+      C[k].magnitude = blk_abs[jj];
     }
   };
   static_assert(64 * PER == ZG, "groups");
@@ -1086,18 +1119,23 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
     return __builtin_amdgcn_readlane(certified.grain, xat) != INT_MIN;
   };
   BlockInfo ahead[PER];
+  Certificate ahead_cert[PER];
   bool have_ahead = false;
   if (j0 < j1 && !usable(j0)) {
-    fetch(j0, ahead);
+    fetch(j0, ahead, ahead_cert);
     have_ahead = true;
   }
   unsigned here = 0;
   for (unsigned g = j0; g < j1; g += here) {
     here = min((unsigned)ZG - g % ZG, j1 - g);
     BlockInfo B[PER];
+    Certificate C[PER];
     const bool have = have_ahead;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) B[k] = ahead[k];
+    for (int k = 0; k < PER; ++k) {
+      B[k] = ahead[k];
+      C[k] = ahead_cert[k];
+    }
     const bool whole = usable(g);
     int at = 0;
     if (whole) at = hold(g / ZG);
@@ -1105,7 +1143,7 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
     const unsigned g1 = g + here;
     have_ahead = false;
     if (g1 < j1 && !usable(g1)) {
-      fetch(g1, ahead);
+      fetch(g1, ahead, ahead_cert);
       have_ahead = true;
       if (whole) at = hold(g / ZG);  // (usable(g1) may have moved the window of held descriptions)
     }
@@ -1136,7 +1174,7 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
         }
       }
     }
-    if (!have) fetch(g, B);  // (a group that was expected to go in one step and did not)
+    if (!have) fetch(g, B, C);  // (a group that was expected to go in one step and did not)
     // the first block from `from_idx` on that the info kernel expects to be added literally (64 * PER: none in this group)
     auto next_risky = [&](unsigned from_idx) -> unsigned {
       unsigned first_risky = 64u * PER;
@@ -1170,11 +1208,7 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
           scan = compose_units(scan, f);
         }
       }
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const UnitsFn before = shuffle_up_units(scan, off);
-        if (lane >= off) scan = compose_units(before, scan);
-      }
+      scan = scan_units(scan);
       UnitsFn excl = shuffle_up_units(scan, 1);
       if (lane == 0) {
         excl.S[0] = excl.S[1] = 0;
@@ -1217,17 +1251,24 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
         to_double();
         // the exactness certificate of zonal_block_sum_kernel: no rounding anywhere in this block for the sum entering it?
         bool exact = false;
+        // the block's certificate from the lane that holds it (k = PER * lane + which)
+        const int owner = (int)(k / PER), which = (int)(k % PER);
+        Certificate mine_c = C[0];
+#pragma unroll
+        for (int c = 1; c < PER; ++c)
+          if (which == c) mine_c = C[c];  // (wave-uniform)
+        const int finest = __builtin_amdgcn_readlane(mine_c.finest, owner);
+        const double block_sum = pass_f64(mine_c.sum, owner), block_abs = pass_f64(mine_c.magnitude, owner);
         if (blk_gexp) {
-          const int finest = blk_gexp[g + k];
           if (finest != INT_MIN && fabs(acc) <= 1.7976931348623157e308) {
             const int held_bit = acc == 0.0 ? INT_MAX : lowbit_exp(acc);
             const int grain = min(finest, held_bit);
             // (0.99: the two magnitudes are float64 sums themselves; the bound has to hold for the exact ones)
-            exact = grain == INT_MAX || (grain > -1000 && grain < 900 && fabs(acc) + blk_abs[g + k] < ldexp(0.99, 53 + grain));
+            exact = grain == INT_MAX || (grain > -1000 && grain < 900 && fabs(acc) + block_abs < ldexp(0.99, 53 + grain));
           }
         }
         if (exact) {
-          acc += blk_sum[g + k];  // exact: the block in one addition
+          acc += block_sum;  // exact: the block in one addition
           ++n_exact;
           if (wanted < k + 1 || k == wanted) {
             wanted = next_risky(k + 1);
