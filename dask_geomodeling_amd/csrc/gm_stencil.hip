@@ -1227,6 +1227,11 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const T* __restrict
       const unsigned char* srcb = shade + row * HP_W + 16 * part;
       if (ocol + 16 <= ow && (((uintptr_t)dst) & 15) == 0) {
         __builtin_nontemporal_store(*(const u32x4*)srcb, (u32x4*)dst);
+      } else if (ocol + 16 <= ow) {
+        // (rows of w - 2 bytes start on 16 bytes one time in eight: the same store, unaligned -- the hardware splits it --
+        //  instead of sixteen 1-byte stores)
+        typedef unsigned u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+        __builtin_nontemporal_store(*(const u32x4*)srcb, (u32x4u*)dst);
       } else {
         for (int k = 0; k < 16 && ocol + k < ow; ++k) dst[k] = srcb[k];
       }
