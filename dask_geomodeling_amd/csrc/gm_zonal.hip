@@ -2755,6 +2755,33 @@ __global__ __launch_bounds__(256) void zonal_chunk_kernel(const T* __restrict__ 
     bool remaining[ZC_LANE];
 #pragma unroll
     for (int k = 0; k < ZC_LANE; ++k) remaining[k] = inside[k] && cell_active<T>(v[k], label[k], n_labels, has_ndv, ndv, thresholds);
+    // what a cell contributes whatever its label: the float64 bincount adds, its top exponent (INT_MAX: not finite; INT_MIN:
+    // zero) and the exponent of its lowest set bit -- once per cell, not once per label of the step
+    double cell_x[ZC_LANE];
+    int cell_hi[ZC_LANE], cell_lo[ZC_LANE];
+#pragma unroll
+    for (int k = 0; k < ZC_LANE; ++k) {
+      cell_x[k] = (double)v[k];
+      cell_hi[k] = INT_MIN;
+      cell_lo[k] = INT_MAX;
+      if constexpr (std::is_same<T, float>::value) {
+        // float32: the exponent field; the lowest set bit e - 150 + ctz(mantissa with its hidden bit) -- one less than the
+        // truth for subnormals, which only makes the test stricter (their top exponent -126: an upper bound)
+        const unsigned magnitude_bits = __float_as_uint(v[k]) & 0x7fffffffu;
+        if (magnitude_bits >= 0x7f800000u) {
+          cell_hi[k] = INT_MAX;
+        } else if (magnitude_bits != 0u) {
+          cell_hi[k] = max((int)(magnitude_bits >> 23), 1) - 127;
+          cell_lo[k] = (int)(magnitude_bits >> 23) + (__ffs((int)(magnitude_bits | 0x800000u)) - 1) - 150;
+        }
+      } else {
+        if (!(fabs(cell_x[k]) <= 1.7976931348623157e308)) {
+          cell_hi[k] = INT_MAX;
+        } else if (cell_x[k] != 0.0) {
+          cell_span<T>(v[k], &cell_hi[k], &cell_lo[k]);
+        }
+      }
+    }
     StepRec note{0.0, 0.0f, 0.0f, -1, SHRT_MIN, SHRT_MAX};
     int found = 0;
     while (true) {
@@ -2769,47 +2796,16 @@ __global__ __launch_bounds__(256) void zonal_chunk_kernel(const T* __restrict__ 
       unsigned n = 0;
       int hi = INT_MIN, lo = INT_MAX;  // (hi == INT_MAX: a NaN or an infinity among the cells)
       double sum = 0.0, magnitude = 0.0;
-      if constexpr (std::is_same<T, float>::value) {
-        // float32 cells: the top exponent is that of the largest magnitude (one integer maximum per cell), the lowest set bit
-        // e - 150 + ctz(mantissa with its hidden bit) -- one less than the truth for subnormals, which only makes the test stricter
-        unsigned widest = 0u;
-        int finest = INT_MAX;
 #pragma unroll
-        for (int k = 0; k < ZC_LANE; ++k) {
-          const bool taken = remaining[k] && label[k] == lead;
-          n += (unsigned)__popcll(__ballot(taken));  // (wave-uniform: the cells of this label in the step)
-          if (taken) {
-            remaining[k] = false;
-            const unsigned magnitude_bits = __float_as_uint(v[k]) & 0x7fffffffu;
-            widest = max(widest, magnitude_bits);
-            if (magnitude_bits != 0u) finest = min(finest, (int)(magnitude_bits >> 23) + (__ffs((int)(magnitude_bits | 0x800000u)) - 1));
-            const double x = (double)v[k];  // what bincount adds
-            sum += x;
-            magnitude += fabs(x);
-          }
-        }
-        if (widest >= 0x7f800000u) hi = INT_MAX;
-        else if (widest != 0u) hi = max((int)(widest >> 23), 1) - 127;
-        if (finest != INT_MAX) lo = finest - 150;
-      } else {
-#pragma unroll
-        for (int k = 0; k < ZC_LANE; ++k) {
-          const bool taken = remaining[k] && label[k] == lead;
-          n += (unsigned)__popcll(__ballot(taken));
-          if (taken) {
-            remaining[k] = false;
-            const double x = (double)v[k];
-            if (!(fabs(x) <= 1.7976931348623157e308)) {
-              hi = INT_MAX;
-            } else if (x != 0.0) {
-              int top, low;
-              cell_span<T>(v[k], &top, &low);
-              hi = max(hi, top);
-              lo = min(lo, low);
-            }
-            sum += x;
-            magnitude += fabs(x);
-          }
+      for (int k = 0; k < ZC_LANE; ++k) {
+        const bool taken = remaining[k] && label[k] == lead;
+        n += (unsigned)__popcll(__ballot(taken));  // (wave-uniform: the cells of this label in the step)
+        if (taken) {
+          remaining[k] = false;
+          hi = max(hi, cell_hi[k]);
+          lo = min(lo, cell_lo[k]);
+          sum += cell_x[k];  // what bincount adds
+          magnitude += fabs(cell_x[k]);
         }
       }
       hi = wave_max(hi);
@@ -3030,6 +3026,25 @@ __global__ __launch_bounds__(256) void zonal_chunk_combine_kernel(const T* __res
       bool have_ahead = false;
       StepCells ahead_one{}, ahead_two{};
       for (unsigned j = 0; j < in_batch; ++j) {
+        if ((j & 15u) == 0) {
+          // the batch did not go as one: its chunks sixteen at a time, the same test (a label that is being replayed fails
+          // in a few places, not everywhere: most sixteens still go in one addition)
+          const bool member = (unsigned)lane >= j && (unsigned)lane < j + 16u && (unsigned)lane < in_batch;
+          const int low = wave_min(member && rec.lo != SHRT_MAX ? (int)rec.lo : INT_MAX);
+          const int top = wave_max(member && rec.hi != SHRT_MIN ? (int)rec.hi : INT_MIN);
+          const double mine_total = member ? rec.total : 0.0;
+          const double before = wave_scan_f64(mine_total) - mine_total;
+          const double inf = __builtin_huge_val();
+          const double below = wave_min_f64(member ? before + (double)rec.low : inf);
+          const double above = wave_max_f64(member ? before + (double)rec.high : -inf);
+          if (__ballot(member && rec.bad != 0) == 0 && additions_exact(acc, top, low, 0x7fffffffu, below, above)) {  // (wave-uniform)
+            acc += wave_sum_exact(mine_total);
+            n_total += wave_sum_u32(member ? rec.count : 0u);
+            have_ahead = false;
+            j += 15u;
+            continue;
+          }
+        }
         const double total = readlane_f64(rec.total, (int)j);
         const double below = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.low), (int)j));
         const double above = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(rec.high), (int)j));
