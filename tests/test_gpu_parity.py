@@ -345,6 +345,44 @@ def test_bilinear_vs_oracle(gpu, dt, shape):
     assert_values_equal(got, O.bilinear_resample(src, hd, wd, ndv), 1, "bilinear %s %s" % (dt, shape))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["product", "staged", "direct"])
+def test_bilinear_routes_vs_oracle(gpu, route):
+    """The general bilinear kernel's two routes (round 5: the source window staged in LDS, or the taps read through the caches --
+    the product takes the second from a zoom of 2.5 on) and its stores onto rows that do not start on 16 bytes, over several
+    workgroups per tile and with no-data cells sprinkled in: against the oracle within 1 ulp, in a process of its own per route
+    (the route is read from the environment once)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from dask_geomodeling_amd.raster import resample\n"
+        "from oracle import ref_numpy as O\n"
+        "from helpers import assert_values_equal\n"
+        "rng = np.random.default_rng(11)\n"
+        "n = 0\n"
+        "for dt in ('f4', 'f8'):\n"
+        "    for hs, ws, hd, wd in ((100, 333, 300, 999), (64, 100, 256, 400), (333, 517, 999, 1551), (200, 200, 499, 501),\n"
+        "                           (300, 300, 800, 700), (90, 700, 541, 1753), (257, 129, 300, 1290), (40, 2000, 37, 1999)):\n"
+        "        src = (rng.standard_normal((2, hs, ws)) * 100).astype(dt)\n"
+        "        ndv = np.dtype(dt).type(np.finfo(dt).max)\n"
+        "        src[rng.random(src.shape) < 0.02] = ndv\n"
+        "        src[1, hs // 2, ws // 3] = np.nan\n"
+        "        got = np.asarray(resample.bilinear(src, hd, wd, ndv))\n"
+        "        assert_values_equal(got, O.bilinear_resample(src, hd, wd, ndv), 1, 'bilinear %%s %%s' %% (dt, (hs, ws, hd, wd)))\n"
+        "        n += 1\n"
+        "print('ROUTES ok', n)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if route != "product":
+        env["GM_BL_STAGED"] = "1" if route == "staged" else "0"
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
+    assert "ROUTES ok 16" in res.stdout
+
+
 # ---- whole views through Blocks, fusion pass and MemorySource ------------------------
 from blocks_util import build_view, leaves_for  # noqa: E402
 from dask_geomodeling_amd import config as gmconfig  # noqa: E402
