@@ -1423,7 +1423,10 @@ __global__ __launch_bounds__(256) void gauss_axis_far_kernel(const T* __restrict
 //     register window, the same arithmetic, two 16-byte stores.
 // The operations and their order are those of the one-axis kernels (SciPy's: centre tap, then the pairs
 // from the farthest in); columns outside the tile are the x line's constant extension, not filtered values.
-constexpr int G2_TH = 32, G2_MAX_RADIUS = 16;
+#ifndef GM_G2_TH
+#define GM_G2_TH 32  // (tuning builds; 48 / 56 rows read less of the source twice and are slower: MEASUREMENTS 11.11)
+#endif
+constexpr int G2_TH = GM_G2_TH, G2_MAX_RADIUS = 16;
 struct Gauss2Args {
   double wy[G2_MAX_RADIUS + 1], wx[G2_MAX_RADIUS + 1];  // weight at distance j along y / x
   double cval;
