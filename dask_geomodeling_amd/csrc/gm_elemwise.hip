@@ -626,16 +626,10 @@ static int run_batch_2d(const gm_program* prog, int n_tiles, const void* const* 
   // A program whose only input is a 1-byte tile (class rasters: Reclassify / Mask / Classify / arithmetic
   // on uint8) is a function of 256 values: tabulate it once with the VM itself, then apply the table
   // with the byte-LUT kernel (gm_tables.hip; 16 pixels per lane, table in LDS).  Bit-exact by
-  // construction.  Small launches and tiles the LUT kernel's 16-byte accesses cannot address keep the VM.
+  // construction.  Small launches keep the VM; tiles that do not sit on 16 bytes take the kernel's row form.
   if (n_in == 1 && n >= LUT8_MIN_ELEMS && gm::dtype_size(code->prog.inputs[0].bits & 0xffu) == 1 &&
       !((code->prog.inputs[0].bits >> 8) & 1u) && n_tiles <= GM_MAX_BATCH * 64) {
-    bool addressable = true;
-    for (int t = 0; t < n_tiles && addressable; ++t) {
-      const uint32_t ip = pitches ? pitches[t] : 0u, op = out_pitches ? out_pitches[t] : 0u;
-      const bool strided = (ip && ip != cols) || (op && op != cols);
-      if (((uintptr_t)inputs[t] % 16) || ((uintptr_t)outs[t] % 16)) addressable = false;
-      if (strided && ((cols % 16) || (ip % 16) || (op % 16))) addressable = false;
-    }
+    const bool addressable = rows < 0xffffffffull && cols < 0xffffffffull;  // (any alignment, any pitch: lut8_rows_kernel)
     if (addressable) {
       const int out_size = gm::dtype_size(code->prog.out_dtype);
       std::call_once(code->lut_once, [&]() {

@@ -563,6 +563,38 @@ __global__ __launch_bounds__(256) void lut8_kernel(Lut8Launch L) {
   }
 }
 
+// The same for tiles the flat kernel cannot address (round 5): windows that start on any byte, rows of any length and pitch --
+// a tile request whose bounding box does not sit on a 16-byte boundary of the resident raster ran on the interpreter
+// instead (Reclassify of a uint8 window: 59 us per 4096^2 request against 36).  A lane still handles P pixels of ONE row;
+// its loads and its 16-byte store are element-aligned only, the last pixels of a row go one by one.
+template <typename E>
+__global__ __launch_bounds__(256) void lut8_rows_kernel(Lut8Launch L, unsigned rows, unsigned blocks_per_row) {
+  constexpr int P = 16 / (int)sizeof(E);
+  __shared__ E table[256];
+  table[threadIdx.x] = ((const E*)L.table)[threadIdx.x];
+  __syncthreads();
+  const unsigned tile = blockIdx.y;
+  const unsigned row = blockIdx.x / blocks_per_row, col = ((blockIdx.x - row * blocks_per_row) * 256u + threadIdx.x) * (unsigned)P;
+  if (row >= rows || col >= L.cols) return;
+  const unsigned ip = L.in_pitch[tile] ? L.in_pitch[tile] : L.cols, op = L.out_pitch[tile] ? L.out_pitch[tile] : L.cols;
+  const unsigned char* in = L.in[tile] + (size_t)row * ip + col;
+  E* out = (E*)L.out[tile] + (size_t)row * op + col;
+  if (col + P <= L.cols) {
+    unsigned char px[P];
+    __builtin_memcpy(px, in, P);  // (no alignment promised: the hardware takes unaligned accesses)
+    E r[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) r[k] = table[px[k]];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4u __attribute__((ext_vector_type(4), aligned(1)));  // (element-aligned rows)
+    u32x4 words;
+    __builtin_memcpy(&words, r, 16);
+    __builtin_nontemporal_store(words, (u32x4u*)out);
+  } else {
+    for (unsigned k = 0; col + k < L.cols; ++k) out[k] = table[in[k]];
+  }
+}
+
 }  // namespace
 
 int gm::lut8_launch(int n_tiles, const void* const* in, const uint32_t* in_pitch, void* const* out,
@@ -573,6 +605,35 @@ int gm::lut8_launch(int n_tiles, const void* const* in, const uint32_t* in_pitch
   L.n = (unsigned long long)rows * cols;
   L.cols = (unsigned)cols;
   L.table = table;
+  // what the flat kernel can address: 16-byte aligned tiles; strided ones with rows and pitches in whole 16-element groups
+  bool flat = true;
+  for (int t = 0; t < n_tiles; ++t) {
+    const uint32_t ip = in_pitch ? in_pitch[t] : 0u, op = out_pitch ? out_pitch[t] : 0u;
+    if (((uintptr_t)in[t] % 16) || ((uintptr_t)out[t] % 16)) flat = false;
+    if ((ip || op) && ((cols % 16) || (ip % 16) || (op % 16))) flat = false;
+  }
+  if (!flat) {
+    for (int t = 0; t < n_tiles; ++t) {
+      L.in[t] = (const unsigned char*)in[t];
+      L.out[t] = (unsigned char*)out[t];
+      L.in_pitch[t] = in_pitch ? in_pitch[t] : 0u;
+      L.out_pitch[t] = out_pitch ? out_pitch[t] : 0u;
+    }
+    const unsigned per_lane = 16u / (unsigned)out_size;
+    const unsigned long long blocks_per_row = (cols + 256ull * per_lane - 1) / (256ull * per_lane);
+    if (blocks_per_row * rows > 0x7fffffffull || rows > 0xffffffffull)
+      return gm::fail(GM_ERR_UNSUPPORTED, "lut8: tile too large for one launch");
+    dim3 grid((unsigned)(blocks_per_row * rows), (unsigned)n_tiles);
+    switch (out_size) {
+      case 1: hipLaunchKernelGGL(lut8_rows_kernel<unsigned char>, grid, dim3(256), 0, stream, L, (unsigned)rows, (unsigned)blocks_per_row); break;
+      case 2: hipLaunchKernelGGL(lut8_rows_kernel<unsigned short>, grid, dim3(256), 0, stream, L, (unsigned)rows, (unsigned)blocks_per_row); break;
+      case 4: hipLaunchKernelGGL(lut8_rows_kernel<unsigned int>, grid, dim3(256), 0, stream, L, (unsigned)rows, (unsigned)blocks_per_row); break;
+      case 8: hipLaunchKernelGGL(lut8_rows_kernel<unsigned long long>, grid, dim3(256), 0, stream, L, (unsigned)rows, (unsigned)blocks_per_row); break;
+      default: return gm::fail(GM_ERR_INVALID, "lut8: element size %d", out_size);
+    }
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+  }
   for (int t = 0; t < n_tiles; ++t) {
     L.in[t] = (const unsigned char*)in[t];
     L.out[t] = (unsigned char*)out[t];

@@ -1528,6 +1528,19 @@ def test_single_byte_input_programs_by_table(gpu, dt, ndv, tiler_route):
         assert_result_equal(whole, want, 0, "whole")
         for tile in ([64, 64], [40, 96], [64, 48]):
             assert_result_equal(raster.RasterTiler(view, tile).get_data(**whole_req), want, 0, "tiles %s" % tile)
+        # windows that start on ANY byte and have any width (round 5: the table kernel's row form; they ran on the VM before):
+        # every output width
+        views = [("reclassify -> i64", view, want["values"]),
+                 ("mask -> u8", raster.Mask(src, 7), O.mask_process({"values": big, "no_data_value": ndv}, 7)["values"]),
+                 ("x + 100 -> int", src + 100, None)]
+        plus = src + 100
+        views[2] = ("x + 100 -> int", plus, O.math_process("add", {"dtype": plus.dtype.name, "fillvalue": plus.fillvalue},
+                                                            {"values": big, "no_data_value": ndv}, 100)["values"])
+        for col0, row0, w, h in ((1, 3, 97, 70), (65, 33, 127, 50), (3, 0, 253, 192), (17, 5, 200, 111), (255, 191, 1, 1), (0, 7, 256, 3)):
+            bbox = (float(col0), float(192 - row0 - h), float(col0 + w), float(192 - row0))
+            for name, v, full in views:
+                got = v.get_data(mode="vals", bbox=bbox, width=w, height=h, projection="EPSG:28992")
+                assert np.array_equal(np.asarray(got["values"]), full[:, row0:row0 + h, col0:col0 + w]), (name, (col0, row0, w, h))
 
 
 @pytest.mark.gpu
