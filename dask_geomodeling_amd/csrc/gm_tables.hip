@@ -176,16 +176,17 @@ __global__ __launch_bounds__(256) void classify_grid_kernel(const float* __restr
                                                             unsigned long long n_groups, const float* __restrict__ thr_g,
                                                             const unsigned short* __restrict__ base_g, int nbins,
                                                             ClassifyGrid G, int chunks, int has_ndv, float ndv, TO fill,
-                                                            unsigned row_groups, unsigned pitch_groups) {
+                                                            unsigned row_groups, unsigned pitch) {
   extern __shared__ __align__(16) unsigned char smem[];
   float* const thr = (float*)smem;                                  // nbins + GRID_SCAN (NaN padded)
   unsigned short* const base = (unsigned short*)(thr + nbins + GRID_SCAN);
   const unsigned long long span = 256ull * CLS_U;
-  // a window of a wider resident raster (row_groups != 0): groups of 4 cells, row_groups to a row, rows pitch_groups apart
-  auto source_group = [&](unsigned long long g) -> unsigned long long {
-    if (row_groups == 0) return g;
+  // a window of a wider resident raster (row_groups != 0): groups of 4 cells, row_groups to a row, rows `pitch` CELLS apart
+  // (round 5: any pitch, any first column -- the loads of a window are element-aligned)
+  auto source_cell = [&](unsigned long long g) -> unsigned long long {
+    if (row_groups == 0) return g * 4ull;
     const unsigned row = (unsigned)g / row_groups;
-    return (unsigned long long)row * pitch_groups + ((unsigned)g - row * row_groups);
+    return (unsigned long long)row * pitch + 4ull * ((unsigned)g - row * row_groups);
   };
   for (int c = 0; c < chunks; ++c) {
     const unsigned long long g0 = ((unsigned long long)blockIdx.x * chunks + c) * span + threadIdx.x;
@@ -193,7 +194,15 @@ __global__ __launch_bounds__(256) void classify_grid_kernel(const float* __restr
 #pragma unroll
     for (int u = 0; u < CLS_U; ++u) {
       const unsigned long long g = g0 + 256ull * u;
-      VecK<float, 4>::load(in + source_group(g < n_groups ? g : n_groups - 1) * 4, v[u]);
+      const float* const at = in + source_cell(g < n_groups ? g : n_groups - 1);
+      if (row_groups == 0) {  // (kernel-uniform)
+        VecK<float, 4>::load(at, v[u]);
+      } else {
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        const f32x4u x = __builtin_nontemporal_load((const f32x4u*)at);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[u][k] = x[k];
+      }
     }
     if (c == 0) {  // staged behind the first tile loads
       for (int i = threadIdx.x; i < nbins + GRID_SCAN; i += 256) thr[i] = i < nbins ? thr_g[i] : __builtin_nanf("");
@@ -851,7 +860,9 @@ int gm_classify2_window(const void* in, int in_dtype, int has_ndv, uint64_t ndv_
                         int bins_are_int, int right, void* out, int out_dtype, uint64_t fill, int rows, int cols, int pitch) {
   if (rows < 0 || cols < 0 || pitch < cols) return gm::fail(GM_ERR_INVALID, "gm_classify2_window: %d x %d cells, pitch %d", rows, cols, pitch);
   if (pitch == cols) return gm_classify2(in, in_dtype, has_ndv, ndv_bits, bins_host, nbins, bins_are_int, right, out, out_dtype, fill, (size_t)rows * cols);
-  if (in_dtype != GM_F32 || bins_are_int || (cols & 3) || (pitch & 3) || (size_t)rows * cols / 4 >= 0x7fffffffull)
+  // (whole groups of 4 cells per row; the window itself may start on any cell and lie in rows of any pitch -- a caller with
+  //  room to the right of an odd width asks for the next multiple of 4 and crops)
+  if (in_dtype != GM_F32 || bins_are_int || (cols & 3) || (size_t)rows * cols / 4 >= 0x7fffffffull)
     return gm::fail(GM_ERR_UNSUPPORTED, "gm_classify2_window: this tile wants a compact copy");
   t_window_cols = (unsigned)cols;
   t_window_pitch = (unsigned)pitch;
@@ -900,7 +911,7 @@ int gm_classify2(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, c
     void* thr_dev = nullptr;
     int rc32 = cached_upload(packed, &thr_dev);
     if (rc32) return rc32;
-    if (nbins > CLS_LINEAR_MAX && (out_dtype == GM_U8 || out_dtype == GM_U16) && ((uintptr_t)in % 16) == 0 &&
+    if (nbins > CLS_LINEAR_MAX && (out_dtype == GM_U8 || out_dtype == GM_U16) && (((uintptr_t)in % 16) == 0 || t_window_cols) &&
         ((uintptr_t)out % 8) == 0 && n / 4 >= 4096) {
       // (the grid of a threshold table is built once: 1024-8192 buckets x two binary searches each were ~25 us of
       //  host time per call, more than the kernel takes for a 4096^2 tile)
@@ -944,7 +955,7 @@ int gm_classify2(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, c
 #define GM_GRID_SCAN(TO_, RIGHT_, SCAN_)                                                                              \
   hipLaunchKernelGGL((classify_grid_kernel<TO_, RIGHT_, U, SCAN_>), dim3((unsigned)blocks), dim3(256), lds, s, (const float*)in, \
                      (TO_*)out, n4, (const float*)thr_dev, (const unsigned short*)base_dev, nbins, G, chunks, has_ndv,  \
-                     ndv32, (TO_)fill, t_window_cols / 4, t_window_pitch / 4)
+                     ndv32, (TO_)fill, t_window_cols / 4, t_window_pitch)
 #define GM_GRID(TO_, RIGHT_)                                \
   do {                                                      \
     if (G.scan == 1) GM_GRID_SCAN(TO_, RIGHT_, 1);          \

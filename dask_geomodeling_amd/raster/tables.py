@@ -147,18 +147,24 @@ def classify_process(data, bins, right):
     eff = P.effective_ndv(values.dtype, data["no_data_value"]) if values.dtype != np.dtype("bool") else None
     if values.dtype == np.dtype("bool") and data["no_data_value"] is not None:
         eff = P.effective_ndv(values.dtype, data["no_data_value"])
-    out = DeviceArray.empty(values.shape, out_dtype)
     if windowed:
-        rc = _lib().gm_classify2_window(
-            ctypes.c_void_p(values.ptr), code_of(values.dtype), 1 if eff is not None else 0,
-            runtime.scalar_bits(eff if eff is not None else 0, values.dtype),
-            payload.ctypes.data_as(ctypes.c_void_p), int(payload.size), are_int, 1 if right else 0,
-            ctypes.c_void_p(out.ptr), code_of(out_dtype), int(fill), values.shape[1], values.shape[2], values.pitch)
-        if rc == 0:
-            return {"values": out, "no_data_value": fill}
-        if rc != 9002:  # GM_ERR_UNSUPPORTED: these edges / this shape want the compact tile
-            runtime.check(rc, "gm_classify")
+        # whole groups of 4 cells per row: a width that is no multiple of 4 runs over the next one where the resident raster has
+        # the cells to read (the classes of the extra cells are cropped away: the result is a window of the padded tile)
+        pad = -values.shape[2] % 4
+        if pad == 0 or values.room_right() >= pad:
+            wide = values.shape[2] + pad
+            out = DeviceArray.empty((1, values.shape[1], wide), out_dtype)
+            rc = _lib().gm_classify2_window(
+                ctypes.c_void_p(values.ptr), code_of(values.dtype), 1 if eff is not None else 0,
+                runtime.scalar_bits(eff if eff is not None else 0, values.dtype),
+                payload.ctypes.data_as(ctypes.c_void_p), int(payload.size), are_int, 1 if right else 0,
+                ctypes.c_void_p(out.ptr), code_of(out_dtype), int(fill), values.shape[1], wide, values.pitch)
+            if rc == 0:
+                return {"values": out.window(0, 0, values.shape[1], values.shape[2]) if pad else out, "no_data_value": fill}
+            if rc != 9002:  # GM_ERR_UNSUPPORTED: these edges / this shape want the compact tile
+                runtime.check(rc, "gm_classify")
         values = values.contiguous()
+    out = DeviceArray.empty(values.shape, out_dtype)
     runtime.check(_lib().gm_classify2(
         ctypes.c_void_p(values.ptr), code_of(values.dtype), 1 if eff is not None else 0,
         runtime.scalar_bits(eff if eff is not None else 0, values.dtype),

@@ -715,10 +715,11 @@ def test_classify_many_edges_large_tile(gpu, kind, right):
 @pytest.mark.parametrize("right", [False, True])
 @pytest.mark.parametrize("kind", ["uniform200", "clustered", "few"])
 def test_classify_many_edges_on_windows_of_a_resident_raster(gpu, kind, right):
-    """Classify of a zero-copy window (rows a pitch apart): the grid kernel reads it where it lies when columns and pitch are
-    whole groups of four cells on a 16-byte boundary (gm_classify2_window); other windows, clustered edges (binary search)
-    and few edges (the program route) come to the same answer through a compact copy.  Also through the Block, as
-    `Classify(A, edges)` over a resident MemorySource meets it."""
+    """Classify of a zero-copy window (rows a pitch apart): the grid kernel reads it where it lies, from any first column and
+    in rows of any pitch (gm_classify2_window; round 5: element-aligned loads -- until then only on 16-byte boundaries); a
+    width that is no multiple of 4 runs over the next one where the raster has cells to its right and is cropped, at the
+    raster's right edge it takes a compact copy, like clustered edges (binary search); few edges take the program route.
+    Also through the Block, as `Classify(A, edges)` over a resident MemorySource meets it."""
     from dask_geomodeling_amd import raster
     from dask_geomodeling_amd.hip.array import DeviceArray
     from dask_geomodeling_amd.raster import tables
@@ -737,7 +738,7 @@ def test_classify_many_edges_on_windows_of_a_resident_raster(gpu, kind, right):
     wide[0, 301, 400:400 + len(bins)] = edges32[:700]
     resident = DeviceArray.from_numpy(wide)
     for row0, col0, h, w in ((0, 0, 700, 1100), (16, 64, 512, 640), (3, 4, 300, 1000), (3, 5, 300, 1000), (9, 8, 600, 1001),
-                             (0, 0, 128, 1100), (100, 96, 17, 132)):
+                             (0, 0, 128, 1100), (100, 96, 17, 132), (5, 99, 200, 1001), (7, 97, 100, 1002), (1, 1, 699, 1098)):
         data = {"values": resident.window(row0, col0, h, w), "no_data_value": ndv}
         want = O.classify_process({"values": wide[:, row0:row0 + h, col0:col0 + w], "no_data_value": ndv}, bins, right)
         got = tables.classify_process(data, bins, right)

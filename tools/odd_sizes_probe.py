@@ -16,6 +16,8 @@ dc = generate_window((big, big), "u1", 7003, 0.0, 12.0, 255, (97, 89), 0, 0, big
 A = raster.MemorySource(da, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
 B = raster.MemorySource(db, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(big)))
 C = raster.MemorySource(dc, np.uint8(255), "EPSG:28992", 1.0, (0.0, float(big)))
+dd = generate_window((big, big), "i4", 7005, 0.0, 256.0, 2147483647, (97, 89), 0, 0, big, big)
+D = raster.MemorySource(dd, np.int32(2147483647), "EPSG:28992", 1.0, (0.0, float(big)))
 views = [
     ("A + B", A + B),
     ("Clip(A * 2, B > 50)", raster.Clip(A * 2, B > 50)),
@@ -26,6 +28,11 @@ views = [
     ("Dilate(C, [3, 5])", raster.Dilate(C, [3, 5])),
     ("Smooth(A, 2)", raster.Smooth(A, 2.0)),
     ("Max(A, B, A * 2)", raster.Max(A, B, A * 2)),
+    ("Mask(Reclassify(D), 1)", raster.Mask(raster.Reclassify(D, [[k, (7 * k) % 1000] for k in range(0, 256, 2)]), 1)),
+    ("Reclassify(D) -> i64", raster.Reclassify(D, [[k, (7 * k) % 1000] for k in range(0, 256, 2)])),
+    ("Classify(A, 200 bins)", raster.Classify(A, list(np.linspace(0, 100, 200)))),
+    ("chain5", raster.Clip(raster.Add(raster.Subtract(raster.Multiply(raster.Add(A, B), 2.5), B), 1.5), A)),
+    ("Mask(C, 1)", raster.Mask(C, 1)),
 ]
 CASES = [(4096, 64, 64), (4096, 65, 33), (4095, 64, 64), (4094, 65, 33), (4093, 64, 64)]
 print("%-26s" % "view" + "".join("%14s" % ("%d@%d,%d" % c) for c in CASES) + "   (us per request: side @ column, row offset of the window)")
