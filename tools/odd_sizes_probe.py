@@ -34,13 +34,30 @@ views = [
     ("chain5", raster.Clip(raster.Add(raster.Subtract(raster.Multiply(raster.Add(A, B), 2.5), B), 1.5), A)),
     ("Mask(C, 1)", raster.Mask(C, 1)),
 ]
+from datetime import datetime, timedelta
+frames = 8
+dtm = generate_window((frames * 8192, 8192), "f4", 7004, 0.0, 100.0, F32MAX, (97, 89), 0, 0, frames * 8192, 8192).reshape((frames, 8192, 8192))
+T = raster.MemorySource(dtm, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, 8192.0), time_first=datetime(2020, 1, 1), time_delta=timedelta(hours=6))
+TREQ = dict(start=datetime(2020, 1, 1), stop=datetime(2020, 1, 3))
+tviews = [
+    ("T * 2, 8 frames", T * 2),
+    ("TemporalAggregate(T, D, mean)", raster.TemporalAggregate(T, "D", "mean")),
+    ("Cumulative(T, sum)", raster.Cumulative(T, "sum")),
+    ("Group(A, B)", raster.Group(A, B)),
+    ("FillNoData(A, B)", raster.FillNoData(A, B)),
+]
 CASES = [(4096, 64, 64), (4096, 65, 33), (4095, 64, 64), (4094, 65, 33), (4093, 64, 64)]
 print("%-26s" % "view" + "".join("%14s" % ("%d@%d,%d" % c) for c in CASES) + "   (us per request: side @ column, row offset of the window)")
-for name, view in views:
+for name, view in views + tviews:
     row = []
+    temporal = name in [t[0] for t in tviews[:3]]
     for side, ox, oy in CASES:
+        if temporal:
+            side, ox, oy = side // 2, ox, oy
         boxes = [(float(i * 4200 + ox), float(j * 4200 + oy), float(i * 4200 + ox + side), float(j * 4200 + oy + side)) for i in range(3) for j in range(3)]
-        reqs = [dict(mode="vals", bbox=b, width=side, height=side, projection="EPSG:28992") for b in boxes]
+        if temporal:
+            boxes = [(float(i * 2100 + ox), float(j * 2100 + oy), float(i * 2100 + ox + side), float(j * 2100 + oy + side)) for i in range(3) for j in range(3)]
+        reqs = [dict(mode="vals", bbox=b, width=side, height=side, projection="EPSG:28992", **(TREQ if temporal else {})) for b in boxes]
         with gmconfig.config.set({"geomodeling.materialize": False}):
             try:
                 for k in range(9):
