@@ -348,6 +348,13 @@ def test_tiled_series_windows_of_several_frames_in_place(gpu, plans, tiler_route
                     got = raster.RasterTiler(view, tile).get_data(**request)
                     assert_result_equal(got, want, 0, "%s tiled by %s, %s" % (type(view).__name__, tile, when))
                 assert_result_equal(view.get_data(**request), want, 0, "%s untiled, %s" % (type(view).__name__, when))
+        # requests whose width is no multiple of 4 (round 5: run over the next multiple where the rasters have the cells, the
+        # result a window of a padded tile of several frames), inside the raster and at its right edge
+        for x0, y0, w, h in ((3, 10, 201, 77), (65, 33, 127, 50), (0, 0, 515, 300), (310, 5, 207, 99), (1, 1, 6, 7)):
+            request = dict(mode="vals", bbox=(float(x0), float(y0), float(x0 + w), float(y0 + h)), width=w, height=h,
+                           projection="EPSG:28992", **windows[0])
+            for view in views[:3]:
+                assert_result_equal(view.get_data(**request), walk(view, request), 0, "%s on %s" % (type(view).__name__, (x0, y0, w, h)))
     # the mosaic of a multi-frame view is written in place (no paste): the tiles' results are windows of it
     with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": True}):
         out = raster.RasterTiler(a * 2, 128).get_data(**dict(box, **windows[0]))["values"]
