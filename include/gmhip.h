@@ -282,7 +282,8 @@ int gm_elemwise_run_batch(const gm_program* prog, int n_tiles, const void* const
  * rows; other windows take the scalar path (correct, slower). */
 int gm_elemwise_run_batch_2d(const gm_program* prog, int n_tiles, const void* const* inputs, const uint32_t* pitches,
                              void* const* outs, const uint32_t* out_pitches, size_t rows, size_t cols);
-/* Device-to-device copy of a 2-D window into another pitch (compaction of a window), asynchronous. */
+/* Device-to-device copy of a 2-D window into another pitch (compaction of a window), asynchronous: a kernel of this library
+ * (16-byte moves, element-aligned on both sides), any alignment and width at the same speed. */
 int gm_copy_2d(void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes, size_t width_bytes, size_t rows);
 /* ... of a window of several planes -- the frames of a series inside a tile of its raster (sources.py:119-149 warps every
  * frame): `planes` windows of `rows` rows; a plane of the source is src_plane_rows rows of src_pitch_bytes, one of the
@@ -367,7 +368,8 @@ int gm_classify(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits /* 
 int gm_classify2(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, const void* bins_host, int nbins,
                  int bins_are_int, int right, void* out, int out_dtype, uint64_t fill, size_t n);
 /* The tile as a window of a wider resident raster: rows x cols cells, rows `pitch` cells apart; out is compact.  Served for
- * float32 tiles whose edges take the grid kernel (more than a handful of float edges, cols and pitch multiples of 4);
+ * float32 tiles whose edges take the grid kernel (more than a handful of float edges; cols a multiple of 4 -- the window may
+ * start on any cell and lie in rows of any pitch: a caller with cells to the right of an odd width asks for the next multiple);
  * GM_ERR_UNSUPPORTED = compact the window and call gm_classify2 (what the window path of the reference's Classify.process,
  * raster/misc.py:387-399, amounts to: it sees the array the source cut out). */
 int gm_classify2_window(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, const void* bins_host, int nbins,
