@@ -62,27 +62,49 @@ struct Pack {
   T v[V];
 };
 
+template <int ALIGN>
+struct Unaligned;  // the access types of load_pack / store_pack, aligned like the cells they hold
+#define GM_UNALIGNED(A, A2, A4, A8, A16)                                           \
+  template <>                                                                      \
+  struct Unaligned<A> {                                                            \
+    typedef unsigned short u16 __attribute__((aligned(A2)));                       \
+    typedef unsigned u32 __attribute__((aligned(A4)));                             \
+    typedef unsigned u2 __attribute__((ext_vector_type(2), aligned(A8)));          \
+    typedef unsigned u4 __attribute__((ext_vector_type(4), aligned(A16)));         \
+  }
+GM_UNALIGNED(1, 1, 1, 1, 1);
+GM_UNALIGNED(2, 2, 2, 2, 2);
+GM_UNALIGNED(4, 2, 4, 4, 4);
+GM_UNALIGNED(8, 2, 4, 8, 8);
+#undef GM_UNALIGNED
+// V cells as one access.  The vector types promise element alignment only (round 5): the instructions are the same, and a frame
+// that has no multiple of V cells -- its successors then start off 16 bytes -- keeps the vector kernels (the last group of a
+// frame is moved back to end with the frame: see the kernels).
 template <typename T, int V>
 __device__ __forceinline__ Pack<T, V> load_pack(const T* p) {
   Pack<T, V> r;
   if constexpr (V == 1) {
     r.v[0] = __builtin_nontemporal_load(p);
   } else if constexpr (sizeof(T) * V == 2) {
-    const unsigned short w = __builtin_nontemporal_load((const unsigned short*)p);
+    typedef typename Unaligned<(int)alignof(T)>::u16 u16u;
+    const unsigned short w = __builtin_nontemporal_load((const u16u*)p);
     memcpy(&r, &w, 2);
   } else if constexpr (sizeof(T) * V == 4) {
-    const unsigned w = __builtin_nontemporal_load((const unsigned*)p);
+    typedef typename Unaligned<(int)alignof(T)>::u32 u32u;
+    const unsigned w = __builtin_nontemporal_load((const u32u*)p);
     memcpy(&r, &w, 4);
   } else if constexpr (sizeof(T) * V == 8) {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    const u2 w = __builtin_nontemporal_load((const u2*)p);
+    typedef typename Unaligned<(int)alignof(T)>::u2 u2u;
+    const u2 w = __builtin_nontemporal_load((const u2u*)p);
     memcpy(&r, &w, 8);
   } else {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef typename Unaligned<(int)alignof(T)>::u4 u4u;
     constexpr int N = (int)(sizeof(T) * V / 16);
     u4 w[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) w[i] = __builtin_nontemporal_load((const u4*)p + i);
+    for (int i = 0; i < N; ++i) w[i] = __builtin_nontemporal_load((const u4u*)p + i);
     memcpy(&r, w, sizeof(r));
   }
   return r;
@@ -92,22 +114,30 @@ template <typename T, int V>
 __device__ __forceinline__ void store_pack(T* p, const Pack<T, V>& r) {
   if constexpr (V == 1) {
     __builtin_nontemporal_store(r.v[0], p);
+  } else if constexpr (sizeof(T) * V == 2) {
+    typedef typename Unaligned<(int)alignof(T)>::u16 u16u;
+    unsigned short w;
+    memcpy(&w, &r, 2);
+    __builtin_nontemporal_store(w, (u16u*)p);
   } else if constexpr (sizeof(T) * V == 4) {
+    typedef typename Unaligned<(int)alignof(T)>::u32 u32u;
     unsigned w;
     memcpy(&w, &r, 4);
-    __builtin_nontemporal_store(w, (unsigned*)p);
+    __builtin_nontemporal_store(w, (u32u*)p);
   } else if constexpr (sizeof(T) * V == 8) {
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    typedef typename Unaligned<(int)alignof(T)>::u2 u2u;
     u2 w;
     memcpy(&w, &r, 8);
-    __builtin_nontemporal_store(w, (u2*)p);
+    __builtin_nontemporal_store(w, (u2u*)p);
   } else {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef typename Unaligned<(int)alignof(T)>::u4 u4u;
     constexpr int N = (int)(sizeof(T) * V / 16);
     u4 w[N];
     memcpy(w, &r, sizeof(r));
 #pragma unroll
-    for (int i = 0; i < N; ++i) __builtin_nontemporal_store(w[i], (u4*)p + i);
+    for (int i = 0; i < N; ++i) __builtin_nontemporal_store(w[i], (u4u*)p + i);
   }
 }
 
@@ -137,8 +167,9 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const Tin* __restrict__ 
                                                         typename OutOf<Tin, STAT>::type fill) {
   using Tout = typename OutOf<Tin, STAT>::type;
   using C = typename Work<Tout>::type;
-  const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
+  long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
   if (p >= pixels) return;
+  if (p + V > pixels) p = pixels - V;  // (the frame's last group ends with the frame: a few cells are worked out twice)
   const int first = B.first[blockIdx.y], count = B.count[blockIdx.y];
   const Tin* src = frames + (long long)first * pixels + p;
   C acc[V];    // sum / min / max
@@ -325,8 +356,9 @@ __global__ __launch_bounds__(256) void cumulative_kernel(const Tin* __restrict__
                                                          typename OutOf<Tin, STAT>::type fill) {
   using Tout = typename OutOf<Tin, STAT>::type;
   using C = typename Work<Tout>::type;
-  const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
+  long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
   if (p >= pixels) return;
+  if (p + V > pixels) p = pixels - V;  // (the frame's last group ends with the frame: a few cells are worked out twice)
   const int first = B.first[blockIdx.y], count = B.count[blockIdx.y];
   const Tin* src = frames + (long long)first * pixels + p;
   C acc[V];
@@ -757,7 +789,7 @@ template <typename Tin, int STAT>
 int launch_aggregate(const void* frames, uint64_t ndv_bits, int has_ndv, long long pixels, const gm_frame_bin* bins,
                      int n_bins, void* out, uint64_t fill_bits, hipStream_t s) {
   using Tout = typename OutOf<Tin, STAT>::type;
-  const bool vec = (pixels % 4) == 0 && ((uintptr_t)frames % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  const bool vec = pixels >= 4;  // (any alignment: load_pack)
   const int V = vec ? 4 : 1;
   const unsigned gx = (unsigned)((pixels + 256LL * V - 1) / (256LL * V));
   for (int b0 = 0; b0 < n_bins; b0 += TB_MAX_BINS) {
@@ -790,7 +822,7 @@ template <typename Tin, int STAT>
 int launch_cumulative(const void* frames, uint64_t ndv_bits, int has_ndv, long long pixels, const gm_frame_bin* bins,
                       int n_bins, int emit_first, int emit_stop, void* out, uint64_t fill_bits, hipStream_t s) {
   using Tout = typename OutOf<Tin, STAT>::type;
-  const bool vec = (pixels % 4) == 0 && ((uintptr_t)frames % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  const bool vec = pixels >= 4;  // (any alignment: load_pack)
   const int V = vec ? 4 : 1;
   const unsigned gx = (unsigned)((pixels + 256LL * V - 1) / (256LL * V));
   for (int b0 = 0; b0 < n_bins; b0 += TB_MAX_BINS) {
@@ -881,8 +913,9 @@ template <typename Tin, bool IS_BOOL, int V>
 __global__ __launch_bounds__(256) void frames_sum_kernel(const Tin* __restrict__ frames, int n, long long pixels,
                                                          typename std::conditional<IS_BOOL, long long, typename SumOf<Tin>::type>::type* __restrict__ out) {
   using A = typename std::conditional<IS_BOOL, long long, typename SumOf<Tin>::type>::type;
-  const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
+  long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
   if (p >= pixels) return;
+  if (p + V > pixels) p = pixels - V;  // (the frame's last group ends with the frame: a few cells are worked out twice)
   const Tin* src = frames + p;
   A acc[V];
 #pragma unroll
@@ -948,9 +981,9 @@ int launch_frames_sum(const void* frames, int n, long long pixels, void* out, hi
     }
   }
   constexpr int VV = 16 / (int)sizeof(A);  // the wider side (the accumulator) sets the vector width
-  const bool vec = VV > 1 && (pixels % VV) == 0 && ((uintptr_t)frames % (VV * sizeof(Tin))) == 0 && ((uintptr_t)out % 16) == 0;
+  const bool vec = VV > 1 && pixels >= VV;  // (any alignment: load_pack)
   if (vec) {
-    const unsigned gx = (unsigned)((pixels / VV + 255) / 256);
+    const unsigned gx = (unsigned)(((pixels + VV - 1) / VV + 255) / 256);
     hipLaunchKernelGGL((frames_sum_kernel<Tin, IS_BOOL, VV>), dim3(gx), dim3(256), 0, s, (const Tin*)frames, n, pixels, (A*)out);
   } else {
     const unsigned gx = (unsigned)((pixels + 255) / 256);

@@ -125,7 +125,7 @@ class FusedTask(object):
         try:
             return tuple((v["values"].dtype.num, v["values"].shape, type(v.get("no_data_value")),
                           self._ndv_key(v.get("no_data_value"))) for v in leaf_values)
-        except (TypeError, KeyError, AttributeError):
+        except (TypeError, KeyError, AttributeError, IndexError):  # (IndexError: a leaf that answered with a bare ndarray)
             return None
 
     _UNFUSABLE = ("unfusable",)  # cached verdict: this kind of tiles runs op by op

@@ -251,3 +251,15 @@ def test_ndarray_operand_that_does_not_broadcast(cpu_vm):
     tile = {"values": np.zeros((3, 5, 7), "f4"), "no_data_value": np.float32(1)}
     with pytest.raises(ValueError, match="broadcast"):
         devops.math_process("add", {"dtype": "float32", "fillvalue": 1.0}, tile, np.zeros((2, 5, 7), "f4"))
+
+
+def test_a_leaf_that_answers_with_a_bare_array_is_not_a_fusable_tile():
+    """What the round-5 temporal fuzzing found (seed 6001061, 23 x 39 rasters): a fused group one of whose leaves answered with a
+    bare ndarray made FusedTask._signature raise numpy's IndexError ("only integers, slices ...") out of get_data instead
+    of declining the fusion -- the group then runs Block by Block."""
+    import numpy as np
+    from dask_geomodeling_amd.fuse import FusedTask
+    task = FusedTask.__new__(FusedTask)
+    assert task._signature([np.zeros((1, 2, 2), dtype="f4")]) is None
+    assert task._signature([{"values": np.zeros((1, 2, 2), dtype="f4"), "no_data_value": None}]) is not None
+    assert task._signature([None]) is None
