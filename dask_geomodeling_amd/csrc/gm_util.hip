@@ -1,6 +1,8 @@
 // K8: helper kernels -- constant fill, synthetic tile generator, all-equal reduction
 // (Clip's early-out, raster/misc.py:108), checksum (null sink), mosaic paste
 // (device side of RasterTiler.process, raster/parallelize.py:118-124).
+#include <vector>
+
 #include "gm_common.h"
 
 namespace {
@@ -357,13 +359,30 @@ int gm_paste_tiles(void* mosaic, int H, int W, int n_tiles, const void* const* t
   // as in gm_paste_tile: rows that are whole 16-byte groups on both sides move as 16-byte words
   bool words = ((uintptr_t)mosaic % 16) == 0 && ((long long)W * itemsize) % 16 == 0;
   long long most_rows = 0;
+  // a tile without cells pastes nothing, as in gm_paste_tile (the reference's int() of a tile size can leave a tile of no
+  // columns at the edge of a request -- parallelize.py:85-86; found by the temporal fuzzer on 17 x 31 rasters): it is left out
+  std::vector<const void*> kept_tile;
+  std::vector<int> kept_th, kept_tw, kept_row0, kept_col0;
   for (int t = 0; t < n_tiles; ++t) {
     if (!tiles[t]) return gm::fail(GM_ERR_INVALID, "gm_paste_tiles: tile %d is null", t);
-    if (th[t] <= 0 || tw[t] <= 0 || row0[t] < 0 || col0[t] < 0 || row0[t] + th[t] > H || col0[t] + tw[t] > W)
+    if (th[t] <= 0 || tw[t] <= 0) continue;
+    if (row0[t] < 0 || col0[t] < 0 || row0[t] + th[t] > H || col0[t] + tw[t] > W)
       return gm::fail(GM_ERR_INVALID, "gm_paste_tiles: tile %d (%d,%d)+(%d,%d) outside mosaic (%d,%d)", t, row0[t], col0[t], th[t], tw[t], H, W);
     words = words && ((uintptr_t)tiles[t] % 16) == 0 && ((long long)tw[t] * itemsize) % 16 == 0 && ((long long)col0[t] * itemsize) % 16 == 0;
     if ((long long)bands * th[t] > most_rows) most_rows = (long long)bands * th[t];
+    kept_tile.push_back(tiles[t]);
+    kept_th.push_back(th[t]);
+    kept_tw.push_back(tw[t]);
+    kept_row0.push_back(row0[t]);
+    kept_col0.push_back(col0[t]);
   }
+  n_tiles = (int)kept_tile.size();
+  if (n_tiles == 0) return GM_OK;
+  tiles = kept_tile.data();
+  th = kept_th.data();
+  tw = kept_tw.data();
+  row0 = kept_row0.data();
+  col0 = kept_col0.data();
   if (most_rows > 65535) {  // (grid.y): tile by tile
     for (int t = 0; t < n_tiles; ++t) {
       int rc = gm_paste_tile(mosaic, H, W, tiles[t], bands, th[t], tw[t], row0[t], col0[t], itemsize);

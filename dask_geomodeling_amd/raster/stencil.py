@@ -148,9 +148,9 @@ def moving_max(values, no_data_value, size, out=None):
     if src.dtype == np.dtype("bool"):
         # the reference fails here too: utils.get_dtype_min has no minimum for bool (spatial.py:198)
         raise ValueError("Invalid integer data type 'b'.")
-    shape = (bands, h - 2 * radius, w - 2 * radius)
-    if bands == 0:
-        return DeviceArray.empty(shape, src.dtype)
+    shape = (bands, max(h - 2 * radius, 0), max(w - 2 * radius, 0))
+    if 0 in shape:  # (no frame in the window, or a tile that is all margin -- a tile of no columns at the edge of a tiled request:
+        return DeviceArray.empty(shape, src.dtype)  # the reference's filter + crop leaves an empty array too; round-5 fuzzing)
     out = _into(out, shape, src.dtype) or DeviceArray.empty(shape, src.dtype)
     has, bits = _ndv_bits(src.dtype, no_data_value)
     L = _lib()
@@ -175,8 +175,8 @@ def hillshade(values, no_data_value, fill, resolution, altitude, azimuth):
         fill_cast = np.int16(bool(fill_cast))
         if no_data_value is not None:
             no_data_value = np.int16(bool(no_data_value))
-    out = DeviceArray.empty((bands, h - 2, w - 2), "u1")
-    if bands == 0:
+    out = DeviceArray.empty((bands, max(h - 2, 0), max(w - 2, 0)), "u1")
+    if 0 in out.shape:  # (as in moving_max)
         return out
     has, bits = _ndv_bits(src.dtype, no_data_value)
     L = _lib()
@@ -260,8 +260,8 @@ def gaussian_smooth(values, no_data_value, fill, sigma_yx, crop_yx=(0, 0), fused
     if not axes:  # nothing to smooth: one pass with the identity kernel does the no-data replacement and the crop
         axes = [(2, None)]
     my, mx = crop_yx
-    if bands == 0:
-        return DeviceArray.empty((0, h - 2 * my, w - 2 * mx), src.dtype)
+    if bands == 0 or h - 2 * my <= 0 or w - 2 * mx <= 0:  # (as in moving_max)
+        return DeviceArray.empty((bands, max(h - 2 * my, 0), max(w - 2 * mx, 0)), src.dtype)
     L = _lib()
     if fused and len(axes) == 2 and src.dtype == np.dtype("f4"):
         (wy, ry), (wx, rx) = gaussian_weights(axes[0][1]), gaussian_weights(axes[1][1])

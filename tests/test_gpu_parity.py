@@ -753,6 +753,36 @@ def test_classify_many_edges_on_windows_of_a_resident_raster(gpu, kind, right):
 
 
 @pytest.mark.gpu
+def test_tiles_without_cells_at_the_edge_of_a_tiled_request(gpu, tiler_route):
+    """What the round-5 temporal fuzzing found on 17 x 31 rasters: the reference's int() of a tile size (parallelize.py:85-86) can
+    leave a tile of NO columns at the edge of a request.  Pasting it pastes nothing (gm_paste_tiles refused the batch: "outside
+    mosaic"), and a stencil over such a tile -- all margin -- answers with an empty tile like the reference's filter + crop
+    (gm_moving_max: "tile smaller than the footprint").  Tiled requests of that kind against the untiled evaluation."""
+    from dask_geomodeling_amd import raster
+    from dask_geomodeling_amd.raster import stencil
+    rng = np.random.default_rng(355)
+    v = (rng.random((3, 17, 31)) * 100).astype("f8")
+    ndv = np.float64(np.finfo("f8").max)
+    v[rng.random(v.shape) < 0.1] = ndv
+    from datetime import datetime, timedelta
+    src = raster.MemorySource(v, ndv, "EPSG:28992", 1.0, (0.0, 17.0), time_first=datetime(2021, 3, 1), time_delta=timedelta(hours=6))
+    views = [src * 0.5, raster.MovingMax(src + 2.5, 5), raster.Dilate(raster.Classify(src, [20.0, 50.0]), [1])]
+    for x0, y0, w, h in ((3, 2, 15, 8), (0, 0, 31, 17), (16, 9, 15, 8), (1, 1, 29, 3)):
+        request = dict(mode="vals", bbox=(float(x0), float(y0), float(x0 + w), float(y0 + h)), width=w, height=h, projection="EPSG:28992",
+                       start=datetime(2021, 3, 1), stop=datetime(2021, 3, 3))
+        for view in views:
+            want = view.get_data(**request)
+            for tile in ([14, 17], [8, 14], [5, 5], [17, 1]):
+                got = raster.RasterTiler(view, tile).get_data(**request)
+                assert_result_equal(got, want, 0, "%s tiled by %s on %s" % (type(view).__name__, tile, (x0, y0, w, h)))
+    # the stencils' own entry points on tiles that are all margin
+    assert tuple(stencil.moving_max(np.zeros((1, 4, 9), "f4"), None, 5).shape) == (1, 0, 5)
+    assert tuple(stencil.moving_max(np.zeros((2, 9, 3), "i4"), None, 5).shape) == (2, 5, 0)
+    assert tuple(stencil.hillshade(np.zeros((1, 2, 5), "f4"), None, 0, (1.0, 1.0), 45.0, 315.0).shape) == (1, 0, 3)
+    assert tuple(stencil.gaussian_smooth(np.zeros((1, 6, 20), "f4"), None, 0, (1.0, 1.0), crop_yx=(3, 4)).shape) == (1, 0, 12)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cell", [0.1, 0.3, 0.7])
 def test_tiler_with_tiles_one_pixel_short_of_their_slot(gpu, cell, tiler_route):
     """The reference truncates tile sizes with int() (parallelize.py:85-86): for cell sizes that are not
