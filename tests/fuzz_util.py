@@ -2,6 +2,8 @@
 table / reduction Blocks on the path, and an evaluator that walks the same tree with the CPU
 oracle (oracle/ref_numpy.py), one reference ``process`` body per Block -- i.e. what the reference
 would compute op by op, against which the fused / cut / batched device evaluation is compared."""
+import os
+
 import numpy as np
 
 from blocks_util import ArrayLeaf
@@ -13,8 +15,9 @@ BINARY = {"Add": "add", "Subtract": "subtract", "Multiply": "multiply", "Divide"
           "LessEqual": "less_equal", "And": "logical_and", "Or": "logical_or", "Xor": "logical_xor"}
 LEAF_KINDS = [("f4", np.float32(np.finfo("f4").max)), ("f4", -9999.0), ("u1", np.uint8(255)), ("i2", np.int16(-1)),
               ("i4", -9999), ("i4", 2147483647), ("f8", float(np.finfo("f8").max))]
-SHAPE = (1, 24, 40)
-REQ = dict(mode="vals", bbox=(0.0, 0.0, 40.0, 24.0), width=40, height=24, projection="EPSG:28992")
+# (GM_FUZZ_SHAPE=HxW: the campaigns of tests/fuzz_more.py on rasters of another shape -- odd ones found what 24 x 40 never met)
+SHAPE = (1,) + tuple(int(x) for x in os.environ.get("GM_FUZZ_SHAPE", "24x40").split("x"))
+REQ = dict(mode="vals", bbox=(0.0, 0.0, float(SHAPE[2]), float(SHAPE[1])), width=SHAPE[2], height=SHAPE[1], projection="EPSG:28992")
 
 
 def make_leaf(rng, tag, k, memory=False):
