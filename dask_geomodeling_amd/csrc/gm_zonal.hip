@@ -1487,16 +1487,46 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
       return key;
     }
   };
+  // What the wave has gathered for the labels it met, a lane per label (round 5): a finished run, and every label of a step that
+  // straddles labels, is merged into its lane here and goes to the label's counters ONCE, when the wave is through (or the 64
+  // lanes are taken: all are written out and start afresh).  Until then a run cost one atomic per quantity -- and a label raster
+  // that is not made of runs one per CELL: 12.6 M cells under 2 labels at random 44 ms, under 40 labels 20 ms.
+  int slot_label = -1, n_slots = 0;
+  unsigned long long slot_count = 0;
+  Key slot_key = NEUTRAL;
+  auto write_slots = [&]() {
+    if (lane < n_slots && slot_count != 0) {
+      atomicAdd(&counts[slot_label], slot_count);
+      if constexpr (STAT == Z_MIN) atomicMin(&extreme[slot_label], slot_key);
+      if constexpr (STAT == Z_MAX) atomicMax(&extreme[slot_label], slot_key);
+    }
+    slot_label = -1;
+    slot_count = 0;
+    slot_key = NEUTRAL;
+    n_slots = 0;
+  };
+  auto merge = [&](int label, unsigned long long n, Key key) {  // (wave-uniform arguments)
+    if (n == 0) return;
+    const unsigned long long hit = __ballot(slot_label == label);
+    int slot;
+    if (hit) {
+      slot = __ffsll((long long)hit) - 1;
+    } else {
+      if (n_slots == 64) write_slots();
+      slot = n_slots++;
+    }
+    if (lane == slot) {
+      slot_label = label;
+      slot_count += n;
+      slot_key = better(slot_key, key);
+    }
+  };
   auto flush = [&]() {  // (wave-uniform call)
     if (run_label < 0) return;
     unsigned long long n = wave_sum_u32(run_count);  // (fewer than 2^32 cells)
     Key key = run_key;
     if constexpr (STAT != Z_COUNT) key = wave_best(key);
-    if (lane == 0 && n != 0) {
-      atomicAdd(&counts[run_label], n);
-      if constexpr (STAT == Z_MIN) atomicMin(&extreme[run_label], key);
-      if constexpr (STAT == Z_MAX) atomicMax(&extreme[run_label], key);
-    }
+    merge(run_label, n, key);
     run_label = -1;
     run_count = 0;
     run_key = NEUTRAL;
@@ -1525,18 +1555,20 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
         run_count += 1;
         run_key = better(run_key, key);
       }
-    } else {  // (a step across label boundaries: run by run)
-      const LabelRuns runs = label_runs(labelled ? label : -1, lane);
-      const unsigned n = run_total(active ? 1u : 0u, runs, [](unsigned a, unsigned b) { return a + b; });
-      Key best = NEUTRAL;
-      if constexpr (STAT != Z_COUNT) best = run_total(active ? key : NEUTRAL, runs, better);
-      if (runs.last && labelled && n != 0) {
-        atomicAdd(&counts[label], (unsigned long long)n);
-        if constexpr (STAT == Z_MIN) atomicMin(&extreme[label], best);
-        if constexpr (STAT == Z_MAX) atomicMax(&extreme[label], best);
+    } else {  // (a step across labels: its distinct labels one after the other, a ballot each)
+      unsigned long long open = mask;
+      while (open) {
+        const int lead = __builtin_amdgcn_readlane(label, __ffsll((long long)open) - 1);
+        const bool mine = active && label == lead;
+        const unsigned long long same = __ballot(mine);
+        Key best = NEUTRAL;
+        if constexpr (STAT != Z_COUNT) best = wave_best(mine ? key : NEUTRAL);
+        merge(lead, (unsigned long long)__popcll(same), best);
+        open &= ~same;
       }
     }
   });
+  write_slots();
   // The run a wave ENDS in meets the other three waves' in LDS, and waves that end in the same label issue their atomics
   // together: under a label that covers the raster every wave ends on the same counters, and atomics on one address
   // serialise (round 3: 4 x fewer of them; count under one label 111 -> see MEASUREMENTS K14).
