@@ -6,7 +6,7 @@ set -u
 TAG=${1:?tag}; NL=${2:-1024}; ST=${3:-sum}; POS=${4:-}
 REPO=$PWD; BASE=$REPO/gpurun_out/zt_$TAG; rm -rf "$BASE"; mkdir -p "$BASE"
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$BASE/raw" -- python3 "$REPO/tools/zonal_trace_driver.py" $NL $ST 5 $POS > "$BASE/log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$BASE/raw" -- python3 "$REPO/${ZT_DRIVER:-tools/zonal_trace_driver.py}" $NL $ST 5 $POS > "$BASE/log" 2>&1
 cd "$REPO"
 python3 - "$BASE" <<'PY'
 import csv, glob, sys
