@@ -677,7 +677,11 @@ int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long 
   memset(&P, 0, sizeof(P));
   gm_percentile_step* plan_dev = nullptr;
   // bins beyond what the 160 KiB of a CU sort: selection in global memory (median_select_kernel)
-  const bool select = long_bins && (longest_all > GM_MAX_MEDIAN_FRAMES_LONG || (size_t)longest_all * 64 * sizeof(C) > 160 * 1024);
+  // (round 5: every long bin.  The 64-lane insertion sort that used to take bins of up to GM_MAX_MEDIAN_FRAMES_LONG frames keeps
+  //  one wave per compute unit busy with ~n^2 / 4 LDS moves per cell: the median of 365 daily frames of a 1024^2 raster took
+  //  337 ms; selected -- 34 passes over the bin -- 12 ms.  GM_MEDIAN_LONG_SORT=1 brings the sort back: tuning runs, tests.)
+  static const bool long_sort = getenv("GM_MEDIAN_LONG_SORT") && atoi(getenv("GM_MEDIAN_LONG_SORT"));
+  const bool select = long_bins && (!long_sort || longest_all > GM_MAX_MEDIAN_FRAMES_LONG || (size_t)longest_all * 64 * sizeof(C) > 160 * 1024);
   if (long_bins) {
     if (plan) {
       int rc = gm_malloc((void**)&plan_dev, sizeof(gm_percentile_step) * (size_t)n_plan);
@@ -697,7 +701,7 @@ int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long 
       P.one_minus_gamma[i] = plan[i].one_minus_gamma;
     }
   }
-  if (longest_all <= 16) {  // short bins: the register sorting network
+  if (longest_all <= 32) {  // short bins: the register sorting network (up to 32 frames: a month of daily frames; round 5)
     const unsigned gxs = (unsigned)((pixels + 255) / 256);
     for (int b0 = 0; b0 < n_bins; b0 += TB_MAX_BINS) {
       Bins B;
@@ -712,7 +716,8 @@ int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long 
                      from_bits<Tin>(ndv_bits), has_ndv, pixels, B, P, (C*)out, from_bits<C>(fill_bits))
       if (longest_all <= 4) { if (plan) GM_MEDIAN_SMALL(true, 4); else GM_MEDIAN_SMALL(false, 4); }
       else if (longest_all <= 8) { if (plan) GM_MEDIAN_SMALL(true, 8); else GM_MEDIAN_SMALL(false, 8); }
-      else { if (plan) GM_MEDIAN_SMALL(true, 16); else GM_MEDIAN_SMALL(false, 16); }
+      else if (longest_all <= 16) { if (plan) GM_MEDIAN_SMALL(true, 16); else GM_MEDIAN_SMALL(false, 16); }
+      else { if (plan) GM_MEDIAN_SMALL(true, 32); else GM_MEDIAN_SMALL(false, 32); }
 #undef GM_MEDIAN_SMALL
     }
     return GM_OK;
