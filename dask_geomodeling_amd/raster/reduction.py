@@ -181,6 +181,9 @@ def _nan_function(stack, statistic, percentile, fill_value, dtype):
                                  extra={"indefinite": True} if like_x86 else None))
 
 
+_MAX_AS_PROGRAM = 8  # rasters
+
+
 def reduce_rasters(stack, statistic, no_data_value=None, dtype=None):
     """Apply a statistic (e.g. "mean") to a stack of rasters, skipping 'no data' values
     (reduction.py:38-119; same arguments, same errors).  ``stack`` is a list of raster responses
@@ -202,7 +205,9 @@ def reduce_rasters(stack, statistic, no_data_value=None, dtype=None):
         values = _pick(stack, statistic, fill_value, dtype)
     elif statistic == "count":
         values = _count(stack, dtype)
-    elif statistic == "max":
+    elif statistic == "max" and len(stack) <= _MAX_AS_PROGRAM:
+        # (few rasters -- the Max Block's two or three: ONE fused program, fmax from left to right; a long stack takes the
+        #  stack kernel like every other statistic: the program of 300 rasters took 0.8 s to plan and run, the kernel 6 ms)
         from ..hip import program as P
         kwargs = {"dtype": dtype, "fillvalue": fill_value}
         values, _ = P.run_expr(lambda leaves: devops.reduce_max_node(kwargs, leaves),
