@@ -507,13 +507,13 @@ enum gm_statistic {
   GM_STAT_MEAN = 4,  /* np.nanmean  */
   GM_STAT_VAR = 5,   /* np.nanvar   */
   GM_STAT_STD = 6,   /* np.nanstd   */
-  GM_STAT_MEDIAN = 7 /* np.nanmedian (gm_temporal_aggregate only; bins of any length: sorted in LDS up to
-                        GM_MAX_MEDIAN_FRAMES_LONG frames, selected in global memory beyond) */
+  GM_STAT_MEDIAN = 7 /* np.nanmedian (gm_temporal_aggregate only; bins of any length: sorted in registers up to 32 frames,
+                        in LDS up to GM_MAX_MEDIAN_FRAMES, selected in global memory beyond) */
 };
 #define GM_MAX_MEDIAN_FRAMES 64       /* per bin, sorted by 256-lane workgroups */
-#define GM_MAX_MEDIAN_FRAMES_LONG 599 /* longer bins: 64-lane workgroups, as far as the 160 KiB of LDS reach
-                                         (640 float32 / 320 float64 values per lane); np.nanmedian itself takes
-                                         another route from 600 frames on */
+#define GM_MAX_MEDIAN_FRAMES_LONG 599 /* what the 64-lane sort reaches in the 160 KiB of LDS (640 float32 / 320 float64 values
+                                         per lane): kept for GM_MEDIAN_LONG_SORT=1 -- since round 5 longer bins are selected,
+                                         40 x faster; np.nanmedian itself takes another route from 600 frames on */
 
 typedef struct gm_frame_bin {
   int32_t first; /* first source frame */

@@ -1219,8 +1219,9 @@ def test_temporal_golden(gpu, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,frames", [("f4", 70), ("f4", 365), ("f4", 599), ("f8", 200), ("f8", 320), ("i2", 130)])
 def test_temporal_median_and_percentiles_over_long_bins(gpu, dtype, frames):
-    """Beyond 64 frames per label (a year of daily frames ...) the sort moves to 64-lane workgroups: up to 599
-    float32 / 320 float64 values per cell in the 160 KiB of LDS, the percentile plan in device memory."""
+    """Beyond 64 frames per label (a year of daily frames ...) the wanted ranks are selected in global memory (round 5; until
+    then an insertion sort in 64-lane workgroups took bins of up to 599 float32 / 320 float64 frames -- still there behind
+    GM_MEDIAN_LONG_SORT=1: test_temporal_medians_over_long_bins_by_the_lds_sort), the percentile plan in device memory."""
     from dask_geomodeling_amd.raster import temporal as T
     rng = np.random.default_rng(frames)
     ndv = np.dtype(dtype).type(-999)
@@ -1238,6 +1239,20 @@ def test_temporal_median_and_percentiles_over_long_bins(gpu, dtype, frames):
     one_more = 600 if np.dtype(out_dtype).itemsize == 4 else 321
     zeros = T.aggregate_frames(np.zeros((one_more, 2, 4), dtype), None, [(0, one_more)], "median", out_dtype).to_numpy()
     assert zeros.shape == (1, 2, 4) and not zeros.any()
+
+
+@pytest.mark.gpu
+def test_temporal_medians_over_long_bins_by_the_lds_sort(gpu):
+    """The test above once more with the 64-lane LDS insertion sort in place of the selection (GM_MEDIAN_LONG_SORT=1, read once
+    per process: a process of its own)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GM_MEDIAN_LONG_SORT="1")
+    here = os.path.abspath(__file__)
+    res = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                          "test_temporal_median_and_percentiles_over_long_bins"], capture_output=True, text=True, env=env, timeout=900)
+    assert res.returncode == 0 and "6 passed" in res.stdout, (res.stdout[-800:], res.stderr[-800:])
 
 
 @pytest.mark.gpu
