@@ -896,81 +896,7 @@ int gm_elemwise_run(const gm_program* prog, const void* const* inputs, void* out
 
 }  // extern "C"
 
-// Device-to-device copy of a 2-D / 3-D window (compaction of a strided view), asynchronous on the compute stream.  Round 5: a
-// kernel of this library instead of hipMemcpy2DAsync / hipMemcpy3DAsync -- the runtime's copy kernels take a window that does
-// not start on 16 bytes, or whose rows are no multiple of 16 bytes wide, several times slower (the 8 frames of a 2048^2 window
-// of a float32 series: 45 us on a 16-byte boundary, 150 us one cell further), and every Block that wants a compact tile pays
-// for it.  A lane moves 16 bytes of a row, element-aligned on both sides (the hardware takes unaligned accesses); a
-// workgroup 4 KiB of each of COPY_ROWS consecutive rows, every load issued before the first store; the last bytes of a row
-// go one by one.
-namespace {
-constexpr int COPY_ROWS = 4;
-__global__ __launch_bounds__(256) void copy_window_kernel(unsigned char* __restrict__ dst, size_t dst_pitch, size_t dst_plane,
-                                                          const unsigned char* __restrict__ src, size_t src_pitch, size_t src_plane,
-                                                          size_t width, size_t rows, unsigned blocks_per_row) {
-  typedef unsigned u32x4u __attribute__((ext_vector_type(4), aligned(1)));
-  const size_t row0 = (size_t)(blockIdx.x / blocks_per_row) * COPY_ROWS;
-  const size_t col = ((size_t)(blockIdx.x % blocks_per_row) * 256 + threadIdx.x) * 16;
-  if (col >= width) return;
-  const unsigned char* s = src + (size_t)blockIdx.y * src_plane + row0 * src_pitch + col;
-  unsigned char* d = dst + (size_t)blockIdx.y * dst_plane + row0 * dst_pitch + col;
-  if (col + 16 <= width) {
-    u32x4u v[COPY_ROWS];
-#pragma unroll
-    for (int r = 0; r < COPY_ROWS; ++r)  // (rows past the window re-read its last row: unconditional loads, nothing stored)
-      v[r] = __builtin_nontemporal_load((const u32x4u*)(s + (row0 + r < rows ? (size_t)r : rows - 1 - row0) * src_pitch));
-#pragma unroll
-    for (int r = 0; r < COPY_ROWS; ++r)
-      if (row0 + r < rows) *(u32x4u*)(d + (size_t)r * dst_pitch) = v[r];
-  } else {
-    for (int r = 0; r < COPY_ROWS && row0 + r < rows; ++r)
-      for (size_t k = 0; col + k < width; ++k) d[(size_t)r * dst_pitch + k] = s[(size_t)r * src_pitch + k];
-  }
-}
-
-int copy_window(void* dst, size_t dst_pitch, size_t dst_plane, const void* src, size_t src_pitch, size_t src_plane, size_t width,
-                size_t rows, size_t planes, hipStream_t stream) {
-  const size_t blocks_per_row = (width + 4095) / 4096, row_groups = (rows + COPY_ROWS - 1) / COPY_ROWS;
-  if (blocks_per_row * row_groups > 0x7fffffffull || blocks_per_row > 0xffffffffull || planes > 65535)
-    return gm::fail(GM_ERR_UNSUPPORTED, "copy of a window of %zu x %zu bytes x %zu planes", rows, width, planes);
-  hipLaunchKernelGGL(copy_window_kernel, dim3((unsigned)(blocks_per_row * row_groups), (unsigned)planes), dim3(256), 0, stream,
-                     (unsigned char*)dst, dst_pitch, dst_plane, (const unsigned char*)src, src_pitch, src_plane, width, rows,
-                     (unsigned)blocks_per_row);
-  GM_HIP(hipGetLastError());
-  return GM_OK;
-}
-}  // namespace
-
-extern "C" int gm_copy_2d(void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes,
-                          size_t width_bytes, size_t rows) {
-  if (!dst || !src) return gm::fail(GM_ERR_INVALID, "null pointer");
-  if (width_bytes == 0 || rows == 0) return GM_OK;
-  if (width_bytes > dst_pitch_bytes || width_bytes > src_pitch_bytes)
-    return gm::fail(GM_ERR_INVALID, "gm_copy_2d: rows of %zu bytes in pitches of %zu / %zu", width_bytes, dst_pitch_bytes, src_pitch_bytes);
-  hipStream_t stream = gm::current_stream();
-  if (!stream) return GM_ERR_NO_DEVICE;
-  return copy_window(dst, dst_pitch_bytes, 0, src, src_pitch_bytes, 0, width_bytes, rows, 1, stream);
-}
-
-// ... of a window of several planes (the frames of a series inside a tile of its raster): `planes` windows of `rows` rows,
-// the source's `src_plane_rows` rows of src_pitch_bytes apart, the destination's dst_plane_rows.  One launch.
-extern "C" int gm_copy_3d(void* dst, size_t dst_pitch_bytes, size_t dst_plane_rows, const void* src, size_t src_pitch_bytes,
-                          size_t src_plane_rows, size_t width_bytes, size_t rows, size_t planes) {
-  if (!dst || !src) return gm::fail(GM_ERR_INVALID, "null pointer");
-  if (width_bytes == 0 || rows == 0 || planes == 0) return GM_OK;
-  if (rows > dst_plane_rows || rows > src_plane_rows || width_bytes > dst_pitch_bytes || width_bytes > src_pitch_bytes)
-    return gm::fail(GM_ERR_INVALID, "gm_copy_3d: window larger than its plane");
-  hipStream_t stream = gm::current_stream();
-  if (!stream) return GM_ERR_NO_DEVICE;
-  for (size_t p0 = 0; p0 < planes; p0 += 65535) {  // (grid.y)
-    const size_t np = planes - p0 < 65535 ? planes - p0 : 65535;
-    if (int rc = copy_window((char*)dst + p0 * dst_plane_rows * dst_pitch_bytes, dst_pitch_bytes, dst_plane_rows * dst_pitch_bytes,
-                             (const char*)src + p0 * src_plane_rows * src_pitch_bytes, src_pitch_bytes,
-                             src_plane_rows * src_pitch_bytes, width_bytes, rows, np, stream))
-      return rc;
-  }
-  return GM_OK;
-}
+// (gm_copy_2d / gm_copy_3d, the compaction of a window: csrc/gm_util.hip -- this file holds no device code)
 
 // gm_elemwise_run_batch_2d over tiles of several bands whose bands are not back to back: input k of tile t is `bands` windows
 // of rows x cols, band_pitches[t * n_inputs + k] elements apart (0: the same operand for every band -- a broadcast scalar);
