@@ -35,6 +35,7 @@ _PERCENTILE_CODE = 11
 # median / percentile sort a cell's values in LDS up to this many rasters; beyond, the temporal kernels select the wanted ranks
 # (round 5: 64, like their own limit -- the LDS insertion sort of 300 rasters took 0.5 s per 2048^2 cells, the selection 30 ms)
 MAX_SORTED_RASTERS = 64
+MAX_SORTED_RASTERS_HALF = 599
 
 
 def parse_percentile_statistic(statistic):
@@ -139,7 +140,8 @@ def _nan_function(stack, statistic, percentile, fill_value, dtype):
     storage = np.dtype("f4") if work.itemsize <= 4 else np.dtype("f8")
     nodes = _stack_nodes(stack)
     n, shape = len(stack), tuple(stack[0]["values"].shape)
-    long_sort = statistic in ("median", "percentile") and n > MAX_SORTED_RASTERS
+    # (float16 stacks -- a 1-byte output dtype -- have no selection kernel: they keep the LDS sort as far as it reaches)
+    long_sort = statistic in ("median", "percentile") and n > (MAX_SORTED_RASTERS_HALF if half else MAX_SORTED_RASTERS)
     if long_sort and half:
         raise NotImplementedError("%s over %d rasters in float16 (a 1-byte output dtype)" % (statistic, n))
     bands = shape[0]

@@ -1270,6 +1270,19 @@ def test_reduce_rasters_median_over_many_rasters(gpu):
         with np.errstate(all="ignore"):
             want = O.reduce_rasters([dict(d) for d in stack], stat)
         assert_result_equal(dict(got, values=np.asarray(got["values"]) + 0.0), dict(want, values=want["values"] + 0.0), 0, stat)
+    # 1-byte rasters (a float16 stack): the LDS sort as far as it reaches -- 599 rasters --, where float32 / float64 stacks are
+    # selected from 65 rasters on (round 5)
+    for n in (70, 300):
+        stack = []
+        for _ in range(n):
+            v = rng.integers(0, 200, size=(1, 6, 9)).astype("u1")
+            v[rng.random(v.shape) < 0.2] = 255
+            stack.append({"values": v, "no_data_value": np.uint8(255)})
+        for stat in ("median", "p25"):
+            got = reduce_rasters([dict(d) for d in stack], stat)
+            with np.errstate(all="ignore"):
+                want = O.reduce_rasters([dict(d) for d in stack], stat)
+            assert_result_equal(dict(got, values=np.asarray(got["values"])), want, 0, "%s of %d uint8 rasters" % (stat, n))
 
 
 @pytest.mark.gpu
