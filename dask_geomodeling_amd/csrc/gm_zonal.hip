@@ -177,6 +177,38 @@ __device__ __forceinline__ double wave_sum_exact(double v) {  // (for sums known
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// Inclusive scans over the lanes in lane order through the same paths (shifts inside the rows of 16 lanes -- a lane without a
+// source takes the identity --, then the row totals are passed on).
+__device__ __forceinline__ double lane_scan_sum_f64(double v) {
+  v += dpp_move_f64<0x111>(0.0, v);        // row_shr:1
+  v += dpp_move_f64<0x112>(0.0, v);        // row_shr:2
+  v += dpp_move_f64<0x114>(0.0, v);        // row_shr:4
+  v += dpp_move_f64<0x118>(0.0, v);        // row_shr:8
+  v += dpp_move_f64<0x142, 0xA>(0.0, v);   // row_bcast15 into rows 1 and 3
+  v += dpp_move_f64<0x143, 0xC>(0.0, v);   // row_bcast31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ double lane_scan_min_f64(double v) {
+  const double inf = __builtin_huge_val();
+  v = fmin(v, dpp_move_f64<0x111>(inf, v));
+  v = fmin(v, dpp_move_f64<0x112>(inf, v));
+  v = fmin(v, dpp_move_f64<0x114>(inf, v));
+  v = fmin(v, dpp_move_f64<0x118>(inf, v));
+  v = fmin(v, dpp_move_f64<0x142, 0xA>(inf, v));
+  v = fmin(v, dpp_move_f64<0x143, 0xC>(inf, v));
+  return v;
+}
+__device__ __forceinline__ double lane_scan_max_f64(double v) { return -lane_scan_min_f64(-v); }
+__device__ __forceinline__ int lane_scan_min_i32(int v) {
+  v = min(v, dpp_move<0x111>(INT_MAX, v));
+  v = min(v, dpp_move<0x112>(INT_MAX, v));
+  v = min(v, dpp_move<0x114>(INT_MAX, v));
+  v = min(v, dpp_move<0x118>(INT_MAX, v));
+  v = min(v, dpp_move<0x142, 0xA>(INT_MAX, v));
+  v = min(v, dpp_move<0x143, 0xC>(INT_MAX, v));
+  return v;
+}
+
 // ... and for the counters of a run (zonal_direct_kernel / zonal_exact_kernel flush a run whenever the wave's label changes -- every
 // other step inside a 128-cell polygon row: the __shfl_xor butterflies there cost 6 LDS-crossbar round trips per quantity)
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
@@ -469,22 +501,18 @@ __device__ __forceinline__ double shuffle_up_f64(double x, int delta) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-__device__ __forceinline__ double broadcast_f64(double x, int lane) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-  const unsigned lo = __shfl((unsigned)u, lane), hi = __shfl((unsigned)(u >> 32), lane);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-// A workgroup of four waves per long label.  A round is 64 x PER consecutive block sums (a lane takes PER of them; any order
-// of addition will do: the result only predicts); wave w takes the rounds w, w + 4, ...: first their totals (into LDS), then
+// A workgroup of eight waves per long label.  A round is 64 x PER consecutive block sums (a lane takes PER of them; any order
+// of addition will do: the result only predicts); wave w takes the rounds w, w + 8, ...: first their totals (into LDS), then
 // -- once one wave has turned the totals into the sums before every round -- the prefixes inside them.  (One label covering
 // the default raster limit, 49 152 blocks: 362 us with one wave, one block per lane and round and the loads not ahead; 59 us
-// with 16 blocks per lane and the loads ahead; the four waves' rounds now overlap.)
+// with 16 blocks per lane, the loads ahead and four waves; round 5: eight waves, the loads of the first pass ahead as well and
+// the sums over the lanes through the data-parallel primitives instead of the LDS crossbar -- 63 -> 14 us.)
+constexpr int ZPRE_WAVES = 8;
 template <typename T>
-__global__ __launch_bounds__(256) void zonal_block_prefix_kernel(const typename Ordered<T>::Key* __restrict__ payload,
-                                                                 const unsigned* __restrict__ first, int n_labels,
-                                                                 const double* __restrict__ blk_sum, double* __restrict__ blk_pred,
-                                                                 unsigned long_from) {
+__global__ __launch_bounds__(64 * ZPRE_WAVES) void zonal_block_prefix_kernel(const typename Ordered<T>::Key* __restrict__ payload,
+                                                                             const unsigned* __restrict__ first, int n_labels,
+                                                                             const double* __restrict__ blk_sum,
+                                                                             double* __restrict__ blk_pred, unsigned long_from) {
   constexpr int PER = 16, ROUND = 64 * PER, RMAX = 2048;  // (RMAX rounds = 2 M blocks = 537 M cells; more: one wave, in order)
   __shared__ double before_round[RMAX];
   const int l = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -500,26 +528,26 @@ __global__ __launch_bounds__(256) void zonal_block_prefix_kernel(const typename 
   {
     double partial = 0.0;
     for (unsigned at = a + lane; at < j0 * ZB; at += 64) partial += (double)Ordered<T>::decode(payload[at]);
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) partial += shuffle_xor(partial, off);
-    head = partial;
+    head = wave_sum_exact(partial);
   }
+  // (a lane's PER blocks of a round are 64 apart: every load and store of the wave is one run of 512 bytes -- with PER consecutive
+  //  blocks per lane each of them touched 64 cache lines, 7 000 cycles per round and pass)
   auto fetch = [&](unsigned j, double* v) {
 #pragma unroll
-    for (int k = 0; k < PER; ++k) v[k] = blk_sum[min(j + PER * lane + k, j1 - 1)];
+    for (int k = 0; k < PER; ++k) v[k] = blk_sum[min(j + 64u * k + lane, j1 - 1)];
   };
-  const unsigned stride = team ? 4u : 1u, mine_first = team ? (unsigned)wave : 0u;
+  const unsigned stride = team ? (unsigned)ZPRE_WAVES : 1u, mine_first = team ? (unsigned)wave : 0u;
+  double ahead[PER];
   if (team) {
-    // pass A: the totals of this wave's rounds
+    // pass A: the totals of this wave's rounds (the next round's sums requested before this round's are added up)
+    if (mine_first < rounds) fetch(j0 + mine_first * ROUND, ahead);
     for (unsigned r = mine_first; r < rounds; r += stride) {
       const unsigned j = j0 + r * ROUND;
-      double v[PER];
-      fetch(j, v);
       double total = 0.0;
 #pragma unroll
-      for (int k = 0; k < PER; ++k) total += j + PER * lane + k < j1 ? v[k] : 0.0;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) total += shuffle_xor(total, off);
+      for (int k = 0; k < PER; ++k) total += j + 64u * k + lane < j1 ? ahead[k] : 0.0;
+      if (r + stride < rounds) fetch(j0 + (r + stride) * ROUND, ahead);
+      total = wave_sum_exact(total);
       if (lane == 0) before_round[r] = total;
     }
     __syncthreads();
@@ -532,12 +560,7 @@ __global__ __launch_bounds__(256) void zonal_block_prefix_kernel(const typename 
         mine[k] = r < rounds ? before_round[r] : 0.0;
         total += mine[k];
       }
-      double scan = total;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const double up = shuffle_up_f64(scan, off);
-        if (lane >= off) scan += up;
-      }
+      const double scan = lane_scan_sum_f64(total);
       double before = head + (scan - total);
 #pragma unroll
       for (int k = 0; k < CHUNK; ++k) {
@@ -548,33 +571,25 @@ __global__ __launch_bounds__(256) void zonal_block_prefix_kernel(const typename 
     }
     __syncthreads();
   }
-  // pass B: the prefixes inside the rounds (team: each round starts from its sum before; one wave: a running sum)
+  // pass B: the prefixes inside the rounds (team: each round starts from its sum before; one wave: a running sum); a round is PER
+  // slabs of 64 consecutive blocks, a lane each: a scan over the lanes per slab, the slabs' totals carried along
   double running = head;
-  double ahead[PER];
-  fetch(j0 + mine_first * ROUND, ahead);
+  if (mine_first < rounds) fetch(j0 + mine_first * ROUND, ahead);
   for (unsigned r = mine_first; r < rounds; r += stride) {
     const unsigned j = j0 + r * ROUND;
     double mine[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) mine[k] = j + PER * lane + k < j1 ? ahead[k] : 0.0;
+    for (int k = 0; k < PER; ++k) mine[k] = j + 64u * k + lane < j1 ? ahead[k] : 0.0;
     if (r + stride < rounds) fetch(j0 + (r + stride) * ROUND, ahead);
-    double total = 0.0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) total += mine[k];
-    double scan = total;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double up = shuffle_up_f64(scan, off);
-      if ((int)lane >= off) scan += up;
-    }
     if (team) running = before_round[r];
-    double before = running + (scan - total);
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      if (j + PER * lane + k < j1) blk_pred[j + PER * lane + k] = before;
-      before += mine[k];
+      const double scan = lane_scan_sum_f64(mine[k]);
+      if (j + 64u * k + lane < j1) blk_pred[j + 64u * k + lane] = running + (scan - mine[k]);
+      const unsigned long long u = (unsigned long long)__double_as_longlong(scan);
+      running += __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(u >> 32), 63) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readlane((int)u, 63)));
     }
-    if (!team) running += broadcast_f64(scan, 63);
   }
 }
 
@@ -1020,6 +1035,7 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
   };
   const unsigned j0 = (a + ZB - 1) / ZB, j1 = b / ZB;
   unsigned n_replayed = 0, n_ahead = 0, n_exact = 0, n_exact_groups = 0;  // literal blocks; ... requested ahead; certified blocks / groups
+  unsigned n_scans = 0, n_walked = 0, n_binade_groups = 0;               // compositions of a group's rest; groups walked / taken in one step
   if (j0 * ZB > a) literally(a, min(j0 * ZB, b));
   // Between literal stretches the sum lives as (binade E, sign, integer s = |sum| / u in [2^52, 2^53)): a block that is
   // valid for it is a handful of scalar integer operations.  The blocks' descriptions are fetched 64 at a time (a lane
@@ -1079,94 +1095,78 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
   };
   static_assert(64 * PER == ZG, "groups");
   // (the first group ends at the next multiple of ZG, so that the later ones coincide with the groups of ginfo[])
-  // The groups' descriptions are held 64 at a time, a lane each (one memory round trip per 64 groups = 16 384 blocks), and read
-  // off the lanes where they are needed; a group's 256 BLOCK descriptions are requested one group ahead -- but only when the
-  // group's description says it will have to be walked: a usable group is expected to go in one step, and asking for its
-  // blocks anyway would put a memory round trip into every iteration.
+  // The groups' descriptions -- of both kinds -- are held 64 groups at a time, a lane each (one memory round trip per 64 groups =
+  // 16 384 blocks), and read off the lanes where they are needed.  A group's 256 BLOCK descriptions are requested ahead only
+  // where the held descriptions say that the group will have to be walked (neither kind covers it): a usable group is expected
+  // to go in one step, and asking for its blocks anyway would put a memory round trip into every iteration.
   const unsigned last_group = (j1 - 1) / ZG;  // (j1 > j0 wherever this is used)
-  unsigned held_from = ~0u;  // group index of lane 0's description
+  unsigned held_from = ~0u;  // group index of lane 0's descriptions
   GroupInfo held;
+  GroupExact certified;
   held.E = INT_MIN;
-  auto hold = [&](unsigned gi) {  // make sure group gi's description is in a lane; returns the lane
+  certified.grain = INT_MIN;
+  unsigned long long to_walk = 0;  // the held groups that no description covers
+  auto hold = [&](unsigned gi) {  // make sure group gi's descriptions are in a lane; returns the lane
     if (held_from == ~0u || gi < held_from || gi >= held_from + 64u) {
       held_from = gi;
-      held = ginfo[min(gi + (unsigned)lane, last_group)];
+      const unsigned mine_g = min(gi + (unsigned)lane, last_group);
+      held = ginfo[mine_g];
+      if (gexact) certified = gexact[mine_g];
+      to_walk = __ballot(held.E == INT_MIN && certified.grain == INT_MIN);
     }
     return (int)(gi - held_from);
-  };
-  unsigned exact_from = ~0u;  // the same for the exactness certificates of the groups
-  GroupExact certified;
-  certified.grain = INT_MIN;
-  auto hold_exact = [&](unsigned gi) {
-    if (exact_from == ~0u || gi < exact_from || gi >= exact_from + 64u) {
-      exact_from = gi;
-      certified = gexact[min(gi + (unsigned)lane, last_group)];
-    }
-    return (int)(gi - exact_from);
   };
   auto pass_f64 = [&](double mine64, int i) -> double {
     const unsigned long long u = (unsigned long long)__double_as_longlong(mine64);
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(u >> 32), i) << 32) |
                                             (unsigned)__builtin_amdgcn_readlane((int)u, i)));
   };
-  // does the group that starts at block g go in one step, as far as its descriptions can tell?
-  auto usable = [&](unsigned g) -> bool {
-    if (!(g < j1 && g % ZG == 0 && j1 - g >= (unsigned)ZG)) return false;
+  // a whole group of ginfo[] / gexact[], all of it blocks of this label's?
+  auto whole_group = [&](unsigned g) -> bool { return g < j1 && g % ZG == 0 && j1 - g >= (unsigned)ZG; };
+  // the first group from block g on that will be walked whatever the sum is by then: a group that is not whole, or a held one
+  // that no description covers (j1: none as far as the held descriptions reach)
+  auto next_walked = [&](unsigned g) -> unsigned {
+    if (g >= j1) return j1;
+    if (!whole_group(g)) return g;
     const int at = hold(g / ZG);
-    if (__builtin_amdgcn_readlane(held.E, at) != INT_MIN) return true;
-    if (!gexact) return false;
-    const int xat = hold_exact(g / ZG);
-    return __builtin_amdgcn_readlane(certified.grain, xat) != INT_MIN;
+    const unsigned long long later = to_walk >> at;
+    if (later == 0) return j1;
+    const unsigned found = g + (unsigned)(__ffsll((long long)later) - 1) * (unsigned)ZG;
+    return found < j1 ? found : j1;
   };
   BlockInfo ahead[PER];
   Certificate ahead_cert[PER];
-  bool have_ahead = false;
-  if (j0 < j1 && !usable(j0)) {
-    fetch(j0, ahead, ahead_cert);
-    have_ahead = true;
+  unsigned ahead_for = j1;  // the group (by its first block) whose descriptions were requested into `ahead` (j1: none)
+  if (j0 < j1) {
+    ahead_for = next_walked(j0);
+    if (ahead_for < j1) fetch(ahead_for, ahead, ahead_cert);
   }
   unsigned here = 0;
   for (unsigned g = j0; g < j1; g += here) {
     here = min((unsigned)ZG - g % ZG, j1 - g);
-    BlockInfo B[PER];
-    Certificate C[PER];
-    const bool have = have_ahead;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      B[k] = ahead[k];
-      C[k] = ahead_cert[k];
-    }
-    const bool whole = usable(g);
+    const bool whole = whole_group(g);
     int at = 0;
     if (whole) at = hold(g / ZG);
-    // the next group's blocks, if it will be walked
-    const unsigned g1 = g + here;
-    have_ahead = false;
-    if (g1 < j1 && !usable(g1)) {
-      fetch(g1, ahead, ahead_cert);
-      have_ahead = true;
-      if (whole) at = hold(g / ZG);  // (usable(g1) may have moved the window of held descriptions)
-    }
     if (whole && as_integer && __builtin_amdgcn_readlane(held.E, at) == E && (__builtin_amdgcn_readlane(held.flags, at) & 1) == negative) {
       const int p0 = (int)(units & 1);
       const long long lo = pass(p0 ? held.lo[1] : held.lo[0], at), hi = pass(p0 ? held.hi[1] : held.hi[0], at);
       if (units + lo >= 4503599627370497ll && units + hi <= 9007199254740991ll) {
         units += pass(p0 ? held.D[1] : held.D[0], at);  // (256 blocks, 65 536 cells: one addition)
+        ++n_binade_groups;
         continue;
       }
     }
     if (whole && gexact) {
-      const int xat = hold_exact(g / ZG);
-      const int finest = __builtin_amdgcn_readlane(certified.grain, xat);
+      const int finest = __builtin_amdgcn_readlane(certified.grain, at);
       if (finest != INT_MIN) {
         to_double();
         if (fabs(acc) <= 1.7976931348623157e308) {
           const int held_bit = acc == 0.0 ? INT_MAX : lowbit_exp(acc);
           const int grain = min(finest, held_bit);
-          const double lo = pass_f64(certified.lo, xat), hi = pass_f64(certified.hi, xat);
+          const double lo = pass_f64(certified.lo, at), hi = pass_f64(certified.hi, at);
           const double reach = fmax(fabs(acc + lo), fabs(acc + hi)) * 1.001;  // (the bounds are float64 sums themselves)
           if (grain == INT_MAX || (grain > -1000 && grain < 900 && reach < ldexp(0.99, 53 + grain) && hi - lo < ldexp(0.99, 52 + grain))) {
-            acc += pass_f64(certified.total, xat);  // 256 blocks without a rounding: one addition
+            acc += pass_f64(certified.total, at);  // 256 blocks without a rounding: one addition
             to_integer();
             ++n_exact_groups;
             continue;
@@ -1174,7 +1174,27 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
         }
       }
     }
-    if (!have) fetch(g, B, C);  // (a group that was expected to go in one step and did not)
+    // This group is walked.  Its blocks' descriptions: requested earlier, or now (a group that was expected to go in one step
+    // and did not); then the same is requested for the next group that is sure to be walked.
+    BlockInfo B[PER];
+    Certificate C[PER];
+    if (ahead_for == g) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        B[k] = ahead[k];
+        C[k] = ahead_cert[k];
+      }
+    } else {
+      fetch(g, B, C);
+    }
+    {
+      const unsigned coming = next_walked(g + here);  // (may move the window of held descriptions on: nothing below needs them)
+      if (coming != ahead_for) {
+        if (coming < j1) fetch(coming, ahead, ahead_cert);
+        ahead_for = coming;
+      }
+    }
+    ++n_walked;
     // the first block from `from_idx` on that the info kernel expects to be added literally (64 * PER: none in this group)
     auto next_risky = [&](unsigned from_idx) -> unsigned {
       unsigned first_risky = 64u * PER;
@@ -1191,6 +1211,7 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
     unsigned wanted = next_risky(0);  // its cells are requested now and used when the composition stops there
     Cells ahead_cells = request(g + min(wanted, here - 1));
     while (start < here) {
+      ++n_scans;
       UnitsFn scan;
       scan.S[0] = scan.S[1] = 0;
       scan.q[0] = 0;
@@ -1274,22 +1295,81 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
           // while): the blocks that follow are asked for the same certificate straight away, one after the other, before the
           // functions of the rest of the group are composed again -- an addition certified exact is bincount's whichever way it
           // was arrived at.  (Three labels of 4 M cells of zero-mean noise: 2 397 blocks turned away, 2.55 ms; see MEASUREMENTS.)
-          if (blk_gexp) {
-            for (int more = 0; more < 16 && k + 1 < here; ++more) {
-              const unsigned nk = k + 1;
-              const int n_owner = (int)(nk / PER), n_which = (int)(nk % PER);
-              Certificate next_c = C[0];
+          if (blk_gexp && k + 1 < here && fabs(acc) <= 1.7976931348623157e308) {
+            // Every lane looks at its own blocks from k + 1 on: the partial sums of the run up to a block lie, relative to the sum
+            // entering the run, inside [LO, HI] = [min (o_j - a_j), max (o_j + a_j)] over the blocks j up to it (o_j: the tree sums
+            // before block j, a_j: its sum of |cells|), and everything is a multiple of 2^G, G = the finest bit of those blocks and
+            // of the sum entering the run.  max(|acc + LO|, |acc + HI|) < 2^(53 + G) and HI - LO < 2^(52 + G): no addition up to
+            // that block rounds, every range of its blocks sums without rounding (the o_j are what they stand for) and the run
+            // goes in ONE addition.  The test can only turn false once along the run: a ballot finds where.
+            const unsigned from = k + 1;
+            const double inf = __builtin_huge_val();
+            double lane_lo = inf, lane_hi = -inf, lane_run = 0.0;
+            int lane_fin = INT_MAX;
+            double o[PER], lo_c[PER], hi_c[PER];
+            int fin_c[PER];
+#pragma unroll
+            for (int c = 0; c < PER; ++c) {
+              const unsigned idx = (unsigned)(PER * lane + c);
+              const bool in = idx >= from && idx < here;
+              o[c] = lane_run;
+              if (in) {
+                lane_lo = fmin(lane_lo, lane_run - C[c].magnitude);
+                lane_hi = fmax(lane_hi, lane_run + C[c].magnitude);
+                lane_fin = min(lane_fin, C[c].finest);  // (INT_MIN: a block without a certificate ends the run)
+                lane_run += C[c].sum;
+              }
+              lo_c[c] = lane_lo;
+              hi_c[c] = lane_hi;
+              fin_c[c] = lane_fin;
+            }
+            // (the sum before the lane's blocks from the lanes below alone: `inclusive - lane_run` would carry what a block past the
+            //  end of the run -- of any size -- rounded away)
+            const double inclusive = lane_scan_sum_f64(lane_run);
+            double before = shuffle_up_f64(inclusive, 1);
+            if (lane == 0) before = 0.0;
+            const double scan_lo = lane_scan_min_f64(before + lane_lo), scan_hi = lane_scan_max_f64(before + lane_hi);
+            const int scan_fin = lane_scan_min_i32(lane_fin);
+            double ex_lo = shuffle_up_f64(scan_lo, 1), ex_hi = shuffle_up_f64(scan_hi, 1);
+            int ex_fin = __shfl_up(scan_fin, 1);
+            if (lane == 0) {
+              ex_lo = inf;
+              ex_hi = -inf;
+              ex_fin = INT_MAX;
+            }
+            const int held_bit = acc == 0.0 ? INT_MAX : lowbit_exp(acc);
+            int stop = PER;  // the lane's first block that the test turns away (PER: none)
+#pragma unroll
+            for (int c = PER - 1; c >= 0; --c) {
+              const unsigned idx = (unsigned)(PER * lane + c);
+              if (idx >= from && idx < here) {
+                const int G = min(held_bit, min(ex_fin, fin_c[c]));
+                const double LO = fmin(ex_lo, before + lo_c[c]), HI = fmax(ex_hi, before + hi_c[c]);
+                const double reach = fmax(fabs(acc + LO), fabs(acc + HI)) * 1.001;  // (the bounds are float64 sums themselves)
+                const bool ok = G == INT_MAX || (G > -1000 && G < 900 && reach < ldexp(0.99, 53 + G) && HI - LO < ldexp(0.99, 52 + G));
+                if (!ok) stop = c;
+              }
+            }
+            const unsigned long long stopped = __ballot(stop < PER);
+            unsigned taken;   // blocks of the run that go in the one addition
+            double run_total;
+            if (stopped == 0) {
+              taken = here - from;
+              run_total = pass_f64(inclusive, 63);
+            } else {
+              const int at_lane = __ffsll((long long)stopped) - 1;
+              const int at_c = __builtin_amdgcn_readlane(stop, at_lane);
+              double upto = before + o[0];
 #pragma unroll
               for (int c = 1; c < PER; ++c)
-                if (n_which == c) next_c = C[c];  // (wave-uniform)
-              const int n_finest = __builtin_amdgcn_readlane(next_c.finest, n_owner);
-              if (n_finest == INT_MIN || !(fabs(acc) <= 1.7976931348623157e308)) break;
-              const int n_grain = min(n_finest, acc == 0.0 ? INT_MAX : lowbit_exp(acc));
-              const double n_abs = pass_f64(next_c.magnitude, n_owner);
-              if (!(n_grain == INT_MAX || (n_grain > -1000 && n_grain < 900 && fabs(acc) + n_abs < ldexp(0.99, 53 + n_grain)))) break;
-              acc += pass_f64(next_c.sum, n_owner);
-              ++n_exact;
-              k = nk;
+                if (at_c == c) upto = before + o[c];  // (wave-uniform)
+              taken = (unsigned)(PER * at_lane + at_c) - from;
+              run_total = pass_f64(upto, at_lane);
+            }
+            if (taken) {
+              acc += run_total;
+              n_exact += taken;
+              k += taken;
             }
           }
           if (wanted < k + 1 || k == wanted) {
@@ -1332,6 +1412,9 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
       atomicAdd(replayed + 1, n_ahead);
       atomicAdd(replayed + 2, n_exact);
       atomicAdd(replayed + 3, n_exact_groups);
+      atomicAdd(replayed + 4, n_scans);
+      atomicAdd(replayed + 5, n_walked);
+      atomicAdd(replayed + 6, n_binade_groups);
     }
   }
 }
@@ -3567,7 +3650,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         const unsigned block_grid = (unsigned)((n_blocks * 64 + 255) / 256), label_grid = (unsigned)(((size_t)n_labels * 64 + 255) / 256);
         hipLaunchKernelGGL(zonal_block_sum_kernel<T>, dim3(block_grid), dim3(256), 0, s, sorted_pay, sorted_keys, (unsigned)cells, n_labels,
                            blk_sum, blk_label, blk_abs, blk_gexp);
-        hipLaunchKernelGGL(zonal_block_prefix_kernel<T>, dim3((unsigned)n_labels), dim3(256), 0, s, sorted_pay, first, n_labels, blk_sum,
+        hipLaunchKernelGGL(zonal_block_prefix_kernel<T>, dim3((unsigned)n_labels), dim3(64 * ZPRE_WAVES), 0, s, sorted_pay, first, n_labels, blk_sum,
                            blk_pred, long_from);
         hipLaunchKernelGGL(zonal_block_info_kernel<T>, dim3(block_grid), dim3(256), 0, s, sorted_pay, first, (unsigned)cells, blk_label,
                            blk_pred, blk_info, long_from);
@@ -3593,8 +3676,9 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
           GM_HIP(hipMemcpyAsync(host, replayed, sizeof(host), hipMemcpyDeviceToHost, s));
           GM_HIP(hipStreamSynchronize(s));
           fprintf(stderr, "[gmhip] zonal block pipeline: %zu blocks, %u of them added literally (%u with their cells requested ahead), "
-                          "%u turned away by the binade analysis but certified exact, %u groups of 256 certified exact\n", n_blocks, host[0],
-                  host[1], host[2], host[3]);
+                          "%u turned away by the binade analysis but certified exact, %u groups of 256 certified exact, %u taken in one "
+                          "step by the binade analysis, %u walked in %u compositions\n", n_blocks, host[0], host[1], host[2], host[3], host[6],
+                  host[5], host[4]);
           (void)gm_free(replayed);
         }
       }

@@ -2330,6 +2330,23 @@ def test_zonal_exactness_certificates(gpu, certify):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunks", ["0", "1"], ids=["block-pipeline", "product"])
+def test_zonal_labels_beyond_64_groups(gpu, chunks):
+    """Labels of 4 - 12 M cells (tests/zonal_long_label_driver.py): the composing wave of the block pipeline holds the
+    descriptions of 64 groups of 256 blocks at a time, so these labels make it move on to the next 64 -- twice and more -- on
+    cells that only grow the sum, on zero-mean noise with and without very fine cells, and on integers; every label with a tail
+    that cancels the sequential sum before it.  With the chunk records off (every label through the pipeline) and on."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GM_ZONAL_CHUNKS=chunks)
+    driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_long_label_driver.py")
+    res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=1800)
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
+    assert "LONG LABELS ok 16" in res.stdout
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["f4", "f8"])
 def test_signed_zeros_through_the_temporal_statistics(gpu, dt):
     """What the temporal fuzzing of round 4 found: NumPy's sums over the frame axis start from add's identity, so a cell whose
