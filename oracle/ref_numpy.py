@@ -438,8 +438,9 @@ def affine_nearest(values, zoom_yx, offset_yx, cval=0.0):
 # R2: bilinear resampling -- OUR spec (parity unpinned, see module docstring)
 # --------------------------------------------------------------------------
 
-def bilinear_resample(array, out_h, out_w, ndv):
+def bilinear_resample(array, out_h, out_w, ndv, window=None):
     """Pixel-centre aligned, edge-clamped, separable bilinear resize of (bands,H,W).
+    ``window`` = (r0, r1, c0, c1): only those rows / columns of the result (the tests of results of 8192^2 cells and more).
 
     For output (r, c):  v = (r+0.5)*(Hs/Hd) - 0.5,  u = (c+0.5)*(Ws/Wd) - 0.5  (float64)
     i0 = floor(v), j0 = floor(u), fv = v-i0, fu = u-j0; taps clamped to the source.
@@ -450,8 +451,9 @@ def bilinear_resample(array, out_h, out_w, ndv):
     non-finite, the output is ``ndv``.
     """
     b, hs, ws = array.shape
-    v = (np.arange(out_h, dtype=np.float64) + 0.5) * (hs / out_h) - 0.5
-    u = (np.arange(out_w, dtype=np.float64) + 0.5) * (ws / out_w) - 0.5
+    r0, r1, c0, c1 = window if window is not None else (0, out_h, 0, out_w)
+    v = (np.arange(r0, r1, dtype=np.float64) + 0.5) * (hs / out_h) - 0.5
+    u = (np.arange(c0, c1, dtype=np.float64) + 0.5) * (ws / out_w) - 0.5
     i0 = np.floor(v)
     j0 = np.floor(u)
     fv = (v - i0)[None, :, None]

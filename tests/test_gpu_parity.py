@@ -2347,6 +2347,39 @@ def test_zonal_labels_beyond_64_groups(gpu, chunks):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layouts,cases", [("0,5,9", 47), ("3,7,10", 48)], ids=["blocks-thirds-one", "stripes-random-outside"])
+def test_zonal_statistics_at_the_raster_limit(gpu, layouts, cases):
+    """3072 x 4096 cells (tests/zonal_full_size_driver.py; all eleven layouts, 174 statistics, when run by hand): 16 x 16 blocks
+    (49 152 labels), three large labels with strays and one label; vertical stripes, 40 labels at random per cell and one label
+    with cells outside -- sum, mean, count, min, max (and medians of the noise) of float32 noise, positive cells and int32
+    against the oracle."""
+    import os
+    import subprocess
+    import sys
+    driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_full_size_driver.py")
+    res = subprocess.run([sys.executable, driver, layouts], capture_output=True, text=True, timeout=1800)
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
+    assert "FULL SIZE ok %d" % cases in res.stdout, res.stdout[-300:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parts,checks", [(["stencils"], 120), (["resample"], 75), (["temporal,stacks", "quick"], 17)],
+                         ids=["stencils", "resample", "temporal-stacks"])
+def test_kernels_of_the_next_rows_at_the_sizes_they_are_timed_on(gpu, parts, checks):
+    """tests/full_size_ops_driver.py: MovingMax (3, 7, 15, 17), HillShade, Smooth and Dilate on 8192^2 tiles and bilinear results of
+    8192^2 cells at six zooms -- windows of the device result (corners, tile seams far from the origin, random places) against
+    the oracle on host copies of those windows --, nearest warps of 8192^2 cells, temporal statistics of 24 frames and stack
+    statistics of 8 rasters whole (a quarter of the timed sizes here; the timed sizes when the driver is run by hand)."""
+    import os
+    import subprocess
+    import sys
+    driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "full_size_ops_driver.py")
+    res = subprocess.run([sys.executable, driver] + parts, capture_output=True, text=True, timeout=1800)
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
+    assert "FULL SIZE OPS ok %d" % checks in res.stdout, res.stdout[-300:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["f4", "f8"])
 def test_signed_zeros_through_the_temporal_statistics(gpu, dt):
     """What the temporal fuzzing of round 4 found: NumPy's sums over the frame axis start from add's identity, so a cell whose
