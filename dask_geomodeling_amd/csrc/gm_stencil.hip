@@ -1424,7 +1424,7 @@ __global__ __launch_bounds__(256) void gauss_axis_far_kernel(const T* __restrict
 // The operations and their order are those of the one-axis kernels (SciPy's: centre tap, then the pairs
 // from the farthest in); columns outside the tile are the x line's constant extension, not filtered values.
 #ifndef GM_G2_TH
-#define GM_G2_TH 32  // (tuning builds; 48 / 56 rows read less of the source twice and are slower: MEASUREMENTS 11.11)
+#define GM_G2_TH 32  // (tuning builds; 48 / 56 rows read less of the source twice and are slower: MEASUREMENTS 11.11, 11.17)
 #endif
 constexpr int G2_TH = GM_G2_TH, G2_MAX_RADIUS = 16;
 struct Gauss2Args {
@@ -1453,25 +1453,22 @@ __global__ __launch_bounds__(256) void gauss2d_kernel(const float* __restrict__ 
         return (ty < 0 || ty >= h) ? A.cval : inside;
       };
       const int top = y0 + oy0 - R;  // tile row of win[0]
-      double win[WIN];
-      {
-        float raw[2 * R];
+      // Every row of the column this lane will need is requested before the first is used (round 5: G2_TH + 2 R loads in
+      // flight per lane; with 8 rows requested a slab ahead a workgroup waited for memory five times in a row, and what the
+      // compute unit's waves had in flight did not cover the latency at HBM's rate)
+      constexpr int TOTAL = G2_TH + 2 * R;
+      float raw[TOTAL];
 #pragma unroll
-        for (int i = 0; i < 2 * R; ++i) raw[i] = load(top + i);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 2 * R; ++i) win[i] = value(raw[i], top + i);
-      }
-      float ahead[8];  // the 8 rows the next step adds, in flight while this step computes
-#pragma unroll
-      for (int i = 0; i < 8; ++i) ahead[i] = load(top + 2 * R + i);
+      for (int i = 0; i < TOTAL; ++i) raw[i] = load(top + i);
       __builtin_amdgcn_sched_barrier(0);
-      for (int slab = 0; slab * 8 < rows; ++slab) {
+      double win[WIN];
+#pragma unroll
+      for (int i = 0; i < 2 * R; ++i) win[i] = value(raw[i], top + i);
+#pragma unroll
+      for (int slab = 0; slab < G2_TH / 8; ++slab) {
         const int first = top + slab * 8 + 2 * R;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) win[2 * R + i] = value(ahead[i], first + i);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ahead[i] = load(first + 8 + i);
+        for (int i = 0; i < 8; ++i) win[2 * R + i] = value(raw[2 * R + slab * 8 + i], first + i);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           double acc = win[r + R] * A.wy[0];

@@ -3,7 +3,8 @@ blocks of several sizes (up to 49 152 labels), vertical stripes, thin bands, a f
 at random per cell (2, 40 and 1000 of them: nothing like runs), one label.  Zero-mean float32 noise with a tenth no data,
 the same made positive, and rounded to int32.  The unit tests reach every route on small rasters; this driver is for what
 only shows at size (windows of 64 groups, tables of many stretches, second attempts with shorter stretches).
-Prints 'FULL SIZE ok <cases>'.  Arguments: [layouts to run, comma separated indices]"""
+Prints 'FULL SIZE ok <cases>'.  Arguments: [layouts to run, comma separated indices]; GM_FULL_MEDIANS=1: medians of the layout of
+49 152 labels too (the oracle takes a while)."""
 import os
 import sys
 
@@ -47,7 +48,7 @@ for i in chosen:
     n = int(labels[labels < np.iinfo(np.int32).max].max()) + 1
     buckets = [(list(range(n)), labels)]
     for tname, values, ndv in (("noise", noise, np.float32(-9999.0)), ("positive", positive, np.float32(-9999.0)), ("int32", ints, np.int32(-9999))):
-        stats = ("sum", "mean", "count", "min", "max") + (("median",) if tname == "noise" and n <= 6592 else ())
+        stats = ("sum", "mean", "count", "min", "max") + (("median",) if tname == "noise" and (n <= 6592 or os.environ.get("GM_FULL_MEDIANS")) else ())
         for stat in stats:
             with np.errstate(all="ignore"):
                 want, want_no = O.aggregate_labelled(buckets, n, values, ndv, None, stat, None)
