@@ -2380,6 +2380,24 @@ def test_kernels_of_the_next_rows_at_the_sizes_they_are_timed_on(gpu, parts, che
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("part,checks", [("temporal", 40), ("stencils", 24), ("resample", 8)])
+def test_tiles_of_more_than_2_to_the_31_cells_through_the_next_rows(gpu, part, checks):
+    """tests/beyond_2_31_driver.py: 40 frames of 8192^2 cells through the temporal statistics and Cumulative, 9 bands of 16384^2
+    through MovingMax / HillShade / Smooth / Dilate, bilinear and nearest results of 3 bands of 32768^2 -- windows at the far end
+    of the results against the oracle.  (Needs ~45 GB of host memory: skipped on smaller hosts.)"""
+    import os
+    import subprocess
+    import sys
+    import psutil
+    if psutil.virtual_memory().available < 96 * 2 ** 30:
+        pytest.skip("needs 96 GB of free host memory")
+    driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "beyond_2_31_driver.py")
+    res = subprocess.run([sys.executable, driver, part], capture_output=True, text=True, timeout=1800)
+    assert res.returncode == 0, (res.stdout[-800:], res.stderr[-2500:])
+    assert "BEYOND 2^31 ok %d" % checks in res.stdout, res.stdout[-300:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", ["f4", "f8"])
 def test_signed_zeros_through_the_temporal_statistics(gpu, dt):
     """What the temporal fuzzing of round 4 found: NumPy's sums over the frame axis start from add's identity, so a cell whose
