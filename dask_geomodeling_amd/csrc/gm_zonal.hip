@@ -1371,6 +1371,28 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
               n_exact += taken;
               k += taken;
             }
+            // Where the run ends the blocks that follow are still asked one by one, a few of them: a block on its own needs no
+            // bound on the run's range (|sum entering it| + its sum of |cells| < 2^(53 + grain) is all), which is what still
+            // holds when the running sum is hardly larger than a block's cells and carries a bit at its last place -- there the
+            // run test gives out after a block or two and every composition of the rest of the group costs ~2.5 us.  (Three
+            // labels of 4 M cells of zero-mean noise: 1 483 compositions with the run test alone, 3.9 ms.)
+            // (after a long run the rest of the group is better composed: a composition takes up to 256 valid blocks at the price of three)
+            for (int more = 0; taken < 8 && more < 16 && k + 1 < here; ++more) {
+              const unsigned nk = k + 1;
+              const int n_owner = (int)(nk / PER), n_which = (int)(nk % PER);
+              Certificate next_c = C[0];
+#pragma unroll
+              for (int c = 1; c < PER; ++c)
+                if (n_which == c) next_c = C[c];  // (wave-uniform)
+              const int n_finest = __builtin_amdgcn_readlane(next_c.finest, n_owner);
+              if (n_finest == INT_MIN || !(fabs(acc) <= 1.7976931348623157e308)) break;
+              const int n_grain = min(n_finest, acc == 0.0 ? INT_MAX : lowbit_exp(acc));
+              const double n_abs = pass_f64(next_c.magnitude, n_owner);
+              if (!(n_grain == INT_MAX || (n_grain > -1000 && n_grain < 900 && fabs(acc) + n_abs < ldexp(0.99, 53 + n_grain)))) break;
+              acc += pass_f64(next_c.sum, n_owner);
+              ++n_exact;
+              k = nk;
+            }
           }
           if (wanted < k + 1 || k == wanted) {
             wanted = next_risky(k + 1);
@@ -3488,7 +3510,11 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         n_stretch = (int64_t)(((size_t)cells + chunk_cells - 1) / chunk_cells);
         const size_t row_bytes = ((size_t)n_stretch + 63) / 64 * 64;  // a label's row of the slot table: whole 64-byte groups
         const size_t table_bytes = (size_t)n_labels * row_bytes;
-        if (table_bytes > ((size_t)64 << 20)) break;
+        // (one byte per label and stretch, cleared by one fill and read once by the labels' waves.  128 MB: 6592 polygons of 48 x 40
+        //  cells in stretches of 768 -- 108 MB -- 735 -> 466 us; 49 152 polygons of 16 x 16 cells -- 201 MB, and 192 labels to a
+        //  stretch: an attempt for nothing -- stay with the per-label certificates, 465 us against 650.  GM_ZONAL_TABLE_MB for A/B runs)
+        static const size_t table_limit = (size_t)(getenv("GM_ZONAL_TABLE_MB") ? atoll(getenv("GM_ZONAL_TABLE_MB")) : 128) << 20;
+        if (table_bytes > table_limit) break;
         if (!chunk.records || chunk.sized_for < n_stretch || chunk.table_for < table_bytes) {
           if ((rc = scratch.take((void**)&chunk.records, sizeof(ChunkRec) * ZC_SLOTS * (size_t)n_stretch))) return rc;
           if ((rc = scratch.take((void**)&chunk.slot_of, table_bytes + 64))) return rc;  // (the verdict behind the table: one fill)

@@ -3,7 +3,8 @@ blocks of several sizes (up to 49 152 labels), vertical stripes, thin bands, a f
 at random per cell (2, 40 and 1000 of them: nothing like runs), one label.  Zero-mean float32 noise with a tenth no data,
 the same made positive, and rounded to int32.  The unit tests reach every route on small rasters; this driver is for what
 only shows at size (windows of 64 groups, tables of many stretches, second attempts with shorter stretches).
-Prints 'FULL SIZE ok <cases>'.  Arguments: [layouts to run, comma separated indices]; GM_FULL_MEDIANS=1: medians of the layout of
+Prints 'FULL SIZE ok <cases>'.  Arguments: [layouts to run, comma separated indices or "all"] [HxW: another raster size, by
+hand]; GM_FULL_MEDIANS=1: medians of the layout of
 49 152 labels too (the oracle takes a while)."""
 import os
 import sys
@@ -17,7 +18,8 @@ from dask_geomodeling_amd.hip import runtime  # noqa: E402
 from oracle import ref_numpy as O  # noqa: E402
 
 runtime.set_device(0)
-h, w = 3072, 4096
+h, w = (int(x) for x in sys.argv[2].split("x")) if len(sys.argv) > 2 else (3072, 4096)   # (by hand: 16384x16384 and the like)
+big = h * w > 3072 * 4096
 rng = np.random.default_rng(55)
 noise = (rng.standard_normal((1, h, w)) * 100).astype("f4")
 holes = rng.random(noise.shape) < 0.1
@@ -40,7 +42,7 @@ layouts = [
     ("one label", np.zeros((h, w), dtype=np.int64)),
     ("one label with 2 % outside", np.where(rng.random((h, w)) < 0.02, np.iinfo(np.int32).max, 0)),
 ]
-chosen = [int(i) for i in sys.argv[1].split(",")] if len(sys.argv) > 1 else range(len(layouts))
+chosen = [int(i) for i in sys.argv[1].split(",")] if len(sys.argv) > 1 and sys.argv[1] != "all" else range(len(layouts))
 cases = 0
 for i in chosen:
     name, labels = layouts[i]
@@ -48,7 +50,7 @@ for i in chosen:
     n = int(labels[labels < np.iinfo(np.int32).max].max()) + 1
     buckets = [(list(range(n)), labels)]
     for tname, values, ndv in (("noise", noise, np.float32(-9999.0)), ("positive", positive, np.float32(-9999.0)), ("int32", ints, np.int32(-9999))):
-        stats = ("sum", "mean", "count", "min", "max") + (("median",) if tname == "noise" and (n <= 6592 or os.environ.get("GM_FULL_MEDIANS")) else ())
+        stats = (("sum", "mean", "count", "max") if big else ("sum", "mean", "count", "min", "max")) + (("median",) if tname == "noise" and (n <= 6592 or os.environ.get("GM_FULL_MEDIANS")) and not big else ())
         for stat in stats:
             with np.errstate(all="ignore"):
                 want, want_no = O.aggregate_labelled(buckets, n, values, ndv, None, stat, None)
