@@ -441,6 +441,25 @@ static __device__ const double POWF_EXP2_L[5] = {0x1.62e42fefa39efp-1, 0x1.ebfbd
 #define POWF_LN2 0x1.62e42fefa39efp-1
 #define POWF_LOG10_2 0x1.34413509f79ffp-2
 
+// The tables in LDS (round 5): the common case of np.power / np.log / np.log10 reads them there -- two gathers per value that no
+// longer share the vector-memory path with the tile's own loads and stores.  A workgroup of the VM_MATH kernels copies them in
+// while its tile loads are in flight (vm_body); the full routines (special values, the float64 class) keep the global tables.
+struct PowfLds {
+  double log2_tab[128][2];
+  double exp2_tab[32];
+};
+__device__ __forceinline__ PowfLds* powf_lds() {
+  __shared__ __align__(16) PowfLds tables;
+  return &tables;
+}
+__device__ __forceinline__ void powf_lds_stage() {  // (the caller synchronises the workgroup afterwards)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  PowfLds* const T = powf_lds();
+  const unsigned t = threadIdx.x;
+  if (t < 128u) ((u32x4*)T->log2_tab)[t] = ((const u32x4*)POWF_LOG2_TAB)[t];
+  else if (t < 144u) ((u32x4*)T->exp2_tab)[t - 128u] = ((const u32x4*)POWF_EXP2_TAB)[t - 128u];
+}
+
 // The two halves of the float32 transcendentals, in float64 arithmetic (round 4):
 //   log2 of a positive finite float32 = e + log2(c) + log2(1 + r), r = z / c - 1, by a table of 128 mantissa intervals (the one
 //     around 1.0 has c = 1: values near 1 keep their RELATIVE precision) and five or seven Taylor terms (|r| <= 2^-8);
@@ -464,18 +483,20 @@ __device__ __forceinline__ double log2_of_positive_f32(unsigned ax) {
 }
 // ... of a NORMAL float32 (no scaling of subnormals): the common case of the routes below, which check for it
 template <int TERMS>
-__device__ __forceinline__ double log2_of_normal_f32(unsigned ax) {
+__device__ __forceinline__ double log2_of_normal_f32(unsigned ax, const double (*tab)[2]) {
   const unsigned tmp = ax - 0x3f338000u;
   const int i = (int)((tmp >> 16) & 127u);
   const int e = (int)tmp >> 23;
   const double z = (double)__uint_as_float(ax - (tmp & 0xff800000u));  // in [0.7, 1.4)
-  const double r = fma(z, POWF_LOG2_TAB[i][0], -1.0);
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  const f64x2 entry = *(const f64x2*)tab[i];  // {1 / c, log2(c)}: one 16-byte read
+  const double r = fma(z, entry.x, -1.0);
   double p = POWF_LOG2_C[TERMS - 1];
 #pragma unroll
   for (int k = TERMS - 2; k >= 2; --k) p = fma(r, p, POWF_LOG2_C[k]);
   p = fma(r, p, POWF_LOG2_C[1]);
   p = fma(r, p, POWF_LOG2_C[0]);
-  return fma(r, p, (double)e + POWF_LOG2_TAB[i][1]);
+  return fma(r, p, (double)e + entry.y);
 }
 __device__ __forceinline__ float exp2_to_f32(double z, double z_lo) {
   z = fmin(fmax(z, -160.0), 130.0);  // (beyond: 0 / inf as float32 either way; keeps 2^k a normal double)
@@ -500,11 +521,11 @@ __device__ __forceinline__ float exp2_to_f32(double z, double z_lo) {
 // negative, infinite and NaN arguments are one unsigned compare away.  `special` = the value still needs the full routine (the
 // caller -- Machine::apply_logf -- runs the common case for ALL its values first, so that their table reads are in flight
 // together, and then asks once per wave whether any value was special).  +-0 is settled here (-inf: rasters are full of zeros).
-__device__ __forceinline__ float logf_common(float xf, double scale, bool& special) {
+__device__ __forceinline__ float logf_common(float xf, double scale, bool& special, const PowfLds* T) {
   const unsigned ix = __float_as_uint(xf);
   const bool ordinary = ix - 0x00800000u < 0x7f800000u - 0x00800000u;  // positive, normal, finite
   const bool zero = (ix << 1) == 0u;
-  const float out = (float)(log2_of_normal_f32<7>(ordinary ? ix : 0x3f800000u) * scale);
+  const float out = (float)(log2_of_normal_f32<7>(ordinary ? ix : 0x3f800000u, T->log2_tab) * scale);
   special = !(ordinary | zero);
   return zero ? -__builtin_inff() : out;
 }
@@ -530,10 +551,10 @@ __device__ __forceinline__ float logf_via_f64(float xf, double scale) {  // scal
 // same values, hence the same bits (rint(32 z) by the 1.5 * 2^52 shift: the same integer).  (+0) ** (a positive finite y) = +0 is
 // settled here as well.  Anything else (a negative or subnormal base, -0, inf / NaN anywhere, |y log2 x| beyond 125) is
 // `special`: Machine::apply_powf runs the common case for ALL its values first and then asks once per wave.
-__device__ __forceinline__ float powf_common(float xf, float yf, bool& special) {
+__device__ __forceinline__ float powf_common(float xf, float yf, bool& special, const PowfLds* T) {
   const unsigned ix = __float_as_uint(xf), ay = __float_as_uint(yf) & 0x7fffffffu;
   const bool base_ok = ix - 0x00800000u < 0x7f800000u - 0x00800000u;  // positive, normal, finite
-  const double zz = (double)yf * log2_of_normal_f32<5>(base_ok ? ix : 0x3f800000u);
+  const double zz = (double)yf * log2_of_normal_f32<5>(base_ok ? ix : 0x3f800000u, T->log2_tab);
   const bool ordinary = base_ok & (ay < 0x7f800000u) & (fabs(zz) <= 125.0);  // (NaN compares false)
   const bool zero = (ix == 0u) & (yf > 0.0f) & (ay < 0x7f800000u);
   // 2^zz as in exp2_to_f32 (a zz out of range gives garbage that `special` replaces; the table index is masked)
@@ -545,7 +566,7 @@ __device__ __forceinline__ float powf_common(float xf, float yf, bool& special) 
   q = fma(rr, q, POWF_EXP2_L[1]);
   q = fma(rr, q, POWF_EXP2_L[0]);
   q = fma(rr, q, 1.0);
-  const long long scaled = __double_as_longlong(POWF_EXP2_TAB[ki & 31]) + ((long long)(ki >> 5) << 52);
+  const long long scaled = __double_as_longlong(T->exp2_tab[ki & 31]) + ((long long)(ki >> 5) << 52);
   const float out = (float)(__longlong_as_double(scaled) * q);
   special = !(ordinary | zero);
   return zero ? 0.0f : out;
@@ -746,6 +767,7 @@ struct Machine {
       const float b_lit = scalar_of<RC>(S.b.value);
       const float b_ndv = opd_has_ndv(S.b) ? b_lit : __builtin_nanf("");
       const float fill = scalar_of<RC>(S.fill);
+      const PowfLds* const tables = powf_lds();
       float xs[N], ys[N], r[N];
       bool bad[N], special[N], any = false;
 #pragma unroll
@@ -754,7 +776,7 @@ struct Machine {
         if constexpr (!B_SCALAR) bad[k] = bad[k] | (b[k] == b_ndv);
         xs[k] = bad[k] ? 1.0f : acc[k];
         ys[k] = B_SCALAR ? b_lit : (bad[k] ? 1.0f : b[k]);
-        r[k] = powf_common(xs[k], ys[k], special[k]);
+        r[k] = powf_common(xs[k], ys[k], special[k], tables);
         any = any | special[k];
       }
       if (__builtin_amdgcn_ballot_w64(any)) {
@@ -770,13 +792,14 @@ struct Machine {
     if constexpr (std::is_same<RC, float>::value) {
       const float a_ndv = opd_has_ndv(S.a) ? scalar_of<RC>(S.a.value) : __builtin_nanf("");
       const float fill = scalar_of<RC>(S.fill);
+      const PowfLds* const tables = powf_lds();
       float xs[N], r[N];
       bool bad[N], special[N], any = false;
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         bad[k] = (acc[k] == a_ndv);
         xs[k] = bad[k] ? 1.0f : acc[k];
-        r[k] = logf_common(xs[k], scale, special[k]);
+        r[k] = logf_common(xs[k], scale, special[k], tables);
         any = any | special[k];
       }
       if (__builtin_amdgcn_ballot_w64(any)) {
@@ -1535,6 +1558,12 @@ __device__ __forceinline__ void vm_body() {
       }
     }
   }
+  if constexpr (FLAVOR == VM_MATH && std::is_same<RC, float>::value) {
+    if (span == 0) {  // the tables of np.power / np.log into LDS while the tile loads are in flight
+      powf_lds_stage();
+      __syncthreads();
+    }
+  }
   if constexpr (FLAVOR == VM_TABLES) {
     const unsigned lds_table = PROG::lds_table(K);
     if (lds_table) {
@@ -1626,6 +1655,10 @@ __global__ __launch_bounds__(256) void vm_tail_kernel(const VmLaunch) {
   void* const out = kload<void*>(K, offsetof(VmLaunch, out) + sizeof(void*) * tile);
   const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
+  if constexpr (FLAVOR == VM_MATH && std::is_same<RC, float>::value) {
+    powf_lds_stage();
+    __syncthreads();
+  }
   if constexpr (FLAVOR == VM_TABLES) {
     const unsigned lds_table = GM_KARG(K, lds_table);
     if (lds_table) {  // the LOOKUP window lives in LDS here as well
