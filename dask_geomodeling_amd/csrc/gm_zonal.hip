@@ -1067,13 +1067,14 @@ __global__ __launch_bounds__(256) void zonal_compose_kernel(const typename Order
     return ((long long)__builtin_amdgcn_readlane((int)(mine64 >> 32), i) << 32) | (unsigned)__builtin_amdgcn_readlane((int)mine64, i);
   };
   to_integer();
-  // Groups of 64 x PER blocks, a lane holding PER consecutive ones (the next group's descriptions are requested before this
-  // group is worked on).  Every block is a function parity -> (units added, parity left): a lane composes its own blocks,
-  // the wave composes the lanes' functions in lane order (six shuffle steps), every lane then knows the sum ENTERING its
-  // first block and walks its blocks, testing each one's validity for the sum entering it; up to the first block that
-  // fails all are one addition, that block is added literally, and the rest of the group is composed again from the sum
-  // it leaves.  (One label over the default raster limit, 49 152 blocks, 16 of them literal: 743 us at one block per lane
-  // and nothing requested ahead.)
+  // Groups of 64 x PER blocks, a lane holding PER consecutive ones (the descriptions of the next group that is sure to be
+  // walked are requested while the groups before it go by).  Every block is a function parity -> (units added, parity left):
+  // a lane composes its own blocks, the wave composes the lanes' functions in lane order (six steps of data-parallel
+  // primitives), every lane then knows the sum ENTERING its first block and walks its blocks, testing each one's validity
+  // for the sum entering it; up to the first block that fails all are one addition; that block -- and, in one lane-parallel
+  // step, the run of blocks behind it that the exactness certificates cover -- is certified exact or added literally, and the
+  // rest of the group is composed again from the sum they leave.  (One label over the default raster limit, 49 152 blocks, 16 of
+  // them literal: 743 us at one block per lane and nothing requested ahead; round 5: 148 us for one label of zero-mean noise.)
   constexpr int PER = 4;
   // (with a block's description come the three numbers of its exactness certificate: asked for only when a block is turned
   //  away they were two dependent memory round trips per such block -- ~2.5 us, 164 times for one label of noise over the
