@@ -3168,9 +3168,58 @@ __global__ __launch_bounds__(256) void zonal_chunk_combine_kernel(const T* __res
       *entry_out = entry;
       return rec;
     };
+    unsigned b0 = 0;
+    // Labels of many chunks (a few labels covering the raster) first try 256 chunks per test, a lane holding FOUR consecutive
+    // ones: the lane composes its four in order -- running total, extreme partial sums -- and the wave's reductions, which are
+    // most of a test's ~3 000 cycles, run once per 256 chunks.  (One label of positive cells over 12.6 M cells, 4096 chunks: the
+    // wave of this kernel 90 -> 25 us.)  The first such batch that does not go as one leaves the rest to the batches of 64 below.
+    if (n_list >= 128u) {
+      auto fetch_four = [&](unsigned at, ChunkRec (&four)[4]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned i = at + 4u * (unsigned)lane + (unsigned)c;
+          const unsigned e = i < n_list ? list[i] : 0u;
+          ChunkRec r{};
+          r.hi = SHRT_MIN;
+          r.lo = SHRT_MAX;
+          if (e) r = records[(size_t)(e >> 8) * ZC_SLOTS + (e & 0xffu) - 1];
+          four[c] = r;
+        }
+      };
+      ChunkRec four_next[4];
+      fetch_four(0u, four_next);
+      for (; b0 < n_list; b0 += 256u) {
+        ChunkRec four[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) four[c] = four_next[c];
+        if (b0 + 256u < n_list) fetch_four(b0 + 256u, four_next);  // (wave-uniform)
+        const double inf = __builtin_huge_val();
+        double run = 0.0, lane_below = inf, lane_above = -inf;
+        int lane_low = INT_MAX, lane_top = INT_MIN;
+        unsigned lane_count = 0u;
+        bool lane_bad = false;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          lane_below = fmin(lane_below, run + (double)four[c].low);
+          lane_above = fmax(lane_above, run + (double)four[c].high);
+          run += four[c].total;
+          if (four[c].lo != SHRT_MAX) lane_low = min(lane_low, (int)four[c].lo);
+          if (four[c].hi != SHRT_MIN) lane_top = max(lane_top, (int)four[c].hi);
+          lane_count += four[c].count;
+          lane_bad = lane_bad || four[c].bad != 0;
+        }
+        const int low = wave_min(lane_low), top = wave_max(lane_top);
+        const double before = wave_scan_f64(run) - run;
+        const double below = wave_min_f64(before + lane_below), above = wave_max_f64(before + lane_above);
+        if (__ballot(lane_bad) != 0 || !additions_exact(acc, top, low, 0x7fffffffu, below, above)) break;  // (wave-uniform)
+        acc += wave_sum_exact(run);
+        n_total += wave_sum_u32(lane_count);
+      }
+    }
     unsigned entry_next = 0u;
-    ChunkRec rec_next = fetch_batch(0u, &entry_next);
-    for (unsigned b0 = 0; b0 < n_list; b0 += 64) {
+    ChunkRec rec_next{};
+    if (b0 < n_list) rec_next = fetch_batch(b0, &entry_next);  // (wave-uniform)
+    for (; b0 < n_list; b0 += 64) {
       const unsigned entry = entry_next;
       const ChunkRec rec = rec_next;
       if (b0 + 64 < n_list) rec_next = fetch_batch(b0 + 64, &entry_next);  // (wave-uniform)
