@@ -1,9 +1,9 @@
 """Tiles of more than 2^31 cells through the kernels of the next rows (GPU box; ~45 GB of host memory, ~35 GB on the device):
 temporal statistics and Cumulative over 40 frames of 8192^2 float32 cells; MovingMax / Dilate / HillShade / Smooth over 9 bands of
-16384^2; bilinear and nearest results of 3 bands of 32768^2.  Windows of the device results against the oracle / NumPy on host
+16384^2; bilinear and nearest results of 3 bands of 32768^2; reduce_rasters over 40 rasters of 8192^2.  Windows of the device results against the oracle / NumPy on host
 copies of the same windows (the statistics are per cell across the frames; the stencils and resamplings are local): a kernel either
 answers right or refuses loudly -- an index that wraps at 2^31 or 2^32 would do neither.
-python tests/beyond_2_31_driver.py [parts: temporal,stencils,resample]; prints 'BEYOND 2^31 ok <checks>'."""
+python tests/beyond_2_31_driver.py [parts: temporal,stencils,resample,stacks]; prints 'BEYOND 2^31 ok <checks>'."""
 import os
 import sys
 import time
@@ -20,7 +20,7 @@ from dask_geomodeling_amd.hip.array import DeviceArray  # noqa: E402
 from dask_geomodeling_amd.raster import temporal  # noqa: E402
 
 runtime.set_device(0)
-parts = sys.argv[1].split(",") if len(sys.argv) > 1 else ["temporal", "stencils", "resample"]
+parts = sys.argv[1].split(",") if len(sys.argv) > 1 else ["temporal", "stencils", "resample", "stacks"]
 checks = 0
 rng = np.random.default_rng(31)
 
@@ -183,4 +183,24 @@ if "resample" in parts:
             assert eq.all(), "nearest window (%d, %d): %d cells differ" % (r0, c0, (~eq).sum())
             checks += 1
         print("nearest windows ok", flush=True)
+if "stacks" in parts:
+    from dask_geomodeling_amd.raster.reduction import reduce_rasters
+    side, n = 8192, 40
+    ndv = np.float32(-9999.0)
+    base = (rng.standard_normal((4, 1, side, side)) * 100).astype("f4")
+    base[rng.random(base.shape) < 0.15] = ndv
+    host = [np.roll(base[i % 4], 7 * i, axis=2) for i in range(n)]
+    stack = [{"values": DeviceArray.from_numpy(h), "no_data_value": ndv} for h in host]
+    print("cells in the stack:", n * side * side, "= 2^31 x %.2f" % (n * side * side / 2.0 ** 31), flush=True)
+    for stat in ("sum", "max", "count", "median", "p90"):
+        got = attempt("reduce_rasters %s" % stat, lambda: np.asarray(reduce_rasters([dict(d) for d in stack], stat)["values"]))
+        if got is None:
+            continue
+        for r0, c0 in ((0, 0), (side - 48, side - 48), (5000, 7000)):
+            sub = [{"values": np.ascontiguousarray(h[:, r0:r0 + 48, c0:c0 + 48]), "no_data_value": ndv} for h in host]
+            with np.errstate(all="ignore"):
+                want = O.reduce_rasters(sub, stat)["values"]
+            assert_values_equal(got[:, r0:r0 + 48, c0:c0 + 48], want, 0, "reduce_rasters %s window (%d, %d)" % (stat, r0, c0))
+            checks += 1
+    print("stacks windows ok", flush=True)
 print("BEYOND 2^31 ok", checks)

@@ -2380,10 +2380,11 @@ def test_kernels_of_the_next_rows_at_the_sizes_they_are_timed_on(gpu, parts, che
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("part,checks", [("temporal", 40), ("stencils", 24), ("resample", 8)])
+@pytest.mark.parametrize("part,checks", [("temporal", 40), ("stencils", 24), ("resample", 8), ("stacks", 15)])
 def test_tiles_of_more_than_2_to_the_31_cells_through_the_next_rows(gpu, part, checks):
     """tests/beyond_2_31_driver.py: 40 frames of 8192^2 cells through the temporal statistics and Cumulative, 9 bands of 16384^2
-    through MovingMax / HillShade / Smooth / Dilate, bilinear and nearest results of 3 bands of 32768^2 -- windows at the far end
+    through MovingMax / HillShade / Smooth / Dilate, bilinear and nearest results of 3 bands of 32768^2, reduce_rasters over 40
+    rasters of 8192^2 -- windows at the far end
     of the results against the oracle.  (Needs ~45 GB of host memory: skipped on smaller hosts.)"""
     import os
     import subprocess
