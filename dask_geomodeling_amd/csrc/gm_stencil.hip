@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void dilate8_kernel(const unsigned char* __res
     if (emit) {
       unsigned char* o = out + ((size_t)b * oh + out_row) * ow + c4;
       if (c4 + 4 <= ow) {
-        __builtin_memcpy(o, &result, 4);
+        typedef unsigned u32u __attribute__((aligned(1)));
+        __builtin_nontemporal_store(result, (u32u*)o);
       } else {
         for (int j = 0; c4 + j < ow; ++j) o[j] = (unsigned char)(result >> (8 * j));
       }
@@ -411,7 +412,10 @@ __global__ __launch_bounds__(256) void dilate8_wide_kernel(const unsigned char* 
         //  pieces by the row's phase (2 + 4 + 2 bytes ...: no faster than the hardware's own split) and rotating
         //  the column segment with the tile row so that an XCD does not stay on one segment (no effect: it is not
         //  the channel aliasing of 8 KiB pitches suspected in round 2).)
-        __builtin_memcpy(o, result, 8);
+        // (past the caches, like the other kernels' results: 8192-wide 37.5 -> 33.8 us, the 8194-wide tile of a Block 31.6 -> 29.3)
+        typedef unsigned u32x2u __attribute__((ext_vector_type(2), aligned(1)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(u32x2{result[0], result[1]}, (u32x2u*)o);
       } else {
         for (int j = 0; c8 + j < ow; ++j) o[j] = (unsigned char)(result[j >> 2] >> (8 * (j & 3)));
       }
@@ -1512,7 +1516,10 @@ __global__ __launch_bounds__(256) void gauss2d_kernel(const float* __restrict__ 
     }
     float* o = out + (size_t)b * oh * ow + (size_t)(oy0 + r) * opitch + ox;
     if (ox + 8 <= ow) {
-      __builtin_memcpy(o, res, 32);
+      // (the result is not read again: past the caches, like every other kernel's; rows of any alignment)
+      typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+      __builtin_nontemporal_store(f32x4{res[0], res[1], res[2], res[3]}, (f32x4u*)o);
+      __builtin_nontemporal_store(f32x4{res[4], res[5], res[6], res[7]}, (f32x4u*)(o + 4));
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k)  // (static indices: a loop over `res` would move the array into LDS)
