@@ -665,16 +665,18 @@ int gm_resample_bilinear_window(const void* src, int dtype, int bands, int hs, i
   const int per = 16 / itemsize;
   const bool vec_src = (ws % per) == 0 && (src_pitch % per) == 0 && ((uintptr_t)src % 16) == 0;
   win_w = vec_src ? ((win_w + per - 1 + per - 1) / per) * per : (win_w | 1);
-  // From a zoom of 2.75 on the taps are read through the caches instead (a destination row of a lane touches two source cells
+  // From a zoom of 3.5 on the taps are read through the caches instead (a destination row of a lane touches two source cells
   // or three, a wave ~100 consecutive ones, and every source row feeds several destination rows out of registers): no staging
   // phase, no barrier, every wave on its own -- 12288^2 results (tools/bilinear_zoom_sweep.py): 3 x 142 -> 117 us, 4 x 153 -> 101,
   // 6 x 136 -> 96; at 2.5 x the two routes meet (150 / 155), below that the staged window wins by as
   // much (1.5 x: 161 against 304).  GM_BL_STAGED=0 / 1 forces a route (tuning runs).
   static const int staged_cfg = getenv("GM_BL_STAGED") ? atoi(getenv("GM_BL_STAGED")) : -1;
-  // (the threshold: first drawn at 2.5 x, where the two routes seemed to meet; over four sweeps on three boxes -- single runs differ
-  //  by +- 10 % -- the staged window takes 123-138 us at 2.5 x against 150-161, and the direct route 110-114 at 3 x against
-  //  114-127: between the two.  The direct route's taps requested a source row ahead were slower: 3 x 112 -> 131, 4 x 95 -> 115.)
-  const bool direct = staged_cfg < 0 ? (2.75 * sy <= 1.0 && 2.75 * sx <= 1.0) : staged_cfg == 0;
+  // (the threshold: first drawn at 2.5 x.  Single runs of either route differ by +- 10 % and more with the state of the part; over four
+  //  sweeps, each configuration in a fresh process, the staged window takes 123-138 us at 2.5 x against 150-161, 114-127 at 3 x
+  //  against 110-114, 108-118 at 4 x against 94-102 -- but inside the long run of tools/kbench.py the direct route's 3 x is 144-160
+  //  and its 4 x 114-132, the staged window's 3 x 132: the window staged in LDS is the steadier of the two, the taps through the
+  //  caches follow the clocks.  Hence: direct from 3.5 x on.  Its taps requested a source row ahead were slower: 3 x 112 -> 131.)
+  const bool direct = staged_cfg < 0 ? (3.5 * sy <= 1.0 && 3.5 * sx <= 1.0) : staged_cfg == 0;
   const bool staged = !direct && win_h * win_w * itemsize <= BL_LDS_BYTES - 2048;
   const size_t lds = staged ? (size_t)(win_h * win_w * itemsize) : 0;
   // (GM_BL_SWZ=0: tiles dealt to the XCDs in launch order -- tuning runs; with the runs per XCD 1.5 x 157 -> 151 us, 3 x 135 -> 125,

@@ -349,7 +349,7 @@ def test_bilinear_vs_oracle(gpu, dt, shape):
 @pytest.mark.parametrize("route", ["product", "staged", "direct"])
 def test_bilinear_routes_vs_oracle(gpu, route):
     """The general bilinear kernel's two routes (round 5: the source window staged in LDS, or the taps read through the caches --
-    the product takes the second from a zoom of 2.75 on) and its stores onto rows that do not start on 16 bytes, over several
+    the product takes the second from a zoom of 3.5 on) and its stores onto rows that do not start on 16 bytes, over several
     workgroups per tile and with no-data cells sprinkled in: against the oracle within 1 ulp, in a process of its own per route
     (the route is read from the environment once)."""
     import os
