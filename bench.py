@@ -42,6 +42,9 @@ F32MAX = float(np.finfo("f4").max)
 LATTICE = (97, 89)
 
 
+MOSAIC_SIDE_DEFAULT = 65536
+
+
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -68,6 +71,14 @@ def parse_args():
                         "holds the four whole 16 GiB leaves as MemorySources (tiles = zero-copy windows); "
                         "procedural = every window is regenerated on the fly inside the timed region")
     p.add_argument("--procedural", action="store_true", help="same as --leaves procedural")
+    p.add_argument("--mosaic-side", type=int, default=MOSAIC_SIDE_DEFAULT,
+                   help="mosaic only: side of the whole mosaic (65536 = BASELINE configs[4]; small mosaics of small tiles leave "
+                        "the GPU idle and time the HOST side of the scheduler, e.g. --mosaic-side 4096 --side 256)")
+    p.add_argument("--no-affinity", action="store_true",
+                   help="mosaic only: workers are not pinned to the cores next to their GPU (geomodeling.worker-affinity off)")
+    p.add_argument("--no-mosaic-curve", action="store_true",
+                   help="--gpus N > 1: skip the strong-scaling mosaic over the N GPUs that rank 0 runs after the weak-scaling "
+                        "headline (secondary.mosaic)")
     p.add_argument("--dry-run", action="store_true",
                    help="exercise the multi-rank timing harness without a GPU (every tile is a 0.2 ms sleep); "
                         "used by the CPU gloo test, never a measurement")
@@ -155,7 +166,7 @@ def build_tiler(raster, side, tile, rank):
 MOSAIC_SIDE = 65536
 
 
-def mosaic_view(raster, leaves="owned"):
+def mosaic_view(raster, leaves="owned", mosaic_side=MOSAIC_SIDE):
     """configs[4]: 10 Blocks (Add, Multiply, Subtract, Divide, Greater, Clip, Classify, Reclassify, Mask
     under a RasterTiler) over four float32 leaves of a 65536^2 mosaic.  leaves: "owned" = procedural
     sources that keep every window they served resident, so a rank holds the leaf windows of ITS tiles
@@ -165,11 +176,11 @@ def mosaic_view(raster, leaves="owned"):
 
     def leaf(seed):
         if leaves == "whole":
-            data = generate_window((MOSAIC_SIDE, MOSAIC_SIDE), "f4", seed, 0.0, 100.0, F32MAX, LATTICE, 0, 0,
-                                   MOSAIC_SIDE, MOSAIC_SIDE)
-            return raster.MemorySource(data, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(MOSAIC_SIDE)))
-        return raster.SyntheticSource((MOSAIC_SIDE, MOSAIC_SIDE), "f4", seed, 0.0, 100.0, F32MAX, LATTICE,
-                                      "EPSG:28992", 1.0, (0.0, float(MOSAIC_SIDE)), resident=(leaves == "owned"))
+            data = generate_window((mosaic_side, mosaic_side), "f4", seed, 0.0, 100.0, F32MAX, LATTICE, 0, 0,
+                                   mosaic_side, mosaic_side)
+            return raster.MemorySource(data, np.float32(F32MAX), "EPSG:28992", 1.0, (0.0, float(mosaic_side)))
+        return raster.SyntheticSource((mosaic_side, mosaic_side), "f4", seed, 0.0, 100.0, F32MAX, LATTICE,
+                                      "EPSG:28992", 1.0, (0.0, float(mosaic_side)), resident=(leaves == "owned"))
     A, B, C, D = leaf(11), leaf(12), leaf(13), leaf(14)
     x = raster.Divide(raster.Subtract(raster.Multiply(raster.Add(A, B), 0.5), C), 2.0)
     x = raster.Clip(x, raster.Greater(D, 20.0))
@@ -512,16 +523,22 @@ def secondary_line(name, raster, runtime, P, get_sync, steps, warmup):
             "kernel": kernel, "traffic": traffic, "traffic_source": traffic_src}
 
 
-def mosaic_through_the_scheduler(devices, side, steps, warmup, leaves, e2e=True):
+def mosaic_through_the_scheduler(devices, side, steps, warmup, leaves, e2e=True, mosaic_side=MOSAIC_SIDE):
     """BASELINE configs[4] through the PRODUCT's one-worker-per-GPU scheduler (dask_geomodeling_amd/shard.py): this process
     only deals -- RasterTiler(view, side).get_data over the whole 65536^2 box with geomodeling.devices = `devices`, results left
     on the GPUs that computed them --, every worker process fuses and runs the tiles t % G it owns and keeps the leaf windows
-    of those tiles resident.  A step = one such request; it returns when every worker's stream is empty.  -> result fields."""
+    of those tiles resident.  A step = one such request; it returns when every worker's stream is empty.  -> result fields.
+    STRONG scaling: the mosaic is the same whatever G is.  Besides the rate the line says what the host side costs per step:
+    `parent_us_per_step` (wall time of the parent's get_data call: two small messages per worker, sent and collected by one
+    thread; includes waiting for the slowest worker's reply), `parent_cpu_us_per_step` (the parent's own CPU time in it),
+    `worker_host_us_per_step` (per worker: wall time between a request's arrival and its reply -- leaf windows, arguments,
+    launches queued) and `device_ms_per_step` per worker (HIP events on its compute stream): a step is device-bound as long
+    as parent + slowest worker host time stay well under the slowest device time."""
     from dask_geomodeling_amd import raster, shard
     G = len(devices)
-    tiler = raster.RasterTiler(mosaic_view(raster, leaves), side)
-    whole = dict(mode="vals", bbox=(0.0, 0.0, float(MOSAIC_SIDE), float(MOSAIC_SIDE)), width=MOSAIC_SIDE,
-                 height=MOSAIC_SIDE, projection="EPSG:28992")
+    tiler = raster.RasterTiler(mosaic_view(raster, leaves, mosaic_side), side)
+    whole = dict(mode="vals", bbox=(0.0, 0.0, float(mosaic_side), float(mosaic_side)), width=mosaic_side,
+                 height=mosaic_side, projection="EPSG:28992")
     pool = shard.pool_for(devices)
 
     def step():
@@ -542,15 +559,22 @@ def mosaic_through_the_scheduler(devices, side, steps, warmup, leaves, e2e=True)
         step()
     pool.sync()
     before = pool.request({w: ("spec_wait",) for w in everybody}, what="kernel statistics")
+    pool.request({w: ("host_stats", True) for w in everybody}, what="host-time counters")
     pool.request({w: ("mark",) for w in everybody}, what="timing marks")   # a HIP event on every worker's compute stream
+    in_step = in_step_cpu = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
+        t1, c1 = time.perf_counter(), time.thread_time()
         step()
+        in_step += time.perf_counter() - t1
+        in_step_cpu += time.thread_time() - c1
     pool.sync()
     elapsed = time.perf_counter() - t0
-    device_ms = max(ms for ms in pool.request({w: ("elapsed",) for w in everybody}, what="timing marks").values())
+    per_worker_ms = pool.request({w: ("elapsed",) for w in everybody}, what="timing marks")
+    device_ms = max(per_worker_ms.values())
+    host = pool.request({w: ("host_stats",) for w in everybody}, what="host-time counters")
     spec = pool.request({w: ("spec_wait",) for w in everybody}, what="kernel statistics")
-    n_tiles = (MOSAIC_SIDE // side) ** 2
+    n_tiles = (mosaic_side // side) ** 2
     per_worker = (n_tiles + G - 1) // G
     per_launch, bytes_px, dtype, kernel = MODEL["mosaic"]
     tiles_per_launch = min(per_worker, per_launch)
@@ -560,16 +584,23 @@ def mosaic_through_the_scheduler(devices, side, steps, warmup, leaves, e2e=True)
     launch_us = device_ms / (steps * launches) * 1e3
     launch_bytes = bytes_px * side * side * tiles_per_launch
     traffic, traffic_src = pmc_traffic("mosaic", tiles_per_launch)
-    out = {"workload": "BASELINE configs[4]: 10-Block view over the 65536^2 mosaic, %d tiles of %dx%d dealt t %% %d over %d worker "
+    out = {"workload": "BASELINE configs[4]: 10-Block view over the %d^2 mosaic, %d tiles of %dx%d dealt t %% %d over %d worker "
                        "process(es) by dask_geomodeling_amd.shard (leaves '%s'), results left on the devices"
-                       % (n_tiles, side, side, G, G, leaves),
-           "value": round(MOSAIC_SIDE * MOSAIC_SIDE * steps / elapsed / 1e6, 1), "unit": "Mpix/s", "steps": steps,
+                       % (mosaic_side, n_tiles, side, side, G, G, leaves),
+           "value": round(mosaic_side * mosaic_side * steps / elapsed / 1e6, 1), "unit": "Mpix/s", "steps": steps,
            "ms_per_step": round(elapsed / steps * 1e3, 4), "device_ms_per_step": round(device_ms / steps, 4),
            "avg_launch_us": round(launch_us, 2), "launches_per_step_per_worker": launches, "tiles_per_worker": per_worker,
            "dtype": dtype, "bytes_per_px": bytes_px, "algorithmic_bytes_per_launch": launch_bytes,
            "achieved_GBps": round(launch_bytes / launch_us / 1e3, 1), "frac": round(launch_bytes / launch_us / 1e3 / HBM_PEAK_GBS, 4),
            "kernel": kernel, "traffic": traffic, "traffic_source": traffic_src, "workers": G,
-           "worker_devices": ["%d:%s" % (d, n) for d, n in zip(devices, pool.device_names)]}
+           "worker_devices": ["%d:%s" % (d, n) for d, n in zip(devices, pool.device_names)],
+           "scaling": "strong", "mosaic": [mosaic_side, mosaic_side], "tiles": n_tiles,
+           "per_worker_device_ms_per_step": [round(per_worker_ms[w] / steps, 4) for w in everybody],
+           "parent_us_per_step": round(in_step / steps * 1e6, 1), "parent_cpu_us_per_step": round(in_step_cpu / steps * 1e6, 1),
+           "worker_host_us_per_step": [round(host[w]["wall_s"] / max(host[w]["runs"], 1) * 1e6, 1) for w in everybody],
+           "worker_host_cpu_us_per_step": [round(host[w]["cpu_s"] / max(host[w]["runs"], 1) * 1e6, 1) for w in everybody],
+           "worker_cpus": [None if host[w]["cpus"] is None else len(host[w]["cpus"]) for w in everybody],
+           "host_over_device": round((in_step / steps * 1e3) / max(device_ms / steps, 1e-9), 4)}
     if e2e:
         # what an ndarray-returning caller gets: the 4 GiB uint8 mosaic assembled on the host, every worker copying its tiles
         # device-to-host straight to their place of a shared-memory mosaic it has pinned (the first request pins)
@@ -582,10 +613,23 @@ def mosaic_through_the_scheduler(devices, side, steps, warmup, leaves, e2e=True)
                 shape = tuple(got["values"].shape)
                 del got
             out["to_host_ms"] = {"first_request": timings[0], "second_request": timings[1], "shape": shape,
-                                 "GBps_second": round(MOSAIC_SIDE ** 2 / timings[1] / 1e6, 1)}
+                                 "GBps_second": round(mosaic_side ** 2 / timings[1] / 1e6, 1)}
         except Exception as e:  # noqa: BLE001 -- e.g. a box whose /dev/shm cannot hold 4 GiB: reported, the timed line stands
             out["to_host_ms"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     return out
+
+
+def dry_mosaic_line(world, steps):
+    """Harness test only (--dry-run): the shape of secondary.mosaic at N ranks without a GPU -- a step is a 2 ms sleep / N."""
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        time.sleep(0.002 / world)
+    elapsed = time.perf_counter() - t0
+    return {"workload": "DRY RUN (no GPU work, harness test only)", "value": round(MOSAIC_SIDE ** 2 * steps / elapsed / 1e6, 1),
+            "unit": "Mpix/s", "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4), "scaling": "strong",
+            "workers": world, "worker_devices": ["%d:dry" % g for g in range(world)],
+            "per_worker_device_ms_per_step": [0.0] * world, "parent_us_per_step": 0.0,
+            "worker_host_us_per_step": [0.0] * world}
 
 
 def main_mosaic(args):
@@ -604,8 +648,12 @@ def main_mosaic(args):
     if visible <= 0:
         raise SystemExit("bench: no HIP device visible")
     devices = tuple(g % visible for g in range(max(args.gpus, 1)))  # (more workers than GPUs share them: the 1-GPU test box)
+    if args.no_affinity:
+        from dask_geomodeling_amd import config as gm_config
+        gm_config.config.set({"geomodeling.worker-affinity": False})
     try:
-        line = mosaic_through_the_scheduler(devices, side, args.steps, args.warmup, leaves, e2e=not args.no_e2e)
+        line = mosaic_through_the_scheduler(devices, side, args.steps, args.warmup, leaves, e2e=not args.no_e2e,
+                                            mosaic_side=args.mosaic_side)
     finally:
         shard.shutdown()
     out = {"metric": "Mpix/s, workload mosaic", "value": line["value"], "unit": "Mpix/s", "n_gpus": len(devices),
@@ -621,7 +669,10 @@ def main_mosaic(args):
                         "avg_launch_us": line["avg_launch_us"], "launches_per_step": line["launches_per_step_per_worker"],
                         "kernel_source_hash": kernel_source_hash()},
            "pct_of_hbm_roofline": round(100.0 * line["value"] * 1e6 * line["bytes_per_px"] / len(devices) / (HBM_PEAK_GBS * 1e9), 2),
-           "device_ms_per_step": line["device_ms_per_step"], "worker_devices": line["worker_devices"]}
+           "device_ms_per_step": line["device_ms_per_step"], "worker_devices": line["worker_devices"],
+           "host": {k: line[k] for k in ("parent_us_per_step", "parent_cpu_us_per_step", "worker_host_us_per_step",
+                                         "worker_host_cpu_us_per_step", "worker_cpus", "per_worker_device_ms_per_step",
+                                         "host_over_device")}}
     if "to_host_ms" in line:
         out["end_to_end"] = {"sharded_get_data_to_host": line["to_host_ms"]}
     print(json.dumps(out), flush=True)
@@ -866,6 +917,39 @@ def main():
                 runtime.sync()
                 runtime.pool_trim()
             out["secondary"] = secondary
+    if world > 1 and not args.no_mosaic_curve and args.workload == "chain5":
+        # The curve north_star asks for (BASELINE configs[4]: "tile tasks sharded 1/2/4/8 GPUs"): the headline above is WEAK
+        # scaling (every rank its own 16 tile pairs).  STRONG scaling of the one 65536^2 mosaic runs through the product's
+        # scheduler, which wants to be the parent of one worker per GPU: every rank gives its GPU's memory back, the ranks
+        # meet, the process group is dissolved (ranks other than 0 leave), and rank 0 -- now an ordinary parent -- deals the
+        # mosaic over the N GPUs and merges the result into its line as secondary.mosaic.
+        try:
+            del jobs
+        except NameError:
+            pass
+        if not args.dry_run:
+            runtime.sync()
+            runtime.pool_trim()
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
+        if rank == 0:
+            try:
+                if args.dry_run:
+                    line = dry_mosaic_line(world, args.secondary_steps)
+                else:
+                    from dask_geomodeling_amd import shard
+                    visible = runtime.device_count()
+                    try:
+                        line = mosaic_through_the_scheduler(tuple(g % visible for g in range(world)), 4096, args.secondary_steps,
+                                                            3, "owned", e2e=not args.no_e2e)
+                    finally:
+                        shard.shutdown()
+            except Exception as e:  # noqa: BLE001 -- the headline was measured and stands
+                line = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            out["secondary"] = {"mosaic": line}
+
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     if dist is not None:

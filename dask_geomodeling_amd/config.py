@@ -15,6 +15,9 @@ besides the reference's own keys this path adds:
                            tiles of a RasterTiler are dealt t % G over them, the host mosaic is assembled from their tiles
   geomodeling.worker-preload  "module:function" every such worker imports and calls before it binds its device (a
                            deployment's own Blocks)
+  geomodeling.worker-affinity  every such worker pins itself to the host cores next to its GPU (the PCI device's
+                           local_cpulist / NUMA node) before it binds the device (default True); workers that share a GPU's
+                           cores split them; False leaves placement to the operating system
   geomodeling.resident-window-bytes  bound of the per-device window cache of resident SyntheticSources (LRU)
 """
 import os
@@ -37,6 +40,7 @@ defaults = {
     "materialize": True,
     "devices": None,
     "worker-preload": None,
+    "worker-affinity": True,
     "resident-window-bytes": 192 << 30,
 }
 

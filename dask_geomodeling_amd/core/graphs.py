@@ -237,6 +237,142 @@ def get_sync(dsk, keys, pack_exception=None, **kwargs):
     return evaluate(keys)
 
 
+class _RunCache(dict):
+    """The results of one run; keys it does not hold are the kept (static) results of the PreparedGraph."""
+
+    __slots__ = ("kept",)
+
+    def __missing__(self, key):
+        return self.kept[key]
+
+
+def _is_resident_answer(value):
+    """A source's answer that is resident data as it stands (DeviceArray.resident): the same for the same task every time."""
+    if type(value) is dict:
+        values = value.get("values")
+        return values is not None and getattr(values, "resident", False) is True
+    return False
+
+
+class PreparedGraph(object):
+    """``get_sync(dsk, keys)`` for a graph that is evaluated again and again -- the fused job a worker of the one-worker-per-GPU
+    scheduler keeps for a (view, request), a prebuilt batch -- with everything that does not depend on the run done once:
+
+    * the look at the graph (plans, dependencies, evaluation order, when a result may be dropped) is kept;
+    * a task WITHOUT dependencies that answered with resident data as it stands (a source's zero-copy window, a kept procedural
+      window: ``DeviceArray.resident``) is not asked again: its answer is kept.  Nothing a kernel computed for the request is
+      ever kept: every launch of the first run happens in every run;
+    * a task all of whose dependencies are kept, and whose function offers ``gm_prepare(*arguments)``, is replaced by what that
+      returns: the same launches with their arguments marshalled once (fuse.BatchedTask.gm_prepare).
+
+    ``run()`` returns what ``get_sync(dsk, keys)`` returns.  Results are dropped as soon as their last consumer has run, as in
+    get_sync.  Not thread-safe: one run at a time (a worker serves one message at a time)."""
+
+    def __init__(self, dsk, keys):
+        self.keys = keys
+        self.wanted = list(keys) if isinstance(keys, list) else [keys]
+        plans, uses = {}, {}
+        stack = list(self.wanted)
+        while stack:
+            key = stack.pop()
+            if key in plans:
+                continue
+            needs = []
+            plans[key] = (_plan_of(dsk[key], dsk, needs), needs)
+            for d in needs:
+                uses[d] = uses.get(d, 0) + 1
+                if d not in plans:
+                    stack.append(d)
+        # evaluation order: get_sync's depth-first walk from the wanted keys, producers first
+        order, seen = [], set()
+        for target in self.wanted:
+            stack = [target]
+            while stack:
+                key = stack[-1]
+                if key in seen:
+                    stack.pop()
+                    continue
+                missing = [d for d in plans[key][1] if d not in seen]
+                if missing:
+                    stack.extend(missing)
+                    continue
+                seen.add(key)
+                order.append(key)
+                stack.pop()
+        self.plans, self.uses, self.order = plans, uses, order
+        self.kept = {}        # key -> kept answer
+        self.program = None   # [(key, plan, releases)] of the tasks that run every time, built by the first run
+        self.runs = 0
+
+    def _compile(self, first_results):
+        """After the first run: which tasks stay, with their arguments resolved as far as they are kept."""
+        plans, kept = self.plans, self.kept
+        for key in self.order:
+            if not plans[key][1] and _is_resident_answer(first_results.get(key)):
+                kept[key] = first_results[key]
+        live = [k for k in self.order if k not in kept]
+        # when a live result may go: after its last live consumer (wanted keys never)
+        remaining = {}
+        for key in live:
+            for d in plans[key][1]:
+                if d not in kept:
+                    remaining[d] = remaining.get(d, 0) + 1
+        for key in self.wanted:
+            remaining[key] = remaining.get(key, 0) + (1 << 30)
+        program = []
+        for key in live:
+            plan, needs = plans[key]
+            releases = []
+            for d in needs:
+                if d in kept:
+                    continue
+                remaining[d] -= 1
+                if remaining[d] == 0:
+                    releases.append(d)
+            if plan[0] == _FLAT:
+                func, args, at = plan[1], list(plan[2]), []
+                for i in plan[3]:
+                    if args[i] in kept:
+                        args[i] = kept[args[i]]
+                    else:
+                        at.append(i)
+                prepare = getattr(func, "gm_prepare", None)
+                if not at and prepare is not None:
+                    prepared = prepare(*args)
+                    if prepared is not None:
+                        func, args = prepared, []
+                plan = (_FLAT, func, tuple(args), tuple(at))
+            program.append((key, plan, tuple(releases)))
+        self.program = program
+
+    def run(self):
+        self.runs += 1
+        if self.program is None:
+            # the first run: get_sync's own walk; the answers of tasks without dependencies are remembered until the kept
+            # ones are picked, everything else goes when its last consumer has run
+            cache, pending = {}, dict(self.uses)
+            for key in self.wanted:
+                pending[key] = pending.get(key, 0) + 1
+            for key in self.order:
+                plan, needs = self.plans[key]
+                cache[key] = _run(plan, cache)
+                for d in needs:
+                    pending[d] -= 1
+                    if pending[d] == 0 and self.plans[d][1]:
+                        del cache[d]
+            self._compile(cache)
+        else:
+            cache = _RunCache()
+            cache.kept = self.kept
+            for key, plan, releases in self.program:
+                cache[key] = _run(plan, cache)
+                for d in releases:
+                    del cache[d]
+        if isinstance(self.keys, list):
+            return [cache[k] for k in self.keys]
+        return cache[self.keys]
+
+
 def _configured_get():
     """The scheduler ``compute`` hands a graph to (graphs.py:42-49): dask's configured one; else ``scheduler_get``; else --
     when ``geomodeling.devices`` lists devices -- the one-worker-per-GPU scheduler (shard.get); else the built-in one."""

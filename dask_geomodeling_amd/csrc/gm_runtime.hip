@@ -55,7 +55,68 @@ struct DeviceState {
   unsigned stagger_turn = 0;
   size_t in_use = 0, cached_bytes = 0;
   bool ready = false;
+  // GM_DEBUG_GUARD: what gm_malloc handed out -> (hipMalloc's block, bytes asked for, serial number)
+  struct Guarded {
+    void* base;
+    size_t bytes;
+    unsigned long long serial;
+  };
+  std::unordered_map<void*, Guarded> guarded;
 };
+
+// GM_DEBUG_GUARD=1 (debug canaries around device buffers).  Every block of gm_malloc is a hipMalloc of its
+// own -- no recycling -- with a poisoned red zone of kGuardZone bytes in front of it and one behind its LAST REQUESTED BYTE
+// (the pool's rounding is not the caller's to write into), and it comes filled with 0xFF bytes (float NaN / integer -1: a
+// kernel that reads what nobody wrote says so loudly instead of finding the previous tenant's tile).  The zones are checked
+// when the block is freed, at every gm_sync and by gm_guard_check; a violation is reported on stderr with the block's size,
+// serial number and the first overwritten byte, counted (gm_guard_check), and fails that gm_free / gm_sync with
+// GM_ERR_GUARD.  Freed blocks go straight back to the driver (hipFree): a kernel that still uses one faults.  Reads past the
+// end of a block are not caught (there are no guard pages); several kernels do read the cells behind a ragged row on purpose.
+constexpr size_t kGuardZone = 4096;
+constexpr unsigned char kGuardByte = 0xA5;
+static bool guard_mode() {
+  static const bool on = []() {
+    const char* e = getenv("GM_DEBUG_GUARD");
+    return e && atoi(e) != 0;
+  }();
+  return on;
+}
+static std::atomic<unsigned long long> g_guard_violations{0};
+static std::atomic<unsigned long long> g_guard_serial{0};
+
+// zones of one block against the poison byte (stream drained by the caller) -> number of violated zones
+static int guard_check_block(void* user, const DeviceState::Guarded& g) {
+  static thread_local std::vector<unsigned char> host;
+  const size_t tail = ((g.bytes + 255) / 256 * 256 - g.bytes) + kGuardZone;  // (up to the end of hipMalloc's block)
+  host.resize(kGuardZone + tail);
+  if (hipMemcpy(host.data(), g.base, kGuardZone, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(host.data() + kGuardZone, (char*)user + g.bytes, tail, hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int bad = 0;
+  for (int zone = 0; zone < 2; ++zone) {
+    const unsigned char* z = host.data() + (zone ? kGuardZone : 0);
+    const size_t n = zone ? tail : kGuardZone;
+    size_t first = n, last = 0, count = 0;
+    for (size_t i = 0; i < n; ++i)
+      if (z[i] != kGuardByte) {
+        if (first == n) first = i;
+        last = i;
+        ++count;
+      }
+    if (!count) continue;
+    ++bad;
+    g_guard_violations.fetch_add(1);
+    if (zone)
+      fprintf(stderr, "libgmhip GM_DEBUG_GUARD: block #%llu of %zu bytes at %p was written PAST ITS END: %zu bytes differ, the first %zu "
+              "and the last %zu bytes behind the block\n", g.serial, g.bytes, user, count, first, last);
+    else
+      fprintf(stderr, "libgmhip GM_DEBUG_GUARD: block #%llu of %zu bytes at %p was written BEFORE ITS START: %zu bytes differ, the "
+              "nearest %zu bytes in front of the block\n", g.serial, g.bytes, user, count, kGuardZone - last);
+  }
+  return bad;
+}
 
 // Tiles of one size come out of hipMalloc with identical low address bits: cell i of A, of B and of the result then
 // sit at the same place of the channel / bank interleave, and a 2-read + 1-write stream keeps three rows of the same
@@ -233,6 +294,14 @@ int gm_get_device(int* device) {
   return GM_OK;
 }
 
+int gm_device_pci_bus_id(int device, char* buf, size_t len) {
+  if (!buf || len < 13) return fail(GM_ERR_INVALID, "a PCI bus id needs 13 bytes");
+  if (int rc = usable()) return rc;
+  if (device < 0 || device >= g_ndev) return fail(GM_ERR_INVALID, "device %d out of range", device);
+  GM_HIP(hipDeviceGetPCIBusId(buf, (int)len, device));  // (no context on `device` is made for this)
+  return GM_OK;
+}
+
 int gm_device_name(char* buf, size_t len) {
   if (!buf || len == 0) return fail(GM_ERR_INVALID, "null buffer");
   DeviceState* d = nullptr;
@@ -253,6 +322,22 @@ int gm_malloc(void** ptr, size_t bytes) {
   if (rc) return rc;
   size_t sz = round_size(bytes);
   std::lock_guard<std::mutex> lk(d->mu);
+  if (guard_mode()) {
+    if (bytes == 0) bytes = 1;
+    const size_t body = (bytes + 255) / 256 * 256;
+    void* base = nullptr;
+    hipError_t e = hipMalloc(&base, kGuardZone + body + kGuardZone);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc (GM_DEBUG_GUARD)");
+    void* user = (char*)base + kGuardZone;
+    GM_HIP(hipMemsetAsync(base, kGuardByte, kGuardZone, d->stream));
+    GM_HIP(hipMemsetAsync(user, 0xFF, bytes, d->stream));
+    GM_HIP(hipMemsetAsync((char*)user + bytes, kGuardByte, body - bytes + kGuardZone, d->stream));
+    d->guarded[user] = DeviceState::Guarded{base, bytes, g_guard_serial.fetch_add(1) + 1};
+    d->live[user] = sz;
+    d->in_use += sz;
+    *ptr = user;
+    return GM_OK;
+  }
   auto it = d->cached.find(sz);
   if (it != d->cached.end()) {
     *ptr = it->second;
@@ -284,6 +369,19 @@ int gm_malloc(void** ptr, size_t bytes) {
   return GM_OK;
 }
 
+int gm_malloc_many(void** ptrs, int n, size_t bytes) {
+  if (!ptrs || n < 0) return fail(GM_ERR_INVALID, "gm_malloc_many: null table or negative count");
+  for (int i = 0; i < n; ++i) {
+    const int rc = gm_malloc(&ptrs[i], bytes);
+    if (rc != GM_OK) {  // (all or nothing)
+      for (int j = 0; j < i; ++j) (void)gm_free(ptrs[j]);
+      for (int j = 0; j < n; ++j) ptrs[j] = nullptr;
+      return rc;
+    }
+  }
+  return GM_OK;
+}
+
 int gm_free(void* ptr) {
   if (!ptr) return GM_OK;
   // the block may belong to any device: search the owner (few devices, cheap)
@@ -295,6 +393,20 @@ int gm_free(void* ptr) {
     size_t sz = it->second;
     d.live.erase(it);
     d.in_use -= sz;
+    auto g = d.guarded.find(ptr);
+    if (g != d.guarded.end()) {  // GM_DEBUG_GUARD: checked, then back to the driver (never recycled)
+      int bad = 0;
+      if (!forked()) {
+        (void)hipStreamSynchronize(d.stream);
+        bad = guard_check_block(ptr, g->second);
+        (void)hipFree(g->second.base);
+      }
+      const DeviceState::Guarded rec = g->second;
+      d.guarded.erase(g);
+      if (bad) return fail(GM_ERR_GUARD, "GM_DEBUG_GUARD: block #%llu of %zu bytes was written outside its bounds (see stderr)",
+                           rec.serial, rec.bytes);
+      return GM_OK;
+    }
     d.cached.emplace(sz, ptr);
     d.cached_bytes += sz;
     return GM_OK;
@@ -483,8 +595,38 @@ int gm_sync(void) {
   hipStream_t s = current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
   GM_HIP(hipStreamSynchronize(s));
+  if (guard_mode()) {
+    unsigned long long total = 0;
+    return gm_guard_check(&total);
+  }
   return GM_OK;
 }
+
+int gm_guard_check(unsigned long long* violations_so_far) {
+  if (violations_so_far) *violations_so_far = g_guard_violations.load();
+  if (!guard_mode()) return GM_OK;
+  DeviceState* d = nullptr;
+  if (int rc = current(&d)) return rc;
+  int bad = 0;
+  {
+    std::lock_guard<std::mutex> lk(d->mu);
+    GM_HIP(hipStreamSynchronize(d->stream));
+    for (auto& kv : d->guarded) {
+      const int b = guard_check_block(kv.first, kv.second);
+      if (b) {  // (reported once: the zones are poisoned again)
+        const DeviceState::Guarded& g = kv.second;
+        (void)hipMemset(g.base, kGuardByte, kGuardZone);
+        (void)hipMemset((char*)kv.first + g.bytes, kGuardByte, (g.bytes + 255) / 256 * 256 - g.bytes + kGuardZone);
+      }
+      bad += b;
+    }
+  }
+  if (violations_so_far) *violations_so_far = g_guard_violations.load();
+  if (bad) return fail(GM_ERR_GUARD, "GM_DEBUG_GUARD: %d red zone(s) of live device blocks were overwritten (see stderr)", bad);
+  return GM_OK;
+}
+
+int gm_guard_enabled(void) { return guard_mode() ? 1 : 0; }
 
 int gm_event_create(void** event) {
   if (!event) return fail(GM_ERR_INVALID, "null pointer");

@@ -3459,8 +3459,9 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     unsigned char* slot_of = nullptr;
     StepRec* steps = nullptr;
     ChunkVerdict* verdict = nullptr;
-    int64_t sized_for = 0;
-    size_t table_for = 0;
+    // what each buffer holds room for: the three do not grow together (attempt 1 has four times the stretches of attempt 0
+    // but a quarter of the steps per stretch: a later frame's attempt 0 can need MORE step records than attempt 1 took)
+    size_t records_for = 0, table_for = 0, steps_for = 0;
   } chunk;
   const unsigned blocks = (unsigned)std::min<int64_t>((cells + 255) / 256, (int64_t)gm::current_cu_count() * 32);
   for (int64_t f = 0; f < frames; ++f) {
@@ -3565,12 +3566,18 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         //  stretch: an attempt for nothing -- stay with the per-label certificates, 465 us against 650.  GM_ZONAL_TABLE_MB for A/B runs)
         static const size_t table_limit = (size_t)(getenv("GM_ZONAL_TABLE_MB") ? atoll(getenv("GM_ZONAL_TABLE_MB")) : 128) << 20;
         if (table_bytes > table_limit) break;
-        if (!chunk.records || chunk.sized_for < n_stretch || chunk.table_for < table_bytes) {
-          if ((rc = scratch.take((void**)&chunk.records, sizeof(ChunkRec) * ZC_SLOTS * (size_t)n_stretch))) return rc;
+        const size_t n_records = ZC_SLOTS * (size_t)n_stretch, n_steps = (chunk_cells / ZC_STEP) * (size_t)n_stretch;
+        if (!chunk.records || chunk.records_for < n_records) {
+          if ((rc = scratch.take((void**)&chunk.records, sizeof(ChunkRec) * n_records))) return rc;
+          chunk.records_for = n_records;
+        }
+        if (!chunk.slot_of || chunk.table_for < table_bytes) {
           if ((rc = scratch.take((void**)&chunk.slot_of, table_bytes + 64))) return rc;  // (the verdict behind the table: one fill)
-          if ((rc = scratch.take((void**)&chunk.steps, sizeof(StepRec) * (chunk_cells / ZC_STEP) * (size_t)n_stretch))) return rc;
-          chunk.sized_for = n_stretch;
           chunk.table_for = table_bytes;
+        }
+        if (!chunk.steps || chunk.steps_for < n_steps) {
+          if ((rc = scratch.take((void**)&chunk.steps, sizeof(StepRec) * n_steps))) return rc;
+          chunk.steps_for = n_steps;
         }
         chunk.verdict = (ChunkVerdict*)(chunk.slot_of + table_bytes);
         GM_HIP(hipMemsetAsync(chunk.slot_of, 0, table_bytes + 64, s));

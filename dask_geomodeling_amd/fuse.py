@@ -334,6 +334,40 @@ class BatchedTask(object):
         return results
 
 
+    def gm_prepare(self, *all_leaf_values):
+        """What ``run`` does per call that does not depend on the call when every leaf value is the same object every time (the
+        resident windows a kept job reads: core/graphs.py PreparedGraph) -> a callable without arguments that allocates the
+        result tiles and launches, or None where ``run`` is needed (tiles that do not fuse, programs in several stages)."""
+        k = self.n_leaves
+        per_tile = [all_leaf_values[i * k:(i + 1) * k] for i in range(len(self.tasks))]
+        rep = self.tasks[0]
+        groups = {}
+        for i, values in enumerate(per_tile):
+            hit = rep.plan_for(values)
+            if hit is None or len(hit[0]) != 1:
+                return None
+            groups.setdefault(id(hit), (hit, []))[1].append(i)
+        launches = []
+        for hit, members in groups.values():
+            (compiled, binding), = hit[0]
+            tiles = [[P.as_device_view(per_tile[i][ref]["values"]) if kind == 0 else P.as_device(ref) for kind, ref in binding]
+                     for i in members]
+            prepared = P.prepare_batch(compiled, tiles, hit[1])
+            if prepared is None:
+                return None
+            launches.append((prepared, members, compiled.out_ndv))
+        n = len(per_tile)
+
+        def run():
+            results = [None] * n
+            for prepared, members, ndv in launches:
+                for i, out in zip(members, prepared.run()):
+                    results[i] = {"values": out, "no_data_value": ndv}
+            return results
+
+        return run
+
+
 def _getitem(seq, index):
     return seq[index]
 

@@ -18,7 +18,7 @@ from .dtypes import code_of
 
 
 class DeviceArray:
-    __slots__ = ("ptr", "shape", "dtype", "device", "_owner", "pitch", "band_pitch", "__weakref__")
+    __slots__ = ("ptr", "shape", "dtype", "device", "_owner", "pitch", "band_pitch", "resident", "__weakref__")
 
     def __init__(self, ptr, shape, dtype, device, owner=None, pitch=None, band_pitch=None):
         self.ptr = ptr
@@ -26,6 +26,10 @@ class DeviceArray:
         self.dtype = np.dtype(dtype)
         self.device = device
         self._owner = owner  # keeps a parent allocation alive for views
+        # a source's answer that IS resident data (a source raster on the device, a zero-copy window of one, a kept procedural
+        # window): the same bytes for the same request every time, so a kept evaluation (core/graphs.py PreparedGraph) may keep
+        # the answer instead of asking again.  Never set on anything a kernel computed for the request.
+        self.resident = False
         # row pitch in elements of a window into a wider raster; None = C-contiguous
         self.pitch = None if pitch is None or int(pitch) == self.shape[-1] else int(pitch)
         # cells between the bands of a window of several bands (the parent's plane); None: one band, or C-contiguous

@@ -961,6 +961,56 @@ def launch_batch(compiled, tiles, shape, outs=None):
     return outs
 
 
+class PreparedBatch(object):
+    """launch_batch with everything that does not change between calls done once: the same program over the same input tiles
+    (resident windows: immutable by contract) into FRESH result tiles.  What is left per call is one allocation call for the
+    result tiles, one launch call, and the DeviceArray objects that own the results.  Made by ``prepare_batch``."""
+
+    __slots__ = ("compiled", "inputs", "n_tiles", "shape", "nbytes", "ptrs", "pitches", "out_ptrs", "out_pitches", "rows", "cols",
+                 "n", "pitched", "program", "device", "dtype")
+
+    def run(self):
+        L = _lib()
+        n_tiles, out_ptrs = self.n_tiles, self.out_ptrs
+        runtime.check(L.gm_malloc_many(out_ptrs, n_tiles, self.nbytes), "gm_malloc_many")
+        shape, dtype, device = self.shape, self.dtype, self.device
+        outs = [DeviceArray(out_ptrs[i], shape, dtype, device) for i in range(n_tiles)]  # (own the blocks from here on)
+        if self.pitched:
+            runtime.check(L.gm_elemwise_run_batch_2d(self.program, n_tiles, self.ptrs, self.pitches, out_ptrs, self.out_pitches,
+                                                     self.rows, self.cols), "gm_elemwise_run_batch_2d")
+        else:
+            runtime.check(L.gm_elemwise_run_batch(self.program, n_tiles, self.ptrs, out_ptrs, self.n), "gm_elemwise_run_batch")
+        return outs
+
+
+def prepare_batch(compiled, tiles, shape):
+    """A PreparedBatch of ``launch_batch(compiled, tiles, shape)`` into fresh result tiles, or None where the launch takes one
+    of the rarer routes (windows of several bands, widths padded to 16 bytes): those keep the general path."""
+    n = _prod(shape)
+    n_in = len(tiles[0]) if tiles else 0
+    if not tiles or any(len(inputs) != n_in for inputs in tiles):
+        return None
+    flat = [x for inputs in tiles for x in inputs]
+    if any(x.band_pitch is not None for x in flat):
+        return None
+    if len(shape) == 3 and shape[0] == 1 and shape[-1] % 4 != 0 and shape[-1] >= 4:
+        return None  # (_padded_launch may apply)
+    runtime.require_device()
+    p = PreparedBatch()
+    p.compiled, p.inputs, p.n_tiles, p.shape, p.n = compiled, flat, len(tiles), tuple(int(d) for d in shape), n
+    p.dtype = np.dtype(compiled.out_dtype)
+    p.nbytes = max(n * p.dtype.itemsize, 1)
+    p.device = runtime.get_device()
+    p.program = ctypes.byref(compiled.program)
+    p.ptrs = (ctypes.c_void_p * max(len(flat), 1))(*[x.ptr for x in flat])
+    p.out_ptrs = (ctypes.c_void_p * len(tiles))()
+    p.pitched = any(x.pitch is not None for x in flat)
+    p.rows, p.cols = _prod(shape[:-1]), int(shape[-1])
+    p.pitches = (ctypes.c_uint32 * max(len(flat), 1))(*[x.pitch or 0 for x in flat]) if p.pitched else None
+    p.out_pitches = (ctypes.c_uint32 * len(tiles))(*[0] * len(tiles)) if p.pitched else None
+    return p
+
+
 def _padded_launch(L, compiled, tiles, flat, shape, n):
     """Windows whose width is no multiple of 4 -- the request a stencil Block grows by its radius, 4096 + 2 columns --
     cannot run on the 16-byte vector kernels, whose groups of 4 cells must not straddle rows.  When every raster input

@@ -77,7 +77,10 @@ def _declare(L):
     sigs = {
         "gm_init": [], "gm_device_count": [], "gm_set_device": [i32],
         "gm_get_device": [c.POINTER(i32)], "gm_device_name": [c.c_char_p, sz],
+        "gm_device_pci_bus_id": [i32, c.c_char_p, sz],
+        "gm_guard_enabled": [], "gm_guard_check": [c.POINTER(c.c_ulonglong)],
         "gm_malloc": [c.POINTER(vp), sz], "gm_free": [vp], "gm_pool_trim": [],
+        "gm_malloc_many": [c.POINTER(vp), i32, sz],
         "gm_mem_info": [c.POINTER(sz), c.POINTER(sz)],
         "gm_pool_stats": [c.POINTER(sz), c.POINTER(sz)],
         "gm_h2d": [vp, vp, sz], "gm_d2h": [vp, vp, sz], "gm_d2d": [vp, vp, sz],
@@ -110,20 +113,33 @@ def device_count():
     return int(lib().gm_device_count())
 
 
+_ok_pid = None       # the pid in which a device was seen (a fork()ed child asks the library again: GM_ERR_FORKED)
+_process_device = None  # (pid, index) once set_device has bound this process
+
+
 def require_device():
+    global _ok_pid
+    if _ok_pid == os.getpid():  # (asked by every allocation: one library call per process instead of one per tile)
+        return
     if device_count() <= 0:
         why = lib().gm_last_error().decode("utf-8", "replace")
         if why.startswith("forked after gm_init"):  # a fork() of a process that had entered the library (GM_ERR_FORKED)
             raise GmHipError(why)
         raise GmHipError("no HIP device visible: the raster compute path needs an MI355X "
                          "(there is no CPU fallback)")
+    _ok_pid = os.getpid()
 
 
 def set_device(index):
+    global _process_device
     check(lib().gm_set_device(int(index)), "gm_set_device")
+    _process_device = (os.getpid(), int(index))
 
 
 def get_device():
+    bound = _process_device
+    if bound is not None and bound[0] == os.getpid():  # (gm_set_device binds the PROCESS: every thread is pointed at it)
+        return bound[1]
     out = ctypes.c_int(0)
     check(lib().gm_get_device(ctypes.byref(out)), "gm_get_device")
     return out.value
@@ -133,6 +149,54 @@ def device_name():
     buf = ctypes.create_string_buffer(256)
     check(lib().gm_device_name(buf, 256), "gm_device_name")
     return buf.value.decode()
+
+
+def device_pci_bus_id(device):
+    """"0000:c1:00.0" of a visible device (the device is not bound by asking)."""
+    buf = ctypes.create_string_buffer(64)
+    check(lib().gm_device_pci_bus_id(int(device), buf, 64), "gm_device_pci_bus_id")
+    return buf.value.decode()
+
+
+def device_local_cpus(device):
+    """The host cores next to a device -- /sys/bus/pci/devices/<bus id>/local_cpulist, else the cores of its numa_node --
+    or None where the platform does not say (a VM without NUMA information, a one-node host: nothing to choose)."""
+    try:
+        base = "/sys/bus/pci/devices/" + device_pci_bus_id(device).lower()
+    except GmHipError:
+        return None
+    for name in ("local_cpulist",):
+        try:
+            with open(os.path.join(base, name)) as f:
+                cpus = parse_cpulist(f.read())
+            if cpus:
+                return cpus
+        except OSError:
+            pass
+    try:
+        with open(os.path.join(base, "numa_node")) as f:
+            node = int(f.read().strip())
+        if node >= 0:
+            with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+                return parse_cpulist(f.read()) or None
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def parse_cpulist(text):
+    """"0-3,8,10-11" -> {0, 1, 2, 3, 8, 10, 11}."""
+    cpus = set()
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        low, _, high = part.partition("-")
+        try:
+            cpus.update(range(int(low), int(high or low) + 1))
+        except ValueError:
+            return set()
+    return cpus
 
 
 def sync():

@@ -119,7 +119,9 @@ class RasterSourceBase(RasterBlock):
                 source = source.band_slice(bands[0], bands[1])  # (several frames: a window whose bands lie a plane apart)
             if process_kwargs.get("whole"):
                 return {"values": source, "no_data_value": fill}  # the request grid IS the source grid
-            return {"values": source.window(window[0], window[1], height, width), "no_data_value": fill}
+            values = source.window(window[0], window[1], height, width)
+            values.resident = True
+            return {"values": values, "no_data_value": fill}
         if not utils.same_projection(process_kwargs["projection"], raster_data.projection):
             raise NotImplementedError(
                 "request projection {} differs from the source's {}: re-projection is outside the "
@@ -161,6 +163,7 @@ class RasterSourceBase(RasterBlock):
         if process_kwargs.get("whole") and raster_data.all_finite():
             # the request grid IS the source grid: the warp would be an identity copy, so the
             # resident tile itself is handed on (responses are immutable by contract)
+            source.resident = True
             return {"values": source, "no_data_value": fill}
         window = process_kwargs.get("window")
         if window is not None and length == 1 and raster_data.all_finite():
@@ -524,6 +527,7 @@ class SyntheticSource(RasterBlock):
                 size = int(values.size) * dtype.itemsize
                 with cls._window_lock:
                     if key not in cls._windows:  # (another thread may have generated the same window meanwhile)
+                        values.resident = True
                         cls._windows[key] = values
                         cls._window_bytes += size
                     while cls._window_bytes > limit and len(cls._windows) > 1:

@@ -127,7 +127,7 @@ def configured_devices():
 
 _SHM_DIR = "/dev/shm" if os.path.isdir("/dev/shm") else None
 _names = itertools.count()
-_segments_lock = threading.Lock()
+_segments_lock = threading.RLock()   # (re-entrant: see _result_lock)
 _live_segments = {}   # name -> Segment this process created (unlinked at exit at the latest)
 
 
@@ -156,7 +156,8 @@ class Segment(object):
 
     @classmethod
     def create(cls, size):
-        name = "gm-shard-%d-%d-%s" % (os.getpid(), next(_names), os.urandom(4).hex())
+        name = "gm-shard-%d-%d-%s-%s-%s" % (os.getpid(), next(_names), os.urandom(4).hex(), _pid_namespace(),
+                                            _start_time(os.getpid()))
         seg = cls(name, size, True)
         with _segments_lock:
             _live_segments[name] = seg
@@ -178,10 +179,31 @@ class Segment(object):
                 pass
 
 
+def _pid_namespace():
+    """Identity of this process's pid namespace (a /dev/shm shared between containers holds files of several)."""
+    try:
+        return "%x" % os.stat("/proc/self/ns/pid").st_ino
+    except OSError:
+        return "0"
+
+
+def _start_time(pid):
+    """Start time (clock ticks since boot) of a process, "0" where /proc does not say: tells a creator from a later process
+    that got its pid."""
+    try:
+        with open("/proc/%d/stat" % pid) as f:
+            return f.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        return "0"
+
+
 def sweep_stale_segments():
     """Remove the shared-memory files of processes that no longer exist (a parent that was killed could not unlink its own:
-    the files are named after their creator's pid).  Called when a pool starts; returns the names removed."""
+    the files are named after their creator's pid, pid namespace and start time).  Files of another pid namespace are not
+    ours to judge (their creator's pid means nothing here); a pid that lives but started at another time is a later process.
+    Called when a pool starts; returns the names removed."""
     removed = []
+    namespace = _pid_namespace()
     if _SHM_DIR is None:
         return removed
     try:
@@ -189,14 +211,17 @@ def sweep_stale_segments():
     except OSError:
         return removed
     for name in names:
+        parts = name.split("-")
         try:
-            pid = int(name.split("-")[2])
+            pid = int(parts[2])
         except (IndexError, ValueError):
             continue
-        if pid == os.getpid():
+        if pid == os.getpid() or len(parts) < 7 or parts[5] != namespace:
             continue
         try:
             os.kill(pid, 0)
+            if parts[6] != "0" and _start_time(pid) not in ("0", parts[6]):
+                raise ProcessLookupError  # (the pid lives, its owner is a later process)
         except ProcessLookupError:
             try:
                 os.unlink(os.path.join(_SHM_DIR, name))
@@ -278,7 +303,7 @@ def _dumps(obj):
 
 # result mosaics: shared-memory ranges the workers have pinned, recycled by size when the ndarray a caller was given
 # has gone (pinning a range anew costs more than the copy into it)
-_result_lock = threading.Lock()
+_result_lock = threading.RLock()   # (re-entrant: a lease finalised by a GC pass inside the lock comes back in here)
 _result_free = {}     # size -> [Segment]
 _result_free_bytes = 0
 
@@ -368,8 +393,10 @@ class Pool(object):
         self.released = []       # run ids whose results the workers may drop (piggybacked on the next message)
         self.forgotten = []      # names of shared-memory ranges that are gone (likewise)
         self.closed = False
+        self.config = _forwarded_config()   # what the workers evaluate under: re-sent when it changes (refresh_config)
         settings = {"preload": preload if preload is not None else _config.get("geomodeling.worker-preload"),
-                    "path": [p for p in sys.path if p], "config": _forwarded_config()}
+                    "path": [p for p in sys.path if p], "config": self.config,
+                    "affinity": bool(_config.get("geomodeling.worker-affinity", True)), "pool_devices": self.devices}
         self.workers = []
         sweep_stale_segments()
         try:
@@ -383,8 +410,9 @@ class Pool(object):
 
     # -- messaging ------------------------------------------------------------------------------------------
     def _housekeeping(self):
-        names, self.forgotten[:] = list(self.forgotten), []
-        runs, self.released[:] = list(self.released), []
+        # (swapped, not copied-then-cleared: a run id appended by a finaliser between the two would be lost)
+        names, self.forgotten = self.forgotten, []
+        runs, self.released = self.released, []
         return names, runs
 
     def request(self, messages, timeout=None, what="request"):
@@ -476,6 +504,19 @@ class Pool(object):
                 except OSError:
                     pass
 
+    def refresh_config(self):
+        """The workers evaluate under the parent's geomodeling.* settings AS THEY ARE NOW: a config.set after the pool
+        started (raster-limit, fuse, root, ...) travels before the next request, and the jobs kept under the old settings --
+        fused or not, checked against the old limits -- are forgotten on both sides."""
+        with self.lock:
+            now = _forwarded_config()
+            if now == self.config or self.closed:
+                return
+            stale = [job.id for job in self.jobs.values()]
+            self.jobs.clear()
+            self.request({w.index: ("config", now, stale) for w in self.workers}, what="a change of configuration")
+            self.config = now
+
     # -- jobs -----------------------------------------------------------------------------------------------
     def job_for(self, key):
         """(job record, known to the workers already?) of a job key; the least recently used jobs are dropped (-> their ids)."""
@@ -528,7 +569,7 @@ def _forwarded_config():
     """The geomodeling.* settings the workers evaluate under (never the device list itself)."""
     keys = ("fuse", "plans", "templates", "resident-window-bytes", "raster-limit", "raster-limit-timesteps",
             "geometry-limit", "root", "strict-file-paths")
-    return {"geomodeling." + k: _config.get("geomodeling." + k) for k in keys if _config.get("geomodeling." + k) is not None}
+    return {"geomodeling." + k: _config.get("geomodeling." + k) for k in keys}
 
 
 _pools = {}
@@ -754,6 +795,7 @@ def get(dsk, keys, devices=None, **kwargs):
     """``get(graph, keys)`` with dask's calling convention over one worker process per GPU.  Raster results come back as
     host ndarrays (a scheduler's results leave the workers), the mosaic of a ``RasterTiler`` key assembled from its tiles."""
     pool = pool_for(devices)
+    pool.refresh_config()
     flat = _flatten(keys)
     G = len(pool.devices)
     units, plans = [], {}   # units: graph keys to evaluate, in dealing order; plans: wanted key -> how it is made of units
@@ -847,6 +889,7 @@ def get_data(view, request, devices=None, materialize=None):
     on one worker.  -> the response, host-resident (``materialize``, default ``geomodeling.materialize``) or a
     ``ShardedTiles`` left on the GPUs."""
     pool = pool_for(devices)
+    pool.refresh_config()
     if materialize is None:
         materialize = bool(_config.get("geomodeling.materialize", True))
     G = len(pool.devices)

@@ -16,6 +16,7 @@ import mmap
 import os
 import pickle
 import sys
+import time
 import traceback
 import zlib
 
@@ -32,6 +33,10 @@ class _State(object):
         self.results = {}    # run id -> [response per unit]
         self.mark = None     # HIP event recorded by the parent's ("mark",): start of a timed region
         self.last_metas = {} # job id -> metas of its last run (a re-run that answers the same says so in one word)
+        self.cpus = None     # the host cores this worker pinned itself to (None: left to the operating system)
+        self.host_s = 0.0    # wall time spent in run / rerun messages (unpickle -> reply queued): ("host_stats",)
+        self.host_cpu_s = 0.0
+        self.host_runs = 0
 
 
 STATE = _State()
@@ -61,15 +66,20 @@ def _loads(data):
     return _Unpickler(io.BytesIO(data)).load()
 
 
+def _apply_config(values):
+    from . import config as _config
+    values = {k: v for k, v in dict(values or {}).items() if v is not None or _config.get(k) is not None}
+    values.update({"geomodeling.devices": None, "geomodeling.materialize": False})
+    _config.config.set(values)
+
+
 def _init(settings):
     for p in settings.get("path") or ():
         if p not in sys.path:
             sys.path.append(p)
     STATE.index, STATE.device = settings["index"], settings["device"]
     from . import config as _config
-    values = dict(settings.get("config") or {})
-    values.update({"geomodeling.devices": None, "geomodeling.materialize": False})
-    _config.config.set(values)
+    _apply_config(settings.get("config"))
     preload = settings.get("preload")
     if preload:
         # "module:function", called before the device is bound (dask's worker preload): what a deployment uses to import its
@@ -80,12 +90,43 @@ def _init(settings):
             getattr(hook, function)()
     from .hip import runtime
     if runtime.device_count() > 0:
+        if settings.get("affinity", True):
+            STATE.cpus = _pin_to_device_cores(runtime, int(STATE.index), settings.get("pool_devices") or (STATE.device,))
         runtime.set_device(int(STATE.device))
         STATE.on_device = True
         return runtime.device_name()
     if not preload:
         raise runtime.GmHipError("no HIP device visible in the worker for device %s (there is no CPU fallback)" % (STATE.device,))
     return None
+
+
+def _pin_to_device_cores(runtime, index, pool_devices):
+    """sched_setaffinity to the cores next to this worker's device BEFORE the device is bound, so that the runtime's own
+    threads (and the kernel compiler's) inherit the mask.  Workers of the pool whose devices have the same cores next to
+    them (the GPUs of one NUMA node, or several workers on one GPU) each take their share of those cores -- every worker
+    works that out by itself from the pool's device list --, so that no two workers' submitting threads sit on one core.
+    -> the sorted cores, or None when nothing was changed."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        cores = {}
+        for d in set(pool_devices):
+            local = runtime.device_local_cpus(int(d))
+            cores[d] = tuple(sorted(set(local) & set(allowed))) if local else ()
+        mine = cores[pool_devices[index]]
+        if not mine:
+            return None
+        group = [i for i, d in enumerate(pool_devices) if cores[d] == mine]
+        k, n = group.index(index), len(group)
+        mine = list(mine)
+        if n > 1 and len(mine) >= 2 * n:   # (at least two cores each: the submitting thread and the runtime's helper)
+            per = len(mine) // n
+            mine = mine[k * per:(k + 1) * per]
+        if not mine or len(mine) == len(allowed):
+            return None
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (OSError, AttributeError, ValueError, KeyError):  # placement is an optimisation: never a reason not to start
+        return None
 
 
 def _meta(response):
@@ -99,9 +140,9 @@ def _meta(response):
     return ("object", response)
 
 
-def _prepare(spec):
+def _prepare(spec, keep=False):
     from . import config as _config
-    from .core.graphs import get_sync
+    from .core.graphs import PreparedGraph, get_sync
     from .fuse import fuse_graph
     kind = spec[0]
     fuse = bool(_config.get("geomodeling.fuse", True))
@@ -118,7 +159,12 @@ def _prepare(spec):
             store, tile_request = pairs[1 + t]
             graph, key = store.get_compute_graph(cached_compute_graph=graph, **tile_request)
             keys.append(key)
-        return ("graph", fuse_graph(graph, keys) if fuse else graph, keys, get_sync)
+        graph = fuse_graph(graph, keys) if fuse else graph
+        if keep:
+            # a job that is kept is run again and again: the look at its graph, its sources' resident windows and the
+            # arguments of its batched launches are kept with it (core/graphs.py PreparedGraph)
+            return ("prepared", PreparedGraph(graph, keys))
+        return ("graph", graph, keys, get_sync)
     if kind == "view":
         _, view, request = spec
         return ("view", view, request)
@@ -137,6 +183,8 @@ def _evaluate(job):
     if job[0] == "graph":
         _, graph, keys, get = job
         results = list(get(graph, keys))
+    elif job[0] == "prepared":
+        results = list(job[1].run())
     else:
         _, view, request = job
         results = [view.get_data(**request)]  # (this process's config: not materialised, no device list)
@@ -221,7 +269,7 @@ def _handle(message):
     kind = message[0]
     if kind == "run":
         _, job_id, run_id, spec, keep = message
-        job = _prepare(spec)
+        job = _prepare(spec, keep)
         if keep:
             STATE.jobs[job_id] = job
         results = STATE.results[run_id] = _run(job)
@@ -276,6 +324,28 @@ def _handle(message):
         if P.spec_pending():
             P.spec_wait()
         return {"launches": P.spec_stats()["launches"], "kernel": P.spec_last_kernel()}
+    if kind == "job_stats":
+        # what is kept with a kept job: runs so far, answers of resident sources kept, launches whose arguments are marshalled once
+        job = STATE.jobs.get(message[1])
+        if job is None or job[0] != "prepared":
+            return None
+        g = job[1]
+        prepared = sum(1 for _, plan, _ in (g.program or ()) if getattr(plan[1], "__name__", "") == "run" and not plan[2])
+        return {"runs": g.runs, "kept": len(g.kept), "live": len(g.program or ()), "prepared": prepared}
+    if kind == "config":
+        _apply_config(message[1])
+        for job_id in message[2]:
+            STATE.jobs.pop(job_id, None)
+            STATE.last_metas.pop(job_id, None)
+        return True
+    if kind == "host_stats":
+        # (reset, ...): host wall / CPU seconds this worker spent answering run / rerun messages, their count, its cores
+        out = {"wall_s": STATE.host_s, "cpu_s": STATE.host_cpu_s, "runs": STATE.host_runs, "cpus": STATE.cpus,
+               "pid": os.getpid()}
+        if len(message) > 1 and message[1]:
+            STATE.host_s = STATE.host_cpu_s = 0.0
+            STATE.host_runs = 0
+        return out
     if kind == "ping":
         return (os.getpid(), STATE.device, len(STATE.jobs), len(STATE.results))
     raise ValueError("unknown message %r" % (kind,))
@@ -323,7 +393,14 @@ def main(fd):
             _drop_names(names)
             if work is None:
                 continue
-            payload = _handle(work)
+            if work[0] in ("run", "rerun"):
+                t0, c0 = time.perf_counter(), time.thread_time()
+                payload = _handle(work)
+                STATE.host_s += time.perf_counter() - t0
+                STATE.host_cpu_s += time.thread_time() - c0
+                STATE.host_runs += 1
+            else:
+                payload = _handle(work)
         except Exception as e:  # noqa: BLE001 -- every failure of a request travels to the parent
             _reply(conn, "error", _error_payload(e))
             continue

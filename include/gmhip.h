@@ -36,6 +36,7 @@ extern "C" {
 #define GM_ERR_INVALID 9001     /* bad argument / malformed program */
 #define GM_ERR_UNSUPPORTED 9002 /* valid request the kernels do not cover */
 #define GM_ERR_NO_DEVICE 9003
+#define GM_ERR_GUARD 9005  /* GM_DEBUG_GUARD=1: a kernel wrote outside a block of gm_malloc (details on stderr) */
 #define GM_ERR_FORKED 9004 /* this process is a fork() of one that had entered the library: see gm_init */
 
 /* ---- element types of tiles in HBM ------------------------------------------- */
@@ -82,6 +83,10 @@ int gm_device_count(void);
  * (core/graphs.py:42-49) -- is pointed at this device, not at HIP's per-thread default 0. */
 int gm_set_device(int device);
 int gm_get_device(int* device);
+/* "domain:bus:device.function" of a visible device, without binding it: what a worker process of the one-worker-per-GPU
+ * scheduler looks up under /sys/bus/pci/devices/<id>/local_cpulist to pin itself to the cores next to ITS GPU before it
+ * binds the device (the reference leaves placement to dask's workers: core/graphs.py:42-49 only picks the scheduler). */
+int gm_device_pci_bus_id(int device, char* buf, size_t len);
 /* Device name / arch string ("gfx950...") of the current device into buf. */
 int gm_device_name(char* buf, size_t len);
 
@@ -89,7 +94,17 @@ int gm_device_name(char* buf, size_t len);
  * hipFree, safe because all work of a device is ordered on one stream). */
 int gm_malloc(void** ptr, size_t bytes);
 int gm_free(void* ptr);
+/* n blocks of `bytes` each in one call (the result tiles of one batched launch: a boundary crossing per launch instead of
+ * one per tile); all or nothing. */
+int gm_malloc_many(void** ptrs, int n, size_t bytes);
 int gm_pool_trim(void);                      /* hipFree all cached blocks */
+/* Debug canaries.  With GM_DEBUG_GUARD=1 in the environment every block of gm_malloc is a device allocation of
+ * its own between two poisoned red zones (4 KiB in front, 4 KiB behind the last byte asked for), comes filled with 0xFF bytes
+ * (NaN / -1: reading what nobody wrote shows), and is never recycled.  The zones are checked at gm_free, at every gm_sync and
+ * here: a violation is described on stderr, counted, and fails the call with GM_ERR_GUARD.  Slow (a synchronisation per free):
+ * for the stress drivers, never for measurements.  gm_guard_check: violations counted so far (also without the mode: 0). */
+int gm_guard_enabled(void);
+int gm_guard_check(unsigned long long* violations_so_far);
 int gm_mem_info(size_t* free_bytes, size_t* total_bytes);
 int gm_pool_stats(size_t* in_use_bytes, size_t* cached_bytes);
 

@@ -69,3 +69,8 @@ def tile_of(value, shape=(1, 3, 5)):
 
 def whoami():
     return {"pid": os.getpid()}
+
+
+def setting(key):
+    from dask_geomodeling_amd import config
+    return {"value": config.get(key), "pid": os.getpid()}

@@ -61,6 +61,20 @@ def test_two_workers_return_the_single_process_mosaic(two_workers):
         assert np.array_equal(_bits(got["values"]), _bits(want["values"])), (type(view).__name__, tile)
         again = tiler.get_data(**_request(side))  # the kept job, the recycled (already pinned) host range
         assert np.array_equal(_bits(again["values"]), _bits(want["values"]))
+        # ... which from its second run on keeps its sources' zero-copy windows and the arguments of its batched launches
+        # (core/graphs.py PreparedGraph): the third run is the first one that is all replay
+        third = tiler.get_data(**_request(side))
+        assert np.array_equal(_bits(third["values"]), _bits(want["values"]))
+        job = next(reversed(two_workers.jobs.values())).id
+        stats = two_workers.request({0: ("job_stats", job), 1: ("job_stats", job)})
+        for w in (0, 1):
+            assert stats[w]["runs"] == 3, stats
+            if isinstance(view, raster.HillShade):
+                # (a tile at the mosaic's edge asks its source for a margin outside the raster: warped, not a window; the two
+                #  interior tiles of a worker read zero-copy windows)
+                assert stats[w]["kept"] >= 2, stats
+            else:
+                assert stats[w]["kept"] >= 8 and stats[w]["prepared"] >= 1, stats
     assert {w.pid for w in two_workers.workers}.isdisjoint({os.getpid()}) and len({w.pid for w in two_workers.workers}) == 2
     assert all("gfx950" in name for name in two_workers.device_names)
     two_workers.request({0: ("mark",), 1: ("mark",)})

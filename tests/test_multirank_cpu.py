@@ -62,6 +62,10 @@ def test_bench_harness_world_size_2_gloo():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["unit"] == "Mpix/s" and out["vs_baseline"] is None and "cpu_baseline" not in out
+    # the strong-scaling mosaic over the N devices, run by rank 0 after the ranks have dissolved their group, in the same line
+    curve = out["secondary"]["mosaic"]
+    assert curve["scaling"] == "strong" and curve["workers"] == 2 and len(curve["worker_devices"]) == 2
+    assert len(curve["per_worker_device_ms_per_step"]) == 2 and curve["value"] > 0
     # 2 ranks x 4 tiles x 64^2 px per step
     assert abs(out["value"] - 2 * 4 * 64 * 64 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) / out["value"] < 0.01
 
@@ -82,6 +86,18 @@ def test_bench_gpus_flag_spawns_its_own_ranks():
     assert abs(out["value"] - 2 * 4 * 64 * 64 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) / out["value"] < 0.01
     assert out["ranks_reported"] == 2 and [r["rank"] for r in out["per_rank"]] == [0, 1]
     assert all(r["Mpix/s"] > 0 and r["ms_per_step"] <= out["ms_per_step"] * 1.001 for r in out["per_rank"])
+    assert out["secondary"]["mosaic"]["scaling"] == "strong" and out["secondary"]["mosaic"]["workers"] == 2
+
+
+@pytest.mark.timeout(300)
+def test_bench_mosaic_curve_can_be_switched_off():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--tiles", "4", "--side", "64", "--dry-run", "--no-mosaic-curve"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and "secondary" not in out
 
 
 @pytest.mark.timeout(120)
@@ -117,11 +133,19 @@ def test_bench_gpus_flag_two_ranks_on_the_gpu_box(gpu):
     holding only the leaf windows of the tiles it owns)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"]
-    res = subprocess.run(base + ["--steps", "10", "--warmup", "3", "--tiles", "4", "--side", "1024"],
+    res = subprocess.run(base + ["--steps", "10", "--warmup", "3", "--tiles", "4", "--side", "1024", "--secondary-steps", "2",
+                                 "--no-e2e"],
                          capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["roofline"]["achieved"] > 0
+    # the driver's command carries the strong-scaling curve point of BASELINE configs[4]: the 65536^2 mosaic dealt over two
+    # workers by the product's scheduler after the ranks have given their GPU back (here both on the box's one GPU)
+    curve = out["secondary"]["mosaic"]
+    assert "error" not in curve, curve
+    assert curve["scaling"] == "strong" and curve["workers"] == 2 and curve["tiles_per_worker"] == 128
+    assert abs(curve["value"] - 65536.0 ** 2 * 2 / (curve["ms_per_step"] * 2e-3) / 1e6) / curve["value"] < 0.01
+    assert len(curve["worker_host_us_per_step"]) == 2 and curve["parent_us_per_step"] > 0
     # (leaves regenerated per request: the two workers share this box's one GPU with whatever else the suite is running)
     res = subprocess.run(base + ["--workload", "mosaic", "--side", "4096", "--steps", "2", "--warmup", "1", "--leaves", "procedural", "--no-e2e"],
                          capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
@@ -139,7 +163,7 @@ def test_bench_world_size_2_on_the_gpu_box(gpu):
     line from rank 0 whose value counts the pixels of both ranks."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "10", "--warmup", "3", "--tiles", "4", "--side", "1024"]
+           "--gpus", "2", "--steps", "10", "--warmup", "3", "--tiles", "4", "--side", "1024", "--no-mosaic-curve"]
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=560, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]

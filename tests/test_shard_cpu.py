@@ -147,6 +147,47 @@ def test_get_with_dask_calling_convention(pool2):
 
 
 @pytest.mark.timeout(120)
+def test_a_later_config_set_reaches_running_workers_and_their_kept_jobs(pool2):
+    """The workers evaluate under the parent's geomodeling.* settings as they are at the request, not at the pool's start;
+    jobs kept under the old settings are forgotten on both sides (the reference reads raster-limit, strict-file-paths, root
+    at evaluation time)."""
+    graph = {"a": (shard_util.setting, "geomodeling.raster-limit"), "b": (shard_util.setting, "geomodeling.raster-limit")}
+    first = shard.get(graph, ["a", "b"])
+    assert {r["value"] for r in first} == {config.get("geomodeling.raster-limit")}
+    A, B = _leaves(7)
+    tiler = raster.RasterTiler(_chain(A, B), [48, 40])
+    want = tiler.get_data(**_request())
+    assert len(pool2.jobs) == 1
+    with config.config.set({"geomodeling.raster-limit": 4321, "geomodeling.fuse": False}):
+        second = shard.get(graph, ["a", "b"])
+        assert {r["value"] for r in second} == {4321}
+        assert {r["pid"] for r in second} == {w.pid for w in pool2.workers}   # the same workers: no restart
+        assert len(pool2.jobs) == 0
+        unfused = tiler.get_data(**_request())   # (a new job, built without the fusion pass)
+        assert np.array_equal(_bits(unfused["values"]), _bits(want["values"]))
+        kept = [r[2] for r in pool2.request({0: ("ping",), 1: ("ping",)}).values()]
+        assert kept == [1, 1]
+    third = shard.get(graph, ["a", "b"])
+    assert {r["value"] for r in third} == {config.get("geomodeling.raster-limit")}
+    kept = [r[2] for r in pool2.request({0: ("ping",), 1: ("ping",)}).values()]
+    assert kept == [0, 0]
+
+
+@pytest.mark.timeout(120)
+def test_workers_report_their_host_time(pool2):
+    """("host_stats",): what bench.py's mosaic line reads per worker -- host seconds in run / rerun messages, their count."""
+    A, B = _leaves(8)
+    tiler = raster.RasterTiler(_chain(A, B), [48, 40])
+    pool2.request({0: ("host_stats", True), 1: ("host_stats", True)})
+    for _ in range(3):
+        tiler.get_data(**_request())
+    stats = pool2.request({0: ("host_stats",), 1: ("host_stats",)})
+    for w in (0, 1):
+        assert stats[w]["runs"] == 3 and 0.0 < stats[w]["wall_s"] < 60.0 and stats[w]["cpu_s"] >= 0.0
+        assert stats[w]["pid"] == pool2.workers[w].pid
+
+
+@pytest.mark.timeout(120)
 def test_tiles_that_are_none_leave_the_fill_value(pool2):
     graph = {"t0": (shard_util.tile_of, 1.0), "t1": (lambda: None,), "t2": (shard_util.tile_of, 3.0),
              "t3": (shard_util.tile_of, 4.0)}
@@ -245,17 +286,23 @@ def test_stale_segments_of_dead_processes_are_swept():
     import subprocess
     child = subprocess.run([sys.executable, "-c", "import os; print(os.getpid())"], capture_output=True, text=True)
     dead = int(child.stdout)
-    stale = "/dev/shm/gm-shard-%d-0-deadbeef" % dead
-    mine = "/dev/shm/gm-shard-%d-999999-cafecafe" % os.getpid()
-    for path in (stale, mine):
+    ns = shard._pid_namespace()
+    stale = "/dev/shm/gm-shard-%d-0-deadbeef-%s-12345" % (dead, ns)
+    mine = "/dev/shm/gm-shard-%d-999999-cafecafe-%s-%s" % (os.getpid(), ns, shard._start_time(os.getpid()))
+    # a live pid whose start time differs: the creator is gone, a later process got its number
+    reused = "/dev/shm/gm-shard-%d-1-deadbeef-%s-1" % (os.getppid(), ns)
+    # the same dead pid in ANOTHER pid namespace (a /dev/shm shared between containers): not ours to judge
+    foreign = "/dev/shm/gm-shard-%d-0-deadbeef-%s-12345" % (dead, "ffffffff")
+    for path in (stale, mine, reused, foreign):
         with open(path, "wb") as f:
             f.write(b"x")
     try:
         removed = shard.sweep_stale_segments()
         assert os.path.basename(stale) in removed and not os.path.exists(stale)
-        assert os.path.exists(mine)
+        assert os.path.basename(reused) in removed and not os.path.exists(reused)
+        assert os.path.exists(mine) and os.path.exists(foreign)
     finally:
-        for path in (stale, mine):
+        for path in (stale, mine, reused, foreign):
             if os.path.exists(path):
                 os.unlink(path)
 
