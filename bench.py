@@ -942,7 +942,7 @@ def main():
                     visible = runtime.device_count()
                     try:
                         line = mosaic_through_the_scheduler(tuple(g % visible for g in range(world)), 4096, args.secondary_steps,
-                                                            3, "owned", e2e=not args.no_e2e)
+                                                            3, "procedural" if args.procedural else args.leaves, e2e=not args.no_e2e)
                     finally:
                         shard.shutdown()
             except Exception as e:  # noqa: BLE001 -- the headline was measured and stands

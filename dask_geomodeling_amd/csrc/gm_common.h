@@ -20,6 +20,11 @@ int hip_fail(hipError_t e, const char* what);
 hipStream_t current_stream();
 int current_cu_count();
 
+// Route counters behind gm_route_stats(): every host-side choice between kernels of one entry point counts the route it took,
+// so that a test which forces a route can assert that the route ran (a threshold that moves cannot turn it vacuous).
+// Families and slots are the GM_ROUTE_* constants of gmhip.h.
+void route_hit(int family, int slot, unsigned long long n = 1);
+
 #define GM_HIP(call)                                  \
   do {                                                \
     hipError_t e_ = (call);                           \

@@ -608,11 +608,13 @@ int gm_resample_bilinear_window(const void* src, int dtype, int bands, int hs, i
   if (!s) return GM_ERR_NO_DEVICE;
   gm_scalar ndv;
   ndv.u64 = ndv_bits;
+  gm::route_hit(GM_ROUTE_BILINEAR, GM_RB_CALLS);
   if (dtype == GM_F32 && hd == 2 * hs && wd == 2 * ws && ws >= 4 && (ws % 4) == 0 && (src_pitch % 4) == 0 &&
       ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
     int shape, swizzle, nt;
     bl2x_config(&shape, &swizzle, &nt);
     if (shape > 0) {
+      gm::route_hit(GM_ROUTE_BILINEAR, GM_RB_TWO_X);
 #define GM_BL2X_K(TH_, TW_, N_, NT_, NTS_, LATE_)                                                                     \
   do {                                                                                                               \
     if (lds2 > 65536) GM_HIP(hipFuncSetAttribute((const void*)bilinear2x_kernel<TH_, TW_, N_, NT_, NTS_, LATE_>,    \
@@ -679,6 +681,7 @@ int gm_resample_bilinear_window(const void* src, int dtype, int bands, int hs, i
   const bool direct = staged_cfg < 0 ? (3.5 * sy <= 1.0 && 3.5 * sx <= 1.0) : staged_cfg == 0;
   const bool staged = !direct && win_h * win_w * itemsize <= BL_LDS_BYTES - 2048;
   const size_t lds = staged ? (size_t)(win_h * win_w * itemsize) : 0;
+  gm::route_hit(GM_ROUTE_BILINEAR, staged ? GM_RB_STAGED : (direct ? GM_RB_DIRECT : GM_RB_UNSTAGED_FALLBACK));
   // (GM_BL_SWZ=0: tiles dealt to the XCDs in launch order -- tuning runs; with the runs per XCD 1.5 x 157 -> 151 us, 3 x 135 -> 125,
   //  12285-wide rows 192 -> 170 -- the staged route only: the direct one loses by it, 4 x 96 -> 122; GM_BL_CACHED=1: staging loads through the caches -- no effect measured)
   static const int stage_flags = (getenv("GM_BL_CACHED") && atoi(getenv("GM_BL_CACHED")) ? 2 : 0) | (getenv("GM_BL_SWZ") && !atoi(getenv("GM_BL_SWZ")) ? 0 : 4);

@@ -243,6 +243,20 @@ int current_cu_count() {
   return d->cu_count;
 }
 
+static std::atomic<unsigned long long> g_routes[GM_ROUTE_FAMILIES][32];
+void route_hit(int family, int slot, unsigned long long n) {
+  if (family >= 0 && family < GM_ROUTE_FAMILIES && slot >= 0 && slot < 32) g_routes[family][slot].fetch_add(n, std::memory_order_relaxed);
+}
+static const int kRouteSlots[GM_ROUTE_FAMILIES] = {GM_RZ_SLOTS, GM_RB_SLOTS, GM_RT_SLOTS, GM_RM_SLOTS, GM_RS_SLOTS};
+static const char* const kRouteNames[GM_ROUTE_FAMILIES][32] = {
+    {"calls", "direct", "chunk_attempts", "chunk_answered", "chunk_gave_up", "exact_all", "exact_partial", "sort_partition", "sort_radix",
+     "select", "lexsort", "block_pipeline", "ordered_sums", "lds_tables", "parcels"},
+    {"calls", "two_x", "staged", "direct", "unstaged_fallback"},
+    {"calls", "lookup32_w4", "lookup32_other", "lut8", "lut8_rows", "classify_registers", "classify_lds", "classify_window", "reclassify"},
+    {"calls", "network", "lds_sort", "select"},
+    {"calls", "hillshade_pairs", "hillshade_single", "movingmax_3x3", "movingmax_stack", "movingmax_columns", "movingmax_keys",
+     "dilate8_wide", "dilate_other", "gauss_one_launch", "gauss_two_pass"}};
+
 static size_t round_size(size_t bytes) {
   if (bytes == 0) bytes = 1;
   if (bytes <= (1u << 20)) {  // next power of two, >= 512 B
@@ -661,6 +675,17 @@ int gm_event_elapsed_ms(void* start, void* stop, float* ms) {
   if (forked()) return forked_fail();
   GM_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
   return GM_OK;
+}
+
+int gm_route_stats(int family, uint64_t* counters, int n) {
+  if (family < 0 || family >= GM_ROUTE_FAMILIES) return -1;
+  for (int i = 0; counters && i < n && i < kRouteSlots[family]; ++i) counters[i] = g_routes[family][i].load(std::memory_order_relaxed);
+  return kRouteSlots[family];
+}
+
+const char* gm_route_name(int family, int slot) {
+  if (family < 0 || family >= GM_ROUTE_FAMILIES || slot < 0 || slot >= kRouteSlots[family]) return nullptr;
+  return kRouteNames[family][slot];
 }
 
 const char* gm_last_error(void) { return g_err.c_str(); }

@@ -1668,6 +1668,7 @@ int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_
     }
     if (bands == 1 && w >= 64 && (h - 2 + d8h - 1) / d8h <= 65535) {
       dim3 wgrid((unsigned)((w - 2 + D8W_COLS - 1) / D8W_COLS), (unsigned)((h - 2 + d8h - 1) / d8h));
+    gm::route_hit(GM_ROUTE_STENCILS, GM_RS_DILATE8_WIDE);
 #define GM_D8W(H_) hipLaunchKernelGGL(dilate8_wide_kernel<H_>, wgrid, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, h, w, in_pitch, out_pitch_or(w - 2), A8)
       if (d8h == 4) GM_D8W(4);
       else if (d8h == 8) GM_D8W(8);
@@ -1681,6 +1682,7 @@ int gm_dilate_window(const void* in, int dtype, int bands, int h, int w, int in_
     GM_COMPACT_ONLY("gm_dilate");
     dim3 grid8((unsigned)((w - 2 + 1023) / 1024), (unsigned)((h - 2 + D8_ROWS - 1) / D8_ROWS), (unsigned)bands);
     if (grid8.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_dilate: tile taller than %d rows", 65535 * D8_ROWS);
+    gm::route_hit(GM_ROUTE_STENCILS, GM_RS_DILATE_OTHER);
     hipLaunchKernelGGL(dilate8_kernel, grid8, dim3(256), 0, s, (const unsigned char*)in, (unsigned char*)out, bands, h, w, A8);
     GM_HIP(hipGetLastError());
     return GM_OK;
@@ -1780,6 +1782,7 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
   if (!s) return GM_ERR_NO_DEVICE;
   if (size == 3 && gm::dtype_size(dtype) <= 4 && (oh + M3_H - 1) / M3_H <= 65535) {
     dim3 grid3((unsigned)((ow + M3_W - 1) / M3_W), (unsigned)((oh + M3_H - 1) / M3_H), (unsigned)bands);
+    gm::route_hit(GM_ROUTE_STENCILS, GM_RS_MOVINGMAX_3X3);
 #define GM_M3(T) hipLaunchKernelGGL(moving_max3_kernel<T>, grid3, dim3(256), 0, s, (const T*)in, (T*)out, h, w, in_pitch, out_pitch_or(ow), has_ndv, from_bits<T>(ndv_bits), lowest<T>())
     switch (dtype) {
       case GM_U8: GM_M3(unsigned char); break;
@@ -1797,6 +1800,7 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
   }
   if (size >= 5 && size <= 15 && gm::dtype_size(dtype) <= 4 && (oh + 15) / 16 <= 65535) {
     const int th = disk_tile_rows(radius);
+    gm::route_hit(GM_ROUTE_STENCILS, GM_RS_MOVINGMAX_STACK);
     dim3 gridd((unsigned)((ow + 255) / 256), (unsigned)((oh + th - 1) / th), (unsigned)bands);
 #define GM_MD(T)                                                                                                  \
   do {                                                                                                            \
@@ -1835,6 +1839,7 @@ int gm_moving_max_window(const void* in, int dtype, int bands, int h, int w, int
   }
   if (window) return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: this footprint / dtype wants a compact tile");
   GM_COMPACT_ONLY("gm_moving_max");
+  gm::route_hit(GM_ROUTE_STENCILS, GM_RS_MOVINGMAX_COLUMNS);
   dim3 grid((unsigned)((ow + MM_TILE_W - 1) / MM_TILE_W), (unsigned)((oh + MM_TILE_H - 1) / MM_TILE_H), (unsigned)bands);
   if (grid.y > 65535) return gm::fail(GM_ERR_UNSUPPORTED, "gm_moving_max: tile too tall");
 #define GM_MM_R(T, RMAX_)                                                                                      \
@@ -1945,6 +1950,7 @@ int gm_gauss_2d_window(const void* in, int dtype, int bands, int h, int w, int i
   const float ndv = from_bits<float>(ndv_bits), fill = from_bits<float>(fill_bits);
   const int tw = 256 - 2 * (radius <= 8 ? 8 : 16);
   dim3 grid((unsigned)((ow + tw - 1) / tw), (unsigned)((oh + G2_TH - 1) / G2_TH), (unsigned)bands);
+  gm::route_hit(GM_ROUTE_STENCILS, GM_RS_GAUSS_ONE_LAUNCH);
 #define GM_G2(R, RCAP)                                                                                              \
   case R:                                                                                                           \
     hipLaunchKernelGGL((gauss2d_kernel<R, RCAP>), grid, dim3(256), 0, s, (const float*)in, (float*)out, h, w, in_pitch,   \
@@ -2010,7 +2016,9 @@ int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int 
   const bool tiled = gm::dtype_size(dtype) <= 4 && tgrid.y <= 65535;  // (8-byte tiles: the window would not fit LDS twice)
   const bool pairs_fit = !getenv("GM_HS_SINGLE") && (h - 2 + HP_H - 1) / HP_H <= 65535;
   dim3 pgrid((unsigned)((w - 2 + HP_W - 1) / HP_W), (unsigned)((h - 2 + HP_H - 1) / HP_H), (unsigned)bands);
+  gm::route_hit(GM_ROUTE_STENCILS, GM_RS_CALLS);
   if (dtype == GM_F32 && pairs_fit) {
+    gm::route_hit(GM_ROUTE_STENCILS, GM_RS_HILLSHADE_PAIRS);
     const float ndv = from_bits<float>(ndv_bits), fill = from_bits<float>(fill_bits);
     if (A.xinv32 != 0.0f && A.yinv32 != 0.0f)
       hipLaunchKernelGGL((hillshade_pair_kernel<float, true>), pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, in_pitch, has_ndv, ndv, fill, A);
@@ -2023,6 +2031,7 @@ int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int 
   const bool int_pairs = pairs_fit && A.xinv32 != 0.0f && A.yinv32 != 0.0f && fabsf(A.xinv32) < 0x1p64f &&
                          fabsf(A.xinv32) > 0x1p-64f && fabsf(A.yinv32) < 0x1p64f && fabsf(A.yinv32) > 0x1p-64f;
   if (int_pairs && gm::dtype_size(dtype) <= 4 && !gm::dtype_is_float(dtype) && dtype != GM_BOOL) {
+    gm::route_hit(GM_ROUTE_STENCILS, GM_RS_HILLSHADE_PAIRS);
 #define GM_HP(T)                                                                                                          \
   hipLaunchKernelGGL((hillshade_pair_kernel<T, true>), pgrid, dim3(256), 0, s, (const T*)in, (unsigned char*)out, h, w, in_pitch, \
                      has_ndv, from_bits<T>(ndv_bits), from_bits<T>(fill_bits), A)
@@ -2038,6 +2047,7 @@ int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int 
     GM_HIP(hipGetLastError());
     return GM_OK;
   }
+  gm::route_hit(GM_ROUTE_STENCILS, GM_RS_HILLSHADE_SINGLE);
 #define GM_HS(T)                                                                                                     \
   do {                                                                                                               \
     if constexpr (sizeof(T) <= 4) {                                                                                  \

@@ -473,6 +473,7 @@ int launch_classify(const void* in, void* out, size_t n, const void* bins_dev, i
       const int chunks = chunks_for(lds, (size_t)span * (sizeof(TI) + sizeof(TO)));                                \
       const unsigned long long blocks = (count + span * chunks - 1) / (span * chunks);                             \
       if (blocks > 0x7fffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "tile too large for one launch");             \
+      gm::route_hit(GM_ROUTE_TABLES, use_lds ? GM_RT_CLASSIFY_LDS : GM_RT_CLASSIFY_REGISTERS);                     \
       if (use_lds)                                                                                                 \
         hipLaunchKernelGGL((classify_kernel<TI, TO, CT, RIGHT_, K_, true, CLS_U_>), dim3((unsigned)blocks), dim3(256), lds, s, \
                            (const TI*)in, (TO*)out, (unsigned long long)(FIRST), (unsigned long long)(END),        \
@@ -633,6 +634,7 @@ int gm::lut8_launch(int n_tiles, const void* const* in, const uint32_t* in_pitch
     if (blocks_per_row * rows > 0x7fffffffull || rows > 0xffffffffull)
       return gm::fail(GM_ERR_UNSUPPORTED, "lut8: tile too large for one launch");
     dim3 grid((unsigned)(blocks_per_row * rows), (unsigned)n_tiles);
+    gm::route_hit(GM_ROUTE_TABLES, GM_RT_LUT8_ROWS);
     switch (out_size) {
       case 1: hipLaunchKernelGGL(lut8_rows_kernel<unsigned char>, grid, dim3(256), 0, stream, L, (unsigned)rows, (unsigned)blocks_per_row); break;
       case 2: hipLaunchKernelGGL(lut8_rows_kernel<unsigned short>, grid, dim3(256), 0, stream, L, (unsigned)rows, (unsigned)blocks_per_row); break;
@@ -653,6 +655,7 @@ int gm::lut8_launch(int n_tiles, const void* const* in, const uint32_t* in_pitch
   const unsigned long long groups = (L.n + per_lane - 1) / per_lane;
   if ((groups + 255) / 256 > 0x7fffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "lut8: tile too large for one launch");
   dim3 grid((unsigned)((groups + 255) / 256), (unsigned)n_tiles);
+  gm::route_hit(GM_ROUTE_TABLES, GM_RT_LUT8);
   switch (out_size) {
     case 1: hipLaunchKernelGGL(lut8_kernel<unsigned char>, grid, dim3(256), 0, stream, L); break;
     case 2: hipLaunchKernelGGL(lut8_kernel<unsigned short>, grid, dim3(256), 0, stream, L); break;
@@ -833,6 +836,7 @@ int gm::lookup32_launch(int n_tiles, const void* const* in, const uint32_t* in_p
     if (cfg[3] == 4) hipLaunchKernelGGL((lookup32_kernel_w4<EXC_>), grid, dim3(256), lds, stream, L); \
     else hipLaunchKernelGGL((lookup32_kernel<EXC_>), grid, dim3(256), lds, stream, L);                \
   } while (0)
+  gm::route_hit(GM_ROUTE_TABLES, cfg[3] == 4 ? GM_RT_LOOKUP32_W4 : GM_RT_LOOKUP32_OTHER);
   switch (table.n_exc) {
     case 0: GM_L32(0); break;
     case 1: GM_L32(1); break;
@@ -952,6 +956,7 @@ int gm_classify2(const void* in, int in_dtype, int has_ndv, uint64_t ndv_bits, c
         const unsigned long long blocks = (n4 + 256ull * U * chunks - 1) / (256ull * U * chunks);
         if (blocks > 0x7fffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "tile too large for one launch");
         const float ndv32 = (float)ndv.f64;
+        gm::route_hit(GM_ROUTE_TABLES, GM_RT_CLASSIFY_WINDOW);
 #define GM_GRID_SCAN(TO_, RIGHT_, SCAN_)                                                                              \
   hipLaunchKernelGGL((classify_grid_kernel<TO_, RIGHT_, U, SCAN_>), dim3((unsigned)blocks), dim3(256), lds, s, (const float*)in, \
                      (TO_*)out, n4, (const float*)thr_dev, (const unsigned short*)base_dev, nbins, G, chunks, has_ndv,  \
@@ -1146,6 +1151,7 @@ int gm_reclassify(const void* in, int in_dtype, const int64_t* keys_host, const 
       const int chunks = chunks_for(lds, (size_t)span * (sizeof(TI) + 8));                                       \
       const unsigned long long blocks = (count + span * chunks - 1) / (span * chunks);                           \
       if (blocks > 0x7fffffffull) return gm::fail(GM_ERR_UNSUPPORTED, "tile too large for one launch");           \
+      gm::route_hit(GM_ROUTE_TABLES, GM_RT_RECLASSIFY);                                                          \
       if (T.use_lds)                                                                                             \
         hipLaunchKernelGGL((reclassify_kernel<TI, K_, true, RCL_U_>), dim3((unsigned)blocks), dim3(256), lds, s,         \
                            (const TI*)in, (unsigned long long*)out, (unsigned long long)(FIRST),                 \

@@ -701,6 +701,8 @@ int launch_median(const void* frames, uint64_t ndv_bits, int has_ndv, long long 
       P.one_minus_gamma[i] = plan[i].one_minus_gamma;
     }
   }
+  gm::route_hit(GM_ROUTE_MEDIANS, GM_RM_CALLS);
+  gm::route_hit(GM_ROUTE_MEDIANS, longest_all <= 32 ? GM_RM_NETWORK : (select ? GM_RM_SELECT : GM_RM_LDS_SORT));
   if (longest_all <= 32) {  // short bins: the register sorting network (up to 32 frames: a month of daily frames; round 5)
     const unsigned gxs = (unsigned)((pixels + 255) / 256);
     for (int b0 = 0; b0 < n_bins; b0 += TB_MAX_BINS) {

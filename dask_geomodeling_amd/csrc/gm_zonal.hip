@@ -3407,6 +3407,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       else if (statistic == Z_MIN) GM_ZD(Z_MIN);
       else GM_ZD(Z_MAX);
 #undef GM_ZD
+      gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_DIRECT);
       GM_HIP(hipGetLastError());
     }
     return GM_OK;
@@ -3509,6 +3510,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     // the stable sort by label of (keys, payload): one counting pass for up to ZP_BINS - 1 labels (which also yields
     // first[]), the general radix sort + the search for the bounds otherwise
     auto sort_by_label = [&](const unsigned* keys_in, const Key* pay_in, unsigned* keys_out, Key* pay_out) -> int {
+      gm::route_hit(GM_ROUTE_ZONAL, partition ? GM_RZ_SORT_PARTITION : GM_RZ_SORT_RADIX);
       if (partition) {
         static const int nw = getenv("GM_ZONAL_PART_WAVES") ? atoi(getenv("GM_ZONAL_PART_WAVES")) : 8;
         const size_t lds = sizeof(unsigned) * part_bins;
@@ -3580,6 +3582,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
           chunk.steps_for = n_steps;
         }
         chunk.verdict = (ChunkVerdict*)(chunk.slot_of + table_bytes);
+        gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_CHUNK_ATTEMPTS);
         GM_HIP(hipMemsetAsync(chunk.slot_of, 0, table_bytes + 64, s));
         HostFlag* const flag = host_flag();
         if (flag) flag->word[0] = flag->word[1] = flag->word[2] = 0u;
@@ -3615,6 +3618,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         chunk_gave_up_hard = chunk_verdict.hard != 0 || n_labels + 1 <= ZP_BINS;
         if (chunk_verdict.hard || chunk_verdict.not_runs || chunk_cells <= (size_t)ZC_STEP) break;  // (shorter stretches would not help)
       }
+      gm::route_hit(GM_ROUTE_ZONAL, answered ? GM_RZ_CHUNK_ANSWERED : GM_RZ_CHUNK_GAVE_UP);
       if (answered) continue;
     }
     if ((rc = key_buffers())) return rc;
@@ -3637,6 +3641,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       // parallel sums answer all the others, and only the cells of those few are sorted and added in order.
       const bool partial = verdict.labels != 0 && verdict.cells != 0 && verdict.cells <= (unsigned long long)cells / 8;
       if (verdict.labels == 0 || partial) {
+        gm::route_hit(GM_ROUTE_ZONAL, partial ? GM_RZ_EXACT_PARTIAL : GM_RZ_EXACT_ALL);
         hipLaunchKernelGGL((zonal_exact_kernel<T, 1>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells,
                            cells_per_wave, n_labels, has_ndv, ndv, thresholds, range, sums, (unsigned char*)nullptr,
                            (unsigned*)nullptr, (Key*)nullptr, (unsigned*)nullptr);
@@ -3687,6 +3692,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       const unsigned label_grid = (unsigned)((n_labels + 255) / 256);
       const unsigned pass_grid = (unsigned)(((size_t)cells + 4 * SEL_WAVE - 1) / (4 * SEL_WAVE));
       GM_HIP(hipMemsetAsync(sel_hist, 0, sizeof(unsigned) * 256 * (size_t)n_labels, s));
+      gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_SELECT);
       hipLaunchKernelGGL(zonal_select_init_kernel, dim3(label_grid), dim3(256), 0, s, first, n_labels, statistic, qval, sel_state, sel_next);
       for (int shift = 8 * ((int)sizeof(T) - 1); shift >= 0; shift -= 8) {
         hipLaunchKernelGGL((zonal_select_pass_kernel<Key, false>), dim3(pass_grid), dim3(256), 0, s, first, pay_b, n_labels, shift, sel_state,
@@ -3702,6 +3708,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       continue;
     }
     if (by_value) {
+      gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_LEXSORT);
       // lexsort((values, labels)): by value, then stably by label
       if ((rc = radix_sort_pairs<Key, unsigned>(temp, pay_a, pay_b, keys_a, keys_b, (size_t)cells, 8 * (int)sizeof(Key), s))) return rc;
       if ((rc = sort_by_label(keys_b, pay_b, keys_a, pay_a))) return rc;
@@ -3718,7 +3725,9 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       static const bool block_pipeline = !(getenv("GM_ZONAL_BLOCKS") && atoi(getenv("GM_ZONAL_BLOCKS")) == 0);
       static const unsigned long_from = getenv("GM_ZONAL_LONG") ? (unsigned)std::max(2 * (int)ZB, atoi(getenv("GM_ZONAL_LONG"))) : ZL_LONG;
       const bool long_labels = block_pipeline && (uint64_t)cells >= long_from && longest >= long_from;
+      gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_ORDERED_SUMS);
       if (long_labels) {
+        gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_BLOCK_PIPELINE);
         const size_t n_blocks = ((size_t)cells + ZB - 1) / ZB;
         if (!blk_sum) {
           if ((rc = scratch.take((void**)&blk_sum, sizeof(double) * n_blocks))) return rc;
@@ -3797,6 +3806,7 @@ int gm_zonal_statistic(const void* values, int dtype, int64_t frames, int64_t ce
   if (n_labels == INT32_MAX) return gm::fail(GM_ERR_UNSUPPORTED, "gm_zonal_statistic: too many labels");
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
+  gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_CALLS);
   // (count / min / max clear `present` in the launch that clears their tallies: zonal_direct_init_kernel)
   const bool direct = (statistic == Z_COUNT || statistic == Z_MIN || statistic == Z_MAX) && frames > 0 && cells > 0;
   if (present && n_labels && !direct) GM_HIP(hipMemsetAsync(present, 0, (size_t)n_labels, s));

@@ -79,6 +79,7 @@ def _declare(L):
         "gm_get_device": [c.POINTER(i32)], "gm_device_name": [c.c_char_p, sz],
         "gm_device_pci_bus_id": [i32, c.c_char_p, sz],
         "gm_guard_enabled": [], "gm_guard_check": [c.POINTER(c.c_ulonglong)],
+        "gm_route_stats": [i32, c.POINTER(u64), i32],
         "gm_malloc": [c.POINTER(vp), sz], "gm_free": [vp], "gm_pool_trim": [],
         "gm_malloc_many": [c.POINTER(vp), i32, sz],
         "gm_mem_info": [c.POINTER(sz), c.POINTER(sz)],
@@ -149,6 +150,37 @@ def device_name():
     buf = ctypes.create_string_buffer(256)
     check(lib().gm_device_name(buf, 256), "gm_device_name")
     return buf.value.decode()
+
+
+ROUTE_FAMILIES = {"zonal": 0, "bilinear": 1, "tables": 2, "medians": 3, "stencils": 4}
+
+
+def route_stats(family):
+    """{route name: times taken since the library was loaded} of one family of entry points ("zonal", "bilinear", "tables",
+    "medians", "stencils"): which kernel route a call took (gm_route_stats).  Tests that force a route assert on the difference
+    of two readings."""
+    L = lib()
+    L.gm_route_name.restype = ctypes.c_char_p
+    L.gm_route_name.argtypes = [ctypes.c_int, ctypes.c_int]
+    code = ROUTE_FAMILIES[family] if isinstance(family, str) else int(family)
+    n = L.gm_route_stats(code, None, 0)
+    if n < 0:
+        raise ValueError("unknown route family %r" % (family,))
+    counters = (ctypes.c_uint64 * n)()
+    L.gm_route_stats(code, counters, n)
+    return {L.gm_route_name(code, i).decode(): int(counters[i]) for i in range(n)}
+
+
+def routes_taken(before, after):
+    """{route: count} of the routes whose counters moved between two readings of route_stats."""
+    return {k: after[k] - before.get(k, 0) for k in after if after[k] != before.get(k, 0)}
+
+
+def guard_violations():
+    """Red-zone violations counted so far (GM_DEBUG_GUARD=1), checking every live block now; raises on a new one."""
+    n = ctypes.c_ulonglong(0)
+    check(lib().gm_guard_check(ctypes.byref(n)), "gm_guard_check")
+    return int(n.value)
 
 
 def device_pci_bus_id(device):

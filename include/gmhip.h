@@ -135,6 +135,75 @@ int gm_event_record(void* event);
 int gm_event_sync(void* event);
 int gm_event_elapsed_ms(void* start, void* stop, float* ms);
 
+/* Route introspection.  Several entry points choose between kernels by the shape of their input (gm_zonal_statistic among
+ * six routes, the bilinear resample among three, tables and medians among two or three each).  Every choice counts itself:
+ * gm_route_stats copies the first n counters of a family (process-wide, monotonic since the library was loaded; returns the
+ * number of slots the family has, or -1 for an unknown family), gm_route_name names a slot (NULL past the end).  The tests
+ * that force a route assert that its counter moved.  Slot 0 of every family counts the calls of its entry point(s). */
+#define GM_ROUTE_ZONAL 0
+#define GM_ROUTE_BILINEAR 1
+#define GM_ROUTE_TABLES 2
+#define GM_ROUTE_MEDIANS 3
+#define GM_ROUTE_STENCILS 4
+#define GM_ROUTE_FAMILIES 5
+int gm_route_stats(int family, uint64_t* counters, int n);
+const char* gm_route_name(int family, int slot);
+
+/* zonal slots */
+#define GM_RZ_CALLS 0
+#define GM_RZ_DIRECT 1           /* count / min / max: run-compressed atomics, one pass */
+#define GM_RZ_CHUNK_ATTEMPTS 2   /* sums: passes of the chunk-record kernel (a frame may take two) */
+#define GM_RZ_CHUNK_ANSWERED 3   /* sums: frames the chunk records answered */
+#define GM_RZ_CHUNK_GAVE_UP 4    /* sums: frames handed on by the chunk records */
+#define GM_RZ_EXACT_ALL 5        /* sums: every label certified exact, parallel sums are the answer */
+#define GM_RZ_EXACT_PARTIAL 6    /* sums: a few labels sorted and added in order, the others parallel */
+#define GM_RZ_SORT_PARTITION 7   /* sorts by label through the counting partition */
+#define GM_RZ_SORT_RADIX 8       /* sorts by label through the radix sort */
+#define GM_RZ_SELECT 9           /* medians / percentiles: partition + radix select */
+#define GM_RZ_LEXSORT 10         /* medians / percentiles: sort by value, then by label */
+#define GM_RZ_BLOCK_PIPELINE 11  /* sums: long labels composed block-parallel */
+#define GM_RZ_ORDERED_SUMS 12    /* sums: the wave-per-label kernel over sorted cells ran */
+#define GM_RZ_LDS_TABLES 13      /* count / min / max: per-workgroup LDS tables (label rasters without runs) */
+#define GM_RZ_PARCELS 14         /* sums / medians: small polygons answered inside one workgroup's stretch */
+#define GM_RZ_SLOTS 15
+/* bilinear slots */
+#define GM_RB_CALLS 0
+#define GM_RB_TWO_X 1            /* the dedicated 2 x kernel */
+#define GM_RB_STAGED 2           /* general kernel, source window staged in LDS */
+#define GM_RB_DIRECT 3           /* general kernel, taps through the caches */
+#define GM_RB_UNSTAGED_FALLBACK 4 /* general kernel, window too large for LDS */
+#define GM_RB_SLOTS 5
+/* table slots */
+#define GM_RT_CALLS 0
+#define GM_RT_LOOKUP32_W4 1      /* LOOKUP(int32) -> 1-byte tile, LDS window + ballot fast path */
+#define GM_RT_LOOKUP32_OTHER 2   /* the other instantiations of the int32 lookup kernel */
+#define GM_RT_LUT8 3             /* programs over one 1-byte tile as a 256-entry table */
+#define GM_RT_LUT8_ROWS 4        /* ... over windows that do not sit on 16 bytes */
+#define GM_RT_CLASSIFY_REGISTERS 5
+#define GM_RT_CLASSIFY_LDS 6
+#define GM_RT_CLASSIFY_WINDOW 7
+#define GM_RT_RECLASSIFY 8
+#define GM_RT_SLOTS 9
+/* median slots (temporal / stack medians) */
+#define GM_RM_CALLS 0
+#define GM_RM_NETWORK 1
+#define GM_RM_LDS_SORT 2
+#define GM_RM_SELECT 3
+#define GM_RM_SLOTS 4
+/* stencil slots */
+#define GM_RS_CALLS 0
+#define GM_RS_HILLSHADE_PAIRS 1
+#define GM_RS_HILLSHADE_SINGLE 2
+#define GM_RS_MOVINGMAX_3X3 3
+#define GM_RS_MOVINGMAX_STACK 4   /* sizes 5-15: nested horizontal maxima in registers */
+#define GM_RS_MOVINGMAX_COLUMNS 5 /* larger disks, column by column */
+#define GM_RS_MOVINGMAX_KEYS 6    /* a -0.0 was staged: the integer-key walk */
+#define GM_RS_DILATE8_WIDE 7
+#define GM_RS_DILATE_OTHER 8
+#define GM_RS_GAUSS_ONE_LAUNCH 9
+#define GM_RS_GAUSS_TWO_PASS 10
+#define GM_RS_SLOTS 11
+
 const char* gm_last_error(void);
 const char* gm_version(void);
 

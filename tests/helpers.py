@@ -76,3 +76,18 @@ def assert_result_equal(actual, expected, max_ulp=0, what=""):
         return
     assert_values_equal(actual["values"], expected["values"], max_ulp, what)
     assert_ndv_equal(actual.get("no_data_value"), expected.get("no_data_value"), what)
+
+
+def print_routes(*families):
+    """Last line of a by-hand driver: which kernel routes its calls took (runtime.route_stats), for the test that started it."""
+    import json
+    from dask_geomodeling_amd.hip import runtime
+    print("ROUTES-TAKEN " + json.dumps({f: runtime.route_stats(f) for f in families}), flush=True)
+
+
+def routes_of(stdout):
+    """{family: {route: count}} from the ROUTES-TAKEN line of a driver's output."""
+    import json
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("ROUTES-TAKEN ")]
+    assert lines, "the driver printed no ROUTES-TAKEN line: %s" % stdout[-300:]
+    return json.loads(lines[-1][len("ROUTES-TAKEN "):])

@@ -61,3 +61,7 @@ for it in range(N):
         bad += 1
         print("FAIL", it, dt, (bands, h, w), size, e)
 print("done", N, "failures", bad)
+print("guard violations", runtime.guard_violations(), "guard mode", runtime.lib().gm_guard_enabled())
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import print_routes  # noqa: E402
+print_routes("stencils")

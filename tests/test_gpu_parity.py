@@ -3,7 +3,7 @@ vectors and against the CPU oracle on seeded inputs.  Run with ``-m gpu`` on an 
 import numpy as np
 import pytest
 
-from helpers import ulp_distance, assert_result_equal, assert_values_equal, load_family
+from helpers import ulp_distance, assert_result_equal, assert_values_equal, load_family, routes_of
 from dask_geomodeling_amd.raster import devops
 from oracle import ref_numpy as O
 
@@ -374,6 +374,8 @@ def test_bilinear_routes_vs_oracle(gpu, route):
         "        assert_values_equal(got, O.bilinear_resample(src, hd, wd, ndv), 1, 'bilinear %%s %%s' %% (dt, (hs, ws, hd, wd)))\n"
         "        n += 1\n"
         "print('ROUTES ok', n)\n"
+        "from helpers import print_routes\n"
+        "print_routes('bilinear')\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     if route != "product":
@@ -381,6 +383,14 @@ def test_bilinear_routes_vs_oracle(gpu, route):
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
     assert "ROUTES ok 16" in res.stdout
+    took = routes_of(res.stdout)["bilinear"]
+    assert took["calls"] == 16, took
+    if route == "staged":
+        assert took["staged"] > 0 and took["direct"] == 0, took
+    elif route == "direct":
+        assert took["direct"] == took["calls"] - took["two_x"] and took["staged"] == 0, took
+    else:   # the product's choice: the cases span both sides of its threshold
+        assert took["staged"] > 0 and took["direct"] > 0, took
 
 
 # ---- whole views through Blocks, fusion pass and MemorySource ------------------------
@@ -894,9 +904,12 @@ def test_hillshade_float32_kernels_agree(gpu, monkeypatch):
     v = np.cumsum(rng.standard_normal((2, 333, 1111)) * 2, axis=2).astype("f4")
     v[rng.random(v.shape) < 0.05] = -9999.0
     pair = stencil.hillshade(v, np.float32(-9999.0), 1, (0.5, 1.0), 45.0, 315.0).to_numpy()
+    from dask_geomodeling_amd.hip import runtime
+    before = runtime.route_stats("stencils")
     monkeypatch.setenv("GM_HS_SINGLE", "1")
     single = stencil.hillshade(v, np.float32(-9999.0), 1, (0.5, 1.0), 45.0, 315.0).to_numpy()
     assert np.array_equal(pair, single)
+    assert runtime.routes_taken(before, runtime.route_stats("stencils")) == {"calls": 1, "hillshade_single": 1}
 
 
 @pytest.mark.gpu
@@ -2259,13 +2272,16 @@ def test_zonal_block_pipeline(gpu, blocks):
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
     assert "BLOCKS ok 240" in res.stdout
+    took = routes_of(res.stdout)["zonal"]   # the route this test names is the route that ran (gm_route_stats)
+    assert took["ordered_sums"] > 0 and took["chunk_attempts"] == 0 and took["exact_all"] == 0, took
+    assert (took["block_pipeline"] > 0) == (blocks == "1"), took
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("part,select", [("1", "1"), ("0", "1"), ("1", "0")], ids=["partition+select", "radix-sort", "partition+lexsort"])
 def test_zonal_label_partition(gpu, part, select):
     """The stable sort by label as one counting pass (csrc/gm_zonal.hip: zonal_part_*_kernel, up to 2047 labels) and as
-    rocPRIM's radix sort; medians / percentiles by radix select per label on the partitioned cells (zonal_select_*_kernel) and
+    this library's own radix sort; medians / percentiles by radix select per label on the partitioned cells (zonal_select_*_kernel) and
     by the two sorts of lexsort -- against the oracle: 240 statistics over label rasters of every texture
     (tests/zonal_partition_driver.py), sums forced through the sort."""
     import os
@@ -2276,6 +2292,14 @@ def test_zonal_label_partition(gpu, part, select):
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
     assert "PARTITION ok 240" in res.stdout
+    took = routes_of(res.stdout)["zonal"]
+    if part == "1":
+        assert took["sort_partition"] > 0, took
+    else:
+        assert took["sort_radix"] > 0 and took["sort_partition"] == 0 and took["select"] == 0, took
+    assert (took["select"] > 0) == (part == "1" and select == "1"), took
+    if part == "0" or select == "0":   # (with both on, only label counts beyond the partition's 2047 take the two sorts)
+        assert took["lexsort"] > 0, took
 
 
 @pytest.mark.gpu
@@ -2294,6 +2318,13 @@ def test_zonal_chunk_records(gpu, chunks):
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
     assert "CHUNKS ok 80" in res.stdout
+    took = routes_of(res.stdout)["zonal"]
+    if chunks == "0":
+        assert took["chunk_attempts"] == 0 and took["chunk_answered"] == 0, took
+    else:
+        assert took["chunk_answered"] > 0, took
+        if chunks == "2":   # no label is handed on because it was replayed too often: what gives up gave up for its layout
+            assert took["chunk_answered"] >= took["chunk_gave_up"], took
 
 
 @pytest.mark.gpu
@@ -2308,6 +2339,8 @@ def test_zonal_exactness_certificates_through_the_chunks(gpu):
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
     assert "CERTIFICATES ok 56" in res.stdout
+    took = routes_of(res.stdout)["zonal"]
+    assert took["chunk_answered"] == took["calls"] > 0 and took["ordered_sums"] == 0 and took["block_pipeline"] == 0, took
 
 
 @pytest.mark.gpu
@@ -2325,6 +2358,8 @@ def test_zonal_exactness_certificates(gpu, certify):
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
     assert "CERTIFICATES ok 56" in res.stdout
+    took = routes_of(res.stdout)["zonal"]
+    assert took["chunk_attempts"] == 0 and took["block_pipeline"] > 0, took
     groups = [int(line.split("certified exact, ")[1].split(" groups")[0]) for line in res.stderr.splitlines() if "groups of 256 certified" in line]
     assert groups and (sum(groups) > 100 if certify == "1" else sum(groups) == 0), groups[:20]
 
@@ -2344,6 +2379,10 @@ def test_zonal_labels_beyond_64_groups(gpu, chunks):
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=1800)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
     assert "LONG LABELS ok 16" in res.stdout
+    took = routes_of(res.stdout)["zonal"]
+    assert (took["chunk_attempts"] > 0) == (chunks == "1"), took
+    if chunks == "0":
+        assert took["block_pipeline"] > 0, took
 
 
 @pytest.mark.gpu

@@ -134,11 +134,12 @@ def test_bench_gpus_flag_two_ranks_on_the_gpu_box(gpu):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"]
     res = subprocess.run(base + ["--steps", "10", "--warmup", "3", "--tiles", "4", "--side", "1024", "--secondary-steps", "2",
-                                 "--no-e2e"],
+                                 "--no-e2e", "--leaves", "procedural"],
                          capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["roofline"]["achieved"] > 0
+    # (leaves regenerated per request: the suite's other tests use the GPU's memory at the same time)
     # the driver's command carries the strong-scaling curve point of BASELINE configs[4]: the 65536^2 mosaic dealt over two
     # workers by the product's scheduler after the ranks have given their GPU back (here both on the box's one GPU)
     curve = out["secondary"]["mosaic"]

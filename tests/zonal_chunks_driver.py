@@ -94,3 +94,5 @@ for it in range(N):
         assert got_no == want_no
         cases += 1
 print("CHUNKS ok %d" % cases)
+from helpers import print_routes  # noqa: E402
+print_routes("zonal")

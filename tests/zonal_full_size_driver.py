@@ -66,3 +66,5 @@ for i in chosen:
             cases += 1
     print(name, "ok", flush=True)
 print("FULL SIZE ok", cases)
+from helpers import print_routes  # noqa: E402
+print_routes("zonal")

@@ -59,3 +59,5 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
         assert got_no == want_no
         cases += 1
 print("PARTITION ok", cases)
+from helpers import print_routes  # noqa: E402
+print_routes("zonal")

@@ -7,8 +7,8 @@ from dask_geomodeling_amd import geometry
 from dask_geomodeling_amd.hip import runtime
 from oracle import ref_numpy as O
 runtime.set_device(0)
-rng = np.random.default_rng(4711)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4711)  # [n] [seed]
 bad = 0
 STATS = [("sum", None), ("mean", None), ("count", None), ("min", None), ("max", None), ("median", None), ("percentile", 0.0),
          ("percentile", 33.3), ("percentile", 100.0)]
@@ -16,6 +16,8 @@ for it in range(N):
     dt = ["f4", "f4", "f8", "u1", "i1", "i2", "u2", "i4", "i8", "?"][int(rng.integers(10))]
     frames = int(rng.integers(1, 3))
     h, w = int(rng.integers(1, 400)), int(rng.integers(1, 900))
+    if it % 10 == 9:  # every tenth raster up to 4 M cells (labels of millions of cells, many stretches per wave, long partitions)
+        h, w = int(rng.integers(600, 2048)), int(rng.integers(900, 2048))
     n = int(rng.integers(1, 60)) if it % 3 else int(rng.integers(1000, 70000))
     layout = int(rng.integers(4))
     if layout == 0:      # blocks (long runs)
@@ -71,3 +73,7 @@ for it in range(N):
         bad += 1
         print("FAIL", it, dt, (frames, h, w), "n", n, "layout", layout, stat, q, "thr" if thr is not None else "", e)
 print("done", N, "failures", bad)
+print("guard violations", runtime.guard_violations(), "guard mode", runtime.lib().gm_guard_enabled())
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import print_routes  # noqa: E402
+print_routes("zonal")
