@@ -250,7 +250,7 @@ void route_hit(int family, int slot, unsigned long long n) {
 static const int kRouteSlots[GM_ROUTE_FAMILIES] = {GM_RZ_SLOTS, GM_RB_SLOTS, GM_RT_SLOTS, GM_RM_SLOTS, GM_RS_SLOTS};
 static const char* const kRouteNames[GM_ROUTE_FAMILIES][32] = {
     {"calls", "direct", "chunk_attempts", "chunk_answered", "chunk_gave_up", "exact_all", "exact_partial", "sort_partition", "sort_radix",
-     "select", "lexsort", "block_pipeline", "ordered_sums", "lds_tables", "parcels"},
+     "select", "lexsort", "block_pipeline", "ordered_sums", "lds_tables", "segment_sort"},
     {"calls", "two_x", "staged", "direct", "unstaged_fallback"},
     {"calls", "lookup32_w4", "lookup32_other", "lut8", "lut8_rows", "classify_registers", "classify_lds", "classify_window", "reclassify"},
     {"calls", "network", "lds_sort", "select"},
@@ -521,9 +521,10 @@ int gm_pool_stats(size_t* in_use_bytes, size_t* cached_bytes) {
 namespace {
 constexpr size_t kBounceBytes = 256u << 10;
 void* bounce_buffer() {
-  // (one per thread that copies, never freed: a thread's exit may come after the runtime's own)
+  // (one per thread that copies, never freed: a thread's exit may come after the runtime's own; portable: a thread that
+  //  moves to another device with gm_set_device keeps copying through it.  The library is built for one device per process.)
   static thread_local void* buffer = nullptr;
-  if (!buffer && hipHostMalloc(&buffer, kBounceBytes, hipHostMallocDefault) != hipSuccess) {
+  if (!buffer && hipHostMalloc(&buffer, kBounceBytes, hipHostMallocPortable) != hipSuccess) {
     (void)hipGetLastError();
     buffer = nullptr;
   }

@@ -1735,6 +1735,105 @@ __global__ __launch_bounds__(256) void zonal_direct_kernel(const T* __restrict__
   }
 }
 
+// count / min / max through tables PRIVATE to a workgroup (round 6).  zonal_direct_kernel above merges a step's distinct labels
+// one ballot at a time and keeps a wave's labels in 64 lanes: right for rasters made of runs, an order of magnitude off for label
+// rasters without runs -- 1000 labels at random per cell: 64 ballots per step and a write-out of all 64 lanes every step, 1.6 ms
+// (count) and 2.8 ms (max) for 12.6 M cells against 60 us for blocky labels.  Here every workgroup keeps a counter (and an extreme
+// key) per label in LDS: a step whose active cells carry one label joins the wave's run in registers as before (one LDS atomic
+// per quantity when the run ends), any other step is one LDS atomic per active lane -- no loop over its labels --, and the
+// workgroup's table goes to the global counters once, entries that were touched only.  Up to ZT_LDS_BYTES of table per workgroup.
+constexpr size_t ZT_LDS_BYTES = 64 * 1024;
+constexpr int ZT_THREADS = 1024;
+template <typename T, int STAT>
+__global__ __launch_bounds__(ZT_THREADS) void zonal_tables_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
+                                                                  size_t cells_per_wave, int n_labels, int has_ndv, T ndv,
+                                                                  const float* __restrict__ thresholds,
+                                                                  unsigned long long* __restrict__ counts,
+                                                                  typename Ordered<T>::Key* __restrict__ extreme,
+                                                                  unsigned char* __restrict__ present) {
+  typedef typename Ordered<T>::Key Key;
+  constexpr Key NEUTRAL = STAT == Z_MIN ? ~(Key)0 : (Key)0;
+  extern __shared__ unsigned long long zt_lds[];  // [n_labels] keys (min / max only), then [n_labels] counters
+  Key* const best_of = (Key*)zt_lds;
+  unsigned* const count_of = (unsigned*)((unsigned char*)zt_lds + (STAT == Z_COUNT ? 0 : sizeof(Key) * (size_t)((n_labels + 1) & ~1)));
+  for (int l = threadIdx.x; l < n_labels; l += ZT_THREADS) {
+    count_of[l] = 0u;
+    if constexpr (STAT != Z_COUNT) best_of[l] = NEUTRAL;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * ZT_THREADS + threadIdx.x) >> 6;
+  const size_t begin = wave * cells_per_wave, end = min(begin + cells_per_wave, cells);  // (cells_per_wave: a multiple of 64)
+  auto better = [](Key a, Key b) -> Key { return STAT == Z_MIN ? (b < a ? b : a) : (b > a ? b : a); };
+  auto wave_best = [&](Key key) -> Key {
+    if constexpr (sizeof(Key) == 4) {
+      return STAT == Z_MIN ? wave_umin((unsigned)key) : wave_umax((unsigned)key);
+    } else {
+#pragma unroll
+      for (int offset = 32; offset >= 1; offset >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)key, offset), hi = __shfl_xor((unsigned)(key >> 32), offset);
+        key = better(key, ((Key)hi << 32) | lo);
+      }
+      return key;
+    }
+  };
+  int run_label = -1, marked = INT_MIN;
+  unsigned run_count = 0;
+  Key run_key = NEUTRAL;
+  auto flush = [&]() {  // (wave-uniform call)
+    if (run_label < 0) return;
+    const unsigned n = wave_sum_u32(run_count);
+    Key key = run_key;
+    if constexpr (STAT != Z_COUNT) key = wave_best(key);
+    if (lane == 0 && n != 0) {
+      atomicAdd(&count_of[run_label], n);
+      if constexpr (STAT == Z_MIN) atomicMin(&best_of[run_label], key);
+      if constexpr (STAT == Z_MAX) atomicMax(&best_of[run_label], key);
+    }
+    run_label = -1;
+    run_count = 0;
+    run_key = NEUTRAL;
+  };
+  walk_cells<T>(values, labels, begin, end, lane, [&](T v, int label, bool inside, size_t i) {
+    (void)inside;
+    (void)i;
+    const bool labelled = (unsigned)label < (unsigned)n_labels;
+    mark_present(present, label, labelled, &marked);
+    bool active = labelled && !(has_ndv && v == ndv);
+    if (thresholds && active) {
+      const float t = thresholds[label];
+      active = !(t != t) && (double)v >= (double)t;
+    }
+    const unsigned long long mask = __ballot(active);
+    if (mask == 0) return;  // (wave-uniform)
+    const int leader_label = __builtin_amdgcn_readlane(label, __ffsll((long long)mask) - 1);
+    const Key key = Ordered<T>::encode(v);
+    if (__all(!active || label == leader_label)) {
+      if (leader_label != run_label) {
+        flush();
+        run_label = leader_label;
+      }
+      if (active) {
+        run_count += 1;
+        run_key = better(run_key, key);
+      }
+    } else if (active) {  // a step across labels: every active lane on its own counter of the workgroup's table
+      atomicAdd(&count_of[label], 1u);
+      if constexpr (STAT == Z_MIN) atomicMin(&best_of[label], key);
+      if constexpr (STAT == Z_MAX) atomicMax(&best_of[label], key);
+    }
+  });
+  flush();
+  __syncthreads();
+  for (int l = threadIdx.x; l < n_labels; l += ZT_THREADS) {
+    const unsigned n = count_of[l];
+    if (n == 0) continue;
+    atomicAdd(&counts[l], (unsigned long long)n);
+    if constexpr (STAT == Z_MIN) atomicMin(&extreme[l], best_of[l]);
+    if constexpr (STAT == Z_MAX) atomicMax(&extreme[l], best_of[l]);
+  }
+}
+
 // tally = 0, extreme = the neutral key, present = 0 (first frame) in ONE launch: three fills of a few KiB cost three launches,
 // a fifth of what a count over 12.6 M cells takes
 template <typename K>
@@ -2822,7 +2921,7 @@ static HostFlag* host_flag() {
   static thread_local HostFlag f;
   int device = -1;
   if (hipGetDevice(&device) != hipSuccess) return nullptr;
-  if (!f.word && hipHostMalloc((void**)&f.word, 64, hipHostMallocDefault) != hipSuccess) {
+  if (!f.word && hipHostMalloc((void**)&f.word, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
     (void)hipGetLastError();
     f.word = nullptr;
     return nullptr;
@@ -2862,6 +2961,7 @@ __global__ __launch_bounds__(256) void zonal_chunk_kernel(const T* __restrict__ 
   unsigned r_count = 0, r_bad = 0, r_first = 255u, r_last = 0u;
   int r_hi = INT_MIN, r_lo = INT_MAX;
   bool dead = false;     // this label raster is not for chunk records (wave-uniform)
+  bool scattered = false;  // the first step's lanes mostly hold several labels each (wave-uniform)
   int marked = INT_MIN;  // the label whose `present` flag the step before has set (INT_MIN: none / several)
   // the cells of the full steps: unconditional 16-byte loads, one step ahead
   auto fetch_v = [&](unsigned step) -> CellQuad<T> {
@@ -2917,6 +3017,19 @@ __global__ __launch_bounds__(256) void zonal_chunk_kernel(const T* __restrict__ 
     bool remaining[ZC_LANE];
 #pragma unroll
     for (int k = 0; k < ZC_LANE; ++k) remaining[k] = inside[k] && cell_active<T>(v[k], label[k], n_labels, has_ndv, ndv, thresholds);
+    if (step == 0 && full) {
+      // A label raster made of runs keeps a lane's four consecutive cells under one label nearly everywhere (stripes 25 cells
+      // wide: 16 % of the lanes see two labels, polygons of 16 x 16 cells 25 %); labels scattered cell by cell do not (two
+      // labels at random: 87 %, twenty: all).  Round 6: a wave whose FIRST step has more than half of its lanes on mixed
+      // labels says so at once -- such a raster used to walk all of its steps here with a loop turn per label and step
+      // (20 labels at random: 424 us) only for the second kernel to find every step marked "add it literally".
+      // (... with MORE THAN EIGHT labels in that step: under a handful of labels the loop below is cheap, and integer cells
+      //  under 2 labels at random are answered here in 133 us against 338 by the certificates of the parallel sums)
+      bool mixed = false;
+#pragma unroll
+      for (int k = 1; k < ZC_LANE; ++k) mixed = mixed || (label[k] != label[0]);
+      scattered = __popcll(__ballot(mixed)) > 32;
+    }
     // what a cell contributes whatever its label: the float64 bincount adds, its top exponent (INT_MAX: not finite; INT_MIN:
     // zero) and the exponent of its lowest set bit -- once per cell, not once per label of the step
     double cell_x[ZC_LANE];
@@ -3019,6 +3132,13 @@ __global__ __launch_bounds__(256) void zonal_chunk_kernel(const T* __restrict__ 
         r_lo = min(r_lo, lo);
         r_first = min(r_first, step);
         r_last = max(r_last, step);
+      }
+    }
+    if (step == 0 && scattered && found > 8 && !dead) {
+      dead = true;
+      if (lane == 0) {
+        verdict->not_runs = 1u;
+        if (verdict_host) verdict_host[2] = 1u;
       }
     }
     if (dead) {
@@ -3358,6 +3478,49 @@ T scalar_from_bits(uint64_t bits) {
 static int64_t stretch() { static const int64_t v = getenv("GM_ZONAL_STRETCH") ? atoll(getenv("GM_ZONAL_STRETCH")) : 2048; return v; }
 static int64_t wave_cap() { static const int64_t v = getenv("GM_ZONAL_WAVECAP") ? atoll(getenv("GM_ZONAL_WAVECAP")) : 16; return v; }
 
+// Medians / percentiles under MANY labels (round 6).  Beyond the counting partition's 2047 labels the two sorts of lexsort were
+// all there was: 12.6 M cells of float32 noise under 49 152 polygons of 16 x 16 cells 1.4 ms, five radix passes, three of them
+// over digits of noise.  What such rasters have instead is SHORT labels: the cells are sorted by label alone (the label's bits:
+// two passes over keys that come in runs), and a workgroup then sorts every label's segment by value in LDS (a bitonic network
+// over the next power of two, padded with the largest key) and writes it back -- what zonal_pick_kernel reads its ranks from.
+// A label of more than ZS_MAX cells sets `too_long` and is left as it is: the caller falls back to the two sorts.
+constexpr unsigned ZS_MAX = 4096, ZS_SMALL = 1024;
+// THREADS lanes per label; labels of (FROM, CAP] cells (the launch for the short labels is one wave per label: its barriers cost
+// nothing; the second launch finds the few longer ones)
+template <typename K, int THREADS, unsigned FROM, unsigned CAP>
+__global__ __launch_bounds__(THREADS) void zonal_segment_sort_kernel(K* __restrict__ payload, const unsigned* __restrict__ first,
+                                                                     int n_labels, unsigned* __restrict__ too_long) {
+  __shared__ K seg[CAP];
+  const int l = blockIdx.x;
+  if (l >= n_labels) return;
+  const unsigned a = first[l], n = first[l + 1] - a;
+  if (n < 2 || n <= FROM) return;
+  if (n > CAP) {
+    if (CAP == ZS_MAX && threadIdx.x == 0) *too_long = 1u;
+    return;
+  }
+  unsigned P = 2;
+  while (P < n) P <<= 1;
+  for (unsigned i = threadIdx.x; i < P; i += THREADS) seg[i] = i < n ? payload[a + i] : ~(K)0;
+  __syncthreads();
+  for (unsigned k = 2; k <= P; k <<= 1) {
+    for (unsigned j = k >> 1; j > 0; j >>= 1) {
+      for (unsigned t = threadIdx.x; t < P / 2; t += THREADS) {
+        // the t-th pair of this stage: i has bit j clear
+        const unsigned i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), partner = i | j;
+        const K x = seg[i], y = seg[partner];
+        const bool ascending = (i & k) == 0;
+        if ((x > y) == ascending) {
+          seg[i] = y;
+          seg[partner] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (unsigned i = threadIdx.x; i < n; i += THREADS) payload[a + i] = seg[i];
+}
+
 struct Scratch {  // device buffers of one call, returned to the pool on every exit path
   void* p[32] = {nullptr};
   int n = 0;
@@ -3390,6 +3553,15 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     const int64_t waves = std::max<int64_t>(1, std::min<int64_t>((cells + stretch() - 1) / stretch(), (int64_t)gm::current_cu_count() * wave_cap()));
     const size_t cells_per_wave = (size_t)(((cells + waves - 1) / waves + 63) / 64 * 64);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
+    // label counts whose table fits a workgroup's LDS take zonal_tables_kernel (GM_ZONAL_TABLES=0: never -- A/B runs, and the
+    // tests compare the two; =2: the old kernel only for rasters the new one cannot take)
+    static const int tables_mode = getenv("GM_ZONAL_TABLES") ? atoi(getenv("GM_ZONAL_TABLES")) : 1;
+    const size_t t_lds = (statistic == Z_COUNT ? 0 : sizeof(Key) * (size_t)((n_labels + 1) & ~1)) + sizeof(unsigned) * (size_t)n_labels;
+    const bool tables = tables_mode != 0 && t_lds <= ZT_LDS_BYTES;
+    // (two workgroups of 16 waves per compute unit at most; a wave walks at least 4 steps)
+    const int64_t t_waves_wanted = std::max<int64_t>(1, std::min<int64_t>((cells + 255) / 256, (int64_t)gm::current_cu_count() * 2 * (ZT_THREADS / 64)));
+    const unsigned t_blocks = (unsigned)((t_waves_wanted + ZT_THREADS / 64 - 1) / (ZT_THREADS / 64));
+    const size_t t_cells_per_wave = (size_t)(((cells + (int64_t)t_blocks * (ZT_THREADS / 64) - 1) / ((int64_t)t_blocks * (ZT_THREADS / 64)) + 63) / 64 * 64);
     for (int64_t f = 0; f < frames; ++f) {
       unsigned char* seen = f == 0 ? present : (unsigned char*)nullptr;
       hipLaunchKernelGGL(zonal_direct_init_kernel<Key>, dim3((n_labels + 255) / 256), dim3(256), 0, s, tally, extreme,
@@ -3398,8 +3570,12 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       long long* counts_f = counts + (size_t)f * n_labels;
 #define GM_ZD(STAT)                                                                                                        \
   do {                                                                                                                     \
-    hipLaunchKernelGGL((zonal_direct_kernel<T, STAT>), dim3(blocks), dim3(256), 0, s, values + (size_t)f * cells, labels,  \
-                       (size_t)cells, cells_per_wave, n_labels, has_ndv, ndv, thresholds, tally, extreme, seen);          \
+    if (tables)                                                                                                            \
+      hipLaunchKernelGGL((zonal_tables_kernel<T, STAT>), dim3(t_blocks), dim3(ZT_THREADS), t_lds, s, values + (size_t)f * cells, \
+                         labels, (size_t)cells, t_cells_per_wave, n_labels, has_ndv, ndv, thresholds, tally, extreme, seen); \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((zonal_direct_kernel<T, STAT>), dim3(blocks), dim3(256), 0, s, values + (size_t)f * cells, labels, \
+                         (size_t)cells, cells_per_wave, n_labels, has_ndv, ndv, thresholds, tally, extreme, seen);         \
     hipLaunchKernelGGL((zonal_direct_result_kernel<T, STAT>), dim3((n_labels + 255) / 256), dim3(256), 0, s, tally, extreme, \
                        n_labels, out_f, counts_f);                                                                        \
   } while (0)
@@ -3407,7 +3583,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       else if (statistic == Z_MIN) GM_ZD(Z_MIN);
       else GM_ZD(Z_MAX);
 #undef GM_ZD
-      gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_DIRECT);
+      gm::route_hit(GM_ROUTE_ZONAL, tables ? GM_RZ_LDS_TABLES : GM_RZ_DIRECT);
       GM_HIP(hipGetLastError());
     }
     return GM_OK;
@@ -3450,6 +3626,10 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   static const bool select_allowed = !(getenv("GM_ZONAL_SELECT") && atoi(getenv("GM_ZONAL_SELECT")) == 0);
   const bool select_path = by_value && select_allowed && partition_allowed && n_labels + 1 <= ZP_BINS;
   const bool partition = partition_allowed && n_labels + 1 <= ZP_BINS && (!by_value || select_path || getenv("GM_ZONAL_PART"));
+  // medians / percentiles beyond the partition's label count: sort by label, then every label's segment by value in LDS
+  // (zonal_segment_sort_kernel; GM_ZONAL_SEGSORT=0: the two sorts of lexsort -- A/B runs, and the tests compare the two)
+  static const bool segsort_allowed = !(getenv("GM_ZONAL_SEGSORT") && atoi(getenv("GM_ZONAL_SEGSORT")) == 0);
+  const bool segsort_path = by_value && !select_path && segsort_allowed && n_labels + 1 > ZP_BINS;
   SelectState* sel_state = nullptr;
   unsigned* sel_hist = nullptr;
   unsigned long long* sel_next = nullptr;
@@ -3706,6 +3886,29 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
                          out_f, counts_f);
       GM_HIP(hipGetLastError());
       continue;
+    }
+    if (segsort_path) {
+      HostFlag* const flag = host_flag();
+      if (flag) {
+        flag->word[4] = 0u;
+        if ((rc = sort_by_label(keys_a, pay_a, keys_b, pay_b))) return rc;
+        hipLaunchKernelGGL((zonal_segment_sort_kernel<Key, 64, 0u, ZS_SMALL>), dim3((unsigned)n_labels), dim3(64), 0, s, pay_b, first, n_labels,
+                           flag->word + 4);
+        hipLaunchKernelGGL((zonal_segment_sort_kernel<Key, 256, ZS_SMALL, ZS_MAX>), dim3((unsigned)n_labels), dim3(256), 0, s, pay_b, first,
+                           n_labels, flag->word + 4);
+        hipLaunchKernelGGL(zonal_pick_kernel<T>, dim3((n_labels + 255) / 256), dim3(256), 0, s, pay_b, first, n_labels, statistic,
+                           qval, out_f, counts_f);
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipEventRecord(flag->event, s));
+        GM_HIP(hipEventSynchronize(flag->event));
+        if (((volatile unsigned*)flag->word)[4] == 0u) {
+          gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_SEGMENT_SORT);
+          continue;
+        }
+        // a label longer than a workgroup sorts: the keys again (the sort above used them up), then the two sorts
+        hipLaunchKernelGGL(zonal_keys_kernel<T>, dim3(blocks), dim3(256), 0, s, frame, labels, (size_t)cells, n_labels, has_ndv, ndv,
+                           thresholds, keys_a, pay_a, (unsigned char*)nullptr);
+      }
     }
     if (by_value) {
       gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_LEXSORT);

@@ -164,7 +164,7 @@ const char* gm_route_name(int family, int slot);
 #define GM_RZ_BLOCK_PIPELINE 11  /* sums: long labels composed block-parallel */
 #define GM_RZ_ORDERED_SUMS 12    /* sums: the wave-per-label kernel over sorted cells ran */
 #define GM_RZ_LDS_TABLES 13      /* count / min / max: per-workgroup LDS tables (label rasters without runs) */
-#define GM_RZ_PARCELS 14         /* sums / medians: small polygons answered inside one workgroup's stretch */
+#define GM_RZ_SEGMENT_SORT 14    /* medians / percentiles under many labels: sort by label, every label's segment sorted in LDS */
 #define GM_RZ_SLOTS 15
 /* bilinear slots */
 #define GM_RB_CALLS 0

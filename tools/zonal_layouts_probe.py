@@ -30,10 +30,13 @@ for name, labels in layouts:
     for tname, tile, ndv in (("f32 noise", dv, np.float32(-9999.0)), ("i32", di, -9999)):
         line = "%-44s %-10s" % (name, tname)
         for stat in ("sum", "count", "max", "median"):
-            geometry.label_statistics(tile, ndv, dl, n_labels, stat, None)
+            for _ in range(3):  # (round 6: three calls before the clock -- a route's scratch buffers are first allocated by its
+                #  second call where the first call's verdict sizes them, and a cold hipMalloc costs milliseconds: round 5's
+                #  figures for the many-label layouts were mostly that)
+                geometry.label_statistics(tile, ndv, dl, n_labels, stat, None)
             runtime.sync()
             t0 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(5):
                 geometry.label_statistics(tile, ndv, dl, n_labels, stat, None)
-            line += "  %s %8.1f" % (stat, (time.perf_counter() - t0) / 3 * 1e6)
+            line += "  %s %8.1f" % (stat, (time.perf_counter() - t0) / 5 * 1e6)
         print(line, flush=True)

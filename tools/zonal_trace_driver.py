@@ -20,12 +20,31 @@ values = (rng.standard_normal((1, h, w)) * 100).astype("f4")
 if positive:
     values = np.abs(values) + np.float32(3.0)
 values[rng.random(values.shape) < 0.1] = -9999.0
-if n_labels == 1:
+layout = os.environ.get("ZT_LAYOUT", "")  # round 6: the layouts of tools/zonal_layouts_probe.py / zonal_noise_labels_probe.py
+yy, xx = np.arange(h)[:, None], np.arange(w)[None, :]
+if layout:
+    labels = {"blocks16": lambda: (yy // 16) * (w // 16) + xx // 16,
+              "blocks32x64": lambda: (yy // 32) * (w // 64) + xx // 64,
+              "blocks48x40": lambda: ((yy + 7) // 48) * ((w + 40 + 13) // 40) + (xx + 13) // 40,
+              "stripes25": lambda: np.broadcast_to(xx // 25, (h, w)),
+              "bands3": lambda: np.broadcast_to(yy // 3, (h, w)),
+              "thirds": lambda: np.where(rng.random((h, w)) < 0.01, 3, np.broadcast_to(yy * 3 // h, (h, w))),
+              }.get(layout, lambda: rng.integers(0, int(layout.replace("random", "") or 1), size=(h, w)))()
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    n_labels = int(labels.max()) + 1
+    if os.environ.get("ZT_INT"):
+        values = np.round(values).astype("i4")
+elif n_labels == 1:
     labels = np.zeros((h, w), dtype=np.int32)
 else:
     labels = ((np.arange(h)[:, None] // 96) * 32 + np.arange(w)[None, :] // 128).astype(np.int32)
     n_labels = 1024
 dev_values, dev_labels = DeviceArray.from_numpy(values), DeviceArray.from_numpy(labels)
+import time  # noqa: E402
+before = runtime.route_stats("zonal")
 for _ in range(repeats):
-    geometry.label_statistics(dev_values, np.float32(-9999.0), dev_labels, n_labels, stat, None)
+    t0 = time.perf_counter()
+    geometry.label_statistics(dev_values, values.dtype.type(-9999.0), dev_labels, n_labels, stat, None)
+    print("call %.1f us" % ((time.perf_counter() - t0) * 1e6), flush=True)
 runtime.sync()
+print("routes", runtime.routes_taken(before, runtime.route_stats("zonal")))
