@@ -410,7 +410,9 @@ int build_entry(const gm_program& key, const std::vector<unsigned long long>& wo
       if ((o->bits & 0xffu) == GM_OPD_TEMP && ((o->bits >> 8) & 0xffu) + 1 > max_tmp) max_tmp = ((o->bits >> 8) & 0xffu) + 1;
   }
   e->n_temps = (int)max_tmp;
-  e->size = (key.n_inputs <= 2 && max_tmp <= 1) ? 0 : ((key.n_inputs <= 4 && max_tmp <= 2) ? 1 : 2);
+  // (size 3, round 6: 9-16 inputs in one launch -- an element-wise sum of 16 resident sources went through intermediate tiles
+  //  before: 384 us per 4096^2 request against 97 for its bytes at the copy ceiling)
+  e->size = (key.n_inputs <= 2 && max_tmp <= 1) ? 0 : ((key.n_inputs <= 4 && max_tmp <= 2) ? 1 : (key.n_inputs <= 8 ? 2 : 3));
   if (has_math && has_tables)
     return gm::fail(GM_ERR_UNSUPPORTED, "pow/exp/log and table lookups in one program (split it)");
   e->flavor = has_math ? VM_MATH : (has_tables ? VM_TABLES : VM_LIGHT);
@@ -693,7 +695,7 @@ static int run_batch_2d(const gm_program* prog, int n_tiles, const void* const* 
   const bool wide_class = code->prog.reg_class == GM_CLASS_F64 || code->prog.reg_class == GM_CLASS_I64;
   // (the 64-bit classes pay 8 elements per lane with their occupancy: 132 VGPRs instead of 70)
   int G = g_tuning.vec == 8 ? 2 : (g_tuning.vec == 4 ? 1 : ((code->n_uops_lowered > 3 || (bytes_per_elem < 8 && !wide_class)) ? 2 : 1));
-  if (code->flavor == VM_MATH || code->size == 2) G = 1;
+  if (code->flavor == VM_MATH || code->size >= 2) G = 1;
   // table ops cost the integer and 64-bit classes too many registers at 8 elements per lane
   // (102-136 VGPRs); the float32 class stays at 84
   if (code->flavor == VM_TABLES && code->prog.reg_class != GM_CLASS_F32 && g_tuning.vec == 0) G = 1;

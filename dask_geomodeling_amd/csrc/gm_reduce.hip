@@ -64,6 +64,59 @@ __device__ __forceinline__ void store_pack(C* p, const Pack<C, V>& r) {
   }
 }
 
+// Where the frames of a cell group come from.  FramesOfStack: frame j of the (n, pixels) stack the reference builds (NaN for no
+// data).  FramesOfRasters (round 6): n SEPARATE rasters of the work dtype read in place -- `stack_array[i, index] = values[index]`
+// (reduction.py:102-107) happens in the load: a cell that utils.get_index calls no data (~np.isclose(values, ndv), utils.py:61-64,
+// with the parameters the host works out per raster) arrives as NaN.  Until then every raster was coded into a stack by a launch
+// of its own and the stack read again: three passes over the bytes and ~20 us of host time per raster.
+struct RasterRef {  // = gm_raster_ref
+  const void* values;
+  double y, tol;
+  unsigned flags, reserved;
+};
+template <typename C>
+struct FramesOfStack {
+  const C* src;
+  long long pixels;
+  template <int V>
+  __device__ __forceinline__ Pack<C, V> load(int j) const { return load_pack<C, V>(src + (long long)j * pixels); }
+};
+template <typename C>
+struct FramesOfRasters {
+  const RasterRef* refs;  // (wave-uniform reads: scalar loads)
+  long long p;
+  template <int V>
+  __device__ __forceinline__ Pack<C, V> load(int j) const {
+    const RasterRef r = refs[j];
+    Pack<C, V> f = load_pack<C, V>((const C*)r.values + p);
+    const bool in_f64 = (r.flags & 1u) != 0, y_finite = (r.flags & 2u) != 0;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      bool close;
+      if (in_f64) {
+        const double xd = (double)f.v[e];
+        close = ((fabs(xd - r.y) <= r.tol) & y_finite) | (xd == r.y);
+      } else {
+        const float xf = (float)f.v[e], yf = (float)r.y;
+        close = ((fabsf(xf - yf) <= (float)r.tol) & y_finite) | (xf == yf);
+      }
+      f.v[e] = close ? std::numeric_limits<C>::quiet_NaN() : f.v[e];
+    }
+    return f;
+  }
+};
+template <typename C>
+struct StackSource {
+  const C* stack;
+  long long pixels;
+  __device__ __forceinline__ FramesOfStack<C> at(long long p) const { return FramesOfStack<C>{stack + p, pixels}; }
+};
+template <typename C>
+struct RasterSource {
+  const RasterRef* refs;
+  __device__ __forceinline__ FramesOfRasters<C> at(long long p) const { return FramesOfRasters<C>{refs, p}; }
+};
+
 // rounding of a float32 result to float16 (NumPy's HALF loops: float32 operation, then npy_float_to_half)
 template <bool HALF, typename C>
 __device__ __forceinline__ C rnd(C x) {
@@ -107,15 +160,15 @@ __device__ __forceinline__ void pw_term(const Pack<C, V>& f, const C (&mean)[V],
 }
 
 // NumPy's pairwise_sum over frames [start, start + len), len <= 128 (loops_utils.h, @TYPE@_pairwise_sum)
-template <typename C, typename A, bool HALF, int V, int MODE>
-__device__ __forceinline__ void pw_leaf(const C* src, long long pixels, int start, int len, const C (&mean)[V], A (&res)[V],
+template <typename C, typename A, bool HALF, int V, int MODE, typename F>
+__device__ __forceinline__ void pw_leaf(const F& fr, int start, int len, const C (&mean)[V], A (&res)[V],
                                         int (&cnt)[V]) {
   A term[V];
   if (len < 8) {
 #pragma unroll
     for (int e = 0; e < V; ++e) res[e] = (A)-0.0;  // (the loop's own start; the reduction adds it to add's identity: reduce_kernel)
     for (int i = 0; i < len; ++i) {
-      pw_term<C, A, HALF, V, MODE>(load_pack<C, V>(src + (long long)(start + i) * pixels), mean, term, cnt);
+      pw_term<C, A, HALF, V, MODE>(fr.template load<V>(start + i), mean, term, cnt);
 #pragma unroll
       for (int e = 0; e < V; ++e) res[e] += term[e];
     }
@@ -125,7 +178,7 @@ __device__ __forceinline__ void pw_leaf(const C* src, long long pixels, int star
   {
     Pack<C, V> f[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) f[u] = load_pack<C, V>(src + (long long)(start + u) * pixels);
+    for (int u = 0; u < 8; ++u) f[u] = fr.template load<V>(start + u);
 #pragma unroll
     for (int u = 0; u < 8; ++u) pw_term<C, A, HALF, V, MODE>(f[u], mean, r[u], cnt);
   }
@@ -133,7 +186,7 @@ __device__ __forceinline__ void pw_leaf(const C* src, long long pixels, int star
   for (; i < len - (len % 8); i += 8) {
     Pack<C, V> f[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) f[u] = load_pack<C, V>(src + (long long)(start + i + u) * pixels);
+    for (int u = 0; u < 8; ++u) f[u] = fr.template load<V>(start + i + u);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       pw_term<C, A, HALF, V, MODE>(f[u], mean, term, cnt);
@@ -144,7 +197,7 @@ __device__ __forceinline__ void pw_leaf(const C* src, long long pixels, int star
 #pragma unroll
   for (int e = 0; e < V; ++e) res[e] = ((r[0][e] + r[1][e]) + (r[2][e] + r[3][e])) + ((r[4][e] + r[5][e]) + (r[6][e] + r[7][e]));
   for (; i < len; ++i) {
-    pw_term<C, A, HALF, V, MODE>(load_pack<C, V>(src + (long long)(start + i) * pixels), mean, term, cnt);
+    pw_term<C, A, HALF, V, MODE>(fr.template load<V>(start + i), mean, term, cnt);
 #pragma unroll
     for (int e = 0; e < V; ++e) res[e] += term[e];
   }
@@ -153,8 +206,8 @@ __device__ __forceinline__ void pw_leaf(const C* src, long long pixels, int star
 // DEPTH >= 0: the recursion unrolled (everything stays in registers; n <= 128 * 2^DEPTH).  DEPTH < 0: stacks of any
 // length -- the recursion walked with an explicit stack of the left halves' sums (a lane-private array indexed at run
 // time lives in scratch memory, which is why the short stacks do not take this route), piece by piece.
-template <typename C, typename A, bool HALF, int V, int MODE, int DEPTH>
-__device__ void pw_sum(const C* src, long long pixels, int start, int n, const C (&mean)[V], A (&res)[V], int (&cnt)[V]) {
+template <typename C, typename A, bool HALF, int V, int MODE, int DEPTH, typename F>
+__device__ void pw_sum(const F& fr, int start, int n, const C (&mean)[V], A (&res)[V], int (&cnt)[V]) {
   if constexpr (DEPTH < 0) {
     // NumPy hands the reduction loop at most `bufsize` = 8192 elements at a time (the ufunc's buffered iterator),
     // so a longer stack is the chain  0.0 + pairwise(first 8192) + pairwise(next 8192) + ...  (measured against
@@ -170,7 +223,7 @@ __device__ void pw_sum(const C* src, long long pixels, int start, int n, const C
       while (sp >= 0) {
         if (phase[sp] == 0) {
           if (len[sp] <= RD_PW_BLOCK || sp == LEVELS - 1) {
-            pw_leaf<C, A, HALF, V, MODE>(src, pixels, at[sp], len[sp], mean, part, cnt);
+            pw_leaf<C, A, HALF, V, MODE>(fr, at[sp], len[sp], mean, part, cnt);
             --sp;
             continue;
           }
@@ -197,29 +250,29 @@ __device__ void pw_sum(const C* src, long long pixels, int start, int n, const C
       for (int e = 0; e < V; ++e) res[e] += part[e];
     }
   } else if constexpr (DEPTH == 0) {
-    pw_leaf<C, A, HALF, V, MODE>(src, pixels, start, n, mean, res, cnt);  // (longer stacks take the DEPTH < 0 form)
+    pw_leaf<C, A, HALF, V, MODE>(fr, start, n, mean, res, cnt);  // (longer stacks take the DEPTH < 0 form)
   } else {
     if (n <= RD_PW_BLOCK) {
-      pw_leaf<C, A, HALF, V, MODE>(src, pixels, start, n, mean, res, cnt);
+      pw_leaf<C, A, HALF, V, MODE>(fr, start, n, mean, res, cnt);
       return;
     }
     int n2 = n / 2;
     n2 -= n2 % 8;
     A right[V];
-    pw_sum<C, A, HALF, V, MODE, DEPTH - 1>(src, pixels, start, n2, mean, res, cnt);
-    pw_sum<C, A, HALF, V, MODE, DEPTH - 1>(src, pixels, start + n2, n - n2, mean, right, cnt);
+    pw_sum<C, A, HALF, V, MODE, DEPTH - 1>(fr, start, n2, mean, res, cnt);
+    pw_sum<C, A, HALF, V, MODE, DEPTH - 1>(fr, start + n2, n - n2, mean, right, cnt);
 #pragma unroll
     for (int e = 0; e < V; ++e) res[e] += right[e];
   }
 }
 
 // sum / product / min / max / mean / var / std / argmin / argmax
-template <typename C, bool HALF, int STAT, int V, int PW_DEPTH = RD_PW_DEPTH>
-__global__ __launch_bounds__(256) void reduce_kernel(const C* __restrict__ stack, int n, long long pixels,
+template <typename C, bool HALF, int STAT, int V, int PW_DEPTH = RD_PW_DEPTH, typename SRC = StackSource<C>>
+__global__ __launch_bounds__(256) void reduce_kernel(const SRC source, int n, long long pixels,
                                                      C* __restrict__ out, C fill) {
   const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
   if (p >= pixels) return;
-  const C* src = stack + p;
+  const auto fr = source.at(p);
   const C nan = std::numeric_limits<C>::quiet_NaN(), inf = std::numeric_limits<C>::infinity();
   C acc[V];
   int cnt[V], arg[V];
@@ -262,7 +315,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const C* __restrict__ stack
     C none[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) none[e] = (C)0;
-    pw_sum<C, A, HALF, V, 0, PW_DEPTH>(src, pixels, 0, n, none, total, cnt);
+    pw_sum<C, A, HALF, V, 0, PW_DEPTH>(fr, 0, n, none, total, cnt);
     // (np.sum puts the loop's result on top of add's identity: cells whose every raster is -0.0 sum to +0.0 -- measured,
     //  NumPy 2.2, round-4 fuzzing; until then such a cell came out as -0.0)
 #pragma unroll
@@ -274,7 +327,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const C* __restrict__ stack
     if constexpr (STAT == GM_RED_VAR || STAT == GM_RED_STD) {
       A squares[V];
       int ignored[V];
-      pw_sum<C, A, HALF, V, 1, PW_DEPTH>(src, pixels, 0, n, r, squares, ignored);
+      pw_sum<C, A, HALF, V, 1, PW_DEPTH>(fr, 0, n, r, squares, ignored);
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         C var = from_f64<HALF, C>((double)rnd<HALF, C>((C)squares[e]) / (double)cnt[e]);
@@ -287,11 +340,11 @@ __global__ __launch_bounds__(256) void reduce_kernel(const C* __restrict__ stack
     for (; j + RD_UNROLL <= n; j += RD_UNROLL) {
       Pack<C, V> f[RD_UNROLL];
 #pragma unroll
-      for (int u = 0; u < RD_UNROLL; ++u) f[u] = load_pack<C, V>(src + (long long)(j + u) * pixels);
+      for (int u = 0; u < RD_UNROLL; ++u) f[u] = fr.template load<V>(j + u);
 #pragma unroll
       for (int u = 0; u < RD_UNROLL; ++u) take(f[u], j + u);
     }
-    for (; j < n; ++j) take(load_pack<C, V>(src + (long long)j * pixels), j);
+    for (; j < n; ++j) take(fr.template load<V>(j), j);
 #pragma unroll
     for (int e = 0; e < V; ++e)
       r[e] = (STAT == GM_RED_ARGMIN || STAT == GM_RED_ARGMAX) ? (C)arg[e] : (STAT == GM_RED_PRODUCT ? rnd<HALF, C>(acc[e]) : acc[e]);
@@ -508,7 +561,7 @@ int launch_reduce(const void* stack, int n, long long pixels, int statistic, con
     const unsigned g1 = (unsigned)((pixels + 255) / 256);
 #define GM_RD_DEEP(STAT)                                                                                               \
   case STAT:                                                                                                           \
-    hipLaunchKernelGGL((reduce_kernel<C, HALF, STAT, 1, -1>), dim3(g1), dim3(256), 0, s, (const C*)stack, n, pixels, (C*)out, fill); \
+    hipLaunchKernelGGL((reduce_kernel<C, HALF, STAT, 1, -1>), dim3(g1), dim3(256), 0, s, StackSource<C>{(const C*)stack, pixels}, n, pixels, (C*)out, fill); \
     break;
     switch (statistic) {
       GM_RD_DEEP(GM_RED_SUM) GM_RD_DEEP(GM_RED_MEAN) GM_RD_DEEP(GM_RED_VAR) GM_RD_DEEP(GM_RED_STD)
@@ -522,19 +575,89 @@ int launch_reduce(const void* stack, int n, long long pixels, int statistic, con
   const unsigned gx = (unsigned)((pixels + 256LL * V - 1) / (256LL * V));
 #define GM_RD(STAT)                                                                                                    \
   case STAT:                                                                                                           \
-    if (vec) hipLaunchKernelGGL((reduce_kernel<C, HALF, STAT, VV>), dim3(gx), dim3(256), 0, s, (const C*)stack, n, pixels, (C*)out, fill); \
-    else hipLaunchKernelGGL((reduce_kernel<C, HALF, STAT, 1>), dim3(gx), dim3(256), 0, s, (const C*)stack, n, pixels, (C*)out, fill);      \
+    if (vec) hipLaunchKernelGGL((reduce_kernel<C, HALF, STAT, VV>), dim3(gx), dim3(256), 0, s, StackSource<C>{(const C*)stack, pixels}, n, pixels, (C*)out, fill); \
+    else hipLaunchKernelGGL((reduce_kernel<C, HALF, STAT, 1>), dim3(gx), dim3(256), 0, s, StackSource<C>{(const C*)stack, pixels}, n, pixels, (C*)out, fill);      \
+    break;
+  // The sums of up to 128 rasters are ONE leaf of NumPy's pairwise recursion: the kernel without the recursion's five unrolled
+  // halvings (round 6: with them the 16-byte float32 kernel took 252 VGPRs and spilled 128 bytes -- whatever n was --, which is
+  // why sums over a stack ran at 1 TB/s next to minima at 4)
+#define GM_RD_ADD(STAT)                                                                                                \
+  case STAT:                                                                                                           \
+    if (n <= RD_PW_BLOCK) {                                                                                            \
+      if (vec) hipLaunchKernelGGL((reduce_kernel<C, HALF, STAT, VV, 0>), dim3(gx), dim3(256), 0, s, StackSource<C>{(const C*)stack, pixels}, n, pixels, (C*)out, fill); \
+      else hipLaunchKernelGGL((reduce_kernel<C, HALF, STAT, 1, 0>), dim3(gx), dim3(256), 0, s, StackSource<C>{(const C*)stack, pixels}, n, pixels, (C*)out, fill);      \
+    } else { /* (129 .. 4096 rasters: one cell per lane -- the 16-byte form of the unrolled recursion spills) */          \
+      hipLaunchKernelGGL((reduce_kernel<C, HALF, STAT, 1>), dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, StackSource<C>{(const C*)stack, pixels}, n, pixels, (C*)out, fill); \
+    }                                                                                                                  \
     break;
   switch (statistic) {
-    GM_RD(GM_RED_SUM) GM_RD(GM_RED_MIN) GM_RD(GM_RED_MAX) GM_RD(GM_RED_MEAN) GM_RD(GM_RED_VAR) GM_RD(GM_RED_STD)
+    GM_RD_ADD(GM_RED_SUM) GM_RD(GM_RED_MIN) GM_RD(GM_RED_MAX) GM_RD_ADD(GM_RED_MEAN) GM_RD_ADD(GM_RED_VAR) GM_RD_ADD(GM_RED_STD)
     GM_RD(GM_RED_PRODUCT) GM_RD(GM_RED_ARGMIN) GM_RD(GM_RED_ARGMAX)
     default: return gm::fail(GM_ERR_INVALID, "gm_reduce_stack: statistic %d", statistic);
   }
 #undef GM_RD
+#undef GM_RD_ADD
   return GM_OK;
 }
 
+// n separate rasters of the work dtype, read in place
+template <typename C>
+int launch_reduce_rasters(const gm_raster_ref* rasters, int n, long long pixels, int statistic, void* out, uint64_t fill_bits, hipStream_t s) {
+  const C fill = fill_of<C>(fill_bits);
+  constexpr int VV = 16 / (int)sizeof(C);
+  bool vec = (pixels % VV) == 0 && ((uintptr_t)out % 16) == 0;
+  for (int i = 0; i < n; ++i) vec = vec && ((uintptr_t)rasters[i].values % 16) == 0;
+  RasterRef* refs = nullptr;
+  int rc = gm_malloc((void**)&refs, sizeof(RasterRef) * (size_t)n);
+  if (rc) return rc;
+  static_assert(sizeof(RasterRef) == sizeof(gm_raster_ref), "gm_raster_ref layout");
+  rc = gm_h2d(refs, rasters, sizeof(RasterRef) * (size_t)n);  // (through the calling thread's pinned bounce buffer)
+  if (rc) {
+    (void)gm_free(refs);
+    return rc;
+  }
+  const RasterSource<C> source{refs};
+  // (sums over more rasters than one leaf of the pairwise recursion: the explicit-stack form, one cell per lane -- the unrolled
+  //  recursion spills once the no-data test is part of every load)
+  const bool deep = n > RD_PW_BLOCK &&
+                    (statistic == GM_RED_SUM || statistic == GM_RED_MEAN || statistic == GM_RED_VAR || statistic == GM_RED_STD);
+  const int V = (vec && !deep) ? VV : 1;
+  const unsigned gx = (unsigned)((pixels + 256LL * V - 1) / (256LL * V));
+#define GM_RR(STAT)                                                                                                                  \
+  case STAT:                                                                                                                         \
+    if (deep) hipLaunchKernelGGL((reduce_kernel<C, false, STAT, 1, -1, RasterSource<C>>), dim3(gx), dim3(256), 0, s, source, n, pixels, (C*)out, fill); \
+    else if (V > 1) hipLaunchKernelGGL((reduce_kernel<C, false, STAT, VV, 0, RasterSource<C>>), dim3(gx), dim3(256), 0, s, source, n, pixels, (C*)out, fill); \
+    else hipLaunchKernelGGL((reduce_kernel<C, false, STAT, 1, 0, RasterSource<C>>), dim3(gx), dim3(256), 0, s, source, n, pixels, (C*)out, fill); \
+    break;
+  switch (statistic) {
+    GM_RR(GM_RED_SUM) GM_RR(GM_RED_MIN) GM_RR(GM_RED_MAX) GM_RR(GM_RED_MEAN) GM_RR(GM_RED_VAR) GM_RR(GM_RED_STD)
+    GM_RR(GM_RED_PRODUCT) GM_RR(GM_RED_ARGMIN) GM_RR(GM_RED_ARGMAX)
+    default: rc = gm::fail(GM_ERR_UNSUPPORTED, "gm_reduce_rasters: statistic %d (medians and percentiles take gm_reduce_stack)", statistic);
+  }
+#undef GM_RR
+  (void)gm_free(refs);  // (the pool is stream-ordered: the launch above reads it before anybody can be handed the block)
+  return rc;
+}
+
 }  // namespace
+
+extern "C" int gm_reduce_rasters(const gm_raster_ref* rasters, int work_dtype, int64_t n, int64_t pixels, int statistic, void* out,
+                                 uint64_t fill_bits) {
+  if (!rasters || !out) return gm::fail(GM_ERR_INVALID, "null pointer");
+  if (n <= 0 || n > 0x7fffffff || pixels < 0) return gm::fail(GM_ERR_INVALID, "gm_reduce_rasters: %lld rasters of %lld pixels", (long long)n, (long long)pixels);
+  for (int64_t i = 0; i < n; ++i)
+    if (!rasters[i].values) return gm::fail(GM_ERR_INVALID, "gm_reduce_rasters: raster %lld is null", (long long)i);
+  if (pixels == 0) return GM_OK;
+  hipStream_t s = gm::current_stream();
+  if (!s) return GM_ERR_NO_DEVICE;
+  int rc;
+  if (work_dtype == GM_F32) rc = launch_reduce_rasters<float>(rasters, (int)n, pixels, statistic, out, fill_bits, s);
+  else if (work_dtype == GM_F64) rc = launch_reduce_rasters<double>(rasters, (int)n, pixels, statistic, out, fill_bits, s);
+  else return gm::fail(GM_ERR_UNSUPPORTED, "gm_reduce_rasters: rasters of dtype %d (float32 / float64 rasters in their own work dtype)", work_dtype);
+  if (rc) return rc;
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
 
 extern "C" int gm_reduce_stack(const void* stack, int work_dtype, int half, int64_t n, int64_t pixels, int statistic,
                                const gm_percentile_step* plan, void* out, uint64_t fill_bits) {

@@ -97,7 +97,7 @@ enum { UOP_GENERIC = 0, UOP_LD = 1, UOP_ST = 2, UOP_ADD = 3, UOP_SUB = 4, UOP_RS
        //        fill = the store's no-data value
        UOP_CLIPCMP = 19 };
 // operand source of a micro-op: 0 = literal, 1 + k = input k, 1 + 8 + k = temp k
-constexpr unsigned UOP_SRC_SCALAR = 0, UOP_SRC_INPUT = 1, UOP_SRC_TEMP = 9;
+constexpr unsigned UOP_SRC_SCALAR = 0, UOP_SRC_INPUT = 1, UOP_SRC_TEMP = 1 + GM_MAX_INPUTS;
 constexpr int GM_MAX_UOPS = 40;
 
 struct gm_uop {
@@ -1314,6 +1314,7 @@ struct Machine {
     }                                                                   \
     break;
       GM_SEL_IN(0) GM_SEL_IN(1) GM_SEL_IN(2) GM_SEL_IN(3) GM_SEL_IN(4) GM_SEL_IN(5) GM_SEL_IN(6) GM_SEL_IN(7)
+      GM_SEL_IN(8) GM_SEL_IN(9) GM_SEL_IN(10) GM_SEL_IN(11) GM_SEL_IN(12) GM_SEL_IN(13) GM_SEL_IN(14) GM_SEL_IN(15)
       GM_SEL_TMP(0) GM_SEL_TMP(1) GM_SEL_TMP(2) GM_SEL_TMP(3)
 #undef GM_SEL_IN
 #undef GM_SEL_TMP
@@ -1729,8 +1730,10 @@ int launch_class(const VmLaunch& args, int size, int G, int flavor, dim3 grid, d
     } else if (size == 1) {                                          \
       if (G >= 2 && G_M >= 2) GM_VM_LAUNCH(RC, G_M, 4, 2, FLAVOR_);  \
       else GM_VM_LAUNCH(RC, 1, 4, 2, FLAVOR_);                       \
-    } else {                                                         \
+    } else if (size == 2) {                                          \
       GM_VM_LAUNCH(RC, 1, 8, 4, FLAVOR_);                            \
+    } else {                                                         \
+      GM_VM_LAUNCH(RC, 1, 16, 4, FLAVOR_);                           \
     }                                                                \
   } while (0)
 

@@ -17,7 +17,7 @@ from .array import DeviceArray, as_device, as_device_view
 from .dtypes import code_of
 from .runtime import gm_scalar
 
-GM_MAX_INPUTS, GM_MAX_STEPS, GM_MAX_TEMPS = 8, 24, 4
+GM_MAX_INPUTS, GM_MAX_STEPS, GM_MAX_TEMPS = 16, 24, 4
 GM_MAX_TABLES, GM_MAX_LINEAR_EDGES = 4, 32
 LOOKUP_MAX_WINDOW, LOOKUP_MAX_EXCEPTIONS = 8192, 8  # the window lives in LDS: 8192 x 8 B = 64 KiB
 CLASS_F32, CLASS_F64, CLASS_I32, CLASS_I64 = 0, 1, 2, 3

@@ -57,9 +57,26 @@ def check_statistic(statistic):
             raise ValueError('Unknown statistic "{}"'.format(statistic))
 
 
+_INDEX_EXTRA = {}   # (dtype, type of the no-data value, its bytes) -> the parameters below: ~20 us of NumPy scalar work per
+                    # raster otherwise, which is what a stack of 60 rasters cost in host time before any kernel ran
+
+
 def _index_extra(dtype, ndv):
     """flags / tolerance of utils.get_index for a tile: isclose for float tiles, exact != for the others."""
     dtype = np.dtype(dtype)
+    try:
+        key = (dtype.str, type(ndv), ndv.tobytes() if isinstance(ndv, np.generic) else ndv)
+        hit = _INDEX_EXTRA.get(key)
+    except TypeError:
+        key = hit = None
+    if hit is None:
+        hit = _index_extra_uncached(dtype, ndv)
+        if key is not None and len(_INDEX_EXTRA) < 4096 and not (isinstance(ndv, float) and ndv != ndv):
+            _INDEX_EXTRA[key] = hit
+    return dict(hit)
+
+
+def _index_extra_uncached(dtype, ndv):
     if dtype.kind == "f":
         in_f64, y, tol, finite = devops.isclose_params(dtype, ndv)
         return {"flags": (1 if in_f64 else 0) | (2 if finite else 0), "tol": tol, "y": y}
@@ -145,6 +162,9 @@ def _nan_function(stack, statistic, percentile, fill_value, dtype):
     if long_sort and half:
         raise NotImplementedError("%s over %d rasters in float16 (a 1-byte output dtype)" % (statistic, n))
     bands = shape[0]
+    in_place = _rasters_in_place(stack, nodes, statistic, storage, half, shape, fill_value, dtype)
+    if in_place is not None:
+        return in_place
     stacked = DeviceArray.empty((n * bands,) + shape[1:], storage)
     for i, node in enumerate(nodes):
         extra = dict(_index_extra(node.dtype, node.ndv), work=storage)
@@ -180,6 +200,48 @@ def _nan_function(stack, statistic, percentile, fill_value, dtype):
         return result
     # (`out[...] = func(...)` assigns the float statistic into the output raster without a finite check,
     #  reduction.py:115: an integer raster of up to 32 bits gets NumPy's x86 conversion of whatever it is)
+    like_x86 = dtype.kind in "iub" and dtype.itemsize <= 4 and dtype != np.dtype("u4")
+    return _through_program(P.Op("copy", [P.Leaf(None, storage, None, values=result)], dtype, None,
+                                 extra={"indefinite": True} if like_x86 else None))
+
+
+class gm_raster_ref(ctypes.Structure):
+    _fields_ = [("values", ctypes.c_void_p), ("ndv_compared", ctypes.c_double), ("tolerance", ctypes.c_double),
+                ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+_RASTERS_IN_PLACE = True  # (the tests switch it off to compare the two routes)
+
+
+def _rasters_in_place(stack, nodes, statistic, storage, half, shape, fill_value, dtype):
+    """Round 6: rasters that already ARE the work dtype (float32 rasters reduced in float32, float64 in float64) are read where
+    they are -- one launch over n tile pointers, the NaN coding of reduction.py:99-107 done in the load (gm_reduce_rasters) --
+    instead of being coded into a stack by a launch each and read again.  -> the result tile, or None for everything else."""
+    from ..hip import program as P
+    from ..hip import runtime
+    from ..hip.array import DeviceArray, as_device
+    from ..hip.dtypes import code_of
+    if not _RASTERS_IN_PLACE or half or statistic in ("median", "percentile") or len(stack) < 2:
+        return None
+    if any(np.dtype(node.dtype) != storage or tuple(np.shape(node.values)) != shape for node in nodes):
+        return None
+    L = _lib()
+    if not getattr(L, "_gm_reduce_rasters_declared", False):
+        L.gm_reduce_rasters.argtypes = [ctypes.POINTER(gm_raster_ref), ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_uint64]
+        L.gm_reduce_rasters.restype = ctypes.c_int
+        L._gm_reduce_rasters_declared = True
+    tiles = [as_device(node.values) for node in nodes]  # (windows of resident rasters are compacted: the kernel reads whole tiles)
+    refs = (gm_raster_ref * len(nodes))()
+    for ref, node, tile in zip(refs, nodes, tiles):
+        extra = _index_extra(node.dtype, node.ndv)
+        ref.values, ref.ndv_compared, ref.tolerance, ref.flags = tile.ptr, extra["y"], extra["tol"], extra["flags"]
+    result = DeviceArray.empty(shape, storage)
+    runtime.check(L.gm_reduce_rasters(refs, code_of(storage), len(nodes), result.size, STATISTICS[statistic], result.ptr,
+                                      runtime.scalar_bits(float(fill_value), storage)), "gm_reduce_rasters")
+    del tiles
+    if storage == dtype:
+        return result
     like_x86 = dtype.kind in "iub" and dtype.itemsize <= 4 and dtype != np.dtype("u4")
     return _through_program(P.Op("copy", [P.Leaf(None, storage, None, values=result)], dtype, None,
                                  extra={"indefinite": True} if like_x86 else None))

@@ -226,7 +226,7 @@ const char* gm_version(void);
  * so a fused chain is bit-identical to the unfused one.
  * ========================================================================== */
 
-#define GM_MAX_INPUTS 8
+#define GM_MAX_INPUTS 16
 #define GM_MAX_STEPS 24
 #define GM_MAX_TEMPS 4
 #define GM_MAX_TABLES 4
@@ -664,6 +664,19 @@ enum gm_reduce_statistic {
 };
 int gm_reduce_stack(const void* stack, int work_dtype, int half, int64_t n, int64_t pixels, int statistic,
                     const gm_percentile_step* plan, void* out, uint64_t fill_bits);
+/* The same statistics (all but MEDIAN / PERCENTILE) over n SEPARATE rasters of the work dtype read in place: the coding of the
+ * stack -- `stack_array[i, index] = values[index]` with index = utils.get_index(values, no_data_value), reduction.py:99-107,
+ * utils.py:61-64 -- happens in the load.  Per raster: its cells (device, `pixels` of them, C-contiguous), and the parameters of
+ * ~np.isclose(values, ndv) as NumPy's promotion rules give them for that raster: the no-data value as compared, the tolerance
+ * 1e-8 + 1e-5 |ndv|, flags bit 0: compare in float64, bit 1: the no-data value is finite.  float32 rasters with work dtype
+ * float32, float64 with float64; anything else (other raster dtypes, a float16 work dtype) goes through gm_reduce_stack. */
+typedef struct gm_raster_ref {
+  const void* values;
+  double ndv_compared, tolerance;
+  uint32_t flags, reserved;
+} gm_raster_ref;
+int gm_reduce_rasters(const gm_raster_ref* rasters, int work_dtype, int64_t n, int64_t pixels, int statistic, void* out,
+                      uint64_t fill_bits);
 
 /* ==========================================================================
  * N4: labelled (zonal) statistics -- the numeric core of geometry.AggregateRaster
