@@ -19,13 +19,14 @@ through the store's plan (``_direct``).  Everything else -- other modes, configu
 ordinary graph path, as does a request whose plan cannot be built.
 """
 
+import collections
 import os
 import threading
 
 import numpy as np
 
 from . import config as _config
-from .core.graphs import Block, _request_token
+from .core.graphs import Block, _is_resident_answer, _request_token
 
 try:  # resolved once: a failing import would search sys.path on every request
     from dask.base import get_scheduler as _dask_get_scheduler
@@ -82,14 +83,22 @@ class _PlainTask(object):
         return self.function(*[values[slot] if isinstance(slot, int) else slot[0] for slot in self.template])
 
 
+MAX_KEPT_BOXES = 256
+
+
 class ViewPlan(object):
     """One fused program over the leaf Blocks of a view, valid for every bbox of one request shape."""
 
-    __slots__ = ("task", "leaves")
+    __slots__ = ("task", "leaves", "boxes")
 
     def __init__(self, task, leaves):
         self.task = task      # fuse.FusedTask: the whole view above its leaves
         self.leaves = leaves  # [(leaf Block, its request without a usable bbox)] in the order of task.leaf_keys
+        # bounding box -> the launch of that box with its arguments marshalled (round 6): a box whose leaves all answered with
+        # resident data as it stands (zero-copy windows: DeviceArray.resident) asks them, plans and marshals once; the next
+        # request for the same box is one allocation and one launch call -- every launch still happens, nothing computed is
+        # kept.  Least recently used first; a tile server's boxes repeat, a box never seen before costs what it cost.
+        self.boxes = collections.OrderedDict()
 
     def leaf_values(self, bbox):
         values = []
@@ -103,7 +112,25 @@ class ViewPlan(object):
         return values
 
     def run(self, bbox):
-        return self.task(*self.leaf_values(bbox))
+        boxes = self.boxes
+        try:
+            kept = boxes.get(bbox)
+        except TypeError:  # (a bounding box that does not hash: a list)
+            bbox = tuple(bbox)
+            kept = boxes.get(bbox)
+        if kept is not None:
+            return kept()
+        values = self.leaf_values(bbox)
+        result = self.task(*values)
+        prepare = getattr(self.task, "gm_prepare", None)
+        if prepare is not None and all(_is_resident_answer(v) for v in values):
+            kept = prepare(*values)
+            if kept is not None:
+                with _lock:
+                    boxes[bbox] = kept
+                    while len(boxes) > MAX_KEPT_BOXES:
+                        boxes.popitem(last=False)
+        return result
 
 
 def _build_view_plan(view, request):

@@ -390,8 +390,9 @@ class MemorySource(RasterSourceBase):
             return None
         fill = self.fillvalue
         fill = fill.item() if hasattr(fill, "item") else fill
-        return {"values": raster_data.on_device().window(window[0], window[1], request["height"], request["width"]),
-                "no_data_value": fill}
+        values = raster_data.on_device().window(window[0], window[1], request["height"], request["width"])
+        values.resident = True  # (a zero-copy window of the resident raster: the same bytes for the same request every time)
+        return {"values": values, "no_data_value": fill}
 
     def get_sources_and_requests(self, **request):
         mode = request["mode"]

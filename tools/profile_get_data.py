@@ -1,5 +1,5 @@
 import sys, time, cProfile, pstats, numpy as np
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dask_geomodeling_amd import raster, config as gmconfig
 from dask_geomodeling_amd.hip import runtime
 from dask_geomodeling_amd.raster.sources import generate_window
