@@ -410,6 +410,14 @@ __global__ __launch_bounds__(THREADS) void bilinear2x_kernel(const float* __rest
   } else if (swizzle == 2 && (tiles_x & 7u) == 0) {
     const unsigned row = pid / tiles_x, j = pid - row * tiles_x;
     pid = row * tiles_x + (j & 7u) * (tiles_x >> 3) + (j >> 3);
+  } else if (swizzle == 3 && (tiles_x & 7u) == 0) {
+    // round 6: every XCD takes a vertical STRIP of the destination, tiles_x / 8 tiles wide, and walks it row by row: the tile
+    // below a tile follows it tiles_x / 8 places later on the same XCD -- both are in flight together, and the two source rows
+    // they share (the lower apron of the one, the first interior rows of the other) come out of that XCD's L2 the second
+    // time: configs[3] fetched 1.24 x its source before, the aprons of every tile from HBM.  The chip as a whole still sweeps
+    // the destination top to bottom.
+    const unsigned strip = tiles_x >> 3, k = pid >> 3;
+    pid = (k / strip) * tiles_x + (pid & 7u) * strip + (k % strip);
   }
   const int band = blockIdx.y;
   const int hd = 2 * hs, wd = 2 * ws;

@@ -16,7 +16,33 @@ F32MAX = float(np.finfo("f4").max)
 I32MAX = 2147483647
 
 
-def timeit(label, bytes_per_call, calls, reps=3):
+# What BINDS the kernels that are not bound by HBM (round 6): wave instructions per launch on the pipe that limits them, from
+# the SQ counters of profiles/r05_pmc_stencils_before.log / r05_pmc_power.log (SQ_INSTS_VALU, SQ_INSTS_LDS per launch over
+# 8192^2 cells; re-collected for round 6 by tools/pmc_kbench.sh: profiles/r06_pmc_stencils.log), priced at what the part issues:
+# a compute unit issues one wave64 vector instruction per clock (4 SIMDs of 16 lanes: /opt/skills/guides/MI355X_MICROARCH.md),
+# float64 ones at half that; its LDS moves 128 bytes per clock, so a ds_read2_b32 of a wave (512 bytes) holds it for 4 clocks.
+# label prefix -> (pipe, wave instructions per cell, clocks per instruction)
+CUS, CLOCK_HZ = 256, 2.4e9
+BINDING = {
+    "hillshade f32 -> u8 (5": ("VALU issue", 3.42e7 / 8192 ** 2, 1.0),
+    "hillshade f32 -> u8 with": ("VALU issue", 3.42e7 / 8192 ** 2, 1.0),
+    "moving max f32, size 15 (": ("LDS pipe", 1.294e7 / 8192 ** 2, 4.0),
+    "moving max f32, size 11 (": ("LDS pipe", 1.135e7 / 8192 ** 2, 4.0),
+    "dilate u8, 2 values": ("VALU issue", 1.679e7 / 8192 ** 2, 1.0),
+    "smooth f32, sigma 2 px, radius 8 (one": ("VALU issue (float64 taps: between 1 and 2 clocks each)", 7.691e7 / 8192 ** 2, 1.5),
+    "smooth f32, sigma 1 px, radius 4 (one": ("VALU issue (float64 taps: between 1 and 2 clocks each)", 4.639e7 / 8192 ** 2, 1.5),
+}
+
+
+def binding_note(label, cells, us):
+    for prefix, (pipe, per_cell, clocks) in BINDING.items():
+        if label.startswith(prefix):
+            floor_us = per_cell * cells * clocks / (CUS * CLOCK_HZ) * 1e6
+            return "  | %.0f us of %s = %.2f of that bound" % (floor_us, pipe, floor_us / us)
+    return ""
+
+
+def timeit(label, bytes_per_call, calls, reps=3, cells=None):
     for f in calls:
         f()
     runtime.sync()
@@ -28,7 +54,8 @@ def timeit(label, bytes_per_call, calls, reps=3):
     e1.record()
     e1.synchronize()
     us = e0.elapsed_ms(e1) / (reps * len(calls)) * 1e3
-    print("%-44s %9.1f us  %7.1f GB/s  (%4.1f%% of 8 TB/s)" % (label, us, bytes_per_call / us / 1e3, bytes_per_call / us / 1e3 / 80), flush=True)
+    print("%-44s %9.1f us  %7.1f GB/s  (%4.1f%% of 8 TB/s)%s" % (label, us, bytes_per_call / us / 1e3, bytes_per_call / us / 1e3 / 80,
+                                                                    binding_note(label, cells, us) if cells else ""), flush=True)
 
 
 def main():
@@ -101,14 +128,14 @@ def main():
         src = [generate_window((side, side), "f4", 90 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side, side) for i in range(T)]
         m = (side - 2) * (side - 2)
         timeit("hillshade f32 -> u8 (5 B/px)", 5.0 * m,
-               [lambda t=t: stencil.hillshade(t, np.float32(F32MAX), 0, (0.5, 0.5), 45.0, 315.0) for t in src])
+               [lambda t=t: stencil.hillshade(t, np.float32(F32MAX), 0, (0.5, 0.5), 45.0, 315.0) for t in src], cells=m)
         srcm = [generate_window((side + 2, side + 2), "f4", 90 + i, 0.0, 100.0, F32MAX, (97, 89), 0, 0, side + 2, side + 2) for i in range(2)]
         timeit("hillshade f32 -> u8 with margin (%d wide, 5 B/px)" % (side + 2), 5.0 * n,
-               [lambda t=t: stencil.hillshade(t, np.float32(F32MAX), 0, (0.5, 0.5), 45.0, 315.0) for t in srcm])
+               [lambda t=t: stencil.hillshade(t, np.float32(F32MAX), 0, (0.5, 0.5), 45.0, 315.0) for t in srcm], cells=n)
         del srcm
         for size in (3, 5, 7, 11, 15):
             timeit("moving max f32, size %d (8 B/px)" % size, 8.0 * (side - size + 1) ** 2,
-                   [lambda t=t: stencil.moving_max(t, np.float32(F32MAX), size) for t in src])
+                   [lambda t=t: stencil.moving_max(t, np.float32(F32MAX), size) for t in src], cells=(side - size + 1) ** 2)
         # the zero-sign pass behind a float launch at work: 2 % of the cells -0.0, 2 % +0.0, the rest negative (every
         # window's maximum a zero, most windows with zeros of both signs)
         from dask_geomodeling_amd.hip.array import DeviceArray
@@ -123,14 +150,14 @@ def main():
                    [lambda t=t: stencil.moving_max(t, np.float32(F32MAX), size) for t in zeros])
         del zeros
         u8 = [generate_window((side, side), "u1", 95 + i, 0.0, 6.0, 255, (50, 50), 0, 0, side, side) for i in range(T)]
-        timeit("dilate u8, 2 values (2 B/px)", 2.0 * m, [lambda t=t: stencil.dilate(t, [1, 3]) for t in u8])
+        timeit("dilate u8, 2 values (2 B/px)", 2.0 * m, [lambda t=t: stencil.dilate(t, [1, 3]) for t in u8], cells=m)
         u8m = [generate_window((side + 2, side + 2), "u1", 95 + i, 0.0, 6.0, 255, (50, 50), 0, 0, side + 2, side + 2) for i in range(T)]
         timeit("dilate u8 with margin (%d wide), 2 values (2 B/px)" % (side + 2), 2.0 * n, [lambda t=t: stencil.dilate(t, [1, 3]) for t in u8m])
         del u8m
         timeit("dilate f32, 2 values (8 B/px)", 8.0 * m, [lambda t=t: stencil.dilate(t, [1.0, 3.0]) for t in src])
         for size_px in (3.0, 6.0):
             timeit("smooth f32, sigma %.0f px, radius %d (one launch, 8 B/px)" % (size_px / 3, int(4 * size_px / 3 + 0.5)), 8.0 * n,
-                   [lambda t=t: stencil.gaussian_smooth(t, np.float32(F32MAX), 0, (size_px / 3, size_px / 3)) for t in src[:2]])
+                   [lambda t=t: stencil.gaussian_smooth(t, np.float32(F32MAX), 0, (size_px / 3, size_px / 3)) for t in src[:2]], cells=n)
             timeit("smooth f32, sigma %.0f px, radius %d (two launches, 16 B/px)" % (size_px / 3, int(4 * size_px / 3 + 0.5)), 16.0 * n,
                    [lambda t=t: stencil.gaussian_smooth(t, np.float32(F32MAX), 0, (size_px / 3, size_px / 3), fused=False) for t in src[:2]])
         for size_px in (18.0, 39.0):  # (radii 24 and 52: what a Smooth of 40 pixels in zoom mode asks for)
