@@ -33,6 +33,8 @@
 #include <limits>
 #include <type_traits>
 
+#include <mutex>
+
 #include "gm_common.h"
 
 namespace {
@@ -2076,6 +2078,134 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
   }
 }
 
+// The two passes of zonal_exact_kernel for label rasters WITHOUT runs (round 6): the ranges (PHASE 0) and the sums (PHASE 1) of
+// a workgroup's cells gather in LDS tables -- a step of one label in registers as above, any other step one LDS atomic per
+// active lane and quantity -- and go to the labels' global records once per workgroup.  zonal_exact_kernel pays a global atomic
+// per run, which for labels scattered cell by cell is one per CELL: such rasters used to skip the certificates altogether and
+// take the partition and the block pipeline (int32 cells under 1000 labels at random: 560 us; here ~150).  The sums are exact
+// whenever they are used (the verdict of PHASE 0 says so), so the order the LDS atomics arrive in is immaterial.
+constexpr int ZX_THREADS = 1024;
+template <typename T, int PHASE>
+__global__ __launch_bounds__(ZX_THREADS) void zonal_tables_exact_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
+                                                                        size_t cells_per_wave, int n_labels, int has_ndv, T ndv,
+                                                                        const float* __restrict__ thresholds, ExactRange* __restrict__ range,
+                                                                        double* __restrict__ sums, unsigned char* __restrict__ present) {
+  extern __shared__ unsigned long long zx_lds[];
+  // PHASE 0: [n] counts, [n] hi, [n] lo, [n] bad (4 bytes each); PHASE 1: [n] sums (8 bytes each)
+  unsigned* const count_of = (unsigned*)zx_lds;
+  int* const hi_of = (int*)(count_of + n_labels);
+  int* const lo_of = hi_of + n_labels;
+  unsigned* const bad_of = (unsigned*)(lo_of + n_labels);
+  double* const sum_of = (double*)zx_lds;
+  for (int l = threadIdx.x; l < n_labels; l += ZX_THREADS) {
+    if constexpr (PHASE == 0) {
+      count_of[l] = 0u;
+      hi_of[l] = INT_MIN;
+      lo_of[l] = INT_MAX;
+      bad_of[l] = 0u;
+    } else {
+      sum_of[l] = 0.0;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * ZX_THREADS + threadIdx.x) >> 6;
+  const size_t begin = wave * cells_per_wave, end = min(begin + cells_per_wave, cells);
+  int run_label = -1, marked = INT_MIN;
+  unsigned run_count = 0, run_bad = 0;
+  int run_hi = INT_MIN, run_lo = INT_MAX;
+  double run_sum = 0.0;
+  auto flush = [&]() {  // (wave-uniform call)
+    if (run_label < 0) return;
+    if constexpr (PHASE == 0) {
+      const unsigned n = wave_sum_u32(run_count), bad = wave_or_u32(run_bad);
+      const int hi = wave_max(run_hi), lo = wave_min(run_lo);
+      if (lane == 0 && n != 0) {
+        atomicAdd(&count_of[run_label], n);
+        atomicMax(&hi_of[run_label], hi);
+        atomicMin(&lo_of[run_label], lo);
+        if (bad) atomicOr(&bad_of[run_label], 1u);
+      }
+    } else {
+      const double total = wave_sum_exact(run_sum);
+      if (lane == 0 && total != 0.0) atomicAdd(&sum_of[run_label], total);
+    }
+    run_label = -1;
+    run_count = run_bad = 0;
+    run_hi = INT_MIN;
+    run_lo = INT_MAX;
+    run_sum = 0.0;
+  };
+  walk_cells<T>(values, labels, begin, end, lane, [&](T v, int label, bool inside, size_t i) {
+    (void)inside;
+    (void)i;
+    const bool labelled = (unsigned)label < (unsigned)n_labels;
+    if constexpr (PHASE == 0) mark_present(present, label, labelled, &marked);
+    bool active = labelled && !(has_ndv && v == ndv);
+    if (thresholds && active) {
+      const float t = thresholds[label];
+      active = !(t != t) && (double)v >= (double)t;
+    }
+    const unsigned long long mask = __ballot(active);
+    if (mask == 0) return;  // (wave-uniform)
+    const double x = (double)v;
+    int top = INT_MIN, low = INT_MAX;
+    unsigned bad = 0;
+    if constexpr (PHASE == 0) {
+      if (active) {
+        if (!(fabs(x) <= 1.7976931348623157e308)) bad = 1;
+        else if (x != 0.0) cell_span<T>(v, &top, &low);
+      }
+    }
+    const int leader_label = __builtin_amdgcn_readlane(label, __ffsll((long long)mask) - 1);
+    if (__all(!active || label == leader_label)) {
+      if (leader_label != run_label) {
+        flush();
+        run_label = leader_label;
+      }
+      if (active) {
+        if constexpr (PHASE == 0) {
+          run_count += 1;
+          run_bad |= bad;
+          run_hi = max(run_hi, top);
+          run_lo = min(run_lo, low);
+        } else {
+          run_sum += x;  // (exact: the verdict of PHASE 0)
+        }
+      }
+    } else if (active) {
+      if constexpr (PHASE == 0) {
+        atomicAdd(&count_of[label], 1u);
+        if (top != INT_MIN) {
+          atomicMax(&hi_of[label], top);
+          atomicMin(&lo_of[label], low);
+        }
+        if (bad) atomicOr(&bad_of[label], 1u);
+      } else if (x != 0.0) {
+        atomicAdd(&sum_of[label], x);
+      }
+    }
+  });
+  flush();
+  __syncthreads();
+  for (int l = threadIdx.x; l < n_labels; l += ZX_THREADS) {
+    if constexpr (PHASE == 0) {
+      const unsigned n = count_of[l];
+      if (n == 0) continue;
+      ExactRange* slot = range + l;
+      atomicAdd(&slot->count, (unsigned long long)n);
+      if (hi_of[l] != INT_MIN) {
+        atomicMax(&slot->hi, hi_of[l]);
+        atomicMin(&slot->lo, lo_of[l]);
+      }
+      if (bad_of[l]) atomicOr(&slot->bad, 1u);
+    } else {
+      const double total = sum_of[l];
+      if (total != 0.0) atomicAdd(&sums[l], total);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void zonal_exact_init_kernel(ExactRange* __restrict__ range, double* __restrict__ sums, int n_labels,
                                                                ExactVerdict* __restrict__ verdict, unsigned* __restrict__ cursor) {
   const int l = blockIdx.x * 256 + threadIdx.x;
@@ -2977,6 +3107,10 @@ __global__ __launch_bounds__(256) void zonal_chunk_kernel(const T* __restrict__ 
     next_l = fetch_l(0);
   }
   for (unsigned step = 0; step < steps; ++step) {
+    // somebody else has found the raster unfit for this pass (more labels in a stretch than records, scattered labels): every
+    // wave used to walk on until it found out for itself -- stripes 25 cells wide: 135 us for an attempt that one wave had
+    // given up after a third of its stretch.  A look at the verdict every fourth step (a scalar load that hits the L2).
+    if ((step & 3u) == 3u && __builtin_amdgcn_readfirstlane((int)__atomic_load_n(&verdict->overflow, __ATOMIC_RELAXED))) return;
     T v[ZC_LANE];
     int label[ZC_LANE];
     bool inside[ZC_LANE];
@@ -3521,6 +3655,32 @@ __global__ __launch_bounds__(THREADS) void zonal_segment_sort_kernel(K* __restri
   for (unsigned i = threadIdx.x; i < n; i += THREADS) payload[a + i] = seg[i];
 }
 
+// which attempt of the chunk records answered a label raster last time (see zonal_run)
+struct ChunkHint {
+  const void* labels;
+  int n_labels;
+  int64_t cells;
+  int attempt;
+};
+static std::mutex g_chunk_hint_mu;
+static ChunkHint g_chunk_hints[8];
+static unsigned g_chunk_hint_turn = 0;
+static int chunk_hint_get(const void* labels, int n_labels, int64_t cells) {
+  std::lock_guard<std::mutex> lk(g_chunk_hint_mu);
+  for (const ChunkHint& h : g_chunk_hints)
+    if (h.labels == labels && h.n_labels == n_labels && h.cells == cells) return h.attempt;
+  return 0;
+}
+static void chunk_hint_set(const void* labels, int n_labels, int64_t cells, int attempt) {
+  std::lock_guard<std::mutex> lk(g_chunk_hint_mu);
+  for (ChunkHint& h : g_chunk_hints)
+    if (h.labels == labels && h.n_labels == n_labels && h.cells == cells) {
+      h.attempt = attempt;
+      return;
+    }
+  g_chunk_hints[g_chunk_hint_turn++ % 8] = ChunkHint{labels, n_labels, cells, attempt};
+}
+
 struct Scratch {  // device buffers of one call, returned to the pool on every exit path
   void* p[32] = {nullptr};
   int n = 0;
@@ -3728,13 +3888,20 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     static const int chunks_mode = getenv("GM_ZONAL_CHUNKS") ? atoi(getenv("GM_ZONAL_CHUNKS")) : 1;
     const bool chunks_allowed = chunks_mode != 0;
     bool chunk_gave_up_hard = false;  // (a sum that keeps rounding: the parallel sums below cannot answer it either)
+    bool chunk_not_runs = false;      // (labels scattered cell by cell: the certificates through the workgroups' LDS tables)
     if (range && chunks_allowed && cells >= ZC_LANE && (uintptr_t)frame % sizeof(CellQuad<T>) == 0 &&
         (uintptr_t)labels % sizeof(LabelQuad) == 0) {
       // stretches of at least `stretch()` cells, whole steps, at most 64 steps each (more, shorter stretches for large rasters).
       // A second attempt in stretches a quarter as long when the first one only found stretches with more labels than records
       // (small polygons, vertical stripes: runs all the same) and the table of the shorter stretches still fits.
       bool answered = false;
-      for (int attempt = 0; attempt < 2 && !answered; ++attempt) {
+      // (a label raster whose first attempt overflowed is remembered -- by address, label count and size: a hint, never more --
+      //  and starts with the shorter stretches next time: the other statistics of the same polygons, the next frames)
+      // (... and a raster whose SUMS gave the pass up -- a long label that keeps rounding: hard -- is remembered with its cells'
+      //  address: the mean after the sum, the next request for the same tile, go to the sorting route at once)
+      const int first_attempt = std::max(chunk_hint_get(labels, n_labels, cells), chunk_hint_get(frame, n_labels, cells));
+      if (first_attempt >= 2) chunk_gave_up_hard = true;
+      for (int attempt = first_attempt; attempt < 2 && !answered; ++attempt) {
         const int64_t shortest = attempt == 0 ? stretch() : std::max<int64_t>(ZC_STEP, stretch() / 4);
         const int64_t most = (int64_t)gm::current_cu_count() * wave_cap() * (attempt == 0 ? 1 : 4);
         int64_t n_stretch = std::max<int64_t>(1, std::min<int64_t>((cells + shortest - 1) / shortest, most));
@@ -3788,6 +3955,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         }
         if (!chunk_verdict.overflow && !chunk_verdict.hard) {
           answered = true;
+          if (attempt != first_attempt || attempt == 1) chunk_hint_set(labels, n_labels, cells, attempt);
           break;
         }
         // (a sum that keeps rounding fails the certificate of the parallel sums below; and they pay an atomic per quantity and
@@ -3796,14 +3964,41 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         // ... where the sort is the counting partition.  Beyond its 2047 labels the atomics spread over thousands of counters and
         // the sort is the radix sort: 6592 polygons of 48 x 40 int32 cells 240 us through the parallel sums, 590 through the sort.
         chunk_gave_up_hard = chunk_verdict.hard != 0 || n_labels + 1 <= ZP_BINS;
+        chunk_not_runs = chunk_verdict.not_runs != 0 && chunk_verdict.hard == 0;
+        if (chunk_verdict.hard) chunk_hint_set(frame, n_labels, cells, 2);
         if (chunk_verdict.hard || chunk_verdict.not_runs || chunk_cells <= (size_t)ZC_STEP) break;  // (shorter stretches would not help)
       }
       gm::route_hit(GM_ROUTE_ZONAL, answered ? GM_RZ_CHUNK_ANSWERED : GM_RZ_CHUNK_GAVE_UP);
       if (answered) continue;
     }
+    unsigned longest = ~0u;  // (cells of the longest label, where a verdict has counted them)
+    // labels scattered cell by cell: the exactness certificates and, where every label passes, the sums -- through tables in
+    // LDS (zonal_tables_exact_kernel; GM_ZONAL_TABLES_EXACT=0: never -- A/B runs, and the tests compare the two)
+    static const bool tables_exact_allowed = !(getenv("GM_ZONAL_TABLES_EXACT") && atoi(getenv("GM_ZONAL_TABLES_EXACT")) == 0);
+    if (range && chunk_not_runs && tables_exact_allowed && (size_t)n_labels * 16 <= ZT_LDS_BYTES) {
+      const size_t lds = (size_t)n_labels * 16;
+      const int64_t waves_wanted = std::max<int64_t>(1, std::min<int64_t>((cells + 255) / 256, (int64_t)gm::current_cu_count() * 2 * (ZX_THREADS / 64)));
+      const unsigned x_blocks = (unsigned)((waves_wanted + ZX_THREADS / 64 - 1) / (ZX_THREADS / 64));
+      const size_t x_cells_per_wave = (size_t)(((cells + (int64_t)x_blocks * (ZX_THREADS / 64) - 1) / ((int64_t)x_blocks * (ZX_THREADS / 64)) + 63) / 64 * 64);
+      hipLaunchKernelGGL(zonal_exact_init_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, verdict_dev, cursor);
+      hipLaunchKernelGGL((zonal_tables_exact_kernel<T, 0>), dim3(x_blocks), dim3(ZX_THREADS), lds, s, frame, labels, (size_t)cells, x_cells_per_wave,
+                         n_labels, has_ndv, ndv, thresholds, range, sums, seen);
+      hipLaunchKernelGGL(zonal_exact_decide_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, n_labels, inexact, verdict_dev);
+      ExactVerdict verdict{1u, 0u, (unsigned long long)cells};
+      if ((rc = gm_d2h(&verdict, verdict_dev, sizeof(verdict)))) return rc;
+      if (verdict.labels == 0) {
+        hipLaunchKernelGGL((zonal_tables_exact_kernel<T, 1>), dim3(x_blocks), dim3(ZX_THREADS), (size_t)n_labels * 8, s, frame, labels, (size_t)cells,
+                           x_cells_per_wave, n_labels, has_ndv, ndv, thresholds, range, sums, (unsigned char*)nullptr);
+        hipLaunchKernelGGL(zonal_exact_result_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, statistic,
+                           out_f, counts_f);
+        GM_HIP(hipGetLastError());
+        gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_LDS_EXACT);
+        continue;
+      }
+      longest = verdict.longest;
+    }
     if ((rc = key_buffers())) return rc;
     bool keys_written = false;
-    unsigned longest = ~0u;  // (cells of the longest label, where a verdict has counted them)
     part.counted = false;
     if (range && !chunk_gave_up_hard) {
       if (partition) {  // (3 MB for the default raster limit and 1024 labels)

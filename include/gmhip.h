@@ -165,7 +165,8 @@ const char* gm_route_name(int family, int slot);
 #define GM_RZ_ORDERED_SUMS 12    /* sums: the wave-per-label kernel over sorted cells ran */
 #define GM_RZ_LDS_TABLES 13      /* count / min / max: per-workgroup LDS tables (label rasters without runs) */
 #define GM_RZ_SEGMENT_SORT 14    /* medians / percentiles under many labels: sort by label, every label's segment sorted in LDS */
-#define GM_RZ_SLOTS 15
+#define GM_RZ_LDS_EXACT 15       /* sums of scattered labels that cannot round: certificates and sums through workgroup LDS tables */
+#define GM_RZ_SLOTS 16
 /* bilinear slots */
 #define GM_RB_CALLS 0
 #define GM_RB_TWO_X 1            /* the dedicated 2 x kernel */
