@@ -595,6 +595,9 @@ def mosaic_through_the_scheduler(devices, side, steps, warmup, leaves, e2e=True,
            "kernel": kernel, "traffic": traffic, "traffic_source": traffic_src, "workers": G,
            "worker_devices": ["%d:%s" % (d, n) for d, n in zip(devices, pool.device_names)],
            "scaling": "strong", "mosaic": [mosaic_side, mosaic_side], "tiles": n_tiles,
+           # (workers that SHARE a device -- a one-GPU box asked for several -- take turns on it: their per-worker device time
+           #  is the device's, `frac` then says nothing about the kernel)
+           "devices_distinct": len(set(devices)) == len(devices),
            "per_worker_device_ms_per_step": [round(per_worker_ms[w] / steps, 4) for w in everybody],
            "parent_us_per_step": round(in_step / steps * 1e6, 1), "parent_cpu_us_per_step": round(in_step_cpu / steps * 1e6, 1),
            "worker_host_us_per_step": [round(host[w]["wall_s"] / max(host[w]["runs"], 1) * 1e6, 1) for w in everybody],

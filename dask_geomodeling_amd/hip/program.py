@@ -1326,6 +1326,38 @@ def run_expr(build, tiles, key=None):
         return values, root.ndv
 
 
+_KEPT_EXPR = {}   # (expression plan, addresses of its resident tiles) -> 0 (seen once) / PreparedBatch / False
+
+
+def drop_kept_launches():
+    """Forget the marshalled launches kept for resident tiles (they hold the tiles: a source that gives its windows back --
+    SyntheticSource.drop_resident_windows -- calls this)."""
+    _KEPT_EXPR.clear()
+
+
+def _kept_expr_launch(cache_key, stage, tiles, shape):
+    """The PreparedBatch of a one-stage expression over exactly these tiles when every one of them is resident data as it stands
+    (DeviceArray.resident), from the third sighting on; else None."""
+    try:
+        where = tuple((v.ptr, v.pitch, v.shape) if v.resident else None for v, _ in tiles)
+    except AttributeError:
+        return None
+    if None in where:
+        return None
+    key = (cache_key, where)
+    kept = _KEPT_EXPR.get(key)
+    if kept is None:
+        if len(_KEPT_EXPR) >= 1024:
+            _KEPT_EXPR.clear()
+        _KEPT_EXPR[key] = 0
+        return None
+    if kept == 0:
+        compiled, binding = stage
+        inputs = [as_device_view(tiles[ref][0]) if kind == 0 else ref for kind, ref in binding]
+        kept = _KEPT_EXPR[key] = prepare_batch(compiled, [inputs], shape) or False
+    return kept or None
+
+
 def _run_expr(build, tiles, key=None):
     """Evaluate ``build(leaves)`` over raster tiles given as (values, ndv) pairs.
 
@@ -1342,6 +1374,11 @@ def _run_expr(build, tiles, key=None):
             if hit is not None:
                 runtime.require_device()
                 stages, shape = hit
+                if len(stages) == 1:
+                    # (the launch over exactly these resident tiles, marshalled once: fuse.FusedTask._kept_launch)
+                    kept = _kept_expr_launch(cache_key, stages[0], tiles, shape)
+                    if kept is not None:
+                        return kept.run()[0], stages[0][0].out_ndv
                 outs = []
                 for compiled, binding in stages:
                     inputs = [as_device_view(tiles[ref][0]) if kind == 0 else (outs[ref] if kind == 2 else ref)

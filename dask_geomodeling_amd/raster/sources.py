@@ -542,6 +542,8 @@ class SyntheticSource(RasterBlock):
         with cls._window_lock:
             cls._windows.clear()
             cls._window_bytes = 0
+        from ..hip import program as _program
+        _program.drop_kept_launches()  # (launches kept for those windows hold them)
 
 
 def generate_window(shape, dtype, seed, lo, hi, ndv, lattice, row0, col0, height, width):
