@@ -100,6 +100,16 @@ def _init(settings):
     return None
 
 
+def _physical_core(cpu):
+    """What tells the hardware threads of one core from those of another: the core's first sibling (the cpu itself where the
+    topology is not exposed)."""
+    try:
+        with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu) as f:
+            return int(f.read().replace("-", ",").split(",")[0])
+    except (OSError, ValueError):
+        return cpu
+
+
 def _pin_to_device_cores(runtime, index, pool_devices):
     """sched_setaffinity to the cores next to this worker's device BEFORE the device is bound, so that the runtime's own
     threads (and the kernel compiler's) inherit the mask.  Workers of the pool whose devices have the same cores next to
@@ -119,8 +129,15 @@ def _pin_to_device_cores(runtime, index, pool_devices):
         k, n = group.index(index), len(group)
         mine = list(mine)
         if n > 1 and len(mine) >= 2 * n:   # (at least two cores each: the submitting thread and the runtime's helper)
-            per = len(mine) // n
-            mine = mine[k * per:(k + 1) * per]
+            # whole PHYSICAL cores each: the hardware threads of a core stay with one worker (cpu 0 and cpu 128 of a
+            # 64-core socket are one core: splitting the sorted list in runs would hand them to two workers)
+            cores = {}
+            for cpu in mine:
+                cores.setdefault(_physical_core(cpu), []).append(cpu)
+            physical = [cores[c] for c in sorted(cores)]
+            per = max(len(physical) // n, 1)
+            share = physical[k * per:(k + 1) * per] if len(physical) >= n else [mine[k::n]]
+            mine = sorted(cpu for group in share for cpu in group)
         if not mine or len(mine) == len(allowed):
             return None
         os.sched_setaffinity(0, mine)
