@@ -105,6 +105,70 @@ struct FramesOfRasters {
     return f;
   }
 };
+// first / last / count (reduction.py:78-91) tell data from no data by utils.get_index alone: a cell that IS NaN is data there (it
+// is picked, it is counted), so the NaN coding above cannot serve them -- the rasters' own cells and the index side by side
+template <typename C, int V>
+struct MaskedPack {
+  Pack<C, V> f;
+  bool data[V];
+};
+template <typename C, int V>
+__device__ __forceinline__ MaskedPack<C, V> load_masked(const RasterRef* refs, long long p, int j) {
+  const RasterRef r = refs[j];
+  MaskedPack<C, V> m;
+  m.f = load_pack<C, V>((const C*)r.values + p);
+  const bool in_f64 = (r.flags & 1u) != 0, y_finite = (r.flags & 2u) != 0;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    bool close;
+    if (in_f64) {
+      const double xd = (double)m.f.v[e];
+      close = ((fabs(xd - r.y) <= r.tol) & y_finite) | (xd == r.y);
+    } else {
+      const float xf = (float)m.f.v[e], yf = (float)r.y;
+      close = ((fabsf(xf - yf) <= (float)r.tol) & y_finite) | (xf == yf);
+    }
+    m.data[e] = !close;
+  }
+  return m;
+}
+constexpr int RD_PICK_UNROLL = 4;
+// STAT 12 / 13 / 1: first / last / count over n separate rasters
+template <typename C, int STAT, int V>
+__global__ __launch_bounds__(256) void pick_rasters_kernel(const RasterRef* __restrict__ refs, int n, long long pixels, C* __restrict__ out, C fill) {
+  const long long p = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
+  if (p >= pixels) return;
+  C acc[V];
+  int cnt[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    acc[e] = fill;
+    cnt[e] = 0;
+  }
+  auto take = [&](const MaskedPack<C, V>& m) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      if (m.data[e]) {
+        acc[e] = m.f.v[e];  // (first: the rasters are walked from the last to the first, like reduction.py:80-81)
+        cnt[e] += 1;
+      }
+    }
+  };
+  int j = 0;
+  for (; j + RD_PICK_UNROLL <= n; j += RD_PICK_UNROLL) {
+    MaskedPack<C, V> m[RD_PICK_UNROLL];
+#pragma unroll
+    for (int u = 0; u < RD_PICK_UNROLL; ++u) m[u] = load_masked<C, V>(refs, p, STAT == 12 ? n - 1 - (j + u) : j + u);
+#pragma unroll
+    for (int u = 0; u < RD_PICK_UNROLL; ++u) take(m[u]);
+  }
+  for (; j < n; ++j) take(load_masked<C, V>(refs, p, STAT == 12 ? n - 1 - j : j));
+  Pack<C, V> res;
+#pragma unroll
+  for (int e = 0; e < V; ++e) res.v[e] = STAT == 1 ? (C)cnt[e] : acc[e];
+  store_pack<C, V>(out + p, res);
+}
+
 template <typename C>
 struct StackSource {
   const C* stack;
@@ -615,6 +679,19 @@ int launch_reduce_rasters(const gm_raster_ref* rasters, int n, long long pixels,
   if (rc) {
     (void)gm_free(refs);
     return rc;
+  }
+  if (statistic == 1 || statistic == 12 || statistic == 13) {  // count / first / last: the rasters' cells and the index side by side
+    const int Vp = vec ? VV : 1;
+    const unsigned gp = (unsigned)((pixels + 256LL * Vp - 1) / (256LL * Vp));
+#define GM_PICK(STAT)                                                                                                          \
+  case STAT:                                                                                                                   \
+    if (vec) hipLaunchKernelGGL((pick_rasters_kernel<C, STAT, VV>), dim3(gp), dim3(256), 0, s, refs, n, pixels, (C*)out, fill); \
+    else hipLaunchKernelGGL((pick_rasters_kernel<C, STAT, 1>), dim3(gp), dim3(256), 0, s, refs, n, pixels, (C*)out, fill);     \
+    break;
+    switch (statistic) { GM_PICK(1) GM_PICK(12) GM_PICK(13) }
+#undef GM_PICK
+    (void)gm_free(refs);
+    return GM_OK;
   }
   const RasterSource<C> source{refs};
   // (sums over more rasters than one leaf of the pairwise recursion: the explicit-stack form, one cell per lane -- the unrolled

@@ -689,9 +689,12 @@ struct Machine {
     break;
           GM_IN_CASE(0) GM_IN_CASE(1) GM_IN_CASE(2) GM_IN_CASE(3)
           GM_IN_CASE(4) GM_IN_CASE(5) GM_IN_CASE(6) GM_IN_CASE(7)
+          GM_IN_CASE(8) GM_IN_CASE(9) GM_IN_CASE(10) GM_IN_CASE(11)
+          GM_IN_CASE(12) GM_IN_CASE(13) GM_IN_CASE(14) GM_IN_CASE(15)
 #undef GM_IN_CASE
           default: break;
         }
+        static_assert(GM_MAX_INPUTS == 16, "one GM_IN_CASE per input");
       } break;
       case GM_OPD_SCALAR: {
         const RC s = scalar_of<RC>(o.value);

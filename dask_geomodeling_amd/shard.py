@@ -294,7 +294,22 @@ class _Pickler(_BasePickler):
         return None
 
 
+_PLAIN = (int, str, float, bool, type(None), bytes)
+
+
+def _is_plain(obj, depth=0):
+    """Nothing but numbers, strings and tuples / lists of them: a message the C pickler writes as it stands (re-runs of kept
+    jobs, syncs, marks: every message of a steady state)."""
+    if type(obj) in _PLAIN:
+        return True
+    if type(obj) in (tuple, list) and depth < 4:
+        return all(_is_plain(x, depth + 1) for x in obj)
+    return False
+
+
 def _dumps(obj):
+    if _is_plain(obj):  # (the cloudpickle / persistent-id machinery below costs ~10 us per message: a re-run at 8 workers is 8 of them)
+        return pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
     import io
     buf = io.BytesIO()
     _Pickler(buf, protocol=pickle.HIGHEST_PROTOCOL).dump(obj)

@@ -671,6 +671,9 @@ int gm_reduce_stack(const void* stack, int work_dtype, int half, int64_t n, int6
  * ~np.isclose(values, ndv) as NumPy's promotion rules give them for that raster: the no-data value as compared, the tolerance
  * 1e-8 + 1e-5 |ndv|, flags bit 0: compare in float64, bit 1: the no-data value is finite.  float32 rasters with work dtype
  * float32, float64 with float64; anything else (other raster dtypes, a float16 work dtype) goes through gm_reduce_stack. */
+#define GM_RED_COUNT 1  /* gm_reduce_rasters only: the number of rasters with data per cell (reduction.py:88-91), as the work dtype */
+#define GM_RED_FIRST 12 /* gm_reduce_rasters only: the first / last raster's cell that is data (reduction.py:78-87); a NaN cell IS data */
+#define GM_RED_LAST 13
 typedef struct gm_raster_ref {
   const void* values;
   double ndv_compared, tolerance;

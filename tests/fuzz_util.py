@@ -20,9 +20,10 @@ SHAPE = (1,) + tuple(int(x) for x in os.environ.get("GM_FUZZ_SHAPE", "24x40").sp
 REQ = dict(mode="vals", bbox=(0.0, 0.0, float(SHAPE[2]), float(SHAPE[1])), width=SHAPE[2], height=SHAPE[1], projection="EPSG:28992")
 
 
-def make_leaf(rng, tag, k, memory=False):
+def make_leaf(rng, tag, k, memory=False, kinds=None):
     """memory=True: a MemorySource (the real source Block; answers any window) instead of an ArrayLeaf."""
-    dt, ndv = LEAF_KINDS[int(rng.integers(len(LEAF_KINDS)))]
+    kinds = kinds or LEAF_KINDS
+    dt, ndv = kinds[int(rng.integers(len(kinds)))]
     if np.dtype(dt).kind == "f":
         v = (rng.random(SHAPE) * 40 - 10).astype(dt)
         v[0, 0, 0] = np.nan if rng.random() < 0.3 else 3.0
@@ -44,6 +45,30 @@ def is_bool(b):
 
 def is_int(b):
     return b.dtype.kind in "iu"
+
+
+def wide_view(rng, tag, n):
+    """A view over n leaves of one register class (float32, or int32 / int16), every leaf folded into the running view by a
+    random Block -- arithmetic, FillNoData, Clip, Max --: ONE program of n inputs where n <= 16 (round 6; the random trees below
+    never use more than three leaves), so that generic steps, fast micro-ops and no-data rules all meet inputs 8 .. 15."""
+    kinds = [LEAF_KINDS[0], LEAF_KINDS[1]] if rng.random() < 0.7 else [LEAF_KINDS[3], LEAF_KINDS[4]]
+    leaves = [make_leaf(rng, tag, k, kinds=kinds) for k in range(n)]
+    view = leaves[0]
+    for leaf in leaves[1:]:
+        choice = rng.random()
+        if choice < 0.35:
+            op = ["Add", "Subtract", "Multiply"][int(rng.integers(3))]
+            view = getattr(raster, op)(view, leaf) if rng.random() < 0.7 else getattr(raster, op)(leaf, view)
+        elif choice < 0.6:
+            view = raster.FillNoData(view, leaf) if rng.random() < 0.5 else raster.FillNoData(leaf, view)
+        elif choice < 0.75:
+            view = raster.Clip(view, leaf)
+        elif choice < 0.9:
+            view = raster.Max(view, leaf)
+        else:
+            view = raster.Clip(view, raster.Greater(leaf, [3, 5.5, 0][int(rng.integers(3))]))
+    view.dtype, view.fillvalue
+    return view
 
 
 def random_view(rng, tag, depth=4, memory=False, smooth=False):

@@ -29,6 +29,27 @@ def test_random_views_fused_vs_oracle(cpu_vm, monkeypatch, seed):
 
 
 @pytest.mark.parametrize("seed", range(40))
+def test_views_over_nine_to_sixteen_leaves(cpu_vm, monkeypatch, seed):
+    """The host side of programs with 9-16 inputs (round 6): fusion, the compiler's operand encoding and the NumPy interpreter of
+    gm_program against the op-by-op oracle (the device's side of it: tests/test_gpu_fuzz.py)."""
+    from dask_geomodeling_amd.raster import devops
+    from dask_geomodeling_amd.hip.runtime import GmHipError
+    from fuzz_util import wide_view
+    monkeypatch.setattr(devops, "all_equal", lambda values, ndv: bool(np.all(np.asarray(values) == ndv)))
+    rng = np.random.default_rng(70_000 + seed)
+    view = wide_view(rng, "wc%d" % seed, int(rng.integers(9, 17)))
+    with np.errstate(all="ignore"):
+        want = oracle_eval(view)
+    try:
+        got = view.get_data(**REQ)
+    except GmHipError as e:
+        if "no HIP device" not in str(e):
+            raise
+        pytest.skip("this view needs a stand-alone kernel (covered by the GPU fuzz test)")
+    assert_result_equal(unsigned_zero(got, view), unsigned_zero(want, view), 0, describe(view))
+
+
+@pytest.mark.parametrize("seed", range(40))
 def test_plans_equal_the_graph_path(cpu_vm, seed):
     """get_data through a cached ViewPlan (plan.py) gives what the graph path gives, on first use and on reuse."""
     from dask_geomodeling_amd import config as gmconfig

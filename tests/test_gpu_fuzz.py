@@ -26,6 +26,25 @@ def test_random_views_on_device(gpu, seed):
         assert_result_equal(unsigned_zero(view.get_data(**REQ), view), want, 0, "unfused " + describe(view))
 
 
+@pytest.mark.parametrize("seed", range(60))
+def test_views_over_nine_to_sixteen_leaves(gpu, seed):
+    """Programs of 9-16 inputs (round 6: GM_MAX_INPUTS 8 -> 16): every leaf folded into the view by a random Block, fused into one
+    launch, against the op-by-op oracle -- and unfused.  (The first version fetched the operands of generic steps through a switch
+    of eight cases: 'first' over nine rasters picked nothing from rasters 8 on.  No tree of the other fuzzers has more than three
+    leaves.)"""
+    from dask_geomodeling_amd import config as gmconfig
+    from fuzz_util import wide_view
+    rng = np.random.default_rng(70_000 + seed)
+    n = int(rng.integers(9, 17))
+    view = wide_view(rng, "w%d" % seed, n)
+    with np.errstate(all="ignore"):
+        want = unsigned_zero(oracle_eval(view), view)
+    got = view.get_data(**REQ)
+    assert_result_equal(unsigned_zero(got, view), want, 0, describe(view))
+    with gmconfig.config.set({"geomodeling.fuse": False}):
+        assert_result_equal(unsigned_zero(view.get_data(**REQ), view), want, 0, "unfused " + describe(view))
+
+
 def test_random_views_evaluated_together(gpu):
     from dask_geomodeling_amd.core.graphs import get_data_many
     views, wants = [], []

@@ -1294,7 +1294,7 @@ def test_reduce_rasters_in_place_vs_the_stack_and_the_oracle(gpu, monkeypatch, d
             stack[i]["values"][0, -1, -1] = stack[i]["no_data_value"]   # one cell without data anywhere ...
         for d in stack[3:]:
             d["values"][0, -1, -1] = d["no_data_value"]
-        for stat in ("sum", "mean", "min", "max", "std", "var", "product", "argmin", "argmax"):
+        for stat in ("sum", "mean", "min", "max", "std", "var", "product", "argmin", "argmax", "first", "last", "count"):
             before = None
             with np.errstate(all="ignore"):
                 want = O.reduce_rasters([dict(d) for d in stack], stat)
