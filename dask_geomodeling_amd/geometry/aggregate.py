@@ -52,6 +52,29 @@ def _lib():
     return L
 
 
+_NDV_CACHE = {}  # (dtype, type of the no-data value, its bytes) -> (has_ndv, bits): ~15 us of NumPy scalar work per call otherwise
+
+
+def _ndv_for(dtype, no_data_value):
+    """(has_ndv, the no-data value as the raster's dtype holds it, as gm_scalar bits) for `frame != no_data_value`
+    (aggregate.py:177): a no-data value the raster's dtype cannot hold equals no cell."""
+    from ..hip import runtime
+    if no_data_value is None:
+        return False, 0
+    try:
+        key = (dtype.str, type(no_data_value), no_data_value.tobytes() if isinstance(no_data_value, np.generic) else no_data_value)
+        hit = _NDV_CACHE.get(key)
+    except TypeError:
+        key = hit = None
+    if hit is None:
+        with np.errstate(all="ignore"):
+            held = np.asarray(no_data_value).astype(dtype)[()]
+            hit = (bool(held == no_data_value), runtime.scalar_bits(held, dtype))
+        if key is not None and len(_NDV_CACHE) < 1024:
+            _NDV_CACHE[key] = hit
+    return hit
+
+
 def label_statistics(values, no_data_value, labels, n_labels, statistic, percentile=None, threshold_values=None):
     """The statistic of ``values`` (frames, height, width) per label of ``labels`` (height, width; int32
     geometry indices, anything outside [0, n_labels) = not covered) over the label's active cells.
@@ -89,12 +112,7 @@ def label_statistics(values, no_data_value, labels, n_labels, statistic, percent
         if thresholds.dtype != np.dtype("f4"):
             raise TypeError("thresholds must be float32 (aggregate.py:532 casts the column with astype('f4'))")
         thresholds = DeviceArray.from_numpy(thresholds)
-    has_ndv = no_data_value is not None
-    with np.errstate(all="ignore"):
-        ndv_bits = runtime.scalar_bits(np.asarray(no_data_value).astype(tile.dtype)[()] if has_ndv else 0, tile.dtype)
-    with np.errstate(all="ignore"):
-        if has_ndv and np.asarray(no_data_value).astype(tile.dtype)[()] != no_data_value:
-            has_ndv = False  # a no-data value the raster's dtype cannot hold equals no cell (frame != value is all True)
+    has_ndv, ndv_bits = _ndv_for(tile.dtype, no_data_value)
     # one device buffer for the three results (counts first: 8-byte aligned), one copy back
     cells = frames * n_labels
     packed = DeviceArray.empty((cells * 12 + n_labels,), "u1")

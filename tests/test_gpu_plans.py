@@ -63,6 +63,35 @@ def test_plan_reused_across_bounding_boxes(gpu, seed):
     assert len(view.__dict__.get("_gm_templates", {})) <= 1  # ... and at most one template
 
 
+@pytest.mark.parametrize("seed", range(30))
+def test_repeated_requests_replay_their_kept_launches(gpu, seed):
+    """Round 6: from the third time a bounding box is asked for, the launch over its resident windows is replayed with its
+    arguments marshalled (plan.ViewPlan.boxes; fuse.FusedTask._kept_launch for graphs made per request; run_expr for Blocks with
+    a kernel of their own over resident stores).  Five rounds over four boxes, plans and templates: every answer is the first
+    round's, bit for bit, and boxes were kept where the view is one fused program over resident windows."""
+    from dask_geomodeling_amd import plan
+    rng = np.random.default_rng(41_000 + seed)
+    view = random_view(rng, "rq%d" % seed, depth=3, memory=True)
+    boxes = [(0.0, 0.0, 16.0, 12.0), (8.0, 4.0, 24.0, 16.0), (24.0, 12.0, 40.0, 24.0), (3.5, 2.25, 19.5, 14.25)]
+    first = {}
+    for turn in range(5):
+        for k, bbox in enumerate(boxes):
+            req = dict(mode="vals", bbox=bbox, width=16, height=12, projection="EPSG:28992")
+            try:
+                got = view.get_data(**req)
+                tpl = _template_path(view, req)
+            except NotImplementedError as e:
+                pytest.skip("not on the device path: %s" % e)
+            if turn == 0:
+                first[k] = got
+                want = _graph_path(view, req)
+                assert_result_equal(unsigned_zero(got, view), unsigned_zero(want, view), 0, "first round, bbox %d of %s" % (k, describe(view)))
+            assert_result_equal(got, first[k], 0, "round %d, bbox %d of %s" % (turn, k, describe(view)))
+            assert_result_equal(tpl, first[k], 0, "template, round %d, bbox %d of %s" % (turn, k, describe(view)))
+    kept = sum(len(p.boxes) for p in view.__dict__.get("_gm_plans", {}).values() if isinstance(p, plan.ViewPlan))
+    print("kept boxes:", kept)
+
+
 def test_plan_exists_for_the_canonical_chain_and_is_reused(gpu, tiler_route):
     from dask_geomodeling_amd import plan, raster
     from dask_geomodeling_amd.hip import DeviceArray
