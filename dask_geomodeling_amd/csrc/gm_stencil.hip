@@ -1067,14 +1067,17 @@ struct HillBatch {
   int in_pitch[HS_BATCH], out_pitch[HS_BATCH];
 };
 struct NoBatch {};
-template <typename T, bool USE_INV, bool BATCH = false>
+// DIRECT (round 6, GM_HS_DIRECT=1): a lane stores its two shades of a row straight to the result as it goes -- 64 lanes x 2
+// bytes are one 128-byte line per wave and row -- instead of parking the block's shades in LDS for a store phase behind a
+// barrier; the exact tier patches its cells in place afterwards.
+template <typename T, bool USE_INV, bool BATCH = false, bool DIRECT = false>
 __global__ __launch_bounds__(256) void hillshade_pair_kernel(const T* __restrict__ in, unsigned char* __restrict__ out,
                                                              int h, int w, int pitch, int has_ndv, T ndv, T fill, HillArgs A,
                                                              typename std::conditional<BATCH, HillBatch, NoBatch>::type B = {}) {
   static_assert(std::is_same<T, float>::value || (std::is_integral<T>::value && sizeof(T) <= 4 && USE_INV), "see above");
   constexpr int PITCH = HP_W + 2;
   __shared__ __align__(16) T tile[(HP_H + 2) * PITCH];
-  __shared__ __align__(16) unsigned char shade[HP_H * HP_W];
+  __shared__ __align__(16) unsigned char shade[DIRECT ? 16 : HP_H * HP_W];
   constexpr unsigned HP_PENDING = 256;
   __shared__ float pending_x[HP_PENDING], pending_y[HP_PENDING];
   __shared__ unsigned short pending_at[HP_PENDING];
@@ -1198,7 +1201,17 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const T* __restrict
       asm("v_cvt_u32_f32 %0, %1" : "=v"(hi) : "v"(v.y));
       packed = lo | (hi << 8);
     }
-    *reinterpret_cast<unsigned short*>(shade + r * HP_W + 2 * threadIdx.x) = (unsigned short)packed;
+    if constexpr (DIRECT) {
+      const int orow = r0 + r, ocol = c0 + 2 * (int)threadIdx.x;
+      if (orow < oh && ocol < ow) {
+        unsigned char* dst = oplane + (size_t)orow * opitch + ocol;
+        typedef unsigned short u16u __attribute__((aligned(1)));
+        if (ocol + 1 < ow) __builtin_nontemporal_store((unsigned short)packed, (u16u*)dst);
+        else *dst = (unsigned char)packed;
+      }
+    } else {
+      *reinterpret_cast<unsigned short*>(shade + r * HP_W + 2 * threadIdx.x) = (unsigned short)packed;
+    }
     top = mid;
     mid = bot;
   }
@@ -1211,14 +1224,29 @@ __global__ __launch_bounds__(256) void hillshade_pair_kernel(const T* __restrict
       const T* p = col + r * PITCH + k;
       const float y = gradient<T>(p[0], p[1], p[2], p[2 * PITCH], p[2 * PITCH + 1], p[2 * PITCH + 2], A.yres, A.yres32, A.yinv, A.yinv32);
       const float x = gradient<T>(p[0], p[PITCH], p[2 * PITCH], p[2], p[PITCH + 2], p[2 * PITCH + 2], A.xres, A.xres32, A.xinv, A.xinv32);
-      shade[r * HP_W + 2 * threadIdx.x + k] = shade_cell(x, y, A);
+      const unsigned char cell = shade_cell(x, y, A);
+      if constexpr (DIRECT) {
+        const int orow = r0 + r, ocol = c0 + 2 * (int)threadIdx.x + k;
+        if (orow < oh && ocol < ow) oplane[(size_t)orow * opitch + ocol] = cell;
+      } else {
+        shade[r * HP_W + 2 * threadIdx.x + k] = cell;
+      }
     }
   }
-  __syncthreads();
+  __syncthreads();  // (also: the lanes' own stores have been acknowledged before another lane patches a cell)
   {
     const unsigned n_pending = min(pending_count, HP_PENDING);
-    for (unsigned i = threadIdx.x; i < n_pending; i += 256) shade[pending_at[i]] = shade_exact(pending_x[i], pending_y[i], A);
+    for (unsigned i = threadIdx.x; i < n_pending; i += 256) {
+      const unsigned char cell = shade_exact(pending_x[i], pending_y[i], A);
+      if constexpr (DIRECT) {
+        const int orow = r0 + (int)(pending_at[i] / HP_W), ocol = c0 + (int)(pending_at[i] % HP_W);
+        if (orow < oh && ocol < ow) oplane[(size_t)orow * opitch + ocol] = cell;
+      } else {
+        shade[pending_at[i]] = cell;
+      }
+    }
   }
+  if constexpr (DIRECT) return;
   __syncthreads();
   // 16 consecutive pixels of a row per lane and step
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -2020,7 +2048,10 @@ int gm_hillshade_window(const void* in, int dtype, int bands, int h, int w, int 
   if (dtype == GM_F32 && pairs_fit) {
     gm::route_hit(GM_ROUTE_STENCILS, GM_RS_HILLSHADE_PAIRS);
     const float ndv = from_bits<float>(ndv_bits), fill = from_bits<float>(fill_bits);
-    if (A.xinv32 != 0.0f && A.yinv32 != 0.0f)
+    static const bool direct_stores = getenv("GM_HS_DIRECT") && atoi(getenv("GM_HS_DIRECT")) != 0;
+    if (direct_stores && A.xinv32 != 0.0f && A.yinv32 != 0.0f)
+      hipLaunchKernelGGL((hillshade_pair_kernel<float, true, false, true>), pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, in_pitch, has_ndv, ndv, fill, A);
+    else if (A.xinv32 != 0.0f && A.yinv32 != 0.0f)
       hipLaunchKernelGGL((hillshade_pair_kernel<float, true>), pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, in_pitch, has_ndv, ndv, fill, A);
     else
       hipLaunchKernelGGL((hillshade_pair_kernel<float, false>), pgrid, dim3(256), 0, s, (const float*)in, (unsigned char*)out, h, w, in_pitch, has_ndv, ndv, fill, A);

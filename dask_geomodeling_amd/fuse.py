@@ -189,7 +189,7 @@ class FusedTask(object):
         scheduler hands this task fresh window OBJECTS of the same windows.  None: not such tiles / first seen just now."""
         try:
             key = tuple((v["values"].ptr, v["values"].pitch, v["values"].shape) if v["values"].resident else None for v in leaf_values)
-        except (AttributeError, KeyError, TypeError):
+        except (AttributeError, KeyError, TypeError, IndexError):  # (IndexError: a leaf that answered with a bare ndarray)
             return None
         if None in key:
             return None

@@ -32,6 +32,7 @@ import itertools
 import mmap
 import os
 import pickle
+import selectors
 import subprocess
 import sys
 import threading
@@ -417,6 +418,11 @@ class Pool(object):
         try:
             for i, device in enumerate(self.devices):
                 self.workers.append(_Worker(i, device, settings))
+            # (one selector for the life of the pool: multiprocessing.connection.wait builds and fills one per call -- a third of
+            #  what a re-run at eight workers cost the parent)
+            self.selector = selectors.DefaultSelector()
+            for w in self.workers:
+                self.selector.register(w.conn.fileno(), selectors.EVENT_READ, w.conn)
             ready = self._collect({w.index: None for w in self.workers}, start_timeout, "start")
             self.device_names = [ready[w.index] for w in self.workers]
         except BaseException:
@@ -454,7 +460,11 @@ class Pool(object):
         replies, errors = {}, []
         deadline = None if timeout is None else time.time() + timeout
         while by_conn:
-            ready = _wait(list(by_conn), 0.25)
+            selector = getattr(self, "selector", None)
+            if selector is not None:
+                ready = [key.data for key, _ in selector.select(0.25) if key.data in by_conn]
+            else:
+                ready = _wait(list(by_conn), 0.25)
             for conn in ready:
                 w = by_conn[conn]
                 try:
@@ -515,9 +525,20 @@ class Pool(object):
                         w.proc.kill()
                         w.proc.wait()
                 try:
+                    if getattr(self, "selector", None) is not None:
+                        self.selector.unregister(w.conn.fileno())
+                except (KeyError, ValueError, OSError):
+                    pass
+                try:
                     w.conn.close()
                 except OSError:
                     pass
+            if getattr(self, "selector", None) is not None:
+                try:
+                    self.selector.close()
+                except OSError:
+                    pass
+                self.selector = None
 
     def refresh_config(self):
         """The workers evaluate under the parent's geomodeling.* settings AS THEY ARE NOW: a config.set after the pool

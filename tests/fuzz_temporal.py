@@ -54,6 +54,10 @@ for seed in range(N):
             except Exception as e:  # noqa
                 bad += 1
                 print("SEED", seed, type(e).__name__, str(e)[:200])
+                if os.environ.get("GM_FUZZ_TRACE"):
+                    import traceback
+                    traceback.print_exc()
+                    print("    request:", request)
                 print("   ", describe(view)[:500])
                 print("   ", {k: str(v) for k, v in request.items() if k in ("mode", "start", "stop")})
     if bad > 25:

@@ -154,6 +154,43 @@ def test_random_temporal_views_against_the_walking_oracle(gpu, seed, monkeypatch
             _same_response(*without_lossy_cells(comparable(got, view), comparable(want, view)), what)
 
 
+@pytest.mark.parametrize("plans", [True, False])
+def test_a_tiler_over_series_that_do_not_line_up(gpu, plans, monkeypatch):
+    """What the round-6 campaign found (tests/fuzz_temporal.py 2000 23x39 9000000, seed 358): a tiled Shift(Divide(series of 7
+    frames, series of 4 frames)) asked for coarser cells -- the fused task is handed leaf answers that are no raster responses, and
+    the key of its kept launches indexed them like one (IndexError instead of the reference's own answer).  Against the walking oracle, every time
+    window, tile by tile (the batched launch) with plans and with a graph per request."""
+    from datetime import datetime
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd import plan, raster
+    from oracle_walk import comparable, walk, without_lossy_cells
+    monkeypatch.setattr(plan, "_BATCHED_TILE_CELLS", 1 << 22 if plans else 0)
+    rng = np.random.default_rng(358)
+    a = (rng.random((7, 23, 39)) * 50).astype("f8")
+    b = rng.integers(0, 9, size=(4, 23, 39)).astype("u2")
+    a[rng.random(a.shape) < 0.1] = np.finfo("f8").max
+    b[rng.random(b.shape) < 0.1] = 65535
+    A = raster.MemorySource(a, np.finfo("f8").max, "EPSG:28992", 1.0, (0.0, 23.0), 1614556800000, 86400000, ["frame %d" % i for i in range(7)])
+    B = raster.MemorySource(b, np.uint16(65535), "EPSG:28992", 1.0, (0.0, 23.0), 1614556800000, 86400000)
+    view = raster.RasterTiler(raster.Shift(raster.Divide(A, B), 3600000), [18, 27])
+    box = dict(mode="vals", bbox=(0.0, 0.0, 39.0, 23.0), width=19, height=11, projection="EPSG:28992")  # (coarser cells: a warp)
+    windows = [{}, {"start": datetime(2021, 2, 28, 21, 30)}, {"start": datetime(2021, 3, 1, 5), "stop": datetime(2021, 3, 2, 22, 30)},
+               {"start": datetime(2021, 3, 2, 14, 30), "stop": datetime(2021, 3, 3, 5, 30)},
+               {"start": datetime(2021, 1, 30, 1), "stop": datetime(2021, 4, 3, 1)}]
+    with gmconfig.config.set({"geomodeling.plans": plans}):
+        for window in windows:
+            request = dict(box, **window)
+            for turn in range(3):  # (the third time round the launches of resident windows are replayed)
+                try:
+                    want = walk(view, request)
+                except Exception:  # noqa: BLE001 -- where the reference's own evaluation raises, so must the device path
+                    with pytest.raises(Exception):
+                        view.get_data(**request)
+                    continue
+                got = view.get_data(**request)
+                _same_response(*without_lossy_cells(comparable(got, view), comparable(want, view)), "%s, turn %d" % (window, turn))
+
+
 @pytest.mark.parametrize("seed", range(120))
 def test_random_memory_views_against_the_walking_oracle(gpu, seed, tiler_route):
     """The random views of this file over MemorySources -- stencils (request enlargement) and Smooth (exact and zoom mode)
