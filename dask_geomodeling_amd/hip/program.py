@@ -966,12 +966,13 @@ class PreparedBatch(object):
     (resident windows: immutable by contract) into FRESH result tiles.  What is left per call is one allocation call for the
     result tiles, one launch call, and the DeviceArray objects that own the results.  Made by ``prepare_batch``."""
 
-    __slots__ = ("compiled", "inputs", "n_tiles", "shape", "nbytes", "ptrs", "pitches", "out_ptrs", "out_pitches", "rows", "cols",
+    __slots__ = ("compiled", "inputs", "n_tiles", "shape", "nbytes", "ptrs", "pitches", "out_type", "out_pitches", "rows", "cols",
                  "n", "pitched", "program", "device", "dtype")
 
     def run(self):
         L = _lib()
-        n_tiles, out_ptrs = self.n_tiles, self.out_ptrs
+        n_tiles = self.n_tiles
+        out_ptrs = self.out_type()  # (a table of its own per call: scheduler threads may run the same kept launch at the same time)
         runtime.check(L.gm_malloc_many(out_ptrs, n_tiles, self.nbytes), "gm_malloc_many")
         shape, dtype, device = self.shape, self.dtype, self.device
         outs = [DeviceArray(out_ptrs[i], shape, dtype, device) for i in range(n_tiles)]  # (own the blocks from here on)
@@ -1003,7 +1004,7 @@ def prepare_batch(compiled, tiles, shape):
     p.device = runtime.get_device()
     p.program = ctypes.byref(compiled.program)
     p.ptrs = (ctypes.c_void_p * max(len(flat), 1))(*[x.ptr for x in flat])
-    p.out_ptrs = (ctypes.c_void_p * len(tiles))()
+    p.out_type = ctypes.c_void_p * len(tiles)
     p.pitched = any(x.pitch is not None for x in flat)
     p.rows, p.cols = _prod(shape[:-1]), int(shape[-1])
     p.pitches = (ctypes.c_uint32 * max(len(flat), 1))(*[x.pitch or 0 for x in flat]) if p.pitched else None

@@ -198,7 +198,7 @@ const char* gm_route_name(int family, int slot);
 #define GM_RS_MOVINGMAX_3X3 3
 #define GM_RS_MOVINGMAX_STACK 4   /* sizes 5-15: nested horizontal maxima in registers */
 #define GM_RS_MOVINGMAX_COLUMNS 5 /* larger disks, column by column */
-#define GM_RS_MOVINGMAX_KEYS 6    /* a -0.0 was staged: the integer-key walk */
+#define GM_RS_MOVINGMAX_KEYS 6    /* reserved (the integer-key walk for windows holding a -0.0 is chosen inside the kernel: nothing on the host counts it) */
 #define GM_RS_DILATE8_WIDE 7
 #define GM_RS_DILATE_OTHER 8
 #define GM_RS_GAUSS_ONE_LAUNCH 9

@@ -92,6 +92,49 @@ def test_repeated_requests_replay_their_kept_launches(gpu, seed):
     print("kept boxes:", kept)
 
 
+def test_kept_launches_from_several_threads(gpu):
+    """Eight scheduler threads asking the same view for the same four boxes at the same time (dask's threaded scheduler shares a
+    view's plans and a template's fused tasks): every answer is the box's own -- a kept launch takes a table of result pointers
+    of its own per call."""
+    import threading
+    from dask_geomodeling_amd import config as gmconfig
+    from dask_geomodeling_amd import raster
+    rng = np.random.default_rng(77)
+    a = (rng.random((1, 96, 128)) * 50).astype("f4")
+    b = (rng.random((1, 96, 128)) * 50).astype("f4")
+    A = raster.MemorySource(a, np.float32(-1.0), "EPSG:28992", 1.0, (0.0, 96.0))
+    B = raster.MemorySource(b, np.float32(-1.0), "EPSG:28992", 1.0, (0.0, 96.0))
+    view = raster.Clip(raster.Add(raster.Subtract(raster.Multiply(raster.Add(A, B), 2.5), B), 1.5), A)
+    boxes = [(0.0, 0.0, 64.0, 48.0), (64.0, 48.0, 128.0, 96.0), (32.0, 16.0, 96.0, 64.0), (0.0, 48.0, 64.0, 96.0)]
+    req = dict(mode="vals", width=64, height=48, projection="EPSG:28992")
+    for plans in (True, False):
+        with gmconfig.config.set({"geomodeling.plans": plans}):
+            want = [np.asarray(view.get_data(bbox=box, **req)["values"]).copy() for box in boxes]
+            for _ in range(3):  # (the launches of all four boxes are kept from here on)
+                for box in boxes:
+                    view.get_data(bbox=box, **req)
+            wrong, errors = [], []
+
+            def worker(first):
+                try:
+                    with gmconfig.config.set({"geomodeling.plans": plans}):
+                        for k in range(120):
+                            i = (first + k) % 4
+                            got = np.asarray(view.get_data(bbox=boxes[i], **req)["values"])
+                            if not np.array_equal(got.view("u4"), want[i].view("u4")):
+                                wrong.append((first, k, i))
+                except Exception as e:  # noqa: BLE001
+                    errors.append(e)
+
+            threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            assert not errors, errors[:2]
+            assert not wrong, wrong[:5]
+
+
 def test_plan_exists_for_the_canonical_chain_and_is_reused(gpu, tiler_route):
     from dask_geomodeling_amd import plan, raster
     from dask_geomodeling_amd.hip import DeviceArray
