@@ -31,6 +31,7 @@
 // HBM traffic: n * itemsize + itemsize bytes per pixel (twice the reads for var / std).
 #include <cmath>
 #include <limits>
+#include <type_traits>
 
 #include "gm_common.h"
 
@@ -474,54 +475,67 @@ __global__ __launch_bounds__(WG) void reduce_sorted_kernel(const C* __restrict__
 
 // Up to 16 rasters -- the usual stack -- sort in registers (Batcher's odd-even merge network, NaN frames entering as
 // +inf behind the data) instead of LDS; the element of the rank a cell needs is picked with a select chain.
-template <typename C, int N>
-__device__ __forceinline__ void sort_network(C (&v)[N]) {
-#pragma unroll
-  for (int p = 1; p < N; p *= 2) {
-#pragma unroll
-    for (int k = p; k >= 1; k /= 2) {
-#pragma unroll
-      for (int j = k % p; j <= N - 1 - k; j += 2 * k) {
-#pragma unroll
-        for (int i = 0; i <= k - 1; ++i) {
-          if (i + j + k <= N - 1 && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
-            const C lo = v[i + j] < v[i + j + k] ? v[i + j] : v[i + j + k];
-            const C hi = v[i + j] < v[i + j + k] ? v[i + j + k] : v[i + j];
-            v[i + j] = lo;
-            v[i + j + k] = hi;
-          }
-        }
-      }
-    }
+// Batcher's odd-even merge sort as a network of compare-exchanges on a lane's registers.  The indices are template constants
+// (round 6): written as nested loops for the unroller, the 32- and 64-element networks -- and the 16-element one of float64 -- were
+// left with run-time indices, so the values lived in scratch memory (16 + 4 N bytes per lane) and every comparator went there.
+template <int Begin, int End, int Step, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (Begin < End) {
+    f(std::integral_constant<int, Begin>{});
+    static_for<Begin + Step, End, Step>(f);
   }
+}
+template <typename C, int N, int P, int K>
+__device__ __forceinline__ void sort_network_step(C (&v)[N]) {
+  static_for<K % P, N - K, 2 * K>([&](auto j) {
+    static_for<0, K, 1>([&](auto i) {
+      constexpr int a = decltype(i)::value + decltype(j)::value, b = a + K;
+      if constexpr (b <= N - 1 && a / (2 * P) == b / (2 * P)) {
+        const C lo = v[a] < v[b] ? v[a] : v[b];
+        const C hi = v[a] < v[b] ? v[b] : v[a];
+        v[a] = lo;
+        v[b] = hi;
+      }
+    });
+  });
+  if constexpr (K / 2 >= 1) sort_network_step<C, N, P, K / 2>(v);
+}
+template <typename C, int N, int P = 1>
+__device__ __forceinline__ void sort_network(C (&v)[N]) {
+  sort_network_step<C, N, P, P>(v);
+  if constexpr (2 * P < N) sort_network<C, N, 2 * P>(v);
 }
 template <typename C, int N>
 __device__ __forceinline__ C pick(const C (&v)[N], int index) {
   C r = v[0];
-#pragma unroll
-  for (int i = 1; i < N; ++i) r = index == i ? v[i] : r;
+  static_for<1, N, 1>([&](auto i) { r = index == decltype(i)::value ? v[decltype(i)::value] : r; });  // (see sort_network)
   return r;
 }
 
-template <typename C, bool HALF, bool PERCENTILE, int N>
-__global__ __launch_bounds__(256) void reduce_sorted_small_kernel(const C* __restrict__ stack, int n, long long pixels,
+template <typename C, bool HALF, bool PERCENTILE, int N, typename SRC = StackSource<C>>
+__global__ __launch_bounds__(256) void reduce_sorted_small_kernel(const SRC source, int n, long long pixels,
                                                                   SortPlan P, C* __restrict__ out, C fill) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p >= pixels) return;
-  const C* src = stack + p;
+  const auto fr = source.at(p);
   C v[N];
   int m = 0;
   // (all N loads first: with each value examined right behind its load the compiler waited for every load before it
   // issued the next -- N memory round trips per pixel)
-  C raw[N];
+  // (... sixteen at a time: all 64 of the largest network in flight at once doubled its registers and spilled)
+  constexpr int CH = N < 16 ? N : 16;
 #pragma unroll
-  for (int j = 0; j < N; ++j) raw[j] = __builtin_nontemporal_load(src + (long long)(j < n ? j : 0) * pixels);
+  for (int j0 = 0; j0 < N; j0 += CH) {
+    C raw[CH];
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const C x = raw[j];
-    const bool nd = j >= n || x != x;
-    v[j] = nd ? std::numeric_limits<C>::infinity() : x;
-    m += nd ? 0 : 1;
+    for (int k = 0; k < CH; ++k) raw[k] = fr.template load<1>(j0 + k < n ? j0 + k : 0).v[0];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const C x = raw[k];
+      const bool nd = j0 + k >= n || x != x;
+      v[j0 + k] = nd ? std::numeric_limits<C>::infinity() : x;
+      m += nd ? 0 : 1;
+    }
   }
   sort_network<C, N>(v);
   C r = fill;
@@ -581,14 +595,18 @@ int launch_reduce(const void* stack, int n, long long pixels, int statistic, con
         P.one_minus_gamma[i] = plan[i].one_minus_gamma;
       }
     }
-    if (n <= 16) {  // the usual stack: sorted in registers
+    // the usual stack: sorted in registers.  Round 6: up to 32 rasters (64 of a 4-byte work dtype) -- the LDS insertion sort that
+    // took over from 17 rasters on ran at 0.2 TB/s (60 rasters of 2048^2: 6.6 ms; their maximum 0.23 ms)
+    if (n <= 32 || (n <= 64 && sizeof(C) == 4)) {
       const unsigned gxs = (unsigned)((pixels + 255) / 256);
 #define GM_SORTED_SMALL(PCT, N_)                                                                                   \
-  hipLaunchKernelGGL((reduce_sorted_small_kernel<C, HALF, PCT, N_>), dim3(gxs), dim3(256), 0, s, (const C*)stack, n, \
+  hipLaunchKernelGGL((reduce_sorted_small_kernel<C, HALF, PCT, N_>), dim3(gxs), dim3(256), 0, s, StackSource<C>{(const C*)stack, pixels}, n, \
                      pixels, P, (C*)out, fill)
       if (n <= 4) { if (percentile) GM_SORTED_SMALL(true, 4); else GM_SORTED_SMALL(false, 4); }
       else if (n <= 8) { if (percentile) GM_SORTED_SMALL(true, 8); else GM_SORTED_SMALL(false, 8); }
-      else { if (percentile) GM_SORTED_SMALL(true, 16); else GM_SORTED_SMALL(false, 16); }
+      else if (n <= 16) { if (percentile) GM_SORTED_SMALL(true, 16); else GM_SORTED_SMALL(false, 16); }
+      else if (n <= 32) { if (percentile) GM_SORTED_SMALL(true, 32); else GM_SORTED_SMALL(false, 32); }
+      else if constexpr (sizeof(C) == 4) { if (percentile) GM_SORTED_SMALL(true, 64); else GM_SORTED_SMALL(false, 64); }
 #undef GM_SORTED_SMALL
       return GM_OK;
     }
@@ -666,8 +684,18 @@ int launch_reduce(const void* stack, int n, long long pixels, int statistic, con
 
 // n separate rasters of the work dtype, read in place
 template <typename C>
-int launch_reduce_rasters(const gm_raster_ref* rasters, int n, long long pixels, int statistic, void* out, uint64_t fill_bits, hipStream_t s) {
+int launch_reduce_rasters(const gm_raster_ref* rasters, int n, long long pixels, int statistic, const gm_percentile_step* plan, void* out,
+                          uint64_t fill_bits, hipStream_t s) {
   const C fill = fill_of<C>(fill_bits);
+  const bool sorted = statistic == GM_RED_MEDIAN || statistic == GM_RED_PERCENTILE;
+  if (sorted) {
+    if (!(n <= 32 || (n <= 64 && sizeof(C) == 4)))
+      return gm::fail(GM_ERR_UNSUPPORTED, "gm_reduce_rasters: median / percentile over %d rasters (up to 32, 64 of a 4-byte dtype: longer stacks take gm_reduce_stack)", n);
+    if (statistic == GM_RED_PERCENTILE && !plan) return gm::fail(GM_ERR_INVALID, "gm_reduce_rasters: percentile without a plan");
+    for (int i = 0; statistic == GM_RED_PERCENTILE && i < n; ++i)
+      if (plan[i].lower < 0 || plan[i].lower > i || plan[i].upper < 0 || plan[i].upper > i)
+        return gm::fail(GM_ERR_INVALID, "gm_reduce_rasters: plan[%d] points outside %d values", i, i + 1);
+  }
   constexpr int VV = 16 / (int)sizeof(C);
   bool vec = (pixels % VV) == 0 && ((uintptr_t)out % 16) == 0;
   for (int i = 0; i < n; ++i) vec = vec && ((uintptr_t)rasters[i].values % 16) == 0;
@@ -694,6 +722,29 @@ int launch_reduce_rasters(const gm_raster_ref* rasters, int n, long long pixels,
     return GM_OK;
   }
   const RasterSource<C> source{refs};
+  if (sorted) {
+    const bool percentile = statistic == GM_RED_PERCENTILE;
+    SortPlan P;
+    memset(&P, 0, sizeof(P));
+    for (int i = 0; percentile && i < n; ++i) {
+      P.lower[i] = (short)plan[i].lower;
+      P.upper[i] = (short)plan[i].upper;
+      P.gamma[i] = plan[i].gamma;
+      P.one_minus_gamma[i] = plan[i].one_minus_gamma;
+    }
+    const unsigned gxs = (unsigned)((pixels + 255) / 256);
+#define GM_SORTED_RASTERS(PCT, N_)                                                                                              \
+  hipLaunchKernelGGL((reduce_sorted_small_kernel<C, false, PCT, N_, RasterSource<C>>), dim3(gxs), dim3(256), 0, s, source, n, pixels, P, \
+                     (C*)out, fill)
+    if (n <= 4) { if (percentile) GM_SORTED_RASTERS(true, 4); else GM_SORTED_RASTERS(false, 4); }
+    else if (n <= 8) { if (percentile) GM_SORTED_RASTERS(true, 8); else GM_SORTED_RASTERS(false, 8); }
+    else if (n <= 16) { if (percentile) GM_SORTED_RASTERS(true, 16); else GM_SORTED_RASTERS(false, 16); }
+    else if (n <= 32) { if (percentile) GM_SORTED_RASTERS(true, 32); else GM_SORTED_RASTERS(false, 32); }
+    else if constexpr (sizeof(C) == 4) { if (percentile) GM_SORTED_RASTERS(true, 64); else GM_SORTED_RASTERS(false, 64); }
+#undef GM_SORTED_RASTERS
+    (void)gm_free(refs);
+    return GM_OK;
+  }
   // (sums over more rasters than one leaf of the pairwise recursion: the explicit-stack form, one cell per lane -- the unrolled
   //  recursion spills once the no-data test is part of every load)
   const bool deep = n > RD_PW_BLOCK &&
@@ -718,8 +769,8 @@ int launch_reduce_rasters(const gm_raster_ref* rasters, int n, long long pixels,
 
 }  // namespace
 
-extern "C" int gm_reduce_rasters(const gm_raster_ref* rasters, int work_dtype, int64_t n, int64_t pixels, int statistic, void* out,
-                                 uint64_t fill_bits) {
+extern "C" int gm_reduce_rasters(const gm_raster_ref* rasters, int work_dtype, int64_t n, int64_t pixels, int statistic,
+                                 const gm_percentile_step* plan, void* out, uint64_t fill_bits) {
   if (!rasters || !out) return gm::fail(GM_ERR_INVALID, "null pointer");
   if (n <= 0 || n > 0x7fffffff || pixels < 0) return gm::fail(GM_ERR_INVALID, "gm_reduce_rasters: %lld rasters of %lld pixels", (long long)n, (long long)pixels);
   for (int64_t i = 0; i < n; ++i)
@@ -728,8 +779,8 @@ extern "C" int gm_reduce_rasters(const gm_raster_ref* rasters, int work_dtype, i
   hipStream_t s = gm::current_stream();
   if (!s) return GM_ERR_NO_DEVICE;
   int rc;
-  if (work_dtype == GM_F32) rc = launch_reduce_rasters<float>(rasters, (int)n, pixels, statistic, out, fill_bits, s);
-  else if (work_dtype == GM_F64) rc = launch_reduce_rasters<double>(rasters, (int)n, pixels, statistic, out, fill_bits, s);
+  if (work_dtype == GM_F32) rc = launch_reduce_rasters<float>(rasters, (int)n, pixels, statistic, plan, out, fill_bits, s);
+  else if (work_dtype == GM_F64) rc = launch_reduce_rasters<double>(rasters, (int)n, pixels, statistic, plan, out, fill_bits, s);
   else return gm::fail(GM_ERR_UNSUPPORTED, "gm_reduce_rasters: rasters of dtype %d (float32 / float64 rasters in their own work dtype)", work_dtype);
   if (rc) return rc;
   GM_HIP(hipGetLastError());

@@ -500,11 +500,19 @@ __device__ __forceinline__ void sort_network(C (&v)[N]) {
     }
   }
 }
+// (round 6: the chain's indices as template constants -- as a loop left to the unroller, the 32-element chain (and the 16-element
+//  one of the 8-byte dtypes) kept a run-time index, which put the whole sorted array into scratch memory: 16 + 4 N bytes per lane)
+template <int I, int N, typename C>
+__device__ __forceinline__ void pick_step(const C (&v)[N], int index, C& r) {
+  if constexpr (I < N) {
+    r = index == I ? v[I] : r;
+    pick_step<I + 1, N, C>(v, index, r);
+  }
+}
 template <typename C, int N>
 __device__ __forceinline__ C pick(const C (&v)[N], int index) {
   C r = v[0];
-#pragma unroll
-  for (int i = 1; i < N; ++i) r = index == i ? v[i] : r;
+  pick_step<1, N, C>(v, index, r);
   return r;
 }
 

@@ -162,7 +162,7 @@ def _nan_function(stack, statistic, percentile, fill_value, dtype):
     if long_sort and half:
         raise NotImplementedError("%s over %d rasters in float16 (a 1-byte output dtype)" % (statistic, n))
     bands = shape[0]
-    in_place = _rasters_in_place(stack, nodes, statistic, storage, half, shape, fill_value, dtype)
+    in_place = _rasters_in_place(stack, nodes, statistic, storage, half, shape, fill_value, dtype, percentile)
     if in_place is not None:
         return in_place
     stacked = DeviceArray.empty((n * bands,) + shape[1:], storage)
@@ -213,7 +213,7 @@ class gm_raster_ref(ctypes.Structure):
 _RASTERS_IN_PLACE = True  # (the tests switch it off to compare the two routes)
 
 
-def _rasters_in_place(stack, nodes, statistic, storage, half, shape, fill_value, dtype):
+def _rasters_in_place(stack, nodes, statistic, storage, half, shape, fill_value, dtype, percentile=None):
     """Round 6: rasters that already ARE the work dtype (float32 rasters reduced in float32, float64 in float64) are read where
     they are -- one launch over n tile pointers, the NaN coding of reduction.py:99-107 done in the load (gm_reduce_rasters) --
     instead of being coded into a stack by a launch each and read again.  -> the result tile, or None for everything else."""
@@ -221,8 +221,10 @@ def _rasters_in_place(stack, nodes, statistic, storage, half, shape, fill_value,
     from ..hip import runtime
     from ..hip.array import DeviceArray, as_device
     from ..hip.dtypes import code_of
-    if not _RASTERS_IN_PLACE or half or statistic in ("median", "percentile") or len(stack) < 2:
+    if not _RASTERS_IN_PLACE or half or len(stack) < 2:
         return None
+    if statistic in ("median", "percentile") and len(stack) > (64 if storage.itemsize == 4 else 32):
+        return None  # (more rasters than a lane sorts in its registers: the coded stack and the LDS sort / the selection)
     if any(np.dtype(node.dtype) != storage or tuple(np.shape(node.values)) != shape for node in nodes):
         return None
     L = _lib()
@@ -233,7 +235,12 @@ def _rasters_in_place(stack, nodes, statistic, storage, half, shape, fill_value,
         extra = _index_extra(node.dtype, node.ndv)
         ref.values, ref.ndv_compared, ref.tolerance, ref.flags = tile.ptr, extra["y"], extra["tol"], extra["flags"]
     result = DeviceArray.empty(shape, storage)
-    runtime.check(L.gm_reduce_rasters(refs, code_of(storage), len(nodes), result.size, STATISTICS[statistic], result.ptr,
+    plan = None
+    if statistic == "percentile":
+        from .temporal import percentile_plan
+        plan = percentile_plan(percentile, len(nodes), np.result_type(dtype, np.float16))
+    code = _PERCENTILE_CODE if statistic == "percentile" else STATISTICS[statistic]
+    runtime.check(L.gm_reduce_rasters(refs, code_of(storage), len(nodes), result.size, code, plan, result.ptr,
                                       runtime.scalar_bits(float(fill_value), storage)), "gm_reduce_rasters")
     del tiles
     if storage == dtype:
@@ -268,7 +275,7 @@ def _picked_in_place(stack, statistic, fill_value, dtype):
         extra = _index_extra(node.dtype, node.ndv)
         ref.values, ref.ndv_compared, ref.tolerance, ref.flags = tile.ptr, extra["y"], extra["tol"], extra["flags"]
     result = DeviceArray.empty(shape, dtype)
-    runtime.check(L.gm_reduce_rasters(refs, code_of(dtype), len(nodes), result.size, _PICK_CODES[statistic], result.ptr,
+    runtime.check(L.gm_reduce_rasters(refs, code_of(dtype), len(nodes), result.size, _PICK_CODES[statistic], None, result.ptr,
                                       runtime.scalar_bits(float(fill_value), dtype)), "gm_reduce_rasters")
     del tiles
     return result
@@ -277,7 +284,7 @@ def _picked_in_place(stack, statistic, fill_value, dtype):
 def _declare_reduce_rasters(L):
     if not getattr(L, "_gm_reduce_rasters_declared", False):
         L.gm_reduce_rasters.argtypes = [ctypes.POINTER(gm_raster_ref), ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
-                                        ctypes.c_void_p, ctypes.c_uint64]
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
         L.gm_reduce_rasters.restype = ctypes.c_int
         L._gm_reduce_rasters_declared = True
 

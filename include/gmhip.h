@@ -665,7 +665,8 @@ enum gm_reduce_statistic {
 };
 int gm_reduce_stack(const void* stack, int work_dtype, int half, int64_t n, int64_t pixels, int statistic,
                     const gm_percentile_step* plan, void* out, uint64_t fill_bits);
-/* The same statistics (all but MEDIAN / PERCENTILE) over n SEPARATE rasters of the work dtype read in place: the coding of the
+/* The same statistics over n SEPARATE rasters of the work dtype read in place (MEDIAN / PERCENTILE: up to 32 rasters, 64 of
+ * float32 -- sorted in registers; `plan` as for gm_reduce_stack, NULL otherwise): the coding of the
  * stack -- `stack_array[i, index] = values[index]` with index = utils.get_index(values, no_data_value), reduction.py:99-107,
  * utils.py:61-64 -- happens in the load.  Per raster: its cells (device, `pixels` of them, C-contiguous), and the parameters of
  * ~np.isclose(values, ndv) as NumPy's promotion rules give them for that raster: the no-data value as compared, the tolerance
@@ -679,8 +680,8 @@ typedef struct gm_raster_ref {
   double ndv_compared, tolerance;
   uint32_t flags, reserved;
 } gm_raster_ref;
-int gm_reduce_rasters(const gm_raster_ref* rasters, int work_dtype, int64_t n, int64_t pixels, int statistic, void* out,
-                      uint64_t fill_bits);
+int gm_reduce_rasters(const gm_raster_ref* rasters, int work_dtype, int64_t n, int64_t pixels, int statistic,
+                      const gm_percentile_step* plan, void* out, uint64_t fill_bits);
 
 /* ==========================================================================
  * N4: labelled (zonal) statistics -- the numeric core of geometry.AggregateRaster

@@ -1294,7 +1294,8 @@ def test_reduce_rasters_in_place_vs_the_stack_and_the_oracle(gpu, monkeypatch, d
             stack[i]["values"][0, -1, -1] = stack[i]["no_data_value"]   # one cell without data anywhere ...
         for d in stack[3:]:
             d["values"][0, -1, -1] = d["no_data_value"]
-        for stat in ("sum", "mean", "min", "max", "std", "var", "product", "argmin", "argmax", "first", "last", "count"):
+        for stat in ("sum", "mean", "min", "max", "std", "var", "product", "argmin", "argmax", "first", "last", "count", "median", "p25",
+                     "p90.5"):
             before = None
             with np.errstate(all="ignore"):
                 want = O.reduce_rasters([dict(d) for d in stack], stat)
@@ -1303,9 +1304,13 @@ def test_reduce_rasters_in_place_vs_the_stack_and_the_oracle(gpu, monkeypatch, d
             through_stack = reduction.reduce_rasters([dict(d) for d in stack], stat)
             monkeypatch.setattr(reduction, "_RASTERS_IN_PLACE", True)
             what = "%s %s n=%d ndv=%r" % (stat, dt, n, ndv0)
-            assert_result_equal(dict(got, values=np.asarray(got["values"])), dict(through_stack, values=np.asarray(through_stack["values"])), 0, what + " (routes)")
+            a, b = dict(got, values=np.asarray(got["values"])), dict(through_stack, values=np.asarray(through_stack["values"]))
+            if stat == "median" or stat.startswith("p"):  # (the register network and the LDS sort may leave the two zeros in either order)
+                from fuzz_util import unsigned_zero as _uz
+                a, b = _uz(a), _uz(b)
+            assert_result_equal(a, b, 0, what + " (routes)")
             mine = dict(got, values=np.asarray(got["values"]))
-            if stat in ("min", "max"):
+            if stat in ("min", "max", "median") or stat.startswith("p"):
                 # (which zero a tie between -0.0 and +0.0 leaves is a property of the host's SIMD loops: DESIGN.md section 2)
                 from fuzz_util import unsigned_zero
                 mine, want = unsigned_zero(mine), unsigned_zero(want)
