@@ -442,6 +442,37 @@ def _direct(block, request):
     return block.process(*args)
 
 
+def _direct_kept(block, request):
+    """``_direct`` for the view a request is asked of, with the ARGUMENTS of its ``process`` kept per request (round 6) when every
+    answer of its sources is resident data as it stands (zero-copy windows: ``DeviceArray.resident``) or carries no raster at
+    all (time stamps, metadata): asking immutable Blocks the same question again gives the same windows.  ``process`` itself --
+    every launch -- runs each time.  Group(A, B) over two resident sources: 49 -> 33 us per request, kernel-bound."""
+    try:
+        key = tuple(sorted((k, tuple(v) if isinstance(v, list) else v) for k, v in request.items()))
+        kept = block.__dict__.get("_gm_direct_args")
+        args = kept.get(key) if kept is not None else None
+    except TypeError:
+        return _direct(block, request)
+    if args is not None:
+        return block.process(*args)
+    args = []
+    keep = True
+    for source, sub in block.get_sources_and_requests(**request):
+        if isinstance(source, Block) and sub is not None:
+            answer = _child(source, sub)
+            keep = keep and (_is_resident_answer(answer) or (isinstance(answer, dict) and "values" not in answer) or answer is None)
+            args.append(answer)
+        else:
+            args.append(source)
+    if keep:
+        with _lock:
+            kept = block.__dict__.setdefault("_gm_direct_args", collections.OrderedDict())
+            kept[key] = args
+            while len(kept) > MAX_KEPT_BOXES:
+                kept.popitem(last=False)
+    return block.process(*args)
+
+
 _running = threading.local()  # .memo: {(id(block), request): response} of the evaluation in progress on this thread
 
 
@@ -520,9 +551,10 @@ def _evaluate(view, request):
     if getattr(view, "gm_direct", False):
         # a Block with a kernel of its own over ONE store (stencils, Smooth, resample): its store is evaluated
         # through the store's plan, the Block's own request planning is all that is redone per request
-        return True, _direct(view, request)
+        return True, _direct_kept(view, request)
     return False, None
 
 
 def clear(view):
     view.__dict__.pop("_gm_plans", None)
+    view.__dict__.pop("_gm_direct_args", None)
