@@ -3310,7 +3310,7 @@ __global__ __launch_bounds__(256) void zonal_chunk_combine_kernel(const T* __res
                                                                   const unsigned char* __restrict__ slot_of,
                                                                   const StepRec* __restrict__ step_records,
                                                                   ChunkVerdict* __restrict__ verdict, unsigned* __restrict__ verdict_host,
-                                                                  unsigned long_from, unsigned patience, int statistic,
+                                                                  unsigned long_from, unsigned patience, int statistic, int lazy,
                                                                   float* __restrict__ out, long long* __restrict__ counts) {
   __shared__ __align__(16) double parked[4][2][ZC_STEP + 32];
   __shared__ unsigned listed[4][ZC_LIST];
@@ -3371,47 +3371,137 @@ __global__ __launch_bounds__(256) void zonal_chunk_combine_kernel(const T* __res
     const unsigned n = park(c, mine);
     if (n) acc = chain_add_parked(mine, acc, n);  // (wave-uniform)
   };
-  for (unsigned round0 = 0; round0 < row_bytes; round0 += ZC_LIST) {
-    // the label's chunks of this round in order: (stretch << 8 | slot); a lane reads 64 stretches' bytes
+  // the label's chunks of a round of the table in order: (stretch << 8 | slot); a lane reads 64 stretches' bytes
+  auto list_round = [&](unsigned round0) -> unsigned {
     unsigned n_list = 0;
-    {
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      const unsigned at = round0 + 64u * (unsigned)lane;
-      u32x4 q[4];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned at = round0 + 64u * (unsigned)lane;
+    u32x4 q[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) q[i] = u32x4{0u, 0u, 0u, 0u};
-      if (at < row_bytes) {
-        const u32x4* const row = reinterpret_cast<const u32x4*>(slot_of + (size_t)l * row_bytes + at);
+    for (int i = 0; i < 4; ++i) q[i] = u32x4{0u, 0u, 0u, 0u};
+    if (at < row_bytes) {
+      const u32x4* const row = reinterpret_cast<const u32x4*>(slot_of + (size_t)l * row_bytes + at);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = row[i];
+      for (int i = 0; i < 4; ++i) q[i] = row[i];
+    }
+    unsigned mine_n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const unsigned word = q[i][c];
+        mine_n += (word & 0xffu ? 1u : 0u) + (word & 0xff00u ? 1u : 0u) + (word & 0xff0000u ? 1u : 0u) + (word & 0xff000000u ? 1u : 0u);
       }
-      unsigned mine_n = 0;
+    unsigned inclusive = mine_n;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int offset = 1; offset < 64; offset <<= 1) {
+      const unsigned other = __shfl_up(inclusive, offset);
+      if (lane >= offset) inclusive += other;
+    }
+    n_list = (unsigned)__builtin_amdgcn_readlane((int)inclusive, 63);
+    if (n_list == 0) return 0u;  // (wave-uniform)
+    unsigned pos = inclusive - mine_n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int byte = 0; byte < 4; ++byte) {
+          const unsigned slot = (q[i][c] >> (8 * byte)) & 0xffu;
+          if (slot) list[pos++] = ((at + 16u * i + 4u * c + byte) << 8) | slot;
+        }
+    return n_list;
+  };
+  // Round 6: the float32 answer without the order.  What the caller keeps of a sum is its rounding into the float32 `agg`
+  // (aggregate.py:187-203), and bincount's sequential float64 sum s_n lies close to ANY float64 sum of the same cells: with
+  // X_k the exact partial sums and M >= |X_k| for all k, s_k = (s_(k-1) + x_k)(1 + d_k), |d_k| <= u = 2^-53, gives
+  // the errors e_k = s_k - X_k obey |e_k| <= (1 + u) |e_(k-1)| + u |X_k|, hence |e_n| <= (1 + u)^n u sum_k |X_k| <= 1.000001 u
+  // sum_k |X_k| (n < 2^31).  The chunk records hold what bounds the |X_k| -- the extreme partial sums inside every chunk,
+  // relative to the sum entering it: W = sum over the chunks of (cells) x (largest |partial sum|) -- and tree sums that differ
+  // from the exact ones by at most tau: a rounding is at most u times the result of its addition, and nothing amplifies it on
+  // the way, so tau <= u x (the sum of the |results| of all the additions that lead to S below).  Level by level: a lane's 4
+  // additions and the 6 across the wave in zonal_chunk_kernel: every cell enters at most one result per level, 10 A in all
+  // (A >= the sum of the |cells|: count x 2^(hi + 1) per chunk); the additions of a chunk's steps onto its record: one per
+  // step that holds a cell, each result a partial sum relative to the chunk's start, at most r = max(-low, high); the chunk
+  // totals (each at most r) through a lane's 4 additions and the 6 across the wave here: 10 levels again -- together V = sum
+  // over the chunks of (min(cells, 64) + 10) r; and the running S, once per batch, at most M (the largest |partial sum|).
+  // tau = 1.5 u (10 A + V + (batches + 8) M).  So s_n lies inside S -/+ E, E = 1.01 u
+  // (W + 2 n tau) + tau -- plus 4 u (M + tau) for the roundings of S -/+ E themselves -- and when both ends of S -/+ E --
+  // divided by n for the mean: a division and a conversion are monotone -- round to the same float32, that float32 is what
+  // bincount's sum rounds to, whatever it rounded on the way.  Zero-mean noise under a few long labels, whose sum sheds and
+  // takes up low bits a few hundred times (each such event a replay or a step of the block pipeline, one after the other:
+  // three labels over 12.6 M cells 1.4 ms), passes with a margin of 10^-2 of a float32 unit in the last place; a sum that
+  // does land next to a float32 tie -- sums of a few cells of 2^-24 beside 1.0 in the tests -- fails and is added in order below.
+  if (lazy) {
+    const double inf = __builtin_huge_val();
+    double S = 0.0, M = 0.0, A = 0.0;
+    unsigned long long n = 0;
+    unsigned batches = 0;
+    bool bad = false;
+    double W = 0.0;  // sum over the chunks of (cells of the chunk) x (the largest |partial sum| inside it)
+    double V = 0.0;  // ... of (steps of the chunk that hold its cells, at most, + 10) x (the largest |partial sum - the sum entering the chunk|)
+    for (unsigned round0 = 0; round0 < row_bytes; round0 += ZC_LIST) {
+      const unsigned n_list = list_round(round0);
+      for (unsigned b0 = 0; b0 < n_list; b0 += 256u) {  // (wave-uniform)
+        ChunkRec four[4];
+        double run = 0.0, lane_abs = 0.0;
+        unsigned lane_count = 0u;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const unsigned word = q[i][c];
-          mine_n += (word & 0xffu ? 1u : 0u) + (word & 0xff00u ? 1u : 0u) + (word & 0xff0000u ? 1u : 0u) + (word & 0xff000000u ? 1u : 0u);
+          const unsigned i = b0 + 4u * (unsigned)lane + (unsigned)c;
+          const unsigned e = i < n_list ? list[i] : 0u;
+          ChunkRec r{};
+          r.hi = SHRT_MIN;
+          if (e) r = records[(size_t)(e >> 8) * ZC_SLOTS + (e & 0xffu) - 1];
+          four[c] = r;
+          run += r.total;
+          lane_count += r.count;
+          bad = bad || r.bad != 0;
+          if (r.hi != SHRT_MIN) lane_abs += ldexp((double)r.count, (int)r.hi + 1);  // (every |cell| < 2^(hi + 1))
         }
-      unsigned inclusive = mine_n;
+        double entering = S + (wave_scan_f64(run) - run), lane_weight = 0.0, lane_chain = 0.0, lane_reach = 0.0;
 #pragma unroll
-      for (int offset = 1; offset < 64; offset <<= 1) {
-        const unsigned other = __shfl_up(inclusive, offset);
-        if (lane >= offset) inclusive += other;
+        for (int c = 0; c < 4; ++c) {
+          const double reach = fmax(fabs(entering + (double)four[c].low), fabs(entering + (double)four[c].high));
+          lane_weight += (double)four[c].count * reach;
+          lane_chain += (double)(min(four[c].count, (unsigned)ZC_MAX_STEPS) + 10u) * fmax(-(double)four[c].low, (double)four[c].high);
+          lane_reach = fmax(lane_reach, reach);
+          entering += four[c].total;
+        }
+        M = fmax(M, wave_max_f64(lane_reach));
+        W += wave_sum_exact(lane_weight);
+        V += wave_sum_exact(lane_chain);
+        S += wave_sum_exact(run);
+        A += wave_sum_exact(lane_abs);
+        n += wave_sum_u32(lane_count);
+        ++batches;
       }
-      n_list = (unsigned)__builtin_amdgcn_readlane((int)inclusive, 63);
-      if (n_list == 0) continue;  // (wave-uniform)
-      unsigned pos = inclusive - mine_n;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int byte = 0; byte < 4; ++byte) {
-            const unsigned slot = (q[i][c] >> (8 * byte)) & 0xffu;
-            if (slot) list[pos++] = ((at + 16u * i + 4u * c + byte) << 8) | slot;
-          }
     }
+    if (n != 0 && __ballot(bad) == 0 && A < 1.0e300 && W < 1.0e300 && V < 1.0e300) {  // (wave-uniform; false for NaN)
+      constexpr double u = 1.1102230246251565e-16;
+      const double tau = 1.5 * u * (10.0 * A + V + (double)(batches + 8u) * M);
+      const double E = 1.01 * u * (W + 4.0 * M + (2.0 * (double)n + 4.0) * tau) + tau;
+      double below = S - E, above = S + E;
+      if (statistic == Z_MEAN) {
+        below /= (double)n;
+        above /= (double)n;
+      }
+      if (lazy == 2 && lane == 0)
+        printf("[gmhip] float32 certificate, label %d: n %llu S %.17g E %.3g (W %.3g V %.3g M %.3g A %.3g tau %.3g, %u batches) -> %.9g .. %.9g\n", l,
+               n, S, E, W, V, M, A, tau, batches, (double)(float)below, (double)(float)above);
+      const float lowest = (float)below, highest = (float)above;
+      if (__float_as_uint(lowest) == __float_as_uint(highest) && fabsf(lowest) < inf) {
+        if (lane == 0) {
+          counts[l] = (long long)n;
+          out[l] = lowest;
+        }
+        return;
+      }
+    }
+  }
+  for (unsigned round0 = 0; round0 < row_bytes; round0 += ZC_LIST) {
+    const unsigned n_list = list_round(round0);
+    if (n_list == 0) continue;  // (wave-uniform)
     // (a batch's records are requested while the batch before it is worked on: one memory round trip per label, not per batch)
     auto fetch_batch = [&](unsigned b0, unsigned* entry_out) -> ChunkRec {
       const unsigned entry = b0 + (unsigned)lane < n_list ? list[b0 + lane] : 0u;
@@ -3887,6 +3977,10 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     // (GM_ZONAL_CHUNKS=2: also the labels of ZL_LONG cells and more stay on this route however often they are replayed -- the tests do)
     static const int chunks_mode = getenv("GM_ZONAL_CHUNKS") ? atoi(getenv("GM_ZONAL_CHUNKS")) : 1;
     const bool chunks_allowed = chunks_mode != 0;
+    // (GM_ZONAL_LAZY=0: no label is answered by the float32 certificate of zonal_chunk_combine_kernel -- every sum in bincount's
+    //  order, as before round 6: A/B runs, and the tests compare the two)
+    //  (=2: the kernel prints every label's bounds)
+    static const int lazy_allowed = getenv("GM_ZONAL_LAZY") ? atoi(getenv("GM_ZONAL_LAZY")) : 1;
     bool chunk_gave_up_hard = false;  // (a sum that keeps rounding: the parallel sums below cannot answer it either)
     bool chunk_not_runs = false;      // (labels scattered cell by cell: the certificates through the workgroups' LDS tables)
     if (range && chunks_allowed && cells >= ZC_LANE && (uintptr_t)frame % sizeof(CellQuad<T>) == 0 &&
@@ -3941,7 +4035,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
                            (size_t)cells, chunk_cells, (unsigned)n_stretch, (unsigned)row_bytes, n_labels, has_ndv, ndv, thresholds,
                            chunk.records, chunk.slot_of, chunk.steps, chunk.verdict,
                            flag ? flag->word : (unsigned*)nullptr, chunks_mode == 2 ? ~0u : chunk_long,
-                           chunks_mode == 2 ? ~0u : ZC_REPLAYS, statistic, out_f, counts_f);
+                           chunks_mode == 2 ? ~0u : ZC_REPLAYS, statistic, lazy_allowed, out_f, counts_f);
         GM_HIP(hipGetLastError());
         ChunkVerdict chunk_verdict{1u, 0u, 1u};
         if (flag) {  // (the one host decision of this route: three words in pinned memory, read once the kernels are through)

@@ -2352,17 +2352,19 @@ def test_zonal_label_partition(gpu, part, select):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunks", ["2", "1", "0"], ids=["chunks-always", "product", "chunks-off"])
-def test_zonal_chunk_records(gpu, chunks):
+@pytest.mark.parametrize("chunks,lazy", [("2", "1"), ("2", "0"), ("1", "1"), ("0", "1")],
+                         ids=["chunks-always", "chunks-always-every-sum-in-order", "product", "chunks-off"])
+def test_zonal_chunk_records(gpu, chunks, lazy):
     """Sums and means without a sort (csrc/gm_zonal.hip: zonal_chunk_kernel leaves a record per (stretch of the raster, label),
     zonal_chunk_combine_kernel walks a label's records in order -- one addition per chunk that cannot round, the chunk's cells
     again from the raster otherwise) against np.bincount's order: 80 statistics over label layouts of many chunks per label,
     every label ending in cells that cancel the sequential sum before them (tests/zonal_chunks_driver.py).  With every label
-    kept on the route, with the product's choice (labels that are replayed too often take the sorting route), and without it."""
+    kept on the route -- with and without the float32 certificate of round 6, which answers the labels whose tails do not cancel
+    --, with the product's choice (labels that are replayed too often take the sorting route), and without the route."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, GM_ZONAL_CHUNKS=chunks)
+    env = dict(os.environ, GM_ZONAL_CHUNKS=chunks, GM_ZONAL_LAZY=lazy)
     driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_chunks_driver.py")
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
@@ -2379,11 +2381,12 @@ def test_zonal_chunk_records(gpu, chunks):
 @pytest.mark.gpu
 def test_zonal_exactness_certificates_through_the_chunks(gpu):
     """The adversarial rasters of the block pipeline's certificates (labels of 450 k - 1 M cells whose tails cancel the sum
-    before them) answered by the chunk records alone (GM_ZONAL_CHUNKS=2: no label is handed to the sorting route)."""
+    before them) answered by the chunk records alone (GM_ZONAL_CHUNKS=2: no label is handed to the sorting route), every sum
+    in bincount's order (GM_ZONAL_LAZY=0: the cancelled sums fail the float32 certificate anyway, the others would not)."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, GM_ZONAL_CHUNKS="2")
+    env = dict(os.environ, GM_ZONAL_CHUNKS="2", GM_ZONAL_LAZY="0")
     driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_certificate_driver.py")
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
@@ -2411,6 +2414,32 @@ def test_zonal_exactness_certificates(gpu, certify):
     assert took["chunk_attempts"] == 0 and took["block_pipeline"] > 0, took
     groups = [int(line.split("certified exact, ")[1].split(" groups")[0]) for line in res.stderr.splitlines() if "groups of 256 certified" in line]
     assert groups and (sum(groups) > 100 if certify == "1" else sum(groups) == 0), groups[:20]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lazy", ["1", "0"], ids=["product", "every-sum-in-order"])
+def test_zonal_float32_certificate(gpu, lazy):
+    """Round 6: a label whose float64 sum -- in any order -- lies far enough from every float32 rounding boundary is answered
+    without bincount's order (csrc/gm_zonal.hip: the first pass of zonal_chunk_combine_kernel over the label's chunk records;
+    the bound is derived there).  tests/zonal_lazy_driver.py: zero-mean noise under long labels (which the certificate must
+    answer: no label of those rasters reaches the sorting route), and what must NOT be answered that way -- exact sums on
+    float32 ties and a hair beside them, sums that cancel to zeros of either sign and to float32 subnormals, cells beyond
+    float32's range, int64 cells, non-finite cells -- against np.bincount's order; and all of it with the certificate off."""
+    import os
+    import subprocess
+    import sys
+    driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_lazy_driver.py")
+    res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=dict(os.environ, GM_ZONAL_LAZY=lazy), timeout=900)
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
+    assert "LAZY ok 74" in res.stdout, res.stdout[-300:]
+    noise = subprocess.run([sys.executable, driver, "noise"], capture_output=True, text=True, env=dict(os.environ, GM_ZONAL_LAZY=lazy), timeout=900)
+    assert noise.returncode == 0 and "LAZY ok 20" in noise.stdout, (noise.stdout[-500:], noise.stderr[-2500:])
+    took = routes_of(noise.stdout)["zonal"]
+    if lazy == "1":   # noise under long labels used to send the frame to the sorting route (`hard`): nothing does now
+        # (a sum may land within the bound of a float32 tie -- a few per cent of the labels of millions of cells: those frames go on)
+        assert took["chunk_answered"] >= 22 and took["chunk_gave_up"] <= 2, took
+    else:
+        assert took["ordered_sums"] > 0, took
 
 
 @pytest.mark.gpu
