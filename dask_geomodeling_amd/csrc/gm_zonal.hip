@@ -1885,7 +1885,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
                                                           const float* __restrict__ thresholds, ExactRange* __restrict__ range,
                                                           double* __restrict__ sums, unsigned char* __restrict__ present,
                                                           unsigned* __restrict__ keys, typename Ordered<T>::Key* __restrict__ payload,
-                                                          unsigned* __restrict__ tile_counts) {
+                                                          unsigned* __restrict__ tile_counts, double* __restrict__ mags = nullptr) {
   // (PHASE 0 also writes the sort keys of zonal_keys_kernel: if the order turns out to matter the sort can start at once --
   // and, with tile_counts, what the label partition's counting pass would find: the cells of every key per tile of TILE
   // cells, one atomic per run and tile)
@@ -1901,7 +1901,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
   int run_label = -1;  // the run the wave is in (wave-uniform); per lane what it has gathered for it
   unsigned run_count = 0, run_bad = 0;
   int run_hi = INT_MIN, run_lo = INT_MAX;
-  double run_sum = 0.0;
+  double run_sum = 0.0, run_mag = 0.0;  // (PHASE 2 = PHASE 1 + the sums of the magnitudes: the float32 certificate of the caller)
   auto tile_flush = [&]() {  // (wave-uniform call; a run that crosses a tile border keeps gathering for its label's range)
     if (run_label < 0) return;
     const unsigned n = wave_sum_u32(tile_n);
@@ -1924,6 +1924,11 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
     } else {
       const double total = wave_sum_exact(run_sum);  // (exact: see above)
       if (lane == 0) atomicAdd(&sums[run_label], total);
+      if constexpr (PHASE == 2) {
+        const double mag = wave_sum_exact(run_mag);
+        if (lane == 0) atomicAdd(&mags[run_label], mag);
+        run_mag = 0.0;
+      }
     }
     run_label = -1;
     run_count = run_bad = 0;
@@ -1980,6 +1985,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
           }
         } else {
           run_sum += x;
+          if constexpr (PHASE == 2) run_mag += fabs(x);
         }
       }
     } else {  // (a step across label boundaries: run by run)
@@ -2008,6 +2014,10 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
       } else {
         const double total = run_total(active ? x : 0.0, runs, [](double a, double b) { return a + b; });  // (exact: see above)
         if (runs.last && labelled && total != 0.0) atomicAdd(&sums[label], total);
+        if constexpr (PHASE == 2) {
+          const double mag = run_total(active ? fabs(x) : 0.0, runs, [](double a, double b) { return a + b; });
+          if (runs.last && labelled && mag != 0.0) atomicAdd(&mags[label], mag);
+        }
       }
     }
   });
@@ -2016,7 +2026,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
   __shared__ unsigned long long end_count[4];
   __shared__ int end_hi[4], end_lo[4];
   __shared__ unsigned end_bad[4];
-  __shared__ double end_sum[4];
+  __shared__ double end_sum[4], end_mag[4];
   {
     const int w = threadIdx.x >> 6;
     if constexpr (PHASE == 0) {
@@ -2032,9 +2042,12 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
       }
     } else {
       const double total = wave_sum_exact(run_sum);  // (exact: see above)
+      double mag = 0.0;
+      if constexpr (PHASE == 2) mag = wave_sum_exact(run_mag);
       if (lane == 0) {
         end_label[w] = run_label;
         end_sum[w] = total;
+        end_mag[w] = mag;
       }
     }
   }
@@ -2062,14 +2075,16 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
         atomicMin(&slot->lo, lo);
         if (bad) atomicOr(&slot->bad, 1u);
       } else {
-        double total = end_sum[w];
+        double total = end_sum[w], mag = end_mag[w];
         for (int v = w + 1; v < 4; ++v) {
           if (end_label[v] == label) {
             total += end_sum[v];  // (exact like every addition of this pass)
+            mag += end_mag[v];
             end_label[v] = -1;
           }
         }
         atomicAdd(&sums[label], total);
+        if constexpr (PHASE == 2) atomicAdd(&mags[label], mag);
       }
     }
   }
@@ -2206,6 +2221,103 @@ __global__ __launch_bounds__(ZX_THREADS) void zonal_tables_exact_kernel(const T*
   }
 }
 
+// Sums of labels WITHOUT runs whose cells do round (round 6: zero-mean noise under 20 labels at random: 1 ms through the sort
+// and the block pipeline): the float32 certificate of zonal_chunk_combine_kernel (derived there) over workgroups instead of
+// chunks.  A workgroup's waves walk adjacent stretches, so a workgroup covers a contiguous range of the raster; per label it
+// leaves a row {sum of its cells in whatever order the LDS atomics arrived, sum of their magnitudes, count, non-finite?}, and
+// a wave per label then walks the workgroups' rows in raster order: the partial sums inside workgroup g lie within
+// (the sum entering g) -/+ mag_g, which bounds sum_k |X_k| by W = sum_g count_g (|entering_g| + mag_g); every addition that led
+// to the row's sum -- per lane and run, across the wave, onto the LDS table -- has a result of at most mag_g, and there are at
+// most count_g + steps per wave + 6 of them per cell level: V = sum_g (count_g + steps + 16) mag_g bounds what the rows' sums
+// and their combination here can be off by.  A label that fails -- a sum next to a float32 tie, a non-finite cell -- raises
+// `failed` and the whole frame goes on to the routes that add in order.
+struct LazyRow {  // 24 bytes per (workgroup, label)
+  double sum, mag;
+  unsigned count, bad;
+};
+template <typename T, int THREADS>
+__global__ __launch_bounds__(THREADS) void zonal_tables_lazy_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
+                                                                    size_t cells_per_wave, int n_labels, int has_ndv, T ndv,
+                                                                    const float* __restrict__ thresholds, LazyRow* __restrict__ rows,
+                                                                    unsigned char* __restrict__ present) {
+  extern __shared__ unsigned long long zx_lds[];
+  double* const sum_of = (double*)zx_lds;
+  double* const mag_of = sum_of + n_labels;
+  unsigned* const count_of = (unsigned*)(mag_of + n_labels);
+  unsigned* const bad_of = count_of + n_labels;
+  for (int l = threadIdx.x; l < n_labels; l += THREADS) {
+    sum_of[l] = 0.0;
+    mag_of[l] = 0.0;
+    count_of[l] = 0u;
+    bad_of[l] = 0u;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * THREADS + threadIdx.x) >> 6;
+  const size_t begin = min(wave * cells_per_wave, cells), end = min(begin + cells_per_wave, cells);
+  int run_label = -1, marked = INT_MIN;
+  unsigned run_count = 0, run_bad = 0;
+  double run_sum = 0.0, run_mag = 0.0;
+  auto flush = [&]() {  // (wave-uniform call)
+    if (run_label < 0) return;
+    const unsigned n = wave_sum_u32(run_count), bad = wave_or_u32(run_bad);
+    const double total = wave_sum_exact(run_sum), mag = wave_sum_exact(run_mag);
+    if (lane == 0 && n != 0) {
+      atomicAdd(&count_of[run_label], n);
+      if (mag != 0.0) {
+        atomicAdd(&sum_of[run_label], total);
+        atomicAdd(&mag_of[run_label], mag);
+      }
+      if (bad) atomicOr(&bad_of[run_label], 1u);
+    }
+    run_label = -1;
+    run_count = run_bad = 0;
+    run_sum = run_mag = 0.0;
+  };
+  walk_cells<T>(values, labels, begin, end, lane, [&](T v, int label, bool inside, size_t i) {
+    (void)inside;
+    (void)i;
+    const bool labelled = (unsigned)label < (unsigned)n_labels;
+    mark_present(present, label, labelled, &marked);
+    bool active = labelled && !(has_ndv && v == ndv);
+    if (thresholds && active) {
+      const float t = thresholds[label];
+      active = !(t != t) && (double)v >= (double)t;
+    }
+    const unsigned long long mask = __ballot(active);
+    if (mask == 0) return;  // (wave-uniform)
+    const double x = (double)v;
+    const bool bad = active && !(fabs(x) <= 1.7976931348623157e308);
+    const int leader_label = __builtin_amdgcn_readlane(label, __ffsll((long long)mask) - 1);
+    if (__all(!active || label == leader_label)) {
+      if (leader_label != run_label) {
+        flush();
+        run_label = leader_label;
+      }
+      if (active) {
+        run_count += 1;
+        run_bad |= bad ? 1u : 0u;
+        if (!bad) {
+          run_sum += x;
+          run_mag += fabs(x);
+        }
+      }
+    } else if (active) {
+      atomicAdd(&count_of[label], 1u);
+      if (bad) {
+        atomicOr(&bad_of[label], 1u);
+      } else if (x != 0.0) {
+        atomicAdd(&sum_of[label], x);
+        atomicAdd(&mag_of[label], fabs(x));
+      }
+    }
+  });
+  flush();
+  __syncthreads();
+  LazyRow* const mine = rows + (size_t)blockIdx.x * n_labels;
+  for (int l = threadIdx.x; l < n_labels; l += THREADS) mine[l] = LazyRow{sum_of[l], mag_of[l], count_of[l], bad_of[l]};
+}
+
 __global__ __launch_bounds__(256) void zonal_exact_init_kernel(ExactRange* __restrict__ range, double* __restrict__ sums, int n_labels,
                                                                ExactVerdict* __restrict__ verdict, unsigned* __restrict__ cursor) {
   const int l = blockIdx.x * 256 + threadIdx.x;
@@ -2233,6 +2345,43 @@ __global__ __launch_bounds__(256) void zonal_exact_decide_kernel(const ExactRang
   inexact[l] = exact ? 0 : 1;
   if (r.count) atomicMax(&verdict->longest, (unsigned)min(r.count, 0xffffffffull));
   if (!exact) {
+    atomicAdd(&verdict->labels, 1u);
+    atomicAdd(&verdict->cells, r.count);
+  }
+}
+
+// Round 6: the labels the exponents turn away, asked again with the float32 certificate of zonal_chunk_combine_kernel (derived
+// there) in its crudest form.  PHASE 2 of zonal_exact_kernel has added a label's cells in some order -- every intermediate
+// result a sum of some of them, at most mag = the sum of their magnitudes; at most 2 count + 16 results: a lane's chain, the
+// reductions across a wave, one atomic per run -- so its sum lies within tau = 1.5 u (2 count + 16) mag of the exact one, and
+// bincount's within 1.01 u count mag (every partial sum is at most mag).  Labels of a few hundred cells -- the rasters of many
+// small polygons that reach this route -- pass unless their sum lies within 10^-9 of a float32 tie: 49 152 polygons of 16 x 16
+// cells of zero-mean noise used to send the ~2 000 of them with a cell next to zero through a gather and six sorting passes
+// (470 us a call).  A label that passes loses its flag (the float32 of its sum is the answer, by monotonicity); the verdict is
+// counted again over those that keep it.
+__global__ __launch_bounds__(256) void zonal_exact_lazy_decide_kernel(const ExactRange* __restrict__ range, const double* __restrict__ sums,
+                                                                      const double* __restrict__ mags, int n_labels, int statistic,
+                                                                      unsigned char* __restrict__ inexact, ExactVerdict* __restrict__ verdict) {
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= n_labels || !inexact[l]) return;
+  const ExactRange r = range[l];
+  const double S = sums[l], mag = mags[l], n = (double)r.count;
+  bool pass = false;
+  if (!r.bad && r.count != 0 && mag < 1.0e300) {  // (false for NaN)
+    constexpr double u = 1.1102230246251565e-16;
+    const double tau = 1.5 * u * (2.0 * n + 16.0) * mag;
+    const double E = 1.01 * u * (n * mag + 4.0 * mag + (2.0 * n + 4.0) * tau) + tau + (mag > 0.0 ? 1.0e-300 : 0.0);
+    double below = S - E, above = S + E;
+    if (statistic == Z_MEAN) {
+      below /= n;
+      above /= n;
+    }
+    const float lowest = (float)below, highest = (float)above;
+    pass = __float_as_uint(lowest) == __float_as_uint(highest) && fabsf(lowest) < __builtin_huge_valf();
+  }
+  if (pass) {
+    inexact[l] = 0;
+  } else {
     atomicAdd(&verdict->labels, 1u);
     atomicAdd(&verdict->cells, r.count);
   }
@@ -3040,6 +3189,80 @@ __device__ __forceinline__ double chain_add_parked(const double* mine, double ac
   return acc;
 }
 
+// (the second kernel of zonal_tables_lazy_kernel: a wave per label over the workgroups' rows)
+__global__ __launch_bounds__(256) void zonal_tables_lazy_label_kernel(const LazyRow* __restrict__ rows, unsigned groups, int n_labels,
+                                                                      double steps_per_wave, int statistic, int verbose,
+                                                                      float* __restrict__ out, long long* __restrict__ counts,
+                                                                      unsigned* __restrict__ failed) {
+  const int l = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (l >= n_labels) return;
+  double S = 0.0, M = 0.0, A = 0.0, W = 0.0, V = 0.0;
+  unsigned long long n = 0;
+  unsigned batches = 0;
+  bool bad = false;
+  for (unsigned g0 = 0; g0 < groups; g0 += 256u) {  // the workgroups in raster order, four per lane
+    LazyRow four[4];
+    double run = 0.0, lane_mag = 0.0;
+    unsigned lane_count = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const unsigned g = g0 + 4u * (unsigned)lane + (unsigned)c;
+      LazyRow r{0.0, 0.0, 0u, 0u};
+      if (g < groups) r = rows[(size_t)g * n_labels + l];
+      four[c] = r;
+      run += r.sum;
+      lane_mag += r.mag;
+      lane_count += r.count;
+      bad = bad || r.bad != 0;
+    }
+    double entering = S + (wave_scan_f64(run) - run), lane_weight = 0.0, lane_chain = 0.0, lane_reach = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double reach = fabs(entering) + four[c].mag;
+      lane_weight += (double)four[c].count * reach;
+      lane_chain += ((double)four[c].count + steps_per_wave + 16.0) * four[c].mag;
+      if (four[c].count) lane_reach = fmax(lane_reach, reach);
+      entering += four[c].sum;
+    }
+    M = fmax(M, wave_max_f64(lane_reach));
+    W += wave_sum_exact(lane_weight);
+    V += wave_sum_exact(lane_chain);
+    S += wave_sum_exact(run);
+    A += wave_sum_exact(lane_mag);
+    n += wave_sum_u32(lane_count);
+    ++batches;
+  }
+  if (n == 0 && __ballot(bad) == 0) {
+    if (lane == 0) {
+      counts[l] = 0;
+      out[l] = std::numeric_limits<float>::quiet_NaN();
+    }
+    return;
+  }
+  if (__ballot(bad) == 0 && A < 1.0e300 && W < 1.0e300 && V < 1.0e300) {  // (wave-uniform; false for NaN)
+    constexpr double u = 1.1102230246251565e-16;
+    const double tau = 1.5 * u * (V + (double)(batches + 8u) * M);
+    const double E = 1.01 * u * (W + 4.0 * M + (2.0 * (double)n + 4.0) * tau) + tau + (A > 0.0 ? 1.0e-300 : 0.0);
+    double below = S - E, above = S + E;
+    if (statistic == Z_MEAN) {
+      below /= (double)n;
+      above /= (double)n;
+    }
+    const float lowest = (float)below, highest = (float)above;
+    if (verbose && lane == 0)
+      printf("[gmhip] float32 certificate (tables), label %d: n %llu S %.17g E %.3g (W %.3g V %.3g M %.3g A %.3g tau %.3g) -> %.9g .. %.9g\n", l, n, S,
+             E, W, V, M, A, tau, (double)lowest, (double)highest);
+    if (__float_as_uint(lowest) == __float_as_uint(highest) && fabsf(lowest) < __builtin_huge_valf()) {
+      if (lane == 0) {
+        counts[l] = (long long)n;
+        out[l] = lowest;
+      }
+      return;
+    }
+  }
+  if (lane == 0) *failed = 1u;
+}
+
 // The verdict of pass 1 where the host can read it without a copy: a pinned word the kernel writes, and the event behind the
 // kernel -- the host waits for pass 1 only, pass 2 is already queued behind it.
 struct HostFlag {
@@ -3480,7 +3703,8 @@ __global__ __launch_bounds__(256) void zonal_chunk_combine_kernel(const T* __res
     if (n != 0 && __ballot(bad) == 0 && A < 1.0e300 && W < 1.0e300 && V < 1.0e300) {  // (wave-uniform; false for NaN)
       constexpr double u = 1.1102230246251565e-16;
       const double tau = 1.5 * u * (10.0 * A + V + (double)(batches + 8u) * M);
-      const double E = 1.01 * u * (W + 4.0 * M + (2.0 * (double)n + 4.0) * tau) + tau;
+      // (+ 1e-300 wherever a cell is not zero: no claim rests on what an adder or an atomic unit does with float64 subnormals)
+      const double E = 1.01 * u * (W + 4.0 * M + (2.0 * (double)n + 4.0) * tau) + tau + (A > 0.0 ? 1.0e-300 : 0.0);
       double below = S - E, above = S + E;
       if (statistic == Z_MEAN) {
         below /= (double)n;
@@ -3857,6 +4081,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     if ((rc = scratch.take((void**)&cursor, sizeof(unsigned)))) return rc;
   }
   unsigned *keys_a = nullptr, *keys_b = nullptr, *first = nullptr;
+  double* mags = nullptr;  // (the sums of the magnitudes beside the parallel sums: the float32 certificate)
   double *blk_sum = nullptr, *blk_pred = nullptr, *blk_abs = nullptr;  // (the block pipeline of the long labels)
   int* blk_gexp = nullptr;
   GroupExact* grp_exact = nullptr;
@@ -4068,6 +4293,41 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     unsigned longest = ~0u;  // (cells of the longest label, where a verdict has counted them)
     // labels scattered cell by cell: the exactness certificates and, where every label passes, the sums -- through tables in
     // LDS (zonal_tables_exact_kernel; GM_ZONAL_TABLES_EXACT=0: never -- A/B runs, and the tests compare the two)
+    // ... first the float32 certificate through the same kind of tables (zonal_tables_lazy_kernel: one pass, no sum in order; a label
+    // that fails sends the frame on.  GM_ZONAL_LAZY_TABLES=0: never -- A/B runs, and the tests compare)
+    static const bool lazy_tables_allowed = !(getenv("GM_ZONAL_LAZY_TABLES") && atoi(getenv("GM_ZONAL_LAZY_TABLES")) == 0);
+    if (range && chunk_not_runs && lazy_allowed && lazy_tables_allowed && (size_t)n_labels * sizeof(LazyRow) <= ZT_LDS_BYTES) {
+      HostFlag* const flag = host_flag();
+      if (flag) {
+        // workgroups: as many as a table of 16 MB holds rows for, 256 ... 2048 (shorter ranges per workgroup: tighter bounds)
+        const int64_t fit = (int64_t)((16u << 20) / ((size_t)n_labels * sizeof(LazyRow)));
+        const bool small = fit >= 1024;  // (workgroups of 4 waves; of 16 when the rows of many labels limit their number)
+        const int waves_per_group = small ? 4 : 16;
+        int64_t groups = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(fit, 2048), (cells + 64 * waves_per_group - 1) / (64 * waves_per_group)));
+        const size_t lazy_cells_per_wave = (size_t)((cells + groups * waves_per_group - 1) / (groups * waves_per_group) + 63) / 64 * 64;
+        groups = (int64_t)(((size_t)cells + lazy_cells_per_wave * waves_per_group - 1) / (lazy_cells_per_wave * waves_per_group));
+        LazyRow* rows = nullptr;
+        if ((rc = scratch.take((void**)&rows, sizeof(LazyRow) * (size_t)groups * n_labels))) return rc;
+        flag->word[5] = 0u;
+        const size_t lds = (size_t)n_labels * sizeof(LazyRow);
+        if (small)
+          hipLaunchKernelGGL((zonal_tables_lazy_kernel<T, 256>), dim3((unsigned)groups), dim3(256), lds, s, frame, labels, (size_t)cells,
+                             lazy_cells_per_wave, n_labels, has_ndv, ndv, thresholds, rows, seen);
+        else
+          hipLaunchKernelGGL((zonal_tables_lazy_kernel<T, 1024>), dim3((unsigned)groups), dim3(1024), lds, s, frame, labels, (size_t)cells,
+                             lazy_cells_per_wave, n_labels, has_ndv, ndv, thresholds, rows, seen);
+        hipLaunchKernelGGL(zonal_tables_lazy_label_kernel, dim3((unsigned)(((size_t)n_labels * 64 + 255) / 256)), dim3(256), 0, s, rows,
+                           (unsigned)groups, n_labels, (double)(lazy_cells_per_wave / 64), statistic, lazy_allowed == 2 ? 1 : 0, out_f, counts_f,
+                           flag->word + 5);
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipEventRecord(flag->event, s));
+        GM_HIP(hipEventSynchronize(flag->event));
+        if (((volatile unsigned*)flag->word)[5] == 0u) {
+          gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_LDS_LAZY);
+          continue;
+        }
+      }
+    }
     static const bool tables_exact_allowed = !(getenv("GM_ZONAL_TABLES_EXACT") && atoi(getenv("GM_ZONAL_TABLES_EXACT")) == 0);
     if (range && chunk_not_runs && tables_exact_allowed && (size_t)n_labels * 16 <= ZT_LDS_BYTES) {
       const size_t lds = (size_t)n_labels * 16;
@@ -4108,12 +4368,32 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       if ((rc = gm_d2h(&verdict, verdict_dev, sizeof(verdict)))) return rc;  // (the one host decision of a sum: through pinned memory)
       // every label exact: the parallel sums are the answer.  A few labels not (they hold at most 1/8 of the cells): the
       // parallel sums answer all the others, and only the cells of those few are sorted and added in order.
+      // (round 6) labels the exponents turn away: the parallel sums with the sums of the magnitudes beside them, and the float32
+      // certificate on those labels (zonal_exact_lazy_decide_kernel); what still needs its cells in order is counted again
+      bool summed = false;
+      if (verdict.labels != 0 && lazy_allowed) {
+        if (!mags && (rc = scratch.take((void**)&mags, sizeof(double) * n_labels))) return rc;
+        GM_HIP(hipMemsetAsync(mags, 0, sizeof(double) * n_labels, s));
+        GM_HIP(hipMemsetAsync(verdict_dev, 0, sizeof(ExactVerdict), s));
+        hipLaunchKernelGGL((zonal_exact_kernel<T, 2>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells,
+                           cells_per_wave, n_labels, has_ndv, ndv, thresholds, range, sums, (unsigned char*)nullptr,
+                           (unsigned*)nullptr, (Key*)nullptr, (unsigned*)nullptr, mags);
+        hipLaunchKernelGGL(zonal_exact_lazy_decide_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, mags, n_labels, statistic,
+                           inexact, verdict_dev);
+        ExactVerdict again{1u, 0u, (unsigned long long)cells};
+        if ((rc = gm_d2h(&again, verdict_dev, sizeof(again)))) return rc;
+        if (again.labels < verdict.labels) gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_EXACT_LAZY, verdict.labels - again.labels);
+        verdict.labels = again.labels;
+        verdict.cells = again.cells;
+        summed = true;
+      }
       const bool partial = verdict.labels != 0 && verdict.cells != 0 && verdict.cells <= (unsigned long long)cells / 8;
       if (verdict.labels == 0 || partial) {
         gm::route_hit(GM_ROUTE_ZONAL, partial ? GM_RZ_EXACT_PARTIAL : GM_RZ_EXACT_ALL);
-        hipLaunchKernelGGL((zonal_exact_kernel<T, 1>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells,
-                           cells_per_wave, n_labels, has_ndv, ndv, thresholds, range, sums, (unsigned char*)nullptr,
-                           (unsigned*)nullptr, (Key*)nullptr, (unsigned*)nullptr);
+        if (!summed)
+          hipLaunchKernelGGL((zonal_exact_kernel<T, 1>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells,
+                             cells_per_wave, n_labels, has_ndv, ndv, thresholds, range, sums, (unsigned char*)nullptr,
+                             (unsigned*)nullptr, (Key*)nullptr, (unsigned*)nullptr);
         hipLaunchKernelGGL(zonal_exact_result_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, statistic,
                            out_f, counts_f);
         if (partial) {

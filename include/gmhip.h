@@ -166,7 +166,9 @@ const char* gm_route_name(int family, int slot);
 #define GM_RZ_LDS_TABLES 13      /* count / min / max: per-workgroup LDS tables (label rasters without runs) */
 #define GM_RZ_SEGMENT_SORT 14    /* medians / percentiles under many labels: sort by label, every label's segment sorted in LDS */
 #define GM_RZ_LDS_EXACT 15       /* sums of scattered labels that cannot round: certificates and sums through workgroup LDS tables */
-#define GM_RZ_SLOTS 16
+#define GM_RZ_LDS_LAZY 16        /* sums of scattered labels answered by the float32 certificate over workgroup LDS tables */
+#define GM_RZ_EXACT_LAZY 17      /* sums: LABELS the exponents turned away that the float32 certificate answered from the parallel sums */
+#define GM_RZ_SLOTS 18
 /* bilinear slots */
 #define GM_RB_CALLS 0
 #define GM_RB_TWO_X 1            /* the dedicated 2 x kernel */
@@ -702,7 +704,10 @@ int gm_reduce_rasters(const gm_raster_ref* rasters, int work_dtype, int64_t n, i
  *             with counts > 0, like `agg[frame_no][select_and_active] = ...`)
  *   present : n_labels bytes (device) or NULL: 1 where the label occurs in `labels` at all
  *             (set(select) - unique_labels are the reference's geometries_no_cells)
- * sum and mean add the cells of a label in raster order in float64, as np.bincount does.
+ * sum and mean are the float32 roundings of np.bincount's sum: the cells of a label added in raster order in float64.
+ * A label whose float64 sum in ANY order lies provably clear of every float32 rounding boundary is answered without that
+ * order (the bound is derived in csrc/gm_zonal.hip: zonal_chunk_combine_kernel); every other label is added in order.
+ * The float32 bits are bincount's either way.  GM_ZONAL_LAZY=0 in the environment: every sum in order.
  * ========================================================================== */
 enum gm_zonal_statistic_code {
   GM_ZONAL_SUM = 0, GM_ZONAL_COUNT = 1, GM_ZONAL_MIN = 2, GM_ZONAL_MAX = 3, GM_ZONAL_MEAN = 4, GM_ZONAL_MEDIAN = 5,

@@ -28,7 +28,7 @@ def test_zonal_stress_driver(gpu):
     assert "done 120 failures 0" in out, out[-2000:]
     took = routes_of(out)["zonal"]
     # the campaign reaches every family of routes (a threshold that moves would show here)
-    for route in ("direct", "lds_tables", "lds_exact", "chunk_answered", "chunk_gave_up", "sort_partition", "sort_radix", "select",
+    for route in ("direct", "lds_tables", "lds_lazy", "exact_lazy_labels", "chunk_answered", "chunk_gave_up", "sort_partition", "sort_radix", "select",
                   "segment_sort", "ordered_sums"):
         assert took[route] > 0, (route, took)
 
@@ -36,11 +36,13 @@ def test_zonal_stress_driver(gpu):
 @pytest.mark.timeout(900)
 def test_zonal_stress_driver_on_the_older_routes(gpu):
     """The same campaign (shorter) with the round-6 routes switched off: count / min / max through the wave-slot kernel instead of
-    the workgroup tables, medians under many labels through the two sorts instead of the segment sort."""
-    out = _run("zonal_stress.py", [60, 4711], env={"GM_ZONAL_TABLES": "0", "GM_ZONAL_SEGSORT": "0"})
-    assert "done 60 failures 0" in out, out[-2000:]
+    the workgroup tables, medians under many labels through the two sorts instead of the segment sort, every sum in bincount's
+    order or certified exact (no float32 certificate: the scattered labels' sums through zonal_tables_exact_kernel)."""
+    out = _run("zonal_stress.py", [120, 4711], env={"GM_ZONAL_TABLES": "0", "GM_ZONAL_SEGSORT": "0", "GM_ZONAL_LAZY": "0"})
+    assert "done 120 failures 0" in out, out[-2000:]
     took = routes_of(out)["zonal"]
     assert took["lds_tables"] == 0 and took["segment_sort"] == 0 and took["direct"] > 0 and took["lexsort"] > 0, took
+    assert took["lds_lazy"] == 0 and took["exact_lazy_labels"] == 0 and took["lds_exact"] > 0, took
 
 
 @pytest.mark.timeout(900)

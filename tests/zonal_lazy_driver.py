@@ -8,6 +8,10 @@ np.bincount order, on data made for it and data made to break it:
            next to powers of two, means whose quotient is a tie): the direction is bincount's roundings' to decide;
   near     an integer + half a float32 unit in the last place + a nudge of 2^-1 ... 2^-59 of that, among pairs of noise cells
            that cancel exactly: from nudges the certificate must accept to nudges below bincount's own rounding drift;
+  scattered  labels at random per cell: the same certificate over the workgroups' LDS tables (zonal_tables_lazy_kernel), on noise,
+           non-finite cells and ties;
+  polygons   thousands of small polygons: the certificate on the parallel sums of zonal_exact_kernel for the labels its
+           exponent test turns away;
   zeros    sums that cancel to +0.0, to a float32 subnormal, to something that underflows to -0.0 / +0.0;
   wide     tiny and huge cells together, cells beyond float32's range (float64 rasters), int64 cells near 2^62, NaN and
            infinities.
@@ -28,7 +32,7 @@ from oracle import ref_numpy as O  # noqa: E402
 runtime.set_device(0)
 rng = np.random.default_rng(606)
 cases = 0
-ONLY = sys.argv[1].split(",") if len(sys.argv) > 1 else ["noise", "ties", "near", "zeros", "wide"]
+ONLY = sys.argv[1].split(",") if len(sys.argv) > 1 else ["noise", "ties", "near", "scattered", "polygons", "zeros", "wide"]
 
 
 def layout(kind, h, w):
@@ -146,6 +150,55 @@ if "near" in ONLY:
             band[pos[3:3 + pairs]] = noise
             band[pos[3 + pairs:3 + 2 * pairs]] = -noise
         check("near %d" % it, labels, n, values, None)
+
+if "scattered" in ONLY:
+    # labels at random per cell (no runs: the certificate over the workgroups' LDS tables, zonal_tables_lazy_kernel): noise; noise
+    # with non-finite cells under some labels; labels that are all zeros but for a float32 tie and cells too fine to count
+    for it in range(6):
+        h, w = int(rng.integers(700, 1300)), int(rng.integers(1100, 2300))
+        n = [12, 40, 300, 2000, 20, 90][it]
+        labels = rng.integers(0, n, size=(h, w)).astype(np.int32)
+        labels[rng.random((h, w)) < 0.02] = np.iinfo(np.int32).max
+        dt = "f8" if it % 3 == 2 else "f4"
+        values = (rng.standard_normal((1, h, w)) * 10 ** float(rng.integers(-2, 4))).astype(dt)
+        ndv = np.dtype(dt).type(-9999)
+        values[rng.random(values.shape) < 0.07] = ndv
+        if it == 4:
+            values[rng.random(values.shape) < 1e-6] = np.inf
+            values[rng.random(values.shape) < 1e-6] = np.nan
+        if it >= 3:
+            flat_v, flat_l = values.reshape(-1), labels.reshape(-1)
+            for l in range(0, n, 7):
+                idx = np.flatnonzero(flat_l == l)
+                flat_v[idx] = 0
+                pick = rng.permutation(len(idx))
+                flat_v[idx[pick[0]]], flat_v[idx[pick[1]]] = 1.0, 2.0 ** -24
+                flat_v[idx[pick[2:2 + len(idx) // 2]]] = rng.choice([-1.0, 1.0]) * 2.0 ** -int(rng.integers(30, 62))
+        check("scattered %d" % it, labels, n, values, ndv)
+
+if "polygons" in ONLY:
+    # thousands of small polygons (more than the chunk records take, beyond the partition's 2047 labels: the parallel sums of
+    # zonal_exact_kernel): noise with cells next to zero -- the exponents turn those labels away, the certificate on the parallel
+    # sums answers them --, and polygons that hold a float32 tie
+    for it in range(4):
+        h, w = int(rng.integers(900, 1400)), int(rng.integers(1500, 2500))
+        by, bx = int(rng.integers(9, 22)), int(rng.integers(9, 22))
+        labels = ((np.arange(h)[:, None] // by) * ((w + bx - 1) // bx) + np.arange(w)[None, :] // bx).astype(np.int32)
+        n = int(labels.max()) + 1
+        labels[rng.random((h, w)) < 0.02] = np.iinfo(np.int32).max
+        dt = "f8" if it == 3 else "f4"
+        values = (rng.standard_normal((1, h, w)) * 100).astype(dt)
+        values[rng.random(values.shape) < 0.01] *= np.dtype(dt).type(1e-9)
+        ndv = np.dtype(dt).type(-9999)
+        values[rng.random(values.shape) < 0.07] = ndv
+        if it >= 2:
+            for py in range(0, h // by, 3):
+                for px in range(0, w // bx, 5):
+                    block = values[0, py * by:(py + 1) * by, px * bx:(px + 1) * bx]
+                    block[...] = 0
+                    block[0, 0], block[-1, -1] = 1.0, 2.0 ** -24
+                    block[1, 1:] = rng.choice([-1.0, 1.0]) * 2.0 ** -int(rng.integers(30, 62))
+        check("polygons %d" % it, labels, n, values, ndv)
 
 if "zeros" in ONLY:
     for it in range(6):
