@@ -2226,14 +2226,16 @@ __global__ __launch_bounds__(ZX_THREADS) void zonal_tables_exact_kernel(const T*
 // chunks.  A workgroup's waves walk adjacent stretches, so a workgroup covers a contiguous range of the raster; per label it
 // leaves a row {sum of its cells in whatever order the LDS atomics arrived, sum of their magnitudes, count, non-finite?}, and
 // a wave per label then walks the workgroups' rows in raster order: the partial sums inside workgroup g lie within
-// (the sum entering g) -/+ mag_g, which bounds sum_k |X_k| by W = sum_g count_g (|entering_g| + mag_g); every addition that led
-// to the row's sum -- per lane and run, across the wave, onto the LDS table -- has a result of at most mag_g, and there are at
-// most count_g + steps per wave + 6 of them per cell level: V = sum_g (count_g + steps + 16) mag_g bounds what the rows' sums
-// and their combination here can be off by.  A label that fails -- a sum next to a float32 tie, a non-finite cell -- raises
+// (the sum entering g) -/+ mag_g, which bounds sum_k |X_k| by W = sum_g count_g (|entering_g| + mag_g).  What the rows' sums and
+// their combination can be off by: a lane's chain over a run of whole steps adds at most (steps per wave) results, each at most
+// the lane's share of mag_g; the reduction across the wave 6 levels of at most mag_g together; every addition onto the table
+// entry -- a flushed run, a scattered cell: counted in `adds` -- a result of at most mag_g; the combination here up to 16 + 6
+// levels more: V = sum_g (adds_g + steps + 32) mag_g.  A label that fails -- a sum next to a float32 tie, a non-finite cell -- raises
 // `failed` and the whole frame goes on to the routes that add in order.
 struct LazyRow {  // 24 bytes per (workgroup, label)
   double sum, mag;
-  unsigned count, bad;
+  unsigned count;
+  unsigned adds;  // additions onto the workgroup's table entry (a flushed run, a scattered cell); bit 31: a non-finite cell
 };
 template <typename T, int THREADS>
 __global__ __launch_bounds__(THREADS) void zonal_tables_lazy_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
@@ -2267,8 +2269,9 @@ __global__ __launch_bounds__(THREADS) void zonal_tables_lazy_kernel(const T* __r
       if (mag != 0.0) {
         atomicAdd(&sum_of[run_label], total);
         atomicAdd(&mag_of[run_label], mag);
+        atomicAdd(&bad_of[run_label], 1u);
       }
-      if (bad) atomicOr(&bad_of[run_label], 1u);
+      if (bad) atomicOr(&bad_of[run_label], 0x80000000u);
     }
     run_label = -1;
     run_count = run_bad = 0;
@@ -2302,13 +2305,26 @@ __global__ __launch_bounds__(THREADS) void zonal_tables_lazy_kernel(const T* __r
           run_mag += fabs(x);
         }
       }
-    } else if (active) {
-      atomicAdd(&count_of[label], 1u);
-      if (bad) {
-        atomicOr(&bad_of[label], 1u);
-      } else if (x != 0.0) {
-        atomicAdd(&sum_of[label], x);
-        atomicAdd(&mag_of[label], fabs(x));
+    } else {
+      // a step of several labels: the lanes of the run's label (a label with strays in it, the larger part of a boundary step)
+      // stay in registers like a step of one label, the others go to the table one by one
+      if (run_label < 0) run_label = leader_label;  // (wave-uniform)
+      if (active && label == run_label) {
+        run_count += 1;
+        run_bad |= bad ? 1u : 0u;
+        if (!bad) {
+          run_sum += x;
+          run_mag += fabs(x);
+        }
+      } else if (active) {
+        atomicAdd(&count_of[label], 1u);
+        if (bad) {
+          atomicOr(&bad_of[label], 0x80000000u);
+        } else if (x != 0.0) {
+          atomicAdd(&sum_of[label], x);
+          atomicAdd(&mag_of[label], fabs(x));
+          atomicAdd(&bad_of[label], 1u);
+        }
       }
     }
   });
@@ -3190,6 +3206,7 @@ __device__ __forceinline__ double chain_add_parked(const double* mine, double ac
 }
 
 // (the second kernel of zonal_tables_lazy_kernel: a wave per label over the workgroups' rows)
+template <int PER>  // rows per lane and batch: 4, or 16 where a label has thousands of rows (a batch is one round of wave reductions)
 __global__ __launch_bounds__(256) void zonal_tables_lazy_label_kernel(const LazyRow* __restrict__ rows, unsigned groups, int n_labels,
                                                                       double steps_per_wave, int statistic, int verbose,
                                                                       float* __restrict__ out, long long* __restrict__ counts,
@@ -3200,27 +3217,40 @@ __global__ __launch_bounds__(256) void zonal_tables_lazy_label_kernel(const Lazy
   unsigned long long n = 0;
   unsigned batches = 0;
   bool bad = false;
-  for (unsigned g0 = 0; g0 < groups; g0 += 256u) {  // the workgroups in raster order, four per lane
-    LazyRow four[4];
+  // (the rows of the next 256 workgroups are requested before this batch's are composed: a wave per label is one memory round
+  //  trip after the other otherwise -- 8192 rows of one label 31 us)
+  auto fetch = [&](unsigned g0, LazyRow (&into)[PER]) {
+#pragma unroll
+    for (int c = 0; c < PER; ++c) {
+      const unsigned g = g0 + (unsigned)PER * (unsigned)lane + (unsigned)c;
+      LazyRow r{0.0, 0.0, 0u, 0u};
+      if (g < groups) r = rows[(size_t)g * n_labels + l];
+      into[c] = r;
+    }
+  };
+  LazyRow ahead[PER];
+  fetch(0u, ahead);
+  for (unsigned g0 = 0; g0 < groups; g0 += 64u * PER) {  // the workgroups in raster order, PER per lane
+    LazyRow four[PER];
     double run = 0.0, lane_mag = 0.0;
     unsigned lane_count = 0u;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const unsigned g = g0 + 4u * (unsigned)lane + (unsigned)c;
-      LazyRow r{0.0, 0.0, 0u, 0u};
-      if (g < groups) r = rows[(size_t)g * n_labels + l];
-      four[c] = r;
+    for (int c = 0; c < PER; ++c) four[c] = ahead[c];
+    if (g0 + 64u * PER < groups) fetch(g0 + 64u * PER, ahead);  // (wave-uniform)
+#pragma unroll
+    for (int c = 0; c < PER; ++c) {
+      const LazyRow r = four[c];
       run += r.sum;
       lane_mag += r.mag;
       lane_count += r.count;
-      bad = bad || r.bad != 0;
+      bad = bad || (r.adds & 0x80000000u) != 0;
     }
     double entering = S + (wave_scan_f64(run) - run), lane_weight = 0.0, lane_chain = 0.0, lane_reach = 0.0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < PER; ++c) {
       const double reach = fabs(entering) + four[c].mag;
       lane_weight += (double)four[c].count * reach;
-      lane_chain += ((double)four[c].count + steps_per_wave + 16.0) * four[c].mag;
+      lane_chain += ((double)(four[c].adds & 0x7fffffffu) + steps_per_wave + 32.0) * four[c].mag;
       if (four[c].count) lane_reach = fmax(lane_reach, reach);
       entering += four[c].sum;
     }
@@ -4082,6 +4112,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   }
   unsigned *keys_a = nullptr, *keys_b = nullptr, *first = nullptr;
   double* mags = nullptr;  // (the sums of the magnitudes beside the parallel sums: the float32 certificate)
+  LazyRow* lazy_rows = nullptr;
   double *blk_sum = nullptr, *blk_pred = nullptr, *blk_abs = nullptr;  // (the block pipeline of the long labels)
   int* blk_gexp = nullptr;
   GroupExact* grp_exact = nullptr;
@@ -4197,6 +4228,64 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       GM_HIP(hipGetLastError());
       return GM_OK;
     };
+    // The float32 certificate over workgroup LDS tables (zonal_tables_lazy_kernel + zonal_tables_lazy_label_kernel): 1 = every label
+    // answered, 0 = not (a label failed, too many labels for a table), < 0 = -error.  GM_ZONAL_LAZY_TABLES=0: never (A/B runs, tests)
+    static const bool lazy_tables_allowed = !(getenv("GM_ZONAL_LAZY_TABLES") && atoi(getenv("GM_ZONAL_LAZY_TABLES")) == 0);
+    static const int lazy_mode = getenv("GM_ZONAL_LAZY") ? atoi(getenv("GM_ZONAL_LAZY")) : 1;
+    bool lazy_tried = false;
+    auto lazy_tables = [&]() -> int {
+      lazy_tried = true;
+      if (!lazy_mode || !lazy_tables_allowed || (size_t)n_labels * sizeof(LazyRow) > ZT_LDS_BYTES) return 0;
+      HostFlag* const flag = host_flag();
+      if (!flag) return 0;
+      // workgroups: as many as a table of 16 MB holds rows for (shorter ranges per workgroup: tighter bounds) -- up to 8192 of one
+      // wave for a few labels, up to 2048 of four waves, of sixteen when the rows of many labels limit their number
+      const int64_t fit = (int64_t)((16u << 20) / ((size_t)n_labels * sizeof(LazyRow)));
+      static const int forced_waves = getenv("GM_ZONAL_LAZY_WAVES") ? atoi(getenv("GM_ZONAL_LAZY_WAVES")) : 0;  // (1, 4, 16: A/B runs)
+      const int waves_per_group = forced_waves ? forced_waves : fit >= 8192 ? 1 : fit >= 1024 ? 4 : 16;
+      int64_t groups = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(fit, waves_per_group == 1 ? 8192 : 2048),
+                                                                (cells + 64 * waves_per_group - 1) / (64 * waves_per_group)));
+      const size_t lazy_cells_per_wave = (size_t)((cells + groups * waves_per_group - 1) / (groups * waves_per_group) + 63) / 64 * 64;
+      groups = (int64_t)(((size_t)cells + lazy_cells_per_wave * waves_per_group - 1) / (lazy_cells_per_wave * waves_per_group));
+      if (!lazy_rows) {
+        if (int rc2 = scratch.take((void**)&lazy_rows, sizeof(LazyRow) * (size_t)groups * n_labels)) return -rc2;
+      }
+      flag->word[5] = 0u;
+      const size_t lds = (size_t)n_labels * sizeof(LazyRow);
+#define GM_ZL(THREADS)                                                                                                              \
+  hipLaunchKernelGGL((zonal_tables_lazy_kernel<T, THREADS>), dim3((unsigned)groups), dim3(THREADS), lds, s, frame, labels, (size_t)cells, \
+                     lazy_cells_per_wave, n_labels, has_ndv, ndv, thresholds, lazy_rows, seen)
+      if (waves_per_group == 1) GM_ZL(64);
+      else if (waves_per_group == 4) GM_ZL(256);
+      else GM_ZL(1024);
+#undef GM_ZL
+      if (groups > 2048)
+        hipLaunchKernelGGL(zonal_tables_lazy_label_kernel<16>, dim3((unsigned)(((size_t)n_labels * 64 + 255) / 256)), dim3(256), 0, s, lazy_rows,
+                           (unsigned)groups, n_labels, (double)(lazy_cells_per_wave / 64), statistic, lazy_mode == 2 ? 1 : 0, out_f, counts_f,
+                           flag->word + 5);
+      else
+        hipLaunchKernelGGL(zonal_tables_lazy_label_kernel<4>, dim3((unsigned)(((size_t)n_labels * 64 + 255) / 256)), dim3(256), 0, s, lazy_rows,
+                           (unsigned)groups, n_labels, (double)(lazy_cells_per_wave / 64), statistic, lazy_mode == 2 ? 1 : 0, out_f, counts_f,
+                           flag->word + 5);
+      hipError_t e = hipGetLastError();
+      if (e == hipSuccess) e = hipEventRecord(flag->event, s);
+      if (e == hipSuccess) e = hipEventSynchronize(flag->event);
+      if (e != hipSuccess) return -gm::hip_fail(e, "zonal_tables_lazy_kernel");
+      if (((volatile unsigned*)flag->word)[5] != 0u) return 0;
+      gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_LDS_LAZY);
+      return 1;
+    };
+    // That route comes BEFORE the chunk records where a wave is a workgroup of its own (up to 85 labels: rows for 8192 stretches,
+    // bounds nearly as tight as the chunk records') -- its pass over the raster keeps a step of one label in registers and is half
+    // the chunk kernel's: one label of 12.6 M cells 126 -> 77 us a call.  A label that fails there takes the chunk records next.
+    // (GM_ZONAL_LAZY_FIRST=0: never first; =1: first for every label count -- A/B runs)
+    static const int lazy_first_mode = getenv("GM_ZONAL_LAZY_FIRST") ? atoi(getenv("GM_ZONAL_LAZY_FIRST")) : -1;
+    const bool lazy_first = lazy_first_mode < 0 ? (size_t)n_labels * sizeof(LazyRow) * 8192 <= (16u << 20) : lazy_first_mode != 0;
+    if (range && lazy_first) {
+      const int answered = lazy_tables();
+      if (answered < 0) return -answered;
+      if (answered) continue;
+    }
     // sums first try the route that sorts nothing (chunk records: zonal_chunk_kernel); GM_ZONAL_CHUNKS=0 switches it off and
     // GM_ZONAL_SORTED=1 skips it together with the other parallel sums (A/B runs, and the tests compare the routes)
     // (GM_ZONAL_CHUNKS=2: also the labels of ZL_LONG cells and more stay on this route however often they are replayed -- the tests do)
@@ -4294,39 +4383,11 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     // labels scattered cell by cell: the exactness certificates and, where every label passes, the sums -- through tables in
     // LDS (zonal_tables_exact_kernel; GM_ZONAL_TABLES_EXACT=0: never -- A/B runs, and the tests compare the two)
     // ... first the float32 certificate through the same kind of tables (zonal_tables_lazy_kernel: one pass, no sum in order; a label
-    // that fails sends the frame on.  GM_ZONAL_LAZY_TABLES=0: never -- A/B runs, and the tests compare)
-    static const bool lazy_tables_allowed = !(getenv("GM_ZONAL_LAZY_TABLES") && atoi(getenv("GM_ZONAL_LAZY_TABLES")) == 0);
-    if (range && chunk_not_runs && lazy_allowed && lazy_tables_allowed && (size_t)n_labels * sizeof(LazyRow) <= ZT_LDS_BYTES) {
-      HostFlag* const flag = host_flag();
-      if (flag) {
-        // workgroups: as many as a table of 16 MB holds rows for, 256 ... 2048 (shorter ranges per workgroup: tighter bounds)
-        const int64_t fit = (int64_t)((16u << 20) / ((size_t)n_labels * sizeof(LazyRow)));
-        const bool small = fit >= 1024;  // (workgroups of 4 waves; of 16 when the rows of many labels limit their number)
-        const int waves_per_group = small ? 4 : 16;
-        int64_t groups = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(fit, 2048), (cells + 64 * waves_per_group - 1) / (64 * waves_per_group)));
-        const size_t lazy_cells_per_wave = (size_t)((cells + groups * waves_per_group - 1) / (groups * waves_per_group) + 63) / 64 * 64;
-        groups = (int64_t)(((size_t)cells + lazy_cells_per_wave * waves_per_group - 1) / (lazy_cells_per_wave * waves_per_group));
-        LazyRow* rows = nullptr;
-        if ((rc = scratch.take((void**)&rows, sizeof(LazyRow) * (size_t)groups * n_labels))) return rc;
-        flag->word[5] = 0u;
-        const size_t lds = (size_t)n_labels * sizeof(LazyRow);
-        if (small)
-          hipLaunchKernelGGL((zonal_tables_lazy_kernel<T, 256>), dim3((unsigned)groups), dim3(256), lds, s, frame, labels, (size_t)cells,
-                             lazy_cells_per_wave, n_labels, has_ndv, ndv, thresholds, rows, seen);
-        else
-          hipLaunchKernelGGL((zonal_tables_lazy_kernel<T, 1024>), dim3((unsigned)groups), dim3(1024), lds, s, frame, labels, (size_t)cells,
-                             lazy_cells_per_wave, n_labels, has_ndv, ndv, thresholds, rows, seen);
-        hipLaunchKernelGGL(zonal_tables_lazy_label_kernel, dim3((unsigned)(((size_t)n_labels * 64 + 255) / 256)), dim3(256), 0, s, rows,
-                           (unsigned)groups, n_labels, (double)(lazy_cells_per_wave / 64), statistic, lazy_allowed == 2 ? 1 : 0, out_f, counts_f,
-                           flag->word + 5);
-        GM_HIP(hipGetLastError());
-        GM_HIP(hipEventRecord(flag->event, s));
-        GM_HIP(hipEventSynchronize(flag->event));
-        if (((volatile unsigned*)flag->word)[5] == 0u) {
-          gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_LDS_LAZY);
-          continue;
-        }
-      }
+    // that fails sends the frame on)
+    if (range && chunk_not_runs && !lazy_tried) {
+      const int answered = lazy_tables();
+      if (answered < 0) return -answered;
+      if (answered) continue;
     }
     static const bool tables_exact_allowed = !(getenv("GM_ZONAL_TABLES_EXACT") && atoi(getenv("GM_ZONAL_TABLES_EXACT")) == 0);
     if (range && chunk_not_runs && tables_exact_allowed && (size_t)n_labels * 16 <= ZT_LDS_BYTES) {

@@ -2441,7 +2441,8 @@ def test_zonal_float32_certificate(gpu, lazy):
     took = routes_of(noise.stdout)["zonal"]
     if lazy == "1":   # noise under long labels used to send the frame to the sorting route (`hard`): nothing does now
         # (a sum may land within the bound of a float32 tie -- a few per cent of the labels of millions of cells: those frames go on)
-        assert took["chunk_answered"] >= 22 and took["chunk_gave_up"] <= 2, took
+        # (up to 85 labels the certificate first runs over per-wave tables, zonal_tables_lazy_kernel: "lds_lazy")
+        assert took["chunk_answered"] + took["lds_lazy"] >= 22 and took["ordered_sums"] <= 2, took
     else:
         assert took["ordered_sums"] > 0, took
 

@@ -28,7 +28,7 @@ def test_zonal_stress_driver(gpu):
     assert "done 120 failures 0" in out, out[-2000:]
     took = routes_of(out)["zonal"]
     # the campaign reaches every family of routes (a threshold that moves would show here)
-    for route in ("direct", "lds_tables", "lds_lazy", "exact_lazy_labels", "chunk_answered", "chunk_gave_up", "sort_partition", "sort_radix", "select",
+    for route in ("direct", "lds_tables", "lds_lazy", "chunk_answered", "chunk_gave_up", "sort_partition", "sort_radix", "select",
                   "segment_sort", "ordered_sums"):
         assert took[route] > 0, (route, took)
 

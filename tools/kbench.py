@@ -242,12 +242,13 @@ def main():
         for name, labels, n_labels in (("1024 labels", blocks, 1024), ("1 label", one, 1)):
             dev_labels = DeviceArray.from_numpy(labels)
             for stat, q in (("sum", None), ("mean", None), ("count", None), ("max", None), ("median", None), ("percentile", 95.0)):
-                geometry.label_statistics(dev_values, np.float32(-9999.0), dev_labels, n_labels, stat, q)
+                for _ in range(3):  # (a route's scratch buffers are sized by its first call's verdict and taken by its second)
+                    geometry.label_statistics(dev_values, np.float32(-9999.0), dev_labels, n_labels, stat, q)
                 runtime.sync()
                 t0 = time.perf_counter()
-                for _ in range(3):
+                for _ in range(5):
                     geometry.label_statistics(dev_values, np.float32(-9999.0), dev_labels, n_labels, stat, q)
-                us = (time.perf_counter() - t0) / 3 * 1e6
+                us = (time.perf_counter() - t0) / 5 * 1e6
                 print("zonal %-10s f32 %d x %d, %-12s %9.1f us  %7.1f GB/s" % (stat + ("" if q is None else str(q)), h, w, name, us, 8.0 * h * w / us / 1e3), flush=True)
         # the rasters above are zero-mean noise: a sum that wanders through the binades and changes sign is the worst case of
         # the in-order float sums.  An elevation-like raster (all cells positive: the sum only grows) for comparison:
@@ -256,22 +257,24 @@ def main():
         dev_positive = DeviceArray.from_numpy(positive)
         for name, labels, n_labels in (("1024 labels", blocks, 1024), ("1 label", one, 1)):
             dev_labels = DeviceArray.from_numpy(labels)
-            geometry.label_statistics(dev_positive, np.float32(-9999.0), dev_labels, n_labels, "sum", None)
-            runtime.sync()
-            t0 = time.perf_counter()
             for _ in range(3):
                 geometry.label_statistics(dev_positive, np.float32(-9999.0), dev_labels, n_labels, "sum", None)
-            us = (time.perf_counter() - t0) / 3 * 1e6
+            runtime.sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                geometry.label_statistics(dev_positive, np.float32(-9999.0), dev_labels, n_labels, "sum", None)
+            us = (time.perf_counter() - t0) / 5 * 1e6
             print("zonal %-10s f32 %d x %d, %-12s %9.1f us  %7.1f GB/s  (positive cells)" % ("sum", h, w, name, us, 8.0 * h * w / us / 1e3), flush=True)
         ints = DeviceArray.from_numpy(np.round(values).astype("i4"))  # an integer raster: sums need no order, hence no sort
         for name, labels, n_labels in (("1024 labels", blocks, 1024), ("1 label", one, 1)):
             dev_labels = DeviceArray.from_numpy(labels)
-            geometry.label_statistics(ints, -9999, dev_labels, n_labels, "sum")
-            runtime.sync()
-            t0 = time.perf_counter()
             for _ in range(3):
                 geometry.label_statistics(ints, -9999, dev_labels, n_labels, "sum")
-            us = (time.perf_counter() - t0) / 3 * 1e6
+            runtime.sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                geometry.label_statistics(ints, -9999, dev_labels, n_labels, "sum")
+            us = (time.perf_counter() - t0) / 5 * 1e6
             print("zonal %-10s i32 %d x %d, %-12s %9.1f us  %7.1f GB/s" % ("sum", h, w, name, us, 8.0 * h * w / us / 1e3), flush=True)
         if opts.get("cpu", "1") == "1":
             from scipy import ndimage
