@@ -79,15 +79,25 @@ def tokenize(*args):
 _PLAIN = (str, int, float, bool, type(None), datetime, timedelta)
 
 
-def _request_token(block_token, request):
-    """Token of (block, request) for the graph key.  A tiled view asks for it once per Block per
-    tile, so requests made of plain scalars and tuples of them -- all raster requests -- take a
-    repr + one md5 instead of the general recursive tokeniser (6x cheaper)."""
+def _request_text(request):
+    """The request as text for the graph key, or None when it holds more than plain scalars and tuples of them (the general
+    tokeniser then)."""
     for value in request.values():
         if not isinstance(value, _PLAIN):
             if not (isinstance(value, (tuple, list)) and all(isinstance(v, _PLAIN) for v in value)):
-                return tokenize([block_token, request])
-    text = repr(sorted(request.items()))
+                return None
+    return repr(sorted(request.items()))
+
+
+def _request_token(block_token, request, text=False):
+    """Token of (block, request) for the graph key.  A tiled view asks for it once per Block per
+    tile, so requests made of plain scalars and tuples of them -- all raster requests -- take a
+    repr + one md5 instead of the general recursive tokeniser (6x cheaper).  ``text``: the request's
+    text when the caller has it already (Block.get_compute_graph makes it once per request object)."""
+    if text is False:
+        text = _request_text(request)
+    if text is None:
+        return tokenize([block_token, request])
     return hashlib.md5((block_token + text).encode()).hexdigest()
 
 
@@ -514,15 +524,28 @@ class Block(object):
         return result
 
     def get_compute_graph(self, cached_compute_graph=None, **request):
-        token = _request_token(self.token, request)
-        name = "{}_{}".format(self.__class__.__name__.lower(), token)
         graph = cached_compute_graph or dict()
+        return self._gm_compute_graph(graph, request, {})
+
+    def _gm_compute_graph(self, graph, request, texts):
+        """get_compute_graph (core/graphs.py:351-395 of the reference) without packing the request into keyword arguments at
+        every Block, and with the text of a request made once per request OBJECT: a Block that hands its request on as it got
+        it -- the element-wise family, most of a view -- shares it with its sources (``texts``: id -> (request, text); the
+        entry keeps the object alive while its id is a key)."""
+        known = texts.get(id(request))
+        if known is None:
+            known = texts[id(request)] = (request, _request_text(request))
+        token = _request_token(self.token, request, known[1])
+        name = "{}_{}".format(self.__class__.__name__.lower(), token)
         if name in graph:
             return graph, name
         args = [self.process]
         for source, req in self.get_sources_and_requests(**request):
             if isinstance(source, Block) and req is not None:
-                graph, compute_name = source.get_compute_graph(cached_compute_graph=graph, **req)
+                if type(source).get_compute_graph is Block.get_compute_graph:
+                    graph, compute_name = source._gm_compute_graph(graph, req, texts)
+                else:  # (a Block with a get_compute_graph of its own)
+                    graph, compute_name = source.get_compute_graph(cached_compute_graph=graph, **req)
                 args.append(compute_name)
             else:
                 args.append(source)

@@ -29,7 +29,7 @@ def test_zonal_stress_driver(gpu):
     took = routes_of(out)["zonal"]
     # the campaign reaches every family of routes (a threshold that moves would show here)
     for route in ("direct", "lds_tables", "lds_lazy", "chunk_answered", "chunk_gave_up", "sort_partition", "sort_radix", "select",
-                  "segment_sort", "ordered_sums"):
+                  "segment_sort"):   # (sums in bincount's order: "ordered_sums" in the test below -- the certificate answers most here)
         assert took[route] > 0, (route, took)
 
 
@@ -42,7 +42,7 @@ def test_zonal_stress_driver_on_the_older_routes(gpu):
     assert "done 120 failures 0" in out, out[-2000:]
     took = routes_of(out)["zonal"]
     assert took["lds_tables"] == 0 and took["segment_sort"] == 0 and took["direct"] > 0 and took["lexsort"] > 0, took
-    assert took["lds_lazy"] == 0 and took["exact_lazy_labels"] == 0 and took["lds_exact"] > 0, took
+    assert took["lds_lazy"] == 0 and took["exact_lazy_labels"] == 0 and took["lds_exact"] > 0 and took["ordered_sums"] > 0, took
 
 
 @pytest.mark.timeout(900)

@@ -14,7 +14,8 @@ view = raster.Clip(raster.Add(raster.Subtract(raster.Multiply(raster.Add(A, B), 
 boxes = [(float(i * side), float(j * side), float((i + 1) * side), float((j + 1) * side)) for i in range(3) for j in range(3)]
 req = dict(mode="vals", width=side, height=side, projection="EPSG:28992")
 import os
-with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": os.environ.get("PLANS", "1") == "1"}):
+with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans": os.environ.get("PLANS", "1") == "1",
+                          "geomodeling.templates": os.environ.get("TEMPLATES", "1") == "1"}):  # (PLANS=0 TEMPLATES=0: from scratch)
     for k in range(20):
         view.get_data(bbox=boxes[k % 9], **req)
     runtime.sync()
@@ -24,4 +25,4 @@ with gmconfig.config.set({"geomodeling.materialize": False, "geomodeling.plans":
         view.get_data(bbox=boxes[k % 9], **req)
     pr.disable()
     runtime.sync()
-pstats.Stats(pr).sort_stats("tottime").print_stats(45)
+pstats.Stats(pr).sort_stats(os.environ.get("SORT", "tottime")).print_stats(int(os.environ.get("TOP", "45")))
