@@ -142,7 +142,7 @@ def _pin_to_device_cores(runtime, index, pool_devices):
             return None
         os.sched_setaffinity(0, mine)
         return mine
-    except (OSError, AttributeError, ValueError, KeyError):  # placement is an optimisation: never a reason not to start
+    except Exception:  # placement is an optimisation: never a reason not to start (whatever the topology files hold)
         return None
 
 
