@@ -631,6 +631,14 @@ def shutdown():
         _pools.clear()
     for pool in pools:
         pool.close()
+    # the result segments kept for the next request: nobody has them mapped any more
+    global _result_free_bytes
+    with _result_lock:
+        kept = [seg for segs in _result_free.values() for seg in segs]
+        _result_free.clear()
+        _result_free_bytes = 0
+    for seg in kept:
+        seg.unlink()
 
 
 atexit.register(shutdown)
