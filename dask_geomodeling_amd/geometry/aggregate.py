@@ -14,6 +14,7 @@ part of this path); step (3) is the tile arithmetic and runs on the device here:
   cells.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -48,9 +49,14 @@ def _lib():
         L.gm_zonal_statistic.argtypes = [c.c_void_p, c.c_int, c.c_int64, c.c_int64, c.c_int, c.c_uint64, c.c_void_p, c.c_int32,
                                          c.c_void_p, c.c_int, c.c_double, c.c_void_p, c.c_void_p, c.c_void_p]
         L.gm_zonal_statistic.restype = c.c_int
+        L.gm_zonal_statistic_host.argtypes = list(L.gm_zonal_statistic.argtypes)
+        L.gm_zonal_statistic_host.restype = c.c_int
         _declared = True
     return L
 
+
+# (GM_ZONAL_HOST=0: results into a device buffer and one copy back by the caller, as before round 6 -- A/B runs, and the tests run both)
+_RESULTS_TO_HOST = os.environ.get("GM_ZONAL_HOST", "1") != "0"
 
 _NDV_CACHE = {}  # (dtype, type of the no-data value, its bytes) -> (has_ndv, bits): ~15 us of NumPy scalar work per call otherwise
 
@@ -113,8 +119,20 @@ def label_statistics(values, no_data_value, labels, n_labels, statistic, percent
             raise TypeError("thresholds must be float32 (aggregate.py:532 casts the column with astype('f4'))")
         thresholds = DeviceArray.from_numpy(thresholds)
     has_ndv, ndv_bits = _ndv_for(tile.dtype, no_data_value)
-    # one device buffer for the three results (counts first: 8-byte aligned), one copy back
     cells = frames * n_labels
+    if _RESULTS_TO_HOST:
+        # the three results straight into host arrays: the library queues their copy behind the kernels of the route it takes,
+        # ahead of that route's verdict -- one wait per call (gm_zonal_statistic_host)
+        counts = np.empty((frames, n_labels), dtype="i8")
+        out = np.empty((frames, n_labels), dtype="f4")
+        present = np.empty((n_labels,), dtype="u1")
+        runtime.check(_lib().gm_zonal_statistic_host(tile.ptr, code_of(tile.dtype), frames, height * width, int(has_ndv), ndv_bits,
+                                                     label_tile.ptr, n_labels, thresholds.ptr if thresholds is not None else None,
+                                                     STATISTICS[statistic], float(percentile or 0.0), out.ctypes.data, counts.ctypes.data,
+                                                     present.ctypes.data),
+                      "gm_zonal_statistic_host")
+        return out, counts, present.astype(bool)
+    # one device buffer for the three results (counts first: 8-byte aligned), one copy back
     packed = DeviceArray.empty((cells * 12 + n_labels,), "u1")
     counts_ptr, out_ptr, present_ptr = packed.ptr, packed.ptr + 8 * cells, packed.ptr + 12 * cells
     runtime.check(_lib().gm_zonal_statistic(tile.ptr, code_of(tile.dtype), frames, height * width, int(has_ndv), ndv_bits,

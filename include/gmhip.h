@@ -717,6 +717,15 @@ int gm_zonal_statistic(const void* values, int dtype, int64_t frames, int64_t ce
                        const int32_t* labels, int32_t n_labels, const float* thresholds, int statistic, double percentile,
                        float* out, int64_t* counts, uint8_t* present);
 
+/* The same with the three results in HOST memory (what aggregate_polygons needs them for: `agg[...] = ...` is NumPy on the host):
+ * out_host frames x n_labels float32, counts_host frames x n_labels int64, present_host n_labels bytes or NULL.  One wait of the
+ * host per call where gm_zonal_statistic + a copy are two: the copy is queued behind the kernels of a route before that route's
+ * verdict is waited for, and trusted only when the verdict says the route answered. */
+int gm_zonal_statistic_host(const void* values, int dtype, int64_t frames, int64_t cells, int has_ndv, uint64_t ndv_bits,
+                            const int32_t* labels, int32_t n_labels, const float* thresholds, int statistic, double percentile,
+                            float* out_host, int64_t* counts_host, uint8_t* present_host);
+
+
 /* Cumulative.process, vals branch (temporal.py:957-1003): running sum / count inside every bin;
  * source frame j goes to output frame j - emit_first for emit_first <= j < emit_stop.
  * statistic: GM_STAT_SUM or GM_STAT_COUNT. */

@@ -37,8 +37,10 @@ def test_zonal_stress_driver(gpu):
 def test_zonal_stress_driver_on_the_older_routes(gpu):
     """The same campaign (shorter) with the round-6 routes switched off: count / min / max through the wave-slot kernel instead of
     the workgroup tables, medians under many labels through the two sorts instead of the segment sort, every sum in bincount's
-    order or certified exact (no float32 certificate: the scattered labels' sums through zonal_tables_exact_kernel)."""
-    out = _run("zonal_stress.py", [120, 4711], env={"GM_ZONAL_TABLES": "0", "GM_ZONAL_SEGSORT": "0", "GM_ZONAL_LAZY": "0"})
+    order or certified exact (no float32 certificate: the scattered labels' sums through zonal_tables_exact_kernel), the results
+    into a device buffer and copied back by the caller (gm_zonal_statistic instead of gm_zonal_statistic_host)."""
+    out = _run("zonal_stress.py", [120, 4711], env={"GM_ZONAL_TABLES": "0", "GM_ZONAL_SEGSORT": "0", "GM_ZONAL_LAZY": "0",
+                                                    "GM_ZONAL_HOST": "0"})
     assert "done 120 failures 0" in out, out[-2000:]
     took = routes_of(out)["zonal"]
     assert took["lds_tables"] == 0 and took["segment_sort"] == 0 and took["direct"] > 0 and took["lexsort"] > 0, took
