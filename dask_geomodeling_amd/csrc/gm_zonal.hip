@@ -4318,7 +4318,10 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     // the chunk kernel's: one label of 12.6 M cells 126 -> 77 us a call.  A label that fails there takes the chunk records next.
     // (GM_ZONAL_LAZY_FIRST=0: never first; =1: first for every label count -- A/B runs)
     static const int lazy_first_mode = getenv("GM_ZONAL_LAZY_FIRST") ? atoi(getenv("GM_ZONAL_LAZY_FIRST")) : -1;
-    const bool lazy_first = lazy_first_mode < 0 ? (size_t)n_labels * sizeof(LazyRow) * 8192 <= (16u << 20) : lazy_first_mode != 0;
+    // (... and where the chunk records' first attempt overflowed last time -- more labels to a stretch than records: stripes, small
+    //  parcels -- and the tables answered instead: remembered with the label raster's address, hint 3)
+    const int label_hint = chunk_hint_get(labels, n_labels, cells);
+    const bool lazy_first = lazy_first_mode < 0 ? ((size_t)n_labels * sizeof(LazyRow) * 8192 <= (16u << 20) || label_hint == 3) : lazy_first_mode != 0;
     if (range && lazy_first) {
       const int answered = lazy_tables();
       if (answered < 0) return -answered;
@@ -4340,12 +4343,12 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       // stretches of at least `stretch()` cells, whole steps, at most 64 steps each (more, shorter stretches for large rasters).
       // A second attempt in stretches a quarter as long when the first one only found stretches with more labels than records
       // (small polygons, vertical stripes: runs all the same) and the table of the shorter stretches still fits.
-      bool answered = false;
+      bool answered = false, by_tables = false;
       // (a label raster whose first attempt overflowed is remembered -- by address, label count and size: a hint, never more --
       //  and starts with the shorter stretches next time: the other statistics of the same polygons, the next frames)
       // (... and a raster whose SUMS gave the pass up -- a long label that keeps rounding: hard -- is remembered with its cells'
       //  address: the mean after the sum, the next request for the same tile, go to the sorting route at once)
-      const int first_attempt = std::max(chunk_hint_get(labels, n_labels, cells), chunk_hint_get(frame, n_labels, cells));
+      const int first_attempt = std::max(label_hint == 3 ? 1 : label_hint, chunk_hint_get(frame, n_labels, cells));
       if (first_attempt >= 2) chunk_gave_up_hard = true;
       for (int attempt = first_attempt; attempt < 2 && !answered; ++attempt) {
         const int64_t shortest = attempt == 0 ? stretch() : std::max<int64_t>(ZC_STEP, stretch() / 4);
@@ -4414,9 +4417,21 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         chunk_gave_up_hard = chunk_verdict.hard != 0 || n_labels + 1 <= ZP_BINS;
         chunk_not_runs = chunk_verdict.not_runs != 0 && chunk_verdict.hard == 0;
         if (chunk_verdict.hard) chunk_hint_set(frame, n_labels, cells, 2);
+        if (attempt == 0 && chunk_verdict.overflow && !chunk_verdict.hard && !chunk_verdict.not_runs && !lazy_tried) {
+          // more labels to a stretch than records (vertical stripes 25 cells wide, small parcels): before the shorter stretches --
+          // four times the records, a pass of 145-200 us -- the tables of zonal_tables_lazy_kernel, whose pass does not care
+          // (stripes under 164 labels 291 -> 150 us a call); what answered is remembered
+          const int tables = lazy_tables();
+          if (tables < 0) return -tables;
+          if (tables) {
+            chunk_hint_set(labels, n_labels, cells, 3);
+            answered = by_tables = true;
+            break;
+          }
+        }
         if (chunk_verdict.hard || chunk_verdict.not_runs || chunk_cells <= (size_t)ZC_STEP) break;  // (shorter stretches would not help)
       }
-      gm::route_hit(GM_ROUTE_ZONAL, answered ? GM_RZ_CHUNK_ANSWERED : GM_RZ_CHUNK_GAVE_UP);
+      gm::route_hit(GM_ROUTE_ZONAL, answered && !by_tables ? GM_RZ_CHUNK_ANSWERED : GM_RZ_CHUNK_GAVE_UP);
       if (answered) continue;
     }
     unsigned longest = ~0u;  // (cells of the longest label, where a verdict has counted them)
