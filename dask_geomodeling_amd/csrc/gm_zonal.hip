@@ -1901,7 +1901,8 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
   int run_label = -1;  // the run the wave is in (wave-uniform); per lane what it has gathered for it
   unsigned run_count = 0, run_bad = 0;
   int run_hi = INT_MIN, run_lo = INT_MAX;
-  double run_sum = 0.0, run_mag = 0.0;  // (PHASE 2 = PHASE 1 + the sums of the magnitudes: the float32 certificate of the caller)
+  double run_sum = 0.0, run_mag = 0.0;  // (PHASE 2 = PHASE 1 + the sums of the magnitudes: the float32 certificate of the caller;
+                                         //  PHASE 3 = PHASE 2 + the labels' counts and `present`: the one pass of a raster of small labels)
   auto tile_flush = [&]() {  // (wave-uniform call; a run that crosses a tile border keeps gathering for its label's range)
     if (run_label < 0) return;
     const unsigned n = wave_sum_u32(tile_n);
@@ -1924,10 +1925,14 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
     } else {
       const double total = wave_sum_exact(run_sum);  // (exact: see above)
       if (lane == 0) atomicAdd(&sums[run_label], total);
-      if constexpr (PHASE == 2) {
+      if constexpr (PHASE >= 2) {
         const double mag = wave_sum_exact(run_mag);
         if (lane == 0) atomicAdd(&mags[run_label], mag);
         run_mag = 0.0;
+      }
+      if constexpr (PHASE == 3) {  // (bits 40 and up of the count: how many additions the label's sum has taken -- its error bound)
+        const unsigned n = wave_sum_u32(run_count);
+        if (lane == 0 && n != 0) atomicAdd(&range[run_label].count, (1ull << 40) | (unsigned long long)n);
       }
     }
     run_label = -1;
@@ -1938,7 +1943,7 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
   };
   walk_cells<T>(values, labels, begin, end, lane, [&](T v, int label, bool inside, size_t i) {
     const bool labelled = (unsigned)label < (unsigned)n_labels;
-    if constexpr (PHASE == 0) mark_present(present, label, labelled, &marked);
+    if constexpr (PHASE == 0 || PHASE == 3) mark_present(present, label, labelled, &marked);
     bool active = labelled && !(has_ndv && v == ndv);
     if (thresholds && active) {
       const float t = thresholds[label];
@@ -1985,7 +1990,8 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
           }
         } else {
           run_sum += x;
-          if constexpr (PHASE == 2) run_mag += fabs(x);
+          if constexpr (PHASE >= 2) run_mag += fabs(x);
+          if constexpr (PHASE == 3) run_count += 1;
         }
       }
     } else {  // (a step across label boundaries: run by run)
@@ -2014,9 +2020,13 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
       } else {
         const double total = run_total(active ? x : 0.0, runs, [](double a, double b) { return a + b; });  // (exact: see above)
         if (runs.last && labelled && total != 0.0) atomicAdd(&sums[label], total);
-        if constexpr (PHASE == 2) {
+        if constexpr (PHASE >= 2) {
           const double mag = run_total(active ? fabs(x) : 0.0, runs, [](double a, double b) { return a + b; });
           if (runs.last && labelled && mag != 0.0) atomicAdd(&mags[label], mag);
+        }
+        if constexpr (PHASE == 3) {
+          const unsigned n = run_total(active ? 1u : 0u, runs, [](unsigned a, unsigned b) { return a + b; });
+          if (runs.last && labelled && n != 0) atomicAdd(&range[label].count, (1ull << 40) | (unsigned long long)n);
         }
       }
     }
@@ -2043,11 +2053,14 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
     } else {
       const double total = wave_sum_exact(run_sum);  // (exact: see above)
       double mag = 0.0;
-      if constexpr (PHASE == 2) mag = wave_sum_exact(run_mag);
+      if constexpr (PHASE >= 2) mag = wave_sum_exact(run_mag);
+      unsigned n = 0;
+      if constexpr (PHASE == 3) n = wave_sum_u32(run_count);
       if (lane == 0) {
         end_label[w] = run_label;
         end_sum[w] = total;
         end_mag[w] = mag;
+        end_count[w] = n;
       }
     }
   }
@@ -2076,15 +2089,20 @@ __global__ __launch_bounds__(256) void zonal_exact_kernel(const T* __restrict__ 
         if (bad) atomicOr(&slot->bad, 1u);
       } else {
         double total = end_sum[w], mag = end_mag[w];
+        unsigned long long n = end_count[w];
         for (int v = w + 1; v < 4; ++v) {
           if (end_label[v] == label) {
             total += end_sum[v];  // (exact like every addition of this pass)
             mag += end_mag[v];
+            n += end_count[v];
             end_label[v] = -1;
           }
         }
         atomicAdd(&sums[label], total);
-        if constexpr (PHASE == 2) atomicAdd(&mags[label], mag);
+        if constexpr (PHASE >= 2) atomicAdd(&mags[label], mag);
+        if constexpr (PHASE == 3) {
+          if (n != 0) atomicAdd(&range[label].count, (1ull << 40) | n);
+        }
       }
     }
   }
@@ -2377,15 +2395,22 @@ __global__ __launch_bounds__(256) void zonal_exact_decide_kernel(const ExactRang
 // counted again over those that keep it.
 __global__ __launch_bounds__(256) void zonal_exact_lazy_decide_kernel(const ExactRange* __restrict__ range, const double* __restrict__ sums,
                                                                       const double* __restrict__ mags, int n_labels, int statistic,
-                                                                      unsigned char* __restrict__ inexact, ExactVerdict* __restrict__ verdict) {
+                                                                      unsigned char* __restrict__ inexact, ExactVerdict* __restrict__ verdict,
+                                                                      int packed_counts = 0, double steps_per_wave = 0.0) {
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= n_labels || !inexact[l]) return;
   const ExactRange r = range[l];
-  const double S = sums[l], mag = mags[l], n = (double)r.count;
+  // (after PHASE 3 the count carries the number of additions onto the label's sum in its bits 40 and up: one per run.  With
+  //  them the sum's own error is u (additions + steps of a wave's stretch + 16) mag instead of u (2 count + 16) mag -- a lane's
+  //  chain over a run adds at most one result per step, the reduction across a wave six levels, every atomic one result --,
+  //  which for polygons whose rows are a step or two is a hundred times less)
+  const unsigned long long cells = packed_counts ? r.count & ((1ull << 40) - 1) : r.count;
+  const double S = sums[l], mag = mags[l], n = (double)cells;
+  const double additions = packed_counts ? (double)(r.count >> 40) + steps_per_wave : 2.0 * n;
   bool pass = false;
-  if (!r.bad && r.count != 0 && mag < 1.0e300) {  // (false for NaN)
+  if (!r.bad && cells != 0 && mag < 1.0e300) {  // (false for NaN)
     constexpr double u = 1.1102230246251565e-16;
-    const double tau = 1.5 * u * (2.0 * n + 16.0) * mag;
+    const double tau = 1.5 * u * (additions + 16.0) * mag;
     const double E = 1.01 * u * (n * mag + 4.0 * mag + (2.0 * n + 4.0) * tau) + tau + (mag > 0.0 ? 1.0e-300 : 0.0);
     double below = S - E, above = S + E;
     if (statistic == Z_MEAN) {
@@ -2395,11 +2420,12 @@ __global__ __launch_bounds__(256) void zonal_exact_lazy_decide_kernel(const Exac
     const float lowest = (float)below, highest = (float)above;
     pass = __float_as_uint(lowest) == __float_as_uint(highest) && fabsf(lowest) < __builtin_huge_valf();
   }
-  if (pass) {
+  if (pass || cells == 0) {  // (a label without an active cell: NaN, whatever is asked)
     inexact[l] = 0;
   } else {
-    atomicAdd(&verdict->labels, 1u);
-    atomicAdd(&verdict->cells, r.count);
+    const unsigned slot = atomicAdd(&verdict->labels, 1u);
+    atomicAdd(&verdict->cells, cells);
+    if (packed_counts) inexact[l] = (unsigned char)(min(slot, 254u) + 1u);  // (its slot among the labels zonal_few_* add in order)
   }
 }
 
@@ -3046,10 +3072,10 @@ struct PartitionBuffers {
 
 __global__ __launch_bounds__(256) void zonal_exact_result_kernel(const ExactRange* __restrict__ range, const double* __restrict__ sums,
                                                                  int n_labels, int statistic, float* __restrict__ out,
-                                                                 long long* __restrict__ counts) {
+                                                                 long long* __restrict__ counts, int packed_counts = 0) {
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= n_labels) return;
-  const unsigned long long n = range[l].count;
+  const unsigned long long n = packed_counts ? range[l].count & ((1ull << 40) - 1) : range[l].count;  // (PHASE 3 of zonal_exact_kernel)
   counts[l] = (long long)n;
   const double total = sums[l];
   out[l] = n == 0 ? std::numeric_limits<float>::quiet_NaN() : (statistic == Z_MEAN ? (float)(total / (double)n) : (float)total);
@@ -3205,6 +3231,107 @@ __device__ __forceinline__ double chain_add_parked(const double* mine, double ac
   return acc;
 }
 
+// The few labels of a raster of thousands of small ones that the float32 certificate of the parallel sums turns away (a sum that
+// cancels to nothing, a sum within 10^-9 of a float32 tie: a handful of 6 144 or 49 152 polygons per call) -- added in bincount's
+// order without a sort of the raster: zonal_exact_lazy_decide_kernel has given each a slot (up to ZF_SLOTS); their active cells
+// are gathered from the raster itself as (cell index, float64 value) into their slot's list (up to ZF_CAP cells each); a
+// workgroup per slot sorts its list by cell index in LDS (a bitonic network) and one lane adds it, one cell after the other.
+// Both kernels leave at once when the verdict counted no label (they are queued before the host knows); more labels than slots
+// or a label longer than a list raise `failed_host`, and the frame goes on to the routes that sort.
+constexpr unsigned ZF_CAP = 4096, ZF_SLOTS = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void zonal_few_gather_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
+                                                               int n_labels, int has_ndv, T ndv, const float* __restrict__ thresholds,
+                                                               const unsigned char* __restrict__ inexact,
+                                                               const ExactVerdict* __restrict__ verdict,
+                                                               unsigned* __restrict__ list_index, double* __restrict__ list_values,
+                                                               int* __restrict__ slot_label, unsigned* __restrict__ slot_cursor) {
+  if (verdict->labels == 0 || verdict->labels > ZF_SLOTS) return;  // (wave-uniform: nothing to add in order / too many)
+  const int lane = threadIdx.x & 63;
+  const size_t stride = (size_t)gridDim.x * 256, rounded = (cells + 63) & ~(size_t)63;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < rounded; i += stride) {  // (whole waves enter every step)
+    const int label = i < cells ? labels[i] : -1;
+    unsigned slot = 0;
+    T v = T(0);
+    if ((unsigned)label < (unsigned)n_labels) slot = inexact[label];
+    if (slot > ZF_SLOTS) slot = 0;
+    if (slot) {
+      v = values[i];
+      if (!cell_active<T>(v, label, n_labels, has_ndv, ndv, thresholds)) slot = 0;
+    }
+    // one atomic per wave and slot (a row of a polygon is 16-64 lanes of one label: a lane each on one counter took 174 us
+    // for forty labels of 1 800 cells)
+    unsigned long long open = __ballot(slot != 0);
+    while (open) {  // (wave-uniform)
+      const unsigned leader = (unsigned)__builtin_amdgcn_readlane((int)slot, __ffsll((long long)open) - 1);
+      const unsigned long long peers = __ballot(slot == leader);
+      unsigned base = 0;
+      if (lane == __ffsll((long long)peers) - 1) base = atomicAdd(&slot_cursor[leader - 1], (unsigned)__popcll(peers));
+      base = (unsigned)__builtin_amdgcn_readlane((int)base, __ffsll((long long)peers) - 1);
+      if (slot == leader) {
+        const unsigned at = base + (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+        if (at == 0) slot_label[slot - 1] = label;
+        if (at < ZF_CAP) {
+          list_index[(slot - 1) * ZF_CAP + at] = (unsigned)i;  // (fewer than 2^31 cells)
+          list_values[(slot - 1) * ZF_CAP + at] = (double)v;   // what bincount adds
+        }
+      }
+      open &= ~peers;
+    }
+  }
+}
+__global__ __launch_bounds__(1024) void zonal_few_ordered_kernel(const unsigned* __restrict__ list_index, const double* __restrict__ list_values,
+                                                                 const int* __restrict__ slot_label, const unsigned* __restrict__ slot_cursor,
+                                                                 const ExactVerdict* __restrict__ verdict, int statistic,
+                                                                 float* __restrict__ out, long long* __restrict__ counts,
+                                                                 unsigned* __restrict__ failed_host) {
+  __shared__ unsigned key[ZF_CAP];
+  __shared__ double val[ZF_CAP];
+  const unsigned n_failed = verdict->labels, slot = blockIdx.x;
+  if (n_failed == 0) return;
+  if (n_failed > ZF_SLOTS) {
+    if (slot == 0 && threadIdx.x == 0) *failed_host = 1u;
+    return;
+  }
+  if (slot >= n_failed) return;
+  const unsigned m = slot_cursor[slot];
+  if (m > ZF_CAP || m == 0) {  // (m == 0 cannot be: a label that failed has active cells)
+    if (threadIdx.x == 0) *failed_host = 1u;
+    return;
+  }
+  unsigned P = 64;
+  while (P < m) P <<= 1;
+  for (unsigned i = threadIdx.x; i < P; i += 1024) {
+    key[i] = i < m ? list_index[slot * ZF_CAP + i] : ~0u;
+    val[i] = i < m ? list_values[slot * ZF_CAP + i] : 0.0;
+  }
+  __syncthreads();
+  for (unsigned size = 2; size <= P; size <<= 1) {
+    for (unsigned gap = size >> 1; gap > 0; gap >>= 1) {
+      for (unsigned t = threadIdx.x; t < P / 2; t += 1024) {
+        const unsigned lo = (t / gap) * 2 * gap + t % gap, hi = lo + gap;
+        const bool up = (lo & size) == 0;
+        const unsigned a = key[lo], b = key[hi];
+        if ((a > b) == up) {
+          key[lo] = b;
+          key[hi] = a;
+          const double x = val[lo];
+          val[lo] = val[hi];
+          val[hi] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) {
+    double acc = 0.0;
+    for (unsigned j = 0; j < m; ++j) acc += val[j];  // np.bincount: one cell after the other, in raster order
+    const int label = slot_label[slot];
+    counts[label] = (long long)m;
+    out[label] = statistic == Z_MEAN ? (float)(acc / (double)m) : (float)acc;
+  }
+}
+
 // gm_zonal_statistic_host: the results on their way to the host BEFORE the one wait of a route that has a verdict to wait for.
 // The routes of the sums end in "kernels queued -> wait for the verdict word -> (the caller copies the results: a second wait)";
 // with the copy queued behind the kernels the verdict's wait covers it (one wake-up of the host per call instead of two: ~20 us
@@ -3216,7 +3343,7 @@ struct HostCopy {
   bool queued = false, valid = false;
 };
 static thread_local HostCopy* t_host_copy = nullptr;
-constexpr size_t kHostCopyBytes = 256u << 10;
+constexpr size_t kHostCopyBytes = 1u << 20;  // (49 152 labels: 639 KB)
 static void* host_copy_staging() {
   static thread_local void* buffer = nullptr;
   if (!buffer && hipHostMalloc(&buffer, kHostCopyBytes, hipHostMallocPortable) != hipSuccess) {
@@ -4148,6 +4275,9 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   unsigned *keys_a = nullptr, *keys_b = nullptr, *first = nullptr;
   double* mags = nullptr;  // (the sums of the magnitudes beside the parallel sums: the float32 certificate)
   LazyRow* lazy_rows = nullptr;
+  unsigned* few_index = nullptr;  // (the labels the parallel sums' certificate turns away, added in order: zonal_few_*)
+  double* few_values = nullptr;
+  unsigned* few_slots = nullptr;
   double *blk_sum = nullptr, *blk_pred = nullptr, *blk_abs = nullptr;  // (the block pipeline of the long labels)
   int* blk_gexp = nullptr;
   GroupExact* grp_exact = nullptr;
@@ -4326,6 +4456,57 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       const int answered = lazy_tables();
       if (answered < 0) return -answered;
       if (answered) continue;
+    }
+    // Rasters of thousands of SMALL labels (parcels: more labels than a workgroup's table holds, a few thousand cells each at
+    // most on average): the parallel sums first -- zonal_exact_kernel PHASE 3: sums, sums of magnitudes and counts, one atomic
+    // each per run -- and the float32 certificate in its crudest form on every label (zonal_exact_lazy_decide_kernel: for a
+    // label of n cells E ~ 4 n u mag, which clears a float32 rounding boundary by orders of magnitude while n is small).  One
+    // pass and one wait; 49 152 polygons of 16 x 16 cells 309 -> ~120 us a call (round 5: 4.9 ms), 6 592 polygons of 48 x 40
+    // 278 -> ~120.  A label that fails (a long one among the small, a sum that cancels to nothing) sends the frame on to the
+    // routes below.  (GM_ZONAL_PARALLEL_FIRST=0: never -- A/B runs, and the tests compare)
+    static const bool parallel_first_allowed = !(getenv("GM_ZONAL_PARALLEL_FIRST") && atoi(getenv("GM_ZONAL_PARALLEL_FIRST")) == 0);
+    // (a raster whose labels failed it in numbers -- zero-mean noise under thousands of labels: a few dozen sums within the
+    //  crude bound of a float32 tie -- is remembered with its cells' address and skips the attempt next time)
+    const void* const parallel_key = (const char*)frame + 2;
+    if (range && lazy_mode && parallel_first_allowed && (size_t)n_labels * sizeof(LazyRow) > ZT_LDS_BYTES &&
+        cells / n_labels <= 4096 && chunk_hint_get(parallel_key, n_labels, cells) == 0) {
+      HostFlag* const flag = host_flag();
+      if (flag) {
+        if (!mags && (rc = scratch.take((void**)&mags, sizeof(double) * n_labels))) return rc;
+        flag->word[6] = 0u;
+        hipLaunchKernelGGL(zonal_exact_init_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, verdict_dev, cursor);
+        GM_HIP(hipMemsetAsync(mags, 0, sizeof(double) * n_labels, s));
+        GM_HIP(hipMemsetAsync(inexact, 1, (size_t)n_labels, s));
+        hipLaunchKernelGGL((zonal_exact_kernel<T, 3>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells, cells_per_wave,
+                           n_labels, has_ndv, ndv, thresholds, range, sums, seen, (unsigned*)nullptr, (Key*)nullptr, (unsigned*)nullptr, mags);
+        hipLaunchKernelGGL(zonal_exact_lazy_decide_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, mags, n_labels, statistic,
+                           inexact, verdict_dev, 1, (double)(cells_per_wave / 64));
+        // (the results as if every label had passed; the few that did not -- up to ZF_SLOTS labels of up to ZF_CAP cells -- are
+        //  added in order behind it; anything else raises the flag and the frame goes on)
+        hipLaunchKernelGGL(zonal_exact_result_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, statistic,
+                           out_f, counts_f, 1);
+        if (!few_index) {
+          if ((rc = scratch.take((void**)&few_index, sizeof(unsigned) * ZF_CAP * ZF_SLOTS))) return rc;
+          if ((rc = scratch.take((void**)&few_values, sizeof(double) * ZF_CAP * ZF_SLOTS))) return rc;
+          if ((rc = scratch.take((void**)&few_slots, (sizeof(int) + sizeof(unsigned)) * ZF_SLOTS))) return rc;
+        }
+        GM_HIP(hipMemsetAsync(few_slots, 0, (sizeof(int) + sizeof(unsigned)) * ZF_SLOTS, s));
+        hipLaunchKernelGGL(zonal_few_gather_kernel<T>, dim3(blocks), dim3(256), 0, s, frame, labels, (size_t)cells, n_labels, has_ndv, ndv,
+                           thresholds, inexact, verdict_dev, few_index, few_values, (int*)few_slots, (unsigned*)few_slots + ZF_SLOTS);
+        hipLaunchKernelGGL(zonal_few_ordered_kernel, dim3(ZF_SLOTS), dim3(1024), 0, s, few_index, few_values, (const int*)few_slots,
+                           (const unsigned*)few_slots + ZF_SLOTS, verdict_dev, statistic, out_f, counts_f, flag->word + 6);
+        GM_HIP(hipGetLastError());
+        host_copy_queue(frames, s);
+        GM_HIP(hipEventRecord(flag->event, s));
+        GM_HIP(hipEventSynchronize(flag->event));
+        const bool answered = ((volatile unsigned*)flag->word)[6] == 0u;
+        host_copy_settle(answered);
+        if (answered) {
+          gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_PARALLEL_LAZY);
+          continue;
+        }
+        chunk_hint_set(parallel_key, n_labels, cells, 1);
+      }
     }
     // sums first try the route that sorts nothing (chunk records: zonal_chunk_kernel); GM_ZONAL_CHUNKS=0 switches it off and
     // GM_ZONAL_SORTED=1 skips it together with the other parallel sums (A/B runs, and the tests compare the routes)

@@ -2433,9 +2433,10 @@ def test_zonal_float32_certificate(gpu, lazy):
     driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_lazy_driver.py")
     res = subprocess.run([sys.executable, driver], capture_output=True, text=True, env=dict(os.environ, GM_ZONAL_LAZY=lazy), timeout=900)
     assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2500:])
-    assert "LAZY ok 94" in res.stdout, res.stdout[-300:]
+    assert "LAZY ok 104" in res.stdout, res.stdout[-300:]
     took = routes_of(res.stdout)["zonal"]
     assert (took["lds_lazy"] > 0) == (lazy == "1") and (took["exact_lazy_labels"] > 0) == (lazy == "1"), took
+    assert (took["parallel_lazy"] >= 6) == (lazy == "1"), took   # (the rasters of thousands of small polygons: one pass)
     noise = subprocess.run([sys.executable, driver, "noise"], capture_output=True, text=True, env=dict(os.environ, GM_ZONAL_LAZY=lazy), timeout=900)
     assert noise.returncode == 0 and "LAZY ok 20" in noise.stdout, (noise.stdout[-500:], noise.stderr[-2500:])
     took = routes_of(noise.stdout)["zonal"]

@@ -12,6 +12,8 @@ np.bincount order, on data made for it and data made to break it:
            non-finite cells and ties;
   polygons   thousands of small polygons: the certificate on the parallel sums of zonal_exact_kernel for the labels its
            exponent test turns away;
+  parcels    thousands of small polygons of positive cells, a handful of them with ties, sums of zero and non-finite cells:
+           one pass of parallel sums, the handful added in order (zonal_few_*);
   zeros    sums that cancel to +0.0, to a float32 subnormal, to something that underflows to -0.0 / +0.0;
   wide     tiny and huge cells together, cells beyond float32's range (float64 rasters), int64 cells near 2^62, NaN and
            infinities.
@@ -32,7 +34,7 @@ from oracle import ref_numpy as O  # noqa: E402
 runtime.set_device(0)
 rng = np.random.default_rng(606)
 cases = 0
-ONLY = sys.argv[1].split(",") if len(sys.argv) > 1 else ["noise", "ties", "near", "scattered", "polygons", "zeros", "wide"]
+ONLY = sys.argv[1].split(",") if len(sys.argv) > 1 else ["noise", "ties", "near", "scattered", "polygons", "parcels", "zeros", "wide"]
 
 
 def layout(kind, h, w):
@@ -199,6 +201,41 @@ if "polygons" in ONLY:
                     block[0, 0], block[-1, -1] = 1.0, 2.0 ** -24
                     block[1, 1:] = rng.choice([-1.0, 1.0]) * 2.0 ** -int(rng.integers(30, 62))
         check("polygons %d" % it, labels, n, values, ndv)
+
+if "parcels" in ONLY:
+    # thousands of small polygons of elevation-like cells (every label passes the certificate on the parallel sums: one pass,
+    # zonal_exact_kernel PHASE 3) but for a handful that hold a float32 tie, a sum that cancels to nothing, a non-finite cell:
+    # those are added in order by zonal_few_gather_kernel / zonal_few_ordered_kernel
+    for it in range(5):
+        h, w = int(rng.integers(900, 1400)), int(rng.integers(1500, 2500))
+        by, bx = int(rng.integers(8, 20)), int(rng.integers(8, 24))   # (4 000 - 40 000 parcels)
+        labels = ((np.arange(h)[:, None] // by) * ((w + bx - 1) // bx) + np.arange(w)[None, :] // bx).astype(np.int32)
+        n = int(labels.max()) + 1
+        labels[rng.random((h, w)) < 0.02] = np.iinfo(np.int32).max
+        dt = ["f4", "f8", "i4", "f4", "f4"][it]
+        base = np.abs(rng.standard_normal((1, h, w))) * 100 + 3
+        values = (np.round(base) if dt == "i4" else base).astype(dt)
+        ndv = np.dtype(dt).type(-9999)
+        values[rng.random(values.shape) < 0.07] = ndv
+        rows_of, cols_of = h // by, (w + bx - 1) // bx
+        for k in range(int(rng.integers(3, 40 if it < 4 else 120))):   # (the last raster: more such labels than there are slots)
+            py, px = int(rng.integers(0, rows_of)), int(rng.integers(0, w // bx))
+            block = values[0, py * by:(py + 1) * by, px * bx:(px + 1) * bx]
+            kind = k % 4 if dt != "i4" else 1
+            if kind == 0:      # a float32 tie and cells too fine to count
+                block[...] = 0
+                block[0, 0], block[-1, -1] = 1.0, 2.0 ** -24
+                block[1, 1:] = rng.choice([-1.0, 1.0]) * 2.0 ** -int(rng.integers(30, 62))
+            elif kind == 1:    # pairs that cancel: a sum of exactly zero
+                half = block.shape[1] // 2
+                block[:, half:2 * half] = -block[:, :half]
+                block[:, 2 * half:] = 0
+            elif kind == 2:    # zero-mean noise around cells next to zero
+                block[...] = (rng.standard_normal(block.shape) * 100).astype(dt)
+                block[0, :3] = np.array([1e-12, -1e-13, 1e-20], dtype=dt)
+            else:              # a non-finite cell
+                block[0, 0] = np.nan if k % 8 == 3 else np.inf
+        check("parcels %d" % it, labels, n, values, ndv)
 
 if "zeros" in ONLY:
     for it in range(6):

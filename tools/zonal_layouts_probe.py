@@ -13,7 +13,9 @@ rng = np.random.default_rng(5)
 values = (rng.standard_normal((1, h, w)) * 100).astype("f4")
 values[rng.random(values.shape) < 0.1] = -9999.0
 ints = np.round(values).astype("i4")
-dv, di = DeviceArray.from_numpy(values), DeviceArray.from_numpy(ints)
+positive = np.abs(values) + np.float32(3.0)   # (elevation-like: the sums only grow)
+positive[values == -9999.0] = -9999.0
+dv, di, dp = DeviceArray.from_numpy(values), DeviceArray.from_numpy(ints), DeviceArray.from_numpy(positive)
 yy, xx = np.arange(h)[:, None], np.arange(w)[None, :]
 layouts = [
     ("blocks 16 x 16 (49152 labels)", (yy // 16) * (w // 16) + xx // 16),
@@ -27,9 +29,9 @@ for name, labels in layouts:
     labels = np.ascontiguousarray(labels, dtype=np.int32)
     n_labels = int(labels.max()) + 1
     dl = DeviceArray.from_numpy(labels)
-    for tname, tile, ndv in (("f32 noise", dv, np.float32(-9999.0)), ("i32", di, -9999)):
+    for tname, tile, ndv in (("f32 noise", dv, np.float32(-9999.0)), ("i32", di, -9999), ("f32 > 0", dp, np.float32(-9999.0))):
         line = "%-44s %-10s" % (name, tname)
-        for stat in ("sum", "count", "max", "median"):
+        for stat in (("sum", "count", "max", "median") if tile is not dp else ("sum", "mean")):
             for _ in range(3):  # (round 6: three calls before the clock -- a route's scratch buffers are first allocated by its
                 #  second call where the first call's verdict sizes them, and a cold hipMalloc costs milliseconds: round 5's
                 #  figures for the many-label layouts were mostly that)
