@@ -2353,15 +2353,21 @@ __global__ __launch_bounds__(THREADS) void zonal_tables_lazy_kernel(const T* __r
 }
 
 __global__ __launch_bounds__(256) void zonal_exact_init_kernel(ExactRange* __restrict__ range, double* __restrict__ sums, int n_labels,
-                                                               ExactVerdict* __restrict__ verdict, unsigned* __restrict__ cursor) {
+                                                               ExactVerdict* __restrict__ verdict, unsigned* __restrict__ cursor,
+                                                               double* __restrict__ mags = nullptr, unsigned char* __restrict__ inexact = nullptr,
+                                                               unsigned* __restrict__ slots = nullptr, int n_slot_words = 0) {
+  // (the one-pass route of the small labels: its other buffers in the same launch -- every launch of a few waves takes ~5 us)
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l == 0) {
     *verdict = ExactVerdict{0u, 0u, 0ull};
     *cursor = 0;
   }
+  if (slots && l < n_slot_words) slots[l] = 0u;
   if (l >= n_labels) return;
   range[l] = ExactRange{0ull, INT_MIN, INT_MAX, 0u};
   sums[l] = 0.0;
+  if (mags) mags[l] = 0.0;
+  if (inexact) inexact[l] = 1;
 }
 
 // per label: can the order matter?  The verdict counts the labels for which it can and the cells they hold, and flags them.
@@ -2396,9 +2402,17 @@ __global__ __launch_bounds__(256) void zonal_exact_decide_kernel(const ExactRang
 __global__ __launch_bounds__(256) void zonal_exact_lazy_decide_kernel(const ExactRange* __restrict__ range, const double* __restrict__ sums,
                                                                       const double* __restrict__ mags, int n_labels, int statistic,
                                                                       unsigned char* __restrict__ inexact, ExactVerdict* __restrict__ verdict,
-                                                                      int packed_counts = 0, double steps_per_wave = 0.0) {
+                                                                      int packed_counts = 0, double steps_per_wave = 0.0,
+                                                                      float* __restrict__ out = nullptr, long long* __restrict__ counts = nullptr) {
   const int l = blockIdx.x * 256 + threadIdx.x;
-  if (l >= n_labels || !inexact[l]) return;
+  if (l >= n_labels) return;
+  if (out) {  // (zonal_exact_result_kernel's work in this launch: the results as if the label passes)
+    const unsigned long long cells_l = packed_counts ? range[l].count & ((1ull << 40) - 1) : range[l].count;
+    counts[l] = (long long)cells_l;
+    out[l] = cells_l == 0 ? std::numeric_limits<float>::quiet_NaN()
+                          : (statistic == Z_MEAN ? (float)(sums[l] / (double)cells_l) : (float)sums[l]);
+  }
+  if (!inexact[l]) return;
   const ExactRange r = range[l];
   // (after PHASE 3 the count carries the number of additions onto the label's sum in its bits 40 and up: one per run.  With
   //  them the sum's own error is u (additions + steps of a wave's stretch + 16) mag instead of u (2 count + 16) mag -- a lane's
@@ -4474,23 +4488,19 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       if (flag) {
         if (!mags && (rc = scratch.take((void**)&mags, sizeof(double) * n_labels))) return rc;
         flag->word[6] = 0u;
-        hipLaunchKernelGGL(zonal_exact_init_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, verdict_dev, cursor);
-        GM_HIP(hipMemsetAsync(mags, 0, sizeof(double) * n_labels, s));
-        GM_HIP(hipMemsetAsync(inexact, 1, (size_t)n_labels, s));
-        hipLaunchKernelGGL((zonal_exact_kernel<T, 3>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells, cells_per_wave,
-                           n_labels, has_ndv, ndv, thresholds, range, sums, seen, (unsigned*)nullptr, (Key*)nullptr, (unsigned*)nullptr, mags);
-        hipLaunchKernelGGL(zonal_exact_lazy_decide_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, mags, n_labels, statistic,
-                           inexact, verdict_dev, 1, (double)(cells_per_wave / 64));
-        // (the results as if every label had passed; the few that did not -- up to ZF_SLOTS labels of up to ZF_CAP cells -- are
-        //  added in order behind it; anything else raises the flag and the frame goes on)
-        hipLaunchKernelGGL(zonal_exact_result_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, n_labels, statistic,
-                           out_f, counts_f, 1);
         if (!few_index) {
           if ((rc = scratch.take((void**)&few_index, sizeof(unsigned) * ZF_CAP * ZF_SLOTS))) return rc;
           if ((rc = scratch.take((void**)&few_values, sizeof(double) * ZF_CAP * ZF_SLOTS))) return rc;
           if ((rc = scratch.take((void**)&few_slots, (sizeof(int) + sizeof(unsigned)) * ZF_SLOTS))) return rc;
         }
-        GM_HIP(hipMemsetAsync(few_slots, 0, (sizeof(int) + sizeof(unsigned)) * ZF_SLOTS, s));
+        hipLaunchKernelGGL(zonal_exact_init_kernel, dim3((std::max<int>(n_labels, 2 * (int)ZF_SLOTS) + 255) / 256), dim3(256), 0, s, range, sums,
+                           n_labels, verdict_dev, cursor, mags, inexact, few_slots, 2 * (int)ZF_SLOTS);
+        hipLaunchKernelGGL((zonal_exact_kernel<T, 3>), dim3(direct_blocks), dim3(256), 0, s, frame, labels, (size_t)cells, cells_per_wave,
+                           n_labels, has_ndv, ndv, thresholds, range, sums, seen, (unsigned*)nullptr, (Key*)nullptr, (unsigned*)nullptr, mags);
+        // (with the results as if every label passed; the few that do not -- up to ZF_SLOTS labels of up to ZF_CAP cells -- are
+        //  added in order behind it; anything else raises the flag and the frame goes on)
+        hipLaunchKernelGGL(zonal_exact_lazy_decide_kernel, dim3((n_labels + 255) / 256), dim3(256), 0, s, range, sums, mags, n_labels, statistic,
+                           inexact, verdict_dev, 1, (double)(cells_per_wave / 64), out_f, counts_f);
         hipLaunchKernelGGL(zonal_few_gather_kernel<T>, dim3(blocks), dim3(256), 0, s, frame, labels, (size_t)cells, n_labels, has_ndv, ndv,
                            thresholds, inexact, verdict_dev, few_index, few_values, (int*)few_slots, (unsigned*)few_slots + ZF_SLOTS);
         hipLaunchKernelGGL(zonal_few_ordered_kernel, dim3(ZF_SLOTS), dim3(1024), 0, s, few_index, few_values, (const int*)few_slots,
