@@ -2481,7 +2481,7 @@ def test_zonal_statistics_at_the_raster_limit(gpu):
     import sys
     driver = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zonal_full_size_driver.py")
     runs = [(layouts, cases, subprocess.Popen([sys.executable, driver, layouts], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-            for layouts, cases in (("0,2", 31), ("3,9", 32))]
+            for layouts, cases in (("0,2", 30), ("3,9", 32))]
     for layouts, cases, proc in runs:
         try:
             out, err = proc.communicate(timeout=1800)
