@@ -24,6 +24,14 @@
 // labels that have to be replayed too often, fall back: sums whose every partial sum is exactly representable -- integer
 // rasters, dyadic data, small polygons -- take two passes of atomics (zonal_exact_kernel; when only a few labels fail that
 // test only their cells are gathered and sorted), everything else the sort.
+// Round 6: what the caller keeps of a sum is its rounding into the float32 `agg` array, and bincount's sequential float64 sum
+// lies within a computable bound of ANY float64 sum of the same cells (derived at zonal_chunk_combine_kernel): a label whose sum
+// +/- that bound rounds to one float32 is answered without the order, every other label is added in order as above.  The
+// test runs first of all -- over the chunk records (labels made of runs), over per-workgroup LDS tables (zonal_tables_lazy_kernel:
+// up to 85 labels, labels scattered cell by cell, stripes), over the parallel sums of rasters of thousands of small labels
+// (zonal_exact_kernel PHASE 3 + zonal_few_*: the handful that fails added in order from lists gathered off the raster) -- and
+// answers nearly every label of nearly every raster in one pass.  GM_ZONAL_LAZY=0: never (the tests run both).
+// gm_zonal_statistic_host hands the results back in host arrays with one wait per call.
 // Results are float32 like the reference's `agg` array; labels without an active cell stay NaN.
 // HBM traffic: 8 algorithmic bytes per cell (value + label); the chunk records move 1.2 x that
 // (profiles/r05_zonal_pmc_1024.json), the full sort ~6-7 x.
