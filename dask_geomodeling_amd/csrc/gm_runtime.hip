@@ -250,7 +250,7 @@ void route_hit(int family, int slot, unsigned long long n) {
 static const int kRouteSlots[GM_ROUTE_FAMILIES] = {GM_RZ_SLOTS, GM_RB_SLOTS, GM_RT_SLOTS, GM_RM_SLOTS, GM_RS_SLOTS};
 static const char* const kRouteNames[GM_ROUTE_FAMILIES][32] = {
     {"calls", "direct", "chunk_attempts", "chunk_answered", "chunk_gave_up", "exact_all", "exact_partial", "sort_partition", "sort_radix",
-     "select", "lexsort", "block_pipeline", "ordered_sums", "lds_tables", "segment_sort", "lds_exact", "lds_lazy", "exact_lazy_labels", "parallel_lazy"},
+     "select", "lexsort", "block_pipeline", "ordered_sums", "lds_tables", "segment_sort", "lds_exact", "lds_lazy", "exact_lazy_labels", "parallel_lazy", "raw_select"},
     {"calls", "two_x", "staged", "direct", "unstaged_fallback"},
     {"calls", "lookup32_w4", "lookup32_other", "lut8", "lut8_rows", "classify_registers", "classify_lds", "classify_window", "reclassify"},
     {"calls", "network", "lds_sort", "select"},

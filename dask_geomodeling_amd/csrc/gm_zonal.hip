@@ -3253,6 +3253,92 @@ __device__ __forceinline__ double chain_add_parked(const double* mine, double ac
   return acc;
 }
 
+// Medians / percentiles under A FEW labels (round 6): the radix select straight off the raster.  The partition that brings every
+// label's cells together costs as much as four select passes over the raster itself (12.6 M cells: 47 + 11 + 5 + 45 us against
+// ~22 us a pass), and a handful of labels needs no partition to keep their histograms apart: a workgroup keeps 256 bins per label
+// in LDS (up to ZR_LABELS labels), a lane adds its cell's digit to its label's row, a workgroup flushes once.  The first pass
+// counts every active cell (its histogram's totals are the labels' counts: zonal_select_raw_counts_kernel turns them into the
+// `first` array the partitioned route gets from its sort, so init / step / result are that route's kernels); later passes count
+// the cells that match the digits chosen so far; the last one looks for the smallest key above the selected one.  Keys of 4
+// bytes (or less): four or fewer digit passes.  One label of 12.6 M float32 cells: median 244 -> ~150 us a call.
+constexpr int ZR_LABELS = 32;
+template <typename T, bool NEXT>
+__global__ __launch_bounds__(256) void zonal_select_raw_pass_kernel(const T* __restrict__ values, const int* __restrict__ labels, size_t cells,
+                                                                    size_t cells_per_wave, int n_labels, int has_ndv, T ndv,
+                                                                    const float* __restrict__ thresholds,
+                                                                    int shift, int first_pass, const SelectState* __restrict__ state,
+                                                                    unsigned* __restrict__ hist, unsigned long long* __restrict__ next,
+                                                                    unsigned char* __restrict__ present) {
+  typedef typename Ordered<T>::Key Key;
+  static_assert(sizeof(Key) == 4, "keys of up to 4 bytes");
+  __shared__ unsigned bins[NEXT ? 1 : ZR_LABELS * 256];
+  __shared__ unsigned prefix_of[ZR_LABELS], wanted[ZR_LABELS], best_of[ZR_LABELS];
+  for (int i = threadIdx.x; i < n_labels; i += 256) {
+    const SelectState st = first_pass ? SelectState{0ull, 0u, 0u, 0u, 0u} : state[i];
+    prefix_of[i] = (unsigned)st.prefix;
+    wanted[i] = (st.want_next && !(st.rank + 1 < st.n_eq) && st.count != 0) ? 1u : 0u;
+    best_of[i] = ~0u;
+  }
+  if constexpr (!NEXT) {
+    for (int i = threadIdx.x; i < n_labels * 256; i += 256) bins[i] = 0u;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  int marked = INT_MIN;
+  // (a wave walks a stretch of its own with its loads four steps ahead, like the count kernel: a grid-stride loop of one cell
+  //  per lane and turn took 29-47 us a pass where the raster's bytes take 20)
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const size_t begin = min(wave * cells_per_wave, cells), end = min(begin + cells_per_wave, cells);
+  walk_cells<T>(values, labels, begin, end, lane, [&](T v, int label, bool inside, size_t i) {
+    (void)i;
+    const bool labelled = inside && (unsigned)label < (unsigned)n_labels;
+    if (first_pass) mark_present(present, label, labelled, &marked);
+    const bool active = labelled && cell_active<T>(v, label, n_labels, has_ndv, ndv, thresholds);
+    const unsigned key = (unsigned)Ordered<T>::encode(v);
+    if constexpr (!NEXT) {
+      const bool match = active && (first_pass || shift + 8 >= 32 || (key >> (shift + 8)) == (prefix_of[label] >> (shift + 8)));
+      const unsigned long long mask = __ballot(match);
+      if (mask == 0) return;  // (wave-uniform)
+      const unsigned bin = match ? (unsigned)label * 256u + ((key >> shift) & 255u) : ~0u;
+      // (cells of one label in one bin -- a raster whose values share their top digit -- go in one addition per wave)
+      const unsigned lead = (unsigned)__builtin_amdgcn_readlane((int)bin, __ffsll((long long)mask) - 1);
+      if (__all(!match || bin == lead)) {
+        if (lane == __ffsll((long long)mask) - 1) atomicAdd(&bins[lead], (unsigned)__popcll(mask));
+      } else if (match) {
+        atomicAdd(&bins[bin], 1u);
+      }
+    } else {
+      // (a plain look at the best so far first: after a few steps hardly a cell is below it, and a median has half of the
+      //  label's cells above the selected key -- an LDS atomic each took the pass from 21 to 42 us)
+      if (active && wanted[label] && key > prefix_of[label] && key < *(volatile unsigned*)&best_of[label]) atomicMin(&best_of[label], key);
+    }
+  });
+  __syncthreads();
+  if constexpr (!NEXT) {
+    for (int i = threadIdx.x; i < n_labels * 256; i += 256) {
+      const unsigned c = bins[i];
+      if (c) atomicAdd(&hist[i], c);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n_labels; i += 256)
+      if (best_of[i] != ~0u) atomicMin(&next[i], (unsigned long long)best_of[i]);
+  }
+}
+// first[l] = the active cells of the labels before l (what the partitioned route reads off its sorted keys): from the totals of
+// the first pass's histograms, which stay where they are for the first step
+__global__ __launch_bounds__(64) void zonal_select_raw_counts_kernel(const unsigned* __restrict__ hist, int n_labels, unsigned* __restrict__ first) {
+  const int lane = threadIdx.x;
+  unsigned running = 0;
+  for (int l = 0; l < n_labels; ++l) {
+    unsigned c = 0;
+    for (int k = lane; k < 256; k += 64) c += hist[(size_t)l * 256 + k];
+    c = wave_sum_u32(c);
+    if (lane == 0) first[l] = running;
+    running += c;
+  }
+  if (lane == 0) first[n_labels] = running;
+}
+
 // The few labels of a raster of thousands of small ones that the float32 certificate of the parallel sums turns away (a sum that
 // cancels to nothing, a sum within 10^-9 of a float32 tie: a handful of 6 144 or 49 152 polygons per call) -- added in bincount's
 // order without a sort of the raster: zonal_exact_lazy_decide_kernel has given each a slot (up to ZF_SLOTS); their active cells
@@ -4297,6 +4383,9 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
   unsigned *keys_a = nullptr, *keys_b = nullptr, *first = nullptr;
   double* mags = nullptr;  // (the sums of the magnitudes beside the parallel sums: the float32 certificate)
   LazyRow* lazy_rows = nullptr;
+  SelectState* raw_state = nullptr;  // (the radix select off the raster: zonal_select_raw_pass_kernel)
+  unsigned *raw_hist = nullptr, *raw_first = nullptr;
+  unsigned long long* raw_next = nullptr;
   unsigned* few_index = nullptr;  // (the labels the parallel sums' certificate turns away, added in order: zonal_few_*)
   double* few_values = nullptr;
   unsigned* few_slots = nullptr;
@@ -4665,6 +4754,44 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         continue;
       }
       longest = verdict.longest;
+    }
+    // medians / percentiles under a few labels of a raster of 4-byte cells (or narrower): the radix select straight off the
+    // raster (zonal_select_raw_pass_kernel; GM_ZONAL_RAW_SELECT=0: never -- A/B runs, and the tests compare the two)
+    static const bool raw_select_allowed = !(getenv("GM_ZONAL_RAW_SELECT") && atoi(getenv("GM_ZONAL_RAW_SELECT")) == 0);
+    if constexpr (sizeof(Key) == 4) {
+      if (by_value && select_allowed && raw_select_allowed && n_labels <= ZR_LABELS) {
+        if (!raw_state) {
+          if ((rc = scratch.take((void**)&raw_state, sizeof(SelectState) * n_labels))) return rc;
+          if ((rc = scratch.take((void**)&raw_hist, sizeof(unsigned) * 256 * (size_t)n_labels))) return rc;
+          if ((rc = scratch.take((void**)&raw_next, sizeof(unsigned long long) * n_labels))) return rc;
+          if ((rc = scratch.take((void**)&raw_first, sizeof(unsigned) * ((size_t)n_labels + 2)))) return rc;
+        }
+        const unsigned label_grid = (unsigned)((n_labels + 255) / 256), step_grid = (unsigned)(((size_t)n_labels * 64 + 255) / 256);
+        const int64_t raw_waves = std::max<int64_t>(1, std::min<int64_t>((cells + 255) / 256, (int64_t)gm::current_cu_count() * 32));
+        const size_t raw_cells_per_wave = (size_t)(((cells + raw_waves - 1) / raw_waves + 63) / 64 * 64);
+        const unsigned raw_grid = (unsigned)((raw_waves + 3) / 4);
+        GM_HIP(hipMemsetAsync(raw_hist, 0, sizeof(unsigned) * 256 * (size_t)n_labels, s));
+        gm::route_hit(GM_ROUTE_ZONAL, GM_RZ_RAW_SELECT);
+        const int top = 8 * ((int)sizeof(T) - 1);
+        for (int shift = top; shift >= 0; shift -= 8) {
+          hipLaunchKernelGGL((zonal_select_raw_pass_kernel<T, false>), dim3(raw_grid), dim3(256), 0, s, frame, labels, (size_t)cells,
+                             raw_cells_per_wave, n_labels, has_ndv, ndv, thresholds, shift, shift == top ? 1 : 0, raw_state, raw_hist,
+                             raw_next, seen);
+          if (shift == top) {
+            hipLaunchKernelGGL(zonal_select_raw_counts_kernel, dim3(1), dim3(64), 0, s, raw_hist, n_labels, raw_first);
+            hipLaunchKernelGGL(zonal_select_init_kernel, dim3(label_grid), dim3(256), 0, s, raw_first, n_labels, statistic, qval, raw_state,
+                               raw_next);
+          }
+          hipLaunchKernelGGL(zonal_select_step_kernel, dim3(step_grid), dim3(256), 0, s, n_labels, shift, raw_state, raw_hist);
+        }
+        hipLaunchKernelGGL((zonal_select_raw_pass_kernel<T, true>), dim3(raw_grid), dim3(256), 0, s, frame, labels, (size_t)cells,
+                           raw_cells_per_wave, n_labels, has_ndv, ndv, thresholds, 0, 0, raw_state, raw_hist, raw_next,
+                           (unsigned char*)nullptr);
+        hipLaunchKernelGGL(zonal_select_result_kernel<T>, dim3(label_grid), dim3(256), 0, s, raw_state, raw_next, n_labels, statistic, qval,
+                           out_f, counts_f);
+        GM_HIP(hipGetLastError());
+        continue;
+      }
     }
     if ((rc = key_buffers())) return rc;
     bool keys_written = false;

@@ -169,7 +169,8 @@ const char* gm_route_name(int family, int slot);
 #define GM_RZ_LDS_LAZY 16        /* sums of scattered labels answered by the float32 certificate over workgroup LDS tables */
 #define GM_RZ_EXACT_LAZY 17      /* sums: LABELS the exponents turned away that the float32 certificate answered from the parallel sums */
 #define GM_RZ_PARALLEL_LAZY 18   /* sums of rasters of thousands of small labels: parallel sums + the float32 certificate on every label, one pass */
-#define GM_RZ_SLOTS 19
+#define GM_RZ_RAW_SELECT 19      /* medians / percentiles under a few labels: radix select straight off the raster, no partition */
+#define GM_RZ_SLOTS 20
 /* bilinear slots */
 #define GM_RB_CALLS 0
 #define GM_RB_TWO_X 1            /* the dedicated 2 x kernel */

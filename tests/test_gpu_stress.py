@@ -29,7 +29,7 @@ def test_zonal_stress_driver(gpu):
     took = routes_of(out)["zonal"]
     # the campaign reaches every family of routes (a threshold that moves would show here)
     # (the chunk records have drivers of their own in tests/test_gpu_parity.py: this campaign's sums are answered before them)
-    for route in ("direct", "lds_tables", "lds_lazy", "parallel_lazy", "sort_partition", "sort_radix", "select", "segment_sort"):
+    for route in ("direct", "lds_tables", "lds_lazy", "parallel_lazy", "sort_partition", "sort_radix", "select", "raw_select", "segment_sort"):
         assert took[route] > 0, (route, took)
 
 
@@ -38,13 +38,15 @@ def test_zonal_stress_driver_on_the_older_routes(gpu):
     """The same campaign (shorter) with the round-6 routes switched off: count / min / max through the wave-slot kernel instead of
     the workgroup tables, medians under many labels through the two sorts instead of the segment sort, every sum in bincount's
     order or certified exact (no float32 certificate: the scattered labels' sums through zonal_tables_exact_kernel), the results
-    into a device buffer and copied back by the caller (gm_zonal_statistic instead of gm_zonal_statistic_host)."""
+    into a device buffer and copied back by the caller (gm_zonal_statistic instead of gm_zonal_statistic_host), medians under a
+    few labels through the partition instead of straight off the raster."""
     out = _run("zonal_stress.py", [120, 4711], env={"GM_ZONAL_TABLES": "0", "GM_ZONAL_SEGSORT": "0", "GM_ZONAL_LAZY": "0",
-                                                    "GM_ZONAL_HOST": "0"})
+                                                    "GM_ZONAL_HOST": "0", "GM_ZONAL_RAW_SELECT": "0"})
     assert "done 120 failures 0" in out, out[-2000:]
     took = routes_of(out)["zonal"]
     assert took["lds_tables"] == 0 and took["segment_sort"] == 0 and took["direct"] > 0 and took["lexsort"] > 0, took
     assert took["lds_lazy"] == 0 and took["exact_lazy_labels"] == 0 and took["lds_exact"] > 0 and took["ordered_sums"] > 0, took
+    assert took["raw_select"] == 0 and took["select"] > 0, took
 
 
 @pytest.mark.timeout(900)
