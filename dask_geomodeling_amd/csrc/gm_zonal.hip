@@ -4636,7 +4636,10 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
       //  and starts with the shorter stretches next time: the other statistics of the same polygons, the next frames)
       // (... and a raster whose SUMS gave the pass up -- a long label that keeps rounding: hard -- is remembered with its cells'
       //  address: the mean after the sum, the next request for the same tile, go to the sorting route at once)
-      const int first_attempt = std::max(label_hint == 3 ? 1 : label_hint, chunk_hint_get(frame, n_labels, cells));
+      // (a key of its own kind per hint -- the pool hands the block of one request's label raster to the next request's cells:
+      //  a hint about labels read as a hint about cells sent a service's every other request to the sorting route)
+      const void* const hard_key = (const char*)frame + 3;
+      const int first_attempt = std::max(label_hint == 3 ? 1 : label_hint, chunk_hint_get(hard_key, n_labels, cells));
       if (first_attempt >= 2) chunk_gave_up_hard = true;
       for (int attempt = first_attempt; attempt < 2 && !answered; ++attempt) {
         const int64_t shortest = attempt == 0 ? stretch() : std::max<int64_t>(ZC_STEP, stretch() / 4);
@@ -4704,7 +4707,7 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
         // the sort is the radix sort: 6592 polygons of 48 x 40 int32 cells 240 us through the parallel sums, 590 through the sort.
         chunk_gave_up_hard = chunk_verdict.hard != 0 || n_labels + 1 <= ZP_BINS;
         chunk_not_runs = chunk_verdict.not_runs != 0 && chunk_verdict.hard == 0;
-        if (chunk_verdict.hard) chunk_hint_set(frame, n_labels, cells, 2);
+        if (chunk_verdict.hard) chunk_hint_set(hard_key, n_labels, cells, 2);
         if (attempt == 0 && chunk_verdict.overflow && !chunk_verdict.hard && !chunk_verdict.not_runs && !lazy_tried) {
           // more labels to a stretch than records (vertical stripes 25 cells wide, small parcels): before the shorter stretches --
           // four times the records, a pass of 145-200 us -- the tables of zonal_tables_lazy_kernel, whose pass does not care
