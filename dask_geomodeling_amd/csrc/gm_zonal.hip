@@ -4563,10 +4563,15 @@ int zonal_run(const void* values_v, int64_t frames, int64_t cells, int has_ndv, 
     //  parcels -- and the tables answered instead: remembered with the label raster's address, hint 3)
     const int label_hint = chunk_hint_get(labels, n_labels, cells);
     const bool lazy_first = lazy_first_mode < 0 ? ((size_t)n_labels * sizeof(LazyRow) * 8192 <= (16u << 20) || label_hint == 3) : lazy_first_mode != 0;
-    if (range && lazy_first) {
+    // (a raster one of whose labels failed the tables' bound for this statistic -- the chunk records' tighter bound answered it, or
+    //  the order did -- is remembered with its cells' address and goes there at once next time: two attempts per call otherwise)
+    const void* const tables_key = (const char*)frame + 1;
+    const int tables_tag = n_labels ^ (statistic << 24);
+    if (range && lazy_first && chunk_hint_get(tables_key, tables_tag, cells) == 0) {
       const int answered = lazy_tables();
       if (answered < 0) return -answered;
       if (answered) continue;
+      if (lazy_tried && lazy_mode) chunk_hint_set(tables_key, tables_tag, cells, 1);
     }
     // Rasters of thousands of SMALL labels (parcels: more labels than a workgroup's table holds, a few thousand cells each at
     // most on average): the parallel sums first -- zonal_exact_kernel PHASE 3: sums, sums of magnitudes and counts, one atomic
